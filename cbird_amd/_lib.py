@@ -1,0 +1,118 @@
+"""ctypes binding of libcbird_hip.so (include/cbird_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing, or no gfx950 device
+is usable, the compute entry points raise.  ``lib()`` only loads and declares symbols, so it
+also works on a machine without a GPU (the "-m 'not gpu'" tests check that every symbol the
+header declares is exported).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcbird_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cbird_hip.h")
+
+CBH_OK = 0
+CBH_E_INVAL = -1
+CBH_E_UNSUPPORTED = -2
+CBH_E_NODEVICE = -3
+CBH_E_NOMEM = -4
+CBH_E_HIP = -5
+CBH_E_OVERFLOW = -6
+CBH_E_NOTLOADED = -7
+CBH_MAX_QUERIES_PER_CALL = 1 << 25
+
+
+class CbhError(RuntimeError):
+    def __init__(self, code: int, what: str = "") -> None:
+        self.code = code
+        L = _state.get("lib")
+        msg = L.cbh_strerror(code).decode() if L is not None else str(code)
+        detail = L.cbh_last_error().decode() if (L is not None and code == CBH_E_HIP) else ""
+        super().__init__(f"{what}: {msg} ({code}) {detail}".strip())
+
+
+class cbh_match(C.Structure):
+    _fields_ = [("id", C.c_uint32), ("score", C.c_int32)]
+
+
+_state: dict = {"lib": None}
+
+_vp = C.c_void_p
+_sz = C.c_size_t
+_SIGS = {
+    "cbh_version": (C.c_int, []),
+    "cbh_device_count": (C.c_int, []),
+    "cbh_strerror": (C.c_char_p, [C.c_int]),
+    "cbh_last_error": (C.c_char_p, []),
+    "cbh_dcthash_batch": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, _vp, C.c_int]),
+    "cbh_dcthash_batch_dev": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, _vp, C.c_int, _vp]),
+    "cbh_idx64_create": (_vp, [C.c_int]),
+    "cbh_idx64_destroy": (None, [_vp]),
+    "cbh_idx64_load": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "cbh_idx64_load_dev": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
+    "cbh_idx64_is_loaded": (C.c_int, [_vp]),
+    "cbh_idx64_add": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "cbh_idx64_remove": (C.c_int, [_vp, _vp, _sz]),
+    "cbh_idx64_count": (_sz, [_vp]),
+    "cbh_idx64_memory_usage": (_sz, [_vp]),
+    "cbh_idx64_media_ids": (C.c_int, [_vp, _vp, _sz, C.POINTER(_sz)]),
+    "cbh_idx64_slice": (_vp, [_vp, _vp, _sz]),
+    "cbh_idx64_download": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "cbh_idx64_find": (C.c_int, [_vp, C.c_uint64, C.c_int, _vp, _sz, C.POINTER(_sz)]),
+    "cbh_idx64_find_batch": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp]),
+    "cbh_idx64_find_batch_dev": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp,
+                                           C.POINTER(C.c_uint64), _vp]),
+    "cbh_idx64_scan_dev": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _sz, _vp, _vp]),
+    "cbh_sort_records_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, _vp]),
+    "cbh_select_records_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, _vp, _vp, C.c_int, _vp]),
+    "cbh_idx64_set_record_capacity": (C.c_int, [_vp, _sz]),
+    "cbh_idx64_time_scan_dev": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _sz, _vp, C.c_int,
+                                          C.POINTER(C.c_float)]),
+    "cbh_time_dcthash_dev": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, _vp, C.c_int, C.c_int,
+                                       C.POINTER(C.c_float)]),
+}
+
+
+def header_symbols() -> list[str]:
+    """every function name include/cbird_hip.h declares"""
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(cbh_[a-z0-9_]+)\s*\(", txt)))
+
+
+def lib() -> C.CDLL:
+    """Load libcbird_hip.so (raises if it has not been built)."""
+    if _state["lib"] is not None:
+        return _state["lib"]
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C cbird_amd/csrc` (the HIP path has no fallback)")
+    try:  # share torch's HIP runtime when torch is in the process (same SONAME libamdhip64.so.7)
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the C-ABI itself
+        pass
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in _SIGS.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _state["lib"] = L
+    return L
+
+
+def check(code: int, what: str) -> None:
+    if code != CBH_OK:
+        raise CbhError(code, what)
+
+
+def require_device() -> int:
+    """Number of usable gfx950 devices; raises CbhError(CBH_E_NODEVICE) when there is none."""
+    n = lib().cbh_device_count()
+    if n <= 0:
+        raise CbhError(CBH_E_NODEVICE, "cbird_amd")
+    return n

@@ -1,0 +1,44 @@
+// cbh_internal.h -- shared declarations between the host shim and the kernel launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "cbird_hip.h"
+
+namespace cbh {
+
+void set_last_error(const char* where, hipError_t e);
+
+#define CBH_HIP(call)                          \
+  do {                                         \
+    hipError_t e_ = (call);                    \
+    if (e_ != hipSuccess) {                    \
+      ::cbh::set_last_error(#call, e_);        \
+      return e_ == hipErrorOutOfMemory ? CBH_E_NOMEM : CBH_E_HIP; \
+    }                                          \
+  } while (0)
+
+// ---- hamm64_scan.hip ------------------------------------------------------------------
+// Appends one record per (query j, slot i) with popc(q[j]^hashes[i]) < thresh, ids[i] != 0,
+// q[j] != 0.  *d_total += number of such pairs; records with slot index >= cap are dropped.
+int launch_hamm64_scan(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n,
+                       const uint64_t* d_q, size_t nq, int thresh, cbh_record* d_rec, size_t cap,
+                       unsigned long long* d_total, hipStream_t stream);
+
+// ---- records.hip ----------------------------------------------------------------------
+// Ascending u64 sort of n records in place (uses d_alt as the ping-pong buffer and d_tmp as
+// scratch; sizes from sort_records_scratch_bytes).
+size_t sort_records_scratch_bytes(size_t n);
+int launch_sort_records(cbh_record* d_rec, cbh_record* d_alt, size_t n, size_t nq, void* d_tmp,
+                        size_t tmp_bytes, hipStream_t stream);
+int launch_select_records(const cbh_record* d_sorted, size_t n, size_t nq, int k, cbh_match* d_out,
+                          uint32_t* d_counts, hipStream_t stream);
+int launch_remove_ids(uint64_t* d_hashes, uint32_t* d_ids, size_t n, const uint32_t* d_sorted_rm,
+                      size_t n_rm, hipStream_t stream);
+
+// ---- dcthash.hip ----------------------------------------------------------------------
+int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_stride,
+                   size_t img_stride, uint64_t* d_out, hipStream_t stream);
+
+}  // namespace cbh

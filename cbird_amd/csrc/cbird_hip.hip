@@ -1,0 +1,689 @@
+// cbird_hip.hip -- host side of the C-ABI in include/cbird_hip.h.
+//
+// Holds the DctHashIndex state on the device (SoA hashes/ids exactly like
+// src/dcthashindex.h:60-64), a pool of per-call workspaces so that find() is re-entrant for
+// cbird's thread-pool callers (src/database.cpp:1400-1432), and the sequencing of
+// scan -> sort -> select.  There is no CPU compute path in this file: if no gfx950 device is
+// usable every compute entry point returns CBH_E_NODEVICE.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "cbh_internal.h"
+
+namespace cbh {
+
+static thread_local std::string t_last_error;
+
+void set_last_error(const char* where, hipError_t e) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
+  t_last_error = buf;
+}
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+bool device_usable(int dev) {
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
+  return strncmp(p.gcnArchName, "gfx950", 6) == 0;
+}
+
+struct Workspace {
+  hipStream_t stream = nullptr;
+  cbh_record* d_rec = nullptr;
+  cbh_record* d_alt = nullptr;
+  size_t rec_cap = 0;
+  void* d_tmp = nullptr;
+  size_t tmp_bytes = 0;
+  unsigned long long* d_total = nullptr;
+  unsigned long long* h_total = nullptr;  // pinned
+  uint64_t* d_q = nullptr;
+  size_t q_cap = 0;
+  cbh_match* d_out = nullptr;
+  size_t out_cap = 0;
+  uint32_t* d_counts = nullptr;
+  size_t counts_cap = 0;
+
+  int init() {
+    CBH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    CBH_HIP(hipMalloc(&d_total, sizeof(unsigned long long)));
+    CBH_HIP(hipHostMalloc(&h_total, sizeof(unsigned long long)));
+    return CBH_OK;
+  }
+  int ensure_records(size_t cap) {
+    if (cap <= rec_cap) return CBH_OK;
+    if (d_rec) (void)hipFree(d_rec);
+    if (d_alt) (void)hipFree(d_alt);
+    if (d_tmp) (void)hipFree(d_tmp);
+    d_rec = d_alt = nullptr;
+    d_tmp = nullptr;
+    rec_cap = 0;
+    CBH_HIP(hipMalloc(&d_rec, cap * sizeof(cbh_record)));
+    CBH_HIP(hipMalloc(&d_alt, cap * sizeof(cbh_record)));
+    tmp_bytes = sort_records_scratch_bytes(cap);
+    CBH_HIP(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
+    rec_cap = cap;
+    return CBH_OK;
+  }
+  template <typename T>
+  static int grow(T** p, size_t* cap, size_t need) {
+    if (need <= *cap) return CBH_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    size_t n = std::max<size_t>(need, 1024);
+    CBH_HIP(hipMalloc(p, n * sizeof(T)));
+    *cap = n;
+    return CBH_OK;
+  }
+  void release() {
+    if (d_rec) (void)hipFree(d_rec);
+    if (d_alt) (void)hipFree(d_alt);
+    if (d_tmp) (void)hipFree(d_tmp);
+    if (d_total) (void)hipFree(d_total);
+    if (h_total) (void)hipHostFree(h_total);
+    if (d_q) (void)hipFree(d_q);
+    if (d_out) (void)hipFree(d_out);
+    if (d_counts) (void)hipFree(d_counts);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+}  // namespace
+}  // namespace cbh
+
+using namespace cbh;
+
+struct cbh_idx64 {
+  int device = 0;
+  bool loaded = false;
+  uint64_t* d_hashes = nullptr;
+  uint32_t* d_ids = nullptr;
+  size_t n = 0;
+  size_t cap = 0;
+  size_t rec_cap_default = (size_t)1 << 24;
+  std::mutex ws_mu;
+  std::vector<Workspace*> ws_free;
+
+  Workspace* acquire(int* rc) {
+    {
+      std::lock_guard<std::mutex> lk(ws_mu);
+      if (!ws_free.empty()) {
+        Workspace* w = ws_free.back();
+        ws_free.pop_back();
+        *rc = CBH_OK;
+        return w;
+      }
+    }
+    Workspace* w = new (std::nothrow) Workspace;
+    if (!w) {
+      *rc = CBH_E_NOMEM;
+      return nullptr;
+    }
+    *rc = w->init();
+    if (*rc) {
+      w->release();
+      delete w;
+      return nullptr;
+    }
+    return w;
+  }
+  void give_back(Workspace* w) {
+    std::lock_guard<std::mutex> lk(ws_mu);
+    ws_free.push_back(w);
+  }
+  int reserve(size_t need) {
+    if (need <= cap) return CBH_OK;
+    size_t ncap = std::max<size_t>(need, cap + cap / 2);
+    ncap = (ncap + 1023) / 1024 * 1024;  // the reference grows in 1024-row chunks (:85-95)
+    uint64_t* nh = nullptr;
+    uint32_t* ni = nullptr;
+    CBH_HIP(hipMalloc(&nh, ncap * sizeof(uint64_t)));
+    hipError_t e = hipMalloc(&ni, ncap * sizeof(uint32_t));
+    if (e != hipSuccess) {
+      (void)hipFree(nh);
+      set_last_error("hipMalloc(ids)", e);
+      return CBH_E_NOMEM;
+    }
+    if (n) {
+      CBH_HIP(hipMemcpy(nh, d_hashes, n * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+      CBH_HIP(hipMemcpy(ni, d_ids, n * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+    }
+    if (d_hashes) (void)hipFree(d_hashes);
+    if (d_ids) (void)hipFree(d_ids);
+    d_hashes = nh;
+    d_ids = ni;
+    cap = ncap;
+    return CBH_OK;
+  }
+};
+
+namespace {
+
+struct WsLease {
+  cbh_idx64* idx;
+  Workspace* ws;
+  WsLease(cbh_idx64* i, int* rc) : idx(i), ws(i->acquire(rc)) {}
+  ~WsLease() {
+    if (ws) idx->give_back(ws);
+  }
+};
+
+// scan into the workspace record buffer, growing it until every record fits.
+// On return *total = number of matching pairs, all of them present in ws->d_rec.
+int scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t nq, int thresh,
+             hipStream_t stream, unsigned long long* total) {
+  int rc = ws->ensure_records(std::max<size_t>(idx->rec_cap_default, 1024));
+  if (rc) return rc;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    CBH_HIP(hipMemsetAsync(ws->d_total, 0, sizeof(unsigned long long), stream));
+    rc = launch_hamm64_scan(idx->d_hashes, idx->d_ids, idx->n, d_q, nq, thresh, ws->d_rec,
+                            ws->rec_cap, ws->d_total, stream);
+    if (rc) return rc;
+    CBH_HIP(hipMemcpyAsync(ws->h_total, ws->d_total, sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, stream));
+    CBH_HIP(hipStreamSynchronize(stream));
+    *total = *ws->h_total;
+    if (*total <= ws->rec_cap) return CBH_OK;
+    // every match must be materialised to be ordered: grow and rescan
+    CBH_HIP(hipStreamSynchronize(stream));
+    rc = ws->ensure_records((size_t)*total + 1024);
+    if (rc) return rc == CBH_E_NOMEM ? CBH_E_OVERFLOW : rc;
+  }
+  return CBH_E_OVERFLOW;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cbh_version(void) { return CBH_VERSION; }
+
+int cbh_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int usable = 0;
+  for (int d = 0; d < n; ++d)
+    if (device_usable(d)) ++usable;
+  return usable;
+}
+
+const char* cbh_strerror(int code) {
+  switch (code) {
+    case CBH_OK: return "ok";
+    case CBH_E_INVAL: return "invalid argument";
+    case CBH_E_UNSUPPORTED: return "unsupported by this build";
+    case CBH_E_NODEVICE: return "no usable gfx950 device";
+    case CBH_E_NOMEM: return "out of memory";
+    case CBH_E_HIP: return "HIP runtime error";
+    case CBH_E_OVERFLOW: return "result does not fit the record buffer";
+    case CBH_E_NOTLOADED: return "index not loaded";
+    default: return "unknown error";
+  }
+}
+
+const char* cbh_last_error(void) { return t_last_error.c_str(); }
+
+/* ---- hashing ---------------------------------------------------------------------------- */
+
+int cbh_dcthash_batch_dev(const void* d_imgs, size_t n, int w, int h, size_t row_stride,
+                          size_t img_stride, void* d_out, int device, void* stream) {
+  if (!device_usable(device)) return CBH_E_NODEVICE;
+  if (n && (!d_imgs || !d_out)) return CBH_E_INVAL;
+  DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = launch_dcthash((const uint8_t*)d_imgs, n, w, h, row_stride, img_stride,
+                          (uint64_t*)d_out, s);
+  if (rc) return rc;
+  if (!stream) CBH_HIP(hipStreamSynchronize(s));
+  return CBH_OK;
+}
+
+int cbh_dcthash_batch(const uint8_t* imgs, size_t n, int w, int h, size_t row_stride,
+                      size_t img_stride, uint64_t* out, int device) {
+  if (!device_usable(device)) return CBH_E_NODEVICE;
+  if (n == 0) return CBH_OK;
+  if (!imgs || !out || w <= 0 || h <= 0 || row_stride < (size_t)w) return CBH_E_INVAL;
+  if (img_stride < (size_t)(h - 1) * row_stride + (size_t)w && n > 1) return CBH_E_INVAL;
+  if (w % 32 || h % 32 || w > 1024 || h > 1024) return CBH_E_UNSUPPORTED;
+  DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  // decoded tiles are staged in chunks of <= 256 MiB; strides are preserved on the device
+  const size_t span1 = (size_t)(h - 1) * row_stride + (size_t)w;
+  size_t per_chunk = std::max<size_t>(1, ((size_t)256 << 20) / std::max<size_t>(img_stride, span1));
+  per_chunk = std::min(per_chunk, n);
+  const size_t chunk_bytes = (per_chunk - 1) * img_stride + span1;
+  uint8_t* d_imgs = nullptr;
+  uint64_t* d_out = nullptr;
+  hipStream_t s = nullptr;
+  int rc = CBH_OK;
+  hipError_t e;
+  if ((e = hipMalloc(&d_imgs, chunk_bytes)) != hipSuccess ||
+      (e = hipMalloc(&d_out, per_chunk * sizeof(uint64_t))) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) {
+    set_last_error("dcthash_batch setup", e);
+    rc = e == hipErrorOutOfMemory ? CBH_E_NOMEM : CBH_E_HIP;
+  }
+  for (size_t i0 = 0; rc == CBH_OK && i0 < n; i0 += per_chunk) {
+    const size_t m = std::min(per_chunk, n - i0);
+    const size_t bytes = (m - 1) * img_stride + span1;
+    if ((e = hipMemcpyAsync(d_imgs, imgs + i0 * img_stride, bytes, hipMemcpyHostToDevice, s)) !=
+        hipSuccess) {
+      set_last_error("hipMemcpyAsync(H2D images)", e);
+      rc = CBH_E_HIP;
+      break;
+    }
+    rc = launch_dcthash(d_imgs, m, w, h, row_stride, img_stride, d_out, s);
+    if (rc) break;
+    if ((e = hipMemcpyAsync(out + i0, d_out, m * sizeof(uint64_t), hipMemcpyDeviceToHost, s)) !=
+            hipSuccess ||
+        (e = hipStreamSynchronize(s)) != hipSuccess) {
+      set_last_error("dcthash_batch D2H", e);
+      rc = CBH_E_HIP;
+    }
+  }
+  if (s) (void)hipStreamDestroy(s);
+  if (d_imgs) (void)hipFree(d_imgs);
+  if (d_out) (void)hipFree(d_out);
+  return rc;
+}
+
+/* ---- DctHashIndex ----------------------------------------------------------------------- */
+
+cbh_idx64* cbh_idx64_create(int device) {
+  if (!device_usable(device)) return nullptr;
+  cbh_idx64* idx = new (std::nothrow) cbh_idx64;
+  if (idx) idx->device = device;
+  return idx;
+}
+
+void cbh_idx64_destroy(cbh_idx64* idx) {
+  if (!idx) return;
+  DeviceGuard g(idx->device);
+  for (Workspace* w : idx->ws_free) {
+    w->release();
+    delete w;
+  }
+  if (idx->d_hashes) (void)hipFree(idx->d_hashes);
+  if (idx->d_ids) (void)hipFree(idx->d_ids);
+  delete idx;
+}
+
+static int idx_append(cbh_idx64* idx, const void* hashes, const void* ids, size_t n,
+                      hipMemcpyKind kind, hipStream_t s) {
+  if (n == 0) return CBH_OK;
+  if (!hashes || !ids) return CBH_E_INVAL;
+  if (idx->n + n > 0xfffffff0ull) return CBH_E_INVAL;
+  int rc = idx->reserve(idx->n + n);
+  if (rc) return rc;
+  CBH_HIP(hipMemcpyAsync(idx->d_hashes + idx->n, hashes, n * sizeof(uint64_t), kind, s));
+  CBH_HIP(hipMemcpyAsync(idx->d_ids + idx->n, ids, n * sizeof(uint32_t), kind, s));
+  CBH_HIP(hipStreamSynchronize(s));
+  idx->n += n;
+  return CBH_OK;
+}
+
+int cbh_idx64_load(cbh_idx64* idx, const uint64_t* hashes, const uint32_t* ids, size_t n) {
+  if (!idx) return CBH_E_INVAL;
+  DeviceGuard g(idx->device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  idx->n = 0;  // load() on a loaded index is a no-op in the reference (:75); here it reloads
+  idx->loaded = true;
+  return idx_append(idx, hashes, ids, n, hipMemcpyHostToDevice, nullptr);
+}
+
+int cbh_idx64_load_dev(cbh_idx64* idx, const void* d_hashes, const void* d_ids, size_t n,
+                       void* stream) {
+  if (!idx) return CBH_E_INVAL;
+  DeviceGuard g(idx->device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  idx->n = 0;
+  idx->loaded = true;
+  return idx_append(idx, d_hashes, d_ids, n, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+}
+
+int cbh_idx64_is_loaded(const cbh_idx64* idx) { return idx && idx->loaded; }
+
+int cbh_idx64_add(cbh_idx64* idx, const uint64_t* hashes, const uint32_t* ids, size_t n) {
+  if (!idx) return CBH_E_INVAL;
+  if (!idx->loaded) return CBH_E_NOTLOADED;  // "it is an error to call this if isLoaded() is false"
+  DeviceGuard g(idx->device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  return idx_append(idx, hashes, ids, n, hipMemcpyHostToDevice, nullptr);
+}
+
+int cbh_idx64_remove(cbh_idx64* idx, const uint32_t* ids, size_t n) {
+  if (!idx) return CBH_E_INVAL;
+  if (!idx->loaded) return CBH_OK;  // `if (!isLoaded()) return;` (:176)
+  if (n == 0 || idx->n == 0) return CBH_OK;
+  if (!ids) return CBH_E_INVAL;
+  DeviceGuard g(idx->device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  std::vector<uint32_t> rm(ids, ids + n);
+  std::sort(rm.begin(), rm.end());
+  rm.erase(std::unique(rm.begin(), rm.end()), rm.end());
+  uint32_t* d_rm = nullptr;
+  CBH_HIP(hipMalloc(&d_rm, rm.size() * sizeof(uint32_t)));
+  int rc = CBH_OK;
+  hipError_t e = hipMemcpy(d_rm, rm.data(), rm.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    set_last_error("hipMemcpy(remove ids)", e);
+    rc = CBH_E_HIP;
+  }
+  if (!rc) rc = launch_remove_ids(idx->d_hashes, idx->d_ids, idx->n, d_rm, rm.size(), nullptr);
+  if (!rc && (e = hipStreamSynchronize(nullptr)) != hipSuccess) {
+    set_last_error("remove sync", e);
+    rc = CBH_E_HIP;
+  }
+  (void)hipFree(d_rm);
+  return rc;
+}
+
+size_t cbh_idx64_count(const cbh_idx64* idx) { return idx ? idx->n : 0; }
+
+size_t cbh_idx64_memory_usage(const cbh_idx64* idx) {
+  return idx ? (sizeof(uint64_t) + sizeof(uint32_t)) * idx->n : 0;
+}
+
+int cbh_idx64_download(const cbh_idx64* idx, uint64_t* hashes, uint32_t* ids, size_t cap) {
+  if (!idx) return CBH_E_INVAL;
+  size_t m = std::min(cap, idx->n);
+  if (m == 0) return CBH_OK;
+  DeviceGuard g(idx->device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  if (hashes) CBH_HIP(hipMemcpy(hashes, idx->d_hashes, m * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  if (ids) CBH_HIP(hipMemcpy(ids, idx->d_ids, m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return CBH_OK;
+}
+
+int cbh_idx64_media_ids(const cbh_idx64* idx, uint32_t* out, size_t cap, size_t* n_out) {
+  if (!idx || !n_out) return CBH_E_INVAL;
+  // bookkeeping, not a hot path: one download + host filter (reference: a loop over the SoA)
+  std::vector<uint64_t> h(idx->n);
+  std::vector<uint32_t> id(idx->n);
+  int rc = cbh_idx64_download(idx, h.data(), id.data(), idx->n);
+  if (rc) return rc;
+  size_t m = 0;
+  for (size_t i = 0; i < idx->n; ++i)
+    if (h[i] != 0) {
+      if (out && m < cap) out[m] = id[i];
+      ++m;
+    }
+  *n_out = m;
+  return CBH_OK;
+}
+
+cbh_idx64* cbh_idx64_slice(const cbh_idx64* idx, const uint32_t* ids, size_t n) {
+  if (!idx || !idx->loaded) return nullptr;  // Q_ASSERT(isLoaded()) (:223)
+  std::vector<uint64_t> h(idx->n);
+  std::vector<uint32_t> id(idx->n);
+  if (cbh_idx64_download(idx, h.data(), id.data(), idx->n)) return nullptr;
+  std::vector<uint32_t> want(ids, ids + (ids ? n : 0));
+  std::sort(want.begin(), want.end());
+  std::vector<uint64_t> sh;
+  std::vector<uint32_t> si;
+  for (size_t i = 0; i < idx->n; ++i)
+    if (std::binary_search(want.begin(), want.end(), id[i])) {
+      sh.push_back(h[i]);
+      si.push_back(id[i]);
+    }
+  cbh_idx64* out = cbh_idx64_create(idx->device);
+  if (!out) return nullptr;
+  if (cbh_idx64_load(out, sh.data(), si.data(), sh.size())) {
+    cbh_idx64_destroy(out);
+    return nullptr;
+  }
+  return out;
+}
+
+int cbh_idx64_set_record_capacity(cbh_idx64* idx, size_t records) {
+  if (!idx || records == 0) return CBH_E_INVAL;
+  idx->rec_cap_default = records;
+  return CBH_OK;
+}
+
+int cbh_idx64_find(cbh_idx64* idx, uint64_t q, int thresh, cbh_match* out, size_t cap,
+                   size_t* n_out) {
+  if (!idx || !n_out || (cap && !out)) return CBH_E_INVAL;
+  *n_out = 0;
+  if (q == 0 || idx->n == 0 || thresh <= 0) return CBH_OK;  // null needle / empty tree (:196-205)
+  DeviceGuard g(idx->device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  int rc;
+  WsLease L(idx, &rc);
+  if (!L.ws) return rc;
+  Workspace* ws = L.ws;
+  rc = Workspace::grow(&ws->d_q, &ws->q_cap, 1);
+  if (rc) return rc;
+  CBH_HIP(hipMemcpyAsync(ws->d_q, &q, sizeof q, hipMemcpyHostToDevice, ws->stream));
+  unsigned long long total = 0;
+  rc = scan_all(idx, ws, ws->d_q, 1, thresh, ws->stream, &total);
+  if (rc) return rc;
+  *n_out = (size_t)total;
+  if (total == 0) return CBH_OK;
+  std::vector<cbh_record> recs;
+  if (total <= 65536) {  // small result: order on the host
+    recs.resize((size_t)total);
+    CBH_HIP(hipMemcpyAsync(recs.data(), ws->d_rec, total * sizeof(cbh_record),
+                           hipMemcpyDeviceToHost, ws->stream));
+    CBH_HIP(hipStreamSynchronize(ws->stream));
+    std::sort(recs.begin(), recs.end());
+  } else {
+    rc = launch_sort_records(ws->d_rec, ws->d_alt, (size_t)total, 1, ws->d_tmp, ws->tmp_bytes,
+                             ws->stream);
+    if (rc) return rc;
+    recs.resize(std::min<size_t>((size_t)total, cap));
+    if (!recs.empty())
+      CBH_HIP(hipMemcpyAsync(recs.data(), ws->d_rec, recs.size() * sizeof(cbh_record),
+                             hipMemcpyDeviceToHost, ws->stream));
+    CBH_HIP(hipStreamSynchronize(ws->stream));
+  }
+  const size_t m = std::min(recs.size(), cap);
+  for (size_t i = 0; i < m; ++i) {
+    out[i].id = CBH_REC_ID(recs[i]);
+    out[i].score = CBH_REC_DIST(recs[i]);
+  }
+  return CBH_OK;
+}
+
+static int find_batch_core(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t nq,
+                           int thresh, int k, cbh_match* d_out, uint32_t* d_counts,
+                           hipStream_t s, unsigned long long* total) {
+  *total = 0;
+  if (idx->n && thresh > 0) {
+    int rc = scan_all(idx, ws, d_q, nq, thresh, s, total);
+    if (rc) return rc;
+    rc = launch_sort_records(ws->d_rec, ws->d_alt, (size_t)*total, nq, ws->d_tmp, ws->tmp_bytes, s);
+    if (rc) return rc;
+  }
+  return launch_select_records(ws->d_rec, (size_t)*total, nq, k, d_out, d_counts, s);
+}
+
+int cbh_idx64_find_batch(cbh_idx64* idx, const uint64_t* q, size_t nq, int thresh,
+                         int max_per_query, cbh_match* out, uint32_t* counts) {
+  if (!idx || max_per_query < 0) return CBH_E_INVAL;
+  if (nq == 0) return CBH_OK;
+  if (!q || !counts || (max_per_query && !out) || nq > CBH_MAX_QUERIES_PER_CALL) return CBH_E_INVAL;
+  DeviceGuard g(idx->device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  int rc;
+  WsLease L(idx, &rc);
+  if (!L.ws) return rc;
+  Workspace* ws = L.ws;
+  const size_t k = (size_t)max_per_query;
+  if ((rc = Workspace::grow(&ws->d_q, &ws->q_cap, nq))) return rc;
+  if ((rc = Workspace::grow(&ws->d_out, &ws->out_cap, std::max<size_t>(1, nq * k)))) return rc;
+  if ((rc = Workspace::grow(&ws->d_counts, &ws->counts_cap, nq))) return rc;
+  CBH_HIP(hipMemcpyAsync(ws->d_q, q, nq * sizeof(uint64_t), hipMemcpyHostToDevice, ws->stream));
+  unsigned long long total = 0;
+  rc = find_batch_core(idx, ws, ws->d_q, nq, thresh, max_per_query, ws->d_out, ws->d_counts,
+                       ws->stream, &total);
+  if (rc) return rc;
+  if (k)
+    CBH_HIP(hipMemcpyAsync(out, ws->d_out, nq * k * sizeof(cbh_match), hipMemcpyDeviceToHost,
+                           ws->stream));
+  CBH_HIP(hipMemcpyAsync(counts, ws->d_counts, nq * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                         ws->stream));
+  CBH_HIP(hipStreamSynchronize(ws->stream));
+  return CBH_OK;
+}
+
+int cbh_idx64_find_batch_dev(cbh_idx64* idx, const void* d_q, size_t nq, int thresh,
+                             int max_per_query, void* d_out, void* d_counts, uint64_t* total_out,
+                             void* stream) {
+  if (!idx || max_per_query < 0) return CBH_E_INVAL;
+  if (total_out) *total_out = 0;
+  if (nq == 0) return CBH_OK;
+  if (!d_q || !d_counts || (max_per_query && !d_out) || nq > CBH_MAX_QUERIES_PER_CALL)
+    return CBH_E_INVAL;
+  DeviceGuard g(idx->device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  int rc;
+  WsLease L(idx, &rc);
+  if (!L.ws) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : L.ws->stream;
+  unsigned long long total = 0;
+  rc = find_batch_core(idx, L.ws, (const uint64_t*)d_q, nq, thresh, max_per_query,
+                       (cbh_match*)d_out, (uint32_t*)d_counts, s, &total);
+  if (rc) return rc;
+  CBH_HIP(hipStreamSynchronize(s));  // the workspace goes back to the pool: its buffers must be idle
+  if (total_out) *total_out = total;
+  return CBH_OK;
+}
+
+int cbh_idx64_scan_dev(cbh_idx64* idx, const void* d_q, size_t nq, int thresh, void* d_records,
+                       size_t cap, void* d_total, void* stream) {
+  if (!idx || !d_total || (cap && !d_records)) return CBH_E_INVAL;
+  if (nq == 0 || idx->n == 0) return CBH_OK;
+  if (!d_q || nq > CBH_MAX_QUERIES_PER_CALL) return CBH_E_INVAL;
+  DeviceGuard g(idx->device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = launch_hamm64_scan(idx->d_hashes, idx->d_ids, idx->n, (const uint64_t*)d_q, nq, thresh,
+                              (cbh_record*)d_records, cap, (unsigned long long*)d_total, s);
+  if (rc) return rc;
+  if (!stream) CBH_HIP(hipStreamSynchronize(s));
+  return CBH_OK;
+}
+
+int cbh_sort_records_dev(void* d_records, size_t n, size_t nq, int device, void* stream) {
+  if (n < 2) return CBH_OK;
+  if (!d_records) return CBH_E_INVAL;
+  if (!device_usable(device)) return CBH_E_NODEVICE;
+  DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  hipStream_t s = (hipStream_t)stream;
+  cbh_record* alt = nullptr;
+  void* tmp = nullptr;
+  const size_t tmp_bytes = sort_records_scratch_bytes(n);
+  CBH_HIP(hipMalloc(&alt, n * sizeof(cbh_record)));
+  hipError_t e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
+  if (e != hipSuccess) {
+    (void)hipFree(alt);
+    set_last_error("hipMalloc(sort scratch)", e);
+    return CBH_E_NOMEM;
+  }
+  int rc = launch_sort_records((cbh_record*)d_records, alt, n, nq, tmp, tmp_bytes, s);
+  e = hipStreamSynchronize(s);
+  (void)hipFree(alt);
+  (void)hipFree(tmp);
+  if (rc) return rc;
+  if (e != hipSuccess) {
+    set_last_error("sort sync", e);
+    return CBH_E_HIP;
+  }
+  return CBH_OK;
+}
+
+int cbh_select_records_dev(const void* d_sorted_records, size_t n, size_t nq, int max_per_query,
+                           void* d_out, void* d_counts, int device, void* stream) {
+  if (nq == 0) return CBH_OK;
+  if (!d_counts || (max_per_query && !d_out) || max_per_query < 0 || (n && !d_sorted_records))
+    return CBH_E_INVAL;
+  if (!device_usable(device)) return CBH_E_NODEVICE;
+  DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = launch_select_records((const cbh_record*)d_sorted_records, n, nq, max_per_query,
+                                 (cbh_match*)d_out, (uint32_t*)d_counts, s);
+  if (rc) return rc;
+  if (!stream) CBH_HIP(hipStreamSynchronize(s));
+  return CBH_OK;
+}
+
+/* ---- measurement ------------------------------------------------------------------------ */
+
+int cbh_idx64_time_scan_dev(cbh_idx64* idx, const void* d_q, size_t nq, int thresh,
+                            void* d_records, size_t cap, void* d_total, int iters, float* ms_avg) {
+  if (!idx || !ms_avg || iters <= 0 || !d_total) return CBH_E_INVAL;
+  DeviceGuard g(idx->device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  int rc;
+  WsLease L(idx, &rc);
+  if (!L.ws) return rc;
+  hipStream_t s = L.ws->stream;
+  hipEvent_t e0, e1;
+  CBH_HIP(hipEventCreate(&e0));
+  CBH_HIP(hipEventCreate(&e1));
+  CBH_HIP(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), s));
+  CBH_HIP(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) {
+    rc = launch_hamm64_scan(idx->d_hashes, idx->d_ids, idx->n, (const uint64_t*)d_q, nq, thresh,
+                            (cbh_record*)d_records, cap, (unsigned long long*)d_total, s);
+    if (rc) break;
+  }
+  CBH_HIP(hipEventRecord(e1, s));
+  CBH_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CBH_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_avg = ms / (float)iters;
+  return rc;
+}
+
+int cbh_time_dcthash_dev(const void* d_imgs, size_t n, int w, int h, size_t row_stride,
+                         size_t img_stride, void* d_out, int device, int iters, float* ms_avg) {
+  if (!ms_avg || iters <= 0) return CBH_E_INVAL;
+  if (!device_usable(device)) return CBH_E_NODEVICE;
+  DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  hipStream_t s;
+  CBH_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  hipEvent_t e0, e1;
+  CBH_HIP(hipEventCreate(&e0));
+  CBH_HIP(hipEventCreate(&e1));
+  int rc = CBH_OK;
+  CBH_HIP(hipEventRecord(e0, s));
+  for (int i = 0; i < iters && !rc; ++i)
+    rc = launch_dcthash((const uint8_t*)d_imgs, n, w, h, row_stride, img_stride, (uint64_t*)d_out, s);
+  CBH_HIP(hipEventRecord(e1, s));
+  CBH_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CBH_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipStreamDestroy(s);
+  *ms_avg = ms / (float)iters;
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,167 @@
+// hamm64_scan.hip -- K3: all-pairs 64-bit Hamming threshold scan for gfx950 (CDNA4).
+//
+// Replaces the per-needle tree walk behind DctHashIndex::find (src/dcthashindex.cpp:193-220;
+// VpTree::thresholdSearch src/tree/vptree.h:228-255) with the exact brute-force predicate the
+// reference states at dcthashindex.cpp:210-217:  hamm64(q, hash[i]) < thresh  &&  id[i] != 0
+// (hamm64 = popcountll(a ^ b), src/hamm.h:24-26), evaluated for a whole batch of needles.
+//
+// Mapping to the machine (see DESIGN.md "k_hamm64_scan")
+//  * haystack slots live in VGPRs: each lane owns H=8 slots (16 VGPRs), a 256-thread workgroup
+//    owns a tile of 2048 slots, loaded once with coalesced 8-B loads;
+//  * needles are wave-uniform: they stream through the scalar cache (s_load_dwordx16 = 8 needles)
+//    and feed the VALU as SGPR operands, so the inner loop has no vector memory traffic at all;
+//  * per (needle, slot): v_xor_b32 + v_bcnt_u32_b32 on the low word (plus xor+bcnt-accumulate on
+//    the high word in the FULL variant); two needles fold into one v_min3_u32 against a running
+//    per-slot minimum.  After QB=8 needles one compare decides whether anything in the
+//    8x8x64 block can be under threshold; only then the exact 64-bit distances are recomputed
+//    and records are appended (wave-aggregated atomic).  PRE (low-word prefilter) is exact
+//    because popc(lo) <= popc(lo)+popc(hi): a pair whose low-word distance is already >= thresh
+//    cannot match.  It is used for small thresholds where the low word alone rejects almost
+//    every block; FULL is used otherwise.
+//  * grid = (slot tiles) x (needle chunks); consecutive blockIdx.x share a needle chunk, so the
+//    workgroups resident at one time stream the same few needle chunks out of L2.
+#include "cbh_internal.h"
+
+namespace cbh {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kH = 8;   // haystack slots per lane
+constexpr int kQB = 8;  // needles per check block (one s_load_dwordx16)
+
+__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) {
+  return min(min(a, b), c);  // -> v_min3_u32
+}
+
+__device__ __forceinline__ void emit(cbh_record* __restrict__ rec, unsigned long long cap,
+                                     unsigned long long* __restrict__ total, uint32_t qidx,
+                                     uint32_t dist, uint32_t id) {
+  unsigned long long slot = atomicAdd(total, 1ull);  // compiler aggregates per wave
+  if (slot < cap) rec[slot] = ((cbh_record)qidx << 39) | ((cbh_record)dist << 32) | id;
+}
+
+// exact evaluation of needles [qa, qb) against this lane's H slots
+template <int H>
+__device__ __forceinline__ void exact_block(const uint2 (&h)[H], uint32_t base_idx, uint32_t n,
+                                            const uint32_t* __restrict__ ids,
+                                            const uint64_t* __restrict__ q, uint32_t qa,
+                                            uint32_t qb, uint32_t thresh,
+                                            cbh_record* __restrict__ rec, unsigned long long cap,
+                                            unsigned long long* __restrict__ total) {
+#pragma unroll 1
+  for (uint32_t qi = qa; qi < qb; ++qi) {
+    const uint64_t qq = q[qi];
+    if (qq == 0) continue;  // null needle: DctHashIndex::find returns nothing (:196-200)
+    const uint32_t ql = (uint32_t)qq, qh = (uint32_t)(qq >> 32);
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const uint32_t d = __popc(h[j].x ^ ql) + __popc(h[j].y ^ qh);
+      if (d < thresh) {
+        const uint32_t idx = base_idx + (uint32_t)j * kThreads;
+        if (idx < n) {
+          const uint32_t id = ids[idx];
+          if (id != 0) emit(rec, cap, total, qi, d, id);
+        }
+      }
+    }
+  }
+}
+
+template <int H, int QB, bool PRE>
+__global__ __launch_bounds__(kThreads) void k_hamm64_scan(
+    const uint2* __restrict__ hay, const uint32_t* __restrict__ ids, uint32_t n,
+    const uint64_t* __restrict__ q, uint32_t nq, uint32_t q_chunk, uint32_t thresh,
+    cbh_record* __restrict__ rec, unsigned long long cap, unsigned long long* __restrict__ total) {
+  const uint32_t base_idx = blockIdx.x * (uint32_t)(kThreads * H) + threadIdx.x;
+  uint2 h[H];
+#pragma unroll
+  for (int j = 0; j < H; ++j) {
+    const uint32_t idx = base_idx + (uint32_t)j * kThreads;
+    h[j] = idx < n ? hay[idx] : make_uint2(0u, 0u);
+  }
+  const uint32_t q0 = blockIdx.y * q_chunk;
+  const uint32_t q1 = min(nq, q0 + q_chunk);
+  uint32_t qb = q0;
+  // needles as (lo,hi) dword pairs; 64-bit pointer bump keeps the 8 loads of a block at constant
+  // offsets from one SGPR base (wave-uniform -> SMEM)
+  const uint2* __restrict__ qp = reinterpret_cast<const uint2*>(q) + (size_t)q0;
+
+  uint2 cur[QB];
+  if (qb + QB <= q1) {
+#pragma unroll
+    for (int i = 0; i < QB; ++i) cur[i] = qp[i];
+  }
+  for (; qb + QB <= q1; qb += QB) {
+    // prefetch the next block of needles while this one is being compared
+    uint2 nxt[QB];
+    qp += QB;
+    if (qb + 2 * QB <= q1) {
+#pragma unroll
+      for (int i = 0; i < QB; ++i) nxt[i] = qp[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < QB; ++i) nxt[i] = make_uint2(0u, 0u);
+    }
+    uint32_t acc[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) acc[j] = 0xffu;
+#pragma unroll
+    for (int i = 0; i < QB; i += 2) {
+      const uint2 qa = cur[i];
+      const uint2 qc = cur[i + 1];
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        uint32_t c0 = __popc(h[j].x ^ qa.x);
+        uint32_t c1 = __popc(h[j].x ^ qc.x);
+        if (!PRE) {
+          c0 += __popc(h[j].y ^ qa.y);
+          c1 += __popc(h[j].y ^ qc.y);
+        }
+        acc[j] = min3u(acc[j], c0, c1);
+      }
+    }
+    uint32_t m = acc[0];
+#pragma unroll
+    for (int j = 1; j + 1 < H; j += 2) m = min3u(m, acc[j], acc[j + 1]);
+    if (H % 2 == 0) m = min(m, acc[H - 1]);
+    if (m < thresh) exact_block<H>(h, base_idx, n, ids, q, qb, qb + QB, thresh, rec, cap, total);
+#pragma unroll
+    for (int i = 0; i < QB; ++i) cur[i] = nxt[i];
+  }
+  if (qb < q1) exact_block<H>(h, base_idx, n, ids, q, qb, q1, thresh, rec, cap, total);
+}
+
+}  // namespace
+
+int launch_hamm64_scan(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n,
+                       const uint64_t* d_q, size_t nq, int thresh, cbh_record* d_rec, size_t cap,
+                       unsigned long long* d_total, hipStream_t stream) {
+  if (n == 0 || nq == 0 || thresh <= 0) return CBH_OK;
+  if (n > 0xfffffff0ull || nq > CBH_MAX_QUERIES_PER_CALL) return CBH_E_INVAL;
+  const uint32_t tile = kThreads * kH;
+  const uint32_t tiles = (uint32_t)((n + tile - 1) / tile);
+  // needle chunk: enough workgroups to fill 256 CUs x 8 waves/SIMD several times over, but each
+  // workgroup amortises its 16 KB tile load over >= 1024 needles when there are that many.
+  uint32_t q_chunk = 16384;
+  while (q_chunk > 1024 && (uint64_t)tiles * ((nq + q_chunk - 1) / q_chunk) < 8192) q_chunk >>= 1;
+  uint32_t chunks = (uint32_t)((nq + q_chunk - 1) / q_chunk);
+  if (chunks > 65535) {
+    q_chunk = (uint32_t)((nq + 65534) / 65535);
+    q_chunk = (q_chunk + kQB - 1) / kQB * kQB;
+    chunks = (uint32_t)((nq + q_chunk - 1) / q_chunk);
+  }
+  dim3 grid(tiles, chunks), block(kThreads);
+  const uint2* hay = reinterpret_cast<const uint2*>(d_hashes);
+  if (thresh <= 5)
+    hipLaunchKernelGGL((k_hamm64_scan<kH, kQB, true>), grid, block, 0, stream, hay, d_ids,
+                       (uint32_t)n, d_q, (uint32_t)nq, q_chunk, (uint32_t)thresh, d_rec,
+                       (unsigned long long)cap, d_total);
+  else
+    hipLaunchKernelGGL((k_hamm64_scan<kH, kQB, false>), grid, block, 0, stream, hay, d_ids,
+                       (uint32_t)n, d_q, (uint32_t)nq, q_chunk, (uint32_t)thresh, d_rec,
+                       (unsigned long long)cap, d_total);
+  CBH_HIP(hipGetLastError());
+  return CBH_OK;
+}
+
+}  // namespace cbh

@@ -1,0 +1,213 @@
+"""Host-side mirror of cbird's Index plugin surface for the DCT-hash path.
+
+Same names, argument meaning and error behaviour as the reference classes so the parity tests
+read like ``unit/testdcthashindex.cpp`` / ``unit/testindexbase.cpp``:
+
+  SearchParams   src/index.h:36-148   (only the fields the hot path reads)
+  Match          src/index.h:157-166  (Index::Match)
+  MatchRange     src/media.h:62-78
+  Media          src/media.h          (only id / dctHash / path: what DctHashIndex touches)
+  DctHashIndex   src/dcthashindex.h:29-67, src/dcthashindex.cpp:30-250
+
+All compute goes through the C-ABI in include/cbird_hip.h (libcbird_hip.so, HIP kernels for
+gfx950).  There is no CPU implementation here: without the library or a device the methods
+raise ``CbhError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+from dataclasses import dataclass, field
+from typing import Iterable, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import CbhError, cbh_match, check
+
+
+@dataclass
+class MatchRange:
+    """src/media.h:62-78"""
+    srcIn: int = -1
+    dstIn: int = -1
+    len: int = 0
+
+
+@dataclass
+class Match:
+    """Index::Match, src/index.h:157-166"""
+    mediaId: int = 0
+    score: int = 0
+    range: MatchRange = field(default_factory=MatchRange)
+
+    def __lt__(self, other: "Match") -> bool:  # src/index.h:284
+        return self.score < other.score
+
+
+@dataclass
+class Media:
+    """The slice of cbird's Media a DctHashIndex needle/haystack item carries."""
+    id: int = 0
+    dctHash: int = 0
+    path: str = ""
+    score: int = -1
+    matchRange: MatchRange = field(default_factory=MatchRange)
+
+    def isValid(self) -> bool:
+        return self.id != 0
+
+
+@dataclass
+class SearchParams:
+    """src/index.h:74-121 (defaults identical)"""
+    AlgoDCT = 0
+    AlgoDCTFeatures = 1
+    AlgoCVFeatures = 2
+    AlgoColor = 3
+    AlgoVideo = 4
+
+    algo: int = 0
+    dctThresh: int = 5
+    cvThresh: int = 25
+    minMatches: int = 1
+    maxMatches: int = 5
+    maxThresh: int = 0
+    filterSelf: bool = True
+    verbose: bool = False
+
+
+def _as_u64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def _as_u32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+class DctHashIndex:
+    """Index for 64-bit dct hashes that uses hamming distance (src/dcthashindex.h:26-29),
+    resident on one MI355X."""
+
+    def __init__(self, device: int = 0, _handle=None) -> None:
+        self._L = _lib.lib()
+        self._device = device
+        self._id = SearchParams.AlgoDCT  # dcthashindex.cpp:31
+        if _handle is not None:
+            self._h = _handle
+        else:
+            self._h = self._L.cbh_idx64_create(device)
+            if not self._h:
+                raise CbhError(_lib.CBH_E_NODEVICE, "cbh_idx64_create")
+
+    def __del__(self) -> None:
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.cbh_idx64_destroy(h)
+
+    # -- Index interface ------------------------------------------------------------------
+    def id(self) -> int:
+        return self._id
+
+    def isLoaded(self) -> bool:
+        return bool(self._L.cbh_idx64_is_loaded(self._h))
+
+    def count(self) -> int:
+        return int(self._L.cbh_idx64_count(self._h))
+
+    def memoryUsage(self) -> int:
+        return int(self._L.cbh_idx64_memory_usage(self._h))
+
+    def load(self, hashes: Sequence[int], ids: Sequence[int]) -> None:
+        """DctHashIndex::load (:70-114).  The reference runs `select id,phash_dct from media
+        where type=1`; here the caller passes the two result columns."""
+        if self.isLoaded():
+            return  # `if (!isLoaded())` (:75)
+        h, i = _as_u64(hashes), _as_u32(ids)
+        if len(h) != len(i):
+            raise ValueError("hashes/ids length mismatch")
+        check(self._L.cbh_idx64_load(self._h, h.ctypes.data, i.ctypes.data, len(h)), "load")
+
+    def load_device(self, d_hashes_ptr: int, d_ids_ptr: int, n: int, stream: int = 0) -> None:
+        """Adopt device-resident columns (copy device-to-device into the index)."""
+        check(self._L.cbh_idx64_load_dev(self._h, d_hashes_ptr, d_ids_ptr, n, stream), "load_dev")
+
+    def add(self, media: Iterable[Media]) -> None:
+        """DctHashIndex::add (:158-173)"""
+        media = list(media)
+        h = _as_u64([m.dctHash for m in media])
+        i = _as_u32([m.id for m in media])
+        check(self._L.cbh_idx64_add(self._h, h.ctypes.data, i.ctypes.data, len(h)), "add")
+
+    def remove(self, ids: Sequence[int]) -> None:
+        """DctHashIndex::remove (:175-191): nullify, never compact."""
+        i = _as_u32(list(ids))
+        check(self._L.cbh_idx64_remove(self._h, i.ctypes.data, len(i)), "remove")
+
+    def mediaIds(self) -> set[int]:
+        """loaded branch of DctHashIndex::mediaIds (:129-133)"""
+        n = C.c_size_t(0)
+        check(self._L.cbh_idx64_media_ids(self._h, None, 0, C.byref(n)), "mediaIds")
+        out = np.zeros(max(1, n.value), np.uint32)
+        check(self._L.cbh_idx64_media_ids(self._h, out.ctypes.data, len(out), C.byref(n)),
+              "mediaIds")
+        return set(int(x) for x in out[: n.value])
+
+    def find(self, m: Media, p: SearchParams) -> list[Match]:
+        """DctHashIndex::find (:193-220)"""
+        target = int(m.dctHash)
+        if not target:
+            warnings.warn(f"no hash for needle: {m.path}")
+            return []
+        if self.count() == 0:
+            warnings.warn("empty/null tree")
+            return []
+        cap = 64
+        while True:
+            buf = (cbh_match * cap)()
+            n = C.c_size_t(0)
+            check(self._L.cbh_idx64_find(self._h, target, int(p.dctThresh), buf, cap, C.byref(n)),
+                  "find")
+            if n.value <= cap:
+                return [Match(buf[i].id, buf[i].score) for i in range(n.value)]
+            cap = n.value
+
+    def slice(self, mediaIds: Iterable[int]) -> "DctHashIndex":
+        """DctHashIndex::slice (:222-250); the caller owns the result."""
+        assert self.isLoaded()
+        i = _as_u32(sorted(set(int(x) for x in mediaIds)))
+        h = self._L.cbh_idx64_slice(self._h, i.ctypes.data, len(i))
+        if not h:
+            raise CbhError(_lib.CBH_E_HIP, "slice")
+        return DctHashIndex(self._device, _handle=h)
+
+    # -- batched entry points (the MI355X-native shape of Database::similar's fan-out) ----------
+    def find_batch(self, hashes: Sequence[int], thresh: int, max_per_query: int):
+        """For every needle hash: first `max_per_query` matches in (score, mediaId) order and the
+        full match count.  Returns (ids[nq,k] u32, scores[nq,k] i32, counts[nq] u32)."""
+        q = _as_u64(hashes)
+        nq, k = len(q), int(max_per_query)
+        out = np.zeros((nq, max(k, 1), 2), np.uint32)
+        counts = np.zeros(nq, np.uint32)
+        check(self._L.cbh_idx64_find_batch(self._h, q.ctypes.data, nq, int(thresh), k,
+                                           out.ctypes.data, counts.ctypes.data), "find_batch")
+        out = out[:, :k, :]
+        return out[:, :, 0].copy(), out[:, :, 1].astype(np.int32), counts
+
+    def download(self):
+        n = self.count()
+        h = np.zeros(n, np.uint64)
+        i = np.zeros(n, np.uint32)
+        check(self._L.cbh_idx64_download(self._h, h.ctypes.data, i.ctypes.data, n), "download")
+        return h, i
+
+    def set_record_capacity(self, records: int) -> None:
+        check(self._L.cbh_idx64_set_record_capacity(self._h, records), "set_record_capacity")
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def device(self) -> int:
+        return self._device

@@ -1,0 +1,146 @@
+/* cbird_hip.h -- C-ABI of libcbird_hip.so: cbird's perceptual-hash build + Hamming find hot
+ * path on AMD MI355X (gfx950 / CDNA4).
+ *
+ * This is the drop-in boundary: plain pointers and sizes only, no C++/torch/Qt types.  Each
+ * entry point names the reference interface it replaces (paths relative to the cbird source
+ * tree, v0.8.1).  A cbird maintainer binds these from a thin `Index` subclass -- see
+ * INTEGRATION.md and cbird_amd/cpp/gpu_dcthashindex.h.
+ *
+ * Conventions
+ *  - return 0 (CBH_OK) or a negative CBH_E_* code; nothing aborts, nothing throws.
+ *  - the caller owns every buffer it passes; the library copies what it keeps.
+ *  - "host" entry points take host pointers and perform the transfers themselves;
+ *    "*_dev" entry points take device pointers (hipMalloc'ed memory of the index's device)
+ *    and enqueue on `stream` (a hipStream_t passed as void*; NULL = the library's stream for
+ *    that call, synchronised before return).
+ *  - find/find_batch/scan may be called concurrently from many host threads on one index
+ *    (cbird calls Index::find from QThreadPool workers under a read lock,
+ *    src/database.cpp:1400-1432,1698); load/add/remove/destroy need exclusive access
+ *    (cbird holds the write lock there, src/database.cpp:371,544,1673).
+ *  - there is NO CPU fallback: without a usable gfx950 device every compute entry point
+ *    returns CBH_E_NODEVICE.
+ */
+#ifndef CBIRD_HIP_H
+#define CBIRD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CBH_VERSION 100 /* 0.1.0 */
+
+enum {
+  CBH_OK = 0,
+  CBH_E_INVAL = -1,       /* bad argument */
+  CBH_E_UNSUPPORTED = -2, /* valid in cbird, not implemented by this build (e.g. image size) */
+  CBH_E_NODEVICE = -3,    /* no HIP device / kernel image not loadable */
+  CBH_E_NOMEM = -4,       /* host or device allocation failed */
+  CBH_E_HIP = -5,         /* HIP runtime error, see cbh_last_error() */
+  CBH_E_OVERFLOW = -6,    /* result does not fit the record buffer; see cbh_idx64_set_record_capacity */
+  CBH_E_NOTLOADED = -7    /* index used before load (src/index.h:233-237) */
+};
+
+/* Index::Match without the MatchRange (src/index.h:157-166); score = Hamming distance. */
+typedef struct cbh_match {
+  uint32_t id;   /* mediaId */
+  int32_t score; /* lower is better */
+} cbh_match;
+
+/* Raw scan record, one per (query, haystack entry) pair under threshold:
+ *   bits 63..39  query index within the call (< 2^25)
+ *   bits 38..32  Hamming distance (0..64)
+ *   bits 31..0   mediaId
+ * so that an ascending u64 sort yields cbird's order: query, then score, then mediaId. */
+typedef uint64_t cbh_record;
+#define CBH_REC_QUERY(r) ((uint32_t)((r) >> 39))
+#define CBH_REC_DIST(r) ((int)(((r) >> 32) & 0x7f))
+#define CBH_REC_ID(r) ((uint32_t)((r)&0xffffffffu))
+#define CBH_MAX_QUERIES_PER_CALL (1u << 25)
+
+typedef struct cbh_idx64 cbh_idx64; /* opaque: DctHashIndex state on one device */
+
+/* ---- library ------------------------------------------------------------------------- */
+int cbh_version(void);
+int cbh_device_count(void);             /* number of usable gfx950 devices, 0 if none */
+const char* cbh_strerror(int code);     /* static string */
+const char* cbh_last_error(void);       /* thread-local detail of the last CBH_E_HIP */
+
+/* ---- hash build: replaces dctHash64(const cv::Mat&, bool) -- src/cvutil.cpp:435-545,
+ * called once per image from Scanner::processImage (src/scanner.cpp:862).
+ * imgs: n 8-bit single-channel images (cv::Mat CV_8UC1 after grayscale()), image i at
+ * imgs + i*img_stride, row y at + y*row_stride.  Supported geometry: w,h multiples of 32
+ * (integer-ratio INTER_AREA path) up to 1024, or exactly 32x32; anything else returns
+ * CBH_E_UNSUPPORTED.  out[i] = 64-bit hash (bit 0 clear unless the hash would be 0 -> 1). */
+int cbh_dcthash_batch(const uint8_t* imgs, size_t n, int w, int h, size_t row_stride,
+                      size_t img_stride, uint64_t* out, int device);
+int cbh_dcthash_batch_dev(const void* d_imgs, size_t n, int w, int h, size_t row_stride,
+                          size_t img_stride, void* d_out, int device, void* stream);
+
+/* ---- DctHashIndex: src/dcthashindex.{h,cpp} -------------------------------------------- */
+cbh_idx64* cbh_idx64_create(int device);                         /* DctHashIndex() :30-41 */
+void cbh_idx64_destroy(cbh_idx64*);                              /* ~DctHashIndex/unload :43-54 */
+/* load(): replaces the SoA fill of DctHashIndex::load (:70-114); the caller runs the SQL
+ * (`select id,phash_dct from media where type=1`, :89) and hands over the two columns.
+ * n == 0 is valid (loaded, empty). */
+int cbh_idx64_load(cbh_idx64*, const uint64_t* hashes, const uint32_t* ids, size_t n);
+int cbh_idx64_load_dev(cbh_idx64*, const void* d_hashes, const void* d_ids, size_t n, void* stream);
+int cbh_idx64_is_loaded(const cbh_idx64*);                       /* isLoaded() */
+int cbh_idx64_add(cbh_idx64*, const uint64_t* hashes, const uint32_t* ids, size_t n); /* add() :158-173 */
+/* remove(): zero id AND hash of every slot whose id is listed, in place (:175-191);
+ * count() does not shrink. */
+int cbh_idx64_remove(cbh_idx64*, const uint32_t* ids, size_t n);
+size_t cbh_idx64_count(const cbh_idx64*);                        /* count() = _numHashes */
+size_t cbh_idx64_memory_usage(const cbh_idx64*);                 /* memoryUsage() = 12 B * count (:56-59) */
+/* mediaIds(), loaded branch (:129-133): ids of slots with hash != 0.  Writes up to cap,
+ * *n_out = full number. */
+int cbh_idx64_media_ids(const cbh_idx64*, uint32_t* out, size_t cap, size_t* n_out);
+/* slice(): new index holding the slots whose id is in ids[], original order (:222-250);
+ * caller destroys it (src/database.cpp:1435,1491). */
+cbh_idx64* cbh_idx64_slice(const cbh_idx64*, const uint32_t* ids, size_t n);
+/* copy the resident SoA back (tests, save()) */
+int cbh_idx64_download(const cbh_idx64*, uint64_t* hashes, uint32_t* ids, size_t cap);
+
+/* find(): every slot with hamm64(q, hash) < thresh and id != 0 (:193-220 with the brute-force
+ * predicate of :210-217), as Match(id, distance), ascending (score, id).  q == 0 -> CBH_OK with
+ * *n_out = 0 (:196-200).  Writes the first min(*n_out, cap) matches; *n_out is the full count. */
+int cbh_idx64_find(cbh_idx64*, uint64_t q, int thresh, cbh_match* out, size_t cap, size_t* n_out);
+/* Batched find + the sort/truncate of Database::searchIndex (src/database.cpp:1729-1735):
+ * for query j, out[j*max_per_query ..] receives its first min(counts[j], max_per_query)
+ * matches in (score, id) order (unused slots zeroed), counts[j] the full match count.
+ * nq <= CBH_MAX_QUERIES_PER_CALL. */
+int cbh_idx64_find_batch(cbh_idx64*, const uint64_t* q, size_t nq, int thresh, int max_per_query,
+                         cbh_match* out, uint32_t* counts);
+/* Same with device-resident queries and outputs (d_out: nq*max_per_query cbh_match,
+ * d_counts: nq u32); *total_out (host) = total number of matching pairs. */
+int cbh_idx64_find_batch_dev(cbh_idx64*, const void* d_q, size_t nq, int thresh,
+                             int max_per_query, void* d_out, void* d_counts,
+                             uint64_t* total_out, void* stream);
+/* Raw scan stage only (the Hamming kernel): appends one cbh_record per matching pair to
+ * d_records (capacity cap records, unordered) and adds the number of matching pairs to
+ * *d_total (u64 on device, NOT reset by the call).  Records beyond cap are dropped but still
+ * counted.  Asynchronous on `stream`.  This is the shard-local step of the multi-GPU path. */
+int cbh_idx64_scan_dev(cbh_idx64*, const void* d_q, size_t nq, int thresh, void* d_records,
+                       size_t cap, void* d_total, void* stream);
+/* Sort records ascending in place (device), n records, only bits [0, 39+ceil(log2(nq))). */
+int cbh_sort_records_dev(void* d_records, size_t n, size_t nq, int device, void* stream);
+/* Records (sorted) -> per-query top max_per_query + counts, as find_batch_dev does. */
+int cbh_select_records_dev(const void* d_sorted_records, size_t n, size_t nq, int max_per_query,
+                           void* d_out, void* d_counts, int device, void* stream);
+/* capacity (records) of the internal match buffer used by find/find_batch; default 1<<24 */
+int cbh_idx64_set_record_capacity(cbh_idx64*, size_t records);
+
+/* ---- measurement support ---------------------------------------------------------------- */
+/* Run the scan kernel `iters` times on the index's own stream bracketed by hipEvents and
+ * return the average kernel time in milliseconds (bench.py roofline leg).  */
+int cbh_idx64_time_scan_dev(cbh_idx64*, const void* d_q, size_t nq, int thresh, void* d_records,
+                            size_t cap, void* d_total, int iters, float* ms_avg);
+int cbh_time_dcthash_dev(const void* d_imgs, size_t n, int w, int h, size_t row_stride,
+                         size_t img_stride, void* d_out, int device, int iters, float* ms_avg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CBIRD_HIP_H */

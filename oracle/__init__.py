@@ -1,0 +1,243 @@
+"""oracle -- TEST INFRASTRUCTURE ONLY (parity checker for the HIP path).
+
+ctypes bindings for
+  * ``libcbird_oracle.so``  -- the plain-C restatement in ``oracle/cbird_oracle.c``
+  * ``_ref/libcbird_ref.so`` -- the real reference VP-tree/hamm64 compiled in place from
+    ``/root/reference`` by ``oracle/Makefile`` (present when it was built in the build
+    container; it travels to the GPU box as a prebuilt file).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package.  Nothing under ``cbird_amd/`` does (tests/test_boundary.py enforces it).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_SO = os.path.join(_HERE, "libcbird_oracle.so")
+_REF_SO = os.path.join(_HERE, "_ref", "libcbird_ref.so")
+
+_u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+
+
+def build(force: bool = False) -> None:
+    """Compile the C restatement (and, when /root/reference exists, oracle/_ref)."""
+    need = force or not os.path.exists(_ORACLE_SO) or (
+        os.path.getmtime(_ORACLE_SO) < os.path.getmtime(os.path.join(_HERE, "cbird_oracle.c")))
+    need_ref = os.path.isdir("/root/reference/src/tree") and (
+        force or not os.path.exists(_REF_SO)
+        or os.path.getmtime(_REF_SO) < os.path.getmtime(os.path.join(_HERE, "ref_wrap.cpp")))
+    if need:
+        subprocess.check_call(["make", "-C", _HERE, "libcbird_oracle.so", "-B"],
+                              stdout=subprocess.DEVNULL)
+    if need_ref:
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+class Oracle:
+    """Plain-C restatement (kind "port")."""
+
+    def __init__(self) -> None:
+        build()
+        L = C.CDLL(_ORACLE_SO)
+        self.L = L
+        L.orc_hamm64.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_hamm64.restype = C.c_int
+        for name in ("orc_scan64", "orc_find64"):
+            f = getattr(L, name)
+            f.argtypes = [_u64p, _u32p, C.c_size_t, C.c_uint64, C.c_int, _u32p, _i32p, C.c_size_t]
+            f.restype = C.c_longlong
+        L.orc_find64_batch.argtypes = [_u64p, _u32p, C.c_size_t, _u64p, C.c_size_t, C.c_int,
+                                       C.c_int, _u32p, _i32p, _u32p]
+        L.orc_find64_batch.restype = None
+        L.orc_count64_pairs.argtypes = [_u64p, _u32p, C.c_size_t, _u64p, C.c_size_t, C.c_int]
+        L.orc_count64_pairs.restype = C.c_longlong
+        L.orc_zigzag81.argtypes = [_i32p]
+        L.orc_dct9_table.argtypes = [_f32p]
+        L.orc_blur_ksize.argtypes = [C.c_int, C.c_int]
+        L.orc_blur_ksize.restype = C.c_int
+        L.orc_dcthash64.argtypes = [_u8p, C.c_int, C.c_int, C.c_size_t, _u64p]
+        L.orc_dcthash64.restype = C.c_int
+        L.orc_dcthash_tile32.argtypes = [_u8p, C.c_int, C.c_int, C.c_size_t, _u8p]
+        L.orc_dcthash_tile32.restype = C.c_int
+        L.orc_dcthash64_batch.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_int, C.c_size_t,
+                                          C.c_size_t, _u64p]
+        L.orc_dcthash64_batch.restype = C.c_int
+        L.orc_hash_from_tile32.argtypes = [_u8p, C.c_void_p, C.c_void_p]
+        L.orc_hash_from_tile32.restype = C.c_uint64
+        for name in ("orc_box_blur", "orc_box_blur_direct"):
+            f = getattr(L, name)
+            f.argtypes = [_u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, _u8p]
+            f.restype = None
+
+    # -- search -------------------------------------------------------------------------
+    def hamm64(self, a: int, b: int) -> int:
+        return self.L.orc_hamm64(a, b)
+
+    def _run(self, fn, hashes, ids, target, thresh):
+        hashes = np.ascontiguousarray(hashes, np.uint64)
+        ids = np.ascontiguousarray(ids, np.uint32)
+        cap = max(1, len(hashes))
+        oi = np.zeros(cap, np.uint32)
+        od = np.zeros(cap, np.int32)
+        m = fn(hashes, ids, len(hashes), int(target), int(thresh), oi, od, cap)
+        return oi[:m].copy(), od[:m].copy()
+
+    def scan64(self, hashes, ids, target, thresh):
+        """matches in haystack order: (ids, dists)"""
+        return self._run(self.L.orc_scan64, hashes, ids, target, thresh)
+
+    def find64(self, hashes, ids, target, thresh):
+        """matches in (score, mediaId) order: (ids, dists)"""
+        return self._run(self.L.orc_find64, hashes, ids, target, thresh)
+
+    def find64_batch(self, hashes, ids, queries, thresh, k):
+        hashes = np.ascontiguousarray(hashes, np.uint64)
+        ids = np.ascontiguousarray(ids, np.uint32)
+        queries = np.ascontiguousarray(queries, np.uint64)
+        nq = len(queries)
+        oi = np.zeros((nq, k), np.uint32)
+        od = np.zeros((nq, k), np.int32)
+        cnt = np.zeros(nq, np.uint32)
+        self.L.orc_find64_batch(hashes, ids, len(hashes), queries, nq, int(thresh), int(k),
+                                oi.reshape(-1), od.reshape(-1), cnt)
+        return oi, od, cnt
+
+    def count64_pairs(self, hashes, ids, queries, thresh) -> int:
+        hashes = np.ascontiguousarray(hashes, np.uint64)
+        ids = np.ascontiguousarray(ids, np.uint32)
+        queries = np.ascontiguousarray(queries, np.uint64)
+        return int(self.L.orc_count64_pairs(hashes, ids, len(hashes), queries, len(queries),
+                                            int(thresh)))
+
+    # -- hashing ------------------------------------------------------------------------
+    def zigzag81(self):
+        z = np.zeros(81, np.int32)
+        self.L.orc_zigzag81(z)
+        return z
+
+    def dct9_table(self):
+        t = np.zeros(9 * 32, np.float32)
+        self.L.orc_dct9_table(t)
+        return t.reshape(9, 32)
+
+    def blur_ksize(self, w, h):
+        return self.L.orc_blur_ksize(w, h)
+
+    def box_blur(self, img, k, direct=False):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.zeros_like(img)
+        (self.L.orc_box_blur_direct if direct else self.L.orc_box_blur)(img, w, h, w, k, out)
+        return out
+
+    def tile32(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        t = np.zeros((32, 32), np.uint8)
+        rc = self.L.orc_dcthash_tile32(img, w, h, w, t.reshape(-1))
+        if rc:
+            raise ValueError(f"orc_dcthash_tile32 rc={rc}")
+        return t
+
+    def hash_from_tile32(self, tile, with_coefs=False):
+        tile = np.ascontiguousarray(tile, np.uint8).reshape(-1)
+        if not with_coefs:
+            return int(self.L.orc_hash_from_tile32(tile, None, None))
+        co = np.zeros(64, np.float32)
+        th = np.zeros(1, np.float32)
+        hv = self.L.orc_hash_from_tile32(tile, co.ctypes.data, th.ctypes.data)
+        return int(hv), co, float(th[0])
+
+    def dcthash64(self, img) -> int:
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        o = np.zeros(1, np.uint64)
+        rc = self.L.orc_dcthash64(img, w, h, w, o)
+        if rc:
+            raise ValueError(f"orc_dcthash64 rc={rc}")
+        return int(o[0])
+
+    def dcthash64_batch(self, imgs):
+        imgs = np.ascontiguousarray(imgs, np.uint8)
+        n, h, w = imgs.shape
+        o = np.zeros(n, np.uint64)
+        rc = self.L.orc_dcthash64_batch(imgs.reshape(-1), n, w, h, w, w * h, o)
+        if rc:
+            raise ValueError(f"orc_dcthash64_batch rc={rc}")
+        return o
+
+
+def ref_available() -> bool:
+    if not os.path.exists(_REF_SO) and os.path.isdir("/root/reference/src/tree"):
+        build()
+    return os.path.exists(_REF_SO)
+
+
+class RefTree:
+    """The real reference VP-tree (kind "reference"); see oracle/ref_wrap.cpp."""
+
+    _L = None
+
+    @classmethod
+    def lib(cls):
+        if cls._L is None:
+            if not ref_available():
+                raise FileNotFoundError(_REF_SO)
+            L = C.CDLL(_REF_SO)
+            L.ref_hamm64.argtypes = [C.c_uint64, C.c_uint64]
+            L.ref_hamm64.restype = C.c_int
+            L.ref_dcttree_create.argtypes = [_u64p, _u32p, C.c_int]
+            L.ref_dcttree_create.restype = C.c_void_p
+            L.ref_dcttree_destroy.argtypes = [C.c_void_p]
+            L.ref_dcttree_search.argtypes = [C.c_void_p, C.c_uint64, C.c_int, _u32p, _i32p, C.c_int]
+            L.ref_dcttree_search.restype = C.c_int
+            L.ref_dcttree_search_many.argtypes = [C.c_void_p, _u64p, C.c_int, C.c_int, C.c_int,
+                                                  C.c_void_p]
+            L.ref_dcttree_search_many.restype = C.c_longlong
+            cls._L = L
+        return cls._L
+
+    def __init__(self, hashes, ids) -> None:
+        L = self.lib()
+        self.hashes = np.ascontiguousarray(hashes, np.uint64)
+        self.ids = np.ascontiguousarray(ids, np.uint32)
+        self.n = len(self.hashes)
+        self.h = L.ref_dcttree_create(self.hashes, self.ids, self.n)
+
+    def search(self, target, thresh):
+        """DctTree::search: (ids, dists) ascending by distance (tie order = heap order)."""
+        if not self.h:
+            return np.zeros(0, np.uint32), np.zeros(0, np.int32)
+        cap = max(1, self.n)
+        oi = np.zeros(cap, np.uint32)
+        od = np.zeros(cap, np.int32)
+        m = self.lib().ref_dcttree_search(self.h, int(target), int(thresh), oi, od, cap)
+        return oi[:m].copy(), od[:m].copy()
+
+    def search_many(self, needles, thresh, threads=1, want_counts=False):
+        needles = np.ascontiguousarray(needles, np.uint64)
+        cnt = np.zeros(len(needles), np.uint32) if want_counts else None
+        tot = self.lib().ref_dcttree_search_many(
+            self.h, needles, len(needles), int(thresh), int(threads),
+            cnt.ctypes.data if cnt is not None else None)
+        return (int(tot), cnt) if want_counts else int(tot)
+
+    def close(self):
+        if self.h:
+            self.lib().ref_dcttree_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,365 @@
+/* oracle/cbird_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of cbird's hash-build + Hamming-find hot path.  It is the
+ * parity checker for the HIP kernels: only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it.  The product (cbird_amd/, libcbird_hip.so)
+ * never links, imports or falls back to anything in oracle/.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - search semantics (orc_scan64*, orc_hamm64): PINNED against the real reference
+ *     VP-tree compiled in place (oracle/_ref, tests/test_oracle_ref.py) and against the
+ *     committed golden vectors generated from it (tests/golden/vptree_*.json).
+ *   - orc_dcthash64: "PARITY UNPINNED" versus the cbird binary.  The arithmetic below
+ *     the call sites (cv::blur, cv::resize, cv::dct, cv::sum) lives in OpenCV 2.4.13.7
+ *     (pinned by cbird.pri:148-152) which is not vendored in /root/reference and not
+ *     installed here, and no reference test pins a hash value (unit/testcvutil.cpp:354
+ *     has the check commented out).  Integer stages follow OpenCV 2.4 semantics as
+ *     recalled in SURVEY.md section 8(a1); the DCT stage is the canonical separable
+ *     f32 form defined in DESIGN.md (fixed fmaf order), which the GPU reproduces
+ *     bit-for-bit.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -mfma -mpopcnt).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_OK 0
+#define ORC_E_UNSUPPORTED (-2)
+#define ORC_E_INVAL (-1)
+
+/* ---- hamm64: src/hamm.h:24-26 ------------------------------------------------------ */
+int orc_hamm64(uint64_t a, uint64_t b) { return __builtin_popcountll(a ^ b); }
+
+/* ---- brute-force threshold scan: the semantics of DctHashIndex::find ---------------
+ * src/dcthashindex.cpp:193-220.  The live code path is the exact VP-tree
+ * (`_tree->search(target, p.dctThresh)`, :208); the compiled-out loop at :210-217 states
+ * the same predicate directly: every entry i with hamm64(target, hash[i]) < thresh,
+ * skipping mediaId 0 (slots nulled by remove(), :183-187).  target == 0 -> no results
+ * (:196-200).  Output here is in haystack order; orc_find64 below sorts it.
+ * Returns the full match count, writes at most cap entries. */
+long long orc_scan64(const uint64_t* hashes, const uint32_t* ids, size_t n, uint64_t target,
+                     int thresh, uint32_t* out_ids, int32_t* out_dist, size_t cap) {
+  long long m = 0;
+  if (target == 0) return 0;
+  for (size_t i = 0; i < n; ++i) {
+    int d = __builtin_popcountll(target ^ hashes[i]);
+    if (d < thresh) {
+      uint32_t id = ids[i];
+      if (id != 0) {
+        if ((size_t)m < cap) {
+          out_ids[m] = id;
+          out_dist[m] = d;
+        }
+        ++m;
+      }
+    }
+  }
+  return m;
+}
+
+typedef struct {
+  int32_t dist;
+  uint32_t id;
+} orc_pair;
+
+static int cmp_pair(const void* a, const void* b) {
+  const orc_pair* x = (const orc_pair*)a;
+  const orc_pair* y = (const orc_pair*)b;
+  if (x->dist != y->dist) return x->dist < y->dist ? -1 : 1;
+  if (x->id != y->id) return x->id < y->id ? -1 : 1;
+  return 0;
+}
+
+/* find = scan + total order (score, mediaId).  The reference returns ascending distance
+ * with heap-order ties (vptree.h:50-69) and searchIndex re-sorts by score with an
+ * unstable std::sort (database.cpp:1729, index.h:284), so tie order is unspecified
+ * there; the build fixes it to (score, mediaId) -- SURVEY.md section 7 hard part 2. */
+long long orc_find64(const uint64_t* hashes, const uint32_t* ids, size_t n, uint64_t target,
+                     int thresh, uint32_t* out_ids, int32_t* out_dist, size_t cap) {
+  long long m = orc_scan64(hashes, ids, n, target, thresh, NULL, NULL, 0);
+  if (m <= 0) return m;
+  uint32_t* tid = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)m);
+  int32_t* td = (int32_t*)malloc(sizeof(int32_t) * (size_t)m);
+  orc_pair* p = (orc_pair*)malloc(sizeof(orc_pair) * (size_t)m);
+  orc_scan64(hashes, ids, n, target, thresh, tid, td, (size_t)m);
+  for (long long i = 0; i < m; ++i) {
+    p[i].dist = td[i];
+    p[i].id = tid[i];
+  }
+  qsort(p, (size_t)m, sizeof(orc_pair), cmp_pair);
+  for (long long i = 0; i < m && (size_t)i < cap; ++i) {
+    out_ids[i] = p[i].id;
+    out_dist[i] = p[i].dist;
+  }
+  free(p);
+  free(tid);
+  free(td);
+  return m;
+}
+
+/* Batched find with a per-query cap: for each query the first min(count, k) matches in
+ * (score, mediaId) order go to out_*[q*k ..], counts[q] = full count.  This is the
+ * reference's find() followed by the sort + truncate of Database::searchIndex
+ * (database.cpp:1729-1735) without the self filter. */
+void orc_find64_batch(const uint64_t* hashes, const uint32_t* ids, size_t n, const uint64_t* q,
+                      size_t nq, int thresh, int k, uint32_t* out_ids, int32_t* out_dist,
+                      uint32_t* counts) {
+  size_t cap = n ? n : 1;
+  uint32_t* tid = (uint32_t*)malloc(sizeof(uint32_t) * cap);
+  int32_t* td = (int32_t*)malloc(sizeof(int32_t) * cap);
+  for (size_t i = 0; i < nq; ++i) {
+    long long m = orc_find64(hashes, ids, n, q[i], thresh, tid, td, cap);
+    counts[i] = (uint32_t)m;
+    for (int j = 0; j < k; ++j) {
+      if (j < m) {
+        out_ids[i * (size_t)k + j] = tid[j];
+        out_dist[i * (size_t)k + j] = td[j];
+      } else {
+        out_ids[i * (size_t)k + j] = 0;
+        out_dist[i * (size_t)k + j] = 0;
+      }
+    }
+  }
+  free(tid);
+  free(td);
+}
+
+/* Count-only all-pairs brute force (used for CPU "port" baseline timing and for
+ * full-size property checks).  Returns sum over queries of match counts. */
+long long orc_count64_pairs(const uint64_t* hashes, const uint32_t* ids, size_t n,
+                            const uint64_t* q, size_t nq, int thresh) {
+  long long total = 0;
+  for (size_t j = 0; j < nq; ++j) {
+    uint64_t t = q[j];
+    if (t == 0) continue;
+    for (size_t i = 0; i < n; ++i) {
+      int d = __builtin_popcountll(t ^ hashes[i]);
+      total += (d < thresh) & (ids[i] != 0);
+    }
+  }
+  return total;
+}
+
+/* ---- dctHash64: src/cvutil.cpp:435-545 --------------------------------------------- */
+
+/* cv::borderInterpolate(p, len, BORDER_REFLECT_101) (OpenCV 2.4 imgproc/filter.cpp). */
+static int reflect101(int p, int len) {
+  if ((unsigned)p < (unsigned)len) return p;
+  if (len == 1) return 0;
+  do {
+    if (p < 0)
+      p = -p;
+    else
+      p = 2 * (len - 1) - p;
+  } while ((unsigned)p >= (unsigned)len);
+  return p;
+}
+
+/* zig-zag order of the 9x9 low-frequency block, first step downwards; equals the
+ * zigZag[81] table at cvutil.cpp:491-495 (checked in tests/test_oracle.py against the
+ * (row,col) list in SURVEY.md 8(a1)). out[i] = row*9+col */
+void orc_zigzag81(int* out) {
+  int k = 0;
+  for (int s = 0; s <= 16; ++s) {
+    if (s & 1) {
+      for (int r = (s < 8 ? s : 8); r >= 0 && s - r <= 8; --r) out[k++] = r * 9 + (s - r);
+    } else {
+      for (int r = (s > 8 ? s - 8 : 0); r <= 8 && r <= s; ++r) out[k++] = r * 9 + (s - r);
+    }
+  }
+}
+
+/* Orthonormal DCT-II basis rows 0..8 for N=32, evaluated in double and rounded once to
+ * f32: C[k][j] = sqrt((k?2:1)/32) * cos(pi*(2j+1)*k/64).  (cv::dct computes the same
+ * transform through a factorised float algorithm whose rounding cannot be reproduced
+ * without its source: "parity unpinned".) */
+void orc_dct9_table(float* c /* [9*32] */) {
+  for (int k = 0; k < 9; ++k)
+    for (int j = 0; j < 32; ++j) {
+      double a = sqrt((k ? 2.0 : 1.0) / 32.0);
+      c[k * 32 + j] = (float)(a * cos(M_PI * (2 * j + 1) * k / 64.0));
+    }
+}
+
+/* kernel size rule, cvutil.cpp:446-455 */
+int orc_blur_ksize(int w, int h) {
+  long long area = (long long)w * h;
+  if (area <= 32 * 32) return 0;
+  if (area <= 64 * 64) return 3;
+  if (area <= 128 * 128) return 5;
+  return 7;
+}
+
+/* cv::blur(src, dst, Size(k,k)) on 8UC1: normalised box filter, centre anchor,
+ * BORDER_REFLECT_101, integer window sum then saturate_cast<uchar>(sum * (1.0/k^2))
+ * (double scale, cvRound).  k is odd so sum/k^2 never hits .5 -> plain nearest. */
+static void box_blur_u8(const uint8_t* src, int w, int h, size_t stride, int k, uint8_t* dst) {
+  /* separable (row sums, then sliding column sums) like OpenCV's RowSum/ColumnSum pair;
+   * pure integer, so the result equals the direct k*k window sum */
+  int r = k / 2;
+  int area = k * k;
+  uint16_t* rs = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)w * (size_t)h);
+  int* xi = (int*)malloc(sizeof(int) * (size_t)(w + 2 * r));
+  for (int x = -r; x < w + r; ++x) xi[x + r] = reflect101(x, w);
+  for (int y = 0; y < h; ++y) {
+    const uint8_t* row = src + (size_t)y * stride;
+    uint16_t* o = rs + (size_t)y * w;
+    int s = 0;
+    for (int t = 0; t < k; ++t) s += row[xi[t]];
+    o[0] = (uint16_t)s;
+    for (int x = 1; x < w; ++x) {
+      s += row[xi[x + k - 1]] - row[xi[x - 1]];
+      o[x] = (uint16_t)s;
+    }
+  }
+  int* cs = (int*)calloc((size_t)w, sizeof(int));
+  for (int dy = -r; dy <= r; ++dy) {
+    const uint16_t* o = rs + (size_t)reflect101(dy, h) * w;
+    for (int x = 0; x < w; ++x) cs[x] += o[x];
+  }
+  for (int y = 0; y < h; ++y) {
+    uint8_t* d = dst + (size_t)y * w;
+    for (int x = 0; x < w; ++x) d[x] = (uint8_t)((2 * cs[x] + area) / (2 * area));
+    if (y + 1 < h) {
+      const uint16_t* add = rs + (size_t)reflect101(y + 1 + r, h) * w;
+      const uint16_t* sub = rs + (size_t)reflect101(y - r, h) * w;
+      for (int x = 0; x < w; ++x) cs[x] += add[x] - sub[x];
+    }
+  }
+  free(cs);
+  free(xi);
+  free(rs);
+}
+
+/* direct k*k window form, kept as an independent cross-check of the separable version
+ * (tests/test_oracle.py) */
+void orc_box_blur_direct(const uint8_t* src, int w, int h, size_t stride, int k, uint8_t* dst) {
+  int r = k / 2;
+  int area = k * k;
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      int s = 0;
+      for (int dy = -r; dy <= r; ++dy) {
+        const uint8_t* row = src + (size_t)reflect101(y + dy, h) * stride;
+        for (int dx = -r; dx <= r; ++dx) s += row[reflect101(x + dx, w)];
+      }
+      dst[(size_t)y * w + x] = (uint8_t)((2 * s + area) / (2 * area));
+    }
+}
+
+void orc_box_blur(const uint8_t* src, int w, int h, size_t stride, int k, uint8_t* dst) {
+  box_blur_u8(src, w, h, stride, k, dst);
+}
+
+/* cv::resize(src, dst, Size(32,32), 0, 0, INTER_AREA), integer-ratio ("area fast") path:
+ * 2x2 -> (a+b+c+d+2)>>2; otherwise saturate_cast<uchar>(sum * (1.f/area)) in float with
+ * cvRound (nearest-even). */
+static int area_resize32_u8(const uint8_t* src, int w, int h, uint8_t* dst /*32*32*/) {
+  if (w == 32 && h == 32) {
+    memcpy(dst, src, 1024);
+    return ORC_OK;
+  }
+  if (w < 32 || h < 32 || (w % 32) || (h % 32)) return ORC_E_UNSUPPORTED;
+  int sx = w / 32, sy = h / 32;
+  float scale = 1.f / (float)(sx * sy);
+  for (int y = 0; y < 32; ++y)
+    for (int x = 0; x < 32; ++x) {
+      int s = 0;
+      for (int dy = 0; dy < sy; ++dy)
+        for (int dx = 0; dx < sx; ++dx) s += src[(size_t)(y * sy + dy) * w + (x * sx + dx)];
+      int v;
+      if (sx == 2 && sy == 2)
+        v = (s + 2) >> 2;
+      else
+        v = (int)lrintf((float)s * scale); /* default rounding mode = nearest-even */
+      dst[y * 32 + x] = (uint8_t)(v > 255 ? 255 : v);
+    }
+  return ORC_OK;
+}
+
+/* Stages 3-6 on a 32x32 u8 tile: canonical separable 9x32 DCT with fixed fmaf order,
+ * zig-zag select 64, mean threshold (double sum -> float, /64), bits 1..63, 0 -> 1.
+ * cvutil.cpp:475-545. Also returns the 64 selected coefficients and threshold when
+ * coefs != NULL (for at-risk-bit statistics). */
+uint64_t orc_hash_from_tile32(const uint8_t* tile, float* coefs /*64 or NULL*/, float* thr_out) {
+  static float C[9 * 32];
+  static int zz[81];
+  static int init = 0;
+  if (!init) {
+    orc_dct9_table(C);
+    orc_zigzag81(zz);
+    init = 1;
+  }
+  float T[32][9]; /* row pass: T[r][k] = sum_j X[r][j] * C[k][j], j ascending */
+  for (int r = 0; r < 32; ++r)
+    for (int k = 0; k < 9; ++k) {
+      float acc = 0.f;
+      for (int j = 0; j < 32; ++j) acc = fmaf((float)tile[r * 32 + j], C[k * 32 + j], acc);
+      T[r][k] = acc;
+    }
+  float Y[81]; /* col pass: Y[u][k] = sum_r C[u][r] * T[r][k], r ascending */
+  for (int u = 0; u < 9; ++u)
+    for (int k = 0; k < 9; ++k) {
+      float acc = 0.f;
+      for (int r = 0; r < 32; ++r) acc = fmaf(C[u * 32 + r], T[r][k], acc);
+      Y[u * 9 + k] = acc;
+    }
+  float sel[64];
+  double sum = 0.0;
+  for (int i = 0; i < 64; ++i) {
+    sel[i] = Y[zz[6 + i]];
+    sum += (double)sel[i];
+  }
+  float thresh = (float)sum / 64;
+  uint64_t hash = 0;
+  for (int i = 1; i < 64; ++i)
+    if (sel[i] > thresh) hash |= 1ULL << i;
+  if (hash == 0) hash = 1;
+  if (coefs) memcpy(coefs, sel, sizeof(sel));
+  if (thr_out) *thr_out = thresh;
+  return hash;
+}
+
+/* Full pipeline for one 8UC1 image.  Returns ORC_OK / ORC_E_*; hash in *out. */
+int orc_dcthash64(const uint8_t* img, int w, int h, size_t stride, uint64_t* out) {
+  if (!img || w <= 0 || h <= 0 || stride < (size_t)w) return ORC_E_INVAL;
+  if (!((w == 32 && h == 32) || (w >= 32 && h >= 32 && w % 32 == 0 && h % 32 == 0)))
+    return ORC_E_UNSUPPORTED;
+  int k = orc_blur_ksize(w, h);
+  uint8_t* blur = (uint8_t*)malloc((size_t)w * h);
+  if (k)
+    box_blur_u8(img, w, h, stride, k, blur);
+  else
+    for (int y = 0; y < h; ++y) memcpy(blur + (size_t)y * w, img + (size_t)y * stride, (size_t)w);
+  uint8_t tile[1024];
+  int rc = area_resize32_u8(blur, w, h, tile);
+  free(blur);
+  if (rc != ORC_OK) return rc;
+  *out = orc_hash_from_tile32(tile, NULL, NULL);
+  return ORC_OK;
+}
+
+/* exposes the intermediate 32x32 tile (blur + area resize) for stage-level tests */
+int orc_dcthash_tile32(const uint8_t* img, int w, int h, size_t stride, uint8_t* tile) {
+  if (!img || w <= 0 || h <= 0 || stride < (size_t)w) return ORC_E_INVAL;
+  int k = orc_blur_ksize(w, h);
+  uint8_t* blur = (uint8_t*)malloc((size_t)w * h);
+  if (k)
+    box_blur_u8(img, w, h, stride, k, blur);
+  else
+    for (int y = 0; y < h; ++y) memcpy(blur + (size_t)y * w, img + (size_t)y * stride, (size_t)w);
+  int rc = area_resize32_u8(blur, w, h, tile);
+  free(blur);
+  return rc;
+}
+
+int orc_dcthash64_batch(const uint8_t* imgs, size_t n, int w, int h, size_t row_stride,
+                        size_t img_stride, uint64_t* out) {
+  for (size_t i = 0; i < n; ++i) {
+    int rc = orc_dcthash64(imgs + i * img_stride, w, h, row_stride, out + i);
+    if (rc != ORC_OK) return rc;
+  }
+  return ORC_OK;
+}
