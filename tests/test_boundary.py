@@ -1,0 +1,76 @@
+"""CPU suite: the C-ABI library loads and exports every symbol include/cbird_hip.h declares; the
+product never touches oracle/; without a device the compute entry points fail loudly."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from cbird_amd import _lib
+
+    L = _lib.lib()
+    names = _lib.header_symbols()
+    assert len(names) >= 25
+    for s in names:
+        assert hasattr(L, s), f"{s} declared in include/cbird_hip.h but not exported"
+    assert set(names) == set(_lib._SIGS), "python binding table out of sync with the header"
+    assert L.cbh_version() == 100
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (cbh_\w+)", out))
+    assert set(names) <= exported
+
+
+def test_error_strings():
+    from cbird_amd import _lib
+
+    L = _lib.lib()
+    assert L.cbh_strerror(0) == b"ok"
+    for code in range(-7, 0):
+        assert L.cbh_strerror(code) not in (b"", b"unknown error")
+
+
+def test_product_never_references_the_oracle():
+    pkg = os.path.join(ROOT, "cbird_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f
+                assert "libcbird_oracle" not in txt and "libcbird_ref" not in txt, f
+                assert "oracle/" not in txt.replace("oracle/cbird_oracle.c", "") or f.endswith(
+                    (".hip", ".h")), f
+    ldd = subprocess.check_output(["ldd", os.path.join(pkg, "libcbird_hip.so")], text=True)
+    assert "oracle" not in ldd and "cbird_ref" not in ldd
+
+
+def test_python_mirror_keeps_reference_defaults():
+    # src/index.h:74-121
+    from cbird_amd import SearchParams
+
+    p = SearchParams()
+    assert (p.algo, p.dctThresh, p.cvThresh, p.minMatches, p.maxMatches) == (0, 5, 25, 1, 5)
+    assert p.filterSelf is True and p.maxThresh == 0
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="only meaningful on a box without a GPU")
+def test_no_device_fails_loudly_no_fallback():
+    import cbird_amd
+    from cbird_amd import _lib
+
+    L = _lib.lib()
+    assert L.cbh_device_count() == 0
+    with pytest.raises(cbird_amd.CbhError) as e:
+        cbird_amd.DctHashIndex()
+    assert e.value.code == _lib.CBH_E_NODEVICE
+    with pytest.raises(cbird_amd.CbhError) as e:
+        cbird_amd.dct_hash64_batch(np.zeros((2, 32, 32), np.uint8))
+    assert e.value.code == _lib.CBH_E_NODEVICE
+    out = np.zeros(1, np.uint64)
+    rc = L.cbh_dcthash_batch_dev(None, 0, 32, 32, 32, 1024, out.ctypes.data, 0, None)
+    assert rc == _lib.CBH_E_NODEVICE

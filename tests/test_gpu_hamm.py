@@ -1,0 +1,242 @@
+"""GPU parity suite for the Hamming find path (k_hamm64_scan + record sort/select) through the
+C-ABI, against the oracle and the reference-generated golden vectors.  Bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import golden_cases, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _matches(ms):
+    return [(m.mediaId, m.score) for m in ms]
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_find_matches_reference_golden(gpu, name):
+    """DctHashIndex::find == the real VP-tree's answers (canonical (score,id) order)."""
+    g = load_golden(name)
+    idx = gpu.DctHashIndex()
+    idx.load(g["hashes"], g["ids"])
+    q = g["queries"]
+    for dht in range(1, 9):
+        offs, gid, gd = g[f"offs_{dht}"], g[f"ids_{dht}"], g[f"dist_{dht}"]
+        gi, gs, gc = idx.find_batch(q, dht, 16)
+        for j in range(len(q)):
+            a, b = int(offs[j]), int(offs[j + 1])
+            assert gc[j] == b - a, (name, dht, j)
+            m = min(16, b - a)
+            assert gi[j, :m].tolist() == gid[a:a + m].tolist(), (name, dht, j)
+            assert gs[j, :m].tolist() == gd[a:a + m].tolist(), (name, dht, j)
+            assert (gi[j, m:] == 0).all()
+    # the single-needle entry point, every needle of the small case at the default threshold
+    if name == "vptree_n4096.npz":
+        p = gpu.SearchParams()
+        offs, gid, gd = g["offs_5"], g["ids_5"], g["dist_5"]
+        for j, t in enumerate(q.tolist()):
+            if t == 0:
+                continue
+            got = _matches(idx.find(gpu.Media(id=0, dctHash=t), p))
+            a, b = int(offs[j]), int(offs[j + 1])
+            assert got == list(zip(gid[a:b].tolist(), gd[a:b].tolist()))
+
+
+@pytest.mark.parametrize("n,nq,seed", [(1, 1, 1), (7, 3, 2), (2047, 9, 3), (2048, 8, 4), (2049, 17, 5),
+                                       (10000, 1000, 6), (70001, 4099, 7)])
+def test_find_batch_vs_oracle_ragged_sizes(gpu, orc, n, nq, seed):
+    from cbird_amd import synth
+
+    h, ids = synth.make_hashes(n, seed=seed, planted_frac=0.2)
+    rng = np.random.default_rng(seed)
+    q = h[rng.integers(0, n, nq)].copy()
+    q[::5] ^= np.uint64(1) << np.uint64(17)
+    idx = gpu.DctHashIndex()
+    idx.load(h, ids)
+    for dht in (1, 2, 5, 6, 8, 13):
+        gi, gs, gc = idx.find_batch(q, dht, 6)
+        wi, ws, wc = orc.find64_batch(h, ids, q, dht, 6)
+        assert (gc == wc).all() and (gi == wi).all() and (gs == ws).all(), (n, nq, dht)
+
+
+def test_thresholds_full_range(gpu, orc):
+    """dht valid range is 0..65 (src/index.cpp:77); 65 matches everything, <=0 nothing."""
+    from cbird_amd import synth
+
+    h, ids = synth.make_hashes(3000, seed=21)
+    idx = gpu.DctHashIndex()
+    idx.load(h, ids)
+    q = h[:5]
+    for dht in (0, 1, 20, 33, 64, 65):
+        gi, gs, gc = idx.find_batch(q, dht, 4)
+        wi, ws, wc = orc.find64_batch(h, ids, q, dht, 4)
+        assert (gc == wc).all() and (gi == wi).all() and (gs == ws).all(), dht
+    assert (idx.find_batch(q, 65, 1)[2] == 3000).all()
+    m = idx.find(gpu.Media(dctHash=int(h[0])), gpu.SearchParams(dctThresh=65))
+    assert len(m) == 3000 and _matches(m) == list(zip(*[x.tolist() for x in orc.find64(h, ids, h[0], 65)]))
+
+
+def test_null_needle_empty_index_removed_slots(gpu, orc):
+    idx = gpu.DctHashIndex()
+    assert not idx.isLoaded() and idx.count() == 0 and idx.memoryUsage() == 0
+    idx.load([], [])
+    assert idx.isLoaded() and idx.count() == 0
+    with pytest.warns(UserWarning):
+        assert idx.find(gpu.Media(id=1, dctHash=2), gpu.SearchParams()) == []  # empty/null tree
+    idx2 = gpu.DctHashIndex()
+    h = np.array([0, 2, 6, 0], np.uint64)
+    ids = np.array([0, 7, 8, 9], np.uint32)
+    idx2.load(h, ids)
+    with pytest.warns(UserWarning):
+        assert idx2.find(gpu.Media(id=1, dctHash=0), gpu.SearchParams()) == []  # null needle
+    assert _matches(idx2.find(gpu.Media(dctHash=2), gpu.SearchParams(dctThresh=3))) == [(7, 0), (8, 1), (9, 1)]
+    gi, gs, gc = idx2.find_batch(np.array([0, 2], np.uint64), 3, 4)
+    assert gc.tolist() == [0, 3]
+    assert idx2.mediaIds() == {7, 8}  # hash != 0 only (dcthashindex.cpp:129-133)
+
+
+def test_add_remove_slice_like_testindexbase(gpu, orc):
+    """unit/testindexbase.cpp:148-218 (remove 3, verify gone, re-add, same results) and
+    unit/testdcthashindex.cpp:27-30 (memoryUsage == 12 B * count)."""
+    from cbird_amd import synth
+
+    h, ids = synth.make_hashes(5000, seed=31, planted_frac=0.3)
+    idx = gpu.DctHashIndex()
+    idx.load(h, ids)
+    assert idx.memoryUsage() == (8 + 4) * idx.count() == 12 * 5000
+    p = gpu.SearchParams(dctThresh=9)
+    # pick 3 items that have matches
+    _, _, cnt = idx.find_batch(h, 9, 1)
+    victims = [int(ids[i]) for i in np.nonzero(cnt > 1)[0][:3]]
+    before = {v: _matches(idx.find(gpu.Media(id=v, dctHash=int(h[v - 1])), p)) for v in victims}
+    idx.remove(victims)
+    assert idx.count() == 5000  # slots are nulled, not compacted
+    h2, ids2 = idx.download()
+    assert all(ids2[v - 1] == 0 and h2[v - 1] == 0 for v in victims)
+    for v in victims:
+        got = _matches(idx.find(gpu.Media(id=v, dctHash=int(h[v - 1])), p))
+        assert all(i not in victims for i, _ in got)
+        oi, od = orc.find64(h2, ids2, h[v - 1], 9)
+        assert got == list(zip(oi.tolist(), od.tolist()))
+    idx.add([gpu.Media(id=v, dctHash=int(h[v - 1])) for v in victims])
+    assert idx.count() == 5003 and idx.memoryUsage() == 12 * 5003
+    for v in victims:
+        assert _matches(idx.find(gpu.Media(id=v, dctHash=int(h[v - 1])), p)) == before[v]
+    # slice(): subset index, original order, caller-owned
+    want = set(int(x) for x in ids[100:400:3])
+    sub = idx.slice(want)
+    sh, si = sub.download()
+    keep = np.isin(ids2, list(want))
+    assert si.tolist() == ids2[keep].tolist() + [v for v in victims if v in want]
+    for t in h[100:130].tolist():
+        oi, od = orc.find64(sh, si, t, 9)
+        assert _matches(sub.find(gpu.Media(dctHash=t), p)) == list(zip(oi.tolist(), od.tolist()))
+
+
+def test_record_buffer_grows_instead_of_truncating(gpu, orc):
+    from cbird_amd import synth
+
+    h, ids = synth.make_hashes(6000, seed=41)
+    h[:] = h[0]  # every pair matches at distance 0: 6000*64 records for 64 needles
+    idx = gpu.DctHashIndex()
+    idx.load(h, ids)
+    idx.set_record_capacity(1000)
+    gi, gs, gc = idx.find_batch(h[:64], 1, 3)
+    assert (gc == 6000).all() and (gi == np.array([1, 2, 3], np.uint32)).all() and (gs == 0).all()
+    m = idx.find(gpu.Media(dctHash=int(h[0])), gpu.SearchParams(dctThresh=1))
+    assert [x.mediaId for x in m] == list(range(1, 6001))
+
+
+def test_raw_scan_records_and_concurrent_readers(gpu, orc):
+    """cbh_idx64_scan_dev record format + thread-safety of find() (QThreadPool readers)."""
+    import threading
+
+    import torch
+
+    from cbird_amd import _lib, synth
+
+    L = _lib.lib()
+    h, ids = synth.make_hashes(30000, seed=51, planted_frac=0.2)
+    idx = gpu.DctHashIndex()
+    idx.load(h, ids)
+    q = h[:3000]
+    dq = torch.from_numpy(q.view(np.int64)).cuda()
+    cap = 1 << 16
+    drec = torch.zeros(cap, dtype=torch.int64, device="cuda")
+    dtot = torch.zeros(1, dtype=torch.int64, device="cuda")
+    _lib.check(L.cbh_idx64_scan_dev(idx.handle, dq.data_ptr(), len(q), 7, drec.data_ptr(), cap,
+                                    dtot.data_ptr(), None), "scan")
+    tot = int(dtot.item())
+    rec = drec[:tot].cpu().numpy().view(np.uint64)
+    got = sorted((int(r >> 39), int((r >> 32) & 0x7F), int(r & 0xFFFFFFFF)) for r in rec.tolist())
+    want = []
+    for j, t in enumerate(q.tolist()):
+        oi, od = orc.find64(h, ids, t, 7)
+        want += [(j, int(d), int(i)) for i, d in zip(oi, od)]
+    assert got == sorted(want)
+
+    p = gpu.SearchParams(dctThresh=7)
+    errs = []
+
+    def worker(lo, hi):
+        try:
+            for j in range(lo, hi):
+                m = _matches(idx.find(gpu.Media(dctHash=int(q[j])), p))
+                oi, od = orc.find64(h, ids, q[j], 7)
+                if m != list(zip(oi.tolist(), od.tolist())):
+                    errs.append(j)
+        except Exception as e:  # pragma: no cover
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(k * 40, k * 40 + 40)) for k in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs
+
+
+def test_all_pairs_full_size_properties(gpu, orc):
+    """BASELINE config 2 size (1M x 1M): properties that do not need a CPU all-pairs run --
+    (i) every non-null needle that is in the index finds itself at distance 0, so counts >= 1;
+    (ii) the pair relation is symmetric: sum of counts == number of records, and the multiset of
+         (needle,match) pairs is closed under swapping (checked through an order-free checksum);
+    (iii) raising the threshold only adds matches; (iv) a 2k-needle sample equals the oracle."""
+    import torch
+
+    from cbird_amd import _lib, synth
+
+    L = _lib.lib()
+    n = 1_000_000
+    h, ids = synth.make_hashes(n, seed=1234)
+    idx = gpu.DctHashIndex()
+    idx.load(h, ids)
+    dq = torch.from_numpy(h.view(np.int64)).cuda()
+    k = 4
+    dout = torch.empty((n, k, 2), dtype=torch.int32, device="cuda")
+    dcnt = torch.empty(n, dtype=torch.int32, device="cuda")
+    prev = None
+    for dht in (2, 5):
+        tot = C.c_uint64(0)
+        _lib.check(L.cbh_idx64_find_batch_dev(idx.handle, dq.data_ptr(), n, dht, k, dout.data_ptr(),
+                                              dcnt.data_ptr(), C.byref(tot), None), "find_batch_dev")
+        cnt = dcnt.cpu().numpy().astype(np.int64)
+        out = dout.cpu().numpy()
+        assert cnt.min() >= 1 and cnt.sum() == tot.value
+        assert (out[:, 0, 1] == 0).all()  # best match is at distance 0 (itself or an exact duplicate)
+        # symmetry checksum over the pairs that fit in k slots for needles with count <= k
+        small = cnt <= k
+        a = np.repeat(np.arange(1, n + 1, dtype=np.uint64)[small], cnt[small])
+        mask = (np.arange(k)[None, :] < cnt[small][:, None])
+        b = out[small][:, :, 0].astype(np.uint64)[mask]
+        assert len(a) == len(b)
+        big_ids = set((np.nonzero(~small)[0] + 1).tolist())
+        keep = np.array([x not in big_ids for x in b.tolist()]) if big_ids else np.ones(len(b), bool)
+        f = lambda x, y: int(((x * np.uint64(0x9E3779B97F4A7C15)) ^ (y * np.uint64(0xC2B2AE3D27D4EB4F))).sum())
+        assert f(a[keep], b[keep]) == f(b[keep], a[keep])
+        if prev is not None:
+            assert (cnt >= prev).all()
+        prev = cnt
+        sample = np.random.default_rng(dht).choice(n, 2000, replace=False)
+        wi, ws, wc = orc.find64_batch(h, ids, h[sample], dht, k)
+        assert (cnt[sample] == wc).all()
+        assert (out[sample][:, :, 0].astype(np.uint32) == wi).all() and (out[sample][:, :, 1] == ws).all()

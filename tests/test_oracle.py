@@ -1,0 +1,201 @@
+"""CPU suite: pins the oracle (oracle/cbird_oracle.c) before anything is compared against it.
+
+ * search semantics against golden vectors produced by the real reference VP-tree
+   (tests/golden/gen_golden.py) and, when oracle/_ref is present, against the tree itself;
+ * hash pipeline: closed-form known-answer tests derived from the definition of the transform
+   (single DCT basis image -> exactly one hash bit), stage-level cross-checks, and the structural
+   facts the reference source states (zig-zag table, bit 0, kernel-size rule).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_cases, load_golden
+
+# (row, col) of the coefficient behind hash bit i, as listed in SURVEY.md 8(a1) from the
+# reference's zigZag table (src/cvutil.cpp:491-495, positions 6..69)
+BIT_RC_HEAD = {0: (3, 0), 1: (2, 1), 2: (1, 2), 3: (0, 3), 4: (0, 4), 5: (1, 3), 6: (2, 2),
+               7: (3, 1), 8: (4, 0), 9: (5, 0), 63: (7, 5)}
+# the reference's table itself, for the structural check only (81 small integers are data)
+ZIGZAG_REF = [0, 9, 1, 2, 10, 18, 27, 19, 11, 3, 4, 12, 20, 28, 36, 45, 37, 29, 21, 13, 5, 6, 14, 22,
+              30, 38, 46, 54, 63, 55, 47, 39, 31, 23, 15, 7, 8, 16, 24, 32, 40, 48, 56, 64, 72, 73, 65,
+              57, 49, 41, 33, 25, 17, 26, 34, 42, 50, 58, 66, 74, 75, 67, 59, 51, 43, 35, 44, 52, 60,
+              68, 76, 77, 69, 61, 53, 62, 70, 78, 79, 71, 80]
+
+
+def test_hamm64(orc):
+    assert orc.hamm64(0, 0) == 0
+    assert orc.hamm64(0, 2**64 - 1) == 64
+    assert orc.hamm64(0xF0F0, 0x0F0F) == 16
+    rng = np.random.default_rng(0)
+    for a, b in rng.integers(0, 2**63, (100, 2)).tolist():
+        assert orc.hamm64(a, b) == bin(a ^ b).count("1")
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_scan_matches_reference_golden(orc, name):
+    g = load_golden(name)
+    h, ids, q = g["hashes"], g["ids"], g["queries"]
+    for dht in range(1, 9):
+        offs, gid, gd = g[f"offs_{dht}"], g[f"ids_{dht}"], g[f"dist_{dht}"]
+        for j, t in enumerate(q.tolist()):
+            i, d = orc.find64(h, ids, t, dht)
+            a, b = offs[j], offs[j + 1]
+            assert i.tolist() == gid[a:b].tolist(), (name, dht, j)
+            assert d.tolist() == gd[a:b].tolist(), (name, dht, j)
+
+
+def test_find_batch_truncation(orc):
+    g = load_golden("vptree_n4096.npz")
+    h, ids, q = g["hashes"], g["ids"], g["queries"][:64]
+    oi, od, cnt = orc.find64_batch(h, ids, q, 8, 3)
+    for j, t in enumerate(q.tolist()):
+        i, d = orc.find64(h, ids, t, 8)
+        assert cnt[j] == len(i)
+        m = min(3, len(i))
+        assert oi[j, :m].tolist() == i[:m].tolist() and od[j, :m].tolist() == d[:m].tolist()
+        assert (oi[j, m:] == 0).all()
+
+
+def test_oracle_vs_real_vptree(orc):
+    """Direct check against the compiled reference tree (skipped where oracle/_ref is absent)."""
+    import oracle
+
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    from cbird_amd import synth
+
+    h, ids = synth.make_hashes(50000, seed=99, planted_frac=0.1)
+    tree = oracle.RefTree(h, ids)
+    rng = np.random.default_rng(5)
+    for t in h[rng.choice(len(h), 300, replace=False)].tolist():
+        for dht in (1, 2, 5, 8, 12):
+            ri, rd = tree.search(t, dht)
+            assert (np.diff(rd) >= 0).all()  # ascending by distance (vptree.h:50-69)
+            oi, od = orc.find64(h, ids, t, dht)
+            order = np.lexsort((ri, rd))
+            assert ri[order].tolist() == oi.tolist() and rd[order].tolist() == od.tolist()
+    tot, cnt = tree.search_many(h[:2000], 5, threads=4, want_counts=True)
+    assert tot == orc.count64_pairs(h, ids, h[:2000], 5) == int(cnt.sum())
+
+
+def test_null_needle_and_removed_slots(orc):
+    h = np.array([0, 2, 6, 0], np.uint64)
+    ids = np.array([0, 7, 8, 9], np.uint32)  # slot 0 removed; slot 3: hash never computed, id valid
+    assert orc.find64(h, ids, 0, 65)[0].tolist() == []  # dcthashindex.cpp:196-200
+    i, d = orc.find64(h, ids, 2, 3)
+    # the hash-0 slot with a valid id IS returned (only id 0 is skipped, :215)
+    assert list(zip(i.tolist(), d.tolist())) == [(7, 0), (8, 1), (9, 1)]
+
+
+# ---- hash pipeline -------------------------------------------------------------------------
+
+def test_zigzag_is_the_reference_table(orc):
+    zz = orc.zigzag81().tolist()
+    assert zz == ZIGZAG_REF
+    for bit, (r, c) in BIT_RC_HEAD.items():
+        assert zz[6 + bit] == r * 9 + c
+
+
+def test_kernel_size_rule(orc):
+    # cvutil.cpp:446-455 (by input AREA)
+    assert orc.blur_ksize(32, 32) == 0
+    assert orc.blur_ksize(64, 16) == 0
+    assert orc.blur_ksize(64, 64) == 3
+    assert orc.blur_ksize(128, 128) == 5
+    assert orc.blur_ksize(128, 129) == 7
+    assert orc.blur_ksize(256, 256) == 7
+
+
+def test_dct_table_is_orthonormal(orc):
+    c = orc.dct9_table().astype(np.float64)
+    assert np.allclose(c @ c.T, np.eye(9), atol=1e-6)
+    assert np.allclose(c[0], np.sqrt(1 / 32))
+
+
+@pytest.mark.parametrize("k", [3, 5, 7])
+def test_box_blur_separable_equals_direct(orc, k):
+    rng = np.random.default_rng(k)
+    for shape in [(64, 64), (96, 160), (33, 47), (8, 300)]:
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        assert (orc.box_blur(img, k) == orc.box_blur(img, k, direct=True)).all()
+
+
+def test_box_blur_against_numpy_definition(orc):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (40, 56), dtype=np.uint8)
+    for k in (3, 5, 7):
+        r = k // 2
+        p = np.pad(img.astype(np.int64), r, mode="reflect")  # numpy 'reflect' == BORDER_REFLECT_101
+        s = sum(p[dy:dy + 40, dx:dx + 56] for dy in range(k) for dx in range(k))
+        want = np.floor(s / (k * k) + 0.5).astype(np.uint8)
+        assert (orc.box_blur(img, k) == want).all()
+
+
+def test_area_resize_rounding(orc):
+    # 256 -> 32: 8x8 block mean, ties to even; 64 -> 32: (s+2)>>2
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (256, 256), dtype=np.uint8)
+    blur = orc.box_blur(img, 7)
+    s = blur.reshape(32, 8, 32, 8).astype(np.int64).sum(axis=(1, 3))
+    want = np.rint(s / 64.0).astype(np.uint8)  # np.rint is half-to-even, s/64 exact
+    assert (orc.tile32(img) == want).all()
+    img = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    blur = orc.box_blur(img, 3)
+    s = blur.reshape(32, 2, 32, 2).astype(np.int64).sum(axis=(1, 3))
+    assert (orc.tile32(img) == ((s + 2) >> 2).astype(np.uint8)).all()
+    t = rng.integers(0, 256, (32, 32), dtype=np.uint8)
+    assert (orc.tile32(t) == t).all()  # 32x32: no blur, resize is a no-op
+
+
+def _basis_image(u, v, n=32, amp=100.0):
+    y = np.arange(n)[:, None]
+    x = np.arange(n)[None, :]
+    f = 128 + amp * np.cos(np.pi * (2 * y + 1) * u / (2 * n)) * np.cos(np.pi * (2 * x + 1) * v / (2 * n))
+    return np.clip(np.rint(f), 0, 255).astype(np.uint8)
+
+
+def test_single_basis_function_sets_exactly_its_bit(orc):
+    """Known answers from the definition: a 32x32 image that is one DCT basis function (u,v) has
+    one dominant coefficient; with the mean threshold only that coefficient's bit is set.
+    Bit 0's coefficient (3,0) is never encoded (loop starts at 1, cvutil.cpp:537) -> hash 0 -> 1."""
+    zz = orc.zigzag81()
+    for bit in range(64):
+        u, v = divmod(int(zz[6 + bit]), 9)
+        hv = orc.dcthash64(_basis_image(u, v))
+        assert hv == ((1 << bit) if bit else 1), (bit, u, v, hex(hv))
+        # negative amplitude: the coefficient is below the mean, every other one is above it
+        hv = orc.dcthash64(_basis_image(u, v, amp=-100.0))
+        full = (2**64 - 2)
+        assert hv == (full & ~(1 << bit) if bit else full), (bit, hex(hv))
+
+
+def test_low_frequency_basis_through_blur_and_resize(orc):
+    zz = orc.zigzag81()
+    for bit in (1, 2, 3, 4, 5, 6, 7, 8, 9):
+        u, v = divmod(int(zz[6 + bit]), 9)
+        img = _basis_image(u, v, n=256)
+        assert orc.dcthash64(img) == 1 << bit
+
+
+def test_hash_never_zero_and_bit0(orc):
+    rng = np.random.default_rng(8)
+    for _ in range(50):
+        hv = orc.dcthash64(rng.integers(0, 256, (32, 32), dtype=np.uint8))
+        assert hv != 0 and (hv & 1) == 0
+
+
+def test_hash_is_scale_stable(orc):
+    """Behavioural property the reference's index tests rely on (unit/testindexbase.cpp:112-146,
+    data set 40x5-sizes): the same picture at another scale lands within the default threshold."""
+    from cbird_amd import synth
+
+    imgs = synth.make_images(6, w=512, h=512, seed=3, dup_frac=0)
+    for im in imgs:
+        big = orc.dcthash64(im)
+        half = orc.dcthash64(im.reshape(256, 2, 256, 2).mean(axis=(1, 3)).round().astype(np.uint8))
+        assert orc.hamm64(big, half) < 5
+
+
+def test_unsupported_geometry_is_an_error(orc):
+    with pytest.raises(ValueError):
+        orc.dcthash64(np.zeros((100, 100), np.uint8))
