@@ -39,6 +39,7 @@ int launch_remove_ids(uint64_t* d_hashes, uint32_t* d_ids, size_t n, const uint3
 
 // ---- dcthash.hip ----------------------------------------------------------------------
 int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_stride,
-                   size_t img_stride, uint64_t* d_out, hipStream_t stream);
+                   size_t img_stride, uint64_t* d_out, hipStream_t stream,
+                   uint8_t* d_tiles = nullptr);
 
 }  // namespace cbh

@@ -257,6 +257,20 @@ int cbh_dcthash_batch_dev(const void* d_imgs, size_t n, int w, int h, size_t row
   return CBH_OK;
 }
 
+int cbh_dcthash_tiles_dev(const void* d_imgs, size_t n, int w, int h, size_t row_stride,
+                          size_t img_stride, void* d_out, void* d_tiles, int device, void* stream) {
+  if (!device_usable(device)) return CBH_E_NODEVICE;
+  if (n && (!d_imgs || !d_out || !d_tiles)) return CBH_E_INVAL;
+  DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = launch_dcthash((const uint8_t*)d_imgs, n, w, h, row_stride, img_stride,
+                          (uint64_t*)d_out, s, (uint8_t*)d_tiles);
+  if (rc) return rc;
+  if (!stream) CBH_HIP(hipStreamSynchronize(s));
+  return CBH_OK;
+}
+
 int cbh_dcthash_batch(const uint8_t* imgs, size_t n, int w, int h, size_t row_stride,
                       size_t img_stride, uint64_t* out, int device) {
   if (!device_usable(device)) return CBH_E_NODEVICE;

@@ -85,7 +85,8 @@ __device__ __forceinline__ void hash_from_tile(const unsigned char* __restrict__
 template <int K>
 __global__ __launch_bounds__(kThreads) void k_dcthash_generic(
     const unsigned char* __restrict__ imgs, int w, int h, size_t row_stride, size_t img_stride,
-    const DctTables* __restrict__ tabs, uint64_t* __restrict__ out) {
+    const DctTables* __restrict__ tabs, uint64_t* __restrict__ out,
+    unsigned char* __restrict__ tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int R = K / 2;
   const int sx = w / 32, sy = h / 32;
@@ -154,7 +155,209 @@ __global__ __launch_bounds__(kThreads) void k_dcthash_generic(
     }
     __syncthreads();
   }
+  if (tiles)
+    for (int i = tid; i < 1024; i += kThreads) tiles[(size_t)blockIdx.x * 1024 + i] = tile[i];
   hash_from_tile(tile, sC, sZ, sT, sY, sThr, out + blockIdx.x);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// k_dcthash_256: the BASELINE configuration (256x256 tiles: 7x7 blur, 8x8 area mean).
+//
+// Work split: a 32-lane half-wave owns one image; lane l owns pixels [8l, 8l+8) of every row
+// (one 8-pixel-wide output column), so a 256-thread workgroup hashes 8 images and every row
+// load is a fully coalesced 256-B segment per half-wave (global_load_dwordx2 per lane).
+// Per row and lane (44 VALU ops for 8 pixels, all integer, exact):
+//   neighbours  2x ds_bpermute (LDS crossbar, no VALU) + 2x v_perm_b32 with a per-lane selector
+//               that turns the two border lanes' halo into the REFLECT_101 mirror of their own
+//               pixels;
+//   horizontal  7-tap sums with v_dot4_u32_u8 against 0/1 byte masks (14 ops for 8 outputs);
+//   vertical    7-row sliding sum on u16 pairs packed in u32 (no field ever borrows/overflows:
+//               7*7*255 + 24 < 2^16): S += H(new) - H(7 rows ago), ring of 7 rows in VGPRs;
+//   divide      nearest(S/49) = ((S+24) * 342393) >> 24 exactly for S <= 12495 (the +24 lives in
+//               the running sum), accumulated over the 8 rows of an output cell; 8 columns of the
+//               cell are this lane's 8 pixels, so the lane ends up with the 8x8 block sum and
+//               rounds it half-to-even (/64) into the 32x32 tile in LDS.
+// The 262 "virtual" rows -3..258 are mapped through REFLECT_101 so top/bottom borders need no
+// special code; row loads run 7 rows ahead of use.
+// Stages 3-6 then run per half-wave on its own tile (row pass: lane = tile row, basis values as
+// wave-uniform SGPR operands; column pass and threshold through LDS) in the oracle's fma order.
+__device__ __forceinline__ unsigned udot4(unsigned a, unsigned b, unsigned c) {
+  return __builtin_amdgcn_udot4(a, b, c, false);
+}
+
+// acc + (p >> 24) in one VALU op (SDWA byte select); hipcc otherwise emits shift + add
+__device__ __forceinline__ unsigned add_byte3(unsigned acc, unsigned p) {
+  unsigned r;
+  asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD"
+      : "=v"(r)
+      : "v"(p), "v"(acc));
+  return r;
+}
+
+template <bool DUMP>
+__global__ __launch_bounds__(kThreads) void k_dcthash_256(
+    const unsigned char* __restrict__ imgs, unsigned n, unsigned row_stride, unsigned img_stride,
+    const DctTables* __restrict__ tabs, uint64_t* __restrict__ out,
+    unsigned char* __restrict__ tiles) {
+  __shared__ __attribute__((aligned(16))) unsigned char sTile[8][1024];
+  __shared__ float sT[8][288];
+  __shared__ float sY[8][84];
+  __shared__ float sC[9 * 33];
+  __shared__ float sThr[8];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int l32 = lane & 31;
+  const int slot = tid >> 5;  // image within the workgroup, 0..7
+  for (int i = tid; i < 288; i += kThreads) sC[(i >> 5) * 33 + (i & 31)] = tabs->C[i];
+
+  const unsigned first = blockIdx.x * 8u;
+  unsigned img = first + (unsigned)slot;
+  const bool valid = img < n;
+  if (!valid) img = n - 1;
+  const unsigned char* __restrict__ base = imgs + (size_t)first * img_stride;  // wave-uniform
+  const unsigned voff = (img - first) * img_stride + (unsigned)l32 * 8u;       // per lane
+
+  // halo exchange: left neighbour's pixels 4..7, right neighbour's pixels 0..3
+  const int addrL = ((l32 == 0 ? lane : lane - 1)) << 2;
+  const int addrR = ((l32 == 31 ? lane : lane + 1)) << 2;
+  // v_perm_b32(S0,S1,sel): selector 4..7 -> S0 byte 0..3, 0..3 -> S1 byte 0..3
+  const unsigned selL = l32 == 0 ? 0x01020300u : 0x07060504u;   // lane 0: (x,px3,px2,px1)
+  const unsigned selR = l32 == 31 ? 0x00000102u : 0x07060504u;  // lane 31: (px254,px253,px252,x)
+
+  uint2 raw[7];
+  unsigned ring[7][4];
+  unsigned S[4];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ring[j][c] = 0u;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) S[c] = 24u | (24u << 16);
+  unsigned acc = 0;
+
+  // virtual row s-3 -> REFLECT_101 source row; steps past the image (s > 261) re-read row 252,
+  // their sums never reach the tile
+  auto row_off = [&](int s) -> unsigned {
+    int v = s - 3;
+    v = v < 0 ? -v : v;
+    v = v > 255 ? 510 - v : v;
+    v = v < 0 ? 0 : v;
+    return (unsigned)v * row_stride + voff;  // 32-bit lane offset from the uniform base
+  };
+  auto halo = [&](const uint2 d, unsigned& DL, unsigned& DR) {
+    const unsigned bl = (unsigned)__builtin_amdgcn_ds_bpermute(addrL, (int)d.y);
+    const unsigned br = (unsigned)__builtin_amdgcn_ds_bpermute(addrR, (int)d.x);
+    DL = __builtin_amdgcn_perm(bl, d.x, selL);  // bytes 1..3 = px -3,-2,-1
+    DR = __builtin_amdgcn_perm(br, d.y, selR);  // bytes 0..2 = px 8,9,10
+  };
+#pragma unroll
+  for (int j = 0; j < 7; ++j) raw[j] = *reinterpret_cast<const uint2*>(base + row_off(j));
+  unsigned DLn, DRn;  // halo of the row consumed by the next step (exchange runs one row ahead)
+  halo(raw[0], DLn, DRn);
+
+  for (int s0 = 0; s0 < 266; s0 += 7) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int s = s0 + j;
+      const unsigned D0 = raw[j].x, D1 = raw[j].y;
+      const unsigned DL = DLn, DR = DRn;
+      raw[j] = *reinterpret_cast<const uint2*>(base + row_off(s + 7));
+      halo(raw[(j + 1) % 7], DLn, DRn);
+      const unsigned T0 = udot4(D0, 0x01010101u, 0u);
+      const unsigned T1 = udot4(D1, 0x01010101u, 0u);
+      const unsigned H0 = udot4(DL, 0x01010100u, T0);
+      const unsigned H1 = udot4(DL, 0x01010000u, udot4(D1, 0x00000001u, T0));
+      const unsigned H2 = udot4(DL, 0x01000000u, udot4(D1, 0x00000101u, T0));
+      const unsigned H3 = udot4(D1, 0x00010101u, T0);
+      const unsigned H4 = udot4(D0, 0x01010100u, T1);
+      const unsigned H5 = udot4(D0, 0x01010000u, udot4(DR, 0x00000001u, T1));
+      const unsigned H6 = udot4(D0, 0x01000000u, udot4(DR, 0x00000101u, T1));
+      const unsigned H7 = udot4(DR, 0x00010101u, T1);
+      const unsigned P[4] = {H0 | (H1 << 16), H2 | (H3 << 16), H4 | (H5 << 16), H6 | (H7 << 16)};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        S[c] = (S[c] - ring[j][c]) + P[c];
+        ring[j][c] = P[c];
+      }
+      // output row y = s - 6 (garbage for s < 6: acc is reset before the first real row)
+      if (s == 6) acc = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc = add_byte3(acc, (S[c] & 0xffffu) * 342393u);  // operands < 2^24 -> v_mul_u32_u24
+        acc = add_byte3(acc, (S[c] >> 16) * 342393u);
+      }
+      const int y = s - 6;
+      if (y >= 0 && (y & 7) == 7) {
+        const unsigned t = (acc + 31u + ((acc >> 6) & 1u)) >> 6;  // /64, half to even
+        if (y < 256) sTile[slot][(y >> 3) * 32 + l32] = (unsigned char)t;
+        acc = 0;
+      }
+    }
+  }
+  __syncthreads();
+  if (DUMP) {  // stage-level parity aid: the 32x32 tile after blur + area resize
+    if (valid)
+      for (int i = l32; i < 256; i += 32)
+        reinterpret_cast<unsigned*>(tiles + (size_t)img * 1024)[i] =
+            reinterpret_cast<const unsigned*>(sTile[slot])[i];
+  }
+
+  // ---- stage 3, row pass: lane = tile row r; T[r][k] = sum_j fmaf(X[r][j], C[k][j], .)
+  {
+    float x[32];
+    const uint4* trow = reinterpret_cast<const uint4*>(&sTile[slot][l32 * 32]);
+    const uint4 a = trow[0], b = trow[1];
+    const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      x[4 * i + 0] = (float)(w[i] & 0xffu);
+      x[4 * i + 1] = (float)((w[i] >> 8) & 0xffu);
+      x[4 * i + 2] = (float)((w[i] >> 16) & 0xffu);
+      x[4 * i + 3] = (float)(w[i] >> 24);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) t = __builtin_fmaf(x[j], tabs->C[k * 32 + j], t);
+      sT[slot][l32 * 9 + k] = t;
+    }
+  }
+  __syncthreads();
+  // ---- column pass: Y[u][k] = sum_r fmaf(C[u][r], T[r][k], .), 81 outputs over 32 lanes
+#pragma unroll
+  for (int rep = 0; rep < 3; ++rep) {
+    const int o = l32 + 32 * rep;
+    if (o < 81) {
+      const int u = o / 9, k = o - u * 9;
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) t = __builtin_fmaf(sC[u * 33 + r], sT[slot][r * 9 + k], t);
+      sY[slot][o] = t;
+    }
+  }
+  __syncthreads();
+  if (l32 == 0) {
+    double sum = 0.0;
+    for (int i = 0; i < 64; ++i) sum += (double)sY[slot][tabs->zz[i]];
+    sThr[slot] = (float)sum / 64;
+  }
+  __syncthreads();
+  {
+    const float thr = sThr[slot];
+    const float c0 = sY[slot][tabs->zz[l32]];
+    const float c1 = sY[slot][tabs->zz[l32 + 32]];
+    const unsigned long long b0 = __ballot(c0 > thr);
+    const unsigned long long b1 = __ballot(c1 > thr);
+    const int sh = (lane >> 5) * 32;
+    unsigned long long hv = ((b0 >> sh) & 0xffffffffull) | (((b1 >> sh) & 0xffffffffull) << 32);
+    hv &= ~1ull;  // bit 0 is never encoded (cvutil.cpp:537)
+    if (hv == 0) hv = 1;
+    if (l32 == 0 && valid) out[img] = hv;
+  }
 }
 
 size_t generic_smem_bytes(int w, int h, int K) {
@@ -206,7 +409,7 @@ static int get_tables(const DctTables** out) {
 }
 
 int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_stride,
-                   size_t img_stride, uint64_t* d_out, hipStream_t stream) {
+                   size_t img_stride, uint64_t* d_out, hipStream_t stream, uint8_t* d_tiles) {
   if (n == 0) return CBH_OK;
   if (w <= 0 || h <= 0 || row_stride < (size_t)w) return CBH_E_INVAL;
   if (w % 32 || h % 32 || w > 1024 || h > 1024) return CBH_E_UNSUPPORTED;
@@ -214,6 +417,18 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
   const DctTables* tabs = nullptr;
   int rc = get_tables(&tabs);
   if (rc) return rc;
+  if (w == 256 && h == 256 && ((uintptr_t)d_imgs % 8) == 0 && row_stride % 8 == 0 &&
+      img_stride % 8 == 0 && row_stride * 256 < (1u << 24) && img_stride < (1u << 28)) {
+    dim3 grid((unsigned)((n + 7) / 8)), block(kThreads);
+    if (d_tiles)
+      hipLaunchKernelGGL(k_dcthash_256<true>, grid, block, 0, stream, d_imgs, (unsigned)n,
+                         (unsigned)row_stride, (unsigned)img_stride, tabs, d_out, d_tiles);
+    else
+      hipLaunchKernelGGL(k_dcthash_256<false>, grid, block, 0, stream, d_imgs, (unsigned)n,
+                         (unsigned)row_stride, (unsigned)img_stride, tabs, d_out, d_tiles);
+    CBH_HIP(hipGetLastError());
+    return CBH_OK;
+  }
   const long long area = (long long)w * h;
   const int K = area <= 32 * 32 ? 0 : area <= 64 * 64 ? 3 : area <= 128 * 128 ? 5 : 7;
   const size_t smem = generic_smem_bytes(w, h, K);
@@ -225,7 +440,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
       CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcthash_generic<KK>),     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));  \
     hipLaunchKernelGGL(k_dcthash_generic<KK>, grid, block, smem, stream, d_imgs, w, h,      \
-                       row_stride, img_stride, tabs, d_out);                                \
+                       row_stride, img_stride, tabs, d_out, d_tiles);                       \
   } while (0)
   switch (K) {
     case 0: CBH_LAUNCH_GENERIC(0); break;

@@ -79,6 +79,11 @@ int cbh_dcthash_batch(const uint8_t* imgs, size_t n, int w, int h, size_t row_st
 int cbh_dcthash_batch_dev(const void* d_imgs, size_t n, int w, int h, size_t row_stride,
                           size_t img_stride, void* d_out, int device, void* stream);
 
+/* Stage-level diagnostics: as cbh_dcthash_batch_dev, and additionally writes the 32x32 u8 tile
+ * each image is reduced to after stages 1-2 (blur + INTER_AREA) to d_tiles[i*1024 ..]. */
+int cbh_dcthash_tiles_dev(const void* d_imgs, size_t n, int w, int h, size_t row_stride,
+                          size_t img_stride, void* d_out, void* d_tiles, int device, void* stream);
+
 /* ---- DctHashIndex: src/dcthashindex.{h,cpp} -------------------------------------------- */
 cbh_idx64* cbh_idx64_create(int device);                         /* DctHashIndex() :30-41 */
 void cbh_idx64_destroy(cbh_idx64*);                              /* ~DctHashIndex/unload :43-54 */
