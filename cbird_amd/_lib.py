@@ -35,6 +35,10 @@ class CbhError(RuntimeError):
         super().__init__(f"{what}: {msg} ({code}) {detail}".strip())
 
 
+class cbh_stats(C.Structure):
+    _fields_ = [("scan_launches", C.c_uint64), ("scan_pairs", C.c_uint64), ("scan_ms", C.c_double)]
+
+
 class cbh_match(C.Structure):
     _fields_ = [("id", C.c_uint32), ("score", C.c_int32)]
 
@@ -71,6 +75,8 @@ _SIGS = {
     "cbh_sort_records_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, _vp]),
     "cbh_select_records_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, _vp, _vp, C.c_int, _vp]),
     "cbh_idx64_set_record_capacity": (C.c_int, [_vp, _sz]),
+    "cbh_idx64_get_stats": (C.c_int, [_vp, C.POINTER(cbh_stats)]),
+    "cbh_idx64_reset_stats": (C.c_int, [_vp]),
     "cbh_idx64_time_scan_dev": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _sz, _vp, C.c_int,
                                           C.POINTER(C.c_float)]),
     "cbh_time_dcthash_dev": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, _vp, C.c_int, C.c_int,

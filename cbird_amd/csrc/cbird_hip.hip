@@ -54,6 +54,7 @@ struct Workspace {
   size_t tmp_bytes = 0;
   unsigned long long* d_total = nullptr;
   unsigned long long* h_total = nullptr;  // pinned
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint64_t* d_q = nullptr;
   size_t q_cap = 0;
   cbh_match* d_out = nullptr;
@@ -65,6 +66,8 @@ struct Workspace {
     CBH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     CBH_HIP(hipMalloc(&d_total, sizeof(unsigned long long)));
     CBH_HIP(hipHostMalloc(&h_total, sizeof(unsigned long long)));
+    CBH_HIP(hipEventCreate(&ev0));
+    CBH_HIP(hipEventCreate(&ev1));
     return CBH_OK;
   }
   int ensure_records(size_t cap) {
@@ -102,6 +105,8 @@ struct Workspace {
     if (d_q) (void)hipFree(d_q);
     if (d_out) (void)hipFree(d_out);
     if (d_counts) (void)hipFree(d_counts);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -119,6 +124,8 @@ struct cbh_idx64 {
   size_t n = 0;
   size_t cap = 0;
   size_t rec_cap_default = (size_t)1 << 24;
+  std::mutex stats_mu;
+  cbh_stats stats = {0, 0, 0.0};
   std::mutex ws_mu;
   std::vector<Workspace*> ws_free;
 
@@ -194,13 +201,24 @@ int scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t nq, int 
   if (rc) return rc;
   for (int attempt = 0; attempt < 3; ++attempt) {
     CBH_HIP(hipMemsetAsync(ws->d_total, 0, sizeof(unsigned long long), stream));
+    CBH_HIP(hipEventRecord(ws->ev0, stream));
     rc = launch_hamm64_scan(idx->d_hashes, idx->d_ids, idx->n, d_q, nq, thresh, ws->d_rec,
                             ws->rec_cap, ws->d_total, stream);
     if (rc) return rc;
+    CBH_HIP(hipEventRecord(ws->ev1, stream));
     CBH_HIP(hipMemcpyAsync(ws->h_total, ws->d_total, sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, stream));
     CBH_HIP(hipStreamSynchronize(stream));
     *total = *ws->h_total;
+    {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ws->ev0, ws->ev1) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(idx->stats_mu);
+        idx->stats.scan_launches += 1;
+        idx->stats.scan_pairs += (uint64_t)idx->n * (uint64_t)nq;
+        idx->stats.scan_ms += (double)ms;
+      }
+    }
     if (*total <= ws->rec_cap) return CBH_OK;
     // every match must be materialised to be ordered: grow and rescan
     CBH_HIP(hipStreamSynchronize(stream));
@@ -466,6 +484,21 @@ cbh_idx64* cbh_idx64_slice(const cbh_idx64* idx, const uint32_t* ids, size_t n) 
     return nullptr;
   }
   return out;
+}
+
+int cbh_idx64_get_stats(const cbh_idx64* idx, cbh_stats* out) {
+  if (!idx || !out) return CBH_E_INVAL;
+  cbh_idx64* m = const_cast<cbh_idx64*>(idx);
+  std::lock_guard<std::mutex> lk(m->stats_mu);
+  *out = m->stats;
+  return CBH_OK;
+}
+
+int cbh_idx64_reset_stats(cbh_idx64* idx) {
+  if (!idx) return CBH_E_INVAL;
+  std::lock_guard<std::mutex> lk(idx->stats_mu);
+  idx->stats = cbh_stats{0, 0, 0.0};
+  return CBH_OK;
 }
 
 int cbh_idx64_set_record_capacity(cbh_idx64* idx, size_t records) {

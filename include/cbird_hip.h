@@ -137,6 +137,17 @@ int cbh_select_records_dev(const void* d_sorted_records, size_t n, size_t nq, in
 /* capacity (records) of the internal match buffer used by find/find_batch; default 1<<24 */
 int cbh_idx64_set_record_capacity(cbh_idx64*, size_t records);
 
+/* Per-index counters of the Hamming scan kernel as launched by find/find_batch(_dev): number of
+ * launches, GPU time between HIP events recorded around each launch on its own stream, and the
+ * (needle x slot) pairs those launches evaluated. */
+typedef struct cbh_stats {
+  uint64_t scan_launches;
+  uint64_t scan_pairs;
+  double scan_ms;
+} cbh_stats;
+int cbh_idx64_get_stats(const cbh_idx64*, cbh_stats* out);
+int cbh_idx64_reset_stats(cbh_idx64*);
+
 /* ---- measurement support ---------------------------------------------------------------- */
 /* Run the scan kernel `iters` times on the index's own stream bracketed by hipEvents and
  * return the average kernel time in milliseconds (bench.py roofline leg).  */
