@@ -1,0 +1,168 @@
+// gpu_dcthashindex.h -- cbird-side binding of the MI355X DctHashIndex (drop-in for
+// src/dcthashindex.{h,cpp}).
+//
+// This is the file a cbird maintainer adds to src/ (see INTEGRATION.md): a subclass of the
+// reference's `Index` plugin interface (src/index.h:150-281) with exactly the overrides of
+// DctHashIndex (src/dcthashindex.h:29-67).  All array work -- storage, add/remove, find, slice --
+// goes through the C-ABI of libcbird_hip.so (include/cbird_hip.h); the SQL of load()/mediaIds()
+// stays here, verbatim in meaning (`select id,phash_dct from media where type=1`,
+// src/dcthashindex.cpp:82-89).
+//
+// It compiles against the real cbird headers ("index.h", Qt6) and, for this repository's tests
+// where Qt6/OpenCV are not installed, against cbird_amd/cpp/mock/index.h which declares the same
+// names with the same signatures.
+#pragma once
+
+#include <algorithm>
+#include <vector>
+
+#include "cbird_hip.h"
+#include "index.h"  // cbird's src/index.h (or the test mock)
+
+class GpuDctHashIndex : public Index {
+  Q_DISABLE_COPY_MOVE(GpuDctHashIndex)
+
+ public:
+  explicit GpuDctHashIndex(int device = 0) : _device(device) {
+    _id = SearchParams::AlgoDCT;  // dcthashindex.cpp:31
+    _idx = cbh_idx64_create(device);
+    if (!_idx) qFatal("GpuDctHashIndex: no usable MI355X (gfx950) device %d", device);
+  }
+  ~GpuDctHashIndex() override { cbh_idx64_destroy(_idx); }
+
+  bool isLoaded() const override { return cbh_idx64_is_loaded(_idx) != 0; }
+  int count() const override { return int(cbh_idx64_count(_idx)); }
+  size_t memoryUsage() const override { return cbh_idx64_memory_usage(_idx); }
+
+  // DctHashIndex::load (dcthashindex.cpp:70-114): hashes always come from the database
+  void load(QSqlDatabase& db, const QString& cachePath, const QString& dataPath) override {
+    (void)cachePath;
+    (void)dataPath;
+    if (isLoaded()) return;
+    QSqlQuery query(db);
+    query.setForwardOnly(true);
+    if (!query.exec("select id,phash_dct from media where type=1")) SQL_FATAL(exec);
+    std::vector<uint64_t> hashes;
+    std::vector<uint32_t> ids;
+    while (query.next()) {
+      ids.push_back(query.value(0).toUInt());
+      hashes.push_back(uint64_t(query.value(1).toLongLong()));
+    }
+    check(cbh_idx64_load(_idx, hashes.data(), ids.data(), hashes.size()), "load");
+  }
+
+  void save(QSqlDatabase& db, const QString& cachePath) override {
+    (void)db;
+    (void)cachePath;  // nothing to cache: the SoA is rebuilt from SQL (dcthashindex.cpp:116-120)
+  }
+
+  QSet<mediaid_t> mediaIds(QSqlDatabase& db, const QString& cachePath,
+                           const QString& dataPath) const override {
+    (void)cachePath;
+    (void)dataPath;
+    QSet<mediaid_t> set;
+    if (isLoaded()) {  // dcthashindex.cpp:129-133
+      size_t n = 0;
+      check(cbh_idx64_media_ids(_idx, nullptr, 0, &n), "mediaIds");
+      std::vector<uint32_t> ids(n ? n : 1);
+      check(cbh_idx64_media_ids(_idx, ids.data(), ids.size(), &n), "mediaIds");
+      for (size_t i = 0; i < n; ++i) set.insert(ids[i]);
+      return set;
+    }
+    QSqlQuery query(db);  // dcthashindex.cpp:136-153
+    query.setForwardOnly(true);
+    if (!query.exec("select id,phash_dct from media where type=1")) SQL_FATAL(exec);
+    while (query.next()) {
+      mediaid_t id = query.value(0).toUInt();
+      uint64_t hash = uint64_t(query.value(1).toLongLong());
+      if (hash != 0) set.insert(id);
+    }
+    return set;
+  }
+
+  // dcthashindex.cpp:158-173 (the tree rebuild disappears: the scan needs no tree)
+  void add(const MediaGroup& media) override {
+    std::vector<uint64_t> hashes;
+    std::vector<uint32_t> ids;
+    for (const Media& m : media) {
+      hashes.push_back(m.dctHash());
+      ids.push_back(uint32_t(m.id()));
+    }
+    check(cbh_idx64_add(_idx, hashes.data(), ids.data(), hashes.size()), "add");
+  }
+
+  // dcthashindex.cpp:175-191
+  void remove(const QVector<int>& removed) override {
+    if (!isLoaded()) return;
+    std::vector<uint32_t> ids;
+    for (int id : removed) ids.push_back(uint32_t(id));
+    check(cbh_idx64_remove(_idx, ids.data(), ids.size()), "remove");
+  }
+
+  // dcthashindex.cpp:193-220.  Thread-safe for concurrent callers (QtConcurrent workers under
+  // Database's read lock, database.cpp:1400-1432,1698).
+  QVector<Index::Match> find(const Media& m, const SearchParams& p) override {
+    QVector<Index::Match> results;
+    uint64_t target = m.dctHash();
+    if (!target) {
+      qWarning() << "no hash for needle:" << m.path();
+      return results;
+    }
+    if (count() <= 0) {
+      qWarning() << "empty/null tree";
+      return results;
+    }
+    std::vector<cbh_match> buf(64);
+    size_t n = 0;
+    for (;;) {
+      check(cbh_idx64_find(_idx, target, p.dctThresh, buf.data(), buf.size(), &n), "find");
+      if (n <= buf.size()) break;
+      buf.resize(n);
+    }
+    for (size_t i = 0; i < n; ++i) results.append(Index::Match(buf[i].id, buf[i].score));
+    return results;
+  }
+
+  // dcthashindex.cpp:222-250; caller deletes (database.cpp:1435,1491)
+  Index* slice(const QSet<uint32_t>& mediaIds) const override {
+    Q_ASSERT(isLoaded());
+    std::vector<uint32_t> ids;
+    for (uint32_t id : mediaIds) ids.push_back(id);
+    cbh_idx64* sub = cbh_idx64_slice(_idx, ids.data(), ids.size());
+    if (!sub) qFatal("GpuDctHashIndex::slice failed: %s", cbh_last_error());
+    return new GpuDctHashIndex(_device, sub);
+  }
+
+  /// MI355X-native extension used by a batched Database::similar: every needle of `needles` in
+  /// one launch; results[i] = matches of needles[i] already sorted by (score, id) and cut at
+  /// maxMatches+1 (room for the self match that searchIndex filters, database.cpp:1733-1735).
+  QVector<QVector<Index::Match>> findBatch(const MediaGroup& needles, const SearchParams& p) {
+    const int k = p.maxMatches + 1;
+    std::vector<uint64_t> q;
+    for (const Media& m : needles) q.push_back(m.dctHash());
+    std::vector<cbh_match> out(q.size() * size_t(k));
+    std::vector<uint32_t> counts(q.size());
+    check(cbh_idx64_find_batch(_idx, q.data(), q.size(), p.dctThresh, k, out.data(), counts.data()),
+          "find_batch");
+    QVector<QVector<Index::Match>> res;
+    for (size_t i = 0; i < q.size(); ++i) {
+      QVector<Index::Match> r;
+      const size_t m = std::min<size_t>(counts[i], size_t(k));
+      for (size_t j = 0; j < m; ++j) r.append(Index::Match(out[i * k + j].id, out[i * k + j].score));
+      res.append(r);
+    }
+    return res;
+  }
+
+ private:
+  GpuDctHashIndex(int device, cbh_idx64* adopted) : _device(device), _idx(adopted) {
+    _id = SearchParams::AlgoDCT;
+  }
+  static void check(int rc, const char* what) {
+    // the reference has no error codes on this surface: SQL problems abort (SQL_FATAL), missing
+    // data warns and returns empty.  A device failure is fatal like a failed allocation.
+    if (rc != CBH_OK) qFatal("GpuDctHashIndex::%s: %s (%s)", what, cbh_strerror(rc), cbh_last_error());
+  }
+  int _device;
+  cbh_idx64* _idx;
+};
