@@ -75,6 +75,7 @@ _SIGS = {
     "cbh_sort_records_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, _vp]),
     "cbh_select_records_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, _vp, _vp, C.c_int, _vp]),
     "cbh_idx64_set_record_capacity": (C.c_int, [_vp, _sz]),
+    "cbh_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "cbh_idx64_get_stats": (C.c_int, [_vp, C.POINTER(cbh_stats)]),
     "cbh_idx64_reset_stats": (C.c_int, [_vp]),
     "cbh_idx64_time_scan_dev": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _sz, _vp, C.c_int,

@@ -26,6 +26,8 @@ int launch_hamm64_scan(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n
                        const uint64_t* d_q, size_t nq, int thresh, cbh_record* d_rec, size_t cap,
                        unsigned long long* d_total, hipStream_t stream);
 
+void set_scan_tuning(int pre_max, int eq_for_dht1, int group);  // <0 = keep
+
 // ---- records.hip ----------------------------------------------------------------------
 // Ascending u64 sort of n records in place (uses d_alt as the ping-pong buffer and d_tmp as
 // scratch; sizes from sort_records_scratch_bytes).

@@ -676,6 +676,23 @@ int cbh_select_records_dev(const void* d_sorted_records, size_t n, size_t nq, in
   return CBH_OK;
 }
 
+int cbh_set_tuning(const char* key, int value) {
+  if (!key) return CBH_E_INVAL;
+  if (!strcmp(key, "scan_pre_max")) {
+    set_scan_tuning(value, -1, -1);
+    return CBH_OK;
+  }
+  if (!strcmp(key, "scan_eq_dht1")) {
+    set_scan_tuning(-1, value, -1);
+    return CBH_OK;
+  }
+  if (!strcmp(key, "scan_group")) {
+    set_scan_tuning(-1, -1, value);
+    return CBH_OK;
+  }
+  return CBH_E_INVAL;
+}
+
 /* ---- measurement ------------------------------------------------------------------------ */
 
 int cbh_idx64_time_scan_dev(cbh_idx64* idx, const void* d_q, size_t nq, int thresh,

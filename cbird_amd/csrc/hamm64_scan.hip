@@ -40,7 +40,7 @@ __device__ __forceinline__ void emit(cbh_record* __restrict__ rec, unsigned long
   if (slot < cap) rec[slot] = ((cbh_record)qidx << 39) | ((cbh_record)dist << 32) | id;
 }
 
-// exact evaluation of needles [qa, qb) against this lane's H slots
+// exact evaluation of needles [qa, qb) (read back from memory) against this lane's H slots
 template <int H>
 __device__ __forceinline__ void exact_block(const uint2 (&h)[H], uint32_t base_idx, uint32_t n,
                                             const uint32_t* __restrict__ ids,
@@ -67,7 +67,36 @@ __device__ __forceinline__ void exact_block(const uint2 (&h)[H], uint32_t base_i
   }
 }
 
-template <int H, int QB, bool PRE>
+// second level of the filter: only slots whose running minimum fell under the threshold are
+// re-evaluated exactly against the QB needles of the block (re-read through the scalar cache)
+template <int H, int QB>
+__device__ __forceinline__ void refine_block(const uint2 (&h)[H], const uint32_t (&acc)[H],
+                                             uint32_t base_idx, uint32_t n,
+                                             const uint32_t* __restrict__ ids,
+                                             const uint64_t* __restrict__ q, uint32_t qb,
+                                             uint32_t thresh, cbh_record* __restrict__ rec,
+                                             unsigned long long cap,
+                                             unsigned long long* __restrict__ total) {
+#pragma unroll
+  for (int j = 0; j < H; ++j) {
+    if (acc[j] < thresh) {
+      const uint32_t idx = base_idx + (uint32_t)j * kThreads;
+      const uint32_t id = idx < n ? ids[idx] : 0u;
+      if (id != 0) {
+#pragma unroll 1
+        for (uint32_t qi = qb; qi < qb + QB; ++qi) {
+          const uint64_t qq = q[qi];
+          const uint32_t d = __popc(h[j].x ^ (uint32_t)qq) + __popc(h[j].y ^ (uint32_t)(qq >> 32));
+          if (d < thresh && qq != 0) emit(rec, cap, total, qi, d, id);
+        }
+      }
+    }
+  }
+}
+
+enum { MODE_PRE = 0, MODE_FULL = 1, MODE_EQ = 2 };
+
+template <int H, int QB, int MODE, bool GROUP>
 __global__ __launch_bounds__(kThreads) void k_hamm64_scan(
     const uint2* __restrict__ hay, const uint32_t* __restrict__ ids, uint32_t n,
     const uint64_t* __restrict__ q, uint32_t nq, uint32_t q_chunk, uint32_t thresh,
@@ -102,36 +131,107 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_scan(
 #pragma unroll
       for (int i = 0; i < QB; ++i) nxt[i] = make_uint2(0u, 0u);
     }
-    uint32_t acc[H];
+    if (MODE == MODE_EQ) {
+      // dht == 1: distance < 1 is equality -- one v_cmp_eq_u64 per pair, OR-ed on the scalar unit
+      unsigned long long any = 0;
 #pragma unroll
-    for (int j = 0; j < H; ++j) acc[j] = 0xffu;
+      for (int i = 0; i < QB; ++i) {
+        const unsigned long long qq = ((unsigned long long)cur[i].y << 32) | cur[i].x;
 #pragma unroll
-    for (int i = 0; i < QB; i += 2) {
-      const uint2 qa = cur[i];
-      const uint2 qc = cur[i + 1];
-#pragma unroll
-      for (int j = 0; j < H; ++j) {
-        uint32_t c0 = __popc(h[j].x ^ qa.x);
-        uint32_t c1 = __popc(h[j].x ^ qc.x);
-        if (!PRE) {
-          c0 += __popc(h[j].y ^ qa.y);
-          c1 += __popc(h[j].y ^ qc.y);
+        for (int j = 0; j < H; ++j) {
+          const unsigned long long hh = ((unsigned long long)h[j].y << 32) | h[j].x;
+          any |= __ballot(hh == qq);
         }
-        acc[j] = min3u(acc[j], c0, c1);
       }
-    }
-    uint32_t m = acc[0];
+      if (any) exact_block<H>(h, base_idx, n, ids, q, qb, qb + QB, thresh, rec, cap, total);
+    } else {
+      uint32_t acc[H];
 #pragma unroll
-    for (int j = 1; j + 1 < H; j += 2) m = min3u(m, acc[j], acc[j + 1]);
-    if (H % 2 == 0) m = min(m, acc[H - 1]);
-    if (m < thresh) exact_block<H>(h, base_idx, n, ids, q, qb, qb + QB, thresh, rec, cap, total);
+      for (int j = 0; j < H; ++j) acc[j] = 0xffu;
+      if (GROUP) {
+        // Issue-rate shaping (tools/ubench/valu_rate.hip): VGPR-only v_xor_b32 runs at 32 lanes/clk
+        // only inside long runs of such ops, while v_bcnt/v_min3 (and any op with an SGPR source)
+        // run at 16 lanes/clk and cost a ~25-cycle mode switch when interleaved.  So: broadcast
+        // the needles into VGPRs, do all QB*H xors back to back, then all the popcounts/minima.
+        uint32_t ql[QB], qh[QB];
+#pragma unroll
+        for (int i = 0; i < QB; ++i) {
+          asm volatile("v_mov_b32 %0, %1" : "=v"(ql[i]) : "s"(cur[i].x));
+          if (MODE == MODE_FULL) asm volatile("v_mov_b32 %0, %1" : "=v"(qh[i]) : "s"(cur[i].y));
+        }
+        uint32_t x[QB][H];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < QB; ++i)
+#pragma unroll
+          for (int j = 0; j < H; ++j) x[i][j] = h[j].x ^ ql[i];
+        __builtin_amdgcn_sched_barrier(0);
+        if (MODE == MODE_FULL) {
+#pragma unroll
+          for (int i = 0; i < QB; ++i)
+#pragma unroll
+            for (int j = 0; j < H; ++j) x[i][j] = (uint32_t)__popc(x[i][j]);
+          uint32_t y[QB][H];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < QB; ++i)
+#pragma unroll
+            for (int j = 0; j < H; ++j) y[i][j] = h[j].y ^ qh[i];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < QB; i += 2)
+#pragma unroll
+            for (int j = 0; j < H; ++j)
+              acc[j] = min3u(acc[j], x[i][j] + (uint32_t)__popc(y[i][j]),
+                             x[i + 1][j] + (uint32_t)__popc(y[i + 1][j]));
+        } else {
+#pragma unroll
+          for (int i = 0; i < QB; i += 2)
+#pragma unroll
+            for (int j = 0; j < H; ++j)
+              acc[j] = min3u(acc[j], (uint32_t)__popc(x[i][j]), (uint32_t)__popc(x[i + 1][j]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+#pragma unroll
+      for (int i = 0; i < QB; i += 2) {
+        const uint2 qa = cur[i];
+        const uint2 qc = cur[i + 1];
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+          uint32_t c0 = __popc(h[j].x ^ qa.x);
+          uint32_t c1 = __popc(h[j].x ^ qc.x);
+          if (MODE == MODE_FULL) {
+            c0 += __popc(h[j].y ^ qa.y);
+            c1 += __popc(h[j].y ^ qc.y);
+          }
+          acc[j] = min3u(acc[j], c0, c1);
+        }
+      }
+      }
+      uint32_t m = acc[0];
+#pragma unroll
+      for (int j = 1; j + 1 < H; j += 2) m = min3u(m, acc[j], acc[j + 1]);
+      if (H % 2 == 0) m = min(m, acc[H - 1]);
+      if (m < thresh) refine_block<H, QB>(h, acc, base_idx, n, ids, q, qb, thresh, rec, cap, total);
+    }
 #pragma unroll
     for (int i = 0; i < QB; ++i) cur[i] = nxt[i];
   }
   if (qb < q1) exact_block<H>(h, base_idx, n, ids, q, qb, q1, thresh, rec, cap, total);
 }
 
+int g_pre_max = 6;  // largest threshold served by the low-word prefilter variant
+int g_eq_for_dht1 = 1;
+int g_group = 1;
+
 }  // namespace
+
+void set_scan_tuning(int pre_max, int eq_for_dht1, int group) {
+  if (pre_max >= 0) g_pre_max = pre_max;
+  if (eq_for_dht1 >= 0) g_eq_for_dht1 = eq_for_dht1;
+  if (group >= 0) g_group = group;
+}
 
 int launch_hamm64_scan(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n,
                        const uint64_t* d_q, size_t nq, int thresh, cbh_record* d_rec, size_t cap,
@@ -152,14 +252,18 @@ int launch_hamm64_scan(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n
   }
   dim3 grid(tiles, chunks), block(kThreads);
   const uint2* hay = reinterpret_cast<const uint2*>(d_hashes);
-  if (thresh <= 5)
-    hipLaunchKernelGGL((k_hamm64_scan<kH, kQB, true>), grid, block, 0, stream, hay, d_ids,
-                       (uint32_t)n, d_q, (uint32_t)nq, q_chunk, (uint32_t)thresh, d_rec,
-                       (unsigned long long)cap, d_total);
-  else
-    hipLaunchKernelGGL((k_hamm64_scan<kH, kQB, false>), grid, block, 0, stream, hay, d_ids,
-                       (uint32_t)n, d_q, (uint32_t)nq, q_chunk, (uint32_t)thresh, d_rec,
-                       (unsigned long long)cap, d_total);
+#define CBH_SCAN(MODE, GROUP)                                                                 \
+  hipLaunchKernelGGL((k_hamm64_scan<kH, kQB, MODE, GROUP>), grid, block, 0, stream, hay,      \
+                     d_ids, (uint32_t)n, d_q, (uint32_t)nq, q_chunk, (uint32_t)thresh, d_rec, \
+                     (unsigned long long)cap, d_total)
+  if (thresh == 1 && g_eq_for_dht1)
+    CBH_SCAN(MODE_EQ, false);
+  else if (thresh <= g_pre_max) {
+    if (g_group) CBH_SCAN(MODE_PRE, true); else CBH_SCAN(MODE_PRE, false);
+  } else {
+    if (g_group) CBH_SCAN(MODE_FULL, true); else CBH_SCAN(MODE_FULL, false);
+  }
+#undef CBH_SCAN
   CBH_HIP(hipGetLastError());
   return CBH_OK;
 }

@@ -148,6 +148,11 @@ typedef struct cbh_stats {
 int cbh_idx64_get_stats(const cbh_idx64*, cbh_stats* out);
 int cbh_idx64_reset_stats(cbh_idx64*);
 
+/* Kernel-variant knobs for experiments (results never change, only speed):
+ *   "scan_pre_max"  largest threshold served by the low-word-prefilter scan variant (default 7)
+ *   "scan_eq_dht1"  1 = dht==1 uses the 64-bit equality variant (default 1) */
+int cbh_set_tuning(const char* key, int value);
+
 /* ---- measurement support ---------------------------------------------------------------- */
 /* Run the scan kernel `iters` times on the index's own stream bracketed by hipEvents and
  * return the average kernel time in milliseconds (bench.py roofline leg).  */
