@@ -7,7 +7,8 @@ missing.
 """
 from ._lib import CbhError, lib, require_device  # noqa: F401
 from .hashing import dct_hash64, dct_hash64_batch  # noqa: F401
-from .index import DctHashIndex, Match, MatchRange, Media, SearchParams  # noqa: F401
+from .index import DctFeaturesIndex, DctHashIndex, Match, MatchRange, Media, SearchParams  # noqa: F401
 
 __all__ = ["CbhError", "lib", "require_device", "dct_hash64", "dct_hash64_batch", "DctHashIndex",
+           "DctFeaturesIndex",
            "Match", "MatchRange", "Media", "SearchParams"]

@@ -75,6 +75,10 @@ _SIGS = {
     "cbh_sort_records_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, _vp]),
     "cbh_select_records_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, _vp, _vp, C.c_int, _vp]),
     "cbh_idx64_set_record_capacity": (C.c_int, [_vp, _sz]),
+    "cbh_idx64_remove_ids_only": (C.c_int, [_vp, _vp, _sz]),
+    "cbh_idx64_hashes_for_id": (C.c_int, [_vp, C.c_uint32, _vp, _sz, C.POINTER(_sz)]),
+    "cbh_fdct_find": (C.c_int, [_vp, _vp, _sz, C.c_uint32, C.c_int, _vp, _sz, C.POINTER(_sz)]),
+    "cbh_fdct_find_batch": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.c_int, _vp, _sz, _vp]),
     "cbh_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "cbh_idx64_get_stats": (C.c_int, [_vp, C.POINTER(cbh_stats)]),
     "cbh_idx64_reset_stats": (C.c_int, [_vp]),

@@ -24,7 +24,8 @@ void set_last_error(const char* where, hipError_t e);
 // q[j] != 0.  *d_total += number of such pairs; records with slot index >= cap are dropped.
 int launch_hamm64_scan(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n,
                        const uint64_t* d_q, size_t nq, int thresh, cbh_record* d_rec, size_t cap,
-                       unsigned long long* d_total, hipStream_t stream);
+                       unsigned long long* d_total, hipStream_t stream, unsigned flags = 0);
+enum { SCAN_KEEP_ID0 = 1u };  // also emit slots whose id is 0 (DctFeaturesIndex top-10 cut)
 
 void set_scan_tuning(int pre_max, int eq_for_dht1, int group);  // <0 = keep
 
@@ -37,7 +38,7 @@ int launch_sort_records(cbh_record* d_rec, cbh_record* d_alt, size_t n, size_t n
 int launch_select_records(const cbh_record* d_sorted, size_t n, size_t nq, int k, cbh_match* d_out,
                           uint32_t* d_counts, hipStream_t stream);
 int launch_remove_ids(uint64_t* d_hashes, uint32_t* d_ids, size_t n, const uint32_t* d_sorted_rm,
-                      size_t n_rm, hipStream_t stream);
+                      size_t n_rm, hipStream_t stream, int zero_hash = 1);
 
 // ---- dcthash.hip ----------------------------------------------------------------------
 int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_stride,

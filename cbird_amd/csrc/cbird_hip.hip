@@ -25,210 +25,9 @@ void set_last_error(const char* where, hipError_t e) {
   t_last_error = buf;
 }
 
-namespace {
-
-struct DeviceGuard {
-  int prev = -1;
-  bool ok = false;
-  explicit DeviceGuard(int dev) {
-    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-    ok = hipSetDevice(dev) == hipSuccess;
-  }
-  ~DeviceGuard() {
-    if (prev >= 0) (void)hipSetDevice(prev);
-  }
-};
-
-bool device_usable(int dev) {
-  hipDeviceProp_t p;
-  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
-  return strncmp(p.gcnArchName, "gfx950", 6) == 0;
-}
-
-struct Workspace {
-  hipStream_t stream = nullptr;
-  cbh_record* d_rec = nullptr;
-  cbh_record* d_alt = nullptr;
-  size_t rec_cap = 0;
-  void* d_tmp = nullptr;
-  size_t tmp_bytes = 0;
-  unsigned long long* d_total = nullptr;
-  unsigned long long* h_total = nullptr;  // pinned
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  uint64_t* d_q = nullptr;
-  size_t q_cap = 0;
-  cbh_match* d_out = nullptr;
-  size_t out_cap = 0;
-  uint32_t* d_counts = nullptr;
-  size_t counts_cap = 0;
-
-  int init() {
-    CBH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    CBH_HIP(hipMalloc(&d_total, sizeof(unsigned long long)));
-    CBH_HIP(hipHostMalloc(&h_total, sizeof(unsigned long long)));
-    CBH_HIP(hipEventCreate(&ev0));
-    CBH_HIP(hipEventCreate(&ev1));
-    return CBH_OK;
-  }
-  int ensure_records(size_t cap) {
-    if (cap <= rec_cap) return CBH_OK;
-    if (d_rec) (void)hipFree(d_rec);
-    if (d_alt) (void)hipFree(d_alt);
-    if (d_tmp) (void)hipFree(d_tmp);
-    d_rec = d_alt = nullptr;
-    d_tmp = nullptr;
-    rec_cap = 0;
-    CBH_HIP(hipMalloc(&d_rec, cap * sizeof(cbh_record)));
-    CBH_HIP(hipMalloc(&d_alt, cap * sizeof(cbh_record)));
-    tmp_bytes = sort_records_scratch_bytes(cap);
-    CBH_HIP(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
-    rec_cap = cap;
-    return CBH_OK;
-  }
-  template <typename T>
-  static int grow(T** p, size_t* cap, size_t need) {
-    if (need <= *cap) return CBH_OK;
-    if (*p) (void)hipFree(*p);
-    *p = nullptr;
-    *cap = 0;
-    size_t n = std::max<size_t>(need, 1024);
-    CBH_HIP(hipMalloc(p, n * sizeof(T)));
-    *cap = n;
-    return CBH_OK;
-  }
-  void release() {
-    if (d_rec) (void)hipFree(d_rec);
-    if (d_alt) (void)hipFree(d_alt);
-    if (d_tmp) (void)hipFree(d_tmp);
-    if (d_total) (void)hipFree(d_total);
-    if (h_total) (void)hipHostFree(h_total);
-    if (d_q) (void)hipFree(d_q);
-    if (d_out) (void)hipFree(d_out);
-    if (d_counts) (void)hipFree(d_counts);
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
-    if (stream) (void)hipStreamDestroy(stream);
-  }
-};
-
-}  // namespace
 }  // namespace cbh
 
-using namespace cbh;
-
-struct cbh_idx64 {
-  int device = 0;
-  bool loaded = false;
-  uint64_t* d_hashes = nullptr;
-  uint32_t* d_ids = nullptr;
-  size_t n = 0;
-  size_t cap = 0;
-  size_t rec_cap_default = (size_t)1 << 24;
-  std::mutex stats_mu;
-  cbh_stats stats = {0, 0, 0.0};
-  std::mutex ws_mu;
-  std::vector<Workspace*> ws_free;
-
-  Workspace* acquire(int* rc) {
-    {
-      std::lock_guard<std::mutex> lk(ws_mu);
-      if (!ws_free.empty()) {
-        Workspace* w = ws_free.back();
-        ws_free.pop_back();
-        *rc = CBH_OK;
-        return w;
-      }
-    }
-    Workspace* w = new (std::nothrow) Workspace;
-    if (!w) {
-      *rc = CBH_E_NOMEM;
-      return nullptr;
-    }
-    *rc = w->init();
-    if (*rc) {
-      w->release();
-      delete w;
-      return nullptr;
-    }
-    return w;
-  }
-  void give_back(Workspace* w) {
-    std::lock_guard<std::mutex> lk(ws_mu);
-    ws_free.push_back(w);
-  }
-  int reserve(size_t need) {
-    if (need <= cap) return CBH_OK;
-    size_t ncap = std::max<size_t>(need, cap + cap / 2);
-    ncap = (ncap + 1023) / 1024 * 1024;  // the reference grows in 1024-row chunks (:85-95)
-    uint64_t* nh = nullptr;
-    uint32_t* ni = nullptr;
-    CBH_HIP(hipMalloc(&nh, ncap * sizeof(uint64_t)));
-    hipError_t e = hipMalloc(&ni, ncap * sizeof(uint32_t));
-    if (e != hipSuccess) {
-      (void)hipFree(nh);
-      set_last_error("hipMalloc(ids)", e);
-      return CBH_E_NOMEM;
-    }
-    if (n) {
-      CBH_HIP(hipMemcpy(nh, d_hashes, n * sizeof(uint64_t), hipMemcpyDeviceToDevice));
-      CBH_HIP(hipMemcpy(ni, d_ids, n * sizeof(uint32_t), hipMemcpyDeviceToDevice));
-    }
-    if (d_hashes) (void)hipFree(d_hashes);
-    if (d_ids) (void)hipFree(d_ids);
-    d_hashes = nh;
-    d_ids = ni;
-    cap = ncap;
-    return CBH_OK;
-  }
-};
-
-namespace {
-
-struct WsLease {
-  cbh_idx64* idx;
-  Workspace* ws;
-  WsLease(cbh_idx64* i, int* rc) : idx(i), ws(i->acquire(rc)) {}
-  ~WsLease() {
-    if (ws) idx->give_back(ws);
-  }
-};
-
-// scan into the workspace record buffer, growing it until every record fits.
-// On return *total = number of matching pairs, all of them present in ws->d_rec.
-int scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t nq, int thresh,
-             hipStream_t stream, unsigned long long* total) {
-  int rc = ws->ensure_records(std::max<size_t>(idx->rec_cap_default, 1024));
-  if (rc) return rc;
-  for (int attempt = 0; attempt < 3; ++attempt) {
-    CBH_HIP(hipMemsetAsync(ws->d_total, 0, sizeof(unsigned long long), stream));
-    CBH_HIP(hipEventRecord(ws->ev0, stream));
-    rc = launch_hamm64_scan(idx->d_hashes, idx->d_ids, idx->n, d_q, nq, thresh, ws->d_rec,
-                            ws->rec_cap, ws->d_total, stream);
-    if (rc) return rc;
-    CBH_HIP(hipEventRecord(ws->ev1, stream));
-    CBH_HIP(hipMemcpyAsync(ws->h_total, ws->d_total, sizeof(unsigned long long),
-                           hipMemcpyDeviceToHost, stream));
-    CBH_HIP(hipStreamSynchronize(stream));
-    *total = *ws->h_total;
-    {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, ws->ev0, ws->ev1) == hipSuccess) {
-        std::lock_guard<std::mutex> lk(idx->stats_mu);
-        idx->stats.scan_launches += 1;
-        idx->stats.scan_pairs += (uint64_t)idx->n * (uint64_t)nq;
-        idx->stats.scan_ms += (double)ms;
-      }
-    }
-    if (*total <= ws->rec_cap) return CBH_OK;
-    // every match must be materialised to be ordered: grow and rescan
-    CBH_HIP(hipStreamSynchronize(stream));
-    rc = ws->ensure_records((size_t)*total + 1024);
-    if (rc) return rc == CBH_E_NOMEM ? CBH_E_OVERFLOW : rc;
-  }
-  return CBH_E_OVERFLOW;
-}
-
-}  // namespace
+#include "cbh_index.h"
 
 extern "C" {
 
@@ -402,7 +201,15 @@ int cbh_idx64_add(cbh_idx64* idx, const uint64_t* hashes, const uint32_t* ids, s
   return idx_append(idx, hashes, ids, n, hipMemcpyHostToDevice, nullptr);
 }
 
-int cbh_idx64_remove(cbh_idx64* idx, const uint32_t* ids, size_t n) {
+static int idx_remove(cbh_idx64* idx, const uint32_t* ids, size_t n, int zero_hash);
+
+int cbh_idx64_remove(cbh_idx64* idx, const uint32_t* ids, size_t n) { return idx_remove(idx, ids, n, 1); }
+
+int cbh_idx64_remove_ids_only(cbh_idx64* idx, const uint32_t* ids, size_t n) {
+  return idx_remove(idx, ids, n, 0);
+}
+
+static int idx_remove(cbh_idx64* idx, const uint32_t* ids, size_t n, int zero_hash) {
   if (!idx) return CBH_E_INVAL;
   if (!idx->loaded) return CBH_OK;  // `if (!isLoaded()) return;` (:176)
   if (n == 0 || idx->n == 0) return CBH_OK;
@@ -420,7 +227,7 @@ int cbh_idx64_remove(cbh_idx64* idx, const uint32_t* ids, size_t n) {
     set_last_error("hipMemcpy(remove ids)", e);
     rc = CBH_E_HIP;
   }
-  if (!rc) rc = launch_remove_ids(idx->d_hashes, idx->d_ids, idx->n, d_rm, rm.size(), nullptr);
+  if (!rc) rc = launch_remove_ids(idx->d_hashes, idx->d_ids, idx->n, d_rm, rm.size(), nullptr, zero_hash);
   if (!rc && (e = hipStreamSynchronize(nullptr)) != hipSuccess) {
     set_last_error("remove sync", e);
     rc = CBH_E_HIP;

@@ -47,7 +47,8 @@ __device__ __forceinline__ void exact_block(const uint2 (&h)[H], uint32_t base_i
                                             const uint64_t* __restrict__ q, uint32_t qa,
                                             uint32_t qb, uint32_t thresh,
                                             cbh_record* __restrict__ rec, unsigned long long cap,
-                                            unsigned long long* __restrict__ total) {
+                                            unsigned long long* __restrict__ total,
+                                            uint32_t keep0) {
 #pragma unroll 1
   for (uint32_t qi = qa; qi < qb; ++qi) {
     const uint64_t qq = q[qi];
@@ -60,7 +61,7 @@ __device__ __forceinline__ void exact_block(const uint2 (&h)[H], uint32_t base_i
         const uint32_t idx = base_idx + (uint32_t)j * kThreads;
         if (idx < n) {
           const uint32_t id = ids[idx];
-          if (id != 0) emit(rec, cap, total, qi, d, id);
+          if (id != 0 || keep0) emit(rec, cap, total, qi, d, id);
         }
       }
     }
@@ -76,13 +77,14 @@ __device__ __forceinline__ void refine_block(const uint2 (&h)[H], const uint32_t
                                              const uint64_t* __restrict__ q, uint32_t qb,
                                              uint32_t thresh, cbh_record* __restrict__ rec,
                                              unsigned long long cap,
-                                             unsigned long long* __restrict__ total) {
+                                             unsigned long long* __restrict__ total,
+                                             uint32_t keep0) {
 #pragma unroll
   for (int j = 0; j < H; ++j) {
     if (acc[j] < thresh) {
       const uint32_t idx = base_idx + (uint32_t)j * kThreads;
       const uint32_t id = idx < n ? ids[idx] : 0u;
-      if (id != 0) {
+      if (idx < n && (id != 0 || keep0)) {
 #pragma unroll 1
         for (uint32_t qi = qb; qi < qb + QB; ++qi) {
           const uint64_t qq = q[qi];
@@ -100,7 +102,8 @@ template <int H, int QB, int MODE, bool GROUP>
 __global__ __launch_bounds__(kThreads) void k_hamm64_scan(
     const uint2* __restrict__ hay, const uint32_t* __restrict__ ids, uint32_t n,
     const uint64_t* __restrict__ q, uint32_t nq, uint32_t q_chunk, uint32_t thresh,
-    cbh_record* __restrict__ rec, unsigned long long cap, unsigned long long* __restrict__ total) {
+    cbh_record* __restrict__ rec, unsigned long long cap, unsigned long long* __restrict__ total,
+    uint32_t keep0) {
   const uint32_t base_idx = blockIdx.x * (uint32_t)(kThreads * H) + threadIdx.x;
   uint2 h[H];
 #pragma unroll
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_scan(
           any |= __ballot(hh == qq);
         }
       }
-      if (any) exact_block<H>(h, base_idx, n, ids, q, qb, qb + QB, thresh, rec, cap, total);
+      if (any) exact_block<H>(h, base_idx, n, ids, q, qb, qb + QB, thresh, rec, cap, total, keep0);
     } else {
       uint32_t acc[H];
 #pragma unroll
@@ -213,12 +216,12 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_scan(
 #pragma unroll
       for (int j = 1; j + 1 < H; j += 2) m = min3u(m, acc[j], acc[j + 1]);
       if (H % 2 == 0) m = min(m, acc[H - 1]);
-      if (m < thresh) refine_block<H, QB>(h, acc, base_idx, n, ids, q, qb, thresh, rec, cap, total);
+      if (m < thresh) refine_block<H, QB>(h, acc, base_idx, n, ids, q, qb, thresh, rec, cap, total, keep0);
     }
 #pragma unroll
     for (int i = 0; i < QB; ++i) cur[i] = nxt[i];
   }
-  if (qb < q1) exact_block<H>(h, base_idx, n, ids, q, qb, q1, thresh, rec, cap, total);
+  if (qb < q1) exact_block<H>(h, base_idx, n, ids, q, qb, q1, thresh, rec, cap, total, keep0);
 }
 
 int g_pre_max = 6;  // largest threshold served by the low-word prefilter variant
@@ -235,7 +238,7 @@ void set_scan_tuning(int pre_max, int eq_for_dht1, int group) {
 
 int launch_hamm64_scan(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n,
                        const uint64_t* d_q, size_t nq, int thresh, cbh_record* d_rec, size_t cap,
-                       unsigned long long* d_total, hipStream_t stream) {
+                       unsigned long long* d_total, hipStream_t stream, unsigned flags) {
   if (n == 0 || nq == 0 || thresh <= 0) return CBH_OK;
   if (n > 0xfffffff0ull || nq > CBH_MAX_QUERIES_PER_CALL) return CBH_E_INVAL;
   const uint32_t tile = kThreads * kH;
@@ -255,7 +258,7 @@ int launch_hamm64_scan(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n
 #define CBH_SCAN(MODE, GROUP)                                                                 \
   hipLaunchKernelGGL((k_hamm64_scan<kH, kQB, MODE, GROUP>), grid, block, 0, stream, hay,      \
                      d_ids, (uint32_t)n, d_q, (uint32_t)nq, q_chunk, (uint32_t)thresh, d_rec, \
-                     (unsigned long long)cap, d_total)
+                     (unsigned long long)cap, d_total, (uint32_t)(flags & 1u))
   if (thresh == 1 && g_eq_for_dht1)
     CBH_SCAN(MODE_EQ, false);
   else if (thresh <= g_pre_max) {

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void k_select_records(const cbh_record* __rest
 // get id = 0 and hash = 0 in place.  rm[] is sorted ascending; one binary search per slot.
 __global__ __launch_bounds__(256) void k_remove_ids(uint64_t* __restrict__ hashes,
                                                     uint32_t* __restrict__ ids, size_t n,
-                                                    const uint32_t* __restrict__ rm, size_t n_rm) {
+                                                    const uint32_t* __restrict__ rm, size_t n_rm,
+                                                    int zero_hash) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t id = ids[i];
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void k_remove_ids(uint64_t* __restrict__ hashe
   }
   if (lo < n_rm && rm[lo] == id) {
     ids[i] = 0;
-    hashes[i] = 0;
+    if (zero_hash) hashes[i] = 0;  // HammingTree::remove keeps the hash (hammingtree.h:349-361)
   }
 }
 
@@ -110,10 +111,11 @@ int launch_select_records(const cbh_record* d_sorted, size_t n, size_t nq, int k
 }
 
 int launch_remove_ids(uint64_t* d_hashes, uint32_t* d_ids, size_t n, const uint32_t* d_sorted_rm,
-                      size_t n_rm, hipStream_t stream) {
+                      size_t n_rm, hipStream_t stream, int zero_hash) {
   if (n == 0 || n_rm == 0) return CBH_OK;
   dim3 grid((unsigned)((n + 255) / 256)), block(256);
-  hipLaunchKernelGGL(k_remove_ids, grid, block, 0, stream, d_hashes, d_ids, n, d_sorted_rm, n_rm);
+  hipLaunchKernelGGL(k_remove_ids, grid, block, 0, stream, d_hashes, d_ids, n, d_sorted_rm, n_rm,
+                     zero_hash);
   CBH_HIP(hipGetLastError());
   return CBH_OK;
 }

@@ -51,6 +51,7 @@ class Media:
     id: int = 0
     dctHash: int = 0
     path: str = ""
+    keyPointHashes: list = field(default_factory=list)  # KeyPointHashList (src/media.h)
     score: int = -1
     matchRange: MatchRange = field(default_factory=MatchRange)
 
@@ -211,3 +212,116 @@ class DctHashIndex:
     @property
     def device(self) -> int:
         return self._device
+
+
+class DctFeaturesIndex:
+    """Index of a feature-based matcher using DCT hashes (src/dctfeaturesindex.h:31-38): up to 400
+    keypoint hashes per image, stored as (mediaId, hash) entries; `find` votes over the 10 nearest
+    entries of every needle hash (src/dctfeaturesindex.cpp:260-358)."""
+
+    def __init__(self, device: int = 0) -> None:
+        self._L = _lib.lib()
+        self._device = device
+        self._id = SearchParams.AlgoDCTFeatures  # dctfeaturesindex.cpp:84
+        self._h = self._L.cbh_idx64_create(device)
+        if not self._h:
+            raise CbhError(_lib.CBH_E_NODEVICE, "cbh_idx64_create")
+
+    def __del__(self) -> None:
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.cbh_idx64_destroy(h)
+
+    def id(self) -> int:
+        return self._id
+
+    def isLoaded(self) -> bool:
+        return bool(self._L.cbh_idx64_is_loaded(self._h))
+
+    def count(self) -> int:
+        """_tree->size(): every inserted hash, removed ones included (dctfeaturesindex.cpp:93)"""
+        return int(self._L.cbh_idx64_count(self._h))
+
+    def memoryUsage(self) -> int:
+        return int(self._L.cbh_idx64_memory_usage(self._h))
+
+    @staticmethod
+    def _flatten(media):
+        ids, hashes = [], []
+        for m in media:
+            kp = list(getattr(m, "keyPointHashes", []) or [])
+            ids += [m.id] * len(kp)
+            hashes += kp
+        return _as_u64(hashes), _as_u32(ids)
+
+    def load(self, rows) -> None:
+        """rows: iterable of (media_id, hashes) as `select media_id,hashes from kphash` yields them
+        (dctfeaturesindex.cpp:129-156)."""
+        ids, hashes = [], []
+        for media_id, hs in rows:
+            hs = list(hs)
+            ids += [media_id] * len(hs)
+            hashes += hs
+        h, i = _as_u64(hashes), _as_u32(ids)
+        check(self._L.cbh_idx64_load(self._h, h.ctypes.data, i.ctypes.data, len(h)), "load")
+
+    def add(self, media) -> None:
+        """dctfeaturesindex.cpp:229-238"""
+        media = list(media)
+        if not media:
+            return
+        h, i = self._flatten(media)
+        check(self._L.cbh_idx64_add(self._h, h.ctypes.data, i.ctypes.data, len(h)), "add")
+
+    def remove(self, ids) -> None:
+        """dctfeaturesindex.cpp:240-249 -> HammingTree::remove: index zeroed, hash kept"""
+        ids = list(ids)
+        if not ids or not self.isLoaded():
+            return
+        i = _as_u32(ids)
+        check(self._L.cbh_idx64_remove_ids_only(self._h, i.ctypes.data, len(i)), "remove")
+
+    def hashesForId(self, media_id: int):
+        n = C.c_size_t(0)
+        check(self._L.cbh_idx64_hashes_for_id(self._h, media_id, None, 0, C.byref(n)), "findIndex")
+        out = np.zeros(max(1, n.value), np.uint64)
+        check(self._L.cbh_idx64_hashes_for_id(self._h, media_id, out.ctypes.data, len(out), C.byref(n)),
+              "findIndex")
+        return out[: n.value]
+
+    def find(self, needle, p: SearchParams) -> list[Match]:
+        hashes = _as_u64(list(getattr(needle, "keyPointHashes", []) or []))
+        if len(hashes) == 0 and needle.id > 0:
+            hashes = self.hashesForId(needle.id)  # _tree->findIndex (:270-276)
+        if len(hashes) == 0:
+            warnings.warn(f"needle has no hashes {needle.id} {needle.path}")
+            return []
+        cap = len(hashes) * 10 + 1
+        buf = (cbh_match * cap)()
+        n = C.c_size_t(0)
+        check(self._L.cbh_fdct_find(self._h, hashes.ctypes.data, len(hashes), needle.id,
+                                    int(p.dctThresh), buf, cap, C.byref(n)), "fdct_find")
+        return [Match(buf[i].id, buf[i].score) for i in range(n.value)]
+
+    def find_batch(self, needles, p: SearchParams):
+        """All needles in one scan; returns a list (per needle) of lists of Match."""
+        needles = list(needles)
+        hs, offs, ids = [], [0], []
+        for m in needles:
+            kp = list(getattr(m, "keyPointHashes", []) or [])
+            hs += kp
+            offs.append(len(hs))
+            ids.append(m.id)
+        h, o, i = _as_u64(hs), _as_u64(offs), _as_u32(ids)
+        cap = len(hs) * 10 + 1
+        buf = (cbh_match * cap)()
+        out_offs = np.zeros(len(needles) + 1, np.uint64)
+        check(self._L.cbh_fdct_find_batch(self._h, h.ctypes.data, o.ctypes.data, i.ctypes.data,
+                                          len(needles), int(p.dctThresh), buf, cap,
+                                          out_offs.ctypes.data), "fdct_find_batch")
+        return [[Match(buf[j].id, buf[j].score) for j in range(int(out_offs[k]), int(out_offs[k + 1]))]
+                for k in range(len(needles))]
+
+    @property
+    def handle(self):
+        return self._h

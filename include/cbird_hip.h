@@ -148,6 +148,29 @@ typedef struct cbh_stats {
 int cbh_idx64_get_stats(const cbh_idx64*, cbh_stats* out);
 int cbh_idx64_reset_stats(cbh_idx64*);
 
+/* ---- DctFeaturesIndex: src/dctfeaturesindex.{h,cpp} over src/tree/hammingtree.h -----------------
+ * The index is a cbh_idx64 whose entries are (mediaId, keypoint hash) pairs, several per media:
+ *   load/add      -> cbh_idx64_load / cbh_idx64_add with one entry per hash (:229-238, :143-156)
+ *   remove        -> cbh_idx64_remove_ids_only: HammingTree::remove zeroes the index and KEEPS the
+ *                    hash (hammingtree.h:349-361, dctfeaturesindex.cpp:240-249)
+ *   count()       -> cbh_idx64_count (= _tree->size(), removed entries included) */
+int cbh_idx64_remove_ids_only(cbh_idx64*, const uint32_t* ids, size_t n);
+/* HammingTree::findIndex (hammingtree.h:110-112): hashes stored for one mediaId */
+int cbh_idx64_hashes_for_id(const cbh_idx64*, uint32_t id, uint64_t* out, size_t cap, size_t* n_out);
+/* DctFeaturesIndex::find (:260-358) for one needle with keypoint hashes[n] and id needle_id:
+ * per needle hash the 10 nearest entries under thresh (removed entries take part in the cut and are
+ * skipped afterwards, :301-308), votes per mediaId, score -1 for the needle itself, 10*avg distance
+ * when no other media got more than one vote, else maxMatches - votes.  Results ascending mediaId
+ * (QMap order).  Exact candidates (the reference tree is approximate). */
+int cbh_fdct_find(cbh_idx64*, const uint64_t* hashes, size_t n, uint32_t needle_id, int thresh,
+                  cbh_match* out, size_t cap, size_t* n_out);
+/* Many needles in one scan: needle i owns hashes[offsets[i] .. offsets[i+1]); results of needle i
+ * go to out[out_offsets[i] .. out_offsets[i+1]).  CBH_E_OVERFLOW when the total exceeds cap
+ * (out_offsets[n_needles] then holds the required capacity). */
+int cbh_fdct_find_batch(cbh_idx64*, const uint64_t* hashes, const uint64_t* offsets,
+                        const uint32_t* needle_ids, size_t n_needles, int thresh, cbh_match* out,
+                        size_t cap, uint64_t* out_offsets);
+
 /* Kernel-variant knobs for experiments (results never change, only speed):
  *   "scan_pre_max"  largest threshold served by the low-word-prefilter scan variant (default 7)
  *   "scan_eq_dht1"  1 = dht==1 uses the 64-bit equality variant (default 1) */

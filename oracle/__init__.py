@@ -73,6 +73,9 @@ class Oracle:
         L.orc_dcthash64_batch.restype = C.c_int
         L.orc_hash_from_tile32.argtypes = [_u8p, C.c_void_p, C.c_void_p]
         L.orc_hash_from_tile32.restype = C.c_uint64
+        L.orc_fdct_find.argtypes = [_u64p, _u32p, C.c_size_t, _u64p, C.c_size_t, C.c_uint32, C.c_int,
+                                    _u32p, _i32p, C.c_size_t]
+        L.orc_fdct_find.restype = C.c_longlong
         for name in ("orc_box_blur", "orc_box_blur_direct"):
             f = getattr(L, name)
             f.argtypes = [_u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, _u8p]
@@ -117,6 +120,18 @@ class Oracle:
         queries = np.ascontiguousarray(queries, np.uint64)
         return int(self.L.orc_count64_pairs(hashes, ids, len(hashes), queries, len(queries),
                                             int(thresh)))
+
+    def fdct_find(self, hashes, ids, needle_hashes, needle_id, thresh):
+        """DctFeaturesIndex::find with exact candidates: (ids, scores) ascending mediaId"""
+        hashes = np.ascontiguousarray(hashes, np.uint64)
+        ids = np.ascontiguousarray(ids, np.uint32)
+        nh = np.ascontiguousarray(needle_hashes, np.uint64)
+        cap = len(nh) * 10 + 1
+        oi = np.zeros(cap, np.uint32)
+        osc = np.zeros(cap, np.int32)
+        m = self.L.orc_fdct_find(hashes, ids, len(hashes), nh, len(nh), int(needle_id), int(thresh),
+                                 oi, osc, cap)
+        return oi[:m].copy(), osc[:m].copy()
 
     # -- hashing ------------------------------------------------------------------------
     def zigzag81(self):
@@ -174,6 +189,72 @@ class Oracle:
         if rc:
             raise ValueError(f"orc_dcthash64_batch rc={rc}")
         return o
+
+
+_REF_QT_SO = os.path.join(_HERE, "_ref", "libcbird_ref_qt.so")
+
+
+def ref_qt_available() -> bool:
+    return os.path.exists(_REF_QT_SO)
+
+
+class RefHammingTree:
+    """The real HammingTree_t<uint32_t> behind DctFeaturesIndex (oracle/ref_wrap_qt.cpp)."""
+
+    _L = None
+
+    @classmethod
+    def lib(cls):
+        if cls._L is None:
+            L = C.CDLL(_REF_QT_SO)
+            L.ref_htree_create.restype = C.c_void_p
+            L.ref_htree_destroy.argtypes = [C.c_void_p]
+            L.ref_htree_size.argtypes = [C.c_void_p]
+            L.ref_htree_size.restype = C.c_size_t
+            L.ref_htree_insert.argtypes = [C.c_void_p, _u32p, _u64p, C.c_size_t]
+            L.ref_htree_remove.argtypes = [C.c_void_p, _u32p, C.c_size_t]
+            L.ref_htree_search.argtypes = [C.c_void_p, C.c_uint64, C.c_int, _u32p, _u64p, _i32p, C.c_int]
+            L.ref_htree_search.restype = C.c_int
+            L.ref_fdct_find.argtypes = [C.c_void_p, _u64p, C.c_int, C.c_int, C.c_int, _u32p, _i32p, C.c_int]
+            L.ref_fdct_find.restype = C.c_int
+            cls._L = L
+        return cls._L
+
+    def __init__(self):
+        self.h = self.lib().ref_htree_create()
+
+    def insert(self, ids, hashes):
+        ids = np.ascontiguousarray(ids, np.uint32)
+        hashes = np.ascontiguousarray(hashes, np.uint64)
+        self.lib().ref_htree_insert(self.h, ids, hashes, len(ids))
+
+    def remove(self, ids):
+        ids = np.ascontiguousarray(ids, np.uint32)
+        self.lib().ref_htree_remove(self.h, ids, len(ids))
+
+    def size(self):
+        return self.lib().ref_htree_size(self.h)
+
+    def search(self, target, thresh, cap=1 << 16):
+        oi = np.zeros(cap, np.uint32)
+        oh = np.zeros(cap, np.uint64)
+        od = np.zeros(cap, np.int32)
+        m = self.lib().ref_htree_search(self.h, int(target), int(thresh), oi, oh, od, cap)
+        return oi[:m].copy(), oh[:m].copy(), od[:m].copy()
+
+    def fdct_find(self, needle_hashes, needle_id, thresh):
+        nh = np.ascontiguousarray(needle_hashes, np.uint64)
+        cap = len(nh) * 10 + 1
+        oi = np.zeros(cap, np.uint32)
+        osc = np.zeros(cap, np.int32)
+        m = self.lib().ref_fdct_find(self.h, nh, len(nh), int(needle_id), int(thresh), oi, osc, cap)
+        return oi[:m].copy(), osc[:m].copy()
+
+    def __del__(self):
+        try:
+            self.lib().ref_htree_destroy(self.h)
+        except Exception:
+            pass
 
 
 def ref_available() -> bool:

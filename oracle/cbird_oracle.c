@@ -363,3 +363,102 @@ int orc_dcthash64_batch(const uint8_t* imgs, size_t n, int w, int h, size_t row_
   }
   return ORC_OK;
 }
+
+/* ---- DctFeaturesIndex::find: src/dctfeaturesindex.cpp:260-358 ---------------------------------
+ * entries = the HammingTree values (mediaId, hash), several per media; removed entries keep their
+ * hash with id 0 (hammingtree.h:349-361).  Candidates are taken by exact brute force (the reference
+ * tree only visits the needle's own leaf, hammingtree.h:248-252, so it returns a subset once the tree
+ * has split; while it is a single leaf of <= 8192 entries it returns exactly these).  Per needle
+ * hash: candidates sorted by distance -- the reference's std::sort leaves equal distances in
+ * unspecified order, fixed here to (distance, mediaId) -- first 10 kept (:301-303), id 0 skipped
+ * AFTER the cut (:308), votes and distance sums per mediaId (:314-323), maxMatches over ids other than
+ * the needle (:325), results in ascending mediaId (QMap) with the score rule of :334-355.
+ * Returns the number of results. */
+typedef struct {
+  int32_t dist;
+  uint32_t id;
+} orc_cand;
+
+static int cmp_cand(const void* a, const void* b) {
+  const orc_cand* x = (const orc_cand*)a;
+  const orc_cand* y = (const orc_cand*)b;
+  if (x->dist != y->dist) return x->dist < y->dist ? -1 : 1;
+  if (x->id != y->id) return x->id < y->id ? -1 : 1;
+  return 0;
+}
+
+static int cmp_u32(const void* a, const void* b) {
+  uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
+  return x < y ? -1 : x > y;
+}
+
+long long orc_fdct_find(const uint64_t* hashes, const uint32_t* ids, size_t n, const uint64_t* nhash,
+                        size_t nn, uint32_t needle_id, int thresh, uint32_t* out_ids,
+                        int32_t* out_scores, size_t cap) {
+  /* votes: at most 10 per needle hash */
+  size_t maxv = nn * 10 + 1;
+  uint32_t* vid = (uint32_t*)malloc(sizeof(uint32_t) * maxv);
+  int32_t* vdist = (int32_t*)malloc(sizeof(int32_t) * maxv);
+  orc_cand* cand = (orc_cand*)malloc(sizeof(orc_cand) * (n ? n : 1));
+  size_t nv = 0;
+  for (size_t j = 0; j < nn; ++j) {
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i) {
+      int d = __builtin_popcountll(nhash[j] ^ hashes[i]);
+      if (d < thresh) {
+        cand[m].dist = d;
+        cand[m].id = ids[i];
+        ++m;
+      }
+    }
+    qsort(cand, m, sizeof(orc_cand), cmp_cand);
+    size_t len = m < 10 ? m : 10;
+    for (size_t k = 0; k < len; ++k) {
+      if (cand[k].id == 0) continue; /* "zero index means deleted" */
+      vid[nv] = cand[k].id;
+      vdist[nv] = cand[k].dist;
+      ++nv;
+    }
+  }
+  /* unique ids ascending */
+  uint32_t* uid = (uint32_t*)malloc(sizeof(uint32_t) * (nv ? nv : 1));
+  memcpy(uid, vid, sizeof(uint32_t) * nv);
+  qsort(uid, nv, sizeof(uint32_t), cmp_u32);
+  size_t nu = 0;
+  for (size_t i = 0; i < nv; ++i)
+    if (i == 0 || uid[i] != uid[i - 1]) uid[nu++] = uid[i];
+  uint32_t* cnt = (uint32_t*)calloc(nu ? nu : 1, sizeof(uint32_t));
+  int* sum = (int*)calloc(nu ? nu : 1, sizeof(int));
+  for (size_t i = 0; i < nv; ++i) {
+    uint32_t* p = (uint32_t*)bsearch(&vid[i], uid, nu, sizeof(uint32_t), cmp_u32);
+    size_t u = (size_t)(p - uid);
+    cnt[u] += 1;
+    sum[u] += vdist[i];
+  }
+  uint32_t maxMatches = 0;
+  for (size_t u = 0; u < nu; ++u)
+    if (uid[u] != needle_id && cnt[u] > maxMatches) maxMatches = cnt[u];
+  long long r = 0;
+  for (size_t u = 0; u < nu; ++u) {
+    int score;
+    float avgScore = (float)sum[u] / (float)cnt[u];
+    if (uid[u] == needle_id)
+      score = -1;
+    else if (maxMatches == 1)
+      score = (int)(10 * avgScore);
+    else
+      score = (int)(maxMatches - cnt[u]);
+    if ((size_t)r < cap) {
+      out_ids[r] = uid[u];
+      out_scores[r] = score;
+    }
+    ++r;
+  }
+  free(sum);
+  free(cnt);
+  free(uid);
+  free(cand);
+  free(vdist);
+  free(vid);
+  return r;
+}
