@@ -39,6 +39,11 @@ class cbh_stats(C.Structure):
     _fields_ = [("scan_launches", C.c_uint64), ("scan_pairs", C.c_uint64), ("scan_ms", C.c_double)]
 
 
+class cbh_vmatch(C.Structure):
+    _fields_ = [("id", C.c_uint32), ("score", C.c_int32), ("src_in", C.c_int32), ("dst_in", C.c_int32),
+                ("len", C.c_int32)]
+
+
 class cbh_match(C.Structure):
     _fields_ = [("id", C.c_uint32), ("score", C.c_int32)]
 
@@ -79,6 +84,20 @@ _SIGS = {
     "cbh_idx64_hashes_for_id": (C.c_int, [_vp, C.c_uint32, _vp, _sz, C.POINTER(_sz)]),
     "cbh_fdct_find": (C.c_int, [_vp, _vp, _sz, C.c_uint32, C.c_int, _vp, _sz, C.POINTER(_sz)]),
     "cbh_fdct_find_batch": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.c_int, _vp, _sz, _vp]),
+    "cbh_vidx_create": (_vp, [C.c_int]),
+    "cbh_vidx_destroy": (None, [_vp]),
+    "cbh_vidx_add_video": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _sz]),
+    "cbh_vidx_remove": (C.c_int, [_vp, _vp, _sz]),
+    "cbh_vidx_count": (_sz, [_vp]),
+    "cbh_vidx_entries": (_sz, [_vp, C.c_int]),
+    "cbh_vidx_find_frame": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_int, C.c_int, _vp, _sz, C.POINTER(_sz)]),
+    "cbh_vidx_find_video": (C.c_int, [_vp, _vp, _vp, _sz, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, _vp, _sz, C.POINTER(_sz)]),
+    "cbh_vidx_find_videos_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, _vp, _sz, _vp]),
+    "cbh_vdx_encode": (_sz, [_vp, _vp, _sz, C.c_char_p, _vp, _sz]),
+    "cbh_vdx_decode": (C.c_longlong, [_vp, _sz, _vp, _vp, _sz]),
+    "cbh_video_dedup": (_sz, [_vp, _sz, C.c_int, _vp]),
     "cbh_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "cbh_idx64_get_stats": (C.c_int, [_vp, C.POINTER(cbh_stats)]),
     "cbh_idx64_reset_stats": (C.c_int, [_vp]),

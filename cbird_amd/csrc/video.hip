@@ -1,0 +1,426 @@
+// video.hip -- DctVideoIndex (src/dctvideoindex.{h,cpp}) on top of the 64-bit scan, the .vdx v2 codec
+// (src/videoindex.cpp:271-429) and the frame de-dup of Media::makeVideoIndex (src/media.cpp:958-1024).
+//
+// The reference keeps per video a list of (frame number, dct hash) in <id>.vdx and builds, lazily, one
+// search structure over all of them: RadixMap<VideoTreeIndex{idx:24, frame:24}> (dctvideoindex.h:37-43,
+// buildTree :113-170).  Here the structure is a cbh_idx64 whose payload is the entry position; the
+// (video index, frame) pair of an entry stays on the host.  Searches are exact (the reference's
+// vradix=0 behaviour, used by its own test unit/testdctvideoindex.cpp:24); vradix>0 only ever returns
+// a subset of this.
+#include <map>
+#include <unordered_map>
+
+#include "cbh_index.h"
+
+struct cbh_vidx {
+  int device = 0;
+  struct Video {
+    uint32_t media_id;
+    std::vector<int32_t> frames;
+    std::vector<uint64_t> hashes;
+  };
+  std::vector<Video> videos;  // _mediaId order (load: ascending id, add: appended)
+  // built state (buildTree)
+  bool built = false;
+  int built_skip = 0;
+  cbh_idx64* idx = nullptr;
+  std::vector<uint32_t> evidx;   // entry -> video index
+  std::vector<int32_t> eframe;   // entry -> frame number
+  std::mutex build_mu;           // QMutex _mutex (dctvideoindex.cpp:118)
+};
+
+namespace {
+
+// insertHashes (dctvideoindex.cpp:61-111) for every video, then upload
+int build(cbh_vidx* v, int skip) {
+  std::lock_guard<std::mutex> lk(v->build_mu);
+  if (v->built) return CBH_OK;  // `if (_tree) return;` -- a later skipFrames does not rebuild (:116)
+  std::vector<uint64_t> hashes;
+  std::vector<uint32_t> ids;
+  v->evidx.clear();
+  v->eframe.clear();
+  for (size_t vi = 0; vi < v->videos.size() && vi < (1u << 24); ++vi) {
+    const auto& vid = v->videos[vi];
+    if (vid.frames.empty()) continue;
+    const int lastFrame = vid.frames.back();
+    for (size_t j = 0; j < vid.hashes.size(); ++j) {
+      const uint64_t h = vid.hashes[j];
+      const int pc = __builtin_popcountll(h);
+      if (pc < 5 || 64 - pc < 5) continue;  // insufficient detail (:89)
+      const int frame = vid.frames[j];
+      if (skip && lastFrame / 2 > skip) {
+        if (frame < skip || frame > lastFrame - skip) continue;  // (:93-95)
+      }
+      hashes.push_back(h);
+      v->evidx.push_back((uint32_t)vi);
+      v->eframe.push_back(frame);
+      ids.push_back((uint32_t)hashes.size());  // payload = entry position + 1 (never 0)
+    }
+  }
+  if (v->idx) cbh_idx64_destroy(v->idx);
+  v->idx = cbh_idx64_create(v->device);
+  if (!v->idx) return CBH_E_NODEVICE;
+  int rc = cbh_idx64_load(v->idx, hashes.data(), ids.data(), hashes.size());
+  if (rc) return rc;
+  v->built = true;
+  v->built_skip = skip;
+  return CBH_OK;
+}
+
+void invalidate(cbh_vidx* v) {
+  std::lock_guard<std::mutex> lk(v->build_mu);
+  v->built = false;
+}
+
+// sorted records of `nq` needle hashes against the built index, copied to the host
+int scan_to_host(cbh_vidx* v, const uint64_t* q, size_t nq, int thresh, std::vector<cbh_record>* recs) {
+  recs->clear();
+  cbh_idx64* idx = v->idx;
+  if (nq == 0 || idx->n == 0 || thresh <= 0) return CBH_OK;
+  if (nq > CBH_MAX_QUERIES_PER_CALL) return CBH_E_INVAL;
+  DeviceGuard g(idx->device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  int rc;
+  WsLease L(idx, &rc);
+  if (!L.ws) return rc;
+  Workspace* ws = L.ws;
+  if ((rc = Workspace::grow(&ws->d_q, &ws->q_cap, nq))) return rc;
+  CBH_HIP(hipMemcpyAsync(ws->d_q, q, nq * sizeof(uint64_t), hipMemcpyHostToDevice, ws->stream));
+  unsigned long long total = 0;
+  rc = scan_all(idx, ws, ws->d_q, nq, thresh, ws->stream, &total);
+  if (rc) return rc;
+  rc = launch_sort_records(ws->d_rec, ws->d_alt, (size_t)total, nq, ws->d_tmp, ws->tmp_bytes, ws->stream);
+  if (rc) return rc;
+  recs->resize((size_t)total);
+  if (total)
+    CBH_HIP(hipMemcpyAsync(recs->data(), ws->d_rec, total * sizeof(cbh_record), hipMemcpyDeviceToHost,
+                           ws->stream));
+  CBH_HIP(hipStreamSynchronize(ws->stream));
+  return CBH_OK;
+}
+
+struct Range {
+  int src, dst;
+};
+
+// scoring of one needle from its (needle frame -> closest entry per media) candidates (:595-654)
+void score_needle(std::map<uint32_t, std::vector<Range>>& cand, int min_matched, int min_near,
+                  std::vector<cbh_vmatch>* out) {
+  const int frameMargin = 15;
+  for (auto& kv : cand) {
+    auto& ranges = kv.second;
+    std::sort(ranges.begin(), ranges.end(), [](const Range& a, const Range& b) { return a.src < b.src; });
+    int numAdjacent = 0, lastFrame = 0;
+    for (const Range& r : ranges) {
+      if (abs(r.dst - lastFrame) < frameMargin) numAdjacent++;
+      lastFrame = r.dst;
+    }
+    const int num = (int)ranges.size();
+    const int percentNear = numAdjacent * 100 / num;
+    if (num < min_matched) continue;
+    if (percentNear < min_near) continue;
+    cbh_vmatch m;
+    m.id = kv.first;
+    m.score = 100 - percentNear;
+    m.src_in = ranges.front().src;
+    m.dst_in = ranges.front().dst;
+    m.len = std::max(ranges.back().src - m.src_in, ranges.back().dst - m.dst_in);
+    out->push_back(m);
+  }
+}
+
+struct VNeedle {
+  size_t begin, end;  // range in the concatenated needle arrays
+  uint32_t id;
+};
+
+int find_videos(cbh_vidx* v, const int32_t* frames, const uint64_t* hashes, const std::vector<VNeedle>& needles,
+                int thresh, int skip, int min_matched, int min_near, int filter_self,
+                std::vector<std::vector<cbh_vmatch>>* results) {
+  results->assign(needles.size(), {});
+  int rc = build(v, skip);
+  if (rc) return rc;
+  // needle frames that survive the (unconditional) trim (:431), concatenated as scan queries
+  std::vector<uint64_t> q;
+  std::vector<int32_t> qframe;
+  std::vector<uint32_t> qneedle;
+  for (size_t k = 0; k < needles.size(); ++k) {
+    const VNeedle& nd = needles[k];
+    if (nd.end <= nd.begin) continue;
+    const int lastFrame = frames[nd.end - 1];
+    for (size_t i = nd.begin; i < nd.end; ++i) {
+      if (frames[i] < skip || frames[i] > lastFrame - skip) continue;
+      q.push_back(hashes[i]);
+      qframe.push_back(frames[i]);
+      qneedle.push_back((uint32_t)k);
+    }
+  }
+  std::vector<cbh_record> recs;
+  rc = scan_to_host(v, q.data(), q.size(), thresh, &recs);
+  if (rc) return rc;
+  // records are ordered (needle frame, distance, entry position): the first record of a media inside
+  // one needle frame is its closest entry, earliest in scan order among equals (:499-502)
+  std::vector<std::map<uint32_t, std::vector<Range>>> cand(needles.size());
+  std::unordered_map<uint32_t, char> seen;
+  size_t i = 0;
+  while (i < recs.size()) {
+    const uint32_t qi = CBH_REC_QUERY(recs[i]);
+    const uint32_t k = qneedle[qi];
+    seen.clear();
+    for (; i < recs.size() && CBH_REC_QUERY(recs[i]) == qi; ++i) {
+      const uint32_t pos = CBH_REC_ID(recs[i]) - 1;
+      const uint32_t id = v->videos[v->evidx[pos]].media_id;
+      if (filter_self && id == needles[k].id) continue;
+      if (seen.emplace(id, 1).second) cand[k][id].push_back(Range{qframe[qi], v->eframe[pos]});
+    }
+  }
+  for (size_t k = 0; k < needles.size(); ++k) score_needle(cand[k], min_matched, min_near, &(*results)[k]);
+  return CBH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+cbh_vidx* cbh_vidx_create(int device) {
+  if (!device_usable(device)) return nullptr;
+  cbh_vidx* v = new (std::nothrow) cbh_vidx;
+  if (v) v->device = device;
+  return v;
+}
+
+void cbh_vidx_destroy(cbh_vidx* v) {
+  if (!v) return;
+  if (v->idx) cbh_idx64_destroy(v->idx);
+  delete v;
+}
+
+int cbh_vidx_add_video(cbh_vidx* v, uint32_t media_id, const int32_t* frames, const uint64_t* hashes,
+                       size_t n) {
+  if (!v || (n && (!frames || !hashes))) return CBH_E_INVAL;
+  cbh_vidx::Video vid;
+  vid.media_id = media_id;
+  vid.frames.assign(frames, frames + n);
+  vid.hashes.assign(hashes, hashes + n);
+  v->videos.push_back(std::move(vid));
+  invalidate(v);  // add(): `delete _tree` (:250-254)
+  return CBH_OK;
+}
+
+int cbh_vidx_remove(cbh_vidx* v, const uint32_t* media_ids, size_t n) {
+  if (!v || (n && !media_ids)) return CBH_E_INVAL;
+  std::vector<uint32_t> rm(media_ids, media_ids + n);
+  std::sort(rm.begin(), rm.end());
+  std::vector<cbh_vidx::Video> keep;
+  for (auto& vid : v->videos)
+    if (!std::binary_search(rm.begin(), rm.end(), vid.media_id)) keep.push_back(std::move(vid));
+  v->videos.swap(keep);
+  invalidate(v);  // remove(): ids dropped, tree deleted (:256-275)
+  return CBH_OK;
+}
+
+size_t cbh_vidx_count(const cbh_vidx* v) { return v ? v->videos.size() : 0; }  // _mediaId.size() (:55-59)
+
+size_t cbh_vidx_entries(cbh_vidx* v, int skip_frames) {
+  if (!v || build(v, skip_frames)) return 0;
+  return v->evidx.size();
+}
+
+int cbh_vidx_find_frame(cbh_vidx* v, uint64_t hash, int thresh, int skip_frames, int src_in,
+                        cbh_vmatch* out, size_t cap, size_t* n_out) {
+  if (!v || !n_out || (cap && !out)) return CBH_E_INVAL;
+  *n_out = 0;
+  if (hash == 0) return CBH_OK;  // "needle has no dct hash" (:331-335)
+  int rc = build(v, skip_frames);
+  if (rc) return rc;
+  std::vector<cbh_record> recs;
+  rc = scan_to_host(v, &hash, 1, thresh, &recs);
+  if (rc) return rc;
+  // nearest frame per video, ascending video index (QMap<mediaid_t mediaIndex, Match>, :346-356)
+  std::map<uint32_t, std::pair<int, int>> nearest;
+  for (cbh_record r : recs) {
+    const uint32_t pos = CBH_REC_ID(r) - 1;
+    const uint32_t vi = v->evidx[pos];
+    if (!nearest.count(vi)) nearest[vi] = {CBH_REC_DIST(r), v->eframe[pos]};  // records ascend (dist, pos)
+  }
+  if (src_in < 0) src_in = 0;
+  size_t m = 0;
+  for (auto& kv : nearest) {
+    if (m < cap) {
+      out[m].id = v->videos[kv.first].media_id;
+      out[m].score = kv.second.first;
+      out[m].src_in = src_in;
+      out[m].dst_in = kv.second.second;
+      out[m].len = 1;
+    }
+    ++m;
+  }
+  *n_out = m;
+  return CBH_OK;
+}
+
+int cbh_vidx_find_video(cbh_vidx* v, const int32_t* frames, const uint64_t* hashes, size_t n,
+                        uint32_t needle_id, int thresh, int skip_frames, int min_frames_matched,
+                        int min_frames_near, int filter_self, cbh_vmatch* out, size_t cap, size_t* n_out) {
+  if (!v || !n_out || (cap && !out) || (n && (!frames || !hashes))) return CBH_E_INVAL;
+  *n_out = 0;
+  std::vector<VNeedle> nd{{0, n, needle_id}};
+  std::vector<std::vector<cbh_vmatch>> res;
+  int rc = find_videos(v, frames, hashes, nd, thresh, skip_frames, min_frames_matched, min_frames_near,
+                       filter_self, &res);
+  if (rc) return rc;
+  *n_out = res[0].size();
+  for (size_t i = 0; i < res[0].size() && i < cap; ++i) out[i] = res[0][i];
+  return CBH_OK;
+}
+
+int cbh_vidx_find_videos_batch(cbh_vidx* v, const int32_t* frames, const uint64_t* hashes,
+                               const uint64_t* offsets, const uint32_t* needle_ids, size_t n_needles,
+                               int thresh, int skip_frames, int min_frames_matched, int min_frames_near,
+                               int filter_self, cbh_vmatch* out, size_t cap, uint64_t* out_offsets) {
+  if (!v || !offsets || !needle_ids || !out_offsets || (cap && !out)) return CBH_E_INVAL;
+  std::vector<VNeedle> nd(n_needles);
+  for (size_t i = 0; i < n_needles; ++i) {
+    if (offsets[i + 1] < offsets[i]) return CBH_E_INVAL;
+    nd[i] = VNeedle{(size_t)offsets[i], (size_t)offsets[i + 1], needle_ids[i]};
+  }
+  std::vector<std::vector<cbh_vmatch>> res;
+  int rc = find_videos(v, frames, hashes, nd, thresh, skip_frames, min_frames_matched, min_frames_near,
+                       filter_self, &res);
+  if (rc) return rc;
+  uint64_t pos = 0;
+  for (size_t i = 0; i < n_needles; ++i) {
+    out_offsets[i] = pos;
+    for (auto& m : res[i]) {
+      if (pos < cap) out[pos] = m;
+      ++pos;
+    }
+  }
+  out_offsets[n_needles] = pos;
+  return pos > cap ? CBH_E_OVERFLOW : CBH_OK;
+}
+
+/* ---- .vdx v2 codec (host) ------------------------------------------------------------------- */
+
+size_t cbh_vdx_encode(const int32_t* frames, const uint64_t* hashes, size_t n, const char* version,
+                      uint8_t* out, size_t cap) {
+  char header[256];
+  const int hl = snprintf(header, sizeof header, "cbird video index:%s:%d:%d:%d:%d:%zu:\n",
+                          version ? version : "0.8.1", 2, 1 /* QSysInfo::LittleEndian */, 1, 8, n);
+  std::vector<uint8_t> buf(header, header + hl);
+  if (n) {
+    if (!frames || !hashes || frames[0] != 0) return 0;  // "first frame must be 0" (:297-300)
+    std::vector<uint8_t> packed;
+    packed.reserve(n);
+    int prev = frames[0], nextByte = prev;
+    for (size_t i = 1; i < n; ++i) {
+      int offset = frames[i] - prev;
+      prev = frames[i];
+      if (offset < 1) return 0;  // non-sequential frame number (:308-313)
+      while (offset > 0) {
+        packed.push_back((uint8_t)nextByte);
+        const int lsb = offset & 0x7F;
+        offset >>= 7;
+        nextByte = lsb | (offset == 0 ? 0x00 : 0x80);
+      }
+    }
+    packed.push_back((uint8_t)nextByte);
+    const uint32_t len = (uint32_t)packed.size();
+    const uint8_t* lp = reinterpret_cast<const uint8_t*>(&len);
+    buf.insert(buf.end(), lp, lp + 4);
+    size_t pad = 8 - ((size_t)hl + 4 + packed.size()) % 8;
+    if (pad == 8) pad = 0;
+    packed.resize(packed.size() + pad);
+    buf.insert(buf.end(), packed.begin(), packed.end());
+    const uint8_t* hp = reinterpret_cast<const uint8_t*>(hashes);
+    buf.insert(buf.end(), hp, hp + n * 8);
+    const char* tr = "cbir";
+    buf.insert(buf.end(), tr, tr + 4);
+  }
+  if (out && buf.size() <= cap) memcpy(out, buf.data(), buf.size());
+  return buf.size();
+}
+
+long long cbh_vdx_decode(const uint8_t* buf, size_t len, int32_t* frames, uint64_t* hashes, size_t cap) {
+  if (!buf) return CBH_E_INVAL;
+  size_t nl = 0;
+  while (nl < len && nl < 255 && buf[nl] != '\n') ++nl;
+  if (nl >= len || buf[nl] != '\n') return CBH_E_INVAL;
+  std::vector<std::string> f;
+  {
+    std::string cur;
+    for (size_t i = 0; i <= nl; ++i) {
+      if (i == nl || buf[i] == ':') {
+        f.push_back(cur);
+        cur.clear();
+      } else
+        cur.push_back((char)buf[i]);
+    }
+  }
+  // "a:b:c:d:e:f:g:" + "\n" -> 8 fields in the reference's split(':') (the last is the newline)
+  if (f.size() != 8 || f[0] != "cbird video index") return CBH_E_INVAL;
+  if (atoi(f[2].c_str()) != 2 || atoi(f[4].c_str()) != 1 || atoi(f[5].c_str()) != 8) return CBH_E_UNSUPPORTED;
+  if (atoi(f[3].c_str()) != 1) return CBH_E_UNSUPPORTED;  // other endianness (:242-245)
+  size_t numFrames = strtoul(f[6].c_str(), nullptr, 10);
+  const size_t hdr = nl + 1;
+  if (numFrames == 0) return 0;
+  if (numFrames > (1u << 24)) numFrames = 1u << 24;  // MAX_FRAMES_PER_VIDEO (:366-370)
+  if (numFrames > cap) return CBH_E_OVERFLOW;
+  if (hdr + 4 > len) return CBH_E_INVAL;
+  uint32_t packedLen;
+  memcpy(&packedLen, buf + hdr, 4);
+  if (packedLen < numFrames || hdr + 4 + (size_t)packedLen > len) return CBH_E_INVAL;
+  int frame = 0, jump = 0, shift = 0;
+  size_t nfr = 0;
+  for (uint32_t i = 0; i < packedLen; ++i) {
+    const uint8_t byte = buf[hdr + 4 + i];
+    if (0 == (byte & 0x80)) {
+      frame += jump | (byte << shift);
+      jump = 0;
+      shift = 0;
+      if (nfr < numFrames && frames) frames[nfr] = frame;
+      ++nfr;
+    } else {
+      jump |= (byte & 0x7F) << shift;
+      shift += 7;
+    }
+  }
+  if (jump || nfr != numFrames) return CBH_E_INVAL;
+  const size_t here = hdr + 4 + packedLen;
+  size_t pad = 8 - (here % 8);
+  if (pad == 8) pad = 0;
+  if (here + pad + numFrames * 8 + 4 > len) return CBH_E_INVAL;  // truncated
+  if (memcmp(buf + here + pad + numFrames * 8, "cbir", 4) != 0) return CBH_E_INVAL;  // trailer (:260-268)
+  if (hashes) memcpy(hashes, buf + here + pad, numFrames * 8);
+  return (long long)numFrames;
+}
+
+/* Media::makeVideoIndex frame de-dup (src/media.cpp:958-1024) over a sequence of frame hashes */
+size_t cbh_video_dedup(const uint64_t* hashes, size_t n, int threshold, uint8_t* keep) {
+  if (n == 0 || !hashes || !keep) return 0;
+  std::vector<uint64_t> window;
+  size_t kept = 1;
+  keep[0] = 1;
+  for (size_t i = 1; i < n; ++i) {
+    keep[i] = 0;
+    if (threshold > 0) {
+      size_t close = 0;
+      for (uint64_t prev : window)
+        if (__builtin_popcountll(prev ^ hashes[i]) < threshold) close++;
+      if (close != window.size()) {
+        window.clear();
+        keep[i] = 1;
+      }
+      window.push_back(hashes[i]);
+    } else
+      keep[i] = 1;
+    kept += keep[i];
+  }
+  if (!keep[n - 1]) {
+    keep[n - 1] = 1;
+    ++kept;
+  }
+  return kept;
+}
+
+}  // extern "C"

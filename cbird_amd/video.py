@@ -1,0 +1,217 @@
+"""Host-side mirror of DctVideoIndex / VideoIndex (src/dctvideoindex.{h,cpp}, src/videoindex.{h,cpp}).
+
+  VideoIndex       frames + hashes of one video and the .vdx v2 file format (save/load/isValid)
+  make_video_index the frame de-dup of Media::makeVideoIndex over a sequence of frame hashes
+  DctVideoIndex    add/remove/count/find (findFrame for image needles, findVideo for video needles)
+
+Compute and format code live in libcbird_hip.so (include/cbird_hip.h); nothing here falls back to CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import warnings
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import CbhError, cbh_vmatch, check
+from .index import Match, MatchRange, SearchParams
+
+CBIRD_VERSION = "0.8.1"
+
+
+@dataclass
+class VideoIndex:
+    """src/videoindex.h:40-67"""
+    frames: list = field(default_factory=list)
+    hashes: list = field(default_factory=list)
+
+    def isEmpty(self) -> bool:
+        return len(self.frames) == 0 or len(self.hashes) == 0
+
+    def to_bytes(self) -> bytes:
+        L = _lib.lib()
+        f = np.ascontiguousarray(self.frames, np.int32)
+        h = np.ascontiguousarray(self.hashes, np.uint64)
+        n = L.cbh_vdx_encode(f.ctypes.data, h.ctypes.data, len(f), CBIRD_VERSION.encode(), None, 0)
+        if n == 0:
+            raise ValueError("invalid video index (first frame must be 0, frames strictly increasing)")
+        buf = np.zeros(n, np.uint8)
+        L.cbh_vdx_encode(f.ctypes.data, h.ctypes.data, len(f), CBIRD_VERSION.encode(), buf.ctypes.data, n)
+        return buf.tobytes()
+
+    def save(self, path: str) -> None:
+        with open(path, "wb") as fp:
+            fp.write(self.to_bytes())
+
+    @staticmethod
+    def from_bytes(data: bytes) -> "VideoIndex":
+        L = _lib.lib()
+        buf = np.frombuffer(data, np.uint8)
+        cap = max(1, len(buf))
+        f = np.zeros(cap, np.int32)
+        h = np.zeros(cap, np.uint64)
+        n = L.cbh_vdx_decode(buf.ctypes.data, len(buf), f.ctypes.data, h.ctypes.data, cap)
+        if n < 0:
+            raise ValueError(f"invalid .vdx data ({n})")
+        return VideoIndex(f[:n].tolist(), [int(x) for x in h[:n]])
+
+    @staticmethod
+    def load(path: str) -> "VideoIndex":
+        with open(path, "rb") as fp:
+            return VideoIndex.from_bytes(fp.read())
+
+    @staticmethod
+    def isValid(path: str) -> bool:
+        try:
+            VideoIndex.load(path)
+            return True
+        except (ValueError, OSError):
+            return False
+
+
+def make_video_index(frame_hashes, threshold: int = 8) -> VideoIndex:
+    """Media::makeVideoIndex (src/media.cpp:925-1037) given the per-frame dct hashes: keeps the frames the
+    reference would store (videoThreshold default 8, src/scanner.h)."""
+    L = _lib.lib()
+    h = np.ascontiguousarray(frame_hashes, np.uint64)
+    keep = np.zeros(max(1, len(h)), np.uint8)
+    L.cbh_video_dedup(h.ctypes.data, len(h), int(threshold), keep.ctypes.data)
+    ix = np.nonzero(keep[: len(h)])[0]
+    return VideoIndex(ix.tolist(), [int(x) for x in h[ix]])
+
+
+@dataclass
+class VideoSearchParams(SearchParams):
+    """video fields of SearchParams (src/index.h:103-107)"""
+    skipFrames: int = 300
+    minFramesMatched: int = 30
+    minFramesNear: int = 60
+    videoRadix: int = 10  # accepted for interface parity; the search is always exact (vradix = 0)
+
+
+class DctVideoIndex:
+    """Detect similar videos with full-frame dct hashes (src/dctvideoindex.h:66-70)."""
+
+    def __init__(self, device: int = 0, data_path: str | None = None) -> None:
+        self._L = _lib.lib()
+        self._id = SearchParams.AlgoVideo
+        self._data_path = data_path
+        self._h = self._L.cbh_vidx_create(device)
+        if not self._h:
+            raise CbhError(_lib.CBH_E_NODEVICE, "cbh_vidx_create")
+        self._loaded = False
+
+    def __del__(self) -> None:
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.cbh_vidx_destroy(h)
+
+    def id(self) -> int:
+        return self._id
+
+    def databaseId(self) -> int:
+        return 0  # dctvideoindex.h:94
+
+    def isLoaded(self) -> bool:
+        return self._loaded
+
+    def count(self) -> int:
+        return int(self._L.cbh_vidx_count(self._h))
+
+    def _add_one(self, media_id: int, vi: VideoIndex) -> None:
+        f = np.ascontiguousarray(vi.frames, np.int32)
+        h = np.ascontiguousarray(vi.hashes, np.uint64)
+        check(self._L.cbh_vidx_add_video(self._h, media_id, f.ctypes.data, h.ctypes.data, len(f)), "add_video")
+
+    def load(self, media_ids, data_path: str | None = None) -> None:
+        """load(): `select id from media where type=video order by id` (:172-211); each id's frames come
+        from <dataPath>/<id>.vdx (insertHashes :64-72); a missing file is warned about and skipped."""
+        if data_path is not None:
+            self._data_path = data_path
+        for mid in media_ids:
+            path = os.path.join(self._data_path, f"{mid}.vdx")
+            if not os.path.exists(path):
+                warnings.warn(f"index file missing: {path}")
+                self._add_one(mid, VideoIndex())
+            else:
+                self._add_one(mid, VideoIndex.load(path))
+        self._loaded = True
+
+    def add(self, media) -> None:
+        """add(): media carry (id, videoIndex) -- dctvideoindex.cpp:250-254"""
+        for m in media:
+            self._add_one(m.id, m.videoIndex)
+        self._loaded = True
+
+    def remove(self, ids) -> None:
+        i = np.ascontiguousarray(list(ids), np.uint32)
+        check(self._L.cbh_vidx_remove(self._h, i.ctypes.data, len(i)), "remove")
+
+    @staticmethod
+    def _matches(buf, n):
+        return [Match(buf[i].id, buf[i].score, MatchRange(buf[i].src_in, buf[i].dst_in, buf[i].len))
+                for i in range(n)]
+
+    def findFrame(self, needle, p: VideoSearchParams):
+        hash_ = int(needle.dctHash)
+        if hash_ == 0:
+            warnings.warn(f"needle has no dct hash {needle.id} {needle.path}")
+            return []
+        cap = max(1, self.count())
+        buf = (cbh_vmatch * cap)()
+        n = C.c_size_t(0)
+        src_in = getattr(needle, "matchRange", MatchRange()).dstIn
+        check(self._L.cbh_vidx_find_frame(self._h, hash_, int(p.dctThresh), int(p.skipFrames), int(src_in), buf,
+                                          cap, C.byref(n)), "find_frame")
+        return self._matches(buf, n.value)
+
+    def findVideo(self, needle, p: VideoSearchParams):
+        vi = needle.videoIndex
+        if vi is None or vi.isEmpty():
+            warnings.warn(f"needle video index is empty: {needle.path}")
+            return []
+        f = np.ascontiguousarray(vi.frames, np.int32)
+        h = np.ascontiguousarray(vi.hashes, np.uint64)
+        cap = max(1, self.count())
+        buf = (cbh_vmatch * cap)()
+        n = C.c_size_t(0)
+        check(self._L.cbh_vidx_find_video(self._h, f.ctypes.data, h.ctypes.data, len(f), needle.id,
+                                          int(p.dctThresh), int(p.skipFrames), int(p.minFramesMatched),
+                                          int(p.minFramesNear), int(bool(p.filterSelf)), buf, cap, C.byref(n)),
+              "find_video")
+        return self._matches(buf, n.value)
+
+    def find(self, needle, p: VideoSearchParams):
+        """dctvideoindex.cpp:277-289: image needle -> findFrame, video needle -> findVideo"""
+        if getattr(needle, "videoIndex", None) is not None:
+            return self.findVideo(needle, p)
+        return self.findFrame(needle, p)
+
+    def find_videos_batch(self, needles, p: VideoSearchParams):
+        needles = list(needles)
+        fr, hs, offs, ids = [], [], [0], []
+        for m in needles:
+            fr += list(m.videoIndex.frames)
+            hs += list(m.videoIndex.hashes)
+            offs.append(len(fr))
+            ids.append(m.id)
+        f = np.ascontiguousarray(fr, np.int32)
+        h = np.ascontiguousarray(hs, np.uint64)
+        o = np.ascontiguousarray(offs, np.uint64)
+        i = np.ascontiguousarray(ids, np.uint32)
+        cap = max(1, self.count() * len(needles))
+        buf = (cbh_vmatch * cap)()
+        out_offs = np.zeros(len(needles) + 1, np.uint64)
+        check(self._L.cbh_vidx_find_videos_batch(self._h, f.ctypes.data, h.ctypes.data, o.ctypes.data,
+                                                 i.ctypes.data, len(needles), int(p.dctThresh),
+                                                 int(p.skipFrames), int(p.minFramesMatched),
+                                                 int(p.minFramesNear), int(bool(p.filterSelf)), buf, cap,
+                                                 out_offs.ctypes.data), "find_videos_batch")
+        return [self._matches(buf[int(out_offs[k]):int(out_offs[k + 1])], int(out_offs[k + 1] - out_offs[k]))
+                for k in range(len(needles))]
+
+    def entries(self, skip_frames: int) -> int:
+        return int(self._L.cbh_vidx_entries(self._h, int(skip_frames)))

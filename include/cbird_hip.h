@@ -171,6 +171,50 @@ int cbh_fdct_find_batch(cbh_idx64*, const uint64_t* hashes, const uint64_t* offs
                         const uint32_t* needle_ids, size_t n_needles, int thresh, cbh_match* out,
                         size_t cap, uint64_t* out_offsets);
 
+/* ---- DctVideoIndex: src/dctvideoindex.{h,cpp}, VideoIndex: src/videoindex.{h,cpp} -----------------
+ * Index::Match with its MatchRange (src/index.h:157-166, src/media.h:62-78). */
+typedef struct cbh_vmatch {
+  uint32_t id;   /* mediaId of the matched video */
+  int32_t score; /* findVideo: 100 - percentNear; findFrame: Hamming distance */
+  int32_t src_in, dst_in, len; /* MatchRange: needle frame, matched frame, length */
+} cbh_vmatch;
+typedef struct cbh_vidx cbh_vidx; /* opaque: DctVideoIndex state */
+
+cbh_vidx* cbh_vidx_create(int device);
+void cbh_vidx_destroy(cbh_vidx*);
+/* load()/add() (:172-211, :250-254) only register media ids; the per-video (frame, hash) lists come
+ * from <dataPath>/<id>.vdx when the tree is built (insertHashes :61-111).  Here the caller hands the
+ * decoded lists over (cbh_vdx_decode below reads the files).  Order of calls = _mediaId order. */
+int cbh_vidx_add_video(cbh_vidx*, uint32_t media_id, const int32_t* frames, const uint64_t* hashes, size_t n);
+int cbh_vidx_remove(cbh_vidx*, const uint32_t* media_ids, size_t n);           /* remove() :256-275 */
+size_t cbh_vidx_count(const cbh_vidx*);                                         /* count() = #videos */
+/* number of entries in the search structure after the insertHashes filters; builds it (buildTree
+ * :113-170) with vtrim = skip_frames if it is not built yet (a built tree is NOT rebuilt for another
+ * skip_frames, like `if (_tree) return;`). */
+size_t cbh_vidx_entries(cbh_vidx*, int skip_frames);
+/* findFrame (:291-387), image needle: nearest frame per video under thresh; results ascending video
+ * index; range = (src_in<0 ? 0 : src_in, matched frame, 1). */
+int cbh_vidx_find_frame(cbh_vidx*, uint64_t hash, int thresh, int skip_frames, int src_in,
+                        cbh_vmatch* out, size_t cap, size_t* n_out);
+/* findVideo (:399-657), video needle given as its (frames, hashes) list (needle_id 0 = not in the db).
+ * thresh = dctThresh, skip_frames = vtrim (skipFrames), min_frames_matched = vfm, min_frames_near = vfn. */
+int cbh_vidx_find_video(cbh_vidx*, const int32_t* frames, const uint64_t* hashes, size_t n,
+                        uint32_t needle_id, int thresh, int skip_frames, int min_frames_matched,
+                        int min_frames_near, int filter_self, cbh_vmatch* out, size_t cap, size_t* n_out);
+/* many video needles in one scan (needle i = [offsets[i], offsets[i+1]) of frames/hashes) */
+int cbh_vidx_find_videos_batch(cbh_vidx*, const int32_t* frames, const uint64_t* hashes,
+                               const uint64_t* offsets, const uint32_t* needle_ids, size_t n_needles,
+                               int thresh, int skip_frames, int min_frames_matched, int min_frames_near,
+                               int filter_self, cbh_vmatch* out, size_t cap, uint64_t* out_offsets);
+/* .vdx v2 (VideoIndex::save_v2/load_v2/verify_v2, src/videoindex.cpp:260-429).  encode returns the file
+ * size (0 = invalid input: first frame must be 0, frames strictly increasing) and writes it when it fits;
+ * decode returns the frame count or a negative CBH_E_* (bad header, truncated, missing "cbir" trailer). */
+size_t cbh_vdx_encode(const int32_t* frames, const uint64_t* hashes, size_t n, const char* cbird_version,
+                      uint8_t* out, size_t cap);
+long long cbh_vdx_decode(const uint8_t* buf, size_t len, int32_t* frames, uint64_t* hashes, size_t cap);
+/* frame de-dup of Media::makeVideoIndex (src/media.cpp:958-1024); keep[i]=1 for stored frames */
+size_t cbh_video_dedup(const uint64_t* hashes, size_t n, int threshold, uint8_t* keep);
+
 /* Kernel-variant knobs for experiments (results never change, only speed):
  *   "scan_pre_max"  largest threshold served by the low-word-prefilter scan variant (default 7)
  *   "scan_eq_dht1"  1 = dht==1 uses the 64-bit equality variant (default 1) */

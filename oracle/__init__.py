@@ -322,3 +322,134 @@ class RefTree:
             self.close()
         except Exception:
             pass
+
+
+# ---- video (DctVideoIndex / VideoIndex) -----------------------------------------------------------
+class _OrcVMatch(C.Structure):
+    _fields_ = [("id", C.c_uint32), ("score", C.c_int32), ("src_in", C.c_int32), ("dst_in", C.c_int32),
+                ("len", C.c_int32)]
+
+
+class VideoOracle:
+    """oracle/cbird_oracle.c: .vdx v2 codec, insertHashes filter, findFrame/findVideo, frame de-dup."""
+
+    def __init__(self) -> None:
+        build()
+        L = C.CDLL(_ORACLE_SO)
+        self.L = L
+        i32p = _i32p
+        L.orc_vdx_encode.argtypes = [i32p, _u64p, C.c_size_t, C.c_char_p, _u8p, C.c_size_t]
+        L.orc_vdx_encode.restype = C.c_size_t
+        L.orc_vdx_decode.argtypes = [_u8p, C.c_size_t, i32p, _u64p, C.c_size_t]
+        L.orc_vdx_decode.restype = C.c_longlong
+        L.orc_video_insert_filter.argtypes = [i32p, _u64p, C.c_size_t, C.c_int, _u8p]
+        L.orc_video_insert_filter.restype = C.c_size_t
+        L.orc_video_find_frame.argtypes = [_u32p, i32p, _u64p, C.c_size_t, _u32p, C.c_size_t, C.c_uint,
+                                           C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.orc_video_find_frame.restype = C.c_longlong
+        L.orc_video_find_video.argtypes = [_u32p, i32p, _u64p, C.c_size_t, _u32p, C.c_size_t, C.c_uint, i32p,
+                                           _u64p, C.c_size_t, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_void_p, C.c_size_t]
+        L.orc_video_find_video.restype = C.c_longlong
+        L.orc_video_dedup.argtypes = [_u64p, C.c_size_t, C.c_int, _u8p]
+        L.orc_video_dedup.restype = C.c_size_t
+
+    def vdx_encode(self, frames, hashes, version="0.8.1") -> bytes:
+        f = np.ascontiguousarray(frames, np.int32)
+        h = np.ascontiguousarray(hashes, np.uint64)
+        cap = 256 + 13 * len(f) + 64
+        out = np.zeros(cap, np.uint8)
+        n = self.L.orc_vdx_encode(f, h, len(f), version.encode(), out, cap)
+        if n == 0:
+            raise ValueError("invalid frames")
+        return out[:n].tobytes()
+
+    def vdx_decode(self, data: bytes):
+        buf = np.frombuffer(data, np.uint8).copy()
+        cap = max(1, len(buf))
+        f = np.zeros(cap, np.int32)
+        h = np.zeros(cap, np.uint64)
+        n = self.L.orc_vdx_decode(buf, len(buf), f, h, cap)
+        if n < 0:
+            raise ValueError(f"vdx decode error {n}")
+        return f[:n].copy(), h[:n].copy()
+
+    def build_entries(self, videos, skip):
+        """videos: list of (media_id, frames, hashes) in _mediaId order -> (evidx, eframe, ehash, mediaIds)
+        after the insertHashes filters"""
+        ev, ef, eh, mids = [], [], [], []
+        for vi, (mid, frames, hashes) in enumerate(videos):
+            mids.append(mid)
+            f = np.ascontiguousarray(frames, np.int32)
+            h = np.ascontiguousarray(hashes, np.uint64)
+            keep = np.zeros(max(1, len(f)), np.uint8)
+            self.L.orc_video_insert_filter(f, h, len(f), int(skip), keep)
+            k = keep[: len(f)].astype(bool)
+            ev.append(np.full(int(k.sum()), vi, np.uint32))
+            ef.append(f[k])
+            eh.append(h[k])
+        cat = lambda xs, dt: np.ascontiguousarray(np.concatenate(xs) if xs else np.zeros(0, dt), dt)
+        return cat(ev, np.uint32), cat(ef, np.int32), cat(eh, np.uint64), np.asarray(mids, np.uint32)
+
+    @staticmethod
+    def _out(buf, n):
+        return [(buf[i].id, buf[i].score, buf[i].src_in, buf[i].dst_in, buf[i].len) for i in range(n)]
+
+    def find_frame(self, entries, hash_, thresh, src_in=-1, radix=0):
+        ev, ef, eh, mids = entries
+        cap = max(1, len(mids))
+        buf = (_OrcVMatch * cap)()
+        n = self.L.orc_video_find_frame(ev, ef, eh, len(ev), mids, len(mids), radix, int(hash_), int(thresh),
+                                        int(src_in), buf, cap)
+        return self._out(buf, n)
+
+    def find_video(self, entries, frames, hashes, needle_id, thresh, skip, vfm, vfn, filter_self=True, radix=0):
+        ev, ef, eh, mids = entries
+        f = np.ascontiguousarray(frames, np.int32)
+        h = np.ascontiguousarray(hashes, np.uint64)
+        cap = max(1, len(mids))
+        buf = (_OrcVMatch * cap)()
+        n = self.L.orc_video_find_video(ev, ef, eh, len(ev), mids, len(mids), radix, f, h, len(f), int(needle_id),
+                                        int(thresh), int(skip), int(vfm), int(vfn), int(bool(filter_self)), buf,
+                                        cap)
+        return self._out(buf, n)
+
+    def dedup(self, hashes, threshold):
+        h = np.ascontiguousarray(hashes, np.uint64)
+        keep = np.zeros(max(1, len(h)), np.uint8)
+        self.L.orc_video_dedup(h, len(h), int(threshold), keep)
+        return keep[: len(h)].astype(bool)
+
+
+class RefRadixMap:
+    """The real RadixMap_t<VideoTreeIndex> (src/tree/radix.h) via oracle/ref_wrap_qt.cpp."""
+
+    def __init__(self, radix: int):
+        L = C.CDLL(_REF_QT_SO)
+        self.L = L
+        L.ref_radix_create.restype = C.c_void_p
+        L.ref_radix_create.argtypes = [C.c_uint]
+        L.ref_radix_destroy.argtypes = [C.c_void_p]
+        L.ref_radix_insert.argtypes = [C.c_void_p, _u32p, _u32p, _u64p, C.c_size_t]
+        L.ref_radix_search.argtypes = [C.c_void_p, C.c_uint64, C.c_int, _u32p, _u32p, _u64p, _i32p, C.c_int]
+        L.ref_radix_search.restype = C.c_int
+        self.h = L.ref_radix_create(radix)
+
+    def insert(self, vidx, frame, hashes):
+        self.L.ref_radix_insert(self.h, np.ascontiguousarray(vidx, np.uint32),
+                                np.ascontiguousarray(frame, np.uint32), np.ascontiguousarray(hashes, np.uint64),
+                                len(vidx))
+
+    def search(self, hash_, thresh, cap=1 << 16):
+        ov = np.zeros(cap, np.uint32)
+        of = np.zeros(cap, np.uint32)
+        oh = np.zeros(cap, np.uint64)
+        od = np.zeros(cap, np.int32)
+        m = self.L.ref_radix_search(self.h, int(hash_), int(thresh), ov, of, oh, od, cap)
+        return ov[:m].copy(), of[:m].copy(), oh[:m].copy(), od[:m].copy()
+
+    def __del__(self):
+        try:
+            self.L.ref_radix_destroy(self.h)
+        except Exception:
+            pass

@@ -22,6 +22,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -461,4 +462,323 @@ long long orc_fdct_find(const uint64_t* hashes, const uint32_t* ids, size_t n, c
   free(vdist);
   free(vid);
   return r;
+}
+
+/* ---- VideoIndex .vdx v2 codec: src/videoindex.cpp:271-429 -------------------------------------
+ * header "cbird video index:<cbird version>:2:<byte order>:1:8:<numFrames>:\n" (byte order =
+ * QSysInfo::ByteOrder, 1 on little endian), u32 packedLen, packed frame deltas (first byte = frame 0;
+ * each delta as 7-bit groups LSB first, bit 7 set on every group but the last), zero padding so that the
+ * hashes start 8-byte aligned relative to the file start, u64 hashes[numFrames], trailer "cbir".
+ * Returns the encoded size (0 on error: first frame must be 0, frames strictly increasing); writes at
+ * most cap bytes. */
+size_t orc_vdx_encode(const int32_t* frames, const uint64_t* hashes, size_t n, const char* version,
+                      uint8_t* out, size_t cap) {
+  char header[256];
+  int hl = snprintf(header, sizeof header, "cbird video index:%s:%d:%d:%d:%d:%zu:\n", version, 2, 1, 1, 8, n);
+  size_t pos = 0;
+#define PUT(ptr, len)                                              \
+  do {                                                             \
+    if (pos + (len) <= cap) memcpy(out + pos, (ptr), (len));       \
+    pos += (len);                                                  \
+  } while (0)
+  PUT(header, (size_t)hl);
+  if (n == 0) return pos;
+  if (frames[0] != 0) return 0;
+  uint8_t* packed = (uint8_t*)malloc(n * 5 + 16);
+  size_t pl = 0;
+  int prev = frames[0];
+  int nextByte = prev;
+  for (size_t i = 1; i < n; ++i) {
+    int offset = frames[i] - prev;
+    prev = frames[i];
+    if (offset < 1) {
+      free(packed);
+      return 0;
+    }
+    while (offset > 0) {
+      packed[pl++] = (uint8_t)nextByte;
+      int lsb = offset & 0x7F;
+      offset >>= 7;
+      nextByte = lsb | (offset == 0 ? 0x00 : 0x80);
+    }
+  }
+  packed[pl++] = (uint8_t)nextByte;
+  uint32_t len = (uint32_t)pl;
+  PUT(&len, 4);
+  size_t here = (size_t)hl + 4 + pl;
+  size_t pad = 8 - (here % 8);
+  if (pad == 8) pad = 0;
+  memset(packed + pl, 0, pad);
+  PUT(packed, pl + pad);
+  PUT(hashes, n * 8);
+  PUT("cbir", 4);
+#undef PUT
+  free(packed);
+  return pos;
+}
+
+/* load_v2 (:349-429) + the trailer check of verify_v2 (:260-268).  Returns the number of frames or a
+ * negative error: -1 bad header, -2 truncated/corrupt, -3 missing trailer, -4 capacity. */
+long long orc_vdx_decode(const uint8_t* buf, size_t len, int32_t* frames, uint64_t* hashes, size_t cap) {
+  size_t nl = 0;
+  while (nl < len && nl < 255 && buf[nl] != '\n') ++nl;
+  if (nl >= len || buf[nl] != '\n') return -1;
+  /* split on ':' -> 8 fields, last one is "\n" */
+  const char* f[8];
+  size_t fl[8];
+  int nf = 0;
+  size_t start = 0;
+  for (size_t i = 0; i <= nl && nf < 8; ++i)
+    if (i == nl || buf[i] == ':') {
+      f[nf] = (const char*)buf + start;
+      fl[nf] = i - start;
+      ++nf;
+      start = i + 1;
+    }
+  if (nf != 7 + 0 && nf != 8) return -1;
+  if (nf == 7) return -1; /* "a:b:c:d:e:f:g:\n" splits into 8 with the final empty/newline field */
+  if (fl[0] != 17 || memcmp(f[0], "cbird video index", 17) != 0) return -1;
+  if (atoi(f[2]) != 2 || atoi(f[4]) != 1 || atoi(f[5]) != 8 || atoi(f[3]) != 1) return -1;
+  unsigned long numFrames = strtoul(f[6], NULL, 10);
+  size_t hdr = nl + 1;
+  if (numFrames == 0) return 0;
+  if (numFrames > (1u << 24)) numFrames = 1u << 24; /* MAX_FRAMES_PER_VIDEO */
+  if (numFrames > cap) return -4;
+  if (hdr + 4 > len) return -2;
+  uint32_t packedLen;
+  memcpy(&packedLen, buf + hdr, 4);
+  if (packedLen < numFrames || hdr + 4 + packedLen > len) return -2;
+  const uint8_t* packed = buf + hdr + 4;
+  int frame = 0, jump = 0, shift = 0;
+  size_t nfr = 0;
+  for (uint32_t i = 0; i < packedLen; ++i) {
+    uint8_t byte = packed[i];
+    if (0 == (byte & 0x80)) {
+      frame += jump | (byte << shift);
+      jump = 0;
+      shift = 0;
+      if (nfr < numFrames) frames[nfr] = frame;
+      ++nfr;
+    } else {
+      jump |= (byte & 0x7F) << shift;
+      shift += 7;
+    }
+  }
+  if (jump) return -2;
+  if (nfr != numFrames) return -2;
+  size_t here = hdr + 4 + packedLen;
+  size_t pad = 8 - (here % 8);
+  if (pad == 8) pad = 0;
+  if (here + pad + numFrames * 8 > len) return -2;
+  memcpy(hashes, buf + here + pad, numFrames * 8);
+  if (here + pad + numFrames * 8 + 4 > len || memcmp(buf + here + pad + numFrames * 8, "cbir", 4) != 0) return -3;
+  return (long long)numFrames;
+}
+
+/* ---- DctVideoIndex: src/dctvideoindex.cpp ---------------------------------------------------------
+ * insertHashes filter (:61-111): drop hashes with < 5 ones or < 5 zeros (:89); when skip != 0 and
+ * lastFrame/2 > skip drop frames < skip or > lastFrame - skip (:93-95).  keep[i] = 1 if entry i enters the
+ * search tree.  Returns the number kept. */
+size_t orc_video_insert_filter(const int32_t* frames, const uint64_t* hashes, size_t n, int skip,
+                               uint8_t* keep) {
+  size_t m = 0;
+  if (n == 0) return 0;
+  int lastFrame = frames[n - 1];
+  for (size_t j = 0; j < n; ++j) {
+    keep[j] = 0;
+    int pc = __builtin_popcountll(hashes[j]);
+    if (pc < 5 || 64 - pc < 5) continue;
+    if (skip && lastFrame / 2 > skip) {
+      if (frames[j] < skip || frames[j] > lastFrame - skip) continue;
+    }
+    keep[j] = 1;
+    ++m;
+  }
+  return m;
+}
+
+/* RadixMap::indexOf (src/tree/radix.h:135-141) */
+static size_t radix_index_of(uint64_t hash, unsigned radix) {
+  uint64_t mask = radix >= 64 ? ~0ull : ((1ull << radix) - 1);
+  return (size_t)((hash >> 1) & mask);
+}
+
+typedef struct {
+  uint32_t id;
+  int32_t score, src_in, dst_in, len;
+} orc_vmatch;
+
+/* findFrame (:291-387): entries = tree values in insertion order (video index ascending, file order
+ * inside a video): evidx[], eframe[], ehash[]; mediaIds[] = _mediaId.  radix 0 = exact scan, > 0 = only
+ * the needle's bucket (reference approximation).  One result per matched video = its closest frame, first
+ * in scan order among equals (strict <, :351); results ascending video index (QMap). */
+long long orc_video_find_frame(const uint32_t* evidx, const int32_t* eframe, const uint64_t* ehash, size_t ne,
+                               const uint32_t* mediaIds, size_t nvid, unsigned radix, uint64_t hash,
+                               int thresh, int src_in, orc_vmatch* out, size_t cap) {
+  if (hash == 0) return 0;
+  int32_t* best = (int32_t*)malloc(sizeof(int32_t) * (nvid ? nvid : 1));
+  int32_t* bestf = (int32_t*)malloc(sizeof(int32_t) * (nvid ? nvid : 1));
+  for (size_t v = 0; v < nvid; ++v) best[v] = -1;
+  size_t bucket = radix_index_of(hash, radix);
+  for (size_t i = 0; i < ne; ++i) {
+    if (radix && radix_index_of(ehash[i], radix) != bucket) continue;
+    int d = __builtin_popcountll(hash ^ ehash[i]);
+    if (d < thresh) {
+      uint32_t v = evidx[i];
+      if (best[v] < 0 || d < best[v]) {
+        best[v] = d;
+        bestf[v] = eframe[i];
+      }
+    }
+  }
+  long long r = 0;
+  if (src_in < 0) src_in = 0;
+  for (size_t v = 0; v < nvid; ++v)
+    if (best[v] >= 0) {
+      if ((size_t)r < cap) {
+        out[r].id = mediaIds[v];
+        out[r].score = best[v];
+        out[r].src_in = src_in;
+        out[r].dst_in = bestf[v];
+        out[r].len = 1;
+      }
+      ++r;
+    }
+  free(best);
+  free(bestf);
+  return r;
+}
+
+typedef struct {
+  int32_t src, dst;
+} orc_range;
+static int cmp_range(const void* a, const void* b) {
+  int x = ((const orc_range*)a)->src, y = ((const orc_range*)b)->src;
+  return x < y ? -1 : x > y;
+}
+
+/* findVideo (:399-657).  Needle frames outside [skip, lastFrame - skip] are dropped unconditionally
+ * (:431); per needle frame and matched media the closest entry (first in scan order among equals, :499-502)
+ * contributes MatchRange(needle frame, entry frame); per media: ranges sorted by needle frame, numAdjacent
+ * counts |dstIn - previous dstIn| < 15 starting from 0 (:606-613), percentNear = numAdjacent*100/num,
+ * rejected when num < minFramesMatched or percentNear < minFramesNear, score = 100 - percentNear, range =
+ * first pair, len = max(src span, dst span).  Results ascending mediaId (QMap). */
+long long orc_video_find_video(const uint32_t* evidx, const int32_t* eframe, const uint64_t* ehash, size_t ne,
+                               const uint32_t* mediaIds, size_t nvid, unsigned radix, const int32_t* nframes,
+                               const uint64_t* nhashes, size_t nn, uint32_t needle_id, int thresh, int skip,
+                               int min_frames_matched, int min_frames_near, int filter_self, orc_vmatch* out,
+                               size_t cap) {
+  if (nn == 0) return 0;
+  /* per video index: list of ranges */
+  orc_range** rg = (orc_range**)calloc(nvid ? nvid : 1, sizeof(orc_range*));
+  size_t* rn = (size_t*)calloc(nvid ? nvid : 1, sizeof(size_t));
+  int32_t* best = (int32_t*)malloc(sizeof(int32_t) * (nvid ? nvid : 1));
+  int32_t* bestf = (int32_t*)malloc(sizeof(int32_t) * (nvid ? nvid : 1));
+  int lastFrame = nframes[nn - 1];
+  for (size_t q = 0; q < nn; ++q) {
+    int srcFrame = nframes[q];
+    if (srcFrame < skip || srcFrame > lastFrame - skip) continue;
+    for (size_t v = 0; v < nvid; ++v) best[v] = -1;
+    size_t bucket = radix_index_of(nhashes[q], radix);
+    for (size_t i = 0; i < ne; ++i) {
+      if (radix && radix_index_of(ehash[i], radix) != bucket) continue;
+      int d = __builtin_popcountll(nhashes[q] ^ ehash[i]);
+      if (d < thresh) {
+        uint32_t v = evidx[i];
+        if (filter_self && mediaIds[v] == needle_id) continue;
+        if (best[v] < 0 || d < best[v]) {
+          best[v] = d;
+          bestf[v] = eframe[i];
+        }
+      }
+    }
+    for (size_t v = 0; v < nvid; ++v)
+      if (best[v] >= 0) {
+        if (!rg[v]) rg[v] = (orc_range*)malloc(sizeof(orc_range) * nn);
+        rg[v][rn[v]].src = srcFrame;
+        rg[v][rn[v]].dst = bestf[v];
+        rn[v]++;
+      }
+  }
+  /* results keyed by media id ascending: order video indices by media id (ids are unique per video) */
+  size_t* order = (size_t*)malloc(sizeof(size_t) * (nvid ? nvid : 1));
+  for (size_t v = 0; v < nvid; ++v) order[v] = v;
+  for (size_t a = 1; a < nvid; ++a) { /* insertion sort: _mediaId is ascending in practice (:186) */
+    size_t x = order[a];
+    size_t b = a;
+    while (b > 0 && mediaIds[order[b - 1]] > mediaIds[x]) {
+      order[b] = order[b - 1];
+      --b;
+    }
+    order[b] = x;
+  }
+  long long r = 0;
+  for (size_t k = 0; k < nvid; ++k) {
+    size_t v = order[k];
+    if (!rn[v]) continue;
+    qsort(rg[v], rn[v], sizeof(orc_range), cmp_range);
+    int numAdjacent = 0, last = 0;
+    for (size_t i = 0; i < rn[v]; ++i) {
+      int frame = rg[v][i].dst;
+      if (abs(frame - last) < 15) numAdjacent++;
+      last = frame;
+    }
+    int num = (int)rn[v];
+    int percentNear = numAdjacent * 100 / num;
+    if (num < min_frames_matched) continue;
+    if (percentNear < min_frames_near) continue;
+    if ((size_t)r < cap) {
+      out[r].id = mediaIds[v];
+      out[r].score = 100 - percentNear;
+      out[r].src_in = rg[v][0].src;
+      out[r].dst_in = rg[v][0].dst;
+      int srcLen = rg[v][rn[v] - 1].src - rg[v][0].src;
+      int dstLen = rg[v][rn[v] - 1].dst - rg[v][0].dst;
+      out[r].len = srcLen > dstLen ? srcLen : dstLen;
+    }
+    ++r;
+  }
+  for (size_t v = 0; v < nvid; ++v) free(rg[v]);
+  free(order);
+  free(rg);
+  free(rn);
+  free(best);
+  free(bestf);
+  return r;
+}
+
+/* Media::makeVideoIndex frame de-dup (src/media.cpp:958-1024).  The first frame is always stored and
+ * does NOT enter the window (:958-965).  Every later frame is compared with the window of hashes seen
+ * since the last stored frame: it is stored (and the window cleared) when at least one window hash is
+ * >= threshold away (`close != window.size()`, :1003-1007) -- so with an empty window (right after the
+ * first frame) it is never stored -- and it is appended to the window in both cases (:1011).  The last
+ * frame is always stored (:1018-1024).  threshold <= 0 stores every frame.  keep[i] = 1 if frame i is
+ * stored; returns the number stored. */
+size_t orc_video_dedup(const uint64_t* hashes, size_t n, int threshold, uint8_t* keep) {
+  if (n == 0) return 0;
+  uint64_t* window = (uint64_t*)malloc(sizeof(uint64_t) * n);
+  size_t wlen = 0, kept = 1;
+  keep[0] = 1;
+  for (size_t i = 1; i < n; ++i) {
+    keep[i] = 0;
+    if (threshold > 0) {
+      size_t close = 0;
+      for (size_t k = 0; k < wlen; ++k)
+        if (__builtin_popcountll(window[k] ^ hashes[i]) < threshold) close++;
+      if (close != wlen) {
+        wlen = 0;
+        keep[i] = 1;
+      }
+      window[wlen++] = hashes[i];
+    } else {
+      keep[i] = 1;
+    }
+    kept += keep[i];
+  }
+  if (!keep[n - 1]) {
+    keep[n - 1] = 1;
+    ++kept;
+  }
+  free(window);
+  return kept;
 }

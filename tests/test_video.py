@@ -1,0 +1,199 @@
+"""DctVideoIndex / VideoIndex (src/dctvideoindex.cpp, src/videoindex.cpp): .vdx codec known answers from
+the reference's own test vectors (unit/testvideoindex.cpp:174-258), oracle vs the real RadixMap, product
+host code vs oracle on CPU, and the GPU find path vs oracle."""
+import numpy as np
+import pytest
+
+# the in-source vectors of unit/testvideoindex.cpp:174-258 (frames, hashes)
+KAT = [([0, 1, 2, 3], [4, 3, 2, 1]), ([0, 1, 2000, 2001], [4, 3, 2, 1]), ([0, 1, 2, 2000], [4, 3, 2, 1]),
+       ([0, 1000, 1001, 1002], [4, 3, 2, 1]), ([0, 1000, 2000, 3000], [4, 3, 2, 1]),
+       ([0, 1000, 1001, 2000, 2001, 3000, 3001, 4000], [4, 3, 2, 1, 1, 2, 3, 4])]
+
+
+@pytest.fixture(scope="module")
+def vorc():
+    from oracle import VideoOracle
+
+    return VideoOracle()
+
+
+def test_vdx_roundtrip_reference_vectors(vorc):
+    from cbird_amd.video import VideoIndex
+
+    for frames, hashes in KAT + [([], [])]:
+        data = vorc.vdx_encode(frames, hashes)
+        f, h = vorc.vdx_decode(data)
+        assert f.tolist() == frames and h.tolist() == hashes
+        # the product codec (host code of libcbird_hip.so) writes the same bytes and reads them back
+        vi = VideoIndex(frames, hashes)
+        assert vi.to_bytes() == data
+        back = VideoIndex.from_bytes(data)
+        assert back.frames == frames and back.hashes == hashes
+
+
+def test_vdx_byte_layout(vorc):
+    """hand-derived from save_v2 (videoindex.cpp:271-347) for frames {0,1,2000,2001}"""
+    data = vorc.vdx_encode([0, 1, 2000, 2001], [4, 3, 2, 1])
+    header = b"cbird video index:0.8.1:2:1:1:8:4:\n"
+    assert data.startswith(header)
+    # frame 0 -> 0x00; +1 -> 0x01; +1999 = 0b1111_1001111 -> 0xCF (0x4F|0x80), 0x0F; +1 -> 0x01
+    packed = bytes([0x00, 0x01, 0xCF, 0x0F, 0x01])
+    off = len(header)
+    assert data[off:off + 4] == (5).to_bytes(4, "little")
+    assert data[off + 4:off + 9] == packed
+    pad = (8 - (off + 4 + 5) % 8) % 8
+    hs = off + 9 + pad
+    assert data[off + 9:hs] == b"\0" * pad
+    assert data[hs:hs + 32] == b"".join(int(x).to_bytes(8, "little") for x in (4, 3, 2, 1))
+    assert data[hs + 32:] == b"cbir"
+
+
+def test_vdx_rejects_corruption(vorc):
+    from cbird_amd.video import VideoIndex
+
+    good = vorc.vdx_encode([0, 5, 9], [1, 2, 3])
+    for bad in (good[:-4], good[:-1], b"not a cbird video index:\n", good.replace(b":2:1:1:8:", b":3:1:1:8:")):
+        with pytest.raises(ValueError):
+            vorc.vdx_decode(bad)
+        with pytest.raises(ValueError):
+            VideoIndex.from_bytes(bad)
+    with pytest.raises(ValueError):
+        vorc.vdx_encode([1, 2], [1, 2])  # first frame must be 0
+    with pytest.raises(ValueError):
+        vorc.vdx_encode([0, 2, 2], [1, 2, 3])  # non-sequential
+
+
+def test_dedup_rule(vorc):
+    """src/media.cpp:958-1024 on a hand-made sequence (threshold 8)"""
+    from cbird_amd.video import make_video_index
+
+    a = 0x0F0F0F0F0F0F0F00
+    far = a ^ 0xFFFF  # 16 bits away
+    seq = [a, far, a ^ 1, a ^ 3, far, far ^ 1, a]
+    keep = vorc.dedup(seq, 8)
+    # frame0 stored; frame1 never (empty window); frame2: window={far}: far vs a^1 is 15 away -> stored;
+    # frame3: window={a^1}: 1 away -> dropped; frame4: window={a^1,a^3}: far -> stored; frame5: window={far}
+    # near -> dropped; frame6 (last): window={far,far^1}: far -> stored
+    assert keep.tolist() == [True, False, True, False, True, False, True]
+    vi = make_video_index(seq, 8)
+    assert vi.frames == [0, 2, 4, 6] and vi.hashes == [seq[0], seq[2], seq[4], seq[6]]
+    assert vorc.dedup(seq, 0).all()
+    rng = np.random.default_rng(1)
+    walk = np.cumsum(rng.integers(0, 2, 500)).astype(np.uint64) * np.uint64(0x0101010101010101)
+    k = vorc.dedup(walk, 8)
+    assert k[0] and k[-1]
+    assert make_video_index(walk, 8).frames == np.nonzero(k)[0].tolist()
+
+
+def test_oracle_candidates_vs_real_radixmap(vorc):
+    import oracle
+
+    if not oracle.ref_qt_available():
+        pytest.skip("oracle/_ref/libcbird_ref_qt.so not built")
+    from cbird_amd import synth_video
+
+    clips = synth_video.make_clips(40, 120, seed=5, subclip_frac=0.2)
+    videos = [(100 + i, f, h) for i, (f, h) in enumerate(clips)]
+    entries = vorc.build_entries(videos, skip=0)
+    ev, ef, eh, mids = entries
+    for radix in (0, 10):
+        rm = oracle.RefRadixMap(radix)
+        rm.insert(ev, ef.astype(np.uint32), eh)
+        for q in eh[::37].tolist():
+            rv, rf, rh, rd = rm.search(q, 6)
+            # reference findFrame reduction (dctvideoindex.cpp:346-356) over the real map's matches
+            nearest = {}
+            for v, f, d in zip(rv.tolist(), rf.tolist(), rd.tolist()):
+                if v not in nearest or d < nearest[v][0]:
+                    nearest[v] = (d, f)
+            want = [(int(mids[v]), d, 0, f, 1) for v, (d, f) in sorted(nearest.items())]
+            assert vorc.find_frame(entries, q, 6, -1, radix=radix) == want
+    # radix 10 returns a subset of radix 0
+    full = vorc.find_frame(entries, int(eh[5]), 9, -1, radix=0)
+    part = vorc.find_frame(entries, int(eh[5]), 9, -1, radix=10)
+    assert {x[0] for x in part} <= {x[0] for x in full}
+
+
+def test_insert_filter_rules(vorc):
+    frames = np.arange(0, 1000, 10, dtype=np.int32)  # lastFrame 990
+    hashes = np.full(100, 0x00FF00FF00FF00FF, np.uint64)
+    hashes[3] = 0xF  # 4 ones -> dropped
+    hashes[4] = ~np.uint64(0xF)  # 4 zeros -> dropped
+    keep = np.zeros(100, np.uint8)
+    vorc.L.orc_video_insert_filter(frames, hashes, 100, 300, keep)  # 990/2 > 300 -> trim both ends
+    want = (frames >= 300) & (frames <= 690)
+    assert keep.astype(bool).tolist() == want.tolist()
+    vorc.L.orc_video_insert_filter(frames, hashes, 100, 600, keep)  # 990/2 < 600 -> no trimming at all
+    want = np.ones(100, bool)
+    want[[3, 4]] = False
+    assert keep.astype(bool).tolist() == want.tolist()
+
+
+def _mk_index(gpu, clips, first_id=100):
+    from cbird_amd.video import DctVideoIndex, VideoIndex
+
+    idx = DctVideoIndex()
+
+    class M:
+        pass
+
+    media = []
+    for i, (f, h) in enumerate(clips):
+        m = M()
+        m.id, m.path, m.videoIndex, m.dctHash = first_id + i, f"v{i}", VideoIndex(f.tolist(), [int(x) for x in h]), 0
+        media.append(m)
+    idx.add(media)
+    return idx, media
+
+
+@pytest.mark.gpu
+def test_gpu_find_video_and_frame_vs_oracle(gpu, vorc):
+    from cbird_amd import synth_video
+    from cbird_amd.video import VideoSearchParams
+
+    clips = synth_video.make_clips(300, 300, seed=11, subclip_frac=0.1, max_gap=8)
+    idx, media = _mk_index(gpu, clips)
+    assert idx.count() == 300 and idx.isLoaded()
+    videos = [(m.id, f, h) for m, (f, h) in zip(media, clips)]
+    for skip, thr, vfm, vfn in ((0, 5, 30, 60), (0, 2, 5, 10), (40, 7, 10, 30)):
+        idx2, _ = _mk_index(gpu, clips)  # the tree is built once per index with the first query's vtrim
+        p = VideoSearchParams(dctThresh=thr, skipFrames=skip, minFramesMatched=vfm, minFramesNear=vfn)
+        entries = vorc.build_entries(videos, skip)
+        assert idx2.entries(skip) == len(entries[0])
+        n_hits = 0
+        for m in media[::7] + media[-30:]:
+            got = [(x.mediaId, x.score, x.range.srcIn, x.range.dstIn, x.range.len) for x in idx2.findVideo(m, p)]
+            want = vorc.find_video(entries, m.videoIndex.frames, m.videoIndex.hashes, m.id, thr, skip, vfm, vfn)
+            assert got == want, (m.id, skip, thr)
+            n_hits += len(got)
+        assert n_hits > 10
+        # image needle
+        for m in media[::29]:
+            m.dctHash = m.videoIndex.hashes[len(m.videoIndex.hashes) // 2]
+            got = [(x.mediaId, x.score, x.range.srcIn, x.range.dstIn, x.range.len) for x in idx2.findFrame(m, p)]
+            assert got == vorc.find_frame(entries, m.dctHash, thr, -1)
+    # video -> itself is the single result when filterSelf is off (unit/testdctvideoindex.cpp:73-76 shape)
+    p = VideoSearchParams(dctThresh=1, skipFrames=0, minFramesMatched=1, minFramesNear=1, filterSelf=False)
+    r = idx.findVideo(media[0], p)
+    assert [x.mediaId for x in r][:1] == [media[0].id] and r[0].score <= 10 and r[0].range.srcIn == 0
+
+
+@pytest.mark.gpu
+def test_gpu_video_batch_remove_add(gpu, vorc):
+    from cbird_amd import synth_video
+    from cbird_amd.video import VideoSearchParams
+
+    clips = synth_video.make_clips(120, 200, seed=3, subclip_frac=0.15, max_gap=8)
+    idx, media = _mk_index(gpu, clips)
+    p = VideoSearchParams(dctThresh=5, skipFrames=0, minFramesMatched=10, minFramesNear=30)
+    singles = [idx.findVideo(m, p) for m in media]
+    batch = idx.find_videos_batch(media, p)
+    key = lambda r: [(x.mediaId, x.score, x.range.srcIn, x.range.dstIn, x.range.len) for x in r]
+    assert [key(a) for a in singles] == [key(b) for b in batch]
+    victims = [m.id for m, r in zip(media, singles) if r][:2]
+    idx.remove(victims)
+    assert idx.count() == 118
+    for r in idx.find_videos_batch(media, p):
+        assert all(x.mediaId not in victims for x in r)
+    idx.add([m for m in media if m.id in victims])
+    assert idx.count() == 120
