@@ -98,6 +98,19 @@ _SIGS = {
     "cbh_vdx_encode": (_sz, [_vp, _vp, _sz, C.c_char_p, _vp, _sz]),
     "cbh_vdx_decode": (C.c_longlong, [_vp, _sz, _vp, _vp, _sz]),
     "cbh_video_dedup": (_sz, [_vp, _sz, C.c_int, _vp]),
+    "cbh_idx256_create": (_vp, [C.c_int]),
+    "cbh_idx256_destroy": (None, [_vp]),
+    "cbh_idx256_add": (C.c_int, [_vp, C.c_uint32, _vp, _sz]),
+    "cbh_idx256_remove": (C.c_int, [_vp, _vp, _sz]),
+    "cbh_idx256_is_loaded": (C.c_int, [_vp]),
+    "cbh_idx256_count": (_sz, [_vp]),
+    "cbh_idx256_memory_usage": (_sz, [_vp]),
+    "cbh_idx256_rows_of": (C.c_int, [_vp, C.c_uint32, C.POINTER(_sz), C.POINTER(_sz)]),
+    "cbh_idx256_download_rows": (C.c_int, [_vp, _sz, _sz, _vp]),
+    "cbh_idx256_knn": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "cbh_idx256_find": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _vp, _sz, C.POINTER(_sz)]),
+    "cbh_idx256_find_batch": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
+    "cbh_idx256_get_stats": (C.c_int, [_vp, C.POINTER(cbh_stats)]),
     "cbh_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "cbh_idx64_get_stats": (C.c_int, [_vp, C.POINTER(cbh_stats)]),
     "cbh_idx64_reset_stats": (C.c_int, [_vp]),

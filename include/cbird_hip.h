@@ -61,6 +61,7 @@ typedef uint64_t cbh_record;
 #define CBH_MAX_QUERIES_PER_CALL (1u << 25)
 
 typedef struct cbh_idx64 cbh_idx64; /* opaque: DctHashIndex state on one device */
+typedef struct cbh_idx256 cbh_idx256; /* opaque: CvFeaturesIndex state */
 
 /* ---- library ------------------------------------------------------------------------- */
 int cbh_version(void);
@@ -147,6 +148,7 @@ typedef struct cbh_stats {
 } cbh_stats;
 int cbh_idx64_get_stats(const cbh_idx64*, cbh_stats* out);
 int cbh_idx64_reset_stats(cbh_idx64*);
+int cbh_idx256_get_stats(const cbh_idx256*, cbh_stats* out);
 
 /* ---- DctFeaturesIndex: src/dctfeaturesindex.{h,cpp} over src/tree/hammingtree.h -----------------
  * The index is a cbh_idx64 whose entries are (mediaId, keypoint hash) pairs, several per media:
@@ -214,6 +216,34 @@ size_t cbh_vdx_encode(const int32_t* frames, const uint64_t* hashes, size_t n, c
 long long cbh_vdx_decode(const uint8_t* buf, size_t len, int32_t* frames, uint64_t* hashes, size_t cap);
 /* frame de-dup of Media::makeVideoIndex (src/media.cpp:958-1024); keep[i]=1 for stored frames */
 size_t cbh_video_dedup(const uint64_t* hashes, size_t n, int threshold, uint8_t* keep);
+
+/* ---- CvFeaturesIndex: src/cvfeaturesindex.{h,cpp} ---------------------------------------------------
+ * N x 32-byte ORB/BRIEF descriptor rows (cv::Mat CV_8U, cvfeaturesindex.h:73) + the first-row -> mediaId
+ * map (_indexMap/_idMap, :77-81).  Searches are exact brute force (the reference asks a FLANN LSH index,
+ * :497, which returns a subset). */
+cbh_idx256* cbh_idx256_create(int device);
+void cbh_idx256_destroy(cbh_idx256*);
+/* add() (:122-150): append one media's rows; n_rows == 0 is skipped ("no descriptors for ...").
+ * load() is add() per row of `select media_id,... from matrix`. */
+int cbh_idx256_add(cbh_idx256*, uint32_t media_id, const uint8_t* rows, size_t n_rows);
+/* remove() (:152-165): the map entry's id becomes 0, descriptors stay and keep taking knn places */
+int cbh_idx256_remove(cbh_idx256*, const uint32_t* ids, size_t n);
+int cbh_idx256_is_loaded(const cbh_idx256*);
+size_t cbh_idx256_count(const cbh_idx256*);        /* count() = _descriptors.rows (:103) */
+size_t cbh_idx256_memory_usage(const cbh_idx256*); /* memoryUsage() = 2 * rows * 32 (:105-120) */
+/* descriptorsForMediaId (:421-436): row range of a media; download of a row range */
+int cbh_idx256_rows_of(const cbh_idx256*, uint32_t media_id, size_t* first, size_t* count);
+int cbh_idx256_download_rows(const cbh_idx256*, size_t first, size_t count, uint8_t* out);
+/* exact `knnSearch(needles, k)` below thresh: out_row/out_dist[nq*k] ordered (distance, row), counts[nq] =
+ * rows under thresh.  nq < 2^23. */
+int cbh_idx256_knn(cbh_idx256*, const uint8_t* needles, size_t nq, int k, int thresh, uint32_t* out_row,
+                   uint16_t* out_dist, uint32_t* counts);
+/* find() (:438-604): knn k (reference: 10) per needle descriptor, distance < thresh (cvThresh), votes per
+ * media, score = median distance * 1000 / votes; results ascending mediaId. */
+int cbh_idx256_find(cbh_idx256*, const uint8_t* needle_rows, size_t n_desc, int thresh, int k, cbh_match* out,
+                    size_t cap, size_t* n_out);
+int cbh_idx256_find_batch(cbh_idx256*, const uint8_t* needle_rows, const uint64_t* offsets, size_t n_needles,
+                          int thresh, int k, cbh_match* out, size_t cap, uint64_t* out_offsets);
 
 /* Kernel-variant knobs for experiments (results never change, only speed):
  *   "scan_pre_max"  largest threshold served by the low-word-prefilter scan variant (default 7)

@@ -453,3 +453,40 @@ class RefRadixMap:
             self.L.ref_radix_destroy(self.h)
         except Exception:
             pass
+
+
+class CvOracle:
+    """oracle/cbird_oracle.c: exact 256-bit knn + CvFeaturesIndex::find scoring."""
+
+    def __init__(self) -> None:
+        build()
+        L = C.CDLL(_ORACLE_SO)
+        self.L = L
+        L.orc_knn256.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int, _u32p, _i32p, _u32p]
+        L.orc_knn256.restype = None
+        L.orc_cvfeatures_find.argtypes = [_u8p, C.c_size_t, _u32p, _u32p, C.c_size_t, _u8p, C.c_size_t, C.c_int,
+                                          C.c_int, _u32p, _i32p, C.c_size_t]
+        L.orc_cvfeatures_find.restype = C.c_longlong
+
+    def knn(self, rows, needles, k, thresh):
+        rows = np.ascontiguousarray(rows, np.uint8)
+        needles = np.ascontiguousarray(needles, np.uint8)
+        nq = len(needles)
+        r = np.zeros((nq, k), np.uint32)
+        d = np.zeros((nq, k), np.int32)
+        c = np.zeros(nq, np.uint32)
+        self.L.orc_knn256(rows.reshape(-1), len(rows), needles.reshape(-1), nq, k, thresh, r.reshape(-1),
+                          d.reshape(-1), c)
+        return r, d, c
+
+    def find(self, rows, first_row, media_id, needles, k, thresh):
+        rows = np.ascontiguousarray(rows, np.uint8)
+        needles = np.ascontiguousarray(needles, np.uint8)
+        fr = np.ascontiguousarray(first_row, np.uint32)
+        mi = np.ascontiguousarray(media_id, np.uint32)
+        cap = len(needles) * k + 1
+        oi = np.zeros(cap, np.uint32)
+        osc = np.zeros(cap, np.int32)
+        m = self.L.orc_cvfeatures_find(rows.reshape(-1), len(rows), fr, mi, len(fr), needles.reshape(-1),
+                                       len(needles), k, thresh, oi, osc, cap)
+        return oi[:m].copy(), osc[:m].copy()

@@ -782,3 +782,129 @@ size_t orc_video_dedup(const uint64_t* hashes, size_t n, int threshold, uint8_t*
   free(window);
   return kept;
 }
+
+/* ---- CvFeaturesIndex: src/cvfeaturesindex.cpp:438-604 ----------------------------------------------
+ * rows: N x 32 bytes (the cv::Mat of all ORB descriptors, cvfeaturesindex.h:73).  Exact brute-force
+ * statement of `_index->knnSearch(descriptors, indices, dists, 10)` followed by `distance < cvThresh`
+ * (:497-508): per needle row the k rows of smallest Hamming distance among those under thresh, ordered
+ * (distance, row) -- FLANN's LSH is approximate and its tie order unspecified.  counts[q] = rows under
+ * thresh. */
+static int hamm256(const uint8_t* a, const uint8_t* b) {
+  uint64_t x[4], y[4];
+  memcpy(x, a, 32);
+  memcpy(y, b, 32);
+  return __builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) +
+         __builtin_popcountll(x[2] ^ y[2]) + __builtin_popcountll(x[3] ^ y[3]);
+}
+
+typedef struct {
+  int32_t dist;
+  uint32_t row;
+} orc_nn;
+static int cmp_nn(const void* a, const void* b) {
+  const orc_nn* x = (const orc_nn*)a;
+  const orc_nn* y = (const orc_nn*)b;
+  if (x->dist != y->dist) return x->dist < y->dist ? -1 : 1;
+  return x->row < y->row ? -1 : x->row > y->row;
+}
+
+void orc_knn256(const uint8_t* rows, size_t n, const uint8_t* needles, size_t nq, int k, int thresh,
+                uint32_t* out_row, int32_t* out_dist, uint32_t* counts) {
+  orc_nn* c = (orc_nn*)malloc(sizeof(orc_nn) * (n ? n : 1));
+  for (size_t q = 0; q < nq; ++q) {
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i) {
+      int d = hamm256(needles + q * 32, rows + i * 32);
+      if (d < thresh) {
+        c[m].dist = d;
+        c[m].row = (uint32_t)i;
+        ++m;
+      }
+    }
+    qsort(c, m, sizeof(orc_nn), cmp_nn);
+    counts[q] = (uint32_t)m;
+    for (int j = 0; j < k; ++j) {
+      out_row[q * (size_t)k + j] = (size_t)j < m ? c[j].row : 0;
+      out_dist[q * (size_t)k + j] = (size_t)j < m ? c[j].dist : 0;
+    }
+  }
+  free(c);
+}
+
+static int cmp_int(const void* a, const void* b) {
+  int x = *(const int*)a, y = *(const int*)b;
+  return x < y ? -1 : x > y;
+}
+
+/* find(): first_row[nm] ascending / media_id[nm] = the _indexMap without its sentinel (media_id 0 =
+ * removed, :152-165).  Per needle row the knn above; row -> media by upper_bound - 1 (:514-516); votes per
+ * media; score = median(distances) * 1000 / votes with the integer rules of :579-592; results ascending
+ * mediaId.  Returns the number of results. */
+long long orc_cvfeatures_find(const uint8_t* rows, size_t n, const uint32_t* first_row, const uint32_t* media_id,
+                              size_t nm, const uint8_t* needles, size_t nq, int k, int thresh, uint32_t* out_ids,
+                              int32_t* out_scores, size_t cap) {
+  uint32_t* row = (uint32_t*)malloc(sizeof(uint32_t) * (nq * (size_t)k + 1));
+  int32_t* dist = (int32_t*)malloc(sizeof(int32_t) * (nq * (size_t)k + 1));
+  uint32_t* cnt = (uint32_t*)malloc(sizeof(uint32_t) * (nq + 1));
+  orc_knn256(rows, n, needles, nq, k, thresh, row, dist, cnt);
+  size_t maxv = nq * (size_t)k + 1;
+  uint32_t* vid = (uint32_t*)malloc(sizeof(uint32_t) * maxv);
+  int* vd = (int*)malloc(sizeof(int) * maxv);
+  size_t nv = 0;
+  for (size_t q = 0; q < nq; ++q) {
+    size_t len = cnt[q] < (uint32_t)k ? cnt[q] : (size_t)k;
+    for (size_t t = 0; t < len; ++t) {
+      uint32_t r = row[q * (size_t)k + t];
+      size_t lo = 0, hi = nm; /* upper_bound(r) */
+      while (lo < hi) {
+        size_t mid = (lo + hi) / 2;
+        if (first_row[mid] <= r)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      if (lo == 0) continue;
+      uint32_t id = media_id[lo - 1];
+      if (!id) continue;
+      vid[nv] = id;
+      vd[nv] = dist[q * (size_t)k + t];
+      ++nv;
+    }
+  }
+  uint32_t* uid = (uint32_t*)malloc(sizeof(uint32_t) * (nv ? nv : 1));
+  memcpy(uid, vid, sizeof(uint32_t) * nv);
+  qsort(uid, nv, sizeof(uint32_t), cmp_u32);
+  size_t nu = 0;
+  for (size_t i = 0; i < nv; ++i)
+    if (i == 0 || uid[i] != uid[i - 1]) uid[nu++] = uid[i];
+  long long r = 0;
+  int* sc = (int*)malloc(sizeof(int) * (nv ? nv : 1));
+  for (size_t u = 0; u < nu; ++u) {
+    size_t m = 0;
+    for (size_t i = 0; i < nv; ++i)
+      if (vid[i] == uid[u]) sc[m++] = vd[i];
+    qsort(sc, m, sizeof(int), cmp_int);
+    int score;
+    size_t middle = m / 2;
+    if (m < 2)
+      score = sc[0];
+    else if (m % 2 == 0)
+      score = (sc[middle - 1] + sc[middle]) / 2;
+    else
+      score = sc[middle];
+    score = score * 1000 / (int)m;
+    if ((size_t)r < cap) {
+      out_ids[r] = uid[u];
+      out_scores[r] = score;
+    }
+    ++r;
+  }
+  free(sc);
+  free(uid);
+  free(vd);
+  free(vid);
+  free(cnt);
+  free(dist);
+  free(row);
+  return r;
+}
