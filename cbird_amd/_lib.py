@@ -111,6 +111,17 @@ _SIGS = {
     "cbh_idx256_find": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _vp, _sz, C.POINTER(_sz)]),
     "cbh_idx256_find_batch": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
     "cbh_idx256_get_stats": (C.c_int, [_vp, C.POINTER(cbh_stats)]),
+    "cbh_color_create": (_vp, [C.c_int]),
+    "cbh_color_destroy": (None, [_vp]),
+    "cbh_color_add": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "cbh_color_remove": (C.c_int, [_vp, _vp, _sz]),
+    "cbh_color_count": (_sz, [_vp]),
+    "cbh_color_is_loaded": (C.c_int, [_vp]),
+    "cbh_color_memory_usage": (_sz, [_vp]),
+    "cbh_color_find_index_data": (C.c_int, [_vp, C.c_uint32, _vp]),
+    "cbh_color_download": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "cbh_color_find": (C.c_int, [_vp, _vp, _vp, _sz, C.POINTER(_sz)]),
+    "cbh_color_find_batch": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _vp]),
     "cbh_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "cbh_idx64_get_stats": (C.c_int, [_vp, C.POINTER(cbh_stats)]),
     "cbh_idx64_reset_stats": (C.c_int, [_vp]),

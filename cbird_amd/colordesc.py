@@ -1,0 +1,99 @@
+"""Host-side mirror of ColorDescIndex / ColorDescriptor (src/colordescindex.{h,cpp}, src/cvutil.h:57-113).
+Descriptor *creation* (k-means over Luv pixels, src/cvutil.cpp:790-1099, non-deterministic by the reference's
+own account) is outside the hot path; descriptors are the reference's 258-byte records."""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+
+import numpy as np
+
+from . import _lib
+from ._lib import CbhError, cbh_match, check
+from .index import Match, SearchParams
+
+DESC_BYTES = 258
+COLOR_DTYPE = np.dtype([("colors", np.uint16, (32, 4)), ("numColors", np.uint8), ("_pad", np.uint8)])
+assert COLOR_DTYPE.itemsize == DESC_BYTES
+
+
+def make_descriptor(luvw, num_colors=None) -> np.ndarray:
+    """luvw: [n<=32, 4] uint16 rows (l,u,v,w compressed as in DescriptorColor) -> one 258-byte record"""
+    d = np.zeros((), COLOR_DTYPE)
+    luvw = np.asarray(luvw, np.uint16).reshape(-1, 4)
+    d["colors"][: len(luvw)] = luvw
+    d["numColors"] = len(luvw) if num_colors is None else num_colors
+    return d
+
+
+class ColorDescIndex:
+    def __init__(self, device: int = 0) -> None:
+        self._L = _lib.lib()
+        self._id = SearchParams.AlgoColor
+        self._h = self._L.cbh_color_create(device)
+        if not self._h:
+            raise CbhError(_lib.CBH_E_NODEVICE, "cbh_color_create")
+
+    def __del__(self) -> None:
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.cbh_color_destroy(h)
+
+    def id(self) -> int:
+        return self._id
+
+    def isLoaded(self) -> bool:
+        return bool(self._L.cbh_color_is_loaded(self._h))
+
+    def count(self) -> int:
+        return int(self._L.cbh_color_count(self._h))
+
+    def memoryUsage(self) -> int:
+        return int(self._L.cbh_color_memory_usage(self._h))
+
+    def add(self, media) -> None:
+        media = list(media)
+        if not media:
+            return
+        ids = np.ascontiguousarray([m.id for m in media], np.uint32)
+        descs = np.ascontiguousarray(np.stack([np.asarray(m.colorDescriptor, COLOR_DTYPE) for m in media]))
+        check(self._L.cbh_color_add(self._h, ids.ctypes.data, descs.ctypes.data, len(ids)), "add")
+
+    load = add
+
+    def remove(self, ids) -> None:
+        i = np.ascontiguousarray(list(ids), np.uint32)
+        check(self._L.cbh_color_remove(self._h, i.ctypes.data, len(i)), "remove")
+
+    def findIndexData(self, m) -> bool:
+        d = np.zeros((), COLOR_DTYPE)
+        buf = np.zeros(DESC_BYTES, np.uint8)
+        if self._L.cbh_color_find_index_data(self._h, m.id, buf.ctypes.data) == 1:
+            m.colorDescriptor = buf.view(COLOR_DTYPE)[0]
+            return True
+        return False
+
+    def find(self, m, p: SearchParams | None = None):
+        target = getattr(m, "colorDescriptor", None)
+        if target is None or int(np.asarray(target, COLOR_DTYPE)["numColors"]) <= 0:
+            if not self.findIndexData(m):
+                warnings.warn(f"needle has no color descriptor {m.id} {m.path}")
+                return []
+            target = m.colorDescriptor
+            if int(target["numColors"]) <= 0:
+                return []
+        t = np.ascontiguousarray(np.asarray(target, COLOR_DTYPE).reshape(1))
+        cap = max(1, self.count())
+        buf = (cbh_match * cap)()
+        n = C.c_size_t(0)
+        check(self._L.cbh_color_find(self._h, t.ctypes.data, buf, cap, C.byref(n)), "find")
+        return [Match(buf[i].id, buf[i].score) for i in range(n.value)]
+
+    def find_batch(self, descs, k: int):
+        d = np.ascontiguousarray(np.asarray(descs, COLOR_DTYPE).reshape(-1))
+        nq = len(d)
+        out = np.zeros((nq, max(k, 1), 2), np.uint32)
+        counts = np.zeros(nq, np.uint32)
+        check(self._L.cbh_color_find_batch(self._h, d.ctypes.data, nq, k, out.ctypes.data, counts.ctypes.data),
+              "find_batch")
+        return out[:, :k, 0].copy(), out[:, :k, 1].astype(np.int32), counts

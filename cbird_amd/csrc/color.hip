@@ -1,0 +1,370 @@
+// color.hip -- ColorDescIndex (src/colordescindex.{h,cpp}) and ColorDescriptor::distance
+// (src/cvutil.cpp:682-749) on gfx950.
+//
+// Reference: a descriptor is 32 x {L,u,v,w : u16} + numColors : u8 (258 bytes, src/cvutil.h:57-113);
+// find() is a linear scan of distance(target, desc[i]) over the whole index (colordescindex.cpp:250-278):
+//   skip when either side has 0 colours or the counts differ by more than 2 (:683-684);
+//   a := the side with more colours (:697-706); score = 1 + sum_{i<numA} min_{j<numB} |a_i - b_j|_2 in
+//   float, colours decompressed as l=L*100/65535, u=U*354/65535-134, v=V*262/65535-140 (cvutil.h:83-87);
+//   Match(id, int(score)) for id != 0, in index order.
+//
+// Layout: the index is stored decompressed and planar -- l/u/v[32][capacity] f32, num[capacity] u8 -- so that a
+// wave reads each colour plane with unit stride (the 258-byte AoS record would give every lane its own cache
+// line).  k_color_dist: one lane per haystack descriptor; the needle's (<= 32) colours are wave-uniform SGPR
+// operands.  Per colour pair 3 sub, 3 mul, 2 add in the reference's association order (no FMA contraction:
+// the library is built with -ffp-contract=off), one running minimum per needle colour and one per haystack
+// colour (either side can be "a"); sqrtf is monotonic, so it is applied to the 32 minima instead of the 1024
+// pair distances (bit-identical result), then summed in index order starting from 1.0f.
+#include <hipcub/hipcub.hpp>
+
+#include <cfloat>
+#include <map>
+
+#include "cbh_index.h"
+
+namespace {
+
+constexpr int kNC = 32;  // ColorDescriptor::NUM_DESC_COLORS
+constexpr size_t kDescBytes = 258;
+
+struct NeedleF {
+  float l[kNC], u[kNC], v[kNC];
+  int num;
+};
+
+__global__ __launch_bounds__(256) void k_color_dist(const float* __restrict__ L, const float* __restrict__ U,
+                                                    const float* __restrict__ V,
+                                                    const unsigned char* __restrict__ num, size_t stride,
+                                                    uint32_t n, const NeedleF* __restrict__ needles,
+                                                    int* __restrict__ out /* [nq][n] */) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const NeedleF& nd = needles[blockIdx.y];  // wave-uniform
+  const int nn = nd.num;
+  const int hn = i < n ? (int)num[i] : 0;
+  float rowmin[kNC];
+#pragma unroll
+  for (int p = 0; p < kNC; ++p) rowmin[p] = FLT_MAX;
+  float colacc = 1.0f;
+  for (int h = 0; h < kNC; ++h) {
+    if (__ballot(h < hn) == 0ull) break;  // no lane of this wave has that many colours
+    const bool hv_ok = h < hn;
+    const float hl = hv_ok ? L[(size_t)h * stride + i] : 0.f;
+    const float hu = hv_ok ? U[(size_t)h * stride + i] : 0.f;
+    const float hv = hv_ok ? V[(size_t)h * stride + i] : 0.f;
+    float colmin = FLT_MAX;
+#pragma unroll
+    for (int p = 0; p < kNC; ++p) {
+      if (p < nn) {  // scalar branch
+        const float dl = nd.l[p] - hl, du = nd.u[p] - hu, dv = nd.v[p] - hv;
+        const float d2 = dl * dl + du * du + dv * dv;
+        rowmin[p] = fminf(rowmin[p], hv_ok ? d2 : FLT_MAX);
+        colmin = fminf(colmin, d2);
+      }
+    }
+    if (hv_ok) colacc += sqrtf(colmin);  // used when the haystack side is "a" (more colours)
+  }
+  int result = -1;
+  if (i < n && nn != 0 && hn != 0 && abs(nn - hn) <= 2) {
+    float score;
+    if (nn < hn) {
+      score = colacc;
+    } else {
+      score = 1.0f;
+#pragma unroll
+      for (int p = 0; p < kNC; ++p)
+        if (p < nn) score += sqrtf(rowmin[p]);
+    }
+    result = (int)score;
+  }
+  if (i < n) out[(size_t)blockIdx.y * n + i] = result;
+}
+
+// key = score<<32 | id for entries that match (score >= 0, id != 0), ~0 otherwise
+__global__ __launch_bounds__(256) void k_color_keys(const int* __restrict__ score,
+                                                    const uint32_t* __restrict__ ids, uint32_t n,
+                                                    unsigned long long* __restrict__ keys) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int s = score[i];
+  const uint32_t id = ids[i];
+  keys[i] = (s >= 0 && id != 0) ? (((unsigned long long)(uint32_t)s << 32) | id) : ~0ull;
+}
+
+void decompress(const uint8_t* desc, NeedleF* out) {  // DescriptorColor::get, cvutil.h:83-87
+  for (int c = 0; c < kNC; ++c) {
+    uint16_t l, u, v;
+    memcpy(&l, desc + c * 8 + 0, 2);
+    memcpy(&u, desc + c * 8 + 2, 2);
+    memcpy(&v, desc + c * 8 + 4, 2);
+    out->l[c] = l * 100.0f / 65535;
+    out->u[c] = u * 354.0f / 65535 - 134.0f;
+    out->v[c] = v * 262.0f / 65535 - 140.0f;
+  }
+  out->num = desc[256];
+}
+
+}  // namespace
+
+struct cbh_color {
+  int device = 0;
+  size_t n = 0, cap = 0;
+  float *dL = nullptr, *dU = nullptr, *dV = nullptr;  // [32][cap]
+  unsigned char* d_num = nullptr;
+  uint32_t* d_ids = nullptr;
+  std::vector<uint8_t> host_desc;  // AoS copy for findIndexData / slice (258 B each)
+  std::vector<uint32_t> host_ids;
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  NeedleF* d_needles = nullptr;
+  size_t needles_cap = 0;
+  int* d_scores = nullptr;
+  size_t scores_cap = 0;
+  unsigned long long *d_keys = nullptr, *d_keys_alt = nullptr;
+  void* d_tmp = nullptr;
+  size_t keys_cap = 0, tmp_bytes = 0;
+};
+
+namespace {
+
+int grow_index(cbh_color* c, size_t need) {
+  if (need <= c->cap) return CBH_OK;
+  const size_t ncap = std::max<size_t>(need, c->cap + c->cap / 2 + 4096);
+  float *nL = nullptr, *nU = nullptr, *nV = nullptr;
+  unsigned char* nn = nullptr;
+  uint32_t* ni = nullptr;
+  CBH_HIP(hipMalloc(&nL, ncap * kNC * 4));
+  CBH_HIP(hipMalloc(&nU, ncap * kNC * 4));
+  CBH_HIP(hipMalloc(&nV, ncap * kNC * 4));
+  CBH_HIP(hipMalloc(&nn, ncap));
+  CBH_HIP(hipMalloc(&ni, ncap * 4));
+  if (c->n) {
+    CBH_HIP(hipMemcpy2D(nL, ncap * 4, c->dL, c->cap * 4, c->n * 4, kNC, hipMemcpyDeviceToDevice));
+    CBH_HIP(hipMemcpy2D(nU, ncap * 4, c->dU, c->cap * 4, c->n * 4, kNC, hipMemcpyDeviceToDevice));
+    CBH_HIP(hipMemcpy2D(nV, ncap * 4, c->dV, c->cap * 4, c->n * 4, kNC, hipMemcpyDeviceToDevice));
+    CBH_HIP(hipMemcpy(nn, c->d_num, c->n, hipMemcpyDeviceToDevice));
+    CBH_HIP(hipMemcpy(ni, c->d_ids, c->n * 4, hipMemcpyDeviceToDevice));
+  }
+  for (void* p : {(void*)c->dL, (void*)c->dU, (void*)c->dV, (void*)c->d_num, (void*)c->d_ids})
+    if (p) (void)hipFree(p);
+  c->dL = nL;
+  c->dU = nU;
+  c->dV = nV;
+  c->d_num = nn;
+  c->d_ids = ni;
+  c->cap = ncap;
+  return CBH_OK;
+}
+
+// upload host descriptors [first, first+m) into the planar device arrays
+int upload(cbh_color* c, size_t first, size_t m) {
+  std::vector<float> pl((size_t)kNC * m), pu((size_t)kNC * m), pv((size_t)kNC * m);
+  std::vector<unsigned char> pn(m);
+  NeedleF f;
+  for (size_t i = 0; i < m; ++i) {
+    decompress(c->host_desc.data() + (first + i) * kDescBytes, &f);
+    for (int k = 0; k < kNC; ++k) {
+      pl[(size_t)k * m + i] = f.l[k];
+      pu[(size_t)k * m + i] = f.u[k];
+      pv[(size_t)k * m + i] = f.v[k];
+    }
+    pn[i] = (unsigned char)f.num;
+  }
+  CBH_HIP(hipMemcpy2D(c->dL + first, c->cap * 4, pl.data(), m * 4, m * 4, kNC, hipMemcpyHostToDevice));
+  CBH_HIP(hipMemcpy2D(c->dU + first, c->cap * 4, pu.data(), m * 4, m * 4, kNC, hipMemcpyHostToDevice));
+  CBH_HIP(hipMemcpy2D(c->dV + first, c->cap * 4, pv.data(), m * 4, m * 4, kNC, hipMemcpyHostToDevice));
+  CBH_HIP(hipMemcpy(c->d_num + first, pn.data(), m, hipMemcpyHostToDevice));
+  CBH_HIP(hipMemcpy(c->d_ids + first, c->host_ids.data() + first, m * 4, hipMemcpyHostToDevice));
+  return CBH_OK;
+}
+
+int ensure_scratch(cbh_color* c, size_t nq, bool keys) {
+  if (!c->stream) CBH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  if (nq > c->needles_cap) {
+    if (c->d_needles) (void)hipFree(c->d_needles);
+    c->d_needles = nullptr;
+    CBH_HIP(hipMalloc(&c->d_needles, nq * sizeof(NeedleF)));
+    c->needles_cap = nq;
+  }
+  if (nq * c->n > c->scores_cap) {
+    if (c->d_scores) (void)hipFree(c->d_scores);
+    c->d_scores = nullptr;
+    CBH_HIP(hipMalloc(&c->d_scores, nq * c->n * 4));
+    c->scores_cap = nq * c->n;
+  }
+  if (keys && c->n > c->keys_cap) {
+    for (void* p : {(void*)c->d_keys, (void*)c->d_keys_alt, c->d_tmp})
+      if (p) (void)hipFree(p);
+    c->d_keys = c->d_keys_alt = nullptr;
+    c->d_tmp = nullptr;
+    CBH_HIP(hipMalloc(&c->d_keys, c->n * 8));
+    CBH_HIP(hipMalloc(&c->d_keys_alt, c->n * 8));
+    c->tmp_bytes = cbh::sort_records_scratch_bytes(c->n);
+    CBH_HIP(hipMalloc(&c->d_tmp, c->tmp_bytes ? c->tmp_bytes : 16));
+    c->keys_cap = c->n;
+  }
+  return CBH_OK;
+}
+
+// scores of nq needles against the whole index -> c->d_scores [nq][n] (enqueued on c->stream)
+int run_dist(cbh_color* c, const uint8_t* needle_descs, size_t nq) {
+  std::vector<NeedleF> nf(nq);
+  for (size_t q = 0; q < nq; ++q) decompress(needle_descs + q * kDescBytes, &nf[q]);
+  CBH_HIP(hipMemcpyAsync(c->d_needles, nf.data(), nq * sizeof(NeedleF), hipMemcpyHostToDevice, c->stream));
+  CBH_HIP(hipStreamSynchronize(c->stream));  // nf is a stack-lifetime buffer
+  dim3 grid((unsigned)((c->n + 255) / 256), (unsigned)nq), block(256);
+  hipLaunchKernelGGL(k_color_dist, grid, block, 0, c->stream, c->dL, c->dU, c->dV, c->d_num, c->cap,
+                     (uint32_t)c->n, c->d_needles, c->d_scores);
+  CBH_HIP(hipGetLastError());
+  return CBH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+cbh_color* cbh_color_create(int device) {
+  if (!cbh::device_usable(device)) return nullptr;
+  cbh_color* c = new (std::nothrow) cbh_color;
+  if (c) c->device = device;
+  return c;
+}
+
+void cbh_color_destroy(cbh_color* c) {
+  if (!c) return;
+  cbh::DeviceGuard g(c->device);
+  for (void* p : {(void*)c->dL, (void*)c->dU, (void*)c->dV, (void*)c->d_num, (void*)c->d_ids, (void*)c->d_needles,
+                  (void*)c->d_scores, (void*)c->d_keys, (void*)c->d_keys_alt, c->d_tmp})
+    if (p) (void)hipFree(p);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+/* add()/load(): append n (mediaId, ColorDescriptor) entries (colordescindex.cpp:123-168, 201-213) */
+int cbh_color_add(cbh_color* c, const uint32_t* ids, const void* descs, size_t n) {
+  if (!c || (n && (!ids || !descs))) return CBH_E_INVAL;
+  if (n == 0) return CBH_OK;
+  cbh::DeviceGuard g(c->device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  std::lock_guard<std::mutex> lk(c->mu);
+  const size_t first = c->n;
+  c->host_desc.insert(c->host_desc.end(), (const uint8_t*)descs, (const uint8_t*)descs + n * kDescBytes);
+  c->host_ids.insert(c->host_ids.end(), ids, ids + n);
+  int rc = grow_index(c, first + n);
+  if (rc) return rc;
+  c->n = first + n;
+  return upload(c, first, n);
+}
+
+/* remove(): id 0 and cleared descriptor in place (:215-229) */
+int cbh_color_remove(cbh_color* c, const uint32_t* ids, size_t n) {
+  if (!c || (n && !ids)) return CBH_E_INVAL;
+  if (c->n == 0 || n == 0) return CBH_OK;  // `if (!isLoaded()) return;`
+  cbh::DeviceGuard g(c->device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  std::lock_guard<std::mutex> lk(c->mu);
+  std::vector<uint32_t> rm(ids, ids + n);
+  std::sort(rm.begin(), rm.end());
+  for (size_t i = 0; i < c->n; ++i)
+    if (std::binary_search(rm.begin(), rm.end(), c->host_ids[i])) {
+      c->host_ids[i] = 0;
+      memset(c->host_desc.data() + i * kDescBytes, 0, kDescBytes);
+      int rc = upload(c, i, 1);
+      if (rc) return rc;
+    }
+  return CBH_OK;
+}
+
+size_t cbh_color_count(const cbh_color* c) { return c ? c->n : 0; }
+int cbh_color_is_loaded(const cbh_color* c) { return c && c->n > 0; }  // `_count > 0` (:114)
+size_t cbh_color_memory_usage(const cbh_color* c) { return c ? (kDescBytes + 4) * c->n : 0; }  // (:118-121)
+
+/* findIndexData (:231-239): first entry with that id */
+int cbh_color_find_index_data(const cbh_color* c, uint32_t id, void* out_desc) {
+  if (!c || !out_desc) return CBH_E_INVAL;
+  for (size_t i = 0; i < c->n; ++i)
+    if (c->host_ids[i] == id) {
+      memcpy(out_desc, c->host_desc.data() + i * kDescBytes, kDescBytes);
+      return 1;
+    }
+  return 0;
+}
+
+int cbh_color_download(const cbh_color* c, uint32_t* ids, void* descs, size_t cap) {
+  if (!c) return CBH_E_INVAL;
+  const size_t m = std::min(cap, c->n);
+  if (ids) memcpy(ids, c->host_ids.data(), m * 4);
+  if (descs) memcpy(descs, c->host_desc.data(), m * kDescBytes);
+  return CBH_OK;
+}
+
+/* find() (:250-278): every entry with a finite distance and id != 0, index order, score = int(distance) */
+int cbh_color_find(cbh_color* c, const void* needle_desc, cbh_match* out, size_t cap, size_t* n_out) {
+  if (!c || !needle_desc || !n_out || (cap && !out)) return CBH_E_INVAL;
+  *n_out = 0;
+  if (((const uint8_t*)needle_desc)[256] == 0 || c->n == 0) return CBH_OK;  // no colours (:259-266)
+  cbh::DeviceGuard g(c->device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  std::lock_guard<std::mutex> lk(c->mu);
+  int rc = ensure_scratch(c, 1, false);
+  if (rc) return rc;
+  rc = run_dist(c, (const uint8_t*)needle_desc, 1);
+  if (rc) return rc;
+  std::vector<int> sc(c->n);
+  CBH_HIP(hipMemcpyAsync(sc.data(), c->d_scores, c->n * 4, hipMemcpyDeviceToHost, c->stream));
+  CBH_HIP(hipStreamSynchronize(c->stream));
+  size_t m = 0;
+  for (size_t i = 0; i < c->n; ++i)
+    if (sc[i] >= 0 && c->host_ids[i] != 0) {
+      if (m < cap) out[m] = cbh_match{c->host_ids[i], sc[i]};
+      ++m;
+    }
+  *n_out = m;
+  return CBH_OK;
+}
+
+/* find() for many needles + the sort/cut of searchIndex (database.cpp:1729-1735): out[q*k..] = first
+ * min(counts[q], k) matches in (score, id) order, counts[q] = all matches */
+int cbh_color_find_batch(cbh_color* c, const void* needle_descs, size_t nq, int k, cbh_match* out,
+                         uint32_t* counts) {
+  if (!c || k < 0 || (nq && (!needle_descs || !counts || (k && !out)))) return CBH_E_INVAL;
+  if (nq == 0) return CBH_OK;
+  memset(counts, 0, nq * 4);
+  if (k) memset(out, 0, nq * (size_t)k * sizeof(cbh_match));
+  if (c->n == 0) return CBH_OK;
+  cbh::DeviceGuard g(c->device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  std::lock_guard<std::mutex> lk(c->mu);
+  const size_t chunk = std::max<size_t>(1, std::min<size_t>(nq, ((size_t)1 << 28) / c->n));  // <= 1 GiB of scores
+  int rc = ensure_scratch(c, chunk, true);
+  if (rc) return rc;
+  std::vector<unsigned long long> head((size_t)k + 1);
+  for (size_t q0 = 0; q0 < nq; q0 += chunk) {
+    const size_t m = std::min(chunk, nq - q0);
+    rc = run_dist(c, (const uint8_t*)needle_descs + q0 * kDescBytes, m);
+    if (rc) return rc;
+    for (size_t q = 0; q < m; ++q) {
+      hipLaunchKernelGGL(k_color_keys, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
+                         c->d_scores + q * c->n, c->d_ids, (uint32_t)c->n, c->d_keys);
+      hipcub::DoubleBuffer<unsigned long long> db(c->d_keys, c->d_keys_alt);
+      size_t tb = c->tmp_bytes;
+      CBH_HIP(hipcub::DeviceRadixSort::SortKeys(c->d_tmp, tb, db, c->n, 0, 64, c->stream));
+      // count = number of keys != ~0: binary search on the host side would need the data; read the head
+      // and count valid scores separately
+      const size_t take = std::min<size_t>((size_t)k, c->n);
+      if (take)
+        CBH_HIP(hipMemcpyAsync(head.data(), db.Current(), take * 8, hipMemcpyDeviceToHost, c->stream));
+      std::vector<int> sc;
+      sc.resize(c->n);
+      CBH_HIP(hipMemcpyAsync(sc.data(), c->d_scores + q * c->n, c->n * 4, hipMemcpyDeviceToHost, c->stream));
+      CBH_HIP(hipStreamSynchronize(c->stream));
+      uint32_t cnt = 0;
+      for (size_t i = 0; i < c->n; ++i) cnt += (sc[i] >= 0 && c->host_ids[i] != 0);
+      counts[q0 + q] = cnt;
+      for (size_t j = 0; j < take && j < cnt; ++j)
+        out[(q0 + q) * (size_t)k + j] = cbh_match{(uint32_t)head[j], (int32_t)(head[j] >> 32)};
+    }
+  }
+  return CBH_OK;
+}
+
+}  // extern "C"

@@ -245,6 +245,27 @@ int cbh_idx256_find(cbh_idx256*, const uint8_t* needle_rows, size_t n_desc, int 
 int cbh_idx256_find_batch(cbh_idx256*, const uint8_t* needle_rows, const uint64_t* offsets, size_t n_needles,
                           int thresh, int k, cbh_match* out, size_t cap, uint64_t* out_offsets);
 
+/* ---- ColorDescIndex: src/colordescindex.{h,cpp}; ColorDescriptor: src/cvutil.h:57-113 -----------------
+ * A descriptor is the reference's 258-byte struct: 32 x {l,u,v,w : uint16} + numColors : uint8 (+1 pad). */
+#define CBH_COLOR_DESC_BYTES 258
+typedef struct cbh_color cbh_color;
+cbh_color* cbh_color_create(int device);
+void cbh_color_destroy(cbh_color*);
+int cbh_color_add(cbh_color*, const uint32_t* ids, const void* descs, size_t n); /* load/add :123-168,201-213 */
+int cbh_color_remove(cbh_color*, const uint32_t* ids, size_t n);                  /* remove :215-229 */
+size_t cbh_color_count(const cbh_color*);
+int cbh_color_is_loaded(const cbh_color*);                                       /* _count > 0 (:114) */
+size_t cbh_color_memory_usage(const cbh_color*);                                 /* (258 + 4) * count (:118-121) */
+int cbh_color_find_index_data(const cbh_color*, uint32_t id, void* out_desc);    /* :231-239; returns 1/0 */
+int cbh_color_download(const cbh_color*, uint32_t* ids, void* descs, size_t cap);
+/* find() (:250-278) with ColorDescriptor::distance (src/cvutil.cpp:682-749): every entry whose distance is
+ * finite (both sides have colours, counts differ by <= 2) and whose id != 0, in index order,
+ * score = int(1 + sum of nearest-colour distances).  Bit-exact to the reference's float arithmetic. */
+int cbh_color_find(cbh_color*, const void* needle_desc, cbh_match* out, size_t cap, size_t* n_out);
+/* many needles + the sort/cut of Database::searchIndex: first min(counts[q], k) matches by (score, id) */
+int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k, cbh_match* out,
+                         uint32_t* counts);
+
 /* Kernel-variant knobs for experiments (results never change, only speed):
  *   "scan_pre_max"  largest threshold served by the low-word-prefilter scan variant (default 7)
  *   "scan_eq_dht1"  1 = dht==1 uses the 64-bit equality variant (default 1) */

@@ -490,3 +490,31 @@ class CvOracle:
         m = self.L.orc_cvfeatures_find(rows.reshape(-1), len(rows), fr, mi, len(fr), needles.reshape(-1),
                                        len(needles), k, thresh, oi, osc, cap)
         return oi[:m].copy(), osc[:m].copy()
+
+
+class ColorOracle:
+    """oracle/cbird_oracle.c: ColorDescriptor::distance / ColorDescIndex::find"""
+
+    def __init__(self) -> None:
+        build()
+        L = C.CDLL(_ORACLE_SO)
+        self.L = L
+        L.orc_color_distance.argtypes = [_u8p, _u8p]
+        L.orc_color_distance.restype = C.c_float
+        L.orc_color_find.argtypes = [_u8p, _u32p, C.c_size_t, _u8p, _u32p, _i32p, C.c_size_t]
+        L.orc_color_find.restype = C.c_longlong
+
+    @staticmethod
+    def _bytes(d):
+        return np.ascontiguousarray(np.frombuffer(np.ascontiguousarray(d).tobytes(), np.uint8))
+
+    def distance(self, a, b) -> float:
+        return float(self.L.orc_color_distance(self._bytes(a), self._bytes(b)))
+
+    def find(self, descs, ids, target):
+        ids = np.ascontiguousarray(ids, np.uint32)
+        cap = max(1, len(ids))
+        oi = np.zeros(cap, np.uint32)
+        osc = np.zeros(cap, np.int32)
+        m = self.L.orc_color_find(self._bytes(descs), ids, len(ids), self._bytes(target), oi, osc, cap)
+        return oi[:m].copy(), osc[:m].copy()

@@ -908,3 +908,69 @@ long long orc_cvfeatures_find(const uint8_t* rows, size_t n, const uint32_t* fir
   free(row);
   return r;
 }
+
+/* ---- ColorDescriptor::distance + ColorDescIndex::find: src/cvutil.cpp:682-749, src/colordescindex.cpp:250-278
+ * desc: 258 bytes = 32 x {l,u,v,w : u16} + numColors : u8 + 1 pad (src/cvutil.h:57-113).  Compiled with
+ * -ffp-contract=off: the reference's release build has no -march flag (cbird.pri:198-217), so its float
+ * expressions are evaluated without FMA, left to right. */
+static void color_get(const uint8_t* desc, int i, float* l_, float* u_, float* v_) {
+  uint16_t l, u, v;
+  memcpy(&l, desc + i * 8 + 0, 2);
+  memcpy(&u, desc + i * 8 + 2, 2);
+  memcpy(&v, desc + i * 8 + 4, 2);
+  *l_ = l * 100.0f / 65535;
+  *u_ = u * 354.0f / 65535 - 134.0f;
+  *v_ = v * 262.0f / 65535 - 140.0f;
+}
+
+float orc_color_distance(const uint8_t* a_, const uint8_t* b_) {
+  int na = a_[256], nb = b_[256];
+  if (na == 0 || nb == 0 || abs(na - nb) > 2) return 3.402823466e+38F; /* FLT_MAX */
+  const uint8_t *a, *b;
+  if (na < nb) {
+    a = b_;
+    b = a_;
+  } else {
+    a = a_;
+    b = b_;
+  }
+  const int numA = a[256], numB = b[256];
+  float minDist[32];
+  for (int i = 0; i < numA; i++) {
+    minDist[i] = 3.402823466e+38F;
+    float l1, u1, v1;
+    color_get(a, i, &l1, &u1, &v1);
+    for (int j = 0; j < numB; j++) {
+      float l2, u2, v2;
+      color_get(b, j, &l2, &u2, &v2);
+      float dl = l1 - l2;
+      float du = u1 - u2;
+      float dv = v1 - v2;
+      float dist = sqrtf(dl * dl + du * du + dv * dv);
+      if (dist < minDist[i]) minDist[i] = dist;
+    }
+  }
+  float score = 1;
+  for (int i = 0; i < numA; i++) score += minDist[i];
+  return score;
+}
+
+/* find(): Match(id, int(distance)) for every entry with finite distance and id != 0, index order */
+long long orc_color_find(const uint8_t* descs, const uint32_t* ids, size_t n, const uint8_t* target,
+                         uint32_t* out_ids, int32_t* out_scores, size_t cap) {
+  long long m = 0;
+  if (target[256] == 0) return 0;
+  for (size_t i = 0; i < n; ++i) {
+    float d = orc_color_distance(target, descs + i * 258);
+    if (d < 3.402823466e+38F) {
+      if (ids[i] != 0) {
+        if ((size_t)m < cap) {
+          out_ids[m] = ids[i];
+          out_scores[m] = (int)d;
+        }
+        ++m;
+      }
+    }
+  }
+  return m;
+}
