@@ -27,6 +27,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# k_hamm64_scan variants: "eq" (dht 1): 1 v_cmp_eq_u64; "pre" (dht 2..6): 1 fast xor + bcnt + 0.5 min3 (+3 %
+# block overhead); "full": 2 fast xor + 2 bcnt + 0.5 min3
+VALU_CYCLES = {"eq": 4.0, "pre": 2.0 + 1.58 * 4, "full": 4.0 + 2.58 * 4}
+
+
+def variant_of(dht):
+    return "eq" if dht == 1 else ("pre" if dht <= 6 else "full")
+
+
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 W = H = 256
 
@@ -219,8 +228,10 @@ def main():
             "note": ("algorithmic bytes (8 B per comparison) exceed HBM peak because the needle tile is "
                      "reused from SGPRs and the 8 MB haystack stays in L2/MALL; the binding unit is the "
                      "integer VALU -- see valu_frac and DESIGN.md"),
-            "valu_ops_per_cmp": {"prefilter(dht<=5)": 2.58, "full": 4.58},
-            "valu_peak_lane_ops_per_s": 256 * 4 * 16 * 2.4e9,
+            # issue model measured with tools/ubench/valu_rate.hip: a wave64 VALU op occupies its SIMD for 4
+            # cycles, 2 inside long runs of plain VGPR-only add/xor/...; cycles per (needle, slot) pair per wave:
+            "valu_cycles_per_pair_wave": VALU_CYCLES,
+            "valu_peak_note": "peak pairs/s of a variant = 1024 SIMDs * 64 lanes * 2.4e9 / cycles",
         },
         "roofline_hash": {
             "kernel": "k_dcthash_256", "bound": "hbm", "achieved": hash_gbs, "peak": HBM_PEAK_GBS,
@@ -229,8 +240,8 @@ def main():
         },
     }
     # weighted VALU fraction of the scan launches
-    ops = sum((2.58 if d <= 5 else 4.58) * shard_n * n * len(scans[d]) for d in dhts)
-    result["roofline"]["valu_frac"] = ops / (sum(sum(v) for v in scans.values()) * 1e-3) / (256 * 4 * 16 * 2.4e9)
+    cyc = sum(VALU_CYCLES[variant_of(d)] * shard_n * n * len(scans[d]) for d in dhts)
+    result["roofline"]["valu_frac"] = (cyc / (1024 * 64 * 2.4e9)) / (sum(sum(v) for v in scans.values()) * 1e-3)
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:

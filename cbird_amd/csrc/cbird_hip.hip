@@ -94,7 +94,7 @@ int cbh_dcthash_batch(const uint8_t* imgs, size_t n, int w, int h, size_t row_st
   if (n == 0) return CBH_OK;
   if (!imgs || !out || w <= 0 || h <= 0 || row_stride < (size_t)w) return CBH_E_INVAL;
   if (img_stride < (size_t)(h - 1) * row_stride + (size_t)w && n > 1) return CBH_E_INVAL;
-  if (w % 32 || h % 32 || w > 1024 || h > 1024) return CBH_E_UNSUPPORTED;
+  if (w < 32 || h < 32 || w > 8192 || h > 8192) return CBH_E_UNSUPPORTED;
   DeviceGuard g(device);
   if (!g.ok) return CBH_E_NODEVICE;
   // decoded tiles are staged in chunks of <= 256 MiB; strides are preserved on the device

@@ -20,7 +20,11 @@
 //
 // k_dcthash_generic: one 256-thread workgroup per image, any w,h in {32} or multiples of 32 up
 // to 1024; the image is consumed as 32 horizontal bands (one per output row) staged in LDS.
+#include <algorithm>
+#include <map>
 #include <mutex>
+#include <tuple>
+#include <vector>
 
 #include "cbh_internal.h"
 
@@ -360,6 +364,106 @@ __global__ __launch_bounds__(kThreads) void k_dcthash_256(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Any other size (w,h >= 32, not both multiples of 32): cv::resize's general INTER_AREA path
+// (resizeArea_) with fractional cell weights.  Two launches: k_blur_u8 writes the blurred u8 image to a
+// scratch buffer (bands of rows staged in LDS, separable box sums), k_area_hash resamples it with the
+// reference's float accumulation order -- per source row buf += S[sx]*alpha over the x table, per output
+// row sum = beta*buf then += beta*buf over the y table, round-half-even -- and hashes the tile.
+struct AreaTab {
+  int si, di;
+  float alpha;
+};
+
+template <int K>
+__global__ __launch_bounds__(kThreads) void k_blur_u8(const unsigned char* __restrict__ imgs, int w, int h,
+                                                      size_t row_stride, size_t img_stride, int band_rows,
+                                                      unsigned char* __restrict__ blur /* n*w*h */) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int R = K / 2;
+  const int rows = band_rows + 2 * R;
+  unsigned short* hs = reinterpret_cast<unsigned short*>(smem);                  // rows*w u16
+  unsigned char* raw = reinterpret_cast<unsigned char*>(hs + (size_t)rows * w);  // rows*w u8
+  const int tid = threadIdx.x;
+  const unsigned char* img = imgs + (size_t)blockIdx.x * img_stride;
+  unsigned char* dst = blur + (size_t)blockIdx.x * (size_t)w * h;
+  const int y0 = blockIdx.y * band_rows;
+  const int nrows = min(band_rows, h - y0);
+  if (K == 0) {
+    for (int i = tid; i < nrows * w; i += kThreads) {
+      const int b = i / w, x = i - b * w;
+      dst[(size_t)(y0 + b) * w + x] = img[(size_t)(y0 + b) * row_stride + x];
+    }
+    return;
+  }
+  for (int i = tid; i < rows * w; i += kThreads) {
+    const int b = i / w, x = i - b * w;
+    raw[i] = img[(size_t)reflect101(y0 - R + b, h) * row_stride + x];
+  }
+  __syncthreads();
+  for (int i = tid; i < rows * w; i += kThreads) {
+    const int b = i / w, x = i - b * w;
+    unsigned int s = 0;
+#pragma unroll
+    for (int dx = -R; dx <= R; ++dx) s += raw[b * w + reflect101(x + dx, w)];
+    hs[i] = (unsigned short)s;
+  }
+  __syncthreads();
+  for (int x = tid; x < w; x += kThreads) {
+    unsigned int s = 0;
+#pragma unroll
+    for (int t = 0; t < (K ? K : 1); ++t) s += hs[t * w + x];
+    for (int j = 0; j < nrows; ++j) {
+      dst[(size_t)(y0 + j) * w + x] = (unsigned char)((2u * s + (unsigned)(K * K)) / (2u * (unsigned)(K * K) + (K == 0)));
+      if (j + 1 < nrows) s += (unsigned)hs[(j + K) * w + x] - (unsigned)hs[j * w + x];
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_area_hash(const unsigned char* __restrict__ blur, int w, int h,
+                                                        const AreaTab* __restrict__ xtab, int xn,
+                                                        const AreaTab* __restrict__ ytab, int yn,
+                                                        const int* __restrict__ xfirst /*33*/,
+                                                        const int* __restrict__ yfirst /*33*/,
+                                                        int isx, int isy /* integer ratios or 0 */,
+                                                        const DctTables* __restrict__ tabs,
+                                                        uint64_t* __restrict__ out,
+                                                        unsigned char* __restrict__ tiles) {
+  __shared__ float sC[288], sT[288], sY[84], sThr[4];
+  __shared__ unsigned char tile[1024], sZ[64];
+  const int tid = threadIdx.x;
+  const unsigned char* src = blur + (size_t)blockIdx.x * (size_t)w * h;
+  for (int i = tid; i < 288; i += kThreads) sC[i] = tabs->C[i];
+  if (tid < 64) sZ[tid] = tabs->zz[tid];
+  for (int o = tid; o < 1024; o += kThreads) {
+    const int dy = o >> 5, dx = o & 31;
+    if (isx) {  // both ratios integer: resizeAreaFast_ (block sum, 2x2 -> (s+2)>>2, else rint(s * (1.f/area)))
+      unsigned int s = 0;
+      for (int yy = 0; yy < isy; ++yy)
+        for (int xx = 0; xx < isx; ++xx) s += src[(size_t)(dy * isy + yy) * w + (dx * isx + xx)];
+      const unsigned int v = (isx == 2 && isy == 2)
+                                 ? (s + 2u) >> 2
+                                 : (unsigned int)__builtin_rintf((float)s * (1.f / (float)(isx * isy)));
+      tile[o] = (unsigned char)(v > 255u ? 255u : v);
+      continue;
+    }
+    float sum = 0.f;
+    for (int j = yfirst[dy]; j < yfirst[dy + 1]; ++j) {
+      const unsigned char* S = src + (size_t)ytab[j].si * w;
+      float buf = 0.f;
+      for (int k = xfirst[dx]; k < xfirst[dx + 1]; ++k) buf += (float)S[xtab[k].si] * xtab[k].alpha;
+      const float t = ytab[j].alpha * buf;
+      sum = (j == yfirst[dy]) ? t : sum + t;
+    }
+    const float r = __builtin_rintf(sum);
+    tile[o] = (unsigned char)(r < 0.f ? 0.f : r > 255.f ? 255.f : r);
+  }
+  __syncthreads();
+  if (tiles)
+    for (int i = tid; i < 1024; i += kThreads) tiles[(size_t)blockIdx.x * 1024 + i] = tile[i];
+  hash_from_tile(tile, sC, sZ, sT, sY, sThr, out + blockIdx.x);
+}
+
 size_t generic_smem_bytes(int w, int h, int K) {
   const int band = h / 32 + 2 * (K / 2);
   return (288 + 288 + 84 + 4) * 4 + (size_t)w * 4 + 1024 + 64 + (size_t)band * w * 3;
@@ -369,6 +473,65 @@ struct TableCache {
   std::mutex mu;
   DctTables* d[16] = {};
 } g_tabs;
+
+}  // namespace
+
+namespace {
+
+// computeResizeAreaTab (OpenCV 2.4 imgwarp.cpp, as recalled): see oracle/cbird_oracle.c for the prose
+std::vector<AreaTab> make_area_tab(int ssize, int dsize, std::vector<int>* first) {
+  std::vector<AreaTab> tab;
+  const double scale = (double)ssize / dsize;
+  first->assign((size_t)dsize + 1, 0);
+  for (int dx = 0; dx < dsize; dx++) {
+    (*first)[(size_t)dx] = (int)tab.size();
+    const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+    const double cellWidth = std::min(scale, ssize - fsx1);
+    int sx1 = (int)__builtin_ceil(fsx1), sx2 = (int)__builtin_floor(fsx2);
+    sx2 = std::min(sx2, ssize - 1);
+    sx1 = std::min(sx1, sx2);
+    if (sx1 - fsx1 > 1e-3) tab.push_back(AreaTab{sx1 - 1, dx, (float)((sx1 - fsx1) / cellWidth)});
+    for (int sx = sx1; sx < sx2; sx++) tab.push_back(AreaTab{sx, dx, (float)(1.0 / cellWidth)});
+    if (fsx2 - sx2 > 1e-3)
+      tab.push_back(AreaTab{sx2, dx, (float)(std::min(std::min(fsx2 - sx2, 1.), cellWidth) / cellWidth)});
+  }
+  (*first)[(size_t)dsize] = (int)tab.size();
+  return tab;
+}
+
+struct AreaTabsDev {
+  AreaTab *x = nullptr, *y = nullptr;
+  int *xfirst = nullptr, *yfirst = nullptr;
+  int xn = 0, yn = 0;
+};
+std::mutex g_area_mu;
+std::map<std::tuple<int, int, int>, AreaTabsDev> g_area;  // (device, w, h)
+
+int get_area_tabs(int w, int h, AreaTabsDev* out) {
+  int dev = 0;
+  CBH_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_area_mu);
+  auto key = std::make_tuple(dev, w, h);
+  auto it = g_area.find(key);
+  if (it == g_area.end()) {
+    std::vector<int> xf, yf;
+    std::vector<AreaTab> xt = make_area_tab(w, 32, &xf), yt = make_area_tab(h, 32, &yf);
+    AreaTabsDev d;
+    d.xn = (int)xt.size();
+    d.yn = (int)yt.size();
+    CBH_HIP(hipMalloc(&d.x, xt.size() * sizeof(AreaTab)));
+    CBH_HIP(hipMalloc(&d.y, yt.size() * sizeof(AreaTab)));
+    CBH_HIP(hipMalloc(&d.xfirst, 33 * sizeof(int)));
+    CBH_HIP(hipMalloc(&d.yfirst, 33 * sizeof(int)));
+    CBH_HIP(hipMemcpy(d.x, xt.data(), xt.size() * sizeof(AreaTab), hipMemcpyHostToDevice));
+    CBH_HIP(hipMemcpy(d.y, yt.data(), yt.size() * sizeof(AreaTab), hipMemcpyHostToDevice));
+    CBH_HIP(hipMemcpy(d.xfirst, xf.data(), 33 * sizeof(int), hipMemcpyHostToDevice));
+    CBH_HIP(hipMemcpy(d.yfirst, yf.data(), 33 * sizeof(int), hipMemcpyHostToDevice));
+    it = g_area.emplace(key, d).first;
+  }
+  *out = it->second;
+  return CBH_OK;
+}
 
 }  // namespace
 
@@ -412,11 +575,49 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
                    size_t img_stride, uint64_t* d_out, hipStream_t stream, uint8_t* d_tiles) {
   if (n == 0) return CBH_OK;
   if (w <= 0 || h <= 0 || row_stride < (size_t)w) return CBH_E_INVAL;
-  if (w % 32 || h % 32 || w > 1024 || h > 1024) return CBH_E_UNSUPPORTED;
+  if (w < 32 || h < 32 || w > 8192 || h > 8192) return CBH_E_UNSUPPORTED;  // < 32: bilinear upscale path
   if (n > 0x7fffffffull) return CBH_E_INVAL;
   const DctTables* tabs = nullptr;
   int rc = get_tables(&tabs);
   if (rc) return rc;
+  if (w % 32 || h % 32 || w > 1024 || h > 1024) {
+    // general INTER_AREA path: blur to scratch, then weighted resample + hash
+    const long long area_ = (long long)w * h;
+    const int K_ = area_ <= 32 * 32 ? 0 : area_ <= 64 * 64 ? 3 : area_ <= 128 * 128 ? 5 : 7;
+    AreaTabsDev at;
+    if ((rc = get_area_tabs(w, h, &at))) return rc;
+    int band = (int)std::min<long long>(h, std::max<long long>(1, (96 * 1024) / (3LL * w) - 2 * (K_ / 2)));
+    const size_t smem = (size_t)(band + 2 * (K_ / 2)) * (size_t)w * 3;
+    const size_t per_chunk = std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)w * h));
+    unsigned char* d_blur = nullptr;
+    CBH_HIP(hipMallocAsync((void**)&d_blur, std::min(per_chunk, n) * (size_t)w * h, stream));
+    for (size_t i0 = 0; i0 < n; i0 += per_chunk) {
+      const size_t m = std::min(per_chunk, n - i0);
+      dim3 g1((unsigned)m, (unsigned)((h + band - 1) / band)), block(kThreads);
+      const unsigned char* src = d_imgs + i0 * img_stride;
+#define CBH_BLUR(KK)                                                                                    \
+  do {                                                                                                  \
+    if (smem > 64 * 1024)                                                                               \
+      CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_u8<KK>),                         \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));              \
+    hipLaunchKernelGGL(k_blur_u8<KK>, g1, block, smem, stream, src, w, h, row_stride, img_stride, band, \
+                       d_blur);                                                                         \
+  } while (0)
+      switch (K_) {
+        case 0: CBH_BLUR(0); break;
+        case 3: CBH_BLUR(3); break;
+        case 5: CBH_BLUR(5); break;
+        default: CBH_BLUR(7); break;
+      }
+#undef CBH_BLUR
+      hipLaunchKernelGGL(k_area_hash, dim3((unsigned)m), block, 0, stream, d_blur, w, h, at.x, at.xn, at.y,
+                         at.yn, at.xfirst, at.yfirst, (w % 32 || h % 32) ? 0 : w / 32, (w % 32 || h % 32) ? 0 : h / 32,
+                         tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
+    }
+    CBH_HIP(hipGetLastError());
+    CBH_HIP(hipFreeAsync(d_blur, stream));
+    return CBH_OK;
+  }
   if (w == 256 && h == 256 && ((uintptr_t)d_imgs % 8) == 0 && row_stride % 8 == 0 &&
       img_stride % 8 == 0 && row_stride * 256 < (1u << 24) && img_stride < (1u << 28)) {
     dim3 grid((unsigned)((n + 7) / 8)), block(kThreads);

@@ -72,9 +72,9 @@ const char* cbh_last_error(void);       /* thread-local detail of the last CBH_E
 /* ---- hash build: replaces dctHash64(const cv::Mat&, bool) -- src/cvutil.cpp:435-545,
  * called once per image from Scanner::processImage (src/scanner.cpp:862).
  * imgs: n 8-bit single-channel images (cv::Mat CV_8UC1 after grayscale()), image i at
- * imgs + i*img_stride, row y at + y*row_stride.  Supported geometry: w,h multiples of 32
- * (integer-ratio INTER_AREA path) up to 1024, or exactly 32x32; anything else returns
- * CBH_E_UNSUPPORTED.  out[i] = 64-bit hash (bit 0 clear unless the hash would be 0 -> 1). */
+ * imgs + i*img_stride, row y at + y*row_stride.  Supported geometry: 32 <= w,h <= 8192 (integer-ratio and
+ * weighted INTER_AREA paths); smaller images take cv::resize's bilinear upscaling path, which is not
+ * implemented: CBH_E_UNSUPPORTED.  out[i] = 64-bit hash (bit 0 clear unless the hash would be 0 -> 1). */
 int cbh_dcthash_batch(const uint8_t* imgs, size_t n, int w, int h, size_t row_stride,
                       size_t img_stride, uint64_t* out, int device);
 int cbh_dcthash_batch_dev(const void* d_imgs, size_t n, int w, int h, size_t row_stride,

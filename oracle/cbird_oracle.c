@@ -254,29 +254,119 @@ void orc_box_blur(const uint8_t* src, int w, int h, size_t stride, int k, uint8_
   box_blur_u8(src, w, h, stride, k, dst);
 }
 
-/* cv::resize(src, dst, Size(32,32), 0, 0, INTER_AREA), integer-ratio ("area fast") path:
- * 2x2 -> (a+b+c+d+2)>>2; otherwise saturate_cast<uchar>(sum * (1.f/area)) in float with
- * cvRound (nearest-even). */
+/* cv::resize(src, dst, Size(32,32), 0, 0, INTER_AREA) for w,h >= 32 (OpenCV 2.4 imgproc/imgwarp.cpp, as
+ * recalled -- "parity unpinned"):
+ *   both ratios integer ("area fast", resizeAreaFast_): block sum; 2x2 -> (a+b+c+d+2)>>2, otherwise
+ *     saturate_cast<uchar>(sum * (1.f/area)) in float with cvRound (nearest-even);
+ *   otherwise (resizeArea_): per axis a table of (src index, dst index, alpha) from
+ *     computeResizeAreaTab -- a partially covered leading pixel with weight (sx1 - fsx1)/cellWidth when that
+ *     exceeds 1e-3, fully covered pixels with 1/cellWidth, a trailing one with
+ *     min(min(fsx2 - sx2, 1), cellWidth)/cellWidth when fsx2 - sx2 > 1e-3 (double arithmetic, alpha stored
+ *     as float) -- then for every source row a float row buffer buf[dx] += S[sx]*alpha in table order, and
+ *     per destination row sum[dx] = beta*buf[dx] for its first source row, += for the following ones,
+ *     finally saturate_cast<uchar>(sum[dx]) (cvRound). */
+typedef struct {
+  int si, di;
+  float alpha;
+} orc_dalpha;
+
+static int resize_area_tab(int ssize, int dsize, double scale, orc_dalpha* tab) {
+  int k = 0;
+  for (int dx = 0; dx < dsize; dx++) {
+    double fsx1 = dx * scale;
+    double fsx2 = fsx1 + scale;
+    double cellWidth = scale < ssize - fsx1 ? scale : ssize - fsx1;
+    int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+    sx2 = sx2 < ssize - 1 ? sx2 : ssize - 1;
+    sx1 = sx1 < sx2 ? sx1 : sx2;
+    if (sx1 - fsx1 > 1e-3) {
+      tab[k].di = dx;
+      tab[k].si = sx1 - 1;
+      tab[k++].alpha = (float)((sx1 - fsx1) / cellWidth);
+    }
+    for (int sx = sx1; sx < sx2; sx++) {
+      tab[k].di = dx;
+      tab[k].si = sx;
+      tab[k++].alpha = (float)(1.0 / cellWidth);
+    }
+    if (fsx2 - sx2 > 1e-3) {
+      double a = fsx2 - sx2;
+      a = a < 1.0 ? a : 1.0;
+      a = a < cellWidth ? a : cellWidth;
+      tab[k].di = dx;
+      tab[k].si = sx2;
+      tab[k++].alpha = (float)(a / cellWidth);
+    }
+  }
+  return k;
+}
+
+/* exported for the stage tests: the tables themselves */
+int orc_resize_area_tab(int ssize, int dsize, int* si, int* di, float* alpha) {
+  orc_dalpha* tab = (orc_dalpha*)malloc(sizeof(orc_dalpha) * (size_t)(ssize + 2 * dsize + 2));
+  int k = resize_area_tab(ssize, dsize, (double)ssize / dsize, tab);
+  for (int i = 0; i < k; ++i) {
+    si[i] = tab[i].si;
+    di[i] = tab[i].di;
+    alpha[i] = tab[i].alpha;
+  }
+  free(tab);
+  return k;
+}
+
 static int area_resize32_u8(const uint8_t* src, int w, int h, uint8_t* dst /*32*32*/) {
   if (w == 32 && h == 32) {
     memcpy(dst, src, 1024);
     return ORC_OK;
   }
-  if (w < 32 || h < 32 || (w % 32) || (h % 32)) return ORC_E_UNSUPPORTED;
-  int sx = w / 32, sy = h / 32;
-  float scale = 1.f / (float)(sx * sy);
-  for (int y = 0; y < 32; ++y)
-    for (int x = 0; x < 32; ++x) {
-      int s = 0;
-      for (int dy = 0; dy < sy; ++dy)
-        for (int dx = 0; dx < sx; ++dx) s += src[(size_t)(y * sy + dy) * w + (x * sx + dx)];
-      int v;
-      if (sx == 2 && sy == 2)
-        v = (s + 2) >> 2;
-      else
-        v = (int)lrintf((float)s * scale); /* default rounding mode = nearest-even */
-      dst[y * 32 + x] = (uint8_t)(v > 255 ? 255 : v);
+  if (w < 32 || h < 32) return ORC_E_UNSUPPORTED; /* upscaling falls to the bilinear path: not restated */
+  if ((w % 32) == 0 && (h % 32) == 0) {
+    int sx = w / 32, sy = h / 32;
+    float scale = 1.f / (float)(sx * sy);
+    for (int y = 0; y < 32; ++y)
+      for (int x = 0; x < 32; ++x) {
+        int s = 0;
+        for (int dy = 0; dy < sy; ++dy)
+          for (int dx = 0; dx < sx; ++dx) s += src[(size_t)(y * sy + dy) * w + (x * sx + dx)];
+        int v;
+        if (sx == 2 && sy == 2)
+          v = (s + 2) >> 2;
+        else
+          v = (int)lrintf((float)s * scale); /* default rounding mode = nearest-even */
+        dst[y * 32 + x] = (uint8_t)(v > 255 ? 255 : v);
+      }
+    return ORC_OK;
+  }
+  orc_dalpha* xtab = (orc_dalpha*)malloc(sizeof(orc_dalpha) * (size_t)(w + 66));
+  orc_dalpha* ytab = (orc_dalpha*)malloc(sizeof(orc_dalpha) * (size_t)(h + 66));
+  int xn = resize_area_tab(w, 32, (double)w / 32, xtab);
+  int yn = resize_area_tab(h, 32, (double)h / 32, ytab);
+  float buf[32], sum[32];
+  int prev_dy = ytab[0].di;
+  for (int dx = 0; dx < 32; ++dx) sum[dx] = 0.f;
+  for (int j = 0; j < yn; ++j) {
+    float beta = ytab[j].alpha;
+    int dy = ytab[j].di, sy = ytab[j].si;
+    const uint8_t* S = src + (size_t)sy * w;
+    for (int dx = 0; dx < 32; ++dx) buf[dx] = 0.f;
+    for (int k = 0; k < xn; ++k) buf[xtab[k].di] += (float)S[xtab[k].si] * xtab[k].alpha;
+    if (dy != prev_dy) {
+      for (int dx = 0; dx < 32; ++dx) {
+        long v = lrintf(sum[dx]);
+        dst[prev_dy * 32 + dx] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        sum[dx] = beta * buf[dx];
+      }
+      prev_dy = dy;
+    } else {
+      for (int dx = 0; dx < 32; ++dx) sum[dx] += beta * buf[dx];
     }
+  }
+  for (int dx = 0; dx < 32; ++dx) {
+    long v = lrintf(sum[dx]);
+    dst[prev_dy * 32 + dx] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+  }
+  free(xtab);
+  free(ytab);
   return ORC_OK;
 }
 
@@ -326,8 +416,7 @@ uint64_t orc_hash_from_tile32(const uint8_t* tile, float* coefs /*64 or NULL*/, 
 /* Full pipeline for one 8UC1 image.  Returns ORC_OK / ORC_E_*; hash in *out. */
 int orc_dcthash64(const uint8_t* img, int w, int h, size_t stride, uint64_t* out) {
   if (!img || w <= 0 || h <= 0 || stride < (size_t)w) return ORC_E_INVAL;
-  if (!((w == 32 && h == 32) || (w >= 32 && h >= 32 && w % 32 == 0 && h % 32 == 0)))
-    return ORC_E_UNSUPPORTED;
+  if (w < 32 || h < 32) return ORC_E_UNSUPPORTED;
   int k = orc_blur_ksize(w, h);
   uint8_t* blur = (uint8_t*)malloc((size_t)w * h);
   if (k)

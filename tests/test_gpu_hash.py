@@ -21,6 +21,32 @@ def test_hash_matches_oracle_random_and_smooth(gpu, orc, w, h):
         assert (got == want).all(), (w, h, [hex(int(x)) for x in (got ^ want)])
 
 
+@pytest.mark.parametrize("w,h", [(100, 100), (33, 47), (600, 400), (257, 256), (400, 533), (1280, 720), (2048, 1536),
+                                 (32, 33), (640, 64)])
+def test_hash_any_size_general_area_path(gpu, orc, w, h):
+    """sizes whose ratio to 32 is not an integer: cv::resize's weighted INTER_AREA path"""
+    from cbird_amd import _lib
+    import torch
+
+    rng = np.random.default_rng(w * 7 + h)
+    n = 5
+    imgs = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    imgs[1] = (128 + 100 * np.sin(xx / 37.0) * np.cos(yy / 23.0)).astype(np.uint8)
+    got = gpu.dct_hash64_batch(imgs)
+    want = orc.dcthash64_batch(imgs)
+    assert (got == want).all(), [hex(int(x)) for x in got ^ want]
+    # stage level: the 32x32 tiles agree byte for byte
+    L = _lib.lib()
+    d = torch.from_numpy(imgs).cuda()
+    out = torch.zeros(n, dtype=torch.int64, device="cuda")
+    tiles = torch.zeros((n, 32, 32), dtype=torch.uint8, device="cuda")
+    _lib.check(L.cbh_dcthash_tiles_dev(d.data_ptr(), n, w, h, w, w * h, out.data_ptr(), tiles.data_ptr(), 0, None), "t")
+    t = tiles.cpu().numpy()
+    for i in range(n):
+        assert (t[i] == orc.tile32(imgs[i])).all()
+
+
 def test_hash_edge_images(gpu, orc):
     imgs = np.zeros((6, 256, 256), np.uint8)
     imgs[1] = 255
@@ -65,7 +91,7 @@ def test_hash_unsupported_geometry(gpu):
     from cbird_amd import _lib
 
     with pytest.raises(gpu.CbhError) as e:
-        gpu.dct_hash64_batch(np.zeros((1, 100, 100), np.uint8))
+        gpu.dct_hash64_batch(np.zeros((1, 20, 100), np.uint8))
     assert e.value.code == _lib.CBH_E_UNSUPPORTED
     assert len(gpu.dct_hash64_batch(np.zeros((0, 256, 256), np.uint8))) == 0
 

@@ -177,6 +177,48 @@ def test_low_frequency_basis_through_blur_and_resize(orc):
         assert orc.dcthash64(img) == 1 << bit
 
 
+def test_area_tables_cover_every_source_pixel_with_unit_weight(orc):
+    """computeResizeAreaTab: per destination cell the weights sum to 1 and every source pixel is used"""
+    import ctypes as C
+
+    for ssize in (33, 47, 100, 257, 600, 1000):
+        si = np.zeros(ssize + 70, np.int32)
+        di = np.zeros(ssize + 70, np.int32)
+        al = np.zeros(ssize + 70, np.float32)
+        f = orc.L.orc_resize_area_tab
+        f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        f.restype = C.c_int
+        k = f(ssize, 32, si.ctypes.data, di.ctypes.data, al.ctypes.data)
+        si, di, al = si[:k], di[:k], al[:k]
+        assert (np.diff(di) >= 0).all() and set(di.tolist()) == set(range(32))
+        for d in range(32):
+            assert abs(al[di == d].sum() - 1.0) < 1e-5
+        assert set(si.tolist()) == set(range(ssize))
+        cover = np.zeros(ssize)
+        np.add.at(cover, si, al * (ssize / 32))
+        assert np.allclose(cover, 1.0, atol=2e-3)  # the 1e-3 cut-off of the reference drops slivers
+
+
+def test_general_area_resize_is_the_rounded_area_mean(orc):
+    rng = np.random.default_rng(12)
+    for h, w in ((100, 100), (33, 47), (400, 600), (255, 256)):
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        k = orc.blur_ksize(w, h)
+        b = orc.box_blur(img, k) if k else img
+
+        def wmat(n):
+            m = np.zeros((32, n))
+            sc = n / 32
+            for d in range(32):
+                a, e = d * sc, (d + 1) * sc
+                for s in range(int(np.floor(a)), min(n, int(np.ceil(e)))):
+                    m[d, s] = max(0.0, min(e, s + 1) - max(a, s)) / sc
+            return m
+
+        exact = wmat(h) @ b.astype(np.float64) @ wmat(w).T
+        assert np.abs(orc.tile32(img).astype(np.float64) - exact).max() <= 0.5 + 1e-3
+
+
 def test_hash_never_zero_and_bit0(orc):
     rng = np.random.default_rng(8)
     for _ in range(50):
@@ -198,4 +240,4 @@ def test_hash_is_scale_stable(orc):
 
 def test_unsupported_geometry_is_an_error(orc):
     with pytest.raises(ValueError):
-        orc.dcthash64(np.zeros((100, 100), np.uint8))
+        orc.dcthash64(np.zeros((20, 100), np.uint8))  # < 32: bilinear upscale path, not restated
