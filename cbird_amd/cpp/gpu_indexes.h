@@ -1,0 +1,290 @@
+// gpu_indexes.h -- cbird-side bindings of the other four Index subclasses to libcbird_hip.so:
+//   GpuDctFeaturesIndex (src/dctfeaturesindex.{h,cpp}), GpuCvFeaturesIndex (src/cvfeaturesindex.{h,cpp}),
+//   GpuColorDescIndex (src/colordescindex.{h,cpp}), GpuDctVideoIndex (src/dctvideoindex.{h,cpp}).
+// Same pattern as gpu_dcthashindex.h: the class keeps cbird's SQL/file handling (tables kphash / matrix /
+// color, <id>.vdx files) and forwards storage + search to the C-ABI.  Methods that only touch SQL
+// (createTables/addRecords/removeRecords) are cbird's own code and are inherited unchanged by deriving from
+// the reference class when built inside cbird; this header shows the search-side overrides.
+//
+// Build note: needs cbird's index.h / media.h (Qt6, OpenCV types KeyPointDescriptors = cv::Mat,
+// ColorDescriptor, VideoIndex).  Unlike gpu_dcthashindex.h it is NOT compiled in this repository's tests
+// (those types have no mock here); the C-ABI calls it makes are the ones exercised by tests/test_fdct.py,
+// tests/test_cvfeatures.py, tests/test_color.py and tests/test_video.py through ctypes.
+#pragma once
+
+#include <vector>
+
+#include "cbird_hip.h"
+#include "colordescindex.h"
+#include "cvfeaturesindex.h"
+#include "dctfeaturesindex.h"
+#include "dctvideoindex.h"
+#include "videoindex.h"
+
+#define CBH_CHECK(call)                                                                   \
+  do {                                                                                    \
+    int rc_ = (call);                                                                     \
+    if (rc_ != CBH_OK) qFatal("%s: %s (%s)", #call, cbh_strerror(rc_), cbh_last_error()); \
+  } while (0)
+
+// ---- DctFeaturesIndex ---------------------------------------------------------------------------------
+class GpuDctFeaturesIndex : public DctFeaturesIndex {  // inherits createTables/addRecords/removeRecords/mediaIds
+ public:
+  GpuDctFeaturesIndex(int device = 0) : _idx(cbh_idx64_create(device)) {
+    if (!_idx) qFatal("no usable MI355X device");
+  }
+  ~GpuDctFeaturesIndex() override { cbh_idx64_destroy(_idx); }
+  bool isLoaded() const override { return cbh_idx64_is_loaded(_idx); }
+  int count() const override { return int(cbh_idx64_count(_idx)); }
+  size_t memoryUsage() const override { return cbh_idx64_memory_usage(_idx); }
+
+  // `select media_id,hashes from kphash` (dctfeaturesindex.cpp:129-156); no cache file is needed
+  void load(QSqlDatabase& db, const QString&, const QString&) override {
+    QSqlQuery query(db);
+    query.setForwardOnly(true);
+    if (!query.exec("select media_id,hashes from kphash")) SQL_FATAL(exec);
+    std::vector<uint64_t> hashes;
+    std::vector<uint32_t> ids;
+    while (query.next()) {
+      const uint32_t mediaId = query.value(0).toUInt();
+      const QByteArray blob = query.value(1).toByteArray();
+      if (size_t(blob.size()) % sizeof(uint64_t) != 0) continue;  // "ignoring invalid data" (:145-148)
+      const uint64_t* p = reinterpret_cast<const uint64_t*>(blob.constData());
+      for (size_t j = 0; j < size_t(blob.size()) / 8; ++j) {
+        ids.push_back(mediaId);
+        hashes.push_back(p[j]);
+      }
+    }
+    CBH_CHECK(cbh_idx64_load(_idx, hashes.data(), ids.data(), hashes.size()));
+  }
+  void save(QSqlDatabase&, const QString&) override {}
+  void add(const MediaGroup& media) override {
+    std::vector<uint64_t> hashes;
+    std::vector<uint32_t> ids;
+    for (const Media& m : media)
+      for (uint64_t h : m.keyPointHashes()) {
+        ids.push_back(uint32_t(m.id()));
+        hashes.push_back(h);
+      }
+    if (!hashes.empty()) CBH_CHECK(cbh_idx64_add(_idx, hashes.data(), ids.data(), hashes.size()));
+  }
+  void remove(const QVector<int>& ids) override {
+    if (ids.count() <= 0 || !isLoaded()) return;
+    std::vector<uint32_t> v(ids.begin(), ids.end());
+    CBH_CHECK(cbh_idx64_remove_ids_only(_idx, v.data(), v.size()));
+  }
+  QVector<Index::Match> find(const Media& needle, const SearchParams& params) override {
+    KeyPointHashList hashes = needle.keyPointHashes();
+    std::vector<uint64_t> h(hashes.begin(), hashes.end());
+    if (h.empty() && needle.id() > 0) {  // _tree->findIndex (:270-276)
+      size_t n = 0;
+      CBH_CHECK(cbh_idx64_hashes_for_id(_idx, uint32_t(needle.id()), nullptr, 0, &n));
+      h.resize(n);
+      CBH_CHECK(cbh_idx64_hashes_for_id(_idx, uint32_t(needle.id()), h.data(), n, &n));
+    }
+    if (h.empty()) {
+      qWarning() << "needle has no hashes" << needle.id() << needle.path();
+      return {};
+    }
+    std::vector<cbh_match> out(h.size() * 10 + 1);
+    size_t n = 0;
+    CBH_CHECK(cbh_fdct_find(_idx, h.data(), h.size(), uint32_t(needle.id()), params.dctThresh, out.data(),
+                            out.size(), &n));
+    QVector<Index::Match> results;
+    for (size_t i = 0; i < n; ++i) results.append(Index::Match(out[i].id, out[i].score));
+    return results;
+  }
+
+ private:
+  cbh_idx64* _idx;
+};
+
+// ---- CvFeaturesIndex ----------------------------------------------------------------------------------
+class GpuCvFeaturesIndex : public CvFeaturesIndex {
+ public:
+  GpuCvFeaturesIndex(int device = 0) : _idx(cbh_idx256_create(device)) {
+    if (!_idx) qFatal("no usable MI355X device");
+  }
+  ~GpuCvFeaturesIndex() override { cbh_idx256_destroy(_idx); }
+  bool isLoaded() const override { return cbh_idx256_is_loaded(_idx); }
+  int count() const override { return int(cbh_idx256_count(_idx)); }
+  size_t memoryUsage() const override { return cbh_idx256_memory_usage(_idx); }
+  // load(): cbird's SQL loop over `matrix` (cvfeaturesindex.cpp:167-250) calling addOne() per row
+  void addOne(uint32_t mediaId, const cv::Mat& desc) {  // desc: rows x 32, CV_8U, continuous
+    if (desc.rows > 0) CBH_CHECK(cbh_idx256_add(_idx, mediaId, desc.ptr<uint8_t>(0), size_t(desc.rows)));
+  }
+  void add(const MediaGroup& media) override {
+    for (const Media& m : media) {
+      const KeyPointDescriptors& desc = m.keyPointDescriptors();
+      if (desc.rows <= 0) {
+        qWarning() << "no descriptors for" << m.path();
+        continue;
+      }
+      addOne(uint32_t(m.id()), desc);
+    }
+  }
+  void remove(const QVector<int>& ids) override {
+    std::vector<uint32_t> v(ids.begin(), ids.end());
+    CBH_CHECK(cbh_idx256_remove(_idx, v.data(), v.size()));
+  }
+  QVector<Index::Match> find(const Media& needle, const SearchParams& params) override {
+    cv::Mat descriptors = needle.keyPointDescriptors();
+    std::vector<uint8_t> own;
+    const uint8_t* rows = descriptors.rows > 0 ? descriptors.ptr<uint8_t>(0) : nullptr;
+    size_t n_desc = size_t(std::max(descriptors.rows, 0));
+    if (!n_desc) {  // descriptorsForMediaId (:443)
+      size_t first = 0, cnt = 0;
+      CBH_CHECK(cbh_idx256_rows_of(_idx, uint32_t(needle.id()), &first, &cnt));
+      own.resize(cnt * 32);
+      if (cnt) CBH_CHECK(cbh_idx256_download_rows(_idx, first, cnt, own.data()));
+      rows = own.data();
+      n_desc = cnt;
+    }
+    if (!n_desc) {
+      qWarning() << "needle has no descriptors" << needle.id() << needle.path();
+      return {};
+    }
+    std::vector<cbh_match> out(n_desc * 10 + 1);
+    size_t n = 0;
+    CBH_CHECK(cbh_idx256_find(_idx, rows, n_desc, params.cvThresh, 10, out.data(), out.size(), &n));
+    QVector<Index::Match> results;
+    for (size_t i = 0; i < n; ++i) results.append(Index::Match(out[i].id, out[i].score));
+    return results;
+  }
+
+ private:
+  cbh_idx256* _idx;
+};
+
+// ---- ColorDescIndex -----------------------------------------------------------------------------------
+static_assert(sizeof(ColorDescriptor) == CBH_COLOR_DESC_BYTES, "ColorDescriptor layout (src/cvutil.h:96-113)");
+class GpuColorDescIndex : public ColorDescIndex {
+ public:
+  GpuColorDescIndex(int device = 0) : _idx(cbh_color_create(device)) {
+    if (!_idx) qFatal("no usable MI355X device");
+  }
+  ~GpuColorDescIndex() override { cbh_color_destroy(_idx); }
+  bool isLoaded() const override { return cbh_color_is_loaded(_idx); }
+  int count() const override { return int(cbh_color_count(_idx)); }
+  size_t memoryUsage() const override { return cbh_color_memory_usage(_idx); }
+  // load(): cbird's `select media_id,color_desc from color` loop (colordescindex.cpp:123-168) -> addRows()
+  void addRows(const uint32_t* ids, const ColorDescriptor* descs, size_t n) {
+    CBH_CHECK(cbh_color_add(_idx, ids, descs, n));
+  }
+  void add(const MediaGroup& media) override {
+    std::vector<uint32_t> ids;
+    std::vector<ColorDescriptor> descs;
+    for (const Media& m : media) {
+      ids.push_back(uint32_t(m.id()));
+      descs.push_back(m.colorDescriptor());
+    }
+    if (!ids.empty()) addRows(ids.data(), descs.data(), ids.size());
+  }
+  void remove(const QVector<int>& toRemove) override {
+    if (!isLoaded()) return;
+    std::vector<uint32_t> v(toRemove.begin(), toRemove.end());
+    CBH_CHECK(cbh_color_remove(_idx, v.data(), v.size()));
+  }
+  bool findIndexData(Media& m) const override {
+    ColorDescriptor d;
+    if (cbh_color_find_index_data(_idx, uint32_t(m.id()), &d) != 1) return false;
+    m.setColorDescriptor(d);
+    return true;
+  }
+  QVector<Index::Match> find(const Media& m, const SearchParams&) override {
+    QVector<Index::Match> results;
+    ColorDescriptor target = m.colorDescriptor();
+    if (target.numColors <= 0) {
+      Media tmp = m;
+      if (findIndexData(tmp))
+        target = tmp.colorDescriptor();
+      else
+        qWarning() << "needle has no color descriptor" << m.id() << m.path();
+      if (target.numColors <= 0) return results;
+    }
+    std::vector<cbh_match> out(size_t(std::max(count(), 1)));
+    size_t n = 0;
+    CBH_CHECK(cbh_color_find(_idx, &target, out.data(), out.size(), &n));
+    for (size_t i = 0; i < n; ++i) results.append(Index::Match(out[i].id, out[i].score));
+    return results;
+  }
+
+ private:
+  cbh_color* _idx;
+};
+
+// ---- DctVideoIndex ------------------------------------------------------------------------------------
+class GpuDctVideoIndex : public DctVideoIndex {
+ public:
+  GpuDctVideoIndex(int device = 0) : _idx(cbh_vidx_create(device)) {
+    if (!_idx) qFatal("no usable MI355X device");
+  }
+  ~GpuDctVideoIndex() override { cbh_vidx_destroy(_idx); }
+  bool isLoaded() const override { return _loaded; }
+  int count() const override { return int(cbh_vidx_count(_idx)); }
+  // load(): `select id from media where type=video order by id` (dctvideoindex.cpp:172-211); each id's
+  // <dataPath>/<id>.vdx is read with cbird's own VideoIndex::load and handed over
+  void load(QSqlDatabase& db, const QString&, const QString& dataPath) override {
+    _dataPath = dataPath;
+    QSqlQuery query(db);
+    query.setForwardOnly(true);
+    if (!query.prepare("select id from media where type=:type order by id")) SQL_FATAL(prepare);
+    query.bindValue(":type", Media::TypeVideo);
+    if (!query.exec()) SQL_FATAL(exec);
+    while (query.next()) addOne(query.value(0).toUInt());
+    _loaded = true;
+  }
+  void add(const MediaGroup& media) override {
+    for (auto& m : media) addOne(uint32_t(m.id()));
+  }
+  void remove(const QVector<int>& ids) override {
+    std::vector<uint32_t> v(ids.begin(), ids.end());
+    CBH_CHECK(cbh_vidx_remove(_idx, v.data(), v.size()));
+  }
+  QVector<Index::Match> find(const Media& needle, const SearchParams& p) override {
+    std::vector<cbh_vmatch> out(size_t(std::max(count(), 1)));
+    size_t n = 0;
+    if (needle.type() == Media::TypeImage) {
+      if (needle.dctHash() == 0) {
+        qWarning() << "needle has no dct hash" << needle.id() << needle.path();
+        return {};
+      }
+      CBH_CHECK(cbh_vidx_find_frame(_idx, needle.dctHash(), p.dctThresh, p.skipFrames,
+                                    needle.matchRange().dstIn, out.data(), out.size(), &n));
+    } else if (needle.type() == Media::TypeVideo) {
+      VideoIndex src;
+      if (needle.id() == 0)
+        src = needle.videoIndex();
+      else
+        src.load(QString("%1/%2.vdx").arg(_dataPath).arg(needle.id()));
+      if (src.isEmpty()) {
+        qWarning() << "needle video index is empty:" << needle.path();
+        return {};
+      }
+      CBH_CHECK(cbh_vidx_find_video(_idx, src.frames.data(), src.hashes.data(), src.frames.size(),
+                                    uint32_t(needle.id()), p.dctThresh, p.skipFrames, p.minFramesMatched,
+                                    p.minFramesNear, p.filterSelf, out.data(), out.size(), &n));
+    }
+    QVector<Index::Match> results;
+    for (size_t i = 0; i < n; ++i) {
+      Index::Match m(out[i].id, out[i].score);
+      m.range = MatchRange(out[i].src_in, out[i].dst_in, out[i].len);
+      results.append(m);
+    }
+    return results;
+  }
+
+ private:
+  void addOne(uint32_t id) {
+    VideoIndex vi;
+    const QString path = QString("%1/%2.vdx").arg(_dataPath).arg(id);
+    if (QFileInfo(path).exists())
+      vi.load(path);
+    else
+      qWarning() << "index file missing:" << path;
+    CBH_CHECK(cbh_vidx_add_video(_idx, id, vi.frames.data(), vi.hashes.data(), vi.frames.size()));
+  }
+  cbh_vidx* _idx;
+  QString _dataPath;
+  bool _loaded = false;
+};
