@@ -86,6 +86,16 @@ class ShardedDctHashIndex:
         self._total = None
         self.last_exchange_records = 0
 
+    def _all_gather(self, out: torch.Tensor, inp: torch.Tensor) -> None:
+        """all_gather_into_tensor; RCCL ("nccl") on device tensors.  With the gloo backend (CPU test-suite,
+        or several ranks sharing one GPU in tests) device tensors are staged through the host."""
+        if inp.is_cuda and dist.get_backend(self.group) == "gloo":
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(o, inp.cpu(), group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_gather_into_tensor(out, inp, group=self.group)
+
     # -- build ---------------------------------------------------------------------------------
     @staticmethod
     def shard_range(n: int, rank: int, world: int):
@@ -103,7 +113,7 @@ class ShardedDctHashIndex:
         if local_hashes.numel() < m:
             pad[local_hashes.numel():] = 0
         out = self.ops.empty(m * self.world, torch.int64)
-        dist.all_gather_into_tensor(out, pad, group=self.group)
+        self._all_gather(out, pad)
         if all(b - a == m for a, b in sizes):
             return out
         return torch.cat([out[r * m: r * m + (b - a)] for r, (a, b) in enumerate(sizes)])
@@ -137,7 +147,7 @@ class ShardedDctHashIndex:
                 scan_events.append((thresh, e0, e1))
             if self.world > 1:  # sizes first: one small all-gather gives max and sum
                 counts = self.ops.empty(self.world, torch.int64)
-                dist.all_gather_into_tensor(counts, total, group=self.group)
+                self._all_gather(counts, total)
                 counts_h = counts.tolist()
                 n_local, n_max, n_total = counts_h[self.rank], max(counts_h), sum(counts_h)
             else:
@@ -150,7 +160,7 @@ class ShardedDctHashIndex:
         else:
             rec[n_local:n_max] = nq << 39  # pad = a record of needle index nq: sorts last
             merged = self.ops.empty(n_max * self.world, torch.int64)
-            dist.all_gather_into_tensor(merged, rec[:n_max], group=self.group)
+            self._all_gather(merged, rec[:n_max])
         self.last_exchange_records = n_total
         # pads sort to the end; only the first n_total records are real
         self.ops.sort_records(merged, merged.numel() if self.world > 1 else n_total, nq + 1)

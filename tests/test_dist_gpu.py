@@ -1,0 +1,64 @@
+"""Two ranks sharing ONE MI355X (gloo for the exchange, HipOps for the device work): the sharded path on
+real device memory equals the unsharded index.  (RCCL itself needs one GPU per rank; the 8-GPU run is the
+driver's.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, n, q_out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cbird_amd import synth
+        from cbird_amd.dist import HipOps, ShardedDctHashIndex
+
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        imgs = torch.from_numpy(synth.make_images(n, seed=99)).to(dev)
+        sh = ShardedDctHashIndex(HipOps(0), record_capacity=1 << 12)
+        a, b = sh.shard_range(n, rank, world)
+        h_local = sh.ops.hash_images(imgs[a:b])
+        allh = sh.gather_hashes(h_local, n)
+        ids = torch.arange(a + 1, b + 1, dtype=torch.int32, device=dev)
+        sh.load_shard(h_local, ids)
+        out = {}
+        for dht in (1, 2, 7):
+            i, s, c = sh.similar(allh, dht, 4)
+            out[dht] = (i.cpu().numpy().copy(), s.cpu().numpy().copy(), c.cpu().numpy().copy())
+        q_out.put((rank, allh.cpu().numpy().copy(), out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_equal_single_index(gpu, orc):
+    from cbird_amd import synth
+
+    n = 601
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=300) for _ in range(2)]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    imgs = synth.make_images(n, seed=99)
+    h = orc.dcthash64_batch(imgs)
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    for rank, allh, out in res:
+        assert (allh.view(np.uint64) == h).all()
+        for dht in (1, 2, 7):
+            wi, ws, wc = orc.find64_batch(h, ids, h, dht, 4)
+            gi, gs, gc = out[dht]
+            assert (gc == wc.astype(np.int32)).all() and (gi.view(np.uint32) == wi).all() and (gs == ws).all()
