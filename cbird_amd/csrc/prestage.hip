@@ -1,0 +1,235 @@
+// prestage.hip -- the steps of Scanner::processImage in front of dctHash64 (src/scanner.cpp:852-862):
+//   grayscale()  cv::cvtColor BGR/BGRA -> gray, 14-bit fixed point (src/cvutil.cpp:1265-1283)
+//   autocrop()   de-letterboxing by scanning outwards from the centre (src/cvutil.cpp:1285-1402)
+// and cbh_process_images, which chains gray -> autocrop -> hash for a batch of decoded images of one size.
+#include <vector>
+
+#include "cbh_index.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_bgr2gray(const unsigned char* __restrict__ src, int w, int h,
+                                                  size_t row_stride, size_t img_stride, int channels,
+                                                  unsigned char* __restrict__ dst /* n*w*h */) {
+  const size_t img = blockIdx.y;
+  const unsigned char* s = src + img * img_stride;
+  unsigned char* d = dst + img * (size_t)w * h;
+  const size_t total = (size_t)w * h;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int y = (int)(i / w), x = (int)(i - (size_t)y * w);
+    const unsigned char* p = s + (size_t)y * row_stride + (size_t)x * channels;
+    d[i] = (unsigned char)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + 8192) >> 14);
+  }
+}
+
+// One workgroup per image.  Row/column run lengths are computed in parallel for every row and column (a
+// superset of what the reference's early-exit loops look at), then one thread replays the reference's
+// selection and centring rules.
+__global__ __launch_bounds__(256) void k_autocrop(const unsigned char* __restrict__ imgs, int cols, int rows,
+                                                  size_t row_stride, size_t img_stride, int range,
+                                                  int* __restrict__ rects /* n*4 */,
+                                                  int* __restrict__ scratch /* n*2*(rows+cols) */) {
+  const unsigned char* img = imgs + (size_t)blockIdx.x * img_stride;
+  int* rowL = scratch + (size_t)blockIdx.x * 2 * (size_t)(rows + cols);
+  int* rowR = rowL + rows;
+  int* colT = rowR + rows;
+  int* colB = colT + cols;
+  const int color = img[0];
+  for (int y = threadIdx.x; y < rows; y += blockDim.x) {
+    const unsigned char* p = img + (size_t)y * row_stride;
+    int left, right;
+    for (left = 0; left < cols; left++)
+      if (abs((int)p[left] - color) > range) break;
+    for (right = cols - 1; right >= 0; right--)
+      if (abs((int)p[right] - color) > range) break;
+    rowL[y] = left;
+    rowR[y] = right + 1;
+  }
+  for (int x = threadIdx.x; x < cols; x += blockDim.x) {
+    int t, b;
+    for (t = 0; t < rows; t++)
+      if (abs((int)img[(size_t)t * row_stride + x] - color) > range) break;
+    for (b = rows - 1; b >= 0; b--)
+      if (abs((int)img[(size_t)b * row_stride + x] - color) > range) break;
+    colT[x] = t;
+    colB[x] = b + 1;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const int minWidthCovered = (int)(cols * 0.66f);
+  const int minHeightCovered = (int)(rows * 0.66f);
+  const int maxHMarginDifference = (int)(cols * 0.05f);
+  const int maxVMarginDifference = (int)(rows * 0.05f);
+  int top;
+  for (top = rows / 2; top >= 0; top--)
+    if (rowL[top] > 0 && rowR[top] < cols && rowL[top] + cols - rowR[top] > minWidthCovered) break;
+  top++;
+  int bottom;
+  for (bottom = rows / 2 + 1; bottom < rows; bottom++)
+    if (rowL[bottom] + cols - rowR[bottom] > minWidthCovered) break;
+  int left;
+  for (left = cols / 2; left >= 0; left--)
+    if (colT[left] > 0 && colB[left] < rows && colT[left] + rows - colB[left] > minHeightCovered) break;
+  left++;
+  int right;
+  for (right = cols / 2 + 1; right < cols; right++)
+    if (colT[right] > 0 && colB[right] < rows && colT[right] + rows - colB[right] > minHeightCovered) break;
+  const int bmargin = rows - bottom;
+  if (abs(top - bmargin) > maxVMarginDifference) {
+    if (top > bmargin)
+      top = bmargin;
+    else
+      bottom = rows - top;
+  }
+  const int rmargin = cols - right;
+  if (abs(left - rmargin) > maxHMarginDifference) {
+    if (left > rmargin)
+      left = rmargin;
+    else
+      right = cols - left;
+  }
+  int* r = rects + (size_t)blockIdx.x * 4;
+  r[0] = 0;
+  r[1] = 0;
+  r[2] = cols;
+  r[3] = rows;
+  if ((left != 0 && right != cols) || (top != 0 && bottom != rows))
+    if (left < right && top < bottom && (right - left) / (float)cols > 0.65f &&
+        (bottom - top) / (float)rows > 0.65f) {
+      r[0] = left;
+      r[1] = top;
+      r[2] = right;
+      r[3] = bottom;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cbh_bgr2gray_dev(const void* d_src, size_t n, int w, int h, size_t row_stride, size_t img_stride,
+                     int channels, void* d_gray, int device, void* stream) {
+  if (!cbh::device_usable(device)) return CBH_E_NODEVICE;
+  if (n == 0) return CBH_OK;
+  if (!d_src || !d_gray || w <= 0 || h <= 0 || (channels != 3 && channels != 4)) return CBH_E_INVAL;
+  cbh::DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned bx = (unsigned)std::min<size_t>(1024, ((size_t)w * h + 255) / 256);
+  for (size_t i0 = 0; i0 < n; i0 += 65535) {
+    const size_t m = std::min<size_t>(65535, n - i0);
+    hipLaunchKernelGGL(k_bgr2gray, dim3(bx, (unsigned)m), dim3(256), 0, s,
+                       (const unsigned char*)d_src + i0 * img_stride, w, h, row_stride, img_stride, channels,
+                       (unsigned char*)d_gray + i0 * (size_t)w * h);
+  }
+  CBH_HIP(hipGetLastError());
+  if (!stream) CBH_HIP(hipStreamSynchronize(s));
+  return CBH_OK;
+}
+
+int cbh_autocrop_dev(const void* d_gray, size_t n, int w, int h, size_t row_stride, size_t img_stride, int range,
+                     void* d_rects, int device, void* stream) {
+  if (!cbh::device_usable(device)) return CBH_E_NODEVICE;
+  if (n == 0) return CBH_OK;
+  if (!d_gray || !d_rects || w <= 0 || h <= 0) return CBH_E_INVAL;
+  cbh::DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  hipStream_t s = (hipStream_t)stream;
+  int* scratch = nullptr;
+  CBH_HIP(hipMallocAsync((void**)&scratch, n * 2 * (size_t)(w + h) * sizeof(int), s));
+  hipLaunchKernelGGL(k_autocrop, dim3((unsigned)n), dim3(256), 0, s, (const unsigned char*)d_gray, w, h,
+                     row_stride, img_stride, range, (int*)d_rects, scratch);
+  CBH_HIP(hipGetLastError());
+  CBH_HIP(hipFreeAsync(scratch, s));
+  if (!stream) CBH_HIP(hipStreamSynchronize(s));
+  return CBH_OK;
+}
+
+/* Scanner::processImage's hash for n decoded images of one size (host buffers): grayscale (channels 3 = BGR,
+ * 4 = BGRA, 1 = already gray) -> autocrop(gray, autocrop_range) when autocrop_range >= 0 -> dctHash64.
+ * rects (optional, n*4 ints) receives the kept region {left, top, right, bottom} of every image. */
+int cbh_process_images(const uint8_t* imgs, size_t n, int w, int h, size_t row_stride, size_t img_stride,
+                       int channels, int autocrop_range, uint64_t* out, int32_t* rects, int device) {
+  if (!cbh::device_usable(device)) return CBH_E_NODEVICE;
+  if (n == 0) return CBH_OK;
+  if (!imgs || !out || w <= 0 || h <= 0 || (channels != 1 && channels != 3 && channels != 4) ||
+      row_stride < (size_t)w * channels)
+    return CBH_E_INVAL;
+  cbh::DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  const size_t span1 = (size_t)(h - 1) * row_stride + (size_t)w * channels;
+  size_t per_chunk = std::max<size_t>(1, ((size_t)256 << 20) / std::max(img_stride, span1));
+  per_chunk = std::min(per_chunk, n);
+  uint8_t *d_src = nullptr, *d_gray = nullptr;
+  uint64_t* d_out = nullptr;
+  int* d_rects = nullptr;
+  hipStream_t s = nullptr;
+  int rc = CBH_OK;
+  auto cleanup = [&]() {
+    if (s) (void)hipStreamDestroy(s);
+    for (void* p : {(void*)d_src, (void*)d_gray, (void*)d_out, (void*)d_rects})
+      if (p) (void)hipFree(p);
+  };
+#define CBH_TRY(call)                       \
+  do {                                      \
+    hipError_t e_ = (call);                 \
+    if (e_ != hipSuccess) {                 \
+      cbh::set_last_error(#call, e_);       \
+      cleanup();                            \
+      return e_ == hipErrorOutOfMemory ? CBH_E_NOMEM : CBH_E_HIP; \
+    }                                       \
+  } while (0)
+  CBH_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  CBH_TRY(hipMalloc(&d_src, (per_chunk - 1) * img_stride + span1));
+  if (channels != 1) CBH_TRY(hipMalloc(&d_gray, per_chunk * (size_t)w * h));
+  CBH_TRY(hipMalloc(&d_out, per_chunk * sizeof(uint64_t)));
+  CBH_TRY(hipMalloc(&d_rects, per_chunk * 4 * sizeof(int)));
+  std::vector<int> hr(per_chunk * 4);
+  for (size_t i0 = 0; rc == CBH_OK && i0 < n; i0 += per_chunk) {
+    const size_t m = std::min(per_chunk, n - i0);
+    CBH_TRY(hipMemcpyAsync(d_src, imgs + i0 * img_stride, (m - 1) * img_stride + span1, hipMemcpyHostToDevice, s));
+    const uint8_t* gray = d_src;
+    size_t gs = row_stride, gi = img_stride;
+    if (channels != 1) {
+      rc = cbh_bgr2gray_dev(d_src, m, w, h, row_stride, img_stride, channels, d_gray, device, s);
+      if (rc) break;
+      gray = d_gray;
+      gs = (size_t)w;
+      gi = (size_t)w * h;
+    }
+    bool cropped = false;
+    if (autocrop_range >= 0) {
+      rc = cbh_autocrop_dev(gray, m, w, h, gs, gi, autocrop_range, d_rects, device, s);
+      if (rc) break;
+      CBH_TRY(hipMemcpyAsync(hr.data(), d_rects, m * 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+      CBH_TRY(hipStreamSynchronize(s));
+      for (size_t i = 0; i < m; ++i)
+        cropped |= hr[i * 4] != 0 || hr[i * 4 + 1] != 0 || hr[i * 4 + 2] != w || hr[i * 4 + 3] != h;
+    } else {
+      for (size_t i = 0; i < m; ++i) {
+        hr[i * 4] = hr[i * 4 + 1] = 0;
+        hr[i * 4 + 2] = w;
+        hr[i * 4 + 3] = h;
+      }
+    }
+    if (!cropped) {
+      rc = cbh::launch_dcthash(gray, m, w, h, gs, gi, d_out, s);
+    } else {
+      // cropped images have their own geometry: one launch per image on its sub-view
+      for (size_t i = 0; i < m && rc == CBH_OK; ++i) {
+        const int* r = &hr[i * 4];
+        rc = cbh::launch_dcthash(gray + i * gi + (size_t)r[1] * gs + r[0], 1, r[2] - r[0], r[3] - r[1], gs, gi,
+                                 d_out + i, s);
+      }
+    }
+    if (rc) break;
+    CBH_TRY(hipMemcpyAsync(out + i0, d_out, m * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    CBH_TRY(hipStreamSynchronize(s));
+    if (rects) memcpy(rects + i0 * 4, hr.data(), m * 4 * sizeof(int));
+  }
+#undef CBH_TRY
+  cleanup();
+  return rc;
+}
+
+}  // extern "C"

@@ -35,3 +35,21 @@ def dct_hash64(img: np.ndarray, device: int = 0) -> int:
     if img.ndim != 2:
         raise ValueError("expected a single-channel 2-D uint8 image")
     return int(dct_hash64_batch(img[None, ...], device)[0])
+
+
+def process_images(imgs: np.ndarray, autocrop: int | None = 20, device: int = 0):
+    """The hash Scanner::processImage stores for decoded images (src/scanner.cpp:852-862): grayscale ->
+    autocrop(gray, 20) when enabled -> dctHash64.  imgs: uint8 [n,h,w] (gray) or [n,h,w,3|4] (BGR/BGRA).
+    Returns (hashes u64[n], rects int32[n,4] = left, top, right, bottom of the kept region)."""
+    imgs = np.ascontiguousarray(imgs)
+    if imgs.dtype != np.uint8 or imgs.ndim not in (3, 4):
+        raise ValueError("expected uint8 [n,h,w] or [n,h,w,c]")
+    n, h, w = imgs.shape[:3]
+    ch = 1 if imgs.ndim == 3 else imgs.shape[3]
+    out = np.zeros(n, np.uint64)
+    rects = np.zeros((n, 4), np.int32)
+    if n:
+        check(_lib.lib().cbh_process_images(imgs.ctypes.data, n, w, h, w * ch, w * h * ch, ch,
+                                            -1 if autocrop is None else int(autocrop), out.ctypes.data,
+                                            rects.ctypes.data, device), "process_images")
+    return out, rects

@@ -80,6 +80,20 @@ int cbh_dcthash_batch(const uint8_t* imgs, size_t n, int w, int h, size_t row_st
 int cbh_dcthash_batch_dev(const void* d_imgs, size_t n, int w, int h, size_t row_stride,
                           size_t img_stride, void* d_out, int device, void* stream);
 
+/* ---- the steps in front of dctHash64 in Scanner::processImage (src/scanner.cpp:852-862) -------------------
+ * grayscale(): cv::cvtColor(BGR2GRAY/BGRA2GRAY) on 8-bit data (src/cvutil.cpp:1265-1283); d_gray is packed
+ * n*w*h bytes. */
+int cbh_bgr2gray_dev(const void* d_src, size_t n, int w, int h, size_t row_stride, size_t img_stride,
+                     int channels, void* d_gray, int device, void* stream);
+/* autocrop(gray, range) (src/cvutil.cpp:1285-1402): d_rects[i] = {left, top, right, bottom} (int32 x4) of the
+ * region kept (the whole image when nothing is cropped). */
+int cbh_autocrop_dev(const void* d_gray, size_t n, int w, int h, size_t row_stride, size_t img_stride, int range,
+                     void* d_rects, int device, void* stream);
+/* processImage's hash for n decoded images of one size in host memory: grayscale (channels 1/3/4) ->
+ * autocrop when autocrop_range >= 0 (cbird uses 20) -> dctHash64 of the kept region.  rects may be NULL. */
+int cbh_process_images(const uint8_t* imgs, size_t n, int w, int h, size_t row_stride, size_t img_stride,
+                       int channels, int autocrop_range, uint64_t* out, int32_t* rects, int device);
+
 /* Stage-level diagnostics: as cbh_dcthash_batch_dev, and additionally writes the 32x32 u8 tile
  * each image is reduced to after stages 1-2 (blur + INTER_AREA) to d_tiles[i*1024 ..]. */
 int cbh_dcthash_tiles_dev(const void* d_imgs, size_t n, int w, int h, size_t row_stride,

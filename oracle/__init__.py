@@ -518,3 +518,43 @@ class ColorOracle:
         osc = np.zeros(cap, np.int32)
         m = self.L.orc_color_find(self._bytes(descs), ids, len(ids), self._bytes(target), oi, osc, cap)
         return oi[:m].copy(), osc[:m].copy()
+
+
+class PrestageOracle:
+    """oracle/cbird_oracle.c: grayscale, autocrop and the processImage hash"""
+
+    def __init__(self) -> None:
+        build()
+        L = C.CDLL(_ORACLE_SO)
+        self.L = L
+        L.orc_bgr2gray.argtypes = [_u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, _u8p]
+        L.orc_autocrop.argtypes = [_u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, _i32p]
+        L.orc_autocrop.restype = C.c_int
+        L.orc_process_image.argtypes = [_u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, _u64p, _i32p]
+        L.orc_process_image.restype = C.c_int
+
+    def bgr2gray(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w, ch = img.shape
+        out = np.zeros((h, w), np.uint8)
+        self.L.orc_bgr2gray(img.reshape(-1), w, h, w * ch, ch, out.reshape(-1))
+        return out
+
+    def autocrop(self, gray, rng=20):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        r = np.zeros(4, np.int32)
+        self.L.orc_autocrop(gray.reshape(-1), w, h, w, int(rng), r)
+        return r
+
+    def process_image(self, img, autocrop=20):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape[:2]
+        ch = 1 if img.ndim == 2 else img.shape[2]
+        out = np.zeros(1, np.uint64)
+        r = np.zeros(4, np.int32)
+        rc = self.L.orc_process_image(img.reshape(-1), w, h, w * ch, ch, -1 if autocrop is None else autocrop,
+                                      out, r)
+        if rc:
+            raise ValueError(f"orc_process_image rc={rc}")
+        return int(out[0]), r

@@ -1063,3 +1063,118 @@ long long orc_color_find(const uint8_t* descs, const uint32_t* ids, size_t n, co
   }
   return m;
 }
+
+/* ---- pre-stages of Scanner::processImage (src/scanner.cpp:852-862) --------------------------------
+ * grayscale(): cv::cvtColor(BGR2GRAY / BGRA2GRAY) on 8-bit data (src/cvutil.cpp:1265-1283).  OpenCV 2.4
+ * uses 14-bit fixed point: (B*1868 + G*9617 + R*4899 + 8192) >> 14 (as recalled: "parity unpinned"). */
+void orc_bgr2gray(const uint8_t* src, int w, int h, size_t stride, int channels, uint8_t* dst) {
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      const uint8_t* p = src + (size_t)y * stride + (size_t)x * channels;
+      dst[(size_t)y * w + x] = (uint8_t)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + 8192) >> 14);
+    }
+}
+
+/* autocrop(): src/cvutil.cpp:1285-1402, restated statement by statement.  rect = {left, top, right,
+ * bottom} of the kept region (the full image when nothing is cropped).  Returns 1 if a crop happens. */
+int orc_autocrop(const uint8_t* img, int cols, int rows, size_t stride, int range, int* rect) {
+  rect[0] = 0;
+  rect[1] = 0;
+  rect[2] = cols;
+  rect[3] = rows;
+  if (rows == 0 || cols == 0) return 0;
+#define PX(y, x) ((int)img[(size_t)(y)*stride + (x)])
+  const int color = PX(0, 0);
+  const int minWidthCovered = (int)(cols * 0.66f);
+  const int minHeightCovered = (int)(rows * 0.66f);
+  const int maxHMarginDifference = (int)(cols * 0.05f);
+  const int maxVMarginDifference = (int)(rows * 0.05f);
+  int top;
+  for (top = rows / 2; top >= 0; top--) {
+    int left, right;
+    for (left = 0; left < cols; left++)
+      if (abs(PX(top, left) - color) > range) break;
+    for (right = cols - 1; right >= 0; right--)
+      if (abs(PX(top, right) - color) > range) break;
+    right++;
+    if (left > 0 && right < cols && left + cols - right > minWidthCovered) break;
+  }
+  top++;
+  int bottom;
+  for (bottom = rows / 2 + 1; bottom < rows; bottom++) {
+    int left, right;
+    for (left = 0; left < cols; left++)
+      if (abs(PX(bottom, left) - color) > range) break;
+    for (right = cols - 1; right >= 0; right--)
+      if (abs(PX(bottom, right) - color) > range) break;
+    right++;
+    if (left + cols - right > minWidthCovered) break;
+  }
+  int left;
+  for (left = cols / 2; left >= 0; left--) {
+    int t, b;
+    for (t = 0; t < rows; t++)
+      if (abs(PX(t, left) - color) > range) break;
+    for (b = rows - 1; b >= 0; b--)
+      if (abs(PX(b, left) - color) > range) break;
+    b++;
+    if (t > 0 && b < rows && t + rows - b > minHeightCovered) break;
+  }
+  left++;
+  int right;
+  for (right = cols / 2 + 1; right < cols; right++) {
+    int t, b;
+    for (t = 0; t < rows; t++)
+      if (abs(PX(t, right) - color) > range) break;
+    for (b = rows - 1; b >= 0; b--)
+      if (abs(PX(b, right) - color) > range) break;
+    b++;
+    if (t > 0 && b < rows && t + rows - b > minHeightCovered) break;
+  }
+#undef PX
+  int bmargin = rows - bottom;
+  if (abs(top - bmargin) > maxVMarginDifference) {
+    if (top > bmargin)
+      top = bmargin;
+    else
+      bottom = rows - top;
+  }
+  int rmargin = cols - right;
+  if (abs(left - rmargin) > maxHMarginDifference) {
+    if (left > rmargin)
+      left = rmargin;
+    else
+      right = cols - left;
+  }
+  if ((left != 0 && right != cols) || (top != 0 && bottom != rows))
+    if (left < right && top < bottom && (right - left) / (float)cols > 0.65f &&
+        (bottom - top) / (float)rows > 0.65f) {
+      rect[0] = left;
+      rect[1] = top;
+      rect[2] = right;
+      rect[3] = bottom;
+      return 1;
+    }
+  return 0;
+}
+
+/* processImage's hash: grayscale -> autocrop(gray, 20) when enabled -> dctHash64 (scanner.cpp:852-862).
+ * channels 1, 3 (BGR) or 4 (BGRA). */
+int orc_process_image(const uint8_t* img, int w, int h, size_t stride, int channels, int autocrop_range,
+                      uint64_t* out, int* rect) {
+  uint8_t* gray = NULL;
+  const uint8_t* g = img;
+  size_t gs = stride;
+  if (channels != 1) {
+    gray = (uint8_t*)malloc((size_t)w * h);
+    orc_bgr2gray(img, w, h, stride, channels, gray);
+    g = gray;
+    gs = (size_t)w;
+  }
+  int r[4] = {0, 0, w, h};
+  if (autocrop_range >= 0) orc_autocrop(g, w, h, gs, autocrop_range, r);
+  if (rect) memcpy(rect, r, sizeof r);
+  int rc = orc_dcthash64(g + (size_t)r[1] * gs + r[0], r[2] - r[0], r[3] - r[1], gs, out);
+  free(gray);
+  return rc;
+}
