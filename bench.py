@@ -117,11 +117,19 @@ def main():
 
     from cbird_amd.dist import HipOps, ShardedDctHashIndex
 
+    # CBH_BENCH_SHARE_GPU=1 (development aid): all ranks on cuda:0 with gloo, to exercise the N>1 code path on
+    # a single-GPU box.  Never set by the driver; RCCL ("nccl") is the real transport.
+    share = os.environ.get("CBH_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     ops = HipOps(local_rank)  # raises without libcbird_hip.so / a gfx950 device: no fallback
     sh = ShardedDctHashIndex(ops, record_capacity=1 << 22)
 
@@ -169,7 +177,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -276,7 +284,7 @@ def cpu_baseline(args, torch, imgs, state, n, dhts):
     budget = args.cpu_seconds
     out = {"cores": cores}
     # -- hash leg (port): bounded sample of the images, one image per task over all cores
-    m_img = min(len(imgs), 4096)
+    m_img = min(len(imgs), 32768)
     sample = imgs[:m_img].cpu().numpy()
     t0 = time.perf_counter()
     parts = np.array_split(np.arange(m_img), cores * 4)

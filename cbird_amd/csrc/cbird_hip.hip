@@ -448,22 +448,19 @@ int cbh_sort_records_dev(void* d_records, size_t n, size_t nq, int device, void*
   cbh_record* alt = nullptr;
   void* tmp = nullptr;
   const size_t tmp_bytes = sort_records_scratch_bytes(n);
-  CBH_HIP(hipMalloc(&alt, n * sizeof(cbh_record)));
-  hipError_t e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
+  // stream-ordered scratch: no device-wide synchronisation, the pool recycles the blocks between calls
+  CBH_HIP(hipMallocAsync((void**)&alt, n * sizeof(cbh_record), s));
+  hipError_t e = hipMallocAsync(&tmp, tmp_bytes ? tmp_bytes : 16, s);
   if (e != hipSuccess) {
-    (void)hipFree(alt);
-    set_last_error("hipMalloc(sort scratch)", e);
+    (void)hipFreeAsync(alt, s);
+    set_last_error("hipMallocAsync(sort scratch)", e);
     return CBH_E_NOMEM;
   }
   int rc = launch_sort_records((cbh_record*)d_records, alt, n, nq, tmp, tmp_bytes, s);
-  e = hipStreamSynchronize(s);
-  (void)hipFree(alt);
-  (void)hipFree(tmp);
+  (void)hipFreeAsync(alt, s);
+  (void)hipFreeAsync(tmp, s);
   if (rc) return rc;
-  if (e != hipSuccess) {
-    set_last_error("sort sync", e);
-    return CBH_E_HIP;
-  }
+  if (!stream) CBH_HIP(hipStreamSynchronize(s));
   return CBH_OK;
 }
 

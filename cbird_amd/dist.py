@@ -165,3 +165,34 @@ class ShardedDctHashIndex:
         # pads sort to the end; only the first n_total records are real
         self.ops.sort_records(merged, merged.numel() if self.world > 1 else n_total, nq + 1)
         return self.ops.select(merged, n_total, nq, max_per_query)
+
+
+class NeedleParallel:
+    """Data parallelism over needles, the reference's own strategy (QtConcurrent::map over the haystack items,
+    src/database.cpp:1400-1432) across processes instead of threads: every rank holds the whole index (the
+    fdct / video / ORB / colour indexes of BASELINE's configs are a few GB, a fraction of one GPU's 288 GB),
+    takes a contiguous slice of the needle list, runs the index's batched find on it and the per-needle
+    results are gathered.  No data-path collective: the only exchange is the final result gather."""
+
+    def __init__(self, group=None) -> None:
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def my_slice(self, n: int):
+        return ShardedDctHashIndex.shard_range(n, self.rank, self.world)
+
+    def run(self, needles, find_batch, gather: bool = True):
+        """find_batch(list_of_needles) -> list of per-needle results (any picklable objects).  Returns the
+        results for ALL needles in order (gather=True) or just this rank's slice."""
+        needles = list(needles)
+        a, b = self.my_slice(len(needles))
+        mine = find_batch(needles[a:b]) if b > a else []
+        if self.world == 1 or not gather:
+            return mine
+        parts = [None] * self.world
+        dist.all_gather_object(parts, mine, group=self.group)
+        out = []
+        for p in parts:
+            out += p
+        return out

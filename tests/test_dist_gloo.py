@@ -125,3 +125,38 @@ def test_shard_ranges_cover_everything():
             r = [ShardedDctHashIndex.shard_range(n, k, w) for k in range(w)]
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+
+
+def _np_worker(rank, world, port, q_out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cbird_amd.dist import NeedleParallel
+
+        npar = NeedleParallel()
+        calls = []
+
+        def fb(chunk):
+            calls.append(len(chunk))
+            return [(x, x * x) for x in chunk]
+
+        res = npar.run(list(range(11)), fb)
+        q_out.put((rank, res, calls, npar.my_slice(11)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_needle_parallel_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_np_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = [q.get(timeout=120) for _ in range(2)]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    slices = sorted(g[3] for g in got)
+    assert slices == [(0, 5), (5, 11)]
+    for rank, res, calls, sl in got:
+        assert res == [(x, x * x) for x in range(11)]
+        assert calls == [sl[1] - sl[0]]

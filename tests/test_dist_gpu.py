@@ -62,3 +62,68 @@ def test_two_ranks_one_gpu_equal_single_index(gpu, orc):
             wi, ws, wc = orc.find64_batch(h, ids, h, dht, 4)
             gi, gs, gc = out[dht]
             assert (gc == wc.astype(np.int32)).all() and (gi.view(np.uint32) == wi).all() and (gs == ws).all()
+
+
+def _video_worker(rank, world, port, q_out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cbird_amd import synth_video
+        from cbird_amd.dist import NeedleParallel
+        from cbird_amd.video import DctVideoIndex, VideoIndex, VideoSearchParams
+
+        clips = synth_video.make_clips(200, 150, seed=21, subclip_frac=0.1, max_gap=8)
+
+        class M:
+            pass
+
+        media = []
+        for i, (f, h) in enumerate(clips):
+            m = M()
+            m.id, m.path, m.videoIndex = i + 1, f"c{i}", VideoIndex(f.tolist(), [int(x) for x in h])
+            media.append(m)
+        idx = DctVideoIndex()
+        idx.add(media)
+        p = VideoSearchParams(dctThresh=5, skipFrames=0, minFramesMatched=10, minFramesNear=30)
+        key = lambda r: [(x.mediaId, x.score, x.range.srcIn, x.range.dstIn, x.range.len) for x in r]
+        res = NeedleParallel().run(media, lambda chunk: [key(r) for r in idx.find_videos_batch(chunk, p)])
+        q_out.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_video_needle_parallel_two_ranks(gpu):
+    """BASELINE configs[4] shape (video search spread over ranks), 2 ranks on one GPU: needle-parallel result ==
+    single-process result"""
+    from cbird_amd import synth_video
+    from cbird_amd.video import DctVideoIndex, VideoIndex, VideoSearchParams
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = [ctx.Process(target=_video_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = [q.get(timeout=300) for _ in range(2)]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    clips = synth_video.make_clips(200, 150, seed=21, subclip_frac=0.1, max_gap=8)
+
+    class M:
+        pass
+
+    media = []
+    for i, (f, h) in enumerate(clips):
+        m = M()
+        m.id, m.path, m.videoIndex = i + 1, f"c{i}", VideoIndex(f.tolist(), [int(x) for x in h])
+        media.append(m)
+    idx = DctVideoIndex()
+    idx.add(media)
+    p = VideoSearchParams(dctThresh=5, skipFrames=0, minFramesMatched=10, minFramesNear=30)
+    want = [[(x.mediaId, x.score, x.range.srcIn, x.range.dstIn, x.range.len) for x in r]
+            for r in idx.find_videos_batch(media, p)]
+    assert sum(len(r) for r in want) > 5
+    for rank, res in got:
+        assert res == want
