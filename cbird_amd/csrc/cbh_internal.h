@@ -29,6 +29,8 @@ enum { SCAN_KEEP_ID0 = 1u };  // also emit slots whose id is 0 (DctFeaturesIndex
 
 void set_scan_tuning(int pre_max, int eq_for_dht1, int group);  // <0 = keep
 
+int g_hash_mfma_set(int v);  // dcthash.hip
+
 // ---- records.hip ----------------------------------------------------------------------
 // Ascending u64 sort of n records in place (uses d_alt as the ping-pong buffer and d_tmp as
 // scratch; sizes from sort_records_scratch_bytes).

@@ -282,7 +282,9 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
 
 /* Kernel-variant knobs for experiments (results never change, only speed):
  *   "scan_pre_max"  largest threshold served by the low-word-prefilter scan variant (default 7)
- *   "scan_eq_dht1"  1 = dht==1 uses the 64-bit equality variant (default 1) */
+ *   "scan_eq_dht1"  1 = dht==1 uses the 64-bit equality variant (default 1)
+ *   "scan_group"    1 = issue-rate-shaped scan variants (default 1)
+ *   "hash_mfma"     1 = 256x256 tiles use k_dcthash_256_mfma (box filter on the matrix cores; default 0) */
 int cbh_set_tuning(const char* key, int value);
 
 /* ---- measurement support ---------------------------------------------------------------- */

@@ -120,3 +120,32 @@ def test_hash_large_batch_sampled(gpu, orc):
     sample = np.random.default_rng(1).choice(n, 256, replace=False)
     want = orc.dcthash64_batch(imgs[torch.from_numpy(sample).cuda()].cpu().numpy())
     assert (got[sample] == want).all()
+
+
+def test_mfma_variant_is_bit_identical(gpu, orc):
+    """k_dcthash_256_mfma (box filter on the matrix cores, tuning knob "hash_mfma") == the default kernel == oracle"""
+    import torch
+
+    from cbird_amd import _lib, synth
+
+    L = _lib.lib()
+    imgs = np.concatenate([synth.make_images(37, seed=3), np.random.default_rng(4).integers(0, 256, (30, 256, 256),
+                                                                                          dtype=np.uint8)])
+    imgs[5] = 0
+    imgs[6] = 255
+    want = orc.dcthash64_batch(imgs)
+    try:
+        L.cbh_set_tuning(b"hash_mfma", 1)
+        got = gpu.dct_hash64_batch(imgs)
+        d = torch.from_numpy(imgs).cuda()
+        out = torch.zeros(len(imgs), dtype=torch.int64, device="cuda")
+        tiles = torch.zeros((len(imgs), 32, 32), dtype=torch.uint8, device="cuda")
+        _lib.check(L.cbh_dcthash_tiles_dev(d.data_ptr(), len(imgs), 256, 256, 256, 65536, out.data_ptr(),
+                                           tiles.data_ptr(), 0, None), "tiles")
+    finally:
+        L.cbh_set_tuning(b"hash_mfma", 0)
+    assert (got == want).all()
+    t = tiles.cpu().numpy()
+    for i in range(0, len(imgs), 7):
+        assert (t[i] == orc.tile32(imgs[i])).all()
+    assert (gpu.dct_hash64_batch(imgs) == want).all()
