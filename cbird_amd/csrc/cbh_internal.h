@@ -29,6 +29,14 @@ enum { SCAN_KEEP_ID0 = 1u };  // also emit slots whose id is 0 (DctFeaturesIndex
 
 void set_scan_tuning(int pre_max, int eq_for_dht1, int group);  // <0 = keep
 
+// ---- hamm64_mfma.hip: the same scan on the matrix cores (FP4 sign dot products) --------
+int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n,
+                            const uint64_t* d_q, size_t nq, int thresh, cbh_record* d_rec,
+                            size_t cap, unsigned long long* d_total, hipStream_t stream,
+                            unsigned flags = 0);
+bool scan_mfma_wanted(size_t n, size_t nq, int thresh);
+void set_scan_mfma(int on);  // <0 = keep
+
 int g_hash_mfma_set(int v);  // dcthash.hip
 
 // ---- records.hip ----------------------------------------------------------------------

@@ -490,6 +490,10 @@ int cbh_set_tuning(const char* key, int value) {
     set_scan_tuning(-1, value, -1);
     return CBH_OK;
   }
+  if (!strcmp(key, "scan_mfma")) {
+    set_scan_mfma(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "hash_mfma")) {
     g_hash_mfma_set(value);
     return CBH_OK;

@@ -69,12 +69,13 @@ __device__ __forceinline__ void exact_block(const uint2 (&h)[H], uint32_t base_i
 }
 
 // second level of the filter: only slots whose running minimum fell under the threshold are
-// re-evaluated exactly against the QB needles of the block (re-read through the scalar cache)
+// re-evaluated exactly against the QB needles of the block.  The needles are still in SGPRs
+// (cur[]), so this costs ~5 VALU ops per needle and no memory access; the media id is fetched
+// only for a pair that really matches (about one in 10^6 on distinct images).
 template <int H, int QB>
 __device__ __forceinline__ void refine_block(const uint2 (&h)[H], const uint32_t (&acc)[H],
-                                             uint32_t base_idx, uint32_t n,
-                                             const uint32_t* __restrict__ ids,
-                                             const uint64_t* __restrict__ q, uint32_t qb,
+                                             const uint2 (&cur)[QB], uint32_t base_idx, uint32_t n,
+                                             const uint32_t* __restrict__ ids, uint32_t qb,
                                              uint32_t thresh, cbh_record* __restrict__ rec,
                                              unsigned long long cap,
                                              unsigned long long* __restrict__ total,
@@ -83,13 +84,20 @@ __device__ __forceinline__ void refine_block(const uint2 (&h)[H], const uint32_t
   for (int j = 0; j < H; ++j) {
     if (acc[j] < thresh) {
       const uint32_t idx = base_idx + (uint32_t)j * kThreads;
-      const uint32_t id = idx < n ? ids[idx] : 0u;
-      if (idx < n && (id != 0 || keep0)) {
-#pragma unroll 1
-        for (uint32_t qi = qb; qi < qb + QB; ++qi) {
-          const uint64_t qq = q[qi];
-          const uint32_t d = __popc(h[j].x ^ (uint32_t)qq) + __popc(h[j].y ^ (uint32_t)(qq >> 32));
-          if (d < thresh && qq != 0) emit(rec, cap, total, qi, d, id);
+      // exact distances of the QB needles to slot j; one branch for the (rare) real match
+      uint32_t d[QB];
+#pragma unroll
+      for (int i = 0; i < QB; ++i) d[i] = __popc(h[j].x ^ cur[i].x) + __popc(h[j].y ^ cur[i].y);
+      uint32_t m = d[0];
+#pragma unroll
+      for (int i = 1; i + 1 < QB; i += 2) m = min3u(m, d[i], d[i + 1]);
+      if (QB % 2 == 0) m = min(m, d[QB - 1]);
+      if (m < thresh && idx < n) {
+        const uint32_t id = ids[idx];
+        if (id != 0 || keep0) {
+#pragma unroll
+          for (int i = 0; i < QB; ++i)
+            if (d[i] < thresh && (cur[i].x | cur[i].y) != 0) emit(rec, cap, total, qb + (uint32_t)i, d[i], id);
         }
       }
     }
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_scan(
 #pragma unroll
       for (int j = 1; j + 1 < H; j += 2) m = min3u(m, acc[j], acc[j + 1]);
       if (H % 2 == 0) m = min(m, acc[H - 1]);
-      if (m < thresh) refine_block<H, QB>(h, acc, base_idx, n, ids, q, qb, thresh, rec, cap, total, keep0);
+      if (m < thresh) refine_block<H, QB>(h, acc, cur, base_idx, n, ids, qb, thresh, rec, cap, total, keep0);
     }
 #pragma unroll
     for (int i = 0; i < QB; ++i) cur[i] = nxt[i];
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_scan(
   if (qb < q1) exact_block<H>(h, base_idx, n, ids, q, qb, q1, thresh, rec, cap, total, keep0);
 }
 
-int g_pre_max = 6;  // largest threshold served by the low-word prefilter variant
+int g_pre_max = 7;  // largest threshold served by the low-word prefilter variant
 int g_eq_for_dht1 = 1;
 int g_group = 1;
 
@@ -241,6 +249,9 @@ int launch_hamm64_scan(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n
                        unsigned long long* d_total, hipStream_t stream, unsigned flags) {
   if (n == 0 || nq == 0 || thresh <= 0) return CBH_OK;
   if (n > 0xfffffff0ull || nq > CBH_MAX_QUERIES_PER_CALL) return CBH_E_INVAL;
+  if (scan_mfma_wanted(n, nq, thresh))
+    return launch_hamm64_scan_mfma(d_hashes, d_ids, n, d_q, nq, thresh, d_rec, cap, d_total, stream,
+                                   flags);
   const uint32_t tile = kThreads * kH;
   const uint32_t tiles = (uint32_t)((n + tile - 1) / tile);
   // needle chunk: enough workgroups to fill 256 CUs x 8 waves/SIMD several times over, but each

@@ -22,10 +22,11 @@ ms = C.c_float(0)
 for name, dq in sets.items():
     idx = cbird_amd.DctHashIndex(); ids = torch.arange(1, N + 1, dtype=torch.int32, device=dev)
     idx.load_device(dq.data_ptr(), ids.data_ptr(), N)
-    for thr in (1, 2, 5, 6, 7, 8):
+    for thr in (1, 2, 5, 8, 12):
         row = []
-        for label, pre, eq, grp in (("pre", 64, 0, 0), ("preG", 64, 0, 1), ("full", 0, 0, 0), ("fullG", 0, 0, 1), ("eq", 0, 1, 0)):
+        for label, pre, eq, grp in (("mfma", 0, 0, 0), ("preG", 64, 0, 1), ("fullG", 0, 0, 1), ("eq", 0, 1, 0)):
             if label == "eq" and thr != 1: continue
+            L.cbh_set_tuning(b"scan_mfma", 1 if label == "mfma" else 0)
             L.cbh_set_tuning(b"scan_pre_max", pre); L.cbh_set_tuning(b"scan_eq_dht1", eq); L.cbh_set_tuning(b"scan_group", grp)
             _lib.check(L.cbh_idx64_time_scan_dev(idx.handle, dq.data_ptr(), N, thr, drec.data_ptr(), cap, dtot.data_ptr(), 1, C.byref(ms)), "w")
             _lib.check(L.cbh_idx64_time_scan_dev(idx.handle, dq.data_ptr(), N, thr, drec.data_ptr(), cap, dtot.data_ptr(), 2, C.byref(ms)), "t")
