@@ -10,7 +10,7 @@ Workload = configs[1] (configs[2] when N > 1, same job sharded): 1M synthetic pr
     build : dctHash64 of every image (k_dcthash_256) -> u64[1M]; all-gather of the hashes when
             N > 1; (re)load of this rank's DctHashIndex shard
     find  : all-pairs DctHashIndex find (1M needles x 1M slots) for every dht in 1..8
-            (k_hamm64_scan + record exchange/sort/select, maxMatches-style cut at k=8)
+            (k_hamm64_mfma + record exchange/sort/select, maxMatches-style cut at k=8)
 value = 64-bit Hamming comparisons/s over the whole step (8 x 10^12 comparisons per step; the
 build time is inside the denominator); images hashed/s is reported next to it.
 Prints ONE JSON line on rank 0.
@@ -27,16 +27,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# k_hamm64_scan variants: "eq" (dht 1): 1 v_cmp_eq_u64; "pre" (dht 2..6): 1 fast xor + bcnt + 0.5 min3 (+3 %
-# block overhead); "full": 2 fast xor + 2 bcnt + 0.5 min3
-VALU_CYCLES = {"eq": 4.0, "pre": 2.0 + 1.58 * 4, "full": 4.0 + 2.58 * 4}
-
-
-def variant_of(dht):
-    return "eq" if dht == 1 else ("pre" if dht <= 6 else "full")
-
-
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# k_hamm64_mfma: one 64-bit comparison = one K=64 sign dot product = 64 multiply-adds on the FP4
+# matrix path; dense FP4 MFMA peak from the same guide (~10 PF; its own micro-benchmark reaches 9.1)
+FP4_PEAK_TFLOPS = 10000.0
+FLOP_PER_CMP = 128.0
 W = H = 256
 
 
@@ -200,6 +195,7 @@ def main():
     scan_ms_avg = sum(sum(v) for v in scans.values()) / sum(len(v) for v in scans.values())
     scan_bytes = 8.0 * shard_n * n  # 8 algorithmic bytes per 64-bit comparison
     scan_gbs = scan_bytes / (scan_ms_avg * 1e-3) / 1e9
+    scan_tflops = FLOP_PER_CMP * shard_n * n / (scan_ms_avg * 1e-3) / 1e12
     hash_bytes = (W * H + 8.0) * shard_n  # 65 536 B read + 8 B written per image
     hash_gbs = hash_bytes / (hash_ms * 1e-3) / 1e9
 
@@ -218,7 +214,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "u64 popcount (find) / u8+f32 (hash)",
+        "dtype": "u64 hashes as 64 x FP4 signs, f32 accumulate (find, exact) / u8+f32 (hash)",
         "data": "synthetic",
         "config": {
             "workload": ("configs[1]: 1M pre-decoded 256x256 images, DctHashIndex build+find on 1xMI355X, "
@@ -230,16 +226,15 @@ def main():
         },
         "dht_sweep": sweep,
         "roofline": {
-            "kernel": "k_hamm64_scan", "bound": "hbm", "achieved": scan_gbs, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": scan_gbs / HBM_PEAK_GBS, "traffic": None,
-            "avg_launch_ms": scan_ms_avg, "algorithmic_bytes_per_launch": scan_bytes,
-            "note": ("algorithmic bytes (8 B per comparison) exceed HBM peak because the needle tile is "
-                     "reused from SGPRs and the 8 MB haystack stays in L2/MALL; the binding unit is the "
-                     "integer VALU -- see valu_frac and DESIGN.md"),
-            # issue model measured with tools/ubench/valu_rate.hip: a wave64 VALU op occupies its SIMD for 4
-            # cycles, 2 inside long runs of plain VGPR-only add/xor/...; cycles per (needle, slot) pair per wave:
-            "valu_cycles_per_pair_wave": VALU_CYCLES,
-            "valu_peak_note": "peak pairs/s of a variant = 1024 SIMDs * 64 lanes * 2.4e9 / cycles",
+            "kernel": "k_hamm64_mfma", "bound": "mfma", "achieved": scan_tflops, "peak": FP4_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": scan_tflops / FP4_PEAK_TFLOPS, "traffic": None,
+            "avg_launch_ms": scan_ms_avg, "algorithmic_flop_per_launch": FLOP_PER_CMP * shard_n * n,
+            "algorithmic_bytes_per_launch": scan_bytes, "hbm_equivalent_GBps": scan_gbs,
+            "note": ("each comparison is a 64-term +-1 dot product (64 - 2*hamm64) on v_mfma_scale_f32_32x32x64_"
+                     "f8f6f4 with FP4 operands: 128 FLOP.  SURVEY 8(d)'s 8 algorithmic bytes per comparison "
+                     "are kept as hbm_equivalent_GBps; the kernel is not memory-bound (traffic = PMC HBM bytes "
+                     "per launch), the binding unit is the matrix core.  avg_launch_ms brackets the needle "
+                     "expansion kernel + the scan kernel of one launch."),
         },
         "roofline_hash": {
             "kernel": "k_dcthash_256", "bound": "hbm", "achieved": hash_gbs, "peak": HBM_PEAK_GBS,
@@ -247,14 +242,11 @@ def main():
             "avg_launch_ms": hash_ms, "algorithmic_bytes_per_launch": hash_bytes,
         },
     }
-    # weighted VALU fraction of the scan launches
-    cyc = sum(VALU_CYCLES[variant_of(d)] * shard_n * n * len(scans[d]) for d in dhts)
-    result["roofline"]["valu_frac"] = (cyc / (1024 * 64 * 2.4e9)) / (sum(sum(v) for v in scans.values()) * 1e-3)
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
             t = json.load(open(pmc))
-            result["roofline"]["traffic"] = t.get("k_hamm64_scan")
+            result["roofline"]["traffic"] = t.get("k_hamm64_mfma")
             result["roofline_hash"]["traffic"] = t.get("k_dcthash_256")
         except Exception:
             pass

@@ -35,7 +35,8 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
                             size_t cap, unsigned long long* d_total, hipStream_t stream,
                             unsigned flags = 0);
 bool scan_mfma_wanted(size_t n, size_t nq, int thresh);
-void set_scan_mfma(int on);  // <0 = keep
+void set_scan_mfma(int on);  // <0 = keep; 2 = force for any size
+void set_scan_mfma_ht(int ht);
 
 int g_hash_mfma_set(int v);  // dcthash.hip
 

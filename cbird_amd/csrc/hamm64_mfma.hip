@@ -42,7 +42,6 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
-constexpr int kHT = 4;  // haystack tiles per wave
 constexpr int kG = 2;   // tiles per accumulator group
 constexpr uint32_t kLoZero = 0x4080u;  // lo16 at distance 0
 constexpr uint32_t kHiZero = 0x4B40u;  // hi16 at distance 0
@@ -93,6 +92,7 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_mfma(
     const uint64_t* __restrict__ q, const uint4* __restrict__ qx, uint32_t nq, uint32_t n_pairs,
     uint32_t pairs_per_chunk, uint32_t thresh, cbh_record* __restrict__ rec,
     unsigned long long cap, unsigned long long* __restrict__ total, uint32_t keep0) {
+  __shared__ float s_c[kWaves][G * 16][64];  // refine scratch: one accumulator group per wave
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t r = lane & 31u, half = lane >> 5;
   const uint32_t tile0 = (blockIdx.x * kWaves + wave) * HT;
@@ -144,29 +144,28 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_mfma(
         }
       const uint32_t mb = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(m0, m1));
       if ((mb & 0xffffu) >= lo_thr || (mb >> 16) >= hi_thr) {
-        // rare: decode the accumulators (C/D layout of the 32x32 MFMA: column = lane & 31 ->
-        // needle, row = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5) -> haystack row in the tile)
+        // rare: park the accumulators in LDS (each lane reads back only its own values, so no
+        // barrier) and walk them in a rolled loop -- keeps this cold path out of the hot loop's
+        // instruction stream.  C/D layout of the 32x32 MFMA: column = lane & 31 -> needle,
+        // row = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5) -> haystack row in the tile.
 #pragma unroll
-        for (int t = 0; t < G; ++t) {
+        for (int t = 0; t < G; ++t)
 #pragma unroll
-          for (int g = 0; g < 16; ++g) {
-            // (copy first: __builtin_bit_cast applied directly to a vector-element lvalue reads
-            // element 0 with this clang)
-            const float cf = c[t][g];
-            const uint32_t bits = __builtin_bit_cast(uint32_t, cf);
-            const uint32_t lo = bits & 0xffffu, hi = bits >> 16;
-            if (lo >= lo_thr || hi >= hi_thr) {
-              const uint32_t row =
-                  (tile0 + t0 + t) * 32u + (uint32_t)((g & 3) + 8 * (g >> 2)) + 4u * half;
-              if (row < n) {
-                const uint32_t id = ids[row];
-                if (id != 0 || keep0) {
-                  const uint32_t qa = p * 64u + r, qb = qa + 32u;
-                  if (lo >= lo_thr && qa < nq && q[qa] != 0)
-                    emit(rec, cap, total, qa, (kLoZero - lo) >> 1, id);
-                  if (hi >= hi_thr && qb < nq && q[qb] != 0)
-                    emit(rec, cap, total, qb, kHiZero - hi, id);
-                }
+          for (int g = 0; g < 16; ++g) s_c[wave][t * 16 + g][lane] = c[t][g];
+#pragma unroll 1
+        for (uint32_t e = 0; e < (uint32_t)G * 16u; ++e) {
+          const uint32_t bits = __builtin_bit_cast(uint32_t, (float)s_c[wave][e][lane]);
+          const uint32_t lo = bits & 0xffffu, hi = bits >> 16;
+          if (lo >= lo_thr || hi >= hi_thr) {
+            const uint32_t g = e & 15u;
+            const uint32_t row = (tile0 + t0 + (e >> 4)) * 32u + (g & 3u) + 8u * (g >> 2) + 4u * half;
+            if (row < n) {
+              const uint32_t id = ids[row];
+              if (id != 0 || keep0) {
+                const uint32_t qa = p * 64u + r, qb = qa + 32u;
+                if (lo >= lo_thr && qa < nq && q[qa] != 0)
+                  emit(rec, cap, total, qa, (kLoZero - lo) >> 1, id);
+                if (hi >= hi_thr && qb < nq && q[qb] != 0) emit(rec, cap, total, qb, kHiZero - hi, id);
               }
             }
           }
@@ -193,12 +192,16 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_mfma(
 }
 
 int g_scan_mfma = 1;        // use the matrix-core scan when the batch is large enough
+int g_mfma_ht = 8;          // haystack tiles per wave (4 or 8)
 uint32_t g_mfma_min_nq = 256;  // below this the needle expansion + tile padding is not worth it
 
 }  // namespace
 
 void set_scan_mfma(int on) {
   if (on >= 0) g_scan_mfma = on;
+}
+void set_scan_mfma_ht(int ht) {
+  if (ht == 2 || ht == 4 || ht == 8) g_mfma_ht = ht;
 }
 
 bool scan_mfma_wanted(size_t n, size_t nq, int thresh) {
@@ -218,7 +221,8 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
   CBH_HIP(hipMallocAsync((void**)&qx, (size_t)nq_pad * 32u, stream));
   hipLaunchKernelGGL(k_expand_needles, dim3((2u * nq_pad + 255u) / 256u), dim3(256), 0, stream, d_q,
                      (uint32_t)nq, nq_pad, qx);
-  const uint32_t rows_per_wg = 32u * kHT * kWaves;
+  const uint32_t ht = (uint32_t)g_mfma_ht;
+  const uint32_t rows_per_wg = 32u * ht * kWaves;
   const uint32_t wgs = (uint32_t)((n + rows_per_wg - 1) / rows_per_wg);
   // needle chunk: >= 8192 workgroups in flight when there is that much work, but each wave
   // amortises its tile expansion over >= 16 needle-tile pairs
@@ -229,10 +233,15 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
     ppc = (n_pairs + 65534) / 65535;
     chunks = (n_pairs + ppc - 1) / ppc;
   }
-  hipLaunchKernelGGL((k_hamm64_mfma<kHT, kG>), dim3(wgs, chunks), dim3(kThreads), 0, stream,
-                     reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx,
-                     (uint32_t)nq, n_pairs, ppc, (uint32_t)thresh, d_rec, (unsigned long long)cap,
-                     d_total, (uint32_t)(flags & 1u));
+#define CBH_MFMA(HT)                                                                            \
+  hipLaunchKernelGGL((k_hamm64_mfma<HT, kG>), dim3(wgs, chunks), dim3(kThreads), 0, stream,     \
+                     reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx,     \
+                     (uint32_t)nq, n_pairs, ppc, (uint32_t)thresh, d_rec,                       \
+                     (unsigned long long)cap, d_total, (uint32_t)(flags & 1u))
+  if (ht == 8) CBH_MFMA(8);
+  else if (ht == 2) CBH_MFMA(2);
+  else CBH_MFMA(4);
+#undef CBH_MFMA
   hipError_t e = hipGetLastError();
   (void)hipFreeAsync(qx, stream);
   CBH_HIP(e);

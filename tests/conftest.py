@@ -29,6 +29,17 @@ def gpu():
     return cbird_amd
 
 
+@pytest.fixture(params=["mfma", "valu"])
+def scan_path(request, gpu):
+    """Run a GPU test once per 64-bit scan kernel: the matrix-core scan (k_hamm64_mfma) forced for
+    any size, and the VALU scan (k_hamm64_scan).  Both must be bit-exact against the oracle."""
+    from cbird_amd import _lib
+
+    _lib.lib().cbh_set_tuning(b"scan_mfma", 2 if request.param == "mfma" else 0)
+    yield request.param
+    _lib.lib().cbh_set_tuning(b"scan_mfma", 1)
+
+
 def load_golden(name):
     return np.load(os.path.join(ROOT, "tests", "golden", name))
 

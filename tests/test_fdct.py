@@ -71,7 +71,7 @@ def test_score_rules(orc):
 
 
 @pytest.mark.gpu
-def test_gpu_matches_golden_and_oracle(gpu, orc):
+def test_gpu_matches_golden_and_oracle(gpu, orc, scan_path):
     g = load_golden("fdct_single_leaf.npz")
     idx = gpu.DctFeaturesIndex()
     h, ids = g["hashes"], g["ids"]
@@ -87,7 +87,7 @@ def test_gpu_matches_golden_and_oracle(gpu, orc):
 
 
 @pytest.mark.gpu
-def test_gpu_add_remove_findindex_batch(gpu, orc):
+def test_gpu_add_remove_findindex_batch(gpu, orc, scan_path):
     from cbird_amd import synth
 
     m, k = 300, 120  # 36k entries: beyond a single reference leaf, exact vs oracle

@@ -7,7 +7,8 @@ import pytest
 
 from conftest import golden_cases, load_golden
 
-pytestmark = pytest.mark.gpu
+# every test runs on both scan kernels (conftest.scan_path): k_hamm64_mfma forced, and k_hamm64_scan
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("scan_path")]
 
 
 def _matches(ms):

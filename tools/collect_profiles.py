@@ -73,7 +73,7 @@ def main():
         return (2.0 * fm + wm) * 1024.0, fm, wm
 
     out = {}
-    for key in ("k_hamm64_scan", "k_dcthash_256"):
+    for key in ("k_hamm64_mfma", "k_hamm64_scan", "k_dcthash_256"):
         t, fm, wm = traffic(key)
         out[key] = t
         out[key + "_detail"] = {"FETCH_SIZE_KiB_raw": fm, "WRITE_SIZE_KiB_raw": wm, "formula": FORMULA}
