@@ -1,0 +1,176 @@
+// hamm256_mfma.hip -- K6m: 256-bit Hamming threshold scan (CvFeaturesIndex brute force,
+// src/cvfeaturesindex.cpp:497-518: the exact search FLANN-LSH approximates) on the matrix cores.
+//
+// Same records as k_hamm256_scan (idx256.hip): one  q<<41 | dist<<32 | row  per (needle descriptor,
+// index row) with popcount(xor of the 32 bytes) < thresh.
+//
+// A 256-bit distance is four chained FP4 sign-dot-product MFMAs (fp4_sign.h) on one accumulator:
+// dot = 256 - 2 * dist, exact in f32.  A wave keeps HT row tiles (32 rows x 256 bits = 16 VGPRs per
+// tile) expanded in registers and streams needle tiles (32 descriptors, pre-expanded once per call
+// into a tile-major FP4 scratch so that every load is a contiguous 512 B per half-wave).  Per
+// (row tile, needle tile): 4 MFMAs, then 8 v_max3_f32 over the 16 results and one compare; the rare
+// hit parks the accumulators in LDS and decodes them in a rolled loop.  VALU work is 2 ops per
+// MFMA, so the kernel runs at the matrix-core rate: 4 x ~43 cycles per 1024 pairs.
+#include "cbh_internal.h"
+#include "fp4_sign.h"
+
+namespace cbh {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int kHT = 4;  // row tiles per wave
+constexpr int kG = 2;   // row tiles per accumulator group (independent MFMA chains in flight)
+
+// needle descriptors -> FP4 scratch, tile-major: uint4 index ((tile*4 + chunk)*2 + half)*32 + c
+// holds the expansion of 32-bit word (2*chunk + half) of descriptor tile*32 + c
+__global__ __launch_bounds__(256) void k_expand_needles256(const uint32_t* __restrict__ q, uint32_t nq,
+                                                           uint32_t nq_pad, uint4* __restrict__ qx) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= 8u * nq_pad) return;
+  const uint32_t c = i & 31u, word = (i >> 5) & 7u, tile = i >> 8;
+  const uint32_t j = tile * 32u + c;
+  qx[i] = fp4_expand32(j < nq ? q[(size_t)j * 8u + word] : 0u);
+}
+
+template <int HT, int G>
+__global__ __launch_bounds__(kThreads) void k_hamm256_mfma(
+    const uint32_t* __restrict__ rows /* 8 words per row */, uint32_t n, const uint4* __restrict__ qx,
+    uint32_t nq, uint32_t n_tiles, uint32_t tiles_per_chunk, uint32_t thresh,
+    unsigned long long* __restrict__ rec, unsigned long long cap,
+    unsigned long long* __restrict__ total) {
+  __shared__ float s_c[kWaves][G * 16][64];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t r = lane & 31u, half = lane >> 5;
+  const uint32_t tile0 = (blockIdx.x * kWaves + wave) * HT;
+  if (tile0 * 32u >= n) return;
+
+  v8i a[HT][4];
+#pragma unroll
+  for (int t = 0; t < HT; ++t) {
+    const uint32_t row = (tile0 + t) * 32u + r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t w = row < n ? rows[(size_t)row * 8u + 2u * k + half] : 0u;
+      a[t][k] = fp4_operand(fp4_expand32(w));
+    }
+  }
+  const uint32_t q0 = blockIdx.y * tiles_per_chunk;
+  const uint32_t q1 = min(n_tiles, q0 + tiles_per_chunk);
+  const uint4* __restrict__ qp = qx + (size_t)q0 * 256u + half * 32u + r;  // + chunk*64 per K chunk
+  const float dot_thr = 256.0f - 2.0f * (float)(thresh - 1u);  // dot >= dot_thr  <=>  dist < thresh
+
+  auto step = [&](const uint32_t qt, const uint4 (&nb)[4]) {
+    v8i b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[k] = fp4_operand(nb[k]);
+#pragma unroll
+    for (int t0 = 0; t0 < HT; t0 += G) {
+      v16f c[G];
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) c[t][g] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int t = 0; t < G; ++t)
+          c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t0 + t][k], b[k], c[t], 4, 4, 0,
+                                                                 kScaleOne, 0, kScaleOne);
+      float m0 = -512.0f, m1 = -512.0f;
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; g += 4) {
+          m0 = __builtin_fmaxf(__builtin_fmaxf(m0, c[t][g]), c[t][g + 1]);      // v_max3_f32
+          m1 = __builtin_fmaxf(__builtin_fmaxf(m1, c[t][g + 2]), c[t][g + 3]);
+        }
+      if (__builtin_fmaxf(m0, m1) >= dot_thr) {
+        // rare: decode through LDS in a rolled loop (C/D layout: column = lane & 31 -> needle,
+        // row = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5) -> index row in the tile)
+#pragma unroll
+        for (int t = 0; t < G; ++t)
+#pragma unroll
+          for (int g = 0; g < 16; ++g) s_c[wave][t * 16 + g][lane] = c[t][g];
+#pragma unroll 1
+        for (uint32_t e = 0; e < (uint32_t)G * 16u; ++e) {
+          const float dot = s_c[wave][e][lane];
+          if (dot >= dot_thr) {
+            const uint32_t g = e & 15u;
+            const uint32_t row = (tile0 + t0 + (e >> 4)) * 32u + (g & 3u) + 8u * (g >> 2) + 4u * half;
+            const uint32_t qi = qt * 32u + r;
+            if (row < n && qi < nq) {
+              const uint32_t d = (uint32_t)(256 - (int)dot) >> 1;
+              const unsigned long long slot = atomicAdd(total, 1ull);
+              if (slot < cap)
+                rec[slot] = ((unsigned long long)qi << 41) | ((unsigned long long)d << 32) | row;
+            }
+          }
+        }
+      }
+    }
+  };
+
+  // two needle tiles per trip, explicit double buffers
+  uint4 x[4], y[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) x[k] = qp[k * 64];
+  uint32_t qt = q0;
+  for (; qt + 1 < q1; qt += 2) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) y[k] = qp[256 + k * 64];
+    step(qt, x);
+    qp += 512;
+    if (qt + 2 < q1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x[k] = qp[k * 64];
+    }
+    step(qt + 1, y);
+  }
+  if (qt < q1) step(qt, x);
+}
+
+int g_scan256_mfma = 1;
+
+}  // namespace
+
+void set_scan256_mfma(int on) {
+  if (on >= 0) g_scan256_mfma = on;
+}
+
+bool scan256_mfma_wanted(size_t n, size_t nq, int thresh) {
+  if (thresh < 1 || thresh > 257) return false;
+  if (g_scan256_mfma == 2) return true;  // forced (tests)
+  return g_scan256_mfma && nq >= 64 && n >= 4096;
+}
+
+int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, size_t nq, int thresh,
+                        unsigned long long* d_rec, size_t cap, unsigned long long* d_total,
+                        hipStream_t stream) {
+  if (n == 0 || nq == 0 || thresh <= 0) return CBH_OK;
+  if (n > 0xfffffff0ull || nq >= (1u << 23) || thresh > 257) return CBH_E_INVAL;
+  const uint32_t n_tiles = (uint32_t)((nq + 31) / 32);
+  const uint32_t nq_pad = n_tiles * 32u;
+  uint4* qx = nullptr;
+  CBH_HIP(hipMallocAsync((void**)&qx, (size_t)nq_pad * 128u, stream));
+  hipLaunchKernelGGL(k_expand_needles256, dim3((8u * nq_pad + 255u) / 256u), dim3(256), 0, stream,
+                     reinterpret_cast<const uint32_t*>(d_q), (uint32_t)nq, nq_pad, qx);
+  const uint32_t rows_per_wg = 32u * kHT * kWaves;
+  const uint32_t wgs = (uint32_t)((n + rows_per_wg - 1) / rows_per_wg);
+  uint32_t tpc = 128;  // needle tiles per chunk (4096 descriptors)
+  while (tpc > 4 && (uint64_t)wgs * ((n_tiles + tpc - 1) / tpc) < 8192) tpc >>= 1;
+  uint32_t chunks = (n_tiles + tpc - 1) / tpc;
+  if (chunks > 65535) {
+    tpc = (n_tiles + 65534) / 65535;
+    chunks = (n_tiles + tpc - 1) / tpc;
+  }
+  hipLaunchKernelGGL((k_hamm256_mfma<kHT, kG>), dim3(wgs, chunks), dim3(kThreads), 0, stream,
+                     reinterpret_cast<const uint32_t*>(d_rows), (uint32_t)n, qx, (uint32_t)nq, n_tiles,
+                     tpc, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total);
+  hipError_t e = hipGetLastError();
+  (void)hipFreeAsync(qx, stream);
+  CBH_HIP(e);
+  return CBH_OK;
+}
+
+}  // namespace cbh

@@ -32,12 +32,11 @@
 // tiles -- pre-expanded once per call by k_expand_needles into a 32-byte-per-needle scratch --
 // through 16-byte loads that the 4 waves share in L1/L2.
 #include "cbh_internal.h"
+#include "fp4_sign.h"
 
 namespace cbh {
 namespace {
 
-typedef int v8i __attribute__((ext_vector_type(8)));
-typedef float v16f __attribute__((ext_vector_type(16)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 256;
@@ -47,22 +46,7 @@ constexpr uint32_t kLoZero = 0x4080u;  // lo16 at distance 0
 constexpr uint32_t kHiZero = 0x4B40u;  // hi16 at distance 0
 // 2^23 + 0x4040 + 64 * 2^15
 constexpr float kC0 = 8388608.0f + 16448.0f + 2097152.0f;
-constexpr int kScaleOne = 0x7f7f7f7f;  // E8M0 127 = 2^0
 constexpr int kScale15 = 0x8e8e8e8e;   // E8M0 142 = 2^15
-
-// 32 bits -> 32 FP4 sign nibbles: bit k -> nibble k = 0x2 (+1.0) if set, 0xA (-1.0) if clear
-__device__ __forceinline__ uint4 expand32(uint32_t w) {
-  uint32_t o[4];
-#pragma unroll
-  for (int d = 0; d < 4; ++d) {
-    uint32_t x = (w >> (8 * d)) & 0xffu;
-    x = (x | (x << 12)) & 0x000f000fu;
-    x = (x | (x << 6)) & 0x03030303u;
-    x = (x | (x << 3)) & 0x11111111u;
-    o[d] = 0xaaaaaaaau ^ (x << 3);
-  }
-  return make_uint4(o[0], o[1], o[2], o[3]);
-}
 
 // needles -> FP4 scratch: needle j -> 2 x uint4 (low word, high word); j >= nq padded with hash 0
 __global__ __launch_bounds__(256) void k_expand_needles(const uint64_t* __restrict__ q, uint32_t nq,
@@ -71,7 +55,7 @@ __global__ __launch_bounds__(256) void k_expand_needles(const uint64_t* __restri
   if (i >= 2u * nq_pad) return;
   const uint32_t j = i >> 1;
   const uint32_t* w = reinterpret_cast<const uint32_t*>(q);
-  qx[i] = expand32(j < nq ? w[i] : 0u);
+  qx[i] = fp4_expand32(j < nq ? w[i] : 0u);
 }
 
 __device__ __forceinline__ void emit(cbh_record* __restrict__ rec, unsigned long long cap,
@@ -103,7 +87,7 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_mfma(
   for (int t = 0; t < HT; ++t) {
     const uint32_t row = (tile0 + t) * 32u + r;
     const uint2 hv = row < n ? hay[row] : make_uint2(0u, 0u);
-    const uint4 e = expand32(half ? hv.y : hv.x);
+    const uint4 e = fp4_expand32(half ? hv.y : hv.x);
     a[t] = v8i{(int)e.x, (int)e.y, (int)e.z, (int)e.w, 0, 0, 0, 0};
   }
   v16f c0;

@@ -196,6 +196,9 @@ int ensure_scratch(cbh_idx256* ix, size_t nq, size_t rec_cap, int k) {
 }
 
 int launch_scan256(cbh_idx256* ix, const uint8_t* d_q, size_t nq, int thresh) {
+  if (cbh::scan256_mfma_wanted(ix->n, nq, thresh))
+    return cbh::launch_scan256_mfma(ix->d_rows, ix->n, d_q, nq, thresh, ix->d_rec, ix->rec_cap, ix->d_total,
+                                    ix->stream);
   const uint32_t tile = kThreads * kH;
   const uint32_t tiles = (uint32_t)((ix->n + tile - 1) / tile);
   uint32_t q_chunk = 4096;

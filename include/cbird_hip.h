@@ -281,7 +281,12 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
                          uint32_t* counts);
 
 /* Kernel-variant knobs for experiments (results never change, only speed):
- *   "scan_pre_max"  largest threshold served by the low-word-prefilter scan variant (default 7)
+ *   "scan_mfma"     64-bit scan on the matrix cores (k_hamm64_mfma): 0 = never, 1 = calls with >= 256
+ *                   needles and >= 4096 slots (default), 2 = always
+ *   "scan_mfma_ht"  haystack tiles per wave in k_hamm64_mfma: 2, 4 or 8 (default 8)
+ *   "scan256_mfma"  256-bit scan on the matrix cores (k_hamm256_mfma): 0 = never, 1 = calls with >= 64
+ *                   needle descriptors and >= 4096 rows (default), 2 = always
+ *   "scan_pre_max"  largest threshold served by the low-word-prefilter VALU scan variant (default 7)
  *   "scan_eq_dht1"  1 = dht==1 uses the 64-bit equality variant (default 1)
  *   "scan_group"    1 = issue-rate-shaped scan variants (default 1)
  *   "hash_mfma"     1 = 256x256 tiles use k_dcthash_256_mfma (box filter on the matrix cores; default 0) */

@@ -40,6 +40,16 @@ def scan_path(request, gpu):
     _lib.lib().cbh_set_tuning(b"scan_mfma", 1)
 
 
+@pytest.fixture(params=["mfma", "valu"])
+def scan256_path(request, gpu):
+    """As scan_path, for the 256-bit scan: k_hamm256_mfma forced, then k_hamm256_scan."""
+    from cbird_amd import _lib
+
+    _lib.lib().cbh_set_tuning(b"scan256_mfma", 2 if request.param == "mfma" else 0)
+    yield request.param
+    _lib.lib().cbh_set_tuning(b"scan256_mfma", 1)
+
+
 def load_golden(name):
     return np.load(os.path.join(ROOT, "tests", "golden", name))
 

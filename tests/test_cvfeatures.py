@@ -73,7 +73,7 @@ class _M:
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_media,per_media", [(7, 5), (300, 100), (41, 500)])
-def test_gpu_knn_and_find_vs_oracle(gpu, cvo, n_media, per_media):
+def test_gpu_knn_and_find_vs_oracle(gpu, cvo, scan256_path, n_media, per_media):
     from cbird_amd.cvfeatures import CvFeaturesIndex
 
     rows, first, ids = make_descriptors(n_media, per_media, n_media + per_media)
@@ -82,7 +82,7 @@ def test_gpu_knn_and_find_vs_oracle(gpu, cvo, n_media, per_media):
     idx.add(media[: n_media // 2])
     idx.add(media[n_media // 2:])
     assert idx.count() == len(rows) and idx.isLoaded() and idx.memoryUsage() == 2 * 32 * len(rows)
-    for k, thr in ((10, 25), (4, 25), (10, 60), (3, 1), (10, 130)):
+    for k, thr in ((10, 25), (4, 25), (10, 60), (3, 1), (10, 130), (2, 257)):
         needles = rows[:: max(1, len(rows) // 97)]
         gr, gd, gc = idx.knn(needles, k, thr)
         wr, wd, wc = cvo.knn(rows, needles, k, thr)
