@@ -7,30 +7,44 @@
 //
 // Why the matrix cores.  PMC shows the VALU scan is bound by integer-VALU issue (one
 // v_bcnt_u32_b32 per 32 bits per pair), not by memory: 0.8 GB of HBM traffic per 10^12 pairs.
-// The distance is also a dot product of sign vectors,
-//   dot(s(a), s(b)) = 64 - 2 * hamm64(a, b),   s(x)_k = +1 if bit k of x is set, else -1,
-// and +-1.0 are exact in FP4 (E2M1: 0x2 / 0xA), so ONE v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64 =
-// one hash) yields the exact distances of 32 haystack rows x 32 needles: 1024 pairs in ~32
-// matrix-core cycles, against ~8.3 (prefilter) / 14.3 (full) VALU cycles per 64 pairs.  All sums
-// are small integers, so the f32 accumulation is exact and results stay bit-identical.
+// The distance is also a dot product of sign vectors (fp4_sign.h),
+//   dot(s(a), s(b)) = 64 - 2 * hamm64(a, b),
+// +-1.0 are exact in FP4, so ONE v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64 = one hash) yields
+// the exact distances of 32 haystack rows x 32 needles: 1024 pairs in ~32 matrix-core cycles,
+// against ~8.3 (prefilter) / 14.3 (full) VALU cycles per 64 pairs.  All sums are small integers,
+// so the f32 accumulation is exact and results stay bit-identical.
 //
 // Keeping the VALU out of the way.  16 f32 results per lane per MFMA would cost 8 v_max3_f32
 // (32 cycles) to reduce -- as much as the MFMA itself.  Two tricks halve that:
-//   * the second needle tile of a pair is multiplied by the MX block scale 2^15 and accumulated
-//     onto the first, on top of C0 = 2^23 + 0x4040 + 64*2^15.  In [2^23, 2^24) one f32 ulp is 1, so
-//     the mantissa holds   (0x4040 + dotA) + 2^15 * (64 + dotB)   exactly, i.e. the f32 bit
-//     pattern is   hi16 = 0x4B00 + (64 - distB),  lo16 = 0x4080 - 2*distA   (dotB even => bit 15
-//     is 0): two distances per register, each half monotone in its distance;
+//   * two needle tiles share one accumulator: the second is multiplied by the MX block scale
+//     2^15 on top of C0 = 2^23 + 0x4040 + 64*2^15.  In [2^23, 2^24) one f32 ulp is 1, so the
+//     mantissa holds  (0x4040 + dotA) + 2^15 * (64 + dotB)  exactly, i.e. the f32 bit pattern is
+//     hi16 = 0x4B00 + (64 + dotB)/2,  lo16 = 0x4040 + dotA  (dotB even => bit 15 is 0): two
+//     distances per register, each half monotone in its distance;
 //   * both halves are positive normal f16 bit patterns, so v_pk_maximum3_f16 (new on gfx950) takes
 //     the per-half maximum of three registers at once: 4 ops per MFMA instead of 8.
-// After the 2*HT MFMAs of a needle-tile pair one compare decides whether any of the
-// 64 x (32*HT) x ... distances is under the threshold; only then the accumulators (still in
-// registers) are decoded and records are emitted.
+//
+// Two variants (both exact):
+//   FULL  K = the 64 bits of one hash; tile B is a second MFMA accumulated onto tile A's.
+//         hi16 = 0x4B40 - distB, lo16 = 0x4080 - 2*distA.  Hits are real matches.
+//   PRE   (thresh <= kPreMaxThresh) low-word prefilter at twice the pair rate: the block scale is
+//         per lane and K block, so lanes 0-31 (K 0..31) carry the LOW words of needle tile A with
+//         scale 1 and lanes 32-63 (K 32..63) the LOW words of tile B with scale 2^15, against the
+//         haystack's low words in both K blocks: ONE MFMA = 2048 low-word distances,
+//         hi16 = 0x4B30 - dloB, lo16 = 0x4060 - 2*dloA.  Sound because popc(lo) >= thresh implies
+//         popc(lo) + popc(hi) >= thresh; candidates are re-evaluated on the full 64 bits.
+//
+// Hits.  After the MFMAs of a group of G haystack tiles one compare of the packed maximum decides
+// whether anything is under the threshold.  Then, tile by tile, the lanes that hold flagged
+// results push (lane, register, field, distance) into a wave-private LDS queue and the whole
+// wave drains it, one candidate per lane: dense result sets (videos, duplicates) are emitted 64 at
+// a time instead of by one lane.
 //
 // Layout.  A workgroup is 4 waves; each wave keeps HT haystack tiles (32 rows each) expanded
-// to FP4 in VGPRs (4 VGPRs per tile: lane (r, half) holds word `half` of row r) and streams needle
-// tiles -- pre-expanded once per call by k_expand_needles into a 32-byte-per-needle scratch --
-// through 16-byte loads that the 4 waves share in L1/L2.
+// to FP4 in VGPRs (4 VGPRs per tile: lane (r, half) holds word `half` of row r; PRE: the low
+// word in both halves) and streams needle tiles -- pre-expanded once per call by
+// k_expand_needles into a 32-byte-per-needle scratch -- through 16-byte loads that the 4 waves
+// share in L1/L2.
 #include "cbh_internal.h"
 #include "fp4_sign.h"
 
@@ -41,12 +55,12 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
-constexpr int kG = 2;   // tiles per accumulator group
-constexpr uint32_t kLoZero = 0x4080u;  // lo16 at distance 0
-constexpr uint32_t kHiZero = 0x4B40u;  // hi16 at distance 0
+constexpr int kG = 2;  // tiles per accumulator group
 // 2^23 + 0x4040 + 64 * 2^15
 constexpr float kC0 = 8388608.0f + 16448.0f + 2097152.0f;
-constexpr int kScale15 = 0x8e8e8e8e;   // E8M0 142 = 2^15
+constexpr int kScale15 = 0x8e8e8e8e;  // E8M0 142 = 2^15
+constexpr int kPreMaxThresh = 4;      // P[popc(32 random bits) < 4] = 1.3e-6: 0.5 % of the groups re-check
+constexpr uint32_t kQueue = 2048;     // 16 registers x 2 fields x 64 lanes: cannot overflow
 
 // needles -> FP4 scratch: needle j -> 2 x uint4 (low word, high word); j >= nq padded with hash 0
 __global__ __launch_bounds__(256) void k_expand_needles(const uint64_t* __restrict__ q, uint32_t nq,
@@ -61,122 +75,219 @@ __global__ __launch_bounds__(256) void k_expand_needles(const uint64_t* __restri
 __device__ __forceinline__ void emit(cbh_record* __restrict__ rec, unsigned long long cap,
                                      unsigned long long* __restrict__ total, uint32_t qidx,
                                      uint32_t dist, uint32_t id) {
-  unsigned long long slot = atomicAdd(total, 1ull);
+  unsigned long long slot = atomicAdd(total, 1ull);  // compiler aggregates per wave
   if (slot < cap) rec[slot] = ((cbh_record)qidx << 39) | ((cbh_record)dist << 32) | id;
 }
 
 __device__ __forceinline__ h2 as_h2(float f) { return __builtin_bit_cast(h2, f); }
+__device__ __forceinline__ uint32_t as_u32(float f) { return __builtin_bit_cast(uint32_t, f); }
 __device__ __forceinline__ h2 pkmax3(h2 a, h2 b, h2 c) {
   return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c);  // v_pk_maximum3_f16
 }
+// The queue below is wave-private and the LDS executes one wave's instructions in order, so a
+// ds_read issued after a ds_write of another lane of the same wave sees it: only the COMPILER must
+// be kept from reordering or caching LDS accesses across the hand-over points (a compiler-level memory
+// clobber; `volatile` would make it wait for every outstanding needle prefetch at each access).
+__device__ __forceinline__ void wave_order() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
 
-template <int HT, int G>
+
+struct HitParams {
+  uint32_t lo_key, hi_key, lo_zero, hi_zero, thresh, n, nq, keep0;
+  const uint64_t* q;
+  const uint32_t* ids;
+  cbh_record* rec;
+  unsigned long long cap;
+  unsigned long long* total;
+};
+
+// Cold path (inlined once per haystack tile of the single step() call site; a real call costs far
+// more per hit: spills around the call and waits on the needle prefetches).
+// One haystack tile's 16 accumulators: the lanes holding flagged results append
+//   dist<<11 | field<<10 | g<<6 | lane
+// to the wave's LDS queue (ballot + mbcnt compaction, count in an SGPR), then the whole wave drains
+// the queue, one candidate per lane.  C/D layout of the 32x32 MFMA: column = lane & 31 -> needle,
+// row = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5) -> haystack row in the tile.
+template <bool PRE>
+__device__ __forceinline__ void handle_tile(const v16f& c, uint32_t row0, uint32_t hay_off, uint32_t p,
+                                            const HitParams& hp, uint32_t* s_queue, const uint2* s_hay) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t cnt = 0;  // wave-uniform
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const uint32_t bits = as_u32(c[g]);
+    const bool fh = bits >= hp.hi_key, fl = (bits << 16) >= hp.lo_key;
+    const uint64_t mh = __builtin_amdgcn_ballot_w64(fh);
+    if (mh != 0) {  // scalar branch, rarely taken
+      if (fh)
+        s_queue[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mh, 0u))] =
+            ((hp.hi_zero - (bits >> 16)) << 11) | (1u << 10) | ((uint32_t)g << 6) | lane;
+      cnt += (uint32_t)__popcll(mh);
+    }
+    const uint64_t ml = __builtin_amdgcn_ballot_w64(fl);
+    if (ml != 0) {
+      if (fl)
+        s_queue[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0u))] =
+            (((hp.lo_zero - (bits & 0xffffu)) >> 1) << 11) | ((uint32_t)g << 6) | lane;
+      cnt += (uint32_t)__popcll(ml);
+    }
+  }
+  wave_order();
+  for (uint32_t k = lane; k < cnt; k += 64u) {
+    const uint32_t e = s_queue[k];
+    const uint32_t src = e & 63u, g = (e >> 6) & 15u, field = (e >> 10) & 1u;
+    const uint32_t rit = (g & 3u) + 8u * (g >> 2) + 4u * (src >> 5);  // row in tile
+    const uint32_t row = row0 + rit;
+    const uint32_t qi = p * 64u + field * 32u + (src & 31u);
+    if (row < hp.n && qi < hp.nq) {
+      uint32_t d = e >> 11;
+      bool ok;
+      if (PRE) {  // low-word candidate: evaluate all 64 bits (raw hashes parked in LDS)
+        const uint2 hv = s_hay[hay_off + rit];
+        const uint64_t nv = hp.q[qi];
+        d = __popc(hv.x ^ (uint32_t)nv) + __popc(hv.y ^ (uint32_t)(nv >> 32));
+        ok = nv != 0 && d < hp.thresh;
+      } else {
+        ok = hp.q[qi] != 0;
+      }
+      if (ok) {
+        const uint32_t id = hp.ids[row];
+        if (id != 0 || hp.keep0) emit(hp.rec, hp.cap, hp.total, qi, d, id);
+      }
+    }
+  }
+  wave_order();
+}
+
+template <int HT, int G, bool PRE>
 __global__ __launch_bounds__(kThreads) void k_hamm64_mfma(
     const uint2* __restrict__ hay, const uint32_t* __restrict__ ids, uint32_t n,
     const uint64_t* __restrict__ q, const uint4* __restrict__ qx, uint32_t nq, uint32_t n_pairs,
     uint32_t pairs_per_chunk, uint32_t thresh, cbh_record* __restrict__ rec,
     unsigned long long cap, unsigned long long* __restrict__ total, uint32_t keep0) {
-  __shared__ float s_c[kWaves][G * 16][64];  // refine scratch: one accumulator group per wave
+  __shared__ uint32_t s_queue_[kWaves][kQueue];  // candidates of one haystack tile
+  __shared__ uint2 s_hay_[PRE ? kWaves : 1][PRE ? HT * 32 : 1];  // PRE: raw hashes for the re-check
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t r = lane & 31u, half = lane >> 5;
   const uint32_t tile0 = (blockIdx.x * kWaves + wave) * HT;
-  if (tile0 * 32u >= n) return;  // whole wave past the end (no barriers in this kernel)
+  if (tile0 * 32u >= n) return;  // whole wave past the end (no workgroup barriers in this kernel)
+  uint32_t* s_queue = s_queue_[wave];
+  uint2* s_hay = s_hay_[PRE ? wave : 0];
 
   v8i a[HT];
 #pragma unroll
   for (int t = 0; t < HT; ++t) {
     const uint32_t row = (tile0 + t) * 32u + r;
     const uint2 hv = row < n ? hay[row] : make_uint2(0u, 0u);
-    const uint4 e = fp4_expand32(half ? hv.y : hv.x);
-    a[t] = v8i{(int)e.x, (int)e.y, (int)e.z, (int)e.w, 0, 0, 0, 0};
+    a[t] = fp4_operand(fp4_expand32((!PRE && half) ? hv.y : hv.x));
+    if (PRE && half == 0) s_hay[t * 32 + r] = hv;
   }
+  wave_order();
   v16f c0;
 #pragma unroll
   for (int g = 0; g < 16; ++g) c0[g] = kC0;
   asm volatile("" : "+v"(c0));  // keep C0 resident: otherwise it is rebuilt (16 v_mov) every trip
+  int scale_b = (PRE && half) ? kScale15 : kScaleOne;
+  asm volatile("" : "+v"(scale_b));
 
   const uint32_t p0 = blockIdx.y * pairs_per_chunk;
   const uint32_t p1 = min(n_pairs, p0 + pairs_per_chunk);
-  // pair p = needles [64p, 64p+64): tile A = first 32, tile B = last 32; 2 uint4 per needle
-  const uint4* __restrict__ qp = qx + ((size_t)p0 * 64u + r) * 2u + half;
-  const uint32_t lo_thr = kLoZero - 2u * (thresh - 1u);  // lo16 >= lo_thr  <=>  distA < thresh
-  const uint32_t hi_thr = kHiZero - (thresh - 1u);       // hi16 >= hi_thr  <=>  distB < thresh
+  // pair p = needles [64p, 64p+64): tile A = first 32, tile B = last 32; 2 uint4 per needle.
+  // FULL: lane (c, half) reads word `half` of needle c of each tile; PRE: the low word of needle
+  // 64p + lane (tile A in K block 0, tile B in K block 1)
+  const uint4* __restrict__ qp =
+      PRE ? qx + ((size_t)p0 * 64u + lane) * 2u : qx + ((size_t)p0 * 64u + r) * 2u + half;
+  const uint32_t lo_zero = PRE ? 0x4060u : 0x4080u;      // lo16 at distance 0
+  const uint32_t hi_zero = PRE ? 0x4B30u : 0x4B40u;      // hi16 at distance 0
+  const uint32_t lo_thr = lo_zero - 2u * (thresh - 1u);  // lo16 >= lo_thr  <=>  distA < thresh
+  const uint32_t hi_thr = hi_zero - (thresh - 1u);       // hi16 >= hi_thr  <=>  distB < thresh
+  const uint32_t lo_key = lo_thr << 16, hi_key = hi_thr << 16;
+  const HitParams hp = {lo_key, hi_key, lo_zero, hi_zero, thresh, n, nq, keep0, q, ids, rec, cap, total};
 
   // one needle-tile pair against the HT resident haystack tiles
   auto step = [&](const uint32_t p, const uint4& nA, const uint4& nB) {
-    const v8i bA = v8i{(int)nA.x, (int)nA.y, (int)nA.z, (int)nA.w, 0, 0, 0, 0};
-    const v8i bB = v8i{(int)nB.x, (int)nB.y, (int)nB.z, (int)nB.w, 0, 0, 0, 0};
-    // G tiles at a time: 2*G MFMAs in flight, G*16 accumulator registers live
+    const v8i bA = fp4_operand(nA);
+    const v8i bB = fp4_operand(nB);
+    // G tiles at a time: G (PRE) or 2*G (FULL) MFMAs in flight, G*16 accumulator registers live
 #pragma unroll
     for (int t0 = 0; t0 < HT; t0 += G) {
       v16f c[G];
 #pragma unroll
       for (int t = 0; t < G; ++t)
         c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t0 + t], bA, c0, 4, 4, 0, kScaleOne,
-                                                               0, kScaleOne);
+                                                               0, PRE ? scale_b : kScaleOne);
+      if (!PRE) {
 #pragma unroll
-      for (int t = 0; t < G; ++t)
-        c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t0 + t], bB, c[t], 4, 4, 0,
-                                                               kScaleOne, 0, kScale15);
-      h2 m0 = {0, 0}, m1 = {0, 0};
+        for (int t = 0; t < G; ++t)
+          c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t0 + t], bB, c[t], 4, 4, 0,
+                                                                 kScaleOne, 0, kScale15);
+      }
+      h2 mt[G];
 #pragma unroll
-      for (int t = 0; t < G; ++t)
+      for (int t = 0; t < G; ++t) {
+        h2 m0 = {0, 0}, m1 = {0, 0};
 #pragma unroll
         for (int g = 0; g < 16; g += 4) {
           m0 = pkmax3(m0, as_h2(c[t][g]), as_h2(c[t][g + 1]));
           m1 = pkmax3(m1, as_h2(c[t][g + 2]), as_h2(c[t][g + 3]));
         }
-      const uint32_t mb = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(m0, m1));
-      if ((mb & 0xffffu) >= lo_thr || (mb >> 16) >= hi_thr) {
-        // rare: park the accumulators in LDS (each lane reads back only its own values, so no
-        // barrier) and walk them in a rolled loop -- keeps this cold path out of the hot loop's
-        // instruction stream.  C/D layout of the 32x32 MFMA: column = lane & 31 -> needle,
-        // row = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5) -> haystack row in the tile.
+        mt[t] = __builtin_elementwise_maximum(m0, m1);
+      }
+      h2 mg = mt[0];
 #pragma unroll
-        for (int t = 0; t < G; ++t)
+      for (int t = 1; t < G; ++t) mg = __builtin_elementwise_maximum(mg, mt[t]);
+      const uint32_t mb = __builtin_bit_cast(uint32_t, mg);
+      if (__builtin_amdgcn_ballot_w64((mb << 16) >= lo_key || mb >= hi_key) != 0) {
+        // wave-uniform from here: something in this group is under the threshold
 #pragma unroll
-          for (int g = 0; g < 16; ++g) s_c[wave][t * 16 + g][lane] = c[t][g];
-#pragma unroll 1
-        for (uint32_t e = 0; e < (uint32_t)G * 16u; ++e) {
-          const uint32_t bits = __builtin_bit_cast(uint32_t, (float)s_c[wave][e][lane]);
-          const uint32_t lo = bits & 0xffffu, hi = bits >> 16;
-          if (lo >= lo_thr || hi >= hi_thr) {
-            const uint32_t g = e & 15u;
-            const uint32_t row = (tile0 + t0 + (e >> 4)) * 32u + (g & 3u) + 8u * (g >> 2) + 4u * half;
-            if (row < n) {
-              const uint32_t id = ids[row];
-              if (id != 0 || keep0) {
-                const uint32_t qa = p * 64u + r, qb = qa + 32u;
-                if (lo >= lo_thr && qa < nq && q[qa] != 0)
-                  emit(rec, cap, total, qa, (kLoZero - lo) >> 1, id);
-                if (hi >= hi_thr && qb < nq && q[qb] != 0) emit(rec, cap, total, qb, kHiZero - hi, id);
-              }
-            }
-          }
+        for (int t = 0; t < G; ++t) {
+          const uint32_t tb = __builtin_bit_cast(uint32_t, mt[t]);
+          if (__builtin_amdgcn_ballot_w64((tb << 16) >= lo_key || tb >= hi_key) == 0) continue;
+          handle_tile<PRE>(c[t], (tile0 + t0 + t) * 32u, (uint32_t)(t0 + t) * 32u, p, hp, s_queue, s_hay);
         }
       }
     }
   };
 
-  // two pairs per trip with explicit double buffers: the loads of the next pair are in flight
-  // while the 2*HT MFMAs of the current one run
-  uint4 x0 = qp[0], x1 = qp[64];
-  uint32_t p = p0;
-  for (; p + 1 < p1; p += 2) {
-    const uint4 y0 = qp[128], y1 = qp[192];
-    step(p, x0, x1);
-    qp += 256;
-    if (p + 2 < p1) {
-      x0 = qp[0];
-      x1 = qp[64];
+  if constexpr (PRE) {
+    // one pair per trip, the next pair's 16-byte tile load in flight meanwhile; a single step() call
+    // site keeps the (not so rare: the prefilter has false positives) re-check code to one copy per tile
+    uint4 cur = qp[0];
+#pragma unroll 1
+    for (uint32_t p = p0; p < p1; ++p) {
+      uint4 nx = cur;
+      if (p + 1 < p1) {
+        qp += 128;
+        nx = qp[0];
+      }
+      step(p, cur, cur);
+      cur = nx;
     }
-    step(p + 1, y0, y1);
+  } else {
+    // two pairs per trip with explicit double buffers: the loads of the next pair are in flight
+    // while the 2*HT MFMAs of the current one run
+    uint4 x0 = qp[0], x1 = qp[64];
+    uint32_t p = p0;
+    for (; p + 1 < p1; p += 2) {
+      const uint4 y0 = qp[128], y1 = qp[192];
+      step(p, x0, x1);
+      qp += 256;
+      if (p + 2 < p1) {
+        x0 = qp[0];
+        x1 = qp[64];
+      }
+      step(p + 1, y0, y1);
+    }
+    if (p < p1) step(p, x0, x1);
   }
-  if (p < p1) step(p, x0, x1);
 }
 
-int g_scan_mfma = 1;        // use the matrix-core scan when the batch is large enough
-int g_mfma_ht = 8;          // haystack tiles per wave (4 or 8)
+int g_scan_mfma = 1;           // use the matrix-core scan when the batch is large enough
+int g_mfma_ht = 8;             // haystack tiles per wave (2, 4 or 8)
+int g_mfma_pre = 1;            // low-word prefilter variant for thresh <= kPreMaxThresh
 uint32_t g_mfma_min_nq = 256;  // below this the needle expansion + tile padding is not worth it
 
 }  // namespace
@@ -186,6 +297,9 @@ void set_scan_mfma(int on) {
 }
 void set_scan_mfma_ht(int ht) {
   if (ht == 2 || ht == 4 || ht == 8) g_mfma_ht = ht;
+}
+void set_scan_mfma_pre(int on) {
+  if (on >= 0) g_mfma_pre = on;
 }
 
 bool scan_mfma_wanted(size_t n, size_t nq, int thresh) {
@@ -217,14 +331,19 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
     ppc = (n_pairs + 65534) / 65535;
     chunks = (n_pairs + ppc - 1) / ppc;
   }
-#define CBH_MFMA(HT)                                                                            \
-  hipLaunchKernelGGL((k_hamm64_mfma<HT, kG>), dim3(wgs, chunks), dim3(kThreads), 0, stream,     \
-                     reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx,     \
-                     (uint32_t)nq, n_pairs, ppc, (uint32_t)thresh, d_rec,                       \
+  const bool pre = g_mfma_pre && thresh <= kPreMaxThresh;
+#define CBH_MFMA(HT, PRE)                                                                        \
+  hipLaunchKernelGGL((k_hamm64_mfma<HT, kG, PRE>), dim3(wgs, chunks), dim3(kThreads), 0, stream, \
+                     reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx,      \
+                     (uint32_t)nq, n_pairs, ppc, (uint32_t)thresh, d_rec,                        \
                      (unsigned long long)cap, d_total, (uint32_t)(flags & 1u))
-  if (ht == 8) CBH_MFMA(8);
-  else if (ht == 2) CBH_MFMA(2);
-  else CBH_MFMA(4);
+  if (ht == 8) {
+    if (pre) CBH_MFMA(8, true); else CBH_MFMA(8, false);
+  } else if (ht == 2) {
+    if (pre) CBH_MFMA(2, true); else CBH_MFMA(2, false);
+  } else {
+    if (pre) CBH_MFMA(4, true); else CBH_MFMA(4, false);
+  }
 #undef CBH_MFMA
   hipError_t e = hipGetLastError();
   (void)hipFreeAsync(qx, stream);

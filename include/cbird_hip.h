@@ -284,6 +284,7 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *   "scan_mfma"     64-bit scan on the matrix cores (k_hamm64_mfma): 0 = never, 1 = calls with >= 256
  *                   needles and >= 4096 slots (default), 2 = always
  *   "scan_mfma_ht"  haystack tiles per wave in k_hamm64_mfma: 2, 4 or 8 (default 8)
+ *   "scan_mfma_pre" 1 = thresholds <= 5 use the low-word prefilter variant of k_hamm64_mfma (default 1)
  *   "scan256_mfma"  256-bit scan on the matrix cores (k_hamm256_mfma): 0 = never, 1 = calls with >= 64
  *                   needle descriptors and >= 4096 rows (default), 2 = always
  *   "scan_pre_max"  largest threshold served by the low-word-prefilter VALU scan variant (default 7)

@@ -297,7 +297,7 @@ int main(int argc, char** argv) {
            ms * 1e-3 * 2.4e9 * 1024 / ((double)n * nq / 1024));                              \
   }
   for (int wg = 1; wg <= 2; ++wg) {
-    const uint32_t iters = 20000, blocks = 256 * wg;
+    const uint32_t iters = 200000, blocks = 256 * wg;
     for (int rep = 0; rep < 2; ++rep) {
       CK(hipEventRecord(e0));
       k_pure<4><<<blocks, 256>>>((const uint4*)bigx, iters, dres);
