@@ -192,24 +192,25 @@ class DctVideoIndex:
 
     def find_videos_batch(self, needles, p: VideoSearchParams):
         needles = list(needles)
-        fr, hs, offs, ids = [], [], [0], []
-        for m in needles:
-            fr += list(m.videoIndex.frames)
-            hs += list(m.videoIndex.hashes)
-            offs.append(len(fr))
-            ids.append(m.id)
-        f = np.ascontiguousarray(fr, np.int32)
-        h = np.ascontiguousarray(hs, np.uint64)
-        o = np.ascontiguousarray(offs, np.uint64)
-        i = np.ascontiguousarray(ids, np.uint32)
-        cap = max(1, self.count() * len(needles))
-        buf = (cbh_vmatch * cap)()
+        f = np.concatenate([np.asarray(m.videoIndex.frames, np.int32) for m in needles] or [np.zeros(0, np.int32)])
+        h = np.concatenate([np.asarray(m.videoIndex.hashes, np.uint64) for m in needles] or [np.zeros(0, np.uint64)])
+        o = np.zeros(len(needles) + 1, np.uint64)
+        np.cumsum([len(m.videoIndex.frames) for m in needles], out=o[1:])
+        i = np.ascontiguousarray([m.id for m in needles], np.uint32)
         out_offs = np.zeros(len(needles) + 1, np.uint64)
-        check(self._L.cbh_vidx_find_videos_batch(self._h, f.ctypes.data, h.ctypes.data, o.ctypes.data,
-                                                 i.ctypes.data, len(needles), int(p.dctThresh),
-                                                 int(p.skipFrames), int(p.minFramesMatched),
-                                                 int(p.minFramesNear), int(bool(p.filterSelf)), buf, cap,
-                                                 out_offs.ctypes.data), "find_videos_batch")
+        cap = max(64, 8 * len(needles))
+        while True:  # the library reports the full size in out_offs[-1] when cap was too small
+            buf = (cbh_vmatch * cap)()
+            rc = self._L.cbh_vidx_find_videos_batch(self._h, f.ctypes.data, h.ctypes.data, o.ctypes.data,
+                                                    i.ctypes.data, len(needles), int(p.dctThresh),
+                                                    int(p.skipFrames), int(p.minFramesMatched),
+                                                    int(p.minFramesNear), int(bool(p.filterSelf)), buf, cap,
+                                                    out_offs.ctypes.data)
+            if rc == _lib.CBH_E_OVERFLOW and int(out_offs[-1]) > cap:
+                cap = int(out_offs[-1])
+                continue
+            check(rc, "find_videos_batch")
+            break
         return [self._matches(buf[int(out_offs[k]):int(out_offs[k + 1])], int(out_offs[k + 1] - out_offs[k]))
                 for k in range(len(needles))]
 
