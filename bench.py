@@ -266,6 +266,25 @@ def main():
         except Exception:
             pass
 
+    if rank == 0 and world == 1:
+        # outside the timed region, for the record: the same launches on the popcount (VALU) kernel
+        # k_hamm64_scan that the matrix-core kernel replaced (identical records; tests/test_gpu_hamm.py)
+        import ctypes as C
+
+        rec, total = sh._buffers()
+        ms = C.c_float(0)
+        pop = {}
+        ops.L.cbh_set_tuning(b"scan_mfma", 0)
+        try:
+            for d in sorted({dhts[0], dhts[len(dhts) // 2], dhts[-1]}):
+                total.zero_()
+                rc = ops.L.cbh_idx64_time_scan_dev(ops.index.handle, state["hashes"].data_ptr(), n, d,
+                                                   rec.data_ptr(), rec.numel(), total.data_ptr(), 1, C.byref(ms))
+                if rc == 0:
+                    pop[str(d)] = round(ms.value, 3)
+        finally:
+            ops.L.cbh_set_tuning(b"scan_mfma", 1)
+        result["popcount_kernel_scan_ms"] = pop
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, torch, imgs, state, n, dhts)
     if rank == 0:

@@ -73,4 +73,27 @@ out["video"] = {"clips": n_clips, "entries": vidx.entries(0), "single_needle_ms"
                 "cmp_per_s_batched": 2000 * 300 * vidx.entries(0) / batch,
                 "batch_hits": sum(len(r) for r in res)}
 print(out["video"], flush=True)
+
+# ---- ColorDescIndex: 1M synthetic descriptors (the reference marks this search "dnf" at 500k, readme.md:293)
+from cbird_amd.colordesc import COLOR_DTYPE
+n_col = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
+rngc = np.random.default_rng(77)
+descs = np.zeros(n_col, COLOR_DTYPE)
+descs["colors"] = rngc.integers(0, 65536, (n_col, 32, 4), dtype=np.uint16)
+descs["numColors"] = rngc.integers(28, 32, n_col, dtype=np.uint8)
+ids_c = np.arange(1, n_col + 1, dtype=np.uint32)
+from cbird_amd.colordesc import ColorDescIndex
+ci = ColorDescIndex()
+_lib.check(L.cbh_color_add(ci._h, ids_c.ctypes.data, descs.ctypes.data, n_col), "color add")
+ci.find_batch(descs[:1], 8)
+t0 = time.time(); reps = 5
+for r_ in range(reps):
+    ci.find_batch(descs[r_:r_ + 1], 8)
+one_c = (time.time() - t0) / reps
+t0 = time.time(); gi, gs, gc = ci.find_batch(descs[:64], 8); b64 = time.time() - t0
+# 258 B and ~9.2e3 flop per descriptor comparison (32x32 colour pairs x 9 flop)
+out["color"] = {"descriptors": n_col, "single_needle_ms": one_c * 1e3, "batch64_s": b64,
+                "desc_cmp_per_s_batched": 64 * n_col / b64, "algorithmic_TFLOPs_batched": 64 * n_col * 9216 / b64 / 1e12,
+                "algorithmic_GBps_batched": 64 * n_col * 258 / b64 / 1e9, "self_first": bool((gi[:, 0] == ids_c[:64]).all())}
+print(out["color"], flush=True)
 print(json.dumps(out))
