@@ -90,6 +90,85 @@ __global__ __launch_bounds__(256) void k_color_keys(const int* __restrict__ scor
   keys[i] = (s >= 0 && id != 0) ? (((unsigned long long)(uint32_t)s << 32) | id) : ~0ull;
 }
 
+
+// ---- top-k per needle without sorting the whole score row (find_batch) -----------------------------------
+// Scores are small integers (1 + 32 colour distances <= 1 + 32 * 451.7 < 16384), so a histogram finds
+// the k-th smallest score exactly; only entries at or under it are collected and ordered on the host.
+constexpr int kBins = 16384;
+constexpr uint32_t kCandCap = 4096;  // per needle; more ties than this -> the full-sort path
+
+__global__ __launch_bounds__(256) void k_color_hist(const int* __restrict__ score,
+                                                    const uint32_t* __restrict__ ids, uint32_t n,
+                                                    uint32_t* __restrict__ hist /* [nq][kBins] */,
+                                                    uint32_t* __restrict__ valid /* [nq] */) {
+  const uint32_t q = blockIdx.y;
+  const int* sc = score + (size_t)q * n;
+  uint32_t local = 0;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const int s = sc[i];
+    if (s >= 0 && ids[i] != 0) {
+      atomicAdd(&hist[(size_t)q * kBins + (uint32_t)min(s, kBins - 1)], 1u);
+      ++local;
+    }
+  }
+  if (local) atomicAdd(&valid[q], local);  // compiler aggregates per wave
+}
+
+// T[q] = smallest score bin whose cumulative count reaches k (kBins - 1 when there are fewer than k)
+__global__ __launch_bounds__(256) void k_color_thresh(const uint32_t* __restrict__ hist, uint32_t k,
+                                                      uint32_t* __restrict__ thr) {
+  __shared__ uint32_t part[256];
+  const uint32_t q = blockIdx.x, t = threadIdx.x;
+  const uint32_t* h = hist + (size_t)q * kBins + t * (kBins / 256);
+  uint32_t sum = 0;
+  for (int b = 0; b < kBins / 256; ++b) sum += h[b];
+  part[t] = sum;
+  __syncthreads();
+  if (t == 0) {
+    uint32_t run = 0, seg = 255, before = 0;
+    bool found = false;
+    for (uint32_t j = 0; j < 256 && !found; ++j) {
+      if (run + part[j] >= k) {
+        seg = j;
+        before = run;
+        found = true;
+      }
+      run += part[j];
+    }
+    uint32_t bin = kBins - 1;
+    if (found) {
+      const uint32_t* hs = hist + (size_t)q * kBins + seg * (kBins / 256);
+      uint32_t c = before;
+      for (int b = 0; b < kBins / 256; ++b) {
+        c += hs[b];
+        if (c >= k) {
+          bin = seg * (kBins / 256) + b;
+          break;
+        }
+      }
+    }
+    thr[q] = bin;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_color_collect(const int* __restrict__ score,
+                                                       const uint32_t* __restrict__ ids, uint32_t n,
+                                                       const uint32_t* __restrict__ thr,
+                                                       unsigned long long* __restrict__ cand /* [nq][kCandCap] */,
+                                                       uint32_t* __restrict__ ncand /* [nq] */) {
+  const uint32_t q = blockIdx.y;
+  const int* sc = score + (size_t)q * n;
+  const int T = (int)thr[q];
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const int s = sc[i];
+    const uint32_t id = ids[i];
+    if (s >= 0 && id != 0 && (min(s, kBins - 1) <= T)) {
+      const uint32_t slot = atomicAdd(&ncand[q], 1u);
+      if (slot < kCandCap) cand[(size_t)q * kCandCap + slot] = ((unsigned long long)(uint32_t)s << 32) | id;
+    }
+  }
+}
+
 void decompress(const uint8_t* desc, NeedleF* out) {  // DescriptorColor::get, cvutil.h:83-87
   for (int c = 0; c < kNC; ++c) {
     uint16_t l, u, v;
@@ -122,6 +201,10 @@ struct cbh_color {
   unsigned long long *d_keys = nullptr, *d_keys_alt = nullptr;
   void* d_tmp = nullptr;
   size_t keys_cap = 0, tmp_bytes = 0;
+  // find_batch top-k scratch
+  uint32_t *d_hist = nullptr, *d_thr = nullptr, *d_ncand = nullptr, *d_valid = nullptr;
+  unsigned long long* d_cand = nullptr;
+  size_t topk_cap = 0;
 };
 
 namespace {
@@ -233,7 +316,8 @@ void cbh_color_destroy(cbh_color* c) {
   if (!c) return;
   cbh::DeviceGuard g(c->device);
   for (void* p : {(void*)c->dL, (void*)c->dU, (void*)c->dV, (void*)c->d_num, (void*)c->d_ids, (void*)c->d_needles,
-                  (void*)c->d_scores, (void*)c->d_keys, (void*)c->d_keys_alt, c->d_tmp})
+                  (void*)c->d_scores, (void*)c->d_keys, (void*)c->d_keys_alt, c->d_tmp, (void*)c->d_hist,
+                  (void*)c->d_thr, (void*)c->d_ncand, (void*)c->d_valid, (void*)c->d_cand})
     if (p) (void)hipFree(p);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -324,6 +408,21 @@ int cbh_color_find(cbh_color* c, const void* needle_desc, cbh_match* out, size_t
 
 /* find() for many needles + the sort/cut of searchIndex (database.cpp:1729-1735): out[q*k..] = first
  * min(counts[q], k) matches in (score, id) order, counts[q] = all matches */
+// one needle through the full sort (ties beyond kCandCap, or k > kCandCap)
+static int color_full_sort_one(cbh_color* c, size_t q_in_chunk, int k, cbh_match* out_q, uint32_t valid) {
+  hipLaunchKernelGGL(k_color_keys, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
+                     c->d_scores + q_in_chunk * c->n, c->d_ids, (uint32_t)c->n, c->d_keys);
+  hipcub::DoubleBuffer<unsigned long long> db(c->d_keys, c->d_keys_alt);
+  size_t tb = c->tmp_bytes;
+  CBH_HIP(hipcub::DeviceRadixSort::SortKeys(c->d_tmp, tb, db, c->n, 0, 64, c->stream));
+  const size_t take = std::min<size_t>(std::min<size_t>((size_t)k, c->n), valid);
+  std::vector<unsigned long long> head(take);
+  if (take) CBH_HIP(hipMemcpyAsync(head.data(), db.Current(), take * 8, hipMemcpyDeviceToHost, c->stream));
+  CBH_HIP(hipStreamSynchronize(c->stream));
+  for (size_t j = 0; j < take; ++j) out_q[j] = cbh_match{(uint32_t)head[j], (int32_t)(head[j] >> 32)};
+  return CBH_OK;
+}
+
 int cbh_color_find_batch(cbh_color* c, const void* needle_descs, size_t nq, int k, cbh_match* out,
                          uint32_t* counts) {
   if (!c || k < 0 || (nq && (!needle_descs || !counts || (k && !out)))) return CBH_E_INVAL;
@@ -337,31 +436,64 @@ int cbh_color_find_batch(cbh_color* c, const void* needle_descs, size_t nq, int 
   const size_t chunk = std::max<size_t>(1, std::min<size_t>(nq, ((size_t)1 << 28) / c->n));  // <= 1 GiB of scores
   int rc = ensure_scratch(c, chunk, true);
   if (rc) return rc;
-  std::vector<unsigned long long> head((size_t)k + 1);
+  if (chunk > c->topk_cap) {
+    for (void* p : {(void*)c->d_hist, (void*)c->d_thr, (void*)c->d_ncand, (void*)c->d_valid, (void*)c->d_cand})
+      if (p) (void)hipFree(p);
+    c->d_hist = c->d_thr = c->d_ncand = c->d_valid = nullptr;
+    c->d_cand = nullptr;
+    c->topk_cap = 0;
+    CBH_HIP(hipMalloc(&c->d_hist, chunk * kBins * 4));
+    CBH_HIP(hipMalloc(&c->d_thr, chunk * 4));
+    CBH_HIP(hipMalloc(&c->d_ncand, chunk * 4));
+    CBH_HIP(hipMalloc(&c->d_valid, chunk * 4));
+    CBH_HIP(hipMalloc(&c->d_cand, chunk * (size_t)kCandCap * 8));
+    c->topk_cap = chunk;
+  }
+  const bool topk = k >= 1 && (uint32_t)k <= kCandCap;
+  std::vector<uint32_t> h_valid, h_ncand;
+  std::vector<unsigned long long> h_cand;
   for (size_t q0 = 0; q0 < nq; q0 += chunk) {
     const size_t m = std::min(chunk, nq - q0);
     rc = run_dist(c, (const uint8_t*)needle_descs + q0 * kDescBytes, m);
     if (rc) return rc;
-    for (size_t q = 0; q < m; ++q) {
-      hipLaunchKernelGGL(k_color_keys, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
-                         c->d_scores + q * c->n, c->d_ids, (uint32_t)c->n, c->d_keys);
-      hipcub::DoubleBuffer<unsigned long long> db(c->d_keys, c->d_keys_alt);
-      size_t tb = c->tmp_bytes;
-      CBH_HIP(hipcub::DeviceRadixSort::SortKeys(c->d_tmp, tb, db, c->n, 0, 64, c->stream));
-      // count = number of keys != ~0: binary search on the host side would need the data; read the head
-      // and count valid scores separately
-      const size_t take = std::min<size_t>((size_t)k, c->n);
-      if (take)
-        CBH_HIP(hipMemcpyAsync(head.data(), db.Current(), take * 8, hipMemcpyDeviceToHost, c->stream));
-      std::vector<int> sc;
-      sc.resize(c->n);
-      CBH_HIP(hipMemcpyAsync(sc.data(), c->d_scores + q * c->n, c->n * 4, hipMemcpyDeviceToHost, c->stream));
+    // number of matches and, exactly, the k-th smallest score of every needle
+    CBH_HIP(hipMemsetAsync(c->d_hist, 0, m * kBins * 4, c->stream));
+    CBH_HIP(hipMemsetAsync(c->d_valid, 0, m * 4, c->stream));
+    CBH_HIP(hipMemsetAsync(c->d_ncand, 0, m * 4, c->stream));
+    const unsigned gx = (unsigned)std::min<size_t>((c->n + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_color_hist, dim3(gx, (unsigned)m), dim3(256), 0, c->stream, c->d_scores, c->d_ids,
+                       (uint32_t)c->n, c->d_hist, c->d_valid);
+    h_valid.resize(m);
+    CBH_HIP(hipMemcpyAsync(h_valid.data(), c->d_valid, m * 4, hipMemcpyDeviceToHost, c->stream));
+    if (topk) {
+      hipLaunchKernelGGL(k_color_thresh, dim3((unsigned)m), dim3(256), 0, c->stream, c->d_hist, (uint32_t)k,
+                         c->d_thr);
+      hipLaunchKernelGGL(k_color_collect, dim3(gx, (unsigned)m), dim3(256), 0, c->stream, c->d_scores, c->d_ids,
+                         (uint32_t)c->n, c->d_thr, c->d_cand, c->d_ncand);
+      h_ncand.resize(m);
+      h_cand.resize(m * (size_t)kCandCap);
+      CBH_HIP(hipMemcpyAsync(h_ncand.data(), c->d_ncand, m * 4, hipMemcpyDeviceToHost, c->stream));
+      CBH_HIP(hipGetLastError());
       CBH_HIP(hipStreamSynchronize(c->stream));
-      uint32_t cnt = 0;
-      for (size_t i = 0; i < c->n; ++i) cnt += (sc[i] >= 0 && c->host_ids[i] != 0);
-      counts[q0 + q] = cnt;
-      for (size_t j = 0; j < take && j < cnt; ++j)
-        out[(q0 + q) * (size_t)k + j] = cbh_match{(uint32_t)head[j], (int32_t)(head[j] >> 32)};
+      for (size_t q = 0; q < m; ++q)  // only the filled part of every candidate list
+        if (h_ncand[q] && h_ncand[q] <= kCandCap)
+          CBH_HIP(hipMemcpyAsync(h_cand.data() + q * kCandCap, c->d_cand + q * kCandCap, (size_t)h_ncand[q] * 8,
+                                 hipMemcpyDeviceToHost, c->stream));
+    }
+    CBH_HIP(hipStreamSynchronize(c->stream));
+    for (size_t q = 0; q < m; ++q) {
+      counts[q0 + q] = h_valid[q];
+      if (k == 0 || h_valid[q] == 0) continue;
+      cbh_match* oq = out + (q0 + q) * (size_t)k;
+      if (topk && h_ncand[q] <= kCandCap) {
+        unsigned long long* cq = h_cand.data() + q * kCandCap;
+        std::sort(cq, cq + h_ncand[q]);  // (score, id): Database::searchIndex order with ties by id
+        const size_t take = std::min<size_t>((size_t)k, h_ncand[q]);
+        for (size_t j = 0; j < take; ++j) oq[j] = cbh_match{(uint32_t)cq[j], (int32_t)(cq[j] >> 32)};
+      } else {
+        rc = color_full_sort_one(c, q, k, oq, h_valid[q]);
+        if (rc) return rc;
+      }
     }
   }
   return CBH_OK;
