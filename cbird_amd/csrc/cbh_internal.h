@@ -37,6 +37,7 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
 bool scan_mfma_wanted(size_t n, size_t nq, int thresh);
 void set_scan_mfma(int on);  // <0 = keep; 2 = force for any size
 void set_scan_mfma_ht(int ht);
+void set_scan_mfma_g(int g);
 void set_scan_mfma_pre(int on);  // low-word prefilter variant for small thresholds
 
 // ---- hamm256_mfma.hip: 256-bit threshold scan on the matrix cores -----------------------

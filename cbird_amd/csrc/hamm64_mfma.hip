@@ -115,27 +115,35 @@ template <bool PRE>
 __device__ __forceinline__ void handle_tile(const v16f& c, uint32_t row0, uint32_t hay_off, uint32_t p,
                                             const HitParams& hp, uint32_t* s_queue, const uint2* s_hay) {
   const uint32_t lane = threadIdx.x & 63u;
+  // quick reject of the tile that did not cause the group's hit
+  h2 m0 = {0, 0}, m1 = {0, 0};
+#pragma unroll
+  for (int g = 0; g < 16; g += 4) {
+    m0 = pkmax3(m0, as_h2(c[g]), as_h2(c[g + 1]));
+    m1 = pkmax3(m1, as_h2(c[g + 2]), as_h2(c[g + 3]));
+  }
+  const uint32_t tb = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(m0, m1));
+  if (__builtin_amdgcn_ballot_w64((tb << 16) >= hp.lo_key || tb >= hp.hi_key) == 0) return;
+
   uint32_t cnt = 0;  // wave-uniform
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
     const uint32_t bits = as_u32(c[g]);
     const bool fh = bits >= hp.hi_key, fl = (bits << 16) >= hp.lo_key;
+    if (__builtin_amdgcn_ballot_w64(fh || fl) == 0) continue;  // scalar branch, rarely not taken
     const uint64_t mh = __builtin_amdgcn_ballot_w64(fh);
-    if (mh != 0) {  // scalar branch, rarely taken
-      if (fh)
-        s_queue[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mh, 0u))] =
-            ((hp.hi_zero - (bits >> 16)) << 11) | (1u << 10) | ((uint32_t)g << 6) | lane;
-      cnt += (uint32_t)__popcll(mh);
-    }
+    if (fh)
+      s_queue[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mh, 0u))] =
+          ((hp.hi_zero - (bits >> 16)) << 11) | (1u << 10) | ((uint32_t)g << 6) | lane;
+    cnt += (uint32_t)__popcll(mh);
     const uint64_t ml = __builtin_amdgcn_ballot_w64(fl);
-    if (ml != 0) {
-      if (fl)
-        s_queue[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0u))] =
-            (((hp.lo_zero - (bits & 0xffffu)) >> 1) << 11) | ((uint32_t)g << 6) | lane;
-      cnt += (uint32_t)__popcll(ml);
-    }
+    if (fl)
+      s_queue[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0u))] =
+          (((hp.lo_zero - (bits & 0xffffu)) >> 1) << 11) | ((uint32_t)g << 6) | lane;
+    cnt += (uint32_t)__popcll(ml);
   }
   wave_order();
+  // drain: one candidate per lane
   for (uint32_t k = lane; k < cnt; k += 64u) {
     const uint32_t e = s_queue[k];
     const uint32_t src = e & 63u, g = (e >> 6) & 15u, field = (e >> 10) & 1u;
@@ -143,17 +151,13 @@ __device__ __forceinline__ void handle_tile(const v16f& c, uint32_t row0, uint32
     const uint32_t row = row0 + rit;
     const uint32_t qi = p * 64u + field * 32u + (src & 31u);
     if (row < hp.n && qi < hp.nq) {
+      const uint64_t nv = hp.q[qi];
       uint32_t d = e >> 11;
-      bool ok;
-      if (PRE) {  // low-word candidate: evaluate all 64 bits (raw hashes parked in LDS)
+      if (PRE) {  // low-word candidate: evaluate all 64 bits (raw slot hashes parked in LDS)
         const uint2 hv = s_hay[hay_off + rit];
-        const uint64_t nv = hp.q[qi];
         d = __popc(hv.x ^ (uint32_t)nv) + __popc(hv.y ^ (uint32_t)(nv >> 32));
-        ok = nv != 0 && d < hp.thresh;
-      } else {
-        ok = hp.q[qi] != 0;
       }
-      if (ok) {
+      if (nv != 0 && d < hp.thresh) {
         const uint32_t id = hp.ids[row];
         if (id != 0 || hp.keep0) emit(hp.rec, hp.cap, hp.total, qi, d, id);
       }
@@ -225,29 +229,21 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_mfma(
           c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t0 + t], bB, c[t], 4, 4, 0,
                                                                  kScaleOne, 0, kScale15);
       }
-      h2 mt[G];
+      // packed per-half maximum of the group's G*16 results: 8 v_pk_maximum3_f16 per tile
+      h2 m0 = {0, 0}, m1 = {0, 0};
 #pragma unroll
-      for (int t = 0; t < G; ++t) {
-        h2 m0 = {0, 0}, m1 = {0, 0};
+      for (int t = 0; t < G; ++t)
 #pragma unroll
         for (int g = 0; g < 16; g += 4) {
           m0 = pkmax3(m0, as_h2(c[t][g]), as_h2(c[t][g + 1]));
           m1 = pkmax3(m1, as_h2(c[t][g + 2]), as_h2(c[t][g + 3]));
         }
-        mt[t] = __builtin_elementwise_maximum(m0, m1);
-      }
-      h2 mg = mt[0];
-#pragma unroll
-      for (int t = 1; t < G; ++t) mg = __builtin_elementwise_maximum(mg, mt[t]);
-      const uint32_t mb = __builtin_bit_cast(uint32_t, mg);
+      const uint32_t mb = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(m0, m1));
       if (__builtin_amdgcn_ballot_w64((mb << 16) >= lo_key || mb >= hi_key) != 0) {
-        // wave-uniform from here: something in this group is under the threshold
+        // wave-uniform from here: something in this group is under the threshold (rare)
 #pragma unroll
-        for (int t = 0; t < G; ++t) {
-          const uint32_t tb = __builtin_bit_cast(uint32_t, mt[t]);
-          if (__builtin_amdgcn_ballot_w64((tb << 16) >= lo_key || tb >= hi_key) == 0) continue;
+        for (int t = 0; t < G; ++t)
           handle_tile<PRE>(c[t], (tile0 + t0 + t) * 32u, (uint32_t)(t0 + t) * 32u, p, hp, s_queue, s_hay);
-        }
       }
     }
   };
@@ -288,6 +284,7 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_mfma(
 int g_scan_mfma = 1;           // use the matrix-core scan when the batch is large enough
 int g_mfma_ht = 8;             // haystack tiles per wave (2, 4 or 8)
 int g_mfma_pre = 1;            // low-word prefilter variant for thresh <= kPreMaxThresh
+int g_mfma_g = 2;              // haystack tiles per accumulator group (2 or 4; HT = 8 only)
 uint32_t g_mfma_min_nq = 256;  // below this the needle expansion + tile padding is not worth it
 
 }  // namespace
@@ -300,6 +297,9 @@ void set_scan_mfma_ht(int ht) {
 }
 void set_scan_mfma_pre(int on) {
   if (on >= 0) g_mfma_pre = on;
+}
+void set_scan_mfma_g(int g) {
+  if (g == 2 || g == 4) g_mfma_g = g;
 }
 
 bool scan_mfma_wanted(size_t n, size_t nq, int thresh) {
@@ -331,13 +331,17 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
     ppc = (n_pairs + 65534) / 65535;
     chunks = (n_pairs + ppc - 1) / ppc;
   }
-  const bool pre = g_mfma_pre && thresh <= kPreMaxThresh;
-#define CBH_MFMA(HT, PRE)                                                                        \
-  hipLaunchKernelGGL((k_hamm64_mfma<HT, kG, PRE>), dim3(wgs, chunks), dim3(kThreads), 0, stream, \
+  // (2 = experiments: the prefilter variant for any threshold it can represent)
+  const bool pre = (g_mfma_pre == 1 && thresh <= kPreMaxThresh) || (g_mfma_pre == 2 && thresh <= 32);
+#define CBH_MFMA_G(HT, GG, PRE)                                                                  \
+  hipLaunchKernelGGL((k_hamm64_mfma<HT, GG, PRE>), dim3(wgs, chunks), dim3(kThreads), 0, stream, \
                      reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx,      \
                      (uint32_t)nq, n_pairs, ppc, (uint32_t)thresh, d_rec,                        \
                      (unsigned long long)cap, d_total, (uint32_t)(flags & 1u))
-  if (ht == 8) {
+#define CBH_MFMA(HT, PRE) CBH_MFMA_G(HT, kG, PRE)
+  if (ht == 8 && g_mfma_g == 4) {
+    if (pre) CBH_MFMA_G(8, 4, true); else CBH_MFMA_G(8, 4, false);
+  } else if (ht == 8) {
     if (pre) CBH_MFMA(8, true); else CBH_MFMA(8, false);
   } else if (ht == 2) {
     if (pre) CBH_MFMA(2, true); else CBH_MFMA(2, false);
@@ -345,6 +349,7 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
     if (pre) CBH_MFMA(4, true); else CBH_MFMA(4, false);
   }
 #undef CBH_MFMA
+#undef CBH_MFMA_G
   hipError_t e = hipGetLastError();
   (void)hipFreeAsync(qx, stream);
   CBH_HIP(e);
