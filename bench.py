@@ -193,8 +193,8 @@ def main():
         fm = sum(x for x, _ in finds[dht]) / len(finds[dht])
         sweep.append({"dht": dht, "scan_kernel_ms": round(sm, 3), "find_ms": round(fm, 3),
                       "scan_cmp_per_s": shard_n * n / sm * 1e3, "matches": finds[dht][0][1]})
-    # k_hamm64_mfma has two instantiations: FULL (64-bit dot products; thresholds > PRE_MAX_DHT) is the
-    # dominant kernel by time and the one the roofline object prices; PRE (low-word prefilter, thresholds
+    # the matrix-core scan has two shapes: k_hamm64_mfma3 (64-bit dot products; thresholds > PRE_MAX_DHT) is
+    # the dominant kernel by time and the one the roofline object prices; PRE (low-word prefilter, thresholds
     # <= PRE_MAX_DHT, hamm64_mfma.hip kPreMaxThresh) executes half the multiply-adds per comparison and
     # is reported beside it with the flops it really issues.
     full = [d for d in dhts if d > PRE_MAX_DHT] or dhts
@@ -233,7 +233,7 @@ def main():
         },
         "dht_sweep": sweep,
         "roofline": {
-            "kernel": "k_hamm64_mfma<8,2,false> (FULL: dht %s)" % ",".join(map(str, full)), "bound": "mfma", "achieved": scan_tflops, "peak": FP4_PEAK_TFLOPS,
+            "kernel": "k_hamm64_mfma3<8,2> (64-bit sign dot products, 3 needle tiles per accumulator: dht %s)" % ",".join(map(str, full)), "bound": "mfma", "achieved": scan_tflops, "peak": FP4_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": scan_tflops / FP4_PEAK_TFLOPS, "traffic": None,
             "avg_launch_ms": scan_ms_avg, "algorithmic_flop_per_launch": FLOP_PER_CMP * shard_n * n,
             "algorithmic_bytes_per_launch": scan_bytes, "hbm_equivalent_GBps": scan_gbs,

@@ -38,6 +38,7 @@ bool scan_mfma_wanted(size_t n, size_t nq, int thresh);
 void set_scan_mfma(int on);  // <0 = keep; 2 = force for any size
 void set_scan_mfma_ht(int ht);
 void set_scan_mfma_g(int g);
+void set_scan_mfma_full3(int on);  // three-needle-tile accumulator variant for thresholds > 4
 void set_scan_mfma_pre(int on);  // low-word prefilter variant for small thresholds
 
 // ---- hamm256_mfma.hip: 256-bit threshold scan on the matrix cores -----------------------

@@ -498,6 +498,10 @@ int cbh_set_tuning(const char* key, int value) {
     set_scan256_mfma(value);
     return CBH_OK;
   }
+  if (!strcmp(key, "scan_mfma_full3")) {
+    set_scan_mfma_full3(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "scan_mfma_g")) {
     set_scan_mfma_g(value);
     return CBH_OK;

@@ -281,7 +281,142 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_mfma(
   }
 }
 
+
+// ---- FULL3: three needle tiles per accumulator, detection by OR instead of maximum ------------------------
+// The VALU reduction shares the issue port with the MFMAs (measured: an FP4 32x32x64 MFMA blocks it ~24 of
+// its ~40 cycles, every VALU op adds 4), so fewer reduction ops per MFMA is the lever.  With w = 64 - dist
+// and b = thresh - 1 the accumulator is built as
+//   2^23 + 2 * sum_{i<3} 2^(7i) * (w_i + b)        (B scales 2^0, 2^7, 2^14; C0 carries 2^23 + the b terms)
+// i.e. three 7-bit fields (w + b <= 127 for thresh <= 64), and  dist_i < thresh  <=>  w_i + b >= 64  <=>
+// bit 6 of field i = bit 7 + 7i of the f32 pattern.  OR-ing registers keeps "some flag bit is set", so
+// v_or3_b32 reduces two registers per op for THREE MFMAs' worth of results: 2.7 VALU ops per MFMA instead
+// of 4, which makes the kernel matrix-core bound.
+constexpr uint32_t kFlagMask3 = (1u << 7) | (1u << 14) | (1u << 21);
+constexpr int kScale7 = (int)0x86868686;   // E8M0 134 = 2^7
+constexpr int kScale14 = (int)0x8d8d8d8d;  // E8M0 141 = 2^14
+
+__device__ __forceinline__ void handle_tile3(const v16f& c, uint32_t row0, uint32_t p3, const HitParams& hp,
+                                             uint32_t* s_queue) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t any = 0;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) any |= as_u32(c[g]);
+  if (__builtin_amdgcn_ballot_w64((any & kFlagMask3) != 0) == 0) return;  // the other tile of the group
+  const uint32_t b = hp.thresh - 1u;
+  uint32_t cnt = 0;  // wave-uniform
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const uint32_t bits = as_u32(c[g]);
+    if (__builtin_amdgcn_ballot_w64((bits & kFlagMask3) != 0) == 0) continue;
+#pragma unroll
+    for (uint32_t f = 0; f < 3; ++f) {
+      const bool fl = (bits >> (7u + 7u * f)) & 1u;
+      const uint64_t m = __builtin_amdgcn_ballot_w64(fl);
+      if (fl)  // entry: dist<<12 | field<<10 | g<<6 | lane
+        s_queue[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+            ((64u + b - ((bits >> (1u + 7u * f)) & 0x7fu)) << 12) | (f << 10) | ((uint32_t)g << 6) | lane;
+      cnt += (uint32_t)__popcll(m);
+    }
+  }
+  wave_order();
+  for (uint32_t k = lane; k < cnt; k += 64u) {
+    const uint32_t e = s_queue[k];
+    const uint32_t src = e & 63u, g = (e >> 6) & 15u, field = (e >> 10) & 3u, d = e >> 12;
+    const uint32_t row = row0 + (g & 3u) + 8u * (g >> 2) + 4u * (src >> 5);
+    const uint32_t qi = p3 * 96u + field * 32u + (src & 31u);
+    if (row < hp.n && qi < hp.nq && hp.q[qi] != 0) {
+      const uint32_t id = hp.ids[row];
+      if (id != 0 || hp.keep0) emit(hp.rec, hp.cap, hp.total, qi, d, id);
+    }
+  }
+  wave_order();
+}
+
+template <int HT, int G>
+__global__ __launch_bounds__(kThreads) void k_hamm64_mfma3(
+    const uint2* __restrict__ hay, const uint32_t* __restrict__ ids, uint32_t n,
+    const uint64_t* __restrict__ q, const uint4* __restrict__ qx, uint32_t nq, uint32_t n_triples,
+    uint32_t triples_per_chunk, uint32_t thresh, cbh_record* __restrict__ rec,
+    unsigned long long cap, unsigned long long* __restrict__ total, uint32_t keep0) {
+  __shared__ uint32_t s_queue_[kWaves][3 * 16 * 64];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t r = lane & 31u, half = lane >> 5;
+  const uint32_t tile0 = (blockIdx.x * kWaves + wave) * HT;
+  if (tile0 * 32u >= n) return;
+  uint32_t* s_queue = s_queue_[wave];
+
+  v8i a[HT];
+#pragma unroll
+  for (int t = 0; t < HT; ++t) {
+    const uint32_t row = (tile0 + t) * 32u + r;
+    const uint2 hv = row < n ? hay[row] : make_uint2(0u, 0u);
+    a[t] = fp4_operand(fp4_expand32(half ? hv.y : hv.x));
+  }
+  // C0 = 2^23 + (64 + 2b) * (1 + 2^7 + 2^14): every field starts at 2 * (32 + b) and gains dot_i = 2 * (w_i - 32)
+  const uint32_t b = thresh - 1u;
+  v16f c0;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) c0[g] = 8388608.0f + (float)((64u + 2u * b) * 16513u);
+  asm volatile("" : "+v"(c0));
+  const HitParams hp = {0, 0, 0, 0, thresh, n, nq, keep0, q, ids, rec, cap, total};
+
+  const uint32_t p0 = blockIdx.y * triples_per_chunk;
+  const uint32_t p1 = min(n_triples, p0 + triples_per_chunk);
+  // triple p = needles [96p, 96p+96): three tiles of 32; lane (c, half) reads word `half` of needle c
+  const uint4* __restrict__ qp = qx + ((size_t)p0 * 96u + r) * 2u + half;
+
+  auto step = [&](const uint32_t p, const uint4& n0, const uint4& n1, const uint4& n2) {
+    const v8i b0 = fp4_operand(n0), b1 = fp4_operand(n1), b2 = fp4_operand(n2);
+#pragma unroll
+    for (int t0 = 0; t0 < HT; t0 += G) {
+      v16f c[G];
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+        c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t0 + t], b0, c0, 4, 4, 0, kScaleOne, 0,
+                                                               kScaleOne);
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+        c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t0 + t], b1, c[t], 4, 4, 0, kScaleOne, 0,
+                                                               kScale7);
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+        c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t0 + t], b2, c[t], 4, 4, 0, kScaleOne, 0,
+                                                               kScale14);
+      uint32_t o0 = 0, o1 = 0;
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; g += 4) {
+          o0 |= as_u32(c[t][g]) | as_u32(c[t][g + 1]);      // v_or3_b32
+          o1 |= as_u32(c[t][g + 2]) | as_u32(c[t][g + 3]);
+        }
+      if (__builtin_amdgcn_ballot_w64(((o0 | o1) & kFlagMask3) != 0) != 0) {
+#pragma unroll
+        for (int t = 0; t < G; ++t) handle_tile3(c[t], (tile0 + t0 + t) * 32u, p, hp, s_queue);
+      }
+    }
+  };
+
+  // one triple (6 * HT MFMAs) per trip, the next triple's three tile loads in flight meanwhile
+  uint4 x0 = qp[0], x1 = qp[64], x2 = qp[128];
+#pragma unroll 1
+  for (uint32_t p = p0; p < p1; ++p) {
+    uint4 y0 = x0, y1 = x1, y2 = x2;
+    if (p + 1 < p1) {
+      qp += 192;
+      y0 = qp[0];
+      y1 = qp[64];
+      y2 = qp[128];
+    }
+    step(p, x0, x1, x2);
+    x0 = y0;
+    x1 = y1;
+    x2 = y2;
+  }
+}
+
 int g_scan_mfma = 1;           // use the matrix-core scan when the batch is large enough
+int g_mfma_full3 = 1;          // three-field variant for kPreMaxThresh < thresh <= 64
 int g_mfma_ht = 8;             // haystack tiles per wave (2, 4 or 8)
 int g_mfma_pre = 1;            // low-word prefilter variant for thresh <= kPreMaxThresh
 int g_mfma_g = 2;              // haystack tiles per accumulator group (2 or 4; HT = 8 only)
@@ -297,6 +432,9 @@ void set_scan_mfma_ht(int ht) {
 }
 void set_scan_mfma_pre(int on) {
   if (on >= 0) g_mfma_pre = on;
+}
+void set_scan_mfma_full3(int on) {
+  if (on >= 0) g_mfma_full3 = on;
 }
 void set_scan_mfma_g(int g) {
   if (g == 2 || g == 4) g_mfma_g = g;
@@ -314,7 +452,8 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
   if (n == 0 || nq == 0 || thresh <= 0) return CBH_OK;
   if (n > 0xfffffff0ull || nq > CBH_MAX_QUERIES_PER_CALL || thresh > 65) return CBH_E_INVAL;
   const uint32_t n_pairs = (uint32_t)((nq + 63) / 64);
-  const uint32_t nq_pad = n_pairs * 64u;
+  const uint32_t n_triples = (uint32_t)((nq + 95) / 96);
+  const uint32_t nq_pad = (uint32_t)((nq + 191) / 192) * 192u;  // whole pairs (64) and whole triples (96)
   uint4* qx = nullptr;
   CBH_HIP(hipMallocAsync((void**)&qx, (size_t)nq_pad * 32u, stream));
   hipLaunchKernelGGL(k_expand_needles, dim3((2u * nq_pad + 255u) / 256u), dim3(256), 0, stream, d_q,
@@ -333,6 +472,23 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
   }
   // (2 = experiments: the prefilter variant for any threshold it can represent)
   const bool pre = (g_mfma_pre == 1 && thresh <= kPreMaxThresh) || (g_mfma_pre == 2 && thresh <= 32);
+  if (!pre && g_mfma_full3 && thresh <= 64 && ht == 8) {
+    uint32_t tpc = 172;  // ~16512 needles per chunk
+    while (tpc > 11 && (uint64_t)wgs * ((n_triples + tpc - 1) / tpc) < 8192) tpc = (tpc + 1) / 2;
+    uint32_t ch3 = (n_triples + tpc - 1) / tpc;
+    if (ch3 > 65535) {
+      tpc = (n_triples + 65534) / 65535;
+      ch3 = (n_triples + tpc - 1) / tpc;
+    }
+    hipLaunchKernelGGL((k_hamm64_mfma3<8, kG>), dim3(wgs, ch3), dim3(kThreads), 0, stream,
+                       reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx, (uint32_t)nq,
+                       n_triples, tpc, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total,
+                       (uint32_t)(flags & 1u));
+    hipError_t e3 = hipGetLastError();
+    (void)hipFreeAsync(qx, stream);
+    CBH_HIP(e3);
+    return CBH_OK;
+  }
 #define CBH_MFMA_G(HT, GG, PRE)                                                                  \
   hipLaunchKernelGGL((k_hamm64_mfma<HT, GG, PRE>), dim3(wgs, chunks), dim3(kThreads), 0, stream, \
                      reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx,      \

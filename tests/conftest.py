@@ -29,15 +29,21 @@ def gpu():
     return cbird_amd
 
 
-@pytest.fixture(params=["mfma", "valu"])
+@pytest.fixture(params=["mfma", "mfma2", "valu"])
 def scan_path(request, gpu):
-    """Run a GPU test once per 64-bit scan kernel: the matrix-core scan (k_hamm64_mfma) forced for
-    any size, and the VALU scan (k_hamm64_scan).  Both must be bit-exact against the oracle."""
+    """Run a GPU test once per 64-bit scan kernel family, all of which must be bit-exact against the oracle:
+    "mfma"  the matrix-core scan forced for any size, as shipped (thresholds <= 4: low-word prefilter
+            variant, 5..64: three needle tiles per accumulator, 65: two);
+    "mfma2" the same with the three-tile variant off (thresholds >= 5 on the two-tile kernel);
+    "valu"  the popcount kernel k_hamm64_scan."""
     from cbird_amd import _lib
 
-    _lib.lib().cbh_set_tuning(b"scan_mfma", 2 if request.param == "mfma" else 0)
+    L = _lib.lib()
+    L.cbh_set_tuning(b"scan_mfma", 0 if request.param == "valu" else 2)
+    L.cbh_set_tuning(b"scan_mfma_full3", 0 if request.param == "mfma2" else 1)
     yield request.param
-    _lib.lib().cbh_set_tuning(b"scan_mfma", 1)
+    L.cbh_set_tuning(b"scan_mfma", 1)
+    L.cbh_set_tuning(b"scan_mfma_full3", 1)
 
 
 @pytest.fixture(params=["mfma", "valu"])

@@ -22,12 +22,12 @@ ms = C.c_float(0)
 for name, dq in sets.items():
     idx = cbird_amd.DctHashIndex(); ids = torch.arange(1, N + 1, dtype=torch.int32, device=dev)
     idx.load_device(dq.data_ptr(), ids.data_ptr(), N)
-    for thr in (2, 4, 5, 6, 8):
+    for thr in (2, 5, 8, 16):
         row = []
-        for label, pre, eq, grp in (("mfma8g2full", 0, 0, 0), ("mfma8g2pre", 0, 0, 0)):
+        for label, pre, eq, grp in (("mfma8g2full", 0, 0, 0), ("mfma8g2ful3", 0, 0, 0), ("mfma8g2pre", 0, 0, 0)):
             if label == "eq" and thr != 1: continue
             L.cbh_set_tuning(b"scan_mfma", 1 if label.startswith("mfma") else 0)
-            if label.startswith("mfma"): L.cbh_set_tuning(b"scan_mfma_ht", int(label[4])); L.cbh_set_tuning(b"scan_mfma_g", int(label[6])); L.cbh_set_tuning(b"scan_mfma_pre", 2 if label.endswith("pre") else 0)
+            if label.startswith("mfma"): L.cbh_set_tuning(b"scan_mfma_ht", int(label[4])); L.cbh_set_tuning(b"scan_mfma_g", int(label[6])); L.cbh_set_tuning(b"scan_mfma_pre", 1 if label.endswith("pre") else 0); L.cbh_set_tuning(b"scan_mfma_full3", 1 if label.endswith("ful3") else 0)
             L.cbh_set_tuning(b"scan_pre_max", pre); L.cbh_set_tuning(b"scan_eq_dht1", eq); L.cbh_set_tuning(b"scan_group", grp)
             _lib.check(L.cbh_idx64_time_scan_dev(idx.handle, dq.data_ptr(), N, thr, drec.data_ptr(), cap, dtot.data_ptr(), 1, C.byref(ms)), "w")
             _lib.check(L.cbh_idx64_time_scan_dev(idx.handle, dq.data_ptr(), N, thr, drec.data_ptr(), cap, dtot.data_ptr(), 2, C.byref(ms)), "t")
