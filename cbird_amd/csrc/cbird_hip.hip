@@ -494,6 +494,10 @@ int cbh_set_tuning(const char* key, int value) {
     set_scan_mfma(value);
     return CBH_OK;
   }
+  if (!strcmp(key, "scan256_g")) {
+    set_scan256_g(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "scan256_mfma")) {
     set_scan256_mfma(value);
     return CBH_OK;

@@ -20,7 +20,6 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
 constexpr int kHT = 4;  // row tiles per wave
-constexpr int kG = 2;   // row tiles per accumulator group (independent MFMA chains in flight)
 
 // needle descriptors -> FP4 scratch, tile-major: uint4 index ((tile*4 + chunk)*2 + half)*32 + c
 // holds the expansion of 32-bit word (2*chunk + half) of descriptor tile*32 + c
@@ -131,11 +130,15 @@ __global__ __launch_bounds__(kThreads) void k_hamm256_mfma(
 }
 
 int g_scan256_mfma = 1;
+int g_scan256_g = 4;  // row tiles per accumulator group = independent 4-MFMA chains in flight (1, 2, 4)
 
 }  // namespace
 
 void set_scan256_mfma(int on) {
   if (on >= 0) g_scan256_mfma = on;
+}
+void set_scan256_g(int g) {
+  if (g == 1 || g == 2 || g == 4) g_scan256_g = g;
 }
 
 bool scan256_mfma_wanted(size_t n, size_t nq, int thresh) {
@@ -164,9 +167,14 @@ int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, siz
     tpc = (n_tiles + 65534) / 65535;
     chunks = (n_tiles + tpc - 1) / tpc;
   }
-  hipLaunchKernelGGL((k_hamm256_mfma<kHT, kG>), dim3(wgs, chunks), dim3(kThreads), 0, stream,
-                     reinterpret_cast<const uint32_t*>(d_rows), (uint32_t)n, qx, (uint32_t)nq, n_tiles,
-                     tpc, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total);
+#define CBH_256(GG)                                                                               \
+  hipLaunchKernelGGL((k_hamm256_mfma<kHT, GG>), dim3(wgs, chunks), dim3(kThreads), 0, stream,     \
+                     reinterpret_cast<const uint32_t*>(d_rows), (uint32_t)n, qx, (uint32_t)nq, n_tiles, \
+                     tpc, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total)
+  if (g_scan256_g == 4) CBH_256(4);
+  else if (g_scan256_g == 1) CBH_256(1);
+  else CBH_256(2);
+#undef CBH_256
   hipError_t e = hipGetLastError();
   (void)hipFreeAsync(qx, stream);
   CBH_HIP(e);
