@@ -8,11 +8,16 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <fstream>
 #include <iostream>
+#include <iterator>
 #include <set>
 #include <string>
 #include <utility>
 #include <vector>
+
+#include "cbird_hip.h"
 
 #define Q_DISABLE_COPY_MOVE(C) \
   C(const C&) = delete;        \
@@ -33,6 +38,29 @@ struct QString : std::string {
   using std::string::string;
   QString() {}
   QString(const std::string& s) : std::string(s) {}
+  QString arg(const std::string& v) const {  // replaces the lowest-numbered %N
+    QString s(*this);
+    for (int n = 1; n < 10; ++n) {
+      const std::string key = "%" + std::to_string(n);
+      const size_t p = s.find(key);
+      if (p != std::string::npos) {
+        s.replace(p, key.size(), v);
+        break;
+      }
+    }
+    return s;
+  }
+  QString arg(unsigned v) const { return arg(std::to_string(v)); }
+  QString arg(int v) const { return arg(std::to_string(v)); }
+};
+struct QByteArray : std::string {
+  using std::string::string;
+  const char* constData() const { return data(); }
+};
+struct QFileInfo {
+  std::string p;
+  explicit QFileInfo(const QString& s) : p(s) {}
+  bool exists() const { return std::ifstream(p).good(); }
 };
 struct QDebugMock {
   template <typename T>
@@ -56,7 +84,7 @@ struct QSet : std::set<T> {
   bool contains(const T& v) const { return this->count(v) != 0; }
 };
 
-// ---- QtSql: an in-memory `media` table -------------------------------------------------------
+// ---- QtSql: in-memory `media` and `kphash` tables ----------------------------------------------------
 struct QSqlDatabase {
   struct Row {
     uint32_t id;
@@ -64,12 +92,16 @@ struct QSqlDatabase {
     int64_t phash_dct;
   };
   std::vector<Row> media;
+  std::vector<std::pair<uint32_t, QByteArray>> kphash;  // (media_id, hashes blob)
 };
 struct QVariant {
-  int64_t v;
+  int64_t v = 0;
+  QByteArray b;
   unsigned toUInt() const { return unsigned(v); }
+  int toInt() const { return int(v); }
   long long toLongLong() const { return v; }
   unsigned long long toULongLong() const { return (unsigned long long)v; }
+  QByteArray toByteArray() const { return b; }
 };
 struct QSqlError {
   QString text() const { return "mock"; }
@@ -77,31 +109,100 @@ struct QSqlError {
 struct QSqlQuery {
   QSqlDatabase& db;
   long pos = -1;
-  bool ok = false;
+  int stmt = 0;  // 1: id,phash_dct of images; 2: kphash rows; 3: ids of one media type
+  int bound_type = 0;
   explicit QSqlQuery(QSqlDatabase& d) : db(d) {}
   void setForwardOnly(bool) {}
-  bool exec(const char* sql) {
-    ok = std::string(sql) == "select id,phash_dct from media where type=1";
+  bool prepare(const char* sql) {
+    stmt = std::string(sql) == "select id from media where type=:type order by id" ? 3 : 0;
+    return stmt != 0;
+  }
+  void bindValue(const char*, int v) { bound_type = v; }
+  bool exec() {
     pos = -1;
-    return ok;
+    return stmt == 3;
+  }
+  bool exec(const char* sql) {
+    const std::string q(sql);
+    stmt = q == "select id,phash_dct from media where type=1" ? 1 : q == "select media_id,hashes from kphash" ? 2 : 0;
+    pos = -1;
+    return stmt != 0;
   }
   bool next() {
+    if (stmt == 2) return ++pos < long(db.kphash.size());
+    const int want = stmt == 1 ? 1 : bound_type;
     while (++pos < long(db.media.size()))
-      if (db.media[size_t(pos)].type == 1) return true;
+      if (db.media[size_t(pos)].type == want) return true;
     return false;
   }
   QVariant value(int col) const {
+    QVariant v;
+    if (stmt == 2) {
+      if (col == 0) v.v = db.kphash[size_t(pos)].first;
+      else v.b = db.kphash[size_t(pos)].second;
+      return v;
+    }
     const auto& r = db.media[size_t(pos)];
-    return QVariant{col == 0 ? int64_t(r.id) : r.phash_dct};
+    v.v = col == 0 ? int64_t(r.id) : r.phash_dct;
+    return v;
   }
   QSqlError lastError() const { return {}; }
 };
 #define SQL_FATAL(x) qFatal("QSqlQuery." #x ": %s", qPrintable(query.lastError().text()));
 
-// ---- src/media.h (the slice DctHashIndex touches) -------------------------------------------------
+// ---- value types the other indexes carry (shapes only) ----------------------------------------------
+typedef uint64_t dcthash_t;
+typedef std::vector<uint64_t> KeyPointHashList;
+namespace cv {
+struct Mat {  // rows x cols bytes, continuous
+  int rows = 0, cols = 0;
+  std::vector<uint8_t> data;
+  Mat() {}
+  Mat(int r, int c) : rows(r), cols(c), data(size_t(r) * size_t(c)) {}
+  template <typename T>
+  const T* ptr(int r) const { return reinterpret_cast<const T*>(data.data() + size_t(r) * size_t(cols)); }
+  template <typename T>
+  T* ptr(int r) { return reinterpret_cast<T*>(data.data() + size_t(r) * size_t(cols)); }
+};
+}  // namespace cv
+typedef cv::Mat KeyPointDescriptors;
+struct DescriptorColor {  // src/cvutil.h:75-97
+  uint16_t l, u, v, w;
+};
+struct ColorDescriptor {  // src/cvutil.h:102-113
+  enum { NUM_DESC_COLORS = 32 };
+  DescriptorColor colors[NUM_DESC_COLORS] = {};
+  uint8_t numColors = 0;
+};  // 32 * 8 + 1, padded to the 2-byte alignment of its members: 258 bytes
+class VideoIndex {  // src/videoindex.h:40-52; load/save through the library's .vdx codec
+ public:
+  std::vector<int> frames;
+  std::vector<dcthash_t> hashes;
+  bool isEmpty() const { return frames.size() == 0 || hashes.size() == 0; }
+  void load(const QString& file) {
+    std::ifstream f(file, std::ios::binary);
+    std::vector<uint8_t> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (buf.empty()) return;
+    frames.resize(buf.size());  // a file of L bytes holds fewer than L frames
+    hashes.resize(buf.size());
+    const long long n = cbh_vdx_decode(buf.data(), buf.size(), frames.data(), hashes.data(), buf.size());
+    frames.resize(size_t(n > 0 ? n : 0));
+    hashes.resize(size_t(n > 0 ? n : 0));
+  }
+  void save(const QString& file) const {
+    const size_t need = cbh_vdx_encode(frames.data(), hashes.data(), frames.size(), "0.8.1", nullptr, 0);
+    std::vector<uint8_t> buf(need);
+    cbh_vdx_encode(frames.data(), hashes.data(), frames.size(), "0.8.1", buf.data(), need);
+    std::ofstream(file, std::ios::binary).write(reinterpret_cast<const char*>(buf.data()), long(need));
+  }
+};
+
+// ---- src/media.h (the slice the indexes touch) ------------------------------------------------------
 class MatchRange {
  public:
   int srcIn = -1, dstIn = -1, len = 0;
+  MatchRange() {}
+  MatchRange(int s, int d, int l) : srcIn(s), dstIn(d), len(l) {}
 };
 class Media {
  public:
@@ -110,13 +211,29 @@ class Media {
   Media(const QString& path, int id, uint64_t dctHash) : _path(path), _id(id), _dctHash(dctHash) {}
   static int typeFlag(int type) { return 1 << (type - 1); }
   int id() const { return _id; }
+  int type() const { return _type; }
+  void setType(int t) { _type = t; }
   uint64_t dctHash() const { return _dctHash; }
   const QString& path() const { return _path; }
+  const KeyPointHashList& keyPointHashes() const { return _kph; }
+  void setKeyPointHashes(const KeyPointHashList& h) { _kph = h; }
+  const KeyPointDescriptors& keyPointDescriptors() const { return _kpd; }
+  void setKeyPointDescriptors(const KeyPointDescriptors& d) { _kpd = d; }
+  const ColorDescriptor& colorDescriptor() const { return _cd; }
+  void setColorDescriptor(const ColorDescriptor& c) { _cd = c; }
+  const VideoIndex& videoIndex() const { return _vi; }
+  void setVideoIndex(const VideoIndex& v) { _vi = v; }
+  const MatchRange& matchRange() const { return _range; }
 
  private:
   QString _path;
-  int _id = 0;
+  int _id = 0, _type = TypeImage;
   uint64_t _dctHash = 0;
+  KeyPointHashList _kph;
+  KeyPointDescriptors _kpd;
+  ColorDescriptor _cd;
+  VideoIndex _vi;
+  MatchRange _range;
 };
 typedef QVector<Media> MediaGroup;
 
@@ -125,6 +242,7 @@ class SearchParams {
  public:
   enum { AlgoDCT = 0, AlgoDCTFeatures = 1, AlgoCVFeatures = 2, AlgoColor = 3, AlgoVideo = 4, NumAlgos = 5 };
   int algo = AlgoDCT, dctThresh = 5, cvThresh = 25, minMatches = 1, maxMatches = 5, maxThresh = 0;
+  int skipFrames = 300, minFramesMatched = 30, minFramesNear = 60;
   bool filterSelf = true;
 };
 

@@ -1,5 +1,6 @@
-"""The cbird-side C++ binding (cbird_amd/cpp/gpu_dcthashindex.h): compiles against a mock of the
-reference's index.h/Qt types on CPU; built and executed against the real library on the GPU box."""
+"""The cbird-side C++ bindings (cbird_amd/cpp/gpu_dcthashindex.h and gpu_indexes.h: all five Index
+subclasses): compiled against a mock of the reference's headers/Qt types on CPU; built and executed
+against the real library on the GPU box."""
 import os
 import subprocess
 
@@ -25,3 +26,19 @@ def test_adapter_runs_on_gpu(gpu):
     out = subprocess.run([os.path.join(CPP, "test_adapter")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "adapter ok" in out.stdout
+
+
+def test_other_four_adapters_compile():
+    subprocess.check_call(["make", "-C", CPP, "-B", "test_adapters4"], stdout=subprocess.DEVNULL)
+    src = open(os.path.join(ROOT, "cbird_amd", "cpp", "gpu_indexes.h")).read()
+    for cls in ("GpuDctFeaturesIndex", "GpuCvFeaturesIndex", "GpuColorDescIndex", "GpuDctVideoIndex"):
+        assert f"class {cls} : public" in src
+
+
+@pytest.mark.gpu
+def test_other_four_adapters_run_on_gpu(gpu, tmp_path):
+    subprocess.check_call(["make", "-C", CPP, "test_adapters4"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(CPP, "test_adapters4"), str(tmp_path)], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "adapters ok" in out.stdout
