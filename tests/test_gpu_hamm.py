@@ -61,6 +61,31 @@ def test_find_batch_vs_oracle_ragged_sizes(gpu, orc, n, nq, seed):
         assert (gc == wc).all() and (gi == wi).all() and (gs == ws).all(), (n, nq, dht)
 
 
+def test_random_shapes_and_thresholds(gpu, orc):
+    """Tile-padding edges of the matrix-core kernels (32-row tiles, 64/96-needle groups, 192-needle scratch
+    padding) and every threshold class, on random shapes; nulls on both sides."""
+    from cbird_amd import synth
+
+    rng = np.random.default_rng(2024)
+    for case in range(24):
+        n = int(rng.integers(1, 6000))
+        nq = int(rng.integers(1, 800))
+        dht = int(rng.choice([1, 2, 3, 4, 5, 6, 9, 17, 32, 33, 64, 65]))
+        h, ids = synth.make_hashes(n, seed=1000 + case, planted_frac=0.3)
+        q = h[rng.integers(0, n, nq)].copy()
+        flip = rng.integers(0, 64, nq).astype(np.uint64)
+        q[::3] ^= (np.uint64(1) << flip[::3])
+        q[rng.integers(0, nq, max(1, nq // 50))] = 0  # null needles never match
+        z = rng.integers(0, n, max(1, n // 40))
+        h[z] = 0
+        ids[z] = 0  # removed slots
+        idx = gpu.DctHashIndex()
+        idx.load(h, ids)
+        gi, gs, gc = idx.find_batch(q, dht, 5)
+        wi, ws, wc = orc.find64_batch(h, ids, q, dht, 5)
+        assert (gc == wc).all() and (gi == wi).all() and (gs == ws).all(), (case, n, nq, dht)
+
+
 def test_thresholds_full_range(gpu, orc):
     """dht valid range is 0..65 (src/index.cpp:77); 65 matches everything, <=0 nothing."""
     from cbird_amd import synth
