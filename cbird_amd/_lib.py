@@ -77,6 +77,8 @@ _SIGS = {
     "cbh_idx64_download": (C.c_int, [_vp, _vp, _vp, _sz]),
     "cbh_idx64_find": (C.c_int, [_vp, C.c_uint64, C.c_int, _vp, _sz, C.POINTER(_sz)]),
     "cbh_idx64_find_batch": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp]),
+    "cbh_idx64_find_batch_masked": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp]),
+    "cbh_idx64_tree_masks": (C.c_int, [_vp, _vp, _sz, _vp]),
     "cbh_idx64_find_batch_dev": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp,
                                            C.POINTER(C.c_uint64), _vp]),
     "cbh_idx64_scan_dev": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _sz, _vp, _vp]),
@@ -87,8 +89,11 @@ _SIGS = {
     "cbh_idx64_hashes_for_id": (C.c_int, [_vp, C.c_uint32, _vp, _sz, C.POINTER(_sz)]),
     "cbh_fdct_find": (C.c_int, [_vp, _vp, _sz, C.c_uint32, C.c_int, _vp, _sz, C.POINTER(_sz)]),
     "cbh_fdct_find_batch": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.c_int, _vp, _sz, _vp]),
+    "cbh_fdct_find_ex": (C.c_int, [_vp, _vp, _sz, C.c_uint32, C.c_int, C.c_int, _vp, _sz, C.POINTER(_sz)]),
+    "cbh_fdct_find_batch_ex": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
     "cbh_vidx_create": (_vp, [C.c_int]),
     "cbh_vidx_destroy": (None, [_vp]),
+    "cbh_vidx_set_radix": (C.c_int, [_vp, C.c_int]),
     "cbh_vidx_add_video": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _sz]),
     "cbh_vidx_remove": (C.c_int, [_vp, _vp, _sz]),
     "cbh_vidx_count": (_sz, [_vp]),

@@ -31,7 +31,10 @@
 // ---- DctFeaturesIndex ---------------------------------------------------------------------------------
 class GpuDctFeaturesIndex : public DctFeaturesIndex {  // inherits createTables/addRecords/removeRecords/mediaIds
  public:
-  GpuDctFeaturesIndex(int device = 0) : _idx(cbh_idx64_create(device)) {
+  // treeCompat = false: exact candidates (superset of the reference's).  true: every needle hash only sees its
+  // HammingTree leaf (src/tree/hammingtree.h:244-252) -- results equal cbird's also on multi-leaf trees.
+  GpuDctFeaturesIndex(int device = 0, bool treeCompat = false)
+      : _idx(cbh_idx64_create(device)), _treeCompat(treeCompat) {
     if (!_idx) qFatal("no usable MI355X device");
   }
   ~GpuDctFeaturesIndex() override { cbh_idx64_destroy(_idx); }
@@ -89,8 +92,8 @@ class GpuDctFeaturesIndex : public DctFeaturesIndex {  // inherits createTables/
     }
     std::vector<cbh_match> out(h.size() * 10 + 1);
     size_t n = 0;
-    CBH_CHECK(cbh_fdct_find(_idx, h.data(), h.size(), uint32_t(needle.id()), params.dctThresh, out.data(),
-                            out.size(), &n));
+    CBH_CHECK(cbh_fdct_find_ex(_idx, h.data(), h.size(), uint32_t(needle.id()), params.dctThresh,
+                               _treeCompat ? 1 : 0, out.data(), out.size(), &n));
     QVector<Index::Match> results;
     for (size_t i = 0; i < n; ++i) results.append(Index::Match(out[i].id, out[i].score));
     return results;
@@ -98,6 +101,7 @@ class GpuDctFeaturesIndex : public DctFeaturesIndex {  // inherits createTables/
 
  private:
   cbh_idx64* _idx;
+  bool _treeCompat;
 };
 
 // ---- CvFeaturesIndex ----------------------------------------------------------------------------------
@@ -217,7 +221,10 @@ class GpuColorDescIndex : public ColorDescIndex {
 // ---- DctVideoIndex ------------------------------------------------------------------------------------
 class GpuDctVideoIndex : public DctVideoIndex {
  public:
-  GpuDctVideoIndex(int device = 0) : _idx(cbh_vidx_create(device)) {
+  // radixCompat = false: exact search (the reference's vradix 0).  true: honour params.videoRadix like the
+  // reference's RadixMap does (a needle frame only sees its bucket, src/tree/radix.h:135-141).
+  GpuDctVideoIndex(int device = 0, bool radixCompat = false)
+      : _idx(cbh_vidx_create(device)), _radixCompat(radixCompat) {
     if (!_idx) qFatal("no usable MI355X device");
   }
   ~GpuDctVideoIndex() override { cbh_vidx_destroy(_idx); }
@@ -245,6 +252,7 @@ class GpuDctVideoIndex : public DctVideoIndex {
   QVector<Index::Match> find(const Media& needle, const SearchParams& p) override {
     std::vector<cbh_vmatch> out(size_t(std::max(count(), 1)));
     size_t n = 0;
+    CBH_CHECK(cbh_vidx_set_radix(_idx, _radixCompat ? p.videoRadix : 0));
     if (needle.type() == Media::TypeImage) {
       if (needle.dctHash() == 0) {
         qWarning() << "needle has no dct hash" << needle.id() << needle.path();
@@ -286,6 +294,7 @@ class GpuDctVideoIndex : public DctVideoIndex {
     CBH_CHECK(cbh_vidx_add_video(_idx, id, vi.frames.data(), vi.hashes.data(), vi.frames.size()));
   }
   cbh_vidx* _idx;
+  bool _radixCompat;
   QString _dataPath;
   bool _loaded = false;
 };

@@ -242,7 +242,7 @@ class SearchParams {
  public:
   enum { AlgoDCT = 0, AlgoDCTFeatures = 1, AlgoCVFeatures = 2, AlgoColor = 3, AlgoVideo = 4, NumAlgos = 5 };
   int algo = AlgoDCT, dctThresh = 5, cvThresh = 25, minMatches = 1, maxMatches = 5, maxThresh = 0;
-  int skipFrames = 300, minFramesMatched = 30, minFramesNear = 60;
+  int skipFrames = 300, minFramesMatched = 30, minFramesNear = 60, videoRadix = 10;
   bool filterSelf = true;
 };
 

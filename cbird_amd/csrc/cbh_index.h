@@ -7,6 +7,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "cbh_internal.h"
@@ -43,6 +44,8 @@ struct Workspace {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint64_t* d_q = nullptr;
   size_t q_cap = 0;
+  uint64_t* d_qmask = nullptr;  // per-needle equal-bits masks (tree / bucket compatible searches)
+  size_t qmask_cap = 0;
   cbh_match* d_out = nullptr;
   size_t out_cap = 0;
   uint32_t* d_counts = nullptr;
@@ -89,6 +92,7 @@ struct Workspace {
     if (d_total) (void)hipFree(d_total);
     if (h_total) (void)hipHostFree(h_total);
     if (d_q) (void)hipFree(d_q);
+    if (d_qmask) (void)hipFree(d_qmask);
     if (d_out) (void)hipFree(d_out);
     if (d_counts) (void)hipFree(d_counts);
     if (ev0) (void)hipEventDestroy(ev0);
@@ -113,6 +117,11 @@ struct cbh_idx64 {
   cbh_stats stats = {0, 0, 0.0};
   std::mutex ws_mu;
   std::vector<Workspace*> ws_free;
+  // HammingTree shape of the current contents (fdct tree-compatible search): node (depth d, prefix p) is
+  // internal iff more than 8192 values share the low d bits p; key = d << 58 | p.  Rebuilt lazily.
+  std::mutex tree_mu;
+  bool tree_valid = false;
+  std::unordered_set<uint64_t> tree_internal;
 
   Workspace* acquire(int* rc) {
     {
@@ -179,14 +188,15 @@ struct WsLease {
 // scan into the workspace record buffer, growing it until every record fits.
 // On return *total = number of matching pairs, all of them present in ws->d_rec.
 inline int scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t nq, int thresh,
-                    hipStream_t stream, unsigned long long* total, unsigned flags = 0) {
+                    hipStream_t stream, unsigned long long* total, unsigned flags = 0,
+                    const uint64_t* d_qmask = nullptr) {
   int rc = ws->ensure_records(std::max<size_t>(idx->rec_cap_default, 1024));
   if (rc) return rc;
   for (int attempt = 0; attempt < 3; ++attempt) {
     CBH_HIP(hipMemsetAsync(ws->d_total, 0, sizeof(unsigned long long), stream));
     CBH_HIP(hipEventRecord(ws->ev0, stream));
     rc = launch_hamm64_scan(idx->d_hashes, idx->d_ids, idx->n, d_q, nq, thresh, ws->d_rec,
-                            ws->rec_cap, ws->d_total, stream, flags);
+                            ws->rec_cap, ws->d_total, stream, flags, d_qmask);
     if (rc) return rc;
     CBH_HIP(hipEventRecord(ws->ev1, stream));
     CBH_HIP(hipMemcpyAsync(ws->h_total, ws->d_total, sizeof(unsigned long long),

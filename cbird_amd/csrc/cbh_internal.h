@@ -22,9 +22,13 @@ void set_last_error(const char* where, hipError_t e);
 // ---- hamm64_scan.hip ------------------------------------------------------------------
 // Appends one record per (query j, slot i) with popc(q[j]^hashes[i]) < thresh, ids[i] != 0,
 // q[j] != 0.  *d_total += number of such pairs; records with slot index >= cap are dropped.
+// d_qmask (optional, one u64 per query): additionally require ((q[j] ^ hashes[i]) & qmask[j]) == 0 -- the
+// reference's approximate structures only compare a needle with the entries that share its low bits
+// (HammingTree leaf, src/tree/hammingtree.h:244-252; RadixMap bucket, src/tree/radix.h:135-141).
 int launch_hamm64_scan(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n,
                        const uint64_t* d_q, size_t nq, int thresh, cbh_record* d_rec, size_t cap,
-                       unsigned long long* d_total, hipStream_t stream, unsigned flags = 0);
+                       unsigned long long* d_total, hipStream_t stream, unsigned flags = 0,
+                       const uint64_t* d_qmask = nullptr);
 enum { SCAN_KEEP_ID0 = 1u };  // also emit slots whose id is 0 (DctFeaturesIndex top-10 cut)
 
 void set_scan_tuning(int pre_max, int eq_for_dht1, int group);  // <0 = keep
@@ -33,7 +37,7 @@ void set_scan_tuning(int pre_max, int eq_for_dht1, int group);  // <0 = keep
 int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n,
                             const uint64_t* d_q, size_t nq, int thresh, cbh_record* d_rec,
                             size_t cap, unsigned long long* d_total, hipStream_t stream,
-                            unsigned flags = 0);
+                            unsigned flags = 0, const uint64_t* d_qmask = nullptr);
 bool scan_mfma_wanted(size_t n, size_t nq, int thresh);
 void set_scan_mfma(int on);  // <0 = keep; 2 = force for any size
 void set_scan_mfma_ht(int ht);

@@ -169,6 +169,10 @@ static int idx_append(cbh_idx64* idx, const void* hashes, const void* ids, size_
   CBH_HIP(hipMemcpyAsync(idx->d_ids + idx->n, ids, n * sizeof(uint32_t), kind, s));
   CBH_HIP(hipStreamSynchronize(s));
   idx->n += n;
+  {
+    std::lock_guard<std::mutex> lk(idx->tree_mu);
+    idx->tree_valid = false;  // the HammingTree shape depends on the contents
+  }
   return CBH_OK;
 }
 
@@ -203,7 +207,13 @@ int cbh_idx64_add(cbh_idx64* idx, const uint64_t* hashes, const uint32_t* ids, s
 
 static int idx_remove(cbh_idx64* idx, const uint32_t* ids, size_t n, int zero_hash);
 
-int cbh_idx64_remove(cbh_idx64* idx, const uint32_t* ids, size_t n) { return idx_remove(idx, ids, n, 1); }
+int cbh_idx64_remove(cbh_idx64* idx, const uint32_t* ids, size_t n) {
+  if (idx) {
+    std::lock_guard<std::mutex> lk(idx->tree_mu);
+    idx->tree_valid = false;
+  }
+  return idx_remove(idx, ids, n, 1);
+}
 
 int cbh_idx64_remove_ids_only(cbh_idx64* idx, const uint32_t* ids, size_t n) {
   return idx_remove(idx, ids, n, 0);
@@ -360,10 +370,11 @@ int cbh_idx64_find(cbh_idx64* idx, uint64_t q, int thresh, cbh_match* out, size_
 
 static int find_batch_core(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t nq,
                            int thresh, int k, cbh_match* d_out, uint32_t* d_counts,
-                           hipStream_t s, unsigned long long* total) {
+                           hipStream_t s, unsigned long long* total,
+                           const uint64_t* d_qmask = nullptr) {
   *total = 0;
   if (idx->n && thresh > 0) {
-    int rc = scan_all(idx, ws, d_q, nq, thresh, s, total);
+    int rc = scan_all(idx, ws, d_q, nq, thresh, s, total, 0, d_qmask);
     if (rc) return rc;
     rc = launch_sort_records(ws->d_rec, ws->d_alt, (size_t)*total, nq, ws->d_tmp, ws->tmp_bytes, s);
     if (rc) return rc;
@@ -373,6 +384,11 @@ static int find_batch_core(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, s
 
 int cbh_idx64_find_batch(cbh_idx64* idx, const uint64_t* q, size_t nq, int thresh,
                          int max_per_query, cbh_match* out, uint32_t* counts) {
+  return cbh_idx64_find_batch_masked(idx, q, nullptr, nq, thresh, max_per_query, out, counts);
+}
+
+int cbh_idx64_find_batch_masked(cbh_idx64* idx, const uint64_t* q, const uint64_t* qmask, size_t nq,
+                                int thresh, int max_per_query, cbh_match* out, uint32_t* counts) {
   if (!idx || max_per_query < 0) return CBH_E_INVAL;
   if (nq == 0) return CBH_OK;
   if (!q || !counts || (max_per_query && !out) || nq > CBH_MAX_QUERIES_PER_CALL) return CBH_E_INVAL;
@@ -387,9 +403,13 @@ int cbh_idx64_find_batch(cbh_idx64* idx, const uint64_t* q, size_t nq, int thres
   if ((rc = Workspace::grow(&ws->d_out, &ws->out_cap, std::max<size_t>(1, nq * k)))) return rc;
   if ((rc = Workspace::grow(&ws->d_counts, &ws->counts_cap, nq))) return rc;
   CBH_HIP(hipMemcpyAsync(ws->d_q, q, nq * sizeof(uint64_t), hipMemcpyHostToDevice, ws->stream));
+  if (qmask) {
+    if ((rc = Workspace::grow(&ws->d_qmask, &ws->qmask_cap, nq))) return rc;
+    CBH_HIP(hipMemcpyAsync(ws->d_qmask, qmask, nq * sizeof(uint64_t), hipMemcpyHostToDevice, ws->stream));
+  }
   unsigned long long total = 0;
   rc = find_batch_core(idx, ws, ws->d_q, nq, thresh, max_per_query, ws->d_out, ws->d_counts,
-                       ws->stream, &total);
+                       ws->stream, &total, qmask ? ws->d_qmask : nullptr);
   if (rc) return rc;
   if (k)
     CBH_HIP(hipMemcpyAsync(out, ws->d_out, nq * k * sizeof(cbh_match), hipMemcpyDeviceToHost,

@@ -9,7 +9,9 @@
 // The reference tree is approximate (it only descends the needle's own branch,
 // hammingtree.h:248-252); the scan is exact, so its candidate set is a superset and equals the
 // tree's while the tree is a single leaf (<= 8192 entries).
+#include <algorithm>
 #include <map>
+#include <unordered_set>
 
 #include "cbh_index.h"
 
@@ -51,8 +53,53 @@ void vote(const cbh_match* top, const uint32_t* counts, const Needle& nd, int k,
   }
 }
 
+// ---- HammingTree-compatible candidate sets -----------------------------------------------------------
+// The reference tree (src/tree/hammingtree.h) is a binary trie on hash bits 0,1,2,...: a node splits on
+// bit = depth (getBit, :243) as soon as more than CLUSTER_SIZE / 8 = 8192 values have been routed to it
+// (:384-414) and never merges again (remove() only zeroes indices, :347-364).  Routed counts only grow, so
+// the final shape does not depend on the insertion order: node (depth d, prefix p) is internal iff more
+// than 8192 stored hashes have low d bits == p.  search() (:244-252) descends the needle's own bits to
+// ONE leaf and scans only that leaf, i.e. it returns the entries under the threshold that share the
+// needle's low `depth(leaf)` bits.  tree_masks() reproduces exactly that as an equal-bits mask per needle
+// hash, which the scan kernels apply to their (rare) hits.
+constexpr size_t kLeafCap = 64 * 1024 / sizeof(uint64_t);
+
+uint64_t bitrev64(uint64_t x) {
+  x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+  x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+  x = ((x >> 4) & 0x0f0f0f0f0f0f0f0full) | ((x & 0x0f0f0f0f0f0f0f0full) << 4);
+  return __builtin_bswap64(x);
+}
+
+void split_node(const std::vector<uint64_t>& rev, size_t lo, size_t hi, int depth, uint64_t prefix,
+                std::unordered_set<uint64_t>* internal) {
+  if (hi - lo <= kLeafCap || depth >= 58) return;  // (the reference allows depth < 63; 2^58 * 8192 entries do not exist)
+  internal->insert(((uint64_t)depth << 58) | prefix);
+  // in bit-reversed order the values whose bit `depth` is 0 come first
+  const uint64_t bit = 1ull << (63 - depth);
+  const uint64_t base = rev[lo] & ~((bit << 1) - 1);  // the bits above `bit` are the (reversed) prefix
+  const size_t mid = std::lower_bound(rev.begin() + (long)lo, rev.begin() + (long)hi, base | bit) - rev.begin();
+  split_node(rev, lo, mid, depth + 1, prefix, internal);
+  split_node(rev, mid, hi, depth + 1, prefix | (1ull << depth), internal);
+}
+
+int ensure_tree(cbh_idx64* idx) {
+  std::lock_guard<std::mutex> lk(idx->tree_mu);
+  if (idx->tree_valid) return CBH_OK;
+  std::vector<uint64_t> h(idx->n);
+  std::vector<uint32_t> ids(idx->n);
+  int rc = idx->n ? cbh_idx64_download(idx, h.data(), ids.data(), idx->n) : CBH_OK;
+  if (rc) return rc;
+  for (auto& x : h) x = bitrev64(x);
+  std::sort(h.begin(), h.end());
+  idx->tree_internal.clear();
+  split_node(h, 0, h.size(), 0, 0, &idx->tree_internal);
+  idx->tree_valid = true;
+  return CBH_OK;
+}
+
 int fdct_core(cbh_idx64* idx, const uint64_t* hashes, const std::vector<Needle>& needles, size_t nq,
-              int thresh, std::vector<std::vector<cbh_match>>* results) {
+              int thresh, std::vector<std::vector<cbh_match>>* results, int tree_compat = 0) {
   const int k = 10;
   results->assign(needles.size(), {});
   if (nq == 0 || idx->n == 0 || thresh <= 0) return CBH_OK;
@@ -67,8 +114,16 @@ int fdct_core(cbh_idx64* idx, const uint64_t* hashes, const std::vector<Needle>&
   if ((rc = Workspace::grow(&ws->d_out, &ws->out_cap, nq * (size_t)k))) return rc;
   if ((rc = Workspace::grow(&ws->d_counts, &ws->counts_cap, nq))) return rc;
   CBH_HIP(hipMemcpyAsync(ws->d_q, hashes, nq * sizeof(uint64_t), hipMemcpyHostToDevice, ws->stream));
+  std::vector<uint64_t> masks;
+  if (tree_compat) {
+    masks.resize(nq);
+    if ((rc = cbh_idx64_tree_masks(idx, hashes, nq, masks.data()))) return rc;
+    if ((rc = Workspace::grow(&ws->d_qmask, &ws->qmask_cap, nq))) return rc;
+    CBH_HIP(hipMemcpyAsync(ws->d_qmask, masks.data(), nq * sizeof(uint64_t), hipMemcpyHostToDevice, ws->stream));
+  }
   unsigned long long total = 0;
-  rc = scan_all(idx, ws, ws->d_q, nq, thresh, ws->stream, &total, SCAN_KEEP_ID0);
+  rc = scan_all(idx, ws, ws->d_q, nq, thresh, ws->stream, &total, SCAN_KEEP_ID0,
+                tree_compat ? ws->d_qmask : nullptr);
   if (rc) return rc;
   rc = launch_sort_records(ws->d_rec, ws->d_alt, (size_t)total, nq, ws->d_tmp, ws->tmp_bytes, ws->stream);
   if (rc) return rc;
@@ -89,13 +144,31 @@ int fdct_core(cbh_idx64* idx, const uint64_t* hashes, const std::vector<Needle>&
 
 extern "C" {
 
+int cbh_idx64_tree_masks(cbh_idx64* idx, const uint64_t* q, size_t nq, uint64_t* out_masks) {
+  if (!idx || (nq && (!q || !out_masks))) return CBH_E_INVAL;
+  int rc = ensure_tree(idx);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(idx->tree_mu);
+  for (size_t i = 0; i < nq; ++i) {
+    int d = 0;
+    while (d < 58 && idx->tree_internal.count(((uint64_t)d << 58) | (q[i] & ((1ull << d) - 1)))) ++d;
+    out_masks[i] = (1ull << d) - 1;  // the leaf holds the entries sharing the needle's low d bits
+  }
+  return CBH_OK;
+}
+
 int cbh_fdct_find(cbh_idx64* idx, const uint64_t* hashes, size_t n, uint32_t needle_id, int thresh,
                   cbh_match* out, size_t cap, size_t* n_out) {
+  return cbh_fdct_find_ex(idx, hashes, n, needle_id, thresh, 0, out, cap, n_out);
+}
+
+int cbh_fdct_find_ex(cbh_idx64* idx, const uint64_t* hashes, size_t n, uint32_t needle_id, int thresh,
+                     int tree_compat, cbh_match* out, size_t cap, size_t* n_out) {
   if (!idx || !n_out || (cap && !out) || (n && !hashes)) return CBH_E_INVAL;
   *n_out = 0;
   std::vector<Needle> nd{{0, n, needle_id}};
   std::vector<std::vector<cbh_match>> res;
-  int rc = fdct_core(idx, hashes, nd, n, thresh, &res);
+  int rc = fdct_core(idx, hashes, nd, n, thresh, &res, tree_compat);
   if (rc) return rc;
   *n_out = res[0].size();
   for (size_t i = 0; i < res[0].size() && i < cap; ++i) out[i] = res[0][i];
@@ -105,6 +178,12 @@ int cbh_fdct_find(cbh_idx64* idx, const uint64_t* hashes, size_t n, uint32_t nee
 int cbh_fdct_find_batch(cbh_idx64* idx, const uint64_t* hashes, const uint64_t* offsets,
                         const uint32_t* needle_ids, size_t n_needles, int thresh, cbh_match* out,
                         size_t cap, uint64_t* out_offsets) {
+  return cbh_fdct_find_batch_ex(idx, hashes, offsets, needle_ids, n_needles, thresh, 0, out, cap, out_offsets);
+}
+
+int cbh_fdct_find_batch_ex(cbh_idx64* idx, const uint64_t* hashes, const uint64_t* offsets,
+                           const uint32_t* needle_ids, size_t n_needles, int thresh, int tree_compat,
+                           cbh_match* out, size_t cap, uint64_t* out_offsets) {
   if (!idx || !offsets || !needle_ids || !out_offsets || (cap && !out)) return CBH_E_INVAL;
   std::vector<Needle> nd(n_needles);
   for (size_t i = 0; i < n_needles; ++i) {
@@ -114,7 +193,7 @@ int cbh_fdct_find_batch(cbh_idx64* idx, const uint64_t* hashes, const uint64_t* 
   const size_t nq = n_needles ? (size_t)offsets[n_needles] : 0;
   if (nq && !hashes) return CBH_E_INVAL;
   std::vector<std::vector<cbh_match>> res;
-  int rc = fdct_core(idx, hashes, nd, nq, thresh, &res);
+  int rc = fdct_core(idx, hashes, nd, nq, thresh, &res, tree_compat);
   if (rc) return rc;
   uint64_t pos = 0;
   for (size_t i = 0; i < n_needles; ++i) {

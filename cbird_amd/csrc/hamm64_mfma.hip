@@ -102,7 +102,16 @@ struct HitParams {
   cbh_record* rec;
   unsigned long long cap;
   unsigned long long* total;
+  const uint2* hay;      // raw slot hashes, read only for the optional equal-bits filter
+  const uint2* qmask;    // optional: bits of (needle ^ slot) that must be zero
 };
+
+// the reference's approximate structures compare a needle only with entries sharing its low bits
+__device__ __forceinline__ bool mask_ok(const HitParams& hp, uint32_t row, uint32_t qi, uint64_t nv) {
+  if (!hp.qmask) return true;
+  const uint2 hv = hp.hay[row], mk = hp.qmask[qi];
+  return (((hv.x ^ (uint32_t)nv) & mk.x) | ((hv.y ^ (uint32_t)(nv >> 32)) & mk.y)) == 0;
+}
 
 // Cold path (inlined once per haystack tile of the single step() call site; a real call costs far
 // more per hit: spills around the call and waits on the needle prefetches).
@@ -157,7 +166,7 @@ __device__ __forceinline__ void handle_tile(const v16f& c, uint32_t row0, uint32
         const uint2 hv = s_hay[hay_off + rit];
         d = __popc(hv.x ^ (uint32_t)nv) + __popc(hv.y ^ (uint32_t)(nv >> 32));
       }
-      if (nv != 0 && d < hp.thresh) {
+      if (nv != 0 && d < hp.thresh && mask_ok(hp, row, qi, nv)) {
         const uint32_t id = hp.ids[row];
         if (id != 0 || hp.keep0) emit(hp.rec, hp.cap, hp.total, qi, d, id);
       }
@@ -171,7 +180,8 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_mfma(
     const uint2* __restrict__ hay, const uint32_t* __restrict__ ids, uint32_t n,
     const uint64_t* __restrict__ q, const uint4* __restrict__ qx, uint32_t nq, uint32_t n_pairs,
     uint32_t pairs_per_chunk, uint32_t thresh, cbh_record* __restrict__ rec,
-    unsigned long long cap, unsigned long long* __restrict__ total, uint32_t keep0) {
+    unsigned long long cap, unsigned long long* __restrict__ total, uint32_t keep0,
+    const uint2* __restrict__ qmask) {
   __shared__ uint32_t s_queue_[kWaves][kQueue];  // candidates of one haystack tile
   __shared__ uint2 s_hay_[PRE ? kWaves : 1][PRE ? HT * 32 : 1];  // PRE: raw hashes for the re-check
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_mfma(
   const uint32_t lo_thr = lo_zero - 2u * (thresh - 1u);  // lo16 >= lo_thr  <=>  distA < thresh
   const uint32_t hi_thr = hi_zero - (thresh - 1u);       // hi16 >= hi_thr  <=>  distB < thresh
   const uint32_t lo_key = lo_thr << 16, hi_key = hi_thr << 16;
-  const HitParams hp = {lo_key, hi_key, lo_zero, hi_zero, thresh, n, nq, keep0, q, ids, rec, cap, total};
+  const HitParams hp = {lo_key, hi_key, lo_zero, hi_zero, thresh, n, nq, keep0, q, ids, rec, cap, total, hay, qmask};
 
   // one needle-tile pair against the HT resident haystack tiles
   auto step = [&](const uint32_t p, const uint4& nA, const uint4& nB) {
@@ -324,7 +334,8 @@ __device__ __forceinline__ void handle_tile3(const v16f& c, uint32_t row0, uint3
     const uint32_t src = e & 63u, g = (e >> 6) & 15u, field = (e >> 10) & 3u, d = e >> 12;
     const uint32_t row = row0 + (g & 3u) + 8u * (g >> 2) + 4u * (src >> 5);
     const uint32_t qi = p3 * 96u + field * 32u + (src & 31u);
-    if (row < hp.n && qi < hp.nq && hp.q[qi] != 0) {
+    const uint64_t nv = (row < hp.n && qi < hp.nq) ? hp.q[qi] : 0;
+    if (nv != 0 && mask_ok(hp, row, qi, nv)) {
       const uint32_t id = hp.ids[row];
       if (id != 0 || hp.keep0) emit(hp.rec, hp.cap, hp.total, qi, d, id);
     }
@@ -337,7 +348,8 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_mfma3(
     const uint2* __restrict__ hay, const uint32_t* __restrict__ ids, uint32_t n,
     const uint64_t* __restrict__ q, const uint4* __restrict__ qx, uint32_t nq, uint32_t n_triples,
     uint32_t triples_per_chunk, uint32_t thresh, cbh_record* __restrict__ rec,
-    unsigned long long cap, unsigned long long* __restrict__ total, uint32_t keep0) {
+    unsigned long long cap, unsigned long long* __restrict__ total, uint32_t keep0,
+    const uint2* __restrict__ qmask) {
   __shared__ uint32_t s_queue_[kWaves][3 * 16 * 64];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t r = lane & 31u, half = lane >> 5;
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_mfma3(
 #pragma unroll
   for (int g = 0; g < 16; ++g) c0[g] = 8388608.0f + (float)((64u + 2u * b) * 16513u);
   asm volatile("" : "+v"(c0));
-  const HitParams hp = {0, 0, 0, 0, thresh, n, nq, keep0, q, ids, rec, cap, total};
+  const HitParams hp = {0, 0, 0, 0, thresh, n, nq, keep0, q, ids, rec, cap, total, hay, qmask};
 
   const uint32_t p0 = blockIdx.y * triples_per_chunk;
   const uint32_t p1 = min(n_triples, p0 + triples_per_chunk);
@@ -448,7 +460,7 @@ bool scan_mfma_wanted(size_t n, size_t nq, int thresh) {
 int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n,
                             const uint64_t* d_q, size_t nq, int thresh, cbh_record* d_rec,
                             size_t cap, unsigned long long* d_total, hipStream_t stream,
-                            unsigned flags) {
+                            unsigned flags, const uint64_t* d_qmask) {
   if (n == 0 || nq == 0 || thresh <= 0) return CBH_OK;
   if (n > 0xfffffff0ull || nq > CBH_MAX_QUERIES_PER_CALL || thresh > 65) return CBH_E_INVAL;
   const uint32_t n_pairs = (uint32_t)((nq + 63) / 64);
@@ -483,7 +495,7 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
     hipLaunchKernelGGL((k_hamm64_mfma3<8, kG>), dim3(wgs, ch3), dim3(kThreads), 0, stream,
                        reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx, (uint32_t)nq,
                        n_triples, tpc, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total,
-                       (uint32_t)(flags & 1u));
+                       (uint32_t)(flags & 1u), reinterpret_cast<const uint2*>(d_qmask));
     hipError_t e3 = hipGetLastError();
     (void)hipFreeAsync(qx, stream);
     CBH_HIP(e3);
@@ -493,7 +505,8 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
   hipLaunchKernelGGL((k_hamm64_mfma<HT, GG, PRE>), dim3(wgs, chunks), dim3(kThreads), 0, stream, \
                      reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx,      \
                      (uint32_t)nq, n_pairs, ppc, (uint32_t)thresh, d_rec,                        \
-                     (unsigned long long)cap, d_total, (uint32_t)(flags & 1u))
+                     (unsigned long long)cap, d_total, (uint32_t)(flags & 1u),                     \
+                     reinterpret_cast<const uint2*>(d_qmask))
 #define CBH_MFMA(HT, PRE) CBH_MFMA_G(HT, kG, PRE)
   if (ht == 8 && g_mfma_g == 4) {
     if (pre) CBH_MFMA_G(8, 4, true); else CBH_MFMA_G(8, 4, false);

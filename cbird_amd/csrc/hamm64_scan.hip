@@ -48,16 +48,17 @@ __device__ __forceinline__ void exact_block(const uint2 (&h)[H], uint32_t base_i
                                             uint32_t qb, uint32_t thresh,
                                             cbh_record* __restrict__ rec, unsigned long long cap,
                                             unsigned long long* __restrict__ total,
-                                            uint32_t keep0) {
+                                            uint32_t keep0, const uint2* __restrict__ qmask) {
 #pragma unroll 1
   for (uint32_t qi = qa; qi < qb; ++qi) {
     const uint64_t qq = q[qi];
     if (qq == 0) continue;  // null needle: DctHashIndex::find returns nothing (:196-200)
     const uint32_t ql = (uint32_t)qq, qh = (uint32_t)(qq >> 32);
+    const uint2 mk = qmask ? qmask[qi] : make_uint2(0u, 0u);  // bits that must be equal (tree/bucket modes)
 #pragma unroll
     for (int j = 0; j < H; ++j) {
       const uint32_t d = __popc(h[j].x ^ ql) + __popc(h[j].y ^ qh);
-      if (d < thresh) {
+      if (d < thresh && (((h[j].x ^ ql) & mk.x) | ((h[j].y ^ qh) & mk.y)) == 0) {
         const uint32_t idx = base_idx + (uint32_t)j * kThreads;
         if (idx < n) {
           const uint32_t id = ids[idx];
@@ -79,7 +80,7 @@ __device__ __forceinline__ void refine_block(const uint2 (&h)[H], const uint32_t
                                              uint32_t thresh, cbh_record* __restrict__ rec,
                                              unsigned long long cap,
                                              unsigned long long* __restrict__ total,
-                                             uint32_t keep0) {
+                                             uint32_t keep0, const uint2* __restrict__ qmask) {
 #pragma unroll
   for (int j = 0; j < H; ++j) {
     if (acc[j] < thresh) {
@@ -97,7 +98,11 @@ __device__ __forceinline__ void refine_block(const uint2 (&h)[H], const uint32_t
         if (id != 0 || keep0) {
 #pragma unroll
           for (int i = 0; i < QB; ++i)
-            if (d[i] < thresh && (cur[i].x | cur[i].y) != 0) emit(rec, cap, total, qb + (uint32_t)i, d[i], id);
+            if (d[i] < thresh && (cur[i].x | cur[i].y) != 0) {
+              const uint2 mk = qmask ? qmask[qb + (uint32_t)i] : make_uint2(0u, 0u);
+              if ((((h[j].x ^ cur[i].x) & mk.x) | ((h[j].y ^ cur[i].y) & mk.y)) == 0)
+                emit(rec, cap, total, qb + (uint32_t)i, d[i], id);
+            }
         }
       }
     }
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_scan(
     const uint2* __restrict__ hay, const uint32_t* __restrict__ ids, uint32_t n,
     const uint64_t* __restrict__ q, uint32_t nq, uint32_t q_chunk, uint32_t thresh,
     cbh_record* __restrict__ rec, unsigned long long cap, unsigned long long* __restrict__ total,
-    uint32_t keep0) {
+    uint32_t keep0, const uint2* __restrict__ qmask) {
   const uint32_t base_idx = blockIdx.x * (uint32_t)(kThreads * H) + threadIdx.x;
   uint2 h[H];
 #pragma unroll
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_scan(
           any |= __ballot(hh == qq);
         }
       }
-      if (any) exact_block<H>(h, base_idx, n, ids, q, qb, qb + QB, thresh, rec, cap, total, keep0);
+      if (any) exact_block<H>(h, base_idx, n, ids, q, qb, qb + QB, thresh, rec, cap, total, keep0, qmask);
     } else {
       uint32_t acc[H];
 #pragma unroll
@@ -224,12 +229,12 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_scan(
 #pragma unroll
       for (int j = 1; j + 1 < H; j += 2) m = min3u(m, acc[j], acc[j + 1]);
       if (H % 2 == 0) m = min(m, acc[H - 1]);
-      if (m < thresh) refine_block<H, QB>(h, acc, cur, base_idx, n, ids, qb, thresh, rec, cap, total, keep0);
+      if (m < thresh) refine_block<H, QB>(h, acc, cur, base_idx, n, ids, qb, thresh, rec, cap, total, keep0, qmask);
     }
 #pragma unroll
     for (int i = 0; i < QB; ++i) cur[i] = nxt[i];
   }
-  if (qb < q1) exact_block<H>(h, base_idx, n, ids, q, qb, q1, thresh, rec, cap, total, keep0);
+  if (qb < q1) exact_block<H>(h, base_idx, n, ids, q, qb, q1, thresh, rec, cap, total, keep0, qmask);
 }
 
 int g_pre_max = 7;  // largest threshold served by the low-word prefilter variant
@@ -246,12 +251,13 @@ void set_scan_tuning(int pre_max, int eq_for_dht1, int group) {
 
 int launch_hamm64_scan(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n,
                        const uint64_t* d_q, size_t nq, int thresh, cbh_record* d_rec, size_t cap,
-                       unsigned long long* d_total, hipStream_t stream, unsigned flags) {
+                       unsigned long long* d_total, hipStream_t stream, unsigned flags,
+                       const uint64_t* d_qmask) {
   if (n == 0 || nq == 0 || thresh <= 0) return CBH_OK;
   if (n > 0xfffffff0ull || nq > CBH_MAX_QUERIES_PER_CALL) return CBH_E_INVAL;
   if (scan_mfma_wanted(n, nq, thresh))
     return launch_hamm64_scan_mfma(d_hashes, d_ids, n, d_q, nq, thresh, d_rec, cap, d_total, stream,
-                                   flags);
+                                   flags, d_qmask);
   const uint32_t tile = kThreads * kH;
   const uint32_t tiles = (uint32_t)((n + tile - 1) / tile);
   // needle chunk: enough workgroups to fill 256 CUs x 8 waves/SIMD several times over, but each
@@ -269,7 +275,8 @@ int launch_hamm64_scan(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n
 #define CBH_SCAN(MODE, GROUP)                                                                 \
   hipLaunchKernelGGL((k_hamm64_scan<kH, kQB, MODE, GROUP>), grid, block, 0, stream, hay,      \
                      d_ids, (uint32_t)n, d_q, (uint32_t)nq, q_chunk, (uint32_t)thresh, d_rec, \
-                     (unsigned long long)cap, d_total, (uint32_t)(flags & 1u))
+                     (unsigned long long)cap, d_total, (uint32_t)(flags & 1u),                \
+                     reinterpret_cast<const uint2*>(d_qmask))
   if (thresh == 1 && g_eq_for_dht1)
     CBH_SCAN(MODE_EQ, false);
   else if (thresh <= g_pre_max) {

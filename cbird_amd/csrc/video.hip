@@ -27,6 +27,9 @@ struct cbh_vidx {
   std::vector<uint32_t> evidx;   // entry -> video index
   std::vector<int32_t> eframe;   // entry -> frame number
   std::mutex build_mu;           // QMutex _mutex (dctvideoindex.cpp:118)
+  // 0 = exact search.  > 0 = RadixMap-compatible: a needle hash only sees the entries of its bucket
+  // (hash >> 1) & (2^radix - 1) (src/tree/radix.h:135-141), like `-p.vradix N` in the reference.
+  unsigned radix = 0;
 };
 
 namespace {
@@ -86,8 +89,14 @@ int scan_to_host(cbh_vidx* v, const uint64_t* q, size_t nq, int thresh, std::vec
   Workspace* ws = L.ws;
   if ((rc = Workspace::grow(&ws->d_q, &ws->q_cap, nq))) return rc;
   CBH_HIP(hipMemcpyAsync(ws->d_q, q, nq * sizeof(uint64_t), hipMemcpyHostToDevice, ws->stream));
+  std::vector<uint64_t> masks;
+  if (v->radix) {  // equal bucket <=> equal bits 1..radix
+    masks.assign(nq, ((1ull << v->radix) - 1) << 1);
+    if ((rc = Workspace::grow(&ws->d_qmask, &ws->qmask_cap, nq))) return rc;
+    CBH_HIP(hipMemcpyAsync(ws->d_qmask, masks.data(), nq * sizeof(uint64_t), hipMemcpyHostToDevice, ws->stream));
+  }
   unsigned long long total = 0;
-  rc = scan_all(idx, ws, ws->d_q, nq, thresh, ws->stream, &total);
+  rc = scan_all(idx, ws, ws->d_q, nq, thresh, ws->stream, &total, 0, v->radix ? ws->d_qmask : nullptr);
   if (rc) return rc;
   rc = launch_sort_records(ws->d_rec, ws->d_alt, (size_t)total, nq, ws->d_tmp, ws->tmp_bytes, ws->stream);
   if (rc) return rc;
@@ -187,6 +196,14 @@ cbh_vidx* cbh_vidx_create(int device) {
   cbh_vidx* v = new (std::nothrow) cbh_vidx;
   if (v) v->device = device;
   return v;
+}
+
+/* RadixMap(params.videoRadix) (dctvideoindex.cpp:128): radix is limited like the reference's constructor does
+ * (radix.h:105-112: 30 - ceil(log2(sizeof(Bucket) + sizeof(Bucket*))) = 24 with its two-vector Bucket) */
+int cbh_vidx_set_radix(cbh_vidx* v, int radix) {
+  if (!v || radix < 0) return CBH_E_INVAL;
+  v->radix = (unsigned)std::min(radix, 24);
+  return CBH_OK;
 }
 
 void cbh_vidx_destroy(cbh_vidx* v) {

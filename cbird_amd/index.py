@@ -183,17 +183,29 @@ class DctHashIndex:
         return DctHashIndex(self._device, _handle=h)
 
     # -- batched entry points (the MI355X-native shape of Database::similar's fan-out) ----------
-    def find_batch(self, hashes: Sequence[int], thresh: int, max_per_query: int):
+    def find_batch(self, hashes: Sequence[int], thresh: int, max_per_query: int, masks=None):
         """For every needle hash: first `max_per_query` matches in (score, mediaId) order and the
-        full match count.  Returns (ids[nq,k] u32, scores[nq,k] i32, counts[nq] u32)."""
+        full match count.  Returns (ids[nq,k] u32, scores[nq,k] i32, counts[nq] u32).
+        masks (optional, one u64 per needle): only entries with ((needle ^ hash) & mask) == 0 qualify."""
         q = _as_u64(hashes)
         nq, k = len(q), int(max_per_query)
         out = np.zeros((nq, max(k, 1), 2), np.uint32)
         counts = np.zeros(nq, np.uint32)
-        check(self._L.cbh_idx64_find_batch(self._h, q.ctypes.data, nq, int(thresh), k,
-                                           out.ctypes.data, counts.ctypes.data), "find_batch")
+        mk = None if masks is None else _as_u64(masks)
+        if mk is not None and len(mk) != nq:
+            raise ValueError("one mask per needle")
+        check(self._L.cbh_idx64_find_batch_masked(self._h, q.ctypes.data, None if mk is None else mk.ctypes.data,
+                                                  nq, int(thresh), k, out.ctypes.data, counts.ctypes.data),
+              "find_batch")
         out = out[:, :k, :]
         return out[:, :, 0].copy(), out[:, :, 1].astype(np.int32), counts
+
+    def tree_masks(self, hashes: Sequence[int]) -> np.ndarray:
+        """HammingTree leaf masks of needle hashes for the current contents (cbh_idx64_tree_masks)"""
+        q = _as_u64(hashes)
+        out = np.zeros(len(q), np.uint64)
+        check(self._L.cbh_idx64_tree_masks(self._h, q.ctypes.data, len(q), out.ctypes.data), "tree_masks")
+        return out
 
     def download(self):
         n = self.count()
@@ -219,10 +231,14 @@ class DctFeaturesIndex:
     keypoint hashes per image, stored as (mediaId, hash) entries; `find` votes over the 10 nearest
     entries of every needle hash (src/dctfeaturesindex.cpp:260-358)."""
 
-    def __init__(self, device: int = 0) -> None:
+    def __init__(self, device: int = 0, tree_compat: bool = False) -> None:
         self._L = _lib.lib()
         self._device = device
         self._id = SearchParams.AlgoDCTFeatures  # dctfeaturesindex.cpp:84
+        # False: exact candidates (a superset of the reference's).  True: every needle hash only sees the
+        # entries of its HammingTree leaf (src/tree/hammingtree.h:244-252), i.e. the reference's own
+        # approximate candidate sets, also on multi-leaf trees.
+        self.tree_compat = bool(tree_compat)
         self._h = self._L.cbh_idx64_create(device)
         if not self._h:
             raise CbhError(_lib.CBH_E_NODEVICE, "cbh_idx64_create")
@@ -299,8 +315,9 @@ class DctFeaturesIndex:
         cap = len(hashes) * 10 + 1
         buf = (cbh_match * cap)()
         n = C.c_size_t(0)
-        check(self._L.cbh_fdct_find(self._h, hashes.ctypes.data, len(hashes), needle.id,
-                                    int(p.dctThresh), buf, cap, C.byref(n)), "fdct_find")
+        check(self._L.cbh_fdct_find_ex(self._h, hashes.ctypes.data, len(hashes), needle.id,
+                                       int(p.dctThresh), int(self.tree_compat), buf, cap, C.byref(n)),
+              "fdct_find")
         return [Match(buf[i].id, buf[i].score) for i in range(n.value)]
 
     def find_batch(self, needles, p: SearchParams):
@@ -316,9 +333,9 @@ class DctFeaturesIndex:
         cap = len(hs) * 10 + 1
         buf = (cbh_match * cap)()
         out_offs = np.zeros(len(needles) + 1, np.uint64)
-        check(self._L.cbh_fdct_find_batch(self._h, h.ctypes.data, o.ctypes.data, i.ctypes.data,
-                                          len(needles), int(p.dctThresh), buf, cap,
-                                          out_offs.ctypes.data), "fdct_find_batch")
+        check(self._L.cbh_fdct_find_batch_ex(self._h, h.ctypes.data, o.ctypes.data, i.ctypes.data,
+                                             len(needles), int(p.dctThresh), int(self.tree_compat), buf, cap,
+                                             out_offs.ctypes.data), "fdct_find_batch")
         return [[Match(buf[j].id, buf[j].score) for j in range(int(out_offs[k]), int(out_offs[k + 1]))]
                 for k in range(len(needles))]
 

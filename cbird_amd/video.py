@@ -89,13 +89,17 @@ class VideoSearchParams(SearchParams):
     skipFrames: int = 300
     minFramesMatched: int = 30
     minFramesNear: int = 60
-    videoRadix: int = 10  # accepted for interface parity; the search is always exact (vradix = 0)
+    videoRadix: int = 10  # `-p.vradix`; only honoured by DctVideoIndex(radix_compat=True), else the search is exact
 
 
 class DctVideoIndex:
     """Detect similar videos with full-frame dct hashes (src/dctvideoindex.h:66-70)."""
 
-    def __init__(self, device: int = 0, data_path: str | None = None) -> None:
+    def __init__(self, device: int = 0, data_path: str | None = None, radix_compat: bool = False) -> None:
+        # False: exact search (the reference's vradix = 0).  True: a needle frame only sees the entries of its
+        # RadixMap bucket, (hash >> 1) & (2^videoRadix - 1) (src/tree/radix.h:135-141): the reference's
+        # approximate candidate sets for `-p.vradix N`.
+        self.radix_compat = bool(radix_compat)
         self._L = _lib.lib()
         self._id = SearchParams.AlgoVideo
         self._data_path = data_path
@@ -155,7 +159,12 @@ class DctVideoIndex:
         return [Match(buf[i].id, buf[i].score, MatchRange(buf[i].src_in, buf[i].dst_in, buf[i].len))
                 for i in range(n)]
 
+    def _apply_radix(self, p) -> None:
+        r = int(getattr(p, "videoRadix", 0)) if self.radix_compat else 0
+        check(self._L.cbh_vidx_set_radix(self._h, r), "set_radix")
+
     def findFrame(self, needle, p: VideoSearchParams):
+        self._apply_radix(p)
         hash_ = int(needle.dctHash)
         if hash_ == 0:
             warnings.warn(f"needle has no dct hash {needle.id} {needle.path}")
@@ -169,6 +178,7 @@ class DctVideoIndex:
         return self._matches(buf, n.value)
 
     def findVideo(self, needle, p: VideoSearchParams):
+        self._apply_radix(p)
         vi = needle.videoIndex
         if vi is None or vi.isEmpty():
             warnings.warn(f"needle video index is empty: {needle.path}")
@@ -191,6 +201,7 @@ class DctVideoIndex:
         return self.findFrame(needle, p)
 
     def find_videos_batch(self, needles, p: VideoSearchParams):
+        self._apply_radix(p)
         needles = list(needles)
         f = np.concatenate([np.asarray(m.videoIndex.frames, np.int32) for m in needles] or [np.zeros(0, np.int32)])
         h = np.concatenate([np.asarray(m.videoIndex.hashes, np.uint64) for m in needles] or [np.zeros(0, np.uint64)])

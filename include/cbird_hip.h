@@ -135,6 +135,18 @@ int cbh_idx64_find_batch(cbh_idx64*, const uint64_t* q, size_t nq, int thresh, i
                          cbh_match* out, uint32_t* counts);
 /* Same with device-resident queries and outputs (d_out: nq*max_per_query cbh_match,
  * d_counts: nq u32); *total_out (host) = total number of matching pairs. */
+/* find_batch with one equal-bits mask per needle: additionally requires ((q ^ hash) & qmask) == 0.  This is
+ * how the reference's APPROXIMATE structures restrict a search -- a HammingTree needle only sees the leaf
+ * that shares its low bits (src/tree/hammingtree.h:244-252), a RadixMap needle only its bucket
+ * (src/tree/radix.h:135-141) -- so with the right masks the results equal the reference's instead of being
+ * a superset.  qmask == NULL is cbh_idx64_find_batch. */
+int cbh_idx64_find_batch_masked(cbh_idx64*, const uint64_t* q, const uint64_t* qmask, size_t nq, int thresh,
+                                int max_per_query, cbh_match* out, uint32_t* counts);
+/* masks that make a search see exactly what HammingTree::search (hammingtree.h:103-108,244-293) would see
+ * for the index's current contents: out_masks[i] = (1 << depth of q[i]'s leaf) - 1.  The tree shape (a node
+ * splits on bit = depth once more than 8192 values were routed to it, :384-414) is rebuilt lazily after
+ * load/add. */
+int cbh_idx64_tree_masks(cbh_idx64*, const uint64_t* q, size_t nq, uint64_t* out_masks);
 int cbh_idx64_find_batch_dev(cbh_idx64*, const void* d_q, size_t nq, int thresh,
                              int max_per_query, void* d_out, void* d_counts,
                              uint64_t* total_out, void* stream);
@@ -183,6 +195,13 @@ int cbh_fdct_find(cbh_idx64*, const uint64_t* hashes, size_t n, uint32_t needle_
 /* Many needles in one scan: needle i owns hashes[offsets[i] .. offsets[i+1]); results of needle i
  * go to out[out_offsets[i] .. out_offsets[i+1]).  CBH_E_OVERFLOW when the total exceeds cap
  * (out_offsets[n_needles] then holds the required capacity). */
+/* as cbh_fdct_find / _batch; tree_compat != 0 restricts every needle hash to its HammingTree leaf
+ * (cbh_idx64_tree_masks), reproducing the reference's approximate candidate sets on multi-leaf trees */
+int cbh_fdct_find_ex(cbh_idx64*, const uint64_t* hashes, size_t n, uint32_t needle_id, int thresh,
+                     int tree_compat, cbh_match* out, size_t cap, size_t* n_out);
+int cbh_fdct_find_batch_ex(cbh_idx64*, const uint64_t* hashes, const uint64_t* offsets,
+                           const uint32_t* needle_ids, size_t n_needles, int thresh, int tree_compat,
+                           cbh_match* out, size_t cap, uint64_t* out_offsets);
 int cbh_fdct_find_batch(cbh_idx64*, const uint64_t* hashes, const uint64_t* offsets,
                         const uint32_t* needle_ids, size_t n_needles, int thresh, cbh_match* out,
                         size_t cap, uint64_t* out_offsets);
@@ -198,6 +217,10 @@ typedef struct cbh_vidx cbh_vidx; /* opaque: DctVideoIndex state */
 
 cbh_vidx* cbh_vidx_create(int device);
 void cbh_vidx_destroy(cbh_vidx*);
+/* 0 (default) = exact search; N > 0 = the reference's RadixMap(videoRadix = N) behaviour: a needle frame only
+ * sees index entries of its bucket (hash >> 1) & (2^N - 1) (src/tree/radix.h:135-141, `-p.vradix`, default 10
+ * in cbird); N is limited to 24 like the reference's constructor does (:105-112) */
+int cbh_vidx_set_radix(cbh_vidx*, int radix);
 /* load()/add() (:172-211, :250-254) only register media ids; the per-video (frame, hash) lists come
  * from <dataPath>/<id>.vdx when the tree is built (insertHashes :61-111).  Here the caller hands the
  * decoded lists over (cbh_vdx_decode below reads the files).  Order of calls = _mediaId order. */

@@ -133,6 +133,32 @@ class Oracle:
                                  oi, osc, cap)
         return oi[:m].copy(), osc[:m].copy()
 
+    def htree_leaf_masks(self, hashes, needle_hashes):
+        """equal-bits masks that restrict a needle hash to its HammingTree leaf (orc_htree_leaf_masks)"""
+        hashes = np.ascontiguousarray(hashes, np.uint64)
+        nh = np.ascontiguousarray(needle_hashes, np.uint64)
+        out = np.zeros(len(nh), np.uint64)
+        self.L.orc_htree_leaf_masks.argtypes = [_u64p, C.c_size_t, _u64p, C.c_size_t, _u64p]
+        self.L.orc_htree_leaf_masks.restype = None
+        self.L.orc_htree_leaf_masks(hashes, len(hashes), nh, len(nh), out)
+        return out
+
+    def fdct_find_tree(self, hashes, ids, needle_hashes, needle_id, thresh):
+        """DctFeaturesIndex::find with the reference tree's (approximate) candidate sets"""
+        hashes = np.ascontiguousarray(hashes, np.uint64)
+        ids = np.ascontiguousarray(ids, np.uint32)
+        nh = np.ascontiguousarray(needle_hashes, np.uint64)
+        mk = self.htree_leaf_masks(hashes, nh)
+        cap = len(nh) * 10 + 1
+        oi = np.zeros(cap, np.uint32)
+        osc = np.zeros(cap, np.int32)
+        f = self.L.orc_fdct_find_masked
+        f.argtypes = [_u64p, _u32p, C.c_size_t, _u64p, _u64p, C.c_size_t, C.c_uint32, C.c_int, _u32p, _i32p,
+                      C.c_size_t]
+        f.restype = C.c_longlong
+        m = f(hashes, ids, len(hashes), nh, mk, len(nh), int(needle_id), int(thresh), oi, osc, cap)
+        return oi[:m].copy(), osc[:m].copy()
+
     # -- hashing ------------------------------------------------------------------------
     def zigzag81(self):
         z = np.zeros(81, np.int32)

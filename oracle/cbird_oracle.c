@@ -482,9 +482,41 @@ static int cmp_u32(const void* a, const void* b) {
   return x < y ? -1 : x > y;
 }
 
+long long orc_fdct_find_masked(const uint64_t* hashes, const uint32_t* ids, size_t n, const uint64_t* nhash,
+                               const uint64_t* nmask, size_t nn, uint32_t needle_id, int thresh,
+                               uint32_t* out_ids, int32_t* out_scores, size_t cap);
+
+/* ---- HammingTree leaf of a needle: src/tree/hammingtree.h --------------------------------------------
+ * insert() (:366-425): a leaf at depth d that would hold more than CLUSTER_SIZE / sizeof(hash) = 8192 values
+ * becomes internal and splits on bit d (getBit(depth) = depth, :243; partition tests hash & (1 << bit), :234-241);
+ * its children are filled by the same rule.  Counts only grow (remove() keeps the hashes, :347-364), so node
+ * (d, prefix) is internal iff more than 8192 stored hashes have that low-d-bit prefix.  search() (:244-252)
+ * follows the needle's bits to one leaf and scans only it.
+ * out_masks[j] = (1 << depth of needle j's leaf) - 1: the entries a search can see are those with
+ * ((hash ^ needle) & mask) == 0.  Deliberately the dumbest possible statement: recount per level. */
+void orc_htree_leaf_masks(const uint64_t* hashes, size_t n, const uint64_t* q, size_t nq, uint64_t* out_masks) {
+  for (size_t j = 0; j < nq; ++j) {
+    int d = 0;
+    for (; d < 58; ++d) {
+      const uint64_t m = (d == 0) ? 0 : ((1ull << d) - 1);
+      size_t cnt = 0;
+      for (size_t i = 0; i < n; ++i) cnt += ((hashes[i] ^ q[j]) & m) == 0;
+      if (cnt <= 8192) break; /* this node is a leaf */
+    }
+    out_masks[j] = (d == 0) ? 0 : ((1ull << d) - 1);
+  }
+}
+
 long long orc_fdct_find(const uint64_t* hashes, const uint32_t* ids, size_t n, const uint64_t* nhash,
                         size_t nn, uint32_t needle_id, int thresh, uint32_t* out_ids,
                         int32_t* out_scores, size_t cap) {
+  return orc_fdct_find_masked(hashes, ids, n, nhash, 0, nn, needle_id, thresh, out_ids, out_scores, cap);
+}
+
+/* nmask (optional): the equal-bits mask of every needle hash (tree-compatible candidates) */
+long long orc_fdct_find_masked(const uint64_t* hashes, const uint32_t* ids, size_t n, const uint64_t* nhash,
+                               const uint64_t* nmask, size_t nn, uint32_t needle_id, int thresh,
+                               uint32_t* out_ids, int32_t* out_scores, size_t cap) {
   /* votes: at most 10 per needle hash */
   size_t maxv = nn * 10 + 1;
   uint32_t* vid = (uint32_t*)malloc(sizeof(uint32_t) * maxv);
@@ -495,7 +527,7 @@ long long orc_fdct_find(const uint64_t* hashes, const uint32_t* ids, size_t n, c
     size_t m = 0;
     for (size_t i = 0; i < n; ++i) {
       int d = __builtin_popcountll(nhash[j] ^ hashes[i]);
-      if (d < thresh) {
+      if (d < thresh && (!nmask || ((nhash[j] ^ hashes[i]) & nmask[j]) == 0)) {
         cand[m].dist = d;
         cand[m].id = ids[i];
         ++m;

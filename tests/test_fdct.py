@@ -119,3 +119,65 @@ def test_gpu_add_remove_findindex_batch(gpu, orc, scan_path):
     for nd, r in zip(media[50:80], res):
         single = idx.find(nd, p)
         assert [(x.mediaId, x.score) for x in r] == [(x.mediaId, x.score) for x in single]
+
+
+# ---- the reference tree is approximate on more than one leaf: tree-compatible mode ------------------------
+def _popc(a):
+    c = np.zeros(len(a), np.int32)
+    for k in range(64):
+        c += ((a >> np.uint64(k)) & np.uint64(1)).astype(np.int32)
+    return c
+
+
+def test_leaf_mask_rule_reproduces_real_multileaf_tree(orc):
+    """fdct_multileaf.npz holds the REAL HammingTree's candidate sets on a 60k-entry (multi-leaf) tree: the
+    restated leaf rule (node (d, prefix) is internal iff > 8192 hashes share the prefix) must select exactly
+    those, and the masked voting must reproduce DctFeaturesIndex::find on that tree."""
+    g = load_golden("fdct_multileaf.npz")
+    h, ids, q, thr = g["hashes"], g["ids"], g["cand_q"], int(g["cand_thresh"])
+    mk = orc.htree_leaf_masks(h, q)
+    assert (mk > 0).all() and len(set(mk.tolist())) >= 1  # deeper than the root: it really is multi-leaf
+    exact_more = 0
+    for j, x in enumerate(q):
+        xr = h ^ x
+        d = _popc(xr)
+        sel = (d < thr) & ((xr & mk[j]) == 0)
+        a, b = int(g["cand_offs"][j]), int(g["cand_offs"][j + 1])
+        want = sorted(zip(g["cand_dist"][a:b].tolist(), g["cand_idx"][a:b].tolist()))
+        assert sorted(zip(d[sel].tolist(), ids[sel].tolist())) == want, j
+        exact_more += int((d < thr).sum()) - (b - a)
+    assert exact_more > 0  # the exact search sees candidates the tree misses: the modes really differ
+    for nh, nid, t, wi, ws in _cases(g):
+        gi, gs = orc.fdct_find_tree(h, ids, nh, nid, t)
+        assert gi.tolist() == wi.tolist() and gs.tolist() == ws.tolist(), (nid, t)
+
+
+@pytest.mark.gpu
+def test_gpu_tree_compatible_mode_equals_real_multileaf_tree(gpu, orc, scan_path):
+    g = load_golden("fdct_multileaf.npz")
+    h, ids, q, thr = g["hashes"], g["ids"], g["cand_q"], int(g["cand_thresh"])
+    raw = gpu.DctHashIndex()
+    raw.load(h, np.maximum(ids, 0))
+    mk = raw.tree_masks(q)
+    assert (mk == orc.htree_leaf_masks(h, q)).all()
+    gi, gs, gc = raw.find_batch(q, thr, 64, masks=mk)
+    for j in range(len(q)):
+        a, b = int(g["cand_offs"][j]), int(g["cand_offs"][j + 1])
+        want = sorted((int(d), int(i)) for d, i in zip(g["cand_dist"][a:b], g["cand_idx"][a:b]) if i != 0)
+        assert gc[j] == len(want) and list(zip(gs[j, :gc[j]].tolist(), gi[j, :gc[j]].tolist())) == want, j
+    # the index class: load everything, remove two media, search with the reference's candidate sets
+    idx = gpu.DctFeaturesIndex(tree_compat=True)
+    idx.load([(int(i), [int(x)]) for i, x in zip(ids.tolist(), h.tolist())])
+    p = gpu.SearchParams()
+    for nh, nid, t, wi, ws in _cases(g):
+        p.dctThresh = t
+        got = idx.find(gpu.Media(id=nid, keyPointHashes=nh.tolist()), p)
+        assert [m.mediaId for m in got] == wi.tolist() and [m.score for m in got] == ws.tolist(), (nid, t)
+    exact = gpu.DctFeaturesIndex()
+    exact.load([(int(i), [int(x)]) for i, x in zip(ids.tolist(), h.tolist())])
+    differ = 0
+    for nh, nid, t, wi, ws in list(_cases(g))[:30]:
+        p.dctThresh = t
+        e = exact.find(gpu.Media(id=nid, keyPointHashes=nh.tolist()), p)
+        differ += [m.mediaId for m in e] != wi.tolist() or [m.score for m in e] != ws.tolist()
+    assert differ > 0  # the default (exact) mode is a different, larger candidate set on this tree

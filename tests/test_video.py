@@ -197,3 +197,41 @@ def test_gpu_video_batch_remove_add(gpu, vorc):
         assert all(x.mediaId not in victims for x in r)
     idx.add([m for m in media if m.id in victims])
     assert idx.count() == 120
+
+
+@pytest.mark.gpu
+def test_gpu_radix_compatible_mode_equals_bucket_search(gpu, vorc):
+    """`-p.vradix N` of the reference: a needle frame only sees its RadixMap bucket.  The oracle's bucket rule is
+    pinned to the real RadixMap (test_oracle_candidates_vs_real_radixmap); DctVideoIndex(radix_compat=True) must
+    equal it, and differ from the exact search where the exact search finds more."""
+    from cbird_amd import synth_video
+    from cbird_amd.video import DctVideoIndex, VideoIndex, VideoSearchParams
+
+    clips = synth_video.make_clips(200, 200, seed=21, subclip_frac=0.15, max_gap=6)
+
+    class M:
+        pass
+
+    media = []
+    for i, (f, h) in enumerate(clips):
+        m = M()
+        m.id, m.path, m.videoIndex, m.dctHash = 500 + i, f"v{i}", VideoIndex(f.tolist(), [int(x) for x in h]), 0
+        media.append(m)
+    videos = [(m.id, f, h) for m, (f, h) in zip(media, clips)]
+    entries = vorc.build_entries(videos, 0)
+    exact_more = 0
+    for radix in (10, 3, 24):
+        idx = DctVideoIndex(radix_compat=True)
+        idx.add(media)
+        p = VideoSearchParams(dctThresh=7, skipFrames=0, minFramesMatched=5, minFramesNear=20, videoRadix=radix)
+        for m in media[::5]:
+            got = [(x.mediaId, x.score, x.range.srcIn, x.range.dstIn, x.range.len) for x in idx.findVideo(m, p)]
+            want = vorc.find_video(entries, m.videoIndex.frames, m.videoIndex.hashes, m.id, 7, 0, 5, 20, radix=radix)
+            assert got == want, (m.id, radix)
+            full = vorc.find_video(entries, m.videoIndex.frames, m.videoIndex.hashes, m.id, 7, 0, 5, 20, radix=0)
+            exact_more += got != full
+        for m in media[::17]:
+            m.dctHash = int(m.videoIndex.hashes[3]) ^ 0x40000000  # a near frame outside the bucket for small radix
+            got = [(x.mediaId, x.score, x.range.srcIn, x.range.dstIn, x.range.len) for x in idx.findFrame(m, p)]
+            assert got == vorc.find_frame(entries, m.dctHash, 7, -1, radix=radix), (m.id, radix)
+    assert exact_more > 0
