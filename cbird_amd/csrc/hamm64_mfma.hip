@@ -61,6 +61,9 @@ constexpr float kC0 = 8388608.0f + 16448.0f + 2097152.0f;
 constexpr int kScale15 = 0x8e8e8e8e;  // E8M0 142 = 2^15
 constexpr int kPreMaxThresh = 4;      // P[popc(32 random bits) < 4] = 1.3e-6: 0.5 % of the groups re-check
 constexpr uint32_t kQueue = 2048;     // 16 registers x 2 fields x 64 lanes: cannot overflow
+// PRE keeps its two low-word distances as 7-bit fields at bits 0 and 15 biased so that "under the
+// threshold" is bit 6 of the field (see the kernel): OR-ing accumulators preserves "some flag is set"
+constexpr uint32_t kFlagMaskPre = (1u << 6) | (1u << 21);
 
 // needles -> FP4 scratch: needle j -> 2 x uint4 (low word, high word); j >= nq padded with hash 0
 __global__ __launch_bounds__(256) void k_expand_needles(const uint64_t* __restrict__ q, uint32_t nq,
@@ -125,20 +128,29 @@ __device__ __forceinline__ void handle_tile(const v16f& c, uint32_t row0, uint32
                                             const HitParams& hp, uint32_t* s_queue, const uint2* s_hay) {
   const uint32_t lane = threadIdx.x & 63u;
   // quick reject of the tile that did not cause the group's hit
-  h2 m0 = {0, 0}, m1 = {0, 0};
+  if (PRE) {
+    uint32_t any = 0;
 #pragma unroll
-  for (int g = 0; g < 16; g += 4) {
-    m0 = pkmax3(m0, as_h2(c[g]), as_h2(c[g + 1]));
-    m1 = pkmax3(m1, as_h2(c[g + 2]), as_h2(c[g + 3]));
+    for (int g = 0; g < 16; ++g) any |= as_u32(c[g]);
+    if (__builtin_amdgcn_ballot_w64((any & kFlagMaskPre) != 0) == 0) return;
+  } else {
+    h2 m0 = {0, 0}, m1 = {0, 0};
+#pragma unroll
+    for (int g = 0; g < 16; g += 4) {
+      m0 = pkmax3(m0, as_h2(c[g]), as_h2(c[g + 1]));
+      m1 = pkmax3(m1, as_h2(c[g + 2]), as_h2(c[g + 3]));
+    }
+    const uint32_t tb = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(m0, m1));
+    if (__builtin_amdgcn_ballot_w64((tb << 16) >= hp.lo_key || tb >= hp.hi_key) == 0) return;
   }
-  const uint32_t tb = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(m0, m1));
-  if (__builtin_amdgcn_ballot_w64((tb << 16) >= hp.lo_key || tb >= hp.hi_key) == 0) return;
 
   uint32_t cnt = 0;  // wave-uniform
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
     const uint32_t bits = as_u32(c[g]);
-    const bool fh = bits >= hp.hi_key, fl = (bits << 16) >= hp.lo_key;
+    // PRE: flag bits (the distance in the entry is not used: candidates are re-evaluated on 64 bits)
+    const bool fh = PRE ? ((bits >> 21) & 1u) != 0 : bits >= hp.hi_key;
+    const bool fl = PRE ? ((bits >> 6) & 1u) != 0 : (bits << 16) >= hp.lo_key;
     if (__builtin_amdgcn_ballot_w64(fh || fl) == 0) continue;  // scalar branch, rarely not taken
     const uint64_t mh = __builtin_amdgcn_ballot_w64(fh);
     if (fh)
@@ -200,9 +212,13 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_mfma(
     if (PRE && half == 0) s_hay[t * 32 + r] = hv;
   }
   wave_order();
+  // FULL2: C0 = kC0 (two 16-bit fields compared against per-threshold keys).
+  // PRE:   C0 = 2^23 + (32 + 2b)(1 + 2^15), b = thresh - 1: field = 32 + 2b + dot_lo in [2b, 64 + 2b] < 128 and
+  //        dlo <= b  <=>  dot_lo >= 32 - 2b  <=>  field >= 64  <=>  bit 6 (tile A) / bit 21 (tile B) is set
   v16f c0;
 #pragma unroll
-  for (int g = 0; g < 16; ++g) c0[g] = kC0;
+  for (int g = 0; g < 16; ++g)
+    c0[g] = PRE ? 8388608.0f + (float)((32u + 2u * (thresh - 1u)) * 32769u) : kC0;
   asm volatile("" : "+v"(c0));  // keep C0 resident: otherwise it is rebuilt (16 v_mov) every trip
   int scale_b = (PRE && half) ? kScale15 : kScaleOne;
   asm volatile("" : "+v"(scale_b));
@@ -239,17 +255,32 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_mfma(
           c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t0 + t], bB, c[t], 4, 4, 0,
                                                                  kScaleOne, 0, kScale15);
       }
-      // packed per-half maximum of the group's G*16 results: 8 v_pk_maximum3_f16 per tile
-      h2 m0 = {0, 0}, m1 = {0, 0};
+      bool hit;
+      if (PRE) {
+        // flag bits survive OR: 8 v_or3_b32 per tile (plain VGPR-only ops, cheaper to issue than the packed max)
+        uint32_t o0 = 0, o1 = 0;
 #pragma unroll
-      for (int t = 0; t < G; ++t)
+        for (int t = 0; t < G; ++t)
 #pragma unroll
-        for (int g = 0; g < 16; g += 4) {
-          m0 = pkmax3(m0, as_h2(c[t][g]), as_h2(c[t][g + 1]));
-          m1 = pkmax3(m1, as_h2(c[t][g + 2]), as_h2(c[t][g + 3]));
-        }
-      const uint32_t mb = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(m0, m1));
-      if (__builtin_amdgcn_ballot_w64((mb << 16) >= lo_key || mb >= hi_key) != 0) {
+          for (int g = 0; g < 16; g += 4) {
+            o0 |= as_u32(c[t][g]) | as_u32(c[t][g + 1]);
+            o1 |= as_u32(c[t][g + 2]) | as_u32(c[t][g + 3]);
+          }
+        hit = ((o0 | o1) & kFlagMaskPre) != 0;
+      } else {
+        // packed per-half maximum of the group's G*16 results: 8 v_pk_maximum3_f16 per tile
+        h2 m0 = {0, 0}, m1 = {0, 0};
+#pragma unroll
+        for (int t = 0; t < G; ++t)
+#pragma unroll
+          for (int g = 0; g < 16; g += 4) {
+            m0 = pkmax3(m0, as_h2(c[t][g]), as_h2(c[t][g + 1]));
+            m1 = pkmax3(m1, as_h2(c[t][g + 2]), as_h2(c[t][g + 3]));
+          }
+        const uint32_t mb = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(m0, m1));
+        hit = (mb << 16) >= lo_key || mb >= hi_key;
+      }
+      if (__builtin_amdgcn_ballot_w64(hit) != 0) {
         // wave-uniform from here: something in this group is under the threshold (rare)
 #pragma unroll
         for (int t = 0; t < G; ++t)

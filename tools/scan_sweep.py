@@ -22,7 +22,7 @@ ms = C.c_float(0)
 for name, dq in sets.items():
     idx = cbird_amd.DctHashIndex(); ids = torch.arange(1, N + 1, dtype=torch.int32, device=dev)
     idx.load_device(dq.data_ptr(), ids.data_ptr(), N)
-    for thr in (2, 5, 8, 16):
+    for thr in (1, 2, 4, 5):
         row = []
         for label, pre, eq, grp in (("mfma8g2full", 0, 0, 0), ("mfma8g2ful3", 0, 0, 0), ("mfma8g2pre", 0, 0, 0)):
             if label == "eq" and thr != 1: continue
