@@ -30,8 +30,8 @@
 //   PRE   (thresh <= kPreMaxThresh) low-word prefilter at twice the pair rate: the block scale is
 //         per lane and K block, so lanes 0-31 (K 0..31) carry the LOW words of needle tile A with
 //         scale 1 and lanes 32-63 (K 32..63) the LOW words of tile B with scale 2^15, against the
-//         haystack's low words in both K blocks: ONE MFMA = 2048 low-word distances,
-//         hi16 = 0x4B30 - dloB, lo16 = 0x4060 - 2*dloA.  Sound because popc(lo) >= thresh implies
+//         haystack's low words in both K blocks: ONE MFMA = 2048 low-word distances, kept as two flag-bit
+//         fields (see FULL3 below) and reduced with v_or3_b32.  Sound because popc(lo) >= thresh implies
 //         popc(lo) + popc(hi) >= thresh; candidates are re-evaluated on the full 64 bits.
 //
 // Hits.  After the MFMAs of a group of G haystack tiles one compare of the packed maximum decides
