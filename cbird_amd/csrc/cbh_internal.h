@@ -51,6 +51,7 @@ int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, siz
                         hipStream_t stream);
 bool scan256_mfma_wanted(size_t n, size_t nq, int thresh);
 void set_scan256_g(int g);
+void set_scan256_ht(int ht);
 void set_scan256_mfma(int on);  // <0 = keep; 2 = force for any size
 
 int g_hash_mfma_set(int v);  // dcthash.hip

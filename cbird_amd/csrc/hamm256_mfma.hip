@@ -19,7 +19,6 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
-constexpr int kHT = 4;  // row tiles per wave
 
 // needle descriptors -> FP4 scratch, tile-major: uint4 index ((tile*4 + chunk)*2 + half)*32 + c
 // holds the expansion of 32-bit word (2*chunk + half) of descriptor tile*32 + c
@@ -130,7 +129,8 @@ __global__ __launch_bounds__(kThreads) void k_hamm256_mfma(
 }
 
 int g_scan256_mfma = 1;
-int g_scan256_g = 4;  // row tiles per accumulator group = independent 4-MFMA chains in flight (1, 2, 4)
+int g_scan256_ht = 6;  // row tiles per wave (2, 4, 6)
+int g_scan256_g = 3;   // row tiles per accumulator group = independent 4-MFMA chains in flight
 
 }  // namespace
 
@@ -138,7 +138,10 @@ void set_scan256_mfma(int on) {
   if (on >= 0) g_scan256_mfma = on;
 }
 void set_scan256_g(int g) {
-  if (g == 1 || g == 2 || g == 4) g_scan256_g = g;
+  if (g >= 1 && g <= 4) g_scan256_g = g;
+}
+void set_scan256_ht(int ht) {
+  if (ht == 2 || ht == 4 || ht == 6) g_scan256_ht = ht;
 }
 
 bool scan256_mfma_wanted(size_t n, size_t nq, int thresh) {
@@ -158,7 +161,7 @@ int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, siz
   CBH_HIP(hipMallocAsync((void**)&qx, (size_t)nq_pad * 128u, stream));
   hipLaunchKernelGGL(k_expand_needles256, dim3((8u * nq_pad + 255u) / 256u), dim3(256), 0, stream,
                      reinterpret_cast<const uint32_t*>(d_q), (uint32_t)nq, nq_pad, qx);
-  const uint32_t rows_per_wg = 32u * kHT * kWaves;
+  const uint32_t rows_per_wg = 32u * (uint32_t)g_scan256_ht * kWaves;
   const uint32_t wgs = (uint32_t)((n + rows_per_wg - 1) / rows_per_wg);
   uint32_t tpc = 128;  // needle tiles per chunk (4096 descriptors)
   while (tpc > 4 && (uint64_t)wgs * ((n_tiles + tpc - 1) / tpc) < 8192) tpc >>= 1;
@@ -167,13 +170,17 @@ int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, siz
     tpc = (n_tiles + 65534) / 65535;
     chunks = (n_tiles + tpc - 1) / tpc;
   }
-#define CBH_256(GG)                                                                               \
-  hipLaunchKernelGGL((k_hamm256_mfma<kHT, GG>), dim3(wgs, chunks), dim3(kThreads), 0, stream,     \
+#define CBH_256(HT, GG)                                                                           \
+  hipLaunchKernelGGL((k_hamm256_mfma<HT, GG>), dim3(wgs, chunks), dim3(kThreads), 0, stream,      \
                      reinterpret_cast<const uint32_t*>(d_rows), (uint32_t)n, qx, (uint32_t)nq, n_tiles, \
                      tpc, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total)
-  if (g_scan256_g == 4) CBH_256(4);
-  else if (g_scan256_g == 1) CBH_256(1);
-  else CBH_256(2);
+  if (g_scan256_ht == 2) {
+    if (g_scan256_g == 1) CBH_256(2, 1); else CBH_256(2, 2);
+  } else if (g_scan256_ht == 6) {
+    if (g_scan256_g == 1) CBH_256(6, 1); else if (g_scan256_g == 2) CBH_256(6, 2); else CBH_256(6, 3);
+  } else {
+    if (g_scan256_g == 4) CBH_256(4, 4); else if (g_scan256_g == 1) CBH_256(4, 1); else CBH_256(4, 2);
+  }
 #undef CBH_256
   hipError_t e = hipGetLastError();
   (void)hipFreeAsync(qx, stream);
