@@ -86,6 +86,29 @@ def test_random_shapes_and_thresholds(gpu, orc):
         assert (gc == wc).all() and (gi == wi).all() and (gs == ws).all(), (case, n, nq, dht)
 
 
+def test_distance_extremes_all_thresholds(gpu, orc):
+    """Distances 0 and 64 (complement) and the neighbourhood of every field boundary of the packed
+    accumulators: identical, complemented and k-bit-flipped copies, every threshold 1..65."""
+    rng = np.random.default_rng(77)
+    base = rng.integers(1, 1 << 63, 600, dtype=np.uint64) << np.uint64(1)
+    h = np.concatenate([base, ~base & ~np.uint64(1)])  # bit 0 kept clear like real dct hashes
+    ids = np.arange(1, len(h) + 1, dtype=np.uint32)
+    q = [base[:40], ~base[:40]]
+    for k in (1, 2, 31, 32, 33, 62, 63):
+        m = np.zeros(40, np.uint64)
+        for j in range(40):
+            bits = rng.choice(64, k, replace=False)
+            m[j] = np.bitwise_or.reduce(np.uint64(1) << bits.astype(np.uint64))
+        q.append(base[40:80] ^ m)
+    q = np.concatenate(q)
+    idx = gpu.DctHashIndex()
+    idx.load(h, ids)
+    for dht in list(range(1, 9)) + [16, 31, 32, 33, 34, 48, 63, 64, 65]:
+        gi, gs, gc = idx.find_batch(q, dht, 4)
+        wi, ws, wc = orc.find64_batch(h, ids, q, dht, 4)
+        assert (gc == wc).all() and (gi == wi).all() and (gs == ws).all(), dht
+
+
 def test_thresholds_full_range(gpu, orc):
     """dht valid range is 0..65 (src/index.cpp:77); 65 matches everything, <=0 nothing."""
     from cbird_amd import synth
