@@ -79,6 +79,84 @@ __global__ __launch_bounds__(256) void k_color_dist(const float* __restrict__ L,
   if (i < n) out[(size_t)blockIdx.y * n + i] = result;
 }
 
+
+// Two haystack descriptors per lane on the packed-f32 ALU (v_pk_add_f32 / v_pk_mul_f32 work on two
+// independent floats per lane and issue like one VALU op): per colour pair 3 pk sub + 3 pk mul + 2 pk add
+// for both descriptors, then the minima per half.  Same operations in the same order as k_color_dist (no
+// contraction: products and sums are rounded separately), so results are bit-identical; missing haystack
+// colours are loaded as 1e18 so their distance (~3e36, finite) can never win a minimum -- one select less.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+
+// Missing colours on EITHER side are 1e18 in L (host: decompress_pad; device: the index planes are padded the
+// same way), so a pair with a missing colour has a distance of ~1e36 (finite) that never wins a minimum and the
+// loop needs no selects.  Squared distances are non-negative finite floats, whose order is the order of their
+// bit patterns as unsigned integers: the minima are v_min_u32 / v_min3_u32 (no NaN canonicalisation ops).
+__global__ __launch_bounds__(256) void k_color_dist2(const float* __restrict__ L, const float* __restrict__ U,
+                                                     const float* __restrict__ V,
+                                                     const unsigned char* __restrict__ num, size_t stride,
+                                                     uint32_t n, const NeedleF* __restrict__ needles,
+                                                     int* __restrict__ out /* [nq][n] */) {
+  const uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 2u;  // descriptors i0, i0 + 1 (stride is even)
+  const NeedleF& nd = needles[blockIdx.y];                             // wave-uniform, colours >= num padded
+  const int nn = nd.num;
+  const int hn0 = i0 < n ? (int)num[i0] : 0, hn1 = i0 + 1 < n ? (int)num[i0 + 1] : 0;
+  const int hmax = max(hn0, hn1);
+  constexpr uint32_t kBig = 0x7f7fffffu;  // FLT_MAX
+  u2 rowmin[kNC];
+#pragma unroll
+  for (int p = 0; p < kNC; ++p) rowmin[p] = u2{kBig, kBig};
+  f2 colacc = {1.0f, 1.0f};
+  for (int h = 0; h < kNC; ++h) {
+    if (__ballot(h < hmax) == 0ull) break;  // no lane of this wave has that many colours
+    f2 hl = {1e18f, 1e18f}, hu = {0.f, 0.f}, hv = {0.f, 0.f};
+    if (i0 < n) {  // planes are padded to an even capacity and with 1e18 beyond every descriptor's colours
+      hl = *reinterpret_cast<const f2*>(L + (size_t)h * stride + i0);
+      hu = *reinterpret_cast<const f2*>(U + (size_t)h * stride + i0);
+      hv = *reinterpret_cast<const f2*>(V + (size_t)h * stride + i0);
+    }
+    u2 colmin = {kBig, kBig};
+#pragma unroll
+    for (int p = 0; p < kNC; p += 2) {
+      const f2 dl0 = f2{nd.l[p], nd.l[p]} - hl, du0 = f2{nd.u[p], nd.u[p]} - hu, dv0 = f2{nd.v[p], nd.v[p]} - hv;
+      const f2 dl1 = f2{nd.l[p + 1], nd.l[p + 1]} - hl, du1 = f2{nd.u[p + 1], nd.u[p + 1]} - hu,
+               dv1 = f2{nd.v[p + 1], nd.v[p + 1]} - hv;
+      const f2 e0 = dl0 * dl0 + du0 * du0 + dv0 * dv0;
+      const f2 e1 = dl1 * dl1 + du1 * du1 + dv1 * dv1;
+      const u2 b0 = __builtin_bit_cast(u2, e0), b1 = __builtin_bit_cast(u2, e1);
+      rowmin[p] = u2{min(rowmin[p].x, b0.x), min(rowmin[p].y, b0.y)};
+      rowmin[p + 1] = u2{min(rowmin[p + 1].x, b1.x), min(rowmin[p + 1].y, b1.y)};
+      colmin = u2{min(min(colmin.x, b0.x), b1.x), min(min(colmin.y, b0.y), b1.y)};  // v_min3_u32
+    }
+    // (scalar copies first: __builtin_bit_cast on a vector-element lvalue reads element 0 with this clang)
+    const uint32_t cm0 = colmin.x, cm1 = colmin.y;
+    if (h < hn0) colacc.x += sqrtf(__builtin_bit_cast(float, cm0));  // haystack side is "a" (more colours)
+    if (h < hn1) colacc.y += sqrtf(__builtin_bit_cast(float, cm1));
+  }
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const uint32_t i = i0 + (uint32_t)e;
+    const int hn = e ? hn1 : hn0;
+    int result = -1;
+    if (i < n && nn != 0 && hn != 0 && abs(nn - hn) <= 2) {
+      float score;
+      if (nn < hn) {
+        score = e ? colacc.y : colacc.x;
+      } else {
+        score = 1.0f;
+#pragma unroll
+        for (int p = 0; p < kNC; ++p)
+          if (p < nn) {
+            const uint32_t rm = e ? rowmin[p].y : rowmin[p].x;
+            score += sqrtf(__builtin_bit_cast(float, rm));
+          }
+      }
+      result = (int)score;
+    }
+    if (i < n) out[(size_t)blockIdx.y * n + i] = result;
+  }
+}
+
 // key = score<<32 | id for entries that match (score >= 0, id != 0), ~0 otherwise
 __global__ __launch_bounds__(256) void k_color_keys(const int* __restrict__ score,
                                                     const uint32_t* __restrict__ ids, uint32_t n,
@@ -92,82 +170,104 @@ __global__ __launch_bounds__(256) void k_color_keys(const int* __restrict__ scor
 
 
 // ---- top-k per needle without sorting the whole score row (find_batch) -----------------------------------
-// Scores are small integers (1 + 32 colour distances <= 1 + 32 * 451.7 < 16384), so a histogram finds
-// the k-th smallest score exactly; only entries at or under it are collected and ordered on the host.
-constexpr int kBins = 16384;
+// Scores are small integers, so the k-th smallest score can be found exactly with a histogram; only entries at
+// or under it are collected and ordered on the host.  The k best of ~10^6 entries lie within a few hundred of
+// the minimum, so the histogram is a 2048-bin window above the per-needle minimum score (k_color_min), kept in
+// LDS per block and flushed once (one pass of global atomics over ALL scores took 5 ms per 64 needles; this
+// takes 0.2 ms).  A k-th score beyond the window, or more ties than kCandCap, falls back to the full sort.
+constexpr int kWin = 2048;
 constexpr uint32_t kCandCap = 4096;  // per needle; more ties than this -> the full-sort path
+
+__global__ __launch_bounds__(256) void k_color_min(const int* __restrict__ score, const uint32_t* __restrict__ ids,
+                                                   uint32_t n, int* __restrict__ smin /* [nq], init INT_MAX */) {
+  const uint32_t q = blockIdx.y;
+  const int* sc = score + (size_t)q * n;
+  int m = 0x7fffffff;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const int s = sc[i];
+    if (s >= 0 && ids[i] != 0) m = min(m, s);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m != 0x7fffffff) atomicMin(&smin[q], m);
+}
 
 __global__ __launch_bounds__(256) void k_color_hist(const int* __restrict__ score,
                                                     const uint32_t* __restrict__ ids, uint32_t n,
-                                                    uint32_t* __restrict__ hist /* [nq][kBins] */,
+                                                    const int* __restrict__ smin,
+                                                    uint32_t* __restrict__ hist /* [nq][kWin] */,
                                                     uint32_t* __restrict__ valid /* [nq] */) {
+  __shared__ uint32_t sh[kWin];
   const uint32_t q = blockIdx.y;
   const int* sc = score + (size_t)q * n;
+  const int base = smin[q];
+  for (int b = threadIdx.x; b < kWin; b += 256) sh[b] = 0;
+  __syncthreads();
   uint32_t local = 0;
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     const int s = sc[i];
     if (s >= 0 && ids[i] != 0) {
-      atomicAdd(&hist[(size_t)q * kBins + (uint32_t)min(s, kBins - 1)], 1u);
       ++local;
+      const int d = s - base;
+      if (d < kWin) atomicAdd(&sh[d], 1u);
     }
   }
+  __syncthreads();
+  for (int b = threadIdx.x; b < kWin; b += 256)
+    if (sh[b]) atomicAdd(&hist[(size_t)q * kWin + b], sh[b]);
   if (local) atomicAdd(&valid[q], local);  // compiler aggregates per wave
 }
 
-// T[q] = smallest score bin whose cumulative count reaches k (kBins - 1 when there are fewer than k)
+// thr[q] = k-th smallest score when it lies inside the window, else INT_MAX (collect everything -> fallback)
 __global__ __launch_bounds__(256) void k_color_thresh(const uint32_t* __restrict__ hist, uint32_t k,
-                                                      uint32_t* __restrict__ thr) {
+                                                      const int* __restrict__ smin, int* __restrict__ thr) {
   __shared__ uint32_t part[256];
   const uint32_t q = blockIdx.x, t = threadIdx.x;
-  const uint32_t* h = hist + (size_t)q * kBins + t * (kBins / 256);
+  const uint32_t* h = hist + (size_t)q * kWin + t * (kWin / 256);
   uint32_t sum = 0;
-  for (int b = 0; b < kBins / 256; ++b) sum += h[b];
+  for (int b = 0; b < kWin / 256; ++b) sum += h[b];
   part[t] = sum;
   __syncthreads();
   if (t == 0) {
-    uint32_t run = 0, seg = 255, before = 0;
-    bool found = false;
-    for (uint32_t j = 0; j < 256 && !found; ++j) {
+    uint32_t run = 0;
+    int bin = -1;
+    for (uint32_t j = 0; j < 256 && bin < 0; ++j) {
       if (run + part[j] >= k) {
-        seg = j;
-        before = run;
-        found = true;
+        const uint32_t* hs = hist + (size_t)q * kWin + j * (kWin / 256);
+        uint32_t c = run;
+        for (int b = 0; b < kWin / 256; ++b) {
+          c += hs[b];
+          if (c >= k) {
+            bin = (int)j * (kWin / 256) + b;
+            break;
+          }
+        }
       }
       run += part[j];
     }
-    uint32_t bin = kBins - 1;
-    if (found) {
-      const uint32_t* hs = hist + (size_t)q * kBins + seg * (kBins / 256);
-      uint32_t c = before;
-      for (int b = 0; b < kBins / 256; ++b) {
-        c += hs[b];
-        if (c >= k) {
-          bin = seg * (kBins / 256) + b;
-          break;
-        }
-      }
-    }
-    thr[q] = bin;
+    thr[q] = bin >= 0 ? smin[q] + bin : 0x7fffffff;
   }
 }
 
 __global__ __launch_bounds__(256) void k_color_collect(const int* __restrict__ score,
                                                        const uint32_t* __restrict__ ids, uint32_t n,
-                                                       const uint32_t* __restrict__ thr,
+                                                       const int* __restrict__ thr,
                                                        unsigned long long* __restrict__ cand /* [nq][kCandCap] */,
                                                        uint32_t* __restrict__ ncand /* [nq] */) {
   const uint32_t q = blockIdx.y;
   const int* sc = score + (size_t)q * n;
-  const int T = (int)thr[q];
+  const int T = thr[q];
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     const int s = sc[i];
     const uint32_t id = ids[i];
-    if (s >= 0 && id != 0 && (min(s, kBins - 1) <= T)) {
+    if (s >= 0 && id != 0 && s <= T) {
       const uint32_t slot = atomicAdd(&ncand[q], 1u);
       if (slot < kCandCap) cand[(size_t)q * kCandCap + slot] = ((unsigned long long)(uint32_t)s << 32) | id;
     }
   }
 }
+
+int g_color_pk = 1;  // 1 = k_color_dist2 (two descriptors per lane, packed f32)
 
 void decompress(const uint8_t* desc, NeedleF* out) {  // DescriptorColor::get, cvutil.h:83-87
   for (int c = 0; c < kNC; ++c) {
@@ -180,9 +280,22 @@ void decompress(const uint8_t* desc, NeedleF* out) {  // DescriptorColor::get, c
     out->v[c] = v * 262.0f / 65535 - 140.0f;
   }
   out->num = desc[256];
+  // colours the reference's loops never visit (index >= numColors): far away, so that a distance involving one
+  // of them (~1e36, finite) can never be a minimum -- lets k_color_dist2 run without per-colour guards
+  for (int c = out->num < kNC ? out->num : kNC; c < kNC; ++c) {
+    out->l[c] = 1e18f;
+    out->u[c] = 0.f;
+    out->v[c] = 0.f;
+  }
 }
 
 }  // namespace
+
+namespace cbh {
+void set_color_pk(int on) {
+  if (on >= 0) g_color_pk = on;
+}
+}  // namespace cbh
 
 struct cbh_color {
   int device = 0;
@@ -202,7 +315,8 @@ struct cbh_color {
   void* d_tmp = nullptr;
   size_t keys_cap = 0, tmp_bytes = 0;
   // find_batch top-k scratch
-  uint32_t *d_hist = nullptr, *d_thr = nullptr, *d_ncand = nullptr, *d_valid = nullptr;
+  uint32_t *d_hist = nullptr, *d_ncand = nullptr, *d_valid = nullptr;
+  int *d_thr = nullptr, *d_smin = nullptr;
   unsigned long long* d_cand = nullptr;
   size_t topk_cap = 0;
 };
@@ -211,7 +325,7 @@ namespace {
 
 int grow_index(cbh_color* c, size_t need) {
   if (need <= c->cap) return CBH_OK;
-  const size_t ncap = std::max<size_t>(need, c->cap + c->cap / 2 + 4096);
+  const size_t ncap = (std::max<size_t>(need, c->cap + c->cap / 2 + 4096) + 1) & ~(size_t)1;  // even: pair loads
   float *nL = nullptr, *nU = nullptr, *nV = nullptr;
   unsigned char* nn = nullptr;
   uint32_t* ni = nullptr;
@@ -294,9 +408,15 @@ int run_dist(cbh_color* c, const uint8_t* needle_descs, size_t nq) {
   for (size_t q = 0; q < nq; ++q) decompress(needle_descs + q * kDescBytes, &nf[q]);
   CBH_HIP(hipMemcpyAsync(c->d_needles, nf.data(), nq * sizeof(NeedleF), hipMemcpyHostToDevice, c->stream));
   CBH_HIP(hipStreamSynchronize(c->stream));  // nf is a stack-lifetime buffer
-  dim3 grid((unsigned)((c->n + 255) / 256), (unsigned)nq), block(256);
-  hipLaunchKernelGGL(k_color_dist, grid, block, 0, c->stream, c->dL, c->dU, c->dV, c->d_num, c->cap,
-                     (uint32_t)c->n, c->d_needles, c->d_scores);
+  if ((c->cap & 1) == 0 && g_color_pk) {
+    dim3 grid((unsigned)((c->n + 511) / 512), (unsigned)nq), block(256);
+    hipLaunchKernelGGL(k_color_dist2, grid, block, 0, c->stream, c->dL, c->dU, c->dV, c->d_num, c->cap,
+                       (uint32_t)c->n, c->d_needles, c->d_scores);
+  } else {
+    dim3 grid((unsigned)((c->n + 255) / 256), (unsigned)nq), block(256);
+    hipLaunchKernelGGL(k_color_dist, grid, block, 0, c->stream, c->dL, c->dU, c->dV, c->d_num, c->cap,
+                       (uint32_t)c->n, c->d_needles, c->d_scores);
+  }
   CBH_HIP(hipGetLastError());
   return CBH_OK;
 }
@@ -317,7 +437,7 @@ void cbh_color_destroy(cbh_color* c) {
   cbh::DeviceGuard g(c->device);
   for (void* p : {(void*)c->dL, (void*)c->dU, (void*)c->dV, (void*)c->d_num, (void*)c->d_ids, (void*)c->d_needles,
                   (void*)c->d_scores, (void*)c->d_keys, (void*)c->d_keys_alt, c->d_tmp, (void*)c->d_hist,
-                  (void*)c->d_thr, (void*)c->d_ncand, (void*)c->d_valid, (void*)c->d_cand})
+                  (void*)c->d_thr, (void*)c->d_smin, (void*)c->d_ncand, (void*)c->d_valid, (void*)c->d_cand})
     if (p) (void)hipFree(p);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -437,13 +557,16 @@ int cbh_color_find_batch(cbh_color* c, const void* needle_descs, size_t nq, int 
   int rc = ensure_scratch(c, chunk, true);
   if (rc) return rc;
   if (chunk > c->topk_cap) {
-    for (void* p : {(void*)c->d_hist, (void*)c->d_thr, (void*)c->d_ncand, (void*)c->d_valid, (void*)c->d_cand})
+    for (void* p : {(void*)c->d_hist, (void*)c->d_thr, (void*)c->d_smin, (void*)c->d_ncand, (void*)c->d_valid,
+                    (void*)c->d_cand})
       if (p) (void)hipFree(p);
-    c->d_hist = c->d_thr = c->d_ncand = c->d_valid = nullptr;
+    c->d_hist = c->d_ncand = c->d_valid = nullptr;
+    c->d_thr = c->d_smin = nullptr;
     c->d_cand = nullptr;
     c->topk_cap = 0;
-    CBH_HIP(hipMalloc(&c->d_hist, chunk * kBins * 4));
+    CBH_HIP(hipMalloc(&c->d_hist, chunk * kWin * 4));
     CBH_HIP(hipMalloc(&c->d_thr, chunk * 4));
+    CBH_HIP(hipMalloc(&c->d_smin, chunk * 4));
     CBH_HIP(hipMalloc(&c->d_ncand, chunk * 4));
     CBH_HIP(hipMalloc(&c->d_valid, chunk * 4));
     CBH_HIP(hipMalloc(&c->d_cand, chunk * (size_t)kCandCap * 8));
@@ -457,17 +580,20 @@ int cbh_color_find_batch(cbh_color* c, const void* needle_descs, size_t nq, int 
     rc = run_dist(c, (const uint8_t*)needle_descs + q0 * kDescBytes, m);
     if (rc) return rc;
     // number of matches and, exactly, the k-th smallest score of every needle
-    CBH_HIP(hipMemsetAsync(c->d_hist, 0, m * kBins * 4, c->stream));
+    CBH_HIP(hipMemsetAsync(c->d_hist, 0, m * kWin * 4, c->stream));
     CBH_HIP(hipMemsetAsync(c->d_valid, 0, m * 4, c->stream));
     CBH_HIP(hipMemsetAsync(c->d_ncand, 0, m * 4, c->stream));
-    const unsigned gx = (unsigned)std::min<size_t>((c->n + 255) / 256, 1024);
+    CBH_HIP(hipMemsetAsync(c->d_smin, 0x7f, m * 4, c->stream));  // 0x7f7f7f7f: above every score
+    const unsigned gx = (unsigned)std::min<size_t>((c->n + 255) / 256, 128);
+    hipLaunchKernelGGL(k_color_min, dim3(gx, (unsigned)m), dim3(256), 0, c->stream, c->d_scores, c->d_ids,
+                       (uint32_t)c->n, c->d_smin);
     hipLaunchKernelGGL(k_color_hist, dim3(gx, (unsigned)m), dim3(256), 0, c->stream, c->d_scores, c->d_ids,
-                       (uint32_t)c->n, c->d_hist, c->d_valid);
+                       (uint32_t)c->n, c->d_smin, c->d_hist, c->d_valid);
     h_valid.resize(m);
     CBH_HIP(hipMemcpyAsync(h_valid.data(), c->d_valid, m * 4, hipMemcpyDeviceToHost, c->stream));
     if (topk) {
       hipLaunchKernelGGL(k_color_thresh, dim3((unsigned)m), dim3(256), 0, c->stream, c->d_hist, (uint32_t)k,
-                         c->d_thr);
+                         c->d_smin, c->d_thr);
       hipLaunchKernelGGL(k_color_collect, dim3(gx, (unsigned)m), dim3(256), 0, c->stream, c->d_scores, c->d_ids,
                          (uint32_t)c->n, c->d_thr, c->d_cand, c->d_ncand);
       h_ncand.resize(m);
