@@ -14,12 +14,28 @@
 
 namespace cbh {
 
+// The kernels' per-call scratch (FP4 needle tiles, blur planes, sort buffers) comes from the stream-ordered
+// allocator.  Its default pool gives freed memory back to the driver at the next synchronisation, so every call
+// would map its scratch anew (milliseconds for GB-sized blur planes): keep it cached instead.
+inline void keep_pool_memory(int dev) {
+  static std::once_flag once[16];
+  if (dev < 0 || dev >= 16) return;
+  std::call_once(once[dev], [dev] {
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+      uint64_t keep = ~0ull;
+      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+  });
+}
+
 struct DeviceGuard {
   int prev = -1;
   bool ok = false;
   explicit DeviceGuard(int dev) {
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     ok = hipSetDevice(dev) == hipSuccess;
+    if (ok) keep_pool_memory(dev);
   }
   ~DeviceGuard() {
     if (prev >= 0) (void)hipSetDevice(prev);

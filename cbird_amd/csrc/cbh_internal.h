@@ -55,6 +55,7 @@ void set_scan256_ht(int ht);
 void set_scan256_mfma(int on);  // <0 = keep; 2 = force for any size
 
 int g_hash_mfma_set(int v);  // dcthash.hip
+void set_hash_fast_any(int on);  // dcthash.hip: fast kernels for geometries other than 256x256 (default on)
 void set_color_pk(int on);   // color.hip: packed-f32 distance kernel (default on)
 
 // ---- records.hip ----------------------------------------------------------------------

@@ -514,6 +514,10 @@ int cbh_set_tuning(const char* key, int value) {
     set_scan_mfma(value);
     return CBH_OK;
   }
+  if (!strcmp(key, "hash_fast_any")) {
+    set_hash_fast_any(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "color_pk")) {
     set_color_pk(value);
     return CBH_OK;

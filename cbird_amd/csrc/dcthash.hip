@@ -723,6 +723,251 @@ __global__ __launch_bounds__(kThreads) void k_area_hash(const unsigned char* __r
   hash_from_tile(tile, sC, sZ, sT, sY, sThr, out + blockIdx.x);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fast path for every geometry other than 256x256 (k_dcthash_256) and 32x32: the same arithmetic as
+// k_blur_u8 + k_area_hash, laid out for throughput.
+//   k_blur_rows<K>  a workgroup stages a band of rows (32 output rows + the K-1 halo rows, REFLECT_101
+//                   applied while loading) of up to 2048 columns in LDS with dword loads, then every lane
+//                   owns 8 adjacent columns like in k_dcthash_256: per row a 16-byte window from LDS,
+//                   horizontal K-tap sums with v_dot4_u32_u8 against compile-time byte masks, vertical
+//                   sliding sums on packed u16 pairs in a register ring, nearest(S / K^2) by multiply-shift
+//                   (exact: see BlurK), one 8-byte store.  HBM: reads (32 + K - 1)/32 of the image, writes it once.
+//   k_area_rows     cv::resize INTER_AREA, horizontal part: one thread per (source row, output column) does
+//                   that column's float accumulation  buf += S[sx] * alpha  in table order (the order is part
+//                   of the result); integer-ratio geometries keep exact integer block sums instead.
+//   k_tile_hash     vertical part (sum = beta * buf, then += in row order; or the integer block sum and
+//                   resizeAreaFast_'s rounding), the 32x32 tile, stages 3-6.
+template <int K>
+struct BlurK;  // nearest(S / K^2) = ((S + add) * m) >> 24, exact for S <= K^2 * 255; (S + add) * m < 2^32
+template <>
+struct BlurK<3> {
+  static constexpr unsigned m = 1864136u, add = 4u;  // 9 * m - 2^24 = 8: error < 2299 * 8 / (9 * 2^24) << 1/9
+};
+template <>
+struct BlurK<5> {
+  static constexpr unsigned m = 671089u, add = 12u;  // 25 * m - 2^24 = 9
+};
+template <>
+struct BlurK<7> {
+  static constexpr unsigned m = 342393u, add = 24u;  // 49 * m - 2^24 = 41
+};
+
+constexpr int kBlurRB = 16;  // output rows per workgroup
+
+// byte mask of window dword d (bytes 4d..4d+3 of the 16-byte window whose byte 4 is the lane's pixel 0) for the
+// K-tap sum centred on the lane's pixel i
+constexpr unsigned tap_mask(int R, int i, int d) {
+  unsigned m = 0;
+  for (int b = 0; b < 4; ++b) {
+    const int byte = 4 * d + b;
+    if (byte >= 4 + i - R && byte <= 4 + i + R) m |= 1u << (8 * b);
+  }
+  return m;
+}
+template <int R, int I>
+__device__ __forceinline__ unsigned hsum_tap(const unsigned (&W)[4]) {
+  unsigned acc = 0;
+  if constexpr (tap_mask(R, I, 0) != 0) acc = udot4(W[0], tap_mask(R, I, 0), acc);
+  if constexpr (tap_mask(R, I, 1) != 0) acc = udot4(W[1], tap_mask(R, I, 1), acc);
+  if constexpr (tap_mask(R, I, 2) != 0) acc = udot4(W[2], tap_mask(R, I, 2), acc);
+  if constexpr (tap_mask(R, I, 3) != 0) acc = udot4(W[3], tap_mask(R, I, 3), acc);
+  return acc;
+}
+
+typedef unsigned u32_any_align __attribute__((aligned(1)));
+
+template <int K>
+__global__ __launch_bounds__(256) void k_blur_rows(const unsigned char* __restrict__ imgs, int w, int h,
+                                                   size_t row_stride, size_t img_stride,
+                                                   unsigned char* __restrict__ blur /* n*w*h */, int pitch) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sband[];  // (kBlurRB + K - 1) rows x pitch
+  constexpr int R = K / 2;
+  const int T = (int)blockDim.x;
+  const int cx0 = (int)blockIdx.x * T * 8;  // first column of this workgroup; LDS column c <-> image x = cx0 - 4 + c
+  const int y0 = (int)blockIdx.y * kBlurRB;
+  const unsigned char* __restrict__ img = imgs + (size_t)blockIdx.z * img_stride;
+  unsigned char* __restrict__ dst = blur + (size_t)blockIdx.z * (size_t)w * (size_t)h;
+  const int out_rows = min(kBlurRB, h - y0);
+  const int rows = out_rows + 2 * R;
+  const int ndw = pitch >> 2;  // = 2 * T + 2
+  // every thread stages the same two window dwords of every row (+ two threads the trailing pair): row-coalesced
+  // loads, no index arithmetic per element
+  // window dwords that lie inside the image: every thread stages the same dword column of every row, all of
+  // the column's loads issued before the first LDS store (the band has at most kBlurRB + K - 1 rows)
+  constexpr int kMaxRows = kBlurRB + K - 1;
+  for (int dwi = (int)threadIdx.x; dwi < ndw; dwi += T) {
+    const int x = cx0 - 4 + 4 * dwi;
+    if (x >= 0 && x + 3 < w) {
+      unsigned v[kMaxRows];
+#pragma unroll
+      for (int rr = 0; rr < kMaxRows; ++rr) {
+        int ry = y0 - R + rr;
+        ry = ry < 0 ? -ry : (ry >= h ? 2 * (h - 1) - ry : ry);  // |overshoot| <= R < h
+        ry = ry < 0 ? 0 : (ry >= h ? h - 1 : ry);                // rows past the band (rr >= rows): any valid row
+        v[rr] = *reinterpret_cast<const u32_any_align*>(img + (size_t)ry * row_stride + x);
+      }
+#pragma unroll
+      for (int rr = 0; rr < kMaxRows; ++rr)
+        if (rr < rows) *reinterpret_cast<unsigned*>(sband + (size_t)rr * pitch + 4 * dwi) = v[rr];
+    }
+  }
+  // the few window bytes across the image border (REFLECT_101): LDS columns [0, 4) when the workgroup starts at
+  // x = 0, and from the first dword that is not entirely inside up to x = w + 2, the last column a sum reads --
+  // spread over all threads as single byte loads so that no wave serialises on them
+  {
+    const int nl = cx0 == 0 ? 4 : 0;
+    const int c_right = ((w - cx0 + 4) >> 2) << 2;            // LDS column of the first uncovered dword
+    const int nr = max(0, min(pitch, w - cx0 + 7) - c_right);  // through x = w + 2
+    const int per_row = nl + nr;
+    for (int e = (int)threadIdx.x; e < per_row * rows; e += T) {
+      const int rr = e / per_row, k = e - rr * per_row;
+      const int c = k < nl ? k : c_right + (k - nl);
+      int xx = cx0 - 4 + c;
+      xx = xx < 0 ? -xx : xx;
+      xx = xx >= w ? 2 * (w - 1) - xx : xx;
+      xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+      sband[(size_t)rr * pitch + c] = img[(size_t)reflect101(y0 - R + rr, h) * row_stride + xx];
+    }
+  }
+  __syncthreads();
+  const int l = (int)threadIdx.x;
+  const int x0 = cx0 + 8 * l;
+  if (x0 >= w) return;
+  const bool full = x0 + 8 <= w;
+  unsigned ring[K][4];
+  unsigned S[4];
+#pragma unroll
+  for (int j = 0; j < K; ++j)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ring[j][c] = 0u;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) S[c] = BlurK<K>::add | (BlurK<K>::add << 16);
+  const unsigned char* __restrict__ win = sband + 8 * l;
+  for (int r0 = 0; r0 < rows; r0 += K) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int rr = r0 + j;
+      if (rr < rows) {
+        const uint2 a = *reinterpret_cast<const uint2*>(win + (size_t)rr * pitch);
+        const uint2 b = *reinterpret_cast<const uint2*>(win + (size_t)rr * pitch + 8);
+        const unsigned W[4] = {a.x, a.y, b.x, b.y};
+        const unsigned P[4] = {hsum_tap<R, 0>(W) | (hsum_tap<R, 1>(W) << 16), hsum_tap<R, 2>(W) | (hsum_tap<R, 3>(W) << 16),
+                               hsum_tap<R, 4>(W) | (hsum_tap<R, 5>(W) << 16), hsum_tap<R, 6>(W) | (hsum_tap<R, 7>(W) << 16)};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          S[c] = (S[c] - ring[j][c]) + P[c];
+          ring[j][c] = P[c];
+        }
+        if (rr >= 2 * R) {
+          unsigned q[8];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            q[2 * c] = ((S[c] & 0xffffu) * BlurK<K>::m) >> 24;
+            q[2 * c + 1] = ((S[c] >> 16) * BlurK<K>::m) >> 24;
+          }
+          unsigned char* __restrict__ o = dst + (size_t)(y0 + rr - 2 * R) * (size_t)w + x0;
+          if (full) {
+            *reinterpret_cast<u32_any_align*>(o) = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
+            *reinterpret_cast<u32_any_align*>(o + 4) = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+              if (x0 + i < w) o[i] = (unsigned char)q[i];
+          }
+        }
+      }
+    }
+  }
+}
+
+// rows[img][j][dx]: float mode (isx == 0): j runs over the y table, value = sum over the x-table entries of
+// output column dx of S[si] * alpha, accumulated in table order without contraction; integer mode: j = source
+// row, value = the exact sum of its isx pixels under column dx (stored as the int's bit pattern)
+__global__ __launch_bounds__(256) void k_area_rows(const unsigned char* __restrict__ src, int w, int h,
+                                                   const AreaTab* __restrict__ xtab, int xn,
+                                                   const int* __restrict__ xfirst,
+                                                   const AreaTab* __restrict__ ytab, int yn, int isx,
+                                                   float* __restrict__ rows, int pitch /* >= w, multiple of 4 */) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_area[];  // 8 source rows, then alpha[xn]
+  unsigned char* s_rows = s_area;
+  float* s_alpha = reinterpret_cast<float*>(s_area + 8 * (size_t)pitch);
+  const unsigned char* __restrict__ img = src + (size_t)blockIdx.y * (size_t)w * (size_t)h;
+  const int j0 = (int)blockIdx.x * 8;
+  const int nrow = min(8, yn - j0);
+  // stage the source rows of these 8 table rows with coalesced dword loads (all loads before the stores)
+  int srow[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) srow[r] = r < nrow ? (isx ? j0 + r : ytab[j0 + r].si) : 0;
+  const int ndw = w >> 2;
+  for (int d = (int)threadIdx.x; d < ndw; d += 256) {
+    unsigned v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = *reinterpret_cast<const u32_any_align*>(img + (size_t)srow[r] * w + 4 * d);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) *reinterpret_cast<unsigned*>(s_rows + (size_t)r * pitch + 4 * d) = v[r];
+  }
+  for (int e = (int)threadIdx.x; e < 8 * (w & 3); e += 256) {  // the last w % 4 columns
+    const int r = e / (w & 3), c = 4 * ndw + (e - r * (w & 3));
+    s_rows[(size_t)r * pitch + c] = img[(size_t)srow[r] * w + c];
+  }
+  if (!isx)
+    for (int i = (int)threadIdx.x; i < xn; i += 256) s_alpha[i] = xtab[i].alpha;
+  __syncthreads();
+  const int jr = (int)threadIdx.x >> 5, dx = (int)threadIdx.x & 31;
+  if (jr >= nrow) return;
+  float* __restrict__ o = rows + ((size_t)blockIdx.y * (size_t)yn + (size_t)(j0 + jr)) * 32 + dx;
+  const unsigned char* __restrict__ S = s_rows + (size_t)jr * pitch;
+  if (isx) {
+    unsigned s = 0;
+    for (int t = 0; t < isx; ++t) s += S[dx * isx + t];
+    *o = __uint_as_float(s);
+    return;
+  }
+  const int k0 = xfirst[dx], k1 = xfirst[dx + 1];
+  S += xtab[k0].si;  // si is consecutive within an output column
+  float buf = 0.f;
+  for (int k = k0; k < k1; ++k) buf += (float)S[k - k0] * s_alpha[k];
+  *o = buf;
+}
+
+__global__ __launch_bounds__(kThreads) void k_tile_hash(const float* __restrict__ rows, int yn,
+                                                        const AreaTab* __restrict__ ytab,
+                                                        const int* __restrict__ yfirst, int isx, int isy,
+                                                        const DctTables* __restrict__ tabs,
+                                                        uint64_t* __restrict__ out,
+                                                        unsigned char* __restrict__ tiles) {
+  __shared__ float sC[288], sT[288], sY[84], sThr[4];
+  __shared__ unsigned char tile[1024], sZ[64];
+  const int tid = threadIdx.x;
+  const float* __restrict__ R = rows + (size_t)blockIdx.x * (size_t)yn * 32;
+  for (int i = tid; i < 288; i += kThreads) sC[i] = tabs->C[i];
+  if (tid < 64) sZ[tid] = tabs->zz[tid];
+  for (int o = tid; o < 1024; o += kThreads) {
+    const int dy = o >> 5, dx = o & 31;
+    if (isx) {  // resizeAreaFast_: exact block sum; 2x2 -> (s+2)>>2, else rint(s * (1.f/area))
+      unsigned s = 0;
+      for (int yy = 0; yy < isy; ++yy) s += __float_as_uint(R[(size_t)(dy * isy + yy) * 32 + dx]);
+      const unsigned v = (isx == 2 && isy == 2) ? (s + 2u) >> 2
+                                                 : (unsigned)__builtin_rintf((float)s * (1.f / (float)(isx * isy)));
+      tile[o] = (unsigned char)(v > 255u ? 255u : v);
+    } else {
+      float sum = 0.f;
+      const int j0 = yfirst[dy], j1 = yfirst[dy + 1];
+      for (int j = j0; j < j1; ++j) {
+        const float t = ytab[j].alpha * R[(size_t)j * 32 + dx];
+        sum = (j == j0) ? t : sum + t;
+      }
+      const float r = __builtin_rintf(sum);
+      tile[o] = (unsigned char)(r < 0.f ? 0.f : r > 255.f ? 255.f : r);
+    }
+  }
+  __syncthreads();
+  if (tiles)
+    for (int i = tid; i < 1024; i += kThreads) tiles[(size_t)blockIdx.x * 1024 + i] = tile[i];
+  hash_from_tile(tile, sC, sZ, sT, sY, sThr, out + blockIdx.x);
+}
+
 size_t generic_smem_bytes(int w, int h, int K) {
   const int band = h / 32 + 2 * (K / 2);
   return (288 + 288 + 84 + 4) * 4 + (size_t)w * 4 + 1024 + 64 + (size_t)band * w * 3;
@@ -878,6 +1123,10 @@ int get_mfma_tables(const MfmaTables** out) {
 
 int g_hash_mfma = 0;
 int g_hash_mfma_set(int v) { return g_hash_mfma = v; }
+int g_hash_fast_any = 1;  // 1 = k_blur_rows/k_area_rows/k_tile_hash for every geometry but 256x256 and 32x32
+void set_hash_fast_any(int on) {
+  if (on >= 0) g_hash_fast_any = on;
+}
 // tuning knob "hash_mfma": 1 = use k_dcthash_256_mfma for 256x256 tiles
 
 // Host-side table construction (same closed forms as the oracle, computed independently here).
@@ -925,6 +1174,59 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
   const DctTables* tabs = nullptr;
   int rc = get_tables(&tabs);
   if (rc) return rc;
+  const bool is256 = (w == 256 && h == 256);
+  if (g_hash_fast_any && !is256 && !(w == 32 && h == 32)) {
+    // every other geometry: k_blur_rows + k_area_rows + k_tile_hash
+    const long long area_ = (long long)w * h;
+    const int K_ = area_ <= 64 * 64 ? 3 : area_ <= 128 * 128 ? 5 : 7;  // (area <= 32*32 is only 32x32 itself)
+    AreaTabsDev at;
+    if ((rc = get_area_tabs(w, h, &at))) return rc;
+    const bool integer = (w % 32 == 0 && h % 32 == 0);
+    const int isx = integer ? w / 32 : 0, isy = integer ? h / 32 : 0;
+    const int yn = integer ? h : at.yn;
+    const int T = std::min(256, ((w + 7) / 8 + 63) / 64 * 64);
+    const int pitch = T * 8 + 8;
+    const size_t smem = (size_t)(kBlurRB + K_ - 1) * (size_t)pitch;
+    const size_t per_chunk = std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)w * h));
+    const size_t mc = std::min(per_chunk, n);
+    unsigned char* d_blur = nullptr;
+    float* d_rows = nullptr;
+    CBH_HIP(hipMallocAsync((void**)&d_blur, mc * (size_t)w * h, stream));
+    CBH_HIP(hipMallocAsync((void**)&d_rows, mc * (size_t)yn * 32 * sizeof(float), stream));
+    for (size_t i0 = 0; i0 < n; i0 += per_chunk) {
+      const size_t m = std::min(per_chunk, n - i0);
+      const unsigned char* src = d_imgs + i0 * img_stride;
+      dim3 gb((unsigned)((w + T * 8 - 1) / (T * 8)), (unsigned)((h + kBlurRB - 1) / kBlurRB), (unsigned)m);
+#define CBH_BLURF(KK)                                                                                   \
+  do {                                                                                                  \
+    if (smem > 64 * 1024)                                                                               \
+      CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_rows<KK>),                       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));              \
+    hipLaunchKernelGGL(k_blur_rows<KK>, gb, dim3((unsigned)T), smem, stream, src, w, h, row_stride,     \
+                       img_stride, d_blur, pitch);                                                      \
+  } while (0)
+      switch (K_) {
+        case 3: CBH_BLURF(3); break;
+        case 5: CBH_BLURF(5); break;
+        default: CBH_BLURF(7); break;
+      }
+#undef CBH_BLURF
+      const int apitch = (w + 3) / 4 * 4 + 4;
+      const size_t asmem = 8 * (size_t)apitch + (size_t)at.xn * sizeof(float);
+      if (asmem > 64 * 1024)
+        CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_area_rows),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)asmem));
+      hipLaunchKernelGGL(k_area_rows, dim3((unsigned)((yn + 7) / 8), (unsigned)m), dim3(256), asmem, stream,
+                         d_blur, w, h, at.x, at.xn, at.xfirst, at.y, yn, isx, d_rows, apitch);
+      hipLaunchKernelGGL(k_tile_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_rows, yn, at.y, at.yfirst,
+                         isx, isy, tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
+    }
+    hipError_t e = hipGetLastError();
+    (void)hipFreeAsync(d_rows, stream);
+    (void)hipFreeAsync(d_blur, stream);
+    CBH_HIP(e);
+    return CBH_OK;
+  }
   if (w % 32 || h % 32 || w > 1024 || h > 1024) {
     // general INTER_AREA path: blur to scratch, then weighted resample + hash
     const long long area_ = (long long)w * h;

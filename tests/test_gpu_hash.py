@@ -149,3 +149,39 @@ def test_mfma_variant_is_bit_identical(gpu, orc):
     for i in range(0, len(imgs), 7):
         assert (t[i] == orc.tile32(imgs[i])).all()
     assert (gpu.dct_hash64_batch(imgs) == want).all()
+
+
+def test_hash_random_geometries_and_strides(gpu, orc):
+    """Random widths/heights (every blur kernel size, widths around the 8-pixel lane groups and the 2048-column
+    workgroups, integer and fractional resize ratios) and padded row/image strides, on the fast general
+    kernels AND the original general kernels ("hash_fast_any" 1 / 0): both bit-exact against the oracle,
+    hashes and 32x32 tiles."""
+    from cbird_amd import _lib
+    import torch
+
+    L = _lib.lib()
+    rng = np.random.default_rng(4321)
+    geos = [(40, 36), (63, 65), (64, 96), (127, 129), (130, 128), (255, 257), (264, 100), (1000, 37), (2047, 33),
+            (2049, 40), (2056, 34), (4100, 64), (96, 4097), (2304, 1728)]
+    geos += [(int(rng.integers(32, 700)), int(rng.integers(32, 700))) for _ in range(10)]
+    try:
+        for (w, h) in geos:
+            n = 3
+            pad_x, pad_img = int(rng.integers(0, 9)), int(rng.integers(0, 50))
+            buf = rng.integers(0, 256, (n, h * (w + pad_x) + pad_img), dtype=np.uint8)
+            imgs = np.stack([buf[i, : h * (w + pad_x)].reshape(h, w + pad_x)[:, :w] for i in range(n)])
+            want = orc.dcthash64_batch(np.ascontiguousarray(imgs))
+            d = torch.from_numpy(buf).cuda()
+            for fast in (1, 0):
+                L.cbh_set_tuning(b"hash_fast_any", fast)
+                out = torch.zeros(n, dtype=torch.int64, device="cuda")
+                tiles = torch.zeros((n, 32, 32), dtype=torch.uint8, device="cuda")
+                _lib.check(L.cbh_dcthash_tiles_dev(d.data_ptr(), n, w, h, w + pad_x, buf.shape[1], out.data_ptr(),
+                                                   tiles.data_ptr(), 0, None), "tiles")
+                got = out.cpu().numpy().view(np.uint64)
+                t = tiles.cpu().numpy()
+                for i in range(n):
+                    assert (t[i] == orc.tile32(np.ascontiguousarray(imgs[i]))).all(), (w, h, fast, i)
+                assert (got == want).all(), (w, h, fast)
+    finally:
+        L.cbh_set_tuning(b"hash_fast_any", 1)

@@ -1,0 +1,16 @@
+"""dctHash64 throughput by image geometry (development aid): which kernel path each size takes and its GB/s"""
+import ctypes as C, sys
+import torch
+sys.path.insert(0, ".")
+from cbird_amd import _lib
+L = _lib.lib()
+dev = torch.device("cuda", 0)
+ms = C.c_float(0)
+for (w, h) in ((256, 256), (128, 128), (512, 512), (1024, 1024), (320, 240), (640, 480), (1024, 768), (300, 200), (1920, 1080)):
+    n = max(64, min(20000, int(2e9 // (w * h))))
+    imgs = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device=dev)
+    out = torch.empty(n, dtype=torch.int64, device=dev)
+    rc = L.cbh_time_dcthash_dev(imgs.data_ptr(), n, w, h, w, w * h, out.data_ptr(), 0, 2, C.byref(ms))
+    rc = L.cbh_time_dcthash_dev(imgs.data_ptr(), n, w, h, w, w * h, out.data_ptr(), 0, 3, C.byref(ms))
+    print(f"{w}x{h}: rc {rc} n {n} {ms.value:8.3f} ms {n / ms.value * 1e3:10.3e} img/s {n * w * h / ms.value * 1e-6:8.1f} GB/s", flush=True)
+    del imgs
