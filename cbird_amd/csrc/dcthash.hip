@@ -1174,7 +1174,9 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
   const DctTables* tabs = nullptr;
   int rc = get_tables(&tabs);
   if (rc) return rc;
-  const bool is256 = (w == 256 && h == 256);
+  // k_dcthash_256 needs 8-byte aligned rows; anything else of that size takes the general kernels
+  const bool is256 = w == 256 && h == 256 && ((uintptr_t)d_imgs % 8) == 0 && row_stride % 8 == 0 &&
+                     img_stride % 8 == 0 && row_stride * 256 < (1u << 24) && img_stride < (1u << 28);
   if (g_hash_fast_any && !is256 && !(w == 32 && h == 32)) {
     // every other geometry: k_blur_rows + k_area_rows + k_tile_hash
     const long long area_ = (long long)w * h;
