@@ -10,7 +10,8 @@ Workload = configs[1] (configs[2] when N > 1, same job sharded): 1M synthetic pr
     build : dctHash64 of every image (k_dcthash_256) -> u64[1M]; all-gather of the hashes when
             N > 1; (re)load of this rank's DctHashIndex shard
     find  : all-pairs DctHashIndex find (1M needles x 1M slots) for every dht in 1..8
-            (k_hamm64_mfma + record exchange/sort/select, maxMatches-style cut at k=8)
+            (k_hamm64_mfma + record exchange/sort/select, maxMatches-style cut at k=8; the
+            post-processing of one threshold overlaps the scan of the next)
 value = 64-bit Hamming comparisons/s over the whole step (8 x 10^12 comparisons per step; the
 build time is inside the denominator); images hashed/s is reported next to it.
 Prints ONE JSON line on rank 0.
@@ -149,14 +150,11 @@ def main():
         sh.load_shard(h_local, ids)
         if record:
             hash_ev.append((e0, e1))
-        for dht in dhts:
-            f0, f1 = ev(), ev()
-            f0.record()
-            res = sh.similar(allh, dht, args.topk, scan_events=scan_ev if record else None)
-            f1.record()
-            if record:
-                find_ev.append((dht, f0, f1, int(sh.last_exchange_records)))
-            state[dht] = res
+        # the whole sweep, software-pipelined: the scan of threshold i+1 runs while the records of threshold i
+        # are exchanged (N > 1), sorted and cut (cbird_amd.dist.ShardedDctHashIndex.similar_sweep)
+        res = sh.similar_sweep(allh, dhts, args.topk, scan_events=scan_ev if record else None,
+                               find_events=find_ev if record else None)
+        state.update(res)
         state["hashes"] = allh
 
     def fence():
@@ -191,7 +189,9 @@ def main():
     for dht in dhts:
         sm = sum(scans[dht]) / len(scans[dht])
         fm = sum(x for x, _ in finds[dht]) / len(finds[dht])
-        sweep.append({"dht": dht, "scan_kernel_ms": round(sm, 3), "find_ms": round(fm, 3),
+        # find_latency_ms: scan start -> cut results ready; the sweep is pipelined, so it spans the next
+        # threshold's scan as well and is not additive
+        sweep.append({"dht": dht, "scan_kernel_ms": round(sm, 3), "find_latency_ms": round(fm, 3),
                       "scan_cmp_per_s": shard_n * n / sm * 1e3, "matches": finds[dht][0][1]})
     # the matrix-core scan has two shapes: k_hamm64_mfma3 (64-bit dot products; thresholds > PRE_MAX_DHT) is
     # the dominant kernel by time and the one the roofline object prices; PRE (low-word prefilter, thresholds

@@ -42,6 +42,21 @@ class HipOps:
     def empty(self, n, dtype):
         return torch.empty(n, dtype=dtype, device=self.torch_device)
 
+    # -- streams (similar_sweep overlaps the scan of one threshold with the post-processing of the previous) ----
+    def side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.torch_device)
+        return self._side
+
+    def current_stream(self):
+        return torch.cuda.current_stream(self.torch_device)
+
+    def stream_ctx(self, stream):
+        return torch.cuda.stream(stream)
+
+    def new_event(self):
+        return torch.cuda.Event(enable_timing=True)
+
     def hash_images(self, imgs: torch.Tensor) -> torch.Tensor:
         """imgs: u8 [n, h, w] on this device -> int64 [n] (u64 bit patterns)"""
         n, h, w = imgs.shape
@@ -128,6 +143,30 @@ class ShardedDctHashIndex:
             self._total = self.ops.empty(1, torch.int64)
         return self._rec, self._total
 
+    def _exchange_and_cut(self, rec, total, nq: int, max_per_query: int):
+        """counts -> (all-gather of the record lists) -> sort -> first max_per_query per needle.  Returns None when a
+        rank's records did not fit its buffer (after growing self.record_capacity for the rescan)."""
+        if self.world > 1:  # sizes first: one small all-gather gives max and sum
+            counts = self.ops.empty(self.world, torch.int64)
+            self._all_gather(counts, total)
+            counts_h = counts.tolist()
+            n_local, n_max, n_total = counts_h[self.rank], max(counts_h), sum(counts_h)
+        else:
+            n_local = n_max = n_total = int(total.item())
+        if n_max > rec.numel():
+            self.record_capacity = int(n_max * 1.25) + 1024  # same decision on every rank
+            return None
+        if self.world == 1:
+            merged = rec
+        else:
+            rec[n_local:n_max] = nq << 39  # pad = a record of needle index nq: sorts last
+            merged = self.ops.empty(n_max * self.world, torch.int64)
+            self._all_gather(merged, rec[:n_max])
+        self.last_exchange_records = n_total
+        # pads sort to the end; only the first n_total records are real
+        self.ops.sort_records(merged, merged.numel() if self.world > 1 else n_total, nq + 1)
+        return self.ops.select(merged, n_total, nq, max_per_query)
+
     def similar(self, queries: torch.Tensor, thresh: int, max_per_query: int, scan_events=None):
         """All needles against the union of all shards.  Returns (ids[nq,k] i32 view of u32,
         scores[nq,k] i32, counts[nq] i32) -- identical on every rank."""
@@ -145,26 +184,73 @@ class ShardedDctHashIndex:
             if scan_events is not None:
                 e1.record()
                 scan_events.append((thresh, e0, e1))
-            if self.world > 1:  # sizes first: one small all-gather gives max and sum
-                counts = self.ops.empty(self.world, torch.int64)
-                self._all_gather(counts, total)
-                counts_h = counts.tolist()
-                n_local, n_max, n_total = counts_h[self.rank], max(counts_h), sum(counts_h)
-            else:
-                n_local = n_max = n_total = int(total.item())
-            if n_max <= self.record_capacity:
-                break
-            self.record_capacity = int(n_max * 1.25) + 1024  # same decision on every rank
-        if self.world == 1:
-            merged = rec
-        else:
-            rec[n_local:n_max] = nq << 39  # pad = a record of needle index nq: sorts last
-            merged = self.ops.empty(n_max * self.world, torch.int64)
-            self._all_gather(merged, rec[:n_max])
-        self.last_exchange_records = n_total
-        # pads sort to the end; only the first n_total records are real
-        self.ops.sort_records(merged, merged.numel() if self.world > 1 else n_total, nq + 1)
-        return self.ops.select(merged, n_total, nq, max_per_query)
+            res = self._exchange_and_cut(rec, total, nq, max_per_query)
+            if res is not None:
+                return res
+
+    def similar_sweep(self, queries: torch.Tensor, thresholds, max_per_query: int, scan_events=None,
+                      find_events=None):
+        """similar() for several thresholds, software-pipelined: while the records of threshold i are exchanged,
+        sorted and cut on a side stream, the scan of threshold i+1 already runs on the main stream (two record
+        buffers).  Returns {thresh: (ids, scores, counts)}, identical to calling similar() per threshold."""
+        nq = queries.numel()
+        if nq >= (1 << 25):
+            raise ValueError("at most 2^25-1 needles per call")
+        ops = self.ops
+        if not hasattr(ops, "side_stream"):  # device work injected by a test: no streams, plain loop
+            return {t: self.similar(queries, t, max_per_query, scan_events) for t in thresholds}
+        main, side = ops.current_stream(), ops.side_stream()
+        if getattr(self, "_sweep_bufs", None) is None or self._sweep_bufs[0][0].numel() < self.record_capacity:
+            self._sweep_bufs = [(ops.empty(self.record_capacity, torch.int64), ops.empty(1, torch.int64))
+                                for _ in range(2)]
+        side.wait_stream(main)  # queries (and the index) are ready
+        results, pending, reuse = {}, None, [None, None]
+
+        def finish(p):
+            thr, rec, total, ev_scan, f0 = p
+            with ops.stream_ctx(side):
+                side.wait_event(ev_scan)
+                res = self._exchange_and_cut(rec, total, nq, max_per_query)
+                done = ops.new_event()
+                done.record(side)
+            if res is None:  # did not fit: drain, grow (record_capacity was raised) and redo this one plainly
+                main.wait_stream(side)
+                self._sweep_bufs = None
+                res = self.similar(queries, thr, max_per_query)
+                done = ops.new_event()
+                done.record(main)
+            elif find_events is not None:
+                find_events.append((thr, f0, done, int(self.last_exchange_records)))
+            return res, done
+
+        for i, thr in enumerate(thresholds):
+            if self._sweep_bufs is None:  # a rescan replaced the buffers
+                self._sweep_bufs = [(ops.empty(self.record_capacity, torch.int64), ops.empty(1, torch.int64))
+                                    for _ in range(2)]
+                reuse = [None, None]
+            rec, total = self._sweep_bufs[i % 2]
+            if reuse[i % 2] is not None:
+                main.wait_event(reuse[i % 2])  # the post-processing that read this buffer has finished
+            f0 = ops.new_event()
+            f0.record(main)
+            total.zero_()
+            if scan_events is not None:
+                e0, e1 = ops.new_event(), ops.new_event()
+                e0.record(main)
+            ops.scan(queries, thr, rec, total)
+            if scan_events is not None:
+                e1.record(main)
+                scan_events.append((thr, e0, e1))
+            ev_scan = ops.new_event()
+            ev_scan.record(main)
+            if pending is not None:
+                j = pending[0]
+                results[pending[1][0]], reuse[j] = finish(pending[1])
+            pending = (i % 2, (thr, rec, total, ev_scan, f0))
+        if pending is not None:
+            results[pending[1][0]], _ = finish(pending[1])
+        main.wait_stream(side)  # results were produced on the side stream
+        return results
 
 
 class NeedleParallel:

@@ -33,6 +33,17 @@ def _worker(rank, world, port, n, q_out):
         for dht in (1, 2, 7):
             i, s, c = sh.similar(allh, dht, 4)
             out[dht] = (i.cpu().numpy().copy(), s.cpu().numpy().copy(), c.cpu().numpy().copy())
+        # the pipelined sweep (scan of threshold i+1 overlapping the exchange/sort/cut of threshold i) must give
+        # the same answers -- including thresholds whose records overflow the tiny buffer and force a rescan
+        sweep = sh.similar_sweep(allh, (1, 2, 7, 9, 3), 4)
+        torch.cuda.synchronize()
+        for dht in (1, 2, 7):
+            i, s, c = sweep[dht]
+            assert (i.cpu().numpy() == out[dht][0]).all() and (s.cpu().numpy() == out[dht][1]).all()
+            assert (c.cpu().numpy() == out[dht][2]).all()
+        for dht in (9, 3):
+            i, s, c = sh.similar(allh, dht, 4)
+            assert (sweep[dht][0] == i).all() and (sweep[dht][1] == s).all() and (sweep[dht][2] == c).all()
         q_out.put((rank, allh.cpu().numpy().copy(), out))
     finally:
         dist.destroy_process_group()
@@ -127,3 +138,25 @@ def test_video_needle_parallel_two_ranks(gpu):
     assert sum(len(r) for r in want) > 5
     for rank, res in got:
         assert res == want
+
+
+def test_sweep_single_rank_equals_per_threshold(gpu, orc):
+    """similar_sweep on one rank (no process group): pipelined result == oracle for every threshold, with a record
+    buffer small enough that some thresholds overflow and are redone"""
+    from cbird_amd import synth
+    from cbird_amd.dist import HipOps, ShardedDctHashIndex
+
+    n = 5000
+    h, ids = synth.make_hashes(n, seed=3, planted_frac=0.4)
+    dev = torch.device("cuda", 0)
+    sh = ShardedDctHashIndex(HipOps(0), record_capacity=1 << 13)
+    dh = torch.from_numpy(h.view(np.int64)).to(dev)
+    sh.load_shard(dh, torch.from_numpy(ids.view(np.int32)).to(dev))
+    ths = (1, 4, 5, 8, 12, 2)
+    res = sh.similar_sweep(dh, ths, 6)
+    torch.cuda.synchronize()
+    for t in ths:
+        wi, ws, wc = orc.find64_batch(h, ids, h, t, 6)
+        gi, gs, gc = res[t]
+        assert (gc.cpu().numpy() == wc.astype(np.int32)).all(), t
+        assert (gi.cpu().numpy().view(np.uint32) == wi).all() and (gs.cpu().numpy() == ws).all(), t
