@@ -67,10 +67,9 @@ class HipOps:
         return out
 
     def load_shard(self, hashes: torch.Tensor, ids: torch.Tensor) -> None:
-        torch.cuda.current_stream(self.torch_device).synchronize()
-        self.index = DctHashIndex(self.device)
+        """(re)load this rank's shard into the same index object (no reallocation when it fits)"""
         _lib.check(self.L.cbh_idx64_load_dev(self.index.handle, hashes.data_ptr(), ids.data_ptr(),
-                                             hashes.numel(), None), "load_dev")
+                                             hashes.numel(), self._stream()), "load_dev")
 
     def scan(self, queries: torch.Tensor, thresh: int, rec: torch.Tensor, total: torch.Tensor) -> None:
         _lib.check(self.L.cbh_idx64_scan_dev(self.index.handle, queries.data_ptr(), queries.numel(),
