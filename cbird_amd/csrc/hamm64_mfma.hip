@@ -24,9 +24,11 @@
 //   * both halves are positive normal f16 bit patterns, so v_pk_maximum3_f16 (new on gfx950) takes
 //     the per-half maximum of three registers at once: 4 ops per MFMA instead of 8.
 //
-// Two variants (both exact):
-//   FULL  K = the 64 bits of one hash; tile B is a second MFMA accumulated onto tile A's.
-//         hi16 = 0x4B40 - distB, lo16 = 0x4080 - 2*distA.  Hits are real matches.
+// Three variants (all exact), chosen by the launcher:
+//   FULL3 (k_hamm64_mfma3, thresholds kPreMaxThresh+1 .. 64) three needle tiles per accumulator, detection by
+//         OR of flag bits -- described at the kernel below; the default for most thresholds.
+//   FULL2 (thresh 65, or FULL3 switched off) K = the 64 bits of one hash; tile B is a second MFMA accumulated
+//         onto tile A's.  hi16 = 0x4B40 - distB, lo16 = 0x4080 - 2*distA.  Hits are real matches.
 //   PRE   (thresh <= kPreMaxThresh) low-word prefilter at twice the pair rate: the block scale is
 //         per lane and K block, so lanes 0-31 (K 0..31) carry the LOW words of needle tile A with
 //         scale 1 and lanes 32-63 (K 32..63) the LOW words of tile B with scale 2^15, against the
