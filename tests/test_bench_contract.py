@@ -1,0 +1,35 @@
+"""bench.py prints ONE JSON line with the contract's keys (small run on the GPU box)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_line_has_the_contract_keys(gpu):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--images", "40000", "--steps", "2",
+                          "--warmup", "1", "--cpu-seconds", "2"], capture_output=True, text=True, timeout=600,
+                         cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 40000.0 ** 2 * 8 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1
+    assert c["find_agrees_with_gpu"] is True and c["hash_agrees_with_gpu"] is True
