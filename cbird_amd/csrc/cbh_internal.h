@@ -52,6 +52,7 @@ int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, siz
 bool scan256_mfma_wanted(size_t n, size_t nq, int thresh);
 void set_scan256_g(int g);
 void set_scan256_ht(int ht);
+void set_scan256_pre(int on);  // first-128-bit prefilter variant (default on)
 void set_scan256_mfma(int on);  // <0 = keep; 2 = force for any size
 
 int g_hash_mfma_set(int v);  // dcthash.hip

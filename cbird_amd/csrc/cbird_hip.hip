@@ -522,6 +522,10 @@ int cbh_set_tuning(const char* key, int value) {
     set_color_pk(value);
     return CBH_OK;
   }
+  if (!strcmp(key, "scan256_pre")) {
+    set_scan256_pre(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "scan256_ht")) {
     set_scan256_ht(value);
     return CBH_OK;

@@ -31,11 +31,15 @@ __global__ __launch_bounds__(256) void k_expand_needles256(const uint32_t* __res
   qx[i] = fp4_expand32(j < nq ? q[(size_t)j * 8u + word] : 0u);
 }
 
-template <int HT, int G>
+// KCH = 4: all 256 bits on the matrix cores.  KCH = 2: the first 128 bits only -- a sound lower bound of the
+// distance (like k_hamm256_scan's first-half filter) at half the MFMA work; candidates under the threshold on
+// 128 bits get their second halves evaluated from the raw rows.  For thresh <= kPre128MaxThresh the bound
+// rejects all but ~10^-5 of the pairs of unrelated descriptors (128 fair bits: mean 64, sigma 5.7).
+template <int HT, int G, int KCH>
 __global__ __launch_bounds__(kThreads) void k_hamm256_mfma(
     const uint32_t* __restrict__ rows /* 8 words per row */, uint32_t n, const uint4* __restrict__ qx,
-    uint32_t nq, uint32_t n_tiles, uint32_t tiles_per_chunk, uint32_t thresh,
-    unsigned long long* __restrict__ rec, unsigned long long cap,
+    const uint32_t* __restrict__ qraw /* 8 words per needle */, uint32_t nq, uint32_t n_tiles,
+    uint32_t tiles_per_chunk, uint32_t thresh, unsigned long long* __restrict__ rec, unsigned long long cap,
     unsigned long long* __restrict__ total) {
   __shared__ float s_c[kWaves][G * 16][64];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -43,12 +47,12 @@ __global__ __launch_bounds__(kThreads) void k_hamm256_mfma(
   const uint32_t tile0 = (blockIdx.x * kWaves + wave) * HT;
   if (tile0 * 32u >= n) return;
 
-  v8i a[HT][4];
+  v8i a[HT][KCH];
 #pragma unroll
   for (int t = 0; t < HT; ++t) {
     const uint32_t row = (tile0 + t) * 32u + r;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < KCH; ++k) {
       const uint32_t w = row < n ? rows[(size_t)row * 8u + 2u * k + half] : 0u;
       a[t][k] = fp4_operand(fp4_expand32(w));
     }
@@ -56,12 +60,13 @@ __global__ __launch_bounds__(kThreads) void k_hamm256_mfma(
   const uint32_t q0 = blockIdx.y * tiles_per_chunk;
   const uint32_t q1 = min(n_tiles, q0 + tiles_per_chunk);
   const uint4* __restrict__ qp = qx + (size_t)q0 * 256u + half * 32u + r;  // + chunk*64 per K chunk
-  const float dot_thr = 256.0f - 2.0f * (float)(thresh - 1u);  // dot >= dot_thr  <=>  dist < thresh
+  // dot over 64*KCH signs >= dot_thr  <=>  distance on those bits < thresh
+  const float dot_thr = (float)(64 * KCH) - 2.0f * (float)(thresh - 1u);
 
-  auto step = [&](const uint32_t qt, const uint4 (&nb)[4]) {
-    v8i b[4];
+  auto step = [&](const uint32_t qt, const uint4 (&nb)[KCH]) {
+    v8i b[KCH];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) b[k] = fp4_operand(nb[k]);
+    for (int k = 0; k < KCH; ++k) b[k] = fp4_operand(nb[k]);
 #pragma unroll
     for (int t0 = 0; t0 < HT; t0 += G) {
       v16f c[G];
@@ -70,7 +75,7 @@ __global__ __launch_bounds__(kThreads) void k_hamm256_mfma(
 #pragma unroll
         for (int g = 0; g < 16; ++g) c[t][g] = 0.0f;
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+      for (int k = 0; k < KCH; ++k)
 #pragma unroll
         for (int t = 0; t < G; ++t)
           c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t0 + t][k], b[k], c[t], 4, 4, 0,
@@ -98,10 +103,16 @@ __global__ __launch_bounds__(kThreads) void k_hamm256_mfma(
             const uint32_t row = (tile0 + t0 + (e >> 4)) * 32u + (g & 3u) + 8u * (g >> 2) + 4u * half;
             const uint32_t qi = qt * 32u + r;
             if (row < n && qi < nq) {
-              const uint32_t d = (uint32_t)(256 - (int)dot) >> 1;
-              const unsigned long long slot = atomicAdd(total, 1ull);
-              if (slot < cap)
-                rec[slot] = ((unsigned long long)qi << 41) | ((unsigned long long)d << 32) | row;
+              uint32_t d = (uint32_t)(64 * KCH - (int)dot) >> 1;
+              if (KCH < 4) {  // the remaining 64-bit chunks from the raw data
+#pragma unroll
+                for (int wd = 2 * KCH; wd < 8; ++wd) d += __popc(rows[(size_t)row * 8u + wd] ^ qraw[(size_t)qi * 8u + wd]);
+              }
+              if (d < thresh) {
+                const unsigned long long slot = atomicAdd(total, 1ull);
+                if (slot < cap)
+                  rec[slot] = ((unsigned long long)qi << 41) | ((unsigned long long)d << 32) | row;
+              }
             }
           }
         }
@@ -110,18 +121,18 @@ __global__ __launch_bounds__(kThreads) void k_hamm256_mfma(
   };
 
   // two needle tiles per trip, explicit double buffers
-  uint4 x[4], y[4];
+  uint4 x[KCH], y[KCH];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) x[k] = qp[k * 64];
+  for (int k = 0; k < KCH; ++k) x[k] = qp[k * 64];
   uint32_t qt = q0;
   for (; qt + 1 < q1; qt += 2) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) y[k] = qp[256 + k * 64];
+    for (int k = 0; k < KCH; ++k) y[k] = qp[256 + k * 64];
     step(qt, x);
     qp += 512;
     if (qt + 2 < q1) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) x[k] = qp[k * 64];
+      for (int k = 0; k < KCH; ++k) x[k] = qp[k * 64];
     }
     step(qt + 1, y);
   }
@@ -129,6 +140,9 @@ __global__ __launch_bounds__(kThreads) void k_hamm256_mfma(
 }
 
 int g_scan256_mfma = 1;
+int g_scan256_pre = 1;     // first-128-bit prefilter variant for thresh <= kPre128MaxThresh
+int g_scan256_pre_ht = 6;   // its row tiles per wave (6, 8, 12)
+constexpr int kPre128MaxThresh = 40;
 int g_scan256_ht = 6;  // row tiles per wave (2, 4, 6)
 int g_scan256_g = 3;   // row tiles per accumulator group = independent 4-MFMA chains in flight
 
@@ -142,6 +156,10 @@ void set_scan256_g(int g) {
 }
 void set_scan256_ht(int ht) {
   if (ht == 2 || ht == 4 || ht == 6) g_scan256_ht = ht;
+  if (ht == 106 || ht == 108 || ht == 112) g_scan256_pre_ht = ht - 100;  // prefilter variant: 106 / 108 / 112
+}
+void set_scan256_pre(int on) {
+  if (on >= 0) g_scan256_pre = on;
 }
 
 bool scan256_mfma_wanted(size_t n, size_t nq, int thresh) {
@@ -161,7 +179,9 @@ int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, siz
   CBH_HIP(hipMallocAsync((void**)&qx, (size_t)nq_pad * 128u, stream));
   hipLaunchKernelGGL(k_expand_needles256, dim3((8u * nq_pad + 255u) / 256u), dim3(256), 0, stream,
                      reinterpret_cast<const uint32_t*>(d_q), (uint32_t)nq, nq_pad, qx);
-  const uint32_t rows_per_wg = 32u * (uint32_t)g_scan256_ht * kWaves;
+  const bool pre128_ = g_scan256_pre && thresh <= kPre128MaxThresh;
+  const int ht = pre128_ ? g_scan256_pre_ht : (g_scan256_ht == 12 || g_scan256_ht == 8 ? 6 : g_scan256_ht);
+  const uint32_t rows_per_wg = 32u * (uint32_t)ht * kWaves;
   const uint32_t wgs = (uint32_t)((n + rows_per_wg - 1) / rows_per_wg);
   uint32_t tpc = 128;  // needle tiles per chunk (4096 descriptors)
   while (tpc > 4 && (uint64_t)wgs * ((n_tiles + tpc - 1) / tpc) < 8192) tpc >>= 1;
@@ -170,16 +190,20 @@ int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, siz
     tpc = (n_tiles + 65534) / 65535;
     chunks = (n_tiles + tpc - 1) / tpc;
   }
-#define CBH_256(HT, GG)                                                                           \
-  hipLaunchKernelGGL((k_hamm256_mfma<HT, GG>), dim3(wgs, chunks), dim3(kThreads), 0, stream,      \
-                     reinterpret_cast<const uint32_t*>(d_rows), (uint32_t)n, qx, (uint32_t)nq, n_tiles, \
-                     tpc, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total)
-  if (g_scan256_ht == 2) {
-    if (g_scan256_g == 1) CBH_256(2, 1); else CBH_256(2, 2);
-  } else if (g_scan256_ht == 6) {
-    if (g_scan256_g == 1) CBH_256(6, 1); else if (g_scan256_g == 2) CBH_256(6, 2); else CBH_256(6, 3);
+  const bool pre128 = g_scan256_pre && thresh <= kPre128MaxThresh;
+#define CBH_256(HT, GG, KC)                                                                       \
+  hipLaunchKernelGGL((k_hamm256_mfma<HT, GG, KC>), dim3(wgs, chunks), dim3(kThreads), 0, stream,  \
+                     reinterpret_cast<const uint32_t*>(d_rows), (uint32_t)n, qx,                  \
+                     reinterpret_cast<const uint32_t*>(d_q), (uint32_t)nq, n_tiles, tpc,          \
+                     (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total)
+  if (pre128) {
+    if (ht == 12) CBH_256(12, 3, 2); else if (ht == 8) CBH_256(8, 2, 2); else CBH_256(6, 3, 2);
+  } else if (ht == 2) {
+    if (g_scan256_g == 1) CBH_256(2, 1, 4); else CBH_256(2, 2, 4);
+  } else if (ht == 6) {
+    if (g_scan256_g == 1) CBH_256(6, 1, 4); else if (g_scan256_g == 2) CBH_256(6, 2, 4); else CBH_256(6, 3, 4);
   } else {
-    if (g_scan256_g == 4) CBH_256(4, 4); else if (g_scan256_g == 1) CBH_256(4, 1); else CBH_256(4, 2);
+    if (g_scan256_g == 4) CBH_256(4, 4, 4); else if (g_scan256_g == 1) CBH_256(4, 1, 4); else CBH_256(4, 2, 4);
   }
 #undef CBH_256
   hipError_t e = hipGetLastError();
