@@ -162,7 +162,7 @@ def test_hash_random_geometries_and_strides(gpu, orc):
     L = _lib.lib()
     rng = np.random.default_rng(4321)
     geos = [(256, 256), (40, 36), (63, 65), (64, 96), (127, 129), (130, 128), (255, 257), (264, 100), (1000, 37), (2047, 33),
-            (2049, 40), (2056, 34), (4100, 64), (96, 4097), (2304, 1728)]
+            (2049, 40), (2056, 34), (4100, 64), (96, 4097), (2304, 1728), (8190, 33), (33, 8192)]
     geos += [(int(rng.integers(32, 700)), int(rng.integers(32, 700))) for _ in range(10)]
     try:
         for (w, h) in geos:
@@ -174,7 +174,7 @@ def test_hash_random_geometries_and_strides(gpu, orc):
             imgs = np.stack([buf[i, : h * (w + pad_x)].reshape(h, w + pad_x)[:, :w] for i in range(n)])
             want = orc.dcthash64_batch(np.ascontiguousarray(imgs))
             d = torch.from_numpy(buf).cuda()
-            for fast in (1, 0):
+            for fast in ((1, 0) if w <= 7000 else (1,)):  # the first general kernels stage 7 full rows in LDS: w <= ~7800
                 L.cbh_set_tuning(b"hash_fast_any", fast)
                 out = torch.zeros(n, dtype=torch.int64, device="cuda")
                 tiles = torch.zeros((n, 32, 32), dtype=torch.uint8, device="cuda")
