@@ -780,14 +780,22 @@ typedef unsigned u32_any_align __attribute__((aligned(1)));
 template <int K>
 __global__ __launch_bounds__(256) void k_blur_rows(const unsigned char* __restrict__ imgs, int w, int h,
                                                    size_t row_stride, size_t img_stride,
-                                                   unsigned char* __restrict__ blur /* n*w*h */, int pitch) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char sband[];  // (kBlurRB + K - 1) rows x pitch
+                                                   unsigned char* __restrict__ blur /* n*w*h */, int pitch,
+                                                   int T /* lanes per image */, int ipb /* images per workgroup */,
+                                                   unsigned n_imgs) {
+  // LDS: one (kBlurRB + K - 1) x pitch band per image slot.  Images up to 2048 columns wide per workgroup use the
+  // whole workgroup (T = blockDim.x, one slot); narrow images share it: ipb images side by side, so
+  // that a 128-pixel-wide image does not leave 3/4 of a wave idle.
+  extern __shared__ __attribute__((aligned(16))) unsigned char sband_all[];
   constexpr int R = K / 2;
-  const int T = (int)blockDim.x;
+  const int slot = (int)threadIdx.x / T, tl = (int)threadIdx.x - slot * T;
+  const unsigned img_i = blockIdx.z * (unsigned)ipb + (unsigned)slot;
+  const bool live = slot < ipb && img_i < n_imgs;
+  unsigned char* __restrict__ sband = sband_all + (size_t)(slot < ipb ? slot : 0) * (size_t)(kBlurRB + K - 1) * (size_t)pitch;
   const int cx0 = (int)blockIdx.x * T * 8;  // first column of this workgroup; LDS column c <-> image x = cx0 - 4 + c
   const int y0 = (int)blockIdx.y * kBlurRB;
-  const unsigned char* __restrict__ img = imgs + (size_t)blockIdx.z * img_stride;
-  unsigned char* __restrict__ dst = blur + (size_t)blockIdx.z * (size_t)w * (size_t)h;
+  const unsigned char* __restrict__ img = imgs + (size_t)(live ? img_i : 0u) * img_stride;
+  unsigned char* __restrict__ dst = blur + (size_t)(live ? img_i : 0u) * (size_t)w * (size_t)h;
   const int out_rows = min(kBlurRB, h - y0);
   const int rows = out_rows + 2 * R;
   const int ndw = pitch >> 2;  // = 2 * T + 2
@@ -796,7 +804,7 @@ __global__ __launch_bounds__(256) void k_blur_rows(const unsigned char* __restri
   // window dwords that lie inside the image: every thread stages the same dword column of every row, all of
   // the column's loads issued before the first LDS store (the band has at most kBlurRB + K - 1 rows)
   constexpr int kMaxRows = kBlurRB + K - 1;
-  for (int dwi = (int)threadIdx.x; dwi < ndw; dwi += T) {
+  for (int dwi = tl; live && dwi < ndw; dwi += T) {
     const int x = cx0 - 4 + 4 * dwi;
     if (x >= 0 && x + 3 < w) {
       unsigned v[kMaxRows];
@@ -820,7 +828,7 @@ __global__ __launch_bounds__(256) void k_blur_rows(const unsigned char* __restri
     const int c_right = ((w - cx0 + 4) >> 2) << 2;            // LDS column of the first uncovered dword
     const int nr = max(0, min(pitch, w - cx0 + 7) - c_right);  // through x = w + 2
     const int per_row = nl + nr;
-    for (int e = (int)threadIdx.x; e < per_row * rows; e += T) {
+    for (int e = tl; live && e < per_row * rows; e += T) {
       const int rr = e / per_row, k = e - rr * per_row;
       const int c = k < nl ? k : c_right + (k - nl);
       int xx = cx0 - 4 + c;
@@ -831,9 +839,9 @@ __global__ __launch_bounds__(256) void k_blur_rows(const unsigned char* __restri
     }
   }
   __syncthreads();
-  const int l = (int)threadIdx.x;
+  const int l = tl;
   const int x0 = cx0 + 8 * l;
-  if (x0 >= w) return;
+  if (!live || x0 >= w) return;
   const bool full = x0 + 8 <= w;
   unsigned ring[K][4];
   unsigned S[4];
@@ -1186,9 +1194,12 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     const bool integer = (w % 32 == 0 && h % 32 == 0);
     const int isx = integer ? w / 32 : 0, isy = integer ? h / 32 : 0;
     const int yn = integer ? h : at.yn;
-    const int T = std::min(256, ((w + 7) / 8 + 63) / 64 * 64);
+    // lanes per image (8 columns each), at most 256; narrower images share a workgroup of up to 256 threads
+    const int T = std::min(256, std::max(4, (w + 7) / 8));
+    // whole-wave widths gain nothing from sharing (and lose workgroup-level parallelism): measured
+    const int ipb = T % 64 == 0 ? 1 : 256 / T, block_threads = (ipb * T + 63) / 64 * 64;
     const int pitch = T * 8 + 8;
-    const size_t smem = (size_t)(kBlurRB + K_ - 1) * (size_t)pitch;
+    const size_t smem = (size_t)ipb * (size_t)(kBlurRB + K_ - 1) * (size_t)pitch;
     const size_t per_chunk = std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)w * h));
     const size_t mc = std::min(per_chunk, n);
     unsigned char* d_blur = nullptr;
@@ -1198,14 +1209,15 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     for (size_t i0 = 0; i0 < n; i0 += per_chunk) {
       const size_t m = std::min(per_chunk, n - i0);
       const unsigned char* src = d_imgs + i0 * img_stride;
-      dim3 gb((unsigned)((w + T * 8 - 1) / (T * 8)), (unsigned)((h + kBlurRB - 1) / kBlurRB), (unsigned)m);
+      dim3 gb((unsigned)((w + T * 8 - 1) / (T * 8)), (unsigned)((h + kBlurRB - 1) / kBlurRB),
+              (unsigned)((m + ipb - 1) / ipb));
 #define CBH_BLURF(KK)                                                                                   \
   do {                                                                                                  \
     if (smem > 64 * 1024)                                                                               \
       CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_rows<KK>),                       \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));              \
-    hipLaunchKernelGGL(k_blur_rows<KK>, gb, dim3((unsigned)T), smem, stream, src, w, h, row_stride,     \
-                       img_stride, d_blur, pitch);                                                      \
+    hipLaunchKernelGGL(k_blur_rows<KK>, gb, dim3((unsigned)block_threads), smem, stream, src, w, h,     \
+                       row_stride, img_stride, d_blur, pitch, T, ipb, (unsigned)m);                     \
   } while (0)
       switch (K_) {
         case 3: CBH_BLURF(3); break;
