@@ -60,6 +60,10 @@ _SIGS = {
     "cbh_dcthash_batch": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, _vp, C.c_int]),
     "cbh_dcthash_batch_dev": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, _vp, C.c_int, _vp]),
     "cbh_dcthash_tiles_dev": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, _vp, _vp, C.c_int, _vp]),
+    "cbh_keypoint_rects": (C.c_longlong, [C.c_int, C.c_int, _vp, _sz, _vp]),
+    "cbh_keypoint_hashes": (C.c_int, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
+    "cbh_dcthash_rects": (C.c_int, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int]),
+    "cbh_keypoint_hashes_dev": (C.c_int, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "cbh_bgr2gray_dev": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, C.c_int, _vp, C.c_int, _vp]),
     "cbh_autocrop_dev": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, C.c_int, _vp, C.c_int, _vp]),
     "cbh_process_images": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, C.c_int, C.c_int, _vp, _vp, C.c_int]),

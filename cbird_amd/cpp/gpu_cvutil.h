@@ -1,0 +1,94 @@
+// gpu_cvutil.h -- drop-ins for the two hash producers of cbird's indexer, on libcbird_hip:
+//
+//   uint64_t dctHash64(const cv::Mat& cvImg, bool inPlace = false)                  src/cvutil.h, src/cvutil.cpp:435-545
+//   void Media::makeKeyPointHashes(const cv::Mat&, const KeyPointList&, KeyPointHashList&) const   src/media.cpp:874-923
+//
+// Same arguments and effects as the originals for 8-bit single-channel images (what Scanner::processImage passes
+// after grayscale(), src/scanner.cpp:859,876-889): the hash is returned, and with inPlace = true the blurred pixels
+// are written back into the caller's image.  A cv::Mat that is a VIEW into a larger image (colRange/rowRange) is
+// blurred with the parent's pixels around it, as cv::blur does (Mat::locateROI); the view's parent is what gets
+// staged on the device.
+//
+// These are per-call conveniences (one image, one H2D copy per call).  The batched entry points
+// cbh_dcthash_batch / cbh_process_images / cbh_keypoint_hashes are what an indexer that wants the GPU's throughput
+// calls with many images at once.
+//
+// Build note: needs cbird's cvutil.h / media.h (OpenCV 2.4 cv::Mat, cv::KeyPoint) on the include path; in this
+// repository it is compiled against cbird_amd/cpp/mock/index.h instead (tests/cpp/test_cvutil.cpp).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "cbird_hip.h"
+
+namespace cbird_gpu {
+
+inline int& hashDevice() {  // the device the per-call helpers use
+  static int dev = 0;
+  return dev;
+}
+
+namespace detail {
+struct ParentView {
+  const uint8_t* base;  // first pixel of the parent image
+  uint32_t w, h, step;
+  int32_t x, y;         // the view's offset inside it
+};
+inline ParentView parentOf(const cv::Mat& m) {
+  cv::Size whole;
+  cv::Point ofs;
+  m.locateROI(whole, ofs);
+  ParentView p;
+  p.step = uint32_t(m.step);
+  p.base = m.data - size_t(ofs.y) * m.step - size_t(ofs.x);
+  p.w = uint32_t(whole.width), p.h = uint32_t(whole.height);
+  p.x = ofs.x, p.y = ofs.y;
+  return p;
+}
+}  // namespace detail
+
+// dctHash64(cvImg, inPlace) for CV_8UC1.  Colour input is converted by the caller exactly as before
+// (grayscale(), cvutil.cpp:1265-1283; on the GPU: cbh_process_images).
+inline uint64_t gpuDctHash64(const cv::Mat& cvImg, bool inPlace = false) {
+  if (cvImg.type() != 0 /* CV_8UC1 */ || cvImg.rows <= 0 || cvImg.cols <= 0)
+    qFatal("gpuDctHash64: expected a non-empty CV_8UC1 image");
+  const detail::ParentView p = detail::parentOf(cvImg);
+  const size_t bytes = size_t(p.h - 1) * p.step + p.w;
+  const uint64_t off = 0;
+  const int32_t rect[4] = {p.x, p.y, cvImg.cols, cvImg.rows};
+  const uint32_t first[2] = {0, 1};
+  uint64_t hash = 0;
+  // in place: the device copy of the parent comes back over the caller's pixels (only the view's rectangle differs)
+  const int rc = cbh_dcthash_rects(p.base, bytes, 1, &off, &p.w, &p.h, &p.step, rect, first, inPlace ? 1 : 0, &hash,
+                                   inPlace ? const_cast<uint8_t*>(p.base) : nullptr, hashDevice());
+  if (rc) qFatal("gpuDctHash64: %s (%s)", cbh_strerror(rc), cbh_last_error());
+  return hash;
+}
+
+// Media::makeKeyPointHashes: the hashes are appended to outHashes like the original does (push_back per rectangle);
+// cvImg is modified by the in-place blurs.
+inline void gpuMakeKeyPointHashes(const cv::Mat& cvImg, const KeyPointList& keyPoints, KeyPointHashList& outHashes) {
+  Q_ASSERT(cvImg.type() == 0);  // grayscale, media.cpp:877
+  if (keyPoints.empty() || cvImg.rows <= 0 || cvImg.cols <= 0) return;
+  const detail::ParentView p = detail::parentOf(cvImg);
+  if (p.x != 0 || p.y != 0 || int(p.w) != cvImg.cols || int(p.h) != cvImg.rows)
+    qFatal("gpuMakeKeyPointHashes: expected a whole image, not a view");
+  std::vector<float> kp;
+  kp.reserve(keyPoints.size() * 3);
+  for (const cv::KeyPoint& k : keyPoints) {
+    kp.push_back(k.pt.x);
+    kp.push_back(k.pt.y);
+    kp.push_back(k.size);
+  }
+  const size_t bytes = size_t(p.h - 1) * p.step + p.w;
+  const uint64_t off = 0;
+  const uint32_t kpFirst[2] = {0, uint32_t(keyPoints.size())};
+  uint32_t outFirst[2] = {0, 0};
+  std::vector<uint64_t> hashes(keyPoints.size());
+  const int rc = cbh_keypoint_hashes(p.base, bytes, 1, &off, &p.w, &p.h, &p.step, kp.data(), kpFirst, hashes.data(),
+                                     outFirst, const_cast<uint8_t*>(p.base), hashDevice());
+  if (rc) qFatal("gpuMakeKeyPointHashes: %s (%s)", cbh_strerror(rc), cbh_last_error());
+  for (uint32_t i = 0; i < outFirst[1]; ++i) outHashes.push_back(hashes[i]);
+}
+
+}  // namespace cbird_gpu

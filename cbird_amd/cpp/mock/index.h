@@ -12,6 +12,7 @@
 #include <fstream>
 #include <iostream>
 #include <iterator>
+#include <memory>
 #include <set>
 #include <string>
 #include <utility>
@@ -154,17 +155,55 @@ struct QSqlQuery {
 typedef uint64_t dcthash_t;
 typedef std::vector<uint64_t> KeyPointHashList;
 namespace cv {
-struct Mat {  // rows x cols bytes, continuous
+struct Size {
+  int width = 0, height = 0;
+};
+struct Point {
+  int x = 0, y = 0;
+};
+struct Point2f {
+  float x = 0, y = 0;
+};
+struct KeyPoint {  // opencv2/features2d: the fields makeKeyPointHashes reads
+  Point2f pt;
+  float size = 0;
+  KeyPoint() {}
+  KeyPoint(float x, float y, float s) : size(s) { pt.x = x, pt.y = y; }
+};
+struct Mat {  // rows x cols bytes (CV_8UC1); views share the parent's storage like cv::Mat
   int rows = 0, cols = 0;
-  std::vector<uint8_t> data;
+  size_t step = 0;
+  uint8_t* data = nullptr;
   Mat() {}
-  Mat(int r, int c) : rows(r), cols(c), data(size_t(r) * size_t(c)) {}
+  Mat(int r, int c) : rows(r), cols(c), step(size_t(c)), _store(new std::vector<uint8_t>(size_t(r) * size_t(c))) {
+    data = _store->data();
+    _whole.width = c, _whole.height = r;
+  }
   template <typename T>
-  const T* ptr(int r) const { return reinterpret_cast<const T*>(data.data() + size_t(r) * size_t(cols)); }
+  const T* ptr(int r) const { return reinterpret_cast<const T*>(data + size_t(r) * step); }
   template <typename T>
-  T* ptr(int r) { return reinterpret_cast<T*>(data.data() + size_t(r) * size_t(cols)); }
+  T* ptr(int r) { return reinterpret_cast<T*>(data + size_t(r) * step); }
+  int type() const { return 0; }      // CV_8UC1
+  int channels() const { return 1; }
+  Mat colRange(int x0, int x1) const {
+    Mat m(*this);
+    m.data += x0, m.cols = x1 - x0, m._ofs.x += x0;
+    return m;
+  }
+  Mat rowRange(int y0, int y1) const {
+    Mat m(*this);
+    m.data += size_t(y0) * step, m.rows = y1 - y0, m._ofs.y += y0;
+    return m;
+  }
+  void locateROI(Size& wholeSize, Point& ofs) const { wholeSize = _whole, ofs = _ofs; }
+
+ private:
+  std::shared_ptr<std::vector<uint8_t>> _store;
+  Size _whole;
+  Point _ofs;
 };
 }  // namespace cv
+typedef std::vector<cv::KeyPoint> KeyPointList;
 typedef cv::Mat KeyPointDescriptors;
 struct DescriptorColor {  // src/cvutil.h:75-97
   uint16_t l, u, v, w;

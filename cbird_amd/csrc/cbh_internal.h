@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "cbird_hip.h"
 
 namespace cbh {
@@ -74,5 +76,15 @@ int launch_remove_ids(uint64_t* d_hashes, uint32_t* d_ids, size_t n, const uint3
 int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_stride,
                    size_t img_stride, uint64_t* d_out, hipStream_t stream,
                    uint8_t* d_tiles = nullptr);
+// rectangles of images hashed one after the other, optionally in place (Media::makeKeyPointHashes); also the path of
+// images with a side < 32
+struct RectImageDesc {
+  unsigned long long off;  // first byte of the image in the batch buffer
+  int w, h;
+  unsigned row_stride;
+  unsigned first, count;   // its rectangles: rects[4*first .. 4*(first+count))
+};
+int launch_rect_hashes(uint8_t* d_base, const std::vector<RectImageDesc>& images, const std::vector<int>& rects,
+                       int write_back, uint64_t* d_out, hipStream_t stream, uint8_t* d_tiles = nullptr);
 
 }  // namespace cbh

@@ -6,6 +6,7 @@
 // scan -> sort -> select.  There is no CPU compute path in this file: if no gfx950 device is
 // usable every compute entry point returns CBH_E_NODEVICE.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -94,7 +95,7 @@ int cbh_dcthash_batch(const uint8_t* imgs, size_t n, int w, int h, size_t row_st
   if (n == 0) return CBH_OK;
   if (!imgs || !out || w <= 0 || h <= 0 || row_stride < (size_t)w) return CBH_E_INVAL;
   if (img_stride < (size_t)(h - 1) * row_stride + (size_t)w && n > 1) return CBH_E_INVAL;
-  if (w < 32 || h < 32 || w > 8192 || h > 8192) return CBH_E_UNSUPPORTED;
+  if (w > 8192 || h > 8192) return CBH_E_UNSUPPORTED;
   DeviceGuard g(device);
   if (!g.ok) return CBH_E_NODEVICE;
   // decoded tiles are staged in chunks of <= 256 MiB; strides are preserved on the device
@@ -135,6 +136,176 @@ int cbh_dcthash_batch(const uint8_t* imgs, size_t n, int w, int h, size_t row_st
   if (d_imgs) (void)hipFree(d_imgs);
   if (d_out) (void)hipFree(d_out);
   return rc;
+}
+
+/* ---- Media::makeKeyPointHashes: src/media.cpp:874-923 ---------------------------------------- */
+
+long long cbh_keypoint_rects(int cols, int rows, const float* kp, size_t nkp, int32_t* rects) {
+  if (nkp && (!kp || !rects)) return CBH_E_INVAL;
+  long long n = 0;
+  for (size_t i = 0; i < nkp; ++i) {
+    const float size = kp[3 * i + 2];
+    if (!(size >= 31)) continue;  // "if resulting rectangle is too small dct hash is worthless" (:885)
+    const float x0 = kp[3 * i], y0 = kp[3 * i + 1];
+    const float x1 = x0 + size, y1 = y0 + size;
+    if (x0 > 0 && y0 > 0 && x1 < cols - 2 && y1 < rows - 2) {
+      rects[3 * n] = (int32_t)std::floor(x0);
+      rects[3 * n + 1] = (int32_t)std::floor(y0);
+      rects[3 * n + 2] = (int32_t)std::ceil(size);
+      ++n;
+    }
+  }
+  return n;
+}
+
+namespace {
+
+// descriptors -> launch_rect_hashes inputs; out_first[i] = first hash of image i, out_first[n] = total
+int keypoint_jobs(size_t n, const uint64_t* img_off, const uint32_t* img_w, const uint32_t* img_h,
+                  const uint32_t* img_row_stride, const float* kp, const uint32_t* kp_first, uint32_t* out_first,
+                  std::vector<cbh::RectImageDesc>* images, std::vector<int>* rects) {
+  images->resize(n);
+  std::vector<int32_t> tmp;
+  size_t total = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (kp_first[i + 1] < kp_first[i] || img_w[i] == 0 || img_h[i] == 0 || img_w[i] > 8192 || img_h[i] > 8192 ||
+        img_row_stride[i] < img_w[i])
+      return CBH_E_INVAL;
+    const size_t nk = kp_first[i + 1] - kp_first[i];
+    tmp.resize(3 * std::max<size_t>(nk, 1));
+    const long long m = cbh_keypoint_rects((int)img_w[i], (int)img_h[i], kp + 3 * (size_t)kp_first[i], nk, tmp.data());
+    if (m < 0) return (int)m;
+    if (total + (size_t)m > 0xffffffffull) return CBH_E_INVAL;
+    (*images)[i] = cbh::RectImageDesc{img_off[i], (int)img_w[i], (int)img_h[i], img_row_stride[i], (unsigned)total,
+                                      (unsigned)m};
+    out_first[i] = (uint32_t)total;
+    for (long long r = 0; r < m; ++r) {
+      rects->push_back(tmp[3 * r]);
+      rects->push_back(tmp[3 * r + 1]);
+      rects->push_back(tmp[3 * r + 2]);
+      rects->push_back(tmp[3 * r + 2]);
+    }
+    total += (size_t)m;
+  }
+  out_first[n] = (uint32_t)total;
+  return CBH_OK;
+}
+
+}  // namespace
+
+int cbh_keypoint_hashes_dev(void* d_imgs, size_t n, const uint64_t* img_off, const uint32_t* img_w,
+                            const uint32_t* img_h, const uint32_t* img_row_stride, const float* kp,
+                            const uint32_t* kp_first, void* d_out, uint32_t* out_first, int device, void* stream) {
+  if (!device_usable(device)) return CBH_E_NODEVICE;
+  if (!out_first) return CBH_E_INVAL;
+  if (n == 0) {
+    out_first[0] = 0;
+    return CBH_OK;
+  }
+  if (!d_imgs || !img_off || !img_w || !img_h || !img_row_stride || !kp_first || (kp_first[n] && !kp) || !d_out)
+    return CBH_E_INVAL;
+  std::vector<cbh::RectImageDesc> images;
+  std::vector<int> rects;
+  int rc = keypoint_jobs(n, img_off, img_w, img_h, img_row_stride, kp, kp_first, out_first, &images, &rects);
+  if (rc) return rc;
+  DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  return launch_rect_hashes((uint8_t*)d_imgs, images, rects, 1, (uint64_t*)d_out, (hipStream_t)stream);
+}
+
+namespace {
+
+// stage the packed images, run k_rect_hashes, fetch hashes (and the modified images)
+int rect_hashes_host(const uint8_t* imgs, size_t imgs_bytes, const std::vector<cbh::RectImageDesc>& images,
+                     const std::vector<int>& rects, int write_back, uint64_t* out_hashes, uint8_t* imgs_after,
+                     int device) {
+  const size_t total = rects.size() / 4;
+  if (total && !out_hashes) return CBH_E_INVAL;
+  if (total == 0) {
+    if (imgs_after) memcpy(imgs_after, imgs, imgs_bytes);
+    return CBH_OK;
+  }
+  DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  uint8_t* d_imgs = nullptr;
+  uint64_t* d_out = nullptr;
+  hipStream_t s = nullptr;
+  hipError_t e;
+  int rc = CBH_OK;
+  if ((e = hipMalloc(&d_imgs, imgs_bytes)) != hipSuccess ||
+      (e = hipMalloc(&d_out, total * sizeof(uint64_t))) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipMemcpyAsync(d_imgs, imgs, imgs_bytes, hipMemcpyHostToDevice, s)) != hipSuccess) {
+    set_last_error("rect hashes setup", e);
+    rc = e == hipErrorOutOfMemory ? CBH_E_NOMEM : CBH_E_HIP;
+  }
+  if (rc == CBH_OK) rc = launch_rect_hashes(d_imgs, images, rects, write_back, d_out, s);
+  if (rc == CBH_OK) {
+    if ((e = hipMemcpyAsync(out_hashes, d_out, total * sizeof(uint64_t), hipMemcpyDeviceToHost, s)) != hipSuccess ||
+        (imgs_after && (e = hipMemcpyAsync(imgs_after, d_imgs, imgs_bytes, hipMemcpyDeviceToHost, s)) != hipSuccess) ||
+        (e = hipStreamSynchronize(s)) != hipSuccess) {
+      set_last_error("rect hashes D2H", e);
+      rc = CBH_E_HIP;
+    }
+  }
+  if (s) (void)hipStreamDestroy(s);
+  if (d_imgs) (void)hipFree(d_imgs);
+  if (d_out) (void)hipFree(d_out);
+  return rc;
+}
+
+int check_images(size_t n, size_t imgs_bytes, const uint64_t* img_off, const uint32_t* img_w, const uint32_t* img_h,
+                 const uint32_t* img_row_stride) {
+  for (size_t i = 0; i < n; ++i) {
+    if (img_w[i] == 0 || img_h[i] == 0 || img_w[i] > 8192 || img_h[i] > 8192 || img_row_stride[i] < img_w[i])
+      return CBH_E_INVAL;
+    const unsigned long long end = img_off[i] + (unsigned long long)(img_h[i] - 1) * img_row_stride[i] + img_w[i];
+    if (end > imgs_bytes) return CBH_E_INVAL;
+  }
+  return CBH_OK;
+}
+
+}  // namespace
+
+int cbh_keypoint_hashes(const uint8_t* imgs, size_t imgs_bytes, size_t n, const uint64_t* img_off,
+                        const uint32_t* img_w, const uint32_t* img_h, const uint32_t* img_row_stride,
+                        const float* kp, const uint32_t* kp_first, uint64_t* out_hashes, uint32_t* out_first,
+                        uint8_t* imgs_after, int device) {
+  if (!device_usable(device)) return CBH_E_NODEVICE;
+  if (!out_first) return CBH_E_INVAL;
+  if (n == 0) {
+    out_first[0] = 0;
+    return CBH_OK;
+  }
+  if (!imgs || !img_off || !img_w || !img_h || !img_row_stride || !kp_first || (kp_first[n] && !kp)) return CBH_E_INVAL;
+  int rc = check_images(n, imgs_bytes, img_off, img_w, img_h, img_row_stride);
+  if (rc) return rc;
+  std::vector<cbh::RectImageDesc> images;
+  std::vector<int> rects;
+  rc = keypoint_jobs(n, img_off, img_w, img_h, img_row_stride, kp, kp_first, out_first, &images, &rects);
+  if (rc) return rc;
+  return rect_hashes_host(imgs, imgs_bytes, images, rects, 1, out_hashes, imgs_after, device);
+}
+
+int cbh_dcthash_rects(const uint8_t* imgs, size_t imgs_bytes, size_t n, const uint64_t* img_off,
+                      const uint32_t* img_w, const uint32_t* img_h, const uint32_t* img_row_stride,
+                      const int32_t* rects, const uint32_t* rect_first, int in_place, uint64_t* out_hashes,
+                      uint8_t* imgs_after, int device) {
+  if (!device_usable(device)) return CBH_E_NODEVICE;
+  if (n == 0) return CBH_OK;
+  if (!imgs || !img_off || !img_w || !img_h || !img_row_stride || !rect_first || (rect_first[n] && !rects))
+    return CBH_E_INVAL;
+  int rc = check_images(n, imgs_bytes, img_off, img_w, img_h, img_row_stride);
+  if (rc) return rc;
+  if (rect_first[0] != 0) return CBH_E_INVAL;
+  std::vector<cbh::RectImageDesc> images(n);
+  for (size_t i = 0; i < n; ++i) {
+    if (rect_first[i + 1] < rect_first[i]) return CBH_E_INVAL;
+    images[i] = cbh::RectImageDesc{img_off[i], (int)img_w[i], (int)img_h[i], img_row_stride[i], rect_first[i],
+                                   rect_first[i + 1] - rect_first[i]};
+  }
+  std::vector<int> r(rects, rects + 4 * (size_t)rect_first[n]);
+  return rect_hashes_host(imgs, imgs_bytes, images, r, in_place ? 1 : 0, out_hashes, imgs_after, device);
 }
 
 /* ---- DctHashIndex ----------------------------------------------------------------------- */

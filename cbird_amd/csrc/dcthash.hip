@@ -21,6 +21,8 @@
 // k_dcthash_generic: one 256-thread workgroup per image, any w,h in {32} or multiples of 32 up
 // to 1024; the image is consumed as 32 horizontal bands (one per output row) staged in LDS.
 #include <algorithm>
+#include <cfloat>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <type_traits>
@@ -981,6 +983,163 @@ size_t generic_smem_bytes(int w, int h, int K) {
   return (288 + 288 + 84 + 4) * 4 + (size_t)w * 4 + 1024 + 64 + (size_t)band * w * 3;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Rectangles of an image, hashed one after the other IN PLACE: Media::makeKeyPointHashes (src/media.cpp:874-923)
+// calls dctHash64(sub, inPlace = true) on up to 400 keypoint squares of the same grey image, and cv::blur writes
+// each blurred square back before the next (overlapping) one is read -- an order dependence inside one image that
+// cannot be broken.  The parallelism is across images: one workgroup per image walks its rectangles in order;
+// inside a rectangle all 256 lanes work (blur: a lane per column and row segment, sliding K-row sums; resize: four
+// of the 1024 tile pixels per lane; stages 3-6: hash_from_tile).  The blur takes the pixels around the rectangle
+// from the parent image (cv::FilterEngine is not "isolated" on a view) and reflects only at the parent's edges.
+// The same kernel serves whole images with a side < 32 (one rectangle = the image, nothing written back): there
+// cv::resize(INTER_AREA) enlarges and runs its 2-tap fixed-point bilinear emulation (mode 3).
+struct RectJob {
+  int x, y, w, h;
+  int mode;    // 0: already 32x32; 1: integer block means; 2: weighted area tables; 3: bilinear emulation (a side < 32)
+  int xt, yt;  // mode 1: block width / height; modes 2, 3: axis table ids
+};
+struct RectImage {
+  unsigned long long off;  // first byte of the image in the batch buffer
+  int w, h;
+  unsigned row_stride;
+  unsigned first, count;   // its jobs: [first, first + count)
+};
+struct AxisTab {
+  int tab_off, first_off;  // mode 2: AreaTab pool offset, `first` (33 ints) offset in the int pool
+  int lin_off;             // mode 3: 96 ints (32 x source offset, 32 x c0, 32 x c1) in the int pool
+};
+
+template <int K>
+__device__ __forceinline__ void blur_rect(const unsigned char* __restrict__ img, int W, int H, size_t stride, int x,
+                                          int y, int rw, int rh, unsigned char* __restrict__ scr) {
+  constexpr int R = K / 2;
+  const int nseg = rw >= kThreads ? 1 : min(rh, kThreads / rw);  // row segments, so that narrow rectangles use all lanes
+  const int rps = (rh + nseg - 1) / nseg;
+  const int items = rw * nseg;
+  for (int it = (int)threadIdx.x; it < items; it += kThreads) {
+    const int g = it / rw, j = it - g * rw;
+    const int r0 = g * rps, r1 = min(rh, r0 + rps);
+    if (r0 >= r1) continue;
+    int pc[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) pc[t] = reflect101(x + j + t - R, W);
+    unsigned ring[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      const unsigned char* row = img + (size_t)reflect101(y + r0 - R + t, H) * stride;
+      unsigned s = 0;
+#pragma unroll
+      for (int u = 0; u < K; ++u) s += row[pc[u]];
+      ring[t] = s;
+    }
+    for (int i = r0; i < r1; ++i) {
+      unsigned S = 0;
+#pragma unroll
+      for (int t = 0; t < K; ++t) S += ring[t];
+      scr[(size_t)i * rw + j] = (unsigned char)((2u * S + (unsigned)(K * K)) / (2u * (unsigned)(K * K)));
+      if (i + 1 < r1) {
+        const unsigned char* row = img + (size_t)reflect101(y + i + 1 + R, H) * stride;
+        unsigned s = 0;
+#pragma unroll
+        for (int u = 0; u < K; ++u) s += row[pc[u]];
+#pragma unroll
+        for (int t = 0; t + 1 < K; ++t) ring[t] = ring[t + 1];
+        ring[K - 1] = s;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_rect_hashes(unsigned char* __restrict__ base,
+                                                          const RectImage* __restrict__ images, unsigned n_images,
+                                                          const RectJob* __restrict__ jobs,
+                                                          const AxisTab* __restrict__ axes,
+                                                          const AreaTab* __restrict__ apool,
+                                                          const int* __restrict__ ipool,
+                                                          unsigned char* __restrict__ scratch, size_t scratch_per_wg,
+                                                          const DctTables* __restrict__ tabs, int write_back,
+                                                          uint64_t* __restrict__ out,
+                                                          unsigned char* __restrict__ tiles) {
+  __shared__ float sC[288], sT[288], sY[84], sThr[4];
+  __shared__ unsigned char tile[1024], sZ[64];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 288; i += kThreads) sC[i] = tabs->C[i];
+  if (tid < 64) sZ[tid] = tabs->zz[tid];
+  unsigned char* __restrict__ scr = scratch + (size_t)blockIdx.x * scratch_per_wg;
+  for (unsigned im = blockIdx.x; im < n_images; im += gridDim.x) {
+    const RectImage I = images[im];
+    unsigned char* img = base + I.off;
+    for (unsigned r = 0; r < I.count; ++r) {
+      const RectJob J = jobs[I.first + r];
+      const long long area = (long long)J.w * J.h;
+      const int K = area <= 32 * 32 ? 0 : area <= 64 * 64 ? 3 : area <= 128 * 128 ? 5 : 7;
+      const unsigned char* src = img + (size_t)J.y * I.row_stride + J.x;
+      size_t sp = I.row_stride;
+      if (K) {
+        if (K == 3) blur_rect<3>(img, I.w, I.h, I.row_stride, J.x, J.y, J.w, J.h, scr);
+        else if (K == 5) blur_rect<5>(img, I.w, I.h, I.row_stride, J.x, J.y, J.w, J.h, scr);
+        else blur_rect<7>(img, I.w, I.h, I.row_stride, J.x, J.y, J.w, J.h, scr);
+        __syncthreads();  // the whole rectangle is blurred (from the old pixels) before any of it is replaced
+        if (write_back)
+          for (long long i = tid; i < area; i += kThreads) {
+            const int yy = (int)(i / J.w), xx = (int)(i - (long long)yy * J.w);
+            img[(size_t)(J.y + yy) * I.row_stride + J.x + xx] = scr[i];
+          }
+        src = scr;
+        sp = (size_t)J.w;
+      }
+      for (int o = tid; o < 1024; o += kThreads) {
+        const int dy = o >> 5, dx = o & 31;
+        if (J.mode == 0) {
+          tile[o] = src[(size_t)dy * sp + dx];
+        } else if (J.mode == 1) {  // resizeAreaFast_: block sum, 2x2 -> (s+2)>>2, else rint(s * (1.f/area))
+          const int isx = J.xt, isy = J.yt;
+          unsigned int s = 0;
+          for (int yy = 0; yy < isy; ++yy)
+            for (int xx = 0; xx < isx; ++xx) s += src[(size_t)(dy * isy + yy) * sp + (dx * isx + xx)];
+          const unsigned int v = (isx == 2 && isy == 2)
+                                     ? (s + 2u) >> 2
+                                     : (unsigned int)__builtin_rintf((float)s * (1.f / (float)(isx * isy)));
+          tile[o] = (unsigned char)(v > 255u ? 255u : v);
+        } else if (J.mode == 2) {  // resizeArea_: the float accumulation order is part of the result
+          const AxisTab ax = axes[J.xt], ay = axes[J.yt];
+          const AreaTab* __restrict__ xtab = apool + ax.tab_off;
+          const AreaTab* __restrict__ ytab = apool + ay.tab_off;
+          const int* __restrict__ xfirst = ipool + ax.first_off;
+          const int* __restrict__ yfirst = ipool + ay.first_off;
+          float sum = 0.f;
+          for (int j = yfirst[dy]; j < yfirst[dy + 1]; ++j) {
+            const unsigned char* S = src + (size_t)ytab[j].si * sp;
+            float buf = 0.f;
+            for (int k = xfirst[dx]; k < xfirst[dx + 1]; ++k) buf += (float)S[xtab[k].si] * xtab[k].alpha;
+            const float t = ytab[j].alpha * buf;
+            sum = (j == yfirst[dy]) ? t : sum + t;
+          }
+          const float rr = __builtin_rintf(sum);
+          tile[o] = (unsigned char)(rr < 0.f ? 0.f : rr > 255.f ? 255.f : rr);
+        } else {  // 2-tap fixed-point resizer with area-mode coefficients (HResizeLinear / VResizeLinear, 8u)
+          const int* __restrict__ xl = ipool + axes[J.xt].lin_off;
+          const int* __restrict__ yl = ipool + axes[J.yt].lin_off;
+          const int sy0 = min(max(yl[dy], 0), J.h - 1), sy1 = min(max(yl[dy] + 1, 0), J.h - 1);
+          const int sx = xl[dx], sx1 = min(sx + 1, J.w - 1);
+          const int a0 = xl[32 + dx], a1 = xl[64 + dx], b0 = yl[32 + dy], b1 = yl[64 + dy];
+          const unsigned char* S0 = src + (size_t)sy0 * sp;
+          const unsigned char* S1 = src + (size_t)sy1 * sp;
+          const int D0 = (int)S0[sx] * a0 + (int)S0[sx1] * a1;
+          const int D1 = (int)S1[sx] * a0 + (int)S1[sx1] * a1;
+          const int v = (((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2;
+          tile[o] = (unsigned char)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+      }
+      __syncthreads();
+      if (tiles)
+        for (int i = tid; i < 1024; i += kThreads) tiles[(size_t)(I.first + r) * 1024 + i] = tile[i];
+      hash_from_tile(tile, sC, sZ, sT, sY, sThr, out + I.first + r);
+      __syncthreads();  // tile / sT / sY are reused, and the written-back pixels are in place for the next rectangle
+    }
+  }
+}
+
 struct TableCache {
   std::mutex mu;
   DctTables* d[16] = {};
@@ -991,9 +1150,21 @@ struct TableCache {
 namespace {
 
 // computeResizeAreaTab (OpenCV 2.4 imgwarp.cpp, as recalled): see oracle/cbird_oracle.c for the prose
+// cv::resize: inv_scale = (double)dsize/ssize; scale = 1./inv_scale (two roundings -- it is not ssize/dsize), and the
+// integer "area fast" path only when |scale - round(scale)| < DBL_EPSILON on both axes: for ssize = 32*m with
+// m = 49, 93, 98, 99, 103 ... the double rounding misses m by an ulp and the weighted tables are used instead.
+double cv_resize_scale(int ssize, int dsize) {
+  const double inv_scale = (double)dsize / ssize;
+  return 1. / inv_scale;
+}
+bool area_fast(int w, int h) {
+  const double sx = cv_resize_scale(w, 32), sy = cv_resize_scale(h, 32);
+  return std::fabs(sx - std::nearbyint(sx)) < DBL_EPSILON && std::fabs(sy - std::nearbyint(sy)) < DBL_EPSILON;
+}
+
 std::vector<AreaTab> make_area_tab(int ssize, int dsize, std::vector<int>* first) {
   std::vector<AreaTab> tab;
-  const double scale = (double)ssize / dsize;
+  const double scale = cv_resize_scale(ssize, dsize);
   first->assign((size_t)dsize + 1, 0);
   for (int dx = 0; dx < dsize; dx++) {
     (*first)[(size_t)dx] = (int)tab.size();
@@ -1173,12 +1344,153 @@ static int get_tables(const DctTables** out) {
   return CBH_OK;
 }
 
+namespace {
+
+// cv::resize(INTER_AREA) with an enlarging axis: coefficient tables of the 2-tap resizer (see oracle/cbird_oracle.c
+// resize_linear_tab for the prose).  96 ints: source offsets, c0, c1.
+void make_linear_tab(int ssize, bool is_x, std::vector<int>* pool) {
+  const double inv_scale = (double)32 / ssize;
+  const double scale = 1. / inv_scale;
+  int ofs[32], c0[32], c1[32];
+  for (int d = 0; d < 32; ++d) {
+    int sx = (int)std::floor(d * scale);
+    float f = (float)((d + 1) - (sx + 1) * inv_scale);
+    f = f <= 0 ? 0.f : f - std::floor(f);
+    if (is_x && sx + 1 >= ssize) {
+      f = 0.f;
+      sx = ssize - 1;
+    }
+    ofs[d] = sx;
+    c0[d] = (int)std::min<long>(32767, std::max<long>(-32768, std::lrintf((1.f - f) * 2048.f)));
+    c1[d] = (int)std::min<long>(32767, std::max<long>(-32768, std::lrintf(f * 2048.f)));
+  }
+  pool->insert(pool->end(), ofs, ofs + 32);
+  pool->insert(pool->end(), c0, c0 + 32);
+  pool->insert(pool->end(), c1, c1 + 32);
+}
+
+struct RectTables {  // axis tables of one launch, deduplicated by (size, kind)
+  std::vector<AxisTab> axes;
+  std::vector<AreaTab> apool;
+  std::vector<int> ipool;
+  std::map<std::tuple<int, int>, int> ids;  // (size, kind: 0 area, 1 linear x, 2 linear y)
+  int get(int size, int kind) {
+    auto key = std::make_tuple(size, kind);
+    auto it = ids.find(key);
+    if (it != ids.end()) return it->second;
+    AxisTab a{0, 0, 0};
+    if (kind == 0) {
+      std::vector<int> first;
+      std::vector<AreaTab> t = make_area_tab(size, 32, &first);
+      a.tab_off = (int)apool.size();
+      a.first_off = (int)ipool.size();
+      apool.insert(apool.end(), t.begin(), t.end());
+      ipool.insert(ipool.end(), first.begin(), first.end());
+    } else {
+      a.lin_off = (int)ipool.size();
+      make_linear_tab(size, kind == 1, &ipool);
+    }
+    axes.push_back(a);
+    return ids[key] = (int)axes.size() - 1;
+  }
+};
+
+}  // namespace
+
+// rects: x, y, w, h per job; images[i].first/count index them.  d_base is written (the blurred rectangles) iff
+// write_back.  Synchronises `stream` before returning (the descriptor uploads come from pageable host vectors).
+int launch_rect_hashes(uint8_t* d_base, const std::vector<RectImageDesc>& images, const std::vector<int>& rects,
+                       int write_back, uint64_t* d_out, hipStream_t stream, uint8_t* d_tiles) {
+  const size_t nj = rects.size() / 4;
+  if (images.empty() || nj == 0) return CBH_OK;
+  const DctTables* tabs = nullptr;
+  int rc = get_tables(&tabs);
+  if (rc) return rc;
+  RectTables rt;
+  std::vector<RectJob> jobs(nj);
+  size_t max_blur = 16;
+  for (size_t i = 0; i < nj; ++i) {
+    RectJob& J = jobs[i];
+    J.x = rects[4 * i], J.y = rects[4 * i + 1], J.w = rects[4 * i + 2], J.h = rects[4 * i + 3];
+    if (J.w <= 0 || J.h <= 0 || J.w > 8192 || J.h > 8192) return CBH_E_INVAL;
+    if ((long long)J.w * J.h > 32 * 32) max_blur = std::max(max_blur, (size_t)J.w * (size_t)J.h);
+    if (J.w == 32 && J.h == 32) {
+      J.mode = 0, J.xt = J.yt = 0;
+    } else if (J.w < 32 || J.h < 32) {
+      J.mode = 3, J.xt = rt.get(J.w, 1), J.yt = rt.get(J.h, 2);
+    } else if (area_fast(J.w, J.h)) {
+      J.mode = 1, J.xt = J.w / 32, J.yt = J.h / 32;
+    } else {
+      J.mode = 2, J.xt = rt.get(J.w, 0), J.yt = rt.get(J.h, 0);
+    }
+  }
+  std::vector<RectImage> imgs(images.size());
+  for (size_t i = 0; i < images.size(); ++i) {
+    const RectImageDesc& d = images[i];
+    if (d.w <= 0 || d.h <= 0 || d.row_stride < (unsigned)d.w || (size_t)d.first + d.count > nj) return CBH_E_INVAL;
+    for (unsigned r = d.first; r < d.first + d.count; ++r)
+      if (jobs[r].x < 0 || jobs[r].y < 0 || jobs[r].x + jobs[r].w > d.w || jobs[r].y + jobs[r].h > d.h)
+        return CBH_E_INVAL;
+    imgs[i] = RectImage{d.off, d.w, d.h, d.row_stride, d.first, d.count};
+  }
+  if (rt.axes.empty()) rt.axes.push_back(AxisTab{0, 0, 0});
+  if (rt.apool.empty()) rt.apool.push_back(AreaTab{0, 0, 0.f});
+  if (rt.ipool.empty()) rt.ipool.push_back(0);
+  max_blur = (max_blur + 255) / 256 * 256;
+  const unsigned grid = (unsigned)std::min<size_t>(images.size(), 2048);
+  RectImage* d_images = nullptr;
+  RectJob* d_jobs = nullptr;
+  AxisTab* d_axes = nullptr;
+  AreaTab* d_apool = nullptr;
+  int* d_ipool = nullptr;
+  unsigned char* d_scr = nullptr;
+  hipError_t e = hipSuccess;
+  auto up = [&](void** dst, const void* src, size_t bytes) {
+    if (e != hipSuccess) return;
+    if ((e = hipMallocAsync(dst, bytes, stream)) != hipSuccess) return;
+    e = hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, stream);
+  };
+  up((void**)&d_images, imgs.data(), imgs.size() * sizeof(RectImage));
+  up((void**)&d_jobs, jobs.data(), jobs.size() * sizeof(RectJob));
+  up((void**)&d_axes, rt.axes.data(), rt.axes.size() * sizeof(AxisTab));
+  up((void**)&d_apool, rt.apool.data(), rt.apool.size() * sizeof(AreaTab));
+  up((void**)&d_ipool, rt.ipool.data(), rt.ipool.size() * sizeof(int));
+  if (e == hipSuccess) e = hipMallocAsync((void**)&d_scr, (size_t)grid * max_blur, stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_rect_hashes, dim3(grid), dim3(kThreads), 0, stream, d_base, d_images, (unsigned)imgs.size(),
+                       d_jobs, d_axes, d_apool, d_ipool, d_scr, max_blur, tabs, write_back, d_out, d_tiles);
+    e = hipGetLastError();
+  }
+  for (void* p : {(void*)d_images, (void*)d_jobs, (void*)d_axes, (void*)d_apool, (void*)d_ipool, (void*)d_scr})
+    if (p) (void)hipFreeAsync(p, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  CBH_HIP(e);
+  return CBH_OK;
+}
+
 int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_stride,
                    size_t img_stride, uint64_t* d_out, hipStream_t stream, uint8_t* d_tiles) {
   if (n == 0) return CBH_OK;
   if (w <= 0 || h <= 0 || row_stride < (size_t)w) return CBH_E_INVAL;
-  if (w < 32 || h < 32 || w > 8192 || h > 8192) return CBH_E_UNSUPPORTED;  // < 32: bilinear upscale path
+  if (w > 8192 || h > 8192) return CBH_E_UNSUPPORTED;
   if (n > 0x7fffffffull) return CBH_E_INVAL;
+  if (w < 32 || h < 32) {
+    // a side enlarges: cv::resize's bilinear emulation, on the rectangle kernel (one rectangle = the whole image)
+    const size_t per_chunk = (size_t)1 << 20;
+    for (size_t i0 = 0; i0 < n; i0 += per_chunk) {
+      const size_t m = std::min(per_chunk, n - i0);
+      std::vector<RectImageDesc> images(m);
+      std::vector<int> rects(4 * m);
+      for (size_t i = 0; i < m; ++i) {
+        images[i] = RectImageDesc{(unsigned long long)(i * img_stride), w, h, (unsigned)row_stride, (unsigned)i, 1u};
+        rects[4 * i] = 0, rects[4 * i + 1] = 0, rects[4 * i + 2] = w, rects[4 * i + 3] = h;
+      }
+      int rc2 = launch_rect_hashes(const_cast<uint8_t*>(d_imgs) + i0 * img_stride, images, rects, 0, d_out + i0, stream,
+                                   d_tiles ? d_tiles + i0 * 1024 : nullptr);
+      if (rc2) return rc2;
+    }
+    return CBH_OK;
+  }
   const DctTables* tabs = nullptr;
   int rc = get_tables(&tabs);
   if (rc) return rc;
@@ -1191,7 +1503,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     const int K_ = area_ <= 64 * 64 ? 3 : area_ <= 128 * 128 ? 5 : 7;  // (area <= 32*32 is only 32x32 itself)
     AreaTabsDev at;
     if ((rc = get_area_tabs(w, h, &at))) return rc;
-    const bool integer = (w % 32 == 0 && h % 32 == 0);
+    const bool integer = area_fast(w, h);
     const int isx = integer ? w / 32 : 0, isy = integer ? h / 32 : 0;
     const int yn = integer ? h : at.yn;
     // lanes per image (8 columns each), at most 256; narrower images share a workgroup of up to 256 threads
@@ -1241,7 +1553,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     CBH_HIP(e);
     return CBH_OK;
   }
-  if (w % 32 || h % 32 || w > 1024 || h > 1024) {
+  if (!area_fast(w, h) || w > 1024 || h > 1024) {
     // general INTER_AREA path: blur to scratch, then weighted resample + hash
     const long long area_ = (long long)w * h;
     const int K_ = area_ <= 32 * 32 ? 0 : area_ <= 64 * 64 ? 3 : area_ <= 128 * 128 ? 5 : 7;
@@ -1272,7 +1584,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
       }
 #undef CBH_BLUR
       hipLaunchKernelGGL(k_area_hash, dim3((unsigned)m), block, 0, stream, d_blur, w, h, at.x, at.xn, at.y,
-                         at.yn, at.xfirst, at.yfirst, (w % 32 || h % 32) ? 0 : w / 32, (w % 32 || h % 32) ? 0 : h / 32,
+                         at.yn, at.xfirst, at.yfirst, area_fast(w, h) ? w / 32 : 0, area_fast(w, h) ? h / 32 : 0,
                          tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
     }
     CBH_HIP(hipGetLastError());

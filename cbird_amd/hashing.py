@@ -53,3 +53,53 @@ def process_images(imgs: np.ndarray, autocrop: int | None = 20, device: int = 0)
                                             -1 if autocrop is None else int(autocrop), out.ctypes.data,
                                             rects.ctypes.data, device), "process_images")
     return out, rects
+
+
+def keypoint_rects(cols: int, rows: int, keypoints) -> np.ndarray:
+    """The rectangles Media::makeKeyPointHashes derives from keypoints (src/media.cpp:880-901): keypoints is
+    [k, 3] float32 (pt.x, pt.y, size); returns int32 [m, 3] (x, y, side)."""
+    kp = np.ascontiguousarray(keypoints, np.float32).reshape(-1, 3)
+    r = np.zeros((max(1, len(kp)), 3), np.int32)
+    n = _lib.lib().cbh_keypoint_rects(int(cols), int(rows), kp.ctypes.data, len(kp), r.ctypes.data)
+    if n < 0:
+        check(int(n), "keypoint_rects")
+    return r[:n].copy()
+
+
+def make_keypoint_hashes(images, keypoints, device: int = 0, return_images: bool = False):
+    """Media::makeKeyPointHashes (src/media.cpp:874-923) for a batch: images is a list of 2-D uint8 grey images (any
+    sizes), keypoints a list of [k_i, 3] float32 arrays (pt.x, pt.y, size) in detector order.  Returns a list of
+    uint64 arrays (one hash per accepted keypoint, in order); with return_images also the images as the in-place
+    blurs of dctHash64(sub, inPlace=true) left them."""
+    if len(images) != len(keypoints):
+        raise ValueError("one keypoint array per image")
+    n = len(images)
+    if n == 0:
+        return ([], []) if return_images else []
+    imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+    if any(im.ndim != 2 or im.size == 0 for im in imgs):
+        raise ValueError("expected non-empty single-channel 2-D uint8 images")
+    kps = [np.ascontiguousarray(k, np.float32).reshape(-1, 3) for k in keypoints]
+    sizes = np.array([im.size for im in imgs], np.uint64)
+    off = np.zeros(n, np.uint64)
+    off[1:] = np.cumsum((sizes[:-1] + np.uint64(15)) // np.uint64(16) * np.uint64(16))  # 16-byte aligned starts
+    total = int(off[-1] + sizes[-1])
+    buf = np.zeros(total, np.uint8)
+    for im, o in zip(imgs, off):
+        buf[int(o): int(o) + im.size] = im.reshape(-1)
+    w = np.array([im.shape[1] for im in imgs], np.uint32)
+    h = np.array([im.shape[0] for im in imgs], np.uint32)
+    kp_first = np.zeros(n + 1, np.uint32)
+    kp_first[1:] = np.cumsum([len(k) for k in kps])
+    kp = np.concatenate(kps) if kp_first[-1] else np.zeros((1, 3), np.float32)
+    out = np.zeros(max(1, int(kp_first[-1])), np.uint64)
+    out_first = np.zeros(n + 1, np.uint32)
+    after = np.zeros(total, np.uint8) if return_images else None
+    check(_lib.lib().cbh_keypoint_hashes(buf.ctypes.data, total, n, off.ctypes.data, w.ctypes.data, h.ctypes.data,
+                                         w.ctypes.data, kp.ctypes.data, kp_first.ctypes.data, out.ctypes.data,
+                                         out_first.ctypes.data, after.ctypes.data if return_images else None,
+                                         device), "keypoint_hashes")
+    hashes = [out[int(out_first[i]): int(out_first[i + 1])].copy() for i in range(n)]
+    if not return_images:
+        return hashes
+    return hashes, [after[int(o): int(o) + im.size].reshape(im.shape).copy() for im, o in zip(imgs, off)]

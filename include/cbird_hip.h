@@ -72,13 +72,44 @@ const char* cbh_last_error(void);       /* thread-local detail of the last CBH_E
 /* ---- hash build: replaces dctHash64(const cv::Mat&, bool) -- src/cvutil.cpp:435-545,
  * called once per image from Scanner::processImage (src/scanner.cpp:862).
  * imgs: n 8-bit single-channel images (cv::Mat CV_8UC1 after grayscale()), image i at
- * imgs + i*img_stride, row y at + y*row_stride.  Supported geometry: 32 <= w,h <= 8192 (integer-ratio and
- * weighted INTER_AREA paths); smaller images take cv::resize's bilinear upscaling path, which is not
- * implemented: CBH_E_UNSUPPORTED.  out[i] = 64-bit hash (bit 0 clear unless the hash would be 0 -> 1). */
+ * imgs + i*img_stride, row y at + y*row_stride.  Supported geometry: 1 <= w,h <= 8192 (cv::resize INTER_AREA's
+ * integer-ratio and weighted paths; with a side < 32 its bilinear emulation for enlarging axes); larger:
+ * CBH_E_UNSUPPORTED.  out[i] = 64-bit hash (bit 0 clear unless the hash would be 0 -> 1). */
 int cbh_dcthash_batch(const uint8_t* imgs, size_t n, int w, int h, size_t row_stride,
                       size_t img_stride, uint64_t* out, int device);
 int cbh_dcthash_batch_dev(const void* d_imgs, size_t n, int w, int h, size_t row_stride,
                           size_t img_stride, void* d_out, int device, void* stream);
+
+/* ---- keypoint hashes: replaces Media::makeKeyPointHashes(cvImg, keyPoints, outHashes) -- src/media.cpp:874-923,
+ * called per image from Scanner::processImage (src/scanner.cpp:888) to produce the DctFeaturesIndex rows.
+ * kp: (x, y, size) float triples = cv::KeyPoint::pt.x, pt.y, size; image i owns kp[3*kp_first[i] .. 3*kp_first[i+1]).
+ * A keypoint becomes the square Rect(floor x, floor y, ceil size) when size >= 31 and it lies inside the image as
+ * :887-894 tests; cbh_keypoint_rects is that rule alone (rects = x, y, s triples; returns their number).
+ * Each square is hashed with dctHash64(sub, inPlace = true), in keypoint order: a blurred square is written back into
+ * the image before the next (possibly overlapping) one is read, exactly like the reference's shared cv::Mat.
+ * Images: 8-bit grey, image i at imgs + img_off[i], img_w[i] x img_h[i], rows img_row_stride[i] bytes apart (sizes may
+ * differ per image; cbird scales to <= 400 px first, scanner.cpp:876).  out_first[i] = index of image i's first hash
+ * (n + 1 entries; out_first[n] = total <= kp_first[n], the capacity out_hashes needs).  imgs_after (NULL or imgs_bytes
+ * bytes) receives the images as the in-place blurs left them.  _dev: d_imgs is modified in place, d_out on the
+ * device, the descriptor arrays on the host; the call returns when the hashes are complete. */
+long long cbh_keypoint_rects(int cols, int rows, const float* kp, size_t nkp, int32_t* rects);
+/* The building block of the above, also the drop-in for dctHash64(view, inPlace) on arbitrary sub-rectangle views
+ * (cvImg.colRange(..).rowRange(..), src/media.cpp:908-910): rects = (x, y, w, h) int32 quadruples, image i owns
+ * rects[4*rect_first[i] .. 4*rect_first[i+1]) (rect_first[0] = 0), hashed in that order; out_hashes[j] belongs to
+ * rectangle j.  The blur takes the pixels around a rectangle from the parent image, as cv::blur does on a view.
+ * in_place != 0: each blurred rectangle is written back before the next is read (inPlace = true); 0: the image is
+ * left alone (inPlace = false on an 8UC1 view copies). */
+int cbh_dcthash_rects(const uint8_t* imgs, size_t imgs_bytes, size_t n, const uint64_t* img_off,
+                      const uint32_t* img_w, const uint32_t* img_h, const uint32_t* img_row_stride,
+                      const int32_t* rects, const uint32_t* rect_first, int in_place, uint64_t* out_hashes,
+                      uint8_t* imgs_after, int device);
+int cbh_keypoint_hashes(const uint8_t* imgs, size_t imgs_bytes, size_t n, const uint64_t* img_off,
+                        const uint32_t* img_w, const uint32_t* img_h, const uint32_t* img_row_stride,
+                        const float* kp, const uint32_t* kp_first, uint64_t* out_hashes, uint32_t* out_first,
+                        uint8_t* imgs_after, int device);
+int cbh_keypoint_hashes_dev(void* d_imgs, size_t n, const uint64_t* img_off, const uint32_t* img_w,
+                            const uint32_t* img_h, const uint32_t* img_row_stride, const float* kp,
+                            const uint32_t* kp_first, void* d_out, uint32_t* out_first, int device, void* stream);
 
 /* ---- the steps in front of dctHash64 in Scanner::processImage (src/scanner.cpp:852-862) -------------------
  * grayscale(): cv::cvtColor(BGR2GRAY/BGRA2GRAY) on 8-bit data (src/cvutil.cpp:1265-1283); d_gray is packed

@@ -216,6 +216,53 @@ class Oracle:
             raise ValueError(f"orc_dcthash64_batch rc={rc}")
         return o
 
+    # ---- Media::makeKeyPointHashes (src/media.cpp:874-923) ----
+    def keypoint_rects(self, cols, rows, kp):
+        kp = np.ascontiguousarray(kp, np.float32).reshape(-1, 3)
+        r = np.zeros((max(1, len(kp)), 3), np.int32)
+        f = self.L.orc_keypoint_rects
+        f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        f.restype = C.c_int
+        n = f(cols, rows, kp.ctypes.data, len(kp), r.ctypes.data)
+        return r[:n].copy()
+
+    def keypoint_hashes(self, img, kp):
+        """returns (hashes u64[], image after the in-place blurs)"""
+        img = np.ascontiguousarray(img, np.uint8).copy()
+        kp = np.ascontiguousarray(kp, np.float32).reshape(-1, 3)
+        h, w = img.shape
+        o = np.zeros(max(1, len(kp)), np.uint64)
+        f = self.L.orc_keypoint_hashes
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
+        f.restype = C.c_int
+        n = f(img.ctypes.data, w, h, w, kp.ctypes.data, len(kp), o.ctypes.data)
+        if n < 0:
+            raise ValueError(f"orc_keypoint_hashes rc={n}")
+        return o[:n].copy(), img
+
+    def dcthash64_rect_inplace(self, img, x, y, rw, rh):
+        """img (2-D u8, C-contiguous) is modified like cv::blur on the view would; returns the hash"""
+        assert img.dtype == np.uint8 and img.flags.c_contiguous
+        h, w = img.shape
+        o = np.zeros(1, np.uint64)
+        f = self.L.orc_dcthash64_rect_inplace
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t] + [C.c_int] * 4 + [C.c_void_p]
+        f.restype = C.c_int
+        rc = f(img.ctypes.data, w, h, w, x, y, rw, rh, o.ctypes.data)
+        if rc:
+            raise ValueError(f"orc_dcthash64_rect_inplace rc={rc}")
+        return int(o[0])
+
+    def resize_linear_tab(self, ssize, is_x):
+        ofs = np.zeros(32, np.int32)
+        c0 = np.zeros(32, np.int16)
+        c1 = np.zeros(32, np.int16)
+        f = self.L.orc_resize_linear_tab
+        f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        f.restype = None
+        f(ssize, int(is_x), ofs.ctypes.data, c0.ctypes.data, c1.ctypes.data)
+        return ofs, c0, c1
+
 
 _REF_QT_SO = os.path.join(_HERE, "_ref", "libcbird_ref_qt.so")
 

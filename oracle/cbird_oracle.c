@@ -20,6 +20,7 @@
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -mfma -mpopcnt).
  */
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -270,6 +271,20 @@ typedef struct {
   float alpha;
 } orc_dalpha;
 
+/* cv::resize derives the source/destination ratio as  inv_scale = (double)dsize/ssize;  scale = 1./inv_scale
+ * -- two roundings, not ssize/dsize -- and takes the integer "area fast" path only when
+ * |scale - saturate_cast<int>(scale)| < DBL_EPSILON on both axes.  The double rounding matters: for
+ * ssize = 32*m with m = 49, 93, 98, 99, 103, ... the reciprocal of the reciprocal misses m by one ulp, so those
+ * sizes go through the weighted tables; and for 3 widths up to 8192 (3885, 6734, 7770) a table weight changes. */
+static double cv_resize_scale(int ssize, int dsize) {
+  double inv_scale = (double)dsize / ssize;
+  return 1. / inv_scale;
+}
+int orc_resize_area_fast(int w, int h) {
+  double sx = cv_resize_scale(w, 32), sy = cv_resize_scale(h, 32);
+  return w >= 32 && h >= 32 && fabs(sx - (double)lrint(sx)) < DBL_EPSILON && fabs(sy - (double)lrint(sy)) < DBL_EPSILON;
+}
+
 static int resize_area_tab(int ssize, int dsize, double scale, orc_dalpha* tab) {
   int k = 0;
   for (int dx = 0; dx < dsize; dx++) {
@@ -304,7 +319,7 @@ static int resize_area_tab(int ssize, int dsize, double scale, orc_dalpha* tab) 
 /* exported for the stage tests: the tables themselves */
 int orc_resize_area_tab(int ssize, int dsize, int* si, int* di, float* alpha) {
   orc_dalpha* tab = (orc_dalpha*)malloc(sizeof(orc_dalpha) * (size_t)(ssize + 2 * dsize + 2));
-  int k = resize_area_tab(ssize, dsize, (double)ssize / dsize, tab);
+  int k = resize_area_tab(ssize, dsize, cv_resize_scale(ssize, dsize), tab);
   for (int i = 0; i < k; ++i) {
     si[i] = tab[i].si;
     di[i] = tab[i].di;
@@ -314,13 +329,85 @@ int orc_resize_area_tab(int ssize, int dsize, int* si, int* di, float* alpha) {
   return k;
 }
 
+/* cv::resize(..., INTER_AREA) when an axis ENLARGES (scale < 1 on either axis; here: a side shorter than 32, e.g.
+ * the 31-pixel keypoint rectangles of Media::makeKeyPointHashes).  "true area interpolation is only implemented
+ * for the case (scale_x >= 1 && scale_y >= 1); in other cases it is emulated using some variant of bilinear
+ * interpolation" (OpenCV 2.4 imgproc/imgwarp.cpp, as recalled -- "parity unpinned"): both axes then run the
+ * 2-tap fixed-point resizer with area-mode coefficients
+ *     s = floor(d*scale);  f = (float)((d+1) - (s+1)*inv_scale);  f = f <= 0 ? 0 : f - floor(f);
+ *     x only: if (s + 1 >= ssize) f = 0, s = ssize-1            (y: the two source rows are clipped to the image)
+ *     coefficients saturate_cast<short>((1-f)*2048), saturate_cast<short>(f*2048)            (cvRound: half-even)
+ *   horizontal: D = S[s]*a0 + S[s+1]*a1 (int)
+ *   vertical:   dst = (((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2 */
+typedef struct {
+  int ofs[32];
+  short c0[32], c1[32];
+} orc_lin_tab;
+
+static short sat_short_round(float v) {
+  long r = lrintf(v);
+  return (short)(r < -32768 ? -32768 : r > 32767 ? 32767 : r);
+}
+
+static void resize_linear_tab(int ssize, int is_x, orc_lin_tab* t) {
+  double inv_scale = (double)32 / ssize;
+  double scale = 1. / inv_scale;
+  for (int d = 0; d < 32; ++d) {
+    int s = (int)floor(d * scale);
+    float f = (float)((d + 1) - (s + 1) * inv_scale);
+    f = f <= 0 ? 0.f : f - floorf(f);
+    if (is_x && s + 1 >= ssize) {
+      f = 0.f;
+      s = ssize - 1;
+    }
+    t->ofs[d] = s;
+    t->c0[d] = sat_short_round((1.f - f) * 2048.f);
+    t->c1[d] = sat_short_round(f * 2048.f);
+  }
+}
+
+/* exported for the stage tests */
+void orc_resize_linear_tab(int ssize, int is_x, int* ofs, short* c0, short* c1) {
+  orc_lin_tab t;
+  resize_linear_tab(ssize, is_x, &t);
+  for (int d = 0; d < 32; ++d) {
+    ofs[d] = t.ofs[d];
+    c0[d] = t.c0[d];
+    c1[d] = t.c1[d];
+  }
+}
+
+static void resize_linear_area32_u8(const uint8_t* src, int w, int h, size_t stride, uint8_t* dst /*32*32*/) {
+  orc_lin_tab xt, yt;
+  resize_linear_tab(w, 1, &xt);
+  resize_linear_tab(h, 0, &yt);
+  for (int dy = 0; dy < 32; ++dy) {
+    int sy0 = yt.ofs[dy], sy1 = sy0 + 1;
+    sy0 = sy0 < 0 ? 0 : sy0 > h - 1 ? h - 1 : sy0;
+    sy1 = sy1 < 0 ? 0 : sy1 > h - 1 ? h - 1 : sy1;
+    const uint8_t* S0 = src + (size_t)sy0 * stride;
+    const uint8_t* S1 = src + (size_t)sy1 * stride;
+    for (int dx = 0; dx < 32; ++dx) {
+      int sx = xt.ofs[dx];
+      int sx1 = sx + 1 < w ? sx + 1 : w - 1; /* its coefficient is 0 there */
+      int D0 = S0[sx] * xt.c0[dx] + S0[sx1] * xt.c1[dx];
+      int D1 = S1[sx] * xt.c0[dx] + S1[sx1] * xt.c1[dx];
+      int v = (((yt.c0[dy] * (D0 >> 4)) >> 16) + ((yt.c1[dy] * (D1 >> 4)) >> 16) + 2) >> 2;
+      dst[dy * 32 + dx] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+    }
+  }
+}
+
 static int area_resize32_u8(const uint8_t* src, int w, int h, uint8_t* dst /*32*32*/) {
   if (w == 32 && h == 32) {
     memcpy(dst, src, 1024);
     return ORC_OK;
   }
-  if (w < 32 || h < 32) return ORC_E_UNSUPPORTED; /* upscaling falls to the bilinear path: not restated */
-  if ((w % 32) == 0 && (h % 32) == 0) {
+  if (w < 32 || h < 32) { /* an axis enlarges: the bilinear emulation, both axes */
+    resize_linear_area32_u8(src, w, h, (size_t)w, dst);
+    return ORC_OK;
+  }
+  if (orc_resize_area_fast(w, h)) {
     int sx = w / 32, sy = h / 32;
     float scale = 1.f / (float)(sx * sy);
     for (int y = 0; y < 32; ++y)
@@ -339,8 +426,8 @@ static int area_resize32_u8(const uint8_t* src, int w, int h, uint8_t* dst /*32*
   }
   orc_dalpha* xtab = (orc_dalpha*)malloc(sizeof(orc_dalpha) * (size_t)(w + 66));
   orc_dalpha* ytab = (orc_dalpha*)malloc(sizeof(orc_dalpha) * (size_t)(h + 66));
-  int xn = resize_area_tab(w, 32, (double)w / 32, xtab);
-  int yn = resize_area_tab(h, 32, (double)h / 32, ytab);
+  int xn = resize_area_tab(w, 32, cv_resize_scale(w, 32), xtab);
+  int yn = resize_area_tab(h, 32, cv_resize_scale(h, 32), ytab);
   float buf[32], sum[32];
   int prev_dy = ytab[0].di;
   for (int dx = 0; dx < 32; ++dx) sum[dx] = 0.f;
@@ -416,7 +503,6 @@ uint64_t orc_hash_from_tile32(const uint8_t* tile, float* coefs /*64 or NULL*/, 
 /* Full pipeline for one 8UC1 image.  Returns ORC_OK / ORC_E_*; hash in *out. */
 int orc_dcthash64(const uint8_t* img, int w, int h, size_t stride, uint64_t* out) {
   if (!img || w <= 0 || h <= 0 || stride < (size_t)w) return ORC_E_INVAL;
-  if (w < 32 || h < 32) return ORC_E_UNSUPPORTED;
   int k = orc_blur_ksize(w, h);
   uint8_t* blur = (uint8_t*)malloc((size_t)w * h);
   if (k)
@@ -452,6 +538,85 @@ int orc_dcthash64_batch(const uint8_t* imgs, size_t n, int w, int h, size_t row_
     if (rc != ORC_OK) return rc;
   }
   return ORC_OK;
+}
+
+/* ---- Media::makeKeyPointHashes: src/media.cpp:874-923 -----------------------------------------------
+ * Rectangles: keypoints with size >= 31 whose square (pt, pt + size) lies inside (0, cols-2) x (0, rows-2)
+ * (float comparisons, :887-894) become Rect(floor x, floor y, ceil size, ceil size) -- anchored at the keypoint,
+ * not centred on it (:896-900).  kp = (x, y, size) triples.  Returns the number of rectangles; rects = x,y,s. */
+int orc_keypoint_rects(int cols, int rows, const float* kp, int nkp, int* rects) {
+  int n = 0;
+  for (int i = 0; i < nkp; ++i) {
+    float size = kp[3 * i + 2];
+    if (size < 31) continue;
+    float x0 = kp[3 * i], y0 = kp[3 * i + 1];
+    float x1 = x0 + size, y1 = y0 + size;
+    if (x0 > 0 && y0 > 0 && x1 < cols - 2 && y1 < rows - 2) {
+      rects[3 * n] = (int)floorf(x0);
+      rects[3 * n + 1] = (int)floorf(y0);
+      rects[3 * n + 2] = (int)ceilf(size);
+      ++n;
+    }
+  }
+  return n;
+}
+
+/* cv::blur on a sub-rectangle VIEW of a larger image: the filter engine is not "isolated", it takes the pixels
+ * around the rectangle from the parent image (FilterEngine::start -> Mat::locateROI, OpenCV 2.4 filter.cpp, as
+ * recalled -- "parity unpinned") and applies BORDER_REFLECT_101 only at the parent's own edges. */
+static void box_blur_roi_u8(const uint8_t* parent, int W, int H, size_t stride, int x, int y, int rw, int rh, int k,
+                            uint8_t* dst /* rw*rh */) {
+  int r = k / 2, area = k * k;
+  for (int i = 0; i < rh; ++i)
+    for (int j = 0; j < rw; ++j) {
+      int s = 0;
+      for (int dy = -r; dy <= r; ++dy) {
+        const uint8_t* row = parent + (size_t)reflect101(y + i + dy, H) * stride;
+        for (int dx = -r; dx <= r; ++dx) s += row[reflect101(x + j + dx, W)];
+      }
+      dst[(size_t)i * rw + j] = (uint8_t)((2 * s + area) / (2 * area));
+    }
+}
+
+/* dctHash64(sub, inPlace = true) for one rectangle of `img` (cvutil.cpp:435-545 with :457-463: 8UC1 input is not
+ * copied, so cv::blur writes its result back into the caller's image -- the engine buffers source rows, the result
+ * is the blur of the pixels as they were before the call).  img is MODIFIED when the rectangle is blurred. */
+int orc_dcthash64_rect_inplace(uint8_t* img, int W, int H, size_t stride, int x, int y, int rw, int rh,
+                               uint64_t* out) {
+  if (!img || x < 0 || y < 0 || rw <= 0 || rh <= 0 || x + rw > W || y + rh > H) return ORC_E_INVAL;
+  int k = orc_blur_ksize(rw, rh);
+  uint8_t* sub = (uint8_t*)malloc((size_t)rw * rh);
+  if (k) {
+    box_blur_roi_u8(img, W, H, stride, x, y, rw, rh, k, sub);
+    for (int i = 0; i < rh; ++i) memcpy(img + (size_t)(y + i) * stride + x, sub + (size_t)i * rw, (size_t)rw);
+  } else {
+    for (int i = 0; i < rh; ++i) memcpy(sub + (size_t)i * rw, img + (size_t)(y + i) * stride + x, (size_t)rw);
+  }
+  uint8_t tile[1024];
+  int rc = area_resize32_u8(sub, rw, rh, tile);
+  free(sub);
+  if (rc != ORC_OK) return rc;
+  *out = orc_hash_from_tile32(tile, NULL, NULL);
+  return ORC_OK;
+}
+
+/* the whole of makeKeyPointHashes for one image: rectangles in keypoint order, each hashed in place, so a later
+ * rectangle sees the blurred pixels an earlier, overlapping one left behind (media.cpp:904-910).  Returns the
+ * number of hashes written (<= nkp) or a negative error. */
+int orc_keypoint_hashes(uint8_t* img, int W, int H, size_t stride, const float* kp, int nkp, uint64_t* out) {
+  if (!img || W <= 0 || H <= 0 || stride < (size_t)W || nkp < 0) return ORC_E_INVAL;
+  int* rects = (int*)malloc(sizeof(int) * 3 * (size_t)(nkp > 0 ? nkp : 1));
+  int n = orc_keypoint_rects(W, H, kp, nkp, rects);
+  for (int i = 0; i < n; ++i) {
+    int rc = orc_dcthash64_rect_inplace(img, W, H, stride, rects[3 * i], rects[3 * i + 1], rects[3 * i + 2],
+                                        rects[3 * i + 2], out + i);
+    if (rc != ORC_OK) {
+      free(rects);
+      return rc;
+    }
+  }
+  free(rects);
+  return n;
 }
 
 /* ---- DctFeaturesIndex::find: src/dctfeaturesindex.cpp:260-358 ---------------------------------

@@ -69,7 +69,8 @@ int main(int argc, char** argv) {
     MediaGroup g;
     for (int i = 0; i < n; ++i) {
       cv::Mat d(per, 32);
-      for (auto& b : d.data) b = uint8_t(rng());
+      for (int r = 0; r < d.rows; ++r)
+        for (int c = 0; c < d.cols; ++c) d.ptr<uint8_t>(r)[c] = uint8_t(rng());
       Media m("img", i + 1, 0);
       m.setKeyPointDescriptors(d);
       g.append(m);

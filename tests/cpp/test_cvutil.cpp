@@ -1,0 +1,62 @@
+// test_cvutil.cpp -- the dctHash64 / makeKeyPointHashes drop-ins (cbird_amd/cpp/gpu_cvutil.h) compiled against the
+// mock cv::Mat, run on the MI355X and compared with values the Python test passes in (computed by the oracle).
+//
+//   test_cvutil <w> <h> <seed> : builds the same pseudo-random image the Python side builds (xorshift bytes),
+//   prints one line per check:  name hash...
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+
+#include "index.h"
+#include "gpu_cvutil.h"
+
+static uint32_t xs(uint32_t& s) {
+  s ^= s << 13, s ^= s >> 17, s ^= s << 5;
+  return s;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 4) return 2;
+  const int w = atoi(argv[1]), h = atoi(argv[2]);
+  uint32_t seed = uint32_t(atoi(argv[3]));
+  cv::Mat img(h, w);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) img.ptr<uint8_t>(y)[x] = uint8_t(xs(seed) >> 24);
+
+  // 1. whole image, not in place: pixels untouched
+  cv::Mat copy(h, w);
+  for (int y = 0; y < h; ++y) memcpy(copy.ptr<uint8_t>(y), img.ptr<uint8_t>(y), size_t(w));
+  printf("whole %" PRIu64 "\n", cbird_gpu::gpuDctHash64(img));
+  for (int y = 0; y < h; ++y)
+    if (memcmp(copy.ptr<uint8_t>(y), img.ptr<uint8_t>(y), size_t(w))) return 3;
+
+  // 2. a view, not in place (blur sees the parent's pixels around it), then in place (pixels change)
+  const int vx = w / 5, vy = h / 4, vw = w / 2, vh = h / 2;
+  cv::Mat view = img.colRange(vx, vx + vw).rowRange(vy, vy + vh);
+  printf("view %" PRIu64 "\n", cbird_gpu::gpuDctHash64(view, false));
+  printf("view_inplace %" PRIu64 "\n", cbird_gpu::gpuDctHash64(view, true));
+  uint64_t sum = 0;
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) sum = sum * 1099511628211ull + img.ptr<uint8_t>(y)[x];
+  printf("after_view_checksum %" PRIu64 "\n", sum);
+
+  // 3. keypoint hashes on the (now partly blurred) image
+  KeyPointList kps;
+  for (int i = 0; i < 40; ++i) {
+    const float size = 31.f * (i % 4 == 0 ? 1.f : i % 4 == 1 ? 1.2f : i % 4 == 2 ? 1.44f : 2.0736f);
+    const float kx = float(xs(seed) % uint32_t(w)) + 0.25f;  // (two statements: argument evaluation order is unspecified)
+    const float ky = float(xs(seed) % uint32_t(h)) + 0.5f;
+    kps.push_back(cv::KeyPoint(kx, ky, size));
+  }
+  KeyPointHashList hashes;
+  hashes.push_back(42);  // appended to, not replaced
+  cbird_gpu::gpuMakeKeyPointHashes(img, kps, hashes);
+  printf("kp");
+  for (uint64_t v : hashes) printf(" %" PRIu64, v);
+  printf("\n");
+  sum = 0;
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) sum = sum * 1099511628211ull + img.ptr<uint8_t>(y)[x];
+  printf("after_kp_checksum %" PRIu64 "\n", sum);
+  return 0;
+}

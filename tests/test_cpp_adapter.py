@@ -42,3 +42,59 @@ def test_other_four_adapters_run_on_gpu(gpu, tmp_path):
                          timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "adapters ok" in out.stdout
+
+
+def test_cvutil_dropins_compile():
+    subprocess.check_call(["make", "-C", CPP, "-B", "test_cvutil"], stdout=subprocess.DEVNULL)
+    src = open(os.path.join(ROOT, "cbird_amd", "cpp", "gpu_cvutil.h")).read()
+    assert "gpuDctHash64(const cv::Mat& cvImg, bool inPlace = false)" in src
+    assert "gpuMakeKeyPointHashes(const cv::Mat& cvImg, const KeyPointList& keyPoints, KeyPointHashList& outHashes)" in src
+
+
+def _xorshift_stream(seed):
+    s = seed & 0xFFFFFFFF
+    while True:
+        s ^= (s << 13) & 0xFFFFFFFF
+        s ^= s >> 17
+        s ^= (s << 5) & 0xFFFFFFFF
+        yield s
+
+
+def _checksum(img):
+    v = 0
+    for b in img.reshape(-1).tolist():
+        v = (v * 1099511628211 + b) & 0xFFFFFFFFFFFFFFFF
+    return v
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,seed", [(200, 150, 7), (400, 300, 99)])
+def test_cvutil_dropins_run_on_gpu(gpu, orc, w, h, seed):
+    """gpuDctHash64 (whole image, view, view in place) and gpuMakeKeyPointHashes through the mock cv::Mat: the C++
+    program and this test build the same image; expected values come from the oracle"""
+    import numpy as np
+
+    subprocess.check_call(["make", "-C", CPP, "test_cvutil"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(CPP, "test_cvutil"), str(w), str(h), str(seed)], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = {ln.split()[0]: [int(x) for x in ln.split()[1:]] for ln in out.stdout.strip().splitlines()}
+    g = _xorshift_stream(seed)
+    img = np.array([next(g) >> 24 for _ in range(w * h)], np.uint8).reshape(h, w)
+    assert got["whole"] == [orc.dcthash64(img)]
+    vx, vy, vw, vh = w // 5, h // 4, w // 2, h // 2
+    work = img.copy()
+    view_hash = orc.dcthash64_rect_inplace(work, vx, vy, vw, vh)
+    assert got["view"] == [view_hash] and got["view_inplace"] == [view_hash]
+    assert view_hash != orc.dcthash64(img[vy:vy + vh, vx:vx + vw])  # an isolated copy reflects at its own border
+    assert got["after_view_checksum"] == [_checksum(work)]
+    kp = []
+    for i in range(40):
+        size = np.float32(31.0) * np.float32([1.0, 1.2, 1.44, 2.0736][i % 4])
+        x = np.float32(next(g) % w) + np.float32(0.25)
+        y = np.float32(next(g) % h) + np.float32(0.5)
+        kp.append([x, y, size])
+    want, after = orc.keypoint_hashes(work, np.array(kp, np.float32))
+    assert len(want) >= 5
+    assert got["kp"] == [42] + want.tolist()
+    assert got["after_kp_checksum"] == [_checksum(after)]

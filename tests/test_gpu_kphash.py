@@ -1,0 +1,118 @@
+"""Media::makeKeyPointHashes (src/media.cpp:874-923) and images with a side < 32 on the GPU (k_rect_hashes),
+bit-exact against the oracle: hashes AND the images as the in-place blurs leave them."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _keypoints(rng, w, h, k):
+    """ORB-like keypoints: sizes 31 * 1.2^level, positions anywhere (some fail the inside-image rule)"""
+    lv = rng.integers(0, 12, k)
+    size = (31.0 * 1.2 ** lv).astype(np.float32)
+    x = rng.uniform(-5, w, k).astype(np.float32)
+    y = rng.uniform(-5, h, k).astype(np.float32)
+    return np.stack([x, y, size], 1)
+
+
+def test_keypoint_rects_rule_matches_oracle(gpu, orc):
+    from cbird_amd.hashing import keypoint_rects
+
+    rng = np.random.default_rng(1)
+    for (w, h) in ((400, 300), (200, 150), (64, 64), (40, 500)):
+        kp = _keypoints(rng, w, h, 300)
+        kp[:20, 2] = rng.uniform(29, 33, 20).astype(np.float32)  # around the size >= 31 cut
+        assert (keypoint_rects(w, h, kp) == orc.keypoint_rects(w, h, kp)).all()
+    assert len(keypoint_rects(400, 300, np.zeros((0, 3), np.float32))) == 0
+
+
+def test_keypoint_hashes_match_oracle(gpu, orc):
+    """a batch of differently sized images, up to 400 keypoints each (scanner.h:70), overlapping squares of every
+    blur class (31 px: none and the bilinear 31 -> 32 resize; <= 64: 3x3; <= 128: 5x5; larger: 7x7; 32, 64 and
+    96-pixel squares for the copy / integer-block paths)"""
+    from cbird_amd.hashing import make_keypoint_hashes
+
+    rng = np.random.default_rng(2)
+    shapes = [(300, 400), (400, 267), (150, 200), (64, 64), (33, 500), (400, 400), (120, 90)]
+    images, kps = [], []
+    for i, (h, w) in enumerate(shapes):
+        yy, xx = np.mgrid[0:h, 0:w]
+        smooth = 128 + 60 * np.sin(xx / 17.0 + i) * np.cos(yy / 23.0) + rng.normal(0, 12, (h, w))
+        images.append(np.clip(smooth, 0, 255).astype(np.uint8))
+        kp = _keypoints(rng, w, h, 400 if i < 3 else 60)
+        kp[:6, 2] = [32.0, 64.0, 96.0, 31.0, 31.5, 128.0]
+        kp[:6, :2] = rng.uniform(1, 20, (6, 2)).astype(np.float32)
+        kps.append(kp)
+    kps[3] = kps[3][:0]  # an image without keypoints
+    got, after = make_keypoint_hashes(images, kps, return_images=True)
+    n_hashes = 0
+    for i in range(len(images)):
+        want, want_img = orc.keypoint_hashes(images[i], kps[i])
+        assert len(got[i]) == len(want), i
+        assert (got[i] == want).all(), (i, np.nonzero(got[i] != want)[0][:5])
+        assert (after[i] == want_img).all(), i
+        n_hashes += len(want)
+    assert n_hashes > 300 and len(got[3]) == 0
+    # without return_images the same hashes
+    again = make_keypoint_hashes(images, kps)
+    assert all((a == b).all() for a, b in zip(again, got))
+
+
+def test_keypoint_hashes_order_dependence(gpu, orc):
+    """two overlapping squares: swapping them changes the result the same way it does in the oracle"""
+    from cbird_amd.hashing import make_keypoint_hashes
+
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (200, 200), dtype=np.uint8)
+    kp = np.array([[10.2, 12.7, 53.6], [30.0, 33.0, 64.3], [20.0, 20.0, 134.0]], np.float32)
+    for order in ([0, 1, 2], [2, 1, 0], [1, 2, 0]):
+        got = make_keypoint_hashes([img], [kp[order]])[0]
+        want, _ = orc.keypoint_hashes(img, kp[order])
+        assert (got == want).all(), order
+    a = make_keypoint_hashes([img], [kp])[0]
+    b = make_keypoint_hashes([img], [kp[[2, 1, 0]]])[0]
+    assert sorted(a.tolist()) != sorted(b.tolist())
+
+
+def test_keypoint_hashes_many_images(gpu, orc):
+    """more images than workgroups in one launch (grid-stride over images), sampled against the oracle"""
+    from cbird_amd.hashing import make_keypoint_hashes
+
+    rng = np.random.default_rng(4)
+    n = 2500
+    images = [rng.integers(0, 256, (int(rng.integers(40, 90)), int(rng.integers(40, 90))), dtype=np.uint8)
+              for _ in range(n)]
+    kps = [_keypoints(rng, im.shape[1], im.shape[0], 6) for im in images]
+    for k in kps:
+        k[:, 2] = rng.choice([31.0, 32.0, 37.2], len(k)).astype(np.float32)
+        k[:, :2] = rng.uniform(0.5, 8, (len(k), 2)).astype(np.float32)
+    got = make_keypoint_hashes(images, kps)
+    assert sum(len(g) for g in got) > n
+    for i in list(range(0, n, 97)) + [n - 1]:
+        want, _ = orc.keypoint_hashes(images[i], kps[i])
+        assert (got[i] == want).all(), i
+
+
+def test_small_images_bilinear_path(gpu, orc):
+    """a side < 32: cv::resize(INTER_AREA) enlarges and runs its bilinear emulation; hashes and tiles"""
+    import torch
+
+    from cbird_amd import _lib
+
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    for (w, h) in ((31, 31), (16, 16), (1, 1), (5, 31), (31, 5), (20, 100), (100, 20), (31, 32), (32, 31), (8, 4000),
+                   (24, 24), (2, 2)):
+        n = 5
+        imgs = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+        want = orc.dcthash64_batch(imgs)
+        assert (gpu.dct_hash64_batch(imgs) == want).all(), (w, h)
+        d = torch.from_numpy(imgs).cuda()
+        out = torch.zeros(n, dtype=torch.int64, device="cuda")
+        tiles = torch.zeros((n, 32, 32), dtype=torch.uint8, device="cuda")
+        _lib.check(L.cbh_dcthash_tiles_dev(d.data_ptr(), n, w, h, w, w * h, out.data_ptr(), tiles.data_ptr(), 0, None),
+                   "tiles")
+        t = tiles.cpu().numpy()
+        for i in range(n):
+            assert (t[i] == orc.tile32(imgs[i])).all(), (w, h, i)
+        assert (out.cpu().numpy().view(np.uint64) == want).all()

@@ -199,6 +199,28 @@ def test_area_tables_cover_every_source_pixel_with_unit_weight(orc):
         assert np.allclose(cover, 1.0, atol=2e-3)  # the 1e-3 cut-off of the reference drops slivers
 
 
+def test_resize_scale_double_rounding(orc):
+    """cv::resize computes scale = 1./((double)32/w): for w = 32*m with m in {49, 93, 98, ...} that is not m, so the
+    integer block path (|scale - round(scale)| < DBL_EPSILON) is not taken; the weighted tables then still
+    describe the same block mean"""
+    import ctypes as C
+    import sys
+
+    f = orc.L.orc_resize_area_fast
+    f.argtypes = [C.c_int, C.c_int]
+    f.restype = C.c_int
+    odd = [m for m in range(1, 257) if abs(1.0 / (32.0 / (32 * m)) - m) >= sys.float_info.epsilon]
+    assert odd[:5] == [49, 93, 98, 99, 103]
+    for m in range(1, 257):
+        assert f(32 * m, 32 * m) == (0 if m in odd else 1), m
+    assert f(256, 256) == 1 and f(256, 1568) == 0 and f(100, 64) == 0 and f(33, 33) == 0
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (1568, 1568), dtype=np.uint8)
+    b = orc.box_blur(img, 7)
+    mean = b.reshape(32, 49, 32, 49).astype(np.float64).mean(axis=(1, 3))
+    assert np.abs(orc.tile32(img).astype(np.float64) - mean).max() <= 0.5 + 1e-3
+
+
 def test_general_area_resize_is_the_rounded_area_mean(orc):
     rng = np.random.default_rng(12)
     for h, w in ((100, 100), (33, 47), (400, 600), (255, 256)):
@@ -238,6 +260,78 @@ def test_hash_is_scale_stable(orc):
         assert orc.hamm64(big, half) < 5
 
 
-def test_unsupported_geometry_is_an_error(orc):
-    with pytest.raises(ValueError):
-        orc.dcthash64(np.zeros((20, 100), np.uint8))  # < 32: bilinear upscale path, not restated
+def test_small_images_take_the_bilinear_emulation(orc):
+    """a side shorter than 32 enlarges: cv::resize(INTER_AREA) runs its 2-tap fixed-point resizer with area-mode
+    coefficients.  Checks of the restated tables and arithmetic: coefficients sum to 2048, offsets stay inside the
+    source, a constant image stays constant, 16 -> 32 duplicates pixels, and 31 -> 32 stays within one grey level
+    of true bilinear-area weights."""
+    for ssize in list(range(1, 32)) + [40, 100]:
+        for is_x in (0, 1):
+            ofs, c0, c1 = orc.resize_linear_tab(ssize, is_x)
+            assert (c0.astype(int) + c1 == 2048).all()
+            assert (ofs >= 0).all() and (ofs <= ssize - 1).all() and (np.diff(ofs) >= 0).all()
+            if is_x:
+                assert (c1[ofs == ssize - 1] == 0).all()
+    rng = np.random.default_rng(3)
+    for h, w in ((31, 31), (20, 100), (100, 20), (1, 1), (5, 31), (16, 16)):
+        assert (orc.tile32(np.full((h, w), 77, np.uint8)) == 77).all()
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        t = orc.tile32(img)  # no blur below 32*32 pixels; (20,100) and (100,20) blur 3x3 first
+        assert t.shape == (32, 32)
+        assert orc.dcthash64(img) == orc.hash_from_tile32(t)
+    img = rng.integers(0, 256, (16, 16), dtype=np.uint8)
+    assert (orc.tile32(img) == np.repeat(np.repeat(img, 2, 0), 2, 1)).all()  # f = 0 everywhere: pixel doubling
+    img = rng.integers(0, 256, (31, 31), dtype=np.uint8)
+    ofs, c0, c1 = orc.resize_linear_tab(31, 1)
+    wx = np.zeros((32, 31))
+    for d in range(32):
+        wx[d, ofs[d]] += c0[d] / 2048
+        wx[d, min(30, ofs[d] + 1)] += c1[d] / 2048
+    assert np.abs(orc.tile32(img).astype(float) - wx @ img.astype(float) @ wx.T).max() <= 1.0
+
+
+def test_keypoint_rects_rule(orc):
+    """media.cpp:882-901: size >= 31, strictly inside (0, cols-2) x (0, rows-2), Rect(floor, floor, ceil)"""
+    kp = np.array([[10.5, 20.25, 31.0],    # kept: (10, 20, 31)
+                   [10.5, 20.25, 30.99],   # too small
+                   [0.0, 5.0, 31.0],       # x0 > 0 fails
+                   [5.0, 0.0, 40.0],       # y0 > 0 fails
+                   [100.0, 50.0, 37.2],    # kept: ceil -> 38
+                   [160.0, 50.0, 38.0],    # x1 = 198 < 198 fails (cols = 200)
+                   [159.9, 50.0, 38.0],    # kept
+                   [50.0, 110.0, 38.0],    # y1 = 148 < 148 fails (rows = 150)
+                   ], np.float32)
+    r = orc.keypoint_rects(200, 150, kp)
+    assert r.tolist() == [[10, 20, 31], [100, 50, 38], [159, 50, 38]]
+
+
+def test_keypoint_hashes_are_sequential_and_in_place(orc):
+    """dctHash64(sub, inPlace=true): a blurred rectangle is written back, later overlapping rectangles see it; the
+    blur takes its border pixels from the parent image, not by reflection at the rectangle's edge"""
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (150, 200), dtype=np.uint8)
+    kp = np.array([[20.3, 30.7, 44.6], [30.0, 40.0, 53.6], [100.2, 20.1, 31.0], [25.0, 35.0, 37.2],
+                   [60.0, 10.0, 134.0]], np.float32)
+    hashes, after = orc.keypoint_hashes(img, kp)
+    assert len(hashes) == 5
+    # replay by hand with the single-rectangle entry point
+    work = img.copy()
+    want = [orc.dcthash64_rect_inplace(work, x, y, s, s) for x, y, s in orc.keypoint_rects(200, 150, kp).tolist()]
+    assert hashes.tolist() == want and (work == after).all()
+    # the 31-pixel rectangle is not blurred (area <= 32*32), the others are: their pixels changed
+    _, after4 = orc.keypoint_hashes(img, kp[:4])  # (the fifth, large rectangle covers that one)
+    assert (after4[20:51, 100:131] == img[20:51, 100:131]).all()
+    assert (after4[30:75, 20:65] != img[30:75, 20:65]).any()
+    # order matters (overlap), and the first rectangle's hash differs from hashing an isolated copy of it,
+    # because the isolated copy reflects at its own border
+    h_rev, _ = orc.keypoint_hashes(img, kp[[1, 0, 2, 3, 4]])
+    assert sorted(h_rev.tolist()) != sorted(hashes.tolist())
+    x, y, s = 20, 30, 45
+    direct = orc.box_blur(img, 3)[y:y + s, x:x + s]  # blur of the whole image = parent neighbours for interior rects
+    assert (after_first_rect(orc, img, x, y, s) == direct).all()
+
+
+def after_first_rect(orc, img, x, y, s):
+    work = img.copy()
+    orc.dcthash64_rect_inplace(work, x, y, s, s)
+    return work[y:y + s, x:x + s]
