@@ -58,6 +58,7 @@ void set_scan256_pre(int on);  // first-128-bit prefilter variant (default on)
 void set_scan256_mfma(int on);  // <0 = keep; 2 = force for any size
 
 int g_hash_mfma_set(int v);  // dcthash.hip
+void set_kp_lds_side(int v);    // dcthash.hip: largest keypoint square processed in LDS (default 134)
 void set_hash_fast_any(int on);  // dcthash.hip: fast kernels for geometries other than 256x256 (default on)
 void set_color_pk(int on);   // color.hip: packed-f32 distance kernel (default on)
 
@@ -84,6 +85,9 @@ struct RectImageDesc {
   unsigned row_stride;
   unsigned first, count;   // its rectangles: rects[4*first .. 4*(first+count))
 };
+int launch_keypoint_hashes(uint8_t* d_base, size_t n, const uint64_t* img_off, const uint32_t* img_w,
+                           const uint32_t* img_h, const uint32_t* img_row_stride, const float* kp,
+                           const uint32_t* kp_first, uint64_t* d_out, uint32_t* out_first, hipStream_t stream);
 int launch_rect_hashes(uint8_t* d_base, const std::vector<RectImageDesc>& images, const std::vector<int>& rects,
                        int write_back, uint64_t* d_out, hipStream_t stream, uint8_t* d_tiles = nullptr);
 

@@ -158,41 +158,6 @@ long long cbh_keypoint_rects(int cols, int rows, const float* kp, size_t nkp, in
   return n;
 }
 
-namespace {
-
-// descriptors -> launch_rect_hashes inputs; out_first[i] = first hash of image i, out_first[n] = total
-int keypoint_jobs(size_t n, const uint64_t* img_off, const uint32_t* img_w, const uint32_t* img_h,
-                  const uint32_t* img_row_stride, const float* kp, const uint32_t* kp_first, uint32_t* out_first,
-                  std::vector<cbh::RectImageDesc>* images, std::vector<int>* rects) {
-  images->resize(n);
-  std::vector<int32_t> tmp;
-  size_t total = 0;
-  for (size_t i = 0; i < n; ++i) {
-    if (kp_first[i + 1] < kp_first[i] || img_w[i] == 0 || img_h[i] == 0 || img_w[i] > 8192 || img_h[i] > 8192 ||
-        img_row_stride[i] < img_w[i])
-      return CBH_E_INVAL;
-    const size_t nk = kp_first[i + 1] - kp_first[i];
-    tmp.resize(3 * std::max<size_t>(nk, 1));
-    const long long m = cbh_keypoint_rects((int)img_w[i], (int)img_h[i], kp + 3 * (size_t)kp_first[i], nk, tmp.data());
-    if (m < 0) return (int)m;
-    if (total + (size_t)m > 0xffffffffull) return CBH_E_INVAL;
-    (*images)[i] = cbh::RectImageDesc{img_off[i], (int)img_w[i], (int)img_h[i], img_row_stride[i], (unsigned)total,
-                                      (unsigned)m};
-    out_first[i] = (uint32_t)total;
-    for (long long r = 0; r < m; ++r) {
-      rects->push_back(tmp[3 * r]);
-      rects->push_back(tmp[3 * r + 1]);
-      rects->push_back(tmp[3 * r + 2]);
-      rects->push_back(tmp[3 * r + 2]);
-    }
-    total += (size_t)m;
-  }
-  out_first[n] = (uint32_t)total;
-  return CBH_OK;
-}
-
-}  // namespace
-
 int cbh_keypoint_hashes_dev(void* d_imgs, size_t n, const uint64_t* img_off, const uint32_t* img_w,
                             const uint32_t* img_h, const uint32_t* img_row_stride, const float* kp,
                             const uint32_t* kp_first, void* d_out, uint32_t* out_first, int device, void* stream) {
@@ -204,13 +169,14 @@ int cbh_keypoint_hashes_dev(void* d_imgs, size_t n, const uint64_t* img_off, con
   }
   if (!d_imgs || !img_off || !img_w || !img_h || !img_row_stride || !kp_first || (kp_first[n] && !kp) || !d_out)
     return CBH_E_INVAL;
-  std::vector<cbh::RectImageDesc> images;
-  std::vector<int> rects;
-  int rc = keypoint_jobs(n, img_off, img_w, img_h, img_row_stride, kp, kp_first, out_first, &images, &rects);
-  if (rc) return rc;
+  for (size_t i = 0; i < n; ++i)
+    if (kp_first[i + 1] < kp_first[i] || img_w[i] == 0 || img_h[i] == 0 || img_w[i] > 8192 || img_h[i] > 8192 ||
+        img_row_stride[i] < img_w[i])
+      return CBH_E_INVAL;
   DeviceGuard g(device);
   if (!g.ok) return CBH_E_NODEVICE;
-  return launch_rect_hashes((uint8_t*)d_imgs, images, rects, 1, (uint64_t*)d_out, (hipStream_t)stream);
+  return launch_keypoint_hashes((uint8_t*)d_imgs, n, img_off, img_w, img_h, img_row_stride, kp, kp_first,
+                                (uint64_t*)d_out, out_first, (hipStream_t)stream);
 }
 
 namespace {
@@ -280,11 +246,39 @@ int cbh_keypoint_hashes(const uint8_t* imgs, size_t imgs_bytes, size_t n, const 
   if (!imgs || !img_off || !img_w || !img_h || !img_row_stride || !kp_first || (kp_first[n] && !kp)) return CBH_E_INVAL;
   int rc = check_images(n, imgs_bytes, img_off, img_w, img_h, img_row_stride);
   if (rc) return rc;
-  std::vector<cbh::RectImageDesc> images;
-  std::vector<int> rects;
-  rc = keypoint_jobs(n, img_off, img_w, img_h, img_row_stride, kp, kp_first, out_first, &images, &rects);
-  if (rc) return rc;
-  return rect_hashes_host(imgs, imgs_bytes, images, rects, 1, out_hashes, imgs_after, device);
+  for (size_t i = 0; i < n; ++i)
+    if (kp_first[i + 1] < kp_first[i]) return CBH_E_INVAL;
+  const size_t nkp = kp_first[n];
+  if (nkp && !out_hashes) return CBH_E_INVAL;
+  DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  uint8_t* d_imgs = nullptr;
+  uint64_t* d_out = nullptr;
+  hipStream_t s = nullptr;
+  hipError_t e;
+  if ((e = hipMalloc(&d_imgs, imgs_bytes)) != hipSuccess ||
+      (e = hipMalloc(&d_out, std::max<size_t>(nkp, 1) * sizeof(uint64_t))) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipMemcpyAsync(d_imgs, imgs, imgs_bytes, hipMemcpyHostToDevice, s)) != hipSuccess) {
+    set_last_error("keypoint_hashes setup", e);
+    rc = e == hipErrorOutOfMemory ? CBH_E_NOMEM : CBH_E_HIP;
+  }
+  if (rc == CBH_OK)
+    rc = launch_keypoint_hashes(d_imgs, n, img_off, img_w, img_h, img_row_stride, kp, kp_first, d_out, out_first, s);
+  if (rc == CBH_OK) {
+    const size_t total = out_first[n];
+    if ((total && (e = hipMemcpyAsync(out_hashes, d_out, total * sizeof(uint64_t), hipMemcpyDeviceToHost, s)) !=
+                      hipSuccess) ||
+        (imgs_after && (e = hipMemcpyAsync(imgs_after, d_imgs, imgs_bytes, hipMemcpyDeviceToHost, s)) != hipSuccess) ||
+        (e = hipStreamSynchronize(s)) != hipSuccess) {
+      set_last_error("keypoint_hashes D2H", e);
+      rc = CBH_E_HIP;
+    }
+  }
+  if (s) (void)hipStreamDestroy(s);
+  if (d_imgs) (void)hipFree(d_imgs);
+  if (d_out) (void)hipFree(d_out);
+  return rc;
 }
 
 int cbh_dcthash_rects(const uint8_t* imgs, size_t imgs_bytes, size_t n, const uint64_t* img_off,
@@ -683,6 +677,10 @@ int cbh_set_tuning(const char* key, int value) {
   }
   if (!strcmp(key, "scan_mfma")) {
     set_scan_mfma(value);
+    return CBH_OK;
+  }
+  if (!strcmp(key, "kp_lds_side")) {
+    set_kp_lds_side(value);
     return CBH_OK;
   }
   if (!strcmp(key, "hash_fast_any")) {

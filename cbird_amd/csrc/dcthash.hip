@@ -51,44 +51,76 @@ __device__ __forceinline__ int reflect101(int p, int len) {
   return p;
 }
 
-// stages 3-6 from a 32x32 u8 tile in LDS; all 256 threads of the workgroup participate.
+// stages 3-6 from a 32x32 u8 tile in LDS; all 256 threads of the workgroup participate (kThreads == 256).  tile and
+// sC must be 16-byte aligned.  The arithmetic (and its order) is orc_hash_from_tile32's: row pass fmaf over j
+// ascending, column pass fmaf over r ascending, the 64 selected coefficients summed in double in index order.
 __device__ __forceinline__ void hash_from_tile(const unsigned char* __restrict__ tile /*LDS*/,
                                                const float* __restrict__ sC /*LDS 288*/,
                                                const unsigned char* __restrict__ sZ /*LDS 64*/,
                                                float* __restrict__ sT /*LDS 288*/,
                                                float* __restrict__ sY /*LDS 81*/,
-                                               float* __restrict__ sThr /*LDS 1*/,
                                                uint64_t* __restrict__ out) {
   const int tid = threadIdx.x;
-  // row pass: 288 outputs (r,k)
-  for (int o = tid; o < 288; o += kThreads) {
-    const int r = o / 9, k = o - r * 9;
+  {
+    // row pass, 288 outputs (r,k): lane -> row r = tid/8 and k = tid%8; the lanes with k == 0 also do k = 8.
+    // The row's 32 pixels arrive as two 16-byte LDS reads, the basis row as eight.
+    const int r = tid >> 3, k = tid & 7;
+    const uint4* trow = reinterpret_cast<const uint4*>(tile + r * 32);
+    const uint4 p0 = trow[0], p1 = trow[1];
+    const unsigned px[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+    const float4* ck = reinterpret_cast<const float4*>(sC + k * 32);
     float acc = 0.f;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) acc = __builtin_fmaf((float)tile[r * 32 + j], sC[k * 32 + j], acc);
+    for (int q = 0; q < 8; ++q) {
+      const float4 c = ck[q];
+      acc = __builtin_fmaf((float)(px[q] & 0xffu), c.x, acc);
+      acc = __builtin_fmaf((float)((px[q] >> 8) & 0xffu), c.y, acc);
+      acc = __builtin_fmaf((float)((px[q] >> 16) & 0xffu), c.z, acc);
+      acc = __builtin_fmaf((float)(px[q] >> 24), c.w, acc);
+    }
     sT[r * 9 + k] = acc;
+    if (k == 0) {
+      const float4* c8 = reinterpret_cast<const float4*>(sC + 8 * 32);
+      float acc8 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 c = c8[q];
+        acc8 = __builtin_fmaf((float)(px[q] & 0xffu), c.x, acc8);
+        acc8 = __builtin_fmaf((float)((px[q] >> 8) & 0xffu), c.y, acc8);
+        acc8 = __builtin_fmaf((float)((px[q] >> 16) & 0xffu), c.z, acc8);
+        acc8 = __builtin_fmaf((float)(px[q] >> 24), c.w, acc8);
+      }
+      sT[r * 9 + 8] = acc8;
+    }
   }
   __syncthreads();
   if (tid < 81) {
     const int u = tid / 9, k = tid - u * 9;
+    const float4* cu = reinterpret_cast<const float4*>(sC + u * 32);
     float acc = 0.f;
 #pragma unroll
-    for (int r = 0; r < 32; ++r) acc = __builtin_fmaf(sC[u * 32 + r], sT[r * 9 + k], acc);
+    for (int q = 0; q < 8; ++q) {
+      const float4 c = cu[q];
+      acc = __builtin_fmaf(c.x, sT[(4 * q) * 9 + k], acc);
+      acc = __builtin_fmaf(c.y, sT[(4 * q + 1) * 9 + k], acc);
+      acc = __builtin_fmaf(c.z, sT[(4 * q + 2) * 9 + k], acc);
+      acc = __builtin_fmaf(c.w, sT[(4 * q + 3) * 9 + k], acc);
+    }
     sY[tid] = acc;
   }
   __syncthreads();
-  if (tid == 0) {
-    double sum = 0.0;
-    for (int i = 0; i < 64; ++i) sum += (double)sY[sZ[i]];
-    *sThr = (float)sum / 64;
-  }
-  __syncthreads();
-  if (tid < 64) {
+  if (tid < 64) {  // wave 0: lane i holds selected coefficient i; the ordered double sum runs on broadcast lanes
     const float c = sY[sZ[tid]];
-    const unsigned long long b = __ballot(tid >= 1 && c > *sThr);
+    const int cb = __builtin_bit_cast(int, c);
+    double sum = 0.0;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) sum += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(cb, i));
+    const float thr = (float)sum / 64;
+    const unsigned long long b = __ballot(tid >= 1 && c > thr);
     if (tid == 0) *out = b ? b : 1ull;
   }
 }
+
 
 template <int K>
 __global__ __launch_bounds__(kThreads) void k_dcthash_generic(
@@ -103,7 +135,7 @@ __global__ __launch_bounds__(kThreads) void k_dcthash_generic(
   float* sC = reinterpret_cast<float*>(smem);                 // 288 f32
   float* sT = sC + 288;                                        // 288 f32
   float* sY = sT + 288;                                        // 81 f32 (+3 pad)
-  float* sThr = sY + 84;                                       // 1 f32 (+3 pad)
+  float* sThr = sY + 84;                                       // (unused, keeps the carve-up)
   unsigned int* colsum = reinterpret_cast<unsigned int*>(sThr + 4);  // w u32
   unsigned char* tile = reinterpret_cast<unsigned char*>(colsum + w);  // 1024 u8
   unsigned char* sZ = tile + 1024;                                      // 64 u8
@@ -165,7 +197,7 @@ __global__ __launch_bounds__(kThreads) void k_dcthash_generic(
   }
   if (tiles)
     for (int i = tid; i < 1024; i += kThreads) tiles[(size_t)blockIdx.x * 1024 + i] = tile[i];
-  hash_from_tile(tile, sC, sZ, sT, sY, sThr, out + blockIdx.x);
+  hash_from_tile(tile, sC, sZ, sT, sY, out + blockIdx.x);
 }
 
 
@@ -690,8 +722,8 @@ __global__ __launch_bounds__(kThreads) void k_area_hash(const unsigned char* __r
                                                         const DctTables* __restrict__ tabs,
                                                         uint64_t* __restrict__ out,
                                                         unsigned char* __restrict__ tiles) {
-  __shared__ float sC[288], sT[288], sY[84], sThr[4];
-  __shared__ unsigned char tile[1024], sZ[64];
+  __shared__ __attribute__((aligned(16))) float sC[288], sT[288], sY[84];
+  __shared__ __attribute__((aligned(16))) unsigned char tile[1024], sZ[64];
   const int tid = threadIdx.x;
   const unsigned char* src = blur + (size_t)blockIdx.x * (size_t)w * h;
   for (int i = tid; i < 288; i += kThreads) sC[i] = tabs->C[i];
@@ -722,7 +754,7 @@ __global__ __launch_bounds__(kThreads) void k_area_hash(const unsigned char* __r
   __syncthreads();
   if (tiles)
     for (int i = tid; i < 1024; i += kThreads) tiles[(size_t)blockIdx.x * 1024 + i] = tile[i];
-  hash_from_tile(tile, sC, sZ, sT, sY, sThr, out + blockIdx.x);
+  hash_from_tile(tile, sC, sZ, sT, sY, out + blockIdx.x);
 }
 
 
@@ -947,8 +979,8 @@ __global__ __launch_bounds__(kThreads) void k_tile_hash(const float* __restrict_
                                                         const DctTables* __restrict__ tabs,
                                                         uint64_t* __restrict__ out,
                                                         unsigned char* __restrict__ tiles) {
-  __shared__ float sC[288], sT[288], sY[84], sThr[4];
-  __shared__ unsigned char tile[1024], sZ[64];
+  __shared__ __attribute__((aligned(16))) float sC[288], sT[288], sY[84];
+  __shared__ __attribute__((aligned(16))) unsigned char tile[1024], sZ[64];
   const int tid = threadIdx.x;
   const float* __restrict__ R = rows + (size_t)blockIdx.x * (size_t)yn * 32;
   for (int i = tid; i < 288; i += kThreads) sC[i] = tabs->C[i];
@@ -975,7 +1007,7 @@ __global__ __launch_bounds__(kThreads) void k_tile_hash(const float* __restrict_
   __syncthreads();
   if (tiles)
     for (int i = tid; i < 1024; i += kThreads) tiles[(size_t)blockIdx.x * 1024 + i] = tile[i];
-  hash_from_tile(tile, sC, sZ, sT, sY, sThr, out + blockIdx.x);
+  hash_from_tile(tile, sC, sZ, sT, sY, out + blockIdx.x);
 }
 
 size_t generic_smem_bytes(int w, int h, int K) {
@@ -1060,8 +1092,8 @@ __global__ __launch_bounds__(kThreads) void k_rect_hashes(unsigned char* __restr
                                                           const DctTables* __restrict__ tabs, int write_back,
                                                           uint64_t* __restrict__ out,
                                                           unsigned char* __restrict__ tiles) {
-  __shared__ float sC[288], sT[288], sY[84], sThr[4];
-  __shared__ unsigned char tile[1024], sZ[64];
+  __shared__ __attribute__((aligned(16))) float sC[288], sT[288], sY[84];
+  __shared__ __attribute__((aligned(16))) unsigned char tile[1024], sZ[64];
   const int tid = threadIdx.x;
   for (int i = tid; i < 288; i += kThreads) sC[i] = tabs->C[i];
   if (tid < 64) sZ[tid] = tabs->zz[tid];
@@ -1134,9 +1166,293 @@ __global__ __launch_bounds__(kThreads) void k_rect_hashes(unsigned char* __restr
       __syncthreads();
       if (tiles)
         for (int i = tid; i < 1024; i += kThreads) tiles[(size_t)(I.first + r) * 1024 + i] = tile[i];
-      hash_from_tile(tile, sC, sZ, sT, sY, sThr, out + I.first + r);
+      hash_from_tile(tile, sC, sZ, sT, sY, out + I.first + r);
       __syncthreads();  // tile / sT / sY are reused, and the written-back pixels are in place for the next rectangle
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// makeKeyPointHashes proper: the rectangle rule of media.cpp:880-901 evaluated on the device from the keypoints
+// themselves (no per-rectangle descriptors cross PCIe), squares up to `lds_side` pixels staged in LDS:
+//   A  the square plus its blur halo is copied from the image into LDS once (REFLECT_101 at the image's edges
+//      resolved while loading); the resize table of this side length is cached in LDS until the side changes
+//   B  K x K box blur from LDS to LDS (a lane per column and row segment, sliding K-row sums)
+//   C  the blurred square goes back to the image (stores only) while the 32x32 tile is formed from LDS
+//   D  hash_from_tile
+// One global round trip per rectangle instead of one per dependent table / pixel access; what remains serial is what
+// the reference makes serial (a rectangle sees the blurred pixels of the ones before it).  Larger squares take the
+// global-memory routine of k_rect_hashes.  Hashes of image i land at out[kp_first[i] + 0, 1, ...]; counts[i] = how many.
+struct KpImage {
+  unsigned long long off;
+  int w, h;
+  unsigned row_stride;
+  unsigned kp_first, kp_count;
+};
+struct SizeInfo {  // per side length s (index s): how a s x s square is reduced to 32 x 32
+  int mode;        // 0 copy, 1 integer blocks (s / 32), 2 area table, 3 bilinear emulation, -1: no table uploaded
+  int tab_off, n;  // mode 2: AreaTab pool offset and entry count
+  int aux_off;     // mode 2: first[33] in the int pool; mode 3: x table (96 ints) followed by the y table (96 ints)
+};
+
+template <int K>
+__device__ __forceinline__ void blur_lds8(const unsigned char* __restrict__ reg, int P, int s,
+                                          unsigned char* __restrict__ dst, int Pb) {
+  // reg: (s + K - 1) rows, pitch P (a multiple of 8, >= 8 * ceil(s / 8) + 8); LDS column c holds the square's column
+  // c - 4, halo included.  Like k_blur_rows: a lane owns 8 adjacent columns, reads a 16-byte window per row, forms the
+  // K-tap sums with v_dot4_u32_u8 against byte masks and slides packed-u16 column sums down its row segment.
+  // dst: s rows, pitch Pb = 8 * ceil(s / 8).
+  constexpr int R = K / 2;
+  const int L = (s + 7) >> 3;
+  const int nseg = min(s, max(1, kThreads / L));
+  const int rps = (s + nseg - 1) / nseg;
+  for (int it = (int)threadIdx.x; it < L * nseg; it += kThreads) {
+    const int g = it / L, l = it - g * L;
+    const int r0 = g * rps, r1 = min(s, r0 + rps);
+    if (r0 >= r1) continue;
+    unsigned ring[K][4];
+    unsigned S[4];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) ring[j][c] = 0u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) S[c] = BlurK<K>::add | (BlurK<K>::add << 16);
+    const unsigned char* __restrict__ win = reg + 8 * l;
+    const int rend = r1 + 2 * R;  // region rows [r0, rend) feed output rows [r0, r1)
+    for (int base = r0; base < rend; base += K) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const int rr = base + j;
+        if (rr < rend) {
+          const uint2 a = *reinterpret_cast<const uint2*>(win + rr * P);
+          const uint2 b = *reinterpret_cast<const uint2*>(win + rr * P + 8);
+          const unsigned W[4] = {a.x, a.y, b.x, b.y};
+          const unsigned Pk[4] = {hsum_tap<R, 0>(W) | (hsum_tap<R, 1>(W) << 16), hsum_tap<R, 2>(W) | (hsum_tap<R, 3>(W) << 16),
+                                  hsum_tap<R, 4>(W) | (hsum_tap<R, 5>(W) << 16), hsum_tap<R, 6>(W) | (hsum_tap<R, 7>(W) << 16)};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            S[c] = (S[c] - ring[j][c]) + Pk[c];
+            ring[j][c] = Pk[c];
+          }
+          if (rr - r0 >= 2 * R) {
+            unsigned q[8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              q[2 * c] = ((S[c] & 0xffffu) * BlurK<K>::m) >> 24;
+              q[2 * c + 1] = ((S[c] >> 16) * BlurK<K>::m) >> 24;
+            }
+            uint2 o;
+            o.x = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
+            o.y = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
+            *reinterpret_cast<uint2*>(dst + (rr - 2 * R) * Pb + 8 * l) = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_kp_hashes(unsigned char* __restrict__ base,
+                                                        const KpImage* __restrict__ images, unsigned n_images,
+                                                        const float* __restrict__ kp,
+                                                        const SizeInfo* __restrict__ sizes,
+                                                        const AreaTab* __restrict__ apool,
+                                                        const int* __restrict__ ipool, int lds_side, int tab_cap,
+                                                        unsigned char* __restrict__ scratch, size_t scratch_per_wg,
+                                                        const DctTables* __restrict__ tabs,
+                                                        uint64_t* __restrict__ out, unsigned* __restrict__ counts) {
+  __shared__ __attribute__((aligned(16))) float sC[288], sT[288], sY[84];
+  __shared__ __attribute__((aligned(16))) unsigned char tile[1024], sZ[64];
+  __shared__ int sFirst[36];
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  // dynamic LDS: [table: tab_cap x (int si, float alpha)] [region: (lds_side + 6) rows x (8*ceil(lds_side/8) + 8)]
+  // [blurred: lds_side rows x 8*ceil(lds_side/8)]   (tab_cap is even: everything stays 16-byte aligned)
+  int* sTabSi = reinterpret_cast<int*>(dyn);
+  float* sTabA = reinterpret_cast<float*>(dyn + (size_t)tab_cap * 4);
+  unsigned char* sReg = dyn + (size_t)tab_cap * 8;
+  const int side8 = (lds_side + 7) & ~7;
+  unsigned char* sBlur = sReg + (size_t)(lds_side + 6) * (side8 + 8);
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 288; i += kThreads) sC[i] = tabs->C[i];
+  if (tid < 64) sZ[tid] = tabs->zz[tid];
+  unsigned char* __restrict__ scr = scratch + (size_t)blockIdx.x * scratch_per_wg;
+  int cached = -1;  // side length whose table is in LDS (uniform)
+  for (unsigned im = blockIdx.x; im < n_images; im += gridDim.x) {
+    const KpImage I = images[im];
+    unsigned char* img = base + I.off;
+    unsigned cnt = 0;
+    for (unsigned q = 0; q < I.kp_count; ++q) {
+      const float* k3 = kp + 3 * (size_t)(I.kp_first + q);
+      const float x0 = k3[0], y0 = k3[1], size = k3[2];
+      if (!(size >= 31.f)) continue;
+      const float x1 = x0 + size, y1 = y0 + size;
+      if (!(x0 > 0 && y0 > 0 && x1 < (float)(I.w - 2) && y1 < (float)(I.h - 2))) continue;
+      const int x = (int)__builtin_floorf(x0), y = (int)__builtin_floorf(y0), s = (int)__builtin_ceilf(size);
+      const SizeInfo si = sizes[s];
+      const int K = s * s <= 32 * 32 ? 0 : s * s <= 64 * 64 ? 3 : s * s <= 128 * 128 ? 5 : 7;
+      uint64_t* dst = out + I.kp_first + cnt;
+      ++cnt;
+      if (s > lds_side || (si.mode == 2 && si.n > tab_cap)) {
+        // ---- global-memory routine (large squares) ----
+        const unsigned char* src = img + (size_t)y * I.row_stride + x;
+        size_t sp = I.row_stride;
+        if (K) {
+          if (K == 3) blur_rect<3>(img, I.w, I.h, I.row_stride, x, y, s, s, scr);
+          else if (K == 5) blur_rect<5>(img, I.w, I.h, I.row_stride, x, y, s, s, scr);
+          else blur_rect<7>(img, I.w, I.h, I.row_stride, x, y, s, s, scr);
+          __syncthreads();
+          for (int i = tid; i < s * s; i += kThreads) {
+            const int yy = i / s, xx = i - yy * s;
+            img[(size_t)(y + yy) * I.row_stride + x + xx] = scr[i];
+          }
+          src = scr;
+          sp = (size_t)s;
+        }
+        for (int o = tid; o < 1024; o += kThreads) {
+          const int dy = o >> 5, dx = o & 31;
+          if (si.mode == 1) {
+            const int b = s / 32;
+            unsigned int sum = 0;
+            for (int yy = 0; yy < b; ++yy)
+              for (int xx = 0; xx < b; ++xx) sum += src[(size_t)(dy * b + yy) * sp + (dx * b + xx)];
+            const unsigned int v = b == 2 ? (sum + 2u) >> 2
+                                          : (unsigned int)__builtin_rintf((float)sum * (1.f / (float)(b * b)));
+            tile[o] = (unsigned char)(v > 255u ? 255u : v);
+          } else {  // mode 2 (sides above 32 that are not exact multiples)
+            const AreaTab* __restrict__ tab = apool + si.tab_off;
+            const int* __restrict__ first = ipool + si.aux_off;
+            float sum = 0.f;
+            for (int j = first[dy]; j < first[dy + 1]; ++j) {
+              const unsigned char* S = src + (size_t)tab[j].si * sp;
+              float buf = 0.f;
+              for (int k = first[dx]; k < first[dx + 1]; ++k) buf += (float)S[tab[k].si] * tab[k].alpha;
+              const float t = tab[j].alpha * buf;
+              sum = (j == first[dy]) ? t : sum + t;
+            }
+            const float rr = __builtin_rintf(sum);
+            tile[o] = (unsigned char)(rr < 0.f ? 0.f : rr > 255.f ? 255.f : rr);
+          }
+        }
+        __syncthreads();
+        hash_from_tile(tile, sC, sZ, sT, sY, dst);
+        __syncthreads();
+        continue;
+      }
+      // ---- A: table (when the side changed) and region -> LDS ----
+      const int R = K / 2, P = ((s + 7) & ~7) + 8, Pb = (s + 7) & ~7, rows = s + 2 * R;
+      if (cached != s) {
+        if (si.mode == 2) {
+          const AreaTab* __restrict__ tab = apool + si.tab_off;
+          for (int i = tid; i < si.n; i += kThreads) {
+            sTabSi[i] = tab[i].si;
+            sTabA[i] = tab[i].alpha;
+          }
+          if (tid < 33) sFirst[tid] = ipool[si.aux_off + tid];
+        } else if (si.mode == 3) {
+          for (int i = tid; i < 192; i += kThreads) sTabSi[i] = ipool[si.aux_off + i];
+        }
+        cached = s;
+      }
+      {
+        // LDS column c <-> image column x - 4 + c; dwords [dw0, dw1) cover the columns the blur reads
+        const int dw0 = (4 - R) >> 2, dw1 = (4 + s + R + 3) >> 2, ndw = dw1 - dw0;
+        for (int i = tid; i < rows * ndw; i += kThreads) {
+          const int rr = i / ndw, dwi = dw0 + (i - rr * ndw);
+          const int gx = x - 4 + 4 * dwi;
+          const unsigned char* row = img + (size_t)reflect101(y - R + rr, I.h) * I.row_stride;
+          unsigned v;
+          if (gx >= 0 && gx + 3 < I.w) {
+            v = *reinterpret_cast<const u32_any_align*>(row + gx);
+          } else {
+            v = (unsigned)row[reflect101(gx, I.w)] | ((unsigned)row[reflect101(gx + 1, I.w)] << 8) |
+                ((unsigned)row[reflect101(gx + 2, I.w)] << 16) | ((unsigned)row[reflect101(gx + 3, I.w)] << 24);
+          }
+          *reinterpret_cast<unsigned*>(sReg + rr * P + 4 * dwi) = v;
+        }
+      }
+      __syncthreads();
+      // ---- B: blur ----
+      const unsigned char* src = sReg + 4;  // K == 0: the square itself, pitch P
+      int sp = P;
+      if (K) {
+        if (K == 3) blur_lds8<3>(sReg, P, s, sBlur, Pb);
+        else if (K == 5) blur_lds8<5>(sReg, P, s, sBlur, Pb);
+        else blur_lds8<7>(sReg, P, s, sBlur, Pb);
+        __syncthreads();
+        src = sBlur;
+        sp = Pb;
+        // ---- C1: back into the image ----
+        const int ndw = (s + 3) >> 2;
+        for (int i = tid; i < s * ndw; i += kThreads) {
+          const int yy = i / ndw, d = i - yy * ndw;
+          const unsigned v = *reinterpret_cast<const unsigned*>(sBlur + yy * Pb + 4 * d);
+          unsigned char* o = img + (size_t)(y + yy) * I.row_stride + x + 4 * d;
+          if (4 * d + 3 < s) {
+            *reinterpret_cast<u32_any_align*>(o) = v;
+          } else {
+            for (int b = 0; 4 * d + b < s; ++b) o[b] = (unsigned char)(v >> (8 * b));
+          }
+        }
+      }
+      // ---- C2: 32x32 tile ----
+#pragma unroll
+      for (int o4 = 0; o4 < 4; ++o4) {
+        const int o = tid + o4 * kThreads;
+        const int dy = o >> 5, dx = o & 31;
+        if (si.mode == 0) {
+          tile[o] = src[dy * sp + dx];
+        } else if (si.mode == 1) {
+          const int b = s / 32;
+          unsigned int sum = 0;
+          for (int yy = 0; yy < b; ++yy)
+            for (int xx = 0; xx < b; ++xx) sum += src[(dy * b + yy) * sp + (dx * b + xx)];
+          const unsigned int v = b == 2 ? (sum + 2u) >> 2
+                                        : (unsigned int)__builtin_rintf((float)sum * (1.f / (float)(b * b)));
+          tile[o] = (unsigned char)(v > 255u ? 255u : v);
+        } else if (si.mode == 2) {
+          float sum = 0.f;
+          const int j0 = sFirst[dy], j1 = sFirst[dy + 1], k0 = sFirst[dx], k1 = sFirst[dx + 1];
+          for (int j = j0; j < j1; ++j) {
+            const unsigned char* S = src + sTabSi[j] * sp;
+            float buf = 0.f;
+            for (int k = k0; k < k1; ++k) buf += (float)S[sTabSi[k]] * sTabA[k];
+            const float t = sTabA[j] * buf;
+            sum = (j == j0) ? t : sum + t;
+          }
+          const float rr = __builtin_rintf(sum);
+          tile[o] = (unsigned char)(rr < 0.f ? 0.f : rr > 255.f ? 255.f : rr);
+        } else {
+          const int* xl = sTabSi;
+          const int* yl = sTabSi + 96;
+          const int sy0 = min(max(yl[dy], 0), s - 1), sy1 = min(max(yl[dy] + 1, 0), s - 1);
+          const int sx = xl[dx], sx1 = min(sx + 1, s - 1);
+          const int a0 = xl[32 + dx], a1 = xl[64 + dx], b0 = yl[32 + dy], b1 = yl[64 + dy];
+          const unsigned char* S0 = src + sy0 * sp;
+          const unsigned char* S1 = src + sy1 * sp;
+          const int D0 = (int)S0[sx] * a0 + (int)S0[sx1] * a1;
+          const int D1 = (int)S1[sx] * a0 + (int)S1[sx1] * a1;
+          const int v = (((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2;
+          tile[o] = (unsigned char)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+      }
+      __syncthreads();
+      // ---- D ----
+      hash_from_tile(tile, sC, sZ, sT, sY, dst);
+      __syncthreads();
+    }
+    if (tid == 0) counts[im] = cnt;
+  }
+}
+
+// out_dense[out_first[i] + t] = out_slots[kp_first[i] + t], t < counts[i]
+__global__ __launch_bounds__(kThreads) void k_kp_compact(const uint64_t* __restrict__ slots,
+                                                         const KpImage* __restrict__ images,
+                                                         const unsigned* __restrict__ out_first,
+                                                         uint64_t* __restrict__ dense, unsigned n_images) {
+  for (unsigned im = blockIdx.x; im < n_images; im += gridDim.x) {
+    const unsigned a = out_first[im], m = out_first[im + 1] - a, src = images[im].kp_first;
+    for (unsigned t = threadIdx.x; t < m; t += kThreads) dense[a + t] = slots[src + t];
   }
 }
 
@@ -1302,6 +1618,10 @@ int get_mfma_tables(const MfmaTables** out) {
 
 int g_hash_mfma = 0;
 int g_hash_mfma_set(int v) { return g_hash_mfma = v; }
+int g_kp_lds_side = 134;  // keypoint squares up to this side are processed in LDS (k_kp_hashes)
+void set_kp_lds_side(int v) {
+  if (v >= 32 && v <= 200) g_kp_lds_side = v;
+}
 int g_hash_fast_any = 1;  // 1 = k_blur_rows/k_area_rows/k_tile_hash for every geometry but 256x256 and 32x32
 void set_hash_fast_any(int on) {
   if (on >= 0) g_hash_fast_any = on;
@@ -1462,6 +1782,122 @@ int launch_rect_hashes(uint8_t* d_base, const std::vector<RectImageDesc>& images
     e = hipGetLastError();
   }
   for (void* p : {(void*)d_images, (void*)d_jobs, (void*)d_axes, (void*)d_apool, (void*)d_ipool, (void*)d_scr})
+    if (p) (void)hipFreeAsync(p, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  CBH_HIP(e);
+  return CBH_OK;
+}
+
+extern int g_kp_lds_side;
+// Media::makeKeyPointHashes for a batch, keypoints evaluated on the device.  kp / kp_first / descriptors are host
+// arrays; d_out receives the hashes densely (image i at out_first[i]); out_first has n + 1 entries.
+int launch_keypoint_hashes(uint8_t* d_base, size_t n, const uint64_t* img_off, const uint32_t* img_w,
+                           const uint32_t* img_h, const uint32_t* img_row_stride, const float* kp,
+                           const uint32_t* kp_first, uint64_t* d_out, uint32_t* out_first, hipStream_t stream) {
+  const size_t nkp = kp_first[n];
+  out_first[0] = 0;
+  if (nkp == 0) {
+    for (size_t i = 0; i <= n; ++i) out_first[i] = 0;
+    return CBH_OK;
+  }
+  const DctTables* tabs = nullptr;
+  int rc = get_tables(&tabs);
+  if (rc) return rc;
+  // side lengths present (candidates only) -> tables
+  std::vector<unsigned char> present(8194, 0);
+  int max_side = 0;
+  for (size_t i = 0; i < nkp; ++i) {
+    const float size = kp[3 * i + 2];
+    if (!(size >= 31.f) || size > 8192.f) continue;
+    const int sd = (int)std::ceil(size);
+    present[(size_t)sd] = 1;
+    max_side = std::max(max_side, sd);
+  }
+  std::vector<SizeInfo> sizes((size_t)std::max(max_side, 32) + 1, SizeInfo{-1, 0, 0, 0});
+  std::vector<AreaTab> apool(1, AreaTab{0, 0, 0.f});
+  std::vector<int> ipool(1, 0);
+  int tab_cap = 192;  // the bilinear tables (2 x 96 ints) share the table area
+  int lds_side = 32;
+  const int kLdsSideMax = g_kp_lds_side;  // default 134 = ORB level 8 (31 * 1.2^8 = 133.3): region + blurred square = 39 KB
+  for (int sd = 31; sd <= max_side; ++sd) {
+    if (!present[(size_t)sd]) continue;
+    SizeInfo& si = sizes[(size_t)sd];
+    if (sd == 32) {
+      si.mode = 0;
+    } else if (sd < 32) {
+      si.mode = 3;
+      si.aux_off = (int)ipool.size();
+      make_linear_tab(sd, true, &ipool);
+      make_linear_tab(sd, false, &ipool);
+    } else if (area_fast(sd, sd)) {
+      si.mode = 1;
+    } else {
+      si.mode = 2;
+      std::vector<int> first;
+      std::vector<AreaTab> t = make_area_tab(sd, 32, &first);
+      si.tab_off = (int)apool.size();
+      si.n = (int)t.size();
+      si.aux_off = (int)ipool.size();
+      apool.insert(apool.end(), t.begin(), t.end());
+      ipool.insert(ipool.end(), first.begin(), first.end());
+      if (sd <= kLdsSideMax) tab_cap = std::max(tab_cap, si.n);
+    }
+    if (sd <= kLdsSideMax) lds_side = std::max(lds_side, sd);
+  }
+  std::vector<KpImage> imgs(n);
+  for (size_t i = 0; i < n; ++i)
+    imgs[i] = KpImage{img_off[i], (int)img_w[i], (int)img_h[i], img_row_stride[i], kp_first[i],
+                      kp_first[i + 1] - kp_first[i]};
+  const size_t scratch_per_wg = max_side > lds_side ? (((size_t)max_side * max_side + 255) / 256 * 256) : 256;
+  tab_cap = (tab_cap + 1) & ~1;
+  const size_t side8 = ((size_t)lds_side + 7) & ~(size_t)7;
+  const size_t smem = (size_t)tab_cap * 8 + (size_t)(lds_side + 6) * (side8 + 8) + (size_t)lds_side * side8;
+  const unsigned grid = (unsigned)std::min<size_t>(n, 2048);
+  KpImage* d_images = nullptr;
+  float* d_kp = nullptr;
+  SizeInfo* d_sizes = nullptr;
+  AreaTab* d_apool = nullptr;
+  int* d_ipool = nullptr;
+  unsigned char* d_scr = nullptr;
+  uint64_t* d_slots = nullptr;
+  unsigned *d_counts = nullptr, *d_first = nullptr;
+  std::vector<unsigned> counts(n);
+  hipError_t e = hipSuccess;
+  auto up = [&](void** dst, const void* src, size_t bytes) {
+    if (e != hipSuccess) return;
+    if ((e = hipMallocAsync(dst, bytes, stream)) != hipSuccess) return;
+    e = hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, stream);
+  };
+  up((void**)&d_images, imgs.data(), imgs.size() * sizeof(KpImage));
+  up((void**)&d_kp, kp, nkp * 3 * sizeof(float));
+  up((void**)&d_sizes, sizes.data(), sizes.size() * sizeof(SizeInfo));
+  up((void**)&d_apool, apool.data(), apool.size() * sizeof(AreaTab));
+  up((void**)&d_ipool, ipool.data(), ipool.size() * sizeof(int));
+  if (e == hipSuccess) e = hipMallocAsync((void**)&d_scr, (size_t)grid * scratch_per_wg, stream);
+  if (e == hipSuccess) e = hipMallocAsync((void**)&d_slots, nkp * sizeof(uint64_t), stream);
+  if (e == hipSuccess) e = hipMallocAsync((void**)&d_counts, n * sizeof(unsigned), stream);
+  if (e == hipSuccess) e = hipMallocAsync((void**)&d_first, (n + 1) * sizeof(unsigned), stream);
+  if (e == hipSuccess && smem > 48 * 1024)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_kp_hashes), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_kp_hashes, dim3(grid), dim3(kThreads), smem, stream, d_base, d_images, (unsigned)n, d_kp,
+                       d_sizes, d_apool, d_ipool, lds_side, tab_cap, d_scr, scratch_per_wg, tabs, d_slots, d_counts);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), d_counts, n * sizeof(unsigned), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e == hipSuccess) {
+    for (size_t i = 0; i < n; ++i) out_first[i + 1] = out_first[i] + counts[i];
+    e = hipMemcpyAsync(d_first, out_first, (n + 1) * sizeof(unsigned), hipMemcpyHostToDevice, stream);
+  }
+  if (e == hipSuccess && out_first[n]) {
+    hipLaunchKernelGGL(k_kp_compact, dim3(grid), dim3(kThreads), 0, stream, d_slots, d_images, d_first, d_out,
+                       (unsigned)n);
+    e = hipGetLastError();
+  }
+  for (void* p : {(void*)d_images, (void*)d_kp, (void*)d_sizes, (void*)d_apool, (void*)d_ipool, (void*)d_scr,
+                  (void*)d_slots, (void*)d_counts, (void*)d_first})
     if (p) (void)hipFreeAsync(p, stream);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   CBH_HIP(e);
