@@ -2,6 +2,7 @@
 //
 //   uint64_t dctHash64(const cv::Mat& cvImg, bool inPlace = false)                  src/cvutil.h, src/cvutil.cpp:435-545
 //   void Media::makeKeyPointHashes(const cv::Mat&, const KeyPointList&, KeyPointHashList&) const   src/media.cpp:874-923
+//   void sizeLongestSide(cv::Mat& img, int size, int filter = INTER_LANCZOS4)        src/cvutil.h:251, cvutil.cpp:1932-1950
 //
 // Same arguments and effects as the originals for 8-bit single-channel images (what Scanner::processImage passes
 // after grayscale(), src/scanner.cpp:859,876-889): the hash is returned, and with inPlace = true the blurred pixels
@@ -17,6 +18,7 @@
 // repository it is compiled against cbird_amd/cpp/mock/index.h instead (tests/cpp/test_cvutil.cpp).
 #pragma once
 #include <cstdint>
+#include <stdexcept>
 #include <vector>
 
 #include "cbird_hip.h"
@@ -50,7 +52,7 @@ inline ParentView parentOf(const cv::Mat& m) {
 // dctHash64(cvImg, inPlace) for CV_8UC1.  Colour input is converted by the caller exactly as before
 // (grayscale(), cvutil.cpp:1265-1283; on the GPU: cbh_process_images).
 inline uint64_t gpuDctHash64(const cv::Mat& cvImg, bool inPlace = false) {
-  if (cvImg.type() != 0 /* CV_8UC1 */ || cvImg.rows <= 0 || cvImg.cols <= 0)
+  if (cvImg.type() != CV_8UC1 || cvImg.rows <= 0 || cvImg.cols <= 0)
     qFatal("gpuDctHash64: expected a non-empty CV_8UC1 image");
   const detail::ParentView p = detail::parentOf(cvImg);
   const size_t bytes = size_t(p.h - 1) * p.step + p.w;
@@ -68,7 +70,7 @@ inline uint64_t gpuDctHash64(const cv::Mat& cvImg, bool inPlace = false) {
 // Media::makeKeyPointHashes: the hashes are appended to outHashes like the original does (push_back per rectangle);
 // cvImg is modified by the in-place blurs.
 inline void gpuMakeKeyPointHashes(const cv::Mat& cvImg, const KeyPointList& keyPoints, KeyPointHashList& outHashes) {
-  Q_ASSERT(cvImg.type() == 0);  // grayscale, media.cpp:877
+  Q_ASSERT(cvImg.type() == CV_8UC1);  // grayscale, media.cpp:877
   if (keyPoints.empty() || cvImg.rows <= 0 || cvImg.cols <= 0) return;
   const detail::ParentView p = detail::parentOf(cvImg);
   if (p.x != 0 || p.y != 0 || int(p.w) != cvImg.cols || int(p.h) != cvImg.rows)
@@ -89,6 +91,20 @@ inline void gpuMakeKeyPointHashes(const cv::Mat& cvImg, const KeyPointList& keyP
                                      outFirst, const_cast<uint8_t*>(p.base), hashDevice());
   if (rc) qFatal("gpuMakeKeyPointHashes: %s (%s)", cbh_strerror(rc), cbh_last_error());
   for (uint32_t i = 0; i < outFirst[1]; ++i) outHashes.push_back(hashes[i]);
+}
+
+// sizeLongestSide(img, size) with the default INTER_LANCZOS4 filter: img is replaced by the resized image.
+inline void gpuSizeLongestSide(cv::Mat& img, int size) {
+  if (img.type() != CV_8UC1 || img.rows <= 0 || img.cols <= 0) qFatal("gpuSizeLongestSide: expected a CV_8UC1 image");
+  int w = 0, h = 0;
+  cbh_longest_side_dims(img.cols, img.rows, size, &w, &h);
+  if (w == 0 || h == 0)  // the reference's own check (cvutil.cpp:1944-1946)
+    throw std::invalid_argument("sizeLongestSide: computed width or height is 0, probably bad input");
+  cv::Mat out(h, w, CV_8UC1);
+  const int rc = cbh_size_longest_side(img.data, 1, img.cols, img.rows, size_t(img.step), 0, size, out.data, &w, &h,
+                                       hashDevice());
+  if (rc) qFatal("gpuSizeLongestSide: %s (%s)", cbh_strerror(rc), cbh_last_error());
+  img = out;
 }
 
 }  // namespace cbird_gpu

@@ -154,6 +154,7 @@ struct QSqlQuery {
 // ---- value types the other indexes carry (shapes only) ----------------------------------------------
 typedef uint64_t dcthash_t;
 typedef std::vector<uint64_t> KeyPointHashList;
+#define CV_8UC1 0
 namespace cv {
 struct Size {
   int width = 0, height = 0;
@@ -179,6 +180,7 @@ struct Mat {  // rows x cols bytes (CV_8UC1); views share the parent's storage l
     data = _store->data();
     _whole.width = c, _whole.height = r;
   }
+  Mat(int r, int c, int /*type: CV_8UC1*/) : Mat(r, c) {}
   template <typename T>
   const T* ptr(int r) const { return reinterpret_cast<const T*>(data + size_t(r) * step); }
   template <typename T>

@@ -2,11 +2,84 @@
 //   grayscale()  cv::cvtColor BGR/BGRA -> gray, 14-bit fixed point (src/cvutil.cpp:1265-1283)
 //   autocrop()   de-letterboxing by scanning outwards from the centre (src/cvutil.cpp:1285-1402)
 // and cbh_process_images, which chains gray -> autocrop -> hash for a batch of decoded images of one size.
+#include <cfloat>
+#include <cmath>
 #include <vector>
 
 #include "cbh_index.h"
 
 namespace {
+
+// cv::resize(..., INTER_LANCZOS4) on 8-bit grey images (sizeLongestSide, src/cvutil.cpp:1932-1950): one thread per
+// destination pixel, 8 x 8 clamped taps with the per-column / per-row fixed-point weights; integer arithmetic
+// throughout (horizontal sums, vertical sum, (v + 2^21) >> 22), so the bytes do not depend on evaluation order.
+// No anti-aliasing -- a reduction reads 64 source pixels per output pixel however large the ratio, so the kernel is
+// bound by the (sparse) source reads, a fraction of the image.
+__global__ __launch_bounds__(256) void k_resize_lanczos4(const unsigned char* __restrict__ src, int w, int h,
+                                                         size_t row_stride, size_t img_stride, int dw, int dh,
+                                                         const int* __restrict__ xofs, const short* __restrict__ xa,
+                                                         const int* __restrict__ yofs, const short* __restrict__ yb,
+                                                         unsigned char* __restrict__ dst /* n*dw*dh */) {
+  const unsigned char* img = src + (size_t)blockIdx.y * img_stride;
+  unsigned char* out = dst + (size_t)blockIdx.y * (size_t)dw * dh;
+  const int total = dw * dh;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int dy = i / dw, dx = i - dy * dw;
+    const int sx0 = xofs[dx] - 3, sy0 = yofs[dy] - 3;
+    int a[8], cx[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a[j] = xa[dx * 8 + j];
+      cx[j] = min(max(sx0 + j, 0), w - 1);
+    }
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const unsigned char* S = img + (size_t)min(max(sy0 + k, 0), h - 1) * row_stride;
+      int D = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) D += (int)S[cx[j]] * a[j];
+      v += D * (int)yb[dy * 8 + k];
+    }
+    v = (v + (1 << 21)) >> 22;
+    out[i] = (unsigned char)(v < 0 ? 0 : v > 255 ? 255 : v);
+  }
+}
+
+// interpolateLanczos4 + the fixed-point conversion of cv::resize (see oracle/cbird_oracle.c orc_lanczos4_tab)
+void lanczos4_tab(int ssize, int dsize, std::vector<int>* ofs, std::vector<short>* coef) {
+  static const double s45 = 0.70710678118654752440084436210485;
+  static const double cs[8][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+  const double inv_scale = (double)dsize / ssize;
+  const double scale = 1. / inv_scale;
+  ofs->resize((size_t)dsize);
+  coef->resize((size_t)dsize * 8);
+  for (int d = 0; d < dsize; ++d) {
+    float fx = (float)((d + 0.5) * scale - 0.5);
+    const int sx = (int)std::floor(fx);
+    fx -= sx;
+    float c[8];
+    if (fx < FLT_EPSILON) {
+      for (int i = 0; i < 8; i++) c[i] = 0;
+      c[3] = 1;
+    } else {
+      float sum = 0;
+      const double y0 = -(fx + 3) * M_PI * 0.25, s0 = std::sin(y0), c0 = std::cos(y0);
+      for (int i = 0; i < 8; i++) {
+        const double y = -(fx + 3 - i) * M_PI * 0.25;
+        c[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+        sum += c[i];
+      }
+      sum = 1.f / sum;
+      for (int i = 0; i < 8; i++) c[i] *= sum;
+    }
+    (*ofs)[(size_t)d] = sx;
+    for (int k = 0; k < 8; ++k) {
+      const long r = std::lrintf(c[k] * 2048.f);
+      (*coef)[(size_t)d * 8 + k] = (short)(r < -32768 ? -32768 : r > 32767 ? 32767 : r);
+    }
+  }
+}
 
 __global__ __launch_bounds__(256) void k_bgr2gray(const unsigned char* __restrict__ src, int w, int h,
                                                   size_t row_stride, size_t img_stride, int channels,
@@ -231,5 +304,109 @@ int cbh_process_images(const uint8_t* imgs, size_t n, int w, int h, size_t row_s
   cleanup();
   return rc;
 }
+
+/* sizeLongestSide's target size (src/cvutil.cpp:1933-1942): float aspect ratio, truncation */
+void cbh_longest_side_dims(int w, int h, int size, int* out_w, int* out_h) {
+  const float aspect = (float)w / (float)h;
+  if (w > h) {
+    *out_w = size;
+    *out_h = (int)((float)size / aspect);
+  } else {
+    *out_h = size;
+    *out_w = (int)(aspect * (float)size);
+  }
+}
+
+int cbh_resize_lanczos4_dev(const void* d_src, size_t n, int w, int h, size_t row_stride, size_t img_stride, int dw,
+                            int dh, void* d_dst, int device, void* stream) {
+  if (!cbh::device_usable(device)) return CBH_E_NODEVICE;
+  if (n == 0) return CBH_OK;
+  if (!d_src || !d_dst || w <= 0 || h <= 0 || dw <= 0 || dh <= 0 || row_stride < (size_t)w || n > 65535 ||
+      (long long)dw * dh > 0x7fffffffLL)
+    return CBH_E_INVAL;
+  cbh::DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<int> xofs, yofs;
+  std::vector<short> xa, yb;
+  lanczos4_tab(w, dw, &xofs, &xa);
+  lanczos4_tab(h, dh, &yofs, &yb);
+  int *d_xofs = nullptr, *d_yofs = nullptr;
+  short *d_xa = nullptr, *d_yb = nullptr;
+  hipError_t e = hipSuccess;
+  auto up = [&](void** dst, const void* src, size_t bytes) {
+    if (e != hipSuccess) return;
+    if ((e = hipMallocAsync(dst, bytes, s)) != hipSuccess) return;
+    e = hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s);
+  };
+  up((void**)&d_xofs, xofs.data(), xofs.size() * sizeof(int));
+  up((void**)&d_yofs, yofs.data(), yofs.size() * sizeof(int));
+  up((void**)&d_xa, xa.data(), xa.size() * sizeof(short));
+  up((void**)&d_yb, yb.data(), yb.size() * sizeof(short));
+  if (e == hipSuccess) {
+    const unsigned gx = (unsigned)std::min<long long>(((long long)dw * dh + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_resize_lanczos4, dim3(gx, (unsigned)n), dim3(256), 0, s, (const unsigned char*)d_src, w, h,
+                       row_stride, img_stride, dw, dh, d_xofs, d_xa, d_yofs, d_yb, (unsigned char*)d_dst);
+    e = hipGetLastError();
+  }
+  for (void* p : {(void*)d_xofs, (void*)d_yofs, (void*)d_xa, (void*)d_yb})
+    if (p) (void)hipFreeAsync(p, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);  // the tables came from pageable host vectors
+  if (e != hipSuccess) {
+    cbh::set_last_error("resize_lanczos4", e);
+    return e == hipErrorOutOfMemory ? CBH_E_NOMEM : CBH_E_HIP;
+  }
+  return CBH_OK;
+}
+
+/* sizeLongestSide(img, size) for n grey images of one geometry in host memory; out receives n packed
+ * out_w x out_h images. */
+int cbh_size_longest_side(const uint8_t* imgs, size_t n, int w, int h, size_t row_stride, size_t img_stride, int size,
+                          uint8_t* out, int* out_w, int* out_h, int device) {
+  if (!cbh::device_usable(device)) return CBH_E_NODEVICE;
+  if (w <= 0 || h <= 0 || size <= 0 || !out_w || !out_h) return CBH_E_INVAL;
+  cbh_longest_side_dims(w, h, size, out_w, out_h);
+  if (*out_w <= 0 || *out_h <= 0) return CBH_E_INVAL;  // "computed width or height is 0, probably bad input"
+  if (n == 0) return CBH_OK;
+  if (!imgs || !out || row_stride < (size_t)w) return CBH_E_INVAL;
+  cbh::DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  const int dw = *out_w, dh = *out_h;
+  const size_t span1 = (size_t)(h - 1) * row_stride + (size_t)w;
+  size_t per_chunk = std::max<size_t>(1, ((size_t)256 << 20) / std::max(img_stride, span1));
+  per_chunk = std::min<size_t>(std::min(per_chunk, n), 65535);
+  uint8_t *d_src = nullptr, *d_dst = nullptr;
+  hipStream_t s = nullptr;
+  int rc = CBH_OK;
+  hipError_t e;
+  if ((e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipMalloc(&d_src, (per_chunk - 1) * img_stride + span1)) != hipSuccess ||
+      (e = hipMalloc(&d_dst, per_chunk * (size_t)dw * dh)) != hipSuccess) {
+    cbh::set_last_error("size_longest_side setup", e);
+    rc = e == hipErrorOutOfMemory ? CBH_E_NOMEM : CBH_E_HIP;
+  }
+  for (size_t i0 = 0; rc == CBH_OK && i0 < n; i0 += per_chunk) {
+    const size_t m = std::min(per_chunk, n - i0);
+    if ((e = hipMemcpyAsync(d_src, imgs + i0 * img_stride, (m - 1) * img_stride + span1, hipMemcpyHostToDevice, s)) !=
+        hipSuccess) {
+      cbh::set_last_error("size_longest_side H2D", e);
+      rc = CBH_E_HIP;
+      break;
+    }
+    rc = cbh_resize_lanczos4_dev(d_src, m, w, h, row_stride, img_stride, dw, dh, d_dst, device, s);
+    if (rc) break;
+    if ((e = hipMemcpyAsync(out + i0 * (size_t)dw * dh, d_dst, m * (size_t)dw * dh, hipMemcpyDeviceToHost, s)) !=
+            hipSuccess ||
+        (e = hipStreamSynchronize(s)) != hipSuccess) {
+      cbh::set_last_error("size_longest_side D2H", e);
+      rc = CBH_E_HIP;
+    }
+  }
+  if (s) (void)hipStreamDestroy(s);
+  if (d_src) (void)hipFree(d_src);
+  if (d_dst) (void)hipFree(d_dst);
+  return rc;
+}
+
 
 }  // extern "C"

@@ -103,3 +103,23 @@ def make_keypoint_hashes(images, keypoints, device: int = 0, return_images: bool
     if not return_images:
         return hashes
     return hashes, [after[int(o): int(o) + im.size].reshape(im.shape).copy() for im, o in zip(imgs, off)]
+
+
+def size_longest_side(imgs: np.ndarray, size: int = 400, device: int = 0) -> np.ndarray:
+    """sizeLongestSide(img, size) (src/cvutil.cpp:1932-1950, INTER_LANCZOS4) for uint8 grey images [n, h, w] of one
+    geometry; returns uint8 [n, h', w'].  size defaults to IndexParams::resizeLongestSide (src/scanner.h:71)."""
+    import ctypes as C
+
+    imgs = np.asarray(imgs)
+    if imgs.dtype != np.uint8 or imgs.ndim != 3:
+        raise ValueError("expected uint8 array [n, h, w]")
+    if imgs.strides[2] != 1:
+        imgs = np.ascontiguousarray(imgs)
+    n, h, w = imgs.shape
+    ow, oh = C.c_int(0), C.c_int(0)
+    L = _lib.lib()
+    L.cbh_longest_side_dims(w, h, int(size), C.byref(ow), C.byref(oh))
+    out = np.zeros((n, max(oh.value, 0), max(ow.value, 0)), np.uint8)
+    check(L.cbh_size_longest_side(imgs.ctypes.data, n, w, h, imgs.strides[1], imgs.strides[0] if n else 0, int(size),
+                                  out.ctypes.data, C.byref(ow), C.byref(oh), device), "size_longest_side")
+    return out

@@ -125,6 +125,17 @@ int cbh_autocrop_dev(const void* d_gray, size_t n, int w, int h, size_t row_stri
 int cbh_process_images(const uint8_t* imgs, size_t n, int w, int h, size_t row_stride, size_t img_stride,
                        int channels, int autocrop_range, uint64_t* out, int32_t* rects, int device);
 
+/* sizeLongestSide(cv::Mat& img, int size, int filter = INTER_LANCZOS4) -- src/cvutil.cpp:1932-1950, the resize in
+ * front of ORB detection (src/scanner.cpp:876, size = IndexParams::resizeLongestSide = 400): target size from the
+ * float aspect ratio (cbh_longest_side_dims; a zero side is the reference's std::invalid_argument -> CBH_E_INVAL),
+ * then cv::resize's 8-bit Lanczos-4 path.  n grey images of one geometry; out / d_dst: n packed out_w x out_h
+ * images.  cbh_resize_lanczos4_dev resizes to any dw x dh. */
+void cbh_longest_side_dims(int w, int h, int size, int* out_w, int* out_h);
+int cbh_size_longest_side(const uint8_t* imgs, size_t n, int w, int h, size_t row_stride, size_t img_stride, int size,
+                          uint8_t* out, int* out_w, int* out_h, int device);
+int cbh_resize_lanczos4_dev(const void* d_src, size_t n, int w, int h, size_t row_stride, size_t img_stride, int dw,
+                            int dh, void* d_dst, int device, void* stream);
+
 /* Stage-level diagnostics: as cbh_dcthash_batch_dev, and additionally writes the 32x32 u8 tile
  * each image is reduced to after stages 1-2 (blur + INTER_AREA) to d_tiles[i*1024 ..]. */
 int cbh_dcthash_tiles_dev(const void* d_imgs, size_t n, int w, int h, size_t row_stride,

@@ -216,6 +216,43 @@ class Oracle:
             raise ValueError(f"orc_dcthash64_batch rc={rc}")
         return o
 
+    # ---- sizeLongestSide (src/cvutil.cpp:1932-1950) ----
+    def longest_side_dims(self, w, h, size):
+        ow, oh = C.c_int(0), C.c_int(0)
+        f = self.L.orc_longest_side_dims
+        f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        f.restype = None
+        f(w, h, size, C.byref(ow), C.byref(oh))
+        return ow.value, oh.value
+
+    def lanczos4_tab(self, ssize, dsize):
+        ofs = np.zeros(dsize, np.int32)
+        coef = np.zeros((dsize, 8), np.int16)
+        f = self.L.orc_lanczos4_tab
+        f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        f.restype = None
+        f(ssize, dsize, ofs.ctypes.data, coef.ctypes.data)
+        return ofs, coef
+
+    def resize_lanczos4(self, img, dw, dh):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.zeros((dh, dw), np.uint8)
+        f = self.L.orc_resize_lanczos4_u8
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        f.restype = C.c_int
+        rc = f(img.ctypes.data, w, h, w, dw, dh, out.ctypes.data)
+        if rc:
+            raise ValueError(f"orc_resize_lanczos4_u8 rc={rc}")
+        return out
+
+    def size_longest_side(self, img, size=400):
+        h, w = img.shape
+        dw, dh = self.longest_side_dims(w, h, size)
+        if dw == 0 or dh == 0:
+            raise ValueError("sizeLongestSide: computed width or height is 0")
+        return self.resize_lanczos4(img, dw, dh)
+
     # ---- Media::makeKeyPointHashes (src/media.cpp:874-923) ----
     def keypoint_rects(self, cols, rows, kp):
         kp = np.ascontiguousarray(kp, np.float32).reshape(-1, 3)

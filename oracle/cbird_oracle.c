@@ -540,6 +540,93 @@ int orc_dcthash64_batch(const uint8_t* imgs, size_t n, int w, int h, size_t row_
   return ORC_OK;
 }
 
+/* ---- sizeLongestSide: src/cvutil.cpp:1932-1950 (called at scanner.cpp:876 before ORB) -------------------------
+ * Target size from the float aspect ratio (:1934-1942), then cv::resize(..., INTER_LANCZOS4), the default filter
+ * (cvutil.h:251).  cv::resize's 8-bit Lanczos path (OpenCV 2.4 imgproc/imgwarp.cpp, as recalled -- "parity
+ * unpinned"): per destination column  fx = (float)((dx+0.5)*scale_x - 0.5); sx = floor(fx); fx -= sx;  eight taps
+ * sx-3..sx+4 with interpolateLanczos4(fx) weights normalised in float, converted to fixed point
+ * saturate_cast<short>(w * 2048); tap positions outside the image are clamped to the edge; rows likewise.
+ * Horizontal pass in int (sum S*alpha), vertical pass in int (sum D*beta), result (v + 2^21) >> 22 saturated --
+ * all integer, so any evaluation order gives the same bytes.  There is no anti-aliasing: a 10x reduction still reads
+ * 8x8 source pixels per output pixel. */
+void orc_longest_side_dims(int w, int h, int size, int* ow, int* oh) {
+  float aspect = (float)w / h;
+  if (w > h) {
+    *ow = size;
+    *oh = (int)(size / aspect);
+  } else {
+    *oh = size;
+    *ow = (int)(aspect * size);
+  }
+}
+
+static void lanczos4_coeffs(float x, float* coeffs) {
+  static const double s45 = 0.70710678118654752440084436210485;
+  static const double cs[8][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+  if (x < FLT_EPSILON) {
+    for (int i = 0; i < 8; i++) coeffs[i] = 0;
+    coeffs[3] = 1;
+    return;
+  }
+  float sum = 0;
+  double y0 = -(x + 3) * M_PI * 0.25, s0 = sin(y0), c0 = cos(y0);
+  for (int i = 0; i < 8; i++) {
+    double y = -(x + 3 - i) * M_PI * 0.25;
+    coeffs[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+    sum += coeffs[i];
+  }
+  sum = 1.f / sum;
+  for (int i = 0; i < 8; i++) coeffs[i] *= sum;
+}
+
+/* per destination index: first source index (the tap "3" position) and 8 fixed-point weights */
+void orc_lanczos4_tab(int ssize, int dsize, int* ofs, short* coef /* dsize*8 */) {
+  double inv_scale = (double)dsize / ssize;
+  double scale = 1. / inv_scale;
+  for (int d = 0; d < dsize; ++d) {
+    float fx = (float)((d + 0.5) * scale - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    float c[8];
+    lanczos4_coeffs(fx, c);
+    ofs[d] = sx;
+    for (int k = 0; k < 8; ++k) coef[d * 8 + k] = sat_short_round(c[k] * 2048.f);
+  }
+}
+
+int orc_resize_lanczos4_u8(const uint8_t* src, int w, int h, size_t stride, int dw, int dh, uint8_t* dst) {
+  if (!src || !dst || w <= 0 || h <= 0 || dw <= 0 || dh <= 0 || stride < (size_t)w) return ORC_E_INVAL;
+  int* xofs = (int*)malloc(sizeof(int) * (size_t)dw);
+  int* yofs = (int*)malloc(sizeof(int) * (size_t)dh);
+  short* xa = (short*)malloc(sizeof(short) * 8 * (size_t)dw);
+  short* yb = (short*)malloc(sizeof(short) * 8 * (size_t)dh);
+  orc_lanczos4_tab(w, dw, xofs, xa);
+  orc_lanczos4_tab(h, dh, yofs, yb);
+  for (int dy = 0; dy < dh; ++dy)
+    for (int dx = 0; dx < dw; ++dx) {
+      int v = 0;
+      for (int k = 0; k < 8; ++k) {
+        int sy = yofs[dy] - 3 + k;
+        sy = sy < 0 ? 0 : sy > h - 1 ? h - 1 : sy;
+        const uint8_t* S = src + (size_t)sy * stride;
+        int D = 0;
+        for (int j = 0; j < 8; ++j) {
+          int sx = xofs[dx] - 3 + j;
+          sx = sx < 0 ? 0 : sx > w - 1 ? w - 1 : sx;
+          D += S[sx] * xa[dx * 8 + j];
+        }
+        v += D * yb[dy * 8 + k];
+      }
+      v = (v + (1 << 21)) >> 22;
+      dst[(size_t)dy * dw + dx] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+    }
+  free(xofs);
+  free(yofs);
+  free(xa);
+  free(yb);
+  return ORC_OK;
+}
+
 /* ---- Media::makeKeyPointHashes: src/media.cpp:874-923 -----------------------------------------------
  * Rectangles: keypoints with size >= 31 whose square (pt, pt + size) lies inside (0, cols-2) x (0, rows-2)
  * (float comparisons, :887-894) become Rect(floor x, floor y, ceil size, ceil size) -- anchored at the keypoint,

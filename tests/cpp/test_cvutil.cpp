@@ -58,5 +58,15 @@ int main(int argc, char** argv) {
   for (int y = 0; y < h; ++y)
     for (int x = 0; x < w; ++x) sum = sum * 1099511628211ull + img.ptr<uint8_t>(y)[x];
   printf("after_kp_checksum %" PRIu64 "\n", sum);
+  // 4. sizeLongestSide on a fresh copy of the original pattern (img itself was blurred above)
+  cv::Mat big(h, w);
+  uint32_t seed2 = uint32_t(atoi(argv[3]));
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) big.ptr<uint8_t>(y)[x] = uint8_t(xs(seed2) >> 24);
+  cbird_gpu::gpuSizeLongestSide(big, 128);
+  sum = 0;
+  for (int y = 0; y < big.rows; ++y)
+    for (int x = 0; x < big.cols; ++x) sum = sum * 1099511628211ull + big.ptr<uint8_t>(y)[x];
+  printf("resized %d %d %" PRIu64 "\n", big.cols, big.rows, sum);
   return 0;
 }

@@ -49,6 +49,7 @@ def test_cvutil_dropins_compile():
     src = open(os.path.join(ROOT, "cbird_amd", "cpp", "gpu_cvutil.h")).read()
     assert "gpuDctHash64(const cv::Mat& cvImg, bool inPlace = false)" in src
     assert "gpuMakeKeyPointHashes(const cv::Mat& cvImg, const KeyPointList& keyPoints, KeyPointHashList& outHashes)" in src
+    assert "gpuSizeLongestSide(cv::Mat& img, int size)" in src
 
 
 def _xorshift_stream(seed):
@@ -98,3 +99,5 @@ def test_cvutil_dropins_run_on_gpu(gpu, orc, w, h, seed):
     assert len(want) >= 5
     assert got["kp"] == [42] + want.tolist()
     assert got["after_kp_checksum"] == [_checksum(after)]
+    small = orc.size_longest_side(img, 128)
+    assert got["resized"] == [small.shape[1], small.shape[0], _checksum(small)]

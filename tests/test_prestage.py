@@ -84,3 +84,73 @@ def test_gpu_process_images_vs_oracle(gpu, po):
         for i in range(4):
             wh, wr = po.process_image(col[i], 20)
             assert rects[i].tolist() == wr.tolist() and int(got[i]) == wh, (ch, i)
+
+
+# ---- sizeLongestSide (src/cvutil.cpp:1932-1950): the resize in front of ORB detection -------------------------
+
+def test_longest_side_dims_and_lanczos_table(orc):
+    """float aspect + truncation (:1934-1942); Lanczos-4 weights: unit DC gain within the fixed-point rounding,
+    symmetric pairs for mirrored phases, identity at integer positions"""
+    assert orc.longest_side_dims(4000, 3000, 400) == (400, 300)
+    assert orc.longest_side_dims(3000, 4000, 400) == (300, 400)
+    assert orc.longest_side_dims(300, 500, 400) == (240, 400)
+    assert orc.longest_side_dims(500, 500, 400) == (400, 400)   # w > h is false: h = size, w = int(1.0 * 400)
+    assert orc.longest_side_dims(1000, 3, 400) == (400, 1)
+    assert orc.longest_side_dims(1000, 1, 400)[1] == 0          # the reference throws std::invalid_argument here
+    for ssize, dsize in ((1000, 400), (4000, 300), (123, 400), (400, 400), (37, 400)):
+        ofs, c = orc.lanczos4_tab(ssize, dsize)
+        assert np.abs(c.astype(int).sum(1) - 2048).max() <= 3
+        assert (np.diff(ofs) >= 0).all() and ofs[0] >= -1 and ofs[-1] <= ssize - 1
+    ofs, c = orc.lanczos4_tab(400, 400)
+    assert (ofs == np.arange(400)).all() and (c[:, 3] == 2048).all() and (np.delete(c, 3, 1) == 0).all()
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (60, 80), dtype=np.uint8)
+    assert (orc.resize_lanczos4(img, 80, 60) == img).all()
+    # against a float evaluation of the same separable filter (weights from the table, no fixed-point rounding)
+    img = rng.integers(0, 256, (300, 500), dtype=np.uint8)
+    out = orc.size_longest_side(img, 400).astype(np.float64)
+    xo, xc = orc.lanczos4_tab(500, 400)
+    yo, yc = orc.lanczos4_tab(300, 240)
+    wx = np.zeros((400, 500))
+    for d in range(400):
+        for j in range(8):
+            wx[d, min(max(xo[d] - 3 + j, 0), 499)] += xc[d, j] / 2048
+    wy = np.zeros((240, 300))
+    for d in range(240):
+        for j in range(8):
+            wy[d, min(max(yo[d] - 3 + j, 0), 299)] += yc[d, j] / 2048
+    ref = np.clip(wy @ img.astype(np.float64) @ wx.T, 0, 255)
+    assert np.abs(out - ref).max() <= 0.5 + 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,size", [(500, 300, 400), (300, 500, 400), (1920, 1080, 400), (123, 77, 400),
+                                      (400, 400, 400), (4000, 3000, 400), (37, 1000, 256), (640, 480, 64)])
+def test_size_longest_side_matches_oracle(gpu, orc, w, h, size):
+    from cbird_amd.hashing import size_longest_side
+
+    rng = np.random.default_rng(w * 7 + h)
+    n = 2 if w * h > 4_000_000 else 3
+    yy, xx = np.mgrid[0:h, 0:w]
+    imgs = np.stack([np.clip(128 + 90 * np.sin(xx / (9.0 + i)) * np.cos(yy / 13.0) + rng.normal(0, 25, (h, w)), 0, 255)
+                     .astype(np.uint8) for i in range(n)])
+    got = size_longest_side(imgs, size)
+    for i in range(n):
+        want = orc.size_longest_side(imgs[i], size)
+        assert got[i].shape == want.shape
+        assert (got[i] == want).all(), (i, np.abs(got[i].astype(int) - want.astype(int)).max())
+    # strided input view (row padding)
+    pad = np.zeros((n, h, w + 5), np.uint8)
+    pad[:, :, :w] = imgs
+    assert (size_longest_side(pad[:, :, :w], size) == got).all()
+
+
+@pytest.mark.gpu
+def test_size_longest_side_errors(gpu):
+    from cbird_amd import _lib
+    from cbird_amd.hashing import size_longest_side
+
+    with pytest.raises(gpu.CbhError) as e:
+        size_longest_side(np.zeros((1, 1, 1000), np.uint8), 400)  # computed height 0
+    assert e.value.code == _lib.CBH_E_INVAL
+    assert size_longest_side(np.zeros((0, 30, 40), np.uint8), 400).shape == (0, 300, 400)
