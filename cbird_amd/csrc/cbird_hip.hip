@@ -683,6 +683,10 @@ int cbh_set_tuning(const char* key, int value) {
     set_kp_lds_side(value);
     return CBH_OK;
   }
+  if (!strcmp(key, "hash_fused")) {
+    set_hash_fused(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "hash_fast_any")) {
     set_hash_fast_any(value);
     return CBH_OK;

@@ -973,9 +973,177 @@ __global__ __launch_bounds__(256) void k_area_rows(const unsigned char* __restri
   *o = buf;
 }
 
+// k_blur_rows and k_area_rows in one pass (the default path): the blurred band stays in LDS and is
+// reduced to 32 floats per source row straight away, so the blurred plane (1 B/px written + 1 B/px read back) never
+// reaches HBM -- traffic falls from ~3.4 to ~1.4 B per pixel.  A workgroup owns `cpw` of the 32 output columns (all 32
+// up to 2048 image columns, 16 up to 4096, 8 up to 8192): its window starts at the first source column of its first
+// cell, so every cell's float accumulation  buf += S * alpha  runs start to end inside one workgroup, in table order.
+// rows[] is indexed by SOURCE row here (k_tile_hash by_src = 1).
+template <int K>
+__global__ __launch_bounds__(256) void k_blur_area(const unsigned char* __restrict__ imgs, int w, int h,
+                                                   size_t row_stride, size_t img_stride,
+                                                   const AreaTab* __restrict__ xtab, const int* __restrict__ xfirst,
+                                                   int isx, int cpw, int pitch /* 8 * blockDim.x + 8 */,
+                                                   float* __restrict__ rows /* n * h * 32 */) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_fused[];
+  constexpr int R = K / 2;
+  constexpr int kMaxRows = kBlurRB + K - 1;
+  const int T = (int)blockDim.x, tid = (int)threadIdx.x;
+  const int bpitch = 8 * T;
+  unsigned char* __restrict__ sband = s_fused;  // kMaxRows x pitch; later the kBlurRB x bpitch blurred rows
+  unsigned char* __restrict__ sblur = s_fused;
+  float* __restrict__ salpha = reinterpret_cast<float*>(s_fused + (size_t)kMaxRows * pitch);
+  const int c0 = (int)blockIdx.x * cpw, c1 = c0 + cpw;
+  const int k_base = isx ? 0 : xfirst[c0], k_end = isx ? 0 : xfirst[c1];
+  const int cx0 = isx ? c0 * isx : xtab[k_base].si;             // first image column of this workgroup's cells
+  const int cxe = isx ? c1 * isx : xtab[k_end - 1].si + 1;      // one past their last column
+  const int y0 = (int)blockIdx.y * kBlurRB;
+  const unsigned char* __restrict__ img = imgs + (size_t)blockIdx.z * img_stride;
+  const int out_rows = min(kBlurRB, h - y0);
+  const int nrows = out_rows + 2 * R;
+  const int ndw = pitch >> 2;
+  for (int i = tid; i < k_end - k_base; i += T) salpha[i] = xtab[k_base + i].alpha;
+  // LDS column c <-> image x = cx0 - 4 + c (as in k_blur_rows)
+  for (int dwi = tid; dwi < ndw; dwi += T) {
+    const int x = cx0 - 4 + 4 * dwi;
+    if (x >= 0 && x + 3 < w) {
+      unsigned v[kMaxRows];
+#pragma unroll
+      for (int rr = 0; rr < kMaxRows; ++rr) {
+        int ry = y0 - R + rr;
+        ry = ry < 0 ? -ry : (ry >= h ? 2 * (h - 1) - ry : ry);
+        ry = ry < 0 ? 0 : (ry >= h ? h - 1 : ry);
+        v[rr] = *reinterpret_cast<const u32_any_align*>(img + (size_t)ry * row_stride + x);
+      }
+#pragma unroll
+      for (int rr = 0; rr < kMaxRows; ++rr)
+        if (rr < nrows) *reinterpret_cast<unsigned*>(sband + (size_t)rr * pitch + 4 * dwi) = v[rr];
+    }
+  }
+  {
+    const int nl = cx0 == 0 ? 4 : 0;
+    const int c_right = ((w - cx0 + 4) >> 2) << 2;
+    const int nr = max(0, min(pitch, w - cx0 + 7) - c_right);
+    const int per_row = nl + nr;
+    for (int e = tid; e < per_row * nrows; e += T) {
+      const int rr = e / per_row, k = e - rr * per_row;
+      const int c = k < nl ? k : c_right + (k - nl);
+      int xx = cx0 - 4 + c;
+      xx = xx < 0 ? -xx : xx;
+      xx = xx >= w ? 2 * (w - 1) - xx : xx;
+      xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+      sband[(size_t)rr * pitch + c] = img[(size_t)reflect101(y0 - R + rr, h) * row_stride + xx];
+    }
+  }
+  __syncthreads();
+  // blur: this lane's 8 columns, all rows of the band.  The results wait in registers until every lane is done with
+  // the band, then overwrite it: the blurred rows alias the band's LDS (one buffer instead of two -> more workgroups
+  // per CU).  The row loop is fully unrolled so that the result registers are indexed statically.
+  uint2 qo[kBlurRB];
+  const bool lane_live = cx0 + 8 * tid < cxe;
+  if (lane_live) {
+    unsigned ring[K][4];
+    unsigned S[4];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) ring[j][c] = 0u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) S[c] = BlurK<K>::add | (BlurK<K>::add << 16);
+    const unsigned char* __restrict__ win = sband + 8 * tid;
+#pragma unroll
+    for (int rr = 0; rr < kMaxRows; ++rr) {
+      if (rr < nrows) {
+        const int j = rr % K;
+        const uint2 a = *reinterpret_cast<const uint2*>(win + (size_t)rr * pitch);
+        const uint2 b = *reinterpret_cast<const uint2*>(win + (size_t)rr * pitch + 8);
+        const unsigned W[4] = {a.x, a.y, b.x, b.y};
+        const unsigned P[4] = {hsum_tap<R, 0>(W) | (hsum_tap<R, 1>(W) << 16), hsum_tap<R, 2>(W) | (hsum_tap<R, 3>(W) << 16),
+                               hsum_tap<R, 4>(W) | (hsum_tap<R, 5>(W) << 16), hsum_tap<R, 6>(W) | (hsum_tap<R, 7>(W) << 16)};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          S[c] = (S[c] - ring[j][c]) + P[c];
+          ring[j][c] = P[c];
+        }
+        if (rr >= 2 * R) {
+          unsigned q[8];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            q[2 * c] = ((S[c] & 0xffffu) * BlurK<K>::m) >> 24;
+            q[2 * c + 1] = ((S[c] >> 16) * BlurK<K>::m) >> 24;
+          }
+          qo[rr - 2 * R].x = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
+          qo[rr - 2 * R].y = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
+        }
+      }
+    }
+  }
+  __syncthreads();  // every lane has read what it needs of the band
+  if (lane_live) {
+#pragma unroll
+    for (int i = 0; i < kBlurRB; ++i)
+      if (i < out_rows) *reinterpret_cast<uint2*>(sblur + (size_t)i * bpitch + 8 * tid) = qo[i];
+  }
+  __syncthreads();
+  // horizontal INTER_AREA pass: one (row, output column) chain per task, in table order.  A lane takes one output
+  // column and two rows at a time (they share the weights), operands fetched eight ahead of the dependent adds.
+  {
+    const int groups = max(1, T / cpw);
+    const int slot = tid / cpw, c = c0 + (tid - slot * cpw);
+    if (slot < groups) {
+      const int k0 = isx ? 0 : xfirst[c], nk = isx ? isx : xfirst[c + 1] - k0;
+      const int col = (isx ? c * isx : xtab[k0].si) - cx0;  // si is consecutive within an output column
+      const float* __restrict__ al = salpha + (k0 - k_base);
+      for (int r = slot; r < out_rows; r += 2 * groups) {
+        const int r2 = r + groups;
+        const bool two = r2 < out_rows;
+        const unsigned char* __restrict__ Sa = sblur + (size_t)r * bpitch + col;
+        const unsigned char* __restrict__ Sb = sblur + (size_t)(two ? r2 : r) * bpitch + col;
+        float* __restrict__ oa = rows + ((size_t)blockIdx.z * (size_t)h + (size_t)(y0 + r)) * 32 + c;
+        float* __restrict__ ob = rows + ((size_t)blockIdx.z * (size_t)h + (size_t)(y0 + (two ? r2 : r))) * 32 + c;
+        if (isx) {
+          unsigned sa = 0, sb = 0;
+          for (int u = 0; u < nk; ++u) {
+            sa += Sa[u];
+            sb += Sb[u];
+          }
+          *oa = __uint_as_float(sa);
+          if (two) *ob = __uint_as_float(sb);
+        } else {
+          float ba = 0.f, bb = 0.f;
+          int k = 0;
+          for (; k + 8 <= nk; k += 8) {
+            float a[8];
+            unsigned pa[8], pb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              a[u] = al[k + u];
+              pa[u] = Sa[k + u];
+              pb[u] = Sb[k + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              ba += (float)pa[u] * a[u];
+              bb += (float)pb[u] * a[u];
+            }
+          }
+          for (; k < nk; ++k) {
+            const float av = al[k];
+            ba += (float)Sa[k] * av;
+            bb += (float)Sb[k] * av;
+          }
+          *oa = ba;
+          if (two) *ob = bb;
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void k_tile_hash(const float* __restrict__ rows, int yn,
                                                         const AreaTab* __restrict__ ytab,
                                                         const int* __restrict__ yfirst, int isx, int isy,
+                                                        int by_src /* rows[] indexed by source row, not table row */,
                                                         const DctTables* __restrict__ tabs,
                                                         uint64_t* __restrict__ out,
                                                         unsigned char* __restrict__ tiles) {
@@ -997,7 +1165,7 @@ __global__ __launch_bounds__(kThreads) void k_tile_hash(const float* __restrict_
       float sum = 0.f;
       const int j0 = yfirst[dy], j1 = yfirst[dy + 1];
       for (int j = j0; j < j1; ++j) {
-        const float t = ytab[j].alpha * R[(size_t)j * 32 + dx];
+        const float t = ytab[j].alpha * R[(size_t)(by_src ? ytab[j].si : j) * 32 + dx];
         sum = (j == j0) ? t : sum + t;
       }
       const float r = __builtin_rintf(sum);
@@ -1622,6 +1790,10 @@ int g_kp_lds_side = 134;  // keypoint squares up to this side are processed in L
 void set_kp_lds_side(int v) {
   if (v >= 32 && v <= 200) g_kp_lds_side = v;
 }
+int g_hash_fused = 1;  // k_blur_area (blur + horizontal area pass in one kernel): 0 off, v >= 1 for widths >= v (measured: wins from 64 up)
+void set_hash_fused(int on) {
+  if (on >= 0) g_hash_fused = on;
+}
 int g_hash_fast_any = 1;  // 1 = k_blur_rows/k_area_rows/k_tile_hash for every geometry but 256x256 and 32x32
 void set_hash_fast_any(int on) {
   if (on >= 0) g_hash_fast_any = on;
@@ -1948,6 +2120,52 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     const int ipb = T % 64 == 0 ? 1 : 256 / T, block_threads = (ipb * T + 63) / 64 * 64;
     const int pitch = T * 8 + 8;
     const size_t smem = (size_t)ipb * (size_t)(kBlurRB + K_ - 1) * (size_t)pitch;
+    if (g_hash_fused && w >= g_hash_fused) {
+      // k_blur_area + k_tile_hash: the blurred plane stays in LDS
+      const int ncol = w <= 2048 ? 1 : w <= 4096 ? 2 : 4, cpw = 32 / ncol;
+      // widest column window of any workgroup (first source column of its first cell .. last of its last)
+      std::vector<int> xf;
+      int win = 0;
+      if (integer) {
+        win = cpw * isx;
+      } else {
+        std::vector<AreaTab> xt = make_area_tab(w, 32, &xf);
+        for (int c = 0; c < 32; c += cpw)
+          win = std::max(win, xt[(size_t)xf[(size_t)(c + cpw)] - 1].si + 1 - xt[(size_t)xf[(size_t)c]].si);
+      }
+      const int Tf = std::min(256, ((win + 7) / 8 + 63) / 64 * 64);
+      if ((win + 7) / 8 > 256) return CBH_E_UNSUPPORTED;  // cannot happen for w <= 8192
+      const int fpitch = Tf * 8 + 8;
+      const size_t fsmem = (size_t)(kBlurRB + K_ - 1) * fpitch + (size_t)(integer ? 0 : at.xn) * sizeof(float);
+      const size_t per_chunk_f = std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)h * 128));
+      float* d_rowsf = nullptr;
+      CBH_HIP(hipMallocAsync((void**)&d_rowsf, std::min(per_chunk_f, n) * (size_t)h * 32 * sizeof(float), stream));
+      for (size_t i0 = 0; i0 < n; i0 += per_chunk_f) {
+        const size_t m = std::min(per_chunk_f, n - i0);
+        const unsigned char* src = d_imgs + i0 * img_stride;
+        dim3 gf((unsigned)ncol, (unsigned)((h + kBlurRB - 1) / kBlurRB), (unsigned)m);
+#define CBH_FUSED(KK)                                                                                    \
+  do {                                                                                                   \
+    if (fsmem > 64 * 1024)                                                                               \
+      CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_area<KK>),                        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsmem));              \
+    hipLaunchKernelGGL(k_blur_area<KK>, gf, dim3((unsigned)Tf), fsmem, stream, src, w, h, row_stride,    \
+                       img_stride, at.x, at.xfirst, isx, cpw, fpitch, d_rowsf);                          \
+  } while (0)
+        switch (K_) {
+          case 3: CBH_FUSED(3); break;
+          case 5: CBH_FUSED(5); break;
+          default: CBH_FUSED(7); break;
+        }
+#undef CBH_FUSED
+        hipLaunchKernelGGL(k_tile_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_rowsf, h, at.y, at.yfirst, isx,
+                           isy, 1, tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
+      }
+      hipError_t ef = hipGetLastError();
+      (void)hipFreeAsync(d_rowsf, stream);
+      CBH_HIP(ef);
+      return CBH_OK;
+    }
     const size_t per_chunk = std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)w * h));
     const size_t mc = std::min(per_chunk, n);
     unsigned char* d_blur = nullptr;
@@ -1981,7 +2199,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
       hipLaunchKernelGGL(k_area_rows, dim3((unsigned)((yn + 7) / 8), (unsigned)m), dim3(256), asmem, stream,
                          d_blur, w, h, at.x, at.xn, at.xfirst, at.y, yn, isx, d_rows, apitch);
       hipLaunchKernelGGL(k_tile_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_rows, yn, at.y, at.yfirst,
-                         isx, isy, tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
+                         isx, isy, 0, tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
     }
     hipError_t e = hipGetLastError();
     (void)hipFreeAsync(d_rows, stream);

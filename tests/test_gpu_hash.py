@@ -165,7 +165,9 @@ def test_hash_random_geometries_and_strides(gpu, orc):
             (2049, 40), (2056, 34), (4100, 64), (96, 4097), (2304, 1728), (8190, 33), (33, 8192),
             # cv::resize's scale = 1/(32/w) misses w/32 by an ulp: 32*49 and 32*93 leave the integer path,
             # 3885 gets a different weight table (oracle: cv_resize_scale)
-            (1568, 1568), (1568, 64), (64, 2976), (3885, 33)]
+            (1568, 1568), (1568, 64), (64, 2976), (3885, 33),
+            # fused kernel: 1 / 2 / 4 column workgroups, widths around their limits, integer ratios
+            (512, 40), (2048, 64), (2050, 33), (4096, 35), (4097, 32), (6000, 48), (8192, 33), (1024, 1024), (4064, 96)]
     geos += [(int(rng.integers(32, 700)), int(rng.integers(32, 700))) for _ in range(10)]
     try:
         for (w, h) in geos:
@@ -177,8 +179,10 @@ def test_hash_random_geometries_and_strides(gpu, orc):
             imgs = np.stack([buf[i, : h * (w + pad_x)].reshape(h, w + pad_x)[:, :w] for i in range(n)])
             want = orc.dcthash64_batch(np.ascontiguousarray(imgs))
             d = torch.from_numpy(buf).cuda()
-            for fast in ((1, 0) if w <= 7000 else (1,)):  # the first general kernels stage 7 full rows in LDS: w <= ~7800
+            # (fast, fused): fused blur+area kernel (widths >= 512), the three-kernel split, the first general kernels
+            for fast, fused in (((1, 1), (1, 0), (0, 0)) if w <= 7000 else ((1, 1), (1, 0))):  # (0,0): LDS limits w <= ~7800
                 L.cbh_set_tuning(b"hash_fast_any", fast)
+                L.cbh_set_tuning(b"hash_fused", fused)
                 out = torch.zeros(n, dtype=torch.int64, device="cuda")
                 tiles = torch.zeros((n, 32, 32), dtype=torch.uint8, device="cuda")
                 _lib.check(L.cbh_dcthash_tiles_dev(d.data_ptr(), n, w, h, w + pad_x, buf.shape[1], out.data_ptr(),
@@ -186,7 +190,8 @@ def test_hash_random_geometries_and_strides(gpu, orc):
                 got = out.cpu().numpy().view(np.uint64)
                 t = tiles.cpu().numpy()
                 for i in range(n):
-                    assert (t[i] == orc.tile32(np.ascontiguousarray(imgs[i]))).all(), (w, h, fast, i)
-                assert (got == want).all(), (w, h, fast)
+                    assert (t[i] == orc.tile32(np.ascontiguousarray(imgs[i]))).all(), (w, h, fast, fused, i)
+                assert (got == want).all(), (w, h, fast, fused)
     finally:
         L.cbh_set_tuning(b"hash_fast_any", 1)
+        L.cbh_set_tuning(b"hash_fused", 1)
