@@ -683,6 +683,10 @@ int cbh_set_tuning(const char* key, int value) {
     set_kp_lds_side(value);
     return CBH_OK;
   }
+  if (!strcmp(key, "hash_stream")) {
+    set_hash_stream(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "hash_fused")) {
     set_hash_fused(value);
     return CBH_OK;

@@ -1140,6 +1140,180 @@ __global__ __launch_bounds__(256) void k_blur_area(const unsigned char* __restri
   }
 }
 
+// Streaming form of k_blur_area for batches with enough workgroups to spare: a workgroup walks down a strip of the
+// image in steps of kStep source rows (a multiple of K, so the register ring keeps its phase) and carries the sliding
+// column sums from step to step -- the K-1 halo rows are read and summed once per strip instead of once per 16-row
+// band (x1.375 fewer loads and tap sums).  Per step: kStep new source rows -> LDS, blur (results lag the rows read by
+// R), blurred rows over the same LDS, horizontal INTER_AREA chains, 32 floats per source row out.
+template <int K>
+struct StreamK {
+  static constexpr int step = K == 7 ? 14 : 15;  // rows per step: a multiple of K
+};
+template <int K>
+__global__ __launch_bounds__(256) void k_blur_area_stream(const unsigned char* __restrict__ imgs, int w, int h,
+                                                          size_t row_stride, size_t img_stride,
+                                                          const AreaTab* __restrict__ xtab,
+                                                          const int* __restrict__ xfirst, int isx, int cpw,
+                                                          int pitch /* 8 * blockDim.x + 8 */, int steps /* per strip */,
+                                                          float* __restrict__ rows /* n * h * 32 */) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_fused[];
+  constexpr int R = K / 2;
+  constexpr int kStep = StreamK<K>::step;
+  const int T = (int)blockDim.x, tid = (int)threadIdx.x;
+  const int bpitch = 8 * T;
+  unsigned char* __restrict__ sband = s_fused;  // kStep x pitch source rows; then the kStep x bpitch blurred rows
+  float* __restrict__ salpha = reinterpret_cast<float*>(s_fused + (size_t)kStep * pitch);
+  const int c0 = (int)blockIdx.x * cpw, c1 = c0 + cpw;
+  const int k_base = isx ? 0 : xfirst[c0], k_end = isx ? 0 : xfirst[c1];
+  const int cx0 = isx ? c0 * isx : xtab[k_base].si;
+  const int cxe = isx ? c1 * isx : xtab[k_end - 1].si + 1;
+  const int strip_out = steps * kStep - 2 * R;            // blurred rows a strip produces
+  const int o0 = (int)blockIdx.y * strip_out;             // first output row of this strip
+  const int o1 = min(h, o0 + strip_out);
+  const unsigned char* __restrict__ img = imgs + (size_t)blockIdx.z * img_stride;
+  const int ndw = pitch >> 2;
+  for (int i = tid; i < k_end - k_base; i += T) salpha[i] = xtab[k_base + i].alpha;
+  const bool lane_live = cx0 + 8 * tid < cxe;
+  unsigned ring[K][4];
+  unsigned S[4];
+#pragma unroll
+  for (int j = 0; j < K; ++j)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ring[j][c] = 0u;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) S[c] = BlurK<K>::add | (BlurK<K>::add << 16);
+  // area-pass lane roles (fixed for the whole strip)
+  const int groups = max(1, T / cpw);
+  const int slot = tid / cpw, cc = c0 + (tid - slot * cpw);
+  const int ak0 = (slot < groups && !isx) ? xfirst[cc] : 0;
+  const int ank = slot < groups ? (isx ? isx : xfirst[cc + 1] - ak0) : 0;
+  const int acol = slot < groups ? ((isx ? cc * isx : xtab[ak0].si) - cx0) : 0;
+  const float* __restrict__ al = salpha + (ak0 - k_base);
+
+  for (int st = 0; st < steps; ++st) {
+    const int s0 = o0 - R + st * kStep;  // first source row consumed in this step (may be < 0 or >= h: reflected)
+    if (s0 - R >= o1) break;             // nothing left to output (uniform)
+    // ---- kStep source rows -> LDS (column c <-> image x = cx0 - 4 + c) ----
+    for (int dwi = tid; dwi < ndw; dwi += T) {
+      const int x = cx0 - 4 + 4 * dwi;
+      if (x >= 0 && x + 3 < w) {
+        unsigned v[kStep];
+#pragma unroll
+        for (int rr = 0; rr < kStep; ++rr) {
+          int ry = s0 + rr;
+          ry = ry < 0 ? -ry : (ry >= h ? 2 * (h - 1) - ry : ry);
+          ry = ry < 0 ? 0 : (ry >= h ? h - 1 : ry);  // rows past what any output needs: any valid row
+          v[rr] = *reinterpret_cast<const u32_any_align*>(img + (size_t)ry * row_stride + x);
+        }
+#pragma unroll
+        for (int rr = 0; rr < kStep; ++rr) *reinterpret_cast<unsigned*>(sband + (size_t)rr * pitch + 4 * dwi) = v[rr];
+      }
+    }
+    {
+      const int nl = cx0 == 0 ? 4 : 0;
+      const int c_right = ((w - cx0 + 4) >> 2) << 2;
+      const int nr = max(0, min(pitch, w - cx0 + 7) - c_right);
+      const int per_row = nl + nr;
+      for (int e = tid; e < per_row * kStep; e += T) {
+        const int rr = e / per_row, k = e - rr * per_row;
+        const int c = k < nl ? k : c_right + (k - nl);
+        int xx = cx0 - 4 + c;
+        xx = xx < 0 ? -xx : xx;
+        xx = xx >= w ? 2 * (w - 1) - xx : xx;
+        xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+        int ry = s0 + rr;
+        ry = ry < 0 ? -ry : (ry >= h ? 2 * (h - 1) - ry : ry);
+        ry = ry < 0 ? 0 : (ry >= h ? h - 1 : ry);
+        sband[(size_t)rr * pitch + c] = img[(size_t)ry * row_stride + xx];
+      }
+    }
+    __syncthreads();
+    // ---- blur: consume the kStep rows; the result for source row s0 + rr is blurred row s0 + rr - R ----
+    uint2 qo[kStep];
+    if (lane_live) {
+      const unsigned char* __restrict__ win = sband + 8 * tid;
+#pragma unroll
+      for (int rr = 0; rr < kStep; ++rr) {
+        const int j = rr % K;
+        const uint2 a = *reinterpret_cast<const uint2*>(win + (size_t)rr * pitch);
+        const uint2 b = *reinterpret_cast<const uint2*>(win + (size_t)rr * pitch + 8);
+        const unsigned W[4] = {a.x, a.y, b.x, b.y};
+        const unsigned P[4] = {hsum_tap<R, 0>(W) | (hsum_tap<R, 1>(W) << 16), hsum_tap<R, 2>(W) | (hsum_tap<R, 3>(W) << 16),
+                               hsum_tap<R, 4>(W) | (hsum_tap<R, 5>(W) << 16), hsum_tap<R, 6>(W) | (hsum_tap<R, 7>(W) << 16)};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          S[c] = (S[c] - ring[j][c]) + P[c];
+          ring[j][c] = P[c];
+        }
+        unsigned q[8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          q[2 * c] = ((S[c] & 0xffffu) * BlurK<K>::m) >> 24;
+          q[2 * c + 1] = ((S[c] >> 16) * BlurK<K>::m) >> 24;
+        }
+        qo[rr].x = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
+        qo[rr].y = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
+      }
+    }
+    __syncthreads();  // every lane has read the source rows
+    if (lane_live) {
+#pragma unroll
+      for (int rr = 0; rr < kStep; ++rr) *reinterpret_cast<uint2*>(sband + (size_t)rr * bpitch + 8 * tid) = qo[rr];
+    }
+    __syncthreads();
+    // ---- horizontal INTER_AREA chains for the valid blurred rows of this step: local row rr <-> image row s0 + rr - R
+    {
+      const int ob = s0 - R;                                  // image row of local row 0
+      const int lo = max(0, o0 - ob), hi = min(kStep, o1 - ob);  // valid local rows [lo, hi)
+      if (slot < groups) {
+        for (int r = lo + slot; r < hi; r += 2 * groups) {
+          const int r2 = r + groups;
+          const bool two = r2 < hi;
+          const unsigned char* __restrict__ Sa = sband + (size_t)r * bpitch + acol;
+          const unsigned char* __restrict__ Sb = sband + (size_t)(two ? r2 : r) * bpitch + acol;
+          float* __restrict__ oa = rows + ((size_t)blockIdx.z * (size_t)h + (size_t)(ob + r)) * 32 + cc;
+          float* __restrict__ obp = rows + ((size_t)blockIdx.z * (size_t)h + (size_t)(ob + (two ? r2 : r))) * 32 + cc;
+          if (isx) {
+            unsigned sa = 0, sb = 0;
+            for (int u = 0; u < ank; ++u) {
+              sa += Sa[u];
+              sb += Sb[u];
+            }
+            *oa = __uint_as_float(sa);
+            if (two) *obp = __uint_as_float(sb);
+          } else {
+            float ba = 0.f, bb = 0.f;
+            int k = 0;
+            for (; k + 8 <= ank; k += 8) {
+              float a[8];
+              unsigned pa[8], pb[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                a[u] = al[k + u];
+                pa[u] = Sa[k + u];
+                pb[u] = Sb[k + u];
+              }
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                ba += (float)pa[u] * a[u];
+                bb += (float)pb[u] * a[u];
+              }
+            }
+            for (; k < ank; ++k) {
+              const float av = al[k];
+              ba += (float)Sa[k] * av;
+              bb += (float)Sb[k] * av;
+            }
+            *oa = ba;
+            if (two) *obp = bb;
+          }
+        }
+      }
+    }
+    __syncthreads();  // the blurred rows are consumed before the next step overwrites them
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void k_tile_hash(const float* __restrict__ rows, int yn,
                                                         const AreaTab* __restrict__ ytab,
                                                         const int* __restrict__ yfirst, int isx, int isy,
@@ -1790,6 +1964,10 @@ int g_kp_lds_side = 134;  // keypoint squares up to this side are processed in L
 void set_kp_lds_side(int v) {
   if (v >= 32 && v <= 200) g_kp_lds_side = v;
 }
+int g_hash_stream = 1;  // k_blur_area_stream: 0 off, 1 auto (strips of 3..8 steps when the batch is large), v >= 2: v steps
+void set_hash_stream(int v) {
+  if (v >= 0) g_hash_stream = v;
+}
 int g_hash_fused = 1;  // k_blur_area (blur + horizontal area pass in one kernel): 0 off, v >= 1 for widths >= v (measured: wins from 64 up)
 void set_hash_fused(int on) {
   if (on >= 0) g_hash_fused = on;
@@ -2143,6 +2321,35 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
       for (size_t i0 = 0; i0 < n; i0 += per_chunk_f) {
         const size_t m = std::min(per_chunk_f, n - i0);
         const unsigned char* src = d_imgs + i0 * img_stride;
+        // streaming form when the batch leaves enough workgroups: strips of `steps` steps
+        const int kstep = K_ == 7 ? 14 : 15;
+        const long long band_wgs = (long long)ncol * ((h + kBlurRB - 1) / kBlurRB) * (long long)m;
+        int steps = (int)std::min<long long>(8, band_wgs / 3072);
+        steps = std::min(steps, (h + 2 * (K_ / 2) + kstep - 1) / kstep);
+        if (w < 192 || h < 128) steps = 0;  // measured: narrow or short images are faster band by band
+        if (g_hash_stream >= 2) steps = g_hash_stream;
+        if (g_hash_stream && steps >= 3) {
+          const int strip_out = steps * kstep - 2 * (K_ / 2);
+          dim3 gs((unsigned)ncol, (unsigned)((h + strip_out - 1) / strip_out), (unsigned)m);
+          const size_t ssmem = (size_t)kstep * fpitch + (size_t)(integer ? 0 : at.xn) * sizeof(float);
+#define CBH_STREAM(KK)                                                                                      \
+  do {                                                                                                      \
+    if (ssmem > 64 * 1024)                                                                                  \
+      CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_area_stream<KK>),                    \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ssmem));                 \
+    hipLaunchKernelGGL(k_blur_area_stream<KK>, gs, dim3((unsigned)Tf), ssmem, stream, src, w, h, row_stride, \
+                       img_stride, at.x, at.xfirst, isx, cpw, fpitch, steps, d_rowsf);                      \
+  } while (0)
+          switch (K_) {
+            case 3: CBH_STREAM(3); break;
+            case 5: CBH_STREAM(5); break;
+            default: CBH_STREAM(7); break;
+          }
+#undef CBH_STREAM
+          hipLaunchKernelGGL(k_tile_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_rowsf, h, at.y, at.yfirst,
+                             isx, isy, 1, tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
+          continue;
+        }
         dim3 gf((unsigned)ncol, (unsigned)((h + kBlurRB - 1) / kBlurRB), (unsigned)m);
 #define CBH_FUSED(KK)                                                                                    \
   do {                                                                                                   \

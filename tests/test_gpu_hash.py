@@ -180,9 +180,13 @@ def test_hash_random_geometries_and_strides(gpu, orc):
             want = orc.dcthash64_batch(np.ascontiguousarray(imgs))
             d = torch.from_numpy(buf).cuda()
             # (fast, fused): fused blur+area kernel (widths >= 512), the three-kernel split, the first general kernels
-            for fast, fused in (((1, 1), (1, 0), (0, 0)) if w <= 7000 else ((1, 1), (1, 0))):  # (0,0): LDS limits w <= ~7800
+            # (fast, fused, stream): fused blur+area kernel per 16-row band (stream 0) or walking down strips of 3 / 8
+            # steps (forced: the automatic choice needs thousands of images), the three-kernel split, the first kernels
+            cfgs = [(1, 1, 0), (1, 1, 3), (1, 1, 8), (1, 0, 0)] + ([(0, 0, 0)] if w <= 7000 else [])  # (0,..): w <= ~7800
+            for fast, fused, stream_steps in cfgs:
                 L.cbh_set_tuning(b"hash_fast_any", fast)
                 L.cbh_set_tuning(b"hash_fused", fused)
+                L.cbh_set_tuning(b"hash_stream", stream_steps)
                 out = torch.zeros(n, dtype=torch.int64, device="cuda")
                 tiles = torch.zeros((n, 32, 32), dtype=torch.uint8, device="cuda")
                 _lib.check(L.cbh_dcthash_tiles_dev(d.data_ptr(), n, w, h, w + pad_x, buf.shape[1], out.data_ptr(),
@@ -190,8 +194,9 @@ def test_hash_random_geometries_and_strides(gpu, orc):
                 got = out.cpu().numpy().view(np.uint64)
                 t = tiles.cpu().numpy()
                 for i in range(n):
-                    assert (t[i] == orc.tile32(np.ascontiguousarray(imgs[i]))).all(), (w, h, fast, fused, i)
-                assert (got == want).all(), (w, h, fast, fused)
+                    assert (t[i] == orc.tile32(np.ascontiguousarray(imgs[i]))).all(), (w, h, fast, fused, stream_steps, i)
+                assert (got == want).all(), (w, h, fast, fused, stream_steps)
     finally:
         L.cbh_set_tuning(b"hash_fast_any", 1)
         L.cbh_set_tuning(b"hash_fused", 1)
+        L.cbh_set_tuning(b"hash_stream", 1)
