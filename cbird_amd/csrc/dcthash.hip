@@ -1327,23 +1327,67 @@ __global__ __launch_bounds__(kThreads) void k_tile_hash(const float* __restrict_
   const float* __restrict__ R = rows + (size_t)blockIdx.x * (size_t)yn * 32;
   for (int i = tid; i < 288; i += kThreads) sC[i] = tabs->C[i];
   if (tid < 64) sZ[tid] = tabs->zz[tid];
-  for (int o = tid; o < 1024; o += kThreads) {
-    const int dy = o >> 5, dx = o & 31;
+  {
+    // a lane owns output column dx and rows dy0, dy0+8, dy0+16, dy0+24: four independent chains, advanced together
+    // with the operands of four steps fetched ahead of the dependent adds (the chains themselves stay in row order)
+    const int dx = tid & 31, dy0 = tid >> 5;
     if (isx) {  // resizeAreaFast_: exact block sum; 2x2 -> (s+2)>>2, else rint(s * (1.f/area))
-      unsigned s = 0;
-      for (int yy = 0; yy < isy; ++yy) s += __float_as_uint(R[(size_t)(dy * isy + yy) * 32 + dx]);
-      const unsigned v = (isx == 2 && isy == 2) ? (s + 2u) >> 2
-                                                 : (unsigned)__builtin_rintf((float)s * (1.f / (float)(isx * isy)));
-      tile[o] = (unsigned char)(v > 255u ? 255u : v);
-    } else {
-      float sum = 0.f;
-      const int j0 = yfirst[dy], j1 = yfirst[dy + 1];
-      for (int j = j0; j < j1; ++j) {
-        const float t = ytab[j].alpha * R[(size_t)(by_src ? ytab[j].si : j) * 32 + dx];
-        sum = (j == j0) ? t : sum + t;
+      unsigned acc[4] = {0u, 0u, 0u, 0u};
+      int yy = 0;
+      for (; yy + 4 <= isy; yy += 4) {
+        unsigned v[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[i][u] = __float_as_uint(R[(size_t)((dy0 + 8 * i) * isy + yy + u) * 32 + dx]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[i] += v[i][u];
       }
-      const float r = __builtin_rintf(sum);
-      tile[o] = (unsigned char)(r < 0.f ? 0.f : r > 255.f ? 255.f : r);
+      for (; yy < isy; ++yy)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += __float_as_uint(R[(size_t)((dy0 + 8 * i) * isy + yy) * 32 + dx]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned v = (isx == 2 && isy == 2) ? (acc[i] + 2u) >> 2
+                                                   : (unsigned)__builtin_rintf((float)acc[i] * (1.f / (float)(isx * isy)));
+        tile[(dy0 + 8 * i) * 32 + dx] = (unsigned char)(v > 255u ? 255u : v);
+      }
+    } else {
+      int j0[4], len[4];
+      float sum[4] = {0.f, 0.f, 0.f, 0.f};
+      int nmax = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        j0[i] = yfirst[dy0 + 8 * i];
+        len[i] = yfirst[dy0 + 8 * i + 1] - j0[i];
+        nmax = max(nmax, len[i]);
+      }
+      for (int k = 0; k < nmax; k += 4) {
+        float al[4][4], v[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int j = j0[i] + min(k + u, len[i] - 1);  // past the end: a valid entry, result unused
+            al[i][u] = ytab[j].alpha;
+            v[i][u] = R[(size_t)(by_src ? ytab[j].si : j) * 32 + dx];
+          }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (k + u < len[i]) {
+              const float t = al[i][u] * v[i][u];
+              sum[i] = (k + u == 0) ? t : sum[i] + t;
+            }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float r = __builtin_rintf(sum[i]);
+        tile[(dy0 + 8 * i) * 32 + dx] = (unsigned char)(r < 0.f ? 0.f : r > 255.f ? 255.f : r);
+      }
     }
   }
   __syncthreads();
