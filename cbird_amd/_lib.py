@@ -124,6 +124,7 @@ _SIGS = {
     "cbh_idx256_download_rows": (C.c_int, [_vp, _sz, _sz, _vp]),
     "cbh_idx256_knn": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp, _vp]),
     "cbh_idx256_find": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _vp, _sz, C.POINTER(_sz)]),
+    "cbh_idx256_radius_match": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _sz, _vp]),
     "cbh_idx256_find_batch": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
     "cbh_idx256_get_stats": (C.c_int, [_vp, C.POINTER(cbh_stats)]),
     "cbh_color_create": (_vp, [C.c_int]),

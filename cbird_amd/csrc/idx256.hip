@@ -220,10 +220,15 @@ int launch_scan256(cbh_idx256* ix, const uint8_t* d_q, size_t nq, int thresh) {
 // knn (k per needle descriptor, below thresh) for nq needle rows on the host side of the index;
 // out_row/out_dist [nq*k], counts[nq] (full number under thresh)
 int knn_core(cbh_idx256* ix, const uint8_t* needles, size_t nq, int k, int thresh, std::vector<uint32_t>* row,
-             std::vector<uint16_t>* dist, std::vector<uint32_t>* counts) {
-  row->assign(nq * (size_t)k, 0);
-  dist->assign(nq * (size_t)k, 0);
-  counts->assign(nq, 0);
+             std::vector<uint16_t>* dist, std::vector<uint32_t>* counts,
+             std::vector<unsigned long long>* all_records = nullptr) {
+  if (!all_records) {
+    row->assign(nq * (size_t)k, 0);
+    dist->assign(nq * (size_t)k, 0);
+    counts->assign(nq, 0);
+  } else {
+    all_records->clear();
+  }
   if (nq == 0 || ix->n == 0 || thresh <= 0 || k <= 0) return CBH_OK;
   if (nq >= (1u << 23)) return CBH_E_INVAL;
   cbh::DeviceGuard g(ix->device);
@@ -259,6 +264,13 @@ int knn_core(cbh_idx256* ix, const uint8_t* needles, size_t nq, int k, int thres
     CBH_HIP(hipcub::DeviceRadixSort::SortKeys(ix->d_tmp, tb, db, (size_t)total, 0, sig_bits256(nq), ix->stream));
     if (db.Current() != ix->d_rec)
       CBH_HIP(hipMemcpyAsync(ix->d_rec, db.Current(), total * 8, hipMemcpyDeviceToDevice, ix->stream));
+  }
+  if (all_records) {  // radius search: every record, already in (needle, distance, row) order
+    all_records->resize((size_t)total);
+    if (total)
+      CBH_HIP(hipMemcpyAsync(all_records->data(), ix->d_rec, total * 8, hipMemcpyDeviceToHost, ix->stream));
+    CBH_HIP(hipStreamSynchronize(ix->stream));
+    return CBH_OK;
   }
   hipLaunchKernelGGL(k_select256, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ix->stream, ix->d_rec,
                      (size_t)total, (uint32_t)nq, k, ix->d_out_row, ix->d_out_dist, ix->d_counts);
@@ -446,6 +458,30 @@ int cbh_idx256_find_batch(cbh_idx256* ix, const uint8_t* needle_rows, const uint
   }
   out_offsets[n_needles] = pos;
   return pos > cap ? CBH_E_OVERFLOW : CBH_OK;
+}
+
+/* cv::BFMatcher(NORM_HAMMING).radiusMatch(queryDescriptors, matches, maxDistance) against the rows of the index as
+ * the train set (src/templatematcher.cpp:134,217): every (query, train) pair with distance <= max_dist, grouped by
+ * query in ascending (distance, train row) order -- OpenCV sorts each query's list by distance and leaves equal
+ * distances in unspecified order.  out_first[q] .. out_first[q+1] delimit query q's matches (nq + 1 entries). */
+int cbh_idx256_radius_match(cbh_idx256* ix, const uint8_t* queries, size_t nq, int max_dist, cbh_dmatch* out,
+                            size_t cap, uint64_t* out_first) {
+  if (!ix || !out_first || (nq && !queries) || (cap && !out)) return CBH_E_INVAL;
+  if (max_dist < 0) max_dist = -1;
+  if (max_dist > 256) max_dist = 256;
+  std::vector<unsigned long long> rec;
+  int rc = knn_core(ix, queries, nq, 1, max_dist + 1, nullptr, nullptr, nullptr, &rec);
+  if (rc) return rc;
+  size_t p = 0;
+  for (size_t q = 0; q < nq; ++q) {
+    out_first[q] = p;
+    while (p < rec.size() && (size_t)(rec[p] >> 41) == q) {
+      if (p < cap) out[p] = cbh_dmatch{(int32_t)q, (int32_t)(uint32_t)rec[p], (int32_t)((rec[p] >> 32) & 0x1ff)};
+      ++p;
+    }
+  }
+  out_first[nq] = p;
+  return p > cap ? CBH_E_OVERFLOW : CBH_OK;
 }
 
 int cbh_idx256_get_stats(const cbh_idx256* ix, cbh_stats* out) {

@@ -81,6 +81,24 @@ class CvFeaturesIndex:
                                      dist.ctypes.data, cnt.ctypes.data), "knn")
         return row, dist, cnt
 
+    def radius_match(self, queries, max_dist: int):
+        """cv::BFMatcher(NORM_HAMMING).radiusMatch(queries, matches, max_dist) with the index rows as the train set
+        (TemplateMatcher, src/templatematcher.cpp:134,217).  Returns (matches int32 [m, 3] = queryIdx, trainIdx,
+        distance, grouped by query in ascending (distance, trainIdx) order; first int64 [nq + 1])."""
+        d = np.ascontiguousarray(queries, np.uint8).reshape(-1, 32)
+        nq = len(d)
+        first = np.zeros(nq + 1, np.uint64)
+        cap = max(1024, 4 * nq)
+        while True:
+            out = np.zeros((cap, 3), np.int32)
+            rc = self._L.cbh_idx256_radius_match(self._h, d.ctypes.data, nq, int(max_dist), out.ctypes.data, cap,
+                                                 first.ctypes.data)
+            if rc == _lib.CBH_E_OVERFLOW:
+                cap = int(first[-1])
+                continue
+            check(rc, "radius_match")
+            return out[: int(first[-1])].copy(), first.astype(np.int64)
+
     def find(self, needle, p: SearchParams):
         d = getattr(needle, "keyPointDescriptors", None)
         if d is None or len(d) == 0:

@@ -323,6 +323,16 @@ int cbh_idx256_find(cbh_idx256*, const uint8_t* needle_rows, size_t n_desc, int 
                     size_t cap, size_t* n_out);
 int cbh_idx256_find_batch(cbh_idx256*, const uint8_t* needle_rows, const uint64_t* offsets, size_t n_needles,
                           int thresh, int k, cbh_match* out, size_t cap, uint64_t* out_offsets);
+/* TemplateMatcher's descriptor match (src/templatematcher.cpp:134,217): cv::BFMatcher(NORM_HAMMING).radiusMatch with
+ * the index rows as the train set (load the template's descriptors with cbh_idx256_add): every (query, train) pair
+ * with distance <= max_dist, grouped by query, each group in ascending (distance, train row) order (OpenCV: by
+ * distance, ties unspecified).  out_first has nq + 1 entries; returns CBH_E_OVERFLOW (with out_first complete) when
+ * cap is too small.  The steps after it (estimateRigidTransform's RANSAC, warpAffine) are OpenCV's and stay there. */
+typedef struct {
+  int32_t query_idx, train_idx, distance; /* cv::DMatch::queryIdx, trainIdx, distance */
+} cbh_dmatch;
+int cbh_idx256_radius_match(cbh_idx256*, const uint8_t* queries, size_t nq, int max_dist, cbh_dmatch* out,
+                            size_t cap, uint64_t* out_first);
 
 /* ---- ColorDescIndex: src/colordescindex.{h,cpp}; ColorDescriptor: src/cvutil.h:57-113 -----------------
  * A descriptor is the reference's 258-byte struct: 32 x {l,u,v,w : uint16} + numColors : uint8 (+1 pad). */

@@ -112,3 +112,36 @@ def test_gpu_knn_and_find_vs_oracle(gpu, cvo, scan256_path, n_media, per_media):
     res = idx.find_batch(media[:6], p)
     for m, r in zip(media[:6], res):
         assert [(x.mediaId, x.score) for x in r] == [(x.mediaId, x.score) for x in idx.find(m, p)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_train", [300, 6000])
+def test_gpu_radius_match_vs_oracle(gpu, cvo, scan256_path, n_train):
+    """cv::BFMatcher(NORM_HAMMING).radiusMatch as TemplateMatcher uses it (src/templatematcher.cpp:134,217): every
+    train row within max_dist (inclusive), per query in ascending (distance, trainIdx) order.  Expected lists: the
+    oracle's exact knn with k = all rows and thresh = max_dist + 1."""
+    from cbird_amd.cvfeatures import CvFeaturesIndex
+
+    rows, _, _ = make_descriptors(n_train // 100, 100, 7)
+    rng = np.random.default_rng(n_train)
+    queries = rows[rng.choice(len(rows), 150, replace=False)].copy()
+    flips = rng.integers(0, 40, len(queries))
+    for q, f in zip(queries, flips):  # planted neighbours at distances 0..39
+        for b in rng.choice(256, int(f), replace=False):
+            q[b >> 3] ^= 1 << (b & 7)
+    idx = CvFeaturesIndex()
+    idx.add([_M(1, rows)])
+    for max_dist in (0, 25, 60, 110, 256):
+        got, first = idx.radius_match(queries, max_dist)
+        k = len(rows) if max_dist >= 110 else 64
+        wr, wd, wc = cvo.knn(rows, queries, k, max_dist + 1)
+        assert first[-1] == len(got) == int(wc.sum()), max_dist
+        for q in range(len(queries)):
+            g = got[first[q]: first[q + 1]]
+            assert len(g) == wc[q] <= k
+            assert (g[:, 0] == q).all()
+            assert g[:, 1].tolist() == wr[q, : wc[q]].tolist() and g[:, 2].tolist() == wd[q, : wc[q]].tolist()
+        if max_dist == 256:
+            assert len(got) == len(queries) * len(rows)
+    e, f = CvFeaturesIndex().radius_match(queries, 25)  # empty train set
+    assert len(e) == 0 and (f == 0).all()
