@@ -141,7 +141,13 @@ def main():
     hash_ev, scan_ev, find_ev = [], [], []
     state = {}
 
+    work = ops.work_stream()  # not torch's default (NULL) stream: the C-ABI calls are synchronous on that one
+
     def step(record: bool):
+        with ops.stream_ctx(work):
+            _step(record)
+
+    def _step(record: bool):
         e0, e1 = ev(), ev()
         e0.record()
         h_local = ops.hash_images(imgs)

@@ -48,6 +48,14 @@ class HipOps:
             self._side = torch.cuda.Stream(device=self.torch_device)
         return self._side
 
+    def work_stream(self):
+        """A non-default stream for the whole step.  The C-ABI treats stream NULL as "synchronous call"
+        (include/cbird_hip.h), and torch's default stream IS the NULL stream: on it every scan / sort / select would
+        block the host and nothing could be queued ahead.  Callers wrap their step in stream_ctx(work_stream())."""
+        if getattr(self, "_work", None) is None:
+            self._work = torch.cuda.Stream(device=self.torch_device)
+        return self._work
+
     def current_stream(self):
         return torch.cuda.current_stream(self.torch_device)
 

@@ -49,9 +49,10 @@ def main():
         scan_ev = []
 
         def step():
-            h = ops.hash_images(imgs)
-            sh.load_shard(h, ids)
-            return sh.similar_sweep(allh, dhts, 8, scan_events=scan_ev)
+            with ops.stream_ctx(ops.work_stream()):  # the NULL stream would make every call synchronous
+                h = ops.hash_images(imgs)
+                sh.load_shard(h, ids)
+                return sh.similar_sweep(allh, dhts, 8, scan_events=scan_ev)
 
         step()
         torch.cuda.synchronize()
