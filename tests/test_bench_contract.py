@@ -33,3 +33,25 @@ def test_bench_line_has_the_contract_keys(gpu):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1
     assert c["find_agrees_with_gpu"] is True and c["hash_agrees_with_gpu"] is True
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_sharing_the_gpu(gpu):
+    """the N > 1 code path of bench.py (sharded index, record exchange, pipelined sweep on the work stream) with both
+    ranks on cuda:0 over gloo (CBH_BENCH_SHARE_GPU=1, a development aid; the driver's runs use RCCL): same match
+    counts as the single-rank run of the same job"""
+    import json
+
+    env = dict(os.environ, CBH_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = ["--images", "60000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--dht", "2,5,8"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                         timeout=600, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2"] + args, capture_output=True, text=True, timeout=900, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    r1 = json.loads(one.stdout.strip().splitlines()[-1])
+    r2 = json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert r2["n_gpus"] == 2 and r2["scaling"] == "strong"
+    assert [s["matches"] for s in r2["dht_sweep"]] == [s["matches"] for s in r1["dht_sweep"]]
