@@ -116,3 +116,31 @@ def test_small_images_bilinear_path(gpu, orc):
         for i in range(n):
             assert (t[i] == orc.tile32(imgs[i])).all(), (w, h, i)
         assert (out.cpu().numpy().view(np.uint64) == want).all()
+
+
+def test_keypoint_hashes_fuzz(gpu, orc):
+    """arbitrary (non-ORB) keypoint sizes -- every side length from 31 up to the image, i.e. all resize modes
+    (bilinear 31, copy 32, integer blocks 64/96/128, weighted tables), the LDS path (<= 134) and the global-memory
+    path (larger) -- on images of random size, with heavily overlapping squares"""
+    from cbird_amd.hashing import make_keypoint_hashes
+
+    rng = np.random.default_rng(77)
+    images, kps = [], []
+    for i in range(60):
+        h, w = int(rng.integers(36, 330)), int(rng.integers(36, 330))
+        images.append(rng.integers(0, 256, (h, w), dtype=np.uint8))
+        k = int(rng.integers(0, 25))
+        m = min(w, h) - 3
+        size = rng.uniform(29, max(31.5, m), k).astype(np.float32)
+        size[rng.random(k) < 0.3] = np.float32(rng.choice([31, 32, 64, 96, 128, 134, 135]))
+        x = rng.uniform(0.1, np.maximum(0.2, w - 2.5 - size)).astype(np.float32)
+        y = rng.uniform(0.1, np.maximum(0.2, h - 2.5 - size)).astype(np.float32)
+        kps.append(np.stack([x, y, size], 1).reshape(-1, 3))
+    got, after = make_keypoint_hashes(images, kps, return_images=True)
+    total = 0
+    for i in range(len(images)):
+        want, want_img = orc.keypoint_hashes(images[i], kps[i])
+        assert len(got[i]) == len(want) and (got[i] == want).all(), (i, images[i].shape, kps[i][:, 2])
+        assert (after[i] == want_img).all(), i
+        total += len(want)
+    assert total > 300
