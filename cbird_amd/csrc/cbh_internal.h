@@ -76,9 +76,14 @@ int launch_remove_ids(uint64_t* d_hashes, uint32_t* d_ids, size_t n, const uint3
                       size_t n_rm, hipStream_t stream, int zero_hash = 1);
 
 // ---- dcthash.hip ----------------------------------------------------------------------
+// view: the images are w x h sub-rectangles at (ox, oy) of pw x ph parents starting at d_imgs -- cv::blur on a
+// cv::Mat view takes its border pixels from the parent (dctHash64 after autocrop(), src/cvutil.cpp:1397-1401)
+struct HashView {
+  int pw, ph, ox, oy;
+};
 int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_stride,
                    size_t img_stride, uint64_t* d_out, hipStream_t stream,
-                   uint8_t* d_tiles = nullptr);
+                   uint8_t* d_tiles = nullptr, const HashView* view = nullptr);
 // rectangles of images hashed one after the other, optionally in place (Media::makeKeyPointHashes); also the path of
 // images with a side < 32
 struct RectImageDesc {

@@ -984,7 +984,10 @@ __global__ __launch_bounds__(256) void k_blur_area(const unsigned char* __restri
                                                    size_t row_stride, size_t img_stride,
                                                    const AreaTab* __restrict__ xtab, const int* __restrict__ xfirst,
                                                    int isx, int cpw, int pitch /* 8 * blockDim.x + 8 */,
-                                                   float* __restrict__ rows /* n * h * 32 */) {
+                                                   float* __restrict__ rows /* n * h * 32 */,
+                                                   int pw, int ph, int ox, int oy /* the image is the w x h view at
+                                                   (ox, oy) of a pw x ph parent starting at imgs: the blur takes its
+                                                   border pixels from the parent, like cv::blur on a cv::Mat view */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_fused[];
   constexpr int R = K / 2;
   constexpr int kMaxRows = kBlurRB + K - 1;
@@ -998,6 +1001,7 @@ __global__ __launch_bounds__(256) void k_blur_area(const unsigned char* __restri
   const int cx0 = isx ? c0 * isx : xtab[k_base].si;             // first image column of this workgroup's cells
   const int cxe = isx ? c1 * isx : xtab[k_end - 1].si + 1;      // one past their last column
   const int y0 = (int)blockIdx.y * kBlurRB;
+  const int gx0 = cx0 + ox;  // parent column of the window's first cell column
   const unsigned char* __restrict__ img = imgs + (size_t)blockIdx.z * img_stride;
   const int out_rows = min(kBlurRB, h - y0);
   const int nrows = out_rows + 2 * R;
@@ -1005,14 +1009,14 @@ __global__ __launch_bounds__(256) void k_blur_area(const unsigned char* __restri
   for (int i = tid; i < k_end - k_base; i += T) salpha[i] = xtab[k_base + i].alpha;
   // LDS column c <-> image x = cx0 - 4 + c (as in k_blur_rows)
   for (int dwi = tid; dwi < ndw; dwi += T) {
-    const int x = cx0 - 4 + 4 * dwi;
-    if (x >= 0 && x + 3 < w) {
+    const int x = gx0 - 4 + 4 * dwi;  // parent column
+    if (x >= 0 && x + 3 < pw) {
       unsigned v[kMaxRows];
 #pragma unroll
       for (int rr = 0; rr < kMaxRows; ++rr) {
-        int ry = y0 - R + rr;
-        ry = ry < 0 ? -ry : (ry >= h ? 2 * (h - 1) - ry : ry);
-        ry = ry < 0 ? 0 : (ry >= h ? h - 1 : ry);
+        int ry = oy + y0 - R + rr;  // parent row
+        ry = ry < 0 ? -ry : (ry >= ph ? 2 * (ph - 1) - ry : ry);
+        ry = ry < 0 ? 0 : (ry >= ph ? ph - 1 : ry);
         v[rr] = *reinterpret_cast<const u32_any_align*>(img + (size_t)ry * row_stride + x);
       }
 #pragma unroll
@@ -1021,18 +1025,18 @@ __global__ __launch_bounds__(256) void k_blur_area(const unsigned char* __restri
     }
   }
   {
-    const int nl = cx0 == 0 ? 4 : 0;
-    const int c_right = ((w - cx0 + 4) >> 2) << 2;
-    const int nr = max(0, min(pitch, w - cx0 + 7) - c_right);
+    const int nl = gx0 < 4 ? 4 : 0;  // the first window dword reaches across the parent's left edge
+    const int c_right = ((pw - gx0 + 4) >> 2) << 2;
+    const int nr = max(0, min(pitch, pw - gx0 + 7) - c_right);
     const int per_row = nl + nr;
     for (int e = tid; e < per_row * nrows; e += T) {
       const int rr = e / per_row, k = e - rr * per_row;
       const int c = k < nl ? k : c_right + (k - nl);
-      int xx = cx0 - 4 + c;
+      int xx = gx0 - 4 + c;
       xx = xx < 0 ? -xx : xx;
-      xx = xx >= w ? 2 * (w - 1) - xx : xx;
-      xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
-      sband[(size_t)rr * pitch + c] = img[(size_t)reflect101(y0 - R + rr, h) * row_stride + xx];
+      xx = xx >= pw ? 2 * (pw - 1) - xx : xx;
+      xx = xx < 0 ? 0 : (xx >= pw ? pw - 1 : xx);
+      sband[(size_t)rr * pitch + c] = img[(size_t)reflect101(oy + y0 - R + rr, ph) * row_stride + xx];
     }
   }
   __syncthreads();
@@ -2299,12 +2303,23 @@ int launch_keypoint_hashes(uint8_t* d_base, size_t n, const uint64_t* img_off, c
 }
 
 int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_stride,
-                   size_t img_stride, uint64_t* d_out, hipStream_t stream, uint8_t* d_tiles) {
+                   size_t img_stride, uint64_t* d_out, hipStream_t stream, uint8_t* d_tiles, const HashView* view) {
   if (n == 0) return CBH_OK;
   if (w <= 0 || h <= 0 || row_stride < (size_t)w) return CBH_E_INVAL;
   if (w > 8192 || h > 8192) return CBH_E_UNSUPPORTED;
   if (n > 0x7fffffffull) return CBH_E_INVAL;
-  if (w < 32 || h < 32) {
+  // a view: the w x h images are sub-rectangles at (ox, oy) of pw x ph parents that start at d_imgs (+ i*img_stride);
+  // the blur takes its border from the parent.  Whole images: the view is the image.
+  HashView vw{w, h, 0, 0};
+  if (view) {
+    vw = *view;
+    if (vw.ox < 0 || vw.oy < 0 || vw.ox + w > vw.pw || vw.oy + h > vw.ph || row_stride < (size_t)vw.pw) return CBH_E_INVAL;
+    if (vw.ox == 0 && vw.oy == 0 && vw.pw == w && vw.ph == h) view = nullptr;
+  }
+  if (view && w == 32 && h == 32)  // no blur: nothing is read outside the view
+    return launch_dcthash(d_imgs + (size_t)vw.oy * row_stride + vw.ox, n, w, h, row_stride, img_stride, d_out, stream,
+                          d_tiles, nullptr);
+  if (w < 32 || h < 32 || (view && !g_hash_fused)) {
     // a side enlarges: cv::resize's bilinear emulation, on the rectangle kernel (one rectangle = the whole image)
     const size_t per_chunk = (size_t)1 << 20;
     for (size_t i0 = 0; i0 < n; i0 += per_chunk) {
@@ -2312,8 +2327,9 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
       std::vector<RectImageDesc> images(m);
       std::vector<int> rects(4 * m);
       for (size_t i = 0; i < m; ++i) {
-        images[i] = RectImageDesc{(unsigned long long)(i * img_stride), w, h, (unsigned)row_stride, (unsigned)i, 1u};
-        rects[4 * i] = 0, rects[4 * i + 1] = 0, rects[4 * i + 2] = w, rects[4 * i + 3] = h;
+        images[i] = RectImageDesc{(unsigned long long)(i * img_stride), vw.pw, vw.ph, (unsigned)row_stride, (unsigned)i,
+                                  1u};
+        rects[4 * i] = vw.ox, rects[4 * i + 1] = vw.oy, rects[4 * i + 2] = w, rects[4 * i + 3] = h;
       }
       int rc2 = launch_rect_hashes(const_cast<uint8_t*>(d_imgs) + i0 * img_stride, images, rects, 0, d_out + i0, stream,
                                    d_tiles ? d_tiles + i0 * 1024 : nullptr);
@@ -2325,9 +2341,9 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
   int rc = get_tables(&tabs);
   if (rc) return rc;
   // k_dcthash_256 needs 8-byte aligned rows; anything else of that size takes the general kernels
-  const bool is256 = w == 256 && h == 256 && ((uintptr_t)d_imgs % 8) == 0 && row_stride % 8 == 0 &&
+  const bool is256 = !view && w == 256 && h == 256 && ((uintptr_t)d_imgs % 8) == 0 && row_stride % 8 == 0 &&
                      img_stride % 8 == 0 && row_stride * 256 < (1u << 24) && img_stride < (1u << 28);
-  if (g_hash_fast_any && !is256 && !(w == 32 && h == 32)) {
+  if ((g_hash_fast_any || view) && !is256 && !(w == 32 && h == 32)) {
     // every other geometry: k_blur_rows + k_area_rows + k_tile_hash
     const long long area_ = (long long)w * h;
     const int K_ = area_ <= 64 * 64 ? 3 : area_ <= 128 * 128 ? 5 : 7;  // (area <= 32*32 is only 32x32 itself)
@@ -2342,7 +2358,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     const int ipb = T % 64 == 0 ? 1 : 256 / T, block_threads = (ipb * T + 63) / 64 * 64;
     const int pitch = T * 8 + 8;
     const size_t smem = (size_t)ipb * (size_t)(kBlurRB + K_ - 1) * (size_t)pitch;
-    if (g_hash_fused && w >= g_hash_fused) {
+    if (view || (g_hash_fused && w >= g_hash_fused)) {
       // k_blur_area + k_tile_hash: the blurred plane stays in LDS
       const int ncol = w <= 2048 ? 1 : w <= 4096 ? 2 : 4, cpw = 32 / ncol;
       // widest column window of any workgroup (first source column of its first cell .. last of its last)
@@ -2370,7 +2386,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
         const long long band_wgs = (long long)ncol * ((h + kBlurRB - 1) / kBlurRB) * (long long)m;
         int steps = (int)std::min<long long>(8, band_wgs / 3072);
         steps = std::min(steps, (h + 2 * (K_ / 2) + kstep - 1) / kstep);
-        if (w < 192 || h < 128) steps = 0;  // measured: narrow or short images are faster band by band
+        if (w < 192 || h < 128 || view) steps = 0;  // measured: narrow or short images are faster band by band
         if (g_hash_stream >= 2) steps = g_hash_stream;
         if (g_hash_stream && steps >= 3) {
           const int strip_out = steps * kstep - 2 * (K_ / 2);
@@ -2401,7 +2417,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
       CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_area<KK>),                        \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsmem));              \
     hipLaunchKernelGGL(k_blur_area<KK>, gf, dim3((unsigned)Tf), fsmem, stream, src, w, h, row_stride,    \
-                       img_stride, at.x, at.xfirst, isx, cpw, fpitch, d_rowsf);                          \
+                       img_stride, at.x, at.xfirst, isx, cpw, fpitch, d_rowsf, vw.pw, vw.ph, vw.ox, vw.oy);  \
   } while (0)
         switch (K_) {
           case 3: CBH_FUSED(3); break;

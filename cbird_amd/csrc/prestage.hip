@@ -291,8 +291,10 @@ int cbh_process_images(const uint8_t* imgs, size_t n, int w, int h, size_t row_s
       // cropped images have their own geometry: one launch per image on its sub-view
       for (size_t i = 0; i < m && rc == CBH_OK; ++i) {
         const int* r = &hr[i * 4];
-        rc = cbh::launch_dcthash(gray + i * gi + (size_t)r[1] * gs + r[0], 1, r[2] - r[0], r[3] - r[1], gs, gi,
-                                 d_out + i, s);
+        // autocrop() narrows cvGray to a VIEW of the full image (cvutil.cpp:1397-1401): dctHash64's blur still
+        // sees the cropped-away margins at the view's edges
+        const cbh::HashView view{w, h, r[0], r[1]};
+        rc = cbh::launch_dcthash(gray + i * gi, 1, r[2] - r[0], r[3] - r[1], gs, gi, d_out + i, s, nullptr, &view);
       }
     }
     if (rc) break;

@@ -121,7 +121,9 @@ int cbh_bgr2gray_dev(const void* d_src, size_t n, int w, int h, size_t row_strid
 int cbh_autocrop_dev(const void* d_gray, size_t n, int w, int h, size_t row_stride, size_t img_stride, int range,
                      void* d_rects, int device, void* stream);
 /* processImage's hash for n decoded images of one size in host memory: grayscale (channels 1/3/4) ->
- * autocrop when autocrop_range >= 0 (cbird uses 20) -> dctHash64 of the kept region.  rects may be NULL. */
+ * autocrop when autocrop_range >= 0 (cbird uses 20) -> dctHash64 of the kept region.  autocrop() leaves cvGray as a
+ * colRange/rowRange VIEW of the full image (src/cvutil.cpp:1397-1401), so -- as with any cv::Mat view -- the blur inside
+ * dctHash64 still reads the cropped-away margins at the view's edges; the same is done here.  rects may be NULL. */
 int cbh_process_images(const uint8_t* imgs, size_t n, int w, int h, size_t row_stride, size_t img_stride,
                        int channels, int autocrop_range, uint64_t* out, int32_t* rects, int device);
 

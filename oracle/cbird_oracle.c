@@ -668,14 +668,15 @@ static void box_blur_roi_u8(const uint8_t* parent, int W, int H, size_t stride, 
 /* dctHash64(sub, inPlace = true) for one rectangle of `img` (cvutil.cpp:435-545 with :457-463: 8UC1 input is not
  * copied, so cv::blur writes its result back into the caller's image -- the engine buffers source rows, the result
  * is the blur of the pixels as they were before the call).  img is MODIFIED when the rectangle is blurred. */
-int orc_dcthash64_rect_inplace(uint8_t* img, int W, int H, size_t stride, int x, int y, int rw, int rh,
-                               uint64_t* out) {
+static int dcthash64_rect(uint8_t* img, int W, int H, size_t stride, int x, int y, int rw, int rh, int write_back,
+                          uint64_t* out) {
   if (!img || x < 0 || y < 0 || rw <= 0 || rh <= 0 || x + rw > W || y + rh > H) return ORC_E_INVAL;
   int k = orc_blur_ksize(rw, rh);
   uint8_t* sub = (uint8_t*)malloc((size_t)rw * rh);
   if (k) {
     box_blur_roi_u8(img, W, H, stride, x, y, rw, rh, k, sub);
-    for (int i = 0; i < rh; ++i) memcpy(img + (size_t)(y + i) * stride + x, sub + (size_t)i * rw, (size_t)rw);
+    if (write_back)
+      for (int i = 0; i < rh; ++i) memcpy(img + (size_t)(y + i) * stride + x, sub + (size_t)i * rw, (size_t)rw);
   } else {
     for (int i = 0; i < rh; ++i) memcpy(sub + (size_t)i * rw, img + (size_t)(y + i) * stride + x, (size_t)rw);
   }
@@ -685,6 +686,16 @@ int orc_dcthash64_rect_inplace(uint8_t* img, int W, int H, size_t stride, int x,
   if (rc != ORC_OK) return rc;
   *out = orc_hash_from_tile32(tile, NULL, NULL);
   return ORC_OK;
+}
+int orc_dcthash64_rect_inplace(uint8_t* img, int W, int H, size_t stride, int x, int y, int rw, int rh,
+                               uint64_t* out) {
+  return dcthash64_rect(img, W, H, stride, x, y, rw, rh, 1, out);
+}
+/* dctHash64(view) with inPlace = false: the same view semantics (blur border from the parent), image untouched.
+ * This is what Scanner::processImage computes after autocrop(), which narrows cvGray to a colRange/rowRange VIEW of
+ * the full image (cvutil.cpp:1397-1401) -- the cropped-away margins still feed the blur at the view's edges. */
+int orc_dcthash64_view(const uint8_t* img, int W, int H, size_t stride, int x, int y, int rw, int rh, uint64_t* out) {
+  return dcthash64_rect((uint8_t*)img, W, H, stride, x, y, rw, rh, 0, out);
 }
 
 /* the whole of makeKeyPointHashes for one image: rectangles in keypoint order, each hashed in place, so a later
@@ -1458,7 +1469,7 @@ int orc_process_image(const uint8_t* img, int w, int h, size_t stride, int chann
   int r[4] = {0, 0, w, h};
   if (autocrop_range >= 0) orc_autocrop(g, w, h, gs, autocrop_range, r);
   if (rect) memcpy(rect, r, sizeof r);
-  int rc = orc_dcthash64(g + (size_t)r[1] * gs + r[0], r[2] - r[0], r[3] - r[1], gs, out);
+  int rc = orc_dcthash64_view(g, w, h, gs, r[0], r[1], r[2] - r[0], r[3] - r[1], out);
   free(gray);
   return rc;
 }

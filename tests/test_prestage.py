@@ -154,3 +154,25 @@ def test_size_longest_side_errors(gpu):
         size_longest_side(np.zeros((1, 1, 1000), np.uint8), 400)  # computed height 0
     assert e.value.code == _lib.CBH_E_INVAL
     assert size_longest_side(np.zeros((0, 30, 40), np.uint8), 400).shape == (0, 300, 400)
+
+
+@pytest.mark.gpu
+def test_autocropped_hash_uses_the_parent_border(gpu, po, orc):
+    """autocrop() narrows cvGray to a colRange/rowRange VIEW (cvutil.cpp:1397-1401) and cv::blur on a view takes its
+    border pixels from the parent image: the hash of a cropped image is the hash of the view, not of an isolated
+    copy of the kept region.  Wide images (two column workgroups of the fused kernel) and small ones."""
+    from cbird_amd.hashing import process_images
+
+    rng = np.random.default_rng(6)
+    differs = 0
+    for (h, w, t, b, le, r) in ((300, 400, 40, 40, 0, 0), (700, 2600, 90, 90, 0, 0), (1200, 900, 0, 0, 100, 120),
+                                (64, 90, 8, 8, 0, 0)):
+        gray = np.stack([letterboxed(rng, h, w, t, b, le, r) for _ in range(2)])
+        got, rects = process_images(gray, 20)
+        for i in range(2):
+            wh, wr = po.process_image(gray[i], 20)
+            assert rects[i].tolist() == wr.tolist() and int(got[i]) == wh, (h, w, i)
+            x0, y0, x1, y1 = wr.tolist()
+            assert (x0, y0, x1, y1) != (0, 0, w, h)
+            differs += int(orc.dcthash64(gray[i][y0:y1, x0:x1]) != wh)
+    assert differs >= 1
