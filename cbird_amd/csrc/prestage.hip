@@ -4,6 +4,7 @@
 // and cbh_process_images, which chains gray -> autocrop -> hash for a batch of decoded images of one size.
 #include <cfloat>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "cbh_index.h"
@@ -288,13 +289,16 @@ int cbh_process_images(const uint8_t* imgs, size_t n, int w, int h, size_t row_s
     if (!cropped) {
       rc = cbh::launch_dcthash(gray, m, w, h, gs, gi, d_out, s);
     } else {
-      // cropped images have their own geometry: one launch per image on its sub-view
-      for (size_t i = 0; i < m && rc == CBH_OK; ++i) {
+      // cropped images have their own geometry: one launch per run of images with the same kept region
+      // (frames of one letterboxed video all share it)
+      for (size_t i = 0, run = 1; i < m && rc == CBH_OK; i += run) {
         const int* r = &hr[i * 4];
+        run = 1;
+        while (i + run < m && !memcmp(r, &hr[(i + run) * 4], 4 * sizeof(int))) ++run;
         // autocrop() narrows cvGray to a VIEW of the full image (cvutil.cpp:1397-1401): dctHash64's blur still
         // sees the cropped-away margins at the view's edges
         const cbh::HashView view{w, h, r[0], r[1]};
-        rc = cbh::launch_dcthash(gray + i * gi, 1, r[2] - r[0], r[3] - r[1], gs, gi, d_out + i, s, nullptr, &view);
+        rc = cbh::launch_dcthash(gray + i * gi, run, r[2] - r[0], r[3] - r[1], gs, gi, d_out + i, s, nullptr, &view);
       }
     }
     if (rc) break;
