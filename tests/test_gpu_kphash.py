@@ -144,3 +144,41 @@ def test_keypoint_hashes_fuzz(gpu, orc):
         assert (after[i] == want_img).all(), i
         total += len(want)
     assert total > 300
+
+
+def test_hash_entry_points_from_concurrent_threads(gpu, orc):
+    """Scanner workers call the hash functions from a QThreadPool: the stateless entry points (and the per-geometry
+    table caches behind them) must tolerate concurrent callers"""
+    import threading
+
+    from cbird_amd.hashing import make_keypoint_hashes, size_longest_side
+
+    rng = np.random.default_rng(9)
+    geos = [(300, 200), (640, 480), (257, 129), (31, 31), (1000, 40), (256, 256), (96, 96), (2050, 64)]
+    imgs = {g: rng.integers(0, 256, (4, g[1], g[0]), dtype=np.uint8) for g in geos}
+    want = {g: orc.dcthash64_batch(imgs[g]) for g in geos}
+    kimg = rng.integers(0, 256, (200, 260), dtype=np.uint8)
+    kp = _keypoints(rng, 260, 200, 80)
+    kwant, _ = orc.keypoint_hashes(kimg, kp)
+    rwant = orc.size_longest_side(kimg, 100)
+    errs = []
+
+    def worker(seed):
+        try:
+            order = np.random.default_rng(seed).permutation(len(geos))
+            for _ in range(3):
+                for j in order:
+                    g = geos[j]
+                    if not (gpu.dct_hash64_batch(imgs[g]) == want[g]).all():
+                        errs.append(("hash", g))
+                if not (make_keypoint_hashes([kimg], [kp])[0] == kwant).all():
+                    errs.append("kp")
+                if not (size_longest_side(kimg[None], 100)[0] == rwant).all():
+                    errs.append("resize")
+        except Exception as e:  # pragma: no cover
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(s,)) for s in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs[:5]
