@@ -679,6 +679,10 @@ int cbh_set_tuning(const char* key, int value) {
     set_scan_mfma(value);
     return CBH_OK;
   }
+  if (!strcmp(key, "kp_blur_side")) {
+    set_kp_blur_side(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "kp_lds_side")) {
     set_kp_lds_side(value);
     return CBH_OK;

@@ -1648,7 +1648,8 @@ __global__ __launch_bounds__(kThreads) void k_kp_hashes(unsigned char* __restric
                                                         const float* __restrict__ kp,
                                                         const SizeInfo* __restrict__ sizes,
                                                         const AreaTab* __restrict__ apool,
-                                                        const int* __restrict__ ipool, int lds_side, int tab_cap,
+                                                        const int* __restrict__ ipool, int lds_side, int blur_side,
+                                                        int tab_cap,
                                                         unsigned char* __restrict__ scratch, size_t scratch_per_wg,
                                                         const DctTables* __restrict__ tabs,
                                                         uint64_t* __restrict__ out, unsigned* __restrict__ counts) {
@@ -1656,13 +1657,12 @@ __global__ __launch_bounds__(kThreads) void k_kp_hashes(unsigned char* __restric
   __shared__ __attribute__((aligned(16))) unsigned char tile[1024], sZ[64];
   __shared__ int sFirst[36];
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-  // dynamic LDS: [table: tab_cap x (int si, float alpha)] [region: (lds_side + 6) rows x (8*ceil(lds_side/8) + 8)]
-  // [blurred: lds_side rows x 8*ceil(lds_side/8)]   (tab_cap is even: everything stays 16-byte aligned)
+  // dynamic LDS: [table: tab_cap x (int si, float alpha)] [region of the current square: (s + K - 1) rows x
+  // (8*ceil(s/8) + 8), s <= lds_side] [its blurred copy when s <= blur_side: s rows x 8*ceil(s/8)]; sized by the
+  // host for the larger of region(lds_side) and region + blurred(blur_side).  tab_cap is even: 16-byte alignment holds.
   int* sTabSi = reinterpret_cast<int*>(dyn);
   float* sTabA = reinterpret_cast<float*>(dyn + (size_t)tab_cap * 4);
   unsigned char* sReg = dyn + (size_t)tab_cap * 8;
-  const int side8 = (lds_side + 7) & ~7;
-  unsigned char* sBlur = sReg + (size_t)(lds_side + 6) * (side8 + 8);
   const int tid = threadIdx.x;
   for (int i = tid; i < 288; i += kThreads) sC[i] = tabs->C[i];
   if (tid < 64) sZ[tid] = tabs->zz[tid];
@@ -1762,69 +1762,81 @@ __global__ __launch_bounds__(kThreads) void k_kp_hashes(unsigned char* __restric
         }
       }
       __syncthreads();
-      // ---- B: blur ----
-      const unsigned char* src = sReg + 4;  // K == 0: the square itself, pitch P
-      int sp = P;
-      if (K) {
+      // ---- B, C: blur, write-back, 32x32 tile.  The blurred square lives in LDS behind the region when it fits
+      // (side <= blur_side), else in this workgroup's global scratch: the same code at two call sites so that each
+      // keeps its address space.
+      auto finish = [&](const unsigned char* __restrict__ src, int sp, const unsigned char* __restrict__ blurred) {
+        if (blurred) {
+          // ---- C1: back into the image ----
+          const int ndw = (s + 3) >> 2;
+          for (int i = tid; i < s * ndw; i += kThreads) {
+            const int yy = i / ndw, d = i - yy * ndw;
+            const unsigned v = *reinterpret_cast<const unsigned*>(blurred + yy * Pb + 4 * d);
+            unsigned char* o = img + (size_t)(y + yy) * I.row_stride + x + 4 * d;
+            if (4 * d + 3 < s) {
+              *reinterpret_cast<u32_any_align*>(o) = v;
+            } else {
+              for (int b = 0; 4 * d + b < s; ++b) o[b] = (unsigned char)(v >> (8 * b));
+            }
+          }
+        }
+        // ---- C2: 32x32 tile ----
+  #pragma unroll
+        for (int o4 = 0; o4 < 4; ++o4) {
+          const int o = tid + o4 * kThreads;
+          const int dy = o >> 5, dx = o & 31;
+          if (si.mode == 0) {
+            tile[o] = src[dy * sp + dx];
+          } else if (si.mode == 1) {
+            const int b = s / 32;
+            unsigned int sum = 0;
+            for (int yy = 0; yy < b; ++yy)
+              for (int xx = 0; xx < b; ++xx) sum += src[(dy * b + yy) * sp + (dx * b + xx)];
+            const unsigned int v = b == 2 ? (sum + 2u) >> 2
+                                          : (unsigned int)__builtin_rintf((float)sum * (1.f / (float)(b * b)));
+            tile[o] = (unsigned char)(v > 255u ? 255u : v);
+          } else if (si.mode == 2) {
+            float sum = 0.f;
+            const int j0 = sFirst[dy], j1 = sFirst[dy + 1], k0 = sFirst[dx], k1 = sFirst[dx + 1];
+            for (int j = j0; j < j1; ++j) {
+              const unsigned char* S = src + sTabSi[j] * sp;
+              float buf = 0.f;
+              for (int k = k0; k < k1; ++k) buf += (float)S[sTabSi[k]] * sTabA[k];
+              const float t = sTabA[j] * buf;
+              sum = (j == j0) ? t : sum + t;
+            }
+            const float rr = __builtin_rintf(sum);
+            tile[o] = (unsigned char)(rr < 0.f ? 0.f : rr > 255.f ? 255.f : rr);
+          } else {
+            const int* xl = sTabSi;
+            const int* yl = sTabSi + 96;
+            const int sy0 = min(max(yl[dy], 0), s - 1), sy1 = min(max(yl[dy] + 1, 0), s - 1);
+            const int sx = xl[dx], sx1 = min(sx + 1, s - 1);
+            const int a0 = xl[32 + dx], a1 = xl[64 + dx], b0 = yl[32 + dy], b1 = yl[64 + dy];
+            const unsigned char* S0 = src + sy0 * sp;
+            const unsigned char* S1 = src + sy1 * sp;
+            const int D0 = (int)S0[sx] * a0 + (int)S0[sx1] * a1;
+            const int D1 = (int)S1[sx] * a0 + (int)S1[sx1] * a1;
+            const int v = (((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2;
+            tile[o] = (unsigned char)(v < 0 ? 0 : v > 255 ? 255 : v);
+          }
+        }
+      };
+      if (!K) {
+        finish(sReg + 4, P, nullptr);  // the square itself, pitch P
+      } else if (s <= blur_side) {
+        unsigned char* __restrict__ sBlur = sReg + (((size_t)rows * P + 15) & ~(size_t)15);
         if (K == 3) blur_lds8<3>(sReg, P, s, sBlur, Pb);
         else if (K == 5) blur_lds8<5>(sReg, P, s, sBlur, Pb);
         else blur_lds8<7>(sReg, P, s, sBlur, Pb);
         __syncthreads();
-        src = sBlur;
-        sp = Pb;
-        // ---- C1: back into the image ----
-        const int ndw = (s + 3) >> 2;
-        for (int i = tid; i < s * ndw; i += kThreads) {
-          const int yy = i / ndw, d = i - yy * ndw;
-          const unsigned v = *reinterpret_cast<const unsigned*>(sBlur + yy * Pb + 4 * d);
-          unsigned char* o = img + (size_t)(y + yy) * I.row_stride + x + 4 * d;
-          if (4 * d + 3 < s) {
-            *reinterpret_cast<u32_any_align*>(o) = v;
-          } else {
-            for (int b = 0; 4 * d + b < s; ++b) o[b] = (unsigned char)(v >> (8 * b));
-          }
-        }
-      }
-      // ---- C2: 32x32 tile ----
-#pragma unroll
-      for (int o4 = 0; o4 < 4; ++o4) {
-        const int o = tid + o4 * kThreads;
-        const int dy = o >> 5, dx = o & 31;
-        if (si.mode == 0) {
-          tile[o] = src[dy * sp + dx];
-        } else if (si.mode == 1) {
-          const int b = s / 32;
-          unsigned int sum = 0;
-          for (int yy = 0; yy < b; ++yy)
-            for (int xx = 0; xx < b; ++xx) sum += src[(dy * b + yy) * sp + (dx * b + xx)];
-          const unsigned int v = b == 2 ? (sum + 2u) >> 2
-                                        : (unsigned int)__builtin_rintf((float)sum * (1.f / (float)(b * b)));
-          tile[o] = (unsigned char)(v > 255u ? 255u : v);
-        } else if (si.mode == 2) {
-          float sum = 0.f;
-          const int j0 = sFirst[dy], j1 = sFirst[dy + 1], k0 = sFirst[dx], k1 = sFirst[dx + 1];
-          for (int j = j0; j < j1; ++j) {
-            const unsigned char* S = src + sTabSi[j] * sp;
-            float buf = 0.f;
-            for (int k = k0; k < k1; ++k) buf += (float)S[sTabSi[k]] * sTabA[k];
-            const float t = sTabA[j] * buf;
-            sum = (j == j0) ? t : sum + t;
-          }
-          const float rr = __builtin_rintf(sum);
-          tile[o] = (unsigned char)(rr < 0.f ? 0.f : rr > 255.f ? 255.f : rr);
-        } else {
-          const int* xl = sTabSi;
-          const int* yl = sTabSi + 96;
-          const int sy0 = min(max(yl[dy], 0), s - 1), sy1 = min(max(yl[dy] + 1, 0), s - 1);
-          const int sx = xl[dx], sx1 = min(sx + 1, s - 1);
-          const int a0 = xl[32 + dx], a1 = xl[64 + dx], b0 = yl[32 + dy], b1 = yl[64 + dy];
-          const unsigned char* S0 = src + sy0 * sp;
-          const unsigned char* S1 = src + sy1 * sp;
-          const int D0 = (int)S0[sx] * a0 + (int)S0[sx1] * a1;
-          const int D1 = (int)S1[sx] * a0 + (int)S1[sx1] * a1;
-          const int v = (((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2;
-          tile[o] = (unsigned char)(v < 0 ? 0 : v > 255 ? 255 : v);
-        }
+        finish(sBlur, Pb, sBlur);
+      } else {
+        if (K == 3) blur_lds8<3>(sReg, P, s, scr, Pb);
+        else if (K == 5) blur_lds8<5>(sReg, P, s, scr, Pb);
+        else blur_lds8<7>(sReg, P, s, scr, Pb);
+        __syncthreads();
+        finish(scr, Pb, scr);
       }
       __syncthreads();
       // ---- D ----
@@ -2008,6 +2020,10 @@ int get_mfma_tables(const MfmaTables** out) {
 
 int g_hash_mfma = 0;
 int g_hash_mfma_set(int v) { return g_hash_mfma = v; }
+int g_kp_blur_side = 112;  // ... and up to this side their blurred copy stays in LDS as well (larger: global scratch)
+void set_kp_blur_side(int v) {
+  if (v >= 32 && v <= 200) g_kp_blur_side = v;
+}
 int g_kp_lds_side = 134;  // keypoint squares up to this side are processed in LDS (k_kp_hashes)
 void set_kp_lds_side(int v) {
   if (v >= 32 && v <= 200) g_kp_lds_side = v;
@@ -2186,7 +2202,7 @@ int launch_rect_hashes(uint8_t* d_base, const std::vector<RectImageDesc>& images
   return CBH_OK;
 }
 
-extern int g_kp_lds_side;
+extern int g_kp_lds_side, g_kp_blur_side;
 // Media::makeKeyPointHashes for a batch, keypoints evaluated on the device.  kp / kp_first / descriptors are host
 // arrays; d_out receives the hashes densely (image i at out_first[i]); out_first has n + 1 entries.
 int launch_keypoint_hashes(uint8_t* d_base, size_t n, const uint64_t* img_off, const uint32_t* img_w,
@@ -2246,10 +2262,15 @@ int launch_keypoint_hashes(uint8_t* d_base, size_t n, const uint64_t* img_off, c
   for (size_t i = 0; i < n; ++i)
     imgs[i] = KpImage{img_off[i], (int)img_w[i], (int)img_h[i], img_row_stride[i], kp_first[i],
                       kp_first[i + 1] - kp_first[i]};
-  const size_t scratch_per_wg = max_side > lds_side ? (((size_t)max_side * max_side + 255) / 256 * 256) : 256;
+  // squares up to blur_side keep their blurred copy in LDS too; larger ones (still <= lds_side) put it in global
+  // scratch, which keeps the LDS footprint at ~27 KB = 6 workgroups per CU instead of 3
+  const int blur_side = std::min(lds_side, g_kp_blur_side);
+  auto up8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
+  auto region_bytes = [&](size_t sd) { return ((sd + 6) * (up8(sd) + 8) + 15) & ~(size_t)15; };
   tab_cap = (tab_cap + 1) & ~1;
-  const size_t side8 = ((size_t)lds_side + 7) & ~(size_t)7;
-  const size_t smem = (size_t)tab_cap * 8 + (size_t)(lds_side + 6) * (side8 + 8) + (size_t)lds_side * side8;
+  const size_t smem = (size_t)tab_cap * 8 +
+                      std::max(region_bytes((size_t)lds_side), region_bytes((size_t)blur_side) + (size_t)blur_side * up8((size_t)blur_side));
+  const size_t scratch_per_wg = max_side > blur_side ? (((size_t)max_side * up8((size_t)max_side) + 255) / 256 * 256) : 256;
   const unsigned grid = (unsigned)std::min<size_t>(n, 2048);
   KpImage* d_images = nullptr;
   float* d_kp = nullptr;
@@ -2280,7 +2301,8 @@ int launch_keypoint_hashes(uint8_t* d_base, size_t n, const uint64_t* img_off, c
                             (int)smem);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_kp_hashes, dim3(grid), dim3(kThreads), smem, stream, d_base, d_images, (unsigned)n, d_kp,
-                       d_sizes, d_apool, d_ipool, lds_side, tab_cap, d_scr, scratch_per_wg, tabs, d_slots, d_counts);
+                       d_sizes, d_apool, d_ipool, lds_side, blur_side, tab_cap, d_scr, scratch_per_wg, tabs, d_slots,
+                       d_counts);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), d_counts, n * sizeof(unsigned), hipMemcpyDeviceToHost, stream);

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=8)
     ap.add_argument("--level", type=int, default=-1, help="force one pyramid level (diagnostics)")
     ap.add_argument("--lds-side", type=int, default=0, help="tuning: largest square processed in LDS")
+    ap.add_argument("--blur-side", type=int, default=0, help="tuning: largest square blurred into LDS")
     ap.add_argument("--size", type=float, default=0, help="force one keypoint size (diagnostics)")
     args = ap.parse_args()
     import ctypes as C
@@ -30,6 +31,8 @@ def main():
     from cbird_amd import _lib
 
     L = _lib.lib()
+    if args.blur_side:
+        L.cbh_set_tuning(b"kp_blur_side", args.blur_side)
     if args.lds_side:
         L.cbh_set_tuning(b"kp_lds_side", args.lds_side)
     rng = np.random.default_rng(1)
