@@ -361,14 +361,23 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *   "scan_mfma"     64-bit scan on the matrix cores (k_hamm64_mfma): 0 = never, 1 = calls with >= 256
  *                   needles and >= 4096 slots (default), 2 = always
  *   "scan_mfma_ht"  haystack tiles per wave in k_hamm64_mfma: 2, 4 or 8 (default 8)
- *   "scan_mfma_pre" 1 = thresholds <= 5 use the low-word prefilter variant of k_hamm64_mfma (default 1)
+ *   "scan_mfma_pre" 1 = thresholds <= 4 use the low-word prefilter variant of k_hamm64_mfma (default 1)
  *   "scan256_mfma"  256-bit scan on the matrix cores (k_hamm256_mfma): 0 = never, 1 = calls with >= 64
  *                   needle descriptors and >= 4096 rows (default), 2 = always
  *   "scan256_pre"   1 = thresholds <= 40 use the first-128-bit prefilter variant of k_hamm256_mfma (default 1)
  *   "scan_pre_max"  largest threshold served by the low-word-prefilter VALU scan variant (default 7)
  *   "scan_eq_dht1"  1 = dht==1 uses the 64-bit equality variant (default 1)
  *   "scan_group"    1 = issue-rate-shaped scan variants (default 1)
- *   "hash_mfma"     1 = 256x256 tiles use k_dcthash_256_mfma (box filter on the matrix cores; default 0) */
+ *   "hash_mfma"     1 = 256x256 tiles use k_dcthash_256_mfma (box filter on the matrix cores; default 0)
+ *   "hash_fast_any" 0 = the first general-geometry kernels (k_blur_u8 + k_area_hash / k_dcthash_generic), 1 = the
+ *                   lane-per-8-columns kernels (default)
+ *   "hash_fused"    0 = three-kernel split (k_blur_rows + k_area_rows + k_tile_hash); v >= 1 = k_blur_area (blur and
+ *                   horizontal INTER_AREA pass in one kernel) for widths >= v (default 1 = all)
+ *   "hash_stream"   streaming form k_blur_area_stream: 0 = never, 1 = when the batch is large enough and the image at
+ *                   least 192 x 128 (default), v >= 2 = always, with v steps per strip
+ *   "kp_lds_side"   largest keypoint square k_kp_hashes stages in LDS (default 134; larger: global-memory routine)
+ *   "kp_blur_side"  largest keypoint square whose blurred copy also stays in LDS (default 112)
+ *   "color_pk"      1 = packed-f32 colour distance kernel (default 1) */
 int cbh_set_tuning(const char* key, int value);
 
 /* ---- measurement support ---------------------------------------------------------------- */
