@@ -70,6 +70,8 @@ _SIGS = {
     "cbh_bgr2gray_dev": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, C.c_int, _vp, C.c_int, _vp]),
     "cbh_autocrop_dev": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, C.c_int, _vp, C.c_int, _vp]),
     "cbh_process_images": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, C.c_int, C.c_int, _vp, _vp, C.c_int]),
+    "cbh_process_images_ex": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp,
+                                        _vp, C.c_int]),
     "cbh_idx64_create": (_vp, [C.c_int]),
     "cbh_idx64_destroy": (None, [_vp]),
     "cbh_idx64_load": (C.c_int, [_vp, _vp, _vp, _sz]),

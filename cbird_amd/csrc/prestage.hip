@@ -224,6 +224,17 @@ int cbh_autocrop_dev(const void* d_gray, size_t n, int w, int h, size_t row_stri
  * rects (optional, n*4 ints) receives the kept region {left, top, right, bottom} of every image. */
 int cbh_process_images(const uint8_t* imgs, size_t n, int w, int h, size_t row_stride, size_t img_stride,
                        int channels, int autocrop_range, uint64_t* out, int32_t* rects, int device) {
+  return cbh_process_images_ex(imgs, n, w, h, row_stride, img_stride, channels, autocrop_range, out, rects, 0, nullptr,
+                               nullptr, device);
+}
+
+/* ... and, from the same upload, the image Scanner::processImage hands to ORB: sizeLongestSide(cvGray, size) of the
+ * (autocropped) grey image (src/scanner.cpp:876).  resized: n slots of size*size bytes, image i packed at the start
+ * of slot i with the dimensions resized_dims[2i], [2i+1] (w, h; 0, 0 where the reference would throw). */
+int cbh_process_images_ex(const uint8_t* imgs, size_t n, int w, int h, size_t row_stride, size_t img_stride,
+                          int channels, int autocrop_range, uint64_t* out, int32_t* rects, int resize_size,
+                          uint8_t* resized, int32_t* resized_dims, int device) {
+  if (resize_size < 0 || resize_size > 8192 || (resize_size > 0 && n && (!resized || !resized_dims))) return CBH_E_INVAL;
   if (!cbh::device_usable(device)) return CBH_E_NODEVICE;
   if (n == 0) return CBH_OK;
   if (!imgs || !out || w <= 0 || h <= 0 || (channels != 1 && channels != 3 && channels != 4) ||
@@ -234,14 +245,15 @@ int cbh_process_images(const uint8_t* imgs, size_t n, int w, int h, size_t row_s
   const size_t span1 = (size_t)(h - 1) * row_stride + (size_t)w * channels;
   size_t per_chunk = std::max<size_t>(1, ((size_t)256 << 20) / std::max(img_stride, span1));
   per_chunk = std::min(per_chunk, n);
-  uint8_t *d_src = nullptr, *d_gray = nullptr;
+  uint8_t *d_src = nullptr, *d_gray = nullptr, *d_res = nullptr;
   uint64_t* d_out = nullptr;
   int* d_rects = nullptr;
   hipStream_t s = nullptr;
   int rc = CBH_OK;
+  const size_t slot = (size_t)resize_size * (size_t)resize_size;
   auto cleanup = [&]() {
     if (s) (void)hipStreamDestroy(s);
-    for (void* p : {(void*)d_src, (void*)d_gray, (void*)d_out, (void*)d_rects})
+    for (void* p : {(void*)d_src, (void*)d_gray, (void*)d_out, (void*)d_rects, (void*)d_res})
       if (p) (void)hipFree(p);
   };
 #define CBH_TRY(call)                       \
@@ -258,6 +270,7 @@ int cbh_process_images(const uint8_t* imgs, size_t n, int w, int h, size_t row_s
   if (channels != 1) CBH_TRY(hipMalloc(&d_gray, per_chunk * (size_t)w * h));
   CBH_TRY(hipMalloc(&d_out, per_chunk * sizeof(uint64_t)));
   CBH_TRY(hipMalloc(&d_rects, per_chunk * 4 * sizeof(int)));
+  if (resize_size > 0) CBH_TRY(hipMalloc(&d_res, per_chunk * slot));
   std::vector<int> hr(per_chunk * 4);
   for (size_t i0 = 0; rc == CBH_OK && i0 < n; i0 += per_chunk) {
     const size_t m = std::min(per_chunk, n - i0);
@@ -302,6 +315,29 @@ int cbh_process_images(const uint8_t* imgs, size_t n, int w, int h, size_t row_s
       }
     }
     if (rc) break;
+    if (resize_size > 0) {
+      // sizeLongestSide of each kept region (a view: cv::resize does not look outside it), one launch per run of
+      // images with the same kept region
+      for (size_t i = 0, run = 1; i < m && rc == CBH_OK; i += run) {
+        const int* r = &hr[i * 4];
+        run = 1;
+        while (i + run < m && !memcmp(r, &hr[(i + run) * 4], 4 * sizeof(int))) ++run;
+        int dw = 0, dh = 0;
+        cbh_longest_side_dims(r[2] - r[0], r[3] - r[1], resize_size, &dw, &dh);
+        if (dw <= 0 || dh <= 0 || dw > resize_size || dh > resize_size) dw = dh = 0;
+        for (size_t t = 0; t < run; ++t) {
+          resized_dims[2 * (i0 + i + t)] = dw;
+          resized_dims[2 * (i0 + i + t) + 1] = dh;
+        }
+        if (dw == 0) continue;
+        rc = cbh_resize_lanczos4_dev(gray + i * gi + (size_t)r[1] * gs + r[0], run, r[2] - r[0], r[3] - r[1], gs, gi,
+                                     dw, dh, d_res + i * slot, device, s);
+        if (rc) break;
+        CBH_TRY(hipMemcpy2DAsync(resized + (i0 + i) * slot, slot, d_res + i * slot, (size_t)dw * dh, (size_t)dw * dh,
+                                 run, hipMemcpyDeviceToHost, s));
+      }
+      if (rc) break;
+    }
     CBH_TRY(hipMemcpyAsync(out + i0, d_out, m * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     CBH_TRY(hipStreamSynchronize(s));
     if (rects) memcpy(rects + i0 * 4, hr.data(), m * 4 * sizeof(int));

@@ -55,6 +55,27 @@ def process_images(imgs: np.ndarray, autocrop: int | None = 20, device: int = 0)
     return out, rects
 
 
+def process_images_ex(imgs: np.ndarray, autocrop: int | None = 20, resize: int = 400, device: int = 0):
+    """process_images plus, from the same upload, sizeLongestSide(cvGray, resize) of every (autocropped) grey image --
+    what Scanner::processImage hands to ORB (src/scanner.cpp:876).  Returns (hashes, rects, list of uint8 images)."""
+    imgs = np.ascontiguousarray(imgs)
+    if imgs.dtype != np.uint8 or imgs.ndim not in (3, 4):
+        raise ValueError("expected uint8 [n,h,w] or [n,h,w,c]")
+    n, h, w = imgs.shape[:3]
+    ch = 1 if imgs.ndim == 3 else imgs.shape[3]
+    out = np.zeros(n, np.uint64)
+    rects = np.zeros((n, 4), np.int32)
+    slots = np.zeros((n, resize * resize), np.uint8)
+    dims = np.zeros((n, 2), np.int32)
+    if n:
+        check(_lib.lib().cbh_process_images_ex(imgs.ctypes.data, n, w, h, w * ch, w * h * ch, ch,
+                                               -1 if autocrop is None else int(autocrop), out.ctypes.data,
+                                               rects.ctypes.data, int(resize), slots.ctypes.data, dims.ctypes.data,
+                                               device), "process_images_ex")
+    small = [slots[i, : dims[i, 0] * dims[i, 1]].reshape(dims[i, 1], dims[i, 0]).copy() for i in range(n)]
+    return out, rects, small
+
+
 def keypoint_rects(cols: int, rows: int, keypoints) -> np.ndarray:
     """The rectangles Media::makeKeyPointHashes derives from keypoints (src/media.cpp:880-901): keypoints is
     [k, 3] float32 (pt.x, pt.y, size); returns int32 [m, 3] (x, y, side)."""

@@ -126,6 +126,13 @@ int cbh_autocrop_dev(const void* d_gray, size_t n, int w, int h, size_t row_stri
  * dctHash64 still reads the cropped-away margins at the view's edges; the same is done here.  rects may be NULL. */
 int cbh_process_images(const uint8_t* imgs, size_t n, int w, int h, size_t row_stride, size_t img_stride,
                        int channels, int autocrop_range, uint64_t* out, int32_t* rects, int device);
+/* The same, and from the same upload the image processImage hands to ORB next: sizeLongestSide(cvGray, resize_size) of
+ * the (autocropped) grey image (src/scanner.cpp:876; cbird: 400).  resized = n slots of resize_size^2 bytes, image i
+ * packed (pitch = its width) at the start of slot i with the size resized_dims[2i] x resized_dims[2i+1] (0 x 0 where
+ * the reference's sizeLongestSide throws).  resize_size 0: exactly cbh_process_images. */
+int cbh_process_images_ex(const uint8_t* imgs, size_t n, int w, int h, size_t row_stride, size_t img_stride,
+                          int channels, int autocrop_range, uint64_t* out, int32_t* rects, int resize_size,
+                          uint8_t* resized, int32_t* resized_dims, int device);
 
 /* sizeLongestSide(cv::Mat& img, int size, int filter = INTER_LANCZOS4) -- src/cvutil.cpp:1932-1950, the resize in
  * front of ORB detection (src/scanner.cpp:876, size = IndexParams::resizeLongestSide = 400): target size from the

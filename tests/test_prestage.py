@@ -176,3 +176,36 @@ def test_autocropped_hash_uses_the_parent_border(gpu, po, orc):
             assert (x0, y0, x1, y1) != (0, 0, w, h)
             differs += int(orc.dcthash64(gray[i][y0:y1, x0:x1]) != wh)
     assert differs >= 1
+
+
+@pytest.mark.gpu
+def test_process_images_ex_also_returns_the_orb_input(gpu, po, orc):
+    """cbh_process_images_ex: hash + kept region as cbh_process_images, plus sizeLongestSide(cvGray, size) of the
+    kept region (a view: the resize does not look outside it) from the same upload"""
+    from cbird_amd.hashing import process_images, process_images_ex
+
+    rng = np.random.default_rng(11)
+    h, w = 300, 500
+    gray = np.stack([letterboxed(rng, h, w, 40, 40, 0, 0), letterboxed(rng, h, w, 40, 40, 0, 0),
+                     rng.integers(0, 256, (h, w), dtype=np.uint8), letterboxed(rng, h, w, 0, 0, 60, 60)])
+    for size in (400, 128):
+        got, rects, small = process_images_ex(gray, 20, size)
+        ref_h, ref_r = process_images(gray, 20)
+        assert (got == ref_h).all() and (rects == ref_r).all()
+        for i in range(len(gray)):
+            x0, y0, x1, y1 = rects[i].tolist()
+            want = orc.size_longest_side(gray[i][y0:y1, x0:x1], size)
+            assert small[i].shape == want.shape and (small[i] == want).all(), (size, i)
+    col = rng.integers(0, 256, (3, 200, 260, 3), dtype=np.uint8)
+    col[1, :25] = 7
+    col[1, -25:] = 7
+    got, rects, small = process_images_ex(col, 20, 100)
+    for i in range(3):
+        g = po.bgr2gray(col[i])
+        x0, y0, x1, y1 = rects[i].tolist()
+        assert (small[i] == orc.size_longest_side(g[y0:y1, x0:x1], 100)).all(), i
+        assert int(got[i]) == po.process_image(col[i], 20)[0]
+    # no autocrop, no images
+    _, r2, s2 = process_images_ex(gray[:1], None, 64)
+    assert r2.tolist() == [[0, 0, w, h]] and s2[0].shape == (38, 64)
+    assert process_images_ex(np.zeros((0, 40, 40), np.uint8), 20, 64)[2] == []
