@@ -30,11 +30,12 @@
 //   FULL2 (thresh 65, or FULL3 switched off) K = the 64 bits of one hash; tile B is a second MFMA accumulated
 //         onto tile A's.  hi16 = 0x4B40 - distB, lo16 = 0x4080 - 2*distA.  Hits are real matches.
 //   PRE   (thresh <= kPreMaxThresh) low-word prefilter at twice the pair rate: the block scale is
-//         per lane and K block, so lanes 0-31 (K 0..31) carry the LOW words of needle tile A with
-//         scale 1 and lanes 32-63 (K 32..63) the LOW words of tile B with scale 2^15, against the
-//         haystack's low words in both K blocks: ONE MFMA = 2048 low-word distances, kept as two flag-bit
-//         fields (see FULL3 below) and reduced with v_or3_b32.  Sound because popc(lo) >= thresh implies
-//         popc(lo) + popc(hi) >= thresh; candidates are re-evaluated on the full 64 bits.
+//         per lane and K block, so lanes 0-31 (K 0..31) carry the LOW words of one needle tile and lanes 32-63
+//         (K 32..63) the LOW words of the next, against the haystack's low words in both K blocks: ONE MFMA =
+//         2048 low-word distances.  Two such MFMAs are chained into one accumulator with block scales
+//         2^-1 | 2^5 and 2^11 | 2^17: four 6-bit flag-bit fields per register (the top one flags by carrying into
+//         the exponent), reduced with v_or3_b32 -- one result VGPR per 256 comparisons.  Sound because
+//         popc(lo) >= thresh implies popc(lo) + popc(hi) >= thresh; candidates are re-evaluated on the full 64 bits.
 //
 // Hits.  After the MFMAs of a group of G haystack tiles one compare of the packed maximum decides
 // whether anything is under the threshold.  Then, tile by tile, the lanes that hold flagged
@@ -63,9 +64,14 @@ constexpr float kC0 = 8388608.0f + 16448.0f + 2097152.0f;
 constexpr int kScale15 = 0x8e8e8e8e;  // E8M0 142 = 2^15
 constexpr int kPreMaxThresh = 4;      // P[popc(32 random bits) < 4] = 1.3e-6: 0.5 % of the groups re-check
 constexpr uint32_t kQueue = 2048;     // 16 registers x 2 fields x 64 lanes: cannot overflow
-// PRE keeps its two low-word distances as 7-bit fields at bits 0 and 15 biased so that "under the
-// threshold" is bit 6 of the field (see the kernel): OR-ing accumulators preserves "some flag is set"
-constexpr uint32_t kFlagMaskPre = (1u << 6) | (1u << 21);
+// PRE keeps FOUR low-word distances per accumulator register as 6-bit fields at bits 0, 6, 12, 18 (two chained
+// MFMAs; see the kernel), biased so that "under the threshold" is bit 5 of the field; the top field's flag is the carry
+// into the f32 exponent (bit 23 of the pattern).  OR-ing accumulators preserves "some flag is set".
+constexpr uint32_t kFlagMaskPre = (1u << 5) | (1u << 11) | (1u << 17) | (1u << 23);
+constexpr int kScaleHalf = 0x7e7e7e7e;       // E8M0 126 = 2^-1
+constexpr int kScale5 = (int)0x84848484;     // 2^5
+constexpr int kScale11 = (int)0x8a8a8a8a;    // 2^11
+constexpr int kScale17 = (int)0x90909090;    // 2^17
 
 // needles -> FP4 scratch: needle j -> 2 x uint4 (low word, high word); j >= nq padded with hash 0
 __global__ __launch_bounds__(256) void k_expand_needles(const uint64_t* __restrict__ q, uint32_t nq,
@@ -146,13 +152,57 @@ __device__ __forceinline__ void handle_tile(const v16f& c, uint32_t row0, uint32
     if (__builtin_amdgcn_ballot_w64((tb << 16) >= hp.lo_key || tb >= hp.hi_key) == 0) return;
   }
 
+  if constexpr (PRE) {
+    // four fields per register; the queue holds 16 registers x 2 fields x 64 lanes, so two passes (fields 0-1, 2-3).
+    // A carry into the exponent (bit 23: the top field is under the threshold) makes the lower fields of that
+    // register unreadable: all four become candidates -- they are re-evaluated on the full 64 bits anyway.
+    for (uint32_t pass = 0; pass < 2; ++pass) {
+      uint32_t cnt = 0;  // wave-uniform
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const uint32_t bits = as_u32(c[g]);
+        const bool carry = ((bits >> 23) & 1u) != 0;
+        const bool f0 = carry || ((bits >> (12u * pass + 5u)) & 1u) != 0;
+        const bool f1 = carry || ((bits >> (12u * pass + 11u)) & 1u) != 0;
+        if (__builtin_amdgcn_ballot_w64(f0 || f1) == 0) continue;
+        const uint64_t m0 = __builtin_amdgcn_ballot_w64(f0);
+        if (f0)  // entry: field<<10 | g<<6 | lane
+          s_queue[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))] =
+              ((2u * pass) << 10) | ((uint32_t)g << 6) | lane;
+        cnt += (uint32_t)__popcll(m0);
+        const uint64_t m1 = __builtin_amdgcn_ballot_w64(f1);
+        if (f1)
+          s_queue[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))] =
+              ((2u * pass + 1u) << 10) | ((uint32_t)g << 6) | lane;
+        cnt += (uint32_t)__popcll(m1);
+      }
+      wave_order();
+      for (uint32_t k = lane; k < cnt; k += 64u) {
+        const uint32_t e = s_queue[k];
+        const uint32_t src = e & 63u, g = (e >> 6) & 15u, field = (e >> 10) & 3u;
+        const uint32_t rit = (g & 3u) + 8u * (g >> 2) + 4u * (src >> 5);  // row in tile
+        const uint32_t row = row0 + rit;
+        const uint32_t qi = p * 64u + field * 32u + (src & 31u);  // p = the first of the step's two pairs
+        if (row < hp.n && qi < hp.nq) {
+          const uint64_t nv = hp.q[qi];
+          const uint2 hv = s_hay[hay_off + rit];  // all 64 bits (raw slot hashes parked in LDS)
+          const uint32_t d = __popc(hv.x ^ (uint32_t)nv) + __popc(hv.y ^ (uint32_t)(nv >> 32));
+          if (nv != 0 && d < hp.thresh && mask_ok(hp, row, qi, nv)) {
+            const uint32_t id = hp.ids[row];
+            if (id != 0 || hp.keep0) emit(hp.rec, hp.cap, hp.total, qi, d, id);
+          }
+        }
+      }
+      wave_order();
+    }
+    return;
+  }
   uint32_t cnt = 0;  // wave-uniform
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
     const uint32_t bits = as_u32(c[g]);
-    // PRE: flag bits (the distance in the entry is not used: candidates are re-evaluated on 64 bits)
-    const bool fh = PRE ? ((bits >> 21) & 1u) != 0 : bits >= hp.hi_key;
-    const bool fl = PRE ? ((bits >> 6) & 1u) != 0 : (bits << 16) >= hp.lo_key;
+    const bool fh = bits >= hp.hi_key;
+    const bool fl = (bits << 16) >= hp.lo_key;
     if (__builtin_amdgcn_ballot_w64(fh || fl) == 0) continue;  // scalar branch, rarely not taken
     const uint64_t mh = __builtin_amdgcn_ballot_w64(fh);
     if (fh)
@@ -175,11 +225,7 @@ __device__ __forceinline__ void handle_tile(const v16f& c, uint32_t row0, uint32
     const uint32_t qi = p * 64u + field * 32u + (src & 31u);
     if (row < hp.n && qi < hp.nq) {
       const uint64_t nv = hp.q[qi];
-      uint32_t d = e >> 11;
-      if (PRE) {  // low-word candidate: evaluate all 64 bits (raw slot hashes parked in LDS)
-        const uint2 hv = s_hay[hay_off + rit];
-        d = __popc(hv.x ^ (uint32_t)nv) + __popc(hv.y ^ (uint32_t)(nv >> 32));
-      }
+      const uint32_t d = e >> 11;
       if (nv != 0 && d < hp.thresh && mask_ok(hp, row, qi, nv)) {
         const uint32_t id = hp.ids[row];
         if (id != 0 || hp.keep0) emit(hp.rec, hp.cap, hp.total, qi, d, id);
@@ -215,15 +261,25 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_mfma(
   }
   wave_order();
   // FULL2: C0 = kC0 (two 16-bit fields compared against per-threshold keys).
-  // PRE:   C0 = 2^23 + (32 + 2b)(1 + 2^15), b = thresh - 1: field = 32 + 2b + dot_lo in [2b, 64 + 2b] < 128 and
-  //        dlo <= b  <=>  dot_lo >= 32 - 2b  <=>  field >= 64  <=>  bit 6 (tile A) / bit 21 (tile B) is set
+  // PRE:   a step takes TWO needle pairs = four needle tiles: MFMA 1 carries tiles 0 | 1 in its K blocks with block
+  //        scales 2^-1 | 2^5, MFMA 2 (accumulating onto it) tiles 2 | 3 with 2^11 | 2^17, and
+  //        C0 = 2^23 + (16 + b)(1 + 2^6 + 2^12 + 2^18), b = thresh - 1, so that field i (6 bits at bit 6i) holds
+  //        16 + b + dot_lo_i / 2 = 32 + b - dlo_i in [b, 32 + b]:  dlo_i <= b  <=>  field >= 32  <=>  bit 5 of the field;
+  //        for the top field that is a carry out of the mantissa, i.e. bit 23 of the f32 pattern (the exponent goes
+  //        from 150 to 151).  The +-0.5 products of the first K block are exact at an accumulator of 2^23 because the
+  //        hardware adds the 32 products of a block (an integer) before it meets the accumulator -- checked on
+  //        4.3e9 results incl. 1e7 hits by tools/ubench/mfma_half_exact.hip.  One result VGPR now answers 256
+  //        low-word comparisons instead of 128: half the v_or3_b32 per comparison.
   v16f c0;
 #pragma unroll
   for (int g = 0; g < 16; ++g)
-    c0[g] = PRE ? 8388608.0f + (float)((32u + 2u * (thresh - 1u)) * 32769u) : kC0;
+    c0[g] = PRE ? 8388608.0f + (float)((16u + (thresh - 1u)) * 266305u) : kC0;  // 266305 = 1 + 2^6 + 2^12 + 2^18
   asm volatile("" : "+v"(c0));  // keep C0 resident: otherwise it is rebuilt (16 v_mov) every trip
-  int scale_b = (PRE && half) ? kScale15 : kScaleOne;
+  // PRE block scales (per lane half = per K block): first MFMA 2^-1 | 2^5, second 2^11 | 2^17
+  int scale_b = PRE ? (half ? kScale5 : kScaleHalf) : kScaleOne;
+  int scale_b2 = PRE ? (half ? kScale17 : kScale11) : kScale15;
   asm volatile("" : "+v"(scale_b));
+  asm volatile("" : "+v"(scale_b2));
 
   const uint32_t p0 = blockIdx.y * pairs_per_chunk;
   const uint32_t p1 = min(n_pairs, p0 + pairs_per_chunk);
@@ -243,20 +299,18 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_mfma(
   auto step = [&](const uint32_t p, const uint4& nA, const uint4& nB) {
     const v8i bA = fp4_operand(nA);
     const v8i bB = fp4_operand(nB);
-    // G tiles at a time: G (PRE) or 2*G (FULL) MFMAs in flight, G*16 accumulator registers live
+    // G tiles at a time: 2*G MFMAs in flight, G*16 accumulator registers live
 #pragma unroll
     for (int t0 = 0; t0 < HT; t0 += G) {
       v16f c[G];
 #pragma unroll
       for (int t = 0; t < G; ++t)
         c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t0 + t], bA, c0, 4, 4, 0, kScaleOne,
-                                                               0, PRE ? scale_b : kScaleOne);
-      if (!PRE) {
+                                                               0, scale_b);
 #pragma unroll
-        for (int t = 0; t < G; ++t)
-          c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t0 + t], bB, c[t], 4, 4, 0,
-                                                                 kScaleOne, 0, kScale15);
-      }
+      for (int t = 0; t < G; ++t)
+        c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t0 + t], bB, c[t], 4, 4, 0,
+                                                               kScaleOne, 0, scale_b2);
       bool hit;
       if (PRE) {
         // flag bits survive OR: 8 v_or3_b32 per tile (plain VGPR-only ops, cheaper to issue than the packed max)
@@ -292,18 +346,24 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_mfma(
   };
 
   if constexpr (PRE) {
-    // one pair per trip, the next pair's 16-byte tile load in flight meanwhile; a single step() call
+    // two pairs per trip, the next two 16-byte tile loads in flight meanwhile; a single step() call
     // site keeps the (not so rare: the prefilter has false positives) re-check code to one copy per tile
-    uint4 cur = qp[0];
+    // (two pairs per step: the chunk length is even, only the call's last pair can be single -- its partner slot is
+    //  fed the same tiles again and its candidates fall out at qi >= nq)
+    // (the partner is chosen by ADDRESS, so that both loads are issued back to back and stay in flight during the
+    //  MFMAs; selecting between the loaded values made the compiler wait for the first load at once)
+    uint4 cur0 = qp[0], cur1 = qp[p0 + 1 < n_pairs ? 128 : 0];
 #pragma unroll 1
-    for (uint32_t p = p0; p < p1; ++p) {
-      uint4 nx = cur;
-      if (p + 1 < p1) {
-        qp += 128;
-        nx = qp[0];
+    for (uint32_t p = p0; p < p1; p += 2) {
+      uint4 nx0 = cur0, nx1 = cur1;
+      if (p + 2 < p1) {
+        qp += 256;
+        nx0 = qp[0];
+        nx1 = qp[p + 3 < n_pairs ? 128 : 0];
       }
-      step(p, cur, cur);
-      cur = nx;
+      step(p, cur0, cur1);
+      cur0 = nx0;
+      cur1 = nx1;
     }
   } else {
     // two pairs per trip with explicit double buffers: the loads of the next pair are in flight
@@ -512,7 +572,7 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
   while (ppc > 16 && (uint64_t)wgs * ((n_pairs + ppc - 1) / ppc) < 8192) ppc >>= 1;
   uint32_t chunks = (n_pairs + ppc - 1) / ppc;
   if (chunks > 65535) {
-    ppc = (n_pairs + 65534) / 65535;
+    ppc = ((n_pairs + 65534) / 65535 + 1u) & ~1u;  // even: the prefilter variant steps two pairs at a time
     chunks = (n_pairs + ppc - 1) / ppc;
   }
   // (2 = experiments: the prefilter variant for any threshold it can represent)
@@ -541,7 +601,7 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
                      (unsigned long long)cap, d_total, (uint32_t)(flags & 1u),                     \
                      reinterpret_cast<const uint2*>(d_qmask))
 #define CBH_MFMA(HT, PRE) CBH_MFMA_G(HT, kG, PRE)
-  if (ht == 8 && g_mfma_g == 4) {
+  if (ht == 8 && (g_mfma_g == 4 || (pre && g_mfma_g != 1))) {  // the prefilter variant reduces 4 tiles at a time (measured)
     if (pre) CBH_MFMA_G(8, 4, true); else CBH_MFMA_G(8, 4, false);
   } else if (ht == 8) {
     if (pre) CBH_MFMA(8, true); else CBH_MFMA(8, false);
