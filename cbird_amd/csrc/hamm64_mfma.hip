@@ -62,7 +62,8 @@ constexpr int kG = 2;  // tiles per accumulator group
 // 2^23 + 0x4040 + 64 * 2^15
 constexpr float kC0 = 8388608.0f + 16448.0f + 2097152.0f;
 constexpr int kScale15 = 0x8e8e8e8e;  // E8M0 142 = 2^15
-constexpr int kPreMaxThresh = 4;      // P[popc(32 random bits) < 4] = 1.3e-6: 0.5 % of the groups re-check
+constexpr int kPreMaxThresh = 4;      // P[popc(32 random bits) < 4] = 1.3e-6 per pair.  At 5 (9.7e-6) the re-checks still pay on
+                                      // uniform hashes (15.5 vs 17.9 ms) but not on image-derived ones (19.2 vs 17.1 ms)
 constexpr uint32_t kQueue = 2048;     // 16 registers x 2 fields x 64 lanes: cannot overflow
 // PRE keeps FOUR low-word distances per accumulator register as 6-bit fields at bits 0, 6, 12, 18 (two chained
 // MFMAs; see the kernel), biased so that "under the threshold" is bit 5 of the field; the top field's flag is the carry
@@ -236,7 +237,7 @@ __device__ __forceinline__ void handle_tile(const v16f& c, uint32_t row0, uint32
 }
 
 template <int HT, int G, bool PRE>
-__global__ __launch_bounds__(kThreads) void k_hamm64_mfma(
+__global__ __launch_bounds__(kThreads, (PRE && G == 2 && HT == 8) ? 3 : 1) void k_hamm64_mfma(
     const uint2* __restrict__ hay, const uint32_t* __restrict__ ids, uint32_t n,
     const uint64_t* __restrict__ q, const uint4* __restrict__ qx, uint32_t nq, uint32_t n_pairs,
     uint32_t pairs_per_chunk, uint32_t thresh, cbh_record* __restrict__ rec,
@@ -601,7 +602,7 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
                      (unsigned long long)cap, d_total, (uint32_t)(flags & 1u),                     \
                      reinterpret_cast<const uint2*>(d_qmask))
 #define CBH_MFMA(HT, PRE) CBH_MFMA_G(HT, kG, PRE)
-  if (ht == 8 && (g_mfma_g == 4 || (pre && g_mfma_g != 1))) {  // the prefilter variant reduces 4 tiles at a time (measured)
+  if (ht == 8 && g_mfma_g == 4) {
     if (pre) CBH_MFMA_G(8, 4, true); else CBH_MFMA_G(8, 4, false);
   } else if (ht == 8) {
     if (pre) CBH_MFMA(8, true); else CBH_MFMA(8, false);

@@ -10,9 +10,8 @@ idx.load_device(dq.data_ptr(), ids.data_ptr(), N)
 cap = 1 << 24
 drec = torch.empty(cap, dtype=torch.int64, device=dev); dtot = torch.zeros(1, dtype=torch.int64, device=dev)
 ms = C.c_float(0)
-for thr in (2, 4, 5):
-    for ht, g, pre in ((8, 2, 1), (8, 4, 1), (4, 2, 1), (8, 2, 2), (8, 2, 0)):
-        if pre == 2 and thr < 5: continue
+for thr in (1, 3, 5, 6):
+    for ht, g, pre in ((8, 2, 2), (8, 2, 0)):
         L.cbh_set_tuning(b"scan_mfma_ht", ht); L.cbh_set_tuning(b"scan_mfma_g", g); L.cbh_set_tuning(b"scan_mfma_pre", pre)
         for it in (1, 3):
             _lib.check(L.cbh_idx64_time_scan_dev(idx.handle, dq.data_ptr(), N, thr, drec.data_ptr(), cap, dtot.data_ptr(), it, C.byref(ms)), "t")
