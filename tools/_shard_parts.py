@@ -1,5 +1,6 @@
+"""Development aid: hash / load / sweep times of one rank's share of an 8-way run, separately."""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, ".")
 import torch, bench
 from cbird_amd.dist import HipOps, ShardedDctHashIndex
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)

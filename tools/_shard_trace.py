@@ -1,3 +1,5 @@
+"""Development aid: three steps of one rank's share of an R-way run (argv[1] = R, default 8) on the work stream,
+to be run under `rocprofv3 --kernel-trace` (see tools/_trace_tail.py for the timeline print)."""
 import os, sys, time
 sys.path.insert(0, ".")
 import torch, bench

@@ -1,3 +1,5 @@
+"""Development aid: print the last N kernels of a rocprofv3 kernel-trace CSV as a timeline (start, end, duration in
+us, queue, kernel name).  usage: _trace_tail.py <kernel_trace.csv> <N>"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
