@@ -289,3 +289,31 @@ def test_all_pairs_full_size_properties(gpu, orc):
         wi, ws, wc = orc.find64_batch(h, ids, h[sample], dht, k)
         assert (cnt[sample] == wc).all()
         assert (out[sample][:, :, 0].astype(np.uint32) == wi).all() and (out[sample][:, :, 1] == ws).all()
+
+
+def test_prefilter_pair_boundaries_and_low_word_collisions(gpu, orc):
+    """The low-word prefilter (thresholds <= 4) steps two needle pairs (128 needles) at a time, four 6-bit fields
+    per accumulator with the top field flagging through the exponent: needle counts around every pair / step /
+    chunk boundary, and a haystack full of entries whose LOW words are within the threshold of a needle's while the
+    high words are not (false positives in every field, including the carrying one, that the 64-bit re-check must
+    drop) next to true matches."""
+    rng = np.random.default_rng(4242)
+    n = 3000
+    lo = rng.integers(0, 1 << 32, 40, dtype=np.uint64) & ~np.uint64(1)
+    h = (rng.integers(0, 1 << 32, n, dtype=np.uint64) << np.uint64(32)) | lo[rng.integers(0, 40, n)]
+    flips = rng.integers(0, 4, n)
+    for i in range(n):  # 0..3 flipped low-word bits
+        for b in rng.choice(np.arange(1, 32), int(flips[i]), replace=False):
+            h[i] ^= np.uint64(1) << np.uint64(b)
+    h[h == 0] = 2
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    idx = gpu.DctHashIndex()
+    idx.load(h, ids)
+    for nq in (1, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 257, 16383, 16385, 32769):
+        q = h[rng.integers(0, n, nq)].copy()
+        q[::2] ^= rng.integers(0, 1 << 32, len(q[::2]), dtype=np.uint64) << np.uint64(32)  # other high word
+        q[1::7] ^= np.uint64(1) << np.uint64(40)                                          # one high bit
+        for dht in ((1, 2, 3, 4) if nq < 1000 else (2, 4)):
+            gi, gs, gc = idx.find_batch(q, dht, 3)
+            wi, ws, wc = orc.find64_batch(h, ids, q, dht, 3)
+            assert (gc == wc).all() and (gi == wi).all() and (gs == ws).all(), (nq, dht)
