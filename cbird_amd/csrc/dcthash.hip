@@ -809,6 +809,27 @@ __device__ __forceinline__ unsigned hsum_tap(const unsigned (&W)[4]) {
   return acc;
 }
 
+// the eight K-tap sums of a lane's 16-byte window, packed in pairs.  K = 7 shares the two full-dword sums between the
+// outputs like k_dcthash_256 does: 14 v_dot4_u32_u8 instead of 20.
+template <int R>
+__device__ __forceinline__ void hsum_pairs(const unsigned (&W)[4], unsigned (&P)[4]) {
+  if constexpr (R == 3) {  // output i = window bytes i+1 .. i+7
+    const unsigned T1 = udot4(W[1], 0x01010101u, 0u), T2 = udot4(W[2], 0x01010101u, 0u);
+    const unsigned H0 = udot4(W[0], 0x01010100u, T1);
+    const unsigned H1 = udot4(W[0], 0x01010000u, udot4(W[2], 0x00000001u, T1));
+    const unsigned H2 = udot4(W[0], 0x01000000u, udot4(W[2], 0x00000101u, T1));
+    const unsigned H3 = udot4(W[2], 0x00010101u, T1);
+    const unsigned H4 = udot4(W[1], 0x01010100u, T2);
+    const unsigned H5 = udot4(W[1], 0x01010000u, udot4(W[3], 0x00000001u, T2));
+    const unsigned H6 = udot4(W[1], 0x01000000u, udot4(W[3], 0x00000101u, T2));
+    const unsigned H7 = udot4(W[3], 0x00010101u, T2);
+    P[0] = H0 | (H1 << 16), P[1] = H2 | (H3 << 16), P[2] = H4 | (H5 << 16), P[3] = H6 | (H7 << 16);
+  } else {
+    P[0] = hsum_tap<R, 0>(W) | (hsum_tap<R, 1>(W) << 16), P[1] = hsum_tap<R, 2>(W) | (hsum_tap<R, 3>(W) << 16);
+    P[2] = hsum_tap<R, 4>(W) | (hsum_tap<R, 5>(W) << 16), P[3] = hsum_tap<R, 6>(W) | (hsum_tap<R, 7>(W) << 16);
+  }
+}
+
 typedef unsigned u32_any_align __attribute__((aligned(1)));
 
 template <int K>
@@ -894,8 +915,8 @@ __global__ __launch_bounds__(256) void k_blur_rows(const unsigned char* __restri
         const uint2 a = *reinterpret_cast<const uint2*>(win + (size_t)rr * pitch);
         const uint2 b = *reinterpret_cast<const uint2*>(win + (size_t)rr * pitch + 8);
         const unsigned W[4] = {a.x, a.y, b.x, b.y};
-        const unsigned P[4] = {hsum_tap<R, 0>(W) | (hsum_tap<R, 1>(W) << 16), hsum_tap<R, 2>(W) | (hsum_tap<R, 3>(W) << 16),
-                               hsum_tap<R, 4>(W) | (hsum_tap<R, 5>(W) << 16), hsum_tap<R, 6>(W) | (hsum_tap<R, 7>(W) << 16)};
+        unsigned P[4];
+        hsum_pairs<R>(W, P);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           S[c] = (S[c] - ring[j][c]) + P[c];
@@ -1062,8 +1083,8 @@ __global__ __launch_bounds__(256) void k_blur_area(const unsigned char* __restri
         const uint2 a = *reinterpret_cast<const uint2*>(win + (size_t)rr * pitch);
         const uint2 b = *reinterpret_cast<const uint2*>(win + (size_t)rr * pitch + 8);
         const unsigned W[4] = {a.x, a.y, b.x, b.y};
-        const unsigned P[4] = {hsum_tap<R, 0>(W) | (hsum_tap<R, 1>(W) << 16), hsum_tap<R, 2>(W) | (hsum_tap<R, 3>(W) << 16),
-                               hsum_tap<R, 4>(W) | (hsum_tap<R, 5>(W) << 16), hsum_tap<R, 6>(W) | (hsum_tap<R, 7>(W) << 16)};
+        unsigned P[4];
+        hsum_pairs<R>(W, P);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           S[c] = (S[c] - ring[j][c]) + P[c];
@@ -1242,8 +1263,8 @@ __global__ __launch_bounds__(256) void k_blur_area_stream(const unsigned char* _
         const uint2 a = *reinterpret_cast<const uint2*>(win + (size_t)rr * pitch);
         const uint2 b = *reinterpret_cast<const uint2*>(win + (size_t)rr * pitch + 8);
         const unsigned W[4] = {a.x, a.y, b.x, b.y};
-        const unsigned P[4] = {hsum_tap<R, 0>(W) | (hsum_tap<R, 1>(W) << 16), hsum_tap<R, 2>(W) | (hsum_tap<R, 3>(W) << 16),
-                               hsum_tap<R, 4>(W) | (hsum_tap<R, 5>(W) << 16), hsum_tap<R, 6>(W) | (hsum_tap<R, 7>(W) << 16)};
+        unsigned P[4];
+        hsum_pairs<R>(W, P);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           S[c] = (S[c] - ring[j][c]) + P[c];
@@ -1618,8 +1639,8 @@ __device__ __forceinline__ void blur_lds8(const unsigned char* __restrict__ reg,
           const uint2 a = *reinterpret_cast<const uint2*>(win + rr * P);
           const uint2 b = *reinterpret_cast<const uint2*>(win + rr * P + 8);
           const unsigned W[4] = {a.x, a.y, b.x, b.y};
-          const unsigned Pk[4] = {hsum_tap<R, 0>(W) | (hsum_tap<R, 1>(W) << 16), hsum_tap<R, 2>(W) | (hsum_tap<R, 3>(W) << 16),
-                                  hsum_tap<R, 4>(W) | (hsum_tap<R, 5>(W) << 16), hsum_tap<R, 6>(W) | (hsum_tap<R, 7>(W) << 16)};
+          unsigned Pk[4];
+        hsum_pairs<R>(W, Pk);
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             S[c] = (S[c] - ring[j][c]) + Pk[c];
