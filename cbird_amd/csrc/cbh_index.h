@@ -57,6 +57,8 @@ struct Workspace {
   size_t tmp_bytes = 0;
   unsigned long long* d_total = nullptr;
   unsigned long long* h_total = nullptr;  // pinned
+  cbh_record* h_small = nullptr;          // pinned: needle in, first kSmallRecs records out (single-needle find)
+  static constexpr size_t kSmallRecs = 512;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint64_t* d_q = nullptr;
   size_t q_cap = 0;
@@ -71,6 +73,7 @@ struct Workspace {
     CBH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     CBH_HIP(hipMalloc(&d_total, sizeof(unsigned long long)));
     CBH_HIP(hipHostMalloc(&h_total, sizeof(unsigned long long)));
+    CBH_HIP(hipHostMalloc(&h_small, (kSmallRecs + 1) * sizeof(cbh_record)));
     CBH_HIP(hipEventCreate(&ev0));
     CBH_HIP(hipEventCreate(&ev1));
     return CBH_OK;
@@ -107,6 +110,7 @@ struct Workspace {
     if (d_tmp) (void)hipFree(d_tmp);
     if (d_total) (void)hipFree(d_total);
     if (h_total) (void)hipHostFree(h_total);
+    if (h_small) (void)hipHostFree(h_small);
     if (d_q) (void)hipFree(d_q);
     if (d_qmask) (void)hipFree(d_qmask);
     if (d_out) (void)hipFree(d_out);

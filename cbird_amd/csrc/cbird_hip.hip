@@ -502,7 +502,40 @@ int cbh_idx64_find(cbh_idx64* idx, uint64_t q, int thresh, cbh_match* out, size_
   Workspace* ws = L.ws;
   rc = Workspace::grow(&ws->d_q, &ws->q_cap, 1);
   if (rc) return rc;
-  CBH_HIP(hipMemcpyAsync(ws->d_q, &q, sizeof q, hipMemcpyHostToDevice, ws->stream));
+  // Fast path (the interactive -similar-to query, Engine::query): needle staged in pinned memory, scan, the match
+  // count and the first kSmallRecs records fetched speculatively -- one stream synchronisation per find.  Larger
+  // results (or a record buffer that is too small) fall through to the general path below.
+  rc = ws->ensure_records(std::max<size_t>(idx->rec_cap_default, 1024));
+  if (rc) return rc;
+  {
+    constexpr size_t kS = Workspace::kSmallRecs;
+    ws->h_small[kS] = (cbh_record)q;
+    CBH_HIP(hipMemcpyAsync(ws->d_q, &ws->h_small[kS], sizeof q, hipMemcpyHostToDevice, ws->stream));
+    CBH_HIP(hipMemsetAsync(ws->d_total, 0, sizeof(unsigned long long), ws->stream));
+    rc = launch_hamm64_scan(idx->d_hashes, idx->d_ids, idx->n, ws->d_q, 1, thresh, ws->d_rec, ws->rec_cap, ws->d_total,
+                            ws->stream, 0, nullptr);
+    if (rc) return rc;
+    CBH_HIP(hipMemcpyAsync(ws->h_total, ws->d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, ws->stream));
+    CBH_HIP(hipMemcpyAsync(ws->h_small, ws->d_rec, std::min(kS, ws->rec_cap) * sizeof(cbh_record),
+                           hipMemcpyDeviceToHost, ws->stream));
+    CBH_HIP(hipStreamSynchronize(ws->stream));
+    const unsigned long long t = *ws->h_total;
+    {
+      std::lock_guard<std::mutex> lk(idx->stats_mu);
+      idx->stats.scan_launches += 1;
+      idx->stats.scan_pairs += (uint64_t)idx->n;
+    }
+    if (t <= std::min(kS, ws->rec_cap)) {
+      *n_out = (size_t)t;
+      std::sort(ws->h_small, ws->h_small + t);
+      const size_t m = std::min<size_t>((size_t)t, cap);
+      for (size_t i = 0; i < m; ++i) {
+        out[i].id = CBH_REC_ID(ws->h_small[i]);
+        out[i].score = CBH_REC_DIST(ws->h_small[i]);
+      }
+      return CBH_OK;
+    }
+  }
   unsigned long long total = 0;
   rc = scan_all(idx, ws, ws->d_q, 1, thresh, ws->stream, &total);
   if (rc) return rc;
