@@ -182,3 +182,60 @@ def test_hash_entry_points_from_concurrent_threads(gpu, orc):
     [t.start() for t in th]
     [t.join() for t in th]
     assert not errs, errs[:5]
+
+
+def test_entry_point_argument_errors(gpu):
+    """error conventions of the C-ABI (negative codes, never abort): empty batches are fine, inconsistent descriptors
+    are CBH_E_INVAL"""
+    import ctypes as C
+
+    from cbird_amd import _lib
+
+    L = _lib.lib()
+    img = np.zeros((50, 60), np.uint8)
+    off = np.zeros(1, np.uint64)
+    w = np.array([60], np.uint32)
+    h = np.array([50], np.uint32)
+    kp = np.array([[5, 5, 31]], np.float32)
+    kpf = np.array([0, 1], np.uint32)
+    out = np.zeros(4, np.uint64)
+    of = np.zeros(2, np.uint32)
+
+    def call(**kw):
+        a = dict(imgs=img.ctypes.data, nbytes=img.size, n=1, off=off.ctypes.data, w=w.ctypes.data, h=h.ctypes.data,
+                 st=w.ctypes.data, kp=kp.ctypes.data, kpf=kpf.ctypes.data, out=out.ctypes.data, of=of.ctypes.data)
+        a.update(kw)
+        return L.cbh_keypoint_hashes(a["imgs"], a["nbytes"], a["n"], a["off"], a["w"], a["h"], a["st"], a["kp"], a["kpf"],
+                                     a["out"], a["of"], None, 0)
+
+    assert call() == 0 and of.tolist() == [0, 1]
+    assert call(n=0) == 0 and of[0] == 0
+    assert call(nbytes=img.size - 1) == _lib.CBH_E_INVAL           # image reaches past the buffer
+    bad_first = np.array([1, 0], np.uint32)
+    assert call(kpf=bad_first.ctypes.data) == _lib.CBH_E_INVAL     # keypoint ranges must not decrease
+    narrow = np.array([59], np.uint32)
+    assert call(st=narrow.ctypes.data) == _lib.CBH_E_INVAL         # row stride below the width
+    assert call(of=None) == _lib.CBH_E_INVAL
+    # rectangles outside their image
+    rects = np.array([[30, 30, 40, 10]], np.int32)
+    rf = np.array([0, 1], np.uint32)
+    rc = L.cbh_dcthash_rects(img.ctypes.data, img.size, 1, off.ctypes.data, w.ctypes.data, h.ctypes.data, w.ctypes.data,
+                             rects.ctypes.data, rf.ctypes.data, 0, out.ctypes.data, None, 0)
+    assert rc == _lib.CBH_E_INVAL
+    rects[0] = [10, 10, 40, 35]
+    rc = L.cbh_dcthash_rects(img.ctypes.data, img.size, 1, off.ctypes.data, w.ctypes.data, h.ctypes.data, w.ctypes.data,
+                             rects.ctypes.data, rf.ctypes.data, 0, out.ctypes.data, None, 0)
+    assert rc == 0 and out[0] == 1  # a constant rectangle hashes to 1
+    # resize to nothing / radius match with a tiny output buffer
+    ow, oh = C.c_int(0), C.c_int(0)
+    assert L.cbh_size_longest_side(img.ctypes.data, 1, 60, 50, 60, 3000, 0, img.ctypes.data, C.byref(ow), C.byref(oh),
+                                   0) == _lib.CBH_E_INVAL
+    from cbird_amd.cvfeatures import CvFeaturesIndex
+
+    rows = np.random.default_rng(0).integers(0, 256, (100, 32), dtype=np.uint8)
+    ix = CvFeaturesIndex()
+    ix.add([type("M", (), dict(id=1, keyPointDescriptors=rows, path=""))()])
+    first = np.zeros(101, np.uint64)
+    m = np.zeros((5, 3), np.int32)
+    rc = L.cbh_idx256_radius_match(ix.handle, rows.ctypes.data, 100, 0, m.ctypes.data, 5, first.ctypes.data)
+    assert rc == _lib.CBH_E_OVERFLOW and first[-1] == 100           # every row matches itself; cap was 5
