@@ -281,6 +281,15 @@ class DctFeaturesIndex:
         h, i = _as_u64(hashes), _as_u32(ids)
         check(self._L.cbh_idx64_load(self._h, h.ctypes.data, i.ctypes.data, len(h)), "load")
 
+    def load_flat(self, hashes, ids) -> None:
+        """the (index, hash) values of a HammingTree as stored in its leaves (the dctfeatures.cache file read by
+        cbird_amd.indexdir.read_hamming_tree): entries with id 0 are removed ones that keep their hash"""
+        h = np.ascontiguousarray(hashes, np.uint64)
+        i = np.ascontiguousarray(ids, np.uint32)
+        if len(h) != len(i):
+            raise ValueError("hashes and ids differ in length")
+        check(self._L.cbh_idx64_load(self._h, h.ctypes.data, i.ctypes.data, len(h)), "load")
+
     def add(self, media) -> None:
         """dctfeaturesindex.cpp:229-238"""
         media = list(media)

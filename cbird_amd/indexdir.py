@@ -19,7 +19,8 @@ layout restated here is the reference's own, file by file:
 
 (database file N belongs to the index whose Index::databaseId() is N = its SearchParams algo id,
 src/index.h:192, src/database.h:47-49.)  `_index/cache/` holds rebuildable caches (HammingTree dump, FLANN
-matrix) that "can be deleted without affecting the index" (src/database.h:51-52): they are ignored.
+matrix) that "can be deleted without affecting the index" (src/database.h:51-52): when they are current they are
+read instead of the SQL tables (see the cache section below), never required.
 
 qCompress (Qt) = 4-byte big-endian uncompressed length followed by a zlib stream.
 
@@ -192,10 +193,34 @@ class IndexDir:
         h, ids = self.dct_columns()
         index.load(h, ids)
 
-    def load_dct_features(self, index) -> None:
+    def cache_path(self) -> str:
+        return os.path.join(self.index_path, "cache")  # src/database.h:51-52
+
+    def load_dct_features(self, index, use_cache: bool = True) -> None:
+        """the kphash table, or cbird's dctfeatures.cache when it is present and not older than media1.db"""
+        cache = os.path.join(self.cache_path(), "dctfeatures.cache")
+        if use_cache and not cache_is_stale(self.db_path(1), cache):
+            ids, hashes = read_hamming_tree(cache)
+            index.load_flat(hashes, ids)
+            return
         index.load(self.kphash_rows())
 
-    def load_cv_features(self, index) -> None:
+    def load_cv_features(self, index, use_cache: bool = True) -> None:
+        cache = os.path.join(self.cache_path(), "cvfeatures.touch")
+        if use_cache and not cache_is_stale(self.db_path(2), cache):
+            # removed media (id 0) keep their rows in the reference; they are added and removed again here
+            media = read_cvfeatures_cache(self.cache_path())
+            tmp_ids, removed, nxt = [], [], 0xFFFF0000
+            for mid, d in media:
+                if mid == 0:
+                    mid = nxt
+                    nxt += 1
+                    removed.append(mid)
+                tmp_ids.append((mid, d))
+            index.add([_M(id=i, keyPointDescriptors=d) for i, d in tmp_ids])
+            if removed:
+                index.remove(removed)
+            return
         index.add([_M(id=i, keyPointDescriptors=d) for i, d in self.matrix_rows()])
 
     def load_color(self, index) -> None:
@@ -205,6 +230,133 @@ class IndexDir:
     def load_video(self, index) -> None:
         """DctVideoIndex::load (dctvideoindex.cpp:172-211): every type-2 media id, frames from <id>.vdx"""
         index.load(self.video_ids(), self.video_path())
+
+
+# ---- the rebuildable caches under _index/cache/ ---------------------------------------------------------------
+# cbird rebuilds them from the SQL tables when they are missing or older than the database file
+# (DBHelper::isCacheFileStale, src/qtutil.cpp:934-937).  They are read here so that a large index loads from the
+# flat cache files instead of millions of SQL rows; nothing depends on them.
+
+def cache_is_stale(db_file: str, cache_file: str) -> bool:
+    """DBHelper::isCacheFileStale: missing cache, or database modified after it"""
+    if not os.path.exists(cache_file):
+        return True
+    if not os.path.exists(db_file):
+        return True
+    return os.path.getmtime(db_file) > os.path.getmtime(cache_file)
+
+
+HAMMING_TREE_HEADER = b"cbird hamming tree:2:4:8:65536"  # FILE_VERSION, sizeof(index_t), sizeof(hash_t), CLUSTER_SIZE
+
+
+def read_hamming_tree(path: str):
+    """`dctfeatures.cache` = HammingTree_t<uint32_t>::write (src/tree/hammingtree.h:156-200, 472-521): a text header
+    line, then the nodes in pre-order -- bool isLeaf; internal: int32 bit, left, right; leaf: uint32 count,
+    uint32 indices[count], uint64 hashes[count].  Returns (ids u32[], hashes u64[]) in leaf order; removed entries
+    keep their hash with id 0 (hammingtree.h:349-361).  The tree shape itself is not needed: the GPU index scans."""
+    with open(path, "rb") as f:
+        data = f.read()
+    nl = data.find(b"\n", 0, 128)
+    if nl < 0 or data[:nl] != HAMMING_TREE_HEADER:
+        raise ValueError(f"not a cbird hamming tree v2 file: {data[:40]!r}")
+    pos = nl + 1
+    ids, hashes = [], []
+    stack = 1  # nodes still to read
+    while stack:
+        if pos >= len(data):  # an empty tree writes nothing after the header
+            break
+        is_leaf = data[pos] != 0
+        pos += 1
+        stack -= 1
+        if not is_leaf:
+            pos += 4  # the split bit
+            stack += 2
+            continue
+        if pos >= len(data):  # readNode: "if (f.atEnd()) ;" -- a leaf flag at the very end carries no count
+            break
+        (count,) = struct.unpack_from("<I", data, pos)
+        pos += 4
+        if count:
+            ids.append(np.frombuffer(data, "<u4", count, pos))
+            pos += 4 * count
+            hashes.append(np.frombuffer(data, "<u8", count, pos))
+            pos += 8 * count
+    if pos != len(data):
+        raise ValueError("trailing bytes after the last tree node")
+    if not ids:
+        return np.zeros(0, np.uint32), np.zeros(0, np.uint64)
+    return np.concatenate(ids).astype(np.uint32), np.concatenate(hashes).astype(np.uint64)
+
+
+def read_cv_matrix(path: str) -> np.ndarray:
+    """`cvfeatures.mat` = saveMatrix (src/cvutil.cpp:129-163): MatrixHeader {u32 id; i32 rows, cols, type, stride}
+    followed by rows x stride bytes"""
+    with open(path, "rb") as f:
+        hdr = f.read(20)
+        if len(hdr) != 20:
+            raise ValueError("short matrix header")
+        _id, rows, cols, typ, stride = struct.unpack("<Iiiii", hdr)
+        if typ != CV_8U or stride != cols or rows < 0:
+            raise ValueError(f"unexpected matrix header rows={rows} cols={cols} type={typ} stride={stride}")
+        raw = f.read(rows * stride)
+    if len(raw) != rows * stride:
+        raise ValueError("short matrix data")
+    return np.frombuffer(raw, np.uint8).reshape(rows, cols).copy()
+
+
+def write_cv_matrix(path: str, m: np.ndarray) -> None:
+    m = np.ascontiguousarray(m, np.uint8)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<Iiiii", 0, m.shape[0], m.shape[1], CV_8U, m.shape[1]))
+        f.write(m.tobytes())
+
+
+def read_u32_map(path: str) -> dict:
+    """saveMap<uint32_t, uint32_t> (src/ioutil.h:203-231): key/value pairs back to back"""
+    a = np.fromfile(path, "<u4")
+    if a.size % 2:
+        raise ValueError("odd number of words in a uint32 map file")
+    return dict(zip(a[0::2].tolist(), a[1::2].tolist()))
+
+
+def write_u32_map(path: str, m: dict) -> None:
+    a = np.array([x for kv in sorted(m.items()) for x in kv], "<u4")  # std::map iterates in key order
+    a.tofile(path)
+
+
+def read_cvfeatures_cache(cache_path: str):
+    """CvFeaturesIndex::loadIndex (src/cvfeaturesindex.cpp:387-391): cvfeatures.mat + _idmap (mediaId -> first row) +
+    _indexmap (first row -> mediaId, 0 after a removal).  Returns [(media_id, u8[rows, 32])] in row order, removed
+    media with id 0 (they keep their rows, like in the reference)."""
+    rows = read_cv_matrix(os.path.join(cache_path, "cvfeatures.mat"))
+    index_map = read_u32_map(os.path.join(cache_path, "cvfeatures_indexmap.map"))
+    starts = sorted(k for k in index_map if k < len(rows))
+    out = []
+    for i, s0 in enumerate(starts):
+        s1 = starts[i + 1] if i + 1 < len(starts) else len(rows)
+        out.append((int(index_map[s0]), rows[s0:s1]))
+    return out
+
+
+def write_cvfeatures_cache(cache_path: str, media) -> None:
+    """media: [(media_id, u8[rows, 32])] ascending id.  Writes what CvFeaturesIndex::saveIndex writes (:406-419),
+    maps without the trailing sentinels (as after load(); loadIndex re-adds them)."""
+    os.makedirs(cache_path, exist_ok=True)
+    id_map, index_map, parts, pos = {}, {}, [], 0
+    for mid, d in media:
+        d = np.ascontiguousarray(d, np.uint8).reshape(-1, 32)
+        if len(d) == 0:
+            continue
+        id_map[int(mid)] = pos
+        index_map[pos] = int(mid)
+        parts.append(d)
+        pos += len(d)
+    write_cv_matrix(os.path.join(cache_path, "cvfeatures.mat"),
+                    np.concatenate(parts) if parts else np.zeros((0, 32), np.uint8))
+    write_u32_map(os.path.join(cache_path, "cvfeatures_idmap.map"), id_map)
+    write_u32_map(os.path.join(cache_path, "cvfeatures_indexmap.map"), index_map)
+    with open(os.path.join(cache_path, "cvfeatures.touch"), "wb") as f:
+        f.write(b"this file indicates index was saved successfully")
 
 
 # ---- writer (test fixture generator; follows createTables/addRecords of each index) ---------------------

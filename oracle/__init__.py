@@ -345,6 +345,20 @@ class RefHammingTree:
     def size(self):
         return self.lib().ref_htree_size(self.h)
 
+    def write(self, path):
+        """HammingTree::write: the dctfeatures.cache file"""
+        f = self.lib().ref_htree_write
+        f.argtypes = [C.c_void_p, C.c_char_p]
+        f.restype = C.c_int
+        if not f(self.h, os.fsencode(path)):
+            raise OSError(f"ref_htree_write({path}) failed")
+
+    def read(self, path):
+        f = self.lib().ref_htree_read
+        f.argtypes = [C.c_void_p, C.c_char_p]
+        f.restype = C.c_int
+        return bool(f(self.h, os.fsencode(path)))
+
     def search(self, target, thresh, cap=1 << 16):
         oi = np.zeros(cap, np.uint32)
         oh = np.zeros(cap, np.uint64)

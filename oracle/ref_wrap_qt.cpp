@@ -66,6 +66,20 @@ void ref_htree_remove(void* t, const uint32_t* ids, size_t n) {
   static_cast<HammingTree*>(t)->remove(set);
 }
 
+// HammingTree::write / read (hammingtree.h:166-200): the `dctfeatures.cache` file of DctFeaturesIndex::save/load
+// (dctfeaturesindex.cpp:34,100-181).  Returns 1 on success.
+int ref_htree_write(void* t, const char* path) {
+  QFile f(QString::fromUtf8(path));
+  if (!f.open(QFile::WriteOnly | QFile::Truncate)) return 0;
+  static_cast<HammingTree*>(t)->write(f);
+  return 1;
+}
+int ref_htree_read(void* t, const char* path) {
+  QFile f(QString::fromUtf8(path));
+  if (!f.open(QFile::ReadOnly)) return 0;
+  return static_cast<HammingTree*>(t)->read(f) ? 1 : 0;
+}
+
 // HammingTree::search (hammingtree.h:103-108): matches sorted by distance (std::sort, unstable)
 int ref_htree_search(void* t, uint64_t hash, int threshold, uint32_t* out_idx, uint64_t* out_hash,
                      int32_t* out_dist, int cap) {

@@ -138,3 +138,156 @@ def test_gpu_indexes_loaded_from_directory_answer_like_direct_ones(gpu, tmp_path
     for i, v in w["vids"]:
         n = _M(id=i, videoIndex=v)
         assert [(r.mediaId, r.score) for r in va.findVideo(n, vp)] == [(r.mediaId, r.score) for r in vb.findVideo(n, vp)]
+
+
+# ---- the rebuildable caches (_index/cache/) -------------------------------------------------------------------
+
+def _gen_htree():
+    import importlib.util
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("gen_htree", os.path.join(here, "golden", "gen_golden_htree_cache.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_hamming_tree_cache_written_by_the_real_tree(tmp_path):
+    """tests/golden/htree_cache.npz holds a dctfeatures.cache file written by the reference's own HammingTree::write
+    (two leaves under a split root, two media removed): the reader returns exactly the values that went in"""
+    from conftest import load_golden
+
+    from cbird_amd.indexdir import read_hamming_tree
+
+    gen = _gen_htree()
+    ids, h = gen.make_inputs()
+    want_ids = ids.copy()
+    want_ids[np.isin(ids, gen.REMOVED)] = 0
+    path = tmp_path / "dctfeatures.cache"
+    load_golden("htree_cache.npz")["cache_bytes"].tofile(path)
+    got_ids, got_h = read_hamming_tree(str(path))
+    assert len(got_ids) == len(ids) == 8300
+    order_g = np.lexsort((got_ids, got_h))
+    order_w = np.lexsort((want_ids, h))
+    assert (got_h[order_g] == h[order_w]).all() and (got_ids[order_g] == want_ids[order_w]).all()
+    # leaf order: the root splits on bit 0, the left leaf holds the hashes with bit 0 clear
+    half = int((h & np.uint64(1) == 0).sum())
+    assert ((got_h[:half] & np.uint64(1)) == 0).all() and ((got_h[half:] & np.uint64(1)) == 1).all()
+    # damaged files are refused
+    bad = tmp_path / "bad.cache"
+    bad.write_bytes(b"cbird hamming tree:1:4:8:65536\n")
+    with pytest.raises(ValueError):
+        read_hamming_tree(str(bad))
+    raw = path.read_bytes()
+    (tmp_path / "trunc.cache").write_bytes(raw + b"\x00")
+    with pytest.raises(ValueError):
+        read_hamming_tree(str(tmp_path / "trunc.cache"))
+    empty = tmp_path / "empty.cache"
+    empty.write_bytes(b"cbird hamming tree:2:4:8:65536\n")
+    assert len(read_hamming_tree(str(empty))[0]) == 0
+
+
+def test_reader_agrees_with_the_real_tree_reading_its_own_file(tmp_path):
+    """when the compiled-in-place reference is available: a fresh real tree reads the golden file back and answers
+    searches like the tree that wrote it (the file is what cbird would load)"""
+    from oracle import RefHammingTree, ref_qt_available
+
+    if not ref_qt_available():
+        pytest.skip("needs oracle/_ref/libcbird_ref_qt.so (built where /root/reference exists)")
+    from conftest import load_golden
+
+    gen = _gen_htree()
+    ids, h = gen.make_inputs()
+    path = tmp_path / "dctfeatures.cache"
+    load_golden("htree_cache.npz")["cache_bytes"].tofile(path)
+    t = RefHammingTree()
+    assert t.read(str(path))  # (HammingTree::read does not restore size(): _count stays 0 in the reference)
+    t2 = tmp_path / "again.cache"
+    t.write(str(t2))
+    assert t2.read_bytes() == path.read_bytes()  # read -> write round trip through the real code is the identity
+
+
+def test_cvfeatures_cache_round_trip(tmp_path):
+    """cvfeatures.mat / _idmap.map / _indexmap.map / .touch (src/cvfeaturesindex.cpp:387-419, src/cvutil.cpp:129-163,
+    src/ioutil.h:203-231): header layout, map layout, removed media (indexmap value 0) keep their rows"""
+    import struct
+
+    from cbird_amd.indexdir import (cache_is_stale, read_cv_matrix, read_cvfeatures_cache, read_u32_map,
+                                    write_cvfeatures_cache, write_u32_map)
+
+    rng = np.random.default_rng(3)
+    media = [(5, rng.integers(0, 256, (7, 32), dtype=np.uint8)), (9, rng.integers(0, 256, (3, 32), dtype=np.uint8)),
+             (12, np.zeros((0, 32), np.uint8)), (20, rng.integers(0, 256, (11, 32), dtype=np.uint8))]
+    cache = tmp_path / "cache"
+    write_cvfeatures_cache(str(cache), media)
+    raw = (cache / "cvfeatures.mat").read_bytes()
+    assert struct.unpack("<Iiiii", raw[:20]) == (0, 21, 32, 0, 32) and len(raw) == 20 + 21 * 32
+    assert read_cv_matrix(str(cache / "cvfeatures.mat")).shape == (21, 32)
+    assert read_u32_map(str(cache / "cvfeatures_idmap.map")) == {5: 0, 9: 7, 20: 10}
+    assert (cache / "cvfeatures_idmap.map").read_bytes() == struct.pack("<6I", 5, 0, 9, 7, 20, 10)
+    got = read_cvfeatures_cache(str(cache))
+    assert [g[0] for g in got] == [5, 9, 20] and all((g[1] == m[1]).all() for g, m in zip(got, [media[0], media[1], media[3]]))
+    # the reference's remove() zeroes the indexmap value; its save() also stores the trailing sentinels
+    im = read_u32_map(str(cache / "cvfeatures_indexmap.map"))
+    im[7] = 0
+    im[21] = 0  # _indexMap[rows] = 0 sentinel
+    write_u32_map(str(cache / "cvfeatures_indexmap.map"), im)
+    got = read_cvfeatures_cache(str(cache))
+    assert [g[0] for g in got] == [5, 0, 20] and len(got[1][1]) == 3
+    # staleness: missing cache, database newer than cache
+    db = tmp_path / "media2.db"
+    db.write_bytes(b"x")
+    assert cache_is_stale(str(db), str(tmp_path / "nope"))
+    os.utime(db, (1, 1))
+    assert not cache_is_stale(str(db), str(cache / "cvfeatures.touch"))
+    os.utime(db, None)
+    os.utime(cache / "cvfeatures.touch", (1, 1))
+    assert cache_is_stale(str(db), str(cache / "cvfeatures.touch"))
+
+
+@pytest.mark.gpu
+def test_gpu_indexes_loaded_from_the_cache_files(gpu, tmp_path):
+    """_index/cache/: the dctfeatures.cache the REAL HammingTree wrote and a cvfeatures cache (incl. a removed media)
+    load into the GPU indexes and answer like indexes fed the same values directly"""
+    from conftest import load_golden
+
+    from cbird_amd.cvfeatures import CvFeaturesIndex
+    from cbird_amd.indexdir import IndexDir, _M, write_cvfeatures_cache
+
+    gen = _gen_htree()
+    ids, h = gen.make_inputs()
+    d = IndexDir(str(tmp_path))
+    os.makedirs(d.cache_path(), exist_ok=True)
+    for k in (1, 2):  # empty databases older than the caches: the caches are current
+        sqlite3.connect(d.db_path(k)).close()
+        os.utime(d.db_path(k), (1, 1))
+    load_golden("htree_cache.npz")["cache_bytes"].tofile(os.path.join(d.cache_path(), "dctfeatures.cache"))
+    fa, fb = gpu.DctFeaturesIndex(), gpu.DctFeaturesIndex()
+    d.load_dct_features(fa)
+    rows = [(int(i), h[ids == i]) for i in np.unique(ids)]
+    fb.load(rows)
+    fb.remove(gen.REMOVED.tolist())
+    assert fa.count() == fb.count() == len(h)
+    p = gpu.SearchParams()
+    for i in (1, 7, 8, 30, 60, 83):
+        m = _M(id=i, keyPointHashes=[int(x) for x in h[ids == i]])
+        assert [(r.mediaId, r.score) for r in fa.find(m, p)] == [(r.mediaId, r.score) for r in fb.find(m, p)], i
+    # cvfeatures
+    rng = np.random.default_rng(8)
+    media = [(i, rng.integers(0, 256, (int(rng.integers(1, 40)), 32), dtype=np.uint8)) for i in range(1, 60)]
+    write_cvfeatures_cache(d.cache_path(), media)
+    from cbird_amd.indexdir import read_u32_map, write_u32_map
+
+    im_path = os.path.join(d.cache_path(), "cvfeatures_indexmap.map")
+    im = read_u32_map(im_path)
+    start_of_17 = [k for k, v in im.items() if v == 17][0]
+    im[start_of_17] = 0  # media 17 removed, the way CvFeaturesIndex::remove leaves the map
+    write_u32_map(im_path, im)
+    ca, cb = CvFeaturesIndex(), CvFeaturesIndex()
+    d.load_cv_features(ca)
+    cb.add([_M(id=i, keyPointDescriptors=m) for i, m in media])
+    cb.remove([17])
+    assert ca.count() == cb.count()
+    for i, m in media[:12] + [media[16]]:
+        n = _M(id=i, keyPointDescriptors=m)
+        assert [(r.mediaId, r.score) for r in ca.find(n, p)] == [(r.mediaId, r.score) for r in cb.find(n, p)], i
