@@ -13,6 +13,7 @@
 // tests/test_fdct.py, tests/test_cvfeatures.py, tests/test_color.py and tests/test_video.py.
 #pragma once
 
+#include <algorithm>
 #include <vector>
 
 #include "cbird_hip.h"
@@ -61,6 +62,14 @@ class GpuDctFeaturesIndex : public DctFeaturesIndex {  // inherits createTables/
     }
     CBH_CHECK(cbh_idx64_load(_idx, hashes.data(), ids.data(), hashes.size()));
   }
+  // slice(): HammingTree::slice keeps the values whose index is in the set (dctfeaturesindex.cpp:239-258); the
+  // caller owns the result
+  Index* slice(const QSet<uint32_t>& mediaIds) const override {
+    std::vector<uint32_t> ids(mediaIds.begin(), mediaIds.end());
+    cbh_idx64* sub = cbh_idx64_slice(_idx, ids.data(), ids.size());
+    if (!sub) qFatal("GpuDctFeaturesIndex::slice: %s", cbh_last_error());
+    return new GpuDctFeaturesIndex(sub, _treeCompat);
+  }
   void save(QSqlDatabase&, const QString&) override {}
   void add(const MediaGroup& media) override {
     std::vector<uint64_t> hashes;
@@ -100,6 +109,7 @@ class GpuDctFeaturesIndex : public DctFeaturesIndex {  // inherits createTables/
   }
 
  private:
+  GpuDctFeaturesIndex(cbh_idx64* adopted, bool treeCompat) : _idx(adopted), _treeCompat(treeCompat) {}
   cbh_idx64* _idx;
   bool _treeCompat;
 };
@@ -107,7 +117,7 @@ class GpuDctFeaturesIndex : public DctFeaturesIndex {  // inherits createTables/
 // ---- CvFeaturesIndex ----------------------------------------------------------------------------------
 class GpuCvFeaturesIndex : public CvFeaturesIndex {
  public:
-  GpuCvFeaturesIndex(int device = 0) : _idx(cbh_idx256_create(device)) {
+  GpuCvFeaturesIndex(int device = 0) : _device(device), _idx(cbh_idx256_create(device)) {
     if (!_idx) qFatal("no usable MI355X device");
   }
   ~GpuCvFeaturesIndex() override { cbh_idx256_destroy(_idx); }
@@ -157,7 +167,26 @@ class GpuCvFeaturesIndex : public CvFeaturesIndex {
     return results;
   }
 
+  // slice(): the descriptors of the given media in ascending id order, like load() builds them
+  // (cvfeaturesindex.cpp:285-312)
+  Index* slice(const QSet<uint32_t>& mediaIds) const override {
+    GpuCvFeaturesIndex* chunk = new GpuCvFeaturesIndex(_device);
+    std::vector<uint32_t> ids(mediaIds.begin(), mediaIds.end());
+    std::sort(ids.begin(), ids.end());
+    std::vector<uint8_t> rows;
+    for (uint32_t id : ids) {
+      size_t first = 0, cnt = 0;
+      CBH_CHECK(cbh_idx256_rows_of(_idx, id, &first, &cnt));
+      if (!cnt) continue;
+      rows.resize(cnt * 32);
+      CBH_CHECK(cbh_idx256_download_rows(_idx, first, cnt, rows.data()));
+      CBH_CHECK(cbh_idx256_add(chunk->_idx, id, rows.data(), cnt));
+    }
+    return chunk;
+  }
+
  private:
+  int _device = 0;
   cbh_idx256* _idx;
 };
 
@@ -165,7 +194,7 @@ class GpuCvFeaturesIndex : public CvFeaturesIndex {
 static_assert(sizeof(ColorDescriptor) == CBH_COLOR_DESC_BYTES, "ColorDescriptor layout (src/cvutil.h:96-113)");
 class GpuColorDescIndex : public ColorDescIndex {
  public:
-  GpuColorDescIndex(int device = 0) : _idx(cbh_color_create(device)) {
+  GpuColorDescIndex(int device = 0) : _device(device), _idx(cbh_color_create(device)) {
     if (!_idx) qFatal("no usable MI355X device");
   }
   ~GpuColorDescIndex() override { cbh_color_destroy(_idx); }
@@ -214,7 +243,24 @@ class GpuColorDescIndex : public ColorDescIndex {
     return results;
   }
 
+  // slice(): the descriptors whose media id is in the set, in index order (colordescindex.cpp:231-248)
+  Index* slice(const QSet<uint32_t>& mediaIds) const override {
+    GpuColorDescIndex* chunk = new GpuColorDescIndex(_device);
+    const size_t n = size_t(count());
+    std::vector<uint32_t> ids(n), keepIds;
+    std::vector<ColorDescriptor> descs(n), keep;
+    if (n) CBH_CHECK(cbh_color_download(_idx, ids.data(), descs.data(), n));
+    for (size_t i = 0; i < n; ++i)
+      if (mediaIds.contains(ids[i])) {
+        keepIds.push_back(ids[i]);
+        keep.push_back(descs[i]);
+      }
+    if (!keepIds.empty()) chunk->addRows(keepIds.data(), keep.data(), keepIds.size());
+    return chunk;
+  }
+
  private:
+  int _device = 0;
   cbh_color* _idx;
 };
 
@@ -224,7 +270,7 @@ class GpuDctVideoIndex : public DctVideoIndex {
   // radixCompat = false: exact search (the reference's vradix 0).  true: honour params.videoRadix like the
   // reference's RadixMap does (a needle frame only sees its bucket, src/tree/radix.h:135-141).
   GpuDctVideoIndex(int device = 0, bool radixCompat = false)
-      : _idx(cbh_vidx_create(device)), _radixCompat(radixCompat) {
+      : _device(device), _idx(cbh_vidx_create(device)), _radixCompat(radixCompat) {
     if (!_idx) qFatal("no usable MI355X device");
   }
   ~GpuDctVideoIndex() override { cbh_vidx_destroy(_idx); }
@@ -283,6 +329,15 @@ class GpuDctVideoIndex : public DctVideoIndex {
     return results;
   }
 
+  // slice(): "replicate what load() does, but use the subset" (dctvideoindex.cpp:389-397)
+  Index* slice(const QSet<uint32_t>& mediaIds) const override {
+    GpuDctVideoIndex* copy = new GpuDctVideoIndex(_device, _radixCompat);
+    copy->_dataPath = _dataPath;
+    for (uint32_t id : mediaIds) copy->addOne(id);
+    copy->_loaded = true;
+    return copy;
+  }
+
  private:
   void addOne(uint32_t id) {
     VideoIndex vi;
@@ -293,6 +348,7 @@ class GpuDctVideoIndex : public DctVideoIndex {
       qWarning() << "index file missing:" << path;
     CBH_CHECK(cbh_vidx_add_video(_idx, id, vi.frames.data(), vi.hashes.data(), vi.frames.size()));
   }
+  int _device = 0;
   cbh_vidx* _idx;
   bool _radixCompat;
   QString _dataPath;

@@ -47,6 +47,19 @@ int main(int argc, char** argv) {
     CHECK(dup);
     Media by_id("n", 6, 0);  // no hashes: taken from the index by id (:270-276)
     CHECK(idx.find(by_id, p).count() == r.count());
+    {  // slice(): only the chosen media remain; the caller deletes the result (database.cpp:1435)
+      QSet<uint32_t> keep;
+      for (uint32_t id : {5u, 6u, 7u, 100u}) keep.insert(id);
+      Index* sub = idx.slice(keep);
+      CHECK(sub && sub->isLoaded() && sub->count() == 4 * per);
+      bool only = true, has5 = false;
+      for (auto& m : sub->find(needle, p)) {
+        only &= keep.contains(m.mediaId);
+        has5 |= m.mediaId == 5;
+      }
+      CHECK(only && has5);
+      delete sub;
+    }
     QVector<int> rm;
     rm.append(5);
     idx.remove(rm);
@@ -81,6 +94,17 @@ int main(int argc, char** argv) {
     CHECK(r.count() >= 1 && r[0].mediaId == 8);  // itself: all descriptors at distance 0
     Media by_id("n", 8, 0);
     CHECK(idx.find(by_id, p).count() == r.count());
+    {
+      QSet<uint32_t> keep;
+      for (uint32_t id : {30u, 8u, 2u}) keep.insert(id);
+      Index* sub = idx.slice(keep);
+      CHECK(sub && sub->count() == 3 * per);
+      QVector<Index::Match> rs = sub->find(g[7], p);
+      CHECK(rs.count() >= 1 && rs[0].mediaId == 8);
+      for (auto& m : rs) CHECK(keep.contains(m.mediaId));
+      CHECK(sub->find(g[20], p).count() == 0 || sub->find(g[20], p)[0].mediaId != 21);  // 21 is not in the slice
+      delete sub;
+    }
     QVector<int> rm;
     rm.append(8);
     idx.remove(rm);
@@ -110,6 +134,21 @@ int main(int argc, char** argv) {
     CHECK(self);
     Media probe("x", 4, 0);
     CHECK(idx.findIndexData(probe) && probe.colorDescriptor().numColors == g[3].colorDescriptor().numColors);
+    {
+      QSet<uint32_t> keep;
+      for (uint32_t id = 1; id <= 50; ++id) keep.insert(id);
+      Index* sub = idx.slice(keep);
+      CHECK(sub && sub->count() == 50);
+      bool self2 = false;
+      for (auto& m : sub->find(g[3], p)) {
+        CHECK(m.mediaId <= 50);
+        self2 |= (m.mediaId == 4 && m.score == 1);
+      }
+      CHECK(self2);
+      Media probe2("x", 300, 0);
+      CHECK(!sub->findIndexData(probe2));
+      delete sub;
+    }
     QVector<int> rm;
     rm.append(4);
     idx.remove(rm);
@@ -147,6 +186,21 @@ int main(int argc, char** argv) {
     Media frame("f", 0, vids[4].hashes[50]);  // a single frame finds both copies
     frame.setType(Media::TypeImage);
     CHECK(idx.find(frame, p).count() == 2);
+    {
+      QSet<uint32_t> keep;
+      for (uint32_t id : {104u, 105u, 111u}) keep.insert(id);
+      Index* sub = idx.slice(keep);
+      CHECK(sub && sub->isLoaded() && sub->count() == 3);
+      QVector<Index::Match> rs = sub->find(needle, p);
+      CHECK(rs.count() == 1 && rs[0].mediaId == 104);
+      QSet<uint32_t> other;
+      other.insert(105u);
+      other.insert(111u);
+      Index* sub2 = idx.slice(other);
+      CHECK(sub2->find(needle, p).count() == 0);  // the copy (104) is not in this slice
+      delete sub2;
+      delete sub;
+    }
     QVector<int> rm;
     rm.append(104);
     idx.remove(rm);

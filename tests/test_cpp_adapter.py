@@ -33,6 +33,9 @@ def test_other_four_adapters_compile():
     src = open(os.path.join(ROOT, "cbird_amd", "cpp", "gpu_indexes.h")).read()
     for cls in ("GpuDctFeaturesIndex", "GpuCvFeaturesIndex", "GpuColorDescIndex", "GpuDctVideoIndex"):
         assert f"class {cls} : public" in src
+    # every search-side virtual the reference classes override is overridden here too
+    assert src.count("Index* slice(const QSet<uint32_t>& mediaIds) const override") == 4
+    assert src.count("find(const Media&") == 4 and src.count(" remove(const QVector<int>&") == 4
 
 
 @pytest.mark.gpu
