@@ -29,6 +29,7 @@ def make_descriptor(luvw, num_colors=None) -> np.ndarray:
 class ColorDescIndex:
     def __init__(self, device: int = 0) -> None:
         self._L = _lib.lib()
+        self._device = device
         self._id = SearchParams.AlgoColor
         self._h = self._L.cbh_color_create(device)
         if not self._h:
@@ -64,6 +65,20 @@ class ColorDescIndex:
     def remove(self, ids) -> None:
         i = np.ascontiguousarray(list(ids), np.uint32)
         check(self._L.cbh_color_remove(self._h, i.ctypes.data, len(i)), "remove")
+
+    def slice(self, mediaIds) -> "ColorDescIndex":
+        """ColorDescIndex::slice (colordescindex.cpp:231-248): entries whose mediaId is in the set, index order"""
+        n = self.count()
+        ids = np.zeros(max(n, 1), np.uint32)
+        descs = np.zeros(max(n, 1), COLOR_DTYPE)
+        if n:
+            check(self._L.cbh_color_download(self._h, ids.ctypes.data, descs.ctypes.data, n), "download")
+        keep = np.isin(ids[:n], np.array(sorted(set(int(x) for x in mediaIds)), np.uint32))
+        chunk = ColorDescIndex(self._device)
+        if keep.any():
+            ki, kd = np.ascontiguousarray(ids[:n][keep]), np.ascontiguousarray(descs[:n][keep])
+            check(self._L.cbh_color_add(chunk._h, ki.ctypes.data, kd.ctypes.data, len(ki)), "add")
+        return chunk
 
     def findIndexData(self, m) -> bool:
         d = np.zeros((), COLOR_DTYPE)

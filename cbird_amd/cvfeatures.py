@@ -18,6 +18,7 @@ class CvFeaturesIndex:
 
     def __init__(self, device: int = 0) -> None:
         self._L = _lib.lib()
+        self._device = device
         self._id = SearchParams.AlgoCVFeatures
         self._h = self._L.cbh_idx256_create(device)
         if not self._h:
@@ -70,6 +71,15 @@ class CvFeaturesIndex:
         if c.value:
             check(self._L.cbh_idx256_download_rows(self._h, f.value, c.value, out.ctypes.data), "download_rows")
         return out
+
+    def slice(self, mediaIds) -> "CvFeaturesIndex":
+        """CvFeaturesIndex::slice (cvfeaturesindex.cpp:285-312): the descriptors of the given media, ascending id"""
+        chunk = CvFeaturesIndex(self._device)
+        for mid in sorted(set(int(x) for x in mediaIds)):
+            d = self.descriptorsForMediaId(mid)
+            if len(d):
+                check(self._L.cbh_idx256_add(chunk._h, mid, np.ascontiguousarray(d).ctypes.data, len(d)), "add")
+        return chunk
 
     def knn(self, needles, k: int, thresh: int):
         d = self._rows(needles)

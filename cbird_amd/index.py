@@ -231,7 +231,7 @@ class DctFeaturesIndex:
     keypoint hashes per image, stored as (mediaId, hash) entries; `find` votes over the 10 nearest
     entries of every needle hash (src/dctfeaturesindex.cpp:260-358)."""
 
-    def __init__(self, device: int = 0, tree_compat: bool = False) -> None:
+    def __init__(self, device: int = 0, tree_compat: bool = False, _handle=None) -> None:
         self._L = _lib.lib()
         self._device = device
         self._id = SearchParams.AlgoDCTFeatures  # dctfeaturesindex.cpp:84
@@ -239,7 +239,7 @@ class DctFeaturesIndex:
         # entries of its HammingTree leaf (src/tree/hammingtree.h:244-252), i.e. the reference's own
         # approximate candidate sets, also on multi-leaf trees.
         self.tree_compat = bool(tree_compat)
-        self._h = self._L.cbh_idx64_create(device)
+        self._h = _handle if _handle is not None else self._L.cbh_idx64_create(device)
         if not self._h:
             raise CbhError(_lib.CBH_E_NODEVICE, "cbh_idx64_create")
 
@@ -247,6 +247,14 @@ class DctFeaturesIndex:
         h, self._h = getattr(self, "_h", None), None
         if h:
             self._L.cbh_idx64_destroy(h)
+
+    def slice(self, mediaIds) -> "DctFeaturesIndex":
+        """DctFeaturesIndex::slice (dctfeaturesindex.cpp:239-258): the values whose mediaId is in the set"""
+        i = _as_u32(sorted(set(int(x) for x in mediaIds)))
+        h = self._L.cbh_idx64_slice(self._h, i.ctypes.data, len(i))
+        if not h:
+            raise CbhError(_lib.CBH_E_HIP, "slice")
+        return DctFeaturesIndex(self._device, self.tree_compat, _handle=h)
 
     def id(self) -> int:
         return self._id

@@ -100,6 +100,7 @@ class DctVideoIndex:
         # RadixMap bucket, (hash >> 1) & (2^videoRadix - 1) (src/tree/radix.h:135-141): the reference's
         # approximate candidate sets for `-p.vradix N`.
         self.radix_compat = bool(radix_compat)
+        self._device = device
         self._L = _lib.lib()
         self._id = SearchParams.AlgoVideo
         self._data_path = data_path
@@ -153,6 +154,15 @@ class DctVideoIndex:
     def remove(self, ids) -> None:
         i = np.ascontiguousarray(list(ids), np.uint32)
         check(self._L.cbh_vidx_remove(self._h, i.ctypes.data, len(i)), "remove")
+
+    def slice(self, mediaIds) -> "DctVideoIndex":
+        """DctVideoIndex::slice (dctvideoindex.cpp:389-397): "replicate what load() does, but use the subset" -- the
+        frames come from <dataPath>/<id>.vdx again, so the index must have been loaded from a data path"""
+        if self._data_path is None:
+            raise ValueError("slice() re-reads the .vdx files: the index needs a data path")
+        copy = DctVideoIndex(self._device, self._data_path, self.radix_compat)
+        copy.load(list(mediaIds))
+        return copy
 
     @staticmethod
     def _matches(buf, n):

@@ -291,3 +291,61 @@ def test_gpu_indexes_loaded_from_the_cache_files(gpu, tmp_path):
     for i, m in media[:12] + [media[16]]:
         n = _M(id=i, keyPointDescriptors=m)
         assert [(r.mediaId, r.score) for r in ca.find(n, p)] == [(r.mediaId, r.score) for r in cb.find(n, p)], i
+
+
+@pytest.mark.gpu
+def test_slice_of_every_index(gpu, tmp_path):
+    """Index::slice of the four non-DctHash indexes (the Python mirrors of the adapters' overrides): the slice answers
+    like an index that was only ever given the chosen media"""
+    from cbird_amd.colordesc import ColorDescIndex
+    from cbird_amd.cvfeatures import CvFeaturesIndex
+    from cbird_amd.indexdir import _M
+    from cbird_amd.video import DctVideoIndex, VideoSearchParams
+
+    d, w = _fixture(tmp_path)
+    p = gpu.SearchParams()
+    keep = [i for i, _ in w["kp"]][::3]
+    # DctFeaturesIndex
+    full, ref = gpu.DctFeaturesIndex(), gpu.DctFeaturesIndex()
+    full.load(w["kp"])
+    ref.load([(i, h) for i, h in w["kp"] if i in set(keep)])
+    sub = full.slice(keep)
+    assert sub.count() == ref.count()
+    for i, hs in w["kp"][:30]:
+        if len(hs):
+            m = _M(id=i, keyPointHashes=[int(x) for x in hs])
+            assert [(r.mediaId, r.score) for r in sub.find(m, p)] == [(r.mediaId, r.score) for r in ref.find(m, p)]
+    # CvFeaturesIndex
+    mats = [x for x in w["mats"] if len(x[1])]
+    keep_c = [i for i, _ in mats][::2]
+    cf, cr = CvFeaturesIndex(), CvFeaturesIndex()
+    cf.add([_M(id=i, keyPointDescriptors=m) for i, m in mats])
+    cr.add([_M(id=i, keyPointDescriptors=m) for i, m in mats if i in set(keep_c)])
+    cs = cf.slice(keep_c)
+    assert cs.count() == cr.count()
+    for i, m in mats[:8]:
+        n = _M(id=i, keyPointDescriptors=m)
+        assert [(r.mediaId, r.score) for r in cs.find(n, p)] == [(r.mediaId, r.score) for r in cr.find(n, p)]
+    # ColorDescIndex
+    xf = ColorDescIndex()
+    xf.add([_M(id=int(i), colorDescriptor=w["cols"][k]) for k, i in enumerate(w["ids"])])
+    keep_x = [int(i) for i in w["ids"][::4]]
+    xs = xf.slice(keep_x)
+    xr = ColorDescIndex()
+    xr.add([_M(id=int(i), colorDescriptor=w["cols"][k]) for k, i in enumerate(w["ids"]) if int(i) in set(keep_x)])
+    assert xs.count() == xr.count() == len(keep_x)
+    assert all((a == b).all() for a, b in zip(xs.find_batch(w["cols"][:5], 6), xr.find_batch(w["cols"][:5], 6)))
+    # DctVideoIndex (re-reads the .vdx files of the subset)
+    vf = DctVideoIndex()
+    d.load_video(vf)
+    keep_v = [i for i, _ in w["vids"]][::2]
+    vs = vf.slice(keep_v)
+    vr = DctVideoIndex()
+    vr.add([_M(id=i, videoIndex=v) for i, v in w["vids"] if i in set(keep_v)])
+    vp = VideoSearchParams(dctThresh=5, skipFrames=0, minFramesMatched=5, minFramesNear=30)
+    assert vs.count() == vr.count() == len(keep_v)
+    for i, v in w["vids"]:
+        n = _M(id=i, videoIndex=v)
+        assert [(r.mediaId, r.score) for r in vs.find(n, vp)] == [(r.mediaId, r.score) for r in vr.find(n, vp)]
+    with pytest.raises(ValueError):
+        vr.slice(keep_v)  # built from memory: no data path to re-read
