@@ -14,6 +14,7 @@
 #pragma once
 
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
 #include "cbird_hip.h"
@@ -124,7 +125,28 @@ class GpuCvFeaturesIndex : public CvFeaturesIndex {
   bool isLoaded() const override { return cbh_idx256_is_loaded(_idx); }
   int count() const override { return int(cbh_idx256_count(_idx)); }
   size_t memoryUsage() const override { return cbh_idx256_memory_usage(_idx); }
-  // load(): cbird's SQL loop over `matrix` (cvfeaturesindex.cpp:167-250) calling addOne() per row
+  // load(): the reference's SQL loop over `matrix` (cvfeaturesindex.cpp:184-232) -- rows arrive in ascending
+  // media_id, empty ones are skipped, inconsistent ones ignored with a message; no FLANN index, no cache file
+  void load(QSqlDatabase& db, const QString&, const QString&) override {
+    QSqlQuery query(db);
+    query.setForwardOnly(true);
+    if (!query.exec("select media_id,rows,cols,type,stride,data from matrix order by media_id")) SQL_FATAL(exec)
+    uint32_t lastId = 0;
+    while (query.next()) {
+      const uint32_t id = query.value(0).toUInt();
+      const int rows = query.value(1).toInt(), cols = query.value(2).toInt(), type = query.value(3).toInt(),
+                stride = query.value(4).toInt();
+      if (rows <= 0) continue;  // "skip empty descriptors as they would violate the requirements on _idMap"
+      const QByteArray data = qUncompress(query.value(5).toByteArray());
+      if (lastId >= id || type != CV_8UC1 || cols != 32 || stride != cols || size_t(data.size()) != size_t(rows) * 32u) {
+        qWarning() << "sql: ignoring invalid data @ media_id=" << id;
+        continue;
+      }
+      CBH_CHECK(cbh_idx256_add(_idx, id, reinterpret_cast<const uint8_t*>(data.constData()), size_t(rows)));
+      lastId = id;
+    }
+  }
+  void save(QSqlDatabase&, const QString&) override {}  // nothing to cache: the rows are the index
   void addOne(uint32_t mediaId, const cv::Mat& desc) {  // desc: rows x 32, CV_8U, continuous
     if (desc.rows > 0) CBH_CHECK(cbh_idx256_add(_idx, mediaId, desc.ptr<uint8_t>(0), size_t(desc.rows)));
   }
@@ -201,7 +223,27 @@ class GpuColorDescIndex : public ColorDescIndex {
   bool isLoaded() const override { return cbh_color_is_loaded(_idx); }
   int count() const override { return int(cbh_color_count(_idx)); }
   size_t memoryUsage() const override { return cbh_color_memory_usage(_idx); }
-  // load(): cbird's `select media_id,color_desc from color` loop (colordescindex.cpp:123-168) -> addRows()
+  // load(): `select media_id,color_desc from color` (colordescindex.cpp:125-150); a blob of the wrong size becomes an
+  // empty descriptor ("no color desc for id ..., correct by re-indexing")
+  void load(QSqlDatabase& db, const QString&, const QString&) override {
+    QSqlQuery query(db);
+    query.setForwardOnly(true);
+    if (!query.exec("select media_id,color_desc from color")) SQL_FATAL(exec)
+    std::vector<uint32_t> ids;
+    std::vector<ColorDescriptor> descs;
+    while (query.next()) {
+      ids.push_back(query.value(0).toUInt());
+      const QByteArray bytes = query.value(1).toByteArray();
+      ColorDescriptor d;
+      if (size_t(bytes.size()) == sizeof(ColorDescriptor))
+        memcpy(&d, bytes.constData(), sizeof(ColorDescriptor));
+      else
+        qWarning() << "no color desc for id" << ids.back() << ", correct by re-indexing";
+      descs.push_back(d);
+    }
+    if (!ids.empty()) addRows(ids.data(), descs.data(), ids.size());
+  }
+  void save(QSqlDatabase&, const QString&) override {}  // "no caching" (colordescindex.cpp:155-159)
   void addRows(const uint32_t* ids, const ColorDescriptor* descs, size_t n) {
     CBH_CHECK(cbh_color_add(_idx, ids, descs, n));
   }

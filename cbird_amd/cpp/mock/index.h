@@ -18,6 +18,8 @@
 #include <utility>
 #include <vector>
 
+#include <zlib.h>
+
 #include "cbird_hip.h"
 
 #define Q_DISABLE_COPY_MOVE(C) \
@@ -74,6 +76,30 @@ struct QDebugMock {
 inline QDebugMock qWarning() { return QDebugMock(); }
 inline const char* qPrintable(const QString& s) { return s.c_str(); }
 
+// Qt's qCompress / qUncompress: 4-byte big-endian uncompressed length + a zlib stream
+inline QByteArray qCompress(const QByteArray& in) {
+  uLongf cap = compressBound(uLong(in.size()));
+  std::string out(4 + cap, '\0');
+  const uint32_t n = uint32_t(in.size());
+  out[0] = char(n >> 24), out[1] = char(n >> 16), out[2] = char(n >> 8), out[3] = char(n);
+  compress(reinterpret_cast<Bytef*>(&out[4]), &cap, reinterpret_cast<const Bytef*>(in.data()), uLong(in.size()));
+  out.resize(4 + cap);
+  QByteArray r;
+  r.assign(out);
+  return r;
+}
+inline QByteArray qUncompress(const QByteArray& in) {
+  QByteArray r;
+  if (in.size() < 4) return r;
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(in.data());
+  uLongf n = (uLongf(p[0]) << 24) | (uLongf(p[1]) << 16) | (uLongf(p[2]) << 8) | uLongf(p[3]);
+  std::string out(n, '\0');
+  if (uncompress(reinterpret_cast<Bytef*>(&out[0]), &n, p + 4, uLong(in.size() - 4)) != Z_OK) return r;
+  out.resize(n);
+  r.assign(out);
+  return r;
+}
+
 template <typename T>
 struct QVector : std::vector<T> {
   using std::vector<T>::vector;
@@ -94,6 +120,13 @@ struct QSqlDatabase {
   };
   std::vector<Row> media;
   std::vector<std::pair<uint32_t, QByteArray>> kphash;  // (media_id, hashes blob)
+  struct MatrixRow {                                     // table `matrix` (cvfeaturesindex.cpp:54-65)
+    uint32_t media_id;
+    int rows, cols, type, stride;
+    QByteArray data;  // qCompress'd row bytes
+  };
+  std::vector<MatrixRow> matrix;                         // must be kept in ascending media_id ("order by media_id")
+  std::vector<std::pair<uint32_t, QByteArray>> color;   // table `color` (media_id, color_desc blob)
 };
 struct QVariant {
   int64_t v = 0;
@@ -110,7 +143,7 @@ struct QSqlError {
 struct QSqlQuery {
   QSqlDatabase& db;
   long pos = -1;
-  int stmt = 0;  // 1: id,phash_dct of images; 2: kphash rows; 3: ids of one media type
+  int stmt = 0;  // 1: id,phash_dct of images; 2: kphash rows; 3: ids of one media type; 4: matrix rows; 5: color rows
   int bound_type = 0;
   explicit QSqlQuery(QSqlDatabase& d) : db(d) {}
   void setForwardOnly(bool) {}
@@ -125,12 +158,18 @@ struct QSqlQuery {
   }
   bool exec(const char* sql) {
     const std::string q(sql);
-    stmt = q == "select id,phash_dct from media where type=1" ? 1 : q == "select media_id,hashes from kphash" ? 2 : 0;
+    stmt = q == "select id,phash_dct from media where type=1" ? 1
+           : q == "select media_id,hashes from kphash"       ? 2
+           : q == "select media_id,rows,cols,type,stride,data from matrix order by media_id" ? 4
+           : q == "select media_id,color_desc from color"    ? 5
+                                                              : 0;
     pos = -1;
     return stmt != 0;
   }
   bool next() {
     if (stmt == 2) return ++pos < long(db.kphash.size());
+    if (stmt == 4) return ++pos < long(db.matrix.size());
+    if (stmt == 5) return ++pos < long(db.color.size());
     const int want = stmt == 1 ? 1 : bound_type;
     while (++pos < long(db.media.size()))
       if (db.media[size_t(pos)].type == want) return true;
@@ -141,6 +180,18 @@ struct QSqlQuery {
     if (stmt == 2) {
       if (col == 0) v.v = db.kphash[size_t(pos)].first;
       else v.b = db.kphash[size_t(pos)].second;
+      return v;
+    }
+    if (stmt == 4) {
+      const auto& m = db.matrix[size_t(pos)];
+      const int64_t f[5] = {int64_t(m.media_id), m.rows, m.cols, m.type, m.stride};
+      if (col < 5) v.v = f[col];
+      else v.b = m.data;
+      return v;
+    }
+    if (stmt == 5) {
+      if (col == 0) v.v = db.color[size_t(pos)].first;
+      else v.b = db.color[size_t(pos)].second;
       return v;
     }
     const auto& r = db.media[size_t(pos)];

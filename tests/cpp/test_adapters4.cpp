@@ -94,6 +94,25 @@ int main(int argc, char** argv) {
     CHECK(r.count() >= 1 && r[0].mediaId == 8);  // itself: all descriptors at distance 0
     Media by_id("n", 8, 0);
     CHECK(idx.find(by_id, p).count() == r.count());
+    {  // load(): the `matrix` table (qCompress'd rows, ascending media_id; empty and inconsistent rows skipped)
+      QSqlDatabase mdb;
+      for (int i = 0; i < n; ++i) {
+        const cv::Mat& d = g[i].keyPointDescriptors();
+        QByteArray raw(reinterpret_cast<const char*>(d.ptr<uint8_t>(0)), size_t(d.rows) * 32);
+        mdb.matrix.push_back({uint32_t(i + 1), d.rows, 32, CV_8UC1, 32, qCompress(raw)});
+        if (i == 10) mdb.matrix.push_back({uint32_t(i + 1), 0, 0, 0, 0, QByteArray()});           // empty: skipped
+        if (i == 20) mdb.matrix.push_back({uint32_t(i + 1), d.rows, 32, CV_8UC1, 31, qCompress(raw)});  // bad stride
+        if (i == 30) mdb.matrix.push_back({5u, d.rows, 32, CV_8UC1, 32, qCompress(raw)});          // id not ascending
+      }
+      GpuCvFeaturesIndex loaded;
+      loaded.load(mdb, "", "");
+      CHECK(loaded.isLoaded() && loaded.count() == idx.count());
+      for (int i : {0, 7, 20, 59}) {
+        QVector<Index::Match> a = idx.find(g[i], p), b = loaded.find(g[i], p);
+        CHECK(a.count() == b.count());
+        for (int k = 0; k < a.count(); ++k) CHECK(a[k].mediaId == b[k].mediaId && a[k].score == b[k].score);
+      }
+    }
     {
       QSet<uint32_t> keep;
       for (uint32_t id : {30u, 8u, 2u}) keep.insert(id);
@@ -134,6 +153,22 @@ int main(int argc, char** argv) {
     CHECK(self);
     Media probe("x", 4, 0);
     CHECK(idx.findIndexData(probe) && probe.colorDescriptor().numColors == g[3].colorDescriptor().numColors);
+    {  // load(): the `color` table; a blob of the wrong size becomes an empty descriptor
+      QSqlDatabase cdb;
+      for (int i = 0; i < n; ++i) {
+        const ColorDescriptor c = g[i].colorDescriptor();
+        cdb.color.push_back({uint32_t(i + 1), QByteArray(reinterpret_cast<const char*>(&c), sizeof(c))});
+      }
+      cdb.color.push_back({9000u, QByteArray("short")});
+      GpuColorDescIndex loaded;
+      loaded.load(cdb, "", "");
+      CHECK(loaded.count() == n + 1);
+      QVector<Index::Match> a = idx.find(g[3], p), b = loaded.find(g[3], p);
+      CHECK(a.count() == b.count());
+      for (int k = 0; k < a.count(); ++k) CHECK(a[k].mediaId == b[k].mediaId && a[k].score == b[k].score);
+      Media empty("x", 9000, 0);
+      CHECK(loaded.findIndexData(empty) && empty.colorDescriptor().numColors == 0);
+    }
     {
       QSet<uint32_t> keep;
       for (uint32_t id = 1; id <= 50; ++id) keep.insert(id);

@@ -36,6 +36,7 @@ def test_other_four_adapters_compile():
     # every search-side virtual the reference classes override is overridden here too
     assert src.count("Index* slice(const QSet<uint32_t>& mediaIds) const override") == 4
     assert src.count("find(const Media&") == 4 and src.count(" remove(const QVector<int>&") == 4
+    assert src.count("void load(QSqlDatabase& db") == 4 and src.count("void save(QSqlDatabase&") >= 3
 
 
 @pytest.mark.gpu
