@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <set>
 #include <vector>
 
 #include "cbird_hip.h"
@@ -244,6 +245,19 @@ class GpuColorDescIndex : public ColorDescIndex {
     if (!ids.empty()) addRows(ids.data(), descs.data(), ids.size());
   }
   void save(QSqlDatabase&, const QString&) override {}  // "no caching" (colordescindex.cpp:155-159)
+  // mediaIds(): the loaded reference reads its private _mediaId array (colordescindex.cpp:161-190), which this class
+  // leaves empty -- the ids come from the GPU index instead (removed entries appear as id 0, like there); not
+  // loaded: the inherited SQL query
+  QSet<mediaid_t> mediaIds(QSqlDatabase& db, const QString& cachePath, const QString& dataPath) const override {
+    if (!isLoaded()) return ColorDescIndex::mediaIds(db, cachePath, dataPath);
+    const size_t n = size_t(count());
+    std::vector<uint32_t> ids(n);
+    std::vector<ColorDescriptor> descs(n);
+    CBH_CHECK(cbh_color_download(_idx, ids.data(), descs.data(), n));
+    QSet<mediaid_t> result;
+    for (uint32_t id : ids) result.insert(id);
+    return result;
+  }
   void addRows(const uint32_t* ids, const ColorDescriptor* descs, size_t n) {
     CBH_CHECK(cbh_color_add(_idx, ids, descs, n));
   }
@@ -336,6 +350,15 @@ class GpuDctVideoIndex : public DctVideoIndex {
   void remove(const QVector<int>& ids) override {
     std::vector<uint32_t> v(ids.begin(), ids.end());
     CBH_CHECK(cbh_vidx_remove(_idx, v.data(), v.size()));
+    for (uint32_t id : v) _ids.erase(id);
+  }
+  // mediaIds(): the loaded reference reads its private _mediaId list (dctvideoindex.cpp:218-231), empty here: this
+  // class keeps its own; not loaded: the inherited SQL + file-exists scan
+  QSet<mediaid_t> mediaIds(QSqlDatabase& db, const QString& cachePath, const QString& dataPath) const override {
+    if (!isLoaded()) return DctVideoIndex::mediaIds(db, cachePath, dataPath);
+    QSet<mediaid_t> result;
+    for (uint32_t id : _ids) result.insert(id);
+    return result;
   }
   QVector<Index::Match> find(const Media& needle, const SearchParams& p) override {
     std::vector<cbh_vmatch> out(size_t(std::max(count(), 1)));
@@ -389,7 +412,9 @@ class GpuDctVideoIndex : public DctVideoIndex {
     else
       qWarning() << "index file missing:" << path;
     CBH_CHECK(cbh_vidx_add_video(_idx, id, vi.frames.data(), vi.hashes.data(), vi.frames.size()));
+    _ids.insert(id);
   }
+  std::set<uint32_t> _ids;  // what DctVideoIndex::_mediaId holds in the reference
   int _device = 0;
   cbh_vidx* _idx;
   bool _radixCompat;

@@ -168,6 +168,13 @@ int main(int argc, char** argv) {
       for (int k = 0; k < a.count(); ++k) CHECK(a[k].mediaId == b[k].mediaId && a[k].score == b[k].score);
       Media empty("x", 9000, 0);
       CHECK(loaded.findIndexData(empty) && empty.colorDescriptor().numColors == 0);
+      QSet<mediaid_t> have = loaded.mediaIds(cdb, "", "");  // from the GPU index, not the (empty) base-class arrays
+      CHECK(have.size() == size_t(n + 1) && have.contains(1) && have.contains(9000) && !have.contains(0));
+      QVector<int> gone;
+      gone.append(2);
+      loaded.remove(gone);
+      have = loaded.mediaIds(cdb, "", "");
+      CHECK(!have.contains(2) && have.contains(0));  // removed entries keep their slot with id 0 (:215-229)
     }
     {
       QSet<uint32_t> keep;
@@ -236,10 +243,12 @@ int main(int argc, char** argv) {
       delete sub2;
       delete sub;
     }
+    CHECK(idx.mediaIds(db, "", tmp).size() == size_t(n) && idx.mediaIds(db, "", tmp).contains(111));
     QVector<int> rm;
     rm.append(104);
     idx.remove(rm);
     CHECK(idx.find(needle, p).count() == 0);
+    CHECK(idx.mediaIds(db, "", tmp).size() == size_t(n - 1) && !idx.mediaIds(db, "", tmp).contains(104));
   }
   printf("adapters ok: DctFeatures, CvFeatures, ColorDesc, DctVideo\n");
   return 0;
