@@ -58,6 +58,7 @@ void set_scan256_pre(int on);  // first-128-bit prefilter variant (default on)
 void set_scan256_mfma(int on);  // <0 = keep; 2 = force for any size
 
 int g_hash_mfma_set(int v);  // dcthash.hip
+void set_hash_dct(int v);       // dcthash.hip: stage 3/5 arithmetic, 1 = as cv::dct/cv::sum (default), 0 = canonical matrix form
 void set_kp_blur_side(int v);   // dcthash.hip: largest keypoint square whose blurred copy stays in LDS (default 112)
 void set_kp_lds_side(int v);    // dcthash.hip: largest keypoint square processed in LDS (default 134)
 void set_hash_stream(int v);     // dcthash.hip: streaming fused kernel (0 off, 1 auto, >= 2: steps per strip)

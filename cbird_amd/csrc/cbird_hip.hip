@@ -768,6 +768,10 @@ int cbh_set_tuning(const char* key, int value) {
     set_scan_mfma_ht(value);
     return CBH_OK;
   }
+  if (!strcmp(key, "hash_dct")) {
+    set_hash_dct(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "hash_mfma")) {
     g_hash_mfma_set(value);
     return CBH_OK;

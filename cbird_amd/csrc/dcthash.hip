@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "cbh_internal.h"
+#include "cv_dct32_dev.h"
 
 namespace cbh {
 namespace {
@@ -40,6 +41,10 @@ constexpr int kThreads = 256;
 struct DctTables {
   float C[9 * 32];
   unsigned char zz[64];  // zig-zag positions 6..69 -> index into the 9x9 block (row*9+col)
+  // stage 3/5 variant (tuning knob "hash_dct"): 1 = cv::dct / cv::sum as OpenCV 2.4 evaluates them (cv_dct32_dev.h,
+  // the default), 0 = the canonical 9x32 matrix form with a fixed fmaf order.  One device copy of the tables per variant.
+  int variant;
+  CvDct32Tabs cv;
 };
 
 __device__ __forceinline__ int reflect101(int p, int len) {
@@ -59,8 +64,46 @@ __device__ __forceinline__ void hash_from_tile(const unsigned char* __restrict__
                                                const unsigned char* __restrict__ sZ /*LDS 64*/,
                                                float* __restrict__ sT /*LDS 288*/,
                                                float* __restrict__ sY /*LDS 81*/,
-                                               uint64_t* __restrict__ out) {
+                                               uint64_t* __restrict__ out,
+                                               const DctTables* __restrict__ tabs) {
   const int tid = threadIdx.x;
+  if (tabs->variant) {
+    // cv::dct as OpenCV 2.4 evaluates it (cv_dct32_dev.h): 32 row transforms on the lanes of wave 0, then the nine
+    // column transforms; cv::sum's grouping for the threshold.  Same barriers as the canonical branch.
+    if (tid < 32) {
+      const uint4* trow = reinterpret_cast<const uint4*>(tile + tid * 32);
+      const uint4 p0 = trow[0], p1 = trow[1];
+      const unsigned px[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+      float x[32], y[9];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        x[4 * q] = (float)(px[q] & 0xffu);
+        x[4 * q + 1] = (float)((px[q] >> 8) & 0xffu);
+        x[4 * q + 2] = (float)((px[q] >> 16) & 0xffu);
+        x[4 * q + 3] = (float)(px[q] >> 24);
+      }
+      cvdct::dct32_first9(x, &tabs->cv, y);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) sT[tid * 9 + k] = y[k];
+    }
+    __syncthreads();
+    if (tid < 9) {
+      float x[32], y[9];
+#pragma unroll
+      for (int r = 0; r < 32; ++r) x[r] = sT[r * 9 + tid];
+      cvdct::dct32_first9(x, &tabs->cv, y);
+#pragma unroll
+      for (int u = 0; u < 9; ++u) sY[u * 9 + tid] = y[u];
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const float c = sY[sZ[tid]];
+      const float thr = (float)cvdct::sum64_lanes(__builtin_bit_cast(int, c)) / 64;
+      const unsigned long long b = __ballot(tid >= 1 && c > thr);
+      if (tid == 0) *out = b ? b : 1ull;
+    }
+    return;
+  }
   {
     // row pass, 288 outputs (r,k): lane -> row r = tid/8 and k = tid%8; the lanes with k == 0 also do k = 8.
     // The row's 32 pixels arrive as two 16-byte LDS reads, the basis row as eight.
@@ -197,7 +240,7 @@ __global__ __launch_bounds__(kThreads) void k_dcthash_generic(
   }
   if (tiles)
     for (int i = tid; i < 1024; i += kThreads) tiles[(size_t)blockIdx.x * 1024 + i] = tile[i];
-  hash_from_tile(tile, sC, sZ, sT, sY, out + blockIdx.x);
+  hash_from_tile(tile, sC, sZ, sT, sY, out + blockIdx.x, tabs);
 }
 
 
@@ -235,7 +278,7 @@ __device__ __forceinline__ unsigned add_byte3(unsigned acc, unsigned p) {
   return r;
 }
 
-template <bool DUMP>
+template <bool DUMP, int DCT>
 __global__ __launch_bounds__(kThreads) void k_dcthash_256(
     const unsigned char* __restrict__ imgs, unsigned n, unsigned row_stride, unsigned img_stride,
     const DctTables* __restrict__ tabs, uint64_t* __restrict__ out,
@@ -358,32 +401,52 @@ __global__ __launch_bounds__(kThreads) void k_dcthash_256(
       x[4 * i + 2] = (float)((w[i] >> 16) & 0xffu);
       x[4 * i + 3] = (float)(w[i] >> 24);
     }
+    if constexpr (DCT == 1) {  // cv::dct's own evaluation (cv_dct32_dev.h)
+      float y[9];
+      cvdct::dct32_first9(x, &tabs->cv, y);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      float t = 0.f;
+      for (int k = 0; k < 9; ++k) sT[slot][l32 * 9 + k] = y[k];
+    } else {
 #pragma unroll
-      for (int j = 0; j < 32; ++j) t = __builtin_fmaf(x[j], tabs->C[k * 32 + j], t);
-      sT[slot][l32 * 9 + k] = t;
+      for (int k = 0; k < 9; ++k) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) t = __builtin_fmaf(x[j], tabs->C[k * 32 + j], t);
+        sT[slot][l32 * 9 + k] = t;
+      }
     }
   }
   __syncthreads();
   // ---- column pass: Y[u][k] = sum_r fmaf(C[u][r], T[r][k], .), 81 outputs over 32 lanes
+  if constexpr (DCT == 1) {
+    if (l32 < 9) {  // nine column transforms per image
+      float x[32], y[9];
 #pragma unroll
-  for (int rep = 0; rep < 3; ++rep) {
-    const int o = l32 + 32 * rep;
-    if (o < 81) {
-      const int u = o / 9, k = o - u * 9;
-      float t = 0.f;
+      for (int r = 0; r < 32; ++r) x[r] = sT[slot][r * 9 + l32];
+      cvdct::dct32_first9(x, &tabs->cv, y);
 #pragma unroll
-      for (int r = 0; r < 32; ++r) t = __builtin_fmaf(sC[u * 33 + r], sT[slot][r * 9 + k], t);
-      sY[slot][o] = t;
+      for (int u = 0; u < 9; ++u) sY[slot][u * 9 + l32] = y[u];
     }
-  }
-  __syncthreads();
-  if (l32 == 0) {
-    double sum = 0.0;
-    for (int i = 0; i < 64; ++i) sum += (double)sY[slot][tabs->zz[i]];
-    sThr[slot] = (float)sum / 64;
+    __syncthreads();
+    if (l32 == 0) sThr[slot] = (float)cvdct::sum64_mem(sY[slot], tabs->zz) / 64;
+  } else {
+#pragma unroll
+    for (int rep = 0; rep < 3; ++rep) {
+      const int o = l32 + 32 * rep;
+      if (o < 81) {
+        const int u = o / 9, k = o - u * 9;
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) t = __builtin_fmaf(sC[u * 33 + r], sT[slot][r * 9 + k], t);
+        sY[slot][o] = t;
+      }
+    }
+    __syncthreads();
+    if (l32 == 0) {
+      double sum = 0.0;
+      for (int i = 0; i < 64; ++i) sum += (double)sY[slot][tabs->zz[i]];
+      sThr[slot] = (float)sum / 64;
+    }
   }
   __syncthreads();
   {
@@ -626,6 +689,28 @@ __global__ __launch_bounds__(256, 2) void k_dcthash_256_mfma(
       for (int i = lane; i < 256; i += 64)
         reinterpret_cast<unsigned*>(tiles + (size_t)img * 1024)[i] = reinterpret_cast<const unsigned*>(sTile[wv])[i];
   }
+  if (tabs->variant) {  // cv::dct's own evaluation (cv_dct32_dev.h): lanes 0..31 = rows, then lanes 0..8 = columns
+    if (lane < 32) {
+      float x[32], y[9];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) x[j] = (float)sTile[wv][lane * 32 + j];
+      cvdct::dct32_first9(x, &tabs->cv, y);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) sT[wv][lane * 9 + k] = y[k];
+    }
+    __syncthreads();
+    if (lane < 9) {
+      float x[32], y[9];
+#pragma unroll
+      for (int r = 0; r < 32; ++r) x[r] = sT[wv][r * 9 + lane];
+      cvdct::dct32_first9(x, &tabs->cv, y);
+#pragma unroll
+      for (int u = 0; u < 9; ++u) sY[wv][u * 9 + lane] = y[u];
+    }
+    __syncthreads();
+    if (lane == 0) sThr[wv] = (float)cvdct::sum64_mem(sY[wv], tabs->zz) / 64;
+    __syncthreads();
+  } else {
   // ---- stages 3-6 on the whole wave: T[r][k] = sum_j fmaf(X[r][j], C[k][j], .) for 288 (r,k)
   for (int o = lane; o < 288; o += 64) {
     const int r = o / 9, k = o - r * 9;
@@ -649,6 +734,7 @@ __global__ __launch_bounds__(256, 2) void k_dcthash_256_mfma(
     sThr[wv] = (float)sum / 64;
   }
   __syncthreads();
+  }
   {
     const float cf = sY[wv][tabs->zz[lane]];
     unsigned long long hv = __ballot(lane >= 1 && cf > sThr[wv]);
@@ -754,7 +840,7 @@ __global__ __launch_bounds__(kThreads) void k_area_hash(const unsigned char* __r
   __syncthreads();
   if (tiles)
     for (int i = tid; i < 1024; i += kThreads) tiles[(size_t)blockIdx.x * 1024 + i] = tile[i];
-  hash_from_tile(tile, sC, sZ, sT, sY, out + blockIdx.x);
+  hash_from_tile(tile, sC, sZ, sT, sY, out + blockIdx.x, tabs);
 }
 
 
@@ -1418,7 +1504,7 @@ __global__ __launch_bounds__(kThreads) void k_tile_hash(const float* __restrict_
   __syncthreads();
   if (tiles)
     for (int i = tid; i < 1024; i += kThreads) tiles[(size_t)blockIdx.x * 1024 + i] = tile[i];
-  hash_from_tile(tile, sC, sZ, sT, sY, out + blockIdx.x);
+  hash_from_tile(tile, sC, sZ, sT, sY, out + blockIdx.x, tabs);
 }
 
 size_t generic_smem_bytes(int w, int h, int K) {
@@ -1577,7 +1663,7 @@ __global__ __launch_bounds__(kThreads) void k_rect_hashes(unsigned char* __restr
       __syncthreads();
       if (tiles)
         for (int i = tid; i < 1024; i += kThreads) tiles[(size_t)(I.first + r) * 1024 + i] = tile[i];
-      hash_from_tile(tile, sC, sZ, sT, sY, out + I.first + r);
+      hash_from_tile(tile, sC, sZ, sT, sY, out + I.first + r, tabs);
       __syncthreads();  // tile / sT / sY are reused, and the written-back pixels are in place for the next rectangle
     }
   }
@@ -1746,7 +1832,7 @@ __global__ __launch_bounds__(kThreads) void k_kp_hashes(unsigned char* __restric
           }
         }
         __syncthreads();
-        hash_from_tile(tile, sC, sZ, sT, sY, dst);
+        hash_from_tile(tile, sC, sZ, sT, sY, dst, tabs);
         __syncthreads();
         continue;
       }
@@ -1861,7 +1947,7 @@ __global__ __launch_bounds__(kThreads) void k_kp_hashes(unsigned char* __restric
       }
       __syncthreads();
       // ---- D ----
-      hash_from_tile(tile, sC, sZ, sT, sY, dst);
+      hash_from_tile(tile, sC, sZ, sT, sY, dst, tabs);
       __syncthreads();
     }
     if (tid == 0) counts[im] = cnt;
@@ -1881,7 +1967,7 @@ __global__ __launch_bounds__(kThreads) void k_kp_compact(const uint64_t* __restr
 
 struct TableCache {
   std::mutex mu;
-  DctTables* d[16] = {};
+  DctTables* d[16][2] = {};  // [device][hash_dct variant]
 } g_tabs;
 
 }  // namespace
@@ -2041,6 +2127,12 @@ int get_mfma_tables(const MfmaTables** out) {
 
 int g_hash_mfma = 0;
 int g_hash_mfma_set(int v) { return g_hash_mfma = v; }
+// tuning knob "hash_dct": stages 3 and 5 of dctHash64 -- 1 (default) = cv::dct / cv::sum as OpenCV 2.4.13.7 evaluates
+// them (cv_dct32_dev.h), 0 = the canonical 9x32 matrix form.  oracle: orc_set_hash_variant.
+int g_hash_dct = 1;
+void set_hash_dct(int v) {
+  if (v == 0 || v == 1) g_hash_dct = v;
+}
 int g_kp_blur_side = 112;  // ... and up to this side their blurred copy stays in LDS as well (larger: global scratch)
 void set_kp_blur_side(int v) {
   if (v >= 32 && v <= 200) g_kp_blur_side = v;
@@ -2080,22 +2172,26 @@ static void make_tables(DctTables* t) {
     }
   }
   for (int i = 0; i < 64; ++i) t->zz[i] = (unsigned char)zz[6 + i];
+  t->variant = 0;
+  cv_dct32_make_tabs(&t->cv);
 }
 
 static int get_tables(const DctTables** out) {
   int dev = 0;
   CBH_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 16) return CBH_E_INVAL;
+  const int variant = g_hash_dct ? 1 : 0;
   std::lock_guard<std::mutex> lk(g_tabs.mu);
-  if (!g_tabs.d[dev]) {
+  if (!g_tabs.d[dev][variant]) {
     DctTables host;
     make_tables(&host);
+    host.variant = variant;
     DctTables* d = nullptr;
     CBH_HIP(hipMalloc(&d, sizeof(DctTables)));
     CBH_HIP(hipMemcpy(d, &host, sizeof(DctTables), hipMemcpyHostToDevice));
-    g_tabs.d[dev] = d;
+    g_tabs.d[dev][variant] = d;
   }
-  *out = g_tabs.d[dev];
+  *out = g_tabs.d[dev][variant];
   return CBH_OK;
 }
 
@@ -2571,12 +2667,15 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
       return CBH_OK;
     }
     dim3 grid((unsigned)((n + 7) / 8)), block(kThreads);
-    if (d_tiles)
-      hipLaunchKernelGGL(k_dcthash_256<true>, grid, block, 0, stream, d_imgs, (unsigned)n,
-                         (unsigned)row_stride, (unsigned)img_stride, tabs, d_out, d_tiles);
-    else
-      hipLaunchKernelGGL(k_dcthash_256<false>, grid, block, 0, stream, d_imgs, (unsigned)n,
-                         (unsigned)row_stride, (unsigned)img_stride, tabs, d_out, d_tiles);
+#define CBH_256(DUMP_, DCT_)                                                                              \
+  hipLaunchKernelGGL((k_dcthash_256<DUMP_, DCT_>), grid, block, 0, stream, d_imgs, (unsigned)n,           \
+                     (unsigned)row_stride, (unsigned)img_stride, tabs, d_out, d_tiles)
+    if (g_hash_dct) {
+      if (d_tiles) CBH_256(true, 1); else CBH_256(false, 1);
+    } else {
+      if (d_tiles) CBH_256(true, 0); else CBH_256(false, 0);
+    }
+#undef CBH_256
     CBH_HIP(hipGetLastError());
     return CBH_OK;
   }

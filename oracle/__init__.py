@@ -73,6 +73,20 @@ class Oracle:
         L.orc_dcthash64_batch.restype = C.c_int
         L.orc_hash_from_tile32.argtypes = [_u8p, C.c_void_p, C.c_void_p]
         L.orc_hash_from_tile32.restype = C.c_uint64
+        L.orc_hash_from_tile32_v.argtypes = [_u8p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_hash_from_tile32_v.restype = C.c_uint64
+        L.orc_hash_from_tile32_f64.argtypes = [_u8p, C.c_void_p, C.c_void_p]
+        L.orc_hash_from_tile32_f64.restype = C.c_uint64
+        L.orc_set_hash_variant.argtypes = [C.c_int]
+        L.orc_get_hash_variant.restype = C.c_int
+        L.orc_hash_tiles_stats.argtypes = [_u8p, C.c_size_t, C.c_int, _u64p, C.c_void_p]
+        L.orc_hash_tiles_stats.restype = None
+        L.orc_hash_tiles_risk.argtypes = [_u8p, C.c_size_t, _u64p, _u64p, _u64p] + [C.c_void_p] * 5
+        L.orc_hash_tiles_risk.restype = None
+        L.orc_cv_dct32x32.argtypes = [_f32p]
+        L.orc_cv_dct32_1d.argtypes = [_f32p, _f32p]
+        L.orc_cv_sum_f32.argtypes = [_f32p, C.c_int]
+        L.orc_cv_sum_f32.restype = C.c_double
         L.orc_fdct_find.argtypes = [_u64p, _u32p, C.c_size_t, _u64p, C.c_size_t, C.c_uint32, C.c_int,
                                     _u32p, _i32p, C.c_size_t]
         L.orc_fdct_find.restype = C.c_longlong
@@ -197,6 +211,58 @@ class Oracle:
         th = np.zeros(1, np.float32)
         hv = self.L.orc_hash_from_tile32(tile, co.ctypes.data, th.ctypes.data)
         return int(hv), co, float(th[0])
+
+    # ---- stage 3/5 arithmetic: 1 = cv::dct / cv::sum as OpenCV 2.4 evaluates them (default), 0 = canonical ----
+    def set_hash_variant(self, v: int):
+        self.L.orc_set_hash_variant(int(v))
+
+    def hash_variant(self) -> int:
+        return int(self.L.orc_get_hash_variant())
+
+    def hash_from_tile32_v(self, tile, variant, with_coefs=False):
+        tile = np.ascontiguousarray(tile, np.uint8).reshape(-1)
+        if variant == 2:  # float64 yardstick
+            co, th = np.zeros(64, np.float64), np.zeros(1, np.float64)
+            hv = self.L.orc_hash_from_tile32_f64(tile, co.ctypes.data, th.ctypes.data)
+        else:
+            co, th = np.zeros(64, np.float32), np.zeros(1, np.float32)
+            hv = self.L.orc_hash_from_tile32_v(tile, int(variant), co.ctypes.data, th.ctypes.data)
+        return (int(hv), co, float(th[0])) if with_coefs else int(hv)
+
+    def hash_tiles_stats(self, tiles, variant):
+        """hashes u64[n] and the per-tile smallest |coef - threshold| for variant 0 / 1 / 2 (float64)"""
+        tiles = np.ascontiguousarray(tiles, np.uint8).reshape(-1, 1024)
+        n = len(tiles)
+        hs, mm = np.zeros(n, np.uint64), np.zeros(n, np.float64)
+        self.L.orc_hash_tiles_stats(tiles.reshape(-1), n, int(variant), hs, mm.ctypes.data)
+        return hs, mm
+
+    def hash_tiles_risk(self, tiles):
+        """dict of per-tile arrays: h0 (canonical), h1 (cv::dct), h2 (float64), min_margin, min_bit, err0, err1, thr64"""
+        tiles = np.ascontiguousarray(tiles, np.uint8).reshape(-1, 1024)
+        n = len(tiles)
+        r = {k: np.zeros(n, np.uint64) for k in ("h0", "h1", "h2")}
+        r.update({k: np.zeros(n, np.float64) for k in ("min_margin", "err0", "err1", "thr64")})
+        r["min_bit"] = np.zeros(n, np.int32)
+        self.L.orc_hash_tiles_risk(tiles.reshape(-1), n, r["h0"], r["h1"], r["h2"], r["min_margin"].ctypes.data,
+                                   r["min_bit"].ctypes.data, r["err0"].ctypes.data, r["err1"].ctypes.data,
+                                   r["thr64"].ctypes.data)
+        return r
+
+    def cv_dct32x32(self, m):
+        m = np.ascontiguousarray(m, np.float32).copy()
+        self.L.orc_cv_dct32x32(m.reshape(-1))
+        return m
+
+    def cv_dct32_1d(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        o = np.zeros(32, np.float32)
+        self.L.orc_cv_dct32_1d(x, o)
+        return o
+
+    def cv_sum_f32(self, x) -> float:
+        x = np.ascontiguousarray(x, np.float32)
+        return float(self.L.orc_cv_sum_f32(x, len(x)))
 
     def dcthash64(self, img) -> int:
         img = np.ascontiguousarray(img, np.uint8)

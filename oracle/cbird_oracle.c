@@ -14,9 +14,13 @@
  *     (pinned by cbird.pri:148-152) which is not vendored in /root/reference and not
  *     installed here, and no reference test pins a hash value (unit/testcvutil.cpp:354
  *     has the check commented out).  Integer stages follow OpenCV 2.4 semantics as
- *     recalled in SURVEY.md section 8(a1); the DCT stage is the canonical separable
- *     f32 form defined in DESIGN.md (fixed fmaf order), which the GPU reproduces
- *     bit-for-bit.
+ *     recalled in SURVEY.md section 8(a1).  The DCT and the sum exist in two evaluations
+ *     behind orc_set_hash_variant(): 1 (default) = cv::dct's factorised float algorithm and
+ *     cv::sum's grouping as recalled (oracle/cv_dct32.c, one labelled unit), 0 = the canonical
+ *     separable f32 matrix form of DESIGN.md (fixed fmaf order).  The GPU reproduces either
+ *     bit for bit (knob "hash_dct"); tools/hash_at_risk.py bounds how many bits the choice,
+ *     or any float evaluation of the same transform, can move; tools/gen_golden_opencv.cpp
+ *     + tests/test_opencv_golden.py pin it the day someone runs it against the real library.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -mfma -mpopcnt).
  */
@@ -457,40 +461,73 @@ static int area_resize32_u8(const uint8_t* src, int w, int h, uint8_t* dst /*32*
   return ORC_OK;
 }
 
-/* Stages 3-6 on a 32x32 u8 tile: canonical separable 9x32 DCT with fixed fmaf order,
- * zig-zag select 64, mean threshold (double sum -> float, /64), bits 1..63, 0 -> 1.
- * cvutil.cpp:475-545. Also returns the 64 selected coefficients and threshold when
- * coefs != NULL (for at-risk-bit statistics). */
-uint64_t orc_hash_from_tile32(const uint8_t* tile, float* coefs /*64 or NULL*/, float* thr_out) {
-  static float C[9 * 32];
-  static int zz[81];
+/* Stages 3-6 on a 32x32 u8 tile (cvutil.cpp:475-545): DCT, zig-zag select 64, mean threshold, bits 1..63, 0 -> 1.
+ * Two evaluations of the float arithmetic OpenCV owns (stage 3 cv::dct, stage 5 cv::sum), chosen by
+ * orc_set_hash_variant():
+ *   1 (default)  cv::dct / cv::sum as OpenCV 2.4.13.7 evaluates them, restated in the labelled unit oracle/cv_dct32.c
+ *                (factorised float DCT via a 16-point complex FFT; sum in float groups of four, accumulated in double)
+ *   0            canonical separable 9x32 matrix form with a fixed fmaf order, sequential double sum
+ * The HIP library has the same switch (tuning knob "hash_dct").  Neither is pinned against the real library here
+ * ("parity unpinned"); tools/hash_at_risk.py measures how often they -- and the float64 evaluation below -- disagree.
+ * Also returns the 64 selected coefficients and the threshold when coefs != NULL (for at-risk-bit statistics). */
+void orc_cv_dct32x32(float* m);
+double orc_cv_sum_f32(const float* src, int len);
+
+static int g_hash_variant = 1;
+void orc_set_hash_variant(int v) { g_hash_variant = v ? 1 : 0; }
+int orc_get_hash_variant(void) { return g_hash_variant; }
+
+static void hash_tables(const float** C, const int** zz) {
+  static float sC[9 * 32];
+  static int szz[81];
   static int init = 0;
   if (!init) {
-    orc_dct9_table(C);
-    orc_zigzag81(zz);
+    orc_dct9_table(sC);
+    orc_zigzag81(szz);
     init = 1;
   }
-  float T[32][9]; /* row pass: T[r][k] = sum_j X[r][j] * C[k][j], j ascending */
-  for (int r = 0; r < 32; ++r)
-    for (int k = 0; k < 9; ++k) {
-      float acc = 0.f;
-      for (int j = 0; j < 32; ++j) acc = fmaf((float)tile[r * 32 + j], C[k * 32 + j], acc);
-      T[r][k] = acc;
-    }
-  float Y[81]; /* col pass: Y[u][k] = sum_r C[u][r] * T[r][k], r ascending */
-  for (int u = 0; u < 9; ++u)
-    for (int k = 0; k < 9; ++k) {
-      float acc = 0.f;
-      for (int r = 0; r < 32; ++r) acc = fmaf(C[u * 32 + r], T[r][k], acc);
-      Y[u * 9 + k] = acc;
-    }
+  *C = sC;
+  *zz = szz;
+}
+
+uint64_t orc_hash_from_tile32_v(const uint8_t* tile, int variant, float* coefs /*64 or NULL*/, float* thr_out) {
+  const float* C;
+  const int* zz;
+  hash_tables(&C, &zz);
+  float Y[81];
   float sel[64];
-  double sum = 0.0;
-  for (int i = 0; i < 64; ++i) {
-    sel[i] = Y[zz[6 + i]];
-    sum += (double)sel[i];
+  float thresh;
+  if (variant) {
+    float m[1024]; /* gray.convertTo(freq, CV_32F); cv::dct(freq, freq) */
+    for (int i = 0; i < 1024; ++i) m[i] = (float)tile[i];
+    orc_cv_dct32x32(m);
+    for (int u = 0; u < 9; ++u)
+      for (int k = 0; k < 9; ++k) Y[u * 9 + k] = m[u * 32 + k];
+    for (int i = 0; i < 64; ++i) sel[i] = Y[zz[6 + i]];
+    float sum = (float)orc_cv_sum_f32(sel, 64); /* float sum = float(cv::sum(freq)[0]) */
+    thresh = sum / 64;
+  } else {
+    float T[32][9]; /* row pass: T[r][k] = sum_j X[r][j] * C[k][j], j ascending */
+    for (int r = 0; r < 32; ++r)
+      for (int k = 0; k < 9; ++k) {
+        float acc = 0.f;
+        for (int j = 0; j < 32; ++j) acc = fmaf((float)tile[r * 32 + j], C[k * 32 + j], acc);
+        T[r][k] = acc;
+      }
+    /* col pass: Y[u][k] = sum_r C[u][r] * T[r][k], r ascending */
+    for (int u = 0; u < 9; ++u)
+      for (int k = 0; k < 9; ++k) {
+        float acc = 0.f;
+        for (int r = 0; r < 32; ++r) acc = fmaf(C[u * 32 + r], T[r][k], acc);
+        Y[u * 9 + k] = acc;
+      }
+    double sum = 0.0;
+    for (int i = 0; i < 64; ++i) {
+      sel[i] = Y[zz[6 + i]];
+      sum += (double)sel[i];
+    }
+    thresh = (float)sum / 64;
   }
-  float thresh = (float)sum / 64;
   uint64_t hash = 0;
   for (int i = 1; i < 64; ++i)
     if (sel[i] > thresh) hash |= 1ULL << i;
@@ -498,6 +535,93 @@ uint64_t orc_hash_from_tile32(const uint8_t* tile, float* coefs /*64 or NULL*/, 
   if (coefs) memcpy(coefs, sel, sizeof(sel));
   if (thr_out) *thr_out = thresh;
   return hash;
+}
+
+uint64_t orc_hash_from_tile32(const uint8_t* tile, float* coefs /*64 or NULL*/, float* thr_out) {
+  return orc_hash_from_tile32_v(tile, g_hash_variant, coefs, thr_out);
+}
+
+/* The same stages in float64 with the exact basis (cos in double, products and sums in double, no float rounding
+ * anywhere): the yardstick of tools/hash_at_risk.py -- a bit is "at risk" when its coefficient is so close to the
+ * threshold that float evaluations of the transform may put it on either side. */
+uint64_t orc_hash_from_tile32_f64(const uint8_t* tile, double* coefs /*64 or NULL*/, double* thr_out) {
+  static double Cd[9 * 32];
+  static int init = 0;
+  const float* Cf;
+  const int* zz;
+  hash_tables(&Cf, &zz);
+  if (!init) {
+    for (int k = 0; k < 9; ++k)
+      for (int j = 0; j < 32; ++j) Cd[k * 32 + j] = sqrt((k ? 2.0 : 1.0) / 32.0) * cos(M_PI * (2 * j + 1) * k / 64.0);
+    init = 1;
+  }
+  double T[32][9], Y[81], sel[64], sum = 0.0;
+  for (int r = 0; r < 32; ++r)
+    for (int k = 0; k < 9; ++k) {
+      double acc = 0;
+      for (int j = 0; j < 32; ++j) acc += (double)tile[r * 32 + j] * Cd[k * 32 + j];
+      T[r][k] = acc;
+    }
+  for (int u = 0; u < 9; ++u)
+    for (int k = 0; k < 9; ++k) {
+      double acc = 0;
+      for (int r = 0; r < 32; ++r) acc += Cd[u * 32 + r] * T[r][k];
+      Y[u * 9 + k] = acc;
+    }
+  for (int i = 0; i < 64; ++i) {
+    sel[i] = Y[zz[6 + i]];
+    sum += sel[i];
+  }
+  const double thresh = sum / 64;
+  uint64_t hash = 0;
+  for (int i = 1; i < 64; ++i)
+    if (sel[i] > thresh) hash |= 1ULL << i;
+  if (hash == 0) hash = 1;
+  if (coefs) memcpy(coefs, sel, sizeof(sel));
+  if (thr_out) *thr_out = thresh;
+  return hash;
+}
+
+/* batch helper for the statistics tool: n tiles -> hashes under variant v (0, 1) or the float64 evaluation (2), plus
+ * per tile the smallest |coef - thresh| over bits 1..63 (in the evaluation's own arithmetic) */
+void orc_hash_tiles_stats(const uint8_t* tiles, size_t n, int v, uint64_t* hashes, double* min_margin) {
+  for (size_t t = 0; t < n; ++t) {
+    double mm = INFINITY;
+    if (v == 2) {
+      double c[64], th;
+      hashes[t] = orc_hash_from_tile32_f64(tiles + t * 1024, c, &th);
+      for (int i = 1; i < 64; ++i) mm = fmin(mm, fabs(c[i] - th));
+    } else {
+      float c[64], th;
+      hashes[t] = orc_hash_from_tile32_v(tiles + t * 1024, v, c, &th);
+      for (int i = 1; i < 64; ++i) mm = fmin(mm, fabs((double)c[i] - (double)th));
+    }
+    if (min_margin) min_margin[t] = mm;
+  }
+}
+
+/* tools/hash_at_risk.py: all three evaluations of one tile side by side.  Per tile: the three hashes; the smallest
+ * float64 margin |coef - thresh| over bits 1..63 and its bit; the largest deviation of a float evaluation's
+ * (coef - thresh) from the float64 one, per variant.  A bit can only come out differently in ANY float evaluation of
+ * the same transform whose error stays below eps if its float64 margin is below eps: that is the at-risk set. */
+void orc_hash_tiles_risk(const uint8_t* tiles, size_t n, uint64_t* h0, uint64_t* h1, uint64_t* h2,
+                         double* min_margin, int32_t* min_bit, double* err0, double* err1, double* thr64) {
+  for (size_t t = 0; t < n; ++t) {
+    float c0[64], c1[64], t0, t1;
+    double c2[64], t2;
+    h0[t] = orc_hash_from_tile32_v(tiles + t * 1024, 0, c0, &t0);
+    h1[t] = orc_hash_from_tile32_v(tiles + t * 1024, 1, c1, &t1);
+    h2[t] = orc_hash_from_tile32_f64(tiles + t * 1024, c2, &t2);
+    double mm = INFINITY, e0 = 0, e1 = 0;
+    int mb = 0;
+    for (int i = 1; i < 64; ++i) {
+      const double d2 = c2[i] - t2;
+      if (fabs(d2) < mm) mm = fabs(d2), mb = i;
+      e0 = fmax(e0, fabs(((double)c0[i] - (double)t0) - d2));
+      e1 = fmax(e1, fabs(((double)c1[i] - (double)t1) - d2));
+    }
+    min_margin[t] = mm, min_bit[t] = mb, err0[t] = e0, err1[t] = e1, thr64[t] = t2;
+  }
 }
 
 /* Full pipeline for one 8UC1 image.  Returns ORC_OK / ORC_E_*; hash in *out. */

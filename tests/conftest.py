@@ -56,6 +56,21 @@ def scan256_path(request, gpu):
     _lib.lib().cbh_set_tuning(b"scan256_mfma", 1)
 
 
+@pytest.fixture(params=["cvdct", "canon"])
+def hash_dct(request, gpu, orc):
+    """Run a GPU hash test under both evaluations of dctHash64's stages 3/5, each bit-exact against the oracle set to
+    the same one: "cvdct" = cv::dct / cv::sum as OpenCV 2.4 evaluates them (cv_dct32_dev.h / oracle/cv_dct32.c, the
+    default), "canon" = the canonical 9x32 matrix form."""
+    from cbird_amd import _lib
+
+    v = 1 if request.param == "cvdct" else 0
+    _lib.lib().cbh_set_tuning(b"hash_dct", v)
+    orc.set_hash_variant(v)
+    yield request.param
+    _lib.lib().cbh_set_tuning(b"hash_dct", 1)
+    orc.set_hash_variant(1)
+
+
 def load_golden(name):
     return np.load(os.path.join(ROOT, "tests", "golden", name))
 

@@ -3,7 +3,7 @@ against oracle/cbird_oracle.c on the same inputs."""
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("hash_dct")]  # every test under both stage-3/5 evaluations
 
 
 @pytest.mark.parametrize("w,h", [(32, 32), (64, 64), (64, 32), (128, 128), (128, 160), (256, 256),
