@@ -59,6 +59,7 @@ struct Workspace {
   unsigned long long* h_total = nullptr;  // pinned
   cbh_record* h_small = nullptr;          // pinned: needle in, first kSmallRecs records out (single-needle find)
   static constexpr size_t kSmallRecs = 512;
+  static constexpr size_t kFindRecs = 65536;  // record capacity a single-needle find starts with
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint64_t* d_q = nullptr;
   size_t q_cap = 0;
@@ -71,7 +72,6 @@ struct Workspace {
 
   int init() {
     CBH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    CBH_HIP(hipMalloc(&d_total, sizeof(unsigned long long)));
     CBH_HIP(hipHostMalloc(&h_total, sizeof(unsigned long long)));
     CBH_HIP(hipHostMalloc(&h_small, (kSmallRecs + 1) * sizeof(cbh_record)));
     CBH_HIP(hipEventCreate(&ev0));
@@ -80,17 +80,30 @@ struct Workspace {
   }
   int ensure_records(size_t cap) {
     if (cap <= rec_cap) return CBH_OK;
-    if (d_rec) (void)hipFree(d_rec);
+    if (d_total) (void)hipFree(d_total);
+    d_rec = nullptr;
+    d_total = nullptr;
+    rec_cap = 0;
+    // one block { u64 count; records[cap] }: the layout the counting select (topk.hip) and the multi-GPU exchange take
+    CBH_HIP(hipMalloc(&d_total, (cap + 1) * sizeof(cbh_record)));
+    d_rec = reinterpret_cast<cbh_record*>(d_total) + 1;
+    rec_cap = cap;
+    return CBH_OK;
+  }
+  // ping-pong buffer + radix scratch of the global sort: only the paths that order ALL records need them (single-needle
+  // find with a large result, fdct, video); the batched cut runs on the counting select and never allocates these
+  size_t alt_cap = 0;
+  int ensure_sort() {
+    if (alt_cap >= rec_cap && d_alt) return CBH_OK;
     if (d_alt) (void)hipFree(d_alt);
     if (d_tmp) (void)hipFree(d_tmp);
-    d_rec = d_alt = nullptr;
+    d_alt = nullptr;
     d_tmp = nullptr;
-    rec_cap = 0;
-    CBH_HIP(hipMalloc(&d_rec, cap * sizeof(cbh_record)));
-    CBH_HIP(hipMalloc(&d_alt, cap * sizeof(cbh_record)));
-    tmp_bytes = sort_records_scratch_bytes(cap);
+    alt_cap = 0;
+    CBH_HIP(hipMalloc(&d_alt, std::max<size_t>(rec_cap, 16) * sizeof(cbh_record)));
+    tmp_bytes = sort_records_scratch_bytes(std::max<size_t>(rec_cap, 16));
     CBH_HIP(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
-    rec_cap = cap;
+    alt_cap = rec_cap;
     return CBH_OK;
   }
   template <typename T>
@@ -105,10 +118,9 @@ struct Workspace {
     return CBH_OK;
   }
   void release() {
-    if (d_rec) (void)hipFree(d_rec);
     if (d_alt) (void)hipFree(d_alt);
     if (d_tmp) (void)hipFree(d_tmp);
-    if (d_total) (void)hipFree(d_total);
+    if (d_total) (void)hipFree(d_total);  // (d_rec lives in the same allocation)
     if (h_total) (void)hipHostFree(h_total);
     if (h_small) (void)hipHostFree(h_small);
     if (d_q) (void)hipFree(d_q);
@@ -184,8 +196,14 @@ struct cbh_idx64 {
       return CBH_E_NOMEM;
     }
     if (n) {
-      CBH_HIP(hipMemcpy(nh, d_hashes, n * sizeof(uint64_t), hipMemcpyDeviceToDevice));
-      CBH_HIP(hipMemcpy(ni, d_ids, n * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+      e = hipMemcpy(nh, d_hashes, n * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+      if (e == hipSuccess) e = hipMemcpy(ni, d_ids, n * sizeof(uint32_t), hipMemcpyDeviceToDevice);
+      if (e != hipSuccess) {  // keep the old arrays, drop the new ones
+        (void)hipFree(nh);
+        (void)hipFree(ni);
+        set_last_error("hipMemcpy(reserve)", e);
+        return CBH_E_HIP;
+      }
     }
     if (d_hashes) (void)hipFree(d_hashes);
     if (d_ids) (void)hipFree(d_ids);

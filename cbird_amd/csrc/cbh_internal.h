@@ -77,6 +77,14 @@ int launch_select_records(const cbh_record* d_sorted, size_t n, size_t nq, int k
 int launch_remove_ids(uint64_t* d_hashes, uint32_t* d_ids, size_t n, const uint32_t* d_sorted_rm,
                       size_t n_rm, hipStream_t stream, int zero_hash = 1);
 
+// ---- topk.hip: K4 counting select over { count, records[cap] } blocks ---------------------------
+constexpr int kTopkMaxK = 64;  // larger cuts take the radix sort (records.hip)
+size_t topk_scratch_bytes(size_t nq, size_t total_cap);
+int topk_scratch_init(void* d_scratch, size_t nq, hipStream_t stream);
+int launch_records_topk(const unsigned long long* d_blocks, unsigned nb, size_t stride, size_t cap, size_t nq, int k,
+                        cbh_match* d_out, uint32_t* d_counts, unsigned* d_status, void* d_scratch,
+                        hipStream_t stream);
+
 // ---- dcthash.hip ----------------------------------------------------------------------
 // view: the images are w x h sub-rectangles at (ox, oy) of pw x ph parents starting at d_imgs -- cv::blur on a
 // cv::Mat view takes its border pixels from the parent (dctHash64 after autocrop(), src/cvutil.cpp:1397-1401)

@@ -505,7 +505,7 @@ int cbh_idx64_find(cbh_idx64* idx, uint64_t q, int thresh, cbh_match* out, size_
   // Fast path (the interactive -similar-to query, Engine::query): needle staged in pinned memory, scan, the match
   // count and the first kSmallRecs records fetched speculatively -- one stream synchronisation per find.  Larger
   // results (or a record buffer that is too small) fall through to the general path below.
-  rc = ws->ensure_records(std::max<size_t>(idx->rec_cap_default, 1024));
+  rc = ws->ensure_records(Workspace::kFindRecs);  // 512 KB; only a result that overflows it grows the workspace (scan_all)
   if (rc) return rc;
   {
     constexpr size_t kS = Workspace::kSmallRecs;
@@ -549,6 +549,7 @@ int cbh_idx64_find(cbh_idx64* idx, uint64_t q, int thresh, cbh_match* out, size_
     CBH_HIP(hipStreamSynchronize(ws->stream));
     std::sort(recs.begin(), recs.end());
   } else {
+    if ((rc = ws->ensure_sort())) return rc;
     rc = launch_sort_records(ws->d_rec, ws->d_alt, (size_t)total, 1, ws->d_tmp, ws->tmp_bytes,
                              ws->stream);
     if (rc) return rc;
@@ -571,12 +572,29 @@ static int find_batch_core(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, s
                            hipStream_t s, unsigned long long* total,
                            const uint64_t* d_qmask = nullptr) {
   *total = 0;
+  int rc = ws->ensure_records(std::max<size_t>(idx->rec_cap_default, 1024));  // (d_total must exist when n == 0)
+  if (rc) return rc;
   if (idx->n && thresh > 0) {
-    int rc = scan_all(idx, ws, d_q, nq, thresh, s, total, 0, d_qmask);
+    rc = scan_all(idx, ws, d_q, nq, thresh, s, total, 0, d_qmask);
     if (rc) return rc;
-    rc = launch_sort_records(ws->d_rec, ws->d_alt, (size_t)*total, nq, ws->d_tmp, ws->tmp_bytes, s);
-    if (rc) return rc;
+  } else {
+    CBH_HIP(hipMemsetAsync(ws->d_total, 0, sizeof(unsigned long long), s));
   }
+  if (k <= kTopkMaxK && *total < ((unsigned long long)1 << 32)) {
+    // K4 counting select (topk.hip): the workspace's { count, records } block is its input as it stands
+    void* scratch = nullptr;
+    unsigned* d_status = nullptr;
+    const size_t ncap = std::min<size_t>(ws->rec_cap, (size_t)*total + 1);  // slots past the count are never read
+    CBH_HIP(hipMallocAsync(&scratch, topk_scratch_bytes(nq, ncap) + 16, s));
+    d_status = (unsigned*)((char*)scratch + topk_scratch_bytes(nq, ncap));
+    rc = topk_scratch_init(scratch, nq, s);
+    if (!rc) rc = launch_records_topk(ws->d_total, 1, 0, ncap, nq, k, d_out, d_counts, d_status, scratch, s);
+    (void)hipFreeAsync(scratch, s);
+    return rc;
+  }
+  if ((rc = ws->ensure_sort())) return rc;
+  rc = launch_sort_records(ws->d_rec, ws->d_alt, (size_t)*total, nq, ws->d_tmp, ws->tmp_bytes, s);
+  if (rc) return rc;
   return launch_select_records(ws->d_rec, (size_t)*total, nq, k, d_out, d_counts, s);
 }
 
@@ -651,6 +669,33 @@ int cbh_idx64_scan_dev(cbh_idx64* idx, const void* d_q, size_t nq, int thresh, v
   hipStream_t s = (hipStream_t)stream;
   int rc = launch_hamm64_scan(idx->d_hashes, idx->d_ids, idx->n, (const uint64_t*)d_q, nq, thresh,
                               (cbh_record*)d_records, cap, (unsigned long long*)d_total, s);
+  if (rc) return rc;
+  if (!stream) CBH_HIP(hipStreamSynchronize(s));
+  return CBH_OK;
+}
+
+int cbh_records_topk_dev(const void* d_blocks, size_t n_blocks, size_t block_stride, size_t cap, size_t nq,
+                         int max_per_query, void* d_out, void* d_counts, void* d_status, int device, void* stream) {
+  if (nq == 0) return CBH_OK;
+  if (!d_counts || !d_status || (max_per_query && !d_out) || max_per_query < 0 || (n_blocks && !d_blocks) ||
+      nq > CBH_MAX_QUERIES_PER_CALL || n_blocks > 1024 || (n_blocks > 1 && block_stride < cap + 1) ||
+      n_blocks * cap >= ((size_t)1 << 32))
+    return CBH_E_INVAL;
+  if (!device_usable(device)) return CBH_E_NODEVICE;
+  DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  hipStream_t s = (hipStream_t)stream;
+  void* scratch = nullptr;  // stream-ordered, recycled by the pool between calls
+  hipError_t e = hipMallocAsync(&scratch, topk_scratch_bytes(nq, n_blocks * cap), s);
+  if (e != hipSuccess) {
+    set_last_error("hipMallocAsync(topk scratch)", e);
+    return CBH_E_NOMEM;
+  }
+  int rc = topk_scratch_init(scratch, nq, s);
+  if (!rc)
+    rc = launch_records_topk((const unsigned long long*)d_blocks, (unsigned)n_blocks, block_stride, cap, nq,
+                             max_per_query, (cbh_match*)d_out, (uint32_t*)d_counts, (unsigned*)d_status, scratch, s);
+  (void)hipFreeAsync(scratch, s);
   if (rc) return rc;
   if (!stream) CBH_HIP(hipStreamSynchronize(s));
   return CBH_OK;

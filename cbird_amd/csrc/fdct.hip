@@ -125,6 +125,7 @@ int fdct_core(cbh_idx64* idx, const uint64_t* hashes, const std::vector<Needle>&
   rc = scan_all(idx, ws, ws->d_q, nq, thresh, ws->stream, &total, SCAN_KEEP_ID0,
                 tree_compat ? ws->d_qmask : nullptr);
   if (rc) return rc;
+  if ((rc = ws->ensure_sort())) return rc;
   rc = launch_sort_records(ws->d_rec, ws->d_alt, (size_t)total, nq, ws->d_tmp, ws->tmp_bytes, ws->stream);
   if (rc) return rc;
   rc = launch_select_records(ws->d_rec, (size_t)total, nq, k, ws->d_out, ws->d_counts, ws->stream);

@@ -98,6 +98,7 @@ int scan_to_host(cbh_vidx* v, const uint64_t* q, size_t nq, int thresh, std::vec
   unsigned long long total = 0;
   rc = scan_all(idx, ws, ws->d_q, nq, thresh, ws->stream, &total, 0, v->radix ? ws->d_qmask : nullptr);
   if (rc) return rc;
+  if ((rc = ws->ensure_sort())) return rc;
   rc = launch_sort_records(ws->d_rec, ws->d_alt, (size_t)total, nq, ws->d_tmp, ws->tmp_bytes, ws->stream);
   if (rc) return rc;
   recs->resize((size_t)total);

@@ -8,10 +8,11 @@ src/database.cpp:1400-1432); this is the MI355X-native counterpart designed from
     needles are replicated (an all-pairs job gathers every rank's freshly built hashes once);
   * each rank scans ITS shard for ALL needles with the same HIP kernel as the single-GPU path and
     produces an unordered list of cbh_record (needle<<39 | distance<<32 | mediaId);
-  * ONE exchange step: all-gather of the per-rank record lists (sizes first, then the lists padded
-    to the longest one).  A threshold search over a union of shards is the union of the per-shard
-    results, so the merged list sorted ascending is exactly the single-GPU list;
-  * every rank then orders the merged records and cuts each needle's list at max_per_query.
+  * ONE exchange step: a single all_gather_into_tensor of fixed-size blocks { count, records[cap] } (the
+    count travels in word 0 -- no sizes-first round, no host synchronisation).  A threshold search over a
+    union of shards is the union of the per-shard results;
+  * every rank then cuts each needle's list at max_per_query with the counting select (topk.hip), which
+    reads the R blocks where the all-gather put them.
 
 `ops` supplies the device work.  `HipOps` (the product) drives the C-ABI and fails loudly without
 the library / a gfx950 device; the CPU test-suite injects its own ops object to exercise the
@@ -84,6 +85,15 @@ class HipOps:
                                              int(thresh), rec.data_ptr(), rec.numel(), total.data_ptr(),
                                              self._stream()), "scan_dev")
 
+    def topk(self, blocks: torch.Tensor, nb: int, stride: int, cap: int, nq: int, k: int, status: torch.Tensor):
+        """K4 counting select over nb blocks { count, records[cap] } (cbh_records_topk_dev); status: int32[1]"""
+        out = torch.empty((nq, max(k, 1), 2), dtype=torch.int32, device=self.torch_device)
+        counts = torch.empty(nq, dtype=torch.int32, device=self.torch_device)
+        _lib.check(self.L.cbh_records_topk_dev(blocks.data_ptr(), nb, stride, cap, nq, k, out.data_ptr(),
+                                               counts.data_ptr(), status.data_ptr(), self.device, self._stream()),
+                   "records_topk_dev")
+        return out[:, :k, 0], out[:, :k, 1], counts
+
     def sort_records(self, rec: torch.Tensor, n: int, nq: int) -> None:
         _lib.check(self.L.cbh_sort_records_dev(rec.data_ptr(), n, nq, self.device, self._stream()),
                    "sort_records_dev")
@@ -98,15 +108,45 @@ class HipOps:
 
 
 class ShardedDctHashIndex:
+    """One exchange step per threshold, and nothing on it synchronises with the host:
+
+        scan     each rank writes ONE block { u64 count; u64 records[cap] } (count = word 0, written by the scan kernel)
+        gather   one all_gather_into_tensor of the R fixed-size blocks                       (R > 1 only)
+        cut      counting select over the R blocks (cbh_records_topk_dev): per needle the first max_per_query
+                 matches in ascending (score, mediaId) order + the match count -- identical on every rank
+
+    A rank whose matches exceed cap is noticed by the cut itself (status word on the device, derived from the gathered
+    counts, hence the same on every rank); the caller looks at it once per call / per sweep and redoes the thresholds
+    concerned with a larger cap."""
+
     def __init__(self, ops, group=None, record_capacity: int = 1 << 22) -> None:
         self.ops = ops
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # record_capacity = what the whole job may produce per threshold; a rank's block holds its share (x2 slack)
         self.record_capacity = record_capacity
-        self._rec = None
-        self._total = None
-        self.last_exchange_records = 0
+        self._bufs = {}
+        self._cap = None          # explicit block capacity (fit_capacity), else derived from record_capacity
+        self._max_count = None    # 0-dim tensor: largest per-rank count seen since the last fit_capacity()
+        self.last_exchange_records = None  # 0-dim tensor (device): records of the last cut, all ranks together
+
+    def _block_cap(self) -> int:
+        if self._cap is not None:
+            return self._cap
+        return max(64, -(-2 * self.record_capacity // self.world) if self.world > 1 else self.record_capacity)
+
+    def fit_capacity(self, slack: float = 1.5, granule: int = 1 << 14) -> int:
+        """Size the exchange blocks to `slack` x the largest per-rank match count seen so far (call after a warm-up
+        pass; one host read).  Every rank computes the same value: the counts come from the gathered blocks.  Smaller
+        blocks = a smaller all-gather per threshold; a later overflow still just doubles them."""
+        if self._max_count is None:
+            return self._block_cap()
+        m = int(self._max_count.item())
+        self._cap = max(granule, -(-int(m * slack) // granule) * granule)
+        self._bufs = {}
+        self._max_count = None
+        return self._cap
 
     def _all_gather(self, out: torch.Tensor, inp: torch.Tensor) -> None:
         """all_gather_into_tensor; RCCL ("nccl") on device tensors.  With the gloo backend (CPU test-suite,
@@ -144,35 +184,38 @@ class ShardedDctHashIndex:
         self.ops.load_shard(hashes, ids)
 
     # -- find ----------------------------------------------------------------------------------
-    def _buffers(self):
-        if self._rec is None or self._rec.numel() < self.record_capacity:
-            self._rec = self.ops.empty(self.record_capacity, torch.int64)
-            self._total = self.ops.empty(1, torch.int64)
-        return self._rec, self._total
+    def _buffers(self, slot: int = 0):
+        """(block, gathered blocks, status) of pipeline slot `slot`; block = int64[1 + cap], word 0 = count"""
+        cap = self._block_cap()
+        b = self._bufs.get(slot)
+        if b is None or b[0].numel() != 1 + cap:
+            blk = self.ops.empty(1 + cap, torch.int64)
+            allb = self.ops.empty((1 + cap) * self.world, torch.int64) if self.world > 1 else blk
+            b = self._bufs[slot] = (blk, allb)
+        return b
 
-    def _exchange_and_cut(self, rec, total, nq: int, max_per_query: int):
-        """counts -> (all-gather of the record lists) -> sort -> first max_per_query per needle.  Returns None when a
-        rank's records did not fit its buffer (after growing self.record_capacity for the rescan)."""
-        if self.world > 1:  # sizes first: one small all-gather gives max and sum
-            counts = self.ops.empty(self.world, torch.int64)
-            self._all_gather(counts, total)
-            counts_h = counts.tolist()
-            n_local, n_max, n_total = counts_h[self.rank], max(counts_h), sum(counts_h)
+    def _scan_into(self, blk, queries, thresh):
+        blk[:1].zero_()
+        self.ops.scan(queries, thresh, blk[1:], blk[:1])
+
+    def _exchange_and_cut(self, blk, allb, nq: int, max_per_query: int, status):
+        """(all-gather of the blocks) -> counting select.  No host synchronisation; `status` (int32[1] on the device)
+        becomes non-zero when some rank's block overflowed."""
+        if self.world > 1:
+            self._all_gather(allb, blk)
+        cap = blk.numel() - 1
+        cnts = allb[:: 1 + cap]
+        self.last_exchange_records = cnts.clamp(max=cap).sum()
+        self._max_count = cnts.max() if self._max_count is None else torch.maximum(self._max_count, cnts.max())
+        return self.ops.topk(allb, self.world, 1 + cap, cap, nq, max_per_query, status)
+
+    def _grow(self):
+        # same decision on every rank (the status word is derived from all ranks' counts)
+        if self._cap is not None:
+            self._cap *= 2
         else:
-            n_local = n_max = n_total = int(total.item())
-        if n_max > rec.numel():
-            self.record_capacity = int(n_max * 1.25) + 1024  # same decision on every rank
-            return None
-        if self.world == 1:
-            merged = rec
-        else:
-            rec[n_local:n_max] = nq << 39  # pad = a record of needle index nq: sorts last
-            merged = self.ops.empty(n_max * self.world, torch.int64)
-            self._all_gather(merged, rec[:n_max])
-        self.last_exchange_records = n_total
-        # pads sort to the end; only the first n_total records are real
-        self.ops.sort_records(merged, merged.numel() if self.world > 1 else n_total, nq + 1)
-        return self.ops.select(merged, n_total, nq, max_per_query)
+            self.record_capacity *= 2
+        self._bufs = {}
 
     def similar(self, queries: torch.Tensor, thresh: int, max_per_query: int, scan_events=None):
         """All needles against the union of all shards.  Returns (ids[nq,k] i32 view of u32,
@@ -181,82 +224,88 @@ class ShardedDctHashIndex:
         if nq >= (1 << 25):
             raise ValueError("at most 2^25-1 needles per call")
         while True:
-            rec, total = self._buffers()
-            total.zero_()
+            blk, allb = self._buffers(0)
+            status = self.ops.empty(1, torch.int32)
+            status.zero_()
             if scan_events is not None:  # HIP events on the stream the scan kernel is launched on
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
+                e0, e1 = self.ops.new_event(), self.ops.new_event()
                 e0.record()
-            self.ops.scan(queries, thresh, rec, total)
+            self._scan_into(blk, queries, thresh)
             if scan_events is not None:
                 e1.record()
-                scan_events.append((thresh, e0, e1))
-            res = self._exchange_and_cut(rec, total, nq, max_per_query)
-            if res is not None:
+            res = self._exchange_and_cut(blk, allb, nq, max_per_query, status)
+            if int(status.item()) == 0:
+                if scan_events is not None:
+                    scan_events.append((thresh, e0, e1))
                 return res
+            self._grow()
 
     def similar_sweep(self, queries: torch.Tensor, thresholds, max_per_query: int, scan_events=None,
                       find_events=None):
-        """similar() for several thresholds, software-pipelined: while the records of threshold i are exchanged,
-        sorted and cut on a side stream, the scan of threshold i+1 already runs on the main stream (two record
-        buffers).  Returns {thresh: (ids, scores, counts)}, identical to calling similar() per threshold."""
+        """similar() for several thresholds, software-pipelined: while the records of threshold i are exchanged
+        and cut on a side stream, the scan of threshold i+1 already runs on the main stream (two blocks).  The host
+        never waits inside the loop; the overflow words of all thresholds are read once at the end and the
+        thresholds concerned are redone.  Returns {thresh: (ids, scores, counts)}, identical to calling similar()
+        per threshold."""
         nq = queries.numel()
         if nq >= (1 << 25):
             raise ValueError("at most 2^25-1 needles per call")
         ops = self.ops
+        thresholds = list(thresholds)
         if not hasattr(ops, "side_stream"):  # device work injected by a test: no streams, plain loop
             return {t: self.similar(queries, t, max_per_query, scan_events) for t in thresholds}
         main, side = ops.current_stream(), ops.side_stream()
-        if getattr(self, "_sweep_bufs", None) is None or self._sweep_bufs[0][0].numel() < self.record_capacity:
-            self._sweep_bufs = [(ops.empty(self.record_capacity, torch.int64), ops.empty(1, torch.int64))
-                                for _ in range(2)]
         side.wait_stream(main)  # queries (and the index) are ready
+        status = ops.empty(len(thresholds), torch.int32)
+        status.zero_()
         results, pending, reuse = {}, None, [None, None]
+        scan_tmp, find_tmp = [], []
 
         def finish(p):
-            thr, rec, total, ev_scan, f0 = p
+            i, thr, blk, allb, ev_scan, f0 = p
             with ops.stream_ctx(side):
                 side.wait_event(ev_scan)
-                res = self._exchange_and_cut(rec, total, nq, max_per_query)
+                res = self._exchange_and_cut(blk, allb, nq, max_per_query, status[i: i + 1])
+                nrec = self.last_exchange_records
                 done = ops.new_event()
                 done.record(side)
-            if res is None:  # did not fit: drain, grow (record_capacity was raised) and redo this one plainly
-                main.wait_stream(side)
-                self._sweep_bufs = None
-                res = self.similar(queries, thr, max_per_query)
-                done = ops.new_event()
-                done.record(main)
-            elif find_events is not None:
-                find_events.append((thr, f0, done, int(self.last_exchange_records)))
+            find_tmp.append((thr, f0, done, nrec))
             return res, done
 
         for i, thr in enumerate(thresholds):
-            if self._sweep_bufs is None:  # a rescan replaced the buffers
-                self._sweep_bufs = [(ops.empty(self.record_capacity, torch.int64), ops.empty(1, torch.int64))
-                                    for _ in range(2)]
-                reuse = [None, None]
-            rec, total = self._sweep_bufs[i % 2]
+            blk, allb = self._buffers(i % 2)
             if reuse[i % 2] is not None:
-                main.wait_event(reuse[i % 2])  # the post-processing that read this buffer has finished
+                main.wait_event(reuse[i % 2])  # the cut that read this block has finished
             f0 = ops.new_event()
             f0.record(main)
-            total.zero_()
-            if scan_events is not None:
-                e0, e1 = ops.new_event(), ops.new_event()
-                e0.record(main)
-            ops.scan(queries, thr, rec, total)
-            if scan_events is not None:
-                e1.record(main)
-                scan_events.append((thr, e0, e1))
+            e0, e1 = ops.new_event(), ops.new_event()
+            e0.record(main)
+            self._scan_into(blk, queries, thr)
+            e1.record(main)
+            scan_tmp.append((thr, e0, e1))
             ev_scan = ops.new_event()
             ev_scan.record(main)
             if pending is not None:
-                j = pending[0]
-                results[pending[1][0]], reuse[j] = finish(pending[1])
-            pending = (i % 2, (thr, rec, total, ev_scan, f0))
+                results[pending[1]], reuse[pending[0] % 2] = finish(pending)
+            pending = (i, thr, blk, allb, ev_scan, f0)
         if pending is not None:
-            results[pending[1][0]], _ = finish(pending[1])
+            results[pending[1]], _ = finish(pending)
         main.wait_stream(side)  # results were produced on the side stream
+        st = status.cpu().tolist()  # the one synchronisation of the sweep
+        redo = [t for t, s in zip(thresholds, st) if s]
+        if scan_events is not None:
+            scan_events += [e for e in scan_tmp if e[0] not in redo]
+        if find_events is not None:
+            find_events += [e for e in find_tmp if e[0] not in redo]
+        for thr in redo:  # a block overflowed: larger blocks, this threshold alone (its own events)
+            self._grow()
+            f0 = ops.new_event()
+            f0.record(main)
+            results[thr] = self.similar(queries, thr, max_per_query, scan_events)
+            if find_events is not None:
+                done = ops.new_event()
+                done.record(main)
+                find_events.append((thr, f0, done, self.last_exchange_records))
         return results
 
 

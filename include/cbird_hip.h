@@ -207,6 +207,17 @@ int cbh_idx64_find_batch_dev(cbh_idx64*, const void* d_q, size_t nq, int thresh,
  * counted.  Asynchronous on `stream`.  This is the shard-local step of the multi-GPU path. */
 int cbh_idx64_scan_dev(cbh_idx64*, const void* d_q, size_t nq, int thresh, void* d_records,
                        size_t cap, void* d_total, void* stream);
+/* K4, the per-needle cut of Database::searchIndex (std::sort by score + stop at maxMatches,
+ * src/database.cpp:1729-1737) as a counting select over UNORDERED scan records -- no global sort, no record count on
+ * the host, nothing synchronises (cbird_amd/csrc/topk.hip).  Input: n_blocks blocks of u64 words, block b at
+ * d_blocks + b*block_stride words = { count, records[cap] } -- what cbh_idx64_scan_dev produces when d_total points
+ * at word 0 and d_records at word 1, and what ONE all_gather_into_tensor of such blocks delivers in the multi-GPU
+ * path.  Output as cbh_idx64_find_batch_dev: the first max_per_query matches of every needle in ascending
+ * (score, mediaId) order + the full match count per needle.  *d_status (u32 on device, NOT reset by the call) gets
+ * bit 0 set when some block's count exceeds cap (records were dropped: rescan with a larger cap).  Asynchronous
+ * on `stream` (NULL: synchronous).  nq <= 2^25, n_blocks*cap < 2^32. */
+int cbh_records_topk_dev(const void* d_blocks, size_t n_blocks, size_t block_stride, size_t cap, size_t nq,
+                         int max_per_query, void* d_out, void* d_counts, void* d_status, int device, void* stream);
 /* Sort records ascending in place (device), n records, only bits [0, 39+ceil(log2(nq))). */
 int cbh_sort_records_dev(void* d_records, size_t n, size_t nq, int device, void* stream);
 /* Records (sorted) -> per-query top max_per_query + counts, as find_batch_dev does. */

@@ -1,5 +1,5 @@
-"""CPU suite, world_size 2 over gloo: the sharding + single all-gather exchange of
-cbird_amd.dist.ShardedDctHashIndex.  The device work is injected (numpy + oracle stand-ins living
+"""CPU suite, world_size 2 over gloo: the sharding + single fixed-size all-gather exchange (count in word 0 of every
+block, overflow noticed by the cut and redone with larger blocks) of cbird_amd.dist.ShardedDctHashIndex.  The device work is injected (numpy + oracle stand-ins living
 in this test file); the product's HipOps is covered by the gpu-marked tests."""
 import os
 import socket
@@ -43,11 +43,16 @@ class FakeOps:
         rec[:m] = torch.tensor(out[:m][::-1], dtype=torch.int64)  # deliberately unordered
         total += n
 
-    def sort_records(self, rec, n, nq):
-        rec[:n] = torch.sort(rec[:n]).values
-
-    def select(self, rec, n, nq, k):
-        r = rec[:n].numpy().view(np.uint64)
+    def topk(self, blocks, nb, stride, cap, nq, k, status):
+        """numpy statement of cbh_records_topk_dev: blocks of { count, records[cap] } -> per-needle cut"""
+        b = blocks.numpy().view(np.uint64)
+        recs = []
+        for i in range(nb):
+            c = int(b[i * stride])
+            if c > cap:
+                status |= 1
+            recs.append(b[i * stride + 1: i * stride + 1 + min(c, cap)])
+        r = np.sort(np.concatenate(recs)) if recs else np.zeros(0, np.uint64)
         qi = (r >> np.uint64(39)).astype(np.int64)
         ids = np.zeros((nq, k), np.int32)
         sc = np.zeros((nq, k), np.int32)
@@ -59,6 +64,9 @@ class FakeOps:
             ids[j, :m] = (seg & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)
             sc[j, :m] = ((seg >> np.uint64(32)) & np.uint64(0x7F)).astype(np.int32)
         return torch.from_numpy(ids), torch.from_numpy(sc), torch.from_numpy(cnt)
+
+    def new_event(self):
+        raise AssertionError("no events on the CPU stand-in")
 
 
 def _free_port():

@@ -71,7 +71,8 @@ def main():
     # the replicated post-processing on the union of all records (what each rank runs after the all-gather)
     sh = ShardedDctHashIndex(ops, record_capacity=1 << 22)
     sh.load_shard(allh, torch.arange(1, n + 1, device=dev, dtype=torch.int32))
-    rec, total = sh._buffers()
+    blk, _ = sh._buffers(0)
+    rec, total = blk[1:], blk[:1]
     for thr in (2, 8):
         total.zero_()
         ops.scan(allh, thr, rec, total)
