@@ -15,7 +15,7 @@
 // calls with many images at once.
 //
 // Build note: needs cbird's cvutil.h / media.h (OpenCV 2.4 cv::Mat, cv::KeyPoint) on the include path; in this
-// repository it is compiled against cbird_amd/cpp/mock/index.h instead (tests/cpp/test_cvutil.cpp).
+// repository it is compiled against tests/cpp/mock/index.h instead (tests/cpp/test_cvutil.cpp).
 #pragma once
 #include <cstdint>
 #include <stdexcept>

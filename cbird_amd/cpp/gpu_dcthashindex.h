@@ -9,7 +9,7 @@
 // src/dcthashindex.cpp:82-89).
 //
 // It compiles against the real cbird headers ("index.h", Qt6) and, for this repository's tests
-// where Qt6/OpenCV are not installed, against cbird_amd/cpp/mock/index.h which declares the same
+// where Qt6/OpenCV are not installed, against tests/cpp/mock/index.h which declares the same
 // names with the same signatures.
 #pragma once
 
@@ -112,10 +112,12 @@ class GpuDctHashIndex : public Index {
       qWarning() << "empty/null tree";
       return results;
     }
+    // cbh_idx64_find_coalesced: same results as cbh_idx64_find; concurrent QtConcurrent workers share one scan per
+    // round trip, and an all-pairs run (Database::similar) ends up served from one whole-index self-join
     std::vector<cbh_match> buf(64);
     size_t n = 0;
     for (;;) {
-      check(cbh_idx64_find(_idx, target, p.dctThresh, buf.data(), buf.size(), &n), "find");
+      check(cbh_idx64_find_coalesced(_idx, target, p.dctThresh, buf.data(), buf.size(), &n), "find");
       if (n <= buf.size()) break;
       buf.resize(n);
     }
@@ -153,6 +155,8 @@ class GpuDctHashIndex : public Index {
     }
     return res;
   }
+
+  cbh_idx64* handle() const { return _idx; }  // for statistics (cbh_idx64_get_stats / cbh_idx64_coalesce_stats)
 
  private:
   GpuDctHashIndex(int device, cbh_idx64* adopted) : _device(device), _idx(adopted) {

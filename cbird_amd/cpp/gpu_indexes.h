@@ -7,7 +7,7 @@
 // the reference class when built inside cbird; this header shows the search-side overrides.
 //
 // Build note: needs cbird's index.h / media.h (Qt6, OpenCV types KeyPointDescriptors = cv::Mat,
-// ColorDescriptor, VideoIndex).  In this repository it is compiled against cbird_amd/cpp/mock/ (declarations
+// ColorDescriptor, VideoIndex).  In this repository it is compiled against tests/cpp/mock/ (declarations
 // of those classes and types with the reference's signatures) and run on the GPU by
 // tests/cpp/test_adapters4.cpp; the scoring rules behind the C-ABI calls are oracle-checked by
 // tests/test_fdct.py, tests/test_cvfeatures.py, tests/test_color.py and tests/test_video.py.

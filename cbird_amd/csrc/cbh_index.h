@@ -2,6 +2,7 @@
 // (cbird_hip.hip, fdct.hip, video.hip).  Not part of the C-ABI.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -133,6 +134,9 @@ struct Workspace {
   }
 };
 
+struct Coalescer;                 // coalesce.hip: combining of concurrent find() callers + self-join cache
+void coalescer_free(Coalescer*);
+
 }  // namespace cbh
 
 using namespace cbh;
@@ -154,6 +158,8 @@ struct cbh_idx64 {
   std::mutex tree_mu;
   bool tree_valid = false;
   std::unordered_set<uint64_t> tree_internal;
+  std::atomic<uint64_t> generation{0};  // bumped by load/add/remove: caches derived from the contents check it
+  Coalescer* coalescer = nullptr;       // created on the first cbh_idx64_find_coalesced (guarded by ws_mu)
 
   Workspace* acquire(int* rc) {
     {

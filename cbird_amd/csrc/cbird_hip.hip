@@ -320,6 +320,7 @@ void cbh_idx64_destroy(cbh_idx64* idx) {
   }
   if (idx->d_hashes) (void)hipFree(idx->d_hashes);
   if (idx->d_ids) (void)hipFree(idx->d_ids);
+  if (idx->coalescer) coalescer_free(idx->coalescer);
   delete idx;
 }
 
@@ -334,6 +335,7 @@ static int idx_append(cbh_idx64* idx, const void* hashes, const void* ids, size_
   CBH_HIP(hipMemcpyAsync(idx->d_ids + idx->n, ids, n * sizeof(uint32_t), kind, s));
   CBH_HIP(hipStreamSynchronize(s));
   idx->n += n;
+  idx->generation++;
   {
     std::lock_guard<std::mutex> lk(idx->tree_mu);
     idx->tree_valid = false;  // the HammingTree shape depends on the contents
@@ -346,6 +348,7 @@ int cbh_idx64_load(cbh_idx64* idx, const uint64_t* hashes, const uint32_t* ids, 
   DeviceGuard g(idx->device);
   if (!g.ok) return CBH_E_NODEVICE;
   idx->n = 0;  // load() on a loaded index is a no-op in the reference (:75); here it reloads
+  idx->generation++;
   idx->loaded = true;
   return idx_append(idx, hashes, ids, n, hipMemcpyHostToDevice, nullptr);
 }
@@ -356,6 +359,7 @@ int cbh_idx64_load_dev(cbh_idx64* idx, const void* d_hashes, const void* d_ids, 
   DeviceGuard g(idx->device);
   if (!g.ok) return CBH_E_NODEVICE;
   idx->n = 0;
+  idx->generation++;
   idx->loaded = true;
   return idx_append(idx, d_hashes, d_ids, n, hipMemcpyDeviceToDevice, (hipStream_t)stream);
 }
@@ -391,6 +395,7 @@ static int idx_remove(cbh_idx64* idx, const uint32_t* ids, size_t n, int zero_ha
   if (!ids) return CBH_E_INVAL;
   DeviceGuard g(idx->device);
   if (!g.ok) return CBH_E_NODEVICE;
+  idx->generation++;
   std::vector<uint32_t> rm(ids, ids + n);
   std::sort(rm.begin(), rm.end());
   rm.erase(std::unique(rm.begin(), rm.end()), rm.end());

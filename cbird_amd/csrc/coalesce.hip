@@ -1,0 +1,366 @@
+// coalesce.hip -- drop-in throughput for an UNMODIFIED caller: concurrent find() calls share scans.
+//
+// cbird's all-pairs search is Database::similar: QtConcurrent::map over the haystack, one
+// searchIndex() -> index->find(needle) per item, from as many pool threads as the host has cores, under a read lock
+// (src/database.cpp:1400-1432, 1698-1700).  Each call is synchronous, so a GPU index that serves them one by one is
+// latency-bound (one 27 us round trip per needle).  Two mechanisms inside cbh_idx64_find_coalesced change that
+// without touching the caller (hard part 6: "internally batch/queue"):
+//
+//  1. COMBINING.  Callers that arrive while a scan is in flight queue up; one of them (the leader) takes everything
+//     that is queued -- up to kMaxBatch needles -- and serves it with ONE scan (needles of different thresholds:
+//     one scan per threshold), then hands each caller its own sorted match list.  T blocking callers = T needles per
+//     round trip.
+//  2. SELF-JOIN CACHE.  The needles of Database::similar are the index's own entries.  The leader keeps a bill of
+//     the wall time it has spent serving rounds for a threshold; once that exceeds the estimated cost of scanning
+//     the WHOLE index against itself (N x N, the 10-20 ms batch job of bench.py at N = 1M), it does exactly that,
+//     once, keeps the sorted records on the host with a needle-hash -> row table, and from then on a find() whose
+//     needle hash is an index entry is a table lookup (ski-rental rule: never more than about twice the better of
+//     the two strategies; a handful of interactive -similar-to queries never triggers it).  load/add/remove bump
+//     the index generation and drop the cache.
+//
+// Results are those of cbh_idx64_find bit for bit: all entries with hamm64 < thresh, id != 0, ascending (score, id).
+#include <chrono>
+#include <condition_variable>
+#include <map>
+#include <memory>
+
+#include "cbh_index.h"
+
+namespace cbh {
+
+namespace {
+constexpr size_t kMaxBatch = 4096;       // needles per combined scan
+constexpr size_t kSpecRecs = 16384;      // records fetched together with the count (one synchronisation per round)
+constexpr size_t kJoinMaxRecords = (size_t)1 << 27;  // self-join results kept on the host: at most 1 GB
+
+struct Req {
+  uint64_t q;
+  int thresh;
+  cbh_match* out;
+  size_t cap;
+  size_t n_out = 0;
+  int rc = CBH_OK;
+  bool done = false;
+};
+
+struct SelfJoin {
+  std::vector<uint32_t> off;     // n + 1 row offsets into rec (row = index slot)
+  std::vector<cbh_record> rec;   // sorted ascending: (slot, score, id)
+};
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+struct Coalescer {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<Req*> pending;
+  bool leader = false;
+  uint64_t epoch = ~0ull;
+  // per threshold: the cache, or the bill that decides when to build it
+  std::map<int, std::shared_ptr<const SelfJoin>> joins;
+  std::map<int, double> spent;
+  std::map<int, bool> too_big;
+  // needle hash -> first slot holding it (open addressing over a host mirror of the hashes)
+  std::vector<uint64_t> h_hashes;
+  std::vector<uint32_t> table;
+  uint64_t table_mask = 0;
+  bool table_valid = false;
+  // pinned staging of the leader
+  uint64_t* h_q = nullptr;
+  cbh_record* h_spec = nullptr;
+  unsigned long long* h_total = nullptr;
+  // statistics
+  cbh_coalesce_stats st = {0, 0, 0, 0, 0};
+  int join_enabled = 1;
+
+  ~Coalescer() {
+    if (h_q) (void)hipHostFree(h_q);
+    if (h_spec) (void)hipHostFree(h_spec);
+    if (h_total) (void)hipHostFree(h_total);
+  }
+  int staging() {
+    if (h_q) return CBH_OK;
+    CBH_HIP(hipHostMalloc(&h_q, kMaxBatch * sizeof(uint64_t)));
+    CBH_HIP(hipHostMalloc(&h_spec, kSpecRecs * sizeof(cbh_record)));
+    CBH_HIP(hipHostMalloc(&h_total, sizeof(unsigned long long)));
+    return CBH_OK;
+  }
+  void invalidate(uint64_t gen) {
+    joins.clear();
+    spent.clear();
+    too_big.clear();
+    table_valid = false;
+    h_hashes.clear();
+    table.clear();
+    epoch = gen;
+  }
+  long slot_of(uint64_t q) const {
+    if (!table_valid) return -1;
+    uint64_t h = q * 0x9E3779B97F4A7C15ull;
+    for (uint64_t i = h >> 20;; ++i) {
+      const uint32_t s = table[i & table_mask];
+      if (!s) return -1;
+      if (h_hashes[s - 1] == q) return (long)s - 1;
+    }
+  }
+};
+
+void coalescer_free(Coalescer* c) { delete c; }
+
+namespace {
+
+void deliver(Req* r, const cbh_record* rec, size_t n) {
+  r->n_out = n;
+  const size_t m = std::min(n, r->cap);
+  for (size_t i = 0; i < m; ++i) {
+    r->out[i].id = CBH_REC_ID(rec[i]);
+    r->out[i].score = CBH_REC_DIST(rec[i]);
+  }
+  r->rc = CBH_OK;
+}
+
+// one combined scan: every request of `batch` has the same threshold.  Records of all needles -> host, ordered.
+int serve_by_scan(cbh_idx64* idx, Coalescer* co, Workspace* ws, std::vector<Req*>& batch) {
+  const size_t nq = batch.size();
+  const int thresh = batch[0]->thresh;
+  int rc = co->staging();
+  if (rc) return rc;
+  if ((rc = ws->ensure_records(Workspace::kFindRecs))) return rc;
+  if ((rc = Workspace::grow(&ws->d_q, &ws->q_cap, nq))) return rc;
+  for (size_t i = 0; i < nq; ++i) co->h_q[i] = batch[i]->q;
+  hipStream_t s = ws->stream;
+  CBH_HIP(hipMemcpyAsync(ws->d_q, co->h_q, nq * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+  CBH_HIP(hipMemsetAsync(ws->d_total, 0, sizeof(unsigned long long), s));
+  rc = launch_hamm64_scan(idx->d_hashes, idx->d_ids, idx->n, ws->d_q, nq, thresh, ws->d_rec, ws->rec_cap, ws->d_total,
+                          s, 0, nullptr);
+  if (rc) return rc;
+  const size_t spec = std::min(kSpecRecs, ws->rec_cap);
+  CBH_HIP(hipMemcpyAsync(co->h_total, ws->d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  CBH_HIP(hipMemcpyAsync(co->h_spec, ws->d_rec, spec * sizeof(cbh_record), hipMemcpyDeviceToHost, s));
+  CBH_HIP(hipStreamSynchronize(s));
+  unsigned long long total = *co->h_total;
+  {
+    std::lock_guard<std::mutex> lk(idx->stats_mu);
+    idx->stats.scan_launches += 1;
+    idx->stats.scan_pairs += (uint64_t)idx->n * (uint64_t)nq;
+  }
+  std::vector<cbh_record> big;
+  cbh_record* recs = co->h_spec;
+  if (total > spec) {
+    if (total > ws->rec_cap) {  // did not fit: the general path grows the buffer and rescans
+      rc = scan_all(idx, ws, ws->d_q, nq, thresh, s, &total);
+      if (rc) return rc;
+    }
+    big.resize((size_t)total);
+    CBH_HIP(hipMemcpyAsync(big.data(), ws->d_rec, (size_t)total * sizeof(cbh_record), hipMemcpyDeviceToHost, s));
+    CBH_HIP(hipStreamSynchronize(s));
+    recs = big.data();
+  }
+  std::sort(recs, recs + total);  // (needle, score, id)
+  size_t a = 0;
+  for (size_t j = 0; j < nq; ++j) {
+    size_t b = a;
+    while (b < total && CBH_REC_QUERY(recs[b]) == j) ++b;
+    deliver(batch[j], recs + a, b - a);
+    a = b;
+  }
+  return CBH_OK;
+}
+
+// the whole index against itself at `thresh`; also (re)builds the hash -> slot table
+int build_self_join(cbh_idx64* idx, Coalescer* co, Workspace* ws, int thresh, std::shared_ptr<const SelfJoin>* out,
+                    bool* too_big) {
+  *too_big = false;
+  const size_t n = idx->n;
+  if (n > CBH_MAX_QUERIES_PER_CALL - 1) {
+    *too_big = true;
+    return CBH_OK;
+  }
+  hipStream_t s = ws->stream;
+  unsigned long long total = 0;
+  int rc = scan_all(idx, ws, idx->d_hashes, n, thresh, s, &total);
+  if (rc == CBH_E_OVERFLOW || (!rc && total > kJoinMaxRecords)) {
+    *too_big = true;
+    return CBH_OK;
+  }
+  if (rc) return rc;
+  if ((rc = ws->ensure_sort())) return rc;
+  if ((rc = launch_sort_records(ws->d_rec, ws->d_alt, (size_t)total, n, ws->d_tmp, ws->tmp_bytes, s))) return rc;
+  auto sj = std::make_shared<SelfJoin>();
+  sj->rec.resize((size_t)total);
+  if (total)
+    CBH_HIP(hipMemcpyAsync(sj->rec.data(), ws->d_rec, (size_t)total * sizeof(cbh_record), hipMemcpyDeviceToHost, s));
+  const bool need_table = !co->table_valid;
+  std::vector<uint64_t> hh;
+  if (need_table) {
+    hh.resize(n);
+    CBH_HIP(hipMemcpyAsync(hh.data(), idx->d_hashes, n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  }
+  CBH_HIP(hipStreamSynchronize(s));
+  sj->off.assign(n + 1, 0);
+  for (size_t i = 0; i < (size_t)total; ++i) sj->off[(size_t)CBH_REC_QUERY(sj->rec[i]) + 1]++;
+  for (size_t j = 0; j < n; ++j) sj->off[j + 1] += sj->off[j];
+  if (need_table) {
+    size_t cap = 1024;
+    while (cap < 2 * n) cap <<= 1;
+    std::vector<uint32_t> tab(cap, 0);
+    const uint64_t mask = cap - 1;
+    for (size_t sl = 0; sl < n; ++sl) {
+      const uint64_t q = hh[sl];
+      if (!q) continue;  // removed slot / null hash: never a needle
+      for (uint64_t i = (q * 0x9E3779B97F4A7C15ull) >> 20;; ++i) {
+        uint32_t& e = tab[i & mask];
+        if (!e) {
+          e = (uint32_t)sl + 1;
+          break;
+        }
+        if (hh[e - 1] == q) break;  // same hash already present: equal needles have equal rows
+      }
+    }
+    co->h_hashes.swap(hh);
+    co->table.swap(tab);
+    co->table_mask = mask;
+    co->table_valid = true;
+  }
+  *out = sj;
+  return CBH_OK;
+}
+
+}  // namespace
+}  // namespace cbh
+
+using namespace cbh;
+
+int cbh_idx64_find_coalesced(cbh_idx64* idx, uint64_t q, int thresh, cbh_match* out, size_t cap, size_t* n_out) {
+  if (!idx || !n_out || (cap && !out)) return CBH_E_INVAL;
+  *n_out = 0;
+  if (q == 0 || idx->n == 0 || thresh <= 0) return CBH_OK;  // as cbh_idx64_find
+  Coalescer* co;
+  {
+    std::lock_guard<std::mutex> lk(idx->ws_mu);
+    if (!idx->coalescer) idx->coalescer = new (std::nothrow) Coalescer;
+    co = idx->coalescer;
+  }
+  if (!co) return CBH_E_NOMEM;
+  Req me{q, thresh, out, cap};
+  std::unique_lock<std::mutex> lk(co->mu);
+  if (co->epoch != idx->generation) co->invalidate(idx->generation);
+  co->st.finds += 1;
+  {
+    auto it = co->joins.find(thresh);
+    if (it != co->joins.end()) {  // cached self-join: a lookup, no device work
+      std::shared_ptr<const SelfJoin> sj = it->second;
+      const long sl = co->slot_of(q);
+      if (sl >= 0) {
+        co->st.cache_hits += 1;
+        lk.unlock();
+        deliver(&me, sj->rec.data() + sj->off[(size_t)sl], sj->off[(size_t)sl + 1] - sj->off[(size_t)sl]);
+        *n_out = me.n_out;
+        return CBH_OK;
+      }
+    }
+  }
+  co->pending.push_back(&me);
+  while (!me.done) {
+    if (co->leader) {
+      co->cv.wait(lk);
+      continue;
+    }
+    // become the leader: serve everything that is queued (this request included), round after round, until this
+    // request is done; then hand the role to whoever is still waiting
+    co->leader = true;
+    while (!me.done) {
+      std::vector<Req*> batch;
+      const size_t take = std::min(co->pending.size(), kMaxBatch);
+      batch.assign(co->pending.begin(), co->pending.begin() + (long)take);
+      co->pending.erase(co->pending.begin(), co->pending.begin() + (long)take);
+      const uint64_t gen = idx->generation;
+      lk.unlock();
+      // ---- device work, no lock held ----
+      const double t0 = now_s();
+      int rc = CBH_OK;
+      DeviceGuard g(idx->device);
+      Workspace* ws = nullptr;
+      if (!g.ok) rc = CBH_E_NODEVICE;
+      if (!rc) ws = idx->acquire(&rc);
+      std::map<int, std::vector<Req*>> by_thr;
+      for (Req* r : batch) by_thr[r->thresh].push_back(r);
+      std::map<int, std::shared_ptr<const SelfJoin>> built;
+      std::map<int, bool> big;
+      std::map<int, double> cost;
+      for (auto& kv : by_thr) {
+        const double t1 = now_s();
+        int r2 = rc;
+        if (!r2) r2 = serve_by_scan(idx, co, ws, kv.second);
+        if (r2)
+          for (Req* r : kv.second) r->rc = r2, r->n_out = 0;
+        cost[kv.first] = now_s() - t1;
+      }
+      // ski-rental: has serving this threshold round by round cost as much as one self-join would?
+      if (!rc && co->join_enabled) {
+        const double n = (double)idx->n;
+        const double est = n * n / 5.0e13 + n * 4.0e-8 + 2.0e-3;
+        for (auto& kv : cost) {
+          double bill;
+          bool skip;
+          {
+            std::lock_guard<std::mutex> l2(co->mu);
+            bill = (co->spent[kv.first] += kv.second);
+            skip = co->joins.count(kv.first) || co->too_big[kv.first] || co->epoch != gen;
+          }
+          if (skip || bill < 0.5 * est) continue;
+          std::shared_ptr<const SelfJoin> sj;
+          bool tb = false;
+          if (build_self_join(idx, co, ws, kv.first, &sj, &tb) == CBH_OK) {
+            if (tb) big[kv.first] = true;
+            else built[kv.first] = sj;
+          }
+        }
+      }
+      if (ws) idx->give_back(ws);
+      const double dt = now_s() - t0;
+      // ---- publish ----
+      lk.lock();
+      co->st.rounds += 1;
+      co->st.scanned_needles += batch.size();
+      (void)dt;
+      if (co->epoch == gen) {
+        for (auto& kv : built) co->joins[kv.first] = kv.second, co->st.self_joins += 1;
+        for (auto& kv : big) co->too_big[kv.first] = true;
+      }
+      for (Req* r : batch) r->done = true;
+      co->cv.notify_all();
+    }
+    co->leader = false;
+    co->cv.notify_all();
+  }
+  lk.unlock();
+  *n_out = me.n_out;
+  return me.rc;
+}
+
+int cbh_idx64_coalesce_stats(cbh_idx64* idx, cbh_coalesce_stats* out) {
+  if (!idx || !out) return CBH_E_INVAL;
+  std::lock_guard<std::mutex> lk(idx->ws_mu);
+  if (!idx->coalescer) {
+    *out = cbh_coalesce_stats{0, 0, 0, 0, 0};
+    return CBH_OK;
+  }
+  std::lock_guard<std::mutex> l2(idx->coalescer->mu);
+  *out = idx->coalescer->st;
+  return CBH_OK;
+}
+
+int cbh_idx64_coalesce_set_self_join(cbh_idx64* idx, int enabled) {
+  if (!idx) return CBH_E_INVAL;
+  std::lock_guard<std::mutex> lk(idx->ws_mu);
+  if (!idx->coalescer) idx->coalescer = new (std::nothrow) Coalescer;
+  if (!idx->coalescer) return CBH_E_NOMEM;
+  std::lock_guard<std::mutex> l2(idx->coalescer->mu);
+  idx->coalescer->join_enabled = enabled ? 1 : 0;
+  if (!enabled) idx->coalescer->invalidate(idx->generation);
+  return CBH_OK;
+}

@@ -198,6 +198,23 @@ int cbh_idx64_find_batch_masked(cbh_idx64*, const uint64_t* q, const uint64_t* q
  * splits on bit = depth once more than 8192 values were routed to it, :384-414) is rebuilt lazily after
  * load/add. */
 int cbh_idx64_tree_masks(cbh_idx64*, const uint64_t* q, size_t nq, uint64_t* out_masks);
+/* find() for an UNMODIFIED caller that issues one synchronous call per needle from many threads
+ * (Database::similar: QtConcurrent::map -> searchIndex -> index->find, src/database.cpp:1400-1432,1698-1700).
+ * Same results as cbh_idx64_find, bit for bit.  Concurrent callers are combined into one scan per round trip, and
+ * once the time spent that way for a threshold exceeds what scanning the whole index against itself would cost
+ * (the needles of an all-pairs search ARE the index entries), that self-join is run once, kept on the host, and
+ * later calls whose needle hash is an index entry become table lookups (cbird_amd/csrc/coalesce.hip).  load / add /
+ * remove drop the cache.  Thread-safe for concurrent readers; writers exclusive, as the reference's lock provides. */
+int cbh_idx64_find_coalesced(cbh_idx64*, uint64_t q, int thresh, cbh_match* out, size_t cap, size_t* n_out);
+typedef struct cbh_coalesce_stats {
+  uint64_t finds;           /* calls */
+  uint64_t cache_hits;      /* answered from a cached self-join */
+  uint64_t rounds;          /* combined scans */
+  uint64_t scanned_needles; /* needles served by those scans (finds - cache_hits, once everything has returned) */
+  uint64_t self_joins;      /* whole-index self-joins built */
+} cbh_coalesce_stats;
+int cbh_idx64_coalesce_stats(cbh_idx64*, cbh_coalesce_stats* out);
+int cbh_idx64_coalesce_set_self_join(cbh_idx64*, int enabled); /* default 1; 0 = combining only */
 int cbh_idx64_find_batch_dev(cbh_idx64*, const void* d_q, size_t nq, int thresh,
                              int max_per_query, void* d_out, void* d_counts,
                              uint64_t* total_out, void* stream);

@@ -28,6 +28,23 @@ def test_adapter_runs_on_gpu(gpu):
     assert "adapter ok" in out.stdout
 
 
+@pytest.mark.gpu
+def test_drop_in_find_under_concurrent_callers(gpu):
+    """GpuDctHashIndex::find from 32 threads, one synchronous call per needle (the reference's Database::similar
+    pattern): every result equals the batched path's; combining + the self-join cache both get exercised"""
+    import json
+
+    subprocess.check_call(["make", "-C", CPP, "test_coalesce"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(CPP, "test_coalesce"), "200000", "32", "6250", "3"], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "coalesce ok" in out.stdout
+    st = json.loads(out.stdout.splitlines()[0])["coalesce"]
+    assert st["finds"] == 200000 and st["cache_hits"] + st["scanned_needles"] == st["finds"]
+    assert st["rounds"] < st["scanned_needles"] or st["scanned_needles"] < 64  # callers really were combined
+    assert st["self_joins"] >= 1 and st["cache_hits"] > 0
+
+
 def test_other_four_adapters_compile():
     subprocess.check_call(["make", "-C", CPP, "-B", "test_adapters4"], stdout=subprocess.DEVNULL)
     src = open(os.path.join(ROOT, "cbird_amd", "cpp", "gpu_indexes.h")).read()
