@@ -159,7 +159,7 @@ struct cbh_idx64 {
   bool tree_valid = false;
   std::unordered_set<uint64_t> tree_internal;
   std::atomic<uint64_t> generation{0};  // bumped by load/add/remove: caches derived from the contents check it
-  Coalescer* coalescer = nullptr;       // created on the first cbh_idx64_find_coalesced (guarded by ws_mu)
+  std::atomic<Coalescer*> coalescer{nullptr};  // created on the first cbh_idx64_find_coalesced
 
   Workspace* acquire(int* rc) {
     {

@@ -58,6 +58,7 @@ void set_scan256_pre(int on);  // first-128-bit prefilter variant (default on)
 void set_scan256_mfma(int on);  // <0 = keep; 2 = force for any size
 
 int g_hash_mfma_set(int v);  // dcthash.hip
+extern int g_fdct_host_vote, g_video_host_reduce;  // fdct.hip: 1 = round-1 host reductions (parity tests)
 void set_hash_dct(int v);       // dcthash.hip: stage 3/5 arithmetic, 1 = as cv::dct/cv::sum (default), 0 = canonical matrix form
 void set_kp_blur_side(int v);   // dcthash.hip: largest keypoint square whose blurred copy stays in LDS (default 112)
 void set_kp_lds_side(int v);    // dcthash.hip: largest keypoint square processed in LDS (default 134)
@@ -81,9 +82,30 @@ int launch_remove_ids(uint64_t* d_hashes, uint32_t* d_ids, size_t n, const uint3
 constexpr int kTopkMaxK = 64;  // larger cuts take the radix sort (records.hip)
 size_t topk_scratch_bytes(size_t nq, size_t total_cap);
 int topk_scratch_init(void* d_scratch, size_t nq, hipStream_t stream);
+int launch_records_group(const unsigned long long* d_blocks, unsigned nb, size_t stride, size_t cap, size_t nq,
+                         unsigned* d_status, void* d_scratch, const unsigned** d_off, const unsigned long long** d_seg,
+                         hipStream_t stream);
 int launch_records_topk(const unsigned long long* d_blocks, unsigned nb, size_t stride, size_t cap, size_t nq, int k,
                         cbh_match* d_out, uint32_t* d_counts, unsigned* d_status, void* d_scratch,
                         hipStream_t stream);
+
+// ---- reduce.hip: K5 (fdct votes) and K8 (video closest-frame + adjacency) on the device ---------
+struct cbh_nmatch {   // one DctFeaturesIndex result of needle image `needle`
+  uint32_t needle, id;
+  int32_t score;
+};
+struct cbh_nvmatch {  // one DctVideoIndex::findVideo result of needle video `needle`
+  uint32_t needle;
+  cbh_vmatch m;
+};
+int sort_keys_u64(unsigned long long* d_keys, size_t n, int end_bit, hipStream_t s);
+int sort_pairs_u64_u32(unsigned long long* d_keys, uint32_t* d_vals, size_t n, int end_bit, hipStream_t s);
+int launch_fdct_vote(const cbh_match* d_top, const uint32_t* d_counts, const uint32_t* d_qneedle, size_t nq, int k,
+                     const uint32_t* d_needle_id, size_t n_needles, std::vector<cbh_nmatch>* h_out, hipStream_t s);
+int launch_video_reduce(const unsigned* d_off, const unsigned long long* d_seg, size_t total, size_t nq,
+                        const uint32_t* d_evidx, const int32_t* d_eframe, const uint32_t* d_vmedia,
+                        const uint32_t* d_qneedle, const int32_t* d_qframe, const uint32_t* d_needle_id, int filter_self,
+                        int min_matched, int min_near, std::vector<cbh_nvmatch>* h_out, hipStream_t s);
 
 // ---- dcthash.hip ----------------------------------------------------------------------
 // view: the images are w x h sub-rectangles at (ox, oy) of pw x ph parents starting at d_imgs -- cv::blur on a

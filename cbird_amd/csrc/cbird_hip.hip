@@ -320,7 +320,7 @@ void cbh_idx64_destroy(cbh_idx64* idx) {
   }
   if (idx->d_hashes) (void)hipFree(idx->d_hashes);
   if (idx->d_ids) (void)hipFree(idx->d_ids);
-  if (idx->coalescer) coalescer_free(idx->coalescer);
+  if (idx->coalescer.load()) coalescer_free(idx->coalescer.load());
   delete idx;
 }
 
@@ -816,6 +816,14 @@ int cbh_set_tuning(const char* key, int value) {
   }
   if (!strcmp(key, "scan_mfma_ht")) {
     set_scan_mfma_ht(value);
+    return CBH_OK;
+  }
+  if (!strcmp(key, "fdct_host_vote")) {
+    g_fdct_host_vote = value ? 1 : 0;
+    return CBH_OK;
+  }
+  if (!strcmp(key, "video_host_reduce")) {
+    g_video_host_reduce = value ? 1 : 0;
     return CBH_OK;
   }
   if (!strcmp(key, "hash_dct")) {

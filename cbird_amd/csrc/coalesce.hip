@@ -23,6 +23,7 @@
 #include <condition_variable>
 #include <map>
 #include <memory>
+#include <thread>
 
 #include "cbh_index.h"
 
@@ -30,7 +31,7 @@ namespace cbh {
 
 namespace {
 constexpr size_t kMaxBatch = 4096;       // needles per combined scan
-constexpr size_t kSpecRecs = 16384;      // records fetched together with the count (one synchronisation per round)
+constexpr size_t kSpecRecs = 2048;       // records fetched together with the count (one synchronisation per round)
 constexpr size_t kJoinMaxRecords = (size_t)1 << 27;  // self-join results kept on the host: at most 1 GB
 
 struct Req {
@@ -53,30 +54,54 @@ double now_s() {
 }
 }  // namespace
 
+// Everything a cache hit needs, immutable once published: readers take it without any lock.
+struct Snapshot {
+  std::vector<std::pair<int, std::shared_ptr<const SelfJoin>>> joins;  // by threshold (a handful)
+  // needle hash -> first slot holding it (open addressing over a host mirror of the hashes)
+  std::shared_ptr<const std::vector<uint64_t>> h_hashes;
+  std::shared_ptr<const std::vector<uint32_t>> table;
+  uint64_t table_mask = 0;
+  long slot_of(uint64_t q) const {
+    const std::vector<uint32_t>& t = *table;
+    const std::vector<uint64_t>& h = *h_hashes;
+    for (uint64_t i = (q * 0x9E3779B97F4A7C15ull) >> 20;; ++i) {
+      const uint32_t s = t[i & table_mask];
+      if (!s) return -1;
+      if (h[s - 1] == q) return (long)s - 1;
+    }
+  }
+};
+
 struct Coalescer {
   std::mutex mu;
   std::condition_variable cv;
   std::vector<Req*> pending;
   bool leader = false;
   uint64_t epoch = ~0ull;
-  // per threshold: the cache, or the bill that decides when to build it
-  std::map<int, std::shared_ptr<const SelfJoin>> joins;
+  // lock-free read side: snap is valid for index generation snap_epoch.  Replaced snapshots are retired, not freed,
+  // until the next invalidation -- which follows an exclusive writer (load/add/remove), so no reader that saw a
+  // matching snap_epoch can still be inside one (the reference's rw-lock contract, src/database.cpp:371,1698).
+  std::atomic<uint64_t> snap_epoch{~0ull};
+  std::atomic<const Snapshot*> snap{nullptr};
+  std::vector<const Snapshot*> retired;
+  // the bill that decides when a threshold's self-join is built
   std::map<int, double> spent;
   std::map<int, bool> too_big;
-  // needle hash -> first slot holding it (open addressing over a host mirror of the hashes)
-  std::vector<uint64_t> h_hashes;
-  std::vector<uint32_t> table;
-  uint64_t table_mask = 0;
-  bool table_valid = false;
   // pinned staging of the leader
   uint64_t* h_q = nullptr;
   cbh_record* h_spec = nullptr;
   unsigned long long* h_total = nullptr;
-  // statistics
-  cbh_coalesce_stats st = {0, 0, 0, 0, 0};
+  // statistics: sharded so that a million cache hits from 64 threads do not fight over one cache line
+  struct alignas(64) Shard {
+    std::atomic<uint64_t> finds{0}, hits{0};
+  };
+  Shard shards[64];
+  uint64_t rounds = 0, scanned = 0, self_joins = 0;  // leader only, under mu
   int join_enabled = 1;
 
   ~Coalescer() {
+    delete snap.load();
+    for (const Snapshot* p : retired) delete p;
     if (h_q) (void)hipHostFree(h_q);
     if (h_spec) (void)hipHostFree(h_spec);
     if (h_total) (void)hipHostFree(h_total);
@@ -88,23 +113,23 @@ struct Coalescer {
     CBH_HIP(hipHostMalloc(&h_total, sizeof(unsigned long long)));
     return CBH_OK;
   }
-  void invalidate(uint64_t gen) {
-    joins.clear();
+  void invalidate(uint64_t gen) {  // under mu
+    snap_epoch.store(~0ull, std::memory_order_release);
+    delete snap.exchange(nullptr);
+    for (const Snapshot* p : retired) delete p;
+    retired.clear();
     spent.clear();
     too_big.clear();
-    table_valid = false;
-    h_hashes.clear();
-    table.clear();
     epoch = gen;
   }
-  long slot_of(uint64_t q) const {
-    if (!table_valid) return -1;
-    uint64_t h = q * 0x9E3779B97F4A7C15ull;
-    for (uint64_t i = h >> 20;; ++i) {
-      const uint32_t s = table[i & table_mask];
-      if (!s) return -1;
-      if (h_hashes[s - 1] == q) return (long)s - 1;
-    }
+  void publish(const Snapshot* s, uint64_t gen) {  // under mu
+    const Snapshot* old = snap.exchange(s, std::memory_order_acq_rel);
+    if (old) retired.push_back(old);
+    snap_epoch.store(gen, std::memory_order_release);
+  }
+  static Shard& my_shard(Shard* sh) {
+    static thread_local const unsigned k = (unsigned)(std::hash<std::thread::id>()(std::this_thread::get_id()) % 64);
+    return sh[k];
   }
 };
 
@@ -170,10 +195,11 @@ int serve_by_scan(cbh_idx64* idx, Coalescer* co, Workspace* ws, std::vector<Req*
   return CBH_OK;
 }
 
-// the whole index against itself at `thresh`; also (re)builds the hash -> slot table
-int build_self_join(cbh_idx64* idx, Coalescer* co, Workspace* ws, int thresh, std::shared_ptr<const SelfJoin>* out,
-                    bool* too_big) {
+// the whole index against itself at `thresh`; builds the hash -> slot table too when `base` has none yet.
+// Returns a new snapshot = base + this join.
+int build_self_join(cbh_idx64* idx, const Snapshot* base, Workspace* ws, int thresh, Snapshot** out, bool* too_big) {
   *too_big = false;
+  *out = nullptr;
   const size_t n = idx->n;
   if (n > CBH_MAX_QUERIES_PER_CALL - 1) {
     *too_big = true;
@@ -193,39 +219,43 @@ int build_self_join(cbh_idx64* idx, Coalescer* co, Workspace* ws, int thresh, st
   sj->rec.resize((size_t)total);
   if (total)
     CBH_HIP(hipMemcpyAsync(sj->rec.data(), ws->d_rec, (size_t)total * sizeof(cbh_record), hipMemcpyDeviceToHost, s));
-  const bool need_table = !co->table_valid;
-  std::vector<uint64_t> hh;
+  const bool need_table = !base || !base->table;
+  auto hh = std::make_shared<std::vector<uint64_t>>();
   if (need_table) {
-    hh.resize(n);
-    CBH_HIP(hipMemcpyAsync(hh.data(), idx->d_hashes, n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    hh->resize(n);
+    CBH_HIP(hipMemcpyAsync(hh->data(), idx->d_hashes, n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
   }
   CBH_HIP(hipStreamSynchronize(s));
   sj->off.assign(n + 1, 0);
   for (size_t i = 0; i < (size_t)total; ++i) sj->off[(size_t)CBH_REC_QUERY(sj->rec[i]) + 1]++;
   for (size_t j = 0; j < n; ++j) sj->off[j + 1] += sj->off[j];
+  std::unique_ptr<Snapshot> sn(new (std::nothrow) Snapshot);
+  if (!sn) return CBH_E_NOMEM;
+  if (base) *sn = *base;
   if (need_table) {
     size_t cap = 1024;
     while (cap < 2 * n) cap <<= 1;
-    std::vector<uint32_t> tab(cap, 0);
+    auto tab = std::make_shared<std::vector<uint32_t>>(cap, 0u);
     const uint64_t mask = cap - 1;
+    const std::vector<uint64_t>& h = *hh;
     for (size_t sl = 0; sl < n; ++sl) {
-      const uint64_t q = hh[sl];
+      const uint64_t q = h[sl];
       if (!q) continue;  // removed slot / null hash: never a needle
       for (uint64_t i = (q * 0x9E3779B97F4A7C15ull) >> 20;; ++i) {
-        uint32_t& e = tab[i & mask];
+        uint32_t& e = (*tab)[i & mask];
         if (!e) {
           e = (uint32_t)sl + 1;
           break;
         }
-        if (hh[e - 1] == q) break;  // same hash already present: equal needles have equal rows
+        if (h[e - 1] == q) break;  // same hash already present: equal needles have equal rows
       }
     }
-    co->h_hashes.swap(hh);
-    co->table.swap(tab);
-    co->table_mask = mask;
-    co->table_valid = true;
+    sn->h_hashes = hh;
+    sn->table = tab;
+    sn->table_mask = mask;
   }
-  *out = sj;
+  sn->joins.emplace_back(thresh, sj);
+  *out = sn.release();
   return CBH_OK;
 }
 
@@ -234,35 +264,45 @@ int build_self_join(cbh_idx64* idx, Coalescer* co, Workspace* ws, int thresh, st
 
 using namespace cbh;
 
+static Coalescer* get_coalescer(cbh_idx64* idx) {
+  Coalescer* co = idx->coalescer.load(std::memory_order_acquire);
+  if (co) return co;
+  std::lock_guard<std::mutex> lk(idx->ws_mu);
+  co = idx->coalescer.load(std::memory_order_acquire);
+  if (!co) {
+    co = new (std::nothrow) Coalescer;
+    idx->coalescer.store(co, std::memory_order_release);
+  }
+  return co;
+}
+
 int cbh_idx64_find_coalesced(cbh_idx64* idx, uint64_t q, int thresh, cbh_match* out, size_t cap, size_t* n_out) {
   if (!idx || !n_out || (cap && !out)) return CBH_E_INVAL;
   *n_out = 0;
   if (q == 0 || idx->n == 0 || thresh <= 0) return CBH_OK;  // as cbh_idx64_find
-  Coalescer* co;
-  {
-    std::lock_guard<std::mutex> lk(idx->ws_mu);
-    if (!idx->coalescer) idx->coalescer = new (std::nothrow) Coalescer;
-    co = idx->coalescer;
-  }
+  Coalescer* co = get_coalescer(idx);
   if (!co) return CBH_E_NOMEM;
   Req me{q, thresh, out, cap};
-  std::unique_lock<std::mutex> lk(co->mu);
-  if (co->epoch != idx->generation) co->invalidate(idx->generation);
-  co->st.finds += 1;
-  {
-    auto it = co->joins.find(thresh);
-    if (it != co->joins.end()) {  // cached self-join: a lookup, no device work
-      std::shared_ptr<const SelfJoin> sj = it->second;
-      const long sl = co->slot_of(q);
-      if (sl >= 0) {
-        co->st.cache_hits += 1;
-        lk.unlock();
-        deliver(&me, sj->rec.data() + sj->off[(size_t)sl], sj->off[(size_t)sl + 1] - sj->off[(size_t)sl]);
-        *n_out = me.n_out;
-        return CBH_OK;
-      }
-    }
+  Coalescer::Shard& shard = Coalescer::my_shard(co->shards);
+  shard.finds.fetch_add(1, std::memory_order_relaxed);
+  // ---- cached self-join: a lookup, no lock, no device work ----
+  const uint64_t gen0 = idx->generation.load(std::memory_order_acquire);
+  if (co->snap_epoch.load(std::memory_order_acquire) == gen0) {
+    const Snapshot* sn = co->snap.load(std::memory_order_acquire);
+    if (sn)
+      for (const auto& kv : sn->joins)
+        if (kv.first == thresh) {
+          const long sl = sn->slot_of(q);
+          if (sl < 0) break;  // not an index entry: combined scan below
+          const SelfJoin& sj = *kv.second;
+          deliver(&me, sj.rec.data() + sj.off[(size_t)sl], sj.off[(size_t)sl + 1] - sj.off[(size_t)sl]);
+          shard.hits.fetch_add(1, std::memory_order_relaxed);
+          *n_out = me.n_out;
+          return CBH_OK;
+        }
   }
+  std::unique_lock<std::mutex> lk(co->mu);
+  if (co->epoch != gen0) co->invalidate(gen0);
   co->pending.push_back(&me);
   while (!me.done) {
     if (co->leader) {
@@ -277,10 +317,11 @@ int cbh_idx64_find_coalesced(cbh_idx64* idx, uint64_t q, int thresh, cbh_match* 
       const size_t take = std::min(co->pending.size(), kMaxBatch);
       batch.assign(co->pending.begin(), co->pending.begin() + (long)take);
       co->pending.erase(co->pending.begin(), co->pending.begin() + (long)take);
-      const uint64_t gen = idx->generation;
+      const uint64_t gen = co->epoch;
+      const Snapshot* base = co->snap.load(std::memory_order_acquire);
+      const bool joins_on = co->join_enabled != 0;
       lk.unlock();
       // ---- device work, no lock held ----
-      const double t0 = now_s();
       int rc = CBH_OK;
       DeviceGuard g(idx->device);
       Workspace* ws = nullptr;
@@ -288,8 +329,6 @@ int cbh_idx64_find_coalesced(cbh_idx64* idx, uint64_t q, int thresh, cbh_match* 
       if (!rc) ws = idx->acquire(&rc);
       std::map<int, std::vector<Req*>> by_thr;
       for (Req* r : batch) by_thr[r->thresh].push_back(r);
-      std::map<int, std::shared_ptr<const SelfJoin>> built;
-      std::map<int, bool> big;
       std::map<int, double> cost;
       for (auto& kv : by_thr) {
         const double t1 = now_s();
@@ -300,37 +339,49 @@ int cbh_idx64_find_coalesced(cbh_idx64* idx, uint64_t q, int thresh, cbh_match* 
         cost[kv.first] = now_s() - t1;
       }
       // ski-rental: has serving this threshold round by round cost as much as one self-join would?
-      if (!rc && co->join_enabled) {
+      Snapshot* fresh = nullptr;
+      std::vector<int> big;
+      if (!rc && joins_on) {
         const double n = (double)idx->n;
         const double est = n * n / 5.0e13 + n * 4.0e-8 + 2.0e-3;
         for (auto& kv : cost) {
+          bool have = false;
+          const Snapshot* cur = fresh ? fresh : base;
+          if (cur)
+            for (const auto& j : cur->joins) have |= (j.first == kv.first);
           double bill;
           bool skip;
           {
             std::lock_guard<std::mutex> l2(co->mu);
             bill = (co->spent[kv.first] += kv.second);
-            skip = co->joins.count(kv.first) || co->too_big[kv.first] || co->epoch != gen;
+            skip = have || co->too_big[kv.first] || co->epoch != gen;
           }
           if (skip || bill < 0.5 * est) continue;
-          std::shared_ptr<const SelfJoin> sj;
+          Snapshot* sn = nullptr;
           bool tb = false;
-          if (build_self_join(idx, co, ws, kv.first, &sj, &tb) == CBH_OK) {
-            if (tb) big[kv.first] = true;
-            else built[kv.first] = sj;
+          if (build_self_join(idx, cur, ws, kv.first, &sn, &tb) == CBH_OK) {
+            if (tb) big.push_back(kv.first);
+            if (sn) {
+              delete fresh;
+              fresh = sn;
+            }
           }
         }
       }
       if (ws) idx->give_back(ws);
-      const double dt = now_s() - t0;
       // ---- publish ----
       lk.lock();
-      co->st.rounds += 1;
-      co->st.scanned_needles += batch.size();
-      (void)dt;
-      if (co->epoch == gen) {
-        for (auto& kv : built) co->joins[kv.first] = kv.second, co->st.self_joins += 1;
-        for (auto& kv : big) co->too_big[kv.first] = true;
+      co->rounds += 1;
+      co->scanned += batch.size();
+      if (co->epoch == gen && idx->generation.load() == gen) {
+        if (fresh) {
+          co->self_joins += fresh->joins.size() - (base ? base->joins.size() : 0);
+          co->publish(fresh, gen);
+          fresh = nullptr;
+        }
+        for (int t : big) co->too_big[t] = true;
       }
+      delete fresh;
       for (Req* r : batch) r->done = true;
       co->cv.notify_all();
     }
@@ -344,23 +395,21 @@ int cbh_idx64_find_coalesced(cbh_idx64* idx, uint64_t q, int thresh, cbh_match* 
 
 int cbh_idx64_coalesce_stats(cbh_idx64* idx, cbh_coalesce_stats* out) {
   if (!idx || !out) return CBH_E_INVAL;
-  std::lock_guard<std::mutex> lk(idx->ws_mu);
-  if (!idx->coalescer) {
-    *out = cbh_coalesce_stats{0, 0, 0, 0, 0};
-    return CBH_OK;
-  }
-  std::lock_guard<std::mutex> l2(idx->coalescer->mu);
-  *out = idx->coalescer->st;
+  *out = cbh_coalesce_stats{0, 0, 0, 0, 0};
+  Coalescer* co = idx->coalescer.load(std::memory_order_acquire);
+  if (!co) return CBH_OK;
+  std::lock_guard<std::mutex> l2(co->mu);
+  for (auto& sh : co->shards) out->finds += sh.finds.load(), out->cache_hits += sh.hits.load();
+  out->rounds = co->rounds, out->scanned_needles = co->scanned, out->self_joins = co->self_joins;
   return CBH_OK;
 }
 
 int cbh_idx64_coalesce_set_self_join(cbh_idx64* idx, int enabled) {
   if (!idx) return CBH_E_INVAL;
-  std::lock_guard<std::mutex> lk(idx->ws_mu);
-  if (!idx->coalescer) idx->coalescer = new (std::nothrow) Coalescer;
-  if (!idx->coalescer) return CBH_E_NOMEM;
-  std::lock_guard<std::mutex> l2(idx->coalescer->mu);
-  idx->coalescer->join_enabled = enabled ? 1 : 0;
-  if (!enabled) idx->coalescer->invalidate(idx->generation);
+  Coalescer* co = get_coalescer(idx);
+  if (!co) return CBH_E_NOMEM;
+  std::lock_guard<std::mutex> l2(co->mu);
+  co->join_enabled = enabled ? 1 : 0;
+  if (!enabled) co->invalidate(idx->generation.load());
   return CBH_OK;
 }

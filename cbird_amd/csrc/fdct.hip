@@ -1,4 +1,5 @@
-// fdct.hip -- DctFeaturesIndex::find on top of the 64-bit scan (host-side aggregation).
+// fdct.hip -- DctFeaturesIndex::find on top of the 64-bit scan; top-10 cut (topk.hip) and vote reduction (reduce.hip)
+// on the device.
 //
 // Reference: src/dctfeaturesindex.cpp:260-358.  The index is a flat multiset of
 // (mediaId, keypoint hash) entries (HammingTree values, src/tree/hammingtree.h:66-74): here a
@@ -14,6 +15,11 @@
 #include <unordered_set>
 
 #include "cbh_index.h"
+
+namespace cbh {
+int g_fdct_host_vote = 0;   // tuning knob "fdct_host_vote": 1 = reduce the votes on the host (round-1 path)
+int g_video_host_reduce = 0;  // tuning knob "video_host_reduce": likewise for DctVideoIndex::findVideo
+}  // namespace cbh
 
 namespace {
 
@@ -125,19 +131,48 @@ int fdct_core(cbh_idx64* idx, const uint64_t* hashes, const std::vector<Needle>&
   rc = scan_all(idx, ws, ws->d_q, nq, thresh, ws->stream, &total, SCAN_KEEP_ID0,
                 tree_compat ? ws->d_qmask : nullptr);
   if (rc) return rc;
-  if ((rc = ws->ensure_sort())) return rc;
-  rc = launch_sort_records(ws->d_rec, ws->d_alt, (size_t)total, nq, ws->d_tmp, ws->tmp_bytes, ws->stream);
+  hipStream_t s = ws->stream;
+  // per needle hash: the first 10 candidates by (distance, id) -- K4 counting select on the workspace block
+  {
+    void* scratch = nullptr;
+    const size_t ncap = std::min<size_t>(ws->rec_cap, (size_t)total + 1);
+    CBH_HIP(hipMallocAsync(&scratch, topk_scratch_bytes(nq, ncap) + 16, s));
+    unsigned* d_status = (unsigned*)((char*)scratch + topk_scratch_bytes(nq, ncap));
+    rc = topk_scratch_init(scratch, nq, s);
+    if (!rc) rc = launch_records_topk(ws->d_total, 1, 0, ncap, nq, k, ws->d_out, ws->d_counts, d_status, scratch, s);
+    (void)hipFreeAsync(scratch, s);
+    if (rc) return rc;
+  }
+  if (g_fdct_host_vote) {  // round-1 path, kept as a second implementation for the parity tests
+    std::vector<cbh_match> top(nq * (size_t)k);
+    std::vector<uint32_t> counts(nq);
+    CBH_HIP(hipMemcpyAsync(top.data(), ws->d_out, top.size() * sizeof(cbh_match), hipMemcpyDeviceToHost, s));
+    CBH_HIP(hipMemcpyAsync(counts.data(), ws->d_counts, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    CBH_HIP(hipStreamSynchronize(s));
+    for (size_t i = 0; i < needles.size(); ++i) vote(top.data(), counts.data(), needles[i], k, &(*results)[i]);
+    return CBH_OK;
+  }
+  // K5 on the device (reduce.hip): votes per (needle image, media), maxMatches, score rule; only results come back
+  std::vector<uint32_t> qneedle(nq), nid(needles.size());
+  for (size_t i = 0; i < needles.size(); ++i) {
+    nid[i] = needles[i].id;
+    for (size_t j = needles[i].begin; j < needles[i].end; ++j) qneedle[j] = (uint32_t)i;
+  }
+  uint32_t *d_qneedle = nullptr, *d_nid = nullptr;
+  hipError_t e = hipMallocAsync((void**)&d_qneedle, nq * 4, s);
+  if (e == hipSuccess) e = hipMallocAsync((void**)&d_nid, std::max<size_t>(1, nid.size()) * 4, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_qneedle, qneedle.data(), nq * 4, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess && !nid.empty()) e = hipMemcpyAsync(d_nid, nid.data(), nid.size() * 4, hipMemcpyHostToDevice, s);
+  std::vector<cbh_nmatch> flat;
+  if (e == hipSuccess) rc = launch_fdct_vote(ws->d_out, ws->d_counts, d_qneedle, nq, k, d_nid, nid.size(), &flat, s);
+  if (d_qneedle) (void)hipFreeAsync(d_qneedle, s);
+  if (d_nid) (void)hipFreeAsync(d_nid, s);
+  CBH_HIP(e);
   if (rc) return rc;
-  rc = launch_select_records(ws->d_rec, (size_t)total, nq, k, ws->d_out, ws->d_counts, ws->stream);
-  if (rc) return rc;
-  std::vector<cbh_match> top(nq * (size_t)k);
-  std::vector<uint32_t> counts(nq);
-  CBH_HIP(hipMemcpyAsync(top.data(), ws->d_out, top.size() * sizeof(cbh_match), hipMemcpyDeviceToHost,
-                         ws->stream));
-  CBH_HIP(hipMemcpyAsync(counts.data(), ws->d_counts, nq * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                         ws->stream));
-  CBH_HIP(hipStreamSynchronize(ws->stream));
-  for (size_t i = 0; i < needles.size(); ++i) vote(top.data(), counts.data(), needles[i], k, &(*results)[i]);
+  std::sort(flat.begin(), flat.end(), [](const cbh_nmatch& a, const cbh_nmatch& b) {
+    return a.needle != b.needle ? a.needle < b.needle : a.id < b.id;  // QMap order: ascending mediaId
+  });
+  for (const cbh_nmatch& m : flat) (*results)[m.needle].push_back(cbh_match{m.id, m.score});
   return CBH_OK;
 }
 

@@ -256,17 +256,17 @@ int topk_scratch_init(void* d_scratch, size_t nq, hipStream_t stream) {
   return CBH_OK;
 }
 
-int launch_records_topk(const unsigned long long* d_blocks, unsigned nb, size_t stride, size_t cap, size_t nq, int k,
-                        cbh_match* d_out, uint32_t* d_counts, unsigned* d_status, void* d_scratch,
-                        hipStream_t stream) {
-  if (nq == 0) return CBH_OK;
+// count -> scan -> scatter: groups the records of the blocks by needle.  On return (stream-ordered) off[0..nq] holds the
+// segment offsets and seg[off[q] .. off[q+1]) the records of needle q as distance<<32 | payload, unordered.
+int launch_records_group(const unsigned long long* d_blocks, unsigned nb, size_t stride, size_t cap, size_t nq,
+                         unsigned* d_status, void* d_scratch, const unsigned** d_off, const unsigned long long** d_seg,
+                         hipStream_t stream) {
   const size_t total_cap = (size_t)nb * cap;
-  if (nq > ((size_t)1 << 25) || total_cap >= ((size_t)1 << 32) || k < 0) return CBH_E_INVAL;
+  if (nq == 0 || nq > ((size_t)1 << 25) || total_cap >= ((size_t)1 << 32)) return CBH_E_INVAL;
   unsigned* cnt = (unsigned*)d_scratch;
   unsigned* off = cnt + nq;
   unsigned* tile = off + nq + 1;
   unsigned* misc = tile + 16384;
-  unsigned* long_list = misc + 4;
   const size_t words = nq + (nq + 1) + 16384 + 4 + nq;
   unsigned long long* seg = (unsigned long long*)((char*)d_scratch + ((words * 4 + 15) & ~(size_t)15));
   const unsigned nt = (unsigned)((nq + kScanTile - 1) / kScanTile);
@@ -281,6 +281,23 @@ int launch_records_topk(const unsigned long long* d_blocks, unsigned nb, size_t 
   if (total_cap)
     hipLaunchKernelGGL(k_topk_scatter, dim3(gslots), dim3(256), 0, stream, d_blocks, nb, stride, cap, (unsigned)nq,
                        cnt, off, seg);
+  CBH_HIP(hipGetLastError());
+  if (d_off) *d_off = off;
+  if (d_seg) *d_seg = seg;
+  return CBH_OK;
+}
+
+int launch_records_topk(const unsigned long long* d_blocks, unsigned nb, size_t stride, size_t cap, size_t nq, int k,
+                        cbh_match* d_out, uint32_t* d_counts, unsigned* d_status, void* d_scratch,
+                        hipStream_t stream) {
+  if (nq == 0) return CBH_OK;
+  if (k < 0) return CBH_E_INVAL;
+  const unsigned* off = nullptr;
+  const unsigned long long* seg = nullptr;
+  int rc = launch_records_group(d_blocks, nb, stride, cap, nq, d_status, d_scratch, &off, &seg, stream);
+  if (rc) return rc;
+  unsigned* misc = (unsigned*)d_scratch + nq + (nq + 1) + 16384;
+  unsigned* long_list = misc + 4;
   hipLaunchKernelGGL(k_topk_select, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, seg, off, (unsigned)nq,
                      k, d_out, d_counts, long_list, misc + 1);
   if (k > 0)

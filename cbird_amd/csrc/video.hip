@@ -6,7 +6,8 @@
 // buildTree :113-170).  Here the structure is a cbh_idx64 whose payload is the entry position; the
 // (video index, frame) pair of an entry stays on the host.  Searches are exact (the reference's
 // vradix=0 behaviour, used by its own test unit/testdctvideoindex.cpp:24); vradix>0 only ever returns
-// a subset of this.
+// a subset of this.  findVideo's reductions (closest frame per video, adjacency scoring) run on the device
+// (reduce.hip); the host versions below remain as a second implementation (knob "video_host_reduce").
 #include <map>
 #include <unordered_map>
 
@@ -26,6 +27,10 @@ struct cbh_vidx {
   cbh_idx64* idx = nullptr;
   std::vector<uint32_t> evidx;   // entry -> video index
   std::vector<int32_t> eframe;   // entry -> frame number
+  // device copies for the on-device reduction (reduce.hip): entry -> video index / frame, video index -> mediaId
+  uint32_t* d_evidx = nullptr;
+  int32_t* d_eframe = nullptr;
+  uint32_t* d_vmedia = nullptr;
   std::mutex build_mu;           // QMutex _mutex (dctvideoindex.cpp:118)
   // 0 = exact search.  > 0 = RadixMap-compatible: a needle hash only sees the entries of its bucket
   // (hash >> 1) & (2^radix - 1) (src/tree/radix.h:135-141), like `-p.vradix N` in the reference.
@@ -65,6 +70,24 @@ int build(cbh_vidx* v, int skip) {
   if (!v->idx) return CBH_E_NODEVICE;
   int rc = cbh_idx64_load(v->idx, hashes.data(), ids.data(), hashes.size());
   if (rc) return rc;
+  {
+    DeviceGuard g(v->device);
+    if (!g.ok) return CBH_E_NODEVICE;
+    for (void* p : {(void*)v->d_evidx, (void*)v->d_eframe, (void*)v->d_vmedia})
+      if (p) (void)hipFree(p);
+    v->d_evidx = nullptr, v->d_eframe = nullptr, v->d_vmedia = nullptr;
+    const size_t ne = std::max<size_t>(1, v->evidx.size()), nv = std::max<size_t>(1, v->videos.size());
+    std::vector<uint32_t> vmedia(v->videos.size());
+    for (size_t i = 0; i < v->videos.size(); ++i) vmedia[i] = v->videos[i].media_id;
+    CBH_HIP(hipMalloc(&v->d_evidx, ne * 4));
+    CBH_HIP(hipMalloc(&v->d_eframe, ne * 4));
+    CBH_HIP(hipMalloc(&v->d_vmedia, nv * 4));
+    if (!v->evidx.empty()) {
+      CBH_HIP(hipMemcpy(v->d_evidx, v->evidx.data(), v->evidx.size() * 4, hipMemcpyHostToDevice));
+      CBH_HIP(hipMemcpy(v->d_eframe, v->eframe.data(), v->eframe.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (!vmedia.empty()) CBH_HIP(hipMemcpy(v->d_vmedia, vmedia.data(), vmedia.size() * 4, hipMemcpyHostToDevice));
+  }
   v->built = true;
   v->built_skip = skip;
   return CBH_OK;
@@ -144,6 +167,70 @@ struct VNeedle {
   uint32_t id;
 };
 
+// scan -> group per needle frame (topk.hip) -> K8 on the device (reduce.hip): closest frame per video, adjacency
+// scoring, gates.  Only the final matches come back.
+int reduce_on_device(cbh_vidx* v, const std::vector<uint64_t>& q, const std::vector<int32_t>& qframe,
+                     const std::vector<uint32_t>& qneedle, const std::vector<VNeedle>& needles, int thresh,
+                     int min_matched, int min_near, int filter_self, std::vector<std::vector<cbh_vmatch>>* results) {
+  cbh_idx64* idx = v->idx;
+  const size_t nq = q.size();
+  if (nq == 0 || idx->n == 0 || thresh <= 0) return CBH_OK;
+  if (nq > CBH_MAX_QUERIES_PER_CALL) return CBH_E_INVAL;
+  DeviceGuard g(idx->device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  int rc;
+  WsLease L(idx, &rc);
+  if (!L.ws) return rc;
+  Workspace* ws = L.ws;
+  hipStream_t s = ws->stream;
+  if ((rc = Workspace::grow(&ws->d_q, &ws->q_cap, nq))) return rc;
+  CBH_HIP(hipMemcpyAsync(ws->d_q, q.data(), nq * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+  std::vector<uint64_t> masks;
+  if (v->radix) {  // equal bucket <=> equal bits 1..radix
+    masks.assign(nq, ((1ull << v->radix) - 1) << 1);
+    if ((rc = Workspace::grow(&ws->d_qmask, &ws->qmask_cap, nq))) return rc;
+    CBH_HIP(hipMemcpyAsync(ws->d_qmask, masks.data(), nq * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+  }
+  unsigned long long total = 0;
+  rc = scan_all(idx, ws, ws->d_q, nq, thresh, s, &total, 0, v->radix ? ws->d_qmask : nullptr);
+  if (rc) return rc;
+  if (total == 0) return CBH_OK;
+  if (total >= (1ull << 32)) return CBH_E_OVERFLOW;
+  std::vector<uint32_t> nid(needles.size());
+  for (size_t i = 0; i < needles.size(); ++i) nid[i] = needles[i].id;
+  void* scratch = nullptr;
+  uint32_t *d_qneedle = nullptr, *d_nid = nullptr;
+  int32_t* d_qframe = nullptr;
+  const size_t sbytes = topk_scratch_bytes(nq, (size_t)total);
+  hipError_t e = hipMallocAsync(&scratch, sbytes + 16, s);
+  if (e == hipSuccess) e = hipMallocAsync((void**)&d_qneedle, nq * 4, s);
+  if (e == hipSuccess) e = hipMallocAsync((void**)&d_qframe, nq * 4, s);
+  if (e == hipSuccess) e = hipMallocAsync((void**)&d_nid, nid.size() * 4, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_qneedle, qneedle.data(), nq * 4, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_qframe, qframe.data(), nq * 4, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_nid, nid.data(), nid.size() * 4, hipMemcpyHostToDevice, s);
+  std::vector<cbh_nvmatch> flat;
+  if (e == hipSuccess) {
+    const unsigned* d_off = nullptr;
+    const unsigned long long* d_seg = nullptr;
+    unsigned* d_status = (unsigned*)((char*)scratch + sbytes);
+    rc = topk_scratch_init(scratch, nq, s);
+    if (!rc) rc = launch_records_group(ws->d_total, 1, 0, (size_t)total, nq, d_status, scratch, &d_off, &d_seg, s);
+    if (!rc)
+      rc = launch_video_reduce(d_off, d_seg, (size_t)total, nq, v->d_evidx, v->d_eframe, v->d_vmedia, d_qneedle, d_qframe,
+                               d_nid, filter_self, min_matched, min_near, &flat, s);
+  }
+  for (void* p : {scratch, (void*)d_qneedle, (void*)d_qframe, (void*)d_nid})
+    if (p) (void)hipFreeAsync(p, s);
+  CBH_HIP(e);
+  if (rc) return rc;
+  std::sort(flat.begin(), flat.end(), [](const cbh_nvmatch& a, const cbh_nvmatch& b) {
+    return a.needle != b.needle ? a.needle < b.needle : a.m.id < b.m.id;  // std::map order: ascending mediaId
+  });
+  for (const cbh_nvmatch& m : flat) (*results)[m.needle].push_back(m.m);
+  return CBH_OK;
+}
+
 int find_videos(cbh_vidx* v, const int32_t* frames, const uint64_t* hashes, const std::vector<VNeedle>& needles,
                 int thresh, int skip, int min_matched, int min_near, int filter_self,
                 std::vector<std::vector<cbh_vmatch>>* results) {
@@ -165,6 +252,8 @@ int find_videos(cbh_vidx* v, const int32_t* frames, const uint64_t* hashes, cons
       qneedle.push_back((uint32_t)k);
     }
   }
+  if (!g_video_host_reduce) return reduce_on_device(v, q, qframe, qneedle, needles, thresh, min_matched, min_near,
+                                                    filter_self, results);
   std::vector<cbh_record> recs;
   rc = scan_to_host(v, q.data(), q.size(), thresh, &recs);
   if (rc) return rc;
@@ -210,6 +299,8 @@ int cbh_vidx_set_radix(cbh_vidx* v, int radix) {
 void cbh_vidx_destroy(cbh_vidx* v) {
   if (!v) return;
   if (v->idx) cbh_idx64_destroy(v->idx);
+  for (void* p : {(void*)v->d_evidx, (void*)v->d_eframe, (void*)v->d_vmedia})
+    if (p) (void)hipFree(p);
   delete v;
 }
 

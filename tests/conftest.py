@@ -71,6 +71,21 @@ def hash_dct(request, gpu, orc):
     orc.set_hash_variant(1)
 
 
+@pytest.fixture(params=["device", "host"])
+def reduce_path(request, gpu):
+    """DctFeaturesIndex / DctVideoIndex finds with their per-needle reductions on the device (reduce.hip: K5 votes,
+    K8 closest frame + adjacency; the shipped path) and on the host (the round-1 std::map loops, knobs
+    "fdct_host_vote" / "video_host_reduce"): two implementations, one oracle."""
+    from cbird_amd import _lib
+
+    v = 1 if request.param == "host" else 0
+    _lib.lib().cbh_set_tuning(b"fdct_host_vote", v)
+    _lib.lib().cbh_set_tuning(b"video_host_reduce", v)
+    yield request.param
+    _lib.lib().cbh_set_tuning(b"fdct_host_vote", 0)
+    _lib.lib().cbh_set_tuning(b"video_host_reduce", 0)
+
+
 def load_golden(name):
     return np.load(os.path.join(ROOT, "tests", "golden", name))
 

@@ -52,16 +52,11 @@ int main(int argc, char** argv) {
   const double t_batch = now() - t0;
   // T threads, one synchronous find() per needle
   std::vector<QVector<Index::Match>> got(total);
-  std::atomic<size_t> next{0};
   t0 = now();
   std::vector<std::thread> th;
   for (int t = 0; t < T; ++t)
-    th.emplace_back([&] {
-      for (;;) {
-        const size_t i = next.fetch_add(1);
-        if (i >= total) return;
-        got[i] = idx.find(needles[int(i)], p);
-      }
+    th.emplace_back([&, t] {  // needle i goes to thread i mod T, as a work-sharing pool would interleave them
+      for (size_t i = size_t(t); i < total; i += size_t(T)) got[i] = idx.find(needles[int(i)], p);
     });
   for (auto& x : th) x.join();
   const double t_find = now() - t0;

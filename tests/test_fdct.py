@@ -71,7 +71,7 @@ def test_score_rules(orc):
 
 
 @pytest.mark.gpu
-def test_gpu_matches_golden_and_oracle(gpu, orc, scan_path):
+def test_gpu_matches_golden_and_oracle(gpu, orc, scan_path, reduce_path):
     g = load_golden("fdct_single_leaf.npz")
     idx = gpu.DctFeaturesIndex()
     h, ids = g["hashes"], g["ids"]
@@ -87,7 +87,7 @@ def test_gpu_matches_golden_and_oracle(gpu, orc, scan_path):
 
 
 @pytest.mark.gpu
-def test_gpu_add_remove_findindex_batch(gpu, orc, scan_path):
+def test_gpu_add_remove_findindex_batch(gpu, orc, scan_path, reduce_path):
     from cbird_amd import synth
 
     m, k = 300, 120  # 36k entries: beyond a single reference leaf, exact vs oracle
@@ -153,7 +153,7 @@ def test_leaf_mask_rule_reproduces_real_multileaf_tree(orc):
 
 
 @pytest.mark.gpu
-def test_gpu_tree_compatible_mode_equals_real_multileaf_tree(gpu, orc, scan_path):
+def test_gpu_tree_compatible_mode_equals_real_multileaf_tree(gpu, orc, scan_path, reduce_path):
     g = load_golden("fdct_multileaf.npz")
     h, ids, q, thr = g["hashes"], g["ids"], g["cand_q"], int(g["cand_thresh"])
     raw = gpu.DctHashIndex()

@@ -147,7 +147,7 @@ def _mk_index(gpu, clips, first_id=100):
 
 
 @pytest.mark.gpu
-def test_gpu_find_video_and_frame_vs_oracle(gpu, vorc):
+def test_gpu_find_video_and_frame_vs_oracle(gpu, vorc, reduce_path):
     from cbird_amd import synth_video
     from cbird_amd.video import VideoSearchParams
 
@@ -179,7 +179,7 @@ def test_gpu_find_video_and_frame_vs_oracle(gpu, vorc):
 
 
 @pytest.mark.gpu
-def test_gpu_video_batch_remove_add(gpu, vorc):
+def test_gpu_video_batch_remove_add(gpu, vorc, reduce_path):
     from cbird_amd import synth_video
     from cbird_amd.video import VideoSearchParams
 
@@ -200,7 +200,7 @@ def test_gpu_video_batch_remove_add(gpu, vorc):
 
 
 @pytest.mark.gpu
-def test_gpu_radix_compatible_mode_equals_bucket_search(gpu, vorc):
+def test_gpu_radix_compatible_mode_equals_bucket_search(gpu, vorc, reduce_path):
     """`-p.vradix N` of the reference: a needle frame only sees its RadixMap bucket.  The oracle's bucket rule is
     pinned to the real RadixMap (test_oracle_candidates_vs_real_radixmap); DctVideoIndex(radix_compat=True) must
     equal it, and differ from the exact search where the exact search finds more."""
