@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline time budget")
+    ap.add_argument("--no-video", action="store_true", help="skip the configs[4] leg (DctVideoIndex sharded by video)")
+    ap.add_argument("--video-clips", type=int, default=10_000)
     return ap.parse_args()
 
 
@@ -276,6 +278,8 @@ def main():
         except Exception:
             pass
 
+    if not args.no_video:
+        result["configs4_video"] = video_leg(args, torch, dist, dev, local_rank, rank, world, share)
     if rank == 0 and world == 1:
         # outside the timed region, for the record: the same launches on the popcount (VALU) kernel
         # k_hamm64_scan that the matrix-core kernel replaced (identical records; tests/test_gpu_hamm.py)
@@ -303,6 +307,61 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def video_leg(args, torch, dist, dev, local_rank, rank, world, share):
+    """BASELINE configs[4], reported beside the contract line (never part of `value`): 10k synthetic clips x 300 frame
+    hashes in a DctVideoIndex sharded BY VIDEO over the ranks (cbird_amd.dist.ShardedDctVideoIndex, SURVEY.md 8e);
+    2000 needle clips (the 1 % planted sub-clips among them) replicated, one batched findVideo per rank -- scan,
+    closest frame per video and adjacency scoring on the device -- and ONE all-gather of the final matches.
+    dht 5, vtrim 0, vfm 30, vfn 60, exact search (vradix 0).  Time = max over ranks, barrier on both sides."""
+    from cbird_amd import synth_video
+    from cbird_amd.dist import ShardedDctVideoIndex
+    from cbird_amd.video import DctVideoIndex, VideoIndex, VideoSearchParams
+
+    clips = synth_video.make_clips_fast(args.video_clips, 300, seed=args.seed, subclip_frac=0.01, max_gap=8)
+
+    class M:
+        pass
+
+    media = []
+    for i, (f, h) in enumerate(clips):
+        m = M()
+        m.id, m.path, m.videoIndex, m.dctHash = i + 1, "", VideoIndex(f, h), 0
+        media.append(m)
+    sv = ShardedDctVideoIndex(lambda: DctVideoIndex(local_rank), device=None if (share or world == 1) else dev)
+    t0 = time.perf_counter()
+    sv.add(media)
+    p = VideoSearchParams(dctThresh=5, skipFrames=0, minFramesMatched=30, minFramesNear=60)
+    needles = media[-min(2000, len(media)):]
+    sv.find_videos_batch(needles[:64], p)  # builds the shard's search structure, warms the kernels
+    t_build = time.perf_counter() - t0
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    best, hits = None, 0
+    for _ in range(3):
+        fence()
+        t0 = time.perf_counter()
+        res = sv.find_videos_batch(needles, p)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        best = dt if best is None else min(best, dt)
+        hits = sum(len(r) for r in res)
+    entries = sum(len(f) for f, _ in clips)  # (a few low-detail hashes are filtered at insert; within 0.1 %)
+    nframes = sum(len(m.videoIndex.frames) for m in needles)
+    return {"workload": "configs[4]: DctVideoIndex, %d clips x 300 frame hashes, %d needle clips batched, dht 5, "
+                        "vfm 30, vfn 60, vradix 0" % (len(clips), len(needles)),
+            "parallelism": f"sharded by video x{world}, needles replicated, one all-gather of final matches",
+            "seconds": best, "needle_clips_per_s": len(needles) / best,
+            "cmp_per_s": float(entries) * nframes / best, "matches": hits, "build_seconds_this_rank": t_build}
 
 
 def cpu_baseline(args, torch, imgs, state, n, dhts):

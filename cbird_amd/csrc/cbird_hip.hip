@@ -819,11 +819,11 @@ int cbh_set_tuning(const char* key, int value) {
     return CBH_OK;
   }
   if (!strcmp(key, "fdct_host_vote")) {
-    g_fdct_host_vote = value ? 1 : 0;
+    g_fdct_host_vote = value;
     return CBH_OK;
   }
   if (!strcmp(key, "video_host_reduce")) {
-    g_video_host_reduce = value ? 1 : 0;
+    g_video_host_reduce = value;
     return CBH_OK;
   }
   if (!strcmp(key, "hash_dct")) {

@@ -282,15 +282,16 @@ int knn_core(cbh_idx256* ix, const uint8_t* needles, size_t nq, int k, int thres
   return CBH_OK;
 }
 
-// votes and scores of one needle image (cvfeaturesindex.cpp:499-596)
-void score256(const cbh_idx256* ix, const uint32_t* row, const uint16_t* dist, const uint32_t* counts, size_t d0,
-              size_t d1, int k, std::vector<cbh_match>* out) {
+// votes and scores of one needle image (cvfeaturesindex.cpp:499-596) from a knn table that already carries the
+// mediaId of every candidate (0 = deleted/removed item, :518)
+void score_media(const uint32_t* media, const uint16_t* dist, const uint32_t* counts, size_t d0, size_t d1, int k,
+                 std::vector<cbh_match>* out) {
   std::map<uint32_t, std::vector<int>> matches;  // QMap<uint32_t, Match_>: ascending mediaId
   for (size_t j = d0; j < d1; ++j) {
     const uint32_t len = std::min<uint32_t>((uint32_t)k, counts[j]);
     for (uint32_t t = 0; t < len; ++t) {
-      const uint32_t mediaId = ix->media_of_row(row[j * (size_t)k + t]);
-      if (!mediaId) continue;  // deleted/removed item (:518)
+      const uint32_t mediaId = media[j * (size_t)k + t];
+      if (!mediaId) continue;
       matches[mediaId].push_back((int)dist[j * (size_t)k + t]);
     }
   }
@@ -308,6 +309,16 @@ void score256(const cbh_idx256* ix, const uint32_t* row, const uint16_t* dist, c
     score = score * 1000 / (int)scores.size();
     out->push_back(cbh_match{kv.first, score});
   }
+}
+
+void score256(const cbh_idx256* ix, const uint32_t* row, const uint16_t* dist, const uint32_t* counts, size_t d0,
+              size_t d1, int k, std::vector<cbh_match>* out) {
+  std::vector<uint32_t> media((d1 - d0) * (size_t)k, 0);
+  for (size_t j = d0; j < d1; ++j) {
+    const uint32_t len = std::min<uint32_t>((uint32_t)k, counts[j]);
+    for (uint32_t t = 0; t < len; ++t) media[(j - d0) * (size_t)k + t] = ix->media_of_row(row[j * (size_t)k + t]);
+  }
+  score_media(media.data(), dist + d0 * (size_t)k, counts + d0, 0, d1 - d0, k, out);
 }
 
 }  // namespace
@@ -420,6 +431,41 @@ int cbh_idx256_knn(cbh_idx256* ix, const uint8_t* needles, size_t nq, int k, int
   memcpy(out_dist, dist.data(), dist.size() * 2);
   memcpy(counts, cnt.data(), cnt.size() * 4);
   return CBH_OK;
+}
+
+/* knn + the mediaId of every candidate row (0 = removed): the shard-local step of the multi-GPU path, where the
+ * first-row -> mediaId map is local to the shard */
+int cbh_idx256_knn_media(cbh_idx256* ix, const uint8_t* needles, size_t nq, int k, int thresh, uint32_t* out_row,
+                         uint16_t* out_dist, uint32_t* out_media, uint32_t* counts) {
+  if (!ix || (nq && (!needles || !out_row || !out_dist || !out_media || !counts))) return CBH_E_INVAL;
+  int rc = cbh_idx256_knn(ix, needles, nq, k, thresh, out_row, out_dist, counts);
+  if (rc) return rc;
+  for (size_t j = 0; j < nq; ++j) {
+    const uint32_t len = std::min<uint32_t>((uint32_t)std::max(k, 0), counts[j]);
+    for (uint32_t t = 0; t < (uint32_t)std::max(k, 0); ++t)
+      out_media[j * (size_t)k + t] = t < len ? ix->media_of_row(out_row[j * (size_t)k + t]) : 0u;
+  }
+  return CBH_OK;
+}
+
+/* the scoring half of find() (:499-596) on a knn table with mediaIds (host code): what every rank runs on the
+ * merged candidate lists in the multi-GPU path */
+int cbh_cvfeatures_score(const uint32_t* media, const uint16_t* dist, const uint32_t* counts, const uint64_t* offsets,
+                         size_t n_needles, int k, cbh_match* out, size_t cap, uint64_t* out_offsets) {
+  if (!offsets || !out_offsets || (cap && !out) || k <= 0) return CBH_E_INVAL;
+  if (n_needles && offsets[n_needles] && (!media || !dist || !counts)) return CBH_E_INVAL;
+  uint64_t pos = 0;
+  for (size_t i = 0; i < n_needles; ++i) {
+    out_offsets[i] = pos;
+    std::vector<cbh_match> res;
+    score_media(media, dist, counts, (size_t)offsets[i], (size_t)offsets[i + 1], k, &res);
+    for (auto& m : res) {
+      if (pos < cap) out[pos] = m;
+      ++pos;
+    }
+  }
+  out_offsets[n_needles] = pos;
+  return pos > cap ? CBH_E_OVERFLOW : CBH_OK;
 }
 
 /* CvFeaturesIndex::find (:438-604) for one needle with n_desc descriptor rows */

@@ -252,7 +252,8 @@ int find_videos(cbh_vidx* v, const int32_t* frames, const uint64_t* hashes, cons
       qneedle.push_back((uint32_t)k);
     }
   }
-  if (!g_video_host_reduce) return reduce_on_device(v, q, qframe, qneedle, needles, thresh, min_matched, min_near,
+  if (g_video_host_reduce == 2 || (g_video_host_reduce == 0 && needles.size() > 1))
+    return reduce_on_device(v, q, qframe, qneedle, needles, thresh, min_matched, min_near,
                                                     filter_self, results);
   std::vector<cbh_record> recs;
   rc = scan_to_host(v, q.data(), q.size(), thresh, &recs);

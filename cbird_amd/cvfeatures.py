@@ -91,6 +91,18 @@ class CvFeaturesIndex:
                                      dist.ctypes.data, cnt.ctypes.data), "knn")
         return row, dist, cnt
 
+    def knn_media(self, needles, k: int, thresh: int):
+        """knn + the mediaId of every candidate row (0 = removed): the shard-local step of ShardedCvFeaturesIndex"""
+        d = self._rows(needles)
+        nq = len(d)
+        row = np.zeros((nq, k), np.uint32)
+        dist = np.zeros((nq, k), np.uint16)
+        media = np.zeros((nq, k), np.uint32)
+        cnt = np.zeros(nq, np.uint32)
+        check(self._L.cbh_idx256_knn_media(self._h, d.ctypes.data, nq, k, int(thresh), row.ctypes.data,
+                                           dist.ctypes.data, media.ctypes.data, cnt.ctypes.data), "knn_media")
+        return row, dist, media, cnt
+
     def radius_match(self, queries, max_dist: int):
         """cv::BFMatcher(NORM_HAMMING).radiusMatch(queries, matches, max_dist) with the index rows as the train set
         (TemplateMatcher, src/templatematcher.cpp:134,217).  Returns (matches int32 [m, 3] = queryIdx, trainIdx,

@@ -309,6 +309,142 @@ class ShardedDctHashIndex:
         return results
 
 
+def _gather_rows(rows, group=None, device=None, cap0: int = 4096):
+    """All ranks' int32 row lists [n_r, w] -> one array, ranks in order.  ONE fixed-size all_gather_into_tensor with the
+    row count in word 0 of every block (the exchange pattern of ShardedDctHashIndex); a block that would not fit is
+    noticed by every rank from the gathered counts and the gather is redone with larger blocks.  `device`: torch
+    device the collective runs on (RCCL needs device tensors; gloo takes host tensors)."""
+    import numpy as np
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rows = np.ascontiguousarray(rows, np.int32)
+    n, w = rows.shape
+    if world == 1:
+        return rows
+    cap = cap0  # the same on every rank; grows to the largest count seen (also the same on every rank)
+    while True:
+        blk = torch.zeros(1 + cap * w, dtype=torch.int32)
+        blk[0] = n
+        m = min(n, cap)
+        blk[1: 1 + m * w] = torch.from_numpy(rows[:m].reshape(-1))
+        src = blk if device is None else blk.to(device)
+        out = torch.empty((1 + cap * w) * world, dtype=torch.int32, device=src.device)
+        dist.all_gather_into_tensor(out, src, group=group)
+        o = out.cpu().numpy().reshape(world, 1 + cap * w)
+        counts = o[:, 0]
+        if int(counts.max()) <= cap:
+            return np.concatenate([o[r, 1: 1 + int(counts[r]) * w].reshape(-1, w) for r in range(world)])
+        cap = int(counts.max())  # same value on every rank
+
+
+class ShardedDctVideoIndex:
+    """DctVideoIndex sharded BY VIDEO: rank r holds the videos [r*V/R, (r+1)*V/R) of the load order, so
+    the closest-frame-per-video reduce and the adjacency scoring of findVideo are local to the shard that owns the
+    video.  Needles are replicated; every rank searches all of them against its videos (one batched launch), and
+    ONE all-gather of the final matches (needle, mediaId, score, range: 24 bytes each) gives every rank the complete
+    result.  A union of disjoint video sets ordered by mediaId is exactly the single-index result
+    (src/dctvideoindex.cpp:475-509,595-654 emit per video, in std::map<mediaId> order)."""
+
+    def __init__(self, make_index, group=None, device=None) -> None:
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.index = make_index()  # a cbird_amd.video.DctVideoIndex (or a stand-in with add / find_videos_batch)
+        self.device = device
+
+    def add(self, media) -> None:
+        """every rank is handed the same list; it keeps its contiguous share"""
+        media = list(media)
+        a, b = ShardedDctHashIndex.shard_range(len(media), self.rank, self.world)
+        self.index.add(media[a:b])
+
+    def find_videos_batch(self, needles, p):
+        import numpy as np
+
+        from .index import Match, MatchRange
+
+        needles = list(needles)
+        local = self.index.find_videos_batch(needles, p)
+        rows = np.array([(k, m.mediaId, m.score, m.range.srcIn, m.range.dstIn, m.range.len)
+                         for k, r in enumerate(local) for m in r], np.int64).reshape(-1, 6)
+        rows = rows.astype(np.uint32).view(np.int32) if len(rows) else np.zeros((0, 6), np.int32)
+        allr = _gather_rows(rows, self.group, self.device)
+        out = [[] for _ in needles]
+        ids = allr[:, 1].view(np.uint32)
+        for i in np.lexsort((ids, allr[:, 0])):  # by needle, then ascending mediaId
+            r = allr[i]
+            out[int(r[0])].append(Match(int(ids[i]), int(r[2]), MatchRange(int(r[3]), int(r[4]), int(r[5]))))
+        return out
+
+
+class ShardedCvFeaturesIndex:
+    """CvFeaturesIndex sharded BY IMAGE: rank r holds the descriptor rows of its images, so the
+    first-row -> mediaId map is local.  Per needle descriptor every rank computes its local k nearest rows
+    (distance, global row, mediaId); one all-gather of those fixed-size tables, a k-way merge of the R sorted lists per
+    descriptor by (distance, global row) -- the order of the unsharded knn -- and the reference's scoring
+    (src/cvfeaturesindex.cpp:499-596, cbh_cvfeatures_score) on the merged table, identically on every rank."""
+
+    def __init__(self, make_index, group=None, device=None) -> None:
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.index = make_index()  # a cbird_amd.cvfeatures.CvFeaturesIndex (or a stand-in with add / knn_media / count)
+        self.device = device
+        self.row_offset = 0
+
+    def add(self, media) -> None:
+        """every rank is handed the same list (ascending media id, as load() does); it keeps its contiguous share and
+        remembers how many rows the ranks before it hold (global row = local row + offset: the tie-break of the knn)"""
+        media = list(media)
+        a, b = ShardedDctHashIndex.shard_range(len(media), self.rank, self.world)
+        self.row_offset = sum(len(m.keyPointDescriptors) for m in media[:a])
+        self.index.add(media[a:b])
+
+    def find_batch(self, needles, p, knn: int = 10):
+        import numpy as np
+
+        from .index import Match
+
+        needles = list(needles)
+        rows = [np.ascontiguousarray(m.keyPointDescriptors, np.uint8).reshape(-1, 32) for m in needles]
+        offs = np.zeros(len(needles) + 1, np.uint64)
+        np.cumsum([len(r) for r in rows], out=offs[1:])
+        allq = np.concatenate(rows) if rows else np.zeros((0, 32), np.uint8)
+        nq = len(allq)
+        row, dst, media, cnt = self.index.knn_media(allq, knn, int(p.cvThresh))
+        # sortable key per candidate: distance << 40 | global row; empty places sort last
+        key = (dst.astype(np.int64) << 40) | (row.astype(np.int64) + self.row_offset)
+        key[np.arange(knn)[None, :] >= np.minimum(cnt, knn)[:, None]] = np.iinfo(np.int64).max
+        if self.world > 1:
+            tab = np.concatenate([key.view(np.int32).reshape(nq, -1), media.view(np.int32),
+                                  cnt.view(np.int32)[:, None]], 1)  # [nq, 2k + k + 1] int32, fixed size
+            t = torch.from_numpy(np.ascontiguousarray(tab)).reshape(-1)
+            src = t if self.device is None else t.to(self.device)
+            out = torch.empty(self.world * t.numel(), dtype=torch.int32, device=src.device)
+            dist.all_gather_into_tensor(out, src, group=self.group)
+            o = out.cpu().numpy().reshape(self.world, nq, 3 * knn + 1)
+            keys = np.ascontiguousarray(o[:, :, : 2 * knn]).view(np.int64)  # [R, nq, k]
+            medias = o[:, :, 2 * knn: 3 * knn].view(np.uint32)
+            cnts = o[:, :, 3 * knn].view(np.uint32).astype(np.int64).sum(0)
+            keys = np.moveaxis(keys, 0, 1).reshape(nq, -1)  # [nq, R*k]
+            medias = np.moveaxis(medias, 0, 1).reshape(nq, -1)
+            order = np.argsort(keys, axis=1, kind="stable")[:, :knn]
+            key = np.take_along_axis(keys, order, 1)
+            media = np.take_along_axis(medias, order, 1)
+            cnt = np.minimum(cnts, np.iinfo(np.uint32).max).astype(np.uint32)
+        dst = np.where(key == np.iinfo(np.int64).max, 0, key >> 40).astype(np.uint16)
+        media = np.ascontiguousarray(media, np.uint32)
+        cnt = np.ascontiguousarray(np.minimum(cnt, knn), np.uint32)  # places filled in the merged table
+        L = _lib.lib()
+        cap = nq * knn + 1
+        buf = (_lib.cbh_match * cap)()
+        out_offs = np.zeros(len(needles) + 1, np.uint64)
+        _lib.check(L.cbh_cvfeatures_score(media.ctypes.data, np.ascontiguousarray(dst).ctypes.data, cnt.ctypes.data,
+                                          offs.ctypes.data, len(needles), knn, buf, cap, out_offs.ctypes.data), "score")
+        return [[Match(buf[j].id, buf[j].score) for j in range(int(out_offs[i]), int(out_offs[i + 1]))]
+                for i in range(len(needles))]
+
+
 class NeedleParallel:
     """Data parallelism over needles, the reference's own strategy (QtConcurrent::map over the haystack items,
     src/database.cpp:1400-1432) across processes instead of threads: every rank holds the whole index (the

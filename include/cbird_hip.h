@@ -354,6 +354,13 @@ int cbh_idx256_download_rows(const cbh_idx256*, size_t first, size_t count, uint
  * rows under thresh.  nq < 2^23. */
 int cbh_idx256_knn(cbh_idx256*, const uint8_t* needles, size_t nq, int k, int thresh, uint32_t* out_row,
                    uint16_t* out_dist, uint32_t* counts);
+/* Multi-GPU halves of find() (shard by image): the knn table with the mediaId of every candidate row
+ * (0 = removed; the first-row -> mediaId map is shard-local), and the scoring of a (merged) table -- votes per media,
+ * median distance * 1000 / votes (:499-596; host code), needle i owning table rows [offsets[i], offsets[i+1]). */
+int cbh_idx256_knn_media(cbh_idx256*, const uint8_t* needles, size_t nq, int k, int thresh, uint32_t* out_row,
+                         uint16_t* out_dist, uint32_t* out_media, uint32_t* counts);
+int cbh_cvfeatures_score(const uint32_t* media, const uint16_t* dist, const uint32_t* counts, const uint64_t* offsets,
+                         size_t n_needles, int k, cbh_match* out, size_t cap, uint64_t* out_offsets);
 /* find() (:438-604): knn k (reference: 10) per needle descriptor, distance < thresh (cvThresh), votes per
  * media, score = median distance * 1000 / votes; results ascending mediaId. */
 int cbh_idx256_find(cbh_idx256*, const uint8_t* needle_rows, size_t n_desc, int thresh, int k, cbh_match* out,

@@ -78,7 +78,7 @@ def reduce_path(request, gpu):
     "fdct_host_vote" / "video_host_reduce"): two implementations, one oracle."""
     from cbird_amd import _lib
 
-    v = 1 if request.param == "host" else 0
+    v = 1 if request.param == "host" else 2  # (0 = auto: device for batches, host for a single needle)
     _lib.lib().cbh_set_tuning(b"fdct_host_vote", v)
     _lib.lib().cbh_set_tuning(b"video_host_reduce", v)
     yield request.param
