@@ -104,6 +104,14 @@ class ColorDescIndex:
         check(self._L.cbh_color_find(self._h, t.ctypes.data, buf, cap, C.byref(n)), "find")
         return [Match(buf[i].id, buf[i].score) for i in range(n.value)]
 
+    def distances(self, descs) -> np.ndarray:
+        """ColorDescriptor::distance (cvutil.cpp:682-749) of every given needle descriptor against every index entry
+        (add order), as float32 [nq, count]; FLT_MAX where the reference returns FLT_MAX"""
+        d = np.ascontiguousarray(descs, COLOR_DTYPE).reshape(-1)
+        out = np.zeros((len(d), self.count()), np.float32)
+        check(self._L.cbh_color_distances(self._h, d.ctypes.data, len(d), out.ctypes.data), "color_distances")
+        return out
+
     def find_batch(self, descs, k: int):
         d = np.ascontiguousarray(np.asarray(descs, COLOR_DTYPE).reshape(-1))
         nq = len(d)

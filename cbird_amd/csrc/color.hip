@@ -27,18 +27,24 @@ namespace {
 constexpr int kNC = 32;  // ColorDescriptor::NUM_DESC_COLORS
 constexpr size_t kDescBytes = 258;
 
-struct NeedleF {
+struct alignas(16) NeedleF {  // 400 bytes: k_color_dist3 reads the components as float4
   float l[kNC], u[kNC], v[kNC];
   int num;
 };
+
+// Launch geometry of the three distance kernels: blockIdx.x = NEEDLE (fastest), blockIdx.y/z = haystack tile.  The
+// workgroups that run together then share one tile: it comes from HBM once per XCD instead of once per needle (with
+// the tile fastest, 64 needles re-streamed a 384 MB index 64 times -- 1.8 TB/s of traffic that held every variant of
+// the kernel at ~14 ms whatever its instruction mix).
+__device__ __forceinline__ uint32_t color_tile() { return blockIdx.y + blockIdx.z * 32768u; }
 
 __global__ __launch_bounds__(256) void k_color_dist(const float* __restrict__ L, const float* __restrict__ U,
                                                     const float* __restrict__ V,
                                                     const unsigned char* __restrict__ num, size_t stride,
                                                     uint32_t n, const NeedleF* __restrict__ needles,
                                                     int* __restrict__ out /* [nq][n] */) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const NeedleF& nd = needles[blockIdx.y];  // wave-uniform
+  const uint32_t i = color_tile() * blockDim.x + threadIdx.x;
+  const NeedleF& nd = needles[blockIdx.x];  // wave-uniform
   const int nn = nd.num;
   const int hn = i < n ? (int)num[i] : 0;
   float rowmin[kNC];
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(256) void k_color_dist(const float* __restrict__ L,
     }
     result = (int)score;
   }
-  if (i < n) out[(size_t)blockIdx.y * n + i] = result;
+  if (i < n) out[(size_t)blockIdx.x * n + i] = result;
 }
 
 
@@ -97,8 +103,8 @@ __global__ __launch_bounds__(256) void k_color_dist2(const float* __restrict__ L
                                                      const unsigned char* __restrict__ num, size_t stride,
                                                      uint32_t n, const NeedleF* __restrict__ needles,
                                                      int* __restrict__ out /* [nq][n] */) {
-  const uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 2u;  // descriptors i0, i0 + 1 (stride is even)
-  const NeedleF& nd = needles[blockIdx.y];                             // wave-uniform, colours >= num padded
+  const uint32_t i0 = (color_tile() * blockDim.x + threadIdx.x) * 2u;  // descriptors i0, i0 + 1 (stride is even)
+  const NeedleF& nd = needles[blockIdx.x];                             // wave-uniform, colours >= num padded
   const int nn = nd.num;
   const int hn0 = i0 < n ? (int)num[i0] : 0, hn1 = i0 + 1 < n ? (int)num[i0 + 1] : 0;
   const int hmax = max(hn0, hn1);
@@ -153,8 +159,108 @@ __global__ __launch_bounds__(256) void k_color_dist2(const float* __restrict__ L
       }
       result = (int)score;
     }
-    if (i < n) out[(size_t)blockIdx.y * n + i] = result;
+    if (i < n) out[(size_t)blockIdx.x * n + i] = result;
   }
+}
+
+// k_color_dist3 (default): the same arithmetic shaped for the VALU's fast path.  tools/ubench/pk_f32_rate.hip on the
+// MI355X: a wave issues one VALU instruction every ~4.3-5 cycles, and a SIMD interleaves TWO waves, so plain
+// v_sub/v_mul/v_add_f32 and v_min3_u32 on VGPR operands retire every ~2.15 cycles per SIMD with 2, 4, 6 or 8 resident
+// waves -- but every 2.8 with 3 (an odd wave has no partner), every 4.1 when an operand is an SGPR (k_color_dist,
+// k_color_dist2 keep the needle in SGPRs), and the packed forms (v_pk_*_f32) every 4.2 for two floats per lane, i.e.
+// no gain.  So: needle colours in VGPRs, 32-bit ops, and an EVEN occupancy.  All 96 needle components + 32 running
+// minima do not fit 128 VGPRs (4 waves), so the needle is taken in two halves of 16 colours: a lane owns one haystack
+// descriptor, walks its colours two at a time against the 16 needle colours of the half (3 sub + 3 mul + 2 add per
+// pair, one v_min3_u32 per needle colour for its running minimum, one per two needle colours for each haystack
+// colour's), and parks the haystack-side minima of the first half in LDS ([colour][lane], conflict-free) for the
+// second half to finish.  40 KB of LDS per workgroup also pins the occupancy at 4 workgroups per CU = 4 waves per
+// SIMD.  Operation order per distance and per sum is k_color_dist's (minima are order-independent; the two sums run
+// over ascending colour index), so the results are bit-identical.  RAW: also the float distance (FLT_MAX where the
+// reference's distance() returns FLT_MAX).
+constexpr int kHalf = kNC / 2;
+template <bool RAW>
+__global__ __launch_bounds__(256) void k_color_dist3(const float* __restrict__ L, const float* __restrict__ U,
+                                                     const float* __restrict__ V,
+                                                     const unsigned char* __restrict__ num, size_t stride,
+                                                     uint32_t n, const NeedleF* __restrict__ needles,
+                                                     int* __restrict__ out /* [nq][n] */,
+                                                     float* __restrict__ raw /* [nq][n] or null */) {
+  __shared__ uint32_t s_cmin[kNC + 8][256];  // +8 rows: 33 KB -> 40 KB, at most 4 workgroups per CU
+  const uint32_t i = color_tile() * blockDim.x + threadIdx.x;
+  const NeedleF& nd = needles[blockIdx.x];  // wave-uniform, colours >= num padded with 1e18
+  const int nn = nd.num;
+  const int hn = i < n ? (int)num[i] : 0;
+  const uint32_t ii = i < n ? i : 0;  // (lanes past the end read descriptor 0 and write nothing)
+  constexpr uint32_t kBig = 0x7f7fffffu;  // FLT_MAX
+  unsigned zero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(zero));  // an index the compiler cannot prove uniform: vector loads below
+  const float4* np4 = reinterpret_cast<const float4*>(&nd) + zero;
+  float colacc = 1.0f, rowacc = 1.0f;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    // this half's 48 needle components straight into VGPRs (every lane reads the same bytes: broadcast lines)
+    float nl[kHalf], nu[kHalf], nv[kHalf];
+#pragma unroll
+    for (int p = 0; p < kHalf / 4; ++p) {
+      const float4 a = np4[half * (kHalf / 4) + p], b = np4[kNC / 4 + half * (kHalf / 4) + p],
+                   c = np4[2 * (kNC / 4) + half * (kHalf / 4) + p];
+      nl[4 * p] = a.x, nl[4 * p + 1] = a.y, nl[4 * p + 2] = a.z, nl[4 * p + 3] = a.w;
+      nu[4 * p] = b.x, nu[4 * p + 1] = b.y, nu[4 * p + 2] = b.z, nu[4 * p + 3] = b.w;
+      nv[4 * p] = c.x, nv[4 * p + 1] = c.y, nv[4 * p + 2] = c.z, nv[4 * p + 3] = c.w;
+    }
+    uint32_t rowmin[kHalf];
+#pragma unroll
+    for (int p = 0; p < kHalf; ++p) rowmin[p] = kBig;
+    // planes are padded with 1e18 beyond every descriptor's colours: no guards in the loop.  The next step's six
+    // values are requested before this step's arithmetic.
+    float al = L[ii], au = U[ii], av = V[ii];
+    float bl = L[stride + ii], bu = U[stride + ii], bv = V[stride + ii];
+    for (int h = 0; h < kNC; h += 2) {
+      if (__ballot(h < hn) == 0ull) break;  // no lane of this wave has that many colours
+      const int hnx = h + 2 < kNC ? h + 2 : h;  // (the last step re-reads its own colours: harmless)
+      const float xal = L[(size_t)hnx * stride + ii], xau = U[(size_t)hnx * stride + ii],
+                  xav = V[(size_t)hnx * stride + ii];
+      const float xbl = L[(size_t)(hnx + 1) * stride + ii], xbu = U[(size_t)(hnx + 1) * stride + ii],
+                  xbv = V[(size_t)(hnx + 1) * stride + ii];
+      uint32_t cmin_a = kBig, cmin_b = kBig;
+      if (half) cmin_a = s_cmin[h][threadIdx.x], cmin_b = s_cmin[h + 1][threadIdx.x];
+#pragma unroll
+      for (int p = 0; p < kHalf; p += 2) {
+        uint32_t da[2], db[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float dl = nl[p + e] - al, du = nu[p + e] - au, dv = nv[p + e] - av;
+          const float el = nl[p + e] - bl, eu = nu[p + e] - bu, ev = nv[p + e] - bv;
+          const float d2a = dl * dl + du * du + dv * dv;
+          const float d2b = el * el + eu * eu + ev * ev;
+          da[e] = __builtin_bit_cast(uint32_t, d2a);
+          db[e] = __builtin_bit_cast(uint32_t, d2b);
+          rowmin[p + e] = min(min(rowmin[p + e], da[e]), db[e]);  // v_min3_u32
+        }
+        cmin_a = min(min(cmin_a, da[0]), da[1]);
+        cmin_b = min(min(cmin_b, db[0]), db[1]);
+      }
+      if (half == 0) {
+        s_cmin[h][threadIdx.x] = cmin_a, s_cmin[h + 1][threadIdx.x] = cmin_b;  // own column only: no barrier needed
+      } else {
+        if (h < hn) colacc += sqrtf(__builtin_bit_cast(float, cmin_a));  // haystack side is "a" (more colours)
+        if (h + 1 < hn) colacc += sqrtf(__builtin_bit_cast(float, cmin_b));
+      }
+      al = xal, au = xau, av = xav, bl = xbl, bu = xbu, bv = xbv;
+    }
+#pragma unroll
+    for (int p = 0; p < kHalf; ++p)  // needle side is "a": sum over needle colours in index order, across the halves
+      if (half * kHalf + p < nn) rowacc += sqrtf(__builtin_bit_cast(float, rowmin[p]));
+  }
+  if (i >= n) return;
+  int result = -1;
+  float score = FLT_MAX;
+  if (nn != 0 && hn != 0 && abs(nn - hn) <= 2) {
+    score = nn < hn ? colacc : rowacc;
+    result = (int)score;
+  }
+  out[(size_t)blockIdx.x * n + i] = result;
+  if (RAW) raw[(size_t)blockIdx.x * n + i] = score;
 }
 
 // key = score<<32 | id for entries that match (score >= 0, id != 0), ~0 otherwise
@@ -267,7 +373,11 @@ __global__ __launch_bounds__(256) void k_color_collect(const int* __restrict__ s
   }
 }
 
-int g_color_pk = 1;  // 1 = k_color_dist2 (two descriptors per lane, packed f32)
+// distance kernel: 1 = k_color_dist2 (two descriptors per lane on packed f32; default: 12.1 ms per 64 needles x 1M
+// descriptors), 2 = k_color_dist3 (32-bit ops on VGPR operands at 4 waves per SIMD: 12.5 ms), 0 = k_color_dist (14.1 ms).
+// All three sit at the VALU issue ceiling of this arithmetic (no FMA: the reference's rounding order) once the launch
+// geometry lets concurrent workgroups share haystack tiles.
+int g_color_pk = 1;
 
 void decompress(const uint8_t* desc, NeedleF* out) {  // DescriptorColor::get, cvutil.h:83-87
   for (int c = 0; c < kNC; ++c) {
@@ -402,18 +512,30 @@ int ensure_scratch(cbh_color* c, size_t nq, bool keys) {
   return CBH_OK;
 }
 
-// scores of nq needles against the whole index -> c->d_scores [nq][n] (enqueued on c->stream)
-int run_dist(cbh_color* c, const uint8_t* needle_descs, size_t nq) {
+// scores of nq needles against the whole index -> c->d_scores [nq][n] (enqueued on c->stream); d_raw: also the float
+// distances (k_color_dist3 only)
+int run_dist(cbh_color* c, const uint8_t* needle_descs, size_t nq, float* d_raw = nullptr) {
   std::vector<NeedleF> nf(nq);
   for (size_t q = 0; q < nq; ++q) decompress(needle_descs + q * kDescBytes, &nf[q]);
   CBH_HIP(hipMemcpyAsync(c->d_needles, nf.data(), nq * sizeof(NeedleF), hipMemcpyHostToDevice, c->stream));
   CBH_HIP(hipStreamSynchronize(c->stream));  // nf is a stack-lifetime buffer
-  if ((c->cap & 1) == 0 && g_color_pk) {
-    dim3 grid((unsigned)((c->n + 511) / 512), (unsigned)nq), block(256);
+  if (g_color_pk >= 2 || d_raw) {
+    const unsigned tiles = (unsigned)((c->n + 255) / 256);
+    dim3 grid((unsigned)nq, std::min(tiles, 32768u), (tiles + 32767u) / 32768u), block(256);
+    if (d_raw)
+      hipLaunchKernelGGL(k_color_dist3<true>, grid, block, 0, c->stream, c->dL, c->dU, c->dV, c->d_num, c->cap,
+                         (uint32_t)c->n, c->d_needles, c->d_scores, d_raw);
+    else
+      hipLaunchKernelGGL(k_color_dist3<false>, grid, block, 0, c->stream, c->dL, c->dU, c->dV, c->d_num, c->cap,
+                         (uint32_t)c->n, c->d_needles, c->d_scores, d_raw);
+  } else if ((c->cap & 1) == 0 && g_color_pk) {
+    const unsigned tiles = (unsigned)((c->n + 511) / 512);
+    dim3 grid((unsigned)nq, std::min(tiles, 32768u), (tiles + 32767u) / 32768u), block(256);
     hipLaunchKernelGGL(k_color_dist2, grid, block, 0, c->stream, c->dL, c->dU, c->dV, c->d_num, c->cap,
                        (uint32_t)c->n, c->d_needles, c->d_scores);
   } else {
-    dim3 grid((unsigned)((c->n + 255) / 256), (unsigned)nq), block(256);
+    const unsigned tiles = (unsigned)((c->n + 255) / 256);
+    dim3 grid((unsigned)nq, std::min(tiles, 32768u), (tiles + 32767u) / 32768u), block(256);
     hipLaunchKernelGGL(k_color_dist, grid, block, 0, c->stream, c->dL, c->dU, c->dV, c->d_num, c->cap,
                        (uint32_t)c->n, c->d_needles, c->d_scores);
   }
@@ -524,6 +646,35 @@ int cbh_color_find(cbh_color* c, const void* needle_desc, cbh_match* out, size_t
     }
   *n_out = m;
   return CBH_OK;
+}
+
+/* ColorDescriptor::distance (cvutil.cpp:682-749) of nq needles against every index entry, as floats: out[q*n + i];
+ * FLT_MAX where the reference returns FLT_MAX (no colours on a side, or the colour counts differ by more than 2).
+ * Entry i is the i-th descriptor added, whatever its id. */
+int cbh_color_distances(cbh_color* c, const void* needle_descs, size_t nq, float* out) {
+  if (!c || (nq && (!needle_descs || !out))) return CBH_E_INVAL;
+  if (nq == 0 || c->n == 0) return CBH_OK;
+  cbh::DeviceGuard g(c->device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  std::lock_guard<std::mutex> lk(c->mu);
+  const size_t chunk = std::max<size_t>(1, std::min<size_t>(nq, ((size_t)1 << 27) / c->n));
+  int rc = ensure_scratch(c, chunk, false);
+  if (rc) return rc;
+  float* d_raw = nullptr;
+  CBH_HIP(hipMalloc(&d_raw, chunk * c->n * sizeof(float)));
+  for (size_t q0 = 0; q0 < nq && !rc; q0 += chunk) {
+    const size_t m = std::min(chunk, nq - q0);
+    rc = run_dist(c, (const uint8_t*)needle_descs + q0 * kDescBytes, m, d_raw);
+    if (rc) break;
+    hipError_t e = hipMemcpyAsync(out + q0 * c->n, d_raw, m * c->n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+      cbh::set_last_error("color distances", e);
+      rc = CBH_E_HIP;
+    }
+  }
+  (void)hipFree(d_raw);
+  return rc;
 }
 
 /* find() for many needles + the sort/cut of searchIndex (database.cpp:1729-1735): out[q*k..] = first

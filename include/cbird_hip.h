@@ -395,6 +395,10 @@ int cbh_color_download(const cbh_color*, uint32_t* ids, void* descs, size_t cap)
  * finite (both sides have colours, counts differ by <= 2) and whose id != 0, in index order,
  * score = int(1 + sum of nearest-colour distances).  Bit-exact to the reference's float arithmetic. */
 int cbh_color_find(cbh_color*, const void* needle_desc, cbh_match* out, size_t cap, size_t* n_out);
+/* ColorDescriptor::distance (src/cvutil.cpp:682-749) as FLOATS, nq needles x every index entry: out[q*count + i]
+ * for entry i in add order (whatever its id); FLT_MAX where the reference returns FLT_MAX (:683-684).  The int
+ * scores of cbh_color_find are (int) of exactly these values. */
+int cbh_color_distances(cbh_color*, const void* needle_descs, size_t nq, float* out);
 /* many needles + the sort/cut of Database::searchIndex: first min(counts[q], k) matches by (score, id) */
 int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k, cbh_match* out,
                          uint32_t* counts);

@@ -143,3 +143,56 @@ def test_gpu_find_bit_exact(gpu, co, n):
         assert gc[q] == len(wi)
         m_ = min(5, len(wi))
         assert gi[q, :m_].tolist() == wi[order][:m_].tolist() and gs[q, :m_].tolist() == ws[order][:m_].tolist()
+
+
+@pytest.fixture(params=[2, 1, 0])
+def color_kernel(request, gpu):
+    """every distance kernel: 1 = k_color_dist2 (packed f32, shipped), 2 = k_color_dist3 (32-bit ops on VGPR operands,
+    needle in two halves; also the one that returns raw floats), 0 = k_color_dist (one descriptor per lane)"""
+    from cbird_amd import _lib
+
+    _lib.lib().cbh_set_tuning(b"color_pk", request.param)
+    yield request.param
+    _lib.lib().cbh_set_tuning(b"color_pk", 1)
+
+
+@pytest.mark.gpu
+def test_gpu_all_kernels_give_the_same_scores(gpu, co, color_kernel):
+    from cbird_amd.colordesc import ColorDescIndex
+
+    d, ids = synth_descriptors(3000, 31)
+    idx = ColorDescIndex()
+    idx.add([_M(int(i), x) for i, x in zip(ids, d)])
+    for q in (0, 7, 1500, 2999):
+        got = idx.find(_M(0, d[q]))
+        wi, ws = co.find(d, ids, d[q])
+        assert [x.mediaId for x in got] == wi.tolist() and [x.score for x in got] == ws.tolist()
+
+
+@pytest.mark.gpu
+def test_gpu_float_distances_are_the_references_bit_for_bit(gpu, co):
+    """the raw float distances (north_star: float colour distances within 1e-5): the VALU kernel keeps the reference's
+    operation order, so the comparison is BITWISE against the oracle's ColorDescriptor::distance
+    (src/cvutil.cpp:682-749); (int) of them are the scores"""
+    from cbird_amd.colordesc import ColorDescIndex
+
+    n = 700
+    d, ids = synth_descriptors(n, 5)
+    d["numColors"][3] = 0       # no colours -> FLT_MAX
+    d["numColors"][4] = 32      # counts differing by more than 2 from most -> FLT_MAX
+    idx = ColorDescIndex()
+    idx.add([_M(int(i), x) for i, x in zip(ids, d)])
+    needles = d[[0, 1, 3, 4, 250, 699]]
+    got = idx.distances(needles)
+    want = np.array([[co.distance(q, x) for x in d] for q in needles], np.float32)
+    assert got.shape == want.shape == (6, n)
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
+    finite = want < 1e38
+    assert finite.sum() > 300 and (~finite).sum() > n  # both branches present
+    rel = np.abs(got[finite] - want[finite]) / want[finite]
+    assert rel.max() <= 1e-5  # (trivially: they are identical)
+    # and the int scores are exactly (int) of these floats
+    for qi, q in enumerate(needles):
+        sc = {x.mediaId: x.score for x in idx.find(_M(0, q))}
+        for i in np.nonzero(finite[qi])[0]:
+            assert sc[int(ids[i])] == int(got[qi, i])
