@@ -59,6 +59,8 @@ void set_scan256_mfma(int on);  // <0 = keep; 2 = force for any size
 
 int g_hash_mfma_set(int v);  // dcthash.hip
 extern int g_fdct_host_vote, g_video_host_reduce;  // fdct.hip: 1 = round-1 host reductions (parity tests)
+void set_hash_div(int v);       // dcthash.hip: k_dcthash_256 divide-by-49 form, 1 = float magic (default), 0 = integer SDWA
+void set_hash_lds_pad(int v);   // dcthash.hip: occupancy experiment knob
 void set_hash_dct(int v);       // dcthash.hip: stage 3/5 arithmetic, 1 = as cv::dct/cv::sum (default), 0 = canonical matrix form
 void set_kp_blur_side(int v);   // dcthash.hip: largest keypoint square whose blurred copy stays in LDS (default 112)
 void set_kp_lds_side(int v);    // dcthash.hip: largest keypoint square processed in LDS (default 134)

@@ -826,6 +826,14 @@ int cbh_set_tuning(const char* key, int value) {
     g_video_host_reduce = value;
     return CBH_OK;
   }
+  if (!strcmp(key, "hash_div")) {
+    set_hash_div(value);
+    return CBH_OK;
+  }
+  if (!strcmp(key, "hash_lds_pad")) {
+    set_hash_lds_pad(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "hash_dct")) {
     set_hash_dct(value);
     return CBH_OK;

@@ -178,6 +178,23 @@ __device__ __forceinline__ double sum64_lanes(int c_bits) {
   return sum;
 }
 
+// the same for an image held by a HALF-wave: lane base + i holds element i in c0_bits and element 32 + i in c1_bits
+// (base = 0 or 32).  Wave-uniform result; no LDS round trips.
+__device__ __forceinline__ double sum64_halfwave(int c0_bits, int c1_bits, int base) {
+  double sum = 0.0;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int src = g < 8 ? c0_bits : c1_bits;
+    const int l = base + 4 * (g & 7);
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(src, l));
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(src, l + 1));
+    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(src, l + 2));
+    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(src, l + 3));
+    sum += (double)(((a + b) + c) + d);
+  }
+  return sum;
+}
+
 // the same from an array in memory (serial, one lane)
 __device__ __forceinline__ double sum64_mem(const float* __restrict__ y, const unsigned char* __restrict__ zz) {
   double sum = 0.0;

@@ -278,7 +278,27 @@ __device__ __forceinline__ unsigned add_byte3(unsigned acc, unsigned p) {
   return r;
 }
 
-template <bool DUMP, int DCT>
+// u16 half of a dword -> f32 in one VALU op (SDWA word select)
+__device__ __forceinline__ float cvt_f32_word0(unsigned p) {
+  float r;
+  asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(r) : "v"(p));
+  return r;
+}
+__device__ __forceinline__ float cvt_f32_word1(unsigned p) {
+  float r;
+  asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(p));
+  return r;
+}
+
+// DIV selects how nearest(S/49) is formed and summed over the 8x8 cell (both exact):
+//   0  integer: ((S+24) * 342393) >> 24 with v_mul_u32_u24_sdwa + v_add_u32_sdwa BYTE_3 -- two "complex" VALU ops per
+//      pixel (ops that only the full VALU pipe executes, ~4.3 cycles per wave each);
+//   1  float magic number: r = fma(float(S), 1/49, 1.5*2^23) is 1.5*2^23 + nearest(S/49) exactly (ulp 1 in that binade;
+//      k/49 is never within 0.0102 of a tie and the product's error is < 2e-5), so the BIT PATTERN of r is
+//      0x4B400000 + quotient: one complex op (the u16 -> f32 convert) + two simple ones (v_fma_f32, v_add_u32 of the
+//      bit patterns; the 64 x 0x4B400000 of a cell leave mod 2^32 at the end).  Measured 4 % SLOWER than form 0
+//      (tools/hash_sweep.py): simple ops cost ~2.15 cycles per wave, complex ~4.3, and they add.
+template <bool DUMP, int DCT, int DIV>
 __global__ __launch_bounds__(kThreads) void k_dcthash_256(
     const unsigned char* __restrict__ imgs, unsigned n, unsigned row_stride, unsigned img_stride,
     const DctTables* __restrict__ tabs, uint64_t* __restrict__ out,
@@ -287,7 +307,6 @@ __global__ __launch_bounds__(kThreads) void k_dcthash_256(
   __shared__ float sT[8][288];
   __shared__ float sY[8][84];
   __shared__ float sC[9 * 33];
-  __shared__ float sThr[8];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -318,7 +337,7 @@ __global__ __launch_bounds__(kThreads) void k_dcthash_256(
     for (int c = 0; c < 4; ++c) ring[j][c] = 0u;
   }
 #pragma unroll
-  for (int c = 0; c < 4; ++c) S[c] = 24u | (24u << 16);
+  for (int c = 0; c < 4; ++c) S[c] = DIV ? 0u : (24u | (24u << 16));
   unsigned acc = 0;
 
   // virtual row s-3 -> REFLECT_101 source row; steps past the image (s > 261) re-read row 252,
@@ -367,13 +386,23 @@ __global__ __launch_bounds__(kThreads) void k_dcthash_256(
       }
       // output row y = s - 6 (garbage for s < 6: acc is reset before the first real row)
       if (s == 6) acc = 0;
+      if constexpr (DIV == 1) {
+        constexpr float k49 = 1.0f / 49.0f, kMagic = 12582912.0f;  // 1.5 * 2^23 = 0x4B400000
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        acc = add_byte3(acc, (S[c] & 0xffffu) * 342393u);  // operands < 2^24 -> v_mul_u32_u24
-        acc = add_byte3(acc, (S[c] >> 16) * 342393u);
+        for (int c = 0; c < 4; ++c) {
+          acc += __builtin_bit_cast(unsigned, __builtin_fmaf(cvt_f32_word0(S[c]), k49, kMagic));
+          acc += __builtin_bit_cast(unsigned, __builtin_fmaf(cvt_f32_word1(S[c]), k49, kMagic));
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          acc = add_byte3(acc, (S[c] & 0xffffu) * 342393u);  // operands < 2^24 -> v_mul_u32_u24
+          acc = add_byte3(acc, (S[c] >> 16) * 342393u);
+        }
       }
       const int y = s - 6;
       if (y >= 0 && (y & 7) == 7) {
+        if constexpr (DIV == 1) acc -= 0xD0000000u;  // 64 x 0x4B400000 mod 2^32
         const unsigned t = (acc + 31u + ((acc >> 6) & 1u)) >> 6;  // /64, half to even
         if (y < 256) sTile[slot][(y >> 3) * 32 + l32] = (unsigned char)t;
         acc = 0;
@@ -427,8 +456,6 @@ __global__ __launch_bounds__(kThreads) void k_dcthash_256(
 #pragma unroll
       for (int u = 0; u < 9; ++u) sY[slot][u * 9 + l32] = y[u];
     }
-    __syncthreads();
-    if (l32 == 0) sThr[slot] = (float)cvdct::sum64_mem(sY[slot], tabs->zz) / 64;
   } else {
 #pragma unroll
     for (int rep = 0; rep < 3; ++rep) {
@@ -441,18 +468,28 @@ __global__ __launch_bounds__(kThreads) void k_dcthash_256(
         sY[slot][o] = t;
       }
     }
-    __syncthreads();
-    if (l32 == 0) {
-      double sum = 0.0;
-      for (int i = 0; i < 64; ++i) sum += (double)sY[slot][tabs->zz[i]];
-      sThr[slot] = (float)sum / 64;
-    }
   }
   __syncthreads();
   {
-    const float thr = sThr[slot];
+    // lane l of a half-wave holds selected coefficients l and 32 + l; the threshold's ordered sum runs on lane
+    // broadcasts (v_readlane) for both images of the wave at once -- no serial chain of LDS reads
     const float c0 = sY[slot][tabs->zz[l32]];
     const float c1 = sY[slot][tabs->zz[l32 + 32]];
+    const int cb0 = __builtin_bit_cast(int, c0), cb1 = __builtin_bit_cast(int, c1);
+    double sumA, sumB;
+    if constexpr (DCT == 1) {
+      sumA = cvdct::sum64_halfwave(cb0, cb1, 0);
+      sumB = cvdct::sum64_halfwave(cb0, cb1, 32);
+    } else {
+      sumA = 0.0, sumB = 0.0;
+#pragma unroll
+      for (int i = 0; i < 64; ++i) {
+        const int src = i < 32 ? cb0 : cb1;
+        sumA += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(src, i & 31));
+        sumB += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(src, 32 + (i & 31)));
+      }
+    }
+    const float thr = (float)((lane >> 5) ? sumB : sumA) / 64;
     const unsigned long long b0 = __ballot(c0 > thr);
     const unsigned long long b1 = __ballot(c1 > thr);
     const int sh = (lane >> 5) * 32;
@@ -2129,6 +2166,18 @@ int g_hash_mfma = 0;
 int g_hash_mfma_set(int v) { return g_hash_mfma = v; }
 // tuning knob "hash_dct": stages 3 and 5 of dctHash64 -- 1 (default) = cv::dct / cv::sum as OpenCV 2.4.13.7 evaluates
 // them (cv_dct32_dev.h), 0 = the canonical 9x32 matrix form.  oracle: orc_set_hash_variant.
+// "hash_div": how k_dcthash_256 divides by 49 (see the kernel): 0 = integer SDWA (default), 1 = float magic number
+// (exact too; measured 4 % slower: 5.57 vs 5.36 ms per 400k images -- on this VALU a "simple" op costs ~2.15 cycles
+// per wave and a "complex" one ~4.3, additively, so 2 complex -> 1 complex + 2 simple is break-even at best).
+// "hash_lds_pad": extra dynamic LDS bytes per workgroup of k_dcthash_256, the occupancy experiment knob (default 0;
+// 3..7 workgroups per CU all run at the same speed: the kernel is bound by VALU issue, not by latency).
+int g_hash_div = 0, g_hash_lds_pad = 0;
+void set_hash_div(int v) {
+  if (v == 0 || v == 1) g_hash_div = v;
+}
+void set_hash_lds_pad(int v) {
+  if (v >= 0 && v <= 64 * 1024) g_hash_lds_pad = v;
+}
 int g_hash_dct = 1;
 void set_hash_dct(int v) {
   if (v == 0 || v == 1) g_hash_dct = v;
@@ -2667,14 +2716,20 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
       return CBH_OK;
     }
     dim3 grid((unsigned)((n + 7) / 8)), block(kThreads);
-#define CBH_256(DUMP_, DCT_)                                                                              \
-  hipLaunchKernelGGL((k_dcthash_256<DUMP_, DCT_>), grid, block, 0, stream, d_imgs, (unsigned)n,           \
-                     (unsigned)row_stride, (unsigned)img_stride, tabs, d_out, d_tiles)
+#define CBH_256(DUMP_, DCT_, DIV_)                                                                         \
+  hipLaunchKernelGGL((k_dcthash_256<DUMP_, DCT_, DIV_>), grid, block, (size_t)g_hash_lds_pad, stream, d_imgs, \
+                     (unsigned)n, (unsigned)row_stride, (unsigned)img_stride, tabs, d_out, d_tiles)
+#define CBH_256D(DCT_, DIV_)                                   \
+  do {                                                        \
+    if (d_tiles) CBH_256(true, DCT_, DIV_);                   \
+    else CBH_256(false, DCT_, DIV_);                          \
+  } while (0)
     if (g_hash_dct) {
-      if (d_tiles) CBH_256(true, 1); else CBH_256(false, 1);
+      if (g_hash_div) CBH_256D(1, 1); else CBH_256D(1, 0);
     } else {
-      if (d_tiles) CBH_256(true, 0); else CBH_256(false, 0);
+      if (g_hash_div) CBH_256D(0, 1); else CBH_256D(0, 0);
     }
+#undef CBH_256D
 #undef CBH_256
     CBH_HIP(hipGetLastError());
     return CBH_OK;

@@ -1,0 +1,26 @@
+"""k_dcthash_256 variants: divide form (hash_div) x occupancy (hash_lds_pad) x DCT form; checks equality of the hashes"""
+import ctypes as C, sys
+import torch
+sys.path.insert(0, ".")
+from cbird_amd import _lib
+import bench
+L = _lib.lib()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 400000
+dev = torch.device("cuda", 0)
+imgs = bench.gen_images(torch, dev, 0, n, n, 1234)
+ms = C.c_float(0)
+ref = {}
+for dct in (1, 0):
+    for div in (1, 0):
+        for pad in (0, 2048, 6144, 12288, 20480):
+            L.cbh_set_tuning(b"hash_dct", dct); L.cbh_set_tuning(b"hash_div", div); L.cbh_set_tuning(b"hash_lds_pad", pad)
+            out = torch.zeros(n, dtype=torch.int64, device=dev)
+            best = 1e9
+            for _ in range(3):
+                _lib.check(L.cbh_time_dcthash_dev(imgs.data_ptr(), n, 256, 256, 256, 65536, out.data_ptr(), 0, 3, C.byref(ms)), "h")
+                best = min(best, ms.value)
+            if dct not in ref:
+                ref[dct] = out.clone()
+            same = bool((out == ref[dct]).all())
+            lds = 21316 + pad
+            print(f"dct {dct} div {div} lds {lds:6d} B ({160*1024//lds} wg/CU): {best:7.3f} ms  {n*65544/best*1e-6:7.1f} GB/s  same={same}", flush=True)
