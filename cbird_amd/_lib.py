@@ -99,6 +99,9 @@ _SIGS = {
     "cbh_idx256_knn_media": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "cbh_cvfeatures_score": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.c_int, _vp, _sz, _vp]),
     "cbh_color_distances": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "cbh_search_index_batch": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _sz,
+                                         _vp, _vp]),
+    "cbh_filter_groups": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, C.c_int, _vp, _vp, _sz, _vp, _vp]),
     "cbh_records_topk_dev": (C.c_int, [_vp, _sz, _sz, _sz, _sz, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
     "cbh_idx64_set_record_capacity": (C.c_int, [_vp, _sz]),
     "cbh_idx64_remove_ids_only": (C.c_int, [_vp, _vp, _sz]),

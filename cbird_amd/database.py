@@ -5,8 +5,10 @@ Only the parts that shape the search RESULT are here (threshold escalation, orde
 cut, minMatches acceptance, duplicate-group filter); SQL, negative-match lists, weeds and path filters are
 storage/bookkeeping (out of scope).
 
-`similar()` has two routes with identical results: the reference's shape (one find() per needle) and, for an
-index that offers `find_batch`, one batched scan per threshold level.
+`similar()` has two routes with identical results: the reference's shape (one find() per needle, Python code
+below) and, for DctHashIndex, the whole job behind the C-ABI (cbh_search_index_batch + cbh_filter_groups).
+oracle/search_index.c restates the same reference lines independently in C; tests/test_database.py holds all three
+against each other.
 """
 from __future__ import annotations
 
@@ -67,10 +69,10 @@ def search_index(index, needle, params: SearchParams, id_map: dict):
 
 
 def _accept_and_dedupe(results, params):
-    """filterMatch's acceptance (group incl. needle must exceed minMatches, database.cpp:1245) and the
-    filterGroups pass (same set of paths found more than once is reported once, :1252-1272); groups are then
-    ordered by the needle's path (:1463)."""
-    groups = [g for g in results if len(g) > params.minMatches]
+    """filterMatch's acceptance (group incl. needle must exceed minMatches, database.cpp:1245; a needle without any
+    match never becomes a group, :1409) and the filterGroups pass (same set of paths found more than once is reported
+    once, :1252-1272); groups are then ordered by the needle's path (:1463)."""
+    groups = [g for g in results if len(g) > 1 and len(g) > params.minMatches]
     groups.sort(key=lambda g: g[0].path)
     if getattr(params, "filterGroups", True):
         seen, out = set(), []
@@ -85,34 +87,50 @@ def _accept_and_dedupe(results, params):
 
 def similar(index, haystack, params: SearchParams, batched: bool = True):
     """Database::similar for an in-memory haystack (list of Media with unique ids): every item is searched
-    as a needle; returns the accepted groups [needle, match1, ...]."""
+    as a needle; returns the accepted groups [needle, match1, ...].
+
+    batched (DctHashIndex): the whole job behind the C-ABI -- cbh_search_index_batch (scans, escalation and the
+    per-needle cut on the device, no per-needle loop here) and cbh_filter_groups (acceptance, duplicate groups,
+    order); this function only turns the surviving rows back into Media objects."""
     id_map = {m.id: m for m in haystack}
+    if batched and hasattr(index, "search_index_batch") and params.algo == SearchParams.AlgoDCT:
+        import ctypes as C
+
+        import numpy as np
+
+        from . import _lib
+
+        hay = list(haystack)
+        ids = np.array([m.id for m in hay], np.uint32)
+        hashes = np.array([m.dctHash for m in hay], np.uint64)
+        mi, ms, mc = index.search_index_batch(hashes, ids, params, valid_ids=ids)
+        # paths enter the C-ABI as ranks: position of each media's path in the sorted order of all paths
+        order = sorted(range(len(hay)), key=lambda i: hay[i].path)
+        rank = np.zeros(len(hay), np.uint32)
+        rank[order] = np.arange(len(hay), dtype=np.uint32)
+        by_id = np.argsort(ids, kind="stable")
+        ids_sorted, rank_sorted = np.ascontiguousarray(ids[by_id]), np.ascontiguousarray(rank[by_id])
+        k = int(params.maxMatches)
+        pairs = np.zeros((len(hay), max(k, 1), 2), np.uint32)
+        pairs[:, :k, 0], pairs[:, :k, 1] = mi, ms.view(np.uint32) if ms.size else ms
+        out_group = np.zeros(max(1, len(hay)), np.uint32)
+        n_out = C.c_size_t(0)
+        _lib.check(_lib.lib().cbh_filter_groups(ids.ctypes.data, pairs.ctypes.data, mc.ctypes.data, len(hay), max(k, 1),
+                                                int(params.minMatches), int(bool(getattr(params, "filterGroups", True))),
+                                                ids_sorted.ctypes.data, rank_sorted.ctypes.data, len(hay),
+                                                out_group.ctypes.data, C.byref(n_out)), "filter_groups")
+        groups = []
+        for j in out_group[: n_out.value].tolist():
+            g = [hay[j]]
+            for t in range(int(mc[j])):
+                media = copy.copy(id_map[int(mi[j, t])])
+                media.score = int(ms[j, t])
+                g.append(media)
+            groups.append(g)
+        return groups
     results = []
-    if batched and hasattr(index, "find_batch") and params.algo == SearchParams.AlgoDCT:
-        # one scan per threshold level instead of one tree walk per needle
-        k = params.maxMatches + 1  # room for the self match removed by filterSelf
-        pending = [m for m in haystack if m.dctHash]
-        found = {}
-        tmp = copy.copy(params)
-        while pending:
-            ids, scores, counts = index.find_batch([m.dctHash for m in pending], tmp.dctThresh, k)
-            nxt = []
-            for j, m in enumerate(pending):
-                n = min(int(counts[j]), k)
-                found[m.id] = [Match(int(ids[j, t]), int(scores[j, t])) for t in range(n)]
-                # escalation looks at the FULL match count (matches.count() <= minMatches, :1705)
-                if params.maxThresh > 0 and int(counts[j]) <= params.minMatches:
-                    nxt.append(m)
-            if not nxt or not _escalate(params, tmp):
-                break
-            pending = nxt
-        for m in haystack:
-            if not m.dctHash:
-                continue
-            results.append([m] + _group_from_matches(m, found.get(m.id, []), params, id_map))
-    else:
-        for m in haystack:
-            if params.algo == SearchParams.AlgoDCT and not m.dctHash:
-                continue
-            results.append([m] + search_index(index, m, params, id_map))
+    for m in haystack:
+        if params.algo == SearchParams.AlgoDCT and not m.dctHash:
+            continue
+        results.append([m] + search_index(index, m, params, id_map))
     return _accept_and_dedupe(results, params)

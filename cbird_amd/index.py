@@ -200,6 +200,23 @@ class DctHashIndex:
         out = out[:, :k, :]
         return out[:, :, 0].copy(), out[:, :, 1].astype(np.int32), counts
 
+    def search_index_batch(self, hashes, needle_ids, p: "SearchParams", valid_ids=None):
+        """Database::searchIndex (src/database.cpp:1691-1757) for every needle at once (cbh_search_index_batch):
+        escalation to p.maxThresh, (score, mediaId) order, filterSelf, cut at p.maxMatches, ids outside `valid_ids`
+        (the caller's idMap; None = all known) skipped.  Returns (ids[nq,maxMatches] u32, scores i32, counts u32)."""
+        q, ni = _as_u64(hashes), _as_u32(needle_ids)
+        nq, k = len(q), int(p.maxMatches)
+        out = np.zeros((nq, max(k, 1), 2), np.uint32)
+        counts = np.zeros(nq, np.uint32)
+        v = None if valid_ids is None else np.unique(_as_u32(valid_ids))
+        check(self._L.cbh_search_index_batch(self._h, q.ctypes.data, ni.ctypes.data, nq, int(p.dctThresh),
+                                             int(p.maxThresh), int(p.minMatches), k, int(bool(p.filterSelf)),
+                                             None if v is None else v.ctypes.data, 0 if v is None else len(v),
+                                             out.ctypes.data, counts.ctypes.data), "search_index_batch")
+        if k == 0:
+            return np.zeros((nq, 0), np.uint32), np.zeros((nq, 0), np.int32), counts
+        return out[:, :k, 0].copy(), out[:, :k, 1].astype(np.int32), counts
+
     def tree_masks(self, hashes: Sequence[int]) -> np.ndarray:
         """HammingTree leaf masks of needle hashes for the current contents (cbh_idx64_tree_masks)"""
         q = _as_u64(hashes)

@@ -255,6 +255,25 @@ int cbh_idx64_get_stats(const cbh_idx64*, cbh_stats* out);
 int cbh_idx64_reset_stats(cbh_idx64*);
 int cbh_idx256_get_stats(const cbh_idx256*, cbh_stats* out);
 
+/* ---- Database::searchIndex / Database::similar for a whole needle batch (cbird_amd/csrc/search.hip) ------------
+ * searchIndex (src/database.cpp:1691-1757) over DctHashIndex for nq needles: find at `thresh`; when max_thresh > 0 the
+ * needles whose match count is <= min_matches are searched again at thresh + 1, + 2, ... <= max_thresh (:1703-1725);
+ * matches in ascending (score, mediaId) order (:1729, ties fixed); the needle's own id dropped when filter_self
+ * (:1735); at most max_matches kept (:1736); ids not in valid_ids_sorted (the caller's idMap; NULL = every id is
+ * known) skipped without consuming a place (:1755).  out[j*max_matches ..], out_counts[j] = kept matches of needle j.
+ * max_matches <= 55. */
+int cbh_search_index_batch(cbh_idx64*, const uint64_t* q, const uint32_t* needle_ids, size_t nq, int thresh,
+                           int max_thresh, int min_matches, int max_matches, int filter_self,
+                           const uint32_t* valid_ids_sorted, size_t n_valid, cbh_match* out, uint32_t* out_counts);
+/* The group filtering of Database::similar on those results (host code): a needle with no match is no group (:1409);
+ * a group needs more than min_matches members, needle included (filterMatch, :1245); with filter_groups a group whose
+ * set of paths equals an earlier group's is dropped (filterMatches, :1252-1272), "earlier" in needle-path order; the
+ * result is in needle-path order (:1463).  Paths enter as ranks: path_rank[i] = position of the path of media
+ * ids_sorted[i] in the sorted order of all paths.  out_group[0..*n_out) = needle indices of the surviving groups. */
+int cbh_filter_groups(const uint32_t* needle_ids, const cbh_match* matches, const uint32_t* counts, size_t nq,
+                      int max_matches, int min_matches, int filter_groups, const uint32_t* ids_sorted,
+                      const uint32_t* path_rank, size_t n_ids, uint32_t* out_group, size_t* n_out);
+
 /* ---- DctFeaturesIndex: src/dctfeaturesindex.{h,cpp} over src/tree/hammingtree.h -----------------
  * The index is a cbh_idx64 whose entries are (mediaId, keypoint hash) pairs, several per media:
  *   load/add      -> cbh_idx64_load / cbh_idx64_add with one entry per hash (:229-238, :143-156)

@@ -264,6 +264,28 @@ class Oracle:
         x = np.ascontiguousarray(x, np.float32)
         return float(self.L.orc_cv_sum_f32(x, len(x)))
 
+    def similar_dct(self, hay_hash, hay_id, hay_rank, idx_hash, idx_id, thresh, max_thresh, min_matches, max_matches,
+                    filter_self=True, filter_groups=True):
+        """oracle/search_index.c: Database::similar over DctHashIndex (searchIndex + filterMatch + filterMatches).
+        Returns a list of (needle position, [(id, score), ...]) in result order."""
+        hh, hi = np.ascontiguousarray(hay_hash, np.uint64), np.ascontiguousarray(hay_id, np.uint32)
+        hr = np.ascontiguousarray(hay_rank, np.int32)
+        ih, ii = np.ascontiguousarray(idx_hash, np.uint64), np.ascontiguousarray(idx_id, np.uint32)
+        n = len(hh)
+        cap_g, cap_i = max(1, n), max(1, n * max(1, max_matches))
+        on, of = np.zeros(cap_g, np.uint32), np.zeros(cap_g + 1, np.uint64)
+        oi, os_ = np.zeros(cap_i, np.uint32), np.zeros(cap_i, np.int32)
+        f = self.L.orc_similar_dct
+        f.argtypes = [_u64p, _u32p, _i32p, C.c_size_t, _u64p, _u32p, C.c_size_t] + [C.c_int] * 6 + \
+                     [_u32p, _u64p, _u32p, _i32p, C.c_size_t, C.c_size_t]
+        f.restype = C.c_longlong
+        g = f(hh, hi, hr, n, ih, ii, len(ih), int(thresh), int(max_thresh), int(min_matches), int(max_matches),
+              int(bool(filter_self)), int(bool(filter_groups)), on, of, oi, os_, cap_g, cap_i)
+        if g < 0:
+            raise ValueError("orc_similar_dct: capacity")
+        return [(int(on[k]), list(zip(oi[int(of[k]):int(of[k + 1])].tolist(), os_[int(of[k]):int(of[k + 1])].tolist())))
+                for k in range(g)]
+
     def dcthash64(self, img) -> int:
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape

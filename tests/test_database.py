@@ -1,5 +1,6 @@
-"""Database::searchIndex / similar restatement (src/database.cpp:1691-1757, 1280-1466): rule-level tests on a
-CPU stand-in index (oracle-backed, test infrastructure) and GPU batched-vs-per-needle equality."""
+"""Database::searchIndex / similar (src/database.cpp:1691-1757, 1280-1466) three ways: cbird_amd/database.py's
+per-needle route, the C-ABI batch route (cbh_search_index_batch + cbh_filter_groups) and the INDEPENDENT C oracle
+oracle/search_index.c -- rule-level cases, an index out of step with the haystack, and the GPU end to end."""
 import numpy as np
 import pytest
 
@@ -58,25 +59,124 @@ def test_search_index_rules(orc):
     assert [m.id for m in g] == [2, 4]
 
 
-def test_similar_batched_equals_per_needle_cpu(orc):
-    from cbird_amd import SearchParams, synth
+PARAM_SETS = [dict(dctThresh=2), dict(dctThresh=5, maxMatches=2), dict(dctThresh=1, maxThresh=4),
+              dict(dctThresh=3, minMatches=2, filterSelf=False), dict(dctThresh=4, minMatches=0),
+              dict(dctThresh=2, maxThresh=7, minMatches=3, maxMatches=7), dict(dctThresh=6, maxMatches=1)]
+
+
+def _case(n=2500, seed=8):
+    """haystack media + an index that is NOT in step with it: ids the haystack does not know (stale entries, skipped
+    like database.cpp:1755), a removed slot (id 0), an item without a hash"""
+    from cbird_amd import synth
+
+    h, ids = synth.make_hashes(n, seed=seed, planted_frac=0.3, max_dist=6)
+    h[17] = 0  # item without hash: never a needle, never found
+    idx_h = np.concatenate([h, h[100:140] ^ np.uint64(2)])          # 40 stale entries close to real ones
+    idx_i = np.concatenate([ids, np.arange(900001, 900041, dtype=np.uint32)])
+    idx_i[55] = 0                                                    # removed slot
+    idx_h[55] = 0
+    return h, ids, idx_h, idx_i
+
+
+def _oracle_groups(orc, h, ids, idx_h, idx_i, p, filter_groups=True):
+    rank = np.argsort(np.argsort([f"/img/{int(i):06d}.jpg" for i in ids])).astype(np.int32)
+    res = orc.similar_dct(h, ids, rank, idx_h, idx_i, p.dctThresh, p.maxThresh, p.minMatches, p.maxMatches,
+                          p.filterSelf, filter_groups)
+    return [[(int(ids[j]), -1)] + m for j, m in res]
+
+
+def _key(groups):
+    return [[(m.id, m.score if t else -1) for t, m in enumerate(g)] for g in groups]
+
+
+def test_python_route_equals_the_independent_c_oracle(orc):
+    """cbird_amd/database.py (per-needle route over an oracle-backed find) against oracle/search_index.c, which
+    restates src/database.cpp:1691-1757,1400-1463 on its own: two statements of the reference, one answer"""
+    import warnings
+
+    from cbird_amd import SearchParams
     from cbird_amd.database import similar
 
-    h, ids = synth.make_hashes(3000, seed=8, planted_frac=0.25, max_dist=6)
-    h[17] = 0  # item without hash: never a needle
+    h, ids, idx_h, idx_i = _case()
     media = _media(h, ids)
-    idx = OracleIndex(orc, h, ids)
-    for p in (SearchParams(dctThresh=2), SearchParams(dctThresh=5, maxMatches=2),
-              SearchParams(dctThresh=1, maxThresh=4), SearchParams(dctThresh=3, minMatches=2, filterSelf=False)):
-        a = similar(idx, media, p, batched=True)
-        b = similar(idx, media, p, batched=False)
-        key = lambda gs: [[(m.id, m.score) for m in g] for g in gs]
-        assert key(a) == key(b)
-        assert len(a) > 10
-        # every group is accepted by filterMatch's rule and reported once
-        assert all(len(g) > p.minMatches for g in a)
-        sets = [tuple(sorted(m.path for m in g)) for g in a]
+    idx = OracleIndex(orc, idx_h, idx_i)
+    for kw in PARAM_SETS:
+        p = SearchParams(**kw)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # "no media with id" for the stale entries
+            got = _key(similar(idx, media, p, batched=False))
+        want = _oracle_groups(orc, h, ids, idx_h, idx_i, p)
+        assert got == want, kw
+        assert len(got) > 5, kw
+        assert all(len(g) > max(1, p.minMatches) for g in got)
+        sets = [tuple(sorted(i for i, _ in g)) for g in got]
         assert len(sets) == len(set(sets))
+        assert not any(i > 900000 or i == 0 for g in got for i, _ in g)  # stale / removed entries never appear
+
+
+def test_filter_groups_c_abi_on_host(orc):
+    """cbh_filter_groups is host code in the C-ABI: acceptance, duplicate groups and order on per-needle results"""
+    import ctypes as C
+    import warnings
+
+    from cbird_amd import SearchParams, _lib
+    from cbird_amd.database import search_index
+
+    h, ids, idx_h, idx_i = _case(800, 3)
+    media = _media(h, ids)
+    idx = OracleIndex(orc, idx_h, idx_i)
+    id_map = {m.id: m for m in media}
+    L = _lib.lib()
+    for kw in (dict(dctThresh=3), dict(dctThresh=5, minMatches=2, maxMatches=4), dict(dctThresh=4, minMatches=0)):
+        p = SearchParams(**kw)
+        k = p.maxMatches
+        pairs = np.zeros((len(media), k, 2), np.uint32)
+        counts = np.zeros(len(media), np.uint32)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for j, m in enumerate(media):
+                g = search_index(idx, m, p, id_map) if m.dctHash else []
+                counts[j] = len(g)
+                for t, x in enumerate(g):
+                    pairs[j, t] = (x.id, x.score)
+        rank = np.argsort(np.argsort([m.path for m in media])).astype(np.uint32)
+        by_id = np.argsort(ids)
+        ids_sorted, rank_sorted = np.ascontiguousarray(ids[by_id]), np.ascontiguousarray(rank[by_id])
+        for fg in (1, 0):
+            out = np.zeros(len(media), np.uint32)
+            n_out = C.c_size_t(0)
+            _lib.check(L.cbh_filter_groups(ids.ctypes.data, pairs.ctypes.data, counts.ctypes.data, len(media), k,
+                                           p.minMatches, fg, ids_sorted.ctypes.data, rank_sorted.ctypes.data,
+                                           len(media), out.ctypes.data, C.byref(n_out)), "filter_groups")
+            got = [[(int(ids[j]), -1)] + [(int(a), int(b)) for a, b in pairs[j, : counts[j]]] for j in out[: n_out.value]]
+            assert got == _oracle_groups(orc, h, ids, idx_h, idx_i, p, filter_groups=bool(fg)), (kw, fg)
+
+
+@pytest.mark.gpu
+def test_similar_behind_the_c_abi_equals_the_oracle(gpu, orc, scan_path):
+    """cbh_search_index_batch + cbh_filter_groups (scans, escalation and cut on the device) == oracle/search_index.c
+    == the per-needle route, on an index with stale and removed entries; includes needles whose cut needs more
+    places than the batch fetched (many stale neighbours: the exact single-needle fallback)"""
+    import warnings
+
+    from cbird_amd import SearchParams
+    from cbird_amd.database import similar
+
+    h, ids, idx_h, idx_i = _case()
+    # twelve stale copies of one hash: its needle (and its planted neighbours) must skip all of them
+    idx_h = np.concatenate([idx_h, np.full(12, h[7], np.uint64)])
+    idx_i = np.concatenate([idx_i, np.arange(910001, 910013, dtype=np.uint32)])
+    media = _media(h, ids)
+    idx = gpu.DctHashIndex()
+    idx.load(idx_h, idx_i)
+    for kw in PARAM_SETS:
+        p = SearchParams(**kw)
+        got = _key(similar(idx, media, p, batched=True))
+        assert got == _oracle_groups(orc, h, ids, idx_h, idx_i, p), kw
+    p = SearchParams(dctThresh=3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert _key(similar(idx, media, p, batched=False)) == _key(similar(idx, media, p, batched=True))
 
 
 @pytest.mark.gpu
