@@ -244,6 +244,9 @@ def main():
             "parallelism": f"haystack row-sharded x{world}, needles replicated",
         },
         "dht_sweep": sweep,
+        # the headline counts 8 x N^2 pair-equivalents per step; thresholds <= 4 run the low-word prefilter (32-bit dot
+        # products + exact 64-bit re-checks of the rare candidates), thresholds >= 5 compare all 64 bits of every pair
+        "full_64bit_compare_rate_per_s": shard_n * n / (scan_ms_avg * 1e-3) * world,
         "roofline": {
             "kernel": "k_hamm64_mfma3<8,2> (64-bit sign dot products, 3 needle tiles per accumulator: dht %s)" % ",".join(map(str, full)), "bound": "mfma", "achieved": scan_tflops, "peak": FP4_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": scan_tflops / FP4_PEAK_TFLOPS, "traffic": None,
@@ -269,12 +272,18 @@ def main():
             "avg_launch_ms": hash_ms, "algorithmic_bytes_per_launch": hash_bytes,
         },
     }
+    # HBM traffic is NOT measured by this run (PMC counters need their own rocprofv3 passes: tools/profile_bench.sh).
+    # The per-launch figures of the committed PMC passes are attached only to the configuration they were taken on
+    # (1M images, one GPU) and are labelled as such; any other --images / --gpus reports traffic = null.
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
+    if os.path.exists(pmc) and n == 1_000_000 and world == 1:
         try:
             t = json.load(open(pmc))
+            src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at 1M images, N=1; not measured in this run)"
             result["roofline"]["traffic"] = t.get("k_hamm64_mfma")
+            result["roofline"]["traffic_source"] = src
             result["roofline_hash"]["traffic"] = t.get("k_dcthash_256")
+            result["roofline_hash"]["traffic_source"] = src
         except Exception:
             pass
 

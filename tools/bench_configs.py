@@ -36,7 +36,14 @@ for k in (4, 10):
     cmp_ = idx.count() * len(needle)
     out[f"orb_knn_k{k}"] = {"rows": idx.count(), "needle_desc": len(needle), "kernel_ms": kms, "wall_ms": wall * 1e3,
                             "cmp256_per_s_kernel": cmp_ / kms * 1e3, "algorithmic_GBps": cmp_ * 32 / kms * 1e3 / 1e9,
-                            "self_found": int((c >= 1).sum())}
+                            "self_found": int((c >= 1).sum()),
+                            # a 500-descriptor needle reads the 1.6 GB row matrix once: HBM-bound (32 B per row)
+                            "roofline": {"kernel": "k_hamm256_mfma (128-bit prefilter)", "bound": "hbm", "unit": "GB/s",
+                                         "achieved": idx.count() * 32 / kms * 1e3 / 1e9, "peak": 8000.0,
+                                         "frac": idx.count() * 32 / kms * 1e3 / 1e9 / 8000.0, "traffic": None,
+                                         "algorithmic_bytes_per_launch": idx.count() * 32,
+                                         "note": "bytes = every row read once per launch (the needle tile is reused from "
+                                                 "registers); SURVEY 8(d)'s 32 B per comparison would count each row once per needle descriptor"}}
     print(k, out[f"orb_knn_k{k}"], flush=True)
 # a batch of 64 needle images (32k needle descriptors) in one launch
 needles = np.concatenate([idx.descriptorsForMediaId(i) for i in range(1, 65)])
@@ -45,7 +52,11 @@ L.cbh_idx256_get_stats(idx.handle, C.byref(st)); ms0, l0 = st.scan_ms, st.scan_l
 t0 = time.time(); r, d, c = idx.knn(needles, 10, 25); wall = time.time() - t0
 L.cbh_idx256_get_stats(idx.handle, C.byref(st)); kms = st.scan_ms - ms0
 out["orb_knn_batch64"] = {"needle_desc": len(needles), "kernel_ms": kms, "wall_ms": wall * 1e3,
-                          "cmp256_per_s_kernel": idx.count() * len(needles) / kms * 1e3}
+                          "cmp256_per_s_kernel": idx.count() * len(needles) / kms * 1e3,
+                          # 32k needle descriptors: matrix-core bound; the 128-bit prefilter issues 256 FLOP per pair
+                          "roofline": {"kernel": "k_hamm256_mfma (128-bit prefilter)", "bound": "mfma", "unit": "TFLOP/s",
+                                       "achieved": idx.count() * len(needles) * 256 / kms * 1e3 / 1e12, "peak": 10000.0,
+                                       "frac": idx.count() * len(needles) * 256 / kms * 1e3 / 1e12 / 10000.0, "traffic": None}}
 print(out["orb_knn_batch64"], flush=True)
 del idx
 
@@ -54,11 +65,11 @@ from cbird_amd import synth_video
 from cbird_amd.video import DctVideoIndex, VideoIndex, VideoSearchParams
 n_clips = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000
 t0 = time.time()
-clips = synth_video.make_clips(n_clips, 300, seed=1234, subclip_frac=0.01, max_gap=8)
+clips = synth_video.make_clips_fast(n_clips, 300, seed=1234, subclip_frac=0.01, max_gap=8)
 vidx = DctVideoIndex()
 media = []
 for i, (f, h) in enumerate(clips):
-    m = M(); m.id, m.path, m.videoIndex = i + 1, f"c{i}", VideoIndex(f.tolist(), [int(x) for x in h]); media.append(m)
+    m = M(); m.id, m.path, m.videoIndex = i + 1, f"c{i}", VideoIndex(f, h); media.append(m)
 vidx.add(media)
 print("built video index", n_clips, "clips in", round(time.time() - t0, 1), "s", flush=True)
 p = VideoSearchParams(dctThresh=5, skipFrames=0, minFramesMatched=30, minFramesNear=60)
@@ -94,6 +105,13 @@ t0 = time.time(); gi, gs, gc = ci.find_batch(descs[:64], 8); b64 = time.time() -
 # 258 B and ~9.2e3 flop per descriptor comparison (32x32 colour pairs x 9 flop)
 out["color"] = {"descriptors": n_col, "single_needle_ms": one_c * 1e3, "batch64_s": b64,
                 "desc_cmp_per_s_batched": 64 * n_col / b64, "algorithmic_TFLOPs_batched": 64 * n_col * 9216 / b64 / 1e12,
-                "algorithmic_GBps_batched": 64 * n_col * 258 / b64 / 1e9, "self_first": bool((gi[:, 0] == ids_c[:64]).all())}
+                "algorithmic_GBps_batched": 64 * n_col * 258 / b64 / 1e9, "self_first": bool((gi[:, 0] == ids_c[:64]).all()),
+                # the reference's rounding order forbids FMA contraction: one flop per VALU lane-op, so the honest
+                # ceiling is the non-fused f32 rate = half the 157 TF FMA peak (MI355X_MICROARCH.md); both are given
+                "roofline": {"kernel": "k_color_dist2", "bound": "valu-f32 (no FMA)", "unit": "TFLOP/s",
+                             "achieved": 64 * n_col * 8192 / b64 / 1e12, "peak": 78.6, "frac": 64 * n_col * 8192 / b64 / 1e12 / 78.6,
+                             "frac_of_fma_peak_157": 64 * n_col * 8192 / b64 / 1e12 / 157.3, "traffic": None,
+                             "note": "8 flop per colour pair (3 sub, 3 mul, 2 add) x 1024 pairs; batch64_s is wall time of "
+                                     "find_batch (distance kernel + top-k + download)"}}
 print(out["color"], flush=True)
 print(json.dumps(out))
