@@ -102,6 +102,7 @@ _SIGS = {
     "cbh_search_index_batch": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _sz,
                                          _vp, _vp]),
     "cbh_filter_groups": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, C.c_int, _vp, _vp, _sz, _vp, _vp]),
+    "cbh_vdx_verify": (C.c_int, [_vp, _sz]),
     "cbh_records_topk_dev": (C.c_int, [_vp, _sz, _sz, _sz, _sz, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
     "cbh_idx64_set_record_capacity": (C.c_int, [_vp, _sz]),
     "cbh_idx64_remove_ids_only": (C.c_int, [_vp, _vp, _sz]),

@@ -156,6 +156,35 @@ class GpuDctHashIndex : public Index {
     return res;
   }
 
+  /// Database::searchIndex (src/database.cpp:1691-1757) for every needle in one call: the maxThresh escalation
+  /// (only needles still at <= minMatches are searched again), (score, mediaId) order, filterSelf, the maxMatches cut,
+  /// and ids that are not in `knownIds` (the caller's idMap keys, ascending; nullptr = all known) skipped WITHOUT
+  /// consuming a place -- unlike findBatch above, whose fixed cut at maxMatches + 1 is only right when every index
+  /// entry is a known media.  result[i] = the matches of needles[i] as searchIndex would append them to its group.
+  QVector<QVector<Index::Match>> searchIndexBatch(const MediaGroup& needles, const SearchParams& p,
+                                                  const std::vector<uint32_t>* knownIds = nullptr) {
+    std::vector<uint64_t> q;
+    std::vector<uint32_t> ids;
+    for (const Media& m : needles) {
+      q.push_back(m.dctHash());
+      ids.push_back(uint32_t(m.id()));
+    }
+    const size_t k = size_t(p.maxMatches);
+    std::vector<cbh_match> out(q.size() * std::max<size_t>(k, 1));
+    std::vector<uint32_t> counts(q.size());
+    check(cbh_search_index_batch(_idx, q.data(), ids.data(), q.size(), p.dctThresh, p.maxThresh, p.minMatches,
+                                 p.maxMatches, p.filterSelf ? 1 : 0, knownIds ? knownIds->data() : nullptr,
+                                 knownIds ? knownIds->size() : 0, out.data(), counts.data()),
+          "search_index_batch");
+    QVector<QVector<Index::Match>> res;
+    for (size_t i = 0; i < q.size(); ++i) {
+      QVector<Index::Match> r;
+      for (size_t j = 0; j < counts[i]; ++j) r.append(Index::Match(out[i * k + j].id, out[i * k + j].score));
+      res.append(r);
+    }
+    return res;
+  }
+
   cbh_idx64* handle() const { return _idx; }  // for statistics (cbh_idx64_get_stats / cbh_idx64_coalesce_stats)
 
  private:

@@ -451,8 +451,8 @@ size_t cbh_vdx_encode(const int32_t* frames, const uint64_t* hashes, size_t n, c
   return buf.size();
 }
 
-long long cbh_vdx_decode(const uint8_t* buf, size_t len, int32_t* frames, uint64_t* hashes, size_t cap) {
-  if (!buf) return CBH_E_INVAL;
+// header of a v2 file: fields of the first line, as checkHeader_v2 (:214-246) accepts them
+static int vdx_header(const uint8_t* buf, size_t len, size_t* hdr_len, size_t* num_frames) {
   size_t nl = 0;
   while (nl < len && nl < 255 && buf[nl] != '\n') ++nl;
   if (nl >= len || buf[nl] != '\n') return CBH_E_INVAL;
@@ -471,10 +471,25 @@ long long cbh_vdx_decode(const uint8_t* buf, size_t len, int32_t* frames, uint64
   if (f.size() != 8 || f[0] != "cbird video index") return CBH_E_INVAL;
   if (atoi(f[2].c_str()) != 2 || atoi(f[4].c_str()) != 1 || atoi(f[5].c_str()) != 8) return CBH_E_UNSUPPORTED;
   if (atoi(f[3].c_str()) != 1) return CBH_E_UNSUPPORTED;  // other endianness (:242-245)
-  size_t numFrames = strtoul(f[6].c_str(), nullptr, 10);
-  const size_t hdr = nl + 1;
+  *num_frames = strtoul(f[6].c_str(), nullptr, 10);
+  *hdr_len = nl + 1;
+  return CBH_OK;
+}
+
+/* VideoIndex::load_v2 (:350-429).  Like the reference's loader it does NOT look at the "cbir" trailer (that is
+ * verify_v2's job, cbh_vdx_verify below), and a file claiming more than MAX_FRAMES_PER_VIDEO frames is loaded up to
+ * that limit (:366-370, :395) instead of being rejected. */
+long long cbh_vdx_decode(const uint8_t* buf, size_t len, int32_t* frames, uint64_t* hashes, size_t cap) {
+  if (!buf) return CBH_E_INVAL;
+  size_t hdr = 0, numFrames = 0;
+  int rc = vdx_header(buf, len, &hdr, &numFrames);
+  if (rc) return rc;
   if (numFrames == 0) return 0;
-  if (numFrames > (1u << 24)) numFrames = 1u << 24;  // MAX_FRAMES_PER_VIDEO (:366-370)
+  bool reduced = false;
+  if (numFrames > (1u << 24)) {  // MAX_FRAMES_PER_VIDEO
+    numFrames = 1u << 24;
+    reduced = true;
+  }
   if (numFrames > cap) return CBH_E_OVERFLOW;
   if (hdr + 4 > len) return CBH_E_INVAL;
   uint32_t packedLen;
@@ -490,6 +505,7 @@ long long cbh_vdx_decode(const uint8_t* buf, size_t len, int32_t* frames, uint64
       shift = 0;
       if (nfr < numFrames && frames) frames[nfr] = frame;
       ++nfr;
+      if (reduced && nfr == numFrames) break;  // (:395)
     } else {
       jump |= (byte & 0x7F) << shift;
       shift += 7;
@@ -499,10 +515,19 @@ long long cbh_vdx_decode(const uint8_t* buf, size_t len, int32_t* frames, uint64
   const size_t here = hdr + 4 + packedLen;
   size_t pad = 8 - (here % 8);
   if (pad == 8) pad = 0;
-  if (here + pad + numFrames * 8 + 4 > len) return CBH_E_INVAL;  // truncated
-  if (memcmp(buf + here + pad + numFrames * 8, "cbir", 4) != 0) return CBH_E_INVAL;  // trailer (:260-268)
+  if (here + pad + numFrames * 8 > len) return CBH_E_INVAL;  // "hashes": short read
   if (hashes) memcpy(hashes, buf + here + pad, numFrames * 8);
   return (long long)numFrames;
+}
+
+/* VideoIndex::verify_v2 (:248-269), what isValid() runs: header fields + the "cbir" trailer at the end of the file
+ * (a file with 0 frames is valid without one).  1 = valid, 0 = not. */
+int cbh_vdx_verify(const uint8_t* buf, size_t len) {
+  if (!buf) return 0;
+  size_t hdr = 0, numFrames = 0;
+  if (vdx_header(buf, len, &hdr, &numFrames)) return 0;
+  if (numFrames == 0) return 1;
+  return len >= hdr + 4 && memcmp(buf + len - 4, "cbir", 4) == 0;
 }
 
 /* Media::makeVideoIndex frame de-dup (src/media.cpp:958-1024) over a sequence of frame hashes */

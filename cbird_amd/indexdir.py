@@ -156,7 +156,10 @@ class IndexDir:
         for media_id, rows, cols, typ, stride, data in con.execute(q):
             if rows <= 0:
                 continue
-            raw = q_uncompress(bytes(data))
+            try:
+                raw = q_uncompress(bytes(data))
+            except (zlib.error, ValueError):
+                continue  # the reference treats a blob that does not uncompress as invalid data and skips the row
             if last >= media_id or typ != CV_8U or stride != cols or len(raw) != rows * stride:
                 continue  # "sql: ignoring invalid data"
             out.append((int(media_id), np.frombuffer(raw, np.uint8).reshape(rows, cols).copy()))

@@ -65,11 +65,14 @@ class VideoIndex:
 
     @staticmethod
     def isValid(path: str) -> bool:
+        """VideoIndex::isValid (src/videoindex.cpp:90-104) -> verify_v2: header fields + the "cbir" trailer"""
         try:
-            VideoIndex.load(path)
-            return True
-        except (ValueError, OSError):
+            with open(path, "rb") as fp:
+                data = fp.read()
+        except OSError:
             return False
+        buf = np.frombuffer(data, np.uint8)
+        return bool(_lib.lib().cbh_vdx_verify(buf.ctypes.data, len(buf))) if len(buf) else False
 
 
 def make_video_index(frame_hashes, threshold: int = 8) -> VideoIndex:

@@ -343,12 +343,15 @@ int cbh_vidx_find_videos_batch(cbh_vidx*, const int32_t* frames, const uint64_t*
                                const uint64_t* offsets, const uint32_t* needle_ids, size_t n_needles,
                                int thresh, int skip_frames, int min_frames_matched, int min_frames_near,
                                int filter_self, cbh_vmatch* out, size_t cap, uint64_t* out_offsets);
-/* .vdx v2 (VideoIndex::save_v2/load_v2/verify_v2, src/videoindex.cpp:260-429).  encode returns the file
+/* .vdx v2 (VideoIndex::save_v2/load_v2/verify_v2, src/videoindex.cpp:248-429).  encode returns the file
  * size (0 = invalid input: first frame must be 0, frames strictly increasing) and writes it when it fits;
- * decode returns the frame count or a negative CBH_E_* (bad header, truncated, missing "cbir" trailer). */
+ * decode = load_v2: the frame count or a negative CBH_E_* (bad header, short data); like the reference's loader it
+ * does not look at the trailer and loads a file with more than 2^24 frames up to that limit; verify = verify_v2
+ * (what VideoIndex::isValid runs): header + "cbir" trailer, 1 = valid. */
 size_t cbh_vdx_encode(const int32_t* frames, const uint64_t* hashes, size_t n, const char* cbird_version,
                       uint8_t* out, size_t cap);
 long long cbh_vdx_decode(const uint8_t* buf, size_t len, int32_t* frames, uint64_t* hashes, size_t cap);
+int cbh_vdx_verify(const uint8_t* buf, size_t len);
 /* frame de-dup of Media::makeVideoIndex (src/media.cpp:958-1024); keep[i]=1 for stored frames */
 size_t cbh_video_dedup(const uint64_t* hashes, size_t n, int threshold, uint8_t* keep);
 

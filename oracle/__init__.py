@@ -586,6 +586,13 @@ class VideoOracle:
             raise ValueError(f"vdx decode error {n}")
         return f[:n].copy(), h[:n].copy()
 
+    def vdx_verify(self, data: bytes) -> bool:
+        buf = np.frombuffer(data, np.uint8).copy()
+        f = self.L.orc_vdx_verify
+        f.argtypes = [_u8p, C.c_size_t]
+        f.restype = C.c_int
+        return bool(f(buf, len(buf))) if len(buf) else False
+
     def build_entries(self, videos, skip):
         """videos: list of (media_id, frames, hashes) in _mediaId order -> (evidx, eframe, ehash, mediaIds)
         after the insertHashes filters"""

@@ -1050,7 +1050,8 @@ long long orc_vdx_decode(const uint8_t* buf, size_t len, int32_t* frames, uint64
   unsigned long numFrames = strtoul(f[6], NULL, 10);
   size_t hdr = nl + 1;
   if (numFrames == 0) return 0;
-  if (numFrames > (1u << 24)) numFrames = 1u << 24; /* MAX_FRAMES_PER_VIDEO */
+  int reduced = 0;
+  if (numFrames > (1u << 24)) numFrames = 1u << 24, reduced = 1; /* MAX_FRAMES_PER_VIDEO (:366-370) */
   if (numFrames > cap) return -4;
   if (hdr + 4 > len) return -2;
   uint32_t packedLen;
@@ -1067,6 +1068,7 @@ long long orc_vdx_decode(const uint8_t* buf, size_t len, int32_t* frames, uint64
       shift = 0;
       if (nfr < numFrames) frames[nfr] = frame;
       ++nfr;
+      if (reduced && nfr == numFrames) break; /* videoindex.cpp:395 */
     } else {
       jump |= (byte & 0x7F) << shift;
       shift += 7;
@@ -1079,8 +1081,29 @@ long long orc_vdx_decode(const uint8_t* buf, size_t len, int32_t* frames, uint64
   if (pad == 8) pad = 0;
   if (here + pad + numFrames * 8 > len) return -2;
   memcpy(hashes, buf + here + pad, numFrames * 8);
-  if (here + pad + numFrames * 8 + 4 > len || memcmp(buf + here + pad + numFrames * 8, "cbir", 4) != 0) return -3;
+  /* load_v2 (:350-429) stops here: the "cbir" trailer is verify_v2's business (:248-269), see orc_vdx_verify */
   return (long long)numFrames;
+}
+
+/* VideoIndex::verify_v2 (:248-269) = isValid(): header as load_v2 checks it, then -- unless the file stores 0 frames --
+ * the last four bytes must be "cbir".  1 = valid. */
+int orc_vdx_verify(const uint8_t* buf, size_t len) {
+  size_t nl = 0;
+  while (nl < len && nl < 255 && buf[nl] != '\n') ++nl;
+  if (nl >= len) return 0;
+  int colons = 0;
+  for (size_t i = 0; i < nl; ++i) colons += buf[i] == ':';
+  if (colons != 7 || nl < 18 || memcmp(buf, "cbird video index:", 18) != 0) return 0;
+  const char* p = (const char*)buf + 18;
+  const char* f[6];
+  int nf = 0;
+  f[nf++] = p;
+  for (size_t i = 18; i < nl && nf < 6; ++i)
+    if (buf[i] == ':') f[nf++] = (const char*)buf + i + 1;
+  if (nf < 6) return 0;
+  if (atoi(f[1]) != 2 || atoi(f[2]) != 1 || atoi(f[3]) != 1 || atoi(f[4]) != 8) return 0;
+  if (strtoul(f[5], NULL, 10) == 0) return 1;
+  return len >= nl + 5 && memcmp(buf + len - 4, "cbir", 4) == 0;
 }
 
 /* ---- DctVideoIndex: src/dctvideoindex.cpp ---------------------------------------------------------

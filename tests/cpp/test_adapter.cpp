@@ -79,6 +79,25 @@ int main() {
     if (db.media[size_t(i)].type != 1 || i + 1 == 7) continue;
     CHECK(res[i].count() >= 1 && res[i][0].score == 0);
   }
+  // searchIndex for the whole batch: self filtered, cut at maxMatches, unknown ids skipped without taking a place
+  {
+    SearchParams sp;
+    sp.dctThresh = 3;
+    sp.maxMatches = 2;
+    std::vector<uint32_t> known;
+    for (auto& r : db.media)
+      if (r.id % 7 != 0) known.push_back(r.id);  // every 7th media is "not in the database" for this caller
+    auto sb = idx.searchIndexBatch(needles, sp, &known);
+    CHECK(sb.count() == 300);
+    for (int i = 0; i < 300; ++i) {
+      CHECK(sb[i].count() <= 2);
+      int prev = -1;
+      for (auto& mt : sb[i]) {
+        CHECK(mt.mediaId != uint32_t(i + 1) && mt.mediaId % 7 != 0 && mt.score < 3 && mt.score >= prev);
+        prev = mt.score;
+      }
+    }
+  }
   QSet<mediaid_t> ids = idx.mediaIds(db, "", "");
   CHECK(ids.size() == size_t(n - n / 50 - 2 + 1));
   printf("adapter ok: %d needles checked\n", checked);

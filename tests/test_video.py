@@ -48,19 +48,45 @@ def test_vdx_byte_layout(vorc):
     assert data[hs + 32:] == b"cbir"
 
 
-def test_vdx_rejects_corruption(vorc):
+def test_vdx_rejects_corruption(vorc, tmp_path):
     from cbird_amd.video import VideoIndex
 
     good = vorc.vdx_encode([0, 5, 9], [1, 2, 3])
-    for bad in (good[:-4], good[:-1], b"not a cbird video index:\n", good.replace(b":2:1:1:8:", b":3:1:1:8:")):
+    for bad in (good[:-5], good[:30], b"not a cbird video index:\n", good.replace(b":2:1:1:8:", b":3:1:1:8:")):
         with pytest.raises(ValueError):
             vorc.vdx_decode(bad)
         with pytest.raises(ValueError):
             VideoIndex.from_bytes(bad)
+        assert not vorc.vdx_verify(bad)
     with pytest.raises(ValueError):
         vorc.vdx_encode([1, 2], [1, 2])  # first frame must be 0
     with pytest.raises(ValueError):
         vorc.vdx_encode([0, 2, 2], [1, 2, 3])  # non-sequential
+
+
+def test_vdx_load_does_not_need_the_trailer_but_isvalid_does(vorc, tmp_path):
+    """load_v2 (src/videoindex.cpp:350-429) never looks at "cbir"; verify_v2 (:248-269, what isValid runs and what
+    Engine::update uses to re-queue videos) does.  A file cut inside the trailer therefore LOADS and is INVALID."""
+    from cbird_amd.video import VideoIndex
+
+    good = vorc.vdx_encode([0, 5, 9, 400], [1, 2, 3, 4])
+    assert vorc.vdx_verify(good)
+    for cut in (good[:-4], good[:-1]):
+        f, h = vorc.vdx_decode(cut)
+        assert f.tolist() == [0, 5, 9, 400] and h.tolist() == [1, 2, 3, 4]
+        vi = VideoIndex.from_bytes(cut)
+        assert vi.frames == [0, 5, 9, 400] and vi.hashes == [1, 2, 3, 4]
+        assert not vorc.vdx_verify(cut)
+        p = tmp_path / "cut.vdx"
+        p.write_bytes(cut)
+        assert not VideoIndex.isValid(str(p))
+    p = tmp_path / "good.vdx"
+    p.write_bytes(good)
+    assert VideoIndex.isValid(str(p)) and not VideoIndex.isValid(str(tmp_path / "missing.vdx"))
+    empty = vorc.vdx_encode([], [])
+    assert vorc.vdx_verify(empty)  # "no frames stored": valid without a trailer (:256-259)
+    p.write_bytes(empty)
+    assert VideoIndex.isValid(str(p))
 
 
 def test_dedup_rule(vorc):
