@@ -7,8 +7,8 @@ storage/bookkeeping (out of scope).
 
 `similar()` has two routes with identical results: the reference's shape (one find() per needle, Python code
 below) and, for DctHashIndex, the whole job behind the C-ABI (cbh_search_index_batch + cbh_filter_groups).
-oracle/search_index.c restates the same reference lines independently in C; tests/test_database.py holds all three
-against each other.
+The test suite holds both against a third, independent C restatement of the same reference lines
+(tests/test_database.py).
 """
 from __future__ import annotations
 
