@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for c in SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F8 SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_WAVE_CYCLES; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --dht 3,6 > /dev/null 2> /tmp/pmc_$c.err
+  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-video --dht 3,6 > /dev/null 2> /tmp/pmc_$c.err
   p=$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)
   if [ -n "$p" ]; then python3 - "$p" "$c" <<'PY'
 import csv, sys
