@@ -15,7 +15,7 @@
 // the library is built with -ffp-contract=off), one running minimum per needle colour and one per haystack
 // colour (either side can be "a"); sqrtf is monotonic, so it is applied to the 32 minima instead of the 1024
 // pair distances (bit-identical result), then summed in index order starting from 1.0f.
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <cfloat>
 #include <map>
@@ -683,12 +683,12 @@ int cbh_color_distances(cbh_color* c, const void* needle_descs, size_t nq, float
 static int color_full_sort_one(cbh_color* c, size_t q_in_chunk, int k, cbh_match* out_q, uint32_t valid) {
   hipLaunchKernelGGL(k_color_keys, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
                      c->d_scores + q_in_chunk * c->n, c->d_ids, (uint32_t)c->n, c->d_keys);
-  hipcub::DoubleBuffer<unsigned long long> db(c->d_keys, c->d_keys_alt);
+  rocprim::double_buffer<unsigned long long> db(c->d_keys, c->d_keys_alt);
   size_t tb = c->tmp_bytes;
-  CBH_HIP(hipcub::DeviceRadixSort::SortKeys(c->d_tmp, tb, db, c->n, 0, 64, c->stream));
+  CBH_HIP(rocprim::radix_sort_keys(c->d_tmp, tb, db, c->n, 0, 64, c->stream));
   const size_t take = std::min<size_t>(std::min<size_t>((size_t)k, c->n), valid);
   std::vector<unsigned long long> head(take);
-  if (take) CBH_HIP(hipMemcpyAsync(head.data(), db.Current(), take * 8, hipMemcpyDeviceToHost, c->stream));
+  if (take) CBH_HIP(hipMemcpyAsync(head.data(), db.current(), take * 8, hipMemcpyDeviceToHost, c->stream));
   CBH_HIP(hipStreamSynchronize(c->stream));
   for (size_t j = 0; j < take; ++j) out_q[j] = cbh_match{(uint32_t)head[j], (int32_t)(head[j] >> 32)};
   return CBH_OK;

@@ -4,10 +4,13 @@
 // u64 sort therefore yields exactly the order cbird produces after Database::searchIndex's
 // std::sort on score (src/database.cpp:1729, operator< src/index.h:284), with the unspecified
 // tie order of the reference fixed to ascending mediaId.  Distances span 7 bits, so this is a
-// counting problem; the radix passes come from rocPRIM (hipcub::DeviceRadixSort) restricted
-// to the significant bits.  Selection (first max_per_query of each needle, database.cpp:1735)
+// counting problem; the batched per-needle cut no longer sorts at all (topk.hip).  What still orders ALL records --
+// a single needle's complete match list, cuts with k > 64 -- uses rocPRIM's radix sort, called directly and
+// restricted to the significant bits.  Selection (first max_per_query of each needle, database.cpp:1735)
 // is one binary search per needle over the sorted list.
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "cbh_internal.h"
 
@@ -84,18 +87,18 @@ __global__ __launch_bounds__(256) void k_remove_ids(uint64_t* __restrict__ hashe
 
 size_t sort_records_scratch_bytes(size_t n) {
   size_t bytes = 0;
-  hipcub::DoubleBuffer<cbh_record> db(nullptr, nullptr);
-  (void)hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, db, n, 0, 64, (hipStream_t)0);
+  rocprim::double_buffer<cbh_record> db(nullptr, nullptr);
+  (void)rocprim::radix_sort_keys(nullptr, bytes, db, n, 0, 64, (hipStream_t)0);
   return bytes;
 }
 
 int launch_sort_records(cbh_record* d_rec, cbh_record* d_alt, size_t n, size_t nq, void* d_tmp,
                         size_t tmp_bytes, hipStream_t stream) {
   if (n < 2) return CBH_OK;
-  hipcub::DoubleBuffer<cbh_record> db(d_rec, d_alt);
-  CBH_HIP(hipcub::DeviceRadixSort::SortKeys(d_tmp, tmp_bytes, db, n, 0, sig_bits(nq), stream));
-  if (db.Current() != d_rec)
-    CBH_HIP(hipMemcpyAsync(d_rec, db.Current(), n * sizeof(cbh_record), hipMemcpyDeviceToDevice,
+  rocprim::double_buffer<cbh_record> db(d_rec, d_alt);
+  CBH_HIP(rocprim::radix_sort_keys(d_tmp, tmp_bytes, db, n, 0, (unsigned)sig_bits(nq), stream));
+  if (db.current() != d_rec)
+    CBH_HIP(hipMemcpyAsync(d_rec, db.current(), n * sizeof(cbh_record), hipMemcpyDeviceToDevice,
                            stream));
   return CBH_OK;
 }
