@@ -101,17 +101,17 @@ def _worker(rank, world, port, n, ragged, q_out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,ragged", [(601, False), (1000, True)])
-def test_sharded_similar_world2_equals_single(n, ragged):
+@pytest.mark.parametrize("n,ragged,world", [(601, False, 2), (1000, True, 2), (457, True, 3)])
+def test_sharded_similar_world2_equals_single(n, ragged, world):
     from cbird_amd import synth
     from oracle import Oracle
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, ragged, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, ragged, q)) for r in range(world)]
     [p.start() for p in procs]
-    results = dict(q.get(timeout=120) for _ in range(2))
+    results = dict(q.get(timeout=120) for _ in range(world))
     [p.join(timeout=60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     h, ids = synth.make_hashes(n, seed=77, planted_frac=0.3)
@@ -119,7 +119,7 @@ def test_sharded_similar_world2_equals_single(n, ragged):
     orc = Oracle()
     for dht in (2, 7):
         wi, ws, wc = orc.find64_batch(h, ids, h, dht, 4)
-        for r in range(2):
+        for r in range(world):
             gi, gs, gc = results[r][dht]
             assert (gc == wc.astype(np.int32)).all(), (dht, r)
             assert (gi.view(np.uint32) == wi).all() and (gs == ws).all(), (dht, r)

@@ -151,6 +151,40 @@ def test_mfma_variant_is_bit_identical(gpu, orc):
     assert (gpu.dct_hash64_batch(imgs) == want).all()
 
 
+def test_float_magic_divide_variant_is_bit_identical(gpu, orc):
+    """k_dcthash_256 with nearest(S/49) taken from the bit pattern of fma(float(S), 1/49, 1.5 * 2^23) (knob "hash_div" 1)
+    == the integer multiply-shift form == oracle, on images that hit every quotient incl. the extremes; the occupancy
+    knob "hash_lds_pad" changes nothing either"""
+    import torch
+
+    from cbird_amd import _lib, synth
+
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+    imgs = np.concatenate([synth.make_images(24, seed=5), rng.integers(0, 256, (24, 256, 256), dtype=np.uint8)])
+    imgs[0] = 0
+    imgs[1] = 255
+    imgs[2, :, ::2] = 255  # column stripes: window sums step through multiples of 255
+    imgs[3] = (np.arange(256)[None, :] * 7 + np.arange(256)[:, None] * 3) % 256
+    want = orc.dcthash64_batch(imgs)
+    d = torch.from_numpy(imgs).cuda()
+    try:
+        for div, pad in ((1, 0), (1, 12288), (0, 20480)):
+            L.cbh_set_tuning(b"hash_div", div)
+            L.cbh_set_tuning(b"hash_lds_pad", pad)
+            assert (gpu.dct_hash64_batch(imgs) == want).all(), (div, pad)
+            out = torch.zeros(len(imgs), dtype=torch.int64, device="cuda")
+            tiles = torch.zeros((len(imgs), 32, 32), dtype=torch.uint8, device="cuda")
+            _lib.check(L.cbh_dcthash_tiles_dev(d.data_ptr(), len(imgs), 256, 256, 256, 65536, out.data_ptr(),
+                                               tiles.data_ptr(), 0, None), "tiles")
+            t = tiles.cpu().numpy()
+            for i in range(0, len(imgs), 5):
+                assert (t[i] == orc.tile32(imgs[i])).all(), (div, pad, i)
+    finally:
+        L.cbh_set_tuning(b"hash_div", 0)
+        L.cbh_set_tuning(b"hash_lds_pad", 0)
+
+
 def test_hash_random_geometries_and_strides(gpu, orc):
     """Random widths/heights (every blur kernel size, widths around the 8-pixel lane groups and the 2048-column
     workgroups, integer and fractional resize ratios) and padded row/image strides, on the fast general
