@@ -826,6 +826,10 @@ int cbh_set_tuning(const char* key, int value) {
     g_video_host_reduce = value;
     return CBH_OK;
   }
+  if (!strcmp(key, "hash_regs")) {
+    set_hash_regs(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "hash_div")) {
     set_hash_div(value);
     return CBH_OK;

@@ -1462,6 +1462,189 @@ __global__ __launch_bounds__(256) void k_blur_area_stream(const unsigned char* _
   }
 }
 
+// (u16 half of a dword) * m in one VALU op (SDWA word select); operands < 2^24
+__device__ __forceinline__ unsigned mul24_word0(unsigned p, unsigned m) {
+  unsigned r;
+  asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD"
+      : "=v"(r)
+      : "v"(p), "v"(m));
+  return r;
+}
+__device__ __forceinline__ unsigned mul24_word1(unsigned p, unsigned m) {
+  unsigned r;
+  asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+      : "=v"(r)
+      : "v"(p), "v"(m));
+  return r;
+}
+
+// k_blur_area_regs: the streaming kernel with the blur input taken STRAIGHT FROM GLOBAL MEMORY into registers, the way
+// k_dcthash_256 does it, instead of being staged through LDS: per source row a lane loads its own 8 pixels (one
+// aligned 8-byte load) and the dword on either side of them (the neighbours' pixels come from L1/L2; the two border
+// lanes mirror their own pixels with a per-lane v_perm selector = REFLECT_101), a ring of PF rows in flight across the
+// step boundaries.  LDS only holds the blurred rows of a step for the horizontal INTER_AREA chains, which are
+// k_blur_area_stream's.  Per step this removes the staging stores, the two window reads per row and lane, one of the
+// three workgroup barriers, and the load latency that sat exposed behind it.
+// Preconditions (checked by the launcher; everything else takes k_blur_area_stream): whole images (no view),
+// w a multiple of 8 and <= 2048 (one workgroup spans the row), image base / row stride / image stride multiples of 8.
+template <int K>
+__global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __restrict__ imgs, int w, int h,
+                                                        unsigned row_stride, size_t img_stride,
+                                                        const AreaTab* __restrict__ xtab,
+                                                        const int* __restrict__ xfirst, int isx,
+                                                        int steps /* per strip */,
+                                                        float* __restrict__ rows /* n * h * 32 */,
+                                                        int ipb /* images side by side in the workgroup */,
+                                                        unsigned n_imgs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_fused[];
+  constexpr int R = K / 2;
+  constexpr int kStep = StreamK<K>::step;
+  constexpr int PF = K == 7 ? 7 : 5;  // rows in flight; divides kStep so that the ring slot of a row is static
+  const int T = (int)blockDim.x, tid = (int)threadIdx.x;
+  const int L = w >> 3;  // lanes per image: 8 columns each.  A 640-pixel row needs 80 lanes: three images share 256
+  const int islot = tid / L;
+  const unsigned img_i = blockIdx.z * (unsigned)ipb + (unsigned)islot;
+  const bool lane_live = islot < ipb && img_i < n_imgs;
+  const int tl = lane_live ? tid - islot * L : 0;
+  unsigned char* __restrict__ sblur_all = s_fused;  // ipb x kStep x w blurred rows
+  unsigned char* __restrict__ sblur = sblur_all + (size_t)(lane_live ? islot : 0) * (size_t)kStep * (size_t)w;
+  float* __restrict__ salpha = reinterpret_cast<float*>(s_fused + (size_t)ipb * (size_t)kStep * (size_t)w);
+  const int k_end = isx ? 0 : xfirst[32];
+  const int strip_out = steps * kStep - 2 * R;
+  const int o0 = (int)blockIdx.y * strip_out;
+  const int o1 = min(h, o0 + strip_out);
+  const unsigned char* __restrict__ img = imgs + (size_t)(lane_live ? img_i : blockIdx.z * (unsigned)ipb) * img_stride;
+  for (int i = tid; i < k_end; i += T) salpha[i] = xtab[i].alpha;
+  // v_perm_b32(S0, S1, sel): selector 4..7 -> S0 byte 0..3, 0..3 -> S1 byte 0..3 (see k_dcthash_256)
+  const unsigned selL = tl == 0 ? 0x01020300u : 0x07060504u;      // lane 0: (x, px3, px2, px1) from its own pixels
+  const unsigned selR = tl == L - 1 ? 0x00000102u : 0x07060504u;  // last lane: (px w-2, w-3, w-4, x)
+  const unsigned offC = 8u * (unsigned)tl;
+  const unsigned offL = tl == 0 ? offC : offC - 4u;
+  const unsigned offR = tl == L - 1 ? offC + 4u : offC + 8u;
+  auto row_base = [&](int s) -> unsigned {  // byte offset of (reflected, clamped) source row s
+    int ry = s < 0 ? -s : (s >= h ? 2 * (h - 1) - s : s);
+    ry = ry < 0 ? 0 : (ry >= h ? h - 1 : ry);
+    return (unsigned)ry * row_stride;
+  };
+  unsigned ring[K][4];
+  unsigned S[4];
+#pragma unroll
+  for (int j = 0; j < K; ++j)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ring[j][c] = 0u;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) S[c] = BlurK<K>::add | (BlurK<K>::add << 16);
+  // area-pass roles: lane = output column cc of row group rg; the T / 32 row groups walk the (image, row) list of the
+  // whole workgroup, two entries per turn (they share the weights)
+  const int G = T >> 5, rg = tid >> 5, cc = tid & 31;
+  const int ak0 = isx ? 0 : xfirst[cc];
+  const int ank = isx ? isx : xfirst[cc + 1] - ak0;
+  const int acol = isx ? cc * isx : xtab[ak0].si;
+  const float* __restrict__ al = salpha + ak0;
+
+  const int sfirst = o0 - R;  // first source row of the strip
+  uint2 rawC[PF];
+  unsigned rawL[PF], rawR[PF];
+#pragma unroll
+  for (int j = 0; j < PF; ++j) {
+    const unsigned rb = row_base(sfirst + j);
+    rawC[j] = *reinterpret_cast<const uint2*>(img + rb + offC);
+    rawL[j] = *reinterpret_cast<const unsigned*>(img + rb + offL);
+    rawR[j] = *reinterpret_cast<const unsigned*>(img + rb + offR);
+  }
+  for (int st = 0; st < steps; ++st) {
+    const int s0 = sfirst + st * kStep;  // first source row consumed in this step
+    if (s0 - R >= o1) break;             // nothing left to output (uniform)
+#pragma unroll
+    for (int rr = 0; rr < kStep; ++rr) {
+      const int j = rr % K, pj = rr % PF;
+      const uint2 dC = rawC[pj];
+      const unsigned dl = rawL[pj], dr = rawR[pj];
+      {
+        const unsigned rb = row_base(s0 + rr + PF);
+        rawC[pj] = *reinterpret_cast<const uint2*>(img + rb + offC);
+        rawL[pj] = *reinterpret_cast<const unsigned*>(img + rb + offL);
+        rawR[pj] = *reinterpret_cast<const unsigned*>(img + rb + offR);
+      }
+      const unsigned W[4] = {__builtin_amdgcn_perm(dl, dC.x, selL), dC.x, dC.y, __builtin_amdgcn_perm(dr, dC.y, selR)};
+      unsigned P[4];
+      hsum_pairs<R>(W, P);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        S[c] = (S[c] - ring[j][c]) + P[c];
+        ring[j][c] = P[c];
+      }
+      // nearest(S / K^2) = byte 3 of (S + add) * m: one SDWA multiply per pixel (word select), then the eight
+      // quotient bytes are gathered with v_perm_b32 (selector 0x0c = zero byte): 14 ops per 8 pixels instead of ~30
+      unsigned pr[8];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        pr[2 * c] = mul24_word0(S[c], BlurK<K>::m);
+        pr[2 * c + 1] = mul24_word1(S[c], BlurK<K>::m);
+      }
+      uint2 qo;
+      qo.x = __builtin_amdgcn_perm(pr[1], pr[0], 0x0c0c0703u) | __builtin_amdgcn_perm(pr[3], pr[2], 0x07030c0cu);
+      qo.y = __builtin_amdgcn_perm(pr[5], pr[4], 0x0c0c0703u) | __builtin_amdgcn_perm(pr[7], pr[6], 0x07030c0cu);
+      if (lane_live) *reinterpret_cast<uint2*>(sblur + (size_t)rr * (size_t)w + offC) = qo;
+    }
+    __syncthreads();
+    // ---- horizontal INTER_AREA chains for the valid blurred rows of this step: local row rr <-> image row s0 + rr - R
+    {
+      const int ob = s0 - R;
+      const int lo = max(0, o0 - ob), hi = min(kStep, o1 - ob);  // valid local rows [lo, hi), the same for every image
+      const int nv = hi - lo;                                     // valid rows per image
+      const int total = nv * ipb;                                 // (image, row) entries of the workgroup
+      for (int e = rg; e < total; e += 2 * G) {
+        const int e2 = e + G;
+        const bool two = e2 < total;
+        const int ia = e / nv, ra = lo + (e - ia * nv);
+        const int ib = two ? e2 / nv : ia, rb_ = two ? lo + (e2 - ib * nv) : ra;
+        const unsigned ga = blockIdx.z * (unsigned)ipb + (unsigned)ia, gb = blockIdx.z * (unsigned)ipb + (unsigned)ib;
+        const bool la = ga < n_imgs, lb = two && gb < n_imgs;
+        const unsigned char* __restrict__ Sa = sblur_all + ((size_t)ia * kStep + (size_t)ra) * (size_t)w + acol;
+        const unsigned char* __restrict__ Sb = sblur_all + ((size_t)ib * kStep + (size_t)rb_) * (size_t)w + acol;
+        float* __restrict__ oa = rows + ((size_t)(la ? ga : 0u) * (size_t)h + (size_t)(ob + ra)) * 32 + cc;
+        float* __restrict__ obp = rows + ((size_t)(lb ? gb : 0u) * (size_t)h + (size_t)(ob + rb_)) * 32 + cc;
+        if (isx) {
+          unsigned sa = 0, sb = 0;
+          for (int u = 0; u < ank; ++u) {
+            sa += Sa[u];
+            sb += Sb[u];
+          }
+          if (la) *oa = __uint_as_float(sa);
+          if (lb) *obp = __uint_as_float(sb);
+        } else {
+          float ba = 0.f, bb = 0.f;
+          int k = 0;
+          for (; k + 8 <= ank; k += 8) {
+            float a[8];
+            unsigned pa[8], pb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              a[u] = al[k + u];
+              pa[u] = Sa[k + u];
+              pb[u] = Sb[k + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              ba += (float)pa[u] * a[u];
+              bb += (float)pb[u] * a[u];
+            }
+          }
+          for (; k < ank; ++k) {
+            const float av = al[k];
+            ba += (float)Sa[k] * av;
+            bb += (float)Sb[k] * av;
+          }
+          if (la) *oa = ba;
+          if (lb) *obp = bb;
+        }
+      }
+    }
+    __syncthreads();  // the blurred rows are consumed before the next step overwrites them
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void k_tile_hash(const float* __restrict__ rows, int yn,
                                                         const AreaTab* __restrict__ ytab,
                                                         const int* __restrict__ yfirst, int isx, int isy,
@@ -2194,6 +2377,10 @@ int g_hash_stream = 1;  // k_blur_area_stream: 0 off, 1 auto (strips of 3..8 ste
 void set_hash_stream(int v) {
   if (v >= 0) g_hash_stream = v;
 }
+int g_hash_regs = 1;  // k_blur_area_regs (blur input from global memory into registers) where its preconditions hold
+void set_hash_regs(int v) {
+  if (v >= 0 && v <= 3) g_hash_regs = v;  // 0 off, 1 on (automatic image packing), 2 on / never pack, 3 on / always pack
+}
 int g_hash_fused = 1;  // k_blur_area (blur + horizontal area pass in one kernel): 0 off, v >= 1 for widths >= v (measured: wins from 64 up)
 void set_hash_fused(int on) {
   if (on >= 0) g_hash_fused = on;
@@ -2580,6 +2767,36 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
           const int strip_out = steps * kstep - 2 * (K_ / 2);
           dim3 gs((unsigned)ncol, (unsigned)((h + strip_out - 1) / strip_out), (unsigned)m);
           const size_t ssmem = (size_t)kstep * fpitch + (size_t)(integer ? 0 : at.xn) * sizeof(float);
+          if (g_hash_regs && ncol == 1 && w % 8 == 0 && ((uintptr_t)src % 8) == 0 && row_stride % 8 == 0 &&
+              img_stride % 8 == 0 && (size_t)h * row_stride < ((size_t)1 << 31)) {
+            // blur input straight from global memory into registers (k_blur_area_regs); LDS = blurred rows + weights
+            // lanes per image = w / 8.  Images whose last wave would be mostly empty share a 256-lane workgroup side by
+            // side (640 px: 80 of 128 lanes busy alone, 240 of 256 as three: +12 %); where the lanes are already
+            // well used the larger workgroup only costs (more waves per barrier: -5..-9 % measured at 400, 512, 1024 px)
+            const int Lr = w / 8, Lw = (Lr + 63) / 64 * 64;
+            const bool pack = g_hash_regs == 3 || (g_hash_regs == 1 && Lr * 100 < Lw * 72);  // knob 2: never, 3: always
+            const int ipb = (Lr <= 128 && pack) ? 256 / Lr : 1;
+            const size_t rsmem = (size_t)ipb * kstep * (size_t)w + (size_t)(integer ? 0 : at.xn) * sizeof(float);
+            const unsigned Tr = (unsigned)std::max(64, (ipb * Lr + 63) / 64 * 64);
+#define CBH_REGS(KK)                                                                                       \
+  do {                                                                                                     \
+    if (rsmem > 64 * 1024)                                                                                 \
+      CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_area_regs<KK>),                     \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)rsmem));                \
+    hipLaunchKernelGGL(k_blur_area_regs<KK>, dim3(1, gs.y, (unsigned)((m + ipb - 1) / ipb)), dim3(Tr), rsmem, stream, \
+                       src, w, h, (unsigned)row_stride, img_stride, at.x, at.xfirst, isx, steps, d_rowsf, ipb,  \
+                       (unsigned)m);                                                                         \
+  } while (0)
+            switch (K_) {
+              case 3: CBH_REGS(3); break;
+              case 5: CBH_REGS(5); break;
+              default: CBH_REGS(7); break;
+            }
+#undef CBH_REGS
+            hipLaunchKernelGGL(k_tile_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_rowsf, h, at.y, at.yfirst,
+                               isx, isy, 1, tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
+            continue;
+          }
 #define CBH_STREAM(KK)                                                                                      \
   do {                                                                                                      \
     if (ssmem > 64 * 1024)                                                                                  \

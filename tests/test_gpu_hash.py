@@ -185,6 +185,48 @@ def test_float_magic_divide_variant_is_bit_identical(gpu, orc):
         L.cbh_set_tuning(b"hash_lds_pad", 0)
 
 
+def test_register_streaming_kernel(gpu, orc):
+    """k_blur_area_regs (blur input straight from global memory; knob "hash_regs") at the geometries it accepts --
+    widths that are multiples of 8 up to 2048, aligned strides -- in strips of 3 and 8 steps, all three blur sizes,
+    integer and fractional resize ratios, heights around the step and strip boundaries: hashes and tiles equal the
+    oracle and the LDS-staged streaming kernel it replaces there"""
+    from cbird_amd import _lib
+    import torch
+
+    L = _lib.lib()
+    rng = np.random.default_rng(99)
+    geos = [(640, 480), (400, 300), (600, 450), (1024, 768), (1920, 1080), (2048, 96), (512, 512), (64, 64), (72, 56),
+            (96, 120), (128, 100), (200, 57), (256, 250), (8, 200), (2040, 33), (320, 41), (320, 42), (320, 43),
+            (1000, 1000), (264, 136)]
+    try:
+        for (w, h) in geos:
+            n = 3
+            row_stride = w + 8 * int(rng.integers(0, 3))
+            img_stride = h * row_stride + 8 * int(rng.integers(0, 5))
+            buf = rng.integers(0, 256, (n, img_stride), dtype=np.uint8)
+            if (w, h) == (640, 480):  # flat and extreme images too
+                buf[0] = 0
+                buf[1] = 255
+            imgs = np.stack([buf[i, : h * row_stride].reshape(h, row_stride)[:, :w] for i in range(n)])
+            want = orc.dcthash64_batch(np.ascontiguousarray(imgs))
+            d = torch.from_numpy(buf).cuda()
+            for regs, steps in ((1, 3), (1, 8), (0, 3)):
+                L.cbh_set_tuning(b"hash_regs", regs)
+                L.cbh_set_tuning(b"hash_stream", steps)
+                out = torch.zeros(n, dtype=torch.int64, device="cuda")
+                tiles = torch.zeros((n, 32, 32), dtype=torch.uint8, device="cuda")
+                _lib.check(L.cbh_dcthash_tiles_dev(d.data_ptr(), n, w, h, row_stride, img_stride, out.data_ptr(),
+                                                   tiles.data_ptr(), 0, None), "tiles")
+                got = out.cpu().numpy().view(np.uint64)
+                t = tiles.cpu().numpy()
+                for i in range(n):
+                    assert (t[i] == orc.tile32(np.ascontiguousarray(imgs[i]))).all(), (w, h, regs, steps, i)
+                assert (got == want).all(), (w, h, regs, steps)
+    finally:
+        L.cbh_set_tuning(b"hash_regs", 1)
+        L.cbh_set_tuning(b"hash_stream", 1)
+
+
 def test_hash_random_geometries_and_strides(gpu, orc):
     """Random widths/heights (every blur kernel size, widths around the 8-pixel lane groups and the 2048-column
     workgroups, integer and fractional resize ratios) and padded row/image strides, on the fast general
