@@ -910,6 +910,39 @@ struct BlurK<7> {
   static constexpr unsigned m = 342393u, add = 24u;  // 49 * m - 2^24 = 41
 };
 
+// (u16 half of a dword) * m in one VALU op (SDWA word select); operands < 2^24
+__device__ __forceinline__ unsigned mul24_word0(unsigned p, unsigned m) {
+  unsigned r;
+  asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD"
+      : "=v"(r)
+      : "v"(p), "v"(m));
+  return r;
+}
+__device__ __forceinline__ unsigned mul24_word1(unsigned p, unsigned m) {
+  unsigned r;
+  asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+      : "=v"(r)
+      : "v"(p), "v"(m));
+  return r;
+}
+
+// the eight blurred pixels of a lane from its four packed column-sum pairs: nearest(S / K^2) = byte 3 of (S + add) * m
+// -- one SDWA multiply per pixel (word select), then the quotient bytes are gathered with v_perm_b32 (selector
+// 0x0c = zero byte): 14 ops per 8 pixels (and/shift + multiply + shift + shift/or packing took ~30)
+template <int K>
+__device__ __forceinline__ uint2 blur_quotients(const unsigned (&S)[4]) {
+  unsigned pr[8];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    pr[2 * c] = mul24_word0(S[c], BlurK<K>::m);
+    pr[2 * c + 1] = mul24_word1(S[c], BlurK<K>::m);
+  }
+  uint2 qo;
+  qo.x = __builtin_amdgcn_perm(pr[1], pr[0], 0x0c0c0703u) | __builtin_amdgcn_perm(pr[3], pr[2], 0x07030c0cu);
+  qo.y = __builtin_amdgcn_perm(pr[5], pr[4], 0x0c0c0703u) | __builtin_amdgcn_perm(pr[7], pr[6], 0x07030c0cu);
+  return qo;
+}
+
 constexpr int kBlurRB = 16;  // output rows per workgroup
 
 // byte mask of window dword d (bytes 4d..4d+3 of the 16-byte window whose byte 4 is the lane's pixel 0) for the
@@ -1214,14 +1247,7 @@ __global__ __launch_bounds__(256) void k_blur_area(const unsigned char* __restri
           ring[j][c] = P[c];
         }
         if (rr >= 2 * R) {
-          unsigned q[8];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            q[2 * c] = ((S[c] & 0xffffu) * BlurK<K>::m) >> 24;
-            q[2 * c + 1] = ((S[c] >> 16) * BlurK<K>::m) >> 24;
-          }
-          qo[rr - 2 * R].x = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
-          qo[rr - 2 * R].y = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
+          qo[rr - 2 * R] = blur_quotients<K>(S);
         }
       }
     }
@@ -1393,14 +1419,7 @@ __global__ __launch_bounds__(256) void k_blur_area_stream(const unsigned char* _
           S[c] = (S[c] - ring[j][c]) + P[c];
           ring[j][c] = P[c];
         }
-        unsigned q[8];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          q[2 * c] = ((S[c] & 0xffffu) * BlurK<K>::m) >> 24;
-          q[2 * c + 1] = ((S[c] >> 16) * BlurK<K>::m) >> 24;
-        }
-        qo[rr].x = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
-        qo[rr].y = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
+        qo[rr] = blur_quotients<K>(S);
       }
     }
     __syncthreads();  // every lane has read the source rows
@@ -1460,22 +1479,6 @@ __global__ __launch_bounds__(256) void k_blur_area_stream(const unsigned char* _
     }
     __syncthreads();  // the blurred rows are consumed before the next step overwrites them
   }
-}
-
-// (u16 half of a dword) * m in one VALU op (SDWA word select); operands < 2^24
-__device__ __forceinline__ unsigned mul24_word0(unsigned p, unsigned m) {
-  unsigned r;
-  asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD"
-      : "=v"(r)
-      : "v"(p), "v"(m));
-  return r;
-}
-__device__ __forceinline__ unsigned mul24_word1(unsigned p, unsigned m) {
-  unsigned r;
-  asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
-      : "=v"(r)
-      : "v"(p), "v"(m));
-  return r;
 }
 
 // k_blur_area_regs: the streaming kernel with the blur input taken STRAIGHT FROM GLOBAL MEMORY into registers, the way
@@ -1574,17 +1577,7 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
         S[c] = (S[c] - ring[j][c]) + P[c];
         ring[j][c] = P[c];
       }
-      // nearest(S / K^2) = byte 3 of (S + add) * m: one SDWA multiply per pixel (word select), then the eight
-      // quotient bytes are gathered with v_perm_b32 (selector 0x0c = zero byte): 14 ops per 8 pixels instead of ~30
-      unsigned pr[8];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        pr[2 * c] = mul24_word0(S[c], BlurK<K>::m);
-        pr[2 * c + 1] = mul24_word1(S[c], BlurK<K>::m);
-      }
-      uint2 qo;
-      qo.x = __builtin_amdgcn_perm(pr[1], pr[0], 0x0c0c0703u) | __builtin_amdgcn_perm(pr[3], pr[2], 0x07030c0cu);
-      qo.y = __builtin_amdgcn_perm(pr[5], pr[4], 0x0c0c0703u) | __builtin_amdgcn_perm(pr[7], pr[6], 0x07030c0cu);
+      const uint2 qo = blur_quotients<K>(S);
       if (lane_live) *reinterpret_cast<uint2*>(sblur + (size_t)rr * (size_t)w + offC) = qo;
     }
     __syncthreads();
@@ -1953,16 +1946,7 @@ __device__ __forceinline__ void blur_lds8(const unsigned char* __restrict__ reg,
             ring[j][c] = Pk[c];
           }
           if (rr - r0 >= 2 * R) {
-            unsigned q[8];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              q[2 * c] = ((S[c] & 0xffffu) * BlurK<K>::m) >> 24;
-              q[2 * c + 1] = ((S[c] >> 16) * BlurK<K>::m) >> 24;
-            }
-            uint2 o;
-            o.x = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
-            o.y = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
-            *reinterpret_cast<uint2*>(dst + (rr - 2 * R) * Pb + 8 * l) = o;
+            *reinterpret_cast<uint2*>(dst + (rr - 2 * R) * Pb + 8 * l) = blur_quotients<K>(S);
           }
         }
       }
