@@ -1489,8 +1489,10 @@ __global__ __launch_bounds__(256) void k_blur_area_stream(const unsigned char* _
 // k_blur_area_stream's.  Per step this removes the staging stores, the two window reads per row and lane, one of the
 // three workgroup barriers, and the load latency that sat exposed behind it.
 // Preconditions (checked by the launcher; everything else takes k_blur_area_stream): whole images (no view),
-// w a multiple of 8 and <= 2048 (one workgroup spans the row), image base / row stride / image stride multiples of 8.
-template <int K>
+// 32 <= w <= 2048 (one workgroup spans the row).  GEN = false: w a multiple of 8 and image base / row stride / image
+// stride multiples of 8 (aligned 8-byte loads, no extra shuffles); GEN = true: any width and alignment (+3 v_perm per
+// row and lane, unaligned dword loads).
+template <int K, bool GEN>
 __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __restrict__ imgs, int w, int h,
                                                         unsigned row_stride, size_t img_stride,
                                                         const AreaTab* __restrict__ xtab,
@@ -1504,26 +1506,65 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
   constexpr int kStep = StreamK<K>::step;
   constexpr int PF = K == 7 ? 7 : 5;  // rows in flight; divides kStep so that the ring slot of a row is static
   const int T = (int)blockDim.x, tid = (int)threadIdx.x;
-  const int L = w >> 3;  // lanes per image: 8 columns each.  A 640-pixel row needs 80 lanes: three images share 256
+  const int L = (w + 7) >> 3;  // lanes per image: 8 columns each.  A 640-pixel row needs 80 lanes: three images share 256
+  const int bp = 8 * L;        // LDS pitch of a blurred row
   const int islot = tid / L;
   const unsigned img_i = blockIdx.z * (unsigned)ipb + (unsigned)islot;
   const bool lane_live = islot < ipb && img_i < n_imgs;
   const int tl = lane_live ? tid - islot * L : 0;
-  unsigned char* __restrict__ sblur_all = s_fused;  // ipb x kStep x w blurred rows
-  unsigned char* __restrict__ sblur = sblur_all + (size_t)(lane_live ? islot : 0) * (size_t)kStep * (size_t)w;
-  float* __restrict__ salpha = reinterpret_cast<float*>(s_fused + (size_t)ipb * (size_t)kStep * (size_t)w);
+  unsigned char* __restrict__ sblur_all = s_fused;  // ipb x kStep x bp blurred rows
+  unsigned char* __restrict__ sblur = sblur_all + (size_t)(lane_live ? islot : 0) * (size_t)kStep * (size_t)bp;
+  float* __restrict__ salpha = reinterpret_cast<float*>(s_fused + (size_t)ipb * (size_t)kStep * (size_t)bp);
   const int k_end = isx ? 0 : xfirst[32];
   const int strip_out = steps * kStep - 2 * R;
   const int o0 = (int)blockIdx.y * strip_out;
   const int o1 = min(h, o0 + strip_out);
   const unsigned char* __restrict__ img = imgs + (size_t)(lane_live ? img_i : blockIdx.z * (unsigned)ipb) * img_stride;
   for (int i = tid; i < k_end; i += T) salpha[i] = xtab[i].alpha;
-  // v_perm_b32(S0, S1, sel): selector 4..7 -> S0 byte 0..3, 0..3 -> S1 byte 0..3 (see k_dcthash_256)
-  const unsigned selL = tl == 0 ? 0x01020300u : 0x07060504u;      // lane 0: (x, px3, px2, px1) from its own pixels
-  const unsigned selR = tl == L - 1 ? 0x00000102u : 0x07060504u;  // last lane: (px w-2, w-3, w-4, x)
-  const unsigned offC = 8u * (unsigned)tl;
-  const unsigned offL = tl == 0 ? offC : offC - 4u;
-  const unsigned offR = tl == L - 1 ? offC + 4u : offC + 8u;
+  // The 16-byte window of a lane (image bytes 8*tl - 4 .. 8*tl + 11) is assembled from three loads and v_perm_b32
+  // with per-lane selectors (v_perm_b32(S0, S1, sel): selector 4..7 -> S0 byte 0..3, 0..3 -> S1 byte 0..3):
+  //   W[0] = perm(left dword, own.x, selL)   W[1] = perm(own.y, own.x, sel1)   W[2] = perm(own.y, own.x, sel2)
+  //   W[3] = perm(right dword, perm(own.y, own.x, selT), selR)
+  // Interior lanes use identity selectors.  REFLECT_101 at the image edges is a matter of selectors and load
+  // offsets of the edge lanes only: lane 0 mirrors its own pixels into the left halo; with w a multiple of 8 the
+  // last lane mirrors its own pixels into the right halo.  GEN (any width): the last lane owns only m = w mod 8 real
+  // pixels -- it loads the LAST eight bytes of the row and shuffles real and mirrored pixels into place, its right
+  // halo comes from those and the dword before them; for m <= 3 the lane before it reads its right halo from the
+  // last dword of the row.  (sel1 / sel2 / selT are the identity and cost nothing unless GEN.)
+  unsigned selL = tl == 0 ? 0x01020300u : 0x07060504u;  // lane 0: (x, px3, px2, px1) from its own pixels
+  unsigned selR = 0x07060504u, sel1 = 0x03020100u, sel2 = 0x07060504u, selT = 0x07060504u;
+  const unsigned offS = 8u * (unsigned)tl;  // where the lane's blurred pixels go in the LDS row
+  unsigned offC = offS;
+  unsigned offL = tl == 0 ? offC : offC - 4u;
+  unsigned offR = offC + 8u;
+  const int m = w & 7;
+  if (!GEN || m == 0) {
+    if (tl == L - 1) selR = 0x00000102u, offR = offC + 4u;  // (px w-2, w-3, w-4, x) from its own pixels
+  } else {
+    auto src_of = [&](int x) { return x <= w - 1 ? x : 2 * (w - 1) - x; };
+    if (tl == L - 1) {
+      offC = (unsigned)(w - 8);
+      offR = (unsigned)(w - 12);
+      sel1 = sel2 = selT = selR = 0u;
+      for (int i = 0; i < 4; ++i) {
+        sel1 |= (unsigned)(src_of(w - m + i) - (w - 8)) << (8 * i);
+        sel2 |= (unsigned)(src_of(w - m + 4 + i) - (w - 8)) << (8 * i);
+      }
+      for (int j = 0; j < 3; ++j) {
+        const int sp = src_of(w - m + 8 + j);
+        if (sp >= w - 8) {
+          selT |= (unsigned)(sp - (w - 8)) << (8 * j);
+          selR |= (unsigned)j << (8 * j);
+        } else {
+          selR |= (unsigned)(4 + sp - (w - 12)) << (8 * j);
+        }
+      }
+    } else if (tl == L - 2 && m <= 3) {
+      offR = (unsigned)(w - 4);
+      selR = 0u;
+      for (int j = 0; j < 3; ++j) selR |= (unsigned)(4 + src_of(w - m + j) - (w - 4)) << (8 * j);
+    }
+  }
   auto row_base = [&](int s) -> unsigned {  // byte offset of (reflected, clamped) source row s
     int ry = s < 0 ? -s : (s >= h ? 2 * (h - 1) - s : s);
     ry = ry < 0 ? 0 : (ry >= h ? h - 1 : ry);
@@ -1548,13 +1589,21 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
   const int sfirst = o0 - R;  // first source row of the strip
   uint2 rawC[PF];
   unsigned rawL[PF], rawR[PF];
+  auto load_row = [&](int s, uint2& c, unsigned& l, unsigned& r) {
+    const unsigned char* __restrict__ p = img + row_base(s);
+    if constexpr (GEN) {  // any alignment
+      c.x = *reinterpret_cast<const u32_any_align*>(p + offC);
+      c.y = *reinterpret_cast<const u32_any_align*>(p + offC + 4);
+      l = *reinterpret_cast<const u32_any_align*>(p + offL);
+      r = *reinterpret_cast<const u32_any_align*>(p + offR);
+    } else {
+      c = *reinterpret_cast<const uint2*>(p + offC);
+      l = *reinterpret_cast<const unsigned*>(p + offL);
+      r = *reinterpret_cast<const unsigned*>(p + offR);
+    }
+  };
 #pragma unroll
-  for (int j = 0; j < PF; ++j) {
-    const unsigned rb = row_base(sfirst + j);
-    rawC[j] = *reinterpret_cast<const uint2*>(img + rb + offC);
-    rawL[j] = *reinterpret_cast<const unsigned*>(img + rb + offL);
-    rawR[j] = *reinterpret_cast<const unsigned*>(img + rb + offR);
-  }
+  for (int j = 0; j < PF; ++j) load_row(sfirst + j, rawC[j], rawL[j], rawR[j]);
   for (int st = 0; st < steps; ++st) {
     const int s0 = sfirst + st * kStep;  // first source row consumed in this step
     if (s0 - R >= o1) break;             // nothing left to output (uniform)
@@ -1563,13 +1612,17 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
       const int j = rr % K, pj = rr % PF;
       const uint2 dC = rawC[pj];
       const unsigned dl = rawL[pj], dr = rawR[pj];
-      {
-        const unsigned rb = row_base(s0 + rr + PF);
-        rawC[pj] = *reinterpret_cast<const uint2*>(img + rb + offC);
-        rawL[pj] = *reinterpret_cast<const unsigned*>(img + rb + offL);
-        rawR[pj] = *reinterpret_cast<const unsigned*>(img + rb + offR);
+      load_row(s0 + rr + PF, rawC[pj], rawL[pj], rawR[pj]);
+      unsigned W[4];
+      W[0] = __builtin_amdgcn_perm(dl, dC.x, selL);
+      if constexpr (GEN) {
+        W[1] = __builtin_amdgcn_perm(dC.y, dC.x, sel1);
+        W[2] = __builtin_amdgcn_perm(dC.y, dC.x, sel2);
+        W[3] = __builtin_amdgcn_perm(dr, __builtin_amdgcn_perm(dC.y, dC.x, selT), selR);
+      } else {
+        W[1] = dC.x, W[2] = dC.y;
+        W[3] = __builtin_amdgcn_perm(dr, dC.y, selR);
       }
-      const unsigned W[4] = {__builtin_amdgcn_perm(dl, dC.x, selL), dC.x, dC.y, __builtin_amdgcn_perm(dr, dC.y, selR)};
       unsigned P[4];
       hsum_pairs<R>(W, P);
 #pragma unroll
@@ -1578,7 +1631,7 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
         ring[j][c] = P[c];
       }
       const uint2 qo = blur_quotients<K>(S);
-      if (lane_live) *reinterpret_cast<uint2*>(sblur + (size_t)rr * (size_t)w + offC) = qo;
+      if (lane_live) *reinterpret_cast<uint2*>(sblur + (size_t)rr * (size_t)bp + offS) = qo;
     }
     __syncthreads();
     // ---- horizontal INTER_AREA chains for the valid blurred rows of this step: local row rr <-> image row s0 + rr - R
@@ -1594,8 +1647,8 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
         const int ib = two ? e2 / nv : ia, rb_ = two ? lo + (e2 - ib * nv) : ra;
         const unsigned ga = blockIdx.z * (unsigned)ipb + (unsigned)ia, gb = blockIdx.z * (unsigned)ipb + (unsigned)ib;
         const bool la = ga < n_imgs, lb = two && gb < n_imgs;
-        const unsigned char* __restrict__ Sa = sblur_all + ((size_t)ia * kStep + (size_t)ra) * (size_t)w + acol;
-        const unsigned char* __restrict__ Sb = sblur_all + ((size_t)ib * kStep + (size_t)rb_) * (size_t)w + acol;
+        const unsigned char* __restrict__ Sa = sblur_all + ((size_t)ia * kStep + (size_t)ra) * (size_t)bp + acol;
+        const unsigned char* __restrict__ Sb = sblur_all + ((size_t)ib * kStep + (size_t)rb_) * (size_t)bp + acol;
         float* __restrict__ oa = rows + ((size_t)(la ? ga : 0u) * (size_t)h + (size_t)(ob + ra)) * 32 + cc;
         float* __restrict__ obp = rows + ((size_t)(lb ? gb : 0u) * (size_t)h + (size_t)(ob + rb_)) * 32 + cc;
         if (isx) {
@@ -2751,31 +2804,37 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
           const int strip_out = steps * kstep - 2 * (K_ / 2);
           dim3 gs((unsigned)ncol, (unsigned)((h + strip_out - 1) / strip_out), (unsigned)m);
           const size_t ssmem = (size_t)kstep * fpitch + (size_t)(integer ? 0 : at.xn) * sizeof(float);
-          if (g_hash_regs && ncol == 1 && w % 8 == 0 && ((uintptr_t)src % 8) == 0 && row_stride % 8 == 0 &&
-              img_stride % 8 == 0 && (size_t)h * row_stride < ((size_t)1 << 31)) {
+          if (g_hash_regs && ncol == 1 && (size_t)h * row_stride < ((size_t)1 << 31)) {
+            const bool gen = !(w % 8 == 0 && ((uintptr_t)src % 8) == 0 && row_stride % 8 == 0 && img_stride % 8 == 0);
             // blur input straight from global memory into registers (k_blur_area_regs); LDS = blurred rows + weights
             // lanes per image = w / 8.  Images whose last wave would be mostly empty share a 256-lane workgroup side by
             // side (640 px: 80 of 128 lanes busy alone, 240 of 256 as three: +12 %); where the lanes are already
             // well used the larger workgroup only costs (more waves per barrier: -5..-9 % measured at 400, 512, 1024 px)
-            const int Lr = w / 8, Lw = (Lr + 63) / 64 * 64;
+            const int Lr = (w + 7) / 8, Lw = (Lr + 63) / 64 * 64;
             const bool pack = g_hash_regs == 3 || (g_hash_regs == 1 && Lr * 100 < Lw * 72);  // knob 2: never, 3: always
             const int ipb = (Lr <= 128 && pack) ? 256 / Lr : 1;
-            const size_t rsmem = (size_t)ipb * kstep * (size_t)w + (size_t)(integer ? 0 : at.xn) * sizeof(float);
+            const size_t rsmem = (size_t)ipb * kstep * (size_t)(8 * Lr) + (size_t)(integer ? 0 : at.xn) * sizeof(float);
             const unsigned Tr = (unsigned)std::max(64, (ipb * Lr + 63) / 64 * 64);
-#define CBH_REGS(KK)                                                                                       \
-  do {                                                                                                     \
-    if (rsmem > 64 * 1024)                                                                                 \
-      CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_area_regs<KK>),                     \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)rsmem));                \
-    hipLaunchKernelGGL(k_blur_area_regs<KK>, dim3(1, gs.y, (unsigned)((m + ipb - 1) / ipb)), dim3(Tr), rsmem, stream, \
-                       src, w, h, (unsigned)row_stride, img_stride, at.x, at.xfirst, isx, steps, d_rowsf, ipb,  \
-                       (unsigned)m);                                                                         \
+#define CBH_REGS_(KK, GG)                                                                                    \
+  do {                                                                                                       \
+    if (rsmem > 64 * 1024)                                                                                   \
+      CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_area_regs<KK, GG>),                   \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)rsmem));                  \
+    hipLaunchKernelGGL((k_blur_area_regs<KK, GG>), dim3(1, gs.y, (unsigned)((m + ipb - 1) / ipb)), dim3(Tr), rsmem, \
+                       stream, src, w, h, (unsigned)row_stride, img_stride, at.x, at.xfirst, isx, steps, d_rowsf,   \
+                       ipb, (unsigned)m);                                                                    \
+  } while (0)
+#define CBH_REGS(KK)              \
+  do {                            \
+    if (gen) CBH_REGS_(KK, true); \
+    else CBH_REGS_(KK, false);    \
   } while (0)
             switch (K_) {
               case 3: CBH_REGS(3); break;
               case 5: CBH_REGS(5); break;
               default: CBH_REGS(7); break;
             }
+#undef CBH_REGS_
 #undef CBH_REGS
             hipLaunchKernelGGL(k_tile_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_rowsf, h, at.y, at.yfirst,
                                isx, isy, 1, tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);

@@ -187,7 +187,8 @@ def test_float_magic_divide_variant_is_bit_identical(gpu, orc):
 
 def test_register_streaming_kernel(gpu, orc):
     """k_blur_area_regs (blur input straight from global memory; knob "hash_regs") at the geometries it accepts --
-    widths that are multiples of 8 up to 2048, aligned strides -- in strips of 3 and 8 steps, all three blur sizes,
+    widths 32..2048: multiples of 8 with aligned strides (aligned 8-byte loads) and any width / stride / base address
+    (the GEN form) -- in strips of 3 and 8 steps, all three blur sizes,
     integer and fractional resize ratios, heights around the step and strip boundaries: hashes and tiles equal the
     oracle and the LDS-staged streaming kernel it replaces there"""
     from cbird_amd import _lib
@@ -198,18 +199,27 @@ def test_register_streaming_kernel(gpu, orc):
     geos = [(640, 480), (400, 300), (600, 450), (1024, 768), (1920, 1080), (2048, 96), (512, 512), (64, 64), (72, 56),
             (96, 120), (128, 100), (200, 57), (256, 250), (8, 200), (2040, 33), (320, 41), (320, 42), (320, 43),
             (1000, 1000), (264, 136)]
+    # the any-width / any-alignment form (GEN): every residue of w mod 8 (the last lane owns 1..7 real pixels; for
+    # residues <= 3 the lane before it takes its right halo from the row's last dword), odd strides and an odd base
+    gen = [(641, 480), (533, 400), (401, 301), (33, 64), (34, 40), (35, 33), (36, 50), (37, 47), (38, 32), (39, 90),
+           (43, 35), (2047, 40), (2041, 37), (1023, 100), (999, 77), (333, 500), (1366, 768), (640, 480), (256, 255)]
     try:
-        for (w, h) in geos:
+        for gi, (w, h) in enumerate(geos + gen):
             n = 3
-            row_stride = w + 8 * int(rng.integers(0, 3))
-            img_stride = h * row_stride + 8 * int(rng.integers(0, 5))
+            unaligned = gi >= len(geos)
+            unit = 1 if unaligned else 8
+            row_stride = w + unit * int(rng.integers(0, 3 if not unaligned else 6))
+            img_stride = h * row_stride + unit * int(rng.integers(0, 5))
+            base = int(rng.integers(1, 8)) if unaligned else 0
             buf = rng.integers(0, 256, (n, img_stride), dtype=np.uint8)
             if (w, h) == (640, 480):  # flat and extreme images too
                 buf[0] = 0
                 buf[1] = 255
             imgs = np.stack([buf[i, : h * row_stride].reshape(h, row_stride)[:, :w] for i in range(n)])
             want = orc.dcthash64_batch(np.ascontiguousarray(imgs))
-            d = torch.from_numpy(buf).cuda()
+            dflat = torch.zeros(buf.size + 16, dtype=torch.uint8, device="cuda")
+            dflat[base : base + buf.size] = torch.from_numpy(buf.reshape(-1)).cuda()
+            d = dflat[base:]
             for regs, steps in ((1, 3), (1, 8), (0, 3)):
                 L.cbh_set_tuning(b"hash_regs", regs)
                 L.cbh_set_tuning(b"hash_stream", steps)
