@@ -123,7 +123,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # CBH_BENCH_FORCE_DIST=1 (development aid): initialise RCCL and run the per-threshold all-gather at world size 1
+    # too, so that a one-GPU box exercises the transport of the N > 1 path.  Never set by the driver.
+    force = os.environ.get("CBH_BENCH_FORCE_DIST") == "1"
+    if force:
+        os.environ["CBH_DIST_FORCE_COLLECTIVES"] = "1"
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -313,7 +319,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(args, torch, imgs, state, n, dhts)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

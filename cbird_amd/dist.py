@@ -20,6 +20,8 @@ sharding and exchange logic over gloo.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -124,6 +126,10 @@ class ShardedDctHashIndex:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # CBH_DIST_FORCE_COLLECTIVES=1: run the collectives at world size 1 too (a one-GPU box can then exercise the
+        # RCCL transport itself -- same code path as R > 1, the gathered buffer is just one block long)
+        self.collective = self.world > 1 or (dist.is_initialized() and
+                                             os.environ.get("CBH_DIST_FORCE_COLLECTIVES") == "1")
         # record_capacity = what the whole job may produce per threshold; a rank's block holds its share (x2 slack)
         self.record_capacity = record_capacity
         self._bufs = {}
@@ -166,7 +172,7 @@ class ShardedDctHashIndex:
 
     def gather_hashes(self, local_hashes: torch.Tensor, n_total: int) -> torch.Tensor:
         """all-gather the per-rank hash slices (needles are replicated on every rank)"""
-        if self.world == 1:
+        if not self.collective:
             return local_hashes
         sizes = [self.shard_range(n_total, r, self.world) for r in range(self.world)]
         m = max(b - a for a, b in sizes)
@@ -190,7 +196,7 @@ class ShardedDctHashIndex:
         b = self._bufs.get(slot)
         if b is None or b[0].numel() != 1 + cap:
             blk = self.ops.empty(1 + cap, torch.int64)
-            allb = self.ops.empty((1 + cap) * self.world, torch.int64) if self.world > 1 else blk
+            allb = self.ops.empty((1 + cap) * self.world, torch.int64) if self.collective else blk
             b = self._bufs[slot] = (blk, allb)
         return b
 
@@ -201,7 +207,7 @@ class ShardedDctHashIndex:
     def _exchange_and_cut(self, blk, allb, nq: int, max_per_query: int, status):
         """(all-gather of the blocks) -> counting select.  No host synchronisation; `status` (int32[1] on the device)
         becomes non-zero when some rank's block overflowed."""
-        if self.world > 1:
+        if self.collective:
             self._all_gather(allb, blk)
         cap = blk.numel() - 1
         cnts = allb[:: 1 + cap]

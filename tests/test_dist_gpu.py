@@ -160,3 +160,56 @@ def test_sweep_single_rank_equals_per_threshold(gpu, orc):
         gi, gs, gc = res[t]
         assert (gc.cpu().numpy() == wc.astype(np.int32)).all(), t
         assert (gi.cpu().numpy().view(np.uint32) == wi).all() and (gs.cpu().numpy() == ws).all(), t
+
+
+def _rccl_worker(port, n, q_out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CBH_DIST_FORCE_COLLECTIVES="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from cbird_amd import synth
+        from cbird_amd.dist import HipOps, ShardedDctHashIndex
+
+        imgs = torch.from_numpy(synth.make_images(n, seed=5)).to(dev)
+        sh = ShardedDctHashIndex(HipOps(0), record_capacity=1 << 12)
+        assert sh.collective and dist.get_backend() == "nccl"
+        h_local = sh.ops.hash_images(imgs)
+        allh = sh.gather_hashes(h_local, n)  # all_gather_into_tensor over RCCL
+        sh.load_shard(h_local, torch.arange(1, n + 1, dtype=torch.int32, device=dev))
+        work = sh.ops.work_stream()
+        with sh.ops.stream_ctx(work):
+            sweep = sh.similar_sweep(allh, (1, 2, 7, 9), 4)  # one all-gather of {count, records} per threshold
+        torch.cuda.synchronize()
+        out = {d: tuple(t.cpu().numpy().copy() for t in sweep[d]) for d in (1, 2, 7, 9)}
+        q_out.put((allh.cpu().numpy().copy(), out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_transport_world1_equals_oracle(gpu, orc):
+    """The RCCL backend itself ("nccl"), forced through the collectives at world size 1: the hash all-gather and the
+    per-threshold block all-gather of the sharded sweep run on the device, on side streams, exactly as at R > 1 (one
+    GPU per box: R > 1 over RCCL is the driver's run)."""
+    from cbird_amd import synth
+
+    n = 777
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    p = ctx.Process(target=_rccl_worker, args=(port, n, q))
+    p.start()
+    allh, out = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    h = orc.dcthash64_batch(synth.make_images(n, seed=5))
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    assert (allh.view(np.uint64) == h).all()
+    for dht in (1, 2, 7, 9):
+        wi, ws, wc = orc.find64_batch(h, ids, h, dht, 4)
+        gi, gs, gc = out[dht]
+        assert (gc == wc.astype(np.int32)).all() and (gi.view(np.uint32) == wi).all() and (gs == ws).all()
