@@ -133,4 +133,10 @@ int launch_keypoint_hashes(uint8_t* d_base, size_t n, const uint64_t* img_off, c
 int launch_rect_hashes(uint8_t* d_base, const std::vector<RectImageDesc>& images, const std::vector<int>& rects,
                        int write_back, uint64_t* d_out, hipStream_t stream, uint8_t* d_tiles = nullptr);
 
+// ---- orb.hip: ORB keypoints + rBRIEF descriptors (Media::makeKeyPoints / makeKeyPointDescriptors) ------------------
+int orb_set_pattern(const int8_t* xy);
+int launch_orb(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const uint32_t* img_w, const uint32_t* img_h,
+               const uint32_t* img_row_stride, int nfeatures, int kp_cap, cbh_keypoint* d_kp, float* d_kp_after,
+               uint8_t* d_desc, uint32_t* d_counts, hipStream_t s);
+
 }  // namespace cbh

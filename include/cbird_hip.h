@@ -111,6 +111,38 @@ int cbh_keypoint_hashes_dev(void* d_imgs, size_t n, const uint64_t* img_off, con
                             const uint32_t* img_h, const uint32_t* img_row_stride, const float* kp,
                             const uint32_t* kp_first, void* d_out, uint32_t* out_first, int device, void* stream);
 
+/* ---- ORB keypoints and descriptors -- Media::makeKeyPoints / makeKeyPointDescriptors (src/media.cpp:859-872) ----
+ * cbird configures OpenCV 2.4's ORB as OrbFeatureDetector(numKeyPoints, 1.2f, 12, 31, 0, 2, HARRIS_SCORE, 31) and a
+ * default OrbDescriptorExtractor (256-bit rBRIEF): 12-level pyramid at 1.2 (cv::resize INTER_LINEAR), FAST-9/16
+ * (threshold 20, 3x3 non-maximum suppression), the 31-pixel border, retainBest(2N) on the FAST score, Harris response
+ * (7x7, k 0.04), retainBest(N), intensity-centroid orientation (cv::fastAtan2), 7x7 sigma-2 Gaussian, rotated test
+ * pairs.  n grey images of any sizes in one buffer (image i: img_w[i] x img_h[i] at byte img_off[i], pitch
+ * img_row_stride[i]; cbird feeds <= 400 px on the longest side, src/scanner.cpp:876).
+ *   kp[i*kp_cap + j]       j-th keypoint of image i as detect() returns it: pyramid level by level, raster order
+ *                          inside a level; x, y in image coordinates, size = 31 * 1.2^octave, angle in degrees
+ *   kp_after[2*(i*kp_cap+j)]  (optional) the keypoint's x, y as compute() leaves them in cbird's non-const list
+ *                          (pt * (1/scale) * scale): what Media::makeKeyPointHashes sees when both algorithms run
+ *   desc[(i*kp_cap+j)*32]  (optional) its descriptor row, the layout CvFeaturesIndex stores
+ *   counts[i]              keypoints found for image i; only the first kp_cap are written -- a count above kp_cap
+ *                          means the call must be repeated with more room (ties are never cut: see below)
+ * Two things differ from the cbird binary by necessity and are stated in oracle/orb_oracle.c: retainBest's handling of
+ * EQUAL responses depends on the C++ library's nth_element -- here every keypoint whose response is >= the n-th best
+ * is kept; and the 256 test pairs are a learned table inside OpenCV (bit_pattern_31_), an input here:
+ * cbh_orb_set_pattern(xy) takes its 1024 integers (x0, y0, x1, y1 per bit, each within [-15, 15]).  Without a pattern
+ * a call that asks for descriptors fails with CBH_E_INVAL; detection alone (desc == NULL) needs none. */
+typedef struct cbh_keypoint {
+  float x, y, size, angle, response;
+  int32_t octave;
+} cbh_keypoint;
+int cbh_orb_set_pattern(const int8_t* xy);
+int cbh_orb(const uint8_t* imgs, size_t imgs_bytes, size_t n, const uint64_t* img_off, const uint32_t* img_w,
+            const uint32_t* img_h, const uint32_t* img_row_stride, int nfeatures, int kp_cap, cbh_keypoint* kp,
+            float* kp_after, uint8_t* desc, uint32_t* counts, int device);
+/* images and outputs in device memory (the size arrays stay on the host); stream NULL = synchronous */
+int cbh_orb_dev(const void* d_imgs, size_t n, const uint64_t* img_off, const uint32_t* img_w, const uint32_t* img_h,
+                const uint32_t* img_row_stride, int nfeatures, int kp_cap, void* d_kp, void* d_kp_after, void* d_desc,
+                void* d_counts, int device, void* stream);
+
 /* ---- the steps in front of dctHash64 in Scanner::processImage (src/scanner.cpp:852-862) -------------------
  * grayscale(): cv::cvtColor(BGR2GRAY/BGRA2GRAY) on 8-bit data (src/cvutil.cpp:1265-1283); d_gray is packed
  * n*w*h bytes. */

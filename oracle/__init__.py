@@ -777,3 +777,140 @@ class PrestageOracle:
         if rc:
             raise ValueError(f"orc_process_image rc={rc}")
         return int(out[0]), r
+
+
+KP_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.float32), ("angle", np.float32),
+                     ("response", np.float32), ("octave", np.int32)])
+
+
+class OrbOracle:
+    """oracle/orb_oracle.c: OpenCV 2.4 ORB as cbird configures it (media.cpp:859-872), parity unpinned.
+    Keypoints are structured arrays of KP_DTYPE (cv::KeyPoint without class_id)."""
+
+    NLEVELS = 12
+
+    def __init__(self) -> None:
+        build()
+        L = C.CDLL(_ORACLE_SO)
+        self.L = L
+        L.orc_orb_scale.restype = C.c_float
+        L.orc_orb_scale.argtypes = [C.c_int]
+        L.orc_harris_response.restype = C.c_float
+        L.orc_harris_response.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+        L.orc_ic_angle.restype = C.c_float
+        L.orc_ic_angle.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_orb_detect.restype = C.c_long
+        L.orc_orb_detect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_long]
+        L.orc_orb_compute.restype = C.c_long
+        L.orc_orb_compute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_long, C.c_void_p]
+        L.orc_orb_descriptor.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_void_p]
+
+    def set_pattern(self, xy) -> None:
+        xy = np.ascontiguousarray(xy, np.int8).reshape(1024)
+        if self.L.orc_orb_set_pattern(xy.ctypes.data_as(C.c_void_p)):
+            raise ValueError("pattern coordinates must lie in [-15, 15]")
+
+    def level_size(self, w, h, level):
+        lw, lh = C.c_int(0), C.c_int(0)
+        self.L.orc_orb_level_size(w, h, level, C.byref(lw), C.byref(lh))
+        return lw.value, lh.value
+
+    def scale(self, level) -> float:
+        return float(self.L.orc_orb_scale(level))
+
+    def features_per_level(self, nfeatures):
+        out = np.zeros(self.NLEVELS, np.int32)
+        self.L.orc_orb_features_per_level(int(nfeatures), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def umax(self):
+        out = np.zeros(17, np.int32)
+        self.L.orc_orb_umax(out.ctypes.data_as(C.c_void_p))
+        return out[:16]
+
+    def gauss7_kernel(self):
+        out = np.zeros(7, np.int32)
+        self.L.orc_gauss7_kernel(out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def resize_linear(self, img, dw, dh):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.zeros((dh, dw), np.uint8)
+        rc = self.L.orc_resize_linear_u8_cv(img.ctypes.data_as(C.c_void_p), w, h, C.c_size_t(w), dw, dh,
+                                            out.ctypes.data_as(C.c_void_p))
+        if rc:
+            raise ValueError("resize_linear")
+        return out
+
+    def pyramid_level(self, img, level):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        lw, lh = self.level_size(w, h, level)
+        out = np.zeros((lh, lw), np.uint8)
+        rc = self.L.orc_orb_pyramid_level(img.ctypes.data_as(C.c_void_p), w, h, C.c_size_t(w), level,
+                                          out.ctypes.data_as(C.c_void_p))
+        if rc:
+            raise ValueError("pyramid_level")
+        return out
+
+    def fast_nms_scores(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.zeros((h, w), np.uint8)
+        self.L.orc_fast_nms_scores(img.ctypes.data_as(C.c_void_p), w, h, C.c_size_t(w), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def harris(self, img, x, y) -> float:
+        img = np.ascontiguousarray(img, np.uint8)
+        return float(self.L.orc_harris_response(img.ctypes.data_as(C.c_void_p), img.shape[1], int(x), int(y)))
+
+    def ic_angle(self, img, x, y) -> float:
+        img = np.ascontiguousarray(img, np.uint8)
+        return float(self.L.orc_ic_angle(img.ctypes.data_as(C.c_void_p), img.shape[1], int(x), int(y)))
+
+    def fast_atan2(self, y, x) -> float:
+        return float(self.L.orc_fast_atan2(float(y), float(x)))
+
+    def gauss7_blur(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.zeros((h, w), np.uint8)
+        self.L.orc_gauss7_blur_u8(img.ctypes.data_as(C.c_void_p), w, h, C.c_size_t(w), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def descriptor(self, blurred, cx, cy, angle_deg):
+        blurred = np.ascontiguousarray(blurred, np.uint8)
+        out = np.zeros(32, np.uint8)
+        self.L.orc_orb_descriptor(blurred.ctypes.data_as(C.c_void_p), blurred.shape[1], int(cx), int(cy),
+                                  float(angle_deg), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def detect(self, img, nfeatures=400):
+        """Media::makeKeyPoints"""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        cap = 4096
+        while True:
+            out = np.zeros(cap, KP_DTYPE)
+            n = self.L.orc_orb_detect(img.ctypes.data_as(C.c_void_p), w, h, C.c_size_t(w), int(nfeatures),
+                                      out.ctypes.data_as(C.c_void_p), cap)
+            if n < 0:
+                raise ValueError(f"orc_orb_detect rc={n}")
+            if n <= cap:
+                return out[:n].copy()
+            cap = int(n)
+
+    def compute(self, img, kps):
+        """Media::makeKeyPointDescriptors: returns (keypoints as the call leaves them, descriptors uint8[n, 32])"""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        kps = np.ascontiguousarray(kps, KP_DTYPE).copy()
+        desc = np.zeros((max(1, len(kps)), 32), np.uint8)
+        n = self.L.orc_orb_compute(img.ctypes.data_as(C.c_void_p), w, h, C.c_size_t(w), kps.ctypes.data_as(C.c_void_p),
+                                   len(kps), desc.ctypes.data_as(C.c_void_p))
+        if n < 0:
+            raise ValueError(f"orc_orb_compute rc={n}")
+        return kps[:n].copy(), desc[:n].copy()

@@ -24,6 +24,7 @@
  * Everything else is integer or strictly-ordered float arithmetic (no FMA: build with -ffp-contract=off), so the HIP
  * path is compared BIT FOR BIT with this file. */
 #include <math.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -93,37 +94,9 @@ void orc_resize_linear_coeffs(int ssize, int dsize, int* ofs, short* c0, short* 
     c1[d] = sat_short(f * 2048.f);
   }
 }
-int orc_resize_linear_u8(const uint8_t* src, int w, int h, size_t stride, int dw, int dh, uint8_t* dst) {
-  if (w < 1 || h < 1 || dw < 1 || dh < 1) return -1;
-  int* xo = (int*)malloc(sizeof(int) * (size_t)(dw + dh));
-  short* xc = (short*)malloc(sizeof(short) * 2 * (size_t)(dw + dh));
-  int* yo = xo + dw;
-  short *xc0 = xc, *xc1 = xc + dw, *yc0 = xc + 2 * dw, *yc1 = xc + 2 * dw + dh;
-  orc_resize_linear_coeffs(w, dw, xo, xc0, xc1);
-  orc_resize_linear_coeffs(h, dh, yo, yc0, yc1);
-  for (int dy = 0; dy < dh; ++dy) {
-    /* the row offsets are NOT clamped by the coefficient loop for y (only x has the xmin/xmax handling): the
-     * invoker clips sy and sy + 1 to [0, h-1]; orc_resize_linear_coeffs already folded the same effect in */
-    int sy0 = yo[dy], sy1 = sy0 + 1 < h ? sy0 + 1 : h - 1;
-    const uint8_t* S0 = src + (size_t)sy0 * stride;
-    const uint8_t* S1 = src + (size_t)sy1 * stride;
-    for (int dx = 0; dx < dw; ++dx) {
-      int sx = xo[dx], sx1 = sx + 1 < w ? sx + 1 : w - 1;
-      int D0 = S0[sx] * xc0[dx] + S0[sx1] * xc1[dx];
-      int D1 = S1[sx] * xc0[dx] + S1[sx1] * xc1[dx];
-      int v = (((yc0[dy] * (D0 >> 4)) >> 16) + ((yc1[dy] * (D1 >> 4)) >> 16) + 2) >> 2;
-      dst[(size_t)dy * dw + dx] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
-    }
-  }
-  free(xo);
-  free(xc);
-  return 0;
-}
-
-/* The y coefficients above differ from the library's in one place that cannot show: for sy < 0 the library keeps
- * fy and clips BOTH rows to row 0 (so the blend is of row 0 with itself), for sy >= h-1 both rows are h-1; the
- * folded form (fy = 0) gives the same value because D0 == D1 there... except that ((b0*(D>>4))>>16) + ((b1*(D>>4))>>16)
- * is not ((2048*(D>>4))>>16) when both shifts truncate.  So the vertical pass keeps the library's form exactly: */
+/* The vertical pass keeps the library's form exactly: no clamping of the coefficient for y (only x has the
+ * xmin / xmax handling); the invoker clips BOTH source rows to [0, h-1], and
+ * ((b0*(D>>4))>>16) + ((b1*(D>>4))>>16) is not ((2048*(D>>4))>>16) when both shifts truncate. */
 static void resize_linear_ycoeffs(int ssize, int dsize, int* ofs, short* c0, short* c1) {
   double inv_scale = (double)dsize / ssize;
   double scale = 1. / inv_scale;
