@@ -7,23 +7,29 @@
 // retainBest's tie rule is canonical: ties kept, raster order).
 //
 // Decomposition (one launch each, all images of the batch at once; nothing visits the host between them):
-//   k_orb_resize   x (levels - 1)   pyramid level l from l-1: cv::resize INTER_LINEAR's 8-bit fixed-point path; the
-//                                   coefficient tables of a workgroup's rows are formed in LDS (double arithmetic
-//                                   as the library's, IEEE on the device).  Level 0 is the caller's image, in place.
-//                                   Only the levels that can hold a keypoint (both sides > 62) are built.
-//   k_orb_fast                      FAST-9/16 score + 3x3 non-maximum suppression per 64x16 tile staged in LDS:
-//                                   16-bit brighter / darker masks, "9 contiguous" by four shift-ands, the score
-//                                   (largest threshold that keeps the corner) only for the rare corners.  Writes the
-//                                   suppressed score map of the keypoint region [31, w-31) x [31, h-31).
-//   k_orb_select                    one workgroup per (image, level): histogram of the scores -> n-th best score
-//                                   (retainBest(2N) on 8-bit keys = counting select) -> ordered compaction ->
-//                                   Harris response per candidate -> radix select of the N-th best float ->
-//                                   ordered compaction -> intensity-centroid orientation (one wave per keypoint).
-//   k_orb_blur                      7x7 sigma-2 Gaussian in OpenCV's 8-bit fixed point per tile (levels with keypoints)
+//   k_orb_level0                    level 0 = the caller's image copied into the pyramid buffer WITH its reflect-101
+//                                   border (4 columns, 3 rows): every later kernel reads aligned dwords without edge cases
+//   k_orb_resize   x (levels - 1)   level l from l-1: cv::resize INTER_LINEAR's 8-bit fixed-point path.  The x / y
+//                                   coefficient tables of a workgroup's rows are formed in LDS (double arithmetic as the
+//                                   library's, IEEE on the device); border pixels are the resized pixels at the reflected
+//                                   coordinates (= copyMakeBorder of the resized level).  Only the levels that can hold a
+//                                   keypoint (both sides > 62) are built.
+//   k_orb_fast                      FAST-9/16 score + 3x3 non-maximum suppression per 64x16 tile staged in LDS by dword
+//                                   loads: a compass-point test rejects most pixels after 4 reads, 16-bit brighter /
+//                                   darker masks, "9 contiguous" by four shift-ands, the score (largest threshold that
+//                                   keeps the corner) only for the rare corners.  Writes the non-zero entries of the
+//                                   suppressed score map (the map is cleared by a memset).
+//   k_orb_select                    one workgroup per (image, level): 16-byte scans of the score map (histogram ->
+//                                   n-th best score: retainBest(2N) on 8-bit keys is a counting select; ordered
+//                                   compaction) -> Harris response per candidate -> radix select of the N-th best float
+//                                   -> ordered compaction -> intensity-centroid orientation (one wave per keypoint).
+//   k_orb_blur                      7x7 sigma-2 Gaussian in OpenCV's 8-bit fixed point: a lane owns 4 columns and walks
+//                                   down a strip of 29 rows; per row three aligned dword loads, the horizontal taps as
+//                                   ten v_dot4_u32_u8 against constant weight masks, the last 7 row sums in registers.
 //   k_orb_describe                  one wave per keypoint: lane t evaluates tests t, t+64, t+128, t+192 of the
 //                                   rotated pattern, four ballots are the 256 bits; also scales the keypoints to
 //                                   image coordinates and writes them level by level per image.
-// All of it is byte / small-integer work on L2-resident pyramids (a 400x300 image: 120 KB + 270 KB of levels); the
+// All of it is byte / small-integer work on L2-resident pyramids (a 400x300 image: 130 KB + 290 KB of levels); the
 // bound is instruction issue and launch geometry, not HBM.
 #include <algorithm>
 #include <cmath>
@@ -38,23 +44,23 @@ namespace {
 
 constexpr int kLevels = 12;       // media.cpp:861
 constexpr int kEdge = 31;         // edgeThreshold
-constexpr int kHalfPatch = 15;    // patchSize 31
 constexpr int kFastT = 20;        // orb.cpp: FastFeatureDetector fd(20, true)
 constexpr float kHarrisK = 0.04f;
+constexpr int kBorderX = 4, kBorderY = 3;  // reflect-101 border stored around every pyramid level
 
 struct OrbImage {
-  unsigned long long src_off;  // level 0 = the caller's image
+  unsigned long long src_off;  // the caller's image
   unsigned src_stride;
   int nlev;                    // levels that can hold keypoints (both sides > 2 * kEdge); they form a prefix
   int w[kLevels], h[kLevels];
-  unsigned pitch[kLevels];               // pitch[0] = src_stride
-  unsigned long long poff[kLevels];      // byte offset of level l >= 1 in the pyramid buffer
-  unsigned long long soff[kLevels];      // byte offset of level l in the score / blurred buffer (pitch = w rounded up to 4)
-  unsigned spitch[kLevels];
+  unsigned pitch[kLevels];               // = round_up(w, 4) + 2 * kBorderX
+  unsigned long long poff[kLevels];      // byte offset of pixel (0, 0) of level l in the pyramid buffer (4-byte aligned)
+  unsigned long long soff[kLevels];      // byte offset of level l in the score / blurred buffer (16-byte aligned)
+  unsigned spitch[kLevels];              // = round_up(w, 16)
   unsigned long long coff[kLevels];      // first candidate slot of level l
   int nfeat[kLevels];
   unsigned tile_first[kLevels + 1];      // FAST tiles (keypoint region): level l owns [tile_first[l], tile_first[l+1])
-  unsigned btile_first[kLevels + 1];     // blur tiles (whole level)
+  unsigned bwg_first[kLevels + 1];       // blur workgroups: level l owns [bwg_first[l], bwg_first[l+1])
   float scale[kLevels];                  // getScale(level): (float)pow((double)1.2f, level), from the host's libm
 };
 
@@ -66,82 +72,137 @@ struct OrbCand {  // one candidate / keypoint of a level, in level coordinates
   unsigned short x, y;
   float response;
   float angle;
+  float ca, sa;  // (float)cos, (float)sin of the angle in radians, as computeOrbDescriptor forms them
 };
-
-__device__ __forceinline__ const unsigned char* level_ptr(const OrbImage& im, int l, const unsigned char* imgs,
-                                                          const unsigned char* pyr) {
-  return l == 0 ? imgs + im.src_off : pyr + im.poff[l];
-}
 
 __device__ __forceinline__ int cv_round_f(float v) { return (int)rintf(v); }  // cvRound: half to even
 __device__ __forceinline__ short sat_short_rn(float v) {
   const float r = rintf(v);
   return (short)(r < -32768.f ? -32768.f : r > 32767.f ? 32767.f : r);
 }
+__device__ __forceinline__ int reflect101(int p, int len) {  // one reflection: |overhang| < len
+  if (p < 0) p = -p;
+  if (p >= len) p = 2 * (len - 1) - p;
+  return p;
+}
 
-// ---- pyramid: cv::resize INTER_LINEAR, 8UC1 (oracle: orc_resize_linear_u8_cv) ---------------------------------------
-constexpr int kResizeRows = 32;
-__global__ __launch_bounds__(256) void k_orb_resize(const OrbImage* __restrict__ images, int level,
+// ---- level 0: copy + border ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_orb_level0(const OrbImage* __restrict__ images,
                                                     const unsigned char* __restrict__ imgs,
                                                     unsigned char* __restrict__ pyr) {
+  const OrbImage& im = images[blockIdx.y];
+  if (im.nlev < 1) return;
+  const int w = im.w[0], h = im.h[0];
+  const int P = (int)im.pitch[0], nd = P >> 2;  // dwords per padded row
+  const int rows = h + 2 * kBorderY;
+  const unsigned char* __restrict__ src = imgs + im.src_off;
+  unsigned* __restrict__ dst = reinterpret_cast<unsigned*>(pyr + im.poff[0] - (size_t)kBorderY * P - kBorderX);
+  for (int i = (int)(blockIdx.x * 256 + threadIdx.x); i < rows * nd; i += (int)(gridDim.x * 256)) {
+    const int r = i / nd, c = i - r * nd;
+    const unsigned char* __restrict__ S = src + (size_t)reflect101(r - kBorderY, h) * im.src_stride;
+    const int x0 = 4 * c - kBorderX;
+    unsigned v = 0;
+    if (x0 >= 0 && x0 + 3 < w) {
+      v = *reinterpret_cast<const unsigned*>(S + x0);  // any alignment
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v |= (unsigned)S[reflect101(min(x0 + j, w + kBorderX + 2), w)] << (8 * j);
+    }
+    dst[(size_t)r * nd + c] = v;
+  }
+}
+
+// ---- pyramid: cv::resize INTER_LINEAR, 8UC1 (oracle: orc_resize_linear_u8_cv) ---------------------------------------
+constexpr int kResizeRows = 16;
+__global__ __launch_bounds__(256) void k_orb_resize(const OrbImage* __restrict__ images, int level,
+                                                    unsigned char* __restrict__ pyr) {
   extern __shared__ __attribute__((aligned(8))) unsigned char s_res[];
+  __shared__ int s_yofs[kResizeRows];
+  __shared__ int s_yc[kResizeRows];
   const OrbImage& im = images[blockIdx.y];
   if (level >= im.nlev) return;
   const int dw = im.w[level], dh = im.h[level], sw = im.w[level - 1], sh = im.h[level - 1];
-  const int y0 = (int)blockIdx.x * kResizeRows;
-  if (y0 >= dh) return;
-  int* __restrict__ xofs = reinterpret_cast<int*>(s_res);
-  short* __restrict__ xc = reinterpret_cast<short*>(s_res + (size_t)dw * 4);  // (c0, c1) pairs
+  const int P = (int)im.pitch[level], nd = P >> 2;
+  const int rows = dh + 2 * kBorderY;
+  const int r0 = (int)blockIdx.x * kResizeRows;
+  if (r0 >= rows) return;
+  int* __restrict__ xofs = reinterpret_cast<int*>(s_res);        // per padded column: source column
+  int* __restrict__ xc = reinterpret_cast<int*>(s_res) + P;      // (c1 << 16) | (c0 & 0xffff)
   const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
-  for (int d = threadIdx.x; d < dw; d += 256) {
+  for (int cp = threadIdx.x; cp < P; cp += 256) {
+    const int d = reflect101(min(cp - kBorderX, dw + kBorderX + 2), dw);
     float f = (float)((d + 0.5) * scale_x - 0.5);
     int s = (int)floorf(f);
     f -= (float)s;
     if (s < 0) f = 0.f, s = 0;
     if (s >= sw - 1) f = 0.f, s = sw - 1;
-    xofs[d] = s;
-    xc[2 * d] = sat_short_rn((1.f - f) * 2048.f);
-    xc[2 * d + 1] = sat_short_rn(f * 2048.f);
+    xofs[cp] = s;
+    xc[cp] = ((int)sat_short_rn(f * 2048.f) << 16) | ((int)sat_short_rn((1.f - f) * 2048.f) & 0xffff);
   }
-  __syncthreads();
-  const unsigned char* __restrict__ src = level_ptr(im, level - 1, imgs, pyr);
-  const unsigned sp = im.pitch[level - 1], dp = im.pitch[level];
-  unsigned char* __restrict__ dst = pyr + im.poff[level];
-  const int y1 = min(dh, y0 + kResizeRows);
-  for (int dy = y0; dy < y1; ++dy) {
+  if (threadIdx.x < kResizeRows) {
+    const int dy = reflect101(min(r0 + (int)threadIdx.x, rows - 1) - kBorderY, dh);
     float fy = (float)((dy + 0.5) * scale_y - 0.5);
     const int sy = (int)floorf(fy);
     fy -= (float)sy;
-    const int b0 = sat_short_rn((1.f - fy) * 2048.f), b1 = sat_short_rn(fy * 2048.f);
-    const int r0 = min(max(sy, 0), sh - 1), r1 = min(max(sy + 1, 0), sh - 1);
-    const unsigned char* __restrict__ S0 = src + (size_t)r0 * sp;
-    const unsigned char* __restrict__ S1 = src + (size_t)r1 * sp;
-    for (int dx = threadIdx.x; dx < dw; dx += 256) {
-      const int sx = xofs[dx], sx1 = min(sx + 1, sw - 1);
-      const int a0 = xc[2 * dx], a1 = xc[2 * dx + 1];
-      const int D0 = S0[sx] * a0 + S0[sx1] * a1;
-      const int D1 = S1[sx] * a0 + S1[sx1] * a1;
+    // both source rows clipped to the image (the library's invoker); the coefficients stay as they are
+    s_yofs[threadIdx.x] = (min(max(sy, 0), sh - 1) << 16) | min(max(sy + 1, 0), sh - 1);
+    s_yc[threadIdx.x] = ((int)sat_short_rn(fy * 2048.f) << 16) | ((int)sat_short_rn((1.f - fy) * 2048.f) & 0xffff);
+  }
+  __syncthreads();
+  const unsigned sp = im.pitch[level - 1];
+  const unsigned char* __restrict__ src = pyr + im.poff[level - 1];
+  unsigned* __restrict__ dst = reinterpret_cast<unsigned*>(pyr + im.poff[level] - (size_t)kBorderY * P - kBorderX);
+  const int nr = min(kResizeRows, rows - r0);
+  for (int i = threadIdx.x; i < nr * nd; i += 256) {
+    const int r = i / nd, c = i - r * nd;
+    const int yo = s_yofs[r], yc = s_yc[r];
+    const int b0 = (short)(yc & 0xffff), b1 = yc >> 16;
+    const unsigned char* __restrict__ S0 = src + (size_t)(yo >> 16) * sp;
+    const unsigned char* __restrict__ S1 = src + (size_t)(yo & 0xffff) * sp;
+    unsigned out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int sx = xofs[4 * c + j], cc = xc[4 * c + j];
+      const int a0 = (short)(cc & 0xffff), a1 = cc >> 16;
+      // sx + 1 <= sw - 1 + 1: the source level carries a border, and a1 == 0 there
+      const int D0 = S0[sx] * a0 + S0[sx + 1] * a1;
+      const int D1 = S1[sx] * a0 + S1[sx + 1] * a1;
       const int v = (((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2;
-      dst[(size_t)dy * dp + dx] = (unsigned char)min(max(v, 0), 255);
+      out |= (unsigned)min(max(v, 0), 255) << (8 * j);
     }
+    dst[(size_t)(r0 + r) * nd + c] = out;
   }
 }
 
 // ---- FAST-9/16 + non-maximum suppression (oracle: orc_fast_nms_scores restricted to the keypoint region) -----------
 constexpr int kTileW = 64, kTileH = 16;
-constexpr int kPxW = kTileW + 8, kPxH = kTileH + 8;  // pixels: outputs + 1 (NMS) + 3 (circle) on every side
+constexpr int kPxW = 76, kPxH = kTileH + 8;  // staged pixels: x from ox0 - 7 (4-byte aligned) to ox0 + 68, 19 dwords
 constexpr int kRawW = kTileW + 2, kRawH = kTileH + 2;
 
-__device__ __forceinline__ int fast_score_at(const unsigned char* __restrict__ c /* centre in the LDS tile */) {
-  // circle offsets in the order of fast.cpp's offsets16
+// circle offsets in the order of fast.cpp's offsets16
+__device__ __forceinline__ void fast_circle(const unsigned char* __restrict__ c, int* d) {
   constexpr int ox[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
   constexpr int oy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
   const int v = c[0];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) d[k] = v - (int)c[oy[k] * kPxW + ox[k]];
+}
+// stage 1: a run of 9 of the 16 contains at least two of the compass points 0, 4, 8, 12 -- four reads reject most pixels
+__device__ __forceinline__ bool fast_compass(const unsigned char* __restrict__ c) {
+  const int v = c[0];
+  const int d0 = v - (int)c[3 * kPxW], d8 = v - (int)c[-3 * kPxW];
+  const int d4 = v - (int)c[3], d12 = v - (int)c[-3];
+  const int dk = (d0 > kFastT) + (d4 > kFastT) + (d8 > kFastT) + (d12 > kFastT);
+  const int br = (d0 < -kFastT) + (d4 < -kFastT) + (d8 < -kFastT) + (d12 < -kFastT);
+  return dk >= 2 || br >= 2;
+}
+// stage 2: the segment test proper on 16-bit brighter / darker masks
+__device__ __forceinline__ bool fast_is_corner(const unsigned char* __restrict__ c) {
   int d[16];
+  fast_circle(c, d);
   unsigned dark = 0, bright = 0;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    d[k] = v - (int)c[oy[k] * kPxW + ox[k]];
     dark |= (unsigned)(d[k] > kFastT) << k;     // x < v - t
     bright |= (unsigned)(d[k] < -kFastT) << k;  // x > v + t
   }
@@ -153,20 +214,37 @@ __device__ __forceinline__ int fast_score_at(const unsigned char* __restrict__ c
     t &= m >> 8;                // 9
     return t != 0;
   };
-  if (!run9(dark) && !run9(bright)) return 0;
-  // cornerScore<16>: max(threshold, max over the 16 arcs of min(d), max over the arcs of min(-d)) - 1
+  return run9(dark) || run9(bright);
+}
+// stage 3: cornerScore<16> = max(threshold, max over the 16 arcs of min(d), max over the arcs of min(-d)) - 1
+__device__ __forceinline__ int fast_corner_score(const unsigned char* __restrict__ c) {
+  int d[16];
+  fast_circle(c, d);
+  // minima / maxima of the 16 arcs of 9 by doubling: arcs of 2, 4, 8, then 8 + 1
+  int mn[16], mx[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) mn[k] = min(d[k], d[(k + 1) & 15]), mx[k] = max(d[k], d[(k + 1) & 15]);
+  int mn4[16], mx4[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) mn4[k] = min(mn[k], mn[(k + 2) & 15]), mx4[k] = max(mx[k], mx[(k + 2) & 15]);
   int best = kFastT;
 #pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    int mn = d[s], mx = d[s];
-#pragma unroll
-    for (int j = 1; j < 9; ++j) {
-      mn = min(mn, d[(s + j) & 15]);
-      mx = max(mx, d[(s + j) & 15]);
-    }
-    best = max(best, max(mn, -mx));
+  for (int k = 0; k < 16; ++k) {
+    const int m9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+    const int M9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+    best = max(best, max(m9, -M9));
   }
   return best - 1;
+}
+// append v to an LDS queue, one atomic per wave
+__device__ __forceinline__ void queue_push(bool pred, unsigned short v, unsigned short* q, int* n) {
+  const unsigned long long m = __ballot(pred);
+  if (m == 0ull) return;
+  const int lane = (int)(threadIdx.x & 63);
+  int base = 0;
+  if (lane == __ffsll((long long)m) - 1) base = atomicAdd(n, __popcll(m));
+  base = __shfl(base, __ffsll((long long)m) - 1);
+  if (pred) q[base + __popcll(m & ((1ull << lane) - 1ull))] = v;
 }
 
 __device__ __forceinline__ bool find_tile(const OrbImage& im, unsigned t, int* level, int* tx, int* ty) {
@@ -183,41 +261,64 @@ __device__ __forceinline__ bool find_tile(const OrbImage& im, unsigned t, int* l
 }
 
 __global__ __launch_bounds__(256) void k_orb_fast(const OrbImage* __restrict__ images,
-                                                  const unsigned char* __restrict__ imgs,
                                                   const unsigned char* __restrict__ pyr,
-                                                  unsigned char* __restrict__ scores) {
-  __shared__ unsigned char s_px[kPxH * kPxW];
+                                                  unsigned char* __restrict__ scores /* cleared */) {
+  __shared__ __attribute__((aligned(16))) unsigned char s_px[kPxH * kPxW];
   __shared__ unsigned char s_raw[kRawH * kRawW];
+  __shared__ unsigned short s_q1[kRawH * kRawW], s_q2[kRawH * kRawW];
+  __shared__ int s_n[2];
   const OrbImage& im = images[blockIdx.y];
   int l, tx, ty;
   if (!find_tile(im, blockIdx.x, &l, &tx, &ty)) return;
   const int w = im.w[l], h = im.h[l];
-  const unsigned char* __restrict__ src = level_ptr(im, l, imgs, pyr);
+  const unsigned char* __restrict__ src = pyr + im.poff[l];
   const unsigned sp = im.pitch[l];
   const int ox0 = kEdge + tx * kTileW, oy0 = kEdge + ty * kTileH;  // first output pixel of the tile
-  const int px0 = ox0 - 4, py0 = oy0 - 4;
-  for (int i = threadIdx.x; i < kPxH * kPxW; i += 256) {
-    const int r = i / kPxW, c = i - r * kPxW;
-    const int y = min(py0 + r, h - 1), x = min(px0 + c, w - 1);  // overhanging tiles: clamped (never used)
-    s_px[i] = src[(size_t)y * sp + x];
+  const int px0 = ox0 - 7, py0 = oy0 - 4;                            // px0 = 24 + 64 tx: dword aligned
+  for (int i = threadIdx.x; i < kPxH * (kPxW / 4); i += 256) {
+    const int r = i / (kPxW / 4), c = i - r * (kPxW / 4);
+    const int y = min(py0 + r, h + kBorderY - 1);                 // overhanging tiles: clamped into the buffer,
+    const int x = min(px0 + 4 * c, (int)sp - 2 * kBorderX);       // those values are never used
+    reinterpret_cast<unsigned*>(s_px)[i] = *reinterpret_cast<const unsigned*>(src + (ptrdiff_t)y * sp + x);
+  }
+  for (int i = threadIdx.x; i < kRawH * kRawW; i += 256) s_raw[i] = 0;
+  if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+  __syncthreads();
+  // three stages with the survivors compacted in between, so that the expensive ones run on full waves
+  auto centre = [&](int i) {
+    const int r = i / kRawW, c = i - r * kRawW;
+    return s_px + (r + 3) * kPxW + (c + 6);
+  };
+  for (int i0 = 0; i0 < kRawH * kRawW; i0 += 256) {
+    const int i = i0 + (int)threadIdx.x;
+    queue_push(i < kRawH * kRawW && fast_compass(centre(min(i, kRawH * kRawW - 1))), (unsigned short)i, s_q1, &s_n[0]);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < kRawH * kRawW; i += 256) {
-    const int r = i / kRawW, c = i - r * kRawW;
-    s_raw[i] = (unsigned char)fast_score_at(s_px + (r + 3) * kPxW + (c + 3));
+  const int n1 = s_n[0];
+  for (int k0 = 0; k0 < n1; k0 += 256) {
+    const int k = k0 + (int)threadIdx.x;
+    const int i = s_q1[min(k, n1 - 1)];
+    queue_push(k < n1 && fast_is_corner(centre(i)), (unsigned short)i, s_q2, &s_n[1]);
+  }
+  __syncthreads();
+  const int n2 = s_n[1];
+  for (int k = threadIdx.x; k < n2; k += 256) {
+    const int i = s_q2[k];
+    s_raw[i] = (unsigned char)fast_corner_score(centre(i));
   }
   __syncthreads();
   unsigned char* __restrict__ out = scores + im.soff[l];
   const unsigned op = im.spitch[l];
   for (int i = threadIdx.x; i < kTileH * kTileW; i += 256) {
     const int r = i / kTileW, c = i - r * kTileW;
-    const int x = ox0 + c, y = oy0 + r;
-    if (x >= w - kEdge || y >= h - kEdge) continue;
     const unsigned char* __restrict__ q = s_raw + (r + 1) * kRawW + (c + 1);
     const int s = q[0];
-    const bool keep = s != 0 && s > q[1] && s > q[-1] && s > q[-kRawW - 1] && s > q[-kRawW] && s > q[-kRawW + 1] &&
-                      s > q[kRawW - 1] && s > q[kRawW] && s > q[kRawW + 1];
-    out[(size_t)y * op + x] = keep ? (unsigned char)s : (unsigned char)0;
+    if (s == 0) continue;
+    const int x = ox0 + c, y = oy0 + r;
+    if (x >= w - kEdge || y >= h - kEdge) continue;
+    if (s > q[1] && s > q[-1] && s > q[-kRawW - 1] && s > q[-kRawW] && s > q[-kRawW + 1] && s > q[kRawW - 1] &&
+        s > q[kRawW] && s > q[kRawW + 1])
+      out[(size_t)y * op + x] = (unsigned char)s;
   }
 }
 
@@ -251,7 +352,7 @@ __device__ __forceinline__ float harris_at(const unsigned char* __restrict__ img
   scale = 1.0f / scale;
   const float scale_sq_sq = scale * scale * scale * scale;
   int a = 0, b = 0, c = 0;
-  const unsigned char* __restrict__ p0 = img + (size_t)(y - 4) * pitch + (x - 4);
+  const unsigned char* __restrict__ p0 = img + (ptrdiff_t)(y - 4) * pitch + (x - 4);
   // three rows of the 9x9 patch in registers at a time
   int r0[9], r1[9], r2[9];
 #pragma unroll
@@ -303,7 +404,6 @@ __device__ __forceinline__ unsigned float_key(float f) {  // order-preserving: l
 }
 
 __global__ __launch_bounds__(256) void k_orb_select(const OrbImage* __restrict__ images,
-                                                    const unsigned char* __restrict__ imgs,
                                                     const unsigned char* __restrict__ pyr,
                                                     const unsigned char* __restrict__ scores,
                                                     OrbCand* __restrict__ cand, unsigned* __restrict__ level_counts) {
@@ -318,65 +418,79 @@ __global__ __launch_bounds__(256) void k_orb_select(const OrbImage* __restrict__
     if (tid == 0) *out_count = 0;
     return;
   }
-  const int w = im.w[l], h = im.h[l];
-  const int iw = w - 2 * kEdge, ih = h - 2 * kEdge;
-  const int area = iw * ih;
+  const int h = im.h[l];
+  const int ih = h - 2 * kEdge;
   const unsigned char* __restrict__ sc = scores + im.soff[l];
   const unsigned sp = im.spitch[l];
+  const int G = (int)(sp >> 4);      // 16-byte groups per score row
+  const int groups = G * ih;         // the rows [31, h-31) in raster order; only keypoint columns are ever non-zero
+  const uint4* __restrict__ sc16 = reinterpret_cast<const uint4*>(sc + (size_t)kEdge * sp);
   const int N = im.nfeat[l];
   OrbCand* __restrict__ cd = cand + im.coff[l];
-  // -- (a) histogram of the suppressed scores
+  // -- (a) one scan of the score map: every suppressed corner of the keypoint region into the candidate list in
+  //        raster order (response = its FAST score for now) + the histogram of the scores
   s_hist[tid] = 0;
   __syncthreads();
-  for (int p = tid; p < area; p += 256) {
-    const int y = p / iw, x = p - y * iw;
-    const int s = sc[(size_t)(y + kEdge) * sp + (x + kEdge)];
-    if (s) atomicAdd(&s_hist[s], 1);
-  }
-  __syncthreads();
-  // -- (b) retainBest(2N): every score >= the 2N-th best survives
-  if (tid == 0) {
-    int total = 0;
-    for (int s = 255; s >= 1; --s) total += s_hist[s];
-    int thr = 1;
-    if (2 * N == 0) {
-      thr = 256;
-    } else if (total > 2 * N) {
-      int acc = 0;
-      for (int s = 255; s >= 1; --s) {
-        acc += s_hist[s];
-        if (acc >= 2 * N) {
-          thr = s;
-          break;
+  int c0 = 0;
+  for (int g0 = 0; g0 < groups; g0 += 256) {
+    const int g = g0 + tid;
+    uint4 q = make_uint4(0u, 0u, 0u, 0u);
+    if (g < groups) q = sc16[g];
+    const unsigned qq[4] = {q.x, q.y, q.z, q.w};
+    int nz = 0;
+    if ((q.x | q.y | q.z | q.w) != 0u) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) nz += ((qq[j >> 2] >> (8 * (j & 3))) & 255u) != 0u;
+    }
+    int tot;
+    int pos = c0 + block_excl_scan(nz, s_w, &tot);
+    if (nz) {
+      const int gy = g / G, gx = g - gy * G;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const unsigned sv = (qq[j >> 2] >> (8 * (j & 3))) & 255u;
+        if (sv) {
+          OrbCand c;
+          c.x = (unsigned short)(16 * gx + j), c.y = (unsigned short)(gy + kEdge);
+          c.response = (float)sv, c.angle = 0.f, c.ca = 0.f, c.sa = 0.f;
+          cd[pos++] = c;
+          atomicAdd(&s_hist[sv], 1);
         }
       }
     }
-    s_pick[0] = thr;
+    c0 += tot;
   }
   __syncthreads();
-  const int thr = s_pick[0];
-  // -- (c) ordered compaction (raster order) + Harris response
+  // -- (b) retainBest(2N): every score >= the 2N-th best survives
+  {
+    // bins in descending order: thread t holds bin 255 - t (bin 0 is never counted)
+    const int v = s_hist[255 - tid];
+    int total;
+    const int excl = block_excl_scan(v, s_w, &total);
+    const int want = 2 * N;
+    if (tid == 0) s_pick[0] = want == 0 ? 256 : 1;  // nothing / everything
+    __syncthreads();
+    if (want > 0 && total > want && excl < want && want <= excl + v) s_pick[0] = 255 - tid;  // the 2N-th best score
+    __syncthreads();
+  }
+  const float thr = (float)s_pick[0];
+  // -- (c) ordered compaction of the list in place
   int c1 = 0;
-  for (int p0 = 0; p0 < area; p0 += 256) {
-    const int p = p0 + tid;
-    int x = 0, y = 0, keep = 0;
-    if (p < area) {
-      y = p / iw, x = p - y * iw;
-      x += kEdge, y += kEdge;
-      keep = sc[(size_t)y * sp + x] >= thr;
+  for (int i0 = 0; i0 < c0; i0 += 256) {
+    const int i = i0 + tid;
+    OrbCand c;
+    int keep = 0;
+    if (i < c0) {
+      c = cd[i];
+      keep = c.response >= thr;
     }
     int tot;
     const int pos = block_excl_scan(keep, s_w, &tot);
-    if (keep) {
-      OrbCand c;
-      c.x = (unsigned short)x, c.y = (unsigned short)y;
-      c.response = 0.f, c.angle = 0.f;
-      cd[c1 + pos] = c;
-    }
+    if (keep) cd[c1 + pos] = c;
     c1 += tot;
   }
   __syncthreads();  // the candidate list is visible to the whole workgroup (global memory, same workgroup)
-  const unsigned char* __restrict__ img = level_ptr(im, l, imgs, pyr);
+  const unsigned char* __restrict__ img = pyr + im.poff[l];
   const unsigned ip = im.pitch[l];
   for (int i = tid; i < c1; i += 256) cd[i].response = harris_at(img, ip, cd[i].x, cd[i].y);
   __syncthreads();
@@ -395,16 +509,13 @@ __global__ __launch_bounds__(256) void k_orb_select(const OrbImage* __restrict__
         if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1);
       }
       __syncthreads();
-      if (tid == 0) {
-        int acc = 0, b = 255;
-        for (; b > 0; --b) {
-          if (acc + s_hist[b] >= want) break;
-          acc += s_hist[b];
-        }
-        s_pick[0] = b;
-        s_pick[1] = want - acc;
+      {
+        const int v = s_hist[255 - tid];
+        int total;
+        const int excl = block_excl_scan(v, s_w, &total);
+        if (excl < want && want <= excl + v) s_pick[0] = 255 - tid, s_pick[1] = want - excl;
+        __syncthreads();
       }
-      __syncthreads();
       prefix |= (unsigned)s_pick[0] << shift;
       mask |= 255u << shift;
       want = s_pick[1];
@@ -429,35 +540,46 @@ __global__ __launch_bounds__(256) void k_orb_select(const OrbImage* __restrict__
   }
   __syncthreads();
   if (tid == 0) *out_count = (unsigned)c2;
-  // -- (f) orientation: IC_Angle over the circular patch of radius 15, one wave per keypoint, lane = row v
-  //        (lane 0: the centre row; lanes 1..15: the row pair +-v)
+  // -- (f) orientation: IC_Angle over the circular patch of radius 15, one wave per keypoint, no loop: lane =
+  //        (row pair +-v, v = lane >> 2; segment of 8 columns u0 = -16 + 8 * (lane & 3)) -- four unaligned dword loads
+  //        per lane, all in flight together, then a wave reduction
   const int lane = tid & 63, wv = tid >> 6;
-  for (int i = wv; i < c2; i += 4) {
-    const int x = cd[i].x, y = cd[i].y;
-    const unsigned char* __restrict__ ctr = img + (size_t)y * ip + x;
-    int m01 = 0, m10 = 0;
-    if (lane == 0) {
-      for (int u = -kHalfPatch; u <= kHalfPatch; ++u) m10 += u * (int)ctr[u];
-    } else if (lane <= kHalfPatch) {
-      // u_max of orb.cpp for half patch 15 (15 15 15 15 14 14 14 13 13 12 11 10 9 8 6 3), one nibble per row
-      const int v = lane;
-      const int um = (int)((0x3689ABCDDEEEFFFFull >> (4 * v)) & 15ull);
-      int v_sum = 0;
-      const unsigned char* __restrict__ pp = ctr + (size_t)v * ip;
-      const unsigned char* __restrict__ pm = ctr - (size_t)v * ip;
-      for (int u = -um; u <= um; ++u) {
-        const int vp = pp[u], vm = pm[u];
-        v_sum += vp - vm;
-        m10 += u * (vp + vm);
-      }
-      m01 = v * v_sum;
-    }
+  {
+    const int v = lane >> 2, u0 = -16 + 8 * (lane & 3);
+    // u_max of orb.cpp for half patch 15 (15 15 15 15 14 14 14 13 13 12 11 10 9 8 6 3), one nibble per row
+    const int um = (int)((0x3689ABCDDEEEFFFFull >> (4 * v)) & 15ull);
+    for (int i = wv; i < c2; i += 4) {
+      const int x = cd[i].x, y = cd[i].y;
+      const unsigned char* __restrict__ pp = img + (ptrdiff_t)(y + v) * ip + (x + u0);
+      const unsigned char* __restrict__ pm = img + (ptrdiff_t)(y - v) * ip + (x + u0);
+      const unsigned p0 = *reinterpret_cast<const unsigned*>(pp), p1 = *reinterpret_cast<const unsigned*>(pp + 4);
+      const unsigned q0 = *reinterpret_cast<const unsigned*>(pm), q1 = *reinterpret_cast<const unsigned*>(pm + 4);
+      int m10 = 0, v_sum = 0;
 #pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
-      m01 += __shfl_xor(m01, d);
-      m10 += __shfl_xor(m10, d);
+      for (int j = 0; j < 8; ++j) {
+        const int u = u0 + j;
+        const int vp = (int)(((j < 4 ? p0 : p1) >> (8 * (j & 3))) & 255u);
+        const int vm = v == 0 ? 0 : (int)(((j < 4 ? q0 : q1) >> (8 * (j & 3))) & 255u);  // the centre row counts once
+        const bool in = u >= -um && u <= um;
+        m10 += in ? u * (vp + vm) : 0;
+        v_sum += in ? vp - vm : 0;
+      }
+      int m01 = v * v_sum;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        m01 += __shfl_xor(m01, d);
+        m10 += __shfl_xor(m10, d);
+      }
+      if (lane == 0) cd[i].angle = fast_atan2_deg((float)m01, (float)m10);
     }
-    if (lane == 0) cd[i].angle = fast_atan2_deg((float)m01, (float)m10);
+  }
+  __syncthreads();
+  // the rotation of the descriptor pattern, once per keypoint (double-precision libm, one lane each)
+  for (int i = tid; i < c2; i += 256) {
+    float angle = cd[i].angle;
+    angle *= (float)(3.14159265358979323846 / 180.f);
+    cd[i].ca = (float)cos((double)angle);
+    cd[i].sa = (float)sin((double)angle);
   }
 }
 
@@ -465,57 +587,73 @@ __global__ __launch_bounds__(256) void k_orb_select(const OrbImage* __restrict__
 struct GaussK {
   int k[7];
 };
-__device__ __forceinline__ int reflect101(int p, int len) {
-  if (p < 0) p = -p;
-  if (p >= len) p = 2 * (len - 1) - p;
-  return p;
+constexpr int kBlurRows = 29;  // output rows per strip: 29 + 6 halo rows = 5 x 7 row steps (ring slot = step % 7, static)
+__device__ __forceinline__ unsigned udot4(unsigned a, unsigned b, unsigned c) {
+  return __builtin_amdgcn_udot4(a, b, c, false);
 }
 __global__ __launch_bounds__(256) void k_orb_blur(const OrbImage* __restrict__ images,
-                                                  const unsigned char* __restrict__ imgs,
                                                   const unsigned char* __restrict__ pyr,
                                                   const unsigned* __restrict__ level_counts, GaussK g,
                                                   unsigned char* __restrict__ blurred) {
-  constexpr int BW = kTileW, BH = kTileH;
-  __shared__ unsigned char s_px[(BH + 6) * (BW + 6)];
-  __shared__ int s_row[(BH + 6) * BW];
   const OrbImage& im = images[blockIdx.y];
   const unsigned t = blockIdx.x;
-  if (t >= im.btile_first[im.nlev]) return;
+  if (t >= im.bwg_first[im.nlev]) return;
   int l = 0;
-  while (t >= im.btile_first[l + 1]) ++l;
+  while (t >= im.bwg_first[l + 1]) ++l;
   if (level_counts[(size_t)blockIdx.y * kLevels + l] == 0) return;
   const int w = im.w[l], h = im.h[l];
-  const int ntx = (w + BW - 1) / BW;
-  const int ty = (int)((t - im.btile_first[l]) / (unsigned)ntx), tx = (int)(t - im.btile_first[l]) - ty * ntx;
-  const int bx = tx * BW, by = ty * BH;
-  const unsigned char* __restrict__ src = level_ptr(im, l, imgs, pyr);
-  const unsigned sp = im.pitch[l];
-  unsigned char* __restrict__ out = blurred + im.soff[l];
+  const int nc = (w + 3) >> 2;  // dword columns
+  const int nstrips = (h + kBlurRows - 1) / kBlurRows;
+  const int item = (int)(t - im.bwg_first[l]) * 256 + (int)threadIdx.x;
+  if (item >= nc * nstrips) return;
+  const int strip = item / nc, cx = item - strip * nc;
+  const int P = (int)im.pitch[l];
+  const unsigned char* __restrict__ col = pyr + im.poff[l] + 4 * cx;  // pixel (4 cx, 0)
+  unsigned char* __restrict__ out = blurred + im.soff[l] + 4 * cx;
   const unsigned op = im.spitch[l];
-  for (int i = threadIdx.x; i < (BH + 6) * (BW + 6); i += 256) {
-    const int r = i / (BW + 6), c = i - r * (BW + 6);
-    const int y = reflect101(min(by + r - 3, h + 2), h), x = reflect101(min(bx + c - 3, w + 2), w);  // overhang: clamped
-    s_px[i] = src[(size_t)y * sp + x];
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < (BH + 6) * BW; i += 256) {
-    const int r = i / BW, c = i - r * BW;
-    const unsigned char* __restrict__ q = s_px + r * (BW + 6) + c;
-    int s = 0;
+  const int y0 = strip * kBlurRows;
+  // constant weight masks: pixel j of the lane's four takes bytes j+1 .. j+7 of the 12-byte window (left | own | right)
+  const unsigned k0 = (unsigned)g.k[0], k1 = (unsigned)g.k[1], k2 = (unsigned)g.k[2], k3 = (unsigned)g.k[3];
+  const unsigned wL0 = k0 << 8 | k1 << 16 | k2 << 24, wO0 = k3 | k2 << 8 | k1 << 16 | k0 << 24;
+  const unsigned wL1 = k0 << 16 | k1 << 24, wO1 = k2 | k3 << 8 | k2 << 16 | k1 << 24, wR1 = k0;
+  const unsigned wL2 = k0 << 24, wO2 = k1 | k2 << 8 | k3 << 16 | k2 << 24, wR2 = k1 | k0 << 8;
+  const unsigned wO3 = k0 | k1 << 8 | k2 << 16 | k3 << 24, wR3 = k2 | k1 << 8 | k0 << 16;
+  unsigned ring[7][4];
 #pragma unroll
-    for (int t = 0; t < 7; ++t) s += g.k[t] * (int)q[t];
-    s_row[i] = s;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < BH * BW; i += 256) {
-    const int r = i / BW, c = i - r * BW;
-    const int x = bx + c, y = by + r;
-    if (x >= w || y >= h) continue;
-    int s = 0;
+  for (int i = 0; i < 7; ++i)
 #pragma unroll
-    for (int t = 0; t < 7; ++t) s += g.k[t] * s_row[(r + t) * BW + c];
-    const int v = (s + (1 << 15)) >> 16;
-    out[(size_t)y * op + x] = (unsigned char)min(max(v, 0), 255);
+    for (int j = 0; j < 4; ++j) ring[i][j] = 0u;
+  for (int s0 = 0; s0 < kBlurRows + 6; s0 += 7) {
+#pragma unroll
+    for (int ss = 0; ss < 7; ++ss) {
+      const int step = s0 + ss;
+      const int y = min(y0 - 3 + step, h + kBorderY - 1);  // strips overhanging the level: clamped into the buffer
+      const unsigned char* __restrict__ rp = col + (ptrdiff_t)y * P;
+      const unsigned L = *reinterpret_cast<const unsigned*>(rp - 4);
+      const unsigned O = *reinterpret_cast<const unsigned*>(rp);
+      const unsigned R = *reinterpret_cast<const unsigned*>(rp + 4);
+      ring[ss][0] = udot4(L, wL0, udot4(O, wO0, 0u));
+      ring[ss][1] = udot4(L, wL1, udot4(O, wO1, udot4(R, wR1, 0u)));
+      ring[ss][2] = udot4(L, wL2, udot4(O, wO2, udot4(R, wR2, 0u)));
+      ring[ss][3] = udot4(O, wO3, udot4(R, wR3, 0u));
+      if (step >= 6) {
+        const int oy = y0 + step - 6;
+        if (oy < h) {
+          unsigned pk = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            // rows oy-3 .. oy+3 sit in ring slots (ss+1)%7 .. ss; the kernel is symmetric
+            const unsigned a = ring[(ss + 1) % 7][j] + ring[ss][j];
+            const unsigned b = ring[(ss + 2) % 7][j] + ring[(ss + 6) % 7][j];
+            const unsigned c = ring[(ss + 3) % 7][j] + ring[(ss + 5) % 7][j];
+            const unsigned d = ring[(ss + 4) % 7][j];
+            const unsigned sum = k0 * a + k1 * b + k2 * c + k3 * d + (1u << 15);
+            pk |= min(sum >> 16, 255u) << (8 * j);
+          }
+          *reinterpret_cast<unsigned*>(out + (size_t)oy * op) = pk;
+        }
+      }
+    }
   }
 }
 
@@ -570,9 +708,7 @@ __global__ __launch_bounds__(256) void k_orb_describe(const OrbImage* __restrict
   }
   if (!out_desc) return;
   const int cx = cv_round_f(lx), cy = cv_round_f(ly);
-  float angle = c.angle;
-  angle *= (float)(3.14159265358979323846 / 180.f);
-  const float a = (float)cos((double)angle), b = (float)sin((double)angle);
+  const float a = c.ca, b = c.sa;
   const unsigned char* __restrict__ ctr = blurred + im.soff[l] + (size_t)cy * im.spitch[l] + cx;
   const int step = (int)im.spitch[l];
   unsigned long long bits[4];
@@ -652,8 +788,9 @@ int launch_orb(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const u
   features_per_level(nfeatures, nper);
   std::vector<OrbImage> images(n);
   unsigned long long pyr_bytes = 0, sc_bytes = 0, cands = 0;
-  unsigned max_tiles = 0, max_btiles = 0;
-  int max_lev = 0, max_w = 1, max_h1 = 1;
+  unsigned max_tiles = 0, max_bwg = 0, max_pitch = 4;
+  int max_lev = 0;
+  int max_h[kLevels] = {0};
   for (size_t i = 0; i < n; ++i) {
     OrbImage& im = images[i];
     memset(&im, 0, sizeof im);
@@ -661,39 +798,36 @@ int launch_orb(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const u
     im.src_stride = img_row_stride[i];
     const int w = (int)img_w[i], h = (int)img_h[i];
     int nl = 0;
-    unsigned tiles = 0, btiles = 0;
+    unsigned tiles = 0, bwg = 0;
     for (int l = 0; l < kLevels; ++l) {
       const float scale = 1 / get_scale(l);
       const int lw = (int)std::nearbyint((double)(w * scale)), lh = (int)std::nearbyint((double)(h * scale));
       if (lw <= 2 * kEdge || lh <= 2 * kEdge) break;
       im.w[l] = lw, im.h[l] = lh;
       im.nfeat[l] = nper[l];
-      if (l == 0) {
-        im.pitch[0] = im.src_stride;
-      } else {
-        im.pitch[l] = (unsigned)((lw + 3) & ~3);
-        im.poff[l] = pyr_bytes;
-        pyr_bytes += ((unsigned long long)im.pitch[l] * lh + 15) & ~15ull;
-        max_w = std::max(max_w, lw);
-        max_h1 = std::max(max_h1, lh);
-      }
-      im.spitch[l] = (unsigned)((lw + 3) & ~3);
+      const unsigned P = (unsigned)((lw + 3) & ~3) + 2 * kBorderX;
+      im.pitch[l] = P;
+      im.poff[l] = pyr_bytes + (unsigned long long)kBorderY * P + kBorderX;
+      pyr_bytes += ((unsigned long long)P * (lh + 2 * kBorderY) + 15) & ~15ull;
+      max_pitch = std::max(max_pitch, P);
+      max_h[l] = std::max(max_h[l], lh);
+      im.spitch[l] = (unsigned)((lw + 15) & ~15);
       im.soff[l] = sc_bytes;
-      sc_bytes += ((unsigned long long)im.spitch[l] * lh + 15) & ~15ull;
+      sc_bytes += (unsigned long long)im.spitch[l] * lh;
       const int iw = lw - 2 * kEdge, ih = lh - 2 * kEdge;
       im.coff[l] = cands;
       cands += (unsigned long long)((iw + 1) / 2) * ((ih + 1) / 2);  // strict 3x3 maxima cannot be neighbours
       im.tile_first[l] = tiles;
       tiles += (unsigned)((iw + kTileW - 1) / kTileW) * (unsigned)((ih + kTileH - 1) / kTileH);
-      im.btile_first[l] = btiles;
-      btiles += (unsigned)((lw + kTileW - 1) / kTileW) * (unsigned)((lh + kTileH - 1) / kTileH);
+      im.bwg_first[l] = bwg;
+      bwg += (unsigned)((((lw + 3) >> 2) * ((lh + kBlurRows - 1) / kBlurRows) + 255) / 256);
       im.scale[l] = get_scale(l);
       nl = l + 1;
     }
-    for (int l = nl; l <= kLevels; ++l) im.tile_first[l] = tiles, im.btile_first[l] = btiles;
+    for (int l = nl; l <= kLevels; ++l) im.tile_first[l] = tiles, im.bwg_first[l] = bwg;
     im.nlev = nl;
     max_tiles = std::max(max_tiles, tiles);
-    max_btiles = std::max(max_btiles, btiles);
+    max_bwg = std::max(max_bwg, bwg);
     max_lev = std::max(max_lev, nl);
   }
   OrbImage* d_images = nullptr;
@@ -715,21 +849,20 @@ int launch_orb(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const u
   // (pageable sources: hipMemcpyAsync has staged them when it returns)
   if (e == hipSuccess) e = hipMemcpyAsync(d_images, images.data(), n * sizeof(OrbImage), hipMemcpyHostToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(d_pat, &pat, sizeof pat, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemsetAsync(d_sc, 0, sc_bytes + 64, s);  // k_orb_fast writes the non-zero scores only
   if (e == hipSuccess) {
     const unsigned ny = (unsigned)n;
-    for (int l = 1; l < max_lev; ++l) {
-      const size_t smem = (size_t)max_w * 8;
-      hipLaunchKernelGGL(k_orb_resize, dim3((unsigned)((max_h1 + kResizeRows - 1) / kResizeRows), ny), dim3(256), smem,
-                         s, d_images, l, d_imgs, d_pyr);
-    }
-    if (max_tiles) {
-      hipLaunchKernelGGL(k_orb_fast, dim3(max_tiles, ny), dim3(256), 0, s, d_images, d_imgs, d_pyr, d_sc);
-    }
-    hipLaunchKernelGGL(k_orb_select, dim3(kLevels, ny), dim3(256), 0, s, d_images, d_imgs, d_pyr, d_sc, d_cand, d_lc);
-    if (d_desc && max_btiles) {
+    if (max_lev >= 1) hipLaunchKernelGGL(k_orb_level0, dim3(32, ny), dim3(256), 0, s, d_images, d_imgs, d_pyr);
+    for (int l = 1; l < max_lev; ++l)
+      hipLaunchKernelGGL(k_orb_resize,
+                         dim3((unsigned)((max_h[l] + 2 * kBorderY + kResizeRows - 1) / kResizeRows), ny), dim3(256),
+                         (size_t)max_pitch * 8, s, d_images, l, d_pyr);
+    if (max_tiles) hipLaunchKernelGGL(k_orb_fast, dim3(max_tiles, ny), dim3(256), 0, s, d_images, d_pyr, d_sc);
+    hipLaunchKernelGGL(k_orb_select, dim3(kLevels, ny), dim3(256), 0, s, d_images, d_pyr, d_sc, d_cand, d_lc);
+    if (d_desc && max_bwg) {
       GaussK g;
       gauss7_kernel(g.k);
-      hipLaunchKernelGGL(k_orb_blur, dim3(max_btiles, ny), dim3(256), 0, s, d_images, d_imgs, d_pyr, d_lc, g, d_sc);
+      hipLaunchKernelGGL(k_orb_blur, dim3(max_bwg, ny), dim3(256), 0, s, d_images, d_pyr, d_lc, g, d_sc);
     }
     hipLaunchKernelGGL(k_orb_describe, dim3((unsigned)((std::max(kp_cap, 1) + 3) / 4), ny), dim3(256), 0, s, d_images,
                        d_sc, d_cand, d_lc, d_pat, kp_cap, d_kp, d_kp_after, d_desc, d_counts);
