@@ -66,6 +66,7 @@ _SIGS = {
     "cbh_keypoint_hashes_dev": (C.c_int, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "cbh_orb_set_pattern": (C.c_int, [_vp]),
     "cbh_orb": (C.c_int, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
+    "cbh_orb_describe": (C.c_int, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "cbh_orb_dev": (C.c_int, [_vp, _sz, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "cbh_longest_side_dims": (None, [C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "cbh_size_longest_side": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, C.c_int, _vp, _vp, _vp, C.c_int]),

@@ -3,6 +3,8 @@
 //   uint64_t dctHash64(const cv::Mat& cvImg, bool inPlace = false)                  src/cvutil.h, src/cvutil.cpp:435-545
 //   void Media::makeKeyPointHashes(const cv::Mat&, const KeyPointList&, KeyPointHashList&) const   src/media.cpp:874-923
 //   void sizeLongestSide(cv::Mat& img, int size, int filter = INTER_LANCZOS4)        src/cvutil.h:251, cvutil.cpp:1932-1950
+//   void Media::makeKeyPoints(const cv::Mat&, int numKeyPoints, KeyPointList&) const                 src/media.cpp:859-866
+//   void Media::makeKeyPointDescriptors(const cv::Mat&, KeyPointList&, KeyPointDescriptors&) const   src/media.cpp:868-872
 //
 // Same arguments and effects as the originals for 8-bit single-channel images (what Scanner::processImage passes
 // after grayscale(), src/scanner.cpp:859,876-889): the hash is returned, and with inPlace = true the blurred pixels
@@ -18,6 +20,7 @@
 // repository it is compiled against tests/cpp/mock/index.h instead (tests/cpp/test_cvutil.cpp).
 #pragma once
 #include <cstdint>
+#include <cstring>
 #include <stdexcept>
 #include <vector>
 
@@ -105,6 +108,73 @@ inline void gpuSizeLongestSide(cv::Mat& img, int size) {
                                        hashDevice());
   if (rc) qFatal("gpuSizeLongestSide: %s (%s)", cbh_strerror(rc), cbh_last_error());
   img = out;
+}
+
+// ---- ORB (cbh_orb*, cbird_amd/csrc/orb.hip) ---------------------------------------------------------------------
+// rBRIEF's test pairs are OpenCV's learned table bit_pattern_31_ (modules/features2d/src/orb.cpp), an input of the
+// library: hand it over once, e.g. gpuOrbSetPattern(bit_pattern_31_) from a translation unit that has the table.
+inline void gpuOrbSetPattern(const int* bitPattern31 /* 256 * 4 */) {
+  int8_t xy[1024];
+  for (int i = 0; i < 1024; ++i) xy[i] = int8_t(bitPattern31[i]);
+  const int rc = cbh_orb_set_pattern(xy);
+  if (rc) qFatal("gpuOrbSetPattern: %s", cbh_strerror(rc));
+}
+
+namespace detail {
+inline void wholeImage(const cv::Mat& cvImg, const char* who, ParentView* p) {
+  if (cvImg.type() != CV_8UC1 || cvImg.rows <= 0 || cvImg.cols <= 0) qFatal("%s: expected a non-empty CV_8UC1 image", who);
+  *p = parentOf(cvImg);
+  if (p->x != 0 || p->y != 0 || int(p->w) != cvImg.cols || int(p->h) != cvImg.rows)
+    qFatal("%s: expected a whole image, not a view", who);
+}
+}  // namespace detail
+
+// Media::makeKeyPoints: outKeypoints is replaced, like cv::FeatureDetector::detect does
+inline void gpuMakeKeyPoints(const cv::Mat& cvImg, int numKeyPoints, KeyPointList& outKeypoints) {
+  detail::ParentView p;
+  detail::wholeImage(cvImg, "gpuMakeKeyPoints", &p);
+  const size_t bytes = size_t(p.h - 1) * p.step + p.w;
+  const uint64_t off = 0;
+  int cap = numKeyPoints + 64;
+  std::vector<cbh_keypoint> kp;
+  uint32_t count = 0;
+  for (;;) {  // ties in retainBest are never cut: a count above the capacity asks for a second call
+    kp.resize(size_t(cap));
+    const int rc = cbh_orb(p.base, bytes, 1, &off, &p.w, &p.h, &p.step, numKeyPoints, cap, kp.data(), nullptr, nullptr,
+                           &count, hashDevice());
+    if (rc) qFatal("gpuMakeKeyPoints: %s (%s)", cbh_strerror(rc), cbh_last_error());
+    if (int(count) <= cap) break;
+    cap = int(count);
+  }
+  outKeypoints.clear();
+  for (uint32_t i = 0; i < count; ++i)
+    outKeypoints.push_back(cv::KeyPoint(kp[i].x, kp[i].y, kp[i].size, kp[i].angle, kp[i].response, kp[i].octave, -1));
+}
+
+// Media::makeKeyPointDescriptors: keyPoints is in/out as in the original (border filter, grouping by octave, the
+// coordinate round trip); outDescriptors becomes a keyPoints.size() x 32 CV_8UC1 matrix
+inline void gpuMakeKeyPointDescriptors(const cv::Mat& cvImg, KeyPointList& keyPoints, KeyPointDescriptors& outDescriptors) {
+  detail::ParentView p;
+  detail::wholeImage(cvImg, "gpuMakeKeyPointDescriptors", &p);
+  const size_t bytes = size_t(p.h - 1) * p.step + p.w;
+  const uint64_t off = 0;
+  std::vector<cbh_keypoint> in(keyPoints.size()), out(keyPoints.size() + 1);
+  for (size_t i = 0; i < keyPoints.size(); ++i) {
+    const cv::KeyPoint& k = keyPoints[i];
+    in[i] = cbh_keypoint{k.pt.x, k.pt.y, k.size, k.angle, k.response, k.octave};
+  }
+  std::vector<uint8_t> desc((keyPoints.size() + 1) * 32);
+  const uint32_t first[2] = {0, uint32_t(keyPoints.size())};
+  uint32_t outFirst[2] = {0, 0};
+  const int rc = cbh_orb_describe(p.base, bytes, 1, &off, &p.w, &p.h, &p.step, in.data(), first, out.data(), desc.data(),
+                                  outFirst, hashDevice());
+  if (rc) qFatal("gpuMakeKeyPointDescriptors: %s (%s)", cbh_strerror(rc), cbh_last_error());
+  keyPoints.clear();
+  outDescriptors = cv::Mat(int(outFirst[1]), 32, CV_8UC1);
+  for (uint32_t i = 0; i < outFirst[1]; ++i) {
+    keyPoints.push_back(cv::KeyPoint(out[i].x, out[i].y, out[i].size, out[i].angle, out[i].response, out[i].octave, -1));
+    memcpy(outDescriptors.ptr<uint8_t>(int(i)), desc.data() + size_t(i) * 32, 32);
+  }
 }
 
 }  // namespace cbird_gpu

@@ -138,5 +138,9 @@ int orb_set_pattern(const int8_t* xy);
 int launch_orb(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const uint32_t* img_w, const uint32_t* img_h,
                const uint32_t* img_row_stride, int nfeatures, int kp_cap, cbh_keypoint* d_kp, float* d_kp_after,
                uint8_t* d_desc, uint32_t* d_counts, hipStream_t s);
+int launch_orb_describe(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const uint32_t* img_w,
+                        const uint32_t* img_h, const uint32_t* img_row_stride, const cbh_keypoint* kp,
+                        const uint32_t* kp_first, cbh_keypoint* out_kp, uint8_t* out_desc, uint32_t* out_first,
+                        hipStream_t s);
 
 }  // namespace cbh

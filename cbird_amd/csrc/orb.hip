@@ -725,6 +725,56 @@ __global__ __launch_bounds__(256) void k_orb_describe(const OrbImage* __restrict
   if (lane < 4) reinterpret_cast<unsigned long long*>(out_desc + o * 32)[lane] = bits[lane];
 }
 
+// the extractor alone on keypoints the caller provides (ORB::operator() with useProvidedKeypoints = true): the host has
+// filtered and grouped them by octave; pt *= 1/scale, descriptor at cvRound(pt), pt *= scale
+struct OrbGivenKp {
+  unsigned img;
+  int octave;
+  float x, y, angle;
+};
+__global__ __launch_bounds__(256) void k_orb_describe_given(const OrbImage* __restrict__ images,
+                                                            const unsigned char* __restrict__ blurred,
+                                                            const OrbGivenKp* __restrict__ kps, unsigned nk,
+                                                            const int* __restrict__ pat,
+                                                            float* __restrict__ out_xy /* 2 per keypoint */,
+                                                            unsigned char* __restrict__ out_desc) {
+  const int lane = (int)(threadIdx.x & 63);
+  const unsigned k = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (k >= nk) return;
+  const OrbGivenKp kp = kps[k];
+  const OrbImage& im = images[kp.img];
+  const int l = kp.octave;
+  const float sf = im.scale[l];
+  float lx = kp.x, ly = kp.y;
+  if (l != 0) {
+    const float inv = 1 / sf;
+    lx *= inv, ly *= inv;
+  }
+  const int cx = cv_round_f(lx), cy = cv_round_f(ly);
+  if (lane == 0) {
+    float ax = lx, ay = ly;
+    if (l != 0) ax *= sf, ay *= sf;
+    out_xy[2 * k] = ax, out_xy[2 * k + 1] = ay;
+  }
+  float angle = kp.angle;
+  angle *= (float)(3.14159265358979323846 / 180.f);
+  const float a = (float)cos((double)angle), b = (float)sin((double)angle);
+  const unsigned char* __restrict__ ctr = blurred + im.soff[l] + (size_t)cy * im.spitch[l] + cx;
+  const int step = (int)im.spitch[l];
+  unsigned long long bits[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int pw = pat[64 * m + lane];
+    const float x0 = (float)(signed char)(pw & 255), y0 = (float)(signed char)((pw >> 8) & 255);
+    const float x1 = (float)(signed char)((pw >> 16) & 255), y1 = (float)(signed char)((pw >> 24) & 255);
+    const int iy0 = cv_round_f(x0 * b + y0 * a), ix0 = cv_round_f(x0 * a - y0 * b);
+    const int iy1 = cv_round_f(x1 * b + y1 * a), ix1 = cv_round_f(x1 * a - y1 * b);
+    const int t0 = ctr[iy0 * step + ix0], t1 = ctr[iy1 * step + ix1];
+    bits[m] = __ballot(t0 < t1);
+  }
+  if (lane < 4) reinterpret_cast<unsigned long long*>(out_desc + (size_t)k * 32)[lane] = bits[lane];
+}
+
 std::mutex g_pat_mu;
 OrbPattern g_pattern;
 bool g_have_pattern = false;
@@ -761,36 +811,23 @@ void features_per_level(int nfeatures, int* out) {  // orb.cpp computeKeyPoints
   out[kLevels - 1] = std::max(nfeatures - sum, 0);
 }
 
-}  // namespace
-
-int orb_set_pattern(const int8_t* xy) {
-  if (!xy) return CBH_E_INVAL;
-  for (int i = 0; i < 1024; ++i)
-    if (xy[i] < -15 || xy[i] > 15) return CBH_E_INVAL;
-  std::lock_guard<std::mutex> lk(g_pat_mu);
-  memcpy(g_pattern.v, xy, 1024);
-  g_have_pattern = true;
-  return CBH_OK;
-}
-
-int launch_orb(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const uint32_t* img_w, const uint32_t* img_h,
-               const uint32_t* img_row_stride, int nfeatures, int kp_cap, cbh_keypoint* d_kp, float* d_kp_after,
-               uint8_t* d_desc, uint32_t* d_counts, hipStream_t s) {
-  OrbPattern pat;
-  if (d_desc) {
-    std::lock_guard<std::mutex> lk(g_pat_mu);
-    if (!g_have_pattern) return CBH_E_INVAL;  // no built-in pattern: it is OpenCV's learned table, an input
-    pat = g_pattern;
-  } else {
-    memset(&pat, 0, sizeof pat);
-  }
-  int nper[kLevels];
-  features_per_level(nfeatures, nper);
-  std::vector<OrbImage> images(n);
+struct OrbPlan {
+  std::vector<OrbImage> images;
   unsigned long long pyr_bytes = 0, sc_bytes = 0, cands = 0;
   unsigned max_tiles = 0, max_bwg = 0, max_pitch = 4;
   int max_lev = 0;
   int max_h[kLevels] = {0};
+};
+// levels, buffer offsets and work lists of every image; level_limit[i] (optional) = levels image i needs at most
+OrbPlan make_plan(size_t n, const uint64_t* img_off, const uint32_t* img_w, const uint32_t* img_h,
+                  const uint32_t* img_row_stride, const int* nper, const int* level_limit) {
+  OrbPlan pl;
+  pl.images.resize(n);
+  auto& images = pl.images;
+  unsigned long long &pyr_bytes = pl.pyr_bytes, &sc_bytes = pl.sc_bytes, &cands = pl.cands;
+  unsigned &max_tiles = pl.max_tiles, &max_bwg = pl.max_bwg, &max_pitch = pl.max_pitch;
+  int& max_lev = pl.max_lev;
+  int* max_h = pl.max_h;
   for (size_t i = 0; i < n; ++i) {
     OrbImage& im = images[i];
     memset(&im, 0, sizeof im);
@@ -802,7 +839,7 @@ int launch_orb(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const u
     for (int l = 0; l < kLevels; ++l) {
       const float scale = 1 / get_scale(l);
       const int lw = (int)std::nearbyint((double)(w * scale)), lh = (int)std::nearbyint((double)(h * scale));
-      if (lw <= 2 * kEdge || lh <= 2 * kEdge) break;
+      if (lw <= 2 * kEdge || lh <= 2 * kEdge || (level_limit && l >= level_limit[i])) break;
       im.w[l] = lw, im.h[l] = lh;
       im.nfeat[l] = nper[l];
       const unsigned P = (unsigned)((lw + 3) & ~3) + 2 * kBorderX;
@@ -830,6 +867,40 @@ int launch_orb(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const u
     max_bwg = std::max(max_bwg, bwg);
     max_lev = std::max(max_lev, nl);
   }
+  return pl;
+}
+
+}  // namespace
+
+int orb_set_pattern(const int8_t* xy) {
+  if (!xy) return CBH_E_INVAL;
+  for (int i = 0; i < 1024; ++i)
+    if (xy[i] < -15 || xy[i] > 15) return CBH_E_INVAL;
+  std::lock_guard<std::mutex> lk(g_pat_mu);
+  memcpy(g_pattern.v, xy, 1024);
+  g_have_pattern = true;
+  return CBH_OK;
+}
+
+int launch_orb(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const uint32_t* img_w, const uint32_t* img_h,
+               const uint32_t* img_row_stride, int nfeatures, int kp_cap, cbh_keypoint* d_kp, float* d_kp_after,
+               uint8_t* d_desc, uint32_t* d_counts, hipStream_t s) {
+  OrbPattern pat;
+  if (d_desc) {
+    std::lock_guard<std::mutex> lk(g_pat_mu);
+    if (!g_have_pattern) return CBH_E_INVAL;  // no built-in pattern: it is OpenCV's learned table, an input
+    pat = g_pattern;
+  } else {
+    memset(&pat, 0, sizeof pat);
+  }
+  int nper[kLevels];
+  features_per_level(nfeatures, nper);
+  OrbPlan pl = make_plan(n, img_off, img_w, img_h, img_row_stride, nper, nullptr);
+  const unsigned long long pyr_bytes = pl.pyr_bytes, sc_bytes = pl.sc_bytes, cands = pl.cands;
+  const unsigned max_tiles = pl.max_tiles, max_bwg = pl.max_bwg, max_pitch = pl.max_pitch;
+  const int max_lev = pl.max_lev;
+  const int* max_h = pl.max_h;
+  const std::vector<OrbImage>& images = pl.images;
   OrbImage* d_images = nullptr;
   unsigned char *d_pyr = nullptr, *d_sc = nullptr;
   OrbCand* d_cand = nullptr;
@@ -873,6 +944,108 @@ int launch_orb(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const u
     rc = e == hipErrorOutOfMemory ? CBH_E_NOMEM : CBH_E_HIP;
   }
   for (void* p : {(void*)d_images, (void*)d_pyr, (void*)d_sc, (void*)d_cand, (void*)d_lc, (void*)d_pat})
+    if (p) (void)hipFreeAsync(p, s);
+  return rc;
+}
+
+// makeKeyPointDescriptors on provided keypoints (host arrays; d_imgs on the device).  out_kp: the keypoints as
+// compute() leaves them (border filter, grouped by octave, pt round trip), image i owns [out_first[i], out_first[i+1])
+int launch_orb_describe(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const uint32_t* img_w,
+                        const uint32_t* img_h, const uint32_t* img_row_stride, const cbh_keypoint* kp,
+                        const uint32_t* kp_first, cbh_keypoint* out_kp, uint8_t* out_desc, uint32_t* out_first,
+                        hipStream_t s) {
+  OrbPattern pat;
+  {
+    std::lock_guard<std::mutex> lk(g_pat_mu);
+    if (!g_have_pattern) return CBH_E_INVAL;
+    pat = g_pattern;
+  }
+  // ORB::operator(): runByImageBorder(keypoints, image size, edgeThreshold) -- Rect::contains on the rounded point --
+  // then one list per octave
+  std::vector<OrbGivenKp> flat;
+  std::vector<int> limit(n, 0);
+  std::vector<unsigned> lc(n * kLevels, 0u);
+  out_first[0] = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const int w = (int)img_w[i], h = (int)img_h[i];
+    std::vector<const cbh_keypoint*> kept;
+    if (w > 2 * kEdge && h > 2 * kEdge)
+      for (uint32_t j = kp_first[i]; j < kp_first[i + 1]; ++j) {
+        const int px = (int)std::nearbyint((double)kp[j].x), py = (int)std::nearbyint((double)kp[j].y);
+        if (px >= kEdge && px < w - kEdge && py >= kEdge && py < h - kEdge) kept.push_back(&kp[j]);
+      }
+    int levels = 0;
+    for (const cbh_keypoint* k : kept) levels = std::max(levels, std::max(k->octave, 0) + 1);
+    if (levels > kLevels) return CBH_E_INVAL;
+    for (int l = 0; l < levels; ++l)
+      for (const cbh_keypoint* k : kept)
+        if (k->octave == l) {
+          // its level must exist and hold the point: ORB's own keypoints always do
+          const float scale = 1 / get_scale(l);
+          const int lw = (int)std::nearbyint((double)(w * scale)), lh = (int)std::nearbyint((double)(h * scale));
+          const int cx = (int)std::nearbyint((double)(k->x * scale)), cy = (int)std::nearbyint((double)(k->y * scale));
+          if (lw <= 2 * kEdge || lh <= 2 * kEdge || cx < 22 || cy < 22 || cx >= lw - 22 || cy >= lh - 22)
+            return CBH_E_INVAL;
+          flat.push_back(OrbGivenKp{(unsigned)i, l, k->x, k->y, k->angle});
+          out_kp[flat.size() - 1] = *k;
+          lc[i * kLevels + l]++;
+        }
+    limit[i] = levels;
+    out_first[i + 1] = (uint32_t)flat.size();
+  }
+  const size_t nk = flat.size();
+  if (nk == 0) return CBH_OK;
+  int nper[kLevels] = {0};
+  OrbPlan pl = make_plan(n, img_off, img_w, img_h, img_row_stride, nper, limit.data());
+  OrbImage* d_images = nullptr;
+  unsigned char *d_pyr = nullptr, *d_sc = nullptr, *d_desc = nullptr;
+  unsigned* d_lc = nullptr;
+  int* d_pat = nullptr;
+  OrbGivenKp* d_kps = nullptr;
+  float* d_xy = nullptr;
+  hipError_t e = hipSuccess;
+  auto alloc = [&](void** p, size_t bytes) {
+    if (e == hipSuccess) e = hipMallocAsync(p, std::max<size_t>(bytes, 256), s);
+  };
+  alloc((void**)&d_images, n * sizeof(OrbImage));
+  alloc((void**)&d_pyr, pl.pyr_bytes + 64);
+  alloc((void**)&d_sc, pl.sc_bytes + 64);
+  alloc((void**)&d_lc, n * kLevels * sizeof(unsigned));
+  alloc((void**)&d_pat, sizeof pat);
+  alloc((void**)&d_kps, nk * sizeof(OrbGivenKp));
+  alloc((void**)&d_xy, nk * 2 * sizeof(float));
+  alloc((void**)&d_desc, nk * 32);
+  std::vector<float> xy(nk * 2);
+  int rc = CBH_OK;
+  if (e == hipSuccess) e = hipMemcpyAsync(d_images, pl.images.data(), n * sizeof(OrbImage), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_pat, &pat, sizeof pat, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_lc, lc.data(), lc.size() * sizeof(unsigned), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_kps, flat.data(), nk * sizeof(OrbGivenKp), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) {
+    const unsigned ny = (unsigned)n;
+    if (pl.max_lev >= 1) hipLaunchKernelGGL(k_orb_level0, dim3(32, ny), dim3(256), 0, s, d_images, d_imgs, d_pyr);
+    for (int l = 1; l < pl.max_lev; ++l)
+      hipLaunchKernelGGL(k_orb_resize,
+                         dim3((unsigned)((pl.max_h[l] + 2 * kBorderY + kResizeRows - 1) / kResizeRows), ny), dim3(256),
+                         (size_t)pl.max_pitch * 8, s, d_images, l, d_pyr);
+    GaussK g;
+    gauss7_kernel(g.k);
+    if (pl.max_bwg) hipLaunchKernelGGL(k_orb_blur, dim3(pl.max_bwg, ny), dim3(256), 0, s, d_images, d_pyr, d_lc, g, d_sc);
+    hipLaunchKernelGGL(k_orb_describe_given, dim3((unsigned)((nk + 3) / 4)), dim3(256), 0, s, d_images, d_sc, d_kps,
+                       (unsigned)nk, d_pat, d_xy, d_desc);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(xy.data(), d_xy, nk * 2 * sizeof(float), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(out_desc, d_desc, nk * 32, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) {
+    set_last_error("orb describe", e);
+    rc = e == hipErrorOutOfMemory ? CBH_E_NOMEM : CBH_E_HIP;
+  } else {
+    for (size_t k = 0; k < nk; ++k) out_kp[k].x = xy[2 * k], out_kp[k].y = xy[2 * k + 1];
+  }
+  for (void* p : {(void*)d_images, (void*)d_pyr, (void*)d_sc, (void*)d_lc, (void*)d_pat, (void*)d_kps, (void*)d_xy,
+                  (void*)d_desc})
     if (p) (void)hipFreeAsync(p, s);
   return rc;
 }
@@ -954,6 +1127,40 @@ int cbh_orb(const uint8_t* imgs, size_t imgs_bytes, size_t n, const uint64_t* im
   if (s) (void)hipStreamSynchronize(s);
   for (void* p : {(void*)d_imgs, (void*)d_kp, (void*)d_after, (void*)d_desc, (void*)d_counts})
     if (p) (void)hipFree(p);
+  if (s) (void)hipStreamDestroy(s);
+  return rc;
+}
+
+int cbh_orb_describe(const uint8_t* imgs, size_t imgs_bytes, size_t n, const uint64_t* img_off, const uint32_t* img_w,
+                     const uint32_t* img_h, const uint32_t* img_row_stride, const cbh_keypoint* kp,
+                     const uint32_t* kp_first, cbh_keypoint* out_kp, uint8_t* out_desc, uint32_t* out_first, int device) {
+  if (!cbh::device_usable(device)) return CBH_E_NODEVICE;
+  if (!out_first) return CBH_E_INVAL;
+  out_first[0] = 0;
+  if (n == 0) return CBH_OK;
+  if (!imgs || !img_off || !img_w || !img_h || !img_row_stride || !kp_first || n > 65535) return CBH_E_INVAL;
+  if (kp_first[n] && (!kp || !out_kp || !out_desc)) return CBH_E_INVAL;
+  for (size_t i = 0; i < n; ++i)
+    if (kp_first[i + 1] < kp_first[i] || img_w[i] == 0 || img_h[i] == 0 || img_w[i] > 8192 || img_h[i] > 8192 ||
+        img_row_stride[i] < img_w[i] || img_off[i] + (uint64_t)(img_h[i] - 1) * img_row_stride[i] + img_w[i] > imgs_bytes)
+      return CBH_E_INVAL;
+  cbh::DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  hipStream_t s = nullptr;
+  uint8_t* d_imgs = nullptr;
+  hipError_t e;
+  int rc = CBH_OK;
+  if ((e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipMalloc(&d_imgs, imgs_bytes)) != hipSuccess ||
+      (e = hipMemcpyAsync(d_imgs, imgs, imgs_bytes, hipMemcpyHostToDevice, s)) != hipSuccess) {
+    cbh::set_last_error("orb describe setup", e);
+    rc = e == hipErrorOutOfMemory ? CBH_E_NOMEM : CBH_E_HIP;
+  }
+  if (rc == CBH_OK)
+    rc = cbh::launch_orb_describe(d_imgs, n, img_off, img_w, img_h, img_row_stride, kp, kp_first, out_kp, out_desc,
+                                  out_first, s);
+  if (s) (void)hipStreamSynchronize(s);
+  if (d_imgs) (void)hipFree(d_imgs);
   if (s) (void)hipStreamDestroy(s);
   return rc;
 }

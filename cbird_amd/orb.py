@@ -105,12 +105,26 @@ def make_keypoints(images, num_keypoints: int = 400, device: int = 0):
     return [r[0] for r in orb(images, num_keypoints, descriptors=False, device=device)]
 
 
-def make_keypoint_descriptors(images, num_keypoints: int = 400, device: int = 0):
-    """makeKeyPoints followed by makeKeyPointDescriptors, as Scanner::processImage runs them
-    (/root/reference/src/scanner.cpp:878-884): a list of (keypoints with pt as compute() leaves it, descriptors)"""
-    res = []
-    for kp, after, desc in orb(images, num_keypoints, descriptors=True, device=device):
-        kp = kp.copy()
-        kp["x"], kp["y"] = after[:, 0], after[:, 1]
-        res.append((kp, desc))
-    return res
+def make_keypoint_descriptors(images, keypoints, device: int = 0):
+    """Media::makeKeyPointDescriptors (/root/reference/src/media.cpp:868-872) for a batch: keypoints is a list of
+    KP_DTYPE arrays (what make_keypoints returned for the same images).  Returns a list of (keypoints as compute()
+    leaves them in the reference's non-const list, descriptors uint8[k, 32])."""
+    n = len(images)
+    if n != len(keypoints):
+        raise ValueError("one keypoint array per image")
+    if n == 0:
+        return []
+    buf, total, off, w, h = _pack(images)
+    kps = [np.ascontiguousarray(k, KP_DTYPE).reshape(-1) for k in keypoints]
+    first = np.zeros(n + 1, np.uint32)
+    first[1:] = np.cumsum([len(k) for k in kps])
+    nk = int(first[-1])
+    kp = np.concatenate(kps) if nk else np.zeros(1, KP_DTYPE)
+    out_kp = np.zeros(max(1, nk), KP_DTYPE)
+    desc = np.zeros((max(1, nk), 32), np.uint8)
+    out_first = np.zeros(n + 1, np.uint32)
+    check(_lib.lib().cbh_orb_describe(buf.ctypes.data, total, n, off.ctypes.data, w.ctypes.data, h.ctypes.data,
+                                      w.ctypes.data, kp.ctypes.data, first.ctypes.data, out_kp.ctypes.data,
+                                      desc.ctypes.data, out_first.ctypes.data, device), "orb_describe")
+    return [(out_kp[int(out_first[i]): int(out_first[i + 1])].copy(),
+             desc[int(out_first[i]): int(out_first[i + 1])].copy()) for i in range(n)]

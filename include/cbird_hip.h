@@ -138,6 +138,16 @@ int cbh_orb_set_pattern(const int8_t* xy);
 int cbh_orb(const uint8_t* imgs, size_t imgs_bytes, size_t n, const uint64_t* img_off, const uint32_t* img_w,
             const uint32_t* img_h, const uint32_t* img_row_stride, int nfeatures, int kp_cap, cbh_keypoint* kp,
             float* kp_after, uint8_t* desc, uint32_t* counts, int device);
+/* Media::makeKeyPointDescriptors alone (src/media.cpp:868-872), on keypoints the caller provides -- ORB::operator()
+ * with useProvidedKeypoints: keypoints whose rounded position lies within 31 pixels of the image border are dropped,
+ * the rest grouped by octave (order kept inside an octave), pt scaled to the level, described, scaled back.  Image i
+ * provides kp[kp_first[i] .. kp_first[i+1]); out_kp / out_desc (room for kp_first[n] entries) receive what compute()
+ * leaves in cbird's non-const keypoint list and the descriptor rows, image i owning [out_first[i], out_first[i+1]).
+ * A keypoint whose octave has no pyramid level in its image, or whose patch leaves that level, is CBH_E_INVAL
+ * (OpenCV would read outside the image). */
+int cbh_orb_describe(const uint8_t* imgs, size_t imgs_bytes, size_t n, const uint64_t* img_off, const uint32_t* img_w,
+                     const uint32_t* img_h, const uint32_t* img_row_stride, const cbh_keypoint* kp,
+                     const uint32_t* kp_first, cbh_keypoint* out_kp, uint8_t* out_desc, uint32_t* out_first, int device);
 /* images and outputs in device memory (the size arrays stay on the host); stream NULL = synchronous */
 int cbh_orb_dev(const void* d_imgs, size_t n, const uint64_t* img_off, const uint32_t* img_w, const uint32_t* img_h,
                 const uint32_t* img_row_stride, int nfeatures, int kp_cap, void* d_kp, void* d_kp_after, void* d_desc,

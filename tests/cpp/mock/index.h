@@ -216,11 +216,15 @@ struct Point {
 struct Point2f {
   float x = 0, y = 0;
 };
-struct KeyPoint {  // opencv2/features2d: the fields makeKeyPointHashes reads
+struct KeyPoint {  // opencv2/features2d (2.4): pt, size, angle, response, octave, class_id
   Point2f pt;
-  float size = 0;
+  float size = 0, angle = -1, response = 0;
+  int octave = 0, class_id = -1;
   KeyPoint() {}
-  KeyPoint(float x, float y, float s) : size(s) { pt.x = x, pt.y = y; }
+  KeyPoint(float x, float y, float s, float a = -1, float r = 0, int o = 0, int c = -1)
+      : size(s), angle(a), response(r), octave(o), class_id(c) {
+    pt.x = x, pt.y = y;
+  }
 };
 struct Mat {  // rows x cols bytes (CV_8UC1); views share the parent's storage like cv::Mat
   int rows = 0, cols = 0;

@@ -6,6 +6,7 @@
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "index.h"
 #include "gpu_cvutil.h"
@@ -68,5 +69,34 @@ int main(int argc, char** argv) {
   for (int y = 0; y < big.rows; ++y)
     for (int x = 0; x < big.cols; ++x) sum = sum * 1099511628211ull + big.ptr<uint8_t>(y)[x];
   printf("resized %d %d %" PRIu64 "\n", big.cols, big.rows, sum);
+  // 5. ORB: makeKeyPoints, then makeKeyPointDescriptors on its result, as Scanner::processImage calls them; the
+  //    pattern is the stand-in the Python side generates too (x = (i * 7 + 3) % 27 - 13 ...)
+  if (w > 62 && h > 62) {
+    int pat[1024];
+    for (int i = 0; i < 1024; ++i) pat[i] = (i * 7 + (i / 4) * 3 + 3) % 27 - 13;
+    cbird_gpu::gpuOrbSetPattern(pat);
+    cv::Mat scene(h, w);
+    uint32_t s3 = uint32_t(atoi(argv[3])) + 17u;
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) scene.ptr<uint8_t>(y)[x] = uint8_t(((x / 9 + y / 7) % 2 ? 200 : 40) + int(xs(s3) % 9u));
+    KeyPointList orbKp;
+    cbird_gpu::gpuMakeKeyPoints(scene, 100, orbKp);
+    printf("orb_n %zu\n", orbKp.size());
+    KeyPointDescriptors descr;
+    cbird_gpu::gpuMakeKeyPointDescriptors(scene, orbKp, descr);
+    sum = 0;
+    for (const cv::KeyPoint& k : orbKp) {
+      uint32_t bits[5];
+      memcpy(bits, &k.pt.x, 4), memcpy(bits + 1, &k.pt.y, 4), memcpy(bits + 2, &k.size, 4);
+      memcpy(bits + 3, &k.angle, 4), memcpy(bits + 4, &k.response, 4);
+      for (uint32_t b : bits) sum = sum * 1099511628211ull + b;
+      sum = sum * 1099511628211ull + uint32_t(k.octave);
+    }
+    printf("orb_kp %zu %" PRIu64 "\n", orbKp.size(), sum);
+    sum = 0;
+    for (int r = 0; r < descr.rows; ++r)
+      for (int c = 0; c < 32; ++c) sum = sum * 1099511628211ull + descr.ptr<uint8_t>(r)[c];
+    printf("orb_desc %d %" PRIu64 "\n", descr.rows, sum);
+  }
   return 0;
 }

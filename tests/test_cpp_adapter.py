@@ -71,6 +71,8 @@ def test_cvutil_dropins_compile():
     assert "gpuDctHash64(const cv::Mat& cvImg, bool inPlace = false)" in src
     assert "gpuMakeKeyPointHashes(const cv::Mat& cvImg, const KeyPointList& keyPoints, KeyPointHashList& outHashes)" in src
     assert "gpuSizeLongestSide(cv::Mat& img, int size)" in src
+    assert "gpuMakeKeyPoints(const cv::Mat& cvImg, int numKeyPoints, KeyPointList& outKeypoints)" in src
+    assert "gpuMakeKeyPointDescriptors(const cv::Mat& cvImg, KeyPointList& keyPoints, KeyPointDescriptors& outDescriptors)" in src
 
 
 def _xorshift_stream(seed):
@@ -122,3 +124,23 @@ def test_cvutil_dropins_run_on_gpu(gpu, orc, w, h, seed):
     assert got["after_kp_checksum"] == [_checksum(after)]
     small = orc.size_longest_side(img, 128)
     assert got["resized"] == [small.shape[1], small.shape[0], _checksum(small)]
+    # ORB drop-ins: gpuMakeKeyPoints then gpuMakeKeyPointDescriptors == the oracle's detect / compute
+    from oracle import OrbOracle
+
+    o = OrbOracle()
+    pat = np.array([(i * 7 + (i // 4) * 3 + 3) % 27 - 13 for i in range(1024)], np.int8)
+    o.set_pattern(pat)
+    g3 = _xorshift_stream((seed + 17) & 0xFFFFFFFF)
+    yy, xx = np.indices((h, w))
+    noise = np.array([next(g3) % 9 for _ in range(w * h)], np.int64).reshape(h, w)
+    scene = (np.where((xx // 9 + yy // 7) % 2 == 1, 200, 40) + noise).astype(np.uint8)
+    kp = o.detect(scene, 100)
+    assert got["orb_n"] == [len(kp)] and len(kp) > 20
+    kp2, desc = o.compute(scene, kp)
+    v = 0
+    for k in kp2:
+        for f in ("x", "y", "size", "angle", "response"):
+            v = (v * 1099511628211 + int(np.float32(k[f]).view(np.uint32))) & 0xFFFFFFFFFFFFFFFF
+        v = (v * 1099511628211 + int(k["octave"])) & 0xFFFFFFFFFFFFFFFF
+    assert got["orb_kp"] == [len(kp2), v]
+    assert got["orb_desc"] == [len(desc), _checksum(desc)]

@@ -231,6 +231,41 @@ def test_gpu_orb_equals_oracle(gpu, orb_orc):
 
 
 @pytest.mark.gpu
+def test_gpu_make_keypoint_descriptors_on_provided_keypoints(gpu, orb_orc):
+    """the extractor alone (makeKeyPointDescriptors as the reference calls it, on the keypoints makeKeyPoints
+    returned): equal to the oracle's compute() -- also for a list that was shuffled, thinned and given keypoints too
+    close to the border (dropped) -- and equal to the fused detect + describe call"""
+    from cbird_amd import orb
+
+    pat = orb.synthetic_pattern(5)
+    orb_orc.set_pattern(pat)
+    orb.set_pattern(pat)
+    rng = np.random.default_rng(21)
+    imgs = [_scene(rng, w, h) for (w, h) in ((400, 300), (320, 400), (150, 110), (64, 64), (40, 40))]
+    kps = orb.make_keypoints(imgs, 400)
+    got = orb.make_keypoint_descriptors(imgs, kps)
+    fused = orb.orb(imgs, 400)
+    for img, k, (k2, d), (fk, fa, fd) in zip(imgs, kps, got, fused):
+        w2, d2 = orb_orc.compute(img, k)
+        assert (k2 == w2).all() and (d == d2).all()
+        assert (fd == d).all() and (fa[:, 0] == k2["x"]).all() and (fa[:, 1] == k2["y"]).all()
+    # a modified list: shuffled, every third dropped, two points near the border added
+    k = kps[0].copy()
+    k = k[rng.permutation(len(k))][::3]
+    extra = np.zeros(2, orb.KP_DTYPE)
+    extra["x"], extra["y"], extra["octave"], extra["angle"] = [5.0, 395.0], [100.0, 100.0], [0, 1], [10.0, 20.0]
+    k = np.concatenate([k[:10], extra, k[10:]])
+    (k2, d), = orb.make_keypoint_descriptors(imgs[:1], [k])
+    w2, d2 = orb_orc.compute(imgs[0], k)
+    assert len(k2) == len(k) - 2 and (k2 == w2).all() and (d == d2).all()
+    # a keypoint whose octave does not exist in its image is an error, not a read outside the level
+    bad = np.zeros(1, orb.KP_DTYPE)
+    bad["x"], bad["y"], bad["octave"] = 32.0, 32.0, 5
+    with pytest.raises(orb._lib.CbhError):
+        orb.make_keypoint_descriptors(imgs[3:4], [bad])
+
+
+@pytest.mark.gpu
 def test_gpu_orb_cos_sin_match_libm(gpu, orb_orc):
     """the one place the device's libm meets the host's: (float)cos(angle), (float)sin(angle) of the descriptor
     rotation.  Every keypoint of a large batch gives the oracle's descriptor, i.e. no rounding difference surfaced."""
