@@ -64,6 +64,10 @@ _SIGS = {
     "cbh_keypoint_hashes": (C.c_int, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "cbh_dcthash_rects": (C.c_int, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int]),
     "cbh_keypoint_hashes_dev": (C.c_int, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "cbh_color_descriptor_dims": (None, [C.c_int, C.c_int, _vp, _vp]),
+    "cbh_color_ellipse_mask": (C.c_int, [C.c_int, C.c_int, _vp]),
+    "cbh_color_descriptors": (C.c_int, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int]),
+    "cbh_color_descriptors_dev": (C.c_int, [_vp, _sz, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
     "cbh_orb_set_pattern": (C.c_int, [_vp]),
     "cbh_orb": (C.c_int, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
     "cbh_orb_describe": (C.c_int, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),

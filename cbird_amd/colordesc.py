@@ -1,6 +1,7 @@
 """Host-side mirror of ColorDescIndex / ColorDescriptor (src/colordescindex.{h,cpp}, src/cvutil.h:57-113).
-Descriptor *creation* (k-means over Luv pixels, src/cvutil.cpp:790-1099, non-deterministic by the reference's
-own account) is outside the hot path; descriptors are the reference's 258-byte records."""
+Descriptors are the reference's 258-byte records; create_descriptors() is ColorDescriptor::create for a batch
+(k-means over Luv pixels, src/cvutil.cpp:790-1099; what can and cannot match the cbird binary is stated in
+include/cbird_hip.h)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -24,6 +25,35 @@ def make_descriptor(luvw, num_colors=None) -> np.ndarray:
     d["colors"][: len(luvw)] = luvw
     d["numColors"] = len(luvw) if num_colors is None else num_colors
     return d
+
+
+def create_descriptors(images, device: int = 0):
+    """ColorDescriptor::create (src/cvutil.cpp:790-1099) for a list of uint8 BGR / BGRA images [h, w, 3 | 4] of any
+    sizes (one channel count per call).  Returns (descriptors COLOR_DTYPE[n], ok bool[n]); ok is False where the
+    reference returns without touching the descriptor ("not enough colors")."""
+    n = len(images)
+    if n == 0:
+        return np.zeros(0, COLOR_DTYPE), np.zeros(0, bool)
+    imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+    ch = imgs[0].shape[2] if imgs[0].ndim == 3 else 0
+    if ch not in (3, 4) or any(im.ndim != 3 or im.shape[2] != ch or im.size == 0 for im in imgs):
+        raise ValueError("expected non-empty uint8 images [h, w, 3] or [h, w, 4] (BGR / BGRA), one channel count")
+    sizes = np.array([im.size for im in imgs], np.uint64)
+    off = np.zeros(n, np.uint64)
+    off[1:] = np.cumsum((sizes[:-1] + np.uint64(15)) // np.uint64(16) * np.uint64(16))
+    total = int(off[-1] + sizes[-1])
+    buf = np.zeros(total, np.uint8)
+    for im, o in zip(imgs, off):
+        buf[int(o): int(o) + im.size] = im.reshape(-1)
+    w = np.array([im.shape[1] for im in imgs], np.uint32)
+    h = np.array([im.shape[0] for im in imgs], np.uint32)
+    stride = (w * np.uint32(ch)).astype(np.uint32)
+    descs = np.zeros(n, COLOR_DTYPE)
+    ok = np.zeros(n, np.uint8)
+    check(_lib.lib().cbh_color_descriptors(buf.ctypes.data, total, n, off.ctypes.data, w.ctypes.data, h.ctypes.data,
+                                           stride.ctypes.data, ch, descs.ctypes.data, ok.ctypes.data, device),
+          "color_descriptors")
+    return descs, ok.astype(bool)
 
 
 class ColorDescIndex:

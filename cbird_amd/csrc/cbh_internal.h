@@ -143,4 +143,9 @@ int launch_orb_describe(const uint8_t* d_imgs, size_t n, const uint64_t* img_off
                         const uint32_t* kp_first, cbh_keypoint* out_kp, uint8_t* out_desc, uint32_t* out_first,
                         hipStream_t s);
 
+// ---- colordesc_create.hip: ColorDescriptor::create for a batch --------------------------------------------------
+int launch_color_descriptors(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const uint32_t* img_w,
+                             const uint32_t* img_h, const uint32_t* img_row_stride, int channels, uint8_t* d_descs,
+                             uint8_t* d_ok, hipStream_t s);
+
 }  // namespace cbh

@@ -1,0 +1,774 @@
+// colordesc_create.hip -- SURVEY.md section 8 row a14: ColorDescriptor::create (/root/reference/src/cvutil.cpp:790-1099)
+// for a batch of BGR / BGRA images resident in HBM: nearest resize to <= 256 px, elliptic mask, float BGR -> Luv,
+// k-means++ seeding and k-means (K = 32, cv::kmeans with TermCriteria(ITER|EPS, 100, 10)), centre-weighted colour
+// frequencies, the 258-byte descriptor.  Bit-exact against oracle/colordesc_oracle.c, whose header states what is and
+// what cannot be pinned against the cbird binary (per-thread RNG state, tie order, the ellipse rim).
+//
+// Everything after the Luv conversion is ORDER-DEPENDENT arithmetic by the reference's construction: the seeding
+// walks `p -= dist[i]` and sums `s += tdist2[i]` in double, centres are float sums in sample order, frequencies are
+// float sums in pixel order.  None of these sums is exact, so none can be re-associated; the only parallelism that
+// reproduces the reference is ACROSS IMAGES.  Hence:
+//   k_cd_prepare   one workgroup per image, pixel-parallel: resize + mask + Luv (the gamma spline collapses into a
+//                  256-entry table because its input is an 8-bit value; the cube-root spline table sits in LDS),
+//                  ordered compaction of the samples that pass `l > 4`
+//   k_cd_cluster   ONE LANE PER IMAGE, a wave = 64 images whose sample / distance / label arrays are interleaved
+//                  (element i of the 64 images is contiguous: every load of the lock-step loops is one coalesced
+//                  768-byte or 256-byte access).  The 32 centres live in 96 VGPRs per lane; sums and counters, which
+//                  are indexed by a per-lane label, in LDS with the lane as the fastest index (conflict-free).
+// Throughput therefore comes from batch size (64 images per wave, one wave per SIMD once 65k images are in flight);
+// latency per image is what the sequential chains cost (~12M dependent double adds).
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "cbh_index.h"
+
+namespace cbh {
+namespace {
+
+constexpr int kK = 32;            // ColorDescriptor::NUM_DESC_COLORS
+constexpr int kMaxSamples = 65536;  // 256 x 256 after sizeLongestSide(rgb, 256)
+constexpr int kTab = 1024;
+
+struct CdImage {
+  unsigned long long src_off;
+  unsigned src_stride;
+  int w, h;        // source
+  int cols, rows;  // after the resize
+  unsigned mask_off;
+};
+
+// ---- host: tables and the ellipse mask (restated separately from the oracle's copy) ----------------------------------
+int cv_round(double v) { return (int)std::nearbyint(v); }
+int cv_floor(double v) {
+  const int i = (int)v;
+  return i - (v < i);
+}
+
+float cv_cbrt(float value) {  // cvCbrt (core/src/mathfuncs.cpp)
+  union {
+    int i;
+    float f;
+  } v, m;
+  v.f = value;
+  const int ix = v.i & 0x7fffffff, s = v.i & 0x80000000;
+  int ex = (ix >> 23) - 127;
+  int shx = ex % 3;
+  shx -= shx >= 0 ? 3 : 0;
+  ex = (ex - shx) / 3;
+  v.i = (ix & ((1 << 23) - 1)) | ((shx + 127) << 23);
+  float fr = v.f;
+  fr = (float)(((((45.2548339756803022511987494 * fr + 192.2798368355061050458134625) * fr +
+                  119.1654824285581628956914143) * fr + 13.43250139086239872172837314) * fr +
+                0.1636161226585754240958355063) /
+               ((((14.80884093219134573786480845 * fr + 151.9714051044435648658557668) * fr +
+                  168.5254414101568283957668343) * fr + 33.9905941350215598754191872) * fr + 1.0));
+  m.f = value;
+  v.f = fr;
+  v.i = (int)(((unsigned)v.i + ((unsigned)ex << 23) + (unsigned)s) & (((unsigned)m.i << 1) != 0u ? ~0u : 0u));
+  return v.f;
+}
+void spline_build(const float* f, int n, float* tab) {
+  float cn = 0;
+  tab[0] = tab[1] = 0.f;
+  for (int i = 1; i < n - 1; i++) {
+    const float t = 3 * (f[i + 1] - 2 * f[i] + f[i - 1]);
+    const float l = 1 / (4 - tab[(i - 1) * 4]);
+    tab[i * 4] = l;
+    tab[i * 4 + 1] = (t - tab[(i - 1) * 4 + 1]) * l;
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    const float c = tab[i * 4 + 1] - tab[i * 4] * cn;
+    const float b = f[i + 1] - f[i] - (cn + c * 2) * (float)0.3333333333333333;
+    const float d = (cn - c) * (float)0.3333333333333333;
+    tab[i * 4] = f[i], tab[i * 4 + 1] = b, tab[i * 4 + 2] = c, tab[i * 4 + 3] = d;
+    cn = c;
+  }
+}
+float spline_at(float x, const float* tab, int n) {
+  int ix = cv_floor((double)x);
+  ix = std::min(std::max(ix, 0), n - 1);
+  x -= ix;
+  tab += ix * 4;
+  return ((tab[3] * x + tab[2]) * x + tab[1]) * x + tab[0];
+}
+struct CdTables {
+  float gamma_lut[256];   // linearised value of an 8-bit channel: spline(sRGBGammaTab)((p * (1/255)) * 1024)
+  float cbrt_tab[kTab * 4];
+};
+const CdTables& tables() {
+  static CdTables t;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    std::vector<float> f(kTab + 1), g(kTab + 1), gtab(kTab * 4);
+    float scale = 1.f / (kTab / 1.5f);
+    for (int i = 0; i <= kTab; i++) {
+      const float x = i * scale;
+      f[i] = x < 0.008856f ? x * 7.787f + 0.13793103448275862f : cv_cbrt(x);
+    }
+    spline_build(f.data(), kTab, t.cbrt_tab);
+    scale = 1.f / (float)kTab;
+    for (int i = 0; i <= kTab; i++) {
+      const float x = i * scale;
+      g[i] = x <= 0.04045f ? x * (1.f / 12.92f) : (float)std::pow((double)(x + 0.055) * (1. / 1.055), 2.4);
+    }
+    spline_build(g.data(), kTab, gtab.data());
+    const float s255 = (float)(1.0 / 255.0);
+    for (int p = 0; p < 256; ++p) t.gamma_lut[p] = spline_at(((float)p * s255 + 0.f) * (float)kTab, gtab.data(), kTab);
+  });
+  return t;
+}
+
+// cv::ellipse(mask, RotatedRect({c/2, r/2}, {0.9 c, 0.9 r}, 0), 255, CV_FILLED): ellipse2Poly + FillConvexPoly (+ Line2)
+constexpr int kXYShift = 16, kXYOne = 1 << kXYShift;
+struct Pt {
+  int x, y;
+};
+float sin_table(int deg) {  // drawing.cpp's SinTable: sin(deg) written with seven decimals
+  char buf[32];
+  snprintf(buf, sizeof buf, "%.7f", std::sin(deg * 3.14159265358979323846 / 180.0));
+  return strtof(buf, nullptr);
+}
+void line2(uint8_t* img, int w, int h, Pt a, Pt b) {
+  auto put = [&](int x, int y) {
+    if (0 <= x && x < w && 0 <= y && y < h) img[(size_t)y * w + x] = 255;
+  };
+  int dx = b.x - a.x, dy = b.y - a.y;
+  const int j = dx < 0 ? -1 : 0, ax = (dx ^ j) - j;
+  const int i = dy < 0 ? -1 : 0, ay = (dy ^ i) - i;
+  int x_step, y_step, ecount;
+  if (ax > ay) {
+    dy = (dy ^ j) - j;
+    a.x ^= b.x & j, b.x ^= a.x & j, a.x ^= b.x & j;
+    a.y ^= b.y & j, b.y ^= a.y & j, a.y ^= b.y & j;
+    x_step = kXYOne;
+    y_step = (int)(((long long)dy << kXYShift) / (ax | 1));
+    ecount = (b.x - a.x) >> kXYShift;
+  } else {
+    dx = (dx ^ i) - i;
+    a.x ^= b.x & i, b.x ^= a.x & i, a.x ^= b.x & i;
+    a.y ^= b.y & i, b.y ^= a.y & i, a.y ^= b.y & i;
+    x_step = (int)(((long long)dx << kXYShift) / (ay | 1));
+    y_step = kXYOne;
+    ecount = (b.y - a.y) >> kXYShift;
+  }
+  a.x += kXYOne >> 1, a.y += kXYOne >> 1;
+  put((b.x + (kXYOne >> 1)) >> kXYShift, (b.y + (kXYOne >> 1)) >> kXYShift);
+  if (ax > ay) {
+    a.x >>= kXYShift;
+    for (; ecount >= 0; --ecount) {
+      put(a.x, a.y >> kXYShift);
+      a.x++, a.y += y_step;
+    }
+  } else {
+    a.y >>= kXYShift;
+    for (; ecount >= 0; --ecount) {
+      put(a.x >> kXYShift, a.y);
+      a.x += x_step, a.y++;
+    }
+  }
+}
+void fill_convex(uint8_t* img, int w, int h, const Pt* v, int npts) {
+  struct {
+    int idx, di, x, dx, ye;
+  } edge[2];
+  const int delta = 1 << (kXYShift - 1);
+  int imin = 0, left = 0, right = 1, edges = npts;
+  int xmin = v[0].x, xmax = v[0].x, ymin = v[0].y, ymax = v[0].y;
+  Pt p0 = v[npts - 1];
+  for (int i = 0; i < npts; i++) {
+    const Pt p = v[i];
+    if (p.y < ymin) ymin = p.y, imin = i;
+    ymax = std::max(ymax, p.y), xmax = std::max(xmax, p.x), xmin = std::min(xmin, p.x);
+    line2(img, w, h, p0, p);
+    p0 = p;
+  }
+  xmin = (xmin + delta) >> kXYShift, xmax = (xmax + delta) >> kXYShift;
+  ymin = (ymin + delta) >> kXYShift, ymax = (ymax + delta) >> kXYShift;
+  if (npts < 3 || xmax < 0 || ymax < 0 || xmin >= w || ymin >= h) return;
+  ymax = std::min(ymax, h - 1);
+  int y = ymin;
+  edge[0].idx = edge[1].idx = imin;
+  edge[0].ye = edge[1].ye = y;
+  edge[0].di = 1, edge[1].di = npts - 1;
+  edge[0].x = edge[1].x = edge[0].dx = edge[1].dx = 0;
+  do {
+    for (int i = 0; i < 2; i++) {
+      if (y >= edge[i].ye) {
+        int idx = edge[i].idx, xs = 0, ty = 0;
+        const int di = edge[i].di;
+        for (;;) {
+          ty = (v[idx].y + delta) >> kXYShift;
+          if (ty > y || edges == 0) break;
+          xs = v[idx].x;
+          idx += di;
+          if (idx >= npts) idx -= npts;
+          edges--;
+        }
+        const int ye = ty, xe = v[idx].x;
+        if (y >= ye) return;
+        edge[i].ye = ye;
+        edge[i].dx = ((xe - xs) * 2 + (ye - y)) / (2 * (ye - y));
+        edge[i].x = xs;
+        edge[i].idx = idx;
+      }
+    }
+    if (edge[left].x > edge[right].x) left ^= 1, right ^= 1;
+    int x1 = edge[left].x, x2 = edge[right].x;
+    if (y >= 0) {
+      int xx1 = (x1 + (kXYOne >> 1)) >> kXYShift, xx2 = (x2 + (kXYOne >> 1)) >> kXYShift;
+      if (xx2 >= 0 && xx1 < w) {
+        xx1 = std::max(xx1, 0), xx2 = std::min(xx2, w - 1);
+        for (int x = xx1; x <= xx2; ++x) img[(size_t)y * w + x] = 255;
+      }
+    }
+    edge[left].x = x1 + edge[left].dx;
+    edge[right].x = x2 + edge[right].dx;
+  } while (++y <= ymax);
+}
+void ellipse_mask(int cols, int rows, uint8_t* mask) {
+  memset(mask, 0, (size_t)cols * rows);
+  const float cxf = cols * 0.5f, cyf = rows * 0.5f, swf = cols * 0.9f, shf = rows * 0.9f;
+  const Pt center = {cv_round((double)(cxf * (1 << kXYShift))), cv_round((double)(cyf * (1 << kXYShift)))};
+  const int aw = std::abs(cv_round((double)(swf * (1 << (kXYShift - 1)))));
+  const int ah = std::abs(cv_round((double)(shf * (1 << (kXYShift - 1)))));
+  int delta = (std::max(aw, ah) + (kXYOne >> 1)) >> kXYShift;
+  delta = delta < 3 ? 90 : delta < 10 ? 30 : delta < 15 ? 18 : 5;
+  Pt pts[80];
+  int n = 0;
+  const float alpha = sin_table(450), beta = sin_table(0);
+  Pt prev = {INT_MIN, INT_MIN};
+  for (int i = 0; i < 360 + delta; i += delta) {
+    const int angle = std::min(i, 360);
+    const double x = (double)aw * sin_table(450 - angle), y = (double)ah * sin_table(angle);
+    const Pt pt = {cv_round((double)center.x + x * alpha - y * beta), cv_round((double)center.y + x * beta + y * alpha)};
+    if (pt.x != prev.x || pt.y != prev.y) pts[n++] = pt, prev = pt;
+  }
+  if (n == 1) pts[n++] = pts[0];
+  fill_convex(mask, cols, rows, pts, n);
+}
+
+void resized_dims(int w, int h, int* ow, int* oh) {  // sizeLongestSide(rgb, 256, INTER_NEAREST), cvutil.cpp:811, 1932-1942
+  *ow = w, *oh = h;
+  if (h > 256 || w > 256) {
+    const float aspect = (float)w / h;
+    if (w > h) {
+      *ow = 256;
+      *oh = (int)(256 / aspect);
+    } else {
+      *oh = 256;
+      *ow = (int)(aspect * 256);
+    }
+  }
+}
+
+// ---- device ----------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_incl_scan_i(int v) {
+  const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// interleaved arrays of a group of 64 images: element i of image `lane`
+__device__ __forceinline__ size_t il(size_t group, unsigned i, unsigned lane) {
+  return (group * kMaxSamples + i) * 64 + lane;
+}
+
+__global__ __launch_bounds__(256) void k_cd_prepare(const CdImage* __restrict__ images,
+                                                    const unsigned char* __restrict__ imgs, int channels,
+                                                    const unsigned char* __restrict__ masks,
+                                                    const CdTables* __restrict__ tabs,
+                                                    float* __restrict__ samples /* [group][i][lane][3] */,
+                                                    unsigned* __restrict__ pos /* row << 16 | col */,
+                                                    int* __restrict__ counts) {
+  __shared__ float s_cbrt[kTab * 4];
+  __shared__ float s_gamma[256];
+  __shared__ int s_xofs[256], s_yofs[256];
+  __shared__ int s_w[4];
+  const int tid = (int)threadIdx.x;
+  const unsigned img_i = blockIdx.x;
+  const CdImage im = images[img_i];
+  const size_t group = img_i >> 6;
+  const unsigned lane = img_i & 63u;
+  for (int i = tid; i < kTab * 4; i += 256) s_cbrt[i] = tabs->cbrt_tab[i];
+  s_gamma[tid] = tabs->gamma_lut[tid];
+  {
+    // resizeNN: sx = min(floor(x * (1 / (dcols / w))), w - 1)   (identity when the image was not resized)
+    const double ifx = 1. / ((double)im.cols / im.w), ify = 1. / ((double)im.rows / im.h);
+    if (tid < im.cols) s_xofs[tid] = min((int)floor(tid * ifx), im.w - 1);
+    if (tid < im.rows) s_yofs[tid] = min((int)floor(tid * ify), im.h - 1);
+  }
+  __syncthreads();
+  // sRGB2XYZ_D65 with the R / B columns swapped for blueIdx 0; D65 white point
+  const float C0 = 0.180423f, C1 = 0.357580f, C2 = 0.412453f, C3 = 0.072169f, C4 = 0.715160f, C5 = 0.212671f,
+              C6 = 0.950227f, C7 = 0.119193f, C8 = 0.019334f;
+  const float d0 = 1.f / (0.950456f + 1.f * 15 + 1.088754f * 3);
+  const float un = 4 * 0.950456f * d0, vn = 9 * 1.f * d0;
+  const float _un = 13 * un, _vn = 13 * vn;
+  const float cbrt_scale = kTab / 1.5f;
+  const unsigned char* __restrict__ src = imgs + im.src_off;
+  const unsigned char* __restrict__ mask = masks + im.mask_off;
+  const int total = im.cols * im.rows;
+  int n_out = 0;
+  for (int p0 = 0; p0 < total; p0 += 256) {
+    const int p = p0 + tid;
+    int keep = 0;
+    float L = 0.f, U = 0.f, V = 0.f;
+    int row = 0, col = 0;
+    if (p < total) {
+      row = p / im.cols, col = p - row * im.cols;
+      const unsigned char* __restrict__ q = src + (size_t)s_yofs[row] * im.src_stride + (size_t)s_xofs[col] * channels;
+      const int alpha = mask[p];
+      // pix = (pix * alpha >> 8) & 0xFF; convertTo(CV_32F) * (1/255); gamma spline == table of the 8-bit value
+      const float R = s_gamma[((int)q[0] * alpha >> 8) & 0xFF];
+      const float G = s_gamma[((int)q[1] * alpha >> 8) & 0xFF];
+      const float B = s_gamma[((int)q[2] * alpha >> 8) & 0xFF];
+      const float X = R * C0 + G * C1 + B * C2;
+      const float Y = R * C3 + G * C4 + B * C5;
+      const float Z = R * C6 + G * C7 + B * C8;
+      float x = Y * cbrt_scale;
+      int ix = (int)floorf(x);
+      ix = min(max(ix, 0), kTab - 1);
+      x -= (float)ix;
+      const float* __restrict__ t = s_cbrt + ix * 4;
+      L = ((t[3] * x + t[2]) * x + t[1]) * x + t[0];
+      L = 116.f * L - 16.f;
+      const float den = X + 15 * Y + 3 * Z;
+      const float d = (4 * 13) / fmaxf(den, FLT_EPSILON);
+      U = L * (X * d - _un);
+      V = L * ((9 * 0.25f) * Y * d - _vn);
+      keep = L > 4;  // histFilter = brightFilter (cvutil.cpp:760-776)
+    }
+    // ordered compaction over the workgroup
+    const int incl = wave_incl_scan_i(keep);
+    const int wv = tid >> 6;
+    __syncthreads();
+    if ((tid & 63) == 63) s_w[wv] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < wv; ++i) base += s_w[i];
+    const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (keep) {
+      const size_t o = il(group, (unsigned)(n_out + base + incl - 1), lane);
+      samples[3 * o] = L, samples[3 * o + 1] = U, samples[3 * o + 2] = V;
+      pos[o] = (unsigned)row << 16 | (unsigned)col;
+    }
+    n_out += tot;
+  }
+  if (tid == 0) counts[img_i] = n_out;
+}
+
+struct Rng {
+  unsigned long long state;
+  __device__ __forceinline__ unsigned next() {
+    state = (unsigned long long)(unsigned)state * 4164903690ull + (unsigned)(state >> 32);
+    return (unsigned)state;
+  }
+  __device__ __forceinline__ double real() {
+    const unsigned t = next();
+    return (double)(((unsigned long long)t << 32) | next()) * 5.4210108624275221700372640043497e-20;
+  }
+};
+
+__device__ __forceinline__ float dist3(float a0, float a1, float a2, float b0, float b1, float b2) {
+  float d = 0.f, t = a0 - b0;  // normL2Sqr_, n = 3: d += t*t in index order, floats
+  d += t * t;
+  t = a1 - b1;
+  d += t * t;
+  t = a2 - b2;
+  d += t * t;
+  return d;
+}
+
+__global__ __launch_bounds__(64) void k_cd_cluster(const CdImage* __restrict__ images, unsigned n_images,
+                                                   const float* __restrict__ samples, const unsigned* __restrict__ pos,
+                                                   const int* __restrict__ counts, float* __restrict__ dists /* 3 slots */,
+                                                   unsigned char* __restrict__ labels,
+                                                   unsigned char* __restrict__ descs /* 258 per image */,
+                                                   unsigned char* __restrict__ ok) {
+  __shared__ float s_sum[3 * kK][64];  // centre sums; later: colour frequencies
+  __shared__ int s_cnt[kK][64];        // cluster sizes; later: representative centre of a colour key
+  const unsigned lane = threadIdx.x;
+  const size_t group = blockIdx.x;
+  const unsigned img_i = (unsigned)group * 64u + lane;
+  const bool live = img_i < n_images;
+  const int N = live ? counts[img_i] : 0;
+  const bool valid = N >= kK;  // "not enough colors": the reference returns without touching the descriptor
+  if (live) ok[img_i] = valid ? 1 : 0;
+  const int n = valid ? N : 0;
+  const size_t slot_stride = (size_t)gridDim.x * kMaxSamples * 64;
+  auto S = [&](int i, float& a, float& b, float& c) {
+    const size_t o = 3 * il(group, (unsigned)i, lane);
+    a = samples[o], b = samples[o + 1], c = samples[o + 2];
+  };
+  auto D = [&](int slot, int i) -> float& { return dists[(size_t)slot * slot_stride + il(group, (unsigned)i, lane)]; };
+
+  float cx[kK], cy[kK], cz[kK];
+#pragma unroll
+  for (int k = 0; k < kK; ++k) cx[k] = cy[k] = cz[k] = 0.f;
+  Rng rng{0xffffffffull};  // RNG(): a fresh thread's generator (oracle header, (1))
+
+  // ---- generateCentersPP(data, centers, K, rng, 3)
+  {
+    int sd = 0, st = 1, st2 = 2;
+    double sum0 = 0;
+    int c0 = n > 0 ? (int)(rng.next() % (unsigned)n) : 0;
+    float a0 = 0, a1 = 0, a2 = 0;
+    if (n > 0) S(c0, a0, a1, a2);
+    cx[0] = a0, cy[0] = a1, cz[0] = a2;
+    for (int i = 0; i < n; ++i) {
+      float b0, b1, b2;
+      S(i, b0, b1, b2);
+      const float d = dist3(b0, b1, b2, a0, a1, a2);
+      D(sd, i) = d;
+      sum0 += d;
+    }
+#pragma unroll 1
+    for (int k = 1; k < kK; ++k) {
+      double bestSum = DBL_MAX;
+      int bestCenter = -1;
+      for (int j = 0; j < 3; ++j) {
+        double p = rng.real() * sum0, s = 0;
+        int i = 0;
+        for (; i < n - 1; ++i)
+          if ((p -= D(sd, i)) <= 0) break;
+        const int ci = i;
+        if (n > 0) S(ci, a0, a1, a2);
+        for (i = 0; i < n; ++i) {
+          float b0, b1, b2;
+          S(i, b0, b1, b2);
+          const float d = dist3(b0, b1, b2, a0, a1, a2);
+          const float old = D(sd, i);
+          const float t = old < d ? old : d;  // std::min(d, dist[i])
+          D(st2, i) = t;
+          s += t;
+        }
+        if (s < bestSum) {
+          bestSum = s;
+          bestCenter = ci;
+          const int t = st;
+          st = st2, st2 = t;
+        }
+      }
+      sum0 = bestSum;
+      {
+        const int t = sd;
+        sd = st, st = t;
+      }
+      if (n > 0) S(max(bestCenter, 0), a0, a1, a2);
+      // centres are written through a switch-free path: k is uniform across the wave
+#pragma unroll
+      for (int kk = 1; kk < kK; ++kk)
+        if (kk == k) cx[kk] = a0, cy[kk] = a1, cz[kk] = a2;
+    }
+  }
+
+  // ---- the k-means loop (attempts = 1; epsilon = 10^2; at most 100 iterations).  Lanes finish after different
+  //      numbers of iterations: a finished lane (fin) keeps its labels and centres and runs zero-trip loops
+  bool fin = n == 0;
+  int iter = 0;
+  double max_center_shift = DBL_MAX;
+#pragma unroll 1
+  for (;;) {
+    if (iter > 0) {
+      const int nn = fin ? 0 : n;
+#pragma unroll
+      for (int k = 0; k < kK; ++k) s_sum[3 * k][lane] = s_sum[3 * k + 1][lane] = s_sum[3 * k + 2][lane] = 0.f, s_cnt[k][lane] = 0;
+      for (int i = 0; i < nn; ++i) {
+        float b0, b1, b2;
+        S(i, b0, b1, b2);
+        const int k = labels[il(group, (unsigned)i, lane)];
+        s_sum[3 * k][lane] += b0, s_sum[3 * k + 1][lane] += b1, s_sum[3 * k + 2][lane] += b2;
+        s_cnt[k][lane]++;
+      }
+      if (!fin) {
+        max_center_shift = 0;
+#pragma unroll 1
+        for (int k = 0; k < kK; ++k) {
+          if (s_cnt[k][lane] != 0) continue;
+          // an empty cluster takes the point farthest from the centre of the biggest cluster
+          int max_k = 0;
+          for (int k1 = 1; k1 < kK; ++k1)
+            if (s_cnt[max_k][lane] < s_cnt[k1][lane]) max_k = k1;
+          const float scale = 1.f / s_cnt[max_k][lane];
+          const float t0 = s_sum[3 * max_k][lane] * scale, t1 = s_sum[3 * max_k + 1][lane] * scale,
+                      t2 = s_sum[3 * max_k + 2][lane] * scale;
+          double max_dist = 0;
+          int farthest_i = -1;
+          for (int i = 0; i < n; ++i) {
+            if (labels[il(group, (unsigned)i, lane)] != max_k) continue;
+            float b0, b1, b2;
+            S(i, b0, b1, b2);
+            const double dist = dist3(b0, b1, b2, t0, t1, t2);
+            if (max_dist <= dist) max_dist = dist, farthest_i = i;
+          }
+          s_cnt[max_k][lane]--;
+          s_cnt[k][lane]++;
+          labels[il(group, (unsigned)farthest_i, lane)] = (unsigned char)k;
+          float b0, b1, b2;
+          S(farthest_i, b0, b1, b2);
+          s_sum[3 * max_k][lane] -= b0, s_sum[3 * max_k + 1][lane] -= b1, s_sum[3 * max_k + 2][lane] -= b2;
+          s_sum[3 * k][lane] += b0, s_sum[3 * k + 1][lane] += b1, s_sum[3 * k + 2][lane] += b2;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kK; ++k) {
+        const float scale = 1.f / s_cnt[k][lane];
+        const float n0 = s_sum[3 * k][lane] * scale, n1 = s_sum[3 * k + 1][lane] * scale, n2 = s_sum[3 * k + 2][lane] * scale;
+        double dist = 0, t = n0 - cx[k];
+        dist += t * t;
+        t = n1 - cy[k];
+        dist += t * t;
+        t = n2 - cz[k];
+        dist += t * t;
+        if (!fin) {
+          max_center_shift = fmax(max_center_shift, dist);
+          cx[k] = n0, cy[k] = n1, cz[k] = n2;
+        }
+      }
+    }
+    if (!fin) {
+      ++iter;
+      fin = iter == 100 || max_center_shift <= 100.0;  // ++iter == MAX(maxCount, 2) || shift <= epsilon^2
+    }
+    if (__all(fin)) break;
+    const int na = fin ? 0 : n;
+    // assign labels (KMeansDistanceComputer)
+    for (int i = 0; i < na; ++i) {
+      float b0, b1, b2;
+      S(i, b0, b1, b2);
+      int k_best = 0;
+      double min_dist = DBL_MAX;
+#pragma unroll
+      for (int k = 0; k < kK; ++k) {
+        const double dist = dist3(b0, b1, b2, cx[k], cy[k], cz[k]);
+        if (min_dist > dist) min_dist = dist, k_best = k;
+      }
+      labels[il(group, (unsigned)i, lane)] = (unsigned char)k_best;
+    }
+  }
+
+  // ---- colour frequencies (cvutil.cpp:903-989) and the descriptor (:1016-1060)
+  if (!valid) return;
+  const CdImage im = images[img_i];
+  unsigned long long key[kK];
+#pragma unroll
+  for (int k = 0; k < kK; ++k) {
+    auto clamp16 = [](int v) {
+      v &= -(v >= 0);
+      return v | ((65535 - v) >> 31);
+    };
+    const unsigned l = (unsigned)clamp16((int)(65535 / 100.0f * cx[k])) & 0xFFFFu;
+    const unsigned u = (unsigned)clamp16((int)(65535 / 354.0f * (cy[k] + 134.0f))) & 0xFFFFu;
+    const unsigned v = (unsigned)clamp16((int)(65535 / 262.0f * (cz[k] + 140.0f))) & 0xFFFFu;
+    key[k] = (unsigned long long)l << 32 | (unsigned long long)u << 16 | (unsigned long long)v;
+  }
+  // centres that compress to the same colour share one frequency (the reference's QHash is keyed by the colour)
+#pragma unroll
+  for (int k = 0; k < kK; ++k) {
+    int rep = k;
+#pragma unroll
+    for (int j = kK - 1; j >= 0; --j)
+      if (j < k && key[j] == key[k]) rep = j;
+    s_cnt[k][lane] = rep;
+    s_sum[k][lane] = 0.f;
+  }
+  float maxDistFromCenter;
+  {
+    const float dx = im.cols / 2.0f, dy = im.rows / 2.0f;
+    maxDistFromCenter = sqrtf(dx * dx + dy * dy);
+  }
+  unsigned present = 0;  // a colour exists in the reference's hash only if some sample carried it
+  for (int i = 0; i < N; ++i) {
+    const size_t o = il(group, (unsigned)i, lane);
+    const int rep = s_cnt[labels[o]][lane];
+    const unsigned pp = pos[o];
+    const int dx = (int)(pp & 0xFFFFu) - im.cols / 2, dy = (int)(pp >> 16) - im.rows / 2;
+    const float dist = sqrtf((float)(dx * dx + dy * dy));
+    s_sum[rep][lane] += (maxDistFromCenter - dist) / maxDistFromCenter;
+    present |= 1u << rep;
+  }
+  float maxFreq = 0;
+#pragma unroll
+  for (int k = 0; k < kK; ++k)
+    if (present >> k & 1u) maxFreq = fmaxf(maxFreq, s_sum[k][lane]);
+  unsigned char* __restrict__ out = descs + (size_t)img_i * 258;
+  for (int b = 0; b < 258; ++b) out[b] = 0;
+  unsigned left = present;
+  int di = 0;
+  while (left) {
+    int best = -1;
+#pragma unroll
+    for (int k = 0; k < kK; ++k) {
+      if (!(left >> k & 1u)) continue;
+      if (best < 0) {
+        best = k;
+        continue;
+      }
+      const float fk = s_sum[k][lane], fb = s_sum[best][lane];
+      if (fk > fb || (fk == fb && key[k] < key[best])) best = k;
+    }
+    left &= ~(1u << best);
+    const unsigned long long kk = key[best];
+    const unsigned short l = (unsigned short)((kk >> 32) & 0xFFFF), u = (unsigned short)((kk >> 16) & 0xFFFF),
+                         v = (unsigned short)(kk & 0xFFFF);
+    const unsigned short wv = (unsigned short)((int)(s_sum[best][lane] * 65535 / maxFreq) & 0xFFFF);
+    unsigned short* __restrict__ o16 = reinterpret_cast<unsigned short*>(out + di * 8);
+    o16[0] = l, o16[1] = u, o16[2] = v, o16[3] = wv;
+    out[256] = (unsigned char)di;  // desc.numColors = descIndex, the index of the last colour (cvutil.cpp:1035)
+    ++di;
+  }
+}
+
+}  // namespace
+
+int launch_color_descriptors(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const uint32_t* img_w,
+                             const uint32_t* img_h, const uint32_t* img_row_stride, int channels, uint8_t* d_descs,
+                             uint8_t* d_ok, hipStream_t s) {
+  std::vector<CdImage> images(n);
+  std::map<std::pair<int, int>, unsigned> mask_of;
+  std::vector<uint8_t> masks;
+  for (size_t i = 0; i < n; ++i) {
+    CdImage& im = images[i];
+    im.src_off = img_off[i];
+    im.src_stride = img_row_stride[i];
+    im.w = (int)img_w[i], im.h = (int)img_h[i];
+    resized_dims(im.w, im.h, &im.cols, &im.rows);
+    if (im.cols < 1 || im.rows < 1) return CBH_E_INVAL;  // sizeLongestSide throws
+    const auto keyv = std::make_pair(im.cols, im.rows);
+    auto it = mask_of.find(keyv);
+    if (it == mask_of.end()) {
+      const unsigned off = (unsigned)masks.size();
+      masks.resize(masks.size() + (size_t)im.cols * im.rows);
+      ellipse_mask(im.cols, im.rows, masks.data() + off);
+      it = mask_of.emplace(keyv, off).first;
+    }
+    im.mask_off = it->second;
+  }
+  const size_t groups = (n + 63) / 64;
+  const size_t per_group = (size_t)kMaxSamples * 64;
+  CdImage* d_images = nullptr;
+  uint8_t *d_masks = nullptr, *d_labels = nullptr;
+  CdTables* d_tabs = nullptr;
+  float *d_samples = nullptr, *d_dists = nullptr;
+  unsigned* d_pos = nullptr;
+  int* d_counts = nullptr;
+  hipError_t e = hipSuccess;
+  auto alloc = [&](void** p, size_t bytes) {
+    if (e == hipSuccess) e = hipMallocAsync(p, std::max<size_t>(bytes, 256), s);
+  };
+  alloc((void**)&d_images, n * sizeof(CdImage));
+  alloc((void**)&d_masks, masks.size());
+  alloc((void**)&d_tabs, sizeof(CdTables));
+  alloc((void**)&d_samples, groups * per_group * 3 * sizeof(float));
+  alloc((void**)&d_dists, groups * per_group * 3 * sizeof(float));
+  alloc((void**)&d_pos, groups * per_group * sizeof(unsigned));
+  alloc((void**)&d_labels, groups * per_group);
+  alloc((void**)&d_counts, n * sizeof(int));
+  int rc = CBH_OK;
+  if (e == hipSuccess) e = hipMemcpyAsync(d_images, images.data(), n * sizeof(CdImage), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_masks, masks.data(), masks.size(), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_tabs, &tables(), sizeof(CdTables), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_cd_prepare, dim3((unsigned)n), dim3(256), 0, s, d_images, d_imgs, channels, d_masks, d_tabs,
+                       d_samples, d_pos, d_counts);
+    hipLaunchKernelGGL(k_cd_cluster, dim3((unsigned)groups), dim3(64), 0, s, d_images, (unsigned)n, d_samples, d_pos,
+                       d_counts, d_dists, d_labels, d_descs, d_ok);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);  // the host tables above must outlive the copies
+  if (e != hipSuccess) {
+    set_last_error("color descriptors", e);
+    rc = e == hipErrorOutOfMemory ? CBH_E_NOMEM : CBH_E_HIP;
+  }
+  for (void* p : {(void*)d_images, (void*)d_masks, (void*)d_tabs, (void*)d_samples, (void*)d_dists, (void*)d_pos,
+                  (void*)d_labels, (void*)d_counts})
+    if (p) (void)hipFreeAsync(p, s);
+  return rc;
+}
+
+void color_ellipse_mask(int cols, int rows, uint8_t* mask) { ellipse_mask(cols, rows, mask); }
+
+}  // namespace cbh
+
+extern "C" {
+
+void cbh_color_descriptor_dims(int w, int h, int* cols, int* rows) { cbh::resized_dims(w, h, cols, rows); }
+
+int cbh_color_ellipse_mask(int cols, int rows, uint8_t* mask) {
+  if (cols < 1 || rows < 1 || cols > 8192 || rows > 8192 || !mask) return CBH_E_INVAL;
+  cbh::color_ellipse_mask(cols, rows, mask);
+  return CBH_OK;
+}
+
+int cbh_color_descriptors_dev(const void* d_imgs, size_t n, const uint64_t* img_off, const uint32_t* img_w,
+                              const uint32_t* img_h, const uint32_t* img_row_stride, int channels, void* d_descs,
+                              void* d_ok, int device, void* stream) {
+  if (!cbh::device_usable(device)) return CBH_E_NODEVICE;
+  if (n == 0) return CBH_OK;
+  if (!d_imgs || !img_off || !img_w || !img_h || !img_row_stride || !d_descs || !d_ok || (channels != 3 && channels != 4) ||
+      n > (1u << 24))
+    return CBH_E_INVAL;
+  for (size_t i = 0; i < n; ++i)
+    if (img_w[i] == 0 || img_h[i] == 0 || img_w[i] > 65535 || img_h[i] > 65535 ||
+        img_row_stride[i] < img_w[i] * (uint32_t)channels)
+      return CBH_E_INVAL;
+  cbh::DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  return cbh::launch_color_descriptors((const uint8_t*)d_imgs, n, img_off, img_w, img_h, img_row_stride, channels,
+                                       (uint8_t*)d_descs, (uint8_t*)d_ok, (hipStream_t)stream);
+}
+
+int cbh_color_descriptors(const uint8_t* imgs, size_t imgs_bytes, size_t n, const uint64_t* img_off, const uint32_t* img_w,
+                          const uint32_t* img_h, const uint32_t* img_row_stride, int channels, uint8_t* descs, uint8_t* ok,
+                          int device) {
+  if (!cbh::device_usable(device)) return CBH_E_NODEVICE;
+  if (n == 0) return CBH_OK;
+  if (!imgs || !descs || !ok || !img_off || !img_w || !img_h || !img_row_stride || (channels != 3 && channels != 4))
+    return CBH_E_INVAL;
+  for (size_t i = 0; i < n; ++i)
+    if (img_w[i] == 0 || img_h[i] == 0 ||
+        img_off[i] + (uint64_t)(img_h[i] - 1) * img_row_stride[i] + (uint64_t)img_w[i] * channels > imgs_bytes)
+      return CBH_E_INVAL;
+  cbh::DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  hipStream_t s = nullptr;
+  uint8_t *d_imgs = nullptr, *d_descs = nullptr, *d_ok = nullptr;
+  hipError_t e;
+  int rc = CBH_OK;
+  if ((e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipMalloc(&d_imgs, imgs_bytes)) != hipSuccess || (e = hipMalloc(&d_descs, n * 258)) != hipSuccess ||
+      (e = hipMalloc(&d_ok, n)) != hipSuccess ||
+      (e = hipMemcpyAsync(d_imgs, imgs, imgs_bytes, hipMemcpyHostToDevice, s)) != hipSuccess) {
+    cbh::set_last_error("color descriptors setup", e);
+    rc = e == hipErrorOutOfMemory ? CBH_E_NOMEM : CBH_E_HIP;
+  }
+  if (rc == CBH_OK)
+    rc = cbh_color_descriptors_dev(d_imgs, n, img_off, img_w, img_h, img_row_stride, channels, d_descs, d_ok, device, s);
+  if (rc == CBH_OK) {
+    if ((e = hipMemcpyAsync(descs, d_descs, n * 258, hipMemcpyDeviceToHost, s)) != hipSuccess ||
+        (e = hipMemcpyAsync(ok, d_ok, n, hipMemcpyDeviceToHost, s)) != hipSuccess ||
+        (e = hipStreamSynchronize(s)) != hipSuccess) {
+      cbh::set_last_error("color descriptors fetch", e);
+      rc = CBH_E_HIP;
+    }
+  }
+  if (s) (void)hipStreamSynchronize(s);
+  for (void* p : {(void*)d_imgs, (void*)d_descs, (void*)d_ok})
+    if (p) (void)hipFree(p);
+  if (s) (void)hipStreamDestroy(s);
+  return rc;
+}
+
+}  // extern "C"

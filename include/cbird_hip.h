@@ -153,6 +153,27 @@ int cbh_orb_dev(const void* d_imgs, size_t n, const uint64_t* img_off, const uin
                 const uint32_t* img_row_stride, int nfeatures, int kp_cap, void* d_kp, void* d_kp_after, void* d_desc,
                 void* d_counts, int device, void* stream);
 
+/* ---- ColorDescriptor::create (src/cvutil.cpp:790-1099) for a batch of 8-bit BGR (channels 3) or BGRA (4) images --
+ * sizeLongestSide(rgb, 256, INTER_NEAREST) when a side exceeds 256; the elliptic centre mask (cv::ellipse of 0.9 x the
+ * image, pix * alpha >> 8); float BGR -> Luv (cv::cvtColor's spline tables); samples with l > 4; cv::kmeans(K = 32,
+ * TermCriteria(ITER|EPS, 100, 10), 1 attempt, KMEANS_PP_CENTERS); per quantised centre colour the sum of
+ * (maxDist - dist) / maxDist over its pixels; colours by descending frequency; w = int(freq * 65535 / maxFreq);
+ * numColors = index of the last colour (as the reference writes it).  descs: n x 258 bytes (32 x {l, u, v, w : u16},
+ * numColors : u8, pad) -- the record ColorDescIndex stores; ok[i] = 0 where the reference returns without touching the
+ * descriptor ("not enough colors": fewer than 32 samples), the record is then all zero.
+ * Three things cannot match the cbird binary by its own construction (oracle/colordesc_oracle.c): kmeans draws from the
+ * worker thread's never-reseeded cv::theRNG() -- here every image starts from a fresh thread's state; equal frequencies
+ * are ordered by key; the rim of the ellipse is OpenCV's polygon fill as recalled.
+ * The _dev call returns when the descriptors are complete (it synchronises the stream). */
+void cbh_color_descriptor_dims(int w, int h, int* cols, int* rows);      /* the working size after the resize */
+int cbh_color_ellipse_mask(int cols, int rows, uint8_t* mask);           /* the mask itself (cols x rows bytes) */
+int cbh_color_descriptors(const uint8_t* imgs, size_t imgs_bytes, size_t n, const uint64_t* img_off, const uint32_t* img_w,
+                          const uint32_t* img_h, const uint32_t* img_row_stride, int channels, uint8_t* descs, uint8_t* ok,
+                          int device);
+int cbh_color_descriptors_dev(const void* d_imgs, size_t n, const uint64_t* img_off, const uint32_t* img_w,
+                              const uint32_t* img_h, const uint32_t* img_row_stride, int channels, void* d_descs,
+                              void* d_ok, int device, void* stream);
+
 /* ---- the steps in front of dctHash64 in Scanner::processImage (src/scanner.cpp:852-862) -------------------
  * grayscale(): cv::cvtColor(BGR2GRAY/BGRA2GRAY) on 8-bit data (src/cvutil.cpp:1265-1283); d_gray is packed
  * n*w*h bytes. */

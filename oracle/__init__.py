@@ -914,3 +914,62 @@ class OrbOracle:
         if n < 0:
             raise ValueError(f"orc_orb_compute rc={n}")
         return kps[:n].copy(), desc[:n].copy()
+
+
+class ColorCreateOracle:
+    """oracle/colordesc_oracle.c: ColorDescriptor::create (cvutil.cpp:790-1099), parity unpinned"""
+
+    def __init__(self) -> None:
+        build()
+        L = C.CDLL(_ORACLE_SO)
+        self.L = L
+        L.orc_cv_cbrt.restype = C.c_float
+        L.orc_cv_cbrt.argtypes = [C.c_float]
+        L.orc_cd_bgr2luv.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.orc_color_descriptor_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p,
+                                                  C.c_void_p]
+        L.orc_cd_kmeans.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+
+    def cbrt(self, x) -> float:
+        return float(self.L.orc_cv_cbrt(float(x)))
+
+    def resized_dims(self, w, h):
+        ow, oh = C.c_int(0), C.c_int(0)
+        self.L.orc_cd_resized_dims(int(w), int(h), C.byref(ow), C.byref(oh))
+        return ow.value, oh.value
+
+    def ellipse_mask(self, cols, rows):
+        m = np.zeros((rows, cols), np.uint8)
+        self.L.orc_cd_ellipse_mask(int(cols), int(rows), m.ctypes.data_as(C.c_void_p))
+        return m
+
+    def bgr2luv(self, b, g, r):
+        out = np.zeros(3, np.float32)
+        self.L.orc_cd_bgr2luv(float(b), float(g), float(r), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def tables(self):
+        g, c = np.zeros(4096, np.float32), np.zeros(4096, np.float32)
+        self.L.orc_cd_tables(g.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p))
+        return g, c
+
+    def kmeans(self, samples):
+        samples = np.ascontiguousarray(samples, np.float32).reshape(-1, 3)
+        labels = np.zeros(len(samples), np.int32)
+        centers = np.zeros((32, 3), np.float32)
+        it = self.L.orc_cd_kmeans(samples.ctypes.data_as(C.c_void_p), len(samples), labels.ctypes.data_as(C.c_void_p),
+                                  centers.ctypes.data_as(C.c_void_p))
+        return labels, centers, it
+
+    def create(self, img):
+        """img: uint8 [h, w, 3 or 4] (BGR / BGRA).  Returns (258-byte descriptor or None when the reference leaves
+        the descriptor untouched, stage = (cols, rows, samples, kmeans iterations))"""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w, ch = img.shape
+        desc = np.zeros(258, np.uint8)
+        stage = np.zeros(4, np.int32)
+        rc = self.L.orc_color_descriptor_create(img.ctypes.data_as(C.c_void_p), w, h, C.c_size_t(w * ch), ch,
+                                                desc.ctypes.data_as(C.c_void_p), stage.ctypes.data_as(C.c_void_p))
+        if rc < 0:
+            raise ValueError(f"orc_color_descriptor_create rc={rc}")
+        return (None if rc == 1 else desc), tuple(int(v) for v in stage)
