@@ -34,7 +34,6 @@ namespace cbh {
 namespace {
 
 constexpr int kK = 32;            // ColorDescriptor::NUM_DESC_COLORS
-constexpr int kMaxSamples = 65536;  // 256 x 256 after sizeLongestSide(rgb, 256)
 constexpr int kTab = 1024;
 
 struct CdImage {
@@ -281,8 +280,8 @@ __device__ __forceinline__ int wave_incl_scan_i(int v) {
 }
 
 // interleaved arrays of a group of 64 images: element i of image `lane`
-__device__ __forceinline__ size_t il(size_t group, unsigned i, unsigned lane) {
-  return (group * kMaxSamples + i) * 64 + lane;
+__device__ __forceinline__ size_t il_cap(size_t group, unsigned i, unsigned lane, unsigned cap) {
+  return (group * cap + i) * 64 + lane;
 }
 
 __global__ __launch_bounds__(256) void k_cd_prepare(const CdImage* __restrict__ images,
@@ -291,7 +290,8 @@ __global__ __launch_bounds__(256) void k_cd_prepare(const CdImage* __restrict__ 
                                                     const CdTables* __restrict__ tabs,
                                                     float* __restrict__ samples /* [group][i][lane][3] */,
                                                     unsigned* __restrict__ pos /* row << 16 | col */,
-                                                    int* __restrict__ counts) {
+                                                    int* __restrict__ counts, unsigned cap /* samples per image slot */) {
+  auto il = [cap](size_t group, unsigned i, unsigned lane) { return il_cap(group, i, lane, cap); };
   __shared__ float s_cbrt[kTab * 4];
   __shared__ float s_gamma[256];
   __shared__ int s_xofs[256], s_yofs[256];
@@ -393,10 +393,11 @@ __device__ __forceinline__ float dist3(float a0, float a1, float a2, float b0, f
 
 __global__ __launch_bounds__(64) void k_cd_cluster(const CdImage* __restrict__ images, unsigned n_images,
                                                    const float* __restrict__ samples, const unsigned* __restrict__ pos,
-                                                   const int* __restrict__ counts, float* __restrict__ dists /* 3 slots */,
+                                                   const int* __restrict__ counts, float* __restrict__ dists /* 4 slots */,
                                                    unsigned char* __restrict__ labels,
                                                    unsigned char* __restrict__ descs /* 258 per image */,
-                                                   unsigned char* __restrict__ ok) {
+                                                   unsigned char* __restrict__ ok, unsigned cap) {
+  auto il = [cap](size_t group, unsigned i, unsigned lane) { return il_cap(group, i, lane, cap); };
   __shared__ float s_sum[3 * kK][64];  // centre sums; later: colour frequencies
   __shared__ int s_cnt[kK][64];        // cluster sizes; later: representative centre of a colour key
   const unsigned lane = threadIdx.x;
@@ -407,12 +408,20 @@ __global__ __launch_bounds__(64) void k_cd_cluster(const CdImage* __restrict__ i
   const bool valid = N >= kK;  // "not enough colors": the reference returns without touching the descriptor
   if (live) ok[img_i] = valid ? 1 : 0;
   const int n = valid ? N : 0;
-  const size_t slot_stride = (size_t)gridDim.x * kMaxSamples * 64;
+  const size_t slot_stride = (size_t)gridDim.x * cap * 64;
   auto S = [&](int i, float& a, float& b, float& c) {
     const size_t o = 3 * il(group, (unsigned)i, lane);
     a = samples[o], b = samples[o + 1], c = samples[o + 2];
   };
   auto D = [&](int slot, int i) -> float& { return dists[(size_t)slot * slot_stride + il(group, (unsigned)i, lane)]; };
+  // The loops below run one lane per image, so nothing hides a load but the lane's own next loads: every loop takes its
+  // elements in blocks of kB whose loads are all issued before the first element is consumed (the compiler cannot do
+  // that itself -- the stores to the per-lane distance slots may alias the loads as far as it knows).
+  constexpr int kB = 8;
+  auto SB = [&](int i0, int cnt, float* b0, float* b1, float* b2) {  // samples i0 .. i0+kB-1, clamped to cnt-1
+#pragma unroll
+    for (int u = 0; u < kB; ++u) S(min(i0 + u, cnt - 1), b0[u], b1[u], b2[u]);
+  };
 
   float cx[kK], cy[kK], cz[kK];
 #pragma unroll
@@ -421,52 +430,83 @@ __global__ __launch_bounds__(64) void k_cd_cluster(const CdImage* __restrict__ i
 
   // ---- generateCentersPP(data, centers, K, rng, 3)
   {
-    int sd = 0, st = 1, st2 = 2;
+    int sd = 0;
     double sum0 = 0;
     int c0 = n > 0 ? (int)(rng.next() % (unsigned)n) : 0;
     float a0 = 0, a1 = 0, a2 = 0;
     if (n > 0) S(c0, a0, a1, a2);
     cx[0] = a0, cy[0] = a1, cz[0] = a2;
-    for (int i = 0; i < n; ++i) {
-      float b0, b1, b2;
-      S(i, b0, b1, b2);
-      const float d = dist3(b0, b1, b2, a0, a1, a2);
-      D(sd, i) = d;
-      sum0 += d;
+    for (int i0 = 0; i0 < n; i0 += kB) {
+      float b0[kB], b1[kB], b2[kB];
+      SB(i0, n, b0, b1, b2);
+#pragma unroll
+      for (int u = 0; u < kB; ++u)
+        if (i0 + u < n) {
+          const float d = dist3(b0[u], b1[u], b2[u], a0, a1, a2);
+          D(sd, i0 + u) = d;
+          sum0 += d;
+        }
     }
+    // One round = the reference's three trials.  Its `dist` array does not change inside a round and the generator is
+    // advanced by exactly two draws per trial whatever the trial finds, so the three trials share their passes: one
+    // walk over dist finds the three candidate centres (three running `p -= dist[i]`), one pass over the samples
+    // produces the three candidate distance arrays and their double sums -- each sum in index order, as the
+    // reference forms it; the first smallest sum wins (`s < bestSum` visits the trials in order).
+    int sc[3] = {1, 2, 3};  // slots of the three candidates; sd = slot of dist
 #pragma unroll 1
     for (int k = 1; k < kK; ++k) {
-      double bestSum = DBL_MAX;
-      int bestCenter = -1;
-      for (int j = 0; j < 3; ++j) {
-        double p = rng.real() * sum0, s = 0;
-        int i = 0;
-        for (; i < n - 1; ++i)
-          if ((p -= D(sd, i)) <= 0) break;
-        const int ci = i;
-        if (n > 0) S(ci, a0, a1, a2);
-        for (i = 0; i < n; ++i) {
-          float b0, b1, b2;
-          S(i, b0, b1, b2);
-          const float d = dist3(b0, b1, b2, a0, a1, a2);
-          const float old = D(sd, i);
-          const float t = old < d ? old : d;  // std::min(d, dist[i])
-          D(st2, i) = t;
-          s += t;
-        }
-        if (s < bestSum) {
-          bestSum = s;
-          bestCenter = ci;
-          const int t = st;
-          st = st2, st2 = t;
-        }
+      double p[3], sj[3] = {0, 0, 0};
+      int ci[3];
+      bool found[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) p[j] = rng.real() * sum0, ci[j] = max(n - 1, 0), found[j] = false;
+      // for (i = 0; i < N-1; i++) if ((p -= dist[i]) <= 0) break;  ci = i
+      for (int i0 = 0; i0 < n - 1 && !(found[0] && found[1] && found[2]); i0 += kB) {
+        float dv[kB];
+#pragma unroll
+        for (int u = 0; u < kB; ++u) dv[u] = D(sd, min(i0 + u, n - 1));
+#pragma unroll
+        for (int u = 0; u < kB; ++u)
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            if (!found[j] && i0 + u < n - 1 && (p[j] -= dv[u]) <= 0) found[j] = true, ci[j] = i0 + u;
       }
+      float c0[3], c1[3], c2[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        c0[j] = c1[j] = c2[j] = 0.f;
+        if (n > 0) S(ci[j], c0[j], c1[j], c2[j]);
+      }
+      for (int i0 = 0; i0 < n; i0 += kB) {
+        float b0[kB], b1[kB], b2[kB], old[kB];
+        SB(i0, n, b0, b1, b2);
+#pragma unroll
+        for (int u = 0; u < kB; ++u) old[u] = D(sd, min(i0 + u, n - 1));
+#pragma unroll
+        for (int u = 0; u < kB; ++u)
+          if (i0 + u < n) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              const float d = dist3(b0[u], b1[u], b2[u], c0[j], c1[j], c2[j]);
+              const float t = old[u] < d ? old[u] : d;  // std::min(d, dist[i])
+              D(sc[j], i0 + u) = t;
+              sj[j] += t;
+            }
+          }
+      }
+      double bestSum = DBL_MAX;
+      int best = 0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (sj[j] < bestSum) bestSum = sj[j], best = j;
       sum0 = bestSum;
       {
+        // std::swap(dist, tdist): the winning candidate becomes dist, the old dist array a candidate slot
         const int t = sd;
-        sd = st, st = t;
+        sd = sc[best];
+        sc[best] = t;
       }
-      if (n > 0) S(max(bestCenter, 0), a0, a1, a2);
+      a0 = c0[best], a1 = c1[best], a2 = c2[best];
       // centres are written through a switch-free path: k is uniform across the wave
 #pragma unroll
       for (int kk = 1; kk < kK; ++kk)
@@ -485,12 +525,19 @@ __global__ __launch_bounds__(64) void k_cd_cluster(const CdImage* __restrict__ i
       const int nn = fin ? 0 : n;
 #pragma unroll
       for (int k = 0; k < kK; ++k) s_sum[3 * k][lane] = s_sum[3 * k + 1][lane] = s_sum[3 * k + 2][lane] = 0.f, s_cnt[k][lane] = 0;
-      for (int i = 0; i < nn; ++i) {
-        float b0, b1, b2;
-        S(i, b0, b1, b2);
-        const int k = labels[il(group, (unsigned)i, lane)];
-        s_sum[3 * k][lane] += b0, s_sum[3 * k + 1][lane] += b1, s_sum[3 * k + 2][lane] += b2;
-        s_cnt[k][lane]++;
+      for (int i0 = 0; i0 < nn; i0 += kB) {
+        float b0[kB], b1[kB], b2[kB];
+        int lb[kB];
+        SB(i0, nn, b0, b1, b2);
+#pragma unroll
+        for (int u = 0; u < kB; ++u) lb[u] = labels[il(group, (unsigned)min(i0 + u, nn - 1), lane)];
+#pragma unroll
+        for (int u = 0; u < kB; ++u)
+          if (i0 + u < nn) {
+            const int k = lb[u];
+            s_sum[3 * k][lane] += b0[u], s_sum[3 * k + 1][lane] += b1[u], s_sum[3 * k + 2][lane] += b2[u];
+            s_cnt[k][lane]++;
+          }
       }
       if (!fin) {
         max_center_shift = 0;
@@ -545,17 +592,22 @@ __global__ __launch_bounds__(64) void k_cd_cluster(const CdImage* __restrict__ i
     if (__all(fin)) break;
     const int na = fin ? 0 : n;
     // assign labels (KMeansDistanceComputer)
-    for (int i = 0; i < na; ++i) {
-      float b0, b1, b2;
-      S(i, b0, b1, b2);
-      int k_best = 0;
-      double min_dist = DBL_MAX;
+    for (int i0 = 0; i0 < na; i0 += kB) {
+      float b0[kB], b1[kB], b2[kB];
+      SB(i0, na, b0, b1, b2);
 #pragma unroll
-      for (int k = 0; k < kK; ++k) {
-        const double dist = dist3(b0, b1, b2, cx[k], cy[k], cz[k]);
-        if (min_dist > dist) min_dist = dist, k_best = k;
-      }
-      labels[il(group, (unsigned)i, lane)] = (unsigned char)k_best;
+      for (int u = 0; u < kB; ++u)
+        if (i0 + u < na) {
+          int k_best = 0;
+          float min_dist = FLT_MAX;  // the reference compares in double; the distances are floats, so the order is the same
+          bool first = true;
+#pragma unroll
+          for (int k = 0; k < kK; ++k) {
+            const float dist = dist3(b0[u], b1[u], b2[u], cx[k], cy[k], cz[k]);
+            if (first || min_dist > dist) min_dist = dist, k_best = k, first = false;
+          }
+          labels[il(group, (unsigned)(i0 + u), lane)] = (unsigned char)k_best;
+        }
     }
   }
 
@@ -590,14 +642,23 @@ __global__ __launch_bounds__(64) void k_cd_cluster(const CdImage* __restrict__ i
     maxDistFromCenter = sqrtf(dx * dx + dy * dy);
   }
   unsigned present = 0;  // a colour exists in the reference's hash only if some sample carried it
-  for (int i = 0; i < N; ++i) {
-    const size_t o = il(group, (unsigned)i, lane);
-    const int rep = s_cnt[labels[o]][lane];
-    const unsigned pp = pos[o];
-    const int dx = (int)(pp & 0xFFFFu) - im.cols / 2, dy = (int)(pp >> 16) - im.rows / 2;
-    const float dist = sqrtf((float)(dx * dx + dy * dy));
-    s_sum[rep][lane] += (maxDistFromCenter - dist) / maxDistFromCenter;
-    present |= 1u << rep;
+  for (int i0 = 0; i0 < N; i0 += kB) {
+    int lb[kB];
+    unsigned pv[kB];
+#pragma unroll
+    for (int u = 0; u < kB; ++u) {
+      const size_t o = il(group, (unsigned)min(i0 + u, N - 1), lane);
+      lb[u] = labels[o], pv[u] = pos[o];
+    }
+#pragma unroll
+    for (int u = 0; u < kB; ++u)
+      if (i0 + u < N) {
+        const int rep = s_cnt[lb[u]][lane];
+        const int dx = (int)(pv[u] & 0xFFFFu) - im.cols / 2, dy = (int)(pv[u] >> 16) - im.rows / 2;
+        const float dist = sqrtf((float)(dx * dx + dy * dy));
+        s_sum[rep][lane] += (maxDistFromCenter - dist) / maxDistFromCenter;
+        present |= 1u << rep;
+      }
   }
   float maxFreq = 0;
 #pragma unroll
@@ -657,7 +718,9 @@ int launch_color_descriptors(const uint8_t* d_imgs, size_t n, const uint64_t* im
     im.mask_off = it->second;
   }
   const size_t groups = (n + 63) / 64;
-  const size_t per_group = (size_t)kMaxSamples * 64;
+  unsigned cap = 64;
+  for (const CdImage& im : images) cap = std::max(cap, (unsigned)(im.cols * im.rows));  // <= kMaxSamples
+  const size_t per_group = (size_t)cap * 64;
   CdImage* d_images = nullptr;
   uint8_t *d_masks = nullptr, *d_labels = nullptr;
   CdTables* d_tabs = nullptr;
@@ -672,7 +735,7 @@ int launch_color_descriptors(const uint8_t* d_imgs, size_t n, const uint64_t* im
   alloc((void**)&d_masks, masks.size());
   alloc((void**)&d_tabs, sizeof(CdTables));
   alloc((void**)&d_samples, groups * per_group * 3 * sizeof(float));
-  alloc((void**)&d_dists, groups * per_group * 3 * sizeof(float));
+  alloc((void**)&d_dists, groups * per_group * 4 * sizeof(float));
   alloc((void**)&d_pos, groups * per_group * sizeof(unsigned));
   alloc((void**)&d_labels, groups * per_group);
   alloc((void**)&d_counts, n * sizeof(int));
@@ -682,9 +745,9 @@ int launch_color_descriptors(const uint8_t* d_imgs, size_t n, const uint64_t* im
   if (e == hipSuccess) e = hipMemcpyAsync(d_tabs, &tables(), sizeof(CdTables), hipMemcpyHostToDevice, s);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_cd_prepare, dim3((unsigned)n), dim3(256), 0, s, d_images, d_imgs, channels, d_masks, d_tabs,
-                       d_samples, d_pos, d_counts);
+                       d_samples, d_pos, d_counts, cap);
     hipLaunchKernelGGL(k_cd_cluster, dim3((unsigned)groups), dim3(64), 0, s, d_images, (unsigned)n, d_samples, d_pos,
-                       d_counts, d_dists, d_labels, d_descs, d_ok);
+                       d_counts, d_dists, d_labels, d_descs, d_ok, cap);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(s);  // the host tables above must outlive the copies
