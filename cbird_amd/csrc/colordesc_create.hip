@@ -612,7 +612,11 @@ __global__ __launch_bounds__(64) void k_cd_cluster(const CdImage* __restrict__ i
   }
 
   // ---- colour frequencies (cvutil.cpp:903-989) and the descriptor (:1016-1060)
-  if (!valid) return;
+  if (!valid) {
+    if (live)  // "not enough colors": the reference leaves the caller's (cleared) descriptor alone
+      for (int b = 0; b < 258; ++b) descs[(size_t)img_i * 258 + b] = 0;
+    return;
+  }
   const CdImage im = images[img_i];
   unsigned long long key[kK];
 #pragma unroll
