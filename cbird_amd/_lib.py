@@ -68,6 +68,8 @@ _SIGS = {
     "cbh_color_ellipse_mask": (C.c_int, [C.c_int, C.c_int, _vp]),
     "cbh_color_descriptors": (C.c_int, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int]),
     "cbh_color_descriptors_dev": (C.c_int, [_vp, _sz, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
+    "cbh_index_images": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                   _vp, _vp, _vp, C.c_int]),
     "cbh_orb_set_pattern": (C.c_int, [_vp]),
     "cbh_orb": (C.c_int, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
     "cbh_orb_describe": (C.c_int, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),

@@ -1,0 +1,85 @@
+"""Scanner::processImage for a batch (/root/reference/src/scanner.cpp:828-895) over cbh_index_images: every feature
+stage of an image chained on the device from one upload.  Field names follow IndexParams (src/scanner.h:60-75) and
+the Media setters processImage calls."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+from .colordesc import COLOR_DTYPE
+from .orb import KP_DTYPE
+
+AlgoDCT, AlgoDCTFeatures, AlgoCVFeatures, AlgoColor = 0, 1, 2, 3  # SearchParams::Algo* (src/index.h:41-47)
+
+
+@dataclass
+class IndexParams:
+    algos: int = (1 << AlgoDCT) | (1 << AlgoDCTFeatures) | (1 << AlgoCVFeatures) | (1 << AlgoColor)
+    autocrop: bool = True
+    numFeatures: int = 400
+    resizeLongestSide: int = 400
+
+
+class _Params(C.Structure):
+    _fields_ = [("autocrop_range", C.c_int), ("algos", C.c_int), ("resize_longest_side", C.c_int),
+                ("num_features", C.c_int), ("kp_cap", C.c_int)]
+
+
+@dataclass
+class IndexResult:
+    dctHash: int = 0
+    cropRect: tuple = ()           # region autocrop kept: (left, top, right, bottom)
+    resizedDims: tuple = (0, 0)    # size of the image the features were taken from
+    keyPoints: np.ndarray = field(default_factory=lambda: np.zeros(0, KP_DTYPE))
+    keyPointDescriptors: np.ndarray = field(default_factory=lambda: np.zeros((0, 32), np.uint8))
+    keyPointHashes: np.ndarray = field(default_factory=lambda: np.zeros(0, np.uint64))
+    colorDescriptor: np.ndarray | None = None
+
+
+def process_images(imgs: np.ndarray, params: IndexParams | None = None, device: int = 0) -> list[IndexResult]:
+    """imgs: uint8 [n, h, w] (grey) or [n, h, w, 3 | 4] (BGR / BGRA), one geometry.  One IndexResult per image."""
+    p = params or IndexParams()
+    imgs = np.asarray(imgs)
+    if imgs.dtype != np.uint8 or imgs.ndim not in (3, 4):
+        raise ValueError("expected uint8 [n, h, w] or [n, h, w, c]")
+    imgs = np.ascontiguousarray(imgs)
+    n, h, w = imgs.shape[:3]
+    ch = 1 if imgs.ndim == 3 else imgs.shape[3]
+    if n == 0:
+        return []
+    cap = p.numFeatures + 64
+    L = _lib.lib()
+    while True:
+        cp = _Params(20 if (p.algos and p.autocrop) else -1, p.algos, p.resizeLongestSide, p.numFeatures, cap)
+        hashes = np.zeros(n, np.uint64)
+        rects = np.zeros((n, 4), np.int32)
+        dims = np.zeros((n, 2), np.int32)
+        kpc = np.zeros(n, np.uint32)
+        kp = np.zeros((n, cap), KP_DTYPE)
+        desc = np.zeros((n, cap, 32), np.uint8)
+        khc = np.zeros(n, np.uint32)
+        kh = np.zeros((n, cap), np.uint64)
+        cd = np.zeros(n, COLOR_DTYPE)
+        cok = np.zeros(n, np.uint8)
+        check(L.cbh_index_images(imgs.ctypes.data, n, w, h, w * ch, w * h * ch, ch, C.byref(cp), hashes.ctypes.data,
+                                 rects.ctypes.data, dims.ctypes.data, kpc.ctypes.data, kp.ctypes.data, desc.ctypes.data,
+                                 khc.ctypes.data, kh.ctypes.data, cd.ctypes.data, cok.ctypes.data, device), "index_images")
+        if int(kpc.max()) <= cap:
+            break
+        cap = int(kpc.max())
+    out = []
+    for i in range(n):
+        c = int(kpc[i])
+        r = IndexResult(dctHash=int(hashes[i]), cropRect=tuple(int(v) for v in rects[i]),
+                        resizedDims=(int(dims[i, 0]), int(dims[i, 1])), keyPoints=kp[i, :c].copy(),
+                        keyPointHashes=kh[i, : int(khc[i])].copy())
+        if p.algos & (1 << AlgoCVFeatures):
+            r.keyPointDescriptors = desc[i, :c].copy()
+        if (p.algos & (1 << AlgoColor)) and cok[i]:
+            r.colorDescriptor = cd[i].copy()
+        out.append(r)
+    return out

@@ -197,6 +197,28 @@ int cbh_process_images_ex(const uint8_t* imgs, size_t n, int w, int h, size_t ro
                           int channels, int autocrop_range, uint64_t* out, int32_t* rects, int resize_size,
                           uint8_t* resized, int32_t* resized_dims, int device);
 
+/* ---- Scanner::processImage for a batch (src/scanner.cpp:828-895): every feature stage of one image, chained on the
+ * device from ONE upload: grayscale -> autocrop -> dctHash64 of the kept region; ColorDescriptor::create of the colour
+ * image; sizeLongestSide(kept region, resize_longest_side); makeKeyPoints; makeKeyPointDescriptors; makeKeyPointHashes
+ * on the keypoints as compute() left them.  n decoded images of one geometry in host memory (channels 1 / 3 / 4).
+ * algos = IndexParams::algos, bit (1 << SearchParams::Algo*): 1 dct, 2 dct features (keypoint hashes), 4 cv features
+ * (ORB descriptors; needs cbh_orb_set_pattern), 8 colour.  Outputs of stages that are switched off may be NULL.
+ *   dct_hashes[n], rects[4n] (kept region: left, top, right, bottom), resized_dims[2n] (0 x 0: the reference throws,
+ *   no features); kp_counts[n] (found; at most kp_cap are written), kp[n * kp_cap] (the keypoint list as processImage
+ *   holds it at the end), desc[n * kp_cap * 32]; kph_counts[n], kp_hashes[n * kp_cap]; color_descs[n * 258],
+ *   color_ok[n]. */
+typedef struct cbh_index_params {
+  int autocrop_range;       /* cbird: 20; < 0: no autocrop (IndexParams::autocrop = false) */
+  int algos;                /* IndexParams::algos */
+  int resize_longest_side;  /* IndexParams::resizeLongestSide = 400 */
+  int num_features;         /* IndexParams::numFeatures = 400 */
+  int kp_cap;               /* room per image in kp / desc / kp_hashes */
+} cbh_index_params;
+int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, size_t row_stride, size_t img_stride, int channels,
+                     const cbh_index_params* p, uint64_t* dct_hashes, int32_t* rects, int32_t* resized_dims,
+                     uint32_t* kp_counts, cbh_keypoint* kp, uint8_t* desc, uint32_t* kph_counts, uint64_t* kp_hashes,
+                     uint8_t* color_descs, uint8_t* color_ok, int device);
+
 /* sizeLongestSide(cv::Mat& img, int size, int filter = INTER_LANCZOS4) -- src/cvutil.cpp:1932-1950, the resize in
  * front of ORB detection (src/scanner.cpp:876, size = IndexParams::resizeLongestSide = 400): target size from the
  * float aspect ratio (cbh_longest_side_dims; a zero side is the reference's std::invalid_argument -> CBH_E_INVAL),

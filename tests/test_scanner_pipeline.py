@@ -1,0 +1,82 @@
+"""Scanner::processImage for a batch (cbh_index_images, /root/reference/src/scanner.cpp:828-895): the chained device
+pipeline equals the stages of the oracle applied one after the other in the reference's order."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _images(rng, n, w, h, border):
+    imgs = np.zeros((n, h, w, 3), np.uint8)
+    for i in range(n):
+        img = np.full((h, w, 3), 120, np.int32)
+        for _ in range(60):
+            x, y = int(rng.integers(0, w - 8)), int(rng.integers(0, h - 8))
+            img[y: y + int(rng.integers(6, h // 3)), x: x + int(rng.integers(6, w // 3))] = rng.integers(0, 256, 3)
+        img = (img + rng.integers(-4, 5, img.shape)).clip(0, 255)
+        if border and i % 2 == 0:   # letterbox: autocrop removes it, every later stage works on the kept region
+            img[: 20 + i] = 0
+            img[h - 25:] = 0
+        imgs[i] = img
+    return imgs
+
+
+@pytest.mark.parametrize("w,h,border", [(480, 360, True), (300, 420, False)])
+def test_pipeline_equals_the_stages_in_order(gpu, orc, w, h, border):
+    from cbird_amd import orb as gorb
+    from cbird_amd.scanner import IndexParams, process_images
+    from oracle import ColorCreateOracle, OrbOracle, PrestageOracle
+
+    rng = np.random.default_rng(w)
+    imgs = _images(rng, 5, w, h, border)
+    pat = gorb.synthetic_pattern(2)
+    gorb.set_pattern(pat)
+    oo, co, po = OrbOracle(), ColorCreateOracle(), PrestageOracle()
+    oo.set_pattern(pat)
+    res = process_images(imgs, IndexParams())
+    ncrop = 0
+    for img, r in zip(imgs, res):
+        gray = po.bgr2gray(img)
+        hsh, rect = po.process_image(img, 20)
+        assert r.dctHash == hsh and r.cropRect == tuple(int(v) for v in rect)
+        ncrop += r.cropRect != (0, 0, w, h)
+        kept = np.ascontiguousarray(gray[rect[1]: rect[3], rect[0]: rect[2]])
+        small = orc.size_longest_side(kept, 400)
+        assert r.resizedDims == (small.shape[1], small.shape[0])
+        kp = oo.detect(small, 400)
+        kp2, desc = oo.compute(small, kp)
+        assert len(kp2) > 100 and (r.keyPoints == kp2).all() and (r.keyPointDescriptors == desc).all()
+        tri = np.stack([kp2["x"], kp2["y"], kp2["size"]], 1)
+        want_h, _ = orc.keypoint_hashes(small, tri)
+        assert len(want_h) > 10 and (r.keyPointHashes == want_h).all()
+        want_c, _ = co.create(img)
+        assert (np.frombuffer(r.colorDescriptor.tobytes(), np.uint8) == want_c).all()
+    assert ncrop > 0 or not border
+    # fdct alone: the hashes start from the keypoints as DETECTED (no descriptor pass rewrote them)
+    only = process_images(imgs[:2], IndexParams(algos=1 << 1))
+    for img, r in zip(imgs[:2], only):
+        gray = po.bgr2gray(img)
+        _, rect = po.process_image(img, 20)
+        small = orc.size_longest_side(np.ascontiguousarray(gray[rect[1]: rect[3], rect[0]: rect[2]]), 400)
+        kp = oo.detect(small, 400)
+        assert (r.keyPoints == kp).all() and r.dctHash == 0 and r.colorDescriptor is None
+        want_h, _ = orc.keypoint_hashes(small, np.stack([kp["x"], kp["y"], kp["size"]], 1))
+        assert (r.keyPointHashes == want_h).all() and len(r.keyPointDescriptors) == 0
+
+
+def test_pipeline_grey_input_and_arguments(gpu, orc):
+    from cbird_amd import _lib
+    from cbird_amd.scanner import IndexParams, process_images
+
+    rng = np.random.default_rng(5)
+    grey = rng.integers(0, 256, (3, 200, 260), dtype=np.uint8)
+    res = process_images(grey, IndexParams(algos=(1 << 0) | (1 << 3), autocrop=False))
+    for img, r in zip(grey, res):
+        assert r.dctHash == orc.dcthash64(img) and r.colorDescriptor is None   # "passed a grayscale image"
+        assert r.cropRect == (0, 0, 260, 200) and len(r.keyPoints) == 0
+    assert process_images(np.zeros((0, 10, 10), np.uint8)) == []
+    with pytest.raises(ValueError):
+        process_images(np.zeros((2, 10), np.uint8))
+    L = _lib.lib()
+    assert L.cbh_index_images(None, 1, 4, 4, 4, 16, 1, None, None, None, None, None, None, None, None, None, None, None,
+                              0) == _lib.CBH_E_INVAL
