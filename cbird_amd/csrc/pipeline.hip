@@ -10,6 +10,7 @@
 //   makeKeyPointHashes on the keypoints compute() left        dcthash.hip (k_kp_hashes)          (:886-889)
 #include <algorithm>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "cbh_index.h"
@@ -32,7 +33,7 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
   cbh::DeviceGuard g(device);
   if (!g.ok) return CBH_E_NODEVICE;
   const size_t span1 = (size_t)(h - 1) * row_stride + (size_t)w * channels;
-  size_t per_chunk = std::max<size_t>(1, ((size_t)512 << 20) / std::max(img_stride, span1));
+  size_t per_chunk = std::max<size_t>(1, ((size_t)2048 << 20) / std::max(img_stride, span1));
   per_chunk = std::min<size_t>(std::min(per_chunk, n), 16384);
   const size_t slot = feats ? (size_t)rs * rs + 16 : 0;  // room per image in the packed resize buffer
   uint8_t *d_src = nullptr, *d_gray = nullptr, *d_res = nullptr, *d_desc = nullptr, *d_cdesc = nullptr, *d_cok = nullptr;
@@ -41,10 +42,15 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
   cbh_keypoint* d_kp = nullptr;
   float* d_after = nullptr;
   uint32_t* d_cnt = nullptr;
-  hipStream_t s = nullptr;
-  int rc = CBH_OK;
+  hipStream_t s = nullptr, s2 = nullptr;
+  hipEvent_t ev_up = nullptr;
+  int rc = CBH_OK, color_rc = CBH_OK;
+  std::thread color_thread;
   auto cleanup = [&]() {
+    if (color_thread.joinable()) color_thread.join();
     if (s) (void)hipStreamSynchronize(s), (void)hipStreamDestroy(s);
+    if (s2) (void)hipStreamSynchronize(s2), (void)hipStreamDestroy(s2);
+    if (ev_up) (void)hipEventDestroy(ev_up);
     for (void* q : {(void*)d_src, (void*)d_gray, (void*)d_res, (void*)d_desc, (void*)d_cdesc, (void*)d_cok, (void*)d_out,
                     (void*)d_kph, (void*)d_rects, (void*)d_kp, (void*)d_after, (void*)d_cnt})
       if (q) (void)hipFree(q);
@@ -59,6 +65,8 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
     }                                                             \
   } while (0)
   CBH_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  CBH_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+  CBH_TRY(hipEventCreateWithFlags(&ev_up, hipEventDisableTiming));
   CBH_TRY(hipMalloc(&d_src, (per_chunk - 1) * img_stride + span1));
   if (channels != 1) CBH_TRY(hipMalloc(&d_gray, per_chunk * (size_t)w * h));
   CBH_TRY(hipMalloc(&d_out, per_chunk * sizeof(uint64_t)));
@@ -95,17 +103,33 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
     }
     // the colour descriptor is made from the ORIGINAL colour image (scanner.cpp:868-872); grey input: "passed a
     // grayscale image", the descriptor stays empty
+    // It runs on its own stream from a helper thread: the clustering kernel is one lane per image (a few dozen waves
+    // with long sequential chains), so it occupies a sliver of the chip for a long time -- the other stages, with
+    // their host synchronisations, run beside it.
+    color_rc = CBH_OK;
     if (a_color) {
       if (channels == 1) {
         memset(color_descs + i0 * 258, 0, m * 258);
         memset(color_ok + i0, 0, m);
       } else {
+        CBH_TRY(hipEventRecord(ev_up, s));
         for (size_t i = 0; i < m; ++i) coff[i] = i * img_stride;
-        rc = cbh_color_descriptors_dev(d_src, m, coff.data(), cw.data(), chh.data(), cst.data(), channels, d_cdesc, d_cok,
-                                       device, s);
-        if (rc) break;
-        CBH_TRY(hipMemcpyAsync(color_descs + i0 * 258, d_cdesc, m * 258, hipMemcpyDeviceToHost, s));
-        CBH_TRY(hipMemcpyAsync(color_ok + i0, d_cok, m, hipMemcpyDeviceToHost, s));
+        color_thread = std::thread([&, m, i0] {
+          cbh::DeviceGuard tg(device);
+          hipError_t e = hipStreamWaitEvent(s2, ev_up, 0);
+          if (e == hipSuccess)
+            color_rc = cbh_color_descriptors_dev(d_src, m, coff.data(), cw.data(), chh.data(), cst.data(), channels, d_cdesc,
+                                                 d_cok, device, s2);
+          if (e == hipSuccess && color_rc == CBH_OK &&
+              ((e = hipMemcpyAsync(color_descs + i0 * 258, d_cdesc, m * 258, hipMemcpyDeviceToHost, s2)) != hipSuccess ||
+               (e = hipMemcpyAsync(color_ok + i0, d_cok, m, hipMemcpyDeviceToHost, s2)) != hipSuccess ||
+               (e = hipStreamSynchronize(s2)) != hipSuccess))
+            ;
+          if (e != hipSuccess) {
+            cbh::set_last_error("index_images colour leg", e);
+            color_rc = CBH_E_HIP;
+          }
+        });
       }
     }
     bool cropped = false;
@@ -137,6 +161,8 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
     }
     if (!feats) {
       CBH_TRY(hipStreamSynchronize(s));
+      if (color_thread.joinable()) color_thread.join();
+      rc = color_rc;
       continue;
     }
     // sizeLongestSide(cvGray, 400) of each kept region, one launch per run of equal regions; the resized images are
@@ -212,6 +238,8 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
         memcpy(kp_hashes + (i0 + i) * cap, hh.data() + out_first[i], (size_t)c * sizeof(uint64_t));
       }
     }
+    if (color_thread.joinable()) color_thread.join();
+    if (rc == CBH_OK) rc = color_rc;
   }
 #undef CBH_TRY
   cleanup();

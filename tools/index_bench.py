@@ -1,0 +1,82 @@
+"""Scanner::processImage throughput through cbh_index_images (host buffers in, host results out: PCIe inclusive):
+n decoded BGR images of one geometry, all four feature algorithms.  Prints images/s, and the oracle's per-stage
+single-core times on a sample beside it.
+
+    python tools/index_bench.py [--images 2048] [--w 640 --h 480] [--algos 15]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=2048)
+    ap.add_argument("--w", type=int, default=640)
+    ap.add_argument("--h", type=int, default=480)
+    ap.add_argument("--algos", type=int, default=15)
+    ap.add_argument("--cpu-images", type=int, default=4)
+    args = ap.parse_args()
+    from cbird_amd import orb as gorb
+    from cbird_amd.scanner import IndexParams, process_images
+
+    rng = np.random.default_rng(1)
+    n, w, h = args.images, args.w, args.h
+    base = np.zeros((16, h, w, 3), np.uint8)
+    for b in base:
+        img = np.full((h, w, 3), 120, np.int32)
+        for _ in range(80):
+            x, y = int(rng.integers(0, w - 8)), int(rng.integers(0, h - 8))
+            img[y: y + int(rng.integers(6, h // 3)), x: x + int(rng.integers(6, w // 3))] = rng.integers(0, 256, 3)
+        b[:] = (img + rng.integers(-4, 5, img.shape)).clip(0, 255)
+    imgs = np.concatenate([base] * ((n + 15) // 16))[:n].copy()
+    pat = gorb.synthetic_pattern()
+    gorb.set_pattern(pat)
+    p = IndexParams(algos=args.algos)
+    process_images(imgs[:64], p)  # warm-up: module load, pools
+    t0 = time.time()
+    res = process_images(imgs, p)
+    dt = time.time() - t0
+    out = {"workload": f"{n} BGR images {w}x{h}, algos {args.algos:#x}, host in / host out", "s": dt,
+           "images_per_s": n / dt, "keypoints_per_image": float(np.mean([len(r.keyPoints) for r in res])),
+           "keypoint_hashes_per_image": float(np.mean([len(r.keyPointHashes) for r in res]))}
+    from oracle import ColorCreateOracle, Oracle, OrbOracle, PrestageOracle
+
+    oo, co, po, orc = OrbOracle(), ColorCreateOracle(), PrestageOracle(), Oracle()
+    oo.set_pattern(pat)
+    m = min(args.cpu_images, n)
+    t = {"gray_autocrop_hash": 0.0, "resize": 0.0, "orb": 0.0, "kp_hashes": 0.0, "color": 0.0}
+    ok = True
+    for i in range(m):
+        a = time.time()
+        gray = po.bgr2gray(imgs[i])
+        hsh, rect = po.process_image(imgs[i], 20)
+        b = time.time()
+        small = orc.size_longest_side(np.ascontiguousarray(gray[rect[1]: rect[3], rect[0]: rect[2]]), 400)
+        c = time.time()
+        kp2, desc = oo.compute(small, oo.detect(small, 400))
+        d = time.time()
+        kh, _ = orc.keypoint_hashes(small, np.stack([kp2["x"], kp2["y"], kp2["size"]], 1))
+        e = time.time()
+        cd, _ = co.create(imgs[i])
+        f = time.time()
+        for k, v in zip(t, (b - a, c - b, d - c, e - d, f - e)):
+            t[k] += v / m
+        r = res[i]
+        if args.algos == 15:
+            ok &= r.dctHash == hsh and (r.keyPoints == kp2).all() and (r.keyPointDescriptors == desc).all()
+            ok &= (r.keyPointHashes == kh).all() and (np.frombuffer(r.colorDescriptor.tobytes(), np.uint8) == cd).all()
+    out["cpu_oracle_ms_per_image_1core"] = {k: round(v * 1e3, 2) for k, v in t.items()}
+    out["cpu_oracle_images_per_s_1core"] = 1.0 / sum(t.values())
+    out["sample_bit_exact"] = bool(ok)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
