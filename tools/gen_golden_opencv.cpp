@@ -3,7 +3,7 @@
 // nobody has run this yet -- the day someone does, tests/test_opencv_golden.py turns "parity unpinned" into a pin (or
 // into a list of the stages to correct in oracle/cbird_oracle.c, oracle/cv_dct32.c and dcthash.hip).
 //
-//   g++ -O2 -std=c++11 tools/gen_golden_opencv.cpp -o gen_golden_opencv `pkg-config --cflags --libs opencv`
+//   g++ -O2 -std=c++11 tools/gen_golden_opencv.cpp -o gen_golden_opencv `pkg-config --cflags --libs opencv`   (core, imgproc, features2d)
 //   ./gen_golden_opencv > opencv_hash.txt
 //   python tools/opencv_golden_to_npz.py opencv_hash.txt tests/golden/opencv_hash.npz
 //
@@ -24,6 +24,19 @@
 //   G <w> <h> <seed> <w*h gray bytes hex>                 (input: channels from seeds seed, seed+1, seed+2 as B, G, R)
 //   L <w> <h> <seed> <size> <ow> <oh> <ow*oh bytes hex>
 //   R <w> <h> <seed> <n> {<x> <y> <side> <hash:016x>}*n <sum of the image's bytes after the in-place blurs>
+// ORB (src/media.cpp:859-872) and the library pieces under ColorDescriptor::create (src/cvutil.cpp:790-1099), stage by
+// stage so that each recalled piece of oracle/orb_oracle.c / oracle/colordesc_oracle.c gets its own pin:
+//   P <w> <h> <seed> <dw> <dh> <dw*dh bytes hex>          cv::resize(INTER_LINEAR): one pyramid step
+//   B <w> <h> <seed> <w*h bytes hex>                      GaussianBlur(7x7, 2, 2, BORDER_REFLECT_101)
+//   F <w> <h> <seed> <n> {<x> <y> <score>}*n              cv::FAST(img, 20, true)
+//   O <w> <h> <seed> <nfeat> <n> {<x:08x> <y:08x> <size:08x> <angle:08x> <response:08x> <octave>}*n <32n bytes hex>
+//                                                         detect() then compute(), keypoints as compute() leaves them
+//   A <count> {<y:08x> <x:08x> <fastAtan2:08x>}*count
+//   M <cols> <rows> <cols*rows bytes hex>                 cv::ellipse(mask, RotatedRect(0.5, 0.9), 255, CV_FILLED)
+//   U <n> {<b> <g> <r> <L:08x> <u:08x> <v:08x>}*n         convertTo(CV_32F) * (1/255) -> cvtColor(CV_BGR2Luv)
+//   K <N> <iterations-unknown:0> <N labels> <96 centre bit patterns :08x>
+//                                                         cv::kmeans(N x 3 samples, 32, (ITER|EPS, 100, 10), 1, PP) with
+//                                                         theRNG().state = 0xffffffff; samples = Luv of gen_image planes
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -95,6 +108,7 @@ int main() {
 #else
 #include <opencv2/core/core.hpp>
 #include <opencv2/core/version.hpp>
+#include <opencv2/features2d/features2d.hpp>
 #include <opencv2/imgproc/imgproc.hpp>
 
 static const char kZigZag[81] = {0,  9,  1,  2,  10, 18, 27, 19, 11, 3,  4,  12, 20, 28, 36, 45, 37, 29, 21, 13, 5,
@@ -208,6 +222,116 @@ int main() {
     uint64_t sum = 0;
     for (size_t i = 0; i < img.size(); ++i) sum += img[i];
     std::printf(" %llu\n", (unsigned long long)sum);
+  }
+  {  // ---- ORB, stage by stage -------------------------------------------------------------------------------
+    const int w = 400, h = 300;
+    const uint32_t seed = 900;
+    std::vector<uint8_t> img = gen_image(w, h, seed);
+    cv::Mat gray(h, w, CV_8UC1, img.data());
+    {
+      cv::Mat lvl;
+      cv::resize(gray, lvl, cv::Size(333, 250), 0, 0, cv::INTER_LINEAR);
+      std::printf("P %d %d %u %d %d ", w, h, seed, lvl.cols, lvl.rows);
+      for (int y = 0; y < lvl.rows; ++y) put_hex(lvl.ptr(y), (size_t)lvl.cols);
+      std::printf("\n");
+    }
+    {
+      cv::Mat bl;
+      cv::GaussianBlur(gray, bl, cv::Size(7, 7), 2, 2, cv::BORDER_REFLECT_101);
+      std::printf("B %d %d %u ", w, h, seed);
+      for (int y = 0; y < h; ++y) put_hex(bl.ptr(y), (size_t)w);
+      std::printf("\n");
+    }
+    {
+      std::vector<cv::KeyPoint> kps;
+      cv::FAST(gray, kps, 20, true);
+      std::printf("F %d %d %u %d", w, h, seed, (int)kps.size());
+      for (size_t i = 0; i < kps.size(); ++i) std::printf(" %d %d %d", (int)kps[i].pt.x, (int)kps[i].pt.y, (int)kps[i].response);
+      std::printf("\n");
+    }
+    {
+      std::vector<cv::KeyPoint> kps;
+      cv::OrbFeatureDetector detector(400, 1.2f, 12, 31, 0, 2, cv::OrbFeatureDetector::HARRIS_SCORE, 31);
+      detector.detect(gray, kps);
+      cv::Mat desc;
+      cv::OrbDescriptorExtractor extractor;
+      extractor.compute(gray, kps, desc);
+      std::printf("O %d %d %u %d %d", w, h, seed, 400, (int)kps.size());
+      for (size_t i = 0; i < kps.size(); ++i) {
+        uint32_t b[5];
+        std::memcpy(b, &kps[i].pt.x, 4), std::memcpy(b + 1, &kps[i].pt.y, 4), std::memcpy(b + 2, &kps[i].size, 4);
+        std::memcpy(b + 3, &kps[i].angle, 4), std::memcpy(b + 4, &kps[i].response, 4);
+        std::printf(" %08x %08x %08x %08x %08x %d", b[0], b[1], b[2], b[3], b[4], kps[i].octave);
+      }
+      std::printf(" ");
+      for (int r = 0; r < desc.rows; ++r) put_hex(desc.ptr(r), 32);
+      std::printf("\n");
+    }
+    {
+      const float ys[] = {0.f, 1.f, 1.f, -3.f, 250.5f, -1e-3f, 7.f, -1234.f}, xs[] = {1.f, 1.f, -1.f, 0.f, -17.25f, 5.f, -7.f, -4321.f};
+      std::printf("A %d", 8);
+      for (int i = 0; i < 8; ++i) {
+        const float a = cv::fastAtan2(ys[i], xs[i]);
+        uint32_t b[3];
+        std::memcpy(b, &ys[i], 4), std::memcpy(b + 1, &xs[i], 4), std::memcpy(b + 2, &a, 4);
+        std::printf(" %08x %08x %08x", b[0], b[1], b[2]);
+      }
+      std::printf("\n");
+    }
+  }
+  {  // ---- the library pieces under ColorDescriptor::create ------------------------------------------------
+    const int dims[][2] = {{256, 192}, {192, 256}, {100, 100}, {40, 30}, {255, 131}};
+    for (int d = 0; d < 5; ++d) {
+      cv::Mat mask(dims[d][1], dims[d][0], CV_8UC1);
+      mask = mask.setTo(0);
+      cv::RotatedRect box(cv::Point2f(mask.cols * 0.5f, mask.rows * 0.5f), cv::Size2f(mask.cols * 0.9f, mask.rows * 0.9f), 0.0f);
+      cv::ellipse(mask, box, 255, CV_FILLED);
+      std::printf("M %d %d ", mask.cols, mask.rows);
+      for (int y = 0; y < mask.rows; ++y) put_hex(mask.ptr(y), (size_t)mask.cols);
+      std::printf("\n");
+    }
+    const int w = 120, h = 90;
+    const uint32_t seed = 950;
+    std::vector<uint8_t> pb = gen_image(w, h, seed), pg = gen_image(w, h, seed + 1), pr = gen_image(w, h, seed + 2);
+    cv::Mat bgr(h, w, CV_8UC3);
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) bgr.at<cv::Vec3b>(y, x) = cv::Vec3b(pb[y * w + x], pg[y * w + x], pr[y * w + x]);
+    cv::Mat luv;
+    bgr.convertTo(luv, CV_32FC3);
+    luv *= 1.0 / 255.0;
+    cv::cvtColor(luv, luv, CV_BGR2Luv);
+    std::printf("U %d", 256);
+    for (int i = 0; i < 256; ++i) {
+      const int y = (i * 37) % h, x = (i * 101) % w;
+      const cv::Vec3b c = bgr.at<cv::Vec3b>(y, x);
+      const cv::Vec3f v = luv.at<cv::Vec3f>(y, x);
+      uint32_t b[3];
+      std::memcpy(b, &v[0], 4), std::memcpy(b + 1, &v[1], 4), std::memcpy(b + 2, &v[2], 4);
+      std::printf(" %d %d %d %08x %08x %08x", c[0], c[1], c[2], b[0], b[1], b[2]);
+    }
+    std::printf("\n");
+    {
+      std::vector<cv::Point3f> samples;
+      for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+          const cv::Vec3f v = luv.at<cv::Vec3f>(y, x);
+          samples.push_back(cv::Point3f(v[0], v[1], v[2]));
+        }
+      cv::theRNG().state = 0xffffffff;  // a fresh thread's generator
+      cv::Mat labels, centers;
+      (void)cv::kmeans(samples, 32, labels, cvTermCriteria(CV_TERMCRIT_ITER | CV_TERMCRIT_EPS, 100, 10), 1,
+                       cv::KMEANS_PP_CENTERS, centers);
+      std::printf("K %d 0", (int)samples.size());
+      for (int i = 0; i < labels.rows; ++i) std::printf(" %d", labels.at<int>(i));
+      for (int k = 0; k < 32; ++k)
+        for (int j = 0; j < 3; ++j) {
+          const float c = centers.at<float>(k, j);
+          uint32_t b;
+          std::memcpy(&b, &c, 4);
+          std::printf(" %08x", b);
+        }
+      std::printf("\n");
+    }
   }
   return 0;
 }

@@ -81,6 +81,42 @@ def parse(path: str) -> dict:
             out["rects"] = np.array([[int(t[5 + 4 * i]), int(t[6 + 4 * i]), int(t[7 + 4 * i])] for i in range(n)], np.int32)
             out["rect_hashes"] = np.array([int(t[8 + 4 * i], 16) for i in range(n)], np.uint64)
             out["rect_after_sum"] = np.array([int(t[5 + 4 * n])], np.uint64)
+        elif t[0] == "P":
+            dw, dh = int(t[4]), int(t[5])
+            out["pyr_whs_dims"] = np.array([int(t[1]), int(t[2]), int(t[3]), dw, dh], np.int64)
+            out["pyr"] = np.frombuffer(bytes.fromhex(t[6]), np.uint8).reshape(dh, dw)
+        elif t[0] == "B":
+            w, h = int(t[1]), int(t[2])
+            out["gauss_whs"] = np.array([w, h, int(t[3])], np.int64)
+            out["gauss"] = np.frombuffer(bytes.fromhex(t[4]), np.uint8).reshape(h, w)
+        elif t[0] == "F":
+            n = int(t[4])
+            out["fast_whs"] = np.array([int(t[1]), int(t[2]), int(t[3])], np.int64)
+            out["fast"] = np.array([int(v) for v in t[5: 5 + 3 * n]], np.int32).reshape(n, 3)
+        elif t[0] == "O":
+            n = int(t[5])
+            out["orb_whs_nfeat"] = np.array([int(t[1]), int(t[2]), int(t[3]), int(t[4])], np.int64)
+            rec = t[6: 6 + 6 * n]
+            out["orb_kp_bits"] = np.array([[int(rec[6 * i + j], 16) for j in range(5)] for i in range(n)], np.uint32).reshape(n, 5)
+            out["orb_octave"] = np.array([int(rec[6 * i + 5]) for i in range(n)], np.int32)
+            out["orb_desc"] = np.frombuffer(bytes.fromhex(t[6 + 6 * n]) if n else b"", np.uint8).reshape(n, 32)
+        elif t[0] == "A":
+            n = int(t[1])
+            out["atan_bits"] = np.array([int(v, 16) for v in t[2: 2 + 3 * n]], np.uint32).reshape(n, 3)
+        elif t[0] == "M":
+            cols, rows = int(t[1]), int(t[2])
+            out[f"mask_{cols}x{rows}"] = np.frombuffer(bytes.fromhex(t[3]), np.uint8).reshape(rows, cols)
+        elif t[0] == "U":
+            n = int(t[1])
+            rec = t[2: 2 + 6 * n]
+            out["luv_bgr"] = np.array([[int(rec[6 * i + j]) for j in range(3)] for i in range(n)], np.uint8)
+            out["luv_bits"] = np.array([[int(rec[6 * i + 3 + j], 16) for j in range(3)] for i in range(n)], np.uint32)
+        elif t[0] == "K":
+            n = int(t[1])
+            out["kmeans_labels"] = np.array([int(v) for v in t[3: 3 + n]], np.int32)
+            out["kmeans_center_bits"] = np.array([int(v, 16) for v in t[3 + n: 3 + n + 96]], np.uint32).reshape(32, 3)
+    if not H:
+        return out
     out["hash_whs"] = np.array([(a, b, c) for a, b, c, *_ in H], np.int64)
     out["hashes"] = np.array([x[3] for x in H], np.uint64)
     out["thresh_bits"] = np.array([x[4] for x in H], np.uint32)
