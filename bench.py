@@ -344,7 +344,8 @@ def video_leg(args, torch, dist, dev, local_rank, rank, world, share):
         m = M()
         m.id, m.path, m.videoIndex, m.dctHash = i + 1, "", VideoIndex(f, h), 0
         media.append(m)
-    sv = ShardedDctVideoIndex(lambda: DctVideoIndex(local_rank), device=None if (share or world == 1) else dev)
+    sv = ShardedDctVideoIndex(lambda: DctVideoIndex(local_rank),
+                              device=dev if (dist.is_initialized() and not share) else None)
     t0 = time.perf_counter()
     sv.add(media)
     p = VideoSearchParams(dctThresh=5, skipFrames=0, minFramesMatched=30, minFramesNear=60)

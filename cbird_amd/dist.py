@@ -109,6 +109,12 @@ class HipOps:
         return out[:, :k, 0], out[:, :k, 1], counts
 
 
+def _force_collectives() -> bool:
+    """CBH_DIST_FORCE_COLLECTIVES=1 with an initialised process group: run the collectives at world size 1 too, so a
+    one-GPU box exercises the RCCL transport of every sharded index (same code path as R > 1)"""
+    return dist.is_initialized() and os.environ.get("CBH_DIST_FORCE_COLLECTIVES") == "1"
+
+
 class ShardedDctHashIndex:
     """One exchange step per threshold, and nothing on it synchronises with the host:
 
@@ -128,8 +134,7 @@ class ShardedDctHashIndex:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         # CBH_DIST_FORCE_COLLECTIVES=1: run the collectives at world size 1 too (a one-GPU box can then exercise the
         # RCCL transport itself -- same code path as R > 1, the gathered buffer is just one block long)
-        self.collective = self.world > 1 or (dist.is_initialized() and
-                                             os.environ.get("CBH_DIST_FORCE_COLLECTIVES") == "1")
+        self.collective = self.world > 1 or _force_collectives()
         # record_capacity = what the whole job may produce per threshold; a rank's block holds its share (x2 slack)
         self.record_capacity = record_capacity
         self._bufs = {}
@@ -325,7 +330,7 @@ def _gather_rows(rows, group=None, device=None, cap0: int = 4096):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rows = np.ascontiguousarray(rows, np.int32)
     n, w = rows.shape
-    if world == 1:
+    if world == 1 and not _force_collectives():
         return rows
     cap = cap0  # the same on every rank; grows to the largest count seen (also the same on every rank)
     while True:
@@ -421,7 +426,7 @@ class ShardedCvFeaturesIndex:
         # sortable key per candidate: distance << 40 | global row; empty places sort last
         key = (dst.astype(np.int64) << 40) | (row.astype(np.int64) + self.row_offset)
         key[np.arange(knn)[None, :] >= np.minimum(cnt, knn)[:, None]] = np.iinfo(np.int64).max
-        if self.world > 1:
+        if self.world > 1 or _force_collectives():
             tab = np.concatenate([key.view(np.int32).reshape(nq, -1), media.view(np.int32),
                                   cnt.view(np.int32)[:, None]], 1)  # [nq, 2k + k + 1] int32, fixed size
             t = torch.from_numpy(np.ascontiguousarray(tab)).reshape(-1)

@@ -183,6 +183,43 @@ def _rccl_worker(port, n, q_out):
             sweep = sh.similar_sweep(allh, (1, 2, 7, 9), 4)  # one all-gather of {count, records} per threshold
         torch.cuda.synchronize()
         out = {d: tuple(t.cpu().numpy().copy() for t in sweep[d]) for d in (1, 2, 7, 9)}
+        # the other two sharded indexes: their one all-gather each over RCCL (device tensors), == the plain index
+        from cbird_amd import synth_video
+        from cbird_amd.cvfeatures import CvFeaturesIndex
+        from cbird_amd.dist import ShardedCvFeaturesIndex, ShardedDctVideoIndex
+        from cbird_amd.index import SearchParams
+        from cbird_amd.video import DctVideoIndex, VideoIndex, VideoSearchParams
+
+        class M:
+            pass
+
+        media = []
+        for i, (f, hh) in enumerate(synth_video.make_clips(60, 120, seed=3, subclip_frac=0.2, max_gap=8)):
+            m = M()
+            m.id, m.path, m.videoIndex = i + 1, f"c{i}", VideoIndex(f.tolist(), [int(x) for x in hh])
+            media.append(m)
+        vp = VideoSearchParams(dctThresh=5, skipFrames=0, minFramesMatched=10, minFramesNear=30)
+        sv = ShardedDctVideoIndex(lambda: DctVideoIndex(0), device=dev)
+        sv.add(media)
+        plain = DctVideoIndex(0)
+        plain.add(media)
+        key = lambda r: [(x.mediaId, x.score, x.range.srcIn, x.range.dstIn, x.range.len) for x in r]
+        assert [key(r) for r in sv.find_videos_batch(media[:20], vp)] == [key(r) for r in plain.find_videos_batch(media[:20], vp)]
+        rng = np.random.default_rng(4)
+        om = []
+        for i in range(40):
+            m = M()
+            m.id, m.path = i + 1, f"o{i}"
+            m.keyPointDescriptors = rng.integers(0, 256, (50, 32), dtype=np.uint8)
+            om.append(m)
+        so = ShardedCvFeaturesIndex(lambda: CvFeaturesIndex(0), device=dev)
+        so.add(om)
+        po = CvFeaturesIndex(0)
+        po.add(om)
+        sp = SearchParams(cvThresh=120)
+        got = so.find_batch(om[:8], sp)
+        want = [po.find(m, sp) for m in om[:8]]
+        assert [[(x.mediaId, x.score) for x in r] for r in got] == [[(x.mediaId, x.score) for x in r] for r in want]
         q_out.put((allh.cpu().numpy().copy(), out))
     finally:
         dist.destroy_process_group()
