@@ -14,7 +14,7 @@
 //                                   library's, IEEE on the device); border pixels are the resized pixels at the reflected
 //                                   coordinates (= copyMakeBorder of the resized level).  Only the levels that can hold a
 //                                   keypoint (both sides > 62) are built.
-//   k_orb_fast                      FAST-9/16 score + 3x3 non-maximum suppression per 64x16 tile staged in LDS by dword
+//   k_orb_fast                      FAST-9/16 score + 3x3 non-maximum suppression per 64x32 tile staged in LDS by dword
 //                                   loads: a compass-point test rejects most pixels after 4 reads, 16-bit brighter /
 //                                   darker masks, "9 contiguous" by four shift-ands, the score (largest threshold that
 //                                   keeps the corner) only for the rare corners.  Writes the non-zero entries of the
@@ -153,6 +153,8 @@ __global__ __launch_bounds__(256) void k_orb_resize(const OrbImage* __restrict__
   const unsigned char* __restrict__ src = pyr + im.poff[level - 1];
   unsigned* __restrict__ dst = reinterpret_cast<unsigned*>(pyr + im.poff[level] - (size_t)kBorderY * P - kBorderX);
   const int nr = min(kResizeRows, rows - r0);
+  // (staging the ~21 source rows of a workgroup in LDS was tried: 2.6x SLOWER -- the four byte loads of neighbouring
+  // pixels already coalesce in the vector L1, the staging only adds LDS traffic and a barrier)
   for (int i = threadIdx.x; i < nr * nd; i += 256) {
     const int r = i / nd, c = i - r * nd;
     const int yo = s_yofs[r], yc = s_yc[r];
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256) void k_orb_resize(const OrbImage* __restrict__
 }
 
 // ---- FAST-9/16 + non-maximum suppression (oracle: orc_fast_nms_scores restricted to the keypoint region) -----------
-constexpr int kTileW = 64, kTileH = 16;
+constexpr int kTileW = 64, kTileH = 32;
 constexpr int kPxW = 76, kPxH = kTileH + 8;  // staged pixels: x from ox0 - 7 (4-byte aligned) to ox0 + 68, 19 dwords
 constexpr int kRawW = kTileW + 2, kRawH = kTileH + 2;
 
@@ -187,14 +189,12 @@ __device__ __forceinline__ void fast_circle(const unsigned char* __restrict__ c,
 #pragma unroll
   for (int k = 0; k < 16; ++k) d[k] = v - (int)c[oy[k] * kPxW + ox[k]];
 }
-// stage 1: a run of 9 of the 16 contains at least two of the compass points 0, 4, 8, 12 -- four reads reject most pixels
+// stage 1: a run of 9 of the 16 contains pixel 0 or pixel 8 (they are opposite), so a corner has one of the two
+// outside [v - t, v + t] -- fast.cpp's own first test; two reads reject most pixels
 __device__ __forceinline__ bool fast_compass(const unsigned char* __restrict__ c) {
   const int v = c[0];
   const int d0 = v - (int)c[3 * kPxW], d8 = v - (int)c[-3 * kPxW];
-  const int d4 = v - (int)c[3], d12 = v - (int)c[-3];
-  const int dk = (d0 > kFastT) + (d4 > kFastT) + (d8 > kFastT) + (d12 > kFastT);
-  const int br = (d0 < -kFastT) + (d4 < -kFastT) + (d8 < -kFastT) + (d12 < -kFastT);
-  return dk >= 2 || br >= 2;
+  return (unsigned)(d0 + kFastT) > 2u * kFastT || (unsigned)(d8 + kFastT) > 2u * kFastT;
 }
 // stage 2: the segment test proper on 16-bit brighter / darker masks
 __device__ __forceinline__ bool fast_is_corner(const unsigned char* __restrict__ c) {
@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256) void k_orb_fast(const OrbImage* __restrict__ i
                                                   const unsigned char* __restrict__ pyr,
                                                   unsigned char* __restrict__ scores /* cleared */) {
   __shared__ __attribute__((aligned(16))) unsigned char s_px[kPxH * kPxW];
-  __shared__ unsigned char s_raw[kRawH * kRawW];
+  __shared__ __attribute__((aligned(4))) unsigned char s_raw[kRawH * kRawW];
+  static_assert(kRawH * kRawW % 4 == 0, "s_raw is cleared by dwords");
   __shared__ unsigned short s_q1[kRawH * kRawW], s_q2[kRawH * kRawW];
   __shared__ int s_n[2];
   const OrbImage& im = images[blockIdx.y];
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256) void k_orb_fast(const OrbImage* __restrict__ i
     const int x = min(px0 + 4 * c, (int)sp - 2 * kBorderX);       // those values are never used
     reinterpret_cast<unsigned*>(s_px)[i] = *reinterpret_cast<const unsigned*>(src + (ptrdiff_t)y * sp + x);
   }
-  for (int i = threadIdx.x; i < kRawH * kRawW; i += 256) s_raw[i] = 0;
+  for (int i = threadIdx.x; i < kRawH * kRawW / 4; i += 256) reinterpret_cast<unsigned*>(s_raw)[i] = 0u;
   if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
   __syncthreads();
   // three stages with the survivors compacted in between, so that the expensive ones run on full waves
@@ -540,37 +541,40 @@ __global__ __launch_bounds__(256) void k_orb_select(const OrbImage* __restrict__
   }
   __syncthreads();
   if (tid == 0) *out_count = (unsigned)c2;
-  // -- (f) orientation: IC_Angle over the circular patch of radius 15, one wave per keypoint, no loop: lane =
-  //        (row pair +-v, v = lane >> 2; segment of 8 columns u0 = -16 + 8 * (lane & 3)) -- four unaligned dword loads
-  //        per lane, all in flight together, then a wave reduction
-  const int lane = tid & 63, wv = tid >> 6;
+  // -- (f) orientation: IC_Angle over the circular patch of radius 15, HALF a wave per keypoint, no loop: lane =
+  //        (row pair +-v, v = (lane & 31) >> 1; 16-column segment u0 = -16 + 16 * (lane & 1)) -- eight unaligned dword
+  //        loads per lane, all in flight together, then a reduction over the 32 lanes
+  const int lane = tid & 63, hw = tid >> 5;  // 8 half-waves
   {
-    const int v = lane >> 2, u0 = -16 + 8 * (lane & 3);
+    const int v = (lane & 31) >> 1, u0 = -16 + 16 * (lane & 1);
     // u_max of orb.cpp for half patch 15 (15 15 15 15 14 14 14 13 13 12 11 10 9 8 6 3), one nibble per row
     const int um = (int)((0x3689ABCDDEEEFFFFull >> (4 * v)) & 15ull);
-    for (int i = wv; i < c2; i += 4) {
-      const int x = cd[i].x, y = cd[i].y;
+    for (int i0 = 0; i0 < c2; i0 += 8) {
+      const int i = i0 + hw;
+      const bool live = i < c2;
+      const int x = live ? cd[i].x : kEdge, y = live ? cd[i].y : kEdge;
       const unsigned char* __restrict__ pp = img + (ptrdiff_t)(y + v) * ip + (x + u0);
       const unsigned char* __restrict__ pm = img + (ptrdiff_t)(y - v) * ip + (x + u0);
-      const unsigned p0 = *reinterpret_cast<const unsigned*>(pp), p1 = *reinterpret_cast<const unsigned*>(pp + 4);
-      const unsigned q0 = *reinterpret_cast<const unsigned*>(pm), q1 = *reinterpret_cast<const unsigned*>(pm + 4);
+      unsigned p[4], q[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) p[k] = *reinterpret_cast<const unsigned*>(pp + 4 * k), q[k] = *reinterpret_cast<const unsigned*>(pm + 4 * k);
       int m10 = 0, v_sum = 0;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < 16; ++j) {
         const int u = u0 + j;
-        const int vp = (int)(((j < 4 ? p0 : p1) >> (8 * (j & 3))) & 255u);
-        const int vm = v == 0 ? 0 : (int)(((j < 4 ? q0 : q1) >> (8 * (j & 3))) & 255u);  // the centre row counts once
+        const int vp = (int)((p[j >> 2] >> (8 * (j & 3))) & 255u);
+        const int vm = v == 0 ? 0 : (int)((q[j >> 2] >> (8 * (j & 3))) & 255u);  // the centre row counts once
         const bool in = u >= -um && u <= um;
         m10 += in ? u * (vp + vm) : 0;
         v_sum += in ? vp - vm : 0;
       }
       int m01 = v * v_sum;
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
+      for (int d = 1; d < 32; d <<= 1) {
         m01 += __shfl_xor(m01, d);
         m10 += __shfl_xor(m10, d);
       }
-      if (lane == 0) cd[i].angle = fast_atan2_deg((float)m01, (float)m10);
+      if (live && (lane & 31) == 0) cd[i].angle = fast_atan2_deg((float)m01, (float)m10);
     }
   }
   __syncthreads();
