@@ -928,6 +928,9 @@ int launch_orb(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const u
   if (e == hipSuccess) {
     const unsigned ny = (unsigned)n;
     if (max_lev >= 1) hipLaunchKernelGGL(k_orb_level0, dim3(32, ny), dim3(256), 0, s, d_images, d_imgs, d_pyr);
+    if ((size_t)max_pitch * 8 > 64 * 1024)  // images wider than 8184 pixels: the x tables pass the default LDS limit
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_orb_resize), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(max_pitch * 8));
     for (int l = 1; l < max_lev; ++l)
       hipLaunchKernelGGL(k_orb_resize,
                          dim3((unsigned)((max_h[l] + 2 * kBorderY + kResizeRows - 1) / kResizeRows), ny), dim3(256),
@@ -1028,6 +1031,9 @@ int launch_orb_describe(const uint8_t* d_imgs, size_t n, const uint64_t* img_off
   if (e == hipSuccess) {
     const unsigned ny = (unsigned)n;
     if (pl.max_lev >= 1) hipLaunchKernelGGL(k_orb_level0, dim3(32, ny), dim3(256), 0, s, d_images, d_imgs, d_pyr);
+    if ((size_t)pl.max_pitch * 8 > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_orb_resize), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(pl.max_pitch * 8));
     for (int l = 1; l < pl.max_lev; ++l)
       hipLaunchKernelGGL(k_orb_resize,
                          dim3((unsigned)((pl.max_h[l] + 2 * kBorderY + kResizeRows - 1) / kResizeRows), ny), dim3(256),

@@ -282,6 +282,21 @@ def test_gpu_orb_cos_sin_match_libm(gpu, orb_orc):
 
 
 @pytest.mark.gpu
+def test_gpu_orb_large_images(gpu, orb_orc):
+    """the sizes the interface admits, not just the 400-pixel images cbird feeds: 12 MP, the widest row (8192), more
+    keypoints asked than cbird ever does"""
+    from cbird_amd import orb
+
+    pat = orb.synthetic_pattern()
+    orb_orc.set_pattern(pat)
+    orb.set_pattern(pat)
+    rng = np.random.default_rng(13)
+    for (w, h, nf) in ((4000, 3000, 400), (8192, 300, 1500)):
+        img = _scene(rng, w, h, nrect=400)
+        _compare(orb_orc, [img], nf, orb.orb([img], nf))
+
+
+@pytest.mark.gpu
 def test_gpu_orb_arguments(gpu):
     from cbird_amd import _lib, orb
 
