@@ -413,7 +413,6 @@ __global__ __launch_bounds__(64) void k_cd_cluster(const CdImage* __restrict__ i
     const size_t o = 3 * il(group, (unsigned)i, lane);
     a = samples[o], b = samples[o + 1], c = samples[o + 2];
   };
-  auto D = [&](int slot, int i) -> float& { return dists[(size_t)slot * slot_stride + il(group, (unsigned)i, lane)]; };
   // The loops below run one lane per image, so nothing hides a load but the lane's own next loads: every loop takes its
   // elements in blocks of kB whose loads are all issued before the first element is consumed (the compiler cannot do
   // that itself -- the stores to the per-lane distance slots may alias the loads as far as it knows).
@@ -430,7 +429,8 @@ __global__ __launch_bounds__(64) void k_cd_cluster(const CdImage* __restrict__ i
 
   // ---- generateCentersPP(data, centers, K, rng, 3)
   {
-    int sd = 0;
+    // the four distance arrays of this lane as base pointers (element i at p[i * 64]): swapped, never re-derived
+    float* pd = dists + il(group, 0u, lane);
     double sum0 = 0;
     int c0 = n > 0 ? (int)(rng.next() % (unsigned)n) : 0;
     float a0 = 0, a1 = 0, a2 = 0;
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(64) void k_cd_cluster(const CdImage* __restrict__ i
       for (int u = 0; u < kB; ++u)
         if (i0 + u < n) {
           const float d = dist3(b0[u], b1[u], b2[u], a0, a1, a2);
-          D(sd, i0 + u) = d;
+          pd[(size_t)(i0 + u) * 64] = d;
           sum0 += d;
         }
     }
@@ -452,7 +452,9 @@ __global__ __launch_bounds__(64) void k_cd_cluster(const CdImage* __restrict__ i
     // walk over dist finds the three candidate centres (three running `p -= dist[i]`), one pass over the samples
     // produces the three candidate distance arrays and their double sums -- each sum in index order, as the
     // reference forms it; the first smallest sum wins (`s < bestSum` visits the trials in order).
-    int sc[3] = {1, 2, 3};  // slots of the three candidates; sd = slot of dist
+    float* pc0 = pd + slot_stride;  // the three candidate arrays (scalars: an indexed array would live in scratch)
+    float* pc1 = pd + 2 * slot_stride;
+    float* pc2 = pd + 3 * slot_stride;
 #pragma unroll 1
     for (int k = 1; k < kK; ++k) {
       double p[3], sj[3] = {0, 0, 0};
@@ -461,15 +463,22 @@ __global__ __launch_bounds__(64) void k_cd_cluster(const CdImage* __restrict__ i
 #pragma unroll
       for (int j = 0; j < 3; ++j) p[j] = rng.real() * sum0, ci[j] = max(n - 1, 0), found[j] = false;
       // for (i = 0; i < N-1; i++) if ((p -= dist[i]) <= 0) break;  ci = i
-      for (int i0 = 0; i0 < n - 1 && !(found[0] && found[1] && found[2]); i0 += kB) {
-        float dv[kB];
+      // (double-buffered: the next block's loads are issued before this block is consumed)
+      {
+        float dv[kB], nx[kB];
 #pragma unroll
-        for (int u = 0; u < kB; ++u) dv[u] = D(sd, min(i0 + u, n - 1));
+        for (int u = 0; u < kB; ++u) dv[u] = n > 0 ? pd[(size_t)min(u, n - 1) * 64] : 0.f;
+        for (int i0 = 0; i0 < n - 1 && !(found[0] && found[1] && found[2]); i0 += kB) {
 #pragma unroll
-        for (int u = 0; u < kB; ++u)
+          for (int u = 0; u < kB; ++u) nx[u] = pd[(size_t)min(i0 + kB + u, n - 1) * 64];
 #pragma unroll
-          for (int j = 0; j < 3; ++j)
-            if (!found[j] && i0 + u < n - 1 && (p[j] -= dv[u]) <= 0) found[j] = true, ci[j] = i0 + u;
+          for (int u = 0; u < kB; ++u)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+              if (!found[j] && i0 + u < n - 1 && (p[j] -= dv[u]) <= 0) found[j] = true, ci[j] = i0 + u;
+#pragma unroll
+          for (int u = 0; u < kB; ++u) dv[u] = nx[u];
+        }
       }
       float c0[3], c1[3], c2[3];
 #pragma unroll
@@ -477,22 +486,31 @@ __global__ __launch_bounds__(64) void k_cd_cluster(const CdImage* __restrict__ i
         c0[j] = c1[j] = c2[j] = 0.f;
         if (n > 0) S(ci[j], c0[j], c1[j], c2[j]);
       }
-      for (int i0 = 0; i0 < n; i0 += kB) {
-        float b0[kB], b1[kB], b2[kB], old[kB];
-        SB(i0, n, b0, b1, b2);
+      {
+        float b0[kB], b1[kB], b2[kB], old[kB], n0[kB], n1[kB], n2[kB], nold[kB];
+        if (n > 0) {
+          SB(0, n, b0, b1, b2);
 #pragma unroll
-        for (int u = 0; u < kB; ++u) old[u] = D(sd, min(i0 + u, n - 1));
+          for (int u = 0; u < kB; ++u) old[u] = pd[(size_t)min(u, n - 1) * 64];
+        }
+        for (int i0 = 0; i0 < n; i0 += kB) {
+          SB(i0 + kB, n, n0, n1, n2);  // clamped to n - 1: the block after the last one re-reads the last sample
 #pragma unroll
-        for (int u = 0; u < kB; ++u)
-          if (i0 + u < n) {
+          for (int u = 0; u < kB; ++u) nold[u] = pd[(size_t)min(i0 + kB + u, n - 1) * 64];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-              const float d = dist3(b0[u], b1[u], b2[u], c0[j], c1[j], c2[j]);
-              const float t = old[u] < d ? old[u] : d;  // std::min(d, dist[i])
-              D(sc[j], i0 + u) = t;
-              sj[j] += t;
+          for (int u = 0; u < kB; ++u)
+            if (i0 + u < n) {
+#pragma unroll
+              for (int j = 0; j < 3; ++j) {
+                const float d = dist3(b0[u], b1[u], b2[u], c0[j], c1[j], c2[j]);
+                const float t = old[u] < d ? old[u] : d;  // std::min(d, dist[i])
+                (j == 0 ? pc0 : j == 1 ? pc1 : pc2)[(size_t)(i0 + u) * 64] = t;
+                sj[j] += t;
+              }
             }
-          }
+#pragma unroll
+          for (int u = 0; u < kB; ++u) b0[u] = n0[u], b1[u] = n1[u], b2[u] = n2[u], old[u] = nold[u];
+        }
       }
       double bestSum = DBL_MAX;
       int best = 0;
@@ -502,11 +520,14 @@ __global__ __launch_bounds__(64) void k_cd_cluster(const CdImage* __restrict__ i
       sum0 = bestSum;
       {
         // std::swap(dist, tdist): the winning candidate becomes dist, the old dist array a candidate slot
-        const int t = sd;
-        sd = sc[best];
-        sc[best] = t;
+        float* const t = pd;
+        if (best == 0) pd = pc0, pc0 = t;
+        else if (best == 1) pd = pc1, pc1 = t;
+        else pd = pc2, pc2 = t;
       }
-      a0 = c0[best], a1 = c1[best], a2 = c2[best];
+      a0 = best == 0 ? c0[0] : best == 1 ? c0[1] : c0[2];
+      a1 = best == 0 ? c1[0] : best == 1 ? c1[1] : c1[2];
+      a2 = best == 0 ? c2[0] : best == 1 ? c2[1] : c2[2];
       // centres are written through a switch-free path: k is uniform across the wave
 #pragma unroll
       for (int kk = 1; kk < kK; ++kk)
