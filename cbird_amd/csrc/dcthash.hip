@@ -1442,9 +1442,18 @@ __global__ __launch_bounds__(256) void k_blur_area_stream(const unsigned char* _
           float* __restrict__ obp = rows + ((size_t)blockIdx.z * (size_t)h + (size_t)(ob + (two ? r2 : r))) * 32 + cc;
           if (isx) {
             unsigned sa = 0, sb = 0;
-            for (int u = 0; u < ank; ++u) {
-              sa += Sa[u];
-              sb += Sb[u];
+            if (((isx | (int)bpitch | acol) & 3) == 0) {  // dword-aligned cells: four pixels per v_dot4 (uniform)
+              const unsigned* __restrict__ A4 = reinterpret_cast<const unsigned*>(Sa);
+              const unsigned* __restrict__ B4 = reinterpret_cast<const unsigned*>(Sb);
+              for (int u = 0; u < (ank >> 2); ++u) {
+                sa = udot4(A4[u], 0x01010101u, sa);
+                sb = udot4(B4[u], 0x01010101u, sb);
+              }
+            } else {
+              for (int u = 0; u < ank; ++u) {
+                sa += Sa[u];
+                sb += Sb[u];
+              }
             }
             *oa = __uint_as_float(sa);
             if (two) *obp = __uint_as_float(sb);
@@ -1653,9 +1662,18 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
         float* __restrict__ obp = rows + ((size_t)(lb ? gb : 0u) * (size_t)h + (size_t)(ob + rb_)) * 32 + cc;
         if (isx) {
           unsigned sa = 0, sb = 0;
-          for (int u = 0; u < ank; ++u) {
-            sa += Sa[u];
-            sb += Sb[u];
+          if (((isx | bp) & 3) == 0) {  // cells start on dword boundaries: four pixels per v_dot4 (uniform branch)
+            const unsigned* __restrict__ A4 = reinterpret_cast<const unsigned*>(Sa);
+            const unsigned* __restrict__ B4 = reinterpret_cast<const unsigned*>(Sb);
+            for (int u = 0; u < (ank >> 2); ++u) {
+              sa = udot4(A4[u], 0x01010101u, sa);
+              sb = udot4(B4[u], 0x01010101u, sb);
+            }
+          } else {
+            for (int u = 0; u < ank; ++u) {
+              sa += Sa[u];
+              sb += Sb[u];
+            }
           }
           if (la) *oa = __uint_as_float(sa);
           if (lb) *obp = __uint_as_float(sb);
