@@ -5,6 +5,7 @@
 //   void sizeLongestSide(cv::Mat& img, int size, int filter = INTER_LANCZOS4)        src/cvutil.h:251, cvutil.cpp:1932-1950
 //   void Media::makeKeyPoints(const cv::Mat&, int numKeyPoints, KeyPointList&) const                 src/media.cpp:859-866
 //   void Media::makeKeyPointDescriptors(const cv::Mat&, KeyPointList&, KeyPointDescriptors&) const   src/media.cpp:868-872
+//   static void ColorDescriptor::create(const cv::Mat& cvImg, ColorDescriptor& desc)                 src/cvutil.cpp:790-1099
 //
 // Same arguments and effects as the originals for 8-bit single-channel images (what Scanner::processImage passes
 // after grayscale(), src/scanner.cpp:859,876-889): the hash is returned, and with inPlace = true the blurred pixels
@@ -175,6 +176,25 @@ inline void gpuMakeKeyPointDescriptors(const cv::Mat& cvImg, KeyPointList& keyPo
     keyPoints.push_back(cv::KeyPoint(out[i].x, out[i].y, out[i].size, out[i].angle, out[i].response, out[i].octave, -1));
     memcpy(outDescriptors.ptr<uint8_t>(int(i)), desc.data() + size_t(i) * 32, 32);
   }
+}
+
+// ColorDescriptor::create: desc is written only when the reference would write it (a BGR / BGRA image with at least 32
+// samples brighter than L = 4); one image per call -- an indexer that wants the GPU's throughput batches them through
+// cbh_color_descriptors / cbh_index_images (the clustering kernel runs one lane per image)
+inline void gpuColorDescriptorCreate(const cv::Mat& cvImg, ColorDescriptor& desc) {
+  if (cvImg.type() != CV_8UC3 && cvImg.type() != CV_8UC4) {
+    qDebug("passed a grayscale image");
+    return;
+  }
+  static_assert(sizeof(ColorDescriptor) == 258, "the record ColorDescIndex stores");
+  const uint64_t off = 0;
+  const uint32_t w = uint32_t(cvImg.cols), h = uint32_t(cvImg.rows), step = uint32_t(cvImg.step);
+  uint8_t rec[258], ok = 0;
+  const int rc = cbh_color_descriptors(cvImg.data, size_t(h - 1) * step + size_t(w) * size_t(cvImg.channels()), 1, &off, &w,
+                                       &h, &step, cvImg.channels(), rec, &ok, hashDevice());
+  if (rc) qFatal("gpuColorDescriptorCreate: %s (%s)", cbh_strerror(rc), cbh_last_error());
+  if (ok) memcpy(&desc, rec, sizeof desc);
+  else qWarning("not enough colors");
 }
 
 }  // namespace cbird_gpu

@@ -74,6 +74,9 @@ struct QDebugMock {
   ~QDebugMock() { std::cerr << '\n'; }
 };
 inline QDebugMock qWarning() { return QDebugMock(); }
+// the printf-style overloads Qt also has (qWarning("..."), qDebug("..."))
+inline void qWarning(const char* msg) { std::cerr << msg << '\n'; }
+inline void qDebug(const char* msg) { std::cerr << msg << '\n'; }
 inline const char* qPrintable(const QString& s) { return s.c_str(); }
 
 // Qt's qCompress / qUncompress: 4-byte big-endian uncompressed length + a zlib stream
@@ -206,6 +209,8 @@ struct QSqlQuery {
 typedef uint64_t dcthash_t;
 typedef std::vector<uint64_t> KeyPointHashList;
 #define CV_8UC1 0
+#define CV_8UC3 16
+#define CV_8UC4 24
 namespace cv {
 struct Size {
   int width = 0, height = 0;
@@ -235,16 +240,21 @@ struct Mat {  // rows x cols bytes (CV_8UC1); views share the parent's storage l
     data = _store->data();
     _whole.width = c, _whole.height = r;
   }
-  Mat(int r, int c, int /*type: CV_8UC1*/) : Mat(r, c) {}
+  Mat(int r, int c, int type) : rows(r), cols(c), _cn((type >> 3) + 1) {  // CV_8UC1 / CV_8UC3 / CV_8UC4
+    step = size_t(c) * size_t(_cn);
+    _store.reset(new std::vector<uint8_t>(size_t(r) * step));
+    data = _store->data();
+    _whole.width = c, _whole.height = r;
+  }
   template <typename T>
   const T* ptr(int r) const { return reinterpret_cast<const T*>(data + size_t(r) * step); }
   template <typename T>
   T* ptr(int r) { return reinterpret_cast<T*>(data + size_t(r) * step); }
-  int type() const { return 0; }      // CV_8UC1
-  int channels() const { return 1; }
+  int type() const { return (_cn - 1) << 3; }
+  int channels() const { return _cn; }
   Mat colRange(int x0, int x1) const {
     Mat m(*this);
-    m.data += x0, m.cols = x1 - x0, m._ofs.x += x0;
+    m.data += size_t(x0) * size_t(_cn), m.cols = x1 - x0, m._ofs.x += x0;
     return m;
   }
   Mat rowRange(int y0, int y1) const {
@@ -255,6 +265,7 @@ struct Mat {  // rows x cols bytes (CV_8UC1); views share the parent's storage l
   void locateROI(Size& wholeSize, Point& ofs) const { wholeSize = _whole, ofs = _ofs; }
 
  private:
+  int _cn = 1;
   std::shared_ptr<std::vector<uint8_t>> _store;
   Size _whole;
   Point _ofs;

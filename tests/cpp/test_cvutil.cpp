@@ -98,5 +98,24 @@ int main(int argc, char** argv) {
       for (int c = 0; c < 32; ++c) sum = sum * 1099511628211ull + descr.ptr<uint8_t>(r)[c];
     printf("orb_desc %d %" PRIu64 "\n", descr.rows, sum);
   }
+  // 6. ColorDescriptor::create on a BGR image built from the same generator; grey input leaves the descriptor alone
+  {
+    cv::Mat bgr(h, w, CV_8UC3);
+    uint32_t s4 = uint32_t(atoi(argv[3])) + 99u;
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x)
+        for (int c = 0; c < 3; ++c)
+          bgr.ptr<uint8_t>(y)[3 * x + c] = uint8_t(((x / 23 + 2 * (y / 17) + c) % 5) * 50 + int(xs(s4) % 7u));
+    ColorDescriptor cd;
+    cbird_gpu::gpuColorDescriptorCreate(bgr, cd);
+    sum = 0;
+    const uint8_t* pb = reinterpret_cast<const uint8_t*>(&cd);
+    for (size_t i = 0; i < 257; ++i) sum = sum * 1099511628211ull + pb[i];
+    printf("color %d %" PRIu64 "\n", int(cd.numColors), sum);
+    ColorDescriptor untouched;
+    untouched.numColors = 77;
+    cbird_gpu::gpuColorDescriptorCreate(img, untouched);  // CV_8UC1
+    printf("color_gray %d\n", int(untouched.numColors));
+  }
   return 0;
 }

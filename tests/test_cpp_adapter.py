@@ -71,6 +71,7 @@ def test_cvutil_dropins_compile():
     assert "gpuDctHash64(const cv::Mat& cvImg, bool inPlace = false)" in src
     assert "gpuMakeKeyPointHashes(const cv::Mat& cvImg, const KeyPointList& keyPoints, KeyPointHashList& outHashes)" in src
     assert "gpuSizeLongestSide(cv::Mat& img, int size)" in src
+    assert "gpuColorDescriptorCreate(const cv::Mat& cvImg, ColorDescriptor& desc)" in src
     assert "gpuMakeKeyPoints(const cv::Mat& cvImg, int numKeyPoints, KeyPointList& outKeypoints)" in src
     assert "gpuMakeKeyPointDescriptors(const cv::Mat& cvImg, KeyPointList& keyPoints, KeyPointDescriptors& outDescriptors)" in src
 
@@ -144,3 +145,15 @@ def test_cvutil_dropins_run_on_gpu(gpu, orc, w, h, seed):
         v = (v * 1099511628211 + int(k["octave"])) & 0xFFFFFFFFFFFFFFFF
     assert got["orb_kp"] == [len(kp2), v]
     assert got["orb_desc"] == [len(desc), _checksum(desc)]
+    # ColorDescriptor::create drop-in
+    from oracle import ColorCreateOracle
+
+    g4 = _xorshift_stream((seed + 99) & 0xFFFFFFFF)
+    bgr = np.zeros((h, w, 3), np.uint8)
+    for y in range(h):
+        for x in range(w):
+            for c in range(3):
+                bgr[y, x, c] = ((x // 23 + 2 * (y // 17) + c) % 5) * 50 + next(g4) % 7
+    want_cd, _ = ColorCreateOracle().create(bgr)
+    assert got["color"] == [int(want_cd[256]), _checksum(want_cd[:257])]
+    assert got["color_gray"] == [77]
