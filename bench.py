@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline time budget")
     ap.add_argument("--no-video", action="store_true", help="skip the configs[4] leg (DctVideoIndex sharded by video)")
     ap.add_argument("--video-clips", type=int, default=10_000)
+    ap.add_argument("--no-features", action="store_true",
+                    help="skip the indexer-stage leg (ORB, ColorDescriptor::create; reported beside the contract line)")
     return ap.parse_args()
 
 
@@ -315,6 +317,8 @@ def main():
         finally:
             ops.L.cbh_set_tuning(b"scan_mfma", 1)
         result["popcount_kernel_scan_ms"] = pop
+    if rank == 0 and world == 1 and not args.no_features:
+        result["indexer_stages"] = features_leg(torch, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, torch, imgs, state, n, dhts)
     if rank == 0:
@@ -322,6 +326,84 @@ def main():
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def features_leg(torch, dev):
+    """The indexer's feature stages, reported beside the contract line and never part
+    of `value`: ORB detect + describe on 2048 resident 400x300 grey images, ColorDescriptor::create on 4096 resident
+    256x192 BGR images (its clustering runs one lane per image: the rate grows with the batch).  Throughput only -- the
+    parity of both lives in the -m gpu tests and in smoke()."""
+    import ctypes as C
+
+    import numpy as np
+
+    from cbird_amd import _lib, orb
+
+    L = _lib.lib()
+    rng = np.random.default_rng(1)
+    out = {}
+
+    def scene(w, h, ch):
+        shape = (h, w) if ch == 1 else (h, w, ch)
+        img = np.full(shape, 128, np.int32)
+        for _ in range((w * h) // 1000):
+            x, y = int(rng.integers(0, w - 4)), int(rng.integers(0, h - 4))
+            img[y: y + int(rng.integers(4, h // 4)), x: x + int(rng.integers(4, w // 4))] = \
+                rng.integers(0, 256, None if ch == 1 else ch)
+        return (img + rng.integers(-4, 5, shape)).clip(0, 255).astype(np.uint8)
+
+    stream = torch.cuda.Stream()
+    # ---- ORB
+    n, w, h, cap = 2048, 400, 300, 512
+    orb.set_pattern(orb.synthetic_pattern())  # a stand-in for OpenCV's learned test pairs (cbird_amd/orb.py)
+    base = np.stack([scene(w, h, 1) for _ in range(32)])
+    d = torch.from_numpy(np.concatenate([base] * (n // 32))).to(dev)
+    off = np.arange(n, dtype=np.uint64) * np.uint64(w * h)
+    ww, hh = np.full(n, w, np.uint32), np.full(n, h, np.uint32)
+    d_kp = torch.zeros((n, cap, 6), dtype=torch.float32, device=dev)
+    d_after = torch.zeros((n, cap, 2), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((n, cap, 32), dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+
+    def run_orb():
+        _lib.check(L.cbh_orb_dev(d.data_ptr(), n, off.ctypes.data, ww.ctypes.data, hh.ctypes.data, ww.ctypes.data, 400, cap,
+                                 d_kp.data_ptr(), d_after.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(), 0,
+                                 C.c_void_p(stream.cuda_stream)), "orb")
+
+    with torch.cuda.stream(stream):
+        run_orb()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(3):
+            run_orb()
+        e1.record(stream)
+        stream.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    nk = int(d_cnt.sum().item())
+    out["orb_detect_describe"] = {"workload": f"{n} grey images {w}x{h} resident, 400 keypoints asked", "ms": round(ms, 3),
+                                  "images_per_s": n / ms * 1e3, "keypoints_per_s": nk / ms * 1e3}
+    del d, d_kp, d_after, d_desc
+    # ---- ColorDescriptor::create
+    n, w, h = 4096, 256, 192
+    base = np.stack([scene(w, h, 3) for _ in range(32)])
+    d = torch.from_numpy(np.concatenate([base] * (n // 32))).to(dev)
+    off = np.arange(n, dtype=np.uint64) * np.uint64(w * h * 3)
+    ww, hh, ss = np.full(n, w, np.uint32), np.full(n, h, np.uint32), np.full(n, 3 * w, np.uint32)
+    d_cd = torch.zeros((n, 258), dtype=torch.uint8, device=dev)
+    d_ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+
+    def run_cd():
+        _lib.check(L.cbh_color_descriptors_dev(d.data_ptr(), n, off.ctypes.data, ww.ctypes.data, hh.ctypes.data,
+                                               ss.ctypes.data, 3, d_cd.data_ptr(), d_ok.data_ptr(), 0,
+                                               C.c_void_p(stream.cuda_stream)), "color_descriptors")
+
+    run_cd()
+    t0 = time.perf_counter()
+    run_cd()  # returns when the descriptors are complete
+    dt = time.perf_counter() - t0
+    out["color_descriptor_create"] = {"workload": f"{n} BGR images {w}x{h} resident", "s": round(dt, 4),
+                                      "images_per_s": n / dt, "descriptors": int(d_ok.sum().item())}
+    return out
 
 
 def video_leg(args, torch, dist, dev, local_rank, rank, world, share):
