@@ -9,6 +9,9 @@
 //   makeKeyPoints / makeKeyPointDescriptors                   orb.hip                            (:878-884)
 //   makeKeyPointHashes on the keypoints compute() left        dcthash.hip (k_kp_hashes)          (:886-889)
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -33,7 +36,9 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
   cbh::DeviceGuard g(device);
   if (!g.ok) return CBH_E_NODEVICE;
   const size_t span1 = (size_t)(h - 1) * row_stride + (size_t)w * channels;
-  size_t per_chunk = std::max<size_t>(1, ((size_t)2048 << 20) / std::max(img_stride, span1));
+  // chunks of up to 8 GB of input (16384 images): the colour leg runs one lane per image, so its rate grows with the
+  // chunk (0.43 s for anything up to 4096 images, 0.48 s for 16384)
+  size_t per_chunk = std::max<size_t>(1, ((size_t)8192 << 20) / std::max(img_stride, span1));
   per_chunk = std::min<size_t>(std::min(per_chunk, n), 16384);
   const size_t slot = feats ? (size_t)rs * rs + 16 : 0;  // room per image in the packed resize buffer
   uint8_t *d_src = nullptr, *d_gray = nullptr, *d_res = nullptr, *d_desc = nullptr, *d_cdesc = nullptr, *d_cok = nullptr;
@@ -48,12 +53,13 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
   std::thread color_thread;
   auto cleanup = [&]() {
     if (color_thread.joinable()) color_thread.join();
-    if (s) (void)hipStreamSynchronize(s), (void)hipStreamDestroy(s);
     if (s2) (void)hipStreamSynchronize(s2), (void)hipStreamDestroy(s2);
     if (ev_up) (void)hipEventDestroy(ev_up);
+    if (s) (void)hipStreamSynchronize(s);
     for (void* q : {(void*)d_src, (void*)d_gray, (void*)d_res, (void*)d_desc, (void*)d_cdesc, (void*)d_cok, (void*)d_out,
                     (void*)d_kph, (void*)d_rects, (void*)d_kp, (void*)d_after, (void*)d_cnt})
-      if (q) (void)hipFree(q);
+      if (q) (void)hipFreeAsync(q, s);  // back to the cached pool (keep_pool_memory): the next call reuses it
+    if (s) (void)hipStreamSynchronize(s), (void)hipStreamDestroy(s);
   };
 #define CBH_TRY(call)                                             \
   do {                                                            \
@@ -67,24 +73,34 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
   CBH_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   CBH_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
   CBH_TRY(hipEventCreateWithFlags(&ev_up, hipEventDisableTiming));
-  CBH_TRY(hipMalloc(&d_src, (per_chunk - 1) * img_stride + span1));
-  if (channels != 1) CBH_TRY(hipMalloc(&d_gray, per_chunk * (size_t)w * h));
-  CBH_TRY(hipMalloc(&d_out, per_chunk * sizeof(uint64_t)));
-  CBH_TRY(hipMalloc(&d_rects, per_chunk * 4 * sizeof(int)));
+  CBH_TRY(hipMallocAsync((void**)&d_src, (per_chunk - 1) * img_stride + span1, s));
+  if (channels != 1) CBH_TRY(hipMallocAsync((void**)&d_gray, per_chunk * (size_t)w * h, s));
+  CBH_TRY(hipMallocAsync((void**)&d_out, per_chunk * sizeof(uint64_t), s));
+  CBH_TRY(hipMallocAsync((void**)&d_rects, per_chunk * 4 * sizeof(int), s));
   if (feats) {
-    CBH_TRY(hipMalloc(&d_res, per_chunk * slot));
-    CBH_TRY(hipMalloc(&d_kp, per_chunk * (size_t)cap * sizeof(cbh_keypoint)));
-    CBH_TRY(hipMalloc(&d_cnt, per_chunk * sizeof(uint32_t)));
+    CBH_TRY(hipMallocAsync((void**)&d_res, per_chunk * slot, s));
+    CBH_TRY(hipMallocAsync((void**)&d_kp, per_chunk * (size_t)cap * sizeof(cbh_keypoint), s));
+    CBH_TRY(hipMallocAsync((void**)&d_cnt, per_chunk * sizeof(uint32_t), s));
     if (a_orb) {
-      CBH_TRY(hipMalloc(&d_after, per_chunk * (size_t)cap * 2 * sizeof(float)));
-      CBH_TRY(hipMalloc(&d_desc, per_chunk * (size_t)cap * 32));
+      CBH_TRY(hipMallocAsync((void**)&d_after, per_chunk * (size_t)cap * 2 * sizeof(float), s));
+      CBH_TRY(hipMallocAsync((void**)&d_desc, per_chunk * (size_t)cap * 32, s));
     }
-    if (a_fdct) CBH_TRY(hipMalloc(&d_kph, per_chunk * (size_t)cap * sizeof(uint64_t)));
+    if (a_fdct) CBH_TRY(hipMallocAsync((void**)&d_kph, per_chunk * (size_t)cap * sizeof(uint64_t), s));
   }
   if (a_color && channels != 1) {
-    CBH_TRY(hipMalloc(&d_cdesc, per_chunk * 258));
-    CBH_TRY(hipMalloc(&d_cok, per_chunk));
+    CBH_TRY(hipMallocAsync((void**)&d_cdesc, per_chunk * 258, s));
+    CBH_TRY(hipMallocAsync((void**)&d_cok, per_chunk, s));
   }
+  const bool trace = getenv("CBH_PIPELINE_TRACE") != nullptr;  // stage times of each chunk on stderr
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto t_last = now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    (void)hipStreamSynchronize(s);
+    const auto t = now();
+    fprintf(stderr, "[cbh_index_images] %-18s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+    t_last = t;
+  };
   std::vector<int> hr(per_chunk * 4);
   std::vector<uint64_t> off(per_chunk), coff(per_chunk);
   std::vector<uint32_t> ws(per_chunk), hs(per_chunk), cw(per_chunk, (uint32_t)w), chh(per_chunk, (uint32_t)h),
@@ -93,7 +109,9 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
   std::vector<float> hafter, tri;
   for (size_t i0 = 0; rc == CBH_OK && i0 < n; i0 += per_chunk) {
     const size_t m = std::min(per_chunk, n - i0);
+    lap("(setup)");
     CBH_TRY(hipMemcpyAsync(d_src, imgs + i0 * img_stride, (m - 1) * img_stride + span1, hipMemcpyHostToDevice, s));
+    lap("upload");
     const uint8_t* gray = d_src;
     size_t gs = row_stride, gi = img_stride;
     if (channels != 1) {
@@ -144,6 +162,7 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
       for (size_t i = 0; i < m; ++i) hr[i * 4] = hr[i * 4 + 1] = 0, hr[i * 4 + 2] = w, hr[i * 4 + 3] = h;
     }
     if (rects) memcpy(rects + i0 * 4, hr.data(), m * 4 * sizeof(int));
+    lap("gray + autocrop");
     if (a_dct) {
       if (!cropped) {
         rc = cbh::launch_dcthash(gray, m, w, h, gs, gi, d_out, s);
@@ -159,6 +178,7 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
       if (rc) break;
       CBH_TRY(hipMemcpyAsync(dct_hashes + i0, d_out, m * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     }
+    lap("dct hash");
     if (!feats) {
       CBH_TRY(hipStreamSynchronize(s));
       if (color_thread.joinable()) color_thread.join();
@@ -186,6 +206,7 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
       cur += run * (size_t)dw * dh;
     }
     if (rc) break;
+    lap("resize");
     if (resized_dims)
       for (size_t i = 0; i < m; ++i) resized_dims[2 * (i0 + i)] = (int)ws[i], resized_dims[2 * (i0 + i) + 1] = (int)hs[i];
     // images the resize rejected get a 1x1 stand-in geometry: no pyramid level, no keypoints
@@ -195,6 +216,7 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
     rc = cbh_orb_dev(d_res, m, off.data(), ow.data(), oh.data(), ow.data(), p->num_features, cap, d_kp, a_orb ? d_after : nullptr,
                      a_orb ? d_desc : nullptr, d_cnt, device, s);
     if (rc) break;
+    lap("orb");
     hkp.resize(m * (size_t)cap);
     CBH_TRY(hipMemcpyAsync(cnt.data(), d_cnt, m * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     CBH_TRY(hipMemcpyAsync(hkp.data(), d_kp, m * (size_t)cap * sizeof(cbh_keypoint), hipMemcpyDeviceToHost, s));
@@ -204,6 +226,7 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
       CBH_TRY(hipMemcpyAsync(desc + i0 * (size_t)cap * 32, d_desc, m * (size_t)cap * 32, hipMemcpyDeviceToHost, s));
     }
     CBH_TRY(hipStreamSynchronize(s));
+    lap("orb download");
     // the keypoint list as processImage holds it after makeKeyPointDescriptors (which rewrites pt) -- or as detected
     for (size_t i = 0; i < m; ++i) {
       kp_counts[i0 + i] = cnt[i];
@@ -214,6 +237,7 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
         kp[(i0 + i) * cap + j] = k;
       }
     }
+    lap("keypoint lists");
     if (a_fdct) {
       tri.clear();
       kp_first[0] = 0;
@@ -225,9 +249,11 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
         }
         kp_first[i + 1] = (uint32_t)(tri.size() / 3);
       }
+      lap("kp triples");
       rc = cbh_keypoint_hashes_dev(d_res, m, off.data(), ow.data(), oh.data(), ow.data(), tri.data(), kp_first.data(), d_kph,
                                    out_first.data(), device, s);
       if (rc) break;
+      lap("kp hashes");
       const size_t total = out_first[m];
       std::vector<uint64_t> hh(std::max<size_t>(total, 1));
       if (total) CBH_TRY(hipMemcpyAsync(hh.data(), d_kph, total * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
