@@ -523,10 +523,14 @@ def cpu_baseline(args, torch, imgs, state, n, dhts):
         kind = "port"
         what = "brute-force popcount scan (oracle/cbird_oracle.c)"
     agrees = True
+    differing = {}
     for dht in dhts:
         gpu_cnt = state[dht][2][torch.from_numpy(needles_ix).to(state[dht][2].device)].cpu().numpy()
         # the real tree also returns removed (id 0) slots; the synthetic index has none
-        agrees &= bool((gpu_cnt.astype(np.int64) == counts[dht].astype(np.int64)).all())
+        bad = int((gpu_cnt.astype(np.int64) != counts[dht].astype(np.int64)).sum())
+        if bad:
+            differing[str(dht)] = bad
+        agrees &= bad == 0
     out.update({
         "value": float(m) * n * len(dhts) / t_find,
         "unit": "needle x index pair-equivalents/s (tree-pruned)" if use_ref else "64-bit Hamming comparisons/s",
@@ -534,6 +538,7 @@ def cpu_baseline(args, torch, imgs, state, n, dhts):
         "sample": (f"{m} needles of the 1M x 1M job x dht {dhts} against the full {n}-entry index with {what}, "
                    f"{cores} threads, {t_find:.1f} s; hash leg: {m_img} images, {t_hash:.1f} s"),
         "find_agrees_with_gpu": agrees,
+        "find_needles_differing_per_dht": differing,
     })
     return out
 

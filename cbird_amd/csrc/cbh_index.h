@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -130,7 +131,7 @@ struct Workspace {
     if (d_counts) (void)hipFree(d_counts);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
-    if (stream) (void)hipStreamDestroy(stream);
+    if (stream) cbh::stream_destroy(stream);
   }
 };
 

@@ -4,6 +4,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "cbird_hip.h"
@@ -11,6 +15,72 @@
 namespace cbh {
 
 void set_last_error(const char* where, hipError_t e);
+
+// ---- stream-ordered scratch memory: one pool PER STREAM -------------------------------------------------------------
+// Every kernel launcher takes its scratch from the stream-ordered allocator and gives it back right behind the last
+// kernel that uses it.  With the device's default pool that memory can be handed to another stream while the first
+// one is still running: measured here (round 2) -- the pipelined threshold sweep, whose scan (needle tiles, main
+// stream) overlaps the previous threshold's cut (counting-select scratch, side stream), returned wrong match counts
+// in 4 of 16 runs at 40k images and in none of 16 once the two stopped sharing a pool.  So each stream gets its own
+// pool (created on first use, kept at its high-water mark); nothing is ever reused across streams.
+struct StreamPools {
+  std::mutex mu;
+  std::map<std::pair<int, hipStream_t>, hipMemPool_t> pools;
+  std::map<int, std::vector<hipMemPool_t>> idle;  // pools of destroyed streams, adopted by the next new stream
+};
+inline StreamPools& stream_pools() {
+  static StreamPools* p = new StreamPools;  // never destroyed: calls may arrive during process teardown
+  return *p;
+}
+inline hipError_t malloc_async(void** p, size_t bytes, hipStream_t s) {
+  if (!s) return hipMallocAsync(p, bytes, s);  // the NULL stream is synchronous by contract: the default pool
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  hipMemPool_t pool = nullptr;
+  {
+    StreamPools& sp = stream_pools();
+    std::lock_guard<std::mutex> lk(sp.mu);
+    auto it = sp.pools.find({dev, s});
+    if (it != sp.pools.end()) {
+      pool = it->second;
+    } else {
+      std::vector<hipMemPool_t>& idle = sp.idle[dev];
+      if (!idle.empty()) {  // everything in it is free and its stream was synchronised before it went away
+        pool = idle.back();
+        idle.pop_back();
+      } else {
+        hipMemPoolProps props;
+        memset(&props, 0, sizeof props);
+        props.allocType = hipMemAllocationTypePinned;
+        props.handleTypes = hipMemHandleTypeNone;
+        props.location.type = hipMemLocationTypeDevice;
+        props.location.id = dev;
+        if ((e = hipMemPoolCreate(&pool, &props)) != hipSuccess) return e;
+        uint64_t keep = ~0ull;  // freed blocks stay cached: the next call finds its scratch mapped
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+      }
+      sp.pools.emplace(std::make_pair(dev, s), pool);
+    }
+  }
+  return hipMallocFromPoolAsync(p, bytes, pool, s);
+}
+// for streams the library creates itself: the stream goes, its pool waits for the next one
+inline void stream_destroy(hipStream_t s) {
+  if (!s) return;
+  (void)hipStreamSynchronize(s);
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    StreamPools& sp = stream_pools();
+    std::lock_guard<std::mutex> lk(sp.mu);
+    auto it = sp.pools.find({dev, s});
+    if (it != sp.pools.end()) {
+      sp.idle[dev].push_back(it->second);
+      sp.pools.erase(it);
+    }
+  }
+  (void)hipStreamDestroy(s);
+}
 
 #define CBH_HIP(call)                          \
   do {                                         \

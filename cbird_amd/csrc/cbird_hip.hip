@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
@@ -132,7 +133,7 @@ int cbh_dcthash_batch(const uint8_t* imgs, size_t n, int w, int h, size_t row_st
       rc = CBH_E_HIP;
     }
   }
-  if (s) (void)hipStreamDestroy(s);
+  if (s) cbh::stream_destroy(s);
   if (d_imgs) (void)hipFree(d_imgs);
   if (d_out) (void)hipFree(d_out);
   return rc;
@@ -214,7 +215,7 @@ int rect_hashes_host(const uint8_t* imgs, size_t imgs_bytes, const std::vector<c
       rc = CBH_E_HIP;
     }
   }
-  if (s) (void)hipStreamDestroy(s);
+  if (s) cbh::stream_destroy(s);
   if (d_imgs) (void)hipFree(d_imgs);
   if (d_out) (void)hipFree(d_out);
   return rc;
@@ -275,7 +276,7 @@ int cbh_keypoint_hashes(const uint8_t* imgs, size_t imgs_bytes, size_t n, const 
       rc = CBH_E_HIP;
     }
   }
-  if (s) (void)hipStreamDestroy(s);
+  if (s) cbh::stream_destroy(s);
   if (d_imgs) (void)hipFree(d_imgs);
   if (d_out) (void)hipFree(d_out);
   return rc;
@@ -590,7 +591,7 @@ static int find_batch_core(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, s
     void* scratch = nullptr;
     unsigned* d_status = nullptr;
     const size_t ncap = std::min<size_t>(ws->rec_cap, (size_t)*total + 1);  // slots past the count are never read
-    CBH_HIP(hipMallocAsync(&scratch, topk_scratch_bytes(nq, ncap) + 16, s));
+    CBH_HIP(cbh::malloc_async(&scratch, topk_scratch_bytes(nq, ncap) + 16, s));
     d_status = (unsigned*)((char*)scratch + topk_scratch_bytes(nq, ncap));
     rc = topk_scratch_init(scratch, nq, s);
     if (!rc) rc = launch_records_topk(ws->d_total, 1, 0, ncap, nq, k, d_out, d_counts, d_status, scratch, s);
@@ -690,10 +691,10 @@ int cbh_records_topk_dev(const void* d_blocks, size_t n_blocks, size_t block_str
   DeviceGuard g(device);
   if (!g.ok) return CBH_E_NODEVICE;
   hipStream_t s = (hipStream_t)stream;
-  void* scratch = nullptr;  // stream-ordered, recycled by the pool between calls
-  hipError_t e = hipMallocAsync(&scratch, topk_scratch_bytes(nq, n_blocks * cap), s);
+  void* scratch = nullptr;  // stream-ordered, recycled by this stream's pool between calls
+  hipError_t e = cbh::malloc_async(&scratch, topk_scratch_bytes(nq, n_blocks * cap), s);
   if (e != hipSuccess) {
-    set_last_error("hipMallocAsync(topk scratch)", e);
+    set_last_error("malloc_async(topk scratch)", e);
     return CBH_E_NOMEM;
   }
   int rc = topk_scratch_init(scratch, nq, s);
@@ -717,11 +718,11 @@ int cbh_sort_records_dev(void* d_records, size_t n, size_t nq, int device, void*
   void* tmp = nullptr;
   const size_t tmp_bytes = sort_records_scratch_bytes(n);
   // stream-ordered scratch: no device-wide synchronisation, the pool recycles the blocks between calls
-  CBH_HIP(hipMallocAsync((void**)&alt, n * sizeof(cbh_record), s));
-  hipError_t e = hipMallocAsync(&tmp, tmp_bytes ? tmp_bytes : 16, s);
+  CBH_HIP(cbh::malloc_async((void**)&alt, n * sizeof(cbh_record), s));
+  hipError_t e = cbh::malloc_async(&tmp, tmp_bytes ? tmp_bytes : 16, s);
   if (e != hipSuccess) {
     (void)hipFreeAsync(alt, s);
-    set_last_error("hipMallocAsync(sort scratch)", e);
+    set_last_error("cbh::malloc_async(sort scratch)", e);
     return CBH_E_NOMEM;
   }
   int rc = launch_sort_records((cbh_record*)d_records, alt, n, nq, tmp, tmp_bytes, s);
@@ -905,7 +906,7 @@ int cbh_time_dcthash_dev(const void* d_imgs, size_t n, int w, int h, size_t row_
   CBH_HIP(hipEventElapsedTime(&ms, e0, e1));
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  (void)hipStreamDestroy(s);
+  cbh::stream_destroy(s);
   *ms_avg = ms / (float)iters;
   return rc;
 }

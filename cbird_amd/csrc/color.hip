@@ -561,7 +561,7 @@ void cbh_color_destroy(cbh_color* c) {
                   (void*)c->d_scores, (void*)c->d_keys, (void*)c->d_keys_alt, c->d_tmp, (void*)c->d_hist,
                   (void*)c->d_thr, (void*)c->d_smin, (void*)c->d_ncand, (void*)c->d_valid, (void*)c->d_cand})
     if (p) (void)hipFree(p);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream) cbh::stream_destroy(c->stream);
   delete c;
 }
 

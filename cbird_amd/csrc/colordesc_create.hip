@@ -754,7 +754,7 @@ int launch_color_descriptors(const uint8_t* d_imgs, size_t n, const uint64_t* im
   int* d_counts = nullptr;
   hipError_t e = hipSuccess;
   auto alloc = [&](void** p, size_t bytes) {
-    if (e == hipSuccess) e = hipMallocAsync(p, std::max<size_t>(bytes, 256), s);
+    if (e == hipSuccess) e = cbh::malloc_async(p, std::max<size_t>(bytes, 256), s);
   };
   alloc((void**)&d_images, n * sizeof(CdImage));
   alloc((void**)&d_masks, masks.size());
@@ -855,7 +855,7 @@ int cbh_color_descriptors(const uint8_t* imgs, size_t imgs_bytes, size_t n, cons
   if (s) (void)hipStreamSynchronize(s);
   for (void* p : {(void*)d_imgs, (void*)d_descs, (void*)d_ok})
     if (p) (void)hipFree(p);
-  if (s) (void)hipStreamDestroy(s);
+  if (s) cbh::stream_destroy(s);
   return rc;
 }
 

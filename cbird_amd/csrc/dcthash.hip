@@ -2589,7 +2589,7 @@ int launch_rect_hashes(uint8_t* d_base, const std::vector<RectImageDesc>& images
   hipError_t e = hipSuccess;
   auto up = [&](void** dst, const void* src, size_t bytes) {
     if (e != hipSuccess) return;
-    if ((e = hipMallocAsync(dst, bytes, stream)) != hipSuccess) return;
+    if ((e = cbh::malloc_async(dst, bytes, stream)) != hipSuccess) return;
     e = hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, stream);
   };
   up((void**)&d_images, imgs.data(), imgs.size() * sizeof(RectImage));
@@ -2597,7 +2597,7 @@ int launch_rect_hashes(uint8_t* d_base, const std::vector<RectImageDesc>& images
   up((void**)&d_axes, rt.axes.data(), rt.axes.size() * sizeof(AxisTab));
   up((void**)&d_apool, rt.apool.data(), rt.apool.size() * sizeof(AreaTab));
   up((void**)&d_ipool, rt.ipool.data(), rt.ipool.size() * sizeof(int));
-  if (e == hipSuccess) e = hipMallocAsync((void**)&d_scr, (size_t)grid * max_blur, stream);
+  if (e == hipSuccess) e = cbh::malloc_async((void**)&d_scr, (size_t)grid * max_blur, stream);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_rect_hashes, dim3(grid), dim3(kThreads), 0, stream, d_base, d_images, (unsigned)imgs.size(),
                        d_jobs, d_axes, d_apool, d_ipool, d_scr, max_blur, tabs, write_back, d_out, d_tiles);
@@ -2692,7 +2692,7 @@ int launch_keypoint_hashes(uint8_t* d_base, size_t n, const uint64_t* img_off, c
   hipError_t e = hipSuccess;
   auto up = [&](void** dst, const void* src, size_t bytes) {
     if (e != hipSuccess) return;
-    if ((e = hipMallocAsync(dst, bytes, stream)) != hipSuccess) return;
+    if ((e = cbh::malloc_async(dst, bytes, stream)) != hipSuccess) return;
     e = hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, stream);
   };
   up((void**)&d_images, imgs.data(), imgs.size() * sizeof(KpImage));
@@ -2700,10 +2700,10 @@ int launch_keypoint_hashes(uint8_t* d_base, size_t n, const uint64_t* img_off, c
   up((void**)&d_sizes, sizes.data(), sizes.size() * sizeof(SizeInfo));
   up((void**)&d_apool, apool.data(), apool.size() * sizeof(AreaTab));
   up((void**)&d_ipool, ipool.data(), ipool.size() * sizeof(int));
-  if (e == hipSuccess) e = hipMallocAsync((void**)&d_scr, (size_t)grid * scratch_per_wg, stream);
-  if (e == hipSuccess) e = hipMallocAsync((void**)&d_slots, nkp * sizeof(uint64_t), stream);
-  if (e == hipSuccess) e = hipMallocAsync((void**)&d_counts, n * sizeof(unsigned), stream);
-  if (e == hipSuccess) e = hipMallocAsync((void**)&d_first, (n + 1) * sizeof(unsigned), stream);
+  if (e == hipSuccess) e = cbh::malloc_async((void**)&d_scr, (size_t)grid * scratch_per_wg, stream);
+  if (e == hipSuccess) e = cbh::malloc_async((void**)&d_slots, nkp * sizeof(uint64_t), stream);
+  if (e == hipSuccess) e = cbh::malloc_async((void**)&d_counts, n * sizeof(unsigned), stream);
+  if (e == hipSuccess) e = cbh::malloc_async((void**)&d_first, (n + 1) * sizeof(unsigned), stream);
   if (e == hipSuccess && smem > 48 * 1024)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_kp_hashes), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
@@ -2807,7 +2807,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
       const size_t fsmem = (size_t)(kBlurRB + K_ - 1) * fpitch + (size_t)(integer ? 0 : at.xn) * sizeof(float);
       const size_t per_chunk_f = std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)h * 128));
       float* d_rowsf = nullptr;
-      CBH_HIP(hipMallocAsync((void**)&d_rowsf, std::min(per_chunk_f, n) * (size_t)h * 32 * sizeof(float), stream));
+      CBH_HIP(cbh::malloc_async((void**)&d_rowsf, std::min(per_chunk_f, n) * (size_t)h * 32 * sizeof(float), stream));
       for (size_t i0 = 0; i0 < n; i0 += per_chunk_f) {
         const size_t m = std::min(per_chunk_f, n - i0);
         const unsigned char* src = d_imgs + i0 * img_stride;
@@ -2903,8 +2903,8 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     const size_t mc = std::min(per_chunk, n);
     unsigned char* d_blur = nullptr;
     float* d_rows = nullptr;
-    CBH_HIP(hipMallocAsync((void**)&d_blur, mc * (size_t)w * h, stream));
-    CBH_HIP(hipMallocAsync((void**)&d_rows, mc * (size_t)yn * 32 * sizeof(float), stream));
+    CBH_HIP(cbh::malloc_async((void**)&d_blur, mc * (size_t)w * h, stream));
+    CBH_HIP(cbh::malloc_async((void**)&d_rows, mc * (size_t)yn * 32 * sizeof(float), stream));
     for (size_t i0 = 0; i0 < n; i0 += per_chunk) {
       const size_t m = std::min(per_chunk, n - i0);
       const unsigned char* src = d_imgs + i0 * img_stride;
@@ -2950,7 +2950,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     const size_t smem = (size_t)(band + 2 * (K_ / 2)) * (size_t)w * 3;
     const size_t per_chunk = std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)w * h));
     unsigned char* d_blur = nullptr;
-    CBH_HIP(hipMallocAsync((void**)&d_blur, std::min(per_chunk, n) * (size_t)w * h, stream));
+    CBH_HIP(cbh::malloc_async((void**)&d_blur, std::min(per_chunk, n) * (size_t)w * h, stream));
     for (size_t i0 = 0; i0 < n; i0 += per_chunk) {
       const size_t m = std::min(per_chunk, n - i0);
       dim3 g1((unsigned)m, (unsigned)((h + band - 1) / band)), block(kThreads);

@@ -140,7 +140,7 @@ int fdct_core(cbh_idx64* idx, const uint64_t* hashes, const std::vector<Needle>&
   {
     void* scratch = nullptr;
     const size_t ncap = std::min<size_t>(ws->rec_cap, (size_t)total + 1);
-    CBH_HIP(hipMallocAsync(&scratch, topk_scratch_bytes(nq, ncap) + 16, s));
+    CBH_HIP(cbh::malloc_async(&scratch, topk_scratch_bytes(nq, ncap) + 16, s));
     unsigned* d_status = (unsigned*)((char*)scratch + topk_scratch_bytes(nq, ncap));
     rc = topk_scratch_init(scratch, nq, s);
     if (!rc) rc = launch_records_topk(ws->d_total, 1, 0, ncap, nq, k, ws->d_out, ws->d_counts, d_status, scratch, s);
@@ -163,8 +163,8 @@ int fdct_core(cbh_idx64* idx, const uint64_t* hashes, const std::vector<Needle>&
     for (size_t j = needles[i].begin; j < needles[i].end; ++j) qneedle[j] = (uint32_t)i;
   }
   uint32_t *d_qneedle = nullptr, *d_nid = nullptr;
-  hipError_t e = hipMallocAsync((void**)&d_qneedle, nq * 4, s);
-  if (e == hipSuccess) e = hipMallocAsync((void**)&d_nid, std::max<size_t>(1, nid.size()) * 4, s);
+  hipError_t e = cbh::malloc_async((void**)&d_qneedle, nq * 4, s);
+  if (e == hipSuccess) e = cbh::malloc_async((void**)&d_nid, std::max<size_t>(1, nid.size()) * 4, s);
   if (e == hipSuccess) e = hipMemcpyAsync(d_qneedle, qneedle.data(), nq * 4, hipMemcpyHostToDevice, s);
   if (e == hipSuccess && !nid.empty()) e = hipMemcpyAsync(d_nid, nid.data(), nid.size() * 4, hipMemcpyHostToDevice, s);
   std::vector<cbh_nmatch> flat;

@@ -176,7 +176,7 @@ int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, siz
   const uint32_t n_tiles = (uint32_t)((nq + 31) / 32);
   const uint32_t nq_pad = n_tiles * 32u;
   uint4* qx = nullptr;
-  CBH_HIP(hipMallocAsync((void**)&qx, (size_t)nq_pad * 128u, stream));
+  CBH_HIP(cbh::malloc_async((void**)&qx, (size_t)nq_pad * 128u, stream));
   hipLaunchKernelGGL(k_expand_needles256, dim3((8u * nq_pad + 255u) / 256u), dim3(256), 0, stream,
                      reinterpret_cast<const uint32_t*>(d_q), (uint32_t)nq, nq_pad, qx);
   const bool pre128_ = g_scan256_pre && thresh <= kPre128MaxThresh;

@@ -561,7 +561,7 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
   const uint32_t n_triples = (uint32_t)((nq + 95) / 96);
   const uint32_t nq_pad = (uint32_t)((nq + 191) / 192) * 192u;  // whole pairs (64) and whole triples (96)
   uint4* qx = nullptr;
-  CBH_HIP(hipMallocAsync((void**)&qx, (size_t)nq_pad * 32u, stream));
+  CBH_HIP(cbh::malloc_async((void**)&qx, (size_t)nq_pad * 32u, stream));
   hipLaunchKernelGGL(k_expand_needles, dim3((2u * nq_pad + 255u) / 256u), dim3(256), 0, stream, d_q,
                      (uint32_t)nq, nq_pad, qx);
   const uint32_t ht = (uint32_t)g_mfma_ht;

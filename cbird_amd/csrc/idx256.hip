@@ -345,7 +345,7 @@ void cbh_idx256_destroy(cbh_idx256* ix) {
   if (ix->h_total) (void)hipHostFree(ix->h_total);
   if (ix->ev0) (void)hipEventDestroy(ix->ev0);
   if (ix->ev1) (void)hipEventDestroy(ix->ev1);
-  if (ix->stream) (void)hipStreamDestroy(ix->stream);
+  if (ix->stream) cbh::stream_destroy(ix->stream);
   delete ix;
 }
 

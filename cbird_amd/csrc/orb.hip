@@ -912,7 +912,7 @@ int launch_orb(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const u
   int* d_pat = nullptr;
   hipError_t e = hipSuccess;
   auto alloc = [&](void** p, size_t bytes) {
-    if (e == hipSuccess) e = hipMallocAsync(p, std::max<size_t>(bytes, 256), s);
+    if (e == hipSuccess) e = cbh::malloc_async(p, std::max<size_t>(bytes, 256), s);
   };
   alloc((void**)&d_images, n * sizeof(OrbImage));
   alloc((void**)&d_pyr, pyr_bytes + 64);
@@ -1012,7 +1012,7 @@ int launch_orb_describe(const uint8_t* d_imgs, size_t n, const uint64_t* img_off
   float* d_xy = nullptr;
   hipError_t e = hipSuccess;
   auto alloc = [&](void** p, size_t bytes) {
-    if (e == hipSuccess) e = hipMallocAsync(p, std::max<size_t>(bytes, 256), s);
+    if (e == hipSuccess) e = cbh::malloc_async(p, std::max<size_t>(bytes, 256), s);
   };
   alloc((void**)&d_images, n * sizeof(OrbImage));
   alloc((void**)&d_pyr, pl.pyr_bytes + 64);
@@ -1137,7 +1137,7 @@ int cbh_orb(const uint8_t* imgs, size_t imgs_bytes, size_t n, const uint64_t* im
   if (s) (void)hipStreamSynchronize(s);
   for (void* p : {(void*)d_imgs, (void*)d_kp, (void*)d_after, (void*)d_desc, (void*)d_counts})
     if (p) (void)hipFree(p);
-  if (s) (void)hipStreamDestroy(s);
+  if (s) cbh::stream_destroy(s);
   return rc;
 }
 
@@ -1171,7 +1171,7 @@ int cbh_orb_describe(const uint8_t* imgs, size_t imgs_bytes, size_t n, const uin
                                   out_first, s);
   if (s) (void)hipStreamSynchronize(s);
   if (d_imgs) (void)hipFree(d_imgs);
-  if (s) (void)hipStreamDestroy(s);
+  if (s) cbh::stream_destroy(s);
   return rc;
 }
 

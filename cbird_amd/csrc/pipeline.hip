@@ -9,10 +9,12 @@
 //   makeKeyPoints / makeKeyPointDescriptors                   orb.hip                            (:878-884)
 //   makeKeyPointHashes on the keypoints compute() left        dcthash.hip (k_kp_hashes)          (:886-889)
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <thread>
 #include <vector>
 
@@ -53,13 +55,13 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
   std::thread color_thread;
   auto cleanup = [&]() {
     if (color_thread.joinable()) color_thread.join();
-    if (s2) (void)hipStreamSynchronize(s2), (void)hipStreamDestroy(s2);
+    if (s2) (void)hipStreamSynchronize(s2), cbh::stream_destroy(s2);
     if (ev_up) (void)hipEventDestroy(ev_up);
     if (s) (void)hipStreamSynchronize(s);
     for (void* q : {(void*)d_src, (void*)d_gray, (void*)d_res, (void*)d_desc, (void*)d_cdesc, (void*)d_cok, (void*)d_out,
                     (void*)d_kph, (void*)d_rects, (void*)d_kp, (void*)d_after, (void*)d_cnt})
       if (q) (void)hipFreeAsync(q, s);  // back to the cached pool (keep_pool_memory): the next call reuses it
-    if (s) (void)hipStreamSynchronize(s), (void)hipStreamDestroy(s);
+    if (s) (void)hipStreamSynchronize(s), cbh::stream_destroy(s);
   };
 #define CBH_TRY(call)                                             \
   do {                                                            \
@@ -73,23 +75,23 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
   CBH_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   CBH_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
   CBH_TRY(hipEventCreateWithFlags(&ev_up, hipEventDisableTiming));
-  CBH_TRY(hipMallocAsync((void**)&d_src, (per_chunk - 1) * img_stride + span1, s));
-  if (channels != 1) CBH_TRY(hipMallocAsync((void**)&d_gray, per_chunk * (size_t)w * h, s));
-  CBH_TRY(hipMallocAsync((void**)&d_out, per_chunk * sizeof(uint64_t), s));
-  CBH_TRY(hipMallocAsync((void**)&d_rects, per_chunk * 4 * sizeof(int), s));
+  CBH_TRY(cbh::malloc_async((void**)&d_src, (per_chunk - 1) * img_stride + span1, s));
+  if (channels != 1) CBH_TRY(cbh::malloc_async((void**)&d_gray, per_chunk * (size_t)w * h, s));
+  CBH_TRY(cbh::malloc_async((void**)&d_out, per_chunk * sizeof(uint64_t), s));
+  CBH_TRY(cbh::malloc_async((void**)&d_rects, per_chunk * 4 * sizeof(int), s));
   if (feats) {
-    CBH_TRY(hipMallocAsync((void**)&d_res, per_chunk * slot, s));
-    CBH_TRY(hipMallocAsync((void**)&d_kp, per_chunk * (size_t)cap * sizeof(cbh_keypoint), s));
-    CBH_TRY(hipMallocAsync((void**)&d_cnt, per_chunk * sizeof(uint32_t), s));
+    CBH_TRY(cbh::malloc_async((void**)&d_res, 2 * per_chunk * slot, s));  // the chunk-wide pass + the odd images redone
+    CBH_TRY(cbh::malloc_async((void**)&d_kp, per_chunk * (size_t)cap * sizeof(cbh_keypoint), s));
+    CBH_TRY(cbh::malloc_async((void**)&d_cnt, per_chunk * sizeof(uint32_t), s));
     if (a_orb) {
-      CBH_TRY(hipMallocAsync((void**)&d_after, per_chunk * (size_t)cap * 2 * sizeof(float), s));
-      CBH_TRY(hipMallocAsync((void**)&d_desc, per_chunk * (size_t)cap * 32, s));
+      CBH_TRY(cbh::malloc_async((void**)&d_after, per_chunk * (size_t)cap * 2 * sizeof(float), s));
+      CBH_TRY(cbh::malloc_async((void**)&d_desc, per_chunk * (size_t)cap * 32, s));
     }
-    if (a_fdct) CBH_TRY(hipMallocAsync((void**)&d_kph, per_chunk * (size_t)cap * sizeof(uint64_t), s));
+    if (a_fdct) CBH_TRY(cbh::malloc_async((void**)&d_kph, per_chunk * (size_t)cap * sizeof(uint64_t), s));
   }
   if (a_color && channels != 1) {
-    CBH_TRY(hipMallocAsync((void**)&d_cdesc, per_chunk * 258, s));
-    CBH_TRY(hipMallocAsync((void**)&d_cok, per_chunk, s));
+    CBH_TRY(cbh::malloc_async((void**)&d_cdesc, per_chunk * 258, s));
+    CBH_TRY(cbh::malloc_async((void**)&d_cok, per_chunk, s));
   }
   const bool trace = getenv("CBH_PIPELINE_TRACE") != nullptr;  // stage times of each chunk on stderr
   auto now = [] { return std::chrono::steady_clock::now(); };
@@ -163,16 +165,43 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
     }
     if (rects) memcpy(rects + i0 * 4, hr.data(), m * 4 * sizeof(int));
     lap("gray + autocrop");
+    // Launch plan for the per-geometry stages (hash, resize).  Runs of equal kept regions take one launch each; when
+    // a few odd regions are scattered among images that share one region (photos: almost all keep the whole frame),
+    // it is cheaper to run that region over the WHOLE chunk once and redo the odd images one by one.
+    size_t n_runs = 0;
+    for (size_t i = 0, run = 1; i < m; i += run, ++n_runs) {
+      run = 1;
+      while (i + run < m && !memcmp(&hr[i * 4], &hr[(i + run) * 4], 4 * sizeof(int))) ++run;
+    }
+    int mode[4] = {0, 0, w, h};
+    size_t n_odd = 0;
+    {
+      std::map<std::array<int, 4>, size_t> freq;
+      for (size_t i = 0; i < m; ++i) ++freq[{hr[i * 4], hr[i * 4 + 1], hr[i * 4 + 2], hr[i * 4 + 3]}];
+      size_t best = 0;
+      for (const auto& kv : freq)
+        if (kv.second > best) best = kv.second, memcpy(mode, kv.first.data(), sizeof mode);
+      n_odd = m - best;
+    }
+    const bool by_mode = 1 + n_odd < n_runs;
+    auto is_mode = [&](size_t i) { return !memcmp(&hr[i * 4], mode, sizeof mode); };
+    auto hash_run = [&](size_t i, size_t run, const int* r) {
+      if (r[0] == 0 && r[1] == 0 && r[2] == w && r[3] == h) return cbh::launch_dcthash(gray + i * gi, run, w, h, gs, gi, d_out + i, s);
+      const cbh::HashView view{w, h, r[0], r[1]};  // the blur sees the cropped-away margins (a cv::Mat view)
+      return cbh::launch_dcthash(gray + i * gi, run, r[2] - r[0], r[3] - r[1], gs, gi, d_out + i, s, nullptr, &view);
+    };
     if (a_dct) {
       if (!cropped) {
         rc = cbh::launch_dcthash(gray, m, w, h, gs, gi, d_out, s);
+      } else if (by_mode) {
+        rc = hash_run(0, m, mode);
+        for (size_t i = 0; i < m && rc == CBH_OK; ++i)
+          if (!is_mode(i)) rc = hash_run(i, 1, &hr[i * 4]);
       } else {
         for (size_t i = 0, run = 1; i < m && rc == CBH_OK; i += run) {
-          const int* r = &hr[i * 4];
           run = 1;
-          while (i + run < m && !memcmp(r, &hr[(i + run) * 4], 4 * sizeof(int))) ++run;
-          const cbh::HashView view{w, h, r[0], r[1]};  // the blur sees the cropped-away margins (a cv::Mat view)
-          rc = cbh::launch_dcthash(gray + i * gi, run, r[2] - r[0], r[3] - r[1], gs, gi, d_out + i, s, nullptr, &view);
+          while (i + run < m && !memcmp(&hr[i * 4], &hr[(i + run) * 4], 4 * sizeof(int))) ++run;
+          rc = hash_run(i, run, &hr[i * 4]);
         }
       }
       if (rc) break;
@@ -185,13 +214,10 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
       rc = color_rc;
       continue;
     }
-    // sizeLongestSide(cvGray, 400) of each kept region, one launch per run of equal regions; the resized images are
-    // packed back to back (ORB and the keypoint hashes take per-image offsets)
+    // sizeLongestSide(cvGray, 400) of each kept region with the same launch plan; the resized images are packed back
+    // to back (ORB and the keypoint hashes take per-image offsets)
     size_t cur = 0;
-    for (size_t i = 0, run = 1; i < m && rc == CBH_OK; i += run) {
-      const int* r = &hr[i * 4];
-      run = 1;
-      while (i + run < m && !memcmp(r, &hr[(i + run) * 4], 4 * sizeof(int))) ++run;
+    auto resize_run = [&](size_t i, size_t run, const int* r) {
       int dw = 0, dh = 0;
       cbh_longest_side_dims(r[2] - r[0], r[3] - r[1], rs, &dw, &dh);
       if (dw <= 0 || dh <= 0 || dw > rs || dh > rs) dw = dh = 0;  // the reference throws: no features for this image
@@ -200,10 +226,22 @@ extern "C" int cbh_index_images(const uint8_t* imgs, size_t n, int w, int h, siz
         ws[i + t] = (uint32_t)dw, hs[i + t] = (uint32_t)dh;
         off[i + t] = cur + t * (size_t)dw * dh;
       }
-      if (dw == 0) continue;
-      rc = cbh_resize_lanczos4_dev(gray + i * gi + (size_t)r[1] * gs + r[0], run, r[2] - r[0], r[3] - r[1], gs, gi, dw, dh,
-                                   d_res + cur, device, s);
+      if (dw == 0) return (int)CBH_OK;
+      const int r2 = cbh_resize_lanczos4_dev(gray + i * gi + (size_t)r[1] * gs + r[0], run, r[2] - r[0], r[3] - r[1], gs, gi,
+                                             dw, dh, d_res + cur, device, s);
       cur += run * (size_t)dw * dh;
+      return r2;
+    };
+    if (by_mode) {
+      rc = resize_run(0, m, mode);
+      for (size_t i = 0; i < m && rc == CBH_OK; ++i)
+        if (!is_mode(i)) rc = resize_run(i, 1, &hr[i * 4]);  // its own slot behind the chunk-wide pass
+    } else {
+      for (size_t i = 0, run = 1; i < m && rc == CBH_OK; i += run) {
+        run = 1;
+        while (i + run < m && !memcmp(&hr[i * 4], &hr[(i + run) * 4], 4 * sizeof(int))) ++run;
+        rc = resize_run(i, run, &hr[i * 4]);
+      }
     }
     if (rc) break;
     lap("resize");

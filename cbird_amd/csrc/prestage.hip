@@ -210,7 +210,7 @@ int cbh_autocrop_dev(const void* d_gray, size_t n, int w, int h, size_t row_stri
   if (!g.ok) return CBH_E_NODEVICE;
   hipStream_t s = (hipStream_t)stream;
   int* scratch = nullptr;
-  CBH_HIP(hipMallocAsync((void**)&scratch, n * 2 * (size_t)(w + h) * sizeof(int), s));
+  CBH_HIP(cbh::malloc_async((void**)&scratch, n * 2 * (size_t)(w + h) * sizeof(int), s));
   hipLaunchKernelGGL(k_autocrop, dim3((unsigned)n), dim3(256), 0, s, (const unsigned char*)d_gray, w, h,
                      row_stride, img_stride, range, (int*)d_rects, scratch);
   CBH_HIP(hipGetLastError());
@@ -252,7 +252,7 @@ int cbh_process_images_ex(const uint8_t* imgs, size_t n, int w, int h, size_t ro
   int rc = CBH_OK;
   const size_t slot = (size_t)resize_size * (size_t)resize_size;
   auto cleanup = [&]() {
-    if (s) (void)hipStreamDestroy(s);
+    if (s) cbh::stream_destroy(s);
     for (void* p : {(void*)d_src, (void*)d_gray, (void*)d_out, (void*)d_rects, (void*)d_res})
       if (p) (void)hipFree(p);
   };
@@ -378,7 +378,7 @@ int cbh_resize_lanczos4_dev(const void* d_src, size_t n, int w, int h, size_t ro
   hipError_t e = hipSuccess;
   auto up = [&](void** dst, const void* src, size_t bytes) {
     if (e != hipSuccess) return;
-    if ((e = hipMallocAsync(dst, bytes, s)) != hipSuccess) return;
+    if ((e = cbh::malloc_async(dst, bytes, s)) != hipSuccess) return;
     e = hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s);
   };
   up((void**)&d_xofs, xofs.data(), xofs.size() * sizeof(int));
@@ -444,7 +444,7 @@ int cbh_size_longest_side(const uint8_t* imgs, size_t n, int w, int h, size_t ro
       rc = CBH_E_HIP;
     }
   }
-  if (s) (void)hipStreamDestroy(s);
+  if (s) cbh::stream_destroy(s);
   if (d_src) (void)hipFree(d_src);
   if (d_dst) (void)hipFree(d_dst);
   return rc;

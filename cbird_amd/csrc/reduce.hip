@@ -188,8 +188,8 @@ int sort_keys_u64(unsigned long long* d_keys, size_t n, int end_bit, hipStream_t
   void* tmp = nullptr;
   size_t bytes = 0;
   CBH_HIP(rocprim::radix_sort_keys(nullptr, bytes, d_keys, alt, n, 0, (unsigned)end_bit, s));
-  CBH_HIP(hipMallocAsync((void**)&alt, n * 8, s));
-  hipError_t e = hipMallocAsync(&tmp, bytes ? bytes : 16, s);
+  CBH_HIP(cbh::malloc_async((void**)&alt, n * 8, s));
+  hipError_t e = cbh::malloc_async(&tmp, bytes ? bytes : 16, s);
   if (e == hipSuccess) e = rocprim::radix_sort_keys(tmp, bytes, d_keys, alt, n, 0, (unsigned)end_bit, s);
   if (e == hipSuccess) e = hipMemcpyAsync(d_keys, alt, n * 8, hipMemcpyDeviceToDevice, s);
   (void)hipFreeAsync(alt, s);
@@ -205,9 +205,9 @@ int sort_pairs_u64_u32(unsigned long long* d_keys, uint32_t* d_vals, size_t n, i
   void* tmp = nullptr;
   size_t bytes = 0;
   CBH_HIP(rocprim::radix_sort_pairs(nullptr, bytes, d_keys, kalt, d_vals, valt, n, 0, (unsigned)end_bit, s));
-  CBH_HIP(hipMallocAsync((void**)&kalt, n * 8, s));
-  hipError_t e = hipMallocAsync((void**)&valt, n * 4, s);
-  if (e == hipSuccess) e = hipMallocAsync(&tmp, bytes ? bytes : 16, s);
+  CBH_HIP(cbh::malloc_async((void**)&kalt, n * 8, s));
+  hipError_t e = cbh::malloc_async((void**)&valt, n * 4, s);
+  if (e == hipSuccess) e = cbh::malloc_async(&tmp, bytes ? bytes : 16, s);
   if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, bytes, d_keys, kalt, d_vals, valt, n, 0, (unsigned)end_bit, s);
   if (e == hipSuccess) e = hipMemcpyAsync(d_keys, kalt, n * 8, hipMemcpyDeviceToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(d_vals, valt, n * 4, hipMemcpyDeviceToDevice, s);
@@ -229,10 +229,10 @@ int launch_fdct_vote(const cbh_match* d_top, const uint32_t* d_counts, const uin
   FdctRun* runs = nullptr;
   unsigned* misc = nullptr;  // [0] = n_runs, [1..] = maxm[n_needles]
   cbh_nmatch* out = nullptr;
-  hipError_t e = hipMallocAsync((void**)&keys, n * 8, s);
-  if (e == hipSuccess) e = hipMallocAsync((void**)&runs, n * sizeof(FdctRun), s);
-  if (e == hipSuccess) e = hipMallocAsync((void**)&misc, (1 + n_needles) * 4, s);
-  if (e == hipSuccess) e = hipMallocAsync((void**)&out, n * sizeof(cbh_nmatch), s);
+  hipError_t e = cbh::malloc_async((void**)&keys, n * 8, s);
+  if (e == hipSuccess) e = cbh::malloc_async((void**)&runs, n * sizeof(FdctRun), s);
+  if (e == hipSuccess) e = cbh::malloc_async((void**)&misc, (1 + n_needles) * 4, s);
+  if (e == hipSuccess) e = cbh::malloc_async((void**)&out, n * sizeof(cbh_nmatch), s);
   int rc = CBH_OK;
   unsigned n_runs = 0;
   if (e == hipSuccess) e = hipMemsetAsync(misc, 0, (1 + n_needles) * 4, s);
@@ -271,10 +271,10 @@ int launch_video_reduce(const unsigned* d_off, const unsigned long long* d_seg, 
   uint32_t* vals = nullptr;
   cbh_nvmatch* out = nullptr;
   unsigned* n_out = nullptr;
-  hipError_t e = hipMallocAsync((void**)&keys, total * 8, s);
-  if (e == hipSuccess) e = hipMallocAsync((void**)&vals, total * 4, s);
-  if (e == hipSuccess) e = hipMallocAsync((void**)&out, total * sizeof(cbh_nvmatch), s);
-  if (e == hipSuccess) e = hipMallocAsync((void**)&n_out, 4, s);
+  hipError_t e = cbh::malloc_async((void**)&keys, total * 8, s);
+  if (e == hipSuccess) e = cbh::malloc_async((void**)&vals, total * 4, s);
+  if (e == hipSuccess) e = cbh::malloc_async((void**)&out, total * sizeof(cbh_nvmatch), s);
+  if (e == hipSuccess) e = cbh::malloc_async((void**)&n_out, 4, s);
   if (e == hipSuccess) e = hipMemsetAsync(n_out, 0, 4, s);
   int rc = CBH_OK;
   unsigned n = 0;

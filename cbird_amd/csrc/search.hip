@@ -92,7 +92,7 @@ int cbh_search_index_batch(cbh_idx64* idx, const uint64_t* q, const uint32_t* ne
       {
         void* scratch = nullptr;
         const size_t ncap = std::min<size_t>(ws->rec_cap, (size_t)total + 1);
-        CBH_HIP(hipMallocAsync(&scratch, topk_scratch_bytes(np, ncap) + 16, s));
+        CBH_HIP(cbh::malloc_async(&scratch, topk_scratch_bytes(np, ncap) + 16, s));
         unsigned* d_status = (unsigned*)((char*)scratch + topk_scratch_bytes(np, ncap));
         rc = topk_scratch_init(scratch, np, s);
         if (!rc) rc = launch_records_topk(ws->d_total, 1, 0, ncap, np, k, ws->d_out, ws->d_counts, d_status, scratch, s);

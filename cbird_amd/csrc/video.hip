@@ -202,10 +202,10 @@ int reduce_on_device(cbh_vidx* v, const std::vector<uint64_t>& q, const std::vec
   uint32_t *d_qneedle = nullptr, *d_nid = nullptr;
   int32_t* d_qframe = nullptr;
   const size_t sbytes = topk_scratch_bytes(nq, (size_t)total);
-  hipError_t e = hipMallocAsync(&scratch, sbytes + 16, s);
-  if (e == hipSuccess) e = hipMallocAsync((void**)&d_qneedle, nq * 4, s);
-  if (e == hipSuccess) e = hipMallocAsync((void**)&d_qframe, nq * 4, s);
-  if (e == hipSuccess) e = hipMallocAsync((void**)&d_nid, nid.size() * 4, s);
+  hipError_t e = cbh::malloc_async(&scratch, sbytes + 16, s);
+  if (e == hipSuccess) e = cbh::malloc_async((void**)&d_qneedle, nq * 4, s);
+  if (e == hipSuccess) e = cbh::malloc_async((void**)&d_qframe, nq * 4, s);
+  if (e == hipSuccess) e = cbh::malloc_async((void**)&d_nid, nid.size() * 4, s);
   if (e == hipSuccess) e = hipMemcpyAsync(d_qneedle, qneedle.data(), nq * 4, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(d_qframe, qframe.data(), nq * 4, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(d_nid, nid.data(), nid.size() * 4, hipMemcpyHostToDevice, s);

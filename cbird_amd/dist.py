@@ -265,6 +265,17 @@ class ShardedDctHashIndex:
         thresholds = list(thresholds)
         if not hasattr(ops, "side_stream"):  # device work injected by a test: no streams, plain loop
             return {t: self.similar(queries, t, max_per_query, scan_events) for t in thresholds}
+        if os.environ.get("CBH_SWEEP_SERIAL") == "1":  # diagnostic knob: no side stream, one threshold after the other
+            res = {}
+            for t in thresholds:
+                f0 = ops.new_event()
+                f0.record(ops.current_stream())
+                res[t] = self.similar(queries, t, max_per_query, scan_events)
+                if find_events is not None:
+                    done = ops.new_event()
+                    done.record(ops.current_stream())
+                    find_events.append((t, f0, done, self.last_exchange_records))
+            return res
         main, side = ops.current_stream(), ops.side_stream()
         side.wait_stream(main)  # queries (and the index) are ready
         status = ops.empty(len(thresholds), torch.int32)

@@ -52,20 +52,25 @@ def process_images(imgs: np.ndarray, params: IndexParams | None = None, device: 
     ch = 1 if imgs.ndim == 3 else imgs.shape[3]
     if n == 0:
         return []
-    cap = p.numFeatures + 64
+    # room per image: ties in retainBest can exceed numFeatures; a call that found more is repeated, and the size that
+    # worked is remembered (equal buffer sizes from call to call also keep the device's scratch pool reusable)
+    cap = max(p.numFeatures + 64, getattr(process_images, "_cap_hint", {}).get(p.numFeatures, 0))
     L = _lib.lib()
     while True:
         cp = _Params(20 if (p.algos and p.autocrop) else -1, p.algos, p.resizeLongestSide, p.numFeatures, cap)
-        hashes = np.zeros(n, np.uint64)
-        rects = np.zeros((n, 4), np.int32)
-        dims = np.zeros((n, 2), np.int32)
-        kpc = np.zeros(n, np.uint32)
-        kp = np.zeros((n, cap), KP_DTYPE)
-        desc = np.zeros((n, cap, 32), np.uint8)
-        khc = np.zeros(n, np.uint32)
-        kh = np.zeros((n, cap), np.uint64)
-        cd = np.zeros(n, COLOR_DTYPE)
-        cok = np.zeros(n, np.uint8)
+        # output buffers are kept between calls (an indexer calls this in a loop): fresh numpy arrays are untouched
+        # pages, and a device-to-host copy into untouched pageable memory pays a page fault per 4 KB
+        key = (n, cap)
+        bufs = getattr(process_images, "_bufs", None)
+        if bufs is None or bufs[0] != key:
+            bufs = (key, np.zeros(n, np.uint64), np.zeros((n, 4), np.int32), np.zeros((n, 2), np.int32),
+                    np.zeros(n, np.uint32), np.zeros((n, cap), KP_DTYPE), np.zeros((n, cap, 32), np.uint8),
+                    np.zeros(n, np.uint32), np.zeros((n, cap), np.uint64), np.zeros(n, COLOR_DTYPE), np.zeros(n, np.uint8))
+            for a in bufs[1:]:
+                a.fill(0)  # touch
+            process_images._bufs = bufs
+        _, hashes, rects, dims, kpc, kp, desc, khc, kh, cd, cok = bufs
+        hashes.fill(0), kpc.fill(0), khc.fill(0), cok.fill(0)
         t0 = time.perf_counter()
         check(L.cbh_index_images(imgs.ctypes.data, n, w, h, w * ch, w * h * ch, ch, C.byref(cp), hashes.ctypes.data,
                                  rects.ctypes.data, dims.ctypes.data, kpc.ctypes.data, kp.ctypes.data, desc.ctypes.data,
@@ -73,7 +78,8 @@ def process_images(imgs: np.ndarray, params: IndexParams | None = None, device: 
         process_images.last_call_seconds = time.perf_counter() - t0  # the C call alone (the rest is Python unpacking)
         if int(kpc.max()) <= cap:
             break
-        cap = int(kpc.max())
+        cap = (int(kpc.max()) + 63) // 64 * 64
+    process_images._cap_hint = {**getattr(process_images, "_cap_hint", {}), p.numFeatures: cap}
     out = []
     for i in range(n):
         c = int(kpc[i])

@@ -250,3 +250,42 @@ def test_rccl_transport_world1_equals_oracle(gpu, orc):
         wi, ws, wc = orc.find64_batch(h, ids, h, dht, 4)
         gi, gs, gc = out[dht]
         assert (gc == wc.astype(np.int32)).all() and (gi.view(np.uint32) == wi).all() and (gs == ws).all()
+
+
+def test_pipelined_sweep_inside_the_bench_step_is_deterministic(gpu):
+    """Regression (round 2): hash -> reload -> pipelined threshold sweep, repeated as bench.py's step does at a SMALL
+    index, where the scans are so short that the scan of threshold i+1 (needle-tile scratch, main stream) always
+    overlaps the cut of threshold i (counting-select scratch, side stream).  With both scratches in the device's
+    default stream-ordered pool the match counts came out wrong in about one bench run in three; every stream now has
+    its own pool (cbh_internal.h: malloc_async).  The counts of every step must equal the un-pipelined ones."""
+    import bench
+    from cbird_amd.dist import HipOps, ShardedDctHashIndex
+
+    dev = torch.device("cuda", 0)
+    n = 40000
+    ops = HipOps(0)
+    sh = ShardedDctHashIndex(ops, record_capacity=1 << 22)
+    imgs = bench.gen_images(torch, dev, 0, n, n, 1234)
+    ids = torch.arange(1, n + 1, device=dev, dtype=torch.int32)
+    dhts = [1, 2, 3, 4, 5, 6, 7, 8]
+    with ops.stream_ctx(ops.work_stream()):
+        h = ops.hash_images(imgs)
+        sh.load_shard(h, ids)
+        ref = {d: sh.similar(h, d, 8) for d in dhts}
+        torch.cuda.synchronize()
+        want = {d: tuple(t.cpu().numpy().copy() for t in ref[d]) for d in dhts}
+        assert want[2][2].sum() > n  # near-duplicates: more than the self matches
+        sh.similar_sweep(h, dhts, 8)
+        torch.cuda.synchronize()
+        sh.fit_capacity()
+        for it in range(120):
+            h2 = ops.hash_images(imgs)
+            sh.load_shard(h2, ids)
+            r = sh.similar_sweep(h2, dhts, 8)
+            torch.cuda.synchronize()
+            for d in dhts:
+                cnt = r[d][2].cpu().numpy()
+                assert (cnt == want[d][2]).all(), (it, d)
+                live = np.arange(8)[None, :] < np.minimum(cnt, 8)[:, None]  # places beyond a needle's count are not written
+                assert (r[d][0].cpu().numpy()[live] == want[d][0][live]).all(), (it, d)
+                assert (r[d][1].cpu().numpy()[live] == want[d][1][live]).all(), (it, d)
