@@ -267,6 +267,7 @@ def test_pipelined_sweep_inside_the_bench_step_is_deterministic(gpu):
     sh = ShardedDctHashIndex(ops, record_capacity=1 << 22)
     imgs = bench.gen_images(torch, dev, 0, n, n, 1234)
     ids = torch.arange(1, n + 1, device=dev, dtype=torch.int32)
+    torch.cuda.synchronize()  # generated on torch's default stream; the work stream below does not wait for it
     dhts = [1, 2, 3, 4, 5, 6, 7, 8]
     with ops.stream_ctx(ops.work_stream()):
         h = ops.hash_images(imgs)
@@ -274,7 +275,7 @@ def test_pipelined_sweep_inside_the_bench_step_is_deterministic(gpu):
         ref = {d: sh.similar(h, d, 8) for d in dhts}
         torch.cuda.synchronize()
         want = {d: tuple(t.cpu().numpy().copy() for t in ref[d]) for d in dhts}
-        assert want[2][2].sum() > n  # near-duplicates: more than the self matches
+        assert n < want[2][2].sum() < 2 * n  # self matches + the planted near-duplicates
         sh.similar_sweep(h, dhts, 8)
         torch.cuda.synchronize()
         sh.fit_capacity()
