@@ -136,6 +136,13 @@ _SIGS = {
     "cbh_vdx_encode": (_sz, [_vp, _vp, _sz, C.c_char_p, _vp, _sz]),
     "cbh_vdx_decode": (C.c_longlong, [_vp, _sz, _vp, _vp, _sz]),
     "cbh_video_dedup": (_sz, [_vp, _sz, C.c_int, _vp]),
+    "cbh_vindexer_create": (_vp, [C.c_int, C.c_int, C.c_int]),
+    "cbh_vindexer_destroy": (None, [_vp]),
+    "cbh_vindexer_resume": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "cbh_vindexer_push": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _sz, _sz]),
+    "cbh_vindexer_push_dev": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _sz, _sz]),
+    "cbh_vindexer_frames_seen": (C.c_longlong, [_vp]),
+    "cbh_vindexer_finish": (C.c_longlong, [_vp, _vp, _vp, _sz]),
     "cbh_idx256_create": (_vp, [C.c_int]),
     "cbh_idx256_destroy": (None, [_vp]),
     "cbh_idx256_add": (C.c_int, [_vp, C.c_uint32, _vp, _sz]),

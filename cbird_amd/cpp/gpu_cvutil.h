@@ -6,6 +6,8 @@
 //   void Media::makeKeyPoints(const cv::Mat&, int numKeyPoints, KeyPointList&) const                 src/media.cpp:859-866
 //   void Media::makeKeyPointDescriptors(const cv::Mat&, KeyPointList&, KeyPointDescriptors&) const   src/media.cpp:868-872
 //   static void ColorDescriptor::create(const cv::Mat& cvImg, ColorDescriptor& desc)                 src/cvutil.cpp:790-1099
+//   void Media::makeVideoIndex(VideoContext&, int threshold, VideoIndex&, const std::function<void(int)>&) const
+//                                                                                                  src/media.cpp:925-1037
 //
 // Same arguments and effects as the originals for 8-bit single-channel images (what Scanner::processImage passes
 // after grayscale(), src/scanner.cpp:859,876-889): the hash is returned, and with inPlace = true the blurred pixels
@@ -20,8 +22,10 @@
 // Build note: needs cbird's cvutil.h / media.h (OpenCV 2.4 cv::Mat, cv::KeyPoint) on the include path; in this
 // repository it is compiled against tests/cpp/mock/index.h instead (tests/cpp/test_cvutil.cpp).
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <stdexcept>
 #include <vector>
 
@@ -195,6 +199,69 @@ inline void gpuColorDescriptorCreate(const cv::Mat& cvImg, ColorDescriptor& desc
   if (rc) qFatal("gpuColorDescriptorCreate: %s (%s)", cbh_strerror(rc), cbh_last_error());
   if (ok) memcpy(&desc, rec, sizeof desc);
   else qWarning("not enough colors");
+}
+
+// Media::makeVideoIndex(video, threshold, outIndex, progressCb) -- src/media.cpp:925-1037.  Same resume rule
+// (:929-936), same result; the frames are collected chunkFrames at a time and hashed on the device
+// (autocrop(img, 20) + dctHash64), the near-frame filter runs in the library between chunks.  VideoContextT is
+// cbird's VideoContext: seek(int), nextFrame(cv::Mat&), metadata().frameRate / .duration.
+template <class VideoContextT>
+inline void gpuMakeVideoIndex(VideoContextT& video, int threshold, VideoIndex& outIndex,
+                              const std::function<void(int)>& progressCb = std::function<void(int)>(),
+                              int chunkFrames = 64) {
+  VideoIndex& index = outIndex;
+  cbh_vindexer* ix = cbh_vindexer_create(hashDevice(), threshold, 20 /* FIXME upstream: index settings, :961 */);
+  if (!ix) qFatal("gpuMakeVideoIndex: no usable device");
+  if (index.frames.size() > 0 && index.frames.size() == index.hashes.size() && video.seek(index.frames.back() + 1)) {
+    static_assert(sizeof(index.frames[0]) == sizeof(int32_t) && sizeof(index.hashes[0]) == sizeof(uint64_t), "");
+    const int rc = cbh_vindexer_resume(ix, reinterpret_cast<const int32_t*>(index.frames.data()),
+                                       reinterpret_cast<const uint64_t*>(index.hashes.data()), index.frames.size());
+    if (rc != CBH_OK) {
+      cbh_vindexer_destroy(ix);
+      qFatal("gpuMakeVideoIndex: cannot resume from the given index");
+    }
+    qDebug("resuming index from frame: %d", index.frames.back() + 1);
+  }
+  index.hashes.clear();
+  index.frames.clear();
+  const int totalFrames = int(video.metadata().frameRate * video.metadata().duration);
+  if (chunkFrames < 1) chunkFrames = 1;
+  std::vector<uint8_t> stage;
+  int cw = 0, ch = 0, held = 0;
+  auto flush = [&]() {
+    if (held == 0) return;
+    const int rc = cbh_vindexer_push(ix, stage.data(), size_t(held), cw, ch, size_t(cw), size_t(cw) * size_t(ch));
+    if (rc != CBH_OK) {
+      cbh_vindexer_destroy(ix);
+      qFatal("gpuMakeVideoIndex: cbh_vindexer_push failed");
+    }
+    held = 0;
+    if (progressCb) progressCb(int(cbh_vindexer_frames_seen(ix) * 100 / std::max(totalFrames, 1)));
+  };
+  cv::Mat cvFrame;
+  while (video.nextFrame(cvFrame)) {
+    if (cvFrame.type() != CV_8UC1 || cvFrame.rows <= 0 || cvFrame.cols <= 0)
+      qFatal("gpuMakeVideoIndex: the decoder is expected to output grey frames (media.cpp:959)");
+    if (cvFrame.cols != cw || cvFrame.rows != ch) {  // first frame (or a mid-stream size change)
+      flush();
+      cw = cvFrame.cols, ch = cvFrame.rows;
+      stage.resize(size_t(chunkFrames) * size_t(cw) * size_t(ch));
+    }
+    uint8_t* dst = stage.data() + size_t(held) * size_t(cw) * size_t(ch);
+    for (int y = 0; y < ch; ++y) memcpy(dst + size_t(y) * size_t(cw), cvFrame.template ptr<uint8_t>(y), size_t(cw));
+    if (++held == chunkFrames) flush();
+    if (cbh_vindexer_frames_seen(ix) + held >= (1 << 24)) break;  // MAX_FRAMES_PER_VIDEO, :1013-1016
+  }
+  flush();
+  const long long n = cbh_vindexer_finish(ix, nullptr, nullptr, 0);
+  if (n > 0) {
+    index.frames.resize(size_t(n));
+    index.hashes.resize(size_t(n));
+    cbh_vindexer_finish(ix, reinterpret_cast<int32_t*>(index.frames.data()),
+                        reinterpret_cast<uint64_t*>(index.hashes.data()), size_t(n));
+  }
+  cbh_vindexer_destroy(ix);
+  if (progressCb) progressCb(100);
 }
 
 }  // namespace cbird_gpu

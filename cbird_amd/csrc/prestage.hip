@@ -96,58 +96,195 @@ __global__ __launch_bounds__(256) void k_bgr2gray(const unsigned char* __restric
   }
 }
 
-// One workgroup per image.  Row/column run lengths are computed in parallel for every row and column (a
-// superset of what the reference's early-exit loops look at), then one thread replays the reference's
-// selection and centring rules.
-__global__ __launch_bounds__(256) void k_autocrop(const unsigned char* __restrict__ imgs, int cols, int rows,
-                                                  size_t row_stride, size_t img_stride, int range,
-                                                  int* __restrict__ rects /* n*4 */,
-                                                  int* __restrict__ scratch /* n*2*(rows+cols) */) {
-  const unsigned char* img = imgs + (size_t)blockIdx.x * img_stride;
-  int* rowL = scratch + (size_t)blockIdx.x * 2 * (size_t)(rows + cols);
+// autocrop(gray, range), src/cvutil.cpp:1285-1402, in two kernels.
+//
+// k_autocrop_runs computes what the reference's four scan loops look at -- for every row the length of the border-
+// coloured run from its left end (rowL) and the end of the run from its right end (rowR), for every column the same
+// from the top (colT) and the bottom (colB); a superset of the rows/columns the early-exit loops visit -- with one
+// WAVE per task and the reference's own early exits inside each task:
+//   * a row task takes eight rows and reads each in 256-byte segments from the left until the first content pixel,
+//     then from the right (a content row costs its two end segments, a bar row is read once); the end segments of
+//     all eight rows are requested together;
+//   * a column task owns 256 adjacent columns and walks down from the top (or up from the bottom) eight rows per step
+//     until every one of its columns has met content.
+// So a frame without bars costs ~1/4 of its bytes, a letterboxed one its bars plus the edges.  Every output has one
+// owner: no atomics.  k_autocrop_decide (one workgroup per image, a wave per search) then replays the selection and centring rules, each of
+// the four searches as a ballot over 64 candidates at a time.
+typedef unsigned ac_u32_any_align __attribute__((aligned(1)));
+constexpr int kAcColChunk = 256;  // columns per column task (4 per lane)
+constexpr int kAcRowsPerStep = 8;  // rows a column task requests per step
+constexpr int kAcRowsPerWave = 8;  // rows per row task
+
+// bit j = pixel x + j is content (differs from the border colour by more than range); pixels at x >= cols are not
+__device__ __forceinline__ unsigned ac_content4(const unsigned char* __restrict__ row, int x, int cols, int color,
+                                                int range) {
+  if (x >= cols) return 0u;
+  unsigned v;
+  if (x + 4 <= cols) {
+    v = *reinterpret_cast<const ac_u32_any_align*>(row + x);
+  } else {
+    v = row[x];
+    if (x + 1 < cols) v |= (unsigned)row[x + 1] << 8;
+    if (x + 2 < cols) v |= (unsigned)row[x + 2] << 16;
+  }
+  const int n = min(4, cols - x);
+  unsigned m = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = (int)((v >> (8 * j)) & 0xffu);
+    m |= (unsigned)(j < n && abs(p - color) > range) << j;
+  }
+  return m;
+}
+
+__global__ __launch_bounds__(256) void k_autocrop_runs(const unsigned char* __restrict__ imgs, int cols, int rows,
+                                                       size_t row_stride, size_t img_stride, int range,
+                                                       int* __restrict__ scratch /* n*2*(rows+cols) */) {
+  const unsigned char* img = imgs + (size_t)blockIdx.y * img_stride;
+  int* rowL = scratch + (size_t)blockIdx.y * 2 * (size_t)(rows + cols);
   int* rowR = rowL + rows;
   int* colT = rowR + rows;
   int* colB = colT + cols;
+  const int lane = (int)threadIdx.x & 63;
+  const int task = (int)blockIdx.x * ((int)blockDim.x >> 6) + ((int)threadIdx.x >> 6);
+  const int nchunks = (cols + kAcColChunk - 1) / kAcColChunk;
+  const int row_tasks = (rows + kAcRowsPerWave - 1) / kAcRowsPerWave;
+  if (task >= row_tasks + 2 * nchunks) return;
   const int color = img[0];
-  for (int y = threadIdx.x; y < rows; y += blockDim.x) {
-    const unsigned char* p = img + (size_t)y * row_stride;
-    int left, right;
-    for (left = 0; left < cols; left++)
-      if (abs((int)p[left] - color) > range) break;
-    for (right = cols - 1; right >= 0; right--)
-      if (abs((int)p[right] - color) > range) break;
-    rowL[y] = left;
-    rowR[y] = right + 1;
+  if (task < row_tasks) {
+    // both end segments of all the wave's rows are requested before any of them is looked at: a content row is
+    // settled by that one round trip
+    const int y0 = task * kAcRowsPerWave;
+    const int xe = (cols - 1) & ~3;  // segment grid anchored at 0; the right scan walks it from the last dword down
+    const int xl = 4 * lane, xr = xe - 4 * lane;
+    unsigned mL[kAcRowsPerWave], mR[kAcRowsPerWave];
+#pragma unroll
+    for (int r = 0; r < kAcRowsPerWave; ++r) {
+      const unsigned char* row = img + (size_t)min(y0 + r, rows - 1) * row_stride;
+      mL[r] = ac_content4(row, xl, cols, color, range);
+      mR[r] = xr >= 0 ? ac_content4(row, xr, cols, color, range) : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < kAcRowsPerWave; ++r) {
+      const int y = y0 + r;
+      if (y >= rows) break;
+      const unsigned char* row = img + (size_t)y * row_stride;
+      int left = cols, right = 0;  // no content at all: left == cols, right + 1 == 0
+      unsigned m = mL[r];
+      for (int x0 = 0;;) {
+        const unsigned long long b = __ballot(m != 0u);
+        if (b) {
+          const int fl = __builtin_ctzll(b);
+          left = x0 + 4 * fl + __builtin_ctz(__shfl(m, fl));
+          break;
+        }
+        x0 += 256;
+        if (x0 >= cols) break;
+        m = ac_content4(row, x0 + xl, cols, color, range);
+      }
+      if (left < cols) {
+        m = mR[r];
+        for (int x0 = xe;;) {
+          const unsigned long long b = __ballot(m != 0u);
+          if (b) {
+            const int fl = __builtin_ctzll(b);  // lowest lane = rightmost dword
+            right = x0 - 4 * fl + (31 - __builtin_clz(__shfl(m, fl))) + 1;
+            break;
+          }
+          x0 -= 256;  // (content exists: the scan ends before x0 runs out)
+          const int x = x0 - 4 * lane;
+          m = x >= 0 ? ac_content4(row, x, cols, color, range) : 0u;
+        }
+      }
+      if (lane == 0) {
+        rowL[y] = left;
+        rowR[y] = right;
+      }
+    }
+    return;
   }
-  for (int x = threadIdx.x; x < cols; x += blockDim.x) {
-    int t, b;
-    for (t = 0; t < rows; t++)
-      if (abs((int)img[(size_t)t * row_stride + x] - color) > range) break;
-    for (b = rows - 1; b >= 0; b--)
-      if (abs((int)img[(size_t)b * row_stride + x] - color) > range) break;
-    colT[x] = t;
-    colB[x] = b + 1;
+  const int ct = task - row_tasks, chunk = ct >> 1;
+  const bool from_top = !(ct & 1);
+  const int x = chunk * kAcColChunk + 4 * lane;
+  // f0..f3: the first content row met from this end (top walker: its index; bottom walker: index + 1)
+  const int none = from_top ? rows : 0;
+  int f0 = none, f1 = none, f2 = none, f3 = none;
+  unsigned live = x < cols ? (1u << min(4, cols - x)) - 1u : 0u;  // columns that have not met content yet
+  for (int s0 = 0; s0 < rows; s0 += kAcRowsPerStep) {
+    // c[j]: bit u = column x + j has content in the u-th row of this step
+    unsigned c[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int u = 0; u < kAcRowsPerStep; ++u) {
+      const int step = s0 + u;
+      const int y = from_top ? step : rows - 1 - step;
+      const unsigned m = (step < rows && live != 0u) ? ac_content4(img + (size_t)y * row_stride, x, cols, color, range) : 0u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c[j] |= ((m >> j) & 1u) << u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if ((live >> j & 1u) && c[j]) {
+        const int step = s0 + __builtin_ctz(c[j]);
+        const int v = from_top ? step : rows - step;
+        if (j == 0) f0 = v;
+        if (j == 1) f1 = v;
+        if (j == 2) f2 = v;
+        if (j == 3) f3 = v;
+        live &= ~(1u << j);
+      }
+    }
+    if (__ballot(live != 0u) == 0ull) break;
   }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
+  const int found[4] = {f0, f1, f2, f3};
+  int* out = from_top ? colT : colB;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (x + j < cols) out[x + j] = found[j];
+}
+
+// first candidate c in [from, to] (step +1) or [to, from] walking down (step -1) for which pred holds, else `miss`
+template <class Pred>
+__device__ __forceinline__ int ac_first(int from, int to, int dir, int miss, Pred pred) {
+  const int lane = (int)threadIdx.x & 63;
+  for (int c0 = from; dir > 0 ? c0 <= to : c0 >= to; c0 += 64 * dir) {
+    const int c = c0 + dir * lane;
+    const bool ok = (dir > 0 ? c <= to : c >= to) && pred(c);
+    const unsigned long long b = __ballot(ok);
+    if (b) return c0 + dir * __builtin_ctzll(b);
+  }
+  return miss;
+}
+
+__global__ __launch_bounds__(256) void k_autocrop_decide(int cols, int rows, const int* __restrict__ scratch,
+                                                         int* __restrict__ rects /* n*4 */) {
+  const int* rowL = scratch + (size_t)blockIdx.x * 2 * (size_t)(rows + cols);
+  const int* rowR = rowL + rows;
+  const int* colT = rowR + rows;
+  const int* colB = colT + cols;
   const int minWidthCovered = (int)(cols * 0.66f);
   const int minHeightCovered = (int)(rows * 0.66f);
   const int maxHMarginDifference = (int)(cols * 0.05f);
   const int maxVMarginDifference = (int)(rows * 0.05f);
-  int top;
-  for (top = rows / 2; top >= 0; top--)
-    if (rowL[top] > 0 && rowR[top] < cols && rowL[top] + cols - rowR[top] > minWidthCovered) break;
-  top++;
-  int bottom;
-  for (bottom = rows / 2 + 1; bottom < rows; bottom++)
-    if (rowL[bottom] + cols - rowR[bottom] > minWidthCovered) break;
-  int left;
-  for (left = cols / 2; left >= 0; left--)
-    if (colT[left] > 0 && colB[left] < rows && colT[left] + rows - colB[left] > minHeightCovered) break;
-  left++;
-  int right;
-  for (right = cols / 2 + 1; right < cols; right++)
-    if (colT[right] > 0 && colB[right] < rows && colT[right] + rows - colB[right] > minHeightCovered) break;
+  __shared__ int s_edge[4];
+  auto col_pred = [&](int x) {
+    return colT[x] > 0 && colB[x] < rows && colT[x] + rows - colB[x] > minHeightCovered;
+  };
+  const int wave = (int)threadIdx.x >> 6;  // one of the four searches each
+  int e;
+  if (wave == 0)
+    e = ac_first(rows / 2, 0, -1, -1, [&](int y) {
+          return rowL[y] > 0 && rowR[y] < cols && rowL[y] + cols - rowR[y] > minWidthCovered;
+        }) + 1;
+  else if (wave == 1)
+    e = ac_first(rows / 2 + 1, rows - 1, 1, rows, [&](int y) { return rowL[y] + cols - rowR[y] > minWidthCovered; });
+  else if (wave == 2)
+    e = ac_first(cols / 2, 0, -1, -1, col_pred) + 1;
+  else
+    e = ac_first(cols / 2 + 1, cols - 1, 1, cols, col_pred);
+  if ((threadIdx.x & 63) == 0) s_edge[wave] = e;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  int top = s_edge[0], bottom = s_edge[1], left = s_edge[2], right = s_edge[3];
   const int bmargin = rows - bottom;
   if (abs(top - bmargin) > maxVMarginDifference) {
     if (top > bmargin)
@@ -211,8 +348,15 @@ int cbh_autocrop_dev(const void* d_gray, size_t n, int w, int h, size_t row_stri
   hipStream_t s = (hipStream_t)stream;
   int* scratch = nullptr;
   CBH_HIP(cbh::malloc_async((void**)&scratch, n * 2 * (size_t)(w + h) * sizeof(int), s));
-  hipLaunchKernelGGL(k_autocrop, dim3((unsigned)n), dim3(256), 0, s, (const unsigned char*)d_gray, w, h,
-                     row_stride, img_stride, range, (int*)d_rects, scratch);
+  const int tasks = (h + kAcRowsPerWave - 1) / kAcRowsPerWave + 2 * ((w + kAcColChunk - 1) / kAcColChunk);
+  for (size_t i0 = 0; i0 < n; i0 += 65535) {
+    const size_t m = std::min<size_t>(65535, n - i0);
+    int* sc = scratch + i0 * 2 * (size_t)(w + h);
+    hipLaunchKernelGGL(k_autocrop_runs, dim3((unsigned)((tasks + 3) / 4), (unsigned)m), dim3(256), 0, s,
+                       (const unsigned char*)d_gray + i0 * img_stride, w, h, row_stride, img_stride, range, sc);
+    hipLaunchKernelGGL(k_autocrop_decide, dim3((unsigned)m), dim3(256), 0, s, w, h, (const int*)sc,
+                       (int*)d_rects + i0 * 4);
+  }
   CBH_HIP(hipGetLastError());
   CBH_HIP(hipFreeAsync(scratch, s));
   if (!stream) CBH_HIP(hipStreamSynchronize(s));

@@ -2,6 +2,8 @@
 
   VideoIndex       frames + hashes of one video and the .vdx v2 file format (save/load/isValid)
   make_video_index the frame de-dup of Media::makeVideoIndex over a sequence of frame hashes
+  VideoIndexer     Media::makeVideoIndex for frames pushed in chunks: autocrop + dctHash64 on the device, the
+                   near-frame filter's state kept between pushes (host arrays or device tensors)
   DctVideoIndex    add/remove/count/find (findFrame for image needles, findVideo for video needles)
 
 Compute and format code live in libcbird_hip.so (include/cbird_hip.h); nothing here falls back to CPU.
@@ -84,6 +86,78 @@ def make_video_index(frame_hashes, threshold: int = 8) -> VideoIndex:
     L.cbh_video_dedup(h.ctypes.data, len(h), int(threshold), keep.ctypes.data)
     ix = np.nonzero(keep[: len(h)])[0]
     return VideoIndex(ix.tolist(), [int(x) for x in h[ix]])
+
+
+class VideoIndexer:
+    """Media::makeVideoIndex (src/media.cpp:925-1037) fed by a decoder that produces frames in chunks.
+
+        ix = VideoIndexer(threshold=8)              # IndexParams::videoThreshold; autocrop(img, 20) as at :961
+        for chunk in decoder:                        # (n, h, w) uint8 numpy array or cuda tensor
+            ix.push(chunk)
+        video_index = ix.finish()
+
+    resume = a VideoIndex written earlier (:929-936): frame numbering continues behind its last frame."""
+
+    def __init__(self, threshold: int = 8, autocrop_range: int = 20, device: int = 0,
+                 resume: VideoIndex | None = None) -> None:
+        self._L = _lib.lib()
+        self._h = self._L.cbh_vindexer_create(int(device), int(threshold), int(autocrop_range))
+        if not self._h:
+            raise CbhError(_lib.CBH_E_NODEVICE, "cbh_vindexer_create")
+        self._device = int(device)
+        if resume is not None and not resume.isEmpty():
+            f = np.ascontiguousarray(resume.frames, np.int32)
+            h = np.ascontiguousarray(resume.hashes, np.uint64)
+            check(self._L.cbh_vindexer_resume(self._h, f.ctypes.data, h.ctypes.data, len(f)), "vindexer_resume")
+
+    def __del__(self) -> None:
+        if getattr(self, "_h", None):
+            self._L.cbh_vindexer_destroy(self._h)
+            self._h = None
+
+    def push(self, frames) -> None:
+        """n grey frames in decode order: (n, h, w) or (h, w); rows and frames may be strided, pixels contiguous"""
+        if hasattr(frames, "data_ptr"):  # torch tensor
+            t = frames if frames.dim() == 3 else frames[None]
+            if t.dtype.itemsize != 1 or t.dim() != 3 or (t.shape[2] > 1 and t.stride(2) != 1):
+                raise ValueError("frames: expected (n, h, w) uint8 with contiguous rows")
+            n, h, w = t.shape
+            if n == 0:
+                return
+            if t.is_cuda:
+                if t.device.index != self._device:
+                    raise ValueError(f"frames live on {t.device}, the indexer on device {self._device}")
+                import torch
+                torch.cuda.current_stream(t.device).synchronize()  # the indexer runs on its own stream
+                check(self._L.cbh_vindexer_push_dev(self._h, t.data_ptr(), n, w, h, t.stride(1), t.stride(0)),
+                      "vindexer_push_dev")
+                return
+            frames = t.numpy()
+        a = np.asarray(frames)
+        if a.ndim == 2:
+            a = a[None]
+        if a.dtype != np.uint8 or a.ndim != 3:
+            raise ValueError("frames: expected (n, h, w) uint8")
+        if a.shape[0] == 0:
+            return
+        if a.shape[2] > 1 and a.strides[2] != 1 or a.strides[1] < a.shape[2] or a.strides[0] < 0:
+            a = np.ascontiguousarray(a)
+        n, h, w = a.shape
+        check(self._L.cbh_vindexer_push(self._h, a.ctypes.data, n, w, h, a.strides[1], a.strides[0]), "vindexer_push")
+
+    @property
+    def frames_seen(self) -> int:
+        """makeVideoIndex's frameNumber: the number the next frame gets"""
+        return int(self._L.cbh_vindexer_frames_seen(self._h))
+
+    def finish(self) -> VideoIndex:
+        n = int(self._L.cbh_vindexer_finish(self._h, None, None, 0))
+        f = np.zeros(max(1, n), np.int32)
+        h = np.zeros(max(1, n), np.uint64)
+        got = int(self._L.cbh_vindexer_finish(self._h, f.ctypes.data, h.ctypes.data, n))
+        if got != n:
+            raise CbhError(_lib.CBH_E_INVAL, f"cbh_vindexer_finish: {got} != {n}")
+        return VideoIndex(f[:n].tolist(), [int(x) for x in h[:n]])
 
 
 @dataclass

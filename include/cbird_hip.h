@@ -440,6 +440,30 @@ int cbh_vdx_verify(const uint8_t* buf, size_t len);
 /* frame de-dup of Media::makeVideoIndex (src/media.cpp:958-1024); keep[i]=1 for stored frames */
 size_t cbh_video_dedup(const uint64_t* hashes, size_t n, int threshold, uint8_t* keep);
 
+/* Media::makeVideoIndex (src/media.cpp:925-1037) for a decoder that delivers its frames in chunks: per frame
+ * grayscale (the decoder outputs grey: a no-op, :958) -> autocrop(img, 20) -> dctHash64 (:961-962, :987-992) on the
+ * device, then the near-frame filter (:994-1011), whose state -- frameNumber, window, the stored (frame, hash) lists --
+ * lives in the handle between pushes.  threshold = IndexParams::videoThreshold (src/scanner.h; <= 0 stores every
+ * frame), autocrop_range = 20 in cbird (< 0: no autocrop).
+ *   resume(): start from an index written earlier (:929-936: the next frame is frames[n-1] + 1 and, like the first
+ *             frame of a fresh run, is stored unconditionally); only before the first push.
+ *   push():   n grey frames of one geometry in host memory, in decode order; push_dev(): the same in device memory
+ *             (a hardware decoder's output).  Frames after MAX_FRAMES_PER_VIDEO (1 << 24, src/dctvideoindex.h:32,50)
+ *             are dropped as at :1013-1016.
+ *   finish(): the index as makeVideoIndex leaves it, with the last frame appended if it was not stored (:1018-1024);
+ *             returns the number of entries and writes them when cap suffices.  Does not change the handle: more
+ *             frames may be pushed afterwards. */
+typedef struct cbh_vindexer cbh_vindexer;
+cbh_vindexer* cbh_vindexer_create(int device, int threshold, int autocrop_range);
+void cbh_vindexer_destroy(cbh_vindexer*);
+int cbh_vindexer_resume(cbh_vindexer*, const int32_t* frames, const uint64_t* hashes, size_t n);
+int cbh_vindexer_push(cbh_vindexer*, const uint8_t* frames, size_t n, int w, int h, size_t row_stride,
+                      size_t img_stride);
+int cbh_vindexer_push_dev(cbh_vindexer*, const void* d_frames, size_t n, int w, int h, size_t row_stride,
+                          size_t img_stride);
+long long cbh_vindexer_frames_seen(const cbh_vindexer*);   /* makeVideoIndex's frameNumber */
+long long cbh_vindexer_finish(const cbh_vindexer*, int32_t* frames, uint64_t* hashes, size_t cap);
+
 /* ---- CvFeaturesIndex: src/cvfeaturesindex.{h,cpp} ---------------------------------------------------
  * N x 32-byte ORB/BRIEF descriptor rows (cv::Mat CV_8U, cvfeaturesindex.h:73) + the first-row -> mediaId
  * map (_indexMap/_idMap, :77-81).  Searches are exact brute force (the reference asks a FLANN LSH index,

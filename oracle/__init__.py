@@ -565,6 +565,8 @@ class VideoOracle:
         L.orc_video_find_video.restype = C.c_longlong
         L.orc_video_dedup.argtypes = [_u64p, C.c_size_t, C.c_int, _u8p]
         L.orc_video_dedup.restype = C.c_size_t
+        L.orc_make_video_index.argtypes = [_u64p, C.c_size_t, C.c_int, C.c_int, i32p, _u64p, C.c_size_t, C.c_size_t]
+        L.orc_make_video_index.restype = C.c_longlong
 
     def vdx_encode(self, frames, hashes, version="0.8.1") -> bytes:
         f = np.ascontiguousarray(frames, np.int32)
@@ -632,6 +634,20 @@ class VideoOracle:
                                         int(thresh), int(skip), int(vfm), int(vfn), int(bool(filter_self)), buf,
                                         cap)
         return self._out(buf, n)
+
+    def make_video_index(self, frame_hashes, threshold, resume=None, max_frames=1 << 24):
+        """Media::makeVideoIndex given every decoded frame's hash; resume = (frames, hashes) of an earlier index"""
+        fh = np.ascontiguousarray(frame_hashes, np.uint64)
+        rf, rh = (np.zeros(0, np.int32), np.zeros(0, np.uint64)) if resume is None else resume
+        cap = len(rf) + len(fh) + 1
+        frames = np.zeros(cap, np.int32)
+        hashes = np.zeros(cap, np.uint64)
+        frames[: len(rf)] = rf
+        hashes[: len(rh)] = rh
+        n = self.L.orc_make_video_index(fh if len(fh) else np.zeros(1, np.uint64), len(fh), int(threshold),
+                                        int(max_frames), frames, hashes, len(rf), cap)
+        assert n >= 0
+        return frames[:n].copy(), hashes[:n].copy()
 
     def dedup(self, hashes, threshold):
         h = np.ascontiguousarray(hashes, np.uint64)

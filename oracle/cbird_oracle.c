@@ -1314,6 +1314,61 @@ size_t orc_video_dedup(const uint64_t* hashes, size_t n, int threshold, uint8_t*
   return kept;
 }
 
+/* Media::makeVideoIndex (src/media.cpp:925-1037) as a whole, given the hash of every decoded frame in decode order
+ * (hash = dctHash64 of the autocropped grey frame, :961-962 / :987-992 -- orc_process_image).  io_frames / io_hashes
+ * hold n_resume entries of an earlier index on entry (:929-936: decoding restarts at io_frames[n_resume-1] + 1; 0 =
+ * fresh run) and the finished index on return (room for cap entries; returns the count, or -1 when cap is too small).
+ * The first decoded frame is stored unconditionally and does not enter the window (:958-968); every later one goes
+ * through the near-frame filter (:994-1011); decoding stops when frameNumber reaches max_frames (:1013-1016,
+ * MAX_FRAMES_PER_VIDEO = 1 << 24); the last frame is appended if it was not stored (:1018-1024). */
+long long orc_make_video_index(const uint64_t* frame_hashes, size_t n, int threshold, int max_frames,
+                               int32_t* io_frames, uint64_t* io_hashes, size_t n_resume, size_t cap) {
+  size_t cnt = n_resume;
+  int frame_number = n_resume ? io_frames[n_resume - 1] + 1 : 0;
+  uint64_t* window = (uint64_t*)malloc(sizeof(uint64_t) * (n + 1));
+  size_t wlen = 0, i = 0;
+  long long rc = 0;
+#define ORC_STORE(hv, fv)                 \
+  do {                                    \
+    if (cnt >= cap) {                     \
+      rc = -1;                            \
+      goto done;                          \
+    }                                     \
+    io_hashes[cnt] = (hv);                \
+    io_frames[cnt] = (fv);                \
+    ++cnt;                                \
+  } while (0)
+  if (i < n) {
+    ORC_STORE(frame_hashes[i], frame_number);
+    frame_number++;
+    ++i;
+  }
+  for (; i < n; ++i) {
+    const uint64_t hash = frame_hashes[i];
+    if (threshold > 0) {
+      size_t close = 0;
+      for (size_t k = 0; k < wlen; ++k)
+        if (__builtin_popcountll(window[k] ^ hash) < threshold) close++;
+      if (close != wlen) {
+        wlen = 0;
+        ORC_STORE(hash, frame_number);
+      }
+      window[wlen++] = hash;
+    } else {
+      ORC_STORE(hash, frame_number);
+    }
+    frame_number++;
+    if (frame_number == max_frames) break;
+  }
+  frame_number--;
+  if (cnt > 0 && io_frames[cnt - 1] != frame_number) ORC_STORE(window[wlen - 1], frame_number);
+  rc = (long long)cnt;
+done:
+#undef ORC_STORE
+  free(window);
+  return rc;
+}
+
 /* ---- CvFeaturesIndex: src/cvfeaturesindex.cpp:438-604 ----------------------------------------------
  * rows: N x 32 bytes (the cv::Mat of all ORB descriptors, cvfeaturesindex.h:73).  Exact brute-force
  * statement of `_index->knnSearch(descriptors, indices, dists, 10)` followed by `distance < cvThresh`

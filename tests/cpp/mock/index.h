@@ -75,8 +75,16 @@ struct QDebugMock {
 };
 inline QDebugMock qWarning() { return QDebugMock(); }
 // the printf-style overloads Qt also has (qWarning("..."), qDebug("..."))
-inline void qWarning(const char* msg) { std::cerr << msg << '\n'; }
-inline void qDebug(const char* msg) { std::cerr << msg << '\n'; }
+template <class... A>
+inline void qWarning(const char* fmt, A... a) {
+  if constexpr (sizeof...(A) == 0) std::cerr << fmt << '\n';
+  else { fprintf(stderr, fmt, a...); fputc('\n', stderr); }
+}
+template <class... A>
+inline void qDebug(const char* fmt, A... a) {
+  if constexpr (sizeof...(A) == 0) std::cerr << fmt << '\n';
+  else { fprintf(stderr, fmt, a...); fputc('\n', stderr); }
+}
 inline const char* qPrintable(const QString& s) { return s.c_str(); }
 
 // Qt's qCompress / qUncompress: 4-byte big-endian uncompressed length + a zlib stream

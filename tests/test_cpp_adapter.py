@@ -157,3 +157,47 @@ def test_cvutil_dropins_run_on_gpu(gpu, orc, w, h, seed):
     want_cd, _ = ColorCreateOracle().create(bgr)
     assert got["color"] == [int(want_cd[256]), _checksum(want_cd[:257])]
     assert got["color_gray"] == [77]
+
+
+def test_makevideoindex_dropin_compiles():
+    subprocess.check_call(["make", "-C", CPP, "-B", "test_makevideoindex"], stdout=subprocess.DEVNULL)
+    src = open(os.path.join(ROOT, "cbird_amd", "cpp", "gpu_cvutil.h")).read()
+    assert "gpuMakeVideoIndex(VideoContextT& video, int threshold, VideoIndex& outIndex" in src
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", [1, 16, 64])
+def test_makevideoindex_dropin_runs_on_gpu(gpu, tmp_path, chunk):
+    """gpuMakeVideoIndex over a mock VideoContext == the oracle's Media::makeVideoIndex: whole clip, resumed from a
+    saved .vdx (media.cpp:929-936), and restarted when the decoder cannot seek"""
+    import numpy as np
+
+    from oracle import PrestageOracle, VideoOracle
+    from test_video_indexer import clip
+
+    po, vo = PrestageOracle(), VideoOracle()
+    w, h, n, thr, stop = 320, 240, 70, 8, 31
+    frames = clip(77, n, h, w, (30, 30, 0, 0), cut_every=13)
+    raw = tmp_path / "frames.raw"
+    frames.tofile(raw)
+    subprocess.check_call(["make", "-C", CPP, "test_makevideoindex"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(CPP, "test_makevideoindex"), str(raw), str(w), str(h), str(n), str(thr),
+                          str(chunk), str(stop)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = {}
+    for line in out.stdout.splitlines():
+        tag, *rest = line.split()
+        got[tag] = rest
+    hashes = np.array([po.process_image(f, autocrop=20)[0] for f in frames], np.uint64)
+
+    def fmt(fh):
+        f, hh = fh
+        return [str(len(f))] + [f"{int(a)}:{int(b)}" for a, b in zip(f, hh)]
+
+    full = vo.make_video_index(hashes, thr)
+    part = vo.make_video_index(hashes[:stop], thr)
+    assert got["full"] == fmt(full)
+    assert got["progress"] == ["100", "1"]
+    assert got["part"] == fmt(part) and int(part[0][-1]) == stop - 1
+    assert got["resumed"] == fmt(vo.make_video_index(hashes[stop:], thr, resume=part))
+    assert got["noseek"] == fmt(full)

@@ -209,3 +209,55 @@ def test_process_images_ex_also_returns_the_orb_input(gpu, po, orc):
     _, r2, s2 = process_images_ex(gray[:1], None, 64)
     assert r2.tolist() == [[0, 0, w, h]] and s2[0].shape == (38, 64)
     assert process_images_ex(np.zeros((0, 40, 40), np.uint8), 20, 64)[2] == []
+
+
+@pytest.mark.gpu
+def test_autocrop_dev_equals_oracle_over_geometries_and_strides(gpu, po):
+    """cbh_autocrop_dev on its own (the rectangles, before any hashing): widths around the 256-byte segment and the
+    4-byte load boundaries, heights around the 8-row steps, odd row strides (unaligned rows), bars of every kind,
+    content inside the bars (subtitles), images that are all border or all content"""
+    import torch
+
+    from cbird_amd import _lib
+
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(99)
+    widths = [1, 2, 3, 4, 5, 7, 63, 64, 65, 255, 256, 257, 300, 511, 513, 777]
+    heights = [1, 2, 3, 7, 8, 9, 15, 17, 64, 65, 100, 203]
+    cases = 0
+    for w in widths:
+        for h in heights:
+            n = 6
+            stride = w + int(rng.integers(0, 6))
+            buf = np.zeros((n, h, stride), np.uint8)
+            for i in range(n):
+                border = int(rng.integers(0, 256))
+                img = np.clip(border + rng.integers(-3, 4, (h, w)), 0, 255).astype(np.uint8)
+                kind = i % 6
+                t = b = l = r = 0
+                if kind in (0, 3):
+                    t, b = int(rng.integers(0, h // 3 + 1)), int(rng.integers(0, h // 3 + 1))
+                if kind in (1, 3):
+                    l, r = int(rng.integers(0, w // 3 + 1)), int(rng.integers(0, w // 3 + 1))
+                if kind == 2:  # symmetric bars (the balanced case that actually crops)
+                    t = b = int(rng.integers(0, h // 5 + 1))
+                if kind != 4 and h - t - b > 0 and w - l - r > 0:  # kind 4: nothing but border
+                    inner = rng.integers(0, 256, (h - t - b, w - l - r))
+                    far = np.abs(inner - border) <= 20  # push most of the content away from the border colour
+                    inner = np.where(far & (rng.random(inner.shape) < 0.9), (border + 128) % 256, inner)
+                    img[t:h - b, l:w - r] = inner.astype(np.uint8)
+                if kind == 5 and h > 4 and w > 8:  # a subtitle inside the bottom bar
+                    img[h - 2, w // 3: w // 2] = (border + 100) % 256
+                buf[i, :, :w] = img
+            d = torch.from_numpy(buf).to(dev)
+            rects = torch.full((n, 4), -7, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            _lib.check(L.cbh_autocrop_dev(d.data_ptr(), n, w, h, stride, h * stride, 20, rects.data_ptr(), 0, None),
+                       "autocrop_dev")
+            torch.cuda.synchronize()
+            got = rects.cpu().numpy()
+            for i in range(n):
+                assert got[i].tolist() == po.autocrop(np.ascontiguousarray(buf[i, :, :w])).tolist(), (w, h, stride, i)
+                cases += 1
+    assert cases == len(widths) * len(heights) * 6
