@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline time budget")
     ap.add_argument("--no-video", action="store_true", help="skip the configs[4] leg (DctVideoIndex sharded by video)")
     ap.add_argument("--video-clips", type=int, default=10_000)
+    ap.add_argument("--no-orb", action="store_true", help="skip the configs[3] leg (CvFeaturesIndex sharded by image)")
+    ap.add_argument("--orb-images", type=int, default=100_000, help="configs[3]: images x 500 descriptors of 256 bits")
     ap.add_argument("--no-features", action="store_true",
                     help="skip the indexer-stage leg (ORB, ColorDescriptor::create; reported beside the contract line)")
     return ap.parse_args()
@@ -297,6 +299,8 @@ def main():
 
     if not args.no_video:
         result["configs4_video"] = video_leg(args, torch, dist, dev, local_rank, rank, world, share)
+    if not args.no_orb:
+        result["configs3_cvfeatures"] = cvfeatures_leg(args, torch, dist, dev, local_rank, rank, world, share)
     if rank == 0 and world == 1:
         # outside the timed region, for the record: the same launches on the popcount (VALU) kernel
         # k_hamm64_scan that the matrix-core kernel replaced (identical records; tests/test_gpu_hamm.py)
@@ -487,6 +491,97 @@ def video_leg(args, torch, dist, dev, local_rank, rank, world, share):
             "parallelism": f"sharded by video x{world}, needles replicated, one all-gather of final matches",
             "seconds": best, "needle_clips_per_s": len(needles) / best,
             "cmp_per_s": float(entries) * nframes / best, "matches": hits, "build_seconds_this_rank": t_build}
+
+
+def cvfeatures_leg(args, torch, dist, dev, local_rank, rank, world, share):
+    """BASELINE configs[3], reported beside the contract line (never part of `value`): 100k images x 500 synthetic
+    256-bit descriptors in a CvFeaturesIndex sharded BY IMAGE over the ranks (cbird_amd.dist.ShardedCvFeaturesIndex,
+    SURVEY.md 8e); 64 needle images (their own descriptors, a third of them perturbed by two bits) replicated: per
+    rank the exact k = 10 nearest rows under cvThresh 25 of every needle descriptor on the matrix cores, ONE
+    all-gather of the fixed-size candidate tables, k-way merge and the reference's scoring on every rank.
+    Time = max over ranks, barrier on both sides.  Every rank draws the descriptors of image i from the same
+    counter-based stream, so no rank materialises another rank's rows."""
+    import numpy as np
+
+    from cbird_amd.cvfeatures import CvFeaturesIndex
+    from cbird_amd.dist import ShardedCvFeaturesIndex, ShardedDctHashIndex
+    from cbird_amd.index import SearchParams
+
+    n_img, per, chunk = int(args.orb_images), 500, 1000
+
+    def rows_of_chunk(c):  # images [c * chunk, (c + 1) * chunk)
+        return np.random.default_rng([args.seed, 3, c]).integers(0, 256, (chunk * per, 32), dtype=np.uint8)
+
+    class Rows:  # descriptors of one image, drawn when (and only where) they are needed
+        cache = {}
+
+        def __init__(self, i):
+            self.i = i
+
+        def __len__(self):
+            return per
+
+        def __array__(self, dtype=None, copy=None):
+            c = self.i // chunk
+            if c not in Rows.cache:
+                Rows.cache.clear()
+                Rows.cache[c] = rows_of_chunk(c)
+            k = self.i - c * chunk
+            return Rows.cache[c][k * per:(k + 1) * per]
+
+    class M:
+        pass
+
+    media = []
+    for i in range(n_img):
+        m = M()
+        m.id, m.path, m.keyPointDescriptors = i + 1, "", Rows(i)
+        media.append(m)
+    sc = ShardedCvFeaturesIndex(lambda: CvFeaturesIndex(local_rank),
+                                device=dev if (dist.is_initialized() and not share) else None)
+    t0 = time.perf_counter()
+    sc.add(media)
+    n_needles = min(64, n_img)
+    first = rows_of_chunk(0)
+    needles = []
+    for i in range(n_needles):
+        m = M()
+        d = first[i * per:(i + 1) * per].copy()
+        d[::3, 5] ^= 0x11
+        m.id, m.path, m.keyPointDescriptors = i + 1, "", d
+        needles.append(m)
+    Rows.cache.clear()
+    p = SearchParams(algo=SearchParams.AlgoCVFeatures, cvThresh=25, minMatches=1, maxMatches=10)
+    sc.find_batch(needles[:2], p, knn=10)
+    t_build = time.perf_counter() - t0
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    best, hits, self_first = None, 0, 0
+    for _ in range(2):
+        fence()
+        t0 = time.perf_counter()
+        res = sc.find_batch(needles, p, knn=10)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        best = dt if best is None else min(best, dt)
+        hits = sum(len(r) for r in res)
+        self_first = sum(1 for i, r in enumerate(res) if r and r[0].mediaId == needles[i].id)
+    a, b = ShardedDctHashIndex.shard_range(n_img, rank, world)
+    pairs = float(n_img) * per * n_needles * per
+    return {"workload": "configs[3]: CvFeaturesIndex, %d images x %d descriptors x 256 bit, %d needle images batched, "
+                        "knn k=10, cvThresh 25" % (n_img, per, n_needles),
+            "parallelism": f"sharded by image x{world}, needles replicated, one all-gather of the candidate tables",
+            "seconds": best, "needle_images_per_s": n_needles / best, "cmp256_per_s": pairs / best, "matches": hits,
+            "needles_ranked_first_themselves": self_first, "rows_this_rank": (b - a) * per,
+            "build_seconds_this_rank": t_build}
 
 
 def cpu_baseline(args, torch, imgs, state, n, dhts):

@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_line_has_the_contract_keys(gpu):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--images", "40000", "--steps", "2",
-                          "--warmup", "1", "--cpu-seconds", "2"], capture_output=True, text=True, timeout=600,
+                          "--warmup", "1", "--cpu-seconds", "2", "--orb-images", "4000"], capture_output=True, text=True,
+                         timeout=600,
                          cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -33,6 +34,8 @@ def test_bench_line_has_the_contract_keys(gpu):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1
     assert c["find_agrees_with_gpu"] is True and c["hash_agrees_with_gpu"] is True
+    o = d["configs3_cvfeatures"]
+    assert o["needles_ranked_first_themselves"] == 64 and o["rows_this_rank"] == 4000 * 500
 
 
 @pytest.mark.gpu
@@ -43,7 +46,8 @@ def test_bench_two_ranks_sharing_the_gpu(gpu):
     import json
 
     env = dict(os.environ, CBH_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    args = ["--images", "60000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--dht", "2,5,8"]
+    args = ["--images", "60000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--dht", "2,5,8", "--orb-images",
+            "3000", "--video-clips", "2000"]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
                          timeout=600, env=env)
     assert one.returncode == 0, one.stderr[-2000:]
@@ -55,3 +59,7 @@ def test_bench_two_ranks_sharing_the_gpu(gpu):
     r2 = json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert r2["n_gpus"] == 2 and r2["scaling"] == "strong"
     assert [s["matches"] for s in r2["dht_sweep"]] == [s["matches"] for s in r1["dht_sweep"]]
+    # the sharded ORB and video legs give the unsharded results
+    assert r2["configs3_cvfeatures"]["matches"] == r1["configs3_cvfeatures"]["matches"] > 0
+    assert r2["configs3_cvfeatures"]["needles_ranked_first_themselves"] == 64
+    assert r2["configs4_video"]["matches"] == r1["configs4_video"]["matches"]
