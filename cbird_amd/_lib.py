@@ -136,6 +136,10 @@ _SIGS = {
     "cbh_vdx_encode": (_sz, [_vp, _vp, _sz, C.c_char_p, _vp, _sz]),
     "cbh_vdx_decode": (C.c_longlong, [_vp, _sz, _vp, _vp, _sz]),
     "cbh_video_dedup": (_sz, [_vp, _sz, C.c_int, _vp]),
+    "cbh_template_scores": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, C.c_int, _vp, _sz, C.c_int, _vp, _vp, _vp,
+                                      C.c_int]),
+    "cbh_template_hashes_dev": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, C.c_int, _vp, _sz, C.c_int, _vp, _vp,
+                                          C.c_int, _vp]),
     "cbh_vindexer_create": (_vp, [C.c_int, C.c_int, C.c_int]),
     "cbh_vindexer_destroy": (None, [_vp]),
     "cbh_vindexer_resume": (C.c_int, [_vp, _vp, _vp, _sz]),

@@ -8,6 +8,7 @@
 //   static void ColorDescriptor::create(const cv::Mat& cvImg, ColorDescriptor& desc)                 src/cvutil.cpp:790-1099
 //   void Media::makeVideoIndex(VideoContext&, int threshold, VideoIndex&, const std::function<void(int)>&) const
 //                                                                                                  src/media.cpp:925-1037
+//   the scoring block of TemplateMatcher::match (mask, two dctHash64, hamm64)                     src/templatematcher.cpp:331-371
 //
 // Same arguments and effects as the originals for 8-bit single-channel images (what Scanner::processImage passes
 // after grayscale(), src/scanner.cpp:859,876-889): the hash is returned, and with inPlace = true the blurred pixels
@@ -262,6 +263,27 @@ inline void gpuMakeVideoIndex(VideoContextT& video, int threshold, VideoIndex& o
   }
   cbh_vindexer_destroy(ix);
   if (progressCb) progressCb(100);
+}
+
+// The scoring block of TemplateMatcher::match, src/templatematcher.cpp:331-371: `img` is the candidate patch as
+// cv::warpAffine(..., tmplImg.size(), ...) left it, tmplImg the template (8-bit, 1 / 3 / 4 channels each).  Replaces
+//     cv::Mat tmplMasked = tmplImg.clone(); grayscale(img, img); { the masking loop }
+//     uint64_t candHash = dctHash64(img); uint64_t tmplHash = dctHash64(tmplMasked); int dist = hamm64(candHash, tmplHash);
+// by   int dist = cbird_gpu::gpuTemplateScore(img, tmplImg);
+// (the caller's img / tmplImg are left as they are: nothing after :371 reads them).
+inline int gpuTemplateScore(const cv::Mat& img, const cv::Mat& tmplImg, uint64_t* candHash = nullptr,
+                            uint64_t* tmplHash = nullptr) {
+  if (img.depth() != CV_8U || tmplImg.depth() != CV_8U || img.rows != tmplImg.rows || img.cols != tmplImg.cols ||
+      img.rows <= 0 || img.cols <= 0)
+    qFatal("gpuTemplateScore: expected two 8-bit images of the template's size");
+  uint64_t ch = 0, th = 0;
+  int32_t score = 0;
+  const int rc = cbh_template_scores(img.data, 1, img.cols, img.rows, size_t(img.step), 0, img.channels(), tmplImg.data,
+                                     size_t(tmplImg.step), tmplImg.channels(), &ch, &th, &score, hashDevice());
+  if (rc != CBH_OK) qFatal("gpuTemplateScore: cbh_template_scores failed");
+  if (candHash) *candHash = ch;
+  if (tmplHash) *tmplHash = th;
+  return score;
 }
 
 }  // namespace cbird_gpu

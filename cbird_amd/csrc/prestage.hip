@@ -314,6 +314,41 @@ __global__ __launch_bounds__(256) void k_autocrop_decide(int cols, int rows, con
     }
 }
 
+// TemplateMatcher::match's masking step (src/templatematcher.cpp:334-364) for n candidate patches against one template:
+// the candidate's grey value is the mask -- where it is 0 (outside the warped patch) the template's pixel is zeroed as
+// well; a BGRA template is premultiplied by its alpha and scales the candidate's grey value by it.  Writes the two grey
+// images dctHash64 is then taken of (dctHash64 greys the masked colour template itself, :366-367).
+__device__ __forceinline__ unsigned tm_gray(unsigned b, unsigned g, unsigned r) {
+  return (b * 1868u + g * 9617u + r * 4899u + 8192u) >> 14;
+}
+__global__ __launch_bounds__(256) void k_tm_mask(const unsigned char* __restrict__ cand, int w, int h, size_t crs,
+                                                 size_t cis, int cc, const unsigned char* __restrict__ tmpl, size_t trs,
+                                                 int tc, unsigned char* __restrict__ cand_gray /* n*w*h */,
+                                                 unsigned char* __restrict__ tmpl_gray /* n*w*h */) {
+  const size_t img = blockIdx.y;
+  const unsigned char* c = cand + img * cis;
+  const size_t total = (size_t)w * h;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int y = (int)(i / w), x = (int)(i - (size_t)y * w);
+    const unsigned char* p = c + (size_t)y * crs + (size_t)x * cc;
+    const unsigned char* t = tmpl + (size_t)y * trs + (size_t)x * tc;
+    unsigned g = cc == 1 ? p[0] : tm_gray(p[0], p[1], p[2]);
+    const unsigned m = g != 0u ? 255u : 0u;
+    unsigned tg;
+    if (tc == 1) {
+      tg = t[0] & m;
+    } else if (tc == 3) {
+      tg = tm_gray(t[0] & m, t[1] & m, t[2] & m);
+    } else {
+      const unsigned a = t[3];
+      tg = tm_gray(((t[0] * a) >> 8) & m, ((t[1] * a) >> 8) & m, ((t[2] * a) >> 8) & m);
+      g = (g * a) >> 8;
+    }
+    cand_gray[img * total + i] = (unsigned char)g;
+    tmpl_gray[img * total + i] = (unsigned char)tg;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -485,6 +520,104 @@ int cbh_process_images_ex(const uint8_t* imgs, size_t n, int w, int h, size_t ro
     CBH_TRY(hipMemcpyAsync(out + i0, d_out, m * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     CBH_TRY(hipStreamSynchronize(s));
     if (rects) memcpy(rects + i0 * 4, hr.data(), m * 4 * sizeof(int));
+  }
+#undef CBH_TRY
+  cleanup();
+  return rc;
+}
+
+/* TemplateMatcher::match's score for n candidate patches of one template (src/templatematcher.cpp:331-374): mask (above),
+ * candHash = dctHash64(cand), tmplHash = dctHash64(tmplMasked), hamm64.  Device buffers; the hashes stay on the device. */
+int cbh_template_hashes_dev(const void* d_cands, size_t n, int w, int h, size_t cand_row_stride, size_t cand_img_stride,
+                            int cand_channels, const void* d_tmpl, size_t tmpl_row_stride, int tmpl_channels,
+                            void* d_cand_hashes, void* d_tmpl_hashes, int device, void* stream) {
+  if (!cbh::device_usable(device)) return CBH_E_NODEVICE;
+  if (n == 0) return CBH_OK;
+  auto ch_ok = [](int c) { return c == 1 || c == 3 || c == 4; };
+  if (!d_cands || !d_tmpl || !d_cand_hashes || !d_tmpl_hashes || w <= 0 || h <= 0 || !ch_ok(cand_channels) ||
+      !ch_ok(tmpl_channels) || cand_row_stride < (size_t)w * cand_channels || tmpl_row_stride < (size_t)w * tmpl_channels)
+    return CBH_E_INVAL;
+  cbh::DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t px = (size_t)w * h;
+  const unsigned bx = (unsigned)std::min<size_t>(1024, (px + 255) / 256);
+  const size_t per = std::min<size_t>(n, std::max<size_t>(1, std::min<size_t>(65535, ((size_t)1 << 30) / px)));
+  unsigned char *cg = nullptr, *tg = nullptr;
+  CBH_HIP(cbh::malloc_async((void**)&cg, per * px, s));
+  CBH_HIP(cbh::malloc_async((void**)&tg, per * px, s));
+  int rc = CBH_OK;
+  for (size_t i0 = 0; i0 < n && rc == CBH_OK; i0 += per) {
+    const size_t m = std::min(per, n - i0);
+    hipLaunchKernelGGL(k_tm_mask, dim3(bx, (unsigned)m), dim3(256), 0, s,
+                       (const unsigned char*)d_cands + i0 * cand_img_stride, w, h, cand_row_stride, cand_img_stride,
+                       cand_channels, (const unsigned char*)d_tmpl, tmpl_row_stride, tmpl_channels, cg, tg);
+    rc = cbh::launch_dcthash(cg, m, w, h, (size_t)w, px, (uint64_t*)d_cand_hashes + i0, s);
+    if (rc == CBH_OK) rc = cbh::launch_dcthash(tg, m, w, h, (size_t)w, px, (uint64_t*)d_tmpl_hashes + i0, s);
+  }
+  hipError_t e = hipGetLastError();
+  (void)hipFreeAsync(cg, s);
+  (void)hipFreeAsync(tg, s);
+  if (rc) return rc;
+  CBH_HIP(e);
+  if (!stream) CBH_HIP(hipStreamSynchronize(s));
+  return CBH_OK;
+}
+
+/* ... the same from host buffers, with the scores (hamm64 of the two hashes; the caller compares with tmThresh,
+ * :373-376).  cand_hashes / tmpl_hashes may be NULL. */
+int cbh_template_scores(const uint8_t* cands, size_t n, int w, int h, size_t cand_row_stride, size_t cand_img_stride,
+                        int cand_channels, const uint8_t* tmpl, size_t tmpl_row_stride, int tmpl_channels,
+                        uint64_t* cand_hashes, uint64_t* tmpl_hashes, int32_t* scores, int device) {
+  if (!cbh::device_usable(device)) return CBH_E_NODEVICE;
+  if (n == 0) return CBH_OK;
+  if (!cands || !tmpl || !scores || w <= 0 || h <= 0 || cand_channels < 1 || cand_channels > 4 || tmpl_channels < 1 ||
+      tmpl_channels > 4 || cand_row_stride < (size_t)w * cand_channels || tmpl_row_stride < (size_t)w * tmpl_channels)
+    return CBH_E_INVAL;
+  const size_t cspan = (size_t)(h - 1) * cand_row_stride + (size_t)w * cand_channels;
+  if (n > 1 && cand_img_stride < cspan) return CBH_E_INVAL;
+  const size_t cis = n > 1 ? cand_img_stride : cspan;
+  const size_t tspan = (size_t)(h - 1) * tmpl_row_stride + (size_t)w * tmpl_channels;
+  cbh::DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  hipStream_t s = nullptr;
+  unsigned char *d_c = nullptr, *d_t = nullptr;
+  uint64_t* d_h = nullptr;
+  auto cleanup = [&]() {
+    if (s) cbh::stream_destroy(s);
+    for (void* p : {(void*)d_c, (void*)d_t, (void*)d_h})
+      if (p) (void)hipFree(p);
+  };
+#define CBH_TRY(call)                       \
+  do {                                      \
+    hipError_t e_ = (call);                 \
+    if (e_ != hipSuccess) {                 \
+      cbh::set_last_error(#call, e_);       \
+      cleanup();                            \
+      return e_ == hipErrorOutOfMemory ? CBH_E_NOMEM : CBH_E_HIP; \
+    }                                       \
+  } while (0)
+  CBH_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  const size_t per = std::min(n, std::max<size_t>(1, ((size_t)256 << 20) / std::max(cis, cspan)));
+  CBH_TRY(hipMalloc(&d_c, (per - 1) * cis + cspan));
+  CBH_TRY(hipMalloc(&d_t, tspan));
+  CBH_TRY(hipMalloc(&d_h, 2 * per * sizeof(uint64_t)));
+  CBH_TRY(hipMemcpyAsync(d_t, tmpl, tspan, hipMemcpyHostToDevice, s));
+  std::vector<uint64_t> hh(2 * per);
+  int rc = CBH_OK;
+  for (size_t i0 = 0; i0 < n; i0 += per) {
+    const size_t m = std::min(per, n - i0);
+    CBH_TRY(hipMemcpyAsync(d_c, cands + i0 * cis, (m - 1) * cis + cspan, hipMemcpyHostToDevice, s));
+    rc = cbh_template_hashes_dev(d_c, m, w, h, cand_row_stride, cis, cand_channels, d_t, tmpl_row_stride, tmpl_channels,
+                                 d_h, d_h + per, device, s);
+    if (rc) break;
+    CBH_TRY(hipMemcpyAsync(hh.data(), d_h, 2 * per * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    CBH_TRY(hipStreamSynchronize(s));
+    for (size_t i = 0; i < m; ++i) {
+      scores[i0 + i] = __builtin_popcountll(hh[i] ^ hh[per + i]);
+      if (cand_hashes) cand_hashes[i0 + i] = hh[i];
+      if (tmpl_hashes) tmpl_hashes[i0 + i] = hh[per + i];
+    }
   }
 #undef CBH_TRY
   cleanup();

@@ -55,6 +55,29 @@ def process_images(imgs: np.ndarray, autocrop: int | None = 20, device: int = 0)
     return out, rects
 
 
+def template_scores(cands: np.ndarray, tmpl: np.ndarray, device: int = 0):
+    """TemplateMatcher::match's score (src/templatematcher.cpp:331-374) for n candidate patches against one template:
+    cands uint8 [n,h,w] or [n,h,w,3|4] as warpAffine left them (0 outside the patch), tmpl uint8 [h,w] or [h,w,3|4].
+    Returns (scores int32[n] = hamm64(candHash, tmplHash), candHashes u64[n], tmplHashes u64[n])."""
+    cands = np.ascontiguousarray(cands)
+    tmpl = np.ascontiguousarray(tmpl)
+    if cands.dtype != np.uint8 or cands.ndim not in (3, 4) or tmpl.dtype != np.uint8 or tmpl.ndim not in (2, 3):
+        raise ValueError("expected uint8 cands [n,h,w(,c)] and tmpl [h,w(,c)]")
+    n, h, w = cands.shape[:3]
+    if tmpl.shape[:2] != (h, w):
+        raise ValueError("the candidate patches are template-sized (warpAffine's dsize = tmplImg.size())")
+    cc = 1 if cands.ndim == 3 else cands.shape[3]
+    tc = 1 if tmpl.ndim == 2 else tmpl.shape[2]
+    scores = np.zeros(n, np.int32)
+    ch = np.zeros(n, np.uint64)
+    th = np.zeros(n, np.uint64)
+    if n:
+        check(_lib.lib().cbh_template_scores(cands.ctypes.data, n, w, h, w * cc, w * h * cc, cc, tmpl.ctypes.data, w * tc,
+                                             tc, ch.ctypes.data, th.ctypes.data, scores.ctypes.data, device),
+              "template_scores")
+    return scores, ch, th
+
+
 def process_images_ex(imgs: np.ndarray, autocrop: int | None = 20, resize: int = 400, device: int = 0):
     """process_images plus, from the same upload, sizeLongestSide(cvGray, resize) of every (autocropped) grey image --
     what Scanner::processImage hands to ORB (src/scanner.cpp:876).  Returns (hashes, rects, list of uint8 images)."""

@@ -464,6 +464,20 @@ int cbh_vindexer_push_dev(cbh_vindexer*, const void* d_frames, size_t n, int w, 
 long long cbh_vindexer_frames_seen(const cbh_vindexer*);   /* makeVideoIndex's frameNumber */
 long long cbh_vindexer_finish(const cbh_vindexer*, int32_t* frames, uint64_t* hashes, size_t cap);
 
+/* ---- TemplateMatcher::match's score (src/templatematcher.cpp:331-374) ------------------------------------------------
+ * For n candidate patches as warpAffine left them (template-sized; channels 1, 3 = BGR or 4 = BGRA; pixels outside the
+ * warped patch are 0) and ONE template image: grayscale(cand); per pixel the candidate's grey value is the mask -- where
+ * it is 0 the template's pixel is zeroed too, a BGRA template is premultiplied by its alpha (and scales the candidate's
+ * grey value by it) (:343-364); candHash = dctHash64(cand), tmplHash = dctHash64(tmplMasked); score = hamm64 of the two
+ * (:366-371; the caller compares with tmThresh, :373).  The descriptor match in front of it is cbh_idx256_radius_match;
+ * estimateRigidTransform / warpAffine between the two stay with the caller (OpenCV). */
+int cbh_template_scores(const uint8_t* cands, size_t n, int w, int h, size_t cand_row_stride, size_t cand_img_stride,
+                        int cand_channels, const uint8_t* tmpl, size_t tmpl_row_stride, int tmpl_channels,
+                        uint64_t* cand_hashes, uint64_t* tmpl_hashes, int32_t* scores, int device);
+int cbh_template_hashes_dev(const void* d_cands, size_t n, int w, int h, size_t cand_row_stride, size_t cand_img_stride,
+                            int cand_channels, const void* d_tmpl, size_t tmpl_row_stride, int tmpl_channels,
+                            void* d_cand_hashes, void* d_tmpl_hashes, int device, void* stream);
+
 /* ---- CvFeaturesIndex: src/cvfeaturesindex.{h,cpp} ---------------------------------------------------
  * N x 32-byte ORB/BRIEF descriptor rows (cv::Mat CV_8U, cvfeaturesindex.h:73) + the first-row -> mediaId
  * map (_indexMap/_idMap, :77-81).  Searches are exact brute force (the reference asks a FLANN LSH index,

@@ -782,6 +782,25 @@ class PrestageOracle:
         self.L.orc_autocrop(gray.reshape(-1), w, h, w, int(rng), r)
         return r
 
+    def template_score(self, cand, tmpl):
+        """TemplateMatcher::match's score (templatematcher.cpp:331-374): (distance, candHash, tmplHash, cand grey as
+        hashed, masked template grey as hashed)"""
+        cand = np.ascontiguousarray(cand, np.uint8)
+        tmpl = np.ascontiguousarray(tmpl, np.uint8)
+        h, w = cand.shape[:2]
+        cc = 1 if cand.ndim == 2 else cand.shape[2]
+        tc = 1 if tmpl.ndim == 2 else tmpl.shape[2]
+        assert tmpl.shape[:2] == (h, w)
+        f = self.L.orc_template_score
+        f.argtypes = [_u8p, C.c_int, C.c_size_t, _u8p, C.c_int, C.c_size_t, C.c_int, C.c_int, _u64p, _u64p, _u8p, _u8p]
+        f.restype = C.c_int
+        ch, th = np.zeros(1, np.uint64), np.zeros(1, np.uint64)
+        cg, tg = np.zeros((h, w), np.uint8), np.zeros((h, w), np.uint8)
+        d = f(cand.reshape(-1), cc, w * cc, tmpl.reshape(-1), tc, w * tc, w, h, ch, th, cg.reshape(-1), tg.reshape(-1))
+        if d < 0:
+            raise ValueError(f"orc_template_score rc={d}")
+        return d, int(ch[0]), int(th[0]), cg, tg
+
     def process_image(self, img, autocrop=20):
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape[:2]

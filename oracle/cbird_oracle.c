@@ -1675,3 +1675,65 @@ int orc_process_image(const uint8_t* img, int w, int h, size_t stride, int chann
   free(gray);
   return rc;
 }
+
+/* TemplateMatcher::match's score for one candidate (src/templatematcher.cpp:331-374), given the candidate patch as
+ * warpAffine left it (template-sized, the candidate's channel count; undefined pixels are 0) and the template image:
+ *   tmplMasked = tmplImg.clone(); grayscale(cand) (:334-337); then per pixel (:343-364) the candidate's grey value is
+ *   "the mask indicator": where it is 0 the template's pixel is zeroed too (srcChannels < 4), and for a BGRA template
+ *   the colour is premultiplied by its alpha, alpha set to 255 and the candidate's grey value scaled by the same alpha;
+ *   candHash = dctHash64(cand), tmplHash = dctHash64(tmplMasked) (dctHash64 greys colour input itself), score =
+ *   hamm64 (:366-371).  Channels 1, 3 (BGR) or 4 (BGRA).  cand_gray / tmpl_gray (optional, w*h bytes) receive the two
+ *   images that were hashed (the template one after dctHash64's own grayscale).  Returns the distance, < 0 on error. */
+int orc_template_score(const uint8_t* cand, int cand_channels, size_t cand_stride, const uint8_t* tmpl,
+                       int tmpl_channels, size_t tmpl_stride, int w, int h, uint64_t* cand_hash, uint64_t* tmpl_hash,
+                       uint8_t* cand_gray, uint8_t* tmpl_gray) {
+  if (w <= 0 || h <= 0 || (cand_channels != 1 && cand_channels != 3 && cand_channels != 4) ||
+      (tmpl_channels != 1 && tmpl_channels != 3 && tmpl_channels != 4))
+    return -1;
+  uint8_t* img = (uint8_t*)malloc((size_t)w * h);                      /* grayscale(img, img) */
+  uint8_t* masked = (uint8_t*)malloc((size_t)w * h * tmpl_channels);   /* tmplImg.clone() */
+  uint8_t* mg = (uint8_t*)malloc((size_t)w * h);
+  if (cand_channels == 1)
+    for (int y = 0; y < h; ++y) memcpy(img + (size_t)y * w, cand + (size_t)y * cand_stride, (size_t)w);
+  else
+    orc_bgr2gray(cand, w, h, cand_stride, cand_channels, img);
+  for (int y = 0; y < h; ++y)
+    memcpy(masked + (size_t)y * w * tmpl_channels, tmpl + (size_t)y * tmpl_stride, (size_t)w * tmpl_channels);
+  const int srcChannels = tmpl_channels;
+  for (int y = 0; y < h; ++y) {
+    uint8_t* src = masked + (size_t)y * w * srcChannels;
+    uint8_t* dst = img + (size_t)y * w;
+    for (int x = 0; x < w; ++x) {
+      uint8_t* dp = dst + x;
+      uint8_t* sp = src + x * srcChannels;
+      const uint8_t dstPixel = *dp;
+      const uint8_t dstMask = dstPixel != 0 ? 255 : 0;
+      if (srcChannels < 4) {
+        for (int j = 0; j < srcChannels; ++j) *sp++ &= dstMask;
+      } else {
+        const int srcAlpha = sp[3];
+        sp[0] = ((sp[0] * srcAlpha) >> 8) & dstMask;
+        sp[1] = ((sp[1] * srcAlpha) >> 8) & dstMask;
+        sp[2] = ((sp[2] * srcAlpha) >> 8) & dstMask;
+        sp[3] = 255;
+        *dp = (uint8_t)((dstPixel * srcAlpha) >> 8);
+      }
+    }
+  }
+  if (srcChannels == 1)
+    memcpy(mg, masked, (size_t)w * h);
+  else
+    orc_bgr2gray(masked, w, h, (size_t)w * srcChannels, srcChannels, mg);
+  uint64_t ch = 0, th = 0;
+  int rc = orc_dcthash64(img, w, h, (size_t)w, &ch);
+  if (rc == 0) rc = orc_dcthash64(mg, w, h, (size_t)w, &th);
+  if (cand_gray) memcpy(cand_gray, img, (size_t)w * h);
+  if (tmpl_gray) memcpy(tmpl_gray, mg, (size_t)w * h);
+  free(img);
+  free(masked);
+  free(mg);
+  if (rc) return -2;
+  if (cand_hash) *cand_hash = ch;
+  if (tmpl_hash) *tmpl_hash = th;
+  return __builtin_popcountll(ch ^ th);
+}

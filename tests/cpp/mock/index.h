@@ -216,6 +216,7 @@ struct QSqlQuery {
 // ---- value types the other indexes carry (shapes only) ----------------------------------------------
 typedef uint64_t dcthash_t;
 typedef std::vector<uint64_t> KeyPointHashList;
+#define CV_8U 0
 #define CV_8UC1 0
 #define CV_8UC3 16
 #define CV_8UC4 24
@@ -260,6 +261,7 @@ struct Mat {  // rows x cols bytes (CV_8UC1); views share the parent's storage l
   T* ptr(int r) { return reinterpret_cast<T*>(data + size_t(r) * step); }
   int type() const { return (_cn - 1) << 3; }
   int channels() const { return _cn; }
+  int depth() const { return 0; }  // CV_8U
   Mat colRange(int x0, int x1) const {
     Mat m(*this);
     m.data += size_t(x0) * size_t(_cn), m.cols = x1 - x0, m._ofs.x += x0;

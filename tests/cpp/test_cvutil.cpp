@@ -117,5 +117,31 @@ int main(int argc, char** argv) {
     cbird_gpu::gpuColorDescriptorCreate(img, untouched);  // CV_8UC1
     printf("color_gray %d\n", int(untouched.numColors));
   }
+  // 7. TemplateMatcher::match's scoring block: the BGR image of step 6 (regenerated) as the template, BGRA variant
+  //    with a varying alpha; the candidate = the template shifted by 3 px with a 12-px undefined (black) margin
+  {
+    cv::Mat tmpl3(h, w, CV_8UC3), tmpl4(h, w, CV_8UC4), cand(h, w, CV_8UC3);
+    uint32_t s5 = uint32_t(atoi(argv[3])) + 99u;
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x)
+        for (int c = 0; c < 3; ++c) {
+          const uint8_t v = uint8_t(((x / 23 + 2 * (y / 17) + c) % 5) * 50 + int(xs(s5) % 7u));
+          tmpl3.ptr<uint8_t>(y)[3 * x + c] = v;
+          tmpl4.ptr<uint8_t>(y)[4 * x + c] = v;
+        }
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) {
+        tmpl4.ptr<uint8_t>(y)[4 * x + 3] = uint8_t(255 - (x + y) % 97);
+        for (int c = 0; c < 3; ++c) {
+          const bool inside = x >= 12 && y >= 12 && x < w - 12 && y < h - 12;
+          cand.ptr<uint8_t>(y)[3 * x + c] = inside ? tmpl3.ptr<uint8_t>(y)[3 * (x - 3) + c] : uint8_t(0);
+        }
+      }
+    uint64_t ch = 0, th = 0;
+    const int d3 = cbird_gpu::gpuTemplateScore(cand, tmpl3, &ch, &th);
+    printf("tm3 %d %" PRIu64 " %" PRIu64 "\n", d3, ch, th);
+    const int d4 = cbird_gpu::gpuTemplateScore(cand, tmpl4, &ch, &th);
+    printf("tm4 %d %" PRIu64 " %" PRIu64 "\n", d4, ch, th);
+  }
   return 0;
 }

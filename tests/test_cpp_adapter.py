@@ -157,6 +157,18 @@ def test_cvutil_dropins_run_on_gpu(gpu, orc, w, h, seed):
     want_cd, _ = ColorCreateOracle().create(bgr)
     assert got["color"] == [int(want_cd[256]), _checksum(want_cd[:257])]
     assert got["color_gray"] == [77]
+    # TemplateMatcher::match's scoring block (gpuTemplateScore)
+    from oracle import PrestageOracle
+
+    po = PrestageOracle()
+    alpha = np.array([[255 - (x + y) % 97 for x in range(w)] for y in range(h)], np.uint8)
+    tmpl4 = np.dstack([bgr, alpha])
+    cand = np.zeros_like(bgr)
+    cand[12:h - 12, 12:w - 12] = bgr[12:h - 12, 9:w - 15]
+    d3, ch3, th3, _, _ = po.template_score(cand, bgr)
+    d4, ch4, th4, _, _ = po.template_score(cand, tmpl4)
+    assert got["tm3"] == [d3, ch3, th3] and got["tm4"] == [d4, ch4, th4]
+    assert ch3 != ch4 and th3 != th4  # the alpha reaches both images
 
 
 def test_makevideoindex_dropin_compiles():
