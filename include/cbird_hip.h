@@ -452,7 +452,9 @@ size_t cbh_video_dedup(const uint64_t* hashes, size_t n, int threshold, uint8_t*
  *             are dropped as at :1013-1016.
  *   finish(): the index as makeVideoIndex leaves it, with the last frame appended if it was not stored (:1018-1024);
  *             returns the number of entries and writes them when cap suffices.  Does not change the handle: more
- *             frames may be pushed afterwards. */
+ *             frames may be pushed afterwards.
+ * One handle = one video, used by one thread at a time (Scanner::processVideo runs one per worker thread); handles of
+ * different threads are independent (each owns its stream and buffers). */
 typedef struct cbh_vindexer cbh_vindexer;
 cbh_vindexer* cbh_vindexer_create(int device, int threshold, int autocrop_range);
 void cbh_vindexer_destroy(cbh_vindexer*);
