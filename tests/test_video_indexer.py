@@ -228,3 +228,31 @@ def test_indexer_output_round_trips_through_vdx_and_findvideo(vo, po, tmp_path):
     assert needle.videoIndex.frames == vids[1].frames
     m = idx.find(needle, p)
     assert [x.mediaId for x in m][:1] == [2]
+
+
+@pytest.mark.gpu
+def test_indexers_on_worker_threads_are_independent(vo, po):
+    """Scanner::processVideo runs one video per worker thread: four indexers fed concurrently (different geometries,
+    chunk sizes and letterboxes) give what each gives alone"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from cbird_amd.video import VideoIndexer
+
+    jobs = [(41, 60, 240, 320, (30, 30, 0, 0), 7), (42, 50, 180, 320, (0, 0, 0, 0), 16),
+            (43, 70, 200, 360, (0, 0, 40, 40), 5), (44, 40, 256, 256, (0, 0, 0, 0), 40)]
+    clips = [clip(s, n, h, w, bars) for (s, n, h, w, bars, _) in jobs]
+    want = [oracle_index(po, vo, c, 8)[0] for c in clips]
+
+    def run(k):
+        ix = VideoIndexer(threshold=8)
+        ch = jobs[k][5]
+        for rep in range(3):  # several rounds so that the threads really overlap
+            ix = VideoIndexer(threshold=8)
+            for i in range(0, len(clips[k]), ch):
+                ix.push(clips[k][i:i + ch])
+        return ix.finish()
+
+    with ThreadPoolExecutor(4) as ex:
+        got = list(ex.map(run, range(4)))
+    for k in range(4):
+        assert got[k].frames == want[k][0].tolist() and got[k].hashes == [int(x) for x in want[k][1]], k
