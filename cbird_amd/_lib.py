@@ -135,6 +135,8 @@ _SIGS = {
                                              C.c_int, _vp, _sz, _vp]),
     "cbh_vdx_encode": (_sz, [_vp, _vp, _sz, C.c_char_p, _vp, _sz]),
     "cbh_vdx_decode": (C.c_longlong, [_vp, _sz, _vp, _vp, _sz]),
+    "cbh_vdx_version": (C.c_int, [_vp, _sz]),
+    "cbh_vdx_encode_v1": (_sz, [_vp, _vp, _sz, _vp, _sz]),
     "cbh_video_dedup": (_sz, [_vp, _sz, C.c_int, _vp]),
     "cbh_template_scores": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, C.c_int, _vp, _sz, C.c_int, _vp, _vp, _vp,
                                       C.c_int]),

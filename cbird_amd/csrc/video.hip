@@ -479,7 +479,7 @@ static int vdx_header(const uint8_t* buf, size_t len, size_t* hdr_len, size_t* n
 /* VideoIndex::load_v2 (:350-429).  Like the reference's loader it does NOT look at the "cbir" trailer (that is
  * verify_v2's job, cbh_vdx_verify below), and a file claiming more than MAX_FRAMES_PER_VIDEO frames is loaded up to
  * that limit (:366-370, :395) instead of being rejected. */
-long long cbh_vdx_decode(const uint8_t* buf, size_t len, int32_t* frames, uint64_t* hashes, size_t cap) {
+static long long vdx_decode_v2(const uint8_t* buf, size_t len, int32_t* frames, uint64_t* hashes, size_t cap) {
   if (!buf) return CBH_E_INVAL;
   size_t hdr = 0, numFrames = 0;
   int rc = vdx_header(buf, len, &hdr, &numFrames);
@@ -520,10 +520,99 @@ long long cbh_vdx_decode(const uint8_t* buf, size_t len, int32_t* frames, uint64
   return (long long)numFrames;
 }
 
-/* VideoIndex::verify_v2 (:248-269), what isValid() runs: header fields + the "cbir" trailer at the end of the file
- * (a file with 0 frames is valid without one).  1 = valid, 0 = not. */
+/* VideoIndex::getVersion (src/videoindex.cpp:41-68): a file that starts with "cbird" is version 2, anything else --
+ * including a file too short to tell -- the old version 1 (u16 frame count, u16 frame numbers, u64 hashes; "limited to
+ * 65k frames/videos"). */
+int cbh_vdx_version(const uint8_t* buf, size_t len) {
+  if (!buf || len < 5) return 1;
+  return memcmp(buf, "cbird", 5) == 0 ? 2 : 1;
+}
+
+/* VideoIndex::load_v1 (:478-541) with its two repairs: frame numbers that wrapped past 65535 (an old writer's bug) cut
+ * the index there (:503-516), and an index whose first frame is not 0 gets a frame 0 with hash 0 in front (:530-535) */
+static long long vdx_decode_v1(const uint8_t* buf, size_t len, int32_t* frames, uint64_t* hashes, size_t cap) {
+  if (len < 2) return CBH_E_INVAL;  // "header"
+  uint16_t numFrames;
+  memcpy(&numFrames, buf, 2);
+  if (numFrames == 0) return 0;
+  const size_t orig = numFrames;
+  if (2 + 2 * orig > len) return CBH_E_INVAL;  // "frame numbers"
+  std::vector<int32_t> f(orig);
+  size_t n = orig;
+  uint16_t last = 0;
+  for (size_t i = 0; i < orig; ++i) {
+    uint16_t frame;
+    memcpy(&frame, buf + 2 + 2 * i, 2);
+    if (frame < last) {
+      if (last > 65000) {  // probably wrapped due to having too many frames
+        if (last != UINT16_MAX) {
+          f[i] = UINT16_MAX;
+          i++;
+        }
+        n = i;
+        break;
+      }
+      return CBH_E_INVAL;  // non-sequential frame number (corrupt file?)
+    }
+    last = frame;
+    f[i] = frame;
+  }
+  if (2 + 2 * orig + 8 * n > len) return CBH_E_INVAL;  // "hashes"
+  const bool fix0 = n && f[0] != 0;
+  if (n + (fix0 ? 1 : 0) > cap) return CBH_E_OVERFLOW;
+  const size_t o = fix0 ? 1 : 0;
+  if (frames) {
+    if (fix0) frames[0] = 0;
+    memcpy(frames + o, f.data(), n * sizeof(int32_t));
+  }
+  if (hashes) {
+    if (fix0) hashes[0] = 0;
+    memcpy(hashes + o, buf + 2 + 2 * orig, n * 8);
+  }
+  return (long long)(n + o);
+}
+
+/* VideoIndex::load (:70-90): version 1 or 2 by the magic; a negative CBH_E_* where the reference's loader fails (it
+ * then leaves the index empty) */
+long long cbh_vdx_decode(const uint8_t* buf, size_t len, int32_t* frames, uint64_t* hashes, size_t cap) {
+  if (!buf) return CBH_E_INVAL;
+  return cbh_vdx_version(buf, len) == 2 ? vdx_decode_v2(buf, len, frames, hashes, cap)
+                                        : vdx_decode_v1(buf, len, frames, hashes, cap);
+}
+
+/* VideoIndex::save_v1 (:448-476), for files an old cbird still has to read: at most INT16_MAX frames, frame numbers
+ * up to 65535 (the rest is dropped, as there).  Returns the size, and writes the file when it fits. */
+size_t cbh_vdx_encode_v1(const int32_t* frames, const uint64_t* hashes, size_t n, uint8_t* out, size_t cap) {
+  if (n && (!frames || !hashes)) return 0;
+  size_t numFrames = n < (size_t)INT16_MAX ? n : (size_t)INT16_MAX;
+  for (size_t i = 0; i < numFrames; ++i)
+    if (frames[i] > UINT16_MAX || frames[i] < 0) {
+      numFrames = i;
+      break;
+    }
+  const size_t size = 2 + 10 * numFrames;
+  if (out && size <= cap) {
+    const uint16_t nf = (uint16_t)numFrames;
+    memcpy(out, &nf, 2);
+    for (size_t i = 0; i < numFrames; ++i) {
+      const uint16_t fr = (uint16_t)frames[i];
+      memcpy(out + 2 + 2 * i, &fr, 2);
+    }
+    if (numFrames) memcpy(out + 2 + 2 * numFrames, hashes, 8 * numFrames);
+  }
+  return size;
+}
+
+/* VideoIndex::isValid (:92-103): verify_v2 (:248-269: header fields + the "cbir" trailer at the end of the file; a file
+ * with 0 frames is valid without one) or verify_v1 (:431-446: the size the frame count implies).  1 = valid, 0 = not. */
 int cbh_vdx_verify(const uint8_t* buf, size_t len) {
   if (!buf) return 0;
+  if (cbh_vdx_version(buf, len) == 1) {
+    if (len < 2) return 0;
+    uint16_t numFrames;
+    memcpy(&numFrames, buf, 2);
+    return len == 2 + (size_t)10 * numFrames;
+  }
   size_t hdr = 0, numFrames = 0;
   if (vdx_header(buf, len, &hdr, &numFrames)) return 0;
   if (numFrames == 0) return 1;

@@ -437,6 +437,11 @@ size_t cbh_vdx_encode(const int32_t* frames, const uint64_t* hashes, size_t n, c
                       uint8_t* out, size_t cap);
 long long cbh_vdx_decode(const uint8_t* buf, size_t len, int32_t* frames, uint64_t* hashes, size_t cap);
 int cbh_vdx_verify(const uint8_t* buf, size_t len);
+/* the old version-1 files (src/videoindex.cpp:41-68, 431-541: u16 frame count, u16 frame numbers, u64 hashes): decode and
+ * verify above pick the version by the magic like VideoIndex::load / isValid and apply load_v1's two repairs (frame
+ * numbers that wrapped past 65535; a missing frame 0); cbh_vdx_version tells which it is, cbh_vdx_encode_v1 = save_v1. */
+int cbh_vdx_version(const uint8_t* buf, size_t len);
+size_t cbh_vdx_encode_v1(const int32_t* frames, const uint64_t* hashes, size_t n, uint8_t* out, size_t cap);
 /* frame de-dup of Media::makeVideoIndex (src/media.cpp:958-1024); keep[i]=1 for stored frames */
 size_t cbh_video_dedup(const uint64_t* hashes, size_t n, int threshold, uint8_t* keep);
 

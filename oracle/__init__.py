@@ -588,6 +588,39 @@ class VideoOracle:
             raise ValueError(f"vdx decode error {n}")
         return f[:n].copy(), h[:n].copy()
 
+    def vdx_any_decode(self, data: bytes):
+        """VideoIndex::load: version 1 or 2 by the magic; None where the loader fails"""
+        f = self.L.orc_vdx_any_decode
+        f.argtypes = [_u8p, C.c_size_t, _i32p, _u64p, C.c_size_t]
+        f.restype = C.c_longlong
+        buf = np.frombuffer(data, np.uint8) if len(data) else np.zeros(1, np.uint8)
+        cap = len(data) + 2
+        fr, hs = np.zeros(cap, np.int32), np.zeros(cap, np.uint64)
+        n = f(buf, len(data), fr, hs, cap)
+        return None if n < 0 else (fr[:n].copy(), hs[:n].copy())
+
+    def vdx_any_verify(self, data: bytes) -> bool:
+        f = self.L.orc_vdx_any_verify
+        f.argtypes = [_u8p, C.c_size_t]
+        f.restype = C.c_int
+        buf = np.frombuffer(data, np.uint8) if len(data) else np.zeros(1, np.uint8)
+        return bool(f(buf, len(data)))
+
+    def vdx_encode_v1(self, frames, hashes) -> bytes:
+        f = self.L.orc_vdx_encode_v1
+        f.argtypes = [_i32p, _u64p, C.c_size_t, _u8p, C.c_size_t]
+        f.restype = C.c_size_t
+        fr = np.ascontiguousarray(frames, np.int32)
+        hs = np.ascontiguousarray(hashes, np.uint64)
+        if len(fr) == 0:
+            fr, hs = np.zeros(1, np.int32), np.zeros(1, np.uint64)
+            n = 0
+        else:
+            n = len(frames)
+        out = np.zeros(2 + 10 * max(1, n), np.uint8)
+        size = f(fr, hs, n, out, len(out))
+        return out[:size].tobytes()
+
     def vdx_verify(self, data: bytes) -> bool:
         buf = np.frombuffer(data, np.uint8).copy()
         f = self.L.orc_vdx_verify

@@ -1737,3 +1737,83 @@ int orc_template_score(const uint8_t* cand, int cand_channels, size_t cand_strid
   if (tmpl_hash) *tmpl_hash = th;
   return __builtin_popcountll(ch ^ th);
 }
+
+/* The version-1 .vdx file (src/videoindex.cpp:41-68 getVersion, :431-446 verify_v1, :448-476 save_v1, :478-541 load_v1):
+ *   u16 numFrames | numFrames x u16 frame number | numFrames x u64 hash
+ * orc_vdx_any_decode = VideoIndex::load (:70-90): "cbird" magic -> load_v2 (orc_vdx_decode), else load_v1 with its two
+ * repairs; orc_vdx_any_verify = VideoIndex::isValid (:92-103).  Negative = the loader fails. */
+long long orc_vdx_any_decode(const uint8_t* buf, size_t len, int32_t* frames, uint64_t* hashes, size_t cap) {
+  if (len >= 5 && memcmp(buf, "cbird", 5) == 0) return orc_vdx_decode(buf, len, frames, hashes, cap);
+  size_t pos = 0;
+  uint16_t numFrames = 0;
+  if (pos + 2 > len) return -1; /* io.read(&numFrames, 1, "header") */
+  memcpy(&numFrames, buf + pos, 2);
+  pos += 2;
+  if (numFrames == 0) return 0;
+  if (pos + 2 * (size_t)numFrames > len) return -2; /* "frame numbers" */
+  const uint8_t* fr = buf + pos;
+  pos += 2 * (size_t)numFrames;
+  if ((size_t)numFrames > cap) return -4;
+  uint16_t last = 0;
+  int count = numFrames; /* the vector sizes, shrunk by the wrap repair */
+  for (int i = 0; i < numFrames; ++i) {
+    uint16_t frame;
+    memcpy(&frame, fr + 2 * i, 2);
+    if (frame < last) {
+      if (last > 65000) {
+        if (last != UINT16_MAX) {
+          frames[i] = UINT16_MAX;
+          i++;
+        }
+        count = i;
+        break;
+      } else {
+        return -2; /* non-sequential frame number (corrupt file?) */
+      }
+    }
+    last = frame;
+    frames[i] = frame;
+  }
+  if (pos + 8 * (size_t)count > len) return -2; /* "hashes" */
+  memcpy(hashes, buf + pos, 8 * (size_t)count);
+  if (count && frames[0] != 0) { /* "fixing non-zero first frame bug" */
+    if ((size_t)count + 1 > cap) return -4;
+    memmove(frames + 1, frames, sizeof(int32_t) * (size_t)count);
+    memmove(hashes + 1, hashes, sizeof(uint64_t) * (size_t)count);
+    frames[0] = 0;
+    hashes[0] = 0;
+    ++count;
+  }
+  return count;
+}
+
+int orc_vdx_any_verify(const uint8_t* buf, size_t len) {
+  if (len >= 5 && memcmp(buf, "cbird", 5) == 0) return orc_vdx_verify(buf, len);
+  uint16_t numFrames = 0;
+  if (len < 2) return 0;
+  memcpy(&numFrames, buf, 2);
+  const size_t size = sizeof(uint16_t) + sizeof(uint16_t) * numFrames + sizeof(uint64_t) * numFrames;
+  return len == size;
+}
+
+/* save_v1 (:448-476) */
+size_t orc_vdx_encode_v1(const int32_t* frames, const uint64_t* hashes, size_t n, uint8_t* out, size_t cap) {
+  uint16_t numFrames = (uint16_t)(n < (size_t)INT16_MAX ? n : (size_t)INT16_MAX);
+  uint16_t* f16 = (uint16_t*)malloc(sizeof(uint16_t) * ((size_t)numFrames + 1));
+  size_t m = 0;
+  for (int i = 0; i < numFrames; ++i) {
+    if (frames[i] > UINT16_MAX) {
+      numFrames = (uint16_t)m;
+      break;
+    }
+    f16[m++] = (uint16_t)frames[i];
+  }
+  const size_t size = 2 + 10 * (size_t)numFrames;
+  if (out && size <= cap) {
+    memcpy(out, &numFrames, 2);
+    memcpy(out + 2, f16, 2 * (size_t)numFrames);
+    memcpy(out + 2 + 2 * (size_t)numFrames, hashes, 8 * (size_t)numFrames);
+  }
+  free(f16);
+  return size;
+}

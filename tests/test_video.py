@@ -64,6 +64,95 @@ def test_vdx_rejects_corruption(vorc, tmp_path):
         vorc.vdx_encode([0, 2, 2], [1, 2, 3])  # non-sequential
 
 
+def _v1(frames, hashes, count=None):
+    """a version-1 file by the format (videoindex.cpp:448-476): u16 count, u16 frame numbers, u64 hashes"""
+    n = len(frames) if count is None else count
+    return (n.to_bytes(2, "little") + b"".join(int(f).to_bytes(2, "little") for f in frames) +
+            b"".join(int(h).to_bytes(8, "little") for h in hashes))
+
+
+def test_vdx_version1_files_load_like_the_reference(vorc, tmp_path):
+    """unit/testvideoindex.cpp testV1Load / testV1Save / testLoad: VideoIndex::load and isValid pick the version by the
+    "cbird" magic (videoindex.cpp:41-68); load_v1's repairs (:503-535); product host code == oracle == the format"""
+    from cbird_amd import _lib
+    from cbird_amd.video import VideoIndex
+
+    L = _lib.lib()
+
+    def version(data):
+        b = np.frombuffer(data, np.uint8) if data else np.zeros(1, np.uint8)
+        return L.cbh_vdx_version(b.ctypes.data, len(data))
+
+    def valid(data):
+        b = np.frombuffer(data, np.uint8) if data else np.zeros(1, np.uint8)
+        return bool(L.cbh_vdx_verify(b.ctypes.data, len(data)))
+
+    def encode_v1(frames, hashes):
+        f, h = np.ascontiguousarray(frames, np.int32), np.ascontiguousarray(hashes, np.uint64)
+        n = L.cbh_vdx_encode_v1(f.ctypes.data, h.ctypes.data, len(f), None, 0)
+        out = np.zeros(n, np.uint8)
+        L.cbh_vdx_encode_v1(f.ctypes.data, h.ctypes.data, len(f), out.ctypes.data, n)
+        return out.tobytes()
+
+    # testV1Save (:71-92): save_v1 then load_v1 round trip
+    frames, hashes = [0, 10, 30], [40404040, 10101010, 30303030]
+    data = encode_v1(frames, hashes)
+    assert data == _v1(frames, hashes) == vorc.vdx_encode_v1(frames, hashes)
+    assert version(data) == 1 and valid(data) and vorc.vdx_any_verify(data)
+    vi = VideoIndex.from_bytes(data)
+    assert vi.frames == frames and vi.hashes == hashes
+    # testLoad (:94-118): a 201-frame version-1 index (frames 0..1999) and its version-2 conversion load identically
+    f201 = list(range(0, 2000, 10)) + [1999]
+    h201 = [int(x) for x in np.random.default_rng(1).integers(1, 2 ** 63, 201, dtype=np.uint64)]
+    v1 = VideoIndex.from_bytes(_v1(f201, h201))
+    assert len(v1.frames) == 201 and v1.frames[0] == 0 and v1.frames[-1] == 1999
+    v2data = v1.to_bytes()
+    assert version(v2data) == 2 and valid(v2data)
+    v2 = VideoIndex.from_bytes(v2data)
+    assert v2.frames == v1.frames and v2.hashes == v1.hashes == h201
+    # version1-truncated / empty / version1-empty (:44-68)
+    cut = _v1(f201, h201)[:-5]
+    assert not valid(cut) and not vorc.vdx_any_verify(cut) and vorc.vdx_any_decode(cut) is None
+    with pytest.raises(ValueError):
+        VideoIndex.from_bytes(cut)
+    assert not valid(b"") and not vorc.vdx_any_verify(b"") and vorc.vdx_any_decode(b"") is None
+    with pytest.raises(ValueError):
+        VideoIndex.from_bytes(b"")
+    none = _v1([], [])
+    assert valid(none) and vorc.vdx_any_verify(none) and VideoIndex.from_bytes(none).isEmpty()
+    # load_v1's repairs: frame numbers that wrapped past 65535 cut the index (:503-516) ...
+    wrap = [0, 30000, 65400, 65500, 100, 200]
+    got = VideoIndex.from_bytes(_v1(wrap, [1, 2, 3, 4, 5, 6]))
+    assert got.frames == [0, 30000, 65400, 65500, 65535] and got.hashes == [1, 2, 3, 4, 5]
+    got = VideoIndex.from_bytes(_v1([0, 7, 65535, 3], [1, 2, 3, 4]))
+    assert got.frames == [0, 7, 65535] and got.hashes == [1, 2, 3]
+    with pytest.raises(ValueError):  # out of order without the wrap signature: corrupt
+        VideoIndex.from_bytes(_v1([0, 500, 100], [1, 2, 3]))
+    # ... and an index that does not start at frame 0 gets one in front (:530-535)
+    got = VideoIndex.from_bytes(_v1([5, 10], [11, 12]))
+    assert got.frames == [0, 5, 10] and got.hashes == [0, 11, 12]
+    # save_v1 drops what the format cannot hold (:452-468)
+    assert VideoIndex.from_bytes(encode_v1([0, 100, 70000, 70001], [1, 2, 3, 4])).frames == [0, 100]
+    # product host code == oracle on random version-1 files, good and damaged
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        n = int(rng.integers(0, 40))
+        fr = np.sort(rng.choice(65536, n, replace=False)) if rng.random() < 0.7 else rng.integers(0, 65536, n)
+        if n and rng.random() < 0.5:
+            fr[0] = 0
+        data = _v1(fr.tolist(), rng.integers(0, 2 ** 63, n).tolist())
+        if rng.random() < 0.2:
+            data = data[: int(rng.integers(0, len(data) + 1))]
+        want = vorc.vdx_any_decode(data)
+        assert valid(data) == vorc.vdx_any_verify(data)
+        if want is None:
+            with pytest.raises(ValueError):
+                VideoIndex.from_bytes(data)
+        else:
+            got = VideoIndex.from_bytes(data)
+            assert got.frames == want[0].tolist() and got.hashes == [int(x) for x in want[1]]
+
+
 def test_vdx_load_does_not_need_the_trailer_but_isvalid_does(vorc, tmp_path):
     """load_v2 (src/videoindex.cpp:350-429) never looks at "cbir"; verify_v2 (:248-269, what isValid runs and what
     Engine::update uses to re-queue videos) does.  A file cut inside the trailer therefore LOADS and is INVALID."""
