@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void k_bgr2gray(const unsigned char* __restric
 //   * a row task takes eight rows and reads each in 256-byte segments from the left until the first content pixel,
 //     then from the right (a content row costs its two end segments, a bar row is read once); the end segments of
 //     all eight rows are requested together;
-//   * a column task owns 256 adjacent columns and walks down from the top (or up from the bottom) eight rows per step
-//     until every one of its columns has met content.
+//   * a column task (second launch) owns 256 adjacent columns and walks down from the top (or up from the bottom) eight
+//     rows per step until every one of its columns has met content, skipping the rows the row tasks found all border.
 // So a frame without bars costs ~1/4 of its bytes, a letterboxed one its bars plus the edges.  Every output has one
 // owner: no atomics.  k_autocrop_decide (one workgroup per image, a wave per search) then replays the selection and centring rules, each of
 // the four searches as a ballot over 64 candidates at a time.
@@ -139,17 +139,20 @@ __device__ __forceinline__ unsigned ac_content4(const unsigned char* __restrict_
 
 __global__ __launch_bounds__(256) void k_autocrop_runs(const unsigned char* __restrict__ imgs, int cols, int rows,
                                                        size_t row_stride, size_t img_stride, int range,
-                                                       int* __restrict__ scratch /* n*2*(rows+cols) */) {
+                                                       int* __restrict__ scratch /* n*2*(rows+cols) */,
+                                                       int phase /* 0: row tasks, 1: column tasks */) {
   const unsigned char* img = imgs + (size_t)blockIdx.y * img_stride;
   int* rowL = scratch + (size_t)blockIdx.y * 2 * (size_t)(rows + cols);
   int* rowR = rowL + rows;
   int* colT = rowR + rows;
   int* colB = colT + cols;
   const int lane = (int)threadIdx.x & 63;
-  const int task = (int)blockIdx.x * ((int)blockDim.x >> 6) + ((int)threadIdx.x >> 6);
   const int nchunks = (cols + kAcColChunk - 1) / kAcColChunk;
   const int row_tasks = (rows + kAcRowsPerWave - 1) / kAcRowsPerWave;
-  if (task >= row_tasks + 2 * nchunks) return;
+  // the column tasks run in a second launch: they skip the rows the row tasks found to be all border (a letterbox is
+  // then read once, not twice)
+  const int task = (phase ? row_tasks : 0) + (int)blockIdx.x * ((int)blockDim.x >> 6) + ((int)threadIdx.x >> 6);
+  if (task >= (phase ? row_tasks + 2 * nchunks : row_tasks)) return;
   const int color = img[0];
   if (task < row_tasks) {
     // both end segments of all the wave's rows are requested before any of them is looked at: a content row is
@@ -217,7 +220,8 @@ __global__ __launch_bounds__(256) void k_autocrop_runs(const unsigned char* __re
     for (int u = 0; u < kAcRowsPerStep; ++u) {
       const int step = s0 + u;
       const int y = from_top ? step : rows - 1 - step;
-      const unsigned m = (step < rows && live != 0u) ? ac_content4(img + (size_t)y * row_stride, x, cols, color, range) : 0u;
+      const bool look = step < rows && live != 0u && rowL[y] < cols;  // (an all-border row has no content)
+      const unsigned m = look ? ac_content4(img + (size_t)y * row_stride, x, cols, color, range) : 0u;
 #pragma unroll
       for (int j = 0; j < 4; ++j) c[j] |= ((m >> j) & 1u) << u;
     }
@@ -383,12 +387,14 @@ int cbh_autocrop_dev(const void* d_gray, size_t n, int w, int h, size_t row_stri
   hipStream_t s = (hipStream_t)stream;
   int* scratch = nullptr;
   CBH_HIP(cbh::malloc_async((void**)&scratch, n * 2 * (size_t)(w + h) * sizeof(int), s));
-  const int tasks = (h + kAcRowsPerWave - 1) / kAcRowsPerWave + 2 * ((w + kAcColChunk - 1) / kAcColChunk);
+  const int row_tasks = (h + kAcRowsPerWave - 1) / kAcRowsPerWave, col_tasks = 2 * ((w + kAcColChunk - 1) / kAcColChunk);
   for (size_t i0 = 0; i0 < n; i0 += 65535) {
     const size_t m = std::min<size_t>(65535, n - i0);
     int* sc = scratch + i0 * 2 * (size_t)(w + h);
-    hipLaunchKernelGGL(k_autocrop_runs, dim3((unsigned)((tasks + 3) / 4), (unsigned)m), dim3(256), 0, s,
-                       (const unsigned char*)d_gray + i0 * img_stride, w, h, row_stride, img_stride, range, sc);
+    hipLaunchKernelGGL(k_autocrop_runs, dim3((unsigned)((row_tasks + 3) / 4), (unsigned)m), dim3(256), 0, s,
+                       (const unsigned char*)d_gray + i0 * img_stride, w, h, row_stride, img_stride, range, sc, 0);
+    hipLaunchKernelGGL(k_autocrop_runs, dim3((unsigned)((col_tasks + 3) / 4), (unsigned)m), dim3(256), 0, s,
+                       (const unsigned char*)d_gray + i0 * img_stride, w, h, row_stride, img_stride, range, sc, 1);
     hipLaunchKernelGGL(k_autocrop_decide, dim3((unsigned)m), dim3(256), 0, s, w, h, (const int*)sc,
                        (int*)d_rects + i0 * 4);
   }
