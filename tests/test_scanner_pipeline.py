@@ -80,3 +80,28 @@ def test_pipeline_grey_input_and_arguments(gpu, orc):
     L = _lib.lib()
     assert L.cbh_index_images(None, 1, 4, 4, 4, 16, 1, None, None, None, None, None, None, None, None, None, None, None,
                               0) == _lib.CBH_E_INVAL
+
+
+@pytest.mark.gpu
+def test_large_batches_are_split_over_host_threads_with_the_same_results(gpu):
+    """cbh_index_images cuts a batch of >= 1024 images without the colour leg into sub-batches on their own host threads
+    and streams (upload of one overlapping the kernels of another): image by image the results of the unsplit calls"""
+    from cbird_amd import orb
+    from cbird_amd.scanner import IndexParams, process_images
+
+    orb.set_pattern(orb.synthetic_pattern())
+    rng = np.random.default_rng(12)
+    base = []
+    for _ in range(25):
+        blocks = rng.integers(20, 256, (8, 10)).astype(np.uint8)
+        base.append(np.kron(blocks, np.ones((12, 12), np.uint8)) + rng.integers(0, 5, (96, 120)).astype(np.uint8))
+    imgs = np.stack([np.roll(base[i % 25], i // 25, axis=1) for i in range(1100)])
+    p = IndexParams(algos=7, numFeatures=60)
+    whole = process_images(imgs, p)                       # 1100 images: two sub-batches of 550
+    parts = process_images(imgs[:600], p) + process_images(imgs[600:], p)  # both below the splitting size
+    assert len(whole) == len(parts) == 1100
+    for a, b in zip(whole, parts):
+        assert a.dctHash == b.dctHash and a.cropRect == b.cropRect and a.resizedDims == b.resizedDims
+        assert (a.keyPoints == b.keyPoints).all() and (a.keyPointDescriptors == b.keyPointDescriptors).all()
+        assert (a.keyPointHashes == b.keyPointHashes).all()
+    assert sum(len(r.keyPoints) for r in whole) > 1100 * 10
