@@ -336,7 +336,7 @@ def features_leg(torch, dev):
     """The indexer's feature stages, reported beside the contract line and never part
     of `value`: ORB detect + describe on 2048 resident 400x300 grey images, ColorDescriptor::create on 4096 resident
     256x192 BGR images (its clustering runs one lane per image: the rate grows with the batch), Media::makeVideoIndex on
-    512 resident letterboxed 1080p frames (row a15).  Throughput only -- the
+    1024 resident letterboxed 1080p frames (row a15).  Throughput only -- the
     parity of both lives in the -m gpu tests and in smoke()."""
     import ctypes as C
 
@@ -410,9 +410,10 @@ def features_leg(torch, dev):
                                       "images_per_s": n / dt, "descriptors": int(d_ok.sum().item())}
     del d, d_cd, d_ok
     # ---- Media::makeVideoIndex: letterboxed 1080p frames resident (a hardware decoder's output), pushed 256 at a time
+    # (the first chunk of a letterboxed video is hashed twice: the kept region is only known after it)
     from cbird_amd.video import VideoIndexer
 
-    n, w, h, bar = 512, 1920, 1080, 140
+    n, w, h, bar = 1024, 1920, 1080, 140
     g = torch.Generator(device=dev).manual_seed(7)
     frames = torch.full((n, h, w), 16, dtype=torch.uint8, device=dev)
     frames += torch.randint(0, 3, (n, h, w), dtype=torch.uint8, device=dev, generator=g)

@@ -40,6 +40,7 @@ struct cbh_vindexer {
   bool full = false;        // frameNumber reached MAX_FRAMES_PER_VIDEO: "too many frames, skipping the rest"
   uint64_t last_hash = 0;
   long long near_frames = 0;
+  int spec[4] = {0, 0, 0, 0}, spec_w = 0, spec_h = 0;  // the kept region the last chunk ended on
 };
 
 namespace {
@@ -89,35 +90,48 @@ void feed(cbh_vindexer* v, uint64_t hash) {
   if (v->frame_number == kMaxFramesPerVideo) v->full = true;  // :1013-1016
 }
 
-// grey frames in device memory -> hashes on the host (autocrop + dctHash64 of the kept VIEW, cvutil.cpp:1397-1401)
+// grey frames in device memory -> hashes on the host (autocrop + dctHash64 of the kept VIEW, cvutil.cpp:1397-1401).
+// The kept region of a video hardly ever changes, so the hash launch does not wait for this chunk's rectangles: it
+// goes out behind the autocrop kernels with the region the previous chunk ended on (the whole frame at the start),
+// rectangles and hashes come back with ONE synchronisation, and only frames whose rectangle turned out different are
+// hashed again (the first chunk of a letterboxed video; a change of letterbox inside one).
 int hash_chunk(cbh_vindexer* v, const uint8_t* d_gray, size_t m, int w, int h, size_t gs, size_t gi) {
   int rc = ensure(v, m);
   if (rc) return rc;
   hipStream_t s = v->s;
   int* hr = v->h_rects.data();
-  bool cropped = false;
-  if (v->autocrop >= 0) {
+  const bool crop = v->autocrop >= 0;
+  int spec[4] = {0, 0, w, h};
+  if (crop && v->spec_w == w && v->spec_h == h) memcpy(spec, v->spec, sizeof spec);
+  auto launch = [&](size_t i, size_t run, const int* r, uint64_t* d_out) {
+    if (r[0] == 0 && r[1] == 0 && r[2] == w && r[3] == h) return cbh::launch_dcthash(d_gray + i * gi, run, w, h, gs, gi, d_out, s);
+    const cbh::HashView view{w, h, r[0], r[1]};
+    return cbh::launch_dcthash(d_gray + i * gi, run, r[2] - r[0], r[3] - r[1], gs, gi, d_out, s, nullptr, &view);
+  };
+  if (crop) {
     rc = cbh_autocrop_dev(d_gray, m, w, h, gs, gi, v->autocrop, v->d_rects, v->device, s);
     if (rc) return rc;
-    CBH_HIP(hipMemcpyAsync(hr, v->d_rects, m * 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-    CBH_HIP(hipStreamSynchronize(s));
-    for (size_t i = 0; i < m && !cropped; ++i)
-      cropped = hr[i * 4] != 0 || hr[i * 4 + 1] != 0 || hr[i * 4 + 2] != w || hr[i * 4 + 3] != h;
   }
-  if (!cropped) {
-    rc = cbh::launch_dcthash(d_gray, m, w, h, gs, gi, v->d_out, s);
-  } else {
-    for (size_t i = 0, run = 1; i < m && rc == CBH_OK; i += run) {
-      const int* r = &hr[i * 4];
-      run = 1;
-      while (i + run < m && !memcmp(r, &hr[(i + run) * 4], 4 * sizeof(int))) ++run;
-      const cbh::HashView view{w, h, r[0], r[1]};
-      rc = cbh::launch_dcthash(d_gray + i * gi, run, r[2] - r[0], r[3] - r[1], gs, gi, v->d_out + i, s, nullptr, &view);
-    }
-  }
+  rc = launch(0, m, spec, v->d_out);
   if (rc) return rc;
+  if (crop) CBH_HIP(hipMemcpyAsync(hr, v->d_rects, m * 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   CBH_HIP(hipMemcpyAsync(v->h_hashes.data(), v->d_out, m * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
   CBH_HIP(hipStreamSynchronize(s));
+  if (!crop) return CBH_OK;
+  bool again = false;
+  for (size_t i = 0, run = 1; i < m; i += run) {
+    const int* r = &hr[i * 4];
+    run = 1;
+    while (i + run < m && !memcmp(r, &hr[(i + run) * 4], 4 * sizeof(int))) ++run;
+    if (!memcmp(r, spec, sizeof spec)) continue;
+    rc = launch(i, run, r, v->d_out + i);
+    if (rc) return rc;
+    CBH_HIP(hipMemcpyAsync(v->h_hashes.data() + i, v->d_out + i, run * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    again = true;
+  }
+  if (again) CBH_HIP(hipStreamSynchronize(s));
+  memcpy(v->spec, &hr[(m - 1) * 4], sizeof v->spec);
+  v->spec_w = w, v->spec_h = h;
   return CBH_OK;
 }
 
