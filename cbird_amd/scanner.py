@@ -92,3 +92,22 @@ def process_images(imgs: np.ndarray, params: IndexParams | None = None, device: 
             r.colorDescriptor = cd[i].copy()
         out.append(r)
     return out
+
+
+def process_image_list(images, params: IndexParams | None = None, device: int = 0) -> list[IndexResult]:
+    """A scanner's work list as it comes -- decoded images of ANY sizes and channel counts, in any order: the images
+    are grouped by geometry (process_images / cbh_index_images takes one geometry per call; camera folders and
+    IDCT-scaled decodes share few), each group goes through the device in one call, and the results come back in the
+    order of the input.  uint8 arrays [h, w] or [h, w, 3 | 4]."""
+    groups: dict = {}
+    for i, im in enumerate(images):
+        a = np.asarray(im)
+        if a.dtype != np.uint8 or a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] not in (3, 4)):
+            raise ValueError(f"image {i}: expected uint8 [h, w] or [h, w, 3 | 4]")
+        groups.setdefault(a.shape, []).append(i)
+    out: list = [None] * len(images)
+    for shape, idx in groups.items():
+        batch = np.stack([np.asarray(images[i]) for i in idx])
+        for i, r in zip(idx, process_images(batch, params, device)):
+            out[i] = r
+    return out

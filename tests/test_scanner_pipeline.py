@@ -105,3 +105,30 @@ def test_large_batches_are_split_over_host_threads_with_the_same_results(gpu):
         assert (a.keyPoints == b.keyPoints).all() and (a.keyPointDescriptors == b.keyPointDescriptors).all()
         assert (a.keyPointHashes == b.keyPointHashes).all()
     assert sum(len(r.keyPoints) for r in whole) > 1100 * 10
+
+
+@pytest.mark.gpu
+def test_mixed_geometries_are_grouped_and_returned_in_input_order(gpu):
+    from cbird_amd import orb
+    from cbird_amd.scanner import IndexParams, process_image_list, process_images
+
+    orb.set_pattern(orb.synthetic_pattern())
+    rng = np.random.default_rng(21)
+    shapes = [(120, 160), (120, 160, 3), (200, 150, 3), (120, 160), (96, 96, 4), (200, 150, 3), (120, 160, 3)]
+    imgs = []
+    for sh in shapes:
+        blocks = rng.integers(20, 256, (sh[0] // 8 + 1, sh[1] // 8 + 1) + sh[2:]).astype(np.uint8)
+        rep = (8, 8) + ((1,) if len(sh) == 3 else ())
+        imgs.append(np.ascontiguousarray(np.kron(blocks, np.ones(rep, np.uint8))[: sh[0], : sh[1]]))
+    p = IndexParams(algos=15, numFeatures=80)
+    got = process_image_list(imgs, p)
+    assert len(got) == len(imgs)
+    for im, r in zip(imgs, got):
+        one = process_images(im[None], p)[0]
+        assert r.dctHash == one.dctHash and r.cropRect == one.cropRect
+        assert (r.keyPoints == one.keyPoints).all() and (r.keyPointDescriptors == one.keyPointDescriptors).all()
+        assert (r.keyPointHashes == one.keyPointHashes).all()
+        assert (r.colorDescriptor is None) == (one.colorDescriptor is None)
+        if r.colorDescriptor is not None:
+            assert r.colorDescriptor.tobytes() == one.colorDescriptor.tobytes()
+    assert process_image_list([], p) == []
