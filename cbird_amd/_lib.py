@@ -39,6 +39,12 @@ class cbh_stats(C.Structure):
     _fields_ = [("scan_launches", C.c_uint64), ("scan_pairs", C.c_uint64), ("scan_ms", C.c_double)]
 
 
+class cbh_shard_stats(C.Structure):
+    _fields_ = [("shards", C.c_uint32), ("devices", C.c_uint32), ("device_mask", C.c_uint32),
+                ("segments", C.c_uint64), ("scans", C.c_uint64), ("rescans", C.c_uint64), ("collectives", C.c_uint64),
+                ("peer_copies", C.c_uint64), ("local_copies", C.c_uint64)]
+
+
 class cbh_vmatch(C.Structure):
     _fields_ = [("id", C.c_uint32), ("score", C.c_int32), ("src_in", C.c_int32), ("dst_in", C.c_int32),
                 ("len", C.c_int32)]
@@ -57,6 +63,7 @@ _SIGS = {
     "cbh_device_count": (C.c_int, []),
     "cbh_strerror": (C.c_char_p, [C.c_int]),
     "cbh_last_error": (C.c_char_p, []),
+    "cbh_trim": (C.c_int, [C.c_int, C.POINTER(C.c_ulonglong)]),
     "cbh_dcthash_batch": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, _vp, C.c_int]),
     "cbh_dcthash_batch_dev": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, _vp, C.c_int, _vp]),
     "cbh_dcthash_tiles_dev": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, _vp, _vp, C.c_int, _vp]),
@@ -83,6 +90,13 @@ _SIGS = {
     "cbh_process_images_ex": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp,
                                         _vp, C.c_int]),
     "cbh_idx64_create": (_vp, [C.c_int]),
+    "cbh_idx64_create_sharded": (_vp, [C.c_uint32, C.c_int]),
+    "cbh_idx64_device_mask": (C.c_uint32, [_vp]),
+    "cbh_idx64_shards_per_device": (C.c_int, [_vp]),
+    "cbh_idx64_shard_count": (C.c_int, [_vp]),
+    "cbh_idx64_shard": (_vp, [_vp, C.c_int]),
+    "cbh_idx64_shard_stats": (C.c_int, [_vp, C.POINTER(cbh_shard_stats)]),
+    "cbh_vidx_create_sharded": (_vp, [C.c_uint32, C.c_int]),
     "cbh_idx64_destroy": (None, [_vp]),
     "cbh_idx64_load": (C.c_int, [_vp, _vp, _vp, _sz]),
     "cbh_idx64_load_dev": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
@@ -210,6 +224,34 @@ def lib() -> C.CDLL:
         f.argtypes = args
     _state["lib"] = L
     return L
+
+
+# ---- index shape: one device, or sharded inside the handle (cbh_idx64_create_sharded) --------------------------------
+# (device_mask, shards_per_device) used by every 64-bit index constructor that is not told otherwise; None = the plain
+# one-device index.  CBH_INDEX_SHARDS="mask:per_device" sets it from the environment (e.g. "0xff:1" = the 8 GPUs of a
+# node, "1:8" = eight logical shards on device 0); the test-suite switches it per test (conftest.index_shape).
+_state["sharding"] = None
+
+
+def set_default_sharding(shape) -> None:
+    _state["sharding"] = None if shape is None else (int(shape[0]), int(shape[1]))
+
+
+def default_sharding():
+    if _state["sharding"] is None and os.environ.get("CBH_INDEX_SHARDS"):
+        m, _, k = os.environ["CBH_INDEX_SHARDS"].partition(":")
+        return int(m, 0), int(k or 1)
+    return _state["sharding"]
+
+
+def create_idx64(device: int, shape=None):
+    """cbh_idx64_create, or cbh_idx64_create_sharded when `shape` (or the process default) asks for shards"""
+    shape = shape if shape is not None else default_sharding()
+    L = lib()
+    h = L.cbh_idx64_create_sharded(shape[0], shape[1]) if shape else L.cbh_idx64_create(device)
+    if not h:
+        raise CbhError(CBH_E_NODEVICE, "cbh_idx64_create" + ("_sharded" if shape else ""))
+    return h
 
 
 def check(code: int, what: str) -> None:

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "cbird_hip.h"
+#include "gpu_devices.h"
 #include "index.h"  // cbird's src/index.h (or the test mock)
 
 class GpuDctHashIndex : public Index {
@@ -27,6 +28,12 @@ class GpuDctHashIndex : public Index {
     _id = SearchParams::AlgoDCT;  // dcthashindex.cpp:31
     _idx = cbh_idx64_create(device);
     if (!_idx) qFatal("GpuDctHashIndex: no usable MI355X (gfx950) device %d", device);
+  }
+  /// one index over several GPUs: `new GpuDctHashIndex(GpuDeviceSet::all())` in Engine::Engine
+  explicit GpuDctHashIndex(const GpuDeviceSet& devs) : _device(devs.first()) {
+    _id = SearchParams::AlgoDCT;
+    _idx = devs.single() ? cbh_idx64_create(_device) : cbh_idx64_create_sharded(devs.mask, devs.shardsPerDevice);
+    if (!_idx) qFatal("GpuDctHashIndex: device mask 0x%x names a device that is not a usable MI355X", devs.mask);
   }
   ~GpuDctHashIndex() override { cbh_idx64_destroy(_idx); }
 

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "cbird_hip.h"
+#include "gpu_devices.h"
 #include "colordescindex.h"
 #include "cvfeaturesindex.h"
 #include "dctfeaturesindex.h"
@@ -39,6 +40,12 @@ class GpuDctFeaturesIndex : public DctFeaturesIndex {  // inherits createTables/
   GpuDctFeaturesIndex(int device = 0, bool treeCompat = false)
       : _idx(cbh_idx64_create(device)), _treeCompat(treeCompat) {
     if (!_idx) qFatal("no usable MI355X device");
+  }
+  // one index over several GPUs / logical shards (GpuDeviceSet, gpu_dcthashindex.h)
+  GpuDctFeaturesIndex(const GpuDeviceSet& devs, bool treeCompat = false)
+      : _idx(devs.single() ? cbh_idx64_create(devs.first()) : cbh_idx64_create_sharded(devs.mask, devs.shardsPerDevice)),
+        _treeCompat(treeCompat) {
+    if (!_idx) qFatal("device mask 0x%x names a device that is not a usable MI355X", devs.mask);
   }
   ~GpuDctFeaturesIndex() override { cbh_idx64_destroy(_idx); }
   bool isLoaded() const override { return cbh_idx64_is_loaded(_idx); }
@@ -329,6 +336,14 @@ class GpuDctVideoIndex : public DctVideoIndex {
       : _device(device), _idx(cbh_vidx_create(device)), _radixCompat(radixCompat) {
     if (!_idx) qFatal("no usable MI355X device");
   }
+  // the frame index over several GPUs / logical shards: entries are in video order, so the row shares are by video
+  GpuDctVideoIndex(const GpuDeviceSet& devs, bool radixCompat = false)
+      : _device(devs.first()),
+        _devs(devs),
+        _idx(devs.single() ? cbh_vidx_create(devs.first()) : cbh_vidx_create_sharded(devs.mask, devs.shardsPerDevice)),
+        _radixCompat(radixCompat) {
+    if (!_idx) qFatal("device mask 0x%x names a device that is not a usable MI355X", devs.mask);
+  }
   ~GpuDctVideoIndex() override { cbh_vidx_destroy(_idx); }
   bool isLoaded() const override { return _loaded; }
   int count() const override { return int(cbh_vidx_count(_idx)); }
@@ -396,7 +411,8 @@ class GpuDctVideoIndex : public DctVideoIndex {
 
   // slice(): "replicate what load() does, but use the subset" (dctvideoindex.cpp:389-397)
   Index* slice(const QSet<uint32_t>& mediaIds) const override {
-    GpuDctVideoIndex* copy = new GpuDctVideoIndex(_device, _radixCompat);
+    GpuDctVideoIndex* copy = _devs.single() ? new GpuDctVideoIndex(_device, _radixCompat)
+                                            : new GpuDctVideoIndex(_devs, _radixCompat);
     copy->_dataPath = _dataPath;
     for (uint32_t id : mediaIds) copy->addOne(id);
     copy->_loaded = true;
@@ -416,6 +432,7 @@ class GpuDctVideoIndex : public DctVideoIndex {
   }
   std::set<uint32_t> _ids;  // what DctVideoIndex::_mediaId holds in the reference
   int _device = 0;
+  GpuDeviceSet _devs;  // (declared before _idx: the sharded constructor initialises it first)
   cbh_vidx* _idx;
   bool _radixCompat;
   QString _dataPath;

@@ -25,7 +25,7 @@ inline void keep_pool_memory(int dev) {
   std::call_once(once[dev], [dev] {
     hipMemPool_t pool = nullptr;
     if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
-      uint64_t keep = ~0ull;
+      uint64_t keep = (uint64_t)1 << 30;  // (a finite mark: freed scratch above 1 GB returns to the driver; cbh_trim)
       (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
     }
   });
@@ -108,6 +108,27 @@ struct Workspace {
     alt_cap = rec_cap;
     return CBH_OK;
   }
+  // give an oversized record block (and the sort buffers sized after it) back: a workspace returns to the pool of its
+  // index and would otherwise hold its high-water mark for good (one whole-index self-join = up to 1 GB + sort scratch)
+  void shrink_records(size_t keep) {
+    if (rec_cap <= keep) return;
+    if (d_total) (void)hipFree(d_total);
+    if (d_alt) (void)hipFree(d_alt);
+    if (d_tmp) (void)hipFree(d_tmp);
+    d_total = nullptr, d_rec = nullptr, d_alt = nullptr, d_tmp = nullptr;
+    rec_cap = 0, alt_cap = 0, tmp_bytes = 0;
+  }
+  // exchange buffers of a sharded index (sharded.hip): [0] a device's concatenated block, [1] the all-gathered blocks
+  void* d_x[2] = {nullptr, nullptr};
+  size_t x_bytes[2] = {0, 0};
+  int ensure_x(int i, size_t bytes) {
+    if (bytes <= x_bytes[i]) return CBH_OK;
+    if (d_x[i]) (void)hipFree(d_x[i]);
+    d_x[i] = nullptr, x_bytes[i] = 0;
+    CBH_HIP(hipMalloc(&d_x[i], bytes));
+    x_bytes[i] = bytes;
+    return CBH_OK;
+  }
   template <typename T>
   static int grow(T** p, size_t* cap, size_t need) {
     if (need <= *cap) return CBH_OK;
@@ -129,6 +150,8 @@ struct Workspace {
     if (d_qmask) (void)hipFree(d_qmask);
     if (d_out) (void)hipFree(d_out);
     if (d_counts) (void)hipFree(d_counts);
+    for (void* p : d_x)
+      if (p) (void)hipFree(p);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (stream) cbh::stream_destroy(stream);
@@ -137,6 +160,8 @@ struct Workspace {
 
 struct Coalescer;                 // coalesce.hip: combining of concurrent find() callers + self-join cache
 void coalescer_free(Coalescer*);
+struct ShardSet;                  // sharded.hip: the children of an index that spans several shards / devices
+void shardset_free(ShardSet*);
 
 }  // namespace cbh
 
@@ -161,6 +186,9 @@ struct cbh_idx64 {
   std::unordered_set<uint64_t> tree_internal;
   std::atomic<uint64_t> generation{0};  // bumped by load/add/remove: caches derived from the contents check it
   std::atomic<Coalescer*> coalescer{nullptr};  // created on the first cbh_idx64_find_coalesced
+  // cbh_idx64_create_sharded: this handle owns no slots itself (d_hashes == nullptr, n = total over the shards); its
+  // children hold contiguous shares on their devices and every search goes through scan_all below (sharded.hip)
+  ShardSet* shards = nullptr;
 
   Workspace* acquire(int* rc) {
     {
@@ -230,12 +258,24 @@ struct WsLease {
   }
 };
 
+namespace cbh {
+// the same contract for an index made of shards: every shard scans its share on its own device and stream, the
+// per-shard { count, records } blocks are exchanged (device-to-device copies inside one device, RCCL all-gather
+// between devices) and end up as ONE block in the root workspace (sharded.hip)
+int sharded_scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t nq, int thresh, hipStream_t stream,
+                     unsigned long long* total, unsigned flags, const uint64_t* d_qmask, size_t max_records);
+int sharded_download(const cbh_idx64* idx, uint64_t* hashes, uint32_t* ids, size_t cap);
+}  // namespace cbh
+
 // scan into the workspace record buffer, growing it until every record fits.
 // On return *total = number of matching pairs, all of them present in ws->d_rec.
+// max_records: a result larger than this is not materialised -- CBH_E_OVERFLOW with *total set, and the workspace is
+// never grown past it (the self-join cache asks before it commits a GB-sized buffer).
 inline int scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t nq, int thresh,
                     hipStream_t stream, unsigned long long* total, unsigned flags = 0,
-                    const uint64_t* d_qmask = nullptr) {
-  int rc = ws->ensure_records(std::max<size_t>(idx->rec_cap_default, 1024));
+                    const uint64_t* d_qmask = nullptr, size_t max_records = ~(size_t)0) {
+  if (idx->shards) return sharded_scan_all(idx, ws, d_q, nq, thresh, stream, total, flags, d_qmask, max_records);
+  int rc = ws->ensure_records(std::min(std::max<size_t>(idx->rec_cap_default, 1024), std::max<size_t>(max_records, 1024)));
   if (rc) return rc;
   for (int attempt = 0; attempt < 3; ++attempt) {
     CBH_HIP(hipMemsetAsync(ws->d_total, 0, sizeof(unsigned long long), stream));
@@ -258,6 +298,7 @@ inline int scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t n
       }
     }
     if (*total <= ws->rec_cap) return CBH_OK;
+    if (*total > max_records) return CBH_E_OVERFLOW;  // the caller does not want a result of this size
     // every match must be materialised to be ordered: grow and rescan
     CBH_HIP(hipStreamSynchronize(stream));
     rc = ws->ensure_records((size_t)*total + 1024);

@@ -15,72 +15,23 @@
 namespace cbh {
 
 void set_last_error(const char* where, hipError_t e);
+void set_last_error_text(const char* text);  // non-HIP failures (RCCL)
 
-// ---- stream-ordered scratch memory: one pool PER STREAM -------------------------------------------------------------
+// ---- stream-ordered scratch memory (cbird_hip.hip) ------------------------------------------------------------------
 // Every kernel launcher takes its scratch from the stream-ordered allocator and gives it back right behind the last
-// kernel that uses it.  With the device's default pool that memory can be handed to another stream while the first
-// one is still running: measured here (round 2) -- the pipelined threshold sweep, whose scan (needle tiles, main
-// stream) overlaps the previous threshold's cut (counting-select scratch, side stream), returned wrong match counts
-// in 4 of 16 runs at 40k images and in none of 16 once the two stopped sharing a pool.  So each stream gets its own
-// pool (created on first use, kept at its high-water mark); nothing is ever reused across streams.
-struct StreamPools {
-  std::mutex mu;
-  std::map<std::pair<int, hipStream_t>, hipMemPool_t> pools;
-  std::map<int, std::vector<hipMemPool_t>> idle;  // pools of destroyed streams, adopted by the next new stream
-};
-inline StreamPools& stream_pools() {
-  static StreamPools* p = new StreamPools;  // never destroyed: calls may arrive during process teardown
-  return *p;
-}
-inline hipError_t malloc_async(void** p, size_t bytes, hipStream_t s) {
-  if (!s) return hipMallocAsync(p, bytes, s);  // the NULL stream is synchronous by contract: the default pool
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return e;
-  hipMemPool_t pool = nullptr;
-  {
-    StreamPools& sp = stream_pools();
-    std::lock_guard<std::mutex> lk(sp.mu);
-    auto it = sp.pools.find({dev, s});
-    if (it != sp.pools.end()) {
-      pool = it->second;
-    } else {
-      std::vector<hipMemPool_t>& idle = sp.idle[dev];
-      if (!idle.empty()) {  // everything in it is free and its stream was synchronised before it went away
-        pool = idle.back();
-        idle.pop_back();
-      } else {
-        hipMemPoolProps props;
-        memset(&props, 0, sizeof props);
-        props.allocType = hipMemAllocationTypePinned;
-        props.handleTypes = hipMemHandleTypeNone;
-        props.location.type = hipMemLocationTypeDevice;
-        props.location.id = dev;
-        if ((e = hipMemPoolCreate(&pool, &props)) != hipSuccess) return e;
-        uint64_t keep = ~0ull;  // freed blocks stay cached: the next call finds its scratch mapped
-        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-      }
-      sp.pools.emplace(std::make_pair(dev, s), pool);
-    }
-  }
-  return hipMallocFromPoolAsync(p, bytes, pool, s);
-}
+// kernel that uses it.  Two sources, switched by cbh_set_tuning("pool_per_stream", v):
+//   1 (default)  one hipMemPool_t per (device, stream): nothing is ever reused across streams.  Pools are bounded:
+//                a pool whose stream is gone or idle is handed to the next new stream (at most kMaxStreamPools live
+//                ones), freed blocks above "pool_keep_mb" go back to the driver at the next synchronisation, and
+//                cbh_trim(device) returns everything that is free
+//   0            the device's default pool (plain hipMallocAsync)
+// History and evidence: DESIGN.md section 7 and tools/ubench/pool_cross_stream.hip.
+hipError_t malloc_async(void** p, size_t bytes, hipStream_t s);
 // for streams the library creates itself: the stream goes, its pool waits for the next one
-inline void stream_destroy(hipStream_t s) {
-  if (!s) return;
-  (void)hipStreamSynchronize(s);
-  int dev = 0;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    StreamPools& sp = stream_pools();
-    std::lock_guard<std::mutex> lk(sp.mu);
-    auto it = sp.pools.find({dev, s});
-    if (it != sp.pools.end()) {
-      sp.idle[dev].push_back(it->second);
-      sp.pools.erase(it);
-    }
-  }
-  (void)hipStreamDestroy(s);
-}
+void stream_destroy(hipStream_t s);
+void set_pool_per_stream(int v);
+void set_pool_keep_mb(int mb);
+int trim_pools(int device, unsigned long long* released_bytes);
 
 #define CBH_HIP(call)                          \
   do {                                         \
@@ -127,6 +78,8 @@ void set_scan256_ht(int ht);
 void set_scan256_pre(int on);  // first-128-bit prefilter variant (default on)
 void set_scan256_mfma(int on);  // <0 = keep; 2 = force for any size
 
+void set_shard_force_rccl(int v);  // sharded.hip: the inter-device collective also with one device (transport test)
+void set_shard_exchange(int v);    // sharded.hip: 0 = ncclAllGather between devices, 1 = peer copies into the root block
 int g_hash_mfma_set(int v);  // dcthash.hip
 extern int g_fdct_host_vote, g_video_host_reduce;  // fdct.hip: 1 = round-1 host reductions (parity tests)
 void set_hash_regs(int v);      // dcthash.hip: register-streaming general-geometry kernel where applicable (default 1)

@@ -27,9 +27,168 @@ void set_last_error(const char* where, hipError_t e) {
   t_last_error = buf;
 }
 
+void set_last_error_text(const char* text) { t_last_error = text ? text : ""; }
+
+// ---- stream-ordered scratch (see cbh_internal.h) ----
+namespace {
+constexpr size_t kMaxStreamPools = 32;  // live (device, stream) pools; beyond that dead / idle streams give theirs up
+struct StreamPools {
+  std::mutex mu;
+  struct Entry {
+    hipMemPool_t pool;
+    uint64_t last_use;
+  };
+  std::map<std::pair<int, hipStream_t>, Entry> pools;
+  std::map<int, std::vector<hipMemPool_t>> idle;  // pools without a stream: everything in them is free
+  uint64_t clock = 0;
+  uint64_t created = 0, adopted = 0, evicted_dead = 0, evicted_idle = 0;
+};
+StreamPools& stream_pools() {
+  static StreamPools* p = new StreamPools;  // never destroyed: calls may arrive during process teardown
+  return *p;
+}
+int g_pool_per_stream = 1;
+uint64_t g_pool_keep_bytes = (uint64_t)1 << 30;  // freed blocks a pool keeps mapped across synchronisations
+
+void apply_threshold(hipMemPool_t pool) {
+  uint64_t keep = g_pool_keep_bytes;
+  (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+}
+
+// under sp.mu: streams that no longer exist (a caller destroyed them: hipStreamQuery fails) or that are idle (every
+// hipFreeAsync queued on them has completed) hand their pool to the idle list.  Dead ones always; idle ones oldest
+// first and only while there are too many.
+void evict(StreamPools& sp, int dev) {
+  std::vector<std::pair<uint64_t, std::pair<int, hipStream_t>>> idle_live;
+  for (auto it = sp.pools.begin(); it != sp.pools.end();) {
+    if (it->first.first != dev) {
+      ++it;
+      continue;
+    }
+    const hipError_t q = hipStreamQuery(it->first.second);
+    if (q == hipErrorNotReady) {
+      ++it;
+      continue;
+    }
+    if (q != hipSuccess) {  // the handle is not a stream any more
+      (void)hipGetLastError();
+      sp.idle[dev].push_back(it->second.pool);
+      sp.evicted_dead++;
+      it = sp.pools.erase(it);
+      continue;
+    }
+    idle_live.push_back({it->second.last_use, it->first});
+    ++it;
+  }
+  std::sort(idle_live.begin(), idle_live.end());
+  for (size_t i = 0; i < idle_live.size() && sp.pools.size() >= kMaxStreamPools; ++i) {
+    auto it = sp.pools.find(idle_live[i].second);
+    sp.idle[dev].push_back(it->second.pool);
+    sp.evicted_idle++;
+    sp.pools.erase(it);
+  }
+}
+}  // namespace
+
+void set_pool_per_stream(int v) { g_pool_per_stream = v ? 1 : 0; }
+void set_pool_keep_mb(int mb) {
+  g_pool_keep_bytes = mb < 0 ? ~0ull : (uint64_t)mb << 20;
+  StreamPools& sp = stream_pools();
+  std::lock_guard<std::mutex> lk(sp.mu);
+  for (auto& kv : sp.pools) apply_threshold(kv.second.pool);
+  for (auto& kv : sp.idle)
+    for (hipMemPool_t p : kv.second) apply_threshold(p);
+}
+
+hipError_t malloc_async(void** p, size_t bytes, hipStream_t s) {
+  if (!s || !g_pool_per_stream) return hipMallocAsync(p, bytes, s);  // (the NULL stream is synchronous by contract)
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  hipMemPool_t pool = nullptr;
+  {
+    StreamPools& sp = stream_pools();
+    std::lock_guard<std::mutex> lk(sp.mu);
+    auto it = sp.pools.find({dev, s});
+    if (it != sp.pools.end()) {
+      pool = it->second.pool;
+      it->second.last_use = ++sp.clock;
+    } else {
+      if (sp.pools.size() >= kMaxStreamPools) evict(sp, dev);
+      std::vector<hipMemPool_t>& idle = sp.idle[dev];
+      if (!idle.empty()) {  // everything in it is free and its stream was idle or gone when it came here
+        pool = idle.back();
+        idle.pop_back();
+        sp.adopted++;
+      } else {
+        hipMemPoolProps props;
+        memset(&props, 0, sizeof props);
+        props.allocType = hipMemAllocationTypePinned;
+        props.handleTypes = hipMemHandleTypeNone;
+        props.location.type = hipMemLocationTypeDevice;
+        props.location.id = dev;
+        if ((e = hipMemPoolCreate(&pool, &props)) != hipSuccess) return e;
+        apply_threshold(pool);
+        sp.created++;
+      }
+      sp.pools.emplace(std::make_pair(dev, s), StreamPools::Entry{pool, ++sp.clock});
+    }
+  }
+  return hipMallocFromPoolAsync(p, bytes, pool, s);
+}
+
+void stream_destroy(hipStream_t s) {
+  if (!s) return;
+  (void)hipStreamSynchronize(s);
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    StreamPools& sp = stream_pools();
+    std::lock_guard<std::mutex> lk(sp.mu);
+    auto it = sp.pools.find({dev, s});
+    if (it != sp.pools.end()) {
+      sp.idle[dev].push_back(it->second.pool);
+      sp.pools.erase(it);
+    }
+  }
+  (void)hipStreamDestroy(s);
+}
+
+// cbh_trim: every free block of every pool of `device` (and of its default pool) goes back to the driver; pools of
+// streams that are gone are dropped from the table on the way
+int trim_pools(int device, unsigned long long* released_bytes) {
+  StreamPools& sp = stream_pools();
+  std::lock_guard<std::mutex> lk(sp.mu);
+  unsigned long long before = 0, after = 0;
+  auto reserved = [](hipMemPool_t p) {
+    uint64_t v = 0;
+    (void)hipMemPoolGetAttribute(p, hipMemPoolAttrReservedMemCurrent, &v);
+    return (unsigned long long)v;
+  };
+  evict(sp, device);
+  std::vector<hipMemPool_t> all;
+  for (auto& kv : sp.pools)
+    if (kv.first.first == device) all.push_back(kv.second.pool);
+  for (hipMemPool_t p : sp.idle[device]) all.push_back(p);
+  hipMemPool_t def = nullptr;
+  if (hipDeviceGetDefaultMemPool(&def, device) == hipSuccess && def) all.push_back(def);
+  for (hipMemPool_t p : all) {
+    before += reserved(p);
+    CBH_HIP(hipMemPoolTrimTo(p, 0));
+    after += reserved(p);
+  }
+  if (released_bytes) *released_bytes = before > after ? before - after : 0;
+  return CBH_OK;
+}
+
 }  // namespace cbh
 
 #include "cbh_index.h"
+
+namespace cbh {  // sharded.hip
+int sharded_load(cbh_idx64* idx, const void* hashes, const void* ids, size_t n, bool on_device, hipStream_t stream);
+int sharded_add(cbh_idx64* idx, const uint64_t* hashes, const uint32_t* ids, size_t n);
+int sharded_remove(cbh_idx64* idx, const uint32_t* ids, size_t n, int zero_hash);
+}  // namespace cbh
 
 extern "C" {
 
@@ -59,6 +218,15 @@ const char* cbh_strerror(int code) {
 }
 
 const char* cbh_last_error(void) { return t_last_error.c_str(); }
+
+int cbh_trim(int device, unsigned long long* released_bytes) {
+  if (released_bytes) *released_bytes = 0;
+  if (!device_usable(device)) return CBH_E_NODEVICE;
+  DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  (void)hipDeviceSynchronize();  // every queued hipFreeAsync has happened: what is free is really free
+  return trim_pools(device, released_bytes);
+}
 
 /* ---- hashing ---------------------------------------------------------------------------- */
 
@@ -322,6 +490,7 @@ void cbh_idx64_destroy(cbh_idx64* idx) {
   if (idx->d_hashes) (void)hipFree(idx->d_hashes);
   if (idx->d_ids) (void)hipFree(idx->d_ids);
   if (idx->coalescer.load()) coalescer_free(idx->coalescer.load());
+  if (idx->shards) shardset_free(idx->shards);
   delete idx;
 }
 
@@ -351,6 +520,11 @@ int cbh_idx64_load(cbh_idx64* idx, const uint64_t* hashes, const uint32_t* ids, 
   idx->n = 0;  // load() on a loaded index is a no-op in the reference (:75); here it reloads
   idx->generation++;
   idx->loaded = true;
+  if (idx->shards) {
+    std::lock_guard<std::mutex> lk(idx->tree_mu);
+    idx->tree_valid = false;
+    return sharded_load(idx, hashes, ids, n, false, nullptr);
+  }
   return idx_append(idx, hashes, ids, n, hipMemcpyHostToDevice, nullptr);
 }
 
@@ -362,6 +536,11 @@ int cbh_idx64_load_dev(cbh_idx64* idx, const void* d_hashes, const void* d_ids, 
   idx->n = 0;
   idx->generation++;
   idx->loaded = true;
+  if (idx->shards) {
+    std::lock_guard<std::mutex> lk(idx->tree_mu);
+    idx->tree_valid = false;
+    return sharded_load(idx, d_hashes, d_ids, n, true, (hipStream_t)stream);
+  }
   return idx_append(idx, d_hashes, d_ids, n, hipMemcpyDeviceToDevice, (hipStream_t)stream);
 }
 
@@ -372,6 +551,15 @@ int cbh_idx64_add(cbh_idx64* idx, const uint64_t* hashes, const uint32_t* ids, s
   if (!idx->loaded) return CBH_E_NOTLOADED;  // "it is an error to call this if isLoaded() is false"
   DeviceGuard g(idx->device);
   if (!g.ok) return CBH_E_NODEVICE;
+  if (idx->shards) {
+    int rc = sharded_add(idx, hashes, ids, n);
+    if (!rc && n) {
+      idx->generation++;
+      std::lock_guard<std::mutex> lk(idx->tree_mu);
+      idx->tree_valid = false;
+    }
+    return rc;
+  }
   return idx_append(idx, hashes, ids, n, hipMemcpyHostToDevice, nullptr);
 }
 
@@ -397,6 +585,7 @@ static int idx_remove(cbh_idx64* idx, const uint32_t* ids, size_t n, int zero_ha
   DeviceGuard g(idx->device);
   if (!g.ok) return CBH_E_NODEVICE;
   idx->generation++;
+  if (idx->shards) return sharded_remove(idx, ids, n, zero_hash);
   std::vector<uint32_t> rm(ids, ids + n);
   std::sort(rm.begin(), rm.end());
   rm.erase(std::unique(rm.begin(), rm.end()), rm.end());
@@ -427,6 +616,7 @@ int cbh_idx64_download(const cbh_idx64* idx, uint64_t* hashes, uint32_t* ids, si
   if (!idx) return CBH_E_INVAL;
   size_t m = std::min(cap, idx->n);
   if (m == 0) return CBH_OK;
+  if (idx->shards) return sharded_download(idx, hashes, ids, m);
   DeviceGuard g(idx->device);
   if (!g.ok) return CBH_E_NODEVICE;
   if (hashes) CBH_HIP(hipMemcpy(hashes, idx->d_hashes, m * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -465,7 +655,9 @@ cbh_idx64* cbh_idx64_slice(const cbh_idx64* idx, const uint32_t* ids, size_t n) 
       sh.push_back(h[i]);
       si.push_back(id[i]);
     }
-  cbh_idx64* out = cbh_idx64_create(idx->device);
+  // a slice of a sharded index is sharded the same way (Database::similarTo searches it like the whole index)
+  cbh_idx64* out = idx->shards ? cbh_idx64_create_sharded(cbh_idx64_device_mask(idx), cbh_idx64_shards_per_device(idx))
+                               : cbh_idx64_create(idx->device);
   if (!out) return nullptr;
   if (cbh_idx64_load(out, sh.data(), si.data(), sh.size())) {
     cbh_idx64_destroy(out);
@@ -492,6 +684,8 @@ int cbh_idx64_reset_stats(cbh_idx64* idx) {
 int cbh_idx64_set_record_capacity(cbh_idx64* idx, size_t records) {
   if (!idx || records == 0) return CBH_E_INVAL;
   idx->rec_cap_default = records;
+  for (int i = 0, r = cbh_idx64_shard_count(idx); idx->shards && i < r; ++i)  // a shard's block holds its share
+    cbh_idx64_shard(idx, i)->rec_cap_default = std::max<size_t>(1024, records / (size_t)r);
   return CBH_OK;
 }
 
@@ -513,7 +707,10 @@ int cbh_idx64_find(cbh_idx64* idx, uint64_t q, int thresh, cbh_match* out, size_
   // results (or a record buffer that is too small) fall through to the general path below.
   rc = ws->ensure_records(Workspace::kFindRecs);  // 512 KB; only a result that overflows it grows the workspace (scan_all)
   if (rc) return rc;
-  {
+  if (idx->shards) {  // the needle goes to every shard: the general path (scan_all) is the sharded one
+    ws->h_small[Workspace::kSmallRecs] = (cbh_record)q;
+    CBH_HIP(hipMemcpyAsync(ws->d_q, &ws->h_small[Workspace::kSmallRecs], sizeof q, hipMemcpyHostToDevice, ws->stream));
+  } else {
     constexpr size_t kS = Workspace::kSmallRecs;
     ws->h_small[kS] = (cbh_record)q;
     CBH_HIP(hipMemcpyAsync(ws->d_q, &ws->h_small[kS], sizeof q, hipMemcpyHostToDevice, ws->stream));
@@ -668,6 +865,7 @@ int cbh_idx64_find_batch_dev(cbh_idx64* idx, const void* d_q, size_t nq, int thr
 int cbh_idx64_scan_dev(cbh_idx64* idx, const void* d_q, size_t nq, int thresh, void* d_records,
                        size_t cap, void* d_total, void* stream) {
   if (!idx || !d_total || (cap && !d_records)) return CBH_E_INVAL;
+  if (idx->shards) return CBH_E_UNSUPPORTED;  // the shard-local step: call it on cbh_idx64_shard(idx, i)
   if (nq == 0 || idx->n == 0) return CBH_OK;
   if (!d_q || nq > CBH_MAX_QUERIES_PER_CALL) return CBH_E_INVAL;
   DeviceGuard g(idx->device);
@@ -847,6 +1045,22 @@ int cbh_set_tuning(const char* key, int value) {
     g_hash_mfma_set(value);
     return CBH_OK;
   }
+  if (!strcmp(key, "pool_per_stream")) {
+    set_pool_per_stream(value);
+    return CBH_OK;
+  }
+  if (!strcmp(key, "pool_keep_mb")) {
+    set_pool_keep_mb(value);
+    return CBH_OK;
+  }
+  if (!strcmp(key, "shard_force_rccl")) {
+    set_shard_force_rccl(value);
+    return CBH_OK;
+  }
+  if (!strcmp(key, "shard_exchange")) {
+    set_shard_exchange(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "scan_group")) {
     set_scan_tuning(-1, -1, value);
     return CBH_OK;
@@ -859,6 +1073,7 @@ int cbh_set_tuning(const char* key, int value) {
 int cbh_idx64_time_scan_dev(cbh_idx64* idx, const void* d_q, size_t nq, int thresh,
                             void* d_records, size_t cap, void* d_total, int iters, float* ms_avg) {
   if (!idx || !ms_avg || iters <= 0 || !d_total) return CBH_E_INVAL;
+  if (idx->shards) return CBH_E_UNSUPPORTED;  // time a shard: cbh_idx64_shard(idx, i)
   DeviceGuard g(idx->device);
   if (!g.ok) return CBH_E_NODEVICE;
   int rc;

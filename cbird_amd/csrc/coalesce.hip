@@ -122,6 +122,14 @@ struct Coalescer {
     too_big.clear();
     epoch = gen;
   }
+  void retire_current(uint64_t gen) {  // under mu; readers may still hold the snapshot
+    snap_epoch.store(~0ull, std::memory_order_release);
+    const Snapshot* old = snap.exchange(nullptr, std::memory_order_acq_rel);
+    if (old) retired.push_back(old);
+    spent.clear();
+    too_big.clear();
+    epoch = gen;
+  }
   void publish(const Snapshot* s, uint64_t gen) {  // under mu
     const Snapshot* old = snap.exchange(s, std::memory_order_acq_rel);
     if (old) retired.push_back(old);
@@ -158,24 +166,33 @@ int serve_by_scan(cbh_idx64* idx, Coalescer* co, Workspace* ws, std::vector<Req*
   for (size_t i = 0; i < nq; ++i) co->h_q[i] = batch[i]->q;
   hipStream_t s = ws->stream;
   CBH_HIP(hipMemcpyAsync(ws->d_q, co->h_q, nq * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-  CBH_HIP(hipMemsetAsync(ws->d_total, 0, sizeof(unsigned long long), s));
-  rc = launch_hamm64_scan(idx->d_hashes, idx->d_ids, idx->n, ws->d_q, nq, thresh, ws->d_rec, ws->rec_cap, ws->d_total,
-                          s, 0, nullptr);
-  if (rc) return rc;
+  unsigned long long total = 0;
   const size_t spec = std::min(kSpecRecs, ws->rec_cap);
-  CBH_HIP(hipMemcpyAsync(co->h_total, ws->d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-  CBH_HIP(hipMemcpyAsync(co->h_spec, ws->d_rec, spec * sizeof(cbh_record), hipMemcpyDeviceToHost, s));
-  CBH_HIP(hipStreamSynchronize(s));
-  unsigned long long total = *co->h_total;
-  {
-    std::lock_guard<std::mutex> lk(idx->stats_mu);
-    idx->stats.scan_launches += 1;
-    idx->stats.scan_pairs += (uint64_t)idx->n * (uint64_t)nq;
+  if (idx->shards) {  // every shard scans; scan_all merges their blocks into this workspace
+    if ((rc = scan_all(idx, ws, ws->d_q, nq, thresh, s, &total))) return rc;
+    if (total && total <= spec) {
+      CBH_HIP(hipMemcpyAsync(co->h_spec, ws->d_rec, (size_t)total * sizeof(cbh_record), hipMemcpyDeviceToHost, s));
+      CBH_HIP(hipStreamSynchronize(s));
+    }
+  } else {
+    CBH_HIP(hipMemsetAsync(ws->d_total, 0, sizeof(unsigned long long), s));
+    rc = launch_hamm64_scan(idx->d_hashes, idx->d_ids, idx->n, ws->d_q, nq, thresh, ws->d_rec, ws->rec_cap, ws->d_total,
+                            s, 0, nullptr);
+    if (rc) return rc;
+    CBH_HIP(hipMemcpyAsync(co->h_total, ws->d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    CBH_HIP(hipMemcpyAsync(co->h_spec, ws->d_rec, spec * sizeof(cbh_record), hipMemcpyDeviceToHost, s));
+    CBH_HIP(hipStreamSynchronize(s));
+    total = *co->h_total;
+    {
+      std::lock_guard<std::mutex> lk(idx->stats_mu);
+      idx->stats.scan_launches += 1;
+      idx->stats.scan_pairs += (uint64_t)idx->n * (uint64_t)nq;
+    }
   }
   std::vector<cbh_record> big;
   cbh_record* recs = co->h_spec;
   if (total > spec) {
-    if (total > ws->rec_cap) {  // did not fit: the general path grows the buffer and rescans
+    if (!idx->shards && total > ws->rec_cap) {  // did not fit: the general path grows the buffer and rescans
       rc = scan_all(idx, ws, ws->d_q, nq, thresh, s, &total);
       if (rc) return rc;
     }
@@ -207,7 +224,22 @@ int build_self_join(cbh_idx64* idx, const Snapshot* base, Workspace* ws, int thr
   }
   hipStream_t s = ws->stream;
   unsigned long long total = 0;
-  int rc = scan_all(idx, ws, idx->d_hashes, n, thresh, s, &total);
+  const bool need_table = !base || !base->table;
+  auto hh = std::make_shared<std::vector<uint64_t>>();
+  // the needles are the index entries themselves, in slot order.  A sharded index has no such array on one device:
+  // its host mirror (needed for the table anyway) is uploaded as the needle list
+  const uint64_t* d_needles = idx->d_hashes;
+  int rc;
+  if (idx->shards) {
+    hh->resize(n);
+    if ((rc = cbh_idx64_download(idx, hh->data(), nullptr, n))) return rc;
+    if ((rc = Workspace::grow(&ws->d_q, &ws->q_cap, n))) return rc;
+    CBH_HIP(hipMemcpyAsync(ws->d_q, hh->data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    d_needles = ws->d_q;
+  }
+  // bounded: an index full of near-duplicates (1e5 equal hashes = 1e10 pairs) must not make one find() ask for tens
+  // of GB -- scan_all learns the count from its first pass and gives up before it grows anything past the limit
+  rc = scan_all(idx, ws, d_needles, n, thresh, s, &total, 0, nullptr, kJoinMaxRecords);
   if (rc == CBH_E_OVERFLOW || (!rc && total > kJoinMaxRecords)) {
     *too_big = true;
     return CBH_OK;
@@ -219,13 +251,13 @@ int build_self_join(cbh_idx64* idx, const Snapshot* base, Workspace* ws, int thr
   sj->rec.resize((size_t)total);
   if (total)
     CBH_HIP(hipMemcpyAsync(sj->rec.data(), ws->d_rec, (size_t)total * sizeof(cbh_record), hipMemcpyDeviceToHost, s));
-  const bool need_table = !base || !base->table;
-  auto hh = std::make_shared<std::vector<uint64_t>>();
-  if (need_table) {
+  if (need_table && !idx->shards) {
     hh->resize(n);
     CBH_HIP(hipMemcpyAsync(hh->data(), idx->d_hashes, n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
   }
   CBH_HIP(hipStreamSynchronize(s));
+  // the workspace goes back to the index's pool: do not let it keep a self-join-sized block (and its sort scratch)
+  ws->shrink_records(std::max<size_t>(idx->rec_cap_default, Workspace::kFindRecs));
   sj->off.assign(n + 1, 0);
   for (size_t i = 0; i < (size_t)total; ++i) sj->off[(size_t)CBH_REC_QUERY(sj->rec[i]) + 1]++;
   for (size_t j = 0; j < n; ++j) sj->off[j + 1] += sj->off[j];
@@ -410,6 +442,9 @@ int cbh_idx64_coalesce_set_self_join(cbh_idx64* idx, int enabled) {
   if (!co) return CBH_E_NOMEM;
   std::lock_guard<std::mutex> l2(co->mu);
   co->join_enabled = enabled ? 1 : 0;
-  if (!enabled) co->invalidate(idx->generation.load());
+  // switching the cache off while finds are running (this is a reader-side call, no writer lock protects it): a reader
+  // may be walking the snapshot right now, so it is RETIRED -- unpublished, freed by the next load/add/remove or with
+  // the index -- never deleted here
+  if (!enabled) co->retire_current(idx->generation.load());
   return CBH_OK;
 }

@@ -1,0 +1,544 @@
+// sharded.hip -- one index over several shards / several GPUs, inside ONE process, behind the same C-ABI handle.
+//
+// cbird is one process: Engine::Engine registers each Index once (src/engine.cpp:38-45) and Database::similar fans
+// find() out from a thread pool (src/database.cpp:1400-1432).  A drop-in that wants all GPUs of the node therefore has
+// to shard INSIDE the handle -- cbh_idx64_create_sharded(device_mask, shards_per_device) returns a cbh_idx64 that every
+// other entry point accepts -- not in a torchrun harness (cbird_amd/dist.py keeps that form for bench.py --gpus N).
+//
+// Layout: the haystack is row-sharded, shard s of R owns the slots [s*n/R, (s+1)*n/R) of a load in load
+// order (add() appends to the emptiest shard and the global order is kept as a segment list); needles are replicated.
+// A threshold search over a union of shards is the union of the per-shard results, so there is exactly one sharded
+// primitive: scan_all (cbh_index.h) -- "all records of these needles, in the root workspace's { count, records }
+// block".  Everything above it (the K4 cut, fdct votes, video reduce, searchIndex escalation, the coalescer's self-join)
+// runs unchanged on the root device over the merged block.
+//
+//   scan      every shard scans its slots for all needles on its own device and stream, into its own block
+//             { u64 count; records[cap] } (needles reach the other devices by peer copies behind an event);
+//             the host reads the R counts (the one synchronisation scan_all always had); only a shard whose block
+//             overflowed grows it and scans again
+//   exchange  inside a device: device-to-device copies of exactly count_s records behind each other;
+//             between devices: ONE grouped ncclAllGather of the per-device blocks, sized to the fullest device
+//             (1 + max count words) -- librccl called directly (ncclCommInitAll, one communicator per device, all
+//             in this process), found with dlopen so that a single-GPU user never loads it;
+//             "shard_exchange" = 1 replaces the collective by hipMemcpyPeerAsync straight into the root block
+//   merge     the D gathered blocks are compacted into the root block; word 0 = total
+//
+// One GPU per box is all this pool offers, so the inter-device leg runs here with one rank ("shard_force_rccl" = 1:
+// a one-device index still goes through ncclAllGather), and everything else -- ragged shards, overflow-redo, removal,
+// order of a merged result -- with R logical shards on one device (tests/test_sharded_capi.py, tests/cpp).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include "cbh_index.h"
+
+namespace cbh {
+
+namespace {
+
+struct Rccl {
+  void* handle = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string why;  // when it could not be loaded
+};
+
+// librccl.so.1: the copy already mapped in this process if there is one (PyTorch ships its own), else the system's
+Rccl* rccl() {
+  static Rccl* r = [] {
+    Rccl* x = new Rccl;
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+      x->handle = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+      if (x->handle) break;
+    }
+    if (!x->handle)
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        x->handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (x->handle) break;
+      }
+    if (!x->handle) {
+      const char* e = dlerror();
+      x->why = e ? e : "librccl not found";
+      return x;
+    }
+#define CBH_SYM(field, name)                                         \
+  x->field = reinterpret_cast<decltype(x->field)>(dlsym(x->handle, name)); \
+  if (!x->field) x->why = std::string("librccl lacks ") + name
+    CBH_SYM(CommInitAll, "ncclCommInitAll");
+    CBH_SYM(CommDestroy, "ncclCommDestroy");
+    CBH_SYM(AllGather, "ncclAllGather");
+    CBH_SYM(GroupStart, "ncclGroupStart");
+    CBH_SYM(GroupEnd, "ncclGroupEnd");
+    CBH_SYM(GetErrorString, "ncclGetErrorString");
+#undef CBH_SYM
+    return x;
+  }();
+  return r;
+}
+
+int g_force_rccl = 0;  // "shard_force_rccl": the collective also at one device (transport test on a one-GPU box)
+int g_exchange = 0;    // "shard_exchange": 0 = ncclAllGather between devices, 1 = peer copies into the root block
+
+}  // namespace
+
+void set_shard_force_rccl(int v) { g_force_rccl = v; }
+void set_shard_exchange(int v) { g_exchange = v; }
+
+struct ShardSet {
+  std::vector<cbh_idx64*> child;  // plain single-device indexes; child[s]->device
+  std::vector<int> devices;       // distinct devices in mask order; devices[0] = root = parent->device
+  std::vector<int> dev_of;        // shard -> position in devices
+  int per_device = 1;
+  uint32_t mask = 0;
+  // global slot order: segment g covers parent slots [global, global+len) = child[shard] slots [local, local+len)
+  struct Seg {
+    uint32_t shard;
+    size_t local, global, len;
+  };
+  std::vector<Seg> segs;
+  // one communicator per device, created with the first exchange that needs them
+  std::mutex coll_mu;  // a communicator takes one grouped call at a time
+  std::vector<ncclComm_t> comms;
+  bool comms_tried = false;
+  // counters for tests / INTEGRATION: how the last exchanges travelled
+  std::atomic<uint64_t> n_scans{0}, n_rescans{0}, n_collectives{0}, n_peer_copies{0}, n_local_copies{0};
+
+  int ensure_comms() {  // under coll_mu
+    if (!comms.empty()) return CBH_OK;
+    if (comms_tried) return CBH_E_UNSUPPORTED;
+    comms_tried = true;
+    Rccl* r = rccl();
+    if (!r->handle || !r->why.empty()) {
+      set_last_error_text(("RCCL unavailable: " + r->why).c_str());
+      return CBH_E_UNSUPPORTED;
+    }
+    std::vector<ncclComm_t> c(devices.size());
+    ncclResult_t e = r->CommInitAll(c.data(), (int)devices.size(), devices.data());
+    if (e != ncclSuccess) {
+      set_last_error_text((std::string("ncclCommInitAll: ") + r->GetErrorString(e)).c_str());
+      return CBH_E_HIP;
+    }
+    comms.swap(c);
+    return CBH_OK;
+  }
+};
+
+void shardset_free(ShardSet* S) {
+  if (!S) return;
+  if (!S->comms.empty()) {
+    Rccl* r = rccl();
+    for (size_t d = 0; d < S->comms.size(); ++d) {
+      DeviceGuard g(S->devices[d]);
+      (void)r->CommDestroy(S->comms[d]);
+    }
+  }
+  for (cbh_idx64* c : S->child) cbh_idx64_destroy(c);
+  delete S;
+}
+
+namespace {
+
+// leases of one call: a workspace per shard, given back (idle) at the end
+struct ShardLeases {
+  ShardSet* S;
+  std::vector<Workspace*> ws;
+  explicit ShardLeases(ShardSet* s) : S(s), ws(s->child.size(), nullptr) {}
+  int acquire_all() {
+    for (size_t s = 0; s < ws.size(); ++s) {
+      DeviceGuard g(S->child[s]->device);
+      if (!g.ok) return CBH_E_NODEVICE;
+      int rc = CBH_OK;
+      ws[s] = S->child[s]->acquire(&rc);
+      if (!ws[s]) return rc ? rc : CBH_E_NOMEM;
+    }
+    return CBH_OK;
+  }
+  ~ShardLeases() {
+    for (size_t s = 0; s < ws.size(); ++s)
+      if (ws[s]) {
+        DeviceGuard g(S->child[s]->device);
+        (void)hipStreamSynchronize(ws[s]->stream);  // its buffers must be idle when the next call takes it
+        S->child[s]->give_back(ws[s]);
+      }
+  }
+};
+
+}  // namespace
+
+int sharded_scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t nq, int thresh, hipStream_t stream,
+                     unsigned long long* total, unsigned flags, const uint64_t* d_qmask, size_t max_records) {
+  ShardSet* S = idx->shards;
+  const size_t R = S->child.size(), D = S->devices.size();
+  const int root = idx->device;
+  *total = 0;
+  // the root block must exist whatever happens (consumers read word 0)
+  int rc = ws->ensure_records(std::min(std::max<size_t>(idx->rec_cap_default, 1024), std::max<size_t>(max_records, 1024)));
+  if (rc) return rc;
+  if (nq == 0 || idx->n == 0 || thresh <= 0) {
+    CBH_HIP(hipMemsetAsync(ws->d_total, 0, sizeof(unsigned long long), stream));
+    CBH_HIP(hipStreamSynchronize(stream));
+    return CBH_OK;
+  }
+  ShardLeases L(S);
+  if ((rc = L.acquire_all())) return rc;
+  CBH_HIP(hipEventRecord(ws->ev0, stream));  // the needles (and masks) are complete on the root device
+  // ---- scan: every shard, its own device and stream ----
+  std::vector<const uint64_t*> q_of(R, d_q), mask_of(R, d_qmask);
+  std::vector<unsigned long long> count(R, 0);
+  std::vector<char> todo(R, 1);
+  for (size_t s = 0; s < R; ++s) todo[s] = S->child[s]->n != 0;
+  float scan_ms = 0.f;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    bool any = false;
+    for (size_t s = 0; s < R; ++s) {
+      if (!todo[s]) continue;
+      any = true;
+      cbh_idx64* c = S->child[s];
+      Workspace* cw = L.ws[s];
+      DeviceGuard g(c->device);
+      if (!g.ok) return CBH_E_NODEVICE;
+      hipStream_t cs = cw->stream;
+      if (attempt == 0) {
+        CBH_HIP(hipStreamWaitEvent(cs, ws->ev0, 0));
+        if (c->device != root) {  // replicate the needles: one peer copy per device and call (8 B per needle)
+          if ((rc = Workspace::grow(&cw->d_q, &cw->q_cap, nq))) return rc;
+          CBH_HIP(hipMemcpyPeerAsync(cw->d_q, c->device, d_q, root, nq * sizeof(uint64_t), cs));
+          q_of[s] = cw->d_q;
+          if (d_qmask) {
+            if ((rc = Workspace::grow(&cw->d_qmask, &cw->qmask_cap, nq))) return rc;
+            CBH_HIP(hipMemcpyPeerAsync(cw->d_qmask, c->device, d_qmask, root, nq * sizeof(uint64_t), cs));
+            mask_of[s] = cw->d_qmask;
+          }
+          S->n_peer_copies++;
+        }
+        if ((rc = cw->ensure_records(std::max<size_t>(c->rec_cap_default, 1024)))) return rc;
+      }
+      CBH_HIP(hipMemsetAsync(cw->d_total, 0, sizeof(unsigned long long), cs));
+      CBH_HIP(hipEventRecord(cw->ev0, cs));
+      rc = launch_hamm64_scan(c->d_hashes, c->d_ids, c->n, q_of[s], nq, thresh, cw->d_rec, cw->rec_cap, cw->d_total, cs,
+                              flags, mask_of[s]);
+      if (rc) return rc;
+      CBH_HIP(hipEventRecord(cw->ev1, cs));
+      CBH_HIP(hipMemcpyAsync(cw->h_total, cw->d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
+      S->n_scans++;
+      if (attempt) S->n_rescans++;
+    }
+    if (!any) break;
+    float worst = 0.f;
+    for (size_t s = 0; s < R; ++s) {
+      if (!todo[s]) continue;
+      cbh_idx64* c = S->child[s];
+      Workspace* cw = L.ws[s];
+      DeviceGuard g(c->device);
+      CBH_HIP(hipStreamSynchronize(cw->stream));
+      count[s] = *cw->h_total;
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, cw->ev0, cw->ev1) == hipSuccess) worst = std::max(worst, ms);
+      todo[s] = 0;
+      if (count[s] > cw->rec_cap) {  // this shard alone grows its block and scans again
+        if (count[s] > max_records) {
+          *total = count[s];
+          return CBH_E_OVERFLOW;
+        }
+        rc = cw->ensure_records((size_t)count[s] + 1024);
+        if (rc) return rc == CBH_E_NOMEM ? CBH_E_OVERFLOW : rc;
+        todo[s] = 1;
+      }
+    }
+    scan_ms += worst;  // the shards run side by side: a round costs what its slowest shard costs
+  }
+  for (size_t s = 0; s < R; ++s)
+    if (todo[s]) return CBH_E_OVERFLOW;
+  {
+    std::lock_guard<std::mutex> lk(idx->stats_mu);
+    idx->stats.scan_launches += 1;
+    idx->stats.scan_pairs += (uint64_t)idx->n * (uint64_t)nq;
+    idx->stats.scan_ms += (double)scan_ms;
+  }
+  unsigned long long sum = 0;
+  for (size_t s = 0; s < R; ++s) sum += count[s];
+  *total = sum;
+  if (sum > max_records && sum > ws->rec_cap) return CBH_E_OVERFLOW;
+  if (sum > ws->rec_cap) {
+    CBH_HIP(hipStreamSynchronize(stream));
+    rc = ws->ensure_records((size_t)sum + 1024);
+    if (rc) return rc == CBH_E_NOMEM ? CBH_E_OVERFLOW : rc;
+  }
+  // ---- exchange ----
+  const bool collective = (D > 1 && g_exchange == 0) || (g_force_rccl && g_exchange == 0);
+  // per-device totals and the position of every shard inside its device's run, and of every device in the result
+  std::vector<unsigned long long> dev_total(D, 0), shard_off(R, 0), dev_off(D, 0);
+  for (size_t s = 0; s < R; ++s) {
+    shard_off[s] = dev_total[S->dev_of[s]];
+    dev_total[S->dev_of[s]] += count[s];
+  }
+  for (size_t d = 1; d < D; ++d) dev_off[d] = dev_off[d - 1] + dev_total[d - 1];
+  std::vector<size_t> first_of(D, R);  // first shard of a device: its stream carries the device's part of the exchange
+  for (size_t s = R; s-- > 0;) first_of[S->dev_of[s]] = s;
+  *ws->h_total = sum;
+  if (!collective) {
+    // every shard copies exactly its records to their final place in the root block
+    for (size_t s = 0; s < R; ++s) {
+      if (!count[s]) continue;
+      cbh_idx64* c = S->child[s];
+      Workspace* cw = L.ws[s];
+      DeviceGuard g(c->device);
+      cbh_record* dst = ws->d_rec + dev_off[S->dev_of[s]] + shard_off[s];
+      if (c->device == root) {
+        CBH_HIP(hipMemcpyAsync(dst, cw->d_rec, count[s] * sizeof(cbh_record), hipMemcpyDeviceToDevice, cw->stream));
+        S->n_local_copies++;
+      } else {
+        CBH_HIP(hipMemcpyPeerAsync(dst, root, cw->d_rec, c->device, count[s] * sizeof(cbh_record), cw->stream));
+        S->n_peer_copies++;
+      }
+      CBH_HIP(hipEventRecord(cw->ev1, cw->stream));
+    }
+    DeviceGuard g(root);
+    for (size_t s = 0; s < R; ++s)
+      if (count[s]) CBH_HIP(hipStreamWaitEvent(stream, L.ws[s]->ev1, 0));
+  } else {
+    // level 1: a device's shards concatenate into ONE block B_d = { count_d, records } (a single shard's own block
+    // already is one); level 2: one grouped all-gather of the B_d, sized to the fullest device; level 3: the root
+    // compacts the D gathered blocks into its workspace block
+    unsigned long long m = 0;
+    for (size_t d = 0; d < D; ++d) m = std::max(m, dev_total[d]);
+    const size_t words = 1 + (size_t)m;
+    std::vector<const void*> send(D, nullptr);
+    std::vector<void*> recv(D, nullptr);
+    for (size_t d = 0; d < D; ++d) {
+      const size_t f = first_of[d];
+      Workspace* fw = L.ws[f];
+      DeviceGuard g(S->devices[d]);
+      if (!g.ok) return CBH_E_NODEVICE;
+      if ((rc = fw->ensure_x(1, D * words * sizeof(cbh_record)))) return rc;
+      recv[d] = fw->d_x[1];
+      if (S->per_device == 1 && fw->rec_cap + 1 >= words) {
+        send[d] = fw->d_total;  // a single shard's block is the device block as it stands: word 0 = count (written by
+        continue;               // the scan kernel), and it is at least `words` long
+      }
+      if ((rc = fw->ensure_x(0, words * sizeof(cbh_record)))) return rc;
+      unsigned long long* B = (unsigned long long*)fw->d_x[0];
+      send[d] = B;
+      *fw->h_total = dev_total[d];
+      CBH_HIP(hipMemcpyAsync(B, fw->h_total, sizeof(unsigned long long), hipMemcpyHostToDevice, fw->stream));
+      for (size_t s = 0; s < R; ++s) {
+        if ((size_t)S->dev_of[s] != d || !count[s]) continue;
+        Workspace* cw = L.ws[s];
+        CBH_HIP(hipMemcpyAsync(B + 1 + shard_off[s], cw->d_rec, count[s] * sizeof(cbh_record), hipMemcpyDeviceToDevice,
+                               cw->stream));
+        S->n_local_copies++;
+        if (s != f) {
+          CBH_HIP(hipEventRecord(cw->ev1, cw->stream));
+          CBH_HIP(hipStreamWaitEvent(fw->stream, cw->ev1, 0));
+        }
+      }
+    }
+    {
+      std::lock_guard<std::mutex> lk(S->coll_mu);
+      if ((rc = S->ensure_comms())) return rc;
+      Rccl* r = rccl();
+      ncclResult_t e = r->GroupStart();
+      for (size_t d = 0; d < D && e == ncclSuccess; ++d) {
+        DeviceGuard g(S->devices[d]);
+        e = r->AllGather(send[d], recv[d], words, ncclUint64, S->comms[d], L.ws[first_of[d]]->stream);
+      }
+      ncclResult_t e2 = r->GroupEnd();
+      if (e == ncclSuccess) e = e2;
+      if (e != ncclSuccess) {
+        set_last_error_text((std::string("ncclAllGather: ") + r->GetErrorString(e)).c_str());
+        return CBH_E_HIP;
+      }
+      S->n_collectives++;
+    }
+    DeviceGuard g(root);
+    Workspace* rw = L.ws[first_of[0]];
+    const unsigned long long* G = (const unsigned long long*)rw->d_x[1];
+    for (size_t d = 0; d < D; ++d)
+      if (dev_total[d])
+        CBH_HIP(hipMemcpyAsync(ws->d_rec + dev_off[d], G + d * words + 1, dev_total[d] * sizeof(cbh_record),
+                               hipMemcpyDeviceToDevice, rw->stream));
+    CBH_HIP(hipEventRecord(rw->ev1, rw->stream));
+    CBH_HIP(hipStreamWaitEvent(stream, rw->ev1, 0));
+  }
+  {
+    DeviceGuard g(root);
+    CBH_HIP(hipMemcpyAsync(ws->d_total, ws->h_total, sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+    CBH_HIP(hipStreamSynchronize(stream));  // scan_all's contract: the block is complete on return
+  }
+  return CBH_OK;
+}
+
+int sharded_download(const cbh_idx64* idx, uint64_t* hashes, uint32_t* ids, size_t cap) {
+  const ShardSet* S = idx->shards;
+  for (const ShardSet::Seg& g : S->segs) {
+    if (g.global >= cap) continue;
+    const size_t m = std::min(g.len, cap - g.global);
+    const cbh_idx64* c = S->child[g.shard];
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return CBH_E_NODEVICE;
+    if (hashes) CBH_HIP(hipMemcpy(hashes + g.global, c->d_hashes + g.local, m * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (ids) CBH_HIP(hipMemcpy(ids + g.global, c->d_ids + g.local, m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  }
+  return CBH_OK;
+}
+
+// load: shard s of R takes [s*n/R, (s+1)*n/R) (cbird_amd/dist.py shard_range); src on the host, or on the
+// root device (load_dev)
+int sharded_load(cbh_idx64* idx, const void* hashes, const void* ids, size_t n, bool on_device, hipStream_t stream) {
+  ShardSet* S = idx->shards;
+  const size_t R = S->child.size();
+  S->segs.clear();
+  idx->n = 0;
+  if (n && (!hashes || !ids)) return CBH_E_INVAL;
+  if (n > 0xfffffff0ull) return CBH_E_INVAL;
+  if (on_device && stream) CBH_HIP(hipStreamSynchronize(stream));  // the source arrays are complete
+  for (size_t s = 0; s < R; ++s) {
+    const size_t a = s * n / R, b = (s + 1) * n / R;
+    cbh_idx64* c = S->child[s];
+    const uint64_t* h = (const uint64_t*)hashes + a;
+    const uint32_t* i = (const uint32_t*)ids + a;
+    int rc;
+    if (!on_device) {
+      rc = cbh_idx64_load(c, h, i, b - a);
+    } else if (c->device == idx->device) {
+      rc = cbh_idx64_load_dev(c, h, i, b - a, nullptr);
+    } else {
+      DeviceGuard g(c->device);
+      if (!g.ok) return CBH_E_NODEVICE;
+      c->n = 0;
+      c->generation++;
+      c->loaded = true;
+      rc = c->reserve(b - a);
+      if (!rc && b > a) {
+        CBH_HIP(hipMemcpyPeer(c->d_hashes, c->device, h, idx->device, (b - a) * sizeof(uint64_t)));
+        CBH_HIP(hipMemcpyPeer(c->d_ids, c->device, i, idx->device, (b - a) * sizeof(uint32_t)));
+        c->n = b - a;
+      }
+    }
+    if (rc) return rc;
+    if (b > a) S->segs.push_back(ShardSet::Seg{(uint32_t)s, 0, a, b - a});
+  }
+  idx->n = n;
+  return CBH_OK;
+}
+
+// add(): the reference appends and rebuilds its tree (src/dcthashindex.cpp:158-173); here the batch goes to the shard
+// that holds the fewest slots, the parent's slot order continues
+int sharded_add(cbh_idx64* idx, const uint64_t* hashes, const uint32_t* ids, size_t n) {
+  ShardSet* S = idx->shards;
+  if (n == 0) return CBH_OK;
+  if (!hashes || !ids) return CBH_E_INVAL;
+  if (idx->n + n > 0xfffffff0ull) return CBH_E_INVAL;
+  size_t best = 0;
+  for (size_t s = 1; s < S->child.size(); ++s)
+    if (S->child[s]->n < S->child[best]->n) best = s;
+  cbh_idx64* c = S->child[best];
+  const size_t local = c->n;
+  int rc = c->loaded ? cbh_idx64_add(c, hashes, ids, n) : cbh_idx64_load(c, hashes, ids, n);
+  if (rc) return rc;
+  if (!S->segs.empty() && S->segs.back().shard == best && S->segs.back().local + S->segs.back().len == local &&
+      S->segs.back().global + S->segs.back().len == idx->n)
+    S->segs.back().len += n;
+  else
+    S->segs.push_back(ShardSet::Seg{(uint32_t)best, local, idx->n, n});
+  idx->n += n;
+  return CBH_OK;
+}
+
+int sharded_remove(cbh_idx64* idx, const uint32_t* ids, size_t n, int zero_hash) {
+  for (cbh_idx64* c : idx->shards->child) {
+    int rc = zero_hash ? cbh_idx64_remove(c, ids, n) : cbh_idx64_remove_ids_only(c, ids, n);
+    if (rc) return rc;
+  }
+  return CBH_OK;
+}
+
+}  // namespace cbh
+
+extern "C" {
+
+cbh_idx64* cbh_idx64_create_sharded(uint32_t device_mask, int shards_per_device) {
+  if (device_mask == 0 || shards_per_device < 0 || shards_per_device > 64) return nullptr;
+  const int per = std::max(1, shards_per_device);
+  std::vector<int> devs;
+  for (int d = 0; d < 32; ++d)
+    if (device_mask & (1u << d)) {
+      if (!device_usable(d)) return nullptr;  // a device of the mask is not there: no silent narrowing
+      devs.push_back(d);
+    }
+  cbh_idx64* idx = new (std::nothrow) cbh_idx64;
+  ShardSet* S = new (std::nothrow) ShardSet;
+  if (!idx || !S) {
+    delete idx;
+    delete S;
+    return nullptr;
+  }
+  idx->device = devs[0];
+  idx->shards = S;
+  S->devices = devs;
+  S->per_device = per;
+  S->mask = device_mask;
+  for (size_t d = 0; d < devs.size(); ++d)
+    for (int k = 0; k < per; ++k) {
+      cbh_idx64* c = cbh_idx64_create(devs[d]);
+      if (!c) {
+        cbh_idx64_destroy(idx);
+        return nullptr;
+      }
+      S->child.push_back(c);
+      S->dev_of.push_back((int)d);
+    }
+  const size_t R = S->child.size();
+  for (cbh_idx64* c : S->child) c->rec_cap_default = std::max<size_t>(65536, idx->rec_cap_default / R);
+  if (devs.size() > 1)  // direct xGMI copies where the platform allows them (RCCL opens its own)
+    for (int a : devs) {
+      DeviceGuard g(a);
+      for (int b : devs)
+        if (a != b) {
+          int can = 0;
+          if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(b, 0);
+        }
+      (void)hipGetLastError();  // "already enabled" is not an error worth keeping
+    }
+  return idx;
+}
+
+uint32_t cbh_idx64_device_mask(const cbh_idx64* idx) {
+  return !idx ? 0 : idx->shards ? idx->shards->mask : (1u << idx->device);
+}
+
+int cbh_idx64_shards_per_device(const cbh_idx64* idx) { return !idx ? 0 : idx->shards ? idx->shards->per_device : 1; }
+
+int cbh_idx64_shard_count(const cbh_idx64* idx) { return !idx ? 0 : idx->shards ? (int)idx->shards->child.size() : 1; }
+
+cbh_idx64* cbh_idx64_shard(cbh_idx64* idx, int i) {
+  if (!idx) return nullptr;
+  if (!idx->shards) return i == 0 ? idx : nullptr;
+  if (i < 0 || (size_t)i >= idx->shards->child.size()) return nullptr;
+  return idx->shards->child[(size_t)i];
+}
+
+int cbh_idx64_shard_stats(const cbh_idx64* idx, cbh_shard_stats* out) {
+  if (!idx || !out) return CBH_E_INVAL;
+  memset(out, 0, sizeof *out);
+  if (!idx->shards) {
+    out->shards = 1, out->devices = 1;
+    return CBH_OK;
+  }
+  const ShardSet* S = idx->shards;
+  out->shards = (uint32_t)S->child.size();
+  out->devices = (uint32_t)S->devices.size();
+  out->device_mask = S->mask;
+  out->scans = S->n_scans.load();
+  out->rescans = S->n_rescans.load();
+  out->collectives = S->n_collectives.load();
+  out->peer_copies = S->n_peer_copies.load();
+  out->local_copies = S->n_local_copies.load();
+  out->segments = S->segs.size();
+  return CBH_OK;
+}
+
+}  // extern "C"

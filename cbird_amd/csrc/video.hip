@@ -15,6 +15,8 @@
 
 struct cbh_vidx {
   int device = 0;
+  uint32_t device_mask = 0;  // != 0: the search structure is a sharded cbh_idx64 (cbh_vidx_create_sharded)
+  int shards_per_device = 1;
   struct Video {
     uint32_t media_id;
     std::vector<int32_t> frames;
@@ -66,7 +68,7 @@ int build(cbh_vidx* v, int skip) {
     }
   }
   if (v->idx) cbh_idx64_destroy(v->idx);
-  v->idx = cbh_idx64_create(v->device);
+  v->idx = v->device_mask ? cbh_idx64_create_sharded(v->device_mask, v->shards_per_device) : cbh_idx64_create(v->device);
   if (!v->idx) return CBH_E_NODEVICE;
   int rc = cbh_idx64_load(v->idx, hashes.data(), ids.data(), hashes.size());
   if (rc) return rc;
@@ -286,6 +288,19 @@ cbh_vidx* cbh_vidx_create(int device) {
   if (!device_usable(device)) return nullptr;
   cbh_vidx* v = new (std::nothrow) cbh_vidx;
   if (v) v->device = device;
+  return v;
+}
+
+cbh_vidx* cbh_vidx_create_sharded(uint32_t device_mask, int shards_per_device) {
+  cbh_idx64* probe = cbh_idx64_create_sharded(device_mask, shards_per_device);  // validates the mask
+  if (!probe) return nullptr;
+  cbh_vidx* v = new (std::nothrow) cbh_vidx;
+  if (v) {
+    v->device = probe->device;
+    v->device_mask = device_mask;
+    v->shards_per_device = shards_per_device;
+  }
+  cbh_idx64_destroy(probe);
   return v;
 }
 

@@ -94,6 +94,14 @@ class HipOps:
         _lib.check(self.L.cbh_records_topk_dev(blocks.data_ptr(), nb, stride, cap, nq, k, out.data_ptr(),
                                                counts.data_ptr(), status.data_ptr(), self.device, self._stream()),
                    "records_topk_dev")
+        # similar_sweep calls this inside stream_ctx(side): the two tensors belong to the side stream's allocator pool
+        # but are read by main-stream code afterwards.  Without this the caching allocator may hand the block to the
+        # next sweep's side-stream cut while a main-stream reader of the old result is still queued.
+        work = getattr(self, "_work", None)
+        for t in (out, counts):
+            if work is not None:
+                t.record_stream(work)
+            t.record_stream(torch.cuda.default_stream(self.torch_device))
         return out[:, :k, 0], out[:, :k, 1], counts
 
     def sort_records(self, rec: torch.Tensor, n: int, nq: int) -> None:
@@ -228,6 +236,16 @@ class ShardedDctHashIndex:
             self.record_capacity *= 2
         self._bufs = {}
 
+    def _grow_to_fit(self, slack: float = 1.5, granule: int = 1 << 14):
+        """after an overflow: blocks of `slack` x the largest per-rank count seen (every rank computes the same value from
+        the gathered counts), at least double the current size"""
+        cur = self._block_cap()
+        want = 2 * cur
+        if self._max_count is not None:
+            want = max(want, -(-int(int(self._max_count.item()) * slack) // granule) * granule)
+        self._cap = want
+        self._bufs = {}
+
     def similar(self, queries: torch.Tensor, thresh: int, max_per_query: int, scan_events=None):
         """All needles against the union of all shards.  Returns (ids[nq,k] i32 view of u32,
         scores[nq,k] i32, counts[nq] i32) -- identical on every rank."""
@@ -319,8 +337,10 @@ class ShardedDctHashIndex:
             scan_events += [e for e in scan_tmp if e[0] not in redo]
         if find_events is not None:
             find_events += [e for e in find_tmp if e[0] not in redo]
-        for thr in redo:  # a block overflowed: larger blocks, this threshold alone (its own events)
-            self._grow()
+        if redo:  # blocks overflowed: grow ONCE for the sweep -- to 1.5 x the fullest rank's count (tracked on the
+            # device, the same value on every rank) -- not once per overflowed threshold (4 overflows = blocks x16)
+            self._grow_to_fit()
+        for thr in redo:  # ... then these thresholds alone (their own events)
             f0 = ops.new_event()
             f0.record(main)
             results[thr] = self.similar(queries, thr, max_per_query, scan_events)

@@ -90,16 +90,13 @@ class DctHashIndex:
     """Index for 64-bit dct hashes that uses hamming distance (src/dcthashindex.h:26-29),
     resident on one MI355X."""
 
-    def __init__(self, device: int = 0, _handle=None) -> None:
+    def __init__(self, device: int = 0, _handle=None, shards=None) -> None:
+        """shards = (device_mask, shards_per_device): one index over several GPUs / logical shards inside this
+        process (cbh_idx64_create_sharded); None = one device (or the process default, _lib.set_default_sharding)"""
         self._L = _lib.lib()
         self._device = device
         self._id = SearchParams.AlgoDCT  # dcthashindex.cpp:31
-        if _handle is not None:
-            self._h = _handle
-        else:
-            self._h = self._L.cbh_idx64_create(device)
-            if not self._h:
-                raise CbhError(_lib.CBH_E_NODEVICE, "cbh_idx64_create")
+        self._h = _handle if _handle is not None else _lib.create_idx64(device, shards)
 
     def __del__(self) -> None:
         h, self._h = getattr(self, "_h", None), None
@@ -234,6 +231,18 @@ class DctHashIndex:
     def set_record_capacity(self, records: int) -> None:
         check(self._L.cbh_idx64_set_record_capacity(self._h, records), "set_record_capacity")
 
+    def shard_count(self) -> int:
+        return int(self._L.cbh_idx64_shard_count(self._h))
+
+    def shard_counts(self) -> list:
+        """slots held by every shard (a plain index: [count])"""
+        return [int(self._L.cbh_idx64_count(self._L.cbh_idx64_shard(self._h, i))) for i in range(self.shard_count())]
+
+    def shard_stats(self) -> "_lib.cbh_shard_stats":
+        st = _lib.cbh_shard_stats()
+        check(self._L.cbh_idx64_shard_stats(self._h, C.byref(st)), "shard_stats")
+        return st
+
     @property
     def handle(self):
         return self._h
@@ -248,7 +257,7 @@ class DctFeaturesIndex:
     keypoint hashes per image, stored as (mediaId, hash) entries; `find` votes over the 10 nearest
     entries of every needle hash (src/dctfeaturesindex.cpp:260-358)."""
 
-    def __init__(self, device: int = 0, tree_compat: bool = False, _handle=None) -> None:
+    def __init__(self, device: int = 0, tree_compat: bool = False, _handle=None, shards=None) -> None:
         self._L = _lib.lib()
         self._device = device
         self._id = SearchParams.AlgoDCTFeatures  # dctfeaturesindex.cpp:84
@@ -256,9 +265,7 @@ class DctFeaturesIndex:
         # entries of its HammingTree leaf (src/tree/hammingtree.h:244-252), i.e. the reference's own
         # approximate candidate sets, also on multi-leaf trees.
         self.tree_compat = bool(tree_compat)
-        self._h = _handle if _handle is not None else self._L.cbh_idx64_create(device)
-        if not self._h:
-            raise CbhError(_lib.CBH_E_NODEVICE, "cbh_idx64_create")
+        self._h = _handle if _handle is not None else _lib.create_idx64(device, shards)
 
     def __del__(self) -> None:
         h, self._h = getattr(self, "_h", None), None

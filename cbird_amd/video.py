@@ -172,7 +172,7 @@ class VideoSearchParams(SearchParams):
 class DctVideoIndex:
     """Detect similar videos with full-frame dct hashes (src/dctvideoindex.h:66-70)."""
 
-    def __init__(self, device: int = 0, data_path: str | None = None, radix_compat: bool = False) -> None:
+    def __init__(self, device: int = 0, data_path: str | None = None, radix_compat: bool = False, shards=None) -> None:
         # False: exact search (the reference's vradix = 0).  True: a needle frame only sees the entries of its
         # RadixMap bucket, (hash >> 1) & (2^videoRadix - 1) (src/tree/radix.h:135-141): the reference's
         # approximate candidate sets for `-p.vradix N`.
@@ -181,7 +181,8 @@ class DctVideoIndex:
         self._L = _lib.lib()
         self._id = SearchParams.AlgoVideo
         self._data_path = data_path
-        self._h = self._L.cbh_vidx_create(device)
+        shards = shards if shards is not None else _lib.default_sharding()  # (device_mask, shards_per_device)
+        self._h = self._L.cbh_vidx_create_sharded(shards[0], shards[1]) if shards else self._L.cbh_vidx_create(device)
         if not self._h:
             raise CbhError(_lib.CBH_E_NODEVICE, "cbh_vidx_create")
         self._loaded = False

@@ -68,6 +68,12 @@ int cbh_version(void);
 int cbh_device_count(void);             /* number of usable gfx950 devices, 0 if none */
 const char* cbh_strerror(int code);     /* static string */
 const char* cbh_last_error(void);       /* thread-local detail of the last CBH_E_HIP */
+/* Scratch memory.  Kernel scratch comes from stream-ordered pools that keep up to "pool_keep_mb" (default 1024) of
+ * freed blocks mapped so that the next call finds its buffers in place.  cbh_trim synchronises `device` and returns
+ * every free block of every pool of the library (and of the device's default pool) to the driver; *released_bytes
+ * (optional) = what that gave back.  Pools of caller-owned streams that no longer exist are dropped on the way (they
+ * are also dropped, and reused, whenever more than 32 streams have pools).  Safe to call at any time between calls. */
+int cbh_trim(int device, unsigned long long* released_bytes);
 
 /* ---- hash build: replaces dctHash64(const cv::Mat&, bool) -- src/cvutil.cpp:435-545,
  * called once per image from Scanner::processImage (src/scanner.cpp:862).
@@ -238,6 +244,34 @@ int cbh_dcthash_tiles_dev(const void* d_imgs, size_t n, int w, int h, size_t row
 /* ---- DctHashIndex: src/dcthashindex.{h,cpp} -------------------------------------------- */
 cbh_idx64* cbh_idx64_create(int device);                         /* DctHashIndex() :30-41 */
 void cbh_idx64_destroy(cbh_idx64*);                              /* ~DctHashIndex/unload :43-54 */
+/* ONE process, several GPUs.  cbird registers each Index once (src/engine.cpp:38-45) and fans find() out from its own
+ * thread pool (src/database.cpp:1400-1432), so a drop-in that is to use every GPU of the node shards INSIDE the handle:
+ * device_mask = bit d set for every HIP device d that takes a share (all must be usable gfx950 devices, else NULL);
+ * shards_per_device >= 2 additionally cuts each device's share into that many logical shards with their own streams
+ * (0 and 1 mean one).  The handle is a cbh_idx64 like any other: load/add/remove/find/find_batch/find_coalesced/slice/
+ * search_index_batch, the fdct_* calls and cbh_vidx / cbh_color built on it all accept it and return what the
+ * one-device index returns, bit for bit.  Rows are sharded in load order, shard s of R owning [s*n/R, (s+1)*n/R); add()
+ * appends to the emptiest shard; needles are replicated; per search every shard scans its rows on its own device into
+ * a { count, records } block, and the blocks meet on the first device of the mask: device-to-device copies inside a
+ * device, ONE grouped ncclAllGather (librccl, dlopen'ed on first use) between devices (cbird_amd/csrc/sharded.hip).
+ * The first device of the mask is the handle's device: *_dev calls take pointers on it. */
+cbh_idx64* cbh_idx64_create_sharded(uint32_t device_mask, int shards_per_device);
+uint32_t cbh_idx64_device_mask(const cbh_idx64*);   /* a plain index: 1 << device */
+int cbh_idx64_shards_per_device(const cbh_idx64*);  /* a plain index: 1 */
+int cbh_idx64_shard_count(const cbh_idx64*);        /* a plain index: 1 */
+/* shard i as a plain one-device index, BORROWED (never destroy it): its count / download / scan_dev / time_scan_dev
+ * show what one shard holds and does; a plain index is its own shard 0 */
+cbh_idx64* cbh_idx64_shard(cbh_idx64*, int i);
+typedef struct cbh_shard_stats {
+  uint32_t shards, devices, device_mask;
+  uint64_t segments;     /* runs of the global slot order (1 per shard after load; add() appends runs) */
+  uint64_t scans;        /* shard-local scan launches */
+  uint64_t rescans;      /* ... of which repeated because a shard's block overflowed */
+  uint64_t collectives;  /* grouped ncclAllGather calls */
+  uint64_t peer_copies;  /* hipMemcpyPeerAsync calls (needles out, records back with "shard_exchange" 1) */
+  uint64_t local_copies; /* device-to-device copies of shard blocks inside one device */
+} cbh_shard_stats;
+int cbh_idx64_shard_stats(const cbh_idx64*, cbh_shard_stats* out);
 /* load(): replaces the SoA fill of DctHashIndex::load (:70-114); the caller runs the SQL
  * (`select id,phash_dct from media where type=1`, :89) and hands over the two columns.
  * n == 0 is valid (loaded, empty). */
@@ -399,6 +433,9 @@ typedef struct cbh_vmatch {
 typedef struct cbh_vidx cbh_vidx; /* opaque: DctVideoIndex state */
 
 cbh_vidx* cbh_vidx_create(int device);
+/* the search structure built over all videos' frames becomes a sharded cbh_idx64 (above); entries are in video order,
+ * so the contiguous row shares are shares BY VIDEO up to one video at each boundary */
+cbh_vidx* cbh_vidx_create_sharded(uint32_t device_mask, int shards_per_device);
 void cbh_vidx_destroy(cbh_vidx*);
 /* 0 (default) = exact search; N > 0 = the reference's RadixMap(videoRadix = N) behaviour: a needle frame only
  * sees index entries of its bucket (hash >> 1) & (2^N - 1) (src/tree/radix.h:135-141, `-p.vradix`, default 10
@@ -575,7 +612,12 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *                   least 192 x 128 (default), v >= 2 = always, with v steps per strip
  *   "kp_lds_side"   largest keypoint square k_kp_hashes stages in LDS (default 134; larger: global-memory routine)
  *   "kp_blur_side"  largest keypoint square whose blurred copy also stays in LDS (default 112)
- *   "color_pk"      1 = packed-f32 colour distance kernel (default 1) */
+ *   "color_pk"      1 = packed-f32 colour distance kernel (default 1)
+ *   "pool_per_stream" 1 = scratch from one memory pool per (device, stream) (default), 0 = the device's default pool
+ *   "pool_keep_mb"  freed scratch a pool keeps mapped across synchronisations, in MB (default 1024; < 0: everything)
+ *   "shard_force_rccl" 1 = a sharded index on ONE device still sends its blocks through ncclAllGather (one rank): the
+ *                   transport test of a one-GPU box (default 0)
+ *   "shard_exchange" 0 = ncclAllGather between devices (default), 1 = hipMemcpyPeerAsync into the root block */
 int cbh_set_tuning(const char* key, int value);
 
 /* ---- measurement support ---------------------------------------------------------------- */

@@ -86,6 +86,25 @@ def reduce_path(request, gpu):
     _lib.lib().cbh_set_tuning(b"video_host_reduce", 0)
 
 
+@pytest.fixture(params=["one", "shards5", "rccl3"])
+def index_shape(request, gpu):
+    """Run a GPU test once per shape of the 64-bit index handle, all of which must give the same answers:
+    "one"     the plain one-device index (cbh_idx64_create);
+    "shards5" cbh_idx64_create_sharded(1 << 0, 5): five logical shards on the one GPU of this pool, five streams,
+              device-to-device copies as the exchange -- ragged shares, the merge, overflow-redo, removal;
+    "rccl3"   three logical shards whose concatenated device block additionally travels through ncclAllGather on a
+              one-rank communicator ("shard_force_rccl"): librccl's transport as the multi-GPU exchange uses it.
+    Every DctHashIndex / DctFeaturesIndex / DctVideoIndex a test creates takes the shape (_lib.set_default_sharding)."""
+    from cbird_amd import _lib
+
+    shape = {"one": None, "shards5": (1, 5), "rccl3": (1, 3)}[request.param]
+    _lib.set_default_sharding(shape)
+    _lib.lib().cbh_set_tuning(b"shard_force_rccl", 1 if request.param == "rccl3" else 0)
+    yield request.param
+    _lib.set_default_sharding(None)
+    _lib.lib().cbh_set_tuning(b"shard_force_rccl", 0)
+
+
 def load_golden(name):
     return np.load(os.path.join(ROOT, "tests", "golden", name))
 

@@ -28,6 +28,8 @@ int main(int argc, char** argv) {
   const int T = argc > 2 ? atoi(argv[2]) : 64;
   const int M = argc > 3 ? atoi(argv[3]) : 16384;
   const int dht = argc > 4 ? atoi(argv[4]) : 2;
+  GpuDeviceSet devs;  // optional: device mask and shards per device of the index under test
+  if (argc > 6) devs = GpuDeviceSet{uint32_t(strtoul(argv[5], nullptr, 0)), atoi(argv[6])};
   QSqlDatabase db;
   std::mt19937_64 rng(99);
   for (int i = 0; i < n; ++i) {
@@ -36,7 +38,7 @@ int main(int argc, char** argv) {
     if (!h) h = 2;
     db.media.push_back({uint32_t(i + 1), 1, int64_t(h)});
   }
-  GpuDctHashIndex idx;
+  GpuDctHashIndex idx(devs);
   idx.load(db, "", "");
   CHECK(idx.count() == n);
   SearchParams p;

@@ -29,6 +29,36 @@ def test_adapter_runs_on_gpu(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [("1", "8"), ("1", "3", "rccl")])
+def test_adapter_over_logical_shards_equals_the_one_device_index(gpu, shape):
+    """GpuDctHashIndex(GpuDeviceSet{mask, shardsPerDevice}): ONE index object over 8 logical shards (and over 3 whose
+    blocks travel through ncclAllGather) -- the whole adapter test again, every find also held against the one-device
+    index beside it.  src/engine.cpp:38-45 registers one object; the shards are inside it."""
+    subprocess.check_call(["make", "-C", CPP, "test_adapter"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(CPP, "test_adapter"), *shape], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "adapter ok" in out.stdout and f"shards {shape[1]} devices 1" in out.stdout
+    if "rccl" in shape:
+        assert "collectives 0" not in out.stdout
+
+
+@pytest.mark.gpu
+def test_drop_in_find_under_concurrent_callers_on_a_sharded_index(gpu):
+    """the 32-thread Database::similar pattern against ONE index of 4 logical shards: combining, the self-join cache
+    built from the shards, results equal to the batched path's"""
+    import json
+
+    subprocess.check_call(["make", "-C", CPP, "test_coalesce"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(CPP, "test_coalesce"), "100000", "32", "3125", "3", "1", "4"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "coalesce ok" in out.stdout
+    st = json.loads(out.stdout.splitlines()[0])["coalesce"]
+    assert st["finds"] == 100000 and st["cache_hits"] + st["scanned_needles"] == st["finds"]
+    assert st["self_joins"] >= 1 and st["cache_hits"] > 0
+
+
+@pytest.mark.gpu
 def test_drop_in_find_under_concurrent_callers(gpu):
     """GpuDctHashIndex::find from 32 threads, one synchronous call per needle (the reference's Database::similar
     pattern): every result equals the batched path's; combining + the self-join cache both get exercised"""

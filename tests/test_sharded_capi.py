@@ -1,0 +1,198 @@
+"""One index over several shards inside ONE process, behind the C-ABI (cbh_idx64_create_sharded, sharded.hip).
+
+cbird registers each Index once and fans find() out from its own thread pool (src/engine.cpp:38-45,
+src/database.cpp:1400-1432), so the drop-in shards inside the handle.  This pool has one GPU per box: the shards are
+logical ones on device 0 (their own streams, device-to-device copies as the exchange), and the inter-device transport
+-- one grouped ncclAllGather of the per-device blocks, librccl called directly -- runs on a one-rank communicator
+("shard_force_rccl").  Everything a sharded handle returns must equal what the one-device index returns, which the
+suites of test_gpu_hamm / test_fdct / test_video / test_database pin to the oracle and to the reference's golden
+vectors: those suites are re-run here, unchanged, with every index they create sharded."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import test_database as TD
+import test_fdct as TF
+import test_gpu_hamm as TH
+import test_video as TV
+from conftest import load_golden
+
+
+@pytest.fixture(params=["shards5", "rccl3", "shards2x"])
+def sharded(request, gpu):
+    """"shards5": five logical shards, copies only; "rccl3": three, their concatenated block through ncclAllGather;
+    "shards2x": two shards with the peer-copy exchange knob (on one device: the same copies as shards5)."""
+    from cbird_amd import _lib
+
+    L = _lib.lib()
+    shape = {"shards5": (1, 5), "rccl3": (1, 3), "shards2x": (1, 2)}[request.param]
+    _lib.set_default_sharding(shape)
+    L.cbh_set_tuning(b"shard_force_rccl", 1 if request.param == "rccl3" else 0)
+    L.cbh_set_tuning(b"shard_exchange", 1 if request.param == "shards2x" else 0)
+    yield request.param
+    _lib.set_default_sharding(None)
+    L.cbh_set_tuning(b"shard_force_rccl", 0)
+    L.cbh_set_tuning(b"shard_exchange", 0)
+
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("sharded")]
+
+# ---- the one-device suites, every index sharded ---------------------------------------------------------------------
+test_find_matches_reference_golden = TH.test_find_matches_reference_golden
+test_find_batch_vs_oracle_ragged_sizes = TH.test_find_batch_vs_oracle_ragged_sizes
+test_random_shapes_and_thresholds = TH.test_random_shapes_and_thresholds
+test_distance_extremes_all_thresholds = TH.test_distance_extremes_all_thresholds
+test_thresholds_full_range = TH.test_thresholds_full_range
+test_null_needle_empty_index_removed_slots = TH.test_null_needle_empty_index_removed_slots
+test_add_remove_slice_like_testindexbase = TH.test_add_remove_slice_like_testindexbase
+test_record_buffer_grows_instead_of_truncating = TH.test_record_buffer_grows_instead_of_truncating
+test_prefilter_pair_boundaries_and_low_word_collisions = TH.test_prefilter_pair_boundaries_and_low_word_collisions
+test_fdct_golden_and_oracle = TF.test_gpu_matches_golden_and_oracle
+test_fdct_add_remove_findindex_batch = TF.test_gpu_add_remove_findindex_batch
+test_fdct_tree_compatible_mode = TF.test_gpu_tree_compatible_mode_equals_real_multileaf_tree
+test_video_find_video_and_frame = TV.test_gpu_find_video_and_frame_vs_oracle
+test_video_batch_remove_add = TV.test_gpu_video_batch_remove_add
+test_video_radix_compatible = TV.test_gpu_radix_compatible_mode_equals_bucket_search
+test_similar_behind_the_c_abi = TD.test_similar_behind_the_c_abi_equals_the_oracle
+vorc = TV.vorc
+
+
+# ---- what only a sharded handle has ---------------------------------------------------------------------------------
+def test_shares_follow_the_shard_range_rule_and_the_order_is_global(gpu, sharded):
+    from cbird_amd import synth
+
+    R = {"shards5": 5, "rccl3": 3, "shards2x": 2}[sharded]
+    for n in (0, 1, R - 1, R, 1000, 12345):
+        h, ids = synth.make_hashes(max(n, 1), seed=7 + n)
+        h, ids = h[:n], ids[:n]
+        idx = gpu.DctHashIndex()
+        idx.load(h, ids)
+        assert idx.shard_count() == R and idx.count() == n and idx.memoryUsage() == 12 * n
+        assert idx.shard_counts() == [(s + 1) * n // R - s * n // R for s in range(R)]  # dist.py shard_range
+        dh, di = idx.download()
+        assert (dh == h).all() and (di == ids).all()
+    # add(): appended runs keep the global order whatever shard they land on
+    h, ids = synth.make_hashes(5000, seed=99)
+    idx = gpu.DctHashIndex()
+    idx.load(h[:1000], ids[:1000])
+    for a, b in ((1000, 1001), (1001, 1700), (1700, 1700), (1700, 4000), (4000, 5000)):
+        idx.add([gpu.Media(id=int(i), dctHash=int(x)) for x, i in zip(h[a:b], ids[a:b])])
+    dh, di = idx.download()
+    assert (dh == h).all() and (di == ids).all() and sum(idx.shard_counts()) == 5000
+    assert max(idx.shard_counts()) - min(idx.shard_counts()) < 2400  # the emptiest shard takes each batch
+    assert idx.mediaIds() == set(int(i) for i, x in zip(ids, h) if x)
+    st = idx.shard_stats()
+    assert st.shards == R and st.devices == 1 and st.device_mask == 1 and st.segments >= R
+
+
+def test_exchange_route_and_overflow_redo_are_what_the_shape_says(gpu, orc, sharded):
+    """the counters of cbh_idx64_shard_stats: "rccl3" really goes through ncclAllGather, the others never; a shard
+    whose block overflows is the only one that scans again"""
+    from cbird_amd import synth
+
+    R = {"shards5": 5, "rccl3": 3, "shards2x": 2}[sharded]
+    h, ids = synth.make_hashes(40000, seed=5, planted_frac=0.3)
+    # every needle matches the whole of shard 0's share at distance 0: that shard overflows, the others do not
+    share0 = 40000 // R
+    h[:share0] = h[0]
+    idx = gpu.DctHashIndex()
+    idx.load(h, ids)
+    idx.set_record_capacity(4096)
+    q = np.concatenate([h[:8], h[share0:share0 + 100]])
+    s0 = idx.shard_stats()
+    gi, gs, gc = idx.find_batch(q, 3, 7)
+    s1 = idx.shard_stats()
+    wi, ws, wc = orc.find64_batch(h, ids, q, 3, 7)
+    assert (gc == wc).all() and (gi == wi).all() and (gs == ws).all()
+    assert s1.scans - s0.scans == R + 1 and s1.rescans - s0.rescans == 1
+    if sharded == "rccl3":
+        assert s1.collectives - s0.collectives == 1 and 1 <= s1.local_copies - s0.local_copies <= R
+    else:
+        assert s1.collectives == 0 and 1 <= s1.local_copies - s0.local_copies <= R
+    assert s1.peer_copies == 0  # one device: nothing crosses xGMI here
+
+
+def test_many_reader_threads_on_one_sharded_handle(gpu, orc, sharded):
+    """Index::find from QThreadPool workers (src/database.cpp:1400-1432): the plain find and the caller-combining
+    find, 8 threads, one handle; each call leases its own workspace per shard"""
+    from cbird_amd import _lib, synth
+
+    L = _lib.lib()
+    h, ids = synth.make_hashes(30000, seed=51, planted_frac=0.2)
+    idx = gpu.DctHashIndex()
+    idx.load(h, ids)
+    q = h[:320]
+    p = gpu.SearchParams(dctThresh=7)
+    want = []
+    for t in q.tolist():
+        oi, od = orc.find64(h, ids, t, 7)
+        want.append(list(zip(oi.tolist(), od.tolist())))
+    errs = []
+
+    def worker(lo, hi, coalesced):
+        try:
+            buf = (_lib.cbh_match * 4096)()
+            n = C.c_size_t(0)
+            for j in range(lo, hi):
+                if coalesced:
+                    _lib.check(L.cbh_idx64_find_coalesced(idx.handle, int(q[j]), 7, buf, 4096, C.byref(n)), "find")
+                    m = [(buf[i].id, buf[i].score) for i in range(n.value)]
+                else:
+                    m = [(x.mediaId, x.score) for x in idx.find(gpu.Media(dctHash=int(q[j])), p)]
+                if m != want[j]:
+                    errs.append(j)
+        except Exception as e:  # pragma: no cover
+            errs.append(repr(e))
+
+    for coalesced in (False, True):
+        th = [threading.Thread(target=worker, args=(k * 40, k * 40 + 40, coalesced)) for k in range(8)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, (coalesced, errs[:5])
+
+
+def test_self_join_cache_of_a_sharded_index_and_its_size_limit(gpu, orc, sharded):
+    """cbh_idx64_find_coalesced builds its whole-index self-join from the shards (needles = the host mirror of the
+    slots in global order); an index whose self-join would not fit is served by combined scans and allocates nothing
+    of that size"""
+    from cbird_amd import _lib, synth
+
+    L = _lib.lib()
+    h, ids = synth.make_hashes(20000, seed=77, planted_frac=0.3)
+    idx = gpu.DctHashIndex()
+    idx.load(h, ids)
+    buf = (_lib.cbh_match * 4096)()
+    n = C.c_size_t(0)
+    st = (C.c_uint64 * 5)()
+    for rep in range(3):
+        for j in range(0, 20000, 7):
+            if not h[j]:
+                continue
+            _lib.check(L.cbh_idx64_find_coalesced(idx.handle, int(h[j]), 5, buf, 4096, C.byref(n)), "find")
+            if j % 700 == 0:
+                oi, od = orc.find64(h, ids, h[j], 5)
+                assert [(buf[i].id, buf[i].score) for i in range(n.value)] == list(zip(oi.tolist(), od.tolist()))
+    _lib.check(L.cbh_idx64_coalesce_stats(idx.handle, st), "stats")
+    assert st[4] >= 1 and st[1] > 0  # a self-join was built and hit
+
+
+def test_sharded_slice_is_sharded_and_video_index_takes_the_shape(gpu, sharded):
+    from cbird_amd import _lib, synth
+
+    L = _lib.lib()
+    h, ids = synth.make_hashes(3000, seed=3)
+    idx = gpu.DctHashIndex()
+    idx.load(h, ids)
+    sl = idx.slice(ids[100:900].tolist())
+    assert sl.shard_count() == idx.shard_count() and sl.count() == 800
+    dh, di = sl.download()
+    assert (di == ids[100:900]).all() and (dh == h[100:900]).all()
+    # the raw shard-local step is a shard's, not the parent's
+    assert L.cbh_idx64_scan_dev(idx.handle, 1, 1, 2, 1, 1, 1, None) == _lib.CBH_E_UNSUPPORTED
+    assert L.cbh_idx64_shard(idx.handle, idx.shard_count()) is None
+    assert L.cbh_idx64_device_mask(idx.handle) == 1
+    # unusable masks are refused outright (no silent narrowing to the devices that exist)
+    assert L.cbh_idx64_create_sharded(0, 1) is None
+    assert L.cbh_idx64_create_sharded(1 << 30, 1) is None

@@ -35,7 +35,27 @@ def main():
         idx.load(hashes, ids)
         idx.find_batch(hashes[:512], 5, 8)
 
-    phases = {"video indexer create/push/finish/destroy": video,
+    def external_stream():
+        """a caller that cycles its own streams (cbird's worker threads come and go): every call arrives on a NEW
+        torch stream that is dropped afterwards -- the library's per-stream scratch pools must not pile up"""
+        from cbird_amd import _lib
+        import ctypes as C
+        L = _lib.lib()
+        s = torch.cuda.Stream()
+        dq = torch.from_numpy(hashes[:4096].view(np.int64)).cuda()
+        with torch.cuda.stream(s):
+            out = torch.empty((4096, 8, 2), dtype=torch.int32, device="cuda")
+            cnt = torch.empty(4096, dtype=torch.int32, device="cuda")
+            tot = C.c_uint64(0)
+            _lib.check(L.cbh_idx64_find_batch_dev(ext_idx.handle, dq.data_ptr(), 4096, 6, 8, out.data_ptr(), cnt.data_ptr(),
+                                                  C.byref(tot), s.cuda_stream), "find_batch_dev")
+        s.synchronize()
+        del s
+
+    ext_idx = DctHashIndex()
+    ext_idx.load(hashes, ids)
+    phases = {"external streams: one new caller stream per call (300 streams)": external_stream,
+              "video indexer create/push/finish/destroy": video,
               "cbh_index_images (all algorithms, 64 images)": lambda: process_images(bgr, IndexParams(algos=15, numFeatures=60)),
               "cbh_process_images (64 frames)": lambda: hash_images(frames, 20),
               "cbh_template_scores (64 candidates)": lambda: template_scores(bgr, tmpl),
@@ -52,6 +72,13 @@ def main():
             fn()
         f1 = free()
         out[name] = {"free_MB_after_warmup": f0 >> 20, "after_150": mid >> 20, "after_300": f1 >> 20}
+    # cbh_trim: what the pools still hold goes back to the driver
+    from cbird_amd import _lib
+    import ctypes as C
+    rel = C.c_ulonglong(0)
+    before = free()
+    _lib.check(_lib.lib().cbh_trim(0, C.byref(rel)), "trim")
+    out["cbh_trim"] = {"released_MB": rel.value >> 20, "free_MB_before": before >> 20, "free_MB_after": free() >> 20}
     print(json.dumps(out))
     bad = [k for k, v in out.items() if v["after_150"] - v["after_300"] > 64]
     assert not bad, bad
