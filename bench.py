@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--video-clips", type=int, default=10_000)
     ap.add_argument("--no-orb", action="store_true", help="skip the configs[3] leg (CvFeaturesIndex sharded by image)")
     ap.add_argument("--orb-images", type=int, default=100_000, help="configs[3]: images x 500 descriptors of 256 bits")
+    ap.add_argument("--no-sharded-leg", action="store_true",
+                    help="skip the single-process leg (ONE DctHashIndex handle over all GPUs: cbh_idx64_create_sharded)")
     ap.add_argument("--no-features", action="store_true",
                     help="skip the indexer-stage leg (ORB, ColorDescriptor::create; reported beside the contract line)")
     return ap.parse_args()
@@ -321,6 +323,8 @@ def main():
         finally:
             ops.L.cbh_set_tuning(b"scan_mfma", 1)
         result["popcount_kernel_scan_ms"] = pop
+    if rank == 0 and not args.no_sharded_leg:
+        result["single_process_sharded"] = sharded_leg(args, world, local_rank, share)
     if rank == 0 and world == 1 and not args.no_features:
         result["indexer_stages"] = features_leg(torch, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -330,6 +334,36 @@ def main():
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sharded_leg(args, world, local_rank, share):
+    """The drop-in's own multi-GPU form, beside the torchrun harness above: ONE process, ONE DctHashIndex handle over
+    the GPUs (cbh_idx64_create_sharded: per-shard scans, ncclAllGather of the per-device blocks through librccl called
+    directly, merge and cut on the first device) -- cbird registers each index once and fans find() out from its own
+    threads (src/engine.cpp:38-45, src/database.cpp:1400-1432).  Runs tools/sharded_leg.py as a child process of rank
+    0 with its own timeout after the timed region (the other ranks idle at the final barrier): with N > 1 over the N
+    GPUs of the job, with N = 1 over 8 logical shards on the one GPU with their block sent through ncclAllGather.  The
+    same all-pairs dht sweep, needles and results resident; never part of `value`."""
+    import subprocess
+
+    if world > 1 and not share:
+        cmd = ["--mask", hex((1 << world) - 1), "--per-device", "1"]
+    else:
+        cmd = ["--mask", hex(1 << local_rank), "--per-device", "8", "--force-rccl"]
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "sharded_leg.py"), "--images", str(args.images), "--dht", args.dht,
+           "--topk", str(args.topk)] + cmd
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "GROUP_RANK",
+              "LOCAL_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE"):
+        env.pop(k, None)
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if out.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"error": f"rc {out.returncode}: " + (out.stderr or out.stdout)[-400:]}
+    except Exception as e:  # a leg beside the contract line must never take the line down
+        return {"error": repr(e)[:400]}
 
 
 def features_leg(torch, dev):

@@ -164,6 +164,10 @@ _SIGS = {
     "cbh_vindexer_frames_seen": (C.c_longlong, [_vp]),
     "cbh_vindexer_finish": (C.c_longlong, [_vp, _vp, _vp, _sz]),
     "cbh_idx256_create": (_vp, [C.c_int]),
+    "cbh_idx256_create_sharded": (_vp, [C.c_uint32, C.c_int]),
+    "cbh_idx256_shard_count": (C.c_int, [_vp]),
+    "cbh_idx256_shard_rows": (_sz, [_vp, C.c_int]),
+    "cbh_idx256_shard_stats": (C.c_int, [_vp, C.POINTER(cbh_shard_stats)]),
     "cbh_idx256_destroy": (None, [_vp]),
     "cbh_idx256_add": (C.c_int, [_vp, C.c_uint32, _vp, _sz]),
     "cbh_idx256_remove": (C.c_int, [_vp, _vp, _sz]),
@@ -223,6 +227,11 @@ def lib() -> C.CDLL:
         f.restype = res
         f.argtypes = args
     _state["lib"] = L
+    # CBH_TUNING="key=value,key=value": kernel-variant / allocator knobs (cbh_set_tuning) for tools and soaks
+    for kv in filter(None, os.environ.get("CBH_TUNING", "").split(",")):
+        k, _, v = kv.partition("=")
+        if L.cbh_set_tuning(k.strip().encode(), int(v)) != CBH_OK:
+            raise ValueError(f"CBH_TUNING: unknown knob {k!r}")
     return L
 
 

@@ -126,6 +126,13 @@ class GpuDctFeaturesIndex : public DctFeaturesIndex {  // inherits createTables/
 // ---- CvFeaturesIndex ----------------------------------------------------------------------------------
 class GpuCvFeaturesIndex : public CvFeaturesIndex {
  public:
+  // one index sharded by image over several GPUs / logical shards (GpuDeviceSet, gpu_devices.h)
+  GpuCvFeaturesIndex(const GpuDeviceSet& devs)
+      : _device(devs.first()),
+        _devs(devs),
+        _idx(devs.single() ? cbh_idx256_create(devs.first()) : cbh_idx256_create_sharded(devs.mask, devs.shardsPerDevice)) {
+    if (!_idx) qFatal("device mask 0x%x names a device that is not a usable MI355X", devs.mask);
+  }
   GpuCvFeaturesIndex(int device = 0) : _device(device), _idx(cbh_idx256_create(device)) {
     if (!_idx) qFatal("no usable MI355X device");
   }
@@ -200,7 +207,7 @@ class GpuCvFeaturesIndex : public CvFeaturesIndex {
   // slice(): the descriptors of the given media in ascending id order, like load() builds them
   // (cvfeaturesindex.cpp:285-312)
   Index* slice(const QSet<uint32_t>& mediaIds) const override {
-    GpuCvFeaturesIndex* chunk = new GpuCvFeaturesIndex(_device);
+    GpuCvFeaturesIndex* chunk = _devs.single() ? new GpuCvFeaturesIndex(_device) : new GpuCvFeaturesIndex(_devs);
     std::vector<uint32_t> ids(mediaIds.begin(), mediaIds.end());
     std::sort(ids.begin(), ids.end());
     std::vector<uint8_t> rows;
@@ -217,6 +224,7 @@ class GpuCvFeaturesIndex : public CvFeaturesIndex {
 
  private:
   int _device = 0;
+  GpuDeviceSet _devs;  // (declared before _idx: the sharded constructor initialises it first)
   cbh_idx256* _idx;
 };
 

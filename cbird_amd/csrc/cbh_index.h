@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "cbh_internal.h"
+#include "cbh_shard.h"
 
 namespace cbh {
 
@@ -46,7 +47,10 @@ struct DeviceGuard {
 
 inline bool device_usable(int dev) {
   hipDeviceProp_t p;
-  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) {
+    (void)hipGetLastError();  // do not leave "invalid device" behind: the next launch check of this thread would see it
+    return false;
+  }
   return strncmp(p.gcnArchName, "gfx950", 6) == 0;
 }
 
@@ -118,17 +122,8 @@ struct Workspace {
     d_total = nullptr, d_rec = nullptr, d_alt = nullptr, d_tmp = nullptr;
     rec_cap = 0, alt_cap = 0, tmp_bytes = 0;
   }
-  // exchange buffers of a sharded index (sharded.hip): [0] a device's concatenated block, [1] the all-gathered blocks
-  void* d_x[2] = {nullptr, nullptr};
-  size_t x_bytes[2] = {0, 0};
-  int ensure_x(int i, size_t bytes) {
-    if (bytes <= x_bytes[i]) return CBH_OK;
-    if (d_x[i]) (void)hipFree(d_x[i]);
-    d_x[i] = nullptr, x_bytes[i] = 0;
-    CBH_HIP(hipMalloc(&d_x[i], bytes));
-    x_bytes[i] = bytes;
-    return CBH_OK;
-  }
+  // exchange buffers of a sharded index (cbh_shard.h): [0] a device's concatenated block, [1] the all-gathered blocks
+  XBuf x[2];
   template <typename T>
   static int grow(T** p, size_t* cap, size_t need) {
     if (need <= *cap) return CBH_OK;
@@ -150,8 +145,7 @@ struct Workspace {
     if (d_qmask) (void)hipFree(d_qmask);
     if (d_out) (void)hipFree(d_out);
     if (d_counts) (void)hipFree(d_counts);
-    for (void* p : d_x)
-      if (p) (void)hipFree(p);
+    for (XBuf& b : x) b.release();
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (stream) cbh::stream_destroy(stream);

@@ -18,18 +18,19 @@ void set_last_error(const char* where, hipError_t e);
 void set_last_error_text(const char* text);  // non-HIP failures (RCCL)
 
 // ---- stream-ordered scratch memory (cbird_hip.hip) ------------------------------------------------------------------
-// Every kernel launcher takes its scratch from the stream-ordered allocator and gives it back right behind the last
-// kernel that uses it.  Two sources, switched by cbh_set_tuning("pool_per_stream", v):
-//   1 (default)  one hipMemPool_t per (device, stream): nothing is ever reused across streams.  Pools are bounded:
-//                a pool whose stream is gone or idle is handed to the next new stream (at most kMaxStreamPools live
-//                ones), freed blocks above "pool_keep_mb" go back to the driver at the next synchronisation, and
-//                cbh_trim(device) returns everything that is free
-//   0            the device's default pool (plain hipMallocAsync)
-// History and evidence: DESIGN.md section 7 and tools/ubench/pool_cross_stream.hip.
+// Every kernel launcher takes its scratch with malloc_async(&p, bytes, stream) and gives it back with
+// free_async(p, stream) right behind the last kernel that uses it (the contract of hipMallocAsync / hipFreeAsync).
+// cbh_set_tuning("scratch_alloc", v) picks the source:
+//   2 (default)  the library's own arena: hipMalloc'ed blocks cached per (device, stream), reused only by the stream
+//                that freed them; bounded ("pool_keep_mb" per stream, 32 stream caches, cbh_trim)
+//   1            one ROCm hipMemPool_t per stream (round 2)         } both hand out memory that is still in use on
+//   0            ROCm's default pool (plain hipMallocAsync)         } this stack: tools/ubench/pool_cross_stream.hip
 hipError_t malloc_async(void** p, size_t bytes, hipStream_t s);
-// for streams the library creates itself: the stream goes, its pool waits for the next one
+hipError_t free_async(void* p, hipStream_t s);
+// for streams the library creates itself: synchronise, hand the cached blocks to the device's orphan list, destroy
 void stream_destroy(hipStream_t s);
-void set_pool_per_stream(int v);
+void set_scratch_mode(int v);
+void set_scratch_poison(int v);
 void set_pool_keep_mb(int mb);
 int trim_pools(int device, unsigned long long* released_bytes);
 
@@ -78,8 +79,8 @@ void set_scan256_ht(int ht);
 void set_scan256_pre(int on);  // first-128-bit prefilter variant (default on)
 void set_scan256_mfma(int on);  // <0 = keep; 2 = force for any size
 
-void set_shard_force_rccl(int v);  // sharded.hip: the inter-device collective also with one device (transport test)
-void set_shard_exchange(int v);    // sharded.hip: 0 = ncclAllGather between devices, 1 = peer copies into the root block
+
+
 int g_hash_mfma_set(int v);  // dcthash.hip
 extern int g_fdct_host_vote, g_video_host_reduce;  // fdct.hip: 1 = round-1 host reductions (parity tests)
 void set_hash_regs(int v);      // dcthash.hip: register-streaming general-geometry kernel where applicable (default 1)

@@ -29,38 +29,87 @@ void set_last_error(const char* where, hipError_t e) {
 
 void set_last_error_text(const char* text) { t_last_error = text ? text : ""; }
 
-// ---- stream-ordered scratch (see cbh_internal.h) ----
+// ---- stream-ordered scratch (see cbh_internal.h) --------------------------------------------------------------------
+// Mode 2 (default): the library's own arena.  Blocks are plain hipMalloc memory, cached per (device, stream); a block
+// freed with free_async(p, s) is at once available again -- but only to allocations on the SAME stream s, which by
+// stream order run after everything that used it.  A block changes streams only when its stream is known idle or gone
+// (stream_destroy, eviction, trim), and goes back to the driver only then.  Nothing here depends on ROCm's
+// hipMallocAsync, whose pools (tools/ubench/pool_cross_stream.hip, profiles/r03_pool_cross_stream.jsonl) hand out
+// memory that is still in use.  Modes 0 / 1 keep those pools (default pool / one pool per stream) for the A/B soak.
 namespace {
-constexpr size_t kMaxStreamPools = 32;  // live (device, stream) pools; beyond that dead / idle streams give theirs up
-struct StreamPools {
-  std::mutex mu;
-  struct Entry {
-    hipMemPool_t pool;
-    uint64_t last_use;
-  };
-  std::map<std::pair<int, hipStream_t>, Entry> pools;
-  std::map<int, std::vector<hipMemPool_t>> idle;  // pools without a stream: everything in them is free
-  uint64_t clock = 0;
-  uint64_t created = 0, adopted = 0, evicted_dead = 0, evicted_idle = 0;
+constexpr size_t kMaxStreamCaches = 32;  // live (device, stream) caches; beyond that dead / idle streams give theirs up
+struct Block {
+  void* p;
+  size_t bytes;
 };
-StreamPools& stream_pools() {
-  static StreamPools* p = new StreamPools;  // never destroyed: calls may arrive during process teardown
-  return *p;
+struct StreamCache {
+  std::vector<Block> free;
+  size_t free_bytes = 0;
+  uint64_t last_use = 0;
+  hipMemPool_t pool = nullptr;  // mode 1 only
+};
+struct LiveInfo {
+  size_t bytes;
+  int dev;
+};
+struct Arena {
+  std::mutex mu;
+  std::map<std::pair<int, hipStream_t>, StreamCache> caches;
+  std::map<int, std::vector<Block>> orphan;  // blocks whose stream is idle or gone: any stream may take them
+  std::map<int, size_t> orphan_bytes;
+  std::map<int, std::vector<hipMemPool_t>> idle_pools;  // mode 1
+  std::map<void*, LiveInfo> live;  // blocks handed out by mode 2
+  uint64_t clock = 0;
+  uint64_t n_malloc = 0, n_reuse = 0, n_adopt = 0, n_evicted_dead = 0, n_evicted_idle = 0, n_released = 0;
+};
+Arena& arena() {
+  static Arena* a = new Arena;  // never destroyed: calls may arrive during process teardown
+  return *a;
 }
-int g_pool_per_stream = 1;
-uint64_t g_pool_keep_bytes = (uint64_t)1 << 30;  // freed blocks a pool keeps mapped across synchronisations
+int g_scratch_mode = 2;
+int g_scratch_poison = 0;  // "scratch_poison": v > 0 fills every block handed out with byte v - 1 (finds kernels that
+                           // read scratch they never wrote: fresh driver memory is zero, a recycled block is not)
+uint64_t g_pool_keep_bytes = (uint64_t)1 << 30;  // freed scratch kept mapped per stream (and per device for orphans)
+
+size_t round_size(size_t b) {
+  if (b <= 256) return 256;
+  if (b <= ((size_t)1 << 20)) {  // next power of two
+    size_t r = 256;
+    while (r < b) r <<= 1;
+    return r;
+  }
+  return (b + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1);  // 2 MiB granules
+}
+
+// smallest cached block that fits without wasting more than half of it (+ 2 MiB); -1 if none
+long best_fit(const std::vector<Block>& v, size_t need) {
+  long best = -1;
+  for (size_t i = 0; i < v.size(); ++i)
+    if (v[i].bytes >= need && v[i].bytes <= 2 * need + ((size_t)2 << 20) && (best < 0 || v[i].bytes < v[(size_t)best].bytes))
+      best = (long)i;
+  return best;
+}
 
 void apply_threshold(hipMemPool_t pool) {
   uint64_t keep = g_pool_keep_bytes;
   (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
 }
 
-// under sp.mu: streams that no longer exist (a caller destroyed them: hipStreamQuery fails) or that are idle (every
-// hipFreeAsync queued on them has completed) hand their pool to the idle list.  Dead ones always; idle ones oldest
-// first and only while there are too many.
-void evict(StreamPools& sp, int dev) {
+// under A.mu, current device = dev.  The cache of an idle / dead stream moves to the orphan list (its blocks are
+// unused: everything queued behind them has completed, or the stream no longer exists), what exceeds the budget is
+// released.  Dead streams always, idle ones oldest first while there are too many caches (or all of them: `all`).
+void evict(Arena& A, int dev, bool all, std::vector<void*>* to_free) {
   std::vector<std::pair<uint64_t, std::pair<int, hipStream_t>>> idle_live;
-  for (auto it = sp.pools.begin(); it != sp.pools.end();) {
+  auto orphanize = [&](StreamCache& c) {
+    for (Block& b : c.free) {
+      A.orphan[dev].push_back(b);
+      A.orphan_bytes[dev] += b.bytes;
+    }
+    c.free.clear();
+    c.free_bytes = 0;
+    if (c.pool) A.idle_pools[dev].push_back(c.pool);
+  };
+  for (auto it = A.caches.begin(); it != A.caches.end();) {
     if (it->first.first != dev) {
       ++it;
       continue;
@@ -72,111 +121,226 @@ void evict(StreamPools& sp, int dev) {
     }
     if (q != hipSuccess) {  // the handle is not a stream any more
       (void)hipGetLastError();
-      sp.idle[dev].push_back(it->second.pool);
-      sp.evicted_dead++;
-      it = sp.pools.erase(it);
+      orphanize(it->second);
+      A.n_evicted_dead++;
+      it = A.caches.erase(it);
       continue;
     }
     idle_live.push_back({it->second.last_use, it->first});
     ++it;
   }
   std::sort(idle_live.begin(), idle_live.end());
-  for (size_t i = 0; i < idle_live.size() && sp.pools.size() >= kMaxStreamPools; ++i) {
-    auto it = sp.pools.find(idle_live[i].second);
-    sp.idle[dev].push_back(it->second.pool);
-    sp.evicted_idle++;
-    sp.pools.erase(it);
+  for (size_t i = 0; i < idle_live.size() && (all || A.caches.size() >= kMaxStreamCaches); ++i) {
+    auto it = A.caches.find(idle_live[i].second);
+    orphanize(it->second);
+    A.n_evicted_idle++;
+    A.caches.erase(it);
+  }
+  // orphans beyond the budget go back to the driver (largest first)
+  std::vector<Block>& o = A.orphan[dev];
+  std::sort(o.begin(), o.end(), [](const Block& x, const Block& y) { return x.bytes < y.bytes; });
+  while (!o.empty() && A.orphan_bytes[dev] > g_pool_keep_bytes) {
+    to_free->push_back(o.back().p);
+    A.orphan_bytes[dev] -= o.back().bytes;
+    o.pop_back();
+    A.n_released++;
   }
 }
 }  // namespace
 
-void set_pool_per_stream(int v) { g_pool_per_stream = v ? 1 : 0; }
+void set_scratch_mode(int v) { g_scratch_mode = v < 0 ? 0 : v > 2 ? 2 : v; }
 void set_pool_keep_mb(int mb) {
   g_pool_keep_bytes = mb < 0 ? ~0ull : (uint64_t)mb << 20;
-  StreamPools& sp = stream_pools();
-  std::lock_guard<std::mutex> lk(sp.mu);
-  for (auto& kv : sp.pools) apply_threshold(kv.second.pool);
-  for (auto& kv : sp.idle)
-    for (hipMemPool_t p : kv.second) apply_threshold(p);
+  Arena& A = arena();
+  std::lock_guard<std::mutex> lk(A.mu);
+  for (auto& kv : A.caches)
+    if (kv.second.pool) apply_threshold(kv.second.pool);
 }
 
+static hipError_t malloc_async_raw(void** p, size_t bytes, hipStream_t s);
 hipError_t malloc_async(void** p, size_t bytes, hipStream_t s) {
-  if (!s || !g_pool_per_stream) return hipMallocAsync(p, bytes, s);  // (the NULL stream is synchronous by contract)
+  hipError_t e = malloc_async_raw(p, bytes, s);
+  if (e == hipSuccess && g_scratch_poison > 0 && bytes) e = hipMemsetAsync(*p, g_scratch_poison - 1, bytes, s);
+  return e;
+}
+void set_scratch_poison(int v) { g_scratch_poison = v; }
+static hipError_t malloc_async_raw(void** p, size_t bytes, hipStream_t s) {
+  if (g_scratch_mode == 0 || (g_scratch_mode == 1 && !s)) return hipMallocAsync(p, bytes, s);
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  hipMemPool_t pool = nullptr;
-  {
-    StreamPools& sp = stream_pools();
-    std::lock_guard<std::mutex> lk(sp.mu);
-    auto it = sp.pools.find({dev, s});
-    if (it != sp.pools.end()) {
-      pool = it->second.pool;
-      it->second.last_use = ++sp.clock;
-    } else {
-      if (sp.pools.size() >= kMaxStreamPools) evict(sp, dev);
-      std::vector<hipMemPool_t>& idle = sp.idle[dev];
-      if (!idle.empty()) {  // everything in it is free and its stream was idle or gone when it came here
-        pool = idle.back();
-        idle.pop_back();
-        sp.adopted++;
-      } else {
-        hipMemPoolProps props;
-        memset(&props, 0, sizeof props);
-        props.allocType = hipMemAllocationTypePinned;
-        props.handleTypes = hipMemHandleTypeNone;
-        props.location.type = hipMemLocationTypeDevice;
-        props.location.id = dev;
-        if ((e = hipMemPoolCreate(&pool, &props)) != hipSuccess) return e;
-        apply_threshold(pool);
-        sp.created++;
+  Arena& A = arena();
+  if (g_scratch_mode == 1) {  // one ROCm pool per stream (round 2's workaround; unsafe, kept for the A/B soak)
+    hipMemPool_t pool = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(A.mu);
+      StreamCache& c = A.caches[{dev, s}];
+      c.last_use = ++A.clock;
+      if (!c.pool) {
+        std::vector<hipMemPool_t>& idle = A.idle_pools[dev];
+        if (!idle.empty()) {
+          c.pool = idle.back();
+          idle.pop_back();
+        } else {
+          hipMemPoolProps props;
+          memset(&props, 0, sizeof props);
+          props.allocType = hipMemAllocationTypePinned;
+          props.handleTypes = hipMemHandleTypeNone;
+          props.location.type = hipMemLocationTypeDevice;
+          props.location.id = dev;
+          if ((e = hipMemPoolCreate(&c.pool, &props)) != hipSuccess) return e;
+          apply_threshold(c.pool);
+        }
       }
-      sp.pools.emplace(std::make_pair(dev, s), StreamPools::Entry{pool, ++sp.clock});
+      pool = c.pool;
+    }
+    return hipMallocFromPoolAsync(p, bytes, pool, s);
+  }
+  const size_t need = round_size(bytes);
+  std::vector<void*> to_free;
+  {
+    std::lock_guard<std::mutex> lk(A.mu);
+    A.n_malloc++;
+    auto it = A.caches.find({dev, s});
+    if (it == A.caches.end()) {
+      if (A.caches.size() >= kMaxStreamCaches) evict(A, dev, false, &to_free);
+      it = A.caches.emplace(std::make_pair(dev, s), StreamCache{}).first;
+    }
+    StreamCache& c = it->second;
+    c.last_use = ++A.clock;
+    long i = best_fit(c.free, need);
+    if (i >= 0) {
+      Block b = c.free[(size_t)i];
+      c.free.erase(c.free.begin() + i);
+      c.free_bytes -= b.bytes;
+      A.live[b.p] = LiveInfo{b.bytes, dev};
+      A.n_reuse++;
+      *p = b.p;
+    } else if ((i = best_fit(A.orphan[dev], need)) >= 0) {
+      std::vector<Block>& o = A.orphan[dev];
+      Block b = o[(size_t)i];
+      o.erase(o.begin() + i);
+      A.orphan_bytes[dev] -= b.bytes;
+      A.live[b.p] = LiveInfo{b.bytes, dev};
+      A.n_adopt++;
+      *p = b.p;
+    } else {
+      *p = nullptr;
     }
   }
-  return hipMallocFromPoolAsync(p, bytes, pool, s);
+  for (void* q : to_free) (void)hipFree(q);
+  if (*p) return hipSuccess;
+  e = hipMalloc(p, need);
+  if (e == hipErrorOutOfMemory) {  // give back everything that is cached and idle, then try once more
+    (void)hipGetLastError();
+    unsigned long long rel = 0;
+    (void)trim_pools(dev, &rel);
+    e = hipMalloc(p, need);
+  }
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(A.mu);
+  A.live[*p] = LiveInfo{need, dev};
+  return hipSuccess;
+}
+
+hipError_t free_async(void* p, hipStream_t s) {
+  if (!p) return hipSuccess;
+  Arena& A = arena();
+  size_t over = 0;
+  int dev = 0;
+  {
+    std::lock_guard<std::mutex> lk(A.mu);
+    auto it = A.live.find(p);
+    if (it == A.live.end()) return hipFreeAsync(p, s);  // a block of modes 0 / 1
+    const LiveInfo info = it->second;
+    dev = info.dev;
+    A.live.erase(it);
+    StreamCache& c = A.caches[{info.dev, s}];
+    c.last_use = ++A.clock;
+    c.free.push_back(Block{p, info.bytes});
+    c.free_bytes += info.bytes;
+    over = c.free_bytes > g_pool_keep_bytes ? c.free_bytes - g_pool_keep_bytes : 0;
+  }
+  if (over && hipStreamQuery(s) == hipSuccess) {  // over budget and nothing queued behind the blocks: release some
+    std::vector<void*> to_free;
+    {
+      std::lock_guard<std::mutex> lk(A.mu);
+      auto it = A.caches.find({dev, s});
+      if (it != A.caches.end()) {
+        StreamCache& c = it->second;
+        std::sort(c.free.begin(), c.free.end(), [](const Block& x, const Block& y) { return x.bytes < y.bytes; });
+        while (!c.free.empty() && c.free_bytes > g_pool_keep_bytes) {
+          to_free.push_back(c.free.back().p);
+          c.free_bytes -= c.free.back().bytes;
+          c.free.pop_back();
+          A.n_released++;
+        }
+      }
+    }
+    for (void* q : to_free) (void)hipFree(q);
+  } else {
+    (void)hipGetLastError();
+  }
+  return hipSuccess;
 }
 
 void stream_destroy(hipStream_t s) {
   if (!s) return;
   (void)hipStreamSynchronize(s);
   int dev = 0;
+  std::vector<void*> to_free;
   if (hipGetDevice(&dev) == hipSuccess) {
-    StreamPools& sp = stream_pools();
-    std::lock_guard<std::mutex> lk(sp.mu);
-    auto it = sp.pools.find({dev, s});
-    if (it != sp.pools.end()) {
-      sp.idle[dev].push_back(it->second.pool);
-      sp.pools.erase(it);
+    Arena& A = arena();
+    std::lock_guard<std::mutex> lk(A.mu);
+    auto it = A.caches.find({dev, s});
+    if (it != A.caches.end()) {  // the stream is idle: its blocks may serve any stream from now on
+      for (Block& b : it->second.free) {
+        A.orphan[dev].push_back(b);
+        A.orphan_bytes[dev] += b.bytes;
+      }
+      if (it->second.pool) A.idle_pools[dev].push_back(it->second.pool);
+      A.caches.erase(it);
+      std::vector<Block>& o = A.orphan[dev];
+      std::sort(o.begin(), o.end(), [](const Block& x, const Block& y) { return x.bytes < y.bytes; });
+      while (!o.empty() && A.orphan_bytes[dev] > g_pool_keep_bytes) {
+        to_free.push_back(o.back().p);
+        A.orphan_bytes[dev] -= o.back().bytes;
+        o.pop_back();
+        A.n_released++;
+      }
     }
   }
   (void)hipStreamDestroy(s);
+  for (void* q : to_free) (void)hipFree(q);
 }
 
-// cbh_trim: every free block of every pool of `device` (and of its default pool) goes back to the driver; pools of
-// streams that are gone are dropped from the table on the way
+// cbh_trim (the caller has synchronised the device): every cached block of `device` goes back to the driver, caches
+// of streams that are gone are dropped, ROCm pools (modes 0 / 1) are trimmed
 int trim_pools(int device, unsigned long long* released_bytes) {
-  StreamPools& sp = stream_pools();
-  std::lock_guard<std::mutex> lk(sp.mu);
-  unsigned long long before = 0, after = 0;
-  auto reserved = [](hipMemPool_t p) {
-    uint64_t v = 0;
-    (void)hipMemPoolGetAttribute(p, hipMemPoolAttrReservedMemCurrent, &v);
-    return (unsigned long long)v;
-  };
-  evict(sp, device);
-  std::vector<hipMemPool_t> all;
-  for (auto& kv : sp.pools)
-    if (kv.first.first == device) all.push_back(kv.second.pool);
-  for (hipMemPool_t p : sp.idle[device]) all.push_back(p);
-  hipMemPool_t def = nullptr;
-  if (hipDeviceGetDefaultMemPool(&def, device) == hipSuccess && def) all.push_back(def);
-  for (hipMemPool_t p : all) {
-    before += reserved(p);
-    CBH_HIP(hipMemPoolTrimTo(p, 0));
-    after += reserved(p);
+  Arena& A = arena();
+  std::vector<void*> to_free;
+  unsigned long long rel = 0;
+  std::vector<hipMemPool_t> pools;
+  {
+    std::lock_guard<std::mutex> lk(A.mu);
+    const uint64_t keep = g_pool_keep_bytes;
+    g_pool_keep_bytes = 0;
+    evict(A, device, true, &to_free);
+    g_pool_keep_bytes = keep;
+    for (auto& kv : A.caches)
+      if (kv.first.first == device && kv.second.pool) pools.push_back(kv.second.pool);
+    for (hipMemPool_t p : A.idle_pools[device]) pools.push_back(p);
   }
-  if (released_bytes) *released_bytes = before > after ? before - after : 0;
+  // (sizes of what evict() released are not tracked per pointer: measure through the driver)
+  size_t f0 = 0, f1 = 0, tot = 0;
+  (void)hipMemGetInfo(&f0, &tot);
+  for (void* q : to_free) (void)hipFree(q);
+  hipMemPool_t def = nullptr;
+  if (hipDeviceGetDefaultMemPool(&def, device) == hipSuccess && def) pools.push_back(def);
+  for (hipMemPool_t p : pools) (void)hipMemPoolTrimTo(p, 0);
+  (void)hipMemGetInfo(&f1, &tot);
+  rel = f1 > f0 ? f1 - f0 : 0;
+  if (released_bytes) *released_bytes = rel;
   return CBH_OK;
 }
 
@@ -792,7 +956,7 @@ static int find_batch_core(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, s
     d_status = (unsigned*)((char*)scratch + topk_scratch_bytes(nq, ncap));
     rc = topk_scratch_init(scratch, nq, s);
     if (!rc) rc = launch_records_topk(ws->d_total, 1, 0, ncap, nq, k, d_out, d_counts, d_status, scratch, s);
-    (void)hipFreeAsync(scratch, s);
+    (void)cbh::free_async(scratch, s);
     return rc;
   }
   if ((rc = ws->ensure_sort())) return rc;
@@ -899,7 +1063,7 @@ int cbh_records_topk_dev(const void* d_blocks, size_t n_blocks, size_t block_str
   if (!rc)
     rc = launch_records_topk((const unsigned long long*)d_blocks, (unsigned)n_blocks, block_stride, cap, nq,
                              max_per_query, (cbh_match*)d_out, (uint32_t*)d_counts, (unsigned*)d_status, scratch, s);
-  (void)hipFreeAsync(scratch, s);
+  (void)cbh::free_async(scratch, s);
   if (rc) return rc;
   if (!stream) CBH_HIP(hipStreamSynchronize(s));
   return CBH_OK;
@@ -919,13 +1083,13 @@ int cbh_sort_records_dev(void* d_records, size_t n, size_t nq, int device, void*
   CBH_HIP(cbh::malloc_async((void**)&alt, n * sizeof(cbh_record), s));
   hipError_t e = cbh::malloc_async(&tmp, tmp_bytes ? tmp_bytes : 16, s);
   if (e != hipSuccess) {
-    (void)hipFreeAsync(alt, s);
+    (void)cbh::free_async(alt, s);
     set_last_error("cbh::malloc_async(sort scratch)", e);
     return CBH_E_NOMEM;
   }
   int rc = launch_sort_records((cbh_record*)d_records, alt, n, nq, tmp, tmp_bytes, s);
-  (void)hipFreeAsync(alt, s);
-  (void)hipFreeAsync(tmp, s);
+  (void)cbh::free_async(alt, s);
+  (void)cbh::free_async(tmp, s);
   if (rc) return rc;
   if (!stream) CBH_HIP(hipStreamSynchronize(s));
   return CBH_OK;
@@ -1045,8 +1209,12 @@ int cbh_set_tuning(const char* key, int value) {
     g_hash_mfma_set(value);
     return CBH_OK;
   }
-  if (!strcmp(key, "pool_per_stream")) {
-    set_pool_per_stream(value);
+  if (!strcmp(key, "scratch_poison")) {
+    set_scratch_poison(value);
+    return CBH_OK;
+  }
+  if (!strcmp(key, "scratch_alloc")) {
+    set_scratch_mode(value);
     return CBH_OK;
   }
   if (!strcmp(key, "pool_keep_mb")) {

@@ -782,7 +782,7 @@ int launch_color_descriptors(const uint8_t* d_imgs, size_t n, const uint64_t* im
   }
   for (void* p : {(void*)d_images, (void*)d_masks, (void*)d_tabs, (void*)d_samples, (void*)d_dists, (void*)d_pos,
                   (void*)d_labels, (void*)d_counts})
-    if (p) (void)hipFreeAsync(p, s);
+    if (p) (void)cbh::free_async(p, s);
   return rc;
 }
 

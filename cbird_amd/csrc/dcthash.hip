@@ -2604,7 +2604,7 @@ int launch_rect_hashes(uint8_t* d_base, const std::vector<RectImageDesc>& images
     e = hipGetLastError();
   }
   for (void* p : {(void*)d_images, (void*)d_jobs, (void*)d_axes, (void*)d_apool, (void*)d_ipool, (void*)d_scr})
-    if (p) (void)hipFreeAsync(p, stream);
+    if (p) (void)cbh::free_async(p, stream);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   CBH_HIP(e);
   return CBH_OK;
@@ -2726,7 +2726,7 @@ int launch_keypoint_hashes(uint8_t* d_base, size_t n, const uint64_t* img_off, c
   }
   for (void* p : {(void*)d_images, (void*)d_kp, (void*)d_sizes, (void*)d_apool, (void*)d_ipool, (void*)d_scr,
                   (void*)d_slots, (void*)d_counts, (void*)d_first})
-    if (p) (void)hipFreeAsync(p, stream);
+    if (p) (void)cbh::free_async(p, stream);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   CBH_HIP(e);
   return CBH_OK;
@@ -2895,7 +2895,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
                            isy, 1, tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
       }
       hipError_t ef = hipGetLastError();
-      (void)hipFreeAsync(d_rowsf, stream);
+      (void)cbh::free_async(d_rowsf, stream);
       CBH_HIP(ef);
       return CBH_OK;
     }
@@ -2935,8 +2935,8 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
                          isx, isy, 0, tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
     }
     hipError_t e = hipGetLastError();
-    (void)hipFreeAsync(d_rows, stream);
-    (void)hipFreeAsync(d_blur, stream);
+    (void)cbh::free_async(d_rows, stream);
+    (void)cbh::free_async(d_blur, stream);
     CBH_HIP(e);
     return CBH_OK;
   }
@@ -2975,7 +2975,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
                          tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
     }
     CBH_HIP(hipGetLastError());
-    CBH_HIP(hipFreeAsync(d_blur, stream));
+    CBH_HIP(cbh::free_async(d_blur, stream));
     return CBH_OK;
   }
   if (w == 256 && h == 256 && ((uintptr_t)d_imgs % 8) == 0 && row_stride % 8 == 0 &&

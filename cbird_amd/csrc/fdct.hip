@@ -144,7 +144,7 @@ int fdct_core(cbh_idx64* idx, const uint64_t* hashes, const std::vector<Needle>&
     unsigned* d_status = (unsigned*)((char*)scratch + topk_scratch_bytes(nq, ncap));
     rc = topk_scratch_init(scratch, nq, s);
     if (!rc) rc = launch_records_topk(ws->d_total, 1, 0, ncap, nq, k, ws->d_out, ws->d_counts, d_status, scratch, s);
-    (void)hipFreeAsync(scratch, s);
+    (void)cbh::free_async(scratch, s);
     if (rc) return rc;
   }
   if (g_fdct_host_vote == 1 || (g_fdct_host_vote == 0 && needles.size() == 1)) {  // host reduction
@@ -169,8 +169,8 @@ int fdct_core(cbh_idx64* idx, const uint64_t* hashes, const std::vector<Needle>&
   if (e == hipSuccess && !nid.empty()) e = hipMemcpyAsync(d_nid, nid.data(), nid.size() * 4, hipMemcpyHostToDevice, s);
   std::vector<cbh_nmatch> flat;
   if (e == hipSuccess) rc = launch_fdct_vote(ws->d_out, ws->d_counts, d_qneedle, nq, k, d_nid, nid.size(), &flat, s);
-  if (d_qneedle) (void)hipFreeAsync(d_qneedle, s);
-  if (d_nid) (void)hipFreeAsync(d_nid, s);
+  if (d_qneedle) (void)cbh::free_async(d_qneedle, s);
+  if (d_nid) (void)cbh::free_async(d_nid, s);
   CBH_HIP(e);
   if (rc) return rc;
   std::sort(flat.begin(), flat.end(), [](const cbh_nmatch& a, const cbh_nmatch& b) {

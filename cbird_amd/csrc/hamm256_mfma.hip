@@ -207,7 +207,7 @@ int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, siz
   }
 #undef CBH_256
   hipError_t e = hipGetLastError();
-  (void)hipFreeAsync(qx, stream);
+  (void)cbh::free_async(qx, stream);
   CBH_HIP(e);
   return CBH_OK;
 }

@@ -591,7 +591,7 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
                        n_triples, tpc, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total,
                        (uint32_t)(flags & 1u), reinterpret_cast<const uint2*>(d_qmask));
     hipError_t e3 = hipGetLastError();
-    (void)hipFreeAsync(qx, stream);
+    (void)cbh::free_async(qx, stream);
     CBH_HIP(e3);
     return CBH_OK;
   }
@@ -614,7 +614,7 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
 #undef CBH_MFMA
 #undef CBH_MFMA_G
   hipError_t e = hipGetLastError();
-  (void)hipFreeAsync(qx, stream);
+  (void)cbh::free_async(qx, stream);
   CBH_HIP(e);
   return CBH_OK;
 }

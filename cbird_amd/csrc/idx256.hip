@@ -119,9 +119,13 @@ int sig_bits256(size_t nq) {
 
 }  // namespace
 
+struct Shards256;  // below: the children of a CvFeaturesIndex that spans several shards / devices
+
 struct cbh_idx256 {
   int device = 0;
   bool loaded = false;
+  Shards256* shards = nullptr;  // cbh_idx256_create_sharded: this handle keeps the maps, its children the rows
+  cbh::XBuf x[2];               // exchange buffers of a child (cbh_shard.h)
   uint8_t* d_rows = nullptr;  // N x 32 B
   size_t n = 0, cap = 0;
   // _indexMap (cvfeaturesindex.h:77): first row -> mediaId (0 = removed), ascending; sentinel (n, 0)
@@ -152,7 +156,7 @@ struct cbh_idx256 {
 
 namespace {
 
-int ensure_scratch(cbh_idx256* ix, size_t nq, size_t rec_cap, int k) {
+int ensure_scratch(cbh_idx256* ix, size_t nq, size_t rec_cap, int k, bool scan_only = false) {
   if (!ix->stream) {
     CBH_HIP(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
     CBH_HIP(hipMalloc(&ix->d_total, 8));
@@ -168,9 +172,11 @@ int ensure_scratch(cbh_idx256* ix, size_t nq, size_t rec_cap, int k) {
     ix->d_tmp = nullptr;
     ix->rec_cap = 0;
     CBH_HIP(hipMalloc(&ix->d_rec, rec_cap * 8));
-    CBH_HIP(hipMalloc(&ix->d_alt, rec_cap * 8));
-    ix->tmp_bytes = cbh::sort_records_scratch_bytes(rec_cap);
-    CBH_HIP(hipMalloc(&ix->d_tmp, ix->tmp_bytes ? ix->tmp_bytes : 16));
+    if (!scan_only) {  // (a shard only scans: the sort and the cut run on the parent)
+      CBH_HIP(hipMalloc(&ix->d_alt, rec_cap * 8));
+      ix->tmp_bytes = cbh::sort_records_scratch_bytes(rec_cap);
+      CBH_HIP(hipMalloc(&ix->d_tmp, ix->tmp_bytes ? ix->tmp_bytes : 16));
+    }
     ix->rec_cap = rec_cap;
   }
   if (nq > ix->q_cap) {
@@ -180,7 +186,7 @@ int ensure_scratch(cbh_idx256* ix, size_t nq, size_t rec_cap, int k) {
     CBH_HIP(hipMalloc(&ix->d_q, nq * 32));
     ix->q_cap = nq;
   }
-  if (nq * (size_t)k > ix->out_cap) {
+  if (!scan_only && nq * (size_t)k > ix->out_cap) {
     if (ix->d_out_row) (void)hipFree(ix->d_out_row);
     if (ix->d_out_dist) (void)hipFree(ix->d_out_dist);
     if (ix->d_counts) (void)hipFree(ix->d_counts);
@@ -217,25 +223,11 @@ int launch_scan256(cbh_idx256* ix, const uint8_t* d_q, size_t nq, int thresh) {
   return CBH_OK;
 }
 
-// knn (k per needle descriptor, below thresh) for nq needle rows on the host side of the index;
-// out_row/out_dist [nq*k], counts[nq] (full number under thresh)
-int knn_core(cbh_idx256* ix, const uint8_t* needles, size_t nq, int k, int thresh, std::vector<uint32_t>* row,
-             std::vector<uint16_t>* dist, std::vector<uint32_t>* counts,
-             std::vector<unsigned long long>* all_records = nullptr) {
-  if (!all_records) {
-    row->assign(nq * (size_t)k, 0);
-    dist->assign(nq * (size_t)k, 0);
-    counts->assign(nq, 0);
-  } else {
-    all_records->clear();
-  }
-  if (nq == 0 || ix->n == 0 || thresh <= 0 || k <= 0) return CBH_OK;
-  if (nq >= (1u << 23)) return CBH_E_INVAL;
-  cbh::DeviceGuard g(ix->device);
-  if (!g.ok) return CBH_E_NODEVICE;
-  std::lock_guard<std::mutex> lk(ix->mu);
-  int rc = ensure_scratch(ix, nq, std::max<size_t>(ix->rec_cap, (size_t)1 << 22), k);
-  if (rc) return rc;
+// every record of nq needle rows (host memory) against the rows of ONE device-resident index, in ix->d_rec on
+// ix->stream; the buffer grows until all of them fit
+int scan_records(cbh_idx256* ix, const uint8_t* needles, size_t nq, int k, int thresh, unsigned long long* total_out,
+                 bool scan_only = false) {
+  int rc;
   CBH_HIP(hipMemcpyAsync(ix->d_q, needles, nq * 32, hipMemcpyHostToDevice, ix->stream));
   unsigned long long total = 0;
   for (int attempt = 0;; ++attempt) {
@@ -255,9 +247,211 @@ int knn_core(cbh_idx256* ix, const uint8_t* needles, size_t nq, int k, int thres
     total = *ix->h_total;
     if (total <= ix->rec_cap) break;
     if (attempt >= 2) return CBH_E_OVERFLOW;
-    rc = ensure_scratch(ix, nq, (size_t)total + 1024, k);
+    rc = ensure_scratch(ix, nq, (size_t)total + 1024, k, scan_only);
     if (rc) return rc == CBH_E_NOMEM ? CBH_E_OVERFLOW : rc;
   }
+  *total_out = total;
+  return CBH_OK;
+}
+
+}  // namespace
+
+// ---- one CvFeaturesIndex over several shards / GPUs (cbh_idx256_create_sharded) ------------------------------------
+// Sharded BY IMAGE: a media's descriptor rows stay together on one shard; the parent keeps the
+// first-row -> mediaId maps in GLOBAL row numbers exactly as the one-device index does, the children hold rows only.
+// Rows arrive media by media (add), so a shard takes media until it has received kShardRun rows, then the emptiest
+// shard takes over: the global row order is the add order, a shard's rows are runs of it (a segment table per shard).
+// A search scans every shard on its own device and stream, rewrites the LOCAL row of every record to the global one
+// (k_rows_to_global: the tie-break of the knn is (distance, global row), and the maps are global), brings the records
+// to the parent with ShardComm::exchange (cbh_shard.h: copies inside a device, ncclAllGather between devices) and
+// sorts / cuts / scores there as the one-device index does.
+struct Shards256 {
+  cbh::ShardComm comm;
+  std::vector<cbh_idx256*> child;
+  struct Seg {
+    uint32_t shard;
+    size_t local, global, len;
+  };
+  std::vector<Seg> segs;  // in global order
+  size_t cur = 0, cur_run = 0;
+  static constexpr size_t kShardRun = 16384;
+  // per shard: the segment table on its device (local start ascending, global - local), rebuilt when rows were added
+  std::vector<uint32_t*> d_seg_local;
+  std::vector<long long*> d_seg_delta;
+  std::vector<uint32_t> n_seg;
+  bool dirty = true;
+};
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_rows_to_global(unsigned long long* __restrict__ rec, unsigned long long n,
+                                                        const uint32_t* __restrict__ seg_local,
+                                                        const long long* __restrict__ seg_delta, uint32_t nseg) {
+  const unsigned long long i = blockIdx.x * 256ull + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long r = rec[i];
+  const uint32_t row = (uint32_t)r;
+  uint32_t lo = 0, hi = nseg;  // last segment whose local start is <= row
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (seg_local[mid] <= row)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  rec[i] = (r & 0xffffffff00000000ull) | (uint32_t)((long long)row + seg_delta[lo]);
+}
+
+int upload_segments(cbh_idx256* ix) {
+  Shards256* S = ix->shards;
+  if (!S->dirty) return CBH_OK;
+  const size_t R = S->child.size();
+  for (size_t s = 0; s < R; ++s) {
+    std::vector<uint32_t> loc;
+    std::vector<long long> delta;
+    for (const Shards256::Seg& g : S->segs)
+      if (g.shard == s) {  // (global order is also local order inside a shard)
+        loc.push_back((uint32_t)g.local);
+        delta.push_back((long long)g.global - (long long)g.local);
+      }
+    cbh::DeviceGuard dg(S->child[s]->device);
+    if (!dg.ok) return CBH_E_NODEVICE;
+    if (S->d_seg_local[s]) (void)hipFree(S->d_seg_local[s]);
+    if (S->d_seg_delta[s]) (void)hipFree(S->d_seg_delta[s]);
+    S->d_seg_local[s] = nullptr, S->d_seg_delta[s] = nullptr;
+    S->n_seg[s] = (uint32_t)loc.size();
+    if (loc.empty()) continue;
+    CBH_HIP(hipMalloc(&S->d_seg_local[s], loc.size() * 4));
+    CBH_HIP(hipMalloc(&S->d_seg_delta[s], loc.size() * 8));
+    CBH_HIP(hipMemcpy(S->d_seg_local[s], loc.data(), loc.size() * 4, hipMemcpyHostToDevice));
+    CBH_HIP(hipMemcpy(S->d_seg_delta[s], delta.data(), delta.size() * 8, hipMemcpyHostToDevice));
+  }
+  S->dirty = false;
+  return CBH_OK;
+}
+
+// as scan_records, over the shards: all records, rows global, in the parent's d_rec on the parent's stream
+int scan_records_sharded(cbh_idx256* ix, const uint8_t* needles, size_t nq, int k, int thresh,
+                         unsigned long long* total_out) {
+  Shards256* S = ix->shards;
+  const size_t R = S->child.size();
+  int rc = upload_segments(ix);
+  if (rc) return rc;
+  std::vector<unsigned long long> count(R, 0);
+  std::vector<char> todo(R, 0);
+  // needles to every shard's device, first scans
+  for (size_t s = 0; s < R; ++s) {
+    cbh_idx256* c = S->child[s];
+    if (!c->n) continue;
+    cbh::DeviceGuard dg(c->device);
+    if (!dg.ok) return CBH_E_NODEVICE;
+    if ((rc = ensure_scratch(c, nq, std::max<size_t>(c->rec_cap, std::max<size_t>(65536, ((size_t)1 << 22) / R)), k, true)))
+      return rc;
+    CBH_HIP(hipMemcpyAsync(c->d_q, needles, nq * 32, hipMemcpyHostToDevice, c->stream));
+    todo[s] = 1;
+  }
+  float scan_ms = 0;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    bool any = false;
+    for (size_t s = 0; s < R; ++s) {
+      if (!todo[s]) continue;
+      any = true;
+      cbh_idx256* c = S->child[s];
+      cbh::DeviceGuard dg(c->device);
+      CBH_HIP(hipMemsetAsync(c->d_total, 0, 8, c->stream));
+      CBH_HIP(hipEventRecord(c->ev0, c->stream));
+      if ((rc = launch_scan256(c, c->d_q, nq, thresh))) return rc;
+      CBH_HIP(hipEventRecord(c->ev1, c->stream));
+      CBH_HIP(hipMemcpyAsync(c->h_total, c->d_total, 8, hipMemcpyDeviceToHost, c->stream));
+      S->comm.n_scans++;
+      if (attempt) S->comm.n_rescans++;
+    }
+    if (!any) break;
+    float worst = 0;
+    for (size_t s = 0; s < R; ++s) {
+      if (!todo[s]) continue;
+      cbh_idx256* c = S->child[s];
+      cbh::DeviceGuard dg(c->device);
+      CBH_HIP(hipStreamSynchronize(c->stream));
+      count[s] = *c->h_total;
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) worst = std::max(worst, ms);
+      todo[s] = 0;
+      if (count[s] > c->rec_cap) {  // this shard alone grows its buffer and scans again
+        rc = ensure_scratch(c, nq, (size_t)count[s] + 1024, k, true);
+        if (rc) return rc == CBH_E_NOMEM ? CBH_E_OVERFLOW : rc;
+        todo[s] = 1;
+      }
+    }
+    scan_ms += worst;
+  }
+  for (size_t s = 0; s < R; ++s)
+    if (todo[s]) return CBH_E_OVERFLOW;
+  ix->scan_ms += scan_ms;
+  ix->scan_pairs += (uint64_t)ix->n * nq;
+  ix->scan_launches++;
+  unsigned long long sum = 0;
+  for (size_t s = 0; s < R; ++s) sum += count[s];
+  if (sum > ix->rec_cap) {
+    cbh::DeviceGuard dg(ix->device);
+    rc = ensure_scratch(ix, nq, (size_t)sum + 1024, k);
+    if (rc) return rc == CBH_E_NOMEM ? CBH_E_OVERFLOW : rc;
+  }
+  // local rows -> global rows, then the exchange
+  std::vector<cbh::ShardPart> parts(R);
+  for (size_t s = 0; s < R; ++s) {
+    cbh_idx256* c = S->child[s];
+    cbh::DeviceGuard dg(c->device);
+    if (count[s]) {
+      hipLaunchKernelGGL(k_rows_to_global, dim3((unsigned)((count[s] + 255) / 256)), dim3(256), 0, c->stream, c->d_rec,
+                         count[s], S->d_seg_local[s], S->d_seg_delta[s], S->n_seg[s]);
+      CBH_HIP(hipGetLastError());
+    }
+    if (!c->stream) {  // an empty shard that never scanned still takes part in a collective
+      if ((rc = ensure_scratch(c, 1, 1024, k, true))) return rc;
+    }
+    parts[s].dev_pos = S->comm.dev_pos_of_shard(s);
+    parts[s].stream = c->stream;
+    parts[s].d_rec = c->d_rec;
+    parts[s].count = count[s];
+    parts[s].ev = c->ev1;
+    parts[s].x = c->x;
+    parts[s].h_word = c->h_total;
+  }
+  cbh::DeviceGuard dg(ix->device);
+  if ((rc = S->comm.exchange(parts, ix->stream, ix->d_rec))) return rc;
+  CBH_HIP(hipStreamSynchronize(ix->stream));
+  for (size_t s = 0; s < R; ++s) {  // the shards' side of a collective has finished too before their buffers are reused
+    cbh_idx256* c = S->child[s];
+    cbh::DeviceGuard dg2(c->device);
+    if (c->stream) CBH_HIP(hipStreamSynchronize(c->stream));
+  }
+  *total_out = sum;
+  return CBH_OK;
+}
+
+// knn (k per needle descriptor, below thresh) for nq needle rows on the host side of the index;
+// out_row/out_dist [nq*k], counts[nq] (full number under thresh)
+int knn_core(cbh_idx256* ix, const uint8_t* needles, size_t nq, int k, int thresh, std::vector<uint32_t>* row,
+             std::vector<uint16_t>* dist, std::vector<uint32_t>* counts,
+             std::vector<unsigned long long>* all_records = nullptr) {
+  if (!all_records) {
+    row->assign(nq * (size_t)k, 0);
+    dist->assign(nq * (size_t)k, 0);
+    counts->assign(nq, 0);
+  } else {
+    all_records->clear();
+  }
+  if (nq == 0 || ix->n == 0 || thresh <= 0 || k <= 0) return CBH_OK;
+  if (nq >= (1u << 23)) return CBH_E_INVAL;
+  cbh::DeviceGuard g(ix->device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  std::lock_guard<std::mutex> lk(ix->mu);
+  int rc = ensure_scratch(ix, nq, std::max<size_t>(ix->rec_cap, (size_t)1 << 22), k);
+  if (rc) return rc;
+  unsigned long long total = 0;
+  if ((rc = ix->shards ? scan_records_sharded(ix, needles, nq, k, thresh, &total) : scan_records(ix, needles, nq, k, thresh, &total)))
+    return rc;
   if (total > 1) {
     rocprim::double_buffer<unsigned long long> db(ix->d_rec, ix->d_alt);
     size_t tb = ix->tmp_bytes;
@@ -336,9 +530,75 @@ cbh_idx256* cbh_idx256_create(int device) {
   return ix;
 }
 
+cbh_idx256* cbh_idx256_create_sharded(uint32_t device_mask, int shards_per_device) {
+  Shards256* S = new (std::nothrow) Shards256;
+  if (!S || !S->comm.init(device_mask, shards_per_device)) {
+    delete S;
+    return nullptr;
+  }
+  cbh_idx256* ix = cbh_idx256_create(S->comm.devices[0]);
+  if (!ix) {
+    delete S;
+    return nullptr;
+  }
+  ix->shards = S;
+  const size_t R = S->comm.shard_count();
+  for (size_t s = 0; s < R; ++s) {
+    cbh_idx256* c = cbh_idx256_create(S->comm.device_of_shard(s));
+    if (!c) {
+      cbh_idx256_destroy(ix);
+      return nullptr;
+    }
+    S->child.push_back(c);
+  }
+  S->d_seg_local.assign(R, nullptr);
+  S->d_seg_delta.assign(R, nullptr);
+  S->n_seg.assign(R, 0);
+  return ix;
+}
+
+int cbh_idx256_shard_count(const cbh_idx256* ix) { return !ix ? 0 : ix->shards ? (int)ix->shards->child.size() : 1; }
+
+size_t cbh_idx256_shard_rows(const cbh_idx256* ix, int i) {
+  if (!ix) return 0;
+  if (!ix->shards) return i == 0 ? ix->n : 0;
+  return i >= 0 && (size_t)i < ix->shards->child.size() ? ix->shards->child[(size_t)i]->n : 0;
+}
+
+int cbh_idx256_shard_stats(const cbh_idx256* ix, cbh_shard_stats* out) {
+  if (!ix || !out) return CBH_E_INVAL;
+  memset(out, 0, sizeof *out);
+  out->shards = 1, out->devices = 1;
+  if (!ix->shards) return CBH_OK;
+  const Shards256* S = ix->shards;
+  out->shards = (uint32_t)S->child.size();
+  out->devices = (uint32_t)S->comm.devices.size();
+  out->device_mask = S->comm.mask;
+  out->segments = S->segs.size();
+  out->scans = S->comm.n_scans.load();
+  out->rescans = S->comm.n_rescans.load();
+  out->collectives = S->comm.n_collectives.load();
+  out->peer_copies = S->comm.n_peer_copies.load();
+  out->local_copies = S->comm.n_local_copies.load();
+  return CBH_OK;
+}
+
 void cbh_idx256_destroy(cbh_idx256* ix) {
   if (!ix) return;
+  if (ix->shards) {
+    Shards256* S = ix->shards;
+    S->comm.destroy_comms();
+    for (size_t s = 0; s < S->child.size(); ++s) {
+      cbh::DeviceGuard g(S->child[s]->device);
+      if (s < S->d_seg_local.size() && S->d_seg_local[s]) (void)hipFree(S->d_seg_local[s]);
+      if (s < S->d_seg_delta.size() && S->d_seg_delta[s]) (void)hipFree(S->d_seg_delta[s]);
+      cbh_idx256_destroy(S->child[s]);
+    }
+    delete S;
+    ix->shards = nullptr;
+  }
   cbh::DeviceGuard g(ix->device);
+  for (cbh::XBuf& b : ix->x) b.release();
   for (void* p : {(void*)ix->d_rows, (void*)ix->d_rec, (void*)ix->d_alt, (void*)ix->d_tmp, (void*)ix->d_total,
                   (void*)ix->d_q, (void*)ix->d_out_row, (void*)ix->d_out_dist, (void*)ix->d_counts})
     if (p) (void)hipFree(p);
@@ -360,7 +620,27 @@ int cbh_idx256_add(cbh_idx256* ix, uint32_t media_id, const uint8_t* rows, size_
   cbh::DeviceGuard g(ix->device);
   if (!g.ok) return CBH_E_NODEVICE;
   std::lock_guard<std::mutex> lk(ix->mu);
-  if (ix->n + n_rows > ix->cap) {
+  if (ix->shards) {  // the rows go to a shard, the maps stay here in global row numbers
+    Shards256* S = ix->shards;
+    if (S->cur_run >= Shards256::kShardRun) {  // the current shard has had its run: the emptiest one takes over
+      size_t best = 0;
+      for (size_t s = 1; s < S->child.size(); ++s)
+        if (S->child[s]->n < S->child[best]->n) best = s;
+      S->cur = best;
+      S->cur_run = 0;
+    }
+    cbh_idx256* c = S->child[S->cur];
+    const size_t local = c->n;
+    int rc = cbh_idx256_add(c, media_id, rows, n_rows);
+    if (rc) return rc;
+    if (!S->segs.empty() && S->segs.back().shard == S->cur && S->segs.back().local + S->segs.back().len == local &&
+        S->segs.back().global + S->segs.back().len == ix->n)
+      S->segs.back().len += n_rows;
+    else
+      S->segs.push_back(Shards256::Seg{(uint32_t)S->cur, local, ix->n, n_rows});
+    S->cur_run += n_rows;
+    S->dirty = true;
+  } else if (ix->n + n_rows > ix->cap) {
     size_t ncap = std::max<size_t>(ix->n + n_rows, ix->cap + ix->cap / 2 + 65536);
     uint8_t* nr = nullptr;
     CBH_HIP(hipMalloc(&nr, ncap * 32));
@@ -369,7 +649,7 @@ int cbh_idx256_add(cbh_idx256* ix, uint32_t media_id, const uint8_t* rows, size_
     ix->d_rows = nr;
     ix->cap = ncap;
   }
-  CBH_HIP(hipMemcpy(ix->d_rows + ix->n * 32, rows, n_rows * 32, hipMemcpyHostToDevice));
+  if (!ix->shards) CBH_HIP(hipMemcpy(ix->d_rows + ix->n * 32, rows, n_rows * 32, hipMemcpyHostToDevice));
   // _idMap[mid] = numDesc; _indexMap[numDesc] = mid; sentinel (numDesc + rows) -> 0
   ix->first_row.back() = (uint32_t)ix->n;
   ix->media_id.back() = media_id;
@@ -412,6 +692,18 @@ int cbh_idx256_rows_of(const cbh_idx256* ix, uint32_t media_id, size_t* first, s
 int cbh_idx256_download_rows(const cbh_idx256* ix, size_t first, size_t count, uint8_t* out) {
   if (!ix || (count && !out) || first + count > ix->n) return CBH_E_INVAL;
   if (!count) return CBH_OK;
+  if (ix->shards) {  // the range may span runs on several shards
+    for (const Shards256::Seg& sg : ix->shards->segs) {
+      const size_t a = std::max(first, sg.global), b = std::min(first + count, sg.global + sg.len);
+      if (a >= b) continue;
+      const cbh_idx256* c = ix->shards->child[sg.shard];
+      cbh::DeviceGuard g(c->device);
+      if (!g.ok) return CBH_E_NODEVICE;
+      CBH_HIP(hipMemcpy(out + (a - first) * 32, c->d_rows + (sg.local + (a - sg.global)) * 32, (b - a) * 32,
+                        hipMemcpyDeviceToHost));
+    }
+    return CBH_OK;
+  }
   cbh::DeviceGuard g(ix->device);
   if (!g.ok) return CBH_E_NODEVICE;
   CBH_HIP(hipMemcpy(out, ix->d_rows + first * 32, count * 32, hipMemcpyDeviceToHost));

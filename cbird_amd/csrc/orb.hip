@@ -951,7 +951,7 @@ int launch_orb(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const u
     rc = e == hipErrorOutOfMemory ? CBH_E_NOMEM : CBH_E_HIP;
   }
   for (void* p : {(void*)d_images, (void*)d_pyr, (void*)d_sc, (void*)d_cand, (void*)d_lc, (void*)d_pat})
-    if (p) (void)hipFreeAsync(p, s);
+    if (p) (void)cbh::free_async(p, s);
   return rc;
 }
 
@@ -1056,7 +1056,7 @@ int launch_orb_describe(const uint8_t* d_imgs, size_t n, const uint64_t* img_off
   }
   for (void* p : {(void*)d_images, (void*)d_pyr, (void*)d_sc, (void*)d_lc, (void*)d_pat, (void*)d_kps, (void*)d_xy,
                   (void*)d_desc})
-    if (p) (void)hipFreeAsync(p, s);
+    if (p) (void)cbh::free_async(p, s);
   return rc;
 }
 

@@ -104,7 +104,7 @@ static int index_images_one(const uint8_t* imgs, size_t n, int w, int h, size_t 
     if (s) (void)hipStreamSynchronize(s);
     for (void* q : {(void*)d_src, (void*)d_gray, (void*)d_res, (void*)d_desc, (void*)d_cdesc, (void*)d_cok, (void*)d_out,
                     (void*)d_kph, (void*)d_rects, (void*)d_kp, (void*)d_after, (void*)d_cnt})
-      if (q) (void)hipFreeAsync(q, s);  // back to the cached pool (keep_pool_memory): the next call reuses it
+      if (q) (void)cbh::free_async(q, s);  // back to the cached pool (keep_pool_memory): the next call reuses it
     if (s) (void)hipStreamSynchronize(s), cbh::stream_destroy(s);
   };
 #define CBH_TRY(call)                                             \

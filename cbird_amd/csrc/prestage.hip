@@ -399,7 +399,7 @@ int cbh_autocrop_dev(const void* d_gray, size_t n, int w, int h, size_t row_stri
                        (int*)d_rects + i0 * 4);
   }
   CBH_HIP(hipGetLastError());
-  CBH_HIP(hipFreeAsync(scratch, s));
+  CBH_HIP(cbh::free_async(scratch, s));
   if (!stream) CBH_HIP(hipStreamSynchronize(s));
   return CBH_OK;
 }
@@ -562,8 +562,8 @@ int cbh_template_hashes_dev(const void* d_cands, size_t n, int w, int h, size_t 
     if (rc == CBH_OK) rc = cbh::launch_dcthash(tg, m, w, h, (size_t)w, px, (uint64_t*)d_tmpl_hashes + i0, s);
   }
   hipError_t e = hipGetLastError();
-  (void)hipFreeAsync(cg, s);
-  (void)hipFreeAsync(tg, s);
+  (void)cbh::free_async(cg, s);
+  (void)cbh::free_async(tg, s);
   if (rc) return rc;
   CBH_HIP(e);
   if (!stream) CBH_HIP(hipStreamSynchronize(s));
@@ -675,7 +675,7 @@ int cbh_resize_lanczos4_dev(const void* d_src, size_t n, int w, int h, size_t ro
     e = hipGetLastError();
   }
   for (void* p : {(void*)d_xofs, (void*)d_yofs, (void*)d_xa, (void*)d_yb})
-    if (p) (void)hipFreeAsync(p, s);
+    if (p) (void)cbh::free_async(p, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);  // the tables came from pageable host vectors
   if (e != hipSuccess) {
     cbh::set_last_error("resize_lanczos4", e);

@@ -192,8 +192,8 @@ int sort_keys_u64(unsigned long long* d_keys, size_t n, int end_bit, hipStream_t
   hipError_t e = cbh::malloc_async(&tmp, bytes ? bytes : 16, s);
   if (e == hipSuccess) e = rocprim::radix_sort_keys(tmp, bytes, d_keys, alt, n, 0, (unsigned)end_bit, s);
   if (e == hipSuccess) e = hipMemcpyAsync(d_keys, alt, n * 8, hipMemcpyDeviceToDevice, s);
-  (void)hipFreeAsync(alt, s);
-  if (tmp) (void)hipFreeAsync(tmp, s);
+  (void)cbh::free_async(alt, s);
+  if (tmp) (void)cbh::free_async(tmp, s);
   CBH_HIP(e);
   return CBH_OK;
 }
@@ -211,9 +211,9 @@ int sort_pairs_u64_u32(unsigned long long* d_keys, uint32_t* d_vals, size_t n, i
   if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, bytes, d_keys, kalt, d_vals, valt, n, 0, (unsigned)end_bit, s);
   if (e == hipSuccess) e = hipMemcpyAsync(d_keys, kalt, n * 8, hipMemcpyDeviceToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(d_vals, valt, n * 4, hipMemcpyDeviceToDevice, s);
-  (void)hipFreeAsync(kalt, s);
-  if (valt) (void)hipFreeAsync(valt, s);
-  if (tmp) (void)hipFreeAsync(tmp, s);
+  (void)cbh::free_async(kalt, s);
+  if (valt) (void)cbh::free_async(valt, s);
+  if (tmp) (void)cbh::free_async(tmp, s);
   CBH_HIP(e);
   return CBH_OK;
 }
@@ -254,7 +254,7 @@ int launch_fdct_vote(const cbh_match* d_top, const uint32_t* d_counts, const uin
     }
   }
   for (void* p : {(void*)keys, (void*)runs, (void*)misc, (void*)out})
-    if (p) (void)hipFreeAsync(p, s);
+    if (p) (void)cbh::free_async(p, s);
   if (rc) return rc;
   CBH_HIP(e);
   return CBH_OK;
@@ -297,7 +297,7 @@ int launch_video_reduce(const unsigned* d_off, const unsigned long long* d_seg, 
     }
   }
   for (void* p : {(void*)keys, (void*)vals, (void*)out, (void*)n_out})
-    if (p) (void)hipFreeAsync(p, s);
+    if (p) (void)cbh::free_async(p, s);
   if (rc) return rc;
   CBH_HIP(e);
   return CBH_OK;

@@ -96,7 +96,7 @@ int cbh_search_index_batch(cbh_idx64* idx, const uint64_t* q, const uint32_t* ne
         unsigned* d_status = (unsigned*)((char*)scratch + topk_scratch_bytes(np, ncap));
         rc = topk_scratch_init(scratch, np, s);
         if (!rc) rc = launch_records_topk(ws->d_total, 1, 0, ncap, np, k, ws->d_out, ws->d_counts, d_status, scratch, s);
-        (void)hipFreeAsync(scratch, s);
+        (void)cbh::free_async(scratch, s);
         if (rc) return rc;
       }
       top.resize(np * (size_t)k);

@@ -16,7 +16,8 @@
 //             { u64 count; records[cap] } (needles reach the other devices by peer copies behind an event);
 //             the host reads the R counts (the one synchronisation scan_all always had); only a shard whose block
 //             overflowed grows it and scans again
-//   exchange  inside a device: device-to-device copies of exactly count_s records behind each other;
+//   exchange  ShardComm::exchange (cbh_shard.h; shared with the sharded CvFeaturesIndex, idx256.hip) --
+//             inside a device: device-to-device copies of exactly count_s records behind each other;
 //             between devices: ONE grouped ncclAllGather of the per-device blocks, sized to the fullest device
 //             (1 + max count words) -- librccl called directly (ncclCommInitAll, one communicator per device, all
 //             in this process), found with dlopen so that a single-GPU user never loads it;
@@ -82,59 +83,175 @@ Rccl* rccl() {
 int g_force_rccl = 0;  // "shard_force_rccl": the collective also at one device (transport test on a one-GPU box)
 int g_exchange = 0;    // "shard_exchange": 0 = ncclAllGather between devices, 1 = peer copies into the root block
 
+int ensure_comms(ShardComm* C) {  // under coll_mu
+  if (!C->comms.empty()) return CBH_OK;
+  if (C->comms_tried) return CBH_E_UNSUPPORTED;
+  C->comms_tried = true;
+  Rccl* r = rccl();
+  if (!r->handle || !r->why.empty()) {
+    set_last_error_text(("RCCL unavailable: " + r->why).c_str());
+    return CBH_E_UNSUPPORTED;
+  }
+  std::vector<ncclComm_t> c(C->devices.size());
+  ncclResult_t e = r->CommInitAll(c.data(), (int)C->devices.size(), C->devices.data());
+  if (e != ncclSuccess) {
+    set_last_error_text((std::string("ncclCommInitAll: ") + r->GetErrorString(e)).c_str());
+    return CBH_E_HIP;
+  }
+  for (ncclComm_t x : c) C->comms.push_back((void*)x);
+  return CBH_OK;
+}
+
 }  // namespace
 
 void set_shard_force_rccl(int v) { g_force_rccl = v; }
 void set_shard_exchange(int v) { g_exchange = v; }
 
+bool ShardComm::init(uint32_t device_mask, int shards_per_device) {
+  if (device_mask == 0 || shards_per_device < 0 || shards_per_device > 64) return false;
+  devices.clear();
+  for (int d = 0; d < 32; ++d)
+    if (device_mask & (1u << d)) {
+      if (!device_usable(d)) return false;  // a device of the mask is not there: no silent narrowing
+      devices.push_back(d);
+    }
+  per_device = std::max(1, shards_per_device);
+  mask = device_mask;
+  if (devices.size() > 1)  // direct xGMI copies where the platform allows them (RCCL opens its own)
+    for (int a : devices) {
+      DeviceGuard g(a);
+      for (int b : devices)
+        if (a != b) {
+          int can = 0;
+          if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(b, 0);
+        }
+      (void)hipGetLastError();  // "already enabled" is not an error worth keeping
+    }
+  return true;
+}
+
+void ShardComm::destroy_comms() {
+  if (comms.empty()) return;
+  Rccl* r = rccl();
+  for (size_t d = 0; d < comms.size(); ++d) {
+    DeviceGuard g(devices[d]);
+    (void)r->CommDestroy((ncclComm_t)comms[d]);
+  }
+  comms.clear();
+}
+
+int ShardComm::exchange(std::vector<ShardPart>& parts, hipStream_t root_stream, unsigned long long* d_dst) {
+  const size_t R = parts.size(), D = devices.size();
+  const int root = devices[0];
+  const bool collective = g_exchange == 0 && (D > 1 || g_force_rccl);
+  // per-device totals, the place of every shard inside its device's run, and of every device in the destination
+  std::vector<unsigned long long> dev_total(D, 0), shard_off(R, 0), dev_off(D, 0);
+  for (size_t s = 0; s < R; ++s) {
+    shard_off[s] = dev_total[(size_t)parts[s].dev_pos];
+    dev_total[(size_t)parts[s].dev_pos] += parts[s].count;
+  }
+  for (size_t d = 1; d < D; ++d) dev_off[d] = dev_off[d - 1] + dev_total[d - 1];
+  std::vector<size_t> first_of(D, R);  // first shard of a device: its stream carries the device's part of a collective
+  for (size_t s = R; s-- > 0;) first_of[(size_t)parts[s].dev_pos] = s;
+  int rc;
+  if (!collective) {
+    // every shard copies exactly its records to their final place on the root device
+    for (size_t s = 0; s < R; ++s) {
+      ShardPart& P = parts[s];
+      if (!P.count) continue;
+      const int dev = devices[(size_t)P.dev_pos];
+      DeviceGuard g(dev);
+      if (!g.ok) return CBH_E_NODEVICE;
+      unsigned long long* dst = d_dst + dev_off[(size_t)P.dev_pos] + shard_off[s];
+      if (dev == root) {
+        CBH_HIP(hipMemcpyAsync(dst, P.d_rec, P.count * 8, hipMemcpyDeviceToDevice, P.stream));
+        n_local_copies++;
+      } else {
+        CBH_HIP(hipMemcpyPeerAsync(dst, root, P.d_rec, dev, P.count * 8, P.stream));
+        n_peer_copies++;
+      }
+      CBH_HIP(hipEventRecord(P.ev, P.stream));
+    }
+    DeviceGuard g(root);
+    for (size_t s = 0; s < R; ++s)
+      if (parts[s].count) CBH_HIP(hipStreamWaitEvent(root_stream, parts[s].ev, 0));
+    return CBH_OK;
+  }
+  unsigned long long m = 0;
+  for (size_t d = 0; d < D; ++d) m = std::max(m, dev_total[d]);
+  const size_t words = 1 + (size_t)m;
+  std::vector<const void*> send(D, nullptr);
+  std::vector<void*> recv(D, nullptr);
+  for (size_t d = 0; d < D; ++d) {
+    const size_t f = first_of[d];
+    if (f == R) return CBH_E_INVAL;  // a device without a shard
+    ShardPart& F = parts[f];
+    DeviceGuard g(devices[d]);
+    if (!g.ok) return CBH_E_NODEVICE;
+    if ((rc = F.x[1].ensure(D * words * 8))) return rc;
+    recv[d] = F.x[1].p;
+    if (per_device == 1 && F.own_block && F.own_cap + 1 >= words) {
+      send[d] = F.own_block;  // a single shard's block is the device block as it stands: word 0 = count (written by
+      continue;               // the scan kernel), and it is at least `words` long
+    }
+    if ((rc = F.x[0].ensure(words * 8))) return rc;
+    unsigned long long* B = (unsigned long long*)F.x[0].p;
+    send[d] = B;
+    *F.h_word = dev_total[d];
+    CBH_HIP(hipMemcpyAsync(B, F.h_word, 8, hipMemcpyHostToDevice, F.stream));
+    for (size_t s = 0; s < R; ++s) {
+      ShardPart& P = parts[s];
+      if ((size_t)P.dev_pos != d || !P.count) continue;
+      CBH_HIP(hipMemcpyAsync(B + 1 + shard_off[s], P.d_rec, P.count * 8, hipMemcpyDeviceToDevice, P.stream));
+      n_local_copies++;
+      if (s != f) {
+        CBH_HIP(hipEventRecord(P.ev, P.stream));
+        CBH_HIP(hipStreamWaitEvent(F.stream, P.ev, 0));
+      }
+    }
+  }
+  {
+    std::lock_guard<std::mutex> lk(coll_mu);
+    if ((rc = ensure_comms(this))) return rc;
+    Rccl* r = rccl();
+    ncclResult_t e = r->GroupStart();
+    for (size_t d = 0; d < D && e == ncclSuccess; ++d) {
+      DeviceGuard g(devices[d]);
+      e = r->AllGather(send[d], recv[d], words, ncclUint64, (ncclComm_t)comms[d], parts[first_of[d]].stream);
+    }
+    ncclResult_t e2 = r->GroupEnd();
+    if (e == ncclSuccess) e = e2;
+    if (e != ncclSuccess) {
+      set_last_error_text((std::string("ncclAllGather: ") + r->GetErrorString(e)).c_str());
+      return CBH_E_HIP;
+    }
+    n_collectives++;
+  }
+  DeviceGuard g(root);
+  ShardPart& Rt = parts[first_of[0]];
+  const unsigned long long* G = (const unsigned long long*)Rt.x[1].p;
+  for (size_t d = 0; d < D; ++d)
+    if (dev_total[d])
+      CBH_HIP(hipMemcpyAsync(d_dst + dev_off[d], G + d * words + 1, dev_total[d] * 8, hipMemcpyDeviceToDevice, Rt.stream));
+  CBH_HIP(hipEventRecord(Rt.ev, Rt.stream));
+  CBH_HIP(hipStreamWaitEvent(root_stream, Rt.ev, 0));
+  return CBH_OK;
+}
+
 struct ShardSet {
-  std::vector<cbh_idx64*> child;  // plain single-device indexes; child[s]->device
-  std::vector<int> devices;       // distinct devices in mask order; devices[0] = root = parent->device
-  std::vector<int> dev_of;        // shard -> position in devices
-  int per_device = 1;
-  uint32_t mask = 0;
+  ShardComm comm;
+  std::vector<cbh_idx64*> child;  // plain single-device indexes; child[s]->device == comm.device_of_shard(s)
   // global slot order: segment g covers parent slots [global, global+len) = child[shard] slots [local, local+len)
   struct Seg {
     uint32_t shard;
     size_t local, global, len;
   };
   std::vector<Seg> segs;
-  // one communicator per device, created with the first exchange that needs them
-  std::mutex coll_mu;  // a communicator takes one grouped call at a time
-  std::vector<ncclComm_t> comms;
-  bool comms_tried = false;
-  // counters for tests / INTEGRATION: how the last exchanges travelled
-  std::atomic<uint64_t> n_scans{0}, n_rescans{0}, n_collectives{0}, n_peer_copies{0}, n_local_copies{0};
-
-  int ensure_comms() {  // under coll_mu
-    if (!comms.empty()) return CBH_OK;
-    if (comms_tried) return CBH_E_UNSUPPORTED;
-    comms_tried = true;
-    Rccl* r = rccl();
-    if (!r->handle || !r->why.empty()) {
-      set_last_error_text(("RCCL unavailable: " + r->why).c_str());
-      return CBH_E_UNSUPPORTED;
-    }
-    std::vector<ncclComm_t> c(devices.size());
-    ncclResult_t e = r->CommInitAll(c.data(), (int)devices.size(), devices.data());
-    if (e != ncclSuccess) {
-      set_last_error_text((std::string("ncclCommInitAll: ") + r->GetErrorString(e)).c_str());
-      return CBH_E_HIP;
-    }
-    comms.swap(c);
-    return CBH_OK;
-  }
 };
 
 void shardset_free(ShardSet* S) {
   if (!S) return;
-  if (!S->comms.empty()) {
-    Rccl* r = rccl();
-    for (size_t d = 0; d < S->comms.size(); ++d) {
-      DeviceGuard g(S->devices[d]);
-      (void)r->CommDestroy(S->comms[d]);
-    }
-  }
+  S->comm.destroy_comms();
   for (cbh_idx64* c : S->child) cbh_idx64_destroy(c);
   delete S;
 }
@@ -171,7 +288,8 @@ struct ShardLeases {
 int sharded_scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t nq, int thresh, hipStream_t stream,
                      unsigned long long* total, unsigned flags, const uint64_t* d_qmask, size_t max_records) {
   ShardSet* S = idx->shards;
-  const size_t R = S->child.size(), D = S->devices.size();
+  ShardComm& C = S->comm;
+  const size_t R = S->child.size();
   const int root = idx->device;
   *total = 0;
   // the root block must exist whatever happens (consumers read word 0)
@@ -203,7 +321,7 @@ int sharded_scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t 
       hipStream_t cs = cw->stream;
       if (attempt == 0) {
         CBH_HIP(hipStreamWaitEvent(cs, ws->ev0, 0));
-        if (c->device != root) {  // replicate the needles: one peer copy per device and call (8 B per needle)
+        if (c->device != root) {  // replicate the needles: one peer copy per shard and call (8 B per needle)
           if ((rc = Workspace::grow(&cw->d_q, &cw->q_cap, nq))) return rc;
           CBH_HIP(hipMemcpyPeerAsync(cw->d_q, c->device, d_q, root, nq * sizeof(uint64_t), cs));
           q_of[s] = cw->d_q;
@@ -212,7 +330,7 @@ int sharded_scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t 
             CBH_HIP(hipMemcpyPeerAsync(cw->d_qmask, c->device, d_qmask, root, nq * sizeof(uint64_t), cs));
             mask_of[s] = cw->d_qmask;
           }
-          S->n_peer_copies++;
+          C.n_peer_copies++;
         }
         if ((rc = cw->ensure_records(std::max<size_t>(c->rec_cap_default, 1024)))) return rc;
       }
@@ -223,8 +341,8 @@ int sharded_scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t 
       if (rc) return rc;
       CBH_HIP(hipEventRecord(cw->ev1, cs));
       CBH_HIP(hipMemcpyAsync(cw->h_total, cw->d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
-      S->n_scans++;
-      if (attempt) S->n_rescans++;
+      C.n_scans++;
+      if (attempt) C.n_rescans++;
     }
     if (!any) break;
     float worst = 0.f;
@@ -267,104 +385,24 @@ int sharded_scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t 
     rc = ws->ensure_records((size_t)sum + 1024);
     if (rc) return rc == CBH_E_NOMEM ? CBH_E_OVERFLOW : rc;
   }
-  // ---- exchange ----
-  const bool collective = (D > 1 && g_exchange == 0) || (g_force_rccl && g_exchange == 0);
-  // per-device totals and the position of every shard inside its device's run, and of every device in the result
-  std::vector<unsigned long long> dev_total(D, 0), shard_off(R, 0), dev_off(D, 0);
+  // ---- exchange: all records into the root block, shard after shard ----
+  std::vector<ShardPart> parts(R);
   for (size_t s = 0; s < R; ++s) {
-    shard_off[s] = dev_total[S->dev_of[s]];
-    dev_total[S->dev_of[s]] += count[s];
+    Workspace* cw = L.ws[s];
+    parts[s].dev_pos = C.dev_pos_of_shard(s);
+    parts[s].stream = cw->stream;
+    parts[s].d_rec = reinterpret_cast<const unsigned long long*>(cw->d_rec);
+    parts[s].count = count[s];
+    parts[s].own_block = cw->d_total;  // { count, records[rec_cap] }
+    parts[s].own_cap = cw->rec_cap;
+    parts[s].ev = cw->ev1;
+    parts[s].x = cw->x;
+    parts[s].h_word = cw->h_total;
   }
-  for (size_t d = 1; d < D; ++d) dev_off[d] = dev_off[d - 1] + dev_total[d - 1];
-  std::vector<size_t> first_of(D, R);  // first shard of a device: its stream carries the device's part of the exchange
-  for (size_t s = R; s-- > 0;) first_of[S->dev_of[s]] = s;
-  *ws->h_total = sum;
-  if (!collective) {
-    // every shard copies exactly its records to their final place in the root block
-    for (size_t s = 0; s < R; ++s) {
-      if (!count[s]) continue;
-      cbh_idx64* c = S->child[s];
-      Workspace* cw = L.ws[s];
-      DeviceGuard g(c->device);
-      cbh_record* dst = ws->d_rec + dev_off[S->dev_of[s]] + shard_off[s];
-      if (c->device == root) {
-        CBH_HIP(hipMemcpyAsync(dst, cw->d_rec, count[s] * sizeof(cbh_record), hipMemcpyDeviceToDevice, cw->stream));
-        S->n_local_copies++;
-      } else {
-        CBH_HIP(hipMemcpyPeerAsync(dst, root, cw->d_rec, c->device, count[s] * sizeof(cbh_record), cw->stream));
-        S->n_peer_copies++;
-      }
-      CBH_HIP(hipEventRecord(cw->ev1, cw->stream));
-    }
-    DeviceGuard g(root);
-    for (size_t s = 0; s < R; ++s)
-      if (count[s]) CBH_HIP(hipStreamWaitEvent(stream, L.ws[s]->ev1, 0));
-  } else {
-    // level 1: a device's shards concatenate into ONE block B_d = { count_d, records } (a single shard's own block
-    // already is one); level 2: one grouped all-gather of the B_d, sized to the fullest device; level 3: the root
-    // compacts the D gathered blocks into its workspace block
-    unsigned long long m = 0;
-    for (size_t d = 0; d < D; ++d) m = std::max(m, dev_total[d]);
-    const size_t words = 1 + (size_t)m;
-    std::vector<const void*> send(D, nullptr);
-    std::vector<void*> recv(D, nullptr);
-    for (size_t d = 0; d < D; ++d) {
-      const size_t f = first_of[d];
-      Workspace* fw = L.ws[f];
-      DeviceGuard g(S->devices[d]);
-      if (!g.ok) return CBH_E_NODEVICE;
-      if ((rc = fw->ensure_x(1, D * words * sizeof(cbh_record)))) return rc;
-      recv[d] = fw->d_x[1];
-      if (S->per_device == 1 && fw->rec_cap + 1 >= words) {
-        send[d] = fw->d_total;  // a single shard's block is the device block as it stands: word 0 = count (written by
-        continue;               // the scan kernel), and it is at least `words` long
-      }
-      if ((rc = fw->ensure_x(0, words * sizeof(cbh_record)))) return rc;
-      unsigned long long* B = (unsigned long long*)fw->d_x[0];
-      send[d] = B;
-      *fw->h_total = dev_total[d];
-      CBH_HIP(hipMemcpyAsync(B, fw->h_total, sizeof(unsigned long long), hipMemcpyHostToDevice, fw->stream));
-      for (size_t s = 0; s < R; ++s) {
-        if ((size_t)S->dev_of[s] != d || !count[s]) continue;
-        Workspace* cw = L.ws[s];
-        CBH_HIP(hipMemcpyAsync(B + 1 + shard_off[s], cw->d_rec, count[s] * sizeof(cbh_record), hipMemcpyDeviceToDevice,
-                               cw->stream));
-        S->n_local_copies++;
-        if (s != f) {
-          CBH_HIP(hipEventRecord(cw->ev1, cw->stream));
-          CBH_HIP(hipStreamWaitEvent(fw->stream, cw->ev1, 0));
-        }
-      }
-    }
-    {
-      std::lock_guard<std::mutex> lk(S->coll_mu);
-      if ((rc = S->ensure_comms())) return rc;
-      Rccl* r = rccl();
-      ncclResult_t e = r->GroupStart();
-      for (size_t d = 0; d < D && e == ncclSuccess; ++d) {
-        DeviceGuard g(S->devices[d]);
-        e = r->AllGather(send[d], recv[d], words, ncclUint64, S->comms[d], L.ws[first_of[d]]->stream);
-      }
-      ncclResult_t e2 = r->GroupEnd();
-      if (e == ncclSuccess) e = e2;
-      if (e != ncclSuccess) {
-        set_last_error_text((std::string("ncclAllGather: ") + r->GetErrorString(e)).c_str());
-        return CBH_E_HIP;
-      }
-      S->n_collectives++;
-    }
-    DeviceGuard g(root);
-    Workspace* rw = L.ws[first_of[0]];
-    const unsigned long long* G = (const unsigned long long*)rw->d_x[1];
-    for (size_t d = 0; d < D; ++d)
-      if (dev_total[d])
-        CBH_HIP(hipMemcpyAsync(ws->d_rec + dev_off[d], G + d * words + 1, dev_total[d] * sizeof(cbh_record),
-                               hipMemcpyDeviceToDevice, rw->stream));
-    CBH_HIP(hipEventRecord(rw->ev1, rw->stream));
-    CBH_HIP(hipStreamWaitEvent(stream, rw->ev1, 0));
-  }
+  if ((rc = C.exchange(parts, stream, reinterpret_cast<unsigned long long*>(ws->d_rec)))) return rc;
   {
     DeviceGuard g(root);
+    *ws->h_total = sum;
     CBH_HIP(hipMemcpyAsync(ws->d_total, ws->h_total, sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
     CBH_HIP(hipStreamSynchronize(stream));  // scan_all's contract: the block is complete on return
   }
@@ -461,56 +499,33 @@ int sharded_remove(cbh_idx64* idx, const uint32_t* ids, size_t n, int zero_hash)
 extern "C" {
 
 cbh_idx64* cbh_idx64_create_sharded(uint32_t device_mask, int shards_per_device) {
-  if (device_mask == 0 || shards_per_device < 0 || shards_per_device > 64) return nullptr;
-  const int per = std::max(1, shards_per_device);
-  std::vector<int> devs;
-  for (int d = 0; d < 32; ++d)
-    if (device_mask & (1u << d)) {
-      if (!device_usable(d)) return nullptr;  // a device of the mask is not there: no silent narrowing
-      devs.push_back(d);
-    }
   cbh_idx64* idx = new (std::nothrow) cbh_idx64;
   ShardSet* S = new (std::nothrow) ShardSet;
-  if (!idx || !S) {
+  if (!idx || !S || !S->comm.init(device_mask, shards_per_device)) {
     delete idx;
     delete S;
     return nullptr;
   }
-  idx->device = devs[0];
+  idx->device = S->comm.devices[0];
   idx->shards = S;
-  S->devices = devs;
-  S->per_device = per;
-  S->mask = device_mask;
-  for (size_t d = 0; d < devs.size(); ++d)
-    for (int k = 0; k < per; ++k) {
-      cbh_idx64* c = cbh_idx64_create(devs[d]);
-      if (!c) {
-        cbh_idx64_destroy(idx);
-        return nullptr;
-      }
-      S->child.push_back(c);
-      S->dev_of.push_back((int)d);
+  const size_t R = S->comm.shard_count();
+  for (size_t s = 0; s < R; ++s) {
+    cbh_idx64* c = cbh_idx64_create(S->comm.device_of_shard(s));
+    if (!c) {
+      cbh_idx64_destroy(idx);
+      return nullptr;
     }
-  const size_t R = S->child.size();
-  for (cbh_idx64* c : S->child) c->rec_cap_default = std::max<size_t>(65536, idx->rec_cap_default / R);
-  if (devs.size() > 1)  // direct xGMI copies where the platform allows them (RCCL opens its own)
-    for (int a : devs) {
-      DeviceGuard g(a);
-      for (int b : devs)
-        if (a != b) {
-          int can = 0;
-          if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(b, 0);
-        }
-      (void)hipGetLastError();  // "already enabled" is not an error worth keeping
-    }
+    c->rec_cap_default = std::max<size_t>(65536, idx->rec_cap_default / R);
+    S->child.push_back(c);
+  }
   return idx;
 }
 
 uint32_t cbh_idx64_device_mask(const cbh_idx64* idx) {
-  return !idx ? 0 : idx->shards ? idx->shards->mask : (1u << idx->device);
+  return !idx ? 0 : idx->shards ? idx->shards->comm.mask : (1u << idx->device);
 }
 
-int cbh_idx64_shards_per_device(const cbh_idx64* idx) { return !idx ? 0 : idx->shards ? idx->shards->per_device : 1; }
+int cbh_idx64_shards_per_device(const cbh_idx64* idx) { return !idx ? 0 : idx->shards ? idx->shards->comm.per_device : 1; }
 
 int cbh_idx64_shard_count(const cbh_idx64* idx) { return !idx ? 0 : idx->shards ? (int)idx->shards->child.size() : 1; }
 
@@ -530,13 +545,13 @@ int cbh_idx64_shard_stats(const cbh_idx64* idx, cbh_shard_stats* out) {
   }
   const ShardSet* S = idx->shards;
   out->shards = (uint32_t)S->child.size();
-  out->devices = (uint32_t)S->devices.size();
-  out->device_mask = S->mask;
-  out->scans = S->n_scans.load();
-  out->rescans = S->n_rescans.load();
-  out->collectives = S->n_collectives.load();
-  out->peer_copies = S->n_peer_copies.load();
-  out->local_copies = S->n_local_copies.load();
+  out->devices = (uint32_t)S->comm.devices.size();
+  out->device_mask = S->comm.mask;
+  out->scans = S->comm.n_scans.load();
+  out->rescans = S->comm.n_rescans.load();
+  out->collectives = S->comm.n_collectives.load();
+  out->peer_copies = S->comm.n_peer_copies.load();
+  out->local_copies = S->comm.n_local_copies.load();
   out->segments = S->segs.size();
   return CBH_OK;
 }

@@ -223,7 +223,7 @@ int reduce_on_device(cbh_vidx* v, const std::vector<uint64_t>& q, const std::vec
                                d_nid, filter_self, min_matched, min_near, &flat, s);
   }
   for (void* p : {scratch, (void*)d_qneedle, (void*)d_qframe, (void*)d_nid})
-    if (p) (void)hipFreeAsync(p, s);
+    if (p) (void)cbh::free_async(p, s);
   CBH_HIP(e);
   if (rc) return rc;
   std::sort(flat.begin(), flat.end(), [](const cbh_nvmatch& a, const cbh_nvmatch& b) {

@@ -16,13 +16,19 @@ from .index import Match, SearchParams
 class CvFeaturesIndex:
     KNN = 10  # `_index->knnSearch(descriptors, ..., 10)` (cvfeaturesindex.cpp:497)
 
-    def __init__(self, device: int = 0) -> None:
+    def __init__(self, device: int = 0, shards=None) -> None:
+        """shards = (device_mask, shards_per_device): one index sharded by image over several GPUs / logical shards in
+        this process (cbh_idx256_create_sharded); None = one device (or the process default, _lib.default_sharding)"""
         self._L = _lib.lib()
         self._device = device
         self._id = SearchParams.AlgoCVFeatures
-        self._h = self._L.cbh_idx256_create(device)
+        shards = shards if shards is not None else _lib.default_sharding()
+        self._h = self._L.cbh_idx256_create_sharded(shards[0], shards[1]) if shards else self._L.cbh_idx256_create(device)
         if not self._h:
             raise CbhError(_lib.CBH_E_NODEVICE, "cbh_idx256_create")
+
+    def shard_rows(self) -> list:
+        return [int(self._L.cbh_idx256_shard_rows(self._h, i)) for i in range(self._L.cbh_idx256_shard_count(self._h))]
 
     def __del__(self) -> None:
         h, self._h = getattr(self, "_h", None), None

@@ -68,11 +68,12 @@ int cbh_version(void);
 int cbh_device_count(void);             /* number of usable gfx950 devices, 0 if none */
 const char* cbh_strerror(int code);     /* static string */
 const char* cbh_last_error(void);       /* thread-local detail of the last CBH_E_HIP */
-/* Scratch memory.  Kernel scratch comes from stream-ordered pools that keep up to "pool_keep_mb" (default 1024) of
- * freed blocks mapped so that the next call finds its buffers in place.  cbh_trim synchronises `device` and returns
- * every free block of every pool of the library (and of the device's default pool) to the driver; *released_bytes
- * (optional) = what that gave back.  Pools of caller-owned streams that no longer exist are dropped on the way (they
- * are also dropped, and reused, whenever more than 32 streams have pools).  Safe to call at any time between calls. */
+/* Scratch memory.  Kernel scratch comes from the library's own stream-ordered arena: hipMalloc'ed blocks cached per
+ * (device, stream) -- a freed block is reused only by the stream that freed it -- keeping up to "pool_keep_mb"
+ * (default 1024) per stream so that the next call finds its buffers in place.  cbh_trim synchronises `device` and
+ * returns every cached block to the driver; *released_bytes (optional) = what that gave back.  Caches of caller-owned
+ * streams that no longer exist are dropped on the way (they are also dropped, their blocks reused, whenever more than
+ * 32 streams have caches).  Safe to call at any time between calls. */
 int cbh_trim(int device, unsigned long long* released_bytes);
 
 /* ---- hash build: replaces dctHash64(const cv::Mat&, bool) -- src/cvutil.cpp:435-545,
@@ -527,6 +528,16 @@ int cbh_template_hashes_dev(const void* d_cands, size_t n, int w, int h, size_t 
  * map (_indexMap/_idMap, :77-81).  Searches are exact brute force (the reference asks a FLANN LSH index,
  * :497, which returns a subset). */
 cbh_idx256* cbh_idx256_create(int device);
+/* ONE CvFeaturesIndex over several GPUs / logical shards in one process (as cbh_idx64_create_sharded): sharded BY IMAGE
+ * -- a media's descriptor rows stay together (runs of 16384 rows per shard in add order), the first-row -> mediaId maps
+ * stay with the handle in global row numbers, every search scans all shards on their own devices and streams, rewrites
+ * the shard-local rows of the records to global ones and merges them on the first device of the mask (device-to-device
+ * copies inside a device, one grouped ncclAllGather between devices).  Every other cbh_idx256_* call accepts the handle
+ * and returns what the one-device index returns, bit for bit (the knn tie-break is (distance, global row)). */
+cbh_idx256* cbh_idx256_create_sharded(uint32_t device_mask, int shards_per_device);
+int cbh_idx256_shard_count(const cbh_idx256*);
+size_t cbh_idx256_shard_rows(const cbh_idx256*, int i); /* rows held by shard i */
+int cbh_idx256_shard_stats(const cbh_idx256*, cbh_shard_stats* out);
 void cbh_idx256_destroy(cbh_idx256*);
 /* add() (:122-150): append one media's rows; n_rows == 0 is skipped ("no descriptors for ...").
  * load() is add() per row of `select media_id,... from matrix`. */
@@ -613,8 +624,9 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *   "kp_lds_side"   largest keypoint square k_kp_hashes stages in LDS (default 134; larger: global-memory routine)
  *   "kp_blur_side"  largest keypoint square whose blurred copy also stays in LDS (default 112)
  *   "color_pk"      1 = packed-f32 colour distance kernel (default 1)
- *   "pool_per_stream" 1 = scratch from one memory pool per (device, stream) (default), 0 = the device's default pool
- *   "pool_keep_mb"  freed scratch a pool keeps mapped across synchronisations, in MB (default 1024; < 0: everything)
+ *   "scratch_alloc" 2 = scratch from the library's arena (default); 1 = one ROCm hipMemPool_t per stream, 0 = ROCm's
+ *                   default pool (hipMallocAsync) -- both measured unsafe on this stack, kept for the A/B soak only
+ *   "pool_keep_mb"  freed scratch kept cached per stream, in MB (default 1024; < 0: everything)
  *   "shard_force_rccl" 1 = a sharded index on ONE device still sends its blocks through ncclAllGather (one rank): the
  *                   transport test of a one-GPU box (default 0)
  *   "shard_exchange" 0 = ncclAllGather between devices (default), 1 = hipMemcpyPeerAsync into the root block */

@@ -13,6 +13,7 @@ import threading
 import numpy as np
 import pytest
 
+import test_cvfeatures as TC
 import test_database as TD
 import test_fdct as TF
 import test_gpu_hamm as TH
@@ -56,7 +57,10 @@ test_video_find_video_and_frame = TV.test_gpu_find_video_and_frame_vs_oracle
 test_video_batch_remove_add = TV.test_gpu_video_batch_remove_add
 test_video_radix_compatible = TV.test_gpu_radix_compatible_mode_equals_bucket_search
 test_similar_behind_the_c_abi = TD.test_similar_behind_the_c_abi_equals_the_oracle
+test_cvfeatures_knn_and_find = TC.test_gpu_knn_and_find_vs_oracle
+test_cvfeatures_radius_match = TC.test_gpu_radius_match_vs_oracle
 vorc = TV.vorc
+cvo = TC.cvo
 
 
 # ---- what only a sharded handle has ---------------------------------------------------------------------------------
@@ -196,3 +200,39 @@ def test_sharded_slice_is_sharded_and_video_index_takes_the_shape(gpu, sharded):
     # unusable masks are refused outright (no silent narrowing to the devices that exist)
     assert L.cbh_idx64_create_sharded(0, 1) is None
     assert L.cbh_idx64_create_sharded(1 << 30, 1) is None
+
+
+def test_cvfeatures_index_sharded_by_image(gpu, sharded):
+    """cbh_idx256_create_sharded: media stay whole on one shard, runs of 16384 rows; rows_of / download_rows speak
+    global row numbers; the knn table (rows, distances, counts) equals the one-device index's"""
+    from cbird_amd import _lib
+
+    R = {"shards5": 5, "rccl3": 3, "shards2x": 2}[sharded]
+    rng = np.random.default_rng(11)
+    n_media, per = 160, 700  # 112000 rows: several runs per shard
+    rows = rng.integers(0, 256, (n_media * per, 32), dtype=np.uint8)
+    rows[per * 3 + 5] = rows[per * 90 + 7]  # equal rows on different shards: the (distance, global row) tie-break
+    from cbird_amd.cvfeatures import CvFeaturesIndex
+    sh = CvFeaturesIndex()
+    _lib.set_default_sharding(None)
+    one = CvFeaturesIndex()
+    L = _lib.lib()
+    for i in range(n_media):
+        blk = np.ascontiguousarray(rows[i * per:(i + 1) * per])
+        for ix in (sh, one):
+            _lib.check(L.cbh_idx256_add(ix._h, i + 1, blk.ctypes.data, per), "add")
+    assert L.cbh_idx256_shard_count(sh._h) == R and sh.count() == one.count() == n_media * per
+    sr = sh.shard_rows()
+    assert sum(sr) == n_media * per and all(x % per == 0 for x in sr) and min(sr) > 0
+    got = np.zeros((per * 3, 32), np.uint8)
+    _lib.check(L.cbh_idx256_download_rows(sh._h, per * 22 + 13, per * 3, got.ctypes.data), "download")
+    assert (got == rows[per * 22 + 13: per * 25 + 13]).all()
+    q = rows[rng.integers(0, len(rows), 600)].copy()
+    q[::3, 5] ^= 0x11
+    a = sh.knn(q, 10, 30)
+    b = one.knn(q, 10, 30)
+    for x, y in zip(a, b):
+        assert (np.asarray(x) == np.asarray(y)).all()
+    st = _lib.cbh_shard_stats()
+    _lib.check(L.cbh_idx256_shard_stats(sh._h, C.byref(st)), "stats")
+    assert st.shards == R and st.scans >= R and (st.collectives >= 1) == (sharded == "rccl3")

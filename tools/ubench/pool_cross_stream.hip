@@ -11,6 +11,7 @@
 //   pool 0  the device's default pool (what plain hipMallocAsync uses)
 //   pool 1  ... with ReleaseThreshold = UINT64_MAX (what the library set on it: keep_pool_memory)
 //   pool 2  one explicit pool per stream (the round-2 workaround)
+//   pool 3  control: no allocator, one hipMalloc'ed buffer per stream
 // Build: hipcc --offload-arch=gfx950 -O2 -pthread -o pool_cross_stream pool_cross_stream.hip
 // Run:   pool_cross_stream [streams=4] [iterations=4000] [host threads: 0 = one for all, 1 = one per stream]
 #include <hip/hip_runtime.h>
@@ -56,6 +57,7 @@ struct Ctx {
   unsigned long long* d_err;
   uint32_t* d_bad;
   unsigned* d_sink;
+  std::vector<uint32_t*> fixed;
 };
 
 static void one_alloc_cycle(Ctx& c, int s, int it, uint32_t& rng) {
@@ -66,7 +68,9 @@ static void one_alloc_cycle(Ctx& c, int s, int it, uint32_t& rng) {
   const uint32_t tag = ((uint32_t)s << 24) | ((uint32_t)it & 0xffffff);
   uint32_t* p = nullptr;
   hipStream_t st = c.streams[s];
-  if (c.pool_mode == 2)
+  if (c.pool_mode == 3)
+    p = c.fixed[s];  // control: no allocator at all, one hipMalloc'ed buffer per stream (validates this harness)
+  else if (c.pool_mode == 2)
     CK(hipMallocFromPoolAsync((void**)&p, bytes, c.pools[s], st));
   else
     CK(hipMallocAsync((void**)&p, bytes, st));
@@ -74,7 +78,8 @@ static void one_alloc_cycle(Ctx& c, int s, int it, uint32_t& rng) {
   hipLaunchKernelGGL(k_fill, dim3(grid), dim3(256), 0, st, p, n, tag);
   hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st, (long long)(5000 + (rng >> 8) % 5000), c.d_sink);  // 100 MHz clock
   hipLaunchKernelGGL(k_verify, dim3(grid), dim3(256), 0, st, p, n, tag, c.d_err, c.d_bad);
-  CK(hipFreeAsync(p, st));
+  CK(hipGetLastError());
+  if (c.pool_mode != 3) CK(hipFreeAsync(p, st));
 }
 
 static unsigned long long run(int pool_mode, int S, int iters, int per_stream_threads) {
@@ -98,6 +103,9 @@ static unsigned long long run(int pool_mode, int S, int iters, int per_stream_th
       uint64_t keep = ~0ull;
       CK(hipMemPoolSetAttribute(c.pools[s], hipMemPoolAttrReleaseThreshold, &keep));
     }
+  c.fixed.assign(S, nullptr);
+  if (pool_mode == 3)
+    for (int s = 0; s < S; ++s) CK(hipMalloc(&c.fixed[s], 24 << 20));
   CK(hipMalloc(&c.d_err, 8));
   CK(hipMalloc(&c.d_bad, 8));
   CK(hipMalloc(&c.d_sink, 4));
@@ -132,6 +140,8 @@ static unsigned long long run(int pool_mode, int S, int iters, int per_stream_th
   for (int s = 0; s < S; ++s) CK(hipStreamDestroy(c.streams[s]));
   for (int s = 0; s < S; ++s)
     if (c.pools[s]) CK(hipMemPoolDestroy(c.pools[s]));
+  for (int s = 0; s < S; ++s)
+    if (c.fixed[s]) CK(hipFree(c.fixed[s]));
   CK(hipFree(c.d_err));
   CK(hipFree(c.d_bad));
   CK(hipFree(c.d_sink));
@@ -144,6 +154,6 @@ int main(int argc, char** argv) {
   const int threads = argc > 3 ? atoi(argv[3]) : 0;
   CK(hipSetDevice(0));
   unsigned long long total = 0;
-  for (int mode = 0; mode < 3; ++mode) total += run(mode, S, iters, threads);
+  for (int mode = 0; mode < 4; ++mode) total += run(mode, S, iters, threads);
   return total ? 1 : 0;
 }
