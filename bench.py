@@ -323,6 +323,15 @@ def main():
         finally:
             ops.L.cbh_set_tuning(b"scan_mfma", 1)
         result["popcount_kernel_scan_ms"] = pop
+    if world > 1:
+        # what every rank actually holds: its share of the images / index slots / descriptor rows, never another's
+        mine = {"rank": rank, "device": local_rank, "images": b - a, "image_bytes": int(imgs.numel()),
+                "index_slots": int(ops.index.count()),
+                "orb_rows": result.get("configs3_cvfeatures", {}).get("rows_this_rank"),
+                "device_bytes_allocated_by_torch": int(torch.cuda.memory_allocated(dev))}
+        parts = [None] * world
+        dist.all_gather_object(parts, mine)
+        result["per_rank_residency"] = parts
     if rank == 0 and not args.no_sharded_leg:
         result["single_process_sharded"] = sharded_leg(args, world, local_rank, share)
     if rank == 0 and world == 1 and not args.no_features:

@@ -104,8 +104,8 @@ __global__ __launch_bounds__(256) void k_select256(const unsigned long long* __r
   const size_t b = lower(((unsigned long long)qi + 1) << 41);
   const size_t cnt = b - a;
   counts[qi] = cnt > 0xffffffffull ? 0xffffffffu : (uint32_t)cnt;
-  for (int j = 0; j < k && (size_t)j < cnt; ++j) {
-    const unsigned long long r = rec[a + (size_t)j];
+  for (int j = 0; j < k; ++j) {  // places past the count are zeroed (the buffers are reused between calls)
+    const unsigned long long r = (size_t)j < cnt ? rec[a + (size_t)j] : 0ull;
     out_row[(size_t)qi * k + j] = (uint32_t)r;
     out_dist[(size_t)qi * k + j] = (uint16_t)((r >> 32) & 0x1ff);
   }

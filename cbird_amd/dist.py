@@ -351,32 +351,47 @@ class ShardedDctHashIndex:
         return results
 
 
-def _gather_rows(rows, group=None, device=None, cap0: int = 4096):
-    """All ranks' int32 row lists [n_r, w] -> one array, ranks in order.  ONE fixed-size all_gather_into_tensor with the
-    row count in word 0 of every block (the exchange pattern of ShardedDctHashIndex); a block that would not fit is
-    noticed by every rank from the gathered counts and the gather is redone with larger blocks.  `device`: torch
-    device the collective runs on (RCCL needs device tensors; gloo takes host tensors)."""
+def _gather_rows(rows, group=None, device=None, cap0: int = 4096, order_cols=None):
+    """All ranks' int32 row lists [n_r, w] -> one array, ranks in order (or ordered by the unsigned columns
+    `order_cols`, most significant first).  ONE fixed-size all_gather_into_tensor with the row count in word 0 of every
+    block (the exchange pattern of ShardedDctHashIndex); a block that would not fit is noticed by every rank from the
+    gathered counts and the gather is redone with larger blocks.  `device`: torch device the collective runs on (RCCL
+    needs device tensors; gloo takes host tensors).  With a device the block is assembled, gathered, compacted and
+    ordered THERE -- one upload of this rank's rows, one download of the final list; the host neither pads nor merges."""
     import numpy as np
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rows = np.ascontiguousarray(rows, np.int32)
     n, w = rows.shape
     if world == 1 and not _force_collectives():
+        if order_cols and n:
+            u = rows.view(np.uint32)
+            rows = rows[np.lexsort(tuple(u[:, c] for c in reversed(order_cols)))]
         return rows
+    tdev = torch.device("cpu") if device is None else device
+    mine = torch.from_numpy(rows).to(tdev, non_blocking=True).reshape(-1)
     cap = cap0  # the same on every rank; grows to the largest count seen (also the same on every rank)
     while True:
-        blk = torch.zeros(1 + cap * w, dtype=torch.int32)
+        blk = torch.zeros(1 + cap * w, dtype=torch.int32, device=tdev)
         blk[0] = n
         m = min(n, cap)
-        blk[1: 1 + m * w] = torch.from_numpy(rows[:m].reshape(-1))
-        src = blk if device is None else blk.to(device)
-        out = torch.empty((1 + cap * w) * world, dtype=torch.int32, device=src.device)
-        dist.all_gather_into_tensor(out, src, group=group)
-        o = out.cpu().numpy().reshape(world, 1 + cap * w)
+        blk[1: 1 + m * w] = mine[: m * w]
+        out = torch.empty((1 + cap * w) * world, dtype=torch.int32, device=tdev)
+        dist.all_gather_into_tensor(out, blk, group=group)
+        o = out.view(world, 1 + cap * w)
         counts = o[:, 0]
-        if int(counts.max()) <= cap:
-            return np.concatenate([o[r, 1: 1 + int(counts[r]) * w].reshape(-1, w) for r in range(world)])
-        cap = int(counts.max())  # same value on every rank
+        cmax = int(counts.max().item())  # the one host read: every rank takes the same decision
+        if cmax <= cap:
+            body = o[:, 1:].reshape(world, cap, w)
+            live = torch.arange(cap, device=tdev)[None, :] < counts[:, None]
+            allr = body[live]  # ranks in order, rows in order
+            if order_cols and allr.shape[0]:
+                key = torch.zeros(allr.shape[0], dtype=torch.int64, device=tdev)
+                for c in order_cols:  # unsigned 32-bit columns folded into one 63-bit key (two columns at most)
+                    key = (key << 32) | (allr[:, c].to(torch.int64) & 0xFFFFFFFF)
+                allr = allr[torch.argsort(key, stable=True)]
+            return allr.cpu().numpy()
+        cap = cmax  # same value on every rank
 
 
 class ShardedDctVideoIndex:
@@ -410,10 +425,11 @@ class ShardedDctVideoIndex:
         rows = np.array([(k, m.mediaId, m.score, m.range.srcIn, m.range.dstIn, m.range.len)
                          for k, r in enumerate(local) for m in r], np.int64).reshape(-1, 6)
         rows = rows.astype(np.uint32).view(np.int32) if len(rows) else np.zeros((0, 6), np.int32)
-        allr = _gather_rows(rows, self.group, self.device)
+        # gathered, compacted and ordered by (needle, mediaId) on the collective's device
+        allr = _gather_rows(rows, self.group, self.device, order_cols=(0, 1))
         out = [[] for _ in needles]
-        ids = allr[:, 1].view(np.uint32)
-        for i in np.lexsort((ids, allr[:, 0])):  # by needle, then ascending mediaId
+        ids = allr[:, 1].view(np.uint32) if len(allr) else np.zeros(0, np.uint32)
+        for i in range(len(allr)):
             r = allr[i]
             out[int(r[0])].append(Match(int(ids[i]), int(r[2]), MatchRange(int(r[3]), int(r[4]), int(r[5]))))
         return out
@@ -461,19 +477,20 @@ class ShardedCvFeaturesIndex:
             tab = np.concatenate([key.view(np.int32).reshape(nq, -1), media.view(np.int32),
                                   cnt.view(np.int32)[:, None]], 1)  # [nq, 2k + k + 1] int32, fixed size
             t = torch.from_numpy(np.ascontiguousarray(tab)).reshape(-1)
-            src = t if self.device is None else t.to(self.device)
+            src = t if self.device is None else t.to(self.device, non_blocking=True)
             out = torch.empty(self.world * t.numel(), dtype=torch.int32, device=src.device)
             dist.all_gather_into_tensor(out, src, group=self.group)
-            o = out.cpu().numpy().reshape(self.world, nq, 3 * knn + 1)
-            keys = np.ascontiguousarray(o[:, :, : 2 * knn]).view(np.int64)  # [R, nq, k]
-            medias = o[:, :, 2 * knn: 3 * knn].view(np.uint32)
-            cnts = o[:, :, 3 * knn].view(np.uint32).astype(np.int64).sum(0)
-            keys = np.moveaxis(keys, 0, 1).reshape(nq, -1)  # [nq, R*k]
-            medias = np.moveaxis(medias, 0, 1).reshape(nq, -1)
-            order = np.argsort(keys, axis=1, kind="stable")[:, :knn]
-            key = np.take_along_axis(keys, order, 1)
-            media = np.take_along_axis(medias, order, 1)
-            cnt = np.minimum(cnts, np.iinfo(np.uint32).max).astype(np.uint32)
+            # k-way merge of the R sorted candidate lists of every needle descriptor where the all-gather left them
+            # (the collective's device): one sort of [nq, R*k] keys, the first k kept; only the merged table
+            # ([nq, k] keys + mediaIds + counts) comes back to the host, which scores it
+            o = out.view(self.world, nq, 3 * knn + 1)
+            keys = o[:, :, : 2 * knn].contiguous().view(torch.int64).permute(1, 0, 2).reshape(nq, -1)  # [nq, R*k]
+            medias = o[:, :, 2 * knn: 3 * knn].permute(1, 0, 2).reshape(nq, -1)
+            cnts = (o[:, :, 3 * knn].to(torch.int64) & 0xFFFFFFFF).sum(0)
+            skey, order = torch.sort(keys, dim=1, stable=True)
+            key = skey[:, :knn].cpu().numpy()
+            media = torch.gather(medias, 1, order[:, :knn]).cpu().numpy().view(np.uint32)
+            cnt = np.minimum(cnts.cpu().numpy(), np.iinfo(np.uint32).max).astype(np.uint32)
         dst = np.where(key == np.iinfo(np.int64).max, 0, key >> 40).astype(np.uint16)
         media = np.ascontiguousarray(media, np.uint32)
         cnt = np.ascontiguousarray(np.minimum(cnt, knn), np.uint32)  # places filled in the merged table

@@ -63,3 +63,41 @@ def test_bench_two_ranks_sharing_the_gpu(gpu):
     assert r2["configs3_cvfeatures"]["matches"] == r1["configs3_cvfeatures"]["matches"] > 0
     assert r2["configs3_cvfeatures"]["needles_ranked_first_themselves"] == 64
     assert r2["configs4_video"]["matches"] == r1["configs4_video"]["matches"]
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_preflight(gpu):
+    """Pre-flight of the driver's 8-GPU run, which this pool cannot offer: `torchrun --nproc-per-node 8 bench.py --gpus
+    8` with all ranks on cuda:0 over gloo (CBH_BENCH_SHARE_GPU=1).  All three legs finish, the contract line is printed
+    once, the match counts of every threshold and of the video / ORB legs equal the N = 1 run of the same job, and no
+    rank holds another rank's data (its images, index slots and descriptor rows are exactly its shard_range share)."""
+    env = dict(os.environ, CBH_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    n, orb = 80001, 4001  # ragged on purpose: 80001 = 8 * 10000 + 1
+    args = ["--images", str(n), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-features", "--no-sharded-leg",
+            "--dht", "2,5,8", "--orb-images", str(orb), "--video-clips", "2000"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                         timeout=600, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    eight = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                            "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"),
+                            "--gpus", "8"] + args, capture_output=True, text=True, timeout=1200, env=env)
+    assert eight.returncode == 0, eight.stderr[-3000:]
+    lines = [ln for ln in eight.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 alone prints
+    r1 = json.loads([ln for ln in one.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    r8 = json.loads(lines[0])
+    assert r8["n_gpus"] == 8 and r8["scaling"] == "strong" and "configs[2]" in r8["config"]["workload"]
+    assert [s["matches"] for s in r8["dht_sweep"]] == [s["matches"] for s in r1["dht_sweep"]]
+    assert r8["configs3_cvfeatures"]["matches"] == r1["configs3_cvfeatures"]["matches"] > 0
+    assert r8["configs3_cvfeatures"]["needles_ranked_first_themselves"] == 64
+    assert r8["configs4_video"]["matches"] == r1["configs4_video"]["matches"]
+    res = r8["per_rank_residency"]
+    assert [p["rank"] for p in res] == list(range(8))
+    for p in res:
+        a, b = p["rank"] * n // 8, (p["rank"] + 1) * n // 8
+        assert p["images"] == b - a == p["index_slots"] and p["image_bytes"] == (b - a) * 256 * 256
+        oa, ob = p["rank"] * orb // 8, (p["rank"] + 1) * orb // 8
+        assert p["orb_rows"] == (ob - oa) * 500
+        # images + hashes + exchange blocks + leg scratch: nowhere near a second rank's 655 MB of images
+        assert p["device_bytes_allocated_by_torch"] < 1.6 * p["image_bytes"] + (256 << 20)
+    assert sum(p["images"] for p in res) == n and sum(p["orb_rows"] for p in res) == orb * 500
