@@ -92,6 +92,8 @@ void set_kp_lds_side(int v);    // dcthash.hip: largest keypoint square processe
 void set_hash_stream(int v);     // dcthash.hip: streaming fused kernel (0 off, 1 auto, >= 2: steps per strip)
 void set_hash_fused(int on);     // dcthash.hip: fused blur + area kernel for widths >= on (default 1 = all; 0 off)
 void set_hash_fast_any(int on);  // dcthash.hip: fast kernels for geometries other than 256x256 (default on)
+void set_cd_chains(int v);   // colordesc_create.hip: 1 = chain-per-lane kernels (default), 0 = k_cd_cluster (lane per image)
+void set_cd_group(int v);    // colordesc_create.hip: images per wave of the seeding kernel (0 = auto)
 void set_color_pk(int on);   // color.hip: packed-f32 distance kernel (default on)
 
 // ---- records.hip ----------------------------------------------------------------------

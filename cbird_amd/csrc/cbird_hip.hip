@@ -69,7 +69,7 @@ Arena& arena() {
 int g_scratch_mode = 2;
 int g_scratch_poison = 0;  // "scratch_poison": v > 0 fills every block handed out with byte v - 1 (finds kernels that
                            // read scratch they never wrote: fresh driver memory is zero, a recycled block is not)
-uint64_t g_pool_keep_bytes = (uint64_t)1 << 30;  // freed scratch kept mapped per stream (and per device for orphans)
+uint64_t g_pool_keep_bytes = (uint64_t)16 << 30;  // cached scratch that outlives its stream, per device ("pool_keep_mb")
 
 size_t round_size(size_t b) {
   if (b <= 256) return 256;
@@ -246,41 +246,20 @@ static hipError_t malloc_async_raw(void** p, size_t bytes, hipStream_t s) {
 hipError_t free_async(void* p, hipStream_t s) {
   if (!p) return hipSuccess;
   Arena& A = arena();
-  size_t over = 0;
-  int dev = 0;
   {
     std::lock_guard<std::mutex> lk(A.mu);
     auto it = A.live.find(p);
     if (it == A.live.end()) return hipFreeAsync(p, s);  // a block of modes 0 / 1
     const LiveInfo info = it->second;
-    dev = info.dev;
     A.live.erase(it);
     StreamCache& c = A.caches[{info.dev, s}];
     c.last_use = ++A.clock;
     c.free.push_back(Block{p, info.bytes});
     c.free_bytes += info.bytes;
-    over = c.free_bytes > g_pool_keep_bytes ? c.free_bytes - g_pool_keep_bytes : 0;
   }
-  if (over && hipStreamQuery(s) == hipSuccess) {  // over budget and nothing queued behind the blocks: release some
-    std::vector<void*> to_free;
-    {
-      std::lock_guard<std::mutex> lk(A.mu);
-      auto it = A.caches.find({dev, s});
-      if (it != A.caches.end()) {
-        StreamCache& c = it->second;
-        std::sort(c.free.begin(), c.free.end(), [](const Block& x, const Block& y) { return x.bytes < y.bytes; });
-        while (!c.free.empty() && c.free_bytes > g_pool_keep_bytes) {
-          to_free.push_back(c.free.back().p);
-          c.free_bytes -= c.free.back().bytes;
-          c.free.pop_back();
-          A.n_released++;
-        }
-      }
-    }
-    for (void* q : to_free) (void)hipFree(q);
-  } else {
-    (void)hipGetLastError();
-  }
+  // a live stream keeps what it has used (the next call of the same caller finds its buffers mapped: a
+               // 50 GB colour-descriptor scratch costs ~1 s to map again); it is given up when the stream goes away
+               // (stream_destroy / eviction: into the orphan list, which IS bounded) or on cbh_trim
   return hipSuccess;
 }
 
@@ -1143,6 +1122,14 @@ int cbh_set_tuning(const char* key, int value) {
   }
   if (!strcmp(key, "hash_fast_any")) {
     set_hash_fast_any(value);
+    return CBH_OK;
+  }
+  if (!strcmp(key, "color_create_group")) {
+    set_cd_group(value);
+    return CBH_OK;
+  }
+  if (!strcmp(key, "color_create_chains")) {
+    set_cd_chains(value);
     return CBH_OK;
   }
   if (!strcmp(key, "color_pk")) {

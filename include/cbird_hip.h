@@ -69,11 +69,12 @@ int cbh_device_count(void);             /* number of usable gfx950 devices, 0 if
 const char* cbh_strerror(int code);     /* static string */
 const char* cbh_last_error(void);       /* thread-local detail of the last CBH_E_HIP */
 /* Scratch memory.  Kernel scratch comes from the library's own stream-ordered arena: hipMalloc'ed blocks cached per
- * (device, stream) -- a freed block is reused only by the stream that freed it -- keeping up to "pool_keep_mb"
- * (default 1024) per stream so that the next call finds its buffers in place.  cbh_trim synchronises `device` and
- * returns every cached block to the driver; *released_bytes (optional) = what that gave back.  Caches of caller-owned
- * streams that no longer exist are dropped on the way (they are also dropped, their blocks reused, whenever more than
- * 32 streams have caches).  Safe to call at any time between calls. */
+ * (device, stream) -- a freed block is reused only by the stream that freed it, so the next call on that stream finds
+ * its buffers mapped.  A stream's cache lives as long as the stream: when the library destroys one of its own streams,
+ * or finds a caller's stream gone or idle while more than 32 streams have caches, the blocks move to a per-device
+ * list any stream may take from, of which at most "pool_keep_mb" (default 16384) stay cached.  cbh_trim synchronises
+ * `device` and returns EVERY cached block to the driver; *released_bytes (optional) = what that gave back.  Safe to
+ * call at any time between calls. */
 int cbh_trim(int device, unsigned long long* released_bytes);
 
 /* ---- hash build: replaces dctHash64(const cv::Mat&, bool) -- src/cvutil.cpp:435-545,
@@ -624,9 +625,11 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *   "kp_lds_side"   largest keypoint square k_kp_hashes stages in LDS (default 134; larger: global-memory routine)
  *   "kp_blur_side"  largest keypoint square whose blurred copy also stays in LDS (default 112)
  *   "color_pk"      1 = packed-f32 colour distance kernel (default 1)
+ *   "color_create_chains" 1 = ColorDescriptor::create's clustering as chain-per-lane kernels (default), 0 = one lane per
+ *                   image (k_cd_cluster, round 2)
  *   "scratch_alloc" 2 = scratch from the library's arena (default); 1 = one ROCm hipMemPool_t per stream, 0 = ROCm's
  *                   default pool (hipMallocAsync) -- both measured unsafe on this stack, kept for the A/B soak only
- *   "pool_keep_mb"  freed scratch kept cached per stream, in MB (default 1024; < 0: everything)
+ *   "pool_keep_mb"  cached scratch that may outlive its stream, per device, in MB (default 16384; < 0: everything)
  *   "shard_force_rccl" 1 = a sharded index on ONE device still sends its blocks through ncclAllGather (one rank): the
  *                   transport test of a one-GPU box (default 0)
  *   "shard_exchange" 0 = ncclAllGather between devices (default), 1 = hipMemcpyPeerAsync into the root block */
