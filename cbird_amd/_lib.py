@@ -45,6 +45,11 @@ class cbh_shard_stats(C.Structure):
                 ("peer_copies", C.c_uint64), ("local_copies", C.c_uint64)]
 
 
+class cbh_filter_params(C.Structure):
+    _fields_ = [("min_matches", C.c_int), ("filter_groups", C.c_int), ("filter_parent", C.c_int), ("path_mode", C.c_int),
+                ("merge_groups", C.c_int), ("expand_groups", C.c_int)]
+
+
 class cbh_vmatch(C.Structure):
     _fields_ = [("id", C.c_uint32), ("score", C.c_int32), ("src_in", C.c_int32), ("dst_in", C.c_int32),
                 ("len", C.c_int32)]
@@ -126,6 +131,15 @@ _SIGS = {
     "cbh_search_index_batch": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _sz,
                                          _vp, _vp]),
     "cbh_filter_groups": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, C.c_int, _vp, _vp, _sz, _vp, _vp]),
+    "cbh_fdct_search_index_batch": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              _vp, _sz, _vp, _vp]),
+    "cbh_vidx_search_index_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, C.c_int, _vp, _sz, _vp, _vp]),
+    "cbh_idx256_search_index_batch": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                C.c_int, _vp, _sz, _vp, _vp]),
+    "cbh_color_search_index_batch": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp, _vp]),
+    "cbh_filter_groups_ex": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp,
+                                       _vp]),
     "cbh_vdx_verify": (C.c_int, [_vp, _sz]),
     "cbh_records_topk_dev": (C.c_int, [_vp, _sz, _sz, _sz, _sz, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
     "cbh_idx64_set_record_capacity": (C.c_int, [_vp, _sz]),

@@ -186,4 +186,116 @@ int cbh_filter_groups(const uint32_t* needle_ids, const cbh_match* matches, cons
   return CBH_OK;
 }
 
+/* The whole of filterMatch (src/database.cpp:1209-1248) and filterMatches (:1250-1278) on per-needle results, host code:
+ * path / inPath (:1217-1229), filterParent (:1231-1242), the count rule (:1245), filterGroups (:1253-1272), then
+ * mergeGroups (Media::mergeGroupList, src/media.cpp:300-324) or expandGroups (:326-331), and the final order by the
+ * first member's path (:1463).  Media enter as ids with three attributes the caller derives from their paths. */
+int cbh_filter_groups_ex(const uint32_t* needle_ids, const cbh_match* matches, const uint32_t* counts, size_t nq,
+                         int max_matches, const cbh_filter_params* p, const uint32_t* ids_sorted,
+                         const uint32_t* path_rank, const uint32_t* dir_id, const uint8_t* under_prefix, size_t n_ids,
+                         uint64_t* out_first, size_t cap_groups, cbh_match* out_members, size_t cap_members,
+                         size_t* n_groups, size_t* n_members) {
+  if (!p || !n_groups || !n_members || (nq && (!needle_ids || !counts)) || (nq && max_matches && !matches) ||
+      (n_ids && (!ids_sorted || !path_rank)) || max_matches < 0 || (p->filter_parent && n_ids && !dir_id) ||
+      (p->path_mode && n_ids && !under_prefix) || p->path_mode < 0 || p->path_mode > 2 || !out_first ||
+      (cap_members && !out_members))
+    return CBH_E_INVAL;
+  *n_groups = *n_members = 0;
+  auto slot_of = [&](uint32_t id) -> long {
+    const uint32_t* q = std::lower_bound(ids_sorted, ids_sorted + n_ids, id);
+    return (q == ids_sorted + n_ids || *q != id) ? -1 : (long)(q - ids_sorted);
+  };
+  struct M {
+    uint32_t id, rank;
+    int32_t score;
+  };
+  typedef std::vector<M> Group;
+  std::vector<Group> list;
+  for (size_t j = 0; j < nq; ++j) {
+    if (counts[j] == 0) continue;  // a needle without a result is no group (:1409)
+    const long ns = slot_of(needle_ids[j]);
+    if (ns < 0) return CBH_E_INVAL;
+    Group g;
+    g.push_back(M{needle_ids[j], path_rank[ns], -1});  // the needle is a haystack Media: score -1 (media.cpp:112)
+    const bool path_on = p->path_mode != 0 && counts[j] + 1 > 1;
+    for (uint32_t t = 0; t < counts[j]; ++t) {
+      const cbh_match& m = matches[j * (size_t)max_matches + t];
+      const long ms = slot_of(m.id);
+      if (ms < 0) return CBH_E_INVAL;
+      // only results under path / not under path: `(!inPath) ^ startsWith(prefix)` keeps the match (:1226-1227)
+      if (path_on && ((p->path_mode == 2) ^ (under_prefix[ms] != 0)) == 0) continue;
+      g.push_back(M{m.id, path_rank[ms], m.score});
+    }
+    if (p->filter_parent && g.size() > 1) {  // remove a match in the needle's directory / zip (:1232-1241)
+      const uint32_t parent = dir_id[ns];
+      Group kept;
+      kept.push_back(g[0]);
+      for (size_t i = 1; i < g.size(); ++i)
+        if (dir_id[slot_of(g[i].id)] != parent) kept.push_back(g[i]);
+      g.swap(kept);
+    }
+    if ((long long)g.size() > (long long)p->min_matches) list.push_back(std::move(g));  // (:1245)
+  }
+  auto by_first_path = [](const Group& a, const Group& b) {
+    if (a.empty()) return true;  // Media::sortGroupList's comparator (media.cpp:336-341)
+    if (b.empty()) return false;
+    return a[0].rank < b[0].rank;
+  };
+  if (p->filter_groups) {
+    std::stable_sort(list.begin(), list.end(), by_first_path);
+    std::set<std::vector<uint32_t>> seen;
+    std::vector<Group> filtered;
+    for (Group& g : list) {
+      std::vector<uint32_t> key;
+      for (const M& m : g) key.push_back(m.rank);
+      std::sort(key.begin(), key.end());
+      if (seen.insert(std::move(key)).second) filtered.push_back(std::move(g));
+    }
+    list.swap(filtered);
+  }
+  if (p->merge_groups) {
+    // merge 1-connected matches: if a contains b's first member, b's other members join a and b is emptied; a is then
+    // ordered by score (std::sort on Media::operator<; equal scores: by path here)
+    auto contains = [](const Group& g, uint32_t id) {
+      for (const M& m : g)
+        if (m.id == id) return true;
+      return false;
+    };
+    for (size_t i = 0; i < list.size(); ++i)
+      for (size_t j = 0; j < list.size(); ++j) {
+        if (i == j) continue;
+        Group& a = list[i];
+        Group& b = list[j];
+        if (!b.empty() && contains(a, b[0].id)) {
+          for (size_t k = 1; k < b.size(); ++k)
+            if (!contains(a, b[k].id)) a.push_back(b[k]);
+          b.clear();
+          std::sort(a.begin(), a.end(), [](const M& x, const M& y) { return x.score != y.score ? x.score < y.score : x.rank < y.rank; });
+        }
+      }
+    std::vector<Group> fin;
+    for (Group& g : list)
+      if (!g.empty()) fin.push_back(std::move(g));
+    list.swap(fin);
+  } else if (p->expand_groups) {
+    std::vector<Group> ex;
+    for (const Group& g : list)
+      for (size_t i = 1; i < g.size(); ++i) ex.push_back(Group{g[0], g[i]});
+    list.swap(ex);
+  }
+  std::stable_sort(list.begin(), list.end(), by_first_path);  // Media::sortGroupList(list, {"path"}) (:1463)
+  size_t members = 0;
+  for (const Group& g : list) members += g.size();
+  *n_groups = list.size();
+  *n_members = members;
+  if (list.size() > cap_groups || members > cap_members) return CBH_E_OVERFLOW;
+  size_t pos = 0;
+  for (size_t gi = 0; gi < list.size(); ++gi) {
+    out_first[gi] = pos;
+    for (const M& m : list[gi]) out_members[pos++] = cbh_match{m.id, m.score};
+  }
+  out_first[list.size()] = pos;  // (out_first has cap_groups + 1 entries)
+  return CBH_OK;
+}
+
 }  // extern "C"

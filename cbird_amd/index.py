@@ -76,6 +76,13 @@ class SearchParams:
     maxThresh: int = 0
     filterSelf: bool = True
     verbose: bool = False
+    # what Database::filterMatch / filterMatches read (src/index.h:97-119, defaults identical)
+    path: str = ""            # subdirectory to accept / reject results from
+    inPath: bool = False      # True = accept results from it, False = reject results from it
+    filterGroups: bool = True
+    filterParent: bool = False
+    expandGroups: bool = False
+    mergeGroups: int = 0
 
 
 def _as_u64(a) -> np.ndarray:

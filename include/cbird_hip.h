@@ -395,6 +395,59 @@ int cbh_filter_groups(const uint32_t* needle_ids, const cbh_match* matches, cons
                       int max_matches, int min_matches, int filter_groups, const uint32_t* ids_sorted,
                       const uint32_t* path_rank, size_t n_ids, uint32_t* out_group, size_t* n_out);
 
+/* searchIndex for a needle batch over the other four indexes (cbird_amd/csrc/searchbatch.hip): per threshold level ONE
+ * batched find of every needle still pending (the *_find_batch entry points below), needles with <= min_matches results
+ * go on to the next level -- dctThresh + 1 for dct features and video, cvThresh + 5 for ORB, no levels for colour
+ * (:1707-1718) -- while it does not pass max_thresh (max_thresh 0: no escalation); then (score, mediaId) order,
+ * filter_self, the max_matches cut and the idMap rule as above.  out[j*max_matches ..], out_counts[j].  Needle data as
+ * in the corresponding *_find_batch call. */
+int cbh_fdct_search_index_batch(cbh_idx64*, const uint64_t* hashes, const uint64_t* offsets, const uint32_t* needle_ids,
+                                size_t n_needles, int thresh, int max_thresh, int tree_compat, int min_matches,
+                                int max_matches, int filter_self, const uint32_t* valid_ids_sorted, size_t n_valid,
+                                cbh_match* out, uint32_t* out_counts);
+struct cbh_vidx;
+struct cbh_vmatch;
+int cbh_vidx_search_index_batch(struct cbh_vidx*, const int32_t* frames, const uint64_t* hashes, const uint64_t* offsets,
+                                const uint32_t* needle_ids, size_t n_needles, int thresh, int max_thresh, int skip_frames,
+                                int min_frames_matched, int min_frames_near, int min_matches, int max_matches,
+                                int filter_self, const uint32_t* valid_ids_sorted, size_t n_valid, struct cbh_vmatch* out,
+                                uint32_t* out_counts);
+int cbh_idx256_search_index_batch(cbh_idx256*, const uint8_t* rows, const uint64_t* offsets, const uint32_t* needle_ids,
+                                  size_t n_needles, int thresh, int max_thresh, int k, int min_matches, int max_matches,
+                                  int filter_self, const uint32_t* valid_ids_sorted, size_t n_valid, cbh_match* out,
+                                  uint32_t* out_counts);
+struct cbh_color;
+int cbh_color_search_index_batch(struct cbh_color*, const void* needle_descs, const uint32_t* needle_ids, size_t n_needles,
+                                 int max_matches, int filter_self, const uint32_t* valid_ids_sorted, size_t n_valid,
+                                 cbh_match* out, uint32_t* out_counts);
+
+/* All of filterMatch (src/database.cpp:1209-1248) and filterMatches (:1250-1278) on those results, host code:
+ *   path_mode      params.path / inPath (:1217-1229): 0 = no path filter, 1 = keep only matches under the prefix
+ *                  (inPath), 2 = keep only matches NOT under it; the needle always stays
+ *   filter_parent  a match in the needle's directory -- or zip archive, Media::dirPath (src/media.cpp:198-208) -- is
+ *                  removed (:1231-1242)
+ *   min_matches    a group needs more than min_matches members, needle included, AFTER those removals (:1245)
+ *   filter_groups  groups in needle-path order, a group whose set of paths was seen before is dropped (:1253-1272)
+ *   merge_groups   Media::mergeGroupList (src/media.cpp:300-324): if group a contains the first member of group b, b's
+ *                  other members join a, a is re-ordered by score (ties: by path) and b disappears
+ *   expand_groups  (when not merging) Media::expandGroupList (:326-331): a,b,c,d becomes (a,b), (a,c), (a,d)
+ * and the final stable order by the first member's path (:1463).  negativeMatch and the weed marks need other tables of
+ * the database and stay with the caller.  Media enter as ids with three attributes the caller derives from their paths,
+ * parallel to ids_sorted: path_rank (position of the path among all sorted paths), dir_id (equal numbers <=> equal
+ * dirPath(); may be NULL without filter_parent), under_prefix (path.startsWith(prefix) as :1223-1227 builds the prefix;
+ * may be NULL with path_mode 0).
+ * Output: group g = out_members[out_first[g] .. out_first[g+1]) as (mediaId, score), the needle first with score -1 (a
+ * haystack Media's default, src/media.cpp:112) unless a merge re-ordered the group.  CBH_E_OVERFLOW with *n_groups /
+ * *n_members = the room needed when cap_groups (+1 entries in out_first) or cap_members is too small. */
+typedef struct cbh_filter_params {
+  int min_matches, filter_groups, filter_parent, path_mode, merge_groups, expand_groups;
+} cbh_filter_params;
+int cbh_filter_groups_ex(const uint32_t* needle_ids, const cbh_match* matches, const uint32_t* counts, size_t nq,
+                         int max_matches, const cbh_filter_params* p, const uint32_t* ids_sorted,
+                         const uint32_t* path_rank, const uint32_t* dir_id, const uint8_t* under_prefix, size_t n_ids,
+                         uint64_t* out_first, size_t cap_groups, cbh_match* out_members, size_t cap_members,
+                         size_t* n_groups, size_t* n_members);
+
 /* ---- DctFeaturesIndex: src/dctfeaturesindex.{h,cpp} over src/tree/hammingtree.h -----------------
  * The index is a cbh_idx64 whose entries are (mediaId, keypoint hash) pairs, several per media:
  *   load/add      -> cbh_idx64_load / cbh_idx64_add with one entry per hash (:229-238, :143-156)

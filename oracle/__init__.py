@@ -286,6 +286,30 @@ class Oracle:
         return [(int(on[k]), list(zip(oi[int(of[k]):int(of[k + 1])].tolist(), os_[int(of[k]):int(of[k + 1])].tolist())))
                 for k in range(g)]
 
+    def filter_groups_paths(self, paths, groups, db_path, param_path, in_path, filter_parent, min_matches,
+                            filter_groups, merge_groups, expand_groups):
+        """oracle/search_index.c orc_filter_groups_paths: filterMatch + filterMatches on path strings.  groups = lists
+        of (index into paths, score), the needle first.  Returns the surviving groups in the same form."""
+        bp = [p.encode() for p in paths]
+        arr = (C.c_char_p * len(bp))(*bp)
+        first = np.zeros(len(groups) + 1, np.uint64)
+        np.cumsum([len(g) for g in groups], out=first[1:])
+        mem = np.array([m for g in groups for m, _ in g], np.int32)
+        sc = np.array([s for g in groups for _, s in g], np.int32)
+        cap_m = max(1, 2 * len(mem) * (4 if expand_groups else 1))
+        cap_g = max(1, len(mem))
+        of, om, os_ = np.zeros(cap_g + 1, np.uint64), np.zeros(cap_m, np.int32), np.zeros(cap_m, np.int32)
+        f = self.L.orc_filter_groups_paths
+        f.argtypes = [C.POINTER(C.c_char_p), _u64p, _i32p, _i32p, C.c_size_t, C.c_char_p, C.c_char_p] + [C.c_int] * 6 + \
+                     [_u64p, _i32p, _i32p, C.c_size_t, C.c_size_t]
+        f.restype = C.c_longlong
+        n = f(arr, first, mem if len(mem) else np.zeros(1, np.int32), sc if len(sc) else np.zeros(1, np.int32),
+              len(groups), db_path.encode(), param_path.encode(), int(in_path), int(filter_parent), int(min_matches),
+              int(filter_groups), int(merge_groups), int(expand_groups), of, om, os_, cap_g, cap_m)
+        if n < 0:
+            raise ValueError("orc_filter_groups_paths: capacity")
+        return [[(int(om[t]), int(os_[t])) for t in range(int(of[g]), int(of[g + 1]))] for g in range(n)]
+
     def dcthash64(self, img) -> int:
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape

@@ -25,6 +25,7 @@
  * hold entries whose id is not in the haystack (stale index) -- they are skipped like :1755.
  */
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -187,4 +188,244 @@ long long orc_similar_dct(const uint64_t* hay_hash, const uint32_t* hay_id, cons
   free(sid);
   free(spos);
   return out_g;
+}
+
+/* ---- filterMatch / filterMatches on path STRINGS (src/database.cpp:1209-1278, src/media.cpp:198-208, 300-331,
+ * 1039-1043, 1083-1099): a third statement beside the C-ABI's id/attribute form (cbh_filter_groups_ex) and
+ * cbird_amd/database.py, working on what the reference works on.  Test infrastructure.
+ *
+ * Groups enter flattened: group g = members[first[g] .. first[g+1]), member = index into paths[] (the needle first),
+ * scores beside them (the needle's is -1).  Groups leave the same way.  Returns the number of groups, -1 = capacity. */
+static const char* const kZipMarkers[20] = {".zip:", ".ZIP:", ".cbz:", ".CBZ:", ".epub:", ".EPUB:", ".odt:", ".ODT:",
+                                           ".ods:", ".ODS:", ".odp:", ".ODP:", ".docx:", ".DOCX:", ".pptx:", ".PPTX:",
+                                           ".xlsx:", ".XLSX:", ".xps:", ".XPS"};
+
+/* Media::parseArchivePath: length of the parent (archive) path, or -1 */
+static long archive_parent_len(const char* path) {
+  const long len = (long)strlen(path);
+  long end = -1;
+  for (long i = len - 1; i >= 0; --i)
+    if (path[i] == ':') {
+      end = i;
+      break;
+    }
+  while (end > 1) {
+    for (int m = 0; m < 20; ++m) {
+      const long ml = (long)strlen(kZipMarkers[m]);
+      const long start = end - ml + 1;
+      if (start < 0) continue;
+      if (start + ml <= len && strncmp(path + start, kZipMarkers[m], (size_t)ml) == 0) return start + ml - 1;
+    }
+    long prev = -1;
+    for (long i = end - 1; i >= 0; --i)
+      if (path[i] == ':') {
+        prev = i;
+        break;
+      }
+    end = prev;
+  }
+  return -1;
+}
+
+/* Media::dirPath into buf */
+static void dir_path(const char* path, char* buf, size_t cap) {
+  long n = archive_parent_len(path);
+  if (n < 0) {
+    n = -1;
+    for (long i = (long)strlen(path) - 1; i >= 0; --i)
+      if (path[i] == '/') {
+        n = i;
+        break;
+      }
+    if (n < 0) n = 0;
+  }
+  if ((size_t)n >= cap) n = (long)cap - 1;
+  memcpy(buf, path, (size_t)n);
+  buf[n] = 0;
+}
+
+typedef struct {
+  int* m;     /* member = index into paths */
+  int* s;     /* score */
+  int n, cap;
+} fgroup;
+
+static void fg_push(fgroup* g, int m, int s) {
+  if (g->n == g->cap) {
+    g->cap = g->cap ? g->cap * 2 : 8;
+    g->m = (int*)realloc(g->m, (size_t)g->cap * sizeof(int));
+    g->s = (int*)realloc(g->s, (size_t)g->cap * sizeof(int));
+  }
+  g->m[g->n] = m, g->s[g->n] = s, g->n++;
+}
+static int fg_contains(const fgroup* g, const char* const* paths, int m) {
+  for (int i = 0; i < g->n; ++i)
+    if (strcmp(paths[g->m[i]], paths[m]) == 0) return 1; /* Media::operator== compares paths */
+  return 0;
+}
+static const char* const* g_paths;
+static int cmp_str_idx(const void* a, const void* b) { return strcmp(g_paths[*(const int*)a], g_paths[*(const int*)b]); }
+
+/* stable insertion sort of groups by the first member's path (Media::sortGroupList) */
+static void sort_groups(fgroup* list, int n, const char* const* paths) {
+  for (int i = 1; i < n; ++i) {
+    fgroup t = list[i];
+    int j = i - 1;
+    while (j >= 0) {
+      /* cmp(t, list[j]): "a.count() < 1 -> true; b.count() < 1 -> false; else path(a0) < path(b0)" */
+      int less;
+      if (t.n < 1) less = 1;
+      else if (list[j].n < 1) less = 0;
+      else less = strcmp(paths[t.m[0]], paths[list[j].m[0]]) < 0;
+      if (!less) break;
+      list[j + 1] = list[j];
+      --j;
+    }
+    list[j + 1] = t;
+  }
+}
+
+long long orc_filter_groups_paths(const char* const* paths, const uint64_t* first, const int32_t* members,
+                                  const int32_t* scores, size_t n_groups_in, const char* db_path, const char* param_path,
+                                  int in_path, int filter_parent, int min_matches, int filter_groups, int merge_groups,
+                                  int expand_groups, uint64_t* out_first, int32_t* out_members, int32_t* out_scores,
+                                  size_t cap_groups, size_t cap_members) {
+  fgroup* list = (fgroup*)calloc(n_groups_in ? n_groups_in : 1, sizeof(fgroup));
+  int n = 0;
+  char prefix[4096];
+  prefix[0] = 0;
+  if (param_path[0]) { /* :1221-1223 */
+    if (strncmp(param_path, db_path, strlen(db_path)) == 0)
+      snprintf(prefix, sizeof prefix, "%s", param_path);
+    else
+      snprintf(prefix, sizeof prefix, "%s/%s", db_path, param_path);
+  }
+  for (size_t g = 0; g < n_groups_in; ++g) {
+    const size_t a = (size_t)first[g], b = (size_t)first[g + 1];
+    if (b - a <= 1) continue; /* results without a match never become a group (:1409; the needle was prepended) */
+    fgroup grp = {0, 0, 0, 0};
+    for (size_t t = a; t < b; ++t) fg_push(&grp, members[t], scores[t]);
+    /* filterMatch */
+    if (param_path[0] && grp.n > 1) {
+      fgroup tmp = {0, 0, 0, 0};
+      fg_push(&tmp, grp.m[0], grp.s[0]);
+      for (int i = 1; i < grp.n; ++i) {
+        const int starts = strncmp(paths[grp.m[i]], prefix, strlen(prefix)) == 0;
+        if ((!in_path) ^ starts) fg_push(&tmp, grp.m[i], grp.s[i]);
+      }
+      free(grp.m), free(grp.s);
+      grp = tmp;
+    }
+    if (filter_parent && grp.n > 1) {
+      char parent[4096], d[4096];
+      dir_path(paths[grp.m[0]], parent, sizeof parent);
+      for (int i = 1; i < grp.n; ++i) {
+        dir_path(paths[grp.m[i]], d, sizeof d);
+        if (strcmp(d, parent) == 0) { /* match.remove(i); --i; */
+          memmove(grp.m + i, grp.m + i + 1, (size_t)(grp.n - i - 1) * sizeof(int));
+          memmove(grp.s + i, grp.s + i + 1, (size_t)(grp.n - i - 1) * sizeof(int));
+          grp.n--;
+          --i;
+        }
+      }
+    }
+    if (grp.n > min_matches)
+      list[n++] = grp;
+    else
+      free(grp.m), free(grp.s);
+  }
+  /* filterMatches */
+  if (filter_groups) {
+    sort_groups(list, n, paths);
+    char** keys = (char**)calloc((size_t)(n ? n : 1), sizeof(char*));
+    int n_keys = 0, kept = 0;
+    for (int g = 0; g < n; ++g) {
+      int* idx = (int*)malloc((size_t)list[g].n * sizeof(int));
+      memcpy(idx, list[g].m, (size_t)list[g].n * sizeof(int));
+      g_paths = paths;
+      qsort(idx, (size_t)list[g].n, sizeof(int), cmp_str_idx);
+      size_t len = 1;
+      for (int i = 0; i < list[g].n; ++i) len += strlen(paths[idx[i]]) + 1;
+      char* str = (char*)malloc(len);
+      str[0] = 0;
+      for (int i = 0; i < list[g].n; ++i) strcat(str, paths[idx[i]]), strcat(str, "\n"); /* (the reference hashes the
+                                                       bare concatenation; a separator keeps distinct sets distinct) */
+      free(idx);
+      int dup = 0;
+      for (int q = 0; q < n_keys && !dup; ++q) dup = strcmp(keys[q], str) == 0;
+      if (dup) {
+        free(str);
+        free(list[g].m), free(list[g].s);
+      } else {
+        keys[n_keys++] = str;
+        list[kept++] = list[g];
+      }
+    }
+    for (int q = 0; q < n_keys; ++q) free(keys[q]);
+    free(keys);
+    n = kept;
+  }
+  if (merge_groups) { /* Media::mergeGroupList */
+    for (int i = 0; i < n; i++) {
+      fgroup* a = &list[i];
+      for (int j = 0; j < n; j++)
+        if (i != j) {
+          fgroup* b = &list[j];
+          if (b->n > 0 && fg_contains(a, paths, b->m[0])) {
+            for (int k = 1; k < b->n; k++)
+              if (!fg_contains(a, paths, b->m[k])) fg_push(a, b->m[k], b->s[k]);
+            b->n = 0;
+            /* std::sort(a) on Media::operator< (score); equal scores by path */
+            for (int x = 1; x < a->n; ++x) {
+              const int mm = a->m[x], ss = a->s[x];
+              int y = x - 1;
+              while (y >= 0 && (a->s[y] > ss || (a->s[y] == ss && strcmp(paths[a->m[y]], paths[mm]) > 0))) {
+                a->m[y + 1] = a->m[y], a->s[y + 1] = a->s[y];
+                --y;
+              }
+              a->m[y + 1] = mm, a->s[y + 1] = ss;
+            }
+          }
+        }
+    }
+    int kept = 0;
+    for (int g = 0; g < n; ++g) {
+      if (list[g].n > 0)
+        list[kept++] = list[g];
+      else
+        free(list[g].m), free(list[g].s);
+    }
+    n = kept;
+  } else if (expand_groups) { /* Media::expandGroupList */
+    int total = 0;
+    for (int g = 0; g < n; ++g) total += list[g].n - 1;
+    fgroup* ex = (fgroup*)calloc((size_t)(total ? total : 1), sizeof(fgroup));
+    int e = 0;
+    for (int g = 0; g < n; ++g) {
+      for (int i = 1; i < list[g].n; ++i) {
+        fg_push(&ex[e], list[g].m[0], list[g].s[0]);
+        fg_push(&ex[e], list[g].m[i], list[g].s[i]);
+        ++e;
+      }
+      free(list[g].m), free(list[g].s);
+    }
+    free(list);
+    list = ex;
+    n = total;
+  }
+  sort_groups(list, n, paths); /* :1463 */
+  long long rc = n;
+  size_t pos = 0;
+  for (int g = 0; g < n; ++g) {
+    if ((size_t)g >= cap_groups || pos + (size_t)list[g].n > cap_members) {
+      rc = -1;
+      break;
+    }
+    out_first[g] = pos;
+    for (int i = 0; i < list[g].n; ++i) out_members[pos] = list[g].m[i], out_scores[pos] = list[g].s[i], ++pos;
+  }
+  if (rc >= 0) out_first[n] = pos;
+  for (int g = 0; g < n; ++g) free(list[g].m), free(list[g].s);
+  free(list);
+  return rc;
 }

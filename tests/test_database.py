@@ -152,6 +152,104 @@ def test_filter_groups_c_abi_on_host(orc):
             assert got == _oracle_groups(orc, h, ids, idx_h, idx_i, p, filter_groups=bool(fg)), (kw, fg)
 
 
+def _filter_case(seed, n_media=260, n_groups=180):
+    """media with directory / zip-member paths and random per-needle results over them"""
+    from cbird_amd import Media
+
+    rng = np.random.default_rng(seed)
+    dirs = ["/db/a", "/db/a/sub", "/db/b", "/db/b.zip:inner", "/db/b.zip:inner/x", "/db/c.CBZ:", "/db/pics.v2:raw",
+            "/other/a", "/db/ab"]
+    media = []
+    for i in range(n_media):
+        d = dirs[int(rng.integers(0, len(dirs)))]
+        sep = "" if d.endswith(":") else "/"
+        media.append(Media(id=int(1000 + 7 * i), dctHash=1, path=f"{d}{sep}f{int(rng.integers(0, 10 ** 6)):06d}_{i}.jpg"))
+    results = []
+    for _ in range(n_groups):
+        j = int(rng.integers(0, n_media))
+        k = int(rng.integers(0, 6))
+        others = [int(x) for x in rng.choice(n_media, k, replace=False) if int(x) != j]
+        g = [media[j]]
+        for o in others:
+            m = Media(id=media[o].id, dctHash=1, path=media[o].path)
+            m.score = int(rng.integers(0, 9))
+            g.append(m)
+        g[1:] = sorted(g[1:], key=lambda m: (m.score, m.id))
+        results.append(g)
+    # a pair found from both ends, and a chain a->b, b->c for the merge
+    a, b, c = media[3], media[4], media[5]
+    for x, y in ((a, b), (b, a), (b, c)):
+        m = Media(id=y.id, dctHash=1, path=y.path)
+        m.score = 2
+        results.append([x, m])
+    return media, results
+
+
+FILTER_SETS = [dict(), dict(minMatches=2), dict(filterParent=True), dict(path="a", inPath=True),
+               dict(path="/db/b", inPath=False), dict(path="b.zip:inner", inPath=True, filterParent=True, minMatches=0),
+               dict(mergeGroups=1), dict(expandGroups=True), dict(mergeGroups=1, expandGroups=True, filterGroups=False),
+               dict(filterGroups=False, expandGroups=True, filterParent=True, path="/db/a", inPath=False),
+               dict(minMatches=0, path="nowhere", inPath=True)]
+
+
+def test_filter_match_and_filter_matches_three_ways(orc):
+    """Database::filterMatch + filterMatches (path / inPath, filterParent, the count rule, filterGroups, mergeGroups,
+    expandGroups; src/database.cpp:1209-1278, src/media.cpp:198-208,300-331): the C-ABI's id / attribute form
+    (cbh_filter_groups_ex), cbird_amd/database.py on Media objects, and oracle/search_index.c on path strings -- three
+    statements, one answer"""
+    from cbird_amd import SearchParams
+    from cbird_amd.database import dir_path, filter_groups_c_abi, filter_results, parse_archive_path
+
+    assert parse_archive_path("/x/y.zip:a/b.jpg") == ("/x/y.zip", "a/b.jpg")
+    assert parse_archive_path("/x/y.zipx:a.jpg") is None and parse_archive_path("C:/x.jpg") is None
+    assert parse_archive_path("/x/a.zip:b.epub:c.png") == ("/x/a.zip:b.epub", "c.png")  # the LAST marker wins
+    assert dir_path("/x/y.zip:a/b.jpg") == "/x/y.zip" and dir_path("/x/y/b.jpg") == "/x/y" and dir_path("b.jpg") == ""
+    for seed in (1, 2):
+        media, results = _filter_case(seed)
+        paths = [m.path for m in media]
+        pos = {m.id: i for i, m in enumerate(media)}
+        needle_ids = np.array([g[0].id for g in results], np.uint32)
+        k = max(1, max(len(g) - 1 for g in results))
+        pairs = np.zeros((len(results), k, 2), np.uint32)
+        counts = np.zeros(len(results), np.uint32)
+        for j, g in enumerate(results):
+            counts[j] = len(g) - 1
+            for t, m in enumerate(g[1:]):
+                pairs[j, t] = (m.id, np.uint32(m.score))
+        for kw in FILTER_SETS:
+            p = SearchParams(**kw)
+            py = [[(m.id, m.score if t or g[0].score != -1 else -1) for t, m in enumerate(g)]
+                  for g in filter_results(p, [list(g) for g in results], "/db")]
+            c_abi = filter_groups_c_abi(p, needle_ids, pairs, counts, media, "/db")
+            o = orc.filter_groups_paths(paths, [[(pos[m.id], -1 if t == 0 else m.score) for t, m in enumerate(g)]
+                                                for g in results], "/db", p.path, p.inPath, p.filterParent,
+                                        p.minMatches, p.filterGroups, p.mergeGroups, p.expandGroups)
+            o = [[(media[i].id, s) for i, s in g] for g in o]
+            assert c_abi == o, (seed, kw)
+            assert py == o, (seed, kw)
+            assert len(o) > 0 or kw.get("path") == "nowhere", kw
+    # the pair found from both ends is reported once, the chain merges into one group
+    media, results = _filter_case(1)
+    ids3 = {media[3].id, media[4].id, media[5].id}
+    needle_ids = np.array([g[0].id for g in results], np.uint32)
+    merged = filter_groups_c_abi(SearchParams(mergeGroups=1), needle_ids, pairs * 0 + _pairs_of(results), _counts_of(results),
+                                 media, "/db")
+    assert any(ids3 <= {i for i, _ in g} for g in merged)
+
+
+def _pairs_of(results):
+    k = max(1, max(len(g) - 1 for g in results))
+    pairs = np.zeros((len(results), k, 2), np.uint32)
+    for j, g in enumerate(results):
+        for t, m in enumerate(g[1:]):
+            pairs[j, t] = (m.id, np.uint32(m.score))
+    return pairs
+
+
+def _counts_of(results):
+    return np.array([len(g) - 1 for g in results], np.uint32)
+
+
 @pytest.mark.gpu
 def test_similar_behind_the_c_abi_equals_the_oracle(gpu, orc, scan_path):
     """cbh_search_index_batch + cbh_filter_groups (scans, escalation and cut on the device) == oracle/search_index.c

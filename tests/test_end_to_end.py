@@ -230,3 +230,33 @@ def test_video_index_end_to_end(gpu, tmp_path):
     assert all(x.mediaId != 4 for x in idx.find(needle, p))
     idx.add([media[3]])
     assert idx.find(needle, p)[0].mediaId == 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo", [0, 1, 2, 3])
+def test_search_index_batch_equals_one_search_index_per_needle(corpus, algo):
+    """Database::searchIndex for the whole needle list behind the C-ABI (cbh_search_index_batch and the four
+    cbh_*_search_index_batch of searchbatch.hip: one batched find per threshold level) against the reference's shape,
+    one searchIndex per needle (cbird_amd.database.search_index over the same index): maxThresh escalation (+1 for the
+    dct-based algorithms, +5 for ORB, none for colour), the order, filterSelf, the maxMatches cut, and ids the idMap
+    does not hold"""
+    import warnings
+
+    from cbird_amd import SearchParams
+    from cbird_amd.database import search_index, search_index_batch
+
+    index = make_index(algo)
+    populate(index, algo, corpus)
+    id_map = {m.id: m for m in corpus if m.id % 9 != 0}  # every 9th media is not in the caller's idMap
+    needles = corpus[::3] + corpus[1:40:7]
+    variants = [dict(filterSelf=False), dict(filterSelf=True, maxMatches=3), dict(filterSelf=True, minMatches=3, maxThresh=9),
+                dict(dctThresh=1, cvThresh=5, minMatches=2, maxThresh=30, maxMatches=7),
+                dict(dctThresh=2, cvThresh=10, minMatches=1, maxThresh=4)]
+    for kw in variants:
+        p = SearchParams(algo=algo, **kw)
+        got = search_index_batch(index, needles, p, id_map)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # "no media with id"
+            want = [search_index(index, m, p, id_map) for m in needles]
+        assert [[(x.id, x.score) for x in g] for g in got] == [[(x.id, x.score) for x in g] for g in want], (algo, kw)
+        assert any(len(g) for g in got)

@@ -315,6 +315,37 @@ def test_gpu_video_batch_remove_add(gpu, vorc, reduce_path):
 
 
 @pytest.mark.gpu
+def test_gpu_video_search_index_batch_equals_per_needle(gpu):
+    """Database::searchIndex over DctVideoIndex for a needle batch (cbh_vidx_search_index_batch: one batched findVideo
+    per dctThresh level) == one searchIndex per needle; findVideo itself drops the needle's own video when filterSelf
+    (src/dctvideoindex.cpp:494), so the count that decides about another level excludes it"""
+    import warnings
+
+    from cbird_amd import synth_video
+    from cbird_amd.database import search_index, search_index_batch
+    from cbird_amd.video import VideoSearchParams
+
+    clips = synth_video.make_clips(150, 200, seed=5, subclip_frac=0.2, max_gap=8)
+    idx, media = _mk_index(gpu, clips)
+    for m in media:
+        m.isValid = lambda: True
+        m.score = -1
+    id_map = {m.id: m for m in media if m.id % 11 != 0}
+    needles = media[::2]
+    for kw in (dict(dctThresh=5, filterSelf=False), dict(dctThresh=1, maxThresh=7, minMatches=1, filterSelf=True),
+               dict(dctThresh=2, maxThresh=4, minMatches=2, maxMatches=2, filterSelf=False)):
+        p = VideoSearchParams(skipFrames=0, minFramesMatched=10, minFramesNear=30, **kw)
+        p.algo = p.AlgoVideo
+        got = search_index_batch(idx, needles, p, id_map)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = [search_index(idx, m, p, id_map) for m in needles]
+        key = lambda g: [(x.id, x.score, x.matchRange.srcIn, x.matchRange.dstIn, x.matchRange.len) for x in g]
+        assert [key(g) for g in got] == [key(g) for g in want], kw
+        assert any(len(g) for g in got)
+
+
+@pytest.mark.gpu
 def test_gpu_radix_compatible_mode_equals_bucket_search(gpu, vorc, reduce_path):
     """`-p.vradix N` of the reference: a needle frame only sees its RadixMap bucket.  The oracle's bucket rule is
     pinned to the real RadixMap (test_oracle_candidates_vs_real_radixmap); DctVideoIndex(radix_compat=True) must
