@@ -138,6 +138,13 @@ _SIGS = {
     "cbh_idx256_search_index_batch": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                 C.c_int, _vp, _sz, _vp, _vp]),
     "cbh_color_search_index_batch": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp, _vp]),
+    "cbh_fdct_find_coalesced": (C.c_int, [_vp, _vp, _sz, C.c_uint32, C.c_int, C.c_int, _vp, _sz, C.POINTER(_sz)]),
+    "cbh_vidx_find_video_coalesced": (C.c_int, [_vp, _vp, _vp, _sz, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                C.c_int, _vp, _sz, C.POINTER(_sz)]),
+    "cbh_idx256_find_coalesced": (C.c_int, [_vp, _vp, _sz, C.c_int, C.c_int, _vp, _sz, C.POINTER(_sz)]),
+    "cbh_color_find_coalesced": (C.c_int, [_vp, _vp, _vp, _sz, C.POINTER(_sz)]),
+    "cbh_color_find_all_batch": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _vp]),
+    "cbh_combine_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "cbh_filter_groups_ex": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp,
                                        _vp]),
     "cbh_vdx_verify": (C.c_int, [_vp, _sz]),

@@ -110,12 +110,14 @@ class GpuDctFeaturesIndex : public DctFeaturesIndex {  // inherits createTables/
     }
     std::vector<cbh_match> out(h.size() * 10 + 1);
     size_t n = 0;
-    CBH_CHECK(cbh_fdct_find_ex(_idx, h.data(), h.size(), uint32_t(needle.id()), params.dctThresh,
+    CBH_CHECK(cbh_fdct_find_coalesced(_idx, h.data(), h.size(), uint32_t(needle.id()), params.dctThresh,
                                _treeCompat ? 1 : 0, out.data(), out.size(), &n));
     QVector<Index::Match> results;
     for (size_t i = 0; i < n; ++i) results.append(Index::Match(out[i].id, out[i].score));
     return results;
   }
+
+  cbh_idx64* handle() const { return _idx; }  // for statistics (cbh_combine_stats)
 
  private:
   GpuDctFeaturesIndex(cbh_idx64* adopted, bool treeCompat) : _idx(adopted), _treeCompat(treeCompat) {}
@@ -198,7 +200,7 @@ class GpuCvFeaturesIndex : public CvFeaturesIndex {
     }
     std::vector<cbh_match> out(n_desc * 10 + 1);
     size_t n = 0;
-    CBH_CHECK(cbh_idx256_find(_idx, rows, n_desc, params.cvThresh, 10, out.data(), out.size(), &n));
+    CBH_CHECK(cbh_idx256_find_coalesced(_idx, rows, n_desc, params.cvThresh, 10, out.data(), out.size(), &n));
     QVector<Index::Match> results;
     for (size_t i = 0; i < n; ++i) results.append(Index::Match(out[i].id, out[i].score));
     return results;
@@ -221,6 +223,8 @@ class GpuCvFeaturesIndex : public CvFeaturesIndex {
     }
     return chunk;
   }
+
+  cbh_idx256* handle() const { return _idx; }  // for statistics (cbh_combine_stats)
 
  private:
   int _device = 0;
@@ -309,7 +313,7 @@ class GpuColorDescIndex : public ColorDescIndex {
     }
     std::vector<cbh_match> out(size_t(std::max(count(), 1)));
     size_t n = 0;
-    CBH_CHECK(cbh_color_find(_idx, &target, out.data(), out.size(), &n));
+    CBH_CHECK(cbh_color_find_coalesced(_idx, &target, out.data(), out.size(), &n));
     for (size_t i = 0; i < n; ++i) results.append(Index::Match(out[i].id, out[i].score));
     return results;
   }
@@ -329,6 +333,8 @@ class GpuColorDescIndex : public ColorDescIndex {
     if (!keepIds.empty()) chunk->addRows(keepIds.data(), keep.data(), keepIds.size());
     return chunk;
   }
+
+  cbh_color* handle() const { return _idx; }  // for statistics (cbh_combine_stats)
 
  private:
   int _device = 0;
@@ -404,7 +410,7 @@ class GpuDctVideoIndex : public DctVideoIndex {
         qWarning() << "needle video index is empty:" << needle.path();
         return {};
       }
-      CBH_CHECK(cbh_vidx_find_video(_idx, src.frames.data(), src.hashes.data(), src.frames.size(),
+      CBH_CHECK(cbh_vidx_find_video_coalesced(_idx, src.frames.data(), src.hashes.data(), src.frames.size(),
                                     uint32_t(needle.id()), p.dctThresh, p.skipFrames, p.minFramesMatched,
                                     p.minFramesNear, p.filterSelf, out.data(), out.size(), &n));
     }
@@ -426,6 +432,8 @@ class GpuDctVideoIndex : public DctVideoIndex {
     copy->_loaded = true;
     return copy;
   }
+
+  cbh_vidx* handle() const { return _idx; }  // for statistics (cbh_combine_stats)
 
  private:
   void addOne(uint32_t id) {

@@ -14,6 +14,7 @@
 
 namespace cbh {
 
+void combiner_drop(const void* handle);  // combine.hip
 void set_last_error(const char* where, hipError_t e);
 void set_last_error_text(const char* text);  // non-HIP failures (RCCL)
 

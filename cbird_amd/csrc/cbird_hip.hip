@@ -625,6 +625,7 @@ cbh_idx64* cbh_idx64_create(int device) {
 
 void cbh_idx64_destroy(cbh_idx64* idx) {
   if (!idx) return;
+  cbh::combiner_drop(idx);  // combine.hip: the queue of cbh_*_find_coalesced callers
   DeviceGuard g(idx->device);
   for (Workspace* w : idx->ws_free) {
     w->release();

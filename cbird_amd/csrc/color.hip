@@ -556,6 +556,7 @@ cbh_color* cbh_color_create(int device) {
 
 void cbh_color_destroy(cbh_color* c) {
   if (!c) return;
+  cbh::combiner_drop(c);  // combine.hip: the queue of cbh_*_find_coalesced callers
   cbh::DeviceGuard g(c->device);
   for (void* p : {(void*)c->dL, (void*)c->dU, (void*)c->dV, (void*)c->d_num, (void*)c->d_ids, (void*)c->d_needles,
                   (void*)c->d_scores, (void*)c->d_keys, (void*)c->d_keys_alt, c->d_tmp, (void*)c->d_hist,
@@ -646,6 +647,42 @@ int cbh_color_find(cbh_color* c, const void* needle_desc, cbh_match* out, size_t
     }
   *n_out = m;
   return CBH_OK;
+}
+
+/* find() for nq needles in one pass: needle q's matches (all of them, index order, as cbh_color_find returns them) at
+ * out[out_offsets[q] .. out_offsets[q+1]); CBH_E_OVERFLOW with out_offsets complete when cap is too small */
+int cbh_color_find_all_batch(cbh_color* c, const void* needle_descs, size_t nq, cbh_match* out, size_t cap,
+                             uint64_t* out_offsets) {
+  if (!c || !out_offsets || (nq && !needle_descs) || (cap && !out)) return CBH_E_INVAL;
+  for (size_t q = 0; q <= nq; ++q) out_offsets[q] = 0;
+  if (nq == 0 || c->n == 0) return CBH_OK;
+  cbh::DeviceGuard g(c->device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  std::lock_guard<std::mutex> lk(c->mu);
+  const size_t chunk = std::max<size_t>(1, std::min<size_t>(nq, ((size_t)1 << 27) / c->n));
+  int rc = ensure_scratch(c, chunk, false);
+  if (rc) return rc;
+  std::vector<int> sc(chunk * c->n);
+  uint64_t pos = 0;
+  for (size_t q0 = 0; q0 < nq; q0 += chunk) {
+    const size_t m = std::min(chunk, nq - q0);
+    rc = run_dist(c, (const uint8_t*)needle_descs + q0 * kDescBytes, m);
+    if (rc) return rc;
+    CBH_HIP(hipMemcpyAsync(sc.data(), c->d_scores, m * c->n * 4, hipMemcpyDeviceToHost, c->stream));
+    CBH_HIP(hipStreamSynchronize(c->stream));
+    for (size_t q = 0; q < m; ++q) {
+      out_offsets[q0 + q] = pos;
+      if (((const uint8_t*)needle_descs)[(q0 + q) * kDescBytes + 256] == 0) continue;  // no colours (:259-266)
+      const int* s = sc.data() + q * c->n;
+      for (size_t i = 0; i < c->n; ++i)
+        if (s[i] >= 0 && c->host_ids[i] != 0) {
+          if (pos < cap) out[pos] = cbh_match{c->host_ids[i], s[i]};
+          ++pos;
+        }
+    }
+  }
+  out_offsets[nq] = pos;
+  return pos > cap ? CBH_E_OVERFLOW : CBH_OK;
 }
 
 /* ColorDescriptor::distance (cvutil.cpp:682-749) of nq needles against every index entry, as floats: out[q*n + i];

@@ -585,6 +585,7 @@ int cbh_idx256_shard_stats(const cbh_idx256* ix, cbh_shard_stats* out) {
 
 void cbh_idx256_destroy(cbh_idx256* ix) {
   if (!ix) return;
+  cbh::combiner_drop(ix);  // combine.hip: the queue of cbh_*_find_coalesced callers
   if (ix->shards) {
     Shards256* S = ix->shards;
     S->comm.destroy_comms();

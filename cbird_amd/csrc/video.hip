@@ -314,6 +314,7 @@ int cbh_vidx_set_radix(cbh_vidx* v, int radix) {
 
 void cbh_vidx_destroy(cbh_vidx* v) {
   if (!v) return;
+  cbh::combiner_drop(v);  // combine.hip: the queue of cbh_*_find_coalesced callers
   if (v->idx) cbh_idx64_destroy(v->idx);
   for (void* p : {(void*)v->d_evidx, (void*)v->d_eframe, (void*)v->d_vmedia})
     if (p) (void)hipFree(p);

@@ -421,6 +421,21 @@ int cbh_color_search_index_batch(struct cbh_color*, const void* needle_descs, co
                                  int max_matches, int filter_self, const uint32_t* valid_ids_sorted, size_t n_valid,
                                  cbh_match* out, uint32_t* out_counts);
 
+/* find() for an UNMODIFIED caller on the other four indexes (cbird_amd/csrc/combine.hip): same arguments and results as
+ * cbh_fdct_find_ex / cbh_vidx_find_video / cbh_idx256_find / cbh_color_find; callers that arrive from other threads
+ * while a search is in flight are served together by ONE call of the index's batch entry point (leader / follower, up
+ * to 256 needles per round trip, requests grouped by equal search parameters).  This is what the Gpu*Index::find
+ * adapters call.  cbh_combine_stats(handle): calls and combined searches so far. */
+int cbh_fdct_find_coalesced(cbh_idx64*, const uint64_t* hashes, size_t n, uint32_t needle_id, int thresh, int tree_compat,
+                            cbh_match* out, size_t cap, size_t* n_out);
+int cbh_vidx_find_video_coalesced(struct cbh_vidx*, const int32_t* frames, const uint64_t* hashes, size_t n,
+                                  uint32_t needle_id, int thresh, int skip_frames, int min_frames_matched,
+                                  int min_frames_near, int filter_self, struct cbh_vmatch* out, size_t cap, size_t* n_out);
+int cbh_idx256_find_coalesced(cbh_idx256*, const uint8_t* needle_rows, size_t n_desc, int thresh, int k, cbh_match* out,
+                              size_t cap, size_t* n_out);
+int cbh_color_find_coalesced(struct cbh_color*, const void* needle_desc, cbh_match* out, size_t cap, size_t* n_out);
+int cbh_combine_stats(const void* handle, uint64_t* finds, uint64_t* rounds);
+
 /* All of filterMatch (src/database.cpp:1209-1248) and filterMatches (:1250-1278) on those results, host code:
  *   path_mode      params.path / inPath (:1217-1229): 0 = no path filter, 1 = keep only matches under the prefix
  *                  (inPath), 2 = keep only matches NOT under it; the needle always stays
@@ -649,6 +664,9 @@ int cbh_color_download(const cbh_color*, uint32_t* ids, void* descs, size_t cap)
  * finite (both sides have colours, counts differ by <= 2) and whose id != 0, in index order,
  * score = int(1 + sum of nearest-colour distances).  Bit-exact to the reference's float arithmetic. */
 int cbh_color_find(cbh_color*, const void* needle_desc, cbh_match* out, size_t cap, size_t* n_out);
+/* cbh_color_find for nq needles in one pass (needle q: out[out_offsets[q] .. out_offsets[q+1]), index order) */
+int cbh_color_find_all_batch(cbh_color*, const void* needle_descs, size_t nq, cbh_match* out, size_t cap,
+                             uint64_t* out_offsets);
 /* ColorDescriptor::distance (src/cvutil.cpp:682-749) as FLOATS, nq needles x every index entry: out[q*count + i]
  * for entry i in add order (whatever its id); FLT_MAX where the reference returns FLT_MAX (:683-684).  The int
  * scores of cbh_color_find are (int) of exactly these values. */

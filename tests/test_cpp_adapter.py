@@ -95,6 +95,22 @@ def test_other_four_adapters_run_on_gpu(gpu, tmp_path):
     assert "adapters ok" in out.stdout
 
 
+@pytest.mark.gpu
+def test_other_four_adapters_find_from_64_threads(gpu, tmp_path):
+    """Index::find of GpuDctFeaturesIndex / GpuCvFeaturesIndex / GpuColorDescIndex / GpuDctVideoIndex from 64 threads at
+    once (Database::similar's QtConcurrent pattern): every result equals the single-threaded answer, and the callers
+    really shared device round trips (cbh_*_find_coalesced, combine.hip)"""
+    import re
+
+    subprocess.check_call(["make", "-C", CPP, "test_combine4"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(CPP, "test_combine4"), "64", str(tmp_path)], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "combine4 ok" in out.stdout
+    per = [float(x) for x in re.findall(r"\(([0-9.]+) needles per round trip\)", out.stdout)]
+    assert len(per) == 4 and all(p > 1.5 for p in per), out.stdout  # callers were combined on every index
+
+
 def test_cvutil_dropins_compile():
     subprocess.check_call(["make", "-C", CPP, "-B", "test_cvutil"], stdout=subprocess.DEVNULL)
     src = open(os.path.join(ROOT, "cbird_amd", "cpp", "gpu_cvutil.h")).read()
