@@ -620,8 +620,51 @@ def cvfeatures_leg(args, torch, dist, dev, local_rank, rank, world, share):
         self_first = sum(1 for i, r in enumerate(res) if r and r[0].mediaId == needles[i].id)
     a, b = ShardedDctHashIndex.shard_range(n_img, rank, world)
     pairs = float(n_img) * per * n_needles * per
+    # ---- kernel figures on this rank's rows, HIP events around the scan launches (cbh_idx256_get_stats): the batched
+    # search (64 needle images = 32k descriptors) and the reference's own query shape, ONE needle image of 500
+    # descriptors (cvfeaturesindex.cpp:497).  Both bounds are stated: the 128-bit prefilter issues two K = 64 FP4 MFMAs
+    # per 32 x 32 pairs (256 FLOP per pair against the 10 PFLOP/s dense FP4 peak), and the rows stream once (32 B each
+    # against 8 TB/s).  At 500 needle descriptors the MFMA bound is 0.82 ms for 5*10^7 rows and the HBM bound 0.2 ms, so
+    # the matrix cores bind there too.
+    import ctypes as C
+
+    from cbird_amd import _lib
+
+    L = _lib.lib()
+    st = _lib.cbh_stats()
+    h256 = sc.index.handle
+    rows_here = (b - a) * per
+
+    def kernel_ms(call, reps):
+        call()
+        L.cbh_idx256_get_stats(h256, C.byref(st))
+        ms0, l0 = st.scan_ms, st.scan_launches
+        for _ in range(reps):
+            call()
+        L.cbh_idx256_get_stats(h256, C.byref(st))
+        return (st.scan_ms - ms0) / max(1, st.scan_launches - l0)
+
+    one = np.ascontiguousarray(needles[0].keyPointDescriptors, np.uint8)
+    allq = np.ascontiguousarray(np.concatenate([m.keyPointDescriptors for m in needles]), np.uint8)
+
+    def roof(nq, ms, kernel):
+        fl = float(rows_here) * nq * 256.0
+        by = float(rows_here) * 32.0
+        return {"kernel": kernel, "needle_descriptors": nq, "rows": rows_here, "avg_launch_ms": ms,
+                "cmp256_per_s": float(rows_here) * nq / (ms * 1e-3),
+                "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": fl / (ms * 1e-3) / 1e12 / FP4_PEAK_TFLOPS, "traffic": None,
+                "hbm": {"achieved_GBps": by / (ms * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBS,
+                        "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": by},
+                "algorithmic_flop_per_launch": fl}
+
+    roofline = {"one_needle_image": roof(len(one), kernel_ms(lambda: sc.index.knn(one, 10, 25), 5),
+                                         "k_hamm256_small<16> (needle tiles stationary, rows streamed)"),
+                "batch_of_64": roof(len(allq), kernel_ms(lambda: sc.index.knn(allq, 10, 25), 2),
+                                    "k_hamm256_mfma<6,3,2> (row tiles stationary, needle tiles streamed)")}
     return {"workload": "configs[3]: CvFeaturesIndex, %d images x %d descriptors x 256 bit, %d needle images batched, "
                         "knn k=10, cvThresh 25" % (n_img, per, n_needles),
+            "roofline": roofline,
             "parallelism": f"sharded by image x{world}, needles replicated, one all-gather of the candidate tables",
             "seconds": best, "needle_images_per_s": n_needles / best, "cmp256_per_s": pairs / best, "matches": hits,
             "needles_ranked_first_themselves": self_first, "rows_this_rank": (b - a) * per,

@@ -77,6 +77,7 @@ int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, siz
 bool scan256_mfma_wanted(size_t n, size_t nq, int thresh);
 void set_scan256_g(int g);
 void set_scan256_ht(int ht);
+void set_scan256_small(int v);  // stationary-needle kernel for <= 512 needle descriptors: 0 / 1, >= 16: its workgroups
 void set_scan256_pre(int on);  // first-128-bit prefilter variant (default on)
 void set_scan256_mfma(int on);  // <0 = keep; 2 = force for any size
 

@@ -1137,6 +1137,10 @@ int cbh_set_tuning(const char* key, int value) {
     set_color_pk(value);
     return CBH_OK;
   }
+  if (!strcmp(key, "scan256_small")) {
+    set_scan256_small(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "scan256_pre")) {
     set_scan256_pre(value);
     return CBH_OK;

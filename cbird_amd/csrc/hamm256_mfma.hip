@@ -11,6 +11,8 @@
 // (row tile, needle tile): 4 MFMAs, then 8 v_max3_f32 over the 16 results and one compare; the rare
 // hit parks the accumulators in LDS and decodes them in a rolled loop.  VALU work is 2 ops per
 // MFMA, so the kernel runs at the matrix-core rate: 4 x ~43 cycles per 1024 pairs.
+#include <algorithm>
+
 #include "cbh_internal.h"
 #include "fp4_sign.h"
 
@@ -139,6 +141,97 @@ __global__ __launch_bounds__(kThreads) void k_hamm256_mfma(
   if (qt < q1) step(qt, x);
 }
 
+// ---- few needles (<= 512 descriptors: one ORB needle image, the reference's query shape, cvfeaturesindex.cpp:497) ----
+// With 16 needle tiles the kernel above gives each wave 6 row tiles and 192 MFMAs of work behind a prologue (row loads,
+// FP4 expansion) that nothing overlaps: 1.5 ms for 5*10^7 rows where the matrix cores need 0.9.  Here the roles are
+// swapped: ALL needle tiles are the stationary operand (first 128 bits: NT x 2 operands of 4 VGPRs), a persistent wave
+// streams row tiles -- the raw words of the next tile are in flight while the current one runs its NT x 2 MFMAs -- and
+// the grid is sized for the machine, not for the needle chunks.  First-128-bit prefilter only (thresh <= 40), hits as
+// above.  Records identical to k_hamm256_mfma / k_hamm256_scan.
+template <int NT>
+__global__ __launch_bounds__(kThreads) void k_hamm256_small(
+    const uint32_t* __restrict__ rows /* 8 words per row */, uint32_t n, const uint4* __restrict__ qx,
+    const uint32_t* __restrict__ qraw, uint32_t nq, uint32_t thresh, unsigned long long* __restrict__ rec,
+    unsigned long long cap, unsigned long long* __restrict__ total) {
+  constexpr int G = 4;  // accumulators in flight
+  __shared__ float s_c[kWaves][G * 16][64];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t r = lane & 31u, half = lane >> 5;
+  v8i b[NT][2];
+#pragma unroll
+  for (int q = 0; q < NT; ++q)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) b[q][k] = fp4_operand(qx[(size_t)q * 256u + (uint32_t)k * 64u + half * 32u + r]);
+  const float dot_thr = 128.0f - 2.0f * (float)(thresh - 1u);
+  const uint32_t n_row_tiles = (n + 31u) / 32u;
+  const uint32_t stride = gridDim.x * kWaves;
+  uint32_t tile = blockIdx.x * kWaves + wave;
+  auto load_raw = [&](uint32_t t, uint32_t& w0, uint32_t& w1) {
+    const uint32_t row = t * 32u + r;
+    const bool in = t < n_row_tiles && row < n;
+    w0 = in ? rows[(size_t)row * 8u + half] : 0u;
+    w1 = in ? rows[(size_t)row * 8u + 2u + half] : 0u;
+  };
+  constexpr int kAhead = 4;  // row tiles in flight (a tile's MFMAs take ~0.6 us, an HBM load under load 1-2 us)
+  uint32_t p0[kAhead], p1[kAhead];
+#pragma unroll
+  for (int u = 0; u < kAhead; ++u) load_raw(tile + (uint32_t)u * stride, p0[u], p1[u]);
+  for (; tile < n_row_tiles; tile += stride) {
+    const v8i a0 = fp4_operand(fp4_expand32(p0[0])), a1 = fp4_operand(fp4_expand32(p1[0]));
+#pragma unroll
+    for (int u = 0; u + 1 < kAhead; ++u) p0[u] = p0[u + 1], p1[u] = p1[u + 1];
+    load_raw(tile + (uint32_t)kAhead * stride, p0[kAhead - 1], p1[kAhead - 1]);  // behind the MFMAs of kAhead tiles
+#pragma unroll
+    for (int q0 = 0; q0 < NT; q0 += G) {
+      v16f c[G];
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) c[t][g] = 0.0f;
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+        c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b[q0 + t][0], c[t], 4, 4, 0, kScaleOne, 0, kScaleOne);
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+        c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b[q0 + t][1], c[t], 4, 4, 0, kScaleOne, 0, kScaleOne);
+      float m0 = -512.0f, m1 = -512.0f;
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; g += 4) {
+          m0 = __builtin_fmaxf(__builtin_fmaxf(m0, c[t][g]), c[t][g + 1]);
+          m1 = __builtin_fmaxf(__builtin_fmaxf(m1, c[t][g + 2]), c[t][g + 3]);
+        }
+      if (__builtin_fmaxf(m0, m1) >= dot_thr) {  // rare: decode through LDS (C/D layout as in k_hamm256_mfma)
+#pragma unroll
+        for (int t = 0; t < G; ++t)
+#pragma unroll
+          for (int g = 0; g < 16; ++g) s_c[wave][t * 16 + g][lane] = c[t][g];
+#pragma unroll 1
+        for (uint32_t e = 0; e < (uint32_t)G * 16u; ++e) {
+          const float dot = s_c[wave][e][lane];
+          if (dot >= dot_thr) {
+            const uint32_t g = e & 15u;
+            const uint32_t row = tile * 32u + (g & 3u) + 8u * (g >> 2) + 4u * half;
+            const uint32_t qi = ((uint32_t)q0 + (e >> 4)) * 32u + r;
+            if (row < n && qi < nq) {
+              uint32_t d = (uint32_t)(128 - (int)dot) >> 1;
+#pragma unroll
+              for (int wd = 4; wd < 8; ++wd) d += __popc(rows[(size_t)row * 8u + wd] ^ qraw[(size_t)qi * 8u + wd]);
+              if (d < thresh) {
+                const unsigned long long slot = atomicAdd(total, 1ull);
+                if (slot < cap) rec[slot] = ((unsigned long long)qi << 41) | ((unsigned long long)d << 32) | row;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+int g_scan256_small = 1;   // "scan256_small": the stationary-needle kernel for <= 512 needle descriptors (default on)
+int g_scan256_small_wgs = 0;  // its grid (workgroups); 0 = 2048
 int g_scan256_mfma = 1;
 int g_scan256_pre = 1;     // first-128-bit prefilter variant for thresh <= kPre128MaxThresh
 int g_scan256_pre_ht = 6;   // its row tiles per wave (6, 8, 12)
@@ -157,6 +250,10 @@ void set_scan256_g(int g) {
 void set_scan256_ht(int ht) {
   if (ht == 2 || ht == 4 || ht == 6) g_scan256_ht = ht;
   if (ht == 106 || ht == 108 || ht == 112) g_scan256_pre_ht = ht - 100;  // prefilter variant: 106 / 108 / 112
+}
+void set_scan256_small(int v) {
+  if (v == 0 || v == 1) g_scan256_small = v;
+  if (v >= 16) g_scan256_small_wgs = v;  // workgroups of the persistent grid
 }
 void set_scan256_pre(int on) {
   if (on >= 0) g_scan256_pre = on;
@@ -179,6 +276,31 @@ int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, siz
   CBH_HIP(cbh::malloc_async((void**)&qx, (size_t)nq_pad * 128u, stream));
   hipLaunchKernelGGL(k_expand_needles256, dim3((8u * nq_pad + 255u) / 256u), dim3(256), 0, stream,
                      reinterpret_cast<const uint32_t*>(d_q), (uint32_t)nq, nq_pad, qx);
+  if (g_scan256_small && g_scan256_pre && thresh <= kPre128MaxThresh && n_tiles <= 16 && (n >= 4096 || g_scan256_mfma == 2)) {
+    // needle tiles padded to the template's count read zero descriptors from the scratch (rows of zero bits never pass:
+    // qi >= nq is dropped in the hit path)
+    const uint32_t nt = n_tiles <= 4 ? 4 : n_tiles <= 8 ? 8 : 16;
+    if (nt != n_tiles) {  // the scratch must hold nt tiles
+      (void)cbh::free_async(qx, stream);
+      qx = nullptr;
+      CBH_HIP(cbh::malloc_async((void**)&qx, (size_t)nt * 32u * 128u, stream));
+      hipLaunchKernelGGL(k_expand_needles256, dim3((8u * nt * 32u + 255u) / 256u), dim3(256), 0, stream,
+                         reinterpret_cast<const uint32_t*>(d_q), (uint32_t)nq, nt * 32u, qx);
+    }
+    const uint32_t row_tiles = (uint32_t)((n + 31) / 32);
+    uint32_t wgs_s = g_scan256_small_wgs > 0 ? (uint32_t)g_scan256_small_wgs : 2048u;  // measured: 512 / 1024 / 2048 / 8192 = 1.22 / 1.10 / 1.07 / 1.07 ms
+    wgs_s = std::min(wgs_s, (row_tiles + kWaves - 1) / kWaves);
+#define CBH_SMALL(NTT)                                                                                               \
+  hipLaunchKernelGGL((k_hamm256_small<NTT>), dim3(wgs_s), dim3(kThreads), 0, stream,                                   \
+                     reinterpret_cast<const uint32_t*>(d_rows), (uint32_t)n, qx, reinterpret_cast<const uint32_t*>(d_q), \
+                     (uint32_t)nq, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total)
+    if (nt == 4) CBH_SMALL(4); else if (nt == 8) CBH_SMALL(8); else CBH_SMALL(16);
+#undef CBH_SMALL
+    hipError_t es = hipGetLastError();
+    (void)cbh::free_async(qx, stream);
+    CBH_HIP(es);
+    return CBH_OK;
+  }
   const bool pre128_ = g_scan256_pre && thresh <= kPre128MaxThresh;
   const int ht = pre128_ ? g_scan256_pre_ht : (g_scan256_ht == 12 || g_scan256_ht == 8 ? 6 : g_scan256_ht);
   const uint32_t rows_per_wg = 32u * (uint32_t)ht * kWaves;

@@ -682,6 +682,8 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *   "scan_mfma_pre" 1 = thresholds <= 4 use the low-word prefilter variant of k_hamm64_mfma (default 1)
  *   "scan256_mfma"  256-bit scan on the matrix cores (k_hamm256_mfma): 0 = never, 1 = calls with >= 64
  *                   needle descriptors and >= 4096 rows (default), 2 = always
+ *   "scan256_small" 1 = searches with <= 512 needle descriptors (one ORB needle image) and thresholds <= 40 use the
+ *                   stationary-needle kernel k_hamm256_small (default 1); >= 16 = workgroups of its persistent grid
  *   "scan256_pre"   1 = thresholds <= 40 use the first-128-bit prefilter variant of k_hamm256_mfma (default 1)
  *   "scan_pre_max"  largest threshold served by the low-word-prefilter VALU scan variant (default 7)
  *   "scan_eq_dht1"  1 = dht==1 uses the 64-bit equality variant (default 1)
