@@ -1181,6 +1181,10 @@ int cbh_set_tuning(const char* key, int value) {
     g_video_host_reduce = value;
     return CBH_OK;
   }
+  if (!strcmp(key, "hash_fuse")) {
+    set_hash_fuse(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "hash_regs")) {
     set_hash_regs(value);
     return CBH_OK;

@@ -790,6 +790,13 @@ struct AreaTab {
   int si, di;
   float alpha;
 };
+// the y table of make_area_tab seen from a SOURCE row (k_blur_area_regs<.., FUSE>): a row contributes to one or two
+// consecutive output rows (scale >= 1).  info: bits 0..7 di of the first entry, bit 8 = that entry opens its cell,
+// bit 9 = it closes it, bit 10 = a second entry exists (cell di + 1), bit 11 / 12 = opens / closes for that one
+struct YRow {
+  float a0, a1;
+  int info, pad;
+};
 
 template <int K>
 __global__ __launch_bounds__(kThreads) void k_blur_u8(const unsigned char* __restrict__ imgs, int w, int h,
@@ -1501,7 +1508,15 @@ __global__ __launch_bounds__(256) void k_blur_area_stream(const unsigned char* _
 // 32 <= w <= 2048 (one workgroup spans the row).  GEN = false: w a multiple of 8 and image base / row stride / image
 // stride multiples of 8 (aligned 8-byte loads, no extra shuffles); GEN = true: any width and alignment (+3 v_perm per
 // row and lane, unaligned dword loads).
-template <int K, bool GEN>
+// FUSE (round 3): the workgroup walks the WHOLE image (one strip) and keeps going where the split version hands over to
+// k_tile_hash: the horizontal sums of a step stay in LDS (ipb x kStep x 32 floats), 32 lanes per image carry the vertical
+// INTER_AREA accumulation from step to step in registers -- entries of the y table in table order, `sum = alpha * v`
+// for a cell's first entry, `sum += alpha * v` after it, exactly k_tile_hash's chain; integer ratios: exact block sums
+// -- and round each finished output row into the image's 32 x 32 tile in LDS.  What leaves the kernel is 1024 bytes per
+// image instead of h x 32 floats (0.64 GB per 2 GB of 400x300 input, written and read back); stages 3-6 run from the
+// tiles (k_tiles_hash).  The vertical lanes do their rows right behind the barrier that ends a step, before their
+// next blur rows: no extra barrier.
+template <int K, bool GEN, bool FUSE>
 __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __restrict__ imgs, int w, int h,
                                                         unsigned row_stride, size_t img_stride,
                                                         const AreaTab* __restrict__ xtab,
@@ -1509,7 +1524,8 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
                                                         int steps /* per strip */,
                                                         float* __restrict__ rows /* n * h * 32 */,
                                                         int ipb /* images side by side in the workgroup */,
-                                                        unsigned n_imgs) {
+                                                        unsigned n_imgs, const YRow* __restrict__ yrow = nullptr,
+                                                        int isy = 0, unsigned char* __restrict__ tiles_out = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_fused[];
   constexpr int R = K / 2;
   constexpr int kStep = StreamK<K>::step;
@@ -1525,6 +1541,9 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
   unsigned char* __restrict__ sblur = sblur_all + (size_t)(lane_live ? islot : 0) * (size_t)kStep * (size_t)bp;
   float* __restrict__ salpha = reinterpret_cast<float*>(s_fused + (size_t)ipb * (size_t)kStep * (size_t)bp);
   const int k_end = isx ? 0 : xfirst[32];
+  // FUSE: horizontal sums of the current step and the tiles, behind the weights (16-byte aligned)
+  float* __restrict__ shrow = salpha + ((k_end + 3) & ~3);
+  unsigned char* __restrict__ stile = reinterpret_cast<unsigned char*>(shrow + (FUSE ? (size_t)ipb * kStep * 32 : 0));
   const int strip_out = steps * kStep - 2 * R;
   const int o0 = (int)blockIdx.y * strip_out;
   const int o1 = min(h, o0 + strip_out);
@@ -1613,6 +1632,11 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
   };
 #pragma unroll
   for (int j = 0; j < PF; ++j) load_row(sfirst + j, rawC[j], rawL[j], rawR[j]);
+  // FUSE: vertical INTER_AREA state of lane (image vi, output column vc), carried across the steps
+  const int vi = tid >> 5, vc = tid & 31;
+  const bool vlane = FUSE && vi < ipb;
+  float vsum = 0.f;
+  unsigned vacc = 0u;
   for (int st = 0; st < steps; ++st) {
     const int s0 = sfirst + st * kStep;  // first source row consumed in this step
     if (s0 - R >= o1) break;             // nothing left to output (uniform)
@@ -1658,8 +1682,10 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
         const bool la = ga < n_imgs, lb = two && gb < n_imgs;
         const unsigned char* __restrict__ Sa = sblur_all + ((size_t)ia * kStep + (size_t)ra) * (size_t)bp + acol;
         const unsigned char* __restrict__ Sb = sblur_all + ((size_t)ib * kStep + (size_t)rb_) * (size_t)bp + acol;
-        float* __restrict__ oa = rows + ((size_t)(la ? ga : 0u) * (size_t)h + (size_t)(ob + ra)) * 32 + cc;
-        float* __restrict__ obp = rows + ((size_t)(lb ? gb : 0u) * (size_t)h + (size_t)(ob + rb_)) * 32 + cc;
+        float* __restrict__ oa = FUSE ? shrow + ((size_t)ia * kStep + (size_t)ra) * 32 + cc
+                                      : rows + ((size_t)(la ? ga : 0u) * (size_t)h + (size_t)(ob + ra)) * 32 + cc;
+        float* __restrict__ obp = FUSE ? shrow + ((size_t)ib * kStep + (size_t)rb_) * 32 + cc
+                                       : rows + ((size_t)(lb ? gb : 0u) * (size_t)h + (size_t)(ob + rb_)) * 32 + cc;
         if (isx) {
           unsigned sa = 0, sb = 0;
           if (((isx | bp) & 3) == 0) {  // cells start on dword boundaries: four pixels per v_dot4 (uniform branch)
@@ -1678,27 +1704,38 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
           if (la) *oa = __uint_as_float(sa);
           if (lb) *obp = __uint_as_float(sb);
         } else {
+          // The weights of a cell are (partial first) mid mid ... mid (partial last) -- make_area_tab gives every
+          // interior pixel the same float(1 / cellWidth) -- so three LDS reads replace one per pixel, and the blurred
+          // pixels come as dwords (aligned reads + v_alignbyte_b32 by the cell's byte offset, v_cvt_f32_ubyteN)
+          // instead of one ds_read_u8 each.  The chain itself is unchanged: ba += float(p[k]) * alpha[k], k ascending.
+          const float a_first = al[0], a_mid = al[ank > 1 ? 1 : 0], a_last = al[ank - 1];
+          const unsigned ma = (unsigned)acol & 3u;  // (rows start on 8-byte boundaries of the LDS buffer)
+          const unsigned* __restrict__ A4 = reinterpret_cast<const unsigned*>(Sa - ma);
+          const unsigned* __restrict__ B4 = reinterpret_cast<const unsigned*>(Sb - ma);
           float ba = 0.f, bb = 0.f;
-          int k = 0;
-          for (; k + 8 <= ank; k += 8) {
-            float a[8];
-            unsigned pa[8], pb[8];
+          unsigned lo_a = A4[0], lo_b = B4[0];
+          const int nw = (ank + 3) >> 2;  // words
+          for (int c = 0; c < nw; ++c) {
+            const unsigned hi_a = A4[c + 1], hi_b = B4[c + 1];
+            const unsigned wa = __builtin_amdgcn_alignbyte(hi_a, lo_a, ma), wb = __builtin_amdgcn_alignbyte(hi_b, lo_b, ma);
+            lo_a = hi_a, lo_b = hi_b;
+            const int k0 = 4 * c;
+            if (c > 0 && k0 + 4 < ank) {  // four interior pixels
+              ba += (float)(wa & 0xffu) * a_mid, bb += (float)(wb & 0xffu) * a_mid;
+              ba += (float)((wa >> 8) & 0xffu) * a_mid, bb += (float)((wb >> 8) & 0xffu) * a_mid;
+              ba += (float)((wa >> 16) & 0xffu) * a_mid, bb += (float)((wb >> 16) & 0xffu) * a_mid;
+              ba += (float)(wa >> 24) * a_mid, bb += (float)(wb >> 24) * a_mid;
+            } else {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              a[u] = al[k + u];
-              pa[u] = Sa[k + u];
-              pb[u] = Sb[k + u];
+              for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u;
+                if (k < ank) {
+                  const float wt = k == 0 ? a_first : (k == ank - 1 ? a_last : a_mid);
+                  ba += (float)((wa >> (8 * u)) & 0xffu) * wt;
+                  bb += (float)((wb >> (8 * u)) & 0xffu) * wt;
+                }
+              }
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              ba += (float)pa[u] * a[u];
-              bb += (float)pb[u] * a[u];
-            }
-          }
-          for (; k < ank; ++k) {
-            const float av = al[k];
-            ba += (float)Sa[k] * av;
-            bb += (float)Sb[k] * av;
           }
           if (la) *oa = ba;
           if (lb) *obp = bb;
@@ -1706,7 +1743,70 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
       }
     }
     __syncthreads();  // the blurred rows are consumed before the next step overwrites them
+    if constexpr (FUSE) {
+      // ---- vertical INTER_AREA for the rows this step produced (the barrier above completed them in LDS)
+      const int ob = s0 - R;
+      const int lo = max(0, o0 - ob), hi = min(kStep, o1 - ob);
+      if (vlane) {
+        const float* __restrict__ hr = shrow + (size_t)vi * kStep * 32 + vc;
+        unsigned char* __restrict__ tl_ = stile + (size_t)vi * 1024 + vc;
+        for (int ra = lo; ra < hi; ++ra) {
+          const int y = ob + ra;
+          const float v = hr[ra * 32];
+          if (isx) {  // resizeAreaFast_: exact block sum; 2x2 -> (s+2)>>2, else rint(s * (1.f/area))
+            vacc += __float_as_uint(v);
+            if ((y + 1) % isy == 0) {
+              const unsigned q = (isx == 2 && isy == 2) ? (vacc + 2u) >> 2
+                                                        : (unsigned)__builtin_rintf((float)vacc * (1.f / (float)(isx * isy)));
+              tl_[(y / isy) * 32] = (unsigned char)(q > 255u ? 255u : q);
+              vacc = 0u;
+            }
+          } else {
+            const YRow yr = yrow[y];  // uniform address: a scalar load, issued ahead of the dependent adds
+            const float t0 = yr.a0 * v;
+            vsum = (yr.info & 0x100) ? t0 : vsum + t0;
+            if (yr.info & 0x200) {
+              const float r = __builtin_rintf(vsum);
+              tl_[(yr.info & 0xff) * 32] = (unsigned char)(r < 0.f ? 0.f : r > 255.f ? 255.f : r);
+            }
+            if (yr.info & 0x400) {  // the row straddles two cells
+              const float t1 = yr.a1 * v;
+              vsum = (yr.info & 0x800) ? t1 : vsum + t1;
+              if (yr.info & 0x1000) {
+                const float r = __builtin_rintf(vsum);
+                tl_[((yr.info & 0xff) + 1) * 32] = (unsigned char)(r < 0.f ? 0.f : r > 255.f ? 255.f : r);
+              }
+            }
+          }
+        }
+      }
+    }
   }
+  if constexpr (FUSE) {
+    __syncthreads();
+    // the tiles of this workgroup's images, coalesced (1024 bytes each)
+    for (int i = tid; i < ipb * 256; i += T) {
+      const unsigned g = blockIdx.z * (unsigned)ipb + (unsigned)(i >> 8);
+      if (g < n_imgs)
+        reinterpret_cast<unsigned*>(tiles_out + (size_t)g * 1024)[i & 255] = reinterpret_cast<const unsigned*>(stile)[i];
+    }
+  }
+}
+
+// stages 3-6 from finished 32 x 32 tiles (k_blur_area_regs<.., FUSE>): one workgroup per image
+__global__ __launch_bounds__(kThreads) void k_tiles_hash(const unsigned char* __restrict__ tiles_in,
+                                                         const DctTables* __restrict__ tabs, uint64_t* __restrict__ out,
+                                                         unsigned char* __restrict__ tiles_copy) {
+  __shared__ __attribute__((aligned(16))) float sC[288], sT[288], sY[84];
+  __shared__ __attribute__((aligned(16))) unsigned char tile[1024], sZ[64];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 288; i += kThreads) sC[i] = tabs->C[i];
+  if (tid < 64) sZ[tid] = tabs->zz[tid];
+  reinterpret_cast<unsigned*>(tile)[tid] = reinterpret_cast<const unsigned*>(tiles_in + (size_t)blockIdx.x * 1024)[tid];
+  __syncthreads();
+  if (tiles_copy)
+    reinterpret_cast<unsigned*>(tiles_copy + (size_t)blockIdx.x * 1024)[tid] = reinterpret_cast<const unsigned*>(tile)[tid];
+  hash_from_tile(tile, sC, sZ, sT, sY, out + blockIdx.x, tabs);
 }
 
 __global__ __launch_bounds__(kThreads) void k_tile_hash(const float* __restrict__ rows, int yn,
@@ -2286,6 +2386,7 @@ struct AreaTabsDev {
   AreaTab *x = nullptr, *y = nullptr;
   int *xfirst = nullptr, *yfirst = nullptr;
   int xn = 0, yn = 0;
+  YRow* yrow = nullptr;  // h entries, nullptr when some source row has more than two entries (never for h >= 32)
 };
 std::mutex g_area_mu;
 std::map<std::tuple<int, int, int>, AreaTabsDev> g_area;  // (device, w, h)
@@ -2310,6 +2411,35 @@ int get_area_tabs(int w, int h, AreaTabsDev* out) {
     CBH_HIP(hipMemcpy(d.y, yt.data(), yt.size() * sizeof(AreaTab), hipMemcpyHostToDevice));
     CBH_HIP(hipMemcpy(d.xfirst, xf.data(), 33 * sizeof(int), hipMemcpyHostToDevice));
     CBH_HIP(hipMemcpy(d.yfirst, yf.data(), 33 * sizeof(int), hipMemcpyHostToDevice));
+    {
+      std::vector<YRow> yr((size_t)h, YRow{0.f, 0.f, 0, 0});
+      std::vector<int> cnt((size_t)h, 0);
+      bool ok = true;
+      for (size_t j = 0; j < yt.size() && ok; ++j) {
+        const AreaTab& e = yt[j];
+        if (e.si < 0 || e.si >= h || e.di < 0 || e.di > 31) {
+          ok = false;
+          break;
+        }
+        const bool opens = (int)j == yf[(size_t)e.di], closes = (int)j + 1 == yf[(size_t)e.di + 1];
+        YRow& r = yr[(size_t)e.si];
+        if (cnt[(size_t)e.si] == 0) {
+          r.a0 = e.alpha;
+          r.info = e.di | (opens ? 0x100 : 0) | (closes ? 0x200 : 0);
+        } else if (cnt[(size_t)e.si] == 1 && e.di == (r.info & 0xff) + 1) {
+          r.a1 = e.alpha;
+          r.info |= 0x400 | (opens ? 0x800 : 0) | (closes ? 0x1000 : 0);
+        } else {
+          ok = false;
+        }
+        cnt[(size_t)e.si]++;
+      }
+      for (int y = 0; y < h && ok; ++y) ok = cnt[(size_t)y] >= 1;
+      if (ok) {
+        CBH_HIP(hipMalloc(&d.yrow, (size_t)h * sizeof(YRow)));
+        CBH_HIP(hipMemcpy(d.yrow, yr.data(), (size_t)h * sizeof(YRow), hipMemcpyHostToDevice));
+      }
+    }
     it = g_area.emplace(key, d).first;
   }
   *out = it->second;
@@ -2432,7 +2562,12 @@ int g_hash_stream = 1;  // k_blur_area_stream: 0 off, 1 auto (strips of 3..8 ste
 void set_hash_stream(int v) {
   if (v >= 0) g_hash_stream = v;
 }
+int g_hash_fuse = 1;  // "hash_fuse": 1 = k_blur_area_regs<.., FUSE> (vertical pass + tile in the strip kernel) when the batch
+                      // gives >= 512 workgroups, 2 = always, 0 = never (k_tile_hash reads the rows back)
 int g_hash_regs = 1;  // k_blur_area_regs (blur input from global memory into registers) where its preconditions hold
+void set_hash_fuse(int v) {
+  if (v >= 0 && v <= 2) g_hash_fuse = v;
+}
 void set_hash_regs(int v) {
   if (v >= 0 && v <= 3) g_hash_regs = v;  // 0 off, 1 on (automatic image packing), 2 on / never pack, 3 on / always pack
 }
@@ -2807,7 +2942,9 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
       const size_t fsmem = (size_t)(kBlurRB + K_ - 1) * fpitch + (size_t)(integer ? 0 : at.xn) * sizeof(float);
       const size_t per_chunk_f = std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)h * 128));
       float* d_rowsf = nullptr;
+      unsigned char* d_ftiles = nullptr;  // the fused kernel's 32 x 32 tiles (1 KB per image)
       CBH_HIP(cbh::malloc_async((void**)&d_rowsf, std::min(per_chunk_f, n) * (size_t)h * 32 * sizeof(float), stream));
+      CBH_HIP(cbh::malloc_async((void**)&d_ftiles, std::min(per_chunk_f, n) * 1024, stream));
       for (size_t i0 = 0; i0 < n; i0 += per_chunk_f) {
         const size_t m = std::min(per_chunk_f, n - i0);
         const unsigned char* src = d_imgs + i0 * img_stride;
@@ -2833,12 +2970,34 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
             const int ipb = (Lr <= 128 && pack) ? 256 / Lr : 1;
             const size_t rsmem = (size_t)ipb * kstep * (size_t)(8 * Lr) + (size_t)(integer ? 0 : at.xn) * sizeof(float);
             const unsigned Tr = (unsigned)std::max(64, (ipb * Lr + 63) / 64 * 64);
+            // whole image per workgroup, vertical pass and tile inside the kernel (FUSE) when the batch still fills
+            // the machine that way: at least two workgroups per CU
+            const int ipb_f = std::min(ipb, 8);
+            const int steps_f = (h + 2 * (K_ / 2) + kstep - 1) / kstep;
+            const size_t k_end_f = integer ? 0 : ((size_t)at.xn + 3) & ~(size_t)3;
+            const size_t fsm = (size_t)ipb_f * kstep * (size_t)(8 * Lr) + k_end_f * sizeof(float) +
+                               (size_t)ipb_f * kstep * 32 * sizeof(float) + (size_t)ipb_f * 1024;
+            // (measured, hash_fuse 0 -> 2: 400x300 +14 %, 533x400 +13 %, 641x480 +10 %, 640x480 +3 %, 1024x768 -7 %,
+            // 1080p -19 %: large images spend little in k_tile_hash and lose occupancy to the extra LDS)
+            const bool fuse = g_hash_fuse && fsm <= 160 * 1024 - 1024 && (integer || at.yrow) &&
+                              (g_hash_fuse >= 2 ||
+                               ((m + (size_t)ipb_f - 1) / (size_t)ipb_f >= 512 && (size_t)w * (size_t)h <= 400000));
+            const unsigned Tf_ = (unsigned)std::max(64, (ipb_f * std::max(Lr, 32) + 63) / 64 * 64);
 #define CBH_REGS_(KK, GG)                                                                                    \
   do {                                                                                                       \
+    if (fuse) {                                                                                              \
+      if (fsm > 64 * 1024)                                                                                   \
+        CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_area_regs<KK, GG, true>),           \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsm));                  \
+      hipLaunchKernelGGL((k_blur_area_regs<KK, GG, true>), dim3(1, 1, (unsigned)((m + ipb_f - 1) / ipb_f)),  \
+                         dim3(std::min(256u, Tf_)), fsm, stream, src, w, h, (unsigned)row_stride, img_stride, at.x,       \
+                         at.xfirst, isx, steps_f, (float*)nullptr, ipb_f, (unsigned)m, at.yrow, isy, d_ftiles);      \
+      break;                                                                                                 \
+    }                                                                                                        \
     if (rsmem > 64 * 1024)                                                                                   \
-      CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_area_regs<KK, GG>),                   \
+      CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_area_regs<KK, GG, false>),            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rsmem));                  \
-    hipLaunchKernelGGL((k_blur_area_regs<KK, GG>), dim3(1, gs.y, (unsigned)((m + ipb - 1) / ipb)), dim3(Tr), rsmem, \
+    hipLaunchKernelGGL((k_blur_area_regs<KK, GG, false>), dim3(1, gs.y, (unsigned)((m + ipb - 1) / ipb)), dim3(Tr), rsmem, \
                        stream, src, w, h, (unsigned)row_stride, img_stride, at.x, at.xfirst, isx, steps, d_rowsf,   \
                        ipb, (unsigned)m);                                                                    \
   } while (0)
@@ -2854,8 +3013,12 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
             }
 #undef CBH_REGS_
 #undef CBH_REGS
-            hipLaunchKernelGGL(k_tile_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_rowsf, h, at.y, at.yfirst,
-                               isx, isy, 1, tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
+            if (fuse)
+              hipLaunchKernelGGL(k_tiles_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_ftiles, tabs, d_out + i0,
+                                 d_tiles ? d_tiles + i0 * 1024 : nullptr);
+            else
+              hipLaunchKernelGGL(k_tile_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_rowsf, h, at.y, at.yfirst,
+                                 isx, isy, 1, tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
             continue;
           }
 #define CBH_STREAM(KK)                                                                                      \
@@ -2896,6 +3059,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
       }
       hipError_t ef = hipGetLastError();
       (void)cbh::free_async(d_rowsf, stream);
+      (void)cbh::free_async(d_ftiles, stream);
       CBH_HIP(ef);
       return CBH_OK;
     }

@@ -220,9 +220,12 @@ def test_register_streaming_kernel(gpu, orc):
             dflat = torch.zeros(buf.size + 16, dtype=torch.uint8, device="cuda")
             dflat[base : base + buf.size] = torch.from_numpy(buf.reshape(-1)).cuda()
             d = dflat[base:]
-            for regs, steps in ((1, 3), (1, 8), (0, 3)):
+            # fuse 2: the whole-image form with the vertical INTER_AREA pass and the tile inside the kernel
+            # (k_blur_area_regs<.., FUSE> + k_tiles_hash), forced for any batch size
+            for regs, steps, fuse in ((1, 3, 0), (1, 8, 0), (1, 3, 2), (0, 3, 0)):
                 L.cbh_set_tuning(b"hash_regs", regs)
                 L.cbh_set_tuning(b"hash_stream", steps)
+                L.cbh_set_tuning(b"hash_fuse", fuse)
                 out = torch.zeros(n, dtype=torch.int64, device="cuda")
                 tiles = torch.zeros((n, 32, 32), dtype=torch.uint8, device="cuda")
                 _lib.check(L.cbh_dcthash_tiles_dev(d.data_ptr(), n, w, h, row_stride, img_stride, out.data_ptr(),
@@ -230,11 +233,12 @@ def test_register_streaming_kernel(gpu, orc):
                 got = out.cpu().numpy().view(np.uint64)
                 t = tiles.cpu().numpy()
                 for i in range(n):
-                    assert (t[i] == orc.tile32(np.ascontiguousarray(imgs[i]))).all(), (w, h, regs, steps, i)
-                assert (got == want).all(), (w, h, regs, steps)
+                    assert (t[i] == orc.tile32(np.ascontiguousarray(imgs[i]))).all(), (w, h, regs, steps, fuse, i)
+                assert (got == want).all(), (w, h, regs, steps, fuse)
     finally:
         L.cbh_set_tuning(b"hash_regs", 1)
         L.cbh_set_tuning(b"hash_stream", 1)
+        L.cbh_set_tuning(b"hash_fuse", 1)
 
 
 def test_hash_random_geometries_and_strides(gpu, orc):
