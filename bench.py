@@ -686,18 +686,29 @@ def cpu_baseline(args, torch, imgs, state, n, dhts):
     ids = np.arange(1, n + 1, dtype=np.uint32)
     budget = args.cpu_seconds
     out = {"cores": cores}
-    # -- hash leg (port): bounded sample of the images, one image per task over all cores
+    # -- hash leg: bounded sample of the images, one slice per task over all cores.  oracle/fast_hash.c is the port
+    # written as a tuned CPU library does stages 1-2 (running column sums, compiler-vectorised, AVX2 clone) -- not OpenCV
+    # itself, which cannot be built here, but no longer the scalar per-pixel restatement either; that one
+    # (oracle/cbird_oracle.c) is timed on a small sample beside it and must give the same hashes.
     m_img = min(len(imgs), 32768)
     sample = imgs[:m_img].cpu().numpy()
     t0 = time.perf_counter()
     parts = np.array_split(np.arange(m_img), cores * 4)
     with ThreadPoolExecutor(cores) as ex:
-        hs = list(ex.map(lambda ix: orc.dcthash64_batch(sample[ix]) if len(ix) else np.zeros(0, np.uint64), parts))
+        hs = list(ex.map(lambda ix: orc.dcthash64_fast256_batch(sample[ix]) if len(ix) else np.zeros(0, np.uint64), parts))
     t_hash = time.perf_counter() - t0
     cpu_h = np.concatenate(hs)
+    m_sc = min(m_img, 16 * cores)
+    t0 = time.perf_counter()
+    parts_sc = np.array_split(np.arange(m_sc), cores)
+    with ThreadPoolExecutor(cores) as ex:
+        hs_sc = list(ex.map(lambda ix: orc.dcthash64_batch(sample[ix]) if len(ix) else np.zeros(0, np.uint64), parts_sc))
+    t_sc = time.perf_counter() - t0
     out["hash_images_per_s"] = m_img / t_hash
-    out["hash_kind"] = "port"
-    out["hash_agrees_with_gpu"] = bool((cpu_h == hashes[:m_img]).all())
+    out["hash_kind"] = "port, vectorised (oracle/fast_hash.c: running column sums, gcc -O3 + AVX2 clone); not OpenCV"
+    out["hash_images_per_s_scalar_port"] = m_sc / t_sc
+    out["hash_agrees_with_gpu"] = bool((cpu_h == hashes[:m_img]).all() and
+                                       (np.concatenate(hs_sc) == hashes[:m_sc]).all())
     # -- find leg
     use_ref = oracle.ref_available()
     rng = np.random.default_rng(args.seed)

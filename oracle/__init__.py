@@ -319,6 +319,19 @@ class Oracle:
             raise ValueError(f"orc_dcthash64 rc={rc}")
         return int(o[0])
 
+    def dcthash64_fast256_batch(self, imgs):
+        """oracle/fast_hash.c: the CPU-baseline form of dctHash64 for 256 x 256 images (same hashes as dcthash64_batch)"""
+        imgs = np.ascontiguousarray(imgs, np.uint8)
+        n, h, w = imgs.shape
+        if (h, w) != (256, 256):
+            raise ValueError("fast256: 256 x 256 images only")
+        o = np.zeros(n, np.uint64)
+        f = self.L.orc_dcthash64_fast256_batch
+        f.argtypes = [np.ctypeslib.ndpointer(np.uint8, flags="C"), C.c_size_t, C.c_size_t, C.c_size_t, _u64p]
+        f.restype = C.c_int
+        f(imgs.reshape(-1), n, w, w * h, o)
+        return o
+
     def dcthash64_batch(self, imgs):
         imgs = np.ascontiguousarray(imgs, np.uint8)
         n, h, w = imgs.shape

@@ -335,3 +335,22 @@ def after_first_rect(orc, img, x, y, s):
     work = img.copy()
     orc.dcthash64_rect_inplace(work, x, y, s, s)
     return work[y:y + s, x:x + s]
+
+
+def test_fast_cpu_hash_equals_the_port(orc):
+    """oracle/fast_hash.c (bench.py's CPU baseline for the hash leg: running column sums, vectorised) gives the hashes of
+    the per-pixel restatement, under both evaluations of stages 3/5, incl. flat, extreme and striped images"""
+    from cbird_amd import synth
+
+    rng = np.random.default_rng(5)
+    imgs = np.concatenate([synth.make_images(40, seed=9), rng.integers(0, 256, (24, 256, 256), dtype=np.uint8)])
+    imgs[0] = 0
+    imgs[1] = 255
+    imgs[2, :, ::2] = 255
+    imgs[3] = (np.arange(256)[None, :] * 7 + np.arange(256)[:, None] * 3) % 256
+    try:
+        for v in (1, 0):
+            orc.set_hash_variant(v)
+            assert (orc.dcthash64_fast256_batch(imgs) == orc.dcthash64_batch(imgs)).all(), v
+    finally:
+        orc.set_hash_variant(1)
