@@ -83,6 +83,7 @@ _SIGS = {
     "cbh_index_images": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _vp, C.c_int]),
     "cbh_orb_set_pattern": (C.c_int, [_vp]),
+    "cbh_orb_retain_best_dev": (C.c_int, [_vp, C.c_uint32, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp]),
     "cbh_orb": (C.c_int, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
     "cbh_orb_describe": (C.c_int, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "cbh_orb_dev": (C.c_int, [_vp, _sz, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp]),

@@ -144,7 +144,7 @@ inline void gpuMakeKeyPoints(const cv::Mat& cvImg, int numKeyPoints, KeyPointLis
   int cap = numKeyPoints + 64;
   std::vector<cbh_keypoint> kp;
   uint32_t count = 0;
-  for (;;) {  // ties in retainBest are never cut: a count above the capacity asks for a second call
+  for (;;) {  // retainBest can keep ties beyond n: a count above the capacity asks for a second call
     kp.resize(size_t(cap));
     const int rc = cbh_orb(p.base, bytes, 1, &off, &p.w, &p.h, &p.step, numKeyPoints, cap, kp.data(), nullptr, nullptr,
                            &count, hashDevice());

@@ -85,6 +85,7 @@ void set_scan256_mfma(int on);  // <0 = keep; 2 = force for any size
 
 int g_hash_mfma_set(int v);  // dcthash.hip
 extern int g_fdct_host_vote, g_video_host_reduce;  // fdct.hip: 1 = round-1 host reductions (parity tests)
+void set_orb_retain_order(int v);  // orb.hip: 1 (default) retainBest in libstdc++'s order, 0 canonical (ties kept, raster order)
 void set_hash_fuse(int v);      // dcthash.hip: vertical INTER_AREA pass + tile inside k_blur_area_regs (0 never, 1 auto, 2 always)
 void set_hash_regs(int v);      // dcthash.hip: register-streaming general-geometry kernel where applicable (default 1)
 void set_hash_div(int v);       // dcthash.hip: k_dcthash_256 divide-by-49 form, 1 = float magic (default), 0 = integer SDWA

@@ -1185,6 +1185,11 @@ int cbh_set_tuning(const char* key, int value) {
     set_hash_fuse(value);
     return CBH_OK;
   }
+  if (!strcmp(key, "orb_retain_order")) {
+    if (value != 0 && value != 1) return CBH_E_INVAL;
+    set_orb_retain_order(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "hash_regs")) {
     set_hash_regs(value);
     return CBH_OK;

@@ -4,7 +4,8 @@
 // for a batch of grey images of any sizes resident in HBM (cbird feeds <= 400 px on the longest side,
 // /root/reference/src/scanner.cpp:876).  Bit-exact against oracle/orb_oracle.c, which carries the statement of what
 // is and is not pinned against the cbird binary (the learned rBRIEF pattern is an INPUT: cbh_orb_set_pattern;
-// retainBest's tie rule is canonical: ties kept, raster order).
+// retainBest leaves the survivors as libstdc++'s nth_element + partition do, or -- orb_retain_order = 0 -- keeps every
+// tie in raster order).
 //
 // Decomposition (one launch each, all images of the batch at once; nothing visits the host between them):
 //   k_orb_level0                    level 0 = the caller's image copied into the pyramid buffer WITH its reflect-101
@@ -404,10 +405,200 @@ __device__ __forceinline__ unsigned float_key(float f) {  // order-preserving: l
   return (b & 0x80000000u) ? ~b : b | 0x80000000u;
 }
 
+// ---- KeyPointsFilter::retainBest in the order libstdc++ leaves the survivors (tuning key orb_retain_order = 1) -----
+// OpenCV 2.4's retainBest is std::nth_element(begin, begin + n, end, response greater), then std::partition of the tail
+// on `response >= keypoints[n - 1].response` (oracle/retain_stl.cpp quotes it).  Which ties survive and in which order
+// therefore follow from the C++ library.  This is libstdc++'s introselect restated for one workgroup: the Hoare
+// partition step is a PAIRING -- the k-th element from the left that is not greater than the pivot is exchanged with
+// the k-th element from the right that the pivot is not greater than, for as long as the first lies left of the second
+// -- so the two stop lists are built with one prefix scan per 256 elements, the exchanges happen in parallel and the cut
+// is where the lists cross.  The O(1) steps (median of three, the final insertion sort of <= 3 elements) and the
+// depth-limit fallback (heap select, which real inputs do not reach) run on thread 0.  Keys and the raster positions
+// they came from travel together; equal keys are never reordered except as the library would.
+struct RetainScratch {
+  float* key;
+  unsigned* ref;
+  unsigned* lp;  // stop positions from the left, ascending
+  unsigned* ra;  // stop positions from the right, ASCENDING (read backwards)
+};
+__device__ __forceinline__ void kr_swap(float* key, unsigned* ref, int a, int b) {
+  const float k = key[a];
+  key[a] = key[b], key[b] = k;
+  const unsigned r = ref[a];
+  ref[a] = ref[b], ref[b] = r;
+}
+// __move_median_to_first(result, a, b, c) under comp(x, y) = key[x] > key[y]
+__device__ void stl_median_to_first(float* key, unsigned* ref, int result, int a, int b, int c) {
+  const float ka = key[a], kb = key[b], kc = key[c];
+  int pick;
+  if (ka > kb)
+    pick = kb > kc ? b : (ka > kc ? c : a);
+  else
+    pick = ka > kc ? a : (kb > kc ? c : b);
+  kr_swap(key, ref, result, pick);
+}
+__device__ void stl_insertion_sort(float* key, unsigned* ref, int first, int last) {
+  if (first == last) return;
+  for (int i = first + 1; i != last; ++i) {
+    const float vk = key[i];
+    const unsigned vr = ref[i];
+    if (vk > key[first]) {  // move_backward(first, i, i + 1)
+      for (int j = i; j > first; --j) key[j] = key[j - 1], ref[j] = ref[j - 1];
+      key[first] = vk, ref[first] = vr;
+    } else {  // __unguarded_linear_insert
+      int hole = i, next = i - 1;
+      while (vk > key[next]) {
+        key[hole] = key[next], ref[hole] = ref[next];
+        hole = next, --next;
+      }
+      key[hole] = vk, ref[hole] = vr;
+    }
+  }
+}
+__device__ void stl_push_heap(float* key, unsigned* ref, int first, int hole, int top, float vk, unsigned vr) {
+  int parent = (hole - 1) / 2;
+  while (hole > top && key[first + parent] > vk) {
+    key[first + hole] = key[first + parent], ref[first + hole] = ref[first + parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  key[first + hole] = vk, ref[first + hole] = vr;
+}
+__device__ void stl_adjust_heap(float* key, unsigned* ref, int first, int hole, int len, float vk, unsigned vr) {
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (key[first + child] > key[first + child - 1]) child--;
+    key[first + hole] = key[first + child], ref[first + hole] = ref[first + child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    key[first + hole] = key[first + child - 1], ref[first + hole] = ref[first + child - 1];
+    hole = child - 1;
+  }
+  stl_push_heap(key, ref, first, hole, top, vk, vr);
+}
+__device__ void stl_heap_select(float* key, unsigned* ref, int first, int middle, int last) {
+  const int len = middle - first;
+  if (len >= 2)  // __make_heap
+    for (int parent = (len - 2) / 2;; --parent) {
+      stl_adjust_heap(key, ref, first, parent, len, key[first + parent], ref[first + parent]);
+      if (parent == 0) break;
+    }
+  for (int i = middle; i < last; ++i)
+    if (key[i] > key[first]) {  // __pop_heap(first, middle, i)
+      const float vk = key[i];
+      const unsigned vr = ref[i];
+      key[i] = key[first], ref[i] = ref[first];
+      stl_adjust_heap(key, ref, first, 0, len, vk, vr);
+    }
+}
+// __unguarded_partition(lo, hi, pivot value p) by the whole workgroup; returns the cut (uniform)
+__device__ int stl_partition(float* key, unsigned* ref, int lo, int hi, float p, const RetainScratch& rs, int* s_w) {
+  const int tid = (int)threadIdx.x;
+  int nL = 0, nR = 0;
+  for (int c = lo; c < hi; c += 256) {
+    const int i = c + tid;
+    int isL = 0, isR = 0;
+    if (i < hi) {
+      const float k = key[i];
+      isL = !(k > p), isR = !(p > k);
+    }
+    int tot;
+    const int ex = block_excl_scan(isL | (isR << 16), s_w, &tot);
+    if (isL) rs.lp[nL + (ex & 0xffff)] = (unsigned)i;
+    if (isR) rs.ra[nR + (ex >> 16)] = (unsigned)i;
+    nL += tot & 0xffff, nR += tot >> 16;
+  }
+  __syncthreads();
+  const int m = min(nL, nR);
+  int mine = 0;
+  for (int k = tid; k < m; k += 256) mine += rs.lp[k] < rs.ra[nR - 1 - k];
+  int K;
+  (void)block_excl_scan(mine, s_w, &K);  // the condition holds for a prefix of k: K exchanges
+  for (int k = tid; k < K; k += 256) kr_swap(key, ref, (int)rs.lp[k], (int)rs.ra[nR - 1 - k]);
+  const int rprev = K > 0 ? (int)rs.ra[nR - K] : hi;
+  const int cut = (K < nL && (int)rs.lp[K] < rprev) ? (int)rs.lp[K] : rprev;
+  __syncthreads();
+  return cut;
+}
+// retainBest(n_points) on key[0, cnt) / ref[0, cnt); returns the new size (uniform).  depth_limit < 0: 2 * lg(cnt)
+__device__ int stl_retain_best(float* key, unsigned* ref, int cnt, int n_points, int depth_limit,
+                               const RetainScratch& rs, int* s_w) {
+  if (n_points < 0 || cnt <= n_points) return cnt;
+  if (n_points == 0) return 0;
+  const int tid = (int)threadIdx.x;
+  int first = 0, last = cnt;
+  int depth = depth_limit >= 0 ? depth_limit : 2 * (31 - __clz(cnt));
+  bool heap = false;
+  while (last - first > 3) {
+    if (depth == 0) {
+      if (tid == 0) {
+        stl_heap_select(key, ref, first, n_points + 1, last);
+        kr_swap(key, ref, first, n_points);
+      }
+      heap = true;
+      break;
+    }
+    --depth;
+    if (tid == 0) stl_median_to_first(key, ref, first, first + 1, first + (last - first) / 2, last - 1);
+    __syncthreads();
+    const int cut = stl_partition(key, ref, first + 1, last, key[first], rs, s_w);
+    if (cut <= n_points)
+      first = cut;
+    else
+      last = cut;
+  }
+  if (!heap && tid == 0) stl_insertion_sort(key, ref, first, last);
+  __syncthreads();
+  // std::partition(begin + n, end, response >= keypoints[n - 1].response): the k-th failing element from the left
+  // changes places with the k-th passing one from the right; T passing elements end up in front
+  const float thr = key[n_points - 1];
+  int mine = 0;
+  for (int i = n_points + tid; i < cnt; i += 256) mine += key[i] >= thr;
+  int T;
+  (void)block_excl_scan(mine, s_w, &T);
+  const int mid = n_points + T;
+  int nA = 0, nB = 0;
+  for (int c = n_points; c < cnt; c += 256) {
+    const int i = c + tid;
+    int isA = 0, isB = 0;
+    if (i < cnt) {
+      const bool pass = key[i] >= thr;
+      isA = i < mid && !pass, isB = i >= mid && pass;
+    }
+    int tot;
+    const int ex = block_excl_scan(isA | (isB << 16), s_w, &tot);
+    if (isA) rs.lp[nA + (ex & 0xffff)] = (unsigned)i;
+    if (isB) rs.ra[nB + (ex >> 16)] = (unsigned)i;
+    nA += tot & 0xffff, nB += tot >> 16;
+  }
+  __syncthreads();
+  for (int k = tid; k < nA; k += 256) kr_swap(key, ref, (int)rs.lp[k], (int)rs.ra[nB - 1 - k]);  // nA == nB
+  __syncthreads();
+  return mid;
+}
+
+__global__ __launch_bounds__(256) void k_retain_best(const float* __restrict__ resp, int cnt, int n_points,
+                                                     int depth_limit, RetainScratch rs, unsigned* __restrict__ order,
+                                                     unsigned* __restrict__ out_count) {
+  __shared__ int s_w[4];
+  const int tid = (int)threadIdx.x;
+  for (int i = tid; i < cnt; i += 256) rs.key[i] = resp[i], rs.ref[i] = (unsigned)i;
+  __syncthreads();
+  const int k = stl_retain_best(rs.key, rs.ref, cnt, n_points, depth_limit, rs, s_w);
+  for (int i = tid; i < k; i += 256) order[i] = rs.ref[i];
+  if (tid == 0) *out_count = (unsigned)k;
+}
+
 __global__ __launch_bounds__(256) void k_orb_select(const OrbImage* __restrict__ images,
                                                     const unsigned char* __restrict__ pyr,
                                                     const unsigned char* __restrict__ scores,
-                                                    OrbCand* __restrict__ cand, unsigned* __restrict__ level_counts) {
+                                                    OrbCand* __restrict__ cand, unsigned* __restrict__ level_counts,
+                                                    int retain_order, RetainScratch rs_all,
+                                                    OrbCand* __restrict__ cand_tmp) {
   __shared__ int s_hist[256];
   __shared__ int s_w[4];
   __shared__ int s_pick[2];
@@ -462,6 +653,33 @@ __global__ __launch_bounds__(256) void k_orb_select(const OrbImage* __restrict__
     c0 += tot;
   }
   __syncthreads();
+  const unsigned char* __restrict__ img = pyr + im.poff[l];
+  const unsigned ip = im.pitch[l];
+  int c2 = 0;
+  if (retain_order == 1) {
+    // -- (b'-e') the same three steps with the survivors in libstdc++'s order: retainBest(2N) on the FAST score,
+    //    HarrisResponses, retainBest(N); the list is then gathered through cand_tmp
+    const RetainScratch rs = {rs_all.key + im.coff[l], rs_all.ref + im.coff[l], rs_all.lp + im.coff[l],
+                              rs_all.ra + im.coff[l]};
+    OrbCand* __restrict__ tmp = cand_tmp + im.coff[l];
+    for (int i = tid; i < c0; i += 256) rs.key[i] = cd[i].response, rs.ref[i] = (unsigned)i;
+    __syncthreads();
+    const int k1 = stl_retain_best(rs.key, rs.ref, c0, 2 * N, -1, rs, s_w);
+    for (int i = tid; i < k1; i += 256) {
+      const unsigned r = rs.ref[i];
+      rs.key[i] = harris_at(img, ip, cd[r].x, cd[r].y);
+    }
+    __syncthreads();
+    c2 = stl_retain_best(rs.key, rs.ref, k1, N, -1, rs, s_w);
+    for (int i = tid; i < c2; i += 256) {
+      OrbCand c = cd[rs.ref[i]];
+      c.response = rs.key[i];
+      tmp[i] = c;
+    }
+    __syncthreads();
+    for (int i = tid; i < c2; i += 256) cd[i] = tmp[i];
+    __syncthreads();
+  } else {
   // -- (b) retainBest(2N): every score >= the 2N-th best survives
   {
     // bins in descending order: thread t holds bin 255 - t (bin 0 is never counted)
@@ -491,8 +709,6 @@ __global__ __launch_bounds__(256) void k_orb_select(const OrbImage* __restrict__
     c1 += tot;
   }
   __syncthreads();  // the candidate list is visible to the whole workgroup (global memory, same workgroup)
-  const unsigned char* __restrict__ img = pyr + im.poff[l];
-  const unsigned ip = im.pitch[l];
   for (int i = tid; i < c1; i += 256) cd[i].response = harris_at(img, ip, cd[i].x, cd[i].y);
   __syncthreads();
   // -- (d) retainBest(N) on the Harris response: radix select of the N-th best key, MSB first
@@ -525,7 +741,6 @@ __global__ __launch_bounds__(256) void k_orb_select(const OrbImage* __restrict__
     key_thr = prefix;
   }
   // -- (e) ordered compaction in place (a write never passes the reads of its own or a later chunk)
-  int c2 = 0;
   for (int i0 = 0; i0 < c1; i0 += 256) {
     const int i = i0 + tid;
     OrbCand c;
@@ -540,6 +755,7 @@ __global__ __launch_bounds__(256) void k_orb_select(const OrbImage* __restrict__
     c2 += tot;
   }
   __syncthreads();
+  }  // retain_order
   if (tid == 0) *out_count = (unsigned)c2;
   // -- (f) orientation: IC_Angle over the circular patch of radius 15, HALF a wave per keypoint, no loop: lane =
   //        (row pair +-v, v = (lane & 31) >> 1; 16-column segment u0 = -16 + 16 * (lane & 1)) -- eight unaligned dword
@@ -779,6 +995,8 @@ __global__ __launch_bounds__(256) void k_orb_describe_given(const OrbImage* __re
   if (lane < 4) reinterpret_cast<unsigned long long*>(out_desc + (size_t)k * 32)[lane] = bits[lane];
 }
 
+int g_retain_order = 1;  // "orb_retain_order": 1 (default) what libstdc++'s nth_element + partition leave -- cbird's Linux
+                         // builds; 0 canonical (every tie kept, raster order)
 std::mutex g_pat_mu;
 OrbPattern g_pattern;
 bool g_have_pattern = false;
@@ -876,6 +1094,31 @@ OrbPlan make_plan(size_t n, const uint64_t* img_off, const uint32_t* img_w, cons
 
 }  // namespace
 
+void set_orb_retain_order(int v) {
+  if (v == 0 || v == 1) g_retain_order = v;
+}
+
+int launch_retain_best(const float* d_resp, uint32_t cnt, int n_points, int depth_limit, uint32_t* d_order,
+                       uint32_t* d_count, hipStream_t s) {
+  RetainScratch rs = {nullptr, nullptr, nullptr, nullptr};
+  void* block = nullptr;
+  const size_t slots = (size_t)cnt + 1;
+  hipError_t e = cbh::malloc_async(&block, slots * 16, s);
+  if (e == hipSuccess) {
+    rs.key = (float*)block, rs.ref = (unsigned*)block + slots, rs.lp = (unsigned*)block + 2 * slots,
+    rs.ra = (unsigned*)block + 3 * slots;
+    hipLaunchKernelGGL(k_retain_best, dim3(1), dim3(256), 0, s, d_resp, (int)cnt, n_points, depth_limit, rs, d_order,
+                       d_count);
+    e = hipGetLastError();
+  }
+  if (block) (void)cbh::free_async(block, s);
+  if (e != hipSuccess) {
+    set_last_error("orb retain_best", e);
+    return e == hipErrorOutOfMemory ? CBH_E_NOMEM : CBH_E_HIP;
+  }
+  return CBH_OK;
+}
+
 int orb_set_pattern(const int8_t* xy) {
   if (!xy) return CBH_E_INVAL;
   for (int i = 0; i < 1024; ++i)
@@ -907,9 +1150,12 @@ int launch_orb(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const u
   const std::vector<OrbImage>& images = pl.images;
   OrbImage* d_images = nullptr;
   unsigned char *d_pyr = nullptr, *d_sc = nullptr;
-  OrbCand* d_cand = nullptr;
+  OrbCand *d_cand = nullptr, *d_cand_tmp = nullptr;
   unsigned* d_lc = nullptr;
   int* d_pat = nullptr;
+  void* d_retain = nullptr;
+  const int retain_order = g_retain_order;
+  RetainScratch rs = {nullptr, nullptr, nullptr, nullptr};
   hipError_t e = hipSuccess;
   auto alloc = [&](void** p, size_t bytes) {
     if (e == hipSuccess) e = cbh::malloc_async(p, std::max<size_t>(bytes, 256), s);
@@ -918,6 +1164,13 @@ int launch_orb(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const u
   alloc((void**)&d_pyr, pyr_bytes + 64);
   alloc((void**)&d_sc, sc_bytes + 64);
   alloc((void**)&d_cand, (cands + 1) * sizeof(OrbCand));
+  if (retain_order == 1) {  // keys, raster positions and the two stop lists of every level + the gathered list
+    alloc((void**)&d_cand_tmp, (cands + 1) * sizeof(OrbCand));
+    alloc(&d_retain, (cands + 1) * 16);
+    if (e == hipSuccess)
+      rs.key = (float*)d_retain, rs.ref = (unsigned*)d_retain + (cands + 1), rs.lp = (unsigned*)d_retain + 2 * (cands + 1),
+      rs.ra = (unsigned*)d_retain + 3 * (cands + 1);
+  }
   alloc((void**)&d_lc, n * kLevels * sizeof(unsigned));
   alloc((void**)&d_pat, sizeof pat);
   int rc = CBH_OK;
@@ -936,7 +1189,8 @@ int launch_orb(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const u
                          dim3((unsigned)((max_h[l] + 2 * kBorderY + kResizeRows - 1) / kResizeRows), ny), dim3(256),
                          (size_t)max_pitch * 8, s, d_images, l, d_pyr);
     if (max_tiles) hipLaunchKernelGGL(k_orb_fast, dim3(max_tiles, ny), dim3(256), 0, s, d_images, d_pyr, d_sc);
-    hipLaunchKernelGGL(k_orb_select, dim3(kLevels, ny), dim3(256), 0, s, d_images, d_pyr, d_sc, d_cand, d_lc);
+    hipLaunchKernelGGL(k_orb_select, dim3(kLevels, ny), dim3(256), 0, s, d_images, d_pyr, d_sc, d_cand, d_lc,
+                       retain_order, rs, d_cand_tmp);
     if (d_desc && max_bwg) {
       GaussK g;
       gauss7_kernel(g.k);
@@ -950,7 +1204,8 @@ int launch_orb(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const u
     set_last_error("orb", e);
     rc = e == hipErrorOutOfMemory ? CBH_E_NOMEM : CBH_E_HIP;
   }
-  for (void* p : {(void*)d_images, (void*)d_pyr, (void*)d_sc, (void*)d_cand, (void*)d_lc, (void*)d_pat})
+  for (void* p : {(void*)d_images, (void*)d_pyr, (void*)d_sc, (void*)d_cand, (void*)d_lc, (void*)d_pat,
+                  (void*)d_cand_tmp, d_retain})
     if (p) (void)cbh::free_async(p, s);
   return rc;
 }
@@ -1065,6 +1320,25 @@ int launch_orb_describe(const uint8_t* d_imgs, size_t n, const uint64_t* img_off
 extern "C" {
 
 int cbh_orb_set_pattern(const int8_t* xy) { return cbh::orb_set_pattern(xy); }
+
+int cbh_orb_retain_best_dev(const void* d_responses, uint32_t count, int n_points, int depth_limit, void* d_order,
+                            void* d_count, int device, void* stream) {
+  if (!cbh::device_usable(device)) return CBH_E_NODEVICE;
+  if (!d_order || !d_count || (count && !d_responses) || count > (1u << 30)) return CBH_E_INVAL;
+  cbh::DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = cbh::launch_retain_best((const float*)d_responses, count, n_points, depth_limit, (uint32_t*)d_order,
+                                   (uint32_t*)d_count, s);
+  if (rc == CBH_OK && !s) {
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+      cbh::set_last_error("orb retain_best sync", e);
+      rc = CBH_E_HIP;
+    }
+  }
+  return rc;
+}
 
 int cbh_orb_dev(const void* d_imgs, size_t n, const uint64_t* img_off, const uint32_t* img_w, const uint32_t* img_h,
                 const uint32_t* img_row_stride, int nfeatures, int kp_cap, void* d_kp, void* d_kp_after, void* d_desc,

@@ -74,7 +74,8 @@ def _pack(images):
 def orb(images, num_keypoints: int = 400, descriptors: bool = True, device: int = 0, kp_cap: int | None = None):
     """makeKeyPoints (+ makeKeyPointDescriptors) for a list of 2-D uint8 grey images of any sizes.
     Returns a list of (keypoints KP_DTYPE[k], keypoints_xy_after_compute float32[k, 2] | None, descriptors
-    uint8[k, 32] | None).  Ties in retainBest are never cut, so an image can return more than num_keypoints."""
+    uint8[k, 32] | None).  retainBest can keep ties at the cut (include/cbird_hip.h, orb_retain_order), so an image can return more than
+    num_keypoints."""
     n = len(images)
     if n == 0:
         return []

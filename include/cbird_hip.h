@@ -126,23 +126,35 @@ int cbh_keypoint_hashes_dev(void* d_imgs, size_t n, const uint64_t* img_off, con
  * (7x7, k 0.04), retainBest(N), intensity-centroid orientation (cv::fastAtan2), 7x7 sigma-2 Gaussian, rotated test
  * pairs.  n grey images of any sizes in one buffer (image i: img_w[i] x img_h[i] at byte img_off[i], pitch
  * img_row_stride[i]; cbird feeds <= 400 px on the longest side, src/scanner.cpp:876).
- *   kp[i*kp_cap + j]       j-th keypoint of image i as detect() returns it: pyramid level by level, raster order
- *                          inside a level; x, y in image coordinates, size = 31 * 1.2^octave, angle in degrees
+ *   kp[i*kp_cap + j]       j-th keypoint of image i as detect() returns it: pyramid level by level, inside a level in
+ *                          the retainBest order selected below; x, y in image coordinates, size = 31 * 1.2^octave,
+ *                          angle in degrees
  *   kp_after[2*(i*kp_cap+j)]  (optional) the keypoint's x, y as compute() leaves them in cbird's non-const list
  *                          (pt * (1/scale) * scale): what Media::makeKeyPointHashes sees when both algorithms run
  *   desc[(i*kp_cap+j)*32]  (optional) its descriptor row, the layout CvFeaturesIndex stores
  *   counts[i]              keypoints found for image i; only the first kp_cap are written -- a count above kp_cap
- *                          means the call must be repeated with more room (ties are never cut: see below)
- * Two things differ from the cbird binary by necessity and are stated in oracle/orb_oracle.c: retainBest's handling of
- * EQUAL responses depends on the C++ library's nth_element -- here every keypoint whose response is >= the n-th best
- * is kept; and the 256 test pairs are a learned table inside OpenCV (bit_pattern_31_), an input here:
- * cbh_orb_set_pattern(xy) takes its 1024 integers (x0, y0, x1, y1 per bit, each within [-15, 15]).  Without a pattern
- * a call that asks for descriptors fails with CBH_E_INVAL; detection alone (desc == NULL) needs none. */
+ *                          means the call must be repeated with more room (ties at a cut can be kept: see below)
+ * Two things depend on what the cbird binary was built with and are stated in oracle/orb_oracle.c.
+ * (1) KeyPointsFilter::retainBest is std::nth_element + std::partition: which of several keypoints with EQUAL response
+ * survive a cut, and the ORDER of the survivors, follow from the C++ library.  cbh_set_tuning("orb_retain_order", v):
+ *   1 (default)  what libstdc++ (the Linux builds' library) leaves: its introselect and partition restated on the
+ *                device and checked against the real std::nth_element (oracle/retain_stl.cpp);
+ *   0            canonical: every keypoint whose response is >= the n-th best is kept, raster order inside a level
+ *                (a superset of what any library leaves).
+ * cbh_orb_retain_best_dev is that one step on its own: count float responses in device memory -> d_order (uint32, room
+ * for count) = the original positions of the survivors of retainBest(n_points) in the order they are left, *d_count =
+ * how many.  depth_limit < 0 is nth_element's own 2 * lg(count); >= 0 enters the selection with that limit (its
+ * heap-select branch, which only adversarial orders reach).
+ * (2) The 256 test pairs are a learned table inside OpenCV (bit_pattern_31_), an input here: cbh_orb_set_pattern(xy)
+ * takes its 1024 integers (x0, y0, x1, y1 per bit, each within [-15, 15]).  Without a pattern a call that asks for
+ * descriptors fails with CBH_E_INVAL; detection alone (desc == NULL) needs none. */
 typedef struct cbh_keypoint {
   float x, y, size, angle, response;
   int32_t octave;
 } cbh_keypoint;
 int cbh_orb_set_pattern(const int8_t* xy);
+int cbh_orb_retain_best_dev(const void* d_responses, uint32_t count, int n_points, int depth_limit, void* d_order,
+                            void* d_count, int device, void* stream);
 int cbh_orb(const uint8_t* imgs, size_t imgs_bytes, size_t n, const uint64_t* img_off, const uint32_t* img_w,
             const uint32_t* img_h, const uint32_t* img_row_stride, int nfeatures, int kp_cap, cbh_keypoint* kp,
             float* kp_after, uint8_t* desc, uint32_t* counts, int device);

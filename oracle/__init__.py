@@ -30,8 +30,10 @@ _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 
 def build(force: bool = False) -> None:
     """Compile the C restatement (and, when /root/reference exists, oracle/_ref)."""
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE)
+            if (f.endswith(".c") or f == "retain_stl.cpp" or f == "Makefile")]
     need = force or not os.path.exists(_ORACLE_SO) or (
-        os.path.getmtime(_ORACLE_SO) < os.path.getmtime(os.path.join(_HERE, "cbird_oracle.c")))
+        os.path.getmtime(_ORACLE_SO) < max(os.path.getmtime(f) for f in srcs))
     need_ref = os.path.isdir("/root/reference/src/tree") and (
         force or not os.path.exists(_REF_SO)
         or os.path.getmtime(_REF_SO) < os.path.getmtime(os.path.join(_HERE, "ref_wrap.cpp")))
@@ -911,6 +913,25 @@ class OrbOracle:
         L.orc_orb_compute.restype = C.c_long
         L.orc_orb_compute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_long, C.c_void_p]
         L.orc_orb_descriptor.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        L.orc_retain_best_stl.restype = C.c_long
+        L.orc_retain_best_stl.argtypes = [_f32p, C.c_long, C.c_int, C.c_int, _i32p]
+        L.orc_orb_set_retain_order.argtypes = [C.c_int]
+        L.orc_orb_set_retain_order.restype = None
+
+    def set_retain_order(self, mode: int) -> None:
+        """0: canonical (every tie kept, raster order); 1: what libstdc++'s nth_element + partition leave
+        (oracle/retain_stl.cpp).  Process-wide, like the pattern."""
+        self.L.orc_orb_set_retain_order(int(mode))
+
+    def retain_best_stl(self, responses, n_points, depth_limit=-1):
+        """KeyPointsFilter::retainBest on the real std::nth_element / std::partition: the original positions of the
+        survivors, in the order they are left.  depth_limit >= 0 enters introselect with that limit (heap-select
+        branch)."""
+        r = np.ascontiguousarray(responses, np.float32)
+        order = np.zeros(max(1, len(r)), np.int32)
+        k = self.L.orc_retain_best_stl(r if len(r) else np.zeros(1, np.float32), len(r), int(n_points),
+                                       int(depth_limit), order)
+        return order[:k].copy()
 
     def set_pattern(self, xy) -> None:
         xy = np.ascontiguousarray(xy, np.int8).reshape(1024)

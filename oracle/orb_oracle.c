@@ -17,9 +17,13 @@
  *       be derived; it is an INPUT here (orc_orb_set_pattern), exactly as in the product (cbh_orb_set_pattern).
  *       tools/orb_pattern_from_opencv.py extracts it from an OpenCV source tree a maintainer has.
  *   (2) KeyPointsFilter::retainBest uses std::nth_element + std::partition: which of several keypoints with EQUAL
- *       response survive, and the ORDER of the survivors, depend on the C++ library that built cbird.  The canonical
- *       rule here (and in the product): every keypoint whose response is >= the n-th best response is kept (what
- *       retainBest documents: ties are not cut), in raster order (row, then column) within a pyramid level.
+ *       response survive, and the ORDER of the survivors, depend on the C++ library that built cbird.  Two orders are
+ *       offered here and in the product (orc_orb_set_retain_order / cbh_set_tuning("orb_retain_order")):
+ *         1 (default)  libstdc++'s, the library of cbird's Linux builds: oracle/retain_stl.cpp runs retainBest's few
+ *                      lines on this image's real std::nth_element / std::partition, so the ORDER is pinned on the
+ *                      library (retainBest's own lines remain recalled);
+ *         0            canonical: every keypoint whose response is >= the n-th best response is kept, in raster order
+ *                      (row, then column) within a pyramid level -- a superset of what any library leaves.
  *
  * Everything else is integer or strictly-ordered float arithmetic (no FMA: build with -ffp-contract=off), so the HIP
  * path is compared BIT FOR BIT with this file. */
@@ -427,6 +431,13 @@ static long retain_best(const float* resp, long cnt, int n, uint8_t* keep) {
   return kept;
 }
 
+/* retainBest's order.  1 (default): what OpenCV 2.4's retainBest leaves when the C++ library is libstdc++ --
+ * oracle/retain_stl.cpp, the real std::nth_element and std::partition.  0: canonical -- every tie kept, raster order
+ * (header, (2)). */
+long orc_retain_best_stl(const float* resp, long cnt, int n_points, int depth_limit, int32_t* order);
+static int g_retain_order = 1;
+void orc_orb_set_retain_order(int mode) { g_retain_order = mode == 1; }
+
 /* returns the number of keypoints (all of them are counted; at most cap are written) or < 0 */
 long orc_orb_detect(const uint8_t* img, int w, int h, size_t stride, int nfeatures, orc_keypoint* out, long cap) {
   if (w < 1 || h < 1 || nfeatures < 0) return -1;
@@ -452,6 +463,28 @@ long orc_orb_detect(const uint8_t* img, int w, int h, size_t stride, int nfeatur
     for (int y = ORB_EDGE; y < lh - ORB_EDGE; ++y)
       for (int x = ORB_EDGE; x < lw - ORB_EDGE; ++x)
         if (sc[(size_t)y * lw + x]) xs[c] = x, ys[c] = y, resp[c] = (float)sc[(size_t)y * lw + x], ++c;
+    if (g_retain_order == 1) { /* the same three steps, survivors in the order the library leaves them */
+      int32_t* ord = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)(cnt + 1));
+      int32_t* ord2 = ord + cnt + 1;
+      const long k1 = orc_retain_best_stl(resp, cnt, 2 * nper[l], -1, ord);
+      float* r2 = (float*)malloc(sizeof(float) * (size_t)(k1 + 1));
+      for (long i = 0; i < k1; ++i) r2[i] = orc_harris_response(lv[l].px, (size_t)lw, xs[ord[i]], ys[ord[i]]);
+      const long k2 = orc_retain_best_stl(r2, k1, nper[l], -1, ord2);
+      const float sf1 = orb_get_scale(l);
+      for (long i = 0; i < k2; ++i, ++total) {
+        if (total >= cap) continue;
+        const int x = xs[ord[ord2[i]]], y = ys[ord[ord2[i]]];
+        orc_keypoint* k = out + total;
+        k->octave = l;
+        k->size = ORB_PATCH * sf1;
+        k->response = r2[ord2[i]];
+        k->angle = orc_ic_angle(lv[l].px, (size_t)lw, x, y);
+        k->x = (float)x, k->y = (float)y;
+        if (l != 0) k->x *= sf1, k->y *= sf1;
+      }
+      free(ord), free(r2), free(sc), free(xs), free(resp), free(keep);
+      continue;
+    }
     /* retainBest(2 * featuresNum) on the FAST score, HarrisResponses, retainBest(featuresNum) */
     retain_best(resp, cnt, 2 * nper[l], keep);
     long c2 = 0;

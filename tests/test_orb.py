@@ -23,7 +23,64 @@ def orb_orc():
     return OrbOracle()
 
 
+@pytest.fixture(params=["canonical", "libstdcxx"])
+def retain_order(request, gpu, orb_orc):
+    """KeyPointsFilter::retainBest's order (include/cbird_hip.h, cbh_orb): the canonical one (ties kept, raster order)
+    and the one libstdc++'s nth_element + partition leave, the product and the oracle switched together."""
+    from cbird_amd import _lib
+
+    v = 1 if request.param == "libstdcxx" else 0
+    _lib.lib().cbh_set_tuning(b"orb_retain_order", v)
+    orb_orc.set_retain_order(v)
+    yield request.param
+    _lib.lib().cbh_set_tuning(b"orb_retain_order", 1)  # the default
+    orb_orc.set_retain_order(1)
+
+
+def _retain_cases(rng):
+    """(responses, n_points) pairs: heavy ties (FAST scores are small integers), distinct floats, constant, sorted
+    either way, organ pipe, sizes around the 256-thread chunk and the <= 3 tail, n at both ends"""
+    out = []
+    for cnt in (0, 1, 2, 3, 4, 5, 7, 255, 256, 257, 511, 513, 1000, 5000, 20011):
+        fam = [rng.integers(21, 60, cnt).astype(np.float32), rng.standard_normal(cnt).astype(np.float32),
+               np.full(cnt, 33, np.float32), np.arange(cnt, dtype=np.float32), np.arange(cnt, dtype=np.float32)[::-1],
+               np.minimum(np.arange(cnt), np.arange(cnt)[::-1]).astype(np.float32),
+               (rng.integers(0, 4, cnt) * 1e-7).astype(np.float32)]
+        for r in fam:
+            for n in sorted({0, 1, 2, 3, cnt // 7, cnt // 2, cnt - 2, cnt - 1, cnt, cnt + 5}):
+                if n >= 0:
+                    out.append((np.array(r, np.float32, order="C", copy=True), int(n)))
+    return out
+
+
 # ---- the oracle's stages (CPU) --------------------------------------------------------------------------------------
+def test_retain_best_on_the_real_nth_element(orb_orc):
+    """oracle/retain_stl.cpp (the real std::nth_element + std::partition): the survivors are the best n plus, possibly,
+    ties of the response left in place n - 1; every strictly better response survives; nothing is duplicated; the
+    heap-select branch (depth limit 0) selects a valid best-n as well"""
+    rng = np.random.default_rng(3)
+    for r, n in _retain_cases(rng):
+        for depth in (-1, 0, 2):
+            k = orb_orc.retain_best_stl(r, n, depth)
+            cnt = len(r)
+            if cnt <= n:
+                assert k.tolist() == list(range(cnt))
+                continue
+            if n == 0:
+                assert len(k) == 0
+                continue
+            assert len(set(k.tolist())) == len(k) >= n
+            nth = np.sort(r)[::-1][n - 1]
+            assert (r[k[:n]] >= nth).all() and set(np.flatnonzero(r > nth).tolist()) <= set(k.tolist())
+            amb = r[k[n - 1]]
+            rest = np.setdiff1d(np.arange(cnt), k[:n])
+            assert sorted(k[n:].tolist()) == sorted(rest[r[rest] >= amb].tolist())
+    # the canonical rule keeps a superset
+    r = rng.integers(21, 40, 3000).astype(np.float32)
+    k = orb_orc.retain_best_stl(r, 500)
+    assert set(k.tolist()) <= set(np.flatnonzero(r >= np.sort(r)[::-1][499]).tolist())
+
+
 def test_oracle_tables(orb_orc):
     o = orb_orc
     # u_max for half patch 15 as every ORB implementation prints it
@@ -141,8 +198,19 @@ def test_oracle_detect_compute_properties(orb_orc):
     img = _scene(rng, 400, 300)
     o = orb_orc
     o.set_pattern(synthetic_pattern())
+    o.set_retain_order(1)
+    kp_stl = o.detect(img, 400)
+    o.set_retain_order(0)
     kp = o.detect(img, 400)
+    o.set_retain_order(1)  # the default
     assert 200 < len(kp) <= 400 + 50
+    # the library's order: nearly the same keypoints with identical values (the two rules differ in the ties at the two
+    # cuts only), level by level, not in raster order
+    as_set = {tuple(k.tolist()) for k in kp}
+    assert 200 < len(kp_stl) <= 400 + 50 and sum(tuple(k.tolist()) in as_set for k in kp_stl) > 0.9 * len(kp_stl)
+    assert (np.diff(kp_stl["octave"]) >= 0).all()
+    l0 = kp_stl[kp_stl["octave"] == 0]
+    assert not (np.diff(np.rint(l0["y"]).astype(int) * 10000 + np.rint(l0["x"]).astype(int)) > 0).all()
     per = o.features_per_level(400)
     for l in range(12):
         sel = kp[kp["octave"] == l]
@@ -208,7 +276,38 @@ def _compare(o, imgs, nfeat, res):
 
 
 @pytest.mark.gpu
-def test_gpu_orb_equals_oracle(gpu, orb_orc):
+def test_gpu_retain_best_equals_libstdcxx(gpu, orb_orc):
+    """cbh_orb_retain_best_dev (the workgroup restatement of introselect + partition in orb.hip) against the real
+    library: the same survivors in the same order, for every case family, through nth_element's own depth limit and
+    through forced limits 0..3 (heap select after 0..3 partition rounds)"""
+    import torch
+
+    from cbird_amd import _lib
+
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    cases = _retain_cases(rng)
+    checked = 0
+    for r, n in cases:
+        cnt = len(r)
+        d_r = torch.from_numpy(r if cnt else np.zeros(1, np.float32)).cuda()
+        d_o = torch.zeros(max(cnt, 1), dtype=torch.int32, device="cuda")
+        d_c = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for depth in (-1, 0, 1, 3):
+            if depth >= 0 and cnt > 6000:
+                continue  # the forced heap branch is one thread: keep it to the sizes that take milliseconds
+            _lib.check(L.cbh_orb_retain_best_dev(d_r.data_ptr(), cnt, n, depth, d_o.data_ptr(), d_c.data_ptr(), 0, None),
+                       "cbh_orb_retain_best_dev")
+            k = int(d_c.item())
+            want = orb_orc.retain_best_stl(r, n, depth)
+            assert k == len(want), (cnt, n, depth, k, len(want))
+            assert (d_o[:k].cpu().numpy() == want).all(), (cnt, n, depth)
+            checked += 1
+    assert checked > 2000
+
+
+@pytest.mark.gpu
+def test_gpu_orb_equals_oracle(gpu, orb_orc, retain_order):
     from cbird_amd import orb
 
     pat = orb.synthetic_pattern()
@@ -266,7 +365,7 @@ def test_gpu_make_keypoint_descriptors_on_provided_keypoints(gpu, orb_orc):
 
 
 @pytest.mark.gpu
-def test_gpu_orb_cos_sin_match_libm(gpu, orb_orc):
+def test_gpu_orb_cos_sin_match_libm(gpu, orb_orc, retain_order):
     """the one place the device's libm meets the host's: (float)cos(angle), (float)sin(angle) of the descriptor
     rotation.  Every keypoint of a large batch gives the oracle's descriptor, i.e. no rounding difference surfaced."""
     from cbird_amd import orb
@@ -282,7 +381,7 @@ def test_gpu_orb_cos_sin_match_libm(gpu, orb_orc):
 
 
 @pytest.mark.gpu
-def test_gpu_orb_large_images(gpu, orb_orc):
+def test_gpu_orb_large_images(gpu, orb_orc, retain_order):
     """the sizes the interface admits, not just the 400-pixel images cbird feeds: 12 MP, the widest row (8192), more
     keypoints asked than cbird ever does"""
     from cbird_amd import orb
