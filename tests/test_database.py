@@ -278,9 +278,44 @@ def test_similar_behind_the_c_abi_equals_the_oracle(gpu, orc, scan_path):
 
 
 @pytest.mark.gpu
-def test_similar_gpu_10k_images_end_to_end(gpu, orc):
-    """BASELINE configs[0] shape at reduced size for the test suite: synthetic 256x256 images -> hash (GPU) ->
-    DctHashIndex -> -p.dht 2 -similar; equals the same pipeline driven through the oracle."""
+def test_similar_gpu_configs0_at_full_size(gpu, orc):
+    """BASELINE configs[0] as stated: 10 000 synthetic 256x256 grey images, `-p.alg dct -p.dht 2 -similar` -- hash
+    kernel -> DctHashIndex -> Database::similar in one batch (cbh_search_index_batch + the group filter) on the GPU,
+    against the CPU statement of the same job (oracle hashes, oracle/search_index.c's similar).  Identical hashes,
+    identical groups in identical order."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import torch
+
+    import bench
+    from cbird_amd import SearchParams
+    from cbird_amd.database import similar
+
+    n = 10_000
+    # bench.py's data set (SURVEY 8d's recipe, generated on the device: synth.make_images takes 100 s for 10k)
+    imgs = bench.gen_images(torch, torch.device("cuda:0"), 0, n, n, 1234).cpu().numpy()
+    h = gpu.dct_hash64_batch(imgs)
+    with ThreadPoolExecutor(8) as ex:  # ctypes releases the GIL
+        parts = list(ex.map(orc.dcthash64_fast256_batch, np.array_split(imgs, 32)))
+    h_cpu = np.concatenate(parts)
+    assert (h == h_cpu).all()
+    assert (orc.dcthash64_batch(imgs[:300]) == h[:300]).all()  # and the scalar port on a sample
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    p = SearchParams(dctThresh=2)
+    want = orc.similar_dct(h_cpu, ids, np.arange(n, dtype=np.int32), h_cpu, ids, 2, 0, p.minMatches, p.maxMatches,
+                           True, True)
+    idx = gpu.DctHashIndex()
+    idx.load(h, ids)
+    got = similar(idx, _media(h, ids), p, batched=True)
+    assert len(got) == len(want) >= 100
+    for g, (j, members) in zip(got, want):
+        assert g[0].id == ids[j] and [(m.id, m.score) for m in g[1:]] == members
+
+
+@pytest.mark.gpu
+def test_similar_gpu_images_end_to_end_three_routes(gpu, orc):
+    """configs[0]'s shape at 600 images, so that the per-needle routes can run beside the batch: synthetic 256x256
+    images -> hash (GPU) -> DctHashIndex -> -p.dht 2 -similar; equals the same pipeline driven through the oracle."""
     from cbird_amd import SearchParams, synth
     from cbird_amd.database import similar
 
