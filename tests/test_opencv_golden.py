@@ -142,9 +142,11 @@ def test_orb_stages_match_opencv():
     for yb, xb, rb in ab:
         y, x = np.uint32(yb).view(np.float32), np.uint32(xb).view(np.float32)
         assert np.float32(o.fast_atan2(y, x)).view(np.uint32) == rb, (y, x)
-    # the detector as a whole: equal as SETS up to the retainBest tie rule (ours keeps every tie) -- every OpenCV
-    # keypoint must be one of ours, with identical response and angle
+    # the detector as a whole, first under the canonical retainBest rule (every tie kept: a superset of what any C++
+    # library leaves) -- every OpenCV keypoint must be one of ours, with identical response and angle
+    o.set_retain_order(0)
     mine = o.detect(img, int(g["orb_whs_nfeat"][3]))
+    o.set_retain_order(1)
     key = {(int(k["octave"]), np.float32(k["x"]).view(np.uint32).item(), np.float32(k["y"]).view(np.uint32).item()): k
            for k in mine}
     # (pt of the goldens went through compute(): compare on the level coordinates)
@@ -161,6 +163,12 @@ def test_orb_stages_match_opencv():
         assert np.float32(hit[0]["angle"]).view(np.uint32) == bits[3] and np.float32(hit[0]["response"]).view(np.uint32) == bits[4]
     assert missing == 0, f"{missing} OpenCV keypoints are not in the oracle's (superset) result"
     assert len(key) >= len(g["orb_octave"])
+    # then in libstdc++'s order (the default; goldens made by an OpenCV built against libstdc++): the same keypoints in
+    # the same ORDER
+    stl = o.detect(img, int(g["orb_whs_nfeat"][3]))
+    assert len(stl) == len(g["orb_octave"]) and (stl["octave"] == g["orb_octave"]).all()
+    assert (stl["angle"].view(np.uint32) == g["orb_kp_bits"][:, 3]).all()
+    assert (stl["response"].view(np.uint32) == g["orb_kp_bits"][:, 4]).all()
 
 
 @pytest.mark.skipif(not _has("luv_bits"), reason="no OpenCV goldens for ColorDescriptor::create yet -- parity UNPINNED")
