@@ -1541,8 +1541,10 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
   unsigned char* __restrict__ sblur = sblur_all + (size_t)(lane_live ? islot : 0) * (size_t)kStep * (size_t)bp;
   float* __restrict__ salpha = reinterpret_cast<float*>(s_fused + (size_t)ipb * (size_t)kStep * (size_t)bp);
   const int k_end = isx ? 0 : xfirst[32];
-  // FUSE: horizontal sums of the current step and the tiles, behind the weights (16-byte aligned)
-  float* __restrict__ shrow = salpha + ((k_end + 3) & ~3);
+  // per-cell edge weights of the area walk (16 floats per cell; fractional ratios only), 16-byte aligned
+  float* __restrict__ swt = salpha + ((k_end + 3) & ~3);
+  // FUSE: horizontal sums of the current step and the tiles, behind the weights
+  float* __restrict__ shrow = swt + (isx ? 0 : 512);
   unsigned char* __restrict__ stile = reinterpret_cast<unsigned char*>(shrow + (FUSE ? (size_t)ipb * kStep * 32 : 0));
   const int strip_out = steps * kStep - 2 * R;
   const int o0 = (int)blockIdx.y * strip_out;
@@ -1614,6 +1616,36 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
   const int acol = isx ? cc * isx : xtab[ak0].si;
   const float* __restrict__ al = salpha + ak0;
 
+  // weights of the lane's cell by pixel position: (partial first) mid ... mid (partial last), +0 past the cell --
+  // make_area_tab gives every interior pixel the same float(1 / cellWidth).  Word 0 and the last two words of the
+  // uniform walk of nw_u words are kept per CELL in LDS (swt: 16 floats per cell, read at the head of a turn so that
+  // they occupy registers in the area phase only); the words between are a_mid for every lane (mid_ok, checked).
+  const unsigned ama = (unsigned)acol & 3u;  // (rows start on 8-byte boundaries of the LDS buffer)
+  int nw_u = 0;
+  bool mid_ok = true;
+  if (!isx) {
+    __syncthreads();  // salpha
+    const float a_first = al[0], a_mid_ = al[ank > 1 ? 1 : 0], a_last = al[ank - 1];
+    auto area_wt = [&](int k) -> float {
+      return k == 0 ? a_first : (k < ank - 1 ? a_mid_ : (k == ank - 1 ? a_last : 0.f));
+    };
+    int amax = ank, amin = ank;  // over the 32 cells (every wave holds all of them)
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+      amax = max(amax, __shfl_xor(amax, d));
+      amin = min(amin, __shfl_xor(amin, d));
+    }
+    nw_u = __builtin_amdgcn_readfirstlane((amax + 3) >> 2);
+    mid_ok = __builtin_amdgcn_readfirstlane(4 * nw_u - 7 <= amin ? 1 : 0) != 0;  // pixels 4 .. 4 nw_u - 9 are interior
+    if (tid < 32) {
+      float* __restrict__ o = swt + 16 * cc;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) o[u] = area_wt(u);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) o[4 + u] = area_wt(4 * (nw_u - 2) + u);
+      o[12] = a_mid_, o[13] = a_first, o[14] = a_last, o[15] = 0.f;
+    }
+  }
   const int sfirst = o0 - R;  // first source row of the strip
   uint2 rawC[PF];
   unsigned rawL[PF], rawR[PF];
@@ -1667,78 +1699,95 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
       if (lane_live) *reinterpret_cast<uint2*>(sblur + (size_t)rr * (size_t)bp + offS) = qo;
     }
     __syncthreads();
-    // ---- horizontal INTER_AREA chains for the valid blurred rows of this step: local row rr <-> image row s0 + rr - R
+    // ---- horizontal INTER_AREA chains for the valid blurred rows of this step: local row rr <-> image row s0 + rr - R.
+    // Row group rg takes the local rows lo + rg, lo + rg + G, ... of every image, two per turn (they share the lane's
+    // weights and give the chain a second, independent accumulator).  No division, no per-lane trip counts: every
+    // lane walks nw_u words; pixels past its own cell carry the weight +0.0f (x + 0.0f == x: the sums are the chains
+    // `ba += float(p[k]) * alpha[k]`, k ascending, of make_area_tab to the bit).
     {
       const int ob = s0 - R;
       const int lo = max(0, o0 - ob), hi = min(kStep, o1 - ob);  // valid local rows [lo, hi), the same for every image
-      const int nv = hi - lo;                                     // valid rows per image
-      const int total = nv * ipb;                                 // (image, row) entries of the workgroup
-      for (int e = rg; e < total; e += 2 * G) {
-        const int e2 = e + G;
-        const bool two = e2 < total;
-        const int ia = e / nv, ra = lo + (e - ia * nv);
-        const int ib = two ? e2 / nv : ia, rb_ = two ? lo + (e2 - ib * nv) : ra;
-        const unsigned ga = blockIdx.z * (unsigned)ipb + (unsigned)ia, gb = blockIdx.z * (unsigned)ipb + (unsigned)ib;
-        const bool la = ga < n_imgs, lb = two && gb < n_imgs;
-        const unsigned char* __restrict__ Sa = sblur_all + ((size_t)ia * kStep + (size_t)ra) * (size_t)bp + acol;
-        const unsigned char* __restrict__ Sb = sblur_all + ((size_t)ib * kStep + (size_t)rb_) * (size_t)bp + acol;
-        float* __restrict__ oa = FUSE ? shrow + ((size_t)ia * kStep + (size_t)ra) * 32 + cc
-                                      : rows + ((size_t)(la ? ga : 0u) * (size_t)h + (size_t)(ob + ra)) * 32 + cc;
-        float* __restrict__ obp = FUSE ? shrow + ((size_t)ib * kStep + (size_t)rb_) * 32 + cc
-                                       : rows + ((size_t)(lb ? gb : 0u) * (size_t)h + (size_t)(ob + rb_)) * 32 + cc;
-        if (isx) {
-          unsigned sa = 0, sb = 0;
-          if (((isx | bp) & 3) == 0) {  // cells start on dword boundaries: four pixels per v_dot4 (uniform branch)
-            const unsigned* __restrict__ A4 = reinterpret_cast<const unsigned*>(Sa);
-            const unsigned* __restrict__ B4 = reinterpret_cast<const unsigned*>(Sb);
-            for (int u = 0; u < (ank >> 2); ++u) {
-              sa = udot4(A4[u], 0x01010101u, sa);
-              sb = udot4(B4[u], 0x01010101u, sb);
-            }
-          } else {
-            for (int u = 0; u < ank; ++u) {
-              sa += Sa[u];
-              sb += Sb[u];
-            }
-          }
-          if (la) *oa = __uint_as_float(sa);
-          if (lb) *obp = __uint_as_float(sb);
-        } else {
-          // The weights of a cell are (partial first) mid mid ... mid (partial last) -- make_area_tab gives every
-          // interior pixel the same float(1 / cellWidth) -- so three LDS reads replace one per pixel, and the blurred
-          // pixels come as dwords (aligned reads + v_alignbyte_b32 by the cell's byte offset, v_cvt_f32_ubyteN)
-          // instead of one ds_read_u8 each.  The chain itself is unchanged: ba += float(p[k]) * alpha[k], k ascending.
-          const float a_first = al[0], a_mid = al[ank > 1 ? 1 : 0], a_last = al[ank - 1];
-          const unsigned ma = (unsigned)acol & 3u;  // (rows start on 8-byte boundaries of the LDS buffer)
-          const unsigned* __restrict__ A4 = reinterpret_cast<const unsigned*>(Sa - ma);
-          const unsigned* __restrict__ B4 = reinterpret_cast<const unsigned*>(Sb - ma);
-          float ba = 0.f, bb = 0.f;
-          unsigned lo_a = A4[0], lo_b = B4[0];
-          const int nw = (ank + 3) >> 2;  // words
-          for (int c = 0; c < nw; ++c) {
-            const unsigned hi_a = A4[c + 1], hi_b = B4[c + 1];
-            const unsigned wa = __builtin_amdgcn_alignbyte(hi_a, lo_a, ma), wb = __builtin_amdgcn_alignbyte(hi_b, lo_b, ma);
-            lo_a = hi_a, lo_b = hi_b;
-            const int k0 = 4 * c;
-            if (c > 0 && k0 + 4 < ank) {  // four interior pixels
-              ba += (float)(wa & 0xffu) * a_mid, bb += (float)(wb & 0xffu) * a_mid;
-              ba += (float)((wa >> 8) & 0xffu) * a_mid, bb += (float)((wb >> 8) & 0xffu) * a_mid;
-              ba += (float)((wa >> 16) & 0xffu) * a_mid, bb += (float)((wb >> 16) & 0xffu) * a_mid;
-              ba += (float)(wa >> 24) * a_mid, bb += (float)(wb >> 24) * a_mid;
+      for (int ia = 0; ia < ipb; ++ia) {
+        const unsigned ga = blockIdx.z * (unsigned)ipb + (unsigned)ia;
+        if (ga >= n_imgs) break;  // uniform
+        const unsigned char* __restrict__ Si = sblur_all + (size_t)ia * (size_t)kStep * (size_t)bp + acol - ama;
+        float* __restrict__ Oi = FUSE ? shrow + (size_t)ia * kStep * 32 + cc
+                                      : rows + ((ptrdiff_t)ga * (ptrdiff_t)h + (ptrdiff_t)ob) * 32 + cc;
+        for (int ra = lo + rg; ra < hi; ra += 2 * G) {
+          const int rb_ = ra + G;
+          const bool two = rb_ < hi;
+          const unsigned* __restrict__ A4 = reinterpret_cast<const unsigned*>(Si + (size_t)ra * (size_t)bp);
+          const unsigned* __restrict__ B4 = reinterpret_cast<const unsigned*>(Si + (size_t)(two ? rb_ : ra) * (size_t)bp);
+          if (isx) {
+            unsigned sa = 0, sb = 0;
+            if (((isx | bp) & 3) == 0) {  // cells start on dword boundaries: four pixels per v_dot4 (uniform branch)
+              for (int u = 0; u < (isx >> 2); ++u) {
+                sa = udot4(A4[u], 0x01010101u, sa);
+                sb = udot4(B4[u], 0x01010101u, sb);
+              }
             } else {
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const int k = k0 + u;
-                if (k < ank) {
-                  const float wt = k == 0 ? a_first : (k == ank - 1 ? a_last : a_mid);
-                  ba += (float)((wa >> (8 * u)) & 0xffu) * wt;
-                  bb += (float)((wb >> (8 * u)) & 0xffu) * wt;
-                }
+              unsigned lo_a = A4[0], lo_b = B4[0];
+              for (int c = 0; c < ((isx + 3) >> 2); ++c) {
+                const unsigned hi_a = A4[c + 1], hi_b = B4[c + 1];
+                unsigned wa = __builtin_amdgcn_alignbyte(hi_a, lo_a, ama), wb = __builtin_amdgcn_alignbyte(hi_b, lo_b, ama);
+                lo_a = hi_a, lo_b = hi_b;
+                const int left = isx - 4 * c;  // uniform
+                if (left < 4) wa &= (1u << (8 * left)) - 1u, wb &= (1u << (8 * left)) - 1u;
+                sa = udot4(wa, 0x01010101u, sa);
+                sb = udot4(wb, 0x01010101u, sb);
               }
             }
+            Oi[ra * 32] = __uint_as_float(sa);
+            if (two) Oi[rb_ * 32] = __uint_as_float(sb);
+          } else {
+            float ba = 0.f, bb = 0.f;
+            unsigned lo_a = A4[0], lo_b = B4[0], wa, wb;
+            const float4 wF4 = *reinterpret_cast<const float4*>(swt + 16 * cc);
+            const float4 wTa = *reinterpret_cast<const float4*>(swt + 16 * cc + 4);
+            const float4 wTb = *reinterpret_cast<const float4*>(swt + 16 * cc + 8);
+            const float4 wM = *reinterpret_cast<const float4*>(swt + 16 * cc + 12);  // a_mid, a_first, a_last
+            const float a_mid = wM.x;
+#define CBH_AREA_WORD(c)                                     \
+  {                                                          \
+    const unsigned hi_a = A4[(c) + 1], hi_b = B4[(c) + 1];   \
+    wa = __builtin_amdgcn_alignbyte(hi_a, lo_a, ama);        \
+    wb = __builtin_amdgcn_alignbyte(hi_b, lo_b, ama);        \
+    lo_a = hi_a, lo_b = hi_b;                                \
+  }
+#define CBH_AREA_PIX4(W0, W1, W2, W3)                                                         \
+  ba += (float)(wa & 0xffu) * (W0), bb += (float)(wb & 0xffu) * (W0);                         \
+  ba += (float)((wa >> 8) & 0xffu) * (W1), bb += (float)((wb >> 8) & 0xffu) * (W1);           \
+  ba += (float)((wa >> 16) & 0xffu) * (W2), bb += (float)((wb >> 16) & 0xffu) * (W2);         \
+  ba += (float)(wa >> 24) * (W3), bb += (float)(wb >> 24) * (W3);
+            CBH_AREA_WORD(0);
+            CBH_AREA_PIX4(wF4.x, wF4.y, wF4.z, wF4.w);
+            if (mid_ok) {
+              for (int c = 1; c < nw_u - 2; ++c) {  // interior words: every pixel of every lane weighs a_mid
+                CBH_AREA_WORD(c);
+                CBH_AREA_PIX4(a_mid, a_mid, a_mid, a_mid);
+              }
+              if (nw_u >= 3) {
+                CBH_AREA_WORD(nw_u - 2);
+                CBH_AREA_PIX4(wTa.x, wTa.y, wTa.z, wTa.w);
+              }
+              if (nw_u >= 2) {
+                CBH_AREA_WORD(nw_u - 1);
+                CBH_AREA_PIX4(wTb.x, wTb.y, wTb.z, wTb.w);
+              }
+            } else {  // cells of very different widths (no area table does this): weights word by word
+              auto area_wt = [&](int k) -> float {
+                return k == 0 ? wM.y : (k < ank - 1 ? a_mid : (k == ank - 1 ? wM.z : 0.f));
+              };
+              for (int c = 1; c < nw_u; ++c) {
+                CBH_AREA_WORD(c);
+                CBH_AREA_PIX4(area_wt(4 * c), area_wt(4 * c + 1), area_wt(4 * c + 2), area_wt(4 * c + 3));
+              }
+            }
+#undef CBH_AREA_WORD
+#undef CBH_AREA_PIX4
+            Oi[ra * 32] = ba;
+            if (two) Oi[rb_ * 32] = bb;
           }
-          if (la) *oa = ba;
-          if (lb) *obp = bb;
         }
       }
     }
@@ -2968,13 +3017,14 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
             const int Lr = (w + 7) / 8, Lw = (Lr + 63) / 64 * 64;
             const bool pack = g_hash_regs == 3 || (g_hash_regs == 1 && Lr * 100 < Lw * 72);  // knob 2: never, 3: always
             const int ipb = (Lr <= 128 && pack) ? 256 / Lr : 1;
-            const size_t rsmem = (size_t)ipb * kstep * (size_t)(8 * Lr) + (size_t)(integer ? 0 : at.xn) * sizeof(float);
+            const size_t k_end_r = integer ? 0 : (((size_t)at.xn + 3) & ~(size_t)3) + 512;  // weights + per-cell edge weights
+            const size_t rsmem = (size_t)ipb * kstep * (size_t)(8 * Lr) + k_end_r * sizeof(float);
             const unsigned Tr = (unsigned)std::max(64, (ipb * Lr + 63) / 64 * 64);
             // whole image per workgroup, vertical pass and tile inside the kernel (FUSE) when the batch still fills
             // the machine that way: at least two workgroups per CU
             const int ipb_f = std::min(ipb, 8);
             const int steps_f = (h + 2 * (K_ / 2) + kstep - 1) / kstep;
-            const size_t k_end_f = integer ? 0 : ((size_t)at.xn + 3) & ~(size_t)3;
+            const size_t k_end_f = k_end_r;
             const size_t fsm = (size_t)ipb_f * kstep * (size_t)(8 * Lr) + k_end_f * sizeof(float) +
                                (size_t)ipb_f * kstep * 32 * sizeof(float) + (size_t)ipb_f * 1024;
             // (measured, hash_fuse 0 -> 2: 400x300 +14 %, 533x400 +13 %, 641x480 +10 %, 640x480 +3 %, 1024x768 -7 %,
