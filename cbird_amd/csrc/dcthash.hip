@@ -3027,11 +3027,13 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
             const size_t k_end_f = k_end_r;
             const size_t fsm = (size_t)ipb_f * kstep * (size_t)(8 * Lr) + k_end_f * sizeof(float) +
                                (size_t)ipb_f * kstep * 32 * sizeof(float) + (size_t)ipb_f * 1024;
-            // (measured, hash_fuse 0 -> 2: 400x300 +14 %, 533x400 +13 %, 641x480 +10 %, 640x480 +3 %, 1024x768 -7 %,
-            // 1080p -19 %: large images spend little in k_tile_hash and lose occupancy to the extra LDS)
+            // (measured, hash_fuse 0 -> 2: 320x240 +30 %, 400x300 +22 %, 533x400 +19 %, 640x480 +8 %, 800x600 +6 %,
+            // 1366x768 +6 %, 1024x768 -2 %, 1280x960 -8 %, 1080p -7 %: large images spend little in k_tile_hash and
+            // lose occupancy to the extra LDS; fractional ratios gain up to ~1 MP)
             const bool fuse = g_hash_fuse && fsm <= 160 * 1024 - 1024 && (integer || at.yrow) &&
                               (g_hash_fuse >= 2 ||
-                               ((m + (size_t)ipb_f - 1) / (size_t)ipb_f >= 512 && (size_t)w * (size_t)h <= 400000));
+                               ((m + (size_t)ipb_f - 1) / (size_t)ipb_f >= 512 &&
+                                (size_t)w * (size_t)h <= (integer ? 400000u : 1100000u)));
             const unsigned Tf_ = (unsigned)std::max(64, (ipb_f * std::max(Lr, 32) + 63) / 64 * 64);
 #define CBH_REGS_(KK, GG)                                                                                    \
   do {                                                                                                       \
