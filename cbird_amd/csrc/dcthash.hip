@@ -3018,7 +3018,8 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
             const bool pack = g_hash_regs == 3 || (g_hash_regs == 1 && Lr * 100 < Lw * 72);  // knob 2: never, 3: always
             const int ipb = (Lr <= 128 && pack) ? 256 / Lr : 1;
             const size_t k_end_r = integer ? 0 : (((size_t)at.xn + 3) & ~(size_t)3) + 512;  // weights + per-cell edge weights
-            const size_t rsmem = (size_t)ipb * kstep * (size_t)(8 * Lr) + k_end_r * sizeof(float);
+            const size_t rsmem = (size_t)ipb * kstep * (size_t)(8 * Lr) + k_end_r * sizeof(float) +
+                                 16;  // the area walk reads whole words: up to 7 bytes past the last blurred row
             const unsigned Tr = (unsigned)std::max(64, (ipb * Lr + 63) / 64 * 64);
             // whole image per workgroup, vertical pass and tile inside the kernel (FUSE) when the batch still fills
             // the machine that way: at least two workgroups per CU

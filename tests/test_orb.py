@@ -407,6 +407,9 @@ def test_gpu_orb_arguments(gpu):
     assert orb.orb([], 400) == []
     with pytest.raises(ValueError):
         orb.orb([np.zeros((4, 4, 3), np.uint8)], 400)
+    assert L.cbh_orb_retain_best_dev(None, 5, 2, -1, None, None, 0, None) == _lib.CBH_E_INVAL
+    assert L.cbh_orb_retain_best_dev(None, 5, 2, -1, None, None, 30, None) == _lib.CBH_E_NODEVICE
+    assert L.cbh_set_tuning(b"orb_retain_order", 2) == _lib.CBH_E_INVAL
     # truncation is reported, not silent: counts above kp_cap
     rng = np.random.default_rng(1)
     img = _scene(rng, 400, 300)
