@@ -3002,7 +3002,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
         const long long band_wgs = (long long)ncol * ((h + kBlurRB - 1) / kBlurRB) * (long long)m;
         int steps = (int)std::min<long long>(8, band_wgs / 3072);
         steps = std::min(steps, (h + 2 * (K_ / 2) + kstep - 1) / kstep);
-        if (w < 192 || h < 128 || view) steps = 0;  // measured: narrow or short images are faster band by band
+        if (w < 32 || h < 32 || view) steps = 0;  // (round 3: the fused strip kernel is 1.4-2.3x the band kernels on 64..160-px images too)
         if (g_hash_stream >= 2) steps = g_hash_stream;
         if (g_hash_stream && steps >= 3) {
           const int strip_out = steps * kstep - 2 * (K_ / 2);
