@@ -1662,8 +1662,13 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
       r = *reinterpret_cast<const unsigned*>(p + offR);
     }
   };
+  // narrow images (L < 32) leave whole waves without a blur lane (the workgroup keeps 32 lanes per image for the area and
+  // vertical passes): those waves skip the row loop and only meet the barriers
+  const bool wave_live = (__builtin_amdgcn_readfirstlane(tid) & ~63) / L < ipb;
+  if (wave_live) {
 #pragma unroll
-  for (int j = 0; j < PF; ++j) load_row(sfirst + j, rawC[j], rawL[j], rawR[j]);
+    for (int j = 0; j < PF; ++j) load_row(sfirst + j, rawC[j], rawL[j], rawR[j]);
+  }
   // FUSE: vertical INTER_AREA state of lane (image vi, output column vc), carried across the steps
   const int vi = tid >> 5, vc = tid & 31;
   const bool vlane = FUSE && vi < ipb;
@@ -1672,6 +1677,7 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
   for (int st = 0; st < steps; ++st) {
     const int s0 = sfirst + st * kStep;  // first source row consumed in this step
     if (s0 - R >= o1) break;             // nothing left to output (uniform)
+    if (wave_live) {
 #pragma unroll
     for (int rr = 0; rr < kStep; ++rr) {
       const int j = rr % K, pj = rr % PF;
@@ -1697,6 +1703,7 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
       }
       const uint2 qo = blur_quotients<K>(S);
       if (lane_live) *reinterpret_cast<uint2*>(sblur + (size_t)rr * (size_t)bp + offS) = qo;
+    }
     }
     __syncthreads();
     // ---- horizontal INTER_AREA chains for the valid blurred rows of this step: local row rr <-> image row s0 + rr - R.
