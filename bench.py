@@ -661,7 +661,7 @@ def cvfeatures_leg(args, torch, dist, dev, local_rank, rank, world, share):
     roofline = {"one_needle_image": roof(len(one), kernel_ms(lambda: sc.index.knn(one, 10, 25), 5),
                                          "k_hamm256_small<16> (needle tiles stationary, rows streamed)"),
                 "batch_of_64": roof(len(allq), kernel_ms(lambda: sc.index.knn(allq, 10, 25), 2),
-                                    "k_hamm256_mfma<6,3,2> (row tiles stationary, needle tiles streamed)")}
+                                    "k_hamm256_mfma3<12,2> (row tiles stationary; needle tiles streamed, three per accumulator)")}
     return {"workload": "configs[3]: CvFeaturesIndex, %d images x %d descriptors x 256 bit, %d needle images batched, "
                         "knn k=10, cvThresh 25" % (n_img, per, n_needles),
             "roofline": roofline,

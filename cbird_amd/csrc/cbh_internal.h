@@ -78,6 +78,7 @@ bool scan256_mfma_wanted(size_t n, size_t nq, int thresh);
 void set_scan256_g(int g);
 void set_scan256_ht(int ht);
 void set_scan256_small(int v);  // stationary-needle kernel for <= 512 needle descriptors: 0 / 1, >= 16: its workgroups
+void set_scan256_f3(int v);   // prefilter with three needle tiles per accumulator (default 1; 0 off; HT*10+G shapes)
 void set_scan256_pre(int on);  // first-128-bit prefilter variant (default on)
 void set_scan256_mfma(int on);  // <0 = keep; 2 = force for any size
 

@@ -1141,6 +1141,10 @@ int cbh_set_tuning(const char* key, int value) {
     set_scan256_small(value);
     return CBH_OK;
   }
+  if (!strcmp(key, "scan256_f3")) {
+    set_scan256_f3(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "scan256_pre")) {
     set_scan256_pre(value);
     return CBH_OK;

@@ -141,6 +141,141 @@ __global__ __launch_bounds__(kThreads) void k_hamm256_mfma(
   if (qt < q1) step(qt, x);
 }
 
+// ---- THREE needle tiles per accumulator (first-128-bit prefilter, thresh <= kPre128MaxThresh) --------------------------
+// k_hamm256_mfma<.., 2> spends 8 result registers per MFMA on one needle tile: 4 v_max3_f32 per MFMA, and on this
+// machine every VALU op costs the issue port 4 of the ~32 cycles an FP4 MFMA has (hamm64_mfma.hip, FULL3): the matrix
+// pipe idles a quarter of the time.  The fields of hamm64_mfma's FULL3 / PRE carry over: with b = thresh - 1 and the B
+// block scales 2^-1, 2^7, 2^15 for the three tiles of a triple (both 64-bit chunks of a tile under the same scale, C0 =
+// 2^23 + (64 + b)(1 + 2^8 + 2^16)) the accumulator ends as
+//     2^23 + sum_i 2^(8i) * (128 + b - d_i),      d_i = distance on the first 128 bits to tile i's descriptor,
+// three 8-bit fields in [b, 128 + b] (no borrow, no carry for b <= 127), and  d_i <= b  <=>  bit 7 of field i = bits 7,
+// 15 of the f32 pattern and, for the top field, the carry out of the mantissa = bit 23 (exponent 150 -> 151; the ulp is
+// then 2: the lowest bit of the sum is rounded away, which can only turn an odd field 0 into a neighbouring even one --
+// a field of exactly 128 is even and stays, so no pair under the threshold is lost).  The +-0.5 products are exact
+// because the hardware adds the 32 products of a K block (an integer) before it meets the accumulator
+// (tools/ubench/mfma_half_exact.hip).  OR keeps "some flag is set": 16 result registers per SIX MFMAs, 1.33 v_or3_b32
+// per MFMA.  A flagged register's candidates (all three fields when the exponent moved, else the flagged ones) are
+// evaluated on all 256 bits from the raw rows -- the records are those of every other 256-bit kernel.
+constexpr int kS256Half = 0x7e7e7e7e;        // E8M0 126 = 2^-1
+constexpr int kS256_7 = (int)0x86868686;     // 2^7
+constexpr int kS256_15 = (int)0x8e8e8e8e;    // 2^15
+constexpr uint32_t kFlag256 = (1u << 7) | (1u << 15) | (1u << 23);
+
+template <int HT, int G>
+__global__ __launch_bounds__(kThreads) void k_hamm256_mfma3(
+    const uint32_t* __restrict__ rows /* 8 words per row */, uint32_t n, const uint4* __restrict__ qx,
+    const uint32_t* __restrict__ qraw /* 8 words per needle */, uint32_t nq, uint32_t n_triples,
+    uint32_t triples_per_chunk, uint32_t thresh, unsigned long long* __restrict__ rec, unsigned long long cap,
+    unsigned long long* __restrict__ total) {
+  __shared__ uint32_t s_c[kWaves][G * 16][64];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t r = lane & 31u, half = lane >> 5;
+  const uint32_t tile0 = (blockIdx.x * kWaves + wave) * HT;
+  if (tile0 * 32u >= n) return;
+
+  v8i a[HT][2];
+#pragma unroll
+  for (int t = 0; t < HT; ++t) {
+    const uint32_t row = (tile0 + t) * 32u + r;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const uint32_t w = row < n ? rows[(size_t)row * 8u + 2u * k + half] : 0u;
+      a[t][k] = fp4_operand(fp4_expand32(w));
+    }
+  }
+  v16f c0;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) c0[g] = 8388608.0f + (float)((64u + (thresh - 1u)) * 65793u);  // 65793 = 1 + 2^8 + 2^16
+  asm volatile("" : "+v"(c0));
+  const uint32_t p0 = blockIdx.y * triples_per_chunk;
+  const uint32_t p1 = min(n_triples, p0 + triples_per_chunk);
+  // triple p = needle tiles 3p, 3p + 1, 3p + 2; a tile is 256 uint4 of scratch, chunk k of it at + 64 k
+  const uint4* __restrict__ qp = qx + (size_t)p0 * 768u + half * 32u + r;
+
+  auto step = [&](const uint32_t p, const uint4 (&nb)[6]) {
+    v8i b[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) b[k] = fp4_operand(nb[k]);
+#pragma unroll
+    for (int t0 = 0; t0 < HT; t0 += G) {
+      v16f c[G];
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+        c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t0 + t][0], b[0], c0, 4, 4, 0, kScaleOne, 0, kS256Half);
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+        c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t0 + t][1], b[1], c[t], 4, 4, 0, kScaleOne, 0, kS256Half);
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+        c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t0 + t][0], b[2], c[t], 4, 4, 0, kScaleOne, 0, kS256_7);
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+        c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t0 + t][1], b[3], c[t], 4, 4, 0, kScaleOne, 0, kS256_7);
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+        c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t0 + t][0], b[4], c[t], 4, 4, 0, kScaleOne, 0, kS256_15);
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+        c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t0 + t][1], b[5], c[t], 4, 4, 0, kScaleOne, 0, kS256_15);
+      uint32_t o0 = 0, o1 = 0;
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; g += 4) {
+          o0 |= __float_as_uint(c[t][g]) | __float_as_uint(c[t][g + 1]);  // v_or3_b32
+          o1 |= __float_as_uint(c[t][g + 2]) | __float_as_uint(c[t][g + 3]);
+        }
+      if (__builtin_amdgcn_ballot_w64(((o0 | o1) & kFlag256) != 0) != 0) {
+        // rare: every lane walks its own results (parked in LDS so that the loop stays rolled)
+#pragma unroll
+        for (int t = 0; t < G; ++t)
+#pragma unroll
+          for (int g = 0; g < 16; ++g) s_c[wave][t * 16 + g][lane] = __float_as_uint(c[t][g]);
+#pragma unroll 1
+        for (uint32_t e = 0; e < (uint32_t)G * 16u; ++e) {
+          const uint32_t bits = s_c[wave][e][lane];
+          if ((bits & kFlag256) == 0u) continue;
+          const uint32_t g = e & 15u;
+          const uint32_t row = (tile0 + t0 + (e >> 4)) * 32u + (g & 3u) + 8u * (g >> 2) + 4u * half;
+          if (row >= n) continue;
+          const bool moved = (bits >> 23) & 1u;  // exponent 151: the lower fields are shifted and rounded -- check all
+#pragma unroll 1
+          for (uint32_t f = 0; f < 3u; ++f) {
+            if (!moved && ((bits >> (7u + 8u * f)) & 1u) == 0u) continue;
+            const uint32_t qi = (p * 3u + f) * 32u + r;
+            if (qi >= nq) continue;
+            uint32_t d = 0;
+#pragma unroll
+            for (int wd = 0; wd < 8; ++wd) d += __popc(rows[(size_t)row * 8u + wd] ^ qraw[(size_t)qi * 8u + wd]);
+            if (d < thresh) {
+              const unsigned long long slot = atomicAdd(total, 1ull);
+              if (slot < cap) rec[slot] = ((unsigned long long)qi << 41) | ((unsigned long long)d << 32) | row;
+            }
+          }
+        }
+      }
+    }
+  };
+
+  // one triple (6 * HT MFMAs) per trip, the next triple's six tile-chunk loads in flight meanwhile
+  uint4 x[6], y[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) x[k] = qp[(k >> 1) * 256 + (k & 1) * 64];
+#pragma unroll 1
+  for (uint32_t p = p0; p < p1; ++p) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) y[k] = x[k];
+    if (p + 1 < p1) {
+      qp += 768;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) y[k] = qp[(k >> 1) * 256 + (k & 1) * 64];
+    }
+    step(p, x);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[k] = y[k];
+  }
+}
+
 // ---- few needles (<= 512 descriptors: one ORB needle image, the reference's query shape, cvfeaturesindex.cpp:497) ----
 // With 16 needle tiles the kernel above gives each wave 6 row tiles and 192 MFMAs of work behind a prologue (row loads,
 // FP4 expansion) that nothing overlaps: 1.5 ms for 5*10^7 rows where the matrix cores need 0.9.  Here the roles are
@@ -233,6 +368,7 @@ __global__ __launch_bounds__(kThreads) void k_hamm256_small(
 int g_scan256_small = 1;   // "scan256_small": the stationary-needle kernel for <= 512 needle descriptors (default on)
 int g_scan256_small_wgs = 0;  // its grid (workgroups); 0 = 2048
 int g_scan256_mfma = 1;
+int g_scan256_f3 = 1;      // "scan256_f3": three needle tiles per accumulator in the prefilter (k_hamm256_mfma3); 0 = one
 int g_scan256_pre = 1;     // first-128-bit prefilter variant for thresh <= kPre128MaxThresh
 int g_scan256_pre_ht = 6;   // its row tiles per wave (6, 8, 12)
 constexpr int kPre128MaxThresh = 40;
@@ -254,6 +390,9 @@ void set_scan256_ht(int ht) {
 void set_scan256_small(int v) {
   if (v == 0 || v == 1) g_scan256_small = v;
   if (v >= 16) g_scan256_small_wgs = v;  // workgroups of the persistent grid
+}
+void set_scan256_f3(int v) {
+  if (v >= 0) g_scan256_f3 = v;  // 0 off, 1 default shape, 62 / 63 / 82 / 122 / 123: HT G
 }
 void set_scan256_pre(int on) {
   if (on >= 0) g_scan256_pre = on;
@@ -299,6 +438,42 @@ int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, siz
     hipError_t es = hipGetLastError();
     (void)cbh::free_async(qx, stream);
     CBH_HIP(es);
+    return CBH_OK;
+  }
+  if (g_scan256_f3 && g_scan256_pre && thresh <= kPre128MaxThresh && n_tiles >= 3) {
+    const uint32_t n_triples = (n_tiles + 2u) / 3u;
+    if (n_triples * 3u != n_tiles) {  // the scratch must hold whole triples (zero descriptors: dropped at qi >= nq)
+      (void)cbh::free_async(qx, stream);
+      qx = nullptr;
+      CBH_HIP(cbh::malloc_async((void**)&qx, (size_t)n_triples * 96u * 128u, stream));
+      hipLaunchKernelGGL(k_expand_needles256, dim3((8u * n_triples * 96u + 255u) / 256u), dim3(256), 0, stream,
+                         reinterpret_cast<const uint32_t*>(d_q), (uint32_t)nq, n_triples * 96u, qx);
+    }
+    const int shape = g_scan256_f3 >= 10 ? g_scan256_f3 : 122;  // measured (1e7 rows x 32 000 needles): 62 / 63 / 82 / 122 / 123 = 12.2 / 11.6 / 11.3 / 10.9 / 10.9 ms, one tile per accumulator 13.4
+    const int ht3 = shape / 10, g3 = shape % 10;
+    const uint32_t rows_per_wg3 = 32u * (uint32_t)ht3 * kWaves;
+    const uint32_t wgs3 = (uint32_t)((n + rows_per_wg3 - 1) / rows_per_wg3);
+    uint32_t tpc3 = 43;  // needle triples per chunk (4128 descriptors)
+    while (tpc3 > 2 && (uint64_t)wgs3 * ((n_triples + tpc3 - 1) / tpc3) < 8192) tpc3 = (tpc3 + 1) >> 1;
+    uint32_t chunks3 = (n_triples + tpc3 - 1) / tpc3;
+    if (chunks3 > 65535) {
+      tpc3 = (n_triples + 65534) / 65535;
+      chunks3 = (n_triples + tpc3 - 1) / tpc3;
+    }
+#define CBH_256F3(HT, GG)                                                                               \
+  hipLaunchKernelGGL((k_hamm256_mfma3<HT, GG>), dim3(wgs3, chunks3), dim3(kThreads), 0, stream,         \
+                     reinterpret_cast<const uint32_t*>(d_rows), (uint32_t)n, qx,                        \
+                     reinterpret_cast<const uint32_t*>(d_q), (uint32_t)nq, n_triples, tpc3,             \
+                     (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total)
+    if (ht3 == 12 && g3 == 3) CBH_256F3(12, 3);
+    else if (ht3 == 12) CBH_256F3(12, 2);
+    else if (ht3 == 8) CBH_256F3(8, 2);
+    else if (g3 == 3) CBH_256F3(6, 3);
+    else CBH_256F3(6, 2);
+#undef CBH_256F3
+    hipError_t e3 = hipGetLastError();
+    (void)cbh::free_async(qx, stream);
+    CBH_HIP(e3);
     return CBH_OK;
   }
   const bool pre128_ = g_scan256_pre && thresh <= kPre128MaxThresh;

@@ -46,19 +46,23 @@ def scan_path(request, gpu):
     L.cbh_set_tuning(b"scan_mfma_full3", 1)
 
 
-@pytest.fixture(params=["mfma", "mfma_rows", "valu"])
+@pytest.fixture(params=["mfma", "mfma_rows", "mfma_rows1", "valu"])
 def scan256_path(request, gpu):
     """As scan_path, for the 256-bit scan: the matrix-core kernels forced for any size -- "mfma": as shipped (searches
     with <= 512 needle descriptors and thresholds <= 40 on the stationary-needle kernel k_hamm256_small, the rest on
-    k_hamm256_mfma), "mfma_rows": k_hamm256_mfma alone -- then "valu": k_hamm256_scan."""
+    k_hamm256_mfma3 / k_hamm256_mfma), "mfma_rows": without k_hamm256_small (the prefilter with three needle tiles per
+    accumulator, k_hamm256_mfma3, from 65 needle descriptors up), "mfma_rows1": k_hamm256_mfma alone (one tile per
+    accumulator) -- then "valu": k_hamm256_scan."""
     from cbird_amd import _lib
 
     L = _lib.lib()
     L.cbh_set_tuning(b"scan256_mfma", 0 if request.param == "valu" else 2)
-    L.cbh_set_tuning(b"scan256_small", 0 if request.param == "mfma_rows" else 1)
+    L.cbh_set_tuning(b"scan256_small", 1 if request.param == "mfma" else 0)
+    L.cbh_set_tuning(b"scan256_f3", 0 if request.param == "mfma_rows1" else 1)
     yield request.param
     L.cbh_set_tuning(b"scan256_mfma", 1)
     L.cbh_set_tuning(b"scan256_small", 1)
+    L.cbh_set_tuning(b"scan256_f3", 1)
 
 
 @pytest.fixture(params=["cvdct", "canon"])
