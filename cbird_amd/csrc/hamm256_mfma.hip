@@ -281,15 +281,18 @@ __global__ __launch_bounds__(kThreads) void k_hamm256_mfma3(
 // FP4 expansion) that nothing overlaps: 1.5 ms for 5*10^7 rows where the matrix cores need 0.9.  Here the roles are
 // swapped: ALL needle tiles are the stationary operand (first 128 bits: NT x 2 operands of 4 VGPRs), a persistent wave
 // streams row tiles -- the raw words of the next tile are in flight while the current one runs its NT x 2 MFMAs -- and
-// the grid is sized for the machine, not for the needle chunks.  First-128-bit prefilter only (thresh <= 40), hits as
-// above.  Records identical to k_hamm256_mfma / k_hamm256_scan.
+// the grid is sized for the machine, not for the needle chunks.  First-128-bit prefilter only (thresh <= 40) with the
+// three-tiles-per-accumulator fields of k_hamm256_mfma3.  Records identical to k_hamm256_mfma / k_hamm256_scan.
 template <int NT>
 __global__ __launch_bounds__(kThreads) void k_hamm256_small(
     const uint32_t* __restrict__ rows /* 8 words per row */, uint32_t n, const uint4* __restrict__ qx,
     const uint32_t* __restrict__ qraw, uint32_t nq, uint32_t thresh, unsigned long long* __restrict__ rec,
     unsigned long long cap, unsigned long long* __restrict__ total) {
-  constexpr int G = 4;  // accumulators in flight
-  __shared__ float s_c[kWaves][G * 16][64];
+  // needle tiles 3j, 3j+1, 3j+2 share accumulator j (the 8-bit flag fields of k_hamm256_mfma3; the last accumulator holds
+  // the one or two tiles that remain): 16 result registers per up to six MFMAs
+  constexpr int NA = (NT + 2) / 3;
+  constexpr int G = 2;  // accumulators in flight
+  __shared__ uint32_t s_c[kWaves][G * 16][64];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t r = lane & 31u, half = lane >> 5;
   v8i b[NT][2];
@@ -297,7 +300,10 @@ __global__ __launch_bounds__(kThreads) void k_hamm256_small(
   for (int q = 0; q < NT; ++q)
 #pragma unroll
     for (int k = 0; k < 2; ++k) b[q][k] = fp4_operand(qx[(size_t)q * 256u + (uint32_t)k * 64u + half * 32u + r]);
-  const float dot_thr = 128.0f - 2.0f * (float)(thresh - 1u);
+  v16f c0;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) c0[g] = 8388608.0f + (float)((64u + (thresh - 1u)) * 65793u);
+  asm volatile("" : "+v"(c0));
   const uint32_t n_row_tiles = (n + 31u) / 32u;
   const uint32_t stride = gridDim.x * kWaves;
   uint32_t tile = blockIdx.x * kWaves + wave;
@@ -317,46 +323,62 @@ __global__ __launch_bounds__(kThreads) void k_hamm256_small(
     for (int u = 0; u + 1 < kAhead; ++u) p0[u] = p0[u + 1], p1[u] = p1[u + 1];
     load_raw(tile + (uint32_t)kAhead * stride, p0[kAhead - 1], p1[kAhead - 1]);  // behind the MFMAs of kAhead tiles
 #pragma unroll
-    for (int q0 = 0; q0 < NT; q0 += G) {
+    for (int j0 = 0; j0 < NA; j0 += G) {
       v16f c[G];
 #pragma unroll
-      for (int t = 0; t < G; ++t)
+      for (int t = 0; t < G; ++t) c[t] = c0;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) c[t][g] = 0.0f;
+      for (int f = 0; f < 3; ++f) {
+        const int sc = f == 0 ? kS256Half : (f == 1 ? kS256_7 : kS256_15);
 #pragma unroll
-      for (int t = 0; t < G; ++t)
-        c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b[q0 + t][0], c[t], 4, 4, 0, kScaleOne, 0, kScaleOne);
-#pragma unroll
-      for (int t = 0; t < G; ++t)
-        c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b[q0 + t][1], c[t], 4, 4, 0, kScaleOne, 0, kScaleOne);
-      float m0 = -512.0f, m1 = -512.0f;
-#pragma unroll
-      for (int t = 0; t < G; ++t)
-#pragma unroll
-        for (int g = 0; g < 16; g += 4) {
-          m0 = __builtin_fmaxf(__builtin_fmaxf(m0, c[t][g]), c[t][g + 1]);
-          m1 = __builtin_fmaxf(__builtin_fmaxf(m1, c[t][g + 2]), c[t][g + 3]);
+        for (int t = 0; t < G; ++t) {
+          const int q = 3 * (j0 + t) + f;
+          if (j0 + t < NA && q < NT)
+            c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b[q][0], c[t], 4, 4, 0, kScaleOne, 0, sc);
         }
-      if (__builtin_fmaxf(m0, m1) >= dot_thr) {  // rare: decode through LDS (C/D layout as in k_hamm256_mfma)
+#pragma unroll
+        for (int t = 0; t < G; ++t) {
+          const int q = 3 * (j0 + t) + f;
+          if (j0 + t < NA && q < NT)
+            c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b[q][1], c[t], 4, 4, 0, kScaleOne, 0, sc);
+        }
+      }
+      // (a field without a tile stays at its C0 value 64 + b < 128: never flagged for b < 64)
+      uint32_t o0 = 0, o1 = 0;
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+        if (j0 + t < NA) {
+#pragma unroll
+          for (int g = 0; g < 16; g += 4) {
+            o0 |= __float_as_uint(c[t][g]) | __float_as_uint(c[t][g + 1]);  // v_or3_b32
+            o1 |= __float_as_uint(c[t][g + 2]) | __float_as_uint(c[t][g + 3]);
+          }
+        }
+      if (__builtin_amdgcn_ballot_w64(((o0 | o1) & kFlag256) != 0) != 0) {  // rare: as in k_hamm256_mfma3
 #pragma unroll
         for (int t = 0; t < G; ++t)
 #pragma unroll
-          for (int g = 0; g < 16; ++g) s_c[wave][t * 16 + g][lane] = c[t][g];
+          for (int g = 0; g < 16; ++g) s_c[wave][t * 16 + g][lane] = (j0 + t < NA) ? __float_as_uint(c[t][g]) : 0u;
 #pragma unroll 1
         for (uint32_t e = 0; e < (uint32_t)G * 16u; ++e) {
-          const float dot = s_c[wave][e][lane];
-          if (dot >= dot_thr) {
-            const uint32_t g = e & 15u;
-            const uint32_t row = tile * 32u + (g & 3u) + 8u * (g >> 2) + 4u * half;
-            const uint32_t qi = ((uint32_t)q0 + (e >> 4)) * 32u + r;
-            if (row < n && qi < nq) {
-              uint32_t d = (uint32_t)(128 - (int)dot) >> 1;
+          const uint32_t bits = s_c[wave][e][lane];
+          if ((bits & kFlag256) == 0u) continue;
+          const uint32_t g = e & 15u;
+          const uint32_t row = tile * 32u + (g & 3u) + 8u * (g >> 2) + 4u * half;
+          if (row >= n) continue;
+          const bool moved = (bits >> 23) & 1u;
+#pragma unroll 1
+          for (uint32_t f = 0; f < 3u; ++f) {
+            if (!moved && ((bits >> (7u + 8u * f)) & 1u) == 0u) continue;
+            const uint32_t qt = 3u * ((uint32_t)j0 + (e >> 4)) + f;
+            const uint32_t qi = qt * 32u + r;
+            if (qt >= (uint32_t)NT || qi >= nq) continue;
+            uint32_t d = 0;
 #pragma unroll
-              for (int wd = 4; wd < 8; ++wd) d += __popc(rows[(size_t)row * 8u + wd] ^ qraw[(size_t)qi * 8u + wd]);
-              if (d < thresh) {
-                const unsigned long long slot = atomicAdd(total, 1ull);
-                if (slot < cap) rec[slot] = ((unsigned long long)qi << 41) | ((unsigned long long)d << 32) | row;
-              }
+            for (int wd = 0; wd < 8; ++wd) d += __popc(rows[(size_t)row * 8u + wd] ^ qraw[(size_t)qi * 8u + wd]);
+            if (d < thresh) {
+              const unsigned long long slot = atomicAdd(total, 1ull);
+              if (slot < cap) rec[slot] = ((unsigned long long)qi << 41) | ((unsigned long long)d << 32) | row;
             }
           }
         }
