@@ -162,7 +162,7 @@ constexpr int kS256_15 = (int)0x8e8e8e8e;    // 2^15
 constexpr uint32_t kFlag256 = (1u << 7) | (1u << 15) | (1u << 23);
 
 template <int HT, int G>
-__global__ __launch_bounds__(kThreads) void k_hamm256_mfma3(
+__global__ __launch_bounds__(kThreads, 2) void k_hamm256_mfma3(  // (2: accumulators in VGPRs, see k_hamm64_mfma3)
     const uint32_t* __restrict__ rows /* 8 words per row */, uint32_t n, const uint4* __restrict__ qx,
     const uint32_t* __restrict__ qraw /* 8 words per needle */, uint32_t nq, uint32_t n_triples,
     uint32_t triples_per_chunk, uint32_t thresh, unsigned long long* __restrict__ rec, unsigned long long cap,
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kThreads) void k_hamm256_mfma3(
 // the grid is sized for the machine, not for the needle chunks.  First-128-bit prefilter only (thresh <= 40) with the
 // three-tiles-per-accumulator fields of k_hamm256_mfma3.  Records identical to k_hamm256_mfma / k_hamm256_scan.
 template <int NT>
-__global__ __launch_bounds__(kThreads) void k_hamm256_small(
+__global__ __launch_bounds__(kThreads, 2) void k_hamm256_small(  // (2: accumulators in VGPRs, see k_hamm64_mfma3)
     const uint32_t* __restrict__ rows /* 8 words per row */, uint32_t n, const uint4* __restrict__ qx,
     const uint32_t* __restrict__ qraw, uint32_t nq, uint32_t thresh, unsigned long long* __restrict__ rec,
     unsigned long long cap, unsigned long long* __restrict__ total) {

@@ -437,8 +437,11 @@ __device__ __forceinline__ void handle_tile3(const v16f& c, uint32_t row0, uint3
   wave_order();
 }
 
+// (two workgroups per CU as the minimum: with at most 256 registers per lane the compiler keeps the accumulators in
+//  VGPRs -- given 512 it puts them in AGPRs and pays a v_accvgpr_read_b32 for every register the OR reduction touches,
+//  32 extra VALU instructions per six MFMAs)
 template <int HT, int G>
-__global__ __launch_bounds__(kThreads) void k_hamm64_mfma3(
+__global__ __launch_bounds__(kThreads, 2) void k_hamm64_mfma3(
     const uint2* __restrict__ hay, const uint32_t* __restrict__ ids, uint32_t n,
     const uint64_t* __restrict__ q, const uint4* __restrict__ qx, uint32_t nq, uint32_t n_triples,
     uint32_t triples_per_chunk, uint32_t thresh, cbh_record* __restrict__ rec,
