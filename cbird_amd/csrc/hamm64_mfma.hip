@@ -546,7 +546,7 @@ void set_scan_mfma_full3(int on) {
   if (on >= 0) g_mfma_full3 = on;
 }
 void set_scan_mfma_g(int g) {
-  if (g == 2 || g == 4) g_mfma_g = g;
+  if (g == 1 || g == 2 || g == 4) g_mfma_g = g;
 }
 
 bool scan_mfma_wanted(size_t n, size_t nq, int thresh) {
@@ -589,10 +589,13 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
       tpc = (n_triples + 65534) / 65535;
       ch3 = (n_triples + tpc - 1) / tpc;
     }
-    hipLaunchKernelGGL((k_hamm64_mfma3<8, kG>), dim3(wgs, ch3), dim3(kThreads), 0, stream,
-                       reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx, (uint32_t)nq,
-                       n_triples, tpc, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total,
-                       (uint32_t)(flags & 1u), reinterpret_cast<const uint2*>(d_qmask));
+#define CBH_MFMA3(GG)                                                                                        \
+  hipLaunchKernelGGL((k_hamm64_mfma3<8, GG>), dim3(wgs, ch3), dim3(kThreads), 0, stream,                     \
+                     reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx, (uint32_t)nq,    \
+                     n_triples, tpc, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total,              \
+                     (uint32_t)(flags & 1u), reinterpret_cast<const uint2*>(d_qmask))
+    if (g_mfma_g == 4) CBH_MFMA3(4); else if (g_mfma_g == 1) CBH_MFMA3(1); else CBH_MFMA3(2);
+#undef CBH_MFMA3
     hipError_t e3 = hipGetLastError();
     (void)cbh::free_async(qx, stream);
     CBH_HIP(e3);
