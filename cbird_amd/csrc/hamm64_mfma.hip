@@ -437,11 +437,12 @@ __device__ __forceinline__ void handle_tile3(const v16f& c, uint32_t row0, uint3
   wave_order();
 }
 
-// (two workgroups per CU as the minimum: with at most 256 registers per lane the compiler keeps the accumulators in
-//  VGPRs -- given 512 it puts them in AGPRs and pays a v_accvgpr_read_b32 for every register the OR reduction touches,
-//  32 extra VALU instructions per six MFMAs)
-template <int HT, int G>
-__global__ __launch_bounds__(kThreads, 2) void k_hamm64_mfma3(
+// (MINB = 2 workgroups per CU as the minimum: with at most 256 registers per lane the compiler keeps the accumulators in
+//  VGPRs -- given 512 it puts them in AGPRs and adds a v_accvgpr_read_b32 for every register the OR reduction touches,
+//  71 instead of 39 VALU instructions per six MFMAs.  Measured on one box, alternating (tools/scan_ab.py): 17.2-17.4 ms
+//  either way -- the reads are not what holds the matrix pipe at 85 %; the VGPR form ships because it issues less.)
+template <int HT, int G, int MINB>
+__global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma3(
     const uint2* __restrict__ hay, const uint32_t* __restrict__ ids, uint32_t n,
     const uint64_t* __restrict__ q, const uint4* __restrict__ qx, uint32_t nq, uint32_t n_triples,
     uint32_t triples_per_chunk, uint32_t thresh, cbh_record* __restrict__ rec,
@@ -589,12 +590,12 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
       tpc = (n_triples + 65534) / 65535;
       ch3 = (n_triples + tpc - 1) / tpc;
     }
-#define CBH_MFMA3(GG)                                                                                        \
-  hipLaunchKernelGGL((k_hamm64_mfma3<8, GG>), dim3(wgs, ch3), dim3(kThreads), 0, stream,                     \
+#define CBH_MFMA3(GG, MB)                                                                                      \
+  hipLaunchKernelGGL((k_hamm64_mfma3<8, GG, MB>), dim3(wgs, ch3), dim3(kThreads), 0, stream,                 \
                      reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx, (uint32_t)nq,    \
                      n_triples, tpc, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total,              \
                      (uint32_t)(flags & 1u), reinterpret_cast<const uint2*>(d_qmask))
-    if (g_mfma_g == 4) CBH_MFMA3(4); else if (g_mfma_g == 1) CBH_MFMA3(1); else CBH_MFMA3(2);
+    if (g_mfma_g == 4) CBH_MFMA3(4, 2); else if (g_mfma_g == 1) CBH_MFMA3(1, 2); else if (g_mfma_full3 == 2) CBH_MFMA3(2, 1); else CBH_MFMA3(2, 2);  // full3 = 2: accumulators in AGPRs (A/B)
 #undef CBH_MFMA3
     hipError_t e3 = hipGetLastError();
     (void)cbh::free_async(qx, stream);
