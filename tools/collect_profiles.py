@@ -78,7 +78,7 @@ def main():
         out[key] = t
         out[key + "_detail"] = {"FETCH_SIZE_KiB_raw": fm, "WRITE_SIZE_KiB_raw": wm, "formula": FORMULA}
     out["source"] = (f"profiles/{TAG}_pmc_FETCH_SIZE.csv, profiles/{TAG}_pmc_WRITE_SIZE.csv (separate rocprofv3 "
-                     "--pmc passes of `bench.py --steps 1 --warmup 0 --no-cpu-baseline`)")
+                     "--pmc passes of `bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-sharded-leg`)")
     with open(os.path.join(DST, "pmc_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
 
