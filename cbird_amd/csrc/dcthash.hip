@@ -1504,7 +1504,8 @@ __global__ __launch_bounds__(256) void k_blur_area_stream(const unsigned char* _
 // step boundaries.  LDS only holds the blurred rows of a step for the horizontal INTER_AREA chains, which are
 // k_blur_area_stream's.  Per step this removes the staging stores, the two window reads per row and lane, one of the
 // three workgroup barriers, and the load latency that sat exposed behind it.
-// Preconditions (checked by the launcher; everything else takes k_blur_area_stream): whole images (no view),
+// Preconditions (checked by the launcher; everything else takes k_blur_area_stream): whole images, or views that span
+// the parent's width (autocrop of a letterboxed frame: only the row mapping changes),
 // 32 <= w <= 2048 (one workgroup spans the row).  GEN = false: w a multiple of 8 and image base / row stride / image
 // stride multiples of 8 (aligned 8-byte loads, no extra shuffles); GEN = true: any width and alignment (+3 v_perm per
 // row and lane, unaligned dword loads).
@@ -1525,7 +1526,9 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
                                                         float* __restrict__ rows /* n * h * 32 */,
                                                         int ipb /* images side by side in the workgroup */,
                                                         unsigned n_imgs, const YRow* __restrict__ yrow = nullptr,
-                                                        int isy = 0, unsigned char* __restrict__ tiles_out = nullptr) {
+                                                        int isy = 0, unsigned char* __restrict__ tiles_out = nullptr,
+                                                        int oy = 0, int ph = 0 /* letterbox view: rows [oy, oy + h) of a
+                                                        parent of ph rows and the same width; 0 = whole image */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_fused[];
   constexpr int R = K / 2;
   constexpr int kStep = StreamK<K>::step;
@@ -1595,9 +1598,11 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
       for (int j = 0; j < 3; ++j) selR |= (unsigned)(4 + src_of(w - m + j) - (w - 4)) << (8 * j);
     }
   }
+  const int hp = ph ? ph : h;  // the rows above and below a view are the parent's; REFLECT_101 at the parent's edges
   auto row_base = [&](int s) -> unsigned {  // byte offset of (reflected, clamped) source row s
-    int ry = s < 0 ? -s : (s >= h ? 2 * (h - 1) - s : s);
-    ry = ry < 0 ? 0 : (ry >= h ? h - 1 : ry);
+    int ry = oy + s;
+    ry = ry < 0 ? -ry : (ry >= hp ? 2 * (hp - 1) - ry : ry);
+    ry = ry < 0 ? 0 : (ry >= hp ? hp - 1 : ry);
     return (unsigned)ry * row_stride;
   };
   unsigned ring[K][4];
@@ -3009,13 +3014,19 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
         const long long band_wgs = (long long)ncol * ((h + kBlurRB - 1) / kBlurRB) * (long long)m;
         int steps = (int)std::min<long long>(8, band_wgs / 3072);
         steps = std::min(steps, (h + 2 * (K_ / 2) + kstep - 1) / kstep);
-        if (w < 32 || h < 32 || view) steps = 0;  // (round 3: the fused strip kernel is 1.4-2.3x the band kernels on 64..160-px images too)
-        if (g_hash_stream >= 2) steps = g_hash_stream;
+        // a view that spans the parent's width (a letterboxed frame after autocrop) differs from a whole image in the
+        // row mapping only: the register-streaming kernel takes it; other views stay on the band kernels
+        const bool lbox = view && vw.ox == 0 && vw.pw == w;
+        const bool regs_ok = g_hash_regs && ncol == 1 && (size_t)vw.ph * row_stride < ((size_t)1 << 31);
+        const bool view_off = view && !(lbox && regs_ok);  // (k_blur_area_stream has no view form either)
+        if (w < 32 || h < 32 || view_off) steps = 0;  // (round 3: the fused strip kernel is 1.4-2.3x the band kernels on 64..160-px images too)
+        if (g_hash_stream >= 2 && !view_off) steps = g_hash_stream;
         if (g_hash_stream && steps >= 3) {
           const int strip_out = steps * kstep - 2 * (K_ / 2);
           dim3 gs((unsigned)ncol, (unsigned)((h + strip_out - 1) / strip_out), (unsigned)m);
           const size_t ssmem = (size_t)kstep * fpitch + (size_t)(integer ? 0 : at.xn) * sizeof(float);
-          if (g_hash_regs && ncol == 1 && (size_t)h * row_stride < ((size_t)1 << 31)) {
+          if (regs_ok) {
+            const int v_oy = view ? vw.oy : 0, v_ph = view ? vw.ph : 0;
             const bool gen = !(w % 8 == 0 && ((uintptr_t)src % 8) == 0 && row_stride % 8 == 0 && img_stride % 8 == 0);
             // blur input straight from global memory into registers (k_blur_area_regs); LDS = blurred rows + weights
             // lanes per image = w / 8.  Images whose last wave would be mostly empty share a 256-lane workgroup side by
@@ -3051,7 +3062,8 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsm));                  \
       hipLaunchKernelGGL((k_blur_area_regs<KK, GG, true>), dim3(1, 1, (unsigned)((m + ipb_f - 1) / ipb_f)),  \
                          dim3(std::min(256u, Tf_)), fsm, stream, src, w, h, (unsigned)row_stride, img_stride, at.x,       \
-                         at.xfirst, isx, steps_f, (float*)nullptr, ipb_f, (unsigned)m, at.yrow, isy, d_ftiles);      \
+                         at.xfirst, isx, steps_f, (float*)nullptr, ipb_f, (unsigned)m, at.yrow, isy, d_ftiles,       \
+                         v_oy, v_ph);                                                                        \
       break;                                                                                                 \
     }                                                                                                        \
     if (rsmem > 64 * 1024)                                                                                   \
@@ -3059,7 +3071,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rsmem));                  \
     hipLaunchKernelGGL((k_blur_area_regs<KK, GG, false>), dim3(1, gs.y, (unsigned)((m + ipb - 1) / ipb)), dim3(Tr), rsmem, \
                        stream, src, w, h, (unsigned)row_stride, img_stride, at.x, at.xfirst, isx, steps, d_rowsf,   \
-                       ipb, (unsigned)m);                                                                    \
+                       ipb, (unsigned)m, (const YRow*)nullptr, 0, (unsigned char*)nullptr, v_oy, v_ph);      \
   } while (0)
 #define CBH_REGS(KK)              \
   do {                            \

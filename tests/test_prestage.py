@@ -161,21 +161,35 @@ def test_autocropped_hash_uses_the_parent_border(gpu, po, orc):
     """autocrop() narrows cvGray to a colRange/rowRange VIEW (cvutil.cpp:1397-1401) and cv::blur on a view takes its
     border pixels from the parent image: the hash of a cropped image is the hash of the view, not of an isolated
     copy of the kept region.  Wide images (two column workgroups of the fused kernel) and small ones."""
+    from cbird_amd import _lib
     from cbird_amd.hashing import process_images
 
+    L = _lib.lib()
     rng = np.random.default_rng(6)
-    differs = 0
-    for (h, w, t, b, le, r) in ((300, 400, 40, 40, 0, 0), (700, 2600, 90, 90, 0, 0), (1200, 900, 0, 0, 100, 120),
-                                (64, 90, 8, 8, 0, 0)):
-        gray = np.stack([letterboxed(rng, h, w, t, b, le, r) for _ in range(2)])
-        got, rects = process_images(gray, 20)
-        for i in range(2):
-            wh, wr = po.process_image(gray[i], 20)
-            assert rects[i].tolist() == wr.tolist() and int(got[i]) == wh, (h, w, i)
-            x0, y0, x1, y1 = wr.tolist()
-            assert (x0, y0, x1, y1) != (0, 0, w, h)
-            differs += int(orc.dcthash64(gray[i][y0:y1, x0:x1]) != wh)
-    assert differs >= 1
+    differs = cropped = 0
+    cases = ((300, 400, 40, 40, 0, 0), (700, 2600, 90, 90, 0, 0), (1200, 900, 0, 0, 100, 120), (64, 90, 8, 8, 0, 0),
+             (480, 640, 60, 60, 0, 0), (1080, 1920, 140, 140, 0, 0), (450, 601, 50, 37, 0, 0), (300, 400, 0, 75, 0, 0),
+             (120, 160, 14, 14, 0, 0), (400, 533, 33, 0, 0, 0), (300, 400, 30, 30, 40, 0))
+    # as shipped (small batches: the band kernels), then with the strip kernels forced -- a view that spans the parent's
+    # width (letterbox) takes the register-streaming kernel with the parent's rows above and below it, split and fused;
+    # any other view must still come out right (it stays on the band kernels)
+    try:
+        for (stream, fuse) in ((1, 1), (3, 0), (8, 2)):
+            L.cbh_set_tuning(b"hash_stream", stream)
+            L.cbh_set_tuning(b"hash_fuse", fuse)
+            for (h, w, t, b, le, r) in cases:
+                gray = np.stack([letterboxed(rng, h, w, t, b, le, r) for _ in range(2)])
+                got, rects = process_images(gray, 20)
+                for i in range(2):
+                    wh, wr = po.process_image(gray[i], 20)
+                    assert rects[i].tolist() == wr.tolist() and int(got[i]) == wh, (h, w, i, stream, fuse)
+                    x0, y0, x1, y1 = wr.tolist()
+                    cropped += (x0, y0, x1, y1) != (0, 0, w, h)  # (one-sided bars are not always cropped)
+                    differs += int(orc.dcthash64(gray[i][y0:y1, x0:x1]) != wh)
+    finally:
+        L.cbh_set_tuning(b"hash_stream", 1)
+        L.cbh_set_tuning(b"hash_fuse", 1)
+    assert differs >= 3 and cropped >= 3 * 2 * 8
 
 
 @pytest.mark.gpu
