@@ -1504,8 +1504,9 @@ __global__ __launch_bounds__(256) void k_blur_area_stream(const unsigned char* _
 // step boundaries.  LDS only holds the blurred rows of a step for the horizontal INTER_AREA chains, which are
 // k_blur_area_stream's.  Per step this removes the staging stores, the two window reads per row and lane, one of the
 // three workgroup barriers, and the load latency that sat exposed behind it.
-// Preconditions (checked by the launcher; everything else takes k_blur_area_stream): whole images, or views that span
-// the parent's width (autocrop of a letterboxed frame: only the row mapping changes),
+// Preconditions (checked by the launcher; everything else takes k_blur_area_stream): whole images, or views whose left
+// and right edges are the parent's or lie at least 4 (+ the last lane's overhang) pixels inside it (autocrop of
+// letterboxed / pillarboxed frames: the row mapping and the edge lanes' roles change, nothing else),
 // 32 <= w <= 2048 (one workgroup spans the row).  GEN = false: w a multiple of 8 and image base / row stride / image
 // stride multiples of 8 (aligned 8-byte loads, no extra shuffles); GEN = true: any width and alignment (+3 v_perm per
 // row and lane, unaligned dword loads).
@@ -1527,8 +1528,9 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
                                                         int ipb /* images side by side in the workgroup */,
                                                         unsigned n_imgs, const YRow* __restrict__ yrow = nullptr,
                                                         int isy = 0, unsigned char* __restrict__ tiles_out = nullptr,
-                                                        int oy = 0, int ph = 0 /* letterbox view: rows [oy, oy + h) of a
-                                                        parent of ph rows and the same width; 0 = whole image */) {
+                                                        int oy = 0, int ph = 0, int ox = 0, int pw = 0
+                                                        /* a view: the w x h rectangle at (ox, oy) of a pw x ph parent
+                                                           that starts at imgs; ph = 0: whole images */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_fused[];
   constexpr int R = K / 2;
   constexpr int kStep = StreamK<K>::step;
@@ -1564,14 +1566,21 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
   // pixels -- it loads the LAST eight bytes of the row and shuffles real and mirrored pixels into place, its right
   // halo comes from those and the dword before them; for m <= 3 the lane before it reads its right halo from the
   // last dword of the row.  (sel1 / sel2 / selT are the identity and cost nothing unless GEN.)
-  unsigned selL = tl == 0 ? 0x01020300u : 0x07060504u;  // lane 0: (x, px3, px2, px1) from its own pixels
+  // A view (cv::blur on a cv::Mat view takes its border from the parent): where the parent has at least 4 more pixels
+  // on the left (li) the first lane is an interior lane; where it has room for the last lane's 8 pixels + 4 on the right
+  // (ri) so is the last one, whatever w mod 8 is -- its columns past the view are computed from real pixels and never
+  // read.  The launcher admits ox = 0 or >= 4 and ox + w = pw or ri; all offsets below are shifted by ox at the end.
+  const bool li = ox >= 4, ri = pw != 0 && ox + 8 * L + 4 <= pw;
+  unsigned selL = (tl == 0 && !li) ? 0x01020300u : 0x07060504u;  // lane 0: (x, px3, px2, px1) from its own pixels
   unsigned selR = 0x07060504u, sel1 = 0x03020100u, sel2 = 0x07060504u, selT = 0x07060504u;
   const unsigned offS = 8u * (unsigned)tl;  // where the lane's blurred pixels go in the LDS row
   unsigned offC = offS;
-  unsigned offL = tl == 0 ? offC : offC - 4u;
+  unsigned offL = (tl == 0 && !li) ? offC : offC - 4u;  // (lane 0 with li: ox - 4 after the shift)
   unsigned offR = offC + 8u;
   const int m = w & 7;
-  if (!GEN || m == 0) {
+  if (ri) {
+    // every lane reads real pixels on its right
+  } else if (!GEN || m == 0) {
     if (tl == L - 1) selR = 0x00000102u, offR = offC + 4u;  // (px w-2, w-3, w-4, x) from its own pixels
   } else {
     auto src_of = [&](int x) { return x <= w - 1 ? x : 2 * (w - 1) - x; };
@@ -1598,6 +1607,7 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
       for (int j = 0; j < 3; ++j) selR |= (unsigned)(4 + src_of(w - m + j) - (w - 4)) << (8 * j);
     }
   }
+  offC += (unsigned)ox, offL += (unsigned)ox, offR += (unsigned)ox;
   const int hp = ph ? ph : h;  // the rows above and below a view are the parent's; REFLECT_101 at the parent's edges
   auto row_base = [&](int s) -> unsigned {  // byte offset of (reflected, clamped) source row s
     int ry = oy + s;
@@ -3014,9 +3024,11 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
         const long long band_wgs = (long long)ncol * ((h + kBlurRB - 1) / kBlurRB) * (long long)m;
         int steps = (int)std::min<long long>(8, band_wgs / 3072);
         steps = std::min(steps, (h + 2 * (K_ / 2) + kstep - 1) / kstep);
-        // a view that spans the parent's width (a letterboxed frame after autocrop) differs from a whole image in the
-        // row mapping only: the register-streaming kernel takes it; other views stay on the band kernels
-        const bool lbox = view && vw.ox == 0 && vw.pw == w;
+        // a view whose vertical edges are the parent's or lie >= 4 pixels inside it (letterboxed / pillarboxed frames
+        // after autocrop) differs from a whole image in the row mapping and in which lanes mirror: the
+        // register-streaming kernel takes it; other views (a margin of 1..3 pixels) stay on the band kernels
+        const int Lv = (w + 7) / 8;
+        const bool lbox = view && (vw.ox == 0 || vw.ox >= 4) && (vw.ox + w == vw.pw || vw.ox + 8 * Lv + 4 <= vw.pw);
         const bool regs_ok = g_hash_regs && ncol == 1 && (size_t)vw.ph * row_stride < ((size_t)1 << 31);
         const bool view_off = view && !(lbox && regs_ok);  // (k_blur_area_stream has no view form either)
         if (w < 32 || h < 32 || view_off) steps = 0;  // (round 3: the fused strip kernel is 1.4-2.3x the band kernels on 64..160-px images too)
@@ -3026,8 +3038,10 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
           dim3 gs((unsigned)ncol, (unsigned)((h + strip_out - 1) / strip_out), (unsigned)m);
           const size_t ssmem = (size_t)kstep * fpitch + (size_t)(integer ? 0 : at.xn) * sizeof(float);
           if (regs_ok) {
-            const int v_oy = view ? vw.oy : 0, v_ph = view ? vw.ph : 0;
-            const bool gen = !(w % 8 == 0 && ((uintptr_t)src % 8) == 0 && row_stride % 8 == 0 && img_stride % 8 == 0);
+            const int v_oy = view ? vw.oy : 0, v_ph = view ? vw.ph : 0, v_ox = view ? vw.ox : 0, v_pw = view ? vw.pw : 0;
+            const bool v_ri = view && vw.ox + 8 * Lv + 4 <= vw.pw;  // the last lane reads real pixels: any w mod 8
+            const bool gen = !((w % 8 == 0 || v_ri) && ((uintptr_t)(src + v_ox) % 8) == 0 && row_stride % 8 == 0 &&
+                               img_stride % 8 == 0);
             // blur input straight from global memory into registers (k_blur_area_regs); LDS = blurred rows + weights
             // lanes per image = w / 8.  Images whose last wave would be mostly empty share a 256-lane workgroup side by
             // side (640 px: 80 of 128 lanes busy alone, 240 of 256 as three: +12 %); where the lanes are already
@@ -3063,7 +3077,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
       hipLaunchKernelGGL((k_blur_area_regs<KK, GG, true>), dim3(1, 1, (unsigned)((m + ipb_f - 1) / ipb_f)),  \
                          dim3(std::min(256u, Tf_)), fsm, stream, src, w, h, (unsigned)row_stride, img_stride, at.x,       \
                          at.xfirst, isx, steps_f, (float*)nullptr, ipb_f, (unsigned)m, at.yrow, isy, d_ftiles,       \
-                         v_oy, v_ph);                                                                        \
+                         v_oy, v_ph, v_ox, v_pw);                                                            \
       break;                                                                                                 \
     }                                                                                                        \
     if (rsmem > 64 * 1024)                                                                                   \
@@ -3071,7 +3085,8 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rsmem));                  \
     hipLaunchKernelGGL((k_blur_area_regs<KK, GG, false>), dim3(1, gs.y, (unsigned)((m + ipb - 1) / ipb)), dim3(Tr), rsmem, \
                        stream, src, w, h, (unsigned)row_stride, img_stride, at.x, at.xfirst, isx, steps, d_rowsf,   \
-                       ipb, (unsigned)m, (const YRow*)nullptr, 0, (unsigned char*)nullptr, v_oy, v_ph);      \
+                       ipb, (unsigned)m, (const YRow*)nullptr, 0, (unsigned char*)nullptr, v_oy, v_ph, v_ox, \
+                       v_pw);                                                                                \
   } while (0)
 #define CBH_REGS(KK)              \
   do {                            \
