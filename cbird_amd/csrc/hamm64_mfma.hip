@@ -236,8 +236,8 @@ __device__ __forceinline__ void handle_tile(const v16f& c, uint32_t row0, uint32
   wave_order();
 }
 
-template <int HT, int G, bool PRE>
-__global__ __launch_bounds__(kThreads, (PRE && G == 2 && HT == 8) ? 3 : 1) void k_hamm64_mfma(
+template <int HT, int G, bool PRE, int MINB = ((PRE && G == 2 && HT == 8) ? 3 : 1)>
+__global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
     const uint2* __restrict__ hay, const uint32_t* __restrict__ ids, uint32_t n,
     const uint64_t* __restrict__ q, const uint4* __restrict__ qx, uint32_t nq, uint32_t n_pairs,
     uint32_t pairs_per_chunk, uint32_t thresh, cbh_record* __restrict__ rec,
@@ -529,6 +529,9 @@ int g_scan_mfma = 1;           // use the matrix-core scan when the batch is lar
 int g_mfma_full3 = 1;          // three-field variant for kPreMaxThresh < thresh <= 64
 int g_mfma_ht = 8;             // haystack tiles per wave (2, 4 or 8)
 int g_mfma_pre = 1;            // low-word prefilter variant for thresh <= kPreMaxThresh
+int g_mfma_pre_minb = 4;       // "scan_mfma_pre" = 11 .. 14: the prefilter compiled for >= 1 / 2 / 3 / 4 workgroups per CU.  Same box,
+                               // alternating (tools/scan_pre_ab.py): 10.8 / 10.8 / 10.1 / 9.8 ms -- this kernel is bound by VALU
+                               // issue, and a fourth wave per SIMD (128 VGPRs, 12 bytes of spill) hides more of it
 int g_mfma_g = 2;              // haystack tiles per accumulator group (2 or 4; HT = 8 only)
 uint32_t g_mfma_min_nq = 256;  // below this the needle expansion + tile padding is not worth it
 
@@ -541,6 +544,10 @@ void set_scan_mfma_ht(int ht) {
   if (ht == 2 || ht == 4 || ht == 8) g_mfma_ht = ht;
 }
 void set_scan_mfma_pre(int on) {
+  if (on >= 11 && on <= 14) {
+    g_mfma_pre_minb = on - 10;
+    return;
+  }
   if (on >= 0) g_mfma_pre = on;
 }
 void set_scan_mfma_full3(int on) {
@@ -595,7 +602,7 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
                      reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx, (uint32_t)nq,    \
                      n_triples, tpc, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total,              \
                      (uint32_t)(flags & 1u), reinterpret_cast<const uint2*>(d_qmask))
-    if (g_mfma_g == 4) CBH_MFMA3(4, 2); else if (g_mfma_g == 1) CBH_MFMA3(1, 2); else if (g_mfma_full3 == 2) CBH_MFMA3(2, 1); else CBH_MFMA3(2, 2);  // full3 = 2: accumulators in AGPRs (A/B)
+    if (g_mfma_g == 4) CBH_MFMA3(4, 2); else if (g_mfma_g == 1) CBH_MFMA3(1, 2); else if (g_mfma_full3 == 2) CBH_MFMA3(2, 1); else if (g_mfma_full3 == 3) CBH_MFMA3(2, 3); else CBH_MFMA3(2, 2);  // full3 = 2: accumulators in AGPRs (A/B)
 #undef CBH_MFMA3
     hipError_t e3 = hipGetLastError();
     (void)cbh::free_async(qx, stream);
@@ -611,6 +618,14 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
 #define CBH_MFMA(HT, PRE) CBH_MFMA_G(HT, kG, PRE)
   if (ht == 8 && g_mfma_g == 4) {
     if (pre) CBH_MFMA_G(8, 4, true); else CBH_MFMA_G(8, 4, false);
+  } else if (ht == 8 && pre && g_mfma_pre_minb != 3) {  // A/B: workgroups per CU the prefilter is compiled for
+#define CBH_MFMA_B(MB)                                                                                    \
+  hipLaunchKernelGGL((k_hamm64_mfma<8, kG, true, MB>), dim3(wgs, chunks), dim3(kThreads), 0, stream,      \
+                     reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx, (uint32_t)nq, \
+                     n_pairs, ppc, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total,             \
+                     (uint32_t)(flags & 1u), reinterpret_cast<const uint2*>(d_qmask))
+    if (g_mfma_pre_minb == 2) CBH_MFMA_B(2); else if (g_mfma_pre_minb == 4) CBH_MFMA_B(4); else CBH_MFMA_B(1);
+#undef CBH_MFMA_B
   } else if (ht == 8) {
     if (pre) CBH_MFMA(8, true); else CBH_MFMA(8, false);
   } else if (ht == 2) {

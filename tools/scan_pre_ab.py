@@ -1,6 +1,7 @@
-"""Same-box A/B of the three-field 64-bit scan: accumulators in VGPRs (scan_mfma_full3 = 1, shipped) against AGPRs
-(= 2, what the compiler chooses when a wave may use 512 registers), alternating, on the bench's image-derived hashes.
-    python tools/scan_ab.py [n=1000000] [rounds=6]"""
+"""Same-box A/B of the prefilter scan (dht 2) by the occupancy it is compiled for: cbh_set_tuning("scan_mfma_pre", 10 +
+min workgroups per CU): 13 = shipped (3 waves per SIMD, 168 VGPRs), 12 (2 waves, 190), 14 (4 waves, 128 VGPRs + spills),
+11 (no limit: accumulators in AGPRs).  Alternating rounds on the bench's image-derived hashes.
+    python tools/scan_pre_ab.py [n=1000000] [rounds=5]"""
 import ctypes as C, json, sys
 import torch
 sys.path.insert(0, ".")
@@ -9,7 +10,7 @@ from cbird_amd import _lib
 import bench
 L = _lib.lib()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-R = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+R = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = torch.device("cuda", 0)
 out = torch.empty(N, dtype=torch.int64, device=dev)
 for c0 in range(0, N, 100000):
@@ -22,11 +23,11 @@ idx.load_device(out.data_ptr(), ids.data_ptr(), N)
 cap = 1 << 24
 drec = torch.empty(cap, dtype=torch.int64, device=dev); dtot = torch.zeros(1, dtype=torch.int64, device=dev)
 ms = C.c_float(0)
-res = {"vgpr": [], "agpr": [], "vgpr_minb3": []}
+res = {}
 for r in range(R):
-    for name, v in (("vgpr", 1), ("agpr", 2), ("vgpr_minb3", 3)):
-        L.cbh_set_tuning(b"scan_mfma_full3", v)
-        _lib.check(L.cbh_idx64_time_scan_dev(idx.handle, out.data_ptr(), N, 7, drec.data_ptr(), cap, dtot.data_ptr(), 4, C.byref(ms)), "t")
-        res[name].append(round(ms.value, 3))
-L.cbh_set_tuning(b"scan_mfma_full3", 1)
+    for v in (13, 12, 14, 11):
+        L.cbh_set_tuning(b"scan_mfma_pre", v)
+        _lib.check(L.cbh_idx64_time_scan_dev(idx.handle, out.data_ptr(), N, 3, drec.data_ptr(), cap, dtot.data_ptr(), 4, C.byref(ms)), "t")
+        res.setdefault(f"minb{v - 10}", []).append([round(ms.value, 3), int(dtot.item())])
+L.cbh_set_tuning(b"scan_mfma_pre", 13)
 print(json.dumps(res))
