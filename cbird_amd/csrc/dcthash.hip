@@ -3063,11 +3063,16 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
             // (measured, hash_fuse 0 -> 2: 320x240 +30 %, 400x300 +22 %, 533x400 +19 %, 640x480 +8 %, 800x600 +6 %,
             // 1366x768 +6 %, 1024x768 -2 %, 1280x960 -8 %, 1080p -7 %: large images spend little in k_tile_hash and
             // lose occupancy to the extra LDS; fractional ratios gain up to ~1 MP)
+            const unsigned Tf_ = (unsigned)std::max(64, (ipb_f * std::max(Lr, 32) + 63) / 64 * 64);
+            // a fused workgroup walks its whole image alone: with one or two waves per workgroup the machine needs
+            // thousands of them before that beats strips of 8 steps (tools/hash_small_batches.py: 400x300, one wave per
+            // image, 1024 images 137 us fused / 86 split, 2048: 160 / 148, 4096: 289 / 298; 800x600, two waves:
+            // 2048 images 553 / 483, 4096: 945 / 951; four-wave workgroups of 3-6 images pay from ~600 up)
+            const size_t fuse_min_wgs = Tf_ <= 64 ? 4096 : Tf_ <= 128 ? 3072 : 512;
             const bool fuse = g_hash_fuse && fsm <= 160 * 1024 - 1024 && (integer || at.yrow) &&
                               (g_hash_fuse >= 2 ||
-                               ((m + (size_t)ipb_f - 1) / (size_t)ipb_f >= 512 &&
+                               ((m + (size_t)ipb_f - 1) / (size_t)ipb_f >= fuse_min_wgs &&
                                 (size_t)w * (size_t)h <= (integer ? 400000u : 1100000u)));
-            const unsigned Tf_ = (unsigned)std::max(64, (ipb_f * std::max(Lr, 32) + 63) / 64 * 64);
 #define CBH_REGS_(KK, GG)                                                                                    \
   do {                                                                                                       \
     if (fuse) {                                                                                              \
