@@ -407,34 +407,36 @@ __device__ __forceinline__ void handle_tile3(const v16f& c, uint32_t row0, uint3
   for (int g = 0; g < 16; ++g) any |= as_u32(c[g]);
   if (__builtin_amdgcn_ballot_w64((any & kFlagMask3) != 0) == 0) return;  // the other tile of the group
   const uint32_t b = hp.thresh - 1u;
-  uint32_t cnt = 0;  // wave-uniform
+  // one pass per field: the queue holds 16 registers x 64 lanes (4 KB per wave, 16 KB per workgroup, so that LDS never
+  // limits the waves per SIMD); the records of a tile come out field by field -- their order in the block is free
+#pragma unroll 1
+  for (uint32_t f = 0; f < 3; ++f) {
+    uint32_t cnt = 0;  // wave-uniform
 #pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const uint32_t bits = as_u32(c[g]);
-    if (__builtin_amdgcn_ballot_w64((bits & kFlagMask3) != 0) == 0) continue;
-#pragma unroll
-    for (uint32_t f = 0; f < 3; ++f) {
+    for (int g = 0; g < 16; ++g) {
+      const uint32_t bits = as_u32(c[g]);
       const bool fl = (bits >> (7u + 7u * f)) & 1u;
       const uint64_t m = __builtin_amdgcn_ballot_w64(fl);
+      if (m == 0) continue;
       if (fl)  // entry: dist<<12 | field<<10 | g<<6 | lane
         s_queue[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
             ((64u + b - ((bits >> (1u + 7u * f)) & 0x7fu)) << 12) | (f << 10) | ((uint32_t)g << 6) | lane;
       cnt += (uint32_t)__popcll(m);
     }
-  }
-  wave_order();
-  for (uint32_t k = lane; k < cnt; k += 64u) {
-    const uint32_t e = s_queue[k];
-    const uint32_t src = e & 63u, g = (e >> 6) & 15u, field = (e >> 10) & 3u, d = e >> 12;
-    const uint32_t row = row0 + (g & 3u) + 8u * (g >> 2) + 4u * (src >> 5);
-    const uint32_t qi = p3 * 96u + field * 32u + (src & 31u);
-    const uint64_t nv = (row < hp.n && qi < hp.nq) ? hp.q[qi] : 0;
-    if (nv != 0 && mask_ok(hp, row, qi, nv)) {
-      const uint32_t id = hp.ids[row];
-      if (id != 0 || hp.keep0) emit(hp.rec, hp.cap, hp.total, qi, d, id);
+    wave_order();
+    for (uint32_t k = lane; k < cnt; k += 64u) {
+      const uint32_t e = s_queue[k];
+      const uint32_t src = e & 63u, g = (e >> 6) & 15u, field = (e >> 10) & 3u, d = e >> 12;
+      const uint32_t row = row0 + (g & 3u) + 8u * (g >> 2) + 4u * (src >> 5);
+      const uint32_t qi = p3 * 96u + field * 32u + (src & 31u);
+      const uint64_t nv = (row < hp.n && qi < hp.nq) ? hp.q[qi] : 0;
+      if (nv != 0 && mask_ok(hp, row, qi, nv)) {
+        const uint32_t id = hp.ids[row];
+        if (id != 0 || hp.keep0) emit(hp.rec, hp.cap, hp.total, qi, d, id);
+      }
     }
+    wave_order();
   }
-  wave_order();
 }
 
 // (MINB = 2 workgroups per CU as the minimum: with at most 256 registers per lane the compiler keeps the accumulators in
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma3(
     uint32_t triples_per_chunk, uint32_t thresh, cbh_record* __restrict__ rec,
     unsigned long long cap, unsigned long long* __restrict__ total, uint32_t keep0,
     const uint2* __restrict__ qmask) {
-  __shared__ uint32_t s_queue_[kWaves][3 * 16 * 64];
+  __shared__ uint32_t s_queue_[kWaves][16 * 64];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t r = lane & 31u, half = lane >> 5;
   const uint32_t tile0 = (blockIdx.x * kWaves + wave) * HT;
@@ -602,7 +604,7 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
                      reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx, (uint32_t)nq,    \
                      n_triples, tpc, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total,              \
                      (uint32_t)(flags & 1u), reinterpret_cast<const uint2*>(d_qmask))
-    if (g_mfma_g == 4) CBH_MFMA3(4, 2); else if (g_mfma_g == 1) CBH_MFMA3(1, 2); else if (g_mfma_full3 == 2) CBH_MFMA3(2, 1); else if (g_mfma_full3 == 3) CBH_MFMA3(2, 3); else CBH_MFMA3(2, 2);  // full3 = 2: accumulators in AGPRs (A/B)
+    if (g_mfma_g == 4) CBH_MFMA3(4, 2); else if (g_mfma_g == 1) CBH_MFMA3(1, 2); else if (g_mfma_full3 == 2) CBH_MFMA3(2, 1); else if (g_mfma_full3 == 3) CBH_MFMA3(2, 3); else CBH_MFMA3(2, 2);  // (compiled for 4 workgroups per CU it spills: 35 ms)  // full3 = 2: accumulators in AGPRs (A/B)
 #undef CBH_MFMA3
     hipError_t e3 = hipGetLastError();
     (void)cbh::free_async(qx, stream);
