@@ -22,11 +22,13 @@ idx.load_device(out.data_ptr(), ids.data_ptr(), N)
 cap = 1 << 24
 drec = torch.empty(cap, dtype=torch.int64, device=dev); dtot = torch.zeros(1, dtype=torch.int64, device=dev)
 ms = C.c_float(0)
-res = {"vgpr": [], "agpr": [], "vgpr_minb3": []}
+res = {"vgpr": [], "agpr": [], "vgpr_minb3": [], "one_tile_per_group": []}
 for r in range(R):
-    for name, v in (("vgpr", 1), ("agpr", 2), ("vgpr_minb3", 3)):
+    for name, v in (("vgpr", 1), ("agpr", 2), ("vgpr_minb3", 3), ("one_tile_per_group", 1)):
         L.cbh_set_tuning(b"scan_mfma_full3", v)
+        L.cbh_set_tuning(b"scan_mfma_g", 1 if name == "one_tile_per_group" else 2)
         _lib.check(L.cbh_idx64_time_scan_dev(idx.handle, out.data_ptr(), N, 7, drec.data_ptr(), cap, dtot.data_ptr(), 4, C.byref(ms)), "t")
         res[name].append(round(ms.value, 3))
 L.cbh_set_tuning(b"scan_mfma_full3", 1)
+L.cbh_set_tuning(b"scan_mfma_g", 2)
 print(json.dumps(res))
