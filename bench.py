@@ -35,6 +35,20 @@ FP4_PEAK_TFLOPS = 10000.0
 FLOP_PER_CMP = 128.0
 PRE_MAX_DHT = 4
 W = H = 256
+# The job is a pure function of (--images, --seed): every image is drawn from (seed, global index), so the match count
+# per threshold does not depend on the number of GPUs or on how the index is sharded.  Counts of the default job and of
+# the 80 k job tools/first_contact.sh runs at N = 2/4/8 (records before the maxMatches cut, self matches included),
+# taken from N = 1 runs whose full result lists equal the real VP-tree's (profiles/r04_bench_1gpu.json: full_identity).
+EXPECTED_MATCHES = {
+    (1_000_000, 1234): {1: 1173680, 2: 1197740, 3: 1199826, 4: 1199976, 5: 1200020, 6: 1200182, 7: 1200936, 8: 1204352},
+    (80_000, 1234): {1: 93880, 2: 95842, 3: 95984, 4: 96000, 5: 96000, 6: 96000, 7: 96000, 8: 96010},
+}
+# (images, seed) -> sha256 of the u64[images] hashes (little-endian), from the same runs: all of them equal to the CPU
+# port's (hash_identity).  The images come from torch's float cos on the device, so this pins the torch build as well.
+EXPECTED_HASH_SHA256 = {
+    (1_000_000, 1234): "ae7b89309a8421bdcab29137646136129fcb4526432740ff084bbdcb5eb0942e",
+    (80_000, 1234): "2dd2076739283ba0b8b8c86577845060bfdd32172b07217f5896cf8059a44532",
+}
 
 
 def parse():
@@ -117,6 +131,8 @@ def main():
                   file=sys.stderr)
         sys.exit(2)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import datetime
+
     import torch
     import torch.distributed as dist
 
@@ -137,10 +153,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
     if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # 120 s: a rank that never arrives makes the others exit non-zero instead of holding the node
+        tmo = datetime.timedelta(seconds=int(os.environ.get("CBH_BENCH_INIT_TIMEOUT", "120")))
         if share:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
     ops = HipOps(local_rank)  # raises without libcbird_hip.so / a gfx950 device: no fallback
     sh = ShardedDctHashIndex(ops, record_capacity=1 << 22)
 
@@ -323,6 +341,30 @@ def main():
         finally:
             ops.L.cbh_set_tuning(b"scan_mfma", 1)
         result["popcount_kernel_scan_ms"] = pop
+    exp = EXPECTED_MATCHES.get((n, args.seed))
+    got_matches = {s_["dht"]: s_["matches"] for s_ in sweep}
+    result["matches_expected"] = None if exp is None or any(d not in exp for d in dhts) else \
+        all(got_matches[d] == exp[d] for d in dhts)
+    if exp is not None and result["matches_expected"] is False:
+        result["matches_expected_table"] = {str(d): exp.get(d) for d in dhts}
+    if rank == 0 and (n, args.seed) in EXPECTED_HASH_SHA256:  # every rank holds all hashes (gather_hashes)
+        import hashlib
+
+        result["hashes_expected"] = hashlib.sha256(
+            state["hashes"].cpu().numpy().tobytes()).hexdigest() == EXPECTED_HASH_SHA256[(n, args.seed)]
+    if dist.is_initialized():
+        # the transport's own view of the job: how many ranks the communicator spans (a sum of ones through it) and
+        # which library carried it
+        ones = torch.ones(1, dtype=torch.int32, device="cpu" if share else dev)
+        dist.all_reduce(ones)
+        backend = dist.get_backend()
+        result["collective"] = {"backend": backend, "communicator_ranks": int(ones.item()),
+                                "world_size": dist.get_world_size()}
+        if backend == "nccl":
+            try:
+                result["collective"]["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception as e:  # the version query is informative only
+                result["collective"]["rccl_version"] = repr(e)[:80]
     if world > 1:
         # what every rank actually holds: its share of the images / index slots / descriptor rows, never another's
         mine = {"rank": rank, "device": local_rank, "images": b - a, "image_bytes": int(imgs.numel()),
@@ -332,16 +374,28 @@ def main():
         parts = [None] * world
         dist.all_gather_object(parts, mine)
         result["per_rank_residency"] = parts
+    done_group = None
+    if dist.is_initialized() and world > 1:
+        # rank 0 now runs a child process beside the line (up to 240 s) while the others wait: that wait happens on a
+        # gloo group with its own long timeout, not inside an RCCL collective under the 120 s watchdog
+        done_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=900))
     if rank == 0 and not args.no_sharded_leg:
         result["single_process_sharded"] = sharded_leg(args, world, local_rank, share)
     if rank == 0 and world == 1 and not args.no_features:
         result["indexer_stages"] = features_leg(torch, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args, torch, imgs, state, n, dhts)
+        result["cpu_baseline"] = cpu_baseline(args, torch, imgs, state, n, dhts, sh, ops)
+        # north_star's acceptance line, as fields of the contract line: every needle's full (mediaId, distance) list
+        # equal to the real VP-tree's, every hash equal to the CPU port's
+        result["full_identity"] = result["cpu_baseline"].get("full_identity")
+        result["hash_identity"] = result["cpu_baseline"].get("hash_identity")
     if rank == 0:
         print(json.dumps(result))
     if dist.is_initialized():
-        dist.barrier()
+        if done_group is not None:
+            dist.barrier(group=done_group)
+        else:
+            dist.barrier()
         dist.destroy_process_group()
 
 
@@ -671,7 +725,100 @@ def cvfeatures_leg(args, torch, dist, dev, local_rank, rank, world, share):
             "build_seconds_this_rank": t_build}
 
 
-def cpu_baseline(args, torch, imgs, state, n, dhts):
+def _csr_of_gpu(torch, res, np):
+    """(ids[nq,k], scores[nq,k], counts[nq]) with k >= max(counts) -> CSR (offsets u64, ids u32, dists i32); the rows
+    are already in (score, mediaId) ascending order (topk.hip)"""
+    gi, gs, gc = res
+    k = gi.shape[1]
+    keep = torch.arange(k, device=gi.device).view(1, -1) < gc.view(-1, 1)
+    ids = gi[keep].cpu().numpy().view(np.uint32)
+    dists = gs[keep].cpu().numpy().astype(np.int32)
+    off = np.zeros(gc.numel() + 1, np.uint64)
+    np.cumsum(gc.cpu().numpy().astype(np.uint64), out=off[1:])
+    return off, ids, dists
+
+
+def _digest(np, *arrays):
+    import hashlib
+
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def full_identity(args, torch, tree, hashes, state, n, sh, cores, thresholds):
+    """Every needle of the job against the whole index through the real VP-tree, full (mediaId, distance) lists in
+    canonical (distance, mediaId) order, against the GPU's full lists (the sweep's lists are cut at --topk: where some
+    needle has more matches than that, the threshold is searched again uncut, outside the timed region)."""
+    import numpy as np
+
+    out = []
+    for dht in thresholds:
+        t0 = time.perf_counter()
+        res = state[dht]
+        kmax = int(res[2].max().item())
+        if kmax > res[0].shape[1]:
+            res = sh.similar(state["hashes"], dht, kmax)
+            torch.cuda.synchronize()
+        g_off, g_ids, g_d = _csr_of_gpu(torch, res, np)
+        t_gpu = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        c_off, c_ids, c_d = tree.search_lists(hashes, dht, threads=cores)
+        t_cpu = time.perf_counter() - t0
+        equal = bool(len(g_ids) == len(c_ids) and (g_off == c_off).all() and (g_ids == c_ids).all()
+                     and (g_d == c_d).all())
+        out.append({"dht": dht, "needles": int(n), "index": int(n), "pairs": int(c_off[-1]),
+                    "longest_list": kmax, "equal": equal,
+                    "sha256_gpu": _digest(np, g_off, g_ids, g_d), "sha256_reference": _digest(np, c_off, c_ids, c_d),
+                    "reference": "src/tree/vptree.h compiled in place (oracle/_ref), %d threads" % cores,
+                    "reference_seconds": round(t_cpu, 2), "gpu_lists_seconds": round(t_gpu, 2)})
+    return out[0] if len(out) == 1 else out
+
+
+def hash_identity(torch, orc, imgs, gpu_hashes, cores):
+    """All images of this rank through the CPU port (oracle/fast_hash.c, the vectorised form; itself checked against the
+    scalar restatement on a sample in cpu_baseline) -- 512 MB chunks through two pinned buffers, the copy of one chunk
+    under the hashing of the previous."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+
+    n = len(imgs)
+    chunk = 8192
+    bufs = [torch.empty((chunk, H, W), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    copy = torch.cuda.Stream()
+    evs = [None, None]
+
+    def start(c):
+        a, b = c * chunk, min(n, (c + 1) * chunk)
+        with torch.cuda.stream(copy):
+            bufs[c % 2][: b - a].copy_(imgs[a:b], non_blocking=True)
+            evs[c % 2] = torch.cuda.Event()
+            evs[c % 2].record(copy)
+
+    t0 = time.perf_counter()
+    nchunks = -(-n // chunk)
+    bad = 0
+    cpu_all = np.empty(n, np.uint64)
+    start(0)
+    with ThreadPoolExecutor(cores) as ex:
+        for c in range(nchunks):
+            evs[c % 2].synchronize()
+            a, b = c * chunk, min(n, (c + 1) * chunk)
+            host = bufs[c % 2].numpy()[: b - a]
+            if c + 1 < nchunks:
+                start(c + 1)
+            parts = [p for p in np.array_split(np.arange(b - a), min(b - a, cores * 2)) if len(p)]
+            hs = list(ex.map(lambda ix: orc.dcthash64_fast256_batch(host[ix[0]: ix[-1] + 1]), parts))
+            cpu_all[a:b] = np.concatenate(hs)
+    dt = time.perf_counter() - t0
+    bad = int((cpu_all != gpu_hashes[:n]).sum())
+    return {"images": int(n), "equal": bad == 0, "differing": bad, "sha256_gpu": _digest(np, gpu_hashes[:n]),
+            "sha256_port": _digest(np, cpu_all), "port": "oracle/fast_hash.c, %d threads" % cores,
+            "seconds": round(dt, 2), "images_per_s_incl_copy": n / dt}
+
+
+def cpu_baseline(args, torch, imgs, state, n, dhts, sh=None, ops=None):
     """The reference's own search structure (real VP-tree, oracle/_ref) -- or the C port when the
     prebuilt reference object is absent -- on this box's host cores, over a bounded sample of the
     same workload; also the checker for the GPU results of the sampled needles."""
@@ -709,6 +856,8 @@ def cpu_baseline(args, torch, imgs, state, n, dhts):
     out["hash_images_per_s_scalar_port"] = m_sc / t_sc
     out["hash_agrees_with_gpu"] = bool((cpu_h == hashes[:m_img]).all() and
                                        (np.concatenate(hs_sc) == hashes[:m_sc]).all())
+    if sh is not None:
+        out["hash_identity"] = hash_identity(torch, orc, imgs, hashes, cores)
     # -- find leg
     use_ref = oracle.ref_available()
     rng = np.random.default_rng(args.seed)
@@ -729,6 +878,9 @@ def cpu_baseline(args, torch, imgs, state, n, dhts):
         t_find = time.perf_counter() - t0
         kind = "reference"
         what = "VP-tree (src/tree/vptree.h compiled in place)"
+        if sh is not None and hasattr(tree, "search_lists") and hasattr(tree.lib(), "ref_dcttree_search_lists"):
+            ident = [d for d in (2,) if d in dhts] or dhts[:1]  # BASELINE configs[0]/[1]: -p.dht 2
+            out["full_identity"] = full_identity(args, torch, tree, hashes, state, n, sh, cores, ident)
     else:
         m = 64
         needles_ix = rng.choice(n, m, replace=False)

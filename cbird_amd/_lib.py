@@ -42,7 +42,8 @@ class cbh_stats(C.Structure):
 class cbh_shard_stats(C.Structure):
     _fields_ = [("shards", C.c_uint32), ("devices", C.c_uint32), ("device_mask", C.c_uint32),
                 ("segments", C.c_uint64), ("scans", C.c_uint64), ("rescans", C.c_uint64), ("collectives", C.c_uint64),
-                ("peer_copies", C.c_uint64), ("local_copies", C.c_uint64)]
+                ("peer_copies", C.c_uint64), ("local_copies", C.c_uint64),
+                ("collective_fallbacks", C.c_uint64)]
 
 
 class cbh_filter_params(C.Structure):
@@ -215,6 +216,7 @@ _SIGS = {
     "cbh_color_find": (C.c_int, [_vp, _vp, _vp, _sz, C.POINTER(_sz)]),
     "cbh_color_find_batch": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _vp]),
     "cbh_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
+    "cbh_get_tuning": (C.c_int, [C.c_char_p, C.POINTER(C.c_longlong)]),
     "cbh_idx64_get_stats": (C.c_int, [_vp, C.POINTER(cbh_stats)]),
     "cbh_idx64_reset_stats": (C.c_int, [_vp]),
     "cbh_idx64_time_scan_dev": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _sz, _vp, C.c_int,

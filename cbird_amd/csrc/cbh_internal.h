@@ -35,6 +35,42 @@ void set_scratch_poison(int v);
 void set_pool_keep_mb(int mb);
 int trim_pools(int device, unsigned long long* released_bytes);
 
+// ---- fault injection (cbird_hip.hip; tests/test_error_paths.py) ------------------------------------------------------
+// Every allocation the library makes -- scratch through malloc_async, index / table memory through hipMalloc, pinned
+// words through hipHostMalloc -- first passes fault_gate().  cbh_set_tuning("fault_alloc_after", n) arms it: the n-th
+// allocation from now (0 = the next one) fails ONCE with hipErrorOutOfMemory, then the gate disarms itself;
+// cbh_get_tuning("fault_alloc_after") reads what is left (-1 = disarmed or fired).  The arena's own calls into the
+// driver are written (hipMalloc)(...) and pass "fault_driver_oom" instead (the trim-and-retry path).
+hipError_t fault_gate();
+hipError_t fault_gate_driver();
+void set_fault_alloc_after(int n);
+void set_fault_driver_oom(int n);
+void set_fault_rccl(int v);  // sharded.hip: 1 = behave as if librccl could not be loaded
+long get_fault_alloc_after();
+unsigned long get_fault_fired();
+unsigned long get_alloc_calls();
+int arena_counter(const char* name, long long* value);
+template <class T>
+static inline hipError_t gated_malloc(T** p, size_t bytes) {
+  hipError_t e = fault_gate();
+  if (e != hipSuccess) {
+    *p = nullptr;
+    return e;
+  }
+  return (hipMalloc)(p, bytes);
+}
+template <class T>
+static inline hipError_t gated_host_malloc(T** p, size_t bytes, unsigned flags = hipHostMallocDefault) {
+  hipError_t e = fault_gate();
+  if (e != hipSuccess) {
+    *p = nullptr;
+    return e;
+  }
+  return (hipHostMalloc)(p, bytes, flags);
+}
+#define hipMalloc(...) ::cbh::gated_malloc(__VA_ARGS__)
+#define hipHostMalloc(...) ::cbh::gated_host_malloc(__VA_ARGS__)
+
 #define CBH_HIP(call)                          \
   do {                                         \
     hipError_t e_ = (call);                    \

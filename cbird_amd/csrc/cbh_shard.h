@@ -8,7 +8,9 @@
 //                     grouped ncclAllGather of the B_d, sized to the fullest device (1 + max count words) -- librccl
 //                     called directly, one communicator per device, all in this process (ncclCommInitAll), loaded with
 //                     dlopen on first use; level 3: the root compacts the D gathered blocks into the destination.
-//                     "shard_exchange" = 1 replaces levels 1-3 by hipMemcpyPeerAsync straight into the destination.
+//                     (the "shard_exchange" = 0 form).  The default, "shard_exchange" = 1, is hipMemcpyPeerAsync of
+//                     exactly count_s records straight into the destination: only the root consumes the records, an
+//                     all-gather would move D times the bytes.  Also the fallback when no communicator can be made.
 // With one device the collective is skipped unless "shard_force_rccl" = 1 (transport test of a one-GPU box).
 #pragma once
 #include <atomic>
@@ -59,6 +61,7 @@ struct ShardComm {
   std::vector<void*> comms;  // ncclComm_t, one per device, created with the first exchange that needs them
   bool comms_tried = false;
   std::atomic<uint64_t> n_scans{0}, n_rescans{0}, n_collectives{0}, n_peer_copies{0}, n_local_copies{0};
+  std::atomic<uint64_t> n_fallbacks{0};  // exchanges that wanted the collective and went by copies (no communicator)
 
   // device list of a mask (every named device must be a usable gfx950); false when the mask is unusable
   bool init(uint32_t device_mask, int shards_per_device);

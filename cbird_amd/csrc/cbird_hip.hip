@@ -6,6 +6,7 @@
 // scan -> sort -> select.  There is no CPU compute path in this file: if no gfx950 device is
 // usable every compute entry point returns CBH_E_NODEVICE.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -59,6 +60,16 @@ struct Arena {
   std::map<int, size_t> orphan_bytes;
   std::map<int, std::vector<hipMemPool_t>> idle_pools;  // mode 1
   std::map<void*, LiveInfo> live;  // blocks handed out by mode 2
+  // blocks a live stream's cache gave up because it exceeded the budget: work queued on that stream may still use them,
+  // so each waits for an event recorded behind that work and goes back to the driver once it has completed
+  struct Pending {
+    void* p;
+    size_t bytes;
+    int dev;
+    hipEvent_t ev;
+  };
+  std::vector<Pending> pending;
+  uint64_t n_trimmed_live = 0, n_oom_retry_stream = 0, n_oom_retry_device = 0;
   uint64_t clock = 0;
   uint64_t n_malloc = 0, n_reuse = 0, n_adopt = 0, n_evicted_dead = 0, n_evicted_idle = 0, n_released = 0;
 };
@@ -70,6 +81,23 @@ int g_scratch_mode = 2;
 int g_scratch_poison = 0;  // "scratch_poison": v > 0 fills every block handed out with byte v - 1 (finds kernels that
                            // read scratch they never wrote: fresh driver memory is zero, a recycled block is not)
 uint64_t g_pool_keep_bytes = (uint64_t)16 << 30;  // cached scratch that outlives its stream, per device ("pool_keep_mb")
+
+// fault injection (cbh_internal.h): countdowns, -1 = disarmed
+std::atomic<long> g_fault_alloc{-1}, g_fault_driver{-1};
+std::atomic<unsigned long> g_fault_fired{0}, g_alloc_calls{0};
+hipError_t countdown(std::atomic<long>& c) {
+  long v = c.load(std::memory_order_relaxed);
+  while (v >= 0) {
+    if (c.compare_exchange_weak(v, v - 1)) {
+      if (v == 0) {
+        g_fault_fired++;
+        return hipErrorOutOfMemory;
+      }
+      return hipSuccess;
+    }
+  }
+  return hipSuccess;
+}
 
 size_t round_size(size_t b) {
   if (b <= 256) return 256;
@@ -148,6 +176,44 @@ void evict(Arena& A, int dev, bool all, std::vector<void*>* to_free) {
 }
 }  // namespace
 
+hipError_t fault_gate() {
+  g_alloc_calls++;
+  return countdown(g_fault_alloc);
+}
+hipError_t fault_gate_driver() { return countdown(g_fault_driver); }
+void set_fault_alloc_after(int n) { g_fault_alloc = n < 0 ? -1 : n; }
+void set_fault_driver_oom(int n) { g_fault_driver = n < 0 ? -1 : n; }
+long get_fault_alloc_after() { return g_fault_alloc.load(); }
+unsigned long get_fault_fired() { return g_fault_fired.load(); }
+unsigned long get_alloc_calls() { return g_alloc_calls.load(); }
+
+namespace {
+// under A.mu: blocks of the pending list whose event has completed (to be hipFree'd outside the lock)
+void reap_pending(Arena& A, std::vector<void*>* to_free, std::vector<hipEvent_t>* evs) {
+  for (size_t i = 0; i < A.pending.size();) {
+    if (hipEventQuery(A.pending[i].ev) == hipErrorNotReady) {
+      ++i;
+      continue;
+    }
+    (void)hipGetLastError();
+    to_free->push_back(A.pending[i].p);
+    evs->push_back(A.pending[i].ev);
+    A.pending[i] = A.pending.back();
+    A.pending.pop_back();
+    A.n_released++;
+  }
+}
+// the driver's allocation of one arena block, through the "fault_driver_oom" gate
+hipError_t driver_malloc(void** p, size_t bytes) {
+  hipError_t e = fault_gate_driver();
+  if (e != hipSuccess) {
+    *p = nullptr;
+    return e;
+  }
+  return (hipMalloc)(p, bytes);
+}
+}  // namespace
+
 void set_scratch_mode(int v) { g_scratch_mode = v < 0 ? 0 : v > 2 ? 2 : v; }
 void set_pool_keep_mb(int mb) {
   g_pool_keep_bytes = mb < 0 ? ~0ull : (uint64_t)mb << 20;
@@ -159,7 +225,12 @@ void set_pool_keep_mb(int mb) {
 
 static hipError_t malloc_async_raw(void** p, size_t bytes, hipStream_t s);
 hipError_t malloc_async(void** p, size_t bytes, hipStream_t s) {
-  hipError_t e = malloc_async_raw(p, bytes, s);
+  hipError_t e = fault_gate();
+  if (e != hipSuccess) {
+    *p = nullptr;
+    return e;
+  }
+  e = malloc_async_raw(p, bytes, s);
   if (e == hipSuccess && g_scratch_poison > 0 && bytes) e = hipMemsetAsync(*p, g_scratch_poison - 1, bytes, s);
   return e;
 }
@@ -198,9 +269,11 @@ static hipError_t malloc_async_raw(void** p, size_t bytes, hipStream_t s) {
   }
   const size_t need = round_size(bytes);
   std::vector<void*> to_free;
+  std::vector<hipEvent_t> evs;
   {
     std::lock_guard<std::mutex> lk(A.mu);
     A.n_malloc++;
+    if (!A.pending.empty()) reap_pending(A, &to_free, &evs);
     auto it = A.caches.find({dev, s});
     if (it == A.caches.end()) {
       if (A.caches.size() >= kMaxStreamCaches) evict(A, dev, false, &to_free);
@@ -229,13 +302,62 @@ static hipError_t malloc_async_raw(void** p, size_t bytes, hipStream_t s) {
     }
   }
   for (void* q : to_free) (void)hipFree(q);
+  for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
   if (*p) return hipSuccess;
-  e = hipMalloc(p, need);
-  if (e == hipErrorOutOfMemory) {  // give back everything that is cached and idle, then try once more
+  e = driver_malloc(p, need);
+  if (e == hipErrorOutOfMemory) {
+    // 1. the calling stream's own cache: its blocks fit nothing (best_fit refused them), and after a synchronise of
+    //    this stream nothing uses them
     (void)hipGetLastError();
-    unsigned long long rel = 0;
-    (void)trim_pools(dev, &rel);
-    e = hipMalloc(p, need);
+    std::vector<Block> mine;
+    {
+      std::lock_guard<std::mutex> lk(A.mu);
+      auto it = A.caches.find({dev, s});
+      if (it != A.caches.end()) {
+        mine.swap(it->second.free);
+        it->second.free_bytes = 0;
+      }
+      A.n_oom_retry_stream++;
+    }
+    (void)hipStreamSynchronize(s);
+    for (Block& b : mine) (void)hipFree(b.p);
+    e = driver_malloc(p, need);
+  }
+  if (e == hipErrorOutOfMemory) {
+    // 2. every cached block of the device, whatever stream holds it: taken out of the caches first (nobody can be
+    //    handed one any more), then the device is synchronised (whatever was queued behind them has run), then freed
+    (void)hipGetLastError();
+    std::vector<void*> all;
+    std::vector<hipEvent_t> pev;
+    {
+      std::lock_guard<std::mutex> lk(A.mu);
+      for (auto& kv : A.caches)
+        if (kv.first.first == dev) {
+          for (Block& b : kv.second.free) all.push_back(b.p);
+          kv.second.free.clear();
+          kv.second.free_bytes = 0;
+        }
+      for (Block& b : A.orphan[dev]) all.push_back(b.p);
+      A.orphan[dev].clear();
+      A.orphan_bytes[dev] = 0;
+      for (size_t i = 0; i < A.pending.size();)
+        if (A.pending[i].dev == dev) {
+          all.push_back(A.pending[i].p);
+          pev.push_back(A.pending[i].ev);
+          A.pending[i] = A.pending.back();
+          A.pending.pop_back();
+        } else {
+          ++i;
+        }
+      A.n_oom_retry_device++;
+    }
+    (void)hipDeviceSynchronize();
+    for (void* q : all) (void)hipFree(q);
+    for (hipEvent_t ev : pev) (void)hipEventDestroy(ev);
+    hipMemPool_t def = nullptr;  // (modes 0 / 1 may have left memory in ROCm's pools)
+    if (hipDeviceGetDefaultMemPool(&def, dev) == hipSuccess && def) (void)hipMemPoolTrimTo(def, 0);
+    (void)hipGetLastError();
+    e = driver_malloc(p, need);
   }
   if (e != hipSuccess) return e;
   std::lock_guard<std::mutex> lk(A.mu);
@@ -256,10 +378,29 @@ hipError_t free_async(void* p, hipStream_t s) {
     c.last_use = ++A.clock;
     c.free.push_back(Block{p, info.bytes});
     c.free_bytes += info.bytes;
+    // A live stream keeps what it has used (the next call of the same caller finds its buffers mapped) up to the
+    // budget of "pool_keep_mb"; beyond it the blocks freed longest ago leave the cache.  Work queued on s may still
+    // use them, so they wait in the pending list behind an event recorded now.
+    if (c.free_bytes > g_pool_keep_bytes) {
+      hipEvent_t ev = nullptr;
+      size_t k = 0;
+      while (k < c.free.size() && c.free_bytes > g_pool_keep_bytes) {
+        hipEvent_t e1 = nullptr;
+        if (hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) break;
+        if (hipEventRecord(e1, s) != hipSuccess) {
+          (void)hipEventDestroy(e1);
+          break;
+        }
+        ev = e1;
+        A.pending.push_back(Arena::Pending{c.free[k].p, c.free[k].bytes, info.dev, ev});
+        c.free_bytes -= c.free[k].bytes;
+        A.n_trimmed_live++;
+        ++k;
+      }
+      c.free.erase(c.free.begin(), c.free.begin() + (long)k);
+      (void)hipGetLastError();
+    }
   }
-  // a live stream keeps what it has used (the next call of the same caller finds its buffers mapped: a
-               // 50 GB colour-descriptor scratch costs ~1 s to map again); it is given up when the stream goes away
-               // (stream_destroy / eviction: into the orphan list, which IS bounded) or on cbh_trim
   return hipSuccess;
 }
 
@@ -298,6 +439,7 @@ void stream_destroy(hipStream_t s) {
 int trim_pools(int device, unsigned long long* released_bytes) {
   Arena& A = arena();
   std::vector<void*> to_free;
+  std::vector<hipEvent_t> evs;
   unsigned long long rel = 0;
   std::vector<hipMemPool_t> pools;
   {
@@ -306,6 +448,7 @@ int trim_pools(int device, unsigned long long* released_bytes) {
     g_pool_keep_bytes = 0;
     evict(A, device, true, &to_free);
     g_pool_keep_bytes = keep;
+    reap_pending(A, &to_free, &evs);  // (the caller synchronised the device: every event has completed)
     for (auto& kv : A.caches)
       if (kv.first.first == device && kv.second.pool) pools.push_back(kv.second.pool);
     for (hipMemPool_t p : A.idle_pools[device]) pools.push_back(p);
@@ -314,6 +457,7 @@ int trim_pools(int device, unsigned long long* released_bytes) {
   size_t f0 = 0, f1 = 0, tot = 0;
   (void)hipMemGetInfo(&f0, &tot);
   for (void* q : to_free) (void)hipFree(q);
+  for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
   hipMemPool_t def = nullptr;
   if (hipDeviceGetDefaultMemPool(&def, device) == hipSuccess && def) pools.push_back(def);
   for (hipMemPool_t p : pools) (void)hipMemPoolTrimTo(p, 0);
@@ -321,6 +465,26 @@ int trim_pools(int device, unsigned long long* released_bytes) {
   rel = f1 > f0 ? f1 - f0 : 0;
   if (released_bytes) *released_bytes = rel;
   return CBH_OK;
+}
+
+// cbh_get_tuning("arena_<name>"): counters and sizes of the scratch arena, all devices together
+int arena_counter(const char* name, long long* value) {
+  Arena& A = arena();
+  std::lock_guard<std::mutex> lk(A.mu);
+  unsigned long long cached = 0, pend = 0, live = 0;
+  for (auto& kv : A.caches) cached += kv.second.free_bytes;
+  for (auto& kv : A.orphan_bytes) cached += kv.second;
+  for (auto& b : A.pending) pend += b.bytes;
+  for (auto& kv : A.live) live += kv.second.bytes;
+  if (!strcmp(name, "cached_bytes")) return *value = (long long)cached, CBH_OK;
+  if (!strcmp(name, "pending_bytes")) return *value = (long long)pend, CBH_OK;
+  if (!strcmp(name, "live_bytes")) return *value = (long long)live, CBH_OK;
+  if (!strcmp(name, "live_blocks")) return *value = (long long)A.live.size(), CBH_OK;
+  if (!strcmp(name, "trimmed_live")) return *value = (long long)A.n_trimmed_live, CBH_OK;
+  if (!strcmp(name, "oom_retry_stream")) return *value = (long long)A.n_oom_retry_stream, CBH_OK;
+  if (!strcmp(name, "oom_retry_device")) return *value = (long long)A.n_oom_retry_device, CBH_OK;
+  if (!strcmp(name, "released")) return *value = (long long)A.n_released, CBH_OK;
+  return CBH_E_INVAL;
 }
 
 }  // namespace cbh
@@ -1238,6 +1402,27 @@ int cbh_set_tuning(const char* key, int value) {
     set_scan_tuning(-1, -1, value);
     return CBH_OK;
   }
+  if (!strcmp(key, "fault_alloc_after")) {
+    set_fault_alloc_after(value);
+    return CBH_OK;
+  }
+  if (!strcmp(key, "fault_driver_oom")) {
+    set_fault_driver_oom(value);
+    return CBH_OK;
+  }
+  if (!strcmp(key, "fault_rccl")) {
+    set_fault_rccl(value);
+    return CBH_OK;
+  }
+  return CBH_E_INVAL;
+}
+
+int cbh_get_tuning(const char* key, long long* value) {
+  if (!key || !value) return CBH_E_INVAL;
+  if (!strcmp(key, "fault_alloc_after")) return *value = get_fault_alloc_after(), CBH_OK;
+  if (!strcmp(key, "fault_fired")) return *value = (long long)get_fault_fired(), CBH_OK;
+  if (!strcmp(key, "alloc_calls")) return *value = (long long)get_alloc_calls(), CBH_OK;
+  if (!strncmp(key, "arena_", 6)) return arena_counter(key + 6, value);
   return CBH_E_INVAL;
 }
 

@@ -43,6 +43,7 @@ struct Rccl {
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string why;  // when it could not be loaded
 };
@@ -74,19 +75,32 @@ Rccl* rccl() {
     CBH_SYM(GroupStart, "ncclGroupStart");
     CBH_SYM(GroupEnd, "ncclGroupEnd");
     CBH_SYM(GetErrorString, "ncclGetErrorString");
+    CBH_SYM(GetVersion, "ncclGetVersion");
 #undef CBH_SYM
+    // the copy found may be the one another library of this process brought along (PyTorch ships its own): use it only
+    // when it is the API generation this file was compiled against (same major version as <rccl/rccl.h>)
+    int v = 0;
+    if (x->why.empty() && (x->GetVersion(&v) != ncclSuccess || v / 10000 != NCCL_VERSION_CODE / 10000))
+      x->why = "librccl version " + std::to_string(v) + " does not match the headers (" + std::to_string(NCCL_VERSION_CODE) + ")";
     return x;
   }();
   return r;
 }
 
 int g_force_rccl = 0;  // "shard_force_rccl": the collective also at one device (transport test on a one-GPU box)
-int g_exchange = 0;    // "shard_exchange": 0 = ncclAllGather between devices, 1 = peer copies into the root block
+// "shard_exchange": 1 = copies of exactly count_s records into the root block (default: only the root device consumes
+// the records, an all-gather would put D times the bytes on the links), 0 = grouped ncclAllGather of the device blocks
+int g_exchange = 1;
+int g_fault_rccl = 0;  // "fault_rccl": librccl treated as absent
 
 int ensure_comms(ShardComm* C) {  // under coll_mu
   if (!C->comms.empty()) return CBH_OK;
   if (C->comms_tried) return CBH_E_UNSUPPORTED;
   C->comms_tried = true;
+  if (g_fault_rccl) {
+    set_last_error_text("RCCL unavailable: fault_rccl");
+    return CBH_E_UNSUPPORTED;
+  }
   Rccl* r = rccl();
   if (!r->handle || !r->why.empty()) {
     set_last_error_text(("RCCL unavailable: " + r->why).c_str());
@@ -106,6 +120,7 @@ int ensure_comms(ShardComm* C) {  // under coll_mu
 
 void set_shard_force_rccl(int v) { g_force_rccl = v; }
 void set_shard_exchange(int v) { g_exchange = v; }
+void set_fault_rccl(int v) { g_fault_rccl = v; }
 
 bool ShardComm::init(uint32_t device_mask, int shards_per_device) {
   if (device_mask == 0 || shards_per_device < 0 || shards_per_device > 64) return false;
@@ -117,7 +132,9 @@ bool ShardComm::init(uint32_t device_mask, int shards_per_device) {
     }
   per_device = std::max(1, shards_per_device);
   mask = device_mask;
-  if (devices.size() > 1)  // direct xGMI copies where the platform allows them (RCCL opens its own)
+  // direct xGMI copies where the platform allows them (RCCL opens its own).  A refusal is not an error: only copies
+  // cross devices (no kernel dereferences a peer pointer), and hipMemcpyPeerAsync stages through the host without it.
+  if (devices.size() > 1)
     for (int a : devices) {
       DeviceGuard g(a);
       for (int b : devices)
@@ -143,7 +160,17 @@ void ShardComm::destroy_comms() {
 int ShardComm::exchange(std::vector<ShardPart>& parts, hipStream_t root_stream, unsigned long long* d_dst) {
   const size_t R = parts.size(), D = devices.size();
   const int root = devices[0];
-  const bool collective = g_exchange == 0 && (D > 1 || g_force_rccl);
+  bool collective = g_exchange == 0 && (D > 1 || g_force_rccl);
+  if (collective) {
+    // no communicator (librccl absent or of another generation, ncclCommInitAll refused): the copies below give the
+    // same block; said once per index in cbh_last_error and on stderr, counted in cbh_shard_stats.collective_fallbacks
+    std::lock_guard<std::mutex> lk(coll_mu);
+    if (ensure_comms(this) != CBH_OK) {
+      collective = false;
+      if (!n_fallbacks.fetch_add(1))
+        fprintf(stderr, "cbird_hip: sharded index exchanges by device copies, not ncclAllGather (%s)\n", cbh_last_error());
+    }
+  }
   // per-device totals, the place of every shard inside its device's run, and of every device in the destination
   std::vector<unsigned long long> dev_total(D, 0), shard_off(R, 0), dev_off(D, 0);
   for (size_t s = 0; s < R; ++s) {
@@ -212,7 +239,7 @@ int ShardComm::exchange(std::vector<ShardPart>& parts, hipStream_t root_stream, 
   }
   {
     std::lock_guard<std::mutex> lk(coll_mu);
-    if ((rc = ensure_comms(this))) return rc;
+    if (comms.empty()) return CBH_E_UNSUPPORTED;  // (destroyed under our feet: an index being torn down)
     Rccl* r = rccl();
     ncclResult_t e = r->GroupStart();
     for (size_t d = 0; d < D && e == ncclSuccess; ++d) {
@@ -258,6 +285,9 @@ void shardset_free(ShardSet* S) {
 
 namespace {
 
+constexpr size_t kKeepXBufBytes = (size_t)64 << 20;  // exchange buffers above this go back after the call
+constexpr size_t kKeepShardRecs = (size_t)1 << 22;   // a shard's record block above this (32 MB) likewise
+
 // leases of one call: a workspace per shard, given back (idle) at the end
 struct ShardLeases {
   ShardSet* S;
@@ -278,6 +308,10 @@ struct ShardLeases {
       if (ws[s]) {
         DeviceGuard g(S->child[s]->device);
         (void)hipStreamSynchronize(ws[s]->stream);  // its buffers must be idle when the next call takes it
+        // one large result (a self-join attempt) must not leave every shard holding a block of that size for good
+        ws[s]->shrink_records(std::max<size_t>(S->child[s]->rec_cap_default, kKeepShardRecs));
+        for (XBuf& x : ws[s]->x)
+          if (x.bytes > kKeepXBufBytes) x.release();
         S->child[s]->give_back(ws[s]);
       }
   }
@@ -309,6 +343,7 @@ int sharded_scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t 
   std::vector<char> todo(R, 1);
   for (size_t s = 0; s < R; ++s) todo[s] = S->child[s]->n != 0;
   float scan_ms = 0.f;
+  unsigned long long running = 0;
   for (int attempt = 0; attempt < 3; ++attempt) {
     bool any = false;
     for (size_t s = 0; s < R; ++s) {
@@ -346,6 +381,7 @@ int sharded_scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t 
     }
     if (!any) break;
     float worst = 0.f;
+    // (running: counts of the shards that are done, across attempts)
     for (size_t s = 0; s < R; ++s) {
       if (!todo[s]) continue;
       cbh_idx64* c = S->child[s];
@@ -356,11 +392,13 @@ int sharded_scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t 
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, cw->ev0, cw->ev1) == hipSuccess) worst = std::max(worst, ms);
       todo[s] = 0;
+      running += count[s];
+      if (running > max_records && running > ws->rec_cap) {  // the merged result cannot fit: nobody grows for it
+        *total = running;
+        return CBH_E_OVERFLOW;
+      }
       if (count[s] > cw->rec_cap) {  // this shard alone grows its block and scans again
-        if (count[s] > max_records) {
-          *total = count[s];
-          return CBH_E_OVERFLOW;
-        }
+        running -= count[s];         // (it reports again after the rescan)
         rc = cw->ensure_records((size_t)count[s] + 1024);
         if (rc) return rc == CBH_E_NOMEM ? CBH_E_OVERFLOW : rc;
         todo[s] = 1;
@@ -552,6 +590,7 @@ int cbh_idx64_shard_stats(const cbh_idx64* idx, cbh_shard_stats* out) {
   out->collectives = S->comm.n_collectives.load();
   out->peer_copies = S->comm.n_peer_copies.load();
   out->local_copies = S->comm.n_local_copies.load();
+  out->collective_fallbacks = S->comm.n_fallbacks.load();
   out->segments = S->segs.size();
   return CBH_OK;
 }

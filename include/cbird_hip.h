@@ -282,8 +282,9 @@ typedef struct cbh_shard_stats {
   uint64_t scans;        /* shard-local scan launches */
   uint64_t rescans;      /* ... of which repeated because a shard's block overflowed */
   uint64_t collectives;  /* grouped ncclAllGather calls */
-  uint64_t peer_copies;  /* hipMemcpyPeerAsync calls (needles out, records back with "shard_exchange" 1) */
+  uint64_t peer_copies;  /* hipMemcpyPeerAsync calls (needles out; records back unless "shard_exchange" is 0) */
   uint64_t local_copies; /* device-to-device copies of shard blocks inside one device */
+  uint64_t collective_fallbacks; /* exchanges that asked for ncclAllGather and went by copies (no communicator) */
 } cbh_shard_stats;
 int cbh_idx64_shard_stats(const cbh_idx64*, cbh_shard_stats* out);
 /* load(): replaces the SoA fill of DctHashIndex::load (:70-114); the caller runs the SQL
@@ -717,8 +718,21 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *   "pool_keep_mb"  cached scratch that may outlive its stream, per device, in MB (default 16384; < 0: everything)
  *   "shard_force_rccl" 1 = a sharded index on ONE device still sends its blocks through ncclAllGather (one rank): the
  *                   transport test of a one-GPU box (default 0)
- *   "shard_exchange" 0 = ncclAllGather between devices (default), 1 = hipMemcpyPeerAsync into the root block */
+ *   "shard_exchange" how the records of a multi-device index reach the root device: 1 = hipMemcpyPeerAsync of exactly
+ *                   count_s records per shard into the root block (default: only the root consumes them), 0 = one
+ *                   grouped ncclAllGather of the per-device blocks (falls back to 1, with a note in cbh_last_error, when
+ *                   librccl cannot be loaded, its version does not match the headers, or ncclCommInitAll fails)
+ * Fault injection (tests/test_error_paths.py; never armed by the library itself):
+ *   "fault_alloc_after" n >= 0: the n-th allocation from now (0 = the next; device, pinned and scratch allocations all
+ *                   count) fails once with out-of-memory and the knob disarms itself; -1 disarms
+ *   "fault_driver_oom" n >= 0: the n-th driver allocation of the scratch arena fails once (its trim-and-retry path)
+ *   "fault_rccl"    1 = librccl is treated as absent */
 int cbh_set_tuning(const char* key, int value);
+/* Read-back for tests and soak tools: "fault_alloc_after" (what is left of the countdown, -1 = disarmed or fired),
+ * "fault_fired", "alloc_calls" (allocations seen since the library loaded), and the scratch arena's
+ * "arena_cached_bytes", "arena_pending_bytes", "arena_live_bytes", "arena_live_blocks", "arena_trimmed_live",
+ * "arena_oom_retry_stream", "arena_oom_retry_device", "arena_released". */
+int cbh_get_tuning(const char* key, long long* value);
 
 /* ---- measurement support ---------------------------------------------------------------- */
 /* Run the scan kernel `iters` times on the index's own stream bracketed by hipEvents and

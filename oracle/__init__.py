@@ -535,6 +535,15 @@ class RefTree:
             L.ref_dcttree_search_many.argtypes = [C.c_void_p, _u64p, C.c_int, C.c_int, C.c_int,
                                                   C.c_void_p]
             L.ref_dcttree_search_many.restype = C.c_longlong
+            if hasattr(L, "ref_dcttree_search_lists"):  # (absent from an oracle/_ref built before round 4)
+                L.ref_dcttree_search_lists.argtypes = [C.c_void_p, _u64p, C.c_int, C.c_int, C.c_int]
+                L.ref_dcttree_search_lists.restype = C.c_void_p
+                L.ref_lists_total.argtypes = [C.c_void_p]
+                L.ref_lists_total.restype = C.c_ulonglong
+                L.ref_lists_copy.argtypes = [C.c_void_p, _u64p, _u32p, _i32p]
+                L.ref_lists_copy.restype = None
+                L.ref_lists_free.argtypes = [C.c_void_p]
+                L.ref_lists_free.restype = None
             cls._L = L
         return cls._L
 
@@ -562,6 +571,22 @@ class RefTree:
             self.h, needles, len(needles), int(thresh), int(threads),
             cnt.ctypes.data if cnt is not None else None)
         return (int(tot), cnt) if want_counts else int(tot)
+
+    def search_lists(self, needles, thresh, threads=1):
+        """Every needle's full result list from the real tree, in CSR form: (offsets u64[nq+1], ids u32[total],
+        dists i32[total]); each list in canonical order (distance, then mediaId, ascending)."""
+        needles = np.ascontiguousarray(needles, np.uint64)
+        L = self.lib()
+        lp = L.ref_dcttree_search_lists(self.h, needles, len(needles), int(thresh), int(threads))
+        try:
+            tot = int(L.ref_lists_total(lp))
+            off = np.zeros(len(needles) + 1, np.uint64)
+            oi = np.zeros(max(1, tot), np.uint32)
+            od = np.zeros(max(1, tot), np.int32)
+            L.ref_lists_copy(lp, off, oi, od)
+        finally:
+            L.ref_lists_free(lp)
+        return off, oi[:tot], od[:tot]
 
     def close(self):
         if self.h:

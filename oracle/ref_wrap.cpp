@@ -15,8 +15,10 @@
 #include <cassert>
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <atomic>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #define Q_ASSERT(x) assert(x)
@@ -112,5 +114,78 @@ long long ref_dcttree_search_many(void* tp, const uint64_t* needles, int nq, int
   for (auto& th : pool) th.join();
   return total.load();
 }
+
+// Full result lists of every needle, for identity checks at full size (bench.py cpu_baseline, tests/test_full_size.py):
+// the same fan-out as ref_dcttree_search_many, but every needle's (mediaId, distance) list is kept, put in the
+// canonical order (distance ascending, then mediaId ascending -- the tree's own order among equal distances is its heap
+// order, which no other structure reproduces) and handed back in CSR form.
+struct RefLists {
+  std::vector<uint64_t> offsets;  // nq + 1
+  std::vector<uint32_t> ids;
+  std::vector<int32_t> dists;
+};
+
+void* ref_dcttree_search_lists(void* tp, const uint64_t* needles, int nq, int threshold, int threads) {
+  auto* t = static_cast<RefTree*>(tp);
+  if (threads < 1) threads = 1;
+  struct Part {
+    std::vector<uint64_t> keys;                   // dist << 32 | id, per needle sorted
+    std::vector<std::pair<int, uint32_t>> spans;  // (needle, count), in the order this worker met them
+  };
+  std::vector<Part> parts{size_t(threads)};
+  std::atomic<int> next(0);
+  auto work = [&](int w) {
+    std::vector<int> distances;
+    std::vector<vpValue> results;
+    Part& p = parts[size_t(w)];
+    for (;;) {
+      int i = next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= nq) break;
+      if (needles[i] == 0 || !t) {  // dcthashindex.cpp:196-200
+        p.spans.emplace_back(i, 0u);
+        continue;
+      }
+      t->tree.search(vpValue{needles[i], 0}, threshold, &results, &distances);
+      size_t at = p.keys.size();
+      for (size_t k = 0; k < results.size(); ++k)
+        p.keys.push_back(uint64_t(uint32_t(distances[k])) << 32 | results[k].id);
+      std::sort(p.keys.begin() + long(at), p.keys.end());
+      p.spans.emplace_back(i, uint32_t(results.size()));
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int k = 1; k < threads; ++k) pool.emplace_back(work, k);
+  work(0);
+  for (auto& th : pool) th.join();
+  auto* out = new RefLists;
+  out->offsets.assign(size_t(nq) + 1, 0);
+  for (auto& p : parts)
+    for (auto& s : p.spans) out->offsets[size_t(s.first) + 1] = s.second;
+  for (int i = 0; i < nq; ++i) out->offsets[size_t(i) + 1] += out->offsets[size_t(i)];
+  out->ids.resize(out->offsets[size_t(nq)]);
+  out->dists.resize(out->offsets[size_t(nq)]);
+  for (auto& p : parts) {
+    size_t at = 0;
+    for (auto& s : p.spans) {
+      size_t o = out->offsets[size_t(s.first)];
+      for (uint32_t k = 0; k < s.second; ++k, ++at) {
+        out->ids[o + k] = uint32_t(p.keys[at]);
+        out->dists[o + k] = int32_t(p.keys[at] >> 32);
+      }
+    }
+  }
+  return out;
+}
+
+unsigned long long ref_lists_total(void* lp) { return static_cast<RefLists*>(lp)->ids.size(); }
+
+void ref_lists_copy(void* lp, uint64_t* offsets, uint32_t* ids, int32_t* dists) {
+  auto* l = static_cast<RefLists*>(lp);
+  std::copy(l->offsets.begin(), l->offsets.end(), offsets);
+  std::copy(l->ids.begin(), l->ids.end(), ids);
+  std::copy(l->dists.begin(), l->dists.end(), dists);
+}
+
+void ref_lists_free(void* lp) { delete static_cast<RefLists*>(lp); }
 
 }  // extern "C"

@@ -49,6 +49,35 @@ def test_config1_one_million_hashes_properties(gpu, orc):
         assert (gc[sample] == wc).all() and (gi[sample] == wi).all() and (gs[sample] == ws).all()
 
 
+def test_config1_every_needle_equals_the_real_vptree(gpu):
+    """north_star's acceptance line at full size: ALL 10^6 needles against the 10^6-entry index, every needle's complete
+    (mediaId, distance) list equal to the reference's own VP-tree (src/tree/vptree.h compiled in place, oracle/_ref) in
+    canonical (distance, mediaId) order -- at dht 2 (BASELINE configs[0]/[1]), 5 and 8 (prefilter and 64-bit kernels)."""
+    import os
+
+    import oracle
+    from cbird_amd import synth
+
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref/libcbird_ref.so absent (built by __graft_entry__.build() where /root/reference exists)")
+    n = 1_000_000
+    h, ids = synth.make_hashes(n, seed=1234, planted_frac=0.02, max_dist=8)
+    idx = gpu.DctHashIndex()
+    idx.load(h, ids)
+    tree = oracle.RefTree(h, ids)
+    threads = len(os.sched_getaffinity(0))
+    for dht in (2, 5, 8):
+        gi, gs, gc = idx.find_batch(h, dht, 8)
+        kmax = int(gc.max())
+        if kmax > 8:
+            gi, gs, gc = idx.find_batch(h, dht, kmax)
+        keep = np.arange(gi.shape[1])[None, :] < gc[:, None]
+        off, ci, cd = tree.search_lists(h, dht, threads=threads)
+        assert (np.diff(off.astype(np.int64)) == gc).all()
+        assert off[-1] > n                                       # (the planted neighbours are there)
+        assert (gi[keep].astype(np.uint32) == ci).all() and (gs[keep].astype(np.int32) == cd).all()
+
+
 def test_config3_orb_50m_rows_properties(gpu):
     from cbird_amd import _lib
     from cbird_amd.cvfeatures import CvFeaturesIndex
