@@ -410,7 +410,7 @@ def sharded_leg(args, world, local_rank, share):
     import subprocess
 
     if world > 1 and not share:
-        cmd = ["--mask", hex((1 << world) - 1), "--per-device", "1"]
+        cmd = ["--mask", hex((1 << world) - 1), "--per-device", "1", "--exchange", "both"]
     else:
         cmd = ["--mask", hex(1 << local_rank), "--per-device", "8", "--force-rccl"]
     cmd = [sys.executable, os.path.join(ROOT, "tools", "sharded_leg.py"), "--images", str(args.images), "--dht", args.dht,

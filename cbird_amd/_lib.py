@@ -31,7 +31,7 @@ class CbhError(RuntimeError):
         self.code = code
         L = _state.get("lib")
         msg = L.cbh_strerror(code).decode() if L is not None else str(code)
-        detail = L.cbh_last_error().decode() if (L is not None and code == CBH_E_HIP) else ""
+        detail = L.cbh_last_error().decode() if (L is not None and code in (CBH_E_HIP, CBH_E_NOMEM)) else ""
         super().__init__(f"{what}: {msg} ({code}) {detail}".strip())
 
 
@@ -215,6 +215,8 @@ _SIGS = {
     "cbh_color_download": (C.c_int, [_vp, _vp, _vp, _sz]),
     "cbh_color_find": (C.c_int, [_vp, _vp, _vp, _sz, C.POINTER(_sz)]),
     "cbh_color_find_batch": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _vp]),
+    "cbh_usable_device_mask": (C.c_uint32, []),
+    "cbh_last_error_code": (C.c_int, []),
     "cbh_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "cbh_get_tuning": (C.c_int, [C.c_char_p, C.POINTER(C.c_longlong)]),
     "cbh_idx64_get_stats": (C.c_int, [_vp, C.POINTER(cbh_stats)]),

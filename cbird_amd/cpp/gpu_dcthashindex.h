@@ -14,11 +14,13 @@
 #pragma once
 
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #include "cbird_hip.h"
 #include "gpu_devices.h"
 #include "index.h"  // cbird's src/index.h (or the test mock)
+#include "gpu_errors.h"
 
 class GpuDctHashIndex : public Index {
   Q_DISABLE_COPY_MOVE(GpuDctHashIndex)
@@ -55,7 +57,7 @@ class GpuDctHashIndex : public Index {
       ids.push_back(query.value(0).toUInt());
       hashes.push_back(uint64_t(query.value(1).toLongLong()));
     }
-    check(cbh_idx64_load(_idx, hashes.data(), ids.data(), hashes.size()), "load");
+    mutate("load", [&] { return cbh_idx64_load(_idx, hashes.data(), ids.data(), hashes.size()); });
   }
 
   void save(QSqlDatabase& db, const QString& cachePath) override {
@@ -70,9 +72,9 @@ class GpuDctHashIndex : public Index {
     QSet<mediaid_t> set;
     if (isLoaded()) {  // dcthashindex.cpp:129-133
       size_t n = 0;
-      check(cbh_idx64_media_ids(_idx, nullptr, 0, &n), "mediaIds");
+      if (!query("mediaIds", [&] { return cbh_idx64_media_ids(_idx, nullptr, 0, &n); })) return set;
       std::vector<uint32_t> ids(n ? n : 1);
-      check(cbh_idx64_media_ids(_idx, ids.data(), ids.size(), &n), "mediaIds");
+      if (!query("mediaIds", [&] { return cbh_idx64_media_ids(_idx, ids.data(), ids.size(), &n); })) return set;
       for (size_t i = 0; i < n; ++i) set.insert(ids[i]);
       return set;
     }
@@ -95,7 +97,7 @@ class GpuDctHashIndex : public Index {
       hashes.push_back(m.dctHash());
       ids.push_back(uint32_t(m.id()));
     }
-    check(cbh_idx64_add(_idx, hashes.data(), ids.data(), hashes.size()), "add");
+    mutate("add", [&] { return cbh_idx64_add(_idx, hashes.data(), ids.data(), hashes.size()); });
   }
 
   // dcthashindex.cpp:175-191
@@ -103,7 +105,7 @@ class GpuDctHashIndex : public Index {
     if (!isLoaded()) return;
     std::vector<uint32_t> ids;
     for (int id : removed) ids.push_back(uint32_t(id));
-    check(cbh_idx64_remove(_idx, ids.data(), ids.size()), "remove");
+    mutate("remove", [&] { return cbh_idx64_remove(_idx, ids.data(), ids.size()); });
   }
 
   // dcthashindex.cpp:193-220.  Thread-safe for concurrent callers (QtConcurrent workers under
@@ -124,7 +126,8 @@ class GpuDctHashIndex : public Index {
     std::vector<cbh_match> buf(64);
     size_t n = 0;
     for (;;) {
-      check(cbh_idx64_find_coalesced(_idx, target, p.dctThresh, buf.data(), buf.size(), &n), "find");
+      if (!query("find", [&] { return cbh_idx64_find_coalesced(_idx, target, p.dctThresh, buf.data(), buf.size(), &n); }))
+        return results;
       if (n <= buf.size()) break;
       buf.resize(n);
     }
@@ -138,7 +141,14 @@ class GpuDctHashIndex : public Index {
     std::vector<uint32_t> ids;
     for (uint32_t id : mediaIds) ids.push_back(id);
     cbh_idx64* sub = cbh_idx64_slice(_idx, ids.data(), ids.size());
-    if (!sub) qFatal("GpuDctHashIndex::slice failed: %s", cbh_last_error());
+    if (!sub && cbh_last_error_code() == CBH_E_NOMEM) {  // transient: give cached scratch back, once more
+      gpuidx::releaseScratch();
+      sub = cbh_idx64_slice(_idx, ids.data(), ids.size());
+    }
+    if (!sub) {  // a slice that cannot be made is an empty one (its searches find nothing), not the end of the process
+      qCritical("GpuDctHashIndex::slice: %s", cbh_last_error());
+      return new GpuDctHashIndex(_device);
+    }
     return new GpuDctHashIndex(_device, sub);
   }
 
@@ -151,9 +161,12 @@ class GpuDctHashIndex : public Index {
     for (const Media& m : needles) q.push_back(m.dctHash());
     std::vector<cbh_match> out(q.size() * size_t(k));
     std::vector<uint32_t> counts(q.size());
-    check(cbh_idx64_find_batch(_idx, q.data(), q.size(), p.dctThresh, k, out.data(), counts.data()),
-          "find_batch");
     QVector<QVector<Index::Match>> res;
+    if (!query("find_batch",
+               [&] { return cbh_idx64_find_batch(_idx, q.data(), q.size(), p.dctThresh, k, out.data(), counts.data()); })) {
+      for (size_t i = 0; i < q.size(); ++i) res.append(QVector<Index::Match>());
+      return res;
+    }
     for (size_t i = 0; i < q.size(); ++i) {
       QVector<Index::Match> r;
       const size_t m = std::min<size_t>(counts[i], size_t(k));
@@ -179,11 +192,15 @@ class GpuDctHashIndex : public Index {
     const size_t k = size_t(p.maxMatches);
     std::vector<cbh_match> out(q.size() * std::max<size_t>(k, 1));
     std::vector<uint32_t> counts(q.size());
-    check(cbh_search_index_batch(_idx, q.data(), ids.data(), q.size(), p.dctThresh, p.maxThresh, p.minMatches,
-                                 p.maxMatches, p.filterSelf ? 1 : 0, knownIds ? knownIds->data() : nullptr,
-                                 knownIds ? knownIds->size() : 0, out.data(), counts.data()),
-          "search_index_batch");
     QVector<QVector<Index::Match>> res;
+    if (!query("search_index_batch", [&] {
+          return cbh_search_index_batch(_idx, q.data(), ids.data(), q.size(), p.dctThresh, p.maxThresh, p.minMatches,
+                                        p.maxMatches, p.filterSelf ? 1 : 0, knownIds ? knownIds->data() : nullptr,
+                                        knownIds ? knownIds->size() : 0, out.data(), counts.data());
+        })) {
+      for (size_t i = 0; i < q.size(); ++i) res.append(QVector<Index::Match>());
+      return res;
+    }
     for (size_t i = 0; i < q.size(); ++i) {
       QVector<Index::Match> r;
       for (size_t j = 0; j < counts[i]; ++j) r.append(Index::Match(out[i * k + j].id, out[i * k + j].score));
@@ -198,10 +215,15 @@ class GpuDctHashIndex : public Index {
   GpuDctHashIndex(int device, cbh_idx64* adopted) : _device(device), _idx(adopted) {
     _id = SearchParams::AlgoDCT;
   }
-  static void check(int rc, const char* what) {
-    // the reference has no error codes on this surface: SQL problems abort (SQL_FATAL), missing
-    // data warns and returns empty.  A device failure is fatal like a failed allocation.
-    if (rc != CBH_OK) qFatal("GpuDctHashIndex::%s: %s (%s)", what, cbh_strerror(rc), cbh_last_error());
+  // the reference has no error codes on this surface (gpu_errors.h, gpuidx::run): load/add/remove retry once after
+  // releasing cached scratch and then abort like the reference's failed allocation; find & co. log and return nothing
+  template <class Call>
+  static void mutate(const char* what, Call&& call) {
+    (void)gpuidx::run(gpuidx::Mutation, (std::string("GpuDctHashIndex::") + what).c_str(), call);
+  }
+  template <class Call>
+  static bool query(const char* what, Call&& call) {
+    return gpuidx::run(gpuidx::Query, (std::string("GpuDctHashIndex::") + what).c_str(), call);
   }
   int _device;
   cbh_idx64* _idx;

@@ -12,10 +12,12 @@
 struct GpuDeviceSet {
   uint32_t mask = 1u;
   int shardsPerDevice = 1;
-  /// every usable gfx950 device of the node, e.g. 0xff on an 8 x MI355X box
+  /// every usable gfx950 device of the node, e.g. 0xff on an 8 x MI355X box (probed per ordinal: a node that lists some
+  /// other device first gives a mask with holes, not the wrong devices); no usable device: mask 1, and the index
+  /// reports the missing device when it is created
   static GpuDeviceSet all() {
-    const int n = cbh_device_count();
-    return GpuDeviceSet{n >= 32 ? 0xffffffffu : ((1u << (n > 0 ? n : 1)) - 1u), 1};
+    const uint32_t m = cbh_usable_device_mask();
+    return GpuDeviceSet{m ? m : 1u, 1};
   }
   bool single() const { return (mask & (mask - 1)) == 0 && shardsPerDevice <= 1; }
   int first() const { return mask ? __builtin_ctz(mask) : 0; }

@@ -25,12 +25,12 @@
 #include "dctfeaturesindex.h"
 #include "dctvideoindex.h"
 #include "videoindex.h"
+#include "gpu_errors.h"
 
-#define CBH_CHECK(call)                                                                   \
-  do {                                                                                    \
-    int rc_ = (call);                                                                     \
-    if (rc_ != CBH_OK) qFatal("%s: %s (%s)", #call, cbh_strerror(rc_), cbh_last_error()); \
-  } while (0)
+// gpu_errors.h (gpuidx::run): a mutation that fails after one retry aborts like the reference's failed allocation; a
+// query that fails logs with qCritical and the caller returns its empty result
+#define CBH_MUTATE(call) (void)gpuidx::run(gpuidx::Mutation, #call, [&] { return (call); })
+#define CBH_QUERY(call) gpuidx::run(gpuidx::Query, #call, [&] { return (call); })
 
 // ---- DctFeaturesIndex ---------------------------------------------------------------------------------
 class GpuDctFeaturesIndex : public DctFeaturesIndex {  // inherits createTables/addRecords/removeRecords/mediaIds
@@ -69,14 +69,22 @@ class GpuDctFeaturesIndex : public DctFeaturesIndex {  // inherits createTables/
         hashes.push_back(p[j]);
       }
     }
-    CBH_CHECK(cbh_idx64_load(_idx, hashes.data(), ids.data(), hashes.size()));
+    CBH_MUTATE(cbh_idx64_load(_idx, hashes.data(), ids.data(), hashes.size()));
   }
   // slice(): HammingTree::slice keeps the values whose index is in the set (dctfeaturesindex.cpp:239-258); the
   // caller owns the result
   Index* slice(const QSet<uint32_t>& mediaIds) const override {
     std::vector<uint32_t> ids(mediaIds.begin(), mediaIds.end());
     cbh_idx64* sub = cbh_idx64_slice(_idx, ids.data(), ids.size());
-    if (!sub) qFatal("GpuDctFeaturesIndex::slice: %s", cbh_last_error());
+    if (!sub && cbh_last_error_code() == CBH_E_NOMEM) {  // transient: give cached scratch back, once more
+      gpuidx::releaseScratch();
+      sub = cbh_idx64_slice(_idx, ids.data(), ids.size());
+    }
+    if (!sub) {  // a slice that cannot be made is an empty one (its searches find nothing), not the end of the process
+      qCritical("GpuDctFeaturesIndex::slice: %s", cbh_last_error());
+      sub = cbh_idx64_create(cbh_idx64_device_mask(_idx) ? __builtin_ctz(cbh_idx64_device_mask(_idx)) : 0);
+      if (!sub) qFatal("GpuDctFeaturesIndex::slice: no usable MI355X device");
+    }
     return new GpuDctFeaturesIndex(sub, _treeCompat);
   }
   void save(QSqlDatabase&, const QString&) override {}
@@ -88,21 +96,21 @@ class GpuDctFeaturesIndex : public DctFeaturesIndex {  // inherits createTables/
         ids.push_back(uint32_t(m.id()));
         hashes.push_back(h);
       }
-    if (!hashes.empty()) CBH_CHECK(cbh_idx64_add(_idx, hashes.data(), ids.data(), hashes.size()));
+    if (!hashes.empty()) CBH_MUTATE(cbh_idx64_add(_idx, hashes.data(), ids.data(), hashes.size()));
   }
   void remove(const QVector<int>& ids) override {
     if (ids.count() <= 0 || !isLoaded()) return;
     std::vector<uint32_t> v(ids.begin(), ids.end());
-    CBH_CHECK(cbh_idx64_remove_ids_only(_idx, v.data(), v.size()));
+    CBH_MUTATE(cbh_idx64_remove_ids_only(_idx, v.data(), v.size()));
   }
   QVector<Index::Match> find(const Media& needle, const SearchParams& params) override {
     KeyPointHashList hashes = needle.keyPointHashes();
     std::vector<uint64_t> h(hashes.begin(), hashes.end());
     if (h.empty() && needle.id() > 0) {  // _tree->findIndex (:270-276)
       size_t n = 0;
-      CBH_CHECK(cbh_idx64_hashes_for_id(_idx, uint32_t(needle.id()), nullptr, 0, &n));
+      if (!CBH_QUERY(cbh_idx64_hashes_for_id(_idx, uint32_t(needle.id()), nullptr, 0, &n))) return {};
       h.resize(n);
-      CBH_CHECK(cbh_idx64_hashes_for_id(_idx, uint32_t(needle.id()), h.data(), n, &n));
+      if (!CBH_QUERY(cbh_idx64_hashes_for_id(_idx, uint32_t(needle.id()), h.data(), n, &n))) return {};
     }
     if (h.empty()) {
       qWarning() << "needle has no hashes" << needle.id() << needle.path();
@@ -110,8 +118,9 @@ class GpuDctFeaturesIndex : public DctFeaturesIndex {  // inherits createTables/
     }
     std::vector<cbh_match> out(h.size() * 10 + 1);
     size_t n = 0;
-    CBH_CHECK(cbh_fdct_find_coalesced(_idx, h.data(), h.size(), uint32_t(needle.id()), params.dctThresh,
-                               _treeCompat ? 1 : 0, out.data(), out.size(), &n));
+    if (!CBH_QUERY(cbh_fdct_find_coalesced(_idx, h.data(), h.size(), uint32_t(needle.id()), params.dctThresh,
+                                           _treeCompat ? 1 : 0, out.data(), out.size(), &n)))
+      return {};
     QVector<Index::Match> results;
     for (size_t i = 0; i < n; ++i) results.append(Index::Match(out[i].id, out[i].score));
     return results;
@@ -159,13 +168,13 @@ class GpuCvFeaturesIndex : public CvFeaturesIndex {
         qWarning() << "sql: ignoring invalid data @ media_id=" << id;
         continue;
       }
-      CBH_CHECK(cbh_idx256_add(_idx, id, reinterpret_cast<const uint8_t*>(data.constData()), size_t(rows)));
+      CBH_MUTATE(cbh_idx256_add(_idx, id, reinterpret_cast<const uint8_t*>(data.constData()), size_t(rows)));
       lastId = id;
     }
   }
   void save(QSqlDatabase&, const QString&) override {}  // nothing to cache: the rows are the index
   void addOne(uint32_t mediaId, const cv::Mat& desc) {  // desc: rows x 32, CV_8U, continuous
-    if (desc.rows > 0) CBH_CHECK(cbh_idx256_add(_idx, mediaId, desc.ptr<uint8_t>(0), size_t(desc.rows)));
+    if (desc.rows > 0) CBH_MUTATE(cbh_idx256_add(_idx, mediaId, desc.ptr<uint8_t>(0), size_t(desc.rows)));
   }
   void add(const MediaGroup& media) override {
     for (const Media& m : media) {
@@ -179,7 +188,7 @@ class GpuCvFeaturesIndex : public CvFeaturesIndex {
   }
   void remove(const QVector<int>& ids) override {
     std::vector<uint32_t> v(ids.begin(), ids.end());
-    CBH_CHECK(cbh_idx256_remove(_idx, v.data(), v.size()));
+    CBH_MUTATE(cbh_idx256_remove(_idx, v.data(), v.size()));
   }
   QVector<Index::Match> find(const Media& needle, const SearchParams& params) override {
     cv::Mat descriptors = needle.keyPointDescriptors();
@@ -188,9 +197,9 @@ class GpuCvFeaturesIndex : public CvFeaturesIndex {
     size_t n_desc = size_t(std::max(descriptors.rows, 0));
     if (!n_desc) {  // descriptorsForMediaId (:443)
       size_t first = 0, cnt = 0;
-      CBH_CHECK(cbh_idx256_rows_of(_idx, uint32_t(needle.id()), &first, &cnt));
+      if (!CBH_QUERY(cbh_idx256_rows_of(_idx, uint32_t(needle.id()), &first, &cnt))) return {};
       own.resize(cnt * 32);
-      if (cnt) CBH_CHECK(cbh_idx256_download_rows(_idx, first, cnt, own.data()));
+      if (cnt && !CBH_QUERY(cbh_idx256_download_rows(_idx, first, cnt, own.data()))) return {};
       rows = own.data();
       n_desc = cnt;
     }
@@ -200,7 +209,8 @@ class GpuCvFeaturesIndex : public CvFeaturesIndex {
     }
     std::vector<cbh_match> out(n_desc * 10 + 1);
     size_t n = 0;
-    CBH_CHECK(cbh_idx256_find_coalesced(_idx, rows, n_desc, params.cvThresh, 10, out.data(), out.size(), &n));
+    if (!CBH_QUERY(cbh_idx256_find_coalesced(_idx, rows, n_desc, params.cvThresh, 10, out.data(), out.size(), &n)))
+      return {};
     QVector<Index::Match> results;
     for (size_t i = 0; i < n; ++i) results.append(Index::Match(out[i].id, out[i].score));
     return results;
@@ -215,11 +225,10 @@ class GpuCvFeaturesIndex : public CvFeaturesIndex {
     std::vector<uint8_t> rows;
     for (uint32_t id : ids) {
       size_t first = 0, cnt = 0;
-      CBH_CHECK(cbh_idx256_rows_of(_idx, id, &first, &cnt));
-      if (!cnt) continue;
+      if (!CBH_QUERY(cbh_idx256_rows_of(_idx, id, &first, &cnt)) || !cnt) continue;
       rows.resize(cnt * 32);
-      CBH_CHECK(cbh_idx256_download_rows(_idx, first, cnt, rows.data()));
-      CBH_CHECK(cbh_idx256_add(chunk->_idx, id, rows.data(), cnt));
+      if (!CBH_QUERY(cbh_idx256_download_rows(_idx, first, cnt, rows.data()))) continue;
+      (void)CBH_QUERY(cbh_idx256_add(chunk->_idx, id, rows.data(), cnt));  // (a slice that lacks a media finds less)
     }
     return chunk;
   }
@@ -272,13 +281,13 @@ class GpuColorDescIndex : public ColorDescIndex {
     const size_t n = size_t(count());
     std::vector<uint32_t> ids(n);
     std::vector<ColorDescriptor> descs(n);
-    CBH_CHECK(cbh_color_download(_idx, ids.data(), descs.data(), n));
     QSet<mediaid_t> result;
+    if (!CBH_QUERY(cbh_color_download(_idx, ids.data(), descs.data(), n))) return result;
     for (uint32_t id : ids) result.insert(id);
     return result;
   }
   void addRows(const uint32_t* ids, const ColorDescriptor* descs, size_t n) {
-    CBH_CHECK(cbh_color_add(_idx, ids, descs, n));
+    CBH_MUTATE(cbh_color_add(_idx, ids, descs, n));
   }
   void add(const MediaGroup& media) override {
     std::vector<uint32_t> ids;
@@ -292,7 +301,7 @@ class GpuColorDescIndex : public ColorDescIndex {
   void remove(const QVector<int>& toRemove) override {
     if (!isLoaded()) return;
     std::vector<uint32_t> v(toRemove.begin(), toRemove.end());
-    CBH_CHECK(cbh_color_remove(_idx, v.data(), v.size()));
+    CBH_MUTATE(cbh_color_remove(_idx, v.data(), v.size()));
   }
   bool findIndexData(Media& m) const override {
     ColorDescriptor d;
@@ -313,7 +322,7 @@ class GpuColorDescIndex : public ColorDescIndex {
     }
     std::vector<cbh_match> out(size_t(std::max(count(), 1)));
     size_t n = 0;
-    CBH_CHECK(cbh_color_find_coalesced(_idx, &target, out.data(), out.size(), &n));
+    if (!CBH_QUERY(cbh_color_find_coalesced(_idx, &target, out.data(), out.size(), &n))) return results;
     for (size_t i = 0; i < n; ++i) results.append(Index::Match(out[i].id, out[i].score));
     return results;
   }
@@ -324,7 +333,7 @@ class GpuColorDescIndex : public ColorDescIndex {
     const size_t n = size_t(count());
     std::vector<uint32_t> ids(n), keepIds;
     std::vector<ColorDescriptor> descs(n), keep;
-    if (n) CBH_CHECK(cbh_color_download(_idx, ids.data(), descs.data(), n));
+    if (n && !CBH_QUERY(cbh_color_download(_idx, ids.data(), descs.data(), n))) return chunk;
     for (size_t i = 0; i < n; ++i)
       if (mediaIds.contains(ids[i])) {
         keepIds.push_back(ids[i]);
@@ -378,7 +387,7 @@ class GpuDctVideoIndex : public DctVideoIndex {
   }
   void remove(const QVector<int>& ids) override {
     std::vector<uint32_t> v(ids.begin(), ids.end());
-    CBH_CHECK(cbh_vidx_remove(_idx, v.data(), v.size()));
+    CBH_MUTATE(cbh_vidx_remove(_idx, v.data(), v.size()));
     for (uint32_t id : v) _ids.erase(id);
   }
   // mediaIds(): the loaded reference reads its private _mediaId list (dctvideoindex.cpp:218-231), empty here: this
@@ -392,14 +401,15 @@ class GpuDctVideoIndex : public DctVideoIndex {
   QVector<Index::Match> find(const Media& needle, const SearchParams& p) override {
     std::vector<cbh_vmatch> out(size_t(std::max(count(), 1)));
     size_t n = 0;
-    CBH_CHECK(cbh_vidx_set_radix(_idx, _radixCompat ? p.videoRadix : 0));
+    if (!CBH_QUERY(cbh_vidx_set_radix(_idx, _radixCompat ? p.videoRadix : 0))) return {};
     if (needle.type() == Media::TypeImage) {
       if (needle.dctHash() == 0) {
         qWarning() << "needle has no dct hash" << needle.id() << needle.path();
         return {};
       }
-      CBH_CHECK(cbh_vidx_find_frame(_idx, needle.dctHash(), p.dctThresh, p.skipFrames,
-                                    needle.matchRange().dstIn, out.data(), out.size(), &n));
+      if (!CBH_QUERY(cbh_vidx_find_frame(_idx, needle.dctHash(), p.dctThresh, p.skipFrames, needle.matchRange().dstIn,
+                                         out.data(), out.size(), &n)))
+        return {};
     } else if (needle.type() == Media::TypeVideo) {
       VideoIndex src;
       if (needle.id() == 0)
@@ -410,9 +420,10 @@ class GpuDctVideoIndex : public DctVideoIndex {
         qWarning() << "needle video index is empty:" << needle.path();
         return {};
       }
-      CBH_CHECK(cbh_vidx_find_video_coalesced(_idx, src.frames.data(), src.hashes.data(), src.frames.size(),
-                                    uint32_t(needle.id()), p.dctThresh, p.skipFrames, p.minFramesMatched,
-                                    p.minFramesNear, p.filterSelf, out.data(), out.size(), &n));
+      if (!CBH_QUERY(cbh_vidx_find_video_coalesced(_idx, src.frames.data(), src.hashes.data(), src.frames.size(),
+                                                   uint32_t(needle.id()), p.dctThresh, p.skipFrames, p.minFramesMatched,
+                                                   p.minFramesNear, p.filterSelf, out.data(), out.size(), &n)))
+        return {};
     }
     QVector<Index::Match> results;
     for (size_t i = 0; i < n; ++i) {
@@ -443,7 +454,7 @@ class GpuDctVideoIndex : public DctVideoIndex {
       vi.load(path);
     else
       qWarning() << "index file missing:" << path;
-    CBH_CHECK(cbh_vidx_add_video(_idx, id, vi.frames.data(), vi.hashes.data(), vi.frames.size()));
+    CBH_MUTATE(cbh_vidx_add_video(_idx, id, vi.frames.data(), vi.hashes.data(), vi.frames.size()));
     _ids.insert(id);
   }
   std::set<uint32_t> _ids;  // what DctVideoIndex::_mediaId holds in the reference

@@ -34,6 +34,31 @@ void set_scratch_mode(int v);
 void set_scratch_poison(int v);
 void set_pool_keep_mb(int mb);
 int trim_pools(int device, unsigned long long* released_bytes);
+// The scratch of one launcher: every block taken through get() goes back with free_async on the same stream when the
+// guard leaves scope -- behind the kernels that were queued, and on every early return (a later allocation that fails,
+// a launch error) as well as at the end.
+struct Scratch {
+  hipStream_t s;
+  void* blocks[16];
+  int n = 0;
+  explicit Scratch(hipStream_t stream) : s(stream) {}
+  Scratch(const Scratch&) = delete;
+  Scratch& operator=(const Scratch&) = delete;
+  template <class T>
+  hipError_t get(T** p, size_t bytes) {
+    void* q = nullptr;
+    *p = nullptr;
+    if (n >= 16) return hipErrorInvalidValue;
+    hipError_t e = malloc_async(&q, bytes, s);
+    if (e != hipSuccess) return e;
+    blocks[n++] = q;
+    *p = static_cast<T*>(q);
+    return hipSuccess;
+  }
+  ~Scratch() {
+    while (n > 0) (void)free_async(blocks[--n], s);
+  }
+};
 
 // ---- fault injection (cbird_hip.hip; tests/test_error_paths.py) ------------------------------------------------------
 // Every allocation the library makes -- scratch through malloc_async, index / table memory through hipMalloc, pinned
@@ -45,6 +70,7 @@ hipError_t fault_gate();
 hipError_t fault_gate_driver();
 void set_fault_alloc_after(int n);
 void set_fault_driver_oom(int n);
+void set_fault_alloc_sticky(int v);
 void set_fault_rccl(int v);  // sharded.hip: 1 = behave as if librccl could not be loaded
 long get_fault_alloc_after();
 unsigned long get_fault_fired();

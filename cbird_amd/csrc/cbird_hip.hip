@@ -21,14 +21,19 @@
 namespace cbh {
 
 static thread_local std::string t_last_error;
+static thread_local int t_last_code = CBH_OK;  // the CBH_E_* that goes with t_last_error (cbh_last_error_code)
 
 void set_last_error(const char* where, hipError_t e) {
   char buf[512];
   snprintf(buf, sizeof buf, "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
   t_last_error = buf;
+  t_last_code = e == hipErrorOutOfMemory ? CBH_E_NOMEM : CBH_E_HIP;
 }
 
-void set_last_error_text(const char* text) { t_last_error = text ? text : ""; }
+void set_last_error_text(const char* text) {
+  t_last_error = text ? text : "";
+  t_last_code = CBH_E_UNSUPPORTED;
+}
 
 // ---- stream-ordered scratch (see cbh_internal.h) --------------------------------------------------------------------
 // Mode 2 (default): the library's own arena.  Blocks are plain hipMalloc memory, cached per (device, stream); a block
@@ -85,9 +90,14 @@ uint64_t g_pool_keep_bytes = (uint64_t)16 << 30;  // cached scratch that outlive
 // fault injection (cbh_internal.h): countdowns, -1 = disarmed
 std::atomic<long> g_fault_alloc{-1}, g_fault_driver{-1};
 std::atomic<unsigned long> g_fault_fired{0}, g_alloc_calls{0};
+std::atomic<int> g_fault_sticky{0};  // "fault_alloc_sticky": once the countdown has run out every allocation fails
 hipError_t countdown(std::atomic<long>& c) {
   long v = c.load(std::memory_order_relaxed);
   while (v >= 0) {
+    if (v == 0 && g_fault_sticky.load() && &c == &g_fault_alloc) {  // stays armed at zero
+      g_fault_fired++;
+      return hipErrorOutOfMemory;
+    }
     if (c.compare_exchange_weak(v, v - 1)) {
       if (v == 0) {
         g_fault_fired++;
@@ -183,6 +193,7 @@ hipError_t fault_gate() {
 hipError_t fault_gate_driver() { return countdown(g_fault_driver); }
 void set_fault_alloc_after(int n) { g_fault_alloc = n < 0 ? -1 : n; }
 void set_fault_driver_oom(int n) { g_fault_driver = n < 0 ? -1 : n; }
+void set_fault_alloc_sticky(int v) { g_fault_sticky = v ? 1 : 0; }
 long get_fault_alloc_after() { return g_fault_alloc.load(); }
 unsigned long get_fault_fired() { return g_fault_fired.load(); }
 unsigned long get_alloc_calls() { return g_alloc_calls.load(); }
@@ -510,6 +521,15 @@ int cbh_device_count(void) {
   return usable;
 }
 
+uint32_t cbh_usable_device_mask(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  uint32_t mask = 0;
+  for (int d = 0; d < n && d < 32; ++d)
+    if (device_usable(d)) mask |= 1u << d;
+  return mask;
+}
+
 const char* cbh_strerror(int code) {
   switch (code) {
     case CBH_OK: return "ok";
@@ -525,6 +545,8 @@ const char* cbh_strerror(int code) {
 }
 
 const char* cbh_last_error(void) { return t_last_error.c_str(); }
+
+int cbh_last_error_code(void) { return t_last_code; }
 
 int cbh_trim(int device, unsigned long long* released_bytes) {
   if (released_bytes) *released_bytes = 0;
@@ -1404,6 +1426,10 @@ int cbh_set_tuning(const char* key, int value) {
   }
   if (!strcmp(key, "fault_alloc_after")) {
     set_fault_alloc_after(value);
+    return CBH_OK;
+  }
+  if (!strcmp(key, "fault_alloc_sticky")) {
+    set_fault_alloc_sticky(value);
     return CBH_OK;
   }
   if (!strcmp(key, "fault_driver_oom")) {

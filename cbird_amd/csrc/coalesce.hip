@@ -107,10 +107,19 @@ struct Coalescer {
     if (h_total) (void)hipHostFree(h_total);
   }
   int staging() {
-    if (h_q) return CBH_OK;
-    CBH_HIP(hipHostMalloc(&h_q, kMaxBatch * sizeof(uint64_t)));
-    CBH_HIP(hipHostMalloc(&h_spec, kSpecRecs * sizeof(cbh_record)));
-    CBH_HIP(hipHostMalloc(&h_total, sizeof(unsigned long long)));
+    if (h_total) return CBH_OK;  // (the last of the three: all or nothing)
+    uint64_t* q = nullptr;
+    cbh_record* spec = nullptr;
+    unsigned long long* total = nullptr;
+    hipError_t e = hipHostMalloc(&q, kMaxBatch * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipHostMalloc(&spec, kSpecRecs * sizeof(cbh_record));
+    if (e == hipSuccess) e = hipHostMalloc(&total, sizeof(unsigned long long));
+    if (e != hipSuccess) {  // a later call starts over; nothing half-made stays behind
+      if (q) (void)hipHostFree(q);
+      if (spec) (void)hipHostFree(spec);
+      CBH_HIP(e);
+    }
+    h_q = q, h_spec = spec, h_total = total;
     return CBH_OK;
   }
   void invalidate(uint64_t gen) {  // under mu

@@ -3014,8 +3014,9 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
       const size_t per_chunk_f = std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)h * 128));
       float* d_rowsf = nullptr;
       unsigned char* d_ftiles = nullptr;  // the fused kernel's 32 x 32 tiles (1 KB per image)
-      CBH_HIP(cbh::malloc_async((void**)&d_rowsf, std::min(per_chunk_f, n) * (size_t)h * 32 * sizeof(float), stream));
-      CBH_HIP(cbh::malloc_async((void**)&d_ftiles, std::min(per_chunk_f, n) * 1024, stream));
+      cbh::Scratch scratch(stream);
+      CBH_HIP(scratch.get(&d_rowsf, std::min(per_chunk_f, n) * (size_t)h * 32 * sizeof(float)));
+      CBH_HIP(scratch.get(&d_ftiles, std::min(per_chunk_f, n) * 1024));
       for (size_t i0 = 0; i0 < n; i0 += per_chunk_f) {
         const size_t m = std::min(per_chunk_f, n - i0);
         const unsigned char* src = d_imgs + i0 * img_stride;
@@ -3149,18 +3150,16 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
         hipLaunchKernelGGL(k_tile_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_rowsf, h, at.y, at.yfirst, isx,
                            isy, 1, tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
       }
-      hipError_t ef = hipGetLastError();
-      (void)cbh::free_async(d_rowsf, stream);
-      (void)cbh::free_async(d_ftiles, stream);
-      CBH_HIP(ef);
+      CBH_HIP(hipGetLastError());
       return CBH_OK;
     }
     const size_t per_chunk = std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)w * h));
     const size_t mc = std::min(per_chunk, n);
     unsigned char* d_blur = nullptr;
     float* d_rows = nullptr;
-    CBH_HIP(cbh::malloc_async((void**)&d_blur, mc * (size_t)w * h, stream));
-    CBH_HIP(cbh::malloc_async((void**)&d_rows, mc * (size_t)yn * 32 * sizeof(float), stream));
+    cbh::Scratch scratch(stream);
+    CBH_HIP(scratch.get(&d_blur, mc * (size_t)w * h));
+    CBH_HIP(scratch.get(&d_rows, mc * (size_t)yn * 32 * sizeof(float)));
     for (size_t i0 = 0; i0 < n; i0 += per_chunk) {
       const size_t m = std::min(per_chunk, n - i0);
       const unsigned char* src = d_imgs + i0 * img_stride;
@@ -3190,10 +3189,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
       hipLaunchKernelGGL(k_tile_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_rows, yn, at.y, at.yfirst,
                          isx, isy, 0, tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
     }
-    hipError_t e = hipGetLastError();
-    (void)cbh::free_async(d_rows, stream);
-    (void)cbh::free_async(d_blur, stream);
-    CBH_HIP(e);
+    CBH_HIP(hipGetLastError());
     return CBH_OK;
   }
   if (!area_fast(w, h) || w > 1024 || h > 1024) {
@@ -3206,7 +3202,8 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     const size_t smem = (size_t)(band + 2 * (K_ / 2)) * (size_t)w * 3;
     const size_t per_chunk = std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)w * h));
     unsigned char* d_blur = nullptr;
-    CBH_HIP(cbh::malloc_async((void**)&d_blur, std::min(per_chunk, n) * (size_t)w * h, stream));
+    cbh::Scratch scratch(stream);
+    CBH_HIP(scratch.get(&d_blur, std::min(per_chunk, n) * (size_t)w * h));
     for (size_t i0 = 0; i0 < n; i0 += per_chunk) {
       const size_t m = std::min(per_chunk, n - i0);
       dim3 g1((unsigned)m, (unsigned)((h + band - 1) / band)), block(kThreads);
@@ -3231,7 +3228,6 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
                          tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
     }
     CBH_HIP(hipGetLastError());
-    CBH_HIP(cbh::free_async(d_blur, stream));
     return CBH_OK;
   }
   if (w == 256 && h == 256 && ((uintptr_t)d_imgs % 8) == 0 && row_stride % 8 == 0 &&

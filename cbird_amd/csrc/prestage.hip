@@ -550,8 +550,9 @@ int cbh_template_hashes_dev(const void* d_cands, size_t n, int w, int h, size_t 
   const unsigned bx = (unsigned)std::min<size_t>(1024, (px + 255) / 256);
   const size_t per = std::min<size_t>(n, std::max<size_t>(1, std::min<size_t>(65535, ((size_t)1 << 30) / px)));
   unsigned char *cg = nullptr, *tg = nullptr;
-  CBH_HIP(cbh::malloc_async((void**)&cg, per * px, s));
-  CBH_HIP(cbh::malloc_async((void**)&tg, per * px, s));
+  cbh::Scratch scratch(s);
+  CBH_HIP(scratch.get(&cg, per * px));
+  CBH_HIP(scratch.get(&tg, per * px));
   int rc = CBH_OK;
   for (size_t i0 = 0; i0 < n && rc == CBH_OK; i0 += per) {
     const size_t m = std::min(per, n - i0);
@@ -562,8 +563,6 @@ int cbh_template_hashes_dev(const void* d_cands, size_t n, int w, int h, size_t 
     if (rc == CBH_OK) rc = cbh::launch_dcthash(tg, m, w, h, (size_t)w, px, (uint64_t*)d_tmpl_hashes + i0, s);
   }
   hipError_t e = hipGetLastError();
-  (void)cbh::free_async(cg, s);
-  (void)cbh::free_async(tg, s);
   if (rc) return rc;
   CBH_HIP(e);
   if (!stream) CBH_HIP(hipStreamSynchronize(s));

@@ -188,13 +188,11 @@ int sort_keys_u64(unsigned long long* d_keys, size_t n, int end_bit, hipStream_t
   void* tmp = nullptr;
   size_t bytes = 0;
   CBH_HIP(rocprim::radix_sort_keys(nullptr, bytes, d_keys, alt, n, 0, (unsigned)end_bit, s));
-  CBH_HIP(cbh::malloc_async((void**)&alt, n * 8, s));
-  hipError_t e = cbh::malloc_async(&tmp, bytes ? bytes : 16, s);
-  if (e == hipSuccess) e = rocprim::radix_sort_keys(tmp, bytes, d_keys, alt, n, 0, (unsigned)end_bit, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_keys, alt, n * 8, hipMemcpyDeviceToDevice, s);
-  (void)cbh::free_async(alt, s);
-  if (tmp) (void)cbh::free_async(tmp, s);
-  CBH_HIP(e);
+  cbh::Scratch scratch(s);
+  CBH_HIP(scratch.get(&alt, n * 8));
+  CBH_HIP(scratch.get(&tmp, bytes ? bytes : 16));
+  CBH_HIP(rocprim::radix_sort_keys(tmp, bytes, d_keys, alt, n, 0, (unsigned)end_bit, s));
+  CBH_HIP(hipMemcpyAsync(d_keys, alt, n * 8, hipMemcpyDeviceToDevice, s));
   return CBH_OK;
 }
 
@@ -205,16 +203,13 @@ int sort_pairs_u64_u32(unsigned long long* d_keys, uint32_t* d_vals, size_t n, i
   void* tmp = nullptr;
   size_t bytes = 0;
   CBH_HIP(rocprim::radix_sort_pairs(nullptr, bytes, d_keys, kalt, d_vals, valt, n, 0, (unsigned)end_bit, s));
-  CBH_HIP(cbh::malloc_async((void**)&kalt, n * 8, s));
-  hipError_t e = cbh::malloc_async((void**)&valt, n * 4, s);
-  if (e == hipSuccess) e = cbh::malloc_async(&tmp, bytes ? bytes : 16, s);
-  if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, bytes, d_keys, kalt, d_vals, valt, n, 0, (unsigned)end_bit, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_keys, kalt, n * 8, hipMemcpyDeviceToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_vals, valt, n * 4, hipMemcpyDeviceToDevice, s);
-  (void)cbh::free_async(kalt, s);
-  if (valt) (void)cbh::free_async(valt, s);
-  if (tmp) (void)cbh::free_async(tmp, s);
-  CBH_HIP(e);
+  cbh::Scratch scratch(s);
+  CBH_HIP(scratch.get(&kalt, n * 8));
+  CBH_HIP(scratch.get(&valt, n * 4));
+  CBH_HIP(scratch.get(&tmp, bytes ? bytes : 16));
+  CBH_HIP(rocprim::radix_sort_pairs(tmp, bytes, d_keys, kalt, d_vals, valt, n, 0, (unsigned)end_bit, s));
+  CBH_HIP(hipMemcpyAsync(d_keys, kalt, n * 8, hipMemcpyDeviceToDevice, s));
+  CBH_HIP(hipMemcpyAsync(d_vals, valt, n * 4, hipMemcpyDeviceToDevice, s));
   return CBH_OK;
 }
 

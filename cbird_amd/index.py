@@ -183,7 +183,7 @@ class DctHashIndex:
         i = _as_u32(sorted(set(int(x) for x in mediaIds)))
         h = self._L.cbh_idx64_slice(self._h, i.ctypes.data, len(i))
         if not h:
-            raise CbhError(_lib.CBH_E_HIP, "slice")
+            raise CbhError(self._L.cbh_last_error_code() or _lib.CBH_E_HIP, "slice")
         return DctHashIndex(self._device, _handle=h)
 
     # -- batched entry points (the MI355X-native shape of Database::similar's fan-out) ----------
@@ -284,7 +284,7 @@ class DctFeaturesIndex:
         i = _as_u32(sorted(set(int(x) for x in mediaIds)))
         h = self._L.cbh_idx64_slice(self._h, i.ctypes.data, len(i))
         if not h:
-            raise CbhError(_lib.CBH_E_HIP, "slice")
+            raise CbhError(self._L.cbh_last_error_code() or _lib.CBH_E_HIP, "slice")
         return DctFeaturesIndex(self._device, self.tree_compat, _handle=h)
 
     def id(self) -> int:

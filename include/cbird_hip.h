@@ -66,8 +66,14 @@ typedef struct cbh_idx256 cbh_idx256; /* opaque: CvFeaturesIndex state */
 /* ---- library ------------------------------------------------------------------------- */
 int cbh_version(void);
 int cbh_device_count(void);             /* number of usable gfx950 devices, 0 if none */
+/* bit d set for every HIP ordinal d < 32 that is a usable gfx950 device (the ordinals need not be contiguous: a node
+ * may list another device first) -- what GpuDeviceSet::all() / cbh_idx64_create_sharded take */
+uint32_t cbh_usable_device_mask(void);
 const char* cbh_strerror(int code);     /* static string */
-const char* cbh_last_error(void);       /* thread-local detail of the last CBH_E_HIP */
+const char* cbh_last_error(void);       /* thread-local detail of the last failure (HIP call and reason) */
+/* the CBH_E_* that goes with cbh_last_error() -- for the entry points that return a handle (create / slice): NULL
+ * says "failed", this says whether it was CBH_E_NOMEM (transient: cbh_trim and try again) or something else */
+int cbh_last_error_code(void);
 /* Scratch memory.  Kernel scratch comes from the library's own stream-ordered arena: hipMalloc'ed blocks cached per
  * (device, stream) -- a freed block is reused only by the stream that freed it, so the next call on that stream finds
  * its buffers mapped.  A stream's cache lives as long as the stream: when the library destroys one of its own streams,
@@ -266,8 +272,11 @@ void cbh_idx64_destroy(cbh_idx64*);                              /* ~DctHashInde
  * search_index_batch, the fdct_* calls and cbh_vidx / cbh_color built on it all accept it and return what the
  * one-device index returns, bit for bit.  Rows are sharded in load order, shard s of R owning [s*n/R, (s+1)*n/R); add()
  * appends to the emptiest shard; needles are replicated; per search every shard scans its rows on its own device into
- * a { count, records } block, and the blocks meet on the first device of the mask: device-to-device copies inside a
- * device, ONE grouped ncclAllGather (librccl, dlopen'ed on first use) between devices (cbird_amd/csrc/sharded.hip).
+ * a { count, records } block, and the records meet on the first device of the mask, which alone consumes them: copies
+ * of exactly count_s records per shard (device-to-device inside a device, hipMemcpyPeerAsync over xGMI between
+ * devices), or -- cbh_set_tuning("shard_exchange", 0) -- ONE grouped ncclAllGather of the per-device blocks (librccl,
+ * dlopen'ed on first use; an index that cannot get a communicator keeps using the copies and says so once in
+ * cbh_last_error / stderr and in cbh_shard_stats.collective_fallbacks) (cbird_amd/csrc/sharded.hip).
  * The first device of the mask is the handle's device: *_dev calls take pointers on it. */
 cbh_idx64* cbh_idx64_create_sharded(uint32_t device_mask, int shards_per_device);
 uint32_t cbh_idx64_device_mask(const cbh_idx64*);   /* a plain index: 1 << device */
@@ -725,6 +734,7 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  * Fault injection (tests/test_error_paths.py; never armed by the library itself):
  *   "fault_alloc_after" n >= 0: the n-th allocation from now (0 = the next; device, pinned and scratch allocations all
  *                   count) fails once with out-of-memory and the knob disarms itself; -1 disarms
+ *   "fault_alloc_sticky" 1 = once that countdown has run out, every later allocation fails too, until disarmed
  *   "fault_driver_oom" n >= 0: the n-th driver allocation of the scratch arena fails once (its trim-and-retry path)
  *   "fault_rccl"    1 = librccl is treated as absent */
 int cbh_set_tuning(const char* key, int value);

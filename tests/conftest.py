@@ -109,9 +109,11 @@ def index_shape(request, gpu):
     shape = {"one": None, "shards5": (1, 5), "rccl3": (1, 3)}[request.param]
     _lib.set_default_sharding(shape)
     _lib.lib().cbh_set_tuning(b"shard_force_rccl", 1 if request.param == "rccl3" else 0)
+    _lib.lib().cbh_set_tuning(b"shard_exchange", 0 if request.param == "rccl3" else 1)  # (default: copies)
     yield request.param
     _lib.set_default_sharding(None)
     _lib.lib().cbh_set_tuning(b"shard_force_rccl", 0)
+    _lib.lib().cbh_set_tuning(b"shard_exchange", 1)
 
 
 def load_golden(name):

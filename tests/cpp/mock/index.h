@@ -80,6 +80,13 @@ inline void qWarning(const char* fmt, A... a) {
   if constexpr (sizeof...(A) == 0) std::cerr << fmt << '\n';
   else { fprintf(stderr, fmt, a...); fputc('\n', stderr); }
 }
+inline int g_mockCriticals = 0;  // how many qCritical lines were logged (tests/cpp/test_errors.cpp)
+template <class... A>
+inline void qCritical(const char* fmt, A... a) {
+  ++g_mockCriticals;
+  if constexpr (sizeof...(A) == 0) std::cerr << fmt << '\n';
+  else { fprintf(stderr, fmt, a...); fputc('\n', stderr); }
+}
 template <class... A>
 inline void qDebug(const char* fmt, A... a) {
   if constexpr (sizeof...(A) == 0) std::cerr << fmt << '\n';

@@ -23,7 +23,10 @@ static int hamm64(uint64_t a, uint64_t b) { return __builtin_popcountll(a ^ b); 
 int main(int argc, char** argv) {
   GpuDeviceSet devs;
   if (argc > 2) devs = GpuDeviceSet{uint32_t(strtoul(argv[1], nullptr, 0)), atoi(argv[2])};
-  if (argc > 3 && !strcmp(argv[3], "rccl")) cbh_set_tuning("shard_force_rccl", 1);  // blocks through ncclAllGather
+  if (argc > 3 && !strcmp(argv[3], "rccl")) {  // blocks through ncclAllGather
+    cbh_set_tuning("shard_force_rccl", 1);
+    cbh_set_tuning("shard_exchange", 0);
+  }
   QSqlDatabase db;
   std::mt19937_64 rng(1234);
   const int n = 20000;

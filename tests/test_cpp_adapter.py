@@ -28,6 +28,35 @@ def test_adapter_runs_on_gpu(gpu):
     assert "adapter ok" in out.stdout
 
 
+def test_error_policy_compiles():
+    subprocess.check_call(["make", "-C", CPP, "-B", "test_errors"], stdout=subprocess.DEVNULL)
+    src = open(os.path.join(ROOT, "cbird_amd", "cpp", "gpu_indexes.h")).read()
+    assert "qFatal(\"%s: %s (%s)\", #call" not in src  # (round 3's abort-on-anything macro is gone)
+
+
+@pytest.mark.gpu
+def test_adapter_survives_device_out_of_memory_in_queries(gpu):
+    """cbird_amd/cpp/gpu_errors.h: an allocation that fails once is retried after cbh_trim and answers; one that keeps
+    failing makes find / findBatch / slice log with qCritical and return nothing, and the same handle answers again
+    afterwards.  The reference aborts only on SQL failures (src/global.h:82) and on its own failed allocations."""
+    subprocess.check_call(["make", "-C", CPP, "test_errors"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(CPP, "test_errors")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "errors ok" in out.stdout and "no results for this call" in out.stderr
+
+
+@pytest.mark.gpu
+def test_adapter_aborts_when_a_mutation_cannot_allocate(gpu):
+    """load() that cannot get its arrays leaves the index out of step with the database: qFatal, like the reference's
+    failed allocation -- and the message names the call and the reason"""
+    import signal
+
+    subprocess.check_call(["make", "-C", CPP, "test_errors"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(CPP, "test_errors"), "mutate"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == -signal.SIGABRT, (out.returncode, out.stdout + out.stderr)
+    assert "GpuDctHashIndex::load: out of memory" in out.stderr
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [("1", "8"), ("1", "3", "rccl")])
 def test_adapter_over_logical_shards_equals_the_one_device_index(gpu, shape):

@@ -21,21 +21,51 @@ import test_video as TV
 from conftest import load_golden
 
 
-@pytest.fixture(params=["shards5", "rccl3", "shards2x"])
+def _shapes():
+    """(name, (device_mask, shards_per_device), exchange, force_rccl, fault_rccl).  On a one-GPU box: logical shards
+    on device 0.  On a box with several GPUs (tools/first_contact.sh) two more shapes join in, through the same suites:
+    every device x 1 shard with both exchanges, and two devices x 2 shards."""
+    shapes = [("shards5", (1, 5), 1, 0, 0), ("rccl3", (1, 3), 0, 1, 0), ("shards2x", (1, 2), 1, 0, 0),
+              ("norccl3", (1, 3), 0, 1, 1)]
+    try:
+        import torch
+
+        ndev = torch.cuda.device_count()  # (counting does not initialise the GPU)
+    except Exception:
+        ndev = 0
+    if ndev > 1:
+        full = (1 << ndev) - 1
+        shapes += [("alldev_copies", (full, 1), 1, 0, 0), ("alldev_rccl", (full, 1), 0, 0, 0),
+                   ("dev2x2", (0x3, 2), 1, 0, 0)]
+    return shapes
+
+
+_SHAPES = {s[0]: s for s in _shapes()}
+
+
+def _R(name):
+    mask, per = _SHAPES[name][1]
+    return bin(mask).count("1") * per
+
+
+@pytest.fixture(params=list(_SHAPES))
 def sharded(request, gpu):
-    """"shards5": five logical shards, copies only; "rccl3": three, their concatenated block through ncclAllGather;
-    "shards2x": two shards with the peer-copy exchange knob (on one device: the same copies as shards5)."""
+    """"shards5": five logical shards, copies only (the default exchange); "rccl3": three, their concatenated block
+    through ncclAllGather ("shard_exchange" 0 + "shard_force_rccl"); "shards2x": two shards, copies; "norccl3": as
+    rccl3 with librccl treated as absent ("fault_rccl"): the exchange must fall back to copies and say so."""
     from cbird_amd import _lib
 
     L = _lib.lib()
-    shape = {"shards5": (1, 5), "rccl3": (1, 3), "shards2x": (1, 2)}[request.param]
+    name, shape, exchange, force, fault = _SHAPES[request.param]
     _lib.set_default_sharding(shape)
-    L.cbh_set_tuning(b"shard_force_rccl", 1 if request.param == "rccl3" else 0)
-    L.cbh_set_tuning(b"shard_exchange", 1 if request.param == "shards2x" else 0)
+    L.cbh_set_tuning(b"shard_force_rccl", force)
+    L.cbh_set_tuning(b"shard_exchange", exchange)
+    L.cbh_set_tuning(b"fault_rccl", fault)
     yield request.param
     _lib.set_default_sharding(None)
     L.cbh_set_tuning(b"shard_force_rccl", 0)
-    L.cbh_set_tuning(b"shard_exchange", 0)
+    L.cbh_set_tuning(b"shard_exchange", 1)
+    L.cbh_set_tuning(b"fault_rccl", 0)
 
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("sharded")]
@@ -67,7 +97,7 @@ cvo = TC.cvo
 def test_shares_follow_the_shard_range_rule_and_the_order_is_global(gpu, sharded):
     from cbird_amd import synth
 
-    R = {"shards5": 5, "rccl3": 3, "shards2x": 2}[sharded]
+    R = _R(sharded)
     for n in (0, 1, R - 1, R, 1000, 12345):
         h, ids = synth.make_hashes(max(n, 1), seed=7 + n)
         h, ids = h[:n], ids[:n]
@@ -88,15 +118,18 @@ def test_shares_follow_the_shard_range_rule_and_the_order_is_global(gpu, sharded
     assert max(idx.shard_counts()) - min(idx.shard_counts()) < 2400  # the emptiest shard takes each batch
     assert idx.mediaIds() == set(int(i) for i, x in zip(ids, h) if x)
     st = idx.shard_stats()
-    assert st.shards == R and st.devices == 1 and st.device_mask == 1 and st.segments >= R
+    mask = _SHAPES[sharded][1][0]
+    assert st.shards == R and st.devices == bin(mask).count("1") and st.device_mask == mask and st.segments >= R
 
 
 def test_exchange_route_and_overflow_redo_are_what_the_shape_says(gpu, orc, sharded):
     """the counters of cbh_idx64_shard_stats: "rccl3" really goes through ncclAllGather, the others never; a shard
     whose block overflows is the only one that scans again"""
-    from cbird_amd import synth
+    from cbird_amd import _lib, synth
 
-    R = {"shards5": 5, "rccl3": 3, "shards2x": 2}[sharded]
+    L = _lib.lib()
+    R = _R(sharded)
+    ndev = bin(_SHAPES[sharded][1][0]).count("1")
     h, ids = synth.make_hashes(40000, seed=5, planted_frac=0.3)
     # every needle matches the whole of shard 0's share at distance 0: that shard overflows, the others do not
     share0 = 40000 // R
@@ -111,11 +144,18 @@ def test_exchange_route_and_overflow_redo_are_what_the_shape_says(gpu, orc, shar
     wi, ws, wc = orc.find64_batch(h, ids, q, 3, 7)
     assert (gc == wc).all() and (gi == wi).all() and (gs == ws).all()
     assert s1.scans - s0.scans == R + 1 and s1.rescans - s0.rescans == 1
-    if sharded == "rccl3":
-        assert s1.collectives - s0.collectives == 1 and 1 <= s1.local_copies - s0.local_copies <= R
+    if sharded in ("rccl3", "alldev_rccl"):
+        assert s1.collectives - s0.collectives == 1 and s1.collective_fallbacks == 0
     else:
-        assert s1.collectives == 0 and 1 <= s1.local_copies - s0.local_copies <= R
-    assert s1.peer_copies == 0  # one device: nothing crosses xGMI here
+        assert s1.collectives == 0
+    if sharded == "norccl3":  # no communicator: copies, counted and explained
+        assert s1.collective_fallbacks - s0.collective_fallbacks == 1
+        assert b"RCCL unavailable" in L.cbh_last_error()
+    if ndev == 1:
+        assert 1 <= s1.local_copies - s0.local_copies <= R
+        assert s1.peer_copies == 0  # one device: nothing crosses xGMI here
+    else:  # needles out to every other device; records back by peer copies unless the collective carried them
+        assert s1.peer_copies - s0.peer_copies >= ndev - 1
 
 
 def test_many_reader_threads_on_one_sharded_handle(gpu, orc, sharded):
@@ -196,7 +236,7 @@ def test_sharded_slice_is_sharded_and_video_index_takes_the_shape(gpu, sharded):
     # the raw shard-local step is a shard's, not the parent's
     assert L.cbh_idx64_scan_dev(idx.handle, 1, 1, 2, 1, 1, 1, None) == _lib.CBH_E_UNSUPPORTED
     assert L.cbh_idx64_shard(idx.handle, idx.shard_count()) is None
-    assert L.cbh_idx64_device_mask(idx.handle) == 1
+    assert L.cbh_idx64_device_mask(idx.handle) == _SHAPES[sharded][1][0]
     # unusable masks are refused outright (no silent narrowing to the devices that exist)
     assert L.cbh_idx64_create_sharded(0, 1) is None
     assert L.cbh_idx64_create_sharded(1 << 30, 1) is None
@@ -207,7 +247,7 @@ def test_cvfeatures_index_sharded_by_image(gpu, sharded):
     global row numbers; the knn table (rows, distances, counts) equals the one-device index's"""
     from cbird_amd import _lib
 
-    R = {"shards5": 5, "rccl3": 3, "shards2x": 2}[sharded]
+    R = _R(sharded)
     rng = np.random.default_rng(11)
     n_media, per = 160, 700  # 112000 rows: several runs per shard
     rows = rng.integers(0, 256, (n_media * per, 32), dtype=np.uint8)
@@ -235,4 +275,4 @@ def test_cvfeatures_index_sharded_by_image(gpu, sharded):
         assert (np.asarray(x) == np.asarray(y)).all()
     st = _lib.cbh_shard_stats()
     _lib.check(L.cbh_idx256_shard_stats(sh._h, C.byref(st)), "stats")
-    assert st.shards == R and st.scans >= R and (st.collectives >= 1) == (sharded == "rccl3")
+    assert st.shards == R and st.scans >= R and (st.collectives >= 1) == (sharded in ("rccl3", "alldev_rccl"))

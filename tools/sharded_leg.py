@@ -3,7 +3,8 @@ the all-pairs threshold sweep of BASELINE configs[1]/[2] through cbh_idx64_find_
 compared, one JSON line.  bench.py starts this as a child process (own timeout) and attaches the line as
 `single_process_sharded`; it also runs on its own:
 
-    python tools/sharded_leg.py --mask 0xff                  # the 8 GPUs of a node, RCCL all-gather between them
+    python tools/sharded_leg.py --mask 0xff                  # the 8 GPUs of a node, records to the root by peer copies
+    python tools/sharded_leg.py --mask 0xff --exchange both  # ... and once more through one grouped ncclAllGather
     python tools/sharded_leg.py --mask 1 --per-device 8      # eight logical shards on device 0 (a one-GPU box)
     python tools/sharded_leg.py --mask 1 --per-device 8 --force-rccl   # ... their block through ncclAllGather too
 
@@ -31,7 +32,9 @@ def main():
     ap.add_argument("--topk", type=int, default=8)
     ap.add_argument("--repeats", type=int, default=3)
     ap.add_argument("--force-rccl", action="store_true")
-    ap.add_argument("--exchange", type=int, default=0, help="0 = ncclAllGather between devices, 1 = peer copies")
+    ap.add_argument("--exchange", default=None,
+                    help="1 = copies into the root block (the library's default), 0 = ncclAllGather between devices, "
+                         "both = one leg each; default: 1, or 0 with --force-rccl")
     args = ap.parse_args()
     import torch
 
@@ -46,7 +49,8 @@ def main():
     dhts = [int(x) for x in args.dht.split(",") if x]
     h, ids = synth.make_hashes(n, seed=1234)
     L.cbh_set_tuning(b"shard_force_rccl", 1 if args.force_rccl else 0)
-    L.cbh_set_tuning(b"shard_exchange", args.exchange)
+    ex = args.exchange if args.exchange is not None else ("0" if args.force_rccl else "1")
+    exchanges = [1, 0] if ex == "both" else [int(ex)]
     dq = torch.from_numpy(h.view(np.int64)).to(dev)
     out = torch.empty((n, args.topk, 2), dtype=torch.int32, device=dev)
     cnt = torch.empty(n, dtype=torch.int32, device=dev)
@@ -64,11 +68,16 @@ def main():
         return (time.perf_counter() - t0) * 1e3, totals
 
     res = {"device_mask": hex(args.mask), "shards_per_device": args.per_device, "images": n, "dht": dhts,
-           "exchange": "peer copies" if args.exchange else "ncclAllGather between devices, copies inside one",
+           "exchange": ["copies into the root block" if e else "ncclAllGather between devices, copies inside one"
+                        for e in exchanges],
            "force_rccl": bool(args.force_rccl)}
     legs = {}
-    for name, make in (("one_device", lambda: L.cbh_idx64_create(root)),
-                       ("sharded", lambda: L.cbh_idx64_create_sharded(args.mask, args.per_device))):
+    plan = [("one_device", lambda: L.cbh_idx64_create(root), 1)]
+    for e in exchanges:
+        plan.append(("sharded" if e == exchanges[0] else "sharded_rccl",
+                     lambda: L.cbh_idx64_create_sharded(args.mask, args.per_device), e))
+    for name, make, e in plan:
+        L.cbh_set_tuning(b"shard_exchange", e)
         hnd = make()
         if not hnd:
             raise SystemExit(f"{name}: cannot create the index (mask {args.mask:#x})")
@@ -86,10 +95,11 @@ def main():
                       "cmp_per_s": float(n) * n * len(dhts) / (min(times) * 1e-3), "matches": totals,
                       "shards": st.shards, "devices": st.devices, "collectives": st.collectives,
                       "peer_copies": st.peer_copies, "local_copies": st.local_copies, "rescans": st.rescans,
+                      "collective_fallbacks": st.collective_fallbacks,
                       "scan_kernel_ms_per_sweep": round(cs.scan_ms / (args.repeats + 1), 3)}
         L.cbh_idx64_destroy(hnd)
     res.update(legs)
-    res["matches_equal"] = legs["one_device"]["matches"] == legs["sharded"]["matches"]
+    res["matches_equal"] = all(l["matches"] == legs["one_device"]["matches"] for l in legs.values())
     res["speedup_vs_one_device"] = legs["one_device"]["sweep_ms"] / legs["sharded"]["sweep_ms"]
     print(json.dumps(res))
     if not res["matches_equal"]:
