@@ -25,6 +25,7 @@ namespace cbh {
 namespace {
 
 constexpr size_t kMaxBatch = 256;  // needles per combined search
+constexpr size_t kMaxRoundWeight = (size_t)32 << 20;  // ... and result places per round (256 MB of cbh_match)
 
 struct Stats {
   uint64_t finds = 0, rounds = 0;
@@ -57,8 +58,10 @@ struct Combiner : CombinerBase {
       while (!me.done) {
         std::vector<Req*> batch;
         Req* first = pending.front();
+        size_t weight = 0;  // result places the round may need (a ColorDescIndex needle returns every entry)
         for (auto it = pending.begin(); it != pending.end() && batch.size() < kMaxBatch;) {
-          if ((*it)->compatible(*first)) {
+          if ((*it)->compatible(*first) && (batch.empty() || weight + (*it)->weight <= kMaxRoundWeight)) {
+            weight += (*it)->weight;
             batch.push_back(*it);
             it = pending.erase(it);
           } else {
@@ -66,7 +69,11 @@ struct Combiner : CombinerBase {
           }
         }
         lk.unlock();
-        serve(batch);
+        try {
+          serve(batch);
+        } catch (...) {  // std::bad_alloc of a staging vector: the round fails, the queue goes on
+          for (Req* r : batch) r->rc = CBH_E_NOMEM, r->n_out = 0;
+        }
         lk.lock();
         st.rounds++;
         for (Req* r : batch) r->done = true;
@@ -104,6 +111,7 @@ struct ReqBase {
   bool done = false;
   int rc = CBH_OK;
   size_t cap = 0, n_out = 0;
+  size_t weight = 1;  // result places this request may need in the round's buffer
 };
 struct FdctReq : ReqBase {
   const uint64_t* hashes;
@@ -259,6 +267,7 @@ int cbh_color_find_coalesced(cbh_color* c, const void* needle_desc, cbh_match* o
   if (!co) return CBH_E_NOMEM;
   ColorReq me;
   me.desc = (const uint8_t*)needle_desc, me.out = out, me.cap = cap;
+  me.weight = std::max<size_t>(1, cbh_color_count(c));  // every entry of the index comes back per needle
   int rc = co->submit(me, [&](std::vector<ColorReq*>& batch) {
     std::vector<uint8_t> d;
     std::vector<uint64_t> oo(batch.size() + 1);

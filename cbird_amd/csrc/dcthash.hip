@@ -329,15 +329,18 @@ __global__ __launch_bounds__(kThreads) void k_dcthash_256(
   const unsigned selR = l32 == 31 ? 0x00000102u : 0x07060504u;  // lane 31: (px254,px253,px252,x)
 
   uint2 raw[7];
-  unsigned ring[7][4];
-  unsigned S[4];
+  // DIV == 3 keeps the eight column sums of a lane unpacked (32 bits each, in the float form 0x4B000000 + S of DIV 2):
+  // twice the ring registers and ring additions, but no packing and no field extraction
+  constexpr int NR = DIV == 3 ? 8 : 4;
+  unsigned ring[7][NR];
+  unsigned S[NR];
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) ring[j][c] = 0u;
+    for (int c = 0; c < NR; ++c) ring[j][c] = 0u;
   }
 #pragma unroll
-  for (int c = 0; c < 4; ++c) S[c] = DIV ? 0u : (24u | (24u << 16));
+  for (int c = 0; c < NR; ++c) S[c] = DIV == 3 ? 0x4B000000u : DIV ? 0u : (24u | (24u << 16));
   unsigned acc = 0;
 
   // virtual row s-3 -> REFLECT_101 source row; steps past the image (s > 261) re-read row 252,
@@ -378,15 +381,49 @@ __global__ __launch_bounds__(kThreads) void k_dcthash_256(
       const unsigned H5 = udot4(D0, 0x01010000u, udot4(DR, 0x00000001u, T1));
       const unsigned H6 = udot4(D0, 0x01000000u, udot4(DR, 0x00000101u, T1));
       const unsigned H7 = udot4(DR, 0x00010101u, T1);
-      const unsigned P[4] = {H0 | (H1 << 16), H2 | (H3 << 16), H4 | (H5 << 16), H6 | (H7 << 16)};
+      if constexpr (DIV == 3) {
+        const unsigned Hs[8] = {H0, H1, H2, H3, H4, H5, H6, H7};
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        S[c] = (S[c] - ring[j][c]) + P[c];
-        ring[j][c] = P[c];
+        for (int c = 0; c < 8; ++c) {
+          S[c] = (S[c] - ring[j][c]) + Hs[c];
+          ring[j][c] = Hs[c];
+        }
+      } else {
+        const unsigned P[4] = {H0 | (H1 << 16), H2 | (H3 << 16), H4 | (H5 << 16), H6 | (H7 << 16)};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          S[c] = (S[c] - ring[j][c]) + P[c];
+          ring[j][c] = P[c];
+        }
       }
       // output row y = s - 6 (garbage for s < 6: acc is reset before the first real row)
       if (s == 6) acc = 0;
-      if constexpr (DIV == 1) {
+      if constexpr (DIV == 3) {
+        float kC = 42799.0f / 2097152.0f;
+        asm volatile("" : "+v"(kC));
+        float f = 8388608.0f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) f = __builtin_fmaf(__builtin_bit_cast(float, S[c]), kC, f);
+        acc += __builtin_bit_cast(unsigned, f);
+      } else if constexpr (DIV == 2) {
+        // one fused multiply-add per pixel divides, rounds and accumulates: 0x4B000000 | S is the float 2^23 + S, and
+        // with c = 42799 * 2^-21 (within 5e-7 of 1/49) the product (2^23 + S) * c = 171196 + S * c is exact inside
+        // the fma; added to an integer-valued accumulator below 2^24 the single rounding is to the nearest integer,
+        // which is nearest(S / 49) for every S <= 12495 (S * c stays 0.0100 away from a tie; checked exhaustively in
+        // tests/test_golden_hash_stages.py).  A chain runs over the lane's 8 pixels of a row (8 * 171196 + 8 * 255 keeps
+        // it below 2^24), its bit pattern joins the cell's integer sum.
+        float kC = 42799.0f / 2097152.0f;
+        asm volatile("" : "+v"(kC));  // a VGPR operand: a 32-bit literal would double the instruction's size
+        float f = 8388608.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const unsigned lo = (S[c] & 0xffffu) | 0x4B000000u;                          // v_and_or_b32
+          const unsigned hi = __builtin_amdgcn_alignbit(0x4B00u, S[c], 16);            // 0x4B000000 | (S >> 16)
+          f = __builtin_fmaf(__builtin_bit_cast(float, lo), kC, f);
+          f = __builtin_fmaf(__builtin_bit_cast(float, hi), kC, f);
+        }
+        acc += __builtin_bit_cast(unsigned, f);
+      } else if constexpr (DIV == 1) {
         constexpr float k49 = 1.0f / 49.0f, kMagic = 12582912.0f;  // 1.5 * 2^23 = 0x4B400000
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -403,6 +440,7 @@ __global__ __launch_bounds__(kThreads) void k_dcthash_256(
       const int y = s - 6;
       if (y >= 0 && (y & 7) == 7) {
         if constexpr (DIV == 1) acc -= 0xD0000000u;  // 64 x 0x4B400000 mod 2^32
+        if constexpr (DIV >= 2) acc -= 8u * (0x4B000000u + 8u * 171196u);  // 8 row chains: 2^23 and 8 x 171196 each
         const unsigned t = (acc + 31u + ((acc >> 6) & 1u)) >> 6;  // /64, half to even
         if (y < 256) sTile[slot][(y >> 3) * 32 + l32] = (unsigned char)t;
         acc = 0;
@@ -2612,7 +2650,7 @@ int g_hash_mfma_set(int v) { return g_hash_mfma = v; }
 // 3..7 workgroups per CU all run at the same speed: the kernel is bound by VALU issue, not by latency).
 int g_hash_div = 0, g_hash_lds_pad = 0;
 void set_hash_div(int v) {
-  if (v == 0 || v == 1) g_hash_div = v;
+  if (v >= 0 && v <= 3) g_hash_div = v;
 }
 void set_hash_lds_pad(int v) {
   if (v >= 0 && v <= 64 * 1024) g_hash_lds_pad = v;
@@ -3255,9 +3293,9 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     else CBH_256(false, DCT_, DIV_);                          \
   } while (0)
     if (g_hash_dct) {
-      if (g_hash_div) CBH_256D(1, 1); else CBH_256D(1, 0);
+      if (g_hash_div == 3) CBH_256D(1, 3); else if (g_hash_div == 2) CBH_256D(1, 2); else if (g_hash_div) CBH_256D(1, 1); else CBH_256D(1, 0);
     } else {
-      if (g_hash_div) CBH_256D(0, 1); else CBH_256D(0, 0);
+      if (g_hash_div == 3) CBH_256D(0, 3); else if (g_hash_div == 2) CBH_256D(0, 2); else if (g_hash_div) CBH_256D(0, 1); else CBH_256D(0, 0);
     }
 #undef CBH_256D
 #undef CBH_256
