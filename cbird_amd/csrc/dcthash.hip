@@ -819,6 +819,286 @@ __global__ __launch_bounds__(256, 2) void k_dcthash_256_mfma(
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_dcthash_256_band: 256x256 tiles with the horizontal half of the 7x7 box filter on the matrix cores and one
+// addition + half a fused multiply-add per pixel left for the VALU (k_dcthash_256 spends 5.9 VALU instructions per
+// pixel and is bound by their issue).
+//
+// One wave = four images, walked top to bottom in lockstep, four rows per step.  v_mfma_i32_16x16x64_i8 computes
+// D[m][n] = sum_k A[m][k] * B[k][n] with M = 16 = 4 images x 4 consecutive rows, N = 16 output columns (a column tile)
+// and K = 64 = 32 source columns of the row itself (weights +1 on the 7 taps of column n) followed by the same 32
+// columns of the row SEVEN ABOVE it (weights -1): D is the horizontal 7-tap sum of row u minus that of row u - 7, which
+// is exactly what a 7-row sliding vertical sum needs -- S(u) = S(u - 1) + D(u), one v_add per pixel, no ring of rows in
+// registers.  The pixels enter as p - 128 (one v_xor per four pixels when a row is staged; the bias cancels in the
+// difference, the seven warm-up rows leave a constant -6272 that the initial S holds).  REFLECT_101 at the left / right
+// border is folded into the band matrices of the first / last column tile, at the top / bottom into the row addresses.
+// In the accumulator layout a lane owns one column of each of the 16 column tiles of one image and receives its rows
+// four at a time, so S, the division and the 8-row part of the 8x8 cell sum stay inside the lane:
+//   division   S lives as the integer 0x4B000000 + S, i.e. the float 2^23 + S.  With c = 42799 * 2^-21 the product
+//              (2^23 + S) * c = 171196 + S * c is exact inside an fma, and added to an integer-valued accumulator below
+//              2^24 the one rounding is to the nearest integer = nearest(S / 49) (S * c stays 0.0100 away from a tie for
+//              every S <= 12495; tests/test_golden_hash_stages.py).  v_pk_fma_f32 does two rows per instruction.
+//   cell       four fmas per accumulator component per cell, bit patterns added as integers, then three DPP steps over
+//              the 8 lanes of a cell (two column tiles packed in one register), /64 half-to-even, one byte to the tile.
+// Rows travel global -> registers (coalesced 16-byte loads, two steps ahead) -> LDS ring of 12 rows per image (272-byte
+// pitch: 8 pad bytes each side, so that the K block of column tile c starts 16-byte aligned at byte 16c) -> one
+// ds_read_b128 per column tile and step in the A-operand layout.  A wave is its own workgroup: no barriers in the loop.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+// the ring is written as pairs of dwords and read back as int4 operands (and reused as floats by the tail): accesses
+// that alias by design, so the compiler must not order them by type
+typedef int v4i_lds __attribute__((ext_vector_type(4), may_alias));
+typedef unsigned int v2u_lds __attribute__((ext_vector_type(2), may_alias));
+typedef unsigned int v4u_lds __attribute__((ext_vector_type(4), may_alias));
+typedef float f32_lds __attribute__((may_alias));
+
+struct BandTables {
+  unsigned int w[3][64][4];  // B operands (i8 x 16 per lane): 0 interior column tile, 1 tile 0 (left edge), 2 tile 15
+};
+
+constexpr int kBandPitch = 272;                   // 8 + 256 + 8
+constexpr int kBandRing = 12;                     // rows of one image in LDS: three steps
+constexpr int kBandImg = kBandRing * kBandPitch;  // 3264 B
+
+template <bool DUMP, int DCT>
+__global__ __launch_bounds__(64) void k_dcthash_256_band(
+    const unsigned char* __restrict__ imgs, unsigned n, unsigned row_stride, unsigned img_stride,
+    const DctTables* __restrict__ tabs, const BandTables* __restrict__ bt, uint64_t* __restrict__ out,
+    unsigned char* __restrict__ tiles) {
+  __shared__ __attribute__((aligned(16))) unsigned char sRing[4 * kBandImg];  // 13 056 B; the tail reuses it
+  __shared__ __attribute__((aligned(16))) unsigned char sTile[4][1024];
+  const int lane = threadIdx.x;
+  const int n16 = lane & 15, q = lane >> 4;
+  const unsigned first = blockIdx.x * 4u;
+  // staging role: image q, 16-byte chunk n16 of a row
+  unsigned mine = first + (unsigned)q;
+  if (mine >= n) mine = n - 1;
+  const unsigned char* __restrict__ base = imgs + (size_t)first * img_stride;  // wave-uniform
+  const unsigned voff = (mine - first) * img_stride + (unsigned)n16 * 16u;
+  const int wr_base = q * kBandImg + 8 + 16 * n16;
+  // A-operand role: M row n16 = image n16 >> 2, row n16 & 3 of the step; chunk q: 0, 1 the row, 2, 3 the row 7 above
+  const int rd_base = (n16 >> 2) * kBandImg + (q & 1) * 16;
+  const int rd_row = (n16 & 3) + (q >= 2 ? 5 : 0);
+  // accumulator role: image q, column n16 of every column tile, rows in the four result registers
+  const v4i_t b0 = *reinterpret_cast<const v4i_t*>(bt->w[0][lane]);
+  const v4i_t bL = *reinterpret_cast<const v4i_t*>(bt->w[1][lane]);
+  const v4i_t bR = *reinterpret_cast<const v4i_t*>(bt->w[2][lane]);
+
+  for (int i = lane; i < 4 * kBandImg / 16; i += 64)
+    reinterpret_cast<v4u_lds*>(sRing)[i] = v4u_lds{0u, 0u, 0u, 0u};  // rows above the image: p - 128 = 0 contributes nothing
+
+  // virtual row w = 0..263 is image row reflect101(w - 5); output row y = w - 8 is complete with row w
+  auto src_off = [&](int w) -> unsigned {
+    int v = w - 5;
+    v = v < 0 ? -v : v;
+    v = v > 255 ? 510 - v : v;
+    return (unsigned)v * row_stride + voff;
+  };
+  uint4 stg[2][4];
+  auto load_step = [&](int t, uint4 (&dst)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[r] = *reinterpret_cast<const uint4*>(base + src_off(4 * t + r));
+  };
+  auto store_step = [&](int t3, const uint4 (&src)[4]) {  // t3 = t % 3: the step's rows take slots 4 * t3 .. + 3
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v2u_lds* p = reinterpret_cast<v2u_lds*>(sRing + wr_base + (4 * t3 + r) * kBandPitch);  // 8-byte aligned
+      p[0] = v2u_lds{src[r].x ^ 0x80808080u, src[r].y ^ 0x80808080u};
+      p[1] = v2u_lds{src[r].z ^ 0x80808080u, src[r].w ^ 0x80808080u};
+    }
+  };
+
+  unsigned S[16];
+  v2f_t f[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    S[c] = 0x4B000000u + 6272u;
+    f[c] = v2f_t{8388608.0f, 8388608.0f};
+  }
+  v2f_t kC = {42799.0f / 2097152.0f, 42799.0f / 2097152.0f};
+  asm volatile("" : "+v"(kC));  // VGPR operands (a literal would double the size of every fma)
+  const v2f_t kInit = {8388608.0f, 8388608.0f};
+  const v4i_t zero4 = {0, 0, 0, 0};
+  const int st_lane = q * 1024 + (n16 >> 3) + 2 * (n16 & 1);  // tile byte of this lane within a cell row
+  const unsigned sel_shift = (unsigned)(n16 & 1) * 16u;
+
+  // one step: rows 4t .. 4t+3 (already in the ring); FIRST = the step opens a cell row, else it closes it
+  auto step = [&](auto first_tag, int t, int t3) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    int slot = 4 * t3 + rd_row;
+    slot = slot >= kBandRing ? slot - kBandRing : slot;
+    const unsigned char* arow = sRing + rd_base + slot * kBandPitch;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const v4i_t a = *reinterpret_cast<const v4i_lds*>(arow + 16 * c);
+      const v4i_t d = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, c == 0 ? bL : c == 15 ? bR : b0, zero4, 0, 0, 0);
+      const unsigned x0 = S[c] + (unsigned)d[0], x1 = x0 + (unsigned)d[1], x2 = x1 + (unsigned)d[2],
+                     x3 = x2 + (unsigned)d[3];
+      S[c] = x3;
+#ifdef CBH_BAND_DEBUG
+      if (DUMP && c == 5 && n16 == 3 && first + (unsigned)q < n) {  // S of column 83, every virtual row
+        unsigned short* dbg = reinterpret_cast<unsigned short*>(tiles + (size_t)(first + (unsigned)q) * 1024);
+        dbg[4 * t + 0] = (unsigned short)x0, dbg[4 * t + 1] = (unsigned short)x1;
+        dbg[4 * t + 2] = (unsigned short)x2, dbg[4 * t + 3] = (unsigned short)x3;
+      }
+#endif
+      const v2f_t p01 = {__builtin_bit_cast(float, x0), __builtin_bit_cast(float, x1)};
+      const v2f_t p23 = {__builtin_bit_cast(float, x2), __builtin_bit_cast(float, x3)};
+      f[c] = __builtin_elementwise_fma(p01, kC, FIRST ? kInit : f[c]);
+      f[c] = __builtin_elementwise_fma(p23, kC, f[c]);
+#ifdef CBH_BAND_DEBUG
+      if (DUMP && c == 5 && n16 == 3 && q == 1 && first == 0) {  // accumulators of image 1 after every step
+        unsigned* dbg = reinterpret_cast<unsigned*>(tiles + (size_t)2 * 1024);
+        const float dx = f[c].x, dy = f[c].y;
+        dbg[2 * t + 0] = __float_as_uint(dx) - 0x4B000000u;
+        dbg[2 * t + 1] = __float_as_uint(dy) - 0x4B000000u;
+      }
+#endif
+    }
+    if constexpr (!FIRST) {
+      const int a_row = (t - 3) >> 1;  // cell row closed by this step (negative during the warm-up)
+      if (a_row >= 0) {
+        unsigned char* dst = &sTile[0][0] + st_lane + a_row * 32;
+#pragma unroll
+        for (int c = 0; c < 16; c += 2) {
+          // every accumulator component: 2^23 + 4 x 171196 + its four quotients
+          constexpr unsigned kBias2 = 2u * (0x4B000000u + 4u * 171196u);
+          // (by value: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whichever one is named)
+          const float fx0 = f[c].x, fy0 = f[c].y, fx1 = f[c + 1].x, fy1 = f[c + 1].y;
+          const unsigned v0 = __float_as_uint(fx0) + __float_as_uint(fy0) - kBias2;
+          const unsigned v1 = __float_as_uint(fx1) + __float_as_uint(fy1) - kBias2;
+          unsigned wv = v0 | (v1 << 16);  // <= 2040 each; <= 16320 after the 8 lanes
+          wv += (unsigned)__builtin_amdgcn_mov_dpp((int)wv, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+          wv += (unsigned)__builtin_amdgcn_mov_dpp((int)wv, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+          wv += (unsigned)__builtin_amdgcn_mov_dpp((int)wv, 0x141, 0xf, 0xf, true);  // row_half_mirror
+          const unsigned cell = (wv >> sel_shift) & 0xffffu;  // even lanes: tile c, odd lanes: tile c + 1
+          dst[2 * c] = (unsigned char)((cell + 31u + ((cell >> 6) & 1u)) >> 6);  // /64, half to even
+        }
+      }
+    }
+  };
+
+  using std::integral_constant;
+  load_step(0, stg[0]);
+  load_step(1, stg[1]);
+  __syncthreads();  // (the zero fill)
+  store_step(0, stg[0]);
+  load_step(2, stg[0]);
+  int t3 = 0;  // t % 3 of the even step
+  for (int t = 0; t < 66; t += 2) {
+    const int t3a = t3, t3b = t3 == 2 ? 0 : t3 + 1, t3c = t3b == 2 ? 0 : t3b + 1;
+    step(integral_constant<bool, true>{}, t, t3a);
+    store_step(t3b, stg[1]);  // rows of step t + 1 (its slots held step t - 2, whose last readers were step t's)
+    if (t + 3 < 66) load_step(t + 3, stg[1]);
+    step(integral_constant<bool, false>{}, t + 1, t3b);
+    if (t + 2 < 66) {
+      store_step(t3c, stg[0]);
+      if (t + 4 < 66) load_step(t + 4, stg[0]);
+    }
+    t3 = t3c;
+  }
+  __syncthreads();
+#ifndef CBH_BAND_DEBUG
+  if (DUMP) {
+    for (int g = 0; g < 4; ++g)
+      if (first + (unsigned)g < n)
+        for (int i = lane; i < 256; i += 64)
+          reinterpret_cast<unsigned*>(tiles + (size_t)(first + (unsigned)g) * 1024)[i] =
+              reinterpret_cast<const unsigned*>(sTile[g])[i];
+  }
+#endif
+  // ---- stages 3-6 as in k_dcthash_256: a half-wave per image, two images at a time; sT / sY live in the ring
+  f32_lds* sT = reinterpret_cast<f32_lds*>(sRing);                    // [2][288]
+  f32_lds* sY = reinterpret_cast<f32_lds*>(sRing) + 2 * 288;           // [2][84]
+  f32_lds* sC = reinterpret_cast<f32_lds*>(sRing) + 2 * 288 + 2 * 84;  // [9 * 33]
+  const int l32 = lane & 31, hw = lane >> 5;
+  if constexpr (DCT == 0)
+    for (int i = lane; i < 288; i += 64) sC[(i >> 5) * 33 + (i & 31)] = tabs->C[i];
+  for (int pass = 0; pass < 2; ++pass) {
+    const int slot = 2 * pass + hw;
+    const unsigned img = first + (unsigned)slot;
+    const bool valid = img < n;
+    __syncthreads();
+    {
+      float x[32];
+      const uint4* trow = reinterpret_cast<const uint4*>(&sTile[slot][l32 * 32]);
+      const uint4 a = trow[0], b = trow[1];
+      const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        x[4 * i + 0] = (float)(w[i] & 0xffu);
+        x[4 * i + 1] = (float)((w[i] >> 8) & 0xffu);
+        x[4 * i + 2] = (float)((w[i] >> 16) & 0xffu);
+        x[4 * i + 3] = (float)(w[i] >> 24);
+      }
+      if constexpr (DCT == 1) {
+        float y[9];
+        cvdct::dct32_first9(x, &tabs->cv, y);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sT[hw * 288 + l32 * 9 + k] = y[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          float t = 0.f;
+#pragma unroll
+          for (int j = 0; j < 32; ++j) t = __builtin_fmaf(x[j], tabs->C[k * 32 + j], t);
+          sT[hw * 288 + l32 * 9 + k] = t;
+        }
+      }
+    }
+    __syncthreads();
+    if constexpr (DCT == 1) {
+      if (l32 < 9) {
+        float x[32], y[9];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) x[r] = sT[hw * 288 + r * 9 + l32];
+        cvdct::dct32_first9(x, &tabs->cv, y);
+#pragma unroll
+        for (int u = 0; u < 9; ++u) sY[hw * 84 + u * 9 + l32] = y[u];
+      }
+    } else {
+#pragma unroll
+      for (int rep = 0; rep < 3; ++rep) {
+        const int o = l32 + 32 * rep;
+        if (o < 81) {
+          const int u = o / 9, k = o - u * 9;
+          float t = 0.f;
+#pragma unroll
+          for (int r = 0; r < 32; ++r) t = __builtin_fmaf(sC[u * 33 + r], sT[hw * 288 + r * 9 + k], t);
+          sY[hw * 84 + o] = t;
+        }
+      }
+    }
+    __syncthreads();
+    {
+      const float c0 = sY[hw * 84 + tabs->zz[l32]];
+      const float c1 = sY[hw * 84 + tabs->zz[l32 + 32]];
+      const int cb0 = __builtin_bit_cast(int, c0), cb1 = __builtin_bit_cast(int, c1);
+      double sumA, sumB;
+      if constexpr (DCT == 1) {
+        sumA = cvdct::sum64_halfwave(cb0, cb1, 0);
+        sumB = cvdct::sum64_halfwave(cb0, cb1, 32);
+      } else {
+        sumA = 0.0, sumB = 0.0;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+          const int src = i < 32 ? cb0 : cb1;
+          sumA += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(src, i & 31));
+          sumB += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(src, 32 + (i & 31)));
+        }
+      }
+      const float thr = (float)(hw ? sumB : sumA) / 64;
+      const unsigned long long bb0 = __ballot(c0 > thr);
+      const unsigned long long bb1 = __ballot(c1 > thr);
+      const int sh = hw * 32;
+      unsigned long long hv = ((bb0 >> sh) & 0xffffffffull) | (((bb1 >> sh) & 0xffffffffull) << 32);
+      hv &= ~1ull;  // bit 0 is never encoded (cvutil.cpp:537)
+      if (hv == 0) hv = 1;
+      if (l32 == 0 && valid) out[img] = hv;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Any other size (w,h >= 32, not both multiples of 32): cv::resize's general INTER_AREA path
 // (resizeArea_) with fractional cell weights.  Two launches: k_blur_u8 writes the blurred u8 image to a
 // scratch buffer (bands of rows staged in LDS, separable box sums), k_area_hash resamples it with the
@@ -2615,6 +2895,50 @@ void make_mfma_tables(MfmaTables* mt) {
   pass2(13, 7, 7, 1);
 }
 
+// B operands of k_dcthash_256_band: lane l = (column n = l & 15 of the tile, chunk q = l >> 4), byte j <-> k = 16 q + j.
+// k < 32: source column 16 c - 8 + k of the row, weight = how many of the 7 taps of output column 16 c + n land on it
+// (REFLECT_101 folds the taps beyond the edge back: weights of 2 in the first / last tile); k >= 32: the same columns
+// of the row seven above, weights negated.
+void make_band_tables(BandTables* bt) {
+  memset(bt, 0, sizeof(*bt));
+  const int tile_of[3] = {7, 0, 15};
+  for (int tb = 0; tb < 3; ++tb)
+    for (int l = 0; l < 64; ++l)
+      for (int j = 0; j < 16; ++j) {
+        const int k = 16 * (l >> 4) + j, kk = k & 31;
+        const int col = 16 * tile_of[tb] - 8 + kk;
+        int wgt = (col >= 0 && col < 256) ? band_weight(16 * tile_of[tb] + (l & 15), col) : 0;
+        if (k >= 32) wgt = -wgt;
+        bt->w[tb][l][j >> 2] |= (unsigned)(wgt & 0xff) << (8 * (j & 3));
+      }
+}
+
+struct BandTabCache {
+  std::mutex mu;
+  BandTables* d[16] = {};
+} g_band_tabs;
+
+int get_band_tables(const BandTables** out) {
+  int dev = 0;
+  CBH_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return CBH_E_INVAL;
+  std::lock_guard<std::mutex> lk(g_band_tabs.mu);
+  if (!g_band_tabs.d[dev]) {
+    std::vector<BandTables> host(1);
+    make_band_tables(host.data());
+    BandTables* d = nullptr;
+    CBH_HIP(hipMalloc(&d, sizeof(BandTables)));
+    hipError_t e = hipMemcpy(d, host.data(), sizeof(BandTables), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      (void)hipFree(d);
+      CBH_HIP(e);
+    }
+    g_band_tabs.d[dev] = d;
+  }
+  *out = g_band_tabs.d[dev];
+  return CBH_OK;
+}
+
 struct MfmaTabCache {
   std::mutex mu;
   MfmaTables* d[16] = {};
@@ -3270,7 +3594,23 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
   }
   if (w == 256 && h == 256 && ((uintptr_t)d_imgs % 8) == 0 && row_stride % 8 == 0 &&
       img_stride % 8 == 0 && row_stride * 256 < (1u << 24) && img_stride < (1u << 28)) {
-    if (g_hash_mfma && ((uintptr_t)d_imgs % 16) == 0 && row_stride % 16 == 0 && img_stride % 16 == 0) {
+    if (g_hash_mfma == 2 && ((uintptr_t)d_imgs % 16) == 0 && row_stride % 16 == 0 && img_stride % 16 == 0) {
+      const BandTables* btab = nullptr;
+      if ((rc = get_band_tables(&btab))) return rc;
+      dim3 gridb((unsigned)((n + 3) / 4)), blockb(64);
+#define CBH_BAND(DUMP_, DCT_)                                                                                      \
+  hipLaunchKernelGGL((k_dcthash_256_band<DUMP_, DCT_>), gridb, blockb, 0, stream, d_imgs, (unsigned)n,             \
+                     (unsigned)row_stride, (unsigned)img_stride, tabs, btab, d_out, d_tiles)
+      if (g_hash_dct) {
+        if (d_tiles) CBH_BAND(true, 1); else CBH_BAND(false, 1);
+      } else {
+        if (d_tiles) CBH_BAND(true, 0); else CBH_BAND(false, 0);
+      }
+#undef CBH_BAND
+      CBH_HIP(hipGetLastError());
+      return CBH_OK;
+    }
+    if (g_hash_mfma == 1 && ((uintptr_t)d_imgs % 16) == 0 && row_stride % 16 == 0 && img_stride % 16 == 0) {
       const MfmaTables* mt = nullptr;
       if ((rc = get_mfma_tables(&mt))) return rc;
       dim3 gridm((unsigned)((n + 3) / 4)), blockm(256);
