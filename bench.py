@@ -297,7 +297,8 @@ def main():
             "note": "low-word prefilter: one K=64 MFMA covers 2 x 1024 32-bit distances; VALU-reduction bound",
         },
         "roofline_hash": {
-            "kernel": "k_dcthash_256", "bound": "hbm", "achieved": hash_gbs, "peak": HBM_PEAK_GBS,
+            "kernel": "k_dcthash_256_band (horizontal 7-tap sums as i8 MFMAs, one add + half an fma per pixel)",
+            "bound": "hbm", "achieved": hash_gbs, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": hash_gbs / HBM_PEAK_GBS, "traffic": None,
             "avg_launch_ms": hash_ms, "algorithmic_bytes_per_launch": hash_bytes,
         },

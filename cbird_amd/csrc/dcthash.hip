@@ -2963,7 +2963,11 @@ int get_mfma_tables(const MfmaTables** out) {
 
 }  // namespace
 
-int g_hash_mfma = 0;
+// "hash_mfma": which kernel hashes 256 x 256 tiles -- 2 (default) k_dcthash_256_band (horizontal box sums on the
+// matrix cores; needs 16-byte aligned rows, else 0 is taken), 0 k_dcthash_256 (all VALU), 1 k_dcthash_256_mfma (round 2:
+// both box passes in f16 on the matrix cores; slower than either).  Staging the rows four steps ahead instead of two
+// (250 VGPRs) changed nothing: 4.83 vs 4.77 ms per 400k images.
+int g_hash_mfma = 2;
 int g_hash_mfma_set(int v) { return g_hash_mfma = v; }
 // tuning knob "hash_dct": stages 3 and 5 of dctHash64 -- 1 (default) = cv::dct / cv::sum as OpenCV 2.4.13.7 evaluates
 // them (cv_dct32_dev.h), 0 = the canonical 9x32 matrix form.  oracle: orc_set_hash_variant.

@@ -710,7 +710,11 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *   "scan_pre_max"  largest threshold served by the low-word-prefilter VALU scan variant (default 7)
  *   "scan_eq_dht1"  1 = dht==1 uses the 64-bit equality variant (default 1)
  *   "scan_group"    1 = issue-rate-shaped scan variants (default 1)
- *   "hash_mfma"     1 = 256x256 tiles use k_dcthash_256_mfma (box filter on the matrix cores; default 0)
+ *   "hash_mfma"     kernel for 256x256 tiles: 2 = k_dcthash_256_band (default: horizontal box sums as i8 MFMAs, one add +
+ *                   half an fma per pixel on the VALU; rows must be 16-byte aligned, otherwise 0 is taken), 0 =
+ *                   k_dcthash_256 (all VALU), 1 = k_dcthash_256_mfma (both box passes in f16 MFMAs; slowest)
+ *   "hash_div"      k_dcthash_256's divide by 49: 0 integer multiply-shift (default), 1 float magic number, 2 / 3 one fma
+ *                   per pixel on the float form 0x4B000000 + S (packed / unpacked column sums); all exact
  *   "hash_fast_any" 0 = the first general-geometry kernels (k_blur_u8 + k_area_hash / k_dcthash_generic), 1 = the
  *                   lane-per-8-columns kernels (default)
  *   "hash_fused"    0 = three-kernel split (k_blur_rows + k_area_rows + k_tile_hash); v >= 1 = k_blur_area (blur and

@@ -65,6 +65,17 @@ def scan256_path(request, gpu):
     L.cbh_set_tuning(b"scan256_f3", 1)
 
 
+@pytest.fixture(params=["band", "valu"])
+def hash256_kernel(request, gpu):
+    """Run a GPU hash test once per kernel for 256 x 256 tiles, both bit-exact against the oracle: "band" =
+    k_dcthash_256_band (the default: horizontal box sums on the matrix cores), "valu" = k_dcthash_256."""
+    from cbird_amd import _lib
+
+    _lib.lib().cbh_set_tuning(b"hash_mfma", 2 if request.param == "band" else 0)
+    yield request.param
+    _lib.lib().cbh_set_tuning(b"hash_mfma", 2)
+
+
 @pytest.fixture(params=["cvdct", "canon"])
 def hash_dct(request, gpu, orc):
     """Run a GPU hash test under both evaluations of dctHash64's stages 3/5, each bit-exact against the oracle set to

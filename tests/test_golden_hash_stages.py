@@ -54,3 +54,23 @@ def test_gpu_reproduces_the_frozen_vectors(gpu, hash_dct):
         assert hs[i].tolist() == g[f"kp_hashes_{i}" + variant].tolist()
         assert int(after[i].astype(np.uint64).sum()) == int(g["kp_after_sum"][i])
     assert (size_longest_side(gen.image(500, 300, 700)[None], 128)[0] == g["resized"]).all()
+
+
+def test_one_fma_divides_rounds_and_accumulates_exactly():
+    """The division step of k_dcthash_256_band (and of k_dcthash_256 under "hash_div" 2 / 3), exhaustively: the column sum
+    S of a 7x7 window (0 .. 49 * 255) lives as the integer 0x4B000000 + S = the float 2^23 + S; with c = 42799 * 2^-21,
+    fma(2^23 + S, c, acc) adds 171196 + nearest(S / 49) to an integer-valued acc below 2^24 -- the blur's
+    round-to-nearest (cv::blur, src/cvutil.cpp:463) and the running sum of an 8x8 cell in one instruction."""
+    c32 = np.float32(42799 / 2 ** 21)
+    assert float(c32) == 42799 / 2 ** 21                      # c is a float
+    S = np.arange(0, 49 * 255 + 1, dtype=np.int64)
+    want = (2 * S + 49) // 98                                # nearest(S / 49); 49 is odd, no ties
+    x = (S.astype(np.uint32) + np.uint32(0x4B000000)).view(np.float32)
+    assert (x.astype(np.float64) == 2.0 ** 23 + S).all()
+    # the product is exact in double (24 x 16 significant bits), the sum too: rounding it once to float is the fma
+    for acc in (2.0 ** 23, 2.0 ** 23 + 3 * 171196 + 3 * 255, 2.0 ** 23 + 7 * 171196 + 7 * 255):
+        y = (x.astype(np.float64) * float(c32) + acc).astype(np.float32)
+        assert (y.astype(np.float64) - acc - 171196 == want).all()
+        assert float(y.max()) < 2.0 ** 24
+    frac = (S * 42799) % 2 ** 21 / 2 ** 21                    # S * c is never closer than 0.01 to a tie
+    assert np.abs(frac - 0.5).min() > 0.01

@@ -47,7 +47,7 @@ def test_hash_any_size_general_area_path(gpu, orc, w, h):
         assert (t[i] == orc.tile32(imgs[i])).all()
 
 
-def test_hash_edge_images(gpu, orc):
+def test_hash_edge_images(gpu, orc, hash256_kernel):
     imgs = np.zeros((6, 256, 256), np.uint8)
     imgs[1] = 255
     imgs[2, ::2] = 255
@@ -69,7 +69,7 @@ def test_hash_strided_views_and_single(gpu, orc):
     assert gpu.dct_hash64(view[2]) == int(want[2])
 
 
-def test_hash_known_answers(gpu, orc):
+def test_hash_known_answers(gpu, orc, hash256_kernel):
     """single DCT basis function -> exactly its bit (see tests/test_oracle.py)"""
     zz = orc.zigzag81()
     imgs32, imgs256, bits = [], [], []
@@ -96,7 +96,7 @@ def test_hash_unsupported_geometry(gpu):
     assert len(gpu.dct_hash64_batch(np.zeros((0, 256, 256), np.uint8))) == 0
 
 
-def test_hash_large_batch_sampled(gpu, orc):
+def test_hash_large_batch_sampled(gpu, orc, hash256_kernel):
     """8192 tiles resident on the device (512 MiB), hashed in one launch; a 256-image sample is
     checked against the oracle and duplicates of the same tile hash identically."""
     import torch
@@ -122,8 +122,52 @@ def test_hash_large_batch_sampled(gpu, orc):
     assert (got[sample] == want).all()
 
 
-def test_mfma_variant_is_bit_identical(gpu, orc):
-    """k_dcthash_256_mfma (box filter on the matrix cores, tuning knob "hash_mfma") == the default kernel == oracle"""
+def test_band_kernel_every_quotient_borders_and_ragged_batches(gpu, orc):
+    """k_dcthash_256_band against the oracle where its own machinery could slip: batches that do not fill the last
+    wave's four images, images that drive the 7x7 sums through every quotient and both extremes, structure confined to
+    the three border rows / columns that REFLECT_101 folds back (the first and last column tile's band matrices, the
+    row addresses), single bright pixels in every corner, and the 32 x 32 tiles byte for byte"""
+    import torch
+
+    from cbird_amd import _lib
+
+    L = _lib.lib()
+    rng = np.random.default_rng(12)
+    imgs = rng.integers(0, 256, (23, 256, 256), dtype=np.uint8)
+    yy, xx = np.mgrid[0:256, 0:256]
+    imgs[0] = ((xx * 7 + yy * 13) % 256).astype(np.uint8)
+    imgs[1] = 0
+    imgs[2] = 255
+    imgs[3] = np.where((xx < 3) | (xx > 252), 255, 0)
+    imgs[4] = np.where((yy < 3) | (yy > 252), 255, 0)
+    imgs[5] = np.where((xx + yy) % 2 == 0, 255, 0)
+    imgs[6] = 0
+    for y, x in ((0, 0), (0, 255), (255, 0), (255, 255), (3, 3), (252, 252), (1, 254)):
+        imgs[6, y, x] = 255
+    imgs[7] = (yy // 8 * 8 + xx // 8) % 256          # constant 8x8 cells
+    imgs[8] = np.minimum(255, (xx // 16) * 17)       # steps on the column tile boundaries
+    imgs[9] = rng.integers(127, 130, (256, 256))     # around the i8 sign change
+    for n in (1, 2, 3, 4, 5, 7, 23):
+        got = gpu.dct_hash64_batch(imgs[:n])
+        assert (got == orc.dcthash64_batch(imgs[:n])).all(), n
+    d = torch.from_numpy(imgs).cuda()
+    out = torch.zeros(len(imgs), dtype=torch.int64, device="cuda")
+    tiles = torch.zeros((len(imgs), 32, 32), dtype=torch.uint8, device="cuda")
+    _lib.check(L.cbh_dcthash_tiles_dev(d.data_ptr(), len(imgs), 256, 256, 256, 65536, out.data_ptr(), tiles.data_ptr(), 0,
+                                       None), "tiles")
+    t = tiles.cpu().numpy()
+    for i in range(len(imgs)):
+        assert (t[i] == orc.tile32(imgs[i])).all(), i
+    # rows that are not 16-byte aligned take k_dcthash_256 (same answers)
+    big = rng.integers(0, 256, (3, 300, 400), dtype=np.uint8)
+    view = big[:, 7:263, 9:265]
+    assert (gpu.dct_hash64_batch(view) == orc.dcthash64_batch(np.ascontiguousarray(view))).all()
+
+
+@pytest.mark.parametrize("knob", [0, 1])
+def test_mfma_variant_is_bit_identical(gpu, orc, knob):
+    """k_dcthash_256 (all VALU, "hash_mfma" 0) and k_dcthash_256_mfma (box filter in f16 on the matrix cores, 1) == the
+    default kernel == oracle"""
     import torch
 
     from cbird_amd import _lib, synth
@@ -135,7 +179,7 @@ def test_mfma_variant_is_bit_identical(gpu, orc):
     imgs[6] = 255
     want = orc.dcthash64_batch(imgs)
     try:
-        L.cbh_set_tuning(b"hash_mfma", 1)
+        L.cbh_set_tuning(b"hash_mfma", knob)
         got = gpu.dct_hash64_batch(imgs)
         d = torch.from_numpy(imgs).cuda()
         out = torch.zeros(len(imgs), dtype=torch.int64, device="cuda")
@@ -143,7 +187,7 @@ def test_mfma_variant_is_bit_identical(gpu, orc):
         _lib.check(L.cbh_dcthash_tiles_dev(d.data_ptr(), len(imgs), 256, 256, 256, 65536, out.data_ptr(),
                                            tiles.data_ptr(), 0, None), "tiles")
     finally:
-        L.cbh_set_tuning(b"hash_mfma", 0)
+        L.cbh_set_tuning(b"hash_mfma", 2)
     assert (got == want).all()
     t = tiles.cpu().numpy()
     for i in range(0, len(imgs), 7):
@@ -152,7 +196,8 @@ def test_mfma_variant_is_bit_identical(gpu, orc):
 
 
 def test_float_magic_divide_variant_is_bit_identical(gpu, orc):
-    """k_dcthash_256 with nearest(S/49) taken from the bit pattern of fma(float(S), 1/49, 1.5 * 2^23) (knob "hash_div" 1)
+    """k_dcthash_256 with nearest(S/49) taken from the bit pattern of fma(float(S), 1/49, 1.5 * 2^23) (knob "hash_div" 1),
+    or accumulated by one fma per pixel on the float form 0x4B000000 + S (2: packed, 3: unpacked column sums)
     == the integer multiply-shift form == oracle, on images that hit every quotient incl. the extremes; the occupancy
     knob "hash_lds_pad" changes nothing either"""
     import torch
@@ -169,7 +214,8 @@ def test_float_magic_divide_variant_is_bit_identical(gpu, orc):
     want = orc.dcthash64_batch(imgs)
     d = torch.from_numpy(imgs).cuda()
     try:
-        for div, pad in ((1, 0), (1, 12288), (0, 20480)):
+        L.cbh_set_tuning(b"hash_mfma", 0)  # (these are knobs of k_dcthash_256)
+        for div, pad in ((1, 0), (1, 12288), (0, 20480), (2, 0), (3, 0)):
             L.cbh_set_tuning(b"hash_div", div)
             L.cbh_set_tuning(b"hash_lds_pad", pad)
             assert (gpu.dct_hash64_batch(imgs) == want).all(), (div, pad)
@@ -183,6 +229,7 @@ def test_float_magic_divide_variant_is_bit_identical(gpu, orc):
     finally:
         L.cbh_set_tuning(b"hash_div", 0)
         L.cbh_set_tuning(b"hash_lds_pad", 0)
+        L.cbh_set_tuning(b"hash_mfma", 2)
 
 
 def test_register_streaming_kernel(gpu, orc):
