@@ -428,43 +428,45 @@ int cbh_vidx_find_videos_batch(cbh_vidx* v, const int32_t* frames, const uint64_
 
 /* ---- .vdx v2 codec (host) ------------------------------------------------------------------- */
 
+// Layout (src/videoindex.cpp:271-337 fixes the bytes, nothing else): text header line, u32 length of the frame-number
+// block, that block -- one byte for frame 0, then every gap to the next stored frame as a base-128 number, least
+// significant group first, bit 7 set on every group but the last -- zero padding up to an 8-byte file offset, the u64
+// hashes, the four characters "cbir".  Two passes: size everything, then write straight into the caller's buffer.
 size_t cbh_vdx_encode(const int32_t* frames, const uint64_t* hashes, size_t n, const char* version,
                       uint8_t* out, size_t cap) {
   char header[256];
-  const int hl = snprintf(header, sizeof header, "cbird video index:%s:%d:%d:%d:%d:%zu:\n",
-                          version ? version : "0.8.1", 2, 1 /* QSysInfo::LittleEndian */, 1, 8, n);
-  std::vector<uint8_t> buf(header, header + hl);
-  if (n) {
-    if (!frames || !hashes || frames[0] != 0) return 0;  // "first frame must be 0" (:297-300)
-    std::vector<uint8_t> packed;
-    packed.reserve(n);
-    int prev = frames[0], nextByte = prev;
-    for (size_t i = 1; i < n; ++i) {
-      int offset = frames[i] - prev;
-      prev = frames[i];
-      if (offset < 1) return 0;  // non-sequential frame number (:308-313)
-      while (offset > 0) {
-        packed.push_back((uint8_t)nextByte);
-        const int lsb = offset & 0x7F;
-        offset >>= 7;
-        nextByte = lsb | (offset == 0 ? 0x00 : 0x80);
-      }
-    }
-    packed.push_back((uint8_t)nextByte);
-    const uint32_t len = (uint32_t)packed.size();
-    const uint8_t* lp = reinterpret_cast<const uint8_t*>(&len);
-    buf.insert(buf.end(), lp, lp + 4);
-    size_t pad = 8 - ((size_t)hl + 4 + packed.size()) % 8;
-    if (pad == 8) pad = 0;
-    packed.resize(packed.size() + pad);
-    buf.insert(buf.end(), packed.begin(), packed.end());
-    const uint8_t* hp = reinterpret_cast<const uint8_t*>(hashes);
-    buf.insert(buf.end(), hp, hp + n * 8);
-    const char* tr = "cbir";
-    buf.insert(buf.end(), tr, tr + 4);
+  const size_t hl = (size_t)snprintf(header, sizeof header, "cbird video index:%s:%d:%d:%d:%d:%zu:\n",
+                                     version ? version : "0.8.1", 2, 1 /* QSysInfo::LittleEndian */, 1, 8, n);
+  if (n == 0) {  // an empty index is its header
+    if (out && hl <= cap) memcpy(out, header, hl);
+    return hl;
   }
-  if (out && buf.size() <= cap) memcpy(out, buf.data(), buf.size());
-  return buf.size();
+  if (!frames || !hashes || frames[0] != 0) return 0;  // the format has no place for a first frame other than 0
+  size_t groups = 1;                                     // (frame 0's byte)
+  for (size_t i = 1; i < n; ++i) {
+    const long long gap = (long long)frames[i] - frames[i - 1];
+    if (gap < 1) return 0;  // frame numbers must rise
+    for (unsigned long long g = (unsigned long long)gap; g; g >>= 7) ++groups;
+  }
+  if (groups > 0xffffffffull) return 0;
+  const size_t pad = (8 - (hl + 4 + groups) % 8) % 8;
+  const size_t total = hl + 4 + groups + pad + n * 8 + 4;
+  if (!out || total > cap) return total;
+  uint8_t* w = out;
+  memcpy(w, header, hl), w += hl;
+  const uint32_t len = (uint32_t)groups;
+  memcpy(w, &len, 4), w += 4;
+  *w++ = 0;
+  for (size_t i = 1; i < n; ++i)
+    for (unsigned long long g = (unsigned long long)((long long)frames[i] - frames[i - 1]); g;) {
+      const uint8_t low = (uint8_t)(g & 0x7f);
+      g >>= 7;
+      *w++ = (uint8_t)(low | (g ? 0x80 : 0x00));
+    }
+  memset(w, 0, pad), w += pad;
+  memcpy(w, hashes, n * 8), w += n * 8;
+  memcpy(w, "cbir", 4);
+  return total;
 }
 
 // header of a v2 file: fields of the first line, as checkHeader_v2 (:214-246) accepts them

@@ -50,6 +50,32 @@ def test_converter_round_trip(tmp_path, orc):
     assert (d["coef_bits"][0] == co.view(np.uint32)).all()
 
 
+def test_pin_report_names_the_first_stage_that_differs(tmp_path, orc):
+    """tools/pin_report.py (the last step of tools/pin_with_opencv.sh) on a throw-away golden file made from the ORACLE's
+    own outputs: every stage agrees; with one tile byte changed the blur / resize stage is the first named, with the
+    cv::dct restatement right behind it ok (it is judged on the golden's tile, not on the oracle's)"""
+    recs = ["V 2.4.13.7-selfmade"]
+    for w, h, seed in ((64, 64, 101), (300, 200, 107), (256, 256, 102)):
+        img = conv.gen_image(w, h, seed)
+        tile = orc.tile32(img)
+        hv, co, th = orc.hash_from_tile32(tile, with_coefs=True)
+        recs.append("H %d %d %d %016x %08x %s %s" % (w, h, seed, hv, np.float32(th).view(np.uint32),
+                                                       " ".join("%08x" % c for c in co.view(np.uint32)), tile.tobytes().hex()))
+    txt, npz = tmp_path / "g.txt", tmp_path / "g.npz"
+    txt.write_text("\n".join(recs) + "\n")
+    np.savez(npz, **conv.parse(str(txt)))
+    env = dict(os.environ, CBH_PIN_GOLD=str(npz))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pin_report.py")], capture_output=True, text=True, env=env)
+    assert out.returncode == 0 and "every stage with a golden agrees" in out.stdout, out.stdout + out.stderr
+    d = dict(np.load(npz))
+    d["tiles"] = d["tiles"].copy()
+    d["tiles"][1, 3, 4] ^= 1
+    np.savez(npz, **d)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pin_report.py")], capture_output=True, text=True, env=env)
+    assert out.returncode == 1, out.stdout + out.stderr
+    assert "FIRST stage that disagrees with OpenCV: cv::blur" in out.stdout and "(300, 200, 107)" in out.stdout
+
+
 @needs_golden
 def test_oracle_matches_opencv(orc):
     g = np.load(GOLD)
