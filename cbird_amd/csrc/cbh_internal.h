@@ -150,6 +150,7 @@ int g_hash_mfma_set(int v);  // dcthash.hip
 extern int g_fdct_host_vote, g_video_host_reduce;  // fdct.hip: 1 = round-1 host reductions (parity tests)
 void set_orb_retain_order(int v);  // orb.hip: 1 (default) retainBest in libstdc++'s order, 0 canonical (ties kept, raster order)
 void set_hash_fuse(int v);      // dcthash.hip: vertical INTER_AREA pass + tile inside k_blur_area_regs (0 never, 1 auto, 2 always)
+void set_hash_area(int v);      // dcthash.hip: 1 = integer sums for the interior of fractional INTER_AREA cells (NOT bit-identical)
 void set_hash_regs(int v);      // dcthash.hip: register-streaming general-geometry kernel where applicable (default 1)
 void set_hash_div(int v);       // dcthash.hip: k_dcthash_256 divide-by-49 form, 1 = float magic (default), 0 = integer SDWA
 void set_hash_lds_pad(int v);   // dcthash.hip: occupancy experiment knob
@@ -162,6 +163,7 @@ void set_hash_fast_any(int on);  // dcthash.hip: fast kernels for geometries oth
 void set_cd_chains(int v);   // colordesc_create.hip: 1 = chain-per-lane kernels (default), 0 = k_cd_cluster (lane per image)
 void set_cd_group(int v);    // colordesc_create.hip: images per wave of the seeding kernel (0 = auto)
 void set_color_pk(int on);   // color.hip: packed-f32 distance kernel (default on)
+void set_color_fma(int on);  // color.hip: fused squares in k_color_dist3 (default off: not bit-identical)
 
 // ---- records.hip ----------------------------------------------------------------------
 // Ascending u64 sort of n records in place (uses d_alt as the ping-pong buffer and d_tmp as

@@ -1319,6 +1319,14 @@ int cbh_set_tuning(const char* key, int value) {
     set_cd_chains(value);
     return CBH_OK;
   }
+  if (!strcmp(key, "hash_area")) {
+    set_hash_area(value);
+    return CBH_OK;
+  }
+  if (!strcmp(key, "color_fma")) {
+    set_color_fma(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "color_pk")) {
     set_color_pk(value);
     return CBH_OK;

@@ -177,8 +177,14 @@ __global__ __launch_bounds__(256) void k_color_dist2(const float* __restrict__ L
 // SIMD.  Operation order per distance and per sum is k_color_dist's (minima are order-independent; the two sums run
 // over ascending colour index), so the results are bit-identical.  RAW: also the float distance (FLT_MAX where the
 // reference's distance() returns FLT_MAX).
+// FMA ("color_fma" 1, never the default): dl^2 + du^2 + dv^2 as one multiply and two fused multiply-adds -- 6
+// floating-point instructions per colour pair instead of 8.  The squared distance then carries one rounding instead of
+// three, so a distance can differ from ColorDescriptor::distance's (src/cvutil.cpp:700-735: plain float expressions,
+// which GCC does not contract across statements at cbird's -O2) in its last bits: within north_star's 1e-5 on the float,
+// but int(score) is not guaranteed to match at an integer boundary.  tools/bench_configs.py reports the rate both ways and
+// how many scores move.
 constexpr int kHalf = kNC / 2;
-template <bool RAW>
+template <bool RAW, bool FMA>
 __global__ __launch_bounds__(256) void k_color_dist3(const float* __restrict__ L, const float* __restrict__ U,
                                                      const float* __restrict__ V,
                                                      const unsigned char* __restrict__ num, size_t stride,
@@ -231,8 +237,8 @@ __global__ __launch_bounds__(256) void k_color_dist3(const float* __restrict__ L
         for (int e = 0; e < 2; ++e) {
           const float dl = nl[p + e] - al, du = nu[p + e] - au, dv = nv[p + e] - av;
           const float el = nl[p + e] - bl, eu = nu[p + e] - bu, ev = nv[p + e] - bv;
-          const float d2a = dl * dl + du * du + dv * dv;
-          const float d2b = el * el + eu * eu + ev * ev;
+          const float d2a = FMA ? __builtin_fmaf(dv, dv, __builtin_fmaf(du, du, dl * dl)) : dl * dl + du * du + dv * dv;
+          const float d2b = FMA ? __builtin_fmaf(ev, ev, __builtin_fmaf(eu, eu, el * el)) : el * el + eu * eu + ev * ev;
           da[e] = __builtin_bit_cast(uint32_t, d2a);
           db[e] = __builtin_bit_cast(uint32_t, d2b);
           rowmin[p + e] = min(min(rowmin[p + e], da[e]), db[e]);  // v_min3_u32
@@ -378,6 +384,7 @@ __global__ __launch_bounds__(256) void k_color_collect(const int* __restrict__ s
 // All three sit at the VALU issue ceiling of this arithmetic (no FMA: the reference's rounding order) once the launch
 // geometry lets concurrent workgroups share haystack tiles.
 int g_color_pk = 1;
+int g_color_fma = 0;  // "color_fma": 1 = k_color_dist3 with fused squares (faster, NOT bit-identical; see the kernel)
 
 void decompress(const uint8_t* desc, NeedleF* out) {  // DescriptorColor::get, cvutil.h:83-87
   for (int c = 0; c < kNC; ++c) {
@@ -402,6 +409,7 @@ void decompress(const uint8_t* desc, NeedleF* out) {  // DescriptorColor::get, c
 }  // namespace
 
 namespace cbh {
+void set_color_fma(int on) { g_color_fma = on ? 1 : 0; }
 void set_color_pk(int on) {
   if (on >= 0) g_color_pk = on;
 }
@@ -519,15 +527,18 @@ int run_dist(cbh_color* c, const uint8_t* needle_descs, size_t nq, float* d_raw 
   for (size_t q = 0; q < nq; ++q) decompress(needle_descs + q * kDescBytes, &nf[q]);
   CBH_HIP(hipMemcpyAsync(c->d_needles, nf.data(), nq * sizeof(NeedleF), hipMemcpyHostToDevice, c->stream));
   CBH_HIP(hipStreamSynchronize(c->stream));  // nf is a stack-lifetime buffer
-  if (g_color_pk >= 2 || d_raw) {
+  if (g_color_pk >= 2 || d_raw || g_color_fma) {
     const unsigned tiles = (unsigned)((c->n + 255) / 256);
     dim3 grid((unsigned)nq, std::min(tiles, 32768u), (tiles + 32767u) / 32768u), block(256);
-    if (d_raw)
-      hipLaunchKernelGGL(k_color_dist3<true>, grid, block, 0, c->stream, c->dL, c->dU, c->dV, c->d_num, c->cap,
-                         (uint32_t)c->n, c->d_needles, c->d_scores, d_raw);
-    else
-      hipLaunchKernelGGL(k_color_dist3<false>, grid, block, 0, c->stream, c->dL, c->dU, c->dV, c->d_num, c->cap,
-                         (uint32_t)c->n, c->d_needles, c->d_scores, d_raw);
+#define CBH_DIST3(RAW_, FMA_)                                                                                       \
+  hipLaunchKernelGGL((k_color_dist3<RAW_, FMA_>), grid, block, 0, c->stream, c->dL, c->dU, c->dV, c->d_num, c->cap, \
+                     (uint32_t)c->n, c->d_needles, c->d_scores, d_raw)
+    if (g_color_fma) {
+      if (d_raw) CBH_DIST3(true, true); else CBH_DIST3(false, true);
+    } else {
+      if (d_raw) CBH_DIST3(true, false); else CBH_DIST3(false, false);
+    }
+#undef CBH_DIST3
   } else if ((c->cap & 1) == 0 && g_color_pk) {
     const unsigned tiles = (unsigned)((c->n + 511) / 512);
     dim3 grid((unsigned)nq, std::min(tiles, 32768u), (tiles + 32767u) / 32768u), block(256);

@@ -12,7 +12,7 @@
 // before sums: the library is built without FMA, this file is compiled with -ffp-contract=off).
 //
 // Selected by the tuning knob "hash_dct" (1 = this unit, the default; 0 = the canonical 9x32 matrix form documented in
-// DESIGN.md section 3).  tools/hash_at_risk.py measures how often the two and a float64 evaluation disagree on a bit.
+// NOTES.md section 3).  tools/hash_at_risk.py measures how often the two and a float64 evaluation disagree on a bit.
 //
 // Everything is written for full unrolling: a lane owns one 32-point transform in registers, every index is a
 // compile-time constant, the twiddles are wave-uniform (scalar loads), and only the first nine outputs are kept --

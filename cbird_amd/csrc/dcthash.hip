@@ -297,7 +297,7 @@ __device__ __forceinline__ float cvt_f32_word1(unsigned p) {
 //      k/49 is never within 0.0102 of a tie and the product's error is < 2e-5), so the BIT PATTERN of r is
 //      0x4B400000 + quotient: one complex op (the u16 -> f32 convert) + two simple ones (v_fma_f32, v_add_u32 of the
 //      bit patterns; the 64 x 0x4B400000 of a cell leave mod 2^32 at the end).  Measured 4 % SLOWER than form 0
-//      (tools/hash_sweep.py): simple ops cost ~2.15 cycles per wave, complex ~4.3, and they add.
+//      (tools/ab/hash_sweep.py): simple ops cost ~2.15 cycles per wave, complex ~4.3, and they add.
 template <bool DUMP, int DCT, int DIV>
 __global__ __launch_bounds__(kThreads) void k_dcthash_256(
     const unsigned char* __restrict__ imgs, unsigned n, unsigned row_stride, unsigned img_stride,
@@ -1846,9 +1846,10 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
                                                         int ipb /* images side by side in the workgroup */,
                                                         unsigned n_imgs, const YRow* __restrict__ yrow = nullptr,
                                                         int isy = 0, unsigned char* __restrict__ tiles_out = nullptr,
-                                                        int oy = 0, int ph = 0, int ox = 0, int pw = 0
+                                                        int oy = 0, int ph = 0, int ox = 0, int pw = 0,
                                                         /* a view: the w x h rectangle at (ox, oy) of a pw x ph parent
-                                                           that starts at imgs; ph = 0: whole images */) {
+                                                           that starts at imgs; ph = 0: whole images */
+                                                        int fast_area = 0 /* "hash_area" 1: see the x chains below */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_fused[];
   constexpr int R = K / 2;
   constexpr int kStep = StreamK<K>::step;
@@ -2101,7 +2102,27 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
   ba += (float)(wa >> 24) * (W3), bb += (float)(wb >> 24) * (W3);
             CBH_AREA_WORD(0);
             CBH_AREA_PIX4(wF4.x, wF4.y, wF4.z, wF4.w);
-            if (mid_ok) {
+            if (mid_ok && fast_area) {
+              // "hash_area" 1 (never the default): the interior pixels all weigh a_mid, so their chain
+              // `ba += float(p) * a_mid` (three instructions per pixel, one rounding per pixel) becomes an exact
+              // integer sum (v_dot4: a quarter of an instruction per pixel) times a_mid, added once.  Mathematically the
+              // same number; the float result differs in its last bits from the chain OpenCV's resizeArea_ runs, so a
+              // tile byte can flip at a rounding boundary (tools/fuzz_hash_sizes.py --area-fast counts how often).
+              unsigned ia = 0, ib = 0;
+              for (int c = 1; c < nw_u - 2; ++c) {
+                CBH_AREA_WORD(c);
+                ia = udot4(wa, 0x01010101u, ia), ib = udot4(wb, 0x01010101u, ib);
+              }
+              ba = __builtin_fmaf((float)ia, a_mid, ba), bb = __builtin_fmaf((float)ib, a_mid, bb);
+              if (nw_u >= 3) {
+                CBH_AREA_WORD(nw_u - 2);
+                CBH_AREA_PIX4(wTa.x, wTa.y, wTa.z, wTa.w);
+              }
+              if (nw_u >= 2) {
+                CBH_AREA_WORD(nw_u - 1);
+                CBH_AREA_PIX4(wTb.x, wTb.y, wTb.z, wTb.w);
+              }
+            } else if (mid_ok) {
               for (int c = 1; c < nw_u - 2; ++c) {  // interior words: every pixel of every lane weighs a_mid
                 CBH_AREA_WORD(c);
                 CBH_AREA_PIX4(a_mid, a_mid, a_mid, a_mid);
@@ -2970,7 +2991,7 @@ int get_mfma_tables(const MfmaTables** out) {
 int g_hash_mfma = 2;
 int g_hash_mfma_set(int v) { return g_hash_mfma = v; }
 // tuning knob "hash_dct": stages 3 and 5 of dctHash64 -- 1 (default) = cv::dct / cv::sum as OpenCV 2.4.13.7 evaluates
-// them (cv_dct32_dev.h), 0 = the canonical 9x32 matrix form.  oracle: orc_set_hash_variant.
+// them (cv_dct32_dev.h), 0 = the canonical 9x32 matrix form (NOTES.md section 3).  oracle: orc_set_hash_variant.
 // "hash_div": how k_dcthash_256 divides by 49 (see the kernel): 0 = integer SDWA (default), 1 = float magic number
 // (exact too; measured 4 % slower: 5.57 vs 5.36 ms per 400k images -- on this VALU a "simple" op costs ~2.15 cycles
 // per wave and a "complex" one ~4.3, additively, so 2 complex -> 1 complex + 2 simple is break-even at best).
@@ -3001,6 +3022,9 @@ void set_hash_stream(int v) {
 }
 int g_hash_fuse = 1;  // "hash_fuse": 1 = k_blur_area_regs<.., FUSE> (vertical pass + tile in the strip kernel) when the batch
                       // gives >= 512 workgroups, 2 = always, 0 = never (k_tile_hash reads the rows back)
+int g_hash_area = 0;  // "hash_area": 1 = k_blur_area_regs sums the interior pixels of a fractional INTER_AREA cell as integers
+                      // (results may differ from the exact chain in a tile byte at a rounding boundary; default 0)
+void set_hash_area(int v) { g_hash_area = v ? 1 : 0; }
 int g_hash_regs = 1;  // k_blur_area_regs (blur input from global memory into registers) where its preconditions hold
 void set_hash_fuse(int v) {
   if (v >= 0 && v <= 2) g_hash_fuse = v;
@@ -3432,7 +3456,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
             // lose occupancy to the extra LDS; fractional ratios gain up to ~1 MP)
             const unsigned Tf_ = (unsigned)std::max(64, (ipb_f * std::max(Lr, 32) + 63) / 64 * 64);
             // a fused workgroup walks its whole image alone: with one or two waves per workgroup the machine needs
-            // thousands of them before that beats strips of 8 steps (tools/hash_small_batches.py: 400x300, one wave per
+            // thousands of them before that beats strips of 8 steps (tools/ab/hash_small_batches.py: 400x300, one wave per
             // image, 1024 images 137 us fused / 86 split, 2048: 160 / 148, 4096: 289 / 298; 800x600, two waves:
             // 2048 images 553 / 483, 4096: 945 / 951; four-wave workgroups of 3-6 images pay from ~600 up)
             const size_t fuse_min_wgs = Tf_ <= 64 ? 4096 : Tf_ <= 128 ? 3072 : 512;
@@ -3449,7 +3473,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
       hipLaunchKernelGGL((k_blur_area_regs<KK, GG, true>), dim3(1, 1, (unsigned)((m + ipb_f - 1) / ipb_f)),  \
                          dim3(std::min(256u, Tf_)), fsm, stream, src, w, h, (unsigned)row_stride, img_stride, at.x,       \
                          at.xfirst, isx, steps_f, (float*)nullptr, ipb_f, (unsigned)m, at.yrow, isy, d_ftiles,       \
-                         v_oy, v_ph, v_ox, v_pw);                                                            \
+                         v_oy, v_ph, v_ox, v_pw, g_hash_area);                                               \
       break;                                                                                                 \
     }                                                                                                        \
     if (rsmem > 64 * 1024)                                                                                   \
@@ -3458,7 +3482,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     hipLaunchKernelGGL((k_blur_area_regs<KK, GG, false>), dim3(1, gs.y, (unsigned)((m + ipb - 1) / ipb)), dim3(Tr), rsmem, \
                        stream, src, w, h, (unsigned)row_stride, img_stride, at.x, at.xfirst, isx, steps, d_rowsf,   \
                        ipb, (unsigned)m, (const YRow*)nullptr, 0, (unsigned char*)nullptr, v_oy, v_ph, v_ox, \
-                       v_pw);                                                                                \
+                       v_pw, g_hash_area);                                                                   \
   } while (0)
 #define CBH_REGS(KK)              \
   do {                            \

@@ -441,7 +441,7 @@ __device__ __forceinline__ void handle_tile3(const v16f& c, uint32_t row0, uint3
 
 // (MINB = 2 workgroups per CU as the minimum: with at most 256 registers per lane the compiler keeps the accumulators in
 //  VGPRs -- given 512 it puts them in AGPRs and adds a v_accvgpr_read_b32 for every register the OR reduction touches,
-//  71 instead of 39 VALU instructions per six MFMAs.  Measured on one box, alternating (tools/scan_ab.py): 17.2-17.4 ms
+//  71 instead of 39 VALU instructions per six MFMAs.  Measured on one box, alternating (tools/ab/scan_ab.py): 17.2-17.4 ms
 //  either way -- the reads are not what holds the matrix pipe at 85 %; the VGPR form ships because it issues less.)
 template <int HT, int G, int MINB>
 __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma3(
@@ -532,7 +532,7 @@ int g_mfma_full3 = 1;          // three-field variant for kPreMaxThresh < thresh
 int g_mfma_ht = 8;             // haystack tiles per wave (2, 4 or 8)
 int g_mfma_pre = 1;            // low-word prefilter variant for thresh <= kPreMaxThresh
 int g_mfma_pre_minb = 4;       // "scan_mfma_pre" = 11 .. 14: the prefilter compiled for >= 1 / 2 / 3 / 4 workgroups per CU.  Same box,
-                               // alternating (tools/scan_pre_ab.py): 10.8 / 10.8 / 10.1 / 9.8 ms -- this kernel is bound by VALU
+                               // alternating (tools/ab/scan_pre_ab.py): 10.8 / 10.8 / 10.1 / 9.8 ms -- this kernel is bound by VALU
                                // issue, and a fourth wave per SIMD (128 VGPRs, 12 bytes of spill) hides more of it
 int g_mfma_g = 2;              // haystack tiles per accumulator group (2 or 4; HT = 8 only)
 uint32_t g_mfma_min_nq = 256;  // below this the needle expansion + tile padding is not worth it

@@ -5,7 +5,7 @@
 // reference states at dcthashindex.cpp:210-217:  hamm64(q, hash[i]) < thresh  &&  id[i] != 0
 // (hamm64 = popcountll(a ^ b), src/hamm.h:24-26), evaluated for a whole batch of needles.
 //
-// Mapping to the machine (see DESIGN.md "k_hamm64_scan")
+// Mapping to the machine (see NOTES.md "k_hamm64_scan")
 //  * haystack slots live in VGPRs: each lane owns H=8 slots (16 VGPRs), a 256-thread workgroup
 //    owns a tile of 2048 slots, loaded once with coalesced 8-B loads;
 //  * needles are wave-uniform: they stream through the scalar cache (s_load_dwordx16 = 8 needles)

@@ -724,6 +724,12 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *   "kp_lds_side"   largest keypoint square k_kp_hashes stages in LDS (default 134; larger: global-memory routine)
  *   "kp_blur_side"  largest keypoint square whose blurred copy also stays in LDS (default 112)
  *   "color_pk"      1 = packed-f32 colour distance kernel (default 1)
+ * Knobs that CHANGE results (within north_star's float tolerance; never the default, and not "experiments"):
+ *   "color_fma"     1 = the colour distance forms dl^2 + du^2 + dv^2 with fused multiply-adds (k_color_dist3<.., FMA>):
+ *                   fewer instructions, distances within 1e-5 (relative) of ColorDescriptor::distance's but not
+ *                   bit-identical, so int(score) can move by one at an integer boundary
+ *   "hash_area"     0 = exact (default): the fractional-ratio INTER_AREA resample keeps OpenCV's float accumulation
+ *                   order; 1 = fast: the horizontal pass may fuse and re-associate (see dcthash.hip k_blur_area_regs)
  *   "color_create_chains" 1 = ColorDescriptor::create's clustering as chain-per-lane kernels (default), 0 = one lane per
  *                   image (k_cd_cluster, round 2)
  *   "scratch_alloc" 2 = scratch from the library's arena (default); 1 = one ROCm hipMemPool_t per stream, 0 = ROCm's

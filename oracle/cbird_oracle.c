@@ -5,7 +5,7 @@
  * bench.py's cpu_baseline leg may load it.  The product (cbird_amd/, libcbird_hip.so)
  * never links, imports or falls back to anything in oracle/.
  *
- * Pinning status (see DESIGN.md "Oracle"):
+ * Pinning status (see DESIGN.md "(c) Oracle", NOTES.md section 4):
  *   - search semantics (orc_scan64*, orc_hamm64): PINNED against the real reference
  *     VP-tree compiled in place (oracle/_ref, tests/test_oracle_ref.py) and against the
  *     committed golden vectors generated from it (tests/golden/vptree_*.json).
@@ -17,7 +17,7 @@
  *     recalled in SURVEY.md section 8(a1).  The DCT and the sum exist in two evaluations
  *     behind orc_set_hash_variant(): 1 (default) = cv::dct's factorised float algorithm and
  *     cv::sum's grouping as recalled (oracle/cv_dct32.c, one labelled unit), 0 = the canonical
- *     separable f32 matrix form of DESIGN.md (fixed fmaf order).  The GPU reproduces either
+ *     separable f32 matrix form of NOTES.md section 3 (fixed fmaf order).  The GPU reproduces either
  *     bit for bit (knob "hash_dct"); tools/hash_at_risk.py bounds how many bits the choice,
  *     or any float evaluation of the same transform, can move; tools/gen_golden_opencv.cpp
  *     + tests/test_opencv_golden.py pin it the day someone runs it against the real library.
@@ -466,7 +466,7 @@ static int area_resize32_u8(const uint8_t* src, int w, int h, uint8_t* dst /*32*
  * orc_set_hash_variant():
  *   1 (default)  cv::dct / cv::sum as OpenCV 2.4.13.7 evaluates them, restated in the labelled unit oracle/cv_dct32.c
  *                (factorised float DCT via a 16-point complex FFT; sum in float groups of four, accumulated in double)
- *   0            canonical separable 9x32 matrix form with a fixed fmaf order, sequential double sum
+ *   0            canonical separable 9x32 matrix form with a fixed fmaf order, sequential double sum (NOTES.md 3)
  * The HIP library has the same switch (tuning knob "hash_dct").  Neither is pinned against the real library here
  * ("parity unpinned"); tools/hash_at_risk.py measures how often they -- and the float64 evaluation below -- disagree.
  * Also returns the 64 selected coefficients and the threshold when coefs != NULL (for at-risk-bit statistics). */

@@ -1,7 +1,7 @@
 """Real OpenCV 2.4.13.7 goldens for dctHash64 and its pre-stages -- WHEN THEY EXIST.
 
 tools/gen_golden_opencv.cpp has to be run where that library is installed (it is not in this image: the hash side of
-the oracle is "parity unpinned"); tools/opencv_golden_to_npz.py turns its output into
+the oracle is "parity unpinned", NOTES.md section 4); tools/opencv_golden_to_npz.py turns its output into
 tests/golden/opencv_hash.npz.  Until that file is committed the golden tests below SKIP, loudly; what always runs is
 the check that the C++ tool and its Python twin generate identical input images (the tool is compiled here with
 -DNO_OPENCV, which leaves only the generator)."""

@@ -1,5 +1,5 @@
 """Secondary measurements for BASELINE configs[3] (ORB 256-bit knn) and configs[4] (video), 1 GPU.
-Not the bench.py contract line -- numbers for DESIGN.md."""
+Not the bench.py contract line -- numbers for DESIGN.md / NOTES.md."""
 import ctypes as C, json, sys, time
 import numpy as np
 sys.path.insert(0, ".")
