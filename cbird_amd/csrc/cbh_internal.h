@@ -140,6 +140,7 @@ bool scan256_mfma_wanted(size_t n, size_t nq, int thresh);
 void set_scan256_g(int g);
 void set_scan256_ht(int ht);
 void set_scan256_small(int v);  // stationary-needle kernel for <= 512 needle descriptors: 0 / 1, >= 16: its workgroups
+void set_scan256_lut(int v);    // k_hamm256_small: FP4 expansion of the streamed rows through an LDS table (default 1)
 void set_scan256_f3(int v);   // prefilter with three needle tiles per accumulator (default 1; 0 off; HT*10+G shapes)
 void set_scan256_pre(int on);  // first-128-bit prefilter variant (default on)
 void set_scan256_mfma(int on);  // <0 = keep; 2 = force for any size
@@ -151,6 +152,7 @@ extern int g_fdct_host_vote, g_video_host_reduce;  // fdct.hip: 1 = round-1 host
 void set_orb_retain_order(int v);  // orb.hip: 1 (default) retainBest in libstdc++'s order, 0 canonical (ties kept, raster order)
 void set_hash_fuse(int v);      // dcthash.hip: vertical INTER_AREA pass + tile inside k_blur_area_regs (0 never, 1 auto, 2 always)
 void set_hash_area(int v);      // dcthash.hip: 1 = integer sums for the interior of fractional INTER_AREA cells (NOT bit-identical)
+void set_hash_wide(int v);      // dcthash.hip: images wider than 2048 px on column strips of the register-streaming kernel (default 1)
 void set_hash_regs(int v);      // dcthash.hip: register-streaming general-geometry kernel where applicable (default 1)
 void set_hash_div(int v);       // dcthash.hip: k_dcthash_256 divide-by-49 form, 1 = float magic (default), 0 = integer SDWA
 void set_hash_lds_pad(int v);   // dcthash.hip: occupancy experiment knob

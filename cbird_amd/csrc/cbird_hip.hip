@@ -1319,6 +1319,10 @@ int cbh_set_tuning(const char* key, int value) {
     set_cd_chains(value);
     return CBH_OK;
   }
+  if (!strcmp(key, "hash_wide")) {
+    set_hash_wide(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "hash_area")) {
     set_hash_area(value);
     return CBH_OK;
@@ -1329,6 +1333,10 @@ int cbh_set_tuning(const char* key, int value) {
   }
   if (!strcmp(key, "color_pk")) {
     set_color_pk(value);
+    return CBH_OK;
+  }
+  if (!strcmp(key, "scan256_lut")) {
+    set_scan256_lut(value);
     return CBH_OK;
   }
   if (!strcmp(key, "scan256_small")) {

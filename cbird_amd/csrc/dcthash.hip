@@ -1849,7 +1849,11 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
                                                         int oy = 0, int ph = 0, int ox = 0, int pw = 0,
                                                         /* a view: the w x h rectangle at (ox, oy) of a pw x ph parent
                                                            that starts at imgs; ph = 0: whole images */
-                                                        int fast_area = 0 /* "hash_area" 1: see the x chains below */) {
+                                                        int fast_area = 0 /* "hash_area" 1: see the x chains below */,
+                                                        int cell0 = 0, int ncell = 32
+                                                        /* a column strip of an image wider than 2048: this launch makes
+                                                           the output cells cell0 .. cell0 + ncell - 1 of every row (xtab /
+                                                           xfirst describe those cells, columns relative to the strip) */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_fused[];
   constexpr int R = K / 2;
   constexpr int kStep = StreamK<K>::step;
@@ -1945,9 +1949,11 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
   // area-pass roles: lane = output column cc of row group rg; the T / 32 row groups walk the (image, row) list of the
   // whole workgroup, two entries per turn (they share the weights)
   const int G = T >> 5, rg = tid >> 5, cc = tid & 31;
-  const int ak0 = isx ? 0 : xfirst[cc];
-  const int ank = isx ? isx : xfirst[cc + 1] - ak0;
-  const int acol = isx ? cc * isx : xtab[ak0].si;
+  const bool cell_live = cc < ncell;             // (a strip: the lanes past its cells walk its last cell and store nothing)
+  const int ccl = cell_live ? cc : ncell - 1;
+  const int ak0 = isx ? 0 : xfirst[ccl];
+  const int ank = isx ? isx : xfirst[ccl + 1] - ak0;
+  const int acol = isx ? ccl * isx : xtab[ak0].si;
   const float* __restrict__ al = salpha + ak0;
 
   // weights of the lane's cell by pixel position: (partial first) mid ... mid (partial last), +0 past the cell --
@@ -2053,7 +2059,7 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
         if (ga >= n_imgs) break;  // uniform
         const unsigned char* __restrict__ Si = sblur_all + (size_t)ia * (size_t)kStep * (size_t)bp + acol - ama;
         float* __restrict__ Oi = FUSE ? shrow + (size_t)ia * kStep * 32 + cc
-                                      : rows + ((ptrdiff_t)ga * (ptrdiff_t)h + (ptrdiff_t)ob) * 32 + cc;
+                                      : rows + ((ptrdiff_t)ga * (ptrdiff_t)h + (ptrdiff_t)ob) * 32 + cell0 + cc;
         for (int ra = lo + rg; ra < hi; ra += 2 * G) {
           const int rb_ = ra + G;
           const bool two = rb_ < hi;
@@ -2078,8 +2084,10 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
                 sb = udot4(wb, 0x01010101u, sb);
               }
             }
-            Oi[ra * 32] = __uint_as_float(sa);
-            if (two) Oi[rb_ * 32] = __uint_as_float(sb);
+            if (cell_live) {
+              Oi[ra * 32] = __uint_as_float(sa);
+              if (two) Oi[rb_ * 32] = __uint_as_float(sb);
+            }
           } else {
             float ba = 0.f, bb = 0.f;
             unsigned lo_a = A4[0], lo_b = B4[0], wa, wb;
@@ -2146,8 +2154,10 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
             }
 #undef CBH_AREA_WORD
 #undef CBH_AREA_PIX4
-            Oi[ra * 32] = ba;
-            if (two) Oi[rb_ * 32] = bb;
+            if (cell_live) {
+              Oi[ra * 32] = ba;
+              if (two) Oi[rb_ * 32] = bb;
+            }
           }
         }
       }
@@ -2856,6 +2866,56 @@ int get_area_tabs(int w, int h, AreaTabsDev* out) {
   return CBH_OK;
 }
 
+// Column strips of an image wider than 2048 pixels (k_blur_area_regs spans a row with one workgroup of <= 256 lanes x 8
+// columns): strip s of ncol makes the output cells [s * 32 / ncol, (s + 1) * 32 / ncol); it covers the source columns of
+// exactly those cells (the blur's 3-pixel border comes from the parent through the view mechanism).
+struct StripTabs {
+  AreaTab* x = nullptr;  // fractional ratios: the cells' table entries, si relative to x0
+  int* xfirst = nullptr;
+  int xn = 0, x0 = 0, ws = 0;
+};
+std::map<std::tuple<int, int, int, int>, StripTabs> g_strips;  // (device, w or -w, ncol, s), under g_area_mu
+
+// integer: the image takes resizeAreaFast_ (both ratios integral, area_fast()): cells are whole pixel runs, no tables
+int get_strip_tabs(int w, bool integer, int ncol, int s, StripTabs* out) {
+  int dev = 0;
+  CBH_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_area_mu);
+  auto key = std::make_tuple(dev, integer ? -w : w, ncol, s);
+  auto it = g_strips.find(key);
+  if (it == g_strips.end()) {
+    const int cpw = 32 / ncol, c_lo = s * cpw, c_hi = c_lo + cpw;
+    StripTabs d;
+    if (integer) {
+      d.x0 = c_lo * (w / 32);
+      d.ws = cpw * (w / 32);
+    } else {
+      std::vector<int> xf;
+      const std::vector<AreaTab> xt = make_area_tab(w, 32, &xf);
+      const int e0 = xf[(size_t)c_lo], e1 = xf[(size_t)c_hi];
+      d.x0 = xt[(size_t)e0].si;
+      d.ws = xt[(size_t)e1 - 1].si + 1 - d.x0;
+      std::vector<AreaTab> st(xt.begin() + e0, xt.begin() + e1);
+      for (AreaTab& e : st) e.si -= d.x0, e.di -= c_lo;
+      std::vector<int> sf(33);
+      for (int c = 0; c <= 32; ++c) sf[(size_t)c] = xf[(size_t)std::min(c_lo + c, c_hi)] - e0;
+      d.xn = (int)st.size();
+      hipError_t e = hipMalloc(&d.x, st.size() * sizeof(AreaTab));
+      if (e == hipSuccess) e = hipMalloc(&d.xfirst, 33 * sizeof(int));
+      if (e == hipSuccess) e = hipMemcpy(d.x, st.data(), st.size() * sizeof(AreaTab), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMemcpy(d.xfirst, sf.data(), 33 * sizeof(int), hipMemcpyHostToDevice);
+      if (e != hipSuccess) {
+        if (d.x) (void)hipFree(d.x);
+        if (d.xfirst) (void)hipFree(d.xfirst);
+        CBH_HIP(e);
+      }
+    }
+    it = g_strips.emplace(key, d).first;
+  }
+  *out = it->second;
+  return CBH_OK;
+}
+
 }  // namespace
 
 namespace {
@@ -3025,6 +3085,8 @@ int g_hash_fuse = 1;  // "hash_fuse": 1 = k_blur_area_regs<.., FUSE> (vertical p
 int g_hash_area = 0;  // "hash_area": 1 = k_blur_area_regs sums the interior pixels of a fractional INTER_AREA cell as integers
                       // (results may differ from the exact chain in a tile byte at a rounding boundary; default 0)
 void set_hash_area(int v) { g_hash_area = v ? 1 : 0; }
+int g_hash_wide = 1;  // "hash_wide": images wider than 2048 on column strips of k_blur_area_regs (1, default) or on the LDS band kernel (0)
+void set_hash_wide(int v) { g_hash_wide = v ? 1 : 0; }
 int g_hash_regs = 1;  // k_blur_area_regs (blur input from global memory into registers) where its preconditions hold
 void set_hash_fuse(int v) {
   if (v >= 0 && v <= 2) g_hash_fuse = v;
@@ -3386,16 +3448,22 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     const size_t smem = (size_t)ipb * (size_t)(kBlurRB + K_ - 1) * (size_t)pitch;
     if (view || (g_hash_fused && w >= g_hash_fused)) {
       // k_blur_area + k_tile_hash: the blurred plane stays in LDS
-      const int ncol = w <= 2048 ? 1 : w <= 4096 ? 2 : 4, cpw = 32 / ncol;
-      // widest column window of any workgroup (first source column of its first cell .. last of its last)
+      // column strips: the fewest (1, 2, 4, 8) whose widest window -- first source column of a strip's first cell .. last of
+      // its last -- fits 256 lanes x 8 columns.  (Fractional cells overlap by a pixel: 8191 columns need 8 strips, which the
+      // fixed 1 / 2 / 4 rule of rounds 1-3 answered with CBH_E_UNSUPPORTED.)
+      int ncol = w <= 2048 ? 1 : w <= 4096 ? 2 : 4, cpw = 32 / ncol, win = 0;
       std::vector<int> xf;
-      int win = 0;
-      if (integer) {
-        win = cpw * isx;
-      } else {
-        std::vector<AreaTab> xt = make_area_tab(w, 32, &xf);
-        for (int c = 0; c < 32; c += cpw)
-          win = std::max(win, xt[(size_t)xf[(size_t)(c + cpw)] - 1].si + 1 - xt[(size_t)xf[(size_t)c]].si);
+      const std::vector<AreaTab> xt_full = integer ? std::vector<AreaTab>() : make_area_tab(w, 32, &xf);
+      for (;; ncol *= 2) {
+        cpw = 32 / ncol;
+        win = 0;
+        if (integer) {
+          win = cpw * isx;
+        } else {
+          for (int c = 0; c < 32; c += cpw)
+            win = std::max(win, xt_full[(size_t)xf[(size_t)(c + cpw)] - 1].si + 1 - xt_full[(size_t)xf[(size_t)c]].si);
+        }
+        if ((win + 7) / 8 <= 256 || ncol == 8) break;
       }
       const int Tf = std::min(256, ((win + 7) / 8 + 63) / 64 * 64);
       if ((win + 7) / 8 > 256) return CBH_E_UNSUPPORTED;  // cannot happen for w <= 8192
@@ -3503,6 +3571,48 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
               hipLaunchKernelGGL(k_tile_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_rowsf, h, at.y, at.yfirst,
                                  isx, isy, 1, tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
             continue;
+          }
+          // images wider than 2048 pixels: the register-streaming kernel on ncol column strips, each a view of the
+          // parent that makes its share of the 32 output cells (round 4; the LDS band kernel below took them before:
+          // 1.25 TB/s at 4000 x 3000 with the VALU 48 % busy, profiles/r04_pmc_geo.txt)
+          if (g_hash_regs && g_hash_wide && ncol > 1 && !view && K_ == 7 && (size_t)h * row_stride < ((size_t)1 << 31)) {
+            StripTabs stt[8];
+            bool ok = true;
+            for (int sidx = 0; sidx < ncol && ok; ++sidx) {
+              if ((rc = get_strip_tabs(w, integer, ncol, sidx, &stt[sidx]))) return rc;
+              const StripTabs& S_ = stt[sidx];
+              const int Ls = (S_.ws + 7) / 8;
+              ok = S_.ws >= 64 && Ls <= 256 && (S_.x0 == 0 || S_.x0 >= 4) &&
+                   (S_.x0 + S_.ws == w || S_.x0 + 8 * Ls + 4 <= w);
+            }
+            if (ok) {
+              for (int sidx = 0; sidx < ncol; ++sidx) {
+                const StripTabs& S_ = stt[sidx];
+                const int ws = S_.ws, Ls = (ws + 7) / 8;
+                const bool s_ri = S_.x0 + 8 * Ls + 4 <= w;
+                const bool gen = !((ws % 8 == 0 || s_ri) && ((uintptr_t)(src + S_.x0) % 8) == 0 && row_stride % 8 == 0 &&
+                                   img_stride % 8 == 0);
+                const size_t k_end_s = integer ? 0 : (((size_t)S_.xn + 3) & ~(size_t)3) + 512;
+                const size_t smem_s = (size_t)kstep * (size_t)(8 * Ls) + k_end_s * sizeof(float) + 16;
+                const unsigned Ts = (unsigned)std::max(64, (Ls + 63) / 64 * 64);
+#define CBH_STRIP(GG)                                                                                             \
+  do {                                                                                                            \
+    if (smem_s > 64 * 1024)                                                                                       \
+      CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_area_regs<7, GG, false>),                  \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s));                      \
+    hipLaunchKernelGGL((k_blur_area_regs<7, GG, false>), dim3(1, gs.y, (unsigned)m), dim3(Ts), smem_s, stream, src, \
+                       ws, h, (unsigned)row_stride, img_stride, integer ? at.x : S_.x, integer ? at.xfirst : S_.xfirst, \
+                       isx, steps, d_rowsf, 1, (unsigned)m, (const YRow*)nullptr, 0, (unsigned char*)nullptr, 0, h,  \
+                       S_.x0, w, g_hash_area, sidx * cpw, cpw);                                                   \
+  } while (0)
+                if (gen) CBH_STRIP(true);
+                else CBH_STRIP(false);
+#undef CBH_STRIP
+              }
+              hipLaunchKernelGGL(k_tile_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_rowsf, h, at.y, at.yfirst,
+                                 isx, isy, 1, tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
+              continue;
+            }
           }
 #define CBH_STREAM(KK)                                                                                      \
   do {                                                                                                      \

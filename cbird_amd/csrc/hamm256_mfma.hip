@@ -283,7 +283,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_hamm256_mfma3(  // (2: accumula
 // streams row tiles -- the raw words of the next tile are in flight while the current one runs its NT x 2 MFMAs -- and
 // the grid is sized for the machine, not for the needle chunks.  First-128-bit prefilter only (thresh <= 40) with the
 // three-tiles-per-accumulator fields of k_hamm256_mfma3.  Records identical to k_hamm256_mfma / k_hamm256_scan.
-template <int NT>
+// LUT (round 4): every streamed row tile has to be expanded to FP4 -- 2 words x 4 dwords x 9 shift / mask instructions
+// per lane, 3.1 of the kernel's 4.6 VALU instructions per MFMA (profiles/r04_pmc_mfma_utilisation.md).  A 256-entry table
+// in LDS (byte -> its 8 sign nibbles) turns that into 8 ds_read_b32 + their addresses.
+template <int NT, bool LUT>
 __global__ __launch_bounds__(kThreads, 2) void k_hamm256_small(  // (2: accumulators in VGPRs, see k_hamm64_mfma3)
     const uint32_t* __restrict__ rows /* 8 words per row */, uint32_t n, const uint4* __restrict__ qx,
     const uint32_t* __restrict__ qraw, uint32_t nq, uint32_t thresh, unsigned long long* __restrict__ rec,
@@ -293,8 +296,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_hamm256_small(  // (2: accumula
   constexpr int NA = (NT + 2) / 3;
   constexpr int G = 2;  // accumulators in flight
   __shared__ uint32_t s_c[kWaves][G * 16][64];
+  __shared__ uint32_t s_lut[LUT ? 256 : 1];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t r = lane & 31u, half = lane >> 5;
+  if constexpr (LUT) {
+    for (uint32_t i = threadIdx.x; i < 256u; i += kThreads) s_lut[i] = fp4_expand32(i).x;
+    __syncthreads();
+  }
+  auto expand = [&](uint32_t w) -> uint4 {
+    if constexpr (LUT)
+      return make_uint4(s_lut[w & 0xffu], s_lut[(w >> 8) & 0xffu], s_lut[(w >> 16) & 0xffu], s_lut[w >> 24]);
+    else
+      return fp4_expand32(w);
+  };
   v8i b[NT][2];
 #pragma unroll
   for (int q = 0; q < NT; ++q)
@@ -318,7 +332,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_hamm256_small(  // (2: accumula
 #pragma unroll
   for (int u = 0; u < kAhead; ++u) load_raw(tile + (uint32_t)u * stride, p0[u], p1[u]);
   for (; tile < n_row_tiles; tile += stride) {
-    const v8i a0 = fp4_operand(fp4_expand32(p0[0])), a1 = fp4_operand(fp4_expand32(p1[0]));
+    const v8i a0 = fp4_operand(expand(p0[0])), a1 = fp4_operand(expand(p1[0]));
 #pragma unroll
     for (int u = 0; u + 1 < kAhead; ++u) p0[u] = p0[u + 1], p1[u] = p1[u + 1];
     load_raw(tile + (uint32_t)kAhead * stride, p0[kAhead - 1], p1[kAhead - 1]);  // behind the MFMAs of kAhead tiles
@@ -389,6 +403,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_hamm256_small(  // (2: accumula
 
 int g_scan256_small = 1;   // "scan256_small": the stationary-needle kernel for <= 512 needle descriptors (default on)
 int g_scan256_small_wgs = 0;  // its grid (workgroups); 0 = 2048
+int g_scan256_lut = 1;        // "scan256_lut": its FP4 expansion through the LDS table (1) or with shifts and masks (0)
 int g_scan256_mfma = 1;
 int g_scan256_f3 = 1;      // "scan256_f3": three needle tiles per accumulator in the prefilter (k_hamm256_mfma3); 0 = one
 int g_scan256_pre = 1;     // first-128-bit prefilter variant for thresh <= kPre128MaxThresh
@@ -409,6 +424,7 @@ void set_scan256_ht(int ht) {
   if (ht == 2 || ht == 4 || ht == 6) g_scan256_ht = ht;
   if (ht == 106 || ht == 108 || ht == 112) g_scan256_pre_ht = ht - 100;  // prefilter variant: 106 / 108 / 112
 }
+void set_scan256_lut(int v) { g_scan256_lut = v ? 1 : 0; }
 void set_scan256_small(int v) {
   if (v == 0 || v == 1) g_scan256_small = v;
   if (v >= 16) g_scan256_small_wgs = v;  // workgroups of the persistent grid
@@ -451,12 +467,18 @@ int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, siz
     const uint32_t row_tiles = (uint32_t)((n + 31) / 32);
     uint32_t wgs_s = g_scan256_small_wgs > 0 ? (uint32_t)g_scan256_small_wgs : 2048u;  // measured: 512 / 1024 / 2048 / 8192 = 1.22 / 1.10 / 1.07 / 1.07 ms
     wgs_s = std::min(wgs_s, (row_tiles + kWaves - 1) / kWaves);
-#define CBH_SMALL(NTT)                                                                                               \
-  hipLaunchKernelGGL((k_hamm256_small<NTT>), dim3(wgs_s), dim3(kThreads), 0, stream,                                   \
+#define CBH_SMALL_(NTT, LL)                                                                                          \
+  hipLaunchKernelGGL((k_hamm256_small<NTT, LL>), dim3(wgs_s), dim3(kThreads), 0, stream,                               \
                      reinterpret_cast<const uint32_t*>(d_rows), (uint32_t)n, qx, reinterpret_cast<const uint32_t*>(d_q), \
                      (uint32_t)nq, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total)
+#define CBH_SMALL(NTT)                \
+  do {                                \
+    if (g_scan256_lut) CBH_SMALL_(NTT, true); \
+    else CBH_SMALL_(NTT, false);      \
+  } while (0)
     if (nt == 4) CBH_SMALL(4); else if (nt == 8) CBH_SMALL(8); else CBH_SMALL(16);
 #undef CBH_SMALL
+#undef CBH_SMALL_
     hipError_t es = hipGetLastError();
     (void)cbh::free_async(qx, stream);
     CBH_HIP(es);

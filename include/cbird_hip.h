@@ -706,6 +706,8 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *                   needle descriptors and >= 4096 rows (default), 2 = always
  *   "scan256_small" 1 = searches with <= 512 needle descriptors (one ORB needle image) and thresholds <= 40 use the
  *                   stationary-needle kernel k_hamm256_small (default 1); >= 16 = workgroups of its persistent grid
+ *   "scan256_lut"   1 = k_hamm256_small expands its streamed rows to FP4 through a 256-entry LDS table (default), 0 = with
+ *                   shifts and masks
  *   "scan256_pre"   1 = thresholds <= 40 use the first-128-bit prefilter variant of k_hamm256_mfma (default 1)
  *   "scan_pre_max"  largest threshold served by the low-word-prefilter VALU scan variant (default 7)
  *   "scan_eq_dht1"  1 = dht==1 uses the 64-bit equality variant (default 1)
@@ -721,6 +723,8 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *                   horizontal INTER_AREA pass in one kernel) for widths >= v (default 1 = all)
  *   "hash_stream"   streaming form k_blur_area_stream: 0 = never, 1 = when the batch is large enough and the image at
  *                   least 192 x 128 (default), v >= 2 = always, with v steps per strip
+ *   "hash_wide"     1 = images wider than 2048 pixels run k_blur_area_regs on 2 or 4 column strips (default), 0 = the LDS
+ *                   band kernel k_blur_area_stream takes them (round 3)
  *   "kp_lds_side"   largest keypoint square k_kp_hashes stages in LDS (default 134; larger: global-memory routine)
  *   "kp_blur_side"  largest keypoint square whose blurred copy also stays in LDS (default 112)
  *   "color_pk"      1 = packed-f32 colour distance kernel (default 1)

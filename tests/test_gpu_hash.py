@@ -47,6 +47,40 @@ def test_hash_any_size_general_area_path(gpu, orc, w, h):
         assert (t[i] == orc.tile32(imgs[i])).all()
 
 
+@pytest.mark.parametrize("w,h", [(3840, 2160), (4000, 3000), (3000, 2000), (2049, 64), (2051, 97), (4096, 4096), (5000, 40),
+                                 (8192, 64), (8191, 33), (6001, 100)])
+def test_hash_images_wider_than_one_workgroup(gpu, orc, w, h):
+    """images wider than 2048 pixels: k_blur_area_regs on 2 or 4 column strips (each a view of the parent making its share
+    of the 32 output cells; "hash_wide" 1, the default) == the LDS band kernel that took them before ("hash_wide" 0) ==
+    oracle, hashes and 32 x 32 tiles; integer and fractional ratios, strips that end on and off 8-pixel boundaries"""
+    import torch
+
+    from cbird_amd import _lib
+
+    L = _lib.lib()
+    rng = np.random.default_rng(w + 3 * h)
+    n = 3 if w * h > 4_000_000 else 9  # enough workgroups for the strip kernels to be chosen for the small ones too
+    imgs = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    imgs[0] = (128 + 100 * np.sin(xx / 97.0) * np.cos(yy / 41.0)).astype(np.uint8)
+    imgs[1, :, : w // 2] = 255  # an edge on the strip boundary of two strips
+    want = orc.dcthash64_batch(imgs)
+    tile0 = orc.tile32(imgs[0])
+    d = torch.from_numpy(imgs).cuda()
+    try:
+        for knob in (1, 0):
+            L.cbh_set_tuning(b"hash_wide", knob)
+            L.cbh_set_tuning(b"hash_stream", 4)  # strips of four steps whatever the batch size
+            assert (gpu.dct_hash64_batch(imgs) == want).all(), (w, h, knob)
+            out = torch.zeros(n, dtype=torch.int64, device="cuda")
+            tiles = torch.zeros((n, 32, 32), dtype=torch.uint8, device="cuda")
+            _lib.check(L.cbh_dcthash_tiles_dev(d.data_ptr(), n, w, h, w, w * h, out.data_ptr(), tiles.data_ptr(), 0, None), "t")
+            assert (tiles[0].cpu().numpy() == tile0).all(), (w, h, knob)
+    finally:
+        L.cbh_set_tuning(b"hash_wide", 1)
+        L.cbh_set_tuning(b"hash_stream", 1)
+
+
 def test_hash_edge_images(gpu, orc, hash256_kernel):
     imgs = np.zeros((6, 256, 256), np.uint8)
     imgs[1] = 255
