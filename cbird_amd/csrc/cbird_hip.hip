@@ -1319,6 +1319,10 @@ int cbh_set_tuning(const char* key, int value) {
     set_cd_chains(value);
     return CBH_OK;
   }
+  if (!strcmp(key, "hash_band_waves")) {
+    set_hash_band_waves(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "hash_wide")) {
     set_hash_wide(value);
     return CBH_OK;

@@ -855,35 +855,44 @@ struct BandTables {
   unsigned int w[3][64][4];  // B operands (i8 x 16 per lane): 0 interior column tile, 1 tile 0 (left edge), 2 tile 15
 };
 
-constexpr int kBandPitch = 272;                   // 8 + 256 + 8
-constexpr int kBandRing = 12;                     // rows of one image in LDS: three steps
-constexpr int kBandImg = kBandRing * kBandPitch;  // 3264 B
+constexpr int kBandPitch = 272;  // 8 + 256 + 8
 
-template <bool DUMP, int DCT>
-__global__ __launch_bounds__(64) void k_dcthash_256_band(
+// NW = waves per workgroup.  1 (default): a wave owns its four images alone (no barrier anywhere in the loop; 17 KB of LDS
+// per wave, 9 waves per CU).  2 (knob "hash_band_waves", measured 5 % slower): two waves share the four images -- each takes 8 of the 16 column tiles, half of the row
+// staging and two of the four images' DCT stages -- so the row ring and the tiles are held once per TWO waves (21 KB per
+// workgroup, 14 waves per CU, half the S / accumulator registers per wave) at the price of one workgroup barrier per step;
+// the ring then has four step slots instead of three so that the rows staged for step t + 1 never overwrite rows a slower
+// wave still reads in step t.
+template <bool DUMP, int DCT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_dcthash_256_band(
     const unsigned char* __restrict__ imgs, unsigned n, unsigned row_stride, unsigned img_stride,
     const DctTables* __restrict__ tabs, const BandTables* __restrict__ bt, uint64_t* __restrict__ out,
     unsigned char* __restrict__ tiles) {
-  __shared__ __attribute__((aligned(16))) unsigned char sRing[4 * kBandImg];  // 13 056 B; the tail reuses it
+  constexpr int kSlots = NW == 1 ? 3 : 4;        // steps of rows one image keeps in LDS
+  constexpr int kRing = 4 * kSlots;              // ... = rows
+  constexpr int kImg = kRing * kBandPitch;       // bytes per image
+  constexpr int TPW = 16 / NW;                   // column tiles per wave
+  constexpr int RPW = 4 / NW;                    // rows of a step staged by one wave
+  __shared__ __attribute__((aligned(16))) unsigned char sRing[4 * kImg];  // 13 056 / 17 408 B; the tail reuses it
   __shared__ __attribute__((aligned(16))) unsigned char sTile[4][1024];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int n16 = lane & 15, q = lane >> 4;
   const unsigned first = blockIdx.x * 4u;
-  // staging role: image q, 16-byte chunk n16 of a row
+  // staging role: image q, 16-byte chunk n16 of a row; wave wv stages rows wv * RPW .. of every step
   unsigned mine = first + (unsigned)q;
   if (mine >= n) mine = n - 1;
-  const unsigned char* __restrict__ base = imgs + (size_t)first * img_stride;  // wave-uniform
+  const unsigned char* __restrict__ base = imgs + (size_t)first * img_stride;  // workgroup-uniform
   const unsigned voff = (mine - first) * img_stride + (unsigned)n16 * 16u;
-  const int wr_base = q * kBandImg + 8 + 16 * n16;
+  const int wr_base = q * kImg + 8 + 16 * n16;
   // A-operand role: M row n16 = image n16 >> 2, row n16 & 3 of the step; chunk q: 0, 1 the row, 2, 3 the row 7 above
-  const int rd_base = (n16 >> 2) * kBandImg + (q & 1) * 16;
-  const int rd_row = (n16 & 3) + (q >= 2 ? 5 : 0);
-  // accumulator role: image q, column n16 of every column tile, rows in the four result registers
+  const int rd_base = (n16 >> 2) * kImg + (q & 1) * 16 + 16 * TPW * wv;
+  const int rd_row = (n16 & 3) + (q >= 2 ? kRing - 7 : 0);
+  // accumulator role: image q, column n16 of each of this wave's column tiles, rows in the four result registers
   const v4i_t b0 = *reinterpret_cast<const v4i_t*>(bt->w[0][lane]);
-  const v4i_t bL = *reinterpret_cast<const v4i_t*>(bt->w[1][lane]);
-  const v4i_t bR = *reinterpret_cast<const v4i_t*>(bt->w[2][lane]);
+  const v4i_t bL = *reinterpret_cast<const v4i_t*>(bt->w[wv == 0 ? 1 : 0][lane]);       // this wave's first tile
+  const v4i_t bR = *reinterpret_cast<const v4i_t*>(bt->w[wv == NW - 1 ? 2 : 0][lane]);  // ... and its last
 
-  for (int i = lane; i < 4 * kBandImg / 16; i += 64)
+  for (int i = threadIdx.x; i < 4 * kImg / 16; i += 64 * NW)
     reinterpret_cast<v4u_lds*>(sRing)[i] = v4u_lds{0u, 0u, 0u, 0u};  // rows above the image: p - 128 = 0 contributes nothing
 
   // virtual row w = 0..263 is image row reflect101(w - 5); output row y = w - 8 is complete with row w
@@ -893,24 +902,24 @@ __global__ __launch_bounds__(64) void k_dcthash_256_band(
     v = v > 255 ? 510 - v : v;
     return (unsigned)v * row_stride + voff;
   };
-  uint4 stg[2][4];
-  auto load_step = [&](int t, uint4 (&dst)[4]) {
+  uint4 stg[2][RPW];
+  auto load_step = [&](int t, uint4 (&dst)[RPW]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dst[r] = *reinterpret_cast<const uint4*>(base + src_off(4 * t + r));
+    for (int r = 0; r < RPW; ++r) dst[r] = *reinterpret_cast<const uint4*>(base + src_off(4 * t + RPW * wv + r));
   };
-  auto store_step = [&](int t3, const uint4 (&src)[4]) {  // t3 = t % 3: the step's rows take slots 4 * t3 .. + 3
+  auto store_step = [&](int ts, const uint4 (&src)[RPW]) {  // ts = t % kSlots: the step's rows take slots 4 * ts .. + 3
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      v2u_lds* p = reinterpret_cast<v2u_lds*>(sRing + wr_base + (4 * t3 + r) * kBandPitch);  // 8-byte aligned
+    for (int r = 0; r < RPW; ++r) {
+      v2u_lds* p = reinterpret_cast<v2u_lds*>(sRing + wr_base + (4 * ts + RPW * wv + r) * kBandPitch);  // 8-byte aligned
       p[0] = v2u_lds{src[r].x ^ 0x80808080u, src[r].y ^ 0x80808080u};
       p[1] = v2u_lds{src[r].z ^ 0x80808080u, src[r].w ^ 0x80808080u};
     }
   };
 
-  unsigned S[16];
-  v2f_t f[16];
+  unsigned S[TPW];
+  v2f_t f[TPW];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) {
+  for (int c = 0; c < TPW; ++c) {
     S[c] = 0x4B000000u + 6272u;
     f[c] = v2f_t{8388608.0f, 8388608.0f};
   }
@@ -918,59 +927,44 @@ __global__ __launch_bounds__(64) void k_dcthash_256_band(
   asm volatile("" : "+v"(kC));  // VGPR operands (a literal would double the size of every fma)
   const v2f_t kInit = {8388608.0f, 8388608.0f};
   const v4i_t zero4 = {0, 0, 0, 0};
-  const int st_lane = q * 1024 + (n16 >> 3) + 2 * (n16 & 1);  // tile byte of this lane within a cell row
+  const int st_lane = q * 1024 + (n16 >> 3) + 2 * (n16 & 1) + 2 * TPW * wv;  // tile byte of this lane within a cell row
   const unsigned sel_shift = (unsigned)(n16 & 1) * 16u;
 
   // one step: rows 4t .. 4t+3 (already in the ring); FIRST = the step opens a cell row, else it closes it
-  auto step = [&](auto first_tag, int t, int t3) {
+  auto step = [&](auto first_tag, int t, int ts) {
     constexpr bool FIRST = decltype(first_tag)::value;
-    int slot = 4 * t3 + rd_row;
-    slot = slot >= kBandRing ? slot - kBandRing : slot;
+    int slot = 4 * ts + rd_row;
+    slot = slot >= kRing ? slot - kRing : slot;
     const unsigned char* arow = sRing + rd_base + slot * kBandPitch;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
+    for (int c = 0; c < TPW; ++c) {
       const v4i_t a = *reinterpret_cast<const v4i_lds*>(arow + 16 * c);
-      const v4i_t d = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, c == 0 ? bL : c == 15 ? bR : b0, zero4, 0, 0, 0);
+      const v4i_t d = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, c == 0 ? bL : c == TPW - 1 ? bR : b0, zero4, 0, 0, 0);
       const unsigned x0 = S[c] + (unsigned)d[0], x1 = x0 + (unsigned)d[1], x2 = x1 + (unsigned)d[2],
                      x3 = x2 + (unsigned)d[3];
       S[c] = x3;
-#ifdef CBH_BAND_DEBUG
-      if (DUMP && c == 5 && n16 == 3 && first + (unsigned)q < n) {  // S of column 83, every virtual row
-        unsigned short* dbg = reinterpret_cast<unsigned short*>(tiles + (size_t)(first + (unsigned)q) * 1024);
-        dbg[4 * t + 0] = (unsigned short)x0, dbg[4 * t + 1] = (unsigned short)x1;
-        dbg[4 * t + 2] = (unsigned short)x2, dbg[4 * t + 3] = (unsigned short)x3;
-      }
-#endif
       const v2f_t p01 = {__builtin_bit_cast(float, x0), __builtin_bit_cast(float, x1)};
       const v2f_t p23 = {__builtin_bit_cast(float, x2), __builtin_bit_cast(float, x3)};
       f[c] = __builtin_elementwise_fma(p01, kC, FIRST ? kInit : f[c]);
       f[c] = __builtin_elementwise_fma(p23, kC, f[c]);
-#ifdef CBH_BAND_DEBUG
-      if (DUMP && c == 5 && n16 == 3 && q == 1 && first == 0) {  // accumulators of image 1 after every step
-        unsigned* dbg = reinterpret_cast<unsigned*>(tiles + (size_t)2 * 1024);
-        const float dx = f[c].x, dy = f[c].y;
-        dbg[2 * t + 0] = __float_as_uint(dx) - 0x4B000000u;
-        dbg[2 * t + 1] = __float_as_uint(dy) - 0x4B000000u;
-      }
-#endif
     }
     if constexpr (!FIRST) {
       const int a_row = (t - 3) >> 1;  // cell row closed by this step (negative during the warm-up)
       if (a_row >= 0) {
         unsigned char* dst = &sTile[0][0] + st_lane + a_row * 32;
 #pragma unroll
-        for (int c = 0; c < 16; c += 2) {
+        for (int c = 0; c < TPW; c += 2) {
           // every accumulator component: 2^23 + 4 x 171196 + its four quotients
           constexpr unsigned kBias2 = 2u * (0x4B000000u + 4u * 171196u);
           // (by value: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whichever one is named)
           const float fx0 = f[c].x, fy0 = f[c].y, fx1 = f[c + 1].x, fy1 = f[c + 1].y;
           const unsigned v0 = __float_as_uint(fx0) + __float_as_uint(fy0) - kBias2;
           const unsigned v1 = __float_as_uint(fx1) + __float_as_uint(fy1) - kBias2;
-          unsigned wv = v0 | (v1 << 16);  // <= 2040 each; <= 16320 after the 8 lanes
-          wv += (unsigned)__builtin_amdgcn_mov_dpp((int)wv, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-          wv += (unsigned)__builtin_amdgcn_mov_dpp((int)wv, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
-          wv += (unsigned)__builtin_amdgcn_mov_dpp((int)wv, 0x141, 0xf, 0xf, true);  // row_half_mirror
-          const unsigned cell = (wv >> sel_shift) & 0xffffu;  // even lanes: tile c, odd lanes: tile c + 1
+          unsigned wv2 = v0 | (v1 << 16);  // <= 2040 each; <= 16320 after the 8 lanes
+          wv2 += (unsigned)__builtin_amdgcn_mov_dpp((int)wv2, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+          wv2 += (unsigned)__builtin_amdgcn_mov_dpp((int)wv2, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+          wv2 += (unsigned)__builtin_amdgcn_mov_dpp((int)wv2, 0x141, 0xf, 0xf, true);  // row_half_mirror
+          const unsigned cell = (wv2 >> sel_shift) & 0xffffu;  // even lanes: tile c, odd lanes: tile c + 1
           dst[2 * c] = (unsigned char)((cell + 31u + ((cell >> 6) & 1u)) >> 6);  // /64, half to even
         }
       }
@@ -983,38 +977,44 @@ __global__ __launch_bounds__(64) void k_dcthash_256_band(
   __syncthreads();  // (the zero fill)
   store_step(0, stg[0]);
   load_step(2, stg[0]);
-  int t3 = 0;  // t % 3 of the even step
+  if constexpr (NW > 1) __syncthreads();
+  int ts = 0;  // t % kSlots of the even step
+  auto nxt = [](int v) { return v == kSlots - 1 ? 0 : v + 1; };
   for (int t = 0; t < 66; t += 2) {
-    const int t3a = t3, t3b = t3 == 2 ? 0 : t3 + 1, t3c = t3b == 2 ? 0 : t3b + 1;
-    step(integral_constant<bool, true>{}, t, t3a);
-    store_step(t3b, stg[1]);  // rows of step t + 1 (its slots held step t - 2, whose last readers were step t's)
+    const int tsa = ts, tsb = nxt(tsa), tsc = nxt(tsb);
+    step(integral_constant<bool, true>{}, t, tsa);
+    store_step(tsb, stg[1]);  // rows of step t + 1: their slots' last readers ran a full step ago (NW 2) / just now (NW 1)
     if (t + 3 < 66) load_step(t + 3, stg[1]);
-    step(integral_constant<bool, false>{}, t + 1, t3b);
+    if constexpr (NW > 1) __syncthreads();
+    step(integral_constant<bool, false>{}, t + 1, tsb);
     if (t + 2 < 66) {
-      store_step(t3c, stg[0]);
+      store_step(tsc, stg[0]);
       if (t + 4 < 66) load_step(t + 4, stg[0]);
     }
-    t3 = t3c;
+    if constexpr (NW > 1) __syncthreads();
+    ts = tsc;
   }
   __syncthreads();
 #ifndef CBH_BAND_DEBUG
   if (DUMP) {
     for (int g = 0; g < 4; ++g)
       if (first + (unsigned)g < n)
-        for (int i = lane; i < 256; i += 64)
+        for (int i = threadIdx.x; i < 256; i += 64 * NW)
           reinterpret_cast<unsigned*>(tiles + (size_t)(first + (unsigned)g) * 1024)[i] =
               reinterpret_cast<const unsigned*>(sTile[g])[i];
   }
 #endif
-  // ---- stages 3-6 as in k_dcthash_256: a half-wave per image, two images at a time; sT / sY live in the ring
-  f32_lds* sT = reinterpret_cast<f32_lds*>(sRing);                    // [2][288]
-  f32_lds* sY = reinterpret_cast<f32_lds*>(sRing) + 2 * 288;           // [2][84]
-  f32_lds* sC = reinterpret_cast<f32_lds*>(sRing) + 2 * 288 + 2 * 84;  // [9 * 33]
+  // ---- stages 3-6 as in k_dcthash_256: a half-wave per image (NW 1: two images at a time, two passes); sT / sY live in
+  // the ring
+  f32_lds* sT = reinterpret_cast<f32_lds*>(sRing);                    // [2 NW][288]
+  f32_lds* sY = reinterpret_cast<f32_lds*>(sRing) + 2 * NW * 288;      // [2 NW][84]
+  f32_lds* sC = sY + 2 * NW * 84;                                      // [9 * 33]
   const int l32 = lane & 31, hw = lane >> 5;
+  const int hx = 2 * wv + hw;  // this half-wave's slot in sT / sY
   if constexpr (DCT == 0)
-    for (int i = lane; i < 288; i += 64) sC[(i >> 5) * 33 + (i & 31)] = tabs->C[i];
-  for (int pass = 0; pass < 2; ++pass) {
-    const int slot = 2 * pass + hw;
+    for (int i = threadIdx.x; i < 288; i += 64 * NW) sC[(i >> 5) * 33 + (i & 31)] = tabs->C[i];
+  for (int pass = 0; pass < 2 / NW; ++pass) {
+    const int slot = NW == 1 ? 2 * pass + hw : hx;
     const unsigned img = first + (unsigned)slot;
     const bool valid = img < n;
     __syncthreads();
@@ -1034,14 +1034,14 @@ __global__ __launch_bounds__(64) void k_dcthash_256_band(
         float y[9];
         cvdct::dct32_first9(x, &tabs->cv, y);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) sT[hw * 288 + l32 * 9 + k] = y[k];
+        for (int k = 0; k < 9; ++k) sT[hx * 288 + l32 * 9 + k] = y[k];
       } else {
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
           float t = 0.f;
 #pragma unroll
           for (int j = 0; j < 32; ++j) t = __builtin_fmaf(x[j], tabs->C[k * 32 + j], t);
-          sT[hw * 288 + l32 * 9 + k] = t;
+          sT[hx * 288 + l32 * 9 + k] = t;
         }
       }
     }
@@ -1050,10 +1050,10 @@ __global__ __launch_bounds__(64) void k_dcthash_256_band(
       if (l32 < 9) {
         float x[32], y[9];
 #pragma unroll
-        for (int r = 0; r < 32; ++r) x[r] = sT[hw * 288 + r * 9 + l32];
+        for (int r = 0; r < 32; ++r) x[r] = sT[hx * 288 + r * 9 + l32];
         cvdct::dct32_first9(x, &tabs->cv, y);
 #pragma unroll
-        for (int u = 0; u < 9; ++u) sY[hw * 84 + u * 9 + l32] = y[u];
+        for (int u = 0; u < 9; ++u) sY[hx * 84 + u * 9 + l32] = y[u];
       }
     } else {
 #pragma unroll
@@ -1063,15 +1063,15 @@ __global__ __launch_bounds__(64) void k_dcthash_256_band(
           const int u = o / 9, k = o - u * 9;
           float t = 0.f;
 #pragma unroll
-          for (int r = 0; r < 32; ++r) t = __builtin_fmaf(sC[u * 33 + r], sT[hw * 288 + r * 9 + k], t);
-          sY[hw * 84 + o] = t;
+          for (int r = 0; r < 32; ++r) t = __builtin_fmaf(sC[u * 33 + r], sT[hx * 288 + r * 9 + k], t);
+          sY[hx * 84 + o] = t;
         }
       }
     }
     __syncthreads();
     {
-      const float c0 = sY[hw * 84 + tabs->zz[l32]];
-      const float c1 = sY[hw * 84 + tabs->zz[l32 + 32]];
+      const float c0 = sY[hx * 84 + tabs->zz[l32]];
+      const float c1 = sY[hx * 84 + tabs->zz[l32 + 32]];
       const int cb0 = __builtin_bit_cast(int, c0), cb1 = __builtin_bit_cast(int, c1);
       double sumA, sumB;
       if constexpr (DCT == 1) {
@@ -3049,6 +3049,14 @@ int get_mfma_tables(const MfmaTables** out) {
 // both box passes in f16 on the matrix cores; slower than either).  Staging the rows four steps ahead instead of two
 // (250 VGPRs) changed nothing: 4.83 vs 4.77 ms per 400k images.
 int g_hash_mfma = 2;
+// "hash_band_waves": waves per workgroup of k_dcthash_256_band.  1 (default) a wave owns its four images; 2 = two waves
+// share them (14 instead of 9 waves per CU).  Measured, same box, alternating (tools/ab/hash_band_ab.py, 400k images):
+// 4.80-4.88 ms with 1, 5.06-5.11 with 2 (compute-only 3.38 / 4.01): the barrier per step and the per-wave fixed work
+// (addresses, staging, the warm-up steps) cost more than the extra occupancy returns -- the kernel is not latency-bound.
+int g_hash_band_waves = 1;
+void set_hash_band_waves(int v) {
+  if (v == 1 || v == 2) g_hash_band_waves = v;
+}
 int g_hash_mfma_set(int v) { return g_hash_mfma = v; }
 // tuning knob "hash_dct": stages 3 and 5 of dctHash64 -- 1 (default) = cv::dct / cv::sum as OpenCV 2.4.13.7 evaluates
 // them (cv_dct32_dev.h), 0 = the canonical 9x32 matrix form (NOTES.md section 3).  oracle: orc_set_hash_variant.
@@ -3735,16 +3743,22 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     if (g_hash_mfma == 2 && ((uintptr_t)d_imgs % 16) == 0 && row_stride % 16 == 0 && img_stride % 16 == 0) {
       const BandTables* btab = nullptr;
       if ((rc = get_band_tables(&btab))) return rc;
-      dim3 gridb((unsigned)((n + 3) / 4)), blockb(64);
-#define CBH_BAND(DUMP_, DCT_)                                                                                      \
-  hipLaunchKernelGGL((k_dcthash_256_band<DUMP_, DCT_>), gridb, blockb, 0, stream, d_imgs, (unsigned)n,             \
+      dim3 gridb((unsigned)((n + 3) / 4));
+#define CBH_BAND_(DUMP_, DCT_, NW_)                                                                                \
+  hipLaunchKernelGGL((k_dcthash_256_band<DUMP_, DCT_, NW_>), gridb, dim3(64 * NW_), 0, stream, d_imgs, (unsigned)n, \
                      (unsigned)row_stride, (unsigned)img_stride, tabs, btab, d_out, d_tiles)
+#define CBH_BAND(DUMP_, DCT_)                       \
+  do {                                              \
+    if (g_hash_band_waves == 1) CBH_BAND_(DUMP_, DCT_, 1); \
+    else CBH_BAND_(DUMP_, DCT_, 2);                 \
+  } while (0)
       if (g_hash_dct) {
         if (d_tiles) CBH_BAND(true, 1); else CBH_BAND(false, 1);
       } else {
         if (d_tiles) CBH_BAND(true, 0); else CBH_BAND(false, 0);
       }
 #undef CBH_BAND
+#undef CBH_BAND_
       CBH_HIP(hipGetLastError());
       return CBH_OK;
     }

@@ -715,6 +715,9 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *   "hash_mfma"     kernel for 256x256 tiles: 2 = k_dcthash_256_band (default: horizontal box sums as i8 MFMAs, one add +
  *                   half an fma per pixel on the VALU; rows must be 16-byte aligned, otherwise 0 is taken), 0 =
  *                   k_dcthash_256 (all VALU), 1 = k_dcthash_256_mfma (both box passes in f16 MFMAs; slowest)
+ *   "hash_band_waves" waves per workgroup of k_dcthash_256_band: 1 (default: a wave owns its four images alone, no
+ *                   barriers, 9 waves per CU) or 2 (two waves share four images' rows and tiles in LDS, 14 waves per CU;
+ *                   measured 5 % slower)
  *   "hash_div"      k_dcthash_256's divide by 49: 0 integer multiply-shift (default), 1 float magic number, 2 / 3 one fma
  *                   per pixel on the float form 0x4B000000 + S (packed / unpacked column sums); all exact
  *   "hash_fast_any" 0 = the first general-geometry kernels (k_blur_u8 + k_area_hash / k_dcthash_generic), 1 = the

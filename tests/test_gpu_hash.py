@@ -184,6 +184,12 @@ def test_band_kernel_every_quotient_borders_and_ragged_batches(gpu, orc):
     for n in (1, 2, 3, 4, 5, 7, 23):
         got = gpu.dct_hash64_batch(imgs[:n])
         assert (got == orc.dcthash64_batch(imgs[:n])).all(), n
+    L.cbh_set_tuning(b"hash_band_waves", 2)  # two waves per workgroup sharing the four images (knob; slower, same bits)
+    try:
+        for n in (3, 23):
+            assert (gpu.dct_hash64_batch(imgs[:n]) == orc.dcthash64_batch(imgs[:n])).all(), n
+    finally:
+        L.cbh_set_tuning(b"hash_band_waves", 1)
     d = torch.from_numpy(imgs).cuda()
     out = torch.zeros(len(imgs), dtype=torch.int64, device="cuda")
     tiles = torch.zeros((len(imgs), 32, 32), dtype=torch.uint8, device="cuda")

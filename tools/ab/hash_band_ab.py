@@ -20,8 +20,9 @@ imgs[4400:4500, :, :3] = 255; imgs[4400:4500, :, -3:] = 1  # the reflected borde
 ms = C.c_float(0)
 res, ref = {}, None
 tiles_ref = None
-for name, knob in (("valu", 0), ("band", 2), ("valu", 0), ("band", 2)):
+for name, knob, nw in (("valu", 0, 2), ("band1", 2, 1), ("band2", 2, 2), ("valu", 0, 2), ("band1", 2, 1), ("band2", 2, 2)):
     L.cbh_set_tuning(b"hash_mfma", knob)
+    L.cbh_set_tuning(b"hash_band_waves", nw)
     out = torch.empty(n, dtype=torch.int64, device=dev)
     for stride, tag in ((65536, "hbm"), (0, "aliased")):
         for _ in range(2):
@@ -40,5 +41,6 @@ for name, knob in (("valu", 0), ("band", 2), ("valu", 0), ("band", 2)):
     if tiles_ref is None:
         tiles_ref = t.clone()
     res[f"{name}_tile_bytes_differing"] = int((t != tiles_ref).sum().item())
-L.cbh_set_tuning(b"hash_mfma", 0)
+L.cbh_set_tuning(b"hash_mfma", 2)
+L.cbh_set_tuning(b"hash_band_waves", 1)
 print(json.dumps({"images": n, **res}))
