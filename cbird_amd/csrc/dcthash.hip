@@ -1949,8 +1949,10 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
   // area-pass roles: lane = output column cc of row group rg; the T / 32 row groups walk the (image, row) list of the
   // whole workgroup, two entries per turn (they share the weights)
   const int G = T >> 5, rg = tid >> 5, cc = tid & 31;
-  const bool cell_live = cc < ncell;             // (a strip: the lanes past its cells walk its last cell and store nothing)
-  const int ccl = cell_live ? cc : ncell - 1;
+  // a strip owns ncell = 16 / 8 / 4 of the 32 cells: the 32 lanes of a row group then take 2 / 4 / 8 rows of those cells at
+  // once instead of idling (lane cc -> cell cc mod ncell, row sub-group cc / ncell); ncell = 32: one row, as ever
+  const int ccl = cc & (ncell - 1);
+  const int Gm = 32 / ncell, Ge = G * Gm, rge = rg * Gm + cc / ncell;
   const int ak0 = isx ? 0 : xfirst[ccl];
   const int ank = isx ? isx : xfirst[ccl + 1] - ak0;
   const int acol = isx ? ccl * isx : xtab[ak0].si;
@@ -2059,9 +2061,9 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
         if (ga >= n_imgs) break;  // uniform
         const unsigned char* __restrict__ Si = sblur_all + (size_t)ia * (size_t)kStep * (size_t)bp + acol - ama;
         float* __restrict__ Oi = FUSE ? shrow + (size_t)ia * kStep * 32 + cc
-                                      : rows + ((ptrdiff_t)ga * (ptrdiff_t)h + (ptrdiff_t)ob) * 32 + cell0 + cc;
-        for (int ra = lo + rg; ra < hi; ra += 2 * G) {
-          const int rb_ = ra + G;
+                                      : rows + ((ptrdiff_t)ga * (ptrdiff_t)h + (ptrdiff_t)ob) * 32 + cell0 + ccl;
+        for (int ra = lo + rge; ra < hi; ra += 2 * Ge) {
+          const int rb_ = ra + Ge;
           const bool two = rb_ < hi;
           const unsigned* __restrict__ A4 = reinterpret_cast<const unsigned*>(Si + (size_t)ra * (size_t)bp);
           const unsigned* __restrict__ B4 = reinterpret_cast<const unsigned*>(Si + (size_t)(two ? rb_ : ra) * (size_t)bp);
@@ -2084,10 +2086,8 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
                 sb = udot4(wb, 0x01010101u, sb);
               }
             }
-            if (cell_live) {
-              Oi[ra * 32] = __uint_as_float(sa);
-              if (two) Oi[rb_ * 32] = __uint_as_float(sb);
-            }
+            Oi[ra * 32] = __uint_as_float(sa);
+            if (two) Oi[rb_ * 32] = __uint_as_float(sb);
           } else {
             float ba = 0.f, bb = 0.f;
             unsigned lo_a = A4[0], lo_b = B4[0], wa, wb;
@@ -2154,10 +2154,8 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
             }
 #undef CBH_AREA_WORD
 #undef CBH_AREA_PIX4
-            if (cell_live) {
-              Oi[ra * 32] = ba;
-              if (two) Oi[rb_ * 32] = bb;
-            }
+            Oi[ra * 32] = ba;
+            if (two) Oi[rb_ * 32] = bb;
           }
         }
       }

@@ -35,6 +35,8 @@ def main():
             w, h = 32 * int(rng.integers(1, 34)), 32 * int(rng.integers(1, 30))  # integer ratios
         elif kind == 1:
             w, h = 8 * int(rng.integers(4, 138)), int(rng.integers(32, 900))
+        elif kind == 2 and c % 5 == 0:
+            w, h = int(rng.integers(2049, 6000)), int(rng.integers(32, 400))  # wider than one workgroup: column strips
         else:
             w, h = int(rng.integers(32, 1100)), int(rng.integers(32, 900))
         n = int(np.clip(args.pixels // (w * h), 64, 6000))
