@@ -344,6 +344,9 @@ int sharded_scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t 
   for (size_t s = 0; s < R; ++s) todo[s] = S->child[s]->n != 0;
   float scan_ms = 0.f;
   unsigned long long running = 0;
+  // kernel timing for cbh_idx64_get_stats only where it can matter: a handful of needles is launch-bound, and every
+  // HIP call counts there (a lone find() on 8 shards: ~12 calls per shard from this one thread)
+  const bool timed = nq >= 256;
   for (int attempt = 0; attempt < 3; ++attempt) {
     bool any = false;
     for (size_t s = 0; s < R; ++s) {
@@ -370,11 +373,11 @@ int sharded_scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t 
         if ((rc = cw->ensure_records(std::max<size_t>(c->rec_cap_default, 1024)))) return rc;
       }
       CBH_HIP(hipMemsetAsync(cw->d_total, 0, sizeof(unsigned long long), cs));
-      CBH_HIP(hipEventRecord(cw->ev0, cs));
+      if (timed) CBH_HIP(hipEventRecord(cw->ev0, cs));
       rc = launch_hamm64_scan(c->d_hashes, c->d_ids, c->n, q_of[s], nq, thresh, cw->d_rec, cw->rec_cap, cw->d_total, cs,
                               flags, mask_of[s]);
       if (rc) return rc;
-      CBH_HIP(hipEventRecord(cw->ev1, cs));
+      if (timed) CBH_HIP(hipEventRecord(cw->ev1, cs));
       CBH_HIP(hipMemcpyAsync(cw->h_total, cw->d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
       C.n_scans++;
       if (attempt) C.n_rescans++;
@@ -390,7 +393,7 @@ int sharded_scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t 
       CBH_HIP(hipStreamSynchronize(cw->stream));
       count[s] = *cw->h_total;
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, cw->ev0, cw->ev1) == hipSuccess) worst = std::max(worst, ms);
+      if (timed && hipEventElapsedTime(&ms, cw->ev0, cw->ev1) == hipSuccess) worst = std::max(worst, ms);
       todo[s] = 0;
       running += count[s];
       if (running > max_records && running > ws->rec_cap) {  // the merged result cannot fit: nobody grows for it
