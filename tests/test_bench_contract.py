@@ -34,6 +34,13 @@ def test_bench_line_has_the_contract_keys(gpu):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1
     assert c["find_agrees_with_gpu"] is True and c["hash_agrees_with_gpu"] is True
+    # north_star's acceptance line as fields: every needle's full (mediaId, distance) list equal to the real VP-tree's
+    # at dht 2, every hash equal to the CPU port's -- digests of both sides in the line
+    fi, hi = d["full_identity"], d["hash_identity"]
+    assert fi["dht"] == 2 and fi["needles"] == 40000 and fi["equal"] is True and fi["sha256_gpu"] == fi["sha256_reference"]
+    assert fi["pairs"] == [s_ for s_ in d["dht_sweep"] if s_["dht"] == 2][0]["matches"]
+    assert hi["images"] == 40000 and hi["equal"] is True and hi["sha256_gpu"] == hi["sha256_port"]
+    assert d["matches_expected"] is None  # (the table holds the default job and first_contact's 80 k job)
     o = d["configs3_cvfeatures"]
     assert o["needles_ranked_first_themselves"] == 64 and o["rows_this_rank"] == 4000 * 500
 
@@ -58,6 +65,7 @@ def test_bench_two_ranks_sharing_the_gpu(gpu):
     r1 = json.loads(one.stdout.strip().splitlines()[-1])
     r2 = json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert r2["n_gpus"] == 2 and r2["scaling"] == "strong"
+    assert r2["collective"]["communicator_ranks"] == 2 and r2["collective"]["world_size"] == 2
     assert [s["matches"] for s in r2["dht_sweep"]] == [s["matches"] for s in r1["dht_sweep"]]
     # the sharded ORB and video legs give the unsharded results
     assert r2["configs3_cvfeatures"]["matches"] == r1["configs3_cvfeatures"]["matches"] > 0
