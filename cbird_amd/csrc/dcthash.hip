@@ -538,286 +538,8 @@ __global__ __launch_bounds__(kThreads) void k_dcthash_256(
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_dcthash_256_mfma: same result as k_dcthash_256, with the 7x7 box filter done on the matrix cores.
-//
-// PMC shows k_dcthash_256 pinned at its VALU issue limit (5.9 integer ops per pixel).  A box filter is the
-// product S = A * P * A^T with a banded 0/1(/2 at the mirrored borders) matrix A, and every number involved is a
-// small integer, so f16 operands with f32 accumulation are EXACT:
-//   pass 1  H = P * A^T      P as f16 1024+p (bit trick: 0x6400 | p), accumulator preset to -(7*1024 + 896) so
-//                            that H - 896 lies in [-896, 889] and converts to f16 without rounding;
-//   pass 2  S = A * H        f32 result S - 6272 (exact), nearest(S/49) = RN(fma(S-6272, 1/49, 2^23 + 128))
-//                            read from the float's low bits (49 is odd: never a tie; the f32 error of the fma,
-//                            < 1e-5, is far below the 1/98 distance to the nearest tie).
-// One wave per image walks eight 32-row bands: stage the band in LDS (coalesced 16-B loads), build the f16 A
-// operands on the fly (a sliding window of four 16-column K blocks), 30 MFMAs for H of the band, then 32 MFMAs
-// for the output rows [32t+16, 32t+48) that need exactly the bands t and t+1.  The pass-1 accumulators already
-// have the layout of a pass-2 B operand (lane = column, registers = rows) once the band matrix is stored with the
-// matching row permutation, so H never leaves registers.  8x8 cell sums: in-lane over 4 rows, DPP over 8 lanes,
-// the two half-waves through LDS.  Stages 3-6 as in k_dcthash_256, on a whole wave.
-typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-typedef float float16_t __attribute__((ext_vector_type(16)));
-typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
-
-struct MfmaTables {
-  // [table][lane][4 dwords] f16 pairs.  pass 1 (B operands): 0..3 interior rel -1,0,+1,+2; 4 left border (tile 0,
-  // K block 0); 5 right border (tile 7, K block 15).  pass 2 (A operands): 6..9 interior (band t blk A, blk B,
-  // band t+1 blk A, blk B); 10,11 top (t=-1: band 0 blk A, B); 12,13 bottom (t=7: band 7 blk A, B).
-  unsigned int w[14][64][4];
-};
-
-__device__ __forceinline__ half8_t as_half8(uint4_t v) {
-  union {
-    uint4_t u;
-    half8_t h;
-  } c;
-  c.u = v;
-  return c.h;
-}
-
-// 8 pixels (2 dwords) -> 8 f16 = 1024 + p, element order (p0,p2,p1,p3,p4,p6,p5,p7)
-__device__ __forceinline__ half8_t px8_to_f16(uint2 d) {
-  uint4_t r;
-  r.x = (d.x & 0x00ff00ffu) | 0x64006400u;
-  r.y = ((d.x >> 8) & 0x00ff00ffu) | 0x64006400u;
-  r.z = (d.y & 0x00ff00ffu) | 0x64006400u;
-  r.w = ((d.y >> 8) & 0x00ff00ffu) | 0x64006400u;
-  return as_half8(r);
-}
-
-// 8 f32 accumulators (exact small integers) -> 8 f16
-__device__ __forceinline__ half8_t acc8_to_f16(const float16_t& a, int base) {
-  typedef __fp16 h2 __attribute__((ext_vector_type(2)));
-  union {
-    h2 p[4];
-    half8_t h;
-  } c;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) c.p[i] = __builtin_amdgcn_cvt_pkrtz(a[base + 2 * i], a[base + 2 * i + 1]);
-  return c.h;
-}
-
-constexpr int kRowPitch = 264;  // LDS row pitch of the staged band: 2y+c banks -> conflict-free ds_read_b64
-
-template <bool DUMP>
-__global__ __launch_bounds__(256, 2) void k_dcthash_256_mfma(
-    const unsigned char* __restrict__ imgs, unsigned n, unsigned row_stride, unsigned img_stride,
-    const DctTables* __restrict__ tabs, const MfmaTables* __restrict__ mt, uint64_t* __restrict__ out,
-    unsigned char* __restrict__ tiles) {
-  __shared__ __attribute__((aligned(16))) unsigned int sTab[14][64][4];          // 14 KB
-  __shared__ __attribute__((aligned(16))) unsigned char sBand[4][32 * kRowPitch];  // 33 KB
-  __shared__ unsigned short sCell[4][2][32 * 32];  // [wave][half-wave] partial 8x8 sums (4 rows each, <= 8160)
-  __shared__ __attribute__((aligned(16))) unsigned char sTile[4][1024];
-  __shared__ float sT[4][288];
-  __shared__ float sY[4][84];
-  __shared__ float sC[9 * 33];
-  __shared__ float sThr[4];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wv = tid >> 6;
-  const int l32 = lane & 31;
-  const int hf = lane >> 5;
-  for (int i = tid; i < 14 * 64 * 4; i += 256) (&sTab[0][0][0])[i] = (&mt->w[0][0][0])[i];
-  for (int i = tid; i < 288; i += 256) sC[(i >> 5) * 33 + (i & 31)] = tabs->C[i];
-  for (int i = tid; i < 4 * 2 * 1024; i += 256) (&sCell[0][0][0])[i] = 0;
-  __syncthreads();
-
-  unsigned img = blockIdx.x * 4u + (unsigned)wv;
-  const bool valid = img < n;
-  if (!valid) img = n - 1;
-  const unsigned char* __restrict__ src = imgs + (size_t)img * img_stride;
-  unsigned char* band = sBand[wv];
-
-  auto tab = [&](int t) -> half8_t { return as_half8(*reinterpret_cast<const uint4_t*>(sTab[t][lane])); };
-
-  // band staging: 32 rows x 256 B = 8 x (64 lanes x 16 B); lane -> row 4k + lane/16, column (lane%16)*16
-  uint4_t stage[8];
-  auto load_band = [&](int b) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const unsigned row = (unsigned)(32 * b + 4 * k + (lane >> 4));
-      stage[k] = *reinterpret_cast<const uint4_t*>(src + (size_t)row * row_stride + (unsigned)(lane & 15) * 16u);
-    }
-  };
-  auto store_band = [&]() {
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-      *reinterpret_cast<uint4_t*>(band + (4 * k + (lane >> 4)) * kRowPitch + (lane & 15) * 16) = stage[k];
-  };
-
-  half8_t Hp[8][2];  // H - 896 of the previous band: [col tile][K block A/B], already in B-operand layout
-#pragma unroll
-  for (int c = 0; c < 8; ++c) Hp[c][0] = Hp[c][1] = as_half8(uint4_t{0u, 0u, 0u, 0u});
-  float16_t init1;  // pass-1 accumulator preset: -(7*1024) for the f16 bias of P, -896 to centre H
-#pragma unroll
-  for (int r = 0; r < 16; ++r) init1[r] = -8064.0f;
-  const float16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-  // division + cell accumulation of one 32x32 output tile (rows 32t+16.., column tile c)
-  auto finish_tile = [&](const float16_t& s2, int t, int c) {
-    // u = fma(S-6272, 1/49, 2^23+128) = 2^23 + nearest(S/49) exactly; integer sums of the bit patterns carry
-    // 4 * 0x4B000000 per cell-quarter, removed once
-    unsigned cs[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      unsigned a = __float_as_uint(__builtin_fmaf(s2[4 * q], 0.02040816326530612f, 8388736.0f));
-#pragma unroll
-      for (int k = 1; k < 4; ++k)
-        a += __float_as_uint(__builtin_fmaf(s2[4 * q + k], 0.02040816326530612f, 8388736.0f));
-      cs[q] = a - 4u * 0x4B000000u;
-    }
-    // sum over the 8 lanes (columns) of a cell with DPP: xor 1, xor 2 inside quads, then the mirrored quad
-    unsigned p01 = cs[0] | (cs[1] << 16), p23 = cs[2] | (cs[3] << 16);
-    p01 += (unsigned)__builtin_amdgcn_mov_dpp((int)p01, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-    p23 += (unsigned)__builtin_amdgcn_mov_dpp((int)p23, 0xB1, 0xf, 0xf, true);
-    p01 += (unsigned)__builtin_amdgcn_mov_dpp((int)p01, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
-    p23 += (unsigned)__builtin_amdgcn_mov_dpp((int)p23, 0x4E, 0xf, 0xf, true);
-    p01 += (unsigned)__builtin_amdgcn_mov_dpp((int)p01, 0x141, 0xf, 0xf, true);  // row_half_mirror
-    p23 += (unsigned)__builtin_amdgcn_mov_dpp((int)p23, 0x141, 0xf, 0xf, true);
-    if ((l32 & 7) == 0) {
-      const int cx = c * 4 + (l32 >> 3);  // cell column 0..31
-      const int cy0 = 4 * t + 2;          // first cell row of this tile (-2 for the top tile)
-      const unsigned v[4] = {p01 & 0xffffu, p01 >> 16, p23 & 0xffffu, p23 >> 16};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int cy = cy0 + q;
-        if (cy >= 0 && cy < 32) sCell[wv][hf][cy * 32 + cx] = (unsigned short)v[q];
-      }
-    }
-  };
-
-  // one band step; PASS1: there is a band b to stage and transform, TT: which pass-2 table set (0 top, 1
-  // interior, 2 bottom).  Control flow inside is static per instantiation.
-  auto band_step = [&](auto pass1_tag, auto tt_tag, int b) {
-    constexpr bool PASS1 = decltype(pass1_tag)::value;
-    constexpr int TT = decltype(tt_tag)::value;
-    const int t = b - 1;
-    half8_t win[4];
-    auto kblock = [&](int kb) -> half8_t {
-      const uint2 d = *reinterpret_cast<const uint2*>(band + l32 * kRowPitch + kb * 16 + hf * 8);
-      return px8_to_f16(d);
-    };
-    if (PASS1) {
-      store_band();
-      if (b + 1 < 8) load_band(b + 1);
-      __syncthreads();
-      win[1] = kblock(0);
-      win[2] = kblock(1);
-      win[3] = kblock(2);
-    }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      half8_t Hn0 = Hp[c][0], Hn1 = Hp[c][1];
-      if (PASS1) {
-        float16_t acc;
-        if (c > 0) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(win[0], tab(0), init1, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(win[1], tab(1), acc, 0, 0, 0);
-        } else {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(win[1], tab(4), init1, 0, 0, 0);
-        }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(win[2], tab(c == 7 ? 5 : 2), acc, 0, 0, 0);
-        if (c < 7) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(win[3], tab(3), acc, 0, 0, 0);
-        Hn0 = acc8_to_f16(acc, 0);
-        Hn1 = acc8_to_f16(acc, 8);
-        if (c < 7) {
-          win[0] = win[2];
-          win[1] = win[3];
-          win[2] = kblock(2 * c + 3);
-          if (c < 6) win[3] = kblock(2 * c + 4);
-        }
-      }
-      float16_t s2;
-      if (TT == 0) {  // top: rows 0..15 from band 0 only (mirrored rows folded into the table)
-        s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tab(10), Hn0, zero16, 0, 0, 0);
-        s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tab(11), Hn1, s2, 0, 0, 0);
-      } else if (TT == 2) {  // bottom: rows 240..255 from band 7 only
-        s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tab(12), Hp[c][0], zero16, 0, 0, 0);
-        s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tab(13), Hp[c][1], s2, 0, 0, 0);
-      } else {
-        s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tab(6), Hp[c][0], zero16, 0, 0, 0);
-        s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tab(7), Hp[c][1], s2, 0, 0, 0);
-        s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tab(8), Hn0, s2, 0, 0, 0);
-        s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tab(9), Hn1, s2, 0, 0, 0);
-      }
-      finish_tile(s2, t, c);
-      Hp[c][0] = Hn0;
-      Hp[c][1] = Hn1;
-    }
-    if (PASS1) __syncthreads();  // the band buffer is rewritten by the next step
-  };
-  using std::integral_constant;
-  load_band(0);
-  band_step(integral_constant<bool, true>{}, integral_constant<int, 0>{}, 0);
-  for (int b = 1; b < 8; ++b) band_step(integral_constant<bool, true>{}, integral_constant<int, 1>{}, b);
-  band_step(integral_constant<bool, false>{}, integral_constant<int, 2>{}, 8);
-  __syncthreads();
-  // 8x8 block mean, half to even -> 32x32 tile
-  for (int i = lane; i < 1024; i += 64) {
-    const unsigned acc = (unsigned)sCell[wv][0][i] + (unsigned)sCell[wv][1][i];
-    sTile[wv][i] = (unsigned char)((acc + 31u + ((acc >> 6) & 1u)) >> 6);
-  }
-  __syncthreads();
-  if (DUMP) {
-    if (valid)
-      for (int i = lane; i < 256; i += 64)
-        reinterpret_cast<unsigned*>(tiles + (size_t)img * 1024)[i] = reinterpret_cast<const unsigned*>(sTile[wv])[i];
-  }
-  if (tabs->variant) {  // cv::dct's own evaluation (cv_dct32_dev.h): lanes 0..31 = rows, then lanes 0..8 = columns
-    if (lane < 32) {
-      float x[32], y[9];
-#pragma unroll
-      for (int j = 0; j < 32; ++j) x[j] = (float)sTile[wv][lane * 32 + j];
-      cvdct::dct32_first9(x, &tabs->cv, y);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) sT[wv][lane * 9 + k] = y[k];
-    }
-    __syncthreads();
-    if (lane < 9) {
-      float x[32], y[9];
-#pragma unroll
-      for (int r = 0; r < 32; ++r) x[r] = sT[wv][r * 9 + lane];
-      cvdct::dct32_first9(x, &tabs->cv, y);
-#pragma unroll
-      for (int u = 0; u < 9; ++u) sY[wv][u * 9 + lane] = y[u];
-    }
-    __syncthreads();
-    if (lane == 0) sThr[wv] = (float)cvdct::sum64_mem(sY[wv], tabs->zz) / 64;
-    __syncthreads();
-  } else {
-  // ---- stages 3-6 on the whole wave: T[r][k] = sum_j fmaf(X[r][j], C[k][j], .) for 288 (r,k)
-  for (int o = lane; o < 288; o += 64) {
-    const int r = o / 9, k = o - r * 9;
-    float tsum = 0.f;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) tsum = __builtin_fmaf((float)sTile[wv][r * 32 + j], sC[k * 33 + j], tsum);
-    sT[wv][r * 9 + k] = tsum;
-  }
-  __syncthreads();
-  for (int o = lane; o < 81; o += 64) {
-    const int u = o / 9, k = o - u * 9;
-    float tsum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 32; ++r) tsum = __builtin_fmaf(sC[u * 33 + r], sT[wv][r * 9 + k], tsum);
-    sY[wv][o] = tsum;
-  }
-  __syncthreads();
-  if (lane == 0) {
-    double sum = 0.0;
-    for (int i = 0; i < 64; ++i) sum += (double)sY[wv][tabs->zz[i]];
-    sThr[wv] = (float)sum / 64;
-  }
-  __syncthreads();
-  }
-  {
-    const float cf = sY[wv][tabs->zz[lane]];
-    unsigned long long hv = __ballot(lane >= 1 && cf > sThr[wv]);
-    if (hv == 0) hv = 1;
-    if (lane == 0 && valid) out[img] = hv;
-  }
-}
-
+// (Round 2's k_dcthash_256_mfma -- both box passes as f16 MFMAs, operands converted on the VALU -- was removed in round 4:
+//  bit-identical but slower than k_dcthash_256 and k_dcthash_256_band; NOTES.md section 2 keeps its description.)
 // ---------------------------------------------------------------------------------------------
 // k_dcthash_256_band: 256x256 tiles with the horizontal half of the 7x7 box filter on the matrix cores and one
 // addition + half a fused multiply-add per pixel left for the VALU (k_dcthash_256 spends 5.9 VALU instructions per
@@ -2920,10 +2642,6 @@ int get_strip_tabs(int w, bool integer, int ncol, int s, StripTabs* out) {
 
 namespace {
 
-unsigned short f16_small_int(int v) {  // exact f16 bit pattern of 0, 1 or 2
-  return v == 0 ? 0x0000 : v == 1 ? 0x3c00 : 0x4000;
-}
-
 int reflect101_host(int p, int len) {
   while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
   return p;
@@ -2934,46 +2652,6 @@ int band_weight(int x, int c) {
   int wgt = 0;
   for (int d = -3; d <= 3; ++d) wgt += reflect101_host(x + d, 256) == c;
   return wgt;
-}
-
-void make_mfma_tables(MfmaTables* mt) {
-  static const int pi8[8] = {0, 2, 1, 3, 4, 6, 5, 7};  // element order produced by px8_to_f16
-  auto put = [&](int table, int lane, int e, int wgt) {
-    unsigned short bits = f16_small_int(wgt);
-    unsigned int& w = mt->w[table][lane][e >> 1];
-    w = (e & 1) ? ((w & 0x0000ffffu) | ((unsigned)bits << 16)) : ((w & 0xffff0000u) | bits);
-  };
-  memset(mt, 0, sizeof(*mt));
-  // pass 1, B operand of (tile c, K block kb): lane (j = l%32, h = l/32), element e -> source column
-  // 16*kb + 8*h + pi8[e]; weight = Aw[32c + j][that column]
-  auto pass1 = [&](int table, int c, int kb) {
-    for (int l = 0; l < 64; ++l)
-      for (int e = 0; e < 8; ++e) put(table, l, e, band_weight(32 * c + (l & 31), 16 * kb + 8 * (l >> 5) + pi8[e]));
-  };
-  pass1(0, 3, 5);   // rel -1
-  pass1(1, 3, 6);   // rel  0
-  pass1(2, 3, 7);   // rel +1
-  pass1(3, 3, 8);   // rel +2
-  pass1(4, 0, 0);   // left border
-  pass1(5, 7, 15);  // right border
-  // pass 2, A operand for output rows y = 32t + 16 + i (i = l%32) against (band bb, block blk): element e of
-  // half h is H row 32*bb + 16*blk + 8*(e/4) + 4*h + e%4 (the C/D register -> row map of the 32x32 MFMA)
-  auto pass2 = [&](int table, int t, int bb, int blk) {
-    for (int l = 0; l < 64; ++l)
-      for (int e = 0; e < 8; ++e) {
-        const int y = 32 * t + 16 + (l & 31);
-        const int row = 32 * bb + 16 * blk + 8 * (e / 4) + 4 * (l >> 5) + (e % 4);
-        put(table, l, e, (y >= 0 && y < 256) ? band_weight(y, row) : 0);
-      }
-  };
-  pass2(6, 3, 3, 0);
-  pass2(7, 3, 3, 1);
-  pass2(8, 3, 4, 0);
-  pass2(9, 3, 4, 1);
-  pass2(10, -1, 0, 0);
-  pass2(11, -1, 0, 1);
-  pass2(12, 7, 7, 0);
-  pass2(13, 7, 7, 1);
 }
 
 // B operands of k_dcthash_256_band: lane l = (column n = l & 15 of the tile, chunk q = l >> 4), byte j <-> k = 16 q + j.
@@ -3020,33 +2698,11 @@ int get_band_tables(const BandTables** out) {
   return CBH_OK;
 }
 
-struct MfmaTabCache {
-  std::mutex mu;
-  MfmaTables* d[16] = {};
-} g_mfma_tabs;
-
-int get_mfma_tables(const MfmaTables** out) {
-  int dev = 0;
-  CBH_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 16) return CBH_E_INVAL;
-  std::lock_guard<std::mutex> lk(g_mfma_tabs.mu);
-  if (!g_mfma_tabs.d[dev]) {
-    std::vector<MfmaTables> host(1);
-    make_mfma_tables(host.data());
-    MfmaTables* d = nullptr;
-    CBH_HIP(hipMalloc(&d, sizeof(MfmaTables)));
-    CBH_HIP(hipMemcpy(d, host.data(), sizeof(MfmaTables), hipMemcpyHostToDevice));
-    g_mfma_tabs.d[dev] = d;
-  }
-  *out = g_mfma_tabs.d[dev];
-  return CBH_OK;
-}
-
 }  // namespace
 
-// "hash_mfma": which kernel hashes 256 x 256 tiles -- 2 (default) k_dcthash_256_band (horizontal box sums on the
-// matrix cores; needs 16-byte aligned rows, else 0 is taken), 0 k_dcthash_256 (all VALU), 1 k_dcthash_256_mfma (round 2:
-// both box passes in f16 on the matrix cores; slower than either).  Staging the rows four steps ahead instead of two
+// "hash_mfma": which kernel hashes 256 x 256 tiles -- non-zero (default 2) k_dcthash_256_band (horizontal box sums on the
+// matrix cores; needs 16-byte aligned rows, else 0 is taken), 0 k_dcthash_256 (all VALU).  (1 selected round 2's f16 kernel,
+// removed in round 4; it now means the same as 2.)  Staging the rows four steps ahead instead of two
 // (250 VGPRs) changed nothing: 4.83 vs 4.77 ms per 400k images.
 int g_hash_mfma = 2;
 // "hash_band_waves": waves per workgroup of k_dcthash_256_band.  1 (default) a wave owns its four images; 2 = two waves
@@ -3110,7 +2766,6 @@ int g_hash_fast_any = 1;  // 1 = k_blur_rows/k_area_rows/k_tile_hash for every g
 void set_hash_fast_any(int on) {
   if (on >= 0) g_hash_fast_any = on;
 }
-// tuning knob "hash_mfma": 1 = use k_dcthash_256_mfma for 256x256 tiles
 
 // Host-side table construction (same closed forms as the oracle, computed independently here).
 static void make_tables(DctTables* t) {
@@ -3740,7 +3395,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
   }
   if (w == 256 && h == 256 && ((uintptr_t)d_imgs % 8) == 0 && row_stride % 8 == 0 &&
       img_stride % 8 == 0 && row_stride * 256 < (1u << 24) && img_stride < (1u << 28)) {
-    if (g_hash_mfma == 2 && ((uintptr_t)d_imgs % 16) == 0 && row_stride % 16 == 0 && img_stride % 16 == 0) {
+    if (g_hash_mfma != 0 && ((uintptr_t)d_imgs % 16) == 0 && row_stride % 16 == 0 && img_stride % 16 == 0) {
       const BandTables* btab = nullptr;
       if ((rc = get_band_tables(&btab))) return rc;
       dim3 gridb((unsigned)((n + 3) / 4));
@@ -3759,19 +3414,6 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
       }
 #undef CBH_BAND
 #undef CBH_BAND_
-      CBH_HIP(hipGetLastError());
-      return CBH_OK;
-    }
-    if (g_hash_mfma == 1 && ((uintptr_t)d_imgs % 16) == 0 && row_stride % 16 == 0 && img_stride % 16 == 0) {
-      const MfmaTables* mt = nullptr;
-      if ((rc = get_mfma_tables(&mt))) return rc;
-      dim3 gridm((unsigned)((n + 3) / 4)), blockm(256);
-      if (d_tiles)
-        hipLaunchKernelGGL(k_dcthash_256_mfma<true>, gridm, blockm, 0, stream, d_imgs, (unsigned)n,
-                           (unsigned)row_stride, (unsigned)img_stride, tabs, mt, d_out, d_tiles);
-      else
-        hipLaunchKernelGGL(k_dcthash_256_mfma<false>, gridm, blockm, 0, stream, d_imgs, (unsigned)n,
-                           (unsigned)row_stride, (unsigned)img_stride, tabs, mt, d_out, d_tiles);
       CBH_HIP(hipGetLastError());
       return CBH_OK;
     }

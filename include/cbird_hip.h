@@ -712,9 +712,9 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *   "scan_pre_max"  largest threshold served by the low-word-prefilter VALU scan variant (default 7)
  *   "scan_eq_dht1"  1 = dht==1 uses the 64-bit equality variant (default 1)
  *   "scan_group"    1 = issue-rate-shaped scan variants (default 1)
- *   "hash_mfma"     kernel for 256x256 tiles: 2 = k_dcthash_256_band (default: horizontal box sums as i8 MFMAs, one add +
- *                   half an fma per pixel on the VALU; rows must be 16-byte aligned, otherwise 0 is taken), 0 =
- *                   k_dcthash_256 (all VALU), 1 = k_dcthash_256_mfma (both box passes in f16 MFMAs; slowest)
+ *   "hash_mfma"     kernel for 256x256 tiles: non-zero (default 2) = k_dcthash_256_band (horizontal box sums as i8 MFMAs,
+ *                   one add + half an fma per pixel on the VALU; rows must be 16-byte aligned, otherwise 0 is taken),
+ *                   0 = k_dcthash_256 (all VALU)
  *   "hash_band_waves" waves per workgroup of k_dcthash_256_band: 1 (default: a wave owns its four images alone, no
  *                   barriers, 9 waves per CU) or 2 (two waves share four images' rows and tiles in LDS, 14 waves per CU;
  *                   measured 5 % slower)
