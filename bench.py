@@ -159,6 +159,15 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
+    done_group = None
+    if dist.is_initialized() and world > 1:
+        # At the end rank 0 runs a child process beside the line (up to 240 s) while the others wait: that wait happens on
+        # a gloo group with its own long timeout, not inside an RCCL collective under the 120 s watchdog.  Made HERE, before
+        # anything is measured or printed: gloo announces every rank's connections on stdout when a group is made, and
+        # those fragments must not meet rank 0's JSON line.
+        done_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=900))
+        dist.barrier(group=done_group)
+        sys.stdout.flush()
     ops = HipOps(local_rank)  # raises without libcbird_hip.so / a gfx950 device: no fallback
     sh = ShardedDctHashIndex(ops, record_capacity=1 << 22)
 
@@ -375,11 +384,6 @@ def main():
         parts = [None] * world
         dist.all_gather_object(parts, mine)
         result["per_rank_residency"] = parts
-    done_group = None
-    if dist.is_initialized() and world > 1:
-        # rank 0 now runs a child process beside the line (up to 240 s) while the others wait: that wait happens on a
-        # gloo group with its own long timeout, not inside an RCCL collective under the 120 s watchdog
-        done_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=900))
     if rank == 0 and not args.no_sharded_leg:
         result["single_process_sharded"] = sharded_leg(args, world, local_rank, share)
     if rank == 0 and world == 1 and not args.no_features:
@@ -391,7 +395,9 @@ def main():
         result["full_identity"] = result["cpu_baseline"].get("full_identity")
         result["hash_identity"] = result["cpu_baseline"].get("hash_identity")
     if rank == 0:
-        print(json.dumps(result))
+        # (N > 1: at a line start whatever a communication library left on the line)
+        sys.stdout.write(("\n" if world > 1 else "") + json.dumps(result) + "\n")
+        sys.stdout.flush()
     if dist.is_initialized():
         if done_group is not None:
             dist.barrier(group=done_group)
