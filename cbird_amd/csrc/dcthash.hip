@@ -2545,42 +2545,48 @@ int get_area_tabs(int w, int h, AreaTabsDev* out) {
     AreaTabsDev d;
     d.xn = (int)xt.size();
     d.yn = (int)yt.size();
-    CBH_HIP(hipMalloc(&d.x, xt.size() * sizeof(AreaTab)));
-    CBH_HIP(hipMalloc(&d.y, yt.size() * sizeof(AreaTab)));
-    CBH_HIP(hipMalloc(&d.xfirst, 33 * sizeof(int)));
-    CBH_HIP(hipMalloc(&d.yfirst, 33 * sizeof(int)));
-    CBH_HIP(hipMemcpy(d.x, xt.data(), xt.size() * sizeof(AreaTab), hipMemcpyHostToDevice));
-    CBH_HIP(hipMemcpy(d.y, yt.data(), yt.size() * sizeof(AreaTab), hipMemcpyHostToDevice));
-    CBH_HIP(hipMemcpy(d.xfirst, xf.data(), 33 * sizeof(int), hipMemcpyHostToDevice));
-    CBH_HIP(hipMemcpy(d.yfirst, yf.data(), 33 * sizeof(int), hipMemcpyHostToDevice));
-    {
+    // all or nothing: a table that could not be made leaves nothing behind (the next call starts over)
+    hipError_t e = hipMalloc(&d.x, xt.size() * sizeof(AreaTab));
+    if (e == hipSuccess) e = hipMalloc(&d.y, yt.size() * sizeof(AreaTab));
+    if (e == hipSuccess) e = hipMalloc(&d.xfirst, 33 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&d.yfirst, 33 * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(d.x, xt.data(), xt.size() * sizeof(AreaTab), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d.y, yt.data(), yt.size() * sizeof(AreaTab), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d.xfirst, xf.data(), 33 * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d.yfirst, yf.data(), 33 * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
       std::vector<YRow> yr((size_t)h, YRow{0.f, 0.f, 0, 0});
       std::vector<int> cnt((size_t)h, 0);
       bool ok = true;
       for (size_t j = 0; j < yt.size() && ok; ++j) {
-        const AreaTab& e = yt[j];
-        if (e.si < 0 || e.si >= h || e.di < 0 || e.di > 31) {
+        const AreaTab& en = yt[j];
+        if (en.si < 0 || en.si >= h || en.di < 0 || en.di > 31) {
           ok = false;
           break;
         }
-        const bool opens = (int)j == yf[(size_t)e.di], closes = (int)j + 1 == yf[(size_t)e.di + 1];
-        YRow& r = yr[(size_t)e.si];
-        if (cnt[(size_t)e.si] == 0) {
-          r.a0 = e.alpha;
-          r.info = e.di | (opens ? 0x100 : 0) | (closes ? 0x200 : 0);
-        } else if (cnt[(size_t)e.si] == 1 && e.di == (r.info & 0xff) + 1) {
-          r.a1 = e.alpha;
+        const bool opens = (int)j == yf[(size_t)en.di], closes = (int)j + 1 == yf[(size_t)en.di + 1];
+        YRow& r = yr[(size_t)en.si];
+        if (cnt[(size_t)en.si] == 0) {
+          r.a0 = en.alpha;
+          r.info = en.di | (opens ? 0x100 : 0) | (closes ? 0x200 : 0);
+        } else if (cnt[(size_t)en.si] == 1 && en.di == (r.info & 0xff) + 1) {
+          r.a1 = en.alpha;
           r.info |= 0x400 | (opens ? 0x800 : 0) | (closes ? 0x1000 : 0);
         } else {
           ok = false;
         }
-        cnt[(size_t)e.si]++;
+        cnt[(size_t)en.si]++;
       }
       for (int y = 0; y < h && ok; ++y) ok = cnt[(size_t)y] >= 1;
       if (ok) {
-        CBH_HIP(hipMalloc(&d.yrow, (size_t)h * sizeof(YRow)));
-        CBH_HIP(hipMemcpy(d.yrow, yr.data(), (size_t)h * sizeof(YRow), hipMemcpyHostToDevice));
+        e = hipMalloc(&d.yrow, (size_t)h * sizeof(YRow));
+        if (e == hipSuccess) e = hipMemcpy(d.yrow, yr.data(), (size_t)h * sizeof(YRow), hipMemcpyHostToDevice);
       }
+    }
+    if (e != hipSuccess) {
+      for (void* q : {(void*)d.x, (void*)d.y, (void*)d.xfirst, (void*)d.yfirst, (void*)d.yrow})
+        if (q) (void)hipFree(q);
+      CBH_HIP(e);
     }
     it = g_area.emplace(key, d).first;
   }
