@@ -394,16 +394,36 @@ def main():
         # equal to the real VP-tree's, every hash equal to the CPU port's
         result["full_identity"] = result["cpu_baseline"].get("full_identity")
         result["hash_identity"] = result["cpu_baseline"].get("hash_identity")
+    def _sync():
+        if dist.is_initialized():
+            if done_group is not None:
+                dist.barrier(group=done_group)
+            else:
+                dist.barrier()
+
+    # The JSON line goes out when every rank has emptied its C stdio buffer (librccl announces its version there when the
+    # first communicator is made; on a pipe that text would otherwise appear when the processes exit, after the line),
+    # and nothing is printed after it.
+    _flush_c_stdio()
+    _sync()
     if rank == 0:
         # (N > 1: at a line start whatever a communication library left on the line)
         sys.stdout.write(("\n" if world > 1 else "") + json.dumps(result) + "\n")
         sys.stdout.flush()
+    _sync()
     if dist.is_initialized():
-        if done_group is not None:
-            dist.barrier(group=done_group)
-        else:
-            dist.barrier()
         dist.destroy_process_group()
+    _flush_c_stdio()
+
+
+def _flush_c_stdio():
+    import ctypes
+
+    try:
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
 
 
 def sharded_leg(args, world, local_rank, share):
