@@ -1813,7 +1813,7 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
             Oi[ra * 32] = __uint_as_float(sa);
             if (two) Oi[rb_ * 32] = __uint_as_float(sb);
           } else {
-            float ba = 0.f, bb = 0.f;
+            v2f_t bab = {0.f, 0.f};  // (row ra, row rb_)
             unsigned lo_a = A4[0], lo_b = B4[0], wa, wb;
             const float4 wF4 = *reinterpret_cast<const float4*>(swt + 16 * cc);
             const float4 wTa = *reinterpret_cast<const float4*>(swt + 16 * cc + 4);
@@ -1827,11 +1827,17 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
     wb = __builtin_amdgcn_alignbyte(hi_b, lo_b, ama);        \
     lo_a = hi_a, lo_b = hi_b;                                \
   }
-#define CBH_AREA_PIX4(W0, W1, W2, W3)                                                         \
-  ba += (float)(wa & 0xffu) * (W0), bb += (float)(wb & 0xffu) * (W0);                         \
-  ba += (float)((wa >> 8) & 0xffu) * (W1), bb += (float)((wb >> 8) & 0xffu) * (W1);           \
-  ba += (float)((wa >> 16) & 0xffu) * (W2), bb += (float)((wb >> 16) & 0xffu) * (W2);         \
-  ba += (float)(wa >> 24) * (W3), bb += (float)(wb >> 24) * (W3);
+// The two rows of a turn share the weights and have independent accumulators: as a float pair their `sum += p * alpha` is one
+// v_pk_mul_f32 + one v_pk_add_f32 (each component an ordinary IEEE multiply / add: the same bits as the scalar chain), i.e. two
+// instructions for two pixels instead of four -- on this VALU every instruction of a mixed stream costs ~4 cycles (NOTES 9).
+#define CBH_AREA_PIX1(SH, W)                                                                      \
+  {                                                                                              \
+    const v2f_t px_ = {(float)((wa >> (SH)) & 0xffu), (float)((wb >> (SH)) & 0xffu)};             \
+    const v2f_t w_ = {(W), (W)};                                                                 \
+    bab = bab + px_ * w_;                                                                         \
+  }
+#define CBH_AREA_PIX4(W0, W1, W2, W3) \
+  CBH_AREA_PIX1(0, W0) CBH_AREA_PIX1(8, W1) CBH_AREA_PIX1(16, W2) CBH_AREA_PIX1(24, W3)
             CBH_AREA_WORD(0);
             CBH_AREA_PIX4(wF4.x, wF4.y, wF4.z, wF4.w);
             if (mid_ok && fast_area) {
@@ -1845,7 +1851,7 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
                 CBH_AREA_WORD(c);
                 ia = udot4(wa, 0x01010101u, ia), ib = udot4(wb, 0x01010101u, ib);
               }
-              ba = __builtin_fmaf((float)ia, a_mid, ba), bb = __builtin_fmaf((float)ib, a_mid, bb);
+              bab = v2f_t{__builtin_fmaf((float)ia, a_mid, bab.x), __builtin_fmaf((float)ib, a_mid, bab.y)};
               if (nw_u >= 3) {
                 CBH_AREA_WORD(nw_u - 2);
                 CBH_AREA_PIX4(wTa.x, wTa.y, wTa.z, wTa.w);
@@ -1878,8 +1884,9 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
             }
 #undef CBH_AREA_WORD
 #undef CBH_AREA_PIX4
-            Oi[ra * 32] = ba;
-            if (two) Oi[rb_ * 32] = bb;
+#undef CBH_AREA_PIX1
+            Oi[ra * 32] = bab.x;
+            if (two) Oi[rb_ * 32] = bab.y;
           }
         }
       }
