@@ -22,7 +22,10 @@ static int hamm64(uint64_t a, uint64_t b) { return __builtin_popcountll(a ^ b); 
 // that many shards (GpuDeviceSet), and every find additionally has to equal the one-device index's answer
 int main(int argc, char** argv) {
   GpuDeviceSet devs;
-  if (argc > 2) devs = GpuDeviceSet{uint32_t(strtoul(argv[1], nullptr, 0)), atoi(argv[2])};
+  if (argc > 1 && !strcmp(argv[1], "all"))  // every usable device of the node, as Engine::Engine would ask for it
+    devs = GpuDeviceSet::all();
+  else if (argc > 2)
+    devs = GpuDeviceSet{uint32_t(strtoul(argv[1], nullptr, 0)), atoi(argv[2])};
   if (argc > 3 && !strcmp(argv[3], "rccl")) {  // blocks through ncclAllGather
     cbh_set_tuning("shard_force_rccl", 1);
     cbh_set_tuning("shard_exchange", 0);

@@ -8,6 +8,7 @@ logical ones on device 0 (their own streams, device-to-device copies as the exch
 suites of test_gpu_hamm / test_fdct / test_video / test_database pin to the oracle and to the reference's golden
 vectors: those suites are re-run here, unchanged, with every index they create sharded."""
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -25,6 +26,14 @@ def _shapes():
     """(name, (device_mask, shards_per_device), exchange, force_rccl, fault_rccl).  On a one-GPU box: logical shards
     on device 0.  On a box with several GPUs (tools/first_contact.sh) two more shapes join in, through the same suites:
     every device x 1 shard with both exchanges, and two devices x 2 shards."""
+    vdev = int(os.environ.get("CBH_VDEV", "0"))
+    if vdev > 1:
+        # tests/shim/vdev.c is preloaded (test_virtual_devices.py): the one GPU answers to `vdev` ordinals.  Only the
+        # shapes that need several ordinals; the collective shape with librccl treated as absent (RCCL refuses two ranks
+        # on one physical GPU), i.e. the fall-back to copies between DIFFERENT ordinals.
+        full = (1 << vdev) - 1
+        return [("alldev_copies", (full, 1), 1, 0, 0), ("alldev_norccl", (full, 1), 0, 0, 1), ("dev2x2", (0x3, 2), 1, 0, 0),
+                ("dev3x1_sparse", (0x5 | (1 << (vdev - 1)), 1), 1, 0, 0)]
     shapes = [("shards5", (1, 5), 1, 0, 0), ("rccl3", (1, 3), 0, 1, 0), ("shards2x", (1, 2), 1, 0, 0),
               ("norccl3", (1, 3), 0, 1, 1)]
     try:
@@ -148,7 +157,7 @@ def test_exchange_route_and_overflow_redo_are_what_the_shape_says(gpu, orc, shar
         assert s1.collectives - s0.collectives == 1 and s1.collective_fallbacks == 0
     else:
         assert s1.collectives == 0
-    if sharded == "norccl3":  # no communicator: copies, counted and explained
+    if sharded in ("norccl3", "alldev_norccl"):  # no communicator: copies, counted and explained
         assert s1.collective_fallbacks - s0.collective_fallbacks == 1
         assert b"RCCL unavailable" in L.cbh_last_error()
     if ndev == 1:
@@ -276,3 +285,28 @@ def test_cvfeatures_index_sharded_by_image(gpu, sharded):
     st = _lib.cbh_shard_stats()
     _lib.check(L.cbh_idx256_shard_stats(sh._h, C.byref(st)), "stats")
     assert st.shards == R and st.scans >= R and (st.collectives >= 1) == (sharded in ("rccl3", "alldev_rccl"))
+
+
+def test_virtual_ordinals_were_really_used(gpu, orc, sharded):
+    """under tests/shim/vdev.c only (test_virtual_devices.py): the shim saw the library switch to non-zero ordinals and
+    copy between ordinals -- the shapes did not quietly collapse onto device 0"""
+    if not os.environ.get("CBH_VDEV"):
+        pytest.skip("needs the virtual-device shim")
+    from cbird_amd import synth
+
+    shim = C.CDLL(None)
+    shim.vdev_stat.restype = C.c_long
+    before = [shim.vdev_stat(i) for i in range(3)]
+    h, ids = synth.make_hashes(5000, seed=21, planted_frac=0.3)
+    idx = gpu.DctHashIndex()
+    idx.load(h, ids)
+    gi, gs, gc = idx.find_batch(h[:300], 4, 7)
+    wi, ws, wc = orc.find64_batch(h, ids, h[:300], 4, 7)
+    assert (gc == wc).all() and (gi == wi).all() and (gs == ws).all()
+    after = [shim.vdev_stat(i) for i in range(3)]
+    ndev = bin(_SHAPES[sharded][1][0]).count("1")
+    assert shim.vdev_stat(3) == int(os.environ["CBH_VDEV"])
+    assert after[0] - before[0] >= ndev - 1   # hipSetDevice(d != 0)
+    assert after[1] - before[1] >= ndev - 1   # hipMemcpyPeer[Async] between ordinals
+    st = idx.shard_stats()
+    assert st.devices == ndev and st.peer_copies >= ndev - 1
