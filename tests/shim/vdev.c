@@ -172,14 +172,121 @@ hipError_t hipMemPoolCreate(hipMemPool_t* pool, const void* props) {
   return real(pool, copy);
 }
 
+/* ---- which ordinal a stream / an event was created under, and the two rules CUDA-style runtimes enforce between them:
+ * a kernel goes to a stream of the CURRENT device, an event is recorded on a stream of ITS device.  HIP is lenient about
+ * the first today; the library must not depend on that (every per-shard step sits inside a DeviceGuard). */
+#include <pthread.h>
+typedef void* hipEvent_t;
+typedef struct { unsigned x, y, z; } dim3_t;
+enum { kTab = 8192 };
+static struct { void* h; int dev; } g_tab[kTab];
+static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
+static long g_wrong_launch = 0, g_wrong_record = 0, g_launches = 0;
+
+static void tab_put(void* h, int dev) {
+  if (!h) return;
+  pthread_mutex_lock(&g_mu);
+  size_t i = ((size_t)h >> 4) % kTab, free_at = kTab;
+  for (size_t k = 0; k < kTab; ++k, i = (i + 1) % kTab) {
+    if (g_tab[i].h == h) { free_at = i; break; }
+    if (!g_tab[i].h || g_tab[i].h == (void*)1) { if (free_at == kTab) free_at = i; if (!g_tab[i].h) break; }
+  }
+  if (free_at != kTab) g_tab[free_at].h = h, g_tab[free_at].dev = dev;
+  pthread_mutex_unlock(&g_mu);
+}
+static int tab_get(void* h, int drop) { /* -1: unknown (the null stream, handles made before the shim saw them) */
+  int dev = -1;
+  if (!h) return -1;
+  pthread_mutex_lock(&g_mu);
+  size_t i = ((size_t)h >> 4) % kTab;
+  for (size_t k = 0; k < kTab && g_tab[i].h; ++k, i = (i + 1) % kTab)
+    if (g_tab[i].h == h) {
+      dev = g_tab[i].dev;
+      if (drop) g_tab[i].h = (void*)1; /* tombstone */
+      break;
+    }
+  pthread_mutex_unlock(&g_mu);
+  return dev;
+}
+
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags) {
+  REAL("hipStreamCreateWithFlags", hipStream_t*, unsigned);
+  hipError_t e = real(s, flags);
+  if (e == kSuccess && s) tab_put(*s, t_dev);
+  return e;
+}
+hipError_t hipStreamCreate(hipStream_t* s) {
+  REAL("hipStreamCreate", hipStream_t*);
+  hipError_t e = real(s);
+  if (e == kSuccess && s) tab_put(*s, t_dev);
+  return e;
+}
+hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned flags, int prio) {
+  REAL("hipStreamCreateWithPriority", hipStream_t*, unsigned, int);
+  hipError_t e = real(s, flags, prio);
+  if (e == kSuccess && s) tab_put(*s, t_dev);
+  return e;
+}
+hipError_t hipStreamDestroy(hipStream_t s) {
+  REAL("hipStreamDestroy", hipStream_t);
+  (void)tab_get(s, 1);
+  return real(s);
+}
+int hipGetStreamDeviceId(hipStream_t s) {
+  const int d = tab_get(s, 0);
+  return d < 0 ? t_dev : d;
+}
+hipError_t hipEventCreate(hipEvent_t* ev) {
+  REAL("hipEventCreate", hipEvent_t*);
+  hipError_t e = real(ev);
+  if (e == kSuccess && ev) tab_put(*ev, t_dev);
+  return e;
+}
+hipError_t hipEventCreateWithFlags(hipEvent_t* ev, unsigned flags) {
+  REAL("hipEventCreateWithFlags", hipEvent_t*, unsigned);
+  hipError_t e = real(ev, flags);
+  if (e == kSuccess && ev) tab_put(*ev, t_dev);
+  return e;
+}
+hipError_t hipEventDestroy(hipEvent_t ev) {
+  REAL("hipEventDestroy", hipEvent_t);
+  (void)tab_get(ev, 1);
+  return real(ev);
+}
+hipError_t hipEventRecord(hipEvent_t ev, hipStream_t s) {
+  REAL("hipEventRecord", hipEvent_t, hipStream_t);
+  const int de = tab_get(ev, 0);
+  int ds = tab_get(s, 0);
+  if (ds < 0) ds = t_dev;
+  if (de >= 0 && de != ds) {
+    if (__sync_fetch_and_add(&g_wrong_record, 1) == 0)
+      fprintf(stderr, "vdev shim: event of ordinal %d recorded on a stream of ordinal %d\n", de, ds);
+  }
+  return real(ev, s);
+}
+hipError_t hipLaunchKernel(const void* f, dim3_t grid, dim3_t block, void** args, size_t shmem, hipStream_t s) {
+  REAL("hipLaunchKernel", const void*, dim3_t, dim3_t, void**, size_t, hipStream_t);
+  const int ds = tab_get(s, 0);
+  __sync_fetch_and_add(&g_launches, 1);
+  if (ds >= 0 && ds != t_dev) {
+    if (__sync_fetch_and_add(&g_wrong_launch, 1) == 0)
+      fprintf(stderr, "vdev shim: kernel launched on a stream of ordinal %d while ordinal %d is current\n", ds, t_dev);
+  }
+  return real(f, grid, block, args, shmem, s);
+}
+
 /* what the shim saw, for the test: 0 = hipSetDevice calls with a non-zero ordinal, 1 = peer copies, 2 = peer enables,
- * 3 = the virtual device count */
+ * 3 = the virtual device count, 4 = kernels launched on a stream of a device that was not current, 5 = events recorded
+ * on a stream of another device, 6 = kernel launches seen */
 long vdev_stat(int which) {
   switch (which) {
     case 0: return g_set_nonzero;
     case 1: return g_peer_copies;
     case 2: return g_peer_enables;
     case 3: return vcount();
+    case 4: return g_wrong_launch;
+    case 5: return g_wrong_record;
+    case 6: return g_launches;
     default: return -1;
   }
 }

@@ -310,3 +310,6 @@ def test_virtual_ordinals_were_really_used(gpu, orc, sharded):
     assert after[1] - before[1] >= ndev - 1   # hipMemcpyPeer[Async] between ordinals
     st = idx.shard_stats()
     assert st.devices == ndev and st.peer_copies >= ndev - 1
+    # device discipline over everything this process has done so far: no kernel went to a stream of an ordinal that was
+    # not current, no event was recorded on another ordinal's stream
+    assert shim.vdev_stat(6) > 0 and shim.vdev_stat(4) == 0 and shim.vdev_stat(5) == 0

@@ -49,7 +49,11 @@ def test_shim_builds_and_interposes_only_ordinal_taking_entry_points():
                     "hipDeviceGetAttribute", "hipDeviceGetPCIBusId", "hipDeviceGetName", "hipDeviceTotalMem",
                     "hipDevicePrimaryCtxGetState", "hipDeviceGetP2PAttribute", "hipDeviceCanAccessPeer",
                     "hipDeviceEnablePeerAccess", "hipMemcpyPeer", "hipMemcpyPeerAsync", "hipDeviceGetDefaultMemPool",
-                    "hipDeviceGetMemPool", "hipMemPoolCreate", "vdev_stat"}
+                    "hipDeviceGetMemPool", "hipMemPoolCreate", "vdev_stat",
+                    # ... and the ones that create / use a stream or an event, only to check which ordinal they belong to
+                    "hipStreamCreate", "hipStreamCreateWithFlags", "hipStreamCreateWithPriority", "hipStreamDestroy",
+                    "hipGetStreamDeviceId", "hipEventCreate", "hipEventCreateWithFlags", "hipEventDestroy",
+                    "hipEventRecord", "hipLaunchKernel"}
 
 
 @pytest.mark.gpu
