@@ -1,7 +1,9 @@
 #!/bin/bash
 # Round 4: which kernels hash a >= 2 MP image and what they issue (kernel trace + one counter per pass).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-for geo in "3840 2160" "4000 3000" "1920 1080"; do
+# usage: tools/pmc_geo_r04.sh ["W H" ...]   (default: the >= 2 MP geometries of profiles/r04_pmc_geo.md)
+[ $# -eq 0 ] && set -- "3840 2160" "4000 3000" "1920 1080"
+for geo in "$@"; do
   set -- $geo
   echo "== $1 x $2"
   rm -rf /tmp/kt_$1
