@@ -1577,14 +1577,21 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
                                                         int cell0 = 0, int ncell = 32
                                                         /* a column strip of an image wider than 2048: this launch makes
                                                            the output cells cell0 .. cell0 + ncell - 1 of every row (xtab /
-                                                           xfirst describe those cells, columns relative to the strip) */) {
+                                                           xfirst describe those cells, columns relative to the strip) */,
+                                                        int cpad = 0
+                                                        /* integer ratios with cells of an even number of dwords: one pad
+                                                           dword behind every cell of a blurred row in LDS (see `bp`) */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_fused[];
   constexpr int R = K / 2;
   constexpr int kStep = StreamK<K>::step;
   constexpr int PF = K == 7 ? 7 : 5;  // rows in flight; divides kStep so that the ring slot of a row is static
   const int T = (int)blockDim.x, tid = (int)threadIdx.x;
   const int L = (w + 7) >> 3;  // lanes per image: 8 columns each.  A 640-pixel row needs 80 lanes: three images share 256
-  const int bp = 8 * L;        // LDS pitch of a blurred row
+  // LDS pitch of a blurred row.  The area phase has the 32 lanes of a row group read dword u of 32 different cells at
+  // once (ds_read_b32: bank = dword mod 32): cells of nd = isx / 4 dwords put them gcd(nd, 32) to a bank -- 8-way at 1024
+  // px, 16-way at 2048 (SQ_LDS_BANK_CONFLICT: 31 % of the kernel's cycles at 1024 x 768).  cpad: every cell is followed
+  // by one pad dword, cell stride nd + 1 (odd): no conflicts; the blur lanes' two dwords never straddle a cell (nd even).
+  const int bp = 8 * L + (cpad ? 128 : 0);
   const int islot = tid / L;
   const unsigned img_i = blockIdx.z * (unsigned)ipb + (unsigned)islot;
   const bool lane_live = islot < ipb && img_i < n_imgs;
@@ -1620,8 +1627,9 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
   const bool li = ox >= 4, ri = pw != 0 && ox + 8 * L + 4 <= pw;
   unsigned selL = (tl == 0 && !li) ? 0x01020300u : 0x07060504u;  // lane 0: (x, px3, px2, px1) from its own pixels
   unsigned selR = 0x07060504u, sel1 = 0x03020100u, sel2 = 0x07060504u, selT = 0x07060504u;
-  const unsigned offS = 8u * (unsigned)tl;  // where the lane's blurred pixels go in the LDS row
-  unsigned offC = offS;
+  // where the lane's blurred pixels go in the LDS row
+  const unsigned offS = 8u * (unsigned)tl + (cpad ? 4u * ((2u * (unsigned)tl) / (unsigned)(isx >> 2)) : 0u);
+  unsigned offC = 8u * (unsigned)tl;  // the lane's own pixels in the source row
   unsigned offL = (tl == 0 && !li) ? offC : offC - 4u;  // (lane 0 with li: ox - 4 after the shift)
   unsigned offR = offC + 8u;
   const int m = w & 7;
@@ -1679,7 +1687,7 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
   const int Gm = 32 / ncell, Ge = G * Gm, rge = rg * Gm + cc / ncell;
   const int ak0 = isx ? 0 : xfirst[ccl];
   const int ank = isx ? isx : xfirst[ccl + 1] - ak0;
-  const int acol = isx ? ccl * isx : xtab[ak0].si;
+  const int acol = isx ? ccl * isx + (cpad ? 4 * ccl : 0) : xtab[ak0].si;
   const float* __restrict__ al = salpha + ak0;
 
   // weights of the lane's cell by pixel position: (partial first) mid ... mid (partial last), +0 past the cell --
@@ -1768,7 +1776,14 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
         ring[j][c] = P[c];
       }
       const uint2 qo = blur_quotients<K>(S);
-      if (lane_live) *reinterpret_cast<uint2*>(sblur + (size_t)rr * (size_t)bp + offS) = qo;
+      if (lane_live) {
+        if (cpad) {  // (uniform) dword-aligned only: ds_write2_b32
+          unsigned* __restrict__ po = reinterpret_cast<unsigned*>(sblur + (size_t)rr * (size_t)bp + offS);
+          po[0] = qo.x, po[1] = qo.y;
+        } else {
+          *reinterpret_cast<uint2*>(sblur + (size_t)rr * (size_t)bp + offS) = qo;
+        }
+      }
     }
     }
     __syncthreads();
@@ -2764,6 +2779,16 @@ int g_hash_area = 0;  // "hash_area": 1 = k_blur_area_regs sums the interior pix
 void set_hash_area(int v) { g_hash_area = v ? 1 : 0; }
 int g_hash_wide = 1;  // "hash_wide": images wider than 2048 on column strips of k_blur_area_regs (1, default) or on the LDS band kernel (0)
 void set_hash_wide(int v) { g_hash_wide = v ? 1 : 0; }
+int g_hash_cell_pad = 1;  // "hash_cell_pad": pad dword behind every cell of a blurred LDS row (k_blur_area_regs, integer ratios): 0 never,
+                          // 1 (default) where the cells would share LDS banks 4 ways or more, 2 from 2 ways on
+void set_hash_cell_pad(int v) { g_hash_cell_pad = v < 0 ? 0 : v > 2 ? 2 : v; }
+// cells of nd = isx / 4 dwords: the 32 lanes of a row group read dword u of their cells together, gcd(nd, 32) to a bank
+static int cell_pad_for(bool integer, int isx) {
+  if (!integer || !g_hash_cell_pad || (isx & 7)) return 0;  // (nd even: a blur lane's two dwords stay in one cell)
+  int g = 1;
+  while (g < 32 && ((isx >> 2) % (2 * g)) == 0) g *= 2;
+  return g >= (g_hash_cell_pad >= 2 ? 2 : 4) ? 1 : 0;
+}
 int g_hash_regs = 1;  // k_blur_area_regs (blur input from global memory into registers) where its preconditions hold
 void set_hash_fuse(int v) {
   if (v >= 0 && v <= 2) g_hash_fuse = v;
@@ -3185,7 +3210,11 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
             const bool pack = g_hash_regs == 3 || (g_hash_regs == 1 && Lr * 100 < Lw * 72);  // knob 2: never, 3: always
             const int ipb = (Lr <= 128 && pack) ? 256 / Lr : 1;
             const size_t k_end_r = integer ? 0 : (((size_t)at.xn + 3) & ~(size_t)3) + 512;  // weights + per-cell edge weights
-            const size_t rsmem = (size_t)ipb * kstep * (size_t)(8 * Lr) + k_end_r * sizeof(float) +
+            // one pad dword per cell of a blurred LDS row where the cells would otherwise share banks 4 ways or more
+            // ("hash_cell_pad": 0 never, 1 default, 2 from 2 ways on)
+            const int cpad = cell_pad_for(integer, isx);
+            const size_t rowb = (size_t)(8 * Lr) + (cpad ? 128 : 0);  // LDS bytes of one blurred row
+            const size_t rsmem = (size_t)ipb * kstep * rowb + k_end_r * sizeof(float) +
                                  16;  // the area walk reads whole words: up to 7 bytes past the last blurred row
             const unsigned Tr = (unsigned)std::max(64, (ipb * Lr + 63) / 64 * 64);
             // whole image per workgroup, vertical pass and tile inside the kernel (FUSE) when the batch still fills
@@ -3193,7 +3222,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
             const int ipb_f = std::min(ipb, 8);
             const int steps_f = (h + 2 * (K_ / 2) + kstep - 1) / kstep;
             const size_t k_end_f = k_end_r;
-            const size_t fsm = (size_t)ipb_f * kstep * (size_t)(8 * Lr) + k_end_f * sizeof(float) +
+            const size_t fsm = (size_t)ipb_f * kstep * rowb + k_end_f * sizeof(float) +
                                (size_t)ipb_f * kstep * 32 * sizeof(float) + (size_t)ipb_f * 1024;
             // (measured, hash_fuse 0 -> 2: 320x240 +30 %, 400x300 +22 %, 533x400 +19 %, 640x480 +8 %, 800x600 +6 %,
             // 1366x768 +6 %, 1024x768 -2 %, 1280x960 -8 %, 1080p -7 %: large images spend little in k_tile_hash and
@@ -3217,7 +3246,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
       hipLaunchKernelGGL((k_blur_area_regs<KK, GG, true>), dim3(1, 1, (unsigned)((m + ipb_f - 1) / ipb_f)),  \
                          dim3(std::min(256u, Tf_)), fsm, stream, src, w, h, (unsigned)row_stride, img_stride, at.x,       \
                          at.xfirst, isx, steps_f, (float*)nullptr, ipb_f, (unsigned)m, at.yrow, isy, d_ftiles,       \
-                         v_oy, v_ph, v_ox, v_pw, g_hash_area);                                               \
+                         v_oy, v_ph, v_ox, v_pw, g_hash_area, 0, 32, cpad);                                  \
       break;                                                                                                 \
     }                                                                                                        \
     if (rsmem > 64 * 1024)                                                                                   \
@@ -3226,7 +3255,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     hipLaunchKernelGGL((k_blur_area_regs<KK, GG, false>), dim3(1, gs.y, (unsigned)((m + ipb - 1) / ipb)), dim3(Tr), rsmem, \
                        stream, src, w, h, (unsigned)row_stride, img_stride, at.x, at.xfirst, isx, steps, d_rowsf,   \
                        ipb, (unsigned)m, (const YRow*)nullptr, 0, (unsigned char*)nullptr, v_oy, v_ph, v_ox, \
-                       v_pw, g_hash_area);                                                                   \
+                       v_pw, g_hash_area, 0, 32, cpad);                                                      \
   } while (0)
 #define CBH_REGS(KK)              \
   do {                            \
@@ -3269,7 +3298,8 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
                 const bool gen = !((ws % 8 == 0 || s_ri) && ((uintptr_t)(src + S_.x0) % 8) == 0 && row_stride % 8 == 0 &&
                                    img_stride % 8 == 0);
                 const size_t k_end_s = integer ? 0 : (((size_t)S_.xn + 3) & ~(size_t)3) + 512;
-                const size_t smem_s = (size_t)kstep * (size_t)(8 * Ls) + k_end_s * sizeof(float) + 16;
+                const int cpad_s = cell_pad_for(integer, isx);
+                const size_t smem_s = (size_t)kstep * (size_t)(8 * Ls + (cpad_s ? 128 : 0)) + k_end_s * sizeof(float) + 16;
                 const unsigned Ts = (unsigned)std::max(64, (Ls + 63) / 64 * 64);
 #define CBH_STRIP(GG)                                                                                             \
   do {                                                                                                            \
@@ -3279,7 +3309,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     hipLaunchKernelGGL((k_blur_area_regs<7, GG, false>), dim3(1, gs.y, (unsigned)m), dim3(Ts), smem_s, stream, src, \
                        ws, h, (unsigned)row_stride, img_stride, integer ? at.x : S_.x, integer ? at.xfirst : S_.xfirst, \
                        isx, steps, d_rowsf, 1, (unsigned)m, (const YRow*)nullptr, 0, (unsigned char*)nullptr, 0, h,  \
-                       S_.x0, w, g_hash_area, sidx * cpw, cpw);                                                   \
+                       S_.x0, w, g_hash_area, sidx * cpw, cpw, cpad_s);                                           \
   } while (0)
                 if (gen) CBH_STRIP(true);
                 else CBH_STRIP(false);

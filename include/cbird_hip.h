@@ -728,6 +728,9 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *                   least 192 x 128 (default), v >= 2 = always, with v steps per strip
  *   "hash_wide"     1 = images wider than 2048 pixels run k_blur_area_regs on 2 or 4 column strips (default), 0 = the LDS
  *                   band kernel k_blur_area_stream takes them (round 3)
+ *   "hash_cell_pad" k_blur_area_regs at integer ratios: one pad dword behind every cell of a blurred row in LDS, so that the
+ *                   32 lanes that read their cells' dwords together use 32 banks: 0 = never, 1 = where cells would share a
+ *                   bank 4 ways or more (default: 512, 1024, 1536, 2048, 2560 px ...), 2 = from 2 ways on.  Same results.
  *   "kp_lds_side"   largest keypoint square k_kp_hashes stages in LDS (default 134; larger: global-memory routine)
  *   "kp_blur_side"  largest keypoint square whose blurred copy also stays in LDS (default 112)
  *   "color_pk"      1 = packed-f32 colour distance kernel (default 1)

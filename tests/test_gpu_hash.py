@@ -81,6 +81,43 @@ def test_hash_images_wider_than_one_workgroup(gpu, orc, w, h):
         L.cbh_set_tuning(b"hash_stream", 1)
 
 
+@pytest.mark.parametrize("w,h", [(512, 160), (768, 96), (1024, 128), (1280, 64), (2048, 96), (4096, 64), (256, 192), (3072, 64)])
+def test_hash_cell_padding_in_lds_changes_nothing(gpu, orc, w, h):
+    """integer ratios whose cells are an even number of dwords: k_blur_area_regs keeps a pad dword behind every cell of a
+    blurred LDS row so that the 32 lanes reading their cells together use 32 banks ("hash_cell_pad": 1 default = where they
+    would share a bank 4 ways or more, 2 = from 2 ways, 0 = never): hashes and tiles == oracle under all three, whole images
+    (fused and strip-split forms) and column strips of wide ones"""
+    import torch
+
+    from cbird_amd import _lib
+
+    L = _lib.lib()
+    rng = np.random.default_rng(7 * w + h)
+    n = 12
+    imgs = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    imgs[0] = (128 + 100 * np.sin(xx / 53.0) * np.cos(yy / 29.0)).astype(np.uint8)
+    want = orc.dcthash64_batch(imgs)
+    tile0 = orc.tile32(imgs[0])
+    d = torch.from_numpy(imgs).cuda()
+    try:
+        for pad in (2, 1, 0):
+            for fuse, stream in ((2, 1), (0, 4)):  # whole image per workgroup; strips of four steps + k_tile_hash
+                L.cbh_set_tuning(b"hash_cell_pad", pad)
+                L.cbh_set_tuning(b"hash_fuse", fuse)
+                L.cbh_set_tuning(b"hash_stream", stream)
+                assert (gpu.dct_hash64_batch(imgs) == want).all(), (w, h, pad, fuse)
+                out = torch.zeros(n, dtype=torch.int64, device="cuda")
+                tiles = torch.zeros((n, 32, 32), dtype=torch.uint8, device="cuda")
+                _lib.check(L.cbh_dcthash_tiles_dev(d.data_ptr(), n, w, h, w, w * h, out.data_ptr(), tiles.data_ptr(), 0, None),
+                           "t")
+                assert (tiles[0].cpu().numpy() == tile0).all(), (w, h, pad, fuse)
+    finally:
+        L.cbh_set_tuning(b"hash_cell_pad", 1)
+        L.cbh_set_tuning(b"hash_fuse", 1)
+        L.cbh_set_tuning(b"hash_stream", 1)
+
+
 def test_hash_edge_images(gpu, orc, hash256_kernel):
     imgs = np.zeros((6, 256, 256), np.uint8)
     imgs[1] = 255
