@@ -174,14 +174,17 @@ def test_autocropped_hash_uses_the_parent_border(gpu, po, orc):
              # aligned and odd offsets, any width mod 8; margins under 4 pixels or too small for the last lane's overhang
              # stay on the band kernels
              (480, 640, 0, 0, 80, 80), (360, 641, 20, 20, 33, 47), (400, 600, 0, 0, 6, 6), (300, 500, 25, 25, 64, 9),
-             (720, 1280, 0, 0, 160, 160), (240, 427, 12, 12, 51, 50), (300, 400, 0, 0, 3, 40), (300, 400, 0, 0, 40, 3))
+             (720, 1280, 0, 0, 160, 160), (240, 427, 12, 12, 51, 50), (300, 400, 0, 0, 3, 40), (300, 400, 0, 0, 40, 3),
+             # views at integer ratios whose cells are an even number of dwords (the padded LDS rows, "hash_cell_pad")
+             (896, 1024, 64, 64, 0, 0), (512, 672, 0, 0, 80, 80), (616, 868, 20, 20, 50, 50), (320, 2048, 32, 32, 0, 0))
     # as shipped (small batches: the band kernels), then with the strip kernels forced -- a view that spans the parent's
     # width (letterbox) takes the register-streaming kernel with the parent's rows above and below it, split and fused;
     # any other view must still come out right (it stays on the band kernels)
     try:
-        for (stream, fuse) in ((1, 1), (3, 0), (8, 2)):
+        for (stream, fuse, pad) in ((1, 1, 1), (3, 0, 2), (8, 2, 2), (8, 2, 0)):
             L.cbh_set_tuning(b"hash_stream", stream)
             L.cbh_set_tuning(b"hash_fuse", fuse)
+            L.cbh_set_tuning(b"hash_cell_pad", pad)
             for (h, w, t, b, le, r) in cases:
                 gray = np.stack([letterboxed(rng, h, w, t, b, le, r) for _ in range(2)])
                 got, rects = process_images(gray, 20)
@@ -194,6 +197,7 @@ def test_autocropped_hash_uses_the_parent_border(gpu, po, orc):
     finally:
         L.cbh_set_tuning(b"hash_stream", 1)
         L.cbh_set_tuning(b"hash_fuse", 1)
+        L.cbh_set_tuning(b"hash_cell_pad", 1)
     assert differs >= 3 and cropped >= 3 * 2 * 14
 
 

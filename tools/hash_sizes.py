@@ -8,15 +8,16 @@ dev = torch.device("cuda", 0)
 ms = C.c_float(0)
 for kv in sys.argv[1:]:  # tuning overrides: key=value (and geos=WxH,WxH,...)
     k, v = kv.split("=")
-    if k in ("geos", "ab"):
+    if k in ("geos", "ab", "bytes"):
         continue
     L.cbh_set_tuning(k.encode(), int(v))
 GEOS = ((256, 256), (128, 128), (512, 512), (1024, 1024), (320, 240), (640, 480), (1024, 768), (300, 200), (1920, 1080), (3840, 2160), (4000, 3000))
 if any(a.startswith("geos=") for a in sys.argv[1:]):
     GEOS = tuple(tuple(int(v) for v in g.split("x")) for a in sys.argv[1:] if a.startswith("geos=") for g in a[5:].split(","))
+BYTES = float(next((a[6:] for a in sys.argv[1:] if a.startswith("bytes=")), 2e9))  # pixels per batch (2 GB: ~1 ms launches)
 AB = [a[3:].split(",") for a in sys.argv[1:] if a.startswith("ab=")]  # ab=key:v1:v2:...  -> A/B the knob per geometry
 for (w, h) in GEOS:
-    n = max(64, min(20000, int(2e9 // (w * h))))
+    n = max(64, min(int(20000 * BYTES / 2e9), int(BYTES // (w * h))))
     imgs = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device=dev)
     out = torch.empty(n, dtype=torch.int64, device=dev)
     if AB:
