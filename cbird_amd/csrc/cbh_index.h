@@ -37,7 +37,11 @@ struct DeviceGuard {
   bool ok = false;
   explicit DeviceGuard(int dev) {
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-    ok = hipSetDevice(dev) == hipSuccess;
+    if (prev == dev) {
+      ok = true, prev = -1;  // already current (every logical shard of a one-device handle): nothing to set or restore
+    } else {
+      ok = hipSetDevice(dev) == hipSuccess;
+    }
     if (ok) keep_pool_memory(dev);
   }
   ~DeviceGuard() {

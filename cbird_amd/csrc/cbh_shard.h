@@ -70,7 +70,9 @@ struct ShardComm {
   int dev_pos_of_shard(size_t s) const { return (int)(s / (size_t)per_device); }
   // parts in shard order (shards of a device adjacent).  On return root_stream waits for everything that lands in
   // d_dst; the shard streams may still be busy with their side of the collective.
-  int exchange(std::vector<ShardPart>& parts, hipStream_t root_stream, unsigned long long* d_dst);
+  // went_collective (optional): whether the records travelled through ncclAllGather (false: by copies)
+  int exchange(std::vector<ShardPart>& parts, hipStream_t root_stream, unsigned long long* d_dst,
+               bool* went_collective = nullptr);
   void destroy_comms();
 };
 
