@@ -1560,7 +1560,11 @@ __global__ __launch_bounds__(256) void k_blur_area_stream(const unsigned char* _
 // image instead of h x 32 floats (0.64 GB per 2 GB of 400x300 input, written and read back); stages 3-6 run from the
 // tiles (k_tiles_hash).  The vertical lanes do their rows right behind the barrier that ends a step, before their
 // next blur rows: no extra barrier.
-template <int K, bool GEN, bool FUSE>
+// KS = source rows per step (a multiple of K and of the rows in flight).  The area phase hands the step's rows to the
+// workgroup's T / 32 row groups two at a time (x 32 / ncell on a column strip), so a step of 14 rows fills a turn of
+// 12 (T = 192), 24, 32, 48 or 64 row slots badly: the launcher picks 21 or 28 rows where that fills the turns better
+// (pick_rows_per_step below; K = 7 only).
+template <int K, bool GEN, bool FUSE, int KS = StreamK<K>::step>
 __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __restrict__ imgs, int w, int h,
                                                         unsigned row_stride, size_t img_stride,
                                                         const AreaTab* __restrict__ xtab,
@@ -1583,8 +1587,9 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
                                                            dword behind every cell of a blurred row in LDS (see `bp`) */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_fused[];
   constexpr int R = K / 2;
-  constexpr int kStep = StreamK<K>::step;
+  constexpr int kStep = KS;
   constexpr int PF = K == 7 ? 7 : 5;  // rows in flight; divides kStep so that the ring slot of a row is static
+  static_assert(KS % K == 0 && KS % PF == 0, "the register ring and the prefetch ring keep their phase across steps");
   const int T = (int)blockDim.x, tid = (int)threadIdx.x;
   const int L = (w + 7) >> 3;  // lanes per image: 8 columns each.  A 640-pixel row needs 80 lanes: three images share 256
   // LDS pitch of a blurred row.  The area phase has the 32 lanes of a row group read dword u of 32 different cells at
@@ -2782,6 +2787,42 @@ void set_hash_wide(int v) { g_hash_wide = v ? 1 : 0; }
 int g_hash_cell_pad = 1;  // "hash_cell_pad": pad dword behind every cell of a blurred LDS row (k_blur_area_regs, integer ratios): 0 never,
                           // 1 (default) where the cells would share LDS banks 4 ways or more, 2 from 2 ways on
 void set_hash_cell_pad(int v) { g_hash_cell_pad = v < 0 ? 0 : v > 2 ? 2 : v; }
+int g_hash_rows_per_step = 1;  // "hash_rows_per_step": 0 = 14 rows per step of k_blur_area_regs<7> always (through round 4), 1 (default) =
+                               // 14 / 21 / 28 by how the step's rows fill the area phase's turns, 21 / 28 = that many wherever possible
+void set_hash_rows_per_step(int v) { g_hash_rows_per_step = (v == 21 || v == 28) ? v : (v ? 1 : 0); }
+// rows per step for a workgroup of T threads making ncell cells per row: a turn of the area phase has 2 T / ncell row slots
+static int pick_rows_per_step(int K, unsigned T, int ncell, size_t lds_per_row, size_t lds_fixed) {
+  if (K != 7 || !g_hash_rows_per_step) return K == 7 ? 14 : 15;
+  auto fits = [&](int ks) { return lds_fixed + (size_t)ks * lds_per_row <= (size_t)64 * 1024; };
+  if (g_hash_rows_per_step > 1) return fits(g_hash_rows_per_step) ? g_hash_rows_per_step : 14;
+  const int cap = (int)(2 * T) / ncell;
+  int best = 14;
+  double best_u = 0.0;
+  for (int ks : {14, 21}) {  // (28 measured too: slower than 21 everywhere, 15-30 % slower than 14 on one-wave workgroups)
+    if (!fits(ks)) break;
+    const int turns = (ks + cap - 1) / cap;
+    const double u = (double)ks / ((double)turns * cap);
+    if (u > best_u + 0.05) best = ks, best_u = u;  // (more rows per step only for a real gain: they cost LDS)
+  }
+  return best;
+}
+// steps per strip of k_blur_area_regs: every strip re-reads the 6 rows of blur halo and its last step may be partly
+// empty, so the rows PROCESSED depend on how h divides: 960 rows in strips of 8 x 14 = 106 output rows are 10 strips =
+// 1120 rows, in strips of 9 x 14 = 120 they are 8 = 1008.  Around the target (which the batch size sets: enough
+// workgroups), the count that processes the fewest rows; ties go to the longer strip.  "hash_stream" >= 2 forces its value.
+static int pick_steps_per_strip(int h, int ks, int target, int halo) {
+  const int all = (h + halo + ks - 1) / ks;  // one strip spanning the image
+  if (g_hash_stream >= 2 || target >= all) return std::max(1, std::min(target, all));
+  int best = target;
+  long long best_rows = -1;
+  for (int st = std::max(2, target - 1); st <= std::min(all, target + 3); ++st) {
+    const int out = st * ks - halo;
+    if (out <= 0) continue;
+    const long long rows = (long long)((h + out - 1) / out) * st * ks;
+    if (best_rows < 0 || rows <= best_rows) best = st, best_rows = rows;
+  }
+  return best;
+}
 // cells of nd = isx / 4 dwords: the 32 lanes of a row group read dword u of their cells together, gcd(nd, 32) to a bank
 static int cell_pad_for(bool integer, int isx) {
   if (!integer || !g_hash_cell_pad || (isx & 7)) return 0;  // (nd even: a blur lane's two dwords stay in one cell)
@@ -3214,20 +3255,27 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
             // ("hash_cell_pad": 0 never, 1 default, 2 from 2 ways on)
             const int cpad = cell_pad_for(integer, isx);
             const size_t rowb = (size_t)(8 * Lr) + (cpad ? 128 : 0);  // LDS bytes of one blurred row
-            const size_t rsmem = (size_t)ipb * kstep * rowb + k_end_r * sizeof(float) +
-                                 16;  // the area walk reads whole words: up to 7 bytes past the last blurred row
             const unsigned Tr = (unsigned)std::max(64, (ipb * Lr + 63) / 64 * 64);
+            // rows per step (14 / 21 / 28) by how they fill the area phase's turns; the strips keep their length in rows
+            const int ks_r = pick_rows_per_step(K_, Tr, 32, (size_t)ipb * rowb, k_end_r * sizeof(float) + 16);
+            const int steps_r = pick_steps_per_strip(h, ks_r, (steps * kstep + ks_r - 1) / ks_r, 2 * (K_ / 2));
+            const int strip_out_r = steps_r * ks_r - 2 * (K_ / 2);
+            const unsigned gsy_r = (unsigned)((h + strip_out_r - 1) / strip_out_r);
+            const size_t rsmem = (size_t)ipb * ks_r * rowb + k_end_r * sizeof(float) +
+                                 16;  // the area walk reads whole words: up to 7 bytes past the last blurred row
             // whole image per workgroup, vertical pass and tile inside the kernel (FUSE) when the batch still fills
             // the machine that way: at least two workgroups per CU
             const int ipb_f = std::min(ipb, 8);
-            const int steps_f = (h + 2 * (K_ / 2) + kstep - 1) / kstep;
             const size_t k_end_f = k_end_r;
-            const size_t fsm = (size_t)ipb_f * kstep * rowb + k_end_f * sizeof(float) +
-                               (size_t)ipb_f * kstep * 32 * sizeof(float) + (size_t)ipb_f * 1024;
+            const unsigned Tf_ = (unsigned)std::max(64, (ipb_f * std::max(Lr, 32) + 63) / 64 * 64);
+            const int ks_f = pick_rows_per_step(K_, std::min(256u, Tf_), 32, (size_t)ipb_f * (rowb + 32 * sizeof(float)),
+                                                k_end_f * sizeof(float) + (size_t)ipb_f * 1024);
+            const int steps_f = (h + 2 * (K_ / 2) + ks_f - 1) / ks_f;
+            const size_t fsm = (size_t)ipb_f * ks_f * rowb + k_end_f * sizeof(float) +
+                               (size_t)ipb_f * ks_f * 32 * sizeof(float) + (size_t)ipb_f * 1024;
             // (measured, hash_fuse 0 -> 2: 320x240 +30 %, 400x300 +22 %, 533x400 +19 %, 640x480 +8 %, 800x600 +6 %,
             // 1366x768 +6 %, 1024x768 -2 %, 1280x960 -8 %, 1080p -7 %: large images spend little in k_tile_hash and
             // lose occupancy to the extra LDS; fractional ratios gain up to ~1 MP)
-            const unsigned Tf_ = (unsigned)std::max(64, (ipb_f * std::max(Lr, 32) + 63) / 64 * 64);
             // a fused workgroup walks its whole image alone: with one or two waves per workgroup the machine needs
             // thousands of them before that beats strips of 8 steps (tools/ab/hash_small_batches.py: 400x300, one wave per
             // image, 1024 images 137 us fused / 86 split, 2048: 160 / 148, 4096: 289 / 298; 800x600, two waves:
@@ -3237,25 +3285,32 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
                               (g_hash_fuse >= 2 ||
                                ((m + (size_t)ipb_f - 1) / (size_t)ipb_f >= fuse_min_wgs &&
                                 (size_t)w * (size_t)h <= (integer ? 400000u : 1100000u)));
-#define CBH_REGS_(KK, GG)                                                                                    \
+#define CBH_REGS_L(KK, GG, KSV)                                                                              \
   do {                                                                                                       \
     if (fuse) {                                                                                              \
       if (fsm > 64 * 1024)                                                                                   \
-        CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_area_regs<KK, GG, true>),           \
+        CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_area_regs<KK, GG, true, KSV>),      \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsm));                  \
-      hipLaunchKernelGGL((k_blur_area_regs<KK, GG, true>), dim3(1, 1, (unsigned)((m + ipb_f - 1) / ipb_f)),  \
+      hipLaunchKernelGGL((k_blur_area_regs<KK, GG, true, KSV>), dim3(1, 1, (unsigned)((m + ipb_f - 1) / ipb_f)), \
                          dim3(std::min(256u, Tf_)), fsm, stream, src, w, h, (unsigned)row_stride, img_stride, at.x,       \
                          at.xfirst, isx, steps_f, (float*)nullptr, ipb_f, (unsigned)m, at.yrow, isy, d_ftiles,       \
                          v_oy, v_ph, v_ox, v_pw, g_hash_area, 0, 32, cpad);                                  \
       break;                                                                                                 \
     }                                                                                                        \
     if (rsmem > 64 * 1024)                                                                                   \
-      CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_area_regs<KK, GG, false>),            \
+      CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_area_regs<KK, GG, false, KSV>),       \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)rsmem));                  \
-    hipLaunchKernelGGL((k_blur_area_regs<KK, GG, false>), dim3(1, gs.y, (unsigned)((m + ipb - 1) / ipb)), dim3(Tr), rsmem, \
-                       stream, src, w, h, (unsigned)row_stride, img_stride, at.x, at.xfirst, isx, steps, d_rowsf,   \
+    hipLaunchKernelGGL((k_blur_area_regs<KK, GG, false, KSV>), dim3(1, gsy_r, (unsigned)((m + ipb - 1) / ipb)), dim3(Tr), rsmem, \
+                       stream, src, w, h, (unsigned)row_stride, img_stride, at.x, at.xfirst, isx, steps_r, d_rowsf, \
                        ipb, (unsigned)m, (const YRow*)nullptr, 0, (unsigned char*)nullptr, v_oy, v_ph, v_ox, \
                        v_pw, g_hash_area, 0, 32, cpad);                                                      \
+  } while (0)
+#define CBH_REGS_(KK, GG)                                    \
+  do {                                                       \
+    const int ks_ = fuse ? ks_f : ks_r;                      \
+    if (KK == 7 && ks_ == 21) CBH_REGS_L(7, GG, 21);         \
+    else if (KK == 7 && ks_ == 28) CBH_REGS_L(7, GG, 28);    \
+    else CBH_REGS_L(KK, GG, StreamK<KK>::step);              \
   } while (0)
 #define CBH_REGS(KK)              \
   do {                            \
@@ -3267,6 +3322,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
               case 5: CBH_REGS(5); break;
               default: CBH_REGS(7); break;
             }
+#undef CBH_REGS_L
 #undef CBH_REGS_
 #undef CBH_REGS
             if (fuse)
@@ -3299,20 +3355,32 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
                                    img_stride % 8 == 0);
                 const size_t k_end_s = integer ? 0 : (((size_t)S_.xn + 3) & ~(size_t)3) + 512;
                 const int cpad_s = cell_pad_for(integer, isx);
-                const size_t smem_s = (size_t)kstep * (size_t)(8 * Ls + (cpad_s ? 128 : 0)) + k_end_s * sizeof(float) + 16;
                 const unsigned Ts = (unsigned)std::max(64, (Ls + 63) / 64 * 64);
-#define CBH_STRIP(GG)                                                                                             \
+                // a strip makes cpw of the 32 cells: 2 Ts / cpw row slots per turn of the area phase, 14 rows fill them badly
+                const int ks_s = pick_rows_per_step(7, Ts, cpw, (size_t)(8 * Ls + (cpad_s ? 128 : 0)), k_end_s * sizeof(float) + 16);
+                const int steps_s = pick_steps_per_strip(h, ks_s, (steps * kstep + ks_s - 1) / ks_s, 6);
+                const int strip_out_s = steps_s * ks_s - 6;
+                const unsigned gsy_s = (unsigned)((h + strip_out_s - 1) / strip_out_s);
+                const size_t smem_s = (size_t)ks_s * (size_t)(8 * Ls + (cpad_s ? 128 : 0)) + k_end_s * sizeof(float) + 16;
+#define CBH_STRIP_L(GG, KSV)                                                                                      \
   do {                                                                                                            \
     if (smem_s > 64 * 1024)                                                                                       \
-      CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_area_regs<7, GG, false>),                  \
+      CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_area_regs<7, GG, false, KSV>),             \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s));                      \
-    hipLaunchKernelGGL((k_blur_area_regs<7, GG, false>), dim3(1, gs.y, (unsigned)m), dim3(Ts), smem_s, stream, src, \
+    hipLaunchKernelGGL((k_blur_area_regs<7, GG, false, KSV>), dim3(1, gsy_s, (unsigned)m), dim3(Ts), smem_s, stream, src, \
                        ws, h, (unsigned)row_stride, img_stride, integer ? at.x : S_.x, integer ? at.xfirst : S_.xfirst, \
-                       isx, steps, d_rowsf, 1, (unsigned)m, (const YRow*)nullptr, 0, (unsigned char*)nullptr, 0, h,  \
+                       isx, steps_s, d_rowsf, 1, (unsigned)m, (const YRow*)nullptr, 0, (unsigned char*)nullptr, 0, h,  \
                        S_.x0, w, g_hash_area, sidx * cpw, cpw, cpad_s);                                           \
+  } while (0)
+#define CBH_STRIP(GG)                               \
+  do {                                              \
+    if (ks_s == 21) CBH_STRIP_L(GG, 21);            \
+    else if (ks_s == 28) CBH_STRIP_L(GG, 28);       \
+    else CBH_STRIP_L(GG, 14);                       \
   } while (0)
                 if (gen) CBH_STRIP(true);
                 else CBH_STRIP(false);
+#undef CBH_STRIP_L
 #undef CBH_STRIP
               }
               hipLaunchKernelGGL(k_tile_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_rowsf, h, at.y, at.yfirst,

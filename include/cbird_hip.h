@@ -728,6 +728,10 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *                   least 192 x 128 (default), v >= 2 = always, with v steps per strip
  *   "hash_wide"     1 = images wider than 2048 pixels run k_blur_area_regs on 2 or 4 column strips (default), 0 = the LDS
  *                   band kernel k_blur_area_stream takes them (round 3)
+ *   "hash_rows_per_step" source rows per step of k_blur_area_regs (7 x 7 blur): 0 = 14 always, 1 (default) = 14, 21 or 28,
+ *                   whichever fills the row slots of the area phase's turns best for the workgroup size and the cells a
+ *                   strip makes (192-thread workgroups: 21; column strips of wide images: 21 / 28; one-wave workgroups:
+ *                   28), 21 / 28 = that many wherever the LDS allows.  Same results.
  *   "hash_cell_pad" k_blur_area_regs at integer ratios: one pad dword behind every cell of a blurred row in LDS, so that the
  *                   32 lanes that read their cells' dwords together use 32 banks: 0 = never, 1 = where cells would share a
  *                   bank 4 ways or more (default: 512, 1024, 1536, 2048, 2560 px ...), 2 = from 2 ways on.  Same results.

@@ -118,6 +118,43 @@ def test_hash_cell_padding_in_lds_changes_nothing(gpu, orc, w, h):
         L.cbh_set_tuning(b"hash_stream", 1)
 
 
+@pytest.mark.parametrize("w,h", [(400, 300), (1280, 200), (1366, 130), (1031, 257), (1536, 96), (2560, 120), (3000, 200), (5000, 90),
+                                 (8000, 64), (704, 576)])
+def test_hash_rows_per_step_changes_nothing(gpu, orc, w, h):
+    """k_blur_area_regs<7> walks an image 14, 21 or 28 source rows per step ("hash_rows_per_step": 1 default = by how the
+    rows fill the area phase's turns, 0 = 14 always, 21 / 28 forced), in strips whose length is chosen for the fewest rows
+    processed: hashes and tiles == oracle under every value, fused and strip-split, whole images and column strips"""
+    import torch
+
+    from cbird_amd import _lib
+
+    L = _lib.lib()
+    rng = np.random.default_rng(11 * w + h)
+    n = 6
+    imgs = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    imgs[0] = (128 + 100 * np.sin(xx / 71.0) * np.cos(yy / 23.0)).astype(np.uint8)
+    want = orc.dcthash64_batch(imgs)
+    tile0 = orc.tile32(imgs[0])
+    d = torch.from_numpy(imgs).cuda()
+    try:
+        for rows in (1, 0, 21, 28):
+            for fuse, stream in ((2, 1), (0, 4), (0, 1)):
+                L.cbh_set_tuning(b"hash_rows_per_step", rows)
+                L.cbh_set_tuning(b"hash_fuse", fuse)
+                L.cbh_set_tuning(b"hash_stream", stream)
+                assert (gpu.dct_hash64_batch(imgs) == want).all(), (w, h, rows, fuse, stream)
+                out = torch.zeros(n, dtype=torch.int64, device="cuda")
+                tiles = torch.zeros((n, 32, 32), dtype=torch.uint8, device="cuda")
+                _lib.check(L.cbh_dcthash_tiles_dev(d.data_ptr(), n, w, h, w, w * h, out.data_ptr(), tiles.data_ptr(), 0, None),
+                           "t")
+                assert (tiles[0].cpu().numpy() == tile0).all(), (w, h, rows, fuse, stream)
+    finally:
+        L.cbh_set_tuning(b"hash_rows_per_step", 1)
+        L.cbh_set_tuning(b"hash_fuse", 1)
+        L.cbh_set_tuning(b"hash_stream", 1)
+
+
 def test_hash_edge_images(gpu, orc, hash256_kernel):
     imgs = np.zeros((6, 256, 256), np.uint8)
     imgs[1] = 255
