@@ -2835,7 +2835,8 @@ void set_hash_fuse(int v) {
   if (v >= 0 && v <= 2) g_hash_fuse = v;
 }
 void set_hash_regs(int v) {
-  if (v >= 0 && v <= 3) g_hash_regs = v;  // 0 off, 1 on (automatic image packing), 2 on / never pack, 3 on / always pack
+  if (v >= 0 && v <= 4) g_hash_regs = v;  // 0 off, 1 on (automatic image packing), 2 on / never pack, 3 on / always pack,
+                                          // 4 on / round 3's packing rule
 }
 int g_hash_fused = 1;  // k_blur_area (blur + horizontal area pass in one kernel): 0 off, v >= 1 for widths >= v (measured: wins from 64 up)
 void set_hash_fused(int on) {
@@ -3248,8 +3249,17 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
             // side (640 px: 80 of 128 lanes busy alone, 240 of 256 as three: +12 %); where the lanes are already
             // well used the larger workgroup only costs (more waves per barrier: -5..-9 % measured at 400, 512, 1024 px)
             const int Lr = (w + 7) / 8, Lw = (Lr + 63) / 64 * 64;
-            const bool pack = g_hash_regs == 3 || (g_hash_regs == 1 && Lr * 100 < Lw * 72);  // knob 2: never, 3: always
-            const int ipb = (Lr <= 128 && pack) ? 256 / Lr : 1;
+            // knob 1 (default): side by side where that puts 15 % more of the lanes to work (400 px: 50 of 64 alone, 250 of
+            // 256 as five: +3..4 %; 720 / 800 px: two images fill 256 lanes no better than one fills 128: -2 % packed; through
+            // round 4 the rule was "alone uses < 72 % of its lanes"); 4: that older rule, 2: never, 3: always
+            // Integer ratios (cheap area phase: the blur lanes decide) count the packed workgroup's own size -- 704 x 576: 176
+            // of 192 lanes as two against 88 of 128 alone, +10 % -- fractional ones count it as 256 lanes: 720 x 540 and
+            // 688 x 516 run 4-5 % faster alone in 128 lanes than as two in 192.
+            const int ipb_try = Lr <= 128 ? 256 / Lr : 1;
+            const int Tp = integer ? (ipb_try * Lr + 63) / 64 * 64 : 256;
+            const bool pack = g_hash_regs == 3 || (g_hash_regs == 4 && Lr * 100 < Lw * 72) ||
+                              (g_hash_regs == 1 && ipb_try > 1 && (long long)ipb_try * Lr * Lw * 100 >= 115LL * Lr * Tp);
+            const int ipb = pack ? ipb_try : 1;
             const size_t k_end_r = integer ? 0 : (((size_t)at.xn + 3) & ~(size_t)3) + 512;  // weights + per-cell edge weights
             // one pad dword per cell of a blurred LDS row where the cells would otherwise share banks 4 ways or more
             // ("hash_cell_pad": 0 never, 1 default, 2 from 2 ways on)

@@ -728,6 +728,9 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *                   least 192 x 128 (default), v >= 2 = always, with v steps per strip
  *   "hash_wide"     1 = images wider than 2048 pixels run k_blur_area_regs on 2 or 4 column strips (default), 0 = the LDS
  *                   band kernel k_blur_area_stream takes them (round 3)
+ *   "hash_regs"     k_blur_area_regs (blur input straight from global memory into registers): 0 = off (LDS band kernels),
+ *                   1 = on (default); images narrower than a workgroup share one side by side where that puts 15 % more
+ *                   of the lanes to work, 2 = on / never side by side, 3 = on / always, 4 = on / round 3's rule
  *   "hash_rows_per_step" source rows per step of k_blur_area_regs (7 x 7 blur): 0 = 14 always, 1 (default) = 14, 21 or 28,
  *                   whichever fills the row slots of the area phase's turns best for the workgroup size and the cells a
  *                   strip makes (192-thread workgroups: 21; column strips of wide images: 21 / 28; one-wave workgroups:
