@@ -3294,7 +3294,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
             const bool fuse = g_hash_fuse && fsm <= 160 * 1024 - 1024 && (integer || at.yrow) &&
                               (g_hash_fuse >= 2 ||
                                ((m + (size_t)ipb_f - 1) / (size_t)ipb_f >= fuse_min_wgs &&
-                                (size_t)w * (size_t)h <= (integer ? 400000u : 1100000u)));
+                                (size_t)w * (size_t)h <= (integer ? 1000000u : 1100000u)));
 #define CBH_REGS_L(KK, GG, KSV)                                                                              \
   do {                                                                                                       \
     if (fuse) {                                                                                              \
