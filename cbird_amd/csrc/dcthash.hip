@@ -566,6 +566,7 @@ __global__ __launch_bounds__(kThreads) void k_dcthash_256(
 // ds_read_b128 per column tile and step in the A-operand layout.  A wave is its own workgroup: no barriers in the loop.
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef float v2f_t __attribute__((ext_vector_type(2)));
+typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
 // the ring is written as pairs of dwords and read back as int4 operands (and reused as floats by the tail): accesses
 // that alias by design, so the compiler must not order them by type
 typedef int v4i_lds __attribute__((ext_vector_type(4), may_alias));
@@ -1613,7 +1614,11 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
   const int strip_out = steps * kStep - 2 * R;
   const int o0 = (int)blockIdx.y * strip_out;
   const int o1 = min(h, o0 + strip_out);
-  const unsigned char* __restrict__ img = imgs + (size_t)(lane_live ? img_i : blockIdx.z * (unsigned)ipb) * img_stride;
+  // Addresses = a workgroup-uniform 64-bit base (first image of the workgroup + the row: scalar registers) + a 32-bit
+  // per-lane offset that never changes (image slot + column): global loads in their `saddr` form, no vector address
+  // arithmetic per row (it took 4 of the 47 VALU instructions of a blur row).  The launcher keeps ipb * img_stride < 2^32.
+  const unsigned char* __restrict__ img = imgs + (size_t)(blockIdx.z * (unsigned)ipb) * img_stride;
+  const unsigned ioff = lane_live ? (unsigned)islot * (unsigned)img_stride : 0u;
   for (int i = tid; i < k_end; i += T) salpha[i] = xtab[i].alpha;
   // The 16-byte window of a lane (image bytes 8*tl - 4 .. 8*tl + 11) is assembled from three loads and v_perm_b32
   // with per-lane selectors (v_perm_b32(S0, S1, sel): selector 4..7 -> S0 byte 0..3, 0..3 -> S1 byte 0..3):
@@ -1667,7 +1672,7 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
       for (int j = 0; j < 3; ++j) selR |= (unsigned)(4 + src_of(w - m + j) - (w - 4)) << (8 * j);
     }
   }
-  offC += (unsigned)ox, offL += (unsigned)ox, offR += (unsigned)ox;
+  offC += (unsigned)ox + ioff, offL += (unsigned)ox + ioff, offR += (unsigned)ox + ioff;
   const int hp = ph ? ph : h;  // the rows above and below a view are the parent's; REFLECT_101 at the parent's edges
   // byte offset of (reflected, clamped) source row s.  REFLECT_101 as min(|y|, 2 (hp - 1) - |y|), clamped at 0 for the rows
   // prefetched far below a small image: five scalar instructions per row instead of the twelve of the compare-and-select
@@ -1733,17 +1738,25 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
   const int sfirst = o0 - R;  // first source row of the strip
   uint2 rawC[PF];
   unsigned rawL[PF], rawR[PF];
+  // (word 3: 32-bit data format, as the runtime's own descriptors on gfx9; untyped loads ignore it.  No stride, 4 GB of range)
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(img), 0, (int)0xffffffffu, 0x27000);
   auto load_row = [&](int s, uint2& c, unsigned& l, unsigned& r) {
-    const unsigned char* __restrict__ p = img + row_base(s);
+    const unsigned char* __restrict__ p = GEN ? img + row_base(s) : img;
     if constexpr (GEN) {  // any alignment
+      // (raw buffer loads work at odd addresses too but buy nothing here: 900x600 -5 %, 533x400 / 1366x768 +-1 %)
       c.x = *reinterpret_cast<const u32_any_align*>(p + offC);
       c.y = *reinterpret_cast<const u32_any_align*>(p + offC + 4);
       l = *reinterpret_cast<const u32_any_align*>(p + offL);
       r = *reinterpret_cast<const u32_any_align*>(p + offR);
     } else {
-      c = *reinterpret_cast<const uint2*>(p + offC);
-      l = *reinterpret_cast<const unsigned*>(p + offL);
-      r = *reinterpret_cast<const unsigned*>(p + offR);
+      // raw buffer loads: address = descriptor base (the workgroup's first image) + per-lane offset (VGPR, constant) + row
+      // offset (SGPR): no vector address arithmetic per row at all (the flat form spent 3-4 v_lshl_add_u64 per row)
+      (void)p;
+      const unsigned so = row_base(s);
+      const v2u_t c2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)offC, (int)so, 0);
+      c.x = c2.x, c.y = c2.y;
+      l = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)offL, (int)so, 0);
+      r = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)offR, (int)so, 0);
     }
   };
   // narrow images (L < 32) leave whole waves without a blur lane (the workgroup keeps 32 lanes per image for the area and
@@ -3264,7 +3277,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
             const int Tp = integer ? (ipb_try * Lr + 63) / 64 * 64 : 256;
             const bool pack = g_hash_regs == 3 || (g_hash_regs == 4 && Lr * 100 < Lw * 72) ||
                               (g_hash_regs == 1 && ipb_try > 1 && (long long)ipb_try * Lr * Lw * 100 >= 115LL * Lr * Tp);
-            const int ipb = pack ? ipb_try : 1;
+            const int ipb = (pack && (unsigned long long)ipb_try * img_stride < (1ull << 32)) ? ipb_try : 1;
             const size_t k_end_r = integer ? 0 : (((size_t)at.xn + 3) & ~(size_t)3) + 512;  // weights + per-cell edge weights
             // one pad dword per cell of a blurred LDS row where the cells would otherwise share banks 4 ways or more
             // ("hash_cell_pad": 0 never, 1 default, 2 from 2 ways on)
