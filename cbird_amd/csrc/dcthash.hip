@@ -1899,6 +1899,7 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
                 CBH_AREA_PIX4(wTb.x, wTb.y, wTb.z, wTb.w);
               }
             } else if (mid_ok) {
+#pragma unroll 2  // (the carried dwords lo_a / lo_b ping-pong between registers instead of being moved every word)
               for (int c = 1; c < nw_u - 2; ++c) {  // interior words: every pixel of every lane weighs a_mid
                 CBH_AREA_WORD(c);
                 CBH_AREA_PIX4(a_mid, a_mid, a_mid, a_mid);
