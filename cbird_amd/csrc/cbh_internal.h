@@ -155,6 +155,7 @@ void set_hash_area(int v);      // dcthash.hip: 1 = integer sums for the interio
 void set_hash_band_waves(int v);  // dcthash.hip: waves per workgroup of k_dcthash_256_band (1, 2)
 void set_hash_wide(int v);      // dcthash.hip: images wider than 2048 px on column strips of the register-streaming kernel (default 1)
 void set_hash_rows_per_step(int v);  // dcthash.hip: source rows per step of k_blur_area_regs<7> (0 = 14 always, 1 = 14 / 21 / 28 by turn fill, 21 / 28 forced)
+void set_hash_tiles2(int v);    // dcthash.hip: stages 3-6 of fused tiles two images per wave (default 1)
 void set_hash_cell_pad(int v);  // dcthash.hip: pad dword per cell of a blurred LDS row where cells would share banks (default 1: from 4 ways)
 void set_hash_regs(int v);      // dcthash.hip: register-streaming general-geometry kernel where applicable (default 1)
 void set_hash_div(int v);       // dcthash.hip: k_dcthash_256 divide-by-49 form, 1 = float magic (default), 0 = integer SDWA

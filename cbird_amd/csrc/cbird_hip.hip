@@ -1331,6 +1331,10 @@ int cbh_set_tuning(const char* key, int value) {
     set_hash_rows_per_step(value);
     return CBH_OK;
   }
+  if (!strcmp(key, "hash_tiles2")) {
+    set_hash_tiles2(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "hash_cell_pad")) {
     set_hash_cell_pad(value);
     return CBH_OK;

@@ -1997,6 +1997,106 @@ __global__ __launch_bounds__(kThreads) void k_tiles_hash(const unsigned char* __
   hash_from_tile(tile, sC, sZ, sT, sY, out + blockIdx.x, tabs);
 }
 
+// The same from two tiles per 64-thread workgroup, a half-wave per image (the tail of k_dcthash_256_band as a kernel of its
+// own): k_tiles_hash keeps four waves per image of which 32, then 9, then 64 lanes ever work.  "hash_tiles2" 1 (default).
+template <int DCT>
+__global__ __launch_bounds__(64) void k_tiles_hash2(const unsigned char* __restrict__ tiles_in, unsigned n,
+                                                    const DctTables* __restrict__ tabs, uint64_t* __restrict__ out,
+                                                    unsigned char* __restrict__ tiles_copy) {
+  __shared__ __attribute__((aligned(16))) unsigned char sTile[2][1024];
+  __shared__ __attribute__((aligned(16))) float sT[2 * 288], sY[2 * 84], sC[9 * 33];
+  const int lane = threadIdx.x, l32 = lane & 31, hw = lane >> 5;
+  const unsigned img = blockIdx.x * 2u + (unsigned)hw;
+  const bool valid = img < n;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const unsigned gi = min(blockIdx.x * 2u + (unsigned)g, n - 1u);
+    const uint4 v = reinterpret_cast<const uint4*>(tiles_in + (size_t)gi * 1024)[lane];
+    reinterpret_cast<uint4*>(sTile[g])[lane] = v;
+    if (tiles_copy && blockIdx.x * 2u + (unsigned)g < n) reinterpret_cast<uint4*>(tiles_copy + (size_t)gi * 1024)[lane] = v;
+  }
+  if constexpr (DCT == 0)
+    for (int i = lane; i < 288; i += 64) sC[(i >> 5) * 33 + (i & 31)] = tabs->C[i];
+  __syncthreads();
+  {
+    float x[32];
+    const uint4* trow = reinterpret_cast<const uint4*>(&sTile[hw][l32 * 32]);
+    const uint4 a = trow[0], b = trow[1];
+    const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      x[4 * i + 0] = (float)(w[i] & 0xffu);
+      x[4 * i + 1] = (float)((w[i] >> 8) & 0xffu);
+      x[4 * i + 2] = (float)((w[i] >> 16) & 0xffu);
+      x[4 * i + 3] = (float)(w[i] >> 24);
+    }
+    if constexpr (DCT == 1) {
+      float y[9];
+      cvdct::dct32_first9(x, &tabs->cv, y);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) sT[hw * 288 + l32 * 9 + k] = y[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) t = __builtin_fmaf(x[j], tabs->C[k * 32 + j], t);
+        sT[hw * 288 + l32 * 9 + k] = t;
+      }
+    }
+  }
+  __syncthreads();
+  if constexpr (DCT == 1) {
+    if (l32 < 9) {
+      float x[32], y[9];
+#pragma unroll
+      for (int r = 0; r < 32; ++r) x[r] = sT[hw * 288 + r * 9 + l32];
+      cvdct::dct32_first9(x, &tabs->cv, y);
+#pragma unroll
+      for (int u = 0; u < 9; ++u) sY[hw * 84 + u * 9 + l32] = y[u];
+    }
+  } else {
+#pragma unroll
+    for (int rep = 0; rep < 3; ++rep) {
+      const int o = l32 + 32 * rep;
+      if (o < 81) {
+        const int u = o / 9, k = o - u * 9;
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) t = __builtin_fmaf(sC[u * 33 + r], sT[hw * 288 + r * 9 + k], t);
+        sY[hw * 84 + o] = t;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const float c0 = sY[hw * 84 + tabs->zz[l32]];
+    const float c1 = sY[hw * 84 + tabs->zz[l32 + 32]];
+    const int cb0 = __builtin_bit_cast(int, c0), cb1 = __builtin_bit_cast(int, c1);
+    double sumA, sumB;
+    if constexpr (DCT == 1) {
+      sumA = cvdct::sum64_halfwave(cb0, cb1, 0);
+      sumB = cvdct::sum64_halfwave(cb0, cb1, 32);
+    } else {
+      sumA = 0.0, sumB = 0.0;
+#pragma unroll
+      for (int i = 0; i < 64; ++i) {
+        const int src = i < 32 ? cb0 : cb1;
+        sumA += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(src, i & 31));
+        sumB += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(src, 32 + (i & 31)));
+      }
+    }
+    const float thr = (float)(hw ? sumB : sumA) / 64;
+    const unsigned long long bb0 = __ballot(c0 > thr);
+    const unsigned long long bb1 = __ballot(c1 > thr);
+    const int sh = hw * 32;
+    unsigned long long hv = ((bb0 >> sh) & 0xffffffffull) | (((bb1 >> sh) & 0xffffffffull) << 32);
+    hv &= ~1ull;  // bit 0 is never encoded (cvutil.cpp:537)
+    if (hv == 0) hv = 1;
+    if (l32 == 0 && valid) out[img] = hv;
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void k_tile_hash(const float* __restrict__ rows, int yn,
                                                         const AreaTab* __restrict__ ytab,
                                                         const int* __restrict__ yfirst, int isx, int isy,
@@ -2803,6 +2903,8 @@ int g_hash_area = 0;  // "hash_area": 1 = k_blur_area_regs sums the interior pix
 void set_hash_area(int v) { g_hash_area = v ? 1 : 0; }
 int g_hash_wide = 1;  // "hash_wide": images wider than 2048 on column strips of k_blur_area_regs (1, default) or on the LDS band kernel (0)
 void set_hash_wide(int v) { g_hash_wide = v ? 1 : 0; }
+int g_hash_tiles2 = 1;  // "hash_tiles2": stages 3-6 of the fused strip kernel's tiles two images per wave (k_tiles_hash2; 0 = k_tiles_hash)
+void set_hash_tiles2(int v) { g_hash_tiles2 = v ? 1 : 0; }
 int g_hash_cell_pad = 1;  // "hash_cell_pad": pad dword behind every cell of a blurred LDS row (k_blur_area_regs, integer ratios): 0 never,
                           // 1 (default) where the cells would share LDS banks 4 ways or more, 2 from 2 ways on
 void set_hash_cell_pad(int v) { g_hash_cell_pad = v < 0 ? 0 : v > 2 ? 2 : v; }
@@ -3354,7 +3456,15 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
 #undef CBH_REGS_L
 #undef CBH_REGS_
 #undef CBH_REGS
-            if (fuse)
+            if (fuse && g_hash_tiles2) {
+              unsigned char* tcopy = d_tiles ? d_tiles + i0 * 1024 : nullptr;
+              if (g_hash_dct)
+                hipLaunchKernelGGL(k_tiles_hash2<1>, dim3((unsigned)((m + 1) / 2)), dim3(64), 0, stream, d_ftiles, (unsigned)m, tabs,
+                                   d_out + i0, tcopy);
+              else
+                hipLaunchKernelGGL(k_tiles_hash2<0>, dim3((unsigned)((m + 1) / 2)), dim3(64), 0, stream, d_ftiles, (unsigned)m, tabs,
+                                   d_out + i0, tcopy);
+            } else if (fuse)
               hipLaunchKernelGGL(k_tiles_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_ftiles, tabs, d_out + i0,
                                  d_tiles ? d_tiles + i0 * 1024 : nullptr);
             else

@@ -735,6 +735,8 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *                   whichever fills the row slots of the area phase's turns best for the workgroup size and the cells a
  *                   strip makes (192-thread workgroups: 21; column strips of wide images: 21 / 28; one-wave workgroups:
  *                   28), 21 / 28 = that many wherever the LDS allows.  Same results.
+ *   "hash_tiles2"   1 (default) = the DCT / threshold / bit stages of the fused strip kernel's tiles run two images per
+ *                   64-thread workgroup (k_tiles_hash2), 0 = one image per 256 threads (k_tiles_hash).  Same results.
  *   "hash_cell_pad" k_blur_area_regs at integer ratios: one pad dword behind every cell of a blurred row in LDS, so that the
  *                   32 lanes that read their cells' dwords together use 32 banks: 0 = never, 1 = where cells would share a
  *                   bank 4 ways or more (default: 512, 1024, 1536, 2048, 2560 px ...), 2 = from 2 ways on.  Same results.

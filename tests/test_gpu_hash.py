@@ -155,6 +155,37 @@ def test_hash_rows_per_step_changes_nothing(gpu, orc, w, h):
         L.cbh_set_tuning(b"hash_stream", 1)
 
 
+@pytest.mark.parametrize("n", [1, 2, 5, 33])
+def test_fused_tiles_are_hashed_two_per_wave_or_one_per_workgroup(gpu, orc, hash_dct, n):
+    """stages 3-6 of the fused strip kernel's tiles: k_tiles_hash2 (two images per 64-thread workgroup, "hash_tiles2" 1, the
+    default) and k_tiles_hash (one image per 256 threads) under both DCT evaluations; odd counts leave half a workgroup
+    empty; the tiles handed back are the oracle's"""
+    import torch
+
+    from cbird_amd import _lib
+
+    L = _lib.lib()
+    w, h = 400, 300
+    rng = np.random.default_rng(5 + n)
+    imgs = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+    want = orc.dcthash64_batch(imgs)
+    d = torch.from_numpy(imgs).cuda()
+    try:
+        L.cbh_set_tuning(b"hash_fuse", 2)
+        for knob in (1, 0):
+            L.cbh_set_tuning(b"hash_tiles2", knob)
+            assert (gpu.dct_hash64_batch(imgs) == want).all(), (n, knob)
+            out = torch.zeros(n, dtype=torch.int64, device="cuda")
+            tiles = torch.zeros((n, 32, 32), dtype=torch.uint8, device="cuda")
+            _lib.check(L.cbh_dcthash_tiles_dev(d.data_ptr(), n, w, h, w, w * h, out.data_ptr(), tiles.data_ptr(), 0, None), "t")
+            t = tiles.cpu().numpy()
+            assert all((t[i] == orc.tile32(imgs[i])).all() for i in range(n)), (n, knob)
+            assert (out.cpu().numpy().view(np.uint64) == want).all(), (n, knob)
+    finally:
+        L.cbh_set_tuning(b"hash_fuse", 1)
+        L.cbh_set_tuning(b"hash_tiles2", 1)
+
+
 def test_hash_edge_images(gpu, orc, hash256_kernel):
     imgs = np.zeros((6, 256, 256), np.uint8)
     imgs[1] = 255
