@@ -559,6 +559,23 @@ def features_leg(torch, dev):
                                       "autocrop(20) + dctHash64 + near-frame filter (threshold 8)",
                           "s": round(best, 5), "frames_per_s": n / best, "GBps": n * w * h / best / 1e9,
                           "frames_stored": stored}
+    del frames
+    # ---- dctHash64 at the sizes the indexer feeds (not 256 x 256): resident batches of 4 GB, the general-geometry kernels
+    # (k_blur_area_regs + k_tiles_hash2 / k_tile_hash); kernel time from the library's own events (cbh_time_dcthash_dev)
+    geo = []
+    msv = C.c_float(0)
+    for (w, h) in ((400, 300), (533, 400), (640, 480), (1024, 768), (1920, 1080), (4000, 3000)):
+        n = max(64, int(4e9 // (w * h)))
+        imgs = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device=dev)
+        hashes = torch.empty(n, dtype=torch.int64, device=dev)
+        best = None
+        for _ in range(2):
+            _lib.check(L.cbh_time_dcthash_dev(imgs.data_ptr(), n, w, h, w, w * h, hashes.data_ptr(), 0, 3, C.byref(msv)), "hash")
+            best = msv.value if best is None else min(best, msv.value)
+        geo.append({"w": w, "h": h, "images": n, "ms": round(best, 3), "images_per_s": n / best * 1e3,
+                    "GBps": n * w * h / best * 1e-6, "hbm_frac": n * w * h / best * 1e-6 / 8000.0})
+        del imgs, hashes
+    out["dct_hash_by_geometry"] = geo
     return out
 
 
