@@ -217,6 +217,7 @@ _SIGS = {
     "cbh_color_find_batch": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _vp]),
     "cbh_usable_device_mask": (C.c_uint32, []),
     "cbh_last_error_code": (C.c_int, []),
+    "cbh_clear_error": (None, []),
     "cbh_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "cbh_get_tuning": (C.c_int, [C.c_char_p, C.POINTER(C.c_longlong)]),
     "cbh_idx64_get_stats": (C.c_int, [_vp, C.POINTER(cbh_stats)]),

@@ -142,7 +142,7 @@ class GpuDctHashIndex : public Index {
     for (uint32_t id : mediaIds) ids.push_back(id);
     cbh_idx64* sub = cbh_idx64_slice(_idx, ids.data(), ids.size());
     if (!sub && cbh_last_error_code() == CBH_E_NOMEM) {  // transient: give cached scratch back, once more
-      gpuidx::releaseScratch();
+      gpuidx::releaseScratch(cbh_idx64_device_mask(_idx));
       sub = cbh_idx64_slice(_idx, ids.data(), ids.size());
     }
     if (!sub) {  // a slice that cannot be made is an empty one (its searches find nothing), not the end of the process
@@ -218,12 +218,12 @@ class GpuDctHashIndex : public Index {
   // the reference has no error codes on this surface (gpu_errors.h, gpuidx::run): load/add/remove retry once after
   // releasing cached scratch and then abort like the reference's failed allocation; find & co. log and return nothing
   template <class Call>
-  static void mutate(const char* what, Call&& call) {
-    (void)gpuidx::run(gpuidx::Mutation, (std::string("GpuDctHashIndex::") + what).c_str(), call);
+  void mutate(const char* what, Call&& call) const {
+    (void)gpuidx::run(gpuidx::Mutation, (std::string("GpuDctHashIndex::") + what).c_str(), call, cbh_idx64_device_mask(_idx));
   }
   template <class Call>
-  static bool query(const char* what, Call&& call) {
-    return gpuidx::run(gpuidx::Query, (std::string("GpuDctHashIndex::") + what).c_str(), call);
+  bool query(const char* what, Call&& call) const {
+    return gpuidx::run(gpuidx::Query, (std::string("GpuDctHashIndex::") + what).c_str(), call, cbh_idx64_device_mask(_idx));
   }
   int _device;
   cbh_idx64* _idx;

@@ -29,8 +29,8 @@
 
 // gpu_errors.h (gpuidx::run): a mutation that fails after one retry aborts like the reference's failed allocation; a
 // query that fails logs with qCritical and the caller returns its empty result
-#define CBH_MUTATE(call) (void)gpuidx::run(gpuidx::Mutation, #call, [&] { return (call); })
-#define CBH_QUERY(call) gpuidx::run(gpuidx::Query, #call, [&] { return (call); })
+#define CBH_MUTATE(call) (void)gpuidx::run(gpuidx::Mutation, #call, [&] { return (call); }, this->scratchMask())
+#define CBH_QUERY(call) gpuidx::run(gpuidx::Query, #call, [&] { return (call); }, this->scratchMask())
 
 // ---- DctFeaturesIndex ---------------------------------------------------------------------------------
 class GpuDctFeaturesIndex : public DctFeaturesIndex {  // inherits createTables/addRecords/removeRecords/mediaIds
@@ -77,7 +77,7 @@ class GpuDctFeaturesIndex : public DctFeaturesIndex {  // inherits createTables/
     std::vector<uint32_t> ids(mediaIds.begin(), mediaIds.end());
     cbh_idx64* sub = cbh_idx64_slice(_idx, ids.data(), ids.size());
     if (!sub && cbh_last_error_code() == CBH_E_NOMEM) {  // transient: give cached scratch back, once more
-      gpuidx::releaseScratch();
+      gpuidx::releaseScratch(scratchMask());
       sub = cbh_idx64_slice(_idx, ids.data(), ids.size());
     }
     if (!sub) {  // a slice that cannot be made is an empty one (its searches find nothing), not the end of the process
@@ -127,6 +127,7 @@ class GpuDctFeaturesIndex : public DctFeaturesIndex {  // inherits createTables/
   }
 
   cbh_idx64* handle() const { return _idx; }  // for statistics (cbh_combine_stats)
+  uint32_t scratchMask() const { return cbh_idx64_device_mask(_idx); }  // the devices this index lives on
 
  private:
   GpuDctFeaturesIndex(cbh_idx64* adopted, bool treeCompat) : _idx(adopted), _treeCompat(treeCompat) {}
@@ -234,6 +235,7 @@ class GpuCvFeaturesIndex : public CvFeaturesIndex {
   }
 
   cbh_idx256* handle() const { return _idx; }  // for statistics (cbh_combine_stats)
+  uint32_t scratchMask() const { return _devs.single() ? 1u << _device : _devs.mask; }  // the devices this index lives on
 
  private:
   int _device = 0;
@@ -344,6 +346,7 @@ class GpuColorDescIndex : public ColorDescIndex {
   }
 
   cbh_color* handle() const { return _idx; }  // for statistics (cbh_combine_stats)
+  uint32_t scratchMask() const { return 1u << _device; }
 
  private:
   int _device = 0;
@@ -458,6 +461,7 @@ class GpuDctVideoIndex : public DctVideoIndex {
     _ids.insert(id);
   }
   std::set<uint32_t> _ids;  // what DctVideoIndex::_mediaId holds in the reference
+  uint32_t scratchMask() const { return _devs.single() ? 1u << _device : _devs.mask; }
   int _device = 0;
   GpuDeviceSet _devs;  // (declared before _idx: the sharded constructor initialises it first)
   cbh_vidx* _idx;

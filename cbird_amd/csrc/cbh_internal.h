@@ -17,13 +17,19 @@ namespace cbh {
 void combiner_drop(const void* handle);  // combine.hip
 void set_last_error(const char* where, hipError_t e);
 void set_last_error_text(const char* text);  // non-HIP failures (RCCL)
+// The thread's error state is per call for the entry points that return a handle: clear_last_error() on entry, and every
+// NULL return goes through fail_handle(code, why) so that cbh_last_error_code() names THIS failure, never an older one.
+void clear_last_error();
+void set_last_error_code(int code);  // keeps the text (a successful fall-back leaves its note, not an error code)
+void* fail_handle(int code, const char* why);  // sets code + text (text kept if `why` is null and a text exists), returns nullptr
 
 // ---- stream-ordered scratch memory (cbird_hip.hip) ------------------------------------------------------------------
 // Every kernel launcher takes its scratch with malloc_async(&p, bytes, stream) and gives it back with
 // free_async(p, stream) right behind the last kernel that uses it (the contract of hipMallocAsync / hipFreeAsync).
 // cbh_set_tuning("scratch_alloc", v) picks the source:
 //   2 (default)  the library's own arena: hipMalloc'ed blocks cached per (device, stream), reused only by the stream
-//                that freed them; bounded ("pool_keep_mb" per stream, 32 stream caches, cbh_trim)
+//                that freed them; bounded ("pool_live_keep_mb" per live stream, "pool_keep_mb" for
+//                blocks that outlive theirs, 32 stream caches, cbh_trim)
 //   1            one ROCm hipMemPool_t per stream (round 2)         } both hand out memory that is still in use on
 //   0            ROCm's default pool (plain hipMallocAsync)         } this stack: tools/ubench/pool_cross_stream.hip
 hipError_t malloc_async(void** p, size_t bytes, hipStream_t s);
@@ -33,6 +39,7 @@ void stream_destroy(hipStream_t s);
 void set_scratch_mode(int v);
 void set_scratch_poison(int v);
 void set_pool_keep_mb(int mb);
+void set_pool_live_keep_mb(int mb);
 int trim_pools(int device, unsigned long long* released_bytes);
 // The scratch of one launcher: every block taken through get() goes back with free_async on the same stream when the
 // guard leaves scope -- behind the kernels that were queued, and on every early return (a later allocation that fails,

@@ -34,6 +34,18 @@ void set_last_error_text(const char* text) {
   t_last_error = text ? text : "";
   t_last_code = CBH_E_UNSUPPORTED;
 }
+void clear_last_error() {
+  t_last_error.clear();
+  t_last_code = CBH_OK;
+}
+void set_last_error_code(int code) { t_last_code = code; }
+void* fail_handle(int code, const char* why) {
+  // a HIP / RCCL failure underneath has already said what happened (and NOMEM is worth keeping: callers retry on it)
+  if (t_last_code == CBH_OK || why) t_last_code = code;
+  if (why) t_last_error = why;
+  else if (t_last_error.empty()) t_last_error = cbh_strerror(code);
+  return nullptr;
+}
 
 // ---- stream-ordered scratch (see cbh_internal.h) --------------------------------------------------------------------
 // Mode 2 (default): the library's own arena.  Blocks are plain hipMalloc memory, cached per (device, stream); a block
@@ -67,8 +79,9 @@ struct Arena {
   std::map<void*, LiveInfo> live;  // blocks handed out by mode 2
   // blocks a live stream's cache gave up because it exceeded the budget: work queued on that stream may still use them,
   // so each waits for an event recorded behind that work and goes back to the driver once it has completed
+  // (one event per trim: the blocks a single free_async gave up wait behind the same point of the stream)
   struct Pending {
-    void* p;
+    std::vector<Block> blocks;
     size_t bytes;
     int dev;
     hipEvent_t ev;
@@ -86,6 +99,26 @@ int g_scratch_mode = 2;
 int g_scratch_poison = 0;  // "scratch_poison": v > 0 fills every block handed out with byte v - 1 (finds kernels that
                            // read scratch they never wrote: fresh driver memory is zero, a recycled block is not)
 uint64_t g_pool_keep_bytes = (uint64_t)16 << 30;  // cached scratch that outlives its stream, per device ("pool_keep_mb")
+// What a LIVE stream's cache may hold ("pool_live_keep_mb").  A budget of its own: the working set of one call can be
+// far above what is worth keeping for streams that are gone (ColorDescriptor::create takes ~50 GB of scratch per 10^5
+// images, one block of it > 16 GiB; released and re-mapped every call it costs 2.3 s instead of 0.31 s per call, NOTES 7),
+// and whatever is cached stays reclaimable -- an allocation the driver refuses gives the caches back before it fails.
+// 0 = a quarter of the device's memory (72 GB of an MI355X's 288), never below the orphan budget's default.
+uint64_t g_pool_live_keep_bytes = 0;
+uint64_t g_live_auto[32] = {};
+uint64_t live_budget(int dev) {
+  if (g_pool_live_keep_bytes) return g_pool_live_keep_bytes;
+  if (dev < 0 || dev >= 32) return (uint64_t)16 << 30;
+  if (!g_live_auto[dev]) {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
+      (void)hipGetLastError();
+      return (uint64_t)16 << 30;
+    }
+    g_live_auto[dev] = std::max<uint64_t>((uint64_t)16 << 30, (uint64_t)tot / 4);
+  }
+  return g_live_auto[dev];
+}
 
 // fault injection (cbh_internal.h): countdowns, -1 = disarmed
 std::atomic<long> g_fault_alloc{-1}, g_fault_driver{-1};
@@ -207,11 +240,11 @@ void reap_pending(Arena& A, std::vector<void*>* to_free, std::vector<hipEvent_t>
       continue;
     }
     (void)hipGetLastError();
-    to_free->push_back(A.pending[i].p);
+    for (Block& b : A.pending[i].blocks) to_free->push_back(b.p);
+    A.n_released += A.pending[i].blocks.size();
     evs->push_back(A.pending[i].ev);
-    A.pending[i] = A.pending.back();
+    A.pending[i] = std::move(A.pending.back());
     A.pending.pop_back();
-    A.n_released++;
   }
 }
 // the driver's allocation of one arena block, through the "fault_driver_oom" gate
@@ -226,6 +259,7 @@ hipError_t driver_malloc(void** p, size_t bytes) {
 }  // namespace
 
 void set_scratch_mode(int v) { g_scratch_mode = v < 0 ? 0 : v > 2 ? 2 : v; }
+void set_pool_live_keep_mb(int mb) { g_pool_live_keep_bytes = mb < 0 ? ~0ull : (uint64_t)mb << 20; }  // 0 = automatic
 void set_pool_keep_mb(int mb) {
   g_pool_keep_bytes = mb < 0 ? ~0ull : (uint64_t)mb << 20;
   Arena& A = arena();
@@ -353,9 +387,9 @@ static hipError_t malloc_async_raw(void** p, size_t bytes, hipStream_t s) {
       A.orphan_bytes[dev] = 0;
       for (size_t i = 0; i < A.pending.size();)
         if (A.pending[i].dev == dev) {
-          all.push_back(A.pending[i].p);
+          for (Block& b : A.pending[i].blocks) all.push_back(b.p);
           pev.push_back(A.pending[i].ev);
-          A.pending[i] = A.pending.back();
+          A.pending[i] = std::move(A.pending.back());
           A.pending.pop_back();
         } else {
           ++i;
@@ -390,25 +424,28 @@ hipError_t free_async(void* p, hipStream_t s) {
     c.free.push_back(Block{p, info.bytes});
     c.free_bytes += info.bytes;
     // A live stream keeps what it has used (the next call of the same caller finds its buffers mapped) up to the
-    // budget of "pool_keep_mb"; beyond it the blocks freed longest ago leave the cache.  Work queued on s may still
-    // use them, so they wait in the pending list behind an event recorded now.
-    if (c.free_bytes > g_pool_keep_bytes) {
+    // budget of "pool_live_keep_mb"; beyond it the blocks freed longest ago leave the cache.  Work queued on s may
+    // still use them, so they wait in the pending list behind ONE event recorded now.
+    const uint64_t budget = live_budget(info.dev);
+    if (c.free_bytes > budget) {
       hipEvent_t ev = nullptr;
-      size_t k = 0;
-      while (k < c.free.size() && c.free_bytes > g_pool_keep_bytes) {
-        hipEvent_t e1 = nullptr;
-        if (hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) break;
-        if (hipEventRecord(e1, s) != hipSuccess) {
-          (void)hipEventDestroy(e1);
-          break;
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+        if (hipEventRecord(ev, s) == hipSuccess) {
+          Arena::Pending pd{{}, 0, info.dev, ev};
+          size_t k = 0;
+          while (k < c.free.size() && c.free_bytes > budget) {
+            pd.blocks.push_back(c.free[k]);
+            pd.bytes += c.free[k].bytes;
+            c.free_bytes -= c.free[k].bytes;
+            A.n_trimmed_live++;
+            ++k;
+          }
+          c.free.erase(c.free.begin(), c.free.begin() + (long)k);
+          A.pending.push_back(std::move(pd));
+        } else {
+          (void)hipEventDestroy(ev);
         }
-        ev = e1;
-        A.pending.push_back(Arena::Pending{c.free[k].p, c.free[k].bytes, info.dev, ev});
-        c.free_bytes -= c.free[k].bytes;
-        A.n_trimmed_live++;
-        ++k;
       }
-      c.free.erase(c.free.begin(), c.free.begin() + (long)k);
       (void)hipGetLastError();
     }
   }
@@ -547,6 +584,7 @@ const char* cbh_strerror(int code) {
 const char* cbh_last_error(void) { return t_last_error.c_str(); }
 
 int cbh_last_error_code(void) { return t_last_code; }
+void cbh_clear_error(void) { clear_last_error(); }
 
 int cbh_trim(int device, unsigned long long* released_bytes) {
   if (released_bytes) *released_bytes = 0;
@@ -803,9 +841,11 @@ int cbh_dcthash_rects(const uint8_t* imgs, size_t imgs_bytes, size_t n, const ui
 /* ---- DctHashIndex ----------------------------------------------------------------------- */
 
 cbh_idx64* cbh_idx64_create(int device) {
-  if (!device_usable(device)) return nullptr;
+  clear_last_error();
+  if (!device_usable(device)) return (cbh_idx64*)fail_handle(CBH_E_NODEVICE, "cbh_idx64_create: no usable gfx950 device at that ordinal");
   cbh_idx64* idx = new (std::nothrow) cbh_idx64;
-  if (idx) idx->device = device;
+  if (!idx) return (cbh_idx64*)fail_handle(CBH_E_NOMEM, "cbh_idx64_create: host allocation failed");
+  idx->device = device;
   return idx;
 }
 
@@ -972,10 +1012,12 @@ int cbh_idx64_media_ids(const cbh_idx64* idx, uint32_t* out, size_t cap, size_t*
 }
 
 cbh_idx64* cbh_idx64_slice(const cbh_idx64* idx, const uint32_t* ids, size_t n) {
-  if (!idx || !idx->loaded) return nullptr;  // Q_ASSERT(isLoaded()) (:223)
+  clear_last_error();
+  if (!idx || !idx->loaded)  // Q_ASSERT(isLoaded()) (:223)
+    return (cbh_idx64*)fail_handle(CBH_E_INVAL, "cbh_idx64_slice: the index is not loaded");
   std::vector<uint64_t> h(idx->n);
   std::vector<uint32_t> id(idx->n);
-  if (cbh_idx64_download(idx, h.data(), id.data(), idx->n)) return nullptr;
+  if (int rc = cbh_idx64_download(idx, h.data(), id.data(), idx->n)) return (cbh_idx64*)fail_handle(rc, nullptr);
   std::vector<uint32_t> want(ids, ids + (ids ? n : 0));
   std::sort(want.begin(), want.end());
   std::vector<uint64_t> sh;
@@ -988,10 +1030,10 @@ cbh_idx64* cbh_idx64_slice(const cbh_idx64* idx, const uint32_t* ids, size_t n) 
   // a slice of a sharded index is sharded the same way (Database::similarTo searches it like the whole index)
   cbh_idx64* out = idx->shards ? cbh_idx64_create_sharded(cbh_idx64_device_mask(idx), cbh_idx64_shards_per_device(idx))
                                : cbh_idx64_create(idx->device);
-  if (!out) return nullptr;
-  if (cbh_idx64_load(out, sh.data(), si.data(), sh.size())) {
+  if (!out) return nullptr;  // (the create call has set the code)
+  if (int rc = cbh_idx64_load(out, sh.data(), si.data(), sh.size())) {
     cbh_idx64_destroy(out);
-    return nullptr;
+    return (cbh_idx64*)fail_handle(rc, nullptr);
   }
   return out;
 }
@@ -1442,6 +1484,10 @@ int cbh_set_tuning(const char* key, int value) {
   }
   if (!strcmp(key, "pool_keep_mb")) {
     set_pool_keep_mb(value);
+    return CBH_OK;
+  }
+  if (!strcmp(key, "pool_live_keep_mb")) {
+    set_pool_live_keep_mb(value);
     return CBH_OK;
   }
   if (!strcmp(key, "shard_force_rccl")) {

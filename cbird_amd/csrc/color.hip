@@ -559,9 +559,11 @@ int run_dist(cbh_color* c, const uint8_t* needle_descs, size_t nq, float* d_raw 
 extern "C" {
 
 cbh_color* cbh_color_create(int device) {
-  if (!cbh::device_usable(device)) return nullptr;
+  cbh::clear_last_error();
+  if (!cbh::device_usable(device)) return (cbh_color*)cbh::fail_handle(CBH_E_NODEVICE, "cbh_color_create: no usable gfx950 device at that ordinal");
   cbh_color* c = new (std::nothrow) cbh_color;
-  if (c) c->device = device;
+  if (!c) return (cbh_color*)cbh::fail_handle(CBH_E_NOMEM, "cbh_color_create: host allocation failed");
+  c->device = device;
   return c;
 }
 

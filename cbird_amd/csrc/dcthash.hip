@@ -2826,15 +2826,14 @@ void make_band_tables(BandTables* bt) {
 
 struct BandTabCache {
   std::mutex mu;
-  BandTables* d[16] = {};
+  std::map<int, BandTables*> d;  // by device ordinal (usable-device masks go up to ordinal 31)
 } g_band_tabs;
 
 int get_band_tables(const BandTables** out) {
   int dev = 0;
   CBH_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 16) return CBH_E_INVAL;
   std::lock_guard<std::mutex> lk(g_band_tabs.mu);
-  if (!g_band_tabs.d[dev]) {
+  if (!g_band_tabs.d.count(dev)) {
     std::vector<BandTables> host(1);
     make_band_tables(host.data());
     BandTables* d = nullptr;
@@ -3647,7 +3646,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
       img_stride % 8 == 0 && row_stride * 256 < (1u << 24) && img_stride < (1u << 28)) {
     if (g_hash_mfma != 0 && ((uintptr_t)d_imgs % 16) == 0 && row_stride % 16 == 0 && img_stride % 16 == 0) {
       const BandTables* btab = nullptr;
-      if ((rc = get_band_tables(&btab))) return rc;
+      if (get_band_tables(&btab) != CBH_OK) goto valu_256;  // no table on this device: the all-VALU kernel needs none
       dim3 gridb((unsigned)((n + 3) / 4));
 #define CBH_BAND_(DUMP_, DCT_, NW_)                                                                                \
   hipLaunchKernelGGL((k_dcthash_256_band<DUMP_, DCT_, NW_>), gridb, dim3(64 * NW_), 0, stream, d_imgs, (unsigned)n, \
@@ -3667,6 +3666,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
       CBH_HIP(hipGetLastError());
       return CBH_OK;
     }
+  valu_256:
     dim3 grid((unsigned)((n + 7) / 8)), block(kThreads);
 #define CBH_256(DUMP_, DCT_, DIV_)                                                                         \
   hipLaunchKernelGGL((k_dcthash_256<DUMP_, DCT_, DIV_>), grid, block, (size_t)g_hash_lds_pad, stream, d_imgs, \

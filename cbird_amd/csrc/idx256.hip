@@ -520,26 +520,28 @@ void score256(const cbh_idx256* ix, const uint32_t* row, const uint16_t* dist, c
 extern "C" {
 
 cbh_idx256* cbh_idx256_create(int device) {
-  if (!cbh::device_usable(device)) return nullptr;
+  cbh::clear_last_error();
+  if (!cbh::device_usable(device)) return (cbh_idx256*)cbh::fail_handle(CBH_E_NODEVICE, "cbh_idx256_create: no usable gfx950 device at that ordinal");
   cbh_idx256* ix = new (std::nothrow) cbh_idx256;
-  if (ix) {
-    ix->device = device;
-    ix->first_row.push_back(0);
-    ix->media_id.push_back(0);
-  }
+  if (!ix) return (cbh_idx256*)cbh::fail_handle(CBH_E_NOMEM, "cbh_idx256_create: host allocation failed");
+  ix->device = device;
+  ix->first_row.push_back(0);
+  ix->media_id.push_back(0);
   return ix;
 }
 
 cbh_idx256* cbh_idx256_create_sharded(uint32_t device_mask, int shards_per_device) {
+  cbh::clear_last_error();
   Shards256* S = new (std::nothrow) Shards256;
-  if (!S || !S->comm.init(device_mask, shards_per_device)) {
+  if (!S) return (cbh_idx256*)cbh::fail_handle(CBH_E_NOMEM, "cbh_idx256_create_sharded: host allocation failed");
+  if (!S->comm.init(device_mask, shards_per_device)) {
     delete S;
-    return nullptr;
+    return (cbh_idx256*)cbh::fail_handle(CBH_E_INVAL, "cbh_idx256_create_sharded: empty mask, a device of the mask is not usable, or shards_per_device out of range");
   }
   cbh_idx256* ix = cbh_idx256_create(S->comm.devices[0]);
   if (!ix) {
     delete S;
-    return nullptr;
+    return nullptr;  // (cbh_idx256_create has set the code)
   }
   ix->shards = S;
   const size_t R = S->comm.shard_count();

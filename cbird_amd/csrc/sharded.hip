@@ -170,6 +170,7 @@ int ShardComm::exchange(std::vector<ShardPart>& parts, hipStream_t root_stream, 
       collective = false;
       if (!n_fallbacks.fetch_add(1))
         fprintf(stderr, "cbird_hip: sharded index exchanges by device copies, not ncclAllGather (%s)\n", cbh_last_error());
+      set_last_error_code(CBH_OK);  // absorbed: the note stays in cbh_last_error, the call has not failed
     }
   }
   // per-device totals, the place of every shard inside its device's run, and of every device in the destination
@@ -551,12 +552,18 @@ int sharded_remove(cbh_idx64* idx, const uint32_t* ids, size_t n, int zero_hash)
 extern "C" {
 
 cbh_idx64* cbh_idx64_create_sharded(uint32_t device_mask, int shards_per_device) {
+  clear_last_error();
   cbh_idx64* idx = new (std::nothrow) cbh_idx64;
   ShardSet* S = new (std::nothrow) ShardSet;
-  if (!idx || !S || !S->comm.init(device_mask, shards_per_device)) {
+  if (!idx || !S) {
     delete idx;
     delete S;
-    return nullptr;
+    return (cbh_idx64*)fail_handle(CBH_E_NOMEM, "cbh_idx64_create_sharded: host allocation failed");
+  }
+  if (!S->comm.init(device_mask, shards_per_device)) {
+    delete idx;
+    delete S;
+    return (cbh_idx64*)fail_handle(CBH_E_INVAL, "cbh_idx64_create_sharded: empty mask, a device of the mask is not usable, or shards_per_device out of range");
   }
   idx->device = S->comm.devices[0];
   idx->shards = S;

@@ -285,15 +285,17 @@ int find_videos(cbh_vidx* v, const int32_t* frames, const uint64_t* hashes, cons
 extern "C" {
 
 cbh_vidx* cbh_vidx_create(int device) {
-  if (!device_usable(device)) return nullptr;
+  clear_last_error();
+  if (!device_usable(device)) return (cbh_vidx*)fail_handle(CBH_E_NODEVICE, "cbh_vidx_create: no usable gfx950 device at that ordinal");
   cbh_vidx* v = new (std::nothrow) cbh_vidx;
-  if (v) v->device = device;
+  if (!v) return (cbh_vidx*)fail_handle(CBH_E_NOMEM, "cbh_vidx_create: host allocation failed");
+  v->device = device;
   return v;
 }
 
 cbh_vidx* cbh_vidx_create_sharded(uint32_t device_mask, int shards_per_device) {
   cbh_idx64* probe = cbh_idx64_create_sharded(device_mask, shards_per_device);  // validates the mask
-  if (!probe) return nullptr;
+  if (!probe) return nullptr;  // (code set by the probe)
   cbh_vidx* v = new (std::nothrow) cbh_vidx;
   if (v) {
     v->device = probe->device;
@@ -301,6 +303,7 @@ cbh_vidx* cbh_vidx_create_sharded(uint32_t device_mask, int shards_per_device) {
     v->shards_per_device = shards_per_device;
   }
   cbh_idx64_destroy(probe);
+  if (!v) return (cbh_vidx*)fail_handle(CBH_E_NOMEM, "cbh_vidx_create_sharded: host allocation failed");
   return v;
 }
 

@@ -145,9 +145,10 @@ bool frames_ok(const void* p, size_t n, int w, int h, size_t row_stride, size_t 
 extern "C" {
 
 cbh_vindexer* cbh_vindexer_create(int device, int threshold, int autocrop_range) {
-  if (!cbh::device_usable(device)) return nullptr;
+  cbh::clear_last_error();
+  if (!cbh::device_usable(device)) return (cbh_vindexer*)cbh::fail_handle(CBH_E_NODEVICE, "cbh_vindexer_create: no usable gfx950 device at that ordinal");
   cbh::DeviceGuard g(device);
-  if (!g.ok) return nullptr;
+  if (!g.ok) return (cbh_vindexer*)cbh::fail_handle(CBH_E_NODEVICE, nullptr);
   cbh_vindexer* v = new cbh_vindexer;
   v->device = device;
   v->threshold = threshold;

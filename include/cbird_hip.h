@@ -74,11 +74,16 @@ const char* cbh_last_error(void);       /* thread-local detail of the last failu
 /* the CBH_E_* that goes with cbh_last_error() -- for the entry points that return a handle (create / slice): NULL
  * says "failed", this says whether it was CBH_E_NOMEM (transient: cbh_trim and try again) or something else */
 int cbh_last_error_code(void);
+/* Forget the thread's last error (text and code).  The entry points that return a handle do this themselves on entry;
+ * a caller that decides on cbh_last_error_code() after an int-returning call (the adapters' retry-after-trim rule,
+ * cbird_amd/cpp/gpu_errors.h) clears first so that the code it reads belongs to that call. */
+void cbh_clear_error(void);
 /* Scratch memory.  Kernel scratch comes from the library's own stream-ordered arena: hipMalloc'ed blocks cached per
  * (device, stream) -- a freed block is reused only by the stream that freed it, so the next call on that stream finds
  * its buffers mapped.  A stream's cache lives as long as the stream: when the library destroys one of its own streams,
  * or finds a caller's stream gone or idle while more than 32 streams have caches, the blocks move to a per-device
- * list any stream may take from, of which at most "pool_keep_mb" (default 16384) stay cached.  cbh_trim synchronises
+ * list any stream may take from, of which at most "pool_keep_mb" (default 16384) stay cached; a live stream's own
+ * cache holds at most "pool_live_keep_mb" (default: a quarter of the device's memory).  cbh_trim synchronises
  * `device` and returns EVERY cached block to the driver; *released_bytes (optional) = what that gave back.  Safe to
  * call at any time between calls. */
 int cbh_trim(int device, unsigned long long* released_bytes);
@@ -754,6 +759,10 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *   "scratch_alloc" 2 = scratch from the library's arena (default); 1 = one ROCm hipMemPool_t per stream, 0 = ROCm's
  *                   default pool (hipMallocAsync) -- both measured unsafe on this stack, kept for the A/B soak only
  *   "pool_keep_mb"  cached scratch that may outlive its stream, per device, in MB (default 16384; < 0: everything)
+ *   "pool_live_keep_mb" what the cache of a LIVE stream may hold, in MB (0 = default: a quarter of the device's memory,
+ *                   at least 16384; < 0: everything).  Beyond it the blocks freed longest ago go back to the driver
+ *                   once the work queued behind them has run.  Its own budget because one call's working set
+ *                   (ColorDescriptor::create: ~50 GB per 10^5 images) may exceed what is worth keeping for dead streams
  *   "shard_force_rccl" 1 = a sharded index on ONE device still sends its blocks through ncclAllGather (one rank): the
  *                   transport test of a one-GPU box (default 0)
  *   "shard_exchange" how the records of a multi-device index reach the root device: 1 = hipMemcpyPeerAsync of exactly

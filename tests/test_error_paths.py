@@ -260,7 +260,7 @@ def test_driver_out_of_memory_is_retried_after_the_caches_are_given_up(gpu, case
     assert _same(got, want) and _tuning(L, b"arena_oom_retry_stream") == r0 + 1
 
 
-def test_a_live_streams_cache_is_bounded_by_pool_keep_mb(gpu):
+def test_a_live_streams_cache_is_bounded_by_pool_live_keep_mb(gpu):
     """free_async keeps what a live stream has used only up to the budget: beyond it the blocks freed longest ago wait
     for the work queued behind them and go back to the driver (round 3 advice: a long-lived caller stream that once
     took a large scratch held it until cbh_trim)"""
@@ -272,7 +272,7 @@ def test_a_live_streams_cache_is_bounded_by_pool_keep_mb(gpu):
     rng = np.random.default_rng(1)
     _free_bytes(L)
     c0 = _tuning(L, b"arena_cached_bytes")  # (caches of streams that are still busy elsewhere)
-    L.cbh_set_tuning(b"pool_keep_mb", 1)
+    L.cbh_set_tuning(b"pool_live_keep_mb", 1)
     try:
         stream = torch.cuda.Stream()
         t0 = _tuning(L, b"arena_trimmed_live")
@@ -285,6 +285,6 @@ def test_a_live_streams_cache_is_bounded_by_pool_keep_mb(gpu):
         assert _tuning(L, b"arena_cached_bytes") <= c0 + (1 << 20)
         assert _tuning(L, b"arena_trimmed_live") > t0
     finally:
-        L.cbh_set_tuning(b"pool_keep_mb", 16384)
+        L.cbh_set_tuning(b"pool_live_keep_mb", 0)
         _free_bytes(L)
     assert _tuning(L, b"arena_pending_bytes") == 0  # cbh_trim reaped what was waiting

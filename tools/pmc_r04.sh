@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 4: matrix-pipe counters of the four shipped MFMA scan kernels + the new hash kernel, one counter per pass.
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"; cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 C="SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES"
 echo "== hamm64 (bench --dht 3,6: one PRE launch + one FULL3 launch at 1M x 1M)"
 for c in $C; do
