@@ -33,7 +33,6 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 # matrix path; dense FP4 MFMA peak from the same guide (~10 PF; its own micro-benchmark reaches 9.1)
 FP4_PEAK_TFLOPS = 10000.0
 FLOP_PER_CMP = 128.0
-PRE_MAX_DHT = 4
 W = H = 256
 # The job is a pure function of (--images, --seed): every image is drawn from (seed, global index), so the match count
 # per threshold does not depend on the number of GPUs or on how the index is sharded.  Counts of the default job and of
@@ -244,10 +243,16 @@ def main():
         # threshold's scan as well and is not additive
         sweep.append({"dht": dht, "scan_kernel_ms": round(sm, 3), "find_latency_ms": round(fm, 3),
                       "scan_cmp_per_s": shard_n * n / sm * 1e3, "matches": finds[dht][0][1]})
-    # the matrix-core scan has two shapes: k_hamm64_mfma3 (64-bit dot products; thresholds > PRE_MAX_DHT) is
-    # the dominant kernel by time and the one the roofline object prices; PRE (low-word prefilter, thresholds
-    # <= PRE_MAX_DHT, hamm64_mfma.hip kPreMaxThresh) executes half the multiply-adds per comparison and
-    # is reported beside it with the flops it really issues.
+    # the matrix-core scan has two shapes: k_hamm64_mfma3 (64-bit dot products; thresholds > PRE_MAX_DHT) and PRE (32-bit
+    # prefilter on lo ^ hi + exact re-check of the candidates; thresholds <= PRE_MAX_DHT = the library's "scan_pre_max"),
+    # which executes half the multiply-adds per comparison.  `roofline` prices whichever of the two takes more of the
+    # step's time; both are reported (roofline_full3, roofline_pre) with the flops they really issue.
+    import ctypes as _ct
+
+    from cbird_amd import _lib as _cl
+
+    _v = _ct.c_longlong(0)
+    PRE_MAX_DHT = int(_v.value) if _cl.lib().cbh_get_tuning(b"scan_pre_max", _ct.byref(_v)) == 0 else 4
     full = [d for d in dhts if d > PRE_MAX_DHT] or dhts
     pre = [d for d in dhts if d <= PRE_MAX_DHT and d not in full]
     scan_ms_avg = sum(sum(scans[d]) for d in full) / sum(len(scans[d]) for d in full)
@@ -283,13 +288,14 @@ def main():
             "parallelism": f"haystack row-sharded x{world}, needles replicated",
         },
         "dht_sweep": sweep,
-        # the headline counts 8 x N^2 pair-equivalents per step; thresholds <= 4 run the low-word prefilter (32-bit dot
-        # products + exact 64-bit re-checks of the rare candidates), thresholds >= 5 compare all 64 bits of every pair
+        # the headline counts 8 x N^2 pair-equivalents per step; thresholds <= PRE_MAX_DHT run the 32-bit prefilter (dot
+        # products of lo ^ hi + exact 64-bit re-checks of the candidates), the others compare all 64 bits of every pair
         "full_64bit_compare_rate_per_s": shard_n * n / (scan_ms_avg * 1e-3) * world,
-        "roofline": {
+        "roofline_full3": {
             "kernel": "k_hamm64_mfma3<8,2> (64-bit sign dot products, 3 needle tiles per accumulator: dht %s)" % ",".join(map(str, full)), "bound": "mfma", "achieved": scan_tflops, "peak": FP4_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": scan_tflops / FP4_PEAK_TFLOPS, "traffic": None,
-            "avg_launch_ms": scan_ms_avg, "algorithmic_flop_per_launch": FLOP_PER_CMP * shard_n * n,
+            "avg_launch_ms": scan_ms_avg, "launches_per_step": len(full),
+            "algorithmic_flop_per_launch": FLOP_PER_CMP * shard_n * n,
             "algorithmic_bytes_per_launch": scan_bytes, "hbm_equivalent_GBps": scan_gbs,
             "note": ("each comparison is a 64-term +-1 dot product (64 - 2*hamm64) on v_mfma_scale_f32_32x32x64_"
                      "f8f6f4 with FP4 operands: 128 FLOP.  SURVEY 8(d)'s 8 algorithmic bytes per comparison "
@@ -297,14 +303,20 @@ def main():
                      "per launch), the binding unit is the matrix core.  avg_launch_ms brackets the needle "
                      "expansion kernel + the scan kernel of one launch."),
         },
-        "roofline_pre": None if not pre else {
-            "kernel": "k_hamm64_mfma<8,2,true> (PRE: dht %s)" % ",".join(map(str, pre)), "bound": "mfma",
-            "avg_launch_ms": sum(sum(scans[d]) for d in pre) / sum(len(scans[d]) for d in pre),
-            "executed_flop_per_launch": 64.0 * shard_n * n,
-            "achieved": 64.0 * shard_n * n / (sum(sum(scans[d]) for d in pre) / sum(len(scans[d]) for d in pre) * 1e-3) / 1e12,
-            "peak": FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "note": "low-word prefilter: one K=64 MFMA covers 2 x 1024 32-bit distances; VALU-reduction bound",
-        },
+        "roofline_pre": None if not pre else (lambda pre_ms: {
+            "kernel": "k_hamm64_mfma<8,2,true,4> (PRE: dht %s)" % ",".join(map(str, pre)), "bound": "mfma",
+            "avg_launch_ms": pre_ms, "launches_per_step": len(pre),
+            "algorithmic_flop_per_launch": 64.0 * shard_n * n,
+            "achieved": 64.0 * shard_n * n / (pre_ms * 1e-3) / 1e12,
+            "peak": FP4_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 64.0 * shard_n * n / (pre_ms * 1e-3) / 1e12 / FP4_PEAK_TFLOPS,
+            "traffic": None,
+            "per_dht_ms": {str(d): round(sum(scans[d]) / len(scans[d]), 3) for d in pre},
+            "note": ("32-bit prefilter on lo ^ hi (a lower bound on the 64-bit distance): one K=64 MFMA covers 2 x 1024 "
+                     "32-term dot products = 64 FLOP per comparison, the work this kernel's algorithm needs (the exact "
+                     "re-check touches 1e-6 .. 6e-5 of the pairs); priced at 128 FLOP per comparison it would read "
+                     "2x this fraction.  Bound by the VALU flag reduction that shares the issue port with the MFMAs "
+                     "(4.25 VALU instructions per MFMA: one v_or3_b32 per two result registers)."),
+        })(sum(sum(scans[d]) for d in pre) / sum(len(scans[d]) for d in pre)),
         "roofline_hash": {
             "kernel": "k_dcthash_256_band (horizontal 7-tap sums as i8 MFMAs, one add + half an fma per pixel)",
             "bound": "hbm", "achieved": hash_gbs, "peak": HBM_PEAK_GBS,
@@ -312,6 +324,11 @@ def main():
             "avg_launch_ms": hash_ms, "algorithmic_bytes_per_launch": hash_bytes,
         },
     }
+    # `roofline` = the scan kernel that takes more of the step (launches x average duration)
+    rf3, rpre = result["roofline_full3"], result["roofline_pre"]
+    dominant = rpre if rpre and rpre["avg_launch_ms"] * rpre["launches_per_step"] > rf3["avg_launch_ms"] * rf3["launches_per_step"] else rf3
+    result["roofline"] = dict(dominant)
+    result["roofline"]["dominant_by"] = "launches_per_step x avg_launch_ms"
     # HBM traffic is NOT measured by this run (PMC counters need their own rocprofv3 passes: tools/profile_bench.sh).
     # The per-launch figures of the committed PMC passes are attached only to the configuration they were taken on
     # (1M images, one GPU) and are labelled as such; any other --images / --gpus reports traffic = null.
@@ -320,8 +337,13 @@ def main():
         try:
             t = json.load(open(pmc))
             src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at 1M images, N=1; not measured in this run)"
-            result["roofline"]["traffic"] = t.get("k_hamm64_mfma")
-            result["roofline"]["traffic_source"] = src
+            for key_, rf_ in (("k_hamm64_mfma", rf3), ("k_hamm64_mfma_pre", rpre)):
+                if rf_ is not None and t.get(key_) is not None:
+                    rf_["traffic"] = t.get(key_)
+                    rf_["traffic_source"] = src
+            result["roofline"]["traffic"] = dominant.get("traffic")
+            if dominant.get("traffic") is not None:
+                result["roofline"]["traffic_source"] = src
             result["roofline_hash"]["traffic"] = t.get("k_dcthash_256")
             result["roofline_hash"]["traffic_source"] = src
         except Exception:

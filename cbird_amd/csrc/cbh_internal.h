@@ -136,6 +136,10 @@ bool scan_mfma_wanted(size_t n, size_t nq, int thresh);
 void set_scan_mfma(int on);  // <0 = keep; 2 = force for any size
 void set_scan_mfma_ht(int ht);
 void set_scan_mfma_g(int g);
+int get_scan_pre_max();         // thresholds <= this run the prefilter kernel at present (0: none)
+void set_scan_pre_max(int t);   // thresholds <= t take the 32-bit prefilter kernel
+void set_scan_pre_fold(int v);  // prefilter word: 1 = lo ^ hi, 0 = lo
+void set_scan_pre_lean(int v);  // 1 = single candidates re-checked on the scalar unit
 void set_scan_mfma_full3(int on);  // three-needle-tile accumulator variant for thresholds > 4
 void set_scan_mfma_pre(int on);  // low-word prefilter variant for small thresholds
 
@@ -173,7 +177,8 @@ void set_kp_lds_side(int v);    // dcthash.hip: largest keypoint square processe
 void set_hash_stream(int v);     // dcthash.hip: streaming fused kernel (0 off, 1 auto, >= 2: steps per strip)
 void set_hash_fused(int on);     // dcthash.hip: fused blur + area kernel for widths >= on (default 1 = all; 0 off)
 void set_hash_fast_any(int on);  // dcthash.hip: fast kernels for geometries other than 256x256 (default on)
-void set_cd_chains(int v);   // colordesc_create.hip: 1 = chain-per-lane kernels (default), 0 = k_cd_cluster (lane per image)
+void set_cd_chains(int v);
+void set_cd_chunk_mb(int v);   // colordesc_create.hip: 1 = chain-per-lane kernels (default), 0 = k_cd_cluster (lane per image)
 void set_cd_group(int v);    // colordesc_create.hip: images per wave of the seeding kernel (0 = auto)
 void set_color_pk(int on);   // color.hip: packed-f32 distance kernel (default on)
 void set_color_fma(int on);  // color.hip: fused squares in k_color_dist3 (default off: not bit-identical)

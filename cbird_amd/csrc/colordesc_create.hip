@@ -1247,13 +1247,19 @@ __global__ __launch_bounds__(64) void k_cdw_finish(const CdW* __restrict__ W, un
 }
 
 int g_cd_group = 0;   // "color_create_group": images per wave of k_cdw_round (0 = from the batch size)
+// "color_create_chunk_mb": scratch one launch may take.  The sample / distance / position / label planes cost 33 bytes per
+// sample slot = 1.6 MB per 256 x 192 image, so a batch is worked off in chunks of that many images (19 000 at the default
+// of 32 GiB; the rate is flat from ~16 000 images on) and every chunk reuses the blocks of the one before: 100 000 images
+// took 150 GB of scratch in one piece -- above any budget the arena keeps cached, so every call mapped it afresh
+// (4-6 s per call against 0.9 s in chunks, tools/ab/color_create_pool.py).
+int g_cd_chunk_mb = 32768;
 int g_cd_chains = 1;  // "color_create_chains": 1 = the chain kernels above (default), 0 = k_cd_cluster (lane per image)
 
 }  // namespace
 
-int launch_color_descriptors(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const uint32_t* img_w,
-                             const uint32_t* img_h, const uint32_t* img_row_stride, int channels, uint8_t* d_descs,
-                             uint8_t* d_ok, hipStream_t s) {
+static int launch_color_descriptors_chunk(const uint8_t* d_imgs, size_t n, const uint64_t* img_off,
+                                          const uint32_t* img_w, const uint32_t* img_h, const uint32_t* img_row_stride,
+                                          int channels, uint8_t* d_descs, uint8_t* d_ok, hipStream_t s) {
   std::vector<CdImage> images(n);
   std::map<std::pair<int, int>, unsigned> mask_of;
   std::vector<uint8_t> masks;
@@ -1377,6 +1383,33 @@ int launch_color_descriptors(const uint8_t* d_imgs, size_t n, const uint64_t* im
   return rc;
 }
 
+int launch_color_descriptors(const uint8_t* d_imgs, size_t n, const uint64_t* img_off, const uint32_t* img_w,
+                             const uint32_t* img_h, const uint32_t* img_row_stride, int channels, uint8_t* d_descs,
+                             uint8_t* d_ok, hipStream_t s) {
+  // images are independent (a chain per image): chunks of at most `per` images, sized by the largest image's slots
+  size_t cap = 64;
+  for (size_t i = 0; i < n; ++i) {
+    int cols = 0, rows = 0;
+    resized_dims((int)img_w[i], (int)img_h[i], &cols, &rows);
+    if (cols < 1 || rows < 1) return CBH_E_INVAL;
+    cap = std::max(cap, (size_t)cols * (size_t)rows);
+  }
+  cap = (cap + 63) & ~(size_t)63;
+  const size_t budget = (size_t)std::max(g_cd_chunk_mb, 64) << 20;
+  size_t per = std::max<size_t>(budget / (33 * cap), 64);
+  if (per >= 4096) per &= ~(size_t)2047;  // whole multiples of the launch shapes' image groups
+  for (size_t i0 = 0; i0 < n; i0 += per) {
+    const size_t m = std::min(per, n - i0);
+    const int rc = launch_color_descriptors_chunk(d_imgs, m, img_off + i0, img_w + i0, img_h + i0, img_row_stride + i0,
+                                                  channels, d_descs + i0 * 258, d_ok + i0, s);
+    if (rc != CBH_OK) return rc;
+  }
+  return CBH_OK;
+}
+
+void set_cd_chunk_mb(int v) {
+  if (v > 0) g_cd_chunk_mb = v;
+}
 void set_cd_chains(int v) { g_cd_chains = v; }
 void set_cd_group(int v) { g_cd_group = v; }
 

@@ -25,17 +25,21 @@
 //     the per-half maximum of three registers at once: 4 ops per MFMA instead of 8.
 //
 // Three variants (all exact), chosen by the launcher:
-//   FULL3 (k_hamm64_mfma3, thresholds kPreMaxThresh+1 .. 64) three needle tiles per accumulator, detection by
+//   FULL3 (k_hamm64_mfma3, thresholds g_pre_max_thresh+1 .. 64) three needle tiles per accumulator, detection by
 //         OR of flag bits -- described at the kernel below; the default for most thresholds.
 //   FULL2 (thresh 65, or FULL3 switched off) K = the 64 bits of one hash; tile B is a second MFMA accumulated
 //         onto tile A's.  hi16 = 0x4B40 - distB, lo16 = 0x4080 - 2*distA.  Hits are real matches.
-//   PRE   (thresh <= kPreMaxThresh) low-word prefilter at twice the pair rate: the block scale is
-//         per lane and K block, so lanes 0-31 (K 0..31) carry the LOW words of one needle tile and lanes 32-63
-//         (K 32..63) the LOW words of the next, against the haystack's low words in both K blocks: ONE MFMA =
-//         2048 low-word distances.  Two such MFMAs are chained into one accumulator with block scales
-//         2^-1 | 2^5 and 2^11 | 2^17: four 6-bit flag-bit fields per register (the top one flags by carrying into
-//         the exponent), reduced with v_or3_b32 -- one result VGPR per 256 comparisons.  Sound because
-//         popc(lo) >= thresh implies popc(lo) + popc(hi) >= thresh; candidates are re-evaluated on the full 64 bits.
+//   PRE   (thresh <= g_pre_max_thresh) 32-bit prefilter at twice the pair rate.  The 32-bit word is the FOLD
+//         f(x) = lo(x) ^ hi(x): bit i of f(a) ^ f(b) is the XOR of bits i and i + 32 of a ^ b, so
+//         popc(f(a) ^ f(b)) <= popc(a ^ b) -- a lower bound on the distance that looks at all 64 bits.  (Round 1-4
+//         used the low word alone: also a lower bound, but the low-frequency coefficients of images agree far more
+//         often than chance; on image-derived hashes the fold passes 2-3x fewer false candidates -- exactly the rate
+//         of uniform random words -- NOTES 11.)  The block scale is per lane and K block, so lanes 0-31 (K 0..31)
+//         carry the folds of one needle tile and lanes 32-63 (K 32..63) the folds of the next, against the
+//         haystack's folds in both K blocks: ONE MFMA = 2048 fold distances.  Two such MFMAs are chained into one
+//         accumulator with block scales 2^-1 | 2^5 and 2^11 | 2^17: four 6-bit flag-bit fields per register (the
+//         top one flags by carrying into the exponent), reduced with v_or3_b32 -- one result VGPR per 256
+//         comparisons.  Candidates are re-evaluated on the full 64 bits.
 //
 // Hits.  After the MFMAs of a group of G haystack tiles one compare of the packed maximum decides
 // whether anything is under the threshold.  Then, tile by tile, the lanes that hold flagged
@@ -62,8 +66,15 @@ constexpr int kG = 2;  // tiles per accumulator group
 // 2^23 + 0x4040 + 64 * 2^15
 constexpr float kC0 = 8388608.0f + 16448.0f + 2097152.0f;
 constexpr int kScale15 = 0x8e8e8e8e;  // E8M0 142 = 2^15
-constexpr int kPreMaxThresh = 4;      // P[popc(32 random bits) < 4] = 1.3e-6 per pair.  At 5 (9.7e-6) the re-checks still pay on
-                                      // uniform hashes (15.5 vs 17.9 ms) but not on image-derived ones (19.2 vs 17.1 ms)
+// Thresholds the prefilter serves ("scan_pre_max").  P[popc(32 random bits) < t] per pair: 1.3e-6 at 4, 9.7e-6 at 5,
+// 5.7e-5 at 6, 2.7e-4 at 7.  Rounds 1-4 stopped at 4: on the low word, image-derived hashes gave 2.7x the candidates of
+// uniform ones at 5 and the vector re-check (~750 cycles per candidate group) lost to FULL3 (19.2 vs 17.1 ms).  With the
+// fold and the deferred re-check (round 5; same box, 1M x 1M image-derived hashes, tools/ab/pre_fold_ab.py): threshold 5
+// 10.0 ms against FULL3's 16.7, threshold 6 13.8 against 16.7, threshold 7 31.7 -- hence 6.
+int g_pre_max_thresh = 6;
+int g_pre_fold = 1;   // "scan_pre_fold": 1 = prefilter on lo ^ hi (default), 0 = on the low word (rounds 1-4, A/B)
+int g_pre_lean = 1;   // "scan_pre_lean": 1 = a group whose candidates sit in ONE register of ONE lane is re-checked on
+                      // the scalar unit (readlane + s_load + s_bcnt1), 0 = always the LDS queue path (A/B)
 constexpr uint32_t kQueue = 2048;     // 16 registers x 2 fields x 64 lanes: cannot overflow
 // PRE keeps FOUR low-word distances per accumulator register as 6-bit fields at bits 0, 6, 12, 18 (two chained
 // MFMAs; see the kernel), biased so that "under the threshold" is bit 5 of the field; the top field's flag is the carry
@@ -74,14 +85,19 @@ constexpr int kScale5 = (int)0x84848484;     // 2^5
 constexpr int kScale11 = (int)0x8a8a8a8a;    // 2^11
 constexpr int kScale17 = (int)0x90909090;    // 2^17
 
-// needles -> FP4 scratch: needle j -> 2 x uint4 (low word, high word); j >= nq padded with hash 0
+// needles -> FP4 scratch: needle j -> 2 x uint4 (low word, high word) at qx[2j], and behind those (qx[2 * nq_pad + j])
+// the prefilter word of needle j (fold ? lo ^ hi : lo); j >= nq padded with hash 0
 __global__ __launch_bounds__(256) void k_expand_needles(const uint64_t* __restrict__ q, uint32_t nq,
-                                                        uint32_t nq_pad, uint4* __restrict__ qx) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;  // one thread per 32-bit word
-  if (i >= 2u * nq_pad) return;
-  const uint32_t j = i >> 1;
+                                                        uint32_t nq_pad, uint4* __restrict__ qx, uint32_t fold) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;  // one thread per output uint4
+  if (i >= 3u * nq_pad) return;
   const uint32_t* w = reinterpret_cast<const uint32_t*>(q);
-  qx[i] = fp4_expand32(j < nq ? w[i] : 0u);
+  if (i < 2u * nq_pad) {
+    qx[i] = fp4_expand32((i >> 1) < nq ? w[i] : 0u);
+  } else {
+    const uint32_t j = i - 2u * nq_pad;
+    qx[i] = fp4_expand32(j < nq ? (fold ? w[2u * j] ^ w[2u * j + 1u] : w[2u * j]) : 0u);
+  }
 }
 
 __device__ __forceinline__ void emit(cbh_record* __restrict__ rec, unsigned long long cap,
@@ -236,16 +252,46 @@ __device__ __forceinline__ void handle_tile(const v16f& c, uint32_t row0, uint32
   wave_order();
 }
 
+// PRE, lean path (candidates in at most kParkLanes lanes of a group -- the common case while candidates are rare: 8192
+// pairs per group x 1e-5 .. 6e-5 per pair).  A candidate costs the matrix pipe nothing but a handful of VALU slots when it
+// is FOUND and is re-checked LATER, 64 at a time:
+//   * each lane that holds a flag parks its accumulators in LDS (ds_write_b128 straight from the MFMA result registers,
+//     under the lanes' own exec mask: LDS issue, no VALU); hit lane by hit lane, lane r reads register r back, ONE
+//     ballot names the flagged registers, and those lanes append a descriptor {register pattern, register | tile |
+//     lane | step} to the wave's pending list -- ~10 VALU instructions per hit lane, no global memory access, so the
+//     wave is back at its MFMAs after two LDS round trips;
+//   * when 64 descriptors are pending (and at the end of the wave's needle chunk) the wave drains the list, one
+//     descriptor per lane: haystack hash from LDS, the needles of the flagged fields from global memory (64 lanes'
+//     loads in flight together), popcount, record.
+// (An immediate scalar re-check -- s_load + s_bcnt1 per candidate -- was built first: no VALU at all, but every event
+//  stalled the wave for a scalar-cache miss, 15.9 ms at threshold 6 where this form takes ~11; NOTES 11.)
+// The wave's 2048-word queue space holds the pending list (2 words per descriptor) below the parking area.
+constexpr uint32_t kParkLanes = 4;
+constexpr uint32_t kPark = kQueue - kParkLanes * 32u;  // word offset of the parking area; pending: < 64 + 4 * 32 descriptors
+
+// OR of accumulator registers [A, B) of a group (register r = tile r / 16, element r % 16), three and then two per
+// v_or3_b32
+template <int A, int B, int G>
+__device__ __forceinline__ uint32_t or_regs(const v16f (&c)[G]) {
+  static_assert(B - A >= 3, "range");
+  uint32_t o = as_u32(c[A >> 4][A & 15]) | as_u32(c[(A + 1) >> 4][(A + 1) & 15]) | as_u32(c[(A + 2) >> 4][(A + 2) & 15]);
+#pragma unroll
+  for (int r = A + 3; r < B; r += 2)
+    o |= as_u32(c[r >> 4][r & 15]) | (r + 1 < B ? as_u32(c[(r + 1) >> 4][(r + 1) & 15]) : 0u);
+  return o;
+}
+
 template <int HT, int G, bool PRE, int MINB = ((PRE && G == 2 && HT == 8) ? 3 : 1)>
 __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
     const uint2* __restrict__ hay, const uint32_t* __restrict__ ids, uint32_t n,
     const uint64_t* __restrict__ q, const uint4* __restrict__ qx, uint32_t nq, uint32_t n_pairs,
     uint32_t pairs_per_chunk, uint32_t thresh, cbh_record* __restrict__ rec,
     unsigned long long cap, unsigned long long* __restrict__ total, uint32_t keep0,
-    const uint2* __restrict__ qmask) {
+    const uint2* __restrict__ qmask, const uint4* __restrict__ qf, uint32_t pre_flags) {
   __shared__ uint32_t s_queue_[kWaves][kQueue];  // candidates of one haystack tile
   __shared__ uint2 s_hay_[PRE ? kWaves : 1][PRE ? HT * 32 : 1];  // PRE: raw hashes for the re-check
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // uniform, and known to be
   const uint32_t r = lane & 31u, half = lane >> 5;
   const uint32_t tile0 = (blockIdx.x * kWaves + wave) * HT;
   if (tile0 * 32u >= n) return;  // whole wave past the end (no workgroup barriers in this kernel)
@@ -257,7 +303,8 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
   for (int t = 0; t < HT; ++t) {
     const uint32_t row = (tile0 + t) * 32u + r;
     const uint2 hv = row < n ? hay[row] : make_uint2(0u, 0u);
-    a[t] = fp4_operand(fp4_expand32((!PRE && half) ? hv.y : hv.x));
+    // PRE: the prefilter word (fold = lo ^ hi, or the low word) in both K blocks
+    a[t] = fp4_operand(fp4_expand32(PRE ? ((pre_flags & 1u) ? hv.x ^ hv.y : hv.x) : (half ? hv.y : hv.x)));
     if (PRE && half == 0) s_hay[t * 32 + r] = hv;
   }
   wave_order();
@@ -285,16 +332,44 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
   const uint32_t p0 = blockIdx.y * pairs_per_chunk;
   const uint32_t p1 = min(n_pairs, p0 + pairs_per_chunk);
   // pair p = needles [64p, 64p+64): tile A = first 32, tile B = last 32; 2 uint4 per needle.
-  // FULL: lane (c, half) reads word `half` of needle c of each tile; PRE: the low word of needle
-  // 64p + lane (tile A in K block 0, tile B in K block 1)
-  const uint4* __restrict__ qp =
-      PRE ? qx + ((size_t)p0 * 64u + lane) * 2u : qx + ((size_t)p0 * 64u + r) * 2u + half;
+  // FULL: lane (c, half) reads word `half` of needle c of each tile; PRE: the prefilter word of needle
+  // 64p + lane (tile A in K block 0, tile B in K block 1), one uint4 per needle in qf
+  const uint4* __restrict__ qp = PRE ? qf + (size_t)p0 * 64u + lane : qx + ((size_t)p0 * 64u + r) * 2u + half;
   const uint32_t lo_zero = PRE ? 0x4060u : 0x4080u;      // lo16 at distance 0
   const uint32_t hi_zero = PRE ? 0x4B30u : 0x4B40u;      // hi16 at distance 0
   const uint32_t lo_thr = lo_zero - 2u * (thresh - 1u);  // lo16 >= lo_thr  <=>  distA < thresh
   const uint32_t hi_thr = hi_zero - (thresh - 1u);       // hi16 >= hi_thr  <=>  distB < thresh
   const uint32_t lo_key = lo_thr << 16, hi_key = hi_thr << 16;
   const HitParams hp = {lo_key, hi_key, lo_zero, hi_zero, thresh, n, nq, keep0, q, ids, rec, cap, total, hay, qmask};
+  const bool lean = PRE && (pre_flags & 2u) != 0;
+  uint32_t npend = 0;  // PRE lean path: descriptors waiting in s_queue (wave-uniform)
+  // one descriptor per lane: the flagged fields of a parked register against all 64 bits
+  auto drain = [&]() {
+    wave_order();
+    for (uint32_t k = lane; k < npend; k += 64u) {
+      const uint32_t bits = s_queue[2u * k], w1 = s_queue[2u * k + 1u];
+      const uint32_t g = w1 & 15u, tile = (w1 >> 4) & 7u, L = (w1 >> 7) & 63u, pp = p0 + 2u * (w1 >> 13);
+      const uint32_t rit = (g & 3u) + 8u * (g >> 2) + 4u * (L >> 5);  // C/D layout, see handle_tile
+      const uint32_t row = (tile0 + tile) * 32u + rit;
+      // a carry into the exponent (top field flagged) leaves the lower fields unreadable: all four are candidates
+      uint32_t fields = ((bits >> 23) & 1u) ? 0xfu
+                                            : (((bits >> 5) & 1u) | (((bits >> 11) & 1u) << 1) | (((bits >> 17) & 1u) << 2));
+      if (row >= hp.n) fields = 0;
+      const uint2 hv = s_hay[tile * 32u + rit];
+      for (; fields; fields &= fields - 1u) {
+        const uint32_t qi = pp * 64u + (uint32_t)__builtin_ctz(fields) * 32u + (L & 31u);
+        if (qi >= hp.nq) continue;
+        const uint64_t nv = hp.q[qi];
+        const uint32_t d = __popc(hv.x ^ (uint32_t)nv) + __popc(hv.y ^ (uint32_t)(nv >> 32));
+        if (nv != 0 && d < hp.thresh && mask_ok(hp, row, qi, nv)) {
+          const uint32_t id = hp.ids[row];
+          if (id != 0 || hp.keep0) emit(hp.rec, hp.cap, hp.total, qi, d, id);
+        }
+      }
+    }
+    wave_order();
+    npend = 0;
+  };
 
   // one needle-tile pair against the HT resident haystack tiles
   auto step = [&](const uint32_t p, const uint4& nA, const uint4& nB) {
@@ -312,18 +387,49 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
       for (int t = 0; t < G; ++t)
         c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t0 + t], bB, c[t], 4, 4, 0,
                                                                kScaleOne, 0, scale_b2);
-      bool hit;
-      if (PRE) {
-        // flag bits survive OR: 8 v_or3_b32 per tile (plain VGPR-only ops, cheaper to issue than the packed max)
-        uint32_t o0 = 0, o1 = 0;
+      if constexpr (PRE) {
+        // flag bits survive OR: v_or3_b32 takes two more registers per op (plain VGPR-only ops, cheaper to issue than
+        // the packed max); two chains of 8 ops
+        constexpr int R = G * 16;
+        const uint32_t flags = (or_regs<0, R / 2, G>(c) | or_regs<R / 2, R, G>(c)) & kFlagMaskPre;
+        const uint64_t hm = __builtin_amdgcn_ballot_w64(flags != 0);
+        if (hm != 0) {
+          // wave-uniform from here: some lane holds a candidate (one group in ~10 at threshold 5, every other at 6)
+          if (lean && R <= 32 && (uint32_t)__popcll(hm) <= kParkLanes) {
+            if (flags != 0) {  // the k-th hit lane parks at kPark + 32 k
+              const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
 #pragma unroll
-        for (int t = 0; t < G; ++t)
+              for (int t = 0; t < G; ++t)
 #pragma unroll
-          for (int g = 0; g < 16; g += 4) {
-            o0 |= as_u32(c[t][g]) | as_u32(c[t][g + 1]);
-            o1 |= as_u32(c[t][g + 2]) | as_u32(c[t][g + 3]);
+                for (int k = 0; k < 4; ++k)
+                  *reinterpret_cast<float4*>(&s_queue[kPark + rank * 32u + (uint32_t)(t * 16 + 4 * k)]) =
+                      make_float4(c[t][4 * k], c[t][4 * k + 1], c[t][4 * k + 2], c[t][4 * k + 3]);
+            }
+            wave_order();
+            const uint32_t w1c = ((uint32_t)t0 << 4) | (((p - p0) >> 1) << 13);  // tile of register 0, step
+            uint32_t rank = 0;
+            for (uint64_t m = hm; m; m &= m - 1, ++rank) {
+              const uint32_t L = (uint32_t)__builtin_ctzll(m);
+              const uint32_t v = s_queue[kPark + rank * 32u + (lane & 31u)];  // lane r < R: register r of lane L
+              const bool fl = (v & kFlagMaskPre) != 0 && lane < (uint32_t)R;
+              const uint64_t bm = __builtin_amdgcn_ballot_w64(fl);
+              if (fl) {
+                const uint32_t slot =
+                    npend + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                // lane = 16 t + g: bits 0-3 the register, bits 4-6 (t0 + t) the wave's tile
+                *reinterpret_cast<uint2*>(&s_queue[2u * slot]) = make_uint2(v, (lane + w1c) | (L << 7));
+              }
+              npend += (uint32_t)__popcll(bm);
+            }
+            wave_order();
+            if (npend >= 64u) drain();
+          } else {
+            if (npend) drain();  // the queue path uses the whole queue space
+#pragma unroll
+            for (int t = 0; t < G; ++t)
+              handle_tile<PRE>(c[t], (tile0 + t0 + t) * 32u, (uint32_t)(t0 + t) * 32u, p, hp, s_queue, s_hay);
           }
-        hit = ((o0 | o1) & kFlagMaskPre) != 0;
+        }
       } else {
         // packed per-half maximum of the group's G*16 results: 8 v_pk_maximum3_f16 per tile
         h2 m0 = {0, 0}, m1 = {0, 0};
@@ -335,13 +441,13 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
             m1 = pkmax3(m1, as_h2(c[t][g + 2]), as_h2(c[t][g + 3]));
           }
         const uint32_t mb = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(m0, m1));
-        hit = (mb << 16) >= lo_key || mb >= hi_key;
-      }
-      if (__builtin_amdgcn_ballot_w64(hit) != 0) {
-        // wave-uniform from here: something in this group is under the threshold (rare)
+        const bool hit = (mb << 16) >= lo_key || mb >= hi_key;
+        if (__builtin_amdgcn_ballot_w64(hit) != 0) {
+          // wave-uniform from here: something in this group is under the threshold (rare)
 #pragma unroll
-        for (int t = 0; t < G; ++t)
-          handle_tile<PRE>(c[t], (tile0 + t0 + t) * 32u, (uint32_t)(t0 + t) * 32u, p, hp, s_queue, s_hay);
+          for (int t = 0; t < G; ++t)
+            handle_tile<PRE>(c[t], (tile0 + t0 + t) * 32u, (uint32_t)(t0 + t) * 32u, p, hp, s_queue, s_hay);
+        }
       }
     }
   };
@@ -353,19 +459,20 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
     //  fed the same tiles again and its candidates fall out at qi >= nq)
     // (the partner is chosen by ADDRESS, so that both loads are issued back to back and stay in flight during the
     //  MFMAs; selecting between the loaded values made the compiler wait for the first load at once)
-    uint4 cur0 = qp[0], cur1 = qp[p0 + 1 < n_pairs ? 128 : 0];
+    uint4 cur0 = qp[0], cur1 = qp[p0 + 1 < n_pairs ? 64 : 0];
 #pragma unroll 1
     for (uint32_t p = p0; p < p1; p += 2) {
       uint4 nx0 = cur0, nx1 = cur1;
       if (p + 2 < p1) {
-        qp += 256;
+        qp += 128;
         nx0 = qp[0];
-        nx1 = qp[p + 3 < n_pairs ? 128 : 0];
+        nx1 = qp[p + 3 < n_pairs ? 64 : 0];
       }
       step(p, cur0, cur1);
       cur0 = nx0;
       cur1 = nx1;
     }
+    if (npend) drain();
   } else {
     // two pairs per trip with explicit double buffers: the loads of the next pair are in flight
     // while the 2*HT MFMAs of the current one run
@@ -552,6 +659,16 @@ void set_scan_mfma_pre(int on) {
   }
   if (on >= 0) g_mfma_pre = on;
 }
+int get_scan_pre_max() { return g_mfma_pre == 1 ? g_pre_max_thresh : g_mfma_pre == 2 ? 32 : 0; }
+void set_scan_pre_max(int t) {
+  if (t >= 0 && t <= 32) g_pre_max_thresh = t;
+}
+void set_scan_pre_fold(int v) {
+  if (v >= 0) g_pre_fold = v != 0;
+}
+void set_scan_pre_lean(int v) {
+  if (v >= 0) g_pre_lean = v != 0;
+}
 void set_scan_mfma_full3(int on) {
   if (on >= 0) g_mfma_full3 = on;
 }
@@ -574,9 +691,11 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
   const uint32_t n_triples = (uint32_t)((nq + 95) / 96);
   const uint32_t nq_pad = (uint32_t)((nq + 191) / 192) * 192u;  // whole pairs (64) and whole triples (96)
   uint4* qx = nullptr;
-  CBH_HIP(cbh::malloc_async((void**)&qx, (size_t)nq_pad * 32u, stream));
-  hipLaunchKernelGGL(k_expand_needles, dim3((2u * nq_pad + 255u) / 256u), dim3(256), 0, stream, d_q,
-                     (uint32_t)nq, nq_pad, qx);
+  CBH_HIP(cbh::malloc_async((void**)&qx, (size_t)nq_pad * 48u, stream));  // 2 words + the prefilter word, 16 B each
+  hipLaunchKernelGGL(k_expand_needles, dim3((3u * nq_pad + 255u) / 256u), dim3(256), 0, stream, d_q,
+                     (uint32_t)nq, nq_pad, qx, (uint32_t)(g_pre_fold != 0));
+  const uint4* qf = qx + 2u * (size_t)nq_pad;
+  const uint32_t pre_flags = (g_pre_fold ? 1u : 0u) | (g_pre_lean ? 2u : 0u);
   const uint32_t ht = (uint32_t)g_mfma_ht;
   const uint32_t rows_per_wg = 32u * ht * kWaves;
   const uint32_t wgs = (uint32_t)((n + rows_per_wg - 1) / rows_per_wg);
@@ -590,7 +709,7 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
     chunks = (n_pairs + ppc - 1) / ppc;
   }
   // (2 = experiments: the prefilter variant for any threshold it can represent)
-  const bool pre = (g_mfma_pre == 1 && thresh <= kPreMaxThresh) || (g_mfma_pre == 2 && thresh <= 32);
+  const bool pre = (g_mfma_pre == 1 && thresh <= g_pre_max_thresh) || (g_mfma_pre == 2 && thresh <= 32);
   if (!pre && g_mfma_full3 && thresh <= 64 && ht == 8) {
     uint32_t tpc = 172;  // ~16512 needles per chunk
     while (tpc > 11 && (uint64_t)wgs * ((n_triples + tpc - 1) / tpc) < 8192) tpc = (tpc + 1) / 2;
@@ -616,7 +735,7 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
                      reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx,      \
                      (uint32_t)nq, n_pairs, ppc, (uint32_t)thresh, d_rec,                        \
                      (unsigned long long)cap, d_total, (uint32_t)(flags & 1u),                     \
-                     reinterpret_cast<const uint2*>(d_qmask))
+                     reinterpret_cast<const uint2*>(d_qmask), qf, pre_flags)
 #define CBH_MFMA(HT, PRE) CBH_MFMA_G(HT, kG, PRE)
   if (ht == 8 && g_mfma_g == 4) {
     if (pre) CBH_MFMA_G(8, 4, true); else CBH_MFMA_G(8, 4, false);
@@ -625,7 +744,7 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
   hipLaunchKernelGGL((k_hamm64_mfma<8, kG, true, MB>), dim3(wgs, chunks), dim3(kThreads), 0, stream,      \
                      reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx, (uint32_t)nq, \
                      n_pairs, ppc, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total,             \
-                     (uint32_t)(flags & 1u), reinterpret_cast<const uint2*>(d_qmask))
+                     (uint32_t)(flags & 1u), reinterpret_cast<const uint2*>(d_qmask), qf, pre_flags)
     if (g_mfma_pre_minb == 2) CBH_MFMA_B(2); else if (g_mfma_pre_minb == 4) CBH_MFMA_B(4); else CBH_MFMA_B(1);
 #undef CBH_MFMA_B
   } else if (ht == 8) {

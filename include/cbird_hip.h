@@ -706,7 +706,13 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *   "scan_mfma"     64-bit scan on the matrix cores (k_hamm64_mfma): 0 = never, 1 = calls with >= 256
  *                   needles and >= 4096 slots (default), 2 = always
  *   "scan_mfma_ht"  haystack tiles per wave in k_hamm64_mfma: 2, 4 or 8 (default 8)
- *   "scan_mfma_pre" 1 = thresholds <= 4 use the low-word prefilter variant of k_hamm64_mfma (default 1)
+ *   "scan_mfma_pre" 1 = thresholds <= "scan_pre_max" use the 32-bit prefilter variant of k_hamm64_mfma (default 1),
+ *                   0 = never, 2 = for every threshold <= 32 (experiments)
+ *   "scan_pre_max"  the largest threshold that takes the prefilter variant (default 6; rounds 1-4: 4)
+ *   "scan_pre_fold" 1 = the prefilter compares lo ^ hi of the hashes (default: a lower bound on the distance that sees
+ *                   all 64 bits), 0 = the low words (rounds 1-4)
+ *   "scan_pre_lean" 1 = prefilter candidates confined to a few lanes are parked, listed and re-checked 64 at a time
+ *                   (default), 0 = every candidate group goes through the per-tile queue path (rounds 1-4)
  *   "scan256_mfma"  256-bit scan on the matrix cores (k_hamm256_mfma): 0 = never, 1 = calls with >= 64
  *                   needle descriptors and >= 4096 rows (default), 2 = always
  *   "scan256_small" 1 = searches with <= 512 needle descriptors (one ORB needle image) and thresholds <= 40 use the
@@ -756,6 +762,8 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *                   order; 1 = fast: the horizontal pass may fuse and re-associate (see dcthash.hip k_blur_area_regs)
  *   "color_create_chains" 1 = ColorDescriptor::create's clustering as chain-per-lane kernels (default), 0 = one lane per
  *                   image (k_cd_cluster, round 2)
+ *   "color_create_chunk_mb" scratch one launch of ColorDescriptor::create may take, in MB (default 32768): larger batches
+ *                   are worked off in chunks of that many images (1.6 MB per 256 x 192 image); results do not change
  *   "scratch_alloc" 2 = scratch from the library's arena (default); 1 = one ROCm hipMemPool_t per stream, 0 = ROCm's
  *                   default pool (hipMallocAsync) -- both measured unsafe on this stack, kept for the A/B soak only
  *   "pool_keep_mb"  cached scratch that may outlive its stream, per device, in MB (default 16384; < 0: everything)
@@ -779,7 +787,8 @@ int cbh_set_tuning(const char* key, int value);
 /* Read-back for tests and soak tools: "fault_alloc_after" (what is left of the countdown, -1 = disarmed or fired),
  * "fault_fired", "alloc_calls" (allocations seen since the library loaded), and the scratch arena's
  * "arena_cached_bytes", "arena_pending_bytes", "arena_live_bytes", "arena_live_blocks", "arena_trimmed_live",
- * "arena_oom_retry_stream", "arena_oom_retry_device", "arena_released". */
+ * "arena_oom_retry_stream", "arena_oom_retry_device", "arena_released"; "scan_pre_max" (the largest threshold that
+ * runs the prefilter scan kernel under the present knobs, 0 = none). */
 int cbh_get_tuning(const char* key, long long* value);
 
 /* ---- measurement support ---------------------------------------------------------------- */

@@ -29,21 +29,27 @@ def gpu():
     return cbird_amd
 
 
-@pytest.fixture(params=["mfma", "mfma2", "valu"])
+@pytest.fixture(params=["mfma", "mfma_r4", "mfma2", "valu"])
 def scan_path(request, gpu):
     """Run a GPU test once per 64-bit scan kernel family, all of which must be bit-exact against the oracle:
-    "mfma"  the matrix-core scan forced for any size, as shipped (thresholds <= 4: low-word prefilter
-            variant, 5..64: three needle tiles per accumulator, 65: two);
-    "mfma2" the same with the three-tile variant off (thresholds >= 5 on the two-tile kernel);
-    "valu"  the popcount kernel k_hamm64_scan."""
+    "mfma"    the matrix-core scan forced for any size, as shipped (thresholds <= 6: the prefilter variant on lo ^ hi
+              with the deferred re-check, 7..64: three needle tiles per accumulator, 65: two);
+    "mfma_r4" the prefilter as rounds 1-4 had it (low word, every candidate group through the per-tile queue path),
+              for the thresholds it serves now;
+    "mfma2"   as "mfma" with the three-tile variant off (thresholds >= 7 on the two-tile kernel);
+    "valu"    the popcount kernel k_hamm64_scan."""
     from cbird_amd import _lib
 
     L = _lib.lib()
     L.cbh_set_tuning(b"scan_mfma", 0 if request.param == "valu" else 2)
     L.cbh_set_tuning(b"scan_mfma_full3", 0 if request.param == "mfma2" else 1)
+    L.cbh_set_tuning(b"scan_pre_fold", 0 if request.param == "mfma_r4" else 1)
+    L.cbh_set_tuning(b"scan_pre_lean", 0 if request.param == "mfma_r4" else 1)
     yield request.param
     L.cbh_set_tuning(b"scan_mfma", 1)
     L.cbh_set_tuning(b"scan_mfma_full3", 1)
+    L.cbh_set_tuning(b"scan_pre_fold", 1)
+    L.cbh_set_tuning(b"scan_pre_lean", 1)
 
 
 @pytest.fixture(params=["mfma", "mfma_rows", "mfma_rows1", "valu"])

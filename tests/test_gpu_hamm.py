@@ -317,3 +317,66 @@ def test_prefilter_pair_boundaries_and_low_word_collisions(gpu, orc):
             gi, gs, gc = idx.find_batch(q, dht, 3)
             wi, ws, wc = orc.find64_batch(h, ids, q, dht, 3)
             assert (gc == wc).all() and (gi == wi).all() and (gs == ws).all(), (nq, dht)
+
+
+def test_fold_prefilter_and_deferred_recheck(gpu, orc):
+    """Round 5's prefilter (thresholds <= 6) compares lo ^ hi and defers the re-check: candidates found in up to four
+    lanes of a group are parked, listed and drained 64 at a time; denser groups go through the queue path after the
+    pending list has been drained.  The haystack mixes (a) entries whose FOLD equals a needle's while the hash does not
+    (x ^ (r | r << 32): false positives in every field, the carrying one included, that the 64-bit re-check drops unless
+    2 popc(r) is under the threshold), (b) true neighbours at 0..7 flipped bits, (c) 300 exact duplicates of one entry
+    (every lane of a group holds a flag: the dense path, entered with descriptors pending) and (d) random entries;
+    needle counts straddle the pair / step / chunk boundaries."""
+    rng = np.random.default_rng(555)
+    base = (rng.integers(1, 1 << 62, 48, dtype=np.uint64) << np.uint64(1))
+    parts = [base]
+    r = rng.integers(0, 1 << 32, 1500, dtype=np.uint64)
+    few = rng.random(1500) < 0.5  # half of them with only 0..3 bits set in r: 64-bit distance 0, 2, 4, 6
+    for i in np.nonzero(few)[0]:
+        r[i] = np.bitwise_or.reduce(np.uint64(1) << rng.choice(np.arange(1, 32), int(rng.integers(0, 4)), replace=False)
+                                    .astype(np.uint64)) if rng.random() < 0.9 else np.uint64(0)
+    parts.append(base[rng.integers(0, 48, 1500)] ^ (r | (r << np.uint64(32))))
+    near = base[rng.integers(0, 48, 1200)].copy()
+    for i in range(len(near)):
+        for b in rng.choice(np.arange(1, 64), int(rng.integers(0, 8)), replace=False):
+            near[i] ^= np.uint64(1) << np.uint64(b)
+    parts.append(near)
+    parts.append(np.full(300, base[7], np.uint64))
+    parts.append(rng.integers(1, 1 << 63, 2000, dtype=np.uint64) << np.uint64(1))
+    h = np.concatenate(parts)
+    h[h == 0] = 2
+    h = h[rng.permutation(len(h))]
+    ids = np.arange(1, len(h) + 1, dtype=np.uint32)
+    idx = gpu.DctHashIndex()
+    idx.load(h, ids)
+    for nq in (1, 64, 65, 128, 129, 193, 511, 4097, 16385):
+        q = h[rng.integers(0, len(h), nq)].copy()
+        q[::3] ^= np.uint64(1) << rng.integers(1, 64, len(q[::3])).astype(np.uint64)
+        q[5::11] = 0  # null needles
+        for dht in ((1, 3, 4, 5, 6, 7) if nq < 1000 else (5, 6)):
+            gi, gs, gc = idx.find_batch(q, dht, 4)
+            wi, ws, wc = orc.find64_batch(h, ids, q, dht, 4)
+            assert (gc == wc).all() and (gi == wi).all() and (gs == ws).all(), (nq, dht)
+
+
+def test_prefilter_beyond_its_range(gpu, orc, scan_path):
+    """The prefilter kernel forced for thresholds 7..16 ("scan_pre_max"): on random hashes one pair in 4000 .. 2 is a
+    candidate, so every group takes the lean path, the queue path, or both in turn -- the re-check must still be exact."""
+    if scan_path == "valu":
+        pytest.skip("matrix-core kernels only")
+    from cbird_amd import _lib, synth
+
+    L = _lib.lib()
+    h, ids = synth.make_hashes(12000, seed=808, planted_frac=0.3, max_dist=14)
+    q = h[:1500].copy()
+    q[::4] ^= np.uint64(0x10100)
+    idx = gpu.DctHashIndex()
+    idx.load(h, ids)
+    L.cbh_set_tuning(b"scan_pre_max", 16)
+    try:
+        for dht in (7, 8, 9, 10, 12, 16):
+            gi, gs, gc = idx.find_batch(q, dht, 5)
+            wi, ws, wc = orc.find64_batch(h, ids, q, dht, 5)
+            assert (gc == wc).all() and (gi == wi).all() and (gs == ws).all(), dht
+    finally:
+        L.cbh_set_tuning(b"scan_pre_max", 6)
