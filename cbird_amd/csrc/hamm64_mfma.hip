@@ -334,14 +334,16 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
   // pair p = needles [64p, 64p+64): tile A = first 32, tile B = last 32; 2 uint4 per needle.
   // FULL: lane (c, half) reads word `half` of needle c of each tile; PRE: the prefilter word of needle
   // 64p + lane (tile A in K block 0, tile B in K block 1), one uint4 per needle in qf
-  const uint4* __restrict__ qp = PRE ? qf + (size_t)p0 * 64u + lane : qx + ((size_t)p0 * 64u + r) * 2u + half;
+  const uint4* __restrict__ qp = qx + ((size_t)p0 * 64u + r) * 2u + half;  // (FULL2; PRE addresses its tiles below)
   const uint32_t lo_zero = PRE ? 0x4060u : 0x4080u;      // lo16 at distance 0
   const uint32_t hi_zero = PRE ? 0x4B30u : 0x4B40u;      // hi16 at distance 0
   const uint32_t lo_thr = lo_zero - 2u * (thresh - 1u);  // lo16 >= lo_thr  <=>  distA < thresh
   const uint32_t hi_thr = hi_zero - (thresh - 1u);       // hi16 >= hi_thr  <=>  distB < thresh
   const uint32_t lo_key = lo_thr << 16, hi_key = hi_thr << 16;
   const HitParams hp = {lo_key, hi_key, lo_zero, hi_zero, thresh, n, nq, keep0, q, ids, rec, cap, total, hay, qmask};
-  const bool lean = PRE && (pre_flags & 2u) != 0;
+  // lanes of a group that may hold candidates for the lean path to take it (0: never; an integer, not a bool -- the
+  // compiler re-materialised a uniform bool as a lane mask with two VALU instructions per group)
+  const uint32_t lean_max = (PRE && (pre_flags & 2u)) ? kParkLanes : 0u;
   uint32_t npend = 0;  // PRE lean path: descriptors waiting in s_queue (wave-uniform)
   // one descriptor per lane: the flagged fields of a parked register against all 64 bits
   auto drain = [&]() {
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
   };
 
   // one needle-tile pair against the HT resident haystack tiles
-  auto step = [&](const uint32_t p, const uint4& nA, const uint4& nB) {
+  auto step = [&](const uint32_t p, const uint4& nA, const uint4& nB) __attribute__((always_inline)) {
     const v8i bA = fp4_operand(nA);
     const v8i bB = fp4_operand(nB);
     // G tiles at a time: 2*G MFMAs in flight, G*16 accumulator registers live
@@ -395,31 +397,36 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
         const uint64_t hm = __builtin_amdgcn_ballot_w64(flags != 0);
         if (hm != 0) {
           // wave-uniform from here: some lane holds a candidate (one group in ~10 at threshold 5, every other at 6)
-          if (lean && R <= 32 && (uint32_t)__popcll(hm) <= kParkLanes) {
-            if (flags != 0) {  // the k-th hit lane parks at kPark + 32 k
-              const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+          if (R <= 32 && (uint32_t)__popcll(hm) <= lean_max) {
+            auto park = [&](uint32_t at) {
 #pragma unroll
               for (int t = 0; t < G; ++t)
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                  *reinterpret_cast<float4*>(&s_queue[kPark + rank * 32u + (uint32_t)(t * 16 + 4 * k)]) =
+                  *reinterpret_cast<float4*>(&s_queue[at + (uint32_t)(t * 16 + 4 * k)]) =
                       make_float4(c[t][4 * k], c[t][4 * k + 1], c[t][4 * k + 2], c[t][4 * k + 3]);
+            };
+            if ((hm & (hm - 1)) == 0) {  // one hit lane (nine events in ten): a fixed address, no per-lane arithmetic
+              if (flags != 0) park(kPark);
+            } else if (flags != 0) {  // the k-th hit lane parks at kPark + 32 k
+              park(kPark + 32u * __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u)));
             }
             wave_order();
+            constexpr uint64_t kLow = R >= 32 ? 0xffffffffull : ((1ull << (R & 31)) - 1ull);  // lane r < R <-> register r
             const uint32_t w1c = ((uint32_t)t0 << 4) | (((p - p0) >> 1) << 13);  // tile of register 0, step
-            uint32_t rank = 0;
-            for (uint64_t m = hm; m; m &= m - 1, ++rank) {
-              const uint32_t L = (uint32_t)__builtin_ctzll(m);
-              const uint32_t v = s_queue[kPark + rank * 32u + (lane & 31u)];  // lane r < R: register r of lane L
-              const bool fl = (v & kFlagMaskPre) != 0 && lane < (uint32_t)R;
-              const uint64_t bm = __builtin_amdgcn_ballot_w64(fl);
-              if (fl) {
-                const uint32_t slot =
-                    npend + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-                // lane = 16 t + g: bits 0-3 the register, bits 4-6 (t0 + t) the wave's tile
-                *reinterpret_cast<uint2*>(&s_queue[2u * slot]) = make_uint2(v, (lane + w1c) | (L << 7));
+            uint32_t at = kPark;
+            for (uint64_t m = hm; m; m &= m - 1, at += 32u) {
+              // lane r < R: register r of the hit lane (the lanes above read on into the next slot, or the first words
+              // behind the wave's queue: inside the workgroup's LDS, and discarded by kLow / lane < R)
+              const uint32_t v = s_queue[at + lane];
+              const bool pred = (v & kFlagMaskPre) != 0;
+              const uint32_t bm = (uint32_t)(__builtin_amdgcn_ballot_w64(pred) & kLow);
+              if (pred && lane < (uint32_t)R) {
+                // lane = 16 t + g: bits 0-3 the register, bits 4-6 (t0 + t) the wave's tile; bits 7-12 the hit lane
+                *reinterpret_cast<uint2*>(&s_queue[2u * (npend + __builtin_amdgcn_mbcnt_lo(bm, 0u))]) =
+                    make_uint2(v, lane | (w1c | ((uint32_t)__builtin_ctzll(m) << 7)));
               }
-              npend += (uint32_t)__popcll(bm);
+              npend += (uint32_t)__popc(bm);
             }
             wave_order();
             if (npend >= 64u) drain();
@@ -453,25 +460,36 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
   };
 
   if constexpr (PRE) {
-    // two pairs per trip, the next two 16-byte tile loads in flight meanwhile; a single step() call
-    // site keeps the (not so rare: the prefilter has false positives) re-check code to one copy per tile
-    // (two pairs per step: the chunk length is even, only the call's last pair can be single -- its partner slot is
-    //  fed the same tiles again and its candidates fall out at qi >= nq)
-    // (the partner is chosen by ADDRESS, so that both loads are issued back to back and stay in flight during the
-    //  MFMAs; selecting between the loaded values made the compiler wait for the first load at once)
-    uint4 cur0 = qp[0], cur1 = qp[p0 + 1 < n_pairs ? 64 : 0];
+    // A step takes two needle pairs (four tiles); the chunk length is even, only the call's last pair can be single -- its
+    // partner slot is fed the same tiles again (chosen by ADDRESS, so that both loads are issued back to back and stay in
+    // flight during the MFMAs) and its candidates fall out at qi >= nq.
+    // Two steps per trip with explicit double buffers (round 5): the single call site of rounds 1-4 cost eight VALU
+    // register moves per step (next -> current, and the default of a prefetch that may not happen) + two 64-bit vector
+    // address updates -- a tenth of the loop's VALU instructions, in a kernel bound by VALU issue.
+    // (raw buffer loads: descriptor base = pair p0's tiles, scalar byte offset of the pair, constant per-lane offset)
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4*>(qf + (size_t)p0 * 64u), 0, (int)0xffffffffu, 0x27000);
+    const uint32_t voff = lane * 16u;
+    auto ldt = [&](uint32_t rel, uint32_t partner) -> uint4 {  // tiles of pair p0 + rel (+ 1: the partner, if it exists)
+      const uint32_t pr = min(rel + partner, n_pairs - 1u - p0);  // (s_min_u32: a select here became vector code)
+      const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)(pr * 1024u), 0);
+      return make_uint4(v.x, v.y, v.z, v.w);
+    };
+    const uint32_t np = p1 - p0;
+    uint4 a0 = ldt(0, 0), a1 = ldt(0, 1);
+    uint32_t rel = 0;
 #pragma unroll 1
-    for (uint32_t p = p0; p < p1; p += 2) {
-      uint4 nx0 = cur0, nx1 = cur1;
-      if (p + 2 < p1) {
-        qp += 128;
-        nx0 = qp[0];
-        nx1 = qp[p + 3 < n_pairs ? 64 : 0];
+    for (; rel + 2 < np; rel += 4) {
+      const uint4 b0 = ldt(rel + 2, 0), b1 = ldt(rel + 2, 1);
+      step(p0 + rel, a0, a1);
+      if (rel + 4 < np) {
+        a0 = ldt(rel + 4, 0);
+        a1 = ldt(rel + 4, 1);
       }
-      step(p, cur0, cur1);
-      cur0 = nx0;
-      cur1 = nx1;
+      step(p0 + rel + 2, b0, b1);
     }
+    if (rel < np) step(p0 + rel, a0, a1);
     if (npend) drain();
   } else {
     // two pairs per trip with explicit double buffers: the loads of the next pair are in flight
