@@ -252,8 +252,8 @@ __device__ __forceinline__ void handle_tile(const v16f& c, uint32_t row0, uint32
   wave_order();
 }
 
-// PRE, lean path (candidates in at most kParkLanes lanes of a group -- the common case while candidates are rare: 8192
-// pairs per group x 1e-5 .. 6e-5 per pair).  A candidate costs the matrix pipe nothing but a handful of VALU slots when it
+// PRE, lean path (hit lanes in rounds of kParkLanes; one round and one lane is the common case while candidates are rare:
+// 8192 pairs per group x 1e-5 .. 6e-5 per pair).  A candidate costs the matrix pipe nothing but a handful of VALU slots when it
 // is FOUND and is re-checked LATER, 64 at a time:
 //   * each lane that holds a flag parks its accumulators in LDS (ds_write_b128 straight from the MFMA result registers,
 //     under the lanes' own exec mask: LDS issue, no VALU); hit lane by hit lane, lane r reads register r back, ONE
@@ -266,8 +266,8 @@ __device__ __forceinline__ void handle_tile(const v16f& c, uint32_t row0, uint32
 // (An immediate scalar re-check -- s_load + s_bcnt1 per candidate -- was built first: no VALU at all, but every event
 //  stalled the wave for a scalar-cache miss, 15.9 ms at threshold 6 where this form takes ~11; NOTES 11.)
 // The wave's 2048-word queue space holds the pending list (2 words per descriptor) below the parking area.
-constexpr uint32_t kParkLanes = 4;
-constexpr uint32_t kPark = kQueue - kParkLanes * 32u;  // word offset of the parking area; pending: < 64 + 4 * 32 descriptors
+constexpr uint32_t kParkLanes = 16;  // hit lanes parked at a time (a denser group takes several rounds)
+constexpr uint32_t kPark = kQueue - kParkLanes * 32u;  // word offset of the parking area; pending: < 64 + 16 * 32 <= 768 descriptors
 
 // OR of accumulator registers [A, B) of a group (register r = tile r / 16, element r % 16), three and then two per
 // v_or3_b32
@@ -281,7 +281,10 @@ __device__ __forceinline__ uint32_t or_regs(const v16f (&c)[G]) {
   return o;
 }
 
-template <int HT, int G, bool PRE, int MINB = ((PRE && G == 2 && HT == 8) ? 3 : 1)>
+// LEAN (PRE only): candidates take the park / list / drain path below; false = the per-tile queue path of rounds 1-4
+// (handle_tile), compiled for the shipped shape only ("scan_pre_lean" 0: A/B and the parity suite's "mfma_r4" leg) --
+// a template parameter because the queue path's code is large and would sit, unused, between the hot loop's blocks.
+template <int HT, int G, bool PRE, int MINB = ((PRE && G == 2 && HT == 8) ? 3 : 1), bool LEAN = true>
 __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
     const uint2* __restrict__ hay, const uint32_t* __restrict__ ids, uint32_t n,
     const uint64_t* __restrict__ q, const uint4* __restrict__ qx, uint32_t nq, uint32_t n_pairs,
@@ -341,9 +344,7 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
   const uint32_t hi_thr = hi_zero - (thresh - 1u);       // hi16 >= hi_thr  <=>  distB < thresh
   const uint32_t lo_key = lo_thr << 16, hi_key = hi_thr << 16;
   const HitParams hp = {lo_key, hi_key, lo_zero, hi_zero, thresh, n, nq, keep0, q, ids, rec, cap, total, hay, qmask};
-  // lanes of a group that may hold candidates for the lean path to take it (0: never; an integer, not a bool -- the
-  // compiler re-materialised a uniform bool as a lane mask with two VALU instructions per group)
-  const uint32_t lean_max = (PRE && (pre_flags & 2u)) ? kParkLanes : 0u;
+
   uint32_t npend = 0;  // PRE lean path: descriptors waiting in s_queue (wave-uniform)
   // one descriptor per lane: the flagged fields of a parked register against all 64 bits
   auto drain = [&]() {
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
         const uint64_t hm = __builtin_amdgcn_ballot_w64(flags != 0);
         if (hm != 0) {
           // wave-uniform from here: some lane holds a candidate (one group in ~10 at threshold 5, every other at 6)
-          if (R <= 32 && (uint32_t)__popcll(hm) <= lean_max) {
+          if constexpr (LEAN && R <= 32) {
             auto park = [&](uint32_t at) {
 #pragma unroll
               for (int t = 0; t < G; ++t)
@@ -406,32 +407,42 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
                   *reinterpret_cast<float4*>(&s_queue[at + (uint32_t)(t * 16 + 4 * k)]) =
                       make_float4(c[t][4 * k], c[t][4 * k + 1], c[t][4 * k + 2], c[t][4 * k + 3]);
             };
-            if ((hm & (hm - 1)) == 0) {  // one hit lane (nine events in ten): a fixed address, no per-lane arithmetic
-              if (flags != 0) park(kPark);
-            } else if (flags != 0) {  // the k-th hit lane parks at kPark + 32 k
-              park(kPark + 32u * __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u)));
-            }
-            wave_order();
             constexpr uint64_t kLow = R >= 32 ? 0xffffffffull : ((1ull << (R & 31)) - 1ull);  // lane r < R <-> register r
             const uint32_t w1c = ((uint32_t)t0 << 4) | (((p - p0) >> 1) << 13);  // tile of register 0, step
-            uint32_t at = kPark;
-            for (uint64_t m = hm; m; m &= m - 1, at += 32u) {
-              // lane r < R: register r of the hit lane (the lanes above read on into the next slot, or the first words
-              // behind the wave's queue: inside the workgroup's LDS, and discarded by kLow / lane < R)
-              const uint32_t v = s_queue[at + lane];
-              const bool pred = (v & kFlagMaskPre) != 0;
-              const uint32_t bm = (uint32_t)(__builtin_amdgcn_ballot_w64(pred) & kLow);
-              if (pred && lane < (uint32_t)R) {
-                // lane = 16 t + g: bits 0-3 the register, bits 4-6 (t0 + t) the wave's tile; bits 7-12 the hit lane
-                *reinterpret_cast<uint2*>(&s_queue[2u * (npend + __builtin_amdgcn_mbcnt_lo(bm, 0u))]) =
-                    make_uint2(v, lane | (w1c | ((uint32_t)__builtin_ctzll(m) << 7)));
+            // hit lanes in chunks of kParkLanes (one chunk unless the group is dense: duplicates, video frames)
+            uint64_t rest = hm;
+            do {
+              uint64_t cm = rest;
+              if ((uint32_t)__popcll(rest) > kParkLanes) {
+                uint64_t rem = rest;
+                for (uint32_t i = 0; i < kParkLanes; ++i) rem &= rem - 1;
+                cm = rest ^ rem;  // the lowest kParkLanes hit lanes
               }
-              npend += (uint32_t)__popc(bm);
-            }
-            wave_order();
-            if (npend >= 64u) drain();
+              rest ^= cm;
+              if ((cm & (cm - 1)) == 0 && cm == hm) {  // one hit lane (nine events in ten): a fixed address
+                if (flags != 0) park(kPark);
+              } else if ((cm >> lane) & 1ull) {  // the k-th hit lane of the chunk parks at kPark + 32 k
+                park(kPark + 32u * __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u)));
+              }
+              wave_order();
+              uint32_t at = kPark;
+              for (uint64_t m = cm; m; m &= m - 1, at += 32u) {
+                // lane r < R: register r of the hit lane (the lanes above read on into the next slot, or the first
+                // words behind the wave's queue: inside the workgroup's LDS, and discarded by kLow / lane < R)
+                const uint32_t v = s_queue[at + lane];
+                const bool pred = (v & kFlagMaskPre) != 0;
+                const uint32_t bm = (uint32_t)(__builtin_amdgcn_ballot_w64(pred) & kLow);
+                if (pred && lane < (uint32_t)R) {
+                  // lane = 16 t + g: bits 0-3 the register, bits 4-6 (t0 + t) the wave's tile; bits 7-12 the hit lane
+                  *reinterpret_cast<uint2*>(&s_queue[2u * (npend + __builtin_amdgcn_mbcnt_lo(bm, 0u))]) =
+                      make_uint2(v, lane | (w1c | ((uint32_t)__builtin_ctzll(m) << 7)));
+                }
+                npend += (uint32_t)__popc(bm);
+              }
+              wave_order();
+              if (npend >= 64u) drain();
+            } while (rest);
           } else {
-            if (npend) drain();  // the queue path uses the whole queue space
 #pragma unroll
             for (int t = 0; t < G; ++t)
               handle_tile<PRE>(c[t], (tile0 + t0 + t) * 32u, (uint32_t)(t0 + t) * 32u, p, hp, s_queue, s_hay);
@@ -478,18 +489,16 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
     };
     const uint32_t np = p1 - p0;
     uint4 a0 = ldt(0, 0), a1 = ldt(0, 1);
-    uint32_t rel = 0;
 #pragma unroll 1
-    for (; rel + 2 < np; rel += 4) {
-      const uint4 b0 = ldt(rel + 2, 0), b1 = ldt(rel + 2, 1);
+    for (uint32_t rel = 0; rel < np; rel += 4) {  // (two call sites of step(): its cold paths are large)
+      const uint4 b0 = ldt(min(rel + 2, np - 1), 0), b1 = ldt(min(rel + 2, np - 1), 1);
       step(p0 + rel, a0, a1);
-      if (rel + 4 < np) {
-        a0 = ldt(rel + 4, 0);
-        a1 = ldt(rel + 4, 1);
+      if (rel + 2 < np) {
+        a0 = ldt(min(rel + 4, np - 1), 0);
+        a1 = ldt(min(rel + 4, np - 1), 1);
+        step(p0 + rel + 2, b0, b1);
       }
-      step(p0 + rel + 2, b0, b1);
     }
-    if (rel < np) step(p0 + rel, a0, a1);
     if (npend) drain();
   } else {
     // two pairs per trip with explicit double buffers: the loads of the next pair are in flight
@@ -602,7 +611,7 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma3(
   // triple p = needles [96p, 96p+96): three tiles of 32; lane (c, half) reads word `half` of needle c
   const uint4* __restrict__ qp = qx + ((size_t)p0 * 96u + r) * 2u + half;
 
-  auto step = [&](const uint32_t p, const uint4& n0, const uint4& n1, const uint4& n2) {
+  auto step = [&](const uint32_t p, const uint4& n0, const uint4& n1, const uint4& n2) __attribute__((always_inline)) {
     const v8i b0 = fp4_operand(n0), b1 = fp4_operand(n1), b2 = fp4_operand(n2);
 #pragma unroll
     for (int t0 = 0; t0 < HT; t0 += G) {
@@ -619,36 +628,41 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma3(
       for (int t = 0; t < G; ++t)
         c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[t0 + t], b2, c[t], 4, 4, 0, kScaleOne, 0,
                                                                kScale14);
-      uint32_t o0 = 0, o1 = 0;
-#pragma unroll
-      for (int t = 0; t < G; ++t)
-#pragma unroll
-        for (int g = 0; g < 16; g += 4) {
-          o0 |= as_u32(c[t][g]) | as_u32(c[t][g + 1]);      // v_or3_b32
-          o1 |= as_u32(c[t][g + 2]) | as_u32(c[t][g + 3]);
-        }
-      if (__builtin_amdgcn_ballot_w64(((o0 | o1) & kFlagMask3) != 0) != 0) {
+      // one v_or3_b32 per two result registers, the last register and the mask in one v_bitop3_b32
+      if (__builtin_amdgcn_ballot_w64((or_regs<0, G * 16, G>(c) & kFlagMask3) != 0) != 0) {
 #pragma unroll
         for (int t = 0; t < G; ++t) handle_tile3(c[t], (tile0 + t0 + t) * 32u, p, hp, s_queue);
       }
     }
   };
 
-  // one triple (6 * HT MFMAs) per trip, the next triple's three tile loads in flight meanwhile
-  uint4 x0 = qp[0], x1 = qp[64], x2 = qp[128];
+  // Two triples (12 * HT MFMAs) per trip with explicit double buffers, the next triple's three tile loads in flight
+  // meanwhile (round 5; as in the prefilter kernel: the single call site cost 12 register moves and three vector address
+  // updates per triple, and this kernel too is bound by what the VALU issues beside the MFMAs -- T = 24 M + 4 V cycles).
+  // Raw buffer loads: descriptor base = triple p0, scalar byte offset of the tile, constant per-lane offset.
+  typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+  (void)qp;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint4*>(qx + (size_t)p0 * 192u), 0, (int)0xffffffffu, 0x27000);
+  const uint32_t voff = (2u * r + half) * 16u;
+  auto ldt = [&](uint32_t rel, uint32_t tile) -> uint4 {  // tile 0..2 of triple p0 + rel
+    const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)(rel * 3072u + tile * 1024u), 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+  };
+  const uint32_t np = p1 - p0;
+  uint4 x0 = ldt(0, 0), x1 = ldt(0, 1), x2 = ldt(0, 2);
 #pragma unroll 1
-  for (uint32_t p = p0; p < p1; ++p) {
-    uint4 y0 = x0, y1 = x1, y2 = x2;
-    if (p + 1 < p1) {
-      qp += 192;
-      y0 = qp[0];
-      y1 = qp[64];
-      y2 = qp[128];
+  for (uint32_t rel = 0; rel < np; rel += 2) {  // (two call sites of step())
+    const uint32_t ry = min(rel + 1, np - 1);
+    const uint4 y0 = ldt(ry, 0), y1 = ldt(ry, 1), y2 = ldt(ry, 2);
+    step(p0 + rel, x0, x1, x2);
+    if (rel + 1 < np) {
+      const uint32_t rx = min(rel + 2, np - 1);
+      x0 = ldt(rx, 0);
+      x1 = ldt(rx, 1);
+      x2 = ldt(rx, 2);
+      step(p0 + rel + 1, y0, y1, y2);
     }
-    step(p, x0, x1, x2);
-    x0 = y0;
-    x1 = y1;
-    x2 = y2;
   }
 }
 
@@ -758,12 +772,12 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
   if (ht == 8 && g_mfma_g == 4) {
     if (pre) CBH_MFMA_G(8, 4, true); else CBH_MFMA_G(8, 4, false);
   } else if (ht == 8 && pre && g_mfma_pre_minb != 3) {  // A/B: workgroups per CU the prefilter is compiled for
-#define CBH_MFMA_B(MB)                                                                                    \
-  hipLaunchKernelGGL((k_hamm64_mfma<8, kG, true, MB>), dim3(wgs, chunks), dim3(kThreads), 0, stream,      \
+#define CBH_MFMA_B(MB, LN)                                                                                \
+  hipLaunchKernelGGL((k_hamm64_mfma<8, kG, true, MB, LN>), dim3(wgs, chunks), dim3(kThreads), 0, stream,  \
                      reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx, (uint32_t)nq, \
                      n_pairs, ppc, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total,             \
                      (uint32_t)(flags & 1u), reinterpret_cast<const uint2*>(d_qmask), qf, pre_flags)
-    if (g_mfma_pre_minb == 2) CBH_MFMA_B(2); else if (g_mfma_pre_minb == 4) CBH_MFMA_B(4); else CBH_MFMA_B(1);
+    if (g_mfma_pre_minb == 2) CBH_MFMA_B(2, true); else if (g_mfma_pre_minb == 4 && !g_pre_lean) CBH_MFMA_B(4, false); else if (g_mfma_pre_minb == 4) CBH_MFMA_B(4, true); else CBH_MFMA_B(1, true);
 #undef CBH_MFMA_B
   } else if (ht == 8) {
     if (pre) CBH_MFMA(8, true); else CBH_MFMA(8, false);
