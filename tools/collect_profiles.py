@@ -73,8 +73,10 @@ def main():
         return (2.0 * fm + wm) * 1024.0, fm, wm
 
     out = {}
-    for key in ("k_hamm64_mfma", "k_hamm64_scan", "k_dcthash_256"):
-        t, fm, wm = traffic(key)
+    # (name prefix of the kernel -> key in pmc_traffic.json; "k_hamm64_mfma<" = the prefilter kernel, "k_hamm64_mfma3" = FULL3)
+    for prefix, key in (("k_hamm64_mfma3", "k_hamm64_mfma"), ("k_hamm64_mfma<", "k_hamm64_mfma_pre"),
+                        ("k_hamm64_scan", "k_hamm64_scan"), ("k_dcthash_256", "k_dcthash_256")):
+        t, fm, wm = traffic(prefix)
         out[key] = t
         out[key + "_detail"] = {"FETCH_SIZE_KiB_raw": fm, "WRITE_SIZE_KiB_raw": wm, "formula": FORMULA}
     out["source"] = (f"profiles/{TAG}_pmc_FETCH_SIZE.csv, profiles/{TAG}_pmc_WRITE_SIZE.csv (separate rocprofv3 "
