@@ -244,7 +244,7 @@ def main():
         sweep.append({"dht": dht, "scan_kernel_ms": round(sm, 3), "find_latency_ms": round(fm, 3),
                       "scan_cmp_per_s": shard_n * n / sm * 1e3, "matches": finds[dht][0][1]})
     # the matrix-core scan has two shapes: k_hamm64_mfma3 (64-bit dot products; thresholds > PRE_MAX_DHT) and PRE (32-bit
-    # prefilter on lo ^ hi + exact re-check of the candidates; thresholds <= PRE_MAX_DHT = the library's "scan_pre_max"),
+    # prefilter on lo ^ hi + exact re-check of the candidates; thresholds <= PRE_MAX_DHT = the library's "scan_mfma_pre_max"),
     # which executes half the multiply-adds per comparison.  `roofline` prices whichever of the two takes more of the
     # step's time; both are reported (roofline_full3, roofline_pre) with the flops they really issue.
     import ctypes as _ct
@@ -252,7 +252,7 @@ def main():
     from cbird_amd import _lib as _cl
 
     _v = _ct.c_longlong(0)
-    PRE_MAX_DHT = int(_v.value) if _cl.lib().cbh_get_tuning(b"scan_pre_max", _ct.byref(_v)) == 0 else 4
+    PRE_MAX_DHT = int(_v.value) if _cl.lib().cbh_get_tuning(b"scan_mfma_pre_max", _ct.byref(_v)) == 0 else 4
     full = [d for d in dhts if d > PRE_MAX_DHT] or dhts
     pre = [d for d in dhts if d <= PRE_MAX_DHT and d not in full]
     scan_ms_avg = sum(sum(scans[d]) for d in full) / sum(len(scans[d]) for d in full)

@@ -141,7 +141,7 @@ void set_scan_pre_max(int t);   // thresholds <= t take the 32-bit prefilter ker
 void set_scan_pre_fold(int v);  // prefilter word: 1 = lo ^ hi, 0 = lo
 void set_scan_pre_lean(int v);  // 1 = single candidates re-checked on the scalar unit
 void set_scan_mfma_full3(int on);  // three-needle-tile accumulator variant for thresholds > 4
-void set_scan_mfma_pre(int on);  // low-word prefilter variant for small thresholds
+void set_scan_mfma_pre(int on);  // 32-bit prefilter variant for small thresholds
 
 // ---- hamm256_mfma.hip: 256-bit threshold scan on the matrix cores -----------------------
 int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, size_t nq, int thresh,

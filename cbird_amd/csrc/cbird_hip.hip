@@ -1433,7 +1433,7 @@ int cbh_set_tuning(const char* key, int value) {
     set_scan_mfma_g(value);
     return CBH_OK;
   }
-  if (!strcmp(key, "scan_pre_max")) {
+  if (!strcmp(key, "scan_mfma_pre_max")) {
     set_scan_pre_max(value);
     return CBH_OK;
   }
@@ -1543,7 +1543,7 @@ int cbh_get_tuning(const char* key, long long* value) {
   if (!strcmp(key, "fault_fired")) return *value = (long long)get_fault_fired(), CBH_OK;
   if (!strcmp(key, "alloc_calls")) return *value = (long long)get_alloc_calls(), CBH_OK;
   if (!strncmp(key, "arena_", 6)) return arena_counter(key + 6, value);
-  if (!strcmp(key, "scan_pre_max")) return *value = get_scan_pre_max(), CBH_OK;
+  if (!strcmp(key, "scan_mfma_pre_max")) return *value = get_scan_pre_max(), CBH_OK;
   return CBH_E_INVAL;
 }
 

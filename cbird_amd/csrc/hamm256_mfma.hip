@@ -297,7 +297,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_hamm256_small(  // (2: accumula
   constexpr int G = 2;  // accumulators in flight
   __shared__ uint32_t s_c[kWaves][G * 16][64];
   __shared__ uint32_t s_lut[LUT ? 256 : 1];
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // uniform, and known to be
   const uint32_t r = lane & 31u, half = lane >> 5;
   if constexpr (LUT) {
     for (uint32_t i = threadIdx.x; i < 256u; i += kThreads) s_lut[i] = fp4_expand32(i).x;
@@ -320,22 +321,31 @@ __global__ __launch_bounds__(kThreads, 2) void k_hamm256_small(  // (2: accumula
   asm volatile("" : "+v"(c0));
   const uint32_t n_row_tiles = (n + 31u) / 32u;
   const uint32_t stride = gridDim.x * kWaves;
-  uint32_t tile = blockIdx.x * kWaves + wave;
+  uint32_t tile0 = blockIdx.x * kWaves + wave;
+  // Raw words of a row tile through raw buffer loads (round 5): descriptor over the n rows, per-lane offset (row in the
+  // tile, word) constant, the tile's offset scalar -- no 64-bit vector address arithmetic, and rows past the end read as
+  // zero by the descriptor's range check instead of a select per word (the launcher keeps n * 32 below 2^32).
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(rows), 0, (int)(n * 32u), 0x27000);
+  const uint32_t voff = r * 32u + half * 4u;
   auto load_raw = [&](uint32_t t, uint32_t& w0, uint32_t& w1) {
-    const uint32_t row = t * 32u + r;
-    const bool in = t < n_row_tiles && row < n;
-    w0 = in ? rows[(size_t)row * 8u + half] : 0u;
-    w1 = in ? rows[(size_t)row * 8u + 2u + half] : 0u;
+    const uint32_t so = min(t, n_row_tiles) * 1024u;  // (a tile past the end: out of range, zeros)
+    w0 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)so, 0);
+    w1 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff + 8u), (int)so, 0);
   };
   constexpr int kAhead = 4;  // row tiles in flight (a tile's MFMAs take ~0.6 us, an HBM load under load 1-2 us)
   uint32_t p0[kAhead], p1[kAhead];
 #pragma unroll
-  for (int u = 0; u < kAhead; ++u) load_raw(tile + (uint32_t)u * stride, p0[u], p1[u]);
-  for (; tile < n_row_tiles; tile += stride) {
-    const v8i a0 = fp4_operand(expand(p0[0])), a1 = fp4_operand(expand(p1[0]));
+  for (int u = 0; u < kAhead; ++u) load_raw(tile0 + (uint32_t)u * stride, p0[u], p1[u]);
+  // kAhead tiles per trip, each from its own pair of registers (round 5: the shifting ring cost six moves per tile)
+#pragma unroll 1
+  for (; tile0 < n_row_tiles; tile0 += (uint32_t)kAhead * stride) {
 #pragma unroll
-    for (int u = 0; u + 1 < kAhead; ++u) p0[u] = p0[u + 1], p1[u] = p1[u + 1];
-    load_raw(tile + (uint32_t)kAhead * stride, p0[kAhead - 1], p1[kAhead - 1]);  // behind the MFMAs of kAhead tiles
+  for (int u = 0; u < kAhead; ++u) {
+    const uint32_t tile = tile0 + (uint32_t)u * stride;
+    if (tile >= n_row_tiles) break;  // (uniform)
+    const v8i a0 = fp4_operand(expand(p0[u])), a1 = fp4_operand(expand(p1[u]));
+    load_raw(tile + (uint32_t)kAhead * stride, p0[u], p1[u]);  // behind the MFMAs of kAhead tiles
 #pragma unroll
     for (int j0 = 0; j0 < NA; j0 += G) {
       v16f c[G];
@@ -399,6 +409,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_hamm256_small(  // (2: accumula
       }
     }
   }
+  }
 }
 
 int g_scan256_small = 1;   // "scan256_small": the stationary-needle kernel for <= 512 needle descriptors (default on)
@@ -453,7 +464,8 @@ int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, siz
   CBH_HIP(cbh::malloc_async((void**)&qx, (size_t)nq_pad * 128u, stream));
   hipLaunchKernelGGL(k_expand_needles256, dim3((8u * nq_pad + 255u) / 256u), dim3(256), 0, stream,
                      reinterpret_cast<const uint32_t*>(d_q), (uint32_t)nq, nq_pad, qx);
-  if (g_scan256_small && g_scan256_pre && thresh <= kPre128MaxThresh && n_tiles <= 16 && (n >= 4096 || g_scan256_mfma == 2)) {
+  if (g_scan256_small && g_scan256_pre && thresh <= kPre128MaxThresh && n_tiles <= 16 && (n >= 4096 || g_scan256_mfma == 2) &&
+      n <= ((size_t)1 << 27) - 64) {  // (its buffer descriptor spans n * 32 bytes)
     // needle tiles padded to the template's count read zero descriptors from the scratch (rows of zero bits never pass:
     // qi >= nq is dropped in the hit path)
     const uint32_t nt = n_tiles <= 4 ? 4 : n_tiles <= 8 ? 8 : 16;

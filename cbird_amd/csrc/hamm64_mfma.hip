@@ -66,7 +66,7 @@ constexpr int kG = 2;  // tiles per accumulator group
 // 2^23 + 0x4040 + 64 * 2^15
 constexpr float kC0 = 8388608.0f + 16448.0f + 2097152.0f;
 constexpr int kScale15 = 0x8e8e8e8e;  // E8M0 142 = 2^15
-// Thresholds the prefilter serves ("scan_pre_max").  P[popc(32 random bits) < t] per pair: 1.3e-6 at 4, 9.7e-6 at 5,
+// Thresholds the prefilter serves ("scan_mfma_pre_max").  P[popc(32 random bits) < t] per pair: 1.3e-6 at 4, 9.7e-6 at 5,
 // 5.7e-5 at 6, 2.7e-4 at 7.  Rounds 1-4 stopped at 4: on the low word, image-derived hashes gave 2.7x the candidates of
 // uniform ones at 5 and the vector re-check (~750 cycles per candidate group) lost to FULL3 (19.2 vs 17.1 ms).  With the
 // fold and the deferred re-check (round 5; same box, 1M x 1M image-derived hashes, tools/ab/pre_fold_ab.py): threshold 5
@@ -76,7 +76,7 @@ int g_pre_fold = 1;   // "scan_pre_fold": 1 = prefilter on lo ^ hi (default), 0 
 int g_pre_lean = 1;   // "scan_pre_lean": 1 = a group whose candidates sit in ONE register of ONE lane is re-checked on
                       // the scalar unit (readlane + s_load + s_bcnt1), 0 = always the LDS queue path (A/B)
 constexpr uint32_t kQueue = 2048;     // 16 registers x 2 fields x 64 lanes: cannot overflow
-// PRE keeps FOUR low-word distances per accumulator register as 6-bit fields at bits 0, 6, 12, 18 (two chained
+// PRE keeps FOUR prefilter-word distances per accumulator register as 6-bit fields at bits 0, 6, 12, 18 (two chained
 // MFMAs; see the kernel), biased so that "under the threshold" is bit 5 of the field; the top field's flag is the carry
 // into the f32 exponent (bit 23 of the pattern).  OR-ing accumulators preserves "some flag is set".
 constexpr uint32_t kFlagMaskPre = (1u << 5) | (1u << 11) | (1u << 17) | (1u << 23);
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
   //        from 150 to 151).  The +-0.5 products of the first K block are exact at an accumulator of 2^23 because the
   //        hardware adds the 32 products of a block (an integer) before it meets the accumulator -- checked on
   //        4.3e9 results incl. 1e7 hits by tools/ubench/mfma_half_exact.hip.  One result VGPR now answers 256
-  //        low-word comparisons instead of 128: half the v_or3_b32 per comparison.
+  //        prefilter comparisons instead of 128: half the v_or3_b32 per comparison.
   v16f c0;
 #pragma unroll
   for (int g = 0; g < 16; ++g)
@@ -667,9 +667,9 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma3(
 }
 
 int g_scan_mfma = 1;           // use the matrix-core scan when the batch is large enough
-int g_mfma_full3 = 1;          // three-field variant for kPreMaxThresh < thresh <= 64
+int g_mfma_full3 = 1;          // three-field variant for g_pre_max_thresh < thresh <= 64
 int g_mfma_ht = 8;             // haystack tiles per wave (2, 4 or 8)
-int g_mfma_pre = 1;            // low-word prefilter variant for thresh <= kPreMaxThresh
+int g_mfma_pre = 1;            // 32-bit prefilter variant for thresh <= g_pre_max_thresh
 int g_mfma_pre_minb = 4;       // "scan_mfma_pre" = 11 .. 14: the prefilter compiled for >= 1 / 2 / 3 / 4 workgroups per CU.  Same box,
                                // alternating (tools/ab/scan_pre_ab.py): 10.8 / 10.8 / 10.1 / 9.8 ms -- this kernel is bound by VALU
                                // issue, and a fourth wave per SIMD (128 VGPRs, 12 bytes of spill) hides more of it

@@ -706,9 +706,9 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *   "scan_mfma"     64-bit scan on the matrix cores (k_hamm64_mfma): 0 = never, 1 = calls with >= 256
  *                   needles and >= 4096 slots (default), 2 = always
  *   "scan_mfma_ht"  haystack tiles per wave in k_hamm64_mfma: 2, 4 or 8 (default 8)
- *   "scan_mfma_pre" 1 = thresholds <= "scan_pre_max" use the 32-bit prefilter variant of k_hamm64_mfma (default 1),
+ *   "scan_mfma_pre" 1 = thresholds <= "scan_mfma_pre_max" use the 32-bit prefilter variant of k_hamm64_mfma (default 1),
  *                   0 = never, 2 = for every threshold <= 32 (experiments)
- *   "scan_pre_max"  the largest threshold that takes the prefilter variant (default 6; rounds 1-4: 4)
+ *   "scan_mfma_pre_max" the largest threshold that takes the prefilter variant (default 6; rounds 1-4: 4)
  *   "scan_pre_fold" 1 = the prefilter compares lo ^ hi of the hashes (default: a lower bound on the distance that sees
  *                   all 64 bits), 0 = the low words (rounds 1-4)
  *   "scan_pre_lean" 1 = prefilter candidates confined to a few lanes are parked, listed and re-checked 64 at a time
@@ -787,7 +787,7 @@ int cbh_set_tuning(const char* key, int value);
 /* Read-back for tests and soak tools: "fault_alloc_after" (what is left of the countdown, -1 = disarmed or fired),
  * "fault_fired", "alloc_calls" (allocations seen since the library loaded), and the scratch arena's
  * "arena_cached_bytes", "arena_pending_bytes", "arena_live_bytes", "arena_live_blocks", "arena_trimmed_live",
- * "arena_oom_retry_stream", "arena_oom_retry_device", "arena_released"; "scan_pre_max" (the largest threshold that
+ * "arena_oom_retry_stream", "arena_oom_retry_device", "arena_released"; "scan_mfma_pre_max" (the largest threshold that
  * runs the prefilter scan kernel under the present knobs, 0 = none). */
 int cbh_get_tuning(const char* key, long long* value);
 
