@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_hamm256_small(  // (2: accumula
   // needle tiles 3j, 3j+1, 3j+2 share accumulator j (the 8-bit flag fields of k_hamm256_mfma3; the last accumulator holds
   // the one or two tiles that remain): 16 result registers per up to six MFMAs
   constexpr int NA = (NT + 2) / 3;
-  constexpr int G = 2;  // accumulators in flight
+  constexpr int G = NA % 3 == 0 ? 3 : 2;  // accumulators in flight (independent MFMA chains)
   __shared__ uint32_t s_c[kWaves][G * 16][64];
   __shared__ uint32_t s_lut[LUT ? 256 : 1];
   const uint32_t lane = threadIdx.x & 63u;
