@@ -163,7 +163,8 @@ extern int g_fdct_host_vote, g_video_host_reduce;  // fdct.hip: 1 = round-1 host
 void set_orb_retain_order(int v);  // orb.hip: 1 (default) retainBest in libstdc++'s order, 0 canonical (ties kept, raster order)
 void set_hash_fuse(int v);      // dcthash.hip: vertical INTER_AREA pass + tile inside k_blur_area_regs (0 never, 1 auto, 2 always)
 void set_hash_area(int v);      // dcthash.hip: 1 = integer sums for the interior of fractional INTER_AREA cells (NOT bit-identical)
-void set_hash_band_waves(int v);  // dcthash.hip: waves per workgroup of k_dcthash_256_band (1, 2)
+void set_hash_band_waves(int v);
+void set_hash_band_area(int v);  // dcthash.hip: waves per workgroup of k_dcthash_256_band (1, 2)
 void set_hash_wide(int v);      // dcthash.hip: images wider than 2048 px on column strips of the register-streaming kernel (default 1)
 void set_hash_rows_per_step(int v);  // dcthash.hip: source rows per step of k_blur_area_regs<7> (0 = 14 always, 1 = 14 / 21 / 28 by turn fill, 21 / 28 forced)
 void set_hash_tiles2(int v);    // dcthash.hip: stages 3-6 of fused tiles two images per wave (default 1)

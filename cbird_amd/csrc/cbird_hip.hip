@@ -1365,6 +1365,10 @@ int cbh_set_tuning(const char* key, int value) {
     set_cd_chains(value);
     return CBH_OK;
   }
+  if (!strcmp(key, "hash_band_area")) {
+    set_hash_band_area(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "hash_band_waves")) {
     set_hash_band_waves(value);
     return CBH_OK;

@@ -580,6 +580,13 @@ struct BandTables {
 
 constexpr int kBandPitch = 272;  // 8 + 256 + 8
 
+// a one-wave workgroup orders its own LDS accesses in hardware; only the compiler must not move them across the phases
+__device__ __forceinline__ void wave_order_lds() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // NW = waves per workgroup.  1 (default): a wave owns its four images alone (no barrier anywhere in the loop; 17 KB of LDS
 // per wave, 9 waves per CU).  2 (knob "hash_band_waves", measured 5 % slower): two waves share the four images -- each takes 8 of the 16 column tiles, half of the row
 // staging and two of the four images' DCT stages -- so the row ring and the tiles are held once per TWO waves (21 KB per
@@ -840,6 +847,223 @@ struct YRow {
   float a0, a1;
   int info, pad;
 };
+
+// ---------------------------------------------------------------------------------------------
+// k_band_area (round 5): k_dcthash_256_band's matrix-core blur for ANY width and height, feeding cv::resize's weighted
+// INTER_AREA path (fractional ratios, resizeArea_) in the reference's float chain order.
+//
+// One wave = four images x one COLUMN STRIP of up to 16 output cells (<= 240 source columns), walked top to bottom in
+// lockstep, four rows per step, like the 256 x 256 kernel: rows travel global -> registers (two steps ahead) -> a 12-row
+// LDS ring per image -> one ds_read_b128 per 16-column tile in the A-operand layout; v_mfma_i32_16x16x64_i8 against a
+// band matrix (K = 32 columns of the row, +1 on the seven taps, ++ the same columns of the row seven above, -1) gives
+// D = Hsum(u) - Hsum(u - 7); S += D is the 7 x 7 box sum, one fma turns 2^23 + S into 2^23 + const + nearest(S / 49)
+// (k_dcthash_256_band's exact division, the constant chosen so that the quotient IS the low byte).  What differs:
+//   * the blurred pixels are needed as bytes.  A lane holds four consecutive ROWS of one column: their quotients are
+//     packed into one dword and stored TRANSPOSED, sT[x][image] = rows y .. y + 3 of column x;
+//   * horizontal INTER_AREA: lane (image, cell) walks its cell's columns in table order and runs the four rows' chains
+//     `sum += float(p) * alpha` as two float pairs (v_cvt_f32_ubyte0..3, v_pk_mul_f32, v_pk_add_f32: ordinary IEEE
+//     multiplies and adds, the bits of the scalar chain) -- 2 instructions per pixel, every lane busy when a strip has 16
+//     cells, no per-lane trip counts (columns past a cell carry the weight +0.0f);
+//   * vertical INTER_AREA in the same lane, which already holds its (image, cell)'s four horizontal sums: the y table seen
+//     from the source row (YRow), k_blur_area_regs<.., FUSE>'s chain; finished tile bytes go straight to global memory;
+//   * REFLECT_101 left / right is folded into per-strip band matrices made on the host (first tile of the first strip,
+//     last two tiles of the last strip), top / bottom into the row addresses.
+// Stages 3-6 run from the tiles (k_tiles_hash2).  Against k_blur_area_regs (blur 5.9 + area 2.75 / 0.7 VALU instructions
+// per pixel): ~2.5 + ~2.2 -- see DESIGN a1.  Preconditions (launcher): whole images, 7 x 7 blur, fractional ratios,
+// cells of at most 30 columns (w <= 960), four images' strides below 2^32.
+struct BaStrip {
+  int xs;       // first source column of the strip's first cell
+  int T;        // 16-column tiles (<= 15)
+  int cell0;    // first output cell
+  int ncell;    // cells (<= 16)
+  int amax;     // longest cell walk (<= 32)
+  int pad_[3];
+  int si0[16];             // first source column of cell c, relative to xs
+  float alpha[16][32];     // its weights in table order, +0.0f past the end
+  unsigned band[3][64][4]; // B operands: the plain band, the strip's first tile, its last tile
+};
+
+template <int T>  // 16-column tiles per strip (the same for every strip of a geometry)
+__global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restrict__ imgs, unsigned n, int w, int h,
+                                                  unsigned row_stride, unsigned img_stride, unsigned long long buf_bytes,
+                                                  const BaStrip* __restrict__ strips, const YRow* __restrict__ yrow,
+                                                  unsigned char* __restrict__ tiles_out) {
+  // LDS, sized by T (separate arrays: the compiler must know that they do not alias): ring 4 x 12 rows x kPitch, sT =
+  // blurred bytes [x][image] = 4 rows (+ 8 columns for the walk's overhang), sA = the cells' weights [16][amax]
+  constexpr int kRing = 12, kPitch = 16 * T + 32, kImg = kRing * kPitch;
+  __shared__ __attribute__((aligned(16))) unsigned char sRing[4 * kImg];
+  // sT[image][x]: the area walk has lane (image, cell) read column si0[cell] + k -- cells 28 columns apart would meet in
+  // the same banks four ways in an [x][image] layout (900 px: half the speed); per-image planes of kTP = 8 (mod 32) dwords
+  // keep the cells of one image and the four images apart.  sA: 33 floats per cell (an odd stride: 16 cells, 16 banks)
+  constexpr int kTP = ((16 * T + 8 + 31) / 32) * 32 + 8;
+  __shared__ __attribute__((aligned(16))) unsigned sT[4 * kTP];
+  __shared__ __attribute__((aligned(16))) float sA[16 * 33];
+  const int lane = threadIdx.x & 63;
+  const int n16 = lane & 15, q = lane >> 4;
+  const BaStrip& st = strips[blockIdx.x];
+  const int xs = st.xs, ncell = st.ncell, amax = st.amax;  // (amax: a multiple of 4)
+  const unsigned first = blockIdx.y * 4u;
+  unsigned mine = first + (unsigned)q;
+  if (mine >= n) mine = n - 1;
+  // staging role: image q, chunk n16 of a row = columns xs - 8 + 16 n16 .. + 15, as two 8-byte halves.  Every lane loads
+  // (no divergent branch around the loads: the compiler then tracks their wait counts): a half left of column 0 reads from
+  // column 0, one past the row's end the next row's first bytes (at the end of the buffer: zeros, by the descriptor's range)
+  // -- all of them columns to which the band matrices give no weight, so any bytes do
+  const unsigned long long base_off = (unsigned long long)first * img_stride;
+  const unsigned long long left = buf_bytes > base_off ? buf_bytes - base_off : 0ull;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(imgs + base_off), 0, (int)(left > 0xffffffffull ? 0xffffffffu : (unsigned)left), 0x27000);
+  const int colA = xs - 8 + 16 * n16;
+  const unsigned voffA = (mine - first) * img_stride + (unsigned)(colA < 0 ? 0 : colA);
+  const unsigned voffB = (mine - first) * img_stride + (unsigned)(colA + 8 < 0 ? 0 : colA + 8);
+  const int wr_base = q * kImg + 16 * n16;
+  // A-operand role (k_dcthash_256_band): M row n16 = image n16 >> 2, row n16 & 3 of the step; chunk q: 0, 1 the row, 2, 3
+  // the row seven above
+  const int rd_base = (n16 >> 2) * kImg + (q & 1) * 16;
+  const int rd_row = (n16 & 3) + (q >= 2 ? kRing - 7 : 0);
+  // band matrices: interior, and those of the strip's first and last tile (the image's left edge in the first strip, its
+  // right edge in the last -- whose tiles end exactly at column w - 1 -- and the interior band everywhere else)
+  const v4i_t b0 = *reinterpret_cast<const v4i_t*>(st.band[0][lane]);
+  const v4i_t bF = *reinterpret_cast<const v4i_t*>(st.band[1][lane]);
+  const v4i_t bL = *reinterpret_cast<const v4i_t*>(st.band[2][lane]);
+  for (int i = lane; i < 4 * kImg / 16; i += 64) reinterpret_cast<v4u_lds*>(sRing)[i] = v4u_lds{0u, 0u, 0u, 0u};
+  for (int i = lane; i < 16 * 32; i += 64) sA[(i >> 5) * 33 + (i & 31)] = st.alpha[i >> 5][i & 31];
+  for (int i = lane; i < 4 * kTP; i += 64) sT[i] = 0u;
+  // virtual row v = 0 .. h + 7 is image row reflect101(v - 5); output row y = v - 8 is complete with row v
+  const int h2 = 2 * (h - 1);
+  auto row_off = [&](int v) -> unsigned {
+    int ry = v - 5;
+    ry = ry < 0 ? -ry : ry;
+    ry = min(ry, h2 - ry);
+    ry = max(ry, 0);
+    return (unsigned)ry * row_stride;
+  };
+  v2u_t stA[2][4], stB[2][4];
+  auto load_step = [&](int t, v2u_t (&a)[4], v2u_t (&b)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const unsigned so = row_off(4 * t + r);
+      a[r] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voffA, (int)so, 0);
+      b[r] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voffB, (int)so, 0);
+    }
+  };
+  auto store_step = [&](int ts, const v2u_t (&a)[4], const v2u_t (&b)[4]) {
+    if (n16 > T) return;  // (a ring row holds T + 1 chunks)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v2u_lds* p = reinterpret_cast<v2u_lds*>(sRing + wr_base + (4 * ts + r) * kPitch);
+      p[0] = v2u_lds{a[r].x ^ 0x80808080u, a[r].y ^ 0x80808080u};
+      p[1] = v2u_lds{b[r].x ^ 0x80808080u, b[r].y ^ 0x80808080u};
+    }
+  };
+  unsigned S[T];
+#pragma unroll
+  for (int c = 0; c < T; ++c) S[c] = 0x4B000000u + 6272u;
+  v2f_t kC = {42799.0f / 2097152.0f, 42799.0f / 2097152.0f};
+  asm volatile("" : "+v"(kC));
+  const v2f_t kInit = {8388608.0f + 68.0f, 8388608.0f + 68.0f};  // 171196 + 68 = 0x29D00: the quotient is the low byte
+  const v4i_t zero4 = {0, 0, 0, 0};
+  // area / vertical role: lane = image ai, cell ac of the strip
+  const int ai = lane >> 4, ac = lane & 15;
+  const bool alive = ac < ncell && first + (unsigned)ai < n;
+  const int asi = st.si0[ac < ncell ? ac : 0];
+  const float* __restrict__ aw = sA + 33 * ac;
+  unsigned char* __restrict__ tdst = tiles_out + (size_t)(first + (unsigned)ai) * 1024 + (unsigned)(st.cell0 + ac);
+  float vsum = 0.f;
+  const int steps = (h + 3) / 4 + 2;
+
+  auto step = [&](int t, int ts) {
+    // ---- blur: rows 4t .. 4t+3 of the ring -> sT
+    int slot = 4 * ts + rd_row;
+    slot = slot >= kRing ? slot - kRing : slot;
+    const unsigned char* arow = sRing + rd_base + slot * kPitch;
+#pragma unroll
+    for (int c = 0; c < T; ++c) {
+      const v4i_t a = *reinterpret_cast<const v4i_lds*>(arow + 16 * c);
+      const v4i_t d = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, c == 0 ? bF : c == T - 1 ? bL : b0, zero4, 0, 0, 0);
+      const unsigned x0 = S[c] + (unsigned)d[0], x1 = x0 + (unsigned)d[1], x2 = x1 + (unsigned)d[2],
+                     x3 = x2 + (unsigned)d[3];
+      S[c] = x3;
+      const v2f_t p01 = {__builtin_bit_cast(float, x0), __builtin_bit_cast(float, x1)};
+      const v2f_t p23 = {__builtin_bit_cast(float, x2), __builtin_bit_cast(float, x3)};
+      const v2f_t f01 = __builtin_elementwise_fma(p01, kC, kInit), f23 = __builtin_elementwise_fma(p23, kC, kInit);
+      const float fa = f01.x, fb = f01.y, fc = f23.x, fd = f23.y;
+      // low bytes of the four quotients -> one dword (rows y .. y + 3 of column 16 c + n16)
+      const unsigned lo = __builtin_amdgcn_perm(__float_as_uint(fb), __float_as_uint(fa), 0x0c0c0400u);
+      const unsigned hi = __builtin_amdgcn_perm(__float_as_uint(fd), __float_as_uint(fc), 0x04000c0cu);
+      sT[q * kTP + 16 * c + n16] = lo | hi;
+    }
+    wave_order_lds();  // (the ring rows read above are overwritten by the caller's next store_step)
+    const int y0 = 4 * (t - 2);  // the step's output rows
+    if (y0 < 0) return;          // (uniform) warm-up
+    // ---- horizontal INTER_AREA: four rows of cell ac of image ai
+    v2f_t acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+    {
+      const unsigned* __restrict__ src = sT + ai * kTP + asi;
+      for (int k0 = 0; k0 < amax; k0 += 4) {  // four columns per trip: their eight LDS reads in flight together
+        unsigned pw_[4];
+        float a_[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pw_[u] = src[k0 + u], a_[u] = aw[k0 + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const v2f_t w2 = {a_[u], a_[u]};
+          const v2f_t p01 = {(float)(pw_[u] & 0xffu), (float)((pw_[u] >> 8) & 0xffu)};
+          const v2f_t p23 = {(float)((pw_[u] >> 16) & 0xffu), (float)(pw_[u] >> 24)};
+          acc01 = acc01 + p01 * w2;
+          acc23 = acc23 + p23 * w2;
+        }
+      }
+    }
+    wave_order_lds();  // (sT is rewritten by the next step's blur)
+    // ---- vertical INTER_AREA: the y table seen from the source row (k_blur_area_regs<.., FUSE>)
+    const float hv[4] = {acc01.x, acc01.y, acc23.x, acc23.y};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int y = y0 + r;
+      if (y >= h) break;  // (uniform)
+      const YRow yr = yrow[y];
+      const float v = hv[r];
+      const float t0 = yr.a0 * v;
+      vsum = (yr.info & 0x100) ? t0 : vsum + t0;
+      if (yr.info & 0x200) {
+        const float rr = __builtin_rintf(vsum);
+        if (alive) tdst[(yr.info & 0xff) * 32] = (unsigned char)(rr < 0.f ? 0.f : rr > 255.f ? 255.f : rr);
+      }
+      if (yr.info & 0x400) {
+        const float t1 = yr.a1 * v;
+        vsum = (yr.info & 0x800) ? t1 : vsum + t1;
+        if (yr.info & 0x1000) {
+          const float rr = __builtin_rintf(vsum);
+          if (alive) tdst[((yr.info & 0xff) + 1) * 32] = (unsigned char)(rr < 0.f ? 0.f : rr > 255.f ? 255.f : rr);
+        }
+      }
+    }
+  };
+
+  load_step(0, stA[0], stB[0]);
+  load_step(1, stA[1], stB[1]);
+  __syncthreads();  // (the fills)
+  store_step(0, stA[0], stB[0]);
+  load_step(2, stA[0], stB[0]);
+  int ts = 0;
+  auto nxt = [](int v) { return v == 2 ? 0 : v + 1; };
+  for (int t = 0; t < steps; t += 2) {
+    const int tsa = ts, tsb = nxt(tsa), tsc = nxt(tsb);
+    wave_order_lds();
+    step(t, tsa);
+    store_step(tsb, stA[1], stB[1]);
+    if (t + 3 < steps) load_step(t + 3, stA[1], stB[1]);
+    wave_order_lds();
+    if (t + 1 < steps) step(t + 1, tsb);
+    if (t + 2 < steps) {
+      store_step(tsc, stA[0], stB[0]);
+      if (t + 4 < steps) load_step(t + 4, stA[0], stB[0]);
+    }
+    ts = tsc;
+  }
+}
+
 
 template <int K>
 __global__ __launch_bounds__(kThreads) void k_blur_u8(const unsigned char* __restrict__ imgs, int w, int h,
@@ -2794,6 +3018,115 @@ int get_strip_tabs(int w, bool integer, int ncol, int s, StripTabs* out) {
 
 namespace {
 
+int reflect101_host(int p, int len);
+
+// Strips and band matrices of k_band_area for images of width w: n_strips >= 2 strips of cps = ceil(32 / n_strips) <= 16
+// cells, each at most 240 source columns wide with cells of at most 32 table entries.  *out = nullptr (and CBH_OK) when
+// the geometry does not fit (the caller takes k_blur_area_regs).
+struct BaTabsDev {
+  BaStrip* strips = nullptr;
+  int n_strips = 0, T = 0, amax = 0;
+};
+std::map<std::pair<int, int>, BaTabsDev> g_ba_tabs;  // (device, w), under g_area_mu
+
+int get_ba_tabs(int w, BaTabsDev* out) {
+  int dev = 0;
+  CBH_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_area_mu);
+  auto key = std::make_pair(dev, w);
+  auto it = g_ba_tabs.find(key);
+  if (it == g_ba_tabs.end()) {
+    BaTabsDev d;
+    std::vector<int> xf;
+    const std::vector<AreaTab> xt = make_area_tab(w, 32, &xf);
+    std::vector<BaStrip> host;
+    auto band_of = [&](int xs0, int c, bool plain, unsigned (*dst)[4]) {
+      for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 16; ++j) {
+          const int k = 16 * (l >> 4) + j, kk = k & 31;
+          const int col = xs0 + 16 * c - 8 + kk, xo = xs0 + 16 * c + (l & 15);
+          int wgt = 0;
+          if (plain) {
+            wgt = std::abs(col - xo) <= 3 ? 1 : 0;
+          } else if (col >= 0 && col < w && xo < w) {
+            for (int dd = -3; dd <= 3; ++dd) wgt += reflect101_host(xo + dd, w) == col;
+          }
+          if (k >= 32) wgt = -wgt;
+          dst[l][j >> 2] |= (unsigned)(wgt & 0xff) << (8 * (j & 3));
+        }
+    };
+    for (int ns = 2; ns <= 4 && host.empty(); ++ns) {
+      const int cps = (32 + ns - 1) / ns;
+      bool ok = cps <= 16;
+      // one tile count for every strip: the widest strip's
+      int Tc = 0;
+      for (int c0 = 0; c0 < 32 && ok; c0 += cps) {
+        const int c1 = std::min(32, c0 + cps);
+        Tc = std::max(Tc, (xt[(size_t)xf[(size_t)c1] - 1].si + 1 - xt[(size_t)xf[(size_t)c0]].si + 15) / 16);
+      }
+      ok = ok && Tc >= 2 && Tc <= 15 && 16 * Tc + 8 <= w;
+      std::vector<BaStrip> cand;
+      for (int c0 = 0; c0 < 32 && ok; c0 += cps) {
+        const int c1 = std::min(32, c0 + cps);
+        BaStrip b;
+        memset(&b, 0, sizeof b);
+        const int xs_cells = xt[(size_t)xf[(size_t)c0]].si;
+        // the strip's tiles start at its first cell -- or further left, so that the LAST strip's tiles end exactly at
+        // column w - 1 (then only its last tile sees the right edge) and no strip reaches past it
+        b.xs = c0 == 0 ? 0 : std::min(xs_cells, w - 16 * Tc);
+        b.T = Tc;
+        b.cell0 = c0;
+        b.ncell = c1 - c0;
+        ok = b.xs == 0 || b.xs >= 8;
+        if (c1 == 32) ok = ok && b.xs == w - 16 * Tc;
+        for (int c = c0; c < c1 && ok; ++c) {
+          const int e0 = xf[(size_t)c], e1 = xf[(size_t)c + 1];
+          ok = e1 - e0 >= 1 && e1 - e0 <= 32;
+          b.amax = std::max(b.amax, e1 - e0);
+          b.si0[c - c0] = xt[(size_t)e0].si - b.xs;
+          ok = ok && b.si0[c - c0] >= 0 && b.si0[c - c0] + (e1 - e0) <= 16 * Tc;
+          for (int e = e0; e < e1 && ok; ++e) {
+            ok = xt[(size_t)e].si == xt[(size_t)e0].si + (e - e0) && xt[(size_t)e].di == c;  // consecutive columns, in order
+            b.alpha[c - c0][e - e0] = xt[(size_t)e].alpha;
+          }
+        }
+        b.amax = (b.amax + 3) & ~3;  // the walk takes four columns per trip (weights +0.0f past a cell's end)
+        band_of(b.xs, 0, true, b.band[0]);
+        band_of(b.xs, 0, false, b.band[1]);
+        band_of(b.xs, Tc - 1, false, b.band[2]);
+        // every tile between must be the plain band: no image edge within three columns of it
+        for (int c = 1; c + 1 < Tc && ok; ++c) {
+          unsigned m[64][4];
+          memset(m, 0, sizeof m);
+          band_of(b.xs, c, false, m);
+          ok = memcmp(m, b.band[0], sizeof m) == 0;
+        }
+        cand.push_back(b);
+      }
+      if (ok) host.swap(cand);
+    }
+    if (!host.empty()) {
+      for (BaStrip& b : host) d.amax = std::max(d.amax, b.amax);
+      for (BaStrip& b : host) b.amax = d.amax;  // (one walk length, hence one LDS size, per geometry)
+      hipError_t e = hipMalloc(&d.strips, host.size() * sizeof(BaStrip));
+      if (e == hipSuccess) e = hipMemcpy(d.strips, host.data(), host.size() * sizeof(BaStrip), hipMemcpyHostToDevice);
+      if (e != hipSuccess) {
+        if (d.strips) (void)hipFree(d.strips);
+        CBH_HIP(e);
+      }
+      d.n_strips = (int)host.size();
+      d.T = host[0].T;
+    }
+    it = g_ba_tabs.emplace(key, d).first;
+  }
+  *out = it->second;
+  return CBH_OK;
+}
+
+}  // namespace
+
+namespace {
+
 int reflect101_host(int p, int len) {
   while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
   return p;
@@ -2860,6 +3193,10 @@ int g_hash_mfma = 2;
 // share them (14 instead of 9 waves per CU).  Measured, same box, alternating (tools/ab/hash_band_ab.py, 400k images):
 // 4.80-4.88 ms with 1, 5.06-5.11 with 2 (compute-only 3.38 / 4.01): the barrier per step and the per-wave fixed work
 // (addresses, staging, the warm-up steps) cost more than the extra occupancy returns -- the kernel is not latency-bound.
+// "hash_band_area": 1 (default) = fractional-ratio geometries with cells of <= 30 columns (w <= 960) take k_band_area (blur on
+// the matrix cores, four rows per area walk), 0 = k_blur_area_regs as through round 4
+int g_hash_band_area = 1;
+void set_hash_band_area(int v) { g_hash_band_area = v ? 1 : 0; }
 int g_hash_band_waves = 1;
 void set_hash_band_waves(int v) {
   if (v == 1 || v == 2) g_hash_band_waves = v;
@@ -3309,6 +3646,42 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     const int ipb = T % 64 == 0 ? 1 : 256 / T, block_threads = (ipb * T + 63) / 64 * 64;
     const int pitch = T * 8 + 8;
     const size_t smem = (size_t)ipb * (size_t)(kBlurRB + K_ - 1) * (size_t)pitch;
+    if (g_hash_band_area && !view && K_ == 7 && !integer && at.yrow && w >= 64 && 4ull * img_stride < (1ull << 32) &&
+        (size_t)h * row_stride < ((size_t)1 << 32)) {
+      BaTabsDev bat;
+      if ((rc = get_ba_tabs(w, &bat))) return rc;
+      if (bat.strips) {
+        const size_t per_chunk_b = 200000;  // (grid y)
+        unsigned char* d_btiles = nullptr;
+        cbh::Scratch scratch(stream);
+        CBH_HIP(scratch.get(&d_btiles, std::min(per_chunk_b, n) * 1024));
+        for (size_t i0 = 0; i0 < n; i0 += per_chunk_b) {
+          const size_t m = std::min(per_chunk_b, n - i0);
+          const unsigned char* src = d_imgs + i0 * img_stride;
+          const unsigned long long bytes = (unsigned long long)(m - 1) * img_stride + (unsigned long long)(h - 1) * row_stride + (unsigned)w;
+#define CBH_BA(TT)                                                                                                       \
+  case TT:                                                                                                              \
+    hipLaunchKernelGGL(k_band_area<TT>, dim3((unsigned)bat.n_strips, (unsigned)((m + 3) / 4)), dim3(64), 0, stream, src, \
+                       (unsigned)m, w, h, (unsigned)row_stride, (unsigned)img_stride, bytes, bat.strips, at.yrow, d_btiles); \
+    break
+          switch (bat.T) {
+            CBH_BA(2); CBH_BA(3); CBH_BA(4); CBH_BA(5); CBH_BA(6); CBH_BA(7); CBH_BA(8); CBH_BA(9); CBH_BA(10); CBH_BA(11);
+            CBH_BA(12); CBH_BA(13); CBH_BA(14); CBH_BA(15);
+            default: return CBH_E_UNSUPPORTED;
+          }
+#undef CBH_BA
+          unsigned char* tcopy = d_tiles ? d_tiles + i0 * 1024 : nullptr;
+          if (g_hash_dct)
+            hipLaunchKernelGGL(k_tiles_hash2<1>, dim3((unsigned)((m + 1) / 2)), dim3(64), 0, stream, d_btiles, (unsigned)m, tabs,
+                               d_out + i0, tcopy);
+          else
+            hipLaunchKernelGGL(k_tiles_hash2<0>, dim3((unsigned)((m + 1) / 2)), dim3(64), 0, stream, d_btiles, (unsigned)m, tabs,
+                               d_out + i0, tcopy);
+          CBH_HIP(hipGetLastError());
+        }
+        return CBH_OK;
+      }
+    }
     if (view || (g_hash_fused && w >= g_hash_fused)) {
       // k_blur_area + k_tile_hash: the blurred plane stays in LDS
       // column strips: the fewest (1, 2, 4, 8) whose widest window -- first source column of a strip's first cell .. last of
