@@ -877,9 +877,12 @@ struct BaStrip {
   int cell0;    // first output cell
   int ncell;    // cells (<= 16)
   int amax;     // longest cell walk (<= 32)
-  int pad_[3];
+  int amin;     // shortest: entries 1 .. amin - 2 of EVERY cell weigh its wmid (checked on the host)
+  int pad_[2];
   int si0[16];             // first source column of cell c, relative to xs
-  float alpha[16][32];     // its weights in table order, +0.0f past the end
+  // weights of cell c in table order: wfirst, then wmid for entries 1 .. amin - 2, then wtail[j] for entry amin - 1 + j
+  // (+0.0f past the cell's end; amax - amin + 1 <= 4 of them)
+  float wfirst[16], wmid[16], wtail[16][4];
   unsigned band[3][64][4]; // B operands: the plain band, the strip's first tile, its last tile
 };
 
@@ -894,14 +897,13 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
   __shared__ __attribute__((aligned(16))) unsigned char sRing[4 * kImg];
   // sT[image][x]: the area walk has lane (image, cell) read column si0[cell] + k -- cells 28 columns apart would meet in
   // the same banks four ways in an [x][image] layout (900 px: half the speed); per-image planes of kTP = 8 (mod 32) dwords
-  // keep the cells of one image and the four images apart.  sA: 33 floats per cell (an odd stride: 16 cells, 16 banks)
+  // keep the cells of one image and the four images apart.  The walk's weights live in registers (first, mid, tail).
   constexpr int kTP = ((16 * T + 8 + 31) / 32) * 32 + 8;
   __shared__ __attribute__((aligned(16))) unsigned sT[4 * kTP];
-  __shared__ __attribute__((aligned(16))) float sA[16 * 33];
   const int lane = threadIdx.x & 63;
   const int n16 = lane & 15, q = lane >> 4;
   const BaStrip& st = strips[blockIdx.x];
-  const int xs = st.xs, ncell = st.ncell, amax = st.amax;  // (amax: a multiple of 4)
+  const int xs = st.xs, ncell = st.ncell, amax = st.amax, amin = st.amin;
   const unsigned first = blockIdx.y * 4u;
   unsigned mine = first + (unsigned)q;
   if (mine >= n) mine = n - 1;
@@ -927,7 +929,6 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
   const v4i_t bF = *reinterpret_cast<const v4i_t*>(st.band[1][lane]);
   const v4i_t bL = *reinterpret_cast<const v4i_t*>(st.band[2][lane]);
   for (int i = lane; i < 4 * kImg / 16; i += 64) reinterpret_cast<v4u_lds*>(sRing)[i] = v4u_lds{0u, 0u, 0u, 0u};
-  for (int i = lane; i < 16 * 32; i += 64) sA[(i >> 5) * 33 + (i & 31)] = st.alpha[i >> 5][i & 31];
   for (int i = lane; i < 4 * kTP; i += 64) sT[i] = 0u;
   // virtual row v = 0 .. h + 7 is image row reflect101(v - 5); output row y = v - 8 is complete with row v
   const int h2 = 2 * (h - 1);
@@ -967,7 +968,10 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
   const int ai = lane >> 4, ac = lane & 15;
   const bool alive = ac < ncell && first + (unsigned)ai < n;
   const int asi = st.si0[ac < ncell ? ac : 0];
-  const float* __restrict__ aw = sA + 33 * ac;
+  const int acc_ = ac < ncell ? ac : 0;
+  const float w_first = st.wfirst[acc_], w_mid = st.wmid[acc_];
+  const float w_t0 = st.wtail[acc_][0], w_t1 = st.wtail[acc_][1], w_t2 = st.wtail[acc_][2], w_t3 = st.wtail[acc_][3];
+  const int ntail = amax - amin + 1;
   unsigned char* __restrict__ tdst = tiles_out + (size_t)(first + (unsigned)ai) * 1024 + (unsigned)(st.cell0 + ac);
   float vsum = 0.f;
   const int steps = (h + 3) / 4 + 2;
@@ -1000,19 +1004,22 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
     v2f_t acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
     {
       const unsigned* __restrict__ src = sT + ai * kTP + asi;
-      for (int k0 = 0; k0 < amax; k0 += 4) {  // four columns per trip: their eight LDS reads in flight together
-        unsigned pw_[4];
-        float a_[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) pw_[u] = src[k0 + u], a_[u] = aw[k0 + u];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const v2f_t w2 = {a_[u], a_[u]};
-          const v2f_t p01 = {(float)(pw_[u] & 0xffu), (float)((pw_[u] >> 8) & 0xffu)};
-          const v2f_t p23 = {(float)((pw_[u] >> 16) & 0xffu), (float)(pw_[u] >> 24)};
-          acc01 = acc01 + p01 * w2;
-          acc23 = acc23 + p23 * w2;
-        }
+      auto col = [&](unsigned pw_, float a_) {
+        const v2f_t w2 = {a_, a_};
+        const v2f_t p01 = {(float)(pw_ & 0xffu), (float)((pw_ >> 8) & 0xffu)};
+        const v2f_t p23 = {(float)((pw_ >> 16) & 0xffu), (float)(pw_ >> 24)};
+        acc01 = acc01 + p01 * w2;
+        acc23 = acc23 + p23 * w2;
+      };
+      col(src[0], w_first);
+#pragma unroll 4
+      for (int k = 1; k < amin - 1; ++k) col(src[k], w_mid);  // interior columns: every lane's cell has them
+      {
+        const unsigned* __restrict__ tp = src + (amin - 1);
+        col(tp[0], w_t0);  // (amin >= 2: entry amin - 1 exists in the shortest cell; longer cells go on)
+        if (ntail > 1) col(tp[1], w_t1);
+        if (ntail > 2) col(tp[2], w_t2);
+        if (ntail > 3) col(tp[3], w_t3);
       }
     }
     wave_order_lds();  // (sT is rewritten by the next step's blur)
@@ -3081,16 +3088,23 @@ int get_ba_tabs(int w, BaTabsDev* out) {
         if (c1 == 32) ok = ok && b.xs == w - 16 * Tc;
         for (int c = c0; c < c1 && ok; ++c) {
           const int e0 = xf[(size_t)c], e1 = xf[(size_t)c + 1];
-          ok = e1 - e0 >= 1 && e1 - e0 <= 32;
+          ok = e1 - e0 >= 2 && e1 - e0 <= 32;
           b.amax = std::max(b.amax, e1 - e0);
+          b.amin = c == c0 ? e1 - e0 : std::min(b.amin, e1 - e0);
           b.si0[c - c0] = xt[(size_t)e0].si - b.xs;
           ok = ok && b.si0[c - c0] >= 0 && b.si0[c - c0] + (e1 - e0) <= 16 * Tc;
           for (int e = e0; e < e1 && ok; ++e) {
             ok = xt[(size_t)e].si == xt[(size_t)e0].si + (e - e0) && xt[(size_t)e].di == c;  // consecutive columns, in order
-            b.alpha[c - c0][e - e0] = xt[(size_t)e].alpha;
           }
         }
-        b.amax = (b.amax + 3) & ~3;  // the walk takes four columns per trip (weights +0.0f past a cell's end)
+        ok = ok && b.amax - b.amin + 1 <= 4;
+        for (int c = c0; c < c1 && ok; ++c) {  // the walk's weights: first, mid (entries 1 .. amin - 2), tail
+          const int e0 = xf[(size_t)c], nn = xf[(size_t)c + 1] - e0;
+          b.wfirst[c - c0] = xt[(size_t)e0].alpha;
+          b.wmid[c - c0] = xt[(size_t)e0 + 1].alpha;
+          for (int k = 1; k <= b.amin - 2 && ok; ++k) ok = xt[(size_t)(e0 + k)].alpha == b.wmid[c - c0];
+          for (int j = 0; j < 4; ++j) b.wtail[c - c0][j] = b.amin - 1 + j < nn ? xt[(size_t)(e0 + b.amin - 1 + j)].alpha : 0.f;
+        }
         band_of(b.xs, 0, true, b.band[0]);
         band_of(b.xs, 0, false, b.band[1]);
         band_of(b.xs, Tc - 1, false, b.band[2]);
@@ -3107,7 +3121,6 @@ int get_ba_tabs(int w, BaTabsDev* out) {
     }
     if (!host.empty()) {
       for (BaStrip& b : host) d.amax = std::max(d.amax, b.amax);
-      for (BaStrip& b : host) b.amax = d.amax;  // (one walk length, hence one LDS size, per geometry)
       hipError_t e = hipMalloc(&d.strips, host.size() * sizeof(BaStrip));
       if (e == hipSuccess) e = hipMemcpy(d.strips, host.data(), host.size() * sizeof(BaStrip), hipMemcpyHostToDevice);
       if (e != hipSuccess) {

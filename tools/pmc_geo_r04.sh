@@ -14,6 +14,6 @@ for geo in "$@"; do
     rm -rf /tmp/pg_$c
     rocprofv3 --pmc $c --output-format csv -d /tmp/pg_$c -- python3 tools/hash_geo_only.py $1 $2 > /dev/null 2> /tmp/pg_$c.err
     p=$(find /tmp/pg_$c -name '*counter_collection.csv' | head -1)
-    [ -n "$p" ] && python3 tools/pmc_sum.py "$p" "$c" k_blur k_area k_tile k_dcthash || { echo "$c: no data"; tail -1 /tmp/pg_$c.err | cut -c1-160; }
+    [ -n "$p" ] && python3 tools/pmc_sum.py "$p" "$c" k_blur k_area k_tile k_dcthash k_band_area || { echo "$c: no data"; tail -1 /tmp/pg_$c.err | cut -c1-160; }
   done
 done
