@@ -3,7 +3,19 @@ against oracle/cbird_oracle.c on the same inputs."""
 import numpy as np
 import pytest
 
-pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("hash_dct")]  # every test under both stage-3/5 evaluations
+# every test under both stage-3/5 evaluations, and with the fractional-ratio geometries of <= 960 columns on k_band_area
+# (round 5, the default) as well as on the kernels that took them before (k_blur_area_regs & co., still the path of every
+# other geometry and of views)
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("hash_dct", "band_area")]
+
+
+@pytest.fixture(params=["band_area", "regs"])
+def band_area(request, gpu):
+    from cbird_amd import _lib
+
+    _lib.lib().cbh_set_tuning(b"hash_band_area", 1 if request.param == "band_area" else 0)
+    yield request.param
+    _lib.lib().cbh_set_tuning(b"hash_band_area", 1)
 
 
 @pytest.mark.parametrize("w,h", [(32, 32), (64, 64), (64, 32), (128, 128), (128, 160), (256, 256),
@@ -481,3 +493,47 @@ def test_hash_random_geometries_and_strides(gpu, orc):
         L.cbh_set_tuning(b"hash_fast_any", 1)
         L.cbh_set_tuning(b"hash_fused", 1)
         L.cbh_set_tuning(b"hash_stream", 1)
+
+
+def test_band_area_kernel_geometries_strides_and_ragged_batches(gpu, orc, band_area):
+    """k_band_area (matrix-core blur + four-row area walks) at the edges of what it accepts: widths 64 .. 960 with every
+    tile count and both kinds of last strip, cells of 2 .. 30 columns, heights that are not multiples of the four-row step
+    and barely above the blur's reach, batches that are not multiples of the four images of a wave, padded row and image
+    strides, odd base addresses -- hashes AND 32 x 32 tiles equal the oracle."""
+    if band_area != "band_area":
+        pytest.skip("the new kernel only")
+    import torch
+
+    from cbird_amd import _lib
+
+    L = _lib.lib()
+    rng = np.random.default_rng(2025)
+    geos = [(64, 301), (65, 33), (66, 32), (79, 129), (96, 97), (100, 35), (127, 200), (160, 121), (200, 150), (239, 37),
+            (241, 241), (300, 200), (333, 250), (400, 300), (401, 299), (479, 361), (480, 270), (533, 400), (600, 401),
+            (640, 481), (641, 480), (700, 99), (720, 405), (799, 601), (854, 480), (900, 34), (959, 540), (960, 541)]
+    for gi, (w, h) in enumerate(geos):
+        n = int(rng.integers(1, 10))
+        row_stride = w + int(rng.integers(0, 7))
+        img_stride = h * row_stride + int(rng.integers(0, 33))
+        base = int(rng.integers(0, 5))
+        buf = rng.integers(0, 256, (n, img_stride), dtype=np.uint8)
+        if gi % 5 == 0:  # smooth content too: the tiles then sit near rounding boundaries less often than noise does
+            ramp = np.linspace(0, 230, row_stride, dtype=np.float32)
+            buf[:, : h * row_stride] = (buf[:, : h * row_stride].reshape(n, h, row_stride) // 8 + ramp[None, None, :]).astype(
+                np.uint8).reshape(n, -1)
+        if gi == 3:
+            buf[0] = 0
+            buf[-1] = 255
+        imgs = np.stack([buf[i, : h * row_stride].reshape(h, row_stride)[:, :w] for i in range(n)])
+        want = orc.dcthash64_batch(np.ascontiguousarray(imgs))
+        dflat = torch.zeros(buf.size + 16, dtype=torch.uint8, device="cuda")
+        dflat[base: base + buf.size] = torch.from_numpy(buf.reshape(-1)).cuda()
+        d = dflat[base:]
+        out = torch.zeros(n, dtype=torch.int64, device="cuda")
+        tiles = torch.zeros((n, 32, 32), dtype=torch.uint8, device="cuda")
+        _lib.check(L.cbh_dcthash_tiles_dev(d.data_ptr(), n, w, h, row_stride, img_stride, out.data_ptr(), tiles.data_ptr(), 0,
+                                           None), "tiles")
+        t = tiles.cpu().numpy()
+        for i in range(n):
+            assert (t[i] == orc.tile32(np.ascontiguousarray(imgs[i]))).all(), (w, h, i)
+        assert (out.cpu().numpy().view(np.uint64) == want).all(), (w, h)
