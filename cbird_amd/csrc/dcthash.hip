@@ -870,15 +870,18 @@ struct YRow {
 //     last two tiles of the last strip), top / bottom into the row addresses.
 // Stages 3-6 run from the tiles (k_tiles_hash2).  Against k_blur_area_regs (blur 5.9 + area 2.75 / 0.7 VALU instructions
 // per pixel): ~2.5 + ~2.2 -- see DESIGN a1.  Preconditions (launcher): whole images, 7 x 7 blur, fractional ratios,
-// cells of at most 30 columns (w <= 960), four images' strides below 2^32.
+// strips of at least 8 cells within 240 columns (w <= 960; 4 cells, w <= 1920, with "hash_band_area" 2), four images'
+// strides below 2^32.
 struct BaStrip {
   int xs;       // first source column of the strip's first cell
   int T;        // 16-column tiles (<= 15)
   int cell0;    // first output cell
   int ncell;    // cells (<= 16)
-  int amax;     // longest cell walk (<= 32)
+  int amax;     // longest cell walk
   int amin;     // shortest: entries 1 .. amin - 2 of EVERY cell weigh its wmid (checked on the host)
-  int pad_[2];
+  int tp;       // dwords between the images' planes of sT: chosen on the host so that the cells' walks (lane = image, cell
+                // reads column si0[cell] + k of its image's plane) meet in as few LDS banks as possible
+  int pad_[1];
   int si0[16];             // first source column of cell c, relative to xs
   // weights of cell c in table order: wfirst, then wmid for entries 1 .. amin - 2, then wtail[j] for entry amin - 1 + j
   // (+0.0f past the cell's end; amax - amin + 1 <= 4 of them)
@@ -886,7 +889,11 @@ struct BaStrip {
   unsigned band[3][64][4]; // B operands: the plain band, the strip's first tile, its last tile
 };
 
-template <int T>  // 16-column tiles per strip (the same for every strip of a geometry)
+// T = 16-column tiles per strip (the same for every strip of a geometry).  RS = rows of a step one lane carries through the
+// area walk: 4 (strips of <= 16 cells: lane = image, cell), 2 (<= 8 cells: lane = image, cell, row pair) or 1 (<= 4 cells:
+// lane = image, cell, row) -- wide cells mean few cells per 240-column strip, and the rows of a step are then spread over the
+// lanes that would idle; the vertical chain passes its running sum from row group to row group by DPP.
+template <int T, int RS>
 __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restrict__ imgs, unsigned n, int w, int h,
                                                   unsigned row_stride, unsigned img_stride, unsigned long long buf_bytes,
                                                   const BaStrip* __restrict__ strips, const YRow* __restrict__ yrow,
@@ -898,12 +905,12 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
   // sT[image][x]: the area walk has lane (image, cell) read column si0[cell] + k -- cells 28 columns apart would meet in
   // the same banks four ways in an [x][image] layout (900 px: half the speed); per-image planes of kTP = 8 (mod 32) dwords
   // keep the cells of one image and the four images apart.  The walk's weights live in registers (first, mid, tail).
-  constexpr int kTP = ((16 * T + 8 + 31) / 32) * 32 + 8;
+  constexpr int kTP = 16 * T + 8 + 40;  // (allocation; the stride in use is st.tp <= kTP)
   __shared__ __attribute__((aligned(16))) unsigned sT[4 * kTP];
   const int lane = threadIdx.x & 63;
   const int n16 = lane & 15, q = lane >> 4;
   const BaStrip& st = strips[blockIdx.x];
-  const int xs = st.xs, ncell = st.ncell, amax = st.amax, amin = st.amin;
+  const int xs = st.xs, ncell = st.ncell, amax = st.amax, amin = st.amin, tp = st.tp;
   const unsigned first = blockIdx.y * 4u;
   unsigned mine = first + (unsigned)q;
   if (mine >= n) mine = n - 1;
@@ -964,14 +971,16 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
   asm volatile("" : "+v"(kC));
   const v2f_t kInit = {8388608.0f + 68.0f, 8388608.0f + 68.0f};  // 171196 + 68 = 0x29D00: the quotient is the low byte
   const v4i_t zero4 = {0, 0, 0, 0};
-  // area / vertical role: lane = image ai, cell ac of the strip
-  const int ai = lane >> 4, ac = lane & 15;
+  // area / vertical role: lane = image ai, cell ac of the strip, row group rg (rows RS rg .. RS rg + RS - 1 of a step)
+  constexpr int G = 4 / RS;
+  const int ai = lane >> 4, ac = (lane & 15) / G, rg = (lane & 15) % G;
   const bool alive = ac < ncell && first + (unsigned)ai < n;
   const int asi = st.si0[ac < ncell ? ac : 0];
   const int acc_ = ac < ncell ? ac : 0;
   const float w_first = st.wfirst[acc_], w_mid = st.wmid[acc_];
   const float w_t0 = st.wtail[acc_][0], w_t1 = st.wtail[acc_][1], w_t2 = st.wtail[acc_][2], w_t3 = st.wtail[acc_][3];
   const int ntail = amax - amin + 1;
+  const unsigned rsh = (unsigned)(8 * RS * rg);  // the lane's rows within a column's dword
   unsigned char* __restrict__ tdst = tiles_out + (size_t)(first + (unsigned)ai) * 1024 + (unsigned)(st.cell0 + ac);
   float vsum = 0.f;
   const int steps = (h + 3) / 4 + 2;
@@ -995,21 +1004,31 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
       // low bytes of the four quotients -> one dword (rows y .. y + 3 of column 16 c + n16)
       const unsigned lo = __builtin_amdgcn_perm(__float_as_uint(fb), __float_as_uint(fa), 0x0c0c0400u);
       const unsigned hi = __builtin_amdgcn_perm(__float_as_uint(fd), __float_as_uint(fc), 0x04000c0cu);
-      sT[q * kTP + 16 * c + n16] = lo | hi;
+      sT[q * tp + 16 * c + n16] = lo | hi;
     }
     wave_order_lds();  // (the ring rows read above are overwritten by the caller's next store_step)
     const int y0 = 4 * (t - 2);  // the step's output rows
     if (y0 < 0) return;          // (uniform) warm-up
-    // ---- horizontal INTER_AREA: four rows of cell ac of image ai
+    // ---- horizontal INTER_AREA: the lane's RS rows of cell ac of image ai
     v2f_t acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
     {
-      const unsigned* __restrict__ src = sT + ai * kTP + asi;
+      const unsigned* __restrict__ src = sT + ai * tp + asi;
       auto col = [&](unsigned pw_, float a_) {
-        const v2f_t w2 = {a_, a_};
-        const v2f_t p01 = {(float)(pw_ & 0xffu), (float)((pw_ >> 8) & 0xffu)};
-        const v2f_t p23 = {(float)((pw_ >> 16) & 0xffu), (float)(pw_ >> 24)};
-        acc01 = acc01 + p01 * w2;
-        acc23 = acc23 + p23 * w2;
+        if constexpr (RS == 4) {
+          const v2f_t w2 = {a_, a_};
+          const v2f_t p01 = {(float)(pw_ & 0xffu), (float)((pw_ >> 8) & 0xffu)};
+          const v2f_t p23 = {(float)((pw_ >> 16) & 0xffu), (float)(pw_ >> 24)};
+          acc01 = acc01 + p01 * w2;
+          acc23 = acc23 + p23 * w2;
+        } else if constexpr (RS == 2) {
+          const unsigned x_ = pw_ >> rsh;
+          const v2f_t w2 = {a_, a_};
+          const v2f_t p01 = {(float)(x_ & 0xffu), (float)((x_ >> 8) & 0xffu)};
+          acc01 = acc01 + p01 * w2;
+        } else {
+          const unsigned x_ = pw_ >> rsh;
+          acc01.x = acc01.x + (float)(x_ & 0xffu) * a_;
+        }
       };
       col(src[0], w_first);
 #pragma unroll 4
@@ -1023,14 +1042,12 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
       }
     }
     wave_order_lds();  // (sT is rewritten by the next step's blur)
-    // ---- vertical INTER_AREA: the y table seen from the source row (k_blur_area_regs<.., FUSE>)
+    // ---- vertical INTER_AREA: the y table seen from the source row (k_blur_area_regs<.., FUSE>).  The rows of a step in
+    // order: row group 0's lanes first, then the running sum moves one lane up (DPP) to row group 1's, ... and from the last
+    // group back to group 0 for the next step.
     const float hv[4] = {acc01.x, acc01.y, acc23.x, acc23.y};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int y = y0 + r;
-      if (y >= h) break;  // (uniform)
+    auto vrow = [&](int y, float v) {
       const YRow yr = yrow[y];
-      const float v = hv[r];
       const float t0 = yr.a0 * v;
       vsum = (yr.info & 0x100) ? t0 : vsum + t0;
       if (yr.info & 0x200) {
@@ -1044,6 +1061,22 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
           const float rr = __builtin_rintf(vsum);
           if (alive) tdst[((yr.info & 0xff) + 1) * 32] = (unsigned char)(rr < 0.f ? 0.f : rr > 255.f ? 255.f : rr);
         }
+      }
+    };
+#pragma unroll
+    for (int ph = 0; ph < G; ++ph) {
+      if (G == 1 || rg == ph) {
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+          const int y = y0 + ph * RS + r;
+          if (y < h) vrow(y, hv[r]);  // (uniform)
+        }
+      }
+      if constexpr (G > 1) {
+        // lane j takes the sum of lane j - 1 of its cell's G lanes (wrapping): quad_perm [3,0,1,2] / [1,0,3,2]
+        const float up = __builtin_bit_cast(
+            float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, vsum), G == 4 ? 0x93 : 0xB1, 0xf, 0xf, true));
+        if (rg == (ph + 1) % G) vsum = up;
       }
     }
   };
@@ -3030,9 +3063,14 @@ int reflect101_host(int p, int len);
 // Strips and band matrices of k_band_area for images of width w: n_strips >= 2 strips of cps = ceil(32 / n_strips) <= 16
 // cells, each at most 240 source columns wide with cells of at most 32 table entries.  *out = nullptr (and CBH_OK) when
 // the geometry does not fit (the caller takes k_blur_area_regs).
+// "hash_band_area": 1 (default) = fractional-ratio geometries whose strips hold >= 8 cells (w <= 960) take k_band_area (blur
+// on the matrix cores, up to four rows per area walk), 2 = also strips of 4 cells (w <= 1920; experiments), 0 =
+// k_blur_area_regs as through round 4
+int g_hash_band_area = 1;
+
 struct BaTabsDev {
   BaStrip* strips = nullptr;
-  int n_strips = 0, T = 0, amax = 0;
+  int n_strips = 0, T = 0, amax = 0, RS = 4;
 };
 std::map<std::pair<int, int>, BaTabsDev> g_ba_tabs;  // (device, w), under g_area_mu
 
@@ -3040,7 +3078,7 @@ int get_ba_tabs(int w, BaTabsDev* out) {
   int dev = 0;
   CBH_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_area_mu);
-  auto key = std::make_pair(dev, w);
+  auto key = std::make_pair(dev, 2 * w + (g_hash_band_area >= 2 ? 1 : 0));
   auto it = g_ba_tabs.find(key);
   if (it == g_ba_tabs.end()) {
     BaTabsDev d;
@@ -3062,9 +3100,13 @@ int get_ba_tabs(int w, BaTabsDev* out) {
           dst[l][j >> 2] |= (unsigned)(wgt & 0xff) << (8 * (j & 3));
         }
     };
-    for (int ns = 2; ns <= 4 && host.empty(); ++ns) {
-      const int cps = (32 + ns - 1) / ns;
-      bool ok = cps <= 16;
+    // cells per strip, in order of preference: 16 or 11 (a lane carries the four rows of a step: RS 4), 8 (two rows: RS 2),
+    // 4 (one row: RS 1 -- measured no better than k_blur_area_regs at 1280 .. 1920 columns and worse beyond, hence only
+    // with "hash_band_area" 2)
+    const int cps_try[4] = {16, 11, 8, 4};
+    for (int ci = 0; ci < (g_hash_band_area >= 2 ? 4 : 3) && host.empty(); ++ci) {
+      const int cps = cps_try[ci];
+      bool ok = true;
       // one tile count for every strip: the widest strip's
       int Tc = 0;
       for (int c0 = 0; c0 < 32 && ok; c0 += cps) {
@@ -3072,6 +3114,8 @@ int get_ba_tabs(int w, BaTabsDev* out) {
         Tc = std::max(Tc, (xt[(size_t)xf[(size_t)c1] - 1].si + 1 - xt[(size_t)xf[(size_t)c0]].si + 15) / 16);
       }
       ok = ok && Tc >= 2 && Tc <= 15 && 16 * Tc + 8 <= w;
+      if (!ok) continue;
+      d.RS = cps > 8 ? 4 : cps == 8 ? 2 : 1;
       std::vector<BaStrip> cand;
       for (int c0 = 0; c0 < 32 && ok; c0 += cps) {
         const int c1 = std::min(32, c0 + cps);
@@ -3088,7 +3132,7 @@ int get_ba_tabs(int w, BaTabsDev* out) {
         if (c1 == 32) ok = ok && b.xs == w - 16 * Tc;
         for (int c = c0; c < c1 && ok; ++c) {
           const int e0 = xf[(size_t)c], e1 = xf[(size_t)c + 1];
-          ok = e1 - e0 >= 2 && e1 - e0 <= 32;
+          ok = e1 - e0 >= 2;
           b.amax = std::max(b.amax, e1 - e0);
           b.amin = c == c0 ? e1 - e0 : std::min(b.amin, e1 - e0);
           b.si0[c - c0] = xt[(size_t)e0].si - b.xs;
@@ -3104,6 +3148,19 @@ int get_ba_tabs(int w, BaTabsDev* out) {
           b.wmid[c - c0] = xt[(size_t)e0 + 1].alpha;
           for (int k = 1; k <= b.amin - 2 && ok; ++k) ok = xt[(size_t)(e0 + k)].alpha == b.wmid[c - c0];
           for (int j = 0; j < 4; ++j) b.wtail[c - c0][j] = b.amin - 1 + j < nn ? xt[(size_t)(e0 + b.amin - 1 + j)].alpha : 0.f;
+        }
+        {  // plane stride: the fewest lanes per LDS bank over the walk (every lane advances by one column per read)
+          int best = 1 << 30;
+          for (int cand_tp = 16 * Tc + 8; cand_tp <= 16 * Tc + 8 + 39; ++cand_tp) {
+            int cnt[32] = {0};
+            for (int im = 0; im < 4; ++im)
+              for (int c = 0; c < b.ncell; ++c) cnt[(b.si0[c] + im * cand_tp) & 31]++;
+            int worst = 0;
+            for (int k = 0; k < 32; ++k) worst = std::max(worst, cnt[k]);
+            // (ties: prefer strides that also keep the blur's stores -- 16 consecutive columns per image -- apart)
+            const int score = worst * 64 + ((cand_tp & 31) == 16 ? 0 : (cand_tp & 15) == 8 ? 1 : 2);
+            if (score < best) best = score, b.tp = cand_tp;
+          }
         }
         band_of(b.xs, 0, true, b.band[0]);
         band_of(b.xs, 0, false, b.band[1]);
@@ -3206,10 +3263,7 @@ int g_hash_mfma = 2;
 // share them (14 instead of 9 waves per CU).  Measured, same box, alternating (tools/ab/hash_band_ab.py, 400k images):
 // 4.80-4.88 ms with 1, 5.06-5.11 with 2 (compute-only 3.38 / 4.01): the barrier per step and the per-wave fixed work
 // (addresses, staging, the warm-up steps) cost more than the extra occupancy returns -- the kernel is not latency-bound.
-// "hash_band_area": 1 (default) = fractional-ratio geometries with cells of <= 30 columns (w <= 960) take k_band_area (blur on
-// the matrix cores, four rows per area walk), 0 = k_blur_area_regs as through round 4
-int g_hash_band_area = 1;
-void set_hash_band_area(int v) { g_hash_band_area = v ? 1 : 0; }
+void set_hash_band_area(int v) { g_hash_band_area = v < 0 ? 0 : v > 2 ? 2 : v; }
 int g_hash_band_waves = 1;
 void set_hash_band_waves(int v) {
   if (v == 1 || v == 2) g_hash_band_waves = v;
@@ -3672,16 +3726,21 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
           const size_t m = std::min(per_chunk_b, n - i0);
           const unsigned char* src = d_imgs + i0 * img_stride;
           const unsigned long long bytes = (unsigned long long)(m - 1) * img_stride + (unsigned long long)(h - 1) * row_stride + (unsigned)w;
-#define CBH_BA(TT)                                                                                                       \
-  case TT:                                                                                                              \
-    hipLaunchKernelGGL(k_band_area<TT>, dim3((unsigned)bat.n_strips, (unsigned)((m + 3) / 4)), dim3(64), 0, stream, src, \
-                       (unsigned)m, w, h, (unsigned)row_stride, (unsigned)img_stride, bytes, bat.strips, at.yrow, d_btiles); \
+#define CBH_BA_(TT, RR)                                                                                                  \
+  hipLaunchKernelGGL((k_band_area<TT, RR>), dim3((unsigned)bat.n_strips, (unsigned)((m + 3) / 4)), dim3(64), 0, stream, src, \
+                     (unsigned)m, w, h, (unsigned)row_stride, (unsigned)img_stride, bytes, bat.strips, at.yrow, d_btiles)
+#define CBH_BA(TT)                       \
+  case TT:                               \
+    if (bat.RS == 4) CBH_BA_(TT, 4);     \
+    else if (bat.RS == 2) CBH_BA_(TT, 2); \
+    else CBH_BA_(TT, 1);                 \
     break
           switch (bat.T) {
             CBH_BA(2); CBH_BA(3); CBH_BA(4); CBH_BA(5); CBH_BA(6); CBH_BA(7); CBH_BA(8); CBH_BA(9); CBH_BA(10); CBH_BA(11);
             CBH_BA(12); CBH_BA(13); CBH_BA(14); CBH_BA(15);
             default: return CBH_E_UNSUPPORTED;
           }
+#undef CBH_BA_
 #undef CBH_BA
           unsigned char* tcopy = d_tiles ? d_tiles + i0 * 1024 : nullptr;
           if (g_hash_dct)
