@@ -608,8 +608,7 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma3(
 
   const uint32_t p0 = blockIdx.y * triples_per_chunk;
   const uint32_t p1 = min(n_triples, p0 + triples_per_chunk);
-  // triple p = needles [96p, 96p+96): three tiles of 32; lane (c, half) reads word `half` of needle c
-  const uint4* __restrict__ qp = qx + ((size_t)p0 * 96u + r) * 2u + half;
+  // triple p = needles [96p, 96p+96): three tiles of 32; lane (c, half) reads word `half` of needle c (below)
 
   auto step = [&](const uint32_t p, const uint4& n0, const uint4& n1, const uint4& n2) __attribute__((always_inline)) {
     const v8i b0 = fp4_operand(n0), b1 = fp4_operand(n1), b2 = fp4_operand(n2);
@@ -641,7 +640,6 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma3(
   // updates per triple, and this kernel too is bound by what the VALU issues beside the MFMAs -- T = 24 M + 4 V cycles).
   // Raw buffer loads: descriptor base = triple p0, scalar byte offset of the tile, constant per-lane offset.
   typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
-  (void)qp;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint4*>(qx + (size_t)p0 * 192u), 0, (int)0xffffffffu, 0x27000);
   const uint32_t voff = (2u * r + half) * 16u;
