@@ -896,8 +896,8 @@ struct BaStrip {
 template <int T, int RS>
 __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restrict__ imgs, unsigned n, int w, int h,
                                                   unsigned row_stride, unsigned img_stride, unsigned long long buf_bytes,
-                                                  const BaStrip* __restrict__ strips, const YRow* __restrict__ yrow,
-                                                  unsigned char* __restrict__ tiles_out) {
+                                                  const BaStrip* __restrict__ strips, int n_strips,
+                                                  const YRow* __restrict__ yrow, unsigned char* __restrict__ tiles_out) {
   // LDS, sized by T (separate arrays: the compiler must know that they do not alias): ring 4 x 12 rows x kPitch, sT =
   // blurred bytes [x][image] = 4 rows (+ 8 columns for the walk's overhang), sA = the cells' weights [16][amax]
   constexpr int kRing = 12, kPitch = 16 * T + 32, kImg = kRing * kPitch;
@@ -909,9 +909,17 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
   __shared__ __attribute__((aligned(16))) unsigned sT[4 * kTP];
   const int lane = threadIdx.x & 63;
   const int n16 = lane & 15, q = lane >> 4;
-  const BaStrip& st = strips[blockIdx.x];
+  // Workgroup -> (group of four images, strip).  The hardware deals consecutive workgroup ids to the 8 XCDs in turn, each
+  // with its own L2: the strips of ONE group overlap by the blur's halo and share the cache lines their boundaries cut
+  // (224 of every 400 bytes of a row: 1.4x the bytes when each strip's XCD fetches its own copy), so they get ids that are
+  // EQUAL mod 8 -- same XCD, same L2, launched within 8 n_strips ids of each other.
+  const unsigned wg = blockIdx.x, ns = (unsigned)n_strips;
+  const unsigned blk = wg / (8u * ns), in_blk = wg % (8u * ns);
+  const unsigned grp = blk * 8u + (in_blk & 7u), sidx = in_blk >> 3;
+  if (grp * 4u >= n) return;  // (the last block of eight groups may be short)
+  const BaStrip& st = strips[sidx];
   const int xs = st.xs, ncell = st.ncell, amax = st.amax, amin = st.amin, tp = st.tp;
-  const unsigned first = blockIdx.y * 4u;
+  const unsigned first = grp * 4u;
   unsigned mine = first + (unsigned)q;
   if (mine >= n) mine = n - 1;
   // staging role: image q, chunk n16 of a row = columns xs - 8 + 16 n16 .. + 15, as two 8-byte halves.  Every lane loads
@@ -3727,8 +3735,9 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
           const unsigned char* src = d_imgs + i0 * img_stride;
           const unsigned long long bytes = (unsigned long long)(m - 1) * img_stride + (unsigned long long)(h - 1) * row_stride + (unsigned)w;
 #define CBH_BA_(TT, RR)                                                                                                  \
-  hipLaunchKernelGGL((k_band_area<TT, RR>), dim3((unsigned)bat.n_strips, (unsigned)((m + 3) / 4)), dim3(64), 0, stream, src, \
-                     (unsigned)m, w, h, (unsigned)row_stride, (unsigned)img_stride, bytes, bat.strips, at.yrow, d_btiles)
+  hipLaunchKernelGGL((k_band_area<TT, RR>), dim3((unsigned)(((m + 3) / 4 + 7) / 8 * 8 * (size_t)bat.n_strips)), dim3(64), 0, \
+                     stream, src, (unsigned)m, w, h, (unsigned)row_stride, (unsigned)img_stride, bytes, bat.strips,      \
+                     bat.n_strips, at.yrow, d_btiles)
 #define CBH_BA(TT)                       \
   case TT:                               \
     if (bat.RS == 4) CBH_BA_(TT, 4);     \
