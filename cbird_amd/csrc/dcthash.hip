@@ -922,18 +922,20 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
   const unsigned first = grp * 4u;
   unsigned mine = first + (unsigned)q;
   if (mine >= n) mine = n - 1;
-  // staging role: image q, chunk n16 of a row = columns xs - 8 + 16 n16 .. + 15, as two 8-byte halves.  Every lane loads
-  // (no divergent branch around the loads: the compiler then tracks their wait counts): a half left of column 0 reads from
-  // column 0, one past the row's end the next row's first bytes (at the end of the buffer: zeros, by the descriptor's range)
-  // -- all of them columns to which the band matrices give no weight, so any bytes do
+  // staging role: image q, chunk n16 of a row = columns xs - 8 + 16 n16 .. + 15, ONE 16-byte load per row and lane (raw
+  // buffer load: any alignment, no divergent branch around it -- the compiler then tracks the loads' wait counts; two
+  // 8-byte halves per lane cost 15-18 % of the streaming rate, tools/ubench/segread.hip).  The one chunk that would start
+  // left of column 0 (first strip, n16 = 0) loads columns 0 .. 15 instead and puts them 8 bytes further into the ring row
+  // -- over the first half of chunk 1, with the same bytes; the ring's bytes for columns -8 .. -1 stay zero.  A chunk past
+  // the row's end reads the next row's first bytes (at the end of the buffer: zeros, by the descriptor's range) -- columns
+  // to which the band matrices give no weight, like those left of column 0.
   const unsigned long long base_off = (unsigned long long)first * img_stride;
   const unsigned long long left = buf_bytes > base_off ? buf_bytes - base_off : 0ull;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<unsigned char*>(imgs + base_off), 0, (int)(left > 0xffffffffull ? 0xffffffffu : (unsigned)left), 0x27000);
   const int colA = xs - 8 + 16 * n16;
   const unsigned voffA = (mine - first) * img_stride + (unsigned)(colA < 0 ? 0 : colA);
-  const unsigned voffB = (mine - first) * img_stride + (unsigned)(colA + 8 < 0 ? 0 : colA + 8);
-  const int wr_base = q * kImg + 16 * n16;
+  const int wr_base = q * kImg + 16 * n16 + (colA < 0 ? 8 : 0);
   // A-operand role (k_dcthash_256_band): M row n16 = image n16 >> 2, row n16 & 3 of the step; chunk q: 0, 1 the row, 2, 3
   // the row seven above
   const int rd_base = (n16 >> 2) * kImg + (q & 1) * 16;
@@ -954,22 +956,19 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
     ry = max(ry, 0);
     return (unsigned)ry * row_stride;
   };
-  v2u_t stA[2][4], stB[2][4];
-  auto load_step = [&](int t, v2u_t (&a)[4], v2u_t (&b)[4]) {
+  typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+  v4u_t stg[2][4];
+  auto load_step = [&](int t, v4u_t (&a)[4]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const unsigned so = row_off(4 * t + r);
-      a[r] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voffA, (int)so, 0);
-      b[r] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voffB, (int)so, 0);
-    }
+    for (int r = 0; r < 4; ++r) a[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voffA, (int)row_off(4 * t + r), 0);
   };
-  auto store_step = [&](int ts, const v2u_t (&a)[4], const v2u_t (&b)[4]) {
+  auto store_step = [&](int ts, const v4u_t (&a)[4]) {
     if (n16 > T) return;  // (a ring row holds T + 1 chunks)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      v2u_lds* p = reinterpret_cast<v2u_lds*>(sRing + wr_base + (4 * ts + r) * kPitch);
+      v2u_lds* p = reinterpret_cast<v2u_lds*>(sRing + wr_base + (4 * ts + r) * kPitch);  // (8-byte aligned)
       p[0] = v2u_lds{a[r].x ^ 0x80808080u, a[r].y ^ 0x80808080u};
-      p[1] = v2u_lds{b[r].x ^ 0x80808080u, b[r].y ^ 0x80808080u};
+      p[1] = v2u_lds{a[r].z ^ 0x80808080u, a[r].w ^ 0x80808080u};
     }
   };
   unsigned S[T];
@@ -1009,7 +1008,8 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
       const v2f_t p23 = {__builtin_bit_cast(float, x2), __builtin_bit_cast(float, x3)};
       const v2f_t f01 = __builtin_elementwise_fma(p01, kC, kInit), f23 = __builtin_elementwise_fma(p23, kC, kInit);
       const float fa = f01.x, fb = f01.y, fc = f23.x, fd = f23.y;
-      // low bytes of the four quotients -> one dword (rows y .. y + 3 of column 16 c + n16)
+      // low bytes of the four quotients -> one dword (rows y .. y + 3 of column 16 c + n16).  (Four ds_write_b8 straight from
+      // the fma results would save these three VALU instructions: measured 12 % SLOWER -- 52 LDS instructions per step.)
       const unsigned lo = __builtin_amdgcn_perm(__float_as_uint(fb), __float_as_uint(fa), 0x0c0c0400u);
       const unsigned hi = __builtin_amdgcn_perm(__float_as_uint(fd), __float_as_uint(fc), 0x04000c0cu);
       sT[q * tp + 16 * c + n16] = lo | hi;
@@ -1089,24 +1089,24 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
     }
   };
 
-  load_step(0, stA[0], stB[0]);
-  load_step(1, stA[1], stB[1]);
+  load_step(0, stg[0]);
+  load_step(1, stg[1]);
   __syncthreads();  // (the fills)
-  store_step(0, stA[0], stB[0]);
-  load_step(2, stA[0], stB[0]);
+  store_step(0, stg[0]);
+  load_step(2, stg[0]);
   int ts = 0;
   auto nxt = [](int v) { return v == 2 ? 0 : v + 1; };
   for (int t = 0; t < steps; t += 2) {
     const int tsa = ts, tsb = nxt(tsa), tsc = nxt(tsb);
     wave_order_lds();
     step(t, tsa);
-    store_step(tsb, stA[1], stB[1]);
-    if (t + 3 < steps) load_step(t + 3, stA[1], stB[1]);
+    store_step(tsb, stg[1]);
+    if (t + 3 < steps) load_step(t + 3, stg[1]);
     wave_order_lds();
     if (t + 1 < steps) step(t + 1, tsb);
     if (t + 2 < steps) {
-      store_step(tsc, stA[0], stB[0]);
-      if (t + 4 < steps) load_step(t + 4, stA[0], stB[0]);
+      store_step(tsc, stg[0]);
+      if (t + 4 < steps) load_step(t + 4, stg[0]);
     }
     ts = tsc;
   }
