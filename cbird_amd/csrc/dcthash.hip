@@ -993,6 +993,13 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
   const int steps = (h + 3) / 4 + 2;
 
   auto step = [&](int t, int ts) {
+    // the y-table entries of the step's four output rows: scalar loads issued HERE, ahead of the blur, so that their
+    // latency is over when the vertical chain wants them (behind the compiler barriers below they came one after the other,
+    // each waited for: four scalar-memory round trips per step)
+    const int y0 = 4 * (t - 2);  // the step's output rows
+    YRow yrs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) yrs[r] = yrow[min(max(y0 + r, 0), h - 1)];
     // ---- blur: rows 4t .. 4t+3 of the ring -> sT
     int slot = 4 * ts + rd_row;
     slot = slot >= kRing ? slot - kRing : slot;
@@ -1015,7 +1022,6 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
       sT[q * tp + 16 * c + n16] = lo | hi;
     }
     wave_order_lds();  // (the ring rows read above are overwritten by the caller's next store_step)
-    const int y0 = 4 * (t - 2);  // the step's output rows
     if (y0 < 0) return;          // (uniform) warm-up
     // ---- horizontal INTER_AREA: the lane's RS rows of cell ac of image ai
     v2f_t acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
@@ -1054,8 +1060,7 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
     // order: row group 0's lanes first, then the running sum moves one lane up (DPP) to row group 1's, ... and from the last
     // group back to group 0 for the next step.
     const float hv[4] = {acc01.x, acc01.y, acc23.x, acc23.y};
-    auto vrow = [&](int y, float v) {
-      const YRow yr = yrow[y];
+    auto vrow = [&](const YRow& yr, float v) {
       const float t0 = yr.a0 * v;
       vsum = (yr.info & 0x100) ? t0 : vsum + t0;
       if (yr.info & 0x200) {
@@ -1077,7 +1082,7 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
           const int y = y0 + ph * RS + r;
-          if (y < h) vrow(y, hv[r]);  // (uniform)
+          if (y < h) vrow(yrs[ph * RS + r], hv[r]);  // (uniform)
         }
       }
       if constexpr (G > 1) {
