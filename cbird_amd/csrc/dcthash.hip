@@ -870,8 +870,7 @@ struct YRow {
 //     last two tiles of the last strip), top / bottom into the row addresses.
 // Stages 3-6 run from the tiles (k_tiles_hash2).  Against k_blur_area_regs (blur 5.9 + area 2.75 / 0.7 VALU instructions
 // per pixel): ~2.5 + ~2.2 -- see DESIGN a1.  Preconditions (launcher): whole images, 7 x 7 blur, fractional ratios,
-// strips of at least 8 cells within 240 columns (w <= 960; 4 cells, w <= 1920, with "hash_band_area" 2), four images'
-// strides below 2^32.
+// strips of at least 4 cells within 240 columns (w <= 1920), four images' strides below 2^32.
 struct BaStrip {
   int xs;       // first source column of the strip's first cell
   int T;        // 16-column tiles (<= 15)
@@ -987,7 +986,6 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
   const float w_first = st.wfirst[acc_], w_mid = st.wmid[acc_];
   const float w_t0 = st.wtail[acc_][0], w_t1 = st.wtail[acc_][1], w_t2 = st.wtail[acc_][2], w_t3 = st.wtail[acc_][3];
   const int ntail = amax - amin + 1;
-  const unsigned rsh = (unsigned)(8 * RS * rg);  // the lane's rows within a column's dword
   unsigned char* __restrict__ tdst = tiles_out + (size_t)(first + (unsigned)ai) * 1024 + (unsigned)(st.cell0 + ac);
   float vsum = 0.f;
   const int steps = (h + 3) / 4 + 2;
@@ -1023,36 +1021,39 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
     }
     wave_order_lds();  // (the ring rows read above are overwritten by the caller's next store_step)
     if (y0 < 0) return;          // (uniform) warm-up
-    // ---- horizontal INTER_AREA: the lane's RS rows of cell ac of image ai
+    // ---- horizontal INTER_AREA: the lane's RS rows of cell ac of image ai.  A column of sT is one dword = four rows; a
+    // lane that carries two rows (one row) reads just its half (byte) of it -- ds_read_u16 / ds_read_u8 hand back the bytes
+    // already shifted into place
     v2f_t acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
     {
       const unsigned* __restrict__ src = sT + ai * tp + asi;
-      auto col = [&](unsigned pw_, float a_) {
+      const unsigned char* __restrict__ bsrc = reinterpret_cast<const unsigned char*>(src) + RS * rg;
+      auto col = [&](int k, float a_) {
         if constexpr (RS == 4) {
+          const unsigned pw_ = src[k];
           const v2f_t w2 = {a_, a_};
           const v2f_t p01 = {(float)(pw_ & 0xffu), (float)((pw_ >> 8) & 0xffu)};
           const v2f_t p23 = {(float)((pw_ >> 16) & 0xffu), (float)(pw_ >> 24)};
           acc01 = acc01 + p01 * w2;
           acc23 = acc23 + p23 * w2;
         } else if constexpr (RS == 2) {
-          const unsigned x_ = pw_ >> rsh;
+          const unsigned x_ = *reinterpret_cast<const unsigned short*>(bsrc + 4 * k);
           const v2f_t w2 = {a_, a_};
-          const v2f_t p01 = {(float)(x_ & 0xffu), (float)((x_ >> 8) & 0xffu)};
+          const v2f_t p01 = {(float)(x_ & 0xffu), (float)(x_ >> 8)};
           acc01 = acc01 + p01 * w2;
         } else {
-          const unsigned x_ = pw_ >> rsh;
-          acc01.x = acc01.x + (float)(x_ & 0xffu) * a_;
+          acc01.x = acc01.x + (float)bsrc[4 * k] * a_;
         }
       };
-      col(src[0], w_first);
+      col(0, w_first);
 #pragma unroll 4
-      for (int k = 1; k < amin - 1; ++k) col(src[k], w_mid);  // interior columns: every lane's cell has them
+      for (int k = 1; k < amin - 1; ++k) col(k, w_mid);  // interior columns: every lane's cell has them
       {
-        const unsigned* __restrict__ tp = src + (amin - 1);
-        col(tp[0], w_t0);  // (amin >= 2: entry amin - 1 exists in the shortest cell; longer cells go on)
-        if (ntail > 1) col(tp[1], w_t1);
-        if (ntail > 2) col(tp[2], w_t2);
-        if (ntail > 3) col(tp[3], w_t3);
+        const int kt = amin - 1;
+        col(kt, w_t0);  // (amin >= 2: entry amin - 1 exists in the shortest cell; longer cells go on)
+        if (ntail > 1) col(kt + 1, w_t1);
+        if (ntail > 2) col(kt + 2, w_t2);
+        if (ntail > 3) col(kt + 3, w_t3);
       }
     }
     wave_order_lds();  // (sT is rewritten by the next step's blur)
@@ -3076,9 +3077,8 @@ int reflect101_host(int p, int len);
 // Strips and band matrices of k_band_area for images of width w: n_strips >= 2 strips of cps = ceil(32 / n_strips) <= 16
 // cells, each at most 240 source columns wide with cells of at most 32 table entries.  *out = nullptr (and CBH_OK) when
 // the geometry does not fit (the caller takes k_blur_area_regs).
-// "hash_band_area": 1 (default) = fractional-ratio geometries whose strips hold >= 8 cells (w <= 960) take k_band_area (blur
-// on the matrix cores, up to four rows per area walk), 2 = also strips of 4 cells (w <= 1920; experiments), 0 =
-// k_blur_area_regs as through round 4
+// "hash_band_area": 1 (default) = fractional-ratio geometries whose strips hold >= 4 cells (w <= 1920) take k_band_area (blur
+// on the matrix cores, up to four rows per area walk), 0 = k_blur_area_regs as through round 4
 int g_hash_band_area = 1;
 
 struct BaTabsDev {
@@ -3091,7 +3091,7 @@ int get_ba_tabs(int w, BaTabsDev* out) {
   int dev = 0;
   CBH_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_area_mu);
-  auto key = std::make_pair(dev, 2 * w + (g_hash_band_area >= 2 ? 1 : 0));
+  auto key = std::make_pair(dev, w);
   auto it = g_ba_tabs.find(key);
   if (it == g_ba_tabs.end()) {
     BaTabsDev d;
@@ -3114,10 +3114,10 @@ int get_ba_tabs(int w, BaTabsDev* out) {
         }
     };
     // cells per strip, in order of preference: 16 or 11 (a lane carries the four rows of a step: RS 4), 8 (two rows: RS 2),
-    // 4 (one row: RS 1 -- measured no better than k_blur_area_regs at 1280 .. 1920 columns and worse beyond, hence only
-    // with "hash_band_area" 2)
+    // 4 (one row: RS 1; w <= 1920).  Two cells per strip (w <= 3840) leave half the walk's lanes idle: measured 1.45 TB/s at
+    // 3840 x 2160 against k_blur_area_regs' 2.6 -- not offered.
     const int cps_try[4] = {16, 11, 8, 4};
-    for (int ci = 0; ci < (g_hash_band_area >= 2 ? 4 : 3) && host.empty(); ++ci) {
+    for (int ci = 0; ci < 4 && host.empty(); ++ci) {
       const int cps = cps_try[ci];
       bool ok = true;
       // one tile count for every strip: the widest strip's

@@ -726,10 +726,10 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *   "hash_mfma"     kernel for 256x256 tiles: non-zero (default 2) = k_dcthash_256_band (horizontal box sums as i8 MFMAs,
  *                   one add + half an fma per pixel on the VALU; rows must be 16-byte aligned, otherwise 0 is taken),
  *                   0 = k_dcthash_256 (all VALU)
- *   "hash_band_area" general geometry with fractional resize ratios: 1 (default) = widths up to ~960 columns (strips of >= 8
+ *   "hash_band_area" general geometry with fractional resize ratios: 1 (default) = widths up to 1920 columns (strips of >= 4
  *                   output cells within 240 columns) take k_band_area -- the 256x256 kernel's matrix-core blur for any width
- *                   and height, four rows of a step per INTER_AREA walk; 2 = also strips of 4 cells (w <= 1920; no faster
- *                   than the round-4 kernels there); 0 = k_blur_area_regs & co. as through round 4.  Bit-identical either way
+ *                   and height, up to four rows of a step per INTER_AREA walk; 0 = k_blur_area_regs & co. as through round 4.
+ *                   Bit-identical either way
  *   "hash_band_waves" waves per workgroup of k_dcthash_256_band: 1 (default: a wave owns its four images alone, no
  *                   barriers, 9 waves per CU) or 2 (two waves share four images' rows and tiles in LDS, 14 waves per CU;
  *                   measured 5 % slower)

@@ -510,7 +510,7 @@ def test_band_area_kernel_geometries_strides_and_ragged_batches(gpu, orc, band_a
     rng = np.random.default_rng(2025)
     geos = [(64, 301), (65, 33), (66, 32), (79, 129), (96, 97), (100, 35), (127, 200), (160, 121), (200, 150), (239, 37),
             (241, 241), (300, 200), (333, 250), (400, 300), (401, 299), (479, 361), (480, 270), (533, 400), (600, 401),
-            (640, 481), (641, 480), (700, 99), (720, 405), (799, 601), (854, 480), (900, 34), (959, 540), (960, 541), (961, 100), (1000, 40)]
+            (640, 481), (641, 480), (700, 99), (720, 405), (799, 601), (854, 480), (900, 34), (959, 540), (960, 541), (961, 100), (1000, 40), (1280, 721), (1366, 70), (1601, 99), (1919, 50), (1920, 1081), (1921, 40)]
     for gi, (w, h) in enumerate(geos):
         n = int(rng.integers(1, 10))
         row_stride = w + int(rng.integers(0, 7))
