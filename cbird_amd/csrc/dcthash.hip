@@ -888,6 +888,15 @@ struct BaStrip {
   unsigned band[3][64][4]; // B operands: the plain band, the strip's first tile, its last tile
 };
 
+// Row bands: a small batch has too few (group, strip) pairs to fill the machine (256 frames of 1920 x 1080: 512 waves for 2560
+// slots, each walking 270 steps), so the 32 output ROWS are dealt to up to 8 waves per (group, strip) as well: band b makes
+// the output rows [c0, c1) and walks the source rows [ra, rb] that feed them (+ two warm-up steps for the blur's seven-row
+// window; a source row that straddles two bands' cells is walked by both).
+struct BaBands {
+  int n;
+  int ra[8], rb[8], c0[8], c1[8];
+};
+
 // T = 16-column tiles per strip (the same for every strip of a geometry).  RS = rows of a step one lane carries through the
 // area walk: 4 (strips of <= 16 cells: lane = image, cell), 2 (<= 8 cells: lane = image, cell, row pair) or 1 (<= 4 cells:
 // lane = image, cell, row) -- wide cells mean few cells per 240-column strip, and the rows of a step are then spread over the
@@ -896,7 +905,11 @@ template <int T, int RS>
 __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restrict__ imgs, unsigned n, int w, int h,
                                                   unsigned row_stride, unsigned img_stride, unsigned long long buf_bytes,
                                                   const BaStrip* __restrict__ strips, int n_strips,
-                                                  const YRow* __restrict__ yrow, unsigned char* __restrict__ tiles_out) {
+                                                  const YRow* __restrict__ yrow, unsigned char* __restrict__ tiles_out,
+                                                  int oy, int ph /* a full-width view: rows oy .. oy + h - 1 of images of ph
+                                                                    rows (letterboxed frames after autocrop; cv::blur takes
+                                                                    its border from the parent); whole images: 0, h */,
+                                                  BaBands bands) {
   // LDS, sized by T (separate arrays: the compiler must know that they do not alias): ring 4 x 12 rows x kPitch, sT =
   // blurred bytes [x][image] = 4 rows (+ 8 columns for the walk's overhang), sA = the cells' weights [16][amax]
   constexpr int kRing = 12, kPitch = 16 * T + 32, kImg = kRing * kPitch;
@@ -912,10 +925,11 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
   // with its own L2: the strips of ONE group overlap by the blur's halo and share the cache lines their boundaries cut
   // (224 of every 400 bytes of a row: 1.4x the bytes when each strip's XCD fetches its own copy), so they get ids that are
   // EQUAL mod 8 -- same XCD, same L2, launched within 8 n_strips ids of each other.
-  const unsigned wg = blockIdx.x, ns = (unsigned)n_strips;
-  const unsigned blk = wg / (8u * ns), in_blk = wg % (8u * ns);
-  const unsigned grp = blk * 8u + (in_blk & 7u), sidx = in_blk >> 3;
+  const unsigned wg = blockIdx.x, ns = (unsigned)n_strips, nsb = ns * (unsigned)bands.n;
+  const unsigned blk = wg / (8u * nsb), in_blk = wg % (8u * nsb);
+  const unsigned grp = blk * 8u + (in_blk & 7u), sidx = (in_blk >> 3) % ns, bidx = (in_blk >> 3) / ns;
   if (grp * 4u >= n) return;  // (the last block of eight groups may be short)
+  const int ra = bands.ra[bidx], rb = bands.rb[bidx], bc0 = bands.c0[bidx], bc1 = bands.c1[bidx];
   const BaStrip& st = strips[sidx];
   const int xs = st.xs, ncell = st.ncell, amax = st.amax, amin = st.amin, tp = st.tp;
   const unsigned first = grp * 4u;
@@ -946,10 +960,10 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
   const v4i_t bL = *reinterpret_cast<const v4i_t*>(st.band[2][lane]);
   for (int i = lane; i < 4 * kImg / 16; i += 64) reinterpret_cast<v4u_lds*>(sRing)[i] = v4u_lds{0u, 0u, 0u, 0u};
   for (int i = lane; i < 4 * kTP; i += 64) sT[i] = 0u;
-  // virtual row v = 0 .. h + 7 is image row reflect101(v - 5); output row y = v - 8 is complete with row v
-  const int h2 = 2 * (h - 1);
+  // virtual row v = 0 .. is row reflect101(oy + ra + v - 5) of the parent; blurred row y = ra + v - 8 is complete with row v
+  const int h2 = 2 * (ph - 1);
   auto row_off = [&](int v) -> unsigned {
-    int ry = v - 5;
+    int ry = oy + ra + v - 5;
     ry = ry < 0 ? -ry : ry;
     ry = min(ry, h2 - ry);
     ry = max(ry, 0);
@@ -988,13 +1002,13 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
   const int ntail = amax - amin + 1;
   unsigned char* __restrict__ tdst = tiles_out + (size_t)(first + (unsigned)ai) * 1024 + (unsigned)(st.cell0 + ac);
   float vsum = 0.f;
-  const int steps = (h + 3) / 4 + 2;
+  const int steps = (rb - ra + 1 + 3) / 4 + 2;
 
   auto step = [&](int t, int ts) {
     // the y-table entries of the step's four output rows: scalar loads issued HERE, ahead of the blur, so that their
     // latency is over when the vertical chain wants them (behind the compiler barriers below they came one after the other,
     // each waited for: four scalar-memory round trips per step)
-    const int y0 = 4 * (t - 2);  // the step's output rows
+    const int y0 = ra + 4 * (t - 2);  // the step's blurred rows
     YRow yrs[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) yrs[r] = yrow[min(max(y0 + r, 0), h - 1)];
@@ -1020,7 +1034,7 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
       sT[q * tp + 16 * c + n16] = lo | hi;
     }
     wave_order_lds();  // (the ring rows read above are overwritten by the caller's next store_step)
-    if (y0 < 0) return;          // (uniform) warm-up
+    if (t < 2) return;           // (uniform) warm-up
     // ---- horizontal INTER_AREA: the lane's RS rows of cell ac of image ai.  A column of sT is one dword = four rows; a
     // lane that carries two rows (one row) reads just its half (byte) of it -- ds_read_u16 / ds_read_u8 hand back the bytes
     // already shifted into place
@@ -1064,16 +1078,17 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
     auto vrow = [&](const YRow& yr, float v) {
       const float t0 = yr.a0 * v;
       vsum = (yr.info & 0x100) ? t0 : vsum + t0;
-      if (yr.info & 0x200) {
+      const int di = yr.info & 0xff;
+      if ((yr.info & 0x200) && di >= bc0 && di < bc1) {  // (a cell of another band: its rows are walked there)
         const float rr = __builtin_rintf(vsum);
-        if (alive) tdst[(yr.info & 0xff) * 32] = (unsigned char)(rr < 0.f ? 0.f : rr > 255.f ? 255.f : rr);
+        if (alive) tdst[di * 32] = (unsigned char)(rr < 0.f ? 0.f : rr > 255.f ? 255.f : rr);
       }
       if (yr.info & 0x400) {
         const float t1 = yr.a1 * v;
         vsum = (yr.info & 0x800) ? t1 : vsum + t1;
-        if (yr.info & 0x1000) {
+        if ((yr.info & 0x1000) && di + 1 >= bc0 && di + 1 < bc1) {
           const float rr = __builtin_rintf(vsum);
-          if (alive) tdst[((yr.info & 0xff) + 1) * 32] = (unsigned char)(rr < 0.f ? 0.f : rr > 255.f ? 255.f : rr);
+          if (alive) tdst[(di + 1) * 32] = (unsigned char)(rr < 0.f ? 0.f : rr > 255.f ? 255.f : rr);
         }
       }
     };
@@ -1083,7 +1098,7 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
           const int y = y0 + ph * RS + r;
-          if (y < h) vrow(yrs[ph * RS + r], hv[r]);  // (uniform)
+          if (y <= rb) vrow(yrs[ph * RS + r], hv[r]);  // (uniform)
         }
       }
       if constexpr (G > 1) {
@@ -3726,8 +3741,9 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     const int ipb = T % 64 == 0 ? 1 : 256 / T, block_threads = (ipb * T + 63) / 64 * 64;
     const int pitch = T * 8 + 8;
     const size_t smem = (size_t)ipb * (size_t)(kBlurRB + K_ - 1) * (size_t)pitch;
-    if (g_hash_band_area && !view && K_ == 7 && !integer && at.yrow && w >= 64 && 4ull * img_stride < (1ull << 32) &&
-        (size_t)h * row_stride < ((size_t)1 << 32)) {
+    // (whole images, and views that span their parent's width: letterboxed frames -- only the row mapping differs)
+    if (g_hash_band_area && (!view || (vw.ox == 0 && vw.pw == w)) && K_ == 7 && !integer && at.yrow && w >= 64 &&
+        4ull * img_stride < (1ull << 32) && (size_t)vw.ph * row_stride < ((size_t)1 << 32)) {
       BaTabsDev bat;
       if ((rc = get_ba_tabs(w, &bat))) return rc;
       if (bat.strips) {
@@ -3738,11 +3754,25 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
         for (size_t i0 = 0; i0 < n; i0 += per_chunk_b) {
           const size_t m = std::min(per_chunk_b, n - i0);
           const unsigned char* src = d_imgs + i0 * img_stride;
-          const unsigned long long bytes = (unsigned long long)(m - 1) * img_stride + (unsigned long long)(h - 1) * row_stride + (unsigned)w;
+          const unsigned long long bytes = (unsigned long long)(m - 1) * img_stride + (unsigned long long)(vw.ph - 1) * row_stride + (unsigned)w;
+          // row bands: enough waves for ~two rounds of the machine's 2560 slots, at least 4 output rows per band
+          BaBands bands;
+          bands.n = 1;
+          while (bands.n < 8 && (m + 3) / 4 * (size_t)bat.n_strips * (size_t)bands.n < 5120) bands.n *= 2;
+          {
+            std::vector<int> yf;
+            const std::vector<AreaTab> yt = make_area_tab(h, 32, &yf);
+            for (int b_ = 0; b_ < bands.n; ++b_) {
+              const int c0_ = 32 * b_ / bands.n, c1_ = 32 * (b_ + 1) / bands.n;
+              bands.c0[b_] = c0_, bands.c1[b_] = c1_;
+              bands.ra[b_] = yt[(size_t)yf[(size_t)c0_]].si;
+              bands.rb[b_] = yt[(size_t)yf[(size_t)c1_] - 1].si;
+            }
+          }
 #define CBH_BA_(TT, RR)                                                                                                  \
-  hipLaunchKernelGGL((k_band_area<TT, RR>), dim3((unsigned)(((m + 3) / 4 + 7) / 8 * 8 * (size_t)bat.n_strips)), dim3(64), 0, \
+  hipLaunchKernelGGL((k_band_area<TT, RR>), dim3((unsigned)(((m + 3) / 4 + 7) / 8 * 8 * (size_t)bat.n_strips * (size_t)bands.n)), dim3(64), 0, \
                      stream, src, (unsigned)m, w, h, (unsigned)row_stride, (unsigned)img_stride, bytes, bat.strips,      \
-                     bat.n_strips, at.yrow, d_btiles)
+                     bat.n_strips, at.yrow, d_btiles, view ? vw.oy : 0, view ? vw.ph : h, bands)
 #define CBH_BA(TT)                       \
   case TT:                               \
     if (bat.RS == 4) CBH_BA_(TT, 4);     \
