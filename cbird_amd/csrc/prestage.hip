@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void k_bgr2gray(const unsigned char* __restric
 //     then from the right (a content row costs its two end segments, a bar row is read once); the end segments of
 //     all eight rows are requested together;
 //   * a column task (second launch) owns 256 adjacent columns and walks down from the top (or up from the bottom) eight
-//     rows per step until every one of its columns has met content, skipping the rows the row tasks found all border.
+//     rows per step until every one of its columns has met content, skipping the rows the row tasks found all border
+//     and the columns outside every row's content span (pillarbox bars: nothing to walk).
 // So a frame without bars costs ~1/4 of its bytes, a letterboxed one its bars plus the edges.  Every output has one
 // owner: no atomics.  k_autocrop_decide (one workgroup per image, a wave per search) then replays the selection and centring rules, each of
 // the four searches as a ballot over 64 candidates at a time.
@@ -213,6 +214,29 @@ __global__ __launch_bounds__(256) void k_autocrop_runs(const unsigned char* __re
   const int none = from_top ? rows : 0;
   int f0 = none, f1 = none, f2 = none, f3 = none;
   unsigned live = x < cols ? (1u << min(4, cols - x)) - 1u : 0u;  // columns that have not met content yet
+  // columns left of every row's first content pixel or right of every row's last one (the bars of a pillarboxed frame)
+  // have none: settled from the row tasks' results, without walking them down the whole frame
+  {
+    int min_l = cols, max_r = 0;
+    for (int y = lane; y < rows; y += 64) {
+      const int l = rowL[y];
+      if (l < cols) min_l = min(min_l, l), max_r = max(max_r, rowR[y]);
+    }
+#pragma unroll
+    for (int d = 32; d; d >>= 1) {
+      min_l = min(min_l, __shfl_xor(min_l, d));
+      max_r = max(max_r, __shfl_xor(max_r, d));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (x + j < min_l || x + j >= max_r) live &= ~(1u << j);
+    if (__ballot(live != 0u) == 0ull) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (x + j < cols) (from_top ? colT : colB)[x + j] = none;
+      return;
+    }
+  }
   for (int s0 = 0; s0 < rows; s0 += kAcRowsPerStep) {
     // c[j]: bit u = column x + j has content in the u-th row of this step
     unsigned c[4] = {0u, 0u, 0u, 0u};

@@ -238,7 +238,7 @@ def test_process_images_ex_also_returns_the_orb_input(gpu, po, orc):
 def test_autocrop_dev_equals_oracle_over_geometries_and_strides(gpu, po):
     """cbh_autocrop_dev on its own (the rectangles, before any hashing): widths around the 256-byte segment and the
     4-byte load boundaries, heights around the 8-row steps, odd row strides (unaligned rows), bars of every kind,
-    content inside the bars (subtitles), images that are all border or all content"""
+    content inside the bars (subtitles, a logo in a side bar), images that are all border or all content"""
     import torch
 
     from cbird_amd import _lib
@@ -272,6 +272,8 @@ def test_autocrop_dev_equals_oracle_over_geometries_and_strides(gpu, po):
                     img[t:h - b, l:w - r] = inner.astype(np.uint8)
                 if kind == 5 and h > 4 and w > 8:  # a subtitle inside the bottom bar
                     img[h - 2, w // 3: w // 2] = (border + 100) % 256
+                if kind == 1 and l > 2 and i % 12 == 1 and w % 2:  # a logo inside the left bar: that bar is walked after all
+                    img[h // 2, l // 2] = (border + 100) % 256
                 buf[i, :, :w] = img
             d = torch.from_numpy(buf).to(dev)
             rects = torch.full((n, 4), -7, dtype=torch.int32, device=dev)

@@ -19,16 +19,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=2048)
     ap.add_argument("--chunk", type=int, default=256)
+    ap.add_argument("--only", default="", help="w,h,bar_rows,side_cols: just that geometry")
     args = ap.parse_args()
     import torch
 
     from cbird_amd.video import VideoIndexer
 
     dev = torch.device("cuda", 0)
-    for (w, h, bar) in ((1920, 1080, 0), (1920, 1080, 140), (1280, 720, 0), (1280, 720, 90), (640, 360, 0),
-                        (640, 360, 45), (256, 256, 0)):
+    geos = ((1920, 1080, 0, 0), (1920, 1080, 140, 0), (1920, 1080, 0, 240), (1280, 720, 0, 0),
+                              (1280, 720, 90, 0), (1280, 720, 0, 160), (640, 360, 0, 0), (640, 360, 45, 0), (256, 256, 0, 0))
+    if args.only:
+        geos = (tuple(int(x) for x in args.only.split(",")),)
+    for (w, h, bar, side) in geos:
         n = args.frames if w * h <= 1280 * 720 else min(args.frames, 1024)
-        g = torch.Generator(device=dev).manual_seed(w + bar)
+        g = torch.Generator(device=dev).manual_seed(w + bar + side)
         # slowly varying content (so the near-frame filter has something to drop) + bars with a little noise
         base = torch.randint(40, 256, (1, h - 2 * bar, w), dtype=torch.uint8, device=dev, generator=g)
         frames = torch.full((n, h, w), 16, dtype=torch.uint8, device=dev)
@@ -37,8 +41,11 @@ def main():
         frames[:, bar:h - bar, :] = torch.clamp(base.to(torch.int16) + noise.to(torch.int16), 40, 255).to(torch.uint8)
         for k in range(0, n, 97):  # scene cuts
             frames[k:, bar:h - bar, :] = torch.roll(frames[k:, bar:h - bar, :], shifts=k * 131 + 7, dims=2)
+        if side:  # pillarbox: 4:3 content in a 16:9 frame
+            frames[:, :, :side] = torch.randint(16, 19, (n, h, side), dtype=torch.uint8, device=dev, generator=g)
+            frames[:, :, w - side:] = torch.randint(16, 19, (n, h, side), dtype=torch.uint8, device=dev, generator=g)
         torch.cuda.synchronize()
-        rec = {"w": w, "h": h, "bar_rows": bar, "frames": n, "chunk": args.chunk}
+        rec = {"w": w, "h": h, "bar_rows": bar, "side_cols": side, "frames": n, "chunk": args.chunk}
         for crop in (20, -1):
             best = None
             for rep in range(3):
