@@ -649,14 +649,21 @@ size_t cbh_video_dedup(const uint64_t* hashes, size_t n, int threshold, uint8_t*
   for (size_t i = 1; i < n; ++i) {
     keep[i] = 0;
     if (threshold > 0) {
-      size_t close = 0;
-      for (uint64_t prev : window)
-        if (__builtin_popcountll(prev ^ hashes[i]) < threshold) close++;
-      if (close != window.size()) {
+      // the window as the set of its hashes: only "is any of them far" is asked of it (vindexer.hip, feed)
+      bool far = false, have = false;
+      for (uint64_t prev : window) {
+        const int d = __builtin_popcountll(prev ^ hashes[i]);
+        if (d >= threshold) {
+          far = true;
+          break;
+        }
+        have |= d == 0;
+      }
+      if (far) {
         window.clear();
         keep[i] = 1;
       }
-      window.push_back(hashes[i]);
+      if (far || !have) window.push_back(hashes[i]);
     } else
       keep[i] = 1;
     kept += keep[i];

@@ -70,17 +70,26 @@ void feed(cbh_vindexer* v, uint64_t hash) {
     return;
   }
   if (v->threshold > 0) {  // :994-1009
-    size_t close = 0;
-    for (uint64_t prev : v->window)
-      if (__builtin_popcountll(prev ^ hash) < v->threshold) close++;
-    if (close != v->window.size()) {
+    // "close != window.size()" = some hash of the window is not near this one.  Only that is asked of the window, so
+    // it is kept as the SET of its hashes (a value already in it is not added again): a static scene repeats a handful
+    // of hashes, and the reference's list -- every frame since the last stored one -- makes this loop quadratic there
+    bool far = false, have = false;
+    for (uint64_t prev : v->window) {
+      const int d = __builtin_popcountll(prev ^ hash);
+      if (d >= v->threshold) {
+        far = true;
+        break;
+      }
+      have |= d == 0;
+    }
+    if (far) {
       v->window.clear();
       v->hashes.push_back(hash);
       v->frames.push_back(v->frame_number);
     } else {
       v->near_frames++;
     }
-    v->window.push_back(hash);
+    if (far || !have) v->window.push_back(hash);
   } else {
     v->hashes.push_back(hash);
     v->frames.push_back(v->frame_number);
@@ -102,6 +111,15 @@ int hash_chunk(cbh_vindexer* v, const uint8_t* d_gray, size_t m, int w, int h, s
   int* hr = v->h_rects.data();
   const bool crop = v->autocrop >= 0;
   int spec[4] = {0, 0, w, h};
+  if (crop && !(v->spec_w == w && v->spec_h == h) && m > 8) {
+    // nothing to go by yet (the first chunk of a video): one frame from the middle of the chunk (the first ones are
+    // often a fade-in) tells the region to speculate on -- 50 us once instead of hashing a letterboxed chunk twice
+    rc = cbh_autocrop_dev(d_gray + (m / 2) * gi, 1, w, h, gs, gi, v->autocrop, v->d_rects, v->device, s);
+    if (rc) return rc;
+    CBH_HIP(hipMemcpyAsync(v->spec, v->d_rects, sizeof v->spec, hipMemcpyDeviceToHost, s));
+    CBH_HIP(hipStreamSynchronize(s));
+    v->spec_w = w, v->spec_h = h;
+  }
   if (crop && v->spec_w == w && v->spec_h == h) memcpy(spec, v->spec, sizeof spec);
   auto launch = [&](size_t i, size_t run, const int* r, uint64_t* d_out) {
     if (r[0] == 0 && r[1] == 0 && r[2] == w && r[3] == h) return cbh::launch_dcthash(d_gray + i * gi, run, w, h, gs, gi, d_out, s);

@@ -198,6 +198,21 @@ def test_dedup_rule(vorc):
     k = vorc.dedup(walk, 8)
     assert k[0] and k[-1]
     assert make_video_index(walk, 8).frames == np.nonzero(k)[0].tolist()
+    # static scenes and slow drift: a few hashes repeating (the library keeps the window as a set), a hash that wanders
+    # a bit at a time (near its neighbours, eventually far from the window's oldest entry), both with cuts in between
+    for seed in range(6):
+        rng = np.random.default_rng(100 + seed)
+        cur, out = int(rng.integers(0, 1 << 62)), []
+        for i in range(3000):
+            r = rng.random()
+            if r < 0.004:
+                cur = int(rng.integers(0, 1 << 62))  # cut
+            elif r < (0.02, 0.3, 0.6)[seed % 3]:
+                cur ^= 1 << int(rng.integers(0, 64))  # drift
+            out.append(cur ^ ((1 << int(rng.integers(0, 64))) if rng.random() < 0.3 else 0))  # flicker
+        out = np.array(out, np.uint64)
+        for thr in (1, 4, 8, 20):
+            assert make_video_index(out, thr).frames == np.nonzero(vorc.dedup(out, thr))[0].tolist(), (seed, thr)
 
 
 def test_oracle_candidates_vs_real_radixmap(vorc):

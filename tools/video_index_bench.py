@@ -31,7 +31,7 @@ def main():
     if args.only:
         geos = (tuple(int(x) for x in args.only.split(",")),)
     for (w, h, bar, side) in geos:
-        n = args.frames if w * h <= 1280 * 720 else min(args.frames, 1024)
+        n = args.frames if w * h <= 1280 * 720 else min(args.frames, 4096) if args.frames > 2048 else min(args.frames, 1024)
         g = torch.Generator(device=dev).manual_seed(w + bar + side)
         # slowly varying content (so the near-frame filter has something to drop) + bars with a little noise
         base = torch.randint(40, 256, (1, h - 2 * bar, w), dtype=torch.uint8, device=dev, generator=g)
