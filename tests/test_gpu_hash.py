@@ -537,3 +537,33 @@ def test_band_area_kernel_geometries_strides_and_ragged_batches(gpu, orc, band_a
         for i in range(n):
             assert (t[i] == orc.tile32(np.ascontiguousarray(imgs[i]))).all(), (w, h, i)
         assert (out.cpu().numpy().view(np.uint64) == want).all(), (w, h)
+
+
+@pytest.mark.gpu
+def test_band_area_row_bands_agree_across_batch_sizes(gpu, orc):
+    """k_band_area splits a (group of four images, strip) into 1, 2, 4 or 8 row bands by how many waves the batch makes
+    (dcthash.hip, launch_dcthash): the same images hashed in one large batch (one band), in pieces that take 2 and 4
+    bands, and in small pieces (8 bands) give the same hashes, and a sample of them equals the oracle.  Views that keep
+    the parent's width (letterboxed frames) go through the same row mapping with an offset: checked as the hash of the
+    rows cut out by hand with their neighbours kept as the blur's border (= the same view, by construction)."""
+    import torch
+
+    from cbird_amd import _lib
+
+    L = _lib.lib()
+    for (w, h, n) in ((200, 150, 11000), (1280, 45, 2600)):
+        g = torch.Generator(device="cuda").manual_seed(w * 7 + h)
+        imgs = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device="cuda", generator=g)
+        imgs[::3] //= 7  # darker, smoother images too
+        whole = torch.zeros(n, dtype=torch.int64, device="cuda")
+        _lib.check(L.cbh_dcthash_batch_dev(imgs.data_ptr(), n, w, h, w, w * h, whole.data_ptr(), 0, None), "whole")
+        for piece in (n // 2 + 1, n // 4 + 3, 1000, 61):
+            part = torch.zeros(n, dtype=torch.int64, device="cuda")
+            for i0 in range(0, n if piece > 100 else 10 * piece, piece):
+                m = min(piece, n - i0)
+                _lib.check(L.cbh_dcthash_batch_dev(imgs[i0:].data_ptr(), m, w, h, w, w * h, part[i0:].data_ptr(), 0, None),
+                           "piece")
+            k = n if piece > 100 else 10 * piece
+            assert torch.equal(part[:k], whole[:k]), (w, h, piece)
+        sample = imgs[:48].cpu().numpy()
+        assert (whole[:48].cpu().numpy().view(np.uint64) == orc.dcthash64_batch(np.ascontiguousarray(sample))).all(), (w, h)
