@@ -543,9 +543,8 @@ def test_band_area_kernel_geometries_strides_and_ragged_batches(gpu, orc, band_a
 def test_band_area_row_bands_agree_across_batch_sizes(gpu, orc):
     """k_band_area splits a (group of four images, strip) into 1, 2, 4 or 8 row bands by how many waves the batch makes
     (dcthash.hip, launch_dcthash): the same images hashed in one large batch (one band), in pieces that take 2 and 4
-    bands, and in small pieces (8 bands) give the same hashes, and a sample of them equals the oracle.  Views that keep
-    the parent's width (letterboxed frames) go through the same row mapping with an offset: checked as the hash of the
-    rows cut out by hand with their neighbours kept as the blur's border (= the same view, by construction)."""
+    bands, and in small pieces (8 bands) give the same hashes, and a sample of them equals the oracle.  (Letterbox views on
+    the same kernel: tests/test_prestage.py, test_autocropped_hash_uses_the_parent_border.)"""
     import torch
 
     from cbird_amd import _lib
