@@ -859,7 +859,7 @@ struct YRow {
 // D = Hsum(u) - Hsum(u - 7); S += D is the 7 x 7 box sum, one fma turns 2^23 + S into 2^23 + const + nearest(S / 49)
 // (k_dcthash_256_band's exact division, the constant chosen so that the quotient IS the low byte).  What differs:
 //   * the blurred pixels are needed as bytes.  A lane holds four consecutive ROWS of one column: their quotients are
-//     packed into one dword and stored TRANSPOSED, sT[x][image] = rows y .. y + 3 of column x;
+//     packed into one dword, sT[image][x] = rows y .. y + 3 of column x (one plane per image);
 //   * horizontal INTER_AREA: lane (image, cell) walks its cell's columns in table order and runs the four rows' chains
 //     `sum += float(p) * alpha` as two float pairs (v_cvt_f32_ubyte0..3, v_pk_mul_f32, v_pk_add_f32: ordinary IEEE
 //     multiplies and adds, the bits of the scalar chain) -- 2 instructions per pixel, every lane busy when a strip has 16
@@ -869,8 +869,9 @@ struct YRow {
 //   * REFLECT_101 left / right is folded into per-strip band matrices made on the host (first tile of the first strip,
 //     last two tiles of the last strip), top / bottom into the row addresses.
 // Stages 3-6 run from the tiles (k_tiles_hash2).  Against k_blur_area_regs (blur 5.9 + area 2.75 / 0.7 VALU instructions
-// per pixel): ~2.5 + ~2.2 -- see DESIGN a1.  Preconditions (launcher): whole images, 7 x 7 blur, fractional ratios,
-// strips of at least 4 cells within 240 columns (w <= 1920), four images' strides below 2^32.
+// per pixel): ~2.5 + ~2.2 -- see DESIGN a1.  Preconditions (launcher): whole images or views that keep their parent's
+// width (oy, ph), 7 x 7 blur, fractional ratios, strips of at least 4 cells within 240 columns (w <= 1920), four images'
+// strides below 2^32.
 struct BaStrip {
   int xs;       // first source column of the strip's first cell
   int T;        // 16-column tiles (<= 15)
@@ -911,7 +912,7 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
                                                                     its border from the parent); whole images: 0, h */,
                                                   BaBands bands) {
   // LDS, sized by T (separate arrays: the compiler must know that they do not alias): ring 4 x 12 rows x kPitch, sT =
-  // blurred bytes [x][image] = 4 rows (+ 8 columns for the walk's overhang), sA = the cells' weights [16][amax]
+  // blurred bytes [image][x], a dword = 4 rows (+ columns for the walk's overhang)
   constexpr int kRing = 12, kPitch = 16 * T + 32, kImg = kRing * kPitch;
   __shared__ __attribute__((aligned(16))) unsigned char sRing[4 * kImg];
   // sT[image][x]: the area walk has lane (image, cell) read column si0[cell] + k -- cells 28 columns apart would meet in

@@ -218,9 +218,17 @@ __global__ __launch_bounds__(256) void k_autocrop_runs(const unsigned char* __re
   // have none: settled from the row tasks' results, without walking them down the whole frame
   {
     int min_l = cols, max_r = 0;
-    for (int y = lane; y < rows; y += 64) {
-      const int l = rowL[y];
-      if (l < cols) min_l = min(min_l, l), max_r = max(max_r, rowR[y]);
+    for (int y0 = 0; y0 < rows; y0 += 512) {  // (sixteen loads in flight per lane: one round trip per 512 rows)
+      int l[8], r[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int y = y0 + 64 * i + lane;
+        l[i] = y < rows ? rowL[y] : cols;
+        r[i] = y < rows ? rowR[y] : 0;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (l[i] < cols) min_l = min(min_l, l[i]), max_r = max(max_r, r[i]);
     }
 #pragma unroll
     for (int d = 32; d; d >>= 1) {
