@@ -869,9 +869,9 @@ struct YRow {
 //   * REFLECT_101 left / right is folded into per-strip band matrices made on the host (first tile of the first strip,
 //     last two tiles of the last strip), top / bottom into the row addresses.
 // Stages 3-6 run from the tiles (k_tiles_hash2).  Against k_blur_area_regs (blur 5.9 + area 2.75 / 0.7 VALU instructions
-// per pixel): ~2.5 + ~2.2 -- see DESIGN a1.  Preconditions (launcher): whole images or views that keep their parent's
-// width (oy, ph), 7 x 7 blur, fractional ratios, strips of at least 4 cells within 240 columns (w <= 1920), four images'
-// strides below 2^32.
+// per pixel): ~2.5 + ~2.2 -- see DESIGN a1.  Preconditions (launcher): whole images, or views whose vertical edges are
+// the parent's or lie >= 8 (left) / >= 3 (right) columns inside it (oy, ph, ox, inner), 7 x 7 blur, fractional ratios,
+// strips of at least 4 cells within 240 columns (w <= 1920), four images' strides below 2^32.
 struct BaStrip {
   int xs;       // first source column of the strip's first cell
   int T;        // 16-column tiles (<= 15)
@@ -907,9 +907,13 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
                                                   unsigned row_stride, unsigned img_stride, unsigned long long buf_bytes,
                                                   const BaStrip* __restrict__ strips, int n_strips,
                                                   const YRow* __restrict__ yrow, unsigned char* __restrict__ tiles_out,
-                                                  int oy, int ph /* a full-width view: rows oy .. oy + h - 1 of images of ph
-                                                                    rows (letterboxed frames after autocrop; cv::blur takes
+                                                  int oy, int ph /* a view: rows oy .. oy + h - 1 of images of ph rows
+                                                                    (letterboxed frames after autocrop; cv::blur takes
                                                                     its border from the parent); whole images: 0, h */,
+                                                  int ox, int inner /* the view's first column in the parent; bit 0 / 1:
+                                                                       its left / right edge lies inside the parent (a
+                                                                       pillarboxed frame): the blur reads the parent's
+                                                                       pixels there instead of mirroring */,
                                                   BaBands bands) {
   // LDS, sized by T (separate arrays: the compiler must know that they do not alias): ring 4 x 12 rows x kPitch, sT =
   // blurred bytes [image][x], a dword = 4 rows (+ columns for the walk's overhang)
@@ -947,7 +951,7 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
   const unsigned long long left = buf_bytes > base_off ? buf_bytes - base_off : 0ull;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<unsigned char*>(imgs + base_off), 0, (int)(left > 0xffffffffull ? 0xffffffffu : (unsigned)left), 0x27000);
-  const int colA = xs - 8 + 16 * n16;
+  const int colA = ox + xs - 8 + 16 * n16;  // (an inner left edge has ox >= 8: never negative)
   const unsigned voffA = (mine - first) * img_stride + (unsigned)(colA < 0 ? 0 : colA);
   const int wr_base = q * kImg + 16 * n16 + (colA < 0 ? 8 : 0);
   // A-operand role (k_dcthash_256_band): M row n16 = image n16 >> 2, row n16 & 3 of the step; chunk q: 0, 1 the row, 2, 3
@@ -957,8 +961,8 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
   // band matrices: interior, and those of the strip's first and last tile (the image's left edge in the first strip, its
   // right edge in the last -- whose tiles end exactly at column w - 1 -- and the interior band everywhere else)
   const v4i_t b0 = *reinterpret_cast<const v4i_t*>(st.band[0][lane]);
-  const v4i_t bF = *reinterpret_cast<const v4i_t*>(st.band[1][lane]);
-  const v4i_t bL = *reinterpret_cast<const v4i_t*>(st.band[2][lane]);
+  const v4i_t bF = *reinterpret_cast<const v4i_t*>(st.band[(inner & 1) ? 0 : 1][lane]);
+  const v4i_t bL = *reinterpret_cast<const v4i_t*>(st.band[(inner & 2) ? 0 : 2][lane]);
   for (int i = lane; i < 4 * kImg / 16; i += 64) reinterpret_cast<v4u_lds*>(sRing)[i] = v4u_lds{0u, 0u, 0u, 0u};
   for (int i = lane; i < 4 * kTP; i += 64) sT[i] = 0u;
   // virtual row v = 0 .. is row reflect101(oy + ra + v - 5) of the parent; blurred row y = ra + v - 8 is complete with row v
@@ -3742,8 +3746,10 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     const int ipb = T % 64 == 0 ? 1 : 256 / T, block_threads = (ipb * T + 63) / 64 * 64;
     const int pitch = T * 8 + 8;
     const size_t smem = (size_t)ipb * (size_t)(kBlurRB + K_ - 1) * (size_t)pitch;
-    // (whole images, and views that span their parent's width: letterboxed frames -- only the row mapping differs)
-    if (g_hash_band_area && (!view || (vw.ox == 0 && vw.pw == w)) && K_ == 7 && !integer && at.yrow && w >= 64 &&
+    // (views: a vertical edge is the parent's, or lies far enough inside it that the blur's three columns -- and on the left
+    // the staging chunk's eight -- are the parent's pixels: letterboxed and pillarboxed frames after autocrop)
+    const bool ba_view = !view || ((vw.ox == 0 || vw.ox >= 8) && (vw.ox + w == vw.pw || vw.ox + w + 3 <= vw.pw));
+    if (g_hash_band_area && ba_view && K_ == 7 && !integer && at.yrow && w >= 64 &&
         4ull * img_stride < (1ull << 32) && (size_t)vw.ph * row_stride < ((size_t)1 << 32)) {
       BaTabsDev bat;
       if ((rc = get_ba_tabs(w, &bat))) return rc;
@@ -3755,7 +3761,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
         for (size_t i0 = 0; i0 < n; i0 += per_chunk_b) {
           const size_t m = std::min(per_chunk_b, n - i0);
           const unsigned char* src = d_imgs + i0 * img_stride;
-          const unsigned long long bytes = (unsigned long long)(m - 1) * img_stride + (unsigned long long)(vw.ph - 1) * row_stride + (unsigned)w;
+          const unsigned long long bytes = (unsigned long long)(m - 1) * img_stride + (unsigned long long)(vw.ph - 1) * row_stride + (unsigned)vw.pw;
           // row bands: enough waves for ~two rounds of the machine's 2560 slots, at least 4 output rows per band
           BaBands bands;
           bands.n = 1;
@@ -3773,7 +3779,8 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
 #define CBH_BA_(TT, RR)                                                                                                  \
   hipLaunchKernelGGL((k_band_area<TT, RR>), dim3((unsigned)(((m + 3) / 4 + 7) / 8 * 8 * (size_t)bat.n_strips * (size_t)bands.n)), dim3(64), 0, \
                      stream, src, (unsigned)m, w, h, (unsigned)row_stride, (unsigned)img_stride, bytes, bat.strips,      \
-                     bat.n_strips, at.yrow, d_btiles, view ? vw.oy : 0, view ? vw.ph : h, bands)
+                     bat.n_strips, at.yrow, d_btiles, view ? vw.oy : 0, view ? vw.ph : h, view ? vw.ox : 0,                \
+                     view ? (vw.ox > 0 ? 1 : 0) | (vw.ox + w < vw.pw ? 2 : 0) : 0, bands)
 #define CBH_BA(TT)                       \
   case TT:                               \
     if (bat.RS == 4) CBH_BA_(TT, 4);     \

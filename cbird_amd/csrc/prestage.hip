@@ -156,53 +156,85 @@ __global__ __launch_bounds__(256) void k_autocrop_runs(const unsigned char* __re
   if (task >= (phase ? row_tasks + 2 * nchunks : row_tasks)) return;
   const int color = img[0];
   if (task < row_tasks) {
-    // both end segments of all the wave's rows are requested before any of them is looked at: a content row is
-    // settled by that one round trip
     const int y0 = task * kAcRowsPerWave;
     const int xe = (cols - 1) & ~3;  // segment grid anchored at 0; the right scan walks it from the last dword down
-    const int xl = 4 * lane, xr = xe - 4 * lane;
-    unsigned mL[kAcRowsPerWave], mR[kAcRowsPerWave];
-#pragma unroll
-    for (int r = 0; r < kAcRowsPerWave; ++r) {
-      const unsigned char* row = img + (size_t)min(y0 + r, rows - 1) * row_stride;
-      mL[r] = ac_content4(row, xl, cols, color, range);
-      mR[r] = xr >= 0 ? ac_content4(row, xr, cols, color, range) : 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < kAcRowsPerWave; ++r) {
-      const int y = y0 + r;
-      if (y >= rows) break;
-      const unsigned char* row = img + (size_t)y * row_stride;
-      int left = cols, right = 0;  // no content at all: left == cols, right + 1 == 0
-      unsigned m = mL[r];
-      for (int x0 = 0;;) {
+    const int xl = 4 * lane;
+    // The reference's scans of one row, a wave per row, in 256-byte segments: from the left until the first content pixel
+    // (cols: none), from the right until the last (its index + 1).
+    auto scan_left = [&](const unsigned char* row) {
+      for (int x0 = 0; x0 < cols; x0 += 256) {
+        const unsigned m = ac_content4(row, x0 + xl, cols, color, range);
         const unsigned long long b = __ballot(m != 0u);
         if (b) {
           const int fl = __builtin_ctzll(b);
-          left = x0 + 4 * fl + __builtin_ctz(__shfl(m, fl));
-          break;
-        }
-        x0 += 256;
-        if (x0 >= cols) break;
-        m = ac_content4(row, x0 + xl, cols, color, range);
-      }
-      if (left < cols) {
-        m = mR[r];
-        for (int x0 = xe;;) {
-          const unsigned long long b = __ballot(m != 0u);
-          if (b) {
-            const int fl = __builtin_ctzll(b);  // lowest lane = rightmost dword
-            right = x0 - 4 * fl + (31 - __builtin_clz(__shfl(m, fl))) + 1;
-            break;
-          }
-          x0 -= 256;  // (content exists: the scan ends before x0 runs out)
-          const int x = x0 - 4 * lane;
-          m = x >= 0 ? ac_content4(row, x, cols, color, range) : 0u;
+          return x0 + 4 * fl + __builtin_ctz(__shfl(m, fl));
         }
       }
-      if (lane == 0) {
-        rowL[y] = left;
-        rowR[y] = right;
+      return cols;
+    };
+    auto scan_right = [&](const unsigned char* row) {  // (content exists: the scan ends before x0 runs out)
+      for (int x0 = xe;; x0 -= 256) {
+        const int x = x0 - 4 * lane;
+        const unsigned m = x >= 0 ? ac_content4(row, x, cols, color, range) : 0u;
+        const unsigned long long b = __ballot(m != 0u);
+        if (b) {
+          const int fl = __builtin_ctzll(b);  // lowest lane = rightmost dword
+          return x0 - 4 * fl + (31 - __builtin_clz(__shfl(m, fl))) + 1;
+        }
+      }
+    };
+    // First look, all eight rows at once: lane = (row r, end e, chunk j) reads 16 bytes of the row's first (e = 0) or last
+    // (e = 1) 64 -- a content row (nearly every row of a frame without bars, every row between the bars of one with) is
+    // settled by that one load and ~100 instructions for the eight of them; the row-by-row scans above are left to the rows
+    // whose first / last 64 pixels are all border.  pend: bit 8 r + 4 e = that end of row r still wants its scan.
+    unsigned long long pend = 0x1111111111111111ull;
+    const unsigned long long img_bytes = (unsigned long long)(rows - 1) * row_stride + (unsigned)cols;
+    if (cols >= 64 && img_bytes < (1ull << 32)) {
+      const int r = lane >> 3, e = (lane >> 2) & 1, j = lane & 3;
+      const int y = min(y0 + r, rows - 1);
+      const int xq = (e ? cols - 64 : 0) + 16 * j;  // [xq, xq + 16) lies inside the row
+      const __amdgpu_buffer_rsrc_t rsrc =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(img), 0, (int)(unsigned)img_bytes, 0x27000);
+      typedef unsigned ac_v4u __attribute__((ext_vector_type(4)));
+      const ac_v4u v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((unsigned)y * (unsigned)row_stride + (unsigned)xq), 0, 0);
+      unsigned m = 0;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int px = (int)((v[d] >> (8 * k)) & 0xffu);
+          m |= (unsigned)(abs(px - color) > range) << (4 * d + k);
+        }
+      // the group's answer: leftmost content column (e = 0: cols if none) / rightmost + 1 (e = 1: 0 if none)
+      int cand = e ? (m ? xq + 32 - __builtin_clz(m) : 0) : (m ? xq + __builtin_ctz(m) : cols);
+#pragma unroll
+      for (int dlt = 1; dlt <= 2; dlt <<= 1) {
+        const int o = __shfl_xor(cand, dlt);
+        cand = e ? max(cand, o) : min(cand, o);
+      }
+      const bool settled = e ? cand > 0 : cand < cols;
+      const bool owner = j == 0 && y0 + r < rows;
+      if (owner && settled) (e ? rowR : rowL)[y0 + r] = cand;
+      pend = __ballot(owner && !settled);
+    } else {
+      if (y0 + kAcRowsPerWave > rows) pend &= (1ull << (8 * (rows - y0))) - 1ull;
+    }
+    while (pend) {  // (uniform)
+      const int r = __builtin_ctzll(pend) >> 3;
+      const bool need_l = (pend >> (8 * r)) & 1ull, need_r = (pend >> (8 * r + 4)) & 1ull;
+      pend &= ~(0xffull << (8 * r));
+      const int y = y0 + r;
+      const unsigned char* row = img + (size_t)y * row_stride;
+      int left = 0;  // (need_r alone: the first look found content from the left)
+      if (need_l) {
+        left = scan_left(row);
+        if (lane == 0) rowL[y] = left;
+      }
+      if (left >= cols) {  // no content at all: left == cols, right + 1 == 0
+        if (lane == 0) rowR[y] = 0;
+      } else if (need_r) {
+        const int right = scan_right(row);
+        if (lane == 0) rowR[y] = right;
       }
     }
     return;
