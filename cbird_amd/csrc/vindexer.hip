@@ -29,8 +29,8 @@ struct cbh_vindexer {
   uint64_t* d_out = nullptr;
   int* d_rects = nullptr;
   size_t n_cap = 0;
-  std::vector<int> h_rects;
-  std::vector<uint64_t> h_hashes;
+  int* h_rects = nullptr;        // pinned: the two copies back are enqueued behind the kernels and waited for ONCE
+  uint64_t* h_hashes = nullptr;  // (into pageable memory each copy is its own blocking round trip)
   // makeVideoIndex's locals
   std::vector<int32_t> frames;
   std::vector<uint64_t> hashes;
@@ -49,12 +49,14 @@ int ensure(cbh_vindexer* v, size_t n) {
   if (n <= v->n_cap) return CBH_OK;
   if (v->d_out) (void)hipFree(v->d_out);
   if (v->d_rects) (void)hipFree(v->d_rects);
-  v->d_out = nullptr, v->d_rects = nullptr, v->n_cap = 0;
+  if (v->h_rects) (void)hipHostFree(v->h_rects);
+  if (v->h_hashes) (void)hipHostFree(v->h_hashes);
+  v->d_out = nullptr, v->d_rects = nullptr, v->h_rects = nullptr, v->h_hashes = nullptr, v->n_cap = 0;
   CBH_HIP(hipMalloc(&v->d_out, n * sizeof(uint64_t)));
   CBH_HIP(hipMalloc(&v->d_rects, n * 4 * sizeof(int)));
+  CBH_HIP(hipHostMalloc((void**)&v->h_rects, n * 4 * sizeof(int), hipHostMallocDefault));
+  CBH_HIP(hipHostMalloc((void**)&v->h_hashes, n * sizeof(uint64_t), hipHostMallocDefault));
   v->n_cap = n;
-  v->h_rects.resize(n * 4);
-  v->h_hashes.resize(n);
   return CBH_OK;
 }
 
@@ -108,7 +110,7 @@ int hash_chunk(cbh_vindexer* v, const uint8_t* d_gray, size_t m, int w, int h, s
   int rc = ensure(v, m);
   if (rc) return rc;
   hipStream_t s = v->s;
-  int* hr = v->h_rects.data();
+  int* hr = v->h_rects;
   const bool crop = v->autocrop >= 0;
   int spec[4] = {0, 0, w, h};
   if (crop && !(v->spec_w == w && v->spec_h == h) && m > 8) {
@@ -133,7 +135,7 @@ int hash_chunk(cbh_vindexer* v, const uint8_t* d_gray, size_t m, int w, int h, s
   rc = launch(0, m, spec, v->d_out);
   if (rc) return rc;
   if (crop) CBH_HIP(hipMemcpyAsync(hr, v->d_rects, m * 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-  CBH_HIP(hipMemcpyAsync(v->h_hashes.data(), v->d_out, m * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  CBH_HIP(hipMemcpyAsync(v->h_hashes, v->d_out, m * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
   CBH_HIP(hipStreamSynchronize(s));
   if (!crop) return CBH_OK;
   bool again = false;
@@ -144,7 +146,7 @@ int hash_chunk(cbh_vindexer* v, const uint8_t* d_gray, size_t m, int w, int h, s
     if (!memcmp(r, spec, sizeof spec)) continue;
     rc = launch(i, run, r, v->d_out + i);
     if (rc) return rc;
-    CBH_HIP(hipMemcpyAsync(v->h_hashes.data() + i, v->d_out + i, run * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    CBH_HIP(hipMemcpyAsync(v->h_hashes + i, v->d_out + i, run * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     again = true;
   }
   if (again) CBH_HIP(hipStreamSynchronize(s));
@@ -186,6 +188,8 @@ void cbh_vindexer_destroy(cbh_vindexer* v) {
   if (v->s) cbh::stream_destroy(v->s);
   for (void* p : {(void*)v->d_src, (void*)v->d_out, (void*)v->d_rects})
     if (p) (void)hipFree(p);
+  if (v->h_rects) (void)hipHostFree(v->h_rects);
+  if (v->h_hashes) (void)hipHostFree(v->h_hashes);
   delete v;
 }
 
