@@ -728,7 +728,9 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *                   0 = k_dcthash_256 (all VALU)
  *   "hash_band_area" general geometry with fractional resize ratios: 1 (default) = widths up to 1920 columns (strips of >= 4
  *                   output cells within 240 columns) take k_band_area -- the 256x256 kernel's matrix-core blur for any width
- *                   and height, up to four rows of a step per INTER_AREA walk; 0 = k_blur_area_regs & co. as through round 4.
+ *                   and height, up to four rows of a step per INTER_AREA walk (whole images, and views whose vertical edges
+ *                   are the parent's or lie >= 8 / >= 3 columns inside it: letterboxed and pillarboxed frames after autocrop;
+ *                   small batches are split into up to 8 row bands per strip); 0 = k_blur_area_regs & co. as through round 4.
  *                   Bit-identical either way
  *   "hash_band_waves" waves per workgroup of k_dcthash_256_band: 1 (default: a wave owns its four images alone, no
  *                   barriers, 9 waves per CU) or 2 (two waves share four images' rows and tiles in LDS, 14 waves per CU;
