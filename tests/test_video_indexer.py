@@ -256,3 +256,28 @@ def test_indexers_on_worker_threads_are_independent(vo, po):
         got = list(ex.map(run, range(4)))
     for k in range(4):
         assert got[k].frames == want[k][0].tolist() and got[k].hashes == [int(x) for x in want[k][1]], k
+
+
+@pytest.mark.gpu
+def test_indexer_when_the_kept_region_changes_inside_a_clip(vo, po):
+    """the hash launch of a chunk speculates on the region the previous chunk ended on (the first chunk: on the region of
+    one of its middle frames) and hashes again only the frames whose rectangle came out different (vindexer.hip,
+    hash_chunk): a clip that fades in from black (nothing to crop), is letterboxed, switches to pillarbox with a logo in a
+    bar and ends without bars must give the oracle's index for any chunking"""
+    from cbird_amd.video import VideoIndexer
+
+    h, w = 216, 384
+    parts = [clip(31, 5, h, w, (0, 0, 0, 0)), clip(32, 23, h, w, (28, 28, 0, 0)), clip(33, 19, h, w, (0, 0, 48, 48)),
+             clip(34, 9, h, w, (28, 28, 0, 0)), clip(35, 11, h, w, (0, 0, 0, 0))]
+    parts[0][:] = 16  # black lead-in: every pixel is border
+    parts[2][:, h // 2, 10] = 200  # a logo pixel inside the left bar
+    frames = np.concatenate(parts)
+    rects = {tuple(po.autocrop(f).tolist()) for f in frames}
+    assert len(rects) >= 3  # whole frame, letterbox, pillarbox
+    (wf, wh), _ = oracle_index(po, vo, frames, 8)
+    for chunk in (1, 9, 16, 40, len(frames)):
+        ix = VideoIndexer(threshold=8)
+        for i in range(0, len(frames), chunk):
+            ix.push(frames[i:i + chunk])
+        got = ix.finish()
+        assert got.frames == wf.tolist() and got.hashes == [int(x) for x in wh], chunk
