@@ -27,7 +27,8 @@ def main():
 
     dev = torch.device("cuda", 0)
     geos = ((1920, 1080, 0, 0), (1920, 1080, 140, 0), (1920, 1080, 0, 240), (1280, 720, 0, 0),
-                              (1280, 720, 90, 0), (1280, 720, 0, 160), (640, 360, 0, 0), (640, 360, 45, 0), (256, 256, 0, 0))
+                              (1280, 720, 90, 0), (1280, 720, 0, 160), (640, 360, 0, 0), (640, 360, 45, 0), (256, 256, 0, 0),
+            (128, 72, 0, 0), (128, 72, 9, 0))  # (cbird's own decode size: maxW = maxH = 128, src/scanner.cpp:1043-1048)
     if args.only:
         geos = (tuple(int(x) for x in args.only.split(",")),)
     for (w, h, bar, side) in geos:
