@@ -138,6 +138,7 @@ void set_scan_mfma_ht(int ht);
 void set_scan_mfma_g(int g);
 int get_scan_pre_max();         // thresholds <= this run the prefilter kernel at present (0: none)
 void set_scan_pre_max(int t);   // thresholds <= t take the 32-bit prefilter kernel
+void set_scan_mfma_chunk(int v); // needle-tile pairs (PRE) / triples x 2/3 (FULL3) per workgroup chunk; 0 = 512 / 172
 void set_scan_pre_fold(int v);  // prefilter word: 1 = lo ^ hi, 0 = lo
 void set_scan_pre_lean(int v);  // 1 = single candidates re-checked on the scalar unit
 void set_scan_mfma_full3(int on);  // three-needle-tile accumulator variant for thresholds > 4

@@ -1441,6 +1441,10 @@ int cbh_set_tuning(const char* key, int value) {
     set_scan_pre_max(value);
     return CBH_OK;
   }
+  if (!strcmp(key, "scan_mfma_chunk")) {
+    set_scan_mfma_chunk(value);
+    return CBH_OK;
+  }
   if (!strcmp(key, "scan_pre_fold")) {
     set_scan_pre_fold(value);
     return CBH_OK;

@@ -693,6 +693,11 @@ int get_scan_pre_max() { return g_mfma_pre == 1 ? g_pre_max_thresh : g_mfma_pre 
 void set_scan_pre_max(int t) {
   if (t >= 0 && t <= 32) g_pre_max_thresh = t;
 }
+int g_mfma_chunk = 0;  // "scan_mfma_chunk": needle-tile pairs per workgroup chunk (0 = 512 for the prefilter kernel, 256 for
+                       // the others; the three-field kernel takes 2/3 of it in triples, 0 = 172)
+void set_scan_mfma_chunk(int v) {
+  if (v == 0 || (v >= 16 && v <= 4096 && v % 2 == 0)) g_mfma_chunk = v;
+}
 void set_scan_pre_fold(int v) {
   if (v >= 0) g_pre_fold = v != 0;
 }
@@ -731,7 +736,10 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
   const uint32_t wgs = (uint32_t)((n + rows_per_wg - 1) / rows_per_wg);
   // needle chunk: >= 8192 workgroups in flight when there is that much work, but each wave
   // amortises its tile expansion over >= 16 needle-tile pairs
-  uint32_t ppc = 256;  // 16384 needles
+  // (prefilter: 512 pairs = 32768 needles per chunk -- a wave drains its pending candidates at the end of its chunk, mostly a
+  // short list: at threshold 6 chunks of 512 / 1024 pairs run 12.63 ms against 12.98 with 256 and 13.35 with 64; the full
+  // kernel is best at 172 triples: 16.05 against 16.25-16.3 with 2-4x that; tools/ab/scan_chunk_ab.py)
+  uint32_t ppc = g_mfma_chunk ? (uint32_t)g_mfma_chunk : (thresh <= g_pre_max_thresh && g_mfma_pre == 1 ? 512u : 256u);
   while (ppc > 16 && (uint64_t)wgs * ((n_pairs + ppc - 1) / ppc) < 8192) ppc >>= 1;
   uint32_t chunks = (n_pairs + ppc - 1) / ppc;
   if (chunks > 65535) {
@@ -741,7 +749,7 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
   // (2 = experiments: the prefilter variant for any threshold it can represent)
   const bool pre = (g_mfma_pre == 1 && thresh <= g_pre_max_thresh) || (g_mfma_pre == 2 && thresh <= 32);
   if (!pre && g_mfma_full3 && thresh <= 64 && ht == 8) {
-    uint32_t tpc = 172;  // ~16512 needles per chunk
+    uint32_t tpc = g_mfma_chunk ? (uint32_t)(g_mfma_chunk * 2 + 2) / 3u : 172u;  // ~16512 needles per chunk
     while (tpc > 11 && (uint64_t)wgs * ((n_triples + tpc - 1) / tpc) < 8192) tpc = (tpc + 1) / 2;
     uint32_t ch3 = (n_triples + tpc - 1) / tpc;
     if (ch3 > 65535) {

@@ -709,6 +709,9 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *   "scan_mfma_pre" 1 = thresholds <= "scan_mfma_pre_max" use the 32-bit prefilter variant of k_hamm64_mfma (default 1),
  *                   0 = never, 2 = for every threshold <= 32 (experiments)
  *   "scan_mfma_pre_max" the largest threshold that takes the prefilter variant (default 6; rounds 1-4: 4)
+ *   "scan_mfma_chunk" needle-tile pairs one workgroup of the 64-bit scan kernels streams (even, 16..4096); 0 (default) =
+ *                   512 for the prefilter kernel (32768 needles: fewer end-of-chunk drains of a short candidate list),
+ *                   256 for the others, 172 triples for the three-field kernel; halved while the grid would be < 8192
  *   "scan_pre_fold" 1 = the prefilter compares lo ^ hi of the hashes (default: a lower bound on the distance that sees
  *                   all 64 bits), 0 = the low words (rounds 1-4)
  *   "scan_pre_lean" 1 = prefilter candidates confined to a few lanes are parked, listed and re-checked 64 at a time
