@@ -347,9 +347,12 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
 
   uint32_t npend = 0;  // PRE lean path: descriptors waiting in s_queue (wave-uniform)
   // one descriptor per lane: the flagged fields of a parked register against all 64 bits
-  auto drain = [&]() {
+  // (whole passes of 64 only -- the newest descriptors; the < 64 oldest wait for company, and for the chunk's end: a pass
+  // costs its global-memory round trip whether one lane works in it or all of them)
+  auto drain = [&](bool all) {
     wave_order();
-    for (uint32_t k = lane; k < npend; k += 64u) {
+    const uint32_t keep = all ? 0u : (npend & 63u);
+    for (uint32_t k = keep + lane; k < npend; k += 64u) {
       const uint32_t bits = s_queue[2u * k], w1 = s_queue[2u * k + 1u];
       const uint32_t g = w1 & 15u, tile = (w1 >> 4) & 7u, L = (w1 >> 7) & 63u, pp = p0 + 2u * (w1 >> 13);
       const uint32_t rit = (g & 3u) + 8u * (g >> 2) + 4u * (L >> 5);  // C/D layout, see handle_tile
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
       }
     }
     wave_order();
-    npend = 0;
+    npend = keep;
   };
 
   // one needle-tile pair against the HT resident haystack tiles
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
                 npend += (uint32_t)__popc(bm);
               }
               wave_order();
-              if (npend >= 64u) drain();
+              if (npend >= 64u) drain(false);
             } while (rest);
           } else {
 #pragma unroll
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
         step(p0 + rel + 2, b0, b1);
       }
     }
-    if (npend) drain();
+    if (npend) drain(true);
   } else {
     // two pairs per trip with explicit double buffers: the loads of the next pair are in flight
     // while the 2*HT MFMAs of the current one run
