@@ -397,18 +397,23 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
         // flag bits survive OR: v_or3_b32 takes two more registers per op (plain VGPR-only ops, cheaper to issue than
         // the packed max); two chains of 8 ops
         constexpr int R = G * 16;
-        const uint32_t flags = (or_regs<0, R / 2, G>(c) | or_regs<R / 2, R, G>(c)) & kFlagMaskPre;
+        // (two chains of 17 and 15 registers: 8 + 7 v_or3_b32; 16 + 16 would take 8 + 8)
+        constexpr int RA = R / 2 + 1;
+        const uint32_t half0 = or_regs<0, RA, G>(c), half1 = or_regs<RA, R, G>(c);
+        const uint32_t flags = (half0 | half1) & kFlagMaskPre;
         const uint64_t hm = __builtin_amdgcn_ballot_w64(flags != 0);
         if (hm != 0) {
           // wave-uniform from here: some lane holds a candidate (one group in ~10 at threshold 5, every other at 6)
           if constexpr (LEAN && R <= 32) {
+            auto park4 = [&](uint32_t at, int t, int k) {  // registers 16 t + 4 k .. + 3 of the lane: one ds_write_b128
+              *reinterpret_cast<float4*>(&s_queue[at + (uint32_t)(t * 16 + 4 * k)]) =
+                  make_float4(c[t][4 * k], c[t][4 * k + 1], c[t][4 * k + 2], c[t][4 * k + 3]);
+            };
             auto park = [&](uint32_t at) {
 #pragma unroll
               for (int t = 0; t < G; ++t)
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                  *reinterpret_cast<float4*>(&s_queue[at + (uint32_t)(t * 16 + 4 * k)]) =
-                      make_float4(c[t][4 * k], c[t][4 * k + 1], c[t][4 * k + 2], c[t][4 * k + 3]);
+                for (int k = 0; k < 4; ++k) park4(at, t, k);
             };
             constexpr uint64_t kLow = R >= 32 ? 0xffffffffull : ((1ull << (R & 31)) - 1ull);  // lane r < R <-> register r
             const uint32_t w1c = ((uint32_t)t0 << 4) | (((p - p0) >> 1) << 13);  // tile of register 0, step
@@ -422,8 +427,29 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
                 cm = rest ^ rem;  // the lowest kParkLanes hit lanes
               }
               rest ^= cm;
+              uint32_t parked = 0xffffffffu;  // registers (= lanes of the read-back) whose parking slot was written
               if ((cm & (cm - 1)) == 0 && cm == hm) {  // one hit lane (nine events in ten): a fixed address
-                if (flags != 0) park(kPark);
+                if constexpr (G == 2) {
+                  // ... and nearly always one flagged register: only the registers of the reduction chain(s) that hold a
+                  // flag are parked -- 0..16 (five ds_write_b128) or 17..31 (four) instead of all eight; a ds_write_b128
+                  // moves 1 KB whatever its exec mask
+                  const bool p0_ = __builtin_amdgcn_ballot_w64((half0 & kFlagMaskPre) != 0) != 0;
+                  const bool p1_ = __builtin_amdgcn_ballot_w64((half1 & kFlagMaskPre) != 0) != 0;
+                  if (flags != 0) {
+                    if (p0_) {
+#pragma unroll
+                      for (int k = 0; k < 4; ++k) park4(kPark, 0, k);
+                    }
+                    if (p0_ || p1_) park4(kPark, 1, 0);
+                    if (p1_) {
+#pragma unroll
+                      for (int k = 1; k < 4; ++k) park4(kPark, 1, k);
+                    }
+                  }
+                  parked = (p0_ ? 0x000fffffu : 0u) | (p1_ ? 0xffff0000u : 0u);
+                } else {
+                  if (flags != 0) park(kPark);
+                }
               } else if ((cm >> lane) & 1ull) {  // the k-th hit lane of the chunk parks at kPark + 32 k
                 park(kPark + 32u * __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u)));
               }
@@ -434,8 +460,8 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
                 // words behind the wave's queue: inside the workgroup's LDS, and discarded by kLow / lane < R)
                 const uint32_t v = s_queue[at + lane];
                 const bool pred = (v & kFlagMaskPre) != 0;
-                const uint32_t bm = (uint32_t)(__builtin_amdgcn_ballot_w64(pred) & kLow);
-                if (pred && lane < (uint32_t)R) {
+                const uint32_t bm = (uint32_t)(__builtin_amdgcn_ballot_w64(pred) & kLow) & parked;
+                if (pred && lane < (uint32_t)R && ((parked >> lane) & 1u)) {
                   // lane = 16 t + g: bits 0-3 the register, bits 4-6 (t0 + t) the wave's tile; bits 7-12 the hit lane
                   *reinterpret_cast<uint2*>(&s_queue[2u * (npend + __builtin_amdgcn_mbcnt_lo(bm, 0u))]) =
                       make_uint2(v, lane | (w1c | ((uint32_t)__builtin_ctzll(m) << 7)));
