@@ -417,60 +417,69 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
             };
             constexpr uint64_t kLow = R >= 32 ? 0xffffffffull : ((1ull << (R & 31)) - 1ull);  // lane r < R <-> register r
             const uint32_t w1c = ((uint32_t)t0 << 4) | (((p - p0) >> 1) << 13);  // tile of register 0, step
-            // hit lanes in chunks of kParkLanes (one chunk unless the group is dense: duplicates, video frames)
-            uint64_t rest = hm;
-            do {
-              uint64_t cm = rest;
-              if ((uint32_t)__popcll(rest) > kParkLanes) {
-                uint64_t rem = rest;
-                for (uint32_t i = 0; i < kParkLanes; ++i) rem &= rem - 1;
-                cm = rest ^ rem;  // the lowest kParkLanes hit lanes
+            // lane r < R reads register r of a hit lane back (the lanes above read on into the next slot, or the first words
+            // behind the wave's queue: inside the workgroup's LDS, and discarded by kLow / lane < R); `ok` = the registers
+            // whose parking slot was written.  Appends {pattern, register | tile | hit lane | step} for every flagged one.
+            auto list = [&](uint32_t at, uint32_t L, uint32_t ok) {
+              const uint32_t v = s_queue[at + lane];
+              const bool pred = (v & kFlagMaskPre) != 0 && ((ok >> (lane & 31u)) & 1u) != 0u;
+              const uint32_t bm = (uint32_t)(__builtin_amdgcn_ballot_w64(pred) & kLow);
+              if (pred && lane < (uint32_t)R) {
+                // lane = 16 t + g: bits 0-3 the register, bits 4-6 (t0 + t) the wave's tile; bits 7-12 the hit lane
+                *reinterpret_cast<uint2*>(&s_queue[2u * (npend + __builtin_amdgcn_mbcnt_lo(bm, 0u))]) =
+                    make_uint2(v, lane | (w1c | (L << 7)));
               }
-              rest ^= cm;
-              uint32_t parked = 0xffffffffu;  // registers (= lanes of the read-back) whose parking slot was written
-              if ((cm & (cm - 1)) == 0 && cm == hm) {  // one hit lane (nine events in ten): a fixed address
-                if constexpr (G == 2) {
-                  // ... and nearly always one flagged register: only the registers of the reduction chain(s) that hold a
-                  // flag are parked -- 0..16 (five ds_write_b128) or 17..31 (four) instead of all eight; a ds_write_b128
-                  // moves 1 KB whatever its exec mask
-                  const bool p0_ = __builtin_amdgcn_ballot_w64((half0 & kFlagMaskPre) != 0) != 0;
-                  const bool p1_ = __builtin_amdgcn_ballot_w64((half1 & kFlagMaskPre) != 0) != 0;
-                  if (flags != 0) {
-                    if (p0_) {
+              npend += (uint32_t)__popc(bm);
+            };
+            if ((hm & (hm - 1)) == 0) {
+              // ONE hit lane (nine events in ten), a fixed address -- and nearly always one flagged register: only the
+              // registers of the reduction chain(s) that hold a flag are parked -- 0..16 (five ds_write_b128) or 17..31
+              // (four) instead of all eight; a ds_write_b128 moves 1 KB whatever its exec mask.  (Masks, not bools: a
+              // uniform bool comes back as v_cndmask + v_cmp.)
+              uint32_t ok = 0xffffffffu;
+              if constexpr (G == 2) {
+                const uint64_t b0 = __builtin_amdgcn_ballot_w64((half0 & kFlagMaskPre) != 0);
+                const uint64_t b1 = __builtin_amdgcn_ballot_w64((half1 & kFlagMaskPre) != 0);
+                if (flags != 0) {
+                  if (b0) {
 #pragma unroll
-                      for (int k = 0; k < 4; ++k) park4(kPark, 0, k);
-                    }
-                    if (p0_ || p1_) park4(kPark, 1, 0);
-                    if (p1_) {
-#pragma unroll
-                      for (int k = 1; k < 4; ++k) park4(kPark, 1, k);
-                    }
+                    for (int k = 0; k < 4; ++k) park4(kPark, 0, k);
                   }
-                  parked = (p0_ ? 0x000fffffu : 0u) | (p1_ ? 0xffff0000u : 0u);
-                } else {
-                  if (flags != 0) park(kPark);
+                  park4(kPark, 1, 0);
+                  if (b1) {
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) park4(kPark, 1, k);
+                  }
                 }
-              } else if ((cm >> lane) & 1ull) {  // the k-th hit lane of the chunk parks at kPark + 32 k
-                park(kPark + 32u * __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u)));
+                ok = (b0 ? 0x000fffffu : 0u) | (b1 ? 0xffff0000u : 0u);
+              } else {
+                if (flags != 0) park(kPark);
               }
               wave_order();
-              uint32_t at = kPark;
-              for (uint64_t m = cm; m; m &= m - 1, at += 32u) {
-                // lane r < R: register r of the hit lane (the lanes above read on into the next slot, or the first
-                // words behind the wave's queue: inside the workgroup's LDS, and discarded by kLow / lane < R)
-                const uint32_t v = s_queue[at + lane];
-                const bool pred = (v & kFlagMaskPre) != 0;
-                const uint32_t bm = (uint32_t)(__builtin_amdgcn_ballot_w64(pred) & kLow) & parked;
-                if (pred && lane < (uint32_t)R && ((parked >> lane) & 1u)) {
-                  // lane = 16 t + g: bits 0-3 the register, bits 4-6 (t0 + t) the wave's tile; bits 7-12 the hit lane
-                  *reinterpret_cast<uint2*>(&s_queue[2u * (npend + __builtin_amdgcn_mbcnt_lo(bm, 0u))]) =
-                      make_uint2(v, lane | (w1c | ((uint32_t)__builtin_ctzll(m) << 7)));
-                }
-                npend += (uint32_t)__popc(bm);
-              }
+              list(kPark, (uint32_t)__builtin_ctzll(hm), ok);
               wave_order();
               if (npend >= 64u) drain(false);
-            } while (rest);
+            } else {
+              // several hit lanes, in chunks of kParkLanes (one chunk unless the group is dense: duplicates, video frames);
+              // the k-th hit lane of a chunk parks all its registers at kPark + 32 k
+              uint64_t rest = hm;
+              do {
+                uint64_t cm = rest;
+                if ((uint32_t)__popcll(rest) > kParkLanes) {
+                  uint64_t rem = rest;
+                  for (uint32_t i = 0; i < kParkLanes; ++i) rem &= rem - 1;
+                  cm = rest ^ rem;  // the lowest kParkLanes hit lanes
+                }
+                rest ^= cm;
+                if ((cm >> lane) & 1ull)
+                  park(kPark + 32u * __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u)));
+                wave_order();
+                uint32_t at = kPark;
+                for (uint64_t m = cm; m; m &= m - 1, at += 32u) list(at, (uint32_t)__builtin_ctzll(m), 0xffffffffu);
+                wave_order();
+                if (npend >= 64u) drain(false);
+              } while (rest);
+            }
           } else {
 #pragma unroll
             for (int t = 0; t < G; ++t)
