@@ -21,8 +21,15 @@
 #include <utility>
 #include <vector>
 
+// Q_ASSERT / qInfo (vptree.h:74,121-234) are Qt's own when Qt headers exist (oracle/Makefile passes -DCBIRD_REF_QT and
+// links Qt5Core: this image's conda Qt 5.9.7); only a build without any Qt falls back to the two stand-ins below, which
+// touch no arithmetic.
+#ifdef CBIRD_REF_QT
+#include <QtCore/QtGlobal>
+#else
 #define Q_ASSERT(x) assert(x)
 #define qInfo printf
+#endif
 
 #include "hamm.h"         // -I/root/reference/src
 #include "tree/vptree.h"  // -I/root/reference/src

@@ -5,8 +5,8 @@
 //   src/tree/hammingtree.h:51-564  HammingTree_t<uint32_t>  (DctFeaturesIndex, src/dctfeaturesindex.h:28)
 //   src/tree/radix.h:36-231        RadixMap_t<index_t>      (DctVideoIndex)
 // They need a handful of Qt names; the build container has a conda Qt 5.9.7 (headers under
-// /opt/conda/include/qt), which lacks Q_DISABLE_COPY_MOVE (5.13+) -- shimmed here together with the
-// three names hammingtree.h/radix.h take from src/global.h:58-66.
+// /opt/conda/include/qt), which lacks Q_DISABLE_COPY_MOVE (5.13+) -- the one shim here; the
+// three names hammingtree.h/radix.h take from src/global.h:58-66 come from that header itself.
 // The index classes themselves (QtSql, Media, OpenCV types) cannot be compiled; the voting logic of
 // DctFeaturesIndex::find (src/dctfeaturesindex.cpp:285-358) is restated in ref_fdct_find below on
 // top of the real tree's candidates.
@@ -22,16 +22,17 @@
 #include <map>
 #include <vector>
 
+// Qt 5.9.7 (this image's conda Qt) predates Q_DISABLE_COPY_MOVE (5.13); the only stand-in in this file.  Everything else
+// the two headers need -- strict_malloc / strict_realloc / dcthash_t -- comes from the reference's own src/global.h,
+// included in place (its Qt6-only `qq` macro is never expanded, so it compiles under Qt5).
 #ifndef Q_DISABLE_COPY_MOVE
 #define Q_DISABLE_COPY_MOVE(Class) \
   Q_DISABLE_COPY(Class)            \
   Class(Class&&) = delete;         \
   Class& operator=(Class&&) = delete;
 #endif
-#define strict_malloc(ptr, count) reinterpret_cast<decltype(ptr)>(malloc(uint(count) * sizeof(*ptr)))
-#define strict_realloc(ptr, count) reinterpret_cast<decltype(ptr)>(realloc(ptr, uint(count) * sizeof(*ptr)))
-typedef uint64_t dcthash_t;
 
+#include "global.h"            // -I/root/reference/src (src/global.h:52-66)
 #include "tree/hammingtree.h"  // -I/root/reference/src
 #include "tree/radix.h"
 

@@ -396,3 +396,82 @@ def test_gpu_radix_compatible_mode_equals_bucket_search(gpu, vorc, reduce_path):
             got = [(x.mediaId, x.score, x.range.srcIn, x.range.dstIn, x.range.len) for x in idx.findFrame(m, p)]
             assert got == vorc.find_frame(entries, m.dctHash, 7, -1, radix=radix), (m.id, radix)
     assert exact_more > 0
+
+
+# ---- fixture pin of a7: the real RadixMap's answers, committed (tests/golden/gen_golden_radix.py) --------------------
+def _radix_golden():
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "radixmap_r0_r10.npz"))
+    offs = g["clip_offs"]
+    clips = [(g["frames"][a:b], g["hashes"][a:b]) for a, b in zip(offs[:-1], offs[1:])]
+    return g, clips
+
+
+def _golden_rows(g, key, qi):
+    a, b = g[key + "_offs"][qi], g[key + "_offs"][qi + 1]
+    return [tuple(int(x) for x in r) for r in g[key][a:b]]
+
+
+def test_oracle_equals_radixmap_golden(vorc):
+    """the oracle's bucket rule + findFrame reduction against the real RadixMap's committed answers (radix 0 and 10) --
+    the same pin as test_oracle_candidates_vs_real_radixmap, but from a fixture, so it also holds where
+    oracle/_ref/libcbird_ref_qt.so cannot be loaded"""
+    g, clips = _radix_golden()
+    videos = [(int(m), f, h) for m, (f, h) in zip(g["media_ids"], clips)]
+    entries = vorc.build_entries(videos, skip=0)
+    ev, ef, eh, _ = entries
+    assert len(eh) == len(g["hashes"])  # no hash is dropped by the insert filter: the golden's entry list is every frame
+    n_rows = 0
+    for radix in g["radixes"].tolist():
+        for thr in g["thresholds"].tolist():
+            key = f"r{radix}_t{thr}"
+            for qi, q in enumerate(g["needles"].tolist()):
+                want = [(m, d, 0, f, 1) for m, d, f in _golden_rows(g, key + "_frame", qi)]
+                assert vorc.find_frame(entries, q, thr, -1, radix=radix) == want, (key, qi)
+                n_rows += len(want)
+                # the raw matches: RadixMap::indexOf (radix.h:135-141) + hamm64 < threshold, restated in numpy
+                mask = np.uint64((1 << radix) - 1)
+                same = ((eh >> np.uint64(1)) & mask) == ((np.uint64(q) >> np.uint64(1)) & mask)
+                d = np.array([bin(int(x) ^ q).count("1") for x in eh[same]], np.int64)
+                hit = d < thr
+                got = sorted(zip(ev[same][hit].tolist(), ef[same][hit].tolist(), d[hit].tolist()))
+                assert got == _golden_rows(g, key + "_raw", qi), (key, qi)
+    assert n_rows > 500
+    # radix 10 must actually hide matches that radix 0 finds, or the fixture pins nothing about buckets
+    assert len(g["r10_t6_raw"]) < len(g["r0_t6_raw"])
+
+
+@pytest.mark.gpu
+def test_gpu_find_frame_equals_radixmap_golden(gpu, reduce_path):
+    """a7 on the GPU box without any checker library: DctVideoIndex(radix_compat) findFrame == the real RadixMap's
+    committed answers, radix 0 (exact: also the default index) and radix 10"""
+    from cbird_amd.video import DctVideoIndex, VideoIndex, VideoSearchParams
+
+    g, clips = _radix_golden()
+
+    class M:
+        pass
+
+    media = []
+    for mid, (f, h) in zip(g["media_ids"].tolist(), clips):
+        m = M()
+        m.id, m.path, m.videoIndex, m.dctHash = mid, f"v{mid}", VideoIndex(f.tolist(), [int(x) for x in h]), 0
+        media.append(m)
+    needle = M()
+    needle.id, needle.path, needle.videoIndex = 1, "needle", VideoIndex([], [])
+    n_rows = 0
+    for radix in g["radixes"].tolist():
+        for compat in ((True, False) if radix == 0 else (True,)):
+            idx = DctVideoIndex(radix_compat=compat)
+            idx.add(media)
+            for thr in g["thresholds"].tolist():
+                p = VideoSearchParams(dctThresh=thr, skipFrames=0, minFramesMatched=1, minFramesNear=1, videoRadix=radix)
+                key = f"r{radix}_t{thr}_frame"
+                for qi, q in enumerate(g["needles"].tolist()):
+                    needle.dctHash = q
+                    got = [(x.mediaId, x.score, x.range.srcIn, x.range.dstIn, x.range.len) for x in idx.findFrame(needle, p)]
+                    want = [(m, d, 0, f, 1) for m, d, f in _golden_rows(g, key, qi)]
+                    assert got == want, (radix, compat, thr, qi)
+                    n_rows += len(want)
+    assert n_rows > 700
