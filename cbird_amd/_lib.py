@@ -164,6 +164,7 @@ _SIGS = {
     "cbh_vidx_add_video": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _sz]),
     "cbh_vidx_remove": (C.c_int, [_vp, _vp, _sz]),
     "cbh_vidx_count": (_sz, [_vp]),
+    "cbh_vidx_memory_usage": (_sz, [_vp]),
     "cbh_vidx_entries": (_sz, [_vp, C.c_int]),
     "cbh_vidx_find_frame": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_int, C.c_int, _vp, _sz, C.POINTER(_sz)]),
     "cbh_vidx_find_video": (C.c_int, [_vp, _vp, _vp, _sz, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -373,6 +373,10 @@ class GpuDctVideoIndex : public DctVideoIndex {
   ~GpuDctVideoIndex() override { cbh_vidx_destroy(_idx); }
   bool isLoaded() const override { return _loaded; }
   int count() const override { return int(cbh_vidx_count(_idx)); }
+  // memoryUsage() (dctvideoindex.cpp:57-59: `_tree ? _tree->stats().memory : 0`): the inherited one would report the
+  // reference's own, never-built, tree -- 0 for ever
+  size_t memoryUsage() const override { return cbh_vidx_memory_usage(_idx); }
+  void save(QSqlDatabase&, const QString&) override {}  // nothing to cache, like the reference (dctvideoindex.cpp:213-216)
   // load(): `select id from media where type=video order by id` (dctvideoindex.cpp:172-211); each id's
   // <dataPath>/<id>.vdx is read with cbird's own VideoIndex::load and handed over
   void load(QSqlDatabase& db, const QString&, const QString& dataPath) override {

@@ -350,6 +350,13 @@ int cbh_vidx_remove(cbh_vidx* v, const uint32_t* media_ids, size_t n) {
 
 size_t cbh_vidx_count(const cbh_vidx* v) { return v ? v->videos.size() : 0; }  // _mediaId.size() (:55-59)
 
+// memoryUsage() (:57-59): nothing before buildTree; then 8 + 6 bytes per entry (hash_t + packed VideoTreeIndex)
+size_t cbh_vidx_memory_usage(const cbh_vidx* v) {
+  if (!v) return 0;
+  std::lock_guard<std::mutex> lk(const_cast<cbh_vidx*>(v)->build_mu);
+  return v->built ? v->evidx.size() * 14u : 0;
+}
+
 size_t cbh_vidx_entries(cbh_vidx* v, int skip_frames) {
   if (!v || build(v, skip_frames)) return 0;
   return v->evidx.size();

@@ -204,6 +204,11 @@ class DctVideoIndex:
     def count(self) -> int:
         return int(self._L.cbh_vidx_count(self._h))
 
+    def memoryUsage(self) -> int:
+        """`_tree ? _tree->stats().memory : 0` (dctvideoindex.cpp:57-59): 0 until the first query builds the structure,
+        then 8 + 6 bytes per entry"""
+        return int(self._L.cbh_vidx_memory_usage(self._h))
+
     def _add_one(self, media_id: int, vi: VideoIndex) -> None:
         f = np.ascontiguousarray(vi.frames, np.int32)
         h = np.ascontiguousarray(vi.hashes, np.uint64)

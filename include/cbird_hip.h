@@ -544,6 +544,11 @@ int cbh_vidx_set_radix(cbh_vidx*, int radix);
 int cbh_vidx_add_video(cbh_vidx*, uint32_t media_id, const int32_t* frames, const uint64_t* hashes, size_t n);
 int cbh_vidx_remove(cbh_vidx*, const uint32_t* media_ids, size_t n);           /* remove() :256-275 */
 size_t cbh_vidx_count(const cbh_vidx*);                                         /* count() = #videos */
+/* memoryUsage() (src/dctvideoindex.cpp:57-59: `_tree ? _tree->stats().memory : 0`): 0 until the search structure is
+ * built; then the payload bytes the reference's RadixMap holds for the same entries -- 8 (hash_t) + 6 (the packed 24+24-bit
+ * VideoTreeIndex, src/dctvideoindex.h:37-43) per entry -- without std::vector's capacity slack and the bucket table
+ * (src/tree/radix.h:80-83,167), which depend on insertion history */
+size_t cbh_vidx_memory_usage(const cbh_vidx*);
 /* number of entries in the search structure after the insertHashes filters; builds it (buildTree
  * :113-170) with vtrim = skip_frames if it is not built yet (a built tree is NOT rebuilt for another
  * skip_frames, like `if (_tree) return;`). */

@@ -9,6 +9,35 @@
 
 #include "gpu_indexes.h"
 
+// ---- the boundary, member by member (compile time) -----------------------------------------------------------------
+// Every virtual a reference subclass overrides (src/dctfeaturesindex.h:42-64, src/cvfeaturesindex.h:42-64,
+// src/colordescindex.h:35-58, src/dctvideoindex.h:77-97) is either overridden by its Gpu twin -- everything that touches
+// the in-memory search state -- or deliberately inherited from the reference class: the SQL-only members
+// (createTables / addRecords / removeRecords, and mediaIds where it is a pure table scan) and the constant getters.
+// &Twin::member has class type Twin exactly when Twin declares it itself.
+#include <type_traits>
+template <class T> struct member_class;
+template <class C, class R, class... A> struct member_class<R (C::*)(A...)> { typedef C type; };
+template <class C, class R, class... A> struct member_class<R (C::*)(A...) const> { typedef C type; };
+#define OVERRIDDEN(Twin, m) \
+  static_assert(std::is_same<member_class<decltype(&Twin::m)>::type, Twin>::value, #Twin " must override " #m)
+#define INHERITED(Twin, m) \
+  static_assert(!std::is_same<member_class<decltype(&Twin::m)>::type, Twin>::value, #Twin "::" #m " is meant to be the reference's")
+#define STATE_MEMBERS(Twin) \
+  OVERRIDDEN(Twin, isLoaded); OVERRIDDEN(Twin, count); OVERRIDDEN(Twin, memoryUsage); OVERRIDDEN(Twin, load); \
+  OVERRIDDEN(Twin, save); OVERRIDDEN(Twin, add); OVERRIDDEN(Twin, remove); OVERRIDDEN(Twin, find); OVERRIDDEN(Twin, slice)
+STATE_MEMBERS(GpuDctFeaturesIndex);
+STATE_MEMBERS(GpuCvFeaturesIndex);
+STATE_MEMBERS(GpuColorDescIndex);
+STATE_MEMBERS(GpuDctVideoIndex);
+OVERRIDDEN(GpuColorDescIndex, mediaIds);      // reads the in-memory ids when loaded (colordescindex.cpp:161-181)
+OVERRIDDEN(GpuColorDescIndex, findIndexData); // descriptor of a loaded item (colordescindex.cpp:277-290)
+OVERRIDDEN(GpuDctVideoIndex, mediaIds);       // the loaded index answers from its own id list (dctvideoindex.cpp:218-231)
+INHERITED(GpuDctFeaturesIndex, mediaIds);     // `select media_id from kphash`: SQL only (dctfeaturesindex.cpp:183-198)
+INHERITED(GpuCvFeaturesIndex, mediaIds);      // `select media_id from matrix`: SQL only (cvfeaturesindex.cpp:214-229)
+INHERITED(GpuDctVideoIndex, databaseId);      // constants of the reference class (dctvideoindex.h:95,97)
+INHERITED(GpuDctVideoIndex, resultTypes);
+
 #define CHECK(c)                                                   \
   do {                                                             \
     if (!(c)) {                                                    \
@@ -218,6 +247,7 @@ int main(int argc, char** argv) {
     CHECK(idx.id() == SearchParams::AlgoVideo && idx.databaseId() == 0 && !idx.isLoaded());
     idx.load(db, "", tmp);
     CHECK(idx.isLoaded() && idx.count() == n);
+    CHECK(idx.memoryUsage() == 0);  // `_tree ? ... : 0` (dctvideoindex.cpp:57-59): nothing is built before the first query
     p.skipFrames = 0;
     p.minFramesMatched = 30;
     p.minFramesNear = 60;
@@ -225,6 +255,12 @@ int main(int argc, char** argv) {
     needle.setType(Media::TypeVideo);
     QVector<Index::Match> r = idx.find(needle, p);
     CHECK(r.count() == 1 && r[0].mediaId == 104 && r[0].score == 0 && r[0].range.srcIn == 0 && r[0].range.dstIn == 0);
+    {
+      size_t entries = 0;  // vtrim 0, every hash has >= 5 ones and zeros: each frame is an entry of 8 + 6 bytes
+      for (auto& v : vids) entries += v.hashes.size();
+      CHECK(idx.memoryUsage() == entries * 14);
+      idx.save(db, "");  // a no-op, like the reference's
+    }
     Media frame("f", 0, vids[4].hashes[50]);  // a single frame finds both copies
     frame.setType(Media::TypeImage);
     CHECK(idx.find(frame, p).count() == 2);

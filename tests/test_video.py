@@ -284,12 +284,14 @@ def test_gpu_find_video_and_frame_vs_oracle(gpu, vorc, reduce_path):
     clips = synth_video.make_clips(300, 300, seed=11, subclip_frac=0.1, max_gap=8)
     idx, media = _mk_index(gpu, clips)
     assert idx.count() == 300 and idx.isLoaded()
+    assert idx.memoryUsage() == 0  # `_tree ? _tree->stats().memory : 0` (dctvideoindex.cpp:57-59): nothing built yet
     videos = [(m.id, f, h) for m, (f, h) in zip(media, clips)]
     for skip, thr, vfm, vfn in ((0, 5, 30, 60), (0, 2, 5, 10), (40, 7, 10, 30)):
         idx2, _ = _mk_index(gpu, clips)  # the tree is built once per index with the first query's vtrim
         p = VideoSearchParams(dctThresh=thr, skipFrames=skip, minFramesMatched=vfm, minFramesNear=vfn)
         entries = vorc.build_entries(videos, skip)
         assert idx2.entries(skip) == len(entries[0])
+        assert idx2.memoryUsage() == 14 * len(entries[0])  # hash_t + packed VideoTreeIndex per entry
         n_hits = 0
         for m in media[::7] + media[-30:]:
             got = [(x.mediaId, x.score, x.range.srcIn, x.range.dstIn, x.range.len) for x in idx2.findVideo(m, p)]
