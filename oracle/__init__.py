@@ -28,6 +28,16 @@ _u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 
 
+def _load_ref(path: str):
+    """dlopen one of oracle/_ref's libraries.  Both link this image's conda Qt 5.9.7 with RUNPATH /opt/conda/lib, a
+    directory that also holds an OLDER libstdc++.so.6 (6.0.28): a process that has not loaded the system's libstdc++ yet
+    would bind that one (libcbird_ref_qt.so then fails on `std::__throw_bad_array_new_length`, and whatever is imported
+    later -- torch -- would meet the old library).  So the system's is loaded first, by soname: the loader reuses it for
+    every later NEEDED libstdc++.so.6."""
+    C.CDLL("libstdc++.so.6", mode=C.RTLD_GLOBAL)
+    return C.CDLL(path)
+
+
 def build(force: bool = False) -> None:
     """Compile the C restatement (and, when /root/reference exists, oracle/_ref)."""
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE)
@@ -443,7 +453,7 @@ class RefHammingTree:
     @classmethod
     def lib(cls):
         if cls._L is None:
-            L = C.CDLL(_REF_QT_SO)
+            L = _load_ref(_REF_QT_SO)
             L.ref_htree_create.restype = C.c_void_p
             L.ref_htree_destroy.argtypes = [C.c_void_p]
             L.ref_htree_size.argtypes = [C.c_void_p]
@@ -524,7 +534,7 @@ class RefTree:
         if cls._L is None:
             if not ref_available():
                 raise FileNotFoundError(_REF_SO)
-            L = C.CDLL(_REF_SO)
+            L = _load_ref(_REF_SO)
             L.ref_hamm64.argtypes = [C.c_uint64, C.c_uint64]
             L.ref_hamm64.restype = C.c_int
             L.ref_dcttree_create.argtypes = [_u64p, _u32p, C.c_int]
@@ -757,7 +767,7 @@ class RefRadixMap:
     """The real RadixMap_t<VideoTreeIndex> (src/tree/radix.h) via oracle/ref_wrap_qt.cpp."""
 
     def __init__(self, radix: int):
-        L = C.CDLL(_REF_QT_SO)
+        L = _load_ref(_REF_QT_SO)
         self.L = L
         L.ref_radix_create.restype = C.c_void_p
         L.ref_radix_create.argtypes = [C.c_uint]
