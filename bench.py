@@ -243,8 +243,9 @@ def main():
         # threshold's scan as well and is not additive
         sweep.append({"dht": dht, "scan_kernel_ms": round(sm, 3), "find_latency_ms": round(fm, 3),
                       "scan_cmp_per_s": shard_n * n / sm * 1e3, "matches": finds[dht][0][1]})
-    # the matrix-core scan has two shapes: k_hamm64_mfma3 (64-bit dot products; thresholds > PRE_MAX_DHT) and PRE (32-bit
-    # prefilter on lo ^ hi + exact re-check of the candidates; thresholds <= PRE_MAX_DHT = the library's "scan_mfma_pre_max"),
+    # the matrix-core scan has two shapes: k_hamm64_mfma3 (64-bit dot products) and PRE (32-bit prefilter on lo ^ hi + exact
+    # re-check of the candidates).  The library picks per launch, from the candidate rate of that launch's data
+    # (hamm64_mfma.hip: pick_pre); "scan_pre_mask" reads back which thresholds took the prefilter in the timed steps,
     # which executes half the multiply-adds per comparison.  `roofline` prices whichever of the two takes more of the
     # step's time; both are reported (roofline_full3, roofline_pre) with the flops they really issue.
     import ctypes as _ct
@@ -252,9 +253,11 @@ def main():
     from cbird_amd import _lib as _cl
 
     _v = _ct.c_longlong(0)
-    PRE_MAX_DHT = int(_v.value) if _cl.lib().cbh_get_tuning(b"scan_mfma_pre_max", _ct.byref(_v)) == 0 else 4
-    full = [d for d in dhts if d > PRE_MAX_DHT] or dhts
-    pre = [d for d in dhts if d <= PRE_MAX_DHT and d not in full]
+    pre_mask = int(_v.value) if _cl.lib().cbh_get_tuning(b"scan_pre_mask", _ct.byref(_v)) == 0 else 0
+    pre = [d for d in dhts if d < 64 and (pre_mask >> d) & 1]
+    full = [d for d in dhts if d not in pre] or dhts
+    pre = [d for d in pre if d not in full]
+    probes = int(_v.value) if _cl.lib().cbh_get_tuning(b"scan_probes", _ct.byref(_v)) == 0 else None
     scan_ms_avg = sum(sum(scans[d]) for d in full) / sum(len(scans[d]) for d in full)
     scan_bytes = 8.0 * shard_n * n  # 8 algorithmic bytes per 64-bit comparison
     scan_gbs = scan_bytes / (scan_ms_avg * 1e-3) / 1e9
@@ -268,7 +271,13 @@ def main():
     result = {
         "metric": "Hamming comparisons/sec + images hashed/sec, 1M-image index, 1/2/4/8 MI355X",
         "value": value,
-        "unit": "64-bit Hamming comparisons/s (whole step: build + dht sweep)",
+        "unit": ("pair-equivalents/s, exact results, whole step (build + dht sweep): every (needle, slot) pair of every threshold "
+                 "counts once; thresholds the library routes to the 32-bit fold prefilter (see kernel_choice) compare "
+                 "lo ^ hi and re-check the candidates on all 64 bits, the others compare all 64 bits of every pair "
+                 "(full_64bit_compare_rate_per_s)"),
+        "kernel_choice": {"prefilter_dht": pre, "full_64bit_dht": full, "chosen_by": "candidate rate of each launch "
+                          "(k_fold_probe: 2048 x 2048 sampled pairs) against scan_pre_rate_e9",
+                          "probes_run_by_the_library_so_far": probes},
         "images_hashed_per_s": shard_n * world / (hash_ms * 1e-3),
         "n_gpus": world,
         "steps": steps,
@@ -288,11 +297,12 @@ def main():
             "parallelism": f"haystack row-sharded x{world}, needles replicated",
         },
         "dht_sweep": sweep,
-        # the headline counts 8 x N^2 pair-equivalents per step; thresholds <= PRE_MAX_DHT run the 32-bit prefilter (dot
-        # products of lo ^ hi + exact 64-bit re-checks of the candidates), the others compare all 64 bits of every pair
+        # the headline counts len(dht) x N^2 pair-equivalents per step; the thresholds of kernel_choice.prefilter_dht run the
+        # 32-bit prefilter (dot products of lo ^ hi + exact 64-bit re-checks of the candidates), the others compare all 64
+        # bits of every pair
         "full_64bit_compare_rate_per_s": shard_n * n / (scan_ms_avg * 1e-3) * world,
         "roofline_full3": {
-            "kernel": "k_hamm64_mfma3<8,2> (64-bit sign dot products, 3 needle tiles per accumulator: dht %s)" % ",".join(map(str, full)), "bound": "mfma", "achieved": scan_tflops, "peak": FP4_PEAK_TFLOPS,
+            "kernel": "k_hamm64_mfma3 (64-bit sign dot products, 3 needle tiles per accumulator: dht %s)" % ",".join(map(str, full)), "bound": "mfma", "achieved": scan_tflops, "peak": FP4_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": scan_tflops / FP4_PEAK_TFLOPS, "traffic": None,
             "avg_launch_ms": scan_ms_avg, "launches_per_step": len(full),
             "algorithmic_flop_per_launch": FLOP_PER_CMP * shard_n * n,
@@ -304,7 +314,8 @@ def main():
                      "expansion kernel + the scan kernel of one launch."),
         },
         "roofline_pre": None if not pre else (lambda pre_ms: {
-            "kernel": "k_hamm64_mfma<8,2,true,4> (PRE: dht %s)" % ",".join(map(str, pre)), "bound": "mfma",
+            "kernel": "k_hamm64_mfma<true> (PRE: dht %s)" % ",".join(map(str, pre)), "bound": "mfma",
+            "binding_unit": "the SIMD issue port, shared by the MFMAs (~24 of 32 cycles each) and the VALU flag reduction",
             "avg_launch_ms": pre_ms, "launches_per_step": len(pre),
             "algorithmic_flop_per_launch": 64.0 * shard_n * n,
             "achieved": 64.0 * shard_n * n / (pre_ms * 1e-3) / 1e12,

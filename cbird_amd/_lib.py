@@ -227,6 +227,7 @@ _SIGS = {
                                           C.POINTER(C.c_float)]),
     "cbh_time_dcthash_dev": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, _sz, _vp, C.c_int, C.c_int,
                                        C.POINTER(C.c_float)]),
+    "cbh_selftest_buffer_range": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
 }
 
 

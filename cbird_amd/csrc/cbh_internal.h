@@ -26,18 +26,14 @@ void* fail_handle(int code, const char* why);  // sets code + text (text kept if
 // ---- stream-ordered scratch memory (cbird_hip.hip) ------------------------------------------------------------------
 // Every kernel launcher takes its scratch with malloc_async(&p, bytes, stream) and gives it back with
 // free_async(p, stream) right behind the last kernel that uses it (the contract of hipMallocAsync / hipFreeAsync).
-// cbh_set_tuning("scratch_alloc", v) picks the source:
-//   2 (default)  the library's own arena: hipMalloc'ed blocks cached per (device, stream), reused only by the stream
-//                that freed them; bounded ("pool_live_keep_mb" per live stream, "pool_keep_mb" for
-//                blocks that outlive theirs, 32 stream caches, cbh_trim)
-//   1            one ROCm hipMemPool_t per stream (round 2)         } both hand out memory that is still in use on
-//   0            ROCm's default pool (plain hipMallocAsync)         } this stack: tools/ubench/pool_cross_stream.hip
+// The source is the library's own arena: hipMalloc'ed blocks cached per (device, stream), reused only by the stream that
+// freed them; bounded ("pool_live_keep_mb" per live stream, "pool_keep_mb" for blocks that outlive theirs, 32 stream
+// caches, cbh_trim).  (ROCm's hipMallocAsync pools hand out memory that is still in use on this stack:
+// tools/ubench/pool_cross_stream.hip.)
 hipError_t malloc_async(void** p, size_t bytes, hipStream_t s);
 hipError_t free_async(void* p, hipStream_t s);
 // for streams the library creates itself: synchronise, hand the cached blocks to the device's orphan list, destroy
 void stream_destroy(hipStream_t s);
-void set_scratch_mode(int v);
-void set_scratch_poison(int v);
 void set_pool_keep_mb(int mb);
 void set_pool_live_keep_mb(int mb);
 int trim_pools(int device, unsigned long long* released_bytes);
@@ -83,6 +79,8 @@ long get_fault_alloc_after();
 unsigned long get_fault_fired();
 unsigned long get_alloc_calls();
 int arena_counter(const char* name, long long* value);
+hipError_t persistent_malloc(void** p, size_t bytes);
+void set_fault_persist_oom(int n);  // "fault_persist_oom": the n-th persistent allocation is refused by the "driver" once
 template <class T>
 static inline hipError_t gated_malloc(T** p, size_t bytes) {
   hipError_t e = fault_gate();
@@ -90,7 +88,7 @@ static inline hipError_t gated_malloc(T** p, size_t bytes) {
     *p = nullptr;
     return e;
   }
-  return (hipMalloc)(p, bytes);
+  return persistent_malloc((void**)p, bytes);  // cbird_hip.hip: gives the scratch arena's caches back before it fails
 }
 template <class T>
 static inline hipError_t gated_host_malloc(T** p, size_t bytes, unsigned flags = hipHostMallocDefault) {
@@ -125,8 +123,6 @@ int launch_hamm64_scan(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n
                        const uint64_t* d_qmask = nullptr);
 enum { SCAN_KEEP_ID0 = 1u };  // also emit slots whose id is 0 (DctFeaturesIndex top-10 cut)
 
-void set_scan_tuning(int pre_max, int eq_for_dht1, int group);  // <0 = keep
-
 // ---- hamm64_mfma.hip: the same scan on the matrix cores (FP4 sign dot products) --------
 int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n,
                             const uint64_t* d_q, size_t nq, int thresh, cbh_record* d_rec,
@@ -134,27 +130,19 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
                             unsigned flags = 0, const uint64_t* d_qmask = nullptr);
 bool scan_mfma_wanted(size_t n, size_t nq, int thresh);
 void set_scan_mfma(int on);  // <0 = keep; 2 = force for any size
-void set_scan_mfma_ht(int ht);
-void set_scan_mfma_g(int g);
-int get_scan_pre_max();         // thresholds <= this run the prefilter kernel at present (0: none)
-void set_scan_pre_max(int t);   // thresholds <= t take the 32-bit prefilter kernel
-void set_scan_mfma_chunk(int v); // needle-tile pairs (PRE) / triples x 2/3 (FULL3) per workgroup chunk; 0 = 512 / 172
-void set_scan_pre_fold(int v);  // prefilter word: 1 = lo ^ hi, 0 = lo
-void set_scan_pre_lean(int v);  // 1 = single candidates re-checked on the scalar unit
-void set_scan_mfma_full3(int on);  // three-needle-tile accumulator variant for thresholds > 4
-void set_scan_mfma_pre(int on);  // 32-bit prefilter variant for small thresholds
+void set_scan_pre_max(int t);   // -1 = prefilter or three-field kernel by the launch's candidate rate (default), 0 = never the
+                                // prefilter, t > 0 = thresholds <= t take it whatever the data
+void set_scan_pre_rate(int e9); // candidate rate x 1e9 up to which the prefilter kernel is taken ("scan_pre_rate_e9")
+long long get_scan_pre_mask();  // bit t = the most recent matrix-core launch at threshold t took the prefilter kernel
+long long get_scan_probes();    // candidate-rate probes run so far
+long long get_scan_probe_rate_e9();  // what the last one found for its threshold, x 1e9 (-1: none yet)
 
 // ---- hamm256_mfma.hip: 256-bit threshold scan on the matrix cores -----------------------
 int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, size_t nq, int thresh,
                         unsigned long long* d_rec, size_t cap, unsigned long long* d_total,
                         hipStream_t stream);
 bool scan256_mfma_wanted(size_t n, size_t nq, int thresh);
-void set_scan256_g(int g);
-void set_scan256_ht(int ht);
-void set_scan256_small(int v);  // stationary-needle kernel for <= 512 needle descriptors: 0 / 1, >= 16: its workgroups
-void set_scan256_lut(int v);    // k_hamm256_small: FP4 expansion of the streamed rows through an LDS table (default 1)
-void set_scan256_f3(int v);   // prefilter with three needle tiles per accumulator (default 1; 0 off; HT*10+G shapes)
-void set_scan256_pre(int on);  // first-128-bit prefilter variant (default on)
+void set_scan256_small(int v);  // stationary-needle kernel for <= 512 needle descriptors: 0 / 1
 void set_scan256_mfma(int on);  // <0 = keep; 2 = force for any size
 
 
@@ -189,6 +177,8 @@ void set_color_fma(int on);  // color.hip: fused squares in k_color_dist3 (defau
 // Ascending u64 sort of n records in place (uses d_alt as the ping-pong buffer and d_tmp as
 // scratch; sizes from sort_records_scratch_bytes).
 size_t sort_records_scratch_bytes(size_t n);
+int sort_keys64_db(unsigned long long* d_keys, unsigned long long* d_alt, size_t n, unsigned end_bit, void* d_tmp,
+                   size_t tmp_bytes, hipStream_t stream, unsigned long long** sorted);  // any 64-bit keys, double buffer
 int launch_sort_records(cbh_record* d_rec, cbh_record* d_alt, size_t n, size_t nq, void* d_tmp,
                         size_t tmp_bytes, hipStream_t stream);
 int launch_select_records(const cbh_record* d_sorted, size_t n, size_t nq, int k, cbh_match* d_out,

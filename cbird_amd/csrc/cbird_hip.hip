@@ -48,12 +48,12 @@ void* fail_handle(int code, const char* why) {
 }
 
 // ---- stream-ordered scratch (see cbh_internal.h) --------------------------------------------------------------------
-// Mode 2 (default): the library's own arena.  Blocks are plain hipMalloc memory, cached per (device, stream); a block
+// The library's own arena.  Blocks are plain hipMalloc memory, cached per (device, stream); a block
 // freed with free_async(p, s) is at once available again -- but only to allocations on the SAME stream s, which by
 // stream order run after everything that used it.  A block changes streams only when its stream is known idle or gone
 // (stream_destroy, eviction, trim), and goes back to the driver only then.  Nothing here depends on ROCm's
 // hipMallocAsync, whose pools (tools/ubench/pool_cross_stream.hip, profiles/r03_pool_cross_stream.jsonl) hand out
-// memory that is still in use.  Modes 0 / 1 keep those pools (default pool / one pool per stream) for the A/B soak.
+// memory that is still in use (rounds 2-5 kept them selectable for the A/B soak: r05's "scratch_alloc" 0 / 1).
 namespace {
 constexpr size_t kMaxStreamCaches = 32;  // live (device, stream) caches; beyond that dead / idle streams give theirs up
 struct Block {
@@ -64,7 +64,6 @@ struct StreamCache {
   std::vector<Block> free;
   size_t free_bytes = 0;
   uint64_t last_use = 0;
-  hipMemPool_t pool = nullptr;  // mode 1 only
 };
 struct LiveInfo {
   size_t bytes;
@@ -75,8 +74,7 @@ struct Arena {
   std::map<std::pair<int, hipStream_t>, StreamCache> caches;
   std::map<int, std::vector<Block>> orphan;  // blocks whose stream is idle or gone: any stream may take them
   std::map<int, size_t> orphan_bytes;
-  std::map<int, std::vector<hipMemPool_t>> idle_pools;  // mode 1
-  std::map<void*, LiveInfo> live;  // blocks handed out by mode 2
+  std::map<void*, LiveInfo> live;  // blocks handed out
   // blocks a live stream's cache gave up because it exceeded the budget: work queued on that stream may still use them,
   // so each waits for an event recorded behind that work and goes back to the driver once it has completed
   // (one event per trim: the blocks a single free_async gave up wait behind the same point of the stream)
@@ -87,7 +85,7 @@ struct Arena {
     hipEvent_t ev;
   };
   std::vector<Pending> pending;
-  uint64_t n_trimmed_live = 0, n_oom_retry_stream = 0, n_oom_retry_device = 0;
+  uint64_t n_trimmed_live = 0, n_oom_retry_stream = 0, n_oom_retry_device = 0, n_oom_retry_persistent = 0;
   uint64_t clock = 0;
   uint64_t n_malloc = 0, n_reuse = 0, n_adopt = 0, n_evicted_dead = 0, n_evicted_idle = 0, n_released = 0;
 };
@@ -95,9 +93,6 @@ Arena& arena() {
   static Arena* a = new Arena;  // never destroyed: calls may arrive during process teardown
   return *a;
 }
-int g_scratch_mode = 2;
-int g_scratch_poison = 0;  // "scratch_poison": v > 0 fills every block handed out with byte v - 1 (finds kernels that
-                           // read scratch they never wrote: fresh driver memory is zero, a recycled block is not)
 uint64_t g_pool_keep_bytes = (uint64_t)16 << 30;  // cached scratch that outlives its stream, per device ("pool_keep_mb")
 // What a LIVE stream's cache may hold ("pool_live_keep_mb").  A budget of its own: the working set of one call can be
 // far above what is worth keeping for streams that are gone (ColorDescriptor::create takes ~50 GB of scratch per 10^5
@@ -105,23 +100,27 @@ uint64_t g_pool_keep_bytes = (uint64_t)16 << 30;  // cached scratch that outlive
 // and whatever is cached stays reclaimable -- an allocation the driver refuses gives the caches back before it fails.
 // 0 = a quarter of the device's memory (72 GB of an MI355X's 288), never below the orphan budget's default.
 uint64_t g_pool_live_keep_bytes = 0;
-uint64_t g_live_auto[32] = {};
+// (per ordinal, from hipDeviceTotalMem: a property of `dev`, whichever device is current -- and asked for in
+// malloc_async before the arena's lock is taken, so free_async finds it cached)
+std::atomic<uint64_t> g_live_auto[32];
 uint64_t live_budget(int dev) {
   if (g_pool_live_keep_bytes) return g_pool_live_keep_bytes;
   if (dev < 0 || dev >= 32) return (uint64_t)16 << 30;
-  if (!g_live_auto[dev]) {
-    size_t fr = 0, tot = 0;
-    if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
+  uint64_t v = g_live_auto[dev].load(std::memory_order_relaxed);
+  if (!v) {
+    size_t tot = 0;
+    if (hipDeviceTotalMem(&tot, dev) != hipSuccess) {
       (void)hipGetLastError();
       return (uint64_t)16 << 30;
     }
-    g_live_auto[dev] = std::max<uint64_t>((uint64_t)16 << 30, (uint64_t)tot / 4);
+    v = std::max<uint64_t>((uint64_t)16 << 30, (uint64_t)tot / 4);
+    g_live_auto[dev].store(v, std::memory_order_relaxed);
   }
-  return g_live_auto[dev];
+  return v;
 }
 
 // fault injection (cbh_internal.h): countdowns, -1 = disarmed
-std::atomic<long> g_fault_alloc{-1}, g_fault_driver{-1};
+std::atomic<long> g_fault_alloc{-1}, g_fault_driver{-1}, g_fault_persist{-1};
 std::atomic<unsigned long> g_fault_fired{0}, g_alloc_calls{0};
 std::atomic<int> g_fault_sticky{0};  // "fault_alloc_sticky": once the countdown has run out every allocation fails
 hipError_t countdown(std::atomic<long>& c) {
@@ -161,11 +160,6 @@ long best_fit(const std::vector<Block>& v, size_t need) {
   return best;
 }
 
-void apply_threshold(hipMemPool_t pool) {
-  uint64_t keep = g_pool_keep_bytes;
-  (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-}
-
 // under A.mu, current device = dev.  The cache of an idle / dead stream moves to the orphan list (its blocks are
 // unused: everything queued behind them has completed, or the stream no longer exists), what exceeds the budget is
 // released.  Dead streams always, idle ones oldest first while there are too many caches (or all of them: `all`).
@@ -178,7 +172,6 @@ void evict(Arena& A, int dev, bool all, std::vector<void*>* to_free) {
     }
     c.free.clear();
     c.free_bytes = 0;
-    if (c.pool) A.idle_pools[dev].push_back(c.pool);
   };
   for (auto it = A.caches.begin(); it != A.caches.end();) {
     if (it->first.first != dev) {
@@ -226,6 +219,7 @@ hipError_t fault_gate() {
 hipError_t fault_gate_driver() { return countdown(g_fault_driver); }
 void set_fault_alloc_after(int n) { g_fault_alloc = n < 0 ? -1 : n; }
 void set_fault_driver_oom(int n) { g_fault_driver = n < 0 ? -1 : n; }
+void set_fault_persist_oom(int n) { g_fault_persist = n < 0 ? -1 : n; }
 void set_fault_alloc_sticky(int v) { g_fault_sticky = v ? 1 : 0; }
 long get_fault_alloc_after() { return g_fault_alloc.load(); }
 unsigned long get_fault_fired() { return g_fault_fired.load(); }
@@ -258,60 +252,75 @@ hipError_t driver_malloc(void** p, size_t bytes) {
 }
 }  // namespace
 
-void set_scratch_mode(int v) { g_scratch_mode = v < 0 ? 0 : v > 2 ? 2 : v; }
-void set_pool_live_keep_mb(int mb) { g_pool_live_keep_bytes = mb < 0 ? ~0ull : (uint64_t)mb << 20; }  // 0 = automatic
-void set_pool_keep_mb(int mb) {
-  g_pool_keep_bytes = mb < 0 ? ~0ull : (uint64_t)mb << 20;
+namespace {
+// Every cached block of `dev`, whatever stream holds it, goes back to the driver: taken out of the caches first (nobody
+// can be handed one any more), then the device is synchronised (whatever was queued behind them has run), then freed.
+// The caller has made `dev` current.
+void release_device(Arena& A, int dev) {
+  std::vector<void*> all;
+  std::vector<hipEvent_t> pev;
+  {
+    std::lock_guard<std::mutex> lk(A.mu);
+    for (auto& kv : A.caches)
+      if (kv.first.first == dev) {
+        for (Block& b : kv.second.free) all.push_back(b.p);
+        kv.second.free.clear();
+        kv.second.free_bytes = 0;
+      }
+    for (Block& b : A.orphan[dev]) all.push_back(b.p);
+    A.orphan[dev].clear();
+    A.orphan_bytes[dev] = 0;
+    for (size_t i = 0; i < A.pending.size();)
+      if (A.pending[i].dev == dev) {
+        for (Block& b : A.pending[i].blocks) all.push_back(b.p);
+        pev.push_back(A.pending[i].ev);
+        A.pending[i] = std::move(A.pending.back());
+        A.pending.pop_back();
+      } else {
+        ++i;
+      }
+  }
+  (void)hipDeviceSynchronize();
+  for (void* q : all) (void)hipFree(q);
+  for (hipEvent_t ev : pev) (void)hipEventDestroy(ev);
+  (void)hipGetLastError();
+}
+}  // namespace
+
+// Index storage, result workspaces, tables: memory that stays with a handle (hipMalloc(...) in the library's sources is
+// this, through gated_malloc).  The arena may be sitting on most of the device -- a live stream keeps up to a quarter of
+// it cached -- and a plain hipMalloc knows nothing of that: refused, it gives the arena's cached and pending blocks of
+// the device back and tries once more, like the arena's own path does ("arena_oom_retry_persistent" counts).
+hipError_t persistent_malloc(void** p, size_t bytes) {
+  hipError_t e = countdown(g_fault_persist);
+  if (e == hipSuccess) e = (hipMalloc)(p, bytes);
+  if (e != hipErrorOutOfMemory) return e;
+  (void)hipGetLastError();
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return hipErrorOutOfMemory;
   Arena& A = arena();
-  std::lock_guard<std::mutex> lk(A.mu);
-  for (auto& kv : A.caches)
-    if (kv.second.pool) apply_threshold(kv.second.pool);
+  {
+    std::lock_guard<std::mutex> lk(A.mu);
+    A.n_oom_retry_persistent++;
+  }
+  release_device(A, dev);
+  return (hipMalloc)(p, bytes);
 }
 
-static hipError_t malloc_async_raw(void** p, size_t bytes, hipStream_t s);
+void set_pool_live_keep_mb(int mb) { g_pool_live_keep_bytes = mb < 0 ? ~0ull : (uint64_t)mb << 20; }  // 0 = automatic
+void set_pool_keep_mb(int mb) { g_pool_keep_bytes = mb < 0 ? ~0ull : (uint64_t)mb << 20; }
+
 hipError_t malloc_async(void** p, size_t bytes, hipStream_t s) {
   hipError_t e = fault_gate();
   if (e != hipSuccess) {
     *p = nullptr;
     return e;
   }
-  e = malloc_async_raw(p, bytes, s);
-  if (e == hipSuccess && g_scratch_poison > 0 && bytes) e = hipMemsetAsync(*p, g_scratch_poison - 1, bytes, s);
-  return e;
-}
-void set_scratch_poison(int v) { g_scratch_poison = v; }
-static hipError_t malloc_async_raw(void** p, size_t bytes, hipStream_t s) {
-  if (g_scratch_mode == 0 || (g_scratch_mode == 1 && !s)) return hipMallocAsync(p, bytes, s);
   int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
+  e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
+  (void)live_budget(dev);  // (cached per ordinal before the lock below: free_async reads it under the lock)
   Arena& A = arena();
-  if (g_scratch_mode == 1) {  // one ROCm pool per stream (round 2's workaround; unsafe, kept for the A/B soak)
-    hipMemPool_t pool = nullptr;
-    {
-      std::lock_guard<std::mutex> lk(A.mu);
-      StreamCache& c = A.caches[{dev, s}];
-      c.last_use = ++A.clock;
-      if (!c.pool) {
-        std::vector<hipMemPool_t>& idle = A.idle_pools[dev];
-        if (!idle.empty()) {
-          c.pool = idle.back();
-          idle.pop_back();
-        } else {
-          hipMemPoolProps props;
-          memset(&props, 0, sizeof props);
-          props.allocType = hipMemAllocationTypePinned;
-          props.handleTypes = hipMemHandleTypeNone;
-          props.location.type = hipMemLocationTypeDevice;
-          props.location.id = dev;
-          if ((e = hipMemPoolCreate(&c.pool, &props)) != hipSuccess) return e;
-          apply_threshold(c.pool);
-        }
-      }
-      pool = c.pool;
-    }
-    return hipMallocFromPoolAsync(p, bytes, pool, s);
-  }
   const size_t need = round_size(bytes);
   std::vector<void*> to_free;
   std::vector<hipEvent_t> evs;
@@ -369,39 +378,13 @@ static hipError_t malloc_async_raw(void** p, size_t bytes, hipStream_t s) {
     e = driver_malloc(p, need);
   }
   if (e == hipErrorOutOfMemory) {
-    // 2. every cached block of the device, whatever stream holds it: taken out of the caches first (nobody can be
-    //    handed one any more), then the device is synchronised (whatever was queued behind them has run), then freed
+    // 2. every cached block of the device, whatever stream holds it
     (void)hipGetLastError();
-    std::vector<void*> all;
-    std::vector<hipEvent_t> pev;
     {
       std::lock_guard<std::mutex> lk(A.mu);
-      for (auto& kv : A.caches)
-        if (kv.first.first == dev) {
-          for (Block& b : kv.second.free) all.push_back(b.p);
-          kv.second.free.clear();
-          kv.second.free_bytes = 0;
-        }
-      for (Block& b : A.orphan[dev]) all.push_back(b.p);
-      A.orphan[dev].clear();
-      A.orphan_bytes[dev] = 0;
-      for (size_t i = 0; i < A.pending.size();)
-        if (A.pending[i].dev == dev) {
-          for (Block& b : A.pending[i].blocks) all.push_back(b.p);
-          pev.push_back(A.pending[i].ev);
-          A.pending[i] = std::move(A.pending.back());
-          A.pending.pop_back();
-        } else {
-          ++i;
-        }
       A.n_oom_retry_device++;
     }
-    (void)hipDeviceSynchronize();
-    for (void* q : all) (void)hipFree(q);
-    for (hipEvent_t ev : pev) (void)hipEventDestroy(ev);
-    hipMemPool_t def = nullptr;  // (modes 0 / 1 may have left memory in ROCm's pools)
-    if (hipDeviceGetDefaultMemPool(&def, dev) == hipSuccess && def) (void)hipMemPoolTrimTo(def, 0);
-    (void)hipGetLastError();
+    release_device(A, dev);
     e = driver_malloc(p, need);
   }
   if (e != hipSuccess) return e;
@@ -416,7 +399,7 @@ hipError_t free_async(void* p, hipStream_t s) {
   {
     std::lock_guard<std::mutex> lk(A.mu);
     auto it = A.live.find(p);
-    if (it == A.live.end()) return hipFreeAsync(p, s);  // a block of modes 0 / 1
+    if (it == A.live.end()) return hipErrorInvalidValue;  // not a block of this arena
     const LiveInfo info = it->second;
     A.live.erase(it);
     StreamCache& c = A.caches[{info.dev, s}];
@@ -466,7 +449,6 @@ void stream_destroy(hipStream_t s) {
         A.orphan[dev].push_back(b);
         A.orphan_bytes[dev] += b.bytes;
       }
-      if (it->second.pool) A.idle_pools[dev].push_back(it->second.pool);
       A.caches.erase(it);
       std::vector<Block>& o = A.orphan[dev];
       std::sort(o.begin(), o.end(), [](const Block& x, const Block& y) { return x.bytes < y.bytes; });
@@ -489,7 +471,6 @@ int trim_pools(int device, unsigned long long* released_bytes) {
   std::vector<void*> to_free;
   std::vector<hipEvent_t> evs;
   unsigned long long rel = 0;
-  std::vector<hipMemPool_t> pools;
   {
     std::lock_guard<std::mutex> lk(A.mu);
     const uint64_t keep = g_pool_keep_bytes;
@@ -497,18 +478,12 @@ int trim_pools(int device, unsigned long long* released_bytes) {
     evict(A, device, true, &to_free);
     g_pool_keep_bytes = keep;
     reap_pending(A, &to_free, &evs);  // (the caller synchronised the device: every event has completed)
-    for (auto& kv : A.caches)
-      if (kv.first.first == device && kv.second.pool) pools.push_back(kv.second.pool);
-    for (hipMemPool_t p : A.idle_pools[device]) pools.push_back(p);
   }
   // (sizes of what evict() released are not tracked per pointer: measure through the driver)
   size_t f0 = 0, f1 = 0, tot = 0;
   (void)hipMemGetInfo(&f0, &tot);
   for (void* q : to_free) (void)hipFree(q);
   for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
-  hipMemPool_t def = nullptr;
-  if (hipDeviceGetDefaultMemPool(&def, device) == hipSuccess && def) pools.push_back(def);
-  for (hipMemPool_t p : pools) (void)hipMemPoolTrimTo(p, 0);
   (void)hipMemGetInfo(&f1, &tot);
   rel = f1 > f0 ? f1 - f0 : 0;
   if (released_bytes) *released_bytes = rel;
@@ -531,6 +506,7 @@ int arena_counter(const char* name, long long* value) {
   if (!strcmp(name, "trimmed_live")) return *value = (long long)A.n_trimmed_live, CBH_OK;
   if (!strcmp(name, "oom_retry_stream")) return *value = (long long)A.n_oom_retry_stream, CBH_OK;
   if (!strcmp(name, "oom_retry_device")) return *value = (long long)A.n_oom_retry_device, CBH_OK;
+  if (!strcmp(name, "oom_retry_persistent")) return *value = (long long)A.n_oom_retry_persistent, CBH_OK;
   if (!strcmp(name, "released")) return *value = (long long)A.n_released, CBH_OK;
   return CBH_E_INVAL;
 }
@@ -543,6 +519,22 @@ namespace cbh {  // sharded.hip
 int sharded_load(cbh_idx64* idx, const void* hashes, const void* ids, size_t n, bool on_device, hipStream_t stream);
 int sharded_add(cbh_idx64* idx, const uint64_t* hashes, const uint32_t* ids, size_t n);
 int sharded_remove(cbh_idx64* idx, const uint32_t* ids, size_t n, int zero_hash);
+}  // namespace cbh
+
+namespace cbh {
+namespace {
+// window = the first 4096 bytes of buf (num_records); lane l reads one dword at voffset 4 l (+ 2048 for the upper lanes)
+// with scalar offsets so[i]; out[i * 64 + l] = what came back
+__global__ void k_selftest_buffer_range(const unsigned* buf, const unsigned* so, unsigned n_so, unsigned* out) {
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(buf), 0, 4096, 0x27000);
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned voff = 4u * lane + (lane >= 32u ? 2048u : 0u);
+  for (unsigned i = 0; i < n_so; ++i) {
+    const unsigned s = (unsigned)__builtin_amdgcn_readfirstlane((int)so[i]);
+    out[i * 64u + lane] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)s, 0);
+  }
+}
+}  // namespace
 }  // namespace cbh
 
 extern "C" {
@@ -1319,229 +1311,44 @@ int cbh_select_records_dev(const void* d_sorted_records, size_t n, size_t nq, in
   return CBH_OK;
 }
 
+// every knob the library has (include/cbird_hip.h documents each): name -> setter
 int cbh_set_tuning(const char* key, int value) {
   if (!key) return CBH_E_INVAL;
-  if (!strcmp(key, "scan_pre_max")) {
-    set_scan_tuning(value, -1, -1);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "scan_eq_dht1")) {
-    set_scan_tuning(-1, value, -1);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "scan_mfma")) {
-    set_scan_mfma(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "kp_blur_side")) {
-    set_kp_blur_side(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "kp_lds_side")) {
-    set_kp_lds_side(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "hash_stream")) {
-    set_hash_stream(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "hash_fused")) {
-    set_hash_fused(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "hash_fast_any")) {
-    set_hash_fast_any(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "color_create_group")) {
-    set_cd_group(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "color_create_chunk_mb")) {
-    set_cd_chunk_mb(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "color_create_chains")) {
-    set_cd_chains(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "hash_band_area")) {
-    set_hash_band_area(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "hash_band_waves")) {
-    set_hash_band_waves(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "hash_wide")) {
-    set_hash_wide(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "hash_rows_per_step")) {
-    set_hash_rows_per_step(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "hash_tiles2")) {
-    set_hash_tiles2(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "hash_cell_pad")) {
-    set_hash_cell_pad(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "hash_area")) {
-    set_hash_area(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "color_fma")) {
-    set_color_fma(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "color_pk")) {
-    set_color_pk(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "scan256_lut")) {
-    set_scan256_lut(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "scan256_small")) {
-    set_scan256_small(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "scan256_f3")) {
-    set_scan256_f3(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "scan256_pre")) {
-    set_scan256_pre(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "scan256_ht")) {
-    set_scan256_ht(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "scan256_g")) {
-    set_scan256_g(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "scan256_mfma")) {
-    set_scan256_mfma(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "scan_mfma_full3")) {
-    set_scan_mfma_full3(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "scan_mfma_g")) {
-    set_scan_mfma_g(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "scan_mfma_pre_max")) {
-    set_scan_pre_max(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "scan_mfma_chunk")) {
-    set_scan_mfma_chunk(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "scan_pre_fold")) {
-    set_scan_pre_fold(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "scan_pre_lean")) {
-    set_scan_pre_lean(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "scan_mfma_pre")) {
-    set_scan_mfma_pre(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "scan_mfma_ht")) {
-    set_scan_mfma_ht(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "fdct_host_vote")) {
-    g_fdct_host_vote = value;
-    return CBH_OK;
-  }
-  if (!strcmp(key, "video_host_reduce")) {
-    g_video_host_reduce = value;
-    return CBH_OK;
-  }
-  if (!strcmp(key, "hash_fuse")) {
-    set_hash_fuse(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "orb_retain_order")) {
-    if (value != 0 && value != 1) return CBH_E_INVAL;
-    set_orb_retain_order(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "hash_regs")) {
-    set_hash_regs(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "hash_div")) {
-    set_hash_div(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "hash_lds_pad")) {
-    set_hash_lds_pad(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "hash_dct")) {
-    set_hash_dct(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "hash_mfma")) {
-    g_hash_mfma_set(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "scratch_poison")) {
-    set_scratch_poison(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "scratch_alloc")) {
-    set_scratch_mode(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "pool_keep_mb")) {
-    set_pool_keep_mb(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "pool_live_keep_mb")) {
-    set_pool_live_keep_mb(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "shard_force_rccl")) {
-    set_shard_force_rccl(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "shard_exchange")) {
-    set_shard_exchange(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "scan_group")) {
-    set_scan_tuning(-1, -1, value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "fault_alloc_after")) {
-    set_fault_alloc_after(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "fault_alloc_sticky")) {
-    set_fault_alloc_sticky(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "fault_driver_oom")) {
-    set_fault_driver_oom(value);
-    return CBH_OK;
-  }
-  if (!strcmp(key, "fault_rccl")) {
-    set_fault_rccl(value);
-    return CBH_OK;
-  }
+  static const struct {
+    const char* name;
+    void (*set)(int);
+  } kKnobs[] = {
+      {"scan_mfma", [](int v) { set_scan_mfma(v); }},
+      {"scan_mfma_pre_max", [](int v) { set_scan_pre_max(v); }},
+      {"scan_pre_rate_e9", [](int v) { set_scan_pre_rate(v); }},
+      {"scan256_mfma", [](int v) { set_scan256_mfma(v); }},
+      {"scan256_small", [](int v) { set_scan256_small(v); }},
+      {"hash_mfma", [](int v) { (void)g_hash_mfma_set(v); }},
+      {"hash_band_area", [](int v) { set_hash_band_area(v); }},
+      {"hash_fuse", [](int v) { set_hash_fuse(v); }},
+      {"hash_stream", [](int v) { set_hash_stream(v); }},
+      {"kp_lds_side", [](int v) { set_kp_lds_side(v); }},
+      {"kp_blur_side", [](int v) { set_kp_blur_side(v); }},
+      {"color_fma", [](int v) { set_color_fma(v); }},
+      {"color_create_chunk_mb", [](int v) { set_cd_chunk_mb(v); }},
+      {"fdct_host_vote", [](int v) { g_fdct_host_vote = v; }},
+      {"video_host_reduce", [](int v) { g_video_host_reduce = v; }},
+      {"orb_retain_order", [](int v) { set_orb_retain_order(v); }},
+      {"pool_keep_mb", [](int v) { set_pool_keep_mb(v); }},
+      {"pool_live_keep_mb", [](int v) { set_pool_live_keep_mb(v); }},
+      {"shard_force_rccl", [](int v) { set_shard_force_rccl(v); }},
+      {"shard_exchange", [](int v) { set_shard_exchange(v); }},
+      {"fault_alloc_after", [](int v) { set_fault_alloc_after(v); }},
+      {"fault_alloc_sticky", [](int v) { set_fault_alloc_sticky(v); }},
+      {"fault_driver_oom", [](int v) { set_fault_driver_oom(v); }},
+      {"fault_persist_oom", [](int v) { set_fault_persist_oom(v); }},
+      {"fault_rccl", [](int v) { set_fault_rccl(v); }},
+  };
+  for (const auto& k : kKnobs)
+    if (!strcmp(key, k.name)) {
+      k.set(value);
+      return CBH_OK;
+    }
   return CBH_E_INVAL;
 }
 
@@ -1551,7 +1358,9 @@ int cbh_get_tuning(const char* key, long long* value) {
   if (!strcmp(key, "fault_fired")) return *value = (long long)get_fault_fired(), CBH_OK;
   if (!strcmp(key, "alloc_calls")) return *value = (long long)get_alloc_calls(), CBH_OK;
   if (!strncmp(key, "arena_", 6)) return arena_counter(key + 6, value);
-  if (!strcmp(key, "scan_mfma_pre_max")) return *value = get_scan_pre_max(), CBH_OK;
+  if (!strcmp(key, "scan_pre_mask")) return *value = get_scan_pre_mask(), CBH_OK;
+  if (!strcmp(key, "scan_probes")) return *value = get_scan_probes(), CBH_OK;
+  if (!strcmp(key, "scan_probe_rate_e9")) return *value = get_scan_probe_rate_e9(), CBH_OK;
   return CBH_E_INVAL;
 }
 
@@ -1585,6 +1394,41 @@ int cbh_idx64_time_scan_dev(cbh_idx64* idx, const void* d_q, size_t nq, int thre
   (void)hipEventDestroy(e1);
   *ms_avg = ms / (float)iters;
   return rc;
+}
+
+int cbh_selftest_buffer_range(int device, int* ok) {
+  if (!ok) return CBH_E_INVAL;
+  *ok = 0;
+  if (!device_usable(device)) return CBH_E_NODEVICE;
+  DeviceGuard g(device);
+  if (!g.ok) return CBH_E_NODEVICE;
+  const unsigned so[] = {0u, 1024u, 2044u, 4092u, 4096u, 5120u, 8192u, 1u << 20, 0x7ffffff0u};
+  const unsigned n_so = sizeof so / sizeof so[0];
+  std::vector<unsigned> host(2048), got(n_so * 64);
+  for (unsigned i = 0; i < 2048; ++i) host[i] = i < 1024 ? 0x10000u + i : 0xDEADBEEFu;  // data | poison behind the window
+  unsigned *d_buf = nullptr, *d_so = nullptr, *d_out = nullptr;
+  hipError_t e = hipMalloc(&d_buf, 8192);
+  if (e == hipSuccess) e = hipMalloc(&d_so, sizeof so);
+  if (e == hipSuccess) e = hipMalloc(&d_out, got.size() * 4);
+  if (e == hipSuccess) e = hipMemcpy(d_buf, host.data(), 8192, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_so, so, sizeof so, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_selftest_buffer_range, dim3(1), dim3(64), 0, 0, d_buf, d_so, n_so, d_out);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(got.data(), d_out, got.size() * 4, hipMemcpyDeviceToHost);
+  for (void* p : {(void*)d_buf, (void*)d_so, (void*)d_out})
+    if (p) (void)hipFree(p);
+  CBH_HIP(e);
+  bool good = true;
+  for (unsigned i = 0; i < n_so; ++i)
+    for (unsigned l = 0; l < 64; ++l) {
+      const unsigned long long off = (unsigned long long)so[i] + 4u * l + (l >= 32 ? 2048u : 0u);
+      const unsigned want = off + 4 <= 4096 ? 0x10000u + (unsigned)(off / 4) : 0u;
+      good = good && got[i * 64 + l] == want;
+    }
+  *ok = good ? 1 : 0;
+  return CBH_OK;
 }
 
 int cbh_time_dcthash_dev(const void* d_imgs, size_t n, int w, int h, size_t row_stride,

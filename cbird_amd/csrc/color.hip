@@ -15,7 +15,6 @@
 // the library is built with -ffp-contract=off), one running minimum per needle colour and one per haystack
 // colour (either side can be "a"); sqrtf is monotonic, so it is applied to the 32 minima instead of the 1024
 // pair distances (bit-identical result), then summed in index order starting from 1.0f.
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include <cfloat>
 #include <map>
@@ -32,58 +31,12 @@ struct alignas(16) NeedleF {  // 400 bytes: k_color_dist3 reads the components a
   int num;
 };
 
-// Launch geometry of the three distance kernels: blockIdx.x = NEEDLE (fastest), blockIdx.y/z = haystack tile.  The
+// Launch geometry of the distance kernels: blockIdx.x = NEEDLE (fastest), blockIdx.y/z = haystack tile.  The
 // workgroups that run together then share one tile: it comes from HBM once per XCD instead of once per needle (with
 // the tile fastest, 64 needles re-streamed a 384 MB index 64 times -- 1.8 TB/s of traffic that held every variant of
 // the kernel at ~14 ms whatever its instruction mix).
 __device__ __forceinline__ uint32_t color_tile() { return blockIdx.y + blockIdx.z * 32768u; }
 
-__global__ __launch_bounds__(256) void k_color_dist(const float* __restrict__ L, const float* __restrict__ U,
-                                                    const float* __restrict__ V,
-                                                    const unsigned char* __restrict__ num, size_t stride,
-                                                    uint32_t n, const NeedleF* __restrict__ needles,
-                                                    int* __restrict__ out /* [nq][n] */) {
-  const uint32_t i = color_tile() * blockDim.x + threadIdx.x;
-  const NeedleF& nd = needles[blockIdx.x];  // wave-uniform
-  const int nn = nd.num;
-  const int hn = i < n ? (int)num[i] : 0;
-  float rowmin[kNC];
-#pragma unroll
-  for (int p = 0; p < kNC; ++p) rowmin[p] = FLT_MAX;
-  float colacc = 1.0f;
-  for (int h = 0; h < kNC; ++h) {
-    if (__ballot(h < hn) == 0ull) break;  // no lane of this wave has that many colours
-    const bool hv_ok = h < hn;
-    const float hl = hv_ok ? L[(size_t)h * stride + i] : 0.f;
-    const float hu = hv_ok ? U[(size_t)h * stride + i] : 0.f;
-    const float hv = hv_ok ? V[(size_t)h * stride + i] : 0.f;
-    float colmin = FLT_MAX;
-#pragma unroll
-    for (int p = 0; p < kNC; ++p) {
-      if (p < nn) {  // scalar branch
-        const float dl = nd.l[p] - hl, du = nd.u[p] - hu, dv = nd.v[p] - hv;
-        const float d2 = dl * dl + du * du + dv * dv;
-        rowmin[p] = fminf(rowmin[p], hv_ok ? d2 : FLT_MAX);
-        colmin = fminf(colmin, d2);
-      }
-    }
-    if (hv_ok) colacc += sqrtf(colmin);  // used when the haystack side is "a" (more colours)
-  }
-  int result = -1;
-  if (i < n && nn != 0 && hn != 0 && abs(nn - hn) <= 2) {
-    float score;
-    if (nn < hn) {
-      score = colacc;
-    } else {
-      score = 1.0f;
-#pragma unroll
-      for (int p = 0; p < kNC; ++p)
-        if (p < nn) score += sqrtf(rowmin[p]);
-    }
-    result = (int)score;
-  }
-  if (i < n) out[(size_t)blockIdx.x * n + i] = result;
-}
 
 
 // Two haystack descriptors per lane on the packed-f32 ALU (v_pk_add_f32 / v_pk_mul_f32 work on two
@@ -379,11 +332,11 @@ __global__ __launch_bounds__(256) void k_color_collect(const int* __restrict__ s
   }
 }
 
-// distance kernel: 1 = k_color_dist2 (two descriptors per lane on packed f32; default: 12.1 ms per 64 needles x 1M
-// descriptors), 2 = k_color_dist3 (32-bit ops on VGPR operands at 4 waves per SIMD: 12.5 ms), 0 = k_color_dist (14.1 ms).
-// All three sit at the VALU issue ceiling of this arithmetic (no FMA: the reference's rounding order) once the launch
-// geometry lets concurrent workgroups share haystack tiles.
-int g_color_pk = 1;
+// distance kernels: k_color_dist2 (two descriptors per lane on packed f32; the default: 12.1 ms per 64 needles x 1M
+// descriptors) and k_color_dist3 (32-bit ops on VGPR operands at 4 waves per SIMD: 12.5 ms; the one that can also hand
+// out the raw floats, and the fused-square form of "color_fma").  Both sit at the VALU issue ceiling of this arithmetic
+// (no FMA: the reference's rounding order) once the launch geometry lets concurrent workgroups share haystack tiles.
+// (Round 1's one-descriptor-per-lane k_color_dist, 14.1 ms, is in the history: r05's "color_pk" 0.)
 int g_color_fma = 0;  // "color_fma": 1 = k_color_dist3 with fused squares (faster, NOT bit-identical; see the kernel)
 
 void decompress(const uint8_t* desc, NeedleF* out) {  // DescriptorColor::get, cvutil.h:83-87
@@ -410,9 +363,6 @@ void decompress(const uint8_t* desc, NeedleF* out) {  // DescriptorColor::get, c
 
 namespace cbh {
 void set_color_fma(int on) { g_color_fma = on ? 1 : 0; }
-void set_color_pk(int on) {
-  if (on >= 0) g_color_pk = on;
-}
 }  // namespace cbh
 
 struct cbh_color {
@@ -527,7 +477,7 @@ int run_dist(cbh_color* c, const uint8_t* needle_descs, size_t nq, float* d_raw 
   for (size_t q = 0; q < nq; ++q) decompress(needle_descs + q * kDescBytes, &nf[q]);
   CBH_HIP(hipMemcpyAsync(c->d_needles, nf.data(), nq * sizeof(NeedleF), hipMemcpyHostToDevice, c->stream));
   CBH_HIP(hipStreamSynchronize(c->stream));  // nf is a stack-lifetime buffer
-  if (g_color_pk >= 2 || d_raw || g_color_fma) {
+  if (d_raw || g_color_fma) {
     const unsigned tiles = (unsigned)((c->n + 255) / 256);
     dim3 grid((unsigned)nq, std::min(tiles, 32768u), (tiles + 32767u) / 32768u), block(256);
 #define CBH_DIST3(RAW_, FMA_)                                                                                       \
@@ -539,15 +489,10 @@ int run_dist(cbh_color* c, const uint8_t* needle_descs, size_t nq, float* d_raw 
       if (d_raw) CBH_DIST3(true, false); else CBH_DIST3(false, false);
     }
 #undef CBH_DIST3
-  } else if ((c->cap & 1) == 0 && g_color_pk) {
+  } else {  // (cap is always even: ensure_cap)
     const unsigned tiles = (unsigned)((c->n + 511) / 512);
     dim3 grid((unsigned)nq, std::min(tiles, 32768u), (tiles + 32767u) / 32768u), block(256);
     hipLaunchKernelGGL(k_color_dist2, grid, block, 0, c->stream, c->dL, c->dU, c->dV, c->d_num, c->cap,
-                       (uint32_t)c->n, c->d_needles, c->d_scores);
-  } else {
-    const unsigned tiles = (unsigned)((c->n + 255) / 256);
-    dim3 grid((unsigned)nq, std::min(tiles, 32768u), (tiles + 32767u) / 32768u), block(256);
-    hipLaunchKernelGGL(k_color_dist, grid, block, 0, c->stream, c->dL, c->dU, c->dV, c->d_num, c->cap,
                        (uint32_t)c->n, c->d_needles, c->d_scores);
   }
   CBH_HIP(hipGetLastError());
@@ -733,12 +678,12 @@ int cbh_color_distances(cbh_color* c, const void* needle_descs, size_t nq, float
 static int color_full_sort_one(cbh_color* c, size_t q_in_chunk, int k, cbh_match* out_q, uint32_t valid) {
   hipLaunchKernelGGL(k_color_keys, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream,
                      c->d_scores + q_in_chunk * c->n, c->d_ids, (uint32_t)c->n, c->d_keys);
-  rocprim::double_buffer<unsigned long long> db(c->d_keys, c->d_keys_alt);
-  size_t tb = c->tmp_bytes;
-  CBH_HIP(rocprim::radix_sort_keys(c->d_tmp, tb, db, c->n, 0, 64, c->stream));
+  unsigned long long* sorted = nullptr;
+  int rc_s = cbh::sort_keys64_db(c->d_keys, c->d_keys_alt, c->n, 64, c->d_tmp, c->tmp_bytes, c->stream, &sorted);
+  if (rc_s) return rc_s;
   const size_t take = std::min<size_t>(std::min<size_t>((size_t)k, c->n), valid);
   std::vector<unsigned long long> head(take);
-  if (take) CBH_HIP(hipMemcpyAsync(head.data(), db.current(), take * 8, hipMemcpyDeviceToHost, c->stream));
+  if (take) CBH_HIP(hipMemcpyAsync(head.data(), sorted, take * 8, hipMemcpyDeviceToHost, c->stream));
   CBH_HIP(hipStreamSynchronize(c->stream));
   for (size_t j = 0; j < take; ++j) out_q[j] = cbh_match{(uint32_t)head[j], (int32_t)(head[j] >> 32)};
   return CBH_OK;

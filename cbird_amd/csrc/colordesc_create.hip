@@ -11,12 +11,9 @@
 //   k_cd_prepare   one workgroup per image, pixel-parallel: resize + mask + Luv (the gamma spline collapses into a
 //                  256-entry table because its input is an 8-bit value; the cube-root spline table sits in LDS),
 //                  ordered compaction of the samples that pass `l > 4`
-//   k_cd_cluster   ONE LANE PER IMAGE, a wave = 64 images whose sample / distance / label arrays are interleaved
-//                  (element i of the 64 images is contiguous: every load of the lock-step loops is one coalesced
-//                  768-byte or 256-byte access).  The 32 centres live in 96 VGPRs per lane; sums and counters, which
-//                  are indexed by a per-lane label, in LDS with the lane as the fastest index (conflict-free).
-// Throughput therefore comes from batch size (64 images per wave, one wave per SIMD once 65k images are in flight);
-// latency per image is what the sequential chains cost (~12M dependent double adds).
+//   k_cdw_*        the chain kernels (round 3, described below): the unit of parallelism is the CHAIN, not the image.
+//                  (Round 2's k_cd_cluster -- one lane per image for everything -- is in the history: r05's
+//                  "color_create_chains" 0.)
 #include <algorithm>
 #include <cfloat>
 #include <climits>
@@ -279,22 +276,14 @@ __device__ __forceinline__ int wave_incl_scan_i(int v) {
   return v;
 }
 
-// interleaved arrays of a group of 64 images: element i of image `lane`
-__device__ __forceinline__ size_t il_cap(size_t group, unsigned i, unsigned lane, unsigned cap) {
-  return (group * cap + i) * 64 + lane;
-}
-
-// PLANAR = false: the interleaved layout of k_cd_cluster (element i of the 64 images of a group contiguous);
-// PLANAR = true: per image three planes L[cap], U[cap], V[cap] at samples + 3 * cap * image (the chain kernels below)
-template <bool PLANAR>
+// per image three planes L[cap], U[cap], V[cap] at samples + 3 * cap * image
 __global__ __launch_bounds__(256) void k_cd_prepare(const CdImage* __restrict__ images,
                                                     const unsigned char* __restrict__ imgs, int channels,
                                                     const unsigned char* __restrict__ masks,
                                                     const CdTables* __restrict__ tabs,
-                                                    float* __restrict__ samples /* [group][i][lane][3] */,
+                                                    float* __restrict__ samples /* [image][3][cap] */,
                                                     unsigned* __restrict__ pos /* row << 16 | col */,
                                                     int* __restrict__ counts, unsigned cap /* samples per image slot */) {
-  auto il = [cap](size_t group, unsigned i, unsigned lane) { return il_cap(group, i, lane, cap); };
   __shared__ float s_cbrt[kTab * 4];
   __shared__ float s_gamma[256];
   __shared__ int s_xofs[256], s_yofs[256];
@@ -302,8 +291,6 @@ __global__ __launch_bounds__(256) void k_cd_prepare(const CdImage* __restrict__ 
   const int tid = (int)threadIdx.x;
   const unsigned img_i = blockIdx.x;
   const CdImage im = images[img_i];
-  const size_t group = img_i >> 6;
-  const unsigned lane = img_i & 63u;
   for (int i = tid; i < kTab * 4; i += 256) s_cbrt[i] = tabs->cbrt_tab[i];
   s_gamma[tid] = tabs->gamma_lut[tid];
   {
@@ -364,15 +351,9 @@ __global__ __launch_bounds__(256) void k_cd_prepare(const CdImage* __restrict__ 
     const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
     if (keep) {
       const unsigned idx = (unsigned)(n_out + base + incl - 1);
-      if (PLANAR) {
-        const size_t b = (size_t)img_i * cap;
-        samples[3 * b + idx] = L, samples[3 * b + cap + idx] = U, samples[3 * b + 2 * (size_t)cap + idx] = V;
-        pos[b + idx] = (unsigned)row << 16 | (unsigned)col;
-      } else {
-        const size_t o = il(group, idx, lane);
-        samples[3 * o] = L, samples[3 * o + 1] = U, samples[3 * o + 2] = V;
-        pos[o] = (unsigned)row << 16 | (unsigned)col;
-      }
+      const size_t b = (size_t)img_i * cap;
+      samples[3 * b + idx] = L, samples[3 * b + cap + idx] = U, samples[3 * b + 2 * (size_t)cap + idx] = V;
+      pos[b + idx] = (unsigned)row << 16 | (unsigned)col;
     }
     n_out += tot;
   }
@@ -401,339 +382,14 @@ __device__ __forceinline__ float dist3(float a0, float a1, float a2, float b0, f
   return d;
 }
 
-__global__ __launch_bounds__(64) void k_cd_cluster(const CdImage* __restrict__ images, unsigned n_images,
-                                                   const float* __restrict__ samples, const unsigned* __restrict__ pos,
-                                                   const int* __restrict__ counts, float* __restrict__ dists /* 4 slots */,
-                                                   unsigned char* __restrict__ labels,
-                                                   unsigned char* __restrict__ descs /* 258 per image */,
-                                                   unsigned char* __restrict__ ok, unsigned cap) {
-  auto il = [cap](size_t group, unsigned i, unsigned lane) { return il_cap(group, i, lane, cap); };
-  __shared__ float s_sum[3 * kK][64];  // centre sums; later: colour frequencies
-  __shared__ int s_cnt[kK][64];        // cluster sizes; later: representative centre of a colour key
-  const unsigned lane = threadIdx.x;
-  const size_t group = blockIdx.x;
-  const unsigned img_i = (unsigned)group * 64u + lane;
-  const bool live = img_i < n_images;
-  const int N = live ? counts[img_i] : 0;
-  const bool valid = N >= kK;  // "not enough colors": the reference returns without touching the descriptor
-  if (live) ok[img_i] = valid ? 1 : 0;
-  const int n = valid ? N : 0;
-  const size_t slot_stride = (size_t)gridDim.x * cap * 64;
-  auto S = [&](int i, float& a, float& b, float& c) {
-    const size_t o = 3 * il(group, (unsigned)i, lane);
-    a = samples[o], b = samples[o + 1], c = samples[o + 2];
-  };
-  // The loops below run one lane per image, so nothing hides a load but the lane's own next loads: every loop takes its
-  // elements in blocks of kB whose loads are all issued before the first element is consumed (the compiler cannot do
-  // that itself -- the stores to the per-lane distance slots may alias the loads as far as it knows).
-  constexpr int kB = 8;
-  auto SB = [&](int i0, int cnt, float* b0, float* b1, float* b2) {  // samples i0 .. i0+kB-1, clamped to cnt-1
-#pragma unroll
-    for (int u = 0; u < kB; ++u) S(min(i0 + u, cnt - 1), b0[u], b1[u], b2[u]);
-  };
-
-  float cx[kK], cy[kK], cz[kK];
-#pragma unroll
-  for (int k = 0; k < kK; ++k) cx[k] = cy[k] = cz[k] = 0.f;
-  Rng rng{0xffffffffull};  // RNG(): a fresh thread's generator (oracle header, (1))
-
-  // ---- generateCentersPP(data, centers, K, rng, 3)
-  {
-    // the four distance arrays of this lane as base pointers (element i at p[i * 64]): swapped, never re-derived
-    float* pd = dists + il(group, 0u, lane);
-    double sum0 = 0;
-    int c0 = n > 0 ? (int)(rng.next() % (unsigned)n) : 0;
-    float a0 = 0, a1 = 0, a2 = 0;
-    if (n > 0) S(c0, a0, a1, a2);
-    cx[0] = a0, cy[0] = a1, cz[0] = a2;
-    for (int i0 = 0; i0 < n; i0 += kB) {
-      float b0[kB], b1[kB], b2[kB];
-      SB(i0, n, b0, b1, b2);
-#pragma unroll
-      for (int u = 0; u < kB; ++u)
-        if (i0 + u < n) {
-          const float d = dist3(b0[u], b1[u], b2[u], a0, a1, a2);
-          pd[(size_t)(i0 + u) * 64] = d;
-          sum0 += d;
-        }
-    }
-    // One round = the reference's three trials.  Its `dist` array does not change inside a round and the generator is
-    // advanced by exactly two draws per trial whatever the trial finds, so the three trials share their passes: one
-    // walk over dist finds the three candidate centres (three running `p -= dist[i]`), one pass over the samples
-    // produces the three candidate distance arrays and their double sums -- each sum in index order, as the
-    // reference forms it; the first smallest sum wins (`s < bestSum` visits the trials in order).
-    float* pc0 = pd + slot_stride;  // the three candidate arrays (scalars: an indexed array would live in scratch)
-    float* pc1 = pd + 2 * slot_stride;
-    float* pc2 = pd + 3 * slot_stride;
-#pragma unroll 1
-    for (int k = 1; k < kK; ++k) {
-      double p[3], sj[3] = {0, 0, 0};
-      int ci[3];
-      bool found[3];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) p[j] = rng.real() * sum0, ci[j] = max(n - 1, 0), found[j] = false;
-      // for (i = 0; i < N-1; i++) if ((p -= dist[i]) <= 0) break;  ci = i
-      // (double-buffered: the next block's loads are issued before this block is consumed)
-      {
-        float dv[kB], nx[kB];
-#pragma unroll
-        for (int u = 0; u < kB; ++u) dv[u] = n > 0 ? pd[(size_t)min(u, n - 1) * 64] : 0.f;
-        for (int i0 = 0; i0 < n - 1 && !(found[0] && found[1] && found[2]); i0 += kB) {
-#pragma unroll
-          for (int u = 0; u < kB; ++u) nx[u] = pd[(size_t)min(i0 + kB + u, n - 1) * 64];
-#pragma unroll
-          for (int u = 0; u < kB; ++u)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-              if (!found[j] && i0 + u < n - 1 && (p[j] -= dv[u]) <= 0) found[j] = true, ci[j] = i0 + u;
-#pragma unroll
-          for (int u = 0; u < kB; ++u) dv[u] = nx[u];
-        }
-      }
-      float c0[3], c1[3], c2[3];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        c0[j] = c1[j] = c2[j] = 0.f;
-        if (n > 0) S(ci[j], c0[j], c1[j], c2[j]);
-      }
-      {
-        float b0[kB], b1[kB], b2[kB], old[kB], n0[kB], n1[kB], n2[kB], nold[kB];
-        if (n > 0) {
-          SB(0, n, b0, b1, b2);
-#pragma unroll
-          for (int u = 0; u < kB; ++u) old[u] = pd[(size_t)min(u, n - 1) * 64];
-        }
-        for (int i0 = 0; i0 < n; i0 += kB) {
-          SB(i0 + kB, n, n0, n1, n2);  // clamped to n - 1: the block after the last one re-reads the last sample
-#pragma unroll
-          for (int u = 0; u < kB; ++u) nold[u] = pd[(size_t)min(i0 + kB + u, n - 1) * 64];
-#pragma unroll
-          for (int u = 0; u < kB; ++u)
-            if (i0 + u < n) {
-#pragma unroll
-              for (int j = 0; j < 3; ++j) {
-                const float d = dist3(b0[u], b1[u], b2[u], c0[j], c1[j], c2[j]);
-                const float t = old[u] < d ? old[u] : d;  // std::min(d, dist[i])
-                (j == 0 ? pc0 : j == 1 ? pc1 : pc2)[(size_t)(i0 + u) * 64] = t;
-                sj[j] += t;
-              }
-            }
-#pragma unroll
-          for (int u = 0; u < kB; ++u) b0[u] = n0[u], b1[u] = n1[u], b2[u] = n2[u], old[u] = nold[u];
-        }
-      }
-      double bestSum = DBL_MAX;
-      int best = 0;
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        if (sj[j] < bestSum) bestSum = sj[j], best = j;
-      sum0 = bestSum;
-      {
-        // std::swap(dist, tdist): the winning candidate becomes dist, the old dist array a candidate slot
-        float* const t = pd;
-        if (best == 0) pd = pc0, pc0 = t;
-        else if (best == 1) pd = pc1, pc1 = t;
-        else pd = pc2, pc2 = t;
-      }
-      a0 = best == 0 ? c0[0] : best == 1 ? c0[1] : c0[2];
-      a1 = best == 0 ? c1[0] : best == 1 ? c1[1] : c1[2];
-      a2 = best == 0 ? c2[0] : best == 1 ? c2[1] : c2[2];
-      // centres are written through a switch-free path: k is uniform across the wave
-#pragma unroll
-      for (int kk = 1; kk < kK; ++kk)
-        if (kk == k) cx[kk] = a0, cy[kk] = a1, cz[kk] = a2;
-    }
-  }
-
-  // ---- the k-means loop (attempts = 1; epsilon = 10^2; at most 100 iterations).  Lanes finish after different
-  //      numbers of iterations: a finished lane (fin) keeps its labels and centres and runs zero-trip loops
-  bool fin = n == 0;
-  int iter = 0;
-  double max_center_shift = DBL_MAX;
-#pragma unroll 1
-  for (;;) {
-    if (iter > 0) {
-      const int nn = fin ? 0 : n;
-#pragma unroll
-      for (int k = 0; k < kK; ++k) s_sum[3 * k][lane] = s_sum[3 * k + 1][lane] = s_sum[3 * k + 2][lane] = 0.f, s_cnt[k][lane] = 0;
-      for (int i0 = 0; i0 < nn; i0 += kB) {
-        float b0[kB], b1[kB], b2[kB];
-        int lb[kB];
-        SB(i0, nn, b0, b1, b2);
-#pragma unroll
-        for (int u = 0; u < kB; ++u) lb[u] = labels[il(group, (unsigned)min(i0 + u, nn - 1), lane)];
-#pragma unroll
-        for (int u = 0; u < kB; ++u)
-          if (i0 + u < nn) {
-            const int k = lb[u];
-            s_sum[3 * k][lane] += b0[u], s_sum[3 * k + 1][lane] += b1[u], s_sum[3 * k + 2][lane] += b2[u];
-            s_cnt[k][lane]++;
-          }
-      }
-      if (!fin) {
-        max_center_shift = 0;
-#pragma unroll 1
-        for (int k = 0; k < kK; ++k) {
-          if (s_cnt[k][lane] != 0) continue;
-          // an empty cluster takes the point farthest from the centre of the biggest cluster
-          int max_k = 0;
-          for (int k1 = 1; k1 < kK; ++k1)
-            if (s_cnt[max_k][lane] < s_cnt[k1][lane]) max_k = k1;
-          const float scale = 1.f / s_cnt[max_k][lane];
-          const float t0 = s_sum[3 * max_k][lane] * scale, t1 = s_sum[3 * max_k + 1][lane] * scale,
-                      t2 = s_sum[3 * max_k + 2][lane] * scale;
-          double max_dist = 0;
-          int farthest_i = -1;
-          for (int i = 0; i < n; ++i) {
-            if (labels[il(group, (unsigned)i, lane)] != max_k) continue;
-            float b0, b1, b2;
-            S(i, b0, b1, b2);
-            const double dist = dist3(b0, b1, b2, t0, t1, t2);
-            if (max_dist <= dist) max_dist = dist, farthest_i = i;
-          }
-          s_cnt[max_k][lane]--;
-          s_cnt[k][lane]++;
-          labels[il(group, (unsigned)farthest_i, lane)] = (unsigned char)k;
-          float b0, b1, b2;
-          S(farthest_i, b0, b1, b2);
-          s_sum[3 * max_k][lane] -= b0, s_sum[3 * max_k + 1][lane] -= b1, s_sum[3 * max_k + 2][lane] -= b2;
-          s_sum[3 * k][lane] += b0, s_sum[3 * k + 1][lane] += b1, s_sum[3 * k + 2][lane] += b2;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < kK; ++k) {
-        const float scale = 1.f / s_cnt[k][lane];
-        const float n0 = s_sum[3 * k][lane] * scale, n1 = s_sum[3 * k + 1][lane] * scale, n2 = s_sum[3 * k + 2][lane] * scale;
-        double dist = 0, t = n0 - cx[k];
-        dist += t * t;
-        t = n1 - cy[k];
-        dist += t * t;
-        t = n2 - cz[k];
-        dist += t * t;
-        if (!fin) {
-          max_center_shift = fmax(max_center_shift, dist);
-          cx[k] = n0, cy[k] = n1, cz[k] = n2;
-        }
-      }
-    }
-    if (!fin) {
-      ++iter;
-      fin = iter == 100 || max_center_shift <= 100.0;  // ++iter == MAX(maxCount, 2) || shift <= epsilon^2
-    }
-    if (__all(fin)) break;
-    const int na = fin ? 0 : n;
-    // assign labels (KMeansDistanceComputer)
-    for (int i0 = 0; i0 < na; i0 += kB) {
-      float b0[kB], b1[kB], b2[kB];
-      SB(i0, na, b0, b1, b2);
-#pragma unroll
-      for (int u = 0; u < kB; ++u)
-        if (i0 + u < na) {
-          int k_best = 0;
-          float min_dist = FLT_MAX;  // the reference compares in double; the distances are floats, so the order is the same
-          bool first = true;
-#pragma unroll
-          for (int k = 0; k < kK; ++k) {
-            const float dist = dist3(b0[u], b1[u], b2[u], cx[k], cy[k], cz[k]);
-            if (first || min_dist > dist) min_dist = dist, k_best = k, first = false;
-          }
-          labels[il(group, (unsigned)(i0 + u), lane)] = (unsigned char)k_best;
-        }
-    }
-  }
-
-  // ---- colour frequencies (cvutil.cpp:903-989) and the descriptor (:1016-1060)
-  if (!valid) {
-    if (live)  // "not enough colors": the reference leaves the caller's (cleared) descriptor alone
-      for (int b = 0; b < 258; ++b) descs[(size_t)img_i * 258 + b] = 0;
-    return;
-  }
-  const CdImage im = images[img_i];
-  unsigned long long key[kK];
-#pragma unroll
-  for (int k = 0; k < kK; ++k) {
-    auto clamp16 = [](int v) {
-      v &= -(v >= 0);
-      return v | ((65535 - v) >> 31);
-    };
-    const unsigned l = (unsigned)clamp16((int)(65535 / 100.0f * cx[k])) & 0xFFFFu;
-    const unsigned u = (unsigned)clamp16((int)(65535 / 354.0f * (cy[k] + 134.0f))) & 0xFFFFu;
-    const unsigned v = (unsigned)clamp16((int)(65535 / 262.0f * (cz[k] + 140.0f))) & 0xFFFFu;
-    key[k] = (unsigned long long)l << 32 | (unsigned long long)u << 16 | (unsigned long long)v;
-  }
-  // centres that compress to the same colour share one frequency (the reference's QHash is keyed by the colour)
-#pragma unroll
-  for (int k = 0; k < kK; ++k) {
-    int rep = k;
-#pragma unroll
-    for (int j = kK - 1; j >= 0; --j)
-      if (j < k && key[j] == key[k]) rep = j;
-    s_cnt[k][lane] = rep;
-    s_sum[k][lane] = 0.f;
-  }
-  float maxDistFromCenter;
-  {
-    const float dx = im.cols / 2.0f, dy = im.rows / 2.0f;
-    maxDistFromCenter = sqrtf(dx * dx + dy * dy);
-  }
-  unsigned present = 0;  // a colour exists in the reference's hash only if some sample carried it
-  for (int i0 = 0; i0 < N; i0 += kB) {
-    int lb[kB];
-    unsigned pv[kB];
-#pragma unroll
-    for (int u = 0; u < kB; ++u) {
-      const size_t o = il(group, (unsigned)min(i0 + u, N - 1), lane);
-      lb[u] = labels[o], pv[u] = pos[o];
-    }
-#pragma unroll
-    for (int u = 0; u < kB; ++u)
-      if (i0 + u < N) {
-        const int rep = s_cnt[lb[u]][lane];
-        const int dx = (int)(pv[u] & 0xFFFFu) - im.cols / 2, dy = (int)(pv[u] >> 16) - im.rows / 2;
-        const float dist = sqrtf((float)(dx * dx + dy * dy));
-        s_sum[rep][lane] += (maxDistFromCenter - dist) / maxDistFromCenter;
-        present |= 1u << rep;
-      }
-  }
-  float maxFreq = 0;
-#pragma unroll
-  for (int k = 0; k < kK; ++k)
-    if (present >> k & 1u) maxFreq = fmaxf(maxFreq, s_sum[k][lane]);
-  unsigned char* __restrict__ out = descs + (size_t)img_i * 258;
-  for (int b = 0; b < 258; ++b) out[b] = 0;
-  unsigned left = present;
-  int di = 0;
-  while (left) {
-    int best = -1;
-#pragma unroll
-    for (int k = 0; k < kK; ++k) {
-      if (!(left >> k & 1u)) continue;
-      if (best < 0) {
-        best = k;
-        continue;
-      }
-      const float fk = s_sum[k][lane], fb = s_sum[best][lane];
-      if (fk > fb || (fk == fb && key[k] < key[best])) best = k;
-    }
-    left &= ~(1u << best);
-    const unsigned long long kk = key[best];
-    const unsigned short l = (unsigned short)((kk >> 32) & 0xFFFF), u = (unsigned short)((kk >> 16) & 0xFFFF),
-                         v = (unsigned short)(kk & 0xFFFF);
-    const unsigned short wv = (unsigned short)((int)(s_sum[best][lane] * 65535 / maxFreq) & 0xFFFF);
-    unsigned short* __restrict__ o16 = reinterpret_cast<unsigned short*>(out + di * 8);
-    o16[0] = l, o16[1] = u, o16[2] = v, o16[3] = wv;
-    out[256] = (unsigned char)di;  // desc.numColors = descIndex, the index of the last colour (cvutil.cpp:1035)
-    ++di;
-  }
-}
 
 
 // ====================================================================================================================
-// Round 3: the same arithmetic as k_cd_cluster, reorganised so that an image no longer waits on one lane's loads.
+// Round 3: an image no longer waits on one lane's loads.
 //
 // What cannot change: every sum of the reference is a rounded sequential chain -- `s += tdist2[i]` and `p -= dist[i]`
 // in double over all samples (k-means++ seeding: 3 candidate sums + 3 walks per round, 31 rounds), the centre sums and
-// the colour frequencies in float in sample order.  k_cd_cluster ran ALL of an image's work, the embarrassingly parallel
+// the colour frequencies in float in sample order.  Round 2 ran ALL of an image's work, the embarrassingly parallel
 // distance evaluations included, on the one lane that owned its chains: 0.43 s of latency for anything up to 4096
 // images.  Here the unit of parallelism is the CHAIN, not the image:
 //   * a lane owns one chain and streams its inputs with 16-byte loads, four blocks ahead (the loads do not depend on the
@@ -746,8 +402,8 @@ __global__ __launch_bounds__(64) void k_cd_cluster(const CdImage* __restrict__ i
 //     32 lanes of an image read the same sample and add it or +0.0f (x + 0 is exact), so the per-cluster sums keep
 //     sample order without a partition; empty clusters, new centres and the shift test by a lane per image;
 //   * colour frequencies: per-sample weights in parallel, then lane (image, colour) chains like the centre sums.
-// Per-image state lives in CdW (global memory) between the launches.  Results are k_cd_cluster's, byte for byte
-// (tests/test_color_create.py runs both against oracle/colordesc_oracle.c; knob "color_create_chains").
+// Per-image state lives in CdW (global memory) between the launches (tests/test_color_create.py: byte for byte
+// oracle/colordesc_oracle.c's).
 // ====================================================================================================================
 struct CdW {
   unsigned long long rng;
@@ -1246,14 +902,12 @@ __global__ __launch_bounds__(64) void k_cdw_finish(const CdW* __restrict__ W, un
   }
 }
 
-int g_cd_group = 0;   // "color_create_group": images per wave of k_cdw_round (0 = from the batch size)
 // "color_create_chunk_mb": scratch one launch may take.  The sample / distance / position / label planes cost 33 bytes per
 // sample slot = 1.6 MB per 256 x 192 image, so a batch is worked off in chunks of that many images (19 000 at the default
 // of 32 GiB; the rate is flat from ~16 000 images on) and every chunk reuses the blocks of the one before: 100 000 images
 // took 150 GB of scratch in one piece -- above any budget the arena keeps cached, so every call mapped it afresh
 // (4-6 s per call against 0.9 s in chunks, tools/ab/color_create_pool.py).
 int g_cd_chunk_mb = 32768;
-int g_cd_chains = 1;  // "color_create_chains": 1 = the chain kernels above (default), 0 = k_cd_cluster (lane per image)
 
 }  // namespace
 
@@ -1280,13 +934,10 @@ static int launch_color_descriptors_chunk(const uint8_t* d_imgs, size_t n, const
     }
     im.mask_off = it->second;
   }
-  const size_t groups = (n + 63) / 64;
   unsigned cap = 64;
   for (const CdImage& im : images) cap = std::max(cap, (unsigned)(im.cols * im.rows));  // <= kMaxSamples
   cap = (cap + 63u) & ~63u;  // (planes start on 16-byte boundaries and can be read four samples at a time)
-  const bool chains = g_cd_chains != 0;
-  const size_t per_group = (size_t)cap * 64;
-  const size_t slots = chains ? n * (size_t)cap : groups * per_group;  // sample slots in every array
+  const size_t slots = n * (size_t)cap;  // sample slots in every array
   CdImage* d_images = nullptr;
   uint8_t *d_masks = nullptr, *d_labels = nullptr;
   CdTables* d_tabs = nullptr;
@@ -1308,32 +959,23 @@ static int launch_color_descriptors_chunk(const uint8_t* d_imgs, size_t n, const
   alloc((void**)&d_pos, slots * sizeof(unsigned));
   alloc((void**)&d_labels, slots);
   alloc((void**)&d_counts, n * sizeof(int));
-  if (chains) {
-    alloc((void**)&d_w, n * sizeof(CdW));
-    alloc((void**)&d_unfinished, sizeof(unsigned));
-    if (e == hipSuccess) e = hipHostMalloc(&h_unfinished, sizeof(unsigned));
-  }
+  alloc((void**)&d_w, n * sizeof(CdW));
+  alloc((void**)&d_unfinished, sizeof(unsigned));
+  if (e == hipSuccess) e = hipHostMalloc(&h_unfinished, sizeof(unsigned));
   int rc = CBH_OK;
   if (e == hipSuccess) e = hipMemcpyAsync(d_images, images.data(), n * sizeof(CdImage), hipMemcpyHostToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(d_masks, masks.data(), masks.size(), hipMemcpyHostToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(d_tabs, &tables(), sizeof(CdTables), hipMemcpyHostToDevice, s);
-  if (e == hipSuccess && !chains) {
-    hipLaunchKernelGGL(k_cd_prepare<false>, dim3((unsigned)n), dim3(256), 0, s, d_images, d_imgs, channels, d_masks,
-                       d_tabs, d_samples, d_pos, d_counts, cap);
-    hipLaunchKernelGGL(k_cd_cluster, dim3((unsigned)groups), dim3(64), 0, s, d_images, (unsigned)n, d_samples, d_pos,
-                       d_counts, d_dists, d_labels, d_descs, d_ok, cap);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess && chains) {
+  if (e == hipSuccess) {
     const unsigned ni = (unsigned)n;
     const size_t slot_stride = slots;  // floats between two distance slots
-    hipLaunchKernelGGL(k_cd_prepare<true>, dim3(ni), dim3(256), 0, s, d_images, d_imgs, channels, d_masks, d_tabs,
+    hipLaunchKernelGGL(k_cd_prepare, dim3(ni), dim3(256), 0, s, d_images, d_imgs, channels, d_masks, d_tabs,
                        d_samples, d_pos, d_counts, cap);
     hipLaunchKernelGGL(k_cdw_init, dim3((ni + 255) / 256), dim3(256), 0, s, d_w, d_counts, ni, d_ok, d_descs);
     // images per wave: two waves per SIMD while the batch allows it (measured at 4096 images: 1 / 2 / 4 / 8 / 16 images
     // per wave = 76 / 60 / 68 / 88 / 131 ms -- the chain phases of one wave hide behind the produce phase of the
     // other), at most 21 (63 chain lanes); a large batch is bound by the HBM traffic of the distance arrays instead
-    const unsigned want = g_cd_group > 0 ? (unsigned)g_cd_group : (ni + 2047) / 2048;
+    const unsigned want = (ni + 2047) / 2048;
     const int G = want <= 1 ? 1 : want <= 2 ? 2 : want <= 4 ? 4 : want <= 8 ? 8 : want <= 16 ? 16 : 21;
     for (int round = 0; round < kK; ++round) {  // generateCentersPP: centre 0, then 31 rounds of three trials
 #define CBH_ROUND(GG)                                                                                                 \
@@ -1410,8 +1052,7 @@ int launch_color_descriptors(const uint8_t* d_imgs, size_t n, const uint64_t* im
 void set_cd_chunk_mb(int v) {
   if (v > 0) g_cd_chunk_mb = v;
 }
-void set_cd_chains(int v) { g_cd_chains = v; }
-void set_cd_group(int v) { g_cd_group = v; }
+
 
 void color_ellipse_mask(int cols, int rows, uint8_t* mask) { ellipse_mask(cols, rows, mask); }
 

@@ -39,12 +39,8 @@ namespace {
 constexpr int kThreads = 256;
 
 struct DctTables {
-  float C[9 * 32];
   unsigned char zz[64];  // zig-zag positions 6..69 -> index into the 9x9 block (row*9+col)
-  // stage 3/5 variant (tuning knob "hash_dct"): 1 = cv::dct / cv::sum as OpenCV 2.4 evaluates them (cv_dct32_dev.h,
-  // the default), 0 = the canonical 9x32 matrix form with a fixed fmaf order.  One device copy of the tables per variant.
-  int variant;
-  CvDct32Tabs cv;
+  CvDct32Tabs cv;        // stages 3 / 5: cv::dct / cv::sum as OpenCV 2.4 evaluates them (cv_dct32_dev.h)
 };
 
 __device__ __forceinline__ int reflect101(int p, int len) {
@@ -56,20 +52,17 @@ __device__ __forceinline__ int reflect101(int p, int len) {
   return p;
 }
 
-// stages 3-6 from a 32x32 u8 tile in LDS; all 256 threads of the workgroup participate (kThreads == 256).  tile and
-// sC must be 16-byte aligned.  The arithmetic (and its order) is orc_hash_from_tile32's: row pass fmaf over j
-// ascending, column pass fmaf over r ascending, the 64 selected coefficients summed in double in index order.
+// stages 3-6 from a 32x32 u8 tile in LDS, called by all 256 threads of a workgroup (wave 0 works); tile must be 16-byte
+// aligned.  cv::dct as OpenCV 2.4 evaluates it (cv_dct32_dev.h): 32 row transforms on the lanes of wave 0, then the nine
+// column transforms; cv::sum's grouping for the threshold.
 __device__ __forceinline__ void hash_from_tile(const unsigned char* __restrict__ tile /*LDS*/,
-                                               const float* __restrict__ sC /*LDS 288*/,
                                                const unsigned char* __restrict__ sZ /*LDS 64*/,
                                                float* __restrict__ sT /*LDS 288*/,
                                                float* __restrict__ sY /*LDS 81*/,
                                                uint64_t* __restrict__ out,
                                                const DctTables* __restrict__ tabs) {
   const int tid = threadIdx.x;
-  if (tabs->variant) {
-    // cv::dct as OpenCV 2.4 evaluates it (cv_dct32_dev.h): 32 row transforms on the lanes of wave 0, then the nine
-    // column transforms; cv::sum's grouping for the threshold.  Same barriers as the canonical branch.
+  {
     if (tid < 32) {
       const uint4* trow = reinterpret_cast<const uint4*>(tile + tid * 32);
       const uint4 p0 = trow[0], p1 = trow[1];
@@ -102,147 +95,59 @@ __device__ __forceinline__ void hash_from_tile(const unsigned char* __restrict__
       const unsigned long long b = __ballot(tid >= 1 && c > thr);
       if (tid == 0) *out = b ? b : 1ull;
     }
-    return;
   }
+}
+
+
+
+
+typedef float f32_lds __attribute__((may_alias));
+// stages 3-6 for one image per HALF-WAVE (both halves of a wave work on their own image): tile = the image's 32 x 32 bytes
+// in LDS, sT / sY = 288 / 84 floats of LDS of its own.  Lane l32 = lane & 31: row transform of tile row l32, then the nine
+// column transforms, then selected coefficients l32 and 32 + l32; the threshold's double sum in cv::sum's grouping runs
+// on lane broadcasts for both images of the wave at once.  Every lane of the workgroup must call it (two barriers
+// inside); returns the hash (valid in every lane of the half-wave).
+__device__ __forceinline__ unsigned long long hash_halfwave(const unsigned char* tile, f32_lds* sT, f32_lds* sY,
+                                                            const DctTables* __restrict__ tabs, int lane) {
+  const int l32 = lane & 31, hw = (lane >> 5) & 1;
   {
-    // row pass, 288 outputs (r,k): lane -> row r = tid/8 and k = tid%8; the lanes with k == 0 also do k = 8.
-    // The row's 32 pixels arrive as two 16-byte LDS reads, the basis row as eight.
-    const int r = tid >> 3, k = tid & 7;
-    const uint4* trow = reinterpret_cast<const uint4*>(tile + r * 32);
-    const uint4 p0 = trow[0], p1 = trow[1];
-    const unsigned px[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-    const float4* ck = reinterpret_cast<const float4*>(sC + k * 32);
-    float acc = 0.f;
+    float x[32], y[9];
+    const uint4* trow = reinterpret_cast<const uint4*>(tile + l32 * 32);
+    const uint4 a = trow[0], b = trow[1];
+    const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const float4 c = ck[q];
-      acc = __builtin_fmaf((float)(px[q] & 0xffu), c.x, acc);
-      acc = __builtin_fmaf((float)((px[q] >> 8) & 0xffu), c.y, acc);
-      acc = __builtin_fmaf((float)((px[q] >> 16) & 0xffu), c.z, acc);
-      acc = __builtin_fmaf((float)(px[q] >> 24), c.w, acc);
+    for (int i = 0; i < 8; ++i) {
+      x[4 * i + 0] = (float)(w[i] & 0xffu);
+      x[4 * i + 1] = (float)((w[i] >> 8) & 0xffu);
+      x[4 * i + 2] = (float)((w[i] >> 16) & 0xffu);
+      x[4 * i + 3] = (float)(w[i] >> 24);
     }
-    sT[r * 9 + k] = acc;
-    if (k == 0) {
-      const float4* c8 = reinterpret_cast<const float4*>(sC + 8 * 32);
-      float acc8 = 0.f;
+    cvdct::dct32_first9(x, &tabs->cv, y);  // cv::dct's own evaluation (cv_dct32_dev.h)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float4 c = c8[q];
-        acc8 = __builtin_fmaf((float)(px[q] & 0xffu), c.x, acc8);
-        acc8 = __builtin_fmaf((float)((px[q] >> 8) & 0xffu), c.y, acc8);
-        acc8 = __builtin_fmaf((float)((px[q] >> 16) & 0xffu), c.z, acc8);
-        acc8 = __builtin_fmaf((float)(px[q] >> 24), c.w, acc8);
-      }
-      sT[r * 9 + 8] = acc8;
-    }
+    for (int k = 0; k < 9; ++k) sT[l32 * 9 + k] = y[k];
   }
   __syncthreads();
-  if (tid < 81) {
-    const int u = tid / 9, k = tid - u * 9;
-    const float4* cu = reinterpret_cast<const float4*>(sC + u * 32);
-    float acc = 0.f;
+  if (l32 < 9) {  // nine column transforms per image
+    float x[32], y[9];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const float4 c = cu[q];
-      acc = __builtin_fmaf(c.x, sT[(4 * q) * 9 + k], acc);
-      acc = __builtin_fmaf(c.y, sT[(4 * q + 1) * 9 + k], acc);
-      acc = __builtin_fmaf(c.z, sT[(4 * q + 2) * 9 + k], acc);
-      acc = __builtin_fmaf(c.w, sT[(4 * q + 3) * 9 + k], acc);
-    }
-    sY[tid] = acc;
+    for (int r = 0; r < 32; ++r) x[r] = sT[r * 9 + l32];
+    cvdct::dct32_first9(x, &tabs->cv, y);
+#pragma unroll
+    for (int u = 0; u < 9; ++u) sY[u * 9 + l32] = y[u];
   }
   __syncthreads();
-  if (tid < 64) {  // wave 0: lane i holds selected coefficient i; the ordered double sum runs on broadcast lanes
-    const float c = sY[sZ[tid]];
-    const int cb = __builtin_bit_cast(int, c);
-    double sum = 0.0;
-#pragma unroll
-    for (int i = 0; i < 64; ++i) sum += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(cb, i));
-    const float thr = (float)sum / 64;
-    const unsigned long long b = __ballot(tid >= 1 && c > thr);
-    if (tid == 0) *out = b ? b : 1ull;
-  }
+  const float c0 = sY[tabs->zz[l32]];
+  const float c1 = sY[tabs->zz[l32 + 32]];
+  const int cb0 = __builtin_bit_cast(int, c0), cb1 = __builtin_bit_cast(int, c1);
+  const double sumA = cvdct::sum64_halfwave(cb0, cb1, 0), sumB = cvdct::sum64_halfwave(cb0, cb1, 32);
+  const float thr = (float)(hw ? sumB : sumA) / 64;
+  const unsigned long long b0 = __ballot(c0 > thr);
+  const unsigned long long b1 = __ballot(c1 > thr);
+  const int sh = hw * 32;
+  unsigned long long hv = ((b0 >> sh) & 0xffffffffull) | (((b1 >> sh) & 0xffffffffull) << 32);
+  hv &= ~1ull;  // bit 0 is never encoded (cvutil.cpp:537)
+  return hv == 0 ? 1ull : hv;
 }
-
-
-template <int K>
-__global__ __launch_bounds__(kThreads) void k_dcthash_generic(
-    const unsigned char* __restrict__ imgs, int w, int h, size_t row_stride, size_t img_stride,
-    const DctTables* __restrict__ tabs, uint64_t* __restrict__ out,
-    unsigned char* __restrict__ tiles) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int R = K / 2;
-  const int sx = w / 32, sy = h / 32;
-  const int band = sy + 2 * R;
-  // LDS carve-up
-  float* sC = reinterpret_cast<float*>(smem);                 // 288 f32
-  float* sT = sC + 288;                                        // 288 f32
-  float* sY = sT + 288;                                        // 81 f32 (+3 pad)
-  float* sThr = sY + 84;                                       // (unused, keeps the carve-up)
-  unsigned int* colsum = reinterpret_cast<unsigned int*>(sThr + 4);  // w u32
-  unsigned char* tile = reinterpret_cast<unsigned char*>(colsum + w);  // 1024 u8
-  unsigned char* sZ = tile + 1024;                                      // 64 u8
-  unsigned short* hs = reinterpret_cast<unsigned short*>(sZ + 64);     // band*w u16
-  unsigned char* raw = reinterpret_cast<unsigned char*>(hs + (size_t)band * w);  // band*w u8
-
-  const int tid = threadIdx.x;
-  const unsigned char* img = imgs + (size_t)blockIdx.x * img_stride;
-  for (int i = tid; i < 288; i += kThreads) sC[i] = tabs->C[i];
-  if (tid < 64) sZ[tid] = tabs->zz[tid];
-
-  if constexpr (K == 0) {
-    // area <= 32*32 with w,h multiples of 32 means exactly 32x32: no blur, resize is a no-op
-    for (int i = tid; i < 1024; i += kThreads) tile[i] = img[(size_t)(i >> 5) * row_stride + (i & 31)];
-    __syncthreads();
-  } else {
-    const bool two = (sx == 2 && sy == 2);
-    const float scale = 1.f / (float)(sx * sy);
-    for (int oy = 0; oy < 32; ++oy) {
-      __syncthreads();
-      // P0: raw band rows -> LDS
-      for (int i = tid; i < band * w; i += kThreads) {
-        const int b = i / w, x = i - b * w;
-        const int ry = reflect101(oy * sy - R + b, h);
-        raw[i] = img[(size_t)ry * row_stride + x];
-      }
-      __syncthreads();
-      // P1: horizontal K-sums
-      for (int i = tid; i < band * w; i += kThreads) {
-        const int b = i / w, x = i - b * w;
-        unsigned int s = 0;
-#pragma unroll
-        for (int dx = -R; dx <= R; ++dx) s += raw[b * w + reflect101(x + dx, w)];
-        hs[i] = (unsigned short)s;
-      }
-      __syncthreads();
-      // P2: vertical K-sums, divide, accumulate the sy blurred rows of this band per column
-      for (int x = tid; x < w; x += kThreads) {
-        unsigned int s = 0;
-#pragma unroll
-        for (int t = 0; t < K; ++t) s += hs[t * w + x];
-        unsigned int acc = 0;
-        for (int j = 0; j < sy; ++j) {
-          acc += (2u * s + (unsigned)(K * K)) / (2u * (unsigned)(K * K));
-          if (j + 1 < sy) s += (unsigned)hs[(j + K) * w + x] - (unsigned)hs[j * w + x];
-        }
-        colsum[x] = acc;
-      }
-      __syncthreads();
-      // P3: sx adjacent columns -> one output pixel, INTER_AREA rounding
-      if (tid < 32) {
-        unsigned int s = 0;
-        for (int dx = 0; dx < sx; ++dx) s += colsum[tid * sx + dx];
-        unsigned int v = two ? (s + 2u) >> 2 : (unsigned int)__builtin_rintf((float)s * scale);
-        tile[oy * 32 + tid] = (unsigned char)(v > 255u ? 255u : v);
-      }
-    }
-    __syncthreads();
-  }
-  if (tiles)
-    for (int i = tid; i < 1024; i += kThreads) tiles[(size_t)blockIdx.x * 1024 + i] = tile[i];
-  hash_from_tile(tile, sC, sZ, sT, sY, out + blockIdx.x, tabs);
-}
-
 
 // ---------------------------------------------------------------------------------------------
 // k_dcthash_256: the BASELINE configuration (256x256 tiles: 7x7 blur, 8x8 area mean).
@@ -278,27 +183,11 @@ __device__ __forceinline__ unsigned add_byte3(unsigned acc, unsigned p) {
   return r;
 }
 
-// u16 half of a dword -> f32 in one VALU op (SDWA word select)
-__device__ __forceinline__ float cvt_f32_word0(unsigned p) {
-  float r;
-  asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(r) : "v"(p));
-  return r;
-}
-__device__ __forceinline__ float cvt_f32_word1(unsigned p) {
-  float r;
-  asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(p));
-  return r;
-}
-
-// DIV selects how nearest(S/49) is formed and summed over the 8x8 cell (both exact):
-//   0  integer: ((S+24) * 342393) >> 24 with v_mul_u32_u24_sdwa + v_add_u32_sdwa BYTE_3 -- two "complex" VALU ops per
-//      pixel (ops that only the full VALU pipe executes, ~4.3 cycles per wave each);
-//   1  float magic number: r = fma(float(S), 1/49, 1.5*2^23) is 1.5*2^23 + nearest(S/49) exactly (ulp 1 in that binade;
-//      k/49 is never within 0.0102 of a tie and the product's error is < 2e-5), so the BIT PATTERN of r is
-//      0x4B400000 + quotient: one complex op (the u16 -> f32 convert) + two simple ones (v_fma_f32, v_add_u32 of the
-//      bit patterns; the 64 x 0x4B400000 of a cell leave mod 2^32 at the end).  Measured 4 % SLOWER than form 0
-//      (tools/ab/hash_sweep.py): simple ops cost ~2.15 cycles per wave, complex ~4.3, and they add.
-template <bool DUMP, int DCT, int DIV>
+// nearest(S/49) is formed and summed over the 8x8 cell as an integer: ((S+24) * 342393) >> 24 with v_mul_u32_u24_sdwa +
+// v_add_u32_sdwa BYTE_3 -- two "complex" VALU ops per pixel.  (Float forms -- a magic-number fma per pixel, and the one
+// fma per pixel on 0x4B000000 + S that k_dcthash_256_band uses -- were built for THIS kernel too: exact, and 4 % slower
+// here: simple ops cost ~2.15 cycles per wave, complex ~4.3, and they add.  r05's "hash_div" 1-3.)
+template <bool DUMP>
 __global__ __launch_bounds__(kThreads) void k_dcthash_256(
     const unsigned char* __restrict__ imgs, unsigned n, unsigned row_stride, unsigned img_stride,
     const DctTables* __restrict__ tabs, uint64_t* __restrict__ out,
@@ -306,13 +195,11 @@ __global__ __launch_bounds__(kThreads) void k_dcthash_256(
   __shared__ __attribute__((aligned(16))) unsigned char sTile[8][1024];
   __shared__ float sT[8][288];
   __shared__ float sY[8][84];
-  __shared__ float sC[9 * 33];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int l32 = lane & 31;
   const int slot = tid >> 5;  // image within the workgroup, 0..7
-  for (int i = tid; i < 288; i += kThreads) sC[(i >> 5) * 33 + (i & 31)] = tabs->C[i];
 
   const unsigned first = blockIdx.x * 8u;
   unsigned img = first + (unsigned)slot;
@@ -329,18 +216,15 @@ __global__ __launch_bounds__(kThreads) void k_dcthash_256(
   const unsigned selR = l32 == 31 ? 0x00000102u : 0x07060504u;  // lane 31: (px254,px253,px252,x)
 
   uint2 raw[7];
-  // DIV == 3 keeps the eight column sums of a lane unpacked (32 bits each, in the float form 0x4B000000 + S of DIV 2):
-  // twice the ring registers and ring additions, but no packing and no field extraction
-  constexpr int NR = DIV == 3 ? 8 : 4;
-  unsigned ring[7][NR];
-  unsigned S[NR];
+  unsigned ring[7][4];
+  unsigned S[4];
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
 #pragma unroll
-    for (int c = 0; c < NR; ++c) ring[j][c] = 0u;
+    for (int c = 0; c < 4; ++c) ring[j][c] = 0u;
   }
 #pragma unroll
-  for (int c = 0; c < NR; ++c) S[c] = DIV == 3 ? 0x4B000000u : DIV ? 0u : (24u | (24u << 16));
+  for (int c = 0; c < 4; ++c) S[c] = 24u | (24u << 16);
   unsigned acc = 0;
 
   // virtual row s-3 -> REFLECT_101 source row; steps past the image (s > 261) re-read row 252,
@@ -381,66 +265,21 @@ __global__ __launch_bounds__(kThreads) void k_dcthash_256(
       const unsigned H5 = udot4(D0, 0x01010000u, udot4(DR, 0x00000001u, T1));
       const unsigned H6 = udot4(D0, 0x01000000u, udot4(DR, 0x00000101u, T1));
       const unsigned H7 = udot4(DR, 0x00010101u, T1);
-      if constexpr (DIV == 3) {
-        const unsigned Hs[8] = {H0, H1, H2, H3, H4, H5, H6, H7};
+      const unsigned P[4] = {H0 | (H1 << 16), H2 | (H3 << 16), H4 | (H5 << 16), H6 | (H7 << 16)};
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          S[c] = (S[c] - ring[j][c]) + Hs[c];
-          ring[j][c] = Hs[c];
-        }
-      } else {
-        const unsigned P[4] = {H0 | (H1 << 16), H2 | (H3 << 16), H4 | (H5 << 16), H6 | (H7 << 16)};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          S[c] = (S[c] - ring[j][c]) + P[c];
-          ring[j][c] = P[c];
-        }
+      for (int c = 0; c < 4; ++c) {
+        S[c] = (S[c] - ring[j][c]) + P[c];
+        ring[j][c] = P[c];
       }
       // output row y = s - 6 (garbage for s < 6: acc is reset before the first real row)
       if (s == 6) acc = 0;
-      if constexpr (DIV == 3) {
-        float kC = 42799.0f / 2097152.0f;
-        asm volatile("" : "+v"(kC));
-        float f = 8388608.0f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) f = __builtin_fmaf(__builtin_bit_cast(float, S[c]), kC, f);
-        acc += __builtin_bit_cast(unsigned, f);
-      } else if constexpr (DIV == 2) {
-        // one fused multiply-add per pixel divides, rounds and accumulates: 0x4B000000 | S is the float 2^23 + S, and
-        // with c = 42799 * 2^-21 (within 5e-7 of 1/49) the product (2^23 + S) * c = 171196 + S * c is exact inside
-        // the fma; added to an integer-valued accumulator below 2^24 the single rounding is to the nearest integer,
-        // which is nearest(S / 49) for every S <= 12495 (S * c stays 0.0100 away from a tie; checked exhaustively in
-        // tests/test_golden_hash_stages.py).  A chain runs over the lane's 8 pixels of a row (8 * 171196 + 8 * 255 keeps
-        // it below 2^24), its bit pattern joins the cell's integer sum.
-        float kC = 42799.0f / 2097152.0f;
-        asm volatile("" : "+v"(kC));  // a VGPR operand: a 32-bit literal would double the instruction's size
-        float f = 8388608.0f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const unsigned lo = (S[c] & 0xffffu) | 0x4B000000u;                          // v_and_or_b32
-          const unsigned hi = __builtin_amdgcn_alignbit(0x4B00u, S[c], 16);            // 0x4B000000 | (S >> 16)
-          f = __builtin_fmaf(__builtin_bit_cast(float, lo), kC, f);
-          f = __builtin_fmaf(__builtin_bit_cast(float, hi), kC, f);
-        }
-        acc += __builtin_bit_cast(unsigned, f);
-      } else if constexpr (DIV == 1) {
-        constexpr float k49 = 1.0f / 49.0f, kMagic = 12582912.0f;  // 1.5 * 2^23 = 0x4B400000
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          acc += __builtin_bit_cast(unsigned, __builtin_fmaf(cvt_f32_word0(S[c]), k49, kMagic));
-          acc += __builtin_bit_cast(unsigned, __builtin_fmaf(cvt_f32_word1(S[c]), k49, kMagic));
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          acc = add_byte3(acc, (S[c] & 0xffffu) * 342393u);  // operands < 2^24 -> v_mul_u32_u24
-          acc = add_byte3(acc, (S[c] >> 16) * 342393u);
-        }
+      for (int c = 0; c < 4; ++c) {
+        acc = add_byte3(acc, (S[c] & 0xffffu) * 342393u);  // operands < 2^24 -> v_mul_u32_u24
+        acc = add_byte3(acc, (S[c] >> 16) * 342393u);
       }
       const int y = s - 6;
       if (y >= 0 && (y & 7) == 7) {
-        if constexpr (DIV == 1) acc -= 0xD0000000u;  // 64 x 0x4B400000 mod 2^32
-        if constexpr (DIV >= 2) acc -= 8u * (0x4B000000u + 8u * 171196u);  // 8 row chains: 2^23 and 8 x 171196 each
         const unsigned t = (acc + 31u + ((acc >> 6) & 1u)) >> 6;  // /64, half to even
         if (y < 256) sTile[slot][(y >> 3) * 32 + l32] = (unsigned char)t;
         acc = 0;
@@ -455,87 +294,9 @@ __global__ __launch_bounds__(kThreads) void k_dcthash_256(
             reinterpret_cast<const unsigned*>(sTile[slot])[i];
   }
 
-  // ---- stage 3, row pass: lane = tile row r; T[r][k] = sum_j fmaf(X[r][j], C[k][j], .)
-  {
-    float x[32];
-    const uint4* trow = reinterpret_cast<const uint4*>(&sTile[slot][l32 * 32]);
-    const uint4 a = trow[0], b = trow[1];
-    const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      x[4 * i + 0] = (float)(w[i] & 0xffu);
-      x[4 * i + 1] = (float)((w[i] >> 8) & 0xffu);
-      x[4 * i + 2] = (float)((w[i] >> 16) & 0xffu);
-      x[4 * i + 3] = (float)(w[i] >> 24);
-    }
-    if constexpr (DCT == 1) {  // cv::dct's own evaluation (cv_dct32_dev.h)
-      float y[9];
-      cvdct::dct32_first9(x, &tabs->cv, y);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) sT[slot][l32 * 9 + k] = y[k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        float t = 0.f;
-#pragma unroll
-        for (int j = 0; j < 32; ++j) t = __builtin_fmaf(x[j], tabs->C[k * 32 + j], t);
-        sT[slot][l32 * 9 + k] = t;
-      }
-    }
-  }
-  __syncthreads();
-  // ---- column pass: Y[u][k] = sum_r fmaf(C[u][r], T[r][k], .), 81 outputs over 32 lanes
-  if constexpr (DCT == 1) {
-    if (l32 < 9) {  // nine column transforms per image
-      float x[32], y[9];
-#pragma unroll
-      for (int r = 0; r < 32; ++r) x[r] = sT[slot][r * 9 + l32];
-      cvdct::dct32_first9(x, &tabs->cv, y);
-#pragma unroll
-      for (int u = 0; u < 9; ++u) sY[slot][u * 9 + l32] = y[u];
-    }
-  } else {
-#pragma unroll
-    for (int rep = 0; rep < 3; ++rep) {
-      const int o = l32 + 32 * rep;
-      if (o < 81) {
-        const int u = o / 9, k = o - u * 9;
-        float t = 0.f;
-#pragma unroll
-        for (int r = 0; r < 32; ++r) t = __builtin_fmaf(sC[u * 33 + r], sT[slot][r * 9 + k], t);
-        sY[slot][o] = t;
-      }
-    }
-  }
-  __syncthreads();
-  {
-    // lane l of a half-wave holds selected coefficients l and 32 + l; the threshold's ordered sum runs on lane
-    // broadcasts (v_readlane) for both images of the wave at once -- no serial chain of LDS reads
-    const float c0 = sY[slot][tabs->zz[l32]];
-    const float c1 = sY[slot][tabs->zz[l32 + 32]];
-    const int cb0 = __builtin_bit_cast(int, c0), cb1 = __builtin_bit_cast(int, c1);
-    double sumA, sumB;
-    if constexpr (DCT == 1) {
-      sumA = cvdct::sum64_halfwave(cb0, cb1, 0);
-      sumB = cvdct::sum64_halfwave(cb0, cb1, 32);
-    } else {
-      sumA = 0.0, sumB = 0.0;
-#pragma unroll
-      for (int i = 0; i < 64; ++i) {
-        const int src = i < 32 ? cb0 : cb1;
-        sumA += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(src, i & 31));
-        sumB += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(src, 32 + (i & 31)));
-      }
-    }
-    const float thr = (float)((lane >> 5) ? sumB : sumA) / 64;
-    const unsigned long long b0 = __ballot(c0 > thr);
-    const unsigned long long b1 = __ballot(c1 > thr);
-    const int sh = (lane >> 5) * 32;
-    unsigned long long hv = ((b0 >> sh) & 0xffffffffull) | (((b1 >> sh) & 0xffffffffull) << 32);
-    hv &= ~1ull;  // bit 0 is never encoded (cvutil.cpp:537)
-    if (hv == 0) hv = 1;
-    if (l32 == 0 && valid) out[img] = hv;
-  }
+  // ---- stages 3-6 per half-wave on its own tile
+  const unsigned long long hv = hash_halfwave(sTile[slot], sT[slot], sY[slot], tabs, lane);
+  if (l32 == 0 && valid) out[img] = hv;
 }
 
 // (Round 2's k_dcthash_256_mfma -- both box passes as f16 MFMAs, operands converted on the VALU -- was removed in round 4:
@@ -572,7 +333,6 @@ typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
 typedef int v4i_lds __attribute__((ext_vector_type(4), may_alias));
 typedef unsigned int v2u_lds __attribute__((ext_vector_type(2), may_alias));
 typedef unsigned int v4u_lds __attribute__((ext_vector_type(4), may_alias));
-typedef float f32_lds __attribute__((may_alias));
 
 struct BandTables {
   unsigned int w[3][64][4];  // B operands (i8 x 16 per lane): 0 interior column tile, 1 tile 0 (left edge), 2 tile 15
@@ -587,44 +347,41 @@ __device__ __forceinline__ void wave_order_lds() {
   asm volatile("" ::: "memory");
 }
 
-// NW = waves per workgroup.  1 (default): a wave owns its four images alone (no barrier anywhere in the loop; 17 KB of LDS
-// per wave, 9 waves per CU).  2 (knob "hash_band_waves", measured 5 % slower): two waves share the four images -- each takes 8 of the 16 column tiles, half of the row
-// staging and two of the four images' DCT stages -- so the row ring and the tiles are held once per TWO waves (21 KB per
-// workgroup, 14 waves per CU, half the S / accumulator registers per wave) at the price of one workgroup barrier per step;
-// the ring then has four step slots instead of three so that the rows staged for step t + 1 never overwrite rows a slower
-// wave still reads in step t.
-template <bool DUMP, int DCT, int NW>
-__global__ __launch_bounds__(64 * NW) void k_dcthash_256_band(
+// A wave owns its four images alone: no barrier anywhere in the loop, 17 KB of LDS per wave, 9 waves per CU.  (Two waves
+// sharing four images -- each half of the column tiles, the ring held once per two waves, 14 waves per CU, one workgroup
+// barrier per step -- measured 5 % slower: r05's "hash_band_waves" 2.)
+template <bool DUMP>
+__global__ __launch_bounds__(64) void k_dcthash_256_band(
     const unsigned char* __restrict__ imgs, unsigned n, unsigned row_stride, unsigned img_stride,
     const DctTables* __restrict__ tabs, const BandTables* __restrict__ bt, uint64_t* __restrict__ out,
     unsigned char* __restrict__ tiles) {
-  constexpr int kSlots = NW == 1 ? 3 : 4;        // steps of rows one image keeps in LDS
+  constexpr int kSlots = 3;                      // steps of rows one image keeps in LDS
   constexpr int kRing = 4 * kSlots;              // ... = rows
   constexpr int kImg = kRing * kBandPitch;       // bytes per image
-  constexpr int TPW = 16 / NW;                   // column tiles per wave
-  constexpr int RPW = 4 / NW;                    // rows of a step staged by one wave
-  __shared__ __attribute__((aligned(16))) unsigned char sRing[4 * kImg];  // 13 056 / 17 408 B; the tail reuses it
+  constexpr int TPW = 16;                        // column tiles
+  constexpr int RPW = 4;                         // rows of a step
+  __shared__ __attribute__((aligned(16))) unsigned char sRing[4 * kImg];  // 13 056 B; the tail reuses it
   // (12 instead of 9 waves per CU -- timed by shrinking this array, hashes wrong -- would buy 4 %: 4.73 vs ~4.9 ms per 400k
   //  images; not worth keeping the tile in registers for)
   __shared__ __attribute__((aligned(16))) unsigned char sTile[4][1024];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
   const int n16 = lane & 15, q = lane >> 4;
   const unsigned first = blockIdx.x * 4u;
-  // staging role: image q, 16-byte chunk n16 of a row; wave wv stages rows wv * RPW .. of every step
+  // staging role: image q, 16-byte chunk n16 of a row
   unsigned mine = first + (unsigned)q;
   if (mine >= n) mine = n - 1;
   const unsigned char* __restrict__ base = imgs + (size_t)first * img_stride;  // workgroup-uniform
   const unsigned voff = (mine - first) * img_stride + (unsigned)n16 * 16u;
   const int wr_base = q * kImg + 8 + 16 * n16;
   // A-operand role: M row n16 = image n16 >> 2, row n16 & 3 of the step; chunk q: 0, 1 the row, 2, 3 the row 7 above
-  const int rd_base = (n16 >> 2) * kImg + (q & 1) * 16 + 16 * TPW * wv;
+  const int rd_base = (n16 >> 2) * kImg + (q & 1) * 16;
   const int rd_row = (n16 & 3) + (q >= 2 ? kRing - 7 : 0);
-  // accumulator role: image q, column n16 of each of this wave's column tiles, rows in the four result registers
+  // accumulator role: image q, column n16 of each of the column tiles, rows in the four result registers
   const v4i_t b0 = *reinterpret_cast<const v4i_t*>(bt->w[0][lane]);
-  const v4i_t bL = *reinterpret_cast<const v4i_t*>(bt->w[wv == 0 ? 1 : 0][lane]);       // this wave's first tile
-  const v4i_t bR = *reinterpret_cast<const v4i_t*>(bt->w[wv == NW - 1 ? 2 : 0][lane]);  // ... and its last
+  const v4i_t bL = *reinterpret_cast<const v4i_t*>(bt->w[1][lane]);  // the first tile (left edge)
+  const v4i_t bR = *reinterpret_cast<const v4i_t*>(bt->w[2][lane]);  // ... and the last
 
-  for (int i = threadIdx.x; i < 4 * kImg / 16; i += 64 * NW)
+  for (int i = threadIdx.x; i < 4 * kImg / 16; i += 64)
     reinterpret_cast<v4u_lds*>(sRing)[i] = v4u_lds{0u, 0u, 0u, 0u};  // rows above the image: p - 128 = 0 contributes nothing
 
   // virtual row w = 0..263 is image row reflect101(w - 5); output row y = w - 8 is complete with row w
@@ -637,12 +394,12 @@ __global__ __launch_bounds__(64 * NW) void k_dcthash_256_band(
   uint4 stg[2][RPW];
   auto load_step = [&](int t, uint4 (&dst)[RPW]) {
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) dst[r] = *reinterpret_cast<const uint4*>(base + src_off(4 * t + RPW * wv + r));
+    for (int r = 0; r < RPW; ++r) dst[r] = *reinterpret_cast<const uint4*>(base + src_off(4 * t + r));
   };
   auto store_step = [&](int ts, const uint4 (&src)[RPW]) {  // ts = t % kSlots: the step's rows take slots 4 * ts .. + 3
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-      v2u_lds* p = reinterpret_cast<v2u_lds*>(sRing + wr_base + (4 * ts + RPW * wv + r) * kBandPitch);  // 8-byte aligned
+      v2u_lds* p = reinterpret_cast<v2u_lds*>(sRing + wr_base + (4 * ts + r) * kBandPitch);  // 8-byte aligned
       p[0] = v2u_lds{src[r].x ^ 0x80808080u, src[r].y ^ 0x80808080u};
       p[1] = v2u_lds{src[r].z ^ 0x80808080u, src[r].w ^ 0x80808080u};
     }
@@ -659,7 +416,7 @@ __global__ __launch_bounds__(64 * NW) void k_dcthash_256_band(
   asm volatile("" : "+v"(kC));  // VGPR operands (a literal would double the size of every fma)
   const v2f_t kInit = {8388608.0f, 8388608.0f};
   const v4i_t zero4 = {0, 0, 0, 0};
-  const int st_lane = q * 1024 + (n16 >> 3) + 2 * (n16 & 1) + 2 * TPW * wv;  // tile byte of this lane within a cell row
+  const int st_lane = q * 1024 + (n16 >> 3) + 2 * (n16 & 1);  // tile byte of this lane within a cell row
   const unsigned sel_shift = (unsigned)(n16 & 1) * 16u;
 
   // one step: rows 4t .. 4t+3 (already in the ring); FIRST = the step opens a cell row, else it closes it
@@ -709,21 +466,18 @@ __global__ __launch_bounds__(64 * NW) void k_dcthash_256_band(
   __syncthreads();  // (the zero fill)
   store_step(0, stg[0]);
   load_step(2, stg[0]);
-  if constexpr (NW > 1) __syncthreads();
   int ts = 0;  // t % kSlots of the even step
   auto nxt = [](int v) { return v == kSlots - 1 ? 0 : v + 1; };
   for (int t = 0; t < 66; t += 2) {
     const int tsa = ts, tsb = nxt(tsa), tsc = nxt(tsb);
     step(integral_constant<bool, true>{}, t, tsa);
-    store_step(tsb, stg[1]);  // rows of step t + 1: their slots' last readers ran a full step ago (NW 2) / just now (NW 1)
+    store_step(tsb, stg[1]);  // rows of step t + 1: their slots' last readers ran just now
     if (t + 3 < 66) load_step(t + 3, stg[1]);
-    if constexpr (NW > 1) __syncthreads();
     step(integral_constant<bool, false>{}, t + 1, tsb);
     if (t + 2 < 66) {
       store_step(tsc, stg[0]);
       if (t + 4 < 66) load_step(t + 4, stg[0]);
     }
-    if constexpr (NW > 1) __syncthreads();
     ts = tsc;
   }
   __syncthreads();
@@ -731,111 +485,28 @@ __global__ __launch_bounds__(64 * NW) void k_dcthash_256_band(
   if (DUMP) {
     for (int g = 0; g < 4; ++g)
       if (first + (unsigned)g < n)
-        for (int i = threadIdx.x; i < 256; i += 64 * NW)
+        for (int i = threadIdx.x; i < 256; i += 64)
           reinterpret_cast<unsigned*>(tiles + (size_t)(first + (unsigned)g) * 1024)[i] =
               reinterpret_cast<const unsigned*>(sTile[g])[i];
   }
 #endif
-  // ---- stages 3-6 as in k_dcthash_256: a half-wave per image (NW 1: two images at a time, two passes); sT / sY live in
-  // the ring
-  f32_lds* sT = reinterpret_cast<f32_lds*>(sRing);                    // [2 NW][288]
-  f32_lds* sY = reinterpret_cast<f32_lds*>(sRing) + 2 * NW * 288;      // [2 NW][84]
-  f32_lds* sC = sY + 2 * NW * 84;                                      // [9 * 33]
-  const int l32 = lane & 31, hw = lane >> 5;
-  const int hx = 2 * wv + hw;  // this half-wave's slot in sT / sY
-  if constexpr (DCT == 0)
-    for (int i = threadIdx.x; i < 288; i += 64 * NW) sC[(i >> 5) * 33 + (i & 31)] = tabs->C[i];
-  for (int pass = 0; pass < 2 / NW; ++pass) {
-    const int slot = NW == 1 ? 2 * pass + hw : hx;
+  // ---- stages 3-6 as in k_dcthash_256: a half-wave per image, two images at a time, two passes; sT / sY live in the ring
+  f32_lds* sT = reinterpret_cast<f32_lds*>(sRing);                // [2][288]
+  f32_lds* sY = reinterpret_cast<f32_lds*>(sRing) + 2 * 288;      // [2][84]
+  const int hw = lane >> 5;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int slot = 2 * pass + hw;
     const unsigned img = first + (unsigned)slot;
-    const bool valid = img < n;
     __syncthreads();
-    {
-      float x[32];
-      const uint4* trow = reinterpret_cast<const uint4*>(&sTile[slot][l32 * 32]);
-      const uint4 a = trow[0], b = trow[1];
-      const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        x[4 * i + 0] = (float)(w[i] & 0xffu);
-        x[4 * i + 1] = (float)((w[i] >> 8) & 0xffu);
-        x[4 * i + 2] = (float)((w[i] >> 16) & 0xffu);
-        x[4 * i + 3] = (float)(w[i] >> 24);
-      }
-      if constexpr (DCT == 1) {
-        float y[9];
-        cvdct::dct32_first9(x, &tabs->cv, y);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) sT[hx * 288 + l32 * 9 + k] = y[k];
-      } else {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          float t = 0.f;
-#pragma unroll
-          for (int j = 0; j < 32; ++j) t = __builtin_fmaf(x[j], tabs->C[k * 32 + j], t);
-          sT[hx * 288 + l32 * 9 + k] = t;
-        }
-      }
-    }
-    __syncthreads();
-    if constexpr (DCT == 1) {
-      if (l32 < 9) {
-        float x[32], y[9];
-#pragma unroll
-        for (int r = 0; r < 32; ++r) x[r] = sT[hx * 288 + r * 9 + l32];
-        cvdct::dct32_first9(x, &tabs->cv, y);
-#pragma unroll
-        for (int u = 0; u < 9; ++u) sY[hx * 84 + u * 9 + l32] = y[u];
-      }
-    } else {
-#pragma unroll
-      for (int rep = 0; rep < 3; ++rep) {
-        const int o = l32 + 32 * rep;
-        if (o < 81) {
-          const int u = o / 9, k = o - u * 9;
-          float t = 0.f;
-#pragma unroll
-          for (int r = 0; r < 32; ++r) t = __builtin_fmaf(sC[u * 33 + r], sT[hx * 288 + r * 9 + k], t);
-          sY[hx * 84 + o] = t;
-        }
-      }
-    }
-    __syncthreads();
-    {
-      const float c0 = sY[hx * 84 + tabs->zz[l32]];
-      const float c1 = sY[hx * 84 + tabs->zz[l32 + 32]];
-      const int cb0 = __builtin_bit_cast(int, c0), cb1 = __builtin_bit_cast(int, c1);
-      double sumA, sumB;
-      if constexpr (DCT == 1) {
-        sumA = cvdct::sum64_halfwave(cb0, cb1, 0);
-        sumB = cvdct::sum64_halfwave(cb0, cb1, 32);
-      } else {
-        sumA = 0.0, sumB = 0.0;
-#pragma unroll
-        for (int i = 0; i < 64; ++i) {
-          const int src = i < 32 ? cb0 : cb1;
-          sumA += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(src, i & 31));
-          sumB += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(src, 32 + (i & 31)));
-        }
-      }
-      const float thr = (float)(hw ? sumB : sumA) / 64;
-      const unsigned long long bb0 = __ballot(c0 > thr);
-      const unsigned long long bb1 = __ballot(c1 > thr);
-      const int sh = hw * 32;
-      unsigned long long hv = ((bb0 >> sh) & 0xffffffffull) | (((bb1 >> sh) & 0xffffffffull) << 32);
-      hv &= ~1ull;  // bit 0 is never encoded (cvutil.cpp:537)
-      if (hv == 0) hv = 1;
-      if (l32 == 0 && valid) out[img] = hv;
-    }
+    const unsigned long long hv = hash_halfwave(sTile[slot], sT + hw * 288, sY + hw * 84, tabs, lane);
+    if ((lane & 31) == 0 && img < n) out[img] = hv;
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Any other size (w,h >= 32, not both multiples of 32): cv::resize's general INTER_AREA path
-// (resizeArea_) with fractional cell weights.  Two launches: k_blur_u8 writes the blurred u8 image to a
-// scratch buffer (bands of rows staged in LDS, separable box sums), k_area_hash resamples it with the
-// reference's float accumulation order -- per source row buf += S[sx]*alpha over the x table, per output
-// row sum = beta*buf then += beta*buf over the y table, round-half-even -- and hashes the tile.
+// (resizeArea_) with fractional cell weights, in the reference's float accumulation order -- per source row
+// buf += S[sx]*alpha over the x table, per output row sum = beta*buf then += beta*buf over the y table, round-half-even.
 struct AreaTab {
   int si, di;
   float alpha;
@@ -1138,111 +809,18 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
   }
 }
 
-
-template <int K>
-__global__ __launch_bounds__(kThreads) void k_blur_u8(const unsigned char* __restrict__ imgs, int w, int h,
-                                                      size_t row_stride, size_t img_stride, int band_rows,
-                                                      unsigned char* __restrict__ blur /* n*w*h */) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int R = K / 2;
-  const int rows = band_rows + 2 * R;
-  unsigned short* hs = reinterpret_cast<unsigned short*>(smem);                  // rows*w u16
-  unsigned char* raw = reinterpret_cast<unsigned char*>(hs + (size_t)rows * w);  // rows*w u8
-  const int tid = threadIdx.x;
-  const unsigned char* img = imgs + (size_t)blockIdx.x * img_stride;
-  unsigned char* dst = blur + (size_t)blockIdx.x * (size_t)w * h;
-  const int y0 = blockIdx.y * band_rows;
-  const int nrows = min(band_rows, h - y0);
-  if (K == 0) {
-    for (int i = tid; i < nrows * w; i += kThreads) {
-      const int b = i / w, x = i - b * w;
-      dst[(size_t)(y0 + b) * w + x] = img[(size_t)(y0 + b) * row_stride + x];
-    }
-    return;
-  }
-  for (int i = tid; i < rows * w; i += kThreads) {
-    const int b = i / w, x = i - b * w;
-    raw[i] = img[(size_t)reflect101(y0 - R + b, h) * row_stride + x];
-  }
-  __syncthreads();
-  for (int i = tid; i < rows * w; i += kThreads) {
-    const int b = i / w, x = i - b * w;
-    unsigned int s = 0;
-#pragma unroll
-    for (int dx = -R; dx <= R; ++dx) s += raw[b * w + reflect101(x + dx, w)];
-    hs[i] = (unsigned short)s;
-  }
-  __syncthreads();
-  for (int x = tid; x < w; x += kThreads) {
-    unsigned int s = 0;
-#pragma unroll
-    for (int t = 0; t < (K ? K : 1); ++t) s += hs[t * w + x];
-    for (int j = 0; j < nrows; ++j) {
-      dst[(size_t)(y0 + j) * w + x] = (unsigned char)((2u * s + (unsigned)(K * K)) / (2u * (unsigned)(K * K) + (K == 0)));
-      if (j + 1 < nrows) s += (unsigned)hs[(j + K) * w + x] - (unsigned)hs[j * w + x];
-    }
-  }
-}
-
-__global__ __launch_bounds__(kThreads) void k_area_hash(const unsigned char* __restrict__ blur, int w, int h,
-                                                        const AreaTab* __restrict__ xtab, int xn,
-                                                        const AreaTab* __restrict__ ytab, int yn,
-                                                        const int* __restrict__ xfirst /*33*/,
-                                                        const int* __restrict__ yfirst /*33*/,
-                                                        int isx, int isy /* integer ratios or 0 */,
-                                                        const DctTables* __restrict__ tabs,
-                                                        uint64_t* __restrict__ out,
-                                                        unsigned char* __restrict__ tiles) {
-  __shared__ __attribute__((aligned(16))) float sC[288], sT[288], sY[84];
-  __shared__ __attribute__((aligned(16))) unsigned char tile[1024], sZ[64];
-  const int tid = threadIdx.x;
-  const unsigned char* src = blur + (size_t)blockIdx.x * (size_t)w * h;
-  for (int i = tid; i < 288; i += kThreads) sC[i] = tabs->C[i];
-  if (tid < 64) sZ[tid] = tabs->zz[tid];
-  for (int o = tid; o < 1024; o += kThreads) {
-    const int dy = o >> 5, dx = o & 31;
-    if (isx) {  // both ratios integer: resizeAreaFast_ (block sum, 2x2 -> (s+2)>>2, else rint(s * (1.f/area)))
-      unsigned int s = 0;
-      for (int yy = 0; yy < isy; ++yy)
-        for (int xx = 0; xx < isx; ++xx) s += src[(size_t)(dy * isy + yy) * w + (dx * isx + xx)];
-      const unsigned int v = (isx == 2 && isy == 2)
-                                 ? (s + 2u) >> 2
-                                 : (unsigned int)__builtin_rintf((float)s * (1.f / (float)(isx * isy)));
-      tile[o] = (unsigned char)(v > 255u ? 255u : v);
-      continue;
-    }
-    float sum = 0.f;
-    for (int j = yfirst[dy]; j < yfirst[dy + 1]; ++j) {
-      const unsigned char* S = src + (size_t)ytab[j].si * w;
-      float buf = 0.f;
-      for (int k = xfirst[dx]; k < xfirst[dx + 1]; ++k) buf += (float)S[xtab[k].si] * xtab[k].alpha;
-      const float t = ytab[j].alpha * buf;
-      sum = (j == yfirst[dy]) ? t : sum + t;
-    }
-    const float r = __builtin_rintf(sum);
-    tile[o] = (unsigned char)(r < 0.f ? 0.f : r > 255.f ? 255.f : r);
-  }
-  __syncthreads();
-  if (tiles)
-    for (int i = tid; i < 1024; i += kThreads) tiles[(size_t)blockIdx.x * 1024 + i] = tile[i];
-  hash_from_tile(tile, sC, sZ, sT, sY, out + blockIdx.x, tabs);
-}
-
-
 // ---------------------------------------------------------------------------------------------
-// Fast path for every geometry other than 256x256 (k_dcthash_256) and 32x32: the same arithmetic as
-// k_blur_u8 + k_area_hash, laid out for throughput.
-//   k_blur_rows<K>  a workgroup stages a band of rows (32 output rows + the K-1 halo rows, REFLECT_101
-//                   applied while loading) of up to 2048 columns in LDS with dword loads, then every lane
-//                   owns 8 adjacent columns like in k_dcthash_256: per row a 16-byte window from LDS,
-//                   horizontal K-tap sums with v_dot4_u32_u8 against compile-time byte masks, vertical
-//                   sliding sums on packed u16 pairs in a register ring, nearest(S / K^2) by multiply-shift
-//                   (exact: see BlurK), one 8-byte store.  HBM: reads (32 + K - 1)/32 of the image, writes it once.
-//   k_area_rows     cv::resize INTER_AREA, horizontal part: one thread per (source row, output column) does
-//                   that column's float accumulation  buf += S[sx] * alpha  in table order (the order is part
-//                   of the result); integer-ratio geometries keep exact integer block sums instead.
-//   k_tile_hash     vertical part (sum = beta * buf, then += in row order; or the integer block sum and
-//                   resizeAreaFast_'s rounding), the 32x32 tile, stages 3-6.
+// The VALU kernels for every geometry other than 256x256 and 32x32 (what k_band_area does not take: integer ratios,
+// 3 x 3 / 5 x 5 blurs, more than 1920 columns, odd views, small batches).  Every lane owns 8 adjacent columns like in
+// k_dcthash_256: horizontal K-tap sums with v_dot4_u32_u8 against compile-time byte masks, vertical sliding sums on
+// packed u16 pairs in a register ring, nearest(S / K^2) by multiply-shift (exact: see BlurK); cv::resize INTER_AREA's
+// horizontal part as float chains  buf += S[sx] * alpha  in table order (the order is part of the result; integer-ratio
+// geometries keep exact integer block sums instead); k_tile_hash: the vertical part (sum = beta * buf, then += in row
+// order; or the integer block sum and resizeAreaFast_'s rounding), the 32x32 tile, stages 3-6.
+//   k_blur_area       a workgroup per 16-row band, rows staged in LDS: any view, any batch size
+//   k_blur_area_regs  a workgroup walks a strip (or the whole image: FUSE) with the rows streamed through registers
+// (Rounds 1-3's k_blur_u8 + k_area_hash, k_blur_rows + k_area_rows and the LDS-streaming k_blur_area_stream are in the
+//  history: r05's "hash_fast_any" 0, "hash_fused" 0, "hash_regs" 0.)
 template <int K>
 struct BlurK;  // nearest(S / K^2) = ((S + add) * m) >> 24, exact for S <= K^2 * 255; (S + add) * m < 2^32
 template <>
@@ -1336,171 +914,10 @@ __device__ __forceinline__ void hsum_pairs(const unsigned (&W)[4], unsigned (&P)
 
 typedef unsigned u32_any_align __attribute__((aligned(1)));
 
-template <int K>
-__global__ __launch_bounds__(256) void k_blur_rows(const unsigned char* __restrict__ imgs, int w, int h,
-                                                   size_t row_stride, size_t img_stride,
-                                                   unsigned char* __restrict__ blur /* n*w*h */, int pitch,
-                                                   int T /* lanes per image */, int ipb /* images per workgroup */,
-                                                   unsigned n_imgs) {
-  // LDS: one (kBlurRB + K - 1) x pitch band per image slot.  Images up to 2048 columns wide per workgroup use the
-  // whole workgroup (T = blockDim.x, one slot); narrow images share it: ipb images side by side, so
-  // that a 128-pixel-wide image does not leave 3/4 of a wave idle.
-  extern __shared__ __attribute__((aligned(16))) unsigned char sband_all[];
-  constexpr int R = K / 2;
-  const int slot = (int)threadIdx.x / T, tl = (int)threadIdx.x - slot * T;
-  const unsigned img_i = blockIdx.z * (unsigned)ipb + (unsigned)slot;
-  const bool live = slot < ipb && img_i < n_imgs;
-  unsigned char* __restrict__ sband = sband_all + (size_t)(slot < ipb ? slot : 0) * (size_t)(kBlurRB + K - 1) * (size_t)pitch;
-  const int cx0 = (int)blockIdx.x * T * 8;  // first column of this workgroup; LDS column c <-> image x = cx0 - 4 + c
-  const int y0 = (int)blockIdx.y * kBlurRB;
-  const unsigned char* __restrict__ img = imgs + (size_t)(live ? img_i : 0u) * img_stride;
-  unsigned char* __restrict__ dst = blur + (size_t)(live ? img_i : 0u) * (size_t)w * (size_t)h;
-  const int out_rows = min(kBlurRB, h - y0);
-  const int rows = out_rows + 2 * R;
-  const int ndw = pitch >> 2;  // = 2 * T + 2
-  // every thread stages the same two window dwords of every row (+ two threads the trailing pair): row-coalesced
-  // loads, no index arithmetic per element
-  // window dwords that lie inside the image: every thread stages the same dword column of every row, all of
-  // the column's loads issued before the first LDS store (the band has at most kBlurRB + K - 1 rows)
-  constexpr int kMaxRows = kBlurRB + K - 1;
-  for (int dwi = tl; live && dwi < ndw; dwi += T) {
-    const int x = cx0 - 4 + 4 * dwi;
-    if (x >= 0 && x + 3 < w) {
-      unsigned v[kMaxRows];
-#pragma unroll
-      for (int rr = 0; rr < kMaxRows; ++rr) {
-        int ry = y0 - R + rr;
-        ry = ry < 0 ? -ry : (ry >= h ? 2 * (h - 1) - ry : ry);  // |overshoot| <= R < h
-        ry = ry < 0 ? 0 : (ry >= h ? h - 1 : ry);                // rows past the band (rr >= rows): any valid row
-        v[rr] = *reinterpret_cast<const u32_any_align*>(img + (size_t)ry * row_stride + x);
-      }
-#pragma unroll
-      for (int rr = 0; rr < kMaxRows; ++rr)
-        if (rr < rows) *reinterpret_cast<unsigned*>(sband + (size_t)rr * pitch + 4 * dwi) = v[rr];
-    }
-  }
-  // the few window bytes across the image border (REFLECT_101): LDS columns [0, 4) when the workgroup starts at
-  // x = 0, and from the first dword that is not entirely inside up to x = w + 2, the last column a sum reads --
-  // spread over all threads as single byte loads so that no wave serialises on them
-  {
-    const int nl = cx0 == 0 ? 4 : 0;
-    const int c_right = ((w - cx0 + 4) >> 2) << 2;            // LDS column of the first uncovered dword
-    const int nr = max(0, min(pitch, w - cx0 + 7) - c_right);  // through x = w + 2
-    const int per_row = nl + nr;
-    for (int e = tl; live && e < per_row * rows; e += T) {
-      const int rr = e / per_row, k = e - rr * per_row;
-      const int c = k < nl ? k : c_right + (k - nl);
-      int xx = cx0 - 4 + c;
-      xx = xx < 0 ? -xx : xx;
-      xx = xx >= w ? 2 * (w - 1) - xx : xx;
-      xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
-      sband[(size_t)rr * pitch + c] = img[(size_t)reflect101(y0 - R + rr, h) * row_stride + xx];
-    }
-  }
-  __syncthreads();
-  const int l = tl;
-  const int x0 = cx0 + 8 * l;
-  if (!live || x0 >= w) return;
-  const bool full = x0 + 8 <= w;
-  unsigned ring[K][4];
-  unsigned S[4];
-#pragma unroll
-  for (int j = 0; j < K; ++j)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) ring[j][c] = 0u;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) S[c] = BlurK<K>::add | (BlurK<K>::add << 16);
-  const unsigned char* __restrict__ win = sband + 8 * l;
-  for (int r0 = 0; r0 < rows; r0 += K) {
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-      const int rr = r0 + j;
-      if (rr < rows) {
-        const uint2 a = *reinterpret_cast<const uint2*>(win + (size_t)rr * pitch);
-        const uint2 b = *reinterpret_cast<const uint2*>(win + (size_t)rr * pitch + 8);
-        const unsigned W[4] = {a.x, a.y, b.x, b.y};
-        unsigned P[4];
-        hsum_pairs<R>(W, P);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          S[c] = (S[c] - ring[j][c]) + P[c];
-          ring[j][c] = P[c];
-        }
-        if (rr >= 2 * R) {
-          unsigned q[8];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            q[2 * c] = ((S[c] & 0xffffu) * BlurK<K>::m) >> 24;
-            q[2 * c + 1] = ((S[c] >> 16) * BlurK<K>::m) >> 24;
-          }
-          unsigned char* __restrict__ o = dst + (size_t)(y0 + rr - 2 * R) * (size_t)w + x0;
-          if (full) {
-            *reinterpret_cast<u32_any_align*>(o) = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
-            *reinterpret_cast<u32_any_align*>(o + 4) = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
-          } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-              if (x0 + i < w) o[i] = (unsigned char)q[i];
-          }
-        }
-      }
-    }
-  }
-}
 
-// rows[img][j][dx]: float mode (isx == 0): j runs over the y table, value = sum over the x-table entries of
-// output column dx of S[si] * alpha, accumulated in table order without contraction; integer mode: j = source
-// row, value = the exact sum of its isx pixels under column dx (stored as the int's bit pattern)
-__global__ __launch_bounds__(256) void k_area_rows(const unsigned char* __restrict__ src, int w, int h,
-                                                   const AreaTab* __restrict__ xtab, int xn,
-                                                   const int* __restrict__ xfirst,
-                                                   const AreaTab* __restrict__ ytab, int yn, int isx,
-                                                   float* __restrict__ rows, int pitch /* >= w, multiple of 4 */) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_area[];  // 8 source rows, then alpha[xn]
-  unsigned char* s_rows = s_area;
-  float* s_alpha = reinterpret_cast<float*>(s_area + 8 * (size_t)pitch);
-  const unsigned char* __restrict__ img = src + (size_t)blockIdx.y * (size_t)w * (size_t)h;
-  const int j0 = (int)blockIdx.x * 8;
-  const int nrow = min(8, yn - j0);
-  // stage the source rows of these 8 table rows with coalesced dword loads (all loads before the stores)
-  int srow[8];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) srow[r] = r < nrow ? (isx ? j0 + r : ytab[j0 + r].si) : 0;
-  const int ndw = w >> 2;
-  for (int d = (int)threadIdx.x; d < ndw; d += 256) {
-    unsigned v[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = *reinterpret_cast<const u32_any_align*>(img + (size_t)srow[r] * w + 4 * d);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) *reinterpret_cast<unsigned*>(s_rows + (size_t)r * pitch + 4 * d) = v[r];
-  }
-  for (int e = (int)threadIdx.x; e < 8 * (w & 3); e += 256) {  // the last w % 4 columns
-    const int r = e / (w & 3), c = 4 * ndw + (e - r * (w & 3));
-    s_rows[(size_t)r * pitch + c] = img[(size_t)srow[r] * w + c];
-  }
-  if (!isx)
-    for (int i = (int)threadIdx.x; i < xn; i += 256) s_alpha[i] = xtab[i].alpha;
-  __syncthreads();
-  const int jr = (int)threadIdx.x >> 5, dx = (int)threadIdx.x & 31;
-  if (jr >= nrow) return;
-  float* __restrict__ o = rows + ((size_t)blockIdx.y * (size_t)yn + (size_t)(j0 + jr)) * 32 + dx;
-  const unsigned char* __restrict__ S = s_rows + (size_t)jr * pitch;
-  if (isx) {
-    unsigned s = 0;
-    for (int t = 0; t < isx; ++t) s += S[dx * isx + t];
-    *o = __uint_as_float(s);
-    return;
-  }
-  const int k0 = xfirst[dx], k1 = xfirst[dx + 1];
-  S += xtab[k0].si;  // si is consecutive within an output column
-  float buf = 0.f;
-  for (int k = k0; k < k1; ++k) buf += (float)S[k - k0] * s_alpha[k];
-  *o = buf;
-}
 
-// k_blur_rows and k_area_rows in one pass (the default path): the blurred band stays in LDS and is
-// reduced to 32 floats per source row straight away, so the blurred plane (1 B/px written + 1 B/px read back) never
-// reaches HBM -- traffic falls from ~3.4 to ~1.4 B per pixel.  A workgroup owns `cpw` of the 32 output columns (all 32
+// Blur and horizontal INTER_AREA in one pass: the blurred band stays in LDS and is reduced to 32 floats per source row
+// straight away, so the blurred plane never reaches HBM.  A workgroup owns `cpw` of the 32 output columns (all 32
 // up to 2048 image columns, 16 up to 4096, 8 up to 8192): its window starts at the first source column of its first
 // cell, so every cell's float accumulation  buf += S * alpha  runs start to end inside one workgroup, in table order.
 // rows[] is indexed by SOURCE row here (k_tile_hash by_src = 1).
@@ -1662,190 +1079,20 @@ __global__ __launch_bounds__(256) void k_blur_area(const unsigned char* __restri
   }
 }
 
-// Streaming form of k_blur_area for batches with enough workgroups to spare: a workgroup walks down a strip of the
-// image in steps of kStep source rows (a multiple of K, so the register ring keeps its phase) and carries the sliding
-// column sums from step to step -- the K-1 halo rows are read and summed once per strip instead of once per 16-row
-// band (x1.375 fewer loads and tap sums).  Per step: kStep new source rows -> LDS, blur (results lag the rows read by
-// R), blurred rows over the same LDS, horizontal INTER_AREA chains, 32 floats per source row out.
+// Streaming form for batches with enough workgroups to spare: a workgroup walks down a strip of the image in steps of
+// kStep source rows (a multiple of K, so the register ring keeps its phase) and carries the sliding column sums from
+// step to step -- the K-1 halo rows are read and summed once per strip instead of once per 16-row band.
 template <int K>
 struct StreamK {
   static constexpr int step = K == 7 ? 14 : 15;  // rows per step: a multiple of K
 };
-template <int K>
-__global__ __launch_bounds__(256) void k_blur_area_stream(const unsigned char* __restrict__ imgs, int w, int h,
-                                                          size_t row_stride, size_t img_stride,
-                                                          const AreaTab* __restrict__ xtab,
-                                                          const int* __restrict__ xfirst, int isx, int cpw,
-                                                          int pitch /* 8 * blockDim.x + 8 */, int steps /* per strip */,
-                                                          float* __restrict__ rows /* n * h * 32 */) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_fused[];
-  constexpr int R = K / 2;
-  constexpr int kStep = StreamK<K>::step;
-  const int T = (int)blockDim.x, tid = (int)threadIdx.x;
-  const int bpitch = 8 * T;
-  unsigned char* __restrict__ sband = s_fused;  // kStep x pitch source rows; then the kStep x bpitch blurred rows
-  float* __restrict__ salpha = reinterpret_cast<float*>(s_fused + (size_t)kStep * pitch);
-  const int c0 = (int)blockIdx.x * cpw, c1 = c0 + cpw;
-  const int k_base = isx ? 0 : xfirst[c0], k_end = isx ? 0 : xfirst[c1];
-  const int cx0 = isx ? c0 * isx : xtab[k_base].si;
-  const int cxe = isx ? c1 * isx : xtab[k_end - 1].si + 1;
-  const int strip_out = steps * kStep - 2 * R;            // blurred rows a strip produces
-  const int o0 = (int)blockIdx.y * strip_out;             // first output row of this strip
-  const int o1 = min(h, o0 + strip_out);
-  const unsigned char* __restrict__ img = imgs + (size_t)blockIdx.z * img_stride;
-  const int ndw = pitch >> 2;
-  for (int i = tid; i < k_end - k_base; i += T) salpha[i] = xtab[k_base + i].alpha;
-  const bool lane_live = cx0 + 8 * tid < cxe;
-  unsigned ring[K][4];
-  unsigned S[4];
-#pragma unroll
-  for (int j = 0; j < K; ++j)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) ring[j][c] = 0u;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) S[c] = BlurK<K>::add | (BlurK<K>::add << 16);
-  // area-pass lane roles (fixed for the whole strip)
-  const int groups = max(1, T / cpw);
-  const int slot = tid / cpw, cc = c0 + (tid - slot * cpw);
-  const int ak0 = (slot < groups && !isx) ? xfirst[cc] : 0;
-  const int ank = slot < groups ? (isx ? isx : xfirst[cc + 1] - ak0) : 0;
-  const int acol = slot < groups ? ((isx ? cc * isx : xtab[ak0].si) - cx0) : 0;
-  const float* __restrict__ al = salpha + (ak0 - k_base);
-
-  for (int st = 0; st < steps; ++st) {
-    const int s0 = o0 - R + st * kStep;  // first source row consumed in this step (may be < 0 or >= h: reflected)
-    if (s0 - R >= o1) break;             // nothing left to output (uniform)
-    // ---- kStep source rows -> LDS (column c <-> image x = cx0 - 4 + c) ----
-    for (int dwi = tid; dwi < ndw; dwi += T) {
-      const int x = cx0 - 4 + 4 * dwi;
-      if (x >= 0 && x + 3 < w) {
-        unsigned v[kStep];
-#pragma unroll
-        for (int rr = 0; rr < kStep; ++rr) {
-          int ry = s0 + rr;
-          ry = ry < 0 ? -ry : (ry >= h ? 2 * (h - 1) - ry : ry);
-          ry = ry < 0 ? 0 : (ry >= h ? h - 1 : ry);  // rows past what any output needs: any valid row
-          v[rr] = *reinterpret_cast<const u32_any_align*>(img + (size_t)ry * row_stride + x);
-        }
-#pragma unroll
-        for (int rr = 0; rr < kStep; ++rr) *reinterpret_cast<unsigned*>(sband + (size_t)rr * pitch + 4 * dwi) = v[rr];
-      }
-    }
-    {
-      const int nl = cx0 == 0 ? 4 : 0;
-      const int c_right = ((w - cx0 + 4) >> 2) << 2;
-      const int nr = max(0, min(pitch, w - cx0 + 7) - c_right);
-      const int per_row = nl + nr;
-      for (int e = tid; e < per_row * kStep; e += T) {
-        const int rr = e / per_row, k = e - rr * per_row;
-        const int c = k < nl ? k : c_right + (k - nl);
-        int xx = cx0 - 4 + c;
-        xx = xx < 0 ? -xx : xx;
-        xx = xx >= w ? 2 * (w - 1) - xx : xx;
-        xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
-        int ry = s0 + rr;
-        ry = ry < 0 ? -ry : (ry >= h ? 2 * (h - 1) - ry : ry);
-        ry = ry < 0 ? 0 : (ry >= h ? h - 1 : ry);
-        sband[(size_t)rr * pitch + c] = img[(size_t)ry * row_stride + xx];
-      }
-    }
-    __syncthreads();
-    // ---- blur: consume the kStep rows; the result for source row s0 + rr is blurred row s0 + rr - R ----
-    uint2 qo[kStep];
-    if (lane_live) {
-      const unsigned char* __restrict__ win = sband + 8 * tid;
-#pragma unroll
-      for (int rr = 0; rr < kStep; ++rr) {
-        const int j = rr % K;
-        const uint2 a = *reinterpret_cast<const uint2*>(win + (size_t)rr * pitch);
-        const uint2 b = *reinterpret_cast<const uint2*>(win + (size_t)rr * pitch + 8);
-        const unsigned W[4] = {a.x, a.y, b.x, b.y};
-        unsigned P[4];
-        hsum_pairs<R>(W, P);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          S[c] = (S[c] - ring[j][c]) + P[c];
-          ring[j][c] = P[c];
-        }
-        qo[rr] = blur_quotients<K>(S);
-      }
-    }
-    __syncthreads();  // every lane has read the source rows
-    if (lane_live) {
-#pragma unroll
-      for (int rr = 0; rr < kStep; ++rr) *reinterpret_cast<uint2*>(sband + (size_t)rr * bpitch + 8 * tid) = qo[rr];
-    }
-    __syncthreads();
-    // ---- horizontal INTER_AREA chains for the valid blurred rows of this step: local row rr <-> image row s0 + rr - R
-    {
-      const int ob = s0 - R;                                  // image row of local row 0
-      const int lo = max(0, o0 - ob), hi = min(kStep, o1 - ob);  // valid local rows [lo, hi)
-      if (slot < groups) {
-        for (int r = lo + slot; r < hi; r += 2 * groups) {
-          const int r2 = r + groups;
-          const bool two = r2 < hi;
-          const unsigned char* __restrict__ Sa = sband + (size_t)r * bpitch + acol;
-          const unsigned char* __restrict__ Sb = sband + (size_t)(two ? r2 : r) * bpitch + acol;
-          float* __restrict__ oa = rows + ((size_t)blockIdx.z * (size_t)h + (size_t)(ob + r)) * 32 + cc;
-          float* __restrict__ obp = rows + ((size_t)blockIdx.z * (size_t)h + (size_t)(ob + (two ? r2 : r))) * 32 + cc;
-          if (isx) {
-            unsigned sa = 0, sb = 0;
-            if (((isx | (int)bpitch | acol) & 3) == 0) {  // dword-aligned cells: four pixels per v_dot4 (uniform)
-              const unsigned* __restrict__ A4 = reinterpret_cast<const unsigned*>(Sa);
-              const unsigned* __restrict__ B4 = reinterpret_cast<const unsigned*>(Sb);
-              for (int u = 0; u < (ank >> 2); ++u) {
-                sa = udot4(A4[u], 0x01010101u, sa);
-                sb = udot4(B4[u], 0x01010101u, sb);
-              }
-            } else {
-              for (int u = 0; u < ank; ++u) {
-                sa += Sa[u];
-                sb += Sb[u];
-              }
-            }
-            *oa = __uint_as_float(sa);
-            if (two) *obp = __uint_as_float(sb);
-          } else {
-            float ba = 0.f, bb = 0.f;
-            int k = 0;
-            for (; k + 8 <= ank; k += 8) {
-              float a[8];
-              unsigned pa[8], pb[8];
-#pragma unroll
-              for (int u = 0; u < 8; ++u) {
-                a[u] = al[k + u];
-                pa[u] = Sa[k + u];
-                pb[u] = Sb[k + u];
-              }
-#pragma unroll
-              for (int u = 0; u < 8; ++u) {
-                ba += (float)pa[u] * a[u];
-                bb += (float)pb[u] * a[u];
-              }
-            }
-            for (; k < ank; ++k) {
-              const float av = al[k];
-              ba += (float)Sa[k] * av;
-              bb += (float)Sb[k] * av;
-            }
-            *oa = ba;
-            if (two) *obp = bb;
-          }
-        }
-      }
-    }
-    __syncthreads();  // the blurred rows are consumed before the next step overwrites them
-  }
-}
 
 // k_blur_area_regs: the streaming kernel with the blur input taken STRAIGHT FROM GLOBAL MEMORY into registers, the way
-// k_dcthash_256 does it, instead of being staged through LDS: per source row a lane loads its own 8 pixels (one
+// k_dcthash_256 does it: per source row a lane loads its own 8 pixels (one
 // aligned 8-byte load) and the dword on either side of them (the neighbours' pixels come from L1/L2; the two border
 // lanes mirror their own pixels with a per-lane v_perm selector = REFLECT_101), a ring of PF rows in flight across the
-// step boundaries.  LDS only holds the blurred rows of a step for the horizontal INTER_AREA chains, which are
-// k_blur_area_stream's.  Per step this removes the staging stores, the two window reads per row and lane, one of the
-// three workgroup barriers, and the load latency that sat exposed behind it.
-// Preconditions (checked by the launcher; everything else takes k_blur_area_stream): whole images, or views whose left
+// step boundaries.  LDS only holds the blurred rows of a step for the horizontal INTER_AREA chains.
+// Preconditions (checked by the launcher; everything else takes k_blur_area): whole images, or views whose left
 // and right edges are the parent's or lie at least 4 (+ the last lane's overhang) pixels inside it (autocrop of
 // letterboxed / pillarboxed frames: the row mapping and the edge lanes' roles change, nothing else),
 // 32 <= w <= 2048 (one workgroup spans the row).  GEN = false: w a multiple of 8 and image base / row stride / image
@@ -1876,7 +1123,6 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
                                                         int oy = 0, int ph = 0, int ox = 0, int pw = 0,
                                                         /* a view: the w x h rectangle at (ox, oy) of a pw x ph parent
                                                            that starts at imgs; ph = 0: whole images */
-                                                        int fast_area = 0 /* "hash_area" 1: see the x chains below */,
                                                         int cell0 = 0, int ncell = 32
                                                         /* a column strip of an image wider than 2048: this launch makes
                                                            the output cells cell0 .. cell0 + ncell - 1 of every row (xtab /
@@ -2176,27 +1422,7 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
   CBH_AREA_PIX1(0, W0) CBH_AREA_PIX1(8, W1) CBH_AREA_PIX1(16, W2) CBH_AREA_PIX1(24, W3)
             CBH_AREA_WORD(0);
             CBH_AREA_PIX4(wF4.x, wF4.y, wF4.z, wF4.w);
-            if (mid_ok && fast_area) {
-              // "hash_area" 1 (never the default): the interior pixels all weigh a_mid, so their chain
-              // `ba += float(p) * a_mid` (three instructions per pixel, one rounding per pixel) becomes an exact
-              // integer sum (v_dot4: a quarter of an instruction per pixel) times a_mid, added once.  Mathematically the
-              // same number; the float result differs in its last bits from the chain OpenCV's resizeArea_ runs, so a
-              // tile byte can flip at a rounding boundary (tools/fuzz_hash_sizes.py --area-fast counts how often).
-              unsigned ia = 0, ib = 0;
-              for (int c = 1; c < nw_u - 2; ++c) {
-                CBH_AREA_WORD(c);
-                ia = udot4(wa, 0x01010101u, ia), ib = udot4(wb, 0x01010101u, ib);
-              }
-              bab = v2f_t{__builtin_fmaf((float)ia, a_mid, bab.x), __builtin_fmaf((float)ib, a_mid, bab.y)};
-              if (nw_u >= 3) {
-                CBH_AREA_WORD(nw_u - 2);
-                CBH_AREA_PIX4(wTa.x, wTa.y, wTa.z, wTa.w);
-              }
-              if (nw_u >= 2) {
-                CBH_AREA_WORD(nw_u - 1);
-                CBH_AREA_PIX4(wTb.x, wTb.y, wTb.z, wTb.w);
-              }
-            } else if (mid_ok) {
+            if (mid_ok) {
 #pragma unroll 2  // (the carried dwords lo_a / lo_b ping-pong between registers instead of being moved every word)
               for (int c = 1; c < nw_u - 2; ++c) {  // interior words: every pixel of every lane weighs a_mid
                 CBH_AREA_WORD(c);
@@ -2279,33 +1505,16 @@ __global__ __launch_bounds__(256) void k_blur_area_regs(const unsigned char* __r
   }
 }
 
-// stages 3-6 from finished 32 x 32 tiles (k_blur_area_regs<.., FUSE>): one workgroup per image
-__global__ __launch_bounds__(kThreads) void k_tiles_hash(const unsigned char* __restrict__ tiles_in,
-                                                         const DctTables* __restrict__ tabs, uint64_t* __restrict__ out,
-                                                         unsigned char* __restrict__ tiles_copy) {
-  __shared__ __attribute__((aligned(16))) float sC[288], sT[288], sY[84];
-  __shared__ __attribute__((aligned(16))) unsigned char tile[1024], sZ[64];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 288; i += kThreads) sC[i] = tabs->C[i];
-  if (tid < 64) sZ[tid] = tabs->zz[tid];
-  reinterpret_cast<unsigned*>(tile)[tid] = reinterpret_cast<const unsigned*>(tiles_in + (size_t)blockIdx.x * 1024)[tid];
-  __syncthreads();
-  if (tiles_copy)
-    reinterpret_cast<unsigned*>(tiles_copy + (size_t)blockIdx.x * 1024)[tid] = reinterpret_cast<const unsigned*>(tile)[tid];
-  hash_from_tile(tile, sC, sZ, sT, sY, out + blockIdx.x, tabs);
-}
 
-// The same from two tiles per 64-thread workgroup, a half-wave per image (the tail of k_dcthash_256_band as a kernel of its
-// own): k_tiles_hash keeps four waves per image of which 32, then 9, then 64 lanes ever work.  "hash_tiles2" 1 (default).
-template <int DCT>
+// stages 3-6 from finished 32 x 32 tiles (k_band_area, k_blur_area_regs<.., FUSE>): two tiles per 64-thread workgroup,
+// a half-wave per image (the tail of k_dcthash_256_band as a kernel of its own)
 __global__ __launch_bounds__(64) void k_tiles_hash2(const unsigned char* __restrict__ tiles_in, unsigned n,
                                                     const DctTables* __restrict__ tabs, uint64_t* __restrict__ out,
                                                     unsigned char* __restrict__ tiles_copy) {
   __shared__ __attribute__((aligned(16))) unsigned char sTile[2][1024];
-  __shared__ __attribute__((aligned(16))) float sT[2 * 288], sY[2 * 84], sC[9 * 33];
+  __shared__ __attribute__((aligned(16))) float sT[2 * 288], sY[2 * 84];
   const int lane = threadIdx.x, l32 = lane & 31, hw = lane >> 5;
   const unsigned img = blockIdx.x * 2u + (unsigned)hw;
-  const bool valid = img < n;
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     const unsigned gi = min(blockIdx.x * 2u + (unsigned)g, n - 1u);
@@ -2313,86 +1522,9 @@ __global__ __launch_bounds__(64) void k_tiles_hash2(const unsigned char* __restr
     reinterpret_cast<uint4*>(sTile[g])[lane] = v;
     if (tiles_copy && blockIdx.x * 2u + (unsigned)g < n) reinterpret_cast<uint4*>(tiles_copy + (size_t)gi * 1024)[lane] = v;
   }
-  if constexpr (DCT == 0)
-    for (int i = lane; i < 288; i += 64) sC[(i >> 5) * 33 + (i & 31)] = tabs->C[i];
   __syncthreads();
-  {
-    float x[32];
-    const uint4* trow = reinterpret_cast<const uint4*>(&sTile[hw][l32 * 32]);
-    const uint4 a = trow[0], b = trow[1];
-    const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      x[4 * i + 0] = (float)(w[i] & 0xffu);
-      x[4 * i + 1] = (float)((w[i] >> 8) & 0xffu);
-      x[4 * i + 2] = (float)((w[i] >> 16) & 0xffu);
-      x[4 * i + 3] = (float)(w[i] >> 24);
-    }
-    if constexpr (DCT == 1) {
-      float y[9];
-      cvdct::dct32_first9(x, &tabs->cv, y);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) sT[hw * 288 + l32 * 9 + k] = y[k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        float t = 0.f;
-#pragma unroll
-        for (int j = 0; j < 32; ++j) t = __builtin_fmaf(x[j], tabs->C[k * 32 + j], t);
-        sT[hw * 288 + l32 * 9 + k] = t;
-      }
-    }
-  }
-  __syncthreads();
-  if constexpr (DCT == 1) {
-    if (l32 < 9) {
-      float x[32], y[9];
-#pragma unroll
-      for (int r = 0; r < 32; ++r) x[r] = sT[hw * 288 + r * 9 + l32];
-      cvdct::dct32_first9(x, &tabs->cv, y);
-#pragma unroll
-      for (int u = 0; u < 9; ++u) sY[hw * 84 + u * 9 + l32] = y[u];
-    }
-  } else {
-#pragma unroll
-    for (int rep = 0; rep < 3; ++rep) {
-      const int o = l32 + 32 * rep;
-      if (o < 81) {
-        const int u = o / 9, k = o - u * 9;
-        float t = 0.f;
-#pragma unroll
-        for (int r = 0; r < 32; ++r) t = __builtin_fmaf(sC[u * 33 + r], sT[hw * 288 + r * 9 + k], t);
-        sY[hw * 84 + o] = t;
-      }
-    }
-  }
-  __syncthreads();
-  {
-    const float c0 = sY[hw * 84 + tabs->zz[l32]];
-    const float c1 = sY[hw * 84 + tabs->zz[l32 + 32]];
-    const int cb0 = __builtin_bit_cast(int, c0), cb1 = __builtin_bit_cast(int, c1);
-    double sumA, sumB;
-    if constexpr (DCT == 1) {
-      sumA = cvdct::sum64_halfwave(cb0, cb1, 0);
-      sumB = cvdct::sum64_halfwave(cb0, cb1, 32);
-    } else {
-      sumA = 0.0, sumB = 0.0;
-#pragma unroll
-      for (int i = 0; i < 64; ++i) {
-        const int src = i < 32 ? cb0 : cb1;
-        sumA += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(src, i & 31));
-        sumB += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(src, 32 + (i & 31)));
-      }
-    }
-    const float thr = (float)(hw ? sumB : sumA) / 64;
-    const unsigned long long bb0 = __ballot(c0 > thr);
-    const unsigned long long bb1 = __ballot(c1 > thr);
-    const int sh = hw * 32;
-    unsigned long long hv = ((bb0 >> sh) & 0xffffffffull) | (((bb1 >> sh) & 0xffffffffull) << 32);
-    hv &= ~1ull;  // bit 0 is never encoded (cvutil.cpp:537)
-    if (hv == 0) hv = 1;
-    if (l32 == 0 && valid) out[img] = hv;
-  }
+  const unsigned long long hv = hash_halfwave(sTile[hw], sT + hw * 288, sY + hw * 84, tabs, lane);
+  if (l32 == 0 && img < n) out[img] = hv;
 }
 
 __global__ __launch_bounds__(kThreads) void k_tile_hash(const float* __restrict__ rows, int yn,
@@ -2402,11 +1534,10 @@ __global__ __launch_bounds__(kThreads) void k_tile_hash(const float* __restrict_
                                                         const DctTables* __restrict__ tabs,
                                                         uint64_t* __restrict__ out,
                                                         unsigned char* __restrict__ tiles) {
-  __shared__ __attribute__((aligned(16))) float sC[288], sT[288], sY[84];
+  __shared__ __attribute__((aligned(16))) float sT[288], sY[84];
   __shared__ __attribute__((aligned(16))) unsigned char tile[1024], sZ[64];
   const int tid = threadIdx.x;
   const float* __restrict__ R = rows + (size_t)blockIdx.x * (size_t)yn * 32;
-  for (int i = tid; i < 288; i += kThreads) sC[i] = tabs->C[i];
   if (tid < 64) sZ[tid] = tabs->zz[tid];
   {
     // a lane owns output column dx and rows dy0, dy0+8, dy0+16, dy0+24: four independent chains, advanced together
@@ -2474,13 +1605,9 @@ __global__ __launch_bounds__(kThreads) void k_tile_hash(const float* __restrict_
   __syncthreads();
   if (tiles)
     for (int i = tid; i < 1024; i += kThreads) tiles[(size_t)blockIdx.x * 1024 + i] = tile[i];
-  hash_from_tile(tile, sC, sZ, sT, sY, out + blockIdx.x, tabs);
+  hash_from_tile(tile, sZ, sT, sY, out + blockIdx.x, tabs);
 }
 
-size_t generic_smem_bytes(int w, int h, int K) {
-  const int band = h / 32 + 2 * (K / 2);
-  return (288 + 288 + 84 + 4) * 4 + (size_t)w * 4 + 1024 + 64 + (size_t)band * w * 3;
-}
 
 // ---------------------------------------------------------------------------------------------
 // Rectangles of an image, hashed one after the other IN PLACE: Media::makeKeyPointHashes (src/media.cpp:874-923)
@@ -2559,10 +1686,9 @@ __global__ __launch_bounds__(kThreads) void k_rect_hashes(unsigned char* __restr
                                                           const DctTables* __restrict__ tabs, int write_back,
                                                           uint64_t* __restrict__ out,
                                                           unsigned char* __restrict__ tiles) {
-  __shared__ __attribute__((aligned(16))) float sC[288], sT[288], sY[84];
+  __shared__ __attribute__((aligned(16))) float sT[288], sY[84];
   __shared__ __attribute__((aligned(16))) unsigned char tile[1024], sZ[64];
   const int tid = threadIdx.x;
-  for (int i = tid; i < 288; i += kThreads) sC[i] = tabs->C[i];
   if (tid < 64) sZ[tid] = tabs->zz[tid];
   unsigned char* __restrict__ scr = scratch + (size_t)blockIdx.x * scratch_per_wg;
   for (unsigned im = blockIdx.x; im < n_images; im += gridDim.x) {
@@ -2633,7 +1759,7 @@ __global__ __launch_bounds__(kThreads) void k_rect_hashes(unsigned char* __restr
       __syncthreads();
       if (tiles)
         for (int i = tid; i < 1024; i += kThreads) tiles[(size_t)(I.first + r) * 1024 + i] = tile[i];
-      hash_from_tile(tile, sC, sZ, sT, sY, out + I.first + r, tabs);
+      hash_from_tile(tile, sZ, sT, sY, out + I.first + r, tabs);
       __syncthreads();  // tile / sT / sY are reused, and the written-back pixels are in place for the next rectangle
     }
   }
@@ -2721,7 +1847,7 @@ __global__ __launch_bounds__(kThreads) void k_kp_hashes(unsigned char* __restric
                                                         unsigned char* __restrict__ scratch, size_t scratch_per_wg,
                                                         const DctTables* __restrict__ tabs,
                                                         uint64_t* __restrict__ out, unsigned* __restrict__ counts) {
-  __shared__ __attribute__((aligned(16))) float sC[288], sT[288], sY[84];
+  __shared__ __attribute__((aligned(16))) float sT[288], sY[84];
   __shared__ __attribute__((aligned(16))) unsigned char tile[1024], sZ[64];
   __shared__ int sFirst[36];
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
@@ -2732,7 +1858,6 @@ __global__ __launch_bounds__(kThreads) void k_kp_hashes(unsigned char* __restric
   float* sTabA = reinterpret_cast<float*>(dyn + (size_t)tab_cap * 4);
   unsigned char* sReg = dyn + (size_t)tab_cap * 8;
   const int tid = threadIdx.x;
-  for (int i = tid; i < 288; i += kThreads) sC[i] = tabs->C[i];
   if (tid < 64) sZ[tid] = tabs->zz[tid];
   unsigned char* __restrict__ scr = scratch + (size_t)blockIdx.x * scratch_per_wg;
   int cached = -1;  // side length whose table is in LDS (uniform)
@@ -2793,7 +1918,7 @@ __global__ __launch_bounds__(kThreads) void k_kp_hashes(unsigned char* __restric
           }
         }
         __syncthreads();
-        hash_from_tile(tile, sC, sZ, sT, sY, dst, tabs);
+        hash_from_tile(tile, sZ, sT, sY, dst, tabs);
         __syncthreads();
         continue;
       }
@@ -2908,7 +2033,7 @@ __global__ __launch_bounds__(kThreads) void k_kp_hashes(unsigned char* __restric
       }
       __syncthreads();
       // ---- D ----
-      hash_from_tile(tile, sC, sZ, sT, sY, dst, tabs);
+      hash_from_tile(tile, sZ, sT, sY, dst, tabs);
       __syncthreads();
     }
     if (tid == 0) counts[im] = cnt;
@@ -2928,7 +2053,7 @@ __global__ __launch_bounds__(kThreads) void k_kp_compact(const uint64_t* __restr
 
 struct TableCache {
   std::mutex mu;
-  DctTables* d[16][2] = {};  // [device][hash_dct variant]
+  DctTables* d[16] = {};  // [device]
 } g_tabs;
 
 }  // namespace
@@ -3288,38 +2413,11 @@ int get_band_tables(const BandTables** out) {
 }  // namespace
 
 // "hash_mfma": which kernel hashes 256 x 256 tiles -- non-zero (default 2) k_dcthash_256_band (horizontal box sums on the
-// matrix cores; needs 16-byte aligned rows, else 0 is taken), 0 k_dcthash_256 (all VALU).  (1 selected round 2's f16 kernel,
-// removed in round 4; it now means the same as 2.)  Staging the rows four steps ahead instead of two
-// (250 VGPRs) changed nothing: 4.83 vs 4.77 ms per 400k images.
+// matrix cores; needs 16-byte aligned rows, else 0 is taken), 0 k_dcthash_256 (all VALU: what runs when the band tables
+// cannot be made; the parity suite runs both).
 int g_hash_mfma = 2;
-// "hash_band_waves": waves per workgroup of k_dcthash_256_band.  1 (default) a wave owns its four images; 2 = two waves
-// share them (14 instead of 9 waves per CU).  Measured, same box, alternating (tools/ab/hash_band_ab.py, 400k images):
-// 4.80-4.88 ms with 1, 5.06-5.11 with 2 (compute-only 3.38 / 4.01): the barrier per step and the per-wave fixed work
-// (addresses, staging, the warm-up steps) cost more than the extra occupancy returns -- the kernel is not latency-bound.
-void set_hash_band_area(int v) { g_hash_band_area = v < 0 ? 0 : v > 2 ? 2 : v; }
-int g_hash_band_waves = 1;
-void set_hash_band_waves(int v) {
-  if (v == 1 || v == 2) g_hash_band_waves = v;
-}
 int g_hash_mfma_set(int v) { return g_hash_mfma = v; }
-// tuning knob "hash_dct": stages 3 and 5 of dctHash64 -- 1 (default) = cv::dct / cv::sum as OpenCV 2.4.13.7 evaluates
-// them (cv_dct32_dev.h), 0 = the canonical 9x32 matrix form (NOTES.md section 3).  oracle: orc_set_hash_variant.
-// "hash_div": how k_dcthash_256 divides by 49 (see the kernel): 0 = integer SDWA (default), 1 = float magic number
-// (exact too; measured 4 % slower: 5.57 vs 5.36 ms per 400k images -- on this VALU a "simple" op costs ~2.15 cycles
-// per wave and a "complex" one ~4.3, additively, so 2 complex -> 1 complex + 2 simple is break-even at best).
-// "hash_lds_pad": extra dynamic LDS bytes per workgroup of k_dcthash_256, the occupancy experiment knob (default 0;
-// 3..7 workgroups per CU all run at the same speed: the kernel is bound by VALU issue, not by latency).
-int g_hash_div = 0, g_hash_lds_pad = 0;
-void set_hash_div(int v) {
-  if (v >= 0 && v <= 3) g_hash_div = v;
-}
-void set_hash_lds_pad(int v) {
-  if (v >= 0 && v <= 64 * 1024) g_hash_lds_pad = v;
-}
-int g_hash_dct = 1;
-void set_hash_dct(int v) {
-  if (v == 0 || v == 1) g_hash_dct = v;
-}
+void set_hash_band_area(int v) { g_hash_band_area = v < 0 ? 0 : v > 2 ? 2 : v; }
 int g_kp_blur_side = 112;  // ... and up to this side their blurred copy stays in LDS as well (larger: global scratch)
 void set_kp_blur_side(int v) {
   if (v >= 32 && v <= 200) g_kp_blur_side = v;
@@ -3328,30 +2426,23 @@ int g_kp_lds_side = 134;  // keypoint squares up to this side are processed in L
 void set_kp_lds_side(int v) {
   if (v >= 32 && v <= 200) g_kp_lds_side = v;
 }
-int g_hash_stream = 1;  // k_blur_area_stream: 0 off, 1 auto (strips of 3..8 steps when the batch is large), v >= 2: v steps
+int g_hash_fuse = 1;  // "hash_fuse": 1 = k_blur_area_regs<.., FUSE> (vertical pass + tile in the strip kernel) when the batch
+                      // gives >= 512 workgroups, 2 = always, 0 = never (k_tile_hash reads the rows back)
+void set_hash_fuse(int v) {
+  if (v >= 0 && v <= 2) g_hash_fuse = v;
+}
+// "hash_stream": k_blur_area_regs on strips: 0 never (k_blur_area's 16-row bands for every batch), 1 = when
+                        // the batch is large enough (strips of 3..8 steps), v >= 2 = always, strips of v steps (the parity
+                        // suite's way to put a handful of images through the strip kernel)
+int g_hash_stream = 1;
 void set_hash_stream(int v) {
   if (v >= 0) g_hash_stream = v;
 }
-int g_hash_fuse = 1;  // "hash_fuse": 1 = k_blur_area_regs<.., FUSE> (vertical pass + tile in the strip kernel) when the batch
-                      // gives >= 512 workgroups, 2 = always, 0 = never (k_tile_hash reads the rows back)
-int g_hash_area = 0;  // "hash_area": 1 = k_blur_area_regs sums the interior pixels of a fractional INTER_AREA cell as integers
-                      // (results may differ from the exact chain in a tile byte at a rounding boundary; default 0)
-void set_hash_area(int v) { g_hash_area = v ? 1 : 0; }
-int g_hash_wide = 1;  // "hash_wide": images wider than 2048 on column strips of k_blur_area_regs (1, default) or on the LDS band kernel (0)
-void set_hash_wide(int v) { g_hash_wide = v ? 1 : 0; }
-int g_hash_tiles2 = 1;  // "hash_tiles2": stages 3-6 of the fused strip kernel's tiles two images per wave (k_tiles_hash2; 0 = k_tiles_hash)
-void set_hash_tiles2(int v) { g_hash_tiles2 = v ? 1 : 0; }
-int g_hash_cell_pad = 1;  // "hash_cell_pad": pad dword behind every cell of a blurred LDS row (k_blur_area_regs, integer ratios): 0 never,
-                          // 1 (default) where the cells would share LDS banks 4 ways or more, 2 from 2 ways on
-void set_hash_cell_pad(int v) { g_hash_cell_pad = v < 0 ? 0 : v > 2 ? 2 : v; }
-int g_hash_rows_per_step = 1;  // "hash_rows_per_step": 0 = 14 rows per step of k_blur_area_regs<7> always (through round 4), 1 (default) =
-                               // 14 / 21 / 28 by how the step's rows fill the area phase's turns, 21 / 28 = that many wherever possible
-void set_hash_rows_per_step(int v) { g_hash_rows_per_step = (v == 21 || v == 28) ? v : (v ? 1 : 0); }
-// rows per step for a workgroup of T threads making ncell cells per row: a turn of the area phase has 2 T / ncell row slots
+// rows per step for a workgroup of T threads making ncell cells per row: a turn of the area phase has 2 T / ncell row
+// slots, and 14 rows fill a turn of 12 (T = 192), 24, 32, 48 or 64 slots badly -- 21 where that fills the turns better
 static int pick_rows_per_step(int K, unsigned T, int ncell, size_t lds_per_row, size_t lds_fixed) {
-  if (K != 7 || !g_hash_rows_per_step) return K == 7 ? 14 : 15;
+  if (K != 7) return 15;
   auto fits = [&](int ks) { return lds_fixed + (size_t)ks * lds_per_row <= (size_t)64 * 1024; };
-  if (g_hash_rows_per_step > 1) return fits(g_hash_rows_per_step) ? g_hash_rows_per_step : 14;
   const int cap = (int)(2 * T) / ncell;
   int best = 14;
   double best_u = 0.0;
@@ -3380,37 +2471,17 @@ static int pick_steps_per_strip(int h, int ks, int target, int halo) {
   }
   return best;
 }
-// cells of nd = isx / 4 dwords: the 32 lanes of a row group read dword u of their cells together, gcd(nd, 32) to a bank
+// integer ratios, cells of nd = isx / 4 dwords: the 32 lanes of a row group read dword u of their cells together, gcd(nd, 32)
+// to a bank -- one pad dword behind every cell of a blurred LDS row where that would be 4 ways or more (512, 1024, 1536 px ...)
 static int cell_pad_for(bool integer, int isx) {
-  if (!integer || !g_hash_cell_pad || (isx & 7)) return 0;  // (nd even: a blur lane's two dwords stay in one cell)
+  if (!integer || (isx & 7)) return 0;  // (nd even: a blur lane's two dwords stay in one cell)
   int g = 1;
   while (g < 32 && ((isx >> 2) % (2 * g)) == 0) g *= 2;
-  return g >= (g_hash_cell_pad >= 2 ? 2 : 4) ? 1 : 0;
-}
-int g_hash_regs = 1;  // k_blur_area_regs (blur input from global memory into registers) where its preconditions hold
-void set_hash_fuse(int v) {
-  if (v >= 0 && v <= 2) g_hash_fuse = v;
-}
-void set_hash_regs(int v) {
-  if (v >= 0 && v <= 4) g_hash_regs = v;  // 0 off, 1 on (automatic image packing), 2 on / never pack, 3 on / always pack,
-                                          // 4 on / round 3's packing rule
-}
-int g_hash_fused = 1;  // k_blur_area (blur + horizontal area pass in one kernel): 0 off, v >= 1 for widths >= v (measured: wins from 64 up)
-void set_hash_fused(int on) {
-  if (on >= 0) g_hash_fused = on;
-}
-int g_hash_fast_any = 1;  // 1 = k_blur_rows/k_area_rows/k_tile_hash for every geometry but 256x256 and 32x32
-void set_hash_fast_any(int on) {
-  if (on >= 0) g_hash_fast_any = on;
+  return g >= 4 ? 1 : 0;
 }
 
 // Host-side table construction (same closed forms as the oracle, computed independently here).
 static void make_tables(DctTables* t) {
-  for (int k = 0; k < 9; ++k)
-    for (int j = 0; j < 32; ++j) {
-      const double a = __builtin_sqrt((k ? 2.0 : 1.0) / 32.0);
-      t->C[k * 32 + j] = (float)(a * __builtin_cos(3.14159265358979323846 * (2 * j + 1) * k / 64.0));
-    }
   // 9x9 zig-zag, first step downwards (equals the table at cvutil.cpp:491-495); keep 6..69
   int zz[81], n = 0;
   for (int s = 0; s <= 16; ++s) {
@@ -3421,7 +2492,6 @@ static void make_tables(DctTables* t) {
     }
   }
   for (int i = 0; i < 64; ++i) t->zz[i] = (unsigned char)zz[6 + i];
-  t->variant = 0;
   cv_dct32_make_tabs(&t->cv);
 }
 
@@ -3429,18 +2499,20 @@ static int get_tables(const DctTables** out) {
   int dev = 0;
   CBH_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 16) return CBH_E_INVAL;
-  const int variant = g_hash_dct ? 1 : 0;
   std::lock_guard<std::mutex> lk(g_tabs.mu);
-  if (!g_tabs.d[dev][variant]) {
+  if (!g_tabs.d[dev]) {
     DctTables host;
     make_tables(&host);
-    host.variant = variant;
     DctTables* d = nullptr;
     CBH_HIP(hipMalloc(&d, sizeof(DctTables)));
-    CBH_HIP(hipMemcpy(d, &host, sizeof(DctTables), hipMemcpyHostToDevice));
-    g_tabs.d[dev][variant] = d;
+    hipError_t e = hipMemcpy(d, &host, sizeof(DctTables), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      (void)hipFree(d);
+      CBH_HIP(e);
+    }
+    g_tabs.d[dev] = d;
   }
-  *out = g_tabs.d[dev][variant];
+  *out = g_tabs.d[dev];
   return CBH_OK;
 }
 
@@ -3707,8 +2779,9 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
   if (view && w == 32 && h == 32)  // no blur: nothing is read outside the view
     return launch_dcthash(d_imgs + (size_t)vw.oy * row_stride + vw.ox, n, w, h, row_stride, img_stride, d_out, stream,
                           d_tiles, nullptr);
-  if (w < 32 || h < 32 || (view && !g_hash_fused)) {
-    // a side enlarges: cv::resize's bilinear emulation, on the rectangle kernel (one rectangle = the whole image)
+  if (w < 32 || h < 32 || (w == 32 && h == 32)) {
+    // a side enlarges (cv::resize's bilinear emulation), or nothing is resized at all: the rectangle kernel, one
+    // rectangle = the whole image
     const size_t per_chunk = (size_t)1 << 20;
     for (size_t i0 = 0; i0 < n; i0 += per_chunk) {
       const size_t m = std::min(per_chunk, n - i0);
@@ -3728,54 +2801,72 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
   const DctTables* tabs = nullptr;
   int rc = get_tables(&tabs);
   if (rc) return rc;
-  // k_dcthash_256 needs 8-byte aligned rows; anything else of that size takes the general kernels
-  const bool is256 = !view && w == 256 && h == 256 && ((uintptr_t)d_imgs % 8) == 0 && row_stride % 8 == 0 &&
-                     img_stride % 8 == 0 && row_stride * 256 < (1u << 24) && img_stride < (1u << 28);
-  if ((g_hash_fast_any || view) && !is256 && !(w == 32 && h == 32)) {
-    // every other geometry: k_blur_rows + k_area_rows + k_tile_hash
-    const long long area_ = (long long)w * h;
-    const int K_ = area_ <= 64 * 64 ? 3 : area_ <= 128 * 128 ? 5 : 7;  // (area <= 32*32 is only 32x32 itself)
-    AreaTabsDev at;
-    if ((rc = get_area_tabs(w, h, &at))) return rc;
-    const bool integer = area_fast(w, h);
-    const int isx = integer ? w / 32 : 0, isy = integer ? h / 32 : 0;
-    const int yn = integer ? h : at.yn;
-    // lanes per image (8 columns each), at most 256; narrower images share a workgroup of up to 256 threads
-    const int T = std::min(256, std::max(4, (w + 7) / 8));
-    // whole-wave widths gain nothing from sharing (and lose workgroup-level parallelism): measured
-    const int ipb = T % 64 == 0 ? 1 : 256 / T, block_threads = (ipb * T + 63) / 64 * 64;
-    const int pitch = T * 8 + 8;
-    const size_t smem = (size_t)ipb * (size_t)(kBlurRB + K_ - 1) * (size_t)pitch;
-    // (views: a vertical edge is the parent's, or lies far enough inside it that the blur's three columns -- and on the left
-    // the staging chunk's eight -- are the parent's pixels: letterboxed and pillarboxed frames after autocrop)
-    const bool ba_view = !view || ((vw.ox == 0 || vw.ox >= 8) && (vw.ox + w == vw.pw || vw.ox + w + 3 <= vw.pw));
-    if (g_hash_band_area && ba_view && K_ == 7 && !integer && at.yrow && w >= 64 &&
-        4ull * img_stride < (1ull << 32) && (size_t)vw.ph * row_stride < ((size_t)1 << 32)) {
-      BaTabsDev bat;
-      if ((rc = get_ba_tabs(w, &bat))) return rc;
-      if (bat.strips) {
-        const size_t per_chunk_b = 200000;  // (grid y)
-        unsigned char* d_btiles = nullptr;
-        cbh::Scratch scratch(stream);
-        CBH_HIP(scratch.get(&d_btiles, std::min(per_chunk_b, n) * 1024));
-        for (size_t i0 = 0; i0 < n; i0 += per_chunk_b) {
-          const size_t m = std::min(per_chunk_b, n - i0);
-          const unsigned char* src = d_imgs + i0 * img_stride;
-          const unsigned long long bytes = (unsigned long long)(m - 1) * img_stride + (unsigned long long)(vw.ph - 1) * row_stride + (unsigned)vw.pw;
-          // row bands: enough waves for ~two rounds of the machine's 2560 slots, at least 4 output rows per band
-          BaBands bands;
-          bands.n = 1;
-          while (bands.n < 8 && (m + 3) / 4 * (size_t)bat.n_strips * (size_t)bands.n < 5120) bands.n *= 2;
-          {
-            std::vector<int> yf;
-            const std::vector<AreaTab> yt = make_area_tab(h, 32, &yf);
-            for (int b_ = 0; b_ < bands.n; ++b_) {
-              const int c0_ = 32 * b_ / bands.n, c1_ = 32 * (b_ + 1) / bands.n;
-              bands.c0[b_] = c0_, bands.c1[b_] = c1_;
-              bands.ra[b_] = yt[(size_t)yf[(size_t)c0_]].si;
-              bands.rb[b_] = yt[(size_t)yf[(size_t)c1_] - 1].si;
-            }
+  // ---- 256 x 256 (8-byte aligned rows; anything else of that size takes the general kernels)
+  if (!view && w == 256 && h == 256 && ((uintptr_t)d_imgs % 8) == 0 && row_stride % 8 == 0 && img_stride % 8 == 0 &&
+      row_stride * 256 < (1u << 24) && img_stride < (1u << 28)) {
+    const BandTables* btab = nullptr;
+    if (g_hash_mfma != 0 && ((uintptr_t)d_imgs % 16) == 0 && row_stride % 16 == 0 && img_stride % 16 == 0 &&
+        get_band_tables(&btab) == CBH_OK) {  // (no table on this device: the all-VALU kernel needs none)
+      dim3 gridb((unsigned)((n + 3) / 4));
+      if (d_tiles)
+        hipLaunchKernelGGL(k_dcthash_256_band<true>, gridb, dim3(64), 0, stream, d_imgs, (unsigned)n, (unsigned)row_stride,
+                           (unsigned)img_stride, tabs, btab, d_out, d_tiles);
+      else
+        hipLaunchKernelGGL(k_dcthash_256_band<false>, gridb, dim3(64), 0, stream, d_imgs, (unsigned)n, (unsigned)row_stride,
+                           (unsigned)img_stride, tabs, btab, d_out, d_tiles);
+    } else {
+      cbh_clear_error();
+      dim3 grid((unsigned)((n + 7) / 8)), block(kThreads);
+      if (d_tiles)
+        hipLaunchKernelGGL(k_dcthash_256<true>, grid, block, 0, stream, d_imgs, (unsigned)n, (unsigned)row_stride,
+                           (unsigned)img_stride, tabs, d_out, d_tiles);
+      else
+        hipLaunchKernelGGL(k_dcthash_256<false>, grid, block, 0, stream, d_imgs, (unsigned)n, (unsigned)row_stride,
+                           (unsigned)img_stride, tabs, d_out, d_tiles);
+    }
+    CBH_HIP(hipGetLastError());
+    return CBH_OK;
+  }
+  // ---- every other geometry
+  const long long area_ = (long long)w * h;
+  const int K_ = area_ <= 64 * 64 ? 3 : area_ <= 128 * 128 ? 5 : 7;  // (area <= 32*32 is only 32x32 itself)
+  AreaTabsDev at;
+  if ((rc = get_area_tabs(w, h, &at))) return rc;
+  const bool integer = area_fast(w, h);
+  const int isx = integer ? w / 32 : 0, isy = integer ? h / 32 : 0;
+  // (views: a vertical edge is the parent's, or lies far enough inside it that the blur's three columns -- and on the left
+  // the staging chunk's eight -- are the parent's pixels: letterboxed and pillarboxed frames after autocrop)
+  const bool ba_view = !view || ((vw.ox == 0 || vw.ox >= 8) && (vw.ox + w == vw.pw || vw.ox + w + 3 <= vw.pw));
+  if (g_hash_band_area && ba_view && K_ == 7 && !integer && at.yrow && w >= 64 &&
+      4ull * img_stride < (1ull << 32) && (size_t)vw.ph * row_stride < ((size_t)1 << 32)) {
+    BaTabsDev bat;
+    if (get_ba_tabs(w, &bat) != CBH_OK) {  // (its table could not be made: k_blur_area_regs needs none)
+      cbh_clear_error();
+      bat.strips = nullptr;
+    }
+    if (bat.strips) {
+      const size_t per_chunk_b = 200000;  // (grid y)
+      unsigned char* d_btiles = nullptr;
+      cbh::Scratch scratch(stream);
+      CBH_HIP(scratch.get(&d_btiles, std::min(per_chunk_b, n) * 1024));
+      for (size_t i0 = 0; i0 < n; i0 += per_chunk_b) {
+        const size_t m = std::min(per_chunk_b, n - i0);
+        const unsigned char* src = d_imgs + i0 * img_stride;
+        const unsigned long long bytes = (unsigned long long)(m - 1) * img_stride + (unsigned long long)(vw.ph - 1) * row_stride + (unsigned)vw.pw;
+        // row bands: enough waves for ~two rounds of the machine's 2560 slots, at least 4 output rows per band
+        BaBands bands;
+        bands.n = 1;
+        while (bands.n < 8 && (m + 3) / 4 * (size_t)bat.n_strips * (size_t)bands.n < 5120) bands.n *= 2;
+        {
+          std::vector<int> yf;
+          const std::vector<AreaTab> yt = make_area_tab(h, 32, &yf);
+          for (int b_ = 0; b_ < bands.n; ++b_) {
+            const int c0_ = 32 * b_ / bands.n, c1_ = 32 * (b_ + 1) / bands.n;
+            bands.c0[b_] = c0_, bands.c1[b_] = c1_;
+            bands.ra[b_] = yt[(size_t)yf[(size_t)c0_]].si;
+            bands.rb[b_] = yt[(size_t)yf[(size_t)c1_] - 1].si;
           }
+        }
 #define CBH_BA_(TT, RR)                                                                                                  \
   hipLaunchKernelGGL((k_band_area<TT, RR>), dim3((unsigned)(((m + 3) / 4 + 7) / 8 * 8 * (size_t)bat.n_strips * (size_t)bands.n)), dim3(64), 0, \
                      stream, src, (unsigned)m, w, h, (unsigned)row_stride, (unsigned)img_stride, bytes, bat.strips,      \
@@ -3787,131 +2878,113 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     else if (bat.RS == 2) CBH_BA_(TT, 2); \
     else CBH_BA_(TT, 1);                 \
     break
-          switch (bat.T) {
-            CBH_BA(2); CBH_BA(3); CBH_BA(4); CBH_BA(5); CBH_BA(6); CBH_BA(7); CBH_BA(8); CBH_BA(9); CBH_BA(10); CBH_BA(11);
-            CBH_BA(12); CBH_BA(13); CBH_BA(14); CBH_BA(15);
-            default: return CBH_E_UNSUPPORTED;
-          }
+        switch (bat.T) {
+          CBH_BA(2); CBH_BA(3); CBH_BA(4); CBH_BA(5); CBH_BA(6); CBH_BA(7); CBH_BA(8); CBH_BA(9); CBH_BA(10); CBH_BA(11);
+          CBH_BA(12); CBH_BA(13); CBH_BA(14); CBH_BA(15);
+          default: return CBH_E_UNSUPPORTED;
+        }
 #undef CBH_BA_
 #undef CBH_BA
-          unsigned char* tcopy = d_tiles ? d_tiles + i0 * 1024 : nullptr;
-          if (g_hash_dct)
-            hipLaunchKernelGGL(k_tiles_hash2<1>, dim3((unsigned)((m + 1) / 2)), dim3(64), 0, stream, d_btiles, (unsigned)m, tabs,
-                               d_out + i0, tcopy);
-          else
-            hipLaunchKernelGGL(k_tiles_hash2<0>, dim3((unsigned)((m + 1) / 2)), dim3(64), 0, stream, d_btiles, (unsigned)m, tabs,
-                               d_out + i0, tcopy);
-          CBH_HIP(hipGetLastError());
-        }
-        return CBH_OK;
+        hipLaunchKernelGGL(k_tiles_hash2, dim3((unsigned)((m + 1) / 2)), dim3(64), 0, stream, d_btiles, (unsigned)m, tabs,
+                           d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
+        CBH_HIP(hipGetLastError());
       }
+      return CBH_OK;
     }
-    if (view || (g_hash_fused && w >= g_hash_fused)) {
-      // k_blur_area + k_tile_hash: the blurred plane stays in LDS
-      // column strips: the fewest (1, 2, 4, 8) whose widest window -- first source column of a strip's first cell .. last of
-      // its last -- fits 256 lanes x 8 columns.  (Fractional cells overlap by a pixel: 8191 columns need 8 strips, which the
-      // fixed 1 / 2 / 4 rule of rounds 1-3 answered with CBH_E_UNSUPPORTED.)
-      int ncol = w <= 2048 ? 1 : w <= 4096 ? 2 : 4, cpw = 32 / ncol, win = 0;
-      std::vector<int> xf;
-      const std::vector<AreaTab> xt_full = integer ? std::vector<AreaTab>() : make_area_tab(w, 32, &xf);
-      for (;; ncol *= 2) {
-        cpw = 32 / ncol;
-        win = 0;
-        if (integer) {
-          win = cpw * isx;
-        } else {
-          for (int c = 0; c < 32; c += cpw)
-            win = std::max(win, xt_full[(size_t)xf[(size_t)(c + cpw)] - 1].si + 1 - xt_full[(size_t)xf[(size_t)c]].si);
-        }
-        if ((win + 7) / 8 <= 256 || ncol == 8) break;
-      }
-      const int Tf = std::min(256, ((win + 7) / 8 + 63) / 64 * 64);
-      if ((win + 7) / 8 > 256) return CBH_E_UNSUPPORTED;  // cannot happen for w <= 8192
-      const int fpitch = Tf * 8 + 8;
-      const size_t fsmem = (size_t)(kBlurRB + K_ - 1) * fpitch + (size_t)(integer ? 0 : at.xn) * sizeof(float);
-      const size_t per_chunk_f = std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)h * 128));
-      float* d_rowsf = nullptr;
-      unsigned char* d_ftiles = nullptr;  // the fused kernel's 32 x 32 tiles (1 KB per image)
-      cbh::Scratch scratch(stream);
-      CBH_HIP(scratch.get(&d_rowsf, std::min(per_chunk_f, n) * (size_t)h * 32 * sizeof(float)));
-      CBH_HIP(scratch.get(&d_ftiles, std::min(per_chunk_f, n) * 1024));
-      for (size_t i0 = 0; i0 < n; i0 += per_chunk_f) {
-        const size_t m = std::min(per_chunk_f, n - i0);
-        const unsigned char* src = d_imgs + i0 * img_stride;
-        // streaming form when the batch leaves enough workgroups: strips of `steps` steps
-        const int kstep = K_ == 7 ? 14 : 15;
-        const long long band_wgs = (long long)ncol * ((h + kBlurRB - 1) / kBlurRB) * (long long)m;
-        int steps = (int)std::min<long long>(8, band_wgs / 3072);
-        steps = std::min(steps, (h + 2 * (K_ / 2) + kstep - 1) / kstep);
-        // a view whose vertical edges are the parent's or lie >= 4 pixels inside it (letterboxed / pillarboxed frames
-        // after autocrop) differs from a whole image in the row mapping and in which lanes mirror: the
-        // register-streaming kernel takes it; other views (a margin of 1..3 pixels) stay on the band kernels
-        const int Lv = (w + 7) / 8;
-        const bool lbox = view && (vw.ox == 0 || vw.ox >= 4) && (vw.ox + w == vw.pw || vw.ox + 8 * Lv + 4 <= vw.pw);
-        const bool regs_ok = g_hash_regs && ncol == 1 && (size_t)vw.ph * row_stride < ((size_t)1 << 31);
-        const bool view_off = view && !(lbox && regs_ok);  // (k_blur_area_stream has no view form either)
-        if (w < 32 || h < 32 || view_off) steps = 0;  // (round 3: the fused strip kernel is 1.4-2.3x the band kernels on 64..160-px images too)
-        if (g_hash_stream >= 2 && !view_off) steps = g_hash_stream;
-        if (g_hash_stream && steps >= 3) {
-          const int strip_out = steps * kstep - 2 * (K_ / 2);
-          dim3 gs((unsigned)ncol, (unsigned)((h + strip_out - 1) / strip_out), (unsigned)m);
-          const size_t ssmem = (size_t)kstep * fpitch + (size_t)(integer ? 0 : at.xn) * sizeof(float);
-          if (regs_ok) {
-            const int v_oy = view ? vw.oy : 0, v_ph = view ? vw.ph : 0, v_ox = view ? vw.ox : 0, v_pw = view ? vw.pw : 0;
-            const bool v_ri = view && vw.ox + 8 * Lv + 4 <= vw.pw;  // the last lane reads real pixels: any w mod 8
-            const bool gen = !((w % 8 == 0 || v_ri) && ((uintptr_t)(src + v_ox) % 8) == 0 && row_stride % 8 == 0 &&
-                               img_stride % 8 == 0);
-            // blur input straight from global memory into registers (k_blur_area_regs); LDS = blurred rows + weights
-            // lanes per image = w / 8.  Images whose last wave would be mostly empty share a 256-lane workgroup side by
-            // side (640 px: 80 of 128 lanes busy alone, 240 of 256 as three: +12 %); where the lanes are already
-            // well used the larger workgroup only costs (more waves per barrier: -5..-9 % measured at 400, 512, 1024 px)
-            const int Lr = (w + 7) / 8, Lw = (Lr + 63) / 64 * 64;
-            // knob 1 (default): side by side where that puts 15 % more of the lanes to work (400 px: 50 of 64 alone, 250 of
-            // 256 as five: +3..4 %; 720 / 800 px: two images fill 256 lanes no better than one fills 128: -2 % packed; through
-            // round 4 the rule was "alone uses < 72 % of its lanes"); 4: that older rule, 2: never, 3: always
-            // Integer ratios (cheap area phase: the blur lanes decide) count the packed workgroup's own size -- 704 x 576: 176
-            // of 192 lanes as two against 88 of 128 alone, +10 % -- fractional ones count it as 256 lanes: 720 x 540 and
-            // 688 x 516 run 4-5 % faster alone in 128 lanes than as two in 192.
-            const int ipb_try = Lr <= 128 ? 256 / Lr : 1;
-            const int Tp = integer ? (ipb_try * Lr + 63) / 64 * 64 : 256;
-            const bool pack = g_hash_regs == 3 || (g_hash_regs == 4 && Lr * 100 < Lw * 72) ||
-                              (g_hash_regs == 1 && ipb_try > 1 && (long long)ipb_try * Lr * Lw * 100 >= 115LL * Lr * Tp);
-            const int ipb = (pack && (unsigned long long)ipb_try * img_stride < (1ull << 32)) ? ipb_try : 1;
-            const size_t k_end_r = integer ? 0 : (((size_t)at.xn + 3) & ~(size_t)3) + 512;  // weights + per-cell edge weights
-            // one pad dword per cell of a blurred LDS row where the cells would otherwise share banks 4 ways or more
-            // ("hash_cell_pad": 0 never, 1 default, 2 from 2 ways on)
-            const int cpad = cell_pad_for(integer, isx);
-            const size_t rowb = (size_t)(8 * Lr) + (cpad ? 128 : 0);  // LDS bytes of one blurred row
-            const unsigned Tr = (unsigned)std::max(64, (ipb * Lr + 63) / 64 * 64);
-            // rows per step (14 / 21 / 28) by how they fill the area phase's turns; the strips keep their length in rows
-            const int ks_r = pick_rows_per_step(K_, Tr, 32, (size_t)ipb * rowb, k_end_r * sizeof(float) + 16);
-            const int steps_r = pick_steps_per_strip(h, ks_r, (steps * kstep + ks_r - 1) / ks_r, 2 * (K_ / 2));
-            const int strip_out_r = steps_r * ks_r - 2 * (K_ / 2);
-            const unsigned gsy_r = (unsigned)((h + strip_out_r - 1) / strip_out_r);
-            const size_t rsmem = (size_t)ipb * ks_r * rowb + k_end_r * sizeof(float) +
-                                 16;  // the area walk reads whole words: up to 7 bytes past the last blurred row
-            // whole image per workgroup, vertical pass and tile inside the kernel (FUSE) when the batch still fills
-            // the machine that way: at least two workgroups per CU
-            const int ipb_f = std::min(ipb, 8);
-            const size_t k_end_f = k_end_r;
-            const unsigned Tf_ = (unsigned)std::max(64, (ipb_f * std::max(Lr, 32) + 63) / 64 * 64);
-            const int ks_f = pick_rows_per_step(K_, std::min(256u, Tf_), 32, (size_t)ipb_f * (rowb + 32 * sizeof(float)),
-                                                k_end_f * sizeof(float) + (size_t)ipb_f * 1024);
-            const int steps_f = (h + 2 * (K_ / 2) + ks_f - 1) / ks_f;
-            const size_t fsm = (size_t)ipb_f * ks_f * rowb + k_end_f * sizeof(float) +
-                               (size_t)ipb_f * ks_f * 32 * sizeof(float) + (size_t)ipb_f * 1024;
-            // (measured, hash_fuse 0 -> 2: 320x240 +30 %, 400x300 +22 %, 533x400 +19 %, 640x480 +8 %, 800x600 +6 %,
-            // 1366x768 +6 %, 1024x768 -2 %, 1280x960 -8 %, 1080p -7 %: large images spend little in k_tile_hash and
-            // lose occupancy to the extra LDS; fractional ratios gain up to ~1 MP)
-            // a fused workgroup walks its whole image alone: with one or two waves per workgroup the machine needs
-            // thousands of them before that beats strips of 8 steps (tools/ab/hash_small_batches.py: 400x300, one wave per
-            // image, 1024 images 137 us fused / 86 split, 2048: 160 / 148, 4096: 289 / 298; 800x600, two waves:
-            // 2048 images 553 / 483, 4096: 945 / 951; four-wave workgroups of 3-6 images pay from ~600 up)
-            const size_t fuse_min_wgs = Tf_ <= 64 ? 4096 : Tf_ <= 128 ? 3072 : 512;
-            const bool fuse = g_hash_fuse && fsm <= 160 * 1024 - 1024 && (integer || at.yrow) &&
-                              (g_hash_fuse >= 2 ||
-                               ((m + (size_t)ipb_f - 1) / (size_t)ipb_f >= fuse_min_wgs &&
-                                (size_t)w * (size_t)h <= (integer ? 1000000u : 1100000u)));
+  }
+  // ---- the VALU kernels: k_blur_area_regs on strips (batches that fill the machine that way), k_blur_area on 16-row bands
+  // column strips: the fewest (1, 2, 4, 8) whose widest window -- first source column of a strip's first cell .. last of
+  // its last -- fits 256 lanes x 8 columns.  (Fractional cells overlap by a pixel: 8191 columns need 8 strips.)
+  int ncol = w <= 2048 ? 1 : w <= 4096 ? 2 : 4, cpw = 32 / ncol, win = 0;
+  std::vector<int> xf;
+  const std::vector<AreaTab> xt_full = integer ? std::vector<AreaTab>() : make_area_tab(w, 32, &xf);
+  for (;; ncol *= 2) {
+    cpw = 32 / ncol;
+    win = 0;
+    if (integer) {
+      win = cpw * isx;
+    } else {
+      for (int c = 0; c < 32; c += cpw)
+        win = std::max(win, xt_full[(size_t)xf[(size_t)(c + cpw)] - 1].si + 1 - xt_full[(size_t)xf[(size_t)c]].si);
+    }
+    if ((win + 7) / 8 <= 256 || ncol == 8) break;
+  }
+  const int Tf = std::min(256, ((win + 7) / 8 + 63) / 64 * 64);
+  if ((win + 7) / 8 > 256) return CBH_E_UNSUPPORTED;  // cannot happen for w <= 8192
+  const int fpitch = Tf * 8 + 8;
+  const size_t fsmem = (size_t)(kBlurRB + K_ - 1) * fpitch + (size_t)(integer ? 0 : at.xn) * sizeof(float);
+  const size_t per_chunk_f = std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)h * 128));
+  float* d_rowsf = nullptr;
+  unsigned char* d_ftiles = nullptr;  // the fused kernel's 32 x 32 tiles (1 KB per image)
+  cbh::Scratch scratch(stream);
+  CBH_HIP(scratch.get(&d_rowsf, std::min(per_chunk_f, n) * (size_t)h * 32 * sizeof(float)));
+  CBH_HIP(scratch.get(&d_ftiles, std::min(per_chunk_f, n) * 1024));
+  for (size_t i0 = 0; i0 < n; i0 += per_chunk_f) {
+    const size_t m = std::min(per_chunk_f, n - i0);
+    const unsigned char* src = d_imgs + i0 * img_stride;
+    unsigned char* tcopy = d_tiles ? d_tiles + i0 * 1024 : nullptr;
+    // strips of `steps` steps when the batch leaves enough workgroups ("hash_stream": 0 never, >= 2 always, of that many)
+    const int kstep = K_ == 7 ? 14 : 15;
+    const long long band_wgs = (long long)ncol * ((h + kBlurRB - 1) / kBlurRB) * (long long)m;
+    int steps = (int)std::min<long long>(8, band_wgs / 3072);
+    steps = std::min(steps, (h + 2 * (K_ / 2) + kstep - 1) / kstep);
+    if (g_hash_stream >= 2) steps = g_hash_stream;
+    if (!g_hash_stream) steps = 0;
+    // a view whose vertical edges are the parent's or lie >= 4 pixels inside it (letterboxed / pillarboxed frames
+    // after autocrop) differs from a whole image in the row mapping and in which lanes mirror: the
+    // register-streaming kernel takes it; other views (a margin of 1..3 pixels) stay on the band kernel
+    const int Lv = (w + 7) / 8;
+    const bool lbox = view && (vw.ox == 0 || vw.ox >= 4) && (vw.ox + w == vw.pw || vw.ox + 8 * Lv + 4 <= vw.pw);
+    if (steps >= 3 && ncol == 1 && (!view || lbox) && (size_t)vw.ph * row_stride < ((size_t)1 << 31)) {
+      const int v_oy = view ? vw.oy : 0, v_ph = view ? vw.ph : 0, v_ox = view ? vw.ox : 0, v_pw = view ? vw.pw : 0;
+      const bool v_ri = view && vw.ox + 8 * Lv + 4 <= vw.pw;  // the last lane reads real pixels: any w mod 8
+      const bool gen = !((w % 8 == 0 || v_ri) && ((uintptr_t)(src + v_ox) % 8) == 0 && row_stride % 8 == 0 &&
+                         img_stride % 8 == 0);
+      // lanes per image = w / 8.  Images whose last wave would be mostly empty share a 256-lane workgroup side by
+      // side (640 px: 80 of 128 lanes busy alone, 240 of 256 as three: +12 %) where that puts 15 % more of the lanes to
+      // work (400 px: 50 of 64 alone, 250 of 256 as five: +3..4 %; 720 / 800 px: two images fill 256 lanes no better than one
+      // fills 128: -2 % packed); where the lanes are already well used the larger workgroup only costs (more waves per
+      // barrier: -5..-9 % measured at 400, 512, 1024 px).  Integer ratios (cheap area phase: the blur lanes decide) count
+      // the packed workgroup's own size -- 704 x 576: 176 of 192 lanes as two against 88 of 128 alone, +10 % --
+      // fractional ones count it as 256 lanes: 720 x 540 and 688 x 516 run 4-5 % faster alone in 128 lanes than as two in 192.
+      const int Lr = (w + 7) / 8, Lw = (Lr + 63) / 64 * 64;
+      const int ipb_try = Lr <= 128 ? 256 / Lr : 1;
+      const int Tp = integer ? (ipb_try * Lr + 63) / 64 * 64 : 256;
+      const bool pack = ipb_try > 1 && (long long)ipb_try * Lr * Lw * 100 >= 115LL * Lr * Tp;
+      const int ipb = (pack && (unsigned long long)ipb_try * img_stride < (1ull << 32)) ? ipb_try : 1;
+      const size_t k_end_r = integer ? 0 : (((size_t)at.xn + 3) & ~(size_t)3) + 512;  // weights + per-cell edge weights
+      const int cpad = cell_pad_for(integer, isx);
+      const size_t rowb = (size_t)(8 * Lr) + (cpad ? 128 : 0);  // LDS bytes of one blurred row
+      const unsigned Tr = (unsigned)std::max(64, (ipb * Lr + 63) / 64 * 64);
+      // rows per step (14 / 21) by how they fill the area phase's turns; the strips keep their length in rows
+      const int ks_r = pick_rows_per_step(K_, Tr, 32, (size_t)ipb * rowb, k_end_r * sizeof(float) + 16);
+      const int steps_r = pick_steps_per_strip(h, ks_r, (steps * kstep + ks_r - 1) / ks_r, 2 * (K_ / 2));
+      const int strip_out_r = steps_r * ks_r - 2 * (K_ / 2);
+      const unsigned gsy_r = (unsigned)((h + strip_out_r - 1) / strip_out_r);
+      const size_t rsmem = (size_t)ipb * ks_r * rowb + k_end_r * sizeof(float) +
+                           16;  // the area walk reads whole words: up to 7 bytes past the last blurred row
+      // whole image per workgroup, vertical pass and tile inside the kernel (FUSE) when the batch still fills
+      // the machine that way: at least two workgroups per CU
+      const int ipb_f = std::min(ipb, 8);
+      const size_t k_end_f = k_end_r;
+      const unsigned Tf_ = (unsigned)std::max(64, (ipb_f * std::max(Lr, 32) + 63) / 64 * 64);
+      const int ks_f = pick_rows_per_step(K_, std::min(256u, Tf_), 32, (size_t)ipb_f * (rowb + 32 * sizeof(float)),
+                                          k_end_f * sizeof(float) + (size_t)ipb_f * 1024);
+      const int steps_f = (h + 2 * (K_ / 2) + ks_f - 1) / ks_f;
+      const size_t fsm = (size_t)ipb_f * ks_f * rowb + k_end_f * sizeof(float) +
+                         (size_t)ipb_f * ks_f * 32 * sizeof(float) + (size_t)ipb_f * 1024;
+      // (measured, hash_fuse 0 -> 2: 320x240 +30 %, 400x300 +22 %, 533x400 +19 %, 640x480 +8 %, 800x600 +6 %,
+      // 1366x768 +6 %, 1024x768 -2 %, 1280x960 -8 %, 1080p -7 %: large images spend little in k_tile_hash and
+      // lose occupancy to the extra LDS; fractional ratios gain up to ~1 MP)
+      // a fused workgroup walks its whole image alone: with one or two waves per workgroup the machine needs
+      // thousands of them before that beats strips of 8 steps (tools/ab/hash_small_batches.py: 400x300, one wave per
+      // image, 1024 images 137 us fused / 86 split, 2048: 160 / 148, 4096: 289 / 298; 800x600, two waves:
+      // 2048 images 553 / 483, 4096: 945 / 951; four-wave workgroups of 3-6 images pay from ~600 up)
+      const size_t fuse_min_wgs = Tf_ <= 64 ? 4096 : Tf_ <= 128 ? 3072 : 512;
+      const bool fuse = g_hash_fuse && fsm <= 160 * 1024 - 1024 && (integer || at.yrow) &&
+                        (g_hash_fuse >= 2 ||
+                         ((m + (size_t)ipb_f - 1) / (size_t)ipb_f >= fuse_min_wgs &&
+                          (size_t)w * (size_t)h <= (integer ? 1000000u : 1100000u)));
 #define CBH_REGS_L(KK, GG, KSV)                                                                              \
   do {                                                                                                       \
     if (fuse) {                                                                                              \
@@ -3921,7 +2994,7 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
       hipLaunchKernelGGL((k_blur_area_regs<KK, GG, true, KSV>), dim3(1, 1, (unsigned)((m + ipb_f - 1) / ipb_f)), \
                          dim3(std::min(256u, Tf_)), fsm, stream, src, w, h, (unsigned)row_stride, img_stride, at.x,       \
                          at.xfirst, isx, steps_f, (float*)nullptr, ipb_f, (unsigned)m, at.yrow, isy, d_ftiles,       \
-                         v_oy, v_ph, v_ox, v_pw, g_hash_area, 0, 32, cpad);                                  \
+                         v_oy, v_ph, v_ox, v_pw, 0, 32, cpad);                                               \
       break;                                                                                                 \
     }                                                                                                        \
     if (rsmem > 64 * 1024)                                                                                   \
@@ -3930,13 +3003,12 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     hipLaunchKernelGGL((k_blur_area_regs<KK, GG, false, KSV>), dim3(1, gsy_r, (unsigned)((m + ipb - 1) / ipb)), dim3(Tr), rsmem, \
                        stream, src, w, h, (unsigned)row_stride, img_stride, at.x, at.xfirst, isx, steps_r, d_rowsf, \
                        ipb, (unsigned)m, (const YRow*)nullptr, 0, (unsigned char*)nullptr, v_oy, v_ph, v_ox, \
-                       v_pw, g_hash_area, 0, 32, cpad);                                                      \
+                       v_pw, 0, 32, cpad);                                                                   \
   } while (0)
 #define CBH_REGS_(KK, GG)                                    \
   do {                                                       \
     const int ks_ = fuse ? ks_f : ks_r;                      \
     if (KK == 7 && ks_ == 21) CBH_REGS_L(7, GG, 21);         \
-    else if (KK == 7 && ks_ == 28) CBH_REGS_L(7, GG, 28);    \
     else CBH_REGS_L(KK, GG, StreamK<KK>::step);              \
   } while (0)
 #define CBH_REGS(KK)              \
@@ -3944,59 +3016,50 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     if (gen) CBH_REGS_(KK, true); \
     else CBH_REGS_(KK, false);    \
   } while (0)
-            switch (K_) {
-              case 3: CBH_REGS(3); break;
-              case 5: CBH_REGS(5); break;
-              default: CBH_REGS(7); break;
-            }
+      switch (K_) {
+        case 3: CBH_REGS(3); break;
+        case 5: CBH_REGS(5); break;
+        default: CBH_REGS(7); break;
+      }
 #undef CBH_REGS_L
 #undef CBH_REGS_
 #undef CBH_REGS
-            if (fuse && g_hash_tiles2) {
-              unsigned char* tcopy = d_tiles ? d_tiles + i0 * 1024 : nullptr;
-              if (g_hash_dct)
-                hipLaunchKernelGGL(k_tiles_hash2<1>, dim3((unsigned)((m + 1) / 2)), dim3(64), 0, stream, d_ftiles, (unsigned)m, tabs,
-                                   d_out + i0, tcopy);
-              else
-                hipLaunchKernelGGL(k_tiles_hash2<0>, dim3((unsigned)((m + 1) / 2)), dim3(64), 0, stream, d_ftiles, (unsigned)m, tabs,
-                                   d_out + i0, tcopy);
-            } else if (fuse)
-              hipLaunchKernelGGL(k_tiles_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_ftiles, tabs, d_out + i0,
-                                 d_tiles ? d_tiles + i0 * 1024 : nullptr);
-            else
-              hipLaunchKernelGGL(k_tile_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_rowsf, h, at.y, at.yfirst,
-                                 isx, isy, 1, tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
-            continue;
-          }
-          // images wider than 2048 pixels: the register-streaming kernel on ncol column strips, each a view of the
-          // parent that makes its share of the 32 output cells (round 4; the LDS band kernel below took them before:
-          // 1.25 TB/s at 4000 x 3000 with the VALU 48 % busy, profiles/r04_pmc_geo.txt)
-          if (g_hash_regs && g_hash_wide && ncol > 1 && !view && K_ == 7 && (size_t)h * row_stride < ((size_t)1 << 31)) {
-            StripTabs stt[8];
-            bool ok = true;
-            for (int sidx = 0; sidx < ncol && ok; ++sidx) {
-              if ((rc = get_strip_tabs(w, integer, ncol, sidx, &stt[sidx]))) return rc;
-              const StripTabs& S_ = stt[sidx];
-              const int Ls = (S_.ws + 7) / 8;
-              ok = S_.ws >= 64 && Ls <= 256 && (S_.x0 == 0 || S_.x0 >= 4) &&
-                   (S_.x0 + S_.ws == w || S_.x0 + 8 * Ls + 4 <= w);
-            }
-            if (ok) {
-              for (int sidx = 0; sidx < ncol; ++sidx) {
-                const StripTabs& S_ = stt[sidx];
-                const int ws = S_.ws, Ls = (ws + 7) / 8;
-                const bool s_ri = S_.x0 + 8 * Ls + 4 <= w;
-                const bool gen = !((ws % 8 == 0 || s_ri) && ((uintptr_t)(src + S_.x0) % 8) == 0 && row_stride % 8 == 0 &&
-                                   img_stride % 8 == 0);
-                const size_t k_end_s = integer ? 0 : (((size_t)S_.xn + 3) & ~(size_t)3) + 512;
-                const int cpad_s = cell_pad_for(integer, isx);
-                const unsigned Ts = (unsigned)std::max(64, (Ls + 63) / 64 * 64);
-                // a strip makes cpw of the 32 cells: 2 Ts / cpw row slots per turn of the area phase, 14 rows fill them badly
-                const int ks_s = pick_rows_per_step(7, Ts, cpw, (size_t)(8 * Ls + (cpad_s ? 128 : 0)), k_end_s * sizeof(float) + 16);
-                const int steps_s = pick_steps_per_strip(h, ks_s, (steps * kstep + ks_s - 1) / ks_s, 6);
-                const int strip_out_s = steps_s * ks_s - 6;
-                const unsigned gsy_s = (unsigned)((h + strip_out_s - 1) / strip_out_s);
-                const size_t smem_s = (size_t)ks_s * (size_t)(8 * Ls + (cpad_s ? 128 : 0)) + k_end_s * sizeof(float) + 16;
+      if (fuse)
+        hipLaunchKernelGGL(k_tiles_hash2, dim3((unsigned)((m + 1) / 2)), dim3(64), 0, stream, d_ftiles, (unsigned)m, tabs,
+                           d_out + i0, tcopy);
+      else
+        hipLaunchKernelGGL(k_tile_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_rowsf, h, at.y, at.yfirst,
+                           isx, isy, 1, tabs, d_out + i0, tcopy);
+      continue;
+    }
+    // images wider than 2048 pixels: the register-streaming kernel on ncol column strips, each a view of the
+    // parent that makes its share of the 32 output cells
+    if (steps >= 3 && ncol > 1 && !view && K_ == 7 && (size_t)h * row_stride < ((size_t)1 << 31)) {
+      StripTabs stt[8];
+      bool ok = true;
+      for (int sidx = 0; sidx < ncol && ok; ++sidx) {
+        if ((rc = get_strip_tabs(w, integer, ncol, sidx, &stt[sidx]))) return rc;
+        const StripTabs& S_ = stt[sidx];
+        const int Ls = (S_.ws + 7) / 8;
+        ok = S_.ws >= 64 && Ls <= 256 && (S_.x0 == 0 || S_.x0 >= 4) &&
+             (S_.x0 + S_.ws == w || S_.x0 + 8 * Ls + 4 <= w);
+      }
+      if (ok) {
+        for (int sidx = 0; sidx < ncol; ++sidx) {
+          const StripTabs& S_ = stt[sidx];
+          const int ws = S_.ws, Ls = (ws + 7) / 8;
+          const bool s_ri = S_.x0 + 8 * Ls + 4 <= w;
+          const bool gen = !((ws % 8 == 0 || s_ri) && ((uintptr_t)(src + S_.x0) % 8) == 0 && row_stride % 8 == 0 &&
+                             img_stride % 8 == 0);
+          const size_t k_end_s = integer ? 0 : (((size_t)S_.xn + 3) & ~(size_t)3) + 512;
+          const int cpad_s = cell_pad_for(integer, isx);
+          const unsigned Ts = (unsigned)std::max(64, (Ls + 63) / 64 * 64);
+          // a strip makes cpw of the 32 cells: 2 Ts / cpw row slots per turn of the area phase, 14 rows fill them badly
+          const int ks_s = pick_rows_per_step(7, Ts, cpw, (size_t)(8 * Ls + (cpad_s ? 128 : 0)), k_end_s * sizeof(float) + 16);
+          const int steps_s = pick_steps_per_strip(h, ks_s, (steps * kstep + ks_s - 1) / ks_s, 6);
+          const int strip_out_s = steps_s * ks_s - 6;
+          const unsigned gsy_s = (unsigned)((h + strip_out_s - 1) / strip_out_s);
+          const size_t smem_s = (size_t)ks_s * (size_t)(8 * Ls + (cpad_s ? 128 : 0)) + k_end_s * sizeof(float) + 16;
 #define CBH_STRIP_L(GG, KSV)                                                                                      \
   do {                                                                                                            \
     if (smem_s > 64 * 1024)                                                                                       \
@@ -4005,43 +3068,26 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     hipLaunchKernelGGL((k_blur_area_regs<7, GG, false, KSV>), dim3(1, gsy_s, (unsigned)m), dim3(Ts), smem_s, stream, src, \
                        ws, h, (unsigned)row_stride, img_stride, integer ? at.x : S_.x, integer ? at.xfirst : S_.xfirst, \
                        isx, steps_s, d_rowsf, 1, (unsigned)m, (const YRow*)nullptr, 0, (unsigned char*)nullptr, 0, h,  \
-                       S_.x0, w, g_hash_area, sidx * cpw, cpw, cpad_s);                                           \
+                       S_.x0, w, sidx * cpw, cpw, cpad_s);                                                        \
   } while (0)
 #define CBH_STRIP(GG)                               \
   do {                                              \
     if (ks_s == 21) CBH_STRIP_L(GG, 21);            \
-    else if (ks_s == 28) CBH_STRIP_L(GG, 28);       \
     else CBH_STRIP_L(GG, 14);                       \
   } while (0)
-                if (gen) CBH_STRIP(true);
-                else CBH_STRIP(false);
+          if (gen) CBH_STRIP(true);
+          else CBH_STRIP(false);
 #undef CBH_STRIP_L
 #undef CBH_STRIP
-              }
-              hipLaunchKernelGGL(k_tile_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_rowsf, h, at.y, at.yfirst,
-                                 isx, isy, 1, tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
-              continue;
-            }
-          }
-#define CBH_STREAM(KK)                                                                                      \
-  do {                                                                                                      \
-    if (ssmem > 64 * 1024)                                                                                  \
-      CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_area_stream<KK>),                    \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ssmem));                 \
-    hipLaunchKernelGGL(k_blur_area_stream<KK>, gs, dim3((unsigned)Tf), ssmem, stream, src, w, h, row_stride, \
-                       img_stride, at.x, at.xfirst, isx, cpw, fpitch, steps, d_rowsf);                      \
-  } while (0)
-          switch (K_) {
-            case 3: CBH_STREAM(3); break;
-            case 5: CBH_STREAM(5); break;
-            default: CBH_STREAM(7); break;
-          }
-#undef CBH_STREAM
-          hipLaunchKernelGGL(k_tile_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_rowsf, h, at.y, at.yfirst,
-                             isx, isy, 1, tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
-          continue;
         }
-        dim3 gf((unsigned)ncol, (unsigned)((h + kBlurRB - 1) / kBlurRB), (unsigned)m);
+        hipLaunchKernelGGL(k_tile_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_rowsf, h, at.y, at.yfirst,
+                           isx, isy, 1, tabs, d_out + i0, tcopy);
+        continue;
+      }
+    }
+    // everything else -- small batches, views with a margin of 1..3 pixels, views of more than 2048 columns: a workgroup
+    // per 16-row band, rows staged in LDS
+    dim3 gf((unsigned)ncol, (unsigned)((h + kBlurRB - 1) / kBlurRB), (unsigned)m);
 #define CBH_FUSED(KK)                                                                                    \
   do {                                                                                                   \
     if (fsmem > 64 * 1024)                                                                               \
@@ -4050,159 +3096,15 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
     hipLaunchKernelGGL(k_blur_area<KK>, gf, dim3((unsigned)Tf), fsmem, stream, src, w, h, row_stride,    \
                        img_stride, at.x, at.xfirst, isx, cpw, fpitch, d_rowsf, vw.pw, vw.ph, vw.ox, vw.oy);  \
   } while (0)
-        switch (K_) {
-          case 3: CBH_FUSED(3); break;
-          case 5: CBH_FUSED(5); break;
-          default: CBH_FUSED(7); break;
-        }
+    switch (K_) {
+      case 3: CBH_FUSED(3); break;
+      case 5: CBH_FUSED(5); break;
+      default: CBH_FUSED(7); break;
+    }
 #undef CBH_FUSED
-        hipLaunchKernelGGL(k_tile_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_rowsf, h, at.y, at.yfirst, isx,
-                           isy, 1, tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
-      }
-      CBH_HIP(hipGetLastError());
-      return CBH_OK;
-    }
-    const size_t per_chunk = std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)w * h));
-    const size_t mc = std::min(per_chunk, n);
-    unsigned char* d_blur = nullptr;
-    float* d_rows = nullptr;
-    cbh::Scratch scratch(stream);
-    CBH_HIP(scratch.get(&d_blur, mc * (size_t)w * h));
-    CBH_HIP(scratch.get(&d_rows, mc * (size_t)yn * 32 * sizeof(float)));
-    for (size_t i0 = 0; i0 < n; i0 += per_chunk) {
-      const size_t m = std::min(per_chunk, n - i0);
-      const unsigned char* src = d_imgs + i0 * img_stride;
-      dim3 gb((unsigned)((w + T * 8 - 1) / (T * 8)), (unsigned)((h + kBlurRB - 1) / kBlurRB),
-              (unsigned)((m + ipb - 1) / ipb));
-#define CBH_BLURF(KK)                                                                                   \
-  do {                                                                                                  \
-    if (smem > 64 * 1024)                                                                               \
-      CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_rows<KK>),                       \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));              \
-    hipLaunchKernelGGL(k_blur_rows<KK>, gb, dim3((unsigned)block_threads), smem, stream, src, w, h,     \
-                       row_stride, img_stride, d_blur, pitch, T, ipb, (unsigned)m);                     \
-  } while (0)
-      switch (K_) {
-        case 3: CBH_BLURF(3); break;
-        case 5: CBH_BLURF(5); break;
-        default: CBH_BLURF(7); break;
-      }
-#undef CBH_BLURF
-      const int apitch = (w + 3) / 4 * 4 + 4;
-      const size_t asmem = 8 * (size_t)apitch + (size_t)at.xn * sizeof(float);
-      if (asmem > 64 * 1024)
-        CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_area_rows),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)asmem));
-      hipLaunchKernelGGL(k_area_rows, dim3((unsigned)((yn + 7) / 8), (unsigned)m), dim3(256), asmem, stream,
-                         d_blur, w, h, at.x, at.xn, at.xfirst, at.y, yn, isx, d_rows, apitch);
-      hipLaunchKernelGGL(k_tile_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_rows, yn, at.y, at.yfirst,
-                         isx, isy, 0, tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
-    }
-    CBH_HIP(hipGetLastError());
-    return CBH_OK;
+    hipLaunchKernelGGL(k_tile_hash, dim3((unsigned)m), dim3(kThreads), 0, stream, d_rowsf, h, at.y, at.yfirst, isx,
+                       isy, 1, tabs, d_out + i0, tcopy);
   }
-  if (!area_fast(w, h) || w > 1024 || h > 1024) {
-    // general INTER_AREA path: blur to scratch, then weighted resample + hash
-    const long long area_ = (long long)w * h;
-    const int K_ = area_ <= 32 * 32 ? 0 : area_ <= 64 * 64 ? 3 : area_ <= 128 * 128 ? 5 : 7;
-    AreaTabsDev at;
-    if ((rc = get_area_tabs(w, h, &at))) return rc;
-    int band = (int)std::min<long long>(h, std::max<long long>(1, (96 * 1024) / (3LL * w) - 2 * (K_ / 2)));
-    const size_t smem = (size_t)(band + 2 * (K_ / 2)) * (size_t)w * 3;
-    const size_t per_chunk = std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)w * h));
-    unsigned char* d_blur = nullptr;
-    cbh::Scratch scratch(stream);
-    CBH_HIP(scratch.get(&d_blur, std::min(per_chunk, n) * (size_t)w * h));
-    for (size_t i0 = 0; i0 < n; i0 += per_chunk) {
-      const size_t m = std::min(per_chunk, n - i0);
-      dim3 g1((unsigned)m, (unsigned)((h + band - 1) / band)), block(kThreads);
-      const unsigned char* src = d_imgs + i0 * img_stride;
-#define CBH_BLUR(KK)                                                                                    \
-  do {                                                                                                  \
-    if (smem > 64 * 1024)                                                                               \
-      CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_u8<KK>),                         \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));              \
-    hipLaunchKernelGGL(k_blur_u8<KK>, g1, block, smem, stream, src, w, h, row_stride, img_stride, band, \
-                       d_blur);                                                                         \
-  } while (0)
-      switch (K_) {
-        case 0: CBH_BLUR(0); break;
-        case 3: CBH_BLUR(3); break;
-        case 5: CBH_BLUR(5); break;
-        default: CBH_BLUR(7); break;
-      }
-#undef CBH_BLUR
-      hipLaunchKernelGGL(k_area_hash, dim3((unsigned)m), block, 0, stream, d_blur, w, h, at.x, at.xn, at.y,
-                         at.yn, at.xfirst, at.yfirst, area_fast(w, h) ? w / 32 : 0, area_fast(w, h) ? h / 32 : 0,
-                         tabs, d_out + i0, d_tiles ? d_tiles + i0 * 1024 : nullptr);
-    }
-    CBH_HIP(hipGetLastError());
-    return CBH_OK;
-  }
-  if (w == 256 && h == 256 && ((uintptr_t)d_imgs % 8) == 0 && row_stride % 8 == 0 &&
-      img_stride % 8 == 0 && row_stride * 256 < (1u << 24) && img_stride < (1u << 28)) {
-    if (g_hash_mfma != 0 && ((uintptr_t)d_imgs % 16) == 0 && row_stride % 16 == 0 && img_stride % 16 == 0) {
-      const BandTables* btab = nullptr;
-      if (get_band_tables(&btab) != CBH_OK) goto valu_256;  // no table on this device: the all-VALU kernel needs none
-      dim3 gridb((unsigned)((n + 3) / 4));
-#define CBH_BAND_(DUMP_, DCT_, NW_)                                                                                \
-  hipLaunchKernelGGL((k_dcthash_256_band<DUMP_, DCT_, NW_>), gridb, dim3(64 * NW_), 0, stream, d_imgs, (unsigned)n, \
-                     (unsigned)row_stride, (unsigned)img_stride, tabs, btab, d_out, d_tiles)
-#define CBH_BAND(DUMP_, DCT_)                       \
-  do {                                              \
-    if (g_hash_band_waves == 1) CBH_BAND_(DUMP_, DCT_, 1); \
-    else CBH_BAND_(DUMP_, DCT_, 2);                 \
-  } while (0)
-      if (g_hash_dct) {
-        if (d_tiles) CBH_BAND(true, 1); else CBH_BAND(false, 1);
-      } else {
-        if (d_tiles) CBH_BAND(true, 0); else CBH_BAND(false, 0);
-      }
-#undef CBH_BAND
-#undef CBH_BAND_
-      CBH_HIP(hipGetLastError());
-      return CBH_OK;
-    }
-  valu_256:
-    dim3 grid((unsigned)((n + 7) / 8)), block(kThreads);
-#define CBH_256(DUMP_, DCT_, DIV_)                                                                         \
-  hipLaunchKernelGGL((k_dcthash_256<DUMP_, DCT_, DIV_>), grid, block, (size_t)g_hash_lds_pad, stream, d_imgs, \
-                     (unsigned)n, (unsigned)row_stride, (unsigned)img_stride, tabs, d_out, d_tiles)
-#define CBH_256D(DCT_, DIV_)                                   \
-  do {                                                        \
-    if (d_tiles) CBH_256(true, DCT_, DIV_);                   \
-    else CBH_256(false, DCT_, DIV_);                          \
-  } while (0)
-    if (g_hash_dct) {
-      if (g_hash_div == 3) CBH_256D(1, 3); else if (g_hash_div == 2) CBH_256D(1, 2); else if (g_hash_div) CBH_256D(1, 1); else CBH_256D(1, 0);
-    } else {
-      if (g_hash_div == 3) CBH_256D(0, 3); else if (g_hash_div == 2) CBH_256D(0, 2); else if (g_hash_div) CBH_256D(0, 1); else CBH_256D(0, 0);
-    }
-#undef CBH_256D
-#undef CBH_256
-    CBH_HIP(hipGetLastError());
-    return CBH_OK;
-  }
-  const long long area = (long long)w * h;
-  const int K = area <= 32 * 32 ? 0 : area <= 64 * 64 ? 3 : area <= 128 * 128 ? 5 : 7;
-  const size_t smem = generic_smem_bytes(w, h, K);
-  if (smem > 160 * 1024) return CBH_E_UNSUPPORTED;
-  dim3 grid((unsigned)n), block(kThreads);
-#define CBH_LAUNCH_GENERIC(KK)                                                              \
-  do {                                                                                      \
-    if (smem > 64 * 1024)                                                                   \
-      CBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dcthash_generic<KK>),     \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));  \
-    hipLaunchKernelGGL(k_dcthash_generic<KK>, grid, block, smem, stream, d_imgs, w, h,      \
-                       row_stride, img_stride, tabs, d_out, d_tiles);                       \
-  } while (0)
-  switch (K) {
-    case 0: CBH_LAUNCH_GENERIC(0); break;
-    case 3: CBH_LAUNCH_GENERIC(3); break;
-    case 5: CBH_LAUNCH_GENERIC(5); break;
-    default: CBH_LAUNCH_GENERIC(7); break;
-  }
-#undef CBH_LAUNCH_GENERIC
   CBH_HIP(hipGetLastError());
   return CBH_OK;
 }

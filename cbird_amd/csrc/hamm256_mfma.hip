@@ -283,10 +283,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_hamm256_mfma3(  // (2: accumula
 // streams row tiles -- the raw words of the next tile are in flight while the current one runs its NT x 2 MFMAs -- and
 // the grid is sized for the machine, not for the needle chunks.  First-128-bit prefilter only (thresh <= 40) with the
 // three-tiles-per-accumulator fields of k_hamm256_mfma3.  Records identical to k_hamm256_mfma / k_hamm256_scan.
-// LUT (round 4): every streamed row tile has to be expanded to FP4 -- 2 words x 4 dwords x 9 shift / mask instructions
+// The table (round 4): every streamed row tile has to be expanded to FP4 -- 2 words x 4 dwords x 9 shift / mask instructions
 // per lane, 3.1 of the kernel's 4.6 VALU instructions per MFMA (profiles/r04_pmc_mfma_utilisation.md).  A 256-entry table
 // in LDS (byte -> its 8 sign nibbles) turns that into 8 ds_read_b32 + their addresses.
-template <int NT, bool LUT>
+template <int NT>
 __global__ __launch_bounds__(kThreads, 2) void k_hamm256_small(  // (2: accumulators in VGPRs, see k_hamm64_mfma3)
     const uint32_t* __restrict__ rows /* 8 words per row */, uint32_t n, const uint4* __restrict__ qx,
     const uint32_t* __restrict__ qraw, uint32_t nq, uint32_t thresh, unsigned long long* __restrict__ rec,
@@ -296,19 +296,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_hamm256_small(  // (2: accumula
   constexpr int NA = (NT + 2) / 3;
   constexpr int G = NA % 3 == 0 ? 3 : 2;  // accumulators in flight (independent MFMA chains)
   __shared__ uint32_t s_c[kWaves][G * 16][64];
-  __shared__ uint32_t s_lut[LUT ? 256 : 1];
+  __shared__ uint32_t s_lut[256];
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // uniform, and known to be
   const uint32_t r = lane & 31u, half = lane >> 5;
-  if constexpr (LUT) {
-    for (uint32_t i = threadIdx.x; i < 256u; i += kThreads) s_lut[i] = fp4_expand32(i).x;
-    __syncthreads();
-  }
+  for (uint32_t i = threadIdx.x; i < 256u; i += kThreads) s_lut[i] = fp4_expand32(i).x;
+  __syncthreads();
   auto expand = [&](uint32_t w) -> uint4 {
-    if constexpr (LUT)
-      return make_uint4(s_lut[w & 0xffu], s_lut[(w >> 8) & 0xffu], s_lut[(w >> 16) & 0xffu], s_lut[w >> 24]);
-    else
-      return fp4_expand32(w);
+    return make_uint4(s_lut[w & 0xffu], s_lut[(w >> 8) & 0xffu], s_lut[(w >> 16) & 0xffu], s_lut[w >> 24]);
   };
   v8i b[NT][2];
 #pragma unroll
@@ -413,38 +408,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_hamm256_small(  // (2: accumula
 }
 
 int g_scan256_small = 1;   // "scan256_small": the stationary-needle kernel for <= 512 needle descriptors (default on)
-int g_scan256_small_wgs = 0;  // its grid (workgroups); 0 = 2048
-int g_scan256_lut = 1;        // "scan256_lut": its FP4 expansion through the LDS table (1) or with shifts and masks (0)
 int g_scan256_mfma = 1;
-int g_scan256_f3 = 1;      // "scan256_f3": three needle tiles per accumulator in the prefilter (k_hamm256_mfma3); 0 = one
-int g_scan256_pre = 1;     // first-128-bit prefilter variant for thresh <= kPre128MaxThresh
-int g_scan256_pre_ht = 6;   // its row tiles per wave (6, 8, 12)
-constexpr int kPre128MaxThresh = 40;
-int g_scan256_ht = 6;  // row tiles per wave (2, 4, 6)
-int g_scan256_g = 3;   // row tiles per accumulator group = independent 4-MFMA chains in flight
+constexpr int kPre128MaxThresh = 40;  // thresholds up to this take a first-128-bit prefilter variant
 
 }  // namespace
 
 void set_scan256_mfma(int on) {
   if (on >= 0) g_scan256_mfma = on;
 }
-void set_scan256_g(int g) {
-  if (g >= 1 && g <= 4) g_scan256_g = g;
-}
-void set_scan256_ht(int ht) {
-  if (ht == 2 || ht == 4 || ht == 6) g_scan256_ht = ht;
-  if (ht == 106 || ht == 108 || ht == 112) g_scan256_pre_ht = ht - 100;  // prefilter variant: 106 / 108 / 112
-}
-void set_scan256_lut(int v) { g_scan256_lut = v ? 1 : 0; }
 void set_scan256_small(int v) {
   if (v == 0 || v == 1) g_scan256_small = v;
-  if (v >= 16) g_scan256_small_wgs = v;  // workgroups of the persistent grid
-}
-void set_scan256_f3(int v) {
-  if (v >= 0) g_scan256_f3 = v;  // 0 off, 1 default shape, 62 / 63 / 82 / 122 / 123: HT G
-}
-void set_scan256_pre(int on) {
-  if (on >= 0) g_scan256_pre = on;
 }
 
 bool scan256_mfma_wanted(size_t n, size_t nq, int thresh) {
@@ -464,7 +437,7 @@ int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, siz
   CBH_HIP(cbh::malloc_async((void**)&qx, (size_t)nq_pad * 128u, stream));
   hipLaunchKernelGGL(k_expand_needles256, dim3((8u * nq_pad + 255u) / 256u), dim3(256), 0, stream,
                      reinterpret_cast<const uint32_t*>(d_q), (uint32_t)nq, nq_pad, qx);
-  if (g_scan256_small && g_scan256_pre && thresh <= kPre128MaxThresh && n_tiles <= 16 && (n >= 4096 || g_scan256_mfma == 2) &&
+  if (g_scan256_small && thresh <= kPre128MaxThresh && n_tiles <= 16 && (n >= 4096 || g_scan256_mfma == 2) &&
       n <= ((size_t)1 << 27) - 64) {  // (its buffer descriptor spans n * 32 bytes)
     // needle tiles padded to the template's count read zero descriptors from the scratch (rows of zero bits never pass:
     // qi >= nq is dropped in the hit path)
@@ -477,26 +450,20 @@ int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, siz
                          reinterpret_cast<const uint32_t*>(d_q), (uint32_t)nq, nt * 32u, qx);
     }
     const uint32_t row_tiles = (uint32_t)((n + 31) / 32);
-    uint32_t wgs_s = g_scan256_small_wgs > 0 ? (uint32_t)g_scan256_small_wgs : 2048u;  // measured: 512 / 1024 / 2048 / 8192 = 1.22 / 1.10 / 1.07 / 1.07 ms
+    uint32_t wgs_s = 2048u;  // workgroups of the persistent grid; measured: 512 / 1024 / 2048 / 8192 = 1.22 / 1.10 / 1.07 / 1.07 ms
     wgs_s = std::min(wgs_s, (row_tiles + kWaves - 1) / kWaves);
-#define CBH_SMALL_(NTT, LL)                                                                                          \
-  hipLaunchKernelGGL((k_hamm256_small<NTT, LL>), dim3(wgs_s), dim3(kThreads), 0, stream,                               \
+#define CBH_SMALL(NTT)                                                                                               \
+  hipLaunchKernelGGL((k_hamm256_small<NTT>), dim3(wgs_s), dim3(kThreads), 0, stream,                                   \
                      reinterpret_cast<const uint32_t*>(d_rows), (uint32_t)n, qx, reinterpret_cast<const uint32_t*>(d_q), \
                      (uint32_t)nq, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total)
-#define CBH_SMALL(NTT)                \
-  do {                                \
-    if (g_scan256_lut) CBH_SMALL_(NTT, true); \
-    else CBH_SMALL_(NTT, false);      \
-  } while (0)
     if (nt == 4) CBH_SMALL(4); else if (nt == 8) CBH_SMALL(8); else CBH_SMALL(16);
 #undef CBH_SMALL
-#undef CBH_SMALL_
     hipError_t es = hipGetLastError();
     (void)cbh::free_async(qx, stream);
     CBH_HIP(es);
     return CBH_OK;
   }
-  if (g_scan256_f3 && g_scan256_pre && thresh <= kPre128MaxThresh && n_tiles >= 3) {
+  if (thresh <= kPre128MaxThresh && n_tiles >= 3) {
     const uint32_t n_triples = (n_tiles + 2u) / 3u;
     if (n_triples * 3u != n_tiles) {  // the scratch must hold whole triples (zero descriptors: dropped at qi >= nq)
       (void)cbh::free_async(qx, stream);
@@ -505,8 +472,9 @@ int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, siz
       hipLaunchKernelGGL(k_expand_needles256, dim3((8u * n_triples * 96u + 255u) / 256u), dim3(256), 0, stream,
                          reinterpret_cast<const uint32_t*>(d_q), (uint32_t)nq, n_triples * 96u, qx);
     }
-    const int shape = g_scan256_f3 >= 10 ? g_scan256_f3 : 122;  // measured (1e7 rows x 32 000 needles): 62 / 63 / 82 / 122 / 123 = 12.2 / 11.6 / 11.3 / 10.9 / 10.9 ms, one tile per accumulator 13.4
-    const int ht3 = shape / 10, g3 = shape % 10;
+    // shape: 12 row tiles per wave, groups of 2 (measured, 1e7 rows x 32 000 needles: 6/2, 6/3, 8/2, 12/2, 12/3 =
+    // 12.2 / 11.6 / 11.3 / 10.9 / 10.9 ms; one tile per accumulator 13.4)
+    constexpr int ht3 = 12;
     const uint32_t rows_per_wg3 = 32u * (uint32_t)ht3 * kWaves;
     const uint32_t wgs3 = (uint32_t)((n + rows_per_wg3 - 1) / rows_per_wg3);
     uint32_t tpc3 = 43;  // needle triples per chunk (4128 descriptors)
@@ -521,19 +489,15 @@ int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, siz
                      reinterpret_cast<const uint32_t*>(d_rows), (uint32_t)n, qx,                        \
                      reinterpret_cast<const uint32_t*>(d_q), (uint32_t)nq, n_triples, tpc3,             \
                      (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total)
-    if (ht3 == 12 && g3 == 3) CBH_256F3(12, 3);
-    else if (ht3 == 12) CBH_256F3(12, 2);
-    else if (ht3 == 8) CBH_256F3(8, 2);
-    else if (g3 == 3) CBH_256F3(6, 3);
-    else CBH_256F3(6, 2);
+    CBH_256F3(12, 2);
 #undef CBH_256F3
     hipError_t e3 = hipGetLastError();
     (void)cbh::free_async(qx, stream);
     CBH_HIP(e3);
     return CBH_OK;
   }
-  const bool pre128_ = g_scan256_pre && thresh <= kPre128MaxThresh;
-  const int ht = pre128_ ? g_scan256_pre_ht : (g_scan256_ht == 12 || g_scan256_ht == 8 ? 6 : g_scan256_ht);
+  // fewer than three needle tiles, or thresholds beyond the prefilter's range: one tile per accumulator
+  constexpr int ht = 6;
   const uint32_t rows_per_wg = 32u * (uint32_t)ht * kWaves;
   const uint32_t wgs = (uint32_t)((n + rows_per_wg - 1) / rows_per_wg);
   uint32_t tpc = 128;  // needle tiles per chunk (4096 descriptors)
@@ -543,21 +507,13 @@ int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, siz
     tpc = (n_tiles + 65534) / 65535;
     chunks = (n_tiles + tpc - 1) / tpc;
   }
-  const bool pre128 = g_scan256_pre && thresh <= kPre128MaxThresh;
+  const bool pre128 = thresh <= kPre128MaxThresh;
 #define CBH_256(HT, GG, KC)                                                                       \
   hipLaunchKernelGGL((k_hamm256_mfma<HT, GG, KC>), dim3(wgs, chunks), dim3(kThreads), 0, stream,  \
                      reinterpret_cast<const uint32_t*>(d_rows), (uint32_t)n, qx,                  \
                      reinterpret_cast<const uint32_t*>(d_q), (uint32_t)nq, n_tiles, tpc,          \
                      (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total)
-  if (pre128) {
-    if (ht == 12) CBH_256(12, 3, 2); else if (ht == 8) CBH_256(8, 2, 2); else CBH_256(6, 3, 2);
-  } else if (ht == 2) {
-    if (g_scan256_g == 1) CBH_256(2, 1, 4); else CBH_256(2, 2, 4);
-  } else if (ht == 6) {
-    if (g_scan256_g == 1) CBH_256(6, 1, 4); else if (g_scan256_g == 2) CBH_256(6, 2, 4); else CBH_256(6, 3, 4);
-  } else {
-    if (g_scan256_g == 4) CBH_256(4, 4, 4); else if (g_scan256_g == 1) CBH_256(4, 1, 4); else CBH_256(4, 2, 4);
-  }
+  if (pre128) CBH_256(6, 3, 2); else CBH_256(6, 3, 4);
 #undef CBH_256
   hipError_t e = hipGetLastError();
   (void)cbh::free_async(qx, stream);

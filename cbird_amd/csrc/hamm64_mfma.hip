@@ -24,12 +24,12 @@
 //   * both halves are positive normal f16 bit patterns, so v_pk_maximum3_f16 (new on gfx950) takes
 //     the per-half maximum of three registers at once: 4 ops per MFMA instead of 8.
 //
-// Three variants (all exact), chosen by the launcher:
-//   FULL3 (k_hamm64_mfma3, thresholds g_pre_max_thresh+1 .. 64) three needle tiles per accumulator, detection by
-//         OR of flag bits -- described at the kernel below; the default for most thresholds.
-//   FULL2 (thresh 65, or FULL3 switched off) K = the 64 bits of one hash; tile B is a second MFMA accumulated
+// Three variants (all exact), chosen by the launcher (pick_pre below: per launch, from the candidate rate of the data):
+//   FULL3 (k_hamm64_mfma3, thresholds up to 64 that the prefilter does not take) three needle tiles per accumulator,
+//         detection by OR of flag bits -- described at the kernel below.
+//   FULL2 (thresh 65 only) K = the 64 bits of one hash; tile B is a second MFMA accumulated
 //         onto tile A's.  hi16 = 0x4B40 - distB, lo16 = 0x4080 - 2*distA.  Hits are real matches.
-//   PRE   (thresh <= g_pre_max_thresh) 32-bit prefilter at twice the pair rate.  The 32-bit word is the FOLD
+//   PRE   (small thresholds while candidates are rare) 32-bit prefilter at twice the pair rate.  The 32-bit word is the FOLD
 //         f(x) = lo(x) ^ hi(x): bit i of f(a) ^ f(b) is the XOR of bits i and i + 32 of a ^ b, so
 //         popc(f(a) ^ f(b)) <= popc(a ^ b) -- a lower bound on the distance that looks at all 64 bits.  (Round 1-4
 //         used the low word alone: also a lower bound, but the low-frequency coefficients of images agree far more
@@ -41,17 +41,24 @@
 //         top one flags by carrying into the exponent), reduced with v_or3_b32 -- one result VGPR per 256
 //         comparisons.  Candidates are re-evaluated on the full 64 bits.
 //
-// Hits.  After the MFMAs of a group of G haystack tiles one compare of the packed maximum decides
-// whether anything is under the threshold.  Then, tile by tile, the lanes that hold flagged
-// results push (lane, register, field, distance) into a wave-private LDS queue and the whole
-// wave drains it, one candidate per lane: dense result sets (videos, duplicates) are emitted 64 at
-// a time instead of by one lane.
+// Hits.  After the MFMAs of a group of G haystack tiles one compare of the reduced flags decides
+// whether anything is under the threshold.  Then the lanes that hold flagged results list them in wave-private
+// LDS and the whole wave works the list off, one candidate per lane.  RECORDS are not written one by one either:
+// every append to the result block moves its counter, ONE address for the whole device, and the L2 takes ~10 ns
+// per atomic on one address whatever its operand -- 10^6 self matches of a self-join are 10 ms of serial atomics
+// beside a 9-16 ms scan, 5 x 10^6 duplicate matches tripled the three-field kernel's time (profiles/
+// r06_adaptive_ab_before.jsonl).  A wave parks its records in LDS (kOutCap of them) and appends them with one atomic.
 //
 // Layout.  A workgroup is 4 waves; each wave keeps HT haystack tiles (32 rows each) expanded
-// to FP4 in VGPRs (4 VGPRs per tile: lane (r, half) holds word `half` of row r; PRE: the low
-// word in both halves) and streams needle tiles -- pre-expanded once per call by
+// to FP4 in VGPRs (4 VGPRs per tile: lane (r, half) holds word `half` of row r; PRE: the fold
+// lo ^ hi in both halves) and streams needle tiles -- pre-expanded once per call by
 // k_expand_needles into a 32-byte-per-needle scratch -- through 16-byte loads that the 4 waves
 // share in L1/L2.
+#include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <vector>
+
 #include "cbh_internal.h"
 #include "fp4_sign.h"
 
@@ -62,20 +69,12 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
-constexpr int kG = 2;  // tiles per accumulator group
+constexpr int kHT = 8;  // haystack tiles a wave keeps in registers (256 rows)
+constexpr int kG = 2;   // tiles per accumulator group
 // 2^23 + 0x4040 + 64 * 2^15
 constexpr float kC0 = 8388608.0f + 16448.0f + 2097152.0f;
 constexpr int kScale15 = 0x8e8e8e8e;  // E8M0 142 = 2^15
-// Thresholds the prefilter serves ("scan_mfma_pre_max").  P[popc(32 random bits) < t] per pair: 1.3e-6 at 4, 9.7e-6 at 5,
-// 5.7e-5 at 6, 2.7e-4 at 7.  Rounds 1-4 stopped at 4: on the low word, image-derived hashes gave 2.7x the candidates of
-// uniform ones at 5 and the vector re-check (~750 cycles per candidate group) lost to FULL3 (19.2 vs 17.1 ms).  With the
-// fold and the deferred re-check (round 5; same box, 1M x 1M image-derived hashes, tools/ab/pre_fold_ab.py): threshold 5
-// 10.0 ms against FULL3's 16.7, threshold 6 13.8 against 16.7, threshold 7 31.7 -- hence 6.
-int g_pre_max_thresh = 6;
-int g_pre_fold = 1;   // "scan_pre_fold": 1 = prefilter on lo ^ hi (default), 0 = on the low word (rounds 1-4, A/B)
-int g_pre_lean = 1;   // "scan_pre_lean": 1 = a group whose candidates sit in ONE register of ONE lane is re-checked on
-                      // the scalar unit (readlane + s_load + s_bcnt1), 0 = always the LDS queue path (A/B)
-constexpr uint32_t kQueue = 2048;     // 16 registers x 2 fields x 64 lanes: cannot overflow
+constexpr uint32_t kQueue = 2048;     // words of wave-private LDS behind the prefilter / two-field kernels
 // PRE keeps FOUR prefilter-word distances per accumulator register as 6-bit fields at bits 0, 6, 12, 18 (two chained
 // MFMAs; see the kernel), biased so that "under the threshold" is bit 5 of the field; the top field's flag is the carry
 // into the f32 exponent (bit 23 of the pattern).  OR-ing accumulators preserves "some flag is set".
@@ -86,9 +85,9 @@ constexpr int kScale11 = (int)0x8a8a8a8a;    // 2^11
 constexpr int kScale17 = (int)0x90909090;    // 2^17
 
 // needles -> FP4 scratch: needle j -> 2 x uint4 (low word, high word) at qx[2j], and behind those (qx[2 * nq_pad + j])
-// the prefilter word of needle j (fold ? lo ^ hi : lo); j >= nq padded with hash 0
+// the prefilter word lo ^ hi of needle j; j >= nq padded with hash 0
 __global__ __launch_bounds__(256) void k_expand_needles(const uint64_t* __restrict__ q, uint32_t nq,
-                                                        uint32_t nq_pad, uint4* __restrict__ qx, uint32_t fold) {
+                                                        uint32_t nq_pad, uint4* __restrict__ qx) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;  // one thread per output uint4
   if (i >= 3u * nq_pad) return;
   const uint32_t* w = reinterpret_cast<const uint32_t*>(q);
@@ -96,15 +95,8 @@ __global__ __launch_bounds__(256) void k_expand_needles(const uint64_t* __restri
     qx[i] = fp4_expand32((i >> 1) < nq ? w[i] : 0u);
   } else {
     const uint32_t j = i - 2u * nq_pad;
-    qx[i] = fp4_expand32(j < nq ? (fold ? w[2u * j] ^ w[2u * j + 1u] : w[2u * j]) : 0u);
+    qx[i] = fp4_expand32(j < nq ? w[2u * j] ^ w[2u * j + 1u] : 0u);
   }
-}
-
-__device__ __forceinline__ void emit(cbh_record* __restrict__ rec, unsigned long long cap,
-                                     unsigned long long* __restrict__ total, uint32_t qidx,
-                                     uint32_t dist, uint32_t id) {
-  unsigned long long slot = atomicAdd(total, 1ull);  // compiler aggregates per wave
-  if (slot < cap) rec[slot] = ((cbh_record)qidx << 39) | ((cbh_record)dist << 32) | id;
 }
 
 __device__ __forceinline__ h2 as_h2(float f) { return __builtin_bit_cast(h2, f); }
@@ -112,7 +104,7 @@ __device__ __forceinline__ uint32_t as_u32(float f) { return __builtin_bit_cast(
 __device__ __forceinline__ h2 pkmax3(h2 a, h2 b, h2 c) {
   return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c);  // v_pk_maximum3_f16
 }
-// The queue below is wave-private and the LDS executes one wave's instructions in order, so a
+// The queues below are wave-private and the LDS executes one wave's instructions in order, so a
 // ds_read issued after a ds_write of another lane of the same wave sees it: only the COMPILER must
 // be kept from reordering or caching LDS accesses across the hand-over points (a compiler-level memory
 // clobber; `volatile` would make it wait for every outstanding needle prefetch at each access).
@@ -121,7 +113,6 @@ __device__ __forceinline__ void wave_order() {
   __builtin_amdgcn_wave_barrier();
   asm volatile("" ::: "memory");
 }
-
 
 struct HitParams {
   uint32_t lo_key, hi_key, lo_zero, hi_zero, thresh, n, nq, keep0;
@@ -134,6 +125,40 @@ struct HitParams {
   const uint2* qmask;    // optional: bits of (needle ^ slot) that must be zero
 };
 
+// ---- records: parked per wave, appended with one atomic ---------------------------------------------------------------
+// s_out = 2 * kOutCap words of the wave's LDS, nout = records parked (wave-uniform; callers keep it in an SGPR).
+// All three functions must be reached by the WHOLE wave (uniform control flow: they ballot).
+constexpr uint32_t kOutCap = 128;
+__device__ __forceinline__ void out_flush(uint32_t* s_out, uint32_t& nout, const HitParams& hp) {
+  if (nout == 0) return;
+  wave_order();
+  const uint32_t lane = threadIdx.x & 63u;
+  unsigned long long base = 0;
+  if (lane == 0) base = atomicAdd(hp.total, (unsigned long long)nout);
+  const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+  const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+  base = ((unsigned long long)bhi << 32) | blo;
+  for (uint32_t k = lane; k < nout; k += 64u) {
+    const uint2 r = *reinterpret_cast<const uint2*>(&s_out[2u * k]);
+    if (base + k < hp.cap) hp.rec[base + k] = ((cbh_record)r.y << 32) | r.x;  // (past cap: counted, not stored)
+  }
+  wave_order();
+  nout = 0;
+}
+// every lane with `has` contributes the record  needle qidx << 39 | dist << 32 | id
+__device__ __forceinline__ void out_push(uint32_t* s_out, uint32_t& nout, bool has, uint32_t qidx, uint32_t dist,
+                                         uint32_t id, const HitParams& hp) {
+  const uint64_t m = __builtin_amdgcn_ballot_w64(has);
+  if (m == 0) return;
+  const uint32_t c = (uint32_t)__popcll(m);
+  if (nout + c > kOutCap) out_flush(s_out, nout, hp);
+  if (has) {
+    const uint32_t pos = nout + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    *reinterpret_cast<uint2*>(&s_out[2u * pos]) = make_uint2(id, (qidx << 7) | dist);
+  }
+  nout += c;
+}
+
 // the reference's approximate structures compare a needle only with entries sharing its low bits
 __device__ __forceinline__ bool mask_ok(const HitParams& hp, uint32_t row, uint32_t qi, uint64_t nv) {
   if (!hp.qmask) return true;
@@ -141,24 +166,16 @@ __device__ __forceinline__ bool mask_ok(const HitParams& hp, uint32_t row, uint3
   return (((hv.x ^ (uint32_t)nv) & mk.x) | ((hv.y ^ (uint32_t)(nv >> 32)) & mk.y)) == 0;
 }
 
-// Cold path (inlined once per haystack tile of the single step() call site; a real call costs far
-// more per hit: spills around the call and waits on the needle prefetches).
+// FULL2, cold path (inlined once per haystack tile of the step's call site).
 // One haystack tile's 16 accumulators: the lanes holding flagged results append
 //   dist<<11 | field<<10 | g<<6 | lane
 // to the wave's LDS queue (ballot + mbcnt compaction, count in an SGPR), then the whole wave drains
 // the queue, one candidate per lane.  C/D layout of the 32x32 MFMA: column = lane & 31 -> needle,
 // row = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5) -> haystack row in the tile.
-template <bool PRE>
-__device__ __forceinline__ void handle_tile(const v16f& c, uint32_t row0, uint32_t hay_off, uint32_t p,
-                                            const HitParams& hp, uint32_t* s_queue, const uint2* s_hay) {
+__device__ __forceinline__ void handle_tile2(const v16f& c, uint32_t row0, uint32_t p, const HitParams& hp,
+                                             uint32_t* s_queue, uint32_t* s_out, uint32_t& nout) {
   const uint32_t lane = threadIdx.x & 63u;
-  // quick reject of the tile that did not cause the group's hit
-  if (PRE) {
-    uint32_t any = 0;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) any |= as_u32(c[g]);
-    if (__builtin_amdgcn_ballot_w64((any & kFlagMaskPre) != 0) == 0) return;
-  } else {
+  {  // quick reject of the tile that did not cause the group's hit
     h2 m0 = {0, 0}, m1 = {0, 0};
 #pragma unroll
     for (int g = 0; g < 16; g += 4) {
@@ -167,52 +184,6 @@ __device__ __forceinline__ void handle_tile(const v16f& c, uint32_t row0, uint32
     }
     const uint32_t tb = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(m0, m1));
     if (__builtin_amdgcn_ballot_w64((tb << 16) >= hp.lo_key || tb >= hp.hi_key) == 0) return;
-  }
-
-  if constexpr (PRE) {
-    // four fields per register; the queue holds 16 registers x 2 fields x 64 lanes, so two passes (fields 0-1, 2-3).
-    // A carry into the exponent (bit 23: the top field is under the threshold) makes the lower fields of that
-    // register unreadable: all four become candidates -- they are re-evaluated on the full 64 bits anyway.
-    for (uint32_t pass = 0; pass < 2; ++pass) {
-      uint32_t cnt = 0;  // wave-uniform
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const uint32_t bits = as_u32(c[g]);
-        const bool carry = ((bits >> 23) & 1u) != 0;
-        const bool f0 = carry || ((bits >> (12u * pass + 5u)) & 1u) != 0;
-        const bool f1 = carry || ((bits >> (12u * pass + 11u)) & 1u) != 0;
-        if (__builtin_amdgcn_ballot_w64(f0 || f1) == 0) continue;
-        const uint64_t m0 = __builtin_amdgcn_ballot_w64(f0);
-        if (f0)  // entry: field<<10 | g<<6 | lane
-          s_queue[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))] =
-              ((2u * pass) << 10) | ((uint32_t)g << 6) | lane;
-        cnt += (uint32_t)__popcll(m0);
-        const uint64_t m1 = __builtin_amdgcn_ballot_w64(f1);
-        if (f1)
-          s_queue[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))] =
-              ((2u * pass + 1u) << 10) | ((uint32_t)g << 6) | lane;
-        cnt += (uint32_t)__popcll(m1);
-      }
-      wave_order();
-      for (uint32_t k = lane; k < cnt; k += 64u) {
-        const uint32_t e = s_queue[k];
-        const uint32_t src = e & 63u, g = (e >> 6) & 15u, field = (e >> 10) & 3u;
-        const uint32_t rit = (g & 3u) + 8u * (g >> 2) + 4u * (src >> 5);  // row in tile
-        const uint32_t row = row0 + rit;
-        const uint32_t qi = p * 64u + field * 32u + (src & 31u);  // p = the first of the step's two pairs
-        if (row < hp.n && qi < hp.nq) {
-          const uint64_t nv = hp.q[qi];
-          const uint2 hv = s_hay[hay_off + rit];  // all 64 bits (raw slot hashes parked in LDS)
-          const uint32_t d = __popc(hv.x ^ (uint32_t)nv) + __popc(hv.y ^ (uint32_t)(nv >> 32));
-          if (nv != 0 && d < hp.thresh && mask_ok(hp, row, qi, nv)) {
-            const uint32_t id = hp.ids[row];
-            if (id != 0 || hp.keep0) emit(hp.rec, hp.cap, hp.total, qi, d, id);
-          }
-        }
-      }
-      wave_order();
-    }
-    return;
   }
   uint32_t cnt = 0;  // wave-uniform
 #pragma unroll
@@ -234,27 +205,31 @@ __device__ __forceinline__ void handle_tile(const v16f& c, uint32_t row0, uint32
   }
   wave_order();
   // drain: one candidate per lane
-  for (uint32_t k = lane; k < cnt; k += 64u) {
-    const uint32_t e = s_queue[k];
+  for (uint32_t k0 = 0; k0 < cnt; k0 += 64u) {
+    const uint32_t k = k0 + lane;
+    const uint32_t e = s_queue[min(k, cnt - 1u)];
     const uint32_t src = e & 63u, g = (e >> 6) & 15u, field = (e >> 10) & 1u;
     const uint32_t rit = (g & 3u) + 8u * (g >> 2) + 4u * (src >> 5);  // row in tile
     const uint32_t row = row0 + rit;
     const uint32_t qi = p * 64u + field * 32u + (src & 31u);
-    if (row < hp.n && qi < hp.nq) {
+    const uint32_t d = e >> 11;
+    bool has = false;
+    uint32_t id = 0;
+    if (k < cnt && row < hp.n && qi < hp.nq) {
       const uint64_t nv = hp.q[qi];
-      const uint32_t d = e >> 11;
       if (nv != 0 && d < hp.thresh && mask_ok(hp, row, qi, nv)) {
-        const uint32_t id = hp.ids[row];
-        if (id != 0 || hp.keep0) emit(hp.rec, hp.cap, hp.total, qi, d, id);
+        id = hp.ids[row];
+        has = id != 0 || hp.keep0;
       }
     }
+    out_push(s_out, nout, has, qi, d, id, hp);
   }
   wave_order();
 }
 
-// PRE, lean path (hit lanes in rounds of kParkLanes; one round and one lane is the common case while candidates are rare:
-// 8192 pairs per group x 1e-5 .. 6e-5 per pair).  A candidate costs the matrix pipe nothing but a handful of VALU slots when it
-// is FOUND and is re-checked LATER, 64 at a time:
+// PRE, the candidate path (hit lanes in rounds of kParkLanes; one round and one lane is the common case while candidates
+// are rare: 8192 pairs per group x 1e-5 .. 6e-5 per pair).  A candidate costs the matrix pipe nothing but a handful of VALU
+// slots when it is FOUND and is re-checked LATER, 64 at a time:
 //   * each lane that holds a flag parks its accumulators in LDS (ds_write_b128 straight from the MFMA result registers,
 //     under the lanes' own exec mask: LDS issue, no VALU); hit lane by hit lane, lane r reads register r back, ONE
 //     ballot names the flagged registers, and those lanes append a descriptor {register pattern, register | tile |
@@ -262,12 +237,15 @@ __device__ __forceinline__ void handle_tile(const v16f& c, uint32_t row0, uint32
 //     wave is back at its MFMAs after two LDS round trips;
 //   * when 64 descriptors are pending (and at the end of the wave's needle chunk) the wave drains the list, one
 //     descriptor per lane: haystack hash from LDS, the needles of the flagged fields from global memory (64 lanes'
-//     loads in flight together), popcount, record.
+//     loads in flight together), popcount; real matches go to the wave's record buffer.
 // (An immediate scalar re-check -- s_load + s_bcnt1 per candidate -- was built first: no VALU at all, but every event
-//  stalled the wave for a scalar-cache miss, 15.9 ms at threshold 6 where this form takes ~11; NOTES 11.)
-// The wave's 2048-word queue space holds the pending list (2 words per descriptor) below the parking area.
+//  stalled the wave for a scalar-cache miss, 15.9 ms at threshold 6 where this form takes ~11; NOTES 11.  The per-tile
+//  queue path of rounds 1-4 -- ~750 cycles per candidate group -- is in the history: r05's "scan_pre_lean" 0.)
+// The wave's 2048 words: pending list (2 words per descriptor) | record buffer | parking area.
 constexpr uint32_t kParkLanes = 16;  // hit lanes parked at a time (a denser group takes several rounds)
-constexpr uint32_t kPark = kQueue - kParkLanes * 32u;  // word offset of the parking area; pending: < 64 + 16 * 32 <= 768 descriptors
+constexpr uint32_t kPark = kQueue - kParkLanes * 32u;  // word offset of the parking area
+constexpr uint32_t kOutOff = kPark - 2u * kOutCap;     // ... of the record buffer; pending: < 64 + 16 * 32 <= kOutOff / 2 descriptors
+static_assert(kOutOff / 2u >= 64u + kParkLanes * 32u, "pending list");
 
 // OR of accumulator registers [A, B) of a group (register r = tile r / 16, element r % 16), three and then two per
 // v_or3_b32
@@ -281,18 +259,19 @@ __device__ __forceinline__ uint32_t or_regs(const v16f (&c)[G]) {
   return o;
 }
 
-// LEAN (PRE only): candidates take the park / list / drain path below; false = the per-tile queue path of rounds 1-4
-// (handle_tile), compiled for the shipped shape only ("scan_pre_lean" 0: A/B and the parity suite's "mfma_r4" leg) --
-// a template parameter because the queue path's code is large and would sit, unused, between the hot loop's blocks.
-template <int HT, int G, bool PRE, int MINB = ((PRE && G == 2 && HT == 8) ? 3 : 1), bool LEAN = true>
-__global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
+// PRE = true: the prefilter kernel (4 workgroups per CU: 128 VGPRs; bound by VALU issue, and a fourth wave per SIMD hides
+// more of it -- same box, compiled for 1 / 2 / 3 / 4: 10.8 / 10.8 / 10.1 / 9.8 ms, r05).  PRE = false: FULL2.
+template <bool PRE>
+__global__ __launch_bounds__(kThreads, PRE ? 4 : 1) void k_hamm64_mfma(
     const uint2* __restrict__ hay, const uint32_t* __restrict__ ids, uint32_t n,
     const uint64_t* __restrict__ q, const uint4* __restrict__ qx, uint32_t nq, uint32_t n_pairs,
     uint32_t pairs_per_chunk, uint32_t thresh, cbh_record* __restrict__ rec,
     unsigned long long cap, unsigned long long* __restrict__ total, uint32_t keep0,
-    const uint2* __restrict__ qmask, const uint4* __restrict__ qf, uint32_t pre_flags) {
-  __shared__ uint32_t s_queue_[kWaves][kQueue];  // candidates of one haystack tile
+    const uint2* __restrict__ qmask, const uint4* __restrict__ qf) {
+  constexpr int HT = kHT, G = kG;
+  __shared__ uint32_t s_queue_[kWaves][kQueue];
   __shared__ uint2 s_hay_[PRE ? kWaves : 1][PRE ? HT * 32 : 1];  // PRE: raw hashes for the re-check
+  __shared__ uint32_t s_out2_[PRE ? 1 : kWaves][PRE ? 1 : 2 * kOutCap];  // FULL2: the record buffer (PRE: inside s_queue)
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // uniform, and known to be
   const uint32_t r = lane & 31u, half = lane >> 5;
@@ -300,14 +279,16 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
   if (tile0 * 32u >= n) return;  // whole wave past the end (no workgroup barriers in this kernel)
   uint32_t* s_queue = s_queue_[wave];
   uint2* s_hay = s_hay_[PRE ? wave : 0];
+  uint32_t* s_out = PRE ? s_queue + kOutOff : s_out2_[PRE ? 0 : wave];
+  uint32_t nout = 0;  // records parked in s_out (wave-uniform)
 
   v8i a[HT];
 #pragma unroll
   for (int t = 0; t < HT; ++t) {
     const uint32_t row = (tile0 + t) * 32u + r;
     const uint2 hv = row < n ? hay[row] : make_uint2(0u, 0u);
-    // PRE: the prefilter word (fold = lo ^ hi, or the low word) in both K blocks
-    a[t] = fp4_operand(fp4_expand32(PRE ? ((pre_flags & 1u) ? hv.x ^ hv.y : hv.x) : (half ? hv.y : hv.x)));
+    // PRE: the prefilter word lo ^ hi in both K blocks
+    a[t] = fp4_operand(fp4_expand32(PRE ? hv.x ^ hv.y : (half ? hv.y : hv.x)));
     if (PRE && half == 0) s_hay[t * 32 + r] = hv;
   }
   wave_order();
@@ -335,42 +316,50 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
   const uint32_t p0 = blockIdx.y * pairs_per_chunk;
   const uint32_t p1 = min(n_pairs, p0 + pairs_per_chunk);
   // pair p = needles [64p, 64p+64): tile A = first 32, tile B = last 32; 2 uint4 per needle.
-  // FULL: lane (c, half) reads word `half` of needle c of each tile; PRE: the prefilter word of needle
+  // FULL2: lane (c, half) reads word `half` of needle c of each tile; PRE: the prefilter word of needle
   // 64p + lane (tile A in K block 0, tile B in K block 1), one uint4 per needle in qf
   const uint4* __restrict__ qp = qx + ((size_t)p0 * 64u + r) * 2u + half;  // (FULL2; PRE addresses its tiles below)
-  const uint32_t lo_zero = PRE ? 0x4060u : 0x4080u;      // lo16 at distance 0
-  const uint32_t hi_zero = PRE ? 0x4B30u : 0x4B40u;      // hi16 at distance 0
+  const uint32_t lo_zero = 0x4080u;                      // lo16 at distance 0
+  const uint32_t hi_zero = 0x4B40u;                      // hi16 at distance 0
   const uint32_t lo_thr = lo_zero - 2u * (thresh - 1u);  // lo16 >= lo_thr  <=>  distA < thresh
   const uint32_t hi_thr = hi_zero - (thresh - 1u);       // hi16 >= hi_thr  <=>  distB < thresh
   const uint32_t lo_key = lo_thr << 16, hi_key = hi_thr << 16;
   const HitParams hp = {lo_key, hi_key, lo_zero, hi_zero, thresh, n, nq, keep0, q, ids, rec, cap, total, hay, qmask};
 
-  uint32_t npend = 0;  // PRE lean path: descriptors waiting in s_queue (wave-uniform)
+  uint32_t npend = 0;  // PRE: descriptors waiting in s_queue (wave-uniform)
   // one descriptor per lane: the flagged fields of a parked register against all 64 bits
   // (whole passes of 64 only -- the newest descriptors; the < 64 oldest wait for company, and for the chunk's end: a pass
   // costs its global-memory round trip whether one lane works in it or all of them)
   auto drain = [&](bool all) {
     wave_order();
     const uint32_t keep = all ? 0u : (npend & 63u);
-    for (uint32_t k = keep + lane; k < npend; k += 64u) {
+    for (uint32_t k0 = keep; k0 < npend; k0 += 64u) {
+      const uint32_t k = min(k0 + lane, npend - 1u);
       const uint32_t bits = s_queue[2u * k], w1 = s_queue[2u * k + 1u];
       const uint32_t g = w1 & 15u, tile = (w1 >> 4) & 7u, L = (w1 >> 7) & 63u, pp = p0 + 2u * (w1 >> 13);
-      const uint32_t rit = (g & 3u) + 8u * (g >> 2) + 4u * (L >> 5);  // C/D layout, see handle_tile
+      const uint32_t rit = (g & 3u) + 8u * (g >> 2) + 4u * (L >> 5);  // C/D layout, see handle_tile2
       const uint32_t row = (tile0 + tile) * 32u + rit;
       // a carry into the exponent (top field flagged) leaves the lower fields unreadable: all four are candidates
       uint32_t fields = ((bits >> 23) & 1u) ? 0xfu
                                             : (((bits >> 5) & 1u) | (((bits >> 11) & 1u) << 1) | (((bits >> 17) & 1u) << 2));
-      if (row >= hp.n) fields = 0;
+      if (row >= hp.n || k0 + lane >= npend) fields = 0;
       const uint2 hv = s_hay[tile * 32u + rit];
-      for (; fields; fields &= fields - 1u) {
-        const uint32_t qi = pp * 64u + (uint32_t)__builtin_ctz(fields) * 32u + (L & 31u);
-        if (qi >= hp.nq) continue;
-        const uint64_t nv = hp.q[qi];
-        const uint32_t d = __popc(hv.x ^ (uint32_t)nv) + __popc(hv.y ^ (uint32_t)(nv >> 32));
-        if (nv != 0 && d < hp.thresh && mask_ok(hp, row, qi, nv)) {
-          const uint32_t id = hp.ids[row];
-          if (id != 0 || hp.keep0) emit(hp.rec, hp.cap, hp.total, qi, d, id);
+      // every lane takes its lowest flagged field per round (nearly always one round: one field per descriptor); the
+      // loop is uniform -- the record buffer ballots
+      while (__builtin_amdgcn_ballot_w64(fields != 0) != 0) {
+        const uint32_t qi = pp * 64u + (uint32_t)__builtin_ctz(fields | 16u) * 32u + (L & 31u);
+        bool has = false;
+        uint32_t d = 0, id = 0;
+        if (fields != 0 && qi < hp.nq) {
+          const uint64_t nv = hp.q[qi];
+          d = __popc(hv.x ^ (uint32_t)nv) + __popc(hv.y ^ (uint32_t)(nv >> 32));
+          if (nv != 0 && d < hp.thresh && mask_ok(hp, row, qi, nv)) {
+            id = hp.ids[row];
+            has = id != 0 || hp.keep0;
+          }
         }
+        out_push(s_out, nout, has, qi, d, id, hp);
+        fields &= fields - 1u;
       }
     }
     wave_order();
@@ -404,86 +393,75 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
         const uint64_t hm = __builtin_amdgcn_ballot_w64(flags != 0);
         if (hm != 0) {
           // wave-uniform from here: some lane holds a candidate (one group in ~10 at threshold 5, every other at 6)
-          if constexpr (LEAN && R <= 32) {
-            auto park4 = [&](uint32_t at, int t, int k) {  // registers 16 t + 4 k .. + 3 of the lane: one ds_write_b128
-              *reinterpret_cast<float4*>(&s_queue[at + (uint32_t)(t * 16 + 4 * k)]) =
-                  make_float4(c[t][4 * k], c[t][4 * k + 1], c[t][4 * k + 2], c[t][4 * k + 3]);
-            };
-            auto park = [&](uint32_t at) {
-#pragma unroll
-              for (int t = 0; t < G; ++t)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) park4(at, t, k);
-            };
-            constexpr uint64_t kLow = R >= 32 ? 0xffffffffull : ((1ull << (R & 31)) - 1ull);  // lane r < R <-> register r
-            const uint32_t w1c = ((uint32_t)t0 << 4) | (((p - p0) >> 1) << 13);  // tile of register 0, step
-            // lane r < R reads register r of a hit lane back (the lanes above read on into the next slot, or the first words
-            // behind the wave's queue: inside the workgroup's LDS, and discarded by kLow / lane < R); `ok` = the registers
-            // whose parking slot was written.  Appends {pattern, register | tile | hit lane | step} for every flagged one.
-            auto list = [&](uint32_t at, uint32_t L, uint32_t ok) {
-              const uint32_t v = s_queue[at + lane];
-              const bool pred = (v & kFlagMaskPre) != 0 && ((ok >> (lane & 31u)) & 1u) != 0u;
-              const uint32_t bm = (uint32_t)(__builtin_amdgcn_ballot_w64(pred) & kLow);
-              if (pred && lane < (uint32_t)R) {
-                // lane = 16 t + g: bits 0-3 the register, bits 4-6 (t0 + t) the wave's tile; bits 7-12 the hit lane
-                *reinterpret_cast<uint2*>(&s_queue[2u * (npend + __builtin_amdgcn_mbcnt_lo(bm, 0u))]) =
-                    make_uint2(v, lane | (w1c | (L << 7)));
-              }
-              npend += (uint32_t)__popc(bm);
-            };
-            if ((hm & (hm - 1)) == 0) {
-              // ONE hit lane (nine events in ten), a fixed address -- and nearly always one flagged register: only the
-              // registers of the reduction chain(s) that hold a flag are parked -- 0..16 (five ds_write_b128) or 17..31
-              // (four) instead of all eight; a ds_write_b128 moves 1 KB whatever its exec mask.  (Masks, not bools: a
-              // uniform bool comes back as v_cndmask + v_cmp.)
-              uint32_t ok = 0xffffffffu;
-              if constexpr (G == 2) {
-                const uint64_t b0 = __builtin_amdgcn_ballot_w64((half0 & kFlagMaskPre) != 0);
-                const uint64_t b1 = __builtin_amdgcn_ballot_w64((half1 & kFlagMaskPre) != 0);
-                if (flags != 0) {
-                  if (b0) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) park4(kPark, 0, k);
-                  }
-                  park4(kPark, 1, 0);
-                  if (b1) {
-#pragma unroll
-                    for (int k = 1; k < 4; ++k) park4(kPark, 1, k);
-                  }
-                }
-                ok = (b0 ? 0x000fffffu : 0u) | (b1 ? 0xffff0000u : 0u);
-              } else {
-                if (flags != 0) park(kPark);
-              }
-              wave_order();
-              list(kPark, (uint32_t)__builtin_ctzll(hm), ok);
-              wave_order();
-              if (npend >= 64u) drain(false);
-            } else {
-              // several hit lanes, in chunks of kParkLanes (one chunk unless the group is dense: duplicates, video frames);
-              // the k-th hit lane of a chunk parks all its registers at kPark + 32 k
-              uint64_t rest = hm;
-              do {
-                uint64_t cm = rest;
-                if ((uint32_t)__popcll(rest) > kParkLanes) {
-                  uint64_t rem = rest;
-                  for (uint32_t i = 0; i < kParkLanes; ++i) rem &= rem - 1;
-                  cm = rest ^ rem;  // the lowest kParkLanes hit lanes
-                }
-                rest ^= cm;
-                if ((cm >> lane) & 1ull)
-                  park(kPark + 32u * __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u)));
-                wave_order();
-                uint32_t at = kPark;
-                for (uint64_t m = cm; m; m &= m - 1, at += 32u) list(at, (uint32_t)__builtin_ctzll(m), 0xffffffffu);
-                wave_order();
-                if (npend >= 64u) drain(false);
-              } while (rest);
-            }
-          } else {
+          static_assert(R == 32, "the parking slots below are 32 registers");
+          auto park4 = [&](uint32_t at, int t, int k) {  // registers 16 t + 4 k .. + 3 of the lane: one ds_write_b128
+            *reinterpret_cast<float4*>(&s_queue[at + (uint32_t)(t * 16 + 4 * k)]) =
+                make_float4(c[t][4 * k], c[t][4 * k + 1], c[t][4 * k + 2], c[t][4 * k + 3]);
+          };
+          auto park = [&](uint32_t at) {
 #pragma unroll
             for (int t = 0; t < G; ++t)
-              handle_tile<PRE>(c[t], (tile0 + t0 + t) * 32u, (uint32_t)(t0 + t) * 32u, p, hp, s_queue, s_hay);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) park4(at, t, k);
+          };
+          const uint32_t w1c = ((uint32_t)t0 << 4) | (((p - p0) >> 1) << 13);  // tile of register 0, step
+          // lane r < 32 reads register r of a hit lane back (the lanes above read on into the next slot, or the first words
+          // behind the wave's queue: inside the workgroup's LDS, and discarded by the mask / lane < 32); `ok` = the registers
+          // whose parking slot was written.  Appends {pattern, register | tile | hit lane | step} for every flagged one.
+          auto list = [&](uint32_t at, uint32_t L, uint32_t ok) {
+            const uint32_t v = s_queue[at + lane];
+            const bool pred = (v & kFlagMaskPre) != 0 && ((ok >> (lane & 31u)) & 1u) != 0u;
+            const uint32_t bm = (uint32_t)(__builtin_amdgcn_ballot_w64(pred) & 0xffffffffull);
+            if (pred && lane < (uint32_t)R) {
+              // lane = 16 t + g: bits 0-3 the register, bits 4-6 (t0 + t) the wave's tile; bits 7-12 the hit lane
+              *reinterpret_cast<uint2*>(&s_queue[2u * (npend + __builtin_amdgcn_mbcnt_lo(bm, 0u))]) =
+                  make_uint2(v, lane | (w1c | (L << 7)));
+            }
+            npend += (uint32_t)__popc(bm);
+          };
+          if ((hm & (hm - 1)) == 0) {
+            // ONE hit lane (nine events in ten), a fixed address -- and nearly always one flagged register: only the
+            // registers of the reduction chain(s) that hold a flag are parked -- 0..16 (five ds_write_b128) or 17..31
+            // (four) instead of all eight; a ds_write_b128 moves 1 KB whatever its exec mask.  (Masks, not bools: a
+            // uniform bool comes back as v_cndmask + v_cmp.)
+            const uint64_t b0 = __builtin_amdgcn_ballot_w64((half0 & kFlagMaskPre) != 0);
+            const uint64_t b1 = __builtin_amdgcn_ballot_w64((half1 & kFlagMaskPre) != 0);
+            if (flags != 0) {
+              if (b0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) park4(kPark, 0, k);
+              }
+              park4(kPark, 1, 0);
+              if (b1) {
+#pragma unroll
+                for (int k = 1; k < 4; ++k) park4(kPark, 1, k);
+              }
+            }
+            const uint32_t ok = (b0 ? 0x000fffffu : 0u) | (b1 ? 0xffff0000u : 0u);
+            wave_order();
+            list(kPark, (uint32_t)__builtin_ctzll(hm), ok);
+            wave_order();
+            if (npend >= 64u) drain(false);
+          } else {
+            // several hit lanes, in chunks of kParkLanes (one chunk unless the group is dense: duplicates, video frames);
+            // the k-th hit lane of a chunk parks all its registers at kPark + 32 k
+            uint64_t rest = hm;
+            do {
+              uint64_t cm = rest;
+              if ((uint32_t)__popcll(rest) > kParkLanes) {
+                uint64_t rem = rest;
+                for (uint32_t i = 0; i < kParkLanes; ++i) rem &= rem - 1;
+                cm = rest ^ rem;  // the lowest kParkLanes hit lanes
+              }
+              rest ^= cm;
+              if ((cm >> lane) & 1ull)
+                park(kPark + 32u * __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u)));
+              wave_order();
+              uint32_t at = kPark;
+              for (uint64_t m = cm; m; m &= m - 1, at += 32u) list(at, (uint32_t)__builtin_ctzll(m), 0xffffffffu);
+              wave_order();
+              if (npend >= 64u) drain(false);
+            } while (rest);
           }
         }
       } else {
@@ -501,8 +479,7 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
         if (__builtin_amdgcn_ballot_w64(hit) != 0) {
           // wave-uniform from here: something in this group is under the threshold (rare)
 #pragma unroll
-          for (int t = 0; t < G; ++t)
-            handle_tile<PRE>(c[t], (tile0 + t0 + t) * 32u, (uint32_t)(t0 + t) * 32u, p, hp, s_queue, s_hay);
+          for (int t = 0; t < G; ++t) handle_tile2(c[t], (tile0 + t0 + t) * 32u, p, hp, s_queue, s_out, nout);
         }
       }
     }
@@ -555,6 +532,7 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma(
     }
     if (p < p1) step(p, x0, x1);
   }
+  out_flush(s_out, nout, hp);
 }
 
 
@@ -572,15 +550,15 @@ constexpr int kScale7 = (int)0x86868686;   // E8M0 134 = 2^7
 constexpr int kScale14 = (int)0x8d8d8d8d;  // E8M0 141 = 2^14
 
 __device__ __forceinline__ void handle_tile3(const v16f& c, uint32_t row0, uint32_t p3, const HitParams& hp,
-                                             uint32_t* s_queue) {
+                                             uint32_t* s_queue, uint32_t* s_out, uint32_t& nout) {
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t any = 0;
 #pragma unroll
   for (int g = 0; g < 16; ++g) any |= as_u32(c[g]);
   if (__builtin_amdgcn_ballot_w64((any & kFlagMask3) != 0) == 0) return;  // the other tile of the group
   const uint32_t b = hp.thresh - 1u;
-  // one pass per field: the queue holds 16 registers x 64 lanes (4 KB per wave, 16 KB per workgroup, so that LDS never
-  // limits the waves per SIMD); the records of a tile come out field by field -- their order in the block is free
+  // one pass per field: the queue holds 16 registers x 64 lanes (4 KB per wave, so that LDS never limits the waves per
+  // SIMD); the records of a tile come out field by field -- their order in the block is free
 #pragma unroll 1
   for (uint32_t f = 0; f < 3; ++f) {
     uint32_t cnt = 0;  // wave-uniform
@@ -596,38 +574,44 @@ __device__ __forceinline__ void handle_tile3(const v16f& c, uint32_t row0, uint3
       cnt += (uint32_t)__popcll(m);
     }
     wave_order();
-    for (uint32_t k = lane; k < cnt; k += 64u) {
-      const uint32_t e = s_queue[k];
+    for (uint32_t k0 = 0; k0 < cnt; k0 += 64u) {
+      const uint32_t k = k0 + lane;
+      const uint32_t e = s_queue[min(k, cnt - 1u)];
       const uint32_t src = e & 63u, g = (e >> 6) & 15u, field = (e >> 10) & 3u, d = e >> 12;
       const uint32_t row = row0 + (g & 3u) + 8u * (g >> 2) + 4u * (src >> 5);
       const uint32_t qi = p3 * 96u + field * 32u + (src & 31u);
-      const uint64_t nv = (row < hp.n && qi < hp.nq) ? hp.q[qi] : 0;
+      const uint64_t nv = (k < cnt && row < hp.n && qi < hp.nq) ? hp.q[qi] : 0;
+      bool has = false;
+      uint32_t id = 0;
       if (nv != 0 && mask_ok(hp, row, qi, nv)) {
-        const uint32_t id = hp.ids[row];
-        if (id != 0 || hp.keep0) emit(hp.rec, hp.cap, hp.total, qi, d, id);
+        id = hp.ids[row];
+        has = id != 0 || hp.keep0;
       }
+      out_push(s_out, nout, has, qi, d, id, hp);
     }
     wave_order();
   }
 }
 
-// (MINB = 2 workgroups per CU as the minimum: with at most 256 registers per lane the compiler keeps the accumulators in
+// (2 workgroups per CU as the minimum: with at most 256 registers per lane the compiler keeps the accumulators in
 //  VGPRs -- given 512 it puts them in AGPRs and adds a v_accvgpr_read_b32 for every register the OR reduction touches,
-//  71 instead of 39 VALU instructions per six MFMAs.  Measured on one box, alternating (tools/ab/scan_ab.py): 17.2-17.4 ms
-//  either way -- the reads are not what holds the matrix pipe at 85 %; the VGPR form ships because it issues less.)
-template <int HT, int G, int MINB>
-__global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma3(
+//  71 instead of 39 VALU instructions per six MFMAs; compiled for 4 workgroups per CU it spills: 35 ms.)
+__global__ __launch_bounds__(kThreads, 2) void k_hamm64_mfma3(
     const uint2* __restrict__ hay, const uint32_t* __restrict__ ids, uint32_t n,
     const uint64_t* __restrict__ q, const uint4* __restrict__ qx, uint32_t nq, uint32_t n_triples,
     uint32_t triples_per_chunk, uint32_t thresh, cbh_record* __restrict__ rec,
     unsigned long long cap, unsigned long long* __restrict__ total, uint32_t keep0,
     const uint2* __restrict__ qmask) {
+  constexpr int HT = kHT, G = kG;
   __shared__ uint32_t s_queue_[kWaves][16 * 64];
+  __shared__ uint32_t s_out_[kWaves][2 * kOutCap];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t r = lane & 31u, half = lane >> 5;
   const uint32_t tile0 = (blockIdx.x * kWaves + wave) * HT;
   if (tile0 * 32u >= n) return;
   uint32_t* s_queue = s_queue_[wave];
+  uint32_t* s_out = s_out_[wave];
+  uint32_t nout = 0;
 
   v8i a[HT];
 #pragma unroll
@@ -668,7 +652,7 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma3(
       // one v_or3_b32 per two result registers, the last register and the mask in one v_bitop3_b32
       if (__builtin_amdgcn_ballot_w64((or_regs<0, G * 16, G>(c) & kFlagMask3) != 0) != 0) {
 #pragma unroll
-        for (int t = 0; t < G; ++t) handle_tile3(c[t], (tile0 + t0 + t) * 32u, p, hp, s_queue);
+        for (int t = 0; t < G; ++t) handle_tile3(c[t], (tile0 + t0 + t) * 32u, p, hp, s_queue, s_out, nout);
       }
     }
   };
@@ -700,16 +684,133 @@ __global__ __launch_bounds__(kThreads, MINB) void k_hamm64_mfma3(
       step(p0 + rel + 1, y0, y1, y2);
     }
   }
+  out_flush(s_out, nout, hp);
+}
+
+// ---- which kernel: the candidate rate of THIS launch's data ---------------------------------------------------------
+// The prefilter kernel is twice as fast as the three-field kernel while its candidates are rare and loses to it when
+// they are not: every candidate costs a park / list / re-check (~110 SIMD cycles per event).  How many there are is a
+// property of the data -- P[popc(fold(a) ^ fold(b)) < t] over the launch's needle x slot pairs: 5.7e-5 at t = 6 and
+// 2.7e-4 at t = 7 for unrelated hashes, but anything for a library of scans of one form, blank frames or a video against
+// itself.  k_fold_probe counts it on kProbeS x kProbeS evenly spaced (slot, needle) samples -- a few microseconds and one
+// host round trip, against launches of milliseconds -- and pick_pre compares the rate with kPreRateMax, the rate at
+// which the two kernels tie (tools/ab/adaptive_ab.py: profiles/r06_adaptive_ab*.jsonl).  Launches too small to pay for
+// the round trip, and a probe that cannot allocate, take the fixed rule of rounds 5 (thresholds <= 6).
+constexpr uint32_t kProbeS = 2048;     // samples per side
+constexpr int kProbeT = 8;             // thresholds 1..8 are counted (the prefilter never pays beyond: 1e-3 per pair at 8)
+constexpr int kPreStatic = 6;          // the fixed rule
+int g_pre_max_thresh = -1;             // "scan_mfma_pre_max": -1 = by candidate rate (default), 0 = never the prefilter,
+                                       // t > 0 = thresholds <= t take it whatever the data (tests, A/B)
+int g_pre_rate_max_e9 = 130000;        // "scan_pre_rate_e9": kPreRateMax x 1e9
+constexpr uint64_t kProbeMinPairs = 1ull << 31;  // ~20 us of scan: below this the probe's round trip is not worth it
+
+// grid (sq / 256, sh / 64): thread = one needle sample against 64 slot samples; counts[t - 1] += pairs with fold
+// distance < t.  Sample i of the slots = row i * n / sh, sample j of the needles = needle (2 j + 1) * nq / (2 sq): in a
+// self-join the two never name the same element while n > 2 sh, so the trivial self matches (which both kernels must emit
+// anyway) are not mistaken for candidates.
+__global__ __launch_bounds__(256) void k_fold_probe(const uint2* __restrict__ hay, uint32_t n, const uint2* __restrict__ q,
+                                                    uint32_t nq, uint32_t sh, uint32_t sq, uint32_t* __restrict__ counts) {
+  __shared__ uint32_t s_f[64];
+  __shared__ uint32_t s_cnt[kProbeT];
+  const uint32_t t = threadIdx.x;
+  if (t < 64) {
+    const uint32_t i = blockIdx.y * 64u + t;
+    const uint2 hv = i < sh ? hay[(uint32_t)(((uint64_t)i * n) / sh)] : make_uint2(0u, 0u);
+    s_f[t] = hv.x ^ hv.y;
+  }
+  if (t < kProbeT) s_cnt[t] = 0;
+  __syncthreads();
+  const uint32_t j = blockIdx.x * 256u + t;
+  const uint32_t nslots = min(64u, sh - blockIdx.y * 64u);
+  uint32_t cnt[kProbeT] = {};
+  if (j < sq) {
+    const uint2 nv = q[(uint32_t)((((uint64_t)2 * j + 1u) * nq) / (2ull * sq))];
+    const uint32_t f = nv.x ^ nv.y;
+    for (uint32_t k = 0; k < nslots; ++k) {
+      const uint32_t d = (uint32_t)__popc(f ^ s_f[k]);
+#pragma unroll
+      for (int th = 0; th < kProbeT; ++th) cnt[th] += d < (uint32_t)(th + 1) ? 1u : 0u;
+    }
+  }
+#pragma unroll
+  for (int th = 0; th < kProbeT; ++th) {
+    uint32_t v = cnt[th];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((t & 63u) == 0 && v) atomicAdd(&s_cnt[th], v);
+  }
+  __syncthreads();
+  if (t < kProbeT && s_cnt[t]) atomicAdd(&counts[t], s_cnt[t]);
+}
+
+// pinned words for the probe's answer: a free list (a slot is in use only inside one synchronous probe)
+std::mutex g_probe_mu;
+std::vector<uint32_t*> g_probe_free;
+uint32_t* probe_slot_get() {
+  {
+    std::lock_guard<std::mutex> lk(g_probe_mu);
+    if (!g_probe_free.empty()) {
+      uint32_t* p = g_probe_free.back();
+      g_probe_free.pop_back();
+      return p;
+    }
+  }
+  uint32_t* p = nullptr;
+  if (hipHostMalloc(&p, kProbeT * sizeof(uint32_t)) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+void probe_slot_put(uint32_t* p) {
+  std::lock_guard<std::mutex> lk(g_probe_mu);
+  g_probe_free.push_back(p);
+}
+
+std::atomic<uint64_t> g_pre_mask{0};          // bit t: the most recent matrix-core launch at threshold t took the prefilter
+std::atomic<uint64_t> g_n_probe{0};           // probes run
+std::atomic<long long> g_last_rate_e9{-1};    // candidate rate x 1e9 the last probe found for its threshold
+
+// true = this launch takes the prefilter kernel
+bool pick_pre(const uint64_t* d_hashes, size_t n, const uint64_t* d_q, size_t nq, int thresh, hipStream_t stream) {
+  if (thresh > 32) return false;
+  if (g_pre_max_thresh >= 0) return thresh <= g_pre_max_thresh;
+  if (thresh > kProbeT) return false;
+  if ((uint64_t)n * (uint64_t)nq < kProbeMinPairs) return thresh <= kPreStatic;
+  uint32_t* d_cnt = nullptr;
+  if (cbh::malloc_async((void**)&d_cnt, kProbeT * sizeof(uint32_t), stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return thresh <= kPreStatic;
+  }
+  uint32_t* h_cnt = probe_slot_get();
+  bool ok = h_cnt != nullptr;
+  const uint32_t sh = (uint32_t)std::min<size_t>(n, kProbeS), sq = (uint32_t)std::min<size_t>(nq, kProbeS);
+  if (ok) {
+    ok = hipMemsetAsync(d_cnt, 0, kProbeT * sizeof(uint32_t), stream) == hipSuccess;
+    if (ok) {
+      hipLaunchKernelGGL(k_fold_probe, dim3((sq + 255u) / 256u, (sh + 63u) / 64u), dim3(256), 0, stream,
+                         reinterpret_cast<const uint2*>(d_hashes), (uint32_t)n, reinterpret_cast<const uint2*>(d_q),
+                         (uint32_t)nq, sh, sq, d_cnt);
+      ok = hipGetLastError() == hipSuccess &&
+           hipMemcpyAsync(h_cnt, d_cnt, kProbeT * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+           hipStreamSynchronize(stream) == hipSuccess;
+    }
+  }
+  (void)cbh::free_async(d_cnt, stream);
+  bool pre = thresh <= kPreStatic;
+  if (ok) {
+    const double rate = (double)h_cnt[thresh - 1] / ((double)sh * (double)sq);
+    g_last_rate_e9 = (long long)(rate * 1e9);
+    g_n_probe++;
+    pre = rate * 1e9 <= (double)g_pre_rate_max_e9;
+  } else {
+    (void)hipGetLastError();
+  }
+  if (h_cnt) probe_slot_put(h_cnt);
+  return pre;
 }
 
 int g_scan_mfma = 1;           // use the matrix-core scan when the batch is large enough
-int g_mfma_full3 = 1;          // three-field variant for g_pre_max_thresh < thresh <= 64
-int g_mfma_ht = 8;             // haystack tiles per wave (2, 4 or 8)
-int g_mfma_pre = 1;            // 32-bit prefilter variant for thresh <= g_pre_max_thresh
-int g_mfma_pre_minb = 4;       // "scan_mfma_pre" = 11 .. 14: the prefilter compiled for >= 1 / 2 / 3 / 4 workgroups per CU.  Same box,
-                               // alternating (tools/ab/scan_pre_ab.py): 10.8 / 10.8 / 10.1 / 9.8 ms -- this kernel is bound by VALU
-                               // issue, and a fourth wave per SIMD (128 VGPRs, 12 bytes of spill) hides more of it
-int g_mfma_g = 2;              // haystack tiles per accumulator group (2 or 4; HT = 8 only)
 uint32_t g_mfma_min_nq = 256;  // below this the needle expansion + tile padding is not worth it
 
 }  // namespace
@@ -717,37 +818,16 @@ uint32_t g_mfma_min_nq = 256;  // below this the needle expansion + tile padding
 void set_scan_mfma(int on) {
   if (on >= 0) g_scan_mfma = on;
 }
-void set_scan_mfma_ht(int ht) {
-  if (ht == 2 || ht == 4 || ht == 8) g_mfma_ht = ht;
-}
-void set_scan_mfma_pre(int on) {
-  if (on >= 11 && on <= 14) {
-    g_mfma_pre_minb = on - 10;
-    return;
-  }
-  if (on >= 0) g_mfma_pre = on;
-}
-int get_scan_pre_max() { return g_mfma_pre == 1 ? g_pre_max_thresh : g_mfma_pre == 2 ? 32 : 0; }
 void set_scan_pre_max(int t) {
-  if (t >= 0 && t <= 32) g_pre_max_thresh = t;
+  if (t >= -1 && t <= 32) g_pre_max_thresh = t;
 }
-int g_mfma_chunk = 0;  // "scan_mfma_chunk": needle-tile pairs per workgroup chunk (0 = 512 for the prefilter kernel, 256 for
-                       // the others; the three-field kernel takes 2/3 of it in triples, 0 = 172)
-void set_scan_mfma_chunk(int v) {
-  if (v == 0 || (v >= 16 && v <= 4096 && v % 2 == 0)) g_mfma_chunk = v;
+void set_scan_pre_rate(int e9) {
+  if (e9 >= 0) g_pre_rate_max_e9 = e9;
 }
-void set_scan_pre_fold(int v) {
-  if (v >= 0) g_pre_fold = v != 0;
-}
-void set_scan_pre_lean(int v) {
-  if (v >= 0) g_pre_lean = v != 0;
-}
-void set_scan_mfma_full3(int on) {
-  if (on >= 0) g_mfma_full3 = on;
-}
-void set_scan_mfma_g(int g) {
-  if (g == 1 || g == 2 || g == 4) g_mfma_g = g;
-}
+// read-backs (cbh_get_tuning): "scan_pre_mask", "scan_probes", "scan_probe_rate_e9"
+long long get_scan_pre_mask() { return (long long)g_pre_mask.load(); }
+long long get_scan_probes() { return (long long)g_n_probe.load(); }
+long long get_scan_probe_rate_e9() { return g_last_rate_e9.load(); }
 
 bool scan_mfma_wanted(size_t n, size_t nq, int thresh) {
   if (g_scan_mfma == 2) return thresh >= 1 && thresh <= 65;  // forced (tests)
@@ -760,78 +840,53 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
                             unsigned flags, const uint64_t* d_qmask) {
   if (n == 0 || nq == 0 || thresh <= 0) return CBH_OK;
   if (n > 0xfffffff0ull || nq > CBH_MAX_QUERIES_PER_CALL || thresh > 65) return CBH_E_INVAL;
+  const bool pre = pick_pre(d_hashes, n, d_q, nq, thresh, stream);
+  if (thresh < 64) {
+    if (pre) g_pre_mask |= 1ull << thresh; else g_pre_mask &= ~(1ull << thresh);
+  }
   const uint32_t n_pairs = (uint32_t)((nq + 63) / 64);
   const uint32_t n_triples = (uint32_t)((nq + 95) / 96);
   const uint32_t nq_pad = (uint32_t)((nq + 191) / 192) * 192u;  // whole pairs (64) and whole triples (96)
   uint4* qx = nullptr;
   CBH_HIP(cbh::malloc_async((void**)&qx, (size_t)nq_pad * 48u, stream));  // 2 words + the prefilter word, 16 B each
   hipLaunchKernelGGL(k_expand_needles, dim3((3u * nq_pad + 255u) / 256u), dim3(256), 0, stream, d_q,
-                     (uint32_t)nq, nq_pad, qx, (uint32_t)(g_pre_fold != 0));
+                     (uint32_t)nq, nq_pad, qx);
   const uint4* qf = qx + 2u * (size_t)nq_pad;
-  const uint32_t pre_flags = (g_pre_fold ? 1u : 0u) | (g_pre_lean ? 2u : 0u);
-  const uint32_t ht = (uint32_t)g_mfma_ht;
-  const uint32_t rows_per_wg = 32u * ht * kWaves;
+  const uint32_t rows_per_wg = 32u * kHT * kWaves;
   const uint32_t wgs = (uint32_t)((n + rows_per_wg - 1) / rows_per_wg);
-  // needle chunk: >= 8192 workgroups in flight when there is that much work, but each wave
-  // amortises its tile expansion over >= 16 needle-tile pairs
-  // (prefilter: 512 pairs = 32768 needles per chunk -- a wave drains its pending candidates at the end of its chunk, mostly a
-  // short list: at threshold 6 chunks of 512 / 1024 pairs run 12.63 ms against 12.98 with 256 and 13.35 with 64; the full
-  // kernel is best at 172 triples: 16.05 against 16.25-16.3 with 2-4x that; tools/ab/scan_chunk_ab.py)
-  uint32_t ppc = g_mfma_chunk ? (uint32_t)g_mfma_chunk : (thresh <= g_pre_max_thresh && g_mfma_pre == 1 ? 512u : 256u);
-  while (ppc > 16 && (uint64_t)wgs * ((n_pairs + ppc - 1) / ppc) < 8192) ppc >>= 1;
-  uint32_t chunks = (n_pairs + ppc - 1) / ppc;
-  if (chunks > 65535) {
-    ppc = ((n_pairs + 65534) / 65535 + 1u) & ~1u;  // even: the prefilter variant steps two pairs at a time
-    chunks = (n_pairs + ppc - 1) / ppc;
-  }
-  // (2 = experiments: the prefilter variant for any threshold it can represent)
-  const bool pre = (g_mfma_pre == 1 && thresh <= g_pre_max_thresh) || (g_mfma_pre == 2 && thresh <= 32);
-  if (!pre && g_mfma_full3 && thresh <= 64 && ht == 8) {
-    uint32_t tpc = g_mfma_chunk ? (uint32_t)(g_mfma_chunk * 2 + 2) / 3u : 172u;  // ~16512 needles per chunk
+  if (!pre && thresh <= 64) {
+    // needle chunk: >= 8192 workgroups in flight when there is that much work, but each wave amortises its tile expansion
+    // over >= 11 needle-tile triples (172 triples = 16512 needles per chunk: 16.05 ms against 16.25-16.3 with 2-4x that,
+    // tools/ab/scan_chunk_ab.py)
+    uint32_t tpc = 172u;
     while (tpc > 11 && (uint64_t)wgs * ((n_triples + tpc - 1) / tpc) < 8192) tpc = (tpc + 1) / 2;
     uint32_t ch3 = (n_triples + tpc - 1) / tpc;
     if (ch3 > 65535) {
       tpc = (n_triples + 65534) / 65535;
       ch3 = (n_triples + tpc - 1) / tpc;
     }
-#define CBH_MFMA3(GG, MB)                                                                                      \
-  hipLaunchKernelGGL((k_hamm64_mfma3<8, GG, MB>), dim3(wgs, ch3), dim3(kThreads), 0, stream,                 \
-                     reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx, (uint32_t)nq,    \
-                     n_triples, tpc, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total,              \
-                     (uint32_t)(flags & 1u), reinterpret_cast<const uint2*>(d_qmask))
-    if (g_mfma_g == 4) CBH_MFMA3(4, 2); else if (g_mfma_g == 1) CBH_MFMA3(1, 2); else if (g_mfma_full3 == 2) CBH_MFMA3(2, 1); else if (g_mfma_full3 == 3) CBH_MFMA3(2, 3); else CBH_MFMA3(2, 2);  // (compiled for 4 workgroups per CU it spills: 35 ms)  // full3 = 2: accumulators in AGPRs (A/B)
-#undef CBH_MFMA3
-    hipError_t e3 = hipGetLastError();
-    (void)cbh::free_async(qx, stream);
-    CBH_HIP(e3);
-    return CBH_OK;
-  }
-#define CBH_MFMA_G(HT, GG, PRE)                                                                  \
-  hipLaunchKernelGGL((k_hamm64_mfma<HT, GG, PRE>), dim3(wgs, chunks), dim3(kThreads), 0, stream, \
-                     reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx,      \
-                     (uint32_t)nq, n_pairs, ppc, (uint32_t)thresh, d_rec,                        \
-                     (unsigned long long)cap, d_total, (uint32_t)(flags & 1u),                     \
-                     reinterpret_cast<const uint2*>(d_qmask), qf, pre_flags)
-#define CBH_MFMA(HT, PRE) CBH_MFMA_G(HT, kG, PRE)
-  if (ht == 8 && g_mfma_g == 4) {
-    if (pre) CBH_MFMA_G(8, 4, true); else CBH_MFMA_G(8, 4, false);
-  } else if (ht == 8 && pre && g_mfma_pre_minb != 3) {  // A/B: workgroups per CU the prefilter is compiled for
-#define CBH_MFMA_B(MB, LN)                                                                                \
-  hipLaunchKernelGGL((k_hamm64_mfma<8, kG, true, MB, LN>), dim3(wgs, chunks), dim3(kThreads), 0, stream,  \
-                     reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx, (uint32_t)nq, \
-                     n_pairs, ppc, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total,             \
-                     (uint32_t)(flags & 1u), reinterpret_cast<const uint2*>(d_qmask), qf, pre_flags)
-    if (g_mfma_pre_minb == 2) CBH_MFMA_B(2, true); else if (g_mfma_pre_minb == 4 && !g_pre_lean) CBH_MFMA_B(4, false); else if (g_mfma_pre_minb == 4) CBH_MFMA_B(4, true); else CBH_MFMA_B(1, true);
-#undef CBH_MFMA_B
-  } else if (ht == 8) {
-    if (pre) CBH_MFMA(8, true); else CBH_MFMA(8, false);
-  } else if (ht == 2) {
-    if (pre) CBH_MFMA(2, true); else CBH_MFMA(2, false);
+    hipLaunchKernelGGL(k_hamm64_mfma3, dim3(wgs, ch3), dim3(kThreads), 0, stream,
+                       reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx, (uint32_t)nq, n_triples, tpc,
+                       (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total, (uint32_t)(flags & 1u),
+                       reinterpret_cast<const uint2*>(d_qmask));
   } else {
-    if (pre) CBH_MFMA(4, true); else CBH_MFMA(4, false);
-  }
+    // (prefilter: 512 pairs = 32768 needles per chunk -- a wave drains its pending candidates at the end of its chunk,
+    // mostly a short list: at threshold 6 chunks of 512 / 1024 pairs run 12.63 ms against 12.98 with 256 and 13.35 with 64)
+    uint32_t ppc = pre ? 512u : 256u;
+    while (ppc > 16 && (uint64_t)wgs * ((n_pairs + ppc - 1) / ppc) < 8192) ppc >>= 1;
+    uint32_t chunks = (n_pairs + ppc - 1) / ppc;
+    if (chunks > 65535) {
+      ppc = ((n_pairs + 65534) / 65535 + 1u) & ~1u;  // even: the prefilter variant steps two pairs at a time
+      chunks = (n_pairs + ppc - 1) / ppc;
+    }
+#define CBH_MFMA(PRE)                                                                                                 \
+  hipLaunchKernelGGL((k_hamm64_mfma<PRE>), dim3(wgs, chunks), dim3(kThreads), 0, stream,                              \
+                     reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, d_q, qx, (uint32_t)nq, n_pairs, ppc, \
+                     (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total, (uint32_t)(flags & 1u),               \
+                     reinterpret_cast<const uint2*>(d_qmask), qf)
+    if (pre) CBH_MFMA(true); else CBH_MFMA(false);
 #undef CBH_MFMA
-#undef CBH_MFMA_G
+  }
   hipError_t e = hipGetLastError();
   (void)cbh::free_async(qx, stream);
   CBH_HIP(e);

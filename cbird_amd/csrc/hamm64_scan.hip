@@ -237,17 +237,9 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_scan(
   if (qb < q1) exact_block<H>(h, base_idx, n, ids, q, qb, q1, thresh, rec, cap, total, keep0, qmask);
 }
 
-int g_pre_max = 7;  // largest threshold served by the low-word prefilter variant
-int g_eq_for_dht1 = 1;
-int g_group = 1;
+constexpr int kPreMax = 7;  // largest threshold served by the low-word prefilter variant (r01: wins up to 7 on this kernel)
 
 }  // namespace
-
-void set_scan_tuning(int pre_max, int eq_for_dht1, int group) {
-  if (pre_max >= 0) g_pre_max = pre_max;
-  if (eq_for_dht1 >= 0) g_eq_for_dht1 = eq_for_dht1;
-  if (group >= 0) g_group = group;
-}
 
 int launch_hamm64_scan(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n,
                        const uint64_t* d_q, size_t nq, int thresh, cbh_record* d_rec, size_t cap,
@@ -277,13 +269,13 @@ int launch_hamm64_scan(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n
                      d_ids, (uint32_t)n, d_q, (uint32_t)nq, q_chunk, (uint32_t)thresh, d_rec, \
                      (unsigned long long)cap, d_total, (uint32_t)(flags & 1u),                \
                      reinterpret_cast<const uint2*>(d_qmask))
-  if (thresh == 1 && g_eq_for_dht1)
+  // (issue-rate-shaped variants only: GROUP; thresholds of 1 compare for equality)
+  if (thresh == 1)
     CBH_SCAN(MODE_EQ, false);
-  else if (thresh <= g_pre_max) {
-    if (g_group) CBH_SCAN(MODE_PRE, true); else CBH_SCAN(MODE_PRE, false);
-  } else {
-    if (g_group) CBH_SCAN(MODE_FULL, true); else CBH_SCAN(MODE_FULL, false);
-  }
+  else if (thresh <= kPreMax)
+    CBH_SCAN(MODE_PRE, true);
+  else
+    CBH_SCAN(MODE_FULL, true);
 #undef CBH_SCAN
   CBH_HIP(hipGetLastError());
   return CBH_OK;

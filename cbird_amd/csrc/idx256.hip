@@ -12,7 +12,6 @@
 // it is a threshold scan: the first 128 bits give a sound lower bound (4 xor + 4 bcnt per pair, min3 over
 // pairs), and only slots whose bound drops under the threshold load their second half and evaluate all 256 bits.
 // Records q<<41 | dist<<32 | row are then ordered and cut at k per needle descriptor.
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include <map>
 
@@ -453,11 +452,12 @@ int knn_core(cbh_idx256* ix, const uint8_t* needles, size_t nq, int k, int thres
   if ((rc = ix->shards ? scan_records_sharded(ix, needles, nq, k, thresh, &total) : scan_records(ix, needles, nq, k, thresh, &total)))
     return rc;
   if (total > 1) {
-    rocprim::double_buffer<unsigned long long> db(ix->d_rec, ix->d_alt);
-    size_t tb = ix->tmp_bytes;
-    CBH_HIP(rocprim::radix_sort_keys(ix->d_tmp, tb, db, (size_t)total, 0, (unsigned)sig_bits256(nq), ix->stream));
-    if (db.current() != ix->d_rec)
-      CBH_HIP(hipMemcpyAsync(ix->d_rec, db.current(), total * 8, hipMemcpyDeviceToDevice, ix->stream));
+    unsigned long long* sorted = nullptr;
+    if ((rc = cbh::sort_keys64_db(ix->d_rec, ix->d_alt, (size_t)total, (unsigned)sig_bits256(nq), ix->d_tmp, ix->tmp_bytes,
+                                  ix->stream, &sorted)))
+      return rc;
+    if (sorted != ix->d_rec)
+      CBH_HIP(hipMemcpyAsync(ix->d_rec, sorted, total * 8, hipMemcpyDeviceToDevice, ix->stream));
   }
   if (all_records) {  // radius search: every record, already in (needle, distance, row) order
     all_records->resize((size_t)total);

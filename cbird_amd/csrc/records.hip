@@ -85,21 +85,69 @@ __global__ __launch_bounds__(256) void k_remove_ids(uint64_t* __restrict__ hashe
 
 }  // namespace
 
+// ---- the library's radix sorts: rocPRIM, instantiated HERE and nowhere else (every caller sorts 64-bit keys; one copy of
+// the sort kernels in the code object instead of one per translation unit) -------------------------------------------
 size_t sort_records_scratch_bytes(size_t n) {
   size_t bytes = 0;
-  rocprim::double_buffer<cbh_record> db(nullptr, nullptr);
+  rocprim::double_buffer<unsigned long long> db(nullptr, nullptr);  // (cbh_record is the same 64 bits under another name)
   (void)rocprim::radix_sort_keys(nullptr, bytes, db, n, 0, 64, (hipStream_t)0);
   return bytes;
 }
 
+// keys [0, n) ascending on bits [0, end_bit); d_alt = a second buffer of n keys, d_tmp / tmp_bytes from
+// sort_records_scratch_bytes(>= n).  *sorted = whichever of the two buffers holds the result.
+int sort_keys64_db(unsigned long long* d_keys, unsigned long long* d_alt, size_t n, unsigned end_bit, void* d_tmp,
+                   size_t tmp_bytes, hipStream_t stream, unsigned long long** sorted) {
+  *sorted = d_keys;
+  if (n < 2) return CBH_OK;
+  rocprim::double_buffer<unsigned long long> db(d_keys, d_alt);
+  CBH_HIP(rocprim::radix_sort_keys(d_tmp, tmp_bytes, db, n, 0, end_bit, stream));
+  *sorted = db.current();
+  return CBH_OK;
+}
+
 int launch_sort_records(cbh_record* d_rec, cbh_record* d_alt, size_t n, size_t nq, void* d_tmp,
                         size_t tmp_bytes, hipStream_t stream) {
+  static_assert(sizeof(cbh_record) == sizeof(unsigned long long), "record width");
+  unsigned long long* cur = nullptr;
+  int rc = sort_keys64_db(reinterpret_cast<unsigned long long*>(d_rec), reinterpret_cast<unsigned long long*>(d_alt), n,
+                          (unsigned)sig_bits(nq), d_tmp, tmp_bytes, stream, &cur);
+  if (rc) return rc;
+  if (cur != reinterpret_cast<unsigned long long*>(d_rec))
+    CBH_HIP(hipMemcpyAsync(d_rec, cur, n * sizeof(cbh_record), hipMemcpyDeviceToDevice, stream));
+  return CBH_OK;
+}
+
+// in place, scratch from the stream-ordered allocator
+int sort_keys_u64(unsigned long long* d_keys, size_t n, int end_bit, hipStream_t s) {
   if (n < 2) return CBH_OK;
-  rocprim::double_buffer<cbh_record> db(d_rec, d_alt);
-  CBH_HIP(rocprim::radix_sort_keys(d_tmp, tmp_bytes, db, n, 0, (unsigned)sig_bits(nq), stream));
-  if (db.current() != d_rec)
-    CBH_HIP(hipMemcpyAsync(d_rec, db.current(), n * sizeof(cbh_record), hipMemcpyDeviceToDevice,
-                           stream));
+  unsigned long long* alt = nullptr;
+  void* tmp = nullptr;
+  const size_t bytes = sort_records_scratch_bytes(n);
+  cbh::Scratch scratch(s);
+  CBH_HIP(scratch.get(&alt, n * 8));
+  CBH_HIP(scratch.get(&tmp, bytes ? bytes : 16));
+  unsigned long long* cur = nullptr;
+  int rc = sort_keys64_db(d_keys, alt, n, (unsigned)end_bit, tmp, bytes, s, &cur);
+  if (rc) return rc;
+  if (cur != d_keys) CBH_HIP(hipMemcpyAsync(d_keys, cur, n * 8, hipMemcpyDeviceToDevice, s));
+  return CBH_OK;
+}
+
+int sort_pairs_u64_u32(unsigned long long* d_keys, uint32_t* d_vals, size_t n, int end_bit, hipStream_t s) {
+  if (n < 2) return CBH_OK;
+  unsigned long long* kalt = nullptr;
+  uint32_t* valt = nullptr;
+  void* tmp = nullptr;
+  size_t bytes = 0;
+  CBH_HIP(rocprim::radix_sort_pairs(nullptr, bytes, d_keys, kalt, d_vals, valt, n, 0, (unsigned)end_bit, s));
+  cbh::Scratch scratch(s);
+  CBH_HIP(scratch.get(&kalt, n * 8));
+  CBH_HIP(scratch.get(&valt, n * 4));
+  CBH_HIP(scratch.get(&tmp, bytes ? bytes : 16));
+  CBH_HIP(rocprim::radix_sort_pairs(tmp, bytes, d_keys, kalt, d_vals, valt, n, 0, (unsigned)end_bit, s));
+  CBH_HIP(hipMemcpyAsync(d_keys, kalt, n * 8, hipMemcpyDeviceToDevice, s));
+  CBH_HIP(hipMemcpyAsync(d_vals, valt, n * 4, hipMemcpyDeviceToDevice, s));
   return CBH_OK;
 }
 

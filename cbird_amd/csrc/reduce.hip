@@ -23,7 +23,6 @@
 // only) -- by (needle, mediaId), the QMap / std::map order of the reference.
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "cbh_internal.h"
 
@@ -180,38 +179,6 @@ __global__ __launch_bounds__(256) void k_video_score(const unsigned long long* _
 }
 
 }  // namespace
-
-// ---- rocPRIM radix sorts (called directly; scratch from the stream-ordered allocator) -------------------------------
-int sort_keys_u64(unsigned long long* d_keys, size_t n, int end_bit, hipStream_t s) {
-  if (n < 2) return CBH_OK;
-  unsigned long long* alt = nullptr;
-  void* tmp = nullptr;
-  size_t bytes = 0;
-  CBH_HIP(rocprim::radix_sort_keys(nullptr, bytes, d_keys, alt, n, 0, (unsigned)end_bit, s));
-  cbh::Scratch scratch(s);
-  CBH_HIP(scratch.get(&alt, n * 8));
-  CBH_HIP(scratch.get(&tmp, bytes ? bytes : 16));
-  CBH_HIP(rocprim::radix_sort_keys(tmp, bytes, d_keys, alt, n, 0, (unsigned)end_bit, s));
-  CBH_HIP(hipMemcpyAsync(d_keys, alt, n * 8, hipMemcpyDeviceToDevice, s));
-  return CBH_OK;
-}
-
-int sort_pairs_u64_u32(unsigned long long* d_keys, uint32_t* d_vals, size_t n, int end_bit, hipStream_t s) {
-  if (n < 2) return CBH_OK;
-  unsigned long long* kalt = nullptr;
-  uint32_t* valt = nullptr;
-  void* tmp = nullptr;
-  size_t bytes = 0;
-  CBH_HIP(rocprim::radix_sort_pairs(nullptr, bytes, d_keys, kalt, d_vals, valt, n, 0, (unsigned)end_bit, s));
-  cbh::Scratch scratch(s);
-  CBH_HIP(scratch.get(&kalt, n * 8));
-  CBH_HIP(scratch.get(&valt, n * 4));
-  CBH_HIP(scratch.get(&tmp, bytes ? bytes : 16));
-  CBH_HIP(rocprim::radix_sort_pairs(tmp, bytes, d_keys, kalt, d_vals, valt, n, 0, (unsigned)end_bit, s));
-  CBH_HIP(hipMemcpyAsync(d_keys, kalt, n * 8, hipMemcpyDeviceToDevice, s));
-  CBH_HIP(hipMemcpyAsync(d_vals, valt, n * 4, hipMemcpyDeviceToDevice, s));
-  return CBH_OK;
-}
 
 // K5.  d_top/d_counts: the per-needle-hash cut (k places each); d_qneedle[nq]: needle image of every needle hash;
 // d_needle_id[n_needles].  On return *h_n = number of results, h_out filled (unordered).  Synchronises `s`.

@@ -707,84 +707,49 @@ int cbh_color_distances(cbh_color*, const void* needle_descs, size_t nq, float* 
 int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k, cbh_match* out,
                          uint32_t* counts);
 
-/* Kernel-variant knobs for experiments (results never change, only speed):
- *   "scan_mfma"     64-bit scan on the matrix cores (k_hamm64_mfma): 0 = never, 1 = calls with >= 256
- *                   needles and >= 4096 slots (default), 2 = always
- *   "scan_mfma_ht"  haystack tiles per wave in k_hamm64_mfma: 2, 4 or 8 (default 8)
- *   "scan_mfma_pre" 1 = thresholds <= "scan_mfma_pre_max" use the 32-bit prefilter variant of k_hamm64_mfma (default 1),
- *                   0 = never, 2 = for every threshold <= 32 (experiments)
- *   "scan_mfma_pre_max" the largest threshold that takes the prefilter variant (default 6; rounds 1-4: 4)
- *   "scan_mfma_chunk" needle-tile pairs one workgroup of the 64-bit scan kernels streams (even, 16..4096); 0 (default) =
- *                   512 for the prefilter kernel (32768 needles: fewer end-of-chunk drains of a short candidate list),
- *                   256 for the others, 172 triples for the three-field kernel; halved while the grid would be < 8192
- *   "scan_pre_fold" 1 = the prefilter compares lo ^ hi of the hashes (default: a lower bound on the distance that sees
- *                   all 64 bits), 0 = the low words (rounds 1-4)
- *   "scan_pre_lean" 1 = prefilter candidates confined to a few lanes are parked, listed and re-checked 64 at a time
- *                   (default), 0 = every candidate group goes through the per-tile queue path (rounds 1-4)
- *   "scan256_mfma"  256-bit scan on the matrix cores (k_hamm256_mfma): 0 = never, 1 = calls with >= 64
- *                   needle descriptors and >= 4096 rows (default), 2 = always
+/* Knobs (25).  Results never change with any of them except "color_fma".  Unknown keys return CBH_E_INVAL.
+ * Which kernel serves a call:
+ *   "scan_mfma"     64-bit scan on the matrix cores (k_hamm64_mfma*): 0 = never (the popcount kernel k_hamm64_scan), 1 = calls
+ *                   with >= 256 needles and >= 4096 slots (default), 2 = always
+ *   "scan_mfma_pre_max" prefilter kernel or three-field 64-bit kernel: -1 (default) = per launch, by the candidate rate of the
+ *                   launch's own data -- P[popc(fold(a) ^ fold(b)) < thresh], counted on 2048 x 2048 sampled (slot, needle)
+ *                   pairs by k_fold_probe; the prefilter while it is <= "scan_pre_rate_e9"; launches of < 2^31 pairs:
+ *                   thresholds <= 6 -- 0 = never the prefilter, t > 0 = thresholds <= t (<= 32) take it whatever the data
+ *   "scan_pre_rate_e9" that rate x 1e9 (default 130000 = 1.3e-4: where the two kernels tie, profiles/r06_adaptive_ab*.jsonl)
+ *   "scan256_mfma"  256-bit scan on the matrix cores (k_hamm256_*): 0 = never (k_hamm256_scan), 1 = calls with >= 64 needle
+ *                   descriptors and >= 4096 rows (default), 2 = always
  *   "scan256_small" 1 = searches with <= 512 needle descriptors (one ORB needle image) and thresholds <= 40 use the
- *                   stationary-needle kernel k_hamm256_small (default 1); >= 16 = workgroups of its persistent grid
- *   "scan256_lut"   1 = k_hamm256_small expands its streamed rows to FP4 through a 256-entry LDS table (default), 0 = with
- *                   shifts and masks
- *   "scan256_pre"   1 = thresholds <= 40 use the first-128-bit prefilter variant of k_hamm256_mfma (default 1)
- *   "scan_pre_max"  largest threshold served by the low-word-prefilter VALU scan variant (default 7)
- *   "scan_eq_dht1"  1 = dht==1 uses the 64-bit equality variant (default 1)
- *   "scan_group"    1 = issue-rate-shaped scan variants (default 1)
- *   "hash_mfma"     kernel for 256x256 tiles: non-zero (default 2) = k_dcthash_256_band (horizontal box sums as i8 MFMAs,
- *                   one add + half an fma per pixel on the VALU; rows must be 16-byte aligned, otherwise 0 is taken),
- *                   0 = k_dcthash_256 (all VALU)
- *   "hash_band_area" general geometry with fractional resize ratios: 1 (default) = widths up to 1920 columns (strips of >= 4
- *                   output cells within 240 columns) take k_band_area -- the 256x256 kernel's matrix-core blur for any width
- *                   and height, up to four rows of a step per INTER_AREA walk (whole images, and views whose vertical edges
- *                   are the parent's or lie >= 8 / >= 3 columns inside it: letterboxed and pillarboxed frames after autocrop;
- *                   small batches are split into up to 8 row bands per strip); 0 = k_blur_area_regs & co. as through round 4.
- *                   Bit-identical either way
- *   "hash_band_waves" waves per workgroup of k_dcthash_256_band: 1 (default: a wave owns its four images alone, no
- *                   barriers, 9 waves per CU) or 2 (two waves share four images' rows and tiles in LDS, 14 waves per CU;
- *                   measured 5 % slower)
- *   "hash_div"      k_dcthash_256's divide by 49: 0 integer multiply-shift (default), 1 float magic number, 2 / 3 one fma
- *                   per pixel on the float form 0x4B000000 + S (packed / unpacked column sums); all exact
- *   "hash_fast_any" 0 = the first general-geometry kernels (k_blur_u8 + k_area_hash / k_dcthash_generic), 1 = the
- *                   lane-per-8-columns kernels (default)
- *   "hash_fused"    0 = three-kernel split (k_blur_rows + k_area_rows + k_tile_hash); v >= 1 = k_blur_area (blur and
- *                   horizontal INTER_AREA pass in one kernel) for widths >= v (default 1 = all)
- *   "hash_stream"   streaming form k_blur_area_stream: 0 = never, 1 = when the batch is large enough and the image at
- *                   least 192 x 128 (default), v >= 2 = always, with v steps per strip
- *   "hash_wide"     1 = images wider than 2048 pixels run k_blur_area_regs on 2 or 4 column strips (default), 0 = the LDS
- *                   band kernel k_blur_area_stream takes them (round 3)
- *   "hash_regs"     k_blur_area_regs (blur input straight from global memory into registers): 0 = off (LDS band kernels),
- *                   1 = on (default); images narrower than a workgroup share one side by side where that puts 15 % more
- *                   of the lanes to work, 2 = on / never side by side, 3 = on / always, 4 = on / round 3's rule
- *   "hash_rows_per_step" source rows per step of k_blur_area_regs (7 x 7 blur): 0 = 14 always, 1 (default) = 14, 21 or 28,
- *                   whichever fills the row slots of the area phase's turns best for the workgroup size and the cells a
- *                   strip makes (192-thread workgroups: 21; column strips of wide images: 21 / 28; one-wave workgroups:
- *                   28), 21 / 28 = that many wherever the LDS allows.  Same results.
- *   "hash_tiles2"   1 (default) = the DCT / threshold / bit stages of the fused strip kernel's tiles run two images per
- *                   64-thread workgroup (k_tiles_hash2), 0 = one image per 256 threads (k_tiles_hash).  Same results.
- *   "hash_cell_pad" k_blur_area_regs at integer ratios: one pad dword behind every cell of a blurred row in LDS, so that the
- *                   32 lanes that read their cells' dwords together use 32 banks: 0 = never, 1 = where cells would share a
- *                   bank 4 ways or more (default: 512, 1024, 1536, 2048, 2560 px ...), 2 = from 2 ways on.  Same results.
+ *                   stationary-needle kernel k_hamm256_small (default), 0 = the row-stationary kernels
+ *   "hash_mfma"     256 x 256 tiles: non-zero (default 2) = k_dcthash_256_band (horizontal box sums as i8 MFMAs; rows must be
+ *                   16-byte aligned, otherwise 0 is taken), 0 = k_dcthash_256 (all VALU; also what runs if the band tables
+ *                   cannot be made)
+ *   "hash_band_area" fractional resize ratios, 7 x 7 blur, <= 1920 columns: 1 (default) = k_band_area (the matrix-core blur
+ *                   for any width and height; whole images and views whose vertical edges are the parent's or lie >= 8 / >= 3
+ *                   columns inside it), 0 = the VALU kernels that serve every other geometry
+ *   "hash_stream"   the VALU kernels: 1 (default) = k_blur_area_regs walks strips of 3..8 steps when the batch has enough
+ *                   workgroups for that, k_blur_area (a workgroup per 16-row band) otherwise; 0 = always the band kernel;
+ *                   v >= 2 = always strips, of v steps
+ *   "hash_fuse"     k_blur_area_regs: 1 (default) = vertical INTER_AREA pass and tile inside the kernel when a workgroup per
+ *                   image still fills the machine, 2 = always, 0 = never (k_tile_hash reads the rows back)
  *   "kp_lds_side"   largest keypoint square k_kp_hashes stages in LDS (default 134; larger: global-memory routine)
  *   "kp_blur_side"  largest keypoint square whose blurred copy also stays in LDS (default 112)
- *   "color_pk"      1 = packed-f32 colour distance kernel (default 1)
- * Knobs that CHANGE results (within north_star's float tolerance; never the default, and not "experiments"):
- *   "color_fma"     1 = the colour distance forms dl^2 + du^2 + dv^2 with fused multiply-adds (k_color_dist3<.., FMA>):
- *                   fewer instructions, distances within 1e-5 (relative) of ColorDescriptor::distance's but not
- *                   bit-identical, so int(score) can move by one at an integer boundary
- *   "hash_area"     0 = exact (default): the fractional-ratio INTER_AREA resample keeps OpenCV's float accumulation
- *                   order; 1 = fast: the horizontal pass may fuse and re-associate (see dcthash.hip k_blur_area_regs)
- *   "color_create_chains" 1 = ColorDescriptor::create's clustering as chain-per-lane kernels (default), 0 = one lane per
- *                   image (k_cd_cluster, round 2)
+ *   "fdct_host_vote", "video_host_reduce"  the per-needle reductions of DctFeaturesIndex / DctVideoIndex finds: 0 (default) =
+ *                   on the device for batches, on the host for a single needle; 1 = host, 2 = device
+ *   "orb_retain_order" KeyPointsFilter::retainBest: 1 (default) = the survivors in the order libstdc++'s nth_element +
+ *                   partition leave them (cbird's Linux builds), 0 = canonical (every tie kept, raster order)
+ * The one knob that CHANGES results (within north_star's float tolerance; not the default: the shipped kernel is
+ * deliberately stricter -- raw floats bitwise equal to ColorDescriptor::distance -- at a cost of 9 % of its time):
+ *   "color_fma"     1 = dl^2 + du^2 + dv^2 with fused multiply-adds: distances within 1e-5 (relative) of the reference's,
+ *                   int(score) can move by one at an integer boundary (2 of 188 902 on profiles/r04_knobs_area_color.json)
+ * Memory:
  *   "color_create_chunk_mb" scratch one launch of ColorDescriptor::create may take, in MB (default 32768): larger batches
- *                   are worked off in chunks of that many images (1.6 MB per 256 x 192 image); results do not change
- *   "scratch_alloc" 2 = scratch from the library's arena (default); 1 = one ROCm hipMemPool_t per stream, 0 = ROCm's
- *                   default pool (hipMallocAsync) -- both measured unsafe on this stack, kept for the A/B soak only
+ *                   are worked off in chunks of that many images (1.6 MB per 256 x 192 image)
  *   "pool_keep_mb"  cached scratch that may outlive its stream, per device, in MB (default 16384; < 0: everything)
- *   "pool_live_keep_mb" what the cache of a LIVE stream may hold, in MB (0 = default: a quarter of the device's memory,
- *                   at least 16384; < 0: everything).  Beyond it the blocks freed longest ago go back to the driver
- *                   once the work queued behind them has run.  Its own budget because one call's working set
- *                   (ColorDescriptor::create: ~50 GB per 10^5 images) may exceed what is worth keeping for dead streams
+ *   "pool_live_keep_mb" what the cache of a LIVE stream may hold, in MB (0 = default: a quarter of the device's memory, at
+ *                   least 16384; < 0: everything).  Beyond it the blocks freed longest ago go back to the driver once the
+ *                   work queued behind them has run.  Whatever is cached stays reclaimable: an allocation the driver
+ *                   refuses -- scratch or index storage alike -- gives the device's cached blocks back and is tried again
+ * Multi-device handles:
  *   "shard_force_rccl" 1 = a sharded index on ONE device still sends its blocks through ncclAllGather (one rank): the
  *                   transport test of a one-GPU box (default 0)
  *   "shard_exchange" how the records of a multi-device index reach the root device: 1 = hipMemcpyPeerAsync of exactly
@@ -795,14 +760,19 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *   "fault_alloc_after" n >= 0: the n-th allocation from now (0 = the next; device, pinned and scratch allocations all
  *                   count) fails once with out-of-memory and the knob disarms itself; -1 disarms
  *   "fault_alloc_sticky" 1 = once that countdown has run out, every later allocation fails too, until disarmed
- *   "fault_driver_oom" n >= 0: the n-th driver allocation of the scratch arena fails once (its trim-and-retry path)
- *   "fault_rccl"    1 = librccl is treated as absent */
+ *   "fault_driver_oom" n >= 0: the n-th driver allocation of the scratch arena is refused once (its trim-and-retry path)
+ *   "fault_persist_oom" n >= 0: the n-th allocation of index / workspace / table memory is refused by the driver once (the
+ *                   arena gives its cached blocks of the device back, the allocation is tried again)
+ *   "fault_rccl"    1 = librccl is treated as absent
+ * (Rounds 1-5 carried 57 knobs, most of them A/B switches between kernel generations; the losers and their switches
+ * went with round 6 -- git history and NOTES.md keep what each measured.) */
 int cbh_set_tuning(const char* key, int value);
 /* Read-back for tests and soak tools: "fault_alloc_after" (what is left of the countdown, -1 = disarmed or fired),
  * "fault_fired", "alloc_calls" (allocations seen since the library loaded), and the scratch arena's
  * "arena_cached_bytes", "arena_pending_bytes", "arena_live_bytes", "arena_live_blocks", "arena_trimmed_live",
- * "arena_oom_retry_stream", "arena_oom_retry_device", "arena_released"; "scan_mfma_pre_max" (the largest threshold that
- * runs the prefilter scan kernel under the present knobs, 0 = none). */
+ * "arena_oom_retry_stream", "arena_oom_retry_device", "arena_oom_retry_persistent", "arena_released"; "scan_pre_mask"
+ * (bit t = the most recent matrix-core launch at threshold t took the prefilter kernel), "scan_probes" (candidate-rate
+ * probes run so far), "scan_probe_rate_e9" (what the last one found for its threshold, x 1e9; -1 = none yet). */
 int cbh_get_tuning(const char* key, long long* value);
 
 /* ---- measurement support ---------------------------------------------------------------- */
@@ -812,6 +782,13 @@ int cbh_idx64_time_scan_dev(cbh_idx64*, const void* d_q, size_t nq, int thresh, 
                             size_t cap, void* d_total, int iters, float* ms_avg);
 int cbh_time_dcthash_dev(const void* d_imgs, size_t n, int w, int h, size_t row_stride,
                          size_t img_stride, void* d_out, int device, int iters, float* ms_avg);
+/* The hardware behaviour three kernels rely on (k_hamm256_small's row tiles past the end, k_band_area's rows at the end of
+ * the buffer, the prestage first look): a raw buffer load whose SCALAR offset alone carries it past the descriptor's
+ * num_records -- the per-lane offset inside the range -- returns zeros and touches nothing.  Loads a 4 KB window of an
+ * 8 KB allocation whose second half is poisoned, with scalar offsets inside, at and beyond the window's end; *ok = 1 iff
+ * every load that starts at or past num_records returned 0 and every load inside it returned the data
+ * (tests/test_boundary.py; no product call depends on this entry point). */
+int cbh_selftest_buffer_range(int device, int* ok);
 
 #ifdef __cplusplus
 }

@@ -29,46 +29,40 @@ def gpu():
     return cbird_amd
 
 
-@pytest.fixture(params=["mfma", "mfma_r4", "mfma2", "valu"])
+@pytest.fixture(params=["mfma", "mfma_pre", "mfma_full", "valu"])
 def scan_path(request, gpu):
     """Run a GPU test once per 64-bit scan kernel family, all of which must be bit-exact against the oracle:
-    "mfma"    the matrix-core scan forced for any size, as shipped (thresholds <= 6: the prefilter variant on lo ^ hi
-              with the deferred re-check, 7..64: three needle tiles per accumulator, 65: two);
-    "mfma_r4" the prefilter as rounds 1-4 had it (low word, every candidate group through the per-tile queue path),
-              for the thresholds it serves now;
-    "mfma2"   as "mfma" with the three-tile variant off (thresholds >= 7 on the two-tile kernel);
-    "valu"    the popcount kernel k_hamm64_scan."""
+    "mfma"      the matrix-core scan forced for any size, kernels chosen as shipped ("scan_mfma_pre_max" -1: thresholds
+                <= 8 by the launch's candidate rate -- <= 6 for launches too small to probe --, 9..64 the three-field
+                kernel, 65 the two-field one);
+    "mfma_pre"  the prefilter kernel for every threshold it can represent (<= 32), however dense its candidates;
+    "mfma_full" never the prefilter: thresholds 1..64 on the three-field kernel;
+    "valu"      the popcount kernel k_hamm64_scan."""
     from cbird_amd import _lib
 
     L = _lib.lib()
     L.cbh_set_tuning(b"scan_mfma", 0 if request.param == "valu" else 2)
-    L.cbh_set_tuning(b"scan_mfma_full3", 0 if request.param == "mfma2" else 1)
-    L.cbh_set_tuning(b"scan_pre_fold", 0 if request.param == "mfma_r4" else 1)
-    L.cbh_set_tuning(b"scan_pre_lean", 0 if request.param == "mfma_r4" else 1)
+    L.cbh_set_tuning(b"scan_mfma_pre_max", {"mfma_pre": 32, "mfma_full": 0}.get(request.param, -1))
     yield request.param
     L.cbh_set_tuning(b"scan_mfma", 1)
-    L.cbh_set_tuning(b"scan_mfma_full3", 1)
-    L.cbh_set_tuning(b"scan_pre_fold", 1)
-    L.cbh_set_tuning(b"scan_pre_lean", 1)
+    L.cbh_set_tuning(b"scan_mfma_pre_max", -1)
 
 
-@pytest.fixture(params=["mfma", "mfma_rows", "mfma_rows1", "valu"])
+@pytest.fixture(params=["mfma", "mfma_rows", "valu"])
 def scan256_path(request, gpu):
     """As scan_path, for the 256-bit scan: the matrix-core kernels forced for any size -- "mfma": as shipped (searches
     with <= 512 needle descriptors and thresholds <= 40 on the stationary-needle kernel k_hamm256_small, the rest on
     k_hamm256_mfma3 / k_hamm256_mfma), "mfma_rows": without k_hamm256_small (the prefilter with three needle tiles per
-    accumulator, k_hamm256_mfma3, from 65 needle descriptors up), "mfma_rows1": k_hamm256_mfma alone (one tile per
-    accumulator) -- then "valu": k_hamm256_scan."""
+    accumulator, k_hamm256_mfma3, from 65 needle descriptors up; fewer, and thresholds > 40: k_hamm256_mfma) -- then
+    "valu": k_hamm256_scan."""
     from cbird_amd import _lib
 
     L = _lib.lib()
     L.cbh_set_tuning(b"scan256_mfma", 0 if request.param == "valu" else 2)
     L.cbh_set_tuning(b"scan256_small", 1 if request.param == "mfma" else 0)
-    L.cbh_set_tuning(b"scan256_f3", 0 if request.param == "mfma_rows1" else 1)
     yield request.param
     L.cbh_set_tuning(b"scan256_mfma", 1)
     L.cbh_set_tuning(b"scan256_small", 1)
-    L.cbh_set_tuning(b"scan256_f3", 1)
 
 
 @pytest.fixture(params=["band", "valu"])
@@ -80,21 +74,6 @@ def hash256_kernel(request, gpu):
     _lib.lib().cbh_set_tuning(b"hash_mfma", 2 if request.param == "band" else 0)
     yield request.param
     _lib.lib().cbh_set_tuning(b"hash_mfma", 2)
-
-
-@pytest.fixture(params=["cvdct", "canon"])
-def hash_dct(request, gpu, orc):
-    """Run a GPU hash test under both evaluations of dctHash64's stages 3/5, each bit-exact against the oracle set to
-    the same one: "cvdct" = cv::dct / cv::sum as OpenCV 2.4 evaluates them (cv_dct32_dev.h / oracle/cv_dct32.c, the
-    default), "canon" = the canonical 9x32 matrix form."""
-    from cbird_amd import _lib
-
-    v = 1 if request.param == "cvdct" else 0
-    _lib.lib().cbh_set_tuning(b"hash_dct", v)
-    orc.set_hash_variant(v)
-    yield request.param
-    _lib.lib().cbh_set_tuning(b"hash_dct", 1)
-    orc.set_hash_variant(1)
 
 
 @pytest.fixture(params=["device", "host"])

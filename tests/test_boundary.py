@@ -74,3 +74,17 @@ def test_no_device_fails_loudly_no_fallback():
     out = np.zeros(1, np.uint64)
     rc = L.cbh_dcthash_batch_dev(None, 0, 32, 32, 32, 1024, out.ctypes.data, 0, None)
     assert rc == _lib.CBH_E_NODEVICE
+
+
+@pytest.mark.gpu
+def test_raw_buffer_loads_past_the_descriptor_range_by_the_scalar_offset_return_zero(gpu):
+    """what k_hamm256_small, k_band_area and the prestage first look rely on instead of a per-lane select: a raw buffer
+    load whose scalar offset carries it past num_records (per-lane offset inside) returns 0 and reads nothing -- the
+    library's own probe loads a 4 KB window of an 8 KB allocation with a poisoned second half"""
+    import ctypes as C
+
+    from cbird_amd import _lib
+
+    ok = C.c_int(0)
+    _lib.check(_lib.lib().cbh_selftest_buffer_range(0, C.byref(ok)), "selftest")
+    assert ok.value == 1

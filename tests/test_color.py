@@ -145,19 +145,10 @@ def test_gpu_find_bit_exact(gpu, co, n):
         assert gi[q, :m_].tolist() == wi[order][:m_].tolist() and gs[q, :m_].tolist() == ws[order][:m_].tolist()
 
 
-@pytest.fixture(params=[2, 1, 0])
-def color_kernel(request, gpu):
-    """every distance kernel: 1 = k_color_dist2 (packed f32, shipped), 2 = k_color_dist3 (32-bit ops on VGPR operands,
-    needle in two halves; also the one that returns raw floats), 0 = k_color_dist (one descriptor per lane)"""
-    from cbird_amd import _lib
-
-    _lib.lib().cbh_set_tuning(b"color_pk", request.param)
-    yield request.param
-    _lib.lib().cbh_set_tuning(b"color_pk", 1)
-
-
 @pytest.mark.gpu
-def test_gpu_all_kernels_give_the_same_scores(gpu, co, color_kernel):
+def test_gpu_scores_of_single_finds(gpu, co):
+    """k_color_dist2 (packed f32, what find() runs); k_color_dist3 -- the kernel that also returns the raw floats -- is
+    covered by test_gpu_float_distances_are_the_references_bit_for_bit"""
     from cbird_amd.colordesc import ColorDescIndex
 
     d, ids = synth_descriptors(3000, 31)

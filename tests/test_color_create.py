@@ -127,19 +127,8 @@ def test_gpu_mask_equals_oracle(gpu, cc):
         assert (a.value, b.value) == cc.resized_dims(w, h)
 
 
-@pytest.fixture(params=["chains", "lane_per_image"])
-def create_path(request, gpu):
-    """ColorDescriptor::create's clustering on both device implementations, each byte-exact against the oracle:
-    "chains" = the chain-per-lane kernels (k_cdw_*, the default), "lane_per_image" = round 2's k_cd_cluster."""
-    from cbird_amd import _lib
-
-    _lib.lib().cbh_set_tuning(b"color_create_chains", 1 if request.param == "chains" else 0)
-    yield request.param
-    _lib.lib().cbh_set_tuning(b"color_create_chains", 1)
-
-
 @pytest.mark.gpu
-def test_gpu_color_descriptors_equal_oracle(gpu, cc, create_path):
+def test_gpu_color_descriptors_equal_oracle(gpu, cc):
     from cbird_amd.colordesc import create_descriptors
 
     rng = np.random.default_rng(8)

@@ -260,6 +260,28 @@ def test_driver_out_of_memory_is_retried_after_the_caches_are_given_up(gpu, case
     assert _same(got, want) and _tuning(L, b"arena_oom_retry_stream") == r0 + 1
 
 
+def test_index_storage_refused_by_the_driver_takes_the_arenas_caches_back(gpu, cases):
+    """a live stream may keep a quarter of the device cached as scratch; index storage, workspaces and
+    tables come from plain hipMalloc, which knows nothing of that.  A refused persistent allocation ("fault_persist_oom")
+    gives the arena's cached and pending blocks of the device back and is tried again -- the caller never sees it"""
+    from cbird_amd import _lib, synth
+
+    L = _lib.lib()
+    cases["dcthash_general"]()  # leaves scratch cached on its stream
+    assert _tuning(L, b"arena_cached_bytes") > 0
+    r0 = _tuning(L, b"arena_oom_retry_persistent")
+    h, ids = synth.make_hashes(50000, seed=2)
+    idx = gpu.DctHashIndex()
+    L.cbh_set_tuning(b"fault_persist_oom", 0)
+    try:
+        idx.load(h, ids)  # its first device allocation is "refused"
+    finally:
+        L.cbh_set_tuning(b"fault_persist_oom", -1)
+    assert _tuning(L, b"arena_oom_retry_persistent") == r0 + 1
+    assert _tuning(L, b"arena_cached_bytes") == 0  # the caches went back to the driver before the retry
+    assert idx.count() == 50000 and [m.mediaId for m in idx.find(gpu.Media(id=0, dctHash=int(h[7])), gpu.SearchParams(dctThresh=1))] == [int(ids[7])]
+
+
 def test_a_live_streams_cache_is_bounded_by_pool_live_keep_mb(gpu):
     """free_async keeps what a live stream has used only up to the budget: beyond it the blocks freed longest ago wait
     for the work queued behind them and go back to the driver (round 3 advice: a long-lived caller stream that once

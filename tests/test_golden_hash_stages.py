@@ -40,10 +40,10 @@ def test_oracle_reproduces_the_frozen_vectors(orc, variant):
 
 
 @pytest.mark.gpu
-def test_gpu_reproduces_the_frozen_vectors(gpu, hash_dct):
+def test_gpu_reproduces_the_frozen_vectors(gpu):
     from cbird_amd.hashing import make_keypoint_hashes, size_longest_side
 
-    variant = "" if hash_dct == "cvdct" else "_canon"
+    variant = ""  # the product ships ONE evaluation of stages 3 / 5: cv::dct / cv::sum as OpenCV 2.4 runs them
     g = load_golden("hash_stages.npz")
     for i, (w, h) in enumerate(gen.GEOMETRIES):
         assert gpu.dct_hash64(gen.image(w, h, 100 + i)) == int(g["hashes" + variant][i]), (w, h)
@@ -57,7 +57,7 @@ def test_gpu_reproduces_the_frozen_vectors(gpu, hash_dct):
 
 
 def test_one_fma_divides_rounds_and_accumulates_exactly():
-    """The division step of k_dcthash_256_band (and of k_dcthash_256 under "hash_div" 2 / 3), exhaustively: the column sum
+    """The division step of k_dcthash_256_band and of k_band_area, exhaustively: the column sum
     S of a 7x7 window (0 .. 49 * 255) lives as the integer 0x4B000000 + S = the float 2^23 + S; with c = 42799 * 2^-21,
     fma(2^23 + S, c, acc) adds 171196 + nearest(S / 49) to an integer-valued acc below 2^24 -- the blur's
     round-to-nearest (cv::blur, src/cvutil.cpp:463) and the running sum of an 8x8 cell in one instruction."""

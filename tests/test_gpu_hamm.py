@@ -292,7 +292,7 @@ def test_all_pairs_full_size_properties(gpu, orc):
 
 
 def test_prefilter_pair_boundaries_and_low_word_collisions(gpu, orc):
-    """The 32-bit prefilter (thresholds <= 6; the "mfma_r4" leg runs it on the low word) steps two needle pairs (128 needles) at a time, four 6-bit fields
+    """The 32-bit prefilter (the "mfma_pre" leg runs it at every threshold) steps two needle pairs (128 needles) at a time, four 6-bit fields
     per accumulator with the top field flagging through the exponent: needle counts around every pair / step /
     chunk boundary, and a haystack full of entries whose LOW words are within the threshold of a needle's while the
     high words are not (false positives in every field, including the carrying one, that the 64-bit re-check must
@@ -361,7 +361,7 @@ def test_fold_prefilter_and_deferred_recheck(gpu, orc):
 
 def test_prefilter_beyond_its_range(gpu, orc, scan_path):
     """The prefilter kernel forced for thresholds 7..16 ("scan_mfma_pre_max"): on random hashes one pair in 4000 .. 2 is a
-    candidate, so every group takes the lean path, the queue path, or both in turn -- the re-check must still be exact."""
+    candidate, so every group parks several hit lanes, in several rounds -- the re-check must still be exact."""
     if scan_path == "valu":
         pytest.skip("matrix-core kernels only")
     from cbird_amd import _lib, synth
@@ -379,4 +379,4 @@ def test_prefilter_beyond_its_range(gpu, orc, scan_path):
             wi, ws, wc = orc.find64_batch(h, ids, q, dht, 5)
             assert (gc == wc).all() and (gi == wi).all() and (gs == ws).all(), dht
     finally:
-        L.cbh_set_tuning(b"scan_mfma_pre_max", 6)
+        L.cbh_set_tuning(b"scan_mfma_pre_max", {"mfma_pre": 32, "mfma_full": 0}.get(scan_path, -1))

@@ -3,10 +3,10 @@ against oracle/cbird_oracle.c on the same inputs."""
 import numpy as np
 import pytest
 
-# every test under both stage-3/5 evaluations, and with the fractional-ratio geometries of <= 960 columns on k_band_area
-# (round 5, the default) as well as on the kernels that took them before (k_blur_area_regs & co., still the path of every
-# other geometry and of views)
-pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("hash_dct", "band_area")]
+# every test with the fractional-ratio geometries of <= 1920 columns on k_band_area (the default) as well as on the VALU
+# kernels (k_blur_area_regs / k_blur_area: what serves every other geometry, odd views, and a device whose band tables
+# cannot be made)
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("band_area")]
 
 
 @pytest.fixture(params=["band_area", "regs"])
@@ -63,8 +63,9 @@ def test_hash_any_size_general_area_path(gpu, orc, w, h):
                                  (8192, 64), (8191, 33), (6001, 100)])
 def test_hash_images_wider_than_one_workgroup(gpu, orc, w, h):
     """images wider than 2048 pixels: k_blur_area_regs on 2 or 4 column strips (each a view of the parent making its share
-    of the 32 output cells; "hash_wide" 1, the default) == the LDS band kernel that took them before ("hash_wide" 0) ==
-    oracle, hashes and 32 x 32 tiles; integer and fractional ratios, strips that end on and off 8-pixel boundaries"""
+    of the 32 output cells; large batches, forced here with "hash_stream" 4) == the LDS band kernel k_blur_area (small
+    batches; "hash_stream" 0) == oracle, hashes and 32 x 32 tiles; integer and fractional ratios, strips that end on and
+    off 8-pixel boundaries"""
     import torch
 
     from cbird_amd import _lib
@@ -80,25 +81,23 @@ def test_hash_images_wider_than_one_workgroup(gpu, orc, w, h):
     tile0 = orc.tile32(imgs[0])
     d = torch.from_numpy(imgs).cuda()
     try:
-        for knob in (1, 0):
-            L.cbh_set_tuning(b"hash_wide", knob)
-            L.cbh_set_tuning(b"hash_stream", 4)  # strips of four steps whatever the batch size
+        for knob in (4, 0):
+            L.cbh_set_tuning(b"hash_stream", knob)  # strips of four steps whatever the batch size / never strips
             assert (gpu.dct_hash64_batch(imgs) == want).all(), (w, h, knob)
             out = torch.zeros(n, dtype=torch.int64, device="cuda")
             tiles = torch.zeros((n, 32, 32), dtype=torch.uint8, device="cuda")
             _lib.check(L.cbh_dcthash_tiles_dev(d.data_ptr(), n, w, h, w, w * h, out.data_ptr(), tiles.data_ptr(), 0, None), "t")
             assert (tiles[0].cpu().numpy() == tile0).all(), (w, h, knob)
     finally:
-        L.cbh_set_tuning(b"hash_wide", 1)
         L.cbh_set_tuning(b"hash_stream", 1)
 
 
 @pytest.mark.parametrize("w,h", [(512, 160), (768, 96), (1024, 128), (1280, 64), (2048, 96), (4096, 64), (256, 192), (3072, 64)])
-def test_hash_cell_padding_in_lds_changes_nothing(gpu, orc, w, h):
+def test_hash_integer_ratios_with_padded_cells(gpu, orc, w, h):
     """integer ratios whose cells are an even number of dwords: k_blur_area_regs keeps a pad dword behind every cell of a
-    blurred LDS row so that the 32 lanes reading their cells together use 32 banks ("hash_cell_pad": 1 default = where they
-    would share a bank 4 ways or more, 2 = from 2 ways, 0 = never): hashes and tiles == oracle under all three, whole images
-    (fused and strip-split forms) and column strips of wide ones"""
+    blurred LDS row where the 32 lanes reading their cells together would share a bank 4 ways or more (512, 1024, 2048 px
+    ...; not 768, 1280): hashes and tiles == oracle, whole images (fused and strip-split forms) and column strips of wide
+    ones"""
     import torch
 
     from cbird_amd import _lib
@@ -113,9 +112,8 @@ def test_hash_cell_padding_in_lds_changes_nothing(gpu, orc, w, h):
     tile0 = orc.tile32(imgs[0])
     d = torch.from_numpy(imgs).cuda()
     try:
-        for pad in (2, 1, 0):
-            for fuse, stream in ((2, 1), (0, 4)):  # whole image per workgroup; strips of four steps + k_tile_hash
-                L.cbh_set_tuning(b"hash_cell_pad", pad)
+        for pad in (1,):
+            for fuse, stream in ((2, 4), (0, 4)):  # whole image per workgroup; strips of four steps + k_tile_hash
                 L.cbh_set_tuning(b"hash_fuse", fuse)
                 L.cbh_set_tuning(b"hash_stream", stream)
                 assert (gpu.dct_hash64_batch(imgs) == want).all(), (w, h, pad, fuse)
@@ -125,17 +123,16 @@ def test_hash_cell_padding_in_lds_changes_nothing(gpu, orc, w, h):
                            "t")
                 assert (tiles[0].cpu().numpy() == tile0).all(), (w, h, pad, fuse)
     finally:
-        L.cbh_set_tuning(b"hash_cell_pad", 1)
         L.cbh_set_tuning(b"hash_fuse", 1)
         L.cbh_set_tuning(b"hash_stream", 1)
 
 
 @pytest.mark.parametrize("w,h", [(400, 300), (1280, 200), (1366, 130), (1031, 257), (1536, 96), (2560, 120), (3000, 200), (5000, 90),
                                  (8000, 64), (704, 576)])
-def test_hash_rows_per_step_changes_nothing(gpu, orc, w, h):
-    """k_blur_area_regs<7> walks an image 14, 21 or 28 source rows per step ("hash_rows_per_step": 1 default = by how the
-    rows fill the area phase's turns, 0 = 14 always, 21 / 28 forced), in strips whose length is chosen for the fewest rows
-    processed: hashes and tiles == oracle under every value, fused and strip-split, whole images and column strips"""
+def test_hash_rows_per_step_14_and_21(gpu, orc, w, h):
+    """k_blur_area_regs<7> walks an image 14 or 21 source rows per step (by how the rows fill the area phase's turns: 21 at
+    1280 / 1366 / 1536 px and on column strips, 14 at 400 px), in strips whose length is chosen for the fewest rows
+    processed: hashes and tiles == oracle, fused and strip-split, whole images and column strips, and the band kernel"""
     import torch
 
     from cbird_amd import _lib
@@ -150,9 +147,8 @@ def test_hash_rows_per_step_changes_nothing(gpu, orc, w, h):
     tile0 = orc.tile32(imgs[0])
     d = torch.from_numpy(imgs).cuda()
     try:
-        for rows in (1, 0, 21, 28):
-            for fuse, stream in ((2, 1), (0, 4), (0, 1)):
-                L.cbh_set_tuning(b"hash_rows_per_step", rows)
+        for rows in (1,):
+            for fuse, stream in ((2, 4), (0, 4), (0, 0)):
                 L.cbh_set_tuning(b"hash_fuse", fuse)
                 L.cbh_set_tuning(b"hash_stream", stream)
                 assert (gpu.dct_hash64_batch(imgs) == want).all(), (w, h, rows, fuse, stream)
@@ -162,16 +158,14 @@ def test_hash_rows_per_step_changes_nothing(gpu, orc, w, h):
                            "t")
                 assert (tiles[0].cpu().numpy() == tile0).all(), (w, h, rows, fuse, stream)
     finally:
-        L.cbh_set_tuning(b"hash_rows_per_step", 1)
         L.cbh_set_tuning(b"hash_fuse", 1)
         L.cbh_set_tuning(b"hash_stream", 1)
 
 
 @pytest.mark.parametrize("n", [1, 2, 5, 33])
-def test_fused_tiles_are_hashed_two_per_wave_or_one_per_workgroup(gpu, orc, hash_dct, n):
-    """stages 3-6 of the fused strip kernel's tiles: k_tiles_hash2 (two images per 64-thread workgroup, "hash_tiles2" 1, the
-    default) and k_tiles_hash (one image per 256 threads) under both DCT evaluations; odd counts leave half a workgroup
-    empty; the tiles handed back are the oracle's"""
+def test_fused_tiles_are_hashed_two_per_wave(gpu, orc, n):
+    """stages 3-6 of the fused strip kernel's tiles: k_tiles_hash2 (two images per 64-thread workgroup); odd counts leave
+    half a workgroup empty; the tiles handed back are the oracle's"""
     import torch
 
     from cbird_amd import _lib
@@ -184,8 +178,8 @@ def test_fused_tiles_are_hashed_two_per_wave_or_one_per_workgroup(gpu, orc, hash
     d = torch.from_numpy(imgs).cuda()
     try:
         L.cbh_set_tuning(b"hash_fuse", 2)
-        for knob in (1, 0):
-            L.cbh_set_tuning(b"hash_tiles2", knob)
+        L.cbh_set_tuning(b"hash_stream", 4)
+        for knob in (1,):
             assert (gpu.dct_hash64_batch(imgs) == want).all(), (n, knob)
             out = torch.zeros(n, dtype=torch.int64, device="cuda")
             tiles = torch.zeros((n, 32, 32), dtype=torch.uint8, device="cuda")
@@ -195,7 +189,7 @@ def test_fused_tiles_are_hashed_two_per_wave_or_one_per_workgroup(gpu, orc, hash
             assert (out.cpu().numpy().view(np.uint64) == want).all(), (n, knob)
     finally:
         L.cbh_set_tuning(b"hash_fuse", 1)
-        L.cbh_set_tuning(b"hash_tiles2", 1)
+        L.cbh_set_tuning(b"hash_stream", 1)
 
 
 def test_hash_edge_images(gpu, orc, hash256_kernel):
@@ -301,12 +295,6 @@ def test_band_kernel_every_quotient_borders_and_ragged_batches(gpu, orc):
     for n in (1, 2, 3, 4, 5, 7, 23):
         got = gpu.dct_hash64_batch(imgs[:n])
         assert (got == orc.dcthash64_batch(imgs[:n])).all(), n
-    L.cbh_set_tuning(b"hash_band_waves", 2)  # two waves per workgroup sharing the four images (knob; slower, same bits)
-    try:
-        for n in (3, 23):
-            assert (gpu.dct_hash64_batch(imgs[:n]) == orc.dcthash64_batch(imgs[:n])).all(), n
-    finally:
-        L.cbh_set_tuning(b"hash_band_waves", 1)
     d = torch.from_numpy(imgs).cuda()
     out = torch.zeros(len(imgs), dtype=torch.int64, device="cuda")
     tiles = torch.zeros((len(imgs), 32, 32), dtype=torch.uint8, device="cuda")
@@ -351,49 +339,12 @@ def test_mfma_variant_is_bit_identical(gpu, orc, knob):
     assert (gpu.dct_hash64_batch(imgs) == want).all()
 
 
-def test_float_magic_divide_variant_is_bit_identical(gpu, orc):
-    """k_dcthash_256 with nearest(S/49) taken from the bit pattern of fma(float(S), 1/49, 1.5 * 2^23) (knob "hash_div" 1),
-    or accumulated by one fma per pixel on the float form 0x4B000000 + S (2: packed, 3: unpacked column sums)
-    == the integer multiply-shift form == oracle, on images that hit every quotient incl. the extremes; the occupancy
-    knob "hash_lds_pad" changes nothing either"""
-    import torch
-
-    from cbird_amd import _lib, synth
-
-    L = _lib.lib()
-    rng = np.random.default_rng(11)
-    imgs = np.concatenate([synth.make_images(24, seed=5), rng.integers(0, 256, (24, 256, 256), dtype=np.uint8)])
-    imgs[0] = 0
-    imgs[1] = 255
-    imgs[2, :, ::2] = 255  # column stripes: window sums step through multiples of 255
-    imgs[3] = (np.arange(256)[None, :] * 7 + np.arange(256)[:, None] * 3) % 256
-    want = orc.dcthash64_batch(imgs)
-    d = torch.from_numpy(imgs).cuda()
-    try:
-        L.cbh_set_tuning(b"hash_mfma", 0)  # (these are knobs of k_dcthash_256)
-        for div, pad in ((1, 0), (1, 12288), (0, 20480), (2, 0), (3, 0)):
-            L.cbh_set_tuning(b"hash_div", div)
-            L.cbh_set_tuning(b"hash_lds_pad", pad)
-            assert (gpu.dct_hash64_batch(imgs) == want).all(), (div, pad)
-            out = torch.zeros(len(imgs), dtype=torch.int64, device="cuda")
-            tiles = torch.zeros((len(imgs), 32, 32), dtype=torch.uint8, device="cuda")
-            _lib.check(L.cbh_dcthash_tiles_dev(d.data_ptr(), len(imgs), 256, 256, 256, 65536, out.data_ptr(),
-                                               tiles.data_ptr(), 0, None), "tiles")
-            t = tiles.cpu().numpy()
-            for i in range(0, len(imgs), 5):
-                assert (t[i] == orc.tile32(imgs[i])).all(), (div, pad, i)
-    finally:
-        L.cbh_set_tuning(b"hash_div", 0)
-        L.cbh_set_tuning(b"hash_lds_pad", 0)
-        L.cbh_set_tuning(b"hash_mfma", 2)
-
-
 def test_register_streaming_kernel(gpu, orc):
-    """k_blur_area_regs (blur input straight from global memory; knob "hash_regs") at the geometries it accepts --
+    """k_blur_area_regs (blur input straight from global memory) at the geometries it accepts --
     widths 32..2048: multiples of 8 with aligned strides (aligned 8-byte loads) and any width / stride / base address
     (the GEN form) -- in strips of 3 and 8 steps, all three blur sizes,
     integer and fractional resize ratios, heights around the step and strip boundaries: hashes and tiles equal the
-    oracle and the LDS-staged streaming kernel it replaces there"""
+    oracle and the LDS-staged band kernel k_blur_area ("hash_stream" 0) that small batches take"""
     from cbird_amd import _lib
     import torch
 
@@ -425,8 +376,7 @@ def test_register_streaming_kernel(gpu, orc):
             d = dflat[base:]
             # fuse 2: the whole-image form with the vertical INTER_AREA pass and the tile inside the kernel
             # (k_blur_area_regs<.., FUSE> + k_tiles_hash), forced for any batch size
-            for regs, steps, fuse in ((1, 3, 0), (1, 8, 0), (1, 3, 2), (0, 3, 0)):
-                L.cbh_set_tuning(b"hash_regs", regs)
+            for regs, steps, fuse in ((1, 3, 0), (1, 8, 0), (1, 3, 2), (0, 0, 0)):
                 L.cbh_set_tuning(b"hash_stream", steps)
                 L.cbh_set_tuning(b"hash_fuse", fuse)
                 out = torch.zeros(n, dtype=torch.int64, device="cuda")
@@ -439,16 +389,14 @@ def test_register_streaming_kernel(gpu, orc):
                     assert (t[i] == orc.tile32(np.ascontiguousarray(imgs[i]))).all(), (w, h, regs, steps, fuse, i)
                 assert (got == want).all(), (w, h, regs, steps, fuse)
     finally:
-        L.cbh_set_tuning(b"hash_regs", 1)
         L.cbh_set_tuning(b"hash_stream", 1)
         L.cbh_set_tuning(b"hash_fuse", 1)
 
 
 def test_hash_random_geometries_and_strides(gpu, orc):
     """Random widths/heights (every blur kernel size, widths around the 8-pixel lane groups and the 2048-column
-    workgroups, integer and fractional resize ratios) and padded row/image strides, on the fast general
-    kernels AND the original general kernels ("hash_fast_any" 1 / 0): both bit-exact against the oracle,
-    hashes and 32x32 tiles."""
+    workgroups, integer and fractional resize ratios) and padded row/image strides, on the band kernel k_blur_area
+    ("hash_stream" 0) and on strips of 3 and 8 steps: bit-exact against the oracle, hashes and 32x32 tiles."""
     from cbird_amd import _lib
     import torch
 
@@ -472,13 +420,9 @@ def test_hash_random_geometries_and_strides(gpu, orc):
             imgs = np.stack([buf[i, : h * (w + pad_x)].reshape(h, w + pad_x)[:, :w] for i in range(n)])
             want = orc.dcthash64_batch(np.ascontiguousarray(imgs))
             d = torch.from_numpy(buf).cuda()
-            # (fast, fused): fused blur+area kernel (widths >= 512), the three-kernel split, the first general kernels
-            # (fast, fused, stream): fused blur+area kernel per 16-row band (stream 0) or walking down strips of 3 / 8
-            # steps (forced: the automatic choice needs thousands of images), the three-kernel split, the first kernels
-            cfgs = [(1, 1, 0), (1, 1, 3), (1, 1, 8), (1, 0, 0)] + ([(0, 0, 0)] if w <= 7000 else [])  # (0,..): w <= ~7800
-            for fast, fused, stream_steps in cfgs:
-                L.cbh_set_tuning(b"hash_fast_any", fast)
-                L.cbh_set_tuning(b"hash_fused", fused)
+            # blur + area kernel per 16-row band (0) or walking down strips of 3 / 8 steps (forced: the automatic choice
+            # needs thousands of images)
+            for fast, fused, stream_steps in ((1, 1, 0), (1, 1, 3), (1, 1, 8)):
                 L.cbh_set_tuning(b"hash_stream", stream_steps)
                 out = torch.zeros(n, dtype=torch.int64, device="cuda")
                 tiles = torch.zeros((n, 32, 32), dtype=torch.uint8, device="cuda")
@@ -490,8 +434,6 @@ def test_hash_random_geometries_and_strides(gpu, orc):
                     assert (t[i] == orc.tile32(np.ascontiguousarray(imgs[i]))).all(), (w, h, fast, fused, stream_steps, i)
                 assert (got == want).all(), (w, h, fast, fused, stream_steps)
     finally:
-        L.cbh_set_tuning(b"hash_fast_any", 1)
-        L.cbh_set_tuning(b"hash_fused", 1)
         L.cbh_set_tuning(b"hash_stream", 1)
 
 

@@ -175,7 +175,7 @@ def test_autocropped_hash_uses_the_parent_border(gpu, po, orc):
              # stay on the band kernels
              (480, 640, 0, 0, 80, 80), (360, 641, 20, 20, 33, 47), (400, 600, 0, 0, 6, 6), (300, 500, 25, 25, 64, 9),
              (720, 1280, 0, 0, 160, 160), (240, 427, 12, 12, 51, 50), (300, 400, 0, 0, 3, 40), (300, 400, 0, 0, 40, 3),
-             # views at integer ratios whose cells are an even number of dwords (the padded LDS rows, "hash_cell_pad")
+             # views at integer ratios whose cells are an even number of dwords (the padded LDS rows)
              (896, 1024, 64, 64, 0, 0), (512, 672, 0, 0, 80, 80), (616, 868, 20, 20, 50, 50), (320, 2048, 32, 32, 0, 0))
     # as shipped (small batches: the band kernels), then with the strip kernels forced -- a view that spans the parent's
     # width (letterbox) takes the register-streaming kernel with the parent's rows above and below it, split and fused;
@@ -183,11 +183,10 @@ def test_autocropped_hash_uses_the_parent_border(gpu, po, orc):
     try:
         # (band: views whose vertical edges are the parent's or lie well inside it take k_band_area, round 5; 0 = the
         # kernels that took them before, still the path of the other views)
-        for (stream, fuse, pad, band) in ((1, 1, 1, 1), (1, 1, 1, 0), (3, 0, 2, 1), (8, 2, 2, 0), (8, 2, 0, 0)):
+        for (stream, fuse, band) in ((1, 1, 1), (1, 1, 0), (3, 0, 1), (8, 2, 0)):
             L.cbh_set_tuning(b"hash_band_area", band)
             L.cbh_set_tuning(b"hash_stream", stream)
             L.cbh_set_tuning(b"hash_fuse", fuse)
-            L.cbh_set_tuning(b"hash_cell_pad", pad)
             for (h, w, t, b, le, r) in cases:
                 gray = np.stack([letterboxed(rng, h, w, t, b, le, r) for _ in range(2)])
                 got, rects = process_images(gray, 20)
@@ -200,7 +199,6 @@ def test_autocropped_hash_uses_the_parent_border(gpu, po, orc):
     finally:
         L.cbh_set_tuning(b"hash_stream", 1)
         L.cbh_set_tuning(b"hash_fuse", 1)
-        L.cbh_set_tuning(b"hash_cell_pad", 1)
         L.cbh_set_tuning(b"hash_band_area", 1)
     assert differs >= 3 and cropped >= 3 * 2 * 14
 

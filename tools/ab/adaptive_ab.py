@@ -110,17 +110,24 @@ for name in SETS:
     for t in T:
         cell = {"pre": [], "full3": [], "auto": []}
         for r in range(R):
-            for kind, knobs in (("pre", {b"scan_mfma_pre": 2}), ("full3", {b"scan_mfma_pre": 0}), ("auto", {b"scan_mfma_pre": 1})):
+            for kind, knobs in (("pre", {b"scan_mfma_pre_max": 32}), ("full3", {b"scan_mfma_pre_max": 0}), ("auto", {b"scan_mfma_pre_max": -1})):
                 for k, v in knobs.items():
                     L.cbh_set_tuning(k, v)
                 _lib.check(L.cbh_idx64_time_scan_dev(idx.handle, dq.data_ptr(), nq, t, drec.data_ptr(), cap, dtot.data_ptr(), 2, C.byref(ms)), "t")
                 cell[kind].append((round(ms.value, 3), int(dtot.item()) // 2))
-        L.cbh_set_tuning(b"scan_mfma_pre", 1)
+                if kind == "auto":
+                    v = C.c_longlong(0)
+                    L.cbh_get_tuning(b"scan_pre_mask", C.byref(v))
+                    auto_pre = bool((v.value >> t) & 1)
+                    L.cbh_get_tuning(b"scan_probe_rate_e9", C.byref(v))
+                    auto_rate = v.value / 1e9
+        L.cbh_set_tuning(b"scan_mfma_pre_max", -1)
         mins = {k: min(x[0] for x in v) for k, v in cell.items()}
         tot = {k: sorted({x[1] for x in v}) for k, v in cell.items()}
         best = min(mins["pre"], mins["full3"])
         out["per_threshold"][str(t)] = {"ms": mins, "records": tot["full3"], "totals_agree": len({tuple(v) for v in tot.values()}) == 1,
-                                        "auto_over_best": round(mins["auto"] / best, 3), "pairs_1e12": n * nq / 1e12}
+                                        "auto_over_best": round(mins["auto"] / best, 3), "pairs_1e12": n * nq / 1e12,
+                                        "auto_kernel": "pre" if auto_pre else "full3", "library_probe_rate": auto_rate}
     res[name] = out
     print(json.dumps({name: out}), flush=True)
     del idx, dh, dq, drec

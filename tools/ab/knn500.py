@@ -16,11 +16,7 @@ needle = idx.descriptorsForMediaId(77).copy()
 needle[::3, 5] ^= 0x11
 st = _lib.cbh_stats()
 res = {}
-for name, knobs in (("rows_stationary", {b"scan256_small": 0}), ("needles_stationary", {b"scan256_small": 1}),
-                    ("needles_stationary_no_lut", {b"scan256_small": 1, b"scan256_lut": 0}),
-                    ("needles_stationary_lut_again", {b"scan256_small": 1, b"scan256_lut": 1}),
-                    ("needles_stationary_wgs768", {b"scan256_small": 768}), ("needles_stationary_wgs1024", {b"scan256_small": 1024}),
-                    ("needles_stationary_wgs2048", {b"scan256_small": 2048}), ("needles_stationary_wgs8192", {b"scan256_small": 8192})):
+for name, knobs in (("rows_stationary", {b"scan256_small": 0}), ("needles_stationary", {b"scan256_small": 1})):
     for k, v in knobs.items():
         L.cbh_set_tuning(k, v)
     r0 = idx.knn(needle, 10, 25)
@@ -34,5 +30,4 @@ for name, knobs in (("rows_stationary", {b"scan256_small": 0}), ("needles_statio
     else:
         assert all((np.asarray(a) == np.asarray(b)).all() for a, b in zip(base, r)), name
     L.cbh_set_tuning(b"scan256_small", 1)
-    L.cbh_set_tuning(b"scan256_lut", 1)
 print(json.dumps(res))

@@ -13,7 +13,8 @@ d["numColors"] = rng.integers(28, 32, n, dtype=np.uint8)
 ids = np.arange(1, n + 1, dtype=np.uint32)
 ci = ColorDescIndex()
 _lib.check(L.cbh_color_add(ci._h, ids.ctypes.data, d.ctypes.data, n), "add")
-for pk in (2, 1, 0):
-    L.cbh_set_tuning(b"color_pk", pk)
+for fma in (0, 1):  # (1: the fused-square form, within 1e-5 of the reference's floats, not bit-identical)
+    L.cbh_set_tuning(b"color_fma", fma)
     ci.find_batch(d[:64], 8)
-    t0 = time.time(); ci.find_batch(d[:64], 8); print("pk", pk, "batch64 s", time.time() - t0, flush=True)
+    t0 = time.time(); ci.find_batch(d[:64], 8); print("color_fma", fma, "batch64 s", time.time() - t0, flush=True)
+L.cbh_set_tuning(b"color_fma", 0)

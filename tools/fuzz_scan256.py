@@ -15,11 +15,9 @@ import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
-PATHS = {"shipped": {b"scan256_mfma": 2, b"scan256_small": 1, b"scan256_f3": 1},
-         "mfma3": {b"scan256_mfma": 2, b"scan256_small": 0, b"scan256_f3": 1},
-         "mfma3_6x2": {b"scan256_mfma": 2, b"scan256_small": 0, b"scan256_f3": 62},
-         "mfma1": {b"scan256_mfma": 2, b"scan256_small": 0, b"scan256_f3": 0},
-         "valu": {b"scan256_mfma": 0, b"scan256_small": 1, b"scan256_f3": 1}}
+PATHS = {"shipped": {b"scan256_mfma": 2, b"scan256_small": 1},
+         "rows": {b"scan256_mfma": 2, b"scan256_small": 0},  # k_hamm256_mfma3 / k_hamm256_mfma without k_hamm256_small
+         "valu": {b"scan256_mfma": 0, b"scan256_small": 1}}
 
 
 def main():

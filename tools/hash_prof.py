@@ -5,7 +5,6 @@ sys.path.insert(0, ".")
 from cbird_amd import _lib
 L = _lib.lib()
 w, h = int(sys.argv[1]), int(sys.argv[2])
-if len(sys.argv) > 3: L.cbh_set_tuning(b"hash_fast_any", int(sys.argv[3]))
 dev = torch.device("cuda", 0)
 n = max(64, min(20000, int(2e9 // (w * h))))
 imgs = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device=dev)

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 4: which kernels hash a >= 2 MP image and what they issue (kernel trace + one counter per pass).
+# Which kernels hash an image of a given geometry and what they issue (kernel trace + one counter per pass).
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"; cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
-# usage: tools/pmc_geo_r04.sh ["W H" ...]   (default: the >= 2 MP geometries of profiles/r04_pmc_geo.md)
+# usage: tools/pmc_geo.sh ["W H" ...]   (default: the >= 2 MP geometries of profiles/r04_pmc_geo.md)
 [ $# -eq 0 ] && set -- "3840 2160" "4000 3000" "1920 1080"
 for geo in "$@"; do
   set -- $geo

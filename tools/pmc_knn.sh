@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5: matrix-pipe counters of the 256-bit scan kernels (tools/knn_only.py 100000 2: one needle image = k_hamm256_small<16>,
+# Matrix-pipe counters of the 256-bit scan kernels (tools/knn_only.py 100000 2: one needle image = k_hamm256_small<16>,
 # 64 needle images = k_hamm256_mfma3<12,2>), one counter per pass.
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"; cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 for c in SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS; do

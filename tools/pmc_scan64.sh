@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5: matrix-pipe / VALU counters of the shipped 64-bit scan kernels, one counter per pass.
+# Matrix-pipe / VALU counters of the shipped 64-bit scan kernels, one counter per pass.
 #   run A: bench.py --dht 3,7  (one PRE launch with rare candidates, one FULL3 launch; 10^12 pairs each)
 #   run B: bench.py --dht 6    (one PRE launch at its last threshold: a candidate in every third group)
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"; cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
