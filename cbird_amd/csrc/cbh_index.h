@@ -71,6 +71,28 @@ struct Workspace {
   static constexpr size_t kSmallRecs = 512;
   static constexpr size_t kFindRecs = 65536;  // record capacity a single-needle find starts with
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // the lone-needle path (cbh_internal.h: launch_find_one): its pinned result block, two device words, a call counter
+  LoneBlock* h_lone = nullptr;
+  unsigned* d_lone = nullptr;
+  unsigned long long lone_seq = 0;
+  int ensure_lone() {
+    if (h_lone && d_lone) return CBH_OK;
+    if (!h_lone) {
+      CBH_HIP(hipHostMalloc(&h_lone, sizeof(LoneBlock), hipHostMallocCoherent));
+      h_lone->done = 0;
+      h_lone->count = 0;
+    }
+    if (!d_lone) {
+      CBH_HIP(hipMalloc(&d_lone, 2 * sizeof(unsigned)));
+      hipError_t e = hipMemset(d_lone, 0, 2 * sizeof(unsigned));
+      if (e != hipSuccess) {
+        (void)hipFree(d_lone);
+        d_lone = nullptr;
+        CBH_HIP(e);
+      }
+    }
+    return CBH_OK;
+  }
   uint64_t* d_q = nullptr;
   size_t q_cap = 0;
   uint64_t* d_qmask = nullptr;  // per-needle equal-bits masks (tree / bucket compatible searches)
@@ -145,6 +167,8 @@ struct Workspace {
     if (d_total) (void)hipFree(d_total);  // (d_rec lives in the same allocation)
     if (h_total) (void)hipHostFree(h_total);
     if (h_small) (void)hipHostFree(h_small);
+    if (h_lone) (void)hipHostFree(h_lone);
+    if (d_lone) (void)hipFree(d_lone);
     if (d_q) (void)hipFree(d_q);
     if (d_qmask) (void)hipFree(d_qmask);
     if (d_out) (void)hipFree(d_out);

@@ -121,7 +121,26 @@ int launch_hamm64_scan(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n
                        const uint64_t* d_q, size_t nq, int thresh, cbh_record* d_rec, size_t cap,
                        unsigned long long* d_total, hipStream_t stream, unsigned flags = 0,
                        const uint64_t* d_qmask = nullptr);
-enum { SCAN_KEEP_ID0 = 1u };  // also emit slots whose id is 0 (DctFeaturesIndex top-10 cut)
+enum { SCAN_KEEP_ID0 = 1u,    // also emit slots whose id is 0 (DctFeaturesIndex top-10 cut)
+       SCAN_PRE_GIVEN = 2u,   // matrix-core scan: the prefilter / three-field choice was made by the caller (a sharded
+       SCAN_PRE_VALUE = 4u }; // handle probes once for all its shards) -- SCAN_PRE_VALUE says which
+
+// ---- the lone needle (Engine::query / -similar-to: one find() at a time) ---------------------------------------------
+// One kernel launch and no copies: the needle travels as a kernel argument, matches go straight into a pinned, coherent
+// host block, the last workgroup to finish publishes the count and a sequence number that the host polls for
+// (hipStreamSynchronize costs ~6.5 us even on a drained stream; the plain path's needle upload, counter reset, two
+// read-backs and synchronisation were 26 us per find, ~25 us PER SHARD on a sharded handle).
+struct LoneBlock {
+  volatile unsigned long long done;  // the call's sequence number, written last
+  unsigned long long count;          // matches found (may exceed kRecs: then the caller takes the general path)
+  static constexpr unsigned kRecs = 512;
+  cbh_record recs[kRecs];            // dist << 32 | id (needle index 0), unordered
+};
+// d_state: two zeroed words of device memory owned by the caller's workspace (the kernel leaves them zeroed)
+int launch_find_one(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n, uint64_t q, int thresh, unsigned* d_state,
+                    LoneBlock* h_block, unsigned long long seq, hipStream_t stream);
+// spin until the block carries `seq` (falls back to a stream synchronisation after ~2 s); CBH_OK / CBH_E_HIP
+int wait_find_one(const LoneBlock* h_block, unsigned long long seq, hipStream_t stream);
 
 // ---- hamm64_mfma.hip: the same scan on the matrix cores (FP4 sign dot products) --------
 int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n,
@@ -129,13 +148,16 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
                             size_t cap, unsigned long long* d_total, hipStream_t stream,
                             unsigned flags = 0, const uint64_t* d_qmask = nullptr);
 bool scan_mfma_wanted(size_t n, size_t nq, int thresh);
+unsigned scan_pre_flags(const uint64_t* d_hashes, size_t n, size_t n_total, const uint64_t* d_q, size_t nq, int thresh,
+                        hipStream_t stream);  // SCAN_PRE_GIVEN | SCAN_PRE_VALUE, probed once for a sharded call
 void set_scan_mfma(int on);  // <0 = keep; 2 = force for any size
 void set_scan_pre_max(int t);   // -1 = prefilter or three-field kernel by the launch's candidate rate (default), 0 = never the
                                 // prefilter, t > 0 = thresholds <= t take it whatever the data
 void set_scan_pre_rate(int e9); // candidate rate x 1e9 up to which the prefilter kernel is taken ("scan_pre_rate_e9")
 long long get_scan_pre_mask();  // bit t = the most recent matrix-core launch at threshold t took the prefilter kernel
 long long get_scan_probes();    // candidate-rate probes run so far
-long long get_scan_probe_rate_e9();  // what the last one found for its threshold, x 1e9 (-1: none yet)
+long long get_scan_probe_rate_e9();  // what the last one found for its threshold, x 1e9 (-1: none yet): candidates ...
+long long get_scan_probe_true_e9();  // ... and true matches
 
 // ---- hamm256_mfma.hip: 256-bit threshold scan on the matrix cores -----------------------
 int launch_scan256_mfma(const uint8_t* d_rows, size_t n, const uint8_t* d_q, size_t nq, int thresh,

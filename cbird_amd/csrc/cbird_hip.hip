@@ -517,6 +517,7 @@ int arena_counter(const char* name, long long* value) {
 
 namespace cbh {  // sharded.hip
 int sharded_load(cbh_idx64* idx, const void* hashes, const void* ids, size_t n, bool on_device, hipStream_t stream);
+int sharded_find_one(cbh_idx64* idx, uint64_t q, int thresh, std::vector<cbh_record>* recs, bool* fits);
 int sharded_add(cbh_idx64* idx, const uint64_t* hashes, const uint32_t* ids, size_t n);
 int sharded_remove(cbh_idx64* idx, const uint32_t* ids, size_t n, int zero_hash);
 }  // namespace cbh
@@ -1066,43 +1067,45 @@ int cbh_idx64_find(cbh_idx64* idx, uint64_t q, int thresh, cbh_match* out, size_
   Workspace* ws = L.ws;
   rc = Workspace::grow(&ws->d_q, &ws->q_cap, 1);
   if (rc) return rc;
-  // Fast path (the interactive -similar-to query, Engine::query): needle staged in pinned memory, scan, the match
-  // count and the first kSmallRecs records fetched speculatively -- one stream synchronisation per find.  Larger
-  // results (or a record buffer that is too small) fall through to the general path below.
-  rc = ws->ensure_records(Workspace::kFindRecs);  // 512 KB; only a result that overflows it grows the workspace (scan_all)
-  if (rc) return rc;
-  if (idx->shards) {  // the needle goes to every shard: the general path (scan_all) is the sharded one
-    ws->h_small[Workspace::kSmallRecs] = (cbh_record)q;
-    CBH_HIP(hipMemcpyAsync(ws->d_q, &ws->h_small[Workspace::kSmallRecs], sizeof q, hipMemcpyHostToDevice, ws->stream));
-  } else {
-    constexpr size_t kS = Workspace::kSmallRecs;
-    ws->h_small[kS] = (cbh_record)q;
-    CBH_HIP(hipMemcpyAsync(ws->d_q, &ws->h_small[kS], sizeof q, hipMemcpyHostToDevice, ws->stream));
-    CBH_HIP(hipMemsetAsync(ws->d_total, 0, sizeof(unsigned long long), ws->stream));
-    rc = launch_hamm64_scan(idx->d_hashes, idx->d_ids, idx->n, ws->d_q, 1, thresh, ws->d_rec, ws->rec_cap, ws->d_total,
-                            ws->stream, 0, nullptr);
-    if (rc) return rc;
-    CBH_HIP(hipMemcpyAsync(ws->h_total, ws->d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, ws->stream));
-    CBH_HIP(hipMemcpyAsync(ws->h_small, ws->d_rec, std::min(kS, ws->rec_cap) * sizeof(cbh_record),
-                           hipMemcpyDeviceToHost, ws->stream));
-    CBH_HIP(hipStreamSynchronize(ws->stream));
-    const unsigned long long t = *ws->h_total;
+  // Fast path (the interactive -similar-to query, Engine::query): ONE kernel launch per shard, needle as a kernel argument,
+  // matches straight into pinned host memory, completion by polling (cbh_internal.h: launch_find_one).  Larger results
+  // (more than LoneBlock::kRecs matches) fall through to the general path below.
+  {
+    std::vector<cbh_record> recs;
+    bool fits = false;
+    if (idx->shards) {
+      rc = sharded_find_one(idx, q, thresh, &recs, &fits);
+      if (rc) return rc;
+    } else {
+      if ((rc = ws->ensure_lone())) return rc;
+      const unsigned long long seq = ++ws->lone_seq;
+      rc = launch_find_one(idx->d_hashes, idx->d_ids, idx->n, q, thresh, ws->d_lone, ws->h_lone, seq, ws->stream);
+      if (rc) return rc;
+      if ((rc = wait_find_one(ws->h_lone, seq, ws->stream))) return rc;
+      const unsigned long long t = ws->h_lone->count;
+      fits = t <= LoneBlock::kRecs;
+      if (fits) recs.assign(ws->h_lone->recs, ws->h_lone->recs + t);
+    }
     {
       std::lock_guard<std::mutex> lk(idx->stats_mu);
       idx->stats.scan_launches += 1;
       idx->stats.scan_pairs += (uint64_t)idx->n;
     }
-    if (t <= std::min(kS, ws->rec_cap)) {
-      *n_out = (size_t)t;
-      std::sort(ws->h_small, ws->h_small + t);
-      const size_t m = std::min<size_t>((size_t)t, cap);
+    if (fits) {
+      *n_out = recs.size();
+      std::sort(recs.begin(), recs.end());
+      const size_t m = std::min(recs.size(), cap);
       for (size_t i = 0; i < m; ++i) {
-        out[i].id = CBH_REC_ID(ws->h_small[i]);
-        out[i].score = CBH_REC_DIST(ws->h_small[i]);
+        out[i].id = CBH_REC_ID(recs[i]);
+        out[i].score = CBH_REC_DIST(recs[i]);
       }
       return CBH_OK;
     }
   }
+  rc = ws->ensure_records(Workspace::kFindRecs);  // 512 KB; only a result that overflows it grows the workspace (scan_all)
+  if (rc) return rc;
+  ws->h_small[Workspace::kSmallRecs] = (cbh_record)q;
+  CBH_HIP(hipMemcpyAsync(ws->d_q, &ws->h_small[Workspace::kSmallRecs], sizeof q, hipMemcpyHostToDevice, ws->stream));
   unsigned long long total = 0;
   rc = scan_all(idx, ws, ws->d_q, 1, thresh, ws->stream, &total);
   if (rc) return rc;
@@ -1344,6 +1347,7 @@ int cbh_set_tuning(const char* key, int value) {
       {"fault_persist_oom", [](int v) { set_fault_persist_oom(v); }},
       {"fault_rccl", [](int v) { set_fault_rccl(v); }},
   };
+  if (!strcmp(key, "orb_retain_order") && value != 0 && value != 1) return CBH_E_INVAL;
   for (const auto& k : kKnobs)
     if (!strcmp(key, k.name)) {
       k.set(value);
@@ -1361,6 +1365,7 @@ int cbh_get_tuning(const char* key, long long* value) {
   if (!strcmp(key, "scan_pre_mask")) return *value = get_scan_pre_mask(), CBH_OK;
   if (!strcmp(key, "scan_probes")) return *value = get_scan_probes(), CBH_OK;
   if (!strcmp(key, "scan_probe_rate_e9")) return *value = get_scan_probe_rate_e9(), CBH_OK;
+  if (!strcmp(key, "scan_probe_true_e9")) return *value = get_scan_probe_true_e9(), CBH_OK;
   return CBH_E_INVAL;
 }
 

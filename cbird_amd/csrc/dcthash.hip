@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <type_traits>
@@ -2261,9 +2262,14 @@ int get_ba_tabs(int w, BaTabsDev* out) {
     // cells per strip, in order of preference: 16 or 11 (a lane carries the four rows of a step: RS 4), 8 (two rows: RS 2),
     // 4 (one row: RS 1; w <= 1920).  Two cells per strip (w <= 3840) leave half the walk's lanes idle: measured 1.45 TB/s at
     // 3840 x 2160 against k_blur_area_regs' 2.6 -- not offered.
-    const int cps_try[4] = {16, 11, 8, 4};
-    for (int ci = 0; ci < 4 && host.empty(); ++ci) {
+    int cps_try[5] = {16, 11, 8, 4, 0};
+    if (const char* ev = getenv("CBH_BA_CPS")) {  // (experiments: this many cells per strip first)
+      const int v = atoi(ev);
+      if (v == 16 || v == 11 || v == 8 || v == 4) cps_try[4] = cps_try[0], cps_try[0] = v;
+    }
+    for (int ci = 0; ci < 5 && host.empty(); ++ci) {
       const int cps = cps_try[ci];
+      if (!cps) continue;
       bool ok = true;
       // one tile count for every strip: the widest strip's
       int Tc = 0;

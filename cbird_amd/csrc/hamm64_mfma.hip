@@ -690,57 +690,68 @@ __global__ __launch_bounds__(kThreads, 2) void k_hamm64_mfma3(
 // ---- which kernel: the candidate rate of THIS launch's data ---------------------------------------------------------
 // The prefilter kernel is twice as fast as the three-field kernel while its candidates are rare and loses to it when
 // they are not: every candidate costs a park / list / re-check (~110 SIMD cycles per event).  How many there are is a
-// property of the data -- P[popc(fold(a) ^ fold(b)) < t] over the launch's needle x slot pairs: 5.7e-5 at t = 6 and
-// 2.7e-4 at t = 7 for unrelated hashes, but anything for a library of scans of one form, blank frames or a video against
-// itself.  k_fold_probe counts it on kProbeS x kProbeS evenly spaced (slot, needle) samples -- a few microseconds and one
-// host round trip, against launches of milliseconds -- and pick_pre compares the rate with kPreRateMax, the rate at
-// which the two kernels tie (tools/ab/adaptive_ab.py: profiles/r06_adaptive_ab*.jsonl).  Launches too small to pay for
-// the round trip, and a probe that cannot allocate, take the fixed rule of rounds 5 (thresholds <= 6).
+// property of the data -- r_cand(t) = P[popc(fold(a) ^ fold(b)) < t] over the launch's needle x slot pairs: 5.7e-5 at
+// t = 6 and 2.7e-4 at t = 7 for unrelated hashes, but anything for a library of scans of one form, blank frames or a video
+// against itself.  The three-field kernel in turn pays for every TRUE match (a flagged group goes through three passes
+// of sixteen ballots): ~4x what a candidate costs the prefilter, so where the candidates are mostly true matches -- a
+// dense cluster of near-identical hashes -- the prefilter wins again, at any rate.  Measured per 10^12 pairs
+// (tools/ab/adaptive_ab.py, profiles/r06_adaptive_ab*.jsonl):  T_pre = 8.8 ms + 6e4 ms x r_cand,  T_full = 16.3 ms +
+// 2.5e5 ms x r_true.  k_fold_probe counts both rates on kProbeS x kProbeS evenly spaced (slot, needle) samples -- a few
+// microseconds and one host round trip, against launches of milliseconds -- and pick_pre takes the prefilter while
+//   r_cand - kTrueWeight x r_true <= kPreRateMax          (the rate at which the two kernels tie: 1.25e-4).
+// Launches too small to pay for the round trip, and a probe that cannot allocate, take the fixed rule of round 5
+// (thresholds <= 6).
 constexpr uint32_t kProbeS = 2048;     // samples per side
 constexpr int kProbeT = 8;             // thresholds 1..8 are counted (the prefilter never pays beyond: 1e-3 per pair at 8)
 constexpr int kPreStatic = 6;          // the fixed rule
 int g_pre_max_thresh = -1;             // "scan_mfma_pre_max": -1 = by candidate rate (default), 0 = never the prefilter,
                                        // t > 0 = thresholds <= t take it whatever the data (tests, A/B)
-int g_pre_rate_max_e9 = 130000;        // "scan_pre_rate_e9": kPreRateMax x 1e9
+int g_pre_rate_max_e9 = 125000;        // "scan_pre_rate_e9": kPreRateMax x 1e9
+constexpr double kTrueWeight = 4.0;
 constexpr uint64_t kProbeMinPairs = 1ull << 31;  // ~20 us of scan: below this the probe's round trip is not worth it
 
 // grid (sq / 256, sh / 64): thread = one needle sample against 64 slot samples; counts[t - 1] += pairs with fold
-// distance < t.  Sample i of the slots = row i * n / sh, sample j of the needles = needle (2 j + 1) * nq / (2 sq): in a
-// self-join the two never name the same element while n > 2 sh, so the trivial self matches (which both kernels must emit
-// anyway) are not mistaken for candidates.
+// distance < t, counts[kProbeT + t - 1] += pairs with 64-bit distance < t.  Sample i of the slots = row i * n / sh, sample j
+// of the needles = needle (2 j + 1) * nq / (2 sq): in a self-join the two never name the same element while n > 2 sh, so
+// the trivial self matches (which both kernels must emit anyway) are not counted.
 __global__ __launch_bounds__(256) void k_fold_probe(const uint2* __restrict__ hay, uint32_t n, const uint2* __restrict__ q,
                                                     uint32_t nq, uint32_t sh, uint32_t sq, uint32_t* __restrict__ counts) {
-  __shared__ uint32_t s_f[64];
-  __shared__ uint32_t s_cnt[kProbeT];
+  __shared__ uint2 s_h[64];
+  __shared__ uint32_t s_cnt[2 * kProbeT];
   const uint32_t t = threadIdx.x;
   if (t < 64) {
     const uint32_t i = blockIdx.y * 64u + t;
-    const uint2 hv = i < sh ? hay[(uint32_t)(((uint64_t)i * n) / sh)] : make_uint2(0u, 0u);
-    s_f[t] = hv.x ^ hv.y;
+    s_h[t] = i < sh ? hay[(uint32_t)(((uint64_t)i * n) / sh)] : make_uint2(0u, 0u);
   }
-  if (t < kProbeT) s_cnt[t] = 0;
+  if (t < 2 * kProbeT) s_cnt[t] = 0;
   __syncthreads();
   const uint32_t j = blockIdx.x * 256u + t;
   const uint32_t nslots = min(64u, sh - blockIdx.y * 64u);
-  uint32_t cnt[kProbeT] = {};
+  uint32_t cnt[kProbeT] = {}, cnt64[kProbeT] = {};
   if (j < sq) {
     const uint2 nv = q[(uint32_t)((((uint64_t)2 * j + 1u) * nq) / (2ull * sq))];
     const uint32_t f = nv.x ^ nv.y;
     for (uint32_t k = 0; k < nslots; ++k) {
-      const uint32_t d = (uint32_t)__popc(f ^ s_f[k]);
+      const uint2 hv = s_h[k];
+      const uint32_t d = (uint32_t)__popc(f ^ hv.x ^ hv.y);
 #pragma unroll
       for (int th = 0; th < kProbeT; ++th) cnt[th] += d < (uint32_t)(th + 1) ? 1u : 0u;
+      if (d < (uint32_t)kProbeT) {  // (rare: a true match is a candidate first)
+        const uint32_t d64 = (uint32_t)__popc(nv.x ^ hv.x) + (uint32_t)__popc(nv.y ^ hv.y);
+#pragma unroll
+        for (int th = 0; th < kProbeT; ++th) cnt64[th] += d64 < (uint32_t)(th + 1) ? 1u : 0u;
+      }
     }
   }
 #pragma unroll
-  for (int th = 0; th < kProbeT; ++th) {
-    uint32_t v = cnt[th];
+  for (int th = 0; th < 2 * kProbeT; ++th) {
+    uint32_t v = th < kProbeT ? cnt[th % kProbeT] : cnt64[th % kProbeT];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
     if ((t & 63u) == 0 && v) atomicAdd(&s_cnt[th], v);
   }
   __syncthreads();
-  if (t < kProbeT && s_cnt[t]) atomicAdd(&counts[t], s_cnt[t]);
+  if (t < 2 * kProbeT && s_cnt[t]) atomicAdd(&counts[t], s_cnt[t]);
 }
 
 // pinned words for the probe's answer: a free list (a slot is in use only inside one synchronous probe)
@@ -756,7 +767,7 @@ uint32_t* probe_slot_get() {
     }
   }
   uint32_t* p = nullptr;
-  if (hipHostMalloc(&p, kProbeT * sizeof(uint32_t)) != hipSuccess) {
+  if (hipHostMalloc(&p, 2 * kProbeT * sizeof(uint32_t)) != hipSuccess) {
     (void)hipGetLastError();
     return nullptr;
   }
@@ -770,15 +781,18 @@ void probe_slot_put(uint32_t* p) {
 std::atomic<uint64_t> g_pre_mask{0};          // bit t: the most recent matrix-core launch at threshold t took the prefilter
 std::atomic<uint64_t> g_n_probe{0};           // probes run
 std::atomic<long long> g_last_rate_e9{-1};    // candidate rate x 1e9 the last probe found for its threshold
+std::atomic<long long> g_last_true_e9{-1};    // ... and the rate of true (64-bit) matches
 
-// true = this launch takes the prefilter kernel
-bool pick_pre(const uint64_t* d_hashes, size_t n, const uint64_t* d_q, size_t nq, int thresh, hipStream_t stream) {
+// true = this launch takes the prefilter kernel.  n_total = the slots the call scans in all (a sharded handle probes one
+// shard's slots on behalf of all of them)
+bool pick_pre(const uint64_t* d_hashes, size_t n, size_t n_total, const uint64_t* d_q, size_t nq, int thresh,
+              hipStream_t stream) {
   if (thresh > 32) return false;
   if (g_pre_max_thresh >= 0) return thresh <= g_pre_max_thresh;
   if (thresh > kProbeT) return false;
-  if ((uint64_t)n * (uint64_t)nq < kProbeMinPairs) return thresh <= kPreStatic;
+  if ((uint64_t)n_total * (uint64_t)nq < kProbeMinPairs) return thresh <= kPreStatic;
   uint32_t* d_cnt = nullptr;
-  if (cbh::malloc_async((void**)&d_cnt, kProbeT * sizeof(uint32_t), stream) != hipSuccess) {
+  if (cbh::malloc_async((void**)&d_cnt, 2 * kProbeT * sizeof(uint32_t), stream) != hipSuccess) {
     (void)hipGetLastError();
     return thresh <= kPreStatic;
   }
@@ -786,23 +800,25 @@ bool pick_pre(const uint64_t* d_hashes, size_t n, const uint64_t* d_q, size_t nq
   bool ok = h_cnt != nullptr;
   const uint32_t sh = (uint32_t)std::min<size_t>(n, kProbeS), sq = (uint32_t)std::min<size_t>(nq, kProbeS);
   if (ok) {
-    ok = hipMemsetAsync(d_cnt, 0, kProbeT * sizeof(uint32_t), stream) == hipSuccess;
+    ok = hipMemsetAsync(d_cnt, 0, 2 * kProbeT * sizeof(uint32_t), stream) == hipSuccess;
     if (ok) {
       hipLaunchKernelGGL(k_fold_probe, dim3((sq + 255u) / 256u, (sh + 63u) / 64u), dim3(256), 0, stream,
                          reinterpret_cast<const uint2*>(d_hashes), (uint32_t)n, reinterpret_cast<const uint2*>(d_q),
                          (uint32_t)nq, sh, sq, d_cnt);
       ok = hipGetLastError() == hipSuccess &&
-           hipMemcpyAsync(h_cnt, d_cnt, kProbeT * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+           hipMemcpyAsync(h_cnt, d_cnt, 2 * kProbeT * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
            hipStreamSynchronize(stream) == hipSuccess;
     }
   }
   (void)cbh::free_async(d_cnt, stream);
   bool pre = thresh <= kPreStatic;
   if (ok) {
-    const double rate = (double)h_cnt[thresh - 1] / ((double)sh * (double)sq);
-    g_last_rate_e9 = (long long)(rate * 1e9);
+    const double pairs = (double)sh * (double)sq;
+    const double r_cand = (double)h_cnt[thresh - 1] / pairs, r_true = (double)h_cnt[kProbeT + thresh - 1] / pairs;
+    g_last_rate_e9 = (long long)(r_cand * 1e9);
+    g_last_true_e9 = (long long)(r_true * 1e9);
     g_n_probe++;
-    pre = rate * 1e9 <= (double)g_pre_rate_max_e9;
+    pre = (r_cand - kTrueWeight * r_true) * 1e9 <= (double)g_pre_rate_max_e9;
   } else {
     (void)hipGetLastError();
   }
@@ -828,6 +844,14 @@ void set_scan_pre_rate(int e9) {
 long long get_scan_pre_mask() { return (long long)g_pre_mask.load(); }
 long long get_scan_probes() { return (long long)g_n_probe.load(); }
 long long get_scan_probe_rate_e9() { return g_last_rate_e9.load(); }
+long long get_scan_probe_true_e9() { return g_last_true_e9.load(); }
+
+// the choice for a call that scans n_total slots in several launches (sharded.hip), made once on one shard's slots:
+// SCAN_PRE_GIVEN | SCAN_PRE_VALUE bits for launch_hamm64_scan's flags
+unsigned scan_pre_flags(const uint64_t* d_hashes, size_t n, size_t n_total, const uint64_t* d_q, size_t nq, int thresh,
+                        hipStream_t stream) {
+  return SCAN_PRE_GIVEN | (pick_pre(d_hashes, n, n_total, d_q, nq, thresh, stream) ? SCAN_PRE_VALUE : 0u);
+}
 
 bool scan_mfma_wanted(size_t n, size_t nq, int thresh) {
   if (g_scan_mfma == 2) return thresh >= 1 && thresh <= 65;  // forced (tests)
@@ -840,7 +864,7 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
                             unsigned flags, const uint64_t* d_qmask) {
   if (n == 0 || nq == 0 || thresh <= 0) return CBH_OK;
   if (n > 0xfffffff0ull || nq > CBH_MAX_QUERIES_PER_CALL || thresh > 65) return CBH_E_INVAL;
-  const bool pre = pick_pre(d_hashes, n, d_q, nq, thresh, stream);
+  const bool pre = (flags & SCAN_PRE_GIVEN) ? (flags & SCAN_PRE_VALUE) != 0 : pick_pre(d_hashes, n, n, d_q, nq, thresh, stream);
   if (thresh < 64) {
     if (pre) g_pre_mask |= 1ull << thresh; else g_pre_mask &= ~(1ull << thresh);
   }

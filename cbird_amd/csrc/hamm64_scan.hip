@@ -237,9 +237,79 @@ __global__ __launch_bounds__(kThreads) void k_hamm64_scan(
   if (qb < q1) exact_block<H>(h, base_idx, n, ids, q, qb, q1, thresh, rec, cap, total, keep0, qmask);
 }
 
+// the lone needle: see cbh_internal.h.  A thread takes 8 slots 256 apart (coalesced 8-byte loads).
+constexpr unsigned kLoneSlots = 8;
+__global__ __launch_bounds__(256) void k_find_one(const uint2* __restrict__ hay, const uint32_t* __restrict__ ids,
+                                                  uint32_t n, uint32_t qlo, uint32_t qhi, uint32_t thresh,
+                                                  unsigned* __restrict__ d_state, LoneBlock* __restrict__ host,
+                                                  unsigned long long seq) {
+  const uint32_t base = blockIdx.x * (256u * kLoneSlots) + threadIdx.x;
+  bool wrote = false;
+#pragma unroll
+  for (unsigned k = 0; k < kLoneSlots; ++k) {
+    const uint32_t i = base + k * 256u;
+    if (i >= n) break;
+    const uint2 hv = hay[i];
+    const uint32_t d = (uint32_t)__popc(hv.x ^ qlo) + (uint32_t)__popc(hv.y ^ qhi);
+    if (d < thresh) {
+      const uint32_t id = ids[i];
+      if (id != 0) {
+        const unsigned slot = atomicAdd(&d_state[0], 1u);
+        if (slot < LoneBlock::kRecs) {
+          host->recs[slot] = ((cbh_record)d << 32) | id;
+          wrote = true;
+        }
+      }
+    }
+  }
+  if (wrote) __threadfence_system();  // this lane's records are in host memory before its workgroup reports
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&d_state[1], 1u) == gridDim.x - 1u) {  // the last workgroup: everyone's matches are counted and written
+      __threadfence();
+      host->count = atomicExch(&d_state[0], 0u);
+      d_state[1] = 0u;
+      __threadfence_system();
+      __hip_atomic_store(const_cast<unsigned long long*>(&host->done), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 constexpr int kPreMax = 7;  // largest threshold served by the low-word prefilter variant (r01: wins up to 7 on this kernel)
 
 }  // namespace
+
+int launch_find_one(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n, uint64_t q, int thresh, unsigned* d_state,
+                    LoneBlock* h_block, unsigned long long seq, hipStream_t stream) {
+  if (n == 0 || n > 0xfffffff0ull || !d_state || !h_block || thresh <= 0) return CBH_E_INVAL;
+  const unsigned per_wg = 256u * kLoneSlots;
+  hipLaunchKernelGGL(k_find_one, dim3((unsigned)((n + per_wg - 1) / per_wg)), dim3(256), 0, stream,
+                     reinterpret_cast<const uint2*>(d_hashes), d_ids, (uint32_t)n, (uint32_t)q, (uint32_t)(q >> 32),
+                     (uint32_t)thresh, d_state, h_block, seq);
+  CBH_HIP(hipGetLastError());
+  return CBH_OK;
+}
+
+int wait_find_one(const LoneBlock* h_block, unsigned long long seq, hipStream_t stream) {
+  const unsigned long long* flag = const_cast<const unsigned long long*>(&h_block->done);
+  for (unsigned spins = 0;; ++spins) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return CBH_OK;
+    if ((spins & 0xfffu) == 0xfffu) {  // every 4096 polls: is the stream still busy at all?
+      const hipError_t q = hipStreamQuery(stream);
+      if (q == hipSuccess) {  // the kernel has retired: its last store is visible by now, or something went wrong
+        return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq ? CBH_OK : CBH_E_HIP;
+      }
+      if (q != hipErrorNotReady) {
+        set_last_error("k_find_one", q);
+        return CBH_E_HIP;
+      }
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+}
 
 int launch_hamm64_scan(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n,
                        const uint64_t* d_q, size_t nq, int thresh, cbh_record* d_rec, size_t cap,

@@ -353,6 +353,16 @@ int sharded_scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t 
   // kernel timing for cbh_idx64_get_stats only where it can matter: a handful of needles is launch-bound, and every
   // HIP call counts there (a lone find() on 8 shards: ~12 calls per shard from this one thread)
   const bool timed = nq >= 256;
+  // prefilter or three-field kernel: one probe for the whole call, on the slots of a shard that lives where the needles
+  // are (every shard probing for itself cost a stream synchronisation per shard and threshold)
+  for (size_t s = 0; s < R; ++s) {
+    cbh_idx64* c = S->child[s];
+    if (c->device == root && c->n != 0 && scan_mfma_wanted(c->n, nq, thresh)) {
+      DeviceGuard g(root);
+      flags |= scan_pre_flags(c->d_hashes, c->n, idx->n, d_q, nq, thresh, stream);
+      break;
+    }
+  }
   for (int attempt = 0; attempt < 3; ++attempt) {
     bool any = false;
     for (size_t s = 0; s < R; ++s) {
@@ -459,6 +469,49 @@ int sharded_scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t 
   // leaves the peers' halves of the all-gather possibly in flight: those streams are synchronised when the leases end.)
   if (!by_collective)
     for (size_t s = 0; s < R; ++s) L.idle[s] = 1;
+  return CBH_OK;
+}
+
+// The lone needle on a sharded handle (cbh_idx64_find): one launch_find_one per shard, issued back to back from this thread,
+// then one poll per shard -- no needle copies, no event waits, no counter resets, no read-backs, no stream synchronisation
+// (what made a find() on 8 shards cost 203 us against 26 on the plain index).  *fits = every shard's matches fitted its
+// LoneBlock (then *recs holds them all, unordered); otherwise the caller takes the general path.
+int sharded_find_one(cbh_idx64* idx, uint64_t q, int thresh, std::vector<cbh_record>* recs, bool* fits) {
+  ShardSet* S = idx->shards;
+  const size_t R = S->child.size();
+  *fits = false;
+  recs->clear();
+  ShardLeases L(S);
+  int rc = L.acquire_all();
+  if (rc) return rc;
+  std::vector<unsigned long long> seq(R, 0);
+  for (size_t s = 0; s < R; ++s) {
+    cbh_idx64* c = S->child[s];
+    if (c->n == 0) continue;
+    DeviceGuard g(c->device);
+    if (!g.ok) return CBH_E_NODEVICE;
+    Workspace* cw = L.ws[s];
+    if ((rc = cw->ensure_lone())) return rc;
+    seq[s] = ++cw->lone_seq;
+    if ((rc = launch_find_one(c->d_hashes, c->d_ids, c->n, q, thresh, cw->d_lone, cw->h_lone, seq[s], cw->stream))) return rc;
+    S->comm.n_scans++;
+  }
+  bool all_fit = true;
+  for (size_t s = 0; s < R; ++s) {
+    if (!seq[s]) {
+      L.idle[s] = 1;
+      continue;
+    }
+    Workspace* cw = L.ws[s];
+    DeviceGuard g(S->child[s]->device);
+    if ((rc = wait_find_one(cw->h_lone, seq[s], cw->stream))) return rc;
+    L.idle[s] = 1;  // its kernel has published its result: nothing of this call is left on the stream
+    const unsigned long long t = cw->h_lone->count;
+    if (t > LoneBlock::kRecs) all_fit = false;
+    else if (all_fit) recs->insert(recs->end(), cw->h_lone->recs, cw->h_lone->recs + t);
+  }
+  *fits = all_fit;
+  if (!all_fit) recs->clear();
   return CBH_OK;
 }
 

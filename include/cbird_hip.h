@@ -712,10 +712,12 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *   "scan_mfma"     64-bit scan on the matrix cores (k_hamm64_mfma*): 0 = never (the popcount kernel k_hamm64_scan), 1 = calls
  *                   with >= 256 needles and >= 4096 slots (default), 2 = always
  *   "scan_mfma_pre_max" prefilter kernel or three-field 64-bit kernel: -1 (default) = per launch, by the candidate rate of the
- *                   launch's own data -- P[popc(fold(a) ^ fold(b)) < thresh], counted on 2048 x 2048 sampled (slot, needle)
- *                   pairs by k_fold_probe; the prefilter while it is <= "scan_pre_rate_e9"; launches of < 2^31 pairs:
- *                   thresholds <= 6 -- 0 = never the prefilter, t > 0 = thresholds <= t (<= 32) take it whatever the data
- *   "scan_pre_rate_e9" that rate x 1e9 (default 130000 = 1.3e-4: where the two kernels tie, profiles/r06_adaptive_ab*.jsonl)
+ *                   launch's own data -- r_cand = P[popc(fold(a) ^ fold(b)) < thresh] and r_true = P[hamm64(a, b) < thresh], counted
+ *                   on 2048 x 2048 sampled (slot, needle) pairs by k_fold_probe; the prefilter while r_cand - 4 r_true <=
+ *                   "scan_pre_rate_e9" (a candidate costs the prefilter a re-check, a true match costs the three-field kernel
+ *                   four times that); launches of < 2^31 pairs: thresholds <= 6 -- 0 = never the prefilter, t > 0 =
+ *                   thresholds <= t (<= 32) take it whatever the data
+ *   "scan_pre_rate_e9" that bound x 1e9 (default 125000 = 1.25e-4: where the two kernels tie, profiles/r06_adaptive_ab*.jsonl)
  *   "scan256_mfma"  256-bit scan on the matrix cores (k_hamm256_*): 0 = never (k_hamm256_scan), 1 = calls with >= 64 needle
  *                   descriptors and >= 4096 rows (default), 2 = always
  *   "scan256_small" 1 = searches with <= 512 needle descriptors (one ORB needle image) and thresholds <= 40 use the
@@ -772,7 +774,8 @@ int cbh_set_tuning(const char* key, int value);
  * "arena_cached_bytes", "arena_pending_bytes", "arena_live_bytes", "arena_live_blocks", "arena_trimmed_live",
  * "arena_oom_retry_stream", "arena_oom_retry_device", "arena_oom_retry_persistent", "arena_released"; "scan_pre_mask"
  * (bit t = the most recent matrix-core launch at threshold t took the prefilter kernel), "scan_probes" (candidate-rate
- * probes run so far), "scan_probe_rate_e9" (what the last one found for its threshold, x 1e9; -1 = none yet). */
+ * probes run so far), "scan_probe_rate_e9" / "scan_probe_true_e9" (the candidate and true-match rates the last one found for its threshold,
+ * x 1e9; -1 = none yet). */
 int cbh_get_tuning(const char* key, long long* value);
 
 /* ---- measurement support ---------------------------------------------------------------- */

@@ -121,13 +121,15 @@ for name in SETS:
                     auto_pre = bool((v.value >> t) & 1)
                     L.cbh_get_tuning(b"scan_probe_rate_e9", C.byref(v))
                     auto_rate = v.value / 1e9
+                    L.cbh_get_tuning(b"scan_probe_true_e9", C.byref(v))
+                    auto_true = v.value / 1e9
         L.cbh_set_tuning(b"scan_mfma_pre_max", -1)
         mins = {k: min(x[0] for x in v) for k, v in cell.items()}
         tot = {k: sorted({x[1] for x in v}) for k, v in cell.items()}
         best = min(mins["pre"], mins["full3"])
         out["per_threshold"][str(t)] = {"ms": mins, "records": tot["full3"], "totals_agree": len({tuple(v) for v in tot.values()}) == 1,
                                         "auto_over_best": round(mins["auto"] / best, 3), "pairs_1e12": n * nq / 1e12,
-                                        "auto_kernel": "pre" if auto_pre else "full3", "library_probe_rate": auto_rate}
+                                        "auto_kernel": "pre" if auto_pre else "full3", "library_probe_rate": auto_rate, "library_probe_true_rate": auto_true}
     res[name] = out
     print(json.dumps({name: out}), flush=True)
     del idx, dh, dq, drec
