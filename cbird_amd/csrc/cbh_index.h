@@ -84,7 +84,9 @@ struct Workspace {
     }
     if (!d_lone) {
       CBH_HIP(hipMalloc(&d_lone, 2 * sizeof(unsigned)));
-      hipError_t e = hipMemset(d_lone, 0, 2 * sizeof(unsigned));
+      // (on THIS stream: hipMemset on the null stream may return before it has run, and the workspace's stream is
+      // non-blocking -- the first find's kernel would count on garbage and never publish)
+      hipError_t e = hipMemsetAsync(d_lone, 0, 2 * sizeof(unsigned), stream);
       if (e != hipSuccess) {
         (void)hipFree(d_lone);
         d_lone = nullptr;

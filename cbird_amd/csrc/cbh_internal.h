@@ -169,31 +169,17 @@ void set_scan256_mfma(int on);  // <0 = keep; 2 = force for any size
 
 
 
-int g_hash_mfma_set(int v);  // dcthash.hip
-extern int g_fdct_host_vote, g_video_host_reduce;  // fdct.hip: 1 = round-1 host reductions (parity tests)
+// ---- setters behind cbh_set_tuning (include/cbird_hip.h documents every knob) ---------------------------------------
+int g_hash_mfma_set(int v);        // dcthash.hip "hash_mfma": 256 x 256 tiles on k_dcthash_256_band (non-zero) or k_dcthash_256 (0)
+void set_hash_band_area(int v);    // dcthash.hip "hash_band_area": k_band_area for fractional ratios up to 1920 columns (1) or never (0)
+void set_hash_stream(int v);       // dcthash.hip "hash_stream": k_blur_area_regs on strips -- 0 never, 1 by batch size, >= 2 always, of v steps
+void set_hash_fuse(int v);         // dcthash.hip "hash_fuse": vertical INTER_AREA pass + tile inside k_blur_area_regs (0 never, 1 auto, 2 always)
+void set_kp_blur_side(int v);      // kphash.hip "kp_blur_side": largest keypoint square whose blurred copy stays in LDS (default 112)
+void set_kp_lds_side(int v);       // kphash.hip "kp_lds_side": largest keypoint square processed in LDS (default 134)
+extern int g_fdct_host_vote, g_video_host_reduce;  // fdct.hip: 0 = device for batches / host for one needle, 1 = host, 2 = device
 void set_orb_retain_order(int v);  // orb.hip: 1 (default) retainBest in libstdc++'s order, 0 canonical (ties kept, raster order)
-void set_hash_fuse(int v);      // dcthash.hip: vertical INTER_AREA pass + tile inside k_blur_area_regs (0 never, 1 auto, 2 always)
-void set_hash_area(int v);      // dcthash.hip: 1 = integer sums for the interior of fractional INTER_AREA cells (NOT bit-identical)
-void set_hash_band_waves(int v);
-void set_hash_band_area(int v);  // dcthash.hip: waves per workgroup of k_dcthash_256_band (1, 2)
-void set_hash_wide(int v);      // dcthash.hip: images wider than 2048 px on column strips of the register-streaming kernel (default 1)
-void set_hash_rows_per_step(int v);  // dcthash.hip: source rows per step of k_blur_area_regs<7> (0 = 14 always, 1 = 14 / 21 / 28 by turn fill, 21 / 28 forced)
-void set_hash_tiles2(int v);    // dcthash.hip: stages 3-6 of fused tiles two images per wave (default 1)
-void set_hash_cell_pad(int v);  // dcthash.hip: pad dword per cell of a blurred LDS row where cells would share banks (default 1: from 4 ways)
-void set_hash_regs(int v);      // dcthash.hip: register-streaming general-geometry kernel where applicable (default 1)
-void set_hash_div(int v);       // dcthash.hip: k_dcthash_256 divide-by-49 form, 1 = float magic (default), 0 = integer SDWA
-void set_hash_lds_pad(int v);   // dcthash.hip: occupancy experiment knob
-void set_hash_dct(int v);       // dcthash.hip: stage 3/5 arithmetic, 1 = as cv::dct/cv::sum (default), 0 = canonical matrix form
-void set_kp_blur_side(int v);   // dcthash.hip: largest keypoint square whose blurred copy stays in LDS (default 112)
-void set_kp_lds_side(int v);    // dcthash.hip: largest keypoint square processed in LDS (default 134)
-void set_hash_stream(int v);     // dcthash.hip: streaming fused kernel (0 off, 1 auto, >= 2: steps per strip)
-void set_hash_fused(int on);     // dcthash.hip: fused blur + area kernel for widths >= on (default 1 = all; 0 off)
-void set_hash_fast_any(int on);  // dcthash.hip: fast kernels for geometries other than 256x256 (default on)
-void set_cd_chains(int v);
-void set_cd_chunk_mb(int v);   // colordesc_create.hip: 1 = chain-per-lane kernels (default), 0 = k_cd_cluster (lane per image)
-void set_cd_group(int v);    // colordesc_create.hip: images per wave of the seeding kernel (0 = auto)
-void set_color_pk(int on);   // color.hip: packed-f32 distance kernel (default on)
-void set_color_fma(int on);  // color.hip: fused squares in k_color_dist3 (default off: not bit-identical)
+void set_cd_chunk_mb(int v);       // colordesc_create.hip "color_create_chunk_mb": MB of scratch one launch may take
+void set_color_fma(int on);        // color.hip "color_fma": fused squares in k_color_dist3 (default off: not bit-identical)
 
 // ---- records.hip ----------------------------------------------------------------------
 // Ascending u64 sort of n records in place (uses d_alt as the ping-pong buffer and d_tmp as
@@ -228,7 +214,7 @@ struct cbh_nvmatch {  // one DctVideoIndex::findVideo result of needle video `ne
   uint32_t needle;
   cbh_vmatch m;
 };
-int sort_keys_u64(unsigned long long* d_keys, size_t n, int end_bit, hipStream_t s);
+int sort_keys_u64(unsigned long long* d_keys, size_t n, int end_bit, hipStream_t s);      // (records.hip: in place, arena scratch)
 int sort_pairs_u64_u32(unsigned long long* d_keys, uint32_t* d_vals, size_t n, int end_bit, hipStream_t s);
 int launch_fdct_vote(const cbh_match* d_top, const uint32_t* d_counts, const uint32_t* d_qneedle, size_t nq, int k,
                      const uint32_t* d_needle_id, size_t n_needles, std::vector<cbh_nmatch>* h_out, hipStream_t s);
@@ -237,7 +223,7 @@ int launch_video_reduce(const unsigned* d_off, const unsigned long long* d_seg, 
                         const uint32_t* d_qneedle, const int32_t* d_qframe, const uint32_t* d_needle_id, int filter_self,
                         int min_matched, int min_near, std::vector<cbh_nvmatch>* h_out, hipStream_t s);
 
-// ---- dcthash.hip ----------------------------------------------------------------------
+// ---- dcthash.hip (whole images), kphash.hip (rectangles, keypoint squares) -------------
 // view: the images are w x h sub-rectangles at (ox, oy) of pw x ph parents starting at d_imgs -- cv::blur on a
 // cv::Mat view takes its border pixels from the parent (dctHash64 after autocrop(), src/cvutil.cpp:1397-1401)
 struct HashView {
