@@ -12,7 +12,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcbird_hip.so")
+# (CBH_LIB_PATH: a development aid -- another build of the library, e.g. for a same-box A/B of two kernel variants)
+LIB_PATH = os.environ.get("CBH_LIB_PATH") or os.path.join(_HERE, "libcbird_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cbird_hip.h")
 
 CBH_OK = 0

@@ -554,22 +554,41 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
     int slot = 4 * ts + rd_row;
     slot = slot >= kRing ? slot - kRing : slot;
     const unsigned char* arow = sRing + rd_base + slot * kPitch;
+    // all T tiles as one group: the A operands are read, the MFMAs issued back to back, then the VALU work of their
+    // results -- neither the LDS round trip nor the MFMA's result latency is waited for tile by tile (tile by tile the
+    // compiler reuses two register sets and fills the MFMA's latency with s_nop: 120 instead of 154 VGPRs, neither of which
+    // limits the 10 waves per CU the LDS allows; +3-10 % at 320 x 240, 800 x 600, 960 x 540, +-1 % elsewhere:
+    // profiles/r06_band_area_blur_groups.txt)
+    constexpr int GB = T;
 #pragma unroll
-    for (int c = 0; c < T; ++c) {
-      const v4i_t a = *reinterpret_cast<const v4i_lds*>(arow + 16 * c);
-      const v4i_t d = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, c == 0 ? bF : c == T - 1 ? bL : b0, zero4, 0, 0, 0);
-      const unsigned x0 = S[c] + (unsigned)d[0], x1 = x0 + (unsigned)d[1], x2 = x1 + (unsigned)d[2],
-                     x3 = x2 + (unsigned)d[3];
-      S[c] = x3;
-      const v2f_t p01 = {__builtin_bit_cast(float, x0), __builtin_bit_cast(float, x1)};
-      const v2f_t p23 = {__builtin_bit_cast(float, x2), __builtin_bit_cast(float, x3)};
-      const v2f_t f01 = __builtin_elementwise_fma(p01, kC, kInit), f23 = __builtin_elementwise_fma(p23, kC, kInit);
-      const float fa = f01.x, fb = f01.y, fc = f23.x, fd = f23.y;
-      // low bytes of the four quotients -> one dword (rows y .. y + 3 of column 16 c + n16).  (Four ds_write_b8 straight from
-      // the fma results would save these three VALU instructions: measured 12 % SLOWER -- 52 LDS instructions per step.)
-      const unsigned lo = __builtin_amdgcn_perm(__float_as_uint(fb), __float_as_uint(fa), 0x0c0c0400u);
-      const unsigned hi = __builtin_amdgcn_perm(__float_as_uint(fd), __float_as_uint(fc), 0x04000c0cu);
-      sT[q * tp + 16 * c + n16] = lo | hi;
+    for (int c0 = 0; c0 < T; c0 += GB) {
+      v4i_t a[GB], d[GB];
+#pragma unroll
+      for (int g = 0; g < GB; ++g)
+        if (c0 + g < T) a[g] = *reinterpret_cast<const v4i_lds*>(arow + 16 * (c0 + g));
+#pragma unroll
+      for (int g = 0; g < GB; ++g)
+        if (c0 + g < T) {
+          const int c = c0 + g;
+          d[g] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[g], c == 0 ? bF : c == T - 1 ? bL : b0, zero4, 0, 0, 0);
+        }
+#pragma unroll
+      for (int g = 0; g < GB; ++g)
+        if (c0 + g < T) {
+          const int c = c0 + g;
+          const unsigned x0 = S[c] + (unsigned)d[g][0], x1 = x0 + (unsigned)d[g][1], x2 = x1 + (unsigned)d[g][2],
+                         x3 = x2 + (unsigned)d[g][3];
+          S[c] = x3;
+          const v2f_t p01 = {__builtin_bit_cast(float, x0), __builtin_bit_cast(float, x1)};
+          const v2f_t p23 = {__builtin_bit_cast(float, x2), __builtin_bit_cast(float, x3)};
+          const v2f_t f01 = __builtin_elementwise_fma(p01, kC, kInit), f23 = __builtin_elementwise_fma(p23, kC, kInit);
+          const float fa = f01.x, fb = f01.y, fc = f23.x, fd = f23.y;
+          // low bytes of the four quotients -> one dword (rows y .. y + 3 of column 16 c + n16).  (Four ds_write_b8 straight
+          // from the fma results would save these three VALU instructions: measured 12 % SLOWER -- 52 LDS instructions per step.)
+          const unsigned lo = __builtin_amdgcn_perm(__float_as_uint(fb), __float_as_uint(fa), 0x0c0c0400u);
+          const unsigned hi = __builtin_amdgcn_perm(__float_as_uint(fd), __float_as_uint(fc), 0x04000c0cu);
+          sT[q * tp + 16 * c + n16] = lo | hi;
+        }
     }
     wave_order_lds();  // (the ring rows read above are overwritten by the caller's next store_step)
     if (t < 2) return;           // (uniform) warm-up
@@ -1592,14 +1611,12 @@ int get_ba_tabs(int w, BaTabsDev* out) {
     // cells per strip, in order of preference: 16 or 11 (a lane carries the four rows of a step: RS 4), 8 (two rows: RS 2),
     // 4 (one row: RS 1; w <= 1920).  Two cells per strip (w <= 3840) leave half the walk's lanes idle: measured 1.45 TB/s at
     // 3840 x 2160 against k_blur_area_regs' 2.6 -- not offered.
-    int cps_try[5] = {16, 11, 8, 4, 0};
-    if (const char* ev = getenv("CBH_BA_CPS")) {  // (experiments: this many cells per strip first)
-      const int v = atoi(ev);
-      if (v == 16 || v == 11 || v == 8 || v == 4) cps_try[4] = cps_try[0], cps_try[0] = v;
-    }
-    for (int ci = 0; ci < 5 && host.empty(); ++ci) {
+    // (fewer cells per strip than the geometry allows -- shorter rings, 15 instead of 10 waves per CU -- lose more to the
+    // strips' halos than the occupancy returns: 400 x 300 2.92 -> 2.72 TB/s with 8 cells, 160 x 120 2.03 -> 1.42;
+    // profiles/r06_band_area_cells_per_strip.txt)
+    const int cps_try[4] = {16, 11, 8, 4};
+    for (int ci = 0; ci < 4 && host.empty(); ++ci) {
       const int cps = cps_try[ci];
-      if (!cps) continue;
       bool ok = true;
       // one tile count for every strip: the widest strip's
       int Tc = 0;

@@ -129,6 +129,7 @@ struct HitParams {
 // s_out = 2 * kOutCap words of the wave's LDS, nout = records parked (wave-uniform; callers keep it in an SGPR).
 // All three functions must be reached by the WHOLE wave (uniform control flow: they ballot).
 constexpr uint32_t kOutCap = 128;
+// (not inlined, the flush costs the prefilter kernel 144 bytes of scratch around the call and 1.5 ms per launch)
 __device__ __forceinline__ void out_flush(uint32_t* s_out, uint32_t& nout, const HitParams& hp) {
   if (nout == 0) return;
   wave_order();
@@ -441,7 +442,9 @@ __global__ __launch_bounds__(kThreads, PRE ? 4 : 1) void k_hamm64_mfma(
             wave_order();
             list(kPark, (uint32_t)__builtin_ctzll(hm), ok);
             wave_order();
-            if (npend >= 64u) drain(false);
+            // (drained at the end of the step: a one-lane event adds at most 32 descriptors, four groups cannot overflow the
+            //  list -- and the drain's code sits once per step instead of once per group: 4.3k instead of 5.5k instructions,
+            //  threshold 6 1.5 % faster, profiles/r06_pre_drain_sites_ab.json)
           } else {
             // several hit lanes, in chunks of kParkLanes (one chunk unless the group is dense: duplicates, video frames);
             // the k-th hit lane of a chunk parks all its registers at kPark + 32 k
@@ -483,6 +486,8 @@ __global__ __launch_bounds__(kThreads, PRE ? 4 : 1) void k_hamm64_mfma(
         }
       }
     }
+    if constexpr (PRE)
+      if (npend >= 64u) drain(false);
   };
 
   if constexpr (PRE) {
@@ -711,9 +716,15 @@ constexpr double kTrueWeight = 4.0;
 constexpr uint64_t kProbeMinPairs = 1ull << 31;  // ~20 us of scan: below this the probe's round trip is not worth it
 
 // grid (sq / 256, sh / 64): thread = one needle sample against 64 slot samples; counts[t - 1] += pairs with fold
-// distance < t, counts[kProbeT + t - 1] += pairs with 64-bit distance < t.  Sample i of the slots = row i * n / sh, sample j
-// of the needles = needle (2 j + 1) * nq / (2 sq): in a self-join the two never name the same element while n > 2 sh, so
-// the trivial self matches (which both kernels must emit anyway) are not counted.
+// distance < t, counts[kProbeT + t - 1] += pairs with 64-bit distance < t.  The samples are pseudo-random rows / needles
+// (a 32-bit mix of the sample number): evenly spaced ones meet the diagonal of a self-join far more often than its share
+// -- a shard of 125 000 slots against its index's 10^6 needles counted 256 self matches among 4.2 x 10^6 sampled pairs,
+// sixty times their true rate, which is how dht 7 first came to take the prefilter on a sharded handle.
+__device__ __forceinline__ uint32_t probe_mix(uint32_t x) {
+  x = ((x >> 16) ^ x) * 0x45d9f3bu;
+  x = ((x >> 16) ^ x) * 0x45d9f3bu;
+  return (x >> 16) ^ x;
+}
 __global__ __launch_bounds__(256) void k_fold_probe(const uint2* __restrict__ hay, uint32_t n, const uint2* __restrict__ q,
                                                     uint32_t nq, uint32_t sh, uint32_t sq, uint32_t* __restrict__ counts) {
   __shared__ uint2 s_h[64];
@@ -721,7 +732,7 @@ __global__ __launch_bounds__(256) void k_fold_probe(const uint2* __restrict__ ha
   const uint32_t t = threadIdx.x;
   if (t < 64) {
     const uint32_t i = blockIdx.y * 64u + t;
-    s_h[t] = i < sh ? hay[(uint32_t)(((uint64_t)i * n) / sh)] : make_uint2(0u, 0u);
+    s_h[t] = i < sh ? hay[sh == n ? i : probe_mix(i) % n] : make_uint2(0u, 0u);
   }
   if (t < 2 * kProbeT) s_cnt[t] = 0;
   __syncthreads();
@@ -729,7 +740,7 @@ __global__ __launch_bounds__(256) void k_fold_probe(const uint2* __restrict__ ha
   const uint32_t nslots = min(64u, sh - blockIdx.y * 64u);
   uint32_t cnt[kProbeT] = {}, cnt64[kProbeT] = {};
   if (j < sq) {
-    const uint2 nv = q[(uint32_t)((((uint64_t)2 * j + 1u) * nq) / (2ull * sq))];
+    const uint2 nv = q[sq == nq ? j : probe_mix(j ^ 0x9e3779b9u) % nq];
     const uint32_t f = nv.x ^ nv.y;
     for (uint32_t k = 0; k < nslots; ++k) {
       const uint2 hv = s_h[k];

@@ -79,6 +79,20 @@ def sharded(request, gpu):
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("sharded")]
 
+
+@pytest.fixture(params=["mfma", "valu"])
+def scan_path(request, gpu):
+    """(overrides conftest's four kernel families for this module: which 64-bit kernel scans a shard is orthogonal to how
+    the shards are put together -- the plain-index suites run every family; here the shipped choice and the popcount
+    kernel)"""
+    from cbird_amd import _lib
+
+    L = _lib.lib()
+    L.cbh_set_tuning(b"scan_mfma", 0 if request.param == "valu" else 2)
+    yield request.param
+    L.cbh_set_tuning(b"scan_mfma", 1)
+
+
 # ---- the one-device suites, every index sharded ---------------------------------------------------------------------
 test_find_matches_reference_golden = TH.test_find_matches_reference_golden
 test_find_batch_vs_oracle_ragged_sizes = TH.test_find_batch_vs_oracle_ragged_sizes
