@@ -93,6 +93,19 @@ def scan_path(request, gpu):
     L.cbh_set_tuning(b"scan_mfma", 1)
 
 
+@pytest.fixture(params=["device"])
+def reduce_path(request, gpu):
+    """(likewise: where the per-needle reductions of fdct / video run is orthogonal to the sharding; the plain-index suites
+    run both, here the device reductions, which are what a sharded handle's batches take)"""
+    from cbird_amd import _lib
+
+    _lib.lib().cbh_set_tuning(b"fdct_host_vote", 2)
+    _lib.lib().cbh_set_tuning(b"video_host_reduce", 2)
+    yield request.param
+    _lib.lib().cbh_set_tuning(b"fdct_host_vote", 0)
+    _lib.lib().cbh_set_tuning(b"video_host_reduce", 0)
+
+
 # ---- the one-device suites, every index sharded ---------------------------------------------------------------------
 test_find_matches_reference_golden = TH.test_find_matches_reference_golden
 test_find_batch_vs_oracle_ragged_sizes = TH.test_find_batch_vs_oracle_ragged_sizes
