@@ -617,7 +617,10 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
         }
       };
       col(0, w_first);
-#pragma unroll 4
+#ifndef CBH_BA_WU
+#define CBH_BA_WU 4
+#endif
+#pragma unroll CBH_BA_WU
       for (int k = 1; k < amin - 1; ++k) col(k, w_mid);  // interior columns: every lane's cell has them
       {
         const int kt = amin - 1;
