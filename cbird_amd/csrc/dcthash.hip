@@ -414,8 +414,11 @@ struct BaStrip {
   int amin;     // shortest: entries 1 .. amin - 2 of EVERY cell weigh its wmid (checked on the host)
   int tp;       // dwords between the images' planes of sT: chosen on the host so that the cells' walks (lane = image, cell
                 // reads column si0[cell] + k of its image's plane) meet in as few LDS banks as possible
-  int pad_[1];
+  int rotm;     // integer ratios with 16 or 32 columns per cell (512, 1024 px): cell width - 1, else 0 -- see rot
   int si0[16];             // first source column of cell c, relative to xs
+  // the block-sum walk of cell c starts at its column rot[c] and wraps (a sum has no order): cells a multiple of 16 columns
+  // apart would otherwise read the same LDS bank in every step of the walk, 8 lanes a bank at 512 px
+  int rot[16];
   // weights of cell c in table order: wfirst, then wmid for entries 1 .. amin - 2, then wtail[j] for entry amin - 1 + j
   // (+0.0f past the cell's end; amax - amin + 1 <= 4 of them)
   float wfirst[16], wmid[16], wtail[16][4];
@@ -435,7 +438,11 @@ struct BaBands {
 // area walk: 4 (strips of <= 16 cells: lane = image, cell), 2 (<= 8 cells: lane = image, cell, row pair) or 1 (<= 4 cells:
 // lane = image, cell, row) -- wide cells mean few cells per 240-column strip, and the rows of a step are then spread over the
 // lanes that would idle; the vertical chain passes its running sum from row group to row group by DPP.
-template <int T, int RS>
+// INT = integer resize ratios on both axes (cv::resize's resizeAreaFast_: exact block sums of isx x isy blurred pixels,
+// rint(float(sum) * (1.f / area)); 640 x 480, 1024 x 768, 512 x 384 ...; round 6): the same staging, ring and blur, but the
+// walk adds bytes -- the four rows of a column dword as two packed 16-bit sums, 4 VALU per column instead of the float
+// chains' 8 -- and the vertical pass adds row sums and rounds once per cell.
+template <int T, int RS, bool INT>
 __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restrict__ imgs, unsigned n, int w, int h,
                                                   unsigned row_stride, unsigned img_stride, unsigned long long buf_bytes,
                                                   const BaStrip* __restrict__ strips, int n_strips,
@@ -447,10 +454,16 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
                                                                        its left / right edge lies inside the parent (a
                                                                        pillarboxed frame): the blur reads the parent's
                                                                        pixels there instead of mirroring */,
-                                                  BaBands bands) {
+                                                  BaBands bands, int isy /* INT: source rows per output row */) {
   // LDS, sized by T (separate arrays: the compiler must know that they do not alias): ring 4 x 12 rows x kPitch, sT =
   // blurred bytes [image][x], a dword = 4 rows (+ columns for the walk's overhang)
-  constexpr int kRing = 12, kPitch = 16 * T + 32, kImg = kRing * kPitch;
+  // A ring row is 16 T + 16 bytes of pixels in a pitch of 16 T + 32.  The blur's ds_read_b128 serves 16 lanes = 4 images x
+  // 4 rows per LDS cycle: rows a pitch apart and images 12 pitches apart must fall on different 16-byte slots of the 64
+  // banks.  They do for every T but 14 (pitch 256 bytes: rows AND images on one slot, 16 ways -- 448, 608-640, 854-896 px
+  // and 1696-1792 px ran at 0.65-0.75 of their neighbours' rate), 6 (rows two ways), 2 and 10 (images two ways).  One more
+  // slot per row cures 14 (+35-45 %) and 6 (+1-2 %); at T = 10 the 768 bytes cost a wave of occupancy and 4 % (320 x 240,
+  // 1280 x 720), so 10 and 2 keep their two-way conflict.  profiles/r06_band_area_int.txt
+  constexpr int kRing = 12, kPitch = 16 * T + 32 + (T == 14 || T == 6 ? 16 : 0), kImg = kRing * kPitch;
   __shared__ __attribute__((aligned(16))) unsigned char sRing[4 * kImg];
   // sT[image][x]: the area walk has lane (image, cell) read column si0[cell] + k -- cells 28 columns apart would meet in
   // the same banks four ways in an [x][image] layout (900 px: half the speed); per-image planes of kTP = 8 (mod 32) dwords
@@ -484,7 +497,9 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
   const unsigned long long left = buf_bytes > base_off ? buf_bytes - base_off : 0ull;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<unsigned char*>(imgs + base_off), 0, (int)(left > 0xffffffffull ? 0xffffffffu : (unsigned)left), 0x27000);
-  const int colA = ox + xs - 8 + 16 * n16;  // (an inner left edge has ox >= 8: never negative)
+  // (lanes past the ring row's T + 1 chunks load chunk T's bytes again -- the same cache lines, dropped by store_step --
+  // instead of up to 112 columns of the neighbouring strip: T = 8 moved 16 chunks through the texture path for every 9 used)
+  const int colA = ox + xs - 8 + 16 * (n16 < T ? n16 : T);  // (an inner left edge has ox >= 8: never negative)
   const unsigned voffA = (mine - first) * img_stride + (unsigned)(colA < 0 ? 0 : colA);
   const int wr_base = q * kImg + 16 * n16 + (colA < 0 ? 8 : 0);
   // A-operand role (k_dcthash_256_band): M row n16 = image n16 >> 2, row n16 & 3 of the step; chunk q: 0, 1 the row, 2, 3
@@ -534,12 +549,16 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
   const int ai = lane >> 4, ac = (lane & 15) / G, rg = (lane & 15) % G;
   const bool alive = ac < ncell && first + (unsigned)ai < n;
   const int asi = st.si0[ac < ncell ? ac : 0];
+  const int rotm = INT ? st.rotm : 0, arot = INT ? st.rot[ac < ncell ? ac : 0] : 0;
   const int acc_ = ac < ncell ? ac : 0;
   const float w_first = st.wfirst[acc_], w_mid = st.wmid[acc_];
   const float w_t0 = st.wtail[acc_][0], w_t1 = st.wtail[acc_][1], w_t2 = st.wtail[acc_][2], w_t3 = st.wtail[acc_][3];
   const int ntail = amax - amin + 1;
   unsigned char* __restrict__ tdst = tiles_out + (size_t)(first + (unsigned)ai) * 1024 + (unsigned)(st.cell0 + ac);
   float vsum = 0.f;
+  unsigned vacc = 0u;                      // INT: the cell's running block sum
+  int ym = 0, cyc = bc0;                   // INT: row within the cell, cell row (uniform; a band starts on a cell boundary)
+  const float inv_area = INT ? 1.f / (float)(amin * isy) : 0.f;
   const int steps = (rb - ra + 1 + 3) / 4 + 2;
 
   auto step = [&](int t, int ts) {
@@ -547,9 +566,11 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
     // latency is over when the vertical chain wants them (behind the compiler barriers below they came one after the other,
     // each waited for: four scalar-memory round trips per step)
     const int y0 = ra + 4 * (t - 2);  // the step's blurred rows
-    YRow yrs[4];
+    YRow yrs[4] = {};
+    if constexpr (!INT) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) yrs[r] = yrow[min(max(y0 + r, 0), h - 1)];
+      for (int r = 0; r < 4; ++r) yrs[r] = yrow[min(max(y0 + r, 0), h - 1)];
+    }
     // ---- blur: rows 4t .. 4t+3 of the ring -> sT
     int slot = 4 * ts + rd_row;
     slot = slot >= kRing ? slot - kRing : slot;
@@ -592,6 +613,72 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
     }
     wave_order_lds();  // (the ring rows read above are overwritten by the caller's next store_step)
     if (t < 2) return;           // (uniform) warm-up
+    if constexpr (INT) {
+      // ---- integer ratios: block sums.  The lane's RS rows of its cell's isx (= amin = amax) columns, exact
+      unsigned hs[4] = {0u, 0u, 0u, 0u};
+      {
+        const unsigned* __restrict__ src = sT + ai * tp + asi;
+        const unsigned char* __restrict__ bsrc = reinterpret_cast<const unsigned char*>(src) + RS * rg;
+        unsigned s02 = 0u, s13 = 0u;  // 16-bit fields: <= 60 columns x 255
+        auto col = [&](int k) {
+          if constexpr (RS == 4) {
+            const unsigned pw_ = src[k];
+            s02 += pw_ & 0x00ff00ffu;                                // rows 0 | 2
+            s13 += __builtin_amdgcn_perm(0u, pw_, 0x0c030c01u);      // rows 1 | 3
+          } else if constexpr (RS == 2) {
+            const unsigned x_ = *reinterpret_cast<const unsigned short*>(bsrc + 4 * k);
+            s02 += __builtin_amdgcn_perm(0u, x_, 0x0c010c00u);       // row a | row b << 16
+          } else {
+            s02 += bsrc[4 * k];
+          }
+        };
+        if (rotm) {  // (uniform)
+          int idx = arot;
+#pragma unroll 4
+          for (int k = 0; k < amin; ++k) {
+            col(idx);
+            idx = (idx + 1) & rotm;
+          }
+        } else {
+#pragma unroll 4
+          for (int k = 0; k < amin; ++k) col(k);
+        }
+        if constexpr (RS == 4) {
+          hs[0] = s02 & 0xffffu, hs[2] = s02 >> 16, hs[1] = s13 & 0xffffu, hs[3] = s13 >> 16;
+        } else if constexpr (RS == 2) {
+          hs[0] = s02 & 0xffffu, hs[1] = s02 >> 16;
+        } else {
+          hs[0] = s02;
+        }
+      }
+      wave_order_lds();  // (sT is rewritten by the next step's blur)
+      // ---- vertical: the rows of a step in order; ym / cyc (row within the cell, cell row) are uniform and advance with
+      // every row, the running sum travels between the row groups' lanes like the float chain's
+#pragma unroll
+      for (int ph = 0; ph < G; ++ph) {
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+          const int y = y0 + ph * RS + r;
+          if (y <= rb) {  // (uniform)
+            if (G == 1 || rg == ph) vacc += hs[r];
+            if (++ym == isy) {
+              if (cyc >= bc0 && cyc < bc1 && (G == 1 || rg == ph)) {
+                const unsigned qv = (unsigned)__builtin_rintf((float)vacc * inv_area);
+                if (alive) tdst[cyc * 32] = (unsigned char)(qv > 255u ? 255u : qv);
+              }
+              if (G == 1 || rg == ph) vacc = 0u;
+              ym = 0;
+              ++cyc;
+            }
+          }
+        }
+        if constexpr (G > 1) {
+          const unsigned up = (unsigned)__builtin_amdgcn_mov_dpp((int)vacc, G == 4 ? 0x93 : 0xB1, 0xf, 0xf, true);
+          if (rg == (ph + 1) % G) vacc = up;
+        }
+      }
+      return;
+    }
     // ---- horizontal INTER_AREA: the lane's RS rows of cell ac of image ai.  A column of sT is one dword = four rows; a
     // lane that carries two rows (one row) reads just its half (byte) of it -- ds_read_u16 / ds_read_u8 hand back the bytes
     // already shifted into place
@@ -617,10 +704,7 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
         }
       };
       col(0, w_first);
-#ifndef CBH_BA_WU
-#define CBH_BA_WU 4
-#endif
-#pragma unroll CBH_BA_WU
+#pragma unroll 4  // (8 or 16 columns' reads in flight instead of 4: +-3 %, noise)
       for (int k = 1; k < amin - 1; ++k) col(k, w_mid);  // interior columns: every lane's cell has them
       {
         const int kt = amin - 1;
@@ -1663,12 +1747,16 @@ int get_ba_tabs(int w, BaTabsDev* out) {
           for (int k = 1; k <= b.amin - 2 && ok; ++k) ok = xt[(size_t)(e0 + k)].alpha == b.wmid[c - c0];
           for (int j = 0; j < 4; ++j) b.wtail[c - c0][j] = b.amin - 1 + j < nn ? xt[(size_t)(e0 + b.amin - 1 + j)].alpha : 0.f;
         }
+        if (b.amin == b.amax && (b.amin == 16 || b.amin == 32)) {
+          b.rotm = b.amin - 1;
+          for (int c = 0; c < b.ncell; ++c) b.rot[c] = c * std::max(1, b.amin / b.ncell) & b.rotm;
+        }
         {  // plane stride: the fewest lanes per LDS bank over the walk (every lane advances by one column per read)
           int best = 1 << 30;
           for (int cand_tp = 16 * Tc + 8; cand_tp <= 16 * Tc + 8 + 39; ++cand_tp) {
             int cnt[32] = {0};
             for (int im = 0; im < 4; ++im)
-              for (int c = 0; c < b.ncell; ++c) cnt[(b.si0[c] + im * cand_tp) & 31]++;
+              for (int c = 0; c < b.ncell; ++c) cnt[(b.si0[c] + b.rot[c] + im * cand_tp) & 31]++;
             int worst = 0;
             for (int k = 0; k < 32; ++k) worst = std::max(worst, cnt[k]);
             // (ties: prefer strides that also keep the blur's stores -- 16 consecutive columns per image -- apart)
@@ -1938,8 +2026,10 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
   const int isx = integer ? w / 32 : 0, isy = integer ? h / 32 : 0;
   // (views: a vertical edge is the parent's, or lies far enough inside it that the blur's three columns -- and on the left
   // the staging chunk's eight -- are the parent's pixels: letterboxed and pillarboxed frames after autocrop)
+  // (integer ratios: every width but 1024 -- strips of 128 columns on rows a multiple of the cache line apart put every row's
+  // 144 staged bytes across three lines, 2.84 TB/s against k_blur_area_regs' 3.1; profiles/r06_band_area_int.txt)
   const bool ba_view = !view || ((vw.ox == 0 || vw.ox >= 8) && (vw.ox + w == vw.pw || vw.ox + w + 3 <= vw.pw));
-  if (g_hash_band_area && ba_view && K_ == 7 && !integer && at.yrow && w >= 64 &&
+  if (g_hash_band_area && ba_view && K_ == 7 && (integer ? isx >= 2 && w != 1024 : at.yrow != nullptr) && w >= 64 &&
       4ull * img_stride < (1ull << 32) && (size_t)vw.ph * row_stride < ((size_t)1 << 32)) {
     BaTabsDev bat;
     if (get_ba_tabs(w, &bat) != CBH_OK) {  // (its table could not be made: k_blur_area_regs needs none)
@@ -1959,7 +2049,13 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
         BaBands bands;
         bands.n = 1;
         while (bands.n < 8 && (m + 3) / 4 * (size_t)bat.n_strips * (size_t)bands.n < 5120) bands.n *= 2;
-        {
+        if (integer) {
+          for (int b_ = 0; b_ < bands.n; ++b_) {
+            const int c0_ = 32 * b_ / bands.n, c1_ = 32 * (b_ + 1) / bands.n;
+            bands.c0[b_] = c0_, bands.c1[b_] = c1_;
+            bands.ra[b_] = c0_ * isy, bands.rb[b_] = c1_ * isy - 1;
+          }
+        } else {
           std::vector<int> yf;
           const std::vector<AreaTab> yt = make_area_tab(h, 32, &yf);
           for (int b_ = 0; b_ < bands.n; ++b_) {
@@ -1970,21 +2066,24 @@ int launch_dcthash(const uint8_t* d_imgs, size_t n, int w, int h, size_t row_str
           }
         }
 #define CBH_BA_(TT, RR)                                                                                                  \
-  hipLaunchKernelGGL((k_band_area<TT, RR>), dim3((unsigned)(((m + 3) / 4 + 7) / 8 * 8 * (size_t)bat.n_strips * (size_t)bands.n)), dim3(64), 0, \
+  if (integer) CBH_BA__(TT, RR, true); else CBH_BA__(TT, RR, false)
+#define CBH_BA__(TT, RR, II)                                                                                             \
+  hipLaunchKernelGGL((k_band_area<TT, RR, II>), dim3((unsigned)(((m + 3) / 4 + 7) / 8 * 8 * (size_t)bat.n_strips * (size_t)bands.n)), dim3(64), 0, \
                      stream, src, (unsigned)m, w, h, (unsigned)row_stride, (unsigned)img_stride, bytes, bat.strips,      \
                      bat.n_strips, at.yrow, d_btiles, view ? vw.oy : 0, view ? vw.ph : h, view ? vw.ox : 0,                \
-                     view ? (vw.ox > 0 ? 1 : 0) | (vw.ox + w < vw.pw ? 2 : 0) : 0, bands)
-#define CBH_BA(TT)                       \
-  case TT:                               \
-    if (bat.RS == 4) CBH_BA_(TT, 4);     \
-    else if (bat.RS == 2) CBH_BA_(TT, 2); \
-    else CBH_BA_(TT, 1);                 \
+                     view ? (vw.ox > 0 ? 1 : 0) | (vw.ox + w < vw.pw ? 2 : 0) : 0, bands, isy)
+#define CBH_BA(TT)                         \
+  case TT:                                 \
+    if (bat.RS == 4) { CBH_BA_(TT, 4); }   \
+    else if (bat.RS == 2) { CBH_BA_(TT, 2); } \
+    else { CBH_BA_(TT, 1); }               \
     break
         switch (bat.T) {
           CBH_BA(2); CBH_BA(3); CBH_BA(4); CBH_BA(5); CBH_BA(6); CBH_BA(7); CBH_BA(8); CBH_BA(9); CBH_BA(10); CBH_BA(11);
           CBH_BA(12); CBH_BA(13); CBH_BA(14); CBH_BA(15);
           default: return CBH_E_UNSUPPORTED;
         }
+#undef CBH_BA__
 #undef CBH_BA_
 #undef CBH_BA
         hipLaunchKernelGGL(k_tiles_hash2, dim3((unsigned)((m + 1) / 2)), dim3(64), 0, stream, d_btiles, (unsigned)m, tabs,

@@ -453,6 +453,10 @@ def test_band_area_kernel_geometries_strides_and_ragged_batches(gpu, orc, band_a
     geos = [(64, 301), (65, 33), (66, 32), (79, 129), (96, 97), (100, 35), (127, 200), (160, 121), (200, 150), (239, 37),
             (241, 241), (300, 200), (333, 250), (400, 300), (401, 299), (479, 361), (480, 270), (533, 400), (600, 401),
             (640, 481), (641, 480), (700, 99), (720, 405), (799, 601), (854, 480), (900, 34), (959, 540), (960, 541), (961, 100), (1000, 40), (1280, 721), (1366, 70), (1601, 99), (1919, 50), (1920, 1081), (1921, 40)]
+    # integer ratios on both axes (round 6: the kernel's block-sum walk): cells of 2 .. 60 columns and 1 .. 34 rows, every
+    # rows-per-lane variant (16 / 11 cells per strip up to 672 columns, 8 up to 960, 4 up to 1920)
+    geos += [(128, 160), (160, 128), (256, 128), (64, 288), (320, 96), (480, 64), (512, 512), (640, 480), (672, 96),
+             (704, 32), (960, 64), (1024, 768), (1280, 704), (1600, 32), (1920, 1088)]
     for gi, (w, h) in enumerate(geos):
         n = int(rng.integers(1, 10))
         row_stride = w + int(rng.integers(0, 7))
@@ -492,7 +496,7 @@ def test_band_area_row_bands_agree_across_batch_sizes(gpu, orc):
     from cbird_amd import _lib
 
     L = _lib.lib()
-    for (w, h, n) in ((200, 150, 11000), (1280, 45, 2600)):
+    for (w, h, n) in ((200, 150, 11000), (1280, 45, 2600), (640, 480, 1400), (1024, 96, 3000)):
         g = torch.Generator(device="cuda").manual_seed(w * 7 + h)
         imgs = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device="cuda", generator=g)
         imgs[::3] //= 7  # darker, smoother images too

@@ -1,6 +1,6 @@
 """Randomised parity soak of dctHash64 over image geometries at batch sizes that take the SHIPPED kernel choice
 (k_dcthash_256, the fused / split register-streaming strip kernels, the band kernels): n images of a random w x h
-(32..1100, a third of them multiples of 8, some with integer resize ratios) hashed in one call, every hash compared
+(32..1100, a third of them multiples of 8; a quarter with integer resize ratios, 32..1952 wide) hashed in one call, every hash compared
 with the oracle (threads over the host cores).  Prints one JSON line.
 
     python tools/fuzz_hash_sizes.py [--cases 30] [--seed 1] [--pixels 60000000]
@@ -32,7 +32,7 @@ def main():
     for c in range(args.cases):
         kind = rng.integers(0, 4)
         if kind == 0:
-            w, h = 32 * int(rng.integers(1, 34)), 32 * int(rng.integers(1, 30))  # integer ratios
+            w, h = 32 * int(rng.integers(1, 62)), 32 * int(rng.integers(1, 40))  # integer ratios (w <= 1952: k_band_area's block-sum walk)
         elif kind == 1:
             w, h = 8 * int(rng.integers(4, 138)), int(rng.integers(32, 900))
         elif kind == 2 and c % 5 == 0:
