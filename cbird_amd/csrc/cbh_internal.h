@@ -120,10 +120,11 @@ static inline hipError_t gated_host_malloc(T** p, size_t bytes, unsigned flags =
 int launch_hamm64_scan(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n,
                        const uint64_t* d_q, size_t nq, int thresh, cbh_record* d_rec, size_t cap,
                        unsigned long long* d_total, hipStream_t stream, unsigned flags = 0,
-                       const uint64_t* d_qmask = nullptr);
+                       const uint64_t* d_qmask = nullptr, const void* qx_given = nullptr);
 enum { SCAN_KEEP_ID0 = 1u,    // also emit slots whose id is 0 (DctFeaturesIndex top-10 cut)
        SCAN_PRE_GIVEN = 2u,   // matrix-core scan: the prefilter / three-field choice was made by the caller (a sharded
-       SCAN_PRE_VALUE = 4u }; // handle probes once for all its shards) -- SCAN_PRE_VALUE says which
+       SCAN_PRE_VALUE = 4u,   // handle probes once for all its shards) -- SCAN_PRE_VALUE says which
+       SCAN_SIBLINGS_SHIFT = 8 }; // bits 8..15: launches against the same needles running side by side on the device (0 = alone)
 
 // ---- the lone needle (Engine::query / -similar-to: one find() at a time) ---------------------------------------------
 // One kernel launch and no copies: the needle travels as a kernel argument, matches go straight into a pinned, coherent
@@ -146,7 +147,11 @@ int wait_find_one(const LoneBlock* h_block, unsigned long long seq, hipStream_t 
 int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n,
                             const uint64_t* d_q, size_t nq, int thresh, cbh_record* d_rec,
                             size_t cap, unsigned long long* d_total, hipStream_t stream,
-                            unsigned flags = 0, const uint64_t* d_qmask = nullptr);
+                            unsigned flags = 0, const uint64_t* d_qmask = nullptr, const void* qx_given = nullptr);
+// the needles of a call in the matrix-core kernels' operand layout, made ONCE for several launches against the same needles
+// on one device (the shards of a sharded handle): *qx = malloc_async on `stream`, to be handed to every launch as qx_given
+// (launches on other streams wait for an event of `stream`) and given back with free_async once they have all finished
+int expand_needles_for_scan(const uint64_t* d_q, size_t nq, hipStream_t stream, void** qx);
 bool scan_mfma_wanted(size_t n, size_t nq, int thresh);
 unsigned scan_pre_flags(const uint64_t* d_hashes, size_t n, size_t n_total, const uint64_t* d_q, size_t nq, int thresh,
                         hipStream_t stream);  // SCAN_PRE_GIVEN | SCAN_PRE_VALUE, probed once for a sharded call

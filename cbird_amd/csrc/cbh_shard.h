@@ -71,8 +71,10 @@ struct ShardComm {
   // parts in shard order (shards of a device adjacent).  On return root_stream waits for everything that lands in
   // d_dst; the shard streams may still be busy with their side of the collective.
   // went_collective (optional): whether the records travelled through ncclAllGather (false: by copies)
+  // root_prefilled (copies only): records that already sit at the start of d_dst (the root device's shards appended them
+  // in place, sharded_scan_all); the parts land behind them
   int exchange(std::vector<ShardPart>& parts, hipStream_t root_stream, unsigned long long* d_dst,
-               bool* went_collective = nullptr);
+               bool* went_collective = nullptr, unsigned long long root_prefilled = 0);
   void destroy_comms();
 };
 

@@ -310,6 +310,8 @@ __global__ __launch_bounds__(64) void k_dcthash_256_band(
       f[c] = __builtin_elementwise_fma(p01, kC, FIRST ? kInit : f[c]);
       f[c] = __builtin_elementwise_fma(p23, kC, f[c]);
     }
+    // (k_band_area's grouping -- 4, 8 or all 16 tiles' operands read, then their MFMAs, then the VALU work -- measured here:
+    //  5.2-5.3 TB/s in every form, and 176 / 198 VGPRs at 8 / 16 cost the third wave per SIMD)
     if constexpr (!FIRST) {
       const int a_row = (t - 3) >> 1;  // cell row closed by this step (negative during the warm-up)
       if (a_row >= 0) {

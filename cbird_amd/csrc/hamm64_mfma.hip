@@ -869,10 +869,29 @@ bool scan_mfma_wanted(size_t n, size_t nq, int thresh) {
   return g_scan_mfma && nq >= g_mfma_min_nq && n >= 4096 && thresh >= 1 && thresh <= 65;
 }
 
+static uint32_t padded_needles(size_t nq) { return (uint32_t)((nq + 191) / 192) * 192u; }  // whole pairs (64) and triples (96)
+
+int expand_needles_for_scan(const uint64_t* d_q, size_t nq, hipStream_t stream, void** qx_out) {
+  *qx_out = nullptr;
+  if (nq == 0 || nq > CBH_MAX_QUERIES_PER_CALL) return CBH_OK;
+  const uint32_t nq_pad = padded_needles(nq);
+  uint4* qx = nullptr;
+  CBH_HIP(malloc_async((void**)&qx, (size_t)nq_pad * 48u, stream));  // 2 words + the prefilter word, 16 B each
+  hipLaunchKernelGGL(k_expand_needles, dim3((3u * nq_pad + 255u) / 256u), dim3(256), 0, stream, d_q,
+                     (uint32_t)nq, nq_pad, qx);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    (void)free_async(qx, stream);
+    CBH_HIP(e);
+  }
+  *qx_out = qx;
+  return CBH_OK;
+}
+
 int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n,
                             const uint64_t* d_q, size_t nq, int thresh, cbh_record* d_rec,
                             size_t cap, unsigned long long* d_total, hipStream_t stream,
-                            unsigned flags, const uint64_t* d_qmask) {
+                            unsigned flags, const uint64_t* d_qmask, const void* qx_given) {
   if (n == 0 || nq == 0 || thresh <= 0) return CBH_OK;
   if (n > 0xfffffff0ull || nq > CBH_MAX_QUERIES_PER_CALL || thresh > 65) return CBH_E_INVAL;
   const bool pre = (flags & SCAN_PRE_GIVEN) ? (flags & SCAN_PRE_VALUE) != 0 : pick_pre(d_hashes, n, n, d_q, nq, thresh, stream);
@@ -881,20 +900,27 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
   }
   const uint32_t n_pairs = (uint32_t)((nq + 63) / 64);
   const uint32_t n_triples = (uint32_t)((nq + 95) / 96);
-  const uint32_t nq_pad = (uint32_t)((nq + 191) / 192) * 192u;  // whole pairs (64) and whole triples (96)
-  uint4* qx = nullptr;
-  CBH_HIP(cbh::malloc_async((void**)&qx, (size_t)nq_pad * 48u, stream));  // 2 words + the prefilter word, 16 B each
-  hipLaunchKernelGGL(k_expand_needles, dim3((3u * nq_pad + 255u) / 256u), dim3(256), 0, stream, d_q,
-                     (uint32_t)nq, nq_pad, qx);
+  const uint32_t nq_pad = padded_needles(nq);
+  const uint4* qx = reinterpret_cast<const uint4*>(qx_given);
+  void* qx_own = nullptr;
+  if (!qx) {
+    int rc = expand_needles_for_scan(d_q, nq, stream, &qx_own);
+    if (rc) return rc;
+    qx = reinterpret_cast<const uint4*>(qx_own);
+  }
   const uint4* qf = qx + 2u * (size_t)nq_pad;
   const uint32_t rows_per_wg = 32u * kHT * kWaves;
+  // launches that run side by side on this device (the shards of a sharded handle): the workgroups that fill the machine are
+  // theirs together -- a shard of 125 000 slots alone cut its needles into chunks of 128 pairs to reach 8192 workgroups and
+  // paid the shorter chunks' per-chunk costs (3 % of the sweep) for parallelism its seven siblings already supplied
+  const uint32_t sib = std::max(1u, (flags >> SCAN_SIBLINGS_SHIFT) & 0xffu);
   const uint32_t wgs = (uint32_t)((n + rows_per_wg - 1) / rows_per_wg);
   if (!pre && thresh <= 64) {
     // needle chunk: >= 8192 workgroups in flight when there is that much work, but each wave amortises its tile expansion
     // over >= 11 needle-tile triples (172 triples = 16512 needles per chunk: 16.05 ms against 16.25-16.3 with 2-4x that,
     // tools/ab/scan_chunk_ab.py)
     uint32_t tpc = 172u;
-    while (tpc > 11 && (uint64_t)wgs * ((n_triples + tpc - 1) / tpc) < 8192) tpc = (tpc + 1) / 2;
+    while (tpc > 11 && (uint64_t)wgs * sib * ((n_triples + tpc - 1) / tpc) < 8192) tpc = (tpc + 1) / 2;
     uint32_t ch3 = (n_triples + tpc - 1) / tpc;
     if (ch3 > 65535) {
       tpc = (n_triples + 65534) / 65535;
@@ -908,7 +934,7 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
     // (prefilter: 512 pairs = 32768 needles per chunk -- a wave drains its pending candidates at the end of its chunk,
     // mostly a short list: at threshold 6 chunks of 512 / 1024 pairs run 12.63 ms against 12.98 with 256 and 13.35 with 64)
     uint32_t ppc = pre ? 512u : 256u;
-    while (ppc > 16 && (uint64_t)wgs * ((n_pairs + ppc - 1) / ppc) < 8192) ppc >>= 1;
+    while (ppc > 16 && (uint64_t)wgs * sib * ((n_pairs + ppc - 1) / ppc) < 8192) ppc >>= 1;
     uint32_t chunks = (n_pairs + ppc - 1) / ppc;
     if (chunks > 65535) {
       ppc = ((n_pairs + 65534) / 65535 + 1u) & ~1u;  // even: the prefilter variant steps two pairs at a time
@@ -923,7 +949,7 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
 #undef CBH_MFMA
   }
   hipError_t e = hipGetLastError();
-  (void)cbh::free_async(qx, stream);
+  if (qx_own) (void)cbh::free_async(qx_own, stream);
   CBH_HIP(e);
   return CBH_OK;
 }

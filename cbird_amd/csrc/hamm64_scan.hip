@@ -314,12 +314,12 @@ int wait_find_one(const LoneBlock* h_block, unsigned long long seq, hipStream_t 
 int launch_hamm64_scan(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n,
                        const uint64_t* d_q, size_t nq, int thresh, cbh_record* d_rec, size_t cap,
                        unsigned long long* d_total, hipStream_t stream, unsigned flags,
-                       const uint64_t* d_qmask) {
+                       const uint64_t* d_qmask, const void* qx_given) {
   if (n == 0 || nq == 0 || thresh <= 0) return CBH_OK;
   if (n > 0xfffffff0ull || nq > CBH_MAX_QUERIES_PER_CALL) return CBH_E_INVAL;
   if (scan_mfma_wanted(n, nq, thresh))
     return launch_hamm64_scan_mfma(d_hashes, d_ids, n, d_q, nq, thresh, d_rec, cap, d_total, stream,
-                                   flags, d_qmask);
+                                   flags, d_qmask, qx_given);
   const uint32_t tile = kThreads * kH;
   const uint32_t tiles = (uint32_t)((n + tile - 1) / tile);
   // needle chunk: enough workgroups to fill 256 CUs x 8 waves/SIMD several times over, but each

@@ -158,7 +158,7 @@ void ShardComm::destroy_comms() {
 }
 
 int ShardComm::exchange(std::vector<ShardPart>& parts, hipStream_t root_stream, unsigned long long* d_dst,
-                        bool* went_collective) {
+                        bool* went_collective, unsigned long long root_prefilled) {
   const size_t R = parts.size(), D = devices.size();
   const int root = devices[0];
   bool collective = g_exchange == 0 && (D > 1 || g_force_rccl);
@@ -175,6 +175,7 @@ int ShardComm::exchange(std::vector<ShardPart>& parts, hipStream_t root_stream, 
   }
   // per-device totals, the place of every shard inside its device's run, and of every device in the destination
   std::vector<unsigned long long> dev_total(D, 0), shard_off(R, 0), dev_off(D, 0);
+  dev_total[0] = root_prefilled;  // (copies only: records the root device's shards appended in place, ahead of everything)
   for (size_t s = 0; s < R; ++s) {
     shard_off[s] = dev_total[(size_t)parts[s].dev_pos];
     dev_total[(size_t)parts[s].dev_pos] += parts[s].count;
@@ -340,31 +341,66 @@ int sharded_scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t 
     CBH_HIP(hipStreamSynchronize(stream));
     return CBH_OK;
   }
+  // (declared ahead of the leases: given back after their destructor has drained every shard stream that may still read it
+  // -- on the paths that succeed the root stream has waited for those shards and nothing is synchronised again)
+  void* qx_root = nullptr;
+  struct QxFree {
+    void*& p;
+    hipStream_t st;
+    int dev;
+    ~QxFree() {
+      if (p) {
+        DeviceGuard g(dev);
+        (void)free_async(p, st);
+      }
+    }
+  } qx_free{qx_root, stream, root};
   ShardLeases L(S);
   if ((rc = L.acquire_all())) return rc;
-  CBH_HIP(hipEventRecord(ws->ev0, stream));  // the needles (and masks) are complete on the root device
   // ---- scan: every shard, its own device and stream ----
   std::vector<const uint64_t*> q_of(R, d_q), mask_of(R, d_qmask);
   std::vector<unsigned long long> count(R, 0);
   std::vector<char> todo(R, 1);
   for (size_t s = 0; s < R; ++s) todo[s] = S->child[s]->n != 0;
+  // Shards that live on the root device append STRAIGHT into the root block through its one counter (the scan kernels
+  // append with one atomic per wave and flush: eight kernels on a counter cost what one does): no block of their own, no
+  // count read-back and stream synchronisation per shard, no copy into place -- per threshold a handle over 8 shards of one
+  // device spent ~140 us between its scans and its cut on exactly those (tools/ab/sharded_trace.py).  Not under the
+  // collective exchange, whose send buffers are the devices' own blocks.
+  const bool collective_mode = g_exchange == 0 && (C.devices.size() > 1 || g_force_rccl);
+  std::vector<char> direct(R, 0);
+  bool any_direct = false;
+  for (size_t s = 0; s < R; ++s) {
+    direct[s] = !collective_mode && todo[s] && S->child[s]->device == root;
+    any_direct = any_direct || direct[s];
+  }
+  unsigned long long direct_count = 0;
   float scan_ms = 0.f;
-  unsigned long long running = 0;
   // kernel timing for cbh_idx64_get_stats only where it can matter: a handful of needles is launch-bound, and every
   // HIP call counts there (a lone find() on 8 shards: ~12 calls per shard from this one thread)
   const bool timed = nq >= 256;
   // prefilter or three-field kernel: one probe for the whole call, on the slots of a shard that lives where the needles
-  // are (every shard probing for itself cost a stream synchronisation per shard and threshold)
+  // are (every shard probing for itself cost a stream synchronisation per shard and threshold); and ONE expansion of the
+  // needles into the matrix-core operand layout for all the shards of the root device (48 bytes per needle: eight of them
+  // per threshold were 3.9 ms of kernel time beside the scans)
   for (size_t s = 0; s < R; ++s) {
     cbh_idx64* c = S->child[s];
     if (c->device == root && c->n != 0 && scan_mfma_wanted(c->n, nq, thresh)) {
       DeviceGuard g(root);
       flags |= scan_pre_flags(c->d_hashes, c->n, idx->n, d_q, nq, thresh, stream);
+      if ((rc = expand_needles_for_scan(d_q, nq, stream, &qx_root))) return rc;
       break;
     }
   }
-  for (int attempt = 0; attempt < 3; ++attempt) {
-    bool any = false;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    bool any = false, any_direct_now = false;
+    for (size_t s = 0; s < R; ++s) any_direct_now = any_direct_now || (todo[s] && direct[s]);
+    {
+      DeviceGuard g(root);
+      if (any_direct_now) CBH_HIP(hipMemsetAsync(ws->d_total, 0, sizeof(unsigned long long), stream));
+      // the needles (and masks, the expansion, the zeroed counter) are complete on the root device
+      if (attempt == 0 || any_direct_now) CBH_HIP(hipEventRecord(ws->ev0, stream));
+    }
     for (size_t s = 0; s < R; ++s) {
       if (!todo[s]) continue;
       any = true;
@@ -373,8 +409,8 @@ int sharded_scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t 
       DeviceGuard g(c->device);
       if (!g.ok) return CBH_E_NODEVICE;
       hipStream_t cs = cw->stream;
+      if (attempt == 0 || direct[s]) CBH_HIP(hipStreamWaitEvent(cs, ws->ev0, 0));
       if (attempt == 0) {
-        CBH_HIP(hipStreamWaitEvent(cs, ws->ev0, 0));
         if (c->device != root) {  // replicate the needles: one peer copy per shard and call (8 B per needle)
           if ((rc = Workspace::grow(&cw->d_q, &cw->q_cap, nq))) return rc;
           CBH_HIP(hipMemcpyPeerAsync(cw->d_q, c->device, d_q, root, nq * sizeof(uint64_t), cs));
@@ -386,21 +422,38 @@ int sharded_scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t 
           }
           C.n_peer_copies++;
         }
-        if ((rc = cw->ensure_records(std::max<size_t>(c->rec_cap_default, 1024)))) return rc;
+        if (!direct[s] && (rc = cw->ensure_records(std::max<size_t>(c->rec_cap_default, 1024)))) return rc;
       }
-      CBH_HIP(hipMemsetAsync(cw->d_total, 0, sizeof(unsigned long long), cs));
+      if (!direct[s]) CBH_HIP(hipMemsetAsync(cw->d_total, 0, sizeof(unsigned long long), cs));
       if (timed) CBH_HIP(hipEventRecord(cw->ev0, cs));
-      rc = launch_hamm64_scan(c->d_hashes, c->d_ids, c->n, q_of[s], nq, thresh, cw->d_rec, cw->rec_cap, cw->d_total, cs,
-                              flags, mask_of[s]);
+      rc = launch_hamm64_scan(c->d_hashes, c->d_ids, c->n, q_of[s], nq, thresh, direct[s] ? ws->d_rec : cw->d_rec,
+                              direct[s] ? ws->rec_cap : cw->rec_cap, direct[s] ? ws->d_total : cw->d_total, cs,
+                              flags | ((unsigned)std::min(C.per_device, 255) << SCAN_SIBLINGS_SHIFT), mask_of[s],
+                              c->device == root ? qx_root : nullptr);
       if (rc) return rc;
-      if (timed) CBH_HIP(hipEventRecord(cw->ev1, cs));
-      CBH_HIP(hipMemcpyAsync(cw->h_total, cw->d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
+      if (timed || direct[s]) CBH_HIP(hipEventRecord(cw->ev1, cs));
+      if (!direct[s])
+        CBH_HIP(hipMemcpyAsync(cw->h_total, cw->d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
       C.n_scans++;
       if (attempt) C.n_rescans++;
     }
     if (!any) break;
     float worst = 0.f;
-    // (running: counts of the shards that are done, across attempts)
+    if (any_direct_now) {  // one wait for all of them, on the root stream
+      DeviceGuard g(root);
+      for (size_t s = 0; s < R; ++s)
+        if (todo[s] && direct[s]) CBH_HIP(hipStreamWaitEvent(stream, L.ws[s]->ev1, 0));
+      CBH_HIP(hipMemcpyAsync(ws->h_total, ws->d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+      CBH_HIP(hipStreamSynchronize(stream));
+      direct_count = *ws->h_total;
+      for (size_t s = 0; s < R; ++s) {
+        if (!todo[s] || !direct[s]) continue;
+        float ms = 0.f;
+        if (timed && hipEventElapsedTime(&ms, L.ws[s]->ev0, L.ws[s]->ev1) == hipSuccess) worst = std::max(worst, ms);
+        todo[s] = 0;
+        L.idle[s] = 1;  // (its stream's last operation is the event the root stream waited for, and that stream is drained)
+      }
+    }
     for (size_t s = 0; s < R; ++s) {
       if (!todo[s]) continue;
       cbh_idx64* c = S->child[s];
@@ -411,19 +464,38 @@ int sharded_scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t 
       float ms = 0.f;
       if (timed && hipEventElapsedTime(&ms, cw->ev0, cw->ev1) == hipSuccess) worst = std::max(worst, ms);
       todo[s] = 0;
-      running += count[s];
-      if (running > max_records && running > ws->rec_cap) {  // the merged result cannot fit: nobody grows for it
-        *total = running;
-        return CBH_E_OVERFLOW;
-      }
       if (count[s] > cw->rec_cap) {  // this shard alone grows its block and scans again
-        running -= count[s];         // (it reports again after the rescan)
+        unsigned long long others = direct_count;
+        for (size_t o = 0; o < R; ++o)
+          if (o != s) others += count[o];
+        if (others + count[s] > max_records && others + count[s] > ws->rec_cap) {  // the merged result cannot fit anyway
+          *total = others + count[s];
+          return CBH_E_OVERFLOW;
+        }
         rc = cw->ensure_records((size_t)count[s] + 1024);
         if (rc) return rc == CBH_E_NOMEM ? CBH_E_OVERFLOW : rc;
         todo[s] = 1;
       }
     }
     scan_ms += worst;  // the shards run side by side: a round costs what its slowest shard costs
+    bool pending = false;
+    for (size_t s = 0; s < R; ++s) pending = pending || todo[s];
+    if (pending) continue;
+    // every shard has reported: does the root block hold the whole result?
+    unsigned long long sum = direct_count;
+    for (size_t s = 0; s < R; ++s) sum += count[s];
+    if (sum <= ws->rec_cap) break;
+    *total = sum;
+    if (sum > max_records) return CBH_E_OVERFLOW;  // nobody grows for it
+    {
+      DeviceGuard g(root);
+      CBH_HIP(hipStreamSynchronize(stream));
+      rc = ws->ensure_records((size_t)sum + 1024);  // (a new block: what the root device's shards appended is gone)
+      if (rc) return rc == CBH_E_NOMEM ? CBH_E_OVERFLOW : rc;
+    }
+    if (!any_direct) break;
+    for (size_t s = 0; s < R; ++s) todo[s] = direct[s];
+    direct_count = 0;
   }
   for (size_t s = 0; s < R; ++s)
     if (todo[s]) return CBH_E_OVERFLOW;
@@ -433,16 +505,17 @@ int sharded_scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t 
     idx->stats.scan_pairs += (uint64_t)idx->n * (uint64_t)nq;
     idx->stats.scan_ms += (double)scan_ms;
   }
-  unsigned long long sum = 0;
-  for (size_t s = 0; s < R; ++s) sum += count[s];
+  unsigned long long sum = direct_count, remote = 0;
+  for (size_t s = 0; s < R; ++s) remote += count[s];
+  sum += remote;
   *total = sum;
-  if (sum > max_records && sum > ws->rec_cap) return CBH_E_OVERFLOW;
-  if (sum > ws->rec_cap) {
-    CBH_HIP(hipStreamSynchronize(stream));
-    rc = ws->ensure_records((size_t)sum + 1024);
-    if (rc) return rc == CBH_E_NOMEM ? CBH_E_OVERFLOW : rc;
+  if (sum > ws->rec_cap) return CBH_E_OVERFLOW;
+  if (!remote && any_direct) {
+    // all of it is in place, the counter holds the sum, and the root stream was drained when the count was read
+    for (size_t s = 0; s < R; ++s) L.idle[s] = 1;
+    return CBH_OK;
   }
-  // ---- exchange: all records into the root block, shard after shard ----
+  // ---- exchange: the other shards' records into the root block, behind what the root device's appended ----
   std::vector<ShardPart> parts(R);
   for (size_t s = 0; s < R; ++s) {
     Workspace* cw = L.ws[s];
@@ -457,7 +530,8 @@ int sharded_scan_all(cbh_idx64* idx, Workspace* ws, const uint64_t* d_q, size_t 
     parts[s].h_word = cw->h_total;
   }
   bool by_collective = true;
-  if ((rc = C.exchange(parts, stream, reinterpret_cast<unsigned long long*>(ws->d_rec), &by_collective))) return rc;
+  if ((rc = C.exchange(parts, stream, reinterpret_cast<unsigned long long*>(ws->d_rec), &by_collective, direct_count)))
+    return rc;
   {
     DeviceGuard g(root);
     *ws->h_total = sum;
