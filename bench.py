@@ -465,14 +465,16 @@ def sharded_leg(args, world, local_rank, share):
     directly, merge and cut on the first device) -- cbird registers each index once and fans find() out from its own
     threads (src/engine.cpp:38-45, src/database.cpp:1400-1432).  Runs tools/sharded_leg.py as a child process of rank
     0 with its own timeout after the timed region (the other ranks idle at the final barrier): with N > 1 over the N
-    GPUs of the job, with N = 1 over 8 logical shards on the one GPU with their block sent through ncclAllGather.  The
-    same all-pairs dht sweep, needles and results resident; never part of `value`."""
+    GPUs of the job, with N = 1 over 8 logical shards on the one GPU -- once with the library's default exchange (copies:
+    "sharded", what `speedup_vs_one_device` is quoted on) and once with their block sent through ncclAllGather
+    ("sharded_rccl": the transport, on a box that has one GPU).  The same all-pairs dht sweep, needles and results
+    resident; never part of `value`."""
     import subprocess
 
     if world > 1 and not share:
         cmd = ["--mask", hex((1 << world) - 1), "--per-device", "1", "--exchange", "both"]
     else:
-        cmd = ["--mask", hex(1 << local_rank), "--per-device", "8", "--force-rccl"]
+        cmd = ["--mask", hex(1 << local_rank), "--per-device", "8", "--force-rccl", "--exchange", "both"]
     cmd = [sys.executable, os.path.join(ROOT, "tools", "sharded_leg.py"), "--images", str(args.images), "--dht", args.dht,
            "--topk", str(args.topk)] + cmd
     env = dict(os.environ)

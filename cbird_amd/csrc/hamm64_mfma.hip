@@ -410,13 +410,18 @@ __global__ __launch_bounds__(kThreads, PRE ? 4 : 1) void k_hamm64_mfma(
           // behind the wave's queue: inside the workgroup's LDS, and discarded by the mask / lane < 32); `ok` = the registers
           // whose parking slot was written.  Appends {pattern, register | tile | hit lane | step} for every flagged one.
           auto list = [&](uint32_t at, uint32_t L, uint32_t ok) {
-            const uint32_t v = s_queue[at + lane];
-            const bool pred = (v & kFlagMaskPre) != 0 && ((ok >> (lane & 31u)) & 1u) != 0u;
+            // (the lane id through an opaque copy: the compiler otherwise hoists this path's lane-derived values -- the
+            // parking area's address, 1 << lane -- out of the chunk loop, runs out of its 128 registers and SPILLS them:
+            // two scratch loads + a wait in front of every list(), i.e. in every other group at threshold 6)
+            uint32_t ln = lane;
+            asm volatile("" : "+v"(ln));
+            const uint32_t v = s_queue[at + ln];
+            const bool pred = (v & kFlagMaskPre) != 0 && ((ok >> (ln & 31u)) & 1u) != 0u;
             const uint32_t bm = (uint32_t)(__builtin_amdgcn_ballot_w64(pred) & 0xffffffffull);
-            if (pred && lane < (uint32_t)R) {
+            if (pred && ln < (uint32_t)R) {
               // lane = 16 t + g: bits 0-3 the register, bits 4-6 (t0 + t) the wave's tile; bits 7-12 the hit lane
               *reinterpret_cast<uint2*>(&s_queue[2u * (npend + __builtin_amdgcn_mbcnt_lo(bm, 0u))]) =
-                  make_uint2(v, lane | (w1c | (L << 7)));
+                  make_uint2(v, ln | (w1c | (L << 7)));
             }
             npend += (uint32_t)__popc(bm);
           };

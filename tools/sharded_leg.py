@@ -101,6 +101,8 @@ def main():
     res.update(legs)
     res["matches_equal"] = all(l["matches"] == legs["one_device"]["matches"] for l in legs.values())
     res["speedup_vs_one_device"] = legs["one_device"]["sweep_ms"] / legs["sharded"]["sweep_ms"]
+    if "sharded_rccl" in legs:
+        res["speedup_vs_one_device_rccl"] = legs["one_device"]["sweep_ms"] / legs["sharded_rccl"]["sweep_ms"]
     print(json.dumps(res))
     if not res["matches_equal"]:
         raise SystemExit(1)
