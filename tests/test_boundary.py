@@ -88,3 +88,21 @@ def test_raw_buffer_loads_past_the_descriptor_range_by_the_scalar_offset_return_
     ok = C.c_int(0)
     _lib.check(_lib.lib().cbh_selftest_buffer_range(0, C.byref(ok)), "selftest")
     assert ok.value == 1
+
+
+def test_scan_kernels_neither_spill_nor_use_scratch():
+    """The compiler's own resource remarks for the scan kernels (tools/kernel_resources.py; cross-compiles, no GPU): the
+    prefilter kernel sits at its 128-register budget for four waves per SIMD and once carried two lane constants in scratch
+    memory, reloaded in front of every candidate list -- a change that pushes it over shows up here, not as a slower bench."""
+    import shutil
+    import subprocess
+    import sys
+
+    if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_resources.py"), "hamm64_mfma.hip", "hamm64_scan.hip",
+                        "hamm256_mfma.hip"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    lines = [l for l in r.stdout.splitlines() if "k_hamm64_mfma<true>" in l]
+    assert len(lines) == 1 and "waves/SIMD 4" in lines[0], r.stdout[-2000:]
