@@ -526,6 +526,9 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
   };
   typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
   v4u_t stg[2][4];
+  // (one code path: with a uniform branch around a faster form for the steps that touch neither the parent's top nor its
+  // bottom -- one offset and three additions instead of four reflections -- the compiler waits for ALL loads where the
+  // branches join: -4 .. -15 %)
   auto load_step = [&](int t, v4u_t (&a)[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) a[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voffA, (int)row_off(4 * t + r), 0);
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
     YRow yrs[4] = {};
     if constexpr (!INT) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) yrs[r] = yrow[min(max(y0 + r, 0), h - 1)];
+      for (int r = 0; r < 4; ++r) yrs[r] = yrow[y0 + r];  // (the table is padded: -8 <= y0, y0 + 3 <= h + 2)
     }
     // ---- blur: rows 4t .. 4t+3 of the ring -> sT
     int slot = 4 * ts + rd_row;
@@ -721,37 +724,44 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
     // order: row group 0's lanes first, then the running sum moves one lane up (DPP) to row group 1's, ... and from the last
     // group back to group 0 for the next step.
     const float hv[4] = {acc01.x, acc01.y, acc23.x, acc23.y};
-    auto vrow = [&](const YRow& yr, float v) {
-      const float t0 = yr.a0 * v;
-      vsum = (yr.info & 0x100) ? t0 : vsum + t0;
-      const int di = yr.info & 0xff;
-      if ((yr.info & 0x200) && di >= bc0 && di < bc1) {  // (a cell of another band: its rows are walked there)
+    // (Most rows neither close a cell nor feed a second one: for those a multiply, a fused multiply-add and ONE scalar
+    // test.  Written as `sum = opens ? t0 : sum + t0` with the store under `closes && cell in band && alive`, every row cost
+    // 2 selects' worth of scalar mask arithmetic plus the whole store predicate built in SGPR pairs -- ~17 scalar
+    // instructions a row, 237 a step beside 306 vector ones, in a kernel whose waves are too few to hide their own
+    // instruction streams.  The empty asm keeps the rare part behind a scalar branch: merged into one predicate it is
+    // evaluated on every row again.)
+    auto put = [&](int di) {
+      if (di >= bc0 && di < bc1) {  // (a cell of another band: its rows are walked there)
         const float rr = __builtin_rintf(vsum);
         if (alive) tdst[di * 32] = (unsigned char)(rr < 0.f ? 0.f : rr > 255.f ? 255.f : rr);
       }
-      if (yr.info & 0x400) {
-        const float t1 = yr.a1 * v;
-        vsum = (yr.info & 0x800) ? t1 : vsum + t1;
-        if ((yr.info & 0x1000) && di + 1 >= bc0 && di + 1 < bc1) {
-          const float rr = __builtin_rintf(vsum);
-          if (alive) tdst[(di + 1) * 32] = (unsigned char)(rr < 0.f ? 0.f : rr > 255.f ? 255.f : rr);
+    };
+    auto vrow = [&](const YRow& yr, float v) {
+      vsum = __builtin_fmaf(vsum, yr.k0, yr.a0 * v);
+      if (yr.info & 0x600) {  // (uniform)
+        asm volatile("");
+        const int di = yr.info & 0xff;
+        if (yr.info & 0x200) put(di);
+        if (yr.info & 0x400) {
+          const float t1 = yr.a1 * v;
+          vsum = (yr.info & 0x800) ? t1 : vsum + t1;
+          if (yr.info & 0x1000) put(di + 1);
         }
       }
     };
+    const int nrow = min(4, rb - y0 + 1);  // rows of the step that belong to the band (4 but for its last step)
 #pragma unroll
-    for (int ph = 0; ph < G; ++ph) {
-      if (G == 1 || rg == ph) {
+    for (int ph_ = 0; ph_ < G; ++ph_) {
+      if (G == 1 || rg == ph_) {
 #pragma unroll
-        for (int r = 0; r < RS; ++r) {
-          const int y = y0 + ph * RS + r;
-          if (y <= rb) vrow(yrs[ph * RS + r], hv[r]);  // (uniform)
-        }
+        for (int r = 0; r < RS; ++r)
+          if (ph_ * RS + r < nrow) vrow(yrs[ph_ * RS + r], hv[r]);  // (uniform)
       }
       if constexpr (G > 1) {
         // lane j takes the sum of lane j - 1 of its cell's G lanes (wrapping): quad_perm [3,0,1,2] / [1,0,3,2]
         const float up = __builtin_bit_cast(
             float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, vsum), G == 4 ? 0x93 : 0xB1, 0xf, 0xf, true));
-        if (rg == (ph + 1) % G) vsum = up;
+        if (rg == (ph_ + 1) % G) vsum = up;
       }
     }
   };
@@ -1536,8 +1546,12 @@ struct AreaTabsDev {
   AreaTab *x = nullptr, *y = nullptr;
   int *xfirst = nullptr, *yfirst = nullptr;
   int xn = 0, yn = 0;
-  YRow* yrow = nullptr;  // h entries, nullptr when some source row has more than two entries (never for h >= 32)
+  YRow* yrow = nullptr;  // h entries, nullptr when some source row has more than two entries (never for h >= 32);
+                         // kYRowPad neutral entries before and behind them (k_band_area reads the four rows of a step
+                         // without clamping their indices)
+  YRow* yrow_base = nullptr;
 };
+constexpr int kYRowPad = 8;
 std::mutex g_area_mu;
 std::map<std::tuple<int, int, int>, AreaTabsDev> g_area;  // (device, w, h)
 
@@ -1563,7 +1577,8 @@ int get_area_tabs(int w, int h, AreaTabsDev* out) {
     if (e == hipSuccess) e = hipMemcpy(d.xfirst, xf.data(), 33 * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d.yfirst, yf.data(), 33 * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-      std::vector<YRow> yr((size_t)h, YRow{0.f, 0.f, 0, 0});
+      std::vector<YRow> yr_all((size_t)h + 2 * kYRowPad, YRow{0.f, 0.f, 0, 1.f});
+      YRow* const yr = yr_all.data() + kYRowPad;
       std::vector<int> cnt((size_t)h, 0);
       bool ok = true;
       for (size_t j = 0; j < yt.size() && ok; ++j) {
@@ -1577,6 +1592,7 @@ int get_area_tabs(int w, int h, AreaTabsDev* out) {
         if (cnt[(size_t)en.si] == 0) {
           r.a0 = en.alpha;
           r.info = en.di | (opens ? 0x100 : 0) | (closes ? 0x200 : 0);
+          r.k0 = opens ? 0.f : 1.f;
         } else if (cnt[(size_t)en.si] == 1 && en.di == (r.info & 0xff) + 1) {
           r.a1 = en.alpha;
           r.info |= 0x400 | (opens ? 0x800 : 0) | (closes ? 0x1000 : 0);
@@ -1587,12 +1603,13 @@ int get_area_tabs(int w, int h, AreaTabsDev* out) {
       }
       for (int y = 0; y < h && ok; ++y) ok = cnt[(size_t)y] >= 1;
       if (ok) {
-        e = hipMalloc(&d.yrow, (size_t)h * sizeof(YRow));
-        if (e == hipSuccess) e = hipMemcpy(d.yrow, yr.data(), (size_t)h * sizeof(YRow), hipMemcpyHostToDevice);
+        e = hipMalloc(&d.yrow_base, yr_all.size() * sizeof(YRow));
+        if (e == hipSuccess) e = hipMemcpy(d.yrow_base, yr_all.data(), yr_all.size() * sizeof(YRow), hipMemcpyHostToDevice);
+        if (e == hipSuccess) d.yrow = d.yrow_base + kYRowPad;
       }
     }
     if (e != hipSuccess) {
-      for (void* q : {(void*)d.x, (void*)d.y, (void*)d.xfirst, (void*)d.yfirst, (void*)d.yrow})
+      for (void* q : {(void*)d.x, (void*)d.y, (void*)d.xfirst, (void*)d.yfirst, (void*)d.yrow_base})
         if (q) (void)hipFree(q);
       CBH_HIP(e);
     }

@@ -31,9 +31,12 @@ struct AreaTab {
 // the y table of make_area_tab seen from a SOURCE row (k_blur_area_regs<.., FUSE>): a row contributes to one or two
 // consecutive output rows (scale >= 1).  info: bits 0..7 di of the first entry, bit 8 = that entry opens its cell,
 // bit 9 = it closes it, bit 10 = a second entry exists (cell di + 1), bit 11 / 12 = opens / closes for that one
+// k0 = 0.f when the first entry opens its cell, 1.f when it continues one: sum = fma(sum, k0, a0 * v) is `t0` or `sum + t0`
+// (one rounding either way) without a select (k_band_area)
 struct YRow {
   float a0, a1;
-  int info, pad;
+  int info;
+  float k0;
 };
 
 namespace {
