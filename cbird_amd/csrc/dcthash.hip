@@ -175,29 +175,37 @@ __global__ __launch_bounds__(kThreads) void k_dcthash_256(
 // (Round 2's k_dcthash_256_mfma -- both box passes as f16 MFMAs, operands converted on the VALU -- was removed in round 4:
 //  bit-identical but slower than k_dcthash_256 and k_dcthash_256_band; NOTES.md section 2 keeps its description.)
 // ---------------------------------------------------------------------------------------------
-// k_dcthash_256_band: 256x256 tiles with the horizontal half of the 7x7 box filter on the matrix cores and one
-// addition + half a fused multiply-add per pixel left for the VALU (k_dcthash_256 spends 5.9 VALU instructions per
-// pixel and is bound by their issue).
+// k_dcthash_256_band: 256x256 tiles with the 7x7 box filter on the matrix cores -- its horizontal half as the product
+// with a band matrix, its vertical half as the accumulation of that product over the rows -- and half a fused
+// multiply-add per pixel left for the VALU (k_dcthash_256 spends 5.9 VALU instructions per pixel and is bound by their
+// issue).
 //
-// One wave = four images, walked top to bottom in lockstep, four rows per step.  v_mfma_i32_16x16x64_i8 computes
-// D[m][n] = sum_k A[m][k] * B[k][n] with M = 16 = 4 images x 4 consecutive rows, N = 16 output columns (a column tile)
-// and K = 64 = 32 source columns of the row itself (weights +1 on the 7 taps of column n) followed by the same 32
-// columns of the row SEVEN ABOVE it (weights -1): D is the horizontal 7-tap sum of row u minus that of row u - 7, which
-// is exactly what a 7-row sliding vertical sum needs -- S(u) = S(u - 1) + D(u), one v_add per pixel, no ring of rows in
-// registers.  The pixels enter as p - 128 (one v_xor per four pixels when a row is staged; the bias cancels in the
-// difference, the seven warm-up rows leave a constant -6272 that the initial S holds).  REFLECT_101 at the left / right
-// border is folded into the band matrices of the first / last column tile, at the top / bottom into the row addresses.
-// In the accumulator layout a lane owns one column of each of the 16 column tiles of one image and receives its rows
-// four at a time, so S, the division and the 8-row part of the 8x8 cell sum stay inside the lane:
-//   division   S lives as the integer 0x4B000000 + S, i.e. the float 2^23 + S.  With c = 42799 * 2^-21 the product
-//              (2^23 + S) * c = 171196 + S * c is exact inside an fma, and added to an integer-valued accumulator below
-//              2^24 the one rounding is to the nearest integer = nearest(S / 49) (S * c stays 0.0100 away from a tie for
-//              every S <= 12495; tests/test_golden_hash_stages.py).  v_pk_fma_f32 does two rows per instruction.
-//   cell       four fmas per accumulator component per cell, bit patterns added as integers, then three DPP steps over
-//              the 8 lanes of a cell (two column tiles packed in one register), /64 half-to-even, one byte to the tile.
-// Rows travel global -> registers (coalesced 16-byte loads, two steps ahead) -> LDS ring of 12 rows per image (272-byte
-// pitch: 8 pad bytes each side, so that the K block of column tile c starts 16-byte aligned at byte 16c) -> one
-// ds_read_b128 per column tile and step in the A-operand layout.  A wave is its own workgroup: no barriers in the loop.
+// One wave = four images, walked top to bottom in lockstep.  v_mfma_i32_16x16x64_i8 computes D = A B + C with M = 16 =
+// 4 images x 4 column STRIPS of 64 columns (one image row at a time), N = 16 output columns (tile c of every strip) and
+// K = 64 = 32 source columns of the row itself (weights +1 on the 7 taps of column n) followed by the same 32 columns of
+// the row SEVEN ABOVE it (weights -1): A B is the horizontal 7-tap sum of row u minus that of row u - 7, which is exactly
+// what a 7-row sliding vertical sum needs -- S(u) = S(u - 1) + A B -- and with C = the accumulator of the previous row
+// the matrix core adds it up itself: the same register meets the same column again on the next row.  (Through round 6's
+// first half the M rows were 4 images x 4 consecutive ROWS: a register held the delta of one row and S cost one v_add per
+// pixel, 128 of the loop's 339 vector instructions per eight rows in a kernel bound by its waves' instruction streams --
+// NOTES 13.5e; 5.45 -> 5.8 TB/s.)  The pixels enter as p - 128 (one v_xor per four pixels when a row is staged; the bias
+// cancels in the difference, the seven warm-up rows leave a constant -6272 that the initial S holds).
+//   borders    a strip's first / last tile is an image edge only in strips 0 / 3, but B is shared by the sixteen M rows:
+//              REFLECT_101's three columns are WRITTEN into the ring's halo bytes when a row is staged (one v_perm + one
+//              ds_write_b32 per row and edge lane) and every tile takes the interior band matrix; top / bottom: the row
+//              addresses.
+//   division   S lives as the integer 0x4B000000 + S, i.e. the float 2^23 + S (i32 accumulation in the matrix core is
+//              exact).  With c = 42799 * 2^-21 the product (2^23 + S) * c = 171196 + S * c is exact inside an fma, and
+//              added to an integer-valued accumulator below 2^24 the one rounding is to the nearest integer = nearest(S / 49)
+//              (S * c stays 0.0100 away from a tie for every S <= 12495; tests/test_golden_hash_stages.py).  v_pk_fma_f32
+//              does two strips per instruction.
+//   cell       a lane's accumulator component holds ONE column over the eight rows of a cell; two strips share a register
+//              as 16-bit halves through three DPP steps over the cell's eight lanes, /64 half-to-even, one byte to the tile.
+// Rows travel global -> registers (coalesced 16-byte loads, two steps of four rows ahead) -> LDS ring of 12 rows per
+// image (272-byte pitch: 8 halo bytes each side, so that the K block of a tile starts 16-byte aligned; 3296 bytes between
+// the images' planes, which puts the four images x four strips of a lane group's ds_read_b128 on sixteen different
+// 16-byte slots of the 64 banks) -> one ds_read_b128 per tile and row in the A-operand layout.  A wave is its own
+// workgroup: no barriers in the loop; 17 KB of LDS per wave, 9 waves per CU.
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
@@ -208,7 +216,7 @@ typedef unsigned int v2u_lds __attribute__((ext_vector_type(2), may_alias));
 typedef unsigned int v4u_lds __attribute__((ext_vector_type(4), may_alias));
 
 struct BandTables {
-  unsigned int w[3][64][4];  // B operands (i8 x 16 per lane): 0 interior column tile, 1 tile 0 (left edge), 2 tile 15
+  unsigned int w[1][64][4];  // the B operand (i8 x 16 per lane) of an interior column tile: the only one (see "borders")
 };
 
 constexpr int kBandPitch = 272;  // 8 + 256 + 8
@@ -220,22 +228,14 @@ __device__ __forceinline__ void wave_order_lds() {
   asm volatile("" ::: "memory");
 }
 
-// A wave owns its four images alone: no barrier anywhere in the loop, 17 KB of LDS per wave, 9 waves per CU.  (Two waves
-// sharing four images -- each half of the column tiles, the ring held once per two waves, 14 waves per CU, one workgroup
-// barrier per step -- measured 5 % slower: r05's "hash_band_waves" 2.)
 template <bool DUMP>
 __global__ __launch_bounds__(64) void k_dcthash_256_band(
     const unsigned char* __restrict__ imgs, unsigned n, unsigned row_stride, unsigned img_stride,
     const DctTables* __restrict__ tabs, const BandTables* __restrict__ bt, uint64_t* __restrict__ out,
     unsigned char* __restrict__ tiles) {
-  constexpr int kSlots = 3;                      // steps of rows one image keeps in LDS
-  constexpr int kRing = 4 * kSlots;              // ... = rows
-  constexpr int kImg = kRing * kBandPitch;       // bytes per image
-  constexpr int TPW = 16;                        // column tiles
-  constexpr int RPW = 4;                         // rows of a step
-  __shared__ __attribute__((aligned(16))) unsigned char sRing[4 * kImg];  // 13 056 B; the tail reuses it
-  // (12 instead of 9 waves per CU -- timed by shrinking this array, hashes wrong -- would buy 4 %: 4.73 vs ~4.9 ms per 400k
-  //  images; not worth keeping the tile in registers for)
+  constexpr int kSlots = 3, kRing = 4 * kSlots;
+  constexpr int kImg = kRing * kBandPitch + 32;  // bytes per image plane (see above)
+  __shared__ __attribute__((aligned(16))) unsigned char sRing[4 * kImg];  // 13 184 B; the tail reuses it
   __shared__ __attribute__((aligned(16))) unsigned char sTile[4][1024];
   const int lane = threadIdx.x & 63;
   const int n16 = lane & 15, q = lane >> 4;
@@ -246,13 +246,16 @@ __global__ __launch_bounds__(64) void k_dcthash_256_band(
   const unsigned char* __restrict__ base = imgs + (size_t)first * img_stride;  // workgroup-uniform
   const unsigned voff = (mine - first) * img_stride + (unsigned)n16 * 16u;
   const int wr_base = q * kImg + 8 + 16 * n16;
-  // A-operand role: M row n16 = image n16 >> 2, row n16 & 3 of the step; chunk q: 0, 1 the row, 2, 3 the row 7 above
-  const int rd_base = (n16 >> 2) * kImg + (q & 1) * 16;
-  const int rd_row = (n16 & 3) + (q >= 2 ? kRing - 7 : 0);
-  // accumulator role: image q, column n16 of each of the column tiles, rows in the four result registers
+  // ... and the halo: chunk 0 mirrors columns 1..3 into columns -1..-3 (ring bytes 5..7 of the row), chunk 15 columns
+  // 252..254 into 258..256 (bytes 264..266); the fourth byte of either dword is a column the band gives no weight
+  const bool edge = n16 == 0 || n16 == 15;
+  const unsigned edge_sel = n16 == 0 ? 0x01020300u : 0x00000102u;
+  const int edge_base = q * kImg + (n16 == 0 ? 4 : 264);
+  // A-operand role: M row n16 = image n16 >> 2, strip n16 & 3; K chunk q: 0, 1 the row, 2, 3 the row seven above it
+  const int rd_base = (n16 >> 2) * kImg + (n16 & 3) * 64 + (q & 1) * 16;
+  const int rd_off = q >= 2 ? kRing - 7 : 0;   // ring rows ahead of the step's first
+  const int rd_wrap = q >= 2 ? kRing * kBandPitch : 0;
   const v4i_t b0 = *reinterpret_cast<const v4i_t*>(bt->w[0][lane]);
-  const v4i_t bL = *reinterpret_cast<const v4i_t*>(bt->w[1][lane]);  // the first tile (left edge)
-  const v4i_t bR = *reinterpret_cast<const v4i_t*>(bt->w[2][lane]);  // ... and the last
 
   for (int i = threadIdx.x; i < 4 * kImg / 16; i += 64)
     reinterpret_cast<v4u_lds*>(sRing)[i] = v4u_lds{0u, 0u, 0u, 0u};  // rows above the image: p - 128 = 0 contributes nothing
@@ -264,72 +267,92 @@ __global__ __launch_bounds__(64) void k_dcthash_256_band(
     v = v > 255 ? 510 - v : v;
     return (unsigned)v * row_stride + voff;
   };
-  uint4 stg[2][RPW];
-  auto load_step = [&](int t, uint4 (&dst)[RPW]) {
+  uint4 stg[2][4];
+  auto load_step = [&](int t, uint4 (&dst)[4]) {
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) dst[r] = *reinterpret_cast<const uint4*>(base + src_off(4 * t + r));
+    for (int r = 0; r < 4; ++r) dst[r] = *reinterpret_cast<const uint4*>(base + src_off(4 * t + r));
   };
-  auto store_step = [&](int ts, const uint4 (&src)[RPW]) {  // ts = t % kSlots: the step's rows take slots 4 * ts .. + 3
+  auto store_step = [&](int ts, const uint4 (&src)[4]) {  // ts = t % kSlots: the step's rows take slots 4 * ts .. + 3
+    unsigned ev[4];
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) {
+    for (int r = 0; r < 4; ++r) {
+      const unsigned x = src[r].x ^ 0x80808080u, y = src[r].y ^ 0x80808080u, z = src[r].z ^ 0x80808080u,
+                     w = src[r].w ^ 0x80808080u;
       v2u_lds* p = reinterpret_cast<v2u_lds*>(sRing + wr_base + (4 * ts + r) * kBandPitch);  // 8-byte aligned
-      p[0] = v2u_lds{src[r].x ^ 0x80808080u, src[r].y ^ 0x80808080u};
-      p[1] = v2u_lds{src[r].z ^ 0x80808080u, src[r].w ^ 0x80808080u};
+      p[0] = v2u_lds{x, y};
+      p[1] = v2u_lds{z, w};
+      const unsigned e = n16 == 0 ? x : w;
+      ev[r] = __builtin_amdgcn_perm(e, e, edge_sel);
+    }
+    if (edge) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<unsigned __attribute__((may_alias))*>(sRing + edge_base + (4 * ts + r) * kBandPitch) = ev[r];
     }
   };
 
-  unsigned S[TPW];
-  v2f_t f[TPW];
+  // S[c][s]: 0x4B000000 + the 7 x 7 box sum at (image q, strip s, tile c, column n16) of the newest row
+  v4i_t S[4];
+  v2f_t f01[4], f23[4];
 #pragma unroll
-  for (int c = 0; c < TPW; ++c) {
-    S[c] = 0x4B000000u + 6272u;
-    f[c] = v2f_t{8388608.0f, 8388608.0f};
+  for (int c = 0; c < 4; ++c) {
+    S[c] = v4i_t{(int)(0x4B000000u + 6272u), (int)(0x4B000000u + 6272u), (int)(0x4B000000u + 6272u),
+                 (int)(0x4B000000u + 6272u)};
+    f01[c] = f23[c] = v2f_t{8388608.0f, 8388608.0f};
   }
   v2f_t kC = {42799.0f / 2097152.0f, 42799.0f / 2097152.0f};
   asm volatile("" : "+v"(kC));  // VGPR operands (a literal would double the size of every fma)
   const v2f_t kInit = {8388608.0f, 8388608.0f};
-  const v4i_t zero4 = {0, 0, 0, 0};
-  const int st_lane = q * 1024 + (n16 >> 3) + 2 * (n16 & 1);  // tile byte of this lane within a cell row
+  // tile byte of this lane within a cell row: even lanes carry strips 0 / 2, odd lanes strips 1 / 3 (8 cells each)
+  const int st_lane = q * 1024 + (n16 >> 3) + 8 * (n16 & 1);
   const unsigned sel_shift = (unsigned)(n16 & 1) * 16u;
 
   // one step: rows 4t .. 4t+3 (already in the ring); FIRST = the step opens a cell row, else it closes it
   auto step = [&](auto first_tag, int t, int ts) {
     constexpr bool FIRST = decltype(first_tag)::value;
-    int slot = 4 * ts + rd_row;
-    slot = slot >= kRing ? slot - kRing : slot;
-    const unsigned char* arow = sRing + rd_base + slot * kBandPitch;
+    // ring row of the lane's K chunk for the step's first row; only the row seven above the LAST row of slot 1 wraps
+    int row0 = 4 * ts + rd_off;
+    row0 = row0 >= kRing ? row0 - kRing : row0;
+    const unsigned char* arow = sRing + rd_base + row0 * kBandPitch;
+    const unsigned char* arow3 = arow + 3 * kBandPitch - (ts == 1 ? rd_wrap : 0);
 #pragma unroll
-    for (int c = 0; c < TPW; ++c) {
-      const v4i_t a = *reinterpret_cast<const v4i_lds*>(arow + 16 * c);
-      const v4i_t d = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, c == 0 ? bL : c == TPW - 1 ? bR : b0, zero4, 0, 0, 0);
-      const unsigned x0 = S[c] + (unsigned)d[0], x1 = x0 + (unsigned)d[1], x2 = x1 + (unsigned)d[2],
-                     x3 = x2 + (unsigned)d[3];
-      S[c] = x3;
-      const v2f_t p01 = {__builtin_bit_cast(float, x0), __builtin_bit_cast(float, x1)};
-      const v2f_t p23 = {__builtin_bit_cast(float, x2), __builtin_bit_cast(float, x3)};
-      f[c] = __builtin_elementwise_fma(p01, kC, FIRST ? kInit : f[c]);
-      f[c] = __builtin_elementwise_fma(p23, kC, f[c]);
+    for (int r = 0; r < 4; ++r) {
+      const unsigned char* ar = r == 3 ? arow3 : arow + r * kBandPitch;
+      v4i_t a[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a[c] = *reinterpret_cast<const v4i_lds*>(ar + 16 * c);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) S[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[c], b0, S[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        // (by value: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whichever one is named)
+        const int s0 = S[c][0], s1 = S[c][1], s2 = S[c][2], s3 = S[c][3];
+        const v2f_t p01 = {__builtin_bit_cast(float, s0), __builtin_bit_cast(float, s1)};
+        const v2f_t p23 = {__builtin_bit_cast(float, s2), __builtin_bit_cast(float, s3)};
+        f01[c] = __builtin_elementwise_fma(p01, kC, (FIRST && r == 0) ? kInit : f01[c]);
+        f23[c] = __builtin_elementwise_fma(p23, kC, (FIRST && r == 0) ? kInit : f23[c]);
+      }
     }
-    // (k_band_area's grouping -- 4, 8 or all 16 tiles' operands read, then their MFMAs, then the VALU work -- measured here:
-    //  5.2-5.3 TB/s in every form, and 176 / 198 VGPRs at 8 / 16 cost the third wave per SIMD)
     if constexpr (!FIRST) {
       const int a_row = (t - 3) >> 1;  // cell row closed by this step (negative during the warm-up)
       if (a_row >= 0) {
         unsigned char* dst = &sTile[0][0] + st_lane + a_row * 32;
+        // every accumulator component: 2^23 + 8 x 171196 + the eight quotients of its column
+        constexpr unsigned kBias = 0x4B000000u + 8u * 171196u;
+        constexpr unsigned kBias2 = kBias + (kBias << 16);
 #pragma unroll
-        for (int c = 0; c < TPW; c += 2) {
-          // every accumulator component: 2^23 + 4 x 171196 + its four quotients
-          constexpr unsigned kBias2 = 2u * (0x4B000000u + 4u * 171196u);
-          // (by value: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whichever one is named)
-          const float fx0 = f[c].x, fy0 = f[c].y, fx1 = f[c + 1].x, fy1 = f[c + 1].y;
-          const unsigned v0 = __float_as_uint(fx0) + __float_as_uint(fy0) - kBias2;
-          const unsigned v1 = __float_as_uint(fx1) + __float_as_uint(fy1) - kBias2;
-          unsigned wv2 = v0 | (v1 << 16);  // <= 2040 each; <= 16320 after the 8 lanes
-          wv2 += (unsigned)__builtin_amdgcn_mov_dpp((int)wv2, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-          wv2 += (unsigned)__builtin_amdgcn_mov_dpp((int)wv2, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
-          wv2 += (unsigned)__builtin_amdgcn_mov_dpp((int)wv2, 0x141, 0xf, 0xf, true);  // row_half_mirror
-          const unsigned cell = (wv2 >> sel_shift) & 0xffffu;  // even lanes: tile c, odd lanes: tile c + 1
-          dst[2 * c] = (unsigned char)((cell + 31u + ((cell >> 6) & 1u)) >> 6);  // /64, half to even
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            // (by value: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whichever one is named)
+            const float fx = h ? f23[c].x : f01[c].x, fy = h ? f23[c].y : f01[c].y;
+            unsigned wv2 = __float_as_uint(fx) + (__float_as_uint(fy) << 16) - kBias2;  // <= 2040 each; <= 16320 after the 8 lanes
+            wv2 += (unsigned)__builtin_amdgcn_mov_dpp((int)wv2, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+            wv2 += (unsigned)__builtin_amdgcn_mov_dpp((int)wv2, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+            wv2 += (unsigned)__builtin_amdgcn_mov_dpp((int)wv2, 0x141, 0xf, 0xf, true);  // row_half_mirror
+            const unsigned cell = (wv2 >> sel_shift) & 0xffffu;  // even lanes: strip 2h, odd lanes: strip 2h + 1
+            dst[16 * h + 2 * c] = (unsigned char)((cell + 31u + ((cell >> 6) & 1u)) >> 6);  // /64, half to even
+          }
         }
       }
     }
@@ -345,9 +368,11 @@ __global__ __launch_bounds__(64) void k_dcthash_256_band(
   auto nxt = [](int v) { return v == kSlots - 1 ? 0 : v + 1; };
   for (int t = 0; t < 66; t += 2) {
     const int tsa = ts, tsb = nxt(tsa), tsc = nxt(tsb);
+    wave_order_lds();
     step(integral_constant<bool, true>{}, t, tsa);
     store_step(tsb, stg[1]);  // rows of step t + 1: their slots' last readers ran just now
     if (t + 3 < 66) load_step(t + 3, stg[1]);
+    wave_order_lds();
     step(integral_constant<bool, false>{}, t + 1, tsb);
     if (t + 2 < 66) {
       store_step(tsc, stg[0]);
@@ -356,7 +381,6 @@ __global__ __launch_bounds__(64) void k_dcthash_256_band(
     ts = tsc;
   }
   __syncthreads();
-#ifndef CBH_BAND_DEBUG
   if (DUMP) {
     for (int g = 0; g < 4; ++g)
       if (first + (unsigned)g < n)
@@ -364,7 +388,6 @@ __global__ __launch_bounds__(64) void k_dcthash_256_band(
           reinterpret_cast<unsigned*>(tiles + (size_t)(first + (unsigned)g) * 1024)[i] =
               reinterpret_cast<const unsigned*>(sTile[g])[i];
   }
-#endif
   // ---- stages 3-6 as in k_dcthash_256: a half-wave per image, two images at a time, two passes; sT / sY live in the ring
   f32_lds* sT = reinterpret_cast<f32_lds*>(sRing);                // [2][288]
   f32_lds* sY = reinterpret_cast<f32_lds*>(sRing) + 2 * 288;      // [2][84]
@@ -1823,29 +1846,18 @@ int reflect101_host(int p, int len) {
   return p;
 }
 
-// Aw[x][c] = number of taps d in [-3,3] with reflect101(x + d) == c
-int band_weight(int x, int c) {
-  int wgt = 0;
-  for (int d = -3; d <= 3; ++d) wgt += reflect101_host(x + d, 256) == c;
-  return wgt;
-}
-
-// B operands of k_dcthash_256_band: lane l = (column n = l & 15 of the tile, chunk q = l >> 4), byte j <-> k = 16 q + j.
-// k < 32: source column 16 c - 8 + k of the row, weight = how many of the 7 taps of output column 16 c + n land on it
-// (REFLECT_101 folds the taps beyond the edge back: weights of 2 in the first / last tile); k >= 32: the same columns
-// of the row seven above, weights negated.
+// The B operand of k_dcthash_256_band: lane l = (column n = l & 15 of the tile, chunk q = l >> 4), byte j <-> k = 16 q + j.
+// k < 32: source column 16 c - 8 + k of the row, weight 1 on the 7 taps of output column 16 c + n (an interior tile: the
+// kernel mirrors the image's edge columns into the ring); k >= 32: the same columns of the row seven above, weights negated.
 void make_band_tables(BandTables* bt) {
   memset(bt, 0, sizeof(*bt));
-  const int tile_of[3] = {7, 0, 15};
-  for (int tb = 0; tb < 3; ++tb)
-    for (int l = 0; l < 64; ++l)
-      for (int j = 0; j < 16; ++j) {
-        const int k = 16 * (l >> 4) + j, kk = k & 31;
-        const int col = 16 * tile_of[tb] - 8 + kk;
-        int wgt = (col >= 0 && col < 256) ? band_weight(16 * tile_of[tb] + (l & 15), col) : 0;
-        if (k >= 32) wgt = -wgt;
-        bt->w[tb][l][j >> 2] |= (unsigned)(wgt & 0xff) << (8 * (j & 3));
-      }
+  for (int l = 0; l < 64; ++l)
+    for (int j = 0; j < 16; ++j) {
+      const int k = 16 * (l >> 4) + j, kk = k & 31;
+      int wgt = std::abs((kk - 8) - (l & 15)) <= 3 ? 1 : 0;
+      if (k >= 32) wgt = -wgt;
+      bt->w[0][l][j >> 2] |= (unsigned)(wgt & 0xff) << (8 * (j & 3));
+    }
 }
 
 struct BandTabCache {

@@ -311,7 +311,7 @@ def test_band_kernel_every_quotient_borders_and_ragged_batches(gpu, orc):
 
 @pytest.mark.parametrize("knob", [0])
 def test_mfma_variant_is_bit_identical(gpu, orc, knob):
-    """k_dcthash_256 (all VALU, "hash_mfma" 0) == the default kernel (k_dcthash_256_band) == oracle, tiles included"""
+    """k_dcthash_256 (all VALU, "hash_mfma" 0) == the default kernel (k_dcthash_256_band: box filter on the matrix cores) == oracle, tiles included"""
     import torch
 
     from cbird_amd import _lib, synth
