@@ -371,13 +371,11 @@ __global__ __launch_bounds__(64) void k_dcthash_256_band(
     wave_order_lds();
     step(integral_constant<bool, true>{}, t, tsa);
     store_step(tsb, stg[1]);  // rows of step t + 1: their slots' last readers ran just now
-    if (t + 3 < 66) load_step(t + 3, stg[1]);
+    load_step(min(t + 3, 65), stg[1]);  // (unconditional: see k_band_area's loop)
     wave_order_lds();
     step(integral_constant<bool, false>{}, t + 1, tsb);
-    if (t + 2 < 66) {
-      store_step(tsc, stg[0]);
-      if (t + 4 < 66) load_step(t + 4, stg[0]);
-    }
+    if (t + 2 < 66) store_step(tsc, stg[0]);
+    load_step(min(t + 4, 65), stg[0]);
     ts = tsc;
   }
   __syncthreads();
@@ -801,13 +799,13 @@ __global__ __launch_bounds__(64) void k_band_area(const unsigned char* __restric
     wave_order_lds();
     step(t, tsa);
     store_step(tsb, stg[1]);
-    if (t + 3 < steps) load_step(t + 3, stg[1]);
+    // (unconditional, with the step index clamped: loads behind a uniform branch make the compiler wait for every
+    // outstanding one where the paths join; the rows a clamped index fetches again are never stored)
+    load_step(min(t + 3, steps - 1), stg[1]);
     wave_order_lds();
     if (t + 1 < steps) step(t + 1, tsb);
-    if (t + 2 < steps) {
-      store_step(tsc, stg[0]);
-      if (t + 4 < steps) load_step(t + 4, stg[0]);
-    }
+    if (t + 2 < steps) store_step(tsc, stg[0]);
+    load_step(min(t + 4, steps - 1), stg[0]);
     ts = tsc;
   }
 }
