@@ -722,9 +722,9 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
  *                   descriptors and >= 4096 rows (default), 2 = always
  *   "scan256_small" 1 = searches with <= 512 needle descriptors (one ORB needle image) and thresholds <= 40 use the
  *                   stationary-needle kernel k_hamm256_small (default), 0 = the row-stationary kernels
- *   "hash_mfma"     256 x 256 tiles: non-zero (default 2) = k_dcthash_256_band (horizontal box sums as i8 MFMAs; rows must be
- *                   16-byte aligned, otherwise 0 is taken), 0 = k_dcthash_256 (all VALU; also what runs if the band tables
- *                   cannot be made)
+ *   "hash_mfma"     256 x 256 tiles: non-zero (default 2) = k_dcthash_256_band (the 7 x 7 box filter as i8 MFMAs, its vertical
+ *                   sum kept in their accumulators; rows must be 16-byte aligned, otherwise 0 is taken), 0 = k_dcthash_256
+ *                   (all VALU; also what runs if the band table cannot be made)
  *   "hash_band_area" fractional resize ratios, 7 x 7 blur, <= 1920 columns: 1 (default) = k_band_area (the matrix-core blur
  *                   for any width and height; whole images and views whose vertical edges are the parent's or lie >= 8 / >= 3
  *                   columns inside it), 0 = the VALU kernels that serve every other geometry
