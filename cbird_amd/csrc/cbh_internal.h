@@ -153,6 +153,16 @@ int launch_hamm64_scan_mfma(const uint64_t* d_hashes, const uint32_t* d_ids, siz
 // (launches on other streams wait for an event of `stream`) and given back with free_async once they have all finished
 int expand_needles_for_scan(const uint64_t* d_q, size_t nq, hipStream_t stream, void** qx);
 bool scan_mfma_wanted(size_t n, size_t nq, int thresh);
+int get_scan_mfma();  // the "scan_mfma" knob: 0 popcount kernel, 1 as shipped, 2 matrix-core scan forced, 3 + the bucketed join where
+                      // its candidate count says so, 4 the join forced wherever it can represent the call
+// ---- hamm64_join.hip: the same search as a bucketed join (multi-index hashing), thresholds <= 8 ----------------------
+bool scan_join_possible(size_t n, size_t nq, int thresh, unsigned flags, const uint64_t* d_qmask);
+long long get_scan_joins();  // calls the join has answered so far (cbh_get_tuning "scan_joins")
+// CBH_OK = done; CBH_E_UNSUPPORTED = the scan is cheaper for this call (decided from the exact candidate count against
+// scan_ms_estimate unless `force`): nothing written, the caller scans
+int launch_hamm64_join(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n, const uint64_t* d_q, size_t nq,
+                       int thresh, cbh_record* d_rec, size_t cap, unsigned long long* d_total, hipStream_t stream,
+                       unsigned flags, bool force, double scan_ms_estimate);
 unsigned scan_pre_flags(const uint64_t* d_hashes, size_t n, size_t n_total, const uint64_t* d_q, size_t nq, int thresh,
                         hipStream_t stream);  // SCAN_PRE_GIVEN | SCAN_PRE_VALUE, probed once for a sharded call
 void set_scan_mfma(int on);  // <0 = keep; 2 = force for any size

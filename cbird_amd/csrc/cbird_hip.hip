@@ -1364,6 +1364,7 @@ int cbh_get_tuning(const char* key, long long* value) {
   if (!strncmp(key, "arena_", 6)) return arena_counter(key + 6, value);
   if (!strcmp(key, "scan_pre_mask")) return *value = get_scan_pre_mask(), CBH_OK;
   if (!strcmp(key, "scan_probes")) return *value = get_scan_probes(), CBH_OK;
+  if (!strcmp(key, "scan_joins")) return *value = get_scan_joins(), CBH_OK;
   if (!strcmp(key, "scan_probe_rate_e9")) return *value = get_scan_probe_rate_e9(), CBH_OK;
   if (!strcmp(key, "scan_probe_true_e9")) return *value = get_scan_probe_true_e9(), CBH_OK;
   return CBH_E_INVAL;

@@ -850,6 +850,7 @@ uint32_t g_mfma_min_nq = 256;  // below this the needle expansion + tile padding
 void set_scan_mfma(int on) {
   if (on >= 0) g_scan_mfma = on;
 }
+int get_scan_mfma() { return g_scan_mfma; }
 void set_scan_pre_max(int t) {
   if (t >= -1 && t <= 32) g_pre_max_thresh = t;
 }
@@ -870,7 +871,7 @@ unsigned scan_pre_flags(const uint64_t* d_hashes, size_t n, size_t n_total, cons
 }
 
 bool scan_mfma_wanted(size_t n, size_t nq, int thresh) {
-  if (g_scan_mfma == 2) return thresh >= 1 && thresh <= 65;  // forced (tests)
+  if (g_scan_mfma >= 2) return thresh >= 1 && thresh <= 65;  // forced (tests)
   return g_scan_mfma && nq >= g_mfma_min_nq && n >= 4096 && thresh >= 1 && thresh <= 65;
 }
 

@@ -317,6 +317,18 @@ int launch_hamm64_scan(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n
                        const uint64_t* d_qmask, const void* qx_given) {
   if (n == 0 || nq == 0 || thresh <= 0) return CBH_OK;
   if (n > 0xfffffff0ull || nq > CBH_MAX_QUERIES_PER_CALL) return CBH_E_INVAL;
+  // thresholds <= 8, "scan_mfma" 3: the bucketed join (hamm64_join.hip) when its candidate count says it is cheaper than
+  // looking at every pair (only asked where a scan would take >= 1 ms); 4: whenever it can represent the call (the parity
+  // suite).  As shipped (1) every pair is compared: the join avoids comparisons, it does not make them faster.
+  {
+    const int mode = get_scan_mfma();
+    const double scan_ms = (double)n * (double)nq * (thresh <= 6 ? 8.8e-12 : 16.3e-12);  // (prefilter / three-field kernel)
+    if ((mode == 4 || (mode == 3 && scan_ms >= 1.0)) && scan_join_possible(n, nq, thresh, flags, d_qmask)) {
+      const int rc = launch_hamm64_join(d_hashes, d_ids, n, d_q, nq, thresh, d_rec, cap, d_total, stream, flags, mode == 4,
+                                        scan_ms);
+      if (rc != CBH_E_UNSUPPORTED) return rc;
+    }
+  }
   if (scan_mfma_wanted(n, nq, thresh))
     return launch_hamm64_scan_mfma(d_hashes, d_ids, n, d_q, nq, thresh, d_rec, cap, d_total, stream,
                                    flags, d_qmask, qx_given);

@@ -29,7 +29,7 @@ def gpu():
     return cbird_amd
 
 
-@pytest.fixture(params=["mfma", "mfma_pre", "mfma_full", "valu"])
+@pytest.fixture(params=["mfma", "mfma_pre", "mfma_full", "valu", "join"])
 def scan_path(request, gpu):
     """Run a GPU test once per 64-bit scan kernel family, all of which must be bit-exact against the oracle:
     "mfma"      the matrix-core scan forced for any size, kernels chosen as shipped ("scan_mfma_pre_max" -1: thresholds
@@ -37,11 +37,13 @@ def scan_path(request, gpu):
                 kernel, 65 the two-field one);
     "mfma_pre"  the prefilter kernel for every threshold it can represent (<= 32), however dense its candidates;
     "mfma_full" never the prefilter: thresholds 1..64 on the three-field kernel;
-    "valu"      the popcount kernel k_hamm64_scan."""
+    "valu"      the popcount kernel k_hamm64_scan;
+    "join"      the bucketed join (hamm64_join.hip) for every call it can take (thresholds <= 8, no needle masks), whatever its
+                candidate count; the rest as "mfma"."""
     from cbird_amd import _lib
 
     L = _lib.lib()
-    L.cbh_set_tuning(b"scan_mfma", 0 if request.param == "valu" else 2)
+    L.cbh_set_tuning(b"scan_mfma", {"valu": 0, "join": 4}.get(request.param, 2))
     L.cbh_set_tuning(b"scan_mfma_pre_max", {"mfma_pre": 32, "mfma_full": 0}.get(request.param, -1))
     yield request.param
     L.cbh_set_tuning(b"scan_mfma", 1)

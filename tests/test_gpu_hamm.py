@@ -380,3 +380,69 @@ def test_prefilter_beyond_its_range(gpu, orc, scan_path):
             assert (gc == wc).all() and (gi == wi).all() and (gs == ws).all(), dht
     finally:
         L.cbh_set_tuning(b"scan_mfma_pre_max", {"mfma_pre": 32, "mfma_full": 0}.get(scan_path, -1))
+
+
+def test_bucketed_join_equals_the_scan_and_steps_aside_on_skewed_data(gpu, orc):
+    """hamm64_join.hip ("scan_mfma" 3: the join where its candidate count says it is cheaper, 4: forced): on 400 000 x
+    400 000 hashes the thresholds 1..8 give the cut lists and record totals of the matrix-core scan -- on near-uniform
+    hashes and with half the slots exact copies in clusters (the join runs: "scan_joins" counts it), and with half the
+    slots sharing their low 16 bits (4 x 10^10 candidate pairs on one chunk value: the sampled count sends the call back to
+    the scan); removed slots and null needles on both sides."""
+    import torch
+
+    from cbird_amd import _lib, synth
+
+    L = _lib.lib()
+    n, k = 400_000, 6
+    rng = np.random.default_rng(77)
+    base, ids = synth.make_hashes(n, seed=4321, planted_frac=0.2)
+    dup = base.copy()
+    dup[rng.permutation(n)[: n // 2]] = dup[rng.integers(0, n, n // 2)]
+    skew = base.copy()
+    half = rng.permutation(n)[: n // 2]
+    skew[half] = (skew[half] & ~np.uint64(0xFFFF)) | np.uint64(0x1234)
+
+    def joins():
+        v = C.c_longlong(0)
+        assert L.cbh_get_tuning(b"scan_joins", C.byref(v)) == 0
+        return v.value
+
+    try:
+        for name, h, modes, thresholds in (("uniform", base, (2, 3, 4), (1, 3, 5, 6, 7, 8)), ("dup50", dup, (2, 3), (2, 4, 6, 8)),
+                                           ("skew", skew, (2, 3), (1, 4, 8))):
+            idz = ids.copy()
+            idz[rng.integers(0, n, 500)] = 0  # removed slots
+            q = h.copy()
+            q[rng.integers(0, n, 300)] = 0  # null needles
+            idx = gpu.DctHashIndex()
+            idx.load(h, idz)
+            dq = torch.from_numpy(q.view(np.int64)).cuda()
+            outs = {}
+            for mode in modes:
+                L.cbh_set_tuning(b"scan_mfma", mode)
+                j0 = joins()
+                for dht in thresholds:
+                    dout = torch.empty((n, k, 2), dtype=torch.int32, device="cuda")
+                    dcnt = torch.empty(n, dtype=torch.int32, device="cuda")
+                    tot = C.c_uint64(0)
+                    _lib.check(L.cbh_idx64_find_batch_dev(idx.handle, dq.data_ptr(), n, dht, k, dout.data_ptr(),
+                                                          dcnt.data_ptr(), C.byref(tot), None), "find_batch_dev")
+                    outs.setdefault(dht, {})[mode] = (int(tot.value), dcnt.cpu().numpy(), dout.cpu().numpy())
+                ran = joins() - j0
+                if mode == 2:
+                    assert ran == 0
+                elif name == "skew":
+                    assert ran < len(thresholds), "the join took a call with 4e10 candidate pairs on one value"
+                elif mode == 4:
+                    assert ran == len(thresholds), (name, mode, ran)
+                else:  # (at this size the largest threshold sits near the cost model's break-even)
+                    assert ran >= len(thresholds) - 1, (name, mode, ran)
+            for dht, by in outs.items():
+                ref = by[2]
+                for mode, got in by.items():
+                    assert got[0] == ref[0] and (got[1] == ref[1]).all(), (name, dht, mode)
+                    m = np.arange(k)[None, :] < np.minimum(ref[1], k)[:, None]
+                    assert (got[2][m] == ref[2][m]).all(), (name, dht, mode)
+            del idx
+    finally:
+        L.cbh_set_tuning(b"scan_mfma", 1)
