@@ -710,7 +710,11 @@ int cbh_color_find_batch(cbh_color*, const void* needle_descs, size_t nq, int k,
 /* Knobs (25).  Results never change with any of them except "color_fma".  Unknown keys return CBH_E_INVAL.
  * Which kernel serves a call:
  *   "scan_mfma"     64-bit scan on the matrix cores (k_hamm64_mfma*): 0 = never (the popcount kernel k_hamm64_scan), 1 = calls
- *                   with >= 256 needles and >= 4096 slots (default), 2 = always
+ *                   with >= 256 needles and >= 4096 slots (default), 2 = always; 3 = as 1, and calls with thresholds <= 8 and
+ *                   no needle masks whose scan would take >= 1 ms go to the bucketed join (hamm64_join.hip: multi-index
+ *                   hashing -- only pairs that share one of max(4, thresh) chunk values are compared; the same records) when
+ *                   its exact candidate count says it is cheaper; 4 = the join for every call it can represent (tests).
+ *                   The join avoids comparisons rather than making them faster: it is opt-in, the default compares every pair
  *   "scan_mfma_pre_max" prefilter kernel or three-field 64-bit kernel: -1 (default) = per launch, by the candidate rate of the
  *                   launch's own data -- r_cand = P[popc(fold(a) ^ fold(b)) < thresh] and r_true = P[hamm64(a, b) < thresh], counted
  *                   on 2048 x 2048 sampled (slot, needle) pairs by k_fold_probe; the prefilter while r_cand - 4 r_true <=
@@ -773,7 +777,7 @@ int cbh_set_tuning(const char* key, int value);
  * "fault_fired", "alloc_calls" (allocations seen since the library loaded), and the scratch arena's
  * "arena_cached_bytes", "arena_pending_bytes", "arena_live_bytes", "arena_live_blocks", "arena_trimmed_live",
  * "arena_oom_retry_stream", "arena_oom_retry_device", "arena_oom_retry_persistent", "arena_released"; "scan_pre_mask"
- * (bit t = the most recent matrix-core launch at threshold t took the prefilter kernel), "scan_probes" (candidate-rate
+ * (bit t = the most recent matrix-core launch at threshold t took the prefilter kernel), "scan_joins" (calls the bucketed join has answered), "scan_probes" (candidate-rate
  * probes run so far), "scan_probe_rate_e9" / "scan_probe_true_e9" (the candidate and true-match rates the last one found for its threshold,
  * x 1e9; -1 = none yet). */
 int cbh_get_tuning(const char* key, long long* value);
