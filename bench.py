@@ -384,7 +384,8 @@ def main():
         finally:
             ops.L.cbh_set_tuning(b"scan_mfma", 1)
         result["popcount_kernel_scan_ms"] = pop
-    if world == 1 and all(1 <= d <= 8 for d in dhts):
+    if world == 1 and all(1 <= d <= 8 for d in dhts) and float(n) * float(n) * 8.8e-12 >= 1.0:  # (the join is only asked where
+        # a scan takes >= 1 ms)
         # Beside the contract line, never part of `value`: the same sweep with "scan_mfma" 3 -- thresholds <= 8 answered by the
         # bucketed join (hamm64_join.hip: multi-index hashing; only pairs that share one of max(4, dht) chunk values are
         # compared, exact results) wherever its candidate count beats the exhaustive scan.  The headline metric counts

@@ -382,7 +382,7 @@ def test_prefilter_beyond_its_range(gpu, orc, scan_path):
         L.cbh_set_tuning(b"scan_mfma_pre_max", {"mfma_pre": 32, "mfma_full": 0}.get(scan_path, -1))
 
 
-def test_bucketed_join_equals_the_scan_and_steps_aside_on_skewed_data(gpu, orc):
+def test_bucketed_join_equals_the_scan_and_steps_aside_on_skewed_data(gpu, orc, scan_path):
     """hamm64_join.hip ("scan_mfma" 3: the join where its candidate count says it is cheaper, 4: forced): on 400 000 x
     400 000 hashes the thresholds 1..8 give the cut lists and record totals of the matrix-core scan -- on near-uniform
     hashes and with half the slots exact copies in clusters (the join runs: "scan_joins" counts it), and with half the
@@ -392,6 +392,8 @@ def test_bucketed_join_equals_the_scan_and_steps_aside_on_skewed_data(gpu, orc):
 
     from cbird_amd import _lib, synth
 
+    if scan_path != "join":
+        pytest.skip("sets the kernel family itself: once is enough")
     L = _lib.lib()
     n, k = 400_000, 6
     rng = np.random.default_rng(77)
