@@ -206,19 +206,36 @@ __global__ __launch_bounds__(kJT) void k_join_pairs(int j, JoinPlan P, uint32_t 
     }
   };
   uint32_t qi = q0;
+  // (a 64-bit pointer bump keeps the eight loads of a block at constant offsets from one SGPR base -- wave-uniform, so they
+  // are scalar loads; the next block is fetched while this one is compared: hamm64_scan.hip's loop)
+  const uint2* __restrict__ qp = reinterpret_cast<const uint2*>(qx) + q0;
+  uint2 cur[8];
+  if (qi + 8u <= q1) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cur[k] = qp[k];
+  }
   for (; qi + 8u <= q1; qi += 8u) {
+    uint2 nxt[8];
+    qp += 8;
+    if (qi + 16u <= q1) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) nxt[k] = qp[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) nxt[k] = make_uint2(0u, 0u);
+    }
     uint32_t m0 = 64u, m1 = 64u;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const uint64_t qq = qx[qi + (uint32_t)k];  // uniform addresses: scalar loads
-      const uint32_t ql = (uint32_t)qq, qh = (uint32_t)(qq >> 32);
-      m0 = min(m0, (uint32_t)__popc(a0l ^ ql) + (uint32_t)__popc(a0h ^ qh));
-      m1 = min(m1, (uint32_t)__popc(a1l ^ ql) + (uint32_t)__popc(a1h ^ qh));
+      m0 = min(m0, (uint32_t)__popc(a0l ^ cur[k].x) + (uint32_t)__popc(a0h ^ cur[k].y));
+      m1 = min(m1, (uint32_t)__popc(a1l ^ cur[k].x) + (uint32_t)__popc(a1h ^ cur[k].y));
     }
     if (__builtin_amdgcn_ballot_w64((live0 && m0 < thresh) || (live1 && m1 < thresh)) != 0) {  // (one block in 10^2 .. 10^4)
 #pragma unroll 1
       for (uint32_t k = 0; k < 8u; ++k) exact(qi + k);
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cur[k] = nxt[k];
   }
 #pragma unroll 1
   for (; qi < q1; ++qi) exact(qi);
