@@ -1,5 +1,6 @@
-"""Repeatability soak of the matrix-core scan kernels: many launches, every result set compared with the VALU
-kernel's (order-independent checksum of the record multiset).  Development aid."""
+"""Repeatability soak of the matrix-core scan kernels (or, third argument 4, of the bucketed join): many launches, every
+result set compared with the VALU kernel's (order-independent checksum of the record multiset).  Development aid.
+    python tools/soak_scan.py [N=300000] [seconds=60] [scan_mfma=1]"""
 import ctypes as C, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -8,6 +9,7 @@ from cbird_amd import _lib, synth
 L = _lib.lib()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300_000
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
+MODE = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # "scan_mfma" of the runs under test: 1 as shipped, 4 the bucketed join for thresholds <= 8
 dev = torch.device("cuda", 0)
 h = synth.make_hashes(N, seed=99, planted_frac=0.3)[0]
 dq = torch.from_numpy(h.view(np.int64)).to(dev)
@@ -26,7 +28,7 @@ ref = {}
 L.cbh_set_tuning(b"scan_mfma", 0)
 for thr in range(1, 13):
     ref[thr] = run(thr)
-L.cbh_set_tuning(b"scan_mfma", 1)
+L.cbh_set_tuning(b"scan_mfma", MODE)
 t0 = time.time(); reps = 0; bad = 0
 while time.time() - t0 < secs:
     for thr in range(1, 13):
@@ -35,4 +37,5 @@ while time.time() - t0 < secs:
             bad += 1
             print("MISMATCH thr", thr, got, ref[thr], flush=True)
     reps += 1
-print("reps", reps, "launches", reps * 12, "mismatches", bad)
+L.cbh_set_tuning(b"scan_mfma", 1)
+print("scan_mfma", MODE, "N", N, "reps", reps, "launches", reps * 12, "mismatches", bad)
