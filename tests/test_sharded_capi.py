@@ -158,6 +158,22 @@ def test_shares_follow_the_shard_range_rule_and_the_order_is_global(gpu, sharded
     assert st.shards == R and st.devices == bin(mask).count("1") and st.device_mask == mask and st.segments >= R
 
 
+def test_bucketed_join_on_every_shard(gpu, orc, sharded):
+    """"scan_mfma" 4 on a sharded handle: every shard answers its slots by the join (hamm64_join.hip), appending into the
+    root block like the scans do -- random shapes, thresholds on both sides of 8, removed slots and null needles"""
+    from cbird_amd import _lib
+
+    if sharded not in ("shards5", "shards2x", "dev2x2", "alldev_copies"):
+        pytest.skip("the copy exchange's shapes: how the records travel is the other tests' subject")
+    L = _lib.lib()
+    L.cbh_set_tuning(b"scan_mfma", 4)
+    try:
+        TH.test_random_shapes_and_thresholds(gpu, orc)
+        TH.test_null_needle_empty_index_removed_slots(gpu, orc)
+    finally:
+        L.cbh_set_tuning(b"scan_mfma", 1)
+
+
 def test_exchange_route_and_overflow_redo_are_what_the_shape_says(gpu, orc, sharded):
     """the counters of cbh_idx64_shard_stats: "rccl3" really goes through ncclAllGather, the others never; a shard
     whose own block overflows is the only one that scans again -- under the copy exchange the shards of the ROOT device
