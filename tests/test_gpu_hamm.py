@@ -61,13 +61,13 @@ def test_find_batch_vs_oracle_ragged_sizes(gpu, orc, n, nq, seed):
         assert (gc == wc).all() and (gi == wi).all() and (gs == ws).all(), (n, nq, dht)
 
 
-def test_random_shapes_and_thresholds(gpu, orc):
+def test_random_shapes_and_thresholds(gpu, orc, cases=24):
     """Tile-padding edges of the matrix-core kernels (32-row tiles, 64/96-needle groups, 192-needle scratch
     padding) and every threshold class, on random shapes; nulls on both sides."""
     from cbird_amd import synth
 
     rng = np.random.default_rng(2024)
-    for case in range(24):
+    for case in range(cases):
         n = int(rng.integers(1, 6000))
         nq = int(rng.integers(1, 800))
         dht = int(rng.choice([1, 2, 3, 4, 5, 6, 9, 17, 32, 33, 64, 65]))

@@ -109,7 +109,13 @@ def reduce_path(request, gpu):
 # ---- the one-device suites, every index sharded ---------------------------------------------------------------------
 test_find_matches_reference_golden = TH.test_find_matches_reference_golden
 test_find_batch_vs_oracle_ragged_sizes = TH.test_find_batch_vs_oracle_ragged_sizes
-test_random_shapes_and_thresholds = TH.test_random_shapes_and_thresholds
+
+
+def test_random_shapes_and_thresholds(gpu, orc, sharded):
+    # (a handle that exchanges through ncclAllGather makes a communicator of its own: eight of the 24 shapes there)
+    TH.test_random_shapes_and_thresholds(gpu, orc, cases=8 if "rccl" in sharded else 24)
+
+
 test_distance_extremes_all_thresholds = TH.test_distance_extremes_all_thresholds
 test_thresholds_full_range = TH.test_thresholds_full_range
 test_null_needle_empty_index_removed_slots = TH.test_null_needle_empty_index_removed_slots
