@@ -97,6 +97,24 @@ __global__ __launch_bounds__(1024) void k_join_scan(JoinPlan P, const uint32_t* 
   }
 }
 
+// the sampled pre-check needs the candidate pairs only: stats[2 j + 1] = sum over chunk j's values of slots x needles
+__global__ __launch_bounds__(1024) void k_join_pairs_only(JoinPlan P, const uint32_t* __restrict__ hist_h,
+                                                          const uint32_t* __restrict__ hist_q,
+                                                          unsigned long long* __restrict__ stats) {
+  const int j = blockIdx.x;
+  const uint32_t nv = 1u << (P.lo[j + 1] - P.lo[j]), off = P.voff[j] + (uint32_t)j;
+  __shared__ unsigned long long sp[1024];
+  unsigned long long p = 0;
+  for (uint32_t v = threadIdx.x; v < nv; v += 1024u) p += (unsigned long long)hist_h[off + v] * hist_q[off + v];
+  sp[threadIdx.x] = p;
+  __syncthreads();
+  for (uint32_t d = 512; d > 0; d >>= 1) {
+    if (threadIdx.x < d) sp[threadIdx.x] += sp[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) stats[2 * j] = 0ull, stats[2 * j + 1] = sp[0];
+}
+
 // item i of x goes to position start[value] + (its turn among the value's items) of chunk j's copy; aux = ids (slots) or
 // nullptr (needles: the item's own index)
 __global__ __launch_bounds__(256) void k_join_scatter(const uint64_t* __restrict__ x, const uint32_t* __restrict__ aux,
@@ -320,15 +338,19 @@ int launch_hamm64_join(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n
   CBH_HIP(scratch.get(&jobstart, nslots * 4));
   CBH_HIP(scratch.get(&stats, 2 * kMaxChunks * 8));
   unsigned long long h_stats[2 * kMaxChunks];
-  auto count = [&](uint32_t sh, uint32_t sq) -> int {  // histograms of every sh-th slot / sq-th needle, scans, read-back
+  auto count = [&](uint32_t sh, uint32_t sq, bool pairs_only) -> int {  // histograms of every sh-th slot / sq-th needle,
+                                                                        // scans (or just the pair count), read-back
     CBH_HIP(hipMemsetAsync(hist_h, 0, nslots * 4, stream));
     CBH_HIP(hipMemsetAsync(hist_q, 0, nslots * 4, stream));
     const size_t nh_ = (n + sh - 1) / sh, nq_ = (nq + sq - 1) / sq;
     hipLaunchKernelGGL(k_join_hist, dim3((unsigned)((nh_ + 255) / 256)), dim3(256), 0, stream, d_hashes, (uint32_t)n, sh, P,
                        hist_h);
     hipLaunchKernelGGL(k_join_hist, dim3((unsigned)((nq_ + 255) / 256)), dim3(256), 0, stream, d_q, (uint32_t)nq, sq, P, hist_q);
-    hipLaunchKernelGGL(k_join_scan, dim3((unsigned)P.m), dim3(1024), 0, stream, P, hist_h, hist_q, start_h, start_q, jobstart,
-                       stats);
+    if (pairs_only)
+      hipLaunchKernelGGL(k_join_pairs_only, dim3((unsigned)P.m), dim3(1024), 0, stream, P, hist_h, hist_q, stats);
+    else
+      hipLaunchKernelGGL(k_join_scan, dim3((unsigned)P.m), dim3(1024), 0, stream, P, hist_h, hist_q, start_h, start_q,
+                         jobstart, stats);
     CBH_HIP(hipGetLastError());
     CBH_HIP(hipMemcpyAsync(h_stats, stats, (size_t)2 * P.m * 8, hipMemcpyDeviceToHost, stream));
     CBH_HIP(hipStreamSynchronize(stream));
@@ -340,14 +362,14 @@ int launch_hamm64_join(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n
     // 16 384 of each side first and leave if THEIR candidate pairs, scaled up, already say the scan is cheaper
     const uint32_t sh = (uint32_t)std::max<size_t>(1, n / 16384), sq = (uint32_t)std::max<size_t>(1, nq / 16384);
     if (sh > 1 || sq > 1) {
-      if ((rc = count(sh, sq))) return rc;
+      if ((rc = count(sh, sq, true))) return rc;
       double sp = 0;
       for (int j = 0; j < P.m; ++j) sp += (double)h_stats[2 * j + 1];
       // (sampling thins the occupied values' pairs by sh x sq on average; a generous factor keeps borderline calls in)
       if (sp * (double)sh * (double)sq * (double)g_join_model_ps_e3 * 1e-12 > 4.0 * scan_ms_estimate) return CBH_E_UNSUPPORTED;
     }
   }
-  if ((rc = count(1, 1))) return rc;
+  if ((rc = count(1, 1, false))) return rc;
   double pairs = 0;
   unsigned long long jobs_max = 0;
   for (int j = 0; j < P.m; ++j) {
