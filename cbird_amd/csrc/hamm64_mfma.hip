@@ -871,7 +871,7 @@ unsigned scan_pre_flags(const uint64_t* d_hashes, size_t n, size_t n_total, cons
 }
 
 bool scan_mfma_wanted(size_t n, size_t nq, int thresh) {
-  if (g_scan_mfma >= 2) return thresh >= 1 && thresh <= 65;  // forced (tests)
+  if (g_scan_mfma == 2 || g_scan_mfma == 4) return thresh >= 1 && thresh <= 65;  // forced (tests); 3 sizes like 1
   return g_scan_mfma && nq >= g_mfma_min_nq && n >= 4096 && thresh >= 1 && thresh <= 65;
 }
 
