@@ -297,6 +297,43 @@ __global__ __launch_bounds__(kJT) void k_join_narrow(int j, JoinPlan P, uint32_t
   join_flush(buf, cnt, rec, cap, total);
 }
 
+// four chunks of 16 bits (thresholds <= 4): the needles need no order at all -- a lane takes a NEEDLE
+// and, chunk after chunk, walks the slots that share its value (the slots' side alone is histogrammed, scanned and
+// scattered: half the bookkeeping of a call whose join proper is a tenth of a millisecond)
+__global__ __launch_bounds__(kJT) void k_join_by_needle(JoinPlan P, uint32_t n, uint32_t nq, const uint64_t* __restrict__ hay_x,
+                                                        const uint32_t* __restrict__ hay_id, const uint64_t* __restrict__ q,
+                                                        const uint32_t* __restrict__ start_h, uint32_t thresh,
+                                                        cbh_record* __restrict__ rec, unsigned long long cap,
+                                                        unsigned long long* __restrict__ total, uint32_t keep0) {
+  __shared__ uint64_t s_out[kJT / 64][kOutCap + 64];
+  const uint32_t i = blockIdx.x * (uint32_t)kJT + threadIdx.x;
+  const uint64_t qq = i < nq ? q[i] : 0ull;
+  const bool live = qq != 0;  // (null needles never match)
+  const uint32_t ql = (uint32_t)qq, qh = (uint32_t)(qq >> 32);
+  uint64_t* buf = s_out[threadIdx.x >> 6];
+  uint32_t cnt = 0;
+#pragma unroll 1
+  for (int j = 0; j < P.m; ++j) {
+    const uint32_t off = P.voff[j] + (uint32_t)j + chunk_of(qq, P.lo[j], P.lo[j + 1]);
+    uint32_t hi_ = live ? start_h[off] : 0u;
+    const uint32_t he = live ? start_h[off + 1] : 0u;
+    const uint64_t* __restrict__ hx = hay_x + (size_t)j * n;
+    while (__builtin_amdgcn_ballot_w64(hi_ < he) != 0) {
+      const bool act = hi_ < he;
+      const uint64_t a = act ? hx[hi_] : 0ull;
+      const uint32_t x0 = (uint32_t)a ^ ql, x1 = (uint32_t)(a >> 32) ^ qh, d = __popc(x0) + __popc(x1);
+      bool hit = act && d < thresh;
+      if (__builtin_amdgcn_ballot_w64(hit) != 0) {
+        uint32_t id = 0;
+        hit = hit && join_mine(P, j, x0, x1, qq, hay_id, (size_t)j * n + hi_, keep0, &id);
+        join_push(buf, cnt, hit, i, d, id, rec, cap, total);
+      }
+      ++hi_;
+    }
+  }
+  join_flush(buf, cnt, rec, cap, total);
+}
+
 constexpr int g_join_model_ps_e3 = 250;  // the launcher's cost model: 0.25 ns of ONE SIMD lane... i.e. 2.5e-13 s of the
                                          // machine per candidate pair (measured 2.8e-13 at threshold 8)
 
@@ -357,17 +394,43 @@ int launch_hamm64_join(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n
     return CBH_OK;
   };
   int rc;
+  // (16-bit chunks only: ~15 slots a value.  At five chunks of 12-13 bits a needle walks 5 x 122 slots by per-lane loads: 5.8 ms
+  // against the 2.9 of sorting both sides)
+  const bool by_needle = P.m == 4;
   if (!force) {
     // a library of near-identical hashes makes the full histogram itself expensive (10^6 atomics on one counter): look at
     // 16 384 of each side first and leave if THEIR candidate pairs, scaled up, already say the scan is cheaper
     const uint32_t sh = (uint32_t)std::max<size_t>(1, n / 16384), sq = (uint32_t)std::max<size_t>(1, nq / 16384);
-    if (sh > 1 || sq > 1) {
+    if (sh > 1 || sq > 1 || by_needle) {
       if ((rc = count(sh, sq, true))) return rc;
       double sp = 0;
       for (int j = 0; j < P.m; ++j) sp += (double)h_stats[2 * j + 1];
-      // (sampling thins the occupied values' pairs by sh x sq on average; a generous factor keeps borderline calls in)
-      if (sp * (double)sh * (double)sq * (double)g_join_model_ps_e3 * 1e-12 > 4.0 * scan_ms_estimate) return CBH_E_UNSUPPORTED;
+      // (sampling thins the occupied values' pairs by sh x sq on average; a generous factor keeps borderline calls in --
+      // the by-needle form has no exact count behind this one: there the estimate decides, with less slack)
+      const double est_ms = sp * (double)sh * (double)sq * (double)g_join_model_ps_e3 * 1e-12;
+      if (est_ms > (by_needle ? 0.6 : 4.0) * scan_ms_estimate) return CBH_E_UNSUPPORTED;
     }
+  }
+  if (by_needle) {
+    uint64_t* hx = nullptr;
+    uint32_t* hid = nullptr;
+    CBH_HIP(scratch.get(&hx, (size_t)P.m * n * 8));
+    CBH_HIP(scratch.get(&hid, (size_t)P.m * n * 4));
+    CBH_HIP(hipMemsetAsync(hist_h, 0, nslots * 4, stream));
+    CBH_HIP(hipMemsetAsync(hist_q, 0, nslots * 4, stream));  // (no needles' side: the scans see empty needle buckets)
+    hipLaunchKernelGGL(k_join_hist, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_hashes, (uint32_t)n, 1u, P,
+                       hist_h);
+    hipLaunchKernelGGL(k_join_scan, dim3((unsigned)P.m), dim3(1024), 0, stream, P, hist_h, hist_q, start_h, start_q, jobstart,
+                       stats);
+    CBH_HIP(hipMemsetAsync(hist_h, 0, nslots * 4, stream));
+    hipLaunchKernelGGL(k_join_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_hashes, d_ids, (uint32_t)n, P,
+                       start_h, hist_h, hx, hid);
+    hipLaunchKernelGGL(k_join_by_needle, dim3((unsigned)((nq + kJT - 1) / kJT)), dim3(kJT), 0, stream, P, (uint32_t)n,
+                       (uint32_t)nq, hx, hid, d_q, start_h, (uint32_t)thresh, d_rec, (unsigned long long)cap, d_total,
+                       (uint32_t)(flags & 1u));
+    CBH_HIP(hipGetLastError());
+    g_n_join++;
+    return CBH_OK;
   }
   if ((rc = count(1, 1, false))) return rc;
   double pairs = 0;
