@@ -9,15 +9,19 @@
 // MORE work than the scan -- the launcher counts the candidate pairs exactly (sum over chunk values of slots x needles, from
 // the two histograms) before it commits, and hands the call back (CBH_E_UNSUPPORTED) when the matrix-core scan is cheaper.
 //
-//   k_join_hist      a histogram of every chunk's values, slots and needles alike (one atomic per item and chunk)
-//   k_join_scan      per chunk: exclusive scans -> where each value's slots / needles start; the jobs of the join (one per
-//                    256 slots x kJQ needles of a value) and their prefix; the chunk's candidate pairs
-//   k_join_scatter   slots (hash, id) and needles (hash, needle index) in chunk-value order, one copy per chunk
-//   k_join_pairs     a workgroup per job: a lane holds one slot, the value's needles stream through the scalar cache; 64-bit
-//                    popcount per pair (the candidates are few enough for the VALU); a pair that also agrees on an EARLIER
-//                    chunk is that chunk's to report; records parked per wave in LDS and appended with one atomic per flush
-// Scratch from the stream-ordered arena; nothing is cached on the index (a call costs two histograms, 2 m scatters and one
-// 64-byte read-back besides the join: ~0.3 ms at 10^6 x 10^6).
+//   k_join_hist        a histogram of every chunk's values, slots and needles alike (one atomic per item and chunk; every
+//                      n / 16384-th item only for the sampled pre-check, whose pairs k_join_pairs_only adds up)
+//   k_join_scan        per chunk: exclusive scans -> where each value's slots / needles start; the jobs of the wide join (one
+//                      per 512 slots x 2048 needles of a value) and their prefix; the chunk's candidate pairs
+//   k_join_scatter     slots (hash, id) and needles (hash, needle index) in chunk-value order, one copy per chunk
+//   k_join_pairs       chunks of <= 11 bits: a workgroup per job, two slots per lane, the value's needles through the scalar
+//                      cache eight at a time, one min-test per block and the exact look only behind it
+//   k_join_narrow      chunks of 12-13 bits (threshold 5): a lane per slot walks its value's needles
+//   k_join_by_needle   four 16-bit chunks (thresholds <= 4): only the slots' side is prepared; a lane per NEEDLE walks the
+//                      ~15 slots of each of its four values
+// A pair that also agrees on an EARLIER chunk is that chunk's to report; records are parked per wave in LDS and appended with
+// one atomic per flush.  Scratch from the stream-ordered arena; nothing is cached on the index (a call at 10^6 x 10^6 costs
+// 0.8 ms of bookkeeping at thresholds <= 4, 1.7 ms above, besides the join proper).
 #include "cbh_internal.h"
 
 #include <atomic>
