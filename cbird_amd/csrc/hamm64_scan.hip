@@ -326,7 +326,10 @@ int launch_hamm64_scan(const uint64_t* d_hashes, const uint32_t* d_ids, size_t n
     if ((mode == 4 || (mode == 3 && scan_ms >= 1.0)) && scan_join_possible(n, nq, thresh, flags, d_qmask)) {
       const int rc = launch_hamm64_join(d_hashes, d_ids, n, d_q, nq, thresh, d_rec, cap, d_total, stream, flags, mode == 4,
                                         scan_ms);
-      if (rc != CBH_E_UNSUPPORTED) return rc;
+      if (rc == CBH_OK || mode == 4 || (rc != CBH_E_UNSUPPORTED && rc != CBH_E_NOMEM)) return rc;
+      // (its scratch is all taken before the first record is written: a join that could not get it, like one whose count
+      // said no, leaves the call to the scan)
+      if (rc == CBH_E_NOMEM) cbh_clear_error();
     }
   }
   if (scan_mfma_wanted(n, nq, thresh))

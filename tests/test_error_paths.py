@@ -314,3 +314,49 @@ def test_a_live_streams_cache_is_bounded_by_pool_live_keep_mb(gpu):
         L.cbh_set_tuning(b"pool_live_keep_mb", 0)
         _free_bytes(L)
     assert _tuning(L, b"arena_pending_bytes") == 0  # cbh_trim reaped what was waiting
+
+
+def test_a_join_that_cannot_get_its_scratch_leaves_the_call_to_the_scan(gpu):
+    """"scan_mfma" 3: every allocation of the bucketed join (hamm64_join.hip) precedes its first record, so a refused one sends
+    the call to the scan instead of failing it -- same results, "scan_joins" unchanged for that call"""
+    import torch
+
+    from cbird_amd import _lib, synth
+
+    L = _lib.lib()
+    n, k = 400_000, 4
+    h, ids = synth.make_hashes(n, seed=11, planted_frac=0.2)
+    idx = gpu.DctHashIndex()
+    idx.load(h, ids)
+    dq = torch.from_numpy(h.view(np.int64)).cuda()
+
+    def run():
+        dout = torch.empty((n, k, 2), dtype=torch.int32, device="cuda")
+        dcnt = torch.empty(n, dtype=torch.int32, device="cuda")
+        tot = C.c_uint64(0)
+        _lib.check(L.cbh_idx64_find_batch_dev(idx.handle, dq.data_ptr(), n, 3, k, dout.data_ptr(), dcnt.data_ptr(), C.byref(tot),
+                                              None), "find_batch_dev")
+        return int(tot.value), dcnt.cpu().numpy(), dout.cpu().numpy()
+
+    want = run()
+    L.cbh_set_tuning(b"scan_mfma", 3)
+    try:
+        j0 = _tuning(L, b"scan_joins")
+        got = run()
+        assert _tuning(L, b"scan_joins") == j0 + 1 and got[0] == want[0] and (got[1] == want[1]).all()
+        fell_back = 0
+        for site in range(12):
+            j1 = _tuning(L, b"scan_joins")
+            L.cbh_set_tuning(b"fault_alloc_after", site)
+            try:
+                got = run()
+            except _lib.CbhError:
+                continue  # (an allocation of the call outside the join: the walk above covers those)
+            finally:
+                L.cbh_set_tuning(b"fault_alloc_after", -1)
+            assert got[0] == want[0] and (got[1] == want[1]).all()
+            fell_back += _tuning(L, b"scan_joins") == j1
+        assert fell_back >= 1
+    finally:
+        L.cbh_set_tuning(b"scan_mfma", 1)
+        L.cbh_set_tuning(b"fault_alloc_after", -1)
